@@ -1,0 +1,189 @@
+/*
+ * starphase_hip.h -- C ABI of the MI355X (gfx950) StarPhase hot-path library (libstarphase_hip.so).
+ *
+ * The reference (PacificBiosciences/pb-StarPhase v2.0.1) exposes no FFI of its own for this path; its hot
+ * path sits behind ordinary Rust calls whose arithmetic is delegated to minimap2 through
+ * minimap2::Aligner::{with_seq,with_index,map}.  The boundary is therefore cut at those call sites
+ * (SURVEY.md 8(b)).  Every entry point below names the reference interface it replaces (paths relative
+ * to the reference checkout).  INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; caller owns every host buffer (sizes passed explicitly); the library owns device
+ *     memory behind opaque handles; no callbacks.
+ *   - every call returns an int32 status (SP_OK = 0); nothing aborts or throws across the boundary;
+ *     sp_last_error() returns a NUL-terminated message for the last failing call on that context.
+ *   - one sp_ctx = one GPU + one HIP stream; a context is used from one host thread at a time
+ *     (the reference is single-threaded: src/cli/diplotype.rs:185-191); contexts are independent.
+ *   - calls are stream-ordered and synchronous on return.
+ *   - results never depend on launch geometry; ties go to the lowest index in the documented order.
+ *   - there is NO CPU fallback: without a usable HIP device sp_ctx_create fails with SP_ERR_NO_DEVICE.
+ */
+#ifndef STARPHASE_HIP_H
+#define STARPHASE_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_ABI_VERSION 1
+
+/* status codes: "expected" outcomes the reference downgrades (CallerError -> NO_MATCH,
+ * src/diplotyper.rs:316-327; src/cyp2d6/errors.rs:4-11) are distinct from fatal ones (src/main.rs:181-185). */
+enum {
+    SP_OK                  = 0,
+    SP_ERR_INVALID_ARG     = 1,
+    SP_ERR_NO_DEVICE       = 2,
+    SP_ERR_HIP             = 3,
+    SP_ERR_OUT_OF_MEMORY   = 4,
+    SP_ERR_TOO_LONG        = 5,   /* sequence longer than the kernels support (65,535 bases per window) */
+    SP_ERR_NO_CHAINING_HEAD = 16, /* CallerError::NoChainingHead  (src/cyp2d6/chaining.rs:321-323) */
+    SP_ERR_NO_CHAINS_FOUND  = 17, /* CallerError::NoChainsFound   (src/cyp2d6/chaining.rs:393-396) */
+    SP_ERR_NO_SCORE_PAIRS   = 18  /* CallerError::NoScorePairs    (src/cyp2d6/chaining.rs:559-562) */
+};
+
+typedef struct sp_ctx    sp_ctx;
+typedef struct sp_seqset sp_seqset;
+typedef struct sp_hla_db sp_hla_db;
+
+/* ------------------------------------------------------------------ context */
+int32_t sp_abi_version(void);
+int32_t sp_device_count(int32_t* count);
+/* device: HIP ordinal.  stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create one. */
+int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out);
+void    sp_ctx_destroy(sp_ctx* ctx);
+const char* sp_last_error(const sp_ctx* ctx);
+int32_t sp_ctx_synchronize(sp_ctx* ctx);
+
+/* ------------------------------------------------------------------ sequences
+ * Replaces the targets handed to minimap2 via Aligner::with_seq / with_index
+ * (src/hla/realigner.rs:56-60,78-79; src/hla/caller.rs:1370-1379; src/cyp2d6/haplotyper.rs:155;
+ * src/cyp2d6/chaining.rs:29-30).  bases: concatenated ASCII; offsets[n+1]: start of each sequence.
+ * Packed on upload to 2 bits/base + an N plane; anything outside ACGT is 'N' and never matches. */
+int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets, uint32_t n, sp_seqset** out);
+void    sp_seqset_free(sp_seqset* set);
+int32_t sp_seqset_count(const sp_seqset* set, uint32_t* n);
+int32_t sp_seqset_length(const sp_seqset* set, uint32_t idx, uint32_t* len);
+
+/* ------------------------------------------------------------------ alignment primitives
+ * One cell = one (A, B) pair = one 64-lane wavefront; lane = diagonal.  The alignment contract (banded
+ * ends-free edit alignment, deterministic tie rules) is specified in DESIGN.md section 3. */
+typedef struct {
+    uint32_t a;        /* index into set A (streamed side; minimap2 "query" at most call sites)     */
+    uint32_t b;        /* index into set B (window side; minimap2 "target")                          */
+    int32_t  diag;     /* anchor diagonal = (b position) - (a position)                              */
+    int32_t  max_ed;   /* give up beyond this many edits (0..SP_MAX_ED)                              */
+} sp_pair;
+
+typedef struct {
+    int32_t ok;        /* 1 = alignment found within max_ed                                          */
+    int32_t nm;        /* #X + #I bases + #D bases  (minimap2 Alignment.nm)                          */
+    int32_t a_start, a_end;   /* half-open span on A                                                 */
+    int32_t b_start, b_end;   /* half-open span on B                                                 */
+    int32_t a_len, b_len;
+} sp_aln;              /* 32 bytes */
+
+#define SP_BAND    64
+#define SP_MAX_ED  255
+#define SP_KMER    16
+#define SP_NO_DIAG INT32_MIN
+/* event word: (type << 30) | b_pos ; b_pos = B bases consumed before the edit */
+#define SP_EV_X 0u     /* mismatch                      (cigar 'X', op 8) */
+#define SP_EV_D 1u     /* consumes one B base only      (cigar 'D', op 2 when B is the target) */
+#define SP_EV_I 2u     /* consumes one A base only      (cigar 'I', op 1 when B is the target) */
+
+/* k-mer vote anchor for each pair (a indexes set A = the k-mer indexed side).  Replaces minimap2's
+ * seed+chain stage inside Aligner::map.  diag_out[i] = b_pos - a_pos, votes_out[i] = #votes (0: no anchor). */
+int32_t sp_anchor_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                        const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs,
+                        int32_t* diag_out, int32_t* votes_out);
+
+/* Align every pair.  Replaces every `aligner.map(...)` on the hot path: src/hla/realigner.rs:116,231,290;
+ * src/hla/caller.rs:1277,1436; src/cyp2d6/haplotyper.rs:198,395; src/cyp2d6/chaining.rs:58.
+ * events (optional, may be NULL): n_pairs * events_stride words, the first nm of each row are valid. */
+int32_t sp_align_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                       const sp_pair* pairs, uint64_t n_pairs,
+                       sp_aln* out, uint32_t* events, uint32_t events_stride);
+
+/* ------------------------------------------------------------------ HLA database
+ * Replaces HlaRealigner::new + create_hla_fasta (src/hla/realigner.rs:42-91,497-526) and the per-call
+ * one-sequence indexes of score_read (src/hla/caller.rs:1370-1379).
+ * Alleles must be given in database key order ("HLA:HLA00001" ascending = BTreeMap order,
+ * src/hla/caller.rs:1413) because ties go to the lowest index.
+ *   gene_of[i]      gene index of allele i
+ *   dna / cdna      gene-strand sequences as stored in the database (dna length 0 = no DNA sequence)
+ *   gene_ref        hg38-forward reference sequence of each gene region incl. the +-100 bp buffer
+ *                   (src/hla/realigner.rs:74-81)
+ *   gene_fwd[g]     is_forward_strand
+ *   exon_start/end  exon coordinates of gene g relative to gene_ref[g] start (hg38 order),
+ *                   exon_off[g]..exon_off[g+1]  
+ */
+typedef struct {
+    uint32_t n_alleles, n_genes;
+    const uint32_t* gene_of;
+    const char* dna;   const uint64_t* dna_off;     /* n_alleles+1 */
+    const char* cdna;  const uint64_t* cdna_off;    /* n_alleles+1 */
+    const char* gene_ref; const uint64_t* gene_ref_off;   /* n_genes+1 */
+    const uint8_t* gene_fwd;
+    const uint32_t* exon_off;                        /* n_genes+1 */
+    const int32_t* exon_start; const int32_t* exon_end;
+    int32_t ref_buffer;                              /* bases of buffer on each side of the gene inside gene_ref (100) */
+} sp_hla_db_desc;
+
+int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* desc, sp_hla_db** out);
+void    sp_hla_db_free(sp_hla_db* db);
+
+/* ------------------------------------------------------------------ K1: read -> best database allele
+ * Replaces HlaRealigner::realign_record (src/hla/realigner.rs:98-350) for a batch of reads.
+ * reads: hg38-forward read sequences already on the device. For read r:
+ *   best_allele  index of the accepted allele (lowest nm/(target_len-unmapped) subject to the 0.5 / 0.03
+ *                cut-offs, :137-141) or -1;  gene = gene_of[best_allele]
+ *   aln          alignment of the read (B) against that allele in hg38 orientation (A): bm.query_* = b_*,
+ *                bm.target_* = a_*
+ *   seg_start/end  optimal_segment_start..end on the read (:266-267), dna_offset / hpc_offset (:270-325);
+ *                status 0 = realigned, 1 = no acceptable allele, 2 = best mapping not Forward (never produced:
+ *                reads are only compared in hg38 orientation), 3 = segment failed to map to the gene reference.
+ */
+typedef struct {
+    int32_t status;
+    int32_t best_allele;
+    int32_t gene;
+    int32_t nm, target_len, unmapped;         /* MappingStats of the best allele (:132-133) */
+    sp_aln  aln;
+    int32_t seg_start, seg_end;
+    int32_t dna_offset, hpc_offset;
+} sp_hla_realign;
+
+int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads,
+                             sp_hla_realign* out /* n_reads */,
+                             uint32_t* cell_out /* optional n_reads*n_alleles: (nm<<16 | span) or 0xFFFFFFFF */);
+
+/* ------------------------------------------------------------------ K2: consensus -> every allele of a gene
+ * Replaces score_read's allele loop + HlaProcessedMatch (src/hla/caller.rs:1411-1510,
+ * src/hla/processed_match.rs:53-263).  cons_dna / cons_cdna: gene-strand consensus and its spliced cDNA
+ * (ASCII).  require_dna mirrors --hla-require-dna, disable_cdna mirrors --disable-cdna-scoring.
+ *   best_allele  running-best winner in database order, -1 if nothing maps (best id stays empty, :1503-1509)
+ *   stats        optional n_alleles*6: cdna (len, nm, unmapped), dna (len, nm, unmapped); -1,-1,-1 = None;
+ *                rows of alleles of other genes are left at -2.
+ */
+typedef struct {
+    int32_t best_allele;
+    int32_t n_scored;            /* alleles visited (gene match and allowed) */
+} sp_hla_best;
+
+int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
+                               const char* cons_dna, uint32_t cons_dna_len,
+                               const char* cons_cdna, uint32_t cons_cdna_len,
+                               int32_t require_dna, int32_t disable_cdna,
+                               sp_hla_best* best, int32_t* stats);
+
+/* ------------------------------------------------------------------ profiling hooks (bench.py)
+ * HIP-event timing of the dominant kernel on the context's own stream. */
+int32_t sp_profile_reset(sp_ctx* ctx);
+int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches, uint64_t* cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,147 @@
+/*
+ * sp_oracle.h -- CPU ORACLE for the StarPhase hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Nothing under oracle/ is part of the product.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library, and only as the checker /
+ * the timed CPU baseline.  The product path (pb-starphase_amd/csrc) never links it.
+ *
+ * What is restated here (reference = PacificBiosciences/pb-StarPhase v2.0.1, paths
+ * relative to /root/reference):
+ *   - score algebra                     src/data_types/mapping.rs:60-84,191-195
+ *   - HLA score pair                    src/hla/mapping.rs:44-61,111-117
+ *   - select_best_mapping               src/util/mapping.rs:22-57
+ *   - process_mm_cigar / add_mapping /
+ *     is_better_match                   src/hla/processed_match.rs:53-263
+ *   - score_read running-best scan      src/hla/caller.rs:1411-1510
+ *   - realign_record acceptance filter  src/hla/realigner.rs:124-146
+ *   - is_passing_dual                   src/hla/caller.rs:1225-1247
+ *   - is_hemizygous_better              src/hla/caller.rs:1583-1653
+ *   - hpc / hpc_pos / revcomp           src/util/homopolymers.rs:18-42, src/util/sequence.rs:9-23
+ *   - multinomial_ln_pmf                src/util/stats.rs:11-37
+ *   - CYP2D6 chain-pair search          src/cyp2d6/chaining.rs:223-903
+ *   - variant-gene diplotype search     src/diplotyper.rs:1211-1550, src/data_types/normalized_variant.rs:431-479
+ *
+ * PARITY STATUS.  Everything in the list above is pinned against the reference's own
+ * known-answer tests (tests/test_oracle_*.py port them one by one).  The base-level
+ * aligner is NOT: in the reference every (nm, start, end, cigar) comes from minimap2
+ * 2.28 (crate minimap2 0.1.23+minimap2.2.28, Cargo.lock:1137-1152), whose sources are
+ * not under /root/reference and which cannot be built here.  osp_wfa()/osp_anchor()
+ * below restate a mathematically defined alignment contract that
+ * coincides with minimap2 on the reference's pinned cases (identical sequence => nm 0
+ * full span; strict ranking on a single mismatch; 'N' mismatches everything; no seeds
+ * => no mapping).  Outside those cases the aligner is "parity unpinned".
+ */
+#ifndef SP_ORACLE_H
+#define SP_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- alignment contract ---------------- */
+#define OSP_BAND      64          /* diagonals per cell: k0-32 .. k0+31                 */
+#define OSP_KMER      16          /* anchor k-mer length                                */
+#define OSP_MAXOCC    4           /* k-mers occurring more often in the indexed side are ignored */
+#define OSP_NEG       (-(1 << 28))
+
+typedef struct {
+    int32_t ok;                   /* 1 = alignment found within max_ed                  */
+    int32_t nm;                   /* #X + #I bases + #D bases                           */
+    int32_t a_start, a_end;       /* half-open span on A (the streamed sequence)        */
+    int32_t b_start, b_end;       /* half-open span on B (the window sequence)          */
+    int32_t a_len, b_len;
+} osp_aln;
+
+/* event word: (type << 30) | b_pos ; type 0 = X, 1 = D (consumes B only), 2 = I (consumes A only);
+ * b_pos = number of B bases consumed before the edit. */
+#define OSP_EV_X 0u
+#define OSP_EV_D 1u
+#define OSP_EV_I 2u
+
+/* ASCII -> code (A=0,C=1,G=2,T=3, everything else 4 = N, never matches). */
+void osp_encode(const char* ascii, size_t n, uint8_t* codes);
+
+/* Banded ends-free edit alignment.  diag = (b position) - (a position) of the anchor.
+ * events may be NULL; otherwise it must hold max_ed words. Returns out->ok. */
+int osp_wfa(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed,
+            osp_aln* out, uint32_t* events, int* n_events);
+
+/* k-mer vote anchor: A is the indexed side. Returns votes (0 = none); *diag = b_pos - a_pos. */
+int osp_anchor(const uint8_t* A, int m, const uint8_t* B, int n, int* diag);
+
+/* events + alignment -> BAM-style cigar (len<<4|op; op 7 '=', 8 'X', 1 'I', 2 'D'); returns #ops */
+int osp_events_to_cigar(const osp_aln* aln, const uint32_t* events, int n_events, uint32_t* cigar, int cap);
+
+/* ---------------- score algebra ---------------- */
+double osp_score_value(uint64_t len, uint64_t nm, uint64_t unmapped);             /* mapping.rs:191-195 */
+double osp_custom_score(uint64_t seq_len, uint64_t nm, uint64_t unmapped, int penalize_unmapped); /* mapping.rs:60-84 */
+
+typedef struct {                  /* what the reference reads off a minimap2::Mapping   */
+    int32_t query_len, query_start, query_end;
+    int32_t target_len, target_start, target_end;
+    int32_t nm;
+    int32_t strand_fwd;
+} osp_mapping;
+
+/* util/mapping.rs:22-57 ; returns index of best mapping or -1; stats3 = {base_len, nm, unmapped} */
+int osp_select_best_mapping(const osp_mapping* maps, int n, int unmapped_from_target, int penalize_unmapped,
+                            int64_t base_length_override, uint64_t stats3[3]);
+
+/* ---------------- HLA processed match ---------------- */
+/* processed_match.rs:210-263 ; out must hold target_len+1 entries; returns 0 ok, -1 unexpected op */
+int osp_process_mm_cigar(const uint32_t* cigar_len, const uint8_t* cigar_op, int n_ops,
+                         uint64_t target_offset, uint64_t target_len, uint64_t clip_start, uint64_t clip_end,
+                         uint64_t* out);
+
+typedef struct {                  /* one level (cDNA or DNA) of an HlaProcessedMatch    */
+    int32_t present;
+    int32_t range_start, range_end;       /* processed_ranges                           */
+    int32_t len, nm, unmapped;            /* full_mapping_stats                         */
+    const uint64_t* pc;                   /* processed cigar (target_len+1), may be NULL if !present */
+} osp_hla_level;
+
+/* processed_match.rs:103-184 ; lhs better than rhs? (two levels) */
+int osp_is_better_match(const osp_hla_level lhs[2], const osp_hla_level rhs[2]);
+
+/* Full score_read restatement on top of the alignment contract (hla/caller.rs:1411-1510):
+ * alleles in DB-id order, per level an allele sequence (len 0 = absent) aligned as A against
+ * the consensus as B; returns best index or -1; stats[(allele*2+level)*3+{0,1,2}] = len,nm,unmapped
+ * (len = -1 when the level has no mapping). */
+typedef struct {
+    const uint8_t* cons[2]; int32_t cons_len[2];   /* level 0 cDNA, level 1 DNA (codes)  */
+    int32_t n_alleles;
+    const uint8_t* const* seq[2];                  /* [level][allele] codes, NULL = no sequence */
+    const int32_t* seq_len[2];
+    const int32_t* diag[2];                        /* [level][allele] anchor diag, INT32_MIN = no anchor */
+    int32_t max_ed;
+} osp_hla_score_problem;
+int osp_hla_score_read(const osp_hla_score_problem* p, int64_t* stats, osp_aln* alns /* n*2, may be NULL */);
+
+/* realign_record acceptance filter (hla/realigner.rs:124-146). alns[i] is the alignment of read(B) vs allele i (A).
+ * Returns best allele index or -1. */
+int osp_hla_pick_allele(const osp_aln* alns, int n, int read_len);
+
+/* hla/caller.rs:1225-1247 ; returns is_passing, fills maf and cdf */
+int osp_is_passing_dual(uint64_t counts1, uint64_t counts2, double min_consensus_fraction, double expected_maf,
+                        double min_cdf, double* maf, double* cdf);
+/* hla/caller.rs:1583-1653 ; s1/s2 < 0 means None */
+int osp_is_hemizygous_better(const int64_t* s1, const int64_t* s2, const uint8_t* is_c1, int n, int is_dual,
+                             uint64_t dual_max_ed_delta, int has_norm, double normalized_coverage,
+                             double* haploid_cost, double* diploid_cost);
+
+/* ---------------- utilities ---------------- */
+size_t osp_hpc(const uint8_t* seq, size_t n, uint8_t* out);                 /* homopolymers.rs:18-23 */
+size_t osp_hpc_pos(const uint8_t* seq, size_t n, size_t position);          /* homopolymers.rs:25-42 */
+int    osp_revcomp(const char* in, size_t n, char* out);                    /* sequence.rs:9-23 ; -1 on bad char */
+double osp_ln_factorial(uint64_t n);                                        /* statrs 0.16 ln_factorial */
+double osp_multinomial_ln_pmf(const double* probs, const uint64_t* obs, int n); /* stats.rs:11-37 */
+double osp_binomial_cdf(double p, uint64_t n, uint64_t x);
+double osp_binomial_ln_pmf(double p, uint64_t n, uint64_t x);
+double osp_normal_ln_pdf(double mean, double sd, double x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,259 @@
+// sp_api.hip -- C ABI of libstarphase_hip: context, sequence sets, generic anchor/align entry points.
+// (HLA entry points live in sp_hla.hip.)  Declared in include/starphase_hip.h.
+#include "sp_internal.h"
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+extern "C" {
+
+int32_t sp_abi_version(void) { return SP_ABI_VERSION; }
+
+int32_t sp_device_count(int32_t* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = (e == hipSuccess) ? n : 0;
+    return e == hipSuccess ? SP_OK : SP_ERR_NO_DEVICE;
+}
+
+int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
+    if (!out) return SP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return SP_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SP_ERR_NO_DEVICE;
+    // gfx950 only: this library carries exactly one code object
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SP_ERR_NO_DEVICE;
+    sp_ctx* ctx = new (std::nothrow) sp_ctx();
+    if (!ctx) return SP_ERR_OUT_OF_MEMORY;
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SP_ERR_HIP; }
+        ctx->own_stream = true;
+    }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return SP_ERR_HIP; }
+    *out = ctx;
+    return SP_OK;
+}
+
+void sp_ctx_destroy(sp_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* sp_last_error(const sp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t sp_ctx_synchronize(sp_ctx* ctx) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+int32_t sp_profile_reset(sp_ctx* ctx) { if (!ctx) return SP_ERR_INVALID_ARG; ctx->prof.clear(); return SP_OK; }
+
+int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches, uint64_t* cells) {
+    if (!ctx || !kernel) return SP_ERR_INVALID_ARG;
+    auto it = ctx->prof.find(kernel);
+    ProfileEntry e; if (it != ctx->prof.end()) e = it->second;
+    if (total_ms) *total_ms = e.ms;
+    if (launches) *launches = e.launches;
+    if (cells) *cells = e.cells;
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------ sequence sets
+static inline uint32_t base_code(char c) {
+    switch (c) {
+        case 'A': case 'a': return 0; case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2; case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+
+int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets, uint32_t n, sp_seqset** out) {
+    if (!ctx || !out || (n && (!bases || !offsets))) return SP_ERR_INVALID_ARG;
+    *out = nullptr;
+    hipSetDevice(ctx->device);
+    sp_seqset* s = new (std::nothrow) sp_seqset();
+    if (!s) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seqset");
+    s->ctx = ctx; s->n = n;
+    s->h_len.resize(n); s->h_word_off.resize((size_t)n + 1);
+    uint64_t total_words = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t len = offsets[i + 1] - offsets[i];
+        if (offsets[i + 1] < offsets[i] || len > 65534) { delete s; return sp_fail(ctx, SP_ERR_TOO_LONG, "seqset: sequence longer than 65,534 bases"); }
+        s->h_len[i] = (int32_t)len;
+        s->max_len = std::max<int32_t>(s->max_len, (int32_t)len);
+        s->h_word_off[i] = total_words;
+        uint64_t w = (len + 15) / 16 + 2;          // data + 2 guard words
+        total_words += (w + 3) & ~3ull;            // 16-byte aligned starts
+    }
+    s->h_word_off[n] = total_words;
+    s->h_words.assign(total_words + 4, 0);
+    std::vector<uint32_t> nplane;
+    for (uint32_t i = 0; i < n; ++i) {
+        const char* p = bases + offsets[i];
+        uint32_t* w = s->h_words.data() + s->h_word_off[i];
+        const int len = s->h_len[i];
+        for (int b = 0; b < len; ++b) {
+            uint32_t c = base_code(p[b]);
+            if (c > 3) {
+                if (!s->has_n) { s->has_n = true; nplane.assign(total_words + 4, 0); }
+                nplane[s->h_word_off[i] + (b >> 4)] |= 1u << ((b & 15) << 1);
+                c = 0;
+            }
+            w[b >> 4] |= c << ((b & 15) << 1);
+        }
+    }
+    auto fail = [&](const char* what) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, what); };
+    size_t wbytes = (total_words + 4) * sizeof(uint32_t);
+    if (hipMalloc(&s->d_words, wbytes) != hipSuccess) return fail("seqset words");
+    if (hipMalloc(&s->d_word_off, ((size_t)n + 1) * sizeof(uint64_t)) != hipSuccess) return fail("seqset offsets");
+    if (hipMalloc(&s->d_len, std::max<size_t>(1, n) * sizeof(int32_t)) != hipSuccess) return fail("seqset lengths");
+    hipMemcpyAsync(s->d_words, s->h_words.data(), wbytes, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(s->d_word_off, s->h_word_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (n) hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (s->has_n) {
+        if (hipMalloc(&s->d_nplane, wbytes) != hipSuccess) return fail("seqset nplane");
+        hipMemcpyAsync(s->d_nplane, nplane.data(), wbytes, hipMemcpyHostToDevice, ctx->stream);
+    }
+    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // the N plane is needed on the host only to build a k-mer index: keep it behind the packed words
+    if (s->has_n) { s->h_words.insert(s->h_words.end(), nplane.begin(), nplane.end()); }
+    *out = s;
+    return SP_OK;
+}
+
+void sp_seqset_free(sp_seqset* s) {
+    if (!s) return;
+    if (s->ctx) hipSetDevice(s->ctx->device);
+    if (s->d_words) hipFree(s->d_words);
+    if (s->d_nplane) hipFree(s->d_nplane);
+    if (s->d_word_off) hipFree(s->d_word_off);
+    if (s->d_len) hipFree(s->d_len);
+    if (s->d_kcode) hipFree(s->d_kcode);
+    if (s->d_kpos) hipFree(s->d_kpos);
+    if (s->d_koff) hipFree(s->d_koff);
+    delete s;
+}
+
+int32_t sp_seqset_count(const sp_seqset* s, uint32_t* n) { if (!s || !n) return SP_ERR_INVALID_ARG; *n = s->n; return SP_OK; }
+int32_t sp_seqset_length(const sp_seqset* s, uint32_t idx, uint32_t* len) {
+    if (!s || !len || idx >= s->n) return SP_ERR_INVALID_ARG;
+    *len = (uint32_t)s->h_len[idx]; return SP_OK;
+}
+
+} // extern "C"
+
+// sorted 16-mer table of every sequence of the set (device code order: base t of the k-mer in bits 2t..2t+1)
+int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
+    if (s->has_index) return SP_OK;
+    hipSetDevice(ctx->device);
+    const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
+    std::vector<uint64_t> koff((size_t)s->n + 1, 0);
+    std::vector<uint32_t> kcode; std::vector<int32_t> kpos;
+    std::vector<std::pair<uint32_t, int32_t>> tmp;
+    for (uint32_t i = 0; i < s->n; ++i) {
+        const uint32_t* w = s->h_words.data() + s->h_word_off[i];
+        const uint32_t* np = s->has_n ? s->h_words.data() + plane_words + s->h_word_off[i] : nullptr;
+        const int len = s->h_len[i];
+        tmp.clear();
+        for (int j = 0; j + SP_KMER <= len; ++j) {
+            const int wi = j >> 4; const int sh = (j & 15) << 1;
+            auto fetch = [&](const uint32_t* p) -> uint32_t {
+                uint64_t v = ((uint64_t)p[wi + 1] << 32) | p[wi];
+                return (uint32_t)(v >> sh);
+            };
+            if (np && fetch(np)) continue;
+            tmp.emplace_back(fetch(w), j);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        koff[i] = kcode.size();
+        for (auto& kv : tmp) { kcode.push_back(kv.first); kpos.push_back(kv.second); }
+    }
+    koff[s->n] = kcode.size();
+    size_t ne = std::max<size_t>(1, kcode.size());
+    if (hipMalloc(&s->d_kcode, ne * 4) != hipSuccess || hipMalloc(&s->d_kpos, ne * 4) != hipSuccess ||
+        hipMalloc(&s->d_koff, koff.size() * 8) != hipSuccess)
+        return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "k-mer index");
+    if (!kcode.empty()) {
+        hipMemcpy(s->d_kcode, kcode.data(), kcode.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(s->d_kpos, kpos.data(), kpos.size() * 4, hipMemcpyHostToDevice);
+    }
+    hipMemcpy(s->d_koff, koff.data(), koff.size() * 8, hipMemcpyHostToDevice);
+    s->has_index = true;
+    return SP_OK;
+}
+
+extern "C" {
+
+int32_t sp_anchor_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                        const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs,
+                        int32_t* diag_out, int32_t* votes_out) {
+    if (!ctx || !A || !B || (n_pairs && (!a_idx || !b_idx || !diag_out || !votes_out))) return SP_ERR_INVALID_ARG;
+    if (n_pairs == 0) return SP_OK;
+    hipSetDevice(ctx->device);
+    for (uint64_t i = 0; i < n_pairs; ++i) if (a_idx[i] >= A->n || b_idx[i] >= B->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: index out of range");
+    int rc = sp_seqset_build_index(ctx, const_cast<sp_seqset*>(A));
+    if (rc) return rc;
+    uint32_t *d_a = nullptr, *d_b = nullptr; int32_t *d_d = nullptr, *d_v = nullptr;
+    size_t nb = n_pairs * 4;
+    if (hipMalloc(&d_a, nb) != hipSuccess || hipMalloc(&d_b, nb) != hipSuccess || hipMalloc(&d_d, nb) != hipSuccess || hipMalloc(&d_v, nb) != hipSuccess) {
+        hipFree(d_a); hipFree(d_b); hipFree(d_d); hipFree(d_v);
+        return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "anchor buffers");
+    }
+    hipMemcpyAsync(d_a, a_idx, nb, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(d_b, b_idx, nb, hipMemcpyHostToDevice, ctx->stream);
+    rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v);
+    if (rc == SP_OK) {
+        hipMemcpyAsync(diag_out, d_d, nb, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(votes_out, d_v, nb, hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "anchor: stream sync failed");
+    }
+    hipFree(d_a); hipFree(d_b); hipFree(d_d); hipFree(d_v);
+    return rc;
+}
+
+int32_t sp_align_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                       const sp_pair* pairs, uint64_t n_pairs,
+                       sp_aln* out, uint32_t* events, uint32_t events_stride) {
+    if (!ctx || !A || !B || (n_pairs && (!pairs || !out))) return SP_ERR_INVALID_ARG;
+    if (events && (events_stride == 0 || events_stride > SP_MAX_ED)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "align: events_stride must be 1..255");
+    if (n_pairs == 0) return SP_OK;
+    hipSetDevice(ctx->device);
+    std::vector<CellDesc> cells(n_pairs);
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        if (pairs[i].a >= A->n || pairs[i].b >= B->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "align: index out of range");
+        if (pairs[i].max_ed < 0 || pairs[i].max_ed > SP_MAX_ED) return sp_fail(ctx, SP_ERR_INVALID_ARG, "align: max_ed must be 0..255");
+        cells[i] = CellDesc{pairs[i].a, pairs[i].b, pairs[i].diag, pairs[i].max_ed, 0, -1};
+    }
+    CellDesc* d_cells = nullptr; sp_aln* d_out = nullptr; uint32_t* d_ev = nullptr;
+    int rc = SP_OK;
+    if (hipMalloc(&d_cells, n_pairs * sizeof(CellDesc)) != hipSuccess || hipMalloc(&d_out, n_pairs * sizeof(sp_aln)) != hipSuccess ||
+        (events && hipMalloc(&d_ev, n_pairs * (size_t)events_stride * 4) != hipSuccess)) {
+        rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "align buffers");
+    } else {
+        hipMemcpyAsync(d_cells, cells.data(), n_pairs * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream);
+        if (events) hipMemsetAsync(d_ev, 0, n_pairs * (size_t)events_stride * 4, ctx->stream);
+        rc = sp_launch_cells(ctx, A, B, d_cells, n_pairs, d_out, d_ev, events_stride, events ? "align_trace" : "align");
+        if (rc == SP_OK) {
+            hipMemcpyAsync(out, d_out, n_pairs * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);
+            if (events) hipMemcpyAsync(events, d_ev, n_pairs * (size_t)events_stride * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("align: ") + hipGetErrorString(hipGetLastError()));
+        }
+    }
+    hipFree(d_cells); hipFree(d_out); hipFree(d_ev);
+    return rc;
+}
+
+} // extern "C"

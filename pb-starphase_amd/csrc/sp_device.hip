@@ -1,0 +1,176 @@
+// sp_device.hip -- generic device kernels of libstarphase_hip (gfx950): k-mer vote anchor and the
+// one-wavefront-per-cell WFA kernel, plus their launchers.
+#include "sp_internal.h"
+#include "sp_wfa.cuh"
+#include <algorithm>
+
+// =============================================================================================
+// anchor: one workgroup per (A, B) pair.  A carries a sorted 16-mer table (built on the host at
+// first use); every 16-mer of B is looked up and votes for its diagonal in an LDS histogram.
+// Replaces minimap2's minimizer seeding + chaining inside Aligner::map (DESIGN.md section 3.1;
+// CPU restatement: oracle/align.c osp_anchor).
+// =============================================================================================
+__global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexView KA, SeqSetView B,
+                                                        const uint32_t* __restrict__ a_idx, const uint32_t* __restrict__ b_idx,
+                                                        uint64_t n_pairs, int32_t* __restrict__ diag_out, int32_t* __restrict__ votes_out,
+                                                        int bins_cap) {
+    extern __shared__ uint32_t lds[];                 // packed u16 vote bins, 2 per dword
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x;
+    for (uint64_t p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+        const uint32_t a = a_idx[p], b = b_idx[p];
+        const int m = A.len[a], n = B.len[b];
+        const int nbins = m + n + 1;
+        if (m < SP_KMER || n < SP_KMER || nbins > bins_cap) {
+            if (tid == 0) { diag_out[p] = 0; votes_out[p] = 0; }
+            continue;
+        }
+        const int nb32 = (nbins + 1) >> 1;
+        for (int i = tid; i < nb32; i += 256) lds[i] = 0;
+        __syncthreads();
+        const uint32_t* bw = B.words + B.word_off[b];
+        const uint32_t* bn = B.nplane ? B.nplane + B.word_off[b] : nullptr;
+        const uint64_t k0 = KA.off[a], k1 = KA.off[a + 1];
+        const uint32_t* kc = KA.code + k0; const int32_t* kp = KA.pos + k0;
+        const int nk = (int)(k1 - k0);
+        for (int j = tid; j + SP_KMER <= n; j += 256) {
+            const int w = j >> 4; const uint32_t sh = (uint32_t)((j & 15) << 1);
+            if (bn && __builtin_amdgcn_alignbit(bn[w + 1], bn[w], sh)) continue;
+            const uint32_t code = __builtin_amdgcn_alignbit(bw[w + 1], bw[w], sh);
+            int lo = 0, hi = nk;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (kc[mid] < code) lo = mid + 1; else hi = mid; }
+            int e = lo; while (e < nk && e - lo <= SP_MAXOCC && kc[e] == code) ++e;
+            const int occ = e - lo;
+            if (occ == 0 || occ > SP_MAXOCC) continue;
+            for (int y = lo; y < e; ++y) {
+                const int bin = j - kp[y] + m;
+                atomicAdd(&lds[bin >> 1], (bin & 1) ? 0x10000u : 1u);
+            }
+        }
+        __syncthreads();
+        // argmax votes, ties -> smallest diagonal
+        unsigned long long best = 0;
+        for (int bin = tid; bin < nbins; bin += 256) {
+            uint32_t v = (lds[bin >> 1] >> ((bin & 1) << 4)) & 0xFFFFu;
+            unsigned long long key = ((unsigned long long)v << 32) | (uint32_t)(0x7FFFFFFF - bin);
+            best = key > best ? key : best;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned long long other = __shfl_xor(best, o);
+            best = other > best ? other : best;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
+            const int v = (int)(best >> 32);
+            const int bin = 0x7FFFFFFF - (int)(best & 0xFFFFFFFFu);
+            diag_out[p] = v > 0 ? bin - m : 0;
+            votes_out[p] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// generic WFA cells: wave w of block b takes cells (b*4 + w), (b*4 + w) + 4*gridDim.x, ...
+// =============================================================================================
+template <bool TRACE, bool HASN>
+__global__ __launch_bounds__(256) void sp_cells_kernel(SeqSetView A, SeqSetView B, const CellDesc* __restrict__ cells, uint64_t n_cells,
+                                                       sp_aln* __restrict__ out, uint32_t* __restrict__ events, uint32_t ev_stride,
+                                                       uint16_t* __restrict__ hist_pool, int hist_rows, int slot_words) {
+    extern __shared__ uint32_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* slot = lds + wave * slot_words;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave, nw = (uint64_t)gridDim.x * 4;
+    uint16_t* hist = TRACE ? hist_pool + gw * (uint64_t)hist_rows * SP_WAVE : nullptr;
+    for (uint64_t c = gw; c < n_cells; c += nw) {
+        const CellDesc cd = cells[c];
+        spw::CellIn in;
+        in.a_words = A.words + A.word_off[cd.a]; in.a_nplane = A.nplane ? A.nplane + A.word_off[cd.a] : nullptr;
+        in.a0 = 0; in.a1 = A.len[cd.a];
+        in.b_words = B.words + B.word_off[cd.b]; in.b_nplane = B.nplane ? B.nplane + B.word_off[cd.b] : nullptr;
+        const int blen = B.len[cd.b];
+        in.b0 = cd.b_hi >= 0 ? cd.b_lo : 0; in.b1 = cd.b_hi >= 0 ? cd.b_hi : blen;
+        in.diag = cd.diag;
+        in.max_ed = cd.max_ed < hist_rows - 1 ? cd.max_ed : hist_rows - 1;
+        spw::CellOut o;
+        uint32_t* ev = (TRACE && events) ? events + c * (uint64_t)ev_stride : nullptr;
+        if (TRACE && ev && (uint32_t)in.max_ed > ev_stride) in.max_ed = (int)ev_stride;
+        if (cd.diag == SP_NO_DIAG) { o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0; }
+        else spw::wfa_cell<TRACE, HASN>(in, slot, slot_words, lane, hist, ev, o);
+        if (lane == 0) {
+            sp_aln r; r.ok = o.ok; r.nm = o.nm; r.a_start = o.a_start; r.a_end = o.a_end;
+            r.b_start = o.b_start; r.b_end = o.b_end; r.a_len = in.a1 - in.a0; r.b_len = in.b1 - in.b0;
+            out[c] = r;
+        }
+    }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+int sp_fail(sp_ctx* ctx, int code, const std::string& msg) { if (ctx) ctx->err = msg; return code; }
+
+void* sp_scratch(sp_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return ctx->scratch;
+    if (ctx->scratch) { hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    size_t want = bytes + bytes / 4;
+    if (hipMalloc(&ctx->scratch, want) != hipSuccess) { ctx->scratch = nullptr; return nullptr; }
+    ctx->scratch_bytes = want;
+    return ctx->scratch;
+}
+
+int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn) {
+    int mn = std::min(A->max_len, B->max_len);
+    int w = (mn + SP_BAND + 30) / 16 + 3;
+    return (hasn ? 4 : 2) * w;
+}
+
+int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                     const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,
+                     int32_t* d_diag, int32_t* d_votes) {
+    if (n_pairs == 0) return SP_OK;
+    if (!A->has_index) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: set A has no k-mer index");
+    int bins_cap = A->max_len + B->max_len + 1;
+    size_t lds_bytes = (size_t)((bins_cap + 1) / 2) * 4;
+    if (lds_bytes > 160 * 1024 - 64) return sp_fail(ctx, SP_ERR_TOO_LONG, "anchor: sequences too long for the LDS vote histogram");
+    SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sp_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    uint64_t grid = std::min<uint64_t>(n_pairs, (uint64_t)ctx->num_cus * 8);
+    ProfScope ps(ctx, "anchor", n_pairs);
+    hipLaunchKernelGGL(sp_anchor_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, ctx->stream,
+                       A->view(), A->kview(), B->view(), d_a_idx, d_b_idx, n_pairs, d_diag, d_votes, bins_cap);
+    SP_HIP_CHECK(ctx, hipGetLastError());
+    return SP_OK;
+}
+
+int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                    const CellDesc* d_cells, uint64_t n_cells,
+                    sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name) {
+    if (n_cells == 0) return SP_OK;
+    const bool trace = d_events != nullptr;
+    const bool hasn = A->has_n || B->has_n;
+    const int slot_words = sp_slot_words(A, B, hasn);
+    const size_t lds_bytes = (size_t)slot_words * 4 * 4;
+    if (lds_bytes > 160 * 1024 - 64) return sp_fail(ctx, SP_ERR_TOO_LONG, "align: sequences too long for the LDS window");
+    uint64_t blocks = (n_cells + 3) / 4;
+    const uint64_t max_blocks = trace ? 1024 : (uint64_t)ctx->num_cus * 16;
+    if (blocks > max_blocks) blocks = max_blocks;
+    const int hist_rows = SP_MAX_ED + 1;
+    uint16_t* hist = nullptr;
+    if (trace) {
+        hist = (uint16_t*)sp_scratch(ctx, blocks * 4 * (size_t)hist_rows * SP_WAVE * sizeof(uint16_t));
+        if (!hist) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "align: traceback scratch");
+    }
+    SeqSetView av = A->view(), bv = B->view();
+    ProfScope ps(ctx, prof_name, n_cells);
+#define SP_LAUNCH(T, N) do { \
+        SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sp_cells_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL((sp_cells_kernel<T, N>), dim3((unsigned)blocks), dim3(256), lds_bytes, ctx->stream, \
+                           av, bv, d_cells, n_cells, d_out, d_events, events_stride, hist, hist_rows, slot_words); } while (0)
+    if (trace) { if (hasn) SP_LAUNCH(true, true); else SP_LAUNCH(true, false); }
+    else       { if (hasn) SP_LAUNCH(false, true); else SP_LAUNCH(false, false); }
+#undef SP_LAUNCH
+    SP_HIP_CHECK(ctx, hipGetLastError());
+    return SP_OK;
+}

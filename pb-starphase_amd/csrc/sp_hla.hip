@@ -1,0 +1,613 @@
+// sp_hla.hip -- HLA hot path on gfx950.
+//   K1  sp_hla_realign_reads    replaces HlaRealigner::realign_record   (src/hla/realigner.rs:98-350)
+//   K2  sp_hla_score_consensus  replaces score_read's allele loop + HlaProcessedMatch
+//                               (src/hla/caller.rs:1411-1510, src/hla/processed_match.rs:53-263)
+// Decisions use f64 exactly as the reference does (MappingScore::score_value, src/data_types/mapping.rs:191-195);
+// alignments come from the one-wavefront-per-cell WFA kernel (sp_wfa.cuh).
+#include "sp_internal.h"
+#include "sp_wfa.cuh"
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
+int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn);
+
+#define K1_CHUNK       128      // alleles per workgroup (4 waves x 32 cells)
+#define K1_MIN_VOTES   16
+#define K2_MIN_VOTES   2
+
+struct sp_hla_db {
+    sp_ctx* ctx = nullptr;
+    uint32_t n_alleles = 0, n_genes = 0;
+    int ref_buffer = 100;
+    std::vector<uint32_t> gene_of;
+    std::vector<uint8_t>  gene_fwd, has_dna;
+    std::vector<std::vector<uint32_t>> gene_alleles;      // allele indices per gene (database order)
+    sp_seqset* dna_gene = nullptr;    // allele DNA as stored (gene strand); len 0 = none
+    sp_seqset* cdna_gene = nullptr;   // allele cDNA as stored
+    sp_seqset* dna_fwd = nullptr;     // allele DNA in hg38 orientation (create_hla_fasta, realigner.rs:497-526)
+    sp_seqset* ref_fwd = nullptr;     // buffered gene references, hg38 forward (realigner.rs:74-81)
+    uint32_t* d_gene_of = nullptr;
+    int32_t*  d_off_fwd = nullptr;    // allele_fwd_pos - ref_fwd_pos (SP_NO_DIAG = no anchor)
+    int32_t*  d_am = nullptr;         // n_alleles*3: ok, am.query_start, am.target_start (allele -> gene ref, realigner.rs:289-310)
+    int32_t*  d_hpc_ref = nullptr;    // hpc_pos(ref_fwd[g], p) for p in 0..len, concatenated
+    uint64_t* d_hpc_ref_off = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// f64 score algebra (src/data_types/mapping.rs:60-84,191-195)
+__device__ __forceinline__ double score_value(int len, int nm, int unmapped) {
+    double num = (double)(nm + unmapped);
+    if (num < 0.1) num = 0.1;
+    return num / (double)len;
+}
+
+// =============================================================================================
+// K1 cells: workgroup = (read r, chunk of K1_CHUNK alleles); every wave runs its cells sequentially.
+// cell_out[r * n_alleles + a] = (nm << 16) | aligned allele span, or SP_CELL_NONE.
+// =============================================================================================
+template <bool HASN>
+__global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads,
+                                                       const uint32_t* __restrict__ gene_of, const int32_t* __restrict__ off_fwd,
+                                                       const int32_t* __restrict__ d_rg, const int32_t* __restrict__ votes_rg,
+                                                       int n_genes, uint32_t n_alleles, uint32_t n_chunks,
+                                                       uint32_t* __restrict__ cell_out, int slot_words) {
+    extern __shared__ uint32_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* slot = lds + wave * slot_words;
+    const uint32_t r = blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
+    // gene filter: a gene is searched when it has >= K1_MIN_VOTES and >= 1/10 of the read's best gene
+    int vmax = 0;
+    for (int g = 0; g < n_genes; ++g) { int v = votes_rg[(uint64_t)r * n_genes + g]; vmax = v > vmax ? v : vmax; }
+    const int vmin = vmax / 10 > K1_MIN_VOTES ? vmax / 10 : K1_MIN_VOTES;
+    const int rlen = reads.len[r];
+    const uint32_t* rw = reads.words + reads.word_off[r];
+    const uint32_t* rn = reads.nplane ? reads.nplane + reads.word_off[r] : nullptr;
+    const uint32_t a_end = min((chunk + 1) * (uint32_t)K1_CHUNK, n_alleles);
+    for (uint32_t a = chunk * K1_CHUNK + wave; a < a_end; a += 4) {
+        uint32_t res = SP_CELL_NONE;
+        const int alen = alleles.len[a];
+        const int off = off_fwd[a];
+        const uint32_t g = gene_of[a];
+        if (alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
+            spw::CellIn in;
+            in.a_words = alleles.words + alleles.word_off[a];
+            in.a_nplane = alleles.nplane ? alleles.nplane + alleles.word_off[a] : nullptr;
+            in.a0 = 0; in.a1 = alen;
+            in.b_words = rw; in.b_nplane = rn; in.b0 = 0; in.b1 = rlen;
+            in.diag = d_rg[(uint64_t)r * n_genes + g] - off;
+            // nm <= 0.03 * aligned span <= 0.03 * allele length (realigner.rs:138-141)
+            int cap = (int)(0.03 * (double)alen) + 1; if (cap > SP_MAX_ED) cap = SP_MAX_ED;
+            in.max_ed = cap;
+            spw::CellOut o;
+            spw::wfa_cell<false, HASN>(in, slot, slot_words, lane, nullptr, nullptr, o);
+            if (o.ok) res = ((uint32_t)o.nm << 16) | (uint32_t)(o.a_end - o.a_start);
+        }
+        if (lane == 0) cell_out[(uint64_t)r * n_alleles + a] = res;
+    }
+}
+
+// K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
+__global__ __launch_bounds__(256) void k1_reduce_kernel(const uint32_t* __restrict__ cell_out, const int32_t* __restrict__ allele_len,
+                                                        uint32_t n_alleles, uint32_t n_reads, int32_t* __restrict__ best_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * 4 + wave;
+    if (r >= n_reads) return;
+    double best = 1.0;             // custom_score(false) of MappingStats(read_len, read_len, 0)
+    int best_idx = 0x7FFFFFFF;
+    for (uint32_t a = lane; a < n_alleles; a += 64) {
+        uint32_t c = cell_out[(uint64_t)r * n_alleles + a];
+        if (c == SP_CELL_NONE) continue;
+        int nm = (int)(c >> 16), span = (int)(c & 0xFFFFu), tlen = allele_len[a];
+        int unmapped = tlen - span;
+        double pen = score_value(tlen, nm, unmapped);
+        double ed = score_value(tlen - unmapped, nm, 0);
+        if (pen <= 0.5 && ed <= 0.03 && ed < best) { best = ed; best_idx = (int)a; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        double ob = __shfl_xor(best, o); int oi = __shfl_xor(best_idx, o);
+        if (ob < best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+    }
+    if (lane == 0) best_out[r] = best_idx == 0x7FFFFFFF ? -1 : best_idx;
+}
+
+// hpc_pos(seq, position) on a packed sequence: number of run boundaries in (0, position]
+// (src/util/homopolymers.rs:25-42).  One wavefront.
+__device__ __forceinline__ int hpc_pos_wave(const uint32_t* __restrict__ w, int len, int position, int lane) {
+    if (len <= 0) return 0;
+    int last = position < len - 1 ? position : len - 1;     // boundaries at p in [1, last]
+    int cnt = 0;
+    for (int base = lane * 16; base <= last; base += 64 * 16) {
+        // bases base .. base+15 ; boundary at p when base[p] != base[p-1]
+        int wi = base >> 4;
+        uint32_t cur = w[wi];
+        uint32_t prev = wi > 0 ? w[wi - 1] : 0;
+        uint32_t shifted = (cur << 2) | (prev >> 30);          // base p-1 aligned to base p
+        uint32_t x = cur ^ shifted; uint32_t diff = (x | (x >> 1)) & 0x55555555u;
+        if (base == 0) diff &= ~1u;                              // p = 0 is not a boundary
+        int hi = last - base;                                    // keep p <= last
+        if (hi < 15) diff &= (hi >= 0) ? ((1u << ((hi + 1) << 1)) - 1u) : 0u;
+        cnt += __builtin_popcount(diff);
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    return cnt;
+}
+
+// K1 finalize: one wavefront per read: full alignment of the accepted allele, segment +-1000 against the
+// gene reference, offsets (realigner.rs:219-331).
+template <bool HASN>
+__global__ __launch_bounds__(256) void k1_finalize_kernel(SeqSetView alleles_fwd, SeqSetView alleles_gene, SeqSetView refs, SeqSetView reads,
+                                                          const uint32_t* __restrict__ gene_of, const int32_t* __restrict__ off_fwd,
+                                                          const int32_t* __restrict__ d_rg, int n_genes,
+                                                          const int32_t* __restrict__ am, const int32_t* __restrict__ hpc_ref,
+                                                          const uint64_t* __restrict__ hpc_ref_off,
+                                                          const int32_t* __restrict__ best_in, uint32_t n_reads,
+                                                          sp_hla_realign* __restrict__ out, int slot_words) {
+    extern __shared__ uint32_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* slot = lds + wave * slot_words;
+    const uint32_t r = blockIdx.x * 4 + wave;
+    if (r >= n_reads) return;
+    sp_hla_realign res;
+    memset(&res, 0, sizeof(res));
+    res.status = 1; res.best_allele = -1; res.gene = -1;
+    const int a = best_in[r];
+    const int rlen = reads.len[r];
+    if (a >= 0) {
+        const uint32_t g = gene_of[a];
+        const int alen = alleles_fwd.len[a];
+        const uint32_t* rw = reads.words + reads.word_off[r];
+        const uint32_t* rn = reads.nplane ? reads.nplane + reads.word_off[r] : nullptr;
+        const int drg = d_rg[(uint64_t)r * n_genes + g];
+        spw::CellIn in;
+        in.a_words = alleles_fwd.words + alleles_fwd.word_off[a];
+        in.a_nplane = alleles_fwd.nplane ? alleles_fwd.nplane + alleles_fwd.word_off[a] : nullptr;
+        in.a0 = 0; in.a1 = alen; in.b_words = rw; in.b_nplane = rn; in.b0 = 0; in.b1 = rlen;
+        in.diag = drg - off_fwd[a];
+        int cap = (int)(0.03 * (double)alen) + 1; if (cap > SP_MAX_ED) cap = SP_MAX_ED;
+        in.max_ed = cap;
+        spw::CellOut bm;
+        spw::wfa_cell<false, HASN>(in, slot, slot_words, lane, nullptr, nullptr, bm);
+        res.best_allele = a; res.gene = (int)g;
+        res.nm = bm.nm; res.target_len = alen; res.unmapped = alen - (bm.a_end - bm.a_start);
+        res.aln.ok = bm.ok; res.aln.nm = bm.nm; res.aln.a_start = bm.a_start; res.aln.a_end = bm.a_end;
+        res.aln.b_start = bm.b_start; res.aln.b_end = bm.b_end; res.aln.a_len = alen; res.aln.b_len = rlen;
+        res.status = 3;
+        if (bm.ok) {
+            const int db_start = bm.b_start, db_end = bm.b_end;
+            const int buffer = 1000;
+            const int buf_start = db_start > buffer ? db_start - buffer : 0;
+            const int buf_end = db_end + buffer < rlen ? db_end + buffer : rlen;
+            const int reflen = refs.len[g];
+            spw::CellIn in2;
+            in2.a_words = refs.words + refs.word_off[g];
+            in2.a_nplane = refs.nplane ? refs.nplane + refs.word_off[g] : nullptr;
+            in2.a0 = 0; in2.a1 = reflen; in2.b_words = rw; in2.b_nplane = rn; in2.b0 = buf_start; in2.b1 = buf_end;
+            in2.diag = drg - buf_start; in2.max_ed = SP_MAX_ED;
+            spw::CellOut rm;
+            spw::wfa_cell<false, HASN>(in2, slot, slot_words, lane, nullptr, nullptr, rm);
+            // select_best_mapping(target-based, penalised): must beat the 1.0 default (util/mapping.rs:22-57)
+            if (rm.ok && score_value(reflen, rm.nm, reflen - (rm.a_end - rm.a_start)) < 1.0) {
+                const int adj_start = buf_start + rm.b_start, adj_end = buf_start + rm.b_end;
+                res.seg_start = db_start < adj_start ? db_start : adj_start;
+                res.seg_end = db_end > adj_end ? db_end : adj_end;
+                const int32_t* hp = hpc_ref + hpc_ref_off[g];
+                int d, h;
+                if (adj_start < db_start || !am[a * 3 + 0]) {
+                    d = rm.a_start; h = hp[d];
+                } else {
+                    int added = am[a * 3 + 2] - am[a * 3 + 1]; if (added < 0) added = 0;
+                    d = added + bm.a_start;
+                    const uint32_t* gw = alleles_gene.words + alleles_gene.word_off[a];
+                    h = hp[added < reflen ? added : reflen] + hpc_pos_wave(gw, alleles_gene.len[a], bm.a_start, lane);
+                }
+                res.dna_offset = d; res.hpc_offset = h;
+                res.status = 0;
+            }
+        }
+    }
+    if (lane == 0) out[r] = res;
+}
+
+// =============================================================================================
+// K2
+// =============================================================================================
+struct K2Level {           // one level of an HlaProcessedMatch (processed_match.rs:10-21)
+    int32_t present, range_start, range_end, len, nm, unmapped;
+};
+
+// build the cell list of one level from the anchor votes (A = consensus set idx level, B = allele)
+__global__ void k2_build_cells_kernel(const uint32_t* __restrict__ allele_idx, uint32_t n, uint32_t cons_idx,
+                                      const int32_t* __restrict__ anchor_diag, const int32_t* __restrict__ anchor_votes,
+                                      const int32_t* __restrict__ allele_len, CellDesc* __restrict__ cells) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    CellDesc c;
+    c.a = allele_idx[i]; c.b = cons_idx; c.max_ed = SP_MAX_ED; c.b_lo = 0; c.b_hi = -1;
+    // anchor diag = allele_pos - cons_pos ; cell diag = cons_pos - allele_pos
+    c.diag = (allele_len[c.a] > 0 && anchor_votes[i] >= K2_MIN_VOTES) ? -anchor_diag[i] : SP_NO_DIAG;
+    cells[i] = c;
+}
+
+// select_best_mapping(query-based, penalised) + add_mapping bookkeeping (caller.rs:1447-1461, processed_match.rs:53-100)
+__global__ void k2_levels_kernel(const sp_aln* __restrict__ alns, uint32_t n, K2Level* __restrict__ lv) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const sp_aln a = alns[i];
+    K2Level l; l.present = 0; l.range_start = l.range_end = 0; l.len = l.nm = l.unmapped = -1;
+    if (a.ok) {
+        int qlen = a.a_len, unmapped = qlen - (a.a_end - a.a_start);
+        if (score_value(qlen, a.nm, unmapped) < 1.0) {
+            int clip_start = a.a_start, clip_end = qlen - a.a_end, t_off = a.b_start, rem = a.b_len - a.b_end;
+            l.present = 1;
+            l.range_start = t_off > clip_start ? t_off - clip_start : 0;
+            l.range_end = a.b_end + (clip_end < rem ? clip_end : rem);
+            l.len = qlen; l.nm = a.nm; l.unmapped = unmapped;
+        }
+    }
+    lv[i] = l;
+}
+
+// pc[e] - pc[s] of process_mm_cigar (processed_match.rs:210-263) from the event list:
+// every X / D / I event contributes 1 at pc index (b_pos + 1); clip padding contributes 1 per base.
+__device__ __forceinline__ int k2_range_edits(const K2Level& l, const sp_aln& a, const uint32_t* __restrict__ ev, int s, int e) {
+    int cnt = 0;
+    for (int x = 0; x < a.nm; ++x) { int p = (int)(ev[x] & 0x3FFFFFFFu) + 1; cnt += (p > s && p <= e); }
+    // soft-clip padding (only non-zero when the allele overhangs the consensus end it touches)
+    int clip_start = a.a_start, t_off = a.b_start;
+    int zero_pad = t_off > clip_start ? t_off - clip_start : 0;
+    // indices zero_pad+1 .. t_off each add 1
+    { int lo = zero_pad + 1 > s + 1 ? zero_pad + 1 : s + 1, hi = t_off < e ? t_off : e; if (hi >= lo) cnt += hi - lo + 1; }
+    int clip_end = a.a_len - a.a_end, rem = a.b_len - a.b_end;
+    int ext = clip_end < rem ? clip_end : rem;
+    { int lo = a.b_end + 1 > s + 1 ? a.b_end + 1 : s + 1, hi = a.b_end + ext < e ? a.b_end + ext : e; if (hi >= lo) cnt += hi - lo + 1; }
+    (void)l;
+    return cnt;
+}
+
+__device__ __forceinline__ bool k2_score_less(const K2Level* l, const K2Level* r) {
+    double ls0 = l[0].present ? score_value(l[0].len, l[0].nm, l[0].unmapped) : 1.0;
+    double rs0 = r[0].present ? score_value(r[0].len, r[0].nm, r[0].unmapped) : 1.0;
+    if (ls0 < rs0) return true;
+    if (ls0 > rs0) return false;
+    double ls1 = l[1].present ? score_value(l[1].len, l[1].nm, l[1].unmapped) : 1.0;
+    double rs1 = r[1].present ? score_value(r[1].len, r[1].nm, r[1].unmapped) : 1.0;
+    return ls1 < rs1;
+}
+
+// Sequential running-best scan of score_read (caller.rs:1411-1500) evaluated in parallel: the block looks for
+// the first candidate after `pos` that beats the current best, adopts it, and continues behind it.
+// lv / alns / ev are laid out [level][i].
+__global__ __launch_bounds__(1024) void k2_scan_kernel(const K2Level* __restrict__ lv, const sp_aln* __restrict__ alns,
+                                                       const uint32_t* __restrict__ ev, uint32_t ev_stride, uint32_t n,
+                                                       int32_t* __restrict__ best_out) {
+    __shared__ K2Level bl[2];
+    __shared__ sp_aln ba[2];
+    __shared__ uint32_t bev[2][SP_MAX_ED + 1];
+    __shared__ int s_first;
+    __shared__ int s_best;
+    const int tid = threadIdx.x;
+    if (tid < 2) { bl[tid].present = 0; bl[tid].range_start = bl[tid].range_end = 0; bl[tid].len = bl[tid].nm = bl[tid].unmapped = -1; ba[tid].nm = 0; }
+    if (tid == 0) { s_best = -1; }
+    __syncthreads();
+    uint32_t pos = 0;
+    while (pos < n) {
+        if (tid == 0) s_first = 0x7FFFFFFF;
+        __syncthreads();
+        const uint32_t i = pos + tid;
+        bool better = false;
+        if (i < n) {
+            K2Level cl[2] = { lv[i], lv[n + i] };
+            bool decided = false;
+            for (int L = 0; L < 2 && !decided; ++L) {
+                if (cl[L].present && bl[L].present) {
+                    int os = cl[L].range_start > bl[L].range_start ? cl[L].range_start : bl[L].range_start;
+                    int oe = cl[L].range_end < bl[L].range_end ? cl[L].range_end : bl[L].range_end;
+                    int cn = 0, bn = 0;
+                    if (os < oe) {
+                        const sp_aln ca = alns[(uint64_t)L * n + i];
+                        cn = k2_range_edits(cl[L], ca, ev + ((uint64_t)L * n + i) * ev_stride, os, oe);
+                        bn = k2_range_edits(bl[L], ba[L], bev[L], os, oe);
+                    }
+                    if (cn < bn) { better = true; decided = true; }
+                    else if (cn > bn) { better = false; decided = true; }
+                } else if (!cl[L].present && !bl[L].present) {
+                } else { better = cl[L].present != 0; decided = true; }
+            }
+            if (!decided) better = k2_score_less(cl, bl);
+        }
+        if (better) atomicMin(&s_first, (int)i);
+        __syncthreads();
+        const int first = s_first;
+        if (first != 0x7FFFFFFF) {
+            if (tid < 2) { bl[tid] = lv[(uint64_t)tid * n + first]; ba[tid] = alns[(uint64_t)tid * n + first]; }
+            for (int x = tid; x < 2 * (SP_MAX_ED + 1); x += 1024) {
+                int L = x / (SP_MAX_ED + 1), y = x % (SP_MAX_ED + 1);
+                bev[L][y] = (uint32_t)y < ev_stride ? ev[((uint64_t)L * n + first) * ev_stride + y] : 0;
+            }
+            if (tid == 0) s_best = first;
+            pos = (uint32_t)first + 1;
+        } else {
+            pos += 1024;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) best_out[0] = s_best;
+}
+
+__global__ void k2_stats_kernel(const K2Level* __restrict__ lv, uint32_t n, const uint32_t* __restrict__ allele_idx, int32_t* __restrict__ stats) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t* s = stats + (uint64_t)allele_idx[i] * 6;
+    for (int L = 0; L < 2; ++L) {
+        K2Level l = lv[(uint64_t)L * n + i];
+        s[L * 3 + 0] = l.present ? l.len : -1; s[L * 3 + 1] = l.present ? l.nm : -1; s[L * 3 + 2] = l.present ? l.unmapped : -1;
+    }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static std::string revcomp(const char* s, size_t n) {
+    std::string r(n, 'N');
+    for (size_t i = 0; i < n; ++i) {
+        char c = s[n - 1 - i];
+        switch (c) { case 'A': case 'a': r[i] = 'T'; break; case 'C': case 'c': r[i] = 'G'; break;
+                     case 'G': case 'g': r[i] = 'C'; break; case 'T': case 't': r[i] = 'A'; break; default: r[i] = 'N'; }
+    }
+    return r;
+}
+
+template <typename T> static T* dev_copy(const std::vector<T>& v) {
+    T* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(1, v.size()) * sizeof(T)) != hipSuccess) return nullptr;
+    if (!v.empty()) (void)hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+
+extern "C" {
+
+void sp_hla_db_free(sp_hla_db* db) {
+    if (!db) return;
+    if (db->ctx) (void)hipSetDevice(db->ctx->device);
+    sp_seqset_free(db->dna_gene); sp_seqset_free(db->cdna_gene); sp_seqset_free(db->dna_fwd); sp_seqset_free(db->ref_fwd);
+    (void)hipFree(db->d_gene_of); (void)hipFree(db->d_off_fwd); (void)hipFree(db->d_am);
+    (void)hipFree(db->d_hpc_ref); (void)hipFree(db->d_hpc_ref_off);
+    delete db;
+}
+
+int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) {
+    if (!ctx || !d || !out || !d->gene_of || !d->dna_off || !d->cdna_off || !d->gene_ref_off || !d->gene_fwd) return SP_ERR_INVALID_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    sp_hla_db* db = new (std::nothrow) sp_hla_db();
+    if (!db) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "hla db");
+    db->ctx = ctx; db->n_alleles = d->n_alleles; db->n_genes = d->n_genes; db->ref_buffer = d->ref_buffer;
+    db->gene_of.assign(d->gene_of, d->gene_of + d->n_alleles);
+    db->gene_fwd.assign(d->gene_fwd, d->gene_fwd + d->n_genes);
+    db->gene_alleles.resize(d->n_genes);
+    db->has_dna.resize(d->n_alleles);
+    for (uint32_t a = 0; a < d->n_alleles; ++a) {
+        if (db->gene_of[a] >= d->n_genes) { delete db; return sp_fail(ctx, SP_ERR_INVALID_ARG, "hla db: gene index out of range"); }
+        db->gene_alleles[db->gene_of[a]].push_back(a);
+        db->has_dna[a] = d->dna_off[a + 1] > d->dna_off[a];
+    }
+    int rc = sp_seqset_upload(ctx, d->dna, d->dna_off, d->n_alleles, &db->dna_gene);
+    if (rc == SP_OK) rc = sp_seqset_upload(ctx, d->cdna, d->cdna_off, d->n_alleles, &db->cdna_gene);
+    if (rc == SP_OK) rc = sp_seqset_upload(ctx, d->gene_ref, d->gene_ref_off, d->n_genes, &db->ref_fwd);
+    if (rc == SP_OK) {
+        // hg38-oriented copy of every DNA allele (create_hla_fasta, realigner.rs:497-526)
+        std::string blob; std::vector<uint64_t> off(d->n_alleles + 1, 0);
+        blob.reserve(d->dna_off[d->n_alleles]);
+        for (uint32_t a = 0; a < d->n_alleles; ++a) {
+            const char* s = d->dna + d->dna_off[a]; size_t len = d->dna_off[a + 1] - d->dna_off[a];
+            if (db->gene_fwd[db->gene_of[a]]) blob.append(s, len); else blob += revcomp(s, len);
+            off[a + 1] = blob.size();
+        }
+        rc = sp_seqset_upload(ctx, blob.data(), off.data(), d->n_alleles, &db->dna_fwd);
+    }
+    if (rc != SP_OK) { sp_hla_db_free(db); return rc; }
+    if ((rc = sp_seqset_build_index(ctx, db->ref_fwd)) != SP_OK) { sp_hla_db_free(db); return rc; }
+    db->d_gene_of = dev_copy(db->gene_of);
+
+    // hpc_pos tables of the gene references (homopolymers.rs:25-42)
+    {
+        std::vector<int32_t> hp; std::vector<uint64_t> hoff(d->n_genes + 1, 0);
+        for (uint32_t g = 0; g < d->n_genes; ++g) {
+            const char* s = d->gene_ref + d->gene_ref_off[g]; size_t len = d->gene_ref_off[g + 1] - d->gene_ref_off[g];
+            hoff[g] = hp.size();
+            int runs = 0;
+            for (size_t p = 0; p <= len; ++p) {
+                if (p > 0 && p < len && s[p] != s[p - 1]) ++runs;
+                if (p == len && len > 0) { hp.push_back(runs + 1); break; }   // position >= len -> number of runs
+                hp.push_back(runs);
+            }
+            if (len == 0) hp.push_back(0);
+        }
+        hoff[d->n_genes] = hp.size();
+        db->d_hpc_ref = dev_copy(hp); db->d_hpc_ref_off = dev_copy(hoff);
+    }
+
+    // per-allele frame offset (allele_fwd vs buffered gene reference) and static allele->reference mapping
+    const uint32_t n = d->n_alleles;
+    std::vector<uint32_t> a_idx(n), b_idx(n);
+    for (uint32_t a = 0; a < n; ++a) { a_idx[a] = db->gene_of[a]; b_idx[a] = a; }
+    uint32_t* d_a = dev_copy(a_idx); uint32_t* d_b = dev_copy(b_idx);
+    int32_t *d_diag = nullptr, *d_votes = nullptr;
+    (void)hipMalloc(&d_diag, std::max<size_t>(1, n) * 4); (void)hipMalloc(&d_votes, std::max<size_t>(1, n) * 4);
+    rc = sp_launch_anchor(ctx, db->ref_fwd, db->dna_fwd, d_a, d_b, n, d_diag, d_votes);
+    std::vector<int32_t> diag(n), votes(n), off_fwd(n, SP_NO_DIAG);
+    if (rc == SP_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(diag.data(), d_diag, n * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(votes.data(), d_votes, n * 4, hipMemcpyDeviceToHost);
+        std::vector<CellDesc> cells(n);
+        for (uint32_t a = 0; a < n; ++a) {
+            bool ok = db->has_dna[a] && votes[a] >= K1_MIN_VOTES;
+            if (ok) off_fwd[a] = diag[a];                       // allele_pos - ref_pos
+            cells[a] = CellDesc{a, db->gene_of[a], ok ? -diag[a] : SP_NO_DIAG, SP_MAX_ED, 0, -1};   // A = allele (query), B = ref (target)
+        }
+        CellDesc* d_cells = dev_copy(cells); sp_aln* d_alns = nullptr;
+        (void)hipMalloc(&d_alns, std::max<size_t>(1, n) * sizeof(sp_aln));
+        rc = sp_launch_cells(ctx, db->dna_fwd, db->ref_fwd, d_cells, n, d_alns, nullptr, 0, "db_allele_ref");
+        if (rc == SP_OK) {
+            (void)hipStreamSynchronize(ctx->stream);
+            std::vector<sp_aln> alns(n);
+            (void)hipMemcpy(alns.data(), d_alns, n * sizeof(sp_aln), hipMemcpyDeviceToHost);
+            std::vector<int32_t> am(n * 3, 0);
+            for (uint32_t a = 0; a < n; ++a) {
+                const sp_aln& x = alns[a];
+                // Forward-only, query-based penalised best mapping must beat 1.0 (realigner.rs:295-305)
+                if (x.ok) {
+                    double num = (double)(x.nm + (x.a_len - (x.a_end - x.a_start))); if (num < 0.1) num = 0.1;
+                    if (num / (double)x.a_len < 1.0) { am[a * 3] = 1; am[a * 3 + 1] = x.a_start; am[a * 3 + 2] = x.b_start; }
+                }
+            }
+            db->d_am = dev_copy(am);
+        }
+        (void)hipFree(d_cells); (void)hipFree(d_alns);
+    }
+    db->d_off_fwd = dev_copy(off_fwd);
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_diag); (void)hipFree(d_votes);
+    if (rc != SP_OK) { sp_hla_db_free(db); return rc; }
+    *out = db;
+    return SP_OK;
+}
+
+int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads, sp_hla_realign* out, uint32_t* cell_out) {
+    if (!ctx || !db || !reads || !out) return SP_ERR_INVALID_ARG;
+    const uint32_t R = reads->n, G = db->n_genes, NA = db->n_alleles;
+    if (R == 0) return SP_OK;
+    (void)hipSetDevice(ctx->device);
+    // 1. anchors read x gene
+    std::vector<uint32_t> a_idx((size_t)R * G), b_idx((size_t)R * G);
+    for (uint32_t r = 0; r < R; ++r) for (uint32_t g = 0; g < G; ++g) { a_idx[(size_t)r * G + g] = g; b_idx[(size_t)r * G + g] = r; }
+    uint32_t* d_a = dev_copy(a_idx); uint32_t* d_b = dev_copy(b_idx);
+    int32_t *d_rg = nullptr, *d_votes = nullptr, *d_best = nullptr; uint32_t* d_cells = nullptr; sp_hla_realign* d_out = nullptr;
+    int rc = SP_OK;
+    if (!d_a || !d_b || hipMalloc(&d_rg, (size_t)R * G * 4) != hipSuccess || hipMalloc(&d_votes, (size_t)R * G * 4) != hipSuccess ||
+        hipMalloc(&d_best, (size_t)R * 4) != hipSuccess || hipMalloc(&d_cells, (size_t)R * NA * 4) != hipSuccess ||
+        hipMalloc(&d_out, (size_t)R * sizeof(sp_hla_realign)) != hipSuccess)
+        rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+    if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes);
+    const bool hasn = db->dna_fwd->has_n || reads->has_n || db->ref_fwd->has_n;
+    // slot must hold the allele/read windows of K1 and the reference/segment windows of the finalize step
+    int slot_words = std::max(sp_slot_words(db->dna_fwd, reads, hasn), sp_slot_words(db->ref_fwd, reads, hasn));
+    const size_t lds_bytes = (size_t)slot_words * 16;
+    if (rc == SP_OK && lds_bytes > 160 * 1024 - 64) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
+    if (rc == SP_OK) {
+        const uint32_t n_chunks = (NA + K1_CHUNK - 1) / K1_CHUNK;
+        ProfScope ps(ctx, "k1_cells", (uint64_t)R * NA);
+        if (hasn) {
+            (void)hipFuncSetAttribute((const void*)k1_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k1_cells_kernel<true>, dim3(R * n_chunks), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), reads->view(),
+                               db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, slot_words);
+        } else {
+            (void)hipFuncSetAttribute((const void*)k1_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k1_cells_kernel<false>, dim3(R * n_chunks), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), reads->view(),
+                               db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, slot_words);
+        }
+        if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_cells launch failed");
+    }
+    if (rc == SP_OK) {
+        ProfScope ps(ctx, "k1_reduce", R);
+        hipLaunchKernelGGL(k1_reduce_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, d_cells, db->dna_fwd->d_len, NA, R, d_best);
+    }
+    if (rc == SP_OK) {
+        ProfScope ps(ctx, "k1_finalize", R);
+        if (hasn) {
+            (void)hipFuncSetAttribute((const void*)k1_finalize_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k1_finalize_kernel<true>, dim3((R + 3) / 4), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), db->dna_gene->view(),
+                               db->ref_fwd->view(), reads->view(), db->d_gene_of, db->d_off_fwd, d_rg, (int)G, db->d_am, db->d_hpc_ref, db->d_hpc_ref_off,
+                               d_best, R, d_out, slot_words);
+        } else {
+            (void)hipFuncSetAttribute((const void*)k1_finalize_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(k1_finalize_kernel<false>, dim3((R + 3) / 4), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), db->dna_gene->view(),
+                               db->ref_fwd->view(), reads->view(), db->d_gene_of, db->d_off_fwd, d_rg, (int)G, db->d_am, db->d_hpc_ref, db->d_hpc_ref_off,
+                               d_best, R, d_out, slot_words);
+        }
+        if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_finalize launch failed");
+    }
+    if (rc == SP_OK) {
+        (void)hipMemcpyAsync(out, d_out, (size_t)R * sizeof(sp_hla_realign), hipMemcpyDeviceToHost, ctx->stream);
+        if (cell_out) (void)hipMemcpyAsync(cell_out, d_cells, (size_t)R * NA * 4, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("realign: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_rg); (void)hipFree(d_votes); (void)hipFree(d_best); (void)hipFree(d_cells); (void)hipFree(d_out);
+    return rc;
+}
+
+int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
+                               const char* cons_dna, uint32_t cons_dna_len, const char* cons_cdna, uint32_t cons_cdna_len,
+                               int32_t require_dna, int32_t disable_cdna, sp_hla_best* best, int32_t* stats) {
+    if (!ctx || !db || !best || gene >= db->n_genes || (cons_dna_len && !cons_dna) || (cons_cdna_len && !cons_cdna)) return SP_ERR_INVALID_ARG;
+    // "If cDNA scoring is disabled, require HLA DNA must be enabled" (caller.rs:517-520)
+    if (disable_cdna && !require_dna) return sp_fail(ctx, SP_ERR_INVALID_ARG, "If cDNA scoring is disabled, require HLA DNA must be enabled");
+    (void)hipSetDevice(ctx->device);
+    best->best_allele = -1; best->n_scored = 0;
+    // allowed alleles of the gene, database order (is_allowed_allele_def, caller.rs:1090-1095)
+    std::vector<uint32_t> idx;
+    for (uint32_t a : db->gene_alleles[gene]) if (db->has_dna[a] || !require_dna) idx.push_back(a);
+    const uint32_t n = (uint32_t)idx.size();
+    best->n_scored = (int32_t)n;
+    if (stats) for (uint32_t a = 0; a < db->n_alleles; ++a) for (int k = 0; k < 6; ++k) stats[(size_t)a * 6 + k] = -2;
+    if (n == 0) return SP_OK;
+    // consensus set: [0] = cDNA, [1] = DNA
+    std::string blob; uint64_t coff[3] = {0, 0, 0};
+    if (!disable_cdna) blob.append(cons_cdna, cons_cdna_len);
+    coff[1] = blob.size();
+    blob.append(cons_dna, cons_dna_len);
+    coff[2] = blob.size();
+    sp_seqset* cons = nullptr;
+    int rc = sp_seqset_upload(ctx, blob.data(), coff, 2, &cons);
+    if (rc != SP_OK) return rc;
+    if ((rc = sp_seqset_build_index(ctx, cons)) != SP_OK) { sp_seqset_free(cons); return rc; }
+    const uint32_t stride = SP_MAX_ED;
+    uint32_t* d_idx = dev_copy(idx);
+    std::vector<uint32_t> lvl(n);
+    uint32_t *d_l0 = nullptr, *d_l1 = nullptr; int32_t *d_diag = nullptr, *d_votes = nullptr, *d_best = nullptr, *d_stats = nullptr;
+    CellDesc* d_cells = nullptr; sp_aln* d_alns = nullptr; uint32_t* d_ev = nullptr; K2Level* d_lv = nullptr;
+    std::fill(lvl.begin(), lvl.end(), 0u); d_l0 = dev_copy(lvl);
+    std::fill(lvl.begin(), lvl.end(), 1u); d_l1 = dev_copy(lvl);
+    if (!d_idx || !d_l0 || !d_l1 || hipMalloc(&d_diag, (size_t)n * 4) != hipSuccess || hipMalloc(&d_votes, (size_t)n * 4) != hipSuccess ||
+        hipMalloc(&d_best, 4) != hipSuccess || hipMalloc(&d_cells, (size_t)n * sizeof(CellDesc)) != hipSuccess ||
+        hipMalloc(&d_alns, (size_t)2 * n * sizeof(sp_aln)) != hipSuccess || hipMalloc(&d_ev, (size_t)2 * n * stride * 4) != hipSuccess ||
+        hipMalloc(&d_lv, (size_t)2 * n * sizeof(K2Level)) != hipSuccess ||
+        (stats && hipMalloc(&d_stats, (size_t)db->n_alleles * 6 * 4) != hipSuccess))
+        rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus buffers");
+    const unsigned tb = 256, nb = (n + tb - 1) / tb;
+    for (int L = 0; L < 2 && rc == SP_OK; ++L) {
+        const sp_seqset* aset = L == 0 ? db->cdna_gene : db->dna_gene;
+        rc = sp_launch_anchor(ctx, cons, aset, L == 0 ? d_l0 : d_l1, d_idx, n, d_diag, d_votes);
+        if (rc != SP_OK) break;
+        hipLaunchKernelGGL(k2_build_cells_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_idx, n, (uint32_t)L, d_diag, d_votes, aset->d_len, d_cells);
+        (void)hipMemsetAsync(d_ev + (size_t)L * n * stride, 0, (size_t)n * stride * 4, ctx->stream);
+        rc = sp_launch_cells(ctx, aset, cons, d_cells, n, d_alns + (size_t)L * n, d_ev + (size_t)L * n * stride, stride, L == 0 ? "k2_cells_cdna" : "k2_cells_dna");
+        if (rc != SP_OK) break;
+        hipLaunchKernelGGL(k2_levels_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_alns + (size_t)L * n, n, d_lv + (size_t)L * n);
+    }
+    if (rc == SP_OK) {
+        ProfScope ps(ctx, "k2_scan", n);
+        hipLaunchKernelGGL(k2_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_lv, d_alns, d_ev, stride, n, d_best);
+    }
+    if (rc == SP_OK && stats) {
+        (void)hipMemcpyAsync(d_stats, stats, (size_t)db->n_alleles * 6 * 4, hipMemcpyHostToDevice, ctx->stream);
+        hipLaunchKernelGGL(k2_stats_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_lv, n, d_idx, d_stats);
+        (void)hipMemcpyAsync(stats, d_stats, (size_t)db->n_alleles * 6 * 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (rc == SP_OK) {
+        int32_t b = -1;
+        (void)hipMemcpyAsync(&b, d_best, 4, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("score_consensus: ") + hipGetErrorString(e));
+        else best->best_allele = b >= 0 ? (int32_t)idx[b] : -1;
+    }
+    (void)hipFree(d_idx); (void)hipFree(d_l0); (void)hipFree(d_l1); (void)hipFree(d_diag); (void)hipFree(d_votes); (void)hipFree(d_best);
+    (void)hipFree(d_cells); (void)hipFree(d_alns); (void)hipFree(d_ev); (void)hipFree(d_lv); (void)hipFree(d_stats);
+    sp_seqset_free(cons);
+    return rc;
+}
+
+} // extern "C"

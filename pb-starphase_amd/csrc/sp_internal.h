@@ -1,0 +1,103 @@
+// sp_internal.h -- shared host/device declarations of libstarphase_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/starphase_hip.h"
+
+#define SP_NEG        (-(1 << 28))
+#define SP_WAVE       64
+#define SP_MAXOCC     4
+#define SP_CELL_NONE  0xFFFFFFFFu
+
+// ---------------------------------------------------------------- device views
+// Packed sequence set in HBM.  2 bits/base, 16 bases per 32-bit word, base b of a sequence sits in bits
+// [2*(b&15), 2*(b&15)+1] of word (b>>4).  Every sequence starts on a 16-byte boundary (4 words) so a wavefront
+// stages it with coalesced dword loads, and is followed by >= 2 zero guard words.  nplane has the same
+// layout with 01 at every non-ACGT base (only allocated when the set contains such bases).
+struct SeqSetView {
+    const uint32_t* words;
+    const uint32_t* nplane;      // nullptr when the set has no N
+    const uint64_t* word_off;    // n+1
+    const int32_t*  len;         // n
+    uint32_t n;
+};
+
+// sorted k-mer table of the sequences of an indexed set (the "A" side of sp_anchor_batch)
+struct KmerIndexView {
+    const uint32_t* code;        // sorted per sequence
+    const int32_t*  pos;
+    const uint64_t* off;         // n+1 entry offsets
+};
+
+struct sp_seqset {
+    sp_ctx* ctx = nullptr;
+    uint32_t n = 0;
+    bool has_n = false;
+    std::vector<int32_t>  h_len;
+    std::vector<uint64_t> h_word_off;
+    std::vector<uint32_t> h_words;     // kept for index building / views
+    uint32_t* d_words = nullptr;
+    uint32_t* d_nplane = nullptr;
+    uint64_t* d_word_off = nullptr;
+    int32_t*  d_len = nullptr;
+    int32_t   max_len = 0;
+    // lazily built k-mer index
+    bool has_index = false;
+    uint32_t* d_kcode = nullptr; int32_t* d_kpos = nullptr; uint64_t* d_koff = nullptr;
+    SeqSetView view() const { return SeqSetView{d_words, d_nplane, d_word_off, d_len, n}; }
+    KmerIndexView kview() const { return KmerIndexView{d_kcode, d_kpos, d_koff}; }
+};
+
+struct ProfileEntry { double ms = 0; uint64_t launches = 0; uint64_t cells = 0; };
+
+struct sp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bool profiling = true;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, ProfileEntry> prof;
+    // reusable scratch
+    void* scratch = nullptr; size_t scratch_bytes = 0;
+    int num_cus = 256;
+};
+
+// cell descriptor consumed by the generic WFA kernel
+struct CellDesc {
+    uint32_t a, b;
+    int32_t  diag;          // b_pos - a_pos (in full-sequence coordinates of a and b views)
+    int32_t  max_ed;
+    int32_t  b_lo, b_hi;    // sub-range of B that is the "real" sequence for this cell (segment views); b_hi<0 => whole
+};
+
+// ---------------------------------------------------------------- launchers (sp_device.hip)
+int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                     const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,
+                     int32_t* d_diag, int32_t* d_votes);
+int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                    const CellDesc* d_cells, uint64_t n_cells,
+                    sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name);
+
+void* sp_scratch(sp_ctx* ctx, size_t bytes);
+int   sp_fail(sp_ctx* ctx, int code, const std::string& msg);
+#define SP_HIP_CHECK(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
+    return sp_fail((ctx), SP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+
+struct ProfScope {
+    sp_ctx* ctx; const char* name; uint64_t cells;
+    ProfScope(sp_ctx* c, const char* n, uint64_t cells_) : ctx(c), name(n), cells(cells_) {
+        if (ctx->profiling && name) hipEventRecord(ctx->ev0, ctx->stream);
+    }
+    ~ProfScope() {
+        if (ctx->profiling && name) {
+            hipEventRecord(ctx->ev1, ctx->stream);
+            hipEventSynchronize(ctx->ev1);
+            float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+            auto& e = ctx->prof[name]; e.ms += ms; e.launches += 1; e.cells += cells;
+        }
+    }
+};

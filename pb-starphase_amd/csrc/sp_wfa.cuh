@@ -1,0 +1,189 @@
+// sp_wfa.cuh -- the wavefront-alignment cell for gfx950: ONE 64-lane wavefront per (A, B) cell,
+// lane l <-> diagonal (diag - 32 + l).  Device-side mirror of the contract in DESIGN.md section 3
+// (restated for the CPU in oracle/align.c; the two must agree bit for bit).
+//
+// Replaces the base-level alignment inside minimap2::Aligner::map at every hot-path call site of the
+// reference (src/hla/realigner.rs:116,231,290; src/hla/caller.rs:1277,1436; src/cyp2d6/haplotyper.rs:198,395;
+// src/cyp2d6/chaining.rs:58).
+//
+// Data movement: both sequences are 2-bit packed in HBM (16 bases per dword).  A wavefront stages only the
+// band-reachable window of each sequence into its private LDS slot with coalesced dword loads (64 dwords =
+// 1,024 bases per wave instruction), then runs entirely out of LDS + registers: the whole DP state is ONE
+// VGPR per lane (furthest-reaching A position on that diagonal) plus one VGPR for the origin diagonal.
+#pragma once
+#include "sp_internal.h"
+
+namespace spw {
+
+__device__ __forceinline__ uint32_t load16(const uint32_t* __restrict__ s, int p) {
+    // 16 bases starting at base position p of an LDS-resident packed sequence (guard word guaranteed)
+    int w = p >> 4;
+    uint32_t lo = s[w], hi = s[w + 1];
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)((p & 15) << 1));
+}
+
+template <bool HASN>
+__device__ __forceinline__ int match16(const uint32_t* __restrict__ LA, const uint32_t* __restrict__ NA, int pa,
+                                       const uint32_t* __restrict__ LB, const uint32_t* __restrict__ NB, int pb, int rem) {
+    uint32_t x = load16(LA, pa) ^ load16(LB, pb);
+    uint32_t mm = (x | (x >> 1)) & 0x55555555u;
+    if (HASN) mm |= (load16(NA, pa) | load16(NB, pb));
+    int nmatch = mm ? ((__builtin_ffs((int)mm) - 1) >> 1) : 16;
+    return nmatch < rem ? nmatch : rem;
+}
+
+struct CellIn {
+    const uint32_t* a_words; const uint32_t* a_nplane; int a0, a1;   // A view [a0,a1) in full-sequence bases
+    const uint32_t* b_words; const uint32_t* b_nplane; int b0, b1;   // B view
+    int diag;      // (b view pos) - (a view pos)
+    int max_ed;
+};
+
+struct CellOut {
+    int ok, nm, a_start, a_end, b_start, b_end;
+};
+
+// stage bases [lo,hi) (full-sequence coordinates) of a packed sequence into dst; returns the base index of dst[0]
+__device__ __forceinline__ int stage(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int lo, int hi, int lane) {
+    int w0 = lo >> 4;
+    int nw = ((hi + 15) >> 4) - w0 + 2;            // + guard words (the source carries >= 2 zero guard words)
+    for (int w = lane; w < nw; w += SP_WAVE) dst[w] = src[w0 + w];
+    return w0 << 4;
+}
+
+__device__ __forceinline__ int words_needed(int lo, int hi) { return ((hi + 15) >> 4) - (lo >> 4) + 2; }
+
+// The cell.  All 64 lanes call it together.  slot: this wave's LDS area (slot_words dwords).
+// hist (TRACE only): this wave's global scratch, (max_ed+1)*64 uint16.  events (TRACE only): >= max_ed words.
+template <bool TRACE, bool HASN>
+__device__ __forceinline__ void wfa_cell(const CellIn& c, uint32_t* __restrict__ slot, int slot_words, int lane,
+                                         uint16_t* __restrict__ hist, uint32_t* __restrict__ events, CellOut& out) {
+    out.ok = 0; out.nm = 0; out.a_start = out.a_end = out.b_start = out.b_end = 0;
+    const int m = c.a1 - c.a0, n = c.b1 - c.b0;
+    if (m <= 0 || n <= 0 || c.max_ed < 0) return;
+    const int kb = c.diag - SP_BAND / 2;
+    // band-reachable windows (view coordinates)
+    int j_min = kb > 0 ? kb : 0;
+    int j_max = m + kb + SP_BAND - 1; if (j_max > n) j_max = n;
+    int i_min = -(kb + SP_BAND - 1); if (i_min < 0) i_min = 0;
+    int i_max = n - kb; if (i_max > m) i_max = m;
+    if (j_max <= j_min || i_max <= i_min) return;
+    const int alo = c.a0 + i_min, ahi = c.a0 + i_max, blo = c.b0 + j_min, bhi = c.b0 + j_max;
+    const int wa = words_needed(alo, ahi), wb = words_needed(blo, bhi);
+    if ((HASN ? 2 : 1) * (wa + wb) > slot_words) return;        // host sizes the slot; defensive
+    uint32_t* LA = slot; uint32_t* LB = slot + wa;
+    uint32_t* NA = HASN ? slot + wa + wb : nullptr; uint32_t* NB = HASN ? slot + 2 * wa + wb : nullptr;
+    const int a_base = stage(LA, c.a_words, alo, ahi, lane);
+    const int b_base = stage(LB, c.b_words, blo, bhi, lane);
+    if (HASN) {
+        // a set without N has no plane: treat as all zero
+        if (c.a_nplane) stage(NA, c.a_nplane, alo, ahi, lane); else for (int w = lane; w < wa; w += SP_WAVE) NA[w] = 0;
+        if (c.b_nplane) stage(NB, c.b_nplane, blo, bhi, lane); else for (int w = lane; w < wb; w += SP_WAVE) NB[w] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int a_sh = c.a0 - a_base, b_sh = c.b0 - b_base;        // LDS base position of view position 0
+    const int k = kb + lane;
+
+    // extension of every lane from view position `start` (SP_NEG = invalid lane); returns new furthest i
+    auto extend = [&](int start) -> int {
+        int i = start;
+        int rem = 0;
+        bool going = false;
+        if (start >= 0) {
+            int ra = m - i, rb = n - (i + k);
+            rem = ra < rb ? ra : rb;
+            going = rem > 0;
+        }
+        if (going) {
+            int nmv = match16<HASN>(LA, NA, i + a_sh, LB, NB, i + k + b_sh, rem);
+            i += nmv; rem -= nmv;
+            going = (nmv == 16) && rem > 0;
+        }
+        // lanes still matching after 16 bases finish cooperatively: all 64 lanes compare 1,024 bases per step
+        uint64_t longmask = __ballot(going);
+        while (longmask) {
+            const int src = __builtin_ctzll(longmask);
+            longmask &= longmask - 1;
+            int ci = __builtin_amdgcn_readlane(i, src);
+            int crem = __builtin_amdgcn_readlane(rem, src);
+            const int ck = kb + src;
+            int total = 0;
+            for (;;) {
+                int off = lane << 4;
+                int r = crem - off;
+                int nmv = r > 0 ? match16<HASN>(LA, NA, ci + off + a_sh, LB, NB, ci + off + ck + b_sh, r) : 0;
+                uint64_t stop = __ballot(nmv < 16);
+                if (stop) {
+                    int t = __builtin_ctzll(stop);
+                    total += (t << 4) + __builtin_amdgcn_readlane(nmv, t);
+                    break;
+                }
+                total += SP_WAVE * 16; ci += SP_WAVE * 16; crem -= SP_WAVE * 16;
+            }
+            if (lane == src) i += total;
+        }
+        return start >= 0 ? i : SP_NEG;
+    };
+
+    // s = 0 : every band diagonal may start for free on the first row / first column
+    int H, O = lane;
+    {
+        int i0 = k < 0 ? -k : 0, j0 = i0 + k;
+        H = extend((i0 < m && j0 < n) ? i0 : SP_NEG);
+    }
+    if (TRACE) hist[lane] = (uint16_t)(H >= 0 ? H : 0xFFFF);
+    int s = 0, end_lane = -1;
+    for (;;) {
+        const bool valid = H >= 0;
+        const int j = H + k;
+        const bool reached = valid && (H == m || j == n);
+        if (__ballot(reached)) {
+            int cdist = lane - SP_BAND / 2; if (cdist < 0) cdist = -cdist;
+            int key = reached ? ((H + j) * 8192 + (SP_BAND - cdist) * 64 + (SP_BAND - 1 - lane)) : -1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(key, o); key = other > key ? other : key; }
+            end_lane = __builtin_amdgcn_readfirstlane((SP_BAND - 1) - (key & 63));
+            break;
+        }
+        if (s == c.max_ed) break;
+        int up = __shfl_up(H, 1), dn = __shfl_down(H, 1);
+        int oup = __shfl_up(O, 1), odn = __shfl_down(O, 1);
+        int best = valid ? H + 1 : SP_NEG; int o = O;
+        if (lane > 0 && up >= 0 && up > best) { best = up; o = oup; }
+        if (lane < SP_BAND - 1 && dn >= 0 && dn + 1 > best) { best = dn + 1; o = odn; }
+        H = extend(best >= 0 ? best : SP_NEG);
+        O = o;
+        ++s;
+        if (TRACE) hist[s * SP_WAVE + lane] = (uint16_t)(H >= 0 ? H : 0xFFFF);
+    }
+    if (end_lane < 0) return;
+    const int he = __builtin_amdgcn_readlane(H, end_lane);
+    const int oe = __builtin_amdgcn_readlane(O, end_lane);
+    out.ok = 1; out.nm = s;
+    out.a_end = he; out.b_end = he + kb + end_lane;
+    {
+        int ko = kb + oe; int i0 = ko < 0 ? -ko : 0;
+        out.a_start = i0; out.b_start = i0 + ko;
+    }
+    if (TRACE) {
+        int l = end_lane;
+        for (int t = s; t > 0; --t) {
+            uint16_t raw = hist[(t - 1) * SP_WAVE + lane];
+            int Hp = raw == 0xFFFF ? SP_NEG : (int)raw;
+            int cc = __builtin_amdgcn_readlane(Hp, l);
+            int uu = l > 0 ? __builtin_amdgcn_readlane(Hp, l - 1) : SP_NEG;
+            int dd = l < SP_BAND - 1 ? __builtin_amdgcn_readlane(Hp, l + 1) : SP_NEG;
+            int best = cc >= 0 ? cc + 1 : SP_NEG; int src = l; uint32_t type = SP_EV_X;
+            if (uu >= 0 && uu > best) { best = uu; src = l - 1; type = SP_EV_D; }
+            if (dd >= 0 && dd + 1 > best) { best = dd + 1; src = l + 1; type = SP_EV_I; }
+            int kk = kb + l;
+            int bpos = type == SP_EV_X ? best - 1 + kk : (type == SP_EV_D ? best + kk - 1 : best + kk);
+            if (lane == 0) events[t - 1] = (type << 30) | (uint32_t)bpos;
+            l = src;
+        }
+    }
+}
+
+} // namespace spw

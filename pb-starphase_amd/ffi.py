@@ -1,0 +1,259 @@
+"""ctypes binding of include/starphase_hip.h (one-to-one; no logic lives here)."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libstarphase_hip.so")
+
+
+class StarphaseError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"starphase_hip error {code}: {msg}")
+        self.code = code
+
+
+SP_OK = 0
+SP_ERR_NO_DEVICE = 2
+SP_NO_DIAG = -(2 ** 31)
+SP_MAX_ED = 255
+
+
+class sp_pair(C.Structure):
+    _fields_ = [("a", C.c_uint32), ("b", C.c_uint32), ("diag", C.c_int32), ("max_ed", C.c_int32)]
+
+
+class sp_aln(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("ok", "nm", "a_start", "a_end", "b_start", "b_end", "a_len", "b_len")]
+
+
+class sp_hla_db_desc(C.Structure):
+    _fields_ = [
+        ("n_alleles", C.c_uint32), ("n_genes", C.c_uint32),
+        ("gene_of", C.c_void_p),
+        ("dna", C.c_char_p), ("dna_off", C.c_void_p),
+        ("cdna", C.c_char_p), ("cdna_off", C.c_void_p),
+        ("gene_ref", C.c_char_p), ("gene_ref_off", C.c_void_p),
+        ("gene_fwd", C.c_void_p),
+        ("exon_off", C.c_void_p), ("exon_start", C.c_void_p), ("exon_end", C.c_void_p),
+        ("ref_buffer", C.c_int32),
+    ]
+
+
+class sp_hla_realign(C.Structure):
+    _fields_ = [("status", C.c_int32), ("best_allele", C.c_int32), ("gene", C.c_int32),
+                ("nm", C.c_int32), ("target_len", C.c_int32), ("unmapped", C.c_int32),
+                ("aln", sp_aln),
+                ("seg_start", C.c_int32), ("seg_end", C.c_int32),
+                ("dna_offset", C.c_int32), ("hpc_offset", C.c_int32)]
+
+
+class sp_hla_best(C.Structure):
+    _fields_ = [("best_allele", C.c_int32), ("n_scored", C.c_int32)]
+
+
+ALN_DTYPE = np.dtype([(n, np.int32) for n in ("ok", "nm", "a_start", "a_end", "b_start", "b_end", "a_len", "b_len")])
+REALIGN_DTYPE = np.dtype([("status", np.int32), ("best_allele", np.int32), ("gene", np.int32),
+                          ("nm", np.int32), ("target_len", np.int32), ("unmapped", np.int32),
+                          ("aln", ALN_DTYPE),
+                          ("seg_start", np.int32), ("seg_end", np.int32),
+                          ("dna_offset", np.int32), ("hpc_offset", np.int32)])
+
+_lib = None
+
+
+def lib():
+    """Load libstarphase_hip.so (in-tree build).  Raises if it is missing: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP extension is the product; there is no fallback)")
+    L = C.CDLL(path)
+    vp, u32, i32, u64 = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint64
+    sigs = {
+        "sp_abi_version": (i32, []),
+        "sp_device_count": (i32, [C.POINTER(i32)]),
+        "sp_ctx_create": (i32, [i32, vp, C.POINTER(vp)]),
+        "sp_ctx_destroy": (None, [vp]),
+        "sp_last_error": (C.c_char_p, [vp]),
+        "sp_ctx_synchronize": (i32, [vp]),
+        "sp_seqset_upload": (i32, [vp, C.c_char_p, vp, u32, C.POINTER(vp)]),
+        "sp_seqset_free": (None, [vp]),
+        "sp_seqset_count": (i32, [vp, C.POINTER(u32)]),
+        "sp_seqset_length": (i32, [vp, u32, C.POINTER(u32)]),
+        "sp_anchor_batch": (i32, [vp, vp, vp, vp, vp, u64, vp, vp]),
+        "sp_align_batch": (i32, [vp, vp, vp, vp, u64, vp, vp, u32]),
+        "sp_hla_db_create": (i32, [vp, C.POINTER(sp_hla_db_desc), C.POINTER(vp)]),
+        "sp_hla_db_free": (None, [vp]),
+        "sp_hla_realign_reads": (i32, [vp, vp, vp, vp, vp]),
+        "sp_hla_score_consensus": (i32, [vp, vp, u32, C.c_char_p, u32, C.c_char_p, u32, i32, i32, C.POINTER(sp_hla_best), vp]),
+        "sp_profile_reset": (i32, [vp]),
+        "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)           # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _concat(seqs):
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    if len(seqs):
+        offs[1:] = np.cumsum([len(s) for s in seqs])
+    blob = "".join(seqs).encode("ascii") if len(seqs) and isinstance(seqs[0], str) else b"".join(seqs)
+    return blob, offs
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        rc = lib().sp_ctx_create(int(device), stream, C.byref(self._h))
+        if rc != SP_OK:
+            raise StarphaseError(rc, "sp_ctx_create failed (no gfx950 device?)")
+
+    def check(self, rc):
+        if rc != SP_OK:
+            raise StarphaseError(rc, lib().sp_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().sp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self.check(lib().sp_ctx_synchronize(self._h))
+
+    def upload(self, seqs):
+        return SeqSet(self, seqs)
+
+    def anchor_batch(self, A, B, a_idx, b_idx):
+        a_idx = np.ascontiguousarray(a_idx, np.uint32)
+        b_idx = np.ascontiguousarray(b_idx, np.uint32)
+        n = len(a_idx)
+        diag = np.zeros(n, np.int32)
+        votes = np.zeros(n, np.int32)
+        self.check(lib().sp_anchor_batch(self._h, A._h, B._h, _ptr(a_idx), _ptr(b_idx), n, _ptr(diag), _ptr(votes)))
+        return diag, votes
+
+    def align_batch(self, A, B, a_idx, b_idx, diag, max_ed, events=False):
+        n = len(a_idx)
+        pairs = np.zeros(n, np.dtype([("a", np.uint32), ("b", np.uint32), ("diag", np.int32), ("max_ed", np.int32)]))
+        pairs["a"] = a_idx
+        pairs["b"] = b_idx
+        pairs["diag"] = diag
+        pairs["max_ed"] = max_ed
+        out = np.zeros(n, ALN_DTYPE)
+        ev = None
+        stride = 0
+        if events:
+            stride = int(np.max(pairs["max_ed"])) if n else 1
+            stride = max(1, stride)
+            ev = np.zeros((n, stride), np.uint32)
+        self.check(lib().sp_align_batch(self._h, A._h, B._h, _ptr(pairs), n, _ptr(out), _ptr(ev), stride))
+        return (out, ev) if events else out
+
+    def profile_reset(self):
+        self.check(lib().sp_profile_reset(self._h))
+
+    def profile_get(self, name):
+        ms, launches, cells = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        self.check(lib().sp_profile_get(self._h, name.encode(), C.byref(ms), C.byref(launches), C.byref(cells)))
+        return ms.value, launches.value, cells.value
+
+
+class SeqSet:
+    def __init__(self, ctx, seqs):
+        self.ctx = ctx
+        self.n = len(seqs)
+        self.lengths = np.array([len(s) for s in seqs], np.int64)
+        blob, offs = _concat(list(seqs))
+        self._h = C.c_void_p()
+        ctx.check(lib().sp_seqset_upload(ctx._h, blob, _ptr(offs), self.n, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().sp_seqset_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HlaDb:
+    """sp_hla_db: alleles in database-key order + gene references (see include/starphase_hip.h)."""
+
+    def __init__(self, ctx, gene_of, dna, cdna, gene_ref, gene_fwd, exons, ref_buffer=100):
+        self.ctx = ctx
+        self.n_alleles = len(dna)
+        self.n_genes = len(gene_ref)
+        gene_of = np.ascontiguousarray(gene_of, np.uint32)
+        dblob, doff = _concat(list(dna))
+        cblob, coff = _concat(list(cdna))
+        rblob, roff = _concat(list(gene_ref))
+        gfwd = np.ascontiguousarray(gene_fwd, np.uint8)
+        eoff = np.zeros(self.n_genes + 1, np.uint32)
+        es, ee = [], []
+        for g, ex in enumerate(exons):
+            eoff[g + 1] = eoff[g] + len(ex)
+            es += [e[0] for e in ex]
+            ee += [e[1] for e in ex]
+        es = np.ascontiguousarray(es, np.int32)
+        ee = np.ascontiguousarray(ee, np.int32)
+        d = sp_hla_db_desc()
+        d.n_alleles, d.n_genes = self.n_alleles, self.n_genes
+        d.gene_of = _ptr(gene_of)
+        d.dna, d.dna_off = dblob, _ptr(doff)
+        d.cdna, d.cdna_off = cblob, _ptr(coff)
+        d.gene_ref, d.gene_ref_off = rblob, _ptr(roff)
+        d.gene_fwd = _ptr(gfwd)
+        d.exon_off, d.exon_start, d.exon_end = _ptr(eoff), _ptr(es), _ptr(ee)
+        d.ref_buffer = ref_buffer
+        self._keep = (gene_of, dblob, doff, cblob, coff, rblob, roff, gfwd, eoff, es, ee)
+        self._h = C.c_void_p()
+        ctx.check(lib().sp_hla_db_create(ctx._h, C.byref(d), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().sp_hla_db_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def realign_reads(self, reads, cells=False):
+        out = np.zeros(reads.n, REALIGN_DTYPE)
+        cell = np.zeros((reads.n, self.n_alleles), np.uint32) if cells else None
+        self.ctx.check(lib().sp_hla_realign_reads(self.ctx._h, self._h, reads._h, _ptr(out), _ptr(cell)))
+        return (out, cell) if cells else out
+
+    def score_consensus(self, gene, cons_dna, cons_cdna, require_dna=False, disable_cdna=False, stats=True):
+        best = sp_hla_best()
+        st = np.full((self.n_alleles, 6), -2, np.int32) if stats else None
+        self.ctx.check(lib().sp_hla_score_consensus(
+            self.ctx._h, self._h, int(gene), cons_dna.encode(), len(cons_dna), cons_cdna.encode(), len(cons_cdna),
+            int(require_dna), int(disable_cdna), C.byref(best), _ptr(st)))
+        return best.best_allele, best.n_scored, st

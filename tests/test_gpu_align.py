@@ -1,0 +1,95 @@
+"""GPU parity: sp_anchor_batch / sp_align_batch (HIP, through the C ABI) vs the CPU oracle, bit exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choice(list("ACGT"), n))
+
+
+def make_cases(rng, pkg):
+    from pb_starphase_amd import synth
+    A, B = [], []
+    # contained: B = flank + mutated(A) + flank
+    for ln in (40, 100, 218, 930, 1100, 3200, 6100):
+        for (ns, ni, nd) in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (3, 2, 2), (12, 5, 6)):
+            if (ns + ni + nd) * 12 + 60 > ln:
+                continue
+            a = rand_seq(rng, ln)
+            core = synth.mutate(rng, a, ns, ni, nd)
+            fl, fr = int(rng.integers(0, 300)), int(rng.integers(0, 300))
+            A.append(a)
+            B.append(rand_seq(rng, fl) + core + rand_seq(rng, fr))
+    # dovetails: A overhangs B at the start / at the end, B overhangs, equal
+    for ln in (300, 1500, 4000):
+        g = rand_seq(rng, ln + 600)
+        a = g[100:100 + ln]
+        A += [a, a, a, a]
+        B += [g[300:], g[:ln - 50], g[100:100 + ln], synth.mutate(rng, g[150:ln + 400], 2, 1, 1)]
+    # N handling and tiny sequences
+    a = rand_seq(rng, 400)
+    A += [a, a[:200] + "N" + a[201:], "ACGT", "ACGTACGTACGTACGTACGT"]
+    B += [a[:100] + "N" + a[101:], a, "ACGT", "TTACGTACGTACGTACGTACGTAA"]
+    # repeats: the 218-mer of the reference's test_weight_sequence shape (two near-identical halves)
+    half = rand_seq(rng, 109)
+    A.append(half + half[:84] + "G" + half[85:])
+    B.append(half + half[:84] + "C" + half[85:])
+    return A, B
+
+
+def compare(oracle, ctx, A, B, a_idx, b_idx, max_ed=255, shift=0):
+    sa, sb = ctx.upload(A), ctx.upload(B)
+    # anchors: B side indexed = "A" of sp_anchor_batch is the indexed set; index the B list, look up A
+    diag, votes = ctx.anchor_batch(sb, sa, b_idx, a_idx)      # diag = a_pos - b_pos
+    exp = [oracle.anchor(B[j], A[i]) for i, j in zip(a_idx, b_idx)]
+    assert diag.tolist() == [d if v > 0 else 0 for d, v in exp]
+    assert votes.tolist() == [v for _, v in exp]
+    cell_diag = (-diag + shift).astype(np.int32)
+    out, ev = ctx.align_batch(sa, sb, a_idx, b_idx, cell_diag, np.full(len(a_idx), max_ed, np.int32), events=True)
+    out2 = ctx.align_batch(sa, sb, a_idx, b_idx, cell_diag, np.full(len(a_idx), max_ed, np.int32), events=False)
+    n_ok = 0
+    for x, (i, j) in enumerate(zip(a_idx, b_idx)):
+        al, oev = oracle.wfa(A[i], B[j], int(cell_diag[x]), max_ed)
+        got = out[x]
+        want = (al.ok, al.nm, al.a_start, al.a_end, al.b_start, al.b_end, al.a_len, al.b_len) if al.ok else None
+        if al.ok:
+            assert tuple(int(v) for v in got.tolist()) == want, (x, i, j, got, want)
+            assert tuple(int(v) for v in out2[x].tolist()) == want, ("untraced", x, got, want)
+            assert ev[x, :al.nm].tolist() == oev.tolist(), (x, ev[x, :al.nm], oev)
+            n_ok += 1
+        else:
+            assert got["ok"] == 0 and out2[x]["ok"] == 0, (x, got)
+    return n_ok
+
+
+def test_align_synthetic(oracle, pkg, gpu_ctx):
+    rng = np.random.default_rng(11)
+    A, B = make_cases(rng, pkg)
+    idx = np.arange(len(A), dtype=np.uint32)
+    n_ok = compare(oracle, gpu_ctx, A, B, idx, idx)
+    assert n_ok >= len(A) - 4
+    # off-centre anchors must give the same contract on both sides
+    for shift in (-20, 7, 31):
+        compare(oracle, gpu_ctx, A, B, idx, idx, shift=shift)
+    # tight edit caps: failures must agree too
+    compare(oracle, gpu_ctx, A, B, idx, idx, max_ed=3)
+    compare(oracle, gpu_ctx, A, B, idx, idx, max_ed=0)
+
+
+def test_align_real_alleles(oracle, pkg, gpu_ctx):
+    """real IMGT/HLA alleles against the GRCh38 gene regions (nm 80..160, band-limited failures included)"""
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture(max_alleles_per_gene=120, seed=5)
+    A = [fx.dna_fwd(a) for a in range(len(fx.ids)) if fx.dna[a]]
+    gene = [int(fx.gene_of[a]) for a in range(len(fx.ids)) if fx.dna[a]]
+    a_idx = np.arange(len(A), dtype=np.uint32)
+    b_idx = np.array(gene, np.uint32)
+    n_ok = compare(oracle, gpu_ctx, A, fx.gene_ref, a_idx, b_idx)
+    assert n_ok > 0.9 * len(A)
+    # alleles against each other (cDNA, short)
+    C = [fx.cdna[a] for a in range(0, len(fx.ids), 3)][:80]
+    ai = np.repeat(np.arange(len(C)), 4).astype(np.uint32)
+    bi = ((ai * 7 + np.tile(np.arange(4), len(C))) % len(C)).astype(np.uint32)
+    compare(oracle, gpu_ctx, C, C, ai, bi)
