@@ -238,3 +238,35 @@ int osp_is_hemizygous_better(const int64_t* s1, const int64_t* s2, const uint8_t
     if (diploid_cost_out) *diploid_cost_out = diploid_cost;
     return haploid_cost < diploid_cost;
 }
+
+/* Whole K1 search of one read on the CPU: anchors against every gene reference, the gene filter, one banded
+ * alignment per candidate allele and the acceptance loop (src/hla/realigner.rs:116-146 on top of the alignment
+ * contract).  Used by the tests and as bench.py's cpu_baseline ("port").  off[a] = allele_pos - ref_pos or INT_MIN. */
+int osp_hla_k1_read(const uint8_t* read, int rlen, int n_genes, const uint8_t* const* refs, const int32_t* ref_len,
+                    int n_alleles, const uint8_t* const* alleles, const int32_t* allele_len, const int32_t* gene_of,
+                    const int32_t* off, uint32_t* cells, int64_t* n_cells_run) {
+    int32_t* d_rg = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_genes);
+    int32_t* v_rg = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_genes);
+    int vmax = 0;
+    for (int g = 0; g < n_genes; ++g) {
+        int d = 0; v_rg[g] = osp_anchor(refs[g], ref_len[g], read, rlen, &d); d_rg[g] = d;
+        if (v_rg[g] > vmax) vmax = v_rg[g];
+    }
+    int vmin = vmax / 10 > 16 ? vmax / 10 : 16;
+    osp_aln* alns = (osp_aln*)calloc((size_t)n_alleles, sizeof(osp_aln));
+    int64_t run = 0;
+    for (int a = 0; a < n_alleles; ++a) {
+        if (cells) cells[a] = 0xFFFFFFFFu;
+        if (allele_len[a] <= 0 || off[a] == INT_MIN) continue;
+        int g = gene_of[a];
+        if (v_rg[g] < vmin) continue;
+        int cap = (int)(0.03 * (double)allele_len[a]) + 1; if (cap > 255) cap = 255;
+        osp_wfa(alleles[a], allele_len[a], read, rlen, d_rg[g] - off[a], cap, &alns[a], NULL, NULL);
+        ++run;
+        if (alns[a].ok && cells) cells[a] = ((uint32_t)alns[a].nm << 16) | (uint32_t)(alns[a].a_end - alns[a].a_start);
+    }
+    int best = osp_hla_pick_allele(alns, n_alleles, rlen);
+    if (n_cells_run) *n_cells_run = run;
+    free(alns); free(d_rg); free(v_rg);
+    return best;
+}

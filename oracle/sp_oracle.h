@@ -123,6 +123,11 @@ int osp_hla_score_read(const osp_hla_score_problem* p, int64_t* stats, osp_aln* 
  * Returns best allele index or -1. */
 int osp_hla_pick_allele(const osp_aln* alns, int n, int read_len);
 
+/* whole K1 search of one read (anchor + gene filter + one cell per allele + acceptance loop) */
+int osp_hla_k1_read(const uint8_t* read, int rlen, int n_genes, const uint8_t* const* refs, const int32_t* ref_len,
+                    int n_alleles, const uint8_t* const* alleles, const int32_t* allele_len, const int32_t* gene_of,
+                    const int32_t* off, uint32_t* cells, int64_t* n_cells_run);
+
 /* hla/caller.rs:1225-1247 ; returns is_passing, fills maf and cdf */
 int osp_is_passing_dual(uint64_t counts1, uint64_t counts2, double min_consensus_fraction, double expected_maf,
                         double min_cdf, double* maf, double* cdf);

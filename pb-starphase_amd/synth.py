@@ -95,7 +95,8 @@ class HlaFixture:
         seq = self.island[g]["sequence"]
         al = self.dna_fwd(a)
         s = self._vote(g, al[:400])                      # island position of allele base 0
-        e = self._vote(g, al[-400:]) + len(al)           # island position just past the allele
+        tail = al[-400:]
+        e = self._vote(g, tail) + len(tail)              # island position just past the allele
         s = max(0, s)
         e = min(len(seq), max(e, s))
         return seq[:s] + al + seq[e:], s
@@ -161,3 +162,40 @@ def mutate(rng, seq, n_sub=0, n_ins=0, n_del=0):
         else:
             s = s[:p] + s[p + 1:]
     return s
+
+
+class Config2Workload:
+    """BASELINE.json configs[1]: HLA-A/-B diplotyping on n_reads synthetic HiFi reads vs the bundled IMGT/HLA DB.
+
+    Truth: two distinct full-length DNA alleles per gene; reads split evenly over genes and haplotypes; read length
+    ~N(15 kb, 3 kb) clipped to the GRCh38 island the reference's tests ship (7.6 / 8.1 kb), HiFi error model.
+    The K2 inputs are synthetic consensuses: the truth haplotype around the allele (gene strand) and its cDNA
+    (the DWFA consensus step itself is a 'next' row)."""
+
+    def __init__(self, fx, n_reads=10000, seed=1):
+        rng = np.random.default_rng(seed)
+        self.fx = fx
+        self.truth = []            # (gene, allele index) per haplotype
+        self.reads = []
+        self.read_truth = []
+        self.consensus = []        # (gene, cons_dna_gene_strand, cons_cdna, truth allele)
+        G = len(fx.genes)
+        per_gene = n_reads // G
+        for g in range(G):
+            full = fx.full_length_alleles(g)
+            pair = rng.choice(full, 2, replace=False).tolist()
+            for h, a in enumerate(pair):
+                hap, s = fx.haplotype(g, a)
+                n = per_gene // 2 + (per_gene % 2 if h == 0 else 0)
+                rs = simulate_reads(rng, hap, s, len(fx.dna[a]), n)
+                self.reads += rs
+                self.read_truth += [(g, a)] * len(rs)
+                self.truth.append((g, a))
+                lo, hi = max(0, s - 60), min(len(hap), s + len(fx.dna[a]) + 60)
+                cons = hap[lo:hi]
+                if not fx.gene_fwd[g]:
+                    cons = revcomp(cons)
+                self.consensus.append((g, cons, fx.cdna[a], a))
+        order = rng.permutation(len(self.reads))
+        self.reads = [self.reads[i] for i in order]
+        self.read_truth = [self.read_truth[i] for i in order]
