@@ -44,18 +44,40 @@ __device__ __forceinline__ double score_value(int len, int nm, int unmapped) {
 }
 
 // =============================================================================================
-// K1 cells: workgroup = (read r, chunk of K1_CHUNK alleles); every wave runs its cells sequentially.
+// K1 cells: workgroup = (read r, chunk of K1_CHUNK alleles).  The read window every cell of the chunk can touch
+// is staged ONCE per workgroup into LDS (coalesced dword loads by all 256 threads); each wave then streams its
+// alleles through a private LDS slot and runs one WFA cell per allele.
 // cell_out[r * n_alleles + a] = (nm << 16) | aligned allele span, or SP_CELL_NONE.
+//
+// Exact branch-and-bound (bound != nullptr): bound[r] holds (num10 << 32 | span) of the best ACCEPTABLE cell
+// finished so far for read r (num10 = 10*nm, or 1 when nm == 0, i.e. max(nm, 0.1) * 10).  A cell whose edit
+// count s already satisfies s / allele_len > best ratio can never win (its span <= allele_len), so its edit cap
+// is lowered to floor(num10 * allele_len / (10 * span)).  Cells that tie the best ratio are never cut, so the
+// lowest-index tie rule of the acceptance loop (realigner.rs:139-141) is preserved.
 // =============================================================================================
+#define K1_NO_BOUND 0xFFFFFFFF00000001ull
+
+__device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int cap) {
+    const uint32_t nb10 = (uint32_t)(b >> 32), sb = (uint32_t)b;
+    if (nb10 == 0xFFFFFFFFu) return cap;
+    unsigned long long smax = ((unsigned long long)nb10 * (unsigned long long)alen) / (10ull * sb);
+    return smax < (unsigned long long)cap ? (int)smax : cap;
+}
+
 template <bool HASN>
 __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads,
                                                        const uint32_t* __restrict__ gene_of, const int32_t* __restrict__ off_fwd,
                                                        const int32_t* __restrict__ d_rg, const int32_t* __restrict__ votes_rg,
                                                        int n_genes, uint32_t n_alleles, uint32_t n_chunks,
-                                                       uint32_t* __restrict__ cell_out, int slot_words) {
+                                                       uint32_t* __restrict__ cell_out, unsigned long long* __restrict__ bound,
+                                                       int b_words, int a_words) {
     extern __shared__ uint32_t lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* slot = lds + wave * slot_words;
+    // layout: [4 control words][B window b_words (x2 with N plane)][4 x A slot a_words (x2 with N plane)]
+    int* ctl = reinterpret_cast<int*>(lds);
+    uint32_t* LB = lds + 4;
+    uint32_t* NB = HASN ? LB + b_words : nullptr;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t* slotA = lds + 4 + (HASN ? 2 : 1) * b_words + wave * (HASN ? 2 : 1) * a_words;
     const uint32_t r = blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
     // gene filter: a gene is searched when it has >= K1_MIN_VOTES and >= 1/10 of the read's best gene
     int vmax = 0;
@@ -64,25 +86,78 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
     const int rlen = reads.len[r];
     const uint32_t* rw = reads.words + reads.word_off[r];
     const uint32_t* rn = reads.nplane ? reads.nplane + reads.word_off[r] : nullptr;
-    const uint32_t a_end = min((chunk + 1) * (uint32_t)K1_CHUNK, n_alleles);
-    for (uint32_t a = chunk * K1_CHUNK + wave; a < a_end; a += 4) {
+    const uint32_t a_first = chunk * K1_CHUNK;
+    const uint32_t a_end = min(a_first + (uint32_t)K1_CHUNK, n_alleles);
+
+    // pass 1: union of the read windows of the active cells
+    if (tid == 0) { ctl[0] = 0x7FFFFFFF; ctl[1] = -1; }
+    __syncthreads();
+    if (tid < K1_CHUNK && a_first + tid < a_end) {
+        const uint32_t a = a_first + tid;
+        const int alen = alleles.len[a], off = off_fwd[a];
+        const uint32_t g = gene_of[a];
+        if (alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
+            const int kb = d_rg[(uint64_t)r * n_genes + g] - off - SP_BAND / 2;
+            int i_min, i_max, j_min, j_max;
+            if (spw::cell_windows(alen, rlen, kb, i_min, i_max, j_min, j_max)) { atomicMin(&ctl[0], j_min); atomicMax(&ctl[1], j_max); }
+        }
+    }
+    __syncthreads();
+    const int w_lo = ctl[0], w_hi = ctl[1];
+    const bool any = w_hi > w_lo;
+    int b_base = 0;
+    if (any) {
+        const int w0 = w_lo >> 4;
+        const int nw = ((w_hi + 15) >> 4) - w0 + 2;
+        for (int w = tid; w < nw; w += 256) { LB[w] = rw[w0 + w]; if (HASN) NB[w] = rn ? rn[w0 + w] : 0u; }
+        b_base = w0 << 4;
+    }
+    __syncthreads();
+
+    for (uint32_t a = a_first + wave; a < a_end; a += 4) {
         uint32_t res = SP_CELL_NONE;
         const int alen = alleles.len[a];
         const int off = off_fwd[a];
         const uint32_t g = gene_of[a];
-        if (alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
-            spw::CellIn in;
-            in.a_words = alleles.words + alleles.word_off[a];
-            in.a_nplane = alleles.nplane ? alleles.nplane + alleles.word_off[a] : nullptr;
-            in.a0 = 0; in.a1 = alen;
-            in.b_words = rw; in.b_nplane = rn; in.b0 = 0; in.b1 = rlen;
-            in.diag = d_rg[(uint64_t)r * n_genes + g] - off;
+        if (any && alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
+            const int kb = d_rg[(uint64_t)r * n_genes + g] - off - SP_BAND / 2;
+            int i_min, i_max, j_min, j_max;
             // nm <= 0.03 * aligned span <= 0.03 * allele length (realigner.rs:138-141)
             int cap = (int)(0.03 * (double)alen) + 1; if (cap > SP_MAX_ED) cap = SP_MAX_ED;
-            in.max_ed = cap;
-            spw::CellOut o;
-            spw::wfa_cell<false, HASN>(in, slot, slot_words, lane, nullptr, nullptr, o);
-            if (o.ok) res = ((uint32_t)o.nm << 16) | (uint32_t)(o.a_end - o.a_start);
+            if (bound) cap = k1_dyn_cap(__hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), alen, cap);
+            if (spw::cell_windows(alen, rlen, kb, i_min, i_max, j_min, j_max)) {
+                const uint32_t* aw = alleles.words + alleles.word_off[a];
+                uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
+                const int a_base = spw::stage(LA, aw, i_min, i_max, lane);
+                if (HASN) {
+                    if (alleles.nplane) spw::stage(NA, alleles.nplane + alleles.word_off[a], i_min, i_max, lane);
+                    else for (int w = lane; w < a_words; w += SP_WAVE) NA[w] = 0;
+                }
+                spw::wave_lds_sync();
+                spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0;
+                spw::wfa_core<false, HASN, false>(LA, NA, -a_base, alen, LB, NB, -b_base, rlen, kb, cap, lane, nullptr, nullptr, o);
+                spw::wave_lds_sync();
+                if (o.ok) {
+                    const int span = o.a_end - o.a_start;
+                    res = ((uint32_t)o.nm << 16) | (uint32_t)span;
+                    if (bound && lane == 0) {
+                        const double pen = score_value(alen, o.nm, alen - span), ed = score_value(span, o.nm, 0);
+                        if (pen <= 0.5 && ed <= 0.03) {
+                            const unsigned long long nn10 = o.nm ? 10ull * (unsigned long long)o.nm : 1ull;
+                            const unsigned long long cand = (nn10 << 32) | (unsigned long long)span;
+                            unsigned long long cur = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            for (;;) {
+                                const unsigned long long cn = cur >> 32, cs = cur & 0xFFFFFFFFull;
+                                const bool better = (cn == 0xFFFFFFFFull) || (nn10 * cs < cn * (unsigned long long)span);
+                                if (!better) break;
+                                const unsigned long long prev = atomicCAS(&bound[r], cur, cand);
+                                if (prev == cur) break;
+                                cur = prev;
+                            }
+                        }
+                    }
+                }
+            }
         }
         if (lane == 0) cell_out[(uint64_t)r * n_alleles + a] = res;
     }
@@ -492,21 +567,35 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
         rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
     if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes);
     const bool hasn = db->dna_fwd->has_n || reads->has_n || db->ref_fwd->has_n;
-    // slot must hold the allele/read windows of K1 and the reference/segment windows of the finalize step
+    // finalize: private per-wave windows of (allele, read) and (reference, read segment)
     int slot_words = std::max(sp_slot_words(db->dna_fwd, reads, hasn), sp_slot_words(db->ref_fwd, reads, hasn));
     const size_t lds_bytes = (size_t)slot_words * 16;
-    if (rc == SP_OK && lds_bytes > 160 * 1024 - 64) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
+    // cells: one shared read window + four allele slots
+    const int b_words = (reads->max_len + 15) / 16 + 4;
+    const int a_words = (db->dna_fwd->max_len + 15) / 16 + 4;
+    const size_t cells_lds = (size_t)(4 + (hasn ? 2 : 1) * (b_words + 4 * a_words)) * 4;
+    if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
+    // exact branch-and-bound is switched off when the caller wants the full cell matrix
+    unsigned long long* d_bound = nullptr;
+    if (rc == SP_OK && !cell_out) {
+        if (hipMalloc(&d_bound, (size_t)R * 8) != hipSuccess) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign bound");
+        else {
+            std::vector<unsigned long long> init(R, K1_NO_BOUND);
+            (void)hipMemcpyAsync(d_bound, init.data(), (size_t)R * 8, hipMemcpyHostToDevice, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+    }
     if (rc == SP_OK) {
         const uint32_t n_chunks = (NA + K1_CHUNK - 1) / K1_CHUNK;
         ProfScope ps(ctx, "k1_cells", (uint64_t)R * NA);
         if (hasn) {
-            (void)hipFuncSetAttribute((const void*)k1_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k1_cells_kernel<true>, dim3(R * n_chunks), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), reads->view(),
-                               db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, slot_words);
+            (void)hipFuncSetAttribute((const void*)k1_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
+            hipLaunchKernelGGL(k1_cells_kernel<true>, dim3(R * n_chunks), dim3(256), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
+                               db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, b_words, a_words);
         } else {
-            (void)hipFuncSetAttribute((const void*)k1_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(k1_cells_kernel<false>, dim3(R * n_chunks), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), reads->view(),
-                               db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, slot_words);
+            (void)hipFuncSetAttribute((const void*)k1_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
+            hipLaunchKernelGGL(k1_cells_kernel<false>, dim3(R * n_chunks), dim3(256), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
+                               db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, b_words, a_words);
         }
         if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_cells launch failed");
     }
@@ -535,7 +624,7 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("realign: ") + hipGetErrorString(e));
     }
-    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_rg); (void)hipFree(d_votes); (void)hipFree(d_best); (void)hipFree(d_cells); (void)hipFree(d_out);
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_rg); (void)hipFree(d_votes); (void)hipFree(d_best); (void)hipFree(d_cells); (void)hipFree(d_out); (void)hipFree(d_bound);
     return rc;
 }
 

@@ -53,38 +53,24 @@ __device__ __forceinline__ int stage(uint32_t* __restrict__ dst, const uint32_t*
 
 __device__ __forceinline__ int words_needed(int lo, int hi) { return ((hi + 15) >> 4) - (lo >> 4) + 2; }
 
-// The cell.  All 64 lanes call it together.  slot: this wave's LDS area (slot_words dwords).
+// neighbour exchange over the whole 64-lane wavefront with DPP (no LDS traffic):
+//   from_lower(x, fill): lane l receives lane l-1 (lane 0 receives fill)    -- wave_shr:1
+//   from_upper(x, fill): lane l receives lane l+1 (lane 63 receives fill)   -- wave_shl:1
+__device__ __forceinline__ int from_lower(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int from_upper(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
+
+// The DP core on two LDS-resident windows.  All 64 lanes call it together.
+//   LA/NA, a_sh : packed A window (+ N plane) and the LDS base position of view position 0 (may be negative)
+//   m, n        : view lengths; kb = diagonal of lane 0 (view coordinates, b - a)
+//   NEED_O      : track the origin diagonal even when it cannot influence a_start (needed for b_start)
 // hist (TRACE only): this wave's global scratch, (max_ed+1)*64 uint16.  events (TRACE only): >= max_ed words.
-template <bool TRACE, bool HASN>
-__device__ __forceinline__ void wfa_cell(const CellIn& c, uint32_t* __restrict__ slot, int slot_words, int lane,
+template <bool TRACE, bool HASN, bool NEED_O>
+__device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const uint32_t* __restrict__ NA, int a_sh, int m,
+                                         const uint32_t* __restrict__ LB, const uint32_t* __restrict__ NB, int b_sh, int n,
+                                         int kb, int max_ed, int lane,
                                          uint16_t* __restrict__ hist, uint32_t* __restrict__ events, CellOut& out) {
-    out.ok = 0; out.nm = 0; out.a_start = out.a_end = out.b_start = out.b_end = 0;
-    const int m = c.a1 - c.a0, n = c.b1 - c.b0;
-    if (m <= 0 || n <= 0 || c.max_ed < 0) return;
-    const int kb = c.diag - SP_BAND / 2;
-    // band-reachable windows (view coordinates)
-    int j_min = kb > 0 ? kb : 0;
-    int j_max = m + kb + SP_BAND - 1; if (j_max > n) j_max = n;
-    int i_min = -(kb + SP_BAND - 1); if (i_min < 0) i_min = 0;
-    int i_max = n - kb; if (i_max > m) i_max = m;
-    if (j_max <= j_min || i_max <= i_min) return;
-    const int alo = c.a0 + i_min, ahi = c.a0 + i_max, blo = c.b0 + j_min, bhi = c.b0 + j_max;
-    const int wa = words_needed(alo, ahi), wb = words_needed(blo, bhi);
-    if ((HASN ? 2 : 1) * (wa + wb) > slot_words) return;        // host sizes the slot; defensive
-    uint32_t* LA = slot; uint32_t* LB = slot + wa;
-    uint32_t* NA = HASN ? slot + wa + wb : nullptr; uint32_t* NB = HASN ? slot + 2 * wa + wb : nullptr;
-    const int a_base = stage(LA, c.a_words, alo, ahi, lane);
-    const int b_base = stage(LB, c.b_words, blo, bhi, lane);
-    if (HASN) {
-        // a set without N has no plane: treat as all zero
-        if (c.a_nplane) stage(NA, c.a_nplane, alo, ahi, lane); else for (int w = lane; w < wa; w += SP_WAVE) NA[w] = 0;
-        if (c.b_nplane) stage(NB, c.b_nplane, blo, bhi, lane); else for (int w = lane; w < wb; w += SP_WAVE) NB[w] = 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int a_sh = c.a0 - a_base, b_sh = c.b0 - b_base;        // LDS base position of view position 0
     const int k = kb + lane;
+    const bool track = NEED_O || TRACE || kb < 0;
 
     // extension of every lane from view position `start` (SP_NEG = invalid lane); returns new furthest i
     auto extend = [&](int start) -> int {
@@ -147,25 +133,32 @@ __device__ __forceinline__ void wfa_cell(const CellIn& c, uint32_t* __restrict__
             end_lane = __builtin_amdgcn_readfirstlane((SP_BAND - 1) - (key & 63));
             break;
         }
-        if (s == c.max_ed) break;
-        int up = __shfl_up(H, 1), dn = __shfl_down(H, 1);
-        int oup = __shfl_up(O, 1), odn = __shfl_down(O, 1);
-        int best = valid ? H + 1 : SP_NEG; int o = O;
-        if (lane > 0 && up >= 0 && up > best) { best = up; o = oup; }
-        if (lane < SP_BAND - 1 && dn >= 0 && dn + 1 > best) { best = dn + 1; o = odn; }
+        if (s == max_ed) break;
+        // invalid lanes hold SP_NEG (+1 keeps them hugely negative), so validity is one sign test on the winner
+        const int up = from_lower(H, SP_NEG), dn = from_upper(H, SP_NEG);
+        int best = H + 1;
+        if (track) {
+            const int oup = from_lower(O, 0), odn = from_upper(O, 0);
+            int o = O;
+            if (up > best) { best = up; o = oup; }
+            if (dn + 1 > best) { best = dn + 1; o = odn; }
+            O = o;
+        } else {
+            best = up > best ? up : best;
+            best = dn + 1 > best ? dn + 1 : best;
+        }
         H = extend(best >= 0 ? best : SP_NEG);
-        O = o;
         ++s;
         if (TRACE) hist[s * SP_WAVE + lane] = (uint16_t)(H >= 0 ? H : 0xFFFF);
     }
     if (end_lane < 0) return;
     const int he = __builtin_amdgcn_readlane(H, end_lane);
-    const int oe = __builtin_amdgcn_readlane(O, end_lane);
+    const int oe = track ? __builtin_amdgcn_readlane(O, end_lane) : end_lane;
     out.ok = 1; out.nm = s;
     out.a_end = he; out.b_end = he + kb + end_lane;
     {
         int ko = kb + oe; int i0 = ko < 0 ? -ko : 0;
-        out.a_start = i0; out.b_start = i0 + ko;
+        out.a_start = i0; out.b_start = i0 + ko;      // b_start is only meaningful when the origin was tracked
     }
     if (TRACE) {
         int l = end_lane;
@@ -184,6 +177,48 @@ __device__ __forceinline__ void wfa_cell(const CellIn& c, uint32_t* __restrict__
             l = src;
         }
     }
+}
+
+// band-reachable windows of a cell (view coordinates); false when the band misses the rectangle
+__device__ __forceinline__ bool cell_windows(int m, int n, int kb, int& i_min, int& i_max, int& j_min, int& j_max) {
+    j_min = kb > 0 ? kb : 0;
+    j_max = m + kb + SP_BAND - 1; if (j_max > n) j_max = n;
+    i_min = -(kb + SP_BAND - 1); if (i_min < 0) i_min = 0;
+    i_max = n - kb; if (i_max > m) i_max = m;
+    return j_max > j_min && i_max > i_min;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The self-contained cell: stages both windows into this wave's private LDS slot, then runs the core.
+template <bool TRACE, bool HASN>
+__device__ __forceinline__ void wfa_cell(const CellIn& c, uint32_t* __restrict__ slot, int slot_words, int lane,
+                                         uint16_t* __restrict__ hist, uint32_t* __restrict__ events, CellOut& out) {
+    out.ok = 0; out.nm = 0; out.a_start = out.a_end = out.b_start = out.b_end = 0;
+    const int m = c.a1 - c.a0, n = c.b1 - c.b0;
+    if (m <= 0 || n <= 0 || c.max_ed < 0) return;
+    const int kb = c.diag - SP_BAND / 2;
+    int i_min, i_max, j_min, j_max;
+    if (!cell_windows(m, n, kb, i_min, i_max, j_min, j_max)) return;
+    const int alo = c.a0 + i_min, ahi = c.a0 + i_max, blo = c.b0 + j_min, bhi = c.b0 + j_max;
+    const int wa = words_needed(alo, ahi), wb = words_needed(blo, bhi);
+    if ((HASN ? 2 : 1) * (wa + wb) > slot_words) return;        // host sizes the slot; defensive
+    uint32_t* LA = slot; uint32_t* LB = slot + wa;
+    uint32_t* NA = HASN ? slot + wa + wb : nullptr; uint32_t* NB = HASN ? slot + 2 * wa + wb : nullptr;
+    const int a_base = stage(LA, c.a_words, alo, ahi, lane);
+    const int b_base = stage(LB, c.b_words, blo, bhi, lane);
+    if (HASN) {
+        // a set without N has no plane: treat as all zero
+        if (c.a_nplane) stage(NA, c.a_nplane, alo, ahi, lane); else for (int w = lane; w < wa; w += SP_WAVE) NA[w] = 0;
+        if (c.b_nplane) stage(NB, c.b_nplane, blo, bhi, lane); else for (int w = lane; w < wb; w += SP_WAVE) NB[w] = 0;
+    }
+    wave_lds_sync();
+    wfa_core<TRACE, HASN, true>(LA, NA, c.a0 - a_base, m, LB, NB, c.b0 - b_base, n, kb, c.max_ed, lane, hist, events, out);
+    wave_lds_sync();      // the slot is reused by the next cell
 }
 
 } // namespace spw

@@ -78,3 +78,7 @@ def test_k1_realign_reads(oracle, pkg, gpu_ctx, small):
                    (e["seg_start"], e["seg_end"], e["dna_offset"], e["hpc_offset"]), (r, o, e)
     assert n_real >= len(reads) - 4
     assert out[len(reads) - 2]["best_allele"] == -1
+    # production mode (no cell matrix requested): exact branch-and-bound must not change a single output field
+    for _ in range(3):
+        pruned = db.realign_reads(rs)
+        assert pruned.tobytes() == out.tobytes()
