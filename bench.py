@@ -170,7 +170,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "cells_per_launch": alg_cells, "avg_launch_ms": avg_ms,
                          "note": "integer-DP kernel: VALU/LDS bound, DB served from L2/MALL; HBM fraction is on the streaming model of SURVEY 8(d)"},
             "kernel_ms": {k: ctx.profile_get(k)[0] / max(1, args.steps) for k in
-                          ("anchor", "k1_cells", "k1_reduce", "k1_finalize", "k2_cells_cdna", "k2_cells_dna", "k2_scan")},
+                          ("anchor", "k1_cells", "k1_cells_deep", "k1_reduce", "k1_finalize", "k2_cells_cdna", "k2_cells_dna", "k2_scan")},
             "concordance": {"k1_gene_correct": k1_gene_ok, "k1_realigned": k1_realigned, "k2_truth_calls": f"{k2_ok}/{len(calls)}"},
             "pcie_inclusive_upload_s": t_up,
         }

@@ -45,6 +45,7 @@ void sp_ctx_destroy(sp_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
+    for (auto& kv : ctx->pool) if (kv.second.first) hipFree(kv.second.first);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);

@@ -121,6 +121,16 @@ void* sp_scratch(sp_ctx* ctx, size_t bytes) {
     return ctx->scratch;
 }
 
+void* sp_pool(sp_ctx* ctx, const char* name, size_t bytes) {
+    auto& e = ctx->pool[name];
+    if (bytes <= e.second && e.first) return e.first;
+    if (e.first) { (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&e.first, want) != hipSuccess) { e.first = nullptr; return nullptr; }
+    e.second = want;
+    return e.first;
+}
+
 int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn) {
     int mn = std::min(A->max_len, B->max_len);
     int w = (mn + SP_BAND + 30) / 16 + 3;

@@ -64,21 +64,26 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
     return smax < (unsigned long long)cap ? (int)smax : cap;
 }
 
+#define K1_PRE 5        // prefetch registers per lane: alleles up to 5*64*16 - 32 = 5,088 bases stream through registers
+
 template <bool HASN>
 __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads,
                                                        const uint32_t* __restrict__ gene_of, const int32_t* __restrict__ off_fwd,
                                                        const int32_t* __restrict__ d_rg, const int32_t* __restrict__ votes_rg,
                                                        int n_genes, uint32_t n_alleles, uint32_t n_chunks,
                                                        uint32_t* __restrict__ cell_out, unsigned long long* __restrict__ bound,
-                                                       int b_words, int a_words) {
+                                                       const uint32_t* __restrict__ read_list, uint32_t* __restrict__ read_maxlen,
+                                                       int pass_cap, int b_words, int a_words) {
     extern __shared__ uint32_t lds[];
-    // layout: [4 control words][B window b_words (x2 with N plane)][4 x A slot a_words (x2 with N plane)]
+    // layout: [4 control words][K1_CHUNK x 4 cell metadata][B window b_words (x2 with N plane)][4 x A slot a_words (x2 with N plane)]
     int* ctl = reinterpret_cast<int*>(lds);
-    uint32_t* LB = lds + 4;
+    int* meta = ctl + 4;                                  // per allele of the chunk: active, alen, kb, word offset (low 32 bits)
+    uint32_t* LB = lds + 4 + 4 * K1_CHUNK;
     uint32_t* NB = HASN ? LB + b_words : nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    uint32_t* slotA = lds + 4 + (HASN ? 2 : 1) * b_words + wave * (HASN ? 2 : 1) * a_words;
-    const uint32_t r = blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
+    uint32_t* slotA = LB + (HASN ? 2 : 1) * b_words + wave * (HASN ? 2 : 1) * a_words;
+    // deeper passes only visit the reads an earlier (shallower) pass could not settle
+    const uint32_t r = read_list ? read_list[blockIdx.x / n_chunks] : blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
     // gene filter: a gene is searched when it has >= K1_MIN_VOTES and >= 1/10 of the read's best gene
     int vmax = 0;
     for (int g = 0; g < n_genes; ++g) { int v = votes_rg[(uint64_t)r * n_genes + g]; vmax = v > vmax ? v : vmax; }
@@ -89,18 +94,26 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
     const uint32_t a_first = chunk * K1_CHUNK;
     const uint32_t a_end = min(a_first + (uint32_t)K1_CHUNK, n_alleles);
 
-    // pass 1: union of the read windows of the active cells
-    if (tid == 0) { ctl[0] = 0x7FFFFFFF; ctl[1] = -1; }
+    // pass 1: per-cell metadata into LDS + union of the read windows of the active cells
+    if (tid == 0) { ctl[0] = 0x7FFFFFFF; ctl[1] = -1; ctl[2] = 0; }
     __syncthreads();
-    if (tid < K1_CHUNK && a_first + tid < a_end) {
-        const uint32_t a = a_first + tid;
-        const int alen = alleles.len[a], off = off_fwd[a];
-        const uint32_t g = gene_of[a];
-        if (alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
-            const int kb = d_rg[(uint64_t)r * n_genes + g] - off - SP_BAND / 2;
-            int i_min, i_max, j_min, j_max;
-            if (spw::cell_windows(alen, rlen, kb, i_min, i_max, j_min, j_max)) { atomicMin(&ctl[0], j_min); atomicMax(&ctl[1], j_max); }
+    if (tid < K1_CHUNK) {
+        int act = 0, alen = 0, kb = 0; uint32_t woff = 0;
+        if (a_first + tid < a_end) {
+            const uint32_t a = a_first + tid;
+            alen = alleles.len[a];
+            const int off = off_fwd[a];
+            const uint32_t g = gene_of[a];
+            if (alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
+                kb = d_rg[(uint64_t)r * n_genes + g] - off - SP_BAND / 2;
+                int i_min, i_max, j_min, j_max;
+                if (spw::cell_windows(alen, rlen, kb, i_min, i_max, j_min, j_max)) {
+                    act = 1; woff = (uint32_t)alleles.word_off[a];
+                    atomicMin(&ctl[0], j_min); atomicMax(&ctl[1], j_max); atomicMax(&ctl[2], alen);
+                }
+            }
         }
+        meta[tid * 4 + 0] = act; meta[tid * 4 + 1] = alen; meta[tid * 4 + 2] = kb; meta[tid * 4 + 3] = (int)woff;
     }
     __syncthreads();
     const int w_lo = ctl[0], w_hi = ctl[1];
@@ -113,54 +126,95 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
         b_base = w0 << 4;
     }
     __syncthreads();
+    if (!any) {
+        for (uint32_t a = a_first + tid; a < a_end; a += 256) cell_out[(uint64_t)r * n_alleles + a] = SP_CELL_NONE;
+        return;
+    }
+    if (read_maxlen && tid == 0) atomicMax(&read_maxlen[r], (uint32_t)ctl[2]);     // longest allele any cell of this read uses
 
-    for (uint32_t a = a_first + wave; a < a_end; a += 4) {
+    // software pipeline: the packed words (and the running bound) of the NEXT cell are fetched into registers
+    // while the current cell's DP runs out of LDS
+    uint32_t pre[K1_PRE];
+    unsigned long long pre_bound = K1_NO_BOUND;
+    auto fetch = [&](int slot_idx) {
+        const int act = meta[slot_idx * 4 + 0], alen = meta[slot_idx * 4 + 1];
+        const uint32_t* aw = alleles.words + (uint32_t)meta[slot_idx * 4 + 3];
+        const int nw = ((alen + 15) >> 4) + 2;
+#pragma unroll
+        for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; pre[t] = (act && w < nw) ? aw[w] : 0u; }
+        if (bound) pre_bound = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    int cur = wave;
+    if (a_first + cur < a_end) fetch(cur);
+    for (; a_first + cur < a_end; cur += 4) {
+        const uint32_t a = a_first + cur;
+        const int act = meta[cur * 4 + 0], alen = meta[cur * 4 + 1], kb = meta[cur * 4 + 2];
+        const int nw = ((alen + 15) >> 4) + 2;
+        const bool fast = nw <= K1_PRE * SP_WAVE;
+        uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
+        const unsigned long long my_bound = pre_bound;
+        if (act) {
+            if (fast) {
+#pragma unroll
+                for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; if (w < nw) LA[w] = pre[t]; }
+            } else {
+                spw::stage(LA, alleles.words + (uint32_t)meta[cur * 4 + 3], 0, alen, lane);
+            }
+            if (HASN) {
+                if (alleles.nplane) spw::stage(NA, alleles.nplane + (uint32_t)meta[cur * 4 + 3], 0, alen, lane);
+                else for (int w = lane; w < nw; w += SP_WAVE) NA[w] = 0;
+            }
+        }
+        spw::wave_lds_sync();
+        if (a_first + cur + 4 < a_end) fetch(cur + 4);
         uint32_t res = SP_CELL_NONE;
-        const int alen = alleles.len[a];
-        const int off = off_fwd[a];
-        const uint32_t g = gene_of[a];
-        if (any && alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
-            const int kb = d_rg[(uint64_t)r * n_genes + g] - off - SP_BAND / 2;
-            int i_min, i_max, j_min, j_max;
+        if (act) {
             // nm <= 0.03 * aligned span <= 0.03 * allele length (realigner.rs:138-141)
             int cap = (int)(0.03 * (double)alen) + 1; if (cap > SP_MAX_ED) cap = SP_MAX_ED;
-            if (bound) cap = k1_dyn_cap(__hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), alen, cap);
-            if (spw::cell_windows(alen, rlen, kb, i_min, i_max, j_min, j_max)) {
-                const uint32_t* aw = alleles.words + alleles.word_off[a];
-                uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
-                const int a_base = spw::stage(LA, aw, i_min, i_max, lane);
-                if (HASN) {
-                    if (alleles.nplane) spw::stage(NA, alleles.nplane + alleles.word_off[a], i_min, i_max, lane);
-                    else for (int w = lane; w < a_words; w += SP_WAVE) NA[w] = 0;
-                }
-                spw::wave_lds_sync();
-                spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0;
-                spw::wfa_core<false, HASN, false>(LA, NA, -a_base, alen, LB, NB, -b_base, rlen, kb, cap, lane, nullptr, nullptr, o);
-                spw::wave_lds_sync();
-                if (o.ok) {
-                    const int span = o.a_end - o.a_start;
-                    res = ((uint32_t)o.nm << 16) | (uint32_t)span;
-                    if (bound && lane == 0) {
-                        const double pen = score_value(alen, o.nm, alen - span), ed = score_value(span, o.nm, 0);
-                        if (pen <= 0.5 && ed <= 0.03) {
-                            const unsigned long long nn10 = o.nm ? 10ull * (unsigned long long)o.nm : 1ull;
-                            const unsigned long long cand = (nn10 << 32) | (unsigned long long)span;
-                            unsigned long long cur = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            for (;;) {
-                                const unsigned long long cn = cur >> 32, cs = cur & 0xFFFFFFFFull;
-                                const bool better = (cn == 0xFFFFFFFFull) || (nn10 * cs < cn * (unsigned long long)span);
-                                if (!better) break;
-                                const unsigned long long prev = atomicCAS(&bound[r], cur, cand);
-                                if (prev == cur) break;
-                                cur = prev;
-                            }
+            if (cap > pass_cap) cap = pass_cap;
+            if (bound) cap = k1_dyn_cap(my_bound, alen, cap);
+            spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0;
+            spw::wfa_core<false, HASN, false>(LA, NA, 0, alen, LB, NB, -b_base, rlen, kb, cap, lane, nullptr, nullptr, o);
+            if (o.ok) {
+                const int span = o.a_end - o.a_start;
+                res = ((uint32_t)o.nm << 16) | (uint32_t)span;
+                if (bound && lane == 0) {
+                    const double pen = score_value(alen, o.nm, alen - span), ed = score_value(span, o.nm, 0);
+                    if (pen <= 0.5 && ed <= 0.03) {
+                        const unsigned long long nn10 = o.nm ? 10ull * (unsigned long long)o.nm : 1ull;
+                        const unsigned long long cand = (nn10 << 32) | (unsigned long long)span;
+                        unsigned long long curb = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (;;) {
+                            const unsigned long long cn = curb >> 32, cs = curb & 0xFFFFFFFFull;
+                            const bool better = (cn == 0xFFFFFFFFull) || (nn10 * cs < cn * (unsigned long long)span);
+                            if (!better) break;
+                            const unsigned long long prev = atomicCAS(&bound[r], curb, cand);
+                            if (prev == curb) break;
+                            curb = prev;
                         }
                     }
                 }
             }
         }
+        spw::wave_lds_sync();
         if (lane == 0) cell_out[(uint64_t)r * n_alleles + a] = res;
     }
+}
+
+// Iterative deepening bookkeeping: after a pass whose cells were capped at pass_cap edits, read r is settled when an
+// acceptable cell exists and no unfinished cell (nm >= pass_cap + 1, span <= max_alen) can reach its ratio:
+//   (pass_cap + 1) / max_alen > num10 / (10 * span)   <=>   10 * (pass_cap + 1) * span > num10 * max_alen
+__global__ void k1_done_kernel(const unsigned long long* __restrict__ bound, uint8_t* __restrict__ done, uint32_t n_reads,
+                               int pass_cap, const uint32_t* __restrict__ read_maxlen,
+                               uint32_t* __restrict__ n_open, uint32_t* __restrict__ open_list) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || done[r]) return;
+    const unsigned long long b = bound[r];
+    const unsigned long long nb10 = b >> 32, sb = b & 0xFFFFFFFFull;
+    const unsigned long long max_alen = read_maxlen[r];
+    if (max_alen == 0 ||                                                  // no cell at all: nothing deeper can appear
+        (nb10 != 0xFFFFFFFFull && 10ull * (unsigned long long)(pass_cap + 1) * sb > nb10 * max_alen)) done[r] = 1;
+    else open_list[atomicAdd(n_open, 1u)] = r;
 }
 
 // K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
@@ -558,13 +612,20 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
     // 1. anchors read x gene
     std::vector<uint32_t> a_idx((size_t)R * G), b_idx((size_t)R * G);
     for (uint32_t r = 0; r < R; ++r) for (uint32_t g = 0; g < G; ++g) { a_idx[(size_t)r * G + g] = g; b_idx[(size_t)r * G + g] = r; }
-    uint32_t* d_a = dev_copy(a_idx); uint32_t* d_b = dev_copy(b_idx);
-    int32_t *d_rg = nullptr, *d_votes = nullptr, *d_best = nullptr; uint32_t* d_cells = nullptr; sp_hla_realign* d_out = nullptr;
+    uint32_t* d_a = (uint32_t*)sp_pool(ctx, "k1_a_idx", (size_t)R * G * 4);
+    uint32_t* d_b = (uint32_t*)sp_pool(ctx, "k1_b_idx", (size_t)R * G * 4);
+    int32_t* d_rg = (int32_t*)sp_pool(ctx, "k1_rg", (size_t)R * G * 4);
+    int32_t* d_votes = (int32_t*)sp_pool(ctx, "k1_votes", (size_t)R * G * 4);
+    int32_t* d_best = (int32_t*)sp_pool(ctx, "k1_best", (size_t)R * 4);
+    uint32_t* d_cells = (uint32_t*)sp_pool(ctx, "k1_cells", (size_t)R * NA * 4);
+    sp_hla_realign* d_out = (sp_hla_realign*)sp_pool(ctx, "k1_out", (size_t)R * sizeof(sp_hla_realign));
     int rc = SP_OK;
-    if (!d_a || !d_b || hipMalloc(&d_rg, (size_t)R * G * 4) != hipSuccess || hipMalloc(&d_votes, (size_t)R * G * 4) != hipSuccess ||
-        hipMalloc(&d_best, (size_t)R * 4) != hipSuccess || hipMalloc(&d_cells, (size_t)R * NA * 4) != hipSuccess ||
-        hipMalloc(&d_out, (size_t)R * sizeof(sp_hla_realign)) != hipSuccess)
-        rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+    if (!d_a || !d_b || !d_rg || !d_votes || !d_best || !d_cells || !d_out) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+    if (rc == SP_OK) {
+        (void)hipMemcpyAsync(d_a, a_idx.data(), (size_t)R * G * 4, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(d_b, b_idx.data(), (size_t)R * G * 4, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes);
     const bool hasn = db->dna_fwd->has_n || reads->has_n || db->ref_fwd->has_n;
     // finalize: private per-wave windows of (allele, read) and (reference, read segment)
@@ -573,31 +634,56 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
     // cells: one shared read window + four allele slots
     const int b_words = (reads->max_len + 15) / 16 + 4;
     const int a_words = (db->dna_fwd->max_len + 15) / 16 + 4;
-    const size_t cells_lds = (size_t)(4 + (hasn ? 2 : 1) * (b_words + 4 * a_words)) * 4;
+    const size_t cells_lds = (size_t)(4 + 4 * K1_CHUNK + (hasn ? 2 : 1) * (b_words + 4 * a_words)) * 4;
     if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
     // exact branch-and-bound is switched off when the caller wants the full cell matrix
     unsigned long long* d_bound = nullptr;
     if (rc == SP_OK && !cell_out) {
-        if (hipMalloc(&d_bound, (size_t)R * 8) != hipSuccess) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign bound");
+        d_bound = (unsigned long long*)sp_pool(ctx, "k1_bound", (size_t)R * 8);
+        if (!d_bound) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign bound");
         else {
             std::vector<unsigned long long> init(R, K1_NO_BOUND);
             (void)hipMemcpyAsync(d_bound, init.data(), (size_t)R * 8, hipMemcpyHostToDevice, ctx->stream);
             (void)hipStreamSynchronize(ctx->stream);
         }
     }
-    if (rc == SP_OK) {
+    // Pruned mode runs the cells as exact iterative deepening: pass 1 caps every cell at 12 edits (plus the running
+    // bound); reads whose best acceptable cell cannot be beaten by any unfinished cell are settled; the few others
+    // are redone at 40 and then at the full 3 % cap.  The full-matrix mode is one un-pruned pass.
+    uint8_t* d_done = nullptr; uint32_t* d_open = nullptr; uint32_t* d_open_list = nullptr; uint32_t* d_maxlen = nullptr;
+    if (rc == SP_OK && d_bound) {
+        d_done = (uint8_t*)sp_pool(ctx, "k1_done", R); d_open = (uint32_t*)sp_pool(ctx, "k1_open", 4);
+        d_open_list = (uint32_t*)sp_pool(ctx, "k1_open_list", (size_t)R * 4); d_maxlen = (uint32_t*)sp_pool(ctx, "k1_maxlen", (size_t)R * 4);
+        if (!d_done || !d_open || !d_open_list || !d_maxlen) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign done flags");
+        else { (void)hipMemsetAsync(d_done, 0, R, ctx->stream); (void)hipMemsetAsync(d_maxlen, 0, (size_t)R * 4, ctx->stream); }
+    }
+    const int pass_caps[3] = {12, 40, SP_MAX_ED};
+    const int n_pass = d_bound ? 3 : 1;
+    uint32_t n_open = R;
+    for (int pass = 0; pass < n_pass && rc == SP_OK; ++pass) {
+        const int pass_cap = d_bound ? pass_caps[pass] : SP_MAX_ED;
         const uint32_t n_chunks = (NA + K1_CHUNK - 1) / K1_CHUNK;
-        ProfScope ps(ctx, "k1_cells", (uint64_t)R * NA);
-        if (hasn) {
-            (void)hipFuncSetAttribute((const void*)k1_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
-            hipLaunchKernelGGL(k1_cells_kernel<true>, dim3(R * n_chunks), dim3(256), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
-                               db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, b_words, a_words);
-        } else {
-            (void)hipFuncSetAttribute((const void*)k1_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
-            hipLaunchKernelGGL(k1_cells_kernel<false>, dim3(R * n_chunks), dim3(256), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
-                               db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, b_words, a_words);
+        const uint32_t* d_list = pass == 0 ? nullptr : d_open_list;
+        {
+            ProfScope ps(ctx, pass == 0 ? "k1_cells" : "k1_cells_deep", (uint64_t)n_open * NA);
+            if (hasn) {
+                (void)hipFuncSetAttribute((const void*)k1_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
+                hipLaunchKernelGGL(k1_cells_kernel<true>, dim3(n_open * n_chunks), dim3(256), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
+                                   db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, pass_cap, b_words, a_words);
+            } else {
+                (void)hipFuncSetAttribute((const void*)k1_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
+                hipLaunchKernelGGL(k1_cells_kernel<false>, dim3(n_open * n_chunks), dim3(256), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
+                                   db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, pass_cap, b_words, a_words);
+            }
+            if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_cells launch failed");
         }
-        if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_cells launch failed");
+        if (rc == SP_OK && d_bound && pass + 1 < n_pass) {
+            (void)hipMemsetAsync(d_open, 0, 4, ctx->stream);
+            hipLaunchKernelGGL(k1_done_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_bound, d_done, R, pass_cap, d_maxlen, d_open, d_open_list);
+            (void)hipMemcpyAsync(&n_open, d_open, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1 done sync");
+            if (n_open == 0) break;
+        }
     }
     if (rc == SP_OK) {
         ProfScope ps(ctx, "k1_reduce", R);
@@ -624,7 +710,6 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("realign: ") + hipGetErrorString(e));
     }
-    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_rg); (void)hipFree(d_votes); (void)hipFree(d_best); (void)hipFree(d_cells); (void)hipFree(d_out); (void)hipFree(d_bound);
     return rc;
 }
 

@@ -63,6 +63,7 @@ struct sp_ctx {
     std::map<std::string, ProfileEntry> prof;
     // reusable scratch
     void* scratch = nullptr; size_t scratch_bytes = 0;
+    std::map<std::string, std::pair<void*, size_t>> pool;   // named grow-only device buffers (no malloc/free per call)
     int num_cus = 256;
 };
 
@@ -83,6 +84,7 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name);
 
 void* sp_scratch(sp_ctx* ctx, size_t bytes);
+void* sp_pool(sp_ctx* ctx, const char* name, size_t bytes);
 int   sp_fail(sp_ctx* ctx, int code, const std::string& msg);
 #define SP_HIP_CHECK(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
     return sp_fail((ctx), SP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)

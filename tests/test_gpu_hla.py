@@ -57,6 +57,10 @@ def test_k1_realign_reads(oracle, pkg, gpu_ctx, small):
         for a in rng.choice(full, 2, replace=False).tolist():
             hap, gs = fx.haplotype(g, a)
             reads += synth.simulate_reads(rng, hap, gs, len(fx.dna[a]), 5, mean_len=6500, sd_len=1200)
+    # noisy reads: the accepted allele has > 8 and > 32 edits, so the deeper passes of the pruned mode are exercised
+    reads.append(synth.mutate(rng, reads[1], 20, 10, 10))
+    reads.append(synth.mutate(rng, reads[12], 60, 35, 35))
+    reads.append(synth.mutate(rng, reads[7], 150, 60, 60))          # beyond the 3 % cut-off
     reads.append("".join(rng.choice(list("ACGT"), 5000)))          # junk read: no allele
     reads.append(reads[0][:3100])                                    # truncated read
     rs = gpu_ctx.upload(reads)
@@ -76,7 +80,7 @@ def test_k1_realign_reads(oracle, pkg, gpu_ctx, small):
             n_real += 1
             assert (o["seg_start"], o["seg_end"], o["dna_offset"], o["hpc_offset"]) == \
                    (e["seg_start"], e["seg_end"], e["dna_offset"], e["hpc_offset"]), (r, o, e)
-    assert n_real >= len(reads) - 4
+    assert n_real >= len(reads) - 5
     assert out[len(reads) - 2]["best_allele"] == -1
     # production mode (no cell matrix requested): exact branch-and-bound must not change a single output field
     for _ in range(3):
