@@ -60,8 +60,13 @@ __device__ __forceinline__ double score_value(int len, int nm, int unmapped) {
 __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int cap) {
     const uint32_t nb10 = (uint32_t)(b >> 32), sb = (uint32_t)b;
     if (nb10 == 0xFFFFFFFFu) return cap;
-    unsigned long long smax = ((unsigned long long)nb10 * (unsigned long long)alen) / (10ull * sb);
-    return smax < (unsigned long long)cap ? (int)smax : cap;
+    // floor(T / D) with T = nb10 * alen < 2^28 and D = 10 * span: float estimate, then an exact +-1 fix-up
+    const uint32_t T = nb10 * (uint32_t)alen, D = 10u * sb;
+    uint32_t q = (uint32_t)(__fdividef((float)T, (float)D));
+    if (q * D > T) --q;
+    if ((q + 1) * D <= T) ++q;
+    if (q * D > T) --q;
+    return q < (uint32_t)cap ? (int)q : cap;
 }
 
 #define K1_PRE 5        // prefetch registers per lane: alleles up to 5*64*16 - 32 = 5,088 bases stream through registers
@@ -75,10 +80,11 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
                                                        const uint32_t* __restrict__ read_list, uint32_t* __restrict__ read_maxlen,
                                                        int pass_cap, int b_words, int a_words) {
     extern __shared__ uint32_t lds[];
-    // layout: [4 control words][K1_CHUNK x 4 cell metadata][B window b_words (x2 with N plane)][4 x A slot a_words (x2 with N plane)]
-    int* ctl = reinterpret_cast<int*>(lds);
-    int* meta = ctl + 4;                                  // per allele of the chunk: active, alen, kb, word offset (low 32 bits)
-    uint32_t* LB = lds + 4 + 4 * K1_CHUNK;
+    // layout: [8 control words][K1_CHUNK x 4 cell metadata][B window b_words (x2 with N plane)][4 x A slot a_words (x2 with N plane)]
+    int* ctl = reinterpret_cast<int*>(lds);               // 0: window lo, 1: window hi, 2: longest active allele, 3: #active in wave 0,
+                                                          // 4: #active, 5: next cell to grab
+    int* meta = ctl + 8;                                  // dense list of active cells: (chunk slot | static cap << 8), alen, kb, word offset
+    uint32_t* LB = lds + 8 + 4 * K1_CHUNK;
     uint32_t* NB = HASN ? LB + b_words : nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint32_t* slotA = LB + (HASN ? 2 : 1) * b_words + wave * (HASN ? 2 : 1) * a_words;
@@ -94,110 +100,119 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
     const uint32_t a_first = chunk * K1_CHUNK;
     const uint32_t a_end = min(a_first + (uint32_t)K1_CHUNK, n_alleles);
 
-    // pass 1: per-cell metadata into LDS + union of the read windows of the active cells
-    if (tid == 0) { ctl[0] = 0x7FFFFFFF; ctl[1] = -1; ctl[2] = 0; }
+    // pass 1 (threads 0..127, one allele each): cell metadata, union of the read windows, dense list of active cells
+    if (tid == 0) { ctl[0] = 0x7FFFFFFF; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = 4; }
     __syncthreads();
-    if (tid < K1_CHUNK) {
-        int act = 0, alen = 0, kb = 0; uint32_t woff = 0;
-        if (a_first + tid < a_end) {
-            const uint32_t a = a_first + tid;
-            alen = alleles.len[a];
-            const int off = off_fwd[a];
-            const uint32_t g = gene_of[a];
-            if (alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
-                kb = d_rg[(uint64_t)r * n_genes + g] - off - SP_BAND / 2;
-                int i_min, i_max, j_min, j_max;
-                if (spw::cell_windows(alen, rlen, kb, i_min, i_max, j_min, j_max)) {
-                    act = 1; woff = (uint32_t)alleles.word_off[a];
-                    atomicMin(&ctl[0], j_min); atomicMax(&ctl[1], j_max); atomicMax(&ctl[2], alen);
-                }
+    int act = 0, alen = 0, kb = 0, cap = 0; uint32_t woff = 0;
+    if (tid < K1_CHUNK && a_first + tid < a_end) {
+        const uint32_t a = a_first + tid;
+        alen = alleles.len[a];
+        const int off = off_fwd[a];
+        const uint32_t g = gene_of[a];
+        if (alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
+            kb = d_rg[(uint64_t)r * n_genes + g] - off - SP_BAND / 2;
+            int i_min, i_max, j_min, j_max;
+            if (spw::cell_windows(alen, rlen, kb, i_min, i_max, j_min, j_max)) {
+                // nm <= 0.03 * aligned span <= 0.03 * allele length (realigner.rs:138-141)
+                cap = (int)(0.03 * (double)alen) + 1; if (cap > SP_MAX_ED) cap = SP_MAX_ED;
+                if (cap > pass_cap) cap = pass_cap;
+                act = 1; woff = (uint32_t)alleles.word_off[a];
+                atomicMin(&ctl[0], j_min); atomicMax(&ctl[1], j_max); atomicMax(&ctl[2], alen);
             }
         }
-        meta[tid * 4 + 0] = act; meta[tid * 4 + 1] = alen; meta[tid * 4 + 2] = kb; meta[tid * 4 + 3] = (int)woff;
+        if (!act) cell_out[(uint64_t)r * n_alleles + a] = SP_CELL_NONE;
     }
+    const unsigned long long bal = __ballot(act != 0);
+    if (tid == 0) ctl[3] = __builtin_popcountll(bal);          // wave 0 publishes its count for wave 1
     __syncthreads();
-    const int w_lo = ctl[0], w_hi = ctl[1];
-    const bool any = w_hi > w_lo;
-    int b_base = 0;
-    if (any) {
+    if (act) {
+        const int slot = __builtin_popcountll(bal & ((1ull << lane) - 1ull)) + (wave == 1 ? ctl[3] : 0);
+        meta[slot * 4 + 0] = tid | (cap << 8); meta[slot * 4 + 1] = alen; meta[slot * 4 + 2] = kb; meta[slot * 4 + 3] = (int)woff;
+    }
+    if (tid == 64) ctl[4] = ctl[3] + __builtin_popcountll(bal);
+    __syncthreads();
+    const int n_act = __builtin_amdgcn_readfirstlane(ctl[4]);
+    if (n_act == 0) return;
+    const int w_lo = __builtin_amdgcn_readfirstlane(ctl[0]), w_hi = __builtin_amdgcn_readfirstlane(ctl[1]);
+    int b_base;
+    {
         const int w0 = w_lo >> 4;
         const int nw = ((w_hi + 15) >> 4) - w0 + 2;
         for (int w = tid; w < nw; w += 256) { LB[w] = rw[w0 + w]; if (HASN) NB[w] = rn ? rn[w0 + w] : 0u; }
         b_base = w0 << 4;
     }
-    __syncthreads();
-    if (!any) {
-        for (uint32_t a = a_first + tid; a < a_end; a += 256) cell_out[(uint64_t)r * n_alleles + a] = SP_CELL_NONE;
-        return;
-    }
     if (read_maxlen && tid == 0) atomicMax(&read_maxlen[r], (uint32_t)ctl[2]);     // longest allele any cell of this read uses
+    __syncthreads();
 
-    // software pipeline: the packed words (and the running bound) of the NEXT cell are fetched into registers
-    // while the current cell's DP runs out of LDS
+    // software pipeline over the dense list: the packed words (and the running bound) of the NEXT cell are fetched into
+    // registers while the current cell's DP runs out of LDS; cells are handed out dynamically (LDS counter)
     uint32_t pre[K1_PRE];
     unsigned long long pre_bound = K1_NO_BOUND;
-    auto fetch = [&](int slot_idx) {
-        const int act = meta[slot_idx * 4 + 0], alen = meta[slot_idx * 4 + 1];
-        const uint32_t* aw = alleles.words + (uint32_t)meta[slot_idx * 4 + 3];
-        const int nw = ((alen + 15) >> 4) + 2;
+    auto fetch = [&](int idx) {
+        const int alen_n = __builtin_amdgcn_readfirstlane(meta[idx * 4 + 1]);
+        const uint32_t* aw = alleles.words + (uint32_t)__builtin_amdgcn_readfirstlane(meta[idx * 4 + 3]);
+        const int nw = ((alen_n + 15) >> 4) + 2;
 #pragma unroll
-        for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; pre[t] = (act && w < nw) ? aw[w] : 0u; }
+        for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; pre[t] = w < nw ? aw[w] : 0u; }
         if (bound) pre_bound = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    int cur = wave;
-    if (a_first + cur < a_end) fetch(cur);
-    for (; a_first + cur < a_end; cur += 4) {
-        const uint32_t a = a_first + cur;
-        const int act = meta[cur * 4 + 0], alen = meta[cur * 4 + 1], kb = meta[cur * 4 + 2];
-        const int nw = ((alen + 15) >> 4) + 2;
+    auto grab = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&ctl[5], 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    int cur = wave;                                       // the first four cells are pre-assigned, the rest grabbed
+    if (cur < n_act) fetch(cur);
+    while (cur < n_act) {
+        const int tag = __builtin_amdgcn_readfirstlane(meta[cur * 4 + 0]);
+        const int c_alen = __builtin_amdgcn_readfirstlane(meta[cur * 4 + 1]), c_kb = __builtin_amdgcn_readfirstlane(meta[cur * 4 + 2]);
+        const uint32_t a = a_first + (uint32_t)(tag & 0xFF);
+        const int nw = ((c_alen + 15) >> 4) + 2;
         const bool fast = nw <= K1_PRE * SP_WAVE;
         uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
         const unsigned long long my_bound = pre_bound;
-        if (act) {
-            if (fast) {
+        if (fast) {
 #pragma unroll
-                for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; if (w < nw) LA[w] = pre[t]; }
-            } else {
-                spw::stage(LA, alleles.words + (uint32_t)meta[cur * 4 + 3], 0, alen, lane);
-            }
-            if (HASN) {
-                if (alleles.nplane) spw::stage(NA, alleles.nplane + (uint32_t)meta[cur * 4 + 3], 0, alen, lane);
-                else for (int w = lane; w < nw; w += SP_WAVE) NA[w] = 0;
-            }
+            for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; if (w < nw) LA[w] = pre[t]; }
+        } else {
+            spw::stage(LA, alleles.words + (uint32_t)meta[cur * 4 + 3], 0, c_alen, lane);
+        }
+        if (HASN) {
+            if (alleles.nplane) spw::stage(NA, alleles.nplane + (uint32_t)meta[cur * 4 + 3], 0, c_alen, lane);
+            else for (int w = lane; w < nw; w += SP_WAVE) NA[w] = 0;
         }
         spw::wave_lds_sync();
-        if (a_first + cur + 4 < a_end) fetch(cur + 4);
+        const int nxt = grab();
+        if (nxt < n_act) fetch(nxt);
+        int c_cap = tag >> 8;
+        if (bound) c_cap = k1_dyn_cap(my_bound, c_alen, c_cap);
+        c_cap = __builtin_amdgcn_readfirstlane(c_cap);
         uint32_t res = SP_CELL_NONE;
-        if (act) {
-            // nm <= 0.03 * aligned span <= 0.03 * allele length (realigner.rs:138-141)
-            int cap = (int)(0.03 * (double)alen) + 1; if (cap > SP_MAX_ED) cap = SP_MAX_ED;
-            if (cap > pass_cap) cap = pass_cap;
-            if (bound) cap = k1_dyn_cap(my_bound, alen, cap);
-            spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0;
-            spw::wfa_core<false, HASN, false>(LA, NA, 0, alen, LB, NB, -b_base, rlen, kb, cap, lane, nullptr, nullptr, o);
-            if (o.ok) {
-                const int span = o.a_end - o.a_start;
-                res = ((uint32_t)o.nm << 16) | (uint32_t)span;
-                if (bound && lane == 0) {
-                    const double pen = score_value(alen, o.nm, alen - span), ed = score_value(span, o.nm, 0);
-                    if (pen <= 0.5 && ed <= 0.03) {
-                        const unsigned long long nn10 = o.nm ? 10ull * (unsigned long long)o.nm : 1ull;
-                        const unsigned long long cand = (nn10 << 32) | (unsigned long long)span;
-                        unsigned long long curb = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        for (;;) {
-                            const unsigned long long cn = curb >> 32, cs = curb & 0xFFFFFFFFull;
-                            const bool better = (cn == 0xFFFFFFFFull) || (nn10 * cs < cn * (unsigned long long)span);
-                            if (!better) break;
-                            const unsigned long long prev = atomicCAS(&bound[r], curb, cand);
-                            if (prev == curb) break;
-                            curb = prev;
-                        }
+        spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0;
+        spw::wfa_core<false, HASN, false>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o);
+        if (o.ok) {
+            const int span = o.a_end - o.a_start;
+            res = ((uint32_t)o.nm << 16) | (uint32_t)span;
+            if (bound && lane == 0) {
+                const double pen = score_value(c_alen, o.nm, c_alen - span), ed = score_value(span, o.nm, 0);
+                if (pen <= 0.5 && ed <= 0.03) {
+                    const unsigned long long nn10 = o.nm ? 10ull * (unsigned long long)o.nm : 1ull;
+                    const unsigned long long cand = (nn10 << 32) | (unsigned long long)span;
+                    unsigned long long curb = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {
+                        const unsigned long long cn = curb >> 32, cs = curb & 0xFFFFFFFFull;
+                        const bool better = (cn == 0xFFFFFFFFull) || (nn10 * cs < cn * (unsigned long long)span);
+                        if (!better) break;
+                        const unsigned long long prev = atomicCAS(&bound[r], curb, cand);
+                        if (prev == curb) break;
+                        curb = prev;
                     }
                 }
             }
         }
         spw::wave_lds_sync();
         if (lane == 0) cell_out[(uint64_t)r * n_alleles + a] = res;
+        cur = nxt;
     }
 }
 
@@ -634,7 +649,7 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
     // cells: one shared read window + four allele slots
     const int b_words = (reads->max_len + 15) / 16 + 4;
     const int a_words = (db->dna_fwd->max_len + 15) / 16 + 4;
-    const size_t cells_lds = (size_t)(4 + 4 * K1_CHUNK + (hasn ? 2 : 1) * (b_words + 4 * a_words)) * 4;
+    const size_t cells_lds = (size_t)(8 + 4 * K1_CHUNK + (hasn ? 2 : 1) * (b_words + 4 * a_words)) * 4;
     if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
     // exact branch-and-bound is switched off when the caller wants the full cell matrix
     unsigned long long* d_bound = nullptr;

@@ -67,8 +67,12 @@ __device__ __forceinline__ int from_upper(int x, int fill) { return __builtin_am
 template <bool TRACE, bool HASN, bool NEED_O>
 __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const uint32_t* __restrict__ NA, int a_sh, int m,
                                          const uint32_t* __restrict__ LB, const uint32_t* __restrict__ NB, int b_sh, int n,
-                                         int kb, int max_ed, int lane,
+                                         int kb_, int max_ed_, int lane,
                                          uint16_t* __restrict__ hist, uint32_t* __restrict__ events, CellOut& out) {
+    // every cell parameter is wave-uniform; pin them to SGPRs so the step loop is scalar control flow
+    m = __builtin_amdgcn_readfirstlane(m); n = __builtin_amdgcn_readfirstlane(n);
+    a_sh = __builtin_amdgcn_readfirstlane(a_sh); b_sh = __builtin_amdgcn_readfirstlane(b_sh);
+    const int kb = __builtin_amdgcn_readfirstlane(kb_), max_ed = __builtin_amdgcn_readfirstlane(max_ed_);
     const int k = kb + lane;
     const bool track = NEED_O || TRACE || kb < 0;
 
