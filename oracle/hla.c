@@ -270,3 +270,35 @@ int osp_hla_k1_read(const uint8_t* read, int rlen, int n_genes, const uint8_t* c
     free(alns); free(d_rg); free(v_rg);
     return best;
 }
+
+/* splice_read (src/hla/caller.rs:1518-1576): exon bases of a read through its aligned pairs.
+ * pos = 0-based reference start of the record; cigar words are BAM style (len << 4 | op; M=0 I=1 D=2 N=3 S=4 H=5 ==7 X=8);
+ * exons are half-open reference ranges in the same coordinate system as pos, in hg38 order.
+ * Outputs the read ranges to concatenate and the offset of missing prefix bases. */
+int osp_splice_read(int64_t pos, const uint32_t* cigar, int n_cigar, const int64_t* exon_start, const int64_t* exon_end, int n_exons,
+                    int32_t* seg_start, int32_t* seg_end, int* n_seg, int64_t* offset_out) {
+    int64_t ref_span = 0;
+    for (int c = 0; c < n_cigar; ++c) { uint32_t op = cigar[c] & 15u, len = cigar[c] >> 4; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_span += len; }
+    int32_t* lookup = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ref_span + 1));
+    for (int64_t i = 0; i <= ref_span; ++i) lookup[i] = -1;
+    int64_t rp = 0; int32_t qp = 0;
+    for (int c = 0; c < n_cigar; ++c) {                       /* aligned_pairs: only M / = / X columns */
+        uint32_t op = cigar[c] & 15u, len = cigar[c] >> 4;
+        if (op == 0 || op == 7 || op == 8) { for (uint32_t i = 0; i < len; ++i) lookup[rp++] = qp++; }
+        else if (op == 1 || op == 4) qp += (int32_t)len;
+        else if (op == 2 || op == 3) rp += len;
+    }
+#define HAS(x) ((x) >= pos && (x) < pos + ref_span && lookup[(x) - pos] >= 0)
+    int64_t offset = 0; int ns = 0;
+    for (int e = 0; e < n_exons; ++e) {
+        int64_t first = exon_start[e], last = exon_end[e] - 1;
+        while (!HAS(first) && first <= last) first += 1;
+        while (!HAS(last) && first <= last) last -= 1;
+        if (ns == 0) offset += first - exon_start[e];
+        if (first <= last) { seg_start[ns] = lookup[first - pos]; seg_end[ns] = lookup[last - pos] + 1; ++ns; }
+    }
+#undef HAS
+    free(lookup);
+    *n_seg = ns; if (offset_out) *offset_out = offset;
+    return 0;
+}

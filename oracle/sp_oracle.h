@@ -123,6 +123,10 @@ int osp_hla_score_read(const osp_hla_score_problem* p, int64_t* stats, osp_aln* 
  * Returns best allele index or -1. */
 int osp_hla_pick_allele(const osp_aln* alns, int n, int read_len);
 
+/* splice_read (hla/caller.rs:1518-1576) */
+int osp_splice_read(int64_t pos, const uint32_t* cigar, int n_cigar, const int64_t* exon_start, const int64_t* exon_end, int n_exons,
+                    int32_t* seg_start, int32_t* seg_end, int* n_seg, int64_t* offset_out);
+
 /* whole K1 search of one read (anchor + gene filter + one cell per allele + acceptance loop) */
 int osp_hla_k1_read(const uint8_t* read, int rlen, int n_genes, const uint8_t* const* refs, const int32_t* ref_len,
                     int n_alleles, const uint8_t* const* alleles, const int32_t* allele_len, const int32_t* gene_of,

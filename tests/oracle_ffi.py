@@ -156,6 +156,21 @@ class Oracle:
         a = np.ascontiguousarray(alns)
         return self.L.osp_hla_pick_allele(a.ctypes.data_as(C.c_void_p), len(a), int(read_len))
 
+    def splice_read(self, pos, cigar, exons):
+        """cigar: list of (len, op) BAM ops; exons: list of (start, end). Returns (segments, offset)"""
+        cg = np.array([(l << 4) | op for l, op in cigar], np.uint32)
+        es = np.array([e[0] for e in exons], np.int64)
+        ee = np.array([e[1] for e in exons], np.int64)
+        ss = np.zeros(len(exons), np.int32)
+        se = np.zeros(len(exons), np.int32)
+        ns = C.c_int32(0)
+        off = C.c_int64(0)
+        self.L.osp_splice_read.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        self.L.osp_splice_read(int(pos), cg.ctypes.data_as(C.c_void_p), len(cg), es.ctypes.data_as(C.c_void_p), ee.ctypes.data_as(C.c_void_p),
+                               len(exons), ss.ctypes.data_as(C.c_void_p), se.ctypes.data_as(C.c_void_p), C.byref(ns), C.byref(off))
+        return [(int(ss[i]), int(se[i])) for i in range(ns.value)], off.value
+
     def hpc(self, s):
         out = np.zeros(max(1, len(s)), np.uint8)
         n = self.L.osp_hpc(s.encode(), len(s), out.ctypes.data_as(C.c_void_p))

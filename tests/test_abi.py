@@ -1,0 +1,51 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/starphase_hip.h declares;
+no compute call is made here.  Also checks the 'fail loudly' behaviour: no device => SP_ERR_NO_DEVICE, never a fallback."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "starphase_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(pkg):
+    lib = C.CDLL(pkg.lib_path())
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/starphase_hip.h but not exported"
+    assert lib.sp_abi_version() == 1
+
+
+def test_binding_matches_header(pkg):
+    pkg.ffi.lib()          # binds every function; raises AttributeError on a missing one
+    import inspect
+    src = inspect.getsource(pkg.ffi)
+    for n in declared_symbols():
+        assert n in src, f"{n} has no ctypes binding"
+
+
+def test_no_device_is_an_error_not_a_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = pkg.ffi.lib()
+    h = C.c_void_p()
+    rc = lib.sp_ctx_create(0, None, C.byref(h))
+    assert rc == pkg.ffi.SP_ERR_NO_DEVICE and not h.value
+    with pytest.raises(pkg.StarphaseError):
+        pkg.Context(0)
+
+
+def test_struct_layouts(pkg):
+    assert C.sizeof(pkg.ffi.sp_aln) == 32
+    assert C.sizeof(pkg.ffi.sp_pair) == 16
+    assert pkg.ffi.ALN_DTYPE.itemsize == 32
+    assert pkg.ffi.REALIGN_DTYPE.itemsize == C.sizeof(pkg.ffi.sp_hla_realign)
