@@ -178,6 +178,17 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
                                int32_t require_dna, int32_t disable_cdna,
                                sp_hla_best* best, int32_t* stats);
 
+/* Replaces score_consensus (src/hla/caller.rs:1258-1319) + splice_read (:1518-1576): the hg38-forward consensus is
+ * placed on the un-buffered gene reference (GPU alignment with traceback), its exon bases are spliced out through the
+ * aligned pairs, both sequences are put on the gene strand and handed to the K2 scoring above.
+ * An empty consensus or one that does not align to the reference gives best_allele = -1 and n_scored = 0
+ * (caller.rs:1263-1267,1282-1287).  cdna_out (optional, cdna_cap bytes) receives the spliced gene-strand cDNA. */
+int32_t sp_hla_type_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
+                              const char* consensus_fwd, uint32_t consensus_len,
+                              int32_t require_dna, int32_t disable_cdna,
+                              sp_hla_best* best, int32_t* stats,
+                              char* cdna_out, uint32_t cdna_cap, uint32_t* cdna_len);
+
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */
 int32_t sp_profile_reset(sp_ctx* ctx);

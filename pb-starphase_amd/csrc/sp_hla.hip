@@ -24,6 +24,7 @@ struct sp_hla_db {
     std::vector<uint32_t> gene_of;
     std::vector<uint8_t>  gene_fwd, has_dna;
     std::vector<std::vector<uint32_t>> gene_alleles;      // allele indices per gene (database order)
+    std::vector<uint32_t> exon_off; std::vector<int32_t> exon_start, exon_end;   // per gene, relative to the buffered reference
     sp_seqset* dna_gene = nullptr;    // allele DNA as stored (gene strand); len 0 = none
     sp_seqset* cdna_gene = nullptr;   // allele cDNA as stored
     sp_seqset* dna_fwd = nullptr;     // allele DNA in hg38 orientation (create_hla_fasta, realigner.rs:497-526)
@@ -531,6 +532,11 @@ int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) 
     db->gene_of.assign(d->gene_of, d->gene_of + d->n_alleles);
     db->gene_fwd.assign(d->gene_fwd, d->gene_fwd + d->n_genes);
     db->gene_alleles.resize(d->n_genes);
+    if (d->exon_off && d->exon_start && d->exon_end) {
+        db->exon_off.assign(d->exon_off, d->exon_off + d->n_genes + 1);
+        db->exon_start.assign(d->exon_start, d->exon_start + db->exon_off[d->n_genes]);
+        db->exon_end.assign(d->exon_end, d->exon_end + db->exon_off[d->n_genes]);
+    } else db->exon_off.assign(d->n_genes + 1, 0);
     db->has_dna.resize(d->n_alleles);
     for (uint32_t a = 0; a < d->n_alleles; ++a) {
         if (db->gene_of[a] >= d->n_genes) { delete db; return sp_fail(ctx, SP_ERR_INVALID_ARG, "hla db: gene index out of range"); }
@@ -797,6 +803,94 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
     (void)hipFree(d_cells); (void)hipFree(d_alns); (void)hipFree(d_ev); (void)hipFree(d_lv); (void)hipFree(d_stats);
     sp_seqset_free(cons);
     return rc;
+}
+
+
+int32_t sp_hla_type_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
+                              const char* consensus_fwd, uint32_t consensus_len,
+                              int32_t require_dna, int32_t disable_cdna,
+                              sp_hla_best* best, int32_t* stats,
+                              char* cdna_out, uint32_t cdna_cap, uint32_t* cdna_len) {
+    if (!ctx || !db || !best || gene >= db->n_genes || (consensus_len && !consensus_fwd)) return SP_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    best->best_allele = -1; best->n_scored = 0;
+    if (cdna_len) *cdna_len = 0;
+    if (stats) for (uint32_t a = 0; a < db->n_alleles; ++a) for (int k = 0; k < 6; ++k) stats[(size_t)a * 6 + k] = -2;
+    if (consensus_len == 0) return SP_OK;                                  // failed consensus => unknown (caller.rs:1263-1267)
+    // 1. place the consensus on the un-buffered gene reference
+    uint64_t off[2] = {0, consensus_len};
+    sp_seqset* cons = nullptr;
+    int rc = sp_seqset_upload(ctx, consensus_fwd, off, 1, &cons);
+    if (rc != SP_OK) return rc;
+    const int reflen = db->ref_fwd->h_len[gene], buffer = db->ref_buffer;
+    const int v_lo = buffer, v_hi = reflen - buffer;                        // region_sequence has no buffer (caller.rs:651-654)
+    uint32_t a_idx = gene, b_idx = 0;
+    uint32_t* d_ab = (uint32_t*)sp_pool(ctx, "tc_idx", 8);
+    int32_t* d_dv = (int32_t*)sp_pool(ctx, "tc_dv", 8);
+    CellDesc* d_cell = (CellDesc*)sp_pool(ctx, "tc_cell", sizeof(CellDesc));
+    sp_aln* d_aln = (sp_aln*)sp_pool(ctx, "tc_aln", sizeof(sp_aln));
+    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "tc_ev", SP_MAX_ED * 4);
+    if (!d_ab || !d_dv || !d_cell || !d_aln || !d_ev || v_hi <= v_lo) { sp_seqset_free(cons); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "type_consensus buffers"); }
+    (void)hipMemcpyAsync(d_ab, &a_idx, 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_ab + 1, &b_idx, 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    rc = sp_launch_anchor(ctx, db->ref_fwd, cons, d_ab, d_ab + 1, 1, d_dv, d_dv + 1);
+    int32_t dv[2] = {0, 0};
+    if (rc == SP_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipMemcpy(dv, d_dv, 8, hipMemcpyDeviceToHost); }
+    sp_aln aln; memset(&aln, 0, sizeof(aln));
+    std::vector<uint32_t> ev(SP_MAX_ED, 0);
+    if (rc == SP_OK && dv[1] >= K2_MIN_VOTES) {
+        // dv[0] = cons_pos - ref_pos (buffered reference); cell: A = consensus, B = reference view [v_lo, v_hi)
+        CellDesc cd{0u, gene, -dv[0] - v_lo, SP_MAX_ED, v_lo, v_hi};
+        (void)hipMemcpyAsync(d_cell, &cd, sizeof(cd), hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemsetAsync(d_ev, 0, SP_MAX_ED * 4, ctx->stream);
+        rc = sp_launch_cells(ctx, cons, db->ref_fwd, d_cell, 1, d_aln, d_ev, SP_MAX_ED, "type_consensus_ref");
+        if (rc == SP_OK) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(&aln, d_aln, sizeof(aln), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(ev.data(), d_ev, SP_MAX_ED * 4, hipMemcpyDeviceToHost);
+        }
+    }
+    sp_seqset_free(cons);
+    if (rc != SP_OK) return rc;
+    // select_best_mapping(target-based, penalised) must beat the 1.0 default (util/mapping.rs:22-57, caller.rs:1289-1297)
+    const int tlen = v_hi - v_lo;
+    bool mapped = aln.ok != 0;
+    if (mapped) { double num = (double)(aln.nm + (tlen - (aln.b_end - aln.b_start))); if (num < 0.1) num = 0.1; mapped = num / (double)tlen < 1.0; }
+    if (!mapped) return SP_OK;                                             // "Failed to align consensus to reference genome" (caller.rs:1282-1287)
+    // 2. aligned pairs of the consensus record: reference view position -> consensus position (M columns only)
+    std::vector<int32_t> lookup((size_t)tlen, -1);
+    {
+        int i = aln.a_start, j = aln.b_start;
+        for (int e = 0; e <= aln.nm; ++e) {
+            const int jn = e < aln.nm ? (int)(ev[e] & 0x3FFFFFFFu) : aln.b_end;
+            for (; j < jn; ++j, ++i) lookup[j] = i;                       // '=' run
+            if (e == aln.nm) break;
+            const uint32_t type = ev[e] >> 30;
+            if (type == SP_EV_X) { lookup[j] = i; ++i; ++j; }            // mismatch is still an aligned pair (cigar M)
+            else if (type == SP_EV_D) { ++j; }                             // reference base without consensus base
+            else { ++i; }                                                  // inserted consensus base
+        }
+    }
+    // 3. splice_read (caller.rs:1518-1576) with exons relative to the view
+    std::string spliced;
+    {
+        auto has = [&](int64_t x) { return x >= 0 && x < tlen && lookup[(size_t)x] >= 0; };
+        for (uint32_t e = db->exon_off[gene]; e < db->exon_off[gene + 1]; ++e) {
+            int64_t first = (int64_t)db->exon_start[e] - buffer, last = (int64_t)db->exon_end[e] - buffer - 1;
+            while (!has(first) && first <= last) ++first;
+            while (!has(last) && first <= last) --last;
+            if (first <= last) spliced.append(consensus_fwd + lookup[(size_t)first], (size_t)(lookup[(size_t)last] + 1 - lookup[(size_t)first]));
+        }
+    }
+    // 4. gene strand (caller.rs:1344-1363); no exon bases => cDNA "N"
+    const bool fwd = db->gene_fwd[gene] != 0;
+    std::string dna_g = fwd ? std::string(consensus_fwd, consensus_len) : revcomp(consensus_fwd, consensus_len);
+    std::string cdna_g = spliced.empty() ? std::string("N") : (fwd ? spliced : revcomp(spliced.data(), spliced.size()));
+    if (cdna_len) *cdna_len = (uint32_t)cdna_g.size();
+    if (cdna_out && cdna_cap) memcpy(cdna_out, cdna_g.data(), std::min<size_t>(cdna_cap, cdna_g.size()));
+    return sp_hla_score_consensus(ctx, db, gene, dna_g.data(), (uint32_t)dna_g.size(), cdna_g.data(), (uint32_t)cdna_g.size(),
+                                  require_dna, disable_cdna, best, stats);
 }
 
 } // extern "C"

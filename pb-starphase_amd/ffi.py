@@ -93,6 +93,7 @@ def lib():
         "sp_hla_db_free": (None, [vp]),
         "sp_hla_realign_reads": (i32, [vp, vp, vp, vp, vp]),
         "sp_hla_score_consensus": (i32, [vp, vp, u32, C.c_char_p, u32, C.c_char_p, u32, i32, i32, C.POINTER(sp_hla_best), vp]),
+        "sp_hla_type_consensus": (i32, [vp, vp, u32, C.c_char_p, u32, i32, i32, C.POINTER(sp_hla_best), vp, C.c_char_p, u32, C.POINTER(u32)]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -249,6 +250,16 @@ class HlaDb:
         cell = np.zeros((reads.n, self.n_alleles), np.uint32) if cells else None
         self.ctx.check(lib().sp_hla_realign_reads(self.ctx._h, self._h, reads._h, _ptr(out), _ptr(cell)))
         return (out, cell) if cells else out
+
+    def type_consensus(self, gene, consensus_fwd, require_dna=False, disable_cdna=False, stats=True):
+        """score_consensus of the reference: hg38-forward consensus in, best allele + spliced gene-strand cDNA out"""
+        best = sp_hla_best()
+        st = np.full((self.n_alleles, 6), -2, np.int32) if stats else None
+        buf = C.create_string_buffer(len(consensus_fwd) + 16)
+        n = C.c_uint32(0)
+        self.ctx.check(lib().sp_hla_type_consensus(self.ctx._h, self._h, int(gene), consensus_fwd.encode(), len(consensus_fwd),
+                                                   int(require_dna), int(disable_cdna), C.byref(best), _ptr(st), buf, len(buf), C.byref(n)))
+        return best.best_allele, best.n_scored, st, buf.raw[:n.value].decode()
 
     def score_consensus(self, gene, cons_dna, cons_cdna, require_dna=False, disable_cdna=False, stats=True):
         best = sp_hla_best()

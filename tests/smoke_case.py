@@ -1,0 +1,34 @@
+"""__graft_entry__.smoke(): one small invocation of the hot path on cuda:0, checked against the CPU oracle."""
+import numpy as np
+
+import hla_expected as hx
+import oracle_ffi
+
+
+def run(pkg):
+    from pb_starphase_amd import synth
+    oracle = oracle_ffi.load()
+    ctx = pkg.Context(0)
+    fx = synth.HlaFixture(max_alleles_per_gene=40, seed=7)
+    db = fx.make_db(pkg, ctx)
+    rng = np.random.default_rng(3)
+    g = 0
+    a = fx.full_length_alleles(g)[0]
+    hap, s = fx.haplotype(g, a)
+    reads = synth.simulate_reads(rng, hap, s, len(fx.dna[a]), 6, mean_len=6000, sd_len=800)
+    rs = ctx.upload(reads)
+    out, cells = db.realign_reads(rs, cells=True)            # K1, full matrix
+    exp, ecells = hx.k1_expected(oracle, fx, reads)
+    assert (cells == ecells).all(), "K1 cell matrix differs from the oracle"
+    for r, e in enumerate(exp):
+        assert out[r]["best_allele"] == e["best_allele"] and out[r]["status"] == e["status"], (r, out[r], e)
+    assert db.realign_reads(rs).tobytes() == out.tobytes(), "pruned K1 differs from exhaustive K1"
+    cons = hap[max(0, s - 80):s + len(fx.dna[a]) + 80]
+    best, n_scored, stats, cdna = db.type_consensus(g, cons)  # K2 through score_consensus
+    ebest, estats = hx.k2_expected(oracle, fx, g, cons if fx.gene_fwd[g] else synth.revcomp(cons), cdna)
+    assert best == ebest, (best, ebest)
+    for al_i, st in estats.items():
+        assert stats[al_i].tolist() == st
+    db.close()
+    rs.close()
+    ctx.close()

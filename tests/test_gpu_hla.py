@@ -86,3 +86,46 @@ def test_k1_realign_reads(oracle, pkg, gpu_ctx, small):
     for _ in range(3):
         pruned = db.realign_reads(rs)
         assert pruned.tobytes() == out.tobytes()
+
+
+def test_type_consensus(oracle, pkg, gpu_ctx, small):
+    """sp_hla_type_consensus = score_consensus + splice_read (src/hla/caller.rs:1258-1319,1518-1576): the hg38-forward
+    consensus goes in, the library places it on the gene reference, splices the cDNA and types it."""
+    from pb_starphase_amd import synth
+    fx, db = small
+    rng = np.random.default_rng(21)
+    for g in range(len(fx.genes)):
+        full = fx.full_length_alleles(g)
+        for trial, a in enumerate(rng.choice(full, 2, replace=False).tolist()):
+            hap, s = fx.haplotype(g, a)
+            cons = hap[max(0, s - 150):s + len(fx.dna[a]) + 150]
+            if trial == 1:
+                cons = synth.mutate(rng, cons, 2, 1, 1)
+            best, n_scored, stats, cdna = db.type_consensus(g, cons)
+            # expected, step by step with the oracle
+            ref = fx.gene_ref[g][fx.buffer:len(fx.gene_ref[g]) - fx.buffer]
+            d, v = oracle.anchor(fx.gene_ref[g], cons)                     # cons_pos - ref_pos (buffered reference)
+            assert v >= 2
+            al, ev = oracle.wfa(cons, ref, -d - fx.buffer)
+            assert al.ok
+            cigar = oracle.cigar(al, ev)
+            bam = [(l, {7: 0, 8: 0, 1: 1, 2: 2}[op]) for l, op in cigar]
+            if al.a_start:
+                bam.insert(0, (al.a_start, 4))
+            exons = [(e0 - fx.buffer, e1 - fx.buffer) for e0, e1 in fx.exons[g]]
+            segs, _ = oracle.splice_read(al.b_start, bam, exons)
+            spliced = "".join(cons[x:y] for x, y in segs)
+            fwd = bool(fx.gene_fwd[g])
+            e_dna = cons if fwd else synth.revcomp(cons)
+            e_cdna = spliced if fwd else synth.revcomp(spliced)
+            assert cdna == e_cdna
+            ebest, estats = hx.k2_expected(oracle, fx, g, e_dna, e_cdna)
+            assert best == ebest and n_scored == len(estats)
+            for al_i, st in estats.items():
+                assert stats[al_i].tolist() == st
+            if trial == 0:
+                assert best == a or (fx.cdna[best] == fx.cdna[a] and fx.dna[best] == fx.dna[a])
+    # empty / unalignable consensus => unknown (caller.rs:1263-1267,1282-1287)
+    assert db.type_consensus(0, "")[0:2] == (-1, 0)
+    junk = "".join(rng.choice(list("ACGT"), 3000))
+    assert db.type_consensus(0, junk)[0] == -1
