@@ -189,6 +189,54 @@ int32_t sp_hla_type_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
                               sp_hla_best* best, int32_t* stats,
                               char* cdna_out, uint32_t cdna_cap, uint32_t* cdna_len);
 
+/* ------------------------------------------------------------------ K5: CYP2D6 chain-pair likelihood search
+ * Replaces find_best_chain_pair (src/cyp2d6/chaining.rs:223-592) with containment_score (:683-731),
+ * get_multinomial_score (:854-903), count_unexpected_alleles (:794-819), unexpected_count (:739-775),
+ * count_inferred_edges (:828-840), check_chain_inferrences (:603-674) and multinomial_ln_pmf (src/util/stats.rs:11-37).
+ * The grammar / enumeration runs on the host exactly as in the reference (LIFO DFS, copy number <= 3); every unordered
+ * chain pair is then scored by one GPU thread in f64 with the reference's operation order, and the winner is
+ * min (primary_score, i, j) -- what the reference's top-10 heap returns (chaining.rs:188-196,565-573).
+ *   hap_type       Cyp2d6RegionType per consensus region (src/cyp2d6/region_label.rs:7-24), SP_CYP_* below
+ *   hap_subtype    subtype label or NULL
+ *   translate / connections / singletons   the three Cyp2d6Config tables (src/cyp2d6/definitions.rs:242-301)
+ *   reads          in BTreeMap (qname) order: read r owns chains [read_chain_off[r], read_chain_off[r+1]) (obs_chains) and
+ *                  weight rows [read_w_off[r], read_w_off[r+1]) (chain_scores); a row holds n_haps (edit distance, overlap) pairs
+ * Returns SP_OK, or SP_ERR_NO_CHAINING_HEAD / SP_ERR_NO_CHAINS_FOUND / SP_ERR_NO_SCORE_PAIRS (CallerError, expected failures).
+ */
+enum { SP_CYP_UNKNOWN = 0, SP_CYP_REP6 = 1, SP_CYP_CYP2D6 = 2, SP_CYP_LINK_REGION = 3, SP_CYP_REP7 = 4, SP_CYP_SPACER = 5,
+       SP_CYP_CYP2D7 = 6, SP_CYP_DELETION = 7, SP_CYP_HYBRID = 8, SP_CYP_FALSE_ALLELE = 9 };
+#define SP_MAX_CHAIN 64
+
+typedef struct {
+    uint32_t n_haps;
+    const int32_t* hap_type;
+    const char* const* hap_subtype;
+    uint32_t n_translate; const char* const* translate_key; const char* const* translate_val;
+    uint32_t n_connections; const char* const* connection_a; const char* const* connection_b;
+    uint32_t n_singletons; const char* const* singletons;
+    uint32_t n_reads;
+    const uint32_t* read_chain_off;     /* n_reads+1 */
+    const uint32_t* chain_off;          /* n_chains+1 */
+    const uint32_t* chain_items;
+    const uint32_t* read_w_off;         /* n_reads+1 */
+    const uint64_t* w_ed;               /* [row][n_haps] */
+    const double*   w_ov;               /* [row][n_haps] */
+    int32_t infer_connections, normalize_all_alleles, ignore_chain_label_limits;
+    double lasso_penalty, ln_ed_penalty, unexpected_chain_penalty, inferred_edge_penalty;   /* ChainPenalties, chaining.rs:107-139 */
+} sp_chain_problem;
+
+typedef struct {
+    int32_t n_possible;                 /* enumerated chains */
+    int32_t index1, index2;             /* winning pair (i <= j) in enumeration order */
+    int32_t n1, n2;
+    int32_t chain1[SP_MAX_CHAIN], chain2[SP_MAX_CHAIN];    /* the pair, sorted (chaining.rs:568-573) */
+    double score, ln_ed_penalty, mn_llh_penalty, allele_expected_penalty, unexpected_chain_penalty, inferred_chain_penalty;
+    uint64_t edit_distance;
+    uint64_t n_pairs_scored;            /* pairs whose read-level terms were evaluated on the GPU */
+} sp_chain_result;
+
+int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* problem, sp_chain_result* result);
+
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */
 int32_t sp_profile_reset(sp_ctx* ctx);

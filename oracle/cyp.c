@@ -1,0 +1,376 @@
+/*
+ * oracle/cyp.c -- CPU ORACLE (test infrastructure only): CYP2D6 chain grammar and the chain-pair likelihood search,
+ * restated from /root/reference/src/cyp2d6/{region_label,chaining}.rs and src/cyp2d6/caller.rs:907-957.
+ * Pinned by the reference's own tests (src/cyp2d6/chaining.rs:950-1195, src/cyp2d6/caller.rs:972-1006), ported in
+ * tests/test_oracle_cyp.py.
+ */
+#include "sp_oracle.h"
+#include "cyp_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include <float.h>
+
+/* ---------------------------------------------------------------- region labels (src/cyp2d6/region_label.rs) */
+static int is_cyp2d(int t) { return t == OSP_CYP2D6 || t == OSP_CYP2D7 || t == OSP_DELETION || t == OSP_HYBRID; }   /* :27-42 */
+static int is_rep(int t) { return t == OSP_REP6 || t == OSP_REP7; }                                                  /* :44-46 */
+static int is_reported(int t) { return t == OSP_CYP2D6 || t == OSP_DELETION || t == OSP_HYBRID; }                    /* :48-54 */
+static int is_allowed_label(int t) { return !(t == OSP_UNKNOWN || t == OSP_FALSE_ALLELE); }                          /* :173-175 */
+
+static const char* type_name(int t) {
+    switch (t) {
+        case OSP_UNKNOWN: return "UNKNOWN"; case OSP_REP6: return "REP6"; case OSP_CYP2D6: return "CYP2D6";
+        case OSP_LINK: return "link_region"; case OSP_REP7: return "REP7"; case OSP_SPACER: return "spacer";
+        case OSP_CYP2D7: return "CYP2D7"; case OSP_DELETION: return "CYP2D6*5"; case OSP_HYBRID: return "Hybrid";
+        default: return "FalseAllele";
+    }
+}
+
+/* full_allele (:131-170) */
+void osp_cyp_full_allele(int type, const char* subtype, char* out, size_t cap) {
+    switch (type) {
+        case OSP_CYP2D6: if (subtype) snprintf(out, cap, "CYP2D6*%s", subtype); else snprintf(out, cap, "CYP2D6"); break;
+        case OSP_HYBRID: if (subtype) snprintf(out, cap, "%s", subtype); else snprintf(out, cap, "Hybrid"); break;
+        case OSP_FALSE_ALLELE: if (subtype) snprintf(out, cap, "FalseAllele_%s", subtype); else snprintf(out, cap, "FalseAllele"); break;
+        default: snprintf(out, cap, "%s", type_name(type));
+    }
+}
+
+/* simplify_allele (:77-128) */
+void osp_cyp_simplify_allele(int type, const char* subtype, int detailed, const osp_cyp_config* cfg, char* out, size_t cap) {
+    if (type == OSP_CYP2D6 || type == OSP_HYBRID) {
+        if (subtype) {
+            for (int i = 0; i < cfg->n_translate; ++i)
+                if (strcmp(cfg->tr_key[i], subtype) == 0) { snprintf(out, cap, "*%s", cfg->tr_val[i]); return; }
+            if (detailed) { snprintf(out, cap, "*%s", subtype); return; }
+            char* endp = NULL;
+            double v = strtod(subtype, &endp);
+            /* Rust's str::parse::<f64> takes the whole string, no leading blanks */
+            if (subtype[0] != '\0' && subtype[0] != ' ' && endp && *endp == '\0' && !(subtype[0] == '0' && (subtype[1] == 'x' || subtype[1] == 'X'))) {
+                snprintf(out, cap, "*%lld", (long long)floor(v));
+            } else snprintf(out, cap, "*%s", subtype);
+            return;
+        }
+        osp_cyp_full_allele(type, subtype, out, cap);
+        return;
+    }
+    if (type == OSP_DELETION) { snprintf(out, cap, "*5"); return; }
+    osp_cyp_full_allele(type, subtype, out, cap);
+}
+
+/* is_allowed_label_pair (:178-222) */
+int osp_cyp_is_allowed_label_pair(int type1, int type2) {
+    int double_star5 = type1 == OSP_DELETION && type2 == OSP_DELETION;
+    int unexpected_order =
+        type2 == OSP_REP6 ||
+        (is_cyp2d(type1) && type1 != OSP_DELETION && type2 != OSP_LINK) ||
+        (type2 == OSP_LINK && !is_cyp2d(type1)) ||
+        (type1 == OSP_LINK && !is_rep(type2)) ||
+        (is_rep(type2) && type1 != OSP_LINK) ||
+        (is_rep(type1) && !(type2 == OSP_SPACER || is_cyp2d(type2))) ||
+        (type2 == OSP_SPACER && !(is_rep(type1) || type1 == OSP_DELETION)) ||
+        (type1 == OSP_SPACER && !is_cyp2d(type2)) ||
+        (type2 == OSP_CYP2D7 && type1 != OSP_SPACER) ||
+        type1 == OSP_CYP2D7;
+    return !double_star5 && !unexpected_order;
+}
+
+static int is_normalizing(int t, int normalize_all) { return normalize_all ? is_cyp2d(t) : t == OSP_CYP2D6; }         /* :253-261 */
+static int is_chain_head(int t, int normalize_all) {                                                                   /* :227-246 */
+    if (t == OSP_REP6 || t == OSP_DELETION) return 1;
+    if (t == OSP_CYP2D6 || t == OSP_HYBRID) return is_normalizing(t, normalize_all);
+    return 0;
+}
+
+/* convert_chain_to_hap (src/cyp2d6/caller.rs:907-957); detail: 0 core, 1 sub-alleles (deep labels are debug only) */
+void osp_cyp_convert_chain_to_hap(const int32_t* chain, int n, const int32_t* type, const char* const* subtype, int detail,
+                                  const osp_cyp_config* cfg, char* out, size_t cap) {
+    out[0] = '\0';
+    int num_non_deletion = 0;
+    for (int x = n - 1; x >= 0; --x) {
+        int t = type[chain[x]];
+        if (is_cyp2d(t) && t != OSP_CYP2D7 && t != OSP_DELETION) num_non_deletion++;
+    }
+    char prev[256] = ""; int run = 0; int first = 1; size_t len = 0;
+    char cur[256];
+#define FLUSH() do { if (run > 0) { len += (size_t)snprintf(out + len, len < cap ? cap - len : 0, "%s%s", first ? "" : " + ", prev); first = 0; \
+        if (run > 1) len += (size_t)snprintf(out + len, len < cap ? cap - len : 0, "x%d", run); } } while (0)
+    for (int x = n - 1; x >= 0; --x) {
+        int h = chain[x], t = type[h];
+        if (!(is_cyp2d(t) && t != OSP_CYP2D7)) continue;
+        if (t == OSP_DELETION && num_non_deletion > 0) continue;
+        osp_cyp_simplify_allele(t, subtype[h], detail == 1, cfg, cur, sizeof(cur));
+        if (run > 0 && strcmp(cur, prev) == 0) { run++; }
+        else { FLUSH(); strcpy(prev, cur); run = 1; }
+    }
+    FLUSH();
+#undef FLUSH
+}
+
+/* ---------------------------------------------------------------- chain pair search (src/cyp2d6/chaining.rs:223-903) */
+typedef struct { int32_t* items; int32_t len; } chain_t;
+
+static int conn_contains(const osp_cyp_config* cfg, const char* a, const char* b) {
+    for (int i = 0; i < cfg->n_conn; ++i) if (strcmp(cfg->conn_a[i], a) == 0 && strcmp(cfg->conn_b[i], b) == 0) return 1;
+    return 0;
+}
+
+/* check_chain_inferrences (:603-674) */
+static void check_chain_inferrences(const osp_chain_problem* p, const int32_t* chain, int n, const uint8_t* inferred,
+                                    int* allowed_inferrence, int* allowed_candidate) {
+    const int H = p->n_haps;
+    int last = chain[n - 1];
+    int last_is_cyp2d = is_cyp2d(p->type[last]);
+    int opt_index = -1;
+    for (int ci = n - 2; ci >= 0; --ci) if (is_cyp2d(p->type[chain[ci]])) { opt_index = ci; break; }
+    int inferrence_detected = 0;
+    for (int w = (opt_index < 0 ? 0 : opt_index); w + 1 < n; ++w) if (inferred[chain[w] * H + chain[w + 1]]) inferrence_detected = 1;
+    if (inferrence_detected) {
+        if (last_is_cyp2d) {
+            if (opt_index >= 0) {
+                int prev = chain[opt_index];
+                char h1[256], h2[256];
+                osp_cyp_simplify_allele(p->type[prev], p->subtype[prev], 0, &p->cfg, h1, sizeof(h1));
+                osp_cyp_simplify_allele(p->type[last], p->subtype[last], 0, &p->cfg, h2, sizeof(h2));
+                int connected = prev != last && conn_contains(&p->cfg, h1, h2);
+                int d7_tail = p->type[last] == OSP_CYP2D7 && p->type[prev] != OSP_CYP2D7 && is_cyp2d(p->type[prev]);
+                int allowed = connected || d7_tail;
+                *allowed_inferrence = allowed; *allowed_candidate = allowed;
+            } else { *allowed_inferrence = 1; *allowed_candidate = 1; }
+        } else { *allowed_inferrence = 1; *allowed_candidate = 0; }
+    } else { *allowed_inferrence = 1; *allowed_candidate = 1; }
+}
+
+/* containment_score (:683-731); adds split_frac * overlap of every best window into hap_weights */
+static uint64_t containment_and_weights(const int32_t* c1, int n1, const int32_t* c2, int n2, const uint64_t* w_ed, const double* w_ov,
+                                        int weight_len, int H, double* hap_weights) {
+    uint64_t optimum = 0, worst = 0;
+    for (int x = 0; x < weight_len; ++x) {
+        uint64_t mn = UINT64_MAX, mx = 0;
+        for (int h = 0; h < H; ++h) { uint64_t v = w_ed[(size_t)x * H + h]; if (v < mn) mn = v; if (v > mx) mx = v; }
+        optimum += mn; worst += mx;
+    }
+    uint64_t best_score = 2 * worst;
+    /* first pass: best score; second pass: the windows that reach it, in the reference's push order */
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t n_best = 0;
+        if (pass == 1) {
+            for (int which = 0; which < 2; ++which) {
+                const int32_t* other = which == 0 ? c1 : c2; int on = which == 0 ? n1 : n2;
+                if (on < weight_len) continue;
+                for (int s = 0; s + weight_len <= on; ++s) {
+                    uint64_t tot = 0;
+                    for (int x = 0; x < weight_len; ++x) tot += w_ed[(size_t)x * H + other[s + x]];
+                    if (tot == best_score) ++n_best;
+                }
+            }
+        }
+        double split_frac = pass == 1 ? 1.0 / (double)n_best : 0.0;
+        for (int which = 0; which < 2; ++which) {
+            const int32_t* other = which == 0 ? c1 : c2; int on = which == 0 ? n1 : n2;
+            if (on < weight_len) continue;
+            for (int s = 0; s + weight_len <= on; ++s) {
+                uint64_t tot = 0;
+                for (int x = 0; x < weight_len; ++x) tot += w_ed[(size_t)x * H + other[s + x]];
+                if (pass == 0) { if (tot < best_score) best_score = tot; }
+                else if (tot == best_score) {
+                    for (int x = 0; x < weight_len; ++x) {
+                        int con = other[s + x];
+                        hap_weights[con] += split_frac * w_ov[(size_t)x * H + con];
+                    }
+                }
+            }
+        }
+    }
+    return best_score - optimum;
+}
+
+/* unexpected_count (:739-775) */
+static uint32_t unexpected_count(const osp_chain_problem* p, const int32_t* chain, int n) {
+    char (*red)[256] = (char (*)[256])malloc(sizeof(char[256]) * (size_t)(n > 0 ? n : 1));
+    int nr = 0;
+    for (int x = 0; x < n; ++x) {
+        int t = p->type[chain[x]];
+        if (is_cyp2d(t) && t != OSP_CYP2D7) osp_cyp_simplify_allele(t, p->subtype[chain[x]], 0, &p->cfg, red[nr++], 256);
+    }
+    uint32_t errors = 0;
+    if (nr == 0 || red[0][0] != '*') errors += 1;
+    if (nr == 1) for (int i = 0; i < p->cfg.n_single; ++i) if (strcmp(p->cfg.singles[i], red[0]) == 0) { errors += 1; break; }
+    for (int x = 0; x + 1 < nr; ++x) if (!conn_contains(&p->cfg, red[x], red[x + 1])) errors += 1;
+    free(red);
+    return errors;
+}
+
+static int is_sub(const int32_t* hay, int hn, const int32_t* needle, int nn) {                                        /* :782-784 */
+    /* slice::windows(0) panics in Rust; the reference never passes an empty chain */
+    for (int s = 0; s + nn <= hn; ++s) if (memcmp(hay + s, needle, sizeof(int32_t) * (size_t)nn) == 0) return 1;
+    return 0;
+}
+
+int osp_cyp_find_best_chain_pair(const osp_chain_problem* p, osp_chain_result* res) {
+    memset(res, 0, sizeof(*res));
+    const int H = p->n_haps;
+    if (p->lasso < 0.0) { res->status = OSP_CHAIN_BAD_ARG; return res->status; }
+    uint8_t* downstream = (uint8_t*)calloc((size_t)H * H + 1, 1);
+    uint8_t* inferred = (uint8_t*)calloc((size_t)H * H + 1, 1);
+    /* observed connections (:245-264) */
+    for (int r = 0; r < p->n_reads; ++r)
+        for (int c = p->read_chain_off[r]; c < p->read_chain_off[r + 1]; ++c) {
+            const int32_t* ch = p->chain_items + p->chain_off[c]; int n = p->chain_off[c + 1] - p->chain_off[c];
+            for (int i = 1; i < n; ++i) {
+                int up = ch[i - 1], down = ch[i];
+                if (is_allowed_label(p->type[up]) && is_allowed_label(p->type[down]) &&
+                    (p->ignore_chain_label_limits || osp_cyp_is_allowed_label_pair(p->type[up], p->type[down]))) downstream[up * H + down] = 1;
+            }
+        }
+    /* inferred connections (:267-305) */
+    if (p->infer_connections) {
+        for (int i = 0; i < H; ++i) {
+            int downstream_no_link = 1; for (int j = 0; j < H; ++j) if (downstream[i * H + j]) downstream_no_link = 0;
+            for (int j = 0; j < H; ++j) {
+                int upstream_no_link = 1; for (int v = 0; v < H; ++v) if (downstream[v * H + j]) upstream_no_link = 0;
+                if ((downstream_no_link || upstream_no_link) && !downstream[i * H + j] && is_allowed_label(p->type[i]) &&
+                    is_allowed_label(p->type[j]) && osp_cyp_is_allowed_label_pair(p->type[i], p->type[j])) inferred[i * H + j] = 1;
+            }
+        }
+    }
+    /* heads (:308-323) */
+    int n_heads = 0; int32_t* heads = (int32_t*)malloc(sizeof(int32_t) * (size_t)(H + 1));
+    for (int i = 0; i < H; ++i) if (p->ignore_chain_label_limits || is_chain_head(p->type[i], p->normalize_all_alleles)) heads[n_heads++] = i;
+    if (n_heads == 0) { res->status = OSP_CHAIN_NO_HEAD; free(downstream); free(inferred); free(heads); return res->status; }
+
+    /* enumeration: remaining_chains is a LIFO stack (:326-391) */
+    size_t stack_cap = 64, stack_n = 0; chain_t* stack = (chain_t*)malloc(sizeof(chain_t) * stack_cap);
+    size_t pos_cap = 64, P = 0; chain_t* possible = (chain_t*)malloc(sizeof(chain_t) * pos_cap);
+#define PUSH(vec, n_, cap_, item) do { if ((n_) == (cap_)) { (cap_) *= 2; (vec) = (chain_t*)realloc((vec), sizeof(chain_t) * (cap_)); } (vec)[(n_)++] = (item); } while (0)
+    for (int i = 0; i < n_heads; ++i) { chain_t c; c.len = 1; c.items = (int32_t*)malloc(sizeof(int32_t)); c.items[0] = heads[i]; PUSH(stack, stack_n, stack_cap, c); }
+    const int max_copy_number = 3;
+    int overflow = 0;
+    while (stack_n > 0) {
+        chain_t cur = stack[--stack_n];
+        int allowed_inf, allowed_cand;
+        check_chain_inferrences(p, cur.items, cur.len, inferred, &allowed_inf, &allowed_cand);
+        if (!allowed_inf) { free(cur.items); continue; }
+        int nonempty = 0;                                      /* convert_chain_to_hap(..SubAlleles..) is non-empty */
+        for (int x = 0; x < cur.len; ++x) { int t = p->type[cur.items[x]]; if (is_cyp2d(t) && t != OSP_CYP2D7) nonempty = 1; }
+        if (p->ignore_chain_label_limits || (nonempty && allowed_cand)) {
+            chain_t keep; keep.len = cur.len; keep.items = (int32_t*)malloc(sizeof(int32_t) * (size_t)cur.len);
+            memcpy(keep.items, cur.items, sizeof(int32_t) * (size_t)cur.len);
+            PUSH(possible, P, pos_cap, keep);
+        }
+        int cur_index = cur.items[cur.len - 1];
+        for (int rep = 0; rep < 2; ++rep) {
+            if (rep == 1 && !p->infer_connections) break;
+            const uint8_t* table = rep == 0 ? downstream : inferred;
+            for (int ext = 0; ext < H; ++ext) {
+                if (!table[cur_index * H + ext]) continue;
+                int count = 0; for (int x = 0; x < cur.len; ++x) if (cur.items[x] == ext) ++count;
+                if (count >= max_copy_number) continue;
+                if (cur.len + 1 > OSP_MAX_CHAIN) { overflow = 1; continue; }
+                chain_t nc; nc.len = cur.len + 1; nc.items = (int32_t*)malloc(sizeof(int32_t) * (size_t)nc.len);
+                memcpy(nc.items, cur.items, sizeof(int32_t) * (size_t)cur.len); nc.items[cur.len] = ext;
+                PUSH(stack, stack_n, stack_cap, nc);
+            }
+        }
+        free(cur.items);
+    }
+#undef PUSH
+    free(stack); free(heads);
+    res->n_possible = (int32_t)P;
+    if (overflow) res->status = OSP_CHAIN_TOO_LONG;
+    if (P == 0 && !overflow) res->status = OSP_CHAIN_NO_CHAINS;
+    if (res->status) { for (size_t i = 0; i < P; ++i) free(possible[i].items); free(possible); free(downstream); free(inferred); return res->status; }
+
+    /* per-chain quantities that do not depend on the partner */
+    uint32_t* unexp = (uint32_t*)calloc(P, sizeof(uint32_t));
+    if (!p->ignore_chain_label_limits) for (size_t i = 0; i < P; ++i) unexp[i] = unexpected_count(p, possible[i].items, possible[i].len);
+
+    /* pair loop (:409-534).  The reference keeps a 10-entry max-heap and skips pairs whose cheap partial cost cannot enter
+     * it; neither changes the winner = min (primary_score, i, j) over the valid pairs, which is what is computed here. */
+    int32_t* hap_counts = (int32_t*)malloc(sizeof(int32_t) * (size_t)H);
+    double* hap_weights = (double*)malloc(sizeof(double) * (size_t)H);
+    double* probs = (double*)malloc(sizeof(double) * (size_t)H);
+    uint64_t* cover = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)H);
+    int have = 0; double best_score = 0; size_t bi = 0, bj = 0;
+    osp_chain_result best; memset(&best, 0, sizeof(best));
+    for (size_t i = 0; i < P; ++i) for (size_t j = i; j < P; ++j) {
+        const chain_t* ci = &possible[i]; const chain_t* cj = &possible[j];
+        memset(hap_counts, 0, sizeof(int32_t) * (size_t)H);
+        for (int x = 0; x < ci->len; ++x) hap_counts[ci->items[x]]++;
+        for (int x = 0; x < cj->len; ++x) hap_counts[cj->items[x]]++;
+        /* count_unexpected_alleles (:794-819) */
+        int32_t unexpected_alleles = 0;
+        for (int h = 0; h < H; ++h) {
+            int t = p->type[h];
+            if (is_allowed_label(t) && (p->ignore_chain_label_limits || is_normalizing(t, p->normalize_all_alleles) || is_reported(t)) && hap_counts[h] > 0)
+                unexpected_alleles += hap_counts[h] - 1;
+        }
+        double allele_expected_penalty = p->lasso * (double)unexpected_alleles;
+        uint64_t unmet = 0;                                    /* (:427-440) debug only */
+        for (int r = 0; r < p->n_reads; ++r) {
+            int supported = 0;
+            for (int c = p->read_chain_off[r]; c < p->read_chain_off[r + 1] && !supported; ++c) {
+                const int32_t* ch = p->chain_items + p->chain_off[c]; int n = p->chain_off[c + 1] - p->chain_off[c];
+                if (is_sub(ci->items, ci->len, ch, n) || is_sub(cj->items, cj->len, ch, n)) supported = 1;
+            }
+            if (!supported) unmet++;
+        }
+        uint32_t mismatch = p->ignore_chain_label_limits ? 0 : unexp[i] + unexp[j];
+        double unexpected_chain_penalty = (double)mismatch * p->unexpected;
+        uint32_t n_inf = 0;                                    /* count_inferred_edges (:828-840) */
+        if (p->infer_connections) {
+            for (int x = 0; x + 1 < ci->len; ++x) if (inferred[ci->items[x] * H + ci->items[x + 1]]) n_inf++;
+            for (int x = 0; x + 1 < cj->len; ++x) if (inferred[cj->items[x] * H + cj->items[x + 1]]) n_inf++;
+        }
+        double inferred_chain_penalty = (double)n_inf * p->inferred;
+        /* read-level part (:466-485) */
+        uint64_t read_combined_ed = 0;
+        for (int h = 0; h < H; ++h) hap_weights[h] = 0.0;
+        for (int r = 0; r < p->n_reads; ++r) {
+            int wl = p->read_w_off[r + 1] - p->read_w_off[r];
+            uint64_t sc = containment_and_weights(ci->items, ci->len, cj->items, cj->len, p->w_ed + (size_t)p->read_w_off[r] * H,
+                                                  p->w_ov + (size_t)p->read_w_off[r] * H, wl, H, hap_weights);
+            uint64_t sum = read_combined_ed + sc; read_combined_ed = sum < read_combined_ed ? UINT64_MAX : sum;   /* saturating_add */
+        }
+        double ln_ed_penalty = (double)read_combined_ed * p->ln_ed;
+        /* get_multinomial_score (:854-903) */
+        int nr = 0; int32_t total = 0; uint64_t cov_sum = 0;
+        for (int h = 0; h < H; ++h) {
+            if (hap_counts[h] > 0 && (p->ignore_chain_label_limits || is_normalizing(p->type[h], p->normalize_all_alleles))) {
+                probs[nr] = (double)hap_counts[h]; total += hap_counts[h];
+                cover[nr] = (uint64_t)round(hap_weights[h]); cov_sum += cover[nr]; nr++;
+            }
+        }
+        for (int x = 0; x < nr; ++x) probs[x] = probs[x] / (double)total;
+        double mn;
+        if (nr == 0 || cov_sum == 0) {
+            int d1 = 0, d2 = 0;
+            for (int x = 0; x < ci->len; ++x) if (p->type[ci->items[x]] == OSP_DELETION) d1 = 1;
+            for (int x = 0; x < cj->len; ++x) if (p->type[cj->items[x]] == OSP_DELETION) d2 = 1;
+            if (!p->normalize_all_alleles && d1 && d2) mn = 0.0; else continue;      /* invalid pair, skipped */
+        } else mn = fabs(osp_multinomial_ln_pmf(probs, cover, nr));
+        double primary = ln_ed_penalty + mn + allele_expected_penalty + unexpected_chain_penalty + inferred_chain_penalty;   /* (:172-174) */
+        if (!have || primary < best_score) {                   /* (i, j) ascending => first minimum = min (score, i, j) */
+            have = 1; best_score = primary; bi = i; bj = j;
+            best.score = primary; best.ln_ed_penalty = ln_ed_penalty; best.mn_llh_penalty = mn; best.allele_expected_penalty = allele_expected_penalty;
+            best.unexpected_chain_penalty = unexpected_chain_penalty; best.inferred_chain_penalty = inferred_chain_penalty;
+            best.edit_distance = read_combined_ed; best.unmet_observations = unmet;
+        }
+    }
+    if (!have) res->status = OSP_CHAIN_NO_PAIRS;
+    else {
+        *res = best; res->status = OSP_CHAIN_OK; res->n_possible = (int32_t)P; res->index1 = (int32_t)bi; res->index2 = (int32_t)bj;
+        const chain_t* a = &possible[bi]; const chain_t* b = &possible[bj];
+        /* best_chain_pair.sort() : lexicographic Vec<usize> order (:568-573) */
+        int cmp = 0; for (int x = 0; x < a->len && x < b->len && !cmp; ++x) cmp = a->items[x] < b->items[x] ? -1 : (a->items[x] > b->items[x]);
+        if (!cmp) cmp = a->len < b->len ? -1 : (a->len > b->len);
+        if (cmp > 0) { const chain_t* t = a; a = b; b = t; }
+        res->n1 = a->len; memcpy(res->chain1, a->items, sizeof(int32_t) * (size_t)a->len);
+        res->n2 = b->len; memcpy(res->chain2, b->items, sizeof(int32_t) * (size_t)b->len);
+    }
+    free(hap_counts); free(hap_weights); free(probs); free(cover); free(unexp);
+    for (size_t i = 0; i < P; ++i) free(possible[i].items);
+    free(possible); free(downstream); free(inferred);
+    return res->status;
+}

@@ -1,0 +1,59 @@
+/* cyp_oracle.h -- CPU ORACLE (test infrastructure only): CYP2D6 chain search interface (see oracle/cyp.c). */
+#ifndef CYP_ORACLE_H
+#define CYP_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Cyp2d6RegionType (src/cyp2d6/region_label.rs:7-24) */
+enum { OSP_UNKNOWN = 0, OSP_REP6 = 1, OSP_CYP2D6 = 2, OSP_LINK = 3, OSP_REP7 = 4, OSP_SPACER = 5, OSP_CYP2D7 = 6,
+       OSP_DELETION = 7, OSP_HYBRID = 8, OSP_FALSE_ALLELE = 9 };
+enum { OSP_CHAIN_OK = 0, OSP_CHAIN_BAD_ARG = 1, OSP_CHAIN_TOO_LONG = 5,
+       OSP_CHAIN_NO_HEAD = 16, OSP_CHAIN_NO_CHAINS = 17, OSP_CHAIN_NO_PAIRS = 18 };   /* CallerError (src/cyp2d6/errors.rs:4-11) */
+#define OSP_MAX_CHAIN 64
+
+typedef struct {                                   /* the three tables of Cyp2d6Config the search reads (definitions.rs:242-301) */
+    int32_t n_translate; const char* const* tr_key; const char* const* tr_val;      /* cyp_translate */
+    int32_t n_conn; const char* const* conn_a; const char* const* conn_b;           /* inferred_connections */
+    int32_t n_single; const char* const* singles;                                    /* unexpected_singletons */
+} osp_cyp_config;
+
+typedef struct {
+    int32_t n_haps;
+    const int32_t* type;                           /* region type per consensus region */
+    const char* const* subtype;                    /* subtype label or NULL */
+    osp_cyp_config cfg;
+    int32_t n_reads;                               /* reads in BTreeMap (qname) order */
+    const int32_t* read_chain_off;                 /* n_reads+1 : chains of read r = [off[r], off[r+1]) */
+    const int32_t* chain_off;                      /* n_chains+1 into chain_items */
+    const int32_t* chain_items;
+    const int32_t* read_w_off;                     /* n_reads+1 : weight rows of read r */
+    const uint64_t* w_ed;                          /* [row][n_haps] edit distance */
+    const double* w_ov;                            /* [row][n_haps] overlap score */
+    int32_t infer_connections, normalize_all_alleles, ignore_chain_label_limits;
+    double lasso, ln_ed, unexpected, inferred;     /* ChainPenalties (chaining.rs:107-139) */
+} osp_chain_problem;
+
+typedef struct {
+    int32_t status;
+    int32_t n_possible;                            /* number of enumerated chains */
+    int32_t index1, index2;                        /* winning pair (i <= j) in enumeration order */
+    int32_t n1, n2;
+    int32_t chain1[OSP_MAX_CHAIN], chain2[OSP_MAX_CHAIN];   /* sorted pair */
+    double score, ln_ed_penalty, mn_llh_penalty, allele_expected_penalty, unexpected_chain_penalty, inferred_chain_penalty;
+    uint64_t edit_distance, unmet_observations;
+} osp_chain_result;
+
+void osp_cyp_full_allele(int type, const char* subtype, char* out, size_t cap);
+void osp_cyp_simplify_allele(int type, const char* subtype, int detailed, const osp_cyp_config* cfg, char* out, size_t cap);
+int  osp_cyp_is_allowed_label_pair(int type1, int type2);
+void osp_cyp_convert_chain_to_hap(const int32_t* chain, int n, const int32_t* type, const char* const* subtype, int detail,
+                                  const osp_cyp_config* cfg, char* out, size_t cap);
+int  osp_cyp_find_best_chain_pair(const osp_chain_problem* p, osp_chain_result* res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

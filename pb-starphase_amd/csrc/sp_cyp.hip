@@ -1,0 +1,391 @@
+// sp_cyp.hip -- K5: CYP2D6 chain-pair likelihood search on gfx950.
+// Replaces find_best_chain_pair and its helpers (src/cyp2d6/chaining.rs:223-903).  Host: label grammar, edge tables,
+// LIFO chain enumeration (sequential by nature, tiny).  Device: one thread per unordered chain pair; the per-read
+// containment scores, the haplotype weights and the multinomial ln-likelihood are accumulated in f64 in exactly the
+// reference's operation order (no FMA contraction, table look-ups for ln n! and ln p), so the scores are bit-identical
+// to the CPU path and the (score, i, j) winner is deterministic.
+#include "sp_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---- region label helpers (src/cyp2d6/region_label.rs) ----
+inline bool t_is_cyp2d(int t) { return t == SP_CYP_CYP2D6 || t == SP_CYP_CYP2D7 || t == SP_CYP_DELETION || t == SP_CYP_HYBRID; }
+inline bool t_is_rep(int t) { return t == SP_CYP_REP6 || t == SP_CYP_REP7; }
+inline bool t_is_reported(int t) { return t == SP_CYP_CYP2D6 || t == SP_CYP_DELETION || t == SP_CYP_HYBRID; }
+inline bool t_allowed(int t) { return t != SP_CYP_UNKNOWN && t != SP_CYP_FALSE_ALLELE; }
+inline bool t_normalizing(int t, bool all) { return all ? t_is_cyp2d(t) : t == SP_CYP_CYP2D6; }
+inline bool t_head(int t, bool all) {
+    if (t == SP_CYP_REP6 || t == SP_CYP_DELETION) return true;
+    if (t == SP_CYP_CYP2D6 || t == SP_CYP_HYBRID) return t_normalizing(t, all);
+    return false;
+}
+// is_allowed_label_pair (region_label.rs:178-222)
+bool label_pair_allowed(int a, int b) {
+    const bool double_star5 = a == SP_CYP_DELETION && b == SP_CYP_DELETION;
+    const bool bad_order = b == SP_CYP_REP6 || (t_is_cyp2d(a) && a != SP_CYP_DELETION && b != SP_CYP_LINK_REGION) ||
+        (b == SP_CYP_LINK_REGION && !t_is_cyp2d(a)) || (a == SP_CYP_LINK_REGION && !t_is_rep(b)) || (t_is_rep(b) && a != SP_CYP_LINK_REGION) ||
+        (t_is_rep(a) && !(b == SP_CYP_SPACER || t_is_cyp2d(b))) || (b == SP_CYP_SPACER && !(t_is_rep(a) || a == SP_CYP_DELETION)) ||
+        (a == SP_CYP_SPACER && !t_is_cyp2d(b)) || (b == SP_CYP_CYP2D7 && a != SP_CYP_SPACER) || a == SP_CYP_CYP2D7;
+    return !double_star5 && !bad_order;
+}
+const char* type_str(int t) {
+    static const char* names[] = {"UNKNOWN", "REP6", "CYP2D6", "link_region", "REP7", "spacer", "CYP2D7", "CYP2D6*5", "Hybrid", "FalseAllele"};
+    return (t >= 0 && t <= 9) ? names[t] : "UNKNOWN";
+}
+std::string full_allele(int t, const char* sub) {                               // region_label.rs:131-170
+    if (t == SP_CYP_CYP2D6) return sub ? std::string("CYP2D6*") + sub : std::string("CYP2D6");
+    if (t == SP_CYP_HYBRID) return sub ? std::string(sub) : std::string("Hybrid");
+    if (t == SP_CYP_FALSE_ALLELE) return sub ? std::string("FalseAllele_") + sub : std::string("FalseAllele");
+    return type_str(t);
+}
+// simplify_allele(detailed = false) (region_label.rs:77-128)
+std::string simple_allele(const sp_chain_problem* p, uint32_t h) {
+    const int t = p->hap_type[h]; const char* sub = p->hap_subtype ? p->hap_subtype[h] : nullptr;
+    if (t == SP_CYP_CYP2D6 || t == SP_CYP_HYBRID) {
+        if (!sub) return full_allele(t, sub);
+        for (uint32_t i = 0; i < p->n_translate; ++i) if (std::strcmp(p->translate_key[i], sub) == 0) return std::string("*") + p->translate_val[i];
+        char* endp = nullptr;
+        const double v = std::strtod(sub, &endp);
+        const bool parsed = sub[0] != '\0' && sub[0] != ' ' && endp && *endp == '\0' && !(sub[0] == '0' && (sub[1] == 'x' || sub[1] == 'X'));
+        if (parsed) return std::string("*") + std::to_string((long long)std::floor(v));
+        return std::string("*") + sub;
+    }
+    if (t == SP_CYP_DELETION) return "*5";
+    return full_allele(t, sub);
+}
+
+struct PairConsts {
+    int H, P, maxlen, R;
+    int ignore_limits, normalize_all, infer;
+    double lasso, ln_ed, unexpected, inferred;
+    uint64_t n_pairs;
+};
+
+} // namespace
+
+// =============================================================================================
+// device
+// =============================================================================================
+#define K5_MAXH 64
+
+__device__ __forceinline__ void k5_pair_from_id(uint64_t pid, int P, int& i, int& j) {
+    // rows i = 0..P-1 hold P - i pairs (j = i..P-1); offset(i) = i*P - i*(i-1)/2
+    double Pd = (double)P;
+    double disc = (2.0 * Pd + 1.0) * (2.0 * Pd + 1.0) - 8.0 * (double)pid;
+    long long ii = (long long)(((2.0 * Pd + 1.0) - sqrt(disc)) * 0.5);
+    if (ii < 0) ii = 0;
+    if (ii > P - 1) ii = P - 1;
+    auto off = [&](long long x) -> uint64_t { return (uint64_t)x * (uint64_t)P - (uint64_t)(x * (x - 1) / 2); };
+    while (ii > 0 && off(ii) > pid) --ii;
+    while (ii + 1 < P && off(ii + 1) <= pid) ++ii;
+    i = (int)ii; j = (int)(pid - off(ii)) + i;
+}
+
+// one thread = one unordered pair (i <= j)
+__global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
+                                                      const uint8_t* __restrict__ chains, const int32_t* __restrict__ chain_len,   // [P][maxlen]
+                                                      const uint32_t* __restrict__ chain_unexp, const uint32_t* __restrict__ chain_inf,
+                                                      const uint8_t* __restrict__ chain_has_del,
+                                                      const uint8_t* __restrict__ hap_lasso, const uint8_t* __restrict__ hap_norm,
+                                                      const int32_t* __restrict__ read_w_off, const uint32_t* __restrict__ w_ed, const double* __restrict__ w_ov,
+                                                      const uint64_t* __restrict__ read_optimum, const uint64_t* __restrict__ read_worst,
+                                                      const double* __restrict__ ln_fact, int ln_fact_n,
+                                                      const double* __restrict__ ln_p, int ln_p_stride,      // ln_p[c * stride + total]
+                                                      unsigned long long* __restrict__ global_best,
+                                                      double* __restrict__ blk_score, unsigned long long* __restrict__ blk_pid,
+                                                      double* __restrict__ blk_comp, unsigned long long* __restrict__ blk_ed,
+                                                      unsigned long long* __restrict__ n_scored) {
+    const uint64_t pid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int H = c.H;
+    bool have = false;
+    double primary = 0.0, comp_lned = 0.0, comp_mn = 0.0, comp_exp = 0.0, comp_unexp = 0.0, comp_inf = 0.0;
+    unsigned long long ed_out = 0;
+    if (pid < c.n_pairs) {
+        int i, j; k5_pair_from_id(pid, c.P, i, j);
+        const uint8_t* ci = chains + (size_t)i * c.maxlen; const uint8_t* cj = chains + (size_t)j * c.maxlen;
+        const int ni = chain_len[i], nj = chain_len[j];
+        unsigned char cnt[K5_MAXH];
+        for (int h = 0; h < H; ++h) cnt[h] = 0;
+        for (int x = 0; x < ni; ++x) cnt[ci[x]]++;
+        for (int x = 0; x < nj; ++x) cnt[cj[x]]++;
+        int unexpected_alleles = 0;                                           // count_unexpected_alleles (chaining.rs:794-819)
+        for (int h = 0; h < H; ++h) if (hap_lasso[h] && cnt[h] > 0) unexpected_alleles += cnt[h] - 1;
+        const double allele_expected_penalty = c.lasso * (double)unexpected_alleles;
+        const unsigned mismatch = c.ignore_limits ? 0u : chain_unexp[i] + chain_unexp[j];
+        const double unexpected_chain_penalty = (double)mismatch * c.unexpected;
+        const unsigned n_inf = c.infer ? chain_inf[i] + chain_inf[j] : 0u;
+        const double inferred_chain_penalty = (double)n_inf * c.inferred;
+        const double partial_cost = allele_expected_penalty + unexpected_chain_penalty + inferred_chain_penalty;
+        // exact pruning: a pair whose cheap partial cost already exceeds the best complete score cannot win (chaining.rs:457-464)
+        const double gb = __longlong_as_double((long long)__hip_atomic_load(global_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (!(partial_cost > gb)) {
+            atomicAdd(n_scored, 1ull);
+            double hw[K5_MAXH];
+            for (int h = 0; h < H; ++h) hw[h] = 0.0;
+            unsigned long long read_combined_ed = 0;
+            for (int r = 0; r < c.R; ++r) {
+                const int row0 = read_w_off[r], wl = read_w_off[r + 1] - row0;
+                const uint32_t* ed = w_ed + (size_t)row0 * H; const double* ov = w_ov + (size_t)row0 * H;
+                unsigned long long best_score = 2ull * read_worst[r];
+                int n_best = 0;
+                // containment_score (chaining.rs:683-731): best window total over both chains, ties kept in visiting order
+                for (int which = 0; which < 2; ++which) {
+                    const uint8_t* o = which ? cj : ci; const int on = which ? nj : ni;
+                    for (int s = 0; s + wl <= on; ++s) {
+                        unsigned long long tot = 0;
+                        for (int x = 0; x < wl; ++x) tot += ed[(size_t)x * H + o[s + x]];
+                        if (tot < best_score) { best_score = tot; n_best = 1; } else if (tot == best_score) ++n_best;
+                    }
+                }
+                const unsigned long long sc = best_score - read_optimum[r];
+                const unsigned long long sum = read_combined_ed + sc;
+                read_combined_ed = sum < read_combined_ed ? 0xFFFFFFFFFFFFFFFFull : sum;        // saturating_add
+                const double split_frac = 1.0 / (double)n_best;
+                for (int which = 0; which < 2; ++which) {
+                    const uint8_t* o = which ? cj : ci; const int on = which ? nj : ni;
+                    for (int s = 0; s + wl <= on; ++s) {
+                        unsigned long long tot = 0;
+                        for (int x = 0; x < wl; ++x) tot += ed[(size_t)x * H + o[s + x]];
+                        if (tot == best_score) for (int x = 0; x < wl; ++x) { const int con = o[s + x]; hw[con] += split_frac * ov[(size_t)x * H + con]; }
+                    }
+                }
+            }
+            const double ln_ed_penalty = (double)read_combined_ed * c.ln_ed;
+            // get_multinomial_score (chaining.rs:854-903) + multinomial_ln_pmf (util/stats.rs:11-37)
+            int nr = 0, total = 0; unsigned long long cov_sum = 0;
+            for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) { ++nr; total += cnt[h]; cov_sum += (unsigned long long)round(hw[h]); }
+            bool valid = true; double mn = 0.0;
+            if (nr == 0 || cov_sum == 0) {
+                valid = !c.normalize_all && chain_has_del[i] && chain_has_del[j];
+            } else {
+                double coeff = cov_sum < (unsigned long long)ln_fact_n ? ln_fact[cov_sum] : ln_fact[ln_fact_n - 1];
+                for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) coeff -= ln_fact[(unsigned long long)round(hw[h])];
+                double acc = 0.0;
+                for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) acc = acc + (double)((unsigned long long)round(hw[h])) * ln_p[(size_t)cnt[h] * ln_p_stride + total];
+                mn = fabs(coeff + acc);
+            }
+            if (valid) {
+                primary = ln_ed_penalty + mn + allele_expected_penalty + unexpected_chain_penalty + inferred_chain_penalty;    // chaining.rs:172-174
+                have = true; comp_lned = ln_ed_penalty; comp_mn = mn; comp_exp = allele_expected_penalty; comp_unexp = unexpected_chain_penalty;
+                comp_inf = inferred_chain_penalty; ed_out = read_combined_ed;
+                atomicMin(global_best, (unsigned long long)__double_as_longlong(primary));   // scores are >= 0: bit order = numeric order
+            }
+        }
+    }
+    // block-level lexicographic min (score, pid)
+    __shared__ double s_score[256]; __shared__ unsigned long long s_pid[256];
+    s_score[threadIdx.x] = have ? primary : 1.0e308 * 10.0; s_pid[threadIdx.x] = have ? pid : 0xFFFFFFFFFFFFFFFFull;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double so = s_score[threadIdx.x + o]; const unsigned long long po = s_pid[threadIdx.x + o];
+            if (po != 0xFFFFFFFFFFFFFFFFull && (s_pid[threadIdx.x] == 0xFFFFFFFFFFFFFFFFull || so < s_score[threadIdx.x] ||
+                                                (so == s_score[threadIdx.x] && po < s_pid[threadIdx.x]))) { s_score[threadIdx.x] = so; s_pid[threadIdx.x] = po; }
+        }
+        __syncthreads();
+    }
+    if (have && s_pid[0] == pid) {
+        blk_score[blockIdx.x] = primary; blk_pid[blockIdx.x] = pid; blk_ed[blockIdx.x] = ed_out;
+        double* cp = blk_comp + (size_t)blockIdx.x * 5; cp[0] = comp_lned; cp[1] = comp_mn; cp[2] = comp_exp; cp[3] = comp_unexp; cp[4] = comp_inf;
+    } else if (threadIdx.x == 0 && s_pid[0] == 0xFFFFFFFFFFFFFFFFull) {
+        blk_pid[blockIdx.x] = 0xFFFFFFFFFFFFFFFFull;
+    }
+}
+
+// =============================================================================================
+// host
+// =============================================================================================
+template <typename T> static T* k5_upload(sp_ctx* ctx, const char* name, const std::vector<T>& v) {
+    T* d = (T*)sp_pool(ctx, name, std::max<size_t>(1, v.size()) * sizeof(T));
+    if (d && !v.empty()) (void)hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+    return d;
+}
+
+extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p, sp_chain_result* res) {
+    if (!ctx || !p || !res || (p->n_haps && !p->hap_type)) return SP_ERR_INVALID_ARG;
+    std::memset(res, 0, sizeof(*res));
+    (void)hipSetDevice(ctx->device);
+    const int H = (int)p->n_haps;
+    if (H > K5_MAXH) return sp_fail(ctx, SP_ERR_INVALID_ARG, "chain pair: more than 64 consensus regions");
+    if (p->lasso_penalty < 0.0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "Lasso penalty must be >= 0.0");      // chaining.rs:233-235
+    const bool ignore = p->ignore_chain_label_limits != 0, norm_all = p->normalize_all_alleles != 0, infer = p->infer_connections != 0;
+    std::vector<int> type(p->hap_type, p->hap_type + H);
+    std::vector<std::string> simple(H);
+    for (int h = 0; h < H; ++h) simple[h] = simple_allele(p, (uint32_t)h);
+    auto connected = [&](const std::string& a, const std::string& b) {
+        for (uint32_t i = 0; i < p->n_connections; ++i) if (a == p->connection_a[i] && b == p->connection_b[i]) return true;
+        return false;
+    };
+    // observed edges (chaining.rs:245-264)
+    std::vector<uint8_t> down((size_t)H * H, 0), inferred((size_t)H * H, 0);
+    for (uint32_t r = 0; r < p->n_reads; ++r)
+        for (uint32_t c = p->read_chain_off[r]; c < p->read_chain_off[r + 1]; ++c)
+            for (uint32_t x = p->chain_off[c] + 1; x < p->chain_off[c + 1]; ++x) {
+                const uint32_t up = p->chain_items[x - 1], dn = p->chain_items[x];
+                if (up >= (uint32_t)H || dn >= (uint32_t)H) return sp_fail(ctx, SP_ERR_INVALID_ARG, "chain pair: consensus index out of range");
+                if (t_allowed(type[up]) && t_allowed(type[dn]) && (ignore || label_pair_allowed(type[up], type[dn]))) down[up * H + dn] = 1;
+            }
+    // inferred edges (chaining.rs:267-305)
+    if (infer) for (int i = 0; i < H; ++i) {
+        bool out_none = true; for (int j = 0; j < H; ++j) out_none &= !down[i * H + j];
+        for (int j = 0; j < H; ++j) {
+            bool in_none = true; for (int v = 0; v < H; ++v) in_none &= !down[v * H + j];
+            if ((out_none || in_none) && !down[i * H + j] && t_allowed(type[i]) && t_allowed(type[j]) && label_pair_allowed(type[i], type[j])) inferred[i * H + j] = 1;
+        }
+    }
+    // chain heads (chaining.rs:308-323)
+    std::vector<std::vector<int>> stack;
+    for (int i = 0; i < H; ++i) if (ignore || t_head(type[i], norm_all)) stack.push_back({i});
+    if (stack.empty()) return SP_ERR_NO_CHAINING_HEAD;
+    // LIFO enumeration, copy number <= 3 (chaining.rs:326-391)
+    std::vector<std::vector<int>> possible;
+    while (!stack.empty()) {
+        std::vector<int> cur = std::move(stack.back()); stack.pop_back();
+        // check_chain_inferrences (chaining.rs:603-674)
+        bool ok_infer = true, ok_cand = true;
+        {
+            const int last = cur.back(); const bool last_d = t_is_cyp2d(type[last]);
+            int prev_pos = -1;
+            for (int x = (int)cur.size() - 2; x >= 0; --x) if (t_is_cyp2d(type[cur[x]])) { prev_pos = x; break; }
+            bool seen = false;
+            for (size_t w = prev_pos < 0 ? 0 : (size_t)prev_pos; w + 1 < cur.size(); ++w) seen |= inferred[cur[w] * H + cur[w + 1]] != 0;
+            if (seen) {
+                if (last_d) {
+                    if (prev_pos >= 0) {
+                        const int pv = cur[prev_pos];
+                        const bool conn = pv != last && connected(simple[pv], simple[last]);
+                        const bool d7_tail = type[last] == SP_CYP_CYP2D7 && type[pv] != SP_CYP_CYP2D7 && t_is_cyp2d(type[pv]);
+                        ok_infer = ok_cand = conn || d7_tail;
+                    }
+                } else ok_cand = false;
+            }
+        }
+        if (!ok_infer) continue;
+        bool reportable = false;                       // convert_chain_to_hap(.., SubAlleles, ..) non-empty (caller.rs:907-957)
+        for (int h : cur) reportable |= t_is_cyp2d(type[h]) && type[h] != SP_CYP_CYP2D7;
+        if (ignore || (reportable && ok_cand)) possible.push_back(cur);
+        const int tail = cur.back();
+        for (int rep = 0; rep < (infer ? 2 : 1); ++rep) {
+            const std::vector<uint8_t>& tab = rep ? inferred : down;
+            for (int e = 0; e < H; ++e) {
+                if (!tab[tail * H + e]) continue;
+                if (std::count(cur.begin(), cur.end(), e) >= 3) continue;
+                if (cur.size() + 1 > SP_MAX_CHAIN) return sp_fail(ctx, SP_ERR_TOO_LONG, "chain pair: chain longer than 64 regions");
+                std::vector<int> nxt(cur); nxt.push_back(e); stack.push_back(std::move(nxt));
+            }
+        }
+    }
+    if (possible.empty()) return SP_ERR_NO_CHAINS_FOUND;
+    const int P = (int)possible.size();
+    res->n_possible = P;
+
+    // flatten for the device
+    int maxlen = 1; for (auto& c : possible) maxlen = std::max(maxlen, (int)c.size());
+    std::vector<uint8_t> chains((size_t)P * maxlen, 0), has_del(P, 0);
+    std::vector<int32_t> clen(P);
+    std::vector<uint32_t> unexp(P, 0), ninf(P, 0);
+    for (int i = 0; i < P; ++i) {
+        const auto& c = possible[i];
+        clen[i] = (int32_t)c.size();
+        for (size_t x = 0; x < c.size(); ++x) { chains[(size_t)i * maxlen + x] = (uint8_t)c[x]; has_del[i] |= type[c[x]] == SP_CYP_DELETION; }
+        for (size_t x = 0; x + 1 < c.size(); ++x) ninf[i] += inferred[c[x] * H + c[x + 1]];
+        // unexpected_count (chaining.rs:739-775)
+        std::vector<const std::string*> red;
+        for (int h : c) if (t_is_cyp2d(type[h]) && type[h] != SP_CYP_CYP2D7) red.push_back(&simple[h]);
+        uint32_t e = 0;
+        if (red.empty() || (*red[0])[0] != '*') e += 1;
+        if (red.size() == 1) for (uint32_t s = 0; s < p->n_singletons; ++s) if (*red[0] == p->singletons[s]) { e += 1; break; }
+        for (size_t x = 0; x + 1 < red.size(); ++x) if (!connected(*red[x], *red[x + 1])) e += 1;
+        unexp[i] = e;
+    }
+    std::vector<uint8_t> hap_lasso(H), hap_norm(H);
+    for (int h = 0; h < H; ++h) {
+        hap_lasso[h] = t_allowed(type[h]) && (ignore || t_normalizing(type[h], norm_all) || t_is_reported(type[h]));
+        hap_norm[h] = ignore || t_normalizing(type[h], norm_all);
+    }
+    const int R = (int)p->n_reads;
+    const uint32_t n_rows = p->read_w_off ? p->read_w_off[R] : 0;
+    std::vector<int32_t> rwo(R + 1, 0);
+    for (int r = 0; r <= R; ++r) rwo[r] = p->read_w_off ? (int32_t)p->read_w_off[r] : 0;
+    std::vector<uint32_t> ed32((size_t)n_rows * H);
+    std::vector<uint64_t> optimum(R, 0), worst(R, 0);
+    for (int r = 0; r < R; ++r) for (int row = rwo[r]; row < rwo[r + 1]; ++row) {
+        uint64_t mn = UINT64_MAX, mx = 0;
+        for (int h = 0; h < H; ++h) {
+            const uint64_t v = p->w_ed[(size_t)row * H + h];
+            if (v > 0x7FFFFFFFull) return sp_fail(ctx, SP_ERR_INVALID_ARG, "chain pair: edit distance does not fit 31 bits");
+            ed32[(size_t)row * H + h] = (uint32_t)v; mn = std::min(mn, v); mx = std::max(mx, v);
+        }
+        optimum[r] += mn; worst[r] += mx;
+    }
+    // ln n! (statrs ln_factorial: cached products up to 170!, ln_gamma beyond) and ln(c / total)
+    double ov_bound = 0.0;                                   // sum over rows of the largest overlap: upper bound of every rounded weight sum
+    for (uint32_t row = 0; row < n_rows; ++row) { double m = 0.0; for (int h = 0; h < H; ++h) m = std::max(m, p->w_ov[(size_t)row * H + h]); ov_bound += m; }
+    const int lf_n = (int)std::ceil(ov_bound) + H + 2;
+    std::vector<double> ln_fact(lf_n);
+    { double f = 1.0; for (int n = 0; n < lf_n; ++n) { if (n >= 2 && n <= 170) f *= (double)n; ln_fact[n] = n <= 170 ? std::log(f) : std::lgamma((double)n + 1.0); } }
+    const int max_cnt = 6, max_total = 6 * std::max(1, H);
+    std::vector<double> ln_p((size_t)(max_cnt + 1) * (max_total + 1), 0.0);
+    for (int cc = 1; cc <= max_cnt; ++cc) for (int t = cc; t <= max_total; ++t) ln_p[(size_t)cc * (max_total + 1) + t] = std::log((double)cc / (double)t);
+
+    const uint64_t n_pairs = (uint64_t)P * ((uint64_t)P + 1) / 2;
+    const uint64_t blocks = (n_pairs + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return sp_fail(ctx, SP_ERR_TOO_LONG, "chain pair: too many chain pairs for one launch");
+    PairConsts pc{H, P, maxlen, R, ignore ? 1 : 0, norm_all ? 1 : 0, infer ? 1 : 0, p->lasso_penalty, p->ln_ed_penalty, p->unexpected_chain_penalty,
+                  p->inferred_edge_penalty, n_pairs};
+    std::vector<double> ovv(p->w_ov, p->w_ov + (size_t)n_rows * H);
+    uint8_t* d_chains = k5_upload(ctx, "k5_chains", chains); int32_t* d_clen = k5_upload(ctx, "k5_clen", clen);
+    uint32_t* d_unexp = k5_upload(ctx, "k5_unexp", unexp); uint32_t* d_ninf = k5_upload(ctx, "k5_ninf", ninf);
+    uint8_t* d_del = k5_upload(ctx, "k5_del", has_del); uint8_t* d_lasso = k5_upload(ctx, "k5_lasso", hap_lasso); uint8_t* d_norm = k5_upload(ctx, "k5_norm", hap_norm);
+    int32_t* d_rwo = k5_upload(ctx, "k5_rwo", rwo); uint32_t* d_ed = k5_upload(ctx, "k5_ed", ed32); double* d_ov = k5_upload(ctx, "k5_ov", ovv);
+    uint64_t* d_opt = k5_upload(ctx, "k5_opt", optimum); uint64_t* d_worst = k5_upload(ctx, "k5_worst", worst);
+    double* d_lf = k5_upload(ctx, "k5_lf", ln_fact); double* d_lp = k5_upload(ctx, "k5_lp", ln_p);
+    unsigned long long* d_gb = (unsigned long long*)sp_pool(ctx, "k5_gb", 16);
+    double* d_bs = (double*)sp_pool(ctx, "k5_bs", blocks * 8); unsigned long long* d_bp = (unsigned long long*)sp_pool(ctx, "k5_bp", blocks * 8);
+    double* d_bc = (double*)sp_pool(ctx, "k5_bc", blocks * 40); unsigned long long* d_be = (unsigned long long*)sp_pool(ctx, "k5_be", blocks * 8);
+    if (!d_chains || !d_clen || !d_unexp || !d_ninf || !d_del || !d_lasso || !d_norm || !d_rwo || !d_ed || !d_ov || !d_opt || !d_worst || !d_lf || !d_lp ||
+        !d_gb || !d_bs || !d_bp || !d_bc || !d_be) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "chain pair buffers");
+    const unsigned long long init[2] = {0x7FF0000000000000ull /* +inf */, 0ull};
+    (void)hipMemcpyAsync(d_gb, init, 16, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemsetAsync(d_bp, 0xFF, blocks * 8, ctx->stream);
+    {
+        ProfScope ps(ctx, "k5_pairs", n_pairs);
+        hipLaunchKernelGGL(k5_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pc, d_chains, d_clen, d_unexp, d_ninf, d_del, d_lasso, d_norm,
+                           d_rwo, d_ed, d_ov, d_opt, d_worst, d_lf, lf_n, d_lp, max_total + 1, d_gb, d_bs, d_bp, d_bc, d_be, d_gb + 1);
+        if (hipGetLastError() != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "k5 launch failed");
+    }
+    std::vector<double> bs(blocks), bc(blocks * 5); std::vector<unsigned long long> bp(blocks), be(blocks);
+    unsigned long long gb[2];
+    (void)hipMemcpyAsync(bs.data(), d_bs, blocks * 8, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(bp.data(), d_bp, blocks * 8, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(bc.data(), d_bc, blocks * 40, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(be.data(), d_be, blocks * 8, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(gb, d_gb, 16, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("chain pair: ") + hipGetErrorString(e));
+    res->n_pairs_scored = gb[1];
+    int64_t wb = -1;
+    for (uint64_t b = 0; b < blocks; ++b) {
+        if (bp[b] == 0xFFFFFFFFFFFFFFFFull) continue;
+        if (wb < 0 || bs[b] < bs[wb] || (bs[b] == bs[wb] && bp[b] < bp[wb])) wb = (int64_t)b;
+    }
+    if (wb < 0) return SP_ERR_NO_SCORE_PAIRS;
+    // pair id -> (i, j)
+    uint64_t pid = bp[wb]; int wi = 0;
+    while (wi + 1 < P && (uint64_t)(wi + 1) * P - (uint64_t)(wi + 1) * wi / 2 <= pid) ++wi;
+    const int wj = (int)(pid - ((uint64_t)wi * P - (uint64_t)wi * (wi - 1) / 2)) + wi;
+    res->index1 = wi; res->index2 = wj;
+    res->score = bs[wb]; res->ln_ed_penalty = bc[wb * 5]; res->mn_llh_penalty = bc[wb * 5 + 1]; res->allele_expected_penalty = bc[wb * 5 + 2];
+    res->unexpected_chain_penalty = bc[wb * 5 + 3]; res->inferred_chain_penalty = bc[wb * 5 + 4]; res->edit_distance = be[wb];
+    const std::vector<int>* a = &possible[wi]; const std::vector<int>* b = &possible[wj];
+    if (*b < *a) std::swap(a, b);                              // best_chain_pair.sort() (chaining.rs:568-573)
+    res->n1 = (int32_t)a->size(); res->n2 = (int32_t)b->size();
+    for (size_t x = 0; x < a->size(); ++x) res->chain1[x] = (*a)[x];
+    for (size_t x = 0; x < b->size(); ++x) res->chain2[x] = (*b)[x];
+    return SP_OK;
+}

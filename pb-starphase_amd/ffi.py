@@ -51,6 +51,29 @@ class sp_hla_realign(C.Structure):
                 ("dna_offset", C.c_int32), ("hpc_offset", C.c_int32)]
 
 
+SP_MAX_CHAIN = 64
+
+
+class sp_chain_problem(C.Structure):
+    _fields_ = [("n_haps", C.c_uint32), ("hap_type", C.c_void_p), ("hap_subtype", C.POINTER(C.c_char_p)),
+                ("n_translate", C.c_uint32), ("translate_key", C.POINTER(C.c_char_p)), ("translate_val", C.POINTER(C.c_char_p)),
+                ("n_connections", C.c_uint32), ("connection_a", C.POINTER(C.c_char_p)), ("connection_b", C.POINTER(C.c_char_p)),
+                ("n_singletons", C.c_uint32), ("singletons", C.POINTER(C.c_char_p)),
+                ("n_reads", C.c_uint32), ("read_chain_off", C.c_void_p), ("chain_off", C.c_void_p), ("chain_items", C.c_void_p),
+                ("read_w_off", C.c_void_p), ("w_ed", C.c_void_p), ("w_ov", C.c_void_p),
+                ("infer_connections", C.c_int32), ("normalize_all_alleles", C.c_int32), ("ignore_chain_label_limits", C.c_int32),
+                ("lasso_penalty", C.c_double), ("ln_ed_penalty", C.c_double), ("unexpected_chain_penalty", C.c_double),
+                ("inferred_edge_penalty", C.c_double)]
+
+
+class sp_chain_result(C.Structure):
+    _fields_ = [("n_possible", C.c_int32), ("index1", C.c_int32), ("index2", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
+                ("chain1", C.c_int32 * SP_MAX_CHAIN), ("chain2", C.c_int32 * SP_MAX_CHAIN),
+                ("score", C.c_double), ("ln_ed_penalty", C.c_double), ("mn_llh_penalty", C.c_double),
+                ("allele_expected_penalty", C.c_double), ("unexpected_chain_penalty", C.c_double), ("inferred_chain_penalty", C.c_double),
+                ("edit_distance", C.c_uint64), ("n_pairs_scored", C.c_uint64)]
+
+
 class sp_hla_best(C.Structure):
     _fields_ = [("best_allele", C.c_int32), ("n_scored", C.c_int32)]
 
@@ -94,6 +117,7 @@ def lib():
         "sp_hla_realign_reads": (i32, [vp, vp, vp, vp, vp]),
         "sp_hla_score_consensus": (i32, [vp, vp, u32, C.c_char_p, u32, C.c_char_p, u32, i32, i32, C.POINTER(sp_hla_best), vp]),
         "sp_hla_type_consensus": (i32, [vp, vp, u32, C.c_char_p, u32, i32, i32, C.POINTER(sp_hla_best), vp, C.c_char_p, u32, C.POINTER(u32)]),
+        "sp_cyp_best_chain_pair": (i32, [vp, C.POINTER(sp_chain_problem), C.POINTER(sp_chain_result)]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -170,6 +194,41 @@ class Context:
             ev = np.zeros((n, stride), np.uint32)
         self.check(lib().sp_align_batch(self._h, A._h, B._h, _ptr(pairs), n, _ptr(out), _ptr(ev), stride))
         return (out, ev) if events else out
+
+    def cyp_best_chain_pair(self, hap_type, hap_subtype, translate, connections, singletons, read_chain_off, chain_off, chain_items,
+                            read_w_off, w_ed, w_ov, infer, normalize_all, ignore_limits, penalties):
+        """sp_cyp_best_chain_pair; returns (status, sp_chain_result).  Expected failures (16/17/18) are returned, not raised."""
+        def strs(items):
+            arr = (C.c_char_p * max(1, len(items)))()
+            for i, s in enumerate(items):
+                arr[i] = s.encode() if s is not None else None
+            return arr
+        p = sp_chain_problem()
+        ht = np.ascontiguousarray(hap_type, np.int32)
+        st = strs(list(hap_subtype))
+        tk, tv = strs([a for a, _ in translate]), strs([b for _, b in translate])
+        ca, cb = strs([a for a, _ in connections]), strs([b for _, b in connections])
+        sg = strs(list(singletons))
+        rco = np.ascontiguousarray(read_chain_off, np.uint32)
+        co = np.ascontiguousarray(chain_off, np.uint32)
+        ci = np.ascontiguousarray(chain_items, np.uint32)
+        rwo = np.ascontiguousarray(read_w_off, np.uint32)
+        ed = np.ascontiguousarray(w_ed, np.uint64)
+        ov = np.ascontiguousarray(w_ov, np.float64)
+        p.n_haps, p.hap_type, p.hap_subtype = len(ht), ht.ctypes.data, st
+        p.n_translate, p.translate_key, p.translate_val = len(translate), tk, tv
+        p.n_connections, p.connection_a, p.connection_b = len(connections), ca, cb
+        p.n_singletons, p.singletons = len(singletons), sg
+        p.n_reads = len(rco) - 1
+        p.read_chain_off, p.chain_off, p.chain_items = rco.ctypes.data, co.ctypes.data, ci.ctypes.data
+        p.read_w_off, p.w_ed, p.w_ov = rwo.ctypes.data, ed.ctypes.data, ov.ctypes.data
+        p.infer_connections, p.normalize_all_alleles, p.ignore_chain_label_limits = int(infer), int(normalize_all), int(ignore_limits)
+        p.lasso_penalty, p.ln_ed_penalty, p.unexpected_chain_penalty, p.inferred_edge_penalty = penalties
+        res = sp_chain_result()
+        rc = lib().sp_cyp_best_chain_pair(self._h, C.byref(p), C.byref(res))
+        if rc not in (0, 16, 17, 18):
+            self.check(rc)
+        return rc, res
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))

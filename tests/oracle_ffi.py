@@ -199,3 +199,136 @@ def load():
             subprocess.check_call(["make", "-s", "-C", ODIR])
         _cached = Oracle(C.CDLL(so))
     return _cached
+
+
+# ------------------------------------------------------------------ CYP2D6 chain search (oracle/cyp.c)
+REGION_TYPES = {"UNKNOWN": 0, "REP6": 1, "CYP2D6": 2, "link_region": 3, "REP7": 4, "spacer": 5, "CYP2D7": 6,
+                "CYP2D6*5": 7, "Hybrid": 8, "FalseAllele": 9}
+OSP_MAX_CHAIN = 64
+
+
+class CypConfig(C.Structure):
+    _fields_ = [("n_translate", C.c_int32), ("tr_key", C.POINTER(C.c_char_p)), ("tr_val", C.POINTER(C.c_char_p)),
+                ("n_conn", C.c_int32), ("conn_a", C.POINTER(C.c_char_p)), ("conn_b", C.POINTER(C.c_char_p)),
+                ("n_single", C.c_int32), ("singles", C.POINTER(C.c_char_p))]
+
+
+class ChainProblem(C.Structure):
+    _fields_ = [("n_haps", C.c_int32), ("type", C.c_void_p), ("subtype", C.POINTER(C.c_char_p)), ("cfg", CypConfig),
+                ("n_reads", C.c_int32), ("read_chain_off", C.c_void_p), ("chain_off", C.c_void_p), ("chain_items", C.c_void_p),
+                ("read_w_off", C.c_void_p), ("w_ed", C.c_void_p), ("w_ov", C.c_void_p),
+                ("infer_connections", C.c_int32), ("normalize_all_alleles", C.c_int32), ("ignore_chain_label_limits", C.c_int32),
+                ("lasso", C.c_double), ("ln_ed", C.c_double), ("unexpected", C.c_double), ("inferred", C.c_double)]
+
+
+class ChainResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_possible", C.c_int32), ("index1", C.c_int32), ("index2", C.c_int32),
+                ("n1", C.c_int32), ("n2", C.c_int32), ("chain1", C.c_int32 * OSP_MAX_CHAIN), ("chain2", C.c_int32 * OSP_MAX_CHAIN),
+                ("score", C.c_double), ("ln_ed_penalty", C.c_double), ("mn_llh_penalty", C.c_double),
+                ("allele_expected_penalty", C.c_double), ("unexpected_chain_penalty", C.c_double), ("inferred_chain_penalty", C.c_double),
+                ("edit_distance", C.c_uint64), ("unmet_observations", C.c_uint64)]
+
+
+def default_cyp_config():
+    """cyp_translate / inferred_connections / unexpected_singletons of the bundled database (data fixture);
+    identical to Cyp2d6Config::default() (src/cyp2d6/definitions.rs:242-301)."""
+    import gzip, json
+    d = json.load(gzip.open(os.path.join(ROOT, "tests", "golden", "cyp2d6_db_v0.14.1.json.gz")))["cyp2d6_config"]
+    return {"translate": sorted(d["cyp_translate"].items()), "connections": sorted(tuple(x) for x in d["inferred_connections"]),
+            "singletons": sorted(d["unexpected_singletons"])}
+
+
+def _strs(items):
+    arr = (C.c_char_p * max(1, len(items)))()
+    for i, s in enumerate(items):
+        arr[i] = s.encode() if s is not None else None
+    return arr
+
+
+class ChainInputs:
+    """flattened find_best_chain_pair inputs shared by the oracle and the product binding"""
+
+    def __init__(self, hap_labels, obs_chains, chain_scores, infer, normalize_all, penalties, ignore_limits, cfg=None):
+        cfg = cfg or default_cyp_config()
+        self.cfg = cfg
+        self.H = len(hap_labels)
+        self.types = np.array([REGION_TYPES[t] if isinstance(t, str) else t for t, _ in hap_labels], np.int32)
+        self.subtypes = [s for _, s in hap_labels]
+        names = sorted(set(obs_chains) | set(chain_scores))          # BTreeMap order; the reference iterates the two maps separately
+        self.chain_names = sorted(obs_chains)
+        self.score_names = sorted(chain_scores)
+        rco, co, items = [0], [0], []
+        for n in self.chain_names:
+            for ch in obs_chains[n]:
+                items += list(ch)
+                co.append(len(items))
+            rco.append(len(co) - 1)
+        self.read_chain_off = np.array(rco, np.int32)
+        self.chain_off = np.array(co, np.int32)
+        self.chain_items = np.array(items if items else [0], np.int32)
+        rwo, ed, ov = [0], [], []
+        for n in self.score_names:
+            for row in chain_scores[n]:
+                assert len(row) == self.H
+                ed.append([r[0] for r in row])
+                ov.append([r[1] for r in row])
+            rwo.append(len(ed))
+        self.read_w_off = np.array(rwo, np.int32)
+        self.w_ed = np.array(ed if ed else [[0] * max(1, self.H)], np.uint64)
+        self.w_ov = np.array(ov if ov else [[0.0] * max(1, self.H)], np.float64)
+        self.infer, self.normalize_all, self.ignore = int(infer), int(normalize_all), int(ignore_limits)
+        self.penalties = penalties          # (lasso, ln_ed, unexpected, inferred)
+        assert len(self.chain_names) == len(self.score_names) or not self.chain_names or not self.score_names
+
+
+DEFAULT_PENALTIES = (4.0, 2.0, 10.0, 2.0)
+
+
+def _cyp_cfg_struct(cfg, keep):
+    c = CypConfig()
+    k, v = _strs([a for a, _ in cfg["translate"]]), _strs([b for _, b in cfg["translate"]])
+    ca, cb = _strs([a for a, _ in cfg["connections"]]), _strs([b for _, b in cfg["connections"]])
+    sg = _strs(cfg["singletons"])
+    keep += [k, v, ca, cb, sg]
+    c.n_translate, c.tr_key, c.tr_val = len(cfg["translate"]), k, v
+    c.n_conn, c.conn_a, c.conn_b = len(cfg["connections"]), ca, cb
+    c.n_single, c.singles = len(cfg["singletons"]), sg
+    return c
+
+
+def oracle_chain_pair(oracle, inp):
+    L = oracle.L
+    keep = []
+    p = ChainProblem()
+    p.n_haps = inp.H
+    p.type = inp.types.ctypes.data
+    st = _strs(inp.subtypes)
+    keep.append(st)
+    p.subtype = st
+    p.cfg = _cyp_cfg_struct(inp.cfg, keep)
+    p.n_reads = max(len(inp.chain_names), len(inp.score_names))
+    # the two maps normally share their keys; tests with an empty side get empty ranges
+    rco = inp.read_chain_off if len(inp.read_chain_off) == p.n_reads + 1 else np.zeros(p.n_reads + 1, np.int32)
+    rwo = inp.read_w_off if len(inp.read_w_off) == p.n_reads + 1 else np.zeros(p.n_reads + 1, np.int32)
+    keep += [rco, rwo]
+    p.read_chain_off, p.chain_off, p.chain_items = rco.ctypes.data, inp.chain_off.ctypes.data, inp.chain_items.ctypes.data
+    p.read_w_off, p.w_ed, p.w_ov = rwo.ctypes.data, inp.w_ed.ctypes.data, inp.w_ov.ctypes.data
+    p.infer_connections, p.normalize_all_alleles, p.ignore_chain_label_limits = inp.infer, inp.normalize_all, inp.ignore
+    p.lasso, p.ln_ed, p.unexpected, p.inferred = inp.penalties
+    res = ChainResult()
+    L.osp_cyp_find_best_chain_pair.restype = C.c_int32
+    L.osp_cyp_find_best_chain_pair(C.byref(p), C.byref(res))
+    return res
+
+
+def chain_hap_string(oracle, chain, hap_labels, detail, cfg=None):
+    cfg = cfg or default_cyp_config()
+    keep = []
+    c = _cyp_cfg_struct(cfg, keep)
+    types = np.array([REGION_TYPES[t] if isinstance(t, str) else t for t, _ in hap_labels], np.int32)
+    st = _strs([s for _, s in hap_labels])
+    ch = np.array(chain, np.int32)
+    out = C.create_string_buffer(1024)
+    oracle.L.osp_cyp_convert_chain_to_hap(ch.ctypes.data_as(C.c_void_p), len(ch), types.ctypes.data_as(C.c_void_p), st, int(detail),
+                                          C.byref(c), out, 1024)
+    return out.value.decode()
