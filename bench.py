@@ -103,7 +103,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = ge.load_package()
-    from pb_starphase_amd import synth
+    from pb_starphase_amd import synth, shard
     ctx = pkg.Context(local_rank)
     fx = synth.HlaFixture()
     db = fx.make_db(pkg, ctx)
@@ -119,9 +119,12 @@ def main():
             b, _n, _s = db.score_consensus(g, cons_dna, cons_cdna, stats=False)
             calls.append(b)
         if world > 1:
-            mine = torch.tensor(calls, dtype=torch.int32, device="cuda")
-            allc = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allc, mine)                      # RCCL: the only exchange step (per-gene results)
+            # RCCL: the only exchange step of the path -- one gather of the per-(sample, gene) call records
+            rec = np.zeros(len(fx.genes), shard.CALL_DTYPE)
+            for g in range(len(fx.genes)):
+                pair = [b for (gg, _c, _d, _a), b in zip(wl.consensus, calls) if gg == g]
+                rec[g] = (rank, g, pair[0], pair[1] if len(pair) > 1 else pair[0])
+            shard.gather_calls(rec, device="cuda")
         return out, calls
 
     def barrier():

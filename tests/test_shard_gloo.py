@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: two gloo ranks shard a synthetic cohort, 'call' their samples and gather the records."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["SP_ROOT"])
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from pb_starphase_amd import shard
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+n_samples, genes = 7, 3
+cost = [(s * 37) % 11 + 1 for s in range(n_samples)]
+mine = shard.partition(n_samples, world, rank, cost)
+calls = np.zeros(len(mine) * genes, shard.CALL_DTYPE)
+for i, s in enumerate(mine):
+    for g in range(genes):
+        calls[i * genes + g] = (s, g, 100 * s + g, 100 * s + g + 1)      # stand-in for the per-gene GPU calls
+table = shard.gather_calls(calls)
+print(json.dumps({"rank": rank, "mine": mine, "table": table.tolist()}))
+dist.destroy_process_group()
+'''
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_partition_properties():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from pb_starphase_amd import shard
+    for n in (0, 1, 5, 8, 256):
+        for world in (1, 2, 4, 8):
+            parts = [shard.partition(n, world, r) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    cost = [5, 1, 1, 1, 1, 1, 4, 4]
+    parts = [shard.partition(8, 2, r, cost) for r in range(2)]
+    assert sorted(sum(parts, [])) == list(range(8))
+    loads = [sum(cost[u] for u in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 1
+    assert len(shard.gather_calls(np.zeros(0, shard.CALL_DTYPE))) == 0
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    import json
+    port = free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SP_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    owned = sorted(outs[0]["mine"] + outs[1]["mine"])
+    assert owned == list(range(7)) and not set(outs[0]["mine"]) & set(outs[1]["mine"])
+    expected = [[s, g, 100 * s + g, 100 * s + g + 1] for s in range(7) for g in range(3)]
+    for o in outs:
+        assert [list(r) for r in o["table"]] == expected            # every rank holds the full, sorted table
