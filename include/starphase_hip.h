@@ -99,6 +99,13 @@ int32_t sp_anchor_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                         const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs,
                         int32_t* diag_out, int32_t* votes_out);
 
+/* Same, up to topk (1..8) placements per pair: peaks of the vote histogram taken best first, every bin within +-128
+ * diagonals of a chosen peak cleared before the next one is taken (multi-copy targets, e.g. CYP2D6 and CYP2D7 in one read).
+ * diag_out / votes_out hold n_pairs * topk entries; unused slots have votes 0. */
+int32_t sp_anchor_batch_topk(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                             const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs, int32_t topk,
+                             int32_t* diag_out, int32_t* votes_out);
+
 /* Align every pair.  Replaces every `aligner.map(...)` on the hot path: src/hla/realigner.rs:116,231,290;
  * src/hla/caller.rs:1277,1436; src/cyp2d6/haplotyper.rs:198,395; src/cyp2d6/chaining.rs:58.
  * events (optional, may be NULL): n_pairs * events_stride words, the first nm of each row are valid. */
@@ -236,6 +243,32 @@ typedef struct {
 } sp_chain_result;
 
 int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* problem, sp_chain_result* result);
+
+/* ------------------------------------------------------------------ K3: CYP2D6 template search in reads
+ * Replaces Cyp2d6Extractor::find_base_type_in_sequence (src/cyp2d6/haplotyper.rs:142-315) for a batch of reads:
+ * every template (D6, D7, *5 signature, hybrids, REP6/REP7, spacer, link_region -- given in the reference's key order,
+ * i.e. sorted by full_allele(), :175-183) is placed on every read (up to 4 placements), hits with more than 5 % edits
+ * are dropped (un-mapped template bases count only for *5 / REP6 / REP7, :185-191,228-232), hits are sorted by
+ * (start, end), overlapping hits (> 0.9 of the shorter) collapse to the better one with *5 priority (:260-296), and hits
+ * whose penalised fraction exceeds max_missing_frac are dropped (:303-306).
+ * hits: grouped by read, in output order; returns the total in n_hits (may exceed hits_cap: call again with more room). */
+typedef struct {
+    int32_t read, template_idx;
+    int32_t start, end;                 /* region on the read */
+    int32_t seq_len, nm, unmapped;      /* MappingStats of the template */
+    int32_t clip_start, clip_end;
+} sp_region_hit;
+
+int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
+                            double max_missing_frac, sp_region_hit* hits, uint64_t hits_cap, uint64_t* n_hits);
+
+/* ------------------------------------------------------------------ K4: consensus weights of read segments
+ * Replaces weight_sequence (src/cyp2d6/chaining.rs:28-103) for a batch of read segments: every allowed consensus
+ * (allowed[c] = label.is_allowed_label()) is placed on every segment; ed[s][c] = nm + un-mapped segment bases,
+ * ov[s][c] = 1 - clipped consensus fraction, defaults (segment length, 0.0); kept[s] = 0 when the reference returns the
+ * empty vector (best penalised fraction > 0.05). */
+int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensus, const uint8_t* allowed, const sp_seqset* segments,
+                               uint64_t* ed, double* ov, uint8_t* kept);
 
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */

@@ -49,8 +49,10 @@ static int list_kmers(const uint8_t* s, int n, kmer_t* out) {
     return cnt;
 }
 
-int osp_anchor(const uint8_t* A, int m, const uint8_t* B, int n, int* diag) {
-    *diag = 0;
+/* top-K anchors: repeatedly take the diagonal with most votes (ties: smallest d), then suppress every bin within
+ * +-OSP_PEAK_SUPPRESS of it.  Returns the number of peaks with >= 1 vote (at most k). */
+int osp_anchor_topk(const uint8_t* A, int m, const uint8_t* B, int n, int k, int* diags, int* votes_out) {
+    for (int i = 0; i < k; ++i) { diags[i] = 0; votes_out[i] = 0; }
     if (m < OSP_KMER || n < OSP_KMER) return 0;
     kmer_t* ta = (kmer_t*)malloc(sizeof(kmer_t) * (size_t)m);
     kmer_t* tb = (kmer_t*)malloc(sizeof(kmer_t) * (size_t)n);
@@ -69,11 +71,25 @@ int osp_anchor(const uint8_t* A, int m, const uint8_t* B, int n, int* diag) {
         if (occ == 0 || occ > OSP_MAXOCC) continue;
         for (int y = lo; y < e; ++y) votes[tb[x].pos - ta[y].pos + m]++;
     }
-    int best = 0, bestd = 0;
-    for (int b = 0; b < nbins; ++b) if (votes[b] > best) { best = votes[b]; bestd = b - m; }  /* ties: smallest d */
+    int found = 0;
+    for (int round = 0; round < k; ++round) {
+        int best = 0, bestb = -1;
+        for (int b = 0; b < nbins; ++b) if (votes[b] > best) { best = votes[b]; bestb = b; }  /* ties: smallest d */
+        if (bestb < 0) break;
+        diags[found] = bestb - m; votes_out[found] = best; ++found;
+        int lo = bestb - OSP_PEAK_SUPPRESS, hi = bestb + OSP_PEAK_SUPPRESS;
+        if (lo < 0) lo = 0;
+        if (hi > nbins - 1) hi = nbins - 1;
+        for (int b = lo; b <= hi; ++b) votes[b] = 0;
+    }
     free(ta); free(tb); free(votes);
-    *diag = bestd;
-    return best;
+    return found;
+}
+
+int osp_anchor(const uint8_t* A, int m, const uint8_t* B, int n, int* diag) {
+    int v = 0;
+    osp_anchor_topk(A, m, B, n, 1, diag, &v);
+    return v;
 }
 
 /* ---------------------------------------------------------------- wavefront alignment */

@@ -374,3 +374,95 @@ int osp_cyp_find_best_chain_pair(const osp_chain_problem* p, osp_chain_result* r
     free(possible); free(downstream); free(inferred);
     return res->status;
 }
+
+/* ---------------------------------------------------------------- weight_sequence (src/cyp2d6/chaining.rs:28-103)
+ * The read segment is the minimap2 target, every allowed consensus a query.  On the alignment contract each consensus
+ * yields at most one mapping (anchor with >= OSP_CYP_MIN_VOTES votes, then one banded cell).
+ * out_ed/out_ov: n_cons entries (defaults (seq_len, 0.0)); returns 1 when the weights are kept, 0 when the reference
+ * returns the empty vec (best penalised fraction > 0.05). */
+int osp_cyp_weight_sequence(const uint8_t* seq, int seq_len, int n_cons, const uint8_t* const* cons, const int32_t* cons_len,
+                            const uint8_t* allowed, uint64_t* out_ed, double* out_ov) {
+    const double maximum_allowed_ed = 0.05;
+    double min_ed_frac = 1.0;
+    for (int c = 0; c < n_cons; ++c) { out_ed[c] = (uint64_t)seq_len; out_ov[c] = 0.0; }
+    for (int c = 0; c < n_cons; ++c) {
+        if (!allowed[c]) continue;                                      /* Unknown / FalseAllele labels are skipped (:52-55) */
+        int diag = 0, votes = osp_anchor(cons[c], cons_len[c], seq, seq_len, &diag);      /* seq_pos - cons_pos */
+        if (votes < OSP_CYP_MIN_VOTES) continue;
+        osp_aln al;
+        if (!osp_wfa(cons[c], cons_len[c], seq, seq_len, diag, 255, &al, NULL, NULL)) continue;
+        uint64_t nm = (uint64_t)al.nm, unmapped = (uint64_t)(seq_len - (al.b_end - al.b_start));
+        uint64_t clipped_start = (uint64_t)al.a_start, clipped_end = (uint64_t)(cons_len[c] - al.a_end);
+        uint64_t match_score = nm + unmapped;
+        double overlap_score = 1.0 - (double)(clipped_start + clipped_end) / (double)cons_len[c];
+        if (match_score < out_ed[c] || (match_score == out_ed[c] && overlap_score > out_ov[c])) {
+            out_ed[c] = match_score; out_ov[c] = overlap_score;
+            double sc = osp_custom_score((uint64_t)seq_len, nm, unmapped, 1);
+            if (sc < min_ed_frac) min_ed_frac = sc;
+        }
+    }
+    return min_ed_frac <= maximum_allowed_ed;
+}
+
+/* ---------------------------------------------------------------- find_base_type_in_sequence (src/cyp2d6/haplotyper.rs:142-315)
+ * templates in key order (sorted by full_allele, :175-183); up to OSP_CYP_TOPK placements per template. */
+static double hit_score(const osp_region_hit* h, int penalize) {
+    return osp_custom_score((uint64_t)h->seq_len, (uint64_t)h->nm, (uint64_t)h->unmapped, penalize);
+}
+static int is_penalized_type(int t) { return t == OSP_DELETION || t == OSP_REP6 || t == OSP_REP7; }              /* :185-191 */
+static double range_overlap_score(int s1, int e1, int s2, int e2) {                                                /* :877-892 */
+    int min_end = e1 < e2 ? e1 : e2, max_start = s1 > s2 ? s1 : s2;
+    if (max_start >= min_end) return 0.0;
+    double l1 = (double)(e1 - s1), l2 = (double)(e2 - s2), shared = (double)(min_end - max_start);
+    return shared / (l1 < l2 ? l1 : l2);
+}
+
+int osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, const uint8_t* const* tmpl, const int32_t* tmpl_len,
+                           const int32_t* tmpl_type, double max_missing_frac, osp_region_hit* out, int cap) {
+    if (seq_len == 0) return 0;
+    const double max_ed_frac = 0.05;
+    int n_un = 0, un_cap = n_templates * OSP_CYP_TOPK + 1;
+    osp_region_hit* un = (osp_region_hit*)malloc(sizeof(osp_region_hit) * (size_t)un_cap);
+    for (int t = 0; t < n_templates; ++t) {
+        int diags[OSP_CYP_TOPK], votes[OSP_CYP_TOPK];
+        int np = osp_anchor_topk(tmpl[t], tmpl_len[t], seq, seq_len, OSP_CYP_TOPK, diags, votes);      /* seq_pos - template_pos */
+        for (int k = 0; k < np; ++k) {
+            if (votes[k] < OSP_CYP_MIN_VOTES) continue;
+            osp_aln al;
+            if (!osp_wfa(tmpl[t], tmpl_len[t], seq, seq_len, diags[k], 255, &al, NULL, NULL)) continue;
+            osp_region_hit h;
+            h.template_idx = t; h.start = al.b_start; h.end = al.b_end;
+            h.seq_len = tmpl_len[t]; h.nm = al.nm; h.unmapped = tmpl_len[t] - (al.a_end - al.a_start);
+            h.clip_start = al.a_start; h.clip_end = tmpl_len[t] - al.a_end;
+            if (hit_score(&h, is_penalized_type(tmpl_type[t])) > max_ed_frac) continue;           /* :228-232 ; Forward only */
+            un[n_un++] = h;
+        }
+    }
+    /* stable sort by (start, end) (:252-255) */
+    for (int i = 1; i < n_un; ++i) {
+        osp_region_hit x = un[i]; int j = i - 1;
+        while (j >= 0 && (un[j].start > x.start || (un[j].start == x.start && un[j].end > x.end))) { un[j + 1] = un[j]; --j; }
+        un[j + 1] = x;
+    }
+    /* collapse overlapping hits (:260-296) */
+    int n_out = 0, have_cur = 0; osp_region_hit cur; memset(&cur, 0, sizeof(cur));
+    osp_region_hit* coll = (osp_region_hit*)malloc(sizeof(osp_region_hit) * (size_t)(n_un + 1));
+    int n_coll = 0;
+    for (int i = 0; i < n_un; ++i) {
+        if (!have_cur) { cur = un[i]; have_cur = 1; continue; }
+        if (range_overlap_score(un[i].start, un[i].end, cur.start, cur.end) > 0.9) {
+            int star5_pairing = is_penalized_type(tmpl_type[un[i].template_idx]) || is_penalized_type(tmpl_type[cur.template_idx]);
+            int penalized_scoring = star5_pairing ? 1 : 0;
+            int up = tmpl_type[un[i].template_idx] == OSP_DELETION ? 1 : 0, cp = tmpl_type[cur.template_idx] == OSP_DELETION ? 1 : 0;   /* :897-902 */
+            if ((hit_score(&un[i], penalized_scoring) < hit_score(&cur, penalized_scoring) && up >= cp) || up > cp) cur = un[i];
+        } else { coll[n_coll++] = cur; cur = un[i]; }
+    }
+    if (have_cur) coll[n_coll++] = cur;
+    for (int i = 0; i < n_coll; ++i) {
+        if (hit_score(&coll[i], 1) > max_missing_frac) continue;                                   /* :303-306 */
+        if (n_out < cap) out[n_out] = coll[i];
+        ++n_out;
+    }
+    free(un); free(coll);
+    return n_out;
+}

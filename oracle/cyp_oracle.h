@@ -53,6 +53,14 @@ void osp_cyp_convert_chain_to_hap(const int32_t* chain, int n, const int32_t* ty
                                   const osp_cyp_config* cfg, char* out, size_t cap);
 int  osp_cyp_find_best_chain_pair(const osp_chain_problem* p, osp_chain_result* res);
 
+#define OSP_CYP_TOPK      4          /* placements tried per (template, read) */
+#define OSP_CYP_MIN_VOTES 4          /* an anchor needs this many 16-mer votes */
+typedef struct { int32_t template_idx, start, end, seq_len, nm, unmapped, clip_start, clip_end; } osp_region_hit;   /* AlleleMapping */
+int  osp_cyp_weight_sequence(const uint8_t* seq, int seq_len, int n_cons, const uint8_t* const* cons, const int32_t* cons_len,
+                             const uint8_t* allowed, uint64_t* out_ed, double* out_ov);
+int  osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, const uint8_t* const* tmpl, const int32_t* tmpl_len,
+                            const int32_t* tmpl_type, double max_missing_frac, osp_region_hit* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

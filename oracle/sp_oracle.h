@@ -45,6 +45,7 @@ extern "C" {
 #define OSP_KMER      16          /* anchor k-mer length                                */
 #define OSP_MAXOCC    4           /* k-mers occurring more often in the indexed side are ignored */
 #define OSP_NEG       (-(1 << 28))
+#define OSP_PEAK_SUPPRESS 128      /* top-K anchors: bins within +-128 diagonals of a chosen peak are cleared   */
 
 typedef struct {
     int32_t ok;                   /* 1 = alignment found within max_ed                  */
@@ -70,6 +71,9 @@ int osp_wfa(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_
 
 /* k-mer vote anchor: A is the indexed side. Returns votes (0 = none); *diag = b_pos - a_pos. */
 int osp_anchor(const uint8_t* A, int m, const uint8_t* B, int n, int* diag);
+
+/* up to k anchors per pair (multi-copy targets such as the CYP2D6 / CYP2D7 paralogs inside one read) */
+int osp_anchor_topk(const uint8_t* A, int m, const uint8_t* B, int n, int k, int* diags, int* votes_out);
 
 /* events + alignment -> BAM-style cigar (len<<4|op; op 7 '=', 8 'X', 1 'I', 2 'D'); returns #ops */
 int osp_events_to_cigar(const osp_aln* aln, const uint32_t* events, int n_events, uint32_t* cigar, int cap);

@@ -156,6 +156,8 @@ int32_t sp_seqset_length(const sp_seqset* s, uint32_t idx, uint32_t* len) {
 
 } // extern "C"
 
+int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
+
 // sorted 16-mer table of every sequence of the set (device code order: base t of the k-mer in bits 2t..2t+1)
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
     if (s->has_index) return SP_OK;
@@ -198,31 +200,35 @@ int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
 
 extern "C" {
 
-int32_t sp_anchor_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
-                        const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs,
-                        int32_t* diag_out, int32_t* votes_out) {
+int32_t sp_anchor_batch_topk(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                             const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs, int32_t topk,
+                             int32_t* diag_out, int32_t* votes_out) {
     if (!ctx || !A || !B || (n_pairs && (!a_idx || !b_idx || !diag_out || !votes_out))) return SP_ERR_INVALID_ARG;
+    if (topk < 1 || topk > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: topk must be 1..8");
     if (n_pairs == 0) return SP_OK;
     hipSetDevice(ctx->device);
     for (uint64_t i = 0; i < n_pairs; ++i) if (a_idx[i] >= A->n || b_idx[i] >= B->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: index out of range");
     int rc = sp_seqset_build_index(ctx, const_cast<sp_seqset*>(A));
     if (rc) return rc;
-    uint32_t *d_a = nullptr, *d_b = nullptr; int32_t *d_d = nullptr, *d_v = nullptr;
-    size_t nb = n_pairs * 4;
-    if (hipMalloc(&d_a, nb) != hipSuccess || hipMalloc(&d_b, nb) != hipSuccess || hipMalloc(&d_d, nb) != hipSuccess || hipMalloc(&d_v, nb) != hipSuccess) {
-        hipFree(d_a); hipFree(d_b); hipFree(d_d); hipFree(d_v);
-        return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "anchor buffers");
-    }
+    const size_t nb = n_pairs * 4, nbk = nb * (size_t)topk;
+    uint32_t* d_a = (uint32_t*)sp_pool(ctx, "anchor_a", nb); uint32_t* d_b = (uint32_t*)sp_pool(ctx, "anchor_b", nb);
+    int32_t* d_d = (int32_t*)sp_pool(ctx, "anchor_d", nbk); int32_t* d_v = (int32_t*)sp_pool(ctx, "anchor_v", nbk);
+    if (!d_a || !d_b || !d_d || !d_v) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "anchor buffers");
     hipMemcpyAsync(d_a, a_idx, nb, hipMemcpyHostToDevice, ctx->stream);
     hipMemcpyAsync(d_b, b_idx, nb, hipMemcpyHostToDevice, ctx->stream);
-    rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v);
+    rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v, topk);
     if (rc == SP_OK) {
-        hipMemcpyAsync(diag_out, d_d, nb, hipMemcpyDeviceToHost, ctx->stream);
-        hipMemcpyAsync(votes_out, d_v, nb, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(diag_out, d_d, nbk, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(votes_out, d_v, nbk, hipMemcpyDeviceToHost, ctx->stream);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "anchor: stream sync failed");
     }
-    hipFree(d_a); hipFree(d_b); hipFree(d_d); hipFree(d_v);
     return rc;
+}
+
+int32_t sp_anchor_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
+                        const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs,
+                        int32_t* diag_out, int32_t* votes_out) {
+    return sp_anchor_batch_topk(ctx, A, B, a_idx, b_idx, n_pairs, 1, diag_out, votes_out);
 }
 
 int32_t sp_align_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,

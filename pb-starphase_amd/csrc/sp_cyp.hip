@@ -389,3 +389,133 @@ extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p
     for (size_t x = 0; x < b->size(); ++x) res->chain2[x] = (*b)[x];
     return SP_OK;
 }
+
+// =============================================================================================
+// K3 / K4: every (query, target) placement through the anchor + WFA-cell kernels, reference logic on the host
+// =============================================================================================
+#define CYP_TOPK      4
+#define CYP_MIN_VOTES 4
+
+int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
+
+__global__ void cyp_build_cells_kernel(const uint32_t* __restrict__ a_idx, const uint32_t* __restrict__ b_idx,
+                                       const int32_t* __restrict__ diag, const int32_t* __restrict__ votes, uint64_t n_pairs, int topk,
+                                       int min_votes, CellDesc* __restrict__ cells) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs * (uint64_t)topk) return;
+    const uint64_t p = i / (uint64_t)topk;
+    CellDesc c; c.a = a_idx[p]; c.b = b_idx[p]; c.max_ed = SP_MAX_ED; c.b_lo = 0; c.b_hi = -1;
+    c.diag = votes[i] >= min_votes ? diag[i] : SP_NO_DIAG;       // anchor: b_pos - a_pos with A the indexed side = the cell's A
+    cells[i] = c;
+}
+
+// all |A| x |B| placements (A = indexed query side, B = target side), result[b][a][k]
+static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, const char* prof, std::vector<sp_aln>& out) {
+    const uint64_t nA = A->n, nB = B->n, n_pairs = nA * nB, n_cells = n_pairs * (uint64_t)topk;
+    out.assign(n_cells, sp_aln{});
+    if (n_pairs == 0) return SP_OK;
+    int rc = sp_seqset_build_index(ctx, const_cast<sp_seqset*>(A));
+    if (rc) return rc;
+    std::vector<uint32_t> ai(n_pairs), bi(n_pairs);
+    for (uint64_t b = 0; b < nB; ++b) for (uint64_t a = 0; a < nA; ++a) { ai[b * nA + a] = (uint32_t)a; bi[b * nA + a] = (uint32_t)b; }
+    uint32_t* d_a = (uint32_t*)sp_pool(ctx, "cyp_a", n_pairs * 4); uint32_t* d_b = (uint32_t*)sp_pool(ctx, "cyp_b", n_pairs * 4);
+    int32_t* d_d = (int32_t*)sp_pool(ctx, "cyp_d", n_cells * 4); int32_t* d_v = (int32_t*)sp_pool(ctx, "cyp_v", n_cells * 4);
+    CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "cyp_cells", n_cells * sizeof(CellDesc));
+    sp_aln* d_alns = (sp_aln*)sp_pool(ctx, "cyp_alns", n_cells * sizeof(sp_aln));
+    if (!d_a || !d_b || !d_d || !d_v || !d_cells || !d_alns) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "cyp placement buffers");
+    (void)hipMemcpyAsync(d_a, ai.data(), n_pairs * 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_b, bi.data(), n_pairs * 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v, topk);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cyp_build_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, d_d, d_v, n_pairs, topk, CYP_MIN_VOTES, d_cells);
+    rc = sp_launch_cells(ctx, A, B, d_cells, n_cells, d_alns, nullptr, 0, prof);
+    if (rc) return rc;
+    (void)hipMemcpyAsync(out.data(), d_alns, n_cells * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("cyp placements: ") + hipGetErrorString(e));
+    return SP_OK;
+}
+
+static inline double cyp_score(int seq_len, int nm, int unmapped, bool penalize) {        // MappingStats::custom_score (data_types/mapping.rs:60-84)
+    const int len = penalize ? seq_len : seq_len - unmapped;
+    double num = (double)(nm + (penalize ? unmapped : 0)); if (num < 0.1) num = 0.1;
+    return num / (double)len;
+}
+
+extern "C" int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensus, const uint8_t* allowed, const sp_seqset* segments,
+                                          uint64_t* ed, double* ov, uint8_t* kept) {
+    if (!ctx || !consensus || !segments || (consensus->n && !allowed) || (segments->n && (!ed || !ov || !kept))) return SP_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    std::vector<sp_aln> alns;
+    int rc = cyp_align_all(ctx, consensus, segments, 1, "k4_weight_cells", alns);
+    if (rc) return rc;
+    const uint32_t C = consensus->n;
+    for (uint32_t s = 0; s < segments->n; ++s) {
+        const int seq_len = segments->h_len[s];
+        double min_ed_frac = 1.0;
+        for (uint32_t c = 0; c < C; ++c) {
+            uint64_t& e = ed[(size_t)s * C + c]; double& o = ov[(size_t)s * C + c];
+            e = (uint64_t)seq_len; o = 0.0;                                  // "deleted" default (chaining.rs:40-41)
+            const sp_aln& al = alns[(size_t)s * C + c];
+            if (!allowed[c] || !al.ok) continue;
+            const int con_len = consensus->h_len[c];
+            const uint64_t nm = (uint64_t)al.nm, unmapped = (uint64_t)(seq_len - (al.b_end - al.b_start));
+            const uint64_t match_score = nm + unmapped;
+            const double overlap_score = 1.0 - (double)(al.a_start + (con_len - al.a_end)) / (double)con_len;
+            if (match_score < e || (match_score == e && overlap_score > o)) {
+                e = match_score; o = overlap_score;
+                const double sc = cyp_score(seq_len, (int)nm, (int)unmapped, true);
+                if (sc < min_ed_frac) min_ed_frac = sc;
+            }
+        }
+        kept[s] = min_ed_frac <= 0.05 ? 1 : 0;                                // maximum_allowed_ed (chaining.rs:45,96-102)
+    }
+    return SP_OK;
+}
+
+extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
+                                       double max_missing_frac, sp_region_hit* hits, uint64_t hits_cap, uint64_t* n_hits) {
+    if (!ctx || !templates || !reads || !n_hits || (templates->n && !template_type) || (hits_cap && !hits)) return SP_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    *n_hits = 0;
+    std::vector<sp_aln> alns;
+    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, "k3_region_cells", alns);
+    if (rc) return rc;
+    const uint32_t T = templates->n;
+    auto penalized_type = [](int t) { return t == SP_CYP_DELETION || t == SP_CYP_REP6 || t == SP_CYP_REP7; };   // haplotyper.rs:185-191
+    std::vector<sp_region_hit> un, coll;
+    for (uint32_t r = 0; r < reads->n; ++r) {
+        if (reads->h_len[r] == 0) continue;
+        un.clear(); coll.clear();
+        for (uint32_t t = 0; t < T; ++t) for (int k = 0; k < CYP_TOPK; ++k) {
+            const sp_aln& al = alns[((size_t)r * T + t) * CYP_TOPK + k];
+            if (!al.ok) continue;
+            const int tlen = templates->h_len[t];
+            sp_region_hit h{(int32_t)r, (int32_t)t, al.b_start, al.b_end, tlen, al.nm, tlen - (al.a_end - al.a_start), al.a_start, tlen - al.a_end};
+            if (cyp_score(h.seq_len, h.nm, h.unmapped, penalized_type(template_type[t])) > 0.05) continue;   // max_ed_frac, :228-232
+            un.push_back(h);
+        }
+        std::stable_sort(un.begin(), un.end(), [](const sp_region_hit& x, const sp_region_hit& y) {
+            return x.start != y.start ? x.start < y.start : x.end < y.end; });
+        bool have = false; sp_region_hit cur{};
+        for (const sp_region_hit& u : un) {
+            if (!have) { cur = u; have = true; continue; }
+            const int min_end = std::min(u.end, cur.end), max_start = std::max(u.start, cur.start);
+            double ovl = 0.0;                                                        // overlap_score (haplotyper.rs:877-892)
+            if (max_start < min_end) ovl = (double)(min_end - max_start) / std::min((double)(u.end - u.start), (double)(cur.end - cur.start));
+            if (ovl > 0.9) {
+                const bool pen = penalized_type(template_type[u.template_idx]) || penalized_type(template_type[cur.template_idx]);
+                const int up = template_type[u.template_idx] == SP_CYP_DELETION, cp = template_type[cur.template_idx] == SP_CYP_DELETION;
+                if ((cyp_score(u.seq_len, u.nm, u.unmapped, pen) < cyp_score(cur.seq_len, cur.nm, cur.unmapped, pen) && up >= cp) || up > cp) cur = u;
+            } else { coll.push_back(cur); cur = u; }
+        }
+        if (have) coll.push_back(cur);
+        for (const sp_region_hit& h : coll) {
+            if (cyp_score(h.seq_len, h.nm, h.unmapped, true) > max_missing_frac) continue;                     // :303-306
+            if (*n_hits < hits_cap) hits[*n_hits] = h;
+            ++*n_hits;
+        }
+    }
+    return SP_OK;
+}

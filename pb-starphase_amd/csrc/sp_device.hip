@@ -13,7 +13,7 @@
 __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexView KA, SeqSetView B,
                                                         const uint32_t* __restrict__ a_idx, const uint32_t* __restrict__ b_idx,
                                                         uint64_t n_pairs, int32_t* __restrict__ diag_out, int32_t* __restrict__ votes_out,
-                                                        int bins_cap) {
+                                                        int bins_cap, int topk) {
     extern __shared__ uint32_t lds[];                 // packed u16 vote bins, 2 per dword
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x;
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
         const int m = A.len[a], n = B.len[b];
         const int nbins = m + n + 1;
         if (m < SP_KMER || n < SP_KMER || nbins > bins_cap) {
-            if (tid == 0) { diag_out[p] = 0; votes_out[p] = 0; }
+            if (tid == 0) for (int k2 = 0; k2 < topk; ++k2) { diag_out[p * topk + k2] = 0; votes_out[p * topk + k2] = 0; }
             continue;
         }
         const int nb32 = (nbins + 1) >> 1;
@@ -48,25 +48,38 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
             }
         }
         __syncthreads();
-        // argmax votes, ties -> smallest diagonal
-        unsigned long long best = 0;
-        for (int bin = tid; bin < nbins; bin += 256) {
-            uint32_t v = (lds[bin >> 1] >> ((bin & 1) << 4)) & 0xFFFFu;
-            unsigned long long key = ((unsigned long long)v << 32) | (uint32_t)(0x7FFFFFFF - bin);
-            best = key > best ? key : best;
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            unsigned long long other = __shfl_xor(best, o);
-            best = other > best ? other : best;
-        }
-        if ((tid & 63) == 0) red[tid >> 6] = best;
-        __syncthreads();
-        if (tid == 0) {
+        // top-K peaks: argmax votes (ties -> smallest diagonal), then clear every bin within +-SP_PEAK_SUPPRESS of it
+        for (int round = 0; round < topk; ++round) {
+            unsigned long long best = 0;
+            for (int bin = tid; bin < nbins; bin += 256) {
+                uint32_t v = (lds[bin >> 1] >> ((bin & 1) << 4)) & 0xFFFFu;
+                unsigned long long key = ((unsigned long long)v << 32) | (uint32_t)(0x7FFFFFFF - bin);
+                best = key > best ? key : best;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                unsigned long long other = __shfl_xor(best, o);
+                best = other > best ? other : best;
+            }
+            if ((tid & 63) == 0) red[tid >> 6] = best;
+            __syncthreads();
+            best = red[0];
             for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
             const int v = (int)(best >> 32);
             const int bin = 0x7FFFFFFF - (int)(best & 0xFFFFFFFFu);
-            diag_out[p] = v > 0 ? bin - m : 0;
-            votes_out[p] = v;
+            if (tid == 0) { diag_out[p * topk + round] = v > 0 ? bin - m : 0; votes_out[p * topk + round] = v; }
+            __syncthreads();
+            if (v == 0) {                                   // nothing left: remaining slots are empty
+                if (tid == 0) for (int k2 = round + 1; k2 < topk; ++k2) { diag_out[p * topk + k2] = 0; votes_out[p * topk + k2] = 0; }
+                break;
+            }
+            if (round + 1 < topk) {
+                int lo = bin - SP_PEAK_SUPPRESS, hi = bin + SP_PEAK_SUPPRESS;
+                if (lo < 0) lo = 0;
+                if (hi > nbins - 1) hi = nbins - 1;
+                // bins are packed two per dword: clear them one lane per bin with a masked atomic AND
+                for (int b2 = lo + tid; b2 <= hi; b2 += 256) atomicAnd(&lds[b2 >> 1], (b2 & 1) ? 0x0000FFFFu : 0xFFFF0000u);
+                __syncthreads();
+            }
         }
         __syncthreads();
     }
@@ -139,7 +152,8 @@ int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn) {
 
 int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,
-                     int32_t* d_diag, int32_t* d_votes) {
+                     int32_t* d_diag, int32_t* d_votes, int topk) {
+    if (topk < 1 || topk > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: topk must be 1..8");
     if (n_pairs == 0) return SP_OK;
     if (!A->has_index) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: set A has no k-mer index");
     int bins_cap = A->max_len + B->max_len + 1;
@@ -149,7 +163,7 @@ int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     uint64_t grid = std::min<uint64_t>(n_pairs, (uint64_t)ctx->num_cus * 8);
     ProfScope ps(ctx, "anchor", n_pairs);
     hipLaunchKernelGGL(sp_anchor_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, ctx->stream,
-                       A->view(), A->kview(), B->view(), d_a_idx, d_b_idx, n_pairs, d_diag, d_votes, bins_cap);
+                       A->view(), A->kview(), B->view(), d_a_idx, d_b_idx, n_pairs, d_diag, d_votes, bins_cap, topk);
     SP_HIP_CHECK(ctx, hipGetLastError());
     return SP_OK;
 }

@@ -11,6 +11,7 @@
 #define SP_WAVE       64
 #define SP_MAXOCC     4
 #define SP_CELL_NONE  0xFFFFFFFFu
+#define SP_PEAK_SUPPRESS 128     // top-K anchors: bins within +-128 diagonals of a chosen peak are cleared
 
 // ---------------------------------------------------------------- device views
 // Packed sequence set in HBM.  2 bits/base, 16 bases per 32-bit word, base b of a sequence sits in bits
@@ -78,7 +79,7 @@ struct CellDesc {
 // ---------------------------------------------------------------- launchers (sp_device.hip)
 int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,
-                     int32_t* d_diag, int32_t* d_votes);
+                     int32_t* d_diag, int32_t* d_votes, int topk = 1);
 int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     const CellDesc* d_cells, uint64_t n_cells,
                     sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name);

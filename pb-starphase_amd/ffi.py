@@ -74,6 +74,9 @@ class sp_chain_result(C.Structure):
                 ("edit_distance", C.c_uint64), ("n_pairs_scored", C.c_uint64)]
 
 
+REGION_HIT_DTYPE = np.dtype([(n, np.int32) for n in ("read", "template_idx", "start", "end", "seq_len", "nm", "unmapped", "clip_start", "clip_end")])
+
+
 class sp_hla_best(C.Structure):
     _fields_ = [("best_allele", C.c_int32), ("n_scored", C.c_int32)]
 
@@ -118,6 +121,9 @@ def lib():
         "sp_hla_score_consensus": (i32, [vp, vp, u32, C.c_char_p, u32, C.c_char_p, u32, i32, i32, C.POINTER(sp_hla_best), vp]),
         "sp_hla_type_consensus": (i32, [vp, vp, u32, C.c_char_p, u32, i32, i32, C.POINTER(sp_hla_best), vp, C.c_char_p, u32, C.POINTER(u32)]),
         "sp_cyp_best_chain_pair": (i32, [vp, C.POINTER(sp_chain_problem), C.POINTER(sp_chain_result)]),
+        "sp_anchor_batch_topk": (i32, [vp, vp, vp, vp, vp, u64, i32, vp, vp]),
+        "sp_cyp_find_regions": (i32, [vp, vp, vp, vp, C.c_double, vp, u64, C.POINTER(u64)]),
+        "sp_cyp_weight_segments": (i32, [vp, vp, vp, vp, vp, vp, vp]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -229,6 +235,33 @@ class Context:
         if rc not in (0, 16, 17, 18):
             self.check(rc)
         return rc, res
+
+    def anchor_batch_topk(self, A, B, a_idx, b_idx, topk):
+        a_idx = np.ascontiguousarray(a_idx, np.uint32)
+        b_idx = np.ascontiguousarray(b_idx, np.uint32)
+        n = len(a_idx)
+        diag = np.zeros((n, topk), np.int32)
+        votes = np.zeros((n, topk), np.int32)
+        self.check(lib().sp_anchor_batch_topk(self._h, A._h, B._h, _ptr(a_idx), _ptr(b_idx), n, int(topk), _ptr(diag), _ptr(votes)))
+        return diag, votes
+
+    def cyp_find_regions(self, templates, template_type, reads, max_missing_frac, cap=None):
+        tt = np.ascontiguousarray(template_type, np.int32)
+        cap = cap or reads.n * 16 + 16
+        hits = np.zeros(cap, REGION_HIT_DTYPE)
+        n = C.c_uint64(0)
+        self.check(lib().sp_cyp_find_regions(self._h, templates._h, _ptr(tt), reads._h, float(max_missing_frac), _ptr(hits), cap, C.byref(n)))
+        if n.value > cap:
+            return self.cyp_find_regions(templates, template_type, reads, max_missing_frac, cap=n.value)
+        return hits[:n.value]
+
+    def cyp_weight_segments(self, consensus, allowed, segments):
+        al = np.ascontiguousarray(allowed, np.uint8)
+        ed = np.zeros((segments.n, consensus.n), np.uint64)
+        ov = np.zeros((segments.n, consensus.n), np.float64)
+        kept = np.zeros(segments.n, np.uint8)
+        self.check(lib().sp_cyp_weight_segments(self._h, consensus._h, _ptr(al), segments._h, _ptr(ed), _ptr(ov), _ptr(kept)))
+        return ed, ov, kept
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))

@@ -199,3 +199,50 @@ class Config2Workload:
         order = rng.permutation(len(self.reads))
         self.reads = [self.reads[i] for i in order]
         self.read_truth = [self.read_truth[i] for i in order]
+
+
+class CypLocus:
+    """Synthetic chr22-like CYP2D6 locus with the region sizes of Cyp2d6Config::default()
+    (src/cyp2d6/definitions.rs:128-240): REP6 2,772 / D6 6,165 / link 2,919 / REP7 2,772 / spacer 1,564 / D7 5,938.
+    D7 = D6 with ~3 % divergence, REP7 = REP6 with differences near its end; templates as the extractor builds them
+    (D6, D7, two hybrids, *5 signature, REP6, REP7, spacer, link_region), in full_allele() order."""
+    TYPES = {"UNKNOWN": 0, "REP6": 1, "CYP2D6": 2, "link_region": 3, "REP7": 4, "spacer": 5, "CYP2D7": 6, "CYP2D6*5": 7, "Hybrid": 8}
+
+    def __init__(self, seed=3):
+        rng = np.random.default_rng(seed)
+        rnd = lambda n: "".join(rng.choice(list("ACGT"), n))
+        self.rep6 = rnd(2772)
+        self.d6 = rnd(6165)
+        self.link = rnd(2919)
+        self.spacer = rnd(1564)
+        d7 = mutate(rng, self.d6, 150, 20, 30)
+        self.d7 = d7[:5938] if len(d7) >= 5938 else d7
+        self.rep7 = self.rep6[:2500] + mutate(rng, self.rep6[2500:], 8, 1, 1)
+        self.left, self.right = rnd(3000), rnd(3000)
+        cut = 2000
+        hyb67 = self.d6[:cut] + self.d7[cut:]          # CYP2D6::CYP2D7 (starts as D6)
+        hyb76 = self.d7[:cut] + self.d6[cut:]          # CYP2D7::CYP2D6
+        star5 = self.rep6[-500:] + self.spacer + self.d7[:1436]     # deletion signature: REP tail joined to the spacer side
+        named = [("CYP2D6", "CYP2D6", self.d6), ("CYP2D6*5", "CYP2D6*5", star5), ("Hybrid", "CYP2D6::CYP2D7::exon2", hyb67),
+                 ("CYP2D7", "CYP2D7", self.d7), ("Hybrid", "CYP2D7::CYP2D6::exon2", hyb76), ("REP6", "REP6", self.rep6),
+                 ("REP7", "REP7", self.rep7), ("link_region", "link_region", self.link), ("spacer", "spacer", self.spacer)]
+        named.sort(key=lambda x: x[1])                 # key order = sorted by full_allele() (haplotyper.rs:175-183)
+        self.template_names = [n for _, n, _ in named]
+        self.template_types = np.array([self.TYPES[t] for t, _, _ in named], np.int32)
+        self.templates = [s for _, _, s in named]
+
+    def haplotype(self, kind="normal"):
+        if kind == "deletion":                         # *5: D6 gone, REP6 joins the spacer
+            return self.left + self.rep6 + self.spacer + self.d7 + self.right
+        if kind == "dup":
+            return self.left + self.rep6 + self.d6 + self.link + self.rep7 + self.d6 + self.link + self.rep7 + self.spacer + self.d7 + self.right
+        return self.left + self.rep6 + self.d6 + self.link + self.rep7 + self.spacer + self.d7 + self.right
+
+    def reads(self, rng, n, kind="normal", mean_len=9000, sd_len=3000):
+        hap = self.haplotype(kind)
+        out = []
+        for _ in range(n):
+            ln = int(min(len(hap), max(2500, rng.normal(mean_len, sd_len))))
+            s = int(rng.integers(0, len(hap) - ln + 1))
+            out.append(hifi_errors(rng, hap[s:s + ln]))
+        return out

@@ -332,3 +332,39 @@ def chain_hap_string(oracle, chain, hap_labels, detail, cfg=None):
     oracle.L.osp_cyp_convert_chain_to_hap(ch.ctypes.data_as(C.c_void_p), len(ch), types.ctypes.data_as(C.c_void_p), st, int(detail),
                                           C.byref(c), out, 1024)
     return out.value.decode()
+
+
+REGION_HIT_DTYPE = np.dtype([(n, np.int32) for n in ("template_idx", "start", "end", "seq_len", "nm", "unmapped", "clip_start", "clip_end")])
+
+
+def oracle_find_base_type(oracle, seq, templates, template_type, max_missing_frac):
+    """find_base_type_in_sequence (src/cyp2d6/haplotyper.rs:142-315) on the alignment contract"""
+    L = oracle.L
+    enc = [oracle.encode(t) for t in templates]
+    ptrs = (C.c_void_p * len(enc))(*[e.ctypes.data for e in enc])
+    lens = np.array([len(e) for e in enc], np.int32)
+    tt = np.ascontiguousarray(template_type, np.int32)
+    s = oracle.encode(seq)
+    out = np.zeros(64, REGION_HIT_DTYPE)
+    L.osp_cyp_find_base_type.restype = C.c_int32
+    L.osp_cyp_find_base_type.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int32]
+    n = L.osp_cyp_find_base_type(s.ctypes.data_as(C.c_void_p), len(s), len(enc), ptrs, lens.ctypes.data_as(C.c_void_p),
+                                 tt.ctypes.data_as(C.c_void_p), float(max_missing_frac), out.ctypes.data_as(C.c_void_p), len(out))
+    return out[:n]
+
+
+def oracle_weight_sequence(oracle, seq, consensus, allowed):
+    """weight_sequence (src/cyp2d6/chaining.rs:28-103) on the alignment contract; returns (ed, ov, kept)"""
+    L = oracle.L
+    enc = [oracle.encode(t) for t in consensus]
+    ptrs = (C.c_void_p * len(enc))(*[e.ctypes.data for e in enc])
+    lens = np.array([len(e) for e in enc], np.int32)
+    al = np.ascontiguousarray(allowed, np.uint8)
+    s = oracle.encode(seq)
+    ed = np.zeros(len(enc), np.uint64)
+    ov = np.zeros(len(enc), np.float64)
+    L.osp_cyp_weight_sequence.restype = C.c_int32
+    L.osp_cyp_weight_sequence.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    kept = L.osp_cyp_weight_sequence(s.ctypes.data_as(C.c_void_p), len(s), len(enc), ptrs, lens.ctypes.data_as(C.c_void_p),
+                                     al.ctypes.data_as(C.c_void_p), ed.ctypes.data_as(C.c_void_p), ov.ctypes.data_as(C.c_void_p))
+    return ed, ov, kept

@@ -51,3 +51,57 @@ def test_synthetic_loci(oracle, gpu_ctx):
             rc, exp = same(oracle, gpu_ctx, inp)
             n_ok += rc == 0
     assert n_ok >= 10
+
+
+def test_topk_anchors(oracle, pkg, gpu_ctx):
+    """a template that occurs twice in a read must give two placements (D6 and its D7 paralog / duplications)"""
+    import ctypes as C
+    from pb_starphase_amd import synth
+    locus = synth.CypLocus(seed=4)
+    rng = np.random.default_rng(1)
+    reads = [locus.haplotype("dup"), locus.haplotype("normal")[2000:20000], "ACGT" * 10]
+    T, R = gpu_ctx.upload(locus.templates), gpu_ctx.upload(reads)
+    a = np.repeat(np.arange(len(locus.templates)), len(reads)).astype(np.uint32)
+    b = np.tile(np.arange(len(reads)), len(locus.templates)).astype(np.uint32)
+    diag, votes = gpu_ctx.anchor_batch_topk(T, R, a, b, 4)
+    for x, (ti, ri) in enumerate(zip(a, b)):
+        A, B = oracle.encode(locus.templates[ti]), oracle.encode(reads[ri])
+        d = (C.c_int32 * 4)()
+        v = (C.c_int32 * 4)()
+        oracle.L.osp_anchor_topk(A.ctypes.data_as(C.c_void_p), len(A), B.ctypes.data_as(C.c_void_p), len(B), 4, d, v)
+        assert votes[x].tolist() == list(v), (ti, ri, votes[x], list(v))
+        assert [int(dd) for dd, vv in zip(diag[x], votes[x]) if vv > 0] == [int(dd) for dd, vv in zip(d, v) if vv > 0]
+    d6 = locus.template_names.index("CYP2D6")
+    assert (votes[d6 * len(reads) + 0] > 400).sum() >= 3       # two D6 copies + the D7 paralog in the duplicated haplotype
+
+
+def test_find_regions_and_weights(oracle, pkg, gpu_ctx):
+    """K3 / K4 against the oracle restatements of find_base_type_in_sequence / weight_sequence"""
+    from pb_starphase_amd import synth
+    locus = synth.CypLocus(seed=5)
+    rng = np.random.default_rng(2)
+    reads = locus.reads(rng, 6, "normal") + locus.reads(rng, 3, "deletion") + locus.reads(rng, 3, "dup", mean_len=16000)
+    reads.append("".join(rng.choice(list("ACGT"), 4000)))
+    T, R = gpu_ctx.upload(locus.templates), gpu_ctx.upload(reads)
+    for max_missing in (1.0, 0.5):
+        hits = gpu_ctx.cyp_find_regions(T, locus.template_types, R, max_missing)
+        n_total = 0
+        for r, read in enumerate(reads):
+            exp = of.oracle_find_base_type(oracle, read, locus.templates, locus.template_types, max_missing)
+            got = hits[hits["read"] == r]
+            assert len(got) == len(exp), (r, got, exp)
+            for g, e in zip(got, exp):
+                assert tuple(int(g[k]) for k in exp.dtype.names) == tuple(int(x) for x in e.tolist()), (r, g, e)
+            n_total += len(exp)
+        assert n_total >= 20
+    # K4: segments cut out of the reads at the K3 hits, weighted against "consensuses" (here: the templates + a noisy copy)
+    hits = gpu_ctx.cyp_find_regions(T, locus.template_types, R, 1.0)
+    segs = [reads[h["read"]][h["start"]:h["end"]] for h in hits][:40] + ["".join(rng.choice(list("ACGT"), 1500))]
+    cons = locus.templates + [synth.mutate(rng, locus.d6, 5, 2, 2), "N" * 50]
+    allowed = np.array([1] * len(locus.templates) + [1, 0], np.uint8)
+    Cs, Ss = gpu_ctx.upload(cons), gpu_ctx.upload(segs)
+    ed, ov, kept = gpu_ctx.cyp_weight_segments(Cs, allowed, Ss)
+    for s, seg in enumerate(segs):
+        e_ed, e_ov, e_kept = of.oracle_weight_sequence(oracle, seg, cons, allowed)
+        assert ed[s].tolist() == e_ed.tolist() and ov[s].tolist() == e_ov.tolist() and kept[s] == e_kept, (s, ed[s], e_ed)
+    assert kept[:-1].sum() >= len(segs) - 3 and kept[-1] == 0
