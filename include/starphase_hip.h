@@ -270,6 +270,19 @@ int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32
 int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensus, const uint8_t* allowed, const sp_seqset* segments,
                                uint64_t* ed, double* ov, uint8_t* kept);
 
+/* ------------------------------------------------------------------ K7: star-allele vector scoring
+ * Replaces the scoring loop of Cyp2d6Extractor::assign_haplotype (src/cyp2d6/haplotyper.rs:470-524): for each typed
+ * sequence, its per-variant state vector (0 ref, 1 alt, 2 ambiguous, 3 unset) is compared with the 0/1 definition of
+ * every star allele; score = (matches at VI variants, matches at all variants), 2 always matches, 3 never does.
+ *   hap_matrix   n_alleles x n_variants (0/1), alleles in haplotype_lookup (BTreeMap) order
+ *   is_vi        n_variants (LoadedVariants::is_vi)
+ *   states       n_seqs x n_variants
+ * Outputs per sequence: best (vi_match, all_match) (starting from the (0,0) of the Unknown label, :472-474) and, in
+ * tie_mask (n_seqs x n_alleles bytes), which alleles reach it; no allele beats or ties (0,0) => all zero.
+ * The caller resolves ties by sorting full_allele() strings (:531-547). */
+int32_t sp_cyp_score_alleles(sp_ctx* ctx, uint32_t n_variants, uint32_t n_alleles, const uint8_t* hap_matrix, const uint8_t* is_vi,
+                             uint32_t n_seqs, const uint8_t* states, uint32_t* best_vi, uint32_t* best_all, uint8_t* tie_mask);
+
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */
 int32_t sp_profile_reset(sp_ctx* ctx);

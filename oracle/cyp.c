@@ -466,3 +466,24 @@ int osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, con
     free(un); free(coll);
     return n_out;
 }
+
+/* assign_haplotype scoring loop (src/cyp2d6/haplotyper.rs:470-524): best (vi_match, all_match) starting from the (0,0)
+ * of the Unknown label; tie[a] = 1 for the alleles in best_id_set */
+void osp_cyp_score_alleles(int n_variants, int n_alleles, const uint8_t* hap_matrix, const uint8_t* is_vi, const uint8_t* states,
+                           uint32_t* best_vi, uint32_t* best_all, uint8_t* tie) {
+    uint32_t bv = 0, ba = 0;
+    for (int a = 0; a < n_alleles; ++a) tie[a] = 0;
+    for (int a = 0; a < n_alleles; ++a) {
+        uint32_t vi_match = 0, all_match = 0;
+        for (int i = 0; i < n_variants; ++i) {
+            uint8_t seq_value = states[i], hap_value = hap_matrix[(size_t)a * n_variants + i];
+            int is_match = (seq_value == 0 || seq_value == 1) ? hap_value == seq_value : seq_value == 2;
+            if (is_match) { all_match += 1; if (is_vi[i]) vi_match += 1; }
+        }
+        if (vi_match > bv || (vi_match == bv && all_match > ba)) {          /* Ordering::Greater: clear + insert */
+            for (int x = 0; x < n_alleles; ++x) tie[x] = 0;
+            tie[a] = 1; bv = vi_match; ba = all_match;
+        } else if (vi_match == bv && all_match == ba) tie[a] = 1;           /* Ordering::Equal: insert (joins Unknown at (0,0)) */
+    }
+    *best_vi = bv; *best_all = ba;
+}

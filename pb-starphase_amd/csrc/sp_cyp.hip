@@ -519,3 +519,62 @@ extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, 
     }
     return SP_OK;
 }
+
+// =============================================================================================
+// K7: star-allele vector scoring (assign_haplotype, src/cyp2d6/haplotyper.rs:470-524)
+// one wavefront per (sequence, allele): lanes stride over the variants, two ballot/popcount reductions
+// =============================================================================================
+__global__ __launch_bounds__(256) void k7_score_kernel(const uint8_t* __restrict__ hap, const uint8_t* __restrict__ is_vi, const uint8_t* __restrict__ states,
+                                                       uint32_t n_variants, uint32_t n_alleles, uint32_t n_seqs, uint32_t* __restrict__ scores /* [seq][allele][2] */) {
+    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= (uint64_t)n_seqs * n_alleles) return;
+    const uint32_t s = (uint32_t)(w / n_alleles), a = (uint32_t)(w % n_alleles);
+    const uint8_t* hv = hap + (size_t)a * n_variants; const uint8_t* sv = states + (size_t)s * n_variants;
+    uint32_t vi = 0, all = 0;
+    for (uint32_t v = lane; v < n_variants; v += 64) {
+        const uint8_t seq_value = sv[v], hap_value = hv[v];
+        const bool is_match = seq_value <= 1 ? hap_value == seq_value : seq_value == 2;      // 3 (unset) never matches
+        all += is_match; vi += is_match && is_vi[v];
+    }
+    for (int o = 32; o > 0; o >>= 1) { vi += __shfl_xor(vi, o); all += __shfl_xor(all, o); }
+    if (lane == 0) { scores[w * 2] = vi; scores[w * 2 + 1] = all; }
+}
+
+extern "C" int32_t sp_cyp_score_alleles(sp_ctx* ctx, uint32_t n_variants, uint32_t n_alleles, const uint8_t* hap_matrix, const uint8_t* is_vi,
+                                        uint32_t n_seqs, const uint8_t* states, uint32_t* best_vi, uint32_t* best_all, uint8_t* tie_mask) {
+    if (!ctx || (n_alleles && n_variants && (!hap_matrix || !is_vi)) || (n_seqs && (!states || !best_vi || !best_all || !tie_mask))) return SP_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    for (uint32_t s = 0; s < n_seqs; ++s) { best_vi[s] = 0; best_all[s] = 0; }
+    if (n_seqs) std::memset(tie_mask, 0, (size_t)n_seqs * n_alleles);
+    if (!n_seqs || !n_alleles) return SP_OK;
+    const size_t hb = (size_t)n_alleles * n_variants, sb = (size_t)n_seqs * n_variants, nw = (size_t)n_seqs * n_alleles;
+    uint8_t* d_hap = (uint8_t*)sp_pool(ctx, "k7_hap", hb + 1); uint8_t* d_vi = (uint8_t*)sp_pool(ctx, "k7_vi", n_variants + 1);
+    uint8_t* d_st = (uint8_t*)sp_pool(ctx, "k7_states", sb + 1); uint32_t* d_sc = (uint32_t*)sp_pool(ctx, "k7_scores", nw * 8);
+    if (!d_hap || !d_vi || !d_st || !d_sc) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_alleles buffers");
+    (void)hipMemcpyAsync(d_hap, hap_matrix, hb, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_vi, is_vi, n_variants, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_st, states, sb, hipMemcpyHostToDevice, ctx->stream);
+    std::vector<uint32_t> sc(nw * 2);
+    {
+        ProfScope ps(ctx, "k7_score", nw);
+        hipLaunchKernelGGL(k7_score_kernel, dim3((unsigned)((nw * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_hap, d_vi, d_st, n_variants, n_alleles, n_seqs, d_sc);
+    }
+    (void)hipMemcpyAsync(sc.data(), d_sc, nw * 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("score_alleles: ") + hipGetErrorString(e));
+    for (uint32_t s = 0; s < n_seqs; ++s) {
+        // running best from (0,0) held by the Unknown label; Greater clears the set, Equal joins it (haplotyper.rs:505-523)
+        uint32_t bv = 0, ba = 0;
+        for (uint32_t a = 0; a < n_alleles; ++a) {
+            const uint32_t v = sc[((size_t)s * n_alleles + a) * 2], al = sc[((size_t)s * n_alleles + a) * 2 + 1];
+            if (v > bv || (v == bv && al > ba)) { bv = v; ba = al; }
+        }
+        best_vi[s] = bv; best_all[s] = ba;
+        for (uint32_t a = 0; a < n_alleles; ++a) {
+            const uint32_t v = sc[((size_t)s * n_alleles + a) * 2], al = sc[((size_t)s * n_alleles + a) * 2 + 1];
+            tie_mask[(size_t)s * n_alleles + a] = (v == bv && al == ba) ? 1 : 0;
+        }
+    }
+    return SP_OK;
+}

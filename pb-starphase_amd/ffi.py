@@ -124,6 +124,7 @@ def lib():
         "sp_anchor_batch_topk": (i32, [vp, vp, vp, vp, vp, u64, i32, vp, vp]),
         "sp_cyp_find_regions": (i32, [vp, vp, vp, vp, C.c_double, vp, u64, C.POINTER(u64)]),
         "sp_cyp_weight_segments": (i32, [vp, vp, vp, vp, vp, vp, vp]),
+        "sp_cyp_score_alleles": (i32, [vp, u32, u32, vp, vp, u32, vp, vp, vp, vp]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -262,6 +263,18 @@ class Context:
         kept = np.zeros(segments.n, np.uint8)
         self.check(lib().sp_cyp_weight_segments(self._h, consensus._h, _ptr(al), segments._h, _ptr(ed), _ptr(ov), _ptr(kept)))
         return ed, ov, kept
+
+    def cyp_score_alleles(self, hap_matrix, is_vi, states):
+        hm = np.ascontiguousarray(hap_matrix, np.uint8)
+        vi = np.ascontiguousarray(is_vi, np.uint8)
+        st = np.ascontiguousarray(states, np.uint8)
+        n_alleles, n_variants = hm.shape
+        n_seqs = st.shape[0]
+        bv = np.zeros(n_seqs, np.uint32)
+        ba = np.zeros(n_seqs, np.uint32)
+        tie = np.zeros((n_seqs, n_alleles), np.uint8)
+        self.check(lib().sp_cyp_score_alleles(self._h, n_variants, n_alleles, _ptr(hm), _ptr(vi), n_seqs, _ptr(st), _ptr(bv), _ptr(ba), _ptr(tie)))
+        return bv, ba, tie
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))

@@ -105,3 +105,42 @@ def test_find_regions_and_weights(oracle, pkg, gpu_ctx):
         e_ed, e_ov, e_kept = of.oracle_weight_sequence(oracle, seg, cons, allowed)
         assert ed[s].tolist() == e_ed.tolist() and ov[s].tolist() == e_ov.tolist() and kept[s] == e_kept, (s, ed[s], e_ed)
     assert kept[:-1].sum() >= len(segs) - 3 and kept[-1] == 0
+
+
+def test_score_alleles(oracle, pkg, gpu_ctx):
+    """K7 vs the oracle restatement of the assign_haplotype scoring loop, on the bundled CYP2D6 definitions
+    (520 star alleles; the variant table is rebuilt from cyp2d6_gene_def of the fixture database)"""
+    import ctypes as C, gzip, json, os
+    db = json.load(gzip.open(os.path.join(os.path.dirname(__file__), "golden", "cyp2d6_db_v0.14.1.json.gz")))["cyp2d6_gene_def"]
+    names = sorted(db)
+    variants = sorted({(v["position"], v["reference"], v["alternate"]) for a in db.values() for v in a["variants"]})
+    vidx = {v: i for i, v in enumerate(variants)}
+    is_vi = np.zeros(len(variants), np.uint8)
+    hap = np.zeros((len(names), len(variants)), np.uint8)
+    for ai, n in enumerate(names):
+        for v in db[n]["variants"]:
+            i = vidx[(v["position"], v["reference"], v["alternate"])]
+            hap[ai, i] = 1
+            if v.get("extras", {}).get("VI") is not None:
+                is_vi[i] = 1
+    assert hap.shape[0] >= 500 and hap.shape[1] >= 350 and is_vi.sum() >= 100
+    rng = np.random.default_rng(8)
+    states = []
+    for k in range(12):
+        st = hap[int(rng.integers(len(names)))].copy()
+        flip = rng.random(len(variants))
+        st[flip < 0.01] ^= 1
+        st[(flip >= 0.01) & (flip < 0.03)] = 2
+        st[(flip >= 0.03) & (flip < 0.08)] = 3
+        states.append(st)
+    states.append(np.full(len(variants), 3, np.uint8))            # nothing set: only Unknown stays at (0, 0)
+    states = np.array(states, np.uint8)
+    bv, ba, tie = gpu_ctx.cyp_score_alleles(hap, is_vi, states)
+    for s in range(len(states)):
+        ev, ea = C.c_uint32(), C.c_uint32()
+        et = np.zeros(len(names), np.uint8)
+        oracle.L.osp_cyp_score_alleles(len(variants), len(names), hap.ctypes.data_as(C.c_void_p), is_vi.ctypes.data_as(C.c_void_p),
+                                       states[s].ctypes.data_as(C.c_void_p), C.byref(ev), C.byref(ea), et.ctypes.data_as(C.c_void_p))
+        assert (bv[s], ba[s]) == (ev.value, ea.value)
+        assert tie[s].tolist() == et.tolist()
+    assert bv[-1] == 0 and ba[-1] == 0
