@@ -283,6 +283,45 @@ int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensus, const ui
 int32_t sp_cyp_score_alleles(sp_ctx* ctx, uint32_t n_variants, uint32_t n_alleles, const uint8_t* hap_matrix, const uint8_t* is_vi,
                              uint32_t n_seqs, const uint8_t* states, uint32_t* best_vi, uint32_t* best_all, uint8_t* tie_mask);
 
+/* ------------------------------------------------------------------ K6: variant-gene diplotype search
+ * Replaces solve_diplotype (src/diplotyper.rs:1211-1371) with find_best_inexact_matches (:1411-1509) and
+ * NormalizedPgxHaplotype::quant_match (src/data_types/normalized_variant.rs:431-479) on integer ids.  The caller keeps the
+ * string work (normalisation, names): variants are ids 0..n_vars-1, haplotypes are listed in defined_haplotypes (BTreeMap)
+ * order, observed variants in BTreeMap<NormalizedVariant> order.
+ *   haplotype h  = AND of slots [slot_off[h], slot_off[h+1]); slot s = OR of alt_var[alt_off[s] .. alt_off[s+1]) (-1 = None)
+ *   obs_gt       SP_GT_* ; obs_ps = phase set or -1 ; obs_sv_label = -1 or the id of the SV haplotype label it carries
+ * Every (het assignment, haplotype side, database haplotype) cell is scored on the GPU (one thread per cell); the host
+ * combines the sides exactly as the reference does (ascending combinations, ties kept, sub-alleles shadow core alleles).
+ * dip[i] = the two haplotype indices of diplotype i (an SV label l is encoded as -(l + 2)); dip_comb[i] = the het
+ * assignment it came from (needed to derive the inexact haplotypes, :1516-1550). */
+enum { SP_GT_HOM_REF = 0, SP_GT_HET_UNPHASED = 1, SP_GT_HET_PHASED = 2, SP_GT_HET_FLIP = 3, SP_GT_HOM_ALT = 4 };
+#define SP_VAR_MAXDIP 4096
+
+typedef struct {
+    int32_t n_haps;
+    const uint8_t* hap_is_sv;
+    const uint8_t* hap_is_core;
+    const int32_t* slot_off;
+    const int32_t* alt_off;
+    const int32_t* alt_var;
+    int32_t n_vars;
+    const uint8_t* var_is_core;
+    int32_t n_obs;
+    const int32_t* obs_var;
+    const int32_t* obs_gt;
+    const int64_t* obs_ps;
+    const int32_t* obs_sv_label;
+} sp_variant_problem;
+
+typedef struct {
+    int64_t score[4];                   /* core missing, core extra, sub missing, sub extra (INT64_MAX = unset) */
+    int32_t n_dip, overflow;
+    int32_t dip[SP_VAR_MAXDIP][2];
+    int32_t dip_comb[SP_VAR_MAXDIP];
+} sp_variant_result;
+
+int32_t sp_variant_solve(sp_ctx* ctx, const sp_variant_problem* problem, sp_variant_result* result);
+
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */
 int32_t sp_profile_reset(sp_ctx* ctx);

@@ -77,6 +77,20 @@ class sp_chain_result(C.Structure):
 REGION_HIT_DTYPE = np.dtype([(n, np.int32) for n in ("read", "template_idx", "start", "end", "seq_len", "nm", "unmapped", "clip_start", "clip_end")])
 
 
+SP_VAR_MAXDIP = 4096
+
+
+class sp_variant_problem(C.Structure):
+    _fields_ = [("n_haps", C.c_int32), ("hap_is_sv", C.c_void_p), ("hap_is_core", C.c_void_p), ("slot_off", C.c_void_p),
+                ("alt_off", C.c_void_p), ("alt_var", C.c_void_p), ("n_vars", C.c_int32), ("var_is_core", C.c_void_p),
+                ("n_obs", C.c_int32), ("obs_var", C.c_void_p), ("obs_gt", C.c_void_p), ("obs_ps", C.c_void_p), ("obs_sv_label", C.c_void_p)]
+
+
+class sp_variant_result(C.Structure):
+    _fields_ = [("score", C.c_int64 * 4), ("n_dip", C.c_int32), ("overflow", C.c_int32), ("dip", (C.c_int32 * 2) * SP_VAR_MAXDIP),
+                ("dip_comb", C.c_int32 * SP_VAR_MAXDIP)]
+
+
 class sp_hla_best(C.Structure):
     _fields_ = [("best_allele", C.c_int32), ("n_scored", C.c_int32)]
 
@@ -125,6 +139,7 @@ def lib():
         "sp_cyp_find_regions": (i32, [vp, vp, vp, vp, C.c_double, vp, u64, C.POINTER(u64)]),
         "sp_cyp_weight_segments": (i32, [vp, vp, vp, vp, vp, vp, vp]),
         "sp_cyp_score_alleles": (i32, [vp, u32, u32, vp, vp, u32, vp, vp, vp, vp]),
+        "sp_variant_solve": (i32, [vp, C.POINTER(sp_variant_problem), C.POINTER(sp_variant_result)]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -275,6 +290,14 @@ class Context:
         tie = np.zeros((n_seqs, n_alleles), np.uint8)
         self.check(lib().sp_cyp_score_alleles(self._h, n_variants, n_alleles, _ptr(hm), _ptr(vi), n_seqs, _ptr(st), _ptr(bv), _ptr(ba), _ptr(tie)))
         return bv, ba, tie
+
+    def variant_solve(self, problem):
+        """problem: an sp_variant_problem (caller keeps the arrays alive).  Returns (score tuple, [(h1, h2, combination)])"""
+        res = sp_variant_result()
+        self.check(lib().sp_variant_solve(self._h, C.byref(problem), C.byref(res)))
+        if res.overflow:
+            raise StarphaseError(5, "more than SP_VAR_MAXDIP tied diplotypes")
+        return tuple(res.score), [(res.dip[i][0], res.dip[i][1], res.dip_comb[i]) for i in range(res.n_dip)]
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))

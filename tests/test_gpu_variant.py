@@ -1,0 +1,73 @@
+"""GPU parity for K6 (sp_variant_solve) against oracle/variant.c on the reference's scenarios and on random problems."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import variant_glue as vg
+from test_oracle_variant import CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_struct(pkg, prob):
+    p = pkg.ffi.sp_variant_problem()
+    s = prob.struct()
+    for f, _ in p._fields_:
+        setattr(p, f, getattr(s, f))
+    return p
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[1])
+def test_reference_scenarios(oracle, pkg, gpu_ctx, case):
+    db, vcf, with_ref, dips, inexact = case
+    _g, prob = vg.load_case(oracle, db, vcf, with_ref)
+    exp = vg.oracle_solve(oracle, prob)
+    got = gpu_ctx.variant_solve(gpu_struct(pkg, prob))
+    assert got == exp
+    called = vg.call_gene(oracle, prob, solver=lambda pr: gpu_ctx.variant_solve(gpu_struct(pkg, pr)))
+    assert [frozenset(d) if d[0] != d[1] else d for d in called["diplotypes"]] == [frozenset(d) if d[0] != d[1] else d for d in dips]
+
+
+class RandomProblem(vg.Problem):
+    def __init__(self, rng, n_vars, n_haps, n_obs):
+        self.var_list = list(range(n_vars))
+        self.haps = []
+        slot_off, alt_off, alt_var = [0], [0], []
+        for h in range(n_haps):
+            ns = int(rng.integers(0, 6))
+            used = rng.choice(n_vars, ns, replace=False).tolist() if ns else []
+            for v in used:
+                alts = [v]
+                if rng.random() < 0.2:
+                    alts.append(-1)                                # optional variant (None alternative)
+                if rng.random() < 0.15:
+                    alts.append(int(rng.integers(n_vars)))         # IUPAC-style alternative
+                alt_var += alts
+                alt_off.append(len(alt_var))
+            slot_off.append(len(alt_off) - 1)
+            self.haps.append({"name": f"h{h}", "core_allele": None if rng.random() < 0.5 else "c"})
+        self.hap_is_sv = (rng.random(n_haps) < 0.05).astype(np.uint8)
+        self.hap_is_core = np.array([1 if h["core_allele"] is None else 0 for h in self.haps], np.uint8)
+        self.slot_off = np.array(slot_off, np.int32)
+        self.alt_off = np.array(alt_off, np.int32)
+        self.alt_var = np.array(alt_var or [0], np.int32)
+        self.var_is_core = (rng.random(n_vars) < 0.6).astype(np.uint8)
+        self.obs = sorted(rng.choice(n_vars, n_obs, replace=False).tolist())
+        self.obs_var = np.array(self.obs, np.int32)
+        self.obs_gt = rng.choice([1, 2, 3, 4], n_obs).astype(np.int32)
+        ps = rng.integers(100, 103, n_obs).astype(np.int64)
+        self.obs_ps = np.where((self.obs_gt == 2) | (self.obs_gt == 3), ps, -1).astype(np.int64)
+        self.obs_sv = np.where(rng.random(n_obs) < 0.03, rng.integers(0, 3, n_obs), -1).astype(np.int32)
+
+
+def test_random_problems(oracle, pkg, gpu_ctx):
+    rng = np.random.default_rng(33)
+    n_nontrivial = 0
+    for k in range(40):
+        prob = RandomProblem(rng, n_vars=24, n_haps=int(rng.integers(3, 60)), n_obs=int(rng.integers(0, 11)))
+        exp = vg.oracle_solve(oracle, prob)
+        got = gpu_ctx.variant_solve(gpu_struct(pkg, prob))
+        assert got == exp, (k, got, exp)
+        n_nontrivial += len(exp[1]) > 0
+    assert n_nontrivial >= 20
