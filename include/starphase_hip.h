@@ -322,6 +322,25 @@ typedef struct {
 
 int32_t sp_variant_solve(sp_ctx* ctx, const sp_variant_problem* problem, sp_variant_result* result);
 
+/* ------------------------------------------------------------------ host-side decisions of the path (no device work)
+ * Small scalar routines the reference evaluates between the kernels; kept behind the same ABI so a host can drop the whole
+ * path in.  statrs 0.16 formulas (Binomial::cdf / ln_pmf, Normal::ln_pdf, ln_factorial). */
+/* is_passing_dual (src/hla/caller.rs:1225-1247): returns 1 when maf >= min_consensus_fraction and Binomial(expected_maf, n).cdf(minor) >= min_cdf */
+int32_t sp_hla_is_passing_dual(uint64_t counts1, uint64_t counts2, double min_consensus_fraction, double expected_maf, double min_cdf,
+                               double* maf_out, double* cdf_out);
+/* is_hemizygous_better (src/hla/caller.rs:1583-1653): scores1/scores2 < 0 mean None; normalized_coverage < 0 means unknown */
+int32_t sp_hla_is_hemizygous_better(const int64_t* scores1, const int64_t* scores2, const uint8_t* is_consensus1, uint32_t n_reads,
+                                    int32_t is_dual, uint64_t dual_max_ed_delta, double normalized_coverage,
+                                    double* haploid_cost, double* diploid_cost);
+/* hpc_pos / hpc_bytes (src/util/homopolymers.rs:18-42) */
+uint64_t sp_hpc_pos(const char* seq, uint64_t len, uint64_t position);
+uint64_t sp_hpc(const char* seq, uint64_t len, char* out);
+/* convert_chain_to_hap (src/cyp2d6/caller.rs:907-957); detail 0 = core alleles, 1 = sub-alleles; returns the string length
+ * (the output is truncated to cap-1 characters) */
+uint32_t sp_cyp_chain_to_hap(const int32_t* chain, uint32_t n, const int32_t* hap_type, const char* const* hap_subtype,
+                             uint32_t n_translate, const char* const* translate_key, const char* const* translate_val,
+                             int32_t detail, char* out, uint32_t cap);
+
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */
 int32_t sp_profile_reset(sp_ctx* ctx);

@@ -1,0 +1,120 @@
+// sp_host.hip -- the scalar host-side decisions of the hot path (no device work), behind the same C ABI.
+#include "sp_internal.h"
+#include <cmath>
+#include <cstring>
+#include <string>
+
+namespace {
+// statrs::function::factorial::ln_factorial: products up to 170!, ln_gamma beyond
+double ln_fact(uint64_t n) {
+    if (n <= 170) { double f = 1.0; for (uint64_t i = 2; i <= n; ++i) f *= (double)i; return std::log(f); }
+    return std::lgamma((double)n + 1.0);
+}
+// statrs Binomial::ln_pmf
+double binom_ln_pmf(double p, uint64_t n, uint64_t x) {
+    if (x > n) return -INFINITY;
+    if (p == 0.0) return x == 0 ? 0.0 : -INFINITY;
+    if (p == 1.0) return x == n ? 0.0 : -INFINITY;
+    return ln_fact(n) - ln_fact(x) - ln_fact(n - x) + (double)x * std::log(p) + (double)(n - x) * std::log(1.0 - p);
+}
+// statrs Binomial::cdf = I_{1-p}(n - x, x + 1), evaluated as the finite sum
+double binom_cdf(double p, uint64_t n, uint64_t x) {
+    if (x >= n) return 1.0;
+    double acc = 0.0;
+    for (uint64_t k = 0; k <= x; ++k) acc += std::exp(binom_ln_pmf(p, n, k));
+    return acc > 1.0 ? 1.0 : acc;
+}
+double normal_ln_pdf(double mean, double sd, double x) {
+    const double ln_sqrt_2pi = 0.91893853320467274178032973640561763986139747363778341281715;
+    const double d = (x - mean) / sd;
+    return (-0.5 * d * d) - ln_sqrt_2pi - std::log(sd);
+}
+bool cyp2d(int t) { return t == SP_CYP_CYP2D6 || t == SP_CYP_CYP2D7 || t == SP_CYP_DELETION || t == SP_CYP_HYBRID; }
+} // namespace
+
+extern "C" {
+
+int32_t sp_hla_is_passing_dual(uint64_t counts1, uint64_t counts2, double min_consensus_fraction, double expected_maf, double min_cdf,
+                               double* maf_out, double* cdf_out) {
+    const uint64_t total = counts1 + counts2, minor = counts1 < counts2 ? counts1 : counts2;
+    const double maf = (double)minor / (double)total;
+    const double cdf = binom_cdf(expected_maf, total, minor);
+    if (maf_out) *maf_out = maf;
+    if (cdf_out) *cdf_out = cdf;
+    return (maf >= min_consensus_fraction && cdf >= min_cdf) ? 1 : 0;
+}
+
+int32_t sp_hla_is_hemizygous_better(const int64_t* s1, const int64_t* s2, const uint8_t* is_c1, uint32_t n, int32_t is_dual,
+                                    uint64_t dual_max_ed_delta, double normalized_coverage, double* haploid_cost_out, double* diploid_cost_out) {
+    uint64_t min_ed = 0;
+    if (is_dual) {
+        uint64_t c1 = 0, c2 = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            // a missing score means the read hit dual_max_ed_delta relative to the other consensus (caller.rs:1597-1599)
+            const uint64_t a = s1[i] >= 0 ? (uint64_t)s1[i] : (s2[i] >= 0 ? (uint64_t)s2[i] : 0) + dual_max_ed_delta;
+            const uint64_t b = s2[i] >= 0 ? (uint64_t)s2[i] : (s1[i] >= 0 ? (uint64_t)s1[i] : 0) + dual_max_ed_delta;
+            const uint64_t m = a < b ? a : b;
+            c1 += a - m; c2 += b - m;
+        }
+        min_ed = c1 < c2 ? c1 : c2;
+    }
+    const double read_count = (double)n;
+    const double haploid_ed_cost = 2.0 * (double)min_ed;                       // ln_ed_penalty
+    const double nc_hap = normalized_coverage >= 0.0 ? normalized_coverage : read_count;
+    const double nc_dev = nc_hap * 0.1;
+    const double haploid_cost = haploid_ed_cost + std::fabs(normal_ln_pdf(nc_hap, nc_dev, read_count));
+    uint64_t obs1 = 0; for (uint32_t i = 0; i < n; ++i) obs1 += is_c1[i] ? 1 : 0;
+    const double balance = is_dual ? 2.0 * std::fabs(binom_ln_pmf(0.5, n, obs1)) : 0.0;     // diploid_balance_penalty
+    const double diploid_cost = balance + std::fabs(normal_ln_pdf(2.0 * nc_hap, nc_dev, read_count));
+    if (haploid_cost_out) *haploid_cost_out = haploid_cost;
+    if (diploid_cost_out) *diploid_cost_out = diploid_cost;
+    return haploid_cost < diploid_cost ? 1 : 0;
+}
+
+uint64_t sp_hpc_pos(const char* seq, uint64_t len, uint64_t position) {
+    uint64_t total = 0, offset = 0, i = 0;
+    while (i < len) {
+        uint64_t run = 1; while (i + run < len && seq[i + run] == seq[i]) ++run;
+        total += run;
+        if (position < total) break;
+        ++offset; i += run;
+    }
+    return offset;
+}
+
+uint64_t sp_hpc(const char* seq, uint64_t len, char* out) {
+    uint64_t o = 0;
+    for (uint64_t i = 0; i < len; ++i) if (i == 0 || seq[i] != seq[i - 1]) out[o++] = seq[i];
+    return o;
+}
+
+uint32_t sp_cyp_chain_to_hap(const int32_t* chain, uint32_t n, const int32_t* hap_type, const char* const* hap_subtype,
+                             uint32_t n_translate, const char* const* translate_key, const char* const* translate_val,
+                             int32_t detail, char* out, uint32_t cap) {
+    auto label = [&](int h) -> std::string {                                    // simplify_allele (region_label.rs:77-128)
+        const int t = hap_type[h]; const char* sub = hap_subtype ? hap_subtype[h] : nullptr;
+        if (t == SP_CYP_DELETION) return "*5";
+        if (!sub) return t == SP_CYP_CYP2D6 ? "CYP2D6" : "Hybrid";
+        for (uint32_t i = 0; i < n_translate; ++i) if (std::strcmp(translate_key[i], sub) == 0) return std::string("*") + translate_val[i];
+        if (detail == 1) return std::string("*") + sub;
+        char* endp = nullptr; const double v = std::strtod(sub, &endp);
+        if (sub[0] && sub[0] != ' ' && endp && *endp == '\0' && !(sub[0] == '0' && (sub[1] == 'x' || sub[1] == 'X'))) return "*" + std::to_string((long long)std::floor(v));
+        return std::string("*") + sub;
+    };
+    int non_deletion = 0;
+    for (uint32_t x = 0; x < n; ++x) { const int t = hap_type[chain[x]]; if (cyp2d(t) && t != SP_CYP_CYP2D7 && t != SP_CYP_DELETION) ++non_deletion; }
+    std::string res, prev; int run = 0;
+    auto flush = [&]() { if (run > 0) { if (!res.empty()) res += " + "; res += prev; if (run > 1) res += "x" + std::to_string(run); } };
+    for (int x = (int)n - 1; x >= 0; --x) {                                     // chains are reported in reverse (caller.rs:913-915)
+        const int h = chain[x], t = hap_type[h];
+        if (!(cyp2d(t) && t != SP_CYP_CYP2D7)) continue;
+        if (t == SP_CYP_DELETION && non_deletion > 0) continue;
+        const std::string cur = label(h);
+        if (run > 0 && cur == prev) ++run; else { flush(); prev = cur; run = 1; }
+    }
+    flush();
+    if (out && cap) { const size_t k = std::min<size_t>(cap - 1, res.size()); std::memcpy(out, res.data(), k); out[k] = '\0'; }
+    return (uint32_t)res.size();
+}
+
+} // extern "C"

@@ -140,6 +140,11 @@ def lib():
         "sp_cyp_weight_segments": (i32, [vp, vp, vp, vp, vp, vp, vp]),
         "sp_cyp_score_alleles": (i32, [vp, u32, u32, vp, vp, u32, vp, vp, vp, vp]),
         "sp_variant_solve": (i32, [vp, C.POINTER(sp_variant_problem), C.POINTER(sp_variant_result)]),
+        "sp_hla_is_passing_dual": (i32, [u64, u64, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "sp_hla_is_hemizygous_better": (i32, [vp, vp, vp, u32, i32, u64, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "sp_hpc_pos": (u64, [C.c_char_p, u64, u64]),
+        "sp_hpc": (u64, [C.c_char_p, u64, C.c_char_p]),
+        "sp_cyp_chain_to_hap": (u32, [vp, u32, vp, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i32, C.c_char_p, u32]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
