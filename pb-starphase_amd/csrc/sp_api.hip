@@ -73,13 +73,6 @@ int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64
 }
 
 // ------------------------------------------------------------------ sequence sets
-static inline uint32_t base_code(char c) {
-    switch (c) {
-        case 'A': case 'a': return 0; case 'C': case 'c': return 1;
-        case 'G': case 'g': return 2; case 'T': case 't': return 3;
-        default: return 4;
-    }
-}
 
 int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets, uint32_t n, sp_seqset** out) {
     if (!ctx || !out || (n && (!bases || !offsets))) return SP_ERR_INVALID_ARG;
@@ -100,37 +93,38 @@ int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets
         total_words += (w + 3) & ~3ull;            // 16-byte aligned starts
     }
     s->h_word_off[n] = total_words;
-    s->h_words.assign(total_words + 4, 0);
-    std::vector<uint32_t> nplane;
-    for (uint32_t i = 0; i < n; ++i) {
-        const char* p = bases + offsets[i];
-        uint32_t* w = s->h_words.data() + s->h_word_off[i];
-        const int len = s->h_len[i];
-        for (int b = 0; b < len; ++b) {
-            uint32_t c = base_code(p[b]);
-            if (c > 3) {
-                if (!s->has_n) { s->has_n = true; nplane.assign(total_words + 4, 0); }
-                nplane[s->h_word_off[i] + (b >> 4)] |= 1u << ((b & 15) << 1);
-                c = 0;
-            }
-            w[b >> 4] |= c << ((b & 15) << 1);
-        }
-    }
     auto fail = [&](const char* what) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, what); };
-    size_t wbytes = (total_words + 4) * sizeof(uint32_t);
+    const size_t wbytes = (total_words + 4) * sizeof(uint32_t);
     if (hipMalloc(&s->d_words, wbytes) != hipSuccess) return fail("seqset words");
     if (hipMalloc(&s->d_word_off, ((size_t)n + 1) * sizeof(uint64_t)) != hipSuccess) return fail("seqset offsets");
     if (hipMalloc(&s->d_len, std::max<size_t>(1, n) * sizeof(int32_t)) != hipSuccess) return fail("seqset lengths");
-    hipMemcpyAsync(s->d_words, s->h_words.data(), wbytes, hipMemcpyHostToDevice, ctx->stream);
     hipMemcpyAsync(s->d_word_off, s->h_word_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
     if (n) hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-    if (s->has_n) {
-        if (hipMalloc(&s->d_nplane, wbytes) != hipSuccess) return fail("seqset nplane");
-        hipMemcpyAsync(s->d_nplane, nplane.data(), wbytes, hipMemcpyHostToDevice, ctx->stream);
+    hipMemsetAsync(s->d_words, 0, wbytes, ctx->stream);
+    const uint64_t n_bases = n ? offsets[n] - offsets[0] : 0;
+    if (n_bases) {
+        // the ASCII bases go over PCIe once and are packed to 2 bits/base on the device (sp_pack_kernel)
+        char* d_ascii = (char*)sp_pool(ctx, "upload_ascii", n_bases);
+        uint64_t* d_off = (uint64_t*)sp_pool(ctx, "upload_off", ((size_t)n + 1) * 8);
+        uint32_t* d_flag = (uint32_t*)sp_pool(ctx, "upload_flag", 4);
+        if (!d_ascii || !d_off || !d_flag) return fail("seqset staging");
+        std::vector<uint64_t> rel((size_t)n + 1);
+        for (uint32_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
+        hipMemcpyAsync(d_ascii, bases + offsets[0], n_bases, hipMemcpyHostToDevice, ctx->stream);
+        hipMemcpyAsync(d_off, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        hipMemsetAsync(d_flag, 0, 4, ctx->stream);
+        sp_launch_pack(ctx, d_ascii, d_off, s->d_word_off, s->d_len, n, s->d_words, nullptr, d_flag);
+        uint32_t flag = 0;
+        hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
+        SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (flag) {
+            s->has_n = true;
+            if (hipMalloc(&s->d_nplane, wbytes) != hipSuccess) return fail("seqset nplane");
+            hipMemsetAsync(s->d_nplane, 0, wbytes, ctx->stream);
+            sp_launch_pack(ctx, d_ascii, d_off, s->d_word_off, s->d_len, n, nullptr, s->d_nplane, d_flag);
+        }
     }
     SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    // the N plane is needed on the host only to build a k-mer index: keep it behind the packed words
-    if (s->has_n) { s->h_words.insert(s->h_words.end(), nplane.begin(), nplane.end()); }
     *out = s;
     return SP_OK;
 }
@@ -163,6 +157,11 @@ int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
     if (s->has_index) return SP_OK;
     hipSetDevice(ctx->device);
     const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
+    if (s->h_words.empty()) {                              // packed on the device: fetch the packed words (and N plane) once
+        s->h_words.assign(plane_words * (s->has_n ? 2 : 1), 0);
+        hipMemcpy(s->h_words.data(), s->d_words, plane_words * 4, hipMemcpyDeviceToHost);
+        if (s->has_n) hipMemcpy(s->h_words.data() + plane_words, s->d_nplane, plane_words * 4, hipMemcpyDeviceToHost);
+    }
     std::vector<uint64_t> koff((size_t)s->n + 1, 0);
     std::vector<uint32_t> kcode; std::vector<int32_t> kpos;
     std::vector<std::pair<uint32_t, int32_t>> tmp;

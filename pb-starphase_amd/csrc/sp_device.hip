@@ -121,6 +121,44 @@ __global__ __launch_bounds__(256) void sp_cells_kernel(SeqSetView A, SeqSetView 
 }
 
 // =============================================================================================
+// 2-bit packing on the device: one thread per output dword (16 bases).  A=0 C=1 G=2 T=3 (either case), anything else is
+// 'N': code 0 in the word plane, 01 in the N plane, and the set is flagged as carrying N.
+// =============================================================================================
+__global__ __launch_bounds__(256) void sp_pack_kernel(const char* __restrict__ ascii, const uint64_t* __restrict__ off, const uint64_t* __restrict__ word_off,
+                                                      const int32_t* __restrict__ len, uint32_t n, uint32_t* __restrict__ words, uint32_t* __restrict__ nplane,
+                                                      uint32_t* __restrict__ flag) {
+    for (uint32_t s = blockIdx.x; s < n; s += gridDim.x) {
+        const int L = len[s]; const char* src = ascii + off[s];
+        const int nw = (L + 15) >> 4;
+        for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+            uint32_t word = 0, nw_bits = 0;
+            const int b0 = w << 4, b1 = b0 + 16 < L ? b0 + 16 : L;
+            for (int b = b0; b < b1; ++b) {
+                uint32_t c;
+                switch (src[b]) {
+                    case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break;
+                    case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break;
+                    default: c = 0; nw_bits |= 1u << ((b & 15) << 1);
+                }
+                word |= c << ((b & 15) << 1);
+            }
+            if (words) words[word_off[s] + w] = word;
+            if (nplane) nplane[word_off[s] + w] = nw_bits;
+            if (nw_bits && flag) atomicOr(flag, 1u);
+        }
+    }
+}
+
+int sp_launch_pack(sp_ctx* ctx, const char* d_ascii, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
+                   uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag) {
+    if (n == 0) return SP_OK;
+    const unsigned grid = std::min<unsigned>(n, (unsigned)ctx->num_cus * 16);
+    hipLaunchKernelGGL(sp_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_ascii, d_off, d_word_off, d_len, n, d_words, d_nplane, d_flag);
+    SP_HIP_CHECK(ctx, hipGetLastError());
+    return SP_OK;
+}
+
+// =============================================================================================
 // host side
 // =============================================================================================
 int sp_fail(sp_ctx* ctx, int code, const std::string& msg) { if (ctx) ctx->err = msg; return code; }

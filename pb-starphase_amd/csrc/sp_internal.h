@@ -84,6 +84,8 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     const CellDesc* d_cells, uint64_t n_cells,
                     sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name);
 
+int sp_launch_pack(sp_ctx* ctx, const char* d_ascii, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
+                   uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag);
 void* sp_scratch(sp_ctx* ctx, size_t bytes);
 void* sp_pool(sp_ctx* ctx, const char* name, size_t bytes);
 int   sp_fail(sp_ctx* ctx, int code, const std::string& msg);
