@@ -13,7 +13,9 @@
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
 int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn);
 
-#define K1_CHUNK       128      // alleles per workgroup (4 waves x 32 cells)
+#define K1_THREADS     256      // 4 waves per workgroup (512 threads measured slower: 44.9 vs 40.5 ms)
+#define K1_WAVES       (K1_THREADS / 64)
+#define K1_CHUNK       K1_THREADS   // alleles per workgroup: one metadata thread each; cells are handed to the waves dynamically
 #define K1_MIN_VOTES   16
 #define K2_MIN_VOTES   2
 
@@ -73,7 +75,7 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
 #define K1_PRE 5        // prefetch registers per lane: alleles up to 5*64*16 - 32 = 5,088 bases stream through registers
 
 template <bool HASN>
-__global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads,
+__global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads,
                                                        const uint32_t* __restrict__ gene_of, const int32_t* __restrict__ off_fwd,
                                                        const int32_t* __restrict__ d_rg, const int32_t* __restrict__ votes_rg,
                                                        int n_genes, uint32_t n_alleles, uint32_t n_chunks,
@@ -81,11 +83,11 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
                                                        const uint32_t* __restrict__ read_list, uint32_t* __restrict__ read_maxlen,
                                                        int pass_cap, int b_words, int a_words) {
     extern __shared__ uint32_t lds[];
-    // layout: [8 control words][K1_CHUNK x 4 cell metadata][B window b_words (x2 with N plane)][4 x A slot a_words (x2 with N plane)]
+    // layout: [32 control words][K1_CHUNK x 4 cell metadata][B window b_words (x2 with N plane)][K1_WAVES x A slot a_words (x2 with N plane)]
     int* ctl = reinterpret_cast<int*>(lds);               // 0: window lo, 1: window hi, 2: longest active allele, 3: #active in wave 0,
                                                           // 4: #active, 5: next cell to grab
-    int* meta = ctl + 8;                                  // dense list of active cells: (chunk slot | static cap << 8), alen, kb, word offset
-    uint32_t* LB = lds + 8 + 4 * K1_CHUNK;
+    int* meta = ctl + 32;                                 // dense list of active cells: (chunk slot | static cap << 8), alen, kb, word offset
+    uint32_t* LB = lds + 32 + 4 * K1_CHUNK;
     uint32_t* NB = HASN ? LB + b_words : nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint32_t* slotA = LB + (HASN ? 2 : 1) * b_words + wave * (HASN ? 2 : 1) * a_words;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
     const uint32_t a_end = min(a_first + (uint32_t)K1_CHUNK, n_alleles);
 
     // pass 1 (threads 0..127, one allele each): cell metadata, union of the read windows, dense list of active cells
-    if (tid == 0) { ctl[0] = 0x7FFFFFFF; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = 4; }
+    if (tid == 0) { ctl[0] = 0x7FFFFFFF; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = K1_WAVES; }
     __syncthreads();
     int act = 0, alen = 0, kb = 0, cap = 0; uint32_t woff = 0;
     if (tid < K1_CHUNK && a_first + tid < a_end) {
@@ -123,14 +125,17 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
         }
         if (!act) cell_out[(uint64_t)r * n_alleles + a] = SP_CELL_NONE;
     }
+    // dense list of the active cells in ascending allele order: per-wave ballots + a prefix over the (up to four) waves
     const unsigned long long bal = __ballot(act != 0);
-    if (tid == 0) ctl[3] = __builtin_popcountll(bal);          // wave 0 publishes its count for wave 1
+    if (lane == 0) ctl[16 + wave] = __builtin_popcountll(bal);
     __syncthreads();
     if (act) {
-        const int slot = __builtin_popcountll(bal & ((1ull << lane) - 1ull)) + (wave == 1 ? ctl[3] : 0);
-        meta[slot * 4 + 0] = tid | (cap << 8); meta[slot * 4 + 1] = alen; meta[slot * 4 + 2] = kb; meta[slot * 4 + 3] = (int)woff;
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += ctl[16 + w];
+        const int slot = before + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        meta[slot * 4 + 0] = tid | (cap << 16); meta[slot * 4 + 1] = alen; meta[slot * 4 + 2] = kb; meta[slot * 4 + 3] = (int)woff;
     }
-    if (tid == 64) ctl[4] = ctl[3] + __builtin_popcountll(bal);
+    if (tid == 0) { int tot = 0; for (int w = 0; w < K1_WAVES; ++w) tot += ctl[16 + w]; ctl[4] = tot; }
     __syncthreads();
     const int n_act = __builtin_amdgcn_readfirstlane(ctl[4]);
     if (n_act == 0) return;
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
     {
         const int w0 = w_lo >> 4;
         const int nw = ((w_hi + 15) >> 4) - w0 + 2;
-        for (int w = tid; w < nw; w += 256) { LB[w] = rw[w0 + w]; if (HASN) NB[w] = rn ? rn[w0 + w] : 0u; }
+        for (int w = tid; w < nw; w += K1_THREADS) { LB[w] = rw[w0 + w]; if (HASN) NB[w] = rn ? rn[w0 + w] : 0u; }
         b_base = w0 << 4;
     }
     if (read_maxlen && tid == 0) atomicMax(&read_maxlen[r], (uint32_t)ctl[2]);     // longest allele any cell of this read uses
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
     while (cur < n_act) {
         const int tag = __builtin_amdgcn_readfirstlane(meta[cur * 4 + 0]);
         const int c_alen = __builtin_amdgcn_readfirstlane(meta[cur * 4 + 1]), c_kb = __builtin_amdgcn_readfirstlane(meta[cur * 4 + 2]);
-        const uint32_t a = a_first + (uint32_t)(tag & 0xFF);
+        const uint32_t a = a_first + (uint32_t)(tag & 0xFFFF);
         const int nw = ((c_alen + 15) >> 4) + 2;
         const bool fast = nw <= K1_PRE * SP_WAVE;
         uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void k1_cells_kernel(SeqSetView alleles, SeqSe
         spw::wave_lds_sync();
         const int nxt = grab();
         if (nxt < n_act) fetch(nxt);
-        int c_cap = tag >> 8;
+        int c_cap = tag >> 16;
         if (bound) c_cap = k1_dyn_cap(my_bound, c_alen, c_cap);
         c_cap = __builtin_amdgcn_readfirstlane(c_cap);
         uint32_t res = SP_CELL_NONE;
@@ -655,7 +660,7 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
     // cells: one shared read window + four allele slots
     const int b_words = (reads->max_len + 15) / 16 + 4;
     const int a_words = (db->dna_fwd->max_len + 15) / 16 + 4;
-    const size_t cells_lds = (size_t)(8 + 4 * K1_CHUNK + (hasn ? 2 : 1) * (b_words + 4 * a_words)) * 4;
+    const size_t cells_lds = (size_t)(32 + 4 * K1_CHUNK + (hasn ? 2 : 1) * (b_words + K1_WAVES * a_words)) * 4;
     if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
     // exact branch-and-bound is switched off when the caller wants the full cell matrix
     unsigned long long* d_bound = nullptr;
@@ -689,11 +694,11 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
             ProfScope ps(ctx, pass == 0 ? "k1_cells" : "k1_cells_deep", (uint64_t)n_open * NA);
             if (hasn) {
                 (void)hipFuncSetAttribute((const void*)k1_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
-                hipLaunchKernelGGL(k1_cells_kernel<true>, dim3(n_open * n_chunks), dim3(256), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
+                hipLaunchKernelGGL(k1_cells_kernel<true>, dim3(n_open * n_chunks), dim3(K1_THREADS), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
                                    db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, pass_cap, b_words, a_words);
             } else {
                 (void)hipFuncSetAttribute((const void*)k1_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
-                hipLaunchKernelGGL(k1_cells_kernel<false>, dim3(n_open * n_chunks), dim3(256), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
+                hipLaunchKernelGGL(k1_cells_kernel<false>, dim3(n_open * n_chunks), dim3(K1_THREADS), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
                                    db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, pass_cap, b_words, a_words);
             }
             if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_cells launch failed");
