@@ -13,10 +13,12 @@
 __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexView KA, SeqSetView B,
                                                         const uint32_t* __restrict__ a_idx, const uint32_t* __restrict__ b_idx,
                                                         uint64_t n_pairs, int32_t* __restrict__ diag_out, int32_t* __restrict__ votes_out,
-                                                        int bins_cap, int topk) {
-    extern __shared__ uint32_t lds[];                 // packed u16 vote bins, 2 per dword
+                                                        int bins_cap, int topk, int tab_cap) {
+    extern __shared__ uint32_t lds[];                 // [packed u16 vote bins, 2 per dword][A's sorted 16-mer codes][their positions]
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x;
+    uint32_t* tab_code = lds + ((bins_cap + 1) >> 1);
+    int32_t* tab_pos = reinterpret_cast<int32_t*>(tab_code + tab_cap);
     for (uint64_t p = blockIdx.x; p < n_pairs; p += gridDim.x) {
         const uint32_t a = a_idx[p], b = b_idx[p];
         const int m = A.len[a], n = B.len[b];
@@ -27,12 +29,15 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
         }
         const int nb32 = (nbins + 1) >> 1;
         for (int i = tid; i < nb32; i += 256) lds[i] = 0;
-        __syncthreads();
         const uint32_t* bw = B.words + B.word_off[b];
         const uint32_t* bn = B.nplane ? B.nplane + B.word_off[b] : nullptr;
         const uint64_t k0 = KA.off[a], k1 = KA.off[a + 1];
-        const uint32_t* kc = KA.code + k0; const int32_t* kp = KA.pos + k0;
         const int nk = (int)(k1 - k0);
+        // A's table moves to LDS once per pair: the binary search then runs at LDS latency instead of L2 latency
+        const bool in_lds = nk <= tab_cap;
+        if (in_lds) for (int i = tid; i < nk; i += 256) { tab_code[i] = KA.code[k0 + i]; tab_pos[i] = KA.pos[k0 + i]; }
+        const uint32_t* kc = in_lds ? tab_code : KA.code + k0; const int32_t* kp = in_lds ? tab_pos : KA.pos + k0;
+        __syncthreads();
         for (int j = tid; j + SP_KMER <= n; j += 256) {
             const int w = j >> 4; const uint32_t sh = (uint32_t)((j & 15) << 1);
             if (bn && __builtin_amdgcn_alignbit(bn[w + 1], bn[w], sh)) continue;
@@ -197,11 +202,15 @@ int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     int bins_cap = A->max_len + B->max_len + 1;
     size_t lds_bytes = (size_t)((bins_cap + 1) / 2) * 4;
     if (lds_bytes > 160 * 1024 - 64) return sp_fail(ctx, SP_ERR_TOO_LONG, "anchor: sequences too long for the LDS vote histogram");
+    // A's 16-mer table rides along in LDS when it fits (8 bytes per k-mer)
+    int tab_cap = A->max_len;
+    if (lds_bytes + (size_t)tab_cap * 8 > 160 * 1024 - 64) tab_cap = 0;
+    lds_bytes += (size_t)tab_cap * 8;
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sp_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     uint64_t grid = std::min<uint64_t>(n_pairs, (uint64_t)ctx->num_cus * 8);
     ProfScope ps(ctx, "anchor", n_pairs);
     hipLaunchKernelGGL(sp_anchor_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, ctx->stream,
-                       A->view(), A->kview(), B->view(), d_a_idx, d_b_idx, n_pairs, d_diag, d_votes, bins_cap, topk);
+                       A->view(), A->kview(), B->view(), d_a_idx, d_b_idx, n_pairs, d_diag, d_votes, bins_cap, topk, tab_cap);
     SP_HIP_CHECK(ctx, hipGetLastError());
     return SP_OK;
 }

@@ -765,25 +765,30 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
     if (rc != SP_OK) return rc;
     if ((rc = sp_seqset_build_index(ctx, cons)) != SP_OK) { sp_seqset_free(cons); return rc; }
     const uint32_t stride = SP_MAX_ED;
-    uint32_t* d_idx = dev_copy(idx);
-    std::vector<uint32_t> lvl(n);
-    uint32_t *d_l0 = nullptr, *d_l1 = nullptr; int32_t *d_diag = nullptr, *d_votes = nullptr, *d_best = nullptr, *d_stats = nullptr;
-    CellDesc* d_cells = nullptr; sp_aln* d_alns = nullptr; uint32_t* d_ev = nullptr; K2Level* d_lv = nullptr;
-    std::fill(lvl.begin(), lvl.end(), 0u); d_l0 = dev_copy(lvl);
-    std::fill(lvl.begin(), lvl.end(), 1u); d_l1 = dev_copy(lvl);
-    if (!d_idx || !d_l0 || !d_l1 || hipMalloc(&d_diag, (size_t)n * 4) != hipSuccess || hipMalloc(&d_votes, (size_t)n * 4) != hipSuccess ||
-        hipMalloc(&d_best, 4) != hipSuccess || hipMalloc(&d_cells, (size_t)n * sizeof(CellDesc)) != hipSuccess ||
-        hipMalloc(&d_alns, (size_t)2 * n * sizeof(sp_aln)) != hipSuccess || hipMalloc(&d_ev, (size_t)2 * n * stride * 4) != hipSuccess ||
-        hipMalloc(&d_lv, (size_t)2 * n * sizeof(K2Level)) != hipSuccess ||
-        (stats && hipMalloc(&d_stats, (size_t)db->n_alleles * 6 * 4) != hipSuccess))
+    std::vector<uint32_t> lvl0(n, 0u), lvl1(n, 1u);
+    uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "k2_idx", (size_t)n * 4);
+    uint32_t* d_l0 = (uint32_t*)sp_pool(ctx, "k2_l0", (size_t)n * 4); uint32_t* d_l1 = (uint32_t*)sp_pool(ctx, "k2_l1", (size_t)n * 4);
+    int32_t* d_diag = (int32_t*)sp_pool(ctx, "k2_diag", (size_t)n * 4); int32_t* d_votes = (int32_t*)sp_pool(ctx, "k2_votes", (size_t)n * 4);
+    int32_t* d_best = (int32_t*)sp_pool(ctx, "k2_best", 4);
+    int32_t* d_stats = stats ? (int32_t*)sp_pool(ctx, "k2_stats", (size_t)db->n_alleles * 6 * 4) : nullptr;
+    CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k2_cells", (size_t)n * sizeof(CellDesc));
+    sp_aln* d_alns = (sp_aln*)sp_pool(ctx, "k2_alns", (size_t)2 * n * sizeof(sp_aln));
+    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "k2_ev", (size_t)2 * n * stride * 4);
+    K2Level* d_lv = (K2Level*)sp_pool(ctx, "k2_lv", (size_t)2 * n * sizeof(K2Level));
+    if (!d_idx || !d_l0 || !d_l1 || !d_diag || !d_votes || !d_best || !d_cells || !d_alns || !d_ev || !d_lv || (stats && !d_stats))
         rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus buffers");
+    else {
+        (void)hipMemcpyAsync(d_idx, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(d_l0, lvl0.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(d_l1, lvl1.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     const unsigned tb = 256, nb = (n + tb - 1) / tb;
     for (int L = 0; L < 2 && rc == SP_OK; ++L) {
         const sp_seqset* aset = L == 0 ? db->cdna_gene : db->dna_gene;
         rc = sp_launch_anchor(ctx, cons, aset, L == 0 ? d_l0 : d_l1, d_idx, n, d_diag, d_votes);
         if (rc != SP_OK) break;
         hipLaunchKernelGGL(k2_build_cells_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_idx, n, (uint32_t)L, d_diag, d_votes, aset->d_len, d_cells);
-        (void)hipMemsetAsync(d_ev + (size_t)L * n * stride, 0, (size_t)n * stride * 4, ctx->stream);
         rc = sp_launch_cells(ctx, aset, cons, d_cells, n, d_alns + (size_t)L * n, d_ev + (size_t)L * n * stride, stride, L == 0 ? "k2_cells_cdna" : "k2_cells_dna");
         if (rc != SP_OK) break;
         hipLaunchKernelGGL(k2_levels_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_alns + (size_t)L * n, n, d_lv + (size_t)L * n);
@@ -804,8 +809,6 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("score_consensus: ") + hipGetErrorString(e));
         else best->best_allele = b >= 0 ? (int32_t)idx[b] : -1;
     }
-    (void)hipFree(d_idx); (void)hipFree(d_l0); (void)hipFree(d_l1); (void)hipFree(d_diag); (void)hipFree(d_votes); (void)hipFree(d_best);
-    (void)hipFree(d_cells); (void)hipFree(d_alns); (void)hipFree(d_ev); (void)hipFree(d_lv); (void)hipFree(d_stats);
     sp_seqset_free(cons);
     return rc;
 }
