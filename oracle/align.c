@@ -76,11 +76,20 @@ int osp_anchor_topk(const uint8_t* A, int m, const uint8_t* B, int n, int k, int
         int best = 0, bestb = -1;
         for (int b = 0; b < nbins; ++b) if (votes[b] > best) { best = votes[b]; bestb = b; }  /* ties: smallest d */
         if (bestb < 0) break;
-        diags[found] = bestb - m; votes_out[found] = best; ++found;
-        int lo = bestb - OSP_PEAK_SUPPRESS, hi = bestb + OSP_PEAK_SUPPRESS;
-        if (lo < 0) lo = 0;
-        if (hi > nbins - 1) hi = nbins - 1;
-        for (int b = lo; b <= hi; ++b) votes[b] = 0;
+        /* a long indel splits the votes over two diagonals: centre the band between the outermost diagonals within
+         * +-OSP_PEAK_SPREAD of the peak that still hold >= max(2, peak/8) votes */
+        int thr = best / 8 > 2 ? best / 8 : 2;
+        int lo = bestb, hi = bestb;
+        for (int b = bestb - OSP_PEAK_SPREAD; b <= bestb + OSP_PEAK_SPREAD; ++b) {
+            if (b < 0 || b >= nbins || votes[b] < thr) continue;
+            if (b < lo) lo = b;
+            if (b > hi) hi = b;
+        }
+        diags[found] = ((lo + hi) >> 1) - m; votes_out[found] = best; ++found;
+        int slo = bestb - OSP_PEAK_SUPPRESS, shi = bestb + OSP_PEAK_SUPPRESS;
+        if (slo < 0) slo = 0;
+        if (shi > nbins - 1) shi = nbins - 1;
+        for (int b = slo; b <= shi; ++b) votes[b] = 0;
     }
     free(ta); free(tb); free(votes);
     return found;

@@ -45,6 +45,7 @@ extern "C" {
 #define OSP_KMER      16          /* anchor k-mer length                                */
 #define OSP_MAXOCC    4           /* k-mers occurring more often in the indexed side are ignored */
 #define OSP_NEG       (-(1 << 28))
+#define OSP_PEAK_SPREAD   48       /* anchor = midpoint of the strongly voted diagonals within +-48 of the peak    */
 #define OSP_PEAK_SUPPRESS 128      /* top-K anchors: bins within +-128 diagonals of a chosen peak are cleared   */
 
 typedef struct {

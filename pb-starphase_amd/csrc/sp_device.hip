@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
                                                         int bins_cap, int topk, int tab_cap) {
     extern __shared__ uint32_t lds[];                 // [packed u16 vote bins, 2 per dword][A's sorted 16-mer codes][their positions]
     __shared__ unsigned long long red[4];
+    __shared__ int spread[2];
     const int tid = threadIdx.x;
     uint32_t* tab_code = lds + ((bins_cap + 1) >> 1);
     int32_t* tab_pos = reinterpret_cast<int32_t*>(tab_code + tab_cap);
@@ -71,7 +72,17 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
             for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
             const int v = (int)(best >> 32);
             const int bin = 0x7FFFFFFF - (int)(best & 0xFFFFFFFFu);
-            if (tid == 0) { diag_out[p * topk + round] = v > 0 ? bin - m : 0; votes_out[p * topk + round] = v; }
+            // a long indel splits the votes over two diagonals: centre the band between the outermost diagonals within
+            // +-SP_PEAK_SPREAD of the peak that still hold >= max(2, peak/8) votes
+            if (tid == 0) { spread[0] = bin; spread[1] = bin; }
+            __syncthreads();
+            if (v > 0 && tid <= 2 * SP_PEAK_SPREAD) {
+                const int b2 = bin - SP_PEAK_SPREAD + tid;
+                const int thr = v / 8 > 2 ? v / 8 : 2;
+                if (b2 >= 0 && b2 < nbins && (int)((lds[b2 >> 1] >> ((b2 & 1) << 4)) & 0xFFFFu) >= thr) { atomicMin(&spread[0], b2); atomicMax(&spread[1], b2); }
+            }
+            __syncthreads();
+            if (tid == 0) { diag_out[p * topk + round] = v > 0 ? ((spread[0] + spread[1]) >> 1) - m : 0; votes_out[p * topk + round] = v; }
             __syncthreads();
             if (v == 0) {                                   // nothing left: remaining slots are empty
                 if (tid == 0) for (int k2 = round + 1; k2 < topk; ++k2) { diag_out[p * topk + k2] = 0; votes_out[p * topk + k2] = 0; }

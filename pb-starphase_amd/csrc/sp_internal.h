@@ -11,6 +11,7 @@
 #define SP_WAVE       64
 #define SP_MAXOCC     4
 #define SP_CELL_NONE  0xFFFFFFFFu
+#define SP_PEAK_SPREAD   48      // anchor = midpoint of the strongly voted diagonals within +-48 of the peak
 #define SP_PEAK_SUPPRESS 128     // top-K anchors: bins within +-128 diagonals of a chosen peak are cleared
 
 // ---------------------------------------------------------------- device views

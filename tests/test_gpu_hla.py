@@ -129,3 +129,50 @@ def test_type_consensus(oracle, pkg, gpu_ctx, small):
     assert db.type_consensus(0, "")[0:2] == (-1, 0)
     junk = "".join(rng.choice(list("ACGT"), 3000))
     assert db.type_consensus(0, junk)[0] == -1
+
+
+def test_k1_full_database_pruned_equals_exhaustive(oracle, pkg, gpu_ctx):
+    """BASELINE configs[1] shape at reduced read count: the full bundled IMGT/HLA database (18,461 alleles), 240 synthetic HiFi
+    reads.  Size-independent properties: the production (branch-and-bound + iterative deepening) mode must reproduce the
+    exhaustive mode byte for byte, every read must land in its gene, and a sample of reads is checked against the oracle."""
+    import ctypes as C
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture()
+    db = fx.make_db(pkg, gpu_ctx)
+    wl = synth.Config2Workload(fx, n_reads=240, seed=77)
+    rng = np.random.default_rng(5)
+    reads = list(wl.reads)
+    for i in (3, 50, 101):                                     # noisy reads that need the deeper passes
+        reads[i] = synth.mutate(rng, reads[i], 25, 12, 12)
+    rs = gpu_ctx.upload(reads)
+    full, cells = db.realign_reads(rs, cells=True)
+    for _ in range(2):
+        assert db.realign_reads(rs).tobytes() == full.tobytes()
+    assert all(full[r]["gene"] == wl.read_truth[r][0] for r in range(len(reads)) if full[r]["status"] == 0)
+    assert (full["status"] == 0).mean() > 0.97
+    # oracle spot check (whole-read K1 search in C)
+    L = oracle.L
+    L.osp_hla_k1_read.restype = C.c_int32
+    refs = [oracle.encode(s) for s in fx.gene_ref]
+    enc = [oracle.encode(fx.dna_fwd(a)) if fx.dna[a] else np.zeros(0, np.uint8) for a in range(len(fx.ids))]
+    off = np.full(len(fx.ids), -2 ** 31, np.int32)
+    for a in range(len(fx.ids)):
+        if len(enc[a]):
+            d, v = oracle.anchor(refs[int(fx.gene_of[a])], enc[a])
+            if v >= 16:
+                off[a] = d
+    ref_ptr = (C.c_void_p * len(refs))(*[r.ctypes.data for r in refs])
+    ref_len = np.array([len(r) for r in refs], np.int32)
+    al_ptr = (C.c_void_p * len(enc))(*[(e.ctypes.data if len(e) else None) for e in enc])
+    al_len = np.array([len(e) for e in enc], np.int32)
+    gene_of = fx.gene_of.astype(np.int32)
+    for r in (0, 3, 17, 50, 199):
+        re = oracle.encode(reads[r])
+        ecell = np.zeros(len(fx.ids), np.uint32)
+        nrun = C.c_int64(0)
+        b = L.osp_hla_k1_read(re.ctypes.data_as(C.c_void_p), len(re), len(refs), ref_ptr, ref_len.ctypes.data_as(C.c_void_p), len(enc), al_ptr,
+                              al_len.ctypes.data_as(C.c_void_p), gene_of.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                              ecell.ctypes.data_as(C.c_void_p), C.byref(nrun))
+        assert b == full[r]["best_allele"]
+        assert (cells[r] == ecell).all()
+    db.close()
