@@ -38,6 +38,8 @@ enum {
     SP_ERR_HIP             = 3,
     SP_ERR_OUT_OF_MEMORY   = 4,
     SP_ERR_TOO_LONG        = 5,   /* sequence longer than the kernels support (65,535 bases per window) */
+    SP_ERR_CAPACITY        = 6,   /* an output array is too small: call again with more room */
+    SP_ERR_CHAIN_COLLAPSE  = 7,   /* the reference panics here ("chain collapse", src/cyp2d6/caller.rs:531-533) */
     SP_ERR_NO_CHAINING_HEAD = 16, /* CallerError::NoChainingHead  (src/cyp2d6/chaining.rs:321-323) */
     SP_ERR_NO_CHAINS_FOUND  = 17, /* CallerError::NoChainsFound   (src/cyp2d6/chaining.rs:393-396) */
     SP_ERR_NO_SCORE_PAIRS   = 18  /* CallerError::NoScorePairs    (src/cyp2d6/chaining.rs:559-562) */
@@ -340,6 +342,23 @@ uint64_t sp_hpc(const char* seq, uint64_t len, char* out);
 uint32_t sp_cyp_chain_to_hap(const int32_t* chain, uint32_t n, const int32_t* hap_type, const char* const* hap_subtype,
                              uint32_t n_translate, const char* const* translate_key, const char* const* translate_val,
                              int32_t detail, char* out, uint32_t cap);
+
+/* chain building between K4 and K5 (src/cyp2d6/caller.rs:429-583): per read, the cartesian product of the minimum-edit
+ * consensuses of its kept segments (:461-491); best_allele_mapping_counts (:478-481); reads without a chain are dropped
+ * (:494-517); chains that use a consensus nothing maps to uniquely are removed (:521-538) and those consensuses are flagged
+ * for mark_false_allele() (:574-583).  Segments of read r = [read_seg_off[r], read_seg_off[r+1]); ed / kept as written by
+ * sp_cyp_weight_segments.  Outputs feed sp_chain_problem directly:
+ *   read_index[k] (k < info->n_reads)  input index of the k-th recorded read (input order = BTreeMap order of the caller)
+ *   read_chain_off[n_reads+1], chain_off[chain_cap+1], chain_items[item_cap]   obs_chains
+ *   read_w_off[n_reads+1], w_seg[n_segments]   chain_scores rows as segment indices into ed / ov
+ *   unique_counts[n_haps], false_allele[n_haps]
+ * Returns SP_OK, SP_ERR_CAPACITY (info holds the sizes needed) or SP_ERR_CHAIN_COLLAPSE. */
+typedef struct { uint32_t n_reads, n_chains, n_items, n_rows; } sp_chain_build_info;
+int32_t sp_cyp_build_chains(uint32_t n_haps, const int32_t* hap_type, uint32_t n_reads, const uint32_t* read_seg_off,
+                            const uint64_t* ed, const uint8_t* kept,
+                            uint32_t* read_index, uint32_t* read_chain_off, uint32_t* chain_off, uint32_t chain_cap,
+                            uint32_t* chain_items, uint32_t item_cap, uint32_t* read_w_off, uint32_t* w_seg,
+                            uint64_t* unique_counts, uint8_t* false_allele, sp_chain_build_info* info);
 
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */

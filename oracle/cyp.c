@@ -487,3 +487,79 @@ void osp_cyp_score_alleles(int n_variants, int n_alleles, const uint8_t* hap_mat
     }
     *best_vi = bv; *best_all = ba;
 }
+
+
+/* ------------------------------------------------------------------ chain building (src/cyp2d6/caller.rs:429-583)
+ * Follows the reference loop literally: putative chains are extended segment by segment with every consensus at the
+ * minimum edit distance (:461-484); a unique minimum adds one to that consensus' count per chain being extended (:478-481);
+ * reads that end with no chain are not recorded (:494-517); chains touching a consensus with no unique support are
+ * removed afterwards (:521-538); consensuses with no unique support become FalseAllele (:574-583). */
+typedef struct { uint32_t n, cap; uint32_t* len; uint32_t** v; } chainset;
+static void cs_push(chainset* c, const uint32_t* base, uint32_t n, uint32_t extra) {
+    if (c->n == c->cap) { c->cap = c->cap ? 2 * c->cap : 8; c->len = realloc(c->len, c->cap * sizeof *c->len); c->v = realloc(c->v, c->cap * sizeof *c->v); }
+    c->v[c->n] = malloc((n + 1) * sizeof(uint32_t));
+    if (n) memcpy(c->v[c->n], base, n * sizeof(uint32_t));
+    c->v[c->n][n] = extra; c->len[c->n] = n + 1; c->n++;
+}
+static void cs_free(chainset* c) { for (uint32_t i = 0; i < c->n; ++i) free(c->v[i]); free(c->len); free(c->v); memset(c, 0, sizeof *c); }
+
+int osp_cyp_build_chains(int n_haps, const int32_t* hap_type, int n_reads, const uint32_t* read_seg_off, const uint64_t* ed,
+                         const uint8_t* kept, uint32_t* read_index, uint32_t* n_kept, uint32_t* read_chain_off, uint32_t* chain_off,
+                         uint32_t chain_cap, uint32_t* chain_items, uint32_t item_cap, uint32_t* read_w_off, uint32_t* w_seg,
+                         uint64_t* unique_counts, uint8_t* false_allele) {
+    chainset* per_read = calloc((size_t)n_reads, sizeof *per_read);
+    uint32_t nk = 0, nrow = 0;
+    int rc = 0;
+    for (int h = 0; h < n_haps; ++h) unique_counts[h] = 0;
+    read_w_off[0] = 0;
+    for (int r = 0; r < n_reads; ++r) {
+        if (read_seg_off[r] == read_seg_off[r + 1]) continue;                       /* :437-439 */
+        chainset cur = {0};
+        uint32_t none = 0;
+        cs_push(&cur, &none, 0, 0); cur.len[0] = 0;                                  /* vec![vec![]] */
+        const uint32_t row0 = nrow;
+        for (uint32_t sgm = read_seg_off[r]; sgm < read_seg_off[r + 1]; ++sgm) {
+            if (!kept[sgm]) continue;                                                /* :451-460 */
+            const uint64_t* w = ed + (size_t)sgm * n_haps;
+            uint64_t mn = w[0]; int nmin = 0;
+            for (int c = 1; c < n_haps; ++c) if (w[c] < mn) mn = w[c];
+            for (int c = 0; c < n_haps; ++c) nmin += w[c] == mn;
+            chainset nxt = {0};
+            for (uint32_t pc = 0; pc < cur.n; ++pc)
+                for (int c = 0; c < n_haps; ++c)
+                    if (w[c] == mn) {
+                        cs_push(&nxt, cur.v[pc], cur.len[pc], (uint32_t)c);
+                        if (nmin == 1) unique_counts[c] += 1;
+                    }
+            cs_free(&cur); cur = nxt;
+            w_seg[nrow++] = sgm;
+        }
+        if (cur.n == 0 || (cur.n == 1 && cur.len[0] == 0)) { cs_free(&cur); nrow = row0; continue; }   /* :494-496: nothing recorded */
+        per_read[r] = cur;
+        read_index[nk++] = (uint32_t)r;
+        read_w_off[nk] = nrow;
+    }
+    /* unique-support filter (:521-538) and flattening */
+    uint32_t nc = 0, ni = 0;
+    read_chain_off[0] = 0; chain_off[0] = 0;
+    for (uint32_t k = 0; k < nk && rc == 0; ++k) {
+        chainset* c = &per_read[read_index[k]];
+        uint32_t kept_chains = 0;
+        for (uint32_t i = 0; i < c->n && rc == 0; ++i) {
+            int ok = 1;
+            for (uint32_t x = 0; x < c->len[i]; ++x) if (unique_counts[c->v[i][x]] == 0) ok = 0;
+            if (!ok) continue;
+            if (nc + 1 > chain_cap || ni + c->len[i] > item_cap) { rc = 1; break; }
+            memcpy(chain_items + ni, c->v[i], c->len[i] * sizeof(uint32_t));
+            ni += c->len[i]; chain_off[++nc] = ni; ++kept_chains;
+        }
+        if (rc == 0 && kept_chains == 0) rc = 2;                                      /* panic!("chain collapse") */
+        read_chain_off[k + 1] = nc;
+    }
+    for (int h = 0; h < n_haps; ++h)
+        false_allele[h] = unique_counts[h] == 0 && hap_type[h] != OSP_UNKNOWN && hap_type[h] != OSP_FALSE_ALLELE;
+    for (int r = 0; r < n_reads; ++r) cs_free(&per_read[r]);
+    free(per_read);
+    *n_kept = nk;
+    return rc;
+}

@@ -64,6 +64,18 @@ int  osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, co
 void osp_cyp_score_alleles(int n_variants, int n_alleles, const uint8_t* hap_matrix, const uint8_t* is_vi, const uint8_t* states,
                            uint32_t* best_vi, uint32_t* best_all, uint8_t* tie);
 
+/* chain building (src/cyp2d6/caller.rs:429-583).  Segments of read r = [read_seg_off[r], read_seg_off[r+1]) in region order;
+ * ed = [segment][n_haps] from weight_sequence, kept[segment] = 0 when weight_sequence returned the empty vector.
+ * Outputs (all caller-sized; return 0 ok, 1 capacity, 2 "chain collapse" panic):
+ *   read_index[k]   the reads that enter qname_chains, in input (BTreeMap) order; *n_kept of them
+ *   read_chain_off / chain_off / chain_items   their chain sets after the unique-support filter
+ *   read_w_off / w_seg   rows of qname_chain_scores as segment indices
+ *   unique_counts[h]     best_allele_mapping_counts;  false_allele[h] = 1 when the region gets mark_false_allele() */
+int osp_cyp_build_chains(int n_haps, const int32_t* hap_type, int n_reads, const uint32_t* read_seg_off, const uint64_t* ed,
+                         const uint8_t* kept, uint32_t* read_index, uint32_t* n_kept, uint32_t* read_chain_off, uint32_t* chain_off,
+                         uint32_t chain_cap, uint32_t* chain_items, uint32_t item_cap, uint32_t* read_w_off, uint32_t* w_seg,
+                         uint64_t* unique_counts, uint8_t* false_allele);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,8 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <vector>
+#include <algorithm>
 
 namespace {
 // statrs::function::factorial::ln_factorial: products up to 170!, ln_gamma beyond
@@ -115,6 +117,76 @@ uint32_t sp_cyp_chain_to_hap(const int32_t* chain, uint32_t n, const int32_t* ha
     flush();
     if (out && cap) { const size_t k = std::min<size_t>(cap - 1, res.size()); std::memcpy(out, res.data(), k); out[k] = '\0'; }
     return (uint32_t)res.size();
+}
+
+int32_t sp_cyp_build_chains(uint32_t n_haps, const int32_t* hap_type, uint32_t n_reads, const uint32_t* read_seg_off,
+                            const uint64_t* ed, const uint8_t* kept,
+                            uint32_t* read_index, uint32_t* read_chain_off, uint32_t* chain_off, uint32_t chain_cap,
+                            uint32_t* chain_items, uint32_t item_cap, uint32_t* read_w_off, uint32_t* w_seg,
+                            uint64_t* unique_counts, uint8_t* false_allele, sp_chain_build_info* info) {
+    if (!hap_type || !read_seg_off || !ed || !kept || !read_index || !read_chain_off || !chain_off || !chain_items || !read_w_off ||
+        !w_seg || !unique_counts || !false_allele || !info || n_haps == 0) return SP_ERR_INVALID_ARG;
+    // pass 1: the minimum-edit choice list of every kept segment, and the unique-support counts.  A unique minimum is counted
+    // once per chain being extended (caller.rs:470-483), i.e. by the product of the choice counts of the read's earlier segments.
+    std::vector<uint32_t> choice_off(1, 0), choices;          // per recorded row
+    std::vector<uint32_t> rec_read, rec_row0, rec_rows;
+    std::fill(unique_counts, unique_counts + n_haps, 0ull);
+    uint32_t n_rows = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const uint32_t row0 = n_rows;
+        const size_t cmark = choices.size();
+        std::vector<uint64_t> pending(n_haps, 0);             // counts are committed even if the read ends up unrecorded (as in the reference)
+        uint64_t width = 1;
+        for (uint32_t sg = read_seg_off[r]; sg < read_seg_off[r + 1]; ++sg) {
+            if (!kept[sg]) continue;
+            const uint64_t* w = ed + (size_t)sg * n_haps;
+            const uint64_t mn = *std::min_element(w, w + n_haps);
+            const size_t before = choices.size();
+            for (uint32_t c = 0; c < n_haps; ++c) if (w[c] == mn) choices.push_back(c);
+            const uint32_t k = (uint32_t)(choices.size() - before);
+            if (k == 1) pending[choices.back()] += width;
+            width *= k;
+            if (width > (1ull << 31)) return SP_ERR_CAPACITY;
+            choice_off.push_back((uint32_t)choices.size());
+            w_seg[n_rows++] = sg;
+        }
+        for (uint32_t c = 0; c < n_haps; ++c) unique_counts[c] += pending[c];
+        if (n_rows == row0) { choices.resize(cmark); continue; }   // no segment or none kept: the read is not recorded
+        rec_read.push_back(r); rec_row0.push_back(row0); rec_rows.push_back(n_rows - row0);
+    }
+    // pass 2: enumerate each read's chains as a mixed-radix counter (first segment most significant = the reference's order)
+    uint64_t nc = 0, ni = 0; bool fits = true, collapse = false;
+    read_chain_off[0] = 0; read_w_off[0] = 0;
+    if (chain_cap) chain_off[0] = 0;
+    for (size_t k = 0; k < rec_read.size(); ++k) {
+        const uint32_t row0 = rec_row0[k], m = rec_rows[k];
+        read_index[k] = rec_read[k];
+        read_w_off[k + 1] = row0 + m;
+        bool supported = true;                                  // segments with several minima keep only supported consensuses
+        std::vector<std::vector<uint32_t>> opts(m);
+        for (uint32_t x = 0; x < m; ++x) {
+            for (uint32_t o = choice_off[row0 + x]; o < choice_off[row0 + x + 1]; ++o) if (unique_counts[choices[o]] > 0) opts[x].push_back(choices[o]);
+            if (opts[x].empty()) supported = false;
+        }
+        if (!supported) { collapse = true; read_chain_off[k + 1] = (uint32_t)nc; continue; }
+        std::vector<uint32_t> digit(m, 0);
+        for (;;) {
+            if (fits && nc + 1 <= chain_cap && ni + m <= item_cap) {
+                for (uint32_t x = 0; x < m; ++x) chain_items[ni + x] = opts[x][digit[x]];
+                chain_off[nc + 1] = (uint32_t)(ni + m);
+            } else fits = false;
+            ++nc; ni += m;
+            int x = (int)m - 1;
+            while (x >= 0 && ++digit[x] == opts[x].size()) digit[x--] = 0;
+            if (x < 0) break;
+        }
+        read_chain_off[k + 1] = (uint32_t)nc;
+    }
+    for (uint32_t h = 0; h < n_haps; ++h)
+        false_allele[h] = unique_counts[h] == 0 && hap_type[h] != SP_CYP_UNKNOWN && hap_type[h] != SP_CYP_FALSE_ALLELE;
+    info->n_reads = (uint32_t)rec_read.size(); info->n_chains = (uint32_t)nc; info->n_items = (uint32_t)ni; info->n_rows = n_rows;
+    if (collapse) return SP_ERR_CHAIN_COLLAPSE;
+    return fits ? SP_OK : SP_ERR_CAPACITY;
 }
 
 } // extern "C"

@@ -145,6 +145,7 @@ def lib():
         "sp_hpc_pos": (u64, [C.c_char_p, u64, u64]),
         "sp_hpc": (u64, [C.c_char_p, u64, C.c_char_p]),
         "sp_cyp_chain_to_hap": (u32, [vp, u32, vp, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i32, C.c_char_p, u32]),
+        "sp_cyp_build_chains": (i32, [u32, vp, u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, vp, vp, vp]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -311,6 +312,38 @@ class Context:
         ms, launches, cells = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         self.check(lib().sp_profile_get(self._h, name.encode(), C.byref(ms), C.byref(launches), C.byref(cells)))
         return ms.value, launches.value, cells.value
+
+
+def build_chains(hap_type, read_seg_off, ed, kept):
+    """sp_cyp_build_chains (host routine).  ed: [segments][n_haps] uint64, kept: [segments] uint8.
+    Returns dict(read_index, chains (list per recorded read of lists), w_rows (list per read of segment indices),
+    unique_counts, false_allele); raises StarphaseError(7) on the reference's 'chain collapse' panic."""
+    hap_type = np.ascontiguousarray(hap_type, np.int32)
+    read_seg_off = np.ascontiguousarray(read_seg_off, np.uint32)
+    ed = np.ascontiguousarray(ed, np.uint64)
+    kept = np.ascontiguousarray(kept, np.uint8)
+    n_haps, n_reads, n_seg = len(hap_type), len(read_seg_off) - 1, len(kept)
+    chain_cap, item_cap = max(16, 4 * n_reads), max(64, 8 * max(1, n_seg))
+    info = (C.c_uint32 * 4)()
+    while True:
+        read_index = np.zeros(max(1, n_reads), np.uint32)
+        rco, rwo = np.zeros(n_reads + 1, np.uint32), np.zeros(n_reads + 1, np.uint32)
+        co, items = np.zeros(chain_cap + 1, np.uint32), np.zeros(item_cap, np.uint32)
+        w_seg = np.zeros(max(1, n_seg), np.uint32)
+        uniq, false_allele = np.zeros(n_haps, np.uint64), np.zeros(n_haps, np.uint8)
+        rc = lib().sp_cyp_build_chains(n_haps, _ptr(hap_type), n_reads, _ptr(read_seg_off), _ptr(ed), _ptr(kept), _ptr(read_index), _ptr(rco),
+                                       _ptr(co), chain_cap, _ptr(items), item_cap, _ptr(rwo), _ptr(w_seg), _ptr(uniq), _ptr(false_allele),
+                                       C.cast(info, C.c_void_p))
+        if rc == 6 and (info[1] > chain_cap or info[2] > item_cap):
+            chain_cap, item_cap = max(chain_cap, info[1]), max(item_cap, info[2])
+            continue
+        break
+    if rc != SP_OK:
+        raise StarphaseError(rc, "sp_cyp_build_chains")
+    nk = info[0]
+    chains = [[[int(x) for x in items[co[c]:co[c + 1]]] for c in range(rco[k], rco[k + 1])] for k in range(nk)]
+    rows = [[int(x) for x in w_seg[rwo[k]:rwo[k + 1]]] for k in range(nk)]
+    return dict(read_index=[int(x) for x in read_index[:nk]], chains=chains, w_rows=rows, unique_counts=uniq, false_allele=false_allele)
 
 
 class SeqSet:

@@ -368,3 +368,30 @@ def oracle_weight_sequence(oracle, seq, consensus, allowed):
     kept = L.osp_cyp_weight_sequence(s.ctypes.data_as(C.c_void_p), len(s), len(enc), ptrs, lens.ctypes.data_as(C.c_void_p),
                                      al.ctypes.data_as(C.c_void_p), ed.ctypes.data_as(C.c_void_p), ov.ctypes.data_as(C.c_void_p))
     return ed, ov, kept
+
+
+def oracle_build_chains(oracle, hap_type, read_seg_off, ed, kept):
+    """osp_cyp_build_chains -> same dict as pb_starphase_amd.ffi.build_chains; returns None on 'chain collapse'"""
+    hap_type = np.ascontiguousarray(hap_type, np.int32)
+    read_seg_off = np.ascontiguousarray(read_seg_off, np.uint32)
+    ed = np.ascontiguousarray(ed, np.uint64)
+    kept = np.ascontiguousarray(kept, np.uint8)
+    n_haps, n_reads, n_seg = len(hap_type), len(read_seg_off) - 1, len(kept)
+    chain_cap, item_cap = 1 << 16, 1 << 20
+    read_index = np.zeros(max(1, n_reads), np.uint32)
+    rco, rwo = np.zeros(n_reads + 1, np.uint32), np.zeros(n_reads + 1, np.uint32)
+    co, items = np.zeros(chain_cap + 1, np.uint32), np.zeros(item_cap, np.uint32)
+    w_seg = np.zeros(max(1, n_seg), np.uint32)
+    uniq, false_allele = np.zeros(n_haps, np.uint64), np.zeros(n_haps, np.uint8)
+    nk = C.c_uint32(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    oracle.L.osp_cyp_build_chains.restype = C.c_int
+    rc = oracle.L.osp_cyp_build_chains(n_haps, p(hap_type), n_reads, p(read_seg_off), p(ed), p(kept), p(read_index), C.byref(nk), p(rco), p(co),
+                                       C.c_uint32(chain_cap), p(items), C.c_uint32(item_cap), p(rwo), p(w_seg), p(uniq), p(false_allele))
+    if rc == 2:
+        return None
+    assert rc == 0
+    nk = nk.value
+    chains = [[[int(x) for x in items[co[c]:co[c + 1]]] for c in range(rco[k], rco[k + 1])] for k in range(nk)]
+    rows = [[int(x) for x in w_seg[rwo[k]:rwo[k + 1]]] for k in range(nk)]
+    return dict(read_index=[int(x) for x in read_index[:nk]], chains=chains, w_rows=rows, unique_counts=uniq, false_allele=false_allele)

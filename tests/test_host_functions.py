@@ -58,3 +58,106 @@ def test_chain_to_hap(pkg):
     assert hap([3, 1, 0], 1) == "*1.001 + *1.002"
     assert hap([3, 1, 0], 0) == "*1x2"
     assert hap([3, 4], 1) == "*1.002x2"
+
+
+def _py_build_chains(hap_type, read_seg_off, ed, kept):
+    """independent pure-Python statement of src/cyp2d6/caller.rs:429-583 (third opinion for the two C versions)"""
+    n_haps = len(hap_type)
+    uniq = [0] * n_haps
+    recorded = []
+    for r in range(len(read_seg_off) - 1):
+        segs = range(read_seg_off[r], read_seg_off[r + 1])
+        if len(segs) == 0:
+            continue
+        chains, rows = [[]], []
+        for sg in segs:
+            if not kept[sg]:
+                continue
+            w = [int(x) for x in ed[sg]]
+            mn = min(w)
+            nmin = w.count(mn)
+            nxt = []
+            for pc in chains:
+                for c in range(n_haps):
+                    if w[c] == mn:
+                        nxt.append(pc + [c])
+                        if nmin == 1:
+                            uniq[c] += 1
+            chains = nxt
+            rows.append(sg)
+        if chains == [[]]:
+            continue
+        recorded.append((r, chains, rows))
+    out = dict(read_index=[], chains=[], w_rows=[])
+    for r, chains, rows in recorded:
+        f = [c for c in chains if all(uniq[x] > 0 for x in c)]
+        if not f:
+            return None
+        out["read_index"].append(r); out["chains"].append(f); out["w_rows"].append(rows)
+    out["unique_counts"] = uniq
+    out["false_allele"] = [int(uniq[h] == 0 and hap_type[h] not in (0, 9)) for h in range(n_haps)]
+    return out
+
+
+def _same_chains(a, b):
+    assert a["read_index"] == b["read_index"] and a["chains"] == b["chains"] and a["w_rows"] == b["w_rows"]
+    assert [int(x) for x in a["unique_counts"]] == [int(x) for x in b["unique_counts"]]
+    assert [int(x) for x in a["false_allele"]] == [int(x) for x in b["false_allele"]]
+
+
+def test_build_chains_handmade(pkg, oracle):
+    """chain building, src/cyp2d6/caller.rs:429-583: ambiguity multiplies chains, a unique minimum is counted once per chain
+    being extended, unsupported consensuses drop out of ambiguous chains and become FalseAllele, dropped segments/reads"""
+    hap_type = [1, 2, 2, 3, 0]                     # REP6, D6, D6, link, Unknown
+    ed = np.array([[0, 9, 9, 9, 9],                # read 0: REP6 unique
+                   [9, 1, 1, 9, 9],                #          D6 ambiguous (haps 1 and 2)
+                   [9, 9, 9, 0, 9],                #          link unique -> counted twice (two chains being extended)
+                   [9, 0, 5, 9, 9],                # read 1: hap 1 unique
+                   [7, 7, 7, 7, 7],                # read 2: dropped segment (kept = 0) only -> read not recorded
+                   [9, 2, 9, 9, 9]], np.uint64)    # read 4: hap 1 unique
+    kept = np.array([1, 1, 1, 1, 0, 1], np.uint8)
+    seg_off = [0, 3, 4, 5, 5, 6]                   # read 3 has no segments at all
+    got = pkg.ffi.build_chains(hap_type, seg_off, ed, kept)
+    assert got["read_index"] == [0, 1, 4]
+    assert got["chains"] == [[[0, 1, 3]], [[1]], [[1]]]          # [0,2,3] removed: hap 2 has no unique support
+    assert got["w_rows"] == [[0, 1, 2], [3], [5]]
+    assert [int(x) for x in got["unique_counts"]] == [1, 2, 0, 2, 0]
+    assert [int(x) for x in got["false_allele"]] == [0, 0, 1, 0, 0]  # Unknown (hap 4) is never re-labelled
+    _same_chains(got, of.oracle_build_chains(oracle, hap_type, seg_off, ed, kept))
+    _same_chains(got, _py_build_chains(hap_type, seg_off, ed, kept))
+    # a read whose only candidate has no unique support anywhere: the reference panics ("chain collapse")
+    ed2 = np.array([[3, 3, 9, 9, 9]], np.uint64)
+    try:
+        pkg.ffi.build_chains(hap_type, [0, 1], ed2, np.ones(1, np.uint8))
+        raise AssertionError("expected SP_ERR_CHAIN_COLLAPSE")
+    except pkg.StarphaseError as e:
+        assert e.code == 7
+    assert of.oracle_build_chains(oracle, hap_type, [0, 1], ed2, np.ones(1, np.uint8)) is None
+
+
+def test_build_chains_random(pkg, oracle):
+    rng = np.random.default_rng(77)
+    n_ok = 0
+    for it in range(200):
+        n_haps = int(rng.integers(1, 9))
+        n_reads = int(rng.integers(0, 12))
+        nseg = rng.integers(0, 5, n_reads)
+        seg_off = np.concatenate([[0], np.cumsum(nseg)]).astype(np.uint32)
+        S = int(seg_off[-1])
+        ed = rng.integers(0, 4, (S, n_haps)).astype(np.uint64)
+        kept = (rng.random(S) < 0.85).astype(np.uint8)
+        hap_type = rng.integers(0, 10, n_haps).astype(np.int32)
+        exp = _py_build_chains([int(x) for x in hap_type], [int(x) for x in seg_off], ed, kept)
+        orc = of.oracle_build_chains(oracle, hap_type, seg_off, ed.reshape(-1), kept)
+        if exp is None:
+            assert orc is None
+            try:
+                pkg.ffi.build_chains(hap_type, seg_off, ed.reshape(-1), kept)
+                raise AssertionError("expected chain collapse")
+            except pkg.StarphaseError as e:
+                assert e.code == 7
+            continue
+        n_ok += 1
+        _same_chains(orc, exp)
+        _same_chains(pkg.ffi.build_chains(hap_type, seg_off, ed.reshape(-1), kept), exp)
+    assert n_ok > 50
