@@ -40,6 +40,7 @@ enum {
     SP_ERR_TOO_LONG        = 5,   /* sequence longer than the kernels support (65,535 bases per window) */
     SP_ERR_CAPACITY        = 6,   /* an output array is too small: call again with more room */
     SP_ERR_CHAIN_COLLAPSE  = 7,   /* the reference panics here ("chain collapse", src/cyp2d6/caller.rs:531-533) */
+    SP_ERR_BAD_VARIANT     = 8,   /* NormalizedVariant::new bails (src/data_types/normalized_variant.rs:45-52,66-84,160-168) */
     SP_ERR_NO_CHAINING_HEAD = 16, /* CallerError::NoChainingHead  (src/cyp2d6/chaining.rs:321-323) */
     SP_ERR_NO_CHAINS_FOUND  = 17, /* CallerError::NoChainsFound   (src/cyp2d6/chaining.rs:393-396) */
     SP_ERR_NO_SCORE_PAIRS   = 18  /* CallerError::NoScorePairs    (src/cyp2d6/chaining.rs:559-562) */
@@ -342,6 +343,17 @@ uint64_t sp_hpc(const char* seq, uint64_t len, char* out);
 uint32_t sp_cyp_chain_to_hap(const int32_t* chain, uint32_t n, const int32_t* hap_type, const char* const* hap_subtype,
                              uint32_t n_translate, const char* const* translate_key, const char* const* translate_val,
                              int32_t detail, char* out, uint32_t cap);
+
+/* NormalizedVariant::new (src/data_types/normalized_variant.rs:43-170) with parse_sequence (:262-279): CPIC allele syntax
+ * ("del", "ins..", "delins..", "XYZ(n)"), anchor base, suffix / prefix trimming, left shift along the reference.
+ * chrom_seq = the contig (NULL = no reference genome: no anchoring / shifting, as in the reference); position is 0-based.
+ * out_ref / out_alt hold cap bytes each.  SP_ERR_BAD_VARIANT for every condition on which the reference bails. */
+int32_t sp_variant_normalize(const char* chrom_seq, uint64_t chrom_len, uint64_t position, const char* ref_allele, const char* alt_allele,
+                             uint64_t* out_position, char* out_ref, char* out_alt, uint32_t cap);
+/* NormalizedVariant::multi_new (:174-214): IUPAC codes and "; " lists expand to several alternatives; is_none[i] = 1 where the
+ * alternative equals the reference allele (Option::None).  Outputs are strided by cap; returns the count in n_out. */
+int32_t sp_variant_multi_normalize(const char* chrom_seq, uint64_t chrom_len, uint64_t position, const char* ref_allele, const char* alt_allele,
+                                   uint32_t max_out, uint32_t* n_out, uint8_t* is_none, uint64_t* out_position, char* out_ref, char* out_alt, uint32_t cap);
 
 /* chain building between K4 and K5 (src/cyp2d6/caller.rs:429-583): per read, the cartesian product of the minimum-edit
  * consensuses of its kept segments (:461-491); best_allele_mapping_counts (:478-481); reads without a chain are dropped

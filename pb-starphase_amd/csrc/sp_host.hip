@@ -32,6 +32,24 @@ double normal_ln_pdf(double mean, double sd, double x) {
     return (-0.5 * d * d) - ln_sqrt_2pi - std::log(sd);
 }
 bool cyp2d(int t) { return t == SP_CYP_CYP2D6 || t == SP_CYP_CYP2D7 || t == SP_CYP_DELETION || t == SP_CYP_HYBRID; }
+// parse_sequence (normalized_variant.rs:262-279)
+std::string cpic_bases(const std::string& t) {
+    const size_t open = t.find('(');
+    if (open != std::string::npos && open > 0 && t.size() >= open + 3 && t.back() == ')' &&
+        std::all_of(t.begin(), t.begin() + open, [](char c) { return c >= 'A' && c <= 'Z'; }) &&
+        std::all_of(t.begin() + open + 1, t.end() - 1, [](char c) { return c >= '0' && c <= '9'; })) {
+        const unsigned long long count = std::strtoull(t.c_str() + open + 1, nullptr, 10);
+        std::string unit = t.substr(0, open), out;
+        if (count * unit.size() > (1u << 20)) return std::string(1, '?');          // refused later by the ACGT check
+        for (unsigned long long i = 0; i < count; ++i) out += unit;
+        return out;
+    }
+    if (t.rfind("delins", 0) == 0) return t.substr(6);
+    if (t.rfind("ins", 0) == 0) return t.substr(3);
+    if (t.rfind("del", 0) == 0) return std::string();
+    return t;
+}
+
 } // namespace
 
 extern "C" {
@@ -117,6 +135,68 @@ uint32_t sp_cyp_chain_to_hap(const int32_t* chain, uint32_t n, const int32_t* ha
     flush();
     if (out && cap) { const size_t k = std::min<size_t>(cap - 1, res.size()); std::memcpy(out, res.data(), k); out[k] = '\0'; }
     return (uint32_t)res.size();
+}
+
+int32_t sp_variant_normalize(const char* chrom_seq, uint64_t chrom_len, uint64_t position, const char* ref_allele, const char* alt_allele,
+                             uint64_t* out_position, char* out_ref, char* out_alt, uint32_t cap) {
+    if (!ref_allele || !alt_allele || !out_position || !out_ref || !out_alt || cap == 0) return SP_ERR_INVALID_ARG;
+    const std::string ref_text(ref_allele), alt_text(alt_allele);
+    if (ref_text.empty()) return SP_ERR_BAD_VARIANT;
+    if (ref_text == "del" && alt_text.rfind("ins", 0) != 0) return SP_ERR_BAD_VARIANT;
+    std::string r = cpic_bases(ref_text), a = cpic_bases(alt_text);
+    uint64_t pos = position;
+    if (chrom_seq) {
+        if (pos + r.size() > chrom_len) return SP_ERR_BAD_VARIANT;                  // the reference would panic on the slice
+        if (r.compare(0, r.size(), chrom_seq + pos, r.size()) != 0) return SP_ERR_BAD_VARIANT;
+    }
+    if (r.empty() && a.empty()) return SP_ERR_BAD_VARIANT;
+    if (r.empty() || a.empty()) {                                                   // one side empty: anchor on a reference base
+        if (a.empty()) { if (pos == 0) return SP_ERR_BAD_VARIANT; if (chrom_seq) --pos; }
+        if (chrom_seq) { if (pos >= chrom_len) return SP_ERR_BAD_VARIANT; r.insert(r.begin(), chrom_seq[pos]); a.insert(a.begin(), chrom_seq[pos]); }
+    }
+    if (r.empty() || a.empty()) return SP_ERR_BAD_VARIANT;                          // (Rust indexes [len-1] and panics)
+    // shared suffix, then shared prefix, never below one base on either side
+    size_t room = std::min(r.size(), a.size()) - 1, cut = 0;
+    while (cut < room && r[r.size() - 1 - cut] == a[a.size() - 1 - cut]) ++cut;
+    r.resize(r.size() - cut); a.resize(a.size() - cut);
+    room = std::min(r.size(), a.size()) - 1; cut = 0;
+    while (cut < room && r[cut] == a[cut]) ++cut;
+    r.erase(0, cut); a.erase(0, cut); pos += cut;
+    // left shift: while the last bases agree, roll both alleles one reference base to the left
+    while (r.back() == a.back() && pos > 0 && chrom_seq) {
+        --pos;
+        r.pop_back(); a.pop_back();
+        r.insert(r.begin(), chrom_seq[pos]); a.insert(a.begin(), chrom_seq[pos]);
+    }
+    auto acgt = [](const std::string& t) { return std::all_of(t.begin(), t.end(), [](char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }); };
+    if (!acgt(r) || !acgt(a)) return SP_ERR_BAD_VARIANT;
+    if (r.size() + 1 > cap || a.size() + 1 > cap) return SP_ERR_CAPACITY;
+    *out_position = pos;
+    std::memcpy(out_ref, r.c_str(), r.size() + 1); std::memcpy(out_alt, a.c_str(), a.size() + 1);
+    return SP_OK;
+}
+
+int32_t sp_variant_multi_normalize(const char* chrom_seq, uint64_t chrom_len, uint64_t position, const char* ref_allele, const char* alt_allele,
+                                   uint32_t max_out, uint32_t* n_out, uint8_t* is_none, uint64_t* out_position, char* out_ref, char* out_alt, uint32_t cap) {
+    if (!ref_allele || !alt_allele || !n_out || !is_none || !out_position || !out_ref || !out_alt) return SP_ERR_INVALID_ARG;
+    static const struct { char code; const char* bases; } iupac[] = { {'K', "GT"}, {'M', "AC"}, {'R', "AG"}, {'S', "CG"}, {'W', "AT"}, {'Y', "CT"},
+                                                                      {'B', "CGT"}, {'D', "AGT"}, {'H', "ACT"}, {'V', "ACG"} };
+    std::vector<std::string> alts;
+    const std::string alt_text(alt_allele);
+    if (alt_text.size() == 1) for (const auto& e : iupac) if (e.code == alt_text[0]) for (const char* b = e.bases; *b; ++b) alts.emplace_back(1, *b);
+    if (alts.empty()) {                                                             // str::split("; ") keeps empty pieces
+        size_t from = 0;
+        for (;;) { const size_t at = alt_text.find("; ", from); alts.push_back(alt_text.substr(from, at == std::string::npos ? at : at - from)); if (at == std::string::npos) break; from = at + 2; }
+    }
+    *n_out = (uint32_t)alts.size();
+    if (alts.size() > max_out) return SP_ERR_CAPACITY;
+    for (size_t i = 0; i < alts.size(); ++i) {
+        is_none[i] = alts[i] == ref_allele;
+        if (is_none[i]) continue;
+        const int32_t rc = sp_variant_normalize(chrom_seq, chrom_len, position, ref_allele, alts[i].c_str(), out_position + i, out_ref + i * (size_t)cap, out_alt + i * (size_t)cap, cap);
+        if (rc != SP_OK) return rc;
+    }
+    return SP_OK;
 }
 
 int32_t sp_cyp_build_chains(uint32_t n_haps, const int32_t* hap_type, uint32_t n_reads, const uint32_t* read_seg_off,

@@ -146,6 +146,8 @@ def lib():
         "sp_hpc": (u64, [C.c_char_p, u64, C.c_char_p]),
         "sp_cyp_chain_to_hap": (u32, [vp, u32, vp, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i32, C.c_char_p, u32]),
         "sp_cyp_build_chains": (i32, [u32, vp, u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, vp, vp, vp]),
+        "sp_variant_normalize": (i32, [C.c_char_p, u64, u64, C.c_char_p, C.c_char_p, C.POINTER(u64), C.c_char_p, C.c_char_p, u32]),
+        "sp_variant_multi_normalize": (i32, [C.c_char_p, u64, u64, C.c_char_p, C.c_char_p, u32, C.POINTER(u32), vp, vp, C.c_char_p, C.c_char_p, u32]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -312,6 +314,37 @@ class Context:
         ms, launches, cells = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         self.check(lib().sp_profile_get(self._h, name.encode(), C.byref(ms), C.byref(launches), C.byref(cells)))
         return ms.value, launches.value, cells.value
+
+
+def normalize_variant(chrom_seq, position, ref, alt, cap=4096):
+    """sp_variant_normalize -> (position, ref, alt); raises StarphaseError(8) where NormalizedVariant::new bails"""
+    pos = C.c_uint64(0)
+    r, a = C.create_string_buffer(cap), C.create_string_buffer(cap)
+    seq = chrom_seq.encode() if isinstance(chrom_seq, str) else chrom_seq
+    rc = lib().sp_variant_normalize(seq, len(seq) if seq is not None else 0, int(position), ref.encode(), alt.encode(), C.byref(pos), r, a, cap)
+    if rc != SP_OK:
+        raise StarphaseError(rc, "sp_variant_normalize")
+    return int(pos.value), r.value.decode(), a.value.decode()
+
+
+def multi_normalize_variant(chrom_seq, position, ref, alt, cap=4096, max_out=16):
+    """sp_variant_multi_normalize -> list of None | (position, ref, alt)"""
+    n = C.c_uint32(0)
+    none = np.zeros(max_out, np.uint8)
+    pos = np.zeros(max_out, np.uint64)
+    r, a = C.create_string_buffer(cap * max_out), C.create_string_buffer(cap * max_out)
+    seq = chrom_seq.encode() if isinstance(chrom_seq, str) else chrom_seq
+    rc = lib().sp_variant_multi_normalize(seq, len(seq) if seq is not None else 0, int(position), ref.encode(), alt.encode(), max_out, C.byref(n),
+                                          _ptr(none), _ptr(pos), r, a, cap)
+    if rc != SP_OK:
+        raise StarphaseError(rc, "sp_variant_multi_normalize")
+    out = []
+    for i in range(n.value):
+        if none[i]:
+            out.append(None)
+        else:
+            out.append((int(pos[i]), r.raw[i * cap:(i + 1) * cap].split(b"\0", 1)[0].decode(), a.raw[i * cap:(i + 1) * cap].split(b"\0", 1)[0].decode()))
+    return out
 
 
 def build_chains(hap_type, read_seg_off, ed, kept):

@@ -27,6 +27,10 @@ def test_reference_scenarios(oracle, pkg, gpu_ctx, case):
     assert got == exp
     called = vg.call_gene(oracle, prob, solver=lambda pr: gpu_ctx.variant_solve(gpu_struct(pkg, pr)))
     assert [frozenset(d) if d[0] != d[1] else d for d in called["diplotypes"]] == [frozenset(d) if d[0] != d[1] else d for d in dips]
+    # the whole product path: strings normalised by the library (sp_variant_normalize), search on the GPU -- same problem, same call
+    _g2, prob2 = vg.load_case(vg.ProductNormalizer(pkg), db, vcf, with_ref)
+    assert prob2.obs == prob.obs and [h["slots"] for h in prob2.haps] == [h["slots"] for h in prob.haps]
+    assert gpu_ctx.variant_solve(gpu_struct(pkg, prob2)) == exp
 
 
 class RandomProblem(vg.Problem):

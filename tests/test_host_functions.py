@@ -161,3 +161,94 @@ def test_build_chains_random(pkg, oracle):
         _same_chains(orc, exp)
         _same_chains(pkg.ffi.build_chains(hap_type, seg_off, ed.reshape(-1), kept), exp)
     assert n_ok > 50
+
+
+# ------------------------------------------------------------------ variant normalisation (a24) in the product library
+import pytest
+import variant_glue as vg
+
+GENOME = {"chr1": "AAAAAAAAAAACACACACAC", "chr2": "ACACACACACAGTAGTAGTA", "chr3": "ACGTACGTACGTACGTACGT"}
+
+
+def test_product_normalize_vectors(pkg, oracle):
+    """the same vectors tests/test_oracle_variant.py pins the oracle on (normalized_variant.rs:43-170,262-279), through sp_variant_normalize"""
+    prod = vg.ProductNormalizer(pkg)
+    n = lambda *a: vg.normalize(prod, *a)
+    assert n("chr1", 10, "A", "C", None) == ("chr1", 10, "A", "C")
+    assert n("chr1", 10, "AC", "AG", None) == ("chr1", 11, "C", "G")
+    assert n("chr1", 10, "CA", "GA", None) == ("chr1", 10, "C", "G")
+    assert n("chr1", 14, "AC", "del", GENOME) == ("chr1", 9, "AAC", "A")
+    assert n("chr1", 14, "del", "insAC", GENOME) == ("chr1", 14, "A", "AAC")
+    assert n("chr1", 12, "AC(2)", "AC(3)", GENOME) == ("chr1", 9, "A", "AAC")
+    assert n("chr2", 10, "AGT", "delinsA", None) == ("chr2", 10, "AGT", "A")
+    for bad in (("chr1", 10, "", "A", None), ("chr1", 10, "del", "A", None), ("chr1", 10, "C", "A", GENOME), ("chr1", 10, "A", "N", None),
+                ("chr9", 10, "A", "C", GENOME), ("chr1", 0, "A", "del", GENOME), ("chr1", 10, "del", "insAC", None)):
+        with pytest.raises(ValueError):
+            n(*bad)
+        with pytest.raises(ValueError):
+            vg.normalize(oracle, *bad)
+    assert vg.multi_new(prod, "chr1", 10, "A", "R", None) == [None, ("chr1", 10, "A", "G")]
+    assert vg.multi_new(prod, "chr1", 10, "A", "Y", None) == [("chr1", 10, "A", "C"), ("chr1", 10, "A", "T")]
+    assert vg.multi_new(prod, "chr1", 10, "A", "delinsCC; delinsCCC", None) == [("chr1", 10, "A", "CC"), ("chr1", 10, "A", "CCC")]
+
+
+def test_product_normalize_fuzz(pkg, oracle):
+    """random CPIC-syntax alleles over a repetitive contig: library == oracle, including which inputs are refused"""
+    rng = np.random.default_rng(5)
+    contig = "".join(rng.choice(list("AC"), 30)) + "ACACACACAC" + "GGGGGG" + "".join(rng.choice(list("ACGT"), 40)) + "TTTTTTAGAGAGAG"
+    prod = vg.ProductNormalizer(pkg)
+    n_ok = n_bad = 0
+    for it in range(3000):
+        pos = int(rng.integers(0, len(contig) - 6))
+        rl = int(rng.integers(0, 5))
+        ref_bases = contig[pos:pos + rl]
+        kind = int(rng.integers(0, 7))
+        rnd = lambda k: "".join(rng.choice(list("ACGT"), k))
+        if kind == 0:
+            ref, alt = (ref_bases or "del"), rnd(int(rng.integers(1, 4)))
+        elif kind == 1:
+            ref, alt = (ref_bases or "del"), "del"
+        elif kind == 2:
+            ref, alt = "del", "ins" + rnd(int(rng.integers(1, 4)))
+        elif kind == 3:
+            ref, alt = (ref_bases or "del"), "delins" + rnd(int(rng.integers(0, 4)))
+        elif kind == 4:                                          # tandem-repeat syntax, genome-consistent or not
+            unit = contig[pos:pos + int(rng.integers(1, 3))]
+            ref, alt = f"{unit}({int(rng.integers(1, 4))})", f"{unit}({int(rng.integers(0, 5))})"
+        elif kind == 5:                                          # duplicate a downstream copy: exercises the left shift
+            ref, alt = (ref_bases or "del"), "ins" + contig[pos:pos + int(rng.integers(1, 4))] if not ref_bases else ref_bases + ref_bases
+        else:
+            ref, alt = rnd(max(1, rl)), rnd(int(rng.integers(1, 4)))   # usually disagrees with the genome
+        for genome in ({"c": contig}, None):
+            try:
+                want = vg.normalize(oracle, "c", pos, ref, alt, genome)
+            except ValueError:
+                want = None
+            try:
+                got = vg.normalize(prod, "c", pos, ref, alt, genome)
+            except ValueError:
+                got = None
+            assert got == want, (pos, ref, alt, genome is not None, got, want)
+            n_ok += want is not None
+            n_bad += want is None
+    assert n_ok > 1500 and n_bad > 300
+
+
+def test_product_loads_reference_databases(pkg, oracle):
+    """load_database_haplotypes (src/diplotyper.rs:437-538) over every committed DB fixture: identical tables whether the strings are
+    normalised by the oracle or by the library"""
+    import json, os, glob
+    ref = json.load(open(os.path.join(vg.GOLDEN, "test_reference.json"))) if os.path.exists(os.path.join(vg.GOLDEN, "test_reference.json")) else None
+    prod = vg.ProductNormalizer(pkg)
+    n = 0
+    for path in sorted(glob.glob(os.path.join(vg.GOLDEN, "variant_dbs", "*.json"))):
+        db = json.load(open(path))
+        for gene, entry in db["gene_entries"].items():
+            for genome in (None, ref):
+                if genome is not None and entry["chromosome"] not in genome:
+                    continue
+                a = vg.load_database_haplotypes(oracle, entry, genome)
+                b = vg.load_database_haplotypes(prod, entry, genome)
+                assert a == b
+                n += 1
+    assert n >= 5

@@ -34,6 +34,8 @@ def normalize(oracle, chrom, pos, ref, alt, genome):
     seq = genome.get(chrom) if genome else None
     if genome is not None and seq is None:
         raise ValueError(f"Reference genome does not contain contig {chrom!r}")
+    if hasattr(oracle, "normalize_variant"):          # the product's host routine (ProductNormalizer below)
+        return oracle.normalize_variant(chrom, pos, ref, alt, seq)
     oracle.L.osp_normalize_variant.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(NormVariant),
                                                 C.c_char_p, C.c_size_t]
     rc = oracle.L.osp_normalize_variant(chrom.encode(), int(pos), ref.encode(), alt.encode(), seq.encode() if seq else None,
@@ -47,8 +49,33 @@ IUPAC = {"K": ["G", "T"], "M": ["A", "C"], "R": ["A", "G"], "S": ["C", "G"], "W"
          "B": ["C", "G", "T"], "D": ["A", "G", "T"], "H": ["A", "C", "T"], "V": ["A", "C", "G"]}
 
 
+class ProductNormalizer:
+    """Routes the string preparation through the library's sp_variant_normalize / sp_variant_multi_normalize."""
+    def __init__(self, pkg):
+        self.pkg = pkg
+
+    def normalize_variant(self, chrom, pos, ref, alt, seq):
+        try:
+            p, r, a = self.pkg.ffi.normalize_variant(seq, pos, ref, alt)
+        except self.pkg.StarphaseError as e:
+            raise ValueError(str(e))
+        return (chrom, p, r, a)
+
+    def multi_new(self, chrom, pos, ref, alt, seq):
+        try:
+            got = self.pkg.ffi.multi_normalize_variant(seq, pos, ref, alt)
+        except self.pkg.StarphaseError as e:
+            raise ValueError(str(e))
+        return [None if g is None else (chrom,) + g for g in got]
+
+
 def multi_new(oracle, chrom, pos, ref, alt, genome):
     """NormalizedVariant::multi_new (src/data_types/normalized_variant.rs:174-214)"""
+    if hasattr(oracle, "multi_new"):
+        seq = genome.get(chrom) if genome else None
+        if genome is not None and seq is None:
+            raise ValueError(f"Reference genome does not contain contig {chrom!r}")
+        return oracle.multi_new(chrom, pos, ref, alt, seq)
     alts = IUPAC.get(alt) or alt.split("; ")
     return [None if a == ref else normalize(oracle, chrom, pos, ref, a, genome) for a in alts]
 
