@@ -204,7 +204,7 @@ class Config2Workload:
 class CypLocus:
     """Synthetic chr22-like CYP2D6 locus with the region sizes of Cyp2d6Config::default()
     (src/cyp2d6/definitions.rs:128-240): REP6 2,772 / D6 6,165 / link 2,919 / REP7 2,772 / spacer 1,564 / D7 5,938.
-    D7 = D6 with ~3 % divergence, REP7 = REP6 with differences near its end; templates as the extractor builds them
+    D7 = D6 with ~3 % divergence, REP7 = REP6 with differences near its end (unrelated last 300 bases); templates as the extractor builds them
     (D6, D7, two hybrids, *5 signature, REP6, REP7, spacer, link_region), in full_allele() order."""
     TYPES = {"UNKNOWN": 0, "REP6": 1, "CYP2D6": 2, "link_region": 3, "REP7": 4, "spacer": 5, "CYP2D7": 6, "CYP2D6*5": 7, "Hybrid": 8}
 
@@ -217,12 +217,17 @@ class CypLocus:
         self.spacer = rnd(1564)
         d7 = mutate(rng, self.d6, 150, 20, 30)
         self.d7 = d7[:5938] if len(d7) >= 5938 else d7
-        self.rep7 = self.rep6[:2500] + mutate(rng, self.rep6[2500:], 8, 1, 1)
+        # REP7 = REP6 except near its end: two edited stretches and an unrelated 300-base tail.  The deletion allele (*5) removes
+        # REP6's tail .. REP7's head (D6 and the link region with them): its REP is REP6 up to the middle of the differing zone and
+        # REP7 after it, so the three REP versions are pairwise distinguishable.
+        m1, m2, tail = mutate(rng, self.rep6[2200:2336], 4, 0, 1), mutate(rng, self.rep6[2336:2472], 4, 1, 0), rnd(300)
+        self.rep7 = self.rep6[:2200] + m1 + m2 + tail
+        self.rep_del = self.rep6[:2336] + m2 + tail
         self.left, self.right = rnd(3000), rnd(3000)
         cut = 2000
         hyb67 = self.d6[:cut] + self.d7[cut:]          # CYP2D6::CYP2D7 (starts as D6)
         hyb76 = self.d7[:cut] + self.d6[cut:]          # CYP2D7::CYP2D6
-        star5 = self.rep6[-500:] + self.spacer + self.d7[:1436]     # deletion signature: REP tail joined to the spacer side
+        star5 = self.left[-500:] + self.rep_del + self.spacer[:228]  # deletion signature: 500 bases upstream + 3,000 across the fused REP
         named = [("CYP2D6", "CYP2D6", self.d6), ("CYP2D6*5", "CYP2D6*5", star5), ("Hybrid", "CYP2D6::CYP2D7::exon2", hyb67),
                  ("CYP2D7", "CYP2D7", self.d7), ("Hybrid", "CYP2D7::CYP2D6::exon2", hyb76), ("REP6", "REP6", self.rep6),
                  ("REP7", "REP7", self.rep7), ("link_region", "link_region", self.link), ("spacer", "spacer", self.spacer)]
@@ -232,8 +237,8 @@ class CypLocus:
         self.templates = [s for _, _, s in named]
 
     def haplotype(self, kind="normal"):
-        if kind == "deletion":                         # *5: D6 gone, REP6 joins the spacer
-            return self.left + self.rep6 + self.spacer + self.d7 + self.right
+        if kind == "deletion":                         # *5: D6 gone, one fused REP left
+            return self.left + self.rep_del + self.spacer + self.d7 + self.right
         if kind == "dup":
             return self.left + self.rep6 + self.d6 + self.link + self.rep7 + self.d6 + self.link + self.rep7 + self.spacer + self.d7 + self.right
         return self.left + self.rep6 + self.d6 + self.link + self.rep7 + self.spacer + self.d7 + self.right
