@@ -325,6 +325,41 @@ typedef struct {
 
 int32_t sp_variant_solve(sp_ctx* ctx, const sp_variant_problem* problem, sp_variant_result* result);
 
+/* ------------------------------------------------------------------ K8: read consensus by dynamic wavefront alignment
+ * Serves the waffle_con calls of the reference: DualConsensusDWFA::{add_sequence_offset, consensus} in
+ * run_dual_consensus_with_offsets (src/hla/caller.rs:1103-1219) and ConsensusDWFA per read group (src/hla/caller.rs:706-747),
+ * with the fields of dwfa_config_from_cli (src/hla/caller.rs:1103-1116).  waffle_con v0.4.4 is not on disk: the contract is the
+ * one in DESIGN.md section 12 / oracle/consensus.c (every read keeps a 64-diagonal edit wavefront against the growing consensus
+ * and votes for the next base; a second consensus is split off where a second base has min_count reads and min_af of the votes).
+ *   reads / read_idx   the sequences (read_idx == NULL: all n = sp_seqset_count(reads) of them, in order)
+ *   offsets            NULL, or per sequence -1 (None: starts with the consensus) or the consensus length at which the sequence is
+ *                      placed; its start is searched in the offset_window bases before that point (add_sequence_offset)
+ *   cons1 / cons2      cap bytes each, NUL terminated ASCII; cons2 is empty unless result->is_dual
+ *   is_cons1, score1, score2   DualConsensus::{is_consensus1, scores1, scores2}; a score of -1 is None
+ * sp_consensus is one pass with cfg->min_af as given.  sp_consensus_dual runs a first pass without splitting to find the
+ * strongest second-base column and then allows the split only at columns at least half as strong (never below cfg->min_af). */
+typedef struct {
+    int32_t min_count;                 /* 3 */
+    int32_t dual_max_ed_delta;         /* 100 */
+    int32_t allow_early_termination;
+    int32_t allow_dual;
+    int32_t offset_window;             /* 400 */
+    int32_t offset_compare_length;     /* 50 (at most 64) */
+    double  min_af;                    /* 0.10 */
+} sp_cons_config;
+
+typedef struct {
+    int32_t is_dual, len1, len2, split_at;
+    int64_t best_w2, best_total;       /* strongest second-base column before any split: its weight / all votes, in 12ths of a read */
+} sp_cons_result;
+
+int32_t sp_consensus(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* read_idx, uint32_t n, const int32_t* offsets,
+                     const sp_cons_config* cfg, char* cons1, char* cons2, uint32_t cap,
+                     uint8_t* is_cons1, int32_t* score1, int32_t* score2, sp_cons_result* result);
+int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* read_idx, uint32_t n, const int32_t* offsets,
+                          const sp_cons_config* cfg, char* cons1, char* cons2, uint32_t cap,
+                          uint8_t* is_cons1, int32_t* score1, int32_t* score2, sp_cons_result* result);
+
 /* ------------------------------------------------------------------ host-side decisions of the path (no device work)
  * Small scalar routines the reference evaluates between the kernels; kept behind the same ABI so a host can drop the whole
  * path in.  statrs 0.16 formulas (Binomial::cdf / ln_pmf, Normal::ln_pdf, ln_factorial). */

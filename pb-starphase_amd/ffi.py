@@ -91,6 +91,15 @@ class sp_variant_result(C.Structure):
                 ("dip_comb", C.c_int32 * SP_VAR_MAXDIP)]
 
 
+class sp_cons_config(C.Structure):
+    _fields_ = [("min_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("allow_early_termination", C.c_int32), ("allow_dual", C.c_int32),
+                ("offset_window", C.c_int32), ("offset_compare_length", C.c_int32), ("min_af", C.c_double)]
+
+
+class sp_cons_result(C.Structure):
+    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64)]
+
+
 class sp_hla_best(C.Structure):
     _fields_ = [("best_allele", C.c_int32), ("n_scored", C.c_int32)]
 
@@ -148,6 +157,8 @@ def lib():
         "sp_cyp_build_chains": (i32, [u32, vp, u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, vp, vp, vp]),
         "sp_variant_normalize": (i32, [C.c_char_p, u64, u64, C.c_char_p, C.c_char_p, C.POINTER(u64), C.c_char_p, C.c_char_p, u32]),
         "sp_variant_multi_normalize": (i32, [C.c_char_p, u64, u64, C.c_char_p, C.c_char_p, u32, C.POINTER(u32), vp, vp, C.c_char_p, C.c_char_p, u32]),
+        "sp_consensus": (i32, [vp, vp, vp, u32, vp, C.POINTER(sp_cons_config), C.c_char_p, C.c_char_p, u32, vp, vp, vp, C.POINTER(sp_cons_result)]),
+        "sp_consensus_dual": (i32, [vp, vp, vp, u32, vp, C.POINTER(sp_cons_config), C.c_char_p, C.c_char_p, u32, vp, vp, vp, C.POINTER(sp_cons_result)]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -306,6 +317,24 @@ class Context:
         if res.overflow:
             raise StarphaseError(5, "more than SP_VAR_MAXDIP tied diplotypes")
         return tuple(res.score), [(res.dip[i][0], res.dip[i][1], res.dip_comb[i]) for i in range(res.n_dip)]
+
+    def consensus(self, reads, cfg, offsets=None, read_idx=None, cap=None, two_pass=False):
+        """sp_consensus / sp_consensus_dual (two_pass) on a SeqSet -> dict like the oracle harness returns"""
+        n = len(read_idx) if read_idx is not None else reads.n
+        idx = np.ascontiguousarray(read_idx, np.uint32) if read_idx is not None else None
+        offs = None
+        if offsets is not None:
+            offs = np.array([-1 if o is None else int(o) for o in offsets], np.int32)
+        lens = reads.lengths if read_idx is None else reads.lengths[np.asarray(read_idx, np.int64)]
+        if cap is None:
+            cap = int(lens.max() if n else 0) + int(max(0, offs.max()) if offs is not None and n else 0) + 64
+        c1, c2 = C.create_string_buffer(cap + 1), C.create_string_buffer(cap + 1)
+        is1, s1, s2 = np.zeros(max(1, n), np.uint8), np.zeros(max(1, n), np.int32), np.zeros(max(1, n), np.int32)
+        res = sp_cons_result()
+        fn = lib().sp_consensus_dual if two_pass else lib().sp_consensus
+        self.check(fn(self._h, reads._h, _ptr(idx), n, _ptr(offs), C.byref(cfg), c1, c2, cap + 1, _ptr(is1), _ptr(s1), _ptr(s2), C.byref(res)))
+        return dict(cons=[c1.value.decode(), c2.value.decode() if res.is_dual else None], is_dual=bool(res.is_dual), is_cons1=is1[:n].astype(bool),
+                    score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, best_w2=res.best_w2, best_total=res.best_total)
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))

@@ -1,0 +1,47 @@
+"""Shared read sets for the consensus tests (oracle quality on CPU, HIP == oracle on GPU)."""
+import numpy as np
+
+
+def hla_pair(fx, g=0, i=10, j=500):
+    fl = fx.full_length_alleles(g)
+    return fx.dna[fl[i]], fx.dna[fl[j]]
+
+
+def cases(fx, synth, oracle):
+    """-> list of (name, reads, offsets, cfg kwargs, two_pass)"""
+    rng = np.random.default_rng(42)
+    s1, s2 = hla_pair(fx)
+    out = []
+    full1 = [synth.hifi_errors(rng, s1) for _ in range(24)]
+    out.append(("single_full_span", full1, None, dict(early_termination=False, dual=False), False))
+    out.append(("single_early_termination", full1, None, dict(early_termination=True, dual=False), False))
+    mix = [synth.hifi_errors(rng, s1) for _ in range(20)] + [synth.hifi_errors(rng, s2) for _ in range(16)]
+    order = rng.permutation(len(mix))
+    mix = [mix[i] for i in order]
+    out.append(("dual_full_span", mix, None, dict(early_termination=False, dual=True), True))
+    out.append(("dual_one_pass", mix, None, dict(early_termination=False, dual=True), False))
+    # partial reads with offsets, as run_dual_consensus_with_offsets passes them: None for the leftmost, else start - min + window/2
+    parts, starts = [], []
+    for hap in (s1, s2):
+        for _ in range(18):
+            a = int(rng.integers(0, 1500)) if rng.random() < 0.7 else 0
+            b = int(rng.integers(len(hap) - 1200, len(hap) + 1))
+            parts.append(synth.hifi_errors(rng, hap[a:b]))
+            starts.append(max(0, a + int(rng.integers(-30, 31))) if a else 0)       # the caller's offsets are estimates
+    mn = min(starts)
+    offs = [None if s == mn else s - mn + 200 for s in starts]
+    out.append(("dual_offsets", parts, offs, dict(early_termination=True, dual=True), True))
+    out.append(("single_offsets", parts[:18], offs[:18], dict(early_termination=True, dual=False), False))
+    # homopolymer-compressed sequences (the reference's first attempt)
+    hpc = [oracle.hpc(r) for r in mix]
+    out.append(("dual_hpc", hpc, None, dict(early_termination=True, dual=True), True))
+    # reads with non-ACGT bases and one unrelated read
+    noisy = [r for r in full1[:10]]
+    noisy[3] = noisy[3][:700] + "N" + noisy[3][701:]
+    noisy[5] = noisy[5][:1500] + "NNN" + noisy[5][1503:]
+    noisy.append("".join(rng.choice(list("ACGT"), 900)))
+    out.append(("single_with_n_and_junk", noisy, None, dict(early_termination=True, dual=False), False))
+    # tiny inputs
+    out.append(("two_reads", full1[:2], None, dict(early_termination=True, dual=True), True))
+    out.append(("one_read", full1[:1], None, dict(early_termination=False, dual=False), False))
+    return out, (s1, s2)

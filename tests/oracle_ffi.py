@@ -395,3 +395,50 @@ def oracle_build_chains(oracle, hap_type, read_seg_off, ed, kept):
     chains = [[[int(x) for x in items[co[c]:co[c + 1]]] for c in range(rco[k], rco[k + 1])] for k in range(nk)]
     rows = [[int(x) for x in w_seg[rwo[k]:rwo[k + 1]]] for k in range(nk)]
     return dict(read_index=[int(x) for x in read_index[:nk]], chains=chains, w_rows=rows, unique_counts=uniq, false_allele=false_allele)
+
+
+class ConsConfig(C.Structure):
+    _fields_ = [("min_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("allow_early_termination", C.c_int32), ("allow_dual", C.c_int32),
+                ("offset_window", C.c_int32), ("offset_compare_length", C.c_int32), ("min_af", C.c_double)]
+
+
+class ConsResult(C.Structure):
+    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64)]
+
+
+def cons_config(min_count=3, min_af=0.10, dual_max_ed_delta=100, early_termination=True, dual=True, offset_window=400, offset_compare_length=50):
+    return ConsConfig(min_count, dual_max_ed_delta, int(early_termination), int(dual), offset_window, offset_compare_length, min_af)
+
+
+def oracle_consensus(oracle, reads, offsets=None, cfg=None, cap=None):
+    """osp_consensus -> dict(cons=[str, str|None], is_dual, is_cons1, score1, score2 (None = -1), split_at, best_w2, best_total)"""
+    cfg = cfg or cons_config()
+    enc = [oracle.encode(r) for r in reads]
+    n = len(reads)
+    lens = np.array([len(r) for r in reads], np.int32)
+    offs = np.array([-1 if o is None else int(o) for o in (offsets or [None] * n)], np.int32)
+    cap = cap or (int(lens.max() if n else 0) + int(max(0, offs.max() if n else 0)) + 64)
+    c1, c2 = np.zeros(cap + 1, np.uint8), np.zeros(cap + 1, np.uint8)
+    is1, s1, s2 = np.zeros(max(1, n), np.uint8), np.zeros(max(1, n), np.int32), np.zeros(max(1, n), np.int32)
+    ptrs = (C.c_void_p * max(1, n))(*[e.ctypes.data for e in enc])
+    res = ConsResult()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    oracle.L.osp_consensus.restype = C.c_int
+    rc = oracle.L.osp_consensus(n, ptrs, p(lens), p(offs), C.byref(cfg), p(c1), p(c2), cap, p(is1), p(s1), p(s2), C.byref(res))
+    assert rc == 0
+    dec = lambda a, k: "".join("ACGT"[x] for x in a[:k])
+    return dict(cons=[dec(c1, res.len1), dec(c2, res.len2) if res.is_dual else None], is_dual=bool(res.is_dual), is_cons1=is1[:n].astype(bool),
+                score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, best_w2=res.best_w2, best_total=res.best_total)
+
+
+def dual_consensus_two_pass(run, reads, offsets=None, cfg=None):
+    """the split policy on top of the one-pass search: pass 1 (no split) finds the strongest second-base column, pass 2 may only
+    split at columns at least half as strong.  run = oracle_consensus-like callable (reads, offsets, cfg)."""
+    cfg = cfg or cons_config()
+    single = ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, 0, cfg.offset_window, cfg.offset_compare_length, cfg.min_af)
+    first = run(reads, offsets, single)
+    if first["best_w2"] == 0:
+        return first
+    af = max(cfg.min_af, 0.5 * float(first["best_w2"]) / float(first["best_total"]))
+    second = ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, 1, cfg.offset_window, cfg.offset_compare_length, af)
+    return run(reads, offsets, second)

@@ -1,0 +1,85 @@
+"""GPU parity for K8 (sp_consensus / sp_consensus_dual) against oracle/consensus.c: identical consensus strings, read
+assignment, per-read edit counts and split column."""
+import numpy as np
+import pytest
+
+import consensus_cases
+import oracle_ffi as of
+from test_oracle_consensus import run_case
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    assert a["cons"] == b["cons"]
+    assert a["is_dual"] == b["is_dual"] and a["split_at"] == b["split_at"]
+    assert a["is_cons1"].tolist() == b["is_cons1"].tolist()
+    assert a["score1"].tolist() == b["score1"].tolist() and a["score2"].tolist() == b["score2"].tolist()
+    assert (a["best_w2"], a["best_total"]) == (b["best_w2"], b["best_total"])
+
+
+def gpu_cfg(pkg, **kw):
+    c = of.cons_config(**kw)
+    return pkg.ffi.sp_cons_config(c.min_count, c.dual_max_ed_delta, c.allow_early_termination, c.allow_dual, c.offset_window, c.offset_compare_length, c.min_af)
+
+
+def test_cases_match_oracle(oracle, pkg, gpu_ctx):
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture()
+    cs, _ = consensus_cases.cases(fx, synth, oracle)
+    for name, reads, offs, kw, two_pass in cs:
+        exp = run_case(oracle, reads, offs, kw, two_pass)
+        got = gpu_ctx.consensus(gpu_ctx.upload(reads), gpu_cfg(pkg, **kw), offsets=offs, two_pass=two_pass)
+        try:
+            same(got, exp)
+        except AssertionError as e:
+            raise AssertionError(f"case {name}: {e}")
+
+
+def test_read_subsets_and_groups(oracle, pkg, gpu_ctx):
+    """the reference re-runs one consensus per read group (src/hla/caller.rs:706-747): read_idx selects the group"""
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture()
+    cs, (s1, s2) = consensus_cases.cases(fx, synth, oracle)
+    name, reads, offs, kw, _ = cs[2]
+    R = gpu_ctx.upload(reads)
+    dual = gpu_ctx.consensus(R, gpu_cfg(pkg, **kw), two_pass=True)
+    kw1 = dict(kw, dual=False)
+    seen = set()
+    for grp in (np.flatnonzero(dual["is_cons1"]), np.flatnonzero(~dual["is_cons1"])):
+        got = gpu_ctx.consensus(R, gpu_cfg(pkg, **kw1), read_idx=grp.astype(np.uint32))
+        exp = of.oracle_consensus(oracle, [reads[i] for i in grp], None, of.cons_config(**kw1))
+        same(got, exp)
+        seen.add(got["cons"][0])
+    assert seen == {s1, s2}
+
+
+def test_random_small_inputs(oracle, pkg, gpu_ctx):
+    """short random haplotypes, heavy noise, ragged offsets: every rule of the contract gets exercised"""
+    from pb_starphase_amd import synth
+    rng = np.random.default_rng(9)
+    n_dual = 0
+    for it in range(25):
+        L = int(rng.integers(150, 700))
+        h1 = "".join(rng.choice(list("ACGT"), L))
+        h2 = synth.mutate(rng, h1, int(rng.integers(1, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2))) if L > 200 else h1
+        reads, offs = [], []
+        for _ in range(int(rng.integers(1, 14))):
+            hap = h1 if rng.random() < 0.5 else h2
+            a = int(rng.integers(0, L // 3)) if rng.random() < 0.5 else 0
+            b = int(rng.integers(2 * L // 3, len(hap) + 1))
+            reads.append(synth.hifi_errors(rng, hap[a:b], p_sub=0.004, p_ins=0.004, p_del=0.004))
+            offs.append(None if a == 0 else a + int(rng.integers(0, 40)))
+        if all(o is not None for o in offs):
+            offs[0] = None
+        kw = dict(early_termination=bool(rng.integers(0, 2)), dual=True, min_count=int(rng.integers(1, 4)), min_af=float(rng.choice([0.1, 0.25])),
+                  dual_max_ed_delta=int(rng.choice([2, 20, 100])), offset_window=int(rng.choice([60, 120, 400])), offset_compare_length=int(rng.choice([20, 50, 64])))
+        two_pass = bool(rng.integers(0, 2))
+        exp = run_case(oracle, reads, offs, kw, two_pass)
+        got = gpu_ctx.consensus(gpu_ctx.upload(reads), gpu_cfg(pkg, **kw), offsets=offs, two_pass=two_pass)
+        try:
+            same(got, exp)
+        except AssertionError as e:
+            raise AssertionError(f"iteration {it}: {e}")
+        n_dual += exp["is_dual"]
+    assert n_dual >= 5
