@@ -360,6 +360,40 @@ int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* r
                           const sp_cons_config* cfg, char* cons1, char* cons2, uint32_t cap,
                           uint8_t* is_cons1, int32_t* score1, int32_t* score2, sp_cons_result* result);
 
+/* ------------------------------------------------------------------ one HLA gene, reads to diplotype
+ * The gene loop of diplotype_hla_batch (src/hla/caller.rs:642-1040) on top of K1 / K8 / K2, without I/O and debug artefacts:
+ * the realigned segments of `gene` (realign[r].status == 0, in input order = qname order) are cut out of the packed reads and
+ * homopolymer-compressed on the device; run_dual_consensus_with_offsets (:1118-1219: HPC first, DNA if is_passing_dual fails);
+ * is_hemizygous_better when the gene is absent-capable (:676-684); one consensus per read group (:706-747); score_consensus on
+ * each (:756,829); heterozygous if the dual passes, else homozygous for the larger group (:889-912).
+ *   realign      the K1 output for `reads` (sp_hla_realign_reads)
+ *   cons1/cons2  cap bytes each: the hg38-forward consensus of each group (empty = none / failed)
+ *   is_cons1     optional, call->n_reads entries: DualConsensus::is_consensus1 of the gene's realigned reads
+ * call->status: 0 = called, 1 = no realigned reads (NO_READS / NO_CALL, :662-668).  allele1/allele2 are database indices,
+ * -1 = unknown (no allele typed), -2 = the absent haplotype of a hemizygous call (:919-923). */
+typedef struct {
+    int32_t min_consensus_count;       /* --min-consensus-count (3) */
+    int32_t dual_max_ed_delta;         /* --dual-max-ed-delta (100) */
+    double  min_consensus_fraction;    /* --min-consensus-fraction (0.10) */
+    double  expected_maf, min_cdf;     /* is_passing_dual (src/hla/caller.rs:1225-1247) */
+    int32_t require_dna, disable_cdna; /* --hla-require-dna, --disable-cdna-scoring */
+    int32_t absent_capable;            /* gene_def.is_absent_capable() */
+    double  normalized_coverage;       /* < 0: unknown */
+} sp_hla_call_config;
+
+typedef struct {
+    int32_t status;
+    int32_t allele1, allele2;
+    int32_t typed1, typed2;            /* best database allele of each consensus (-1 = none) */
+    int32_t n_reads, counts1, counts2;
+    int32_t is_dual, dual_passed, is_hemizygous, used_dna_dual;
+    int32_t cons1_len, cons2_len;
+    double  maf, cdf;
+} sp_hla_call;
+
+int32_t sp_hla_diplotype_gene(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene, const sp_seqset* reads, const sp_hla_realign* realign,
+                              const sp_hla_call_config* cfg, sp_hla_call* call, char* cons1, char* cons2, uint32_t cap, uint8_t* is_cons1);
+
 /* ------------------------------------------------------------------ host-side decisions of the path (no device work)
  * Small scalar routines the reference evaluates between the kernels; kept behind the same ABI so a host can drop the whole
  * path in.  statrs 0.16 formulas (Binomial::cdf / ln_pmf, Normal::ln_pdf, ln_factorial). */

@@ -100,6 +100,26 @@ class sp_cons_result(C.Structure):
     _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64)]
 
 
+class sp_hla_call_config(C.Structure):
+    _fields_ = [("min_consensus_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("min_consensus_fraction", C.c_double),
+                ("expected_maf", C.c_double), ("min_cdf", C.c_double), ("require_dna", C.c_int32), ("disable_cdna", C.c_int32),
+                ("absent_capable", C.c_int32), ("normalized_coverage", C.c_double)]
+
+
+class sp_hla_call(C.Structure):
+    _fields_ = [("status", C.c_int32), ("allele1", C.c_int32), ("allele2", C.c_int32), ("typed1", C.c_int32), ("typed2", C.c_int32),
+                ("n_reads", C.c_int32), ("counts1", C.c_int32), ("counts2", C.c_int32), ("is_dual", C.c_int32), ("dual_passed", C.c_int32),
+                ("is_hemizygous", C.c_int32), ("used_dna_dual", C.c_int32), ("cons1_len", C.c_int32), ("cons2_len", C.c_int32),
+                ("maf", C.c_double), ("cdf", C.c_double)]
+
+
+def hla_call_config(min_consensus_count=3, dual_max_ed_delta=100, min_consensus_fraction=0.10, expected_maf=0.45, min_cdf=0.001,
+                    require_dna=False, disable_cdna=False, absent_capable=False, normalized_coverage=-1.0):
+    """defaults of the `diplotype` CLI (src/cli/diplotype.rs:110-190)"""
+    return sp_hla_call_config(min_consensus_count, dual_max_ed_delta, min_consensus_fraction, expected_maf, min_cdf, int(require_dna),
+                              int(disable_cdna), int(absent_capable), normalized_coverage)
+
+
 class sp_hla_best(C.Structure):
     _fields_ = [("best_allele", C.c_int32), ("n_scored", C.c_int32)]
 
@@ -159,6 +179,7 @@ def lib():
         "sp_variant_multi_normalize": (i32, [C.c_char_p, u64, u64, C.c_char_p, C.c_char_p, u32, C.POINTER(u32), vp, vp, C.c_char_p, C.c_char_p, u32]),
         "sp_consensus": (i32, [vp, vp, vp, u32, vp, C.POINTER(sp_cons_config), C.c_char_p, C.c_char_p, u32, vp, vp, vp, C.POINTER(sp_cons_result)]),
         "sp_consensus_dual": (i32, [vp, vp, vp, u32, vp, C.POINTER(sp_cons_config), C.c_char_p, C.c_char_p, u32, vp, vp, vp, C.POINTER(sp_cons_result)]),
+        "sp_hla_diplotype_gene": (i32, [vp, vp, u32, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, C.c_char_p, u32, vp]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -478,6 +499,16 @@ class HlaDb:
         cell = np.zeros((reads.n, self.n_alleles), np.uint32) if cells else None
         self.ctx.check(lib().sp_hla_realign_reads(self.ctx._h, self._h, reads._h, _ptr(out), _ptr(cell)))
         return (out, cell) if cells else out
+
+    def diplotype_gene(self, gene, reads, realign, cfg=None, cap=65536):
+        """sp_hla_diplotype_gene -> (sp_hla_call, consensus1, consensus2, is_consensus1 of the gene's realigned reads)"""
+        cfg = cfg or hla_call_config()
+        call = sp_hla_call()
+        c1, c2 = C.create_string_buffer(cap), C.create_string_buffer(cap)
+        is1 = np.zeros(max(1, reads.n), np.uint8)
+        realign = np.ascontiguousarray(realign)
+        self.ctx.check(lib().sp_hla_diplotype_gene(self.ctx._h, self._h, int(gene), reads._h, _ptr(realign), C.byref(cfg), C.byref(call), c1, c2, cap, _ptr(is1)))
+        return call, c1.value.decode(), c2.value.decode(), is1[:call.n_reads].astype(bool)
 
     def type_consensus(self, gene, consensus_fwd, require_dna=False, disable_cdna=False, stats=True):
         """score_consensus of the reference: hg38-forward consensus in, best allele + spliced gene-strand cDNA out"""

@@ -1,0 +1,61 @@
+"""Reads to diplotype through the C ABI (sp_hla_realign_reads + sp_hla_diplotype_gene) against the same pipeline assembled from
+the oracle: identical consensus strings, read grouping, typed alleles and calls; and the calls are the simulated truth."""
+import numpy as np
+import pytest
+
+import hla_expected as hx
+import hla_pipeline as hp
+
+pytestmark = pytest.mark.gpu
+
+
+def simulate(fx, synth, rng, g, alleles, n_per_hap):
+    reads = []
+    for a in alleles:
+        hap, s = fx.haplotype(g, a)
+        reads += synth.simulate_reads(rng, hap, s, len(fx.dna[a]), n_per_hap)
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order]
+
+
+def same_alleles(fx, a, b):
+    return a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+
+
+@pytest.mark.parametrize("scenario", ["het_both_genes", "hom_a_het_b"])
+def test_reads_to_diplotype(oracle, pkg, gpu_ctx, scenario):
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture(max_alleles_per_gene=150, seed=4)
+    db = fx.make_db(pkg, gpu_ctx)
+    rng = np.random.default_rng(11 if scenario == "het_both_genes" else 12)
+    truth, reads = {}, []
+    for g in range(len(fx.genes)):
+        fl = fx.full_length_alleles(g)
+        pick = rng.choice(fl, 2, replace=False).tolist()
+        if scenario == "hom_a_het_b" and g == 0:
+            pick = [pick[0], pick[0]]
+        truth[g] = pick
+        reads += simulate(fx, synth, rng, g, pick, 14)
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    R = gpu_ctx.upload(reads)
+    k1_gpu = db.realign_reads(R)
+    k1_exp, _ = hx.k1_expected(oracle, fx, reads)
+    for g in range(len(fx.genes)):
+        call, c1, c2, is1 = db.diplotype_gene(g, R, k1_gpu)
+        exp = hp.diplotype_gene(oracle, fx, g, reads, k1_exp, synth)
+        assert call.status == exp["status"] == 0 and call.n_reads == exp["n_reads"]
+        assert (c1, c2) == (exp["cons1"], exp["cons2"])
+        assert is1.tolist() == [bool(x) for x in exp["is_cons1"]]
+        assert (call.is_dual, call.dual_passed, call.used_dna_dual, call.counts1, call.counts2) == \
+               (exp["is_dual"], exp["dual_passed"], exp["used_dna_dual"], exp["counts1"], exp["counts2"])
+        assert (call.typed1, call.typed2, call.allele1, call.allele2) == (exp["typed1"], exp["typed2"], exp["allele1"], exp["allele2"])
+        assert abs(call.maf - exp["maf"]) <= 1e-12 and abs(call.cdf - exp["cdf"]) <= 1e-9
+        # and the call is the truth the reads were simulated from
+        got = sorted([call.allele1, call.allele2])
+        want = sorted(truth[g])
+        assert all(same_alleles(fx, a, b) for a, b in zip(got, want)) or all(same_alleles(fx, a, b) for a, b in zip(got, want[::-1])), (g, got, want)
+    # a gene without reads
+    empty = gpu_ctx.upload(["ACGT" * 200])
+    call, c1, c2, _ = db.diplotype_gene(0, empty, db.realign_reads(empty))
+    assert call.status == 1 and call.n_reads == 0 and (c1, c2) == ("", "")
