@@ -353,6 +353,20 @@ typedef struct {
     int64_t best_w2, best_total;       /* strongest second-base column before any split: its weight / all votes, in 12ths of a read */
 } sp_cons_result;
 
+/* batched form: independent problems advance in lockstep (one base per kernel launch for all of them), so a batch costs as many
+ * launches as its longest consensus.  outputs[p].status is SP_OK or SP_ERR_CAPACITY (cap too small for that consensus). */
+typedef struct {
+    const sp_seqset* reads; const uint32_t* read_idx; uint32_t n; const int32_t* offsets;
+    sp_cons_config cfg;
+} sp_cons_problem;
+typedef struct {
+    char* cons1; char* cons2; uint32_t cap;
+    uint8_t* is_cons1; int32_t* score1; int32_t* score2;
+    sp_cons_result result; int32_t status;
+} sp_cons_output;
+int32_t sp_consensus_batch(sp_ctx* ctx, uint32_t n_problems, const sp_cons_problem* problems, sp_cons_output* outputs);
+int32_t sp_consensus_dual_batch(sp_ctx* ctx, uint32_t n_problems, const sp_cons_problem* problems, sp_cons_output* outputs);
+
 int32_t sp_consensus(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* read_idx, uint32_t n, const int32_t* offsets,
                      const sp_cons_config* cfg, char* cons1, char* cons2, uint32_t cap,
                      uint8_t* is_cons1, int32_t* score1, int32_t* score2, sp_cons_result* result);

@@ -21,7 +21,10 @@ namespace {
 
 constexpr int CB = 64;          // band
 constexpr int CH = 32;          // lane of diagonal 0
-constexpr int CWAVES = 4;       // reads per workgroup
+constexpr int CWAVES = 16;      // reads per workgroup
+constexpr int CSLOTS = 8;       // vote counters are spread over this many slots (blockIdx & 7), one 128-byte line each:
+                                // same-line device atomics serialise (profiles/microbench/step_latency.hip)
+constexpr int CSTRIDE = 32;     // words per slot
 enum { F_ACTIVE = 1, F_FINISHED = 2, F_LOST = 4 };
 
 struct ConsCtrl {               // state before a step
@@ -30,15 +33,27 @@ struct ConsCtrl {               // state before a step
 };
 struct ConsMeta { int32_t e, c0, flags, pad; };
 
+// One consensus problem of a batch.  All problems of a batch advance in lockstep, one base per launch; a workgroup belongs to
+// exactly one problem (each problem's reads are padded to a multiple of CWAVES in the flattened read order).  The descriptors
+// travel in the kernel argument block (scalar loads), per-read constants are gathered once into ReadInfo: a step is a chain
+// of only two dependent memory round trips (state + control, then the read words at the wavefront tips).
+constexpr int CMAXP = 8;        // problems per launch sequence
 struct ConsParams {
-    SeqSetView reads; const uint32_t* idx; int n; const int32_t* offsets;
+    int n, first, first_block;  // reads; flattened index of local read 0; first workgroup of the problem
     int min_count, delta, et, allow_dual, window, cmp_len; double min_af;
     uint8_t* C; int cap;        // [2][cap] base codes; consensus 2 shares [0, split_at) with consensus 1
-    uint32_t* votes;            // [2][cap+1][8] : w[4], end
-    int32_t* H;                 // [2][n][64]
-    ConsMeta* meta;             // [2][n]
+    uint32_t* votes;            // [2][cap+1][CSLOTS][8] : w[4], end
     ConsCtrl* ctrl;             // [2]
 };
+struct ReadInfo { const uint32_t* w; const uint32_t* np; int n, off; long long pad; };
+struct ConsBatch {
+    ConsParams p[CMAXP]; int n_prob;
+    const ReadInfo* info;       // [total]
+    int32_t* H;                 // [2][total][64]
+    ConsMeta* meta;             // [2][total]
+    int total;
+};
+struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first; };
 
 struct ReadView { const uint32_t* w; const uint32_t* np; int n; };
 
@@ -52,21 +67,31 @@ struct Decision { int go[2]; int base[2]; int split; long long best_w2, best_tot
 
 __device__ __forceinline__ Decision decide(const ConsParams& P, const ConsCtrl& c, int t) {
     Decision d; d.go[0] = d.go[1] = 0; d.base[0] = d.base[1] = 0; d.split = 0; d.best_w2 = c.best_w2; d.best_total = c.best_total;
-    const int ncons = c.dual ? 2 : 1;
-    for (int i = 0; i < ncons; ++i) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !c.dual) continue;
         if (c.stopped[i]) continue;
-        const uint32_t* v = P.votes + ((size_t)i * (P.cap + 1) + t) * 8;
-        long long w[4] = { v[0], v[1], v[2], v[3] };
-        const long long end = v[4], total = w[0] + w[1] + w[2] + w[3];
-        int b1 = 0, b2 = -1;
-        for (int b = 1; b < 4; ++b) if (w[b] > w[b1]) b1 = b;
-        for (int b = 0; b < 4; ++b) if (b != b1 && (b2 < 0 || w[b] > w[b2])) b2 = b;
-        const bool go = P.et ? w[b1] > 0 : (total > end && w[b1] > 0);
+        if (t >= P.cap) continue;                                                  // out of room: the consensus is cut at cap
+        const uint32_t* v = P.votes + ((size_t)i * (P.cap + 1) + t) * (CSLOTS * CSTRIDE);
+        long long w[4] = { 0, 0, 0, 0 }, end = 0;
+#pragma unroll
+        for (int sl = 0; sl < CSLOTS; ++sl) {
+            const uint4 q = *reinterpret_cast<const uint4*>(v + sl * CSTRIDE);
+            w[0] += q.x; w[1] += q.y; w[2] += q.z; w[3] += q.w; end += v[sl * CSTRIDE + 4];
+        }
+        const long long total = w[0] + w[1] + w[2] + w[3];
+        int b1 = 0; long long w1 = w[0];                                           // heaviest base, ties to the lower code
+#pragma unroll
+        for (int b = 1; b < 4; ++b) if (w[b] > w1) { b1 = b; w1 = w[b]; }
+        int b2 = -1; long long w2 = -1;                                            // heaviest of the others, ties to the lower code
+#pragma unroll
+        for (int b = 0; b < 4; ++b) if (b != b1 && w[b] > w2) { b2 = b; w2 = w[b]; }
+        const bool go = P.et ? w1 > 0 : (total > end && w1 > 0);
         if (!go) continue;
         d.go[i] = 1; d.base[i] = b1;
-        if (!c.dual && w[b2] >= 12ll * P.min_count) {
-            if (w[b2] * d.best_total > d.best_w2 * total) { d.best_w2 = w[b2]; d.best_total = total; }
-            if (P.allow_dual && (double)w[b2] >= P.min_af * (double)total) { d.split = 1; d.go[1] = 1; d.base[1] = b2; }
+        if (!c.dual && w2 >= 12ll * P.min_count) {
+            if (w2 * d.best_total > d.best_w2 * total) { d.best_w2 = w2; d.best_total = total; }
+            if (P.allow_dual && (double)w2 >= P.min_af * (double)total) { d.split = 1; d.go[1] = 1; d.base[1] = b2; }
         }
     }
     return d;
@@ -74,9 +99,9 @@ __device__ __forceinline__ Decision decide(const ConsParams& P, const ConsCtrl& 
 
 // consensus i at absolute position pos as seen by launch t (position t itself is this launch's decision, not yet in memory)
 struct ConsView {
-    const uint8_t* C; int cap, split_at, t; int base_t[2];
+    const uint8_t* C; int cap, split_at, t; int base0, base1;
     __device__ __forceinline__ int at(int i, int pos) const {
-        if (pos == t) return base_t[i];
+        if (pos == t) return i ? base1 : base0;
         return (i == 1 && pos < split_at) ? C[pos] : C[(size_t)i * cap + pos];
     }
 };
@@ -127,7 +152,7 @@ __device__ __forceinline__ int find_start(const ReadView& rv, const ConsView& cv
         const int centre = off - W / 2;
         for (int j = max(1, jlo - 2 * L); j <= jhi; ++j) {
             const int x = cv.at(i, off - j);
-            const unsigned long long Eq = peq[x & 3];
+            const unsigned long long Eq = x == 0 ? peq[0] : x == 1 ? peq[1] : x == 2 ? peq[2] : peq[3];
             const unsigned long long Xv = Eq | Mv;
             const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             unsigned long long Ph = Mv | ~(Xh | Pv), Mh = Pv & Xh;
@@ -146,15 +171,25 @@ __device__ __forceinline__ int find_start(const ReadView& rv, const ConsView& cv
     return (int)(key & ((1ull << 22) - 1));
 }
 
-__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsParams P, int t) {
+__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B, int t) {
     __shared__ uint32_t lv[2][8];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CMAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
+    const ConsParams P = B.p[pi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * CWAVES + wave;
+    const int lead = (int)blockIdx.x == P.first_block;
+    const int r = ((int)blockIdx.x - P.first_block) * CWAVES + wave;
+    const size_t g = (size_t)P.first + r;                     // slot in the flattened state arrays (padding slots exist in memory)
+    // everything this wave will need from memory that does not depend on the decision is requested up front
+    const ReadInfo ri = B.info[g];
+    const ConsMeta m0 = B.meta[g], m1 = B.meta[(size_t)B.total + g];
+    const int h0 = B.H[g * CB + lane], h1 = B.H[((size_t)B.total + g) * CB + lane];
     ConsCtrl cin;
     Decision dec;
     if (t >= 0) {
         cin = P.ctrl[t & 1];
-        if (cin.done) { if (blockIdx.x == 0 && threadIdx.x == 0) P.ctrl[(t + 1) & 1] = cin; return; }
+        if (cin.done) { if (lead && threadIdx.x == 0) P.ctrl[(t + 1) & 1] = cin; return; }
         dec = decide(P, cin, t);
     } else {
         cin = P.ctrl[0];
@@ -163,8 +198,9 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsParams 
     const int dual = (t >= 0) && (cin.dual || dec.split);
     const int split_at = dec.split ? t : cin.split_at;
     if (threadIdx.x < 16) lv[threadIdx.x >> 3][threadIdx.x & 7] = 0;
-    if (t >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (t >= 0 && lead && threadIdx.x == 0) {
         ConsCtrl co = cin;
+#pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (dec.go[i]) { P.C[(size_t)i * P.cap + t] = (uint8_t)dec.base[i]; co.len[i] = t + 1; co.stopped[i] = 0; }
             else if (i == 0 || cin.dual) co.stopped[i] = 1;
@@ -175,24 +211,21 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsParams 
     }
     __syncthreads();
     if (r < P.n) {
-        const uint32_t rid = P.idx ? P.idx[r] : (uint32_t)r;
-        ReadView rv; rv.w = P.reads.words + P.reads.word_off[rid]; rv.np = P.reads.nplane ? P.reads.nplane + P.reads.word_off[rid] : nullptr;
-        rv.n = P.reads.len[rid];
-        const int off = P.offsets ? P.offsets[r] : -1;
-        ConsView cv; cv.C = P.C; cv.cap = P.cap; cv.split_at = split_at; cv.t = t; cv.base_t[0] = dec.base[0]; cv.base_t[1] = dec.base[1];
+        ReadView rv; rv.w = ri.w; rv.np = ri.np; rv.n = ri.n;
+        const int off = ri.off;
+        ConsView cv; cv.C = P.C; cv.cap = P.cap; cv.split_at = split_at; cv.t = t; cv.base0 = dec.base[0]; cv.base1 = dec.base[1];
         Dwfa d[2];
+#pragma unroll
         for (int i = 0; i < 2; ++i) { d[i].H = SP_NEG; d[i].e = 0; d[i].c0 = 0; d[i].flags = 0; }
         if (t < 0) {
             if (off < 0) { d[0].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0); d[0].H = lane == CH ? 0 : SP_NEG; }
         } else {
-            const ConsMeta m0 = P.meta[r];
-            d[0].H = P.H[(size_t)r * CB + lane]; d[0].e = m0.e; d[0].c0 = m0.c0; d[0].flags = m0.flags;
+            d[0].H = h0; d[0].e = m0.e; d[0].c0 = m0.c0; d[0].flags = m0.flags;
             if (dec.split) d[1] = d[0];
-            else if (cin.dual) {
-                const ConsMeta m1 = P.meta[(size_t)P.n + r];
-                d[1].H = P.H[((size_t)P.n + r) * CB + lane]; d[1].e = m1.e; d[1].c0 = m1.c0; d[1].flags = m1.flags;
-            }
-            for (int i = 0; i < (dual ? 2 : 1); ++i) {
+            else if (cin.dual) { d[1].H = h1; d[1].e = m1.e; d[1].c0 = m1.c0; d[1].flags = m1.flags; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !dual) continue;
                 if (!dec.go[i]) continue;
                 const int len = t + 1;
                 if (d[i].flags & F_ACTIVE) {
@@ -215,7 +248,9 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsParams 
             }
         }
         // votes for position t+1
-        for (int i = 0; i < (dual ? 2 : 1); ++i) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && !dual) continue;
             if (t >= 0 && !dec.go[i]) continue;
             if (!(d[i].flags & F_ACTIVE) || (d[i].flags & (F_FINISHED | F_LOST))) continue;
             if (dual) { const Dwfa& o = d[1 - i]; if ((o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < d[i].e) continue; }
@@ -227,38 +262,61 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsParams 
             for (int b = 0; b < 4; ++b) { seen[b] = __ballot(code == b) != 0; dc += seen[b]; }
             const bool ended = __ballot(tip) != 0 && __ballot(code == 4) == 0;      // every tip sits at the end of the read
             if (lane == 0) {
-                if (dc) { for (int b = 0; b < 4; ++b) if (seen[b]) atomicAdd(&lv[i][b], 12u / dc); }
+                if (dc) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) if (seen[b]) atomicAdd(&lv[i][b], 12u / dc);
+                }
                 else if (ended) atomicAdd(&lv[i][4], 12u);
             }
         }
         // store
-        for (int i = 0; i < (dual ? 2 : 1); ++i) {
-            if (lane == 0) { ConsMeta m; m.e = d[i].e; m.c0 = d[i].c0; m.flags = d[i].flags; m.pad = 0; P.meta[(size_t)i * P.n + r] = m; }
-            P.H[((size_t)i * P.n + r) * CB + lane] = d[i].H;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && !dual) continue;
+            if (lane == 0) { ConsMeta m; m.e = d[i].e; m.c0 = d[i].c0; m.flags = d[i].flags; m.pad = 0; B.meta[(size_t)i * B.total + g] = m; }
+            B.H[((size_t)i * B.total + g) * CB + lane] = d[i].H;
         }
     }
     __syncthreads();
     if (threadIdx.x < 16) {
         const int i = threadIdx.x >> 3, j = threadIdx.x & 7;
         const uint32_t v = lv[i][j];
-        if (v) atomicAdd(P.votes + ((size_t)i * (P.cap + 1) + (t + 1)) * 8 + j, v);
+        if (v && t + 1 <= P.cap) atomicAdd(P.votes + (((size_t)i * (P.cap + 1) + (t + 1)) * CSLOTS + (blockIdx.x & (CSLOTS - 1))) * CSTRIDE + j, v);
     }
 }
 
-__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsParams P, int which, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
+// gathers the per-read constants of one problem into the flattened ReadInfo array (once per batch)
+__global__ void cons_setup_kernel(ConsSetup S, ReadInfo* __restrict__ info) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= S.n) return;
+    const uint32_t rid = S.idx ? S.idx[r] : (uint32_t)r;
+    ReadInfo ri;
+    ri.w = S.reads.words + S.reads.word_off[rid];
+    ri.np = S.reads.nplane ? S.reads.nplane + S.reads.word_off[rid] : nullptr;
+    ri.n = S.reads.len[rid]; ri.off = S.offsets ? S.offsets[r] : -1; ri.pad = 0;
+    info[S.first + r] = ri;
+}
+
+__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBatch B, int which, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CMAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
+    const ConsParams P = B.p[pi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * CWAVES + wave;
+    const int r = ((int)blockIdx.x - P.first_block) * CWAVES + wave;
     if (r >= P.n) return;
+    const size_t g = (size_t)P.first + r;
     const ConsCtrl c = P.ctrl[which];
-    const uint32_t rid = P.idx ? P.idx[r] : (uint32_t)r;
-    const int n = P.reads.len[rid];
+    const int n = B.info[g].n;
     int sc[2] = { -1, -1 };
-    for (int i = 0; i < (c.dual ? 2 : 1); ++i) {
-        const ConsMeta m = P.meta[(size_t)i * P.n + r];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !c.dual) continue;
+        const ConsMeta m = B.meta[(size_t)i * B.total + g];
         if (!(m.flags & F_ACTIVE) || (m.flags & F_LOST)) continue;
         int e = m.e;
         if (!P.et) {
-            const int h = P.H[((size_t)i * P.n + r) * CB + lane], k = lane - CH;
+            const int h = B.H[((size_t)i * B.total + g) * CB + lane], k = lane - CH;
             int rest = (h >= 0 && h + k == c.len[i] - m.c0) ? n - h : (1 << 30);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(rest, o); rest = other < rest ? other : rest; }
@@ -267,112 +325,198 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsPar
         sc[i] = e;
     }
     if (lane == 0) {
-        score1[r] = sc[0]; score2[r] = sc[1];
-        is_cons1[r] = !(sc[1] >= 0 && (sc[0] < 0 || sc[1] < sc[0]));
+        score1[g] = sc[0]; score2[g] = sc[1];
+        is_cons1[g] = !(sc[1] >= 0 && (sc[0] < 0 || sc[1] < sc[0]));
     }
 }
 
 } // namespace
 
-extern "C" {
-
-int32_t sp_consensus(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* read_idx, uint32_t n, const int32_t* offsets,
-                     const sp_cons_config* cfg, char* cons1, char* cons2, uint32_t cap,
-                     uint8_t* is_cons1, int32_t* score1, int32_t* score2, sp_cons_result* result) {
-    if (!ctx) return SP_ERR_INVALID_ARG;
-    if (!reads || !cfg || !cons1 || !cons2 || !is_cons1 || !score1 || !score2 || !result || cap == 0)
-        return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: null argument");
-    if (cfg->offset_compare_length > 64 || cfg->offset_compare_length < 0 || cfg->offset_window < 0 || cfg->min_count < 0)
-        return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: offset_compare_length must be <= 64");
-    if (cap >= (1u << 22)) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must be below 4,194,304");
-    if (!read_idx) n = reads->n;
-    std::memset(result, 0, sizeof *result);
-    result->split_at = -1; result->best_total = 1;
-    cons1[0] = cons2[0] = '\0';
-    if (n == 0) return SP_OK;
-    if (read_idx) for (uint32_t i = 0; i < n; ++i) if (read_idx[i] >= reads->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: read index out of range");
-    SP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+// host side of a batch of at most CMAXP problems: all of them advance one base per launch until every one has stopped
+static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* probs, sp_cons_output* outs) {
     hipStream_t st = ctx->stream;
-
-    ConsParams P;
-    P.reads = reads->view(); P.n = (int)n; P.cap = (int)cap;
-    P.min_count = cfg->min_count; P.delta = cfg->dual_max_ed_delta; P.et = cfg->allow_early_termination != 0; P.allow_dual = cfg->allow_dual != 0;
-    P.window = cfg->offset_window; P.cmp_len = cfg->offset_compare_length; P.min_af = cfg->min_af;
-    uint32_t* d_idx = nullptr; int32_t* d_off = nullptr;
-    if (read_idx) { d_idx = (uint32_t*)sp_pool(ctx, "cons_idx", sizeof(uint32_t) * n); if (!d_idx) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "cons_idx"); }
-    if (offsets)  { d_off = (int32_t*)sp_pool(ctx, "cons_off", sizeof(int32_t) * n); if (!d_off) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "cons_off"); }
-    P.idx = d_idx; P.offsets = d_off;
-    const size_t votes_bytes = sizeof(uint32_t) * 8 * 2 * ((size_t)cap + 1);
-    P.C = (uint8_t*)sp_pool(ctx, "cons_C", 2 * (size_t)cap);
-    P.votes = (uint32_t*)sp_pool(ctx, "cons_votes", votes_bytes);
-    P.H = (int32_t*)sp_pool(ctx, "cons_H", sizeof(int32_t) * 2 * (size_t)n * CB);
-    P.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * 2 * (size_t)n);
-    P.ctrl = (ConsCtrl*)sp_pool(ctx, "cons_ctrl", sizeof(ConsCtrl) * 2);
-    uint8_t* d_is1 = (uint8_t*)sp_pool(ctx, "cons_is1", n);
-    int32_t* d_sc = (int32_t*)sp_pool(ctx, "cons_scores", sizeof(int32_t) * 2 * (size_t)n);
-    if (!P.C || !P.votes || !P.H || !P.meta || !P.ctrl || !d_is1 || !d_sc) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus buffers");
-    if (read_idx) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, read_idx, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st));
-    if (offsets)  SP_HIP_CHECK(ctx, hipMemcpyAsync(d_off, offsets, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemsetAsync(P.votes, 0, votes_bytes, st));
-    SP_HIP_CHECK(ctx, hipMemsetAsync(P.meta, 0, sizeof(ConsMeta) * 2 * (size_t)n, st));
+    ConsBatch B; std::memset(&B, 0, sizeof B);
+    B.n_prob = (int)n_prob;
+    std::vector<ConsSetup> setup(n_prob);
+    std::vector<uint32_t> h_idx; std::vector<int32_t> h_off;
+    std::vector<size_t> idx_at(n_prob), off_at(n_prob), c_at(n_prob), v_at(n_prob);
+    size_t total = 0, c_bytes = 0, v_words = 0; int max_cap = 0, n_blocks = 0;
+    for (uint32_t p = 0; p < n_prob; ++p) {
+        const sp_cons_problem& q = probs[p];
+        const uint32_t n = q.read_idx ? q.n : q.reads->n;
+        ConsParams& P = B.p[p];
+        P.n = (int)n; P.cap = (int)outs[p].cap - 1;                                   // one byte of the caller's buffer is the NUL
+        P.first = (int)total; P.first_block = n_blocks;
+        P.min_count = q.cfg.min_count; P.delta = q.cfg.dual_max_ed_delta; P.et = q.cfg.allow_early_termination != 0; P.allow_dual = q.cfg.allow_dual != 0;
+        P.window = q.cfg.offset_window; P.cmp_len = q.cfg.offset_compare_length; P.min_af = q.cfg.min_af;
+        const uint32_t nb = (n + CWAVES - 1) / CWAVES;
+        n_blocks += (int)nb;
+        setup[p].reads = q.reads->view(); setup[p].n = (int)n; setup[p].first = (int)total;
+        total += (size_t)nb * CWAVES;
+        idx_at[p] = h_idx.size(); if (q.read_idx) h_idx.insert(h_idx.end(), q.read_idx, q.read_idx + n);
+        off_at[p] = h_off.size(); if (q.offsets) h_off.insert(h_off.end(), q.offsets, q.offsets + n);
+        c_at[p] = c_bytes; c_bytes += 2 * (size_t)std::max(P.cap, 1);
+        v_at[p] = v_words; v_words += (size_t)2 * (P.cap + 1) * CSLOTS * CSTRIDE;
+        max_cap = std::max(max_cap, P.cap);
+    }
+    if (n_blocks == 0) return SP_OK;
+    uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "cons_idx", sizeof(uint32_t) * std::max<size_t>(1, h_idx.size()));
+    int32_t* d_off = (int32_t*)sp_pool(ctx, "cons_off", sizeof(int32_t) * std::max<size_t>(1, h_off.size()));
+    uint8_t* d_C = (uint8_t*)sp_pool(ctx, "cons_C", c_bytes);
+    uint32_t* d_votes = (uint32_t*)sp_pool(ctx, "cons_votes", sizeof(uint32_t) * v_words);
+    ConsCtrl* d_ctrl = (ConsCtrl*)sp_pool(ctx, "cons_ctrl", sizeof(ConsCtrl) * 2 * n_prob);
+    ReadInfo* d_info = (ReadInfo*)sp_pool(ctx, "cons_info", sizeof(ReadInfo) * total);
+    B.info = d_info; B.total = (int)total;
+    B.H = (int32_t*)sp_pool(ctx, "cons_H", sizeof(int32_t) * 2 * total * CB);
+    B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * 2 * total);
+    uint8_t* d_is1 = (uint8_t*)sp_pool(ctx, "cons_is1", total);
+    int32_t* d_sc = (int32_t*)sp_pool(ctx, "cons_scores", sizeof(int32_t) * 2 * total);
+    if (!d_idx || !d_off || !d_C || !d_votes || !d_ctrl || !d_info || !B.H || !B.meta || !d_is1 || !d_sc)
+        return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus buffers");
+    for (uint32_t p = 0; p < n_prob; ++p) {
+        setup[p].idx = probs[p].read_idx ? d_idx + idx_at[p] : nullptr;
+        setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr;
+        B.p[p].C = d_C + c_at[p]; B.p[p].votes = d_votes + v_at[p]; B.p[p].ctrl = d_ctrl + 2 * p;
+    }
     ConsCtrl c0; std::memset(&c0, 0, sizeof c0); c0.split_at = -1; c0.stopped[1] = 1; c0.best_total = 1;
-    ConsCtrl init[2] = { c0, c0 };
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(P.ctrl, init, sizeof init, hipMemcpyHostToDevice, st));
+    std::vector<ConsCtrl> h_ctrl(2 * (size_t)n_prob, c0);
+    if (!h_idx.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, h_idx.data(), sizeof(uint32_t) * h_idx.size(), hipMemcpyHostToDevice, st));
+    if (!h_off.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_off, h_off.data(), sizeof(int32_t) * h_off.size(), hipMemcpyHostToDevice, st));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ctrl, h_ctrl.data(), sizeof(ConsCtrl) * h_ctrl.size(), hipMemcpyHostToDevice, st));
+    SP_HIP_CHECK(ctx, hipMemsetAsync(d_votes, 0, sizeof(uint32_t) * v_words, st));
+    SP_HIP_CHECK(ctx, hipMemsetAsync(B.meta, 0, sizeof(ConsMeta) * 2 * total, st));
+    SP_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(ReadInfo) * total, st));
+    for (uint32_t p = 0; p < n_prob; ++p)
+        if (setup[p].n) hipLaunchKernelGGL(cons_setup_kernel, dim3((setup[p].n + 255) / 256), dim3(256), 0, st, setup[p], d_info);
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));      // the pageable host sources above must stay valid until copied
 
-    const dim3 grid((n + CWAVES - 1) / CWAVES), block(CWAVES * SP_WAVE);
-    ConsCtrl cur = c0;
+    const dim3 grid((uint32_t)n_blocks), block(CWAVES * SP_WAVE);
     int last = -1;
     {
-        ProfScope ps(ctx, "cons_steps", n);
-        hipLaunchKernelGGL(cons_step_kernel, grid, block, 0, st, P, -1);
-        for (int t = 0; t < (int)cap; ++t) {
-            hipLaunchKernelGGL(cons_step_kernel, grid, block, 0, st, P, t);
+        ProfScope ps(ctx, "cons_steps", total);
+        hipLaunchKernelGGL(cons_step_kernel, grid, block, 0, st, B, -1);
+        for (int t = 0; t <= max_cap; ++t) {                 // launch t = max_cap only records the stop of a consensus that filled its room
+            hipLaunchKernelGGL(cons_step_kernel, grid, block, 0, st, B, t);
             last = t;
-            if ((t & 255) == 255 || t + 1 == (int)cap) {
-                SP_HIP_CHECK(ctx, hipMemcpyAsync(&cur, P.ctrl + ((t + 1) & 1), sizeof cur, hipMemcpyDeviceToHost, st));
+            if ((t & 255) == 255 || t == max_cap) {
+                SP_HIP_CHECK(ctx, hipMemcpyAsync(h_ctrl.data(), d_ctrl, sizeof(ConsCtrl) * h_ctrl.size(), hipMemcpyDeviceToHost, st));
                 SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
-                if (cur.done) break;
+                bool all = true;
+                for (uint32_t p = 0; p < n_prob; ++p) all = all && h_ctrl[2 * p + ((t + 1) & 1)].done;
+                if (all) break;
             }
         }
     }
     SP_HIP_CHECK(ctx, hipGetLastError());
     const int which = (last + 1) & 1;
-    hipLaunchKernelGGL(cons_finalize_kernel, grid, block, 0, st, P, which, d_is1, d_sc, d_sc + n);
-    std::vector<uint8_t> hc(2 * (size_t)cap);
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(hc.data(), P.C, hc.size(), hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(is_cons1, d_is1, n, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(score1, d_sc, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(score2, d_sc + n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(&cur, P.ctrl + which, sizeof cur, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(cons_finalize_kernel, grid, block, 0, st, B, which, d_is1, d_sc, d_sc + total);
+    std::vector<uint8_t> hc(c_bytes), h_is1(total);
+    std::vector<int32_t> h_sc(2 * total);
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(hc.data(), d_C, c_bytes, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_is1.data(), d_is1, total, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_sc.data(), d_sc, sizeof(int32_t) * 2 * total, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_ctrl.data(), d_ctrl, sizeof(ConsCtrl) * h_ctrl.size(), hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
     SP_HIP_CHECK(ctx, hipGetLastError());
-    // a consensus that is still growing when cap is reached is truncated there (len == cap): the caller sized cap too small
     static const char dec[4] = { 'A', 'C', 'G', 'T' };
-    const int len1 = cur.len[0], len2 = cur.dual ? cur.len[1] : 0;
-    if ((uint32_t)len1 >= cap || (uint32_t)len2 >= cap) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_consensus: consensus reached cap");
-    for (int p = 0; p < len1; ++p) cons1[p] = dec[hc[p] & 3];
-    cons1[len1] = '\0';
-    for (int p = 0; p < len2; ++p) cons2[p] = dec[(p < cur.split_at ? hc[p] : hc[(size_t)cap + p]) & 3];
-    cons2[len2] = '\0';
-    result->is_dual = cur.dual; result->len1 = len1; result->len2 = len2; result->split_at = cur.split_at;
-    result->best_w2 = cur.best_w2; result->best_total = cur.best_total;
-    return SP_OK;
+    int32_t rc = SP_OK;
+    for (uint32_t p = 0; p < n_prob; ++p) {
+        const ConsParams& P = B.p[p]; sp_cons_output& o = outs[p];
+        const ConsCtrl& cur = h_ctrl[2 * p + which];
+        const uint8_t* c = hc.data() + c_at[p];
+        const int len1 = cur.len[0], len2 = cur.dual ? cur.len[1] : 0;
+        for (int x = 0; x < len1; ++x) o.cons1[x] = dec[c[x] & 3];
+        o.cons1[len1] = '\0';
+        for (int x = 0; x < len2; ++x) o.cons2[x] = dec[(x < cur.split_at ? c[x] : c[(size_t)P.cap + x]) & 3];
+        o.cons2[len2] = '\0';
+        for (int r = 0; r < P.n; ++r) { o.is_cons1[r] = h_is1[P.first + r]; o.score1[r] = h_sc[P.first + r]; o.score2[r] = h_sc[total + P.first + r]; }
+        o.result.is_dual = cur.dual; o.result.len1 = len1; o.result.len2 = len2; o.result.split_at = cur.split_at;
+        o.result.best_w2 = cur.best_w2; o.result.best_total = cur.best_total;
+        // a consensus that filled its buffer was still growing: the caller sized cap too small
+        if (len1 >= P.cap || len2 >= P.cap) { o.status = SP_ERR_CAPACITY; rc = SP_ERR_CAPACITY; }
+    }
+    if (rc != SP_OK) sp_fail(ctx, rc, "sp_consensus: a consensus reached cap");
+    return rc;
+}
+
+static int32_t run_batch(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* probs, sp_cons_output* outs) {
+    for (uint32_t p = 0; p < n_prob; ++p) {
+        const sp_cons_problem& q = probs[p]; sp_cons_output& o = outs[p];
+        if (!q.reads || !o.cons1 || !o.cons2 || o.cap == 0 || !o.is_cons1 || !o.score1 || !o.score2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: null argument");
+        if (q.cfg.offset_compare_length > 64 || q.cfg.offset_compare_length < 0 || q.cfg.offset_window < 0 || q.cfg.min_count < 0)
+            return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: offset_compare_length must be in [0, 64]");
+        if (o.cap >= (1u << 22)) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must be below 4,194,304");
+        std::memset(&o.result, 0, sizeof o.result); o.result.split_at = -1; o.result.best_total = 1; o.status = SP_OK;
+        o.cons1[0] = o.cons2[0] = '\0';
+        const uint32_t n = q.read_idx ? q.n : q.reads->n;
+        if (q.read_idx) for (uint32_t i = 0; i < n; ++i) if (q.read_idx[i] >= q.reads->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: read index out of range");
+    }
+    SP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int32_t rc = SP_OK;
+    for (uint32_t at = 0; at < n_prob; at += CMAXP) {
+        const int32_t e = run_chunk(ctx, std::min<uint32_t>(CMAXP, n_prob - at), probs + at, outs + at);
+        if (e != SP_OK && e != SP_ERR_CAPACITY) return e;
+        if (e != SP_OK) rc = e;
+    }
+    return rc;
+}
+
+extern "C" {
+
+int32_t sp_consensus_batch(sp_ctx* ctx, uint32_t n_problems, const sp_cons_problem* problems, sp_cons_output* outputs) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (n_problems == 0) return SP_OK;
+    if (!problems || !outputs) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_batch: null argument");
+    return run_batch(ctx, n_problems, problems, outputs);
+}
+
+int32_t sp_consensus_dual_batch(sp_ctx* ctx, uint32_t n_problems, const sp_cons_problem* problems, sp_cons_output* outputs) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (n_problems == 0) return SP_OK;
+    if (!problems || !outputs) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_dual_batch: null argument");
+    std::vector<sp_cons_problem> pass(problems, problems + n_problems);
+    for (auto& q : pass) q.cfg.allow_dual = 0;
+    int32_t rc = run_batch(ctx, n_problems, pass.data(), outputs);
+    if (rc != SP_OK) return rc;
+    std::vector<sp_cons_problem> again; std::vector<sp_cons_output> outs2; std::vector<uint32_t> who;
+    for (uint32_t p = 0; p < n_problems; ++p) {
+        if (outputs[p].result.best_w2 == 0) continue;                   // no column with min_count reads on a second base: nothing to split
+        sp_cons_problem q = problems[p];
+        q.cfg.allow_dual = 1;
+        const double strongest = 0.5 * (double)outputs[p].result.best_w2 / (double)outputs[p].result.best_total;
+        if (strongest > q.cfg.min_af) q.cfg.min_af = strongest;
+        again.push_back(q); outs2.push_back(outputs[p]); who.push_back(p);
+    }
+    if (again.empty()) return SP_OK;
+    rc = run_batch(ctx, (uint32_t)again.size(), again.data(), outs2.data());
+    for (size_t k = 0; k < who.size(); ++k) outputs[who[k]] = outs2[k];
+    return rc;
+}
+
+int32_t sp_consensus(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* read_idx, uint32_t n, const int32_t* offsets,
+                     const sp_cons_config* cfg, char* cons1, char* cons2, uint32_t cap,
+                     uint8_t* is_cons1, int32_t* score1, int32_t* score2, sp_cons_result* result) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!reads || !cfg || !result) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: null argument");
+    sp_cons_problem q; q.reads = reads; q.read_idx = read_idx; q.n = n; q.offsets = offsets; q.cfg = *cfg;
+    sp_cons_output o; std::memset(&o, 0, sizeof o);
+    o.cons1 = cons1; o.cons2 = cons2; o.cap = cap; o.is_cons1 = is_cons1; o.score1 = score1; o.score2 = score2;
+    const int32_t rc = run_batch(ctx, 1, &q, &o);
+    *result = o.result;
+    return rc;
 }
 
 int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* read_idx, uint32_t n, const int32_t* offsets,
                           const sp_cons_config* cfg, char* cons1, char* cons2, uint32_t cap,
                           uint8_t* is_cons1, int32_t* score1, int32_t* score2, sp_cons_result* result) {
     if (!ctx) return SP_ERR_INVALID_ARG;
-    if (!cfg) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_dual: null config");
-    sp_cons_config pass = *cfg;
-    pass.allow_dual = 0;
-    int32_t rc = sp_consensus(ctx, reads, read_idx, n, offsets, &pass, cons1, cons2, cap, is_cons1, score1, score2, result);
-    if (rc != SP_OK || result->best_w2 == 0) return rc;
-    pass.allow_dual = 1;
-    const double strongest = 0.5 * (double)result->best_w2 / (double)result->best_total;
-    pass.min_af = cfg->min_af > strongest ? cfg->min_af : strongest;
-    return sp_consensus(ctx, reads, read_idx, n, offsets, &pass, cons1, cons2, cap, is_cons1, score1, score2, result);
+    if (!reads || !cfg || !result) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_dual: null argument");
+    sp_cons_problem q; q.reads = reads; q.read_idx = read_idx; q.n = n; q.offsets = offsets; q.cfg = *cfg;
+    sp_cons_output o; std::memset(&o, 0, sizeof o);
+    o.cons1 = cons1; o.cons2 = cons2; o.cap = cap; o.is_cons1 = is_cons1; o.score1 = score1; o.score2 = score2;
+    const int32_t rc = sp_consensus_dual_batch(ctx, 1, &q, &o);
+    *result = o.result;
+    return rc;
 }
 
 } // extern "C"

@@ -100,6 +100,15 @@ class sp_cons_result(C.Structure):
     _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64)]
 
 
+class sp_cons_problem(C.Structure):
+    _fields_ = [("reads", C.c_void_p), ("read_idx", C.c_void_p), ("n", C.c_uint32), ("offsets", C.c_void_p), ("cfg", sp_cons_config)]
+
+
+class sp_cons_output(C.Structure):
+    _fields_ = [("cons1", C.c_void_p), ("cons2", C.c_void_p), ("cap", C.c_uint32), ("is_cons1", C.c_void_p), ("score1", C.c_void_p),
+                ("score2", C.c_void_p), ("result", sp_cons_result), ("status", C.c_int32)]
+
+
 class sp_hla_call_config(C.Structure):
     _fields_ = [("min_consensus_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("min_consensus_fraction", C.c_double),
                 ("expected_maf", C.c_double), ("min_cdf", C.c_double), ("require_dna", C.c_int32), ("disable_cdna", C.c_int32),
@@ -179,6 +188,8 @@ def lib():
         "sp_variant_multi_normalize": (i32, [C.c_char_p, u64, u64, C.c_char_p, C.c_char_p, u32, C.POINTER(u32), vp, vp, C.c_char_p, C.c_char_p, u32]),
         "sp_consensus": (i32, [vp, vp, vp, u32, vp, C.POINTER(sp_cons_config), C.c_char_p, C.c_char_p, u32, vp, vp, vp, C.POINTER(sp_cons_result)]),
         "sp_consensus_dual": (i32, [vp, vp, vp, u32, vp, C.POINTER(sp_cons_config), C.c_char_p, C.c_char_p, u32, vp, vp, vp, C.POINTER(sp_cons_result)]),
+        "sp_consensus_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
+        "sp_consensus_dual_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
         "sp_hla_diplotype_gene": (i32, [vp, vp, u32, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, C.c_char_p, u32, vp]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
@@ -356,6 +367,33 @@ class Context:
         self.check(fn(self._h, reads._h, _ptr(idx), n, _ptr(offs), C.byref(cfg), c1, c2, cap + 1, _ptr(is1), _ptr(s1), _ptr(s2), C.byref(res)))
         return dict(cons=[c1.value.decode(), c2.value.decode() if res.is_dual else None], is_dual=bool(res.is_dual), is_cons1=is1[:n].astype(bool),
                     score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, best_w2=res.best_w2, best_total=res.best_total)
+
+    def consensus_batch(self, problems, two_pass=False):
+        """problems: list of dict(reads=SeqSet, cfg=sp_cons_config, offsets=None|list, read_idx=None|array, cap=None).
+        sp_consensus_batch / sp_consensus_dual_batch -> list of result dicts (as consensus())"""
+        k = len(problems)
+        P, O, keep = (sp_cons_problem * k)(), (sp_cons_output * k)(), []
+        for j, q in enumerate(problems):
+            reads, idx = q["reads"], q.get("read_idx")
+            n = len(idx) if idx is not None else reads.n
+            idx = np.ascontiguousarray(idx, np.uint32) if idx is not None else None
+            offs = np.array([-1 if o is None else int(o) for o in q["offsets"]], np.int32) if q.get("offsets") is not None else None
+            lens = reads.lengths if idx is None else reads.lengths[idx.astype(np.int64)]
+            cap = q.get("cap") or (int(lens.max() if n else 0) + int(max(0, offs.max()) if offs is not None and n else 0) + 64)
+            c1, c2 = C.create_string_buffer(cap + 1), C.create_string_buffer(cap + 1)
+            is1, s1, s2 = np.zeros(max(1, n), np.uint8), np.zeros(max(1, n), np.int32), np.zeros(max(1, n), np.int32)
+            keep.append((idx, offs, c1, c2, is1, s1, s2, n))
+            P[j].reads, P[j].read_idx, P[j].n, P[j].offsets, P[j].cfg = reads._h, (idx.ctypes.data if idx is not None else None), n, (offs.ctypes.data if offs is not None else None), q["cfg"]
+            O[j].cons1, O[j].cons2, O[j].cap = C.cast(c1, C.c_void_p), C.cast(c2, C.c_void_p), cap + 1
+            O[j].is_cons1, O[j].score1, O[j].score2 = is1.ctypes.data, s1.ctypes.data, s2.ctypes.data
+        fn = lib().sp_consensus_dual_batch if two_pass else lib().sp_consensus_batch
+        self.check(fn(self._h, k, P, O))
+        out = []
+        for j, (idx, offs, c1, c2, is1, s1, s2, n) in enumerate(keep):
+            res = O[j].result
+            out.append(dict(cons=[c1.value.decode(), c2.value.decode() if res.is_dual else None], is_dual=bool(res.is_dual), is_cons1=is1[:n].astype(bool),
+                            score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, best_w2=res.best_w2, best_total=res.best_total))
+        return out
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))

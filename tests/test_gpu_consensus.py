@@ -83,3 +83,20 @@ def test_random_small_inputs(oracle, pkg, gpu_ctx):
             raise AssertionError(f"iteration {it}: {e}")
         n_dual += exp["is_dual"]
     assert n_dual >= 5
+
+
+def test_batch_equals_one_by_one(oracle, pkg, gpu_ctx):
+    """independent problems advanced in lockstep (sp_consensus_batch / sp_consensus_dual_batch) give what they give alone"""
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture()
+    cs, _ = consensus_cases.cases(fx, synth, oracle)
+    for two_pass in (False, True):
+        chosen = [c for c in cs if c[4] == two_pass]
+        sets = [gpu_ctx.upload(reads) for _, reads, _, _, _ in chosen]
+        probs = [dict(reads=S, cfg=gpu_cfg(pkg, **kw), offsets=offs) for S, (_, _, offs, kw, _) in zip(sets, chosen)]
+        got = gpu_ctx.consensus_batch(probs, two_pass=two_pass)
+        for g, (name, reads, offs, kw, tp) in zip(got, chosen):
+            try:
+                same(g, run_case(oracle, reads, offs, kw, tp))
+            except AssertionError as e:
+                raise AssertionError(f"case {name} (two_pass={two_pass}): {e}")
