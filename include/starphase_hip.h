@@ -382,7 +382,7 @@ int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* r
  * each (:756,829); heterozygous if the dual passes, else homozygous for the larger group (:889-912).
  *   realign      the K1 output for `reads` (sp_hla_realign_reads)
  *   cons1/cons2  cap bytes each: the hg38-forward consensus of each group (empty = none / failed)
- *   is_cons1     optional, call->n_reads entries: DualConsensus::is_consensus1 of the gene's realigned reads
+ *   is_cons1     optional, one entry per read of `reads`: DualConsensus::is_consensus1 (0 for reads not realigned to the gene)
  * call->status: 0 = called, 1 = no realigned reads (NO_READS / NO_CALL, :662-668).  allele1/allele2 are database indices,
  * -1 = unknown (no allele typed), -2 = the absent haplotype of a hemizygous call (:919-923). */
 typedef struct {
@@ -407,6 +407,12 @@ typedef struct {
 
 int32_t sp_hla_diplotype_gene(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene, const sp_seqset* reads, const sp_hla_realign* realign,
                               const sp_hla_call_config* cfg, sp_hla_call* call, char* cons1, char* cons2, uint32_t cap, uint8_t* is_cons1);
+/* several genes at once: their consensus problems advance in lockstep on the GPU (the gene buckets are independent,
+ * src/hla/caller.rs:642), so the whole sample costs as many launches as its longest gene.  cfgs / calls: n_genes entries;
+ * cons: n_genes * 2 * cap bytes, consensus c of gene k at cons + (2k + c) * cap. */
+int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_genes, const uint32_t* genes, const sp_seqset* reads,
+                               const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
+                               char* cons, uint32_t cap, uint8_t* is_cons1);
 
 /* ------------------------------------------------------------------ host-side decisions of the path (no device work)
  * Small scalar routines the reference evaluates between the kernels; kept behind the same ABI so a host can drop the whole

@@ -65,20 +65,29 @@ __device__ __forceinline__ int read_base(const ReadView& rv, int h) {
 
 struct Decision { int go[2]; int base[2]; int split; long long best_w2, best_total; };
 
-__device__ __forceinline__ Decision decide(const ConsParams& P, const ConsCtrl& c, int t) {
+// Every wave re-derives the decision for position t.  Lanes 0-15 fetch the 2 x CSLOTS vote slots (one 128-byte line each) and the
+// sums are formed with three shuffle steps, so the whole decision costs one memory round trip and a handful of registers.
+__device__ __forceinline__ Decision decide(const ConsParams& P, const ConsCtrl& c, int t, int lane) {
     Decision d; d.go[0] = d.go[1] = 0; d.base[0] = d.base[1] = 0; d.split = 0; d.best_w2 = c.best_w2; d.best_total = c.best_total;
+    if (t >= P.cap) return d;                                                      // out of room: the consensus is cut at cap
+    uint32_t x[5] = { 0, 0, 0, 0, 0 };
+    if (lane < 2 * CSLOTS) {
+        const uint32_t* v = P.votes + (((size_t)(lane >> 3) * (P.cap + 1) + t) * CSLOTS + (lane & (CSLOTS - 1))) * CSTRIDE;
+        const uint4 q = *reinterpret_cast<const uint4*>(v);
+        x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; x[4] = v[4];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        x[j] += __shfl_xor(x[j], 1); x[j] += __shfl_xor(x[j], 2); x[j] += __shfl_xor(x[j], 4);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (i == 1 && !c.dual) continue;
         if (c.stopped[i]) continue;
-        if (t >= P.cap) continue;                                                  // out of room: the consensus is cut at cap
-        const uint32_t* v = P.votes + ((size_t)i * (P.cap + 1) + t) * (CSLOTS * CSTRIDE);
-        long long w[4] = { 0, 0, 0, 0 }, end = 0;
+        long long w[4];
 #pragma unroll
-        for (int sl = 0; sl < CSLOTS; ++sl) {
-            const uint4 q = *reinterpret_cast<const uint4*>(v + sl * CSTRIDE);
-            w[0] += q.x; w[1] += q.y; w[2] += q.z; w[3] += q.w; end += v[sl * CSTRIDE + 4];
-        }
+        for (int b = 0; b < 4; ++b) w[b] = (long long)(uint32_t)__builtin_amdgcn_readlane((int)x[b], i * CSLOTS);
+        const long long end = (long long)(uint32_t)__builtin_amdgcn_readlane((int)x[4], i * CSLOTS);
         const long long total = w[0] + w[1] + w[2] + w[3];
         int b1 = 0; long long w1 = w[0];                                           // heaviest base, ties to the lower code
 #pragma unroll
@@ -190,7 +199,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B
     if (t >= 0) {
         cin = P.ctrl[t & 1];
         if (cin.done) { if (lead && threadIdx.x == 0) P.ctrl[(t + 1) & 1] = cin; return; }
-        dec = decide(P, cin, t);
+        dec = decide(P, cin, t, lane);
     } else {
         cin = P.ctrl[0];
         dec.go[0] = dec.go[1] = 0; dec.base[0] = dec.base[1] = 0; dec.split = 0; dec.best_w2 = 0; dec.best_total = 1;
@@ -212,13 +221,12 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B
     __syncthreads();
     if (r < P.n) {
         ReadView rv; rv.w = ri.w; rv.np = ri.np; rv.n = ri.n;
-        const int off = ri.off;
         ConsView cv; cv.C = P.C; cv.cap = P.cap; cv.split_at = split_at; cv.t = t; cv.base0 = dec.base[0]; cv.base1 = dec.base[1];
         Dwfa d[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { d[i].H = SP_NEG; d[i].e = 0; d[i].c0 = 0; d[i].flags = 0; }
         if (t < 0) {
-            if (off < 0) { d[0].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0); d[0].H = lane == CH ? 0 : SP_NEG; }
+            if (ri.off < 0) { d[0].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0); d[0].H = lane == CH ? 0 : SP_NEG; }
         } else {
             d[0].H = h0; d[0].e = m0.e; d[0].c0 = m0.c0; d[0].flags = m0.flags;
             if (dec.split) d[1] = d[0];
@@ -228,16 +236,8 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B
                 if (i == 1 && !dual) continue;
                 if (!dec.go[i]) continue;
                 const int len = t + 1;
-                if (d[i].flags & F_ACTIVE) {
-                    if (!(d[i].flags & (F_FINISHED | F_LOST))) dwfa_push(d[i], rv, cv, i, len - d[i].c0, dec.base[i], P.et, lane);
-                } else if (off == len) {
-                    d[i].c0 = find_start(rv, cv, i, off, P.window, P.cmp_len, lane);
-                    d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
-                    for (int T = 1; T <= len - d[i].c0; ++T) {
-                        if (d[i].flags & (F_FINISHED | F_LOST)) break;
-                        dwfa_push(d[i], rv, cv, i, T, cv.at(i, d[i].c0 + T - 1), P.et, lane);
-                    }
-                }
+                // (a read whose offset equals len is placed by cons_activate_kernel, launched right after this step)
+                if ((d[i].flags & F_ACTIVE) && !(d[i].flags & (F_FINISHED | F_LOST))) dwfa_push(d[i], rv, cv, i, len - d[i].c0, dec.base[i], P.et, lane);
             }
             if (dual) {
                 const int both = (d[0].flags & F_ACTIVE) && (d[1].flags & F_ACTIVE) && !(d[0].flags & F_LOST) && !(d[1].flags & F_LOST);
@@ -282,6 +282,76 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B
         const int i = threadIdx.x >> 3, j = threadIdx.x & 7;
         const uint32_t v = lv[i][j];
         if (v && t + 1 <= P.cap) atomicAdd(P.votes + (((size_t)i * (P.cap + 1) + (t + 1)) * CSLOTS + (blockIdx.x & (CSLOTS - 1))) * CSTRIDE + j, v);
+    }
+}
+
+// Late reads (add_sequence_offset): the reads whose offset equals the length the consensus reached in step t are placed by
+// this kernel, launched right after that step (the host knows the offsets, so it knows when to launch it): start search in the
+// window before the offset, catch-up pushes, dual bookkeeping and the read's vote for position t+1.
+struct ActItem { int prob, r; };
+
+__global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatch B, int t, const ActItem* __restrict__ items, int n_items) {
+    const int lane = threadIdx.x & 63, it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= n_items) return;
+    const ActItem item = items[it];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CMAXP; ++i) if (i == item.prob) pi = i;
+    const ConsParams P = B.p[pi];
+    const size_t g = (size_t)P.first + item.r;
+    const ReadInfo ri = B.info[g];
+    const ConsCtrl c = P.ctrl[(t + 1) & 1];                    // state after step t
+    ReadView rv; rv.w = ri.w; rv.np = ri.np; rv.n = ri.n;
+    ConsView cv; cv.C = P.C; cv.cap = P.cap; cv.split_at = c.split_at; cv.t = -1; cv.base0 = cv.base1 = 0;   // position t is in memory by now
+    const int len = t + 1;
+    Dwfa d[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const ConsMeta m = B.meta[(size_t)i * B.total + g];
+        d[i].H = B.H[((size_t)i * B.total + g) * CB + lane]; d[i].e = m.e; d[i].c0 = m.c0; d[i].flags = (i == 1 && !c.dual) ? 0 : m.flags;
+    }
+    int placed[2] = { 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !c.dual) continue;
+        if (c.len[i] != len || c.stopped[i] || (d[i].flags & F_ACTIVE) || ri.off != len) continue;
+        placed[i] = 1;
+        d[i].c0 = find_start(rv, cv, i, ri.off, P.window, P.cmp_len, lane);
+        d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
+        for (int T = 1; T <= len - d[i].c0; ++T) {
+            if (d[i].flags & (F_FINISHED | F_LOST)) break;
+            dwfa_push(d[i], rv, cv, i, T, cv.at(i, d[i].c0 + T - 1), P.et, lane);
+        }
+    }
+    if (!placed[0] && !placed[1]) return;
+    if (c.dual) {
+        const int both = (d[0].flags & F_ACTIVE) && (d[1].flags & F_ACTIVE) && !(d[0].flags & F_LOST) && !(d[1].flags & F_LOST);
+        if (both) {
+            if (d[0].e > d[1].e + P.delta) d[0].flags |= F_LOST;
+            else if (d[1].e > d[0].e + P.delta) d[1].flags |= F_LOST;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!placed[i]) continue;
+        if (lane == 0) { ConsMeta m; m.e = d[i].e; m.c0 = d[i].c0; m.flags = d[i].flags; m.pad = 0; B.meta[(size_t)i * B.total + g] = m; }
+        B.H[((size_t)i * B.total + g) * CB + lane] = d[i].H;
+        if (d[i].flags & (F_FINISHED | F_LOST)) continue;
+        if (c.dual) { const Dwfa& o = d[1 - i]; if ((o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < d[i].e) continue; }
+        const int T = len - d[i].c0, k = lane - CH;
+        const bool tip = d[i].H >= 0 && d[i].H + k == T;
+        const int code = (tip && d[i].H < rv.n) ? read_base(rv, d[i].H) : 5;
+        int seen[4], dc = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { seen[b] = __ballot(code == b) != 0; dc += seen[b]; }
+        const bool ended = __ballot(tip) != 0 && __ballot(code == 4) == 0;
+        if (lane == 0 && len <= P.cap) {
+            uint32_t* v = P.votes + (((size_t)i * (P.cap + 1) + len) * CSLOTS + (blockIdx.x & (CSLOTS - 1))) * CSTRIDE;
+            if (dc) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (seen[b]) atomicAdd(v + b, 12u / dc);
+            } else if (ended) atomicAdd(v + 4, 12u);
+        }
     }
 }
 
@@ -360,6 +430,15 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         max_cap = std::max(max_cap, P.cap);
     }
     if (n_blocks == 0) return SP_OK;
+    // late reads, ordered by the step that places them
+    std::vector<std::pair<int, ActItem>> late;
+    for (uint32_t p = 0; p < n_prob; ++p) if (probs[p].offsets)
+        for (int r = 0; r < B.p[p].n; ++r) if (probs[p].offsets[r] >= 1) late.push_back({ probs[p].offsets[r], ActItem{ (int)p, r } });
+    std::stable_sort(late.begin(), late.end(), [](const std::pair<int, ActItem>& a, const std::pair<int, ActItem>& b) { return a.first < b.first; });
+    std::vector<ActItem> h_act(late.size());
+    for (size_t i = 0; i < late.size(); ++i) h_act[i] = late[i].second;
+    ActItem* d_act = (ActItem*)sp_pool(ctx, "cons_act", sizeof(ActItem) * std::max<size_t>(1, h_act.size()));
+    if (!d_act) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus buffers");
     uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "cons_idx", sizeof(uint32_t) * std::max<size_t>(1, h_idx.size()));
     int32_t* d_off = (int32_t*)sp_pool(ctx, "cons_off", sizeof(int32_t) * std::max<size_t>(1, h_off.size()));
     uint8_t* d_C = (uint8_t*)sp_pool(ctx, "cons_C", c_bytes);
@@ -382,6 +461,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     std::vector<ConsCtrl> h_ctrl(2 * (size_t)n_prob, c0);
     if (!h_idx.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, h_idx.data(), sizeof(uint32_t) * h_idx.size(), hipMemcpyHostToDevice, st));
     if (!h_off.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_off, h_off.data(), sizeof(int32_t) * h_off.size(), hipMemcpyHostToDevice, st));
+    if (!h_act.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_act, h_act.data(), sizeof(ActItem) * h_act.size(), hipMemcpyHostToDevice, st));
     SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ctrl, h_ctrl.data(), sizeof(ConsCtrl) * h_ctrl.size(), hipMemcpyHostToDevice, st));
     SP_HIP_CHECK(ctx, hipMemsetAsync(d_votes, 0, sizeof(uint32_t) * v_words, st));
     SP_HIP_CHECK(ctx, hipMemsetAsync(B.meta, 0, sizeof(ConsMeta) * 2 * total, st));
@@ -392,12 +472,20 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
 
     const dim3 grid((uint32_t)n_blocks), block(CWAVES * SP_WAVE);
     int last = -1;
+    size_t act_at = 0;
     {
         ProfScope ps(ctx, "cons_steps", total);
         hipLaunchKernelGGL(cons_step_kernel, grid, block, 0, st, B, -1);
         for (int t = 0; t <= max_cap; ++t) {                 // launch t = max_cap only records the stop of a consensus that filled its room
             hipLaunchKernelGGL(cons_step_kernel, grid, block, 0, st, B, t);
             last = t;
+            size_t hi = act_at;
+            while (hi < late.size() && late[hi].first == t + 1) ++hi;
+            if (hi > act_at) {
+                const int cnt = (int)(hi - act_at);
+                hipLaunchKernelGGL(cons_activate_kernel, dim3((cnt + 3) / 4), dim3(4 * SP_WAVE), 0, st, B, t, d_act + act_at, cnt);
+                act_at = hi;
+            }
             if ((t & 255) == 255 || t == max_cap) {
                 SP_HIP_CHECK(ctx, hipMemcpyAsync(h_ctrl.data(), d_ctrl, sizeof(ConsCtrl) * h_ctrl.size(), hipMemcpyDeviceToHost, st));
                 SP_HIP_CHECK(ctx, hipStreamSynchronize(st));

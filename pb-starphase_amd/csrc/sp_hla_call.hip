@@ -82,41 +82,45 @@ __global__ void __launch_bounds__(HPC_WAVES * SP_WAVE) hpc_kernel(const uint32_t
     if (lane == 0) out_len[s] = kept;
 }
 
-// a library-owned packed set living in pooled buffers
-struct PooledSet {
-    sp_seqset set;
-    uint64_t* d_word_off = nullptr;
-};
-
 } // namespace
 
 extern "C" {
 
-int32_t sp_hla_diplotype_gene(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene, const sp_seqset* reads, const sp_hla_realign* realign,
-                              const sp_hla_call_config* cfg, sp_hla_call* call, char* cons1, char* cons2, uint32_t cap, uint8_t* is_cons1_out) {
+int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_genes, const uint32_t* genes, const sp_seqset* reads,
+                               const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
+                               char* cons, uint32_t cap, uint8_t* is_cons1_out) {
     if (!ctx) return SP_ERR_INVALID_ARG;
-    if (!db || !reads || !realign || !cfg || !call || !cons1 || !cons2 || cap == 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_gene: null argument");
-    std::memset(call, 0, sizeof *call);
-    call->allele1 = call->allele2 = call->typed1 = call->typed2 = -1;
-    cons1[0] = cons2[0] = '\0';
-    // realigned_records of this gene, in input (qname) order
+    if (!db || !reads || !realign || !cfgs || !calls || !cons || !genes || cap == 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_genes: null argument");
+    if (is_cons1_out) std::memset(is_cons1_out, 0, reads->n);
+    struct Gene { uint32_t first = 0, n = 0; int is_dual = 0, pass = 0, hemi = 0, used_dna = 0; int32_t c1 = 0, c2 = 0; double maf = 0, cdf = 0; };
+    std::vector<Gene> G(n_genes);
+    // realigned_records of every gene, in input (qname) order, flattened gene after gene
     std::vector<uint32_t> sel;
-    for (uint32_t r = 0; r < reads->n; ++r) if (realign[r].status == 0 && realign[r].gene == (int32_t)gene) sel.push_back(r);
+    for (uint32_t k = 0; k < n_genes; ++k) {
+        sp_hla_call& call = calls[k];
+        std::memset(&call, 0, sizeof call);
+        call.allele1 = call.allele2 = call.typed1 = call.typed2 = -1;
+        cons[(size_t)(2 * k) * cap] = cons[(size_t)(2 * k + 1) * cap] = '\0';
+        G[k].first = (uint32_t)sel.size();
+        for (uint32_t r = 0; r < reads->n; ++r) if (realign[r].status == 0 && realign[r].gene == (int32_t)genes[k]) sel.push_back(r);
+        G[k].n = (uint32_t)sel.size() - G[k].first;
+        call.n_reads = (int32_t)G[k].n;
+        if (G[k].n == 0) call.status = 1;                                          // NO_READS / NO_CALL (caller.rs:662-668)
+    }
     const uint32_t n = (uint32_t)sel.size();
-    call->n_reads = (int32_t)n;
-    if (n == 0) { call->status = 1; return SP_OK; }                                 // NO_READS / NO_CALL (caller.rs:662-668)
+    if (n == 0) return SP_OK;
     SP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
-    // ---- segments on the device
+    // ---- segments of all genes on the device
     std::vector<int32_t> h_start(n), h_len(n);
     std::vector<uint64_t> h_woff(n + 1, 0);
     int32_t max_len = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const sp_hla_realign& q = realign[sel[i]];
         h_start[i] = q.seg_start; h_len[i] = q.seg_end - q.seg_start;
-        if (h_len[i] <= 0 || q.seg_end > reads->h_len[sel[i]]) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_gene: segment outside its read");
-        if (h_len[i] > HPC_MAX) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_hla_diplotype_gene: segment longer than 32,768 bases");
+        if (h_len[i] <= 0 || q.seg_end > reads->h_len[sel[i]]) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_genes: segment outside its read");
+        if (h_len[i] > HPC_MAX) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_hla_diplotype_genes: segment longer than 32,768 bases");
         max_len = std::max(max_len, h_len[i]);
         h_woff[i + 1] = h_woff[i] + (uint64_t)((((h_len[i] + 15) >> 4) + 2 + 3) & ~3);
     }
@@ -131,7 +135,7 @@ int32_t sp_hla_diplotype_gene(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene, c
     uint32_t* d_segn = reads->has_n ? (uint32_t*)sp_pool(ctx, "hc_segn", sizeof(uint32_t) * total_words) : nullptr;
     uint32_t* d_hpcn = reads->has_n ? (uint32_t*)sp_pool(ctx, "hc_hpcn", sizeof(uint32_t) * total_words) : nullptr;
     if (!d_idx || !d_start || !d_len || !d_hlen || !d_woff || !d_seg || !d_hpc || (reads->has_n && (!d_segn || !d_hpcn)))
-        return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_hla_diplotype_gene buffers");
+        return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_hla_diplotype_genes buffers");
     SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, sel.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, st));
     SP_HIP_CHECK(ctx, hipMemcpyAsync(d_start, h_start.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
     SP_HIP_CHECK(ctx, hipMemcpyAsync(d_len, h_len.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
@@ -149,91 +153,139 @@ int32_t sp_hla_diplotype_gene(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene, c
     seg.ctx = ctx; seg.n = n; seg.has_n = reads->has_n; seg.d_words = d_seg; seg.d_nplane = d_segn; seg.d_word_off = d_woff; seg.d_len = d_len; seg.max_len = max_len;
     hpc = seg; hpc.d_words = d_hpc; hpc.d_nplane = d_hpcn; hpc.d_len = d_hlen;
 
-    // ---- run_dual_consensus_with_offsets (caller.rs:1118-1219)
-    sp_cons_config cc;
-    cc.min_count = cfg->min_consensus_count; cc.min_af = cfg->min_consensus_fraction; cc.dual_max_ed_delta = cfg->dual_max_ed_delta;
-    cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 400; cc.offset_compare_length = 50;      // dwfa_config_from_cli (:1103-1116)
-    const int half_window = cc.offset_window / 2;
+    // ---- run_dual_consensus_with_offsets (caller.rs:1118-1219), all genes in lockstep
+    const int half_window = 200;                                                   // offset_window 400 (dwfa_config_from_cli, :1103-1116)
+    const uint32_t ccap = (uint32_t)max_len + 512 + 400 + 1;
+    std::vector<uint32_t> ident(n);
+    for (uint32_t i = 0; i < n; ++i) ident[i] = i;
     std::vector<int32_t> off(n), sc1(n), sc2(n);
     std::vector<uint8_t> is1(n);
-    const uint32_t ccap = (uint32_t)max_len + 512 + (uint32_t)cc.offset_window;
-    std::vector<char> t1(ccap + 1), t2(ccap + 1);
-    sp_cons_result cres;
-    auto offsets_of = [&](bool use_hpc, const uint8_t* group, int which) {
+    std::vector<char> text((size_t)2 * n_genes * ccap);
+    auto cons_config = [&](uint32_t k, int dual) {
+        sp_cons_config cc;
+        cc.min_count = cfgs[k].min_consensus_count; cc.min_af = cfgs[k].min_consensus_fraction; cc.dual_max_ed_delta = cfgs[k].dual_max_ed_delta;
+        cc.allow_early_termination = 1; cc.allow_dual = dual; cc.offset_window = 400; cc.offset_compare_length = 50;
+        return cc;
+    };
+    // offsets of the members (group < 0: every read of the gene) relative to their minimum (caller.rs:1127-1141,709-735)
+    auto set_offsets = [&](uint32_t k, bool use_hpc, int group) {
         int32_t mn = INT32_MAX;
-        for (uint32_t i = 0; i < n; ++i) if (!group || group[i] == which) mn = std::min(mn, use_hpc ? realign[sel[i]].hpc_offset : realign[sel[i]].dna_offset);
-        for (uint32_t i = 0; i < n; ++i) { const int32_t o = use_hpc ? realign[sel[i]].hpc_offset : realign[sel[i]].dna_offset; off[i] = o == mn ? -1 : o - mn + half_window; }
+        for (uint32_t i = G[k].first; i < G[k].first + G[k].n; ++i) if (group < 0 || is1[i] == group) mn = std::min(mn, use_hpc ? realign[sel[i]].hpc_offset : realign[sel[i]].dna_offset);
+        for (uint32_t i = G[k].first; i < G[k].first + G[k].n; ++i) if (group < 0 || is1[i] == group) {
+            const int32_t o = use_hpc ? realign[sel[i]].hpc_offset : realign[sel[i]].dna_offset;
+            off[i] = o == mn ? -1 : o - mn + half_window;
+        }
     };
-    auto passing = [&](int32_t* c1, int32_t* c2, double* maf, double* cdf) {
-        *c1 = 0; for (uint32_t i = 0; i < n; ++i) *c1 += is1[i]; *c2 = (int32_t)n - *c1;
-        if (!cres.is_dual) { *maf = 0.0; *cdf = 0.0; return 0; }                     // DualPassingStats::new_non_dual
-        return sp_hla_is_passing_dual((uint64_t)*c1, (uint64_t)*c2, cfg->min_consensus_fraction, cfg->expected_maf, cfg->min_cdf, maf, cdf);
-    };
-    offsets_of(true, nullptr, 0);
-    int32_t rc = sp_consensus_dual(ctx, &hpc, nullptr, n, off.data(), &cc, t1.data(), t2.data(), ccap, is1.data(), sc1.data(), sc2.data(), &cres);
-    if (rc != SP_OK) return rc;
-    int32_t c1 = 0, c2 = 0; double maf = 0, cdf = 0;
-    int pass = passing(&c1, &c2, &maf, &cdf);
-    call->used_dna_dual = 0;
-    if (!pass) {                                                                     // HPC did not separate the reads: full-length DNA (:1180-1218)
-        offsets_of(false, nullptr, 0);
-        rc = sp_consensus_dual(ctx, &seg, nullptr, n, off.data(), &cc, t1.data(), t2.data(), ccap, is1.data(), sc1.data(), sc2.data(), &cres);
+    auto dual_batch = [&](const std::vector<uint32_t>& which, bool use_hpc) -> int32_t {
+        std::vector<sp_cons_problem> P(which.size()); std::vector<sp_cons_output> O(which.size());
+        for (size_t x = 0; x < which.size(); ++x) {
+            const uint32_t k = which[x];
+            set_offsets(k, use_hpc, -1);
+            P[x].reads = use_hpc ? &hpc : &seg; P[x].read_idx = ident.data() + G[k].first; P[x].n = G[k].n; P[x].offsets = off.data() + G[k].first; P[x].cfg = cons_config(k, 1);
+            std::memset(&O[x], 0, sizeof O[x]);
+            O[x].cons1 = text.data() + (size_t)(2 * k) * ccap; O[x].cons2 = text.data() + (size_t)(2 * k + 1) * ccap; O[x].cap = ccap;
+            O[x].is_cons1 = is1.data() + G[k].first; O[x].score1 = sc1.data() + G[k].first; O[x].score2 = sc2.data() + G[k].first;
+        }
+        const int32_t rc = sp_consensus_dual_batch(ctx, (uint32_t)P.size(), P.data(), O.data());
         if (rc != SP_OK) return rc;
-        pass = passing(&c1, &c2, &maf, &cdf);
-        call->used_dna_dual = 1;
-    }
-    int is_dual = cres.is_dual;
-    // ---- hemizygosity (caller.rs:676-684)
-    int hemi = 0;
-    if (cfg->absent_capable) {
-        std::vector<int64_t> s1(n), s2(n);
-        for (uint32_t i = 0; i < n; ++i) { s1[i] = sc1[i]; s2[i] = sc2[i]; }
-        double hc = 0, dc = 0;
-        hemi = sp_hla_is_hemizygous_better(s1.data(), s2.data(), is1.data(), n, is_dual, (uint64_t)cfg->dual_max_ed_delta, cfg->normalized_coverage, &hc, &dc);
-        if (hemi) { is_dual = 0; std::fill(is1.begin(), is1.end(), (uint8_t)1); }   // boiler-plate non-dual consensus (:687-701)
-    }
-    // ---- one consensus per group on the DNA segments (caller.rs:706-747)
-    sp_cons_config single = cc; single.allow_dual = 0;
-    std::vector<uint32_t> grp; std::vector<int32_t> goff, gs1, gs2; std::vector<uint8_t> gis;
-    auto group_consensus = [&](int which, char* out, int32_t* out_len) -> int32_t {
-        grp.clear(); goff.clear();
-        offsets_of(false, is1.data(), which);
-        for (uint32_t i = 0; i < n; ++i) if (is1[i] == which) { grp.push_back(i); goff.push_back(off[i]); }
-        out[0] = '\0'; *out_len = 0;
-        if (grp.empty()) return SP_OK;
-        gs1.resize(grp.size()); gs2.resize(grp.size()); gis.resize(grp.size());
-        sp_cons_result r2;
-        const int32_t e = sp_consensus(ctx, &seg, grp.data(), (uint32_t)grp.size(), goff.data(), &single, t1.data(), t2.data(), ccap, gis.data(), gs1.data(), gs2.data(), &r2);
-        if (e == SP_ERR_CAPACITY) return SP_OK;                                    // "Failed to generate a consensus" => empty string => unknown (:741-755)
-        if (e != SP_OK) return e;
-        if ((uint32_t)r2.len1 + 1 > cap) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_hla_diplotype_gene: consensus buffer too small");
-        std::memcpy(out, t1.data(), (size_t)r2.len1 + 1); *out_len = r2.len1;
+        for (size_t x = 0; x < which.size(); ++x) {
+            Gene& g = G[which[x]];
+            g.is_dual = O[x].result.is_dual;
+            g.c1 = 0; for (uint32_t i = g.first; i < g.first + g.n; ++i) g.c1 += is1[i];
+            g.c2 = (int32_t)g.n - g.c1;
+            if (!g.is_dual) { g.pass = 0; g.maf = g.cdf = 0.0; }                  // DualPassingStats::new_non_dual
+            else g.pass = sp_hla_is_passing_dual((uint64_t)g.c1, (uint64_t)g.c2, cfgs[which[x]].min_consensus_fraction, cfgs[which[x]].expected_maf, cfgs[which[x]].min_cdf, &g.maf, &g.cdf);
+        }
         return SP_OK;
     };
-    rc = group_consensus(1, cons1, &call->cons1_len);
+    std::vector<uint32_t> todo;
+    for (uint32_t k = 0; k < n_genes; ++k) if (G[k].n) todo.push_back(k);
+    int32_t rc = dual_batch(todo, true);
     if (rc != SP_OK) return rc;
-    sp_hla_best b1; std::memset(&b1, 0, sizeof b1); b1.best_allele = -1;
-    rc = sp_hla_type_consensus(ctx, db, gene, cons1, (uint32_t)call->cons1_len, cfg->require_dna, cfg->disable_cdna, &b1, nullptr, nullptr, 0, nullptr);
-    if (rc != SP_OK) return rc;
-    call->typed1 = b1.best_allele;
-    call->is_dual = is_dual; call->is_hemizygous = hemi; call->counts1 = c1; call->counts2 = c2; call->maf = maf; call->cdf = cdf;
-    if (is_dual) {
-        rc = group_consensus(0, cons2, &call->cons2_len);
+    std::vector<uint32_t> retry;
+    for (uint32_t k : todo) if (!G[k].pass) retry.push_back(k);                    // HPC did not separate the reads: full-length DNA (:1180-1218)
+    if (!retry.empty()) {
+        rc = dual_batch(retry, false);
         if (rc != SP_OK) return rc;
-        sp_hla_best b2; std::memset(&b2, 0, sizeof b2); b2.best_allele = -1;
-        rc = sp_hla_type_consensus(ctx, db, gene, cons2, (uint32_t)call->cons2_len, cfg->require_dna, cfg->disable_cdna, &b2, nullptr, nullptr, 0, nullptr);
-        if (rc != SP_OK) return rc;
-        call->typed2 = b2.best_allele;
-        call->dual_passed = pass;
-        if (pass) { call->allele1 = b1.best_allele; call->allele2 = b2.best_allele; }                       // heterozygous (:893-895)
-        else if (c1 > c2) call->allele1 = call->allele2 = b1.best_allele;                                   // homozygous for the dominant allele (:896-903)
-        else call->allele1 = call->allele2 = b2.best_allele;
-    } else {
-        call->dual_passed = 0;
-        call->allele1 = call->allele2 = b1.best_allele;                                                      // :905-912
-        if (hemi) call->allele1 = -2;                                                                        // (NO_CALL_HAP, allele) (:919-923)
+        for (uint32_t k : retry) G[k].used_dna = 1;
     }
-    if (is_cons1_out) for (uint32_t i = 0; i < n; ++i) is_cons1_out[i] = is1[i];
+    // ---- hemizygosity (caller.rs:676-684)
+    for (uint32_t k : todo) if (cfgs[k].absent_capable) {
+        Gene& g = G[k];
+        std::vector<int64_t> s1(g.n), s2(g.n);
+        for (uint32_t i = 0; i < g.n; ++i) { s1[i] = sc1[g.first + i]; s2[i] = sc2[g.first + i]; }
+        double hc = 0, dc = 0;
+        g.hemi = sp_hla_is_hemizygous_better(s1.data(), s2.data(), is1.data() + g.first, g.n, g.is_dual, (uint64_t)cfgs[k].dual_max_ed_delta, cfgs[k].normalized_coverage, &hc, &dc);
+        if (g.hemi) { g.is_dual = 0; std::fill(is1.begin() + g.first, is1.begin() + g.first + g.n, (uint8_t)1); }   // boiler-plate non-dual consensus (:687-701)
+    }
+    // ---- one consensus per read group on the DNA segments (caller.rs:706-747), every group of every gene in lockstep
+    struct Grp { uint32_t k; int which; size_t at, n; };
+    std::vector<Grp> groups; std::vector<uint32_t> gidx; std::vector<int32_t> goff;
+    for (uint32_t k : todo) for (int which = 1; which >= (G[k].is_dual ? 0 : 1); --which) {
+        set_offsets(k, false, which);
+        Grp g{ k, which, gidx.size(), 0 };
+        for (uint32_t i = G[k].first; i < G[k].first + G[k].n; ++i) if (is1[i] == which) { gidx.push_back(i); goff.push_back(off[i]); }
+        g.n = gidx.size() - g.at;
+        if (g.n) groups.push_back(g);
+    }
+    {
+        std::vector<sp_cons_problem> P(groups.size()); std::vector<sp_cons_output> O(groups.size());
+        std::vector<uint8_t> gis(gidx.size()); std::vector<int32_t> gs1(gidx.size()), gs2(gidx.size());
+        std::vector<char> spare((size_t)groups.size() * ccap);
+        for (size_t x = 0; x < groups.size(); ++x) {
+            const Grp& g = groups[x];
+            P[x].reads = &seg; P[x].read_idx = gidx.data() + g.at; P[x].n = (uint32_t)g.n; P[x].offsets = goff.data() + g.at; P[x].cfg = cons_config(g.k, 0);
+            std::memset(&O[x], 0, sizeof O[x]);
+            O[x].cons1 = text.data() + (size_t)(2 * g.k + (g.which ? 0 : 1)) * ccap; O[x].cons2 = spare.data() + x * ccap; O[x].cap = ccap;
+            O[x].is_cons1 = gis.data() + g.at; O[x].score1 = gs1.data() + g.at; O[x].score2 = gs2.data() + g.at;
+        }
+        for (uint32_t k : todo) text[(size_t)(2 * k) * ccap] = text[(size_t)(2 * k + 1) * ccap] = '\0';
+        rc = sp_consensus_batch(ctx, (uint32_t)P.size(), P.data(), O.data());
+        if (rc != SP_OK && rc != SP_ERR_CAPACITY) return rc;
+        for (size_t x = 0; x < groups.size(); ++x) if (O[x].status != SP_OK) O[x].cons1[0] = '\0';   // "Failed to generate a consensus" => empty => unknown (:741-755)
+    }
+    // ---- typing and the call (caller.rs:756-923)
+    for (uint32_t k : todo) {
+        Gene& g = G[k]; sp_hla_call& call = calls[k];
+        const char* t1 = text.data() + (size_t)(2 * k) * ccap; const char* t2 = text.data() + (size_t)(2 * k + 1) * ccap;
+        const size_t l1 = std::strlen(t1), l2 = g.is_dual ? std::strlen(t2) : 0;
+        if (l1 + 1 > cap || l2 + 1 > cap) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_hla_diplotype_genes: consensus buffer too small");
+        char* o1 = cons + (size_t)(2 * k) * cap; char* o2 = cons + (size_t)(2 * k + 1) * cap;
+        std::memcpy(o1, t1, l1 + 1); call.cons1_len = (int32_t)l1;
+        sp_hla_best b1; std::memset(&b1, 0, sizeof b1); b1.best_allele = -1;
+        rc = sp_hla_type_consensus(ctx, db, genes[k], o1, (uint32_t)l1, cfgs[k].require_dna, cfgs[k].disable_cdna, &b1, nullptr, nullptr, 0, nullptr);
+        if (rc != SP_OK) return rc;
+        call.typed1 = b1.best_allele;
+        call.is_dual = g.is_dual; call.is_hemizygous = g.hemi; call.counts1 = g.c1; call.counts2 = g.c2; call.maf = g.maf; call.cdf = g.cdf; call.used_dna_dual = g.used_dna;
+        if (g.is_dual) {
+            std::memcpy(o2, t2, l2 + 1); call.cons2_len = (int32_t)l2;
+            sp_hla_best b2; std::memset(&b2, 0, sizeof b2); b2.best_allele = -1;
+            rc = sp_hla_type_consensus(ctx, db, genes[k], o2, (uint32_t)l2, cfgs[k].require_dna, cfgs[k].disable_cdna, &b2, nullptr, nullptr, 0, nullptr);
+            if (rc != SP_OK) return rc;
+            call.typed2 = b2.best_allele;
+            call.dual_passed = g.pass;
+            if (g.pass) { call.allele1 = b1.best_allele; call.allele2 = b2.best_allele; }                       // heterozygous (:893-895)
+            else if (g.c1 > g.c2) call.allele1 = call.allele2 = b1.best_allele;                                // homozygous for the dominant allele (:896-903)
+            else call.allele1 = call.allele2 = b2.best_allele;
+        } else {
+            call.dual_passed = 0;
+            call.allele1 = call.allele2 = b1.best_allele;                                                       // :905-912
+            if (g.hemi) call.allele1 = -2;                                                                       // (NO_CALL_HAP, allele) (:919-923)
+        }
+        if (is_cons1_out) for (uint32_t i = g.first; i < g.first + g.n; ++i) is_cons1_out[sel[i]] = is1[i];
+    }
+    return SP_OK;
+}
+
+int32_t sp_hla_diplotype_gene(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene, const sp_seqset* reads, const sp_hla_realign* realign,
+                              const sp_hla_call_config* cfg, sp_hla_call* call, char* cons1, char* cons2, uint32_t cap, uint8_t* is_cons1_out) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!cons1 || !cons2 || cap == 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_gene: null argument");
+    std::vector<char> both((size_t)2 * cap);
+    const int32_t rc = sp_hla_diplotype_genes(ctx, db, 1, &gene, reads, realign, cfg, call, both.data(), cap, is_cons1_out);
+    if (rc != SP_OK) { cons1[0] = cons2[0] = '\0'; return rc; }
+    std::memcpy(cons1, both.data(), std::strlen(both.data()) + 1);
+    std::memcpy(cons2, both.data() + cap, std::strlen(both.data() + cap) + 1);
     return SP_OK;
 }
 

@@ -49,3 +49,13 @@ for g in range(len(fx.genes)):
     print(f"gene {fx.genes[g]}: {len(sel)} segments, hpc on host {t_hpc:.2f}s, dual(HPC, two pass) {t_dual*1e3:.1f} ms (kernels {ms_dual[0]:.1f} ms / {ms_dual[1]} passes), "
           f"groups {t_grp*1e3:.1f} ms (kernels {ms_grp[0]:.1f} ms); is_dual={dual['is_dual']} split_at={dual['split_at']} group sizes {int(dual['is_cons1'].sum())}/{int((~dual['is_cons1']).sum())}; "
           f"lens {[len(x['cons'][0]) for x in groups]}; consensus == truth allele (as substring): {[any(t in x['cons'][0] for t in truth) for x in groups]}")
+
+# the whole sample through the gene driver (all genes batched)
+for rep in range(3):
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    calls, _ = db.diplotype_genes(list(range(len(fx.genes))), reads, out)
+    dt = time.perf_counter() - t0
+    prof = {k: ctx.profile_get(k) for k in ("hla_segments", "cons_steps", "k2_cells_cdna", "k2_cells_dna", "k2_scan")}
+print(f"sp_hla_diplotype_genes (both genes, {n_reads} reads): {dt*1e3:.1f} ms; kernels:", {k: round(v[0], 1) for k, v in prof.items()},
+      "calls:", [(c.allele1, c.allele2, c.is_dual, c.dual_passed) for c, _a, _b in calls], "truth:", [a for (_g, _c, _d, a) in wl.consensus])

@@ -55,6 +55,13 @@ def test_reads_to_diplotype(oracle, pkg, gpu_ctx, scenario):
         got = sorted([call.allele1, call.allele2])
         want = sorted(truth[g])
         assert all(same_alleles(fx, a, b) for a, b in zip(got, want)) or all(same_alleles(fx, a, b) for a, b in zip(got, want[::-1])), (g, got, want)
+    # all genes in one call (their consensus problems advance in lockstep): same calls, same consensuses
+    both, is1_all = db.diplotype_genes(list(range(len(fx.genes))), R, k1_gpu)
+    for g, (call, c1, c2) in enumerate(both):
+        one, o1, o2, o_is1 = db.diplotype_gene(g, R, k1_gpu)
+        assert (c1, c2) == (o1, o2)
+        assert bytes(call) == bytes(one)
+        assert is1_all[(k1_gpu["status"] == 0) & (k1_gpu["gene"] == g)].tolist() == o_is1.tolist()
     # a gene without reads
     empty = gpu_ctx.upload(["ACGT" * 200])
     call, c1, c2, _ = db.diplotype_gene(0, empty, db.realign_reads(empty))
