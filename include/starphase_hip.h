@@ -351,6 +351,7 @@ typedef struct {
 typedef struct {
     int32_t is_dual, len1, len2, split_at;
     int64_t best_w2, best_total;       /* strongest second-base column before any split: its weight / all votes, in 12ths of a read */
+    int64_t split_w2, split_total;     /* the same two numbers for the column at which consensus 2 was split off */
 } sp_cons_result;
 
 /* batched form: independent problems advance in lockstep (one base per kernel launch for all of them), so a batch costs as many

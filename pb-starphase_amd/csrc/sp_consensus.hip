@@ -30,6 +30,7 @@ enum { F_ACTIVE = 1, F_FINISHED = 2, F_LOST = 4 };
 struct ConsCtrl {               // state before a step
     int32_t dual, split_at, stopped[2], len[2], done, pad;
     long long best_w2, best_total;
+    long long split_w2, split_total;     // the votes of the column at which the second consensus was split off
 };
 struct ConsMeta { int32_t e, c0, flags, pad; };
 
@@ -49,7 +50,7 @@ struct ReadInfo { const uint32_t* w; const uint32_t* np; int n, off; long long p
 struct ConsBatch {
     ConsParams p[CMAXP]; int n_prob;
     const ReadInfo* info;       // [total]
-    int32_t* H;                 // [2][total][64]
+    uint16_t* H;                // [2][total][64] furthest read position per diagonal (0xFFFF = none): 128 bytes per read and consensus
     ConsMeta* meta;             // [2][total]
     int total;
 };
@@ -57,18 +58,22 @@ struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets
 
 struct ReadView { const uint32_t* w; const uint32_t* np; int n; };
 
+__device__ __forceinline__ int h_load(const uint16_t* H, size_t at) { const uint16_t v = H[at]; return v == 0xFFFF ? SP_NEG : (int)v; }
+__device__ __forceinline__ void h_store(uint16_t* H, size_t at, int h) { H[at] = h < 0 ? (uint16_t)0xFFFF : (uint16_t)h; }
+
 __device__ __forceinline__ int read_base(const ReadView& rv, int h) {
     const uint32_t sh = (uint32_t)(h & 15) << 1;
     if (rv.np && ((rv.np[h >> 4] >> sh) & 1u)) return 4;
     return (int)((rv.w[h >> 4] >> sh) & 3u);
 }
 
-struct Decision { int go[2]; int base[2]; int split; long long best_w2, best_total; };
+struct Decision { int go[2]; int base[2]; int split; long long best_w2, best_total, split_w2, split_total; };
 
 // Every wave re-derives the decision for position t.  Lanes 0-15 fetch the 2 x CSLOTS vote slots (one 128-byte line each) and the
 // sums are formed with three shuffle steps, so the whole decision costs one memory round trip and a handful of registers.
 __device__ __forceinline__ Decision decide(const ConsParams& P, const ConsCtrl& c, int t, int lane) {
     Decision d; d.go[0] = d.go[1] = 0; d.base[0] = d.base[1] = 0; d.split = 0; d.best_w2 = c.best_w2; d.best_total = c.best_total;
+    d.split_w2 = c.split_w2; d.split_total = c.split_total;
     if (t >= P.cap) return d;                                                      // out of room: the consensus is cut at cap
     uint32_t x[5] = { 0, 0, 0, 0, 0 };
     if (lane < 2 * CSLOTS) {
@@ -100,7 +105,7 @@ __device__ __forceinline__ Decision decide(const ConsParams& P, const ConsCtrl& 
         d.go[i] = 1; d.base[i] = b1;
         if (!c.dual && w2 >= 12ll * P.min_count) {
             if (w2 * d.best_total > d.best_w2 * total) { d.best_w2 = w2; d.best_total = total; }
-            if (P.allow_dual && (double)w2 >= P.min_af * (double)total) { d.split = 1; d.go[1] = 1; d.base[1] = b2; }
+            if (P.allow_dual && (double)w2 >= P.min_af * (double)total) { d.split = 1; d.go[1] = 1; d.base[1] = b2; d.split_w2 = w2; d.split_total = total; }
         }
     }
     return d;
@@ -192,8 +197,11 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B
     const size_t g = (size_t)P.first + r;                     // slot in the flattened state arrays (padding slots exist in memory)
     // everything this wave will need from memory that does not depend on the decision is requested up front
     const ReadInfo ri = B.info[g];
-    const ConsMeta m0 = B.meta[g], m1 = B.meta[(size_t)B.total + g];
-    const int h0 = B.H[g * CB + lane], h1 = B.H[((size_t)B.total + g) * CB + lane];
+    const bool second = P.allow_dual != 0;                   // problems that cannot split never touch the second state
+    const ConsMeta m0 = B.meta[g];
+    ConsMeta m1; m1.e = 0; m1.c0 = 0; m1.flags = 0; m1.pad = 0;
+    if (second) m1 = B.meta[(size_t)B.total + g];
+    const int h0 = h_load(B.H, g * CB + lane), h1 = second ? h_load(B.H, ((size_t)B.total + g) * CB + lane) : SP_NEG;
     ConsCtrl cin;
     Decision dec;
     if (t >= 0) {
@@ -202,7 +210,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B
         dec = decide(P, cin, t, lane);
     } else {
         cin = P.ctrl[0];
-        dec.go[0] = dec.go[1] = 0; dec.base[0] = dec.base[1] = 0; dec.split = 0; dec.best_w2 = 0; dec.best_total = 1;
+        dec.go[0] = dec.go[1] = 0; dec.base[0] = dec.base[1] = 0; dec.split = 0; dec.best_w2 = 0; dec.best_total = 1; dec.split_w2 = 0; dec.split_total = 1;
     }
     const int dual = (t >= 0) && (cin.dual || dec.split);
     const int split_at = dec.split ? t : cin.split_at;
@@ -215,6 +223,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B
             else if (i == 0 || cin.dual) co.stopped[i] = 1;
         }
         co.dual = dual; co.split_at = split_at; co.best_w2 = dec.best_w2; co.best_total = dec.best_total;
+        co.split_w2 = dec.split_w2; co.split_total = dec.split_total;
         co.done = !(dec.go[0] || dec.go[1]);
         P.ctrl[(t + 1) & 1] = co;
     }
@@ -274,7 +283,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B
         for (int i = 0; i < 2; ++i) {
             if (i == 1 && !dual) continue;
             if (lane == 0) { ConsMeta m; m.e = d[i].e; m.c0 = d[i].c0; m.flags = d[i].flags; m.pad = 0; B.meta[(size_t)i * B.total + g] = m; }
-            B.H[((size_t)i * B.total + g) * CB + lane] = d[i].H;
+            h_store(B.H, ((size_t)i * B.total + g) * CB + lane, d[i].H);
         }
     }
     __syncthreads();
@@ -308,7 +317,7 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatch B,
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const ConsMeta m = B.meta[(size_t)i * B.total + g];
-        d[i].H = B.H[((size_t)i * B.total + g) * CB + lane]; d[i].e = m.e; d[i].c0 = m.c0; d[i].flags = (i == 1 && !c.dual) ? 0 : m.flags;
+        d[i].H = h_load(B.H, ((size_t)i * B.total + g) * CB + lane); d[i].e = m.e; d[i].c0 = m.c0; d[i].flags = (i == 1 && !c.dual) ? 0 : m.flags;
     }
     int placed[2] = { 0, 0 };
 #pragma unroll
@@ -335,7 +344,7 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatch B,
     for (int i = 0; i < 2; ++i) {
         if (!placed[i]) continue;
         if (lane == 0) { ConsMeta m; m.e = d[i].e; m.c0 = d[i].c0; m.flags = d[i].flags; m.pad = 0; B.meta[(size_t)i * B.total + g] = m; }
-        B.H[((size_t)i * B.total + g) * CB + lane] = d[i].H;
+        h_store(B.H, ((size_t)i * B.total + g) * CB + lane, d[i].H);
         if (d[i].flags & (F_FINISHED | F_LOST)) continue;
         if (c.dual) { const Dwfa& o = d[1 - i]; if ((o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < d[i].e) continue; }
         const int T = len - d[i].c0, k = lane - CH;
@@ -386,7 +395,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
         if (!(m.flags & F_ACTIVE) || (m.flags & F_LOST)) continue;
         int e = m.e;
         if (!P.et) {
-            const int h = B.H[((size_t)i * B.total + g) * CB + lane], k = lane - CH;
+            const int h = h_load(B.H, ((size_t)i * B.total + g) * CB + lane), k = lane - CH;
             int rest = (h >= 0 && h + k == c.len[i] - m.c0) ? n - h : (1 << 30);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(rest, o); rest = other < rest ? other : rest; }
@@ -446,7 +455,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     ConsCtrl* d_ctrl = (ConsCtrl*)sp_pool(ctx, "cons_ctrl", sizeof(ConsCtrl) * 2 * n_prob);
     ReadInfo* d_info = (ReadInfo*)sp_pool(ctx, "cons_info", sizeof(ReadInfo) * total);
     B.info = d_info; B.total = (int)total;
-    B.H = (int32_t*)sp_pool(ctx, "cons_H", sizeof(int32_t) * 2 * total * CB);
+    B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * 2 * total * CB);
     B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * 2 * total);
     uint8_t* d_is1 = (uint8_t*)sp_pool(ctx, "cons_is1", total);
     int32_t* d_sc = (int32_t*)sp_pool(ctx, "cons_scores", sizeof(int32_t) * 2 * total);
@@ -457,7 +466,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr;
         B.p[p].C = d_C + c_at[p]; B.p[p].votes = d_votes + v_at[p]; B.p[p].ctrl = d_ctrl + 2 * p;
     }
-    ConsCtrl c0; std::memset(&c0, 0, sizeof c0); c0.split_at = -1; c0.stopped[1] = 1; c0.best_total = 1;
+    ConsCtrl c0; std::memset(&c0, 0, sizeof c0); c0.split_at = -1; c0.stopped[1] = 1; c0.best_total = 1; c0.split_total = 1;
     std::vector<ConsCtrl> h_ctrl(2 * (size_t)n_prob, c0);
     if (!h_idx.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, h_idx.data(), sizeof(uint32_t) * h_idx.size(), hipMemcpyHostToDevice, st));
     if (!h_off.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_off, h_off.data(), sizeof(int32_t) * h_off.size(), hipMemcpyHostToDevice, st));
@@ -520,6 +529,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         for (int r = 0; r < P.n; ++r) { o.is_cons1[r] = h_is1[P.first + r]; o.score1[r] = h_sc[P.first + r]; o.score2[r] = h_sc[total + P.first + r]; }
         o.result.is_dual = cur.dual; o.result.len1 = len1; o.result.len2 = len2; o.result.split_at = cur.split_at;
         o.result.best_w2 = cur.best_w2; o.result.best_total = cur.best_total;
+        o.result.split_w2 = cur.split_w2; o.result.split_total = cur.split_total;
         // a consensus that filled its buffer was still growing: the caller sized cap too small
         if (len1 >= P.cap || len2 >= P.cap) { o.status = SP_ERR_CAPACITY; rc = SP_ERR_CAPACITY; }
     }
@@ -534,6 +544,7 @@ static int32_t run_batch(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         if (q.cfg.offset_compare_length > 64 || q.cfg.offset_compare_length < 0 || q.cfg.offset_window < 0 || q.cfg.min_count < 0)
             return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: offset_compare_length must be in [0, 64]");
         if (o.cap >= (1u << 22)) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must be below 4,194,304");
+        if (q.reads->max_len >= 65535) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: sequences must be shorter than 65,535 bases");
         std::memset(&o.result, 0, sizeof o.result); o.result.split_at = -1; o.result.best_total = 1; o.status = SP_OK;
         o.cons1[0] = o.cons2[0] = '\0';
         const uint32_t n = q.read_idx ? q.n : q.reads->n;
@@ -562,22 +573,42 @@ int32_t sp_consensus_dual_batch(sp_ctx* ctx, uint32_t n_problems, const sp_cons_
     if (!ctx) return SP_ERR_INVALID_ARG;
     if (n_problems == 0) return SP_OK;
     if (!problems || !outputs) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_dual_batch: null argument");
-    std::vector<sp_cons_problem> pass(problems, problems + n_problems);
-    for (auto& q : pass) q.cfg.allow_dual = 0;
-    int32_t rc = run_batch(ctx, n_problems, pass.data(), outputs);
-    if (rc != SP_OK) return rc;
+    // The two passes of the policy run side by side: next to the pass that never splits (it finds the strongest second-base
+    // column) a speculative pass splits at the first column that reaches cfg.min_af.  No earlier column can reach the final
+    // threshold X >= cfg.min_af either, so if that column also reaches X the speculative pass IS the second pass; only otherwise
+    // the second pass is run on its own.
+    std::vector<sp_cons_problem> pr(2 * (size_t)n_problems); std::vector<sp_cons_output> out(2 * (size_t)n_problems);
+    std::vector<std::vector<char>> text(n_problems); std::vector<std::vector<uint8_t>> fl(n_problems); std::vector<std::vector<int32_t>> sc(n_problems);
+    for (uint32_t p = 0; p < n_problems; ++p) {
+        const uint32_t n = problems[p].read_idx ? problems[p].n : (problems[p].reads ? problems[p].reads->n : 0);
+        text[p].assign((size_t)2 * std::max<uint32_t>(outputs[p].cap, 1), 0); fl[p].assign(std::max<uint32_t>(n, 1), 0); sc[p].assign((size_t)2 * std::max<uint32_t>(n, 1), 0);
+        pr[2 * p] = problems[p]; pr[2 * p].cfg.allow_dual = 0;
+        out[2 * p] = outputs[p];
+        out[2 * p].cons1 = text[p].data(); out[2 * p].cons2 = text[p].data() + outputs[p].cap; out[2 * p].is_cons1 = fl[p].data();
+        out[2 * p].score1 = sc[p].data(); out[2 * p].score2 = sc[p].data() + std::max<uint32_t>(n, 1);
+        pr[2 * p + 1] = problems[p]; pr[2 * p + 1].cfg.allow_dual = 1;
+        out[2 * p + 1] = outputs[p];
+    }
+    int32_t rc = run_batch(ctx, 2 * n_problems, pr.data(), out.data());
+    if (rc != SP_OK && rc != SP_ERR_CAPACITY) return rc;
     std::vector<sp_cons_problem> again; std::vector<sp_cons_output> outs2; std::vector<uint32_t> who;
     for (uint32_t p = 0; p < n_problems; ++p) {
-        if (outputs[p].result.best_w2 == 0) continue;                   // no column with min_count reads on a second base: nothing to split
-        sp_cons_problem q = problems[p];
-        q.cfg.allow_dual = 1;
-        const double strongest = 0.5 * (double)outputs[p].result.best_w2 / (double)outputs[p].result.best_total;
-        if (strongest > q.cfg.min_af) q.cfg.min_af = strongest;
+        const sp_cons_result& single = out[2 * p].result; const sp_cons_result& spec = out[2 * p + 1].result;
+        outputs[p] = out[2 * p + 1];
+        if (single.best_w2 == 0 || !spec.is_dual) continue;            // nothing to split, or no column reaches even cfg.min_af: the speculative pass never split
+        const double strongest = 0.5 * (double)single.best_w2 / (double)single.best_total;
+        const double x = problems[p].cfg.min_af > strongest ? problems[p].cfg.min_af : strongest;
+        if ((double)spec.split_w2 >= x * (double)spec.split_total) continue;
+        sp_cons_problem q = problems[p]; q.cfg.allow_dual = 1; q.cfg.min_af = x;
         again.push_back(q); outs2.push_back(outputs[p]); who.push_back(p);
     }
-    if (again.empty()) return SP_OK;
-    rc = run_batch(ctx, (uint32_t)again.size(), again.data(), outs2.data());
-    for (size_t k = 0; k < who.size(); ++k) outputs[who[k]] = outs2[k];
+    if (!again.empty()) {
+        const int32_t rc2 = run_batch(ctx, (uint32_t)again.size(), again.data(), outs2.data());
+        if (rc2 != SP_OK && rc2 != SP_ERR_CAPACITY) return rc2;
+        for (size_t k = 0; k < who.size(); ++k) outputs[who[k]] = outs2[k];
+    }
+    rc = SP_OK;
+    for (uint32_t p = 0; p < n_problems; ++p) if (outputs[p].status != SP_OK) rc = outputs[p].status;
     return rc;
 }
 

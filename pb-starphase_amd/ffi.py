@@ -97,7 +97,8 @@ class sp_cons_config(C.Structure):
 
 
 class sp_cons_result(C.Structure):
-    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64)]
+    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64),
+                ("split_w2", C.c_int64), ("split_total", C.c_int64)]
 
 
 class sp_cons_problem(C.Structure):

@@ -41,6 +41,18 @@ def cases(fx, synth, oracle):
     noisy[5] = noisy[5][:1500] + "NNN" + noisy[5][1503:]
     noisy.append("".join(rng.choice(list("ACGT"), 900)))
     out.append(("single_with_n_and_junk", noisy, None, dict(early_termination=True, dual=False), False))
+    # a recurrent artefact (15 % of the reads of both haplotypes) ahead of the real difference: the one-pass rule would split there,
+    # the two-pass policy must not (the speculative second pass of the library is rejected and re-run)
+    h1 = "".join(rng.choice(list("ACGT"), 600))
+    h2 = h1[:300] + ("A" if h1[300] != "A" else "C") + h1[301:]
+    art = []
+    for i in range(40):
+        hap = h1 if i % 2 == 0 else h2
+        if i % 20 < 3:
+            hap = hap[:100] + ("G" if hap[100] != "G" else "T") + hap[101:]
+        art.append(hap)
+    out.append(("dual_artefact_column_first", art, None, dict(early_termination=False, dual=True), True))
+    out.append(("dual_artefact_one_pass", art, None, dict(early_termination=False, dual=True), False))
     # tiny inputs
     out.append(("two_reads", full1[:2], None, dict(early_termination=True, dual=True), True))
     out.append(("one_read", full1[:1], None, dict(early_termination=False, dual=False), False))

@@ -35,6 +35,9 @@ def test_consensus_quality(pkg, oracle):
     n = got["single_with_n_and_junk"]
     assert n["cons"][0] == s1 and n["score1"][-1] == -1 or n["score1"][-1] > 100                   # the unrelated read is lost or far away
     assert got["one_read"]["cons"][0] == cs[-1][1][0]
+    a2, a1 = got["dual_artefact_column_first"], got["dual_artefact_one_pass"]
+    assert a1["is_dual"] and a1["split_at"] == 100                       # the naive rule falls for the artefact
+    assert a2["is_dual"] and a2["split_at"] == 300 and int(a2["is_cons1"].sum()) == 20
 
 
 def _ed_to(a, b):
