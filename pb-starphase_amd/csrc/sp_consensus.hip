@@ -122,26 +122,31 @@ struct ConsView {
 
 struct Dwfa { int H, e, c0, flags; };
 
-// the consensus (cons i) now has T bases after c0; `nb` is its newest base
-__device__ __forceinline__ void dwfa_push(Dwfa& d, const ReadView& rv, const ConsView& cv, int i, int T, int nb, int et, int lane) {
+// the consensus now has T bases after c0; `nb` is its newest base.  rb(h) = read base at h, ca(pos) = consensus base at pos.
+template <class RB, class CA>
+__device__ __forceinline__ void dwfa_push_t(Dwfa& d, int n, RB rb, CA ca, int T, int nb, int et, int lane) {
     const int k = lane - CH;
-    if (d.H >= 0 && d.H + k == T - 1 && d.H < rv.n && read_base(rv, d.H) == nb) d.H += 1;      // only the old tips can move
+    if (d.H >= 0 && d.H + k == T - 1 && d.H < n && rb(d.H) == nb) d.H += 1;                       // only the old tips can move
     while (!__ballot(d.H >= 0 && d.H + k == T)) {
         const int c = d.H, up = spw::from_lower(d.H, SP_NEG), dn = spw::from_upper(d.H, SP_NEG);
         int best = SP_NEG;
-        if (c >= 0 && c < rv.n && c + k < T) best = c + 1;
+        if (c >= 0 && c < n && c + k < T) best = c + 1;
         if (up >= 0 && up + k <= T && up + k >= 0 && up > best) best = up;
-        if (dn >= 0 && dn < rv.n && dn + 1 + k >= 0 && dn + 1 > best) best = dn + 1;
+        if (dn >= 0 && dn < n && dn + 1 + k >= 0 && dn + 1 > best) best = dn + 1;
         if (!__ballot(best >= 0)) { d.flags |= F_LOST; return; }
         d.H = best; d.e += 1;
         for (;;) {
-            bool go = d.H >= 0 && d.H < rv.n && d.H + k < T;
-            if (go) { const int rb = read_base(rv, d.H); go = rb < 4 && rb == cv.at(i, d.c0 + d.H + k); }
+            bool go = d.H >= 0 && d.H < n && d.H + k < T;
+            if (go) { const int x = rb(d.H); go = x < 4 && x == ca(d.c0 + d.H + k); }
             if (!__ballot(go)) break;
             if (go) d.H += 1;
         }
     }
-    if (et && __ballot(d.H == rv.n)) d.flags |= F_FINISHED;
+    if (et && __ballot(d.H == n)) d.flags |= F_FINISHED;
+}
+
+__device__ __forceinline__ void dwfa_push(Dwfa& d, const ReadView& rv, const ConsView& cv, int i, int T, int nb, int et, int lane) {
+    dwfa_push_t(d, rv.n, [&](int h) { return read_base(rv, h); }, [&](int pos) { return cv.at(i, pos); }, T, nb, et, lane);
 }
 
 // placement of a late read: Sellers' search of its first L bases in the last W consensus bases, one Myers bit-vector scan per
@@ -299,8 +304,13 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B
 // window before the offset, catch-up pushes, dual bookkeeping and the read's vote for position t+1.
 struct ActItem { int prob, r; };
 
+constexpr int ACT_CONS = 512;   // consensus bases a wave keeps in LDS while a late read catches up (offset_window + slack)
+constexpr int ACT_READ = 640;   // read bases it keeps (catch-up length + band + edits)
+
 __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatch B, int t, const ActItem* __restrict__ items, int n_items) {
-    const int lane = threadIdx.x & 63, it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint8_t ccache[4][ACT_CONS];
+    __shared__ uint8_t rcache[4][ACT_READ];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, it = blockIdx.x * 4 + wv;
     if (it >= n_items) return;
     const ActItem item = items[it];
     int pi = 0;
@@ -327,10 +337,18 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatch B,
         placed[i] = 1;
         d[i].c0 = find_start(rv, cv, i, ri.off, P.window, P.cmp_len, lane);
         d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
-        for (int T = 1; T <= len - d[i].c0; ++T) {
+        // the catch-up runs out of LDS: the consensus from the start found up to now, and the head of the read
+        const int c0 = d[i].c0, span = len - c0;
+        for (int x = lane; x < span && x < ACT_CONS; x += SP_WAVE) ccache[wv][x] = (uint8_t)cv.at(i, c0 + x);
+        for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) rcache[wv][x] = (uint8_t)read_base(rv, x);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        auto rb = [&](int h) { return h < ACT_READ ? (int)rcache[wv][h] : read_base(rv, h); };
+        auto ca = [&](int pos) { const int x = pos - c0; return x < ACT_CONS ? (int)ccache[wv][x] : cv.at(i, pos); };
+        for (int T = 1; T <= span; ++T) {
             if (d[i].flags & (F_FINISHED | F_LOST)) break;
-            dwfa_push(d[i], rv, cv, i, T, cv.at(i, d[i].c0 + T - 1), P.et, lane);
+            dwfa_push_t(d[i], rv.n, rb, ca, T, ca(c0 + T - 1), P.et, lane);
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if (!placed[0] && !placed[1]) return;
     if (c.dual) {
