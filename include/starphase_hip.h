@@ -375,6 +375,28 @@ int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* r
                           const sp_cons_config* cfg, char* cons1, char* cons2, uint32_t cap,
                           uint8_t* is_cons1, int32_t* score1, int32_t* score2, sp_cons_result* result);
 
+/* multi-way consensus by repeated two-way splits: the role of PriorityConsensusDWFA::{add_seeded_sequence_chain, consensus} in the
+ * CYP2D6 caller (src/cyp2d6/caller.rs:162-270).  Every read contributes one sequence per level (the reference chains the
+ * homopolymer-compressed segment, then the raw segment) with its own offset; seeds force an initial grouping (:231-238).
+ * Contract: solve(group, level) = run sp_consensus_dual on the group's level sequences; if it splits, solve(consensus-1 reads,
+ * level) followed by solve(the others, level); else solve(group, level + 1), or emit the group after the last level.  Initial
+ * groups: the unseeded reads, then each seed in ascending order.  Offsets inside a group are re-based on the group's smallest
+ * one (that read starts the consensus, the others keep their distance to it plus half the window).  Finally every emitted group
+ * gets one consensus per level (sp_consensus).  All problems of a round run in lockstep on the GPU.
+ *   levels[l]   the sequences of level l (n each, same read order); offsets[l] = NULL or n entries (-1 = None); seeds = NULL or n (-1 = None)
+ *   group_of    n entries: index of the emitted group of every read (MultiConsensus::sequence_indices)
+ *   cons        max_groups * n_levels * cap bytes: consensus of group g at level l at cons + (g * n_levels + l) * cap
+ * Returns SP_ERR_CAPACITY when there are more than max_groups groups (n_groups then holds the number needed). */
+typedef struct {
+    uint32_t n_levels, n;
+    const sp_seqset* const* levels;
+    const int32_t* const* offsets;
+    const int32_t* seeds;
+    sp_cons_config cfg;
+} sp_priority_problem;
+int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* problem, uint32_t max_groups, uint32_t cap,
+                              uint32_t* n_groups, int32_t* group_of, char* cons);
+
 /* ------------------------------------------------------------------ one HLA gene, reads to diplotype
  * The gene loop of diplotype_hla_batch (src/hla/caller.rs:642-1040) on top of K1 / K8 / K2, without I/O and debug artefacts:
  * the realigned segments of `gene` (realign[r].status == 0, in input order = qname order) are cut out of the packed reads and

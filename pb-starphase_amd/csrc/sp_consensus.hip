@@ -16,6 +16,8 @@
 #include "sp_wfa.cuh"
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <string>
 
 namespace {
 
@@ -654,6 +656,87 @@ int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* r
     const int32_t rc = sp_consensus_dual_batch(ctx, 1, &q, &o);
     *result = o.result;
     return rc;
+}
+
+int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* pr, uint32_t max_groups, uint32_t cap,
+                              uint32_t* n_groups, int32_t* group_of, char* cons) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!pr || !n_groups || !group_of || !cons || !pr->levels || pr->n_levels == 0 || cap < 2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: null argument");
+    for (uint32_t l = 0; l < pr->n_levels; ++l) if (!pr->levels[l] || pr->levels[l]->n != pr->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: every level needs one sequence per read");
+    *n_groups = 0;
+    const uint32_t n = pr->n, NL = pr->n_levels;
+    if (n == 0) return SP_OK;
+    const int half = pr->cfg.offset_window / 2;
+    struct Item { std::vector<uint32_t> members; uint32_t level; std::string key; };
+    // initial groups: unseeded reads first, then the seeds in ascending order
+    std::vector<Item> work, done;
+    {
+        std::map<int32_t, std::vector<uint32_t>> by_seed;
+        for (uint32_t r = 0; r < n; ++r) by_seed[pr->seeds ? (pr->seeds[r] < 0 ? -1 : pr->seeds[r]) : -1].push_back(r);
+        uint32_t ord = 0;
+        for (auto& kv : by_seed) { Item it; it.members = kv.second; it.level = 0; it.key = std::string(1, (char)('a' + std::min<uint32_t>(ord, 25))) + std::to_string(ord); ++ord; work.push_back(std::move(it)); }
+    }
+    auto rebased = [&](const std::vector<uint32_t>& m, uint32_t level, std::vector<int32_t>& out) -> bool {
+        const int32_t* src = pr->offsets ? pr->offsets[level] : nullptr;
+        if (!src) return false;
+        int64_t mn = INT64_MAX;
+        for (uint32_t r : m) mn = std::min<int64_t>(mn, src[r] < 0 ? 0 : src[r]);
+        out.resize(m.size());
+        for (size_t i = 0; i < m.size(); ++i) { const int64_t o = src[m[i]] < 0 ? 0 : src[m[i]]; out[i] = o == mn ? -1 : (int32_t)(o - mn + (mn == 0 ? 0 : half)); }
+        return true;
+    };
+    while (!work.empty()) {
+        // one round: every open group as one two-way problem, all in lockstep
+        const size_t k = work.size();
+        std::vector<sp_cons_problem> P(k); std::vector<sp_cons_output> O(k);
+        std::vector<std::vector<int32_t>> offs(k), s1(k), s2(k); std::vector<std::vector<uint8_t>> is1(k); std::vector<std::vector<char>> text(k);
+        for (size_t x = 0; x < k; ++x) {
+            const Item& it = work[x];
+            const sp_seqset* set = pr->levels[it.level];
+            int32_t longest = 0; for (uint32_t r : it.members) longest = std::max(longest, set->h_len[r]);
+            const bool has_off = rebased(it.members, it.level, offs[x]);
+            int32_t far = 0; if (has_off) for (int32_t o : offs[x]) far = std::max(far, o);
+            const uint32_t c = (uint32_t)longest + (uint32_t)far + 66;
+            s1[x].resize(it.members.size()); s2[x].resize(it.members.size()); is1[x].resize(it.members.size()); text[x].assign((size_t)2 * c, 0);
+            P[x].reads = set; P[x].read_idx = it.members.data(); P[x].n = (uint32_t)it.members.size(); P[x].offsets = has_off ? offs[x].data() : nullptr;
+            P[x].cfg = pr->cfg; P[x].cfg.allow_dual = 1;
+            std::memset(&O[x], 0, sizeof O[x]);
+            O[x].cons1 = text[x].data(); O[x].cons2 = text[x].data() + c; O[x].cap = c; O[x].is_cons1 = is1[x].data(); O[x].score1 = s1[x].data(); O[x].score2 = s2[x].data();
+        }
+        const int32_t rc = sp_consensus_dual_batch(ctx, (uint32_t)k, P.data(), O.data());
+        if (rc != SP_OK) return rc;
+        std::vector<Item> next;
+        for (size_t x = 0; x < k; ++x) {
+            Item& it = work[x];
+            std::vector<uint32_t> g1, g2;
+            for (size_t i = 0; i < it.members.size(); ++i) (is1[x][i] ? g1 : g2).push_back(it.members[i]);
+            if (O[x].result.is_dual && !g1.empty() && !g2.empty()) {
+                Item a; a.members = std::move(g1); a.level = it.level; a.key = it.key + "0"; next.push_back(std::move(a));
+                Item b; b.members = std::move(g2); b.level = it.level; b.key = it.key + "1"; next.push_back(std::move(b));
+            } else if (it.level + 1 < NL) { it.level += 1; it.key += "_"; next.push_back(std::move(it)); }
+            else done.push_back(std::move(it));
+        }
+        work.swap(next);
+        if (done.size() + work.size() > (size_t)n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: more groups than reads");
+    }
+    std::sort(done.begin(), done.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
+    *n_groups = (uint32_t)done.size();
+    for (size_t g = 0; g < done.size(); ++g) for (uint32_t r : done[g].members) group_of[r] = (int32_t)g;
+    if (done.size() > max_groups) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_consensus_priority: more groups than max_groups");
+    // one consensus per emitted group and level
+    const size_t k = done.size() * NL;
+    std::vector<sp_cons_problem> P(k); std::vector<sp_cons_output> O(k);
+    std::vector<std::vector<int32_t>> offs(k), s1(k), s2(k); std::vector<std::vector<uint8_t>> is1(k); std::vector<std::vector<char>> spare(k);
+    for (size_t g = 0; g < done.size(); ++g) for (uint32_t l = 0; l < NL; ++l) {
+        const size_t x = g * NL + l; const Item& it = done[g];
+        const bool has_off = rebased(it.members, l, offs[x]);
+        s1[x].resize(it.members.size()); s2[x].resize(it.members.size()); is1[x].resize(it.members.size()); spare[x].assign(cap, 0);
+        P[x].reads = pr->levels[l]; P[x].read_idx = it.members.data(); P[x].n = (uint32_t)it.members.size(); P[x].offsets = has_off ? offs[x].data() : nullptr;
+        P[x].cfg = pr->cfg; P[x].cfg.allow_dual = 0;
+        std::memset(&O[x], 0, sizeof O[x]);
+        O[x].cons1 = cons + x * (size_t)cap; O[x].cons2 = spare[x].data(); O[x].cap = cap; O[x].is_cons1 = is1[x].data(); O[x].score1 = s1[x].data(); O[x].score2 = s2[x].data();
+    }
+    return sp_consensus_batch(ctx, (uint32_t)k, P.data(), O.data());
 }
 
 } // extern "C"

@@ -110,6 +110,11 @@ class sp_cons_output(C.Structure):
                 ("score2", C.c_void_p), ("result", sp_cons_result), ("status", C.c_int32)]
 
 
+class sp_priority_problem(C.Structure):
+    _fields_ = [("n_levels", C.c_uint32), ("n", C.c_uint32), ("levels", C.POINTER(C.c_void_p)), ("offsets", C.POINTER(C.c_void_p)), ("seeds", C.c_void_p),
+                ("cfg", sp_cons_config)]
+
+
 class sp_hla_call_config(C.Structure):
     _fields_ = [("min_consensus_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("min_consensus_fraction", C.c_double),
                 ("expected_maf", C.c_double), ("min_cdf", C.c_double), ("require_dna", C.c_int32), ("disable_cdna", C.c_int32),
@@ -191,6 +196,7 @@ def lib():
         "sp_consensus_dual": (i32, [vp, vp, vp, u32, vp, C.POINTER(sp_cons_config), C.c_char_p, C.c_char_p, u32, vp, vp, vp, C.POINTER(sp_cons_result)]),
         "sp_consensus_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
         "sp_consensus_dual_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
+        "sp_consensus_priority": (i32, [vp, C.POINTER(sp_priority_problem), u32, u32, C.POINTER(u32), vp, C.c_char_p]),
         "sp_hla_diplotype_gene": (i32, [vp, vp, u32, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, C.c_char_p, u32, vp]),
         "sp_hla_diplotype_genes": (i32, [vp, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
         "sp_profile_reset": (i32, [vp]),
@@ -396,6 +402,29 @@ class Context:
             out.append(dict(cons=[c1.value.decode(), c2.value.decode() if res.is_dual else None], is_dual=bool(res.is_dual), is_cons1=is1[:n].astype(bool),
                             score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, best_w2=res.best_w2, best_total=res.best_total))
         return out
+
+    def consensus_priority(self, levels, cfg, offsets=None, seeds=None, max_groups=64, cap=None):
+        """sp_consensus_priority: levels = list of SeqSet (one sequence per read each) -> (group_of, [[consensus per level] per group])"""
+        nl, n = len(levels), levels[0].n
+        cap = cap or int(max(int(L.lengths.max()) if L.n else 0 for L in levels)) + 1024
+        lv = (C.c_void_p * nl)(*[L._h for L in levels])
+        keep = []
+        of = (C.c_void_p * nl)()
+        for l in range(nl):
+            if offsets is not None and offsets[l] is not None:
+                a = np.array([-1 if o is None else int(o) for o in offsets[l]], np.int32)
+                keep.append(a)
+                of[l] = a.ctypes.data
+            else:
+                of[l] = None
+        sd = np.array([-1 if x is None else int(x) for x in seeds], np.int32) if seeds is not None else None
+        pr = sp_priority_problem(nl, n, lv, of, (sd.ctypes.data if sd is not None else None), cfg)
+        ng = C.c_uint32(0)
+        group_of = np.zeros(max(1, n), np.int32)
+        buf = C.create_string_buffer(max_groups * nl * cap)
+        self.check(lib().sp_consensus_priority(self._h, C.byref(pr), max_groups, cap, C.byref(ng), _ptr(group_of), buf))
+        text = lambda j: buf.raw[j * cap:(j + 1) * cap].split(b"\0", 1)[0].decode()
+        return group_of[:n].copy(), [[text(g * nl + l) for l in range(nl)] for g in range(ng.value)]
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))

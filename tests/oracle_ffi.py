@@ -442,3 +442,43 @@ def dual_consensus_two_pass(run, reads, offsets=None, cfg=None):
     af = max(cfg.min_af, 0.5 * float(first["best_w2"]) / float(first["best_total"]))
     second = ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, 1, cfg.offset_window, cfg.offset_compare_length, af)
     return run(reads, offsets, second)
+
+
+def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None):
+    """The multi-way contract of sp_consensus_priority on top of the oracle's two-way consensus (include/starphase_hip.h):
+    levels = list (per level) of lists of strings.  Returns (group_of, [[consensus per level] per group])."""
+    n, nl = len(levels[0]), len(levels)
+    half = cfg.offset_window // 2
+    run = lambda rd, offs, c: oracle_consensus(oracle, rd, offs, c)
+    single = ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, 0, cfg.offset_window, cfg.offset_compare_length, cfg.min_af)
+    dual = ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, 1, cfg.offset_window, cfg.offset_compare_length, cfg.min_af)
+
+    def rebased(members, level):
+        if offsets is None or offsets[level] is None:
+            return None
+        vals = [0 if offsets[level][r] is None else int(offsets[level][r]) for r in members]
+        mn = min(vals)
+        return [None if v == mn else v - mn + (0 if mn == 0 else half) for v in vals]
+
+    def solve(members, level):
+        res = dual_consensus_two_pass(run, [levels[level][r] for r in members], rebased(members, level), dual)
+        g1 = [r for r, f in zip(members, res["is_cons1"]) if f]
+        g2 = [r for r, f in zip(members, res["is_cons1"]) if not f]
+        if res["is_dual"] and g1 and g2:
+            return solve(g1, level) + solve(g2, level)
+        if level + 1 < nl:
+            return solve(members, level + 1)
+        return [members]
+
+    keys = sorted(set(-1 if (seeds is None or seeds[r] is None) else int(seeds[r]) for r in range(n)))
+    groups = []
+    for k in keys:
+        members = [r for r in range(n) if (-1 if (seeds is None or seeds[r] is None) else int(seeds[r])) == k]
+        groups += solve(members, 0)
+    group_of = np.zeros(n, np.int32)
+    cons = []
+    for g, members in enumerate(groups):
+        for r in members:
+            group_of[r] = g
+        cons.append([oracle_consensus(oracle, [levels[l][r] for r in members], rebased(members, l), single)["cons"][0] for l in range(nl)])
+    return group_of, cons

@@ -100,3 +100,38 @@ def test_batch_equals_one_by_one(oracle, pkg, gpu_ctx):
                 same(g, run_case(oracle, reads, offs, kw, tp))
             except AssertionError as e:
                 raise AssertionError(f"case {name} (two_pass={two_pass}): {e}")
+
+
+def test_priority_consensus(oracle, pkg, gpu_ctx):
+    """multi-way consensus (the PriorityConsensusDWFA role, src/cyp2d6/caller.rs:162-270): reads of four similar alleles plus two
+    seeded region types, two levels (homopolymer-compressed, raw), clipped reads with offsets"""
+    from pb_starphase_amd import synth
+    rng = np.random.default_rng(31)
+    base = "".join(rng.choice(list("ACGT"), 1500))
+    alleles = [base, synth.mutate(rng, base, 4, 1, 0), synth.mutate(rng, base, 3, 0, 1), synth.mutate(rng, synth.mutate(rng, base, 4, 1, 0), 3, 0, 0)]
+    rep = "".join(rng.choice(list("ACGT"), 700))
+    spacer = "".join(rng.choice(list("ACGT"), 500))
+    raw, offs, seeds, truth = [], [], [], []
+    for a, seq in enumerate(alleles):
+        for _ in range(9):
+            clip = int(rng.integers(40, 300)) if rng.random() < 0.3 else 0
+            raw.append(synth.hifi_errors(rng, seq[clip:])); offs.append(None if clip == 0 else clip + 50); seeds.append(None); truth.append(a)
+    for s_id, seq in ((1, rep), (3, spacer)):
+        for _ in range(6):
+            raw.append(synth.hifi_errors(rng, seq)); offs.append(None); seeds.append(s_id); truth.append(10 + s_id)
+    order = rng.permutation(len(raw))
+    raw, offs, seeds, truth = [raw[i] for i in order], [offs[i] for i in order], [seeds[i] for i in order], [truth[i] for i in order]
+    hpc = [oracle.hpc(r) for r in raw]
+    hoffs = [None if o is None else oracle.hpc_pos(alleles[t], o - 50) + 50 for o, t in zip(offs, truth)]
+    kw = dict(early_termination=True, dual=True, offset_window=100, offset_compare_length=64)
+    e_group, e_cons = of.oracle_priority_consensus(oracle, [hpc, raw], of.cons_config(**kw), [hoffs, offs], seeds)
+    g_group, g_cons = gpu_ctx.consensus_priority([gpu_ctx.upload(hpc), gpu_ctx.upload(raw)], gpu_cfg(pkg, **kw), [hoffs, offs], seeds)
+    assert g_group.tolist() == e_group.tolist() and g_cons == e_cons
+    # and the grouping is the truth: one group per allele / region type, its raw consensus is that sequence
+    by_group = {}
+    for g, t in zip(g_group.tolist(), truth):
+        by_group.setdefault(g, set()).add(t)
+    assert all(len(v) == 1 for v in by_group.values()) and len(by_group) == 6
+    want = {**{a: s for a, s in enumerate(alleles)}, 11: rep, 13: spacer}
+    for g, ts in by_group.items():
+        assert g_cons[g][1] == want[next(iter(ts))]
