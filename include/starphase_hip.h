@@ -286,6 +286,19 @@ int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensus, const ui
 int32_t sp_cyp_score_alleles(sp_ctx* ctx, uint32_t n_variants, uint32_t n_alleles, const uint8_t* hap_matrix, const uint8_t* is_vi,
                              uint32_t n_seqs, const uint8_t* states, uint32_t* best_vi, uint32_t* best_all, uint8_t* tie_mask);
 
+/* ------------------------------------------------------------------ K9: per-variant state of typed sequences
+ * The role of WFAGraph::from_reference_variants + edit_distance_with_pruning + the traversed-node loop of assign_haplotype
+ * (src/cyp2d6/haplotyper.rs:371-468): which allele of every database variant a consensus carries.  hiphase v1.2.1 is not on disk;
+ * the contract: the sequence is placed on the backbone (GPU alignment with traceback); for every variant whose
+ * reference span lies inside the aligned part, the sequence window facing [p - 24, p + |ref| + 24) is compared (global edit
+ * distance, one GPU thread per pair) with that backbone window carrying the reference allele and carrying the alternate allele:
+ * 0 = closer to the reference, 1 = closer to the alternate, 2 = equally close (ambiguous), 3 = not covered / not aligned.
+ *   backbone    the CYP2D6_wfa_backbone slice of the reference; var_pos 0-based on it; var_ref / var_alt normalised ACGT alleles
+ *   states      sp_seqset_count(seqs) * n_variants, ready for sp_cyp_score_alleles;  alns (optional) placement of every sequence */
+int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, const char* backbone, uint32_t backbone_len, uint32_t n_variants,
+                              const int32_t* var_pos, const char* const* var_ref, const char* const* var_alt,
+                              uint8_t* states, sp_aln* alns);
+
 /* ------------------------------------------------------------------ K6: variant-gene diplotype search
  * Replaces solve_diplotype (src/diplotyper.rs:1211-1371) with find_best_inexact_matches (:1411-1509) and
  * NormalizedPgxHaplotype::quant_match (src/data_types/normalized_variant.rs:431-479) on integer ids.  The caller keeps the

@@ -563,3 +563,59 @@ int osp_cyp_build_chains(int n_haps, const int32_t* hap_type, int n_reads, const
     *n_kept = nk;
     return rc;
 }
+
+
+/* ------------------------------------------------------------------ variant states of a sequence on the backbone (see cyp_oracle.h) */
+static int code_of(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+static int lev(const uint8_t* a, int la, const uint8_t* b, int lb) {
+    int* row = (int*)malloc(sizeof(int) * (size_t)(lb + 1));
+    for (int j = 0; j <= lb; ++j) row[j] = j;
+    for (int i = 1; i <= la; ++i) {
+        int diag = row[0]; row[0] = i;
+        for (int j = 1; j <= lb; ++j) {
+            int v = diag + ((a[i - 1] < 4 && a[i - 1] == b[j - 1]) ? 0 : 1);
+            if (row[j] + 1 < v) v = row[j] + 1;
+            if (row[j - 1] + 1 < v) v = row[j - 1] + 1;
+            diag = row[j]; row[j] = v;
+        }
+    }
+    int r = row[lb]; free(row); return r;
+}
+
+int osp_cyp_variant_states(const uint8_t* seq, int seq_len, const uint8_t* backbone, int backbone_len, int n_variants, const int32_t* var_pos,
+                           const char* const* var_ref, const char* const* var_alt, uint8_t* states, int32_t* aln_out) {
+    for (int v = 0; v < n_variants; ++v) states[v] = 3;
+    if (aln_out) memset(aln_out, 0, sizeof(int32_t) * 5);
+    int diag = 0;
+    if (osp_anchor(seq, seq_len, backbone, backbone_len, &diag) < OSP_CYP_MIN_VOTES) return 0;      /* backbone_pos - seq_pos */
+    osp_aln al; uint32_t ev[256]; int nev = 0;
+    if (!osp_wfa(seq, seq_len, backbone, backbone_len, diag, 255, &al, ev, &nev)) return 0;
+    if (aln_out) { aln_out[0] = al.a_start; aln_out[1] = al.a_end; aln_out[2] = al.b_start; aln_out[3] = al.b_end; aln_out[4] = al.nm; }
+    for (int v = 0; v < n_variants; ++v) {
+        const int p = var_pos[v], rl = (int)strlen(var_ref[v]), alen = (int)strlen(var_alt[v]);
+        if (p < al.b_start || p + rl > al.b_end) continue;
+        int ws = p - OSP_K9_FLANK, we = p + rl + OSP_K9_FLANK;
+        if (ws < al.b_start) ws = al.b_start;
+        if (we > al.b_end) we = al.b_end;
+        /* sequence position facing backbone position b: deletions before b pull it back, insertions before b push it on */
+        int sa = al.a_start + (ws - al.b_start), ea = al.a_start + (we - al.b_start);
+        for (int e = 0; e < nev; ++e) {
+            const uint32_t type = ev[e] >> 30; const int bp = (int)(ev[e] & 0x3FFFFFFFu);
+            if (type == OSP_EV_D) { if (bp < ws) --sa; if (bp < we) --ea; }
+            else if (type == OSP_EV_I) { if (bp < ws) ++sa; if (bp < we) ++ea; }
+        }
+        if (sa < 0) sa = 0;
+        if (ea > seq_len) ea = seq_len;
+        if (ea < sa) ea = sa;
+        const int lr = we - ws, la = lr - rl + alen;
+        uint8_t* href = (uint8_t*)malloc((size_t)lr + 1), *halt = (uint8_t*)malloc((size_t)la + 1);
+        memcpy(href, backbone + ws, (size_t)lr);
+        memcpy(halt, backbone + ws, (size_t)(p - ws));
+        for (int i = 0; i < alen; ++i) halt[p - ws + i] = (uint8_t)code_of(var_alt[v][i]);
+        memcpy(halt + (p - ws) + alen, backbone + p + rl, (size_t)(we - p - rl));
+        const int dr = lev(seq + sa, ea - sa, href, lr), da = lev(seq + sa, ea - sa, halt, la);
+        states[v] = dr < da ? 0 : (da < dr ? 1 : 2);
+        free(href); free(halt);
+    }
+    return 1;
+}

@@ -64,6 +64,17 @@ int  osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, co
 void osp_cyp_score_alleles(int n_variants, int n_alleles, const uint8_t* hap_matrix, const uint8_t* is_vi, const uint8_t* states,
                            uint32_t* best_vi, uint32_t* best_all, uint8_t* tie);
 
+/* per-variant state of a sequence against the CYP2D6 backbone: the role of WFAGraph::edit_distance_with_pruning + traversed nodes in
+ * assign_haplotype (src/cyp2d6/haplotyper.rs:371-468; hiphase v1.2.1 is not on disk -- PARITY UNPINNED, contract in DESIGN.md 13).
+ * The sequence is placed on the backbone (anchor + banded alignment with traceback); for every variant whose reference span lies in
+ * the aligned part, the sequence window that faces [p - 24, p + |ref| + 24) is compared (global edit distance) with that backbone
+ * window carrying the reference allele and carrying the alternate allele: closer to ref = 0, closer to alt = 1, equal = 2;
+ * variants outside the aligned part stay 3.  var_pos is 0-based on the backbone; alleles are ACGT strings (normalised, with anchor
+ * base for indels).  Returns 1 when the sequence aligned (aln_out filled), 0 otherwise (all states 3). */
+#define OSP_K9_FLANK 24
+int osp_cyp_variant_states(const uint8_t* seq, int seq_len, const uint8_t* backbone, int backbone_len, int n_variants, const int32_t* var_pos,
+                           const char* const* var_ref, const char* const* var_alt, uint8_t* states, int32_t* aln_out /* a_start, a_end, b_start, b_end, nm */);
+
 /* chain building (src/cyp2d6/caller.rs:429-583).  Segments of read r = [read_seg_off[r], read_seg_off[r+1]) in region order;
  * ed = [segment][n_haps] from weight_sequence, kept[segment] = 0 when weight_sequence returned the empty vector.
  * Outputs (all caller-sized; return 0 ok, 1 capacity, 2 "chain collapse" panic):

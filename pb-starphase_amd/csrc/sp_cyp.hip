@@ -578,3 +578,125 @@ extern "C" int32_t sp_cyp_score_alleles(sp_ctx* ctx, uint32_t n_variants, uint32
     }
     return SP_OK;
 }
+
+
+// =============================================================================================
+// K9: per-variant state of typed sequences on the CYP2D6 backbone -- the role of the graph alignment in assign_haplotype
+// (src/cyp2d6/haplotyper.rs:371-468; hiphase's WFAGraph is not on disk, contract in DESIGN.md section 13 / oracle/cyp.c):
+// each sequence is placed on the backbone with traceback (anchor + cell kernels); for every variant inside the aligned part the
+// sequence window facing [p - 24, p + |ref| + 24) is compared with that backbone window carrying the reference and the alternate
+// allele.  The (window, haplotype) pairs of all sequences and variants are one batch of small global edit distances: one thread
+// per pair, DP row in LDS.
+// =============================================================================================
+#define K9_FLANK 24
+#define K9_MAXLEN 192          // longest window / haplotype a pair may hold (2 * 24 + alleles)
+
+struct K9Pair { uint32_t a_off, b_off; uint16_t a_len, b_len; };
+
+__global__ __launch_bounds__(64) void k9_pair_ed_kernel(const uint8_t* __restrict__ pool, const K9Pair* __restrict__ pairs, uint32_t n_pairs, uint16_t* __restrict__ out) {
+    __shared__ uint16_t row[64][K9_MAXLEN + 1];
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_pairs) return;
+    const K9Pair p = pairs[i];
+    const uint8_t* a = pool + p.a_off; const uint8_t* b = pool + p.b_off;
+    uint16_t* r = row[threadIdx.x];
+    for (int j = 0; j <= p.b_len; ++j) r[j] = (uint16_t)j;
+    for (int x = 1; x <= p.a_len; ++x) {
+        const uint8_t ca = a[x - 1];
+        uint16_t diag = r[0]; r[0] = (uint16_t)x;
+        for (int j = 1; j <= p.b_len; ++j) {
+            uint16_t v = (uint16_t)(diag + ((ca < 4 && ca == b[j - 1]) ? 0 : 1));
+            const uint16_t up = (uint16_t)(r[j] + 1), left = (uint16_t)(r[j - 1] + 1);
+            v = up < v ? up : v; v = left < v ? left : v;
+            diag = r[j]; r[j] = v;
+        }
+    }
+    out[i] = r[p.b_len];
+}
+
+extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, const char* backbone, uint32_t backbone_len, uint32_t n_variants,
+                                         const int32_t* var_pos, const char* const* var_ref, const char* const* var_alt,
+                                         uint8_t* states, sp_aln* alns_out) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!seqs || !backbone || (n_variants && (!var_pos || !var_ref || !var_alt)) || (seqs->n && n_variants && !states)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_cyp_variant_states: null argument");
+    (void)hipSetDevice(ctx->device);
+    const uint32_t S = seqs->n;
+    if (states) std::memset(states, 3, (size_t)S * n_variants);
+    if (S == 0) return SP_OK;
+    // place every sequence on the backbone (sequence = indexed / streamed side A, backbone = window side B), with traceback
+    sp_seqset* bb = nullptr;
+    const uint64_t boff[2] = { 0, backbone_len };
+    int32_t rc = sp_seqset_upload(ctx, backbone, boff, 1, &bb);
+    if (rc != SP_OK) return rc;
+    std::vector<uint32_t> ai(S), bi(S, 0); for (uint32_t i = 0; i < S; ++i) ai[i] = i;
+    std::vector<int32_t> diag(S), votes(S);
+    rc = sp_anchor_batch(ctx, seqs, bb, ai.data(), bi.data(), S, diag.data(), votes.data());
+    std::vector<sp_pair> pairs; std::vector<uint32_t> who;
+    if (rc == SP_OK) for (uint32_t i = 0; i < S; ++i) if (votes[i] >= CYP_MIN_VOTES) { pairs.push_back(sp_pair{ i, 0, diag[i], SP_MAX_ED }); who.push_back(i); }
+    std::vector<sp_aln> alns(pairs.size()); std::vector<uint32_t> events(pairs.size() * (size_t)SP_MAX_ED);
+    if (rc == SP_OK && !pairs.empty()) rc = sp_align_batch(ctx, seqs, bb, pairs.data(), pairs.size(), alns.data(), events.data(), SP_MAX_ED);
+    sp_seqset_free(bb);
+    if (rc != SP_OK) return rc;
+    if (alns_out) { std::memset(alns_out, 0, sizeof(sp_aln) * S); for (size_t x = 0; x < who.size(); ++x) alns_out[who[x]] = alns[x]; }
+    if (n_variants == 0) return SP_OK;
+    auto code = [](char c) -> uint8_t { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; };
+    std::vector<uint8_t> bcode(backbone_len);
+    for (uint32_t i = 0; i < backbone_len; ++i) bcode[i] = code(backbone[i]);
+    // the pairs: per (sequence, variant) the sequence window against the reference haplotype and against the alternate haplotype
+    const size_t plane_words = (size_t)seqs->h_word_off[seqs->n] + 4;             // the host copy exists: the anchor step indexed the set
+    std::vector<uint8_t> pool; std::vector<K9Pair> kp; std::vector<std::pair<uint32_t, uint32_t>> owner;
+    for (size_t x = 0; x < who.size(); ++x) {
+        const sp_aln& al = alns[x];
+        if (!al.ok) continue;
+        const uint32_t sidx = who[x];
+        const uint32_t* w = seqs->h_words.data() + seqs->h_word_off[sidx];
+        const uint32_t* np = seqs->has_n ? seqs->h_words.data() + plane_words + seqs->h_word_off[sidx] : nullptr;
+        const int slen = seqs->h_len[sidx];
+        const uint32_t* ev = events.data() + x * (size_t)SP_MAX_ED;
+        for (uint32_t v = 0; v < n_variants; ++v) {
+            const int p = var_pos[v], rl = (int)std::strlen(var_ref[v]), alen = (int)std::strlen(var_alt[v]);
+            if (p < al.b_start || p + rl > al.b_end) continue;
+            const int ws = std::max(p - K9_FLANK, al.b_start), we = std::min(p + rl + K9_FLANK, al.b_end);
+            int sa = al.a_start + (ws - al.b_start), ea = al.a_start + (we - al.b_start);
+            for (int e = 0; e < al.nm; ++e) {
+                const uint32_t type = ev[e] >> 30; const int bp = (int)(ev[e] & 0x3FFFFFFFu);
+                if (type == SP_EV_D) { sa -= bp < ws; ea -= bp < we; }
+                else if (type == SP_EV_I) { sa += bp < ws; ea += bp < we; }
+            }
+            sa = std::max(sa, 0); ea = std::min(ea, slen); ea = std::max(ea, sa);
+            const int lr = we - ws, la = lr - rl + alen, lw = ea - sa;
+            if (lr > K9_MAXLEN || la > K9_MAXLEN || lw > K9_MAXLEN) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_cyp_variant_states: variant allele longer than the window buffer");
+            const uint32_t o_w = (uint32_t)pool.size();
+            for (int h = sa; h < ea; ++h) { const uint32_t sh = (uint32_t)(h & 15) << 1; pool.push_back((np && ((np[h >> 4] >> sh) & 1u)) ? 4 : (uint8_t)((w[h >> 4] >> sh) & 3u)); }
+            const uint32_t o_r = (uint32_t)pool.size();
+            pool.insert(pool.end(), bcode.begin() + ws, bcode.begin() + we);
+            const uint32_t o_a = (uint32_t)pool.size();
+            pool.insert(pool.end(), bcode.begin() + ws, bcode.begin() + p);
+            for (int i = 0; i < alen; ++i) pool.push_back(code(var_alt[v][i]));
+            pool.insert(pool.end(), bcode.begin() + p + rl, bcode.begin() + we);
+            kp.push_back(K9Pair{ o_w, o_r, (uint16_t)lw, (uint16_t)lr });
+            kp.push_back(K9Pair{ o_w, o_a, (uint16_t)lw, (uint16_t)la });
+            owner.push_back({ sidx, v });
+        }
+    }
+    if (kp.empty()) return SP_OK;
+    uint8_t* d_pool = (uint8_t*)sp_pool(ctx, "k9_pool", pool.size());
+    K9Pair* d_pairs = (K9Pair*)sp_pool(ctx, "k9_pairs", kp.size() * sizeof(K9Pair));
+    uint16_t* d_out = (uint16_t*)sp_pool(ctx, "k9_out", kp.size() * sizeof(uint16_t));
+    if (!d_pool || !d_pairs || !d_out) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "k9 buffers");
+    std::vector<uint16_t> ed(kp.size());
+    (void)hipMemcpyAsync(d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_pairs, kp.data(), kp.size() * sizeof(K9Pair), hipMemcpyHostToDevice, ctx->stream);
+    {
+        ProfScope ps(ctx, "k9_pair_ed", kp.size());
+        hipLaunchKernelGGL(k9_pair_ed_kernel, dim3((unsigned)((kp.size() + 63) / 64)), dim3(64), 0, ctx->stream, d_pool, d_pairs, (uint32_t)kp.size(), d_out);
+    }
+    (void)hipMemcpyAsync(ed.data(), d_out, kp.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("k9: ") + hipGetErrorString(e));
+    for (size_t x = 0; x < owner.size(); ++x) {
+        const uint16_t dr = ed[2 * x], da = ed[2 * x + 1];
+        states[(size_t)owner[x].first * n_variants + owner[x].second] = dr < da ? 0 : (da < dr ? 1 : 2);
+    }
+    return SP_OK;
+}

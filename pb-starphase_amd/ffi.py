@@ -196,6 +196,7 @@ def lib():
         "sp_consensus_dual": (i32, [vp, vp, vp, u32, vp, C.POINTER(sp_cons_config), C.c_char_p, C.c_char_p, u32, vp, vp, vp, C.POINTER(sp_cons_result)]),
         "sp_consensus_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
         "sp_consensus_dual_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
+        "sp_cyp_variant_states": (i32, [vp, vp, C.c_char_p, u32, u32, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), vp, vp]),
         "sp_consensus_priority": (i32, [vp, C.POINTER(sp_priority_problem), u32, u32, C.POINTER(u32), vp, C.c_char_p]),
         "sp_hla_diplotype_gene": (i32, [vp, vp, u32, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, C.c_char_p, u32, vp]),
         "sp_hla_diplotype_genes": (i32, [vp, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
@@ -425,6 +426,17 @@ class Context:
         self.check(lib().sp_consensus_priority(self._h, C.byref(pr), max_groups, cap, C.byref(ng), _ptr(group_of), buf))
         text = lambda j: buf.raw[j * cap:(j + 1) * cap].split(b"\0", 1)[0].decode()
         return group_of[:n].copy(), [[text(g * nl + l) for l in range(nl)] for g in range(ng.value)]
+
+    def cyp_variant_states(self, seqs, backbone, var_pos, var_ref, var_alt):
+        """sp_cyp_variant_states on a SeqSet -> (states [n_seqs][n_variants] uint8, placements sp_aln array)"""
+        nv = len(var_pos)
+        pos = np.ascontiguousarray(var_pos, np.int32)
+        refs = (C.c_char_p * max(1, nv))(*[r.encode() for r in var_ref])
+        alts = (C.c_char_p * max(1, nv))(*[a.encode() for a in var_alt])
+        states = np.full((seqs.n, nv), 3, np.uint8)
+        alns = np.zeros(max(1, seqs.n), ALN_DTYPE)
+        self.check(lib().sp_cyp_variant_states(self._h, seqs._h, backbone.encode(), len(backbone), nv, _ptr(pos), refs, alts, _ptr(states), _ptr(alns)))
+        return states, alns[:seqs.n]
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))

@@ -482,3 +482,18 @@ def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None):
             group_of[r] = g
         cons.append([oracle_consensus(oracle, [levels[l][r] for r in members], rebased(members, l), single)["cons"][0] for l in range(nl)])
     return group_of, cons
+
+
+def oracle_variant_states(oracle, seq, backbone, var_pos, var_ref, var_alt):
+    """osp_cyp_variant_states -> (states uint8[n_variants], (a_start, a_end, b_start, b_end, nm) or None)"""
+    nv = len(var_pos)
+    se, be = oracle.encode(seq), oracle.encode(backbone)
+    pos = np.ascontiguousarray(var_pos, np.int32)
+    refs = (C.c_char_p * max(1, nv))(*[r.encode() for r in var_ref])
+    alts = (C.c_char_p * max(1, nv))(*[a.encode() for a in var_alt])
+    states = np.full(nv, 3, np.uint8)
+    aln = np.zeros(5, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    oracle.L.osp_cyp_variant_states.restype = C.c_int
+    ok = oracle.L.osp_cyp_variant_states(p(se), len(se), p(be), len(be), nv, p(pos), refs, alts, p(states), p(aln))
+    return states, (tuple(int(x) for x in aln) if ok else None)

@@ -144,3 +144,71 @@ def test_score_alleles(oracle, pkg, gpu_ctx):
         assert (bv[s], ba[s]) == (ev.value, ea.value)
         assert tie[s].tolist() == et.tolist()
     assert bv[-1] == 0 and ba[-1] == 0
+
+
+def make_variant_panel(rng, backbone, n=48):
+    """non-overlapping variants on the backbone: SNVs, small insertions / deletions (anchored), one longer deletion, one two-alt site"""
+    pos = sorted(rng.choice(np.arange(150, len(backbone) - 150, 40), n, replace=False).tolist())
+    out = []
+    for k, p in enumerate(pos):
+        ref = backbone[p]
+        kind = k % 6
+        if kind in (0, 1, 2):
+            out.append((p, ref, rng.choice([c for c in "ACGT" if c != ref])))
+        elif kind == 3:
+            out.append((p, ref, ref + "".join(rng.choice(list("ACGT"), int(rng.integers(1, 4))))))
+        elif kind == 4:
+            out.append((p, backbone[p:p + int(rng.integers(2, 5))], ref))
+        else:
+            out.append((p, backbone[p:p + 10], ref))
+    p0 = out[0][0]
+    out.append((p0, out[0][1], next(c for c in "ACGT" if c not in (out[0][1], out[0][2]))))      # second alternate at the first site
+    return out
+
+
+def apply_variants(backbone, variants, chosen):
+    s, shift = backbone, 0
+    for i in sorted(chosen, key=lambda i: variants[i][0]):
+        p, ref, alt = variants[i]
+        assert s[p + shift:p + shift + len(ref)] == ref
+        s = s[:p + shift] + alt + s[p + shift + len(ref):]
+        shift += len(alt) - len(ref)
+    return s
+
+
+def test_variant_states(oracle, pkg, gpu_ctx):
+    """K9 against the oracle, and against the alleles the sequences were built from"""
+    from pb_starphase_amd import synth
+    rng = np.random.default_rng(44)
+    backbone = "".join(rng.choice(list("ACGT"), 6200))
+    variants = make_variant_panel(rng, backbone)
+    nv = len(variants)
+    pos, refs, alts = [v[0] for v in variants], [v[1] for v in variants], [v[2] for v in variants]
+    seqs, truth = [], []
+    for k in range(8):
+        chosen = sorted(rng.choice(nv - 1, int(rng.integers(0, 14)), replace=False).tolist())
+        full = apply_variants(backbone, variants, chosen)
+        lo, hi = (0, len(full)) if k % 3 == 0 else (int(rng.integers(100, 900)), len(full) - int(rng.integers(100, 900)))
+        s = full[lo:hi]
+        if k % 2:
+            s = synth.hifi_errors(rng, s)
+        seqs.append(s)
+        truth.append(set(chosen))
+    seqs.append("".join(rng.choice(list("ACGT"), 2000)))                                           # does not align: all states 3
+    states, alns = gpu_ctx.cyp_variant_states(gpu_ctx.upload(seqs), backbone, pos, refs, alts)
+    n_called = 0
+    for i, seq in enumerate(seqs):
+        e_states, e_aln = of.oracle_variant_states(oracle, seq, backbone, pos, refs, alts)
+        assert states[i].tolist() == e_states.tolist(), (i, np.flatnonzero(states[i] != e_states))
+        if e_aln is None:
+            assert not alns[i]["ok"] and (states[i] == 3).all()
+            continue
+        assert (int(alns[i]["a_start"]), int(alns[i]["a_end"]), int(alns[i]["b_start"]), int(alns[i]["b_end"]), int(alns[i]["nm"])) == e_aln
+        if i < len(truth) and i % 2 == 0:                                                         # noise-free sequences: the states are the truth
+            for v in range(nv - 1):
+                if states[i][v] == 3:
+                    continue
+                n_called += 1
+                assert states[i][v] == (1 if v in truth[i] else 0), (i, v, variants[v])
+    assert n_called > 100
+    assert (states[-1] == 3).all()
