@@ -299,6 +299,45 @@ int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, const char* ba
                               const int32_t* var_pos, const char* const* var_ref, const char* const* var_alt,
                               uint8_t* states, sp_aln* alns);
 
+/* ------------------------------------------------------------------ CYP2D6, reads to diplotype
+ * diplotype_cyp2d6 (src/cyp2d6/caller.rs:39-741) on top of K3 / K8 / K9 / K7 / K4 / K5, without I/O and debug artefacts:
+ * regions of interest (:126-139) -> consensus inputs with offsets and seeds (:176-245) -> multi-way consensus (:268) ->
+ * merge_consensus_results (:750-898) -> typing of every consensus with find_full_type_in_sequence / assign_haplotype
+ * (src/cyp2d6/haplotyper.rs:326-602) and duplicate detection (:331-375) -> weights, chains, best chain pair (:429-640) ->
+ * haplotype strings (:660-690).
+ *   templates          Cyp2d6Extractor::hybrid_sequences in full_allele() order (haplotyper.rs:175-183) with type, subtype label and
+ *                      template_deep[t] = 1 when the label is in mapped_hybrids (typed further by its variants)
+ *   backbone, var_*    the CYP2D6_wfa_backbone slice and LoadedVariants::ordered_variants on it (0-based), is_vi flags
+ *   allele_subtype / hap_matrix   haplotype_lookup in BTreeMap order: star-allele label ("4.001") and its 0/1 vector
+ *   translate / connections / singletons   the three Cyp2d6Config tables
+ * call->status: 0 called, 1 = no reads (NO_READS), 7 = chain collapse, 16/17/18 = CallerError (NO_MATCH).  hap1/hap2 carry the
+ * sub-allele strings, core1/core2 the core-allele strings (Cyp2d6DetailLevel::SubAlleles / CoreAlleles). */
+typedef struct {
+    const sp_seqset* templates; const int32_t* template_type; const char* const* template_subtype; const uint8_t* template_deep;
+    const char* backbone; uint32_t backbone_len;
+    uint32_t n_variants; const int32_t* var_pos; const char* const* var_ref; const char* const* var_alt; const uint8_t* var_is_vi;
+    uint32_t n_alleles; const char* const* allele_subtype; const uint8_t* hap_matrix;
+    uint32_t n_translate; const char* const* translate_key; const char* const* translate_val;
+    uint32_t n_connections; const char* const* connection_a; const char* const* connection_b;
+    uint32_t n_singletons; const char* const* singletons;
+    int32_t min_consensus_count, dual_max_ed_delta; double min_consensus_fraction;
+    int32_t infer_connections, normalize_d6_only;
+} sp_cyp_problem;
+
+#define SP_CYP_MAXCONS 64
+typedef struct {
+    int32_t status;
+    int32_t n_consensus;                          /* final consensus regions (hap_regions) */
+    int32_t cons_type[SP_CYP_MAXCONS];            /* SP_CYP_* after typing, duplicate and false-allele marking */
+    char    cons_subtype[SP_CYP_MAXCONS][48];     /* "" = none */
+    int32_t n1, n2; int32_t chain1[SP_MAX_CHAIN], chain2[SP_MAX_CHAIN];
+    double  score;
+    char hap1[256], hap2[256], core1[256], core2[256];
+} sp_cyp_call;
+
+int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* problem, const sp_seqset* reads, sp_cyp_call* call,
+                         char* consensus /* optional: SP_CYP_MAXCONS * cons_cap bytes */, uint32_t cons_cap);
+
 /* ------------------------------------------------------------------ K6: variant-gene diplotype search
  * Replaces solve_diplotype (src/diplotyper.rs:1211-1371) with find_best_inexact_matches (:1411-1509) and
  * NormalizedPgxHaplotype::quant_match (src/data_types/normalized_variant.rs:431-479) on integer ids.  The caller keeps the

@@ -152,6 +152,30 @@ int32_t sp_seqset_length(const sp_seqset* s, uint32_t idx, uint32_t* len) {
 
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
 
+int sp_seqset_fetch_host(sp_ctx* ctx, sp_seqset* s) {
+    if (!s->h_words.empty()) return SP_OK;
+    hipSetDevice(ctx->device);
+    const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
+    s->h_words.assign(plane_words * (s->has_n ? 2 : 1), 0);
+    if (hipMemcpy(s->h_words.data(), s->d_words, plane_words * 4, hipMemcpyDeviceToHost) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "fetch packed words");
+    if (s->has_n && hipMemcpy(s->h_words.data() + plane_words, s->d_nplane, plane_words * 4, hipMemcpyDeviceToHost) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "fetch N plane");
+    return SP_OK;
+}
+
+std::string sp_seqset_decode(sp_ctx* ctx, const sp_seqset* s, uint32_t i) {
+    if (sp_seqset_fetch_host(ctx, const_cast<sp_seqset*>(s)) != SP_OK || i >= s->n) return std::string();
+    const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
+    const uint32_t* w = s->h_words.data() + s->h_word_off[i];
+    const uint32_t* np = s->has_n ? s->h_words.data() + plane_words + s->h_word_off[i] : nullptr;
+    std::string out((size_t)s->h_len[i], 'N');
+    for (int h = 0; h < s->h_len[i]; ++h) {
+        const uint32_t sh = (uint32_t)(h & 15) << 1;
+        if (np && ((np[h >> 4] >> sh) & 1u)) continue;
+        out[h] = "ACGT"[(w[h >> 4] >> sh) & 3u];
+    }
+    return out;
+}
+
 // sorted 16-mer table of every sequence of the set (device code order: base t of the k-mer in bits 2t..2t+1)
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
     if (s->has_index) return SP_OK;

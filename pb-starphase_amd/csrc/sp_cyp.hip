@@ -700,3 +700,230 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
     }
     return SP_OK;
 }
+
+
+// =============================================================================================
+// CYP2D6, reads to diplotype: the host-side counterpart of diplotype_cyp2d6 (src/cyp2d6/caller.rs:39-741)
+// =============================================================================================
+namespace {
+
+struct Label { int type = SP_CYP_UNKNOWN; bool has_sub = false; std::string sub; };
+static std::string label_full(const Label& l) { return full_allele(l.type, l.has_sub ? l.sub.c_str() : nullptr); }
+static bool label_allowed(const Label& l) { return l.type != SP_CYP_UNKNOWN && l.type != SP_CYP_FALSE_ALLELE; }          // region_label.rs:171-173
+// simplify_allele(detailed = true) (region_label.rs:101-128)
+static std::string label_reduced(const Label& l, const sp_cyp_problem* pr) {
+    if (l.type == SP_CYP_CYP2D6 || l.type == SP_CYP_HYBRID) {
+        if (!l.has_sub) return label_full(l);
+        for (uint32_t i = 0; i < pr->n_translate; ++i) if (l.sub == pr->translate_key[i]) return std::string("*") + pr->translate_val[i];
+        return "*" + l.sub;
+    }
+    if (l.type == SP_CYP_DELETION) return "*5";
+    return label_full(l);
+}
+
+// find_full_type_in_sequence + assign_haplotype for a batch of sequences (src/cyp2d6/haplotyper.rs:326-602)
+static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::vector<std::string>& seqs, double max_missing, bool force, std::vector<Label>& out) {
+    out.assign(seqs.size(), Label());
+    std::vector<uint32_t> live;                                        // an empty sequence has no matches: Unknown
+    std::string blob; std::vector<uint64_t> off(1, 0);
+    for (uint32_t i = 0; i < seqs.size(); ++i) if (!seqs[i].empty()) { live.push_back(i); blob += seqs[i]; off.push_back(blob.size()); }
+    if (live.empty()) return SP_OK;
+    sp_seqset* set = nullptr;
+    int32_t rc = sp_seqset_upload(ctx, blob.data(), off.data(), (uint32_t)live.size(), &set);
+    if (rc != SP_OK) return rc;
+    std::vector<sp_region_hit> hits(live.size() * 16 + 16); uint64_t nh = 0;
+    rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh);
+    if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh); }
+    std::vector<uint8_t> states((size_t)live.size() * pr->n_variants, 3);
+    if (rc == SP_OK) rc = sp_cyp_variant_states(ctx, set, pr->backbone, pr->backbone_len, pr->n_variants, pr->var_pos, pr->var_ref, pr->var_alt, states.data(), nullptr);
+    std::vector<uint32_t> bvi(live.size()), ball(live.size()); std::vector<uint8_t> tie((size_t)live.size() * std::max<uint32_t>(pr->n_alleles, 1));
+    if (rc == SP_OK && pr->n_alleles && pr->n_variants)
+        rc = sp_cyp_score_alleles(ctx, pr->n_variants, pr->n_alleles, pr->hap_matrix, pr->var_is_vi, (uint32_t)live.size(), states.data(), bvi.data(), ball.data(), tie.data());
+    sp_seqset_free(set);
+    if (rc != SP_OK) return rc;
+    for (uint32_t x = 0; x < live.size(); ++x) {
+        // the best match of this sequence: lowest penalised score, first on ties (:344-349)
+        int best = -1; double bs = 0;
+        for (uint64_t h = 0; h < nh; ++h) if (hits[h].read == (int32_t)x) {
+            const double sc = cyp_score(hits[h].seq_len, hits[h].nm, hits[h].unmapped, true);
+            if (best < 0 || sc < bs) { best = (int)h; bs = sc; }
+        }
+        Label& lab = out[live[x]];
+        if (best < 0) continue;                                        // "no matches found" => Unknown (caller.rs:350-355)
+        const int t = hits[best].template_idx;
+        if (!pr->template_deep[t]) { lab.type = pr->template_type[t]; lab.has_sub = pr->template_subtype && pr->template_subtype[t]; if (lab.has_sub) lab.sub = pr->template_subtype[t]; continue; }
+        std::vector<Label> cands;
+        for (uint32_t a = 0; a < pr->n_alleles; ++a) if (tie[(size_t)x * pr->n_alleles + a]) { Label c; c.type = SP_CYP_CYP2D6; c.has_sub = true; c.sub = pr->allele_subtype[a]; cands.push_back(c); }
+        if (bvi[x] == 0 && ball[x] == 0) cands.push_back(Label());     // the Unknown label the search starts from (haplotyper.rs:471-473)
+        if (cands.empty()) continue;
+        if (cands.size() > 1) {
+            if (!force) continue;                                       // ambiguous => Unknown (:543-546)
+            std::stable_sort(cands.begin(), cands.end(), [](const Label& p, const Label& q) { return label_full(p) < label_full(q); });
+        }
+        lab = cands[0];
+    }
+    return SP_OK;
+}
+
+} // namespace
+
+extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, char* consensus, uint32_t cons_cap) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!pr || !reads || !call || !pr->templates || !pr->template_type || !pr->template_deep || !pr->backbone) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_cyp_diplotype: null argument");
+    (void)hipSetDevice(ctx->device);
+    std::memset(call, 0, sizeof *call);
+    const uint32_t R = reads->n;
+    // 1. regions of interest (caller.rs:126-139): max_missing_chain_frac = 0.5
+    std::vector<sp_region_hit> hits((size_t)R * 8 + 16); uint64_t nh = 0;
+    int32_t rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh);
+    if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh); }
+    if (rc != SP_OK) return rc;
+    hits.resize(nh);
+    // 2. consensus inputs (caller.rs:176-245): max_missing_consensus_frac = 0.5, offset window +-50
+    std::vector<uint32_t> c_idx; std::vector<int32_t> c_start, c_len, boff, hoff, seeds; std::vector<uint32_t> c_hit;
+    for (uint32_t h = 0; h < hits.size(); ++h) {
+        const sp_region_hit& q = hits[h];
+        if (cyp_score(q.seq_len, q.nm, q.unmapped, true) > 0.5) continue;
+        c_idx.push_back((uint32_t)q.read); c_start.push_back(q.start); c_len.push_back(q.end - q.start); c_hit.push_back(h);
+        boff.push_back(q.clip_start == 0 ? -1 : q.clip_start + 50);
+        const std::string guide = sp_seqset_decode(ctx, pr->templates, (uint32_t)q.template_idx);
+        const int32_t hp = (int32_t)sp_hpc_pos(guide.data(), guide.size(), (uint64_t)q.clip_start);       // hpc_with_guide (homopolymers.rs:53-64)
+        hoff.push_back(hp == 0 ? -1 : hp + 50);
+        int seed = -1;
+        switch (pr->template_type[q.template_idx]) { case SP_CYP_DELETION: seed = 0; break; case SP_CYP_REP6: seed = 1; break; case SP_CYP_REP7: seed = 2; break;
+                                                     case SP_CYP_SPACER: seed = 3; break; case SP_CYP_LINK_REGION: seed = 4; break; default: break; }
+        seeds.push_back(seed);
+    }
+    if (c_idx.empty()) { call->status = 1; return SP_OK; }                                                 // NO_READS (caller.rs:254-266)
+    sp_seqset raw, hpc;
+    rc = sp_make_segments(ctx, reads, c_idx, c_start, c_len, "cypc", &raw, &hpc);
+    if (rc != SP_OK) return rc;
+    // 3. multi-way consensus, homopolymer-compressed level first (caller.rs:162-270)
+    sp_cons_config cc;
+    cc.min_count = pr->min_consensus_count; cc.min_af = pr->min_consensus_fraction; cc.dual_max_ed_delta = pr->dual_max_ed_delta;
+    cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 100; cc.offset_compare_length = 64;      // the library compares at most 64 bases
+    const uint32_t n_in = raw.n;
+    const sp_seqset* levels[2] = { &hpc, &raw };
+    const int32_t* offs[2] = { hoff.data(), boff.data() };
+    sp_priority_problem pp; pp.n_levels = 2; pp.n = n_in; pp.levels = levels; pp.offsets = offs; pp.seeds = seeds.data(); pp.cfg = cc;
+    const uint32_t cap = (uint32_t)raw.max_len + 1024;
+    std::vector<int32_t> group_of(n_in); uint32_t n_groups = 0;
+    std::vector<char> text((size_t)SP_CYP_MAXCONS * 2 * cap);
+    rc = sp_consensus_priority(ctx, &pp, SP_CYP_MAXCONS, cap, &n_groups, group_of.data(), text.data());
+    if (rc != SP_OK) return rc;
+    std::vector<std::string> hpc_cons(n_groups), full_cons(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) { hpc_cons[g] = text.data() + (size_t)(2 * g) * cap; full_cons[g] = text.data() + (size_t)(2 * g + 1) * cap; }
+    // 4. merge_consensus_results (caller.rs:750-898): max_missing_typing_frac = 0.1, no forced assignment
+    std::vector<Label> glabel;
+    rc = type_sequences(ctx, pr, full_cons, 0.1, false, glabel);
+    if (rc != SP_OK) return rc;
+    std::map<std::pair<std::string, std::string>, std::vector<uint32_t>> cset;
+    std::map<std::string, std::vector<uint32_t>> uset;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        if (!label_allowed(glabel[g])) uset[hpc_cons[g]].push_back(g);
+        else cset[{ hpc_cons[g], label_reduced(glabel[g], pr) }].push_back(g);
+    }
+    std::vector<std::pair<std::string, std::string>> ignored;
+    for (auto& u : uset) {
+        std::vector<std::pair<std::string, std::string>> others;
+        for (auto& kv : cset) if (kv.first.first == u.first) others.push_back(kv.first);
+        if (others.size() == 1) { auto& dst = cset[others[0]]; dst.insert(dst.end(), u.second.begin(), u.second.end()); }
+        else { if (others.size() > 1) ignored.push_back({ u.first, "UNKNOWN" }); cset[{ u.first, "UNKNOWN" }] = u.second; }
+    }
+    if (cset.size() > SP_CYP_MAXCONS) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_cyp_diplotype: more than SP_CYP_MAXCONS consensus regions");
+    std::vector<std::string> final_cons; std::vector<int32_t> seq_idx(n_in, -1);
+    {
+        std::vector<sp_cons_problem> P; std::vector<sp_cons_output> O; std::vector<size_t> slot;
+        std::vector<std::vector<uint32_t>> members; std::vector<std::vector<int32_t>> moffs, ms1, ms2; std::vector<std::vector<uint8_t>> mis; std::vector<std::vector<char>> mtext;
+        sp_cons_config single = cc; single.allow_dual = 0;
+        for (auto& kv : cset) {
+            const size_t ci = final_cons.size();
+            std::vector<uint32_t> mem;
+            for (uint32_t s2 = 0; s2 < n_in; ++s2) if (std::find(kv.second.begin(), kv.second.end(), (uint32_t)group_of[s2]) != kv.second.end()) { mem.push_back(s2); seq_idx[s2] = (int32_t)ci; }
+            if (std::find(ignored.begin(), ignored.end(), kv.first) != ignored.end()) { final_cons.push_back(std::string()); continue; }
+            if (kv.second.size() == 1) { final_cons.push_back(full_cons[kv.second[0]]); continue; }
+            final_cons.push_back(std::string());                                                             // merge: one consensus over all their reads (:852-871)
+            int32_t mn = INT32_MAX; for (uint32_t s2 : mem) mn = std::min(mn, boff[s2] < 0 ? 0 : boff[s2]);
+            std::vector<int32_t> mo; for (uint32_t s2 : mem) { const int32_t v = boff[s2] < 0 ? 0 : boff[s2]; mo.push_back(v == mn ? -1 : v - mn + (mn == 0 ? 0 : 50)); }
+            members.push_back(mem); moffs.push_back(mo); slot.push_back(ci);
+        }
+        P.resize(members.size()); O.resize(members.size()); ms1.resize(members.size()); ms2.resize(members.size()); mis.resize(members.size()); mtext.resize(members.size());
+        for (size_t x = 0; x < members.size(); ++x) {
+            ms1[x].resize(members[x].size()); ms2[x].resize(members[x].size()); mis[x].resize(members[x].size()); mtext[x].assign((size_t)2 * cap, 0);
+            P[x].reads = &raw; P[x].read_idx = members[x].data(); P[x].n = (uint32_t)members[x].size(); P[x].offsets = moffs[x].data(); P[x].cfg = single;
+            std::memset(&O[x], 0, sizeof O[x]);
+            O[x].cons1 = mtext[x].data(); O[x].cons2 = mtext[x].data() + cap; O[x].cap = cap; O[x].is_cons1 = mis[x].data(); O[x].score1 = ms1[x].data(); O[x].score2 = ms2[x].data();
+        }
+        if (!P.empty()) { rc = sp_consensus_batch(ctx, (uint32_t)P.size(), P.data(), O.data()); if (rc != SP_OK) return rc; }
+        for (size_t x = 0; x < members.size(); ++x) final_cons[slot[x]] = mtext[x].data();
+    }
+    // 5. typing of the final consensus regions, forced assignment, duplicates become FalseAllele (caller.rs:331-375)
+    std::vector<Label> labels;
+    rc = type_sequences(ctx, pr, final_cons, 0.1, true, labels);
+    if (rc != SP_OK) return rc;
+    for (size_t i = 0; i < final_cons.size(); ++i)
+        for (size_t j = 0; j < i; ++j) if (final_cons[j] == final_cons[i]) { labels[i].type = SP_CYP_FALSE_ALLELE; break; }
+    const uint32_t H = (uint32_t)final_cons.size();
+    // 6. weights of every region of interest, chains, best chain pair (caller.rs:429-640)
+    std::vector<uint32_t> a_idx(hits.size()); std::vector<int32_t> a_start(hits.size()), a_len(hits.size());
+    std::vector<uint32_t> seg_off(R + 1, 0);
+    for (size_t h = 0; h < hits.size(); ++h) { a_idx[h] = (uint32_t)hits[h].read; a_start[h] = hits[h].start; a_len[h] = hits[h].end - hits[h].start; seg_off[hits[h].read + 1] += 1; }
+    for (uint32_t r = 0; r < R; ++r) seg_off[r + 1] += seg_off[r];
+    sp_seqset all;
+    rc = sp_make_segments(ctx, reads, a_idx, a_start, a_len, "cypa", &all, nullptr);
+    if (rc != SP_OK) return rc;
+    std::string blob; std::vector<uint64_t> off(1, 0);
+    for (const std::string& c : final_cons) { blob += c; off.push_back(blob.size()); }
+    sp_seqset* cons_set = nullptr;
+    rc = sp_seqset_upload(ctx, blob.data(), off.data(), H, &cons_set);
+    if (rc != SP_OK) return rc;
+    std::vector<uint8_t> allowed(H); for (uint32_t h = 0; h < H; ++h) allowed[h] = label_allowed(labels[h]) && !final_cons[h].empty();
+    std::vector<uint64_t> ed((size_t)all.n * H); std::vector<double> ov((size_t)all.n * H); std::vector<uint8_t> kept(all.n);
+    rc = sp_cyp_weight_segments(ctx, cons_set, allowed.data(), &all, ed.data(), ov.data(), kept.data());
+    sp_seqset_free(cons_set);
+    if (rc != SP_OK) return rc;
+    std::vector<int32_t> types(H); for (uint32_t h = 0; h < H; ++h) types[h] = labels[h].type;
+    std::vector<uint32_t> read_index(R + 1), rco(R + 1), rwo(R + 1), w_seg(all.n + 1), chain_off, chain_items;
+    std::vector<uint64_t> uniq(H); std::vector<uint8_t> fa(H);
+    sp_chain_build_info info; uint32_t chain_cap = 4 * R + 16, item_cap = 8 * all.n + 64;
+    for (;;) {
+        chain_off.assign(chain_cap + 1, 0); chain_items.assign(item_cap, 0);
+        rc = sp_cyp_build_chains(H, types.data(), R, seg_off.data(), ed.data(), kept.data(), read_index.data(), rco.data(), chain_off.data(), chain_cap,
+                                 chain_items.data(), item_cap, rwo.data(), w_seg.data(), uniq.data(), fa.data(), &info);
+        if (rc == SP_ERR_CAPACITY && (info.n_chains > chain_cap || info.n_items > item_cap)) { chain_cap = std::max(chain_cap, info.n_chains); item_cap = std::max(item_cap, info.n_items); continue; }
+        break;
+    }
+    if (rc == SP_ERR_CHAIN_COLLAPSE) { call->status = SP_ERR_CHAIN_COLLAPSE; return SP_OK; }
+    if (rc != SP_OK) return sp_fail(ctx, rc, "sp_cyp_diplotype: chain building");
+    for (uint32_t h = 0; h < H; ++h) if (fa[h]) labels[h].type = SP_CYP_FALSE_ALLELE;                       // mark_false_allele (:574-583)
+    call->n_consensus = (int32_t)H;
+    std::vector<const char*> subs(H);
+    for (uint32_t h = 0; h < H; ++h) {
+        call->cons_type[h] = labels[h].type;
+        std::snprintf(call->cons_subtype[h], sizeof call->cons_subtype[h], "%s", labels[h].has_sub ? labels[h].sub.c_str() : "");
+        subs[h] = labels[h].has_sub ? labels[h].sub.c_str() : nullptr; types[h] = labels[h].type;
+        if (consensus && cons_cap) std::snprintf(consensus + (size_t)h * cons_cap, cons_cap, "%s", final_cons[h].c_str());
+    }
+    std::vector<uint64_t> w_ed((size_t)info.n_rows * H); std::vector<double> w_ov((size_t)info.n_rows * H);
+    for (uint32_t row = 0; row < info.n_rows; ++row) for (uint32_t h = 0; h < H; ++h) { w_ed[(size_t)row * H + h] = ed[(size_t)w_seg[row] * H + h]; w_ov[(size_t)row * H + h] = ov[(size_t)w_seg[row] * H + h]; }
+    sp_chain_problem cp; std::memset(&cp, 0, sizeof cp);
+    cp.n_haps = H; cp.hap_type = types.data(); cp.hap_subtype = subs.data();
+    cp.n_translate = pr->n_translate; cp.translate_key = pr->translate_key; cp.translate_val = pr->translate_val;
+    cp.n_connections = pr->n_connections; cp.connection_a = pr->connection_a; cp.connection_b = pr->connection_b;
+    cp.n_singletons = pr->n_singletons; cp.singletons = pr->singletons;
+    cp.n_reads = info.n_reads; cp.read_chain_off = rco.data(); cp.chain_off = chain_off.data(); cp.chain_items = chain_items.data();
+    cp.read_w_off = rwo.data(); cp.w_ed = w_ed.data(); cp.w_ov = w_ov.data();
+    cp.infer_connections = pr->infer_connections; cp.normalize_all_alleles = !pr->normalize_d6_only; cp.ignore_chain_label_limits = 0;
+    cp.lasso_penalty = 4.0; cp.ln_ed_penalty = 2.0; cp.unexpected_chain_penalty = 10.0; cp.inferred_edge_penalty = 2.0;      // ChainPenalties::default (chaining.rs:107-139)
+    sp_chain_result cr;
+    rc = sp_cyp_best_chain_pair(ctx, &cp, &cr);
+    if (rc == SP_ERR_NO_CHAINING_HEAD || rc == SP_ERR_NO_CHAINS_FOUND || rc == SP_ERR_NO_SCORE_PAIRS) { call->status = rc; return SP_OK; }
+    if (rc != SP_OK) return rc;
+    call->n1 = cr.n1; call->n2 = cr.n2; call->score = cr.score;
+    std::memcpy(call->chain1, cr.chain1, sizeof(int32_t) * cr.n1); std::memcpy(call->chain2, cr.chain2, sizeof(int32_t) * cr.n2);
+    sp_cyp_chain_to_hap(cr.chain1, cr.n1, types.data(), subs.data(), pr->n_translate, pr->translate_key, pr->translate_val, 1, call->hap1, sizeof call->hap1);
+    sp_cyp_chain_to_hap(cr.chain2, cr.n2, types.data(), subs.data(), pr->n_translate, pr->translate_key, pr->translate_val, 1, call->hap2, sizeof call->hap2);
+    sp_cyp_chain_to_hap(cr.chain1, cr.n1, types.data(), subs.data(), pr->n_translate, pr->translate_key, pr->translate_val, 0, call->core1, sizeof call->core1);
+    sp_cyp_chain_to_hap(cr.chain2, cr.n2, types.data(), subs.data(), pr->n_translate, pr->translate_key, pr->translate_val, 0, call->core2, sizeof call->core2);
+    return SP_OK;
+}

@@ -84,6 +84,61 @@ __global__ void __launch_bounds__(HPC_WAVES * SP_WAVE) hpc_kernel(const uint32_t
 
 } // namespace
 
+// segments [start, start + len) of reads[idx] as a packed set in pooled buffers "<prefix>_*" (and, optionally, their
+// homopolymer-compressed form): the data never leaves the GPU.  The sets stay valid until the next call with the same prefix.
+int sp_make_segments(sp_ctx* ctx, const sp_seqset* reads, const std::vector<uint32_t>& idx, const std::vector<int32_t>& start,
+                     const std::vector<int32_t>& len, const char* prefix, sp_seqset* seg, sp_seqset* hpc) {
+    const uint32_t n = (uint32_t)idx.size();
+    hipStream_t st = ctx->stream;
+    std::vector<uint64_t> h_woff((size_t)n + 1, 0);
+    int32_t max_len = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (idx[i] >= reads->n || len[i] <= 0 || start[i] < 0 || start[i] + len[i] > reads->h_len[idx[i]]) return sp_fail(ctx, SP_ERR_INVALID_ARG, "segment outside its read");
+        if (hpc && len[i] > HPC_MAX) return sp_fail(ctx, SP_ERR_TOO_LONG, "segment longer than 32,768 bases");
+        max_len = std::max(max_len, len[i]);
+        h_woff[i + 1] = h_woff[i] + (uint64_t)((((len[i] + 15) >> 4) + 2 + 3) & ~3);
+    }
+    const uint64_t total_words = h_woff[n] + 4;
+    const std::string px(prefix);
+    auto pool = [&](const char* what, size_t bytes) { return sp_pool(ctx, (px + what).c_str(), std::max<size_t>(bytes, 16)); };
+    uint32_t* d_idx = (uint32_t*)pool("_idx", sizeof(uint32_t) * n);
+    int32_t* d_start = (int32_t*)pool("_start", sizeof(int32_t) * n);
+    int32_t* d_len = (int32_t*)pool("_len", sizeof(int32_t) * n);
+    int32_t* d_hlen = hpc ? (int32_t*)pool("_hlen", sizeof(int32_t) * n) : nullptr;
+    uint64_t* d_woff = (uint64_t*)pool("_woff", sizeof(uint64_t) * ((size_t)n + 1));
+    uint32_t* d_seg = (uint32_t*)pool("_seg", sizeof(uint32_t) * total_words);
+    uint32_t* d_hpc = hpc ? (uint32_t*)pool("_hpc", sizeof(uint32_t) * total_words) : nullptr;
+    uint32_t* d_segn = reads->has_n ? (uint32_t*)pool("_segn", sizeof(uint32_t) * total_words) : nullptr;
+    uint32_t* d_hpcn = (hpc && reads->has_n) ? (uint32_t*)pool("_hpcn", sizeof(uint32_t) * total_words) : nullptr;
+    if (!d_idx || !d_start || !d_len || !d_woff || !d_seg || (hpc && (!d_hlen || !d_hpc)) || (reads->has_n && (!d_segn || (hpc && !d_hpcn))))
+        return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "segment buffers");
+    if (n) {
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, st));
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_start, start.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_len, len.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    }
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_woff, h_woff.data(), sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, st));
+    std::vector<int32_t> h_hlen(n, 0);
+    if (n) {
+        ProfScope ps(ctx, "segments", n);
+        hipLaunchKernelGGL(seg_slice_kernel, dim3((n + SEG_WAVES - 1) / SEG_WAVES), dim3(SEG_WAVES * SP_WAVE), 0, st,
+                           reads->view(), d_idx, d_start, d_len, d_woff, (int)n, d_seg, d_segn);
+        if (hpc) hipLaunchKernelGGL(hpc_kernel, dim3((n + HPC_WAVES - 1) / HPC_WAVES), dim3(HPC_WAVES * SP_WAVE), 0, st,
+                                    d_seg, d_segn, d_woff, d_len, (int)n, d_hpc, d_hpcn, d_hlen);
+    }
+    if (n && hpc) SP_HIP_CHECK(ctx, hipMemcpyAsync(h_hlen.data(), d_hlen, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    SP_HIP_CHECK(ctx, hipGetLastError());
+    *seg = sp_seqset();
+    seg->ctx = ctx; seg->n = n; seg->has_n = reads->has_n; seg->d_words = d_seg; seg->d_nplane = d_segn; seg->d_word_off = d_woff; seg->d_len = d_len; seg->max_len = max_len;
+    seg->h_len = len; seg->h_word_off = h_woff;
+    if (hpc) {
+        *hpc = *seg;
+        hpc->d_words = d_hpc; hpc->d_nplane = d_hpcn; hpc->d_len = d_hlen; hpc->h_len = h_hlen;
+    }
+    return SP_OK;
+}
+
 extern "C" {
 
 int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_genes, const uint32_t* genes, const sp_seqset* reads,
@@ -110,48 +165,20 @@ int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
     const uint32_t n = (uint32_t)sel.size();
     if (n == 0) return SP_OK;
     SP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
 
     // ---- segments of all genes on the device
     std::vector<int32_t> h_start(n), h_len(n);
-    std::vector<uint64_t> h_woff(n + 1, 0);
     int32_t max_len = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const sp_hla_realign& q = realign[sel[i]];
         h_start[i] = q.seg_start; h_len[i] = q.seg_end - q.seg_start;
-        if (h_len[i] <= 0 || q.seg_end > reads->h_len[sel[i]]) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_genes: segment outside its read");
-        if (h_len[i] > HPC_MAX) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_hla_diplotype_genes: segment longer than 32,768 bases");
         max_len = std::max(max_len, h_len[i]);
-        h_woff[i + 1] = h_woff[i] + (uint64_t)((((h_len[i] + 15) >> 4) + 2 + 3) & ~3);
     }
-    const uint64_t total_words = h_woff[n];
-    uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "hc_idx", sizeof(uint32_t) * n);
-    int32_t* d_start = (int32_t*)sp_pool(ctx, "hc_start", sizeof(int32_t) * n);
-    int32_t* d_len = (int32_t*)sp_pool(ctx, "hc_len", sizeof(int32_t) * n);
-    int32_t* d_hlen = (int32_t*)sp_pool(ctx, "hc_hlen", sizeof(int32_t) * n);
-    uint64_t* d_woff = (uint64_t*)sp_pool(ctx, "hc_woff", sizeof(uint64_t) * (n + 1));
-    uint32_t* d_seg = (uint32_t*)sp_pool(ctx, "hc_seg", sizeof(uint32_t) * total_words);
-    uint32_t* d_hpc = (uint32_t*)sp_pool(ctx, "hc_hpc", sizeof(uint32_t) * total_words);
-    uint32_t* d_segn = reads->has_n ? (uint32_t*)sp_pool(ctx, "hc_segn", sizeof(uint32_t) * total_words) : nullptr;
-    uint32_t* d_hpcn = reads->has_n ? (uint32_t*)sp_pool(ctx, "hc_hpcn", sizeof(uint32_t) * total_words) : nullptr;
-    if (!d_idx || !d_start || !d_len || !d_hlen || !d_woff || !d_seg || !d_hpc || (reads->has_n && (!d_segn || !d_hpcn)))
-        return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_hla_diplotype_genes buffers");
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, sel.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_start, h_start.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_len, h_len.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_woff, h_woff.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, st));
-    {
-        ProfScope ps(ctx, "hla_segments", n);
-        hipLaunchKernelGGL(seg_slice_kernel, dim3((n + SEG_WAVES - 1) / SEG_WAVES), dim3(SEG_WAVES * SP_WAVE), 0, st,
-                           reads->view(), d_idx, d_start, d_len, d_woff, (int)n, d_seg, d_segn);
-        hipLaunchKernelGGL(hpc_kernel, dim3((n + HPC_WAVES - 1) / HPC_WAVES), dim3(HPC_WAVES * SP_WAVE), 0, st,
-                           d_seg, d_segn, d_woff, d_len, (int)n, d_hpc, d_hpcn, d_hlen);
-    }
-    SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    SP_HIP_CHECK(ctx, hipGetLastError());
     sp_seqset seg, hpc;
-    seg.ctx = ctx; seg.n = n; seg.has_n = reads->has_n; seg.d_words = d_seg; seg.d_nplane = d_segn; seg.d_word_off = d_woff; seg.d_len = d_len; seg.max_len = max_len;
-    hpc = seg; hpc.d_words = d_hpc; hpc.d_nplane = d_hpcn; hpc.d_len = d_hlen;
+    {
+        const int32_t e = sp_make_segments(ctx, reads, sel, h_start, h_len, "hc", &seg, &hpc);
+        if (e != SP_OK) return e;
+    }
 
     // ---- run_dual_consensus_with_offsets (caller.rs:1118-1219), all genes in lockstep
     const int half_window = 200;                                                   // offset_window 400 (dwfa_config_from_cli, :1103-1116)

@@ -87,6 +87,10 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
 
 int sp_launch_pack(sp_ctx* ctx, const char* d_ascii, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
                    uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag);
+int sp_make_segments(sp_ctx* ctx, const sp_seqset* reads, const std::vector<uint32_t>& idx, const std::vector<int32_t>& start,
+                     const std::vector<int32_t>& len, const char* prefix, sp_seqset* seg, sp_seqset* hpc);   // sp_hla_call.hip
+int sp_seqset_fetch_host(sp_ctx* ctx, sp_seqset* s);                      // packed words (and N plane) of a set on the host, fetched once
+std::string sp_seqset_decode(sp_ctx* ctx, const sp_seqset* s, uint32_t i); // ASCII of sequence i
 void* sp_scratch(sp_ctx* ctx, size_t bytes);
 void* sp_pool(sp_ctx* ctx, const char* name, size_t bytes);
 int   sp_fail(sp_ctx* ctx, int code, const std::string& msg);

@@ -115,6 +115,27 @@ class sp_priority_problem(C.Structure):
                 ("cfg", sp_cons_config)]
 
 
+class sp_cyp_problem(C.Structure):
+    _fields_ = [("templates", C.c_void_p), ("template_type", C.c_void_p), ("template_subtype", C.POINTER(C.c_char_p)), ("template_deep", C.c_void_p),
+                ("backbone", C.c_char_p), ("backbone_len", C.c_uint32),
+                ("n_variants", C.c_uint32), ("var_pos", C.c_void_p), ("var_ref", C.POINTER(C.c_char_p)), ("var_alt", C.POINTER(C.c_char_p)), ("var_is_vi", C.c_void_p),
+                ("n_alleles", C.c_uint32), ("allele_subtype", C.POINTER(C.c_char_p)), ("hap_matrix", C.c_void_p),
+                ("n_translate", C.c_uint32), ("translate_key", C.POINTER(C.c_char_p)), ("translate_val", C.POINTER(C.c_char_p)),
+                ("n_connections", C.c_uint32), ("connection_a", C.POINTER(C.c_char_p)), ("connection_b", C.POINTER(C.c_char_p)),
+                ("n_singletons", C.c_uint32), ("singletons", C.POINTER(C.c_char_p)),
+                ("min_consensus_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("min_consensus_fraction", C.c_double),
+                ("infer_connections", C.c_int32), ("normalize_d6_only", C.c_int32)]
+
+
+SP_CYP_MAXCONS = 64
+
+
+class sp_cyp_call(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_consensus", C.c_int32), ("cons_type", C.c_int32 * SP_CYP_MAXCONS), ("cons_subtype", (C.c_char * 48) * SP_CYP_MAXCONS),
+                ("n1", C.c_int32), ("n2", C.c_int32), ("chain1", C.c_int32 * 64), ("chain2", C.c_int32 * 64), ("score", C.c_double),
+                ("hap1", C.c_char * 256), ("hap2", C.c_char * 256), ("core1", C.c_char * 256), ("core2", C.c_char * 256)]
+
+
 class sp_hla_call_config(C.Structure):
     _fields_ = [("min_consensus_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("min_consensus_fraction", C.c_double),
                 ("expected_maf", C.c_double), ("min_cdf", C.c_double), ("require_dna", C.c_int32), ("disable_cdna", C.c_int32),
@@ -197,6 +218,7 @@ def lib():
         "sp_consensus_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
         "sp_consensus_dual_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
         "sp_cyp_variant_states": (i32, [vp, vp, C.c_char_p, u32, u32, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), vp, vp]),
+        "sp_cyp_diplotype": (i32, [vp, C.POINTER(sp_cyp_problem), vp, C.POINTER(sp_cyp_call), C.c_char_p, u32]),
         "sp_consensus_priority": (i32, [vp, C.POINTER(sp_priority_problem), u32, u32, C.POINTER(u32), vp, C.c_char_p]),
         "sp_hla_diplotype_gene": (i32, [vp, vp, u32, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, C.c_char_p, u32, vp]),
         "sp_hla_diplotype_genes": (i32, [vp, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
@@ -437,6 +459,34 @@ class Context:
         alns = np.zeros(max(1, seqs.n), ALN_DTYPE)
         self.check(lib().sp_cyp_variant_states(self._h, seqs._h, backbone.encode(), len(backbone), nv, _ptr(pos), refs, alts, _ptr(states), _ptr(alns)))
         return states, alns[:seqs.n]
+
+    def cyp_diplotype(self, templates, template_type, template_subtype, template_deep, backbone, variants, is_vi, allele_subtype, hap_matrix,
+                      cfg, reads, min_count=3, min_af=0.10, delta=100, infer=False, normalize_d6_only=False, cons_cap=16384):
+        """sp_cyp_diplotype.  templates: SeqSet; variants: [(pos, ref, alt)]; cfg: dict(translate, connections, singletons).
+        Returns (sp_cyp_call, [consensus strings], [(type, subtype|None)])"""
+        def strs(items):
+            arr = (C.c_char_p * max(1, len(items)))()
+            for i, x in enumerate(items):
+                arr[i] = x.encode() if x is not None else None
+            return arr
+        tt = np.ascontiguousarray(template_type, np.int32)
+        deep = np.ascontiguousarray(template_deep, np.uint8)
+        pos = np.ascontiguousarray([v[0] for v in variants], np.int32)
+        vi = np.ascontiguousarray(is_vi, np.uint8)
+        hm = np.ascontiguousarray(hap_matrix, np.uint8)
+        keep = [strs(list(template_subtype)), strs([v[1] for v in variants]), strs([v[2] for v in variants]), strs(list(allele_subtype)),
+                strs([a for a, _ in cfg["translate"]]), strs([b for _, b in cfg["translate"]]),
+                strs([a for a, _ in cfg["connections"]]), strs([b for _, b in cfg["connections"]]), strs(list(cfg["singletons"]))]
+        pr = sp_cyp_problem(templates._h, tt.ctypes.data, keep[0], deep.ctypes.data, backbone.encode(), len(backbone),
+                            len(variants), pos.ctypes.data, keep[1], keep[2], vi.ctypes.data, len(allele_subtype), keep[3], hm.ctypes.data,
+                            len(cfg["translate"]), keep[4], keep[5], len(cfg["connections"]), keep[6], keep[7], len(cfg["singletons"]), keep[8],
+                            min_count, delta, min_af, int(infer), int(normalize_d6_only))
+        call = sp_cyp_call()
+        buf = C.create_string_buffer(SP_CYP_MAXCONS * cons_cap)
+        self.check(lib().sp_cyp_diplotype(self._h, C.byref(pr), reads._h, C.byref(call), buf, cons_cap))
+        cons = [buf.raw[i * cons_cap:(i + 1) * cons_cap].split(b"\0", 1)[0].decode() for i in range(call.n_consensus)]
+        labels = [(int(call.cons_type[i]), (call.cons_subtype[i].value.decode() or None)) for i in range(call.n_consensus)]
+        return call, cons, labels
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))

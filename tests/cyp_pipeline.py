@@ -1,0 +1,165 @@
+"""diplotype_cyp2d6 (src/cyp2d6/caller.rs:39-741) assembled from the CPU oracle's pieces -- the expected result for
+sp_cyp_diplotype (test infrastructure).  Steps and reference lines are those of the library's driver (pb-starphase_amd/csrc/sp_cyp_call.hip)."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_ffi as of
+
+T = of.REGION_TYPES
+SEEDS = {T["CYP2D6*5"]: 0, T["REP6"]: 1, T["REP7"]: 2, T["spacer"]: 3, T["link_region"]: 4}      # caller.rs:229-236
+
+
+def score(h, penalize):
+    """MappingStats::custom_score (src/data_types/mapping.rs:60-84)"""
+    ln = h["seq_len"] if penalize else h["seq_len"] - h["unmapped"]
+    return max(float(h["nm"] + (h["unmapped"] if penalize else 0)), 0.1) / float(ln)
+
+
+def full_allele(oracle, typ, sub):
+    out = C.create_string_buffer(256)
+    oracle.L.osp_cyp_full_allele(int(typ), sub.encode() if sub is not None else None, out, 256)
+    return out.value.decode()
+
+
+def simplify(oracle, typ, sub, cfg):
+    keep = []
+    c = of._cyp_cfg_struct(cfg, keep)
+    out = C.create_string_buffer(256)
+    oracle.L.osp_cyp_simplify_allele(int(typ), sub.encode() if sub is not None else None, 1, C.byref(c), out, 256)
+    return out.value.decode()
+
+
+class Db:
+    """the typing database a sample needs: templates in full_allele() order, backbone + variants, star-allele definitions"""
+    def __init__(self, names, types, subtypes, seqs, deep, backbone, variants, is_vi, allele_subtypes, hap_matrix):
+        self.names, self.types, self.subtypes, self.seqs, self.deep = names, np.asarray(types, np.int32), subtypes, seqs, deep
+        self.backbone, self.variants, self.is_vi = backbone, variants, np.asarray(is_vi, np.uint8)
+        self.allele_subtypes, self.hap_matrix = allele_subtypes, np.asarray(hap_matrix, np.uint8)
+
+
+def score_alleles(oracle, db, states):
+    nv, na = len(db.variants), len(db.allele_subtypes)
+    bv, ba = C.c_uint32(0), C.c_uint32(0)
+    tie = np.zeros(max(1, na), np.uint8)
+    st = np.ascontiguousarray(states, np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    oracle.L.osp_cyp_score_alleles(nv, na, p(np.ascontiguousarray(db.hap_matrix)), p(db.is_vi), p(st), C.byref(bv), C.byref(ba), p(tie))
+    return (bv.value, ba.value), tie[:na]
+
+
+def full_type(oracle, db, seq, max_missing, force):
+    """find_full_type_in_sequence + assign_haplotype (src/cyp2d6/haplotyper.rs:326-602) -> (type, subtype)"""
+    hits = of.oracle_find_base_type(oracle, seq, db.seqs, db.types, max_missing) if seq else []
+    if len(hits) == 0:
+        return (T["UNKNOWN"], None)                                          # "no matches found" -> Unknown (caller.rs:350-355)
+    best = min(range(len(hits)), key=lambda i: (score(hits[i], True), i))
+    t = int(hits[best]["template_idx"])
+    if not db.deep[t]:
+        return (int(db.types[t]), db.subtypes[t])
+    states, _aln = of.oracle_variant_states(oracle, seq, db.backbone, [v[0] for v in db.variants], [v[1] for v in db.variants], [v[2] for v in db.variants])
+    (bv, ba), tie = score_alleles(oracle, db, states)
+    cands = [(T["CYP2D6"], db.allele_subtypes[a]) for a in range(len(tie)) if tie[a]]
+    if (bv, ba) == (0, 0):
+        cands.append((T["UNKNOWN"], None))
+    if len(cands) == 1:
+        return cands[0]
+    if not cands:
+        return (T["UNKNOWN"], None)
+    cands.sort(key=lambda c: full_allele(oracle, *c))
+    return cands[0] if force else (T["UNKNOWN"], None)
+
+
+def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, infer=False, normalize_d6_only=False):
+    cfg = cfg or of.default_cyp_config()
+    out = dict(status=0, hap1="", hap2="")
+    # 1. regions of interest (caller.rs:126-139)
+    regions = [of.oracle_find_base_type(oracle, r, db.seqs, db.types, 0.5) for r in reads]
+    # 2. sequences for the consensus (caller.rs:176-213)
+    raw, hpc, boff, hoff, seeds = [], [], [], [], []
+    for r, hits in enumerate(regions):
+        for h in hits:
+            if score(h, True) > 0.5:
+                continue
+            seq = reads[r][int(h["start"]):int(h["end"])]
+            clip = int(h["clip_start"])
+            raw.append(seq); hpc.append(oracle.hpc(seq))
+            boff.append(None if clip == 0 else clip + 50)
+            hp = oracle.hpc_pos(db.seqs[int(h["template_idx"])], clip)
+            hoff.append(None if hp == 0 else hp + 50)
+            seeds.append(SEEDS.get(int(db.types[int(h["template_idx"])])))
+    if not raw:
+        out["status"] = 1                                                    # NO_READS (caller.rs:254-266)
+        return out
+    ccfg = of.cons_config(min_count=min_count, min_af=min_af, dual_max_ed_delta=delta, early_termination=True, dual=True, offset_window=100, offset_compare_length=64)
+    group_of, cons = of.oracle_priority_consensus(oracle, [hpc, raw], ccfg, [hoff, boff], seeds)
+    # 4. merge_consensus_results (caller.rs:750-898)
+    cset, uset = {}, {}
+    for g, (hc, fc) in enumerate(cons):
+        lab = full_type(oracle, db, fc, 0.1, False)
+        if lab[0] in (T["UNKNOWN"], T["FalseAllele"]):
+            uset.setdefault(hc, []).append(g)
+        else:
+            cset.setdefault((hc, simplify(oracle, lab[0], lab[1], cfg)), []).append(g)
+    ignored = set()
+    for hc in sorted(uset):
+        others = [k for k in sorted(cset) if k[0] == hc]
+        if len(others) == 1:
+            cset[others[0]] += uset[hc]
+        else:
+            if len(others) > 1:
+                ignored.add((hc, "UNKNOWN"))
+            cset[(hc, "UNKNOWN")] = uset[hc]
+    single = of.cons_config(min_count=min_count, min_af=min_af, dual_max_ed_delta=delta, early_termination=True, dual=False, offset_window=100, offset_compare_length=64)
+    final, seq_idx = [], [-1] * len(raw)
+    for key in sorted(cset):
+        members = [s for s in range(len(raw)) if group_of[s] in cset[key]]
+        for s in members:
+            seq_idx[s] = len(final)
+        if key in ignored:
+            final.append("")
+        elif len(cset[key]) == 1:
+            final.append(cons[cset[key][0]][1])
+        else:
+            vals = [0 if boff[s] is None else boff[s] for s in members]
+            mn = min(vals)
+            offs = [None if v == mn else v - mn + (0 if mn == 0 else 50) for v in vals]
+            final.append(of.oracle_consensus(oracle, [raw[s] for s in members], offs, single)["cons"][0])
+    # 5. typing (caller.rs:331-375)
+    labels, seen = [], set()
+    for fc in final:
+        lab = full_type(oracle, db, fc, 0.1, True)
+        if fc in seen:                                                       # two groups with the same sequence: mark_false_allele keeps the subtype
+            lab = (T["FalseAllele"], lab[1])
+        else:
+            seen.add(fc)
+        labels.append(lab)
+    out.update(consensus=final, labels=list(labels), sequence_indices=seq_idx)
+    # 6. chains (caller.rs:429-640)
+    segs, seg_off = [], [0]
+    for r, hits in enumerate(regions):
+        segs += [reads[r][int(h["start"]):int(h["end"])] for h in hits]
+        seg_off.append(len(segs))
+    allowed = np.array([lab[0] not in (T["UNKNOWN"], T["FalseAllele"]) for lab in labels], np.uint8)
+    ed, ov, kept = [], [], []
+    for s in segs:
+        e, o, k = of.oracle_weight_sequence(oracle, s, final, allowed)
+        ed.append(e); ov.append(o); kept.append(k)
+    ed, ov, kept = np.array(ed, np.uint64).reshape(len(segs), len(final)), np.array(ov, np.float64).reshape(len(segs), len(final)), np.array(kept, np.uint8)
+    types = np.array([lab[0] for lab in labels], np.int32)
+    built = of.oracle_build_chains(oracle, types, np.array(seg_off, np.uint32), ed.reshape(-1), kept)
+    if built is None:
+        out["status"] = 7
+        return out
+    labels2 = [(T["FalseAllele"], s) if built["false_allele"][h] else (t, s) for h, (t, s) in enumerate(labels)]
+    obs = {f"r{r:06d}": built["chains"][k] for k, r in enumerate(built["read_index"])}
+    scores = {f"r{r:06d}": [[(int(ed[sg][c]), float(ov[sg][c])) for c in range(len(labels2))] for sg in built["w_rows"][k]] for k, r in enumerate(built["read_index"])}
+    inp = of.ChainInputs(labels2, obs, scores, infer, not normalize_d6_only, of.DEFAULT_PENALTIES, False, cfg)
+    res = of.oracle_chain_pair(oracle, inp)
+    out.update(status=int(res.status), labels=labels2)
+    if res.status == 0:
+        ch1, ch2 = list(res.chain1[:res.n1]), list(res.chain2[:res.n2])
+        out.update(chain1=ch1, chain2=ch2, score=res.score,
+                   hap1=of.chain_hap_string(oracle, ch1, labels2, 1, cfg), hap2=of.chain_hap_string(oracle, ch2, labels2, 1, cfg),
+                   core1=of.chain_hap_string(oracle, ch1, labels2, 0, cfg), core2=of.chain_hap_string(oracle, ch2, labels2, 0, cfg))
+    return out

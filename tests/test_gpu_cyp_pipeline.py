@@ -120,3 +120,31 @@ def test_config3_pipeline(oracle, pkg, gpu_ctx, scenario, expected):
     got = {product_hap(pkg, list(g_res.chain1[:g_res.n1]), g_labels, cfg), product_hap(pkg, list(g_res.chain2[:g_res.n2]), g_labels, cfg)}
     exp = {of.chain_hap_string(oracle, list(o_res.chain1[:o_res.n1]), o_labels, 0, cfg), of.chain_hap_string(oracle, list(o_res.chain2[:o_res.n2]), o_labels, 0, cfg)}
     assert got == exp == expected, (got, exp)
+
+
+@pytest.mark.parametrize("scenario,expected", [("*1/*4", {"*1", "*4"}), ("*5/*2", {"*5", "*2"}), ("*4x2/*1", {"*4x2", "*1"}), ("*2/*10", {"*2", "*10"})])
+def test_reads_to_diplotype(oracle, pkg, gpu_ctx, scenario, expected):
+    """sp_cyp_diplotype (diplotype_cyp2d6, src/cyp2d6/caller.rs:39-741) from raw reads: K3 -> K8 multi-way consensus -> merge -> K9 + K7 typing
+    -> K4 -> chains -> K5 -> strings, against the same pipeline assembled from the oracle (tests/cyp_pipeline.py) and against the truth"""
+    import cyp_fixture as cf
+    import cyp_pipeline as cp
+    from pb_starphase_amd import synth
+    locus = synth.CypLocus(seed=11)
+    db, d6 = cf.make_db(locus, synth, np.random.default_rng(5))
+    reads = cf.sample(locus, synth, np.random.default_rng(7), d6, scenario, 120)
+    exp = cp.diplotype(oracle, db, reads)
+    cfg = of.default_cyp_config()
+    call, cons, labels = gpu_ctx.cyp_diplotype(gpu_ctx.upload(db.seqs), db.types, db.subtypes, db.deep, db.backbone, db.variants, db.is_vi,
+                                                db.allele_subtypes, db.hap_matrix, cfg, gpu_ctx.upload(reads))
+    assert call.status == exp["status"] == 0
+    assert cons == exp["consensus"]
+    assert labels == [(int(t), s) for t, s in exp["labels"]]
+    assert list(call.chain1[:call.n1]) == exp["chain1"] and list(call.chain2[:call.n2]) == exp["chain2"]
+    assert call.score == exp["score"]
+    got = (call.hap1.decode(), call.hap2.decode(), call.core1.decode(), call.core2.decode())
+    assert got == (exp["hap1"], exp["hap2"], exp["core1"], exp["core2"])
+    assert {got[0], got[1]} == expected
+    # no reads at all
+    call, cons, labels = gpu_ctx.cyp_diplotype(gpu_ctx.upload(db.seqs), db.types, db.subtypes, db.deep, db.backbone, db.variants, db.is_vi,
+                                                db.allele_subtypes, db.hap_matrix, cfg, gpu_ctx.upload(["ACGT" * 500]))
+    assert call.status == 1 and call.n_consensus == 0
