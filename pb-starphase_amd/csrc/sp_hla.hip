@@ -33,6 +33,8 @@ struct sp_hla_db {
     sp_seqset* ref_fwd = nullptr;     // buffered gene references, hg38 forward (realigner.rs:74-81)
     uint32_t* d_gene_of = nullptr;
     int32_t*  d_off_fwd = nullptr;    // allele_fwd_pos - ref_fwd_pos (SP_NO_DIAG = no anchor)
+    uint32_t* d_order = nullptr;      // K1 visits the alleles sorted by (gene, frame offset, hg38-strand sequence) ...
+    int32_t*  d_lcp = nullptr;        // ... d_lcp[i] = common prefix of order[i-1] and order[i] when they share gene and frame offset, else 0
     int32_t*  d_am = nullptr;         // n_alleles*3: ok, am.query_start, am.target_start (allele -> gene ref, realigner.rs:289-310)
     int32_t*  d_hpc_ref = nullptr;    // hpc_pos(ref_fwd[g], p) for p in 0..len, concatenated
     uint64_t* d_hpc_ref_off = nullptr;
@@ -73,6 +75,8 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
 }
 
 #define K1_PRE 5        // prefetch registers per lane: alleles up to 5*64*16 - 32 = 5,088 bases stream through registers
+#define K1_META 6       // metadata words per active cell
+#define K1_UNIT 8       // consecutive active cells a wave takes at a time (prefix sharing only carries inside a unit)
 
 template <bool HASN>
 __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads,
@@ -81,13 +85,15 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
                                                        int n_genes, uint32_t n_alleles, uint32_t n_chunks,
                                                        uint32_t* __restrict__ cell_out, unsigned long long* __restrict__ bound,
                                                        const uint32_t* __restrict__ read_list, uint32_t* __restrict__ read_maxlen,
+                                                       const uint32_t* __restrict__ order, const int32_t* __restrict__ lcp_tab,
                                                        int pass_cap, int b_words, int a_words) {
     extern __shared__ uint32_t lds[];
-    // layout: [32 control words][K1_CHUNK x 4 cell metadata][B window b_words (x2 with N plane)][K1_WAVES x A slot a_words (x2 with N plane)]
+    // layout: [32 control words][K1_CHUNK x 6 cell metadata][B window b_words (x2 with N plane)][K1_WAVES x A slot a_words (x2 with N plane)]
     int* ctl = reinterpret_cast<int*>(lds);               // 0: window lo, 1: window hi, 2: longest active allele, 3: #active in wave 0,
-                                                          // 4: #active, 5: next cell to grab
-    int* meta = ctl + 32;                                 // dense list of active cells: (chunk slot | static cap << 8), alen, kb, word offset
-    uint32_t* LB = lds + 32 + 4 * K1_CHUNK;
+                                                          // 4: #active, 5: next unit to grab
+    int* meta = ctl + 32;                                 // dense list of active cells: (chunk slot | static cap << 16), alen, kb, word offset,
+                                                          // allele index, prefix shared with the allele one slot earlier
+    uint32_t* LB = lds + 32 + K1_META * K1_CHUNK;
     uint32_t* NB = HASN ? LB + b_words : nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint32_t* slotA = LB + (HASN ? 2 : 1) * b_words + wave * (HASN ? 2 : 1) * a_words;
@@ -107,8 +113,10 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
     if (tid == 0) { ctl[0] = 0x7FFFFFFF; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = K1_WAVES; }
     __syncthreads();
     int act = 0, alen = 0, kb = 0, cap = 0; uint32_t woff = 0;
+    uint32_t a_mine = 0; int lcp_mine = 0;
     if (tid < K1_CHUNK && a_first + tid < a_end) {
-        const uint32_t a = a_first + tid;
+        const uint32_t a = order[a_first + tid];          // the chunk is a slice of the visiting order, not of the index space
+        a_mine = a; lcp_mine = tid > 0 ? lcp_tab[a_first + tid] : 0;
         alen = alleles.len[a];
         const int off = off_fwd[a];
         const uint32_t g = gene_of[a];
@@ -133,7 +141,8 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
         int before = 0;
         for (int w = 0; w < wave; ++w) before += ctl[16 + w];
         const int slot = before + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-        meta[slot * 4 + 0] = tid | (cap << 16); meta[slot * 4 + 1] = alen; meta[slot * 4 + 2] = kb; meta[slot * 4 + 3] = (int)woff;
+        int* m = meta + slot * K1_META;
+        m[0] = tid | (cap << 16); m[1] = alen; m[2] = kb; m[3] = (int)woff; m[4] = (int)a_mine; m[5] = lcp_mine;
     }
     if (tid == 0) { int tot = 0; for (int w = 0; w < K1_WAVES; ++w) tot += ctl[16 + w]; ctl[4] = tot; }
     __syncthreads();
@@ -151,74 +160,98 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
     __syncthreads();
 
     // software pipeline over the dense list: the packed words (and the running bound) of the NEXT cell are fetched into
-    // registers while the current cell's DP runs out of LDS; cells are handed out dynamically (LDS counter)
+    // registers while the current cell's DP runs out of LDS; units of K1_UNIT consecutive cells are handed out dynamically.
+    //
+    // Prefix sharing (exact): the list follows the database's visiting order, so neighbours mostly start with the same bases.
+    // A cell that runs out of edits has looked at A[0 .. explored] only (wfa_core); if the next cell's allele shares that prefix
+    // (same gene, same frame offset => same diagonal, same read window), is allowed no more edits than the run had, and sits right
+    // behind it in the order, its run would be the same run cut at the same or an earlier step: it fails too and is not executed.
+    // The chain carries on from a skipped cell with the executed run's extent and the smaller cap.
     uint32_t pre[K1_PRE];
     unsigned long long pre_bound = K1_NO_BOUND;
+    int pre_for = -1;
     auto fetch = [&](int idx) {
-        const int alen_n = __builtin_amdgcn_readfirstlane(meta[idx * 4 + 1]);
-        const uint32_t* aw = alleles.words + (uint32_t)__builtin_amdgcn_readfirstlane(meta[idx * 4 + 3]);
+        const int alen_n = __builtin_amdgcn_readfirstlane(meta[idx * K1_META + 1]);
+        const uint32_t* aw = alleles.words + (uint32_t)__builtin_amdgcn_readfirstlane(meta[idx * K1_META + 3]);
         const int nw = ((alen_n + 15) >> 4) + 2;
 #pragma unroll
         for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; pre[t] = w < nw ? aw[w] : 0u; }
         if (bound) pre_bound = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pre_for = idx;
     };
     auto grab = [&]() -> int {
         int v = 0;
         if (lane == 0) v = atomicAdd(&ctl[5], 1);
         return __builtin_amdgcn_readfirstlane(v);
     };
-    int cur = wave;                                       // the first four cells are pre-assigned, the rest grabbed
-    if (cur < n_act) fetch(cur);
-    while (cur < n_act) {
-        const int tag = __builtin_amdgcn_readfirstlane(meta[cur * 4 + 0]);
-        const int c_alen = __builtin_amdgcn_readfirstlane(meta[cur * 4 + 1]), c_kb = __builtin_amdgcn_readfirstlane(meta[cur * 4 + 2]);
-        const uint32_t a = a_first + (uint32_t)(tag & 0xFFFF);
-        const int nw = ((c_alen + 15) >> 4) + 2;
-        const bool fast = nw <= K1_PRE * SP_WAVE;
-        uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
-        const unsigned long long my_bound = pre_bound;
-        if (fast) {
+    const int n_units = (n_act + K1_UNIT - 1) / K1_UNIT;
+    int unit = wave;                                      // the first units are pre-assigned, the rest grabbed
+    if (unit < n_units) fetch(unit * K1_UNIT);
+    while (unit < n_units) {
+        const int c_begin = unit * K1_UNIT, c_end = min(c_begin + K1_UNIT, n_act);
+        const int nxt_unit = grab();
+        int p_slot = -2, p_fail = 0, p_extent = 0, p_cap = 0;
+        for (int cur = c_begin; cur < c_end; ++cur) {
+            const int* m = meta + cur * K1_META;
+            const int tag = __builtin_amdgcn_readfirstlane(m[0]);
+            const int c_alen = __builtin_amdgcn_readfirstlane(m[1]), c_kb = __builtin_amdgcn_readfirstlane(m[2]);
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane(m[4]);
+            const int c_lcp = __builtin_amdgcn_readfirstlane(m[5]), c_slot = tag & 0xFFFF;
+            if (pre_for != cur) fetch(cur);
+            const unsigned long long my_bound = pre_bound;
+            int c_cap = tag >> 16;
+            if (bound) c_cap = k1_dyn_cap(my_bound, c_alen, c_cap);
+            c_cap = __builtin_amdgcn_readfirstlane(c_cap);
+            const int nxt = cur + 1 < c_end ? cur + 1 : (nxt_unit < n_units ? nxt_unit * K1_UNIT : -1);
+            if (p_fail && c_slot == p_slot + 1 && c_lcp > p_extent && c_cap <= p_cap) {
+                if (lane == 0) cell_out[(uint64_t)r * n_alleles + a] = SP_CELL_NONE;
+                p_slot = c_slot; p_cap = c_cap;
+                if (nxt >= 0) fetch(nxt);
+                continue;
+            }
+            const int nw = ((c_alen + 15) >> 4) + 2;
+            const bool fast = nw <= K1_PRE * SP_WAVE;
+            uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
+            if (fast) {
 #pragma unroll
-            for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; if (w < nw) LA[w] = pre[t]; }
-        } else {
-            spw::stage(LA, alleles.words + (uint32_t)meta[cur * 4 + 3], 0, c_alen, lane);
-        }
-        if (HASN) {
-            if (alleles.nplane) spw::stage(NA, alleles.nplane + (uint32_t)meta[cur * 4 + 3], 0, c_alen, lane);
-            else for (int w = lane; w < nw; w += SP_WAVE) NA[w] = 0;
-        }
-        spw::wave_lds_sync();
-        const int nxt = grab();
-        if (nxt < n_act) fetch(nxt);
-        int c_cap = tag >> 16;
-        if (bound) c_cap = k1_dyn_cap(my_bound, c_alen, c_cap);
-        c_cap = __builtin_amdgcn_readfirstlane(c_cap);
-        uint32_t res = SP_CELL_NONE;
-        spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0;
-        spw::wfa_core<false, HASN, false>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o);
-        if (o.ok) {
-            const int span = o.a_end - o.a_start;
-            res = ((uint32_t)o.nm << 16) | (uint32_t)span;
-            if (bound && lane == 0) {
-                const double pen = score_value(c_alen, o.nm, c_alen - span), ed = score_value(span, o.nm, 0);
-                if (pen <= 0.5 && ed <= 0.03) {
-                    const unsigned long long nn10 = o.nm ? 10ull * (unsigned long long)o.nm : 1ull;
-                    const unsigned long long cand = (nn10 << 32) | (unsigned long long)span;
-                    unsigned long long curb = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (;;) {
-                        const unsigned long long cn = curb >> 32, cs = curb & 0xFFFFFFFFull;
-                        const bool better = (cn == 0xFFFFFFFFull) || (nn10 * cs < cn * (unsigned long long)span);
-                        if (!better) break;
-                        const unsigned long long prev = atomicCAS(&bound[r], curb, cand);
-                        if (prev == curb) break;
-                        curb = prev;
+                for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; if (w < nw) LA[w] = pre[t]; }
+            } else {
+                spw::stage(LA, alleles.words + (uint32_t)m[3], 0, c_alen, lane);
+            }
+            if (HASN) {
+                if (alleles.nplane) spw::stage(NA, alleles.nplane + (uint32_t)m[3], 0, c_alen, lane);
+                else for (int w = lane; w < nw; w += SP_WAVE) NA[w] = 0;
+            }
+            spw::wave_lds_sync();
+            if (nxt >= 0) fetch(nxt);
+            uint32_t res = SP_CELL_NONE;
+            spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0; o.explored = 0x7FFFFFFF;
+            spw::wfa_core<false, HASN, false>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o);
+            if (o.ok) {
+                const int span = o.a_end - o.a_start;
+                res = ((uint32_t)o.nm << 16) | (uint32_t)span;
+                if (bound && lane == 0) {
+                    const double pen = score_value(c_alen, o.nm, c_alen - span), ed = score_value(span, o.nm, 0);
+                    if (pen <= 0.5 && ed <= 0.03) {
+                        const unsigned long long nn10 = o.nm ? 10ull * (unsigned long long)o.nm : 1ull;
+                        const unsigned long long cand = (nn10 << 32) | (unsigned long long)span;
+                        unsigned long long curb = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (;;) {
+                            const unsigned long long cn = curb >> 32, cs = curb & 0xFFFFFFFFull;
+                            const bool better = (cn == 0xFFFFFFFFull) || (nn10 * cs < cn * (unsigned long long)span);
+                            if (!better) break;
+                            const unsigned long long prev = atomicCAS(&bound[r], curb, cand);
+                            if (prev == curb) break;
+                            curb = prev;
+                        }
                     }
                 }
             }
+            p_slot = c_slot; p_fail = !o.ok; p_extent = __builtin_amdgcn_readfirstlane(o.explored); p_cap = c_cap;
+            spw::wave_lds_sync();
+            if (lane == 0) cell_out[(uint64_t)r * n_alleles + a] = res;
         }
-        spw::wave_lds_sync();
-        if (lane == 0) cell_out[(uint64_t)r * n_alleles + a] = res;
-        cur = nxt;
+        unit = nxt_unit;
     }
 }
 
@@ -522,7 +555,7 @@ void sp_hla_db_free(sp_hla_db* db) {
     if (!db) return;
     if (db->ctx) (void)hipSetDevice(db->ctx->device);
     sp_seqset_free(db->dna_gene); sp_seqset_free(db->cdna_gene); sp_seqset_free(db->dna_fwd); sp_seqset_free(db->ref_fwd);
-    (void)hipFree(db->d_gene_of); (void)hipFree(db->d_off_fwd); (void)hipFree(db->d_am);
+    (void)hipFree(db->d_gene_of); (void)hipFree(db->d_off_fwd); (void)hipFree(db->d_am); (void)hipFree(db->d_order); (void)hipFree(db->d_lcp);
     (void)hipFree(db->d_hpc_ref); (void)hipFree(db->d_hpc_ref_off);
     delete db;
 }
@@ -551,9 +584,9 @@ int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) 
     int rc = sp_seqset_upload(ctx, d->dna, d->dna_off, d->n_alleles, &db->dna_gene);
     if (rc == SP_OK) rc = sp_seqset_upload(ctx, d->cdna, d->cdna_off, d->n_alleles, &db->cdna_gene);
     if (rc == SP_OK) rc = sp_seqset_upload(ctx, d->gene_ref, d->gene_ref_off, d->n_genes, &db->ref_fwd);
+    std::string blob; std::vector<uint64_t> off(d->n_alleles + 1, 0);
     if (rc == SP_OK) {
         // hg38-oriented copy of every DNA allele (create_hla_fasta, realigner.rs:497-526)
-        std::string blob; std::vector<uint64_t> off(d->n_alleles + 1, 0);
         blob.reserve(d->dna_off[d->n_alleles]);
         for (uint32_t a = 0; a < d->n_alleles; ++a) {
             const char* s = d->dna + d->dna_off[a]; size_t len = d->dna_off[a + 1] - d->dna_off[a];
@@ -624,6 +657,34 @@ int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) 
         (void)hipFree(d_cells); (void)hipFree(d_alns);
     }
     db->d_off_fwd = dev_copy(off_fwd);
+    {
+        // K1 visiting order: alleles that start alike sit next to each other, so a cell that runs out of edits inside the prefix it
+        // shares with its successor settles the successor too (k1_cells_kernel).  Results never depend on the order.
+        std::vector<uint32_t> order(n);
+        for (uint32_t a = 0; a < n; ++a) order[a] = a;
+        auto live = [&](uint32_t a) { return off[a + 1] > off[a] && off_fwd[a] != SP_NO_DIAG; };
+        auto text = [&](uint32_t a) { return std::make_pair(blob.data() + off[a], (size_t)(off[a + 1] - off[a])); };
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            if (live(x) != live(y)) return live(x);
+            if (!live(x)) return x < y;
+            if (db->gene_of[x] != db->gene_of[y]) return db->gene_of[x] < db->gene_of[y];
+            if (off_fwd[x] != off_fwd[y]) return off_fwd[x] < off_fwd[y];
+            const auto tx = text(x), ty = text(y);
+            const int c = std::memcmp(tx.first, ty.first, std::min(tx.second, ty.second));
+            if (c != 0) return c < 0;
+            if (tx.second != ty.second) return tx.second < ty.second;
+            return x < y; });
+        std::vector<int32_t> lcp(n, 0);
+        for (uint32_t i = 1; i < n; ++i) {
+            const uint32_t x = order[i - 1], y = order[i];
+            if (!live(x) || !live(y) || db->gene_of[x] != db->gene_of[y] || off_fwd[x] != off_fwd[y]) continue;
+            const auto tx = text(x), ty = text(y);
+            const size_t m = std::min(tx.second, ty.second); size_t k = 0;
+            while (k < m && tx.first[k] == ty.first[k]) ++k;
+            lcp[i] = (int32_t)std::min<size_t>(k, 1u << 30);
+        }
+        db->d_order = dev_copy(order); db->d_lcp = dev_copy(lcp);
+    }
     (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_diag); (void)hipFree(d_votes);
     if (rc != SP_OK) { sp_hla_db_free(db); return rc; }
     *out = db;
@@ -660,7 +721,7 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
     // cells: one shared read window + four allele slots
     const int b_words = (reads->max_len + 15) / 16 + 4;
     const int a_words = (db->dna_fwd->max_len + 15) / 16 + 4;
-    const size_t cells_lds = (size_t)(32 + 4 * K1_CHUNK + (hasn ? 2 : 1) * (b_words + K1_WAVES * a_words)) * 4;
+    const size_t cells_lds = (size_t)(32 + K1_META * K1_CHUNK + (hasn ? 2 : 1) * (b_words + K1_WAVES * a_words)) * 4;
     if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
     // exact branch-and-bound is switched off when the caller wants the full cell matrix
     unsigned long long* d_bound = nullptr;
@@ -695,11 +756,11 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
             if (hasn) {
                 (void)hipFuncSetAttribute((const void*)k1_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
                 hipLaunchKernelGGL(k1_cells_kernel<true>, dim3(n_open * n_chunks), dim3(K1_THREADS), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
-                                   db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, pass_cap, b_words, a_words);
+                                   db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, db->d_order, db->d_lcp, pass_cap, b_words, a_words);
             } else {
                 (void)hipFuncSetAttribute((const void*)k1_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
                 hipLaunchKernelGGL(k1_cells_kernel<false>, dim3(n_open * n_chunks), dim3(K1_THREADS), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
-                                   db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, pass_cap, b_words, a_words);
+                                   db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, db->d_order, db->d_lcp, pass_cap, b_words, a_words);
             }
             if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_cells launch failed");
         }

@@ -41,6 +41,7 @@ struct CellIn {
 
 struct CellOut {
     int ok, nm, a_start, a_end, b_start, b_end;
+    int explored;      // ok == 0 (edit cap exhausted): the largest A position any diagonal reached, i.e. the last A base the run looked at
 };
 
 // stage bases [lo,hi) (full-sequence coordinates) of a packed sequence into dst; returns the base index of dst[0]
@@ -155,7 +156,16 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
         ++s;
         if (TRACE) hist[s * SP_WAVE + lane] = (uint16_t)(H >= 0 ? H : 0xFFFF);
     }
-    if (end_lane < 0) return;
+    if (end_lane < 0) {
+        // the cap ran out.  Every live diagonal stopped on a mismatch at A[H]; furthest-reaching points only grow with s, so no base
+        // beyond max H was ever compared: a run on another A with the same first max H + 1 bases is this run, step for step.
+        int hm = H;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(hm, o); hm = other > hm ? other : hm; }
+        out.explored = hm;
+        return;
+    }
+    out.explored = -1;
     const int he = __builtin_amdgcn_readlane(H, end_lane);
     const int oe = track ? __builtin_amdgcn_readlane(O, end_lane) : end_lane;
     out.ok = 1; out.nm = s;
