@@ -76,7 +76,7 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
 
 #define K1_PRE 5        // prefetch registers per lane: alleles up to 5*64*16 - 32 = 5,088 bases stream through registers
 #define K1_META 6       // metadata words per active cell
-#define K1_UNIT 8       // consecutive active cells a wave takes at a time (prefix sharing only carries inside a unit)
+#define K1_UNIT 16       // consecutive active cells a wave takes at a time (prefix sharing only carries inside a unit)
 
 template <bool HASN>
 __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads,
