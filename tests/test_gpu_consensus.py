@@ -135,3 +135,31 @@ def test_priority_consensus(oracle, pkg, gpu_ctx):
     want = {**{a: s for a, s in enumerate(alleles)}, 11: rep, 13: spacer}
     for g, ts in by_group.items():
         assert g_cons[g][1] == want[next(iter(ts))]
+
+
+def test_edge_cases(oracle, pkg, gpu_ctx):
+    """empty inputs, no read at the start, room too small, bad configuration"""
+    import ctypes as C
+    reads = ["ACGTACGTAGCTAGCTAGGATCGATCGATCGGCTAGCTAGCATCGACTAGCTACGATCG" * 4] * 5
+    S = gpu_ctx.upload(reads)
+    # every read is late: nothing starts the consensus (as in the oracle)
+    kw = dict(early_termination=True, dual=False)
+    got = gpu_ctx.consensus(S, gpu_cfg(pkg, **kw), offsets=[30] * 5)
+    same(got, of.oracle_consensus(oracle, reads, [30] * 5, of.cons_config(**kw)))
+    assert got["cons"][0] == "" and got["score1"].tolist() == [-1] * 5
+    # an empty selection
+    got = gpu_ctx.consensus(S, gpu_cfg(pkg, **kw), read_idx=np.zeros(0, np.uint32), cap=64)
+    assert got["cons"] == ["", None]
+    # the consensus does not fit
+    with pytest.raises(pkg.StarphaseError) as e:
+        gpu_ctx.consensus(S, gpu_cfg(pkg, **kw), cap=50)
+    assert e.value.code == 6
+    # offset_compare_length beyond the 64 bases the placement search supports
+    with pytest.raises(pkg.StarphaseError) as e:
+        gpu_ctx.consensus(S, gpu_cfg(pkg, offset_compare_length=100, **kw))
+    assert e.value.code == 1
+    # one read, two reads that disagree everywhere
+    for rs in (reads[:1], ["ACGT" * 40, "TTGCA" * 30]):
+        for two_pass in (False, True):
+            kw2 = dict(early_termination=False, dual=True, min_count=1)
+            same(gpu_ctx.consensus(gpu_ctx.upload(rs), gpu_cfg(pkg, **kw2), two_pass=two_pass), run_case(oracle, rs, None, kw2, two_pass))
