@@ -33,6 +33,7 @@ struct sp_hla_db {
     sp_seqset* ref_fwd = nullptr;     // buffered gene references, hg38 forward (realigner.rs:74-81)
     uint32_t* d_gene_of = nullptr;
     int32_t*  d_off_fwd = nullptr;    // allele_fwd_pos - ref_fwd_pos (SP_NO_DIAG = no anchor)
+    std::vector<uint32_t> h_order;
     uint32_t* d_order = nullptr;      // K1 visits the alleles sorted by (gene, frame offset, hg38-strand sequence) ...
     int32_t*  d_lcp = nullptr;        // ... d_lcp[i] = common prefix of order[i-1] and order[i] when they share gene and frame offset, else 0
     int32_t*  d_am = nullptr;         // n_alleles*3: ok, am.query_start, am.target_start (allele -> gene ref, realigner.rs:289-310)
@@ -52,7 +53,8 @@ __device__ __forceinline__ double score_value(int len, int nm, int unmapped) {
 // K1 cells: workgroup = (read r, chunk of K1_CHUNK alleles).  The read window every cell of the chunk can touch
 // is staged ONCE per workgroup into LDS (coalesced dword loads by all 256 threads); each wave then streams its
 // alleles through a private LDS slot and runs one WFA cell per allele.
-// cell_out[r * n_alleles + a] = (nm << 16) | aligned allele span, or SP_CELL_NONE.
+// cell_out[r * n_alleles + p] = (nm << 16) | aligned allele span, or SP_CELL_NONE, p = position of the allele in the visiting order
+// (a workgroup's results are one contiguous stretch of the row; the reduce maps positions back to allele indices).
 //
 // Exact branch-and-bound (bound != nullptr): bound[r] holds (num10 << 32 | span) of the best ACCEPTABLE cell
 // finished so far for read r (num10 = 10*nm, or 1 when nm == 0, i.e. max(nm, 0.1) * 10).  A cell whose edit
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
                 atomicMin(&ctl[0], j_min); atomicMax(&ctl[1], j_max); atomicMax(&ctl[2], alen);
             }
         }
-        if (!act) cell_out[(uint64_t)r * n_alleles + a] = SP_CELL_NONE;
+        if (!act) cell_out[(uint64_t)r * n_alleles + a_first + tid] = SP_CELL_NONE;
     }
     // dense list of the active cells in ascending allele order: per-wave ballots + a prefix over the (up to four) waves
     const unsigned long long bal = __ballot(act != 0);
@@ -195,7 +197,6 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
             const int* m = meta + cur * K1_META;
             const int tag = __builtin_amdgcn_readfirstlane(m[0]);
             const int c_alen = __builtin_amdgcn_readfirstlane(m[1]), c_kb = __builtin_amdgcn_readfirstlane(m[2]);
-            const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane(m[4]);
             const int c_lcp = __builtin_amdgcn_readfirstlane(m[5]), c_slot = tag & 0xFFFF;
             if (pre_for != cur) fetch(cur);
             const unsigned long long my_bound = pre_bound;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
             c_cap = __builtin_amdgcn_readfirstlane(c_cap);
             const int nxt = cur + 1 < c_end ? cur + 1 : (nxt_unit < n_units ? nxt_unit * K1_UNIT : -1);
             if (p_fail && c_slot == p_slot + 1 && c_lcp > p_extent && c_cap <= p_cap) {
-                if (lane == 0) cell_out[(uint64_t)r * n_alleles + a] = SP_CELL_NONE;
+                if (lane == 0) cell_out[(uint64_t)r * n_alleles + a_first + c_slot] = SP_CELL_NONE;
                 p_slot = c_slot; p_cap = c_cap;
                 if (nxt >= 0) fetch(nxt);
                 continue;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
             }
             p_slot = c_slot; p_fail = !o.ok; p_extent = __builtin_amdgcn_readfirstlane(o.explored); p_cap = c_cap;
             spw::wave_lds_sync();
-            if (lane == 0) cell_out[(uint64_t)r * n_alleles + a] = res;
+            if (lane == 0) cell_out[(uint64_t)r * n_alleles + a_first + c_slot] = res;
         }
         unit = nxt_unit;
     }
@@ -273,20 +274,21 @@ __global__ void k1_done_kernel(const unsigned long long* __restrict__ bound, uin
 
 // K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
 __global__ __launch_bounds__(256) void k1_reduce_kernel(const uint32_t* __restrict__ cell_out, const int32_t* __restrict__ allele_len,
-                                                        uint32_t n_alleles, uint32_t n_reads, int32_t* __restrict__ best_out) {
+                                                        const uint32_t* __restrict__ order, uint32_t n_alleles, uint32_t n_reads, int32_t* __restrict__ best_out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t r = blockIdx.x * 4 + wave;
     if (r >= n_reads) return;
     double best = 1.0;             // custom_score(false) of MappingStats(read_len, read_len, 0)
     int best_idx = 0x7FFFFFFF;
-    for (uint32_t a = lane; a < n_alleles; a += 64) {
-        uint32_t c = cell_out[(uint64_t)r * n_alleles + a];
+    for (uint32_t p = lane; p < n_alleles; p += 64) {
+        uint32_t c = cell_out[(uint64_t)r * n_alleles + p];
         if (c == SP_CELL_NONE) continue;
+        const uint32_t a = order[p];                         // ties go to the lowest allele index, whatever the visiting order
         int nm = (int)(c >> 16), span = (int)(c & 0xFFFFu), tlen = allele_len[a];
         int unmapped = tlen - span;
         double pen = score_value(tlen, nm, unmapped);
         double ed = score_value(tlen - unmapped, nm, 0);
-        if (pen <= 0.5 && ed <= 0.03 && ed < best) { best = ed; best_idx = (int)a; }
+        if (pen <= 0.5 && ed <= 0.03 && (ed < best || (ed == best && (int)a < best_idx))) { best = ed; best_idx = (int)a; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         double ob = __shfl_xor(best, o); int oi = __shfl_xor(best_idx, o);
@@ -683,7 +685,7 @@ int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) 
             while (k < m && tx.first[k] == ty.first[k]) ++k;
             lcp[i] = (int32_t)std::min<size_t>(k, 1u << 30);
         }
-        db->d_order = dev_copy(order); db->d_lcp = dev_copy(lcp);
+        db->d_order = dev_copy(order); db->d_lcp = dev_copy(lcp); db->h_order = order;
     }
     (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_diag); (void)hipFree(d_votes);
     if (rc != SP_OK) { sp_hla_db_free(db); return rc; }
@@ -774,7 +776,7 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
     }
     if (rc == SP_OK) {
         ProfScope ps(ctx, "k1_reduce", R);
-        hipLaunchKernelGGL(k1_reduce_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, d_cells, db->dna_fwd->d_len, NA, R, d_best);
+        hipLaunchKernelGGL(k1_reduce_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, d_cells, db->dna_fwd->d_len, db->d_order, NA, R, d_best);
     }
     if (rc == SP_OK) {
         ProfScope ps(ctx, "k1_finalize", R);
@@ -796,6 +798,14 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
         if (cell_out) (void)hipMemcpyAsync(cell_out, d_cells, (size_t)R * NA * 4, hipMemcpyDeviceToHost, ctx->stream);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("realign: ") + hipGetErrorString(e));
+        if (rc == SP_OK && cell_out) {                        // the device rows are in visiting order: hand them out by allele index
+            std::vector<uint32_t> row(NA);
+            for (uint32_t r = 0; r < R; ++r) {
+                uint32_t* c = cell_out + (size_t)r * NA;
+                for (uint32_t p2 = 0; p2 < NA; ++p2) row[db->h_order[p2]] = c[p2];
+                std::memcpy(c, row.data(), (size_t)NA * 4);
+            }
+        }
     }
     return rc;
 }
