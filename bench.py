@@ -224,6 +224,12 @@ def main():
                "kernel_ms": {k: ctx.profile_get(k)[0] / args.e2e_steps for k in ("anchor", "k1_cells", "hla_segments", "cons_steps", "k2_cells_cdna", "k2_cells_dna", "k2_scan")},
                "diplotypes_equal_truth": f"{ok}/{len(genes)} genes"}
 
+    traffic, traffic_note = None, None
+    tfile = os.path.join(ROOT, "profiles", "r01", "traffic_k1_cells.json")
+    if os.path.exists(tfile) and args.reads == 10000:
+        rec = json.load(open(tfile))
+        traffic, traffic_note = rec["hbm_bytes_per_launch"], "from the committed rocprofv3 PMC passes of this workload (" + rec["method"] + ")"
+
     if rank == 0:
         total_reads = args.reads * world * args.steps
         line = {
@@ -235,7 +241,7 @@ def main():
                                    "(18,461 alleles, 11,199 with DNA), 4 consensuses" % args.reads,
                        "reads_per_gpu": args.reads, "alleles": len(fx.ids), "parallelism": "one sample per GPU, RCCL all_gather of calls"},
             "roofline": {"bound": "hbm", "kernel": "k1_cells_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "cells_per_launch": alg_cells, "avg_launch_ms": avg_ms,
                          "note": "integer-DP kernel: VALU/LDS bound, DB served from L2/MALL; HBM fraction is on the streaming model of SURVEY 8(d)"},
             "kernel_ms": kernel_ms,

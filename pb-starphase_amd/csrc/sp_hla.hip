@@ -90,12 +90,13 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
                                                        const uint32_t* __restrict__ order, const int32_t* __restrict__ lcp_tab,
                                                        int pass_cap, int b_words, int a_words) {
     extern __shared__ uint32_t lds[];
-    // layout: [32 control words][K1_CHUNK x 6 cell metadata][B window b_words (x2 with N plane)][K1_WAVES x A slot a_words (x2 with N plane)]
+    // layout: [32 control words][K1_CHUNK x 6 cell metadata][K1_CHUNK results][B window b_words (x2 with N plane)][K1_WAVES x A slot a_words (x2 with N plane)]
     int* ctl = reinterpret_cast<int*>(lds);               // 0: window lo, 1: window hi, 2: longest active allele, 3: #active in wave 0,
                                                           // 4: #active, 5: next unit to grab
     int* meta = ctl + 32;                                 // dense list of active cells: (chunk slot | static cap << 16), alen, kb, word offset,
                                                           // allele index, prefix shared with the allele one slot earlier
-    uint32_t* LB = lds + 32 + K1_META * K1_CHUNK;
+    uint32_t* cres = lds + 32 + K1_META * K1_CHUNK;        // results of the chunk, written out in one coalesced sweep at the end
+    uint32_t* LB = cres + K1_CHUNK;
     uint32_t* NB = HASN ? LB + b_words : nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint32_t* slotA = LB + (HASN ? 2 : 1) * b_words + wave * (HASN ? 2 : 1) * a_words;
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
                 atomicMin(&ctl[0], j_min); atomicMax(&ctl[1], j_max); atomicMax(&ctl[2], alen);
             }
         }
+        cres[tid] = SP_CELL_NONE;
         if (!act) cell_out[(uint64_t)r * n_alleles + a_first + tid] = SP_CELL_NONE;
     }
     // dense list of the active cells in ascending allele order: per-wave ballots + a prefix over the (up to four) waves
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
             c_cap = __builtin_amdgcn_readfirstlane(c_cap);
             const int nxt = cur + 1 < c_end ? cur + 1 : (nxt_unit < n_units ? nxt_unit * K1_UNIT : -1);
             if (p_fail && c_slot == p_slot + 1 && c_lcp > p_extent && c_cap <= p_cap) {
-                if (lane == 0) cell_out[(uint64_t)r * n_alleles + a_first + c_slot] = SP_CELL_NONE;
+                // (a cell that is not executed keeps the SP_CELL_NONE its result slot was initialised with)
                 p_slot = c_slot; p_cap = c_cap;
                 if (nxt >= 0) fetch(nxt);
                 continue;
@@ -250,10 +252,12 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
             }
             p_slot = c_slot; p_fail = !o.ok; p_extent = __builtin_amdgcn_readfirstlane(o.explored); p_cap = c_cap;
             spw::wave_lds_sync();
-            if (lane == 0) cell_out[(uint64_t)r * n_alleles + a_first + c_slot] = res;
+            if (lane == 0) cres[c_slot] = res;
         }
         unit = nxt_unit;
     }
+    __syncthreads();
+    if (tid < K1_CHUNK && a_first + tid < a_end && act) cell_out[(uint64_t)r * n_alleles + a_first + tid] = cres[tid];
 }
 
 // Iterative deepening bookkeeping: after a pass whose cells were capped at pass_cap edits, read r is settled when an
@@ -723,7 +727,7 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
     // cells: one shared read window + four allele slots
     const int b_words = (reads->max_len + 15) / 16 + 4;
     const int a_words = (db->dna_fwd->max_len + 15) / 16 + 4;
-    const size_t cells_lds = (size_t)(32 + K1_META * K1_CHUNK + (hasn ? 2 : 1) * (b_words + K1_WAVES * a_words)) * 4;
+    const size_t cells_lds = (size_t)(32 + (K1_META + 1) * K1_CHUNK + (hasn ? 2 : 1) * (b_words + K1_WAVES * a_words)) * 4;
     if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
     // exact branch-and-bound is switched off when the caller wants the full cell matrix
     unsigned long long* d_bound = nullptr;

@@ -156,16 +156,15 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
         ++s;
         if (TRACE) hist[s * SP_WAVE + lane] = (uint16_t)(H >= 0 ? H : 0xFFFF);
     }
-    if (end_lane < 0) {
-        // the cap ran out.  Every live diagonal stopped on a mismatch at A[H]; furthest-reaching points only grow with s, so no base
-        // beyond max H was ever compared: a run on another A with the same first max H + 1 bases is this run, step for step.
+    {
+        // When the cap ran out, every live diagonal stopped on a mismatch at A[H]; furthest-reaching points only grow with s, so no
+        // base beyond max H was ever compared: a run on another A with the same first max H + 1 bases is this run, step for step.
         int hm = H;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(hm, o); hm = other > hm ? other : hm; }
-        out.explored = hm;
-        return;
+        out.explored = end_lane < 0 ? hm : -1;
     }
-    out.explored = -1;
+    if (end_lane < 0) return;
     const int he = __builtin_amdgcn_readlane(H, end_lane);
     const int oe = track ? __builtin_amdgcn_readlane(O, end_lane) : end_lane;
     out.ok = 1; out.nm = s;

@@ -34,3 +34,27 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     for k in sorted(acc):
         for c in sorted(acc[k]):
             print("  %-48s %-24s sum=%.6g n=%d per_dispatch=%.6g" % (k, c, acc[k][c], cnt[(k, c)], acc[k][c] / cnt[(k, c)]))
+
+# HBM traffic of the dominant kernel per main launch, for bench.py's roofline.traffic (MI355X_MICROARCH.md, HBM: FETCH_SIZE and
+# WRITE_SIZE are KB; gfx950 tallies 128-byte read requests at 64 bytes, so FETCH_SIZE is doubled).  The deep passes of
+# k1_cells_kernel are small launches of the same kernel: only dispatches within 10x of the largest one count as main launches.
+import json
+vals = {}
+for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    v = []
+    for f in find(sub + "/**/*counter_collection.csv"):
+        for row in csv.DictReader(open(f)):
+            if "k1_cells_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                v.append(float(row.get("Counter_Value", 0) or 0))
+    # one row per (dispatch, XCD/instance) may exist: group by Dispatch_Id when available
+    vals[counter] = v
+if vals.get("FETCH_SIZE") and vals.get("WRITE_SIZE"):
+    def per_main(v):
+        big = [x for x in v if x * 10 >= max(v)]
+        return sum(big) / len(big), len(big)
+    f, nf = per_main(vals["FETCH_SIZE"]); w, nw = per_main(vals["WRITE_SIZE"])
+    rec = {"kernel": "k1_cells_kernel", "fetch_kb_per_launch": f, "write_kb_per_launch": w, "main_launches": nf,
+           "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/run_rocprof.sh); KB -> bytes; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)"}
+    json.dump(rec, open(os.path.join(out, "traffic_k1_cells.json"), "w"), indent=1)
+    print("== traffic", rec)
