@@ -289,7 +289,7 @@ int32_t sp_cyp_score_alleles(sp_ctx* ctx, uint32_t n_variants, uint32_t n_allele
 /* ------------------------------------------------------------------ K9: per-variant state of typed sequences
  * The role of WFAGraph::from_reference_variants + edit_distance_with_pruning + the traversed-node loop of assign_haplotype
  * (src/cyp2d6/haplotyper.rs:371-468): which allele of every database variant a consensus carries.  hiphase v1.2.1 is not on disk;
- * the contract (DESIGN.md section 13): the sequence is placed on the backbone (GPU alignment with traceback); for every variant whose
+ * the contract (DESIGN.md section 10): the sequence is placed on the backbone (GPU alignment with traceback); for every variant whose
  * reference span lies inside the aligned part, the sequence window facing [p - 24, p + |ref| + 24) is compared (global edit
  * distance, one GPU thread per pair) with that backbone window carrying the reference allele and carrying the alternate allele:
  * 0 = closer to the reference, 1 = closer to the alternate, 2 = equally close (ambiguous), 3 = not covered / not aligned.
@@ -381,7 +381,7 @@ int32_t sp_variant_solve(sp_ctx* ctx, const sp_variant_problem* problem, sp_vari
  * Serves the waffle_con calls of the reference: DualConsensusDWFA::{add_sequence_offset, consensus} in
  * run_dual_consensus_with_offsets (src/hla/caller.rs:1103-1219) and ConsensusDWFA per read group (src/hla/caller.rs:706-747),
  * with the fields of dwfa_config_from_cli (src/hla/caller.rs:1103-1116).  waffle_con v0.4.4 is not on disk: the contract is the
- * one in DESIGN.md section 12 / oracle/consensus.c (every read keeps a 64-diagonal edit wavefront against the growing consensus
+ * one in DESIGN.md section 9 / oracle/consensus.c (every read keeps a 64-diagonal edit wavefront against the growing consensus
  * and votes for the next base; a second consensus is split off where a second base has min_count reads and min_af of the votes).
  *   reads / read_idx   the sequences (read_idx == NULL: all n = sp_seqset_count(reads) of them, in order)
  *   offsets            NULL, or per sequence -1 (None: starts with the consensus) or the consensus length at which the sequence is

@@ -3,7 +3,7 @@
  *
  * The reference delegates consensus to the third-party crate waffle_con v0.4.4 (Cargo.lock:2246-2248), whose sources are
  * not under /root/reference; no reference test runs a consensus.  PARITY UNPINNED: this file states the
- * contract the HIP path implements (DESIGN.md section 12), built on waffle_con's published idea -- every read keeps an
+ * contract the HIP path implements (DESIGN.md section 9), built on waffle_con's published idea -- every read keeps an
  * edit-distance wavefront against the growing consensus, reads vote for the next base, a second consensus is split off
  * when a second base has enough support -- with every rule made explicit and deterministic:
  *   call sites it serves      src/hla/caller.rs:1103-1219 (dual, HPC then DNA, offsets, early termination)

@@ -65,7 +65,7 @@ void osp_cyp_score_alleles(int n_variants, int n_alleles, const uint8_t* hap_mat
                            uint32_t* best_vi, uint32_t* best_all, uint8_t* tie);
 
 /* per-variant state of a sequence against the CYP2D6 backbone: the role of WFAGraph::edit_distance_with_pruning + traversed nodes in
- * assign_haplotype (src/cyp2d6/haplotyper.rs:371-468; hiphase v1.2.1 is not on disk -- PARITY UNPINNED, contract in DESIGN.md 13).
+ * assign_haplotype (src/cyp2d6/haplotyper.rs:371-468; hiphase v1.2.1 is not on disk -- PARITY UNPINNED, contract in DESIGN.md 10).
  * The sequence is placed on the backbone (anchor + banded alignment with traceback); for every variant whose reference span lies in
  * the aligned part, the sequence window that faces [p - 24, p + |ref| + 24) is compared (global edit distance) with that backbone
  * window carrying the reference allele and carrying the alternate allele: closer to ref = 0, closer to alt = 1, equal = 2;

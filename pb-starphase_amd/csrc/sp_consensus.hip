@@ -3,7 +3,7 @@
 // Serves the waffle_con call sites of the reference: DualConsensusDWFA in run_dual_consensus_with_offsets
 // (src/hla/caller.rs:1103-1219) and the per-group ConsensusDWFA (src/hla/caller.rs:706-747), configured as
 // dwfa_config_from_cli does (src/hla/caller.rs:1103-1116).  waffle_con itself (v0.4.4) is a third-party crate that is not
-// on disk, so the contract is the one stated in DESIGN.md section 12 and restated for the CPU in oracle/consensus.c; the
+// on disk, so the contract is the one stated in DESIGN.md section 9 and restated for the CPU in oracle/consensus.c; the
 // two agree bit for bit (consensus strings, read assignment, per-read edit counts).
 //
 // Mapping: ONE wavefront per read, one lane per diagonal (64-diagonal band, lane l <-> consensus pos - read pos = l - 32),

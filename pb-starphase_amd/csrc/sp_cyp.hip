@@ -582,7 +582,7 @@ extern "C" int32_t sp_cyp_score_alleles(sp_ctx* ctx, uint32_t n_variants, uint32
 
 // =============================================================================================
 // K9: per-variant state of typed sequences on the CYP2D6 backbone -- the role of the graph alignment in assign_haplotype
-// (src/cyp2d6/haplotyper.rs:371-468; hiphase's WFAGraph is not on disk, contract in DESIGN.md section 13 / oracle/cyp.c):
+// (src/cyp2d6/haplotyper.rs:371-468; hiphase's WFAGraph is not on disk, contract in DESIGN.md section 10 / oracle/cyp.c):
 // each sequence is placed on the backbone with traceback (anchor + cell kernels); for every variant inside the aligned part the
 // sequence window facing [p - 24, p + |ref| + 24) is compared with that backbone window carrying the reference and the alternate
 // allele.  The (window, haplotype) pairs of all sequences and variants are one batch of small global edit distances: one thread
