@@ -40,7 +40,8 @@ struct ConsMeta { int32_t e, c0, flags, pad; };
 // exactly one problem (each problem's reads are padded to a multiple of CWAVES in the flattened read order).  The descriptors
 // travel in the kernel argument block (scalar loads), per-read constants are gathered once into ReadInfo: a step is a chain
 // of only two dependent memory round trips (state + control, then the read words at the wavefront tips).
-constexpr int CMAXP = 8;        // problems per launch sequence
+constexpr int CMAXP = 32;       // problems per launch sequence: their descriptors travel in the kernel argument block (32 x 80 bytes);
+                                // batches of up to 8 use an 8-entry block, whose launches are ~2 us shorter
 struct ConsParams {
     int n, first, first_block;  // reads; flattened index of local read 0; first workgroup of the problem
     int min_count, delta, et, allow_dual, window, cmp_len; double min_af;
@@ -49,8 +50,8 @@ struct ConsParams {
     ConsCtrl* ctrl;             // [2]
 };
 struct ReadInfo { const uint32_t* w; const uint32_t* np; int n, off; long long pad; };
-struct ConsBatch {
-    ConsParams p[CMAXP]; int n_prob;
+template <int MAXP> struct ConsBatchT {
+    ConsParams p[MAXP]; int n_prob;
     const ReadInfo* info;       // [total]
     uint16_t* H;                // [2][total][64] furthest read position per diagonal (0xFFFF = none): 128 bytes per read and consensus
     ConsMeta* meta;             // [2][total]
@@ -192,11 +193,12 @@ __device__ __forceinline__ int find_start(const ReadView& rv, const ConsView& cv
     return (int)(key & ((1ull << 22) - 1));
 }
 
-__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatch B, int t) {
+template <int MAXP>
+__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<MAXP> B, int t) {
     __shared__ uint32_t lv[2][8];
     int pi = 0;
 #pragma unroll
-    for (int i = 1; i < CMAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
+    for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
     const ConsParams P = B.p[pi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lead = (int)blockIdx.x == P.first_block;
@@ -309,7 +311,8 @@ struct ActItem { int prob, r; };
 constexpr int ACT_CONS = 512;   // consensus bases a wave keeps in LDS while a late read catches up (offset_window + slack)
 constexpr int ACT_READ = 640;   // read bases it keeps (catch-up length + band + edits)
 
-__global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatch B, int t, const ActItem* __restrict__ items, int n_items) {
+template <int MAXP>
+__global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatchT<MAXP> B, int t, const ActItem* __restrict__ items, int n_items) {
     __shared__ uint8_t ccache[4][ACT_CONS];
     __shared__ uint8_t rcache[4][ACT_READ];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, it = blockIdx.x * 4 + wv;
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatch B,
     const ActItem item = items[it];
     int pi = 0;
 #pragma unroll
-    for (int i = 1; i < CMAXP; ++i) if (i == item.prob) pi = i;
+    for (int i = 1; i < MAXP; ++i) if (i == item.prob) pi = i;
     const ConsParams P = B.p[pi];
     const size_t g = (size_t)P.first + item.r;
     const ReadInfo ri = B.info[g];
@@ -396,10 +399,11 @@ __global__ void cons_setup_kernel(ConsSetup S, ReadInfo* __restrict__ info) {
     info[S.first + r] = ri;
 }
 
-__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBatch B, int which, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
+template <int MAXP>
+__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBatchT<MAXP> B, int which, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
     int pi = 0;
 #pragma unroll
-    for (int i = 1; i < CMAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
+    for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
     const ConsParams P = B.p[pi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = ((int)blockIdx.x - P.first_block) * CWAVES + wave;
@@ -432,9 +436,10 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
 } // namespace
 
 // host side of a batch of at most CMAXP problems: all of them advance one base per launch until every one has stopped
+template <int MAXP>
 static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* probs, sp_cons_output* outs) {
     hipStream_t st = ctx->stream;
-    ConsBatch B; std::memset(&B, 0, sizeof B);
+    ConsBatchT<MAXP> B; std::memset(&B, 0, sizeof B);
     B.n_prob = (int)n_prob;
     std::vector<ConsSetup> setup(n_prob);
     std::vector<uint32_t> h_idx; std::vector<int32_t> h_off;
@@ -504,15 +509,15 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     size_t act_at = 0;
     {
         ProfScope ps(ctx, "cons_steps", total);
-        hipLaunchKernelGGL(cons_step_kernel, grid, block, 0, st, B, -1);
+        hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B, -1);
         for (int t = 0; t <= max_cap; ++t) {                 // launch t = max_cap only records the stop of a consensus that filled its room
-            hipLaunchKernelGGL(cons_step_kernel, grid, block, 0, st, B, t);
+            hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B, t);
             last = t;
             size_t hi = act_at;
             while (hi < late.size() && late[hi].first == t + 1) ++hi;
             if (hi > act_at) {
                 const int cnt = (int)(hi - act_at);
-                hipLaunchKernelGGL(cons_activate_kernel, dim3((cnt + 3) / 4), dim3(4 * SP_WAVE), 0, st, B, t, d_act + act_at, cnt);
+                hipLaunchKernelGGL(cons_activate_kernel<MAXP>, dim3((cnt + 3) / 4), dim3(4 * SP_WAVE), 0, st, B, t, d_act + act_at, cnt);
                 act_at = hi;
             }
             if ((t & 255) == 255 || t == max_cap) {
@@ -526,7 +531,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     }
     SP_HIP_CHECK(ctx, hipGetLastError());
     const int which = (last + 1) & 1;
-    hipLaunchKernelGGL(cons_finalize_kernel, grid, block, 0, st, B, which, d_is1, d_sc, d_sc + total);
+    hipLaunchKernelGGL(cons_finalize_kernel<MAXP>, grid, block, 0, st, B, which, d_is1, d_sc, d_sc + total);
     std::vector<uint8_t> hc(c_bytes), h_is1(total);
     std::vector<int32_t> h_sc(2 * total);
     SP_HIP_CHECK(ctx, hipMemcpyAsync(hc.data(), d_C, c_bytes, hipMemcpyDeviceToHost, st));
@@ -573,7 +578,8 @@ static int32_t run_batch(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     SP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int32_t rc = SP_OK;
     for (uint32_t at = 0; at < n_prob; at += CMAXP) {
-        const int32_t e = run_chunk(ctx, std::min<uint32_t>(CMAXP, n_prob - at), probs + at, outs + at);
+        const uint32_t k = std::min<uint32_t>(CMAXP, n_prob - at);
+        const int32_t e = k <= 8 ? run_chunk<8>(ctx, k, probs + at, outs + at) : run_chunk<CMAXP>(ctx, k, probs + at, outs + at);
         if (e != SP_OK && e != SP_ERR_CAPACITY) return e;
         if (e != SP_OK) rc = e;
     }

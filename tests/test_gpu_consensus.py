@@ -163,3 +163,23 @@ def test_edge_cases(oracle, pkg, gpu_ctx):
         for two_pass in (False, True):
             kw2 = dict(early_termination=False, dual=True, min_count=1)
             same(gpu_ctx.consensus(gpu_ctx.upload(rs), gpu_cfg(pkg, **kw2), two_pass=two_pass), run_case(oracle, rs, None, kw2, two_pass))
+
+
+def test_many_problems_in_one_batch(oracle, pkg, gpu_ctx):
+    """a cohort-style batch: 40 small independent problems (more than one launch sequence holds) give what they give alone"""
+    from pb_starphase_amd import synth
+    rng = np.random.default_rng(77)
+    probs, exps = [], []
+    for k in range(40):
+        hap = "".join(rng.choice(list("ACGT"), int(rng.integers(200, 500))))
+        other = synth.mutate(rng, hap, 3, 0, 0) if k % 3 else hap
+        reads = [synth.hifi_errors(rng, hap if rng.random() < 0.5 else other, p_sub=0.002, p_ins=0.002, p_del=0.002) for _ in range(int(rng.integers(3, 12)))]
+        kw = dict(early_termination=bool(k % 2), dual=True, min_count=2)
+        probs.append(dict(reads=gpu_ctx.upload(reads), cfg=gpu_cfg(pkg, **kw)))
+        exps.append(run_case(oracle, reads, None, kw, True))
+    got = gpu_ctx.consensus_batch(probs, two_pass=True)
+    for k, (g, e) in enumerate(zip(got, exps)):
+        try:
+            same(g, e)
+        except AssertionError as err:
+            raise AssertionError(f"problem {k}: {err}")
