@@ -579,7 +579,7 @@ static int32_t run_batch(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     int32_t rc = SP_OK;
     for (uint32_t at = 0; at < n_prob; at += CMAXP) {
         const uint32_t k = std::min<uint32_t>(CMAXP, n_prob - at);
-        const int32_t e = k <= 8 ? run_chunk<8>(ctx, k, probs + at, outs + at) : run_chunk<CMAXP>(ctx, k, probs + at, outs + at);
+        const int32_t e = k <= 4 ? run_chunk<4>(ctx, k, probs + at, outs + at) : k <= 8 ? run_chunk<8>(ctx, k, probs + at, outs + at) : run_chunk<CMAXP>(ctx, k, probs + at, outs + at);
         if (e != SP_OK && e != SP_ERR_CAPACITY) return e;
         if (e != SP_OK) rc = e;
     }
