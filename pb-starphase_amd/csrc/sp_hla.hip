@@ -80,7 +80,8 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
 #define K1_META 6       // metadata words per active cell
 #define K1_UNIT 16       // consecutive active cells a wave takes at a time (prefix sharing only carries inside a unit)
 
-template <bool HASN>
+// DEEP only names the later (deeper, much smaller) passes of the iterative deepening differently, so that profilers list them apart
+template <bool HASN, bool DEEP>
 __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads,
                                                        const uint32_t* __restrict__ gene_of, const int32_t* __restrict__ off_fwd,
                                                        const int32_t* __restrict__ d_rg, const int32_t* __restrict__ votes_rg,
@@ -759,15 +760,13 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
         const uint32_t* d_list = pass == 0 ? nullptr : d_open_list;
         {
             ProfScope ps(ctx, pass == 0 ? "k1_cells" : "k1_cells_deep", (uint64_t)n_open * NA);
-            if (hasn) {
-                (void)hipFuncSetAttribute((const void*)k1_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
-                hipLaunchKernelGGL(k1_cells_kernel<true>, dim3(n_open * n_chunks), dim3(K1_THREADS), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
+            auto go = [&](auto kernel) {
+                (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
+                hipLaunchKernelGGL(kernel, dim3(n_open * n_chunks), dim3(K1_THREADS), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
                                    db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, db->d_order, db->d_lcp, pass_cap, b_words, a_words);
-            } else {
-                (void)hipFuncSetAttribute((const void*)k1_cells_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
-                hipLaunchKernelGGL(k1_cells_kernel<false>, dim3(n_open * n_chunks), dim3(K1_THREADS), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
-                                   db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, db->d_order, db->d_lcp, pass_cap, b_words, a_words);
-            }
+            };
+            if (hasn) { if (pass == 0) go(k1_cells_kernel<true, false>); else go(k1_cells_kernel<true, true>); }
+            else { if (pass == 0) go(k1_cells_kernel<false, false>); else go(k1_cells_kernel<false, true>); }
             if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_cells launch failed");
         }
         if (rc == SP_OK && d_bound && pass + 1 < n_pass) {

@@ -44,7 +44,7 @@ for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     v = []
     for f in find(sub + "/**/*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
-            if "k1_cells_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+            if "k1_cells_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:   # both instantiations; the 10x rule below drops the deep passes
                 v.append(float(row.get("Counter_Value", 0) or 0))
     # one row per (dispatch, XCD/instance) may exist: group by Dispatch_Id when available
     vals[counter] = v
