@@ -154,7 +154,8 @@ __device__ __forceinline__ void dwfa_push(Dwfa& d, const ReadView& rv, const Con
 
 // placement of a late read: Sellers' search of its first L bases in the last W consensus bases, one Myers bit-vector scan per
 // lane over the end positions it owns (an occurrence of an L-base pattern with <= L edits spans <= 2L text bases)
-__device__ __forceinline__ int find_start(const ReadView& rv, const ConsView& cv, int i, int off, int W, int L, int lane) {
+template <class CA>
+__device__ __forceinline__ int find_start(const ReadView& rv, CA ca, int off, int W, int L, int lane) {
     const int ws = off - W > 0 ? off - W : 0, M = off - ws;
     if (L > rv.n) L = rv.n;
     if (M <= 0 || L <= 0) return off;
@@ -173,7 +174,7 @@ __device__ __forceinline__ int find_start(const ReadView& rv, const ConsView& cv
         int score = L;
         const int centre = off - W / 2;
         for (int j = max(1, jlo - 2 * L); j <= jhi; ++j) {
-            const int x = cv.at(i, off - j);
+            const int x = ca(off - j);
             const unsigned long long Eq = x == 0 ? peq[0] : x == 1 ? peq[1] : x == 2 ? peq[2] : peq[3];
             const unsigned long long Xv = Eq | Mv;
             const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
@@ -340,15 +341,17 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatchT<M
         if (i == 1 && !c.dual) continue;
         if (c.len[i] != len || c.stopped[i] || (d[i].flags & F_ACTIVE) || ri.off != len) continue;
         placed[i] = 1;
-        d[i].c0 = find_start(rv, cv, i, ri.off, P.window, P.cmp_len, lane);
-        d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
-        // the catch-up runs out of LDS: the consensus from the start found up to now, and the head of the read
-        const int c0 = d[i].c0, span = len - c0;
-        for (int x = lane; x < span && x < ACT_CONS; x += SP_WAVE) ccache[wv][x] = (uint8_t)cv.at(i, c0 + x);
+        // the window in front of the offset and the head of the read go to LDS once: both the start search and the catch-up run out of it
+        const int ws = ri.off - P.window > 0 ? ri.off - P.window : 0;
+        for (int x = lane; x < len - ws && x < ACT_CONS; x += SP_WAVE) ccache[wv][x] = (uint8_t)cv.at(i, ws + x);
         for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) rcache[wv][x] = (uint8_t)read_base(rv, x);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         auto rb = [&](int h) { return h < ACT_READ ? (int)rcache[wv][h] : read_base(rv, h); };
-        auto ca = [&](int pos) { const int x = pos - c0; return x < ACT_CONS ? (int)ccache[wv][x] : cv.at(i, pos); };
+        auto ca = [&](int pos) { const int x = pos - ws; return (x >= 0 && x < ACT_CONS) ? (int)ccache[wv][x] : cv.at(i, pos); };
+        ReadView rvc = rv;
+        d[i].c0 = find_start(rvc, ca, ri.off, P.window, P.cmp_len, lane);
+        d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
+        const int c0 = d[i].c0, span = len - c0;
         for (int T = 1; T <= span; ++T) {
             if (d[i].flags & (F_FINISHED | F_LOST)) break;
             dwfa_push_t(d[i], rv.n, rb, ca, T, ca(c0 + T - 1), P.et, lane);
