@@ -442,8 +442,13 @@ __global__ void k2_levels_kernel(const sp_aln* __restrict__ alns, uint32_t n, K2
 // pc[e] - pc[s] of process_mm_cigar (processed_match.rs:210-263) from the event list:
 // every X / D / I event contributes 1 at pc index (b_pos + 1); clip padding contributes 1 per base.
 __device__ __forceinline__ int k2_range_edits(const K2Level& l, const sp_aln& a, const uint32_t* __restrict__ ev, int s, int e) {
-    int cnt = 0;
-    for (int x = 0; x < a.nm; ++x) { int p = (int)(ev[x] & 0x3FFFFFFFu) + 1; cnt += (p > s && p <= e); }
+    // the events are in path order, so their B positions never decrease: two binary searches instead of a pass over all of them
+    auto upto = [&](int x) {                              // events whose pc index (b_pos + 1) is <= x
+        int lo = 0, hi = a.nm;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)(ev[mid] & 0x3FFFFFFFu) + 1 <= x) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    int cnt = upto(e) - upto(s);
     // soft-clip padding (only non-zero when the allele overhangs the consensus end it touches)
     int clip_start = a.a_start, t_off = a.b_start;
     int zero_pad = t_off > clip_start ? t_off - clip_start : 0;
