@@ -151,6 +151,7 @@ int32_t sp_seqset_length(const sp_seqset* s, uint32_t idx, uint32_t* len) {
 } // extern "C"
 
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
+static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::vector<uint32_t>& kcode, std::vector<int32_t>& kpos);
 
 int sp_seqset_fetch_host(sp_ctx* ctx, sp_seqset* s) {
     if (!s->h_words.empty()) return SP_OK;
@@ -159,6 +160,67 @@ int sp_seqset_fetch_host(sp_ctx* ctx, sp_seqset* s) {
     s->h_words.assign(plane_words * (s->has_n ? 2 : 1), 0);
     if (hipMemcpy(s->h_words.data(), s->d_words, plane_words * 4, hipMemcpyDeviceToHost) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "fetch packed words");
     if (s->has_n && hipMemcpy(s->h_words.data() + plane_words, s->d_nplane, plane_words * 4, hipMemcpyDeviceToHost) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "fetch N plane");
+    return SP_OK;
+}
+
+// A short-lived set of a few sequences (a consensus, a backbone) without a single allocation: packed on the host, device buffers
+// from the pool "<prefix>_*", k-mer index built straight from the host words.  The set is a value: never sp_seqset_free it; it
+// stays valid until the next call with the same prefix.
+int sp_seqset_make_small(sp_ctx* ctx, const char* prefix, const char* bases, const uint64_t* offsets, uint32_t n, bool with_index, sp_seqset* out) {
+    hipSetDevice(ctx->device);
+    *out = sp_seqset();
+    sp_seqset& s = *out;
+    s.ctx = ctx; s.n = n;
+    s.h_len.resize(n); s.h_word_off.resize((size_t)n + 1);
+    uint64_t total_words = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t len = offsets[i + 1] - offsets[i];
+        if (offsets[i + 1] < offsets[i] || len > 65534) return sp_fail(ctx, SP_ERR_TOO_LONG, "seqset: sequence longer than 65,534 bases");
+        s.h_len[i] = (int32_t)len; s.max_len = std::max<int32_t>(s.max_len, (int32_t)len);
+        s.h_word_off[i] = total_words;
+        total_words += (((len + 15) / 16 + 2) + 3) & ~3ull;
+    }
+    s.h_word_off[n] = total_words;
+    const size_t plane_words = (size_t)total_words + 4;
+    std::vector<uint32_t> words(plane_words, 0), nplane(plane_words, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const char* src = bases + offsets[i];
+        uint32_t* w = words.data() + s.h_word_off[i]; uint32_t* np = nplane.data() + s.h_word_off[i];
+        for (int b = 0; b < s.h_len[i]; ++b) {
+            uint32_t c = 0;
+            switch (src[b]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break;
+                              default: np[b >> 4] |= 1u << ((b & 15) << 1); s.has_n = true; }
+            w[b >> 4] |= c << ((b & 15) << 1);
+        }
+    }
+    s.h_words = words;
+    if (s.has_n) s.h_words.insert(s.h_words.end(), nplane.begin(), nplane.end());
+    const std::string px(prefix);
+    auto pool = [&](const char* what, size_t bytes) { return sp_pool(ctx, (px + what).c_str(), std::max<size_t>(bytes, 16)); };
+    s.d_words = (uint32_t*)pool("_w", plane_words * 4);
+    s.d_nplane = s.has_n ? (uint32_t*)pool("_n", plane_words * 4) : nullptr;
+    s.d_word_off = (uint64_t*)pool("_o", ((size_t)n + 1) * 8);
+    s.d_len = (int32_t*)pool("_l", std::max<size_t>(1, n) * 4);
+    if (!s.d_words || !s.d_word_off || !s.d_len || (s.has_n && !s.d_nplane)) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "small seqset");
+    hipMemcpyAsync(s.d_words, words.data(), plane_words * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (s.has_n) hipMemcpyAsync(s.d_nplane, nplane.data(), plane_words * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(s.d_word_off, s.h_word_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (n) hipMemcpyAsync(s.d_len, s.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    std::vector<uint64_t> koff; std::vector<uint32_t> kcode; std::vector<int32_t> kpos;
+    if (with_index) {
+        kmer_tables(&s, koff, kcode, kpos);
+        s.d_kcode = (uint32_t*)pool("_kc", std::max<size_t>(1, kcode.size()) * 4);
+        s.d_kpos = (int32_t*)pool("_kp", std::max<size_t>(1, kpos.size()) * 4);
+        s.d_koff = (uint64_t*)pool("_ko", koff.size() * 8);
+        if (!s.d_kcode || !s.d_kpos || !s.d_koff) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "small seqset index");
+        if (!kcode.empty()) {
+            hipMemcpyAsync(s.d_kcode, kcode.data(), kcode.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+            hipMemcpyAsync(s.d_kpos, kpos.data(), kpos.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        }
+        hipMemcpyAsync(s.d_koff, koff.data(), koff.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+        s.has_index = true;
+    }
+    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // the host vectors above go out of scope
     return SP_OK;
 }
 
@@ -176,18 +238,10 @@ std::string sp_seqset_decode(sp_ctx* ctx, const sp_seqset* s, uint32_t i) {
     return out;
 }
 
-// sorted 16-mer table of every sequence of the set (device code order: base t of the k-mer in bits 2t..2t+1)
-int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
-    if (s->has_index) return SP_OK;
-    hipSetDevice(ctx->device);
+// sorted 16-mer table of every sequence of a set whose packed words are on the host
+static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::vector<uint32_t>& kcode, std::vector<int32_t>& kpos) {
     const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
-    if (s->h_words.empty()) {                              // packed on the device: fetch the packed words (and N plane) once
-        s->h_words.assign(plane_words * (s->has_n ? 2 : 1), 0);
-        hipMemcpy(s->h_words.data(), s->d_words, plane_words * 4, hipMemcpyDeviceToHost);
-        if (s->has_n) hipMemcpy(s->h_words.data() + plane_words, s->d_nplane, plane_words * 4, hipMemcpyDeviceToHost);
-    }
-    std::vector<uint64_t> koff((size_t)s->n + 1, 0);
-    std::vector<uint32_t> kcode; std::vector<int32_t> kpos;
+    koff.assign((size_t)s->n + 1, 0); kcode.clear(); kpos.clear();
     std::vector<std::pair<uint32_t, int32_t>> tmp;
     for (uint32_t i = 0; i < s->n; ++i) {
         const uint32_t* w = s->h_words.data() + s->h_word_off[i];
@@ -208,6 +262,20 @@ int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
         for (auto& kv : tmp) { kcode.push_back(kv.first); kpos.push_back(kv.second); }
     }
     koff[s->n] = kcode.size();
+}
+
+// sorted 16-mer table of every sequence of the set (device code order: base t of the k-mer in bits 2t..2t+1)
+int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
+    if (s->has_index) return SP_OK;
+    hipSetDevice(ctx->device);
+    const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
+    if (s->h_words.empty()) {                              // packed on the device: fetch the packed words (and N plane) once
+        s->h_words.assign(plane_words * (s->has_n ? 2 : 1), 0);
+        hipMemcpy(s->h_words.data(), s->d_words, plane_words * 4, hipMemcpyDeviceToHost);
+        if (s->has_n) hipMemcpy(s->h_words.data() + plane_words, s->d_nplane, plane_words * 4, hipMemcpyDeviceToHost);
+    }
+    std::vector<uint64_t> koff; std::vector<uint32_t> kcode; std::vector<int32_t> kpos;
+    kmer_tables(s, koff, kcode, kpos);
     size_t ne = std::max<size_t>(1, kcode.size());
     if (hipMalloc(&s->d_kcode, ne * 4) != hipSuccess || hipMalloc(&s->d_kpos, ne * 4) != hipSuccess ||
         hipMalloc(&s->d_koff, koff.size() * 8) != hipSuccess)

@@ -839,10 +839,9 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
     coff[1] = blob.size();
     blob.append(cons_dna, cons_dna_len);
     coff[2] = blob.size();
-    sp_seqset* cons = nullptr;
-    int rc = sp_seqset_upload(ctx, blob.data(), coff, 2, &cons);
+    sp_seqset cons_set; sp_seqset* cons = &cons_set;       // pooled: no allocation, no free
+    int rc = sp_seqset_make_small(ctx, "k2_cons", blob.data(), coff, 2, true, cons);
     if (rc != SP_OK) return rc;
-    if ((rc = sp_seqset_build_index(ctx, cons)) != SP_OK) { sp_seqset_free(cons); return rc; }
     const uint32_t stride = SP_MAX_ED;
     std::vector<uint32_t> lvl0(n, 0u), lvl1(n, 1u);
     uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "k2_idx", (size_t)n * 4);
@@ -888,7 +887,6 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("score_consensus: ") + hipGetErrorString(e));
         else best->best_allele = b >= 0 ? (int32_t)idx[b] : -1;
     }
-    sp_seqset_free(cons);
     return rc;
 }
 
@@ -906,8 +904,8 @@ int32_t sp_hla_type_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
     if (consensus_len == 0) return SP_OK;                                  // failed consensus => unknown (caller.rs:1263-1267)
     // 1. place the consensus on the un-buffered gene reference
     uint64_t off[2] = {0, consensus_len};
-    sp_seqset* cons = nullptr;
-    int rc = sp_seqset_upload(ctx, consensus_fwd, off, 1, &cons);
+    sp_seqset cons_set; sp_seqset* cons = &cons_set;       // pooled: no allocation, no free
+    int rc = sp_seqset_make_small(ctx, "tc_cons", consensus_fwd, off, 1, false, cons);
     if (rc != SP_OK) return rc;
     const int reflen = db->ref_fwd->h_len[gene], buffer = db->ref_buffer;
     const int v_lo = buffer, v_hi = reflen - buffer;                        // region_sequence has no buffer (caller.rs:651-654)
@@ -917,7 +915,7 @@ int32_t sp_hla_type_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
     CellDesc* d_cell = (CellDesc*)sp_pool(ctx, "tc_cell", sizeof(CellDesc));
     sp_aln* d_aln = (sp_aln*)sp_pool(ctx, "tc_aln", sizeof(sp_aln));
     uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "tc_ev", SP_MAX_ED * 4);
-    if (!d_ab || !d_dv || !d_cell || !d_aln || !d_ev || v_hi <= v_lo) { sp_seqset_free(cons); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "type_consensus buffers"); }
+    if (!d_ab || !d_dv || !d_cell || !d_aln || !d_ev || v_hi <= v_lo) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "type_consensus buffers");
     (void)hipMemcpyAsync(d_ab, &a_idx, 4, hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemcpyAsync(d_ab + 1, &b_idx, 4, hipMemcpyHostToDevice, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
@@ -938,7 +936,6 @@ int32_t sp_hla_type_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
             (void)hipMemcpy(ev.data(), d_ev, SP_MAX_ED * 4, hipMemcpyDeviceToHost);
         }
     }
-    sp_seqset_free(cons);
     if (rc != SP_OK) return rc;
     // select_best_mapping(target-based, penalised) must beat the 1.0 default (util/mapping.rs:22-57, caller.rs:1289-1297)
     const int tlen = v_hi - v_lo;

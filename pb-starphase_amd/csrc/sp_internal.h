@@ -89,6 +89,7 @@ int sp_launch_pack(sp_ctx* ctx, const char* d_ascii, const uint64_t* d_off, cons
                    uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag);
 int sp_make_segments(sp_ctx* ctx, const sp_seqset* reads, const std::vector<uint32_t>& idx, const std::vector<int32_t>& start,
                      const std::vector<int32_t>& len, const char* prefix, sp_seqset* seg, sp_seqset* hpc);   // sp_hla_call.hip
+int sp_seqset_make_small(sp_ctx* ctx, const char* prefix, const char* bases, const uint64_t* offsets, uint32_t n, bool with_index, sp_seqset* out);   // pooled, never freed
 int sp_seqset_fetch_host(sp_ctx* ctx, sp_seqset* s);                      // packed words (and N plane) of a set on the host, fetched once
 std::string sp_seqset_decode(sp_ctx* ctx, const sp_seqset* s, uint32_t i); // ASCII of sequence i
 void* sp_scratch(sp_ctx* ctx, size_t bytes);
