@@ -46,6 +46,8 @@ void sp_ctx_destroy(sp_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     for (auto& kv : ctx->pool) if (kv.second.first) hipFree(kv.second.first);
+    sp_profile_flush(ctx);
+    for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -60,10 +62,11 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx) {
     return SP_OK;
 }
 
-int32_t sp_profile_reset(sp_ctx* ctx) { if (!ctx) return SP_ERR_INVALID_ARG; ctx->prof.clear(); return SP_OK; }
+int32_t sp_profile_reset(sp_ctx* ctx) { if (!ctx) return SP_ERR_INVALID_ARG; sp_profile_flush(ctx); ctx->prof.clear(); return SP_OK; }
 
 int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches, uint64_t* cells) {
     if (!ctx || !kernel) return SP_ERR_INVALID_ARG;
+    sp_profile_flush(ctx);
     auto it = ctx->prof.find(kernel);
     ProfileEntry e; if (it != ctx->prof.end()) e = it->second;
     if (total_ms) *total_ms = e.ms;
@@ -149,6 +152,16 @@ int32_t sp_seqset_length(const sp_seqset* s, uint32_t idx, uint32_t* len) {
 }
 
 } // extern "C"
+
+void sp_profile_flush(sp_ctx* ctx) {
+    for (auto& p : ctx->prof_pending) {
+        hipEventSynchronize(p.e1);
+        float ms = 0; hipEventElapsedTime(&ms, p.e0, p.e1);
+        auto& e = ctx->prof[p.name]; e.ms += ms; e.launches += 1; e.cells += p.cells;
+        ctx->prof_free.push_back(p.e0); ctx->prof_free.push_back(p.e1);
+    }
+    ctx->prof_pending.clear();
+}
 
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
 static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::vector<uint32_t>& kcode, std::vector<int32_t>& kpos);

@@ -63,6 +63,11 @@ struct sp_ctx {
     bool profiling = true;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, ProfileEntry> prof;
+    // timed regions whose events have been recorded but not read yet: reading them is put off until somebody asks for the numbers
+    // (or the list gets long), so that timing a kernel does not make the host wait for it
+    struct PendingProf { hipEvent_t e0, e1; const char* name; uint64_t cells; };
+    std::vector<PendingProf> prof_pending;
+    std::vector<hipEvent_t> prof_free;
     // reusable scratch
     void* scratch = nullptr; size_t scratch_bytes = 0;
     std::map<std::string, std::pair<void*, size_t>> pool;   // named grow-only device buffers (no malloc/free per call)
@@ -98,17 +103,20 @@ int   sp_fail(sp_ctx* ctx, int code, const std::string& msg);
 #define SP_HIP_CHECK(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
     return sp_fail((ctx), SP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
 
+void sp_profile_flush(sp_ctx* ctx);                                           // sp_api.hip
 struct ProfScope {
-    sp_ctx* ctx; const char* name; uint64_t cells;
+    sp_ctx* ctx; const char* name; uint64_t cells; hipEvent_t e0 = nullptr, e1 = nullptr;
     ProfScope(sp_ctx* c, const char* n, uint64_t cells_) : ctx(c), name(n), cells(cells_) {
-        if (ctx->profiling && name) hipEventRecord(ctx->ev0, ctx->stream);
+        if (!(ctx->profiling && name)) return;
+        auto take = [&]() { hipEvent_t e = nullptr; if (!ctx->prof_free.empty()) { e = ctx->prof_free.back(); ctx->prof_free.pop_back(); } else if (hipEventCreate(&e) != hipSuccess) e = nullptr; return e; };
+        e0 = take(); e1 = take();
+        if (e0 && e1) hipEventRecord(e0, ctx->stream);
     }
     ~ProfScope() {
-        if (ctx->profiling && name) {
-            hipEventRecord(ctx->ev1, ctx->stream);
-            hipEventSynchronize(ctx->ev1);
-            float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-            auto& e = ctx->prof[name]; e.ms += ms; e.launches += 1; e.cells += cells;
-        }
+        if (!(e0 && e1)) { if (e0) ctx->prof_free.push_back(e0); if (e1) ctx->prof_free.push_back(e1); return; }
+        hipEventRecord(e1, ctx->stream);
+        ctx->prof_pending.push_back({e0, e1, name, cells});
+        if (ctx->prof_pending.size() >= 2048) sp_profile_flush(ctx);
     }
 };
+
