@@ -34,6 +34,9 @@ struct sp_hla_db {
     uint32_t* d_gene_of = nullptr;
     int32_t*  d_off_fwd = nullptr;    // allele_fwd_pos - ref_fwd_pos (SP_NO_DIAG = no anchor)
     std::vector<uint32_t> h_order;
+    // allowed alleles of a gene in database order (is_allowed_allele_def), on the host and on the device, built on first use
+    struct GeneList { std::vector<uint32_t> idx; uint32_t* d_idx = nullptr; uint32_t* d_l0 = nullptr; uint32_t* d_l1 = nullptr; };
+    mutable std::map<uint32_t, GeneList> gene_lists;       // key = gene * 2 + require_dna
     uint32_t* d_order = nullptr;      // K1 visits the alleles sorted by (gene, frame offset, hg38-strand sequence) ...
     int32_t*  d_lcp = nullptr;        // ... d_lcp[i] = common prefix of order[i-1] and order[i] when they share gene and frame offset, else 0
     int32_t*  d_am = nullptr;         // n_alleles*3: ok, am.query_start, am.target_start (allele -> gene ref, realigner.rs:289-310)
@@ -569,6 +572,7 @@ void sp_hla_db_free(sp_hla_db* db) {
     sp_seqset_free(db->dna_gene); sp_seqset_free(db->cdna_gene); sp_seqset_free(db->dna_fwd); sp_seqset_free(db->ref_fwd);
     (void)hipFree(db->d_gene_of); (void)hipFree(db->d_off_fwd); (void)hipFree(db->d_am); (void)hipFree(db->d_order); (void)hipFree(db->d_lcp);
     (void)hipFree(db->d_hpc_ref); (void)hipFree(db->d_hpc_ref_off);
+    for (auto& kv : db->gene_lists) { (void)hipFree(kv.second.d_idx); (void)hipFree(kv.second.d_l0); (void)hipFree(kv.second.d_l1); }
     delete db;
 }
 
@@ -827,8 +831,14 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
     (void)hipSetDevice(ctx->device);
     best->best_allele = -1; best->n_scored = 0;
     // allowed alleles of the gene, database order (is_allowed_allele_def, caller.rs:1090-1095)
-    std::vector<uint32_t> idx;
-    for (uint32_t a : db->gene_alleles[gene]) if (db->has_dna[a] || !require_dna) idx.push_back(a);
+    sp_hla_db::GeneList& gl = db->gene_lists[gene * 2 + (require_dna ? 1u : 0u)];
+    if (!gl.d_idx) {
+        for (uint32_t a : db->gene_alleles[gene]) if (db->has_dna[a] || !require_dna) gl.idx.push_back(a);
+        std::vector<uint32_t> l0(gl.idx.size(), 0u), l1(gl.idx.size(), 1u);
+        gl.d_idx = dev_copy(gl.idx); gl.d_l0 = dev_copy(l0); gl.d_l1 = dev_copy(l1);
+        if (!gl.d_idx || !gl.d_l0 || !gl.d_l1) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus allele list");
+    }
+    const std::vector<uint32_t>& idx = gl.idx;
     const uint32_t n = (uint32_t)idx.size();
     best->n_scored = (int32_t)n;
     if (stats) for (uint32_t a = 0; a < db->n_alleles; ++a) for (int k = 0; k < 6; ++k) stats[(size_t)a * 6 + k] = -2;
@@ -843,9 +853,7 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
     int rc = sp_seqset_make_small(ctx, "k2_cons", blob.data(), coff, 2, true, cons);
     if (rc != SP_OK) return rc;
     const uint32_t stride = SP_MAX_ED;
-    std::vector<uint32_t> lvl0(n, 0u), lvl1(n, 1u);
-    uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "k2_idx", (size_t)n * 4);
-    uint32_t* d_l0 = (uint32_t*)sp_pool(ctx, "k2_l0", (size_t)n * 4); uint32_t* d_l1 = (uint32_t*)sp_pool(ctx, "k2_l1", (size_t)n * 4);
+    uint32_t* d_idx = gl.d_idx; uint32_t* d_l0 = gl.d_l0; uint32_t* d_l1 = gl.d_l1;
     int32_t* d_diag = (int32_t*)sp_pool(ctx, "k2_diag", (size_t)n * 4); int32_t* d_votes = (int32_t*)sp_pool(ctx, "k2_votes", (size_t)n * 4);
     int32_t* d_best = (int32_t*)sp_pool(ctx, "k2_best", 4);
     int32_t* d_stats = stats ? (int32_t*)sp_pool(ctx, "k2_stats", (size_t)db->n_alleles * 6 * 4) : nullptr;
@@ -855,12 +863,6 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
     K2Level* d_lv = (K2Level*)sp_pool(ctx, "k2_lv", (size_t)2 * n * sizeof(K2Level));
     if (!d_idx || !d_l0 || !d_l1 || !d_diag || !d_votes || !d_best || !d_cells || !d_alns || !d_ev || !d_lv || (stats && !d_stats))
         rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus buffers");
-    else {
-        (void)hipMemcpyAsync(d_idx, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
-        (void)hipMemcpyAsync(d_l0, lvl0.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
-        (void)hipMemcpyAsync(d_l1, lvl1.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream);
-    }
     const unsigned tb = 256, nb = (n + tb - 1) / tb;
     for (int L = 0; L < 2 && rc == SP_OK; ++L) {
         const sp_seqset* aset = L == 0 ? db->cdna_gene : db->dna_gene;
