@@ -488,6 +488,13 @@ int32_t sp_hla_diplotype_gene(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene, c
 int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_genes, const uint32_t* genes, const sp_seqset* reads,
                                const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
                                char* cons, uint32_t cap, uint8_t* is_cons1);
+/* a cohort at once: `reads` holds the reads of n_samples samples (read_sample[r] = sample of read r; one sp_hla_realign_reads call
+ * serves them all), and the consensus problems of every (sample, gene) advance in lockstep -- for WGS-sized samples a launch costs
+ * the same whether it serves one sample or dozens.  cfgs: n_genes entries; calls: n_samples * n_genes, sample-major;
+ * cons: n_samples * n_genes * 2 * cap bytes, laid out like calls. */
+int32_t sp_hla_diplotype_cohort(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_samples, const uint32_t* read_sample, uint32_t n_genes, const uint32_t* genes,
+                                const sp_seqset* reads, const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
+                                char* cons, uint32_t cap, uint8_t* is_cons1);
 
 /* ------------------------------------------------------------------ host-side decisions of the path (no device work)
  * Small scalar routines the reference evaluates between the kernels; kept behind the same ABI so a host can drop the whole

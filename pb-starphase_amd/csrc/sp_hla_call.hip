@@ -139,13 +139,11 @@ int sp_make_segments(sp_ctx* ctx, const sp_seqset* reads, const std::vector<uint
     return SP_OK;
 }
 
-extern "C" {
-
-int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_genes, const uint32_t* genes, const sp_seqset* reads,
+// the solve over units = (sample, gene) pairs; read_sample == nullptr: one sample, units are genes
+static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_genes, const uint32_t* genes, const uint32_t* unit_sample,
+                               const uint32_t* read_sample, const sp_seqset* reads,
                                const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
                                char* cons, uint32_t cap, uint8_t* is_cons1_out) {
-    if (!ctx) return SP_ERR_INVALID_ARG;
-    if (!db || !reads || !realign || !cfgs || !calls || !cons || !genes || cap == 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_genes: null argument");
     if (is_cons1_out) std::memset(is_cons1_out, 0, reads->n);
     struct Gene { uint32_t first = 0, n = 0; int is_dual = 0, pass = 0, hemi = 0, used_dna = 0; int32_t c1 = 0, c2 = 0; double maf = 0, cdf = 0; };
     std::vector<Gene> G(n_genes);
@@ -157,7 +155,8 @@ int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
         call.allele1 = call.allele2 = call.typed1 = call.typed2 = -1;
         cons[(size_t)(2 * k) * cap] = cons[(size_t)(2 * k + 1) * cap] = '\0';
         G[k].first = (uint32_t)sel.size();
-        for (uint32_t r = 0; r < reads->n; ++r) if (realign[r].status == 0 && realign[r].gene == (int32_t)genes[k]) sel.push_back(r);
+        for (uint32_t r = 0; r < reads->n; ++r)
+            if (realign[r].status == 0 && realign[r].gene == (int32_t)genes[k] && (!read_sample || read_sample[r] == unit_sample[k])) sel.push_back(r);
         G[k].n = (uint32_t)sel.size() - G[k].first;
         call.n_reads = (int32_t)G[k].n;
         if (G[k].n == 0) call.status = 1;                                          // NO_READS / NO_CALL (caller.rs:662-668)
@@ -302,6 +301,28 @@ int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
         if (is_cons1_out) for (uint32_t i = g.first; i < g.first + g.n; ++i) is_cons1_out[sel[i]] = is1[i];
     }
     return SP_OK;
+}
+
+extern "C" {
+
+int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_genes, const uint32_t* genes, const sp_seqset* reads,
+                               const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
+                               char* cons, uint32_t cap, uint8_t* is_cons1_out) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!db || !reads || !realign || !cfgs || !calls || !cons || !genes || cap == 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_genes: null argument");
+    return hla_solve_units(ctx, db, n_genes, genes, nullptr, nullptr, reads, realign, cfgs, calls, cons, cap, is_cons1_out);
+}
+
+int32_t sp_hla_diplotype_cohort(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_samples, const uint32_t* read_sample, uint32_t n_genes, const uint32_t* genes,
+                                const sp_seqset* reads, const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
+                                char* cons, uint32_t cap, uint8_t* is_cons1_out) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!db || !reads || !realign || !cfgs || !calls || !cons || !genes || !read_sample || cap == 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_cohort: null argument");
+    for (uint32_t r = 0; r < reads->n; ++r) if (read_sample[r] >= n_samples) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_cohort: sample index out of range");
+    const uint32_t units = n_samples * n_genes;
+    std::vector<uint32_t> ug(units), us(units); std::vector<sp_hla_call_config> uc(units);
+    for (uint32_t s = 0; s < n_samples; ++s) for (uint32_t g = 0; g < n_genes; ++g) { ug[s * n_genes + g] = genes[g]; us[s * n_genes + g] = s; uc[s * n_genes + g] = cfgs[g]; }
+    return hla_solve_units(ctx, db, units, ug.data(), us.data(), read_sample, reads, realign, uc.data(), calls, cons, cap, is_cons1_out);
 }
 
 int32_t sp_hla_diplotype_gene(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene, const sp_seqset* reads, const sp_hla_realign* realign,

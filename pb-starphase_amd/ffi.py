@@ -222,6 +222,7 @@ def lib():
         "sp_consensus_priority": (i32, [vp, C.POINTER(sp_priority_problem), u32, u32, C.POINTER(u32), vp, C.c_char_p]),
         "sp_hla_diplotype_gene": (i32, [vp, vp, u32, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, C.c_char_p, u32, vp]),
         "sp_hla_diplotype_genes": (i32, [vp, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
+        "sp_hla_diplotype_cohort": (i32, [vp, vp, u32, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -653,6 +654,20 @@ class HlaDb:
         self.ctx.check(lib().sp_hla_diplotype_genes(self.ctx._h, self._h, k, _ptr(g), reads._h, _ptr(realign), cf, calls, buf, cap, _ptr(is1)))
         text = lambda j: buf.raw[j * cap:(j + 1) * cap].split(b"\0", 1)[0].decode()
         return [(calls[i], text(2 * i), text(2 * i + 1)) for i in range(k)], is1[:reads.n].astype(bool)
+
+    def diplotype_cohort(self, n_samples, read_sample, genes, reads, realign, cfgs=None, cap=16384):
+        """sp_hla_diplotype_cohort -> calls[sample][gene] = (sp_hla_call, consensus1, consensus2), and is_consensus1 per read"""
+        k = len(genes)
+        g = np.ascontiguousarray(genes, np.uint32)
+        rs = np.ascontiguousarray(read_sample, np.uint32)
+        cf = (sp_hla_call_config * k)(*[(cfgs[i] if cfgs else hla_call_config()) for i in range(k)])
+        calls = (sp_hla_call * (k * n_samples))()
+        buf = C.create_string_buffer(2 * k * n_samples * cap)
+        is1 = np.zeros(max(1, reads.n), np.uint8)
+        realign = np.ascontiguousarray(realign)
+        self.ctx.check(lib().sp_hla_diplotype_cohort(self.ctx._h, self._h, n_samples, _ptr(rs), k, _ptr(g), reads._h, _ptr(realign), cf, calls, buf, cap, _ptr(is1)))
+        text = lambda j: buf.raw[j * cap:(j + 1) * cap].split(b"\0", 1)[0].decode()
+        return [[(calls[s * k + i], text(2 * (s * k + i)), text(2 * (s * k + i) + 1)) for i in range(k)] for s in range(n_samples)], is1[:reads.n].astype(bool)
 
     def type_consensus(self, gene, consensus_fwd, require_dna=False, disable_cdna=False, stats=True):
         """score_consensus of the reference: hg38-forward consensus in, best allele + spliced gene-strand cDNA out"""

@@ -66,3 +66,44 @@ def test_reads_to_diplotype(oracle, pkg, gpu_ctx, scenario):
     empty = gpu_ctx.upload(["ACGT" * 200])
     call, c1, c2, _ = db.diplotype_gene(0, empty, db.realign_reads(empty))
     assert call.status == 1 and call.n_reads == 0 and (c1, c2) == ("", "")
+
+
+def test_cohort_equals_sample_by_sample(oracle, pkg, gpu_ctx):
+    """BASELINE configs[4] in miniature: several WGS-sized samples in one read set, one realignment call, every (sample, gene)
+    consensus problem in lockstep (sp_hla_diplotype_cohort) -- the same calls and consensuses as one sample at a time, and the truth"""
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture()
+    db = fx.make_db(pkg, gpu_ctx)
+    rng = np.random.default_rng(99)
+    n_samples = 5
+    reads, sample_of, truth = [], [], []
+    for s in range(n_samples):
+        t = {}
+        for g in range(len(fx.genes)):
+            pick = rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist()
+            if s == 3 and g == 1:
+                pick = [pick[0], pick[0]]                          # one homozygous gene
+            t[g] = sorted(pick)
+            for a in pick:
+                hap, st = fx.haplotype(g, a)
+                rs = synth.simulate_reads(rng, hap, st, len(fx.dna[a]), 20, mean_len=7000, sd_len=1500, min_overlap=2500)
+                reads += rs; sample_of += [s] * len(rs)
+        truth.append(t)
+    order = rng.permutation(len(reads))
+    reads, sample_of = [reads[i] for i in order], [sample_of[i] for i in order]
+    R = gpu_ctx.upload(reads)
+    k1 = db.realign_reads(R)
+    genes = list(range(len(fx.genes)))
+    cohort, is1 = db.diplotype_cohort(n_samples, sample_of, genes, R, k1)
+    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+    for s in range(n_samples):
+        mine = [i for i, x in enumerate(sample_of) if x == s]
+        Rs = gpu_ctx.upload([reads[i] for i in mine])
+        alone, is1_s = db.diplotype_genes(genes, Rs, db.realign_reads(Rs))
+        for g in genes:
+            c, c1, c2 = cohort[s][g]
+            a, a1, a2 = alone[g]
+            assert (c1, c2) == (a1, a2) and bytes(c) == bytes(a)
+            got, want = sorted([c.allele1, c.allele2]), truth[s][g]
+            assert all(same(x, y) for x, y in zip(got, want)) or all(same(x, y) for x, y in zip(got, want[::-1])), (s, g, got, want)
+        assert is1[mine].tolist() == is1_s.tolist()
