@@ -145,10 +145,7 @@ def main():
 
     def step():
         out = db.realign_reads(reads)
-        calls = []
-        for (g, cons_dna, cons_cdna, _a) in wl.consensus:
-            b, _n, _s = db.score_consensus(g, cons_dna, cons_cdna, stats=False)
-            calls.append(b)
+        calls = [b for b, _n in db.score_consensus_batch([(g, cons_dna, cons_cdna) for (g, cons_dna, cons_cdna, _a) in wl.consensus])]
         if world > 1:
             # RCCL: the only exchange step of the path -- one gather of the per-(sample, gene) call records
             rec = np.zeros(len(fx.genes), shard.CALL_DTYPE)

@@ -188,6 +188,13 @@ int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
                                int32_t require_dna, int32_t disable_cdna,
                                sp_hla_best* best, int32_t* stats);
 
+/* the same for n consensuses at once (different genes allowed): every (consensus, allele) pair of a level is one cell of one launch,
+ * one scan workgroup per consensus.  No per-allele statistics in the batched form. */
+int32_t sp_hla_score_consensus_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n, const uint32_t* genes,
+                                     const char* const* cons_dna, const uint32_t* cons_dna_len,
+                                     const char* const* cons_cdna, const uint32_t* cons_cdna_len,
+                                     int32_t require_dna, int32_t disable_cdna, sp_hla_best* best /* n */);
+
 /* Replaces score_consensus (src/hla/caller.rs:1258-1319) + splice_read (:1518-1576): the hg38-forward consensus is
  * placed on the un-buffered gene reference (GPU alignment with traceback), its exon bases are spliced out through the
  * aligned pairs, both sequences are put on the gene strand and handed to the K2 scoring above.
@@ -198,6 +205,12 @@ int32_t sp_hla_type_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
                               int32_t require_dna, int32_t disable_cdna,
                               sp_hla_best* best, int32_t* stats,
                               char* cdna_out, uint32_t cdna_cap, uint32_t* cdna_len);
+
+/* n hg38-forward consensuses at once: one placement launch, host splicing, one batched K2 (the gene drivers type all the
+ * consensuses of a sample / cohort this way). */
+int32_t sp_hla_type_consensus_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n, const uint32_t* genes,
+                                    const char* const* consensus_fwd, const uint32_t* consensus_len,
+                                    int32_t require_dna, int32_t disable_cdna, sp_hla_best* best /* n */);
 
 /* ------------------------------------------------------------------ K5: CYP2D6 chain-pair likelihood search
  * Replaces find_best_chain_pair (src/cyp2d6/chaining.rs:223-592) with containment_score (:683-731),

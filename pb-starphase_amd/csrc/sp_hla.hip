@@ -411,13 +411,13 @@ struct K2Level {           // one level of an HlaProcessedMatch (processed_match
 };
 
 // build the cell list of one level from the anchor votes (A = consensus set idx level, B = allele)
-__global__ void k2_build_cells_kernel(const uint32_t* __restrict__ allele_idx, uint32_t n, uint32_t cons_idx,
+__global__ void k2_build_cells_kernel(const uint32_t* __restrict__ allele_idx, uint32_t n, const uint32_t* __restrict__ cons_idx,
                                       const int32_t* __restrict__ anchor_diag, const int32_t* __restrict__ anchor_votes,
                                       const int32_t* __restrict__ allele_len, CellDesc* __restrict__ cells) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     CellDesc c;
-    c.a = allele_idx[i]; c.b = cons_idx; c.max_ed = SP_MAX_ED; c.b_lo = 0; c.b_hi = -1;
+    c.a = allele_idx[i]; c.b = cons_idx[i]; c.max_ed = SP_MAX_ED; c.b_lo = 0; c.b_hi = -1;
     // anchor diag = allele_pos - cons_pos ; cell diag = cons_pos - allele_pos
     c.diag = (allele_len[c.a] > 0 && anchor_votes[i] >= K2_MIN_VOTES) ? -anchor_diag[i] : SP_NO_DIAG;
     cells[i] = c;
@@ -477,9 +477,11 @@ __device__ __forceinline__ bool k2_score_less(const K2Level* l, const K2Level* r
 // Sequential running-best scan of score_read (caller.rs:1411-1500) evaluated in parallel: the block looks for
 // the first candidate after `pos` that beats the current best, adopts it, and continues behind it.
 // lv / alns / ev are laid out [level][i].
-__global__ __launch_bounds__(1024) void k2_scan_kernel(const K2Level* __restrict__ lv, const sp_aln* __restrict__ alns,
-                                                       const uint32_t* __restrict__ ev, uint32_t ev_stride, uint32_t n,
-                                                       int32_t* __restrict__ best_out) {
+// one workgroup per consensus: its candidates are entries [seg_off[b], seg_off[b+1]) of the batch (level arrays laid out [2][total])
+__global__ __launch_bounds__(1024) void k2_scan_kernel(const K2Level* __restrict__ lv_all, const sp_aln* __restrict__ alns_all,
+                                                       const uint32_t* __restrict__ ev_all, uint32_t ev_stride, uint32_t total,
+                                                       const uint32_t* __restrict__ seg_off, int32_t* __restrict__ best_out) {
+    const uint32_t seg = seg_off[blockIdx.x], n = seg_off[blockIdx.x + 1] - seg;
     __shared__ K2Level bl[2];
     __shared__ sp_aln ba[2];
     __shared__ uint32_t bev[2][SP_MAX_ED + 1];
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(1024) void k2_scan_kernel(const K2Level* __restrict
         const uint32_t i = pos + tid;
         bool better = false;
         if (i < n) {
-            K2Level cl[2] = { lv[i], lv[n + i] };
+            K2Level cl[2] = { lv_all[seg + i], lv_all[(uint64_t)total + seg + i] };
             bool decided = false;
             for (int L = 0; L < 2 && !decided; ++L) {
                 if (cl[L].present && bl[L].present) {
@@ -504,8 +506,8 @@ __global__ __launch_bounds__(1024) void k2_scan_kernel(const K2Level* __restrict
                     int oe = cl[L].range_end < bl[L].range_end ? cl[L].range_end : bl[L].range_end;
                     int cn = 0, bn = 0;
                     if (os < oe) {
-                        const sp_aln ca = alns[(uint64_t)L * n + i];
-                        cn = k2_range_edits(cl[L], ca, ev + ((uint64_t)L * n + i) * ev_stride, os, oe);
+                        const sp_aln ca = alns_all[(uint64_t)L * total + seg + i];
+                        cn = k2_range_edits(cl[L], ca, ev_all + ((uint64_t)L * total + seg + i) * ev_stride, os, oe);
                         bn = k2_range_edits(bl[L], ba[L], bev[L], os, oe);
                     }
                     if (cn < bn) { better = true; decided = true; }
@@ -519,10 +521,10 @@ __global__ __launch_bounds__(1024) void k2_scan_kernel(const K2Level* __restrict
         __syncthreads();
         const int first = s_first;
         if (first != 0x7FFFFFFF) {
-            if (tid < 2) { bl[tid] = lv[(uint64_t)tid * n + first]; ba[tid] = alns[(uint64_t)tid * n + first]; }
+            if (tid < 2) { bl[tid] = lv_all[(uint64_t)tid * total + seg + first]; ba[tid] = alns_all[(uint64_t)tid * total + seg + first]; }
             for (int x = tid; x < 2 * (SP_MAX_ED + 1); x += 1024) {
                 int L = x / (SP_MAX_ED + 1), y = x % (SP_MAX_ED + 1);
-                bev[L][y] = (uint32_t)y < ev_stride ? ev[((uint64_t)L * n + first) * ev_stride + y] : 0;
+                bev[L][y] = (uint32_t)y < ev_stride ? ev_all[((uint64_t)L * total + seg + first) * ev_stride + y] : 0;
             }
             if (tid == 0) s_best = first;
             pos = (uint32_t)first + 1;
@@ -531,15 +533,15 @@ __global__ __launch_bounds__(1024) void k2_scan_kernel(const K2Level* __restrict
         }
         __syncthreads();
     }
-    if (tid == 0) best_out[0] = s_best;
+    if (tid == 0) best_out[blockIdx.x] = s_best;
 }
 
-__global__ void k2_stats_kernel(const K2Level* __restrict__ lv, uint32_t n, const uint32_t* __restrict__ allele_idx, int32_t* __restrict__ stats) {
+__global__ void k2_stats_kernel(const K2Level* __restrict__ lv, uint32_t total, uint32_t seg, uint32_t n, const uint32_t* __restrict__ allele_idx, int32_t* __restrict__ stats) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int32_t* s = stats + (uint64_t)allele_idx[i] * 6;
+    int32_t* s = stats + (uint64_t)allele_idx[seg + i] * 6;
     for (int L = 0; L < 2; ++L) {
-        K2Level l = lv[(uint64_t)L * n + i];
+        K2Level l = lv[(uint64_t)L * total + seg + i];
         s[L * 3 + 0] = l.present ? l.len : -1; s[L * 3 + 1] = l.present ? l.nm : -1; s[L * 3 + 2] = l.present ? l.unmapped : -1;
     }
 }
@@ -822,76 +824,216 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
     return rc;
 }
 
-int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
-                               const char* cons_dna, uint32_t cons_dna_len, const char* cons_cdna, uint32_t cons_cdna_len,
-                               int32_t require_dna, int32_t disable_cdna, sp_hla_best* best, int32_t* stats) {
-    if (!ctx || !db || !best || gene >= db->n_genes || (cons_dna_len && !cons_dna) || (cons_cdna_len && !cons_cdna)) return SP_ERR_INVALID_ARG;
+// K2 for a batch of consensuses: every (consensus, allowed allele) pair of a level is one cell of one launch, one scan workgroup
+// per consensus.  items: gene, gene-strand DNA consensus, spliced cDNA consensus.  stats (optional): per item n_alleles * 6.
+struct K2Item { uint32_t gene; const char* dna; uint32_t dna_len; const char* cdna; uint32_t cdna_len; };
+static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items, const K2Item* items, int32_t require_dna, int32_t disable_cdna,
+                              sp_hla_best* best, int32_t* const* stats) {
     // "If cDNA scoring is disabled, require HLA DNA must be enabled" (caller.rs:517-520)
     if (disable_cdna && !require_dna) return sp_fail(ctx, SP_ERR_INVALID_ARG, "If cDNA scoring is disabled, require HLA DNA must be enabled");
     (void)hipSetDevice(ctx->device);
-    best->best_allele = -1; best->n_scored = 0;
-    // allowed alleles of the gene, database order (is_allowed_allele_def, caller.rs:1090-1095)
-    sp_hla_db::GeneList& gl = db->gene_lists[gene * 2 + (require_dna ? 1u : 0u)];
-    if (!gl.d_idx) {
-        for (uint32_t a : db->gene_alleles[gene]) if (db->has_dna[a] || !require_dna) gl.idx.push_back(a);
-        std::vector<uint32_t> l0(gl.idx.size(), 0u), l1(gl.idx.size(), 1u);
-        gl.d_idx = dev_copy(gl.idx); gl.d_l0 = dev_copy(l0); gl.d_l1 = dev_copy(l1);
-        if (!gl.d_idx || !gl.d_l0 || !gl.d_l1) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus allele list");
+    // allowed alleles of each item's gene, database order (is_allowed_allele_def, caller.rs:1090-1095)
+    std::vector<const sp_hla_db::GeneList*> lists(n_items);
+    std::vector<uint32_t> seg_off(n_items + 1, 0), h_idx, h_c0, h_c1;
+    std::string blob; std::vector<uint64_t> coff(1, 0);
+    for (uint32_t k = 0; k < n_items; ++k) {
+        if (items[k].gene >= db->n_genes) return sp_fail(ctx, SP_ERR_INVALID_ARG, "score_consensus: gene out of range");
+        sp_hla_db::GeneList& gl = db->gene_lists[items[k].gene * 2 + (require_dna ? 1u : 0u)];
+        if (gl.idx.empty() && !gl.d_idx) { for (uint32_t a : db->gene_alleles[items[k].gene]) if (db->has_dna[a] || !require_dna) gl.idx.push_back(a); gl.d_idx = dev_copy(gl.idx); }
+        lists[k] = &gl;
+        best[k].best_allele = -1; best[k].n_scored = (int32_t)gl.idx.size();
+        if (stats && stats[k]) for (uint32_t a = 0; a < db->n_alleles; ++a) for (int x = 0; x < 6; ++x) stats[k][(size_t)a * 6 + x] = -2;
+        seg_off[k + 1] = seg_off[k] + (uint32_t)gl.idx.size();
+        h_idx.insert(h_idx.end(), gl.idx.begin(), gl.idx.end());
+        h_c0.insert(h_c0.end(), gl.idx.size(), 2 * k); h_c1.insert(h_c1.end(), gl.idx.size(), 2 * k + 1);
+        // consensus set: [2k] = cDNA, [2k+1] = DNA
+        if (!disable_cdna) blob.append(items[k].cdna, items[k].cdna_len);
+        coff.push_back(blob.size());
+        blob.append(items[k].dna, items[k].dna_len);
+        coff.push_back(blob.size());
     }
-    const std::vector<uint32_t>& idx = gl.idx;
-    const uint32_t n = (uint32_t)idx.size();
-    best->n_scored = (int32_t)n;
-    if (stats) for (uint32_t a = 0; a < db->n_alleles; ++a) for (int k = 0; k < 6; ++k) stats[(size_t)a * 6 + k] = -2;
-    if (n == 0) return SP_OK;
-    // consensus set: [0] = cDNA, [1] = DNA
-    std::string blob; uint64_t coff[3] = {0, 0, 0};
-    if (!disable_cdna) blob.append(cons_cdna, cons_cdna_len);
-    coff[1] = blob.size();
-    blob.append(cons_dna, cons_dna_len);
-    coff[2] = blob.size();
+    const uint32_t T = seg_off[n_items];
+    if (T == 0) return SP_OK;
     sp_seqset cons_set; sp_seqset* cons = &cons_set;       // pooled: no allocation, no free
-    int rc = sp_seqset_make_small(ctx, "k2_cons", blob.data(), coff, 2, true, cons);
+    int rc = sp_seqset_make_small(ctx, "k2_cons", blob.data(), coff.data(), 2 * n_items, true, cons);
     if (rc != SP_OK) return rc;
     const uint32_t stride = SP_MAX_ED;
-    uint32_t* d_idx = gl.d_idx; uint32_t* d_l0 = gl.d_l0; uint32_t* d_l1 = gl.d_l1;
-    int32_t* d_diag = (int32_t*)sp_pool(ctx, "k2_diag", (size_t)n * 4); int32_t* d_votes = (int32_t*)sp_pool(ctx, "k2_votes", (size_t)n * 4);
-    int32_t* d_best = (int32_t*)sp_pool(ctx, "k2_best", 4);
-    int32_t* d_stats = stats ? (int32_t*)sp_pool(ctx, "k2_stats", (size_t)db->n_alleles * 6 * 4) : nullptr;
-    CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k2_cells", (size_t)n * sizeof(CellDesc));
-    sp_aln* d_alns = (sp_aln*)sp_pool(ctx, "k2_alns", (size_t)2 * n * sizeof(sp_aln));
-    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "k2_ev", (size_t)2 * n * stride * 4);
-    K2Level* d_lv = (K2Level*)sp_pool(ctx, "k2_lv", (size_t)2 * n * sizeof(K2Level));
-    if (!d_idx || !d_l0 || !d_l1 || !d_diag || !d_votes || !d_best || !d_cells || !d_alns || !d_ev || !d_lv || (stats && !d_stats))
-        rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus buffers");
-    const unsigned tb = 256, nb = (n + tb - 1) / tb;
+    uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "k2_idx", (size_t)T * 4);
+    uint32_t* d_c0 = (uint32_t*)sp_pool(ctx, "k2_l0", (size_t)T * 4); uint32_t* d_c1 = (uint32_t*)sp_pool(ctx, "k2_l1", (size_t)T * 4);
+    uint32_t* d_seg = (uint32_t*)sp_pool(ctx, "k2_seg", (size_t)(n_items + 1) * 4);
+    int32_t* d_diag = (int32_t*)sp_pool(ctx, "k2_diag", (size_t)T * 4); int32_t* d_votes = (int32_t*)sp_pool(ctx, "k2_votes", (size_t)T * 4);
+    int32_t* d_best = (int32_t*)sp_pool(ctx, "k2_best", (size_t)n_items * 4);
+    CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k2_cells", (size_t)T * sizeof(CellDesc));
+    sp_aln* d_alns = (sp_aln*)sp_pool(ctx, "k2_alns", (size_t)2 * T * sizeof(sp_aln));
+    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "k2_ev", (size_t)2 * T * stride * 4);
+    K2Level* d_lv = (K2Level*)sp_pool(ctx, "k2_lv", (size_t)2 * T * sizeof(K2Level));
+    if (!d_idx || !d_c0 || !d_c1 || !d_seg || !d_diag || !d_votes || !d_best || !d_cells || !d_alns || !d_ev || !d_lv)
+        return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus buffers");
+    (void)hipMemcpyAsync(d_idx, h_idx.data(), (size_t)T * 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_c0, h_c0.data(), (size_t)T * 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_c1, h_c1.data(), (size_t)T * 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_seg, seg_off.data(), (size_t)(n_items + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    const unsigned tb = 256, nb = (T + tb - 1) / tb;
     for (int L = 0; L < 2 && rc == SP_OK; ++L) {
         const sp_seqset* aset = L == 0 ? db->cdna_gene : db->dna_gene;
-        rc = sp_launch_anchor(ctx, cons, aset, L == 0 ? d_l0 : d_l1, d_idx, n, d_diag, d_votes);
+        const uint32_t* d_c = L == 0 ? d_c0 : d_c1;
+        rc = sp_launch_anchor(ctx, cons, aset, d_c, d_idx, T, d_diag, d_votes);
         if (rc != SP_OK) break;
-        hipLaunchKernelGGL(k2_build_cells_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_idx, n, (uint32_t)L, d_diag, d_votes, aset->d_len, d_cells);
-        rc = sp_launch_cells(ctx, aset, cons, d_cells, n, d_alns + (size_t)L * n, d_ev + (size_t)L * n * stride, stride, L == 0 ? "k2_cells_cdna" : "k2_cells_dna");
+        hipLaunchKernelGGL(k2_build_cells_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_idx, T, d_c, d_diag, d_votes, aset->d_len, d_cells);
+        rc = sp_launch_cells(ctx, aset, cons, d_cells, T, d_alns + (size_t)L * T, d_ev + (size_t)L * T * stride, stride, L == 0 ? "k2_cells_cdna" : "k2_cells_dna");
         if (rc != SP_OK) break;
-        hipLaunchKernelGGL(k2_levels_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_alns + (size_t)L * n, n, d_lv + (size_t)L * n);
+        hipLaunchKernelGGL(k2_levels_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_alns + (size_t)L * T, T, d_lv + (size_t)L * T);
     }
     if (rc == SP_OK) {
-        ProfScope ps(ctx, "k2_scan", n);
-        hipLaunchKernelGGL(k2_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_lv, d_alns, d_ev, stride, n, d_best);
+        ProfScope ps(ctx, "k2_scan", T);
+        hipLaunchKernelGGL(k2_scan_kernel, dim3(n_items), dim3(1024), 0, ctx->stream, d_lv, d_alns, d_ev, stride, T, d_seg, d_best);
     }
     if (rc == SP_OK && stats) {
-        (void)hipMemcpyAsync(d_stats, stats, (size_t)db->n_alleles * 6 * 4, hipMemcpyHostToDevice, ctx->stream);
-        hipLaunchKernelGGL(k2_stats_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_lv, n, d_idx, d_stats);
-        (void)hipMemcpyAsync(stats, d_stats, (size_t)db->n_alleles * 6 * 4, hipMemcpyDeviceToHost, ctx->stream);
+        int32_t* d_stats = (int32_t*)sp_pool(ctx, "k2_stats", (size_t)db->n_alleles * 6 * 4);
+        if (!d_stats) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus stats");
+        for (uint32_t k = 0; k < n_items; ++k) if (stats[k]) {
+            const uint32_t n = seg_off[k + 1] - seg_off[k];
+            (void)hipMemcpyAsync(d_stats, stats[k], (size_t)db->n_alleles * 6 * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (n) hipLaunchKernelGGL(k2_stats_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, ctx->stream, d_lv, T, seg_off[k], n, d_idx, d_stats);
+            (void)hipMemcpyAsync(stats[k], d_stats, (size_t)db->n_alleles * 6 * 4, hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
     }
     if (rc == SP_OK) {
-        int32_t b = -1;
-        (void)hipMemcpyAsync(&b, d_best, 4, hipMemcpyDeviceToHost, ctx->stream);
+        std::vector<int32_t> b(n_items, -1);
+        (void)hipMemcpyAsync(b.data(), d_best, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("score_consensus: ") + hipGetErrorString(e));
-        else best->best_allele = b >= 0 ? (int32_t)idx[b] : -1;
+        else for (uint32_t k = 0; k < n_items; ++k) best[k].best_allele = b[k] >= 0 ? (int32_t)lists[k]->idx[b[k]] : -1;
     }
     return rc;
 }
 
+int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
+                               const char* cons_dna, uint32_t cons_dna_len, const char* cons_cdna, uint32_t cons_cdna_len,
+                               int32_t require_dna, int32_t disable_cdna, sp_hla_best* best, int32_t* stats) {
+    if (!ctx || !db || !best || gene >= db->n_genes || (cons_dna_len && !cons_dna) || (cons_cdna_len && !cons_cdna)) return SP_ERR_INVALID_ARG;
+    const K2Item item{ gene, cons_dna, cons_dna_len, cons_cdna, cons_cdna_len };
+    int32_t* st[1] = { stats };
+    return k2_score_batch(ctx, db, 1, &item, require_dna, disable_cdna, best, stats ? st : nullptr);
+}
+
+int32_t sp_hla_score_consensus_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n, const uint32_t* genes,
+                                     const char* const* cons_dna, const uint32_t* cons_dna_len, const char* const* cons_cdna, const uint32_t* cons_cdna_len,
+                                     int32_t require_dna, int32_t disable_cdna, sp_hla_best* best) {
+    if (!ctx || !db || (n && (!genes || !cons_dna || !cons_dna_len || !cons_cdna || !cons_cdna_len || !best))) return SP_ERR_INVALID_ARG;
+    std::vector<K2Item> items(n);
+    for (uint32_t k = 0; k < n; ++k) items[k] = K2Item{ genes[k], cons_dna[k], cons_dna_len[k], cons_cdna[k], cons_cdna_len[k] };
+    return n ? k2_score_batch(ctx, db, n, items.data(), require_dna, disable_cdna, best, nullptr) : SP_OK;
+}
+
+
+// score_consensus + splice_read for a batch of hg38-forward consensuses: all placements on the gene references are one anchor launch
+// and one traced cell launch, the splicing is host work on the event lists, and the typing is one k2_score_batch.
+struct TypeItem { uint32_t gene; const char* cons; uint32_t len; };
+static int32_t type_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items, const TypeItem* items, int32_t require_dna, int32_t disable_cdna,
+                          sp_hla_best* best, int32_t* const* stats, std::vector<std::string>* cdna_out) {
+    (void)hipSetDevice(ctx->device);
+    for (uint32_t k = 0; k < n_items; ++k) {
+        if (items[k].gene >= db->n_genes || (items[k].len && !items[k].cons)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "type_consensus: bad item");
+        best[k].best_allele = -1; best[k].n_scored = 0;
+        if (stats && stats[k]) for (uint32_t a = 0; a < db->n_alleles; ++a) for (int x = 0; x < 6; ++x) stats[k][(size_t)a * 6 + x] = -2;
+    }
+    if (cdna_out) cdna_out->assign(n_items, std::string());
+    // 1. place every non-empty consensus on its un-buffered gene reference (an empty one is a failed consensus: unknown, caller.rs:1263-1267)
+    std::vector<uint32_t> live;
+    std::string blob; std::vector<uint64_t> off(1, 0);
+    for (uint32_t k = 0; k < n_items; ++k) if (items[k].len) { live.push_back(k); blob.append(items[k].cons, items[k].len); off.push_back(blob.size()); }
+    const uint32_t n = (uint32_t)live.size();
+    if (n == 0) return SP_OK;
+    sp_seqset cons_set; sp_seqset* cons = &cons_set;       // pooled: no allocation, no free
+    int rc = sp_seqset_make_small(ctx, "tc_cons", blob.data(), off.data(), n, false, cons);
+    if (rc != SP_OK) return rc;
+    const int buffer = db->ref_buffer;
+    std::vector<uint32_t> a_idx(n), b_idx(n);
+    for (uint32_t x = 0; x < n; ++x) { a_idx[x] = items[live[x]].gene; b_idx[x] = x; }
+    uint32_t* d_ab = (uint32_t*)sp_pool(ctx, "tc_idx", (size_t)2 * n * 4);
+    int32_t* d_dv = (int32_t*)sp_pool(ctx, "tc_dv", (size_t)2 * n * 4);
+    CellDesc* d_cell = (CellDesc*)sp_pool(ctx, "tc_cell", (size_t)n * sizeof(CellDesc));
+    sp_aln* d_aln = (sp_aln*)sp_pool(ctx, "tc_aln", (size_t)n * sizeof(sp_aln));
+    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "tc_ev", (size_t)n * SP_MAX_ED * 4);
+    if (!d_ab || !d_dv || !d_cell || !d_aln || !d_ev) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "type_consensus buffers");
+    (void)hipMemcpyAsync(d_ab, a_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_ab + n, b_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    rc = sp_launch_anchor(ctx, db->ref_fwd, cons, d_ab, d_ab + n, n, d_dv, d_dv + n);
+    if (rc != SP_OK) return rc;
+    std::vector<int32_t> dv((size_t)2 * n);
+    (void)hipMemcpyAsync(dv.data(), d_dv, (size_t)2 * n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    std::vector<CellDesc> cells(n);
+    for (uint32_t x = 0; x < n; ++x) {
+        const uint32_t gene = items[live[x]].gene;
+        const int v_lo = buffer, v_hi = db->ref_fwd->h_len[gene] - buffer;          // region_sequence has no buffer (caller.rs:651-654)
+        if (v_hi <= v_lo) return sp_fail(ctx, SP_ERR_INVALID_ARG, "type_consensus: reference shorter than its buffer");
+        // dv[x] = cons_pos - ref_pos (buffered reference); cell: A = consensus, B = reference view [v_lo, v_hi)
+        cells[x] = CellDesc{ x, gene, dv[n + x] >= K2_MIN_VOTES ? -dv[x] - v_lo : SP_NO_DIAG, SP_MAX_ED, v_lo, v_hi };
+    }
+    (void)hipMemcpyAsync(d_cell, cells.data(), (size_t)n * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemsetAsync(d_ev, 0, (size_t)n * SP_MAX_ED * 4, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    rc = sp_launch_cells(ctx, cons, db->ref_fwd, d_cell, n, d_aln, d_ev, SP_MAX_ED, "type_consensus_ref");
+    if (rc != SP_OK) return rc;
+    std::vector<sp_aln> alns(n); std::vector<uint32_t> evs((size_t)n * SP_MAX_ED);
+    (void)hipMemcpyAsync(alns.data(), d_aln, (size_t)n * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(evs.data(), d_ev, (size_t)n * SP_MAX_ED * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "type_consensus placement");
+    // 2. splice, put on the gene strand
+    std::vector<std::string> dna_g(n), cdna_g(n); std::vector<K2Item> k2; std::vector<uint32_t> k2_of;
+    for (uint32_t x = 0; x < n; ++x) {
+        const TypeItem& it = items[live[x]];
+        const uint32_t gene = it.gene;
+        const sp_aln& aln = alns[x]; const uint32_t* ev = evs.data() + (size_t)x * SP_MAX_ED;
+        const int v_lo = buffer, v_hi = db->ref_fwd->h_len[gene] - buffer, tlen = v_hi - v_lo;
+        // select_best_mapping(target-based, penalised) must beat the 1.0 default (util/mapping.rs:22-57, caller.rs:1289-1297)
+        bool mapped = aln.ok != 0;
+        if (mapped) { double num = (double)(aln.nm + (tlen - (aln.b_end - aln.b_start))); if (num < 0.1) num = 0.1; mapped = num / (double)tlen < 1.0; }
+        if (!mapped) continue;                                             // "Failed to align consensus to reference genome" (caller.rs:1282-1287)
+        // aligned pairs of the consensus record: reference view position -> consensus position (M columns only)
+        std::vector<int32_t> lookup((size_t)tlen, -1);
+        {
+            int i = aln.a_start, j = aln.b_start;
+            for (int e = 0; e <= aln.nm; ++e) {
+                const int jn = e < aln.nm ? (int)(ev[e] & 0x3FFFFFFFu) : aln.b_end;
+                for (; j < jn; ++j, ++i) lookup[j] = i;                   // '=' run
+                if (e == aln.nm) break;
+                const uint32_t type = ev[e] >> 30;
+                if (type == SP_EV_X) { lookup[j] = i; ++i; ++j; }        // mismatch is still an aligned pair (cigar M)
+                else if (type == SP_EV_D) { ++j; }                         // reference base without consensus base
+                else { ++i; }                                              // inserted consensus base
+            }
+        }
+        // splice_read (caller.rs:1518-1576) with exons relative to the view
+        std::string spliced;
+        auto has = [&](int64_t p2) { return p2 >= 0 && p2 < tlen && lookup[(size_t)p2] >= 0; };
+        for (uint32_t e = db->exon_off[gene]; e < db->exon_off[gene + 1]; ++e) {
+            int64_t first = (int64_t)db->exon_start[e] - buffer, last = (int64_t)db->exon_end[e] - buffer - 1;
+            while (!has(first) && first <= last) ++first;
+            while (!has(last) && first <= last) --last;
+            if (first <= last) spliced.append(it.cons + lookup[(size_t)first], (size_t)(lookup[(size_t)last] + 1 - lookup[(size_t)first]));
+        }
+        // gene strand (caller.rs:1344-1363); no exon bases => cDNA "N"
+        const bool fwd = db->gene_fwd[gene] != 0;
+        dna_g[x] = fwd ? std::string(it.cons, it.len) : revcomp(it.cons, it.len);
+        cdna_g[x] = spliced.empty() ? std::string("N") : (fwd ? spliced : revcomp(spliced.data(), spliced.size()));
+        if (cdna_out) (*cdna_out)[live[x]] = cdna_g[x];
+        k2.push_back(K2Item{ gene, dna_g[x].data(), (uint32_t)dna_g[x].size(), cdna_g[x].data(), (uint32_t)cdna_g[x].size() });
+        k2_of.push_back(live[x]);
+    }
+    if (k2.empty()) return SP_OK;
+    std::vector<sp_hla_best> b2(k2.size()); std::vector<int32_t*> st2(k2.size(), nullptr);
+    if (stats) for (size_t y = 0; y < k2.size(); ++y) st2[y] = stats[k2_of[y]];
+    rc = k2_score_batch(ctx, db, (uint32_t)k2.size(), k2.data(), require_dna, disable_cdna, b2.data(), stats ? st2.data() : nullptr);
+    if (rc != SP_OK) return rc;
+    for (size_t y = 0; y < k2.size(); ++y) best[k2_of[y]] = b2[y];
+    return SP_OK;
+}
 
 int32_t sp_hla_type_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
                               const char* consensus_fwd, uint32_t consensus_len,
@@ -899,84 +1041,25 @@ int32_t sp_hla_type_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,
                               sp_hla_best* best, int32_t* stats,
                               char* cdna_out, uint32_t cdna_cap, uint32_t* cdna_len) {
     if (!ctx || !db || !best || gene >= db->n_genes || (consensus_len && !consensus_fwd)) return SP_ERR_INVALID_ARG;
-    (void)hipSetDevice(ctx->device);
-    best->best_allele = -1; best->n_scored = 0;
     if (cdna_len) *cdna_len = 0;
-    if (stats) for (uint32_t a = 0; a < db->n_alleles; ++a) for (int k = 0; k < 6; ++k) stats[(size_t)a * 6 + k] = -2;
-    if (consensus_len == 0) return SP_OK;                                  // failed consensus => unknown (caller.rs:1263-1267)
-    // 1. place the consensus on the un-buffered gene reference
-    uint64_t off[2] = {0, consensus_len};
-    sp_seqset cons_set; sp_seqset* cons = &cons_set;       // pooled: no allocation, no free
-    int rc = sp_seqset_make_small(ctx, "tc_cons", consensus_fwd, off, 1, false, cons);
-    if (rc != SP_OK) return rc;
-    const int reflen = db->ref_fwd->h_len[gene], buffer = db->ref_buffer;
-    const int v_lo = buffer, v_hi = reflen - buffer;                        // region_sequence has no buffer (caller.rs:651-654)
-    uint32_t a_idx = gene, b_idx = 0;
-    uint32_t* d_ab = (uint32_t*)sp_pool(ctx, "tc_idx", 8);
-    int32_t* d_dv = (int32_t*)sp_pool(ctx, "tc_dv", 8);
-    CellDesc* d_cell = (CellDesc*)sp_pool(ctx, "tc_cell", sizeof(CellDesc));
-    sp_aln* d_aln = (sp_aln*)sp_pool(ctx, "tc_aln", sizeof(sp_aln));
-    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "tc_ev", SP_MAX_ED * 4);
-    if (!d_ab || !d_dv || !d_cell || !d_aln || !d_ev || v_hi <= v_lo) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "type_consensus buffers");
-    (void)hipMemcpyAsync(d_ab, &a_idx, 4, hipMemcpyHostToDevice, ctx->stream);
-    (void)hipMemcpyAsync(d_ab + 1, &b_idx, 4, hipMemcpyHostToDevice, ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream);
-    rc = sp_launch_anchor(ctx, db->ref_fwd, cons, d_ab, d_ab + 1, 1, d_dv, d_dv + 1);
-    int32_t dv[2] = {0, 0};
-    if (rc == SP_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipMemcpy(dv, d_dv, 8, hipMemcpyDeviceToHost); }
-    sp_aln aln; memset(&aln, 0, sizeof(aln));
-    std::vector<uint32_t> ev(SP_MAX_ED, 0);
-    if (rc == SP_OK && dv[1] >= K2_MIN_VOTES) {
-        // dv[0] = cons_pos - ref_pos (buffered reference); cell: A = consensus, B = reference view [v_lo, v_hi)
-        CellDesc cd{0u, gene, -dv[0] - v_lo, SP_MAX_ED, v_lo, v_hi};
-        (void)hipMemcpyAsync(d_cell, &cd, sizeof(cd), hipMemcpyHostToDevice, ctx->stream);
-        (void)hipMemsetAsync(d_ev, 0, SP_MAX_ED * 4, ctx->stream);
-        rc = sp_launch_cells(ctx, cons, db->ref_fwd, d_cell, 1, d_aln, d_ev, SP_MAX_ED, "type_consensus_ref");
-        if (rc == SP_OK) {
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipMemcpy(&aln, d_aln, sizeof(aln), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(ev.data(), d_ev, SP_MAX_ED * 4, hipMemcpyDeviceToHost);
-        }
+    const TypeItem item{ gene, consensus_fwd, consensus_len };
+    int32_t* st[1] = { stats };
+    std::vector<std::string> cd;
+    const int32_t rc = type_batch(ctx, db, 1, &item, require_dna, disable_cdna, best, stats ? st : nullptr, &cd);
+    if (rc == SP_OK && !cd.empty()) {
+        if (cdna_len) *cdna_len = (uint32_t)cd[0].size();
+        if (cdna_out && cdna_cap) memcpy(cdna_out, cd[0].data(), std::min<size_t>(cdna_cap, cd[0].size()));
     }
-    if (rc != SP_OK) return rc;
-    // select_best_mapping(target-based, penalised) must beat the 1.0 default (util/mapping.rs:22-57, caller.rs:1289-1297)
-    const int tlen = v_hi - v_lo;
-    bool mapped = aln.ok != 0;
-    if (mapped) { double num = (double)(aln.nm + (tlen - (aln.b_end - aln.b_start))); if (num < 0.1) num = 0.1; mapped = num / (double)tlen < 1.0; }
-    if (!mapped) return SP_OK;                                             // "Failed to align consensus to reference genome" (caller.rs:1282-1287)
-    // 2. aligned pairs of the consensus record: reference view position -> consensus position (M columns only)
-    std::vector<int32_t> lookup((size_t)tlen, -1);
-    {
-        int i = aln.a_start, j = aln.b_start;
-        for (int e = 0; e <= aln.nm; ++e) {
-            const int jn = e < aln.nm ? (int)(ev[e] & 0x3FFFFFFFu) : aln.b_end;
-            for (; j < jn; ++j, ++i) lookup[j] = i;                       // '=' run
-            if (e == aln.nm) break;
-            const uint32_t type = ev[e] >> 30;
-            if (type == SP_EV_X) { lookup[j] = i; ++i; ++j; }            // mismatch is still an aligned pair (cigar M)
-            else if (type == SP_EV_D) { ++j; }                             // reference base without consensus base
-            else { ++i; }                                                  // inserted consensus base
-        }
-    }
-    // 3. splice_read (caller.rs:1518-1576) with exons relative to the view
-    std::string spliced;
-    {
-        auto has = [&](int64_t x) { return x >= 0 && x < tlen && lookup[(size_t)x] >= 0; };
-        for (uint32_t e = db->exon_off[gene]; e < db->exon_off[gene + 1]; ++e) {
-            int64_t first = (int64_t)db->exon_start[e] - buffer, last = (int64_t)db->exon_end[e] - buffer - 1;
-            while (!has(first) && first <= last) ++first;
-            while (!has(last) && first <= last) --last;
-            if (first <= last) spliced.append(consensus_fwd + lookup[(size_t)first], (size_t)(lookup[(size_t)last] + 1 - lookup[(size_t)first]));
-        }
-    }
-    // 4. gene strand (caller.rs:1344-1363); no exon bases => cDNA "N"
-    const bool fwd = db->gene_fwd[gene] != 0;
-    std::string dna_g = fwd ? std::string(consensus_fwd, consensus_len) : revcomp(consensus_fwd, consensus_len);
-    std::string cdna_g = spliced.empty() ? std::string("N") : (fwd ? spliced : revcomp(spliced.data(), spliced.size()));
-    if (cdna_len) *cdna_len = (uint32_t)cdna_g.size();
-    if (cdna_out && cdna_cap) memcpy(cdna_out, cdna_g.data(), std::min<size_t>(cdna_cap, cdna_g.size()));
-    return sp_hla_score_consensus(ctx, db, gene, dna_g.data(), (uint32_t)dna_g.size(), cdna_g.data(), (uint32_t)cdna_g.size(),
-                                  require_dna, disable_cdna, best, stats);
+    return rc;
+}
+
+int32_t sp_hla_type_consensus_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n, const uint32_t* genes,
+                                    const char* const* consensus_fwd, const uint32_t* consensus_len,
+                                    int32_t require_dna, int32_t disable_cdna, sp_hla_best* best) {
+    if (!ctx || !db || (n && (!genes || !consensus_fwd || !consensus_len || !best))) return SP_ERR_INVALID_ARG;
+    std::vector<TypeItem> items(n);
+    for (uint32_t k = 0; k < n; ++k) items[k] = TypeItem{ genes[k], consensus_fwd[k], consensus_len[k] };
+    return n ? type_batch(ctx, db, n, items.data(), require_dna, disable_cdna, best, nullptr, nullptr) : SP_OK;
 }
 
 } // extern "C"

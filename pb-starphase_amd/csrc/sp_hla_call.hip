@@ -270,32 +270,43 @@ static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
         if (rc != SP_OK && rc != SP_ERR_CAPACITY) return rc;
         for (size_t x = 0; x < groups.size(); ++x) if (O[x].status != SP_OK) O[x].cons1[0] = '\0';   // "Failed to generate a consensus" => empty => unknown (:741-755)
     }
-    // ---- typing and the call (caller.rs:756-923)
+    // ---- typing (score_consensus, caller.rs:756,829): every consensus of every unit in one batch
+    std::vector<uint32_t> tg; std::vector<const char*> tp; std::vector<uint32_t> tl; std::vector<std::pair<uint32_t, int>> tw;
     for (uint32_t k : todo) {
-        Gene& g = G[k]; sp_hla_call& call = calls[k];
+        const Gene& g = G[k];
         const char* t1 = text.data() + (size_t)(2 * k) * ccap; const char* t2 = text.data() + (size_t)(2 * k + 1) * ccap;
         const size_t l1 = std::strlen(t1), l2 = g.is_dual ? std::strlen(t2) : 0;
         if (l1 + 1 > cap || l2 + 1 > cap) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_hla_diplotype_genes: consensus buffer too small");
-        char* o1 = cons + (size_t)(2 * k) * cap; char* o2 = cons + (size_t)(2 * k + 1) * cap;
-        std::memcpy(o1, t1, l1 + 1); call.cons1_len = (int32_t)l1;
-        sp_hla_best b1; std::memset(&b1, 0, sizeof b1); b1.best_allele = -1;
-        rc = sp_hla_type_consensus(ctx, db, genes[k], o1, (uint32_t)l1, cfgs[k].require_dna, cfgs[k].disable_cdna, &b1, nullptr, nullptr, 0, nullptr);
+        std::memcpy(cons + (size_t)(2 * k) * cap, t1, l1 + 1); calls[k].cons1_len = (int32_t)l1;
+        tg.push_back(genes[k]); tp.push_back(cons + (size_t)(2 * k) * cap); tl.push_back((uint32_t)l1); tw.push_back({ k, 0 });
+        if (g.is_dual) {
+            std::memcpy(cons + (size_t)(2 * k + 1) * cap, t2, l2 + 1); calls[k].cons2_len = (int32_t)l2;
+            tg.push_back(genes[k]); tp.push_back(cons + (size_t)(2 * k + 1) * cap); tl.push_back((uint32_t)l2); tw.push_back({ k, 1 });
+        }
+    }
+    // one batch per (require_dna, disable_cdna) setting in use (normally one: they are run-wide switches of the CLI)
+    for (int combo = 0; combo < 4; ++combo) {
+        const int rd = combo & 1, dc = combo >> 1;
+        std::vector<uint32_t> g2; std::vector<const char*> p2; std::vector<uint32_t> l2v; std::vector<size_t> at;
+        for (size_t x = 0; x < tw.size(); ++x) if ((cfgs[tw[x].first].require_dna != 0) == rd && (cfgs[tw[x].first].disable_cdna != 0) == dc) { g2.push_back(tg[x]); p2.push_back(tp[x]); l2v.push_back(tl[x]); at.push_back(x); }
+        if (g2.empty()) continue;
+        std::vector<sp_hla_best> tb(g2.size());
+        rc = sp_hla_type_consensus_batch(ctx, db, (uint32_t)g2.size(), g2.data(), p2.data(), l2v.data(), rd, dc, tb.data());
         if (rc != SP_OK) return rc;
-        call.typed1 = b1.best_allele;
+        for (size_t y = 0; y < at.size(); ++y) (tw[at[y]].second ? calls[tw[at[y]].first].typed2 : calls[tw[at[y]].first].typed1) = tb[y].best_allele;
+    }
+    // ---- the call (caller.rs:889-923)
+    for (uint32_t k : todo) {
+        Gene& g = G[k]; sp_hla_call& call = calls[k];
         call.is_dual = g.is_dual; call.is_hemizygous = g.hemi; call.counts1 = g.c1; call.counts2 = g.c2; call.maf = g.maf; call.cdf = g.cdf; call.used_dna_dual = g.used_dna;
         if (g.is_dual) {
-            std::memcpy(o2, t2, l2 + 1); call.cons2_len = (int32_t)l2;
-            sp_hla_best b2; std::memset(&b2, 0, sizeof b2); b2.best_allele = -1;
-            rc = sp_hla_type_consensus(ctx, db, genes[k], o2, (uint32_t)l2, cfgs[k].require_dna, cfgs[k].disable_cdna, &b2, nullptr, nullptr, 0, nullptr);
-            if (rc != SP_OK) return rc;
-            call.typed2 = b2.best_allele;
             call.dual_passed = g.pass;
-            if (g.pass) { call.allele1 = b1.best_allele; call.allele2 = b2.best_allele; }                       // heterozygous (:893-895)
-            else if (g.c1 > g.c2) call.allele1 = call.allele2 = b1.best_allele;                                // homozygous for the dominant allele (:896-903)
-            else call.allele1 = call.allele2 = b2.best_allele;
+            if (g.pass) { call.allele1 = call.typed1; call.allele2 = call.typed2; }                            // heterozygous (:893-895)
+            else if (g.c1 > g.c2) call.allele1 = call.allele2 = call.typed1;                                    // homozygous for the dominant allele (:896-903)
+            else call.allele1 = call.allele2 = call.typed2;
         } else {
             call.dual_passed = 0;
-            call.allele1 = call.allele2 = b1.best_allele;                                                       // :905-912
+            call.allele1 = call.allele2 = call.typed1;                                                          // :905-912
             if (g.hemi) call.allele1 = -2;                                                                       // (NO_CALL_HAP, allele) (:919-923)
         }
         if (is_cons1_out) for (uint32_t i = g.first; i < g.first + g.n; ++i) is_cons1_out[sel[i]] = is1[i];

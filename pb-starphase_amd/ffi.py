@@ -198,6 +198,8 @@ def lib():
         "sp_hla_db_free": (None, [vp]),
         "sp_hla_realign_reads": (i32, [vp, vp, vp, vp, vp]),
         "sp_hla_score_consensus": (i32, [vp, vp, u32, C.c_char_p, u32, C.c_char_p, u32, i32, i32, C.POINTER(sp_hla_best), vp]),
+        "sp_hla_score_consensus_batch": (i32, [vp, vp, u32, vp, C.POINTER(C.c_char_p), vp, C.POINTER(C.c_char_p), vp, i32, i32, vp]),
+        "sp_hla_type_consensus_batch": (i32, [vp, vp, u32, vp, C.POINTER(C.c_char_p), vp, i32, i32, vp]),
         "sp_hla_type_consensus": (i32, [vp, vp, u32, C.c_char_p, u32, i32, i32, C.POINTER(sp_hla_best), vp, C.c_char_p, u32, C.POINTER(u32)]),
         "sp_cyp_best_chain_pair": (i32, [vp, C.POINTER(sp_chain_problem), C.POINTER(sp_chain_result)]),
         "sp_anchor_batch_topk": (i32, [vp, vp, vp, vp, vp, u64, i32, vp, vp]),
@@ -678,6 +680,25 @@ class HlaDb:
         self.ctx.check(lib().sp_hla_type_consensus(self.ctx._h, self._h, int(gene), consensus_fwd.encode(), len(consensus_fwd),
                                                    int(require_dna), int(disable_cdna), C.byref(best), _ptr(st), buf, len(buf), C.byref(n)))
         return best.best_allele, best.n_scored, st, buf.raw[:n.value].decode()
+
+    def score_consensus_batch(self, items, require_dna=False, disable_cdna=False):
+        """items: [(gene, cons_dna, cons_cdna)] -> list of (best allele, n_scored)"""
+        n = len(items)
+        g = np.array([it[0] for it in items], np.uint32)
+        d = (C.c_char_p * max(1, n))(*[it[1].encode() for it in items]); dl = np.array([len(it[1]) for it in items], np.uint32)
+        c = (C.c_char_p * max(1, n))(*[it[2].encode() for it in items]); cl = np.array([len(it[2]) for it in items], np.uint32)
+        best = (sp_hla_best * max(1, n))()
+        self.ctx.check(lib().sp_hla_score_consensus_batch(self.ctx._h, self._h, n, _ptr(g), d, _ptr(dl), c, _ptr(cl), int(require_dna), int(disable_cdna), best))
+        return [(best[i].best_allele, best[i].n_scored) for i in range(n)]
+
+    def type_consensus_batch(self, items, require_dna=False, disable_cdna=False):
+        """items: [(gene, consensus_fwd)] -> list of (best allele, n_scored)"""
+        n = len(items)
+        g = np.array([it[0] for it in items], np.uint32)
+        d = (C.c_char_p * max(1, n))(*[it[1].encode() for it in items]); dl = np.array([len(it[1]) for it in items], np.uint32)
+        best = (sp_hla_best * max(1, n))()
+        self.ctx.check(lib().sp_hla_type_consensus_batch(self.ctx._h, self._h, n, _ptr(g), d, _ptr(dl), int(require_dna), int(disable_cdna), best))
+        return [(best[i].best_allele, best[i].n_scored) for i in range(n)]
 
     def score_consensus(self, gene, cons_dna, cons_cdna, require_dna=False, disable_cdna=False, stats=True):
         best = sp_hla_best()
