@@ -57,6 +57,11 @@ template <int MAXP> struct ConsBatchT {
     ConsMeta* meta;             // [2][total]
     int total;
 };
+// large batches (a cohort): the descriptors live in device memory and a table maps every workgroup to its problem
+template <> struct ConsBatchT<0> {
+    const ConsParams* p; const int* block_prob; int n_prob;
+    const ReadInfo* info; uint16_t* H; ConsMeta* meta; int total;
+};
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first; };
 
 struct ReadView { const uint32_t* w; const uint32_t* np; int n; };
@@ -198,8 +203,11 @@ template <int MAXP>
 __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<MAXP> B, int t) {
     __shared__ uint32_t lv[2][8];
     int pi = 0;
+    if constexpr (MAXP == 0) pi = B.block_prob[blockIdx.x];
+    else {
 #pragma unroll
-    for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
+        for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
+    }
     const ConsParams P = B.p[pi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lead = (int)blockIdx.x == P.first_block;
@@ -320,8 +328,11 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatchT<M
     if (it >= n_items) return;
     const ActItem item = items[it];
     int pi = 0;
+    if constexpr (MAXP == 0) pi = item.prob;
+    else {
 #pragma unroll
-    for (int i = 1; i < MAXP; ++i) if (i == item.prob) pi = i;
+        for (int i = 1; i < MAXP; ++i) if (i == item.prob) pi = i;
+    }
     const ConsParams P = B.p[pi];
     const size_t g = (size_t)P.first + item.r;
     const ReadInfo ri = B.info[g];
@@ -405,8 +416,11 @@ __global__ void cons_setup_kernel(ConsSetup S, ReadInfo* __restrict__ info) {
 template <int MAXP>
 __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBatchT<MAXP> B, int which, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
     int pi = 0;
+    if constexpr (MAXP == 0) pi = B.block_prob[blockIdx.x];
+    else {
 #pragma unroll
-    for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
+        for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
+    }
     const ConsParams P = B.p[pi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = ((int)blockIdx.x - P.first_block) * CWAVES + wave;
@@ -444,6 +458,8 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     hipStream_t st = ctx->stream;
     ConsBatchT<MAXP> B; std::memset(&B, 0, sizeof B);
     B.n_prob = (int)n_prob;
+    std::vector<ConsParams> hp(n_prob);                      // the descriptors; they end up in the kernel arguments or, for MAXP == 0, in device memory
+    std::vector<int> block_prob;
     std::vector<ConsSetup> setup(n_prob);
     std::vector<uint32_t> h_idx; std::vector<int32_t> h_off;
     std::vector<size_t> idx_at(n_prob), off_at(n_prob), c_at(n_prob), v_at(n_prob);
@@ -451,13 +467,14 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     for (uint32_t p = 0; p < n_prob; ++p) {
         const sp_cons_problem& q = probs[p];
         const uint32_t n = q.read_idx ? q.n : q.reads->n;
-        ConsParams& P = B.p[p];
+        ConsParams& P = hp[p];
         P.n = (int)n; P.cap = (int)outs[p].cap - 1;                                   // one byte of the caller's buffer is the NUL
         P.first = (int)total; P.first_block = n_blocks;
         P.min_count = q.cfg.min_count; P.delta = q.cfg.dual_max_ed_delta; P.et = q.cfg.allow_early_termination != 0; P.allow_dual = q.cfg.allow_dual != 0;
         P.window = q.cfg.offset_window; P.cmp_len = q.cfg.offset_compare_length; P.min_af = q.cfg.min_af;
         const uint32_t nb = (n + CWAVES - 1) / CWAVES;
         n_blocks += (int)nb;
+        if (MAXP == 0) block_prob.insert(block_prob.end(), nb, (int)p);
         setup[p].reads = q.reads->view(); setup[p].n = (int)n; setup[p].first = (int)total;
         total += (size_t)nb * CWAVES;
         idx_at[p] = h_idx.size(); if (q.read_idx) h_idx.insert(h_idx.end(), q.read_idx, q.read_idx + n);
@@ -470,7 +487,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     // late reads, ordered by the step that places them
     std::vector<std::pair<int, ActItem>> late;
     for (uint32_t p = 0; p < n_prob; ++p) if (probs[p].offsets)
-        for (int r = 0; r < B.p[p].n; ++r) if (probs[p].offsets[r] >= 1) late.push_back({ probs[p].offsets[r], ActItem{ (int)p, r } });
+        for (int r = 0; r < hp[p].n; ++r) if (probs[p].offsets[r] >= 1) late.push_back({ probs[p].offsets[r], ActItem{ (int)p, r } });
     std::stable_sort(late.begin(), late.end(), [](const std::pair<int, ActItem>& a, const std::pair<int, ActItem>& b) { return a.first < b.first; });
     std::vector<ActItem> h_act(late.size());
     for (size_t i = 0; i < late.size(); ++i) h_act[i] = late[i].second;
@@ -492,7 +509,17 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     for (uint32_t p = 0; p < n_prob; ++p) {
         setup[p].idx = probs[p].read_idx ? d_idx + idx_at[p] : nullptr;
         setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr;
-        B.p[p].C = d_C + c_at[p]; B.p[p].votes = d_votes + v_at[p]; B.p[p].ctrl = d_ctrl + 2 * p;
+        hp[p].C = d_C + c_at[p]; hp[p].votes = d_votes + v_at[p]; hp[p].ctrl = d_ctrl + 2 * p;
+    }
+    if constexpr (MAXP == 0) {
+        ConsParams* d_probs = (ConsParams*)sp_pool(ctx, "cons_probs", sizeof(ConsParams) * n_prob);
+        int* d_block_prob = (int*)sp_pool(ctx, "cons_block_prob", sizeof(int) * block_prob.size());
+        if (!d_probs || !d_block_prob) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus descriptors");
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_probs, hp.data(), sizeof(ConsParams) * n_prob, hipMemcpyHostToDevice, st));
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_block_prob, block_prob.data(), sizeof(int) * block_prob.size(), hipMemcpyHostToDevice, st));
+        B.p = d_probs; B.block_prob = d_block_prob;
+    } else {
+        for (uint32_t p = 0; p < n_prob; ++p) B.p[p] = hp[p];
     }
     ConsCtrl c0; std::memset(&c0, 0, sizeof c0); c0.split_at = -1; c0.stopped[1] = 1; c0.best_total = 1; c0.split_total = 1;
     std::vector<ConsCtrl> h_ctrl(2 * (size_t)n_prob, c0);
@@ -546,7 +573,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     static const char dec[4] = { 'A', 'C', 'G', 'T' };
     int32_t rc = SP_OK;
     for (uint32_t p = 0; p < n_prob; ++p) {
-        const ConsParams& P = B.p[p]; sp_cons_output& o = outs[p];
+        const ConsParams& P = hp[p]; sp_cons_output& o = outs[p];
         const ConsCtrl& cur = h_ctrl[2 * p + which];
         const uint8_t* c = hc.data() + c_at[p];
         const int len1 = cur.len[0], len2 = cur.dual ? cur.len[1] : 0;
@@ -580,9 +607,11 @@ static int32_t run_batch(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     }
     SP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int32_t rc = SP_OK;
-    for (uint32_t at = 0; at < n_prob; at += CMAXP) {
-        const uint32_t k = std::min<uint32_t>(CMAXP, n_prob - at);
-        const int32_t e = k <= 4 ? run_chunk<4>(ctx, k, probs + at, outs + at) : k <= 8 ? run_chunk<8>(ctx, k, probs + at, outs + at) : run_chunk<CMAXP>(ctx, k, probs + at, outs + at);
+    const uint32_t big = 4096;                               // problems per launch sequence once the descriptors live in device memory
+    for (uint32_t at = 0; at < n_prob; at += big) {
+        const uint32_t k = std::min<uint32_t>(big, n_prob - at);
+        const int32_t e = k <= 4 ? run_chunk<4>(ctx, k, probs + at, outs + at) : k <= 8 ? run_chunk<8>(ctx, k, probs + at, outs + at)
+                        : k <= CMAXP ? run_chunk<CMAXP>(ctx, k, probs + at, outs + at) : run_chunk<0>(ctx, k, probs + at, outs + at);
         if (e != SP_OK && e != SP_ERR_CAPACITY) return e;
         if (e != SP_OK) rc = e;
     }
