@@ -1,4 +1,5 @@
-"""__graft_entry__.smoke(): one small invocation of the hot path on cuda:0, checked against the CPU oracle."""
+"""__graft_entry__.smoke(): one small invocation of the hot path on cuda:0 (K1, K2, and the reads-to-diplotype gene solve with K8),
+checked against the CPU oracle."""
 import numpy as np
 
 import hla_expected as hx
@@ -29,6 +30,12 @@ def run(pkg):
     assert best == ebest, (best, ebest)
     for al_i, st in estats.items():
         assert stats[al_i].tolist() == st
+    # reads -> diplotype of the gene (segments + HPC on the device, K8 consensus, K2 typing) against the oracle-assembled pipeline
+    import hla_pipeline
+    call, c1, c2, is1 = db.diplotype_gene(g, rs, out)
+    e = hla_pipeline.diplotype_gene(oracle, fx, g, reads, exp, synth)
+    assert (c1, c2) == (e["cons1"], e["cons2"]), "consensus differs from the oracle"
+    assert (call.status, call.allele1, call.allele2, call.is_dual) == (e["status"], e["allele1"], e["allele2"], e["is_dual"]), (call.allele1, call.allele2, e)
     db.close()
     rs.close()
     ctx.close()
