@@ -8,6 +8,7 @@
 #include "sp_wfa.cuh"
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
@@ -709,8 +710,29 @@ int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) 
     return SP_OK;
 }
 
+static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads, sp_hla_realign* out, uint32_t* cell_out);
+
 int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads, sp_hla_realign* out, uint32_t* cell_out) {
     if (!ctx || !db || !reads || !out) return SP_ERR_INVALID_ARG;
+    // big batches go through in slices of 65,536 reads (a shallow view of the same packed words): the read x allele matrix of a
+    // slice is what bounds the device memory of a call, however many reads the caller hands over
+    const char* env = std::getenv("SP_K1_SLICE");              // (tests shrink the slice to exercise this path)
+    const uint32_t slice = env && std::atoi(env) > 0 ? (uint32_t)std::atoi(env) : 65536u;
+    if (reads->n <= slice) return k1_realign_chunk(ctx, db, reads, out, cell_out);
+    for (uint32_t r0 = 0; r0 < reads->n; r0 += slice) {
+        const uint32_t k = std::min<uint32_t>(slice, reads->n - r0);
+        sp_seqset part;
+        part.ctx = reads->ctx; part.n = k; part.has_n = reads->has_n; part.max_len = reads->max_len;
+        part.d_words = reads->d_words; part.d_nplane = reads->d_nplane; part.d_word_off = reads->d_word_off + r0; part.d_len = reads->d_len + r0;
+        part.h_len.assign(reads->h_len.begin() + r0, reads->h_len.begin() + r0 + k);
+        part.h_word_off.assign(reads->h_word_off.begin() + r0, reads->h_word_off.begin() + r0 + k + 1);
+        const int32_t rc = k1_realign_chunk(ctx, db, &part, out + r0, cell_out ? cell_out + (size_t)r0 * db->n_alleles : nullptr);
+        if (rc != SP_OK) return rc;
+    }
+    return SP_OK;
+}
+
+static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads, sp_hla_realign* out, uint32_t* cell_out) {
     const uint32_t R = reads->n, G = db->n_genes, NA = db->n_alleles;
     if (R == 0) return SP_OK;
     (void)hipSetDevice(ctx->device);
