@@ -556,6 +556,20 @@ int32_t sp_cyp_build_chains(uint32_t n_haps, const int32_t* hap_type, uint32_t n
                             uint32_t* chain_items, uint32_t item_cap, uint32_t* read_w_off, uint32_t* w_seg,
                             uint64_t* unique_counts, uint8_t* false_allele, sp_chain_build_info* info);
 
+/* result strings (src/data_types/pgx_diplotype.rs, src/data_types/region_variants.rs) */
+/* Diplotype::diplotype ("h1/h2", :13-20) or, pharmcat != 0, Diplotype::pharmcat_diplotype (haplotypes containing '+' in brackets, :51-64);
+ * returns the string length (the output is truncated to cap-1 characters) */
+uint32_t sp_diplotype_string(const char* hap1, const char* hap2, int32_t pharmcat, char* out, uint32_t cap);
+/* InexactHaplotype::new + full_haplotype (:138-196): variants = RegionVariant{label, is_vi, state}, taken in BTreeSet order
+ * (label, is_vi, state; duplicates collapse); every variant that is not a Match is appended as " <sign><label>" with the sign of
+ * RegionVariant's Display ('+' Unexpected, '-' Missing, '?' the ambiguous / unknown states, region_variants.rs:44-60) and the
+ * whole is put in parentheses; match_type: sub-allele match when all match, core match when every VI variant matches. */
+enum { SP_REL_UNKNOWN = 0, SP_REL_MATCH = 1, SP_REL_UNEXPECTED = 2, SP_REL_MISSING = 3, SP_REL_AMBIGUOUS_UNEXPECTED = 4,
+       SP_REL_AMBIGUOUS_MISSING = 5, SP_REL_UNKNOWN_UNEXPECTED = 6, SP_REL_UNKNOWN_MISSING = 7 };     /* VariantAlleleRelationship */
+enum { SP_INEXACT_UNKNOWN = 0, SP_INEXACT_NO_MATCH = 1, SP_INEXACT_CORE_MATCH = 2, SP_INEXACT_SUBALLELE_MATCH = 3 };   /* InexactMatchType */
+uint32_t sp_inexact_haplotype(const char* base_haplotype, uint32_t n_variants, const char* const* labels, const uint8_t* is_vi,
+                              const int32_t* states, int32_t* match_type, char* out, uint32_t cap);
+
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */
 int32_t sp_profile_reset(sp_ctx* ctx);

@@ -155,6 +155,12 @@ double osp_binomial_cdf(double p, uint64_t n, uint64_t x);
 double osp_binomial_ln_pmf(double p, uint64_t n, uint64_t x);
 double osp_normal_ln_pdf(double mean, double sd, double x);
 
+/* result strings: Diplotype::{diplotype, pharmcat_diplotype} (src/data_types/pgx_diplotype.rs:13-65) and InexactHaplotype::{new,
+ * full_haplotype} (:138-196) with RegionVariant's Display (src/data_types/region_variants.rs:44-60); variants must be given in
+ * BTreeSet order.  match_type: 1 no match, 2 core match, 3 sub-allele match. */
+void osp_diplotype_string(const char* hap1, const char* hap2, int pharmcat, char* out, size_t cap);
+int  osp_inexact_haplotype(const char* base, int n, const char* const* labels, const uint8_t* is_vi, const int32_t* states, char* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

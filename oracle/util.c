@@ -1,3 +1,5 @@
+#include <stdlib.h>
+#include <stdio.h>
 /*
  * oracle/util.c -- CPU ORACLE (test infrastructure only): small helpers + the statrs 0.16.0 functions the
  * reference calls (Cargo.lock:1897-1899; the crate is not under /root/reference, formulas restated from
@@ -89,4 +91,30 @@ double osp_normal_ln_pdf(double mean, double sd, double x) {
     const double LN_SQRT_2PI = 0.91893853320467274178032973640561763986139747363778341281715;
     double d = (x - mean) / sd;
     return (-0.5 * d * d) - LN_SQRT_2PI - log(sd);
+}
+
+
+/* Diplotype::diplotype / pharmcat_diplotype (src/data_types/pgx_diplotype.rs:13-65) */
+void osp_diplotype_string(const char* hap1, const char* hap2, int pharmcat, char* out, size_t cap) {
+    const int b1 = pharmcat && strchr(hap1, '+') != NULL, b2 = pharmcat && strchr(hap2, '+') != NULL;
+    snprintf(out, cap, "%s%s%s/%s%s%s", b1 ? "[" : "", hap1, b1 ? "]" : "", b2 ? "[" : "", hap2, b2 ? "]" : "");
+}
+
+/* InexactHaplotype::new + full_haplotype (src/data_types/pgx_diplotype.rs:138-196); states follow VariantAlleleRelationship's
+ * declaration order (1 = Match, 2 = Unexpected, 3 = Missing, everything else prints '?') */
+int osp_inexact_haplotype(const char* base, int n, const char* const* labels, const uint8_t* is_vi, const int32_t* states, char* out, size_t cap) {
+    int core = 1, sub = 1, modified = 0;
+    size_t len = 0;
+    char* buf = (char*)malloc(cap + 2);
+    len += (size_t)snprintf(buf + len, cap - len, "%s", base);
+    for (int i = 0; i < n; ++i) {
+        if (states[i] == 1) continue;
+        sub = 0; if (is_vi[i]) core = 0;
+        const char sign = states[i] == 2 ? '+' : (states[i] == 3 ? '-' : '?');
+        if (len < cap) len += (size_t)snprintf(buf + len, cap - len, " %c%s", sign, labels[i]);
+        modified = 1;
+    }
+    if (modified) snprintf(out, cap, "(%s)", buf); else snprintf(out, cap, "%s", buf);
+    free(buf);
+    return sub ? 3 : (core ? 2 : 1);
 }

@@ -199,6 +199,38 @@ int32_t sp_variant_multi_normalize(const char* chrom_seq, uint64_t chrom_len, ui
     return SP_OK;
 }
 
+uint32_t sp_diplotype_string(const char* hap1, const char* hap2, int32_t pharmcat, char* out, uint32_t cap) {
+    auto side = [&](const char* h) { std::string t(h ? h : ""); return (pharmcat && t.find('+') != std::string::npos) ? "[" + t + "]" : t; };
+    const std::string res = side(hap1) + "/" + side(hap2);
+    if (out && cap) { const size_t k = std::min<size_t>(cap - 1, res.size()); std::memcpy(out, res.data(), k); out[k] = '\0'; }
+    return (uint32_t)res.size();
+}
+
+uint32_t sp_inexact_haplotype(const char* base_haplotype, uint32_t n_variants, const char* const* labels, const uint8_t* is_vi,
+                              const int32_t* states, int32_t* match_type, char* out, uint32_t cap) {
+    struct Rv { std::string label; int vi, state; };
+    std::vector<Rv> set;
+    for (uint32_t i = 0; i < n_variants; ++i) set.push_back(Rv{ labels[i] ? labels[i] : "", is_vi[i] ? 1 : 0, states[i] });
+    auto less = [](const Rv& a, const Rv& b) { if (a.label != b.label) return a.label < b.label; if (a.vi != b.vi) return a.vi < b.vi; return a.state < b.state; };
+    std::sort(set.begin(), set.end(), less);
+    set.erase(std::unique(set.begin(), set.end(), [](const Rv& a, const Rv& b) { return a.label == b.label && a.vi == b.vi && a.state == b.state; }), set.end());
+    bool core = true, sub = true;
+    std::string hap(base_haplotype ? base_haplotype : "");
+    bool modified = false;
+    for (const Rv& v : set) {
+        if (v.state == SP_REL_MATCH) continue;
+        sub = false; if (v.vi) core = false;
+        hap += ' ';
+        hap += v.state == SP_REL_UNEXPECTED ? '+' : (v.state == SP_REL_MISSING ? '-' : '?');
+        hap += v.label;
+        modified = true;
+    }
+    if (modified) hap = "(" + hap + ")";
+    if (match_type) *match_type = sub ? SP_INEXACT_SUBALLELE_MATCH : (core ? SP_INEXACT_CORE_MATCH : SP_INEXACT_NO_MATCH);
+    if (out && cap) { const size_t k = std::min<size_t>(cap - 1, hap.size()); std::memcpy(out, hap.data(), k); out[k] = '\0'; }
+    return (uint32_t)hap.size();
+}
+
 int32_t sp_cyp_build_chains(uint32_t n_haps, const int32_t* hap_type, uint32_t n_reads, const uint32_t* read_seg_off,
                             const uint64_t* ed, const uint8_t* kept,
                             uint32_t* read_index, uint32_t* read_chain_off, uint32_t* chain_off, uint32_t chain_cap,

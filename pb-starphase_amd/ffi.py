@@ -225,6 +225,8 @@ def lib():
         "sp_hla_diplotype_gene": (i32, [vp, vp, u32, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, C.c_char_p, u32, vp]),
         "sp_hla_diplotype_genes": (i32, [vp, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
         "sp_hla_diplotype_cohort": (i32, [vp, vp, u32, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
+        "sp_diplotype_string": (u32, [C.c_char_p, C.c_char_p, i32, C.c_char_p, u32]),
+        "sp_inexact_haplotype": (u32, [C.c_char_p, u32, C.POINTER(C.c_char_p), vp, vp, C.POINTER(i32), C.c_char_p, u32]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }

@@ -252,3 +252,60 @@ def test_product_loads_reference_databases(pkg, oracle):
                 assert a == b
                 n += 1
     assert n >= 5
+
+
+# ------------------------------------------------------------------ result strings (src/data_types/pgx_diplotype.rs:237-316, region_variants.rs:66-110)
+REL = dict(Unknown=0, Match=1, Unexpected=2, Missing=3, AmbiguousUnexpected=4, AmbiguousMissing=5, UnknownUnexpected=6, UnknownMissing=7)
+
+
+def _dip(pkg, oracle, h1, h2, pharmcat):
+    out, oout = C.create_string_buffer(256), C.create_string_buffer(256)
+    pkg.ffi.lib().sp_diplotype_string(h1.encode(), h2.encode(), int(pharmcat), out, 256)
+    oracle.L.osp_diplotype_string(h1.encode(), h2.encode(), int(pharmcat), oout, C.c_size_t(256))
+    assert out.value == oout.value
+    return out.value.decode()
+
+
+def _inexact(pkg, oracle, base, variants):
+    """variants: [(label, is_vi, state name)] in any order for the library; the oracle gets them in BTreeSet order"""
+    def call_lib(vs):
+        labels = (C.c_char_p * max(1, len(vs)))(*[v[0].encode() for v in vs])
+        vi = np.array([v[1] for v in vs], np.uint8)
+        st = np.array([REL[v[2]] for v in vs], np.int32)
+        mt, out = C.c_int32(0), C.create_string_buffer(512)
+        pkg.ffi.lib().sp_inexact_haplotype(base.encode(), len(vs), labels, vi.ctypes.data, st.ctypes.data, C.byref(mt), out, 512)
+        return mt.value, out.value.decode()
+    ordered = sorted(set(variants), key=lambda v: (v[0], v[1], REL[v[2]]))
+    labels = (C.c_char_p * max(1, len(ordered)))(*[v[0].encode() for v in ordered])
+    vi = np.array([v[1] for v in ordered], np.uint8)
+    st = np.array([REL[v[2]] for v in ordered], np.int32)
+    oout = C.create_string_buffer(512)
+    oracle.L.osp_inexact_haplotype.restype = C.c_int
+    omt = oracle.L.osp_inexact_haplotype(base.encode(), len(ordered), labels, vi.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), oout, C.c_size_t(512))
+    got = call_lib(list(reversed(variants)) + variants[:1])            # shuffled and with a duplicate: the library sorts and dedups
+    assert got == (omt, oout.value.decode())
+    return got
+
+
+def test_diplotype_strings(pkg, oracle):
+    """test_diplotype / test_pharmcat_diplotype (src/data_types/pgx_diplotype.rs:237-256)"""
+    assert _dip(pkg, oracle, "B", "A", False) == "B/A"
+    assert _dip(pkg, oracle, "*4", "*1", True) == "*4/*1"
+    assert _dip(pkg, oracle, "*4x2", "*1", True) == "*4x2/*1"
+    assert _dip(pkg, oracle, "*4 + *68", "*1", True) == "[*4 + *68]/*1"
+    assert _dip(pkg, oracle, "*4 + *68", "*1", False) == "*4 + *68/*1"
+
+
+def test_inexact_haplotype_strings(pkg, oracle):
+    """test_inexact_haplotype (src/data_types/pgx_diplotype.rs:276-316) and RegionVariant's Display (region_variants.rs:66-110)"""
+    SUB, CORE, NO = 3, 2, 1
+    assert _inexact(pkg, oracle, "*1.001", [("rs123", 1, "Match"), ("rs456", 0, "Match")]) == (SUB, "*1.001")
+    assert _inexact(pkg, oracle, "*1.001", [("rs123", 1, "Match"), ("rs456", 0, "Unexpected")]) == (CORE, "(*1.001 +rs456)")
+    assert _inexact(pkg, oracle, "*1", [("rs123", 1, "Missing"), ("rs456", 0, "Unexpected")]) == (NO, "(*1 -rs123 +rs456)")
+    assert _inexact(pkg, oracle, "*3", []) == (SUB, "*3")
+    for state in ("AmbiguousUnexpected", "AmbiguousMissing", "UnknownUnexpected", "UnknownMissing", "Unknown"):
+        assert _inexact(pkg, oracle, "*9", [("rs012", 0, state)]) == (CORE, "(*9 ?rs012)")
+    # InexactDiplotype::new joins the two full haplotypes (:99-106)
+    h1 = _inexact(pkg, oracle, "*1", [("v1", 1, "Match"), ("v2", 1, "Unexpected")])[1]
+    h2 = _inexact(pkg, oracle, "*2", [("v2", 1, "Match")])[1]
+    assert _dip(pkg, oracle, h1, h2, False) == "(*1 +v2)/*2"
