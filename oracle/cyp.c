@@ -410,7 +410,7 @@ static double hit_score(const osp_region_hit* h, int penalize) {
     return osp_custom_score((uint64_t)h->seq_len, (uint64_t)h->nm, (uint64_t)h->unmapped, penalize);
 }
 static int is_penalized_type(int t) { return t == OSP_DELETION || t == OSP_REP6 || t == OSP_REP7; }              /* :185-191 */
-static double range_overlap_score(int s1, int e1, int s2, int e2) {                                                /* :877-892 */
+double osp_cyp_overlap_score(int s1, int e1, int s2, int e2) {                                                /* :877-892 */
     int min_end = e1 < e2 ? e1 : e2, max_start = s1 > s2 ? s1 : s2;
     if (max_start >= min_end) return 0.0;
     double l1 = (double)(e1 - s1), l2 = (double)(e2 - s2), shared = (double)(min_end - max_start);
@@ -450,7 +450,7 @@ int osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, con
     int n_coll = 0;
     for (int i = 0; i < n_un; ++i) {
         if (!have_cur) { cur = un[i]; have_cur = 1; continue; }
-        if (range_overlap_score(un[i].start, un[i].end, cur.start, cur.end) > 0.9) {
+        if (osp_cyp_overlap_score(un[i].start, un[i].end, cur.start, cur.end) > 0.9) {
             int star5_pairing = is_penalized_type(tmpl_type[un[i].template_idx]) || is_penalized_type(tmpl_type[cur.template_idx]);
             int penalized_scoring = star5_pairing ? 1 : 0;
             int up = tmpl_type[un[i].template_idx] == OSP_DELETION ? 1 : 0, cp = tmpl_type[cur.template_idx] == OSP_DELETION ? 1 : 0;   /* :897-902 */

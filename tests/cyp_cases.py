@@ -136,3 +136,11 @@ def synthetic_problem(rng, n_d6=4, n_reads=60, noise=0.15, infer=True):
         obs[name] = chains
         sc[name] = rows
     return labels, obs, sc, infer
+
+
+# test_weight_sequence (src/cyp2d6/chaining.rs:1051-1080): three consensuses that differ in one base, a segment equal to the first one,
+# and the same segment with that base unknown
+_WS_HEAD = "AGCCCATTCTGGCCCCTTCCCCACATGCCAGGACAATGTAGTCCTTGTCACCAATCTGGGCAGTCAGAGTTGGGTCAGTGGGG"
+_WS_TAIL = ("ACATGGGATTATGGGCAAGGGTAACAGCCCATTCTGGCCCCTTCCCCACATGCCAGGACAATGTAGTCCTTGTCACCAATCTGGGCAGTCAGAGTTGGGTCAGTGGGGGACATGGGATTATGGGCAAGGGTAAC")
+WEIGHT_SEQUENCE_CONSENSUS = [_WS_HEAD + b + _WS_TAIL for b in "ACG"]
+WEIGHT_SEQUENCE_SEGMENTS = [_WS_HEAD + "A" + _WS_TAIL, _WS_HEAD + "N" + _WS_TAIL]

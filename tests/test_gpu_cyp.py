@@ -212,3 +212,18 @@ def test_variant_states(oracle, pkg, gpu_ctx):
                 assert states[i][v] == (1 if v in truth[i] else 0), (i, v, variants[v])
     assert n_called > 100
     assert (states[-1] == 3).all()
+
+
+def test_weight_sequence_reference_vectors(oracle, pkg, gpu_ctx):
+    """test_weight_sequence (src/cyp2d6/chaining.rs:1051-1080) through K4"""
+    cons = gpu_ctx.upload(cyp_cases.WEIGHT_SEQUENCE_CONSENSUS)
+    segs = gpu_ctx.upload(cyp_cases.WEIGHT_SEQUENCE_SEGMENTS)
+    ed, ov, kept = gpu_ctx.cyp_weight_segments(cons, np.ones(3, np.uint8), segs)
+    s0 = list(zip(ed[0].tolist(), ov[0].tolist()))
+    s1 = list(zip(ed[1].tolist(), ov[1].tolist()))
+    assert kept.tolist() == [1, 1]
+    assert min(s0) == s0[0] and s0[0] < s0[1] and s0[0] < s0[2]
+    assert s1[0] == s1[1] == s1[2]
+    for k, seg in enumerate(cyp_cases.WEIGHT_SEQUENCE_SEGMENTS):
+        e_ed, e_ov, e_kept = of.oracle_weight_sequence(oracle, seg, cyp_cases.WEIGHT_SEQUENCE_CONSENSUS, np.ones(3, np.uint8))
+        assert ed[k].tolist() == e_ed.tolist() and ov[k].tolist() == e_ov.tolist() and kept[k] == e_kept

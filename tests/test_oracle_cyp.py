@@ -55,3 +55,25 @@ def test_synthetic_problems_are_solvable(oracle):
         if res.status == 0:
             assert res.n_possible >= 2 and res.score >= 0.0
     assert n_ok >= 4
+
+
+def test_weight_sequence_reference_vectors(oracle):
+    """src/cyp2d6/chaining.rs:1051-1080: one mismatch ranks strictly worse, an unknown base makes the three consensuses equal"""
+    import numpy as np
+    import oracle_ffi as of
+    assert len(cyp_cases.WEIGHT_SEQUENCE_CONSENSUS[0]) == 218
+    allowed = np.ones(3, np.uint8)
+    ed, ov, kept = of.oracle_weight_sequence(oracle, cyp_cases.WEIGHT_SEQUENCE_SEGMENTS[0], cyp_cases.WEIGHT_SEQUENCE_CONSENSUS, allowed)
+    score = list(zip(ed.tolist(), ov.tolist()))
+    assert kept and min(score) == score[0] and score[0] < score[1] and score[0] < score[2]
+    ed, ov, kept = of.oracle_weight_sequence(oracle, cyp_cases.WEIGHT_SEQUENCE_SEGMENTS[1], cyp_cases.WEIGHT_SEQUENCE_CONSENSUS, allowed)
+    score = list(zip(ed.tolist(), ov.tolist()))
+    assert kept and score[0] == score[1] == score[2]
+
+
+def test_overlap_score(oracle):
+    """src/cyp2d6/haplotyper.rs:936-941"""
+    import ctypes as C
+    f = oracle.L.osp_cyp_overlap_score
+    f.restype = C.c_double
+    assert f(0, 1, 1, 2) == 0.0 and f(0, 10, 1, 5) == 1.0 and f(0, 10, 5, 100) == 0.5 and f(15, 100, 0, 20) == 0.25
