@@ -390,6 +390,40 @@ typedef struct {
 
 int32_t sp_variant_solve(sp_ctx* ctx, const sp_variant_problem* problem, sp_variant_result* result);
 
+/* is_deletion (src/diplotyper.rs:1020-1174): which defined deletion haplotype, if any, a deleted region [start, end) (0-based,
+ * end exclusive) is; its label is what load_sv_vcf_variants (:739-857) attaches to the observed SV (obs_sv_label above).
+ * Full-gene deletions are tried first (is_full_deletion, :1034-1089: a gene counts when its coordinates lie inside the region),
+ * then partial ones (is_partial_deletion, :1098-1174: the first..last exon inside the region, indices mirrored on the reverse
+ * strand).  Within a class the definitions are walked in the order given -- the caller lists them in label (BTreeMap) order
+ * -- a generic definition matches when its genes are all among the deleted ones and is kept until a later one matches, a
+ * specific definition needs the exact set (genes, and exon ranges for partial ones) and ends the walk.
+ *   genes g = 0..n_genes-1: gene_start/gene_end, gene_forward, exons [exon_off[g], exon_off[g+1]) in reference order
+ *   full definition d: genes full_gene[full_off[d] .. full_off[d+1])
+ *   partial definition d: entries [partial_off[d], partial_off[d+1]) = (partial_gene, exons partial_first .. partial_end exclusive)
+ *   a gene id of -1 = a gene without a definition in the gene collection -> SP_ERR_BAD_ARG (the reference bails, :1042-1046)
+ * kind: 0 no match, 1 full deletion, 2 partial deletion; index: the matching definition within its class. */
+typedef struct {
+    int32_t n_genes;
+    const int64_t* gene_start;
+    const int64_t* gene_end;
+    const uint8_t* gene_forward;
+    const int32_t* exon_off;
+    const int64_t* exon_start;
+    const int64_t* exon_end;
+    int32_t n_full;
+    const uint8_t* full_generic;
+    const int32_t* full_off;
+    const int32_t* full_gene;
+    int32_t n_partial;
+    const uint8_t* partial_generic;
+    const int32_t* partial_off;
+    const int32_t* partial_gene;
+    const int32_t* partial_first;
+    const int32_t* partial_end;
+} sp_sv_definitions;
+
+int32_t sp_variant_is_deletion(const sp_sv_definitions* defs, uint64_t start, uint64_t end, int32_t* kind, int32_t* index);
+
 /* ------------------------------------------------------------------ K8: read consensus by dynamic wavefront alignment
  * Serves the waffle_con calls of the reference: DualConsensusDWFA::{add_sequence_offset, consensus} in
  * run_dual_consensus_with_offsets (src/hla/caller.rs:1103-1219) and ConsensusDWFA per read group (src/hla/caller.rs:706-747),

@@ -210,3 +210,81 @@ int osp_solve_diplotype(const osp_variant_problem* p, osp_variant_result* res) {
     free(base); free(base_sv); free(het); free(ps_seen);
     return 0;
 }
+
+/* ---- is_deletion (src/diplotyper.rs:1020-1026): full-gene deletions first, then partial ones ---- */
+
+/* is_full_deletion (src/diplotyper.rs:1034-1089) */
+static int full_deletion(const osp_sv_definitions* d, uint64_t start, uint64_t end, int32_t* index) {
+    uint8_t* deleted = (uint8_t*)calloc((size_t)d->n_genes + 1, 1);
+    /* :1036-1046 every gene named by a definition needs a gene definition */
+    for (int i = 0; i < d->full_off[d->n_full]; ++i) if (d->full_gene[i] < 0 || d->full_gene[i] >= d->n_genes) { free(deleted); return -1; }
+    /* :1049-1064 deletable genes that lie FULLY inside the region */
+    for (int i = 0; i < d->full_off[d->n_full]; ++i) {
+        int g = d->full_gene[i];
+        if ((uint64_t)d->gene_start[g] >= start && (uint64_t)d->gene_end[g] <= end) deleted[g] = 1;
+    }
+    int n_deleted = 0; for (int g = 0; g < d->n_genes; ++g) n_deleted += deleted[g];
+    *index = -1;
+    for (int k = 0; k < d->n_full; ++k) {                                   /* :1068-1086, BTreeMap (label) order */
+        int lo = d->full_off[k], hi = d->full_off[k + 1], all_in = 1, uniq = 0;
+        for (int i = lo; i < hi; ++i) {
+            if (!deleted[d->full_gene[i]]) all_in = 0;
+            int dup = 0; for (int j = lo; j < i; ++j) if (d->full_gene[j] == d->full_gene[i]) dup = 1;
+            uniq += !dup;
+        }
+        if (d->full_generic[k]) { if (all_in) *index = k; }                 /* superset: keep looking for a specific one */
+        else if (all_in && uniq == n_deleted) { *index = k; break; }        /* set equality */
+    }
+    free(deleted);
+    return 0;
+}
+
+/* is_partial_deletion (src/diplotyper.rs:1098-1174) */
+static int partial_deletion(const osp_sv_definitions* d, uint64_t start, uint64_t end, int32_t* index) {
+    int n = d->n_genes;
+    uint8_t* deletable = (uint8_t*)calloc((size_t)n + 1, 1);
+    int32_t* first = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    int32_t* last = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    int rc = 0;
+    for (int i = 0; i < d->partial_off[d->n_partial]; ++i) {               /* :1100-1110 */
+        if (d->partial_gene[i] < 0 || d->partial_gene[i] >= n) { rc = -1; goto done; }
+        deletable[d->partial_gene[i]] = 1;
+    }
+    for (int g = 0; g < n; ++g) {                                           /* :1113-1148 first..last exon fully inside the region */
+        first[g] = last[g] = -1;
+        if (!deletable[g]) continue;
+        int ne = d->exon_off[g + 1] - d->exon_off[g];
+        for (int x = 0; x < ne; ++x) {
+            uint64_t es = (uint64_t)d->exon_start[d->exon_off[g] + x], ee = (uint64_t)d->exon_end[d->exon_off[g] + x];
+            if (es >= start && ee <= end) { if (first[g] < 0) first[g] = x; last[g] = x; }
+        }
+        if (!d->gene_forward[g] && first[g] >= 0) {                         /* exons are stored in reference orientation (:1131-1139) */
+            int f = ne - 1 - last[g], l = ne - 1 - first[g];
+            first[g] = f; last[g] = l;
+        }
+    }
+    int n_deleted = 0; for (int g = 0; g < n; ++g) n_deleted += first[g] >= 0;
+    *index = -1;
+    for (int k = 0; k < d->n_partial; ++k) {                                /* :1153-1171 */
+        int lo = d->partial_off[k], hi = d->partial_off[k + 1], keys_in = 1, same = 1;
+        for (int i = lo; i < hi; ++i) {
+            int g = d->partial_gene[i];
+            if (first[g] < 0) { keys_in = 0; same = 0; continue; }
+            if (first[g] != d->partial_first[i] || last[g] + 1 != d->partial_end[i]) same = 0;
+        }
+        if (d->partial_generic[k]) { if (keys_in) *index = k; }
+        else if (same && hi - lo == n_deleted) { *index = k; break; }       /* map equality: same genes, same ranges */
+    }
+done:
+    free(deletable); free(first); free(last);
+    return rc;
+}
+
+int osp_is_deletion(const osp_sv_definitions* d, uint64_t start, uint64_t end, int32_t* kind, int32_t* index) {
+    *kind = 0; *index = -1;
+    if (full_deletion(d, start, end, index) != 0) return -1;
+    if (*index >= 0) { *kind = 1; return 0; }
+    if (partial_deletion(d, start, end, index) != 0) return -1;
+    if (*index >= 0) *kind = 2;
+    return 0;
+}

@@ -52,6 +52,18 @@ void osp_quant_match(const osp_variant_problem* p, int h, const int32_t* obs, in
 void osp_find_best_inexact(const osp_variant_problem* p, const int32_t* obs, const int32_t* obs_sv_label, int n_obs, osp_inexact* out);
 int  osp_solve_diplotype(const osp_variant_problem* p, osp_variant_result* res);
 
+/* gene collection + structural variant definitions of one gene entry, flattened (same layout as sp_sv_definitions) */
+typedef struct {
+    int32_t n_genes;
+    const int64_t* gene_start; const int64_t* gene_end; const uint8_t* gene_forward;
+    const int32_t* exon_off; const int64_t* exon_start; const int64_t* exon_end;
+    int32_t n_full; const uint8_t* full_generic; const int32_t* full_off; const int32_t* full_gene;
+    int32_t n_partial; const uint8_t* partial_generic; const int32_t* partial_off; const int32_t* partial_gene;
+    const int32_t* partial_first; const int32_t* partial_end;
+} osp_sv_definitions;
+/* 0 ok (kind 0 none / 1 full / 2 partial, index within the class), -1 = a definition names a gene without a gene definition */
+int osp_is_deletion(const osp_sv_definitions* d, uint64_t start, uint64_t end, int32_t* kind, int32_t* index);
+
 #ifdef __cplusplus
 }
 #endif

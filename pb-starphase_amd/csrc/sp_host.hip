@@ -5,6 +5,8 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <map>
+#include <set>
 
 namespace {
 // statrs::function::factorial::ln_factorial: products up to 170!, ln_gamma beyond
@@ -299,6 +301,59 @@ int32_t sp_cyp_build_chains(uint32_t n_haps, const int32_t* hap_type, uint32_t n
     info->n_reads = (uint32_t)rec_read.size(); info->n_chains = (uint32_t)nc; info->n_items = (uint32_t)ni; info->n_rows = n_rows;
     if (collapse) return SP_ERR_CHAIN_COLLAPSE;
     return fits ? SP_OK : SP_ERR_CAPACITY;
+}
+
+// is_deletion (src/diplotyper.rs:1020-1174).  Kept on the host: a handful of interval tests per SV record.
+int32_t sp_variant_is_deletion(const sp_sv_definitions* defs, uint64_t start, uint64_t end, int32_t* kind, int32_t* index) {
+    if (!defs || !kind || !index || defs->n_genes < 0 || defs->n_full < 0 || defs->n_partial < 0) return SP_ERR_INVALID_ARG;
+    *kind = 0; *index = -1;
+    const sp_sv_definitions& d = *defs;
+    auto inside = [&](int64_t s, int64_t e) { return (uint64_t)s >= start && (uint64_t)e <= end; };
+    auto known = [&](int32_t g) { return g >= 0 && g < d.n_genes; };
+
+    // full-gene deletions: the set of named genes the region swallows whole
+    if (d.n_full > 0) {
+        std::set<int32_t> gone;
+        for (int32_t i = 0; i < d.full_off[d.n_full]; ++i) {
+            const int32_t g = d.full_gene[i];
+            if (!known(g)) return SP_ERR_INVALID_ARG;
+            if (inside(d.gene_start[g], d.gene_end[g])) gone.insert(g);
+        }
+        for (int32_t k = 0; k < d.n_full; ++k) {
+            const std::set<int32_t> want(d.full_gene + d.full_off[k], d.full_gene + d.full_off[k + 1]);
+            if (d.full_generic[k]) {
+                if (std::includes(gone.begin(), gone.end(), want.begin(), want.end())) *index = k;     // a later specific one may still win
+            } else if (want == gone) { *index = k; break; }
+        }
+        if (*index >= 0) { *kind = 1; return SP_OK; }
+    }
+
+    // partial deletions: per named gene, the transcript-order range of exons the region swallows whole
+    if (d.n_partial > 0) {
+        std::map<int32_t, std::pair<int32_t, int32_t>> gone;
+        for (int32_t i = 0; i < d.partial_off[d.n_partial]; ++i) if (!known(d.partial_gene[i])) return SP_ERR_INVALID_ARG;
+        for (int32_t i = 0; i < d.partial_off[d.n_partial]; ++i) {
+            const int32_t g = d.partial_gene[i];
+            if (gone.count(g)) continue;
+            const int32_t e0 = d.exon_off[g], ne = d.exon_off[g + 1] - e0;
+            int32_t lo = -1, hi = -1;
+            for (int32_t x = 0; x < ne; ++x) if (inside(d.exon_start[e0 + x], d.exon_end[e0 + x])) { if (lo < 0) lo = x; hi = x; }
+            if (lo < 0) continue;
+            gone[g] = d.gene_forward[g] ? std::make_pair(lo, hi + 1) : std::make_pair(ne - 1 - hi, ne - lo);
+        }
+        for (int32_t k = 0; k < d.n_partial; ++k) {
+            std::map<int32_t, std::pair<int32_t, int32_t>> want;
+            bool keys_gone = true;
+            for (int32_t i = d.partial_off[k]; i < d.partial_off[k + 1]; ++i) {
+                want[d.partial_gene[i]] = std::make_pair(d.partial_first[i], d.partial_end[i]);
+                keys_gone = keys_gone && gone.count(d.partial_gene[i]) > 0;
+            }
+            if (d.partial_generic[k]) { if (keys_gone) *index = k; }
+            else if (want == gone) { *index = k; break; }
+        }
+        if (*index >= 0) *kind = 2;
+    }
+    return SP_OK;
 }
 
 } // extern "C"

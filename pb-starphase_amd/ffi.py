@@ -91,6 +91,14 @@ class sp_variant_result(C.Structure):
                 ("dip_comb", C.c_int32 * SP_VAR_MAXDIP)]
 
 
+class sp_sv_definitions(C.Structure):
+    _fields_ = [("n_genes", C.c_int32), ("gene_start", C.c_void_p), ("gene_end", C.c_void_p), ("gene_forward", C.c_void_p),
+                ("exon_off", C.c_void_p), ("exon_start", C.c_void_p), ("exon_end", C.c_void_p),
+                ("n_full", C.c_int32), ("full_generic", C.c_void_p), ("full_off", C.c_void_p), ("full_gene", C.c_void_p),
+                ("n_partial", C.c_int32), ("partial_generic", C.c_void_p), ("partial_off", C.c_void_p), ("partial_gene", C.c_void_p),
+                ("partial_first", C.c_void_p), ("partial_end", C.c_void_p)]
+
+
 class sp_cons_config(C.Structure):
     _fields_ = [("min_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("allow_early_termination", C.c_int32), ("allow_dual", C.c_int32),
                 ("offset_window", C.c_int32), ("offset_compare_length", C.c_int32), ("min_af", C.c_double)]
@@ -207,6 +215,7 @@ def lib():
         "sp_cyp_weight_segments": (i32, [vp, vp, vp, vp, vp, vp, vp]),
         "sp_cyp_score_alleles": (i32, [vp, u32, u32, vp, vp, u32, vp, vp, vp, vp]),
         "sp_variant_solve": (i32, [vp, C.POINTER(sp_variant_problem), C.POINTER(sp_variant_result)]),
+        "sp_variant_is_deletion": (i32, [C.POINTER(sp_sv_definitions), u64, u64, C.POINTER(i32), C.POINTER(i32)]),
         "sp_hla_is_passing_dual": (i32, [u64, u64, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sp_hla_is_hemizygous_better": (i32, [vp, vp, vp, u32, i32, u64, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sp_hpc_pos": (u64, [C.c_char_p, u64, u64]),
@@ -511,6 +520,66 @@ def normalize_variant(chrom_seq, position, ref, alt, cap=4096):
     if rc != SP_OK:
         raise StarphaseError(rc, "sp_variant_normalize")
     return int(pos.value), r.value.decode(), a.value.decode()
+
+
+class SvDefinitions:
+    """GeneCollection (src/data_types/gene_definition.rs) + one gene entry's PgxStructuralVariants
+    (src/database/pgx_structural_variants.rs), flattened for sp_variant_is_deletion.  gene_dict: name -> {"coordinates": {start, end},
+    "exons": [{start, end}], "is_forward_strand"}; structural_variants: {"full_gene_deletions": {label: {"is_generic",
+    "full_genes_deleted": [gene]}}, "partial_gene_deletions": {label: {"is_generic", "exons_deleted": {gene: {start, end}}}}}.
+    Definitions are kept in label order (the reference walks BTreeMaps)."""
+
+    def __init__(self, gene_dict, structural_variants):
+        names = sorted(gene_dict)
+        gid = {g: i for i, g in enumerate(names)}
+        self.gene_start = np.array([gene_dict[g]["coordinates"]["start"] for g in names] or [0], np.int64)
+        self.gene_end = np.array([gene_dict[g]["coordinates"]["end"] for g in names] or [0], np.int64)
+        self.gene_forward = np.array([1 if gene_dict[g]["is_forward_strand"] else 0 for g in names] or [0], np.uint8)
+        exon_off, es, ee = [0], [], []
+        for g in names:
+            for x in gene_dict[g]["exons"]:
+                es.append(x["start"]); ee.append(x["end"])
+            exon_off.append(len(es))
+        self.exon_off = np.array(exon_off, np.int32)
+        self.exon_start, self.exon_end = np.array(es or [0], np.int64), np.array(ee or [0], np.int64)
+        full = structural_variants.get("full_gene_deletions", {})
+        part = structural_variants.get("partial_gene_deletions", {})
+        self.full_labels, self.partial_labels = sorted(full), sorted(part)
+        fo, fg = [0], []
+        for k in self.full_labels:
+            fg += [gid.get(g, -1) for g in sorted(full[k]["full_genes_deleted"])]
+            fo.append(len(fg))
+        po, pg, pf, pe = [0], [], [], []
+        for k in self.partial_labels:
+            for g in sorted(part[k]["exons_deleted"]):
+                pg.append(gid.get(g, -1)); pf.append(part[k]["exons_deleted"][g]["start"]); pe.append(part[k]["exons_deleted"][g]["end"])
+            po.append(len(pg))
+        self.full_generic = np.array([1 if full[k]["is_generic"] else 0 for k in self.full_labels] or [0], np.uint8)
+        self.partial_generic = np.array([1 if part[k]["is_generic"] else 0 for k in self.partial_labels] or [0], np.uint8)
+        self.full_off, self.full_gene = np.array(fo, np.int32), np.array(fg or [0], np.int32)
+        self.partial_off, self.partial_gene = np.array(po, np.int32), np.array(pg or [0], np.int32)
+        self.partial_first, self.partial_end = np.array(pf or [0], np.int32), np.array(pe or [0], np.int32)
+        self.n_genes = len(names)
+
+    def struct(self, cls=None):
+        d = (cls or sp_sv_definitions)()
+        d.n_genes, d.n_full, d.n_partial = self.n_genes, len(self.full_labels), len(self.partial_labels)
+        for f in ("gene_start", "gene_end", "gene_forward", "exon_off", "exon_start", "exon_end", "full_generic", "full_off", "full_gene",
+                  "partial_generic", "partial_off", "partial_gene", "partial_first", "partial_end"):
+            setattr(d, f, getattr(self, f).ctypes.data)
+        return d
+
+    def label(self, kind, index):
+        return None if kind == 0 else (self.full_labels if kind == 1 else self.partial_labels)[index]
+
+    def is_deletion(self, start, end):
+        """is_deletion (src/diplotyper.rs:1020): the label of the defined deletion covering [start, end), or None"""
+        kind, index = C.c_int32(0), C.c_int32(-1)
+        d = self.struct()
+        rc = lib().sp_variant_is_deletion(C.byref(d), int(start), int(end), C.byref(kind), C.byref(index))
+        if rc != SP_OK:
+            raise StarphaseError(rc, "sp_variant_is_deletion")
+        return self.label(kind.value, index.value)
 
 
 def multi_normalize_variant(chrom_seq, position, ref, alt, cap=4096, max_out=16):

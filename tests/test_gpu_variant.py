@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import variant_glue as vg
-from test_oracle_variant import CASES
+from test_oracle_variant import CASES, SV_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +31,39 @@ def test_reference_scenarios(oracle, pkg, gpu_ctx, case):
     _g2, prob2 = vg.load_case(vg.ProductNormalizer(pkg), db, vcf, with_ref)
     assert prob2.obs == prob.obs and [h["slots"] for h in prob2.haps] == [h["slots"] for h in prob.haps]
     assert gpu_ctx.variant_solve(gpu_struct(pkg, prob2)) == exp
+
+
+@pytest.mark.parametrize("case", SV_CASES, ids=lambda c: c[0])
+def test_sv_scenarios(oracle, pkg, gpu_ctx, case):
+    """test_multiple_sv_haplotypes (src/diplotyper.rs:2276-2304): SV records labelled by sp_variant_is_deletion, solved by K6,
+    strings built by sp_inexact_haplotype / sp_diplotype_string"""
+    sv_vcf, dips, inexact = case
+    _g, prob = vg.load_case(vg.ProductNormalizer(pkg), "DPYD-sv-test", "DPYD-sv-test/empty_small.vcf.gz", True, sv_vcf_key=sv_vcf,
+                            is_deletion=lambda defs, s, e: defs.is_deletion(s, e))
+    _g, oprob = vg.load_case(oracle, "DPYD-sv-test", "DPYD-sv-test/empty_small.vcf.gz", True, sv_vcf_key=sv_vcf)
+    assert prob.obs == oprob.obs and prob.obs_sv.tolist() == oprob.obs_sv.tolist()
+    assert gpu_ctx.variant_solve(gpu_struct(pkg, prob)) == vg.oracle_solve(oracle, oprob)
+    got = vg.call_gene(oracle, prob, solver=lambda pr: gpu_ctx.variant_solve(gpu_struct(pkg, pr)))
+    assert got["diplotypes"] == dips
+    L = pkg.ffi.lib()
+
+    def full(hap):
+        rel = dict(Match=1, Unexpected=2, Missing=3)
+        vs = list(hap[1])
+        labels = (C.c_char_p * max(1, len(vs)))(*[v[0].encode() for v in vs])
+        vi, st = np.array([v[1] for v in vs] or [0], np.uint8), np.array([rel[v[2]] for v in vs] or [0], np.int32)
+        mt, out = C.c_int32(0), C.create_string_buffer(512)
+        L.sp_inexact_haplotype(hap[0].encode(), len(vs), labels, vi.ctypes.data, st.ctypes.data, C.byref(mt), out, 512)
+        return out.value
+    if inexact is None:
+        assert got["inexact"] is None
+    else:
+        strings = []
+        for a, b in got["inexact"]:
+            out = C.create_string_buffer(512)
+            L.sp_diplotype_string(full(a), full(b), 0, out, 512)
+            strings.append(out.value.decode())
+        assert strings == inexact
 
 
 class RandomProblem(vg.Problem):

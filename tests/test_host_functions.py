@@ -309,3 +309,56 @@ def test_inexact_haplotype_strings(pkg, oracle):
     h1 = _inexact(pkg, oracle, "*1", [("v1", 1, "Match"), ("v2", 1, "Unexpected")])[1]
     h2 = _inexact(pkg, oracle, "*2", [("v2", 1, "Match")])[1]
     assert _dip(pkg, oracle, h1, h2, False) == "(*1 +v2)/*2"
+
+
+# ------------------------------------------------------------------ is_deletion (src/diplotyper.rs:1020-1174)
+def test_is_deletion_vectors(pkg, oracle):
+    """test_deletion_search (src/diplotyper.rs:2169-2251) through sp_variant_is_deletion; reverse strand; undefined gene"""
+    import pytest
+    import variant_glue as vg
+    from test_oracle_variant import DELETION_SEARCH, deletion_search_defs
+    genes, svs, defs = deletion_search_defs(pkg)
+    for start, end, want in DELETION_SEARCH:
+        assert defs.is_deletion(start, end) == want, (start, end)
+    genes["gene2"]["is_forward_strand"] = False
+    rev = pkg.ffi.SvDefinitions(genes, svs)
+    assert rev.is_deletion(100, 145) == "specific_partial" and rev.is_deletion(125, 200) == "generic_partial"
+    svs["partial_gene_deletions"]["ghost"] = {"is_generic": True, "exons_deleted": {"gene3": {"start": 0, "end": 1}}}
+    with pytest.raises(pkg.StarphaseError):
+        pkg.ffi.SvDefinitions(genes, svs).is_deletion(0, 1)
+    assert pkg.ffi.SvDefinitions(genes, {}).is_deletion(0, 1000) is None          # a gene entry without definitions
+
+
+def test_is_deletion_random(pkg, oracle):
+    """random gene collections / definitions / regions: the library and the oracle pick the same definition"""
+    import variant_glue as vg
+    rng = np.random.default_rng(77)
+    for _trial in range(60):
+        genes, pos = {}, 0
+        for g in range(int(rng.integers(1, 5))):
+            pos += int(rng.integers(5, 40))
+            start, exons = pos, []
+            for _x in range(int(rng.integers(1, 6))):
+                e = pos + int(rng.integers(3, 20))
+                exons.append({"start": pos, "end": e})
+                pos = e + int(rng.integers(2, 20))
+            genes[f"g{g}"] = {"coordinates": {"chrom": "c", "start": start, "end": exons[-1]["end"]}, "exons": exons,
+                              "is_forward_strand": bool(rng.integers(0, 2))}
+        names = sorted(genes)
+        pick = lambda: [names[i] for i in sorted(rng.choice(len(names), size=int(rng.integers(1, len(names) + 1)), replace=False))]
+        svs = {"full_gene_deletions": {}, "partial_gene_deletions": {}}
+        for k in range(int(rng.integers(0, 4))):
+            svs["full_gene_deletions"][f"f{k}"] = {"is_generic": bool(rng.integers(0, 2)), "full_genes_deleted": pick()}
+        for k in range(int(rng.integers(0, 5))):
+            ex = {}
+            for g in pick():
+                ne = len(genes[g]["exons"])
+                a = int(rng.integers(0, ne)); b = int(rng.integers(a + 1, ne + 1))
+                ex[g] = {"start": a, "end": b}
+            svs["partial_gene_deletions"][f"p{k}"] = {"is_generic": bool(rng.integers(0, 2)), "exons_deleted": ex}
+        defs = pkg.ffi.SvDefinitions(genes, svs)
+        edges = sorted({0, pos + 10} | {x[k] for g in genes.values() for x in g["exons"] for k in ("start", "end")})
+        for _q in range(40):
+            a, b = sorted(int(v) for v in rng.choice(edges, size=2, replace=False))
+            a, b = max(0, a - int(rng.integers(0, 2))), b + int(rng.integers(0, 2))
+            assert defs.is_deletion(a, b) == vg.oracle_is_deletion(oracle, defs, a, b), (genes, svs, a, b)

@@ -105,3 +105,89 @@ def test_diplotyper_scenarios(oracle, case):
     if vcf.endswith("suballele_match.vcf.gz"):
         assert got["simple"] == [("*2", "*2")]
 
+
+
+# ------------------------------------------------------------------ structural variants
+def deletion_search_defs(pkg):
+    """the gene collection and definitions of test_deletion_search (src/diplotyper.rs:2169-2234)"""
+    genes = {"gene1": {"coordinates": {"chrom": "chrom", "start": 10, "end": 50}, "is_forward_strand": True,
+                       "exons": [{"start": 10, "end": 20}, {"start": 30, "end": 50}]},
+             "gene2": {"coordinates": {"chrom": "chrom", "start": 100, "end": 200}, "is_forward_strand": True,
+                       "exons": [{"start": 100, "end": 120}, {"start": 130, "end": 140}, {"start": 150, "end": 200}]}}
+    svs = {"full_gene_deletions": {"generic_del": {"is_generic": True, "full_genes_deleted": ["gene2"]},
+                                   "double_full_del": {"is_generic": False, "full_genes_deleted": ["gene1", "gene2"]}},
+           "partial_gene_deletions": {"generic_partial": {"is_generic": True, "exons_deleted": {"gene2": {"start": 0, "end": 3}}},
+                                      "specific_partial": {"is_generic": False, "exons_deleted": {"gene2": {"start": 1, "end": 3}}},
+                                      "multigene_partial": {"is_generic": False, "exons_deleted": {"gene1": {"start": 1, "end": 2},
+                                                                                                  "gene2": {"start": 0, "end": 1}}}}}
+    return genes, svs, pkg.ffi.SvDefinitions(genes, svs)
+
+
+DELETION_SEARCH = [                                 # src/diplotyper.rs:2237-2250
+    (0, 1, None), (125, 127, None), (125, 135, None), (5, 55, None),
+    (100, 200, "generic_del"), (30, 200, "generic_del"), (5, 200, "double_full_del"),
+    (100, 150, "generic_partial"), (125, 200, "specific_partial"), (25, 125, "multigene_partial"),
+]
+
+
+def test_deletion_search(oracle, pkg):
+    """test_deletion_search (src/diplotyper.rs:2169-2251)"""
+    _g, _s, defs = deletion_search_defs(pkg)
+    for start, end, want in DELETION_SEARCH:
+        assert vg.oracle_is_deletion(oracle, defs, start, end) == want, (start, end)
+
+
+def test_deletion_search_reverse_strand_and_missing_gene(oracle, pkg):
+    """exon indices are mirrored on the reverse strand (:1131-1139); a definition naming an undefined gene is an error (:1042-1046)"""
+    genes, svs, _d = deletion_search_defs(pkg)
+    genes["gene2"]["is_forward_strand"] = False
+    defs = pkg.ffi.SvDefinitions(genes, svs)
+    assert vg.oracle_is_deletion(oracle, defs, 100, 145) == "specific_partial"     # reference exons 0-1 = transcript exons 1..3
+    assert vg.oracle_is_deletion(oracle, defs, 125, 200) == "generic_partial"      # reference exons 1-2 = transcript exons 0..2: only generic
+    svs["full_gene_deletions"]["ghost_del"] = {"is_generic": False, "full_genes_deleted": ["gene3"]}
+    with pytest.raises(ValueError):
+        vg.oracle_is_deletion(oracle, pkg.ffi.SvDefinitions(genes, svs), 0, 1)
+
+
+def inexact_string(oracle, hap):
+    """InexactHaplotype::full_haplotype through the oracle's osp_inexact_haplotype"""
+    import ctypes as C
+    import numpy as np
+    rel = dict(Match=1, Unexpected=2, Missing=3)
+    vs = sorted(hap[1], key=lambda v: (v[0], v[1], rel[v[2]]))
+    labels = (C.c_char_p * max(1, len(vs)))(*[v[0].encode() for v in vs])
+    vi, st = np.array([v[1] for v in vs] or [0], np.uint8), np.array([rel[v[2]] for v in vs] or [0], np.int32)
+    out = C.create_string_buffer(512)
+    oracle.L.osp_inexact_haplotype(hap[0].encode(), len(vs), labels, vi.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), out, C.c_size_t(512))
+    return out.value.decode()
+
+
+SV_CASES = [
+    # (sv vcf, expected diplotypes, expected inexact diplotype strings or None)     test_multiple_sv_haplotypes (src/diplotyper.rs:2276-2304)
+    ("DPYD-sv-test/multi_del.vcf.gz", [("generic exon del", "generic exon del")], None),
+    ("DPYD-sv-test/hom_del.vcf.gz", [("NO_MATCH", "NO_MATCH")], ["generic exon del/(generic exon del +generic exon del)"]),
+]
+
+
+@pytest.mark.parametrize("case", SV_CASES, ids=lambda c: c[0])
+def test_multiple_sv_haplotypes(oracle, case):
+    sv_vcf, dips, inexact = case
+    _gene, prob = vg.load_case(oracle, "DPYD-sv-test", "DPYD-sv-test/empty_small.vcf.gz", True, sv_vcf_key=sv_vcf)
+    assert len(prob.obs) == 2 and all(len(v) == 5 for v in prob.obs)
+    got = vg.call_gene(oracle, prob)
+    assert got["diplotypes"] == dips, got
+    if inexact is None:
+        assert got["inexact"] is None and got["simple"] == dips
+    else:
+        assert [inexact_string(oracle, a) + "/" + inexact_string(oracle, b) for a, b in got["inexact"]] == inexact
+
+
+def test_simplify_diplotypes():
+    """test_simplify_diplotypes (src/diplotyper.rs:2253-2273) + the SV keys of build_core_allele_lookup (:389-396)"""
+    lookup = {"*1.002": "*1", "*2.001": "*2", "*3.001": "*3", "*4.001": "*4"}
+    assert vg.simplify_diplotypes([("*1.002", "*2.001"), ("*2.001", "*3.001"), ("*3.001", "*4.001")], lookup) == [("*1", "*2"), ("*2", "*3"), ("*3", "*4")]
+    haps = [{"name": "*1", "core_allele": None}, {"name": "*2.001", "core_allele": "*2"}]
+    svs = {"full_gene_deletions": {"*5.001": {}}, "partial_gene_deletions": {"generic exon del": {}}}
+    assert vg.build_core_allele_lookup(haps, svs) == {"*1": "*1", "*2.001": "*2", "*5.001": "*5", "generic exon del": "generic exon del"}
+    with pytest.raises(KeyError):
+        vg.simplify_diplotypes([("*9", "*1")], lookup)

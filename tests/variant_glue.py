@@ -154,11 +154,121 @@ def load_vcf_variants(oracle, vcf, variant_hash, genome):
     return found
 
 
+class SvDefsStruct(C.Structure):
+    """osp_sv_definitions (same layout as the library's sp_sv_definitions)"""
+    _fields_ = [("n_genes", C.c_int32), ("gene_start", C.c_void_p), ("gene_end", C.c_void_p), ("gene_forward", C.c_void_p),
+                ("exon_off", C.c_void_p), ("exon_start", C.c_void_p), ("exon_end", C.c_void_p),
+                ("n_full", C.c_int32), ("full_generic", C.c_void_p), ("full_off", C.c_void_p), ("full_gene", C.c_void_p),
+                ("n_partial", C.c_int32), ("partial_generic", C.c_void_p), ("partial_off", C.c_void_p), ("partial_gene", C.c_void_p),
+                ("partial_first", C.c_void_p), ("partial_end", C.c_void_p)]
+
+
+def oracle_is_deletion(oracle, defs, start, end):
+    """defs: the package's SvDefinitions (a pure-Python flattening); the decision is oracle/variant.c's osp_is_deletion"""
+    kind, index = C.c_int32(0), C.c_int32(-1)
+    d = defs.struct(SvDefsStruct)
+    oracle.L.osp_is_deletion.restype = C.c_int
+    oracle.L.osp_is_deletion.argtypes = [C.POINTER(SvDefsStruct), C.c_uint64, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    if oracle.L.osp_is_deletion(C.byref(d), int(start), int(end), C.byref(kind), C.byref(index)) != 0:
+        raise ValueError("Gene collection does not contain a definition for a deletable gene")
+    return defs.label(kind.value, index.value)
+
+
+def load_sv_vcf_variants(is_deletion, vcf, structural_variants, gene_dict, max_sv_length=1000000):
+    """load_sv_vcf_variants (src/diplotyper.rs:739-857) on the rows of one decoded test VCF.  Returns {sv variant: (genotype, ps)};
+    an SV variant is the 5-tuple (chrom, start, "", "", ("Deletion", start, end, label)) -- NormalizedVariant::new_sv's fields, so
+    tuple order = the derived Ord (sv_stats None sorts before Some: shorter tuples first)."""
+    if not structural_variants:
+        return {}
+    genes = set()
+    for fd in structural_variants.get("full_gene_deletions", {}).values():
+        genes |= set(fd["full_genes_deleted"])
+    for pd in structural_variants.get("partial_gene_deletions", {}).values():
+        genes |= set(pd["exons_deleted"])
+    chrom, lo, hi = None, None, 0
+    for g in sorted(genes):
+        if g not in gene_dict:
+            raise ValueError(f"Missing gene definition ({g}) for structural variant")
+        c = gene_dict[g]["coordinates"]
+        if chrom is not None and chrom != c["chrom"]:
+            raise ValueError("Structural variant gene set is not all on the same chromosome")
+        chrom = c["chrom"]
+        lo, hi = c["start"] if lo is None else min(lo, c["start"]), max(hi, c["end"])
+    if chrom is None:
+        return {}
+    sample = [c for c in vcf["columns"] if c not in ("CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT")][0]
+    found = {}
+    for row in vcf["rows"]:
+        info = dict(kv.split("=", 1) for kv in row["INFO"].split(";") if "=" in kv)
+        start = int(row["POS"]) - 1
+        if row["CHROM"] != chrom or len(row["ALT"].split(",")) != 1:
+            continue
+        if "SVTYPE" not in info:
+            raise ValueError("No INFO:SVTYPE in record")
+        if info["SVTYPE"] != "DEL":
+            continue
+        if "END" not in info:
+            raise ValueError("No INFO:END in record")
+        end = int(info["END"])
+        if not (start < hi and end > lo):            # the indexed fetch of the gene span
+            continue
+        if end - start > max_sv_length:
+            continue
+        label = is_deletion(start, end)
+        if label is None:
+            continue
+        fmt = dict(zip(row["FORMAT"].split(":"), row[sample].split(":")))
+        gt = fmt["GT"]
+        a = gt.replace("|", "/").split("/")
+        if len(a) != 2 or "." in a:
+            continue
+        phased = "|" in gt
+        ps = None
+        if phased:
+            if fmt.get("PS", ".") != ".":
+                ps = int(fmt["PS"])
+            else:
+                phased = False
+        g1, g2 = int(a[0]), int(a[1])
+        assert g1 < 2 and g2 < 2
+        if g1 == g2:
+            if g1 == 0:
+                continue
+            code = 4
+        elif phased:
+            code = 2 if g1 == 0 else 3
+        else:
+            code = 1
+        key = (chrom, start, "", "", ("Deletion", start, end, label))
+        if key in found:
+            raise ValueError("Detected duplicate entry for normalized SV")
+        found[key] = (code, ps)
+    return found
+
+
+def build_core_allele_lookup(haps, structural_variants):
+    """src/diplotyper.rs:378-399"""
+    lookup = {h["name"]: (h["core_allele"] or h["name"]) for h in haps}
+    for cls in ("full_gene_deletions", "partial_gene_deletions"):
+        for key in (structural_variants or {}).get(cls, {}):
+            lookup[key] = key.split(".")[0]
+    return lookup
+
+
+def simplify_diplotypes(diplotypes, lookup):
+    """src/diplotyper.rs:408-421 (KeyError where the reference reports a missing core allele)"""
+    return [(lookup[a], lookup[b]) for a, b in diplotypes]
+
+
 class Problem:
-    def __init__(self, variant_hash, haps, observed):
-        self.var_list = sorted(variant_hash)
+    def __init__(self, variant_hash, haps, observed, structural_variants=None):
+        # observed SVs are variants too (they reach quant_match as "extra" ones); all SVs are core variants (:156-164)
+        sv_obs = [v for v in observed if len(v) == 5]
+        self.var_list = sorted(set(variant_hash) | set(sv_obs))
         self.var_id = {v: i for i, v in enumerate(self.var_list)}
-        self.var_meta = [variant_hash[v] for v in self.var_list]
+        self.var_meta = [variant_hash.get(v) or {"variant_id": None, "name": "structural_variant", "is_core_variant": True} for v in self.var_list]
+        self.sv_labels = sorted({v[4][3] for v in sv_obs})
+        self.core_lookup = build_core_allele_lookup(haps, structural_variants)
         self.haps = haps
         slot_off, alt_off, alt_var = [0], [0], []
         for h in haps:
@@ -176,7 +286,7 @@ class Problem:
         self.obs_var = np.array([self.var_id[v] for v in self.obs] or [0], np.int32)
         self.obs_gt = np.array([observed[v][0] for v in self.obs] or [0], np.int32)
         self.obs_ps = np.array([(-1 if observed[v][1] is None else observed[v][1]) for v in self.obs] or [0], np.int64)
-        self.obs_sv = np.full(max(1, len(self.obs)), -1, np.int32)
+        self.obs_sv = np.array([(self.sv_labels.index(v[4][3]) if len(v) == 5 else -1) for v in self.obs] or [-1], np.int32)
 
     def struct(self):
         p = VariantProblem()
@@ -245,14 +355,23 @@ def inexact_haplotype(oracle, prob, h, obs_ids):
 def call_gene(oracle, prob, solver=None):
     """solve + the packaging of call_diplotypes (src/diplotyper.rs:130-204): returns dict(diplotypes, simple, inexact)"""
     score, dips = (solver or oracle_solve)(oracle, prob) if solver is None else solver(prob)
-    names = lambda d: (prob.haps[d[0]]["name"], prob.haps[d[1]]["name"])
-    core = {h["name"]: (h["core_allele"] or h["name"]) for h in prob.haps}
+    hap_name = lambda h: prob.sv_labels[-h - 2] if h < 0 else prob.haps[h]["name"]       # an SV label is encoded as -(label + 2)
+    names = lambda d: (hap_name(d[0]), hap_name(d[1]))
+    core = prob.core_lookup
     main = [names(d) for d in dips]
+
+    def side(h, obs_ids):
+        if h >= 0:
+            return inexact_haplotype(oracle, prob, h, obs_ids)
+        # the SV short-circuit (:1414-1431): the first label names the haplotype, the other labels are unexpected core variants
+        labels = [prob.var_list[v][4][3] for v in obs_ids if len(prob.var_list[v]) == 5]
+        assert labels[0] == hap_name(h)
+        return (labels[0], frozenset((l, True, "Unexpected") for l in labels[1:]))
     ext = []
     for d in dips:
         h1, h2 = het_split(prob, d[2]) if any(g != 4 for g in prob.obs_gt[:len(prob.obs)]) else (
             [int(v) for v in prob.obs_var[:len(prob.obs)]], [int(v) for v in prob.obs_var[:len(prob.obs)]])
-        ext.append((inexact_haplotype(oracle, prob, d[0], h1), inexact_haplotype(oracle, prob, d[1], h2)))
+        ext.append((side(d[0], h1), side(d[1], h2)))
     if score == (0, 0, 0, 0):
         return {"score": score, "diplotypes": main, "simple": [(core[a], core[b]) for a, b in main], "inexact": None}
     if score[:2] == (0, 0):
@@ -261,7 +380,8 @@ def call_gene(oracle, prob, solver=None):
     return {"score": score, "diplotypes": [("NO_MATCH", "NO_MATCH")], "simple": [("NO_MATCH", "NO_MATCH")], "inexact": ext}
 
 
-def load_case(oracle, db_name, vcf_key, with_reference):
+def load_case(oracle, db_name, vcf_key, with_reference, sv_vcf_key=None, is_deletion=None):
+    """is_deletion(defs, start, end) -> label | None decides the SV records of sv_vcf_key (default: the oracle's osp_is_deletion)"""
     db = json.load(open(os.path.join(GOLDEN, "variant_dbs", db_name + ".json")))
     gene_name = sorted(db["gene_entries"])[0]
     gene = db["gene_entries"][gene_name]
@@ -269,4 +389,11 @@ def load_case(oracle, db_name, vcf_key, with_reference):
     vh, haps = load_database_haplotypes(oracle, gene, genome)
     vcf = json.load(open(os.path.join(GOLDEN, "variant_vcfs.json")))[vcf_key]
     obs = load_vcf_variants(oracle, vcf, vh, genome)
-    return gene_name, Problem(vh, haps, obs)
+    svs = gene.get("structural_variants")
+    if sv_vcf_key is not None and svs:
+        import __graft_entry__ as ge
+        defs = ge.load_package().ffi.SvDefinitions(db["gene_collection"]["gene_dict"], svs)       # pure-Python flattening
+        decide = (lambda s, e: is_deletion(defs, s, e)) if is_deletion else (lambda s, e: oracle_is_deletion(oracle, defs, s, e))
+        sv_vcf = json.load(open(os.path.join(GOLDEN, "variant_vcfs.json")))[sv_vcf_key]
+        obs.update(load_sv_vcf_variants(decide, sv_vcf, svs, db["gene_collection"]["gene_dict"]))
+    return gene_name, Problem(vh, haps, obs, svs)
