@@ -214,6 +214,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
             if (p_fail && c_slot == p_slot + 1 && c_lcp > p_extent && c_cap <= p_cap) {
                 // (a cell that is not executed keeps the SP_CELL_NONE its result slot was initialised with)
                 p_slot = c_slot; p_cap = c_cap;
+                SP_STAT(1, 1);
                 if (nxt >= 0) fetch(nxt);
                 continue;
             }
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
             spw::wave_lds_sync();
             if (nxt >= 0) fetch(nxt);
             uint32_t res = SP_CELL_NONE;
+            SP_STAT(0, 1); SP_STAT(7, c_cap); SP_STAT(48 + (c_cap < 15 ? c_cap : 15), 1);
             spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0; o.explored = 0x7FFFFFFF;
             spw::wfa_core<false, HASN, false>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o);
             if (o.ok) {
@@ -1085,3 +1087,11 @@ int32_t sp_hla_type_consensus_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n
 }
 
 } // extern "C"
+
+#ifdef SP_K1_STATS
+extern "C" int32_t sp_debug_wfa_stats(uint64_t* out, int32_t reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wfa_stats), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wfa_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

@@ -13,23 +13,39 @@
 #pragma once
 #include "sp_internal.h"
 
+#ifdef SP_K1_STATS
+// profiling build only (profiles/scripts/k1_stats.sh): wave-level event counters of the DP core
+static __device__ unsigned long long g_wfa_stats[64];
+#define SP_STAT(i, v) do { if (lane == 0) atomicAdd(&g_wfa_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define SP_STAT(i, v) do { } while (0)
+#endif
+
 namespace spw {
 
-__device__ __forceinline__ uint32_t load16(const uint32_t* __restrict__ s, int p) {
-    // 16 bases starting at base position p of an LDS-resident packed sequence (guard word guaranteed)
-    int w = p >> 4;
-    uint32_t lo = s[w], hi = s[w + 1];
-    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)((p & 15) << 1));
+// Positions inside the core are kept in BIT units (2 x base position): the alignbit shift is then the position itself (the
+// instruction reads its low 5 bits), the first set bit of the mismatch mask is the match length, nothing is shifted back and forth.
+__device__ __forceinline__ uint32_t load16b(const uint32_t* __restrict__ s, int p2) {
+    // 16 bases starting at bit position p2 of an LDS-resident packed sequence (guard word guaranteed)
+    const int w = p2 >> 5;
+    const uint32_t lo = s[w], hi = s[w + 1];
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)p2);
 }
 
+// v_ffbl_b32 as the hardware defines it: index of the lowest set bit, 0xFFFFFFFF for 0 (the C builtins are undefined there and
+// cost a compare + select to make defined; the caller clamps with an unsigned min instead)
+__device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+
+// matched length in bit units, at most 32 (16 bases) and at most rem2 (> 0)
 template <bool HASN>
-__device__ __forceinline__ int match16(const uint32_t* __restrict__ LA, const uint32_t* __restrict__ NA, int pa,
-                                       const uint32_t* __restrict__ LB, const uint32_t* __restrict__ NB, int pb, int rem) {
-    uint32_t x = load16(LA, pa) ^ load16(LB, pb);
+__device__ __forceinline__ int match16b(const uint32_t* __restrict__ LA, const uint32_t* __restrict__ NA, int pa2,
+                                        const uint32_t* __restrict__ LB, const uint32_t* __restrict__ NB, int pb2, int rem2) {
+    const uint32_t x = load16b(LA, pa2) ^ load16b(LB, pb2);
     uint32_t mm = (x | (x >> 1)) & 0x55555555u;
-    if (HASN) mm |= (load16(NA, pa) | load16(NB, pb));
-    int nmatch = mm ? ((__builtin_ffs((int)mm) - 1) >> 1) : 16;
-    return nmatch < rem ? nmatch : rem;
+    if (HASN) mm |= (load16b(NA, pa2) | load16b(NB, pb2));
+    const uint32_t f = ffbl_raw(mm);
+    const uint32_t c = f < 32u ? f : 32u;
+    return (int)(c < (uint32_t)rem2 ? c : (uint32_t)rem2);
 }
 
 struct CellIn {
@@ -60,6 +76,18 @@ __device__ __forceinline__ int words_needed(int lo, int hi) { return ((hi + 15) 
 __device__ __forceinline__ int from_lower(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int from_upper(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
 
+// max(acc, neighbour's x) in ONE instruction: the DPP operand rides on v_max_i32; a lane without that neighbour keeps acc
+// (s_nop 1: a VGPR written by a VALU instruction needs two wait states before a DPP read, and the assembler does not look
+// inside inline asm)
+__device__ __forceinline__ int max_from_lower(int x, int acc) {
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x));
+    return acc;
+}
+__device__ __forceinline__ int max_from_upper(int x, int acc) {
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x));
+    return acc;
+}
+
 // The DP core on two LDS-resident windows.  All 64 lanes call it together.
 //   LA/NA, a_sh : packed A window (+ N plane) and the LDS base position of view position 0 (may be negative)
 //   m, n        : view lengths; kb = diagonal of lane 0 (view coordinates, b - a)
@@ -76,85 +104,91 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
     const int kb = __builtin_amdgcn_readfirstlane(kb_), max_ed = __builtin_amdgcn_readfirstlane(max_ed_);
     const int k = kb + lane;
     const bool track = NEED_O || TRACE || kb < 0;
+    // per-lane constants (bit units): the furthest A position diagonal k can hold -- a live lane sits there exactly when it has
+    // reached the last row or column -- and the offsets of the two windows
+    const int lim = m < n - k ? m : n - k;
+    const int lim2 = lim << 1;
+    const int a2 = a_sh << 1, b2 = (k + b_sh) << 1;
+    const int NEG2 = SP_NEG * 2;
 
-    // extension of every lane from view position `start` (SP_NEG = invalid lane); returns new furthest i
-    auto extend = [&](int start) -> int {
-        int i = start;
-        int rem = 0;
-        bool going = false;
-        if (start >= 0) {
-            int ra = m - i, rb = n - (i + k);
-            rem = ra < rb ? ra : rb;
-            going = rem > 0;
-        }
+    // extension of every lane from bit position i (negative = dead lane, left as it is: dead values only ever grow by 2 per
+    // step from SP_NEG * 2 and stay far below 0); returns the new furthest position
+    auto extend = [&](int i) -> int {
+        int rem = lim2 - i;
+        bool going = i >= 0 && rem > 0;
         if (going) {
-            int nmv = match16<HASN>(LA, NA, i + a_sh, LB, NB, i + k + b_sh, rem);
-            i += nmv; rem -= nmv;
-            going = (nmv == 16) && rem > 0;
+            const int nmv = match16b<HASN>(LA, NA, i + a2, LB, NB, i + b2, rem);
+            i += nmv;
+            going = nmv == 32 && rem > 32;
+            rem -= nmv;
         }
         // lanes still matching after 16 bases finish cooperatively: all 64 lanes compare 1,024 bases per step
         uint64_t longmask = __ballot(going);
         while (longmask) {
             const int src = __builtin_ctzll(longmask);
             longmask &= longmask - 1;
+            SP_STAT(5, 1);
             int ci = __builtin_amdgcn_readlane(i, src);
             int crem = __builtin_amdgcn_readlane(rem, src);
-            const int ck = kb + src;
+            const int cb2 = (kb + src + b_sh) << 1;
             int total = 0;
             for (;;) {
-                int off = lane << 4;
-                int r = crem - off;
-                int nmv = r > 0 ? match16<HASN>(LA, NA, ci + off + a_sh, LB, NB, ci + off + ck + b_sh, r) : 0;
-                uint64_t stop = __ballot(nmv < 16);
+                SP_STAT(6, 1);
+                const int off = lane << 5;
+                const int r = crem - off;
+                const int nmv = r > 0 ? match16b<HASN>(LA, NA, ci + off + a2, LB, NB, ci + off + cb2, r) : 0;
+                const uint64_t stop = __ballot(nmv < 32);
                 if (stop) {
-                    int t = __builtin_ctzll(stop);
-                    total += (t << 4) + __builtin_amdgcn_readlane(nmv, t);
+                    const int t = __builtin_ctzll(stop);
+                    total += (t << 5) + __builtin_amdgcn_readlane(nmv, t);
                     break;
                 }
-                total += SP_WAVE * 16; ci += SP_WAVE * 16; crem -= SP_WAVE * 16;
+                total += SP_WAVE * 32; ci += SP_WAVE * 32; crem -= SP_WAVE * 32;
             }
             if (lane == src) i += total;
         }
-        return start >= 0 ? i : SP_NEG;
+        return i;
     };
 
     // s = 0 : every band diagonal may start for free on the first row / first column
     int H, O = lane;
     {
-        int i0 = k < 0 ? -k : 0, j0 = i0 + k;
-        H = extend((i0 < m && j0 < n) ? i0 : SP_NEG);
+        const int i0 = k < 0 ? -k : 0;
+        H = extend(i0 < lim ? i0 << 1 : NEG2);
     }
-    if (TRACE) hist[lane] = (uint16_t)(H >= 0 ? H : 0xFFFF);
+    if (TRACE) hist[lane] = (uint16_t)(H >= 0 ? H >> 1 : 0xFFFF);
     int s = 0, end_lane = -1;
     for (;;) {
-        const bool valid = H >= 0;
-        const int j = H + k;
-        const bool reached = valid && (H == m || j == n);
+        const bool reached = H == lim2;                   // dead lanes are negative and lim2 > NEG2 + 2 * SP_MAX_ED
         if (__ballot(reached)) {
+            const int Hb = H >> 1, j = Hb + k;
             int cdist = lane - SP_BAND / 2; if (cdist < 0) cdist = -cdist;
-            int key = reached ? ((H + j) * 8192 + (SP_BAND - cdist) * 64 + (SP_BAND - 1 - lane)) : -1;
+            int key = reached ? ((Hb + j) * 8192 + (SP_BAND - cdist) * 64 + (SP_BAND - 1 - lane)) : -1;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { int other = __shfl_xor(key, o); key = other > key ? other : key; }
             end_lane = __builtin_amdgcn_readfirstlane((SP_BAND - 1) - (key & 63));
             break;
         }
         if (s == max_ed) break;
-        // invalid lanes hold SP_NEG (+1 keeps them hugely negative), so validity is one sign test on the winner
-        const int up = from_lower(H, SP_NEG), dn = from_upper(H, SP_NEG);
-        int best = H + 1;
+        // a dead lane is hugely negative (+2 keeps it so), so validity is one sign test on the winner
+        const int t = H + 2;                               // mismatch on the same diagonal; seen from the diagonal below it is
+                                                           // the step "up from the upper neighbour"
+        int best;
         if (track) {
+            const int up = from_lower(H, NEG2), dn = from_upper(t, NEG2);
             const int oup = from_lower(O, 0), odn = from_upper(O, 0);
             int o = O;
+            best = t;
             if (up > best) { best = up; o = oup; }
-            if (dn + 1 > best) { best = dn + 1; o = odn; }
+            if (dn > best) { best = dn; o = odn; }
             O = o;
         } else {
-            best = up > best ? up : best;
-            best = dn + 1 > best ? dn + 1 : best;
+            best = max_from_lower(H, t);
+            best = max_from_upper(t, best);
         }
-        H = extend(best >= 0 ? best : SP_NEG);
+        H = extend(best);
         ++s;
-        if (TRACE) hist[s * SP_WAVE + lane] = (uint16_t)(H >= 0 ? H : 0xFFFF);
+        if (TRACE) hist[s * SP_WAVE + lane] = (uint16_t)(H >= 0 ? H >> 1 : 0xFFFF);
     }
     {
         // When the cap ran out, every live diagonal stopped on a mismatch at A[H]; furthest-reaching points only grow with s, so no
@@ -162,10 +196,12 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
         int hm = H;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(hm, o); hm = other > hm ? other : hm; }
-        out.explored = end_lane < 0 ? hm : -1;
+        out.explored = end_lane < 0 ? (hm >> 1) : -1;
     }
+    SP_STAT(3, s); SP_STAT(end_lane < 0 ? 16 + (s < 15 ? s : 15) : 32 + (s < 15 ? s : 15), 1);
+    if (end_lane >= 0) { SP_STAT(2, 1); SP_STAT(4, s); }
     if (end_lane < 0) return;
-    const int he = __builtin_amdgcn_readlane(H, end_lane);
+    const int he = __builtin_amdgcn_readlane(H, end_lane) >> 1;
     const int oe = track ? __builtin_amdgcn_readlane(O, end_lane) : end_lane;
     out.ok = 1; out.nm = s;
     out.a_end = he; out.b_end = he + kb + end_lane;
