@@ -80,9 +80,8 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
     return q < (uint32_t)cap ? (int)q : cap;
 }
 
-#define K1_PRE 5        // prefetch registers per lane: alleles up to 5*64*16 - 32 = 5,088 bases stream through registers
 #define K1_META 6       // metadata words per active cell
-#define K1_UNIT 16       // consecutive active cells a wave takes at a time (prefix sharing only carries inside a unit)
+#define K1_UNIT 32       // consecutive active cells a wave takes at a time (prefix sharing only carries inside a unit; < 64: one lane per cell)
 
 // DEEP only names the later (deeper, much smaller) passes of the iterative deepening differently, so that profilers list them apart
 template <bool HASN, bool DEEP>
@@ -168,75 +167,54 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
     if (read_maxlen && tid == 0) atomicMax(&read_maxlen[r], (uint32_t)ctl[2]);     // longest allele any cell of this read uses
     __syncthreads();
 
-    // software pipeline over the dense list: the packed words (and the running bound) of the NEXT cell are fetched into
-    // registers while the current cell's DP runs out of LDS; units of K1_UNIT consecutive cells are handed out dynamically.
+    // Units of K1_UNIT consecutive cells of the dense list are handed out to the waves dynamically.  Inside a unit lane j keeps the
+    // metadata of cell j in registers, so everything that is per cell but not part of the DP -- the edit cap under the current
+    // bound, the scan for the next cell that has to run -- is done for the whole unit at once.
     //
     // Prefix sharing (exact): the list follows the database's visiting order, so neighbours mostly start with the same bases.
     // A cell that runs out of edits has looked at A[0 .. explored] only (wfa_core); if the next cell's allele shares that prefix
     // (same gene, same frame offset => same diagonal, same read window), is allowed no more edits than the run had, and sits right
     // behind it in the order, its run would be the same run cut at the same or an earlier step: it fails too and is not executed.
-    // The chain carries on from a skipped cell with the executed run's extent and the smaller cap.
-    uint32_t pre[K1_PRE];
-    unsigned long long pre_bound = K1_NO_BOUND;
-    int pre_for = -1;
-    auto fetch = [&](int idx) {
-        const int alen_n = __builtin_amdgcn_readfirstlane(meta[idx * K1_META + 1]);
-        const uint32_t* aw = alleles.words + (uint32_t)__builtin_amdgcn_readfirstlane(meta[idx * K1_META + 3]);
-        const int nw = ((alen_n + 15) >> 4) + 2;
-#pragma unroll
-        for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; pre[t] = w < nw ? aw[w] : 0u; }
-        if (bound) pre_bound = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pre_for = idx;
-    };
+    // The chain carries on from a skipped cell with the executed run's extent and the smaller cap (caps along a chain never grow).
+    // Any bound value ever observed is a valid one (bounds only tighten), so the caps of a unit may come from one read of it.
     auto grab = [&]() -> int {
         int v = 0;
         if (lane == 0) v = atomicAdd(&ctl[5], 1);
         return __builtin_amdgcn_readfirstlane(v);
     };
+    uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
     const int n_units = (n_act + K1_UNIT - 1) / K1_UNIT;
     int unit = wave;                                      // the first units are pre-assigned, the rest grabbed
-    if (unit < n_units) fetch(unit * K1_UNIT);
     while (unit < n_units) {
-        const int c_begin = unit * K1_UNIT, c_end = min(c_begin + K1_UNIT, n_act);
+        const int c_begin = unit * K1_UNIT;
+        const int c_n = min(K1_UNIT, n_act - c_begin);
         const int nxt_unit = grab();
-        int p_slot = -2, p_fail = 0, p_extent = 0, p_cap = 0;
-        for (int cur = c_begin; cur < c_end; ++cur) {
-            const int* m = meta + cur * K1_META;
-            const int tag = __builtin_amdgcn_readfirstlane(m[0]);
-            const int c_alen = __builtin_amdgcn_readfirstlane(m[1]), c_kb = __builtin_amdgcn_readfirstlane(m[2]);
-            const int c_lcp = __builtin_amdgcn_readfirstlane(m[5]), c_slot = tag & 0xFFFF;
-            if (pre_for != cur) fetch(cur);
-            const unsigned long long my_bound = pre_bound;
-            int c_cap = tag >> 16;
-            if (bound) c_cap = k1_dyn_cap(my_bound, c_alen, c_cap);
-            c_cap = __builtin_amdgcn_readfirstlane(c_cap);
-            const int nxt = cur + 1 < c_end ? cur + 1 : (nxt_unit < n_units ? nxt_unit * K1_UNIT : -1);
-            if (p_fail && c_slot == p_slot + 1 && c_lcp > p_extent && c_cap <= p_cap) {
-                // (a cell that is not executed keeps the SP_CELL_NONE its result slot was initialised with)
-                p_slot = c_slot; p_cap = c_cap;
-                SP_STAT(1, 1);
-                if (nxt >= 0) fetch(nxt);
-                continue;
-            }
-            const int nw = ((c_alen + 15) >> 4) + 2;
-            const bool fast = nw <= K1_PRE * SP_WAVE;
-            uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
-            if (fast) {
-#pragma unroll
-                for (int t = 0; t < K1_PRE; ++t) { const int w = lane + t * SP_WAVE; if (w < nw) LA[w] = pre[t]; }
-            } else {
-                spw::stage(LA, alleles.words + (uint32_t)m[3], 0, c_alen, lane);
-            }
+        int u_tag = 0, u_alen = 0, u_kb = 0, u_woff = 0, u_lcp = 0;
+        if (lane < c_n) {
+            const int* m = meta + (c_begin + lane) * K1_META;
+            u_tag = m[0]; u_alen = m[1]; u_kb = m[2]; u_woff = m[3]; u_lcp = m[5];
+        }
+        const int u_slot = u_tag & 0xFFFF;
+        // lane j: does cell j sit right behind cell j-1 in the visiting order?  (dense-list neighbours need not be)
+        const int u_adjacent = u_slot == spw::from_lower(u_slot, -2) + 1;
+        int jc = 0;
+        while (jc < c_n) {
+            int u_cap = u_tag >> 16;
+            if (bound) u_cap = k1_dyn_cap(__hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), u_alen, u_cap);
+            const int c_alen = __builtin_amdgcn_readlane(u_alen, jc), c_kb = __builtin_amdgcn_readlane(u_kb, jc);
+            const int c_cap = __builtin_amdgcn_readlane(u_cap, jc), c_slot = __builtin_amdgcn_readlane(u_slot, jc);
+            const uint32_t c_woff = (uint32_t)__builtin_amdgcn_readlane(u_woff, jc);
+            spw::stage(LA, alleles.words + c_woff, 0, c_alen, lane);
             if (HASN) {
-                if (alleles.nplane) spw::stage(NA, alleles.nplane + (uint32_t)m[3], 0, c_alen, lane);
-                else for (int w = lane; w < nw; w += SP_WAVE) NA[w] = 0;
+                if (alleles.nplane) spw::stage(NA, alleles.nplane + c_woff, 0, c_alen, lane);
+                else for (int w = lane; w < ((c_alen + 15) >> 4) + 2; w += SP_WAVE) NA[w] = 0;
             }
             spw::wave_lds_sync();
-            if (nxt >= 0) fetch(nxt);
             uint32_t res = SP_CELL_NONE;
             SP_STAT(0, 1); SP_STAT(7, c_cap); SP_STAT(48 + (c_cap < 15 ? c_cap : 15), 1);
             spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0; o.explored = 0x7FFFFFFF;
             spw::wfa_core<false, HASN, false>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o);
+            int nxt = jc + 1;
             if (o.ok) {
                 const int span = o.a_end - o.a_start;
                 res = ((uint32_t)o.nm << 16) | (uint32_t)span;
@@ -256,10 +234,19 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
                         }
                     }
                 }
+            } else {
+                // the cells behind jc that this failed run settles: adjacent in the order, sharing more than the explored prefix,
+                // caps not growing -- the first lane behind jc that breaks the chain is the next cell to run
+                const int extent = __builtin_amdgcn_readfirstlane(o.explored);
+                const bool carries = u_adjacent && u_lcp > extent && u_cap <= spw::from_lower(u_cap, -1);
+                const unsigned long long behind = ~0ull << nxt;                               // nxt <= 63
+                const unsigned long long stop = (__ballot(!carries) & behind) | (1ull << c_n);
+                nxt = __builtin_ctzll(stop);
+                SP_STAT(1, nxt - jc - 1);
             }
-            p_slot = c_slot; p_fail = !o.ok; p_extent = __builtin_amdgcn_readfirstlane(o.explored); p_cap = c_cap;
             spw::wave_lds_sync();
             if (lane == 0) cres[c_slot] = res;
+            jc = nxt;
         }
         unit = nxt_unit;
     }

@@ -88,6 +88,21 @@ __device__ __forceinline__ int max_from_upper(int x, int acc) {
     return acc;
 }
 
+// max over the 64 lanes, wave-uniform result: four DPP butterflies inside each row of 16 (quad swaps, half mirror, mirror --
+// every lane has a partner, no fill needed), then the four row results meet on the scalar side
+__device__ __forceinline__ int wave_max(int v) {
+    int r;
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(r) : "v"(v));
+    const int r0 = __builtin_amdgcn_readlane(r, 0), r1 = __builtin_amdgcn_readlane(r, 16);
+    const int r2 = __builtin_amdgcn_readlane(r, 32), r3 = __builtin_amdgcn_readlane(r, 48);
+    const int x = r0 > r1 ? r0 : r1, y = r2 > r3 ? r2 : r3;
+    return x > y ? x : y;
+}
+
 // The DP core on two LDS-resident windows.  All 64 lanes call it together.
 //   LA/NA, a_sh : packed A window (+ N plane) and the LDS base position of view position 0 (may be negative)
 //   m, n        : view lengths; kb = diagonal of lane 0 (view coordinates, b - a)
@@ -193,10 +208,7 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
     {
         // When the cap ran out, every live diagonal stopped on a mismatch at A[H]; furthest-reaching points only grow with s, so no
         // base beyond max H was ever compared: a run on another A with the same first max H + 1 bases is this run, step for step.
-        int hm = H;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(hm, o); hm = other > hm ? other : hm; }
-        out.explored = end_lane < 0 ? (hm >> 1) : -1;
+        out.explored = end_lane < 0 ? (wave_max(H) >> 1) : -1;
     }
     SP_STAT(3, s); SP_STAT(end_lane < 0 ? 16 + (s < 15 ? s : 15) : 32 + (s < 15 ? s : 15), 1);
     if (end_lane >= 0) { SP_STAT(2, 1); SP_STAT(4, s); }
