@@ -197,6 +197,8 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
         const int u_slot = u_tag & 0xFFFF;
         // lane j: does cell j sit right behind cell j-1 in the visiting order?  (dense-list neighbours need not be)
         const int u_adjacent = u_slot == spw::from_lower(u_slot, -2) + 1;
+        // the state the previous cell of this unit left for its successor (wfa_core, Snap)
+        int snap_for = -1, snap_s = -1, snap_H = 0;
         int jc = 0;
         while (jc < c_n) {
             int u_cap = u_tag >> 16;
@@ -213,8 +215,22 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
             uint32_t res = SP_CELL_NONE;
             SP_STAT(0, 1); SP_STAT(7, c_cap); SP_STAT(48 + (c_cap < 15 ? c_cap : 15), 1);
             spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0; o.explored = 0x7FFFFFFF;
-            spw::wfa_core<false, HASN, false>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o);
             int nxt = jc + 1;
+            if (c_kb >= 0) {
+                // the successor in the order shares u_lcp bases with this allele: leave it the last state that stayed inside them,
+                // and start from the state the predecessor left when it was made for this cell and is not past this cell's cap
+                const bool has_succ = nxt < c_n && __builtin_amdgcn_readlane(u_adjacent, nxt & 63);
+                const int thr2 = has_succ ? __builtin_amdgcn_readlane(u_lcp, nxt & 63) << 1 : 0;
+                const bool resume = snap_for == jc && snap_s >= 0 && snap_s <= c_cap;
+                SP_STAT(8, resume ? 1 : 0); SP_STAT(9, resume ? snap_s + 1 : 0);
+                int out_s = -1, out_H = 0;
+                spw::wfa_core<false, HASN, false, true>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o,
+                                                        thr2, resume ? snap_s : -1, snap_H, &out_s, &out_H);
+                snap_for = nxt; snap_s = __builtin_amdgcn_readfirstlane(out_s); snap_H = out_H;
+            } else {
+                spw::wfa_core<false, HASN, false>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o);
+                snap_for = -1;
+            }
             if (o.ok) {
                 const int span = o.a_end - o.a_start;
                 res = ((uint32_t)o.nm << 16) | (uint32_t)span;

@@ -108,11 +108,19 @@ __device__ __forceinline__ int wave_max(int v) {
 //   m, n        : view lengths; kb = diagonal of lane 0 (view coordinates, b - a)
 //   NEED_O      : track the origin diagonal even when it cannot influence a_start (needed for b_start)
 // hist (TRACE only): this wave's global scratch, (max_ed+1)*64 uint16.  events (TRACE only): >= max_ed words.
-template <bool TRACE, bool HASN, bool NEED_O>
+// Snapshot / resume (K1 only): a run on another A that shares its first L bases with this one, on the same B and diagonal, is
+// this run step for step while no lane has gone past A[L-1] (a lane parked at H has compared A[H] and nothing beyond).  With
+// thr2 = 2L the core hands back the last such state (out_s steps done, out_H per lane; out_s < 0: none), and a run given
+// in_s >= 0 starts from (in_s, in_H) instead of from scratch.  Only used when the origin is not tracked.
+struct Snap { int thr2, in_s, in_H, out_s, out_H; };
+
+template <bool TRACE, bool HASN, bool NEED_O, bool SNAP = false>
 __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const uint32_t* __restrict__ NA, int a_sh, int m,
                                          const uint32_t* __restrict__ LB, const uint32_t* __restrict__ NB, int b_sh, int n,
                                          int kb_, int max_ed_, int lane,
-                                         uint16_t* __restrict__ hist, uint32_t* __restrict__ events, CellOut& out) {
+                                         uint16_t* __restrict__ hist, uint32_t* __restrict__ events, CellOut& out,
+                                         const int snap_thr2 = 0, const int snap_in_s = -1, const int snap_in_H = 0,
+                                         int* __restrict__ snap_out_s = nullptr, int* __restrict__ snap_out_H = nullptr) {
     // every cell parameter is wave-uniform; pin them to SGPRs so the step loop is scalar control flow
     m = __builtin_amdgcn_readfirstlane(m); n = __builtin_amdgcn_readfirstlane(n);
     a_sh = __builtin_amdgcn_readfirstlane(a_sh); b_sh = __builtin_amdgcn_readfirstlane(b_sh);
@@ -167,13 +175,20 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
 
     // s = 0 : every band diagonal may start for free on the first row / first column
     int H, O = lane;
-    {
+    int s = 0, end_lane = -1;
+    bool below = SNAP;
+    int keep_s = -1, keep_H = 0;
+    if (SNAP && __builtin_amdgcn_readfirstlane(snap_in_s) >= 0) {
+        H = snap_in_H; s = __builtin_amdgcn_readfirstlane(snap_in_s);
+    } else {
         const int i0 = k < 0 ? -k : 0;
         H = extend(i0 < lim ? i0 << 1 : NEG2);
     }
     if (TRACE) hist[lane] = (uint16_t)(H >= 0 ? H >> 1 : 0xFFFF);
-    int s = 0, end_lane = -1;
     for (;;) {
+        if (SNAP && below) {
+            if (__ballot(H >= snap_thr2)) below = false; else { keep_H = H; keep_s = s; }
+        }
         const bool reached = H == lim2;                   // dead lanes are negative and lim2 > NEG2 + 2 * SP_MAX_ED
         if (__ballot(reached)) {
             const int Hb = H >> 1, j = Hb + k;
@@ -210,18 +225,19 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
         // base beyond max H was ever compared: a run on another A with the same first max H + 1 bases is this run, step for step.
         out.explored = end_lane < 0 ? (wave_max(H) >> 1) : -1;
     }
+    if (SNAP) { *snap_out_s = keep_s; *snap_out_H = keep_H; }
     SP_STAT(3, s); SP_STAT(end_lane < 0 ? 16 + (s < 15 ? s : 15) : 32 + (s < 15 ? s : 15), 1);
     if (end_lane >= 0) { SP_STAT(2, 1); SP_STAT(4, s); }
-    if (end_lane < 0) return;
-    const int he = __builtin_amdgcn_readlane(H, end_lane) >> 1;
-    const int oe = track ? __builtin_amdgcn_readlane(O, end_lane) : end_lane;
-    out.ok = 1; out.nm = s;
-    out.a_end = he; out.b_end = he + kb + end_lane;
-    {
-        int ko = kb + oe; int i0 = ko < 0 ? -ko : 0;
-        out.a_start = i0; out.b_start = i0 + ko;      // b_start is only meaningful when the origin was tracked
-    }
-    if (TRACE) {
+    // one exit, every field assigned by value (an early return here leaves the struct in scratch memory)
+    const bool done = end_lane >= 0;
+    const int el = done ? end_lane : 0;
+    const int he = __builtin_amdgcn_readlane(H, el) >> 1;
+    const int oe = track ? __builtin_amdgcn_readlane(O, el) : el;
+    const int ko = kb + oe, i0 = ko < 0 ? -ko : 0;
+    out.ok = done ? 1 : 0; out.nm = done ? s : 0;
+    out.a_end = done ? he : 0; out.b_end = done ? he + kb + el : 0;
+    out.a_start = done ? i0 : 0; out.b_start = done ? i0 + ko : 0;      // b_start is only meaningful when the origin was tracked
+    if (TRACE && done) {
         int l = end_lane;
         for (int t = s; t > 0; --t) {
             uint16_t raw = hist[(t - 1) * SP_WAVE + lane];
