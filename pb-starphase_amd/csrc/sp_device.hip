@@ -233,7 +233,7 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     const bool trace = d_events != nullptr;
     const bool hasn = A->has_n || B->has_n;
     const int slot_words = sp_slot_words(A, B, hasn);
-    const size_t lds_bytes = (size_t)slot_words * 4 * 4;
+    const size_t lds_bytes = (size_t)slot_words * 4 * 4 + SP_LDS_TAIL;
     if (lds_bytes > 160 * 1024 - 64) return sp_fail(ctx, SP_ERR_TOO_LONG, "align: sequences too long for the LDS window");
     uint64_t blocks = (n_cells + 3) / 4;
     const uint64_t max_blocks = trace ? 1024 : (uint64_t)ctx->num_cus * 16;

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
                 const int thr2 = has_succ ? __builtin_amdgcn_readlane(u_lcp, nxt & 63) << 1 : 0;
                 const bool resume = snap_for == jc && snap_s >= 0 && snap_s <= c_cap;
                 SP_STAT(8, resume ? 1 : 0); SP_STAT(9, resume ? snap_s + 1 : 0);
+                SP_STAT(10, (jc > 0 && snap_for != jc) ? 1 : 0);                      // ran right behind a chain of settled cells
+                SP_STAT(11, (snap_for == jc && snap_s < 0) ? 1 : 0);                  // adjacent predecessor, but it left no state
+                SP_STAT(12, (snap_for == jc && snap_s > c_cap) ? 1 : 0);
                 int out_s = -1, out_H = 0;
                 spw::wfa_core<false, HASN, false, true>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o,
                                                         thr2, resume ? snap_s : -1, snap_H, &out_s, &out_H);
@@ -762,11 +765,11 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     const bool hasn = db->dna_fwd->has_n || reads->has_n || db->ref_fwd->has_n;
     // finalize: private per-wave windows of (allele, read) and (reference, read segment)
     int slot_words = std::max(sp_slot_words(db->dna_fwd, reads, hasn), sp_slot_words(db->ref_fwd, reads, hasn));
-    const size_t lds_bytes = (size_t)slot_words * 16;
+    const size_t lds_bytes = (size_t)slot_words * 16 + SP_LDS_TAIL;
     // cells: one shared read window + four allele slots
     const int b_words = (reads->max_len + 15) / 16 + 4;
     const int a_words = (db->dna_fwd->max_len + 15) / 16 + 4;
-    const size_t cells_lds = (size_t)(32 + (K1_META + 1) * K1_CHUNK + (hasn ? 2 : 1) * (b_words + K1_WAVES * a_words)) * 4;
+    const size_t cells_lds = (size_t)(32 + (K1_META + 1) * K1_CHUNK + (hasn ? 2 : 1) * (b_words + K1_WAVES * a_words)) * 4 + SP_LDS_TAIL;
     if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
     // exact branch-and-bound is switched off when the caller wants the full cell matrix
     unsigned long long* d_bound = nullptr;

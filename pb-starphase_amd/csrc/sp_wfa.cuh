@@ -25,11 +25,20 @@ namespace spw {
 
 // Positions inside the core are kept in BIT units (2 x base position): the alignbit shift is then the position itself (the
 // instruction reads its low 5 bits), the first set bit of the mismatch mask is the match length, nothing is shifted back and forth.
-__device__ __forceinline__ uint32_t load16b(const uint32_t* __restrict__ s, int p2) {
+// The windows are addressed by their LDS byte address held in an SGPR: word address = scalar base + 4 * (p2 >> 5) is one
+// shift-add per load (a generic pointer makes the compiler rebuild "lds base + constant + index" with extra adds every time).
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+__device__ __forceinline__ uint32_t lds_addr(const uint32_t* p) {
+    uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_cu32*)p);
+    asm("" : "+s"(a));        // opaque: otherwise a compile-time-known window offset is re-added as literals at every use
+    return a;
+}
+__device__ __forceinline__ uint32_t load16b(uint32_t base, int p2) {
     // 16 bases starting at bit position p2 of an LDS-resident packed sequence (guard word guaranteed)
-    const int w = p2 >> 5;
-    const uint32_t lo = s[w], hi = s[w + 1];
-    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)p2);
+    uint32_t addr;                                  // base + 4 * (p2 >> 5): shift, then ONE shift-add (the compiler's canonical
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(addr) : "v"(p2 >> 5), "s"(base));        // form, (p2 >> 3) & ~3 then add, takes three)
+    lds_cu32* w = (lds_cu32*)(uintptr_t)addr;
+    return __builtin_amdgcn_alignbit(w[1], w[0], (uint32_t)p2);
 }
 
 // v_ffbl_b32 as the hardware defines it: index of the lowest set bit, 0xFFFFFFFF for 0 (the C builtins are undefined there and
@@ -38,8 +47,7 @@ __device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) { uint32_t r; asm("v_ff
 
 // matched length in bit units, at most 32 (16 bases) and at most rem2 (> 0)
 template <bool HASN>
-__device__ __forceinline__ int match16b(const uint32_t* __restrict__ LA, const uint32_t* __restrict__ NA, int pa2,
-                                        const uint32_t* __restrict__ LB, const uint32_t* __restrict__ NB, int pb2, int rem2) {
+__device__ __forceinline__ int match16b(uint32_t LA, uint32_t NA, int pa2, uint32_t LB, uint32_t NB, int pb2, int rem2) {
     const uint32_t x = load16b(LA, pa2) ^ load16b(LB, pb2);
     uint32_t mm = (x | (x >> 1)) & 0x55555555u;
     if (HASN) mm |= (load16b(NA, pa2) | load16b(NB, pb2));
@@ -115,8 +123,8 @@ __device__ __forceinline__ int wave_max(int v) {
 struct Snap { int thr2, in_s, in_H, out_s, out_H; };
 
 template <bool TRACE, bool HASN, bool NEED_O, bool SNAP = false>
-__device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const uint32_t* __restrict__ NA, int a_sh, int m,
-                                         const uint32_t* __restrict__ LB, const uint32_t* __restrict__ NB, int b_sh, int n,
+__device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA_, const uint32_t* __restrict__ NA_, int a_sh, int m,
+                                         const uint32_t* __restrict__ LB_, const uint32_t* __restrict__ NB_, int b_sh, int n,
                                          int kb_, int max_ed_, int lane,
                                          uint16_t* __restrict__ hist, uint32_t* __restrict__ events, CellOut& out,
                                          const int snap_thr2 = 0, const int snap_in_s = -1, const int snap_in_H = 0,
@@ -125,6 +133,8 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
     m = __builtin_amdgcn_readfirstlane(m); n = __builtin_amdgcn_readfirstlane(n);
     a_sh = __builtin_amdgcn_readfirstlane(a_sh); b_sh = __builtin_amdgcn_readfirstlane(b_sh);
     const int kb = __builtin_amdgcn_readfirstlane(kb_), max_ed = __builtin_amdgcn_readfirstlane(max_ed_);
+    const uint32_t LA = lds_addr(LA_), LB = lds_addr(LB_), NA = HASN ? lds_addr(NA_) : 0u, NB = HASN ? lds_addr(NB_) : 0u;
+    const uint32_t lane4 = (uint32_t)lane << 2;
     const int k = kb + lane;
     const bool track = NEED_O || TRACE || kb < 0;
     // per-lane constants (bit units): the furthest A position diagonal k can hold -- a live lane sits there exactly when it has
@@ -145,7 +155,10 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
             going = nmv == 32 && rem > 32;
             rem -= nmv;
         }
-        // lanes still matching after 16 bases finish cooperatively: all 64 lanes compare 1,024 bases per step
+        // lanes still matching after 16 bases finish cooperatively: all 64 lanes compare 1,024 bases per step.  Lane l takes
+        // bases [16 l, 16 l + 16) of the stretch: the word index is (scalar word of the stretch start) + l and the alignbit shift is
+        // scalar, so the per-lane work is two adds, the compare and the clamp.  Lanes past the end of the stretch clamp to 0 (their
+        // loads may touch words behind the staged window: still inside this workgroup's LDS, values unused).
         uint64_t longmask = __ballot(going);
         while (longmask) {
             const int src = __builtin_ctzll(longmask);
@@ -154,21 +167,31 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA, const 
             int ci = __builtin_amdgcn_readlane(i, src);
             int crem = __builtin_amdgcn_readlane(rem, src);
             const int cb2 = (kb + src + b_sh) << 1;
-            int total = 0;
             for (;;) {
                 SP_STAT(6, 1);
-                const int off = lane << 5;
-                const int r = crem - off;
-                const int nmv = r > 0 ? match16b<HASN>(LA, NA, ci + off + a2, LB, NB, ci + off + cb2, r) : 0;
+                const int pa = ci + a2, pb = ci + cb2;                       // scalar bit positions of the stretch in the two windows
+                const uint32_t oa = (uint32_t)((pa >> 5) << 2), ob = (uint32_t)((pb >> 5) << 2);      // scalar
+                lds_cu32* wa = (lds_cu32*)(uintptr_t)((LA + oa) + lane4);
+                lds_cu32* wb = (lds_cu32*)(uintptr_t)((LB + ob) + lane4);
+                const uint32_t x = __builtin_amdgcn_alignbit(wa[1], wa[0], (uint32_t)pa) ^ __builtin_amdgcn_alignbit(wb[1], wb[0], (uint32_t)pb);
+                uint32_t mm = (x | (x >> 1)) & 0x55555555u;
+                if (HASN) {
+                    lds_cu32* na = (lds_cu32*)(uintptr_t)((NA + oa) + lane4); lds_cu32* nb = (lds_cu32*)(uintptr_t)((NB + ob) + lane4);
+                    mm |= __builtin_amdgcn_alignbit(na[1], na[0], (uint32_t)pa) | __builtin_amdgcn_alignbit(nb[1], nb[0], (uint32_t)pb);
+                }
+                int r = crem - (lane << 5); r = r > 0 ? r : 0;
+                const uint32_t f = ffbl_raw(mm);
+                const uint32_t c = f < 32u ? f : 32u;
+                const int nmv = (int)(c < (uint32_t)r ? c : (uint32_t)r);
                 const uint64_t stop = __ballot(nmv < 32);
                 if (stop) {
                     const int t = __builtin_ctzll(stop);
-                    total += (t << 5) + __builtin_amdgcn_readlane(nmv, t);
+                    ci += (t << 5) + __builtin_amdgcn_readlane(nmv, t);
                     break;
                 }
-                total += SP_WAVE * 32; ci += SP_WAVE * 32; crem -= SP_WAVE * 32;
+                ci += SP_WAVE * 32; crem -= SP_WAVE * 32;
             }
-            if (lane == src) i += total;
+            if (lane == src) i = ci;
         }
         return i;
     };
