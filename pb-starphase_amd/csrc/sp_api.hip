@@ -97,7 +97,7 @@ int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets
     }
     s->h_word_off[n] = total_words;
     auto fail = [&](const char* what) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, what); };
-    const size_t wbytes = (total_words + 4) * sizeof(uint32_t);
+    const size_t wbytes = (total_words + SP_SEQ_PAD_WORDS) * sizeof(uint32_t);
     if (hipMalloc(&s->d_words, wbytes) != hipSuccess) return fail("seqset words");
     if (hipMalloc(&s->d_word_off, ((size_t)n + 1) * sizeof(uint64_t)) != hipSuccess) return fail("seqset offsets");
     if (hipMalloc(&s->d_len, std::max<size_t>(1, n) * sizeof(int32_t)) != hipSuccess) return fail("seqset lengths");
@@ -169,7 +169,7 @@ static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::ve
 int sp_seqset_fetch_host(sp_ctx* ctx, sp_seqset* s) {
     if (!s->h_words.empty()) return SP_OK;
     hipSetDevice(ctx->device);
-    const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
+    const size_t plane_words = (size_t)s->h_word_off[s->n] + SP_SEQ_PAD_WORDS;
     s->h_words.assign(plane_words * (s->has_n ? 2 : 1), 0);
     if (hipMemcpy(s->h_words.data(), s->d_words, plane_words * 4, hipMemcpyDeviceToHost) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "fetch packed words");
     if (s->has_n && hipMemcpy(s->h_words.data() + plane_words, s->d_nplane, plane_words * 4, hipMemcpyDeviceToHost) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "fetch N plane");
@@ -194,7 +194,7 @@ int sp_seqset_make_small(sp_ctx* ctx, const char* prefix, const char* bases, con
         total_words += (((len + 15) / 16 + 2) + 3) & ~3ull;
     }
     s.h_word_off[n] = total_words;
-    const size_t plane_words = (size_t)total_words + 4;
+    const size_t plane_words = (size_t)total_words + SP_SEQ_PAD_WORDS;
     std::vector<uint32_t> words(plane_words, 0), nplane(plane_words, 0);
     for (uint32_t i = 0; i < n; ++i) {
         const char* src = bases + offsets[i];
@@ -239,7 +239,7 @@ int sp_seqset_make_small(sp_ctx* ctx, const char* prefix, const char* bases, con
 
 std::string sp_seqset_decode(sp_ctx* ctx, const sp_seqset* s, uint32_t i) {
     if (sp_seqset_fetch_host(ctx, const_cast<sp_seqset*>(s)) != SP_OK || i >= s->n) return std::string();
-    const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
+    const size_t plane_words = (size_t)s->h_word_off[s->n] + SP_SEQ_PAD_WORDS;
     const uint32_t* w = s->h_words.data() + s->h_word_off[i];
     const uint32_t* np = s->has_n ? s->h_words.data() + plane_words + s->h_word_off[i] : nullptr;
     std::string out((size_t)s->h_len[i], 'N');
@@ -253,7 +253,7 @@ std::string sp_seqset_decode(sp_ctx* ctx, const sp_seqset* s, uint32_t i) {
 
 // sorted 16-mer table of every sequence of a set whose packed words are on the host
 static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::vector<uint32_t>& kcode, std::vector<int32_t>& kpos) {
-    const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
+    const size_t plane_words = (size_t)s->h_word_off[s->n] + SP_SEQ_PAD_WORDS;
     koff.assign((size_t)s->n + 1, 0); kcode.clear(); kpos.clear();
     std::vector<std::pair<uint32_t, int32_t>> tmp;
     for (uint32_t i = 0; i < s->n; ++i) {
@@ -281,7 +281,7 @@ static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::ve
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
     if (s->has_index) return SP_OK;
     hipSetDevice(ctx->device);
-    const size_t plane_words = (size_t)s->h_word_off[s->n] + 4;
+    const size_t plane_words = (size_t)s->h_word_off[s->n] + SP_SEQ_PAD_WORDS;
     if (s->h_words.empty()) {                              // packed on the device: fetch the packed words (and N plane) once
         s->h_words.assign(plane_words * (s->has_n ? 2 : 1), 0);
         hipMemcpy(s->h_words.data(), s->d_words, plane_words * 4, hipMemcpyDeviceToHost);

@@ -81,6 +81,7 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
 }
 
 #define K1_META 6       // metadata words per active cell
+#define K1_PRE_WORDS 320 // words of an allele the register prefetch covers
 #define K1_UNIT 32       // consecutive active cells a wave takes at a time (prefix sharing only carries inside a unit; < 64: one lane per cell)
 
 // DEEP only names the later (deeper, much smaller) passes of the iterative deepening differently, so that profilers list them apart
@@ -183,6 +184,17 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
         return __builtin_amdgcn_readfirstlane(v);
     };
     uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
+    // Register prefetch of one allele, fixed shape: lane l takes words [4l, 4l+4) and word 256+l (sequences start 16-byte aligned
+    // and the set is padded, SP_SEQ_PAD_WORDS), 320 words = 5,088 bases + guard; longer alleles are staged directly.  The
+    // running bound of the read comes along: any value it ever had is a valid bound.
+    uint4 pre4 = make_uint4(0, 0, 0, 0); uint32_t pre1 = 0; unsigned long long pre_bound = K1_NO_BOUND; int pre_for = -1;
+    auto prefetch = [&](int idx, uint32_t woff) {
+        const uint32_t* aw = alleles.words + woff;
+        pre4 = *reinterpret_cast<const uint4*>(aw + 4 * lane);
+        pre1 = aw[256 + lane];
+        if (bound) pre_bound = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pre_for = idx;
+    };
     const int n_units = (n_act + K1_UNIT - 1) / K1_UNIT;
     int unit = wave;                                      // the first units are pre-assigned, the rest grabbed
     while (unit < n_units) {
@@ -200,13 +212,23 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
         // the state the previous cell of this unit left for its successor (wfa_core, Snap)
         int snap_for = -1, snap_s = -1, snap_H = 0;
         int jc = 0;
+        if (pre_for != c_begin) prefetch(c_begin, (uint32_t)__builtin_amdgcn_readlane(u_woff, 0));
         while (jc < c_n) {
+            if (pre_for != c_begin + jc) prefetch(c_begin + jc, (uint32_t)__builtin_amdgcn_readlane(u_woff, jc));      // (behind a chain)
             int u_cap = u_tag >> 16;
-            if (bound) u_cap = k1_dyn_cap(__hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), u_alen, u_cap);
+            if (bound) u_cap = k1_dyn_cap(pre_bound, u_alen, u_cap);
             const int c_alen = __builtin_amdgcn_readlane(u_alen, jc), c_kb = __builtin_amdgcn_readlane(u_kb, jc);
             const int c_cap = __builtin_amdgcn_readlane(u_cap, jc), c_slot = __builtin_amdgcn_readlane(u_slot, jc);
             const uint32_t c_woff = (uint32_t)__builtin_amdgcn_readlane(u_woff, jc);
-            spw::stage(LA, alleles.words + c_woff, 0, c_alen, lane);
+            if (((c_alen + 15) >> 4) + 2 <= K1_PRE_WORDS) {
+                *reinterpret_cast<uint4*>(LA + 4 * lane) = pre4;
+                LA[256 + lane] = pre1;
+            } else {
+                spw::stage(LA, alleles.words + c_woff, 0, c_alen, lane);
+            }
+            // the most likely next cell streams into the registers while this one runs
+            if (jc + 1 < c_n) prefetch(c_begin + jc + 1, (uint32_t)__builtin_amdgcn_readlane(u_woff, (jc + 1) & 63));
+            else if (nxt_unit < n_units) prefetch(nxt_unit * K1_UNIT, (uint32_t)__builtin_amdgcn_readfirstlane(meta[nxt_unit * K1_UNIT * K1_META + 3]));
             if (HASN) {
                 if (alleles.nplane) spw::stage(NA, alleles.nplane + c_woff, 0, c_alen, lane);
                 else for (int w = lane; w < ((c_alen + 15) >> 4) + 2; w += SP_WAVE) NA[w] = 0;
@@ -767,8 +789,9 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     int slot_words = std::max(sp_slot_words(db->dna_fwd, reads, hasn), sp_slot_words(db->ref_fwd, reads, hasn));
     const size_t lds_bytes = (size_t)slot_words * 16 + SP_LDS_TAIL;
     // cells: one shared read window + four allele slots
-    const int b_words = (reads->max_len + 15) / 16 + 4;
-    const int a_words = (db->dna_fwd->max_len + 15) / 16 + 4;
+    // (both multiples of 4 words: the allele slots take 16-byte LDS stores; a slot always holds a whole register prefetch)
+    const int b_words = (((reads->max_len + 15) / 16 + 4) + 3) & ~3;
+    const int a_words = std::max(K1_PRE_WORDS, (((db->dna_fwd->max_len + 15) / 16 + 4) + 3) & ~3);
     const size_t cells_lds = (size_t)(32 + (K1_META + 1) * K1_CHUNK + (hasn ? 2 : 1) * (b_words + K1_WAVES * a_words)) * 4 + SP_LDS_TAIL;
     if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
     // exact branch-and-bound is switched off when the caller wants the full cell matrix

@@ -8,6 +8,7 @@
 #include "../../include/starphase_hip.h"
 
 #define SP_NEG        (-(1 << 28))
+#define SP_SEQ_PAD_WORDS 512     // zero words behind the last sequence of a set: fixed-shape prefetches (k1_cells) may read past a sequence
 #define SP_LDS_TAIL    288       // bytes behind the last LDS window: the cooperative extension of wfa_core reads up to 65 words past a stretch
 #define SP_WAVE       64
 #define SP_MAXOCC     4
