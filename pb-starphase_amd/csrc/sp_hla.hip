@@ -14,10 +14,20 @@
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
 int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn);
 
-#define K1_THREADS     256      // 4 waves per workgroup (512 threads measured slower: 44.9 vs 40.5 ms)
-#define K1_WAVES       (K1_THREADS / 64)
-#define K1_CHUNK       K1_THREADS   // alleles per workgroup: one metadata thread each; cells are handed to the waves dynamically
+#ifndef K1_GROUPS
+#define K1_GROUPS      1        // groups of 64 visiting-order positions one k1_cells workgroup (= one wavefront) walks through
+#endif
+#define K1_CHUNK       (64 * K1_GROUPS)
 #define K1_MIN_VOTES   16
+
+// the alleles by position of the K1 visiting order (structure of arrays, one coalesced load per field and group of 64 positions)
+struct K1Positions {
+    const int32_t* alen;      // allele length, 0 = no DNA sequence
+    const int32_t* off;       // frame offset (allele_fwd_pos - ref_fwd_pos), SP_NO_DIAG = no anchor
+    const uint32_t* gene;
+    const uint32_t* woff;     // first packed word of the allele in dna_fwd
+    const int32_t* lcp;       // prefix shared with the position before (same gene and frame offset), else 0
+};
 #define K2_MIN_VOTES   2
 
 struct sp_hla_db {
@@ -40,6 +50,7 @@ struct sp_hla_db {
     mutable std::map<uint32_t, GeneList> gene_lists;       // key = gene * 2 + require_dna
     uint32_t* d_order = nullptr;      // K1 visits the alleles sorted by (gene, frame offset, hg38-strand sequence) ...
     int32_t*  d_lcp = nullptr;        // ... d_lcp[i] = common prefix of order[i-1] and order[i] when they share gene and frame offset, else 0
+    int32_t*  d_pos = nullptr;        // 5 x n_alleles: the K1Positions arrays
     int32_t*  d_am = nullptr;         // n_alleles*3: ok, am.query_start, am.target_start (allele -> gene ref, realigner.rs:289-310)
     int32_t*  d_hpc_ref = nullptr;    // hpc_pos(ref_fwd[g], p) for p in 0..len, concatenated
     uint64_t* d_hpc_ref_off = nullptr;
@@ -54,9 +65,8 @@ __device__ __forceinline__ double score_value(int len, int nm, int unmapped) {
 }
 
 // =============================================================================================
-// K1 cells: workgroup = (read r, chunk of K1_CHUNK alleles).  The read window every cell of the chunk can touch
-// is staged ONCE per workgroup into LDS (coalesced dword loads by all 256 threads); each wave then streams its
-// alleles through a private LDS slot and runs one WFA cell per allele.
+// K1 cells: workgroup = one wavefront = (read r, K1_CHUNK positions of the visiting order).  The read window every cell of the
+// chunk can touch is staged once into LDS; the alleles stream through one LDS slot, one WFA cell each.
 // cell_out[r * n_alleles + p] = (nm << 16) | aligned allele span, or SP_CELL_NONE, p = position of the allele in the visiting order
 // (a workgroup's results are one contiguous stretch of the row; the reduce maps positions back to allele indices).
 //
@@ -80,31 +90,34 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
     return q < (uint32_t)cap ? (int)q : cap;
 }
 
-#define K1_META 6       // metadata words per active cell
 #define K1_PRE_WORDS 320 // words of an allele the register prefetch covers
-#define K1_UNIT 32       // consecutive active cells a wave takes at a time (prefix sharing only carries inside a unit; < 64: one lane per cell)
 
 // DEEP only names the later (deeper, much smaller) passes of the iterative deepening differently, so that profilers list them apart
+// One wavefront = one workgroup = (read, K1_GROUPS x 64 consecutive positions of the visiting order).  Lane j of a group IS cell j:
+// its metadata stays in that lane's registers, its result too, and whatever is per cell but not part of the DP -- the edit cap under
+// the current bound, the scan for the next cell that has to run -- is one vector operation over the group.  Nothing waits for another
+// wave (workgroups of 2, 4, 8 waves measured 13.3 / 15.5 / 19.9 ms against 12.6 ms: every wave idles until the slowest is done).
+//
+// Prefix sharing (exact): the positions follow the database's visiting order, so neighbours mostly start with the same bases.
+// A cell that runs out of edits has looked at A[0 .. explored] only (wfa_core); if the next cell's allele shares that prefix
+// (same gene, same frame offset => same diagonal, same read window), is allowed no more edits than the run had, and sits right
+// behind it in the order, its run would be the same run cut at the same or an earlier step: it fails too and is not executed.
+// The chain carries on from a skipped cell with the executed run's extent and the smaller cap (caps along a chain never grow).
+// Any bound value ever observed is a valid one (bounds only tighten), so the caps of a group may come from one read of it.
 template <bool HASN, bool DEEP>
-__global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads,
-                                                       const uint32_t* __restrict__ gene_of, const int32_t* __restrict__ off_fwd,
-                                                       const int32_t* __restrict__ d_rg, const int32_t* __restrict__ votes_rg,
-                                                       int n_genes, uint32_t n_alleles, uint32_t n_chunks,
-                                                       uint32_t* __restrict__ cell_out, unsigned long long* __restrict__ bound,
-                                                       const uint32_t* __restrict__ read_list, uint32_t* __restrict__ read_maxlen,
-                                                       const uint32_t* __restrict__ order, const int32_t* __restrict__ lcp_tab,
-                                                       int pass_cap, int b_words, int a_words) {
+__global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads, K1Positions pos,
+                                                      const int32_t* __restrict__ d_rg, const int32_t* __restrict__ votes_rg,
+                                                      int n_genes, uint32_t n_alleles, uint32_t n_chunks,
+                                                      uint32_t* __restrict__ cell_out, unsigned long long* __restrict__ bound,
+                                                      const uint32_t* __restrict__ read_list, uint32_t* __restrict__ read_maxlen,
+                                                      int pass_cap, int b_words, int a_words) {
     extern __shared__ uint32_t lds[];
-    // layout: [32 control words][K1_CHUNK x 6 cell metadata][K1_CHUNK results][B window b_words (x2 with N plane)][K1_WAVES x A slot a_words (x2 with N plane)]
-    int* ctl = reinterpret_cast<int*>(lds);               // 0: window lo, 1: window hi, 2: longest active allele, 3: #active in wave 0,
-                                                          // 4: #active, 5: next unit to grab
-    int* meta = ctl + 32;                                 // dense list of active cells: (chunk slot | static cap << 16), alen, kb, word offset,
-                                                          // allele index, prefix shared with the allele one slot earlier
-    uint32_t* cres = lds + 32 + K1_META * K1_CHUNK;        // results of the chunk, written out in one coalesced sweep at the end
-    uint32_t* LB = cres + K1_CHUNK;
+    // layout: [B window b_words (x2 with N plane)][A slot a_words (x2 with N plane)]
+    uint32_t* LB = lds;
     uint32_t* NB = HASN ? LB + b_words : nullptr;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    uint32_t* slotA = LB + (HASN ? 2 : 1) * b_words + wave * (HASN ? 2 : 1) * a_words;
+    uint32_t* LA = LB + (HASN ? 2 : 1) * b_words;
+    uint32_t* NA = HASN ? LA + a_words : nullptr;
+    const int lane = threadIdx.x;
     // deeper passes only visit the reads an earlier (shallower) pass could not settle
     const uint32_t r = read_list ? read_list[blockIdx.x / n_chunks] : blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
     // gene filter: a gene is searched when it has >= K1_MIN_VOTES and >= 1/10 of the read's best gene
@@ -114,76 +127,54 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
     const int rlen = reads.len[r];
     const uint32_t* rw = reads.words + reads.word_off[r];
     const uint32_t* rn = reads.nplane ? reads.nplane + reads.word_off[r] : nullptr;
-    const uint32_t a_first = chunk * K1_CHUNK;
-    const uint32_t a_end = min(a_first + (uint32_t)K1_CHUNK, n_alleles);
+    const uint32_t p_first = chunk * (uint32_t)(64 * K1_GROUPS);
 
-    // pass 1 (threads 0..127, one allele each): cell metadata, union of the read windows, dense list of active cells
-    if (tid == 0) { ctl[0] = 0x7FFFFFFF; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = K1_WAVES; }
-    __syncthreads();
-    int act = 0, alen = 0, kb = 0, cap = 0; uint32_t woff = 0;
-    uint32_t a_mine = 0; int lcp_mine = 0;
-    if (tid < K1_CHUNK && a_first + tid < a_end) {
-        const uint32_t a = order[a_first + tid];          // the chunk is a slice of the visiting order, not of the index space
-        a_mine = a; lcp_mine = tid > 0 ? lcp_tab[a_first + tid] : 0;
-        alen = alleles.len[a];
-        const int off = off_fwd[a];
-        const uint32_t g = gene_of[a];
-        if (alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
-            kb = d_rg[(uint64_t)r * n_genes + g] - off - SP_BAND / 2;
-            int i_min, i_max, j_min, j_max;
-            if (spw::cell_windows(alen, rlen, kb, i_min, i_max, j_min, j_max)) {
-                // nm <= 0.03 * aligned span <= 0.03 * allele length (realigner.rs:138-141)
-                cap = (int)(0.03 * (double)alen) + 1; if (cap > SP_MAX_ED) cap = SP_MAX_ED;
-                if (cap > pass_cap) cap = pass_cap;
-                act = 1; woff = (uint32_t)alleles.word_off[a];
-                atomicMin(&ctl[0], j_min); atomicMax(&ctl[1], j_max); atomicMax(&ctl[2], alen);
+    // the cell of a position: active?  diagonal, static cap, packed words, prefix shared with the position before
+    struct Cell { int act, alen, kb, cap, lcp; uint32_t woff; };
+    auto load_cell = [&](uint32_t p, int& j_min, int& j_max) -> Cell {
+        Cell c; c.act = 0; c.alen = 0; c.kb = 0; c.cap = 0; c.lcp = 0; c.woff = 0; j_min = 0x7FFFFFFF; j_max = -1;
+        if (p < n_alleles) {
+            c.alen = pos.alen[p];
+            const int off = pos.off[p];
+            const uint32_t g = pos.gene[p];
+            if (c.alen > 0 && off != SP_NO_DIAG && votes_rg[(uint64_t)r * n_genes + g] >= vmin) {
+                c.kb = d_rg[(uint64_t)r * n_genes + g] - off - SP_BAND / 2;
+                int i_min, i_max;
+                if (spw::cell_windows(c.alen, rlen, c.kb, i_min, i_max, j_min, j_max)) {
+                    // nm <= 0.03 * aligned span <= 0.03 * allele length (realigner.rs:138-141)
+                    c.cap = (int)(0.03 * (double)c.alen) + 1; if (c.cap > SP_MAX_ED) c.cap = SP_MAX_ED;
+                    if (c.cap > pass_cap) c.cap = pass_cap;
+                    c.act = 1; c.woff = pos.woff[p]; c.lcp = pos.lcp[p];
+                } else { j_min = 0x7FFFFFFF; j_max = -1; }
             }
         }
-        cres[tid] = SP_CELL_NONE;
-        if (!act) cell_out[(uint64_t)r * n_alleles + a_first + tid] = SP_CELL_NONE;
+        return c;
+    };
+
+    // pass 1: union of the read windows of every cell of the workgroup, longest allele in use
+    int w_lo = 0x7FFFFFFF, w_hi = -1, longest = 0;
+#pragma unroll
+    for (int g = 0; g < K1_GROUPS; ++g) {
+        int j_min, j_max;
+        const Cell c = load_cell(p_first + g * 64 + lane, j_min, j_max);
+        w_lo = j_min < w_lo ? j_min : w_lo; w_hi = j_max > w_hi ? j_max : w_hi;
+        longest = c.act && c.alen > longest ? c.alen : longest;
     }
-    // dense list of the active cells in ascending allele order: per-wave ballots + a prefix over the (up to four) waves
-    const unsigned long long bal = __ballot(act != 0);
-    if (lane == 0) ctl[16 + wave] = __builtin_popcountll(bal);
-    __syncthreads();
-    if (act) {
-        int before = 0;
-        for (int w = 0; w < wave; ++w) before += ctl[16 + w];
-        const int slot = before + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-        int* m = meta + slot * K1_META;
-        m[0] = tid | (cap << 16); m[1] = alen; m[2] = kb; m[3] = (int)woff; m[4] = (int)a_mine; m[5] = lcp_mine;
+    w_lo = -spw::wave_max(-w_lo); w_hi = spw::wave_max(w_hi); longest = spw::wave_max(longest);
+    if (w_hi < 0) {                                       // nothing to run (the positions of another gene, mostly)
+#pragma unroll
+        for (int g = 0; g < K1_GROUPS; ++g) { const uint32_t p = p_first + g * 64 + lane; if (p < n_alleles) cell_out[(uint64_t)r * n_alleles + p] = SP_CELL_NONE; }
+        return;
     }
-    if (tid == 0) { int tot = 0; for (int w = 0; w < K1_WAVES; ++w) tot += ctl[16 + w]; ctl[4] = tot; }
-    __syncthreads();
-    const int n_act = __builtin_amdgcn_readfirstlane(ctl[4]);
-    if (n_act == 0) return;
-    const int w_lo = __builtin_amdgcn_readfirstlane(ctl[0]), w_hi = __builtin_amdgcn_readfirstlane(ctl[1]);
     int b_base;
     {
         const int w0 = w_lo >> 4;
         const int nw = ((w_hi + 15) >> 4) - w0 + 2;
-        for (int w = tid; w < nw; w += K1_THREADS) { LB[w] = rw[w0 + w]; if (HASN) NB[w] = rn ? rn[w0 + w] : 0u; }
+        for (int w = lane; w < nw; w += SP_WAVE) { LB[w] = rw[w0 + w]; if (HASN) NB[w] = rn ? rn[w0 + w] : 0u; }
         b_base = w0 << 4;
     }
-    if (read_maxlen && tid == 0) atomicMax(&read_maxlen[r], (uint32_t)ctl[2]);     // longest allele any cell of this read uses
-    __syncthreads();
+    if (read_maxlen && lane == 0) atomicMax(&read_maxlen[r], (uint32_t)longest);     // longest allele any cell of this read uses
 
-    // Units of K1_UNIT consecutive cells of the dense list are handed out to the waves dynamically.  Inside a unit lane j keeps the
-    // metadata of cell j in registers, so everything that is per cell but not part of the DP -- the edit cap under the current
-    // bound, the scan for the next cell that has to run -- is done for the whole unit at once.
-    //
-    // Prefix sharing (exact): the list follows the database's visiting order, so neighbours mostly start with the same bases.
-    // A cell that runs out of edits has looked at A[0 .. explored] only (wfa_core); if the next cell's allele shares that prefix
-    // (same gene, same frame offset => same diagonal, same read window), is allowed no more edits than the run had, and sits right
-    // behind it in the order, its run would be the same run cut at the same or an earlier step: it fails too and is not executed.
-    // The chain carries on from a skipped cell with the executed run's extent and the smaller cap (caps along a chain never grow).
-    // Any bound value ever observed is a valid one (bounds only tighten), so the caps of a unit may come from one read of it.
-    auto grab = [&]() -> int {
-        int v = 0;
-        if (lane == 0) v = atomicAdd(&ctl[5], 1);
-        return __builtin_amdgcn_readfirstlane(v);
-    };
-    uint32_t* LA = slotA; uint32_t* NA = HASN ? slotA + a_words : nullptr;
     // Register prefetch of one allele, fixed shape: lane l takes words [4l, 4l+4) and word 256+l (sequences start 16-byte aligned
     // and the set is padded, SP_SEQ_PAD_WORDS), 320 words = 5,088 bases + guard; longer alleles are staged directly.  The
     // running bound of the read comes along: any value it ever had is a valid bound.
@@ -195,70 +186,62 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
         if (bound) pre_bound = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pre_for = idx;
     };
-    const int n_units = (n_act + K1_UNIT - 1) / K1_UNIT;
-    int unit = wave;                                      // the first units are pre-assigned, the rest grabbed
-    while (unit < n_units) {
-        const int c_begin = unit * K1_UNIT;
-        const int c_n = min(K1_UNIT, n_act - c_begin);
-        const int nxt_unit = grab();
-        int u_tag = 0, u_alen = 0, u_kb = 0, u_woff = 0, u_lcp = 0;
-        if (lane < c_n) {
-            const int* m = meta + (c_begin + lane) * K1_META;
-            u_tag = m[0]; u_alen = m[1]; u_kb = m[2]; u_woff = m[3]; u_lcp = m[5];
-        }
-        const int u_slot = u_tag & 0xFFFF;
-        // lane j: does cell j sit right behind cell j-1 in the visiting order?  (dense-list neighbours need not be)
-        const int u_adjacent = u_slot == spw::from_lower(u_slot, -2) + 1;
-        // the state the previous cell of this unit left for its successor (wfa_core, Snap)
+
+    for (int g = 0; g < K1_GROUPS; ++g) {
+        const uint32_t p_mine = p_first + g * 64 + lane;
+        int jm0, jm1;
+        const Cell u = load_cell(p_mine, jm0, jm1);
+        const unsigned long long active = __ballot(u.act != 0);
+        uint32_t res = SP_CELL_NONE;
+        // lane j: is the cell right before it in the order active too?  (a chain or a saved state never crosses a gap or a group)
+        const int u_adjacent = u.act && spw::from_lower(u.act, 0);
+        // the state the previous cell left for its successor (wfa_core, Snap)
         int snap_for = -1, snap_s = -1, snap_H = 0;
-        int jc = 0;
-        if (pre_for != c_begin) prefetch(c_begin, (uint32_t)__builtin_amdgcn_readlane(u_woff, 0));
-        while (jc < c_n) {
-            if (pre_for != c_begin + jc) prefetch(c_begin + jc, (uint32_t)__builtin_amdgcn_readlane(u_woff, jc));      // (behind a chain)
-            int u_cap = u_tag >> 16;
-            if (bound) u_cap = k1_dyn_cap(pre_bound, u_alen, u_cap);
-            const int c_alen = __builtin_amdgcn_readlane(u_alen, jc), c_kb = __builtin_amdgcn_readlane(u_kb, jc);
-            const int c_cap = __builtin_amdgcn_readlane(u_cap, jc), c_slot = __builtin_amdgcn_readlane(u_slot, jc);
-            const uint32_t c_woff = (uint32_t)__builtin_amdgcn_readlane(u_woff, jc);
+        int jc = active ? __builtin_ctzll(active) : 64;
+        while (jc < 64) {
+            const int c_key = g * 64 + jc;
+            if (pre_for != c_key) prefetch(c_key, (uint32_t)__builtin_amdgcn_readlane((int)u.woff, jc));      // (first of a group, behind a chain)
+            int u_cap = u.cap;
+            if (bound) u_cap = k1_dyn_cap(pre_bound, u.alen, u_cap);
+            const int c_alen = __builtin_amdgcn_readlane(u.alen, jc), c_kb = __builtin_amdgcn_readlane(u.kb, jc);
+            const int c_cap = __builtin_amdgcn_readlane(u_cap, jc);
+            const uint32_t c_woff = (uint32_t)__builtin_amdgcn_readlane((int)u.woff, jc);
             if (((c_alen + 15) >> 4) + 2 <= K1_PRE_WORDS) {
                 *reinterpret_cast<uint4*>(LA + 4 * lane) = pre4;
                 LA[256 + lane] = pre1;
             } else {
                 spw::stage(LA, alleles.words + c_woff, 0, c_alen, lane);
             }
-            // the most likely next cell streams into the registers while this one runs
-            if (jc + 1 < c_n) prefetch(c_begin + jc + 1, (uint32_t)__builtin_amdgcn_readlane(u_woff, (jc + 1) & 63));
-            else if (nxt_unit < n_units) prefetch(nxt_unit * K1_UNIT, (uint32_t)__builtin_amdgcn_readfirstlane(meta[nxt_unit * K1_UNIT * K1_META + 3]));
+            // the next active cell streams into the registers while this one runs (it is the next to run unless this run settles it)
+            const unsigned long long later = jc < 63 ? active & (~0ull << (jc + 1)) : 0ull;
+            const int jn = later ? __builtin_ctzll(later) : 64;
+            if (jn < 64) prefetch(g * 64 + jn, (uint32_t)__builtin_amdgcn_readlane((int)u.woff, jn & 63));
             if (HASN) {
                 if (alleles.nplane) spw::stage(NA, alleles.nplane + c_woff, 0, c_alen, lane);
                 else for (int w = lane; w < ((c_alen + 15) >> 4) + 2; w += SP_WAVE) NA[w] = 0;
             }
             spw::wave_lds_sync();
-            uint32_t res = SP_CELL_NONE;
             SP_STAT(0, 1); SP_STAT(7, c_cap); SP_STAT(48 + (c_cap < 15 ? c_cap : 15), 1);
             spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0; o.explored = 0x7FFFFFFF;
-            int nxt = jc + 1;
+            int nxt = jn;
             if (c_kb >= 0) {
-                // the successor in the order shares u_lcp bases with this allele: leave it the last state that stayed inside them,
+                // the successor in the order shares its lcp with this allele: leave it the last state that stayed inside those bases,
                 // and start from the state the predecessor left when it was made for this cell and is not past this cell's cap
-                const bool has_succ = nxt < c_n && __builtin_amdgcn_readlane(u_adjacent, nxt & 63);
-                const int thr2 = has_succ ? __builtin_amdgcn_readlane(u_lcp, nxt & 63) << 1 : 0;
+                const bool has_succ = jc < 63 && __builtin_amdgcn_readlane(u_adjacent, (jc + 1) & 63);
+                const int thr2 = has_succ ? __builtin_amdgcn_readlane(u.lcp, (jc + 1) & 63) << 1 : 0;
                 const bool resume = snap_for == jc && snap_s >= 0 && snap_s <= c_cap;
                 SP_STAT(8, resume ? 1 : 0); SP_STAT(9, resume ? snap_s + 1 : 0);
-                SP_STAT(10, (jc > 0 && snap_for != jc) ? 1 : 0);                      // ran right behind a chain of settled cells
-                SP_STAT(11, (snap_for == jc && snap_s < 0) ? 1 : 0);                  // adjacent predecessor, but it left no state
-                SP_STAT(12, (snap_for == jc && snap_s > c_cap) ? 1 : 0);
                 int out_s = -1, out_H = 0;
                 spw::wfa_core<false, HASN, false, true>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o,
                                                         thr2, resume ? snap_s : -1, snap_H, &out_s, &out_H);
-                snap_for = nxt; snap_s = __builtin_amdgcn_readfirstlane(out_s); snap_H = out_H;
+                snap_for = jc + 1; snap_s = __builtin_amdgcn_readfirstlane(out_s); snap_H = out_H;
             } else {
                 spw::wfa_core<false, HASN, false>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o);
                 snap_for = -1;
             }
             if (o.ok) {
                 const int span = o.a_end - o.a_start;
-                res = ((uint32_t)o.nm << 16) | (uint32_t)span;
+                if (lane == jc) res = ((uint32_t)o.nm << 16) | (uint32_t)span;
                 if (bound && lane == 0) {
                     const double pen = score_value(c_alen, o.nm, c_alen - span), ed = score_value(span, o.nm, 0);
                     if (pen <= 0.5 && ed <= 0.03) {
@@ -275,24 +258,23 @@ __global__ __launch_bounds__(K1_THREADS) void k1_cells_kernel(SeqSetView alleles
                         }
                     }
                 }
-            } else {
+            } else if (jc < 63) {
                 // the cells behind jc that this failed run settles: adjacent in the order, sharing more than the explored prefix,
-                // caps not growing -- the first lane behind jc that breaks the chain is the next cell to run
+                // caps not growing -- the first lane behind jc that breaks the chain ends it; the next active lane from there runs
                 const int extent = __builtin_amdgcn_readfirstlane(o.explored);
-                const bool carries = u_adjacent && u_lcp > extent && u_cap <= spw::from_lower(u_cap, -1);
-                const unsigned long long behind = ~0ull << nxt;                               // nxt <= 63
-                const unsigned long long stop = (__ballot(!carries) & behind) | (1ull << c_n);
-                nxt = __builtin_ctzll(stop);
-                SP_STAT(1, nxt - jc - 1);
+                const bool carries = u_adjacent && u.lcp > extent && u_cap <= spw::from_lower(u_cap, -1);
+                const unsigned long long behind = ~0ull << (jc + 1);
+                const unsigned long long stop = __ballot(!carries) & behind;
+                const int brk = stop ? __builtin_ctzll(stop) : 64;
+                const unsigned long long rest = brk < 64 ? active & (~0ull << brk) : 0ull;
+                nxt = rest ? __builtin_ctzll(rest) : 64;
+                SP_STAT(1, __builtin_popcountll(active & behind & ~rest));
             }
             spw::wave_lds_sync();
-            if (lane == 0) cres[c_slot] = res;
             jc = nxt;
         }
-        unit = nxt_unit;
+        if (p_mine < n_alleles) cell_out[(uint64_t)r * n_alleles + p_mine] = res;
     }
-    __syncthreads();
-    if (tid < K1_CHUNK && a_first + tid < a_end && act) cell_out[(uint64_t)r * n_alleles + a_first + tid] = cres[tid];
 }
 
 // Iterative deepening bookkeeping: after a pass whose cells were capped at pass_cap edits, read r is settled when an
@@ -603,7 +585,7 @@ void sp_hla_db_free(sp_hla_db* db) {
     if (!db) return;
     if (db->ctx) (void)hipSetDevice(db->ctx->device);
     sp_seqset_free(db->dna_gene); sp_seqset_free(db->cdna_gene); sp_seqset_free(db->dna_fwd); sp_seqset_free(db->ref_fwd);
-    (void)hipFree(db->d_gene_of); (void)hipFree(db->d_off_fwd); (void)hipFree(db->d_am); (void)hipFree(db->d_order); (void)hipFree(db->d_lcp);
+    (void)hipFree(db->d_gene_of); (void)hipFree(db->d_off_fwd); (void)hipFree(db->d_am); (void)hipFree(db->d_order); (void)hipFree(db->d_lcp); (void)hipFree(db->d_pos);
     (void)hipFree(db->d_hpc_ref); (void)hipFree(db->d_hpc_ref_off);
     for (auto& kv : db->gene_lists) { (void)hipFree(kv.second.d_idx); (void)hipFree(kv.second.d_l0); (void)hipFree(kv.second.d_l1); }
     delete db;
@@ -733,6 +715,17 @@ int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) 
             lcp[i] = (int32_t)std::min<size_t>(k, 1u << 30);
         }
         db->d_order = dev_copy(order); db->d_lcp = dev_copy(lcp); db->h_order = order;
+        // the same facts by position (K1Positions): length, frame offset, gene, first packed word, shared prefix
+        std::vector<int32_t> posv((size_t)5 * n, 0);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t a = order[i];
+            posv[i] = db->dna_fwd->h_len[a];
+            posv[(size_t)n + i] = off_fwd[a];
+            posv[(size_t)2 * n + i] = (int32_t)db->gene_of[a];
+            posv[(size_t)3 * n + i] = (int32_t)(uint32_t)db->dna_fwd->h_word_off[a];
+            posv[(size_t)4 * n + i] = lcp[i];
+        }
+        db->d_pos = dev_copy(posv);
     }
     (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_diag); (void)hipFree(d_votes);
     if (rc != SP_OK) { sp_hla_db_free(db); return rc; }
@@ -792,7 +785,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     // (both multiples of 4 words: the allele slots take 16-byte LDS stores; a slot always holds a whole register prefetch)
     const int b_words = (((reads->max_len + 15) / 16 + 4) + 3) & ~3;
     const int a_words = std::max(K1_PRE_WORDS, (((db->dna_fwd->max_len + 15) / 16 + 4) + 3) & ~3);
-    const size_t cells_lds = (size_t)(32 + (K1_META + 1) * K1_CHUNK + (hasn ? 2 : 1) * (b_words + K1_WAVES * a_words)) * 4 + SP_LDS_TAIL;
+    const size_t cells_lds = (size_t)((hasn ? 2 : 1) * (b_words + a_words)) * 4 + SP_LDS_TAIL;
     if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
     // exact branch-and-bound is switched off when the caller wants the full cell matrix
     unsigned long long* d_bound = nullptr;
@@ -826,8 +819,11 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
             ProfScope ps(ctx, pass == 0 ? "k1_cells" : "k1_cells_deep", (uint64_t)n_open * NA);
             auto go = [&](auto kernel) {
                 (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds);
-                hipLaunchKernelGGL(kernel, dim3(n_open * n_chunks), dim3(K1_THREADS), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(),
-                                   db->d_gene_of, db->d_off_fwd, d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, db->d_order, db->d_lcp, pass_cap, b_words, a_words);
+                K1Positions pos;
+                pos.alen = db->d_pos; pos.off = db->d_pos + NA; pos.gene = reinterpret_cast<const uint32_t*>(db->d_pos + (size_t)2 * NA);
+                pos.woff = reinterpret_cast<const uint32_t*>(db->d_pos + (size_t)3 * NA); pos.lcp = db->d_pos + (size_t)4 * NA;
+                hipLaunchKernelGGL(kernel, dim3(n_open * n_chunks), dim3(64), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(), pos,
+                                   d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, pass_cap, b_words, a_words);
             };
             if (hasn) { if (pass == 0) go(k1_cells_kernel<true, false>); else go(k1_cells_kernel<true, true>); }
             else { if (pass == 0) go(k1_cells_kernel<false, false>); else go(k1_cells_kernel<false, true>); }
