@@ -197,12 +197,13 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
         const int u_adjacent = u.act && spw::from_lower(u.act, 0);
         // the state the previous cell left for its successor (wfa_core, Snap)
         int snap_for = -1, snap_s = -1, snap_H = 0;
+        // the caps of the group under the bound they were last worked out for (redone only when the bound has moved)
+        int u_cap = u.cap; unsigned long long cap_bound = K1_NO_BOUND;
         int jc = active ? __builtin_ctzll(active) : 64;
         while (jc < 64) {
             const int c_key = g * 64 + jc;
             if (pre_for != c_key) prefetch(c_key, (uint32_t)__builtin_amdgcn_readlane((int)u.woff, jc));      // (first of a group, behind a chain)
-            int u_cap = u.cap;
-            if (bound) u_cap = k1_dyn_cap(pre_bound, u.alen, u_cap);
+            if (bound && pre_bound != cap_bound) { u_cap = k1_dyn_cap(pre_bound, u.alen, u.cap); cap_bound = pre_bound; }
             const int c_alen = __builtin_amdgcn_readlane(u.alen, jc), c_kb = __builtin_amdgcn_readlane(u.kb, jc);
             const int c_cap = __builtin_amdgcn_readlane(u_cap, jc);
             const uint32_t c_woff = (uint32_t)__builtin_amdgcn_readlane((int)u.woff, jc);
