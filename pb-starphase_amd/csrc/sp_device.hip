@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
     const int tid = threadIdx.x;
     uint32_t* tab_code = lds + ((bins_cap + 1) >> 1);
     int32_t* tab_pos = reinterpret_cast<int32_t*>(tab_code + tab_cap);
+    int tab_a = -1;                                   // the A whose table sits in LDS
     for (uint64_t p = blockIdx.x; p < n_pairs; p += gridDim.x) {
         const uint32_t a = a_idx[p], b = b_idx[p];
         const int m = A.len[a], n = B.len[b];
@@ -34,23 +35,49 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
         const uint32_t* bn = B.nplane ? B.nplane + B.word_off[b] : nullptr;
         const uint64_t k0 = KA.off[a], k1 = KA.off[a + 1];
         const int nk = (int)(k1 - k0);
-        // A's table moves to LDS once per pair: the binary search then runs at LDS latency instead of L2 latency
+        // A's table moves to LDS once per run of pairs with the same A (a workgroup strides over the pair list, and callers lay
+        // pairs out gene-minor, so a workgroup mostly keeps one table): the binary search then runs at LDS latency, not L2 latency
         const bool in_lds = nk <= tab_cap;
-        if (in_lds) for (int i = tid; i < nk; i += 256) { tab_code[i] = KA.code[k0 + i]; tab_pos[i] = KA.pos[k0 + i]; }
+        if (in_lds && (int)a != tab_a) for (int i = tid; i < nk; i += 256) { tab_code[i] = KA.code[k0 + i]; tab_pos[i] = KA.pos[k0 + i]; }
+        tab_a = in_lds ? (int)a : -1;
         const uint32_t* kc = in_lds ? tab_code : KA.code + k0; const int32_t* kp = in_lds ? tab_pos : KA.pos + k0;
         __syncthreads();
-        for (int j = tid; j + SP_KMER <= n; j += 256) {
-            const int w = j >> 4; const uint32_t sh = (uint32_t)((j & 15) << 1);
-            if (bn && __builtin_amdgcn_alignbit(bn[w + 1], bn[w], sh)) continue;
-            const uint32_t code = __builtin_amdgcn_alignbit(bw[w + 1], bw[w], sh);
-            int lo = 0, hi = nk;
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (kc[mid] < code) lo = mid + 1; else hi = mid; }
-            int e = lo; while (e < nk && e - lo <= SP_MAXOCC && kc[e] == code) ++e;
-            const int occ = e - lo;
-            if (occ == 0 || occ > SP_MAXOCC) continue;
-            for (int y = lo; y < e; ++y) {
-                const int bin = j - kp[y] + m;
-                atomicAdd(&lds[bin >> 1], (bin & 1) ? 0x10000u : 1u);
+        // four lookups per thread run side by side: a lower bound over nk entries takes the same number of halvings for every k-mer,
+        // so the four dependent load chains overlap instead of queueing behind one another (one wave per SIMD here: nothing else would)
+        const int steps = nk > 0 ? 32 - __builtin_clz((unsigned)nk) : 0;
+        for (int j0 = tid; j0 + SP_KMER <= n; j0 += 256 * 4) {
+            uint32_t code[4]; int lo[4], hi[4], jj[4]; bool live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 256;
+                jj[u] = j;
+                bool ok = j + SP_KMER <= n;
+                const int w = ok ? j >> 4 : 0; const uint32_t sh = (uint32_t)((j & 15) << 1);
+                if (ok && bn && __builtin_amdgcn_alignbit(bn[w + 1], bn[w], sh)) ok = false;
+                code[u] = __builtin_amdgcn_alignbit(bw[w + 1], bw[w], sh);
+                lo[u] = 0; hi[u] = ok ? nk : 0; live[u] = ok;
+            }
+            for (int st = 0; st < steps; ++st) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool open = lo[u] < hi[u];
+                    int mid = (lo[u] + hi[u]) >> 1; mid = mid < nk ? mid : nk - 1;
+                    const bool less = kc[mid] < code[u];
+                    lo[u] = open && less ? mid + 1 : lo[u];
+                    hi[u] = open && !less ? mid : hi[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!live[u]) continue;
+                const int l = lo[u];
+                int e = l; while (e < nk && e - l <= SP_MAXOCC && kc[e] == code[u]) ++e;
+                const int occ = e - l;
+                if (occ == 0 || occ > SP_MAXOCC) continue;
+                for (int y = l; y < e; ++y) {
+                    const int bin = jj[u] - kp[y] + m;
+                    atomicAdd(&lds[bin >> 1], (bin & 1) ? 0x10000u : 1u);
+                }
             }
         }
         __syncthreads();
