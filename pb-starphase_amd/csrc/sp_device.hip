@@ -10,12 +10,15 @@
 // Replaces minimap2's minimizer seeding + chaining inside Aligner::map (DESIGN.md section 3.1;
 // CPU restatement: oracle/align.c osp_anchor).
 // =============================================================================================
-__global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexView KA, SeqSetView B,
+#ifndef SP_ANCHOR_THREADS
+#define SP_ANCHOR_THREADS 512      // 256: 2.65 ms, 512: 2.14 ms, 1024: 3.65 ms for the 20,000 (read, gene) pairs of the bench step
+#endif
+__global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView A, KmerIndexView KA, SeqSetView B,
                                                         const uint32_t* __restrict__ a_idx, const uint32_t* __restrict__ b_idx,
                                                         uint64_t n_pairs, int32_t* __restrict__ diag_out, int32_t* __restrict__ votes_out,
                                                         int bins_cap, int topk, int tab_cap) {
     extern __shared__ uint32_t lds[];                 // [packed u16 vote bins, 2 per dword][A's sorted 16-mer codes][their positions]
-    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long red[SP_ANCHOR_THREADS / 64];
     __shared__ int spread[2];
     const int tid = threadIdx.x;
     uint32_t* tab_code = lds + ((bins_cap + 1) >> 1);
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
             continue;
         }
         const int nb32 = (nbins + 1) >> 1;
-        for (int i = tid; i < nb32; i += 256) lds[i] = 0;
+        for (int i = tid; i < nb32; i += SP_ANCHOR_THREADS) lds[i] = 0;
         const uint32_t* bw = B.words + B.word_off[b];
         const uint32_t* bn = B.nplane ? B.nplane + B.word_off[b] : nullptr;
         const uint64_t k0 = KA.off[a], k1 = KA.off[a + 1];
@@ -38,18 +41,18 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
         // A's table moves to LDS once per run of pairs with the same A (a workgroup strides over the pair list, and callers lay
         // pairs out gene-minor, so a workgroup mostly keeps one table): the binary search then runs at LDS latency, not L2 latency
         const bool in_lds = nk <= tab_cap;
-        if (in_lds && (int)a != tab_a) for (int i = tid; i < nk; i += 256) { tab_code[i] = KA.code[k0 + i]; tab_pos[i] = KA.pos[k0 + i]; }
+        if (in_lds && (int)a != tab_a) for (int i = tid; i < nk; i += SP_ANCHOR_THREADS) { tab_code[i] = KA.code[k0 + i]; tab_pos[i] = KA.pos[k0 + i]; }
         tab_a = in_lds ? (int)a : -1;
         const uint32_t* kc = in_lds ? tab_code : KA.code + k0; const int32_t* kp = in_lds ? tab_pos : KA.pos + k0;
         __syncthreads();
         // four lookups per thread run side by side: a lower bound over nk entries takes the same number of halvings for every k-mer,
         // so the four dependent load chains overlap instead of queueing behind one another (one wave per SIMD here: nothing else would)
         const int steps = nk > 0 ? 32 - __builtin_clz((unsigned)nk) : 0;
-        for (int j0 = tid; j0 + SP_KMER <= n; j0 += 256 * 4) {
+        for (int j0 = tid; j0 + SP_KMER <= n; j0 += SP_ANCHOR_THREADS * 4) {
             uint32_t code[4]; int lo[4], hi[4], jj[4]; bool live[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * 256;
+                const int j = j0 + u * SP_ANCHOR_THREADS;
                 jj[u] = j;
                 bool ok = j + SP_KMER <= n;
                 const int w = ok ? j >> 4 : 0; const uint32_t sh = (uint32_t)((j & 15) << 1);
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
         // top-K peaks: argmax votes (ties -> smallest diagonal), then clear every bin within +-SP_PEAK_SUPPRESS of it
         for (int round = 0; round < topk; ++round) {
             unsigned long long best = 0;
-            for (int bin = tid; bin < nbins; bin += 256) {
+            for (int bin = tid; bin < nbins; bin += SP_ANCHOR_THREADS) {
                 uint32_t v = (lds[bin >> 1] >> ((bin & 1) << 4)) & 0xFFFFu;
                 unsigned long long key = ((unsigned long long)v << 32) | (uint32_t)(0x7FFFFFFF - bin);
                 best = key > best ? key : best;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
             if ((tid & 63) == 0) red[tid >> 6] = best;
             __syncthreads();
             best = red[0];
-            for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
+            for (int w = 1; w < SP_ANCHOR_THREADS / 64; ++w) best = red[w] > best ? red[w] : best;
             const int v = (int)(best >> 32);
             const int bin = 0x7FFFFFFF - (int)(best & 0xFFFFFFFFu);
             // a long indel splits the votes over two diagonals: centre the band between the outermost diagonals within
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void sp_anchor_kernel(SeqSetView A, KmerIndexV
                 if (lo < 0) lo = 0;
                 if (hi > nbins - 1) hi = nbins - 1;
                 // bins are packed two per dword: clear them one lane per bin with a masked atomic AND
-                for (int b2 = lo + tid; b2 <= hi; b2 += 256) atomicAnd(&lds[b2 >> 1], (b2 & 1) ? 0x0000FFFFu : 0xFFFF0000u);
+                for (int b2 = lo + tid; b2 <= hi; b2 += SP_ANCHOR_THREADS) atomicAnd(&lds[b2 >> 1], (b2 & 1) ? 0x0000FFFFu : 0xFFFF0000u);
                 __syncthreads();
             }
         }
@@ -247,7 +250,7 @@ int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sp_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     uint64_t grid = std::min<uint64_t>(n_pairs, (uint64_t)ctx->num_cus * 8);
     ProfScope ps(ctx, "anchor", n_pairs);
-    hipLaunchKernelGGL(sp_anchor_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, ctx->stream,
+    hipLaunchKernelGGL(sp_anchor_kernel, dim3((unsigned)grid), dim3(SP_ANCHOR_THREADS), lds_bytes, ctx->stream,
                        A->view(), A->kview(), B->view(), d_a_idx, d_b_idx, n_pairs, d_diag, d_votes, bins_cap, topk, tab_cap);
     SP_HIP_CHECK(ctx, hipGetLastError());
     return SP_OK;
