@@ -63,6 +63,8 @@ def test_k1_realign_reads(oracle, pkg, gpu_ctx, small):
     reads.append(synth.mutate(rng, reads[7], 150, 60, 60))          # beyond the 3 % cut-off
     reads.append("".join(rng.choice(list("ACGT"), 5000)))          # junk read: no allele
     reads.append(reads[0][:3100])                                    # truncated read
+    reads.append(reads[2][len(reads[2]) - 2600:])                    # starts inside the alleles: negative band diagonals (no snapshot / resume)
+    reads.append(reads[6][1500:1500 + 3000])
     rs = gpu_ctx.upload(reads)
     out, cells = db.realign_reads(rs, cells=True)
     exp, ecells = hx.k1_expected(oracle, fx, reads)
@@ -80,12 +82,39 @@ def test_k1_realign_reads(oracle, pkg, gpu_ctx, small):
             n_real += 1
             assert (o["seg_start"], o["seg_end"], o["dna_offset"], o["hpc_offset"]) == \
                    (e["seg_start"], e["seg_end"], e["dna_offset"], e["hpc_offset"]), (r, o, e)
-    assert n_real >= len(reads) - 5
-    assert out[len(reads) - 2]["best_allele"] == -1
+    assert n_real >= len(reads) - 7
+    assert out[len(reads) - 4]["best_allele"] == -1
     # production mode (no cell matrix requested): exact branch-and-bound must not change a single output field
     for _ in range(3):
         pruned = db.realign_reads(rs)
         assert pruned.tobytes() == out.tobytes()
+
+
+def test_k1_reads_with_n(oracle, pkg, gpu_ctx, small):
+    """reads carrying N bases take the N-plane variants of every K1 kernel (an N never matches, not even another N)"""
+    from pb_starphase_amd import synth
+    fx, db = small
+    rng = np.random.default_rng(21)
+    reads = []
+    for g in range(len(fx.genes)):
+        a = int(rng.choice(fx.full_length_alleles(g)))
+        hap, gs = fx.haplotype(g, a)
+        reads += synth.simulate_reads(rng, hap, gs, len(fx.dna[a]), 4, mean_len=6500, sd_len=1200)
+    for r in (0, 3, 5):
+        s = list(reads[r])
+        for p in rng.choice(len(s), 6, replace=False):
+            s[int(p)] = "N"
+        reads[r] = "".join(s)
+    reads[1] = reads[1][:2000] + "N" * 40 + reads[1][2040:]          # a run of N: more edits than the first pass allows
+    rs = gpu_ctx.upload(reads)
+    out, cells = db.realign_reads(rs, cells=True)
+    exp, ecells = hx.k1_expected(oracle, fx, reads)
+    assert (cells == ecells).all(), np.argwhere(cells != ecells)[:10]
+    for r, e in enumerate(exp):
+        assert out[r]["status"] == e["status"] and out[r]["best_allele"] == e["best_allele"], (r, out[r], e)
+        if e["best_allele"] >= 0:
+            assert (out[r]["nm"], out[r]["target_len"], out[r]["unmapped"]) == (e["nm"], e["target_len"], e["unmapped"])
+    assert db.realign_reads(rs).tobytes() == out.tobytes()
 
 
 def test_type_consensus(oracle, pkg, gpu_ctx, small):
