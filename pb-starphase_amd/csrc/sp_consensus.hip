@@ -89,9 +89,12 @@ __device__ __forceinline__ Decision decide(const ConsParams& P, const ConsCtrl& 
         const uint4 q = *reinterpret_cast<const uint4*>(v);
         x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; x[4] = v[4];
     }
+    // sums over each group of 8 lanes with DPP (quad swaps, then the half-row mirror): no LDS traffic, three adds per counter
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        x[j] += __shfl_xor(x[j], 1); x[j] += __shfl_xor(x[j], 2); x[j] += __shfl_xor(x[j], 4);
+        x[j] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[j], 0xB1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
+        x[j] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[j], 0x4E, 0xf, 0xf, true);      // quad_perm:[2,3,0,1]
+        x[j] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[j], 0x141, 0xf, 0xf, true);     // row_half_mirror
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
