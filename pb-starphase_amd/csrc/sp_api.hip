@@ -46,6 +46,7 @@ void sp_ctx_destroy(sp_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     for (auto& kv : ctx->pool) if (kv.second.first) hipFree(kv.second.first);
+    for (auto& kv : ctx->host_pool) if (kv.second.first) hipHostFree(kv.second.first);
     sp_profile_flush(ctx);
     for (hipEvent_t e : ctx->prof_free) hipEventDestroy(e);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -255,12 +256,15 @@ std::string sp_seqset_decode(sp_ctx* ctx, const sp_seqset* s, uint32_t i) {
 static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::vector<uint32_t>& kcode, std::vector<int32_t>& kpos) {
     const size_t plane_words = (size_t)s->h_word_off[s->n] + SP_SEQ_PAD_WORDS;
     koff.assign((size_t)s->n + 1, 0); kcode.clear(); kpos.clear();
-    std::vector<std::pair<uint32_t, int32_t>> tmp;
+    // (code, position) pairs in position order, then a stable LSD radix sort on the code (3 passes of 11 bits): the table is sorted
+    // by (code, position) like a comparison sort of the pairs would leave it, in a fraction of the time -- this runs on the host
+    // between two launches every time a consensus is typed
+    std::vector<uint32_t> c0, c1; std::vector<int32_t> p0, p1;
     for (uint32_t i = 0; i < s->n; ++i) {
         const uint32_t* w = s->h_words.data() + s->h_word_off[i];
         const uint32_t* np = s->has_n ? s->h_words.data() + plane_words + s->h_word_off[i] : nullptr;
         const int len = s->h_len[i];
-        tmp.clear();
+        c0.clear(); p0.clear();
         for (int j = 0; j + SP_KMER <= len; ++j) {
             const int wi = j >> 4; const int sh = (j & 15) << 1;
             auto fetch = [&](const uint32_t* p) -> uint32_t {
@@ -268,11 +272,20 @@ static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::ve
                 return (uint32_t)(v >> sh);
             };
             if (np && fetch(np)) continue;
-            tmp.emplace_back(fetch(w), j);
+            c0.push_back(fetch(w)); p0.push_back(j);
         }
-        std::sort(tmp.begin(), tmp.end());
+        const size_t m = c0.size();
+        c1.resize(m); p1.resize(m);
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = pass * 11; const uint32_t mask = pass == 2 ? 0x3FFu : 0x7FFu;
+            uint32_t count[2049] = {0};
+            for (size_t x = 0; x < m; ++x) ++count[((c0[x] >> shift) & mask) + 1];
+            for (int b = 0; b < 2048; ++b) count[b + 1] += count[b];
+            for (size_t x = 0; x < m; ++x) { const uint32_t at = count[(c0[x] >> shift) & mask]++; c1[at] = c0[x]; p1[at] = p0[x]; }
+            c0.swap(c1); p0.swap(p1);
+        }
         koff[i] = kcode.size();
-        for (auto& kv : tmp) { kcode.push_back(kv.first); kpos.push_back(kv.second); }
+        kcode.insert(kcode.end(), c0.begin(), c0.end()); kpos.insert(kpos.end(), p0.begin(), p0.end());
     }
     koff[s->n] = kcode.size();
 }

@@ -858,10 +858,12 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_finalize launch failed");
     }
     if (rc == SP_OK) {
-        (void)hipMemcpyAsync(out, d_out, (size_t)R * sizeof(sp_hla_realign), hipMemcpyDeviceToHost, ctx->stream);
+        void* h_out = sp_host_pool(ctx, "k1_out", (size_t)R * sizeof(sp_hla_realign));
+        (void)hipMemcpyAsync(h_out ? h_out : (void*)out, d_out, (size_t)R * sizeof(sp_hla_realign), hipMemcpyDeviceToHost, ctx->stream);
         if (cell_out) (void)hipMemcpyAsync(cell_out, d_cells, (size_t)R * NA * 4, hipMemcpyDeviceToHost, ctx->stream);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("realign: ") + hipGetErrorString(e));
+        else if (h_out) std::memcpy(out, h_out, (size_t)R * sizeof(sp_hla_realign));
         if (rc == SP_OK && cell_out) {                        // the device rows are in visiting order: hand them out by allele index
             std::vector<uint32_t> row(NA);
             for (uint32_t r = 0; r < R; ++r) {

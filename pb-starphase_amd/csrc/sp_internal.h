@@ -73,6 +73,7 @@ struct sp_ctx {
     // reusable scratch
     void* scratch = nullptr; size_t scratch_bytes = 0;
     std::map<std::string, std::pair<void*, size_t>> pool;   // named grow-only device buffers (no malloc/free per call)
+    std::map<std::string, std::pair<void*, size_t>> host_pool;   // named grow-only pinned host buffers (results leave the device through them)
     int num_cus = 256;
 };
 
@@ -101,6 +102,7 @@ int sp_seqset_fetch_host(sp_ctx* ctx, sp_seqset* s);                      // pac
 std::string sp_seqset_decode(sp_ctx* ctx, const sp_seqset* s, uint32_t i); // ASCII of sequence i
 void* sp_scratch(sp_ctx* ctx, size_t bytes);
 void* sp_pool(sp_ctx* ctx, const char* name, size_t bytes);
+void* sp_host_pool(sp_ctx* ctx, const char* name, size_t bytes);
 int   sp_fail(sp_ctx* ctx, int code, const std::string& msg);
 #define SP_HIP_CHECK(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
     return sp_fail((ctx), SP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
