@@ -85,14 +85,14 @@ __device__ __forceinline__ int from_lower(int x, int fill) { return __builtin_am
 __device__ __forceinline__ int from_upper(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
 
 // max(acc, neighbour's x) in ONE instruction: the DPP operand rides on v_max_i32; a lane without that neighbour keeps acc
-// (s_nop 1: a VGPR written by a VALU instruction needs two wait states before a DPP read, and the assembler does not look
-// inside inline asm)
+// (s_nop 4: a DPP read needs two wait states after a VALU write of that VGPR and five after a VALU write of EXEC, and the
+// compiler's hazard recogniser does not look inside inline asm -- the nop covers the worst case)
 __device__ __forceinline__ int max_from_lower(int x, int acc) {
-    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x));
+    asm("s_nop 4\n\tv_max_i32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x));
     return acc;
 }
 __device__ __forceinline__ int max_from_upper(int x, int acc) {
-    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x));
+    asm("s_nop 4\n\tv_max_i32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x));
     return acc;
 }
 
@@ -100,7 +100,7 @@ __device__ __forceinline__ int max_from_upper(int x, int acc) {
 // every lane has a partner, no fill needed), then the four row results meet on the scalar side
 __device__ __forceinline__ int wave_max(int v) {
     int r;
-    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 4\n\tv_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
