@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
                                                       int n_genes, uint32_t n_alleles, uint32_t n_chunks,
                                                       uint32_t* __restrict__ cell_out, unsigned long long* __restrict__ bound,
                                                       const uint32_t* __restrict__ read_list, uint32_t* __restrict__ read_maxlen,
+                                                      unsigned long long* __restrict__ winner, const uint32_t* __restrict__ order,
                                                       int pass_cap, int b_words, int a_words) {
     extern __shared__ uint32_t lds[];
     // layout: [B window b_words (x2 with N plane)][A slot a_words (x2 with N plane)]
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
     w_lo = -spw::wave_max(-w_lo); w_hi = spw::wave_max(w_hi); longest = spw::wave_max(longest);
     if (w_hi < 0) {                                       // nothing to run (the positions of another gene, mostly)
 #pragma unroll
-        for (int g = 0; g < K1_GROUPS; ++g) { const uint32_t p = p_first + g * 64 + lane; if (p < n_alleles) cell_out[(uint64_t)r * n_alleles + p] = SP_CELL_NONE; }
+        for (int g = 0; g < K1_GROUPS; ++g) { const uint32_t p = p_first + g * 64 + lane; if (cell_out && p < n_alleles) cell_out[(uint64_t)r * n_alleles + p] = SP_CELL_NONE; }
         return;
     }
     int b_base;
@@ -257,6 +258,24 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
                             if (prev == curb) break;
                             curb = prev;
                         }
+                        if (winner) {
+                            // the read's best acceptable cell so far, by the very comparison k1_reduce_kernel makes on the cell
+                            // matrix (f64 ratio, ties to the lowest allele index): nm << 40 | span << 24 | allele
+                            const uint32_t a = order[p_first + g * 64 + jc];
+                            const unsigned long long mine = ((unsigned long long)o.nm << 40) | ((unsigned long long)span << 24) | a;
+                            unsigned long long cw = __hip_atomic_load(&winner[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            for (;;) {
+                                bool better = cw == ~0ull;
+                                if (!better) {
+                                    const double ced = score_value((int)((cw >> 24) & 0xFFFFu), (int)(cw >> 40), 0);
+                                    better = ed < ced || (ed == ced && a < (uint32_t)(cw & 0xFFFFFFu));
+                                }
+                                if (!better) break;
+                                const unsigned long long prev = atomicCAS(&winner[r], cw, mine);
+                                if (prev == cw) break;
+                                cw = prev;
+                            }
+                        }
                     }
                 }
             } else if (jc < 63) {
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
             spw::wave_lds_sync();
             jc = nxt;
         }
-        if (p_mine < n_alleles) cell_out[(uint64_t)r * n_alleles + p_mine] = res;
+        if (cell_out && p_mine < n_alleles) cell_out[(uint64_t)r * n_alleles + p_mine] = res;
     }
 }
 
@@ -295,6 +314,12 @@ __global__ void k1_done_kernel(const unsigned long long* __restrict__ bound, uin
 }
 
 // K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
+// production mode keeps no cell matrix: the cells kernels maintain the winner word of every read (see there), this unpacks it
+__global__ void k1_winner_kernel(const unsigned long long* __restrict__ winner, uint32_t n_reads, int32_t* __restrict__ best_out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads) { const unsigned long long w = winner[r]; best_out[r] = w == ~0ull ? -1 : (int32_t)(w & 0xFFFFFFu); }
+}
+
 __global__ __launch_bounds__(256) void k1_reduce_kernel(const uint32_t* __restrict__ cell_out, const int32_t* __restrict__ allele_len,
                                                         const uint32_t* __restrict__ order, uint32_t n_alleles, uint32_t n_reads, int32_t* __restrict__ best_out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -768,10 +793,13 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     int32_t* d_rg = (int32_t*)sp_pool(ctx, "k1_rg", (size_t)R * G * 4);
     int32_t* d_votes = (int32_t*)sp_pool(ctx, "k1_votes", (size_t)R * G * 4);
     int32_t* d_best = (int32_t*)sp_pool(ctx, "k1_best", (size_t)R * 4);
-    uint32_t* d_cells = (uint32_t*)sp_pool(ctx, "k1_cells", (size_t)R * NA * 4);
+    // the read x allele matrix only exists when the caller asked for it (738 MB per 10,000 reads with the bundled database)
+    uint32_t* d_cells = cell_out ? (uint32_t*)sp_pool(ctx, "k1_cells", (size_t)R * NA * 4) : nullptr;
+    unsigned long long* d_win = cell_out ? nullptr : (unsigned long long*)sp_pool(ctx, "k1_winner", (size_t)R * 8);
     sp_hla_realign* d_out = (sp_hla_realign*)sp_pool(ctx, "k1_out", (size_t)R * sizeof(sp_hla_realign));
     int rc = SP_OK;
-    if (!d_a || !d_b || !d_rg || !d_votes || !d_best || !d_cells || !d_out) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+    if (!d_a || !d_b || !d_rg || !d_votes || !d_best || (cell_out ? !d_cells : !d_win) || !d_out || NA >= (1u << 24)) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+    if (rc == SP_OK && d_win) (void)hipMemsetAsync(d_win, 0xFF, (size_t)R * 8, ctx->stream);
     if (rc == SP_OK) {
         (void)hipMemcpyAsync(d_a, a_idx.data(), (size_t)R * G * 4, hipMemcpyHostToDevice, ctx->stream);
         (void)hipMemcpyAsync(d_b, b_idx.data(), (size_t)R * G * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -824,7 +852,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
                 pos.alen = db->d_pos; pos.off = db->d_pos + NA; pos.gene = reinterpret_cast<const uint32_t*>(db->d_pos + (size_t)2 * NA);
                 pos.woff = reinterpret_cast<const uint32_t*>(db->d_pos + (size_t)3 * NA); pos.lcp = db->d_pos + (size_t)4 * NA;
                 hipLaunchKernelGGL(kernel, dim3(n_open * n_chunks), dim3(64), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(), pos,
-                                   d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, pass_cap, b_words, a_words);
+                                   d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, d_win, db->d_order, pass_cap, b_words, a_words);
             };
             if (hasn) { if (pass == 0) go(k1_cells_kernel<true, false>); else go(k1_cells_kernel<true, true>); }
             else { if (pass == 0) go(k1_cells_kernel<false, false>); else go(k1_cells_kernel<false, true>); }
@@ -840,7 +868,8 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     }
     if (rc == SP_OK) {
         ProfScope ps(ctx, "k1_reduce", R);
-        hipLaunchKernelGGL(k1_reduce_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, d_cells, db->dna_fwd->d_len, db->d_order, NA, R, d_best);
+        if (d_win) hipLaunchKernelGGL(k1_winner_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_win, R, d_best);
+        else hipLaunchKernelGGL(k1_reduce_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, d_cells, db->dna_fwd->d_len, db->d_order, NA, R, d_best);
     }
     if (rc == SP_OK) {
         ProfScope ps(ctx, "k1_finalize", R);
