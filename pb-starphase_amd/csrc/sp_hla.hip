@@ -314,6 +314,14 @@ __global__ void k1_done_kernel(const unsigned long long* __restrict__ bound, uin
 }
 
 // K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
+// pair p of the K1 anchor is (gene p % G, read p / G); every read starts without a bound
+__global__ void k1_init_kernel(uint32_t* __restrict__ a_idx, uint32_t* __restrict__ b_idx, uint32_t n_reads, uint32_t n_genes,
+                               unsigned long long* __restrict__ bound) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_reads * n_genes) { a_idx[p] = p % n_genes; b_idx[p] = p / n_genes; }
+    if (bound && p < n_reads) bound[p] = K1_NO_BOUND;
+}
+
 // production mode keeps no cell matrix: the cells kernels maintain the winner word of every read (see there), this unpacks it
 __global__ void k1_winner_kernel(const unsigned long long* __restrict__ winner, uint32_t n_reads, int32_t* __restrict__ best_out) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -786,8 +794,6 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     if (R == 0) return SP_OK;
     (void)hipSetDevice(ctx->device);
     // 1. anchors read x gene
-    std::vector<uint32_t> a_idx((size_t)R * G), b_idx((size_t)R * G);
-    for (uint32_t r = 0; r < R; ++r) for (uint32_t g = 0; g < G; ++g) { a_idx[(size_t)r * G + g] = g; b_idx[(size_t)r * G + g] = r; }
     uint32_t* d_a = (uint32_t*)sp_pool(ctx, "k1_a_idx", (size_t)R * G * 4);
     uint32_t* d_b = (uint32_t*)sp_pool(ctx, "k1_b_idx", (size_t)R * G * 4);
     int32_t* d_rg = (int32_t*)sp_pool(ctx, "k1_rg", (size_t)R * G * 4);
@@ -800,11 +806,13 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     int rc = SP_OK;
     if (!d_a || !d_b || !d_rg || !d_votes || !d_best || (cell_out ? !d_cells : !d_win) || !d_out || NA >= (1u << 24)) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
     if (rc == SP_OK && d_win) (void)hipMemsetAsync(d_win, 0xFF, (size_t)R * 8, ctx->stream);
-    if (rc == SP_OK) {
-        (void)hipMemcpyAsync(d_a, a_idx.data(), (size_t)R * G * 4, hipMemcpyHostToDevice, ctx->stream);
-        (void)hipMemcpyAsync(d_b, b_idx.data(), (size_t)R * G * 4, hipMemcpyHostToDevice, ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream);
+    // the (gene, read) pair list of the anchor and the empty bounds are written on the device: no host vectors, no waiting for copies
+    unsigned long long* d_bound = nullptr;
+    if (rc == SP_OK && !cell_out) {
+        d_bound = (unsigned long long*)sp_pool(ctx, "k1_bound", (size_t)R * 8);
+        if (!d_bound) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign bound");
     }
+    if (rc == SP_OK) hipLaunchKernelGGL(k1_init_kernel, dim3((R * G + 255) / 256), dim3(256), 0, ctx->stream, d_a, d_b, R, G, d_bound);
     if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes);
     const bool hasn = db->dna_fwd->has_n || reads->has_n || db->ref_fwd->has_n;
     // finalize: private per-wave windows of (allele, read) and (reference, read segment)
@@ -816,17 +824,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     const int a_words = std::max(K1_PRE_WORDS, (((db->dna_fwd->max_len + 15) / 16 + 4) + 3) & ~3);
     const size_t cells_lds = (size_t)((hasn ? 2 : 1) * (b_words + a_words)) * 4 + SP_LDS_TAIL;
     if (rc == SP_OK && (lds_bytes > 160 * 1024 - 64 || cells_lds > 160 * 1024 - 64)) rc = sp_fail(ctx, SP_ERR_TOO_LONG, "realign: window too long");
-    // exact branch-and-bound is switched off when the caller wants the full cell matrix
-    unsigned long long* d_bound = nullptr;
-    if (rc == SP_OK && !cell_out) {
-        d_bound = (unsigned long long*)sp_pool(ctx, "k1_bound", (size_t)R * 8);
-        if (!d_bound) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign bound");
-        else {
-            std::vector<unsigned long long> init(R, K1_NO_BOUND);
-            (void)hipMemcpyAsync(d_bound, init.data(), (size_t)R * 8, hipMemcpyHostToDevice, ctx->stream);
-            (void)hipStreamSynchronize(ctx->stream);
-        }
-    }
+    // (exact branch-and-bound is switched off when the caller wants the full cell matrix: d_bound stays null)
     // Pruned mode runs the cells as exact iterative deepening: pass 1 caps every cell at 12 edits (plus the running
     // bound); reads whose best acceptable cell cannot be beaten by any unfinished cell are settled; the few others
     // are redone at 40 and then at the full 3 % cap.  The full-matrix mode is one un-pruned pass.
