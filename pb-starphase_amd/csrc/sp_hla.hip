@@ -90,6 +90,9 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
     return q < (uint32_t)cap ? (int)q : cap;
 }
 
+#ifndef K1_CAP1
+#define K1_CAP1 12       // edit cap of the first deepening pass
+#endif
 #define K1_PRE_WORDS 320 // words of an allele the register prefetch covers
 
 // DEEP only names the later (deeper, much smaller) passes of the iterative deepening differently, so that profilers list them apart
@@ -835,7 +838,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         if (!d_done || !d_open || !d_open_list || !d_maxlen) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign done flags");
         else { (void)hipMemsetAsync(d_done, 0, R, ctx->stream); (void)hipMemsetAsync(d_maxlen, 0, (size_t)R * 4, ctx->stream); }
     }
-    const int pass_caps[3] = {12, 40, SP_MAX_ED};
+    const int pass_caps[3] = {K1_CAP1, 40, SP_MAX_ED};
     const int n_pass = d_bound ? 3 : 1;
     uint32_t n_open = R;
     for (int pass = 0; pass < n_pass && rc == SP_OK; ++pass) {
