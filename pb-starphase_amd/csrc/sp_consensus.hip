@@ -156,6 +156,38 @@ __device__ __forceinline__ void dwfa_push_t(Dwfa& d, int n, RB rb, CA ca, int T,
     if (et && __ballot(d.H == n)) d.flags |= F_FINISHED;
 }
 
+// A freshly placed read catches up with `span` consensus bases at once.  Pushing them one by one (dwfa_push_t for T = 1 .. span)
+// leaves, after the last push, the wavefront of the smallest edit count at which some diagonal reaches consensus column `span`,
+// every diagonal extended as far as it goes inside those columns: while a wavefront still has a tip the pushes only extend
+// tips, and a new wavefront is only built when none is left, i.e. from diagonals that are all parked on a mismatch (or the read
+// end), where the column bound of that moment excludes nothing.  So the same state is reached by building wavefront after
+// wavefront with the extension bounded by `span` alone -- one pass over the span instead of one full push per base.
+// Early termination makes the per-base order observable (a read that ends inside the span freezes at that column): callers keep
+// the per-base loop for reads that could end inside the span.
+template <class RB, class CA>
+__device__ __forceinline__ void dwfa_catchup_t(Dwfa& d, int n, RB rb, CA ca, int span, int lane) {
+    const int k = lane - CH;
+    auto extend = [&]() {
+        for (;;) {
+            bool go = d.H >= 0 && d.H < n && d.H + k < span;
+            if (go) { const int x = rb(d.H); go = x < 4 && x == ca(d.c0 + d.H + k); }
+            if (!__ballot(go)) break;
+            if (go) d.H += 1;
+        }
+    };
+    extend();
+    while (!__ballot(d.H >= 0 && d.H + k == span)) {
+        const int c = d.H, up = spw::from_lower(d.H, SP_NEG), dn = spw::from_upper(d.H, SP_NEG);
+        int best = SP_NEG;
+        if (c >= 0 && c < n && c + k < span) best = c + 1;
+        if (up >= 0 && up + k <= span && up + k >= 0 && up > best) best = up;
+        if (dn >= 0 && dn < n && dn + 1 + k >= 0 && dn + 1 > best) best = dn + 1;
+        if (!__ballot(best >= 0)) { d.flags |= F_LOST; break; }
+        d.H = best; d.e += 1;
+        extend();
+    }
+}
+
 __device__ __forceinline__ void dwfa_push(Dwfa& d, const ReadView& rv, const ConsView& cv, int i, int T, int nb, int et, int lane) {
     dwfa_push_t(d, rv.n, [&](int h) { return read_base(rv, h); }, [&](int pos) { return cv.at(i, pos); }, T, nb, et, lane);
 }
@@ -366,9 +398,13 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatchT<M
         d[i].c0 = find_start(rvc, ca, ri.off, P.window, P.cmp_len, lane);
         d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
         const int c0 = d[i].c0, span = len - c0;
-        for (int T = 1; T <= span; ++T) {
-            if (d[i].flags & (F_FINISHED | F_LOST)) break;
-            dwfa_push_t(d[i], rv.n, rb, ca, T, ca(c0 + T - 1), P.et, lane);
+        if (span > 0 && !(d[i].flags & F_FINISHED) && !(P.et && rv.n <= span + CB)) {
+            dwfa_catchup_t(d[i], rv.n, rb, ca, span, lane);
+        } else {
+            for (int T = 1; T <= span; ++T) {
+                if (d[i].flags & (F_FINISHED | F_LOST)) break;
+                dwfa_push_t(d[i], rv.n, rb, ca, T, ca(c0 + T - 1), P.et, lane);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
