@@ -164,18 +164,10 @@ __device__ __forceinline__ void dwfa_push_t(Dwfa& d, int n, RB rb, CA ca, int T,
 // wavefront with the extension bounded by `span` alone -- one pass over the span instead of one full push per base.
 // Early termination makes the per-base order observable (a read that ends inside the span freezes at that column): callers keep
 // the per-base loop for reads that could end inside the span.
-template <class RB, class CA>
-__device__ __forceinline__ void dwfa_catchup_t(Dwfa& d, int n, RB rb, CA ca, int span, int lane) {
+template <class EXT>
+__device__ __forceinline__ void dwfa_catchup_t(Dwfa& d, int n, EXT extend, int span, int lane) {
     const int k = lane - CH;
-    auto extend = [&]() {
-        for (;;) {
-            bool go = d.H >= 0 && d.H < n && d.H + k < span;
-            if (go) { const int x = rb(d.H); go = x < 4 && x == ca(d.c0 + d.H + k); }
-            if (!__ballot(go)) break;
-            if (go) d.H += 1;
-        }
-    };
-    extend();
+    extend();                                            // every diagonal as far as it matches inside the span
     while (!__ballot(d.H >= 0 && d.H + k == span)) {
         const int c = d.H, up = spw::from_lower(d.H, SP_NEG), dn = spw::from_upper(d.H, SP_NEG);
         int best = SP_NEG;
@@ -359,6 +351,9 @@ template <int MAXP>
 __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatchT<MAXP> B, int t, const ActItem* __restrict__ items, int n_items) {
     __shared__ uint8_t ccache[4][ACT_CONS];
     __shared__ uint8_t rcache[4][ACT_READ];
+    // the same two windows 2 bits per base (16 bases per dword, two guard words): the catch-up compares 16 bases per step out of them
+    __shared__ uint32_t cpack[4][ACT_CONS / 16 + 2];
+    __shared__ uint32_t rpack[4][ACT_READ / 16 + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, it = blockIdx.x * 4 + wv;
     if (it >= n_items) return;
     const ActItem item = items[it];
@@ -392,6 +387,19 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatchT<M
         for (int x = lane; x < len - ws && x < ACT_CONS; x += SP_WAVE) ccache[wv][x] = (uint8_t)cv.at(i, ws + x);
         for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) rcache[wv][x] = (uint8_t)read_base(rv, x);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // packed copies: the consensus window from its byte codes (a lane packs 16 of them), the read words straight from memory
+        const int cwin = len - ws;
+        const bool packed = rv.np == nullptr && cwin <= ACT_CONS;
+        if (packed) {
+            for (int w = lane; w < ACT_CONS / 16 + 2; w += SP_WAVE) {
+                uint32_t word = 0;
+                for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < cwin) word |= (uint32_t)(ccache[wv][x] & 3u) << (b << 1); }
+                cpack[wv][w] = word;
+            }
+            const int rwords = ((rv.n < ACT_READ ? rv.n : ACT_READ) + 15) >> 4;
+            for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) rpack[wv][w] = w < rwords ? rv.w[w] : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         auto rb = [&](int h) { return h < ACT_READ ? (int)rcache[wv][h] : read_base(rv, h); };
         auto ca = [&](int pos) { const int x = pos - ws; return (x >= 0 && x < ACT_CONS) ? (int)ccache[wv][x] : cv.at(i, pos); };
         ReadView rvc = rv;
@@ -399,7 +407,40 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatchT<M
         d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
         const int c0 = d[i].c0, span = len - c0;
         if (span > 0 && !(d[i].flags & F_FINISHED) && !(P.et && rv.n <= span + CB)) {
-            dwfa_catchup_t(d[i], rv.n, rb, ca, span, lane);
+            const int kk = lane - CH;
+            if (packed) {
+                // 16 bases per step: xor of the two funnel-shifted words, first differing base, clamped by what is left of the read and
+                // of the span (H <= span + 32 < ACT_READ - 16 and the consensus window starts at or before c0: every word is cached)
+                const int cbase = c0 - ws;
+                dwfa_catchup_t(d[i], rv.n, [&]() {
+                    for (;;) {
+                        Dwfa& q = d[i];
+                        int left = rv.n - q.H; { const int l2 = span - (q.H + kk); left = l2 < left ? l2 : left; }
+                        const bool go = q.H >= 0 && left > 0;
+                        int nm = 0;
+                        if (go) {
+                            const int pr = q.H, pc = cbase + q.H + kk;
+                            const uint32_t a = __builtin_amdgcn_alignbit(rpack[wv][(pr >> 4) + 1], rpack[wv][pr >> 4], (uint32_t)(pr & 15) << 1);
+                            const uint32_t b = __builtin_amdgcn_alignbit(cpack[wv][(pc >> 4) + 1], cpack[wv][pc >> 4], (uint32_t)(pc & 15) << 1);
+                            const uint32_t x = a ^ b, mm = (x | (x >> 1)) & 0x55555555u;
+                            nm = mm ? (__builtin_ctz(mm) >> 1) : 16;
+                            nm = nm < left ? nm : left;
+                            q.H += nm;
+                        }
+                        if (!__ballot(go && nm == 16 && left > 16)) break;
+                    }
+                }, span, lane);
+            } else {
+                dwfa_catchup_t(d[i], rv.n, [&]() {
+                    for (;;) {
+                        Dwfa& q = d[i];
+                        bool go = q.H >= 0 && q.H < rv.n && q.H + kk < span;
+                        if (go) { const int x = rb(q.H); go = x < 4 && x == ca(q.c0 + q.H + kk); }
+                        if (!__ballot(go)) break;
+                        if (go) q.H += 1;
+                    }
+                }, span, lane);
+            }
         } else {
             for (int T = 1; T <= span; ++T) {
                 if (d[i].flags & (F_FINISHED | F_LOST)) break;
