@@ -136,7 +136,8 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA_, const
     const uint32_t LA = lds_addr(LA_), LB = lds_addr(LB_), NA = HASN ? lds_addr(NA_) : 0u, NB = HASN ? lds_addr(NB_) : 0u;
     const uint32_t lane4 = (uint32_t)lane << 2;
     const int k = kb + lane;
-    const bool track = NEED_O || TRACE || kb < 0;
+    // (SNAP callers only come with kb >= 0: the origin diagonal is then never needed and the branch on it leaves the step loop)
+    const bool track = NEED_O || TRACE || (!SNAP && kb < 0);
     // per-lane constants (bit units): the furthest A position diagonal k can hold -- a live lane sits there exactly when it has
     // reached the last row or column -- and the offsets of the two windows
     const int lim = m < n - k ? m : n - k;
