@@ -148,14 +148,14 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA_, const
     // extension of every lane from bit position i (negative = dead lane, left as it is: dead values only ever grow by 2 per
     // step from SP_NEG * 2 and stay far below 0); returns the new furthest position
     auto extend = [&](int i) -> int {
+        // every lane compares, dead lanes included (their addresses fall outside the LDS allocation: such reads return 0) and are
+        // masked afterwards; a live lane has 0 <= rem, and rem = 0 (parked on the last row / column) clamps its match to 0
         int rem = lim2 - i;
-        bool going = i >= 0 && rem > 0;
-        if (going) {
-            const int nmv = match16b<HASN>(LA, NA, i + a2, LB, NB, i + b2, rem);
-            i += nmv;
-            going = nmv == 32 && rem > 32;
-            rem -= nmv;
-        }
+        int nmv = match16b<HASN>(LA, NA, i + a2, LB, NB, i + b2, rem);
+        nmv = i >= 0 ? nmv : 0;
+        i += nmv;
+        bool going = nmv == 32 && rem > 32;
+        rem -= nmv;
         // lanes still matching after 16 bases finish cooperatively: all 64 lanes compare 1,024 bases per step.  Lane l takes
         // bases [16 l, 16 l + 16) of the stretch: the word index is (scalar word of the stretch start) + l and the alignbit shift is
         // scalar, so the per-lane work is two adds, the compare and the clamp.  Lanes past the end of the stretch clamp to 0 (their
