@@ -123,7 +123,12 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
     uint32_t* NA = HASN ? LA + a_words : nullptr;
     const int lane = threadIdx.x;
     // deeper passes only visit the reads an earlier (shallower) pass could not settle
-    const uint32_t r = read_list ? read_list[blockIdx.x / n_chunks] : blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
+    // workgroups are dealt to the 8 XCDs round-robin by index: index % 8 picks the chunk's residue class, so one XCD only ever sees
+    // 1/8 of the database positions and keeps those alleles in its own L2 (n_chunks is the padded count, a multiple of 8)
+    const uint32_t per_read = n_chunks >> 3, j = blockIdx.x >> 3;
+    const uint32_t slot = j / per_read, chunk = (j % per_read) * 8 + (blockIdx.x & 7);
+    const uint32_t r = read_list ? read_list[slot] : slot;
+    if (chunk * (uint32_t)K1_CHUNK >= n_alleles) return;
     // gene filter: a gene is searched when it has >= K1_MIN_VOTES and >= 1/10 of the read's best gene
     int vmax = 0;
     for (int g = 0; g < n_genes; ++g) { int v = votes_rg[(uint64_t)r * n_genes + g]; vmax = v > vmax ? v : vmax; }
@@ -843,7 +848,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     uint32_t n_open = R;
     for (int pass = 0; pass < n_pass && rc == SP_OK; ++pass) {
         const int pass_cap = d_bound ? pass_caps[pass] : SP_MAX_ED;
-        const uint32_t n_chunks = (NA + K1_CHUNK - 1) / K1_CHUNK;
+        const uint32_t n_chunks = (((NA + K1_CHUNK - 1) / K1_CHUNK) + 7) & ~7u;       // padded to the 8 XCDs (k1_cells_kernel)
         const uint32_t* d_list = pass == 0 ? nullptr : d_open_list;
         {
             ProfScope ps(ctx, pass == 0 ? "k1_cells" : "k1_cells_deep", (uint64_t)n_open * NA);
