@@ -242,7 +242,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "cells_per_launch": alg_cells, "avg_launch_ms": avg_ms,
                          "note": "integer-DP kernel bound by VALU issue (rocprofv3 SQ_ACTIVE_INST_VALU ~ 90 % of the issue slots, profiles/r01), DB served from "
                                  "L2/MALL.  'achieved' is the streaming model of SURVEY 8(d) over EVERY (read, allele) cell the launch settles; "
-                                 "exact prefix sharing settles ~2/3 of them without running them, so the figure can exceed the HBM peak -- "
+                                 "exact prefix sharing settles ~2/3 of them without running them and each XCD keeps its eighth of the database in L2, so the figure can exceed the HBM peak -- "
                                  "'traffic' is what actually crossed HBM"},
             "kernel_ms": kernel_ms,
             "concordance": {"k1_gene_correct": k1_gene_ok, "k1_realigned": k1_realigned, "k2_truth_calls": f"{k2_ok}/{len(calls)}"},
