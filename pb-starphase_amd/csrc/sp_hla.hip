@@ -14,10 +14,7 @@
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
 int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn);
 
-#ifndef K1_GROUPS
-#define K1_GROUPS      1        // groups of 64 visiting-order positions one k1_cells workgroup (= one wavefront) walks through
-#endif
-#define K1_CHUNK       (64 * K1_GROUPS)
+#define K1_CHUNK       64       // visiting-order positions of one k1_cells workgroup (= one wavefront; 128 and 256 per workgroup measured slower)
 #define K1_MIN_VOTES   16
 
 // the alleles by position of the K1 visiting order (structure of arrays, one coalesced load per field and group of 64 positions)
@@ -96,7 +93,7 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
 #define K1_PRE_WORDS 320 // words of an allele the register prefetch covers
 
 // DEEP only names the later (deeper, much smaller) passes of the iterative deepening differently, so that profilers list them apart
-// One wavefront = one workgroup = (read, K1_GROUPS x 64 consecutive positions of the visiting order).  Lane j of a group IS cell j:
+// One wavefront = one workgroup = (read, 64 consecutive positions of the visiting order).  Lane j IS cell j:
 // its metadata stays in that lane's registers, its result too, and whatever is per cell but not part of the DP -- the edit cap under
 // the current bound, the scan for the next cell that has to run -- is one vector operation over the group.  Nothing waits for another
 // wave (workgroups of 2, 4, 8 waves measured 13.3 / 15.5 / 19.9 ms against 12.6 ms: every wave idles until the slowest is done).
@@ -136,7 +133,7 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
     const int rlen = reads.len[r];
     const uint32_t* rw = reads.words + reads.word_off[r];
     const uint32_t* rn = reads.nplane ? reads.nplane + reads.word_off[r] : nullptr;
-    const uint32_t p_first = chunk * (uint32_t)(64 * K1_GROUPS);
+    const uint32_t p_first = chunk * (uint32_t)K1_CHUNK;
 
     // the cell of a position: active?  diagonal, static cap, packed words, prefix shared with the position before
     struct Cell { int act, alen, kb, cap, lcp; uint32_t woff; };
@@ -160,30 +157,16 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
         return c;
     };
 
-    // pass 1: union of the read windows of every cell of the workgroup, longest allele in use
-    int w_lo = 0x7FFFFFFF, w_hi = -1, longest = 0;
-#pragma unroll
-    for (int g = 0; g < K1_GROUPS; ++g) {
-        int j_min, j_max;
-        const Cell c = load_cell(p_first + g * 64 + lane, j_min, j_max);
-        w_lo = j_min < w_lo ? j_min : w_lo; w_hi = j_max > w_hi ? j_max : w_hi;
-        longest = c.act && c.alen > longest ? c.alen : longest;
-    }
+    // the 64 cells of the workgroup: metadata, union of their read windows, longest allele in use
+    const uint32_t p_mine = p_first + lane;
+    int w_lo, w_hi;
+    const Cell u = load_cell(p_mine, w_lo, w_hi);
+    int longest = u.act ? u.alen : 0;
     w_lo = -spw::wave_max(-w_lo); w_hi = spw::wave_max(w_hi); longest = spw::wave_max(longest);
     if (w_hi < 0) {                                       // nothing to run (the positions of another gene, mostly)
-#pragma unroll
-        for (int g = 0; g < K1_GROUPS; ++g) { const uint32_t p = p_first + g * 64 + lane; if (cell_out && p < n_alleles) cell_out[(uint64_t)r * n_alleles + p] = SP_CELL_NONE; }
+        if (cell_out && p_mine < n_alleles) cell_out[(uint64_t)r * n_alleles + p_mine] = SP_CELL_NONE;
         return;
     }
-    int b_base;
-    {
-        const int w0 = w_lo >> 4;
-        const int nw = ((w_hi + 15) >> 4) - w0 + 2;
-        for (int w = lane; w < nw; w += SP_WAVE) { LB[w] = rw[w0 + w]; if (HASN) NB[w] = rn ? rn[w0 + w] : 0u; }
-        b_base = w0 << 4;
-    }
-    if (read_maxlen && lane == 0) atomicMax(&read_maxlen[r], (uint32_t)longest);     // longest allele any cell of this read uses
-
     // Register prefetch of one allele, fixed shape: lane l takes words [4l, 4l+4) and word 256+l (sequences start 16-byte aligned
     // and the set is padded, SP_SEQ_PAD_WORDS), 320 words = 5,088 bases + guard; longer alleles are staged directly.  The
     // running bound of the read comes along: any value it ever had is a valid bound.
@@ -195,11 +178,19 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
         if (bound) pre_bound = __hip_atomic_load(&bound[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pre_for = idx;
     };
-
-    for (int g = 0; g < K1_GROUPS; ++g) {
-        const uint32_t p_mine = p_first + g * 64 + lane;
-        int jm0, jm1;
-        const Cell u = load_cell(p_mine, jm0, jm1);
+    {
+        const int g = 0;
+        const unsigned long long active0 = __ballot(u.act != 0);
+        // the first allele is on its way while the read window is staged
+        { const int j0 = __builtin_ctzll(active0); prefetch(j0, (uint32_t)__builtin_amdgcn_readlane((int)u.woff, j0)); }
+        int b_base;
+        {
+            const int w0 = w_lo >> 4;
+            const int nw = ((w_hi + 15) >> 4) - w0 + 2;
+            for (int w = lane; w < nw; w += SP_WAVE) { LB[w] = rw[w0 + w]; if (HASN) NB[w] = rn ? rn[w0 + w] : 0u; }
+            b_base = w0 << 4;
+        }
+        if (read_maxlen && lane == 0) atomicMax(&read_maxlen[r], (uint32_t)longest);     // longest allele any cell of this read uses
         const unsigned long long active = __ballot(u.act != 0);
         uint32_t res = SP_CELL_NONE;
         // lane j: is the cell right before it in the order active too?  (a chain or a saved state never crosses a gap or a group)
