@@ -100,22 +100,24 @@ __device__ __forceinline__ Decision decide(const ConsParams& P, const ConsCtrl& 
     for (int i = 0; i < 2; ++i) {
         if (i == 1 && !c.dual) continue;
         if (c.stopped[i]) continue;
-        long long w[4];
+        // (32-bit counters: a column holds at most 12 units per read; only the cross products below need 64 bits, and the scalar
+        // unit has no ordered 64-bit compare -- with wider types every comparison here becomes a vector instruction)
+        uint32_t w[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) w[b] = (long long)(uint32_t)__builtin_amdgcn_readlane((int)x[b], i * CSLOTS);
-        const long long end = (long long)(uint32_t)__builtin_amdgcn_readlane((int)x[4], i * CSLOTS);
-        const long long total = w[0] + w[1] + w[2] + w[3];
-        int b1 = 0; long long w1 = w[0];                                           // heaviest base, ties to the lower code
+        for (int b = 0; b < 4; ++b) w[b] = (uint32_t)__builtin_amdgcn_readlane((int)x[b], i * CSLOTS);
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)x[4], i * CSLOTS);
+        const uint32_t total = w[0] + w[1] + w[2] + w[3];
+        int b1 = 0; uint32_t w1 = w[0];                                            // heaviest base, ties to the lower code
 #pragma unroll
         for (int b = 1; b < 4; ++b) if (w[b] > w1) { b1 = b; w1 = w[b]; }
-        int b2 = -1; long long w2 = -1;                                            // heaviest of the others, ties to the lower code
+        int b2 = -1; uint32_t w2 = 0; bool have2 = false;                          // heaviest of the others, ties to the lower code
 #pragma unroll
-        for (int b = 0; b < 4; ++b) if (b != b1 && w[b] > w2) { b2 = b; w2 = w[b]; }
+        for (int b = 0; b < 4; ++b) if (b != b1 && (!have2 || w[b] > w2)) { b2 = b; w2 = w[b]; have2 = true; }
         const bool go = P.et ? w1 > 0 : (total > end && w1 > 0);
         if (!go) continue;
         d.go[i] = 1; d.base[i] = b1;
-        if (!c.dual && w2 >= 12ll * P.min_count) {
-            if (w2 * d.best_total > d.best_w2 * total) { d.best_w2 = w2; d.best_total = total; }
+        if (!c.dual && w2 >= 12u * (uint32_t)P.min_count) {
+            if ((unsigned long long)w2 * (unsigned long long)d.best_total > (unsigned long long)d.best_w2 * (unsigned long long)total) { d.best_w2 = w2; d.best_total = total; }
             if (P.allow_dual && (double)w2 >= P.min_af * (double)total) { d.split = 1; d.go[1] = 1; d.base[1] = b2; d.split_w2 = w2; d.split_total = total; }
         }
     }
