@@ -75,6 +75,9 @@ __device__ __forceinline__ int read_base(const ReadView& rv, int h) {
     return (int)((rv.w[h >> 4] >> sh) & 3u);
 }
 
+// 12 / d for d = 1..4 distinct tip bases without an integer division
+__device__ __forceinline__ uint32_t vote_units(int d) { return d == 1 ? 12u : d == 2 ? 6u : d == 3 ? 4u : 3u; }
+
 struct Decision { int go[2]; int base[2]; int split; long long best_w2, best_total, split_w2, split_total; };
 
 // Every wave re-derives the decision for position t.  Lanes 0-15 fetch the 2 x CSLOTS vote slots (one 128-byte line each) and the
@@ -320,7 +323,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
             if (lane == 0) {
                 if (dc) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) if (seen[b]) atomicAdd(&lv[i][b], 12u / dc);
+                    for (int b = 0; b < 4; ++b) if (seen[b]) atomicAdd(&lv[i][b], vote_units(dc));
                 }
                 else if (ended) atomicAdd(&lv[i][4], 12u);
             }
@@ -477,7 +480,7 @@ __global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatchT<M
             uint32_t* v = P.votes + (((size_t)i * (P.cap + 1) + len) * CSLOTS + (blockIdx.x & (CSLOTS - 1))) * CSTRIDE;
             if (dc) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) if (seen[b]) atomicAdd(v + b, 12u / dc);
+                for (int b = 0; b < 4; ++b) if (seen[b]) atomicAdd(v + b, vote_units(dc));
             } else if (ended) atomicAdd(v + 4, 12u);
         }
     }
