@@ -268,6 +268,9 @@ int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     return SP_OK;
 }
 
+#ifndef SP_TRACE_BLOCKS_PER_CU
+#define SP_TRACE_BLOCKS_PER_CU 16     // traced cells: every wave owns 32 KB of wavefront history in the scratch pool (512 MB at 16 workgroups per CU; 4: 0.93 ms, 8: 0.87 ms, 16: 0.74 ms for the two K2 levels of the bench step)
+#endif
 int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     const CellDesc* d_cells, uint64_t n_cells,
                     sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name) {
@@ -278,7 +281,7 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     const size_t lds_bytes = (size_t)slot_words * 4 * 4 + SP_LDS_TAIL;
     if (lds_bytes > 160 * 1024 - 64) return sp_fail(ctx, SP_ERR_TOO_LONG, "align: sequences too long for the LDS window");
     uint64_t blocks = (n_cells + 3) / 4;
-    const uint64_t max_blocks = trace ? 1024 : (uint64_t)ctx->num_cus * 16;
+    const uint64_t max_blocks = trace ? (uint64_t)ctx->num_cus * SP_TRACE_BLOCKS_PER_CU : (uint64_t)ctx->num_cus * 16;
     if (blocks > max_blocks) blocks = max_blocks;
     const int hist_rows = SP_MAX_ED + 1;
     uint16_t* hist = nullptr;
