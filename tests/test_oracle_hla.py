@@ -101,6 +101,20 @@ def test_is_better_match_rules(oracle):
     assert _better(oracle, d, e) == ((3 + 0) / 10 < (0 + 4) / 10)
 
 
+def test_score_min(oracle):
+    """test_score_min (src/hla/mapping.rs:220-229): HlaMappingScore orders by (cDNA score, DNA score).  The levels do not overlap, so
+    is_better_match falls through to the score comparison (processed_match.rs:127-131, 180-183).  The three constructor panics of the
+    same file (:193-217: a level with some but not all of its fields) have no counterpart: a flattened level is present or absent."""
+    pc = [0] * 11
+    def score(c, d, lo):                      # (nm + unmapped) / len on each level; lo picks a disjoint range
+        return [_level(1, lo, lo + 5, 10, int(round(c * 10)), 0, pc), _level(1, lo, lo + 5, 10, int(round(d * 10)), 0, pc)]
+    s1, s2, s3 = score(1.0, 0.5, 0), score(0.9, 1.0, 5), score(1.0, 0.2, 5)
+    assert _better(oracle, s2, s1) and not _better(oracle, s1, s2)              # s1.min(s2) == s2
+    assert _better(oracle, s3, s1) and not _better(oracle, s1, s3)              # s1.min(s3) == s3
+    s2b = score(0.9, 1.0, 0)
+    assert _better(oracle, s2b, s3) and not _better(oracle, s3, s2b)            # s2.min(s3) == s2
+
+
 def test_is_passing_dual(oracle):
     """src/hla/caller.rs:1837-1845 test_is_passing_dual (min_cdf 0.001, min fraction 0.10, expected maf 0.5)"""
     f = lambda c1, c2: bool(oracle.L.osp_is_passing_dual(c1, c2, 0.10, 0.5, 0.001, None, None))
