@@ -209,32 +209,35 @@ int sp_seqset_make_small(sp_ctx* ctx, const char* prefix, const char* bases, con
     }
     s.h_words = words;
     if (s.has_n) s.h_words.insert(s.h_words.end(), nplane.begin(), nplane.end());
-    const std::string px(prefix);
-    auto pool = [&](const char* what, size_t bytes) { return sp_pool(ctx, (px + what).c_str(), std::max<size_t>(bytes, 16)); };
-    s.d_words = (uint32_t*)pool("_w", plane_words * 4);
-    s.d_nplane = s.has_n ? (uint32_t*)pool("_n", plane_words * 4) : nullptr;
-    s.d_word_off = (uint64_t*)pool("_o", ((size_t)n + 1) * 8);
-    s.d_len = (int32_t*)pool("_l", std::max<size_t>(1, n) * 4);
-    if (!s.d_words || !s.d_word_off || !s.d_len || (s.has_n && !s.d_nplane)) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "small seqset");
-    hipMemcpyAsync(s.d_words, words.data(), plane_words * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (s.has_n) hipMemcpyAsync(s.d_nplane, nplane.data(), plane_words * 4, hipMemcpyHostToDevice, ctx->stream);
-    hipMemcpyAsync(s.d_word_off, s.h_word_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (n) hipMemcpyAsync(s.d_len, s.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    // every array of the set goes into ONE device buffer through ONE pinned staging buffer: a single DMA instead of seven pageable
+    // copies (each of those waits for the runtime's bounce buffer: ~0.1 ms per set, as much as the typing launches they feed)
     std::vector<uint64_t> koff; std::vector<uint32_t> kcode; std::vector<int32_t> kpos;
+    if (with_index) kmer_tables(&s, koff, kcode, kpos);
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t b_words = plane_words * 4, b_npl = s.has_n ? plane_words * 4 : 0, b_off = ((size_t)n + 1) * 8, b_len = std::max<size_t>(1, n) * 4;
+    const size_t b_kc = with_index ? std::max<size_t>(1, kcode.size()) * 4 : 0, b_kp = with_index ? std::max<size_t>(1, kpos.size()) * 4 : 0;
+    const size_t b_ko = with_index ? koff.size() * 8 : 0;
+    const size_t o_words = 0, o_npl = o_words + up16(b_words), o_off = o_npl + up16(b_npl), o_len = o_off + up16(b_off);
+    const size_t o_kc = o_len + up16(b_len), o_kp = o_kc + up16(b_kc), o_ko = o_kp + up16(b_kp), total = o_ko + up16(b_ko);
+    const std::string px(prefix);
+    char* dev = (char*)sp_pool(ctx, (px + "_all").c_str(), total);
+    char* stage = (char*)sp_host_pool(ctx, (px + "_stage").c_str(), total);
+    if (!dev || !stage) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "small seqset");
+    std::memcpy(stage + o_words, words.data(), b_words);
+    if (s.has_n) std::memcpy(stage + o_npl, nplane.data(), b_npl);
+    std::memcpy(stage + o_off, s.h_word_off.data(), b_off);
+    if (n) std::memcpy(stage + o_len, s.h_len.data(), (size_t)n * 4);
     if (with_index) {
-        kmer_tables(&s, koff, kcode, kpos);
-        s.d_kcode = (uint32_t*)pool("_kc", std::max<size_t>(1, kcode.size()) * 4);
-        s.d_kpos = (int32_t*)pool("_kp", std::max<size_t>(1, kpos.size()) * 4);
-        s.d_koff = (uint64_t*)pool("_ko", koff.size() * 8);
-        if (!s.d_kcode || !s.d_kpos || !s.d_koff) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "small seqset index");
-        if (!kcode.empty()) {
-            hipMemcpyAsync(s.d_kcode, kcode.data(), kcode.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-            hipMemcpyAsync(s.d_kpos, kpos.data(), kpos.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-        }
-        hipMemcpyAsync(s.d_koff, koff.data(), koff.size() * 8, hipMemcpyHostToDevice, ctx->stream);
-        s.has_index = true;
+        if (!kcode.empty()) { std::memcpy(stage + o_kc, kcode.data(), kcode.size() * 4); std::memcpy(stage + o_kp, kpos.data(), kpos.size() * 4); }
+        std::memcpy(stage + o_ko, koff.data(), b_ko);
     }
-    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // the host vectors above go out of scope
+    s.d_words = (uint32_t*)(dev + o_words);
+    s.d_nplane = s.has_n ? (uint32_t*)(dev + o_npl) : nullptr;
+    s.d_word_off = (uint64_t*)(dev + o_off);
+    s.d_len = (int32_t*)(dev + o_len);
+    if (with_index) { s.d_kcode = (uint32_t*)(dev + o_kc); s.d_kpos = (int32_t*)(dev + o_kp); s.d_koff = (uint64_t*)(dev + o_ko); s.has_index = true; }
+    hipMemcpyAsync(dev, stage, total, hipMemcpyHostToDevice, ctx->stream);
+    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // the staging buffer is reused by the next set with this prefix
     return SP_OK;
 }
 
