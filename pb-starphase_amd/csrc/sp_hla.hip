@@ -936,22 +936,23 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
     int rc = sp_seqset_make_small(ctx, "k2_cons", blob.data(), coff.data(), 2 * n_items, true, cons);
     if (rc != SP_OK) return rc;
     const uint32_t stride = SP_MAX_ED;
-    uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "k2_idx", (size_t)T * 4);
-    uint32_t* d_c0 = (uint32_t*)sp_pool(ctx, "k2_l0", (size_t)T * 4); uint32_t* d_c1 = (uint32_t*)sp_pool(ctx, "k2_l1", (size_t)T * 4);
-    uint32_t* d_seg = (uint32_t*)sp_pool(ctx, "k2_seg", (size_t)(n_items + 1) * 4);
+    // the four index arrays travel as one block through pinned memory (one DMA instead of four pageable copies)
+    const size_t in_words = (size_t)3 * T + n_items + 1;
+    uint32_t* d_in = (uint32_t*)sp_pool(ctx, "k2_in", in_words * 4);
+    uint32_t* h_in = (uint32_t*)sp_host_pool(ctx, "k2_in_stage", in_words * 4);
+    uint32_t* d_idx = d_in; uint32_t* d_c0 = d_in ? d_in + T : nullptr; uint32_t* d_c1 = d_in ? d_in + 2 * (size_t)T : nullptr;
+    uint32_t* d_seg = d_in ? d_in + 3 * (size_t)T : nullptr;
     int32_t* d_diag = (int32_t*)sp_pool(ctx, "k2_diag", (size_t)T * 4); int32_t* d_votes = (int32_t*)sp_pool(ctx, "k2_votes", (size_t)T * 4);
     int32_t* d_best = (int32_t*)sp_pool(ctx, "k2_best", (size_t)n_items * 4);
     CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k2_cells", (size_t)T * sizeof(CellDesc));
     sp_aln* d_alns = (sp_aln*)sp_pool(ctx, "k2_alns", (size_t)2 * T * sizeof(sp_aln));
     uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "k2_ev", (size_t)2 * T * stride * 4);
     K2Level* d_lv = (K2Level*)sp_pool(ctx, "k2_lv", (size_t)2 * T * sizeof(K2Level));
-    if (!d_idx || !d_c0 || !d_c1 || !d_seg || !d_diag || !d_votes || !d_best || !d_cells || !d_alns || !d_ev || !d_lv)
+    if (!d_in || !h_in || !d_diag || !d_votes || !d_best || !d_cells || !d_alns || !d_ev || !d_lv)
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus buffers");
-    (void)hipMemcpyAsync(d_idx, h_idx.data(), (size_t)T * 4, hipMemcpyHostToDevice, ctx->stream);
-    (void)hipMemcpyAsync(d_c0, h_c0.data(), (size_t)T * 4, hipMemcpyHostToDevice, ctx->stream);
-    (void)hipMemcpyAsync(d_c1, h_c1.data(), (size_t)T * 4, hipMemcpyHostToDevice, ctx->stream);
-    (void)hipMemcpyAsync(d_seg, seg_off.data(), (size_t)(n_items + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream);
+    std::memcpy(h_in, h_idx.data(), (size_t)T * 4); std::memcpy(h_in + T, h_c0.data(), (size_t)T * 4);
+    std::memcpy(h_in + 2 * (size_t)T, h_c1.data(), (size_t)T * 4); std::memcpy(h_in + 3 * (size_t)T, seg_off.data(), (size_t)(n_items + 1) * 4);
+    (void)hipMemcpyAsync(d_in, h_in, in_words * 4, hipMemcpyHostToDevice, ctx->stream);      // (h_in is reused by the next call: the results' sync below covers it)
     const unsigned tb = 256, nb = (T + tb - 1) / tb;
     for (int L = 0; L < 2 && rc == SP_OK; ++L) {
         const sp_seqset* aset = L == 0 ? db->cdna_gene : db->dna_gene;
