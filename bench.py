@@ -103,8 +103,8 @@ def cpu_baseline(fx, wl, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
