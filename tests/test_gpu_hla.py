@@ -117,6 +117,58 @@ def test_k1_reads_with_n(oracle, pkg, gpu_ctx, small):
     assert db.realign_reads(rs).tobytes() == out.tobytes()
 
 
+class _SyntheticGene:
+    """a one-gene database of long alleles in the shape HlaFixture hands to the library and to hla_expected"""
+    def __init__(self, rng, synth, ref_len=7600, n_alleles=40):
+        self.genes, self.buffer = ["SYN-1"], 100
+        ref = "".join(rng.choice(list("ACGT"), ref_len))
+        self.gene_ref, self.gene_fwd = [ref], [1]
+        core = ref[300:ref_len - 300]                                 # 7,000 bases: beyond the 5,088 the register prefetch covers
+        self.exons = [[(400, 700), (1500, 1800), (3000, 3300)]]
+        self.dna, self.cdna, self.ids = [], [], []
+        base_variants = [core]
+        for k in range(n_alleles - 1):
+            parent = base_variants[int(rng.integers(0, len(base_variants)))]
+            child = synth.mutate(rng, parent, int(rng.integers(1, 5)), int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+            base_variants.append(child)
+        for k, seq in enumerate(base_variants):
+            if k % 9 == 4:
+                seq = seq[:int(rng.integers(2500, 4800))]            # a few partial alleles: mixed fast / direct staging in one group
+            self.ids.append(f"SYN{k:04d}")
+            self.dna.append(seq)
+            self.cdna.append(seq[100:400] + seq[1200:1500])
+        self.gene_of = np.zeros(len(self.ids), np.uint32)
+
+    def dna_fwd(self, a):
+        return self.dna[a]
+
+
+def test_k1_long_alleles(oracle, pkg, gpu_ctx):
+    """alleles longer than the fixed-shape register prefetch (5,088 bases) go through the direct staging path of k1_cells and
+    through cooperative extensions of several thousand bases"""
+    from pb_starphase_amd import synth
+    rng = np.random.default_rng(31)
+    fx = _SyntheticGene(rng, synth)
+    db = pkg.HlaDb(gpu_ctx, fx.gene_of, fx.dna, fx.cdna, fx.gene_ref, fx.gene_fwd, fx.exons, fx.buffer)
+    reads = []
+    for a in (0, 7, 13, 22, 31):
+        hap = fx.gene_ref[0][:300] + fx.dna[a] + fx.gene_ref[0][300 + len(fx.dna[a]):] if len(fx.dna[a]) > 6000 else fx.gene_ref[0]
+        reads.append(synth.hifi_errors(rng, hap))
+        reads.append(synth.hifi_errors(rng, hap[150:-200]))
+    reads.append(synth.mutate(rng, reads[0], 30, 12, 12))
+    rs = gpu_ctx.upload(reads)
+    out, cells = db.realign_reads(rs, cells=True)
+    exp, ecells = hx.k1_expected(oracle, fx, reads)
+    assert (cells == ecells).all(), np.argwhere(cells != ecells)[:10]
+    for r, e in enumerate(exp):
+        assert out[r]["status"] == e["status"] and out[r]["best_allele"] == e["best_allele"], (r, out[r], e)
+        if e["best_allele"] >= 0:
+            assert (out[r]["nm"], out[r]["target_len"], out[r]["unmapped"]) == (e["nm"], e["target_len"], e["unmapped"])
+    assert (out["status"] == 0).sum() >= len(reads) - 2
+    assert db.realign_reads(rs).tobytes() == out.tobytes()
+    db.close()
+
+
 def test_type_consensus(oracle, pkg, gpu_ctx, small):
     """sp_hla_type_consensus = score_consensus + splice_read (src/hla/caller.rs:1258-1319,1518-1576): the hg38-forward
     consensus goes in, the library places it on the gene reference, splices the cDNA and types it."""
