@@ -147,6 +147,9 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA_, const
 
     // extension of every lane from bit position i (negative = dead lane, left as it is: dead values only ever grow by 2 per
     // step from SP_NEG * 2 and stay far below 0); returns the new furthest position
+    // the kept cooperative scan (see extend): diagonal (lane), bit position of its block 0, blocks that hold a stop, stop offsets
+    int scan_src = -1, scan_base = 0, scan_fm = 0;
+    uint64_t scan_stop = 0;
     auto extend = [&](int i) -> int {
         // every lane compares, dead lanes included (their addresses fall outside the LDS allocation: such reads return 0) and are
         // masked afterwards; a live lane has 0 <= rem, and rem = 0 (parked on the last row / column) clamps its match to 0
@@ -156,43 +159,59 @@ __device__ __forceinline__ void wfa_core(const uint32_t* __restrict__ LA_, const
         i += nmv;
         bool going = nmv == 32 && rem > 32;
         rem -= nmv;
-        // lanes still matching after 16 bases finish cooperatively: all 64 lanes compare 1,024 bases per step.  Lane l takes
-        // bases [16 l, 16 l + 16) of the stretch: the word index is (scalar word of the stretch start) + l and the alignbit shift is
-        // scalar, so the per-lane work is two adds, the compare and the clamp.  Lanes past the end of the stretch clamp to 0 (their
-        // loads may touch words behind the staged window: still inside this workgroup's LDS, values unused).
+        // lanes still matching after 16 bases finish cooperatively: all 64 lanes compare 1,024 bases per step.  The stretch is cut
+        // into blocks of 16 bases aligned in A (the block the stretch starts in was compared up to the start a moment ago: nothing
+        // to mask); lane l takes block l: the word index is (scalar word of block 0) + l and the alignbit shift is scalar, so the
+        // per-lane work is two adds, the compare and the clamp.  Lanes past the end of the stretch clamp to 0 (their loads may touch
+        // words behind the staged window: still inside this workgroup's LDS, values unused).
+        // One scan tells where EVERY block of those 1,024 bases first differs.  It is kept (diagonal, first block, stop mask, offsets
+        // per lane), and the next long stretch on that diagonal -- after a substitution the alignment stays on it -- is answered
+        // from the kept scan: furthest-reaching points only grow, and whatever lies between a block's start and the new stretch
+        // start has just been compared equal, so the kept first stop of a block is its first stop at or behind the new start.
         uint64_t longmask = __ballot(going);
         while (longmask) {
             const int src = __builtin_ctzll(longmask);
             longmask &= longmask - 1;
             SP_STAT(5, 1);
-            int ci = __builtin_amdgcn_readlane(i, src);
-            int crem = __builtin_amdgcn_readlane(rem, src);
-            const int cb2 = (kb + src + b_sh) << 1;
-            for (;;) {
-                SP_STAT(6, 1);
-                const int pa = ci + a2, pb = ci + cb2;                       // scalar bit positions of the stretch in the two windows
-                const uint32_t oa = (uint32_t)((pa >> 5) << 2), ob = (uint32_t)((pb >> 5) << 2);      // scalar
-                lds_cu32* wa = (lds_cu32*)(uintptr_t)((LA + oa) + lane4);
-                lds_cu32* wb = (lds_cu32*)(uintptr_t)((LB + ob) + lane4);
-                const uint32_t x = __builtin_amdgcn_alignbit(wa[1], wa[0], (uint32_t)pa) ^ __builtin_amdgcn_alignbit(wb[1], wb[0], (uint32_t)pb);
-                uint32_t mm = (x | (x >> 1)) & 0x55555555u;
-                if (HASN) {
-                    lds_cu32* na = (lds_cu32*)(uintptr_t)((NA + oa) + lane4); lds_cu32* nb = (lds_cu32*)(uintptr_t)((NB + ob) + lane4);
-                    mm |= __builtin_amdgcn_alignbit(na[1], na[0], (uint32_t)pa) | __builtin_amdgcn_alignbit(nb[1], nb[0], (uint32_t)pb);
-                }
-                int r = crem - (lane << 5); r = r > 0 ? r : 0;
-                const uint32_t f = ffbl_raw(mm);
-                const uint32_t c = f < 32u ? f : 32u;
-                const int nmv = (int)(c < (uint32_t)r ? c : (uint32_t)r);
-                const uint64_t stop = __ballot(nmv < 32);
-                if (stop) {
-                    const int t = __builtin_ctzll(stop);
-                    ci += (t << 5) + __builtin_amdgcn_readlane(nmv, t);
-                    break;
-                }
-                ci += SP_WAVE * 32; crem -= SP_WAVE * 32;
+            const int ci = __builtin_amdgcn_readlane(i, src);
+            const int crem = __builtin_amdgcn_readlane(rem, src);
+            int stop_at = -1;
+            if (src == scan_src && (unsigned)(ci - scan_base) < (unsigned)(SP_WAVE * 32)) {
+                const int blk = (ci - scan_base) >> 5;
+                const uint64_t later = scan_stop >> blk;
+                if (later) { const int t = blk + __builtin_ctzll(later); stop_at = scan_base + (t << 5) + __builtin_amdgcn_readlane(scan_fm, t); SP_STAT(13, 1); }
             }
-            if (lane == src) i = ci;
+            if (stop_at < 0) {
+                const int cb2 = (kb + src + b_sh) << 1;
+                int ca = ci & ~31;
+                int left = crem + (ci - ca);                                 // bits from block 0 to the end of the diagonal's range
+                for (;;) {
+                    SP_STAT(6, 1);
+                    const int pa = ca + a2, pb = ca + cb2;                   // scalar bit positions of block 0 in the two windows
+                    const uint32_t oa = (uint32_t)((pa >> 5) << 2), ob = (uint32_t)((pb >> 5) << 2);      // scalar
+                    lds_cu32* wa = (lds_cu32*)(uintptr_t)((LA + oa) + lane4);
+                    lds_cu32* wb = (lds_cu32*)(uintptr_t)((LB + ob) + lane4);
+                    const uint32_t x = __builtin_amdgcn_alignbit(wa[1], wa[0], (uint32_t)pa) ^ __builtin_amdgcn_alignbit(wb[1], wb[0], (uint32_t)pb);
+                    uint32_t mm = (x | (x >> 1)) & 0x55555555u;
+                    if (HASN) {
+                        lds_cu32* na = (lds_cu32*)(uintptr_t)((NA + oa) + lane4); lds_cu32* nb = (lds_cu32*)(uintptr_t)((NB + ob) + lane4);
+                        mm |= __builtin_amdgcn_alignbit(na[1], na[0], (uint32_t)pa) | __builtin_amdgcn_alignbit(nb[1], nb[0], (uint32_t)pb);
+                    }
+                    int r = left - (lane << 5); r = r > 0 ? r : 0;
+                    const uint32_t f = ffbl_raw(mm);
+                    const uint32_t c = f < 32u ? f : 32u;
+                    const int fm = (int)(c < (uint32_t)r ? c : (uint32_t)r);
+                    const uint64_t stop = __ballot(fm < 32);
+                    if (stop) {
+                        const int t = __builtin_ctzll(stop);
+                        stop_at = ca + (t << 5) + __builtin_amdgcn_readlane(fm, t);
+                        scan_src = src; scan_base = ca; scan_stop = stop; scan_fm = fm;
+                        break;
+                    }
+                    ca += SP_WAVE * 32; left -= SP_WAVE * 32;
+                }
+            }
+            if (lane == src) i = stop_at;
         }
         return i;
     };

@@ -25,5 +25,5 @@ st = np.zeros(64, np.uint64)
 L.sp_debug_wfa_stats(st.ctypes.data, 0)
 st = [int(x) for x in st]
 out = {"executed": st[0], "skipped": st[1], "finished": st[2], "steps": st[3], "steps_in_finished": st[4], "long_lanes": st[5],
-       "long_iterations": st[6], "cap_sum": st[7], "resumed": st[8], "rounds_saved": st[9], "after_chain": st[10], "no_state": st[11], "state_past_cap": st[12], "failed_by_steps": st[16:32], "finished_by_steps": st[32:48], "executed_by_cap": st[48:64]}
+       "long_iterations": st[6], "cap_sum": st[7], "resumed": st[8], "rounds_saved": st[9], "long_stretches_from_kept_scan": st[13], "after_chain": st[10], "no_state": st[11], "state_past_cap": st[12], "failed_by_steps": st[16:32], "finished_by_steps": st[32:48], "executed_by_cap": st[48:64]}
 print(json.dumps(out))
