@@ -152,7 +152,7 @@ def main():
             for g in range(len(fx.genes)):
                 pair = [b for (gg, _c, _d, _a), b in zip(wl.consensus, calls) if gg == g]
                 rec[g] = (rank, g, pair[0], pair[1] if len(pair) > 1 else pair[0])
-            shard.gather_calls(rec, device="cuda" if backend == "nccl" else "cpu")
+            shard.gather_calls(rec, device="cuda" if backend == "nccl" else "cpu", same_count=True)
         return out, calls
 
     def barrier():

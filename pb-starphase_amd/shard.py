@@ -23,9 +23,11 @@ def partition(n_units, world, rank, cost=None):
     return [u for u in range(n_units) if owner[u] == rank]
 
 
-def gather_calls(calls, device=None):
+def gather_calls(calls, device=None, same_count=False):
     """All ranks contribute their call records; every rank receives the full, sample/gene-sorted table.
-    Records are fixed size, so one all_gather of the counts and one of a padded int32 tensor suffice."""
+    Records are fixed size, so one all_gather of the counts and one of a padded int32 tensor suffice; with same_count (every
+    rank holds the same number of records, e.g. one sample with G genes each) the counts are not exchanged: one collective,
+    no host round trip for the sizes."""
     import torch
     import torch.distributed as dist
     calls = np.ascontiguousarray(calls, CALL_DTYPE)
@@ -33,9 +35,12 @@ def gather_calls(calls, device=None):
         return np.sort(calls, order=["sample", "gene"])
     world = dist.get_world_size()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    n = torch.tensor([len(calls)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
+    if same_count:
+        counts = [torch.tensor([len(calls)], dtype=torch.int64) for _ in range(world)]
+    else:
+        n = torch.tensor([len(calls)], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts, n)
     nmax = int(max(int(c.item()) for c in counts))
     flat = np.zeros((nmax, 4), np.int32)
     if len(calls):

@@ -26,6 +26,12 @@ for i, s in enumerate(mine):
     for g in range(genes):
         calls[i * genes + g] = (s, g, 100 * s + g, 100 * s + g + 1)      # stand-in for the per-gene GPU calls
 table = shard.gather_calls(calls)
+# equal record counts on every rank: the variant without the count exchange gives the same table
+even = np.zeros(genes, shard.CALL_DTYPE)
+for g in range(genes):
+    even[g] = (rank, g, 7 * rank + g, 7 * rank + g + 1)
+t1, t2 = shard.gather_calls(even), shard.gather_calls(even, same_count=True)
+assert t1.tolist() == t2.tolist() and len(t2) == world * genes
 print(json.dumps({"rank": rank, "mine": mine, "table": table.tolist()}))
 dist.destroy_process_group()
 '''
