@@ -93,3 +93,56 @@ def test_align_real_alleles(oracle, pkg, gpu_ctx):
     ai = np.repeat(np.arange(len(C)), 4).astype(np.uint32)
     bi = ((ai * 7 + np.tile(np.arange(4), len(C))) % len(C)).astype(np.uint32)
     compare(oracle, gpu_ctx, C, C, ai, bi)
+
+
+def _edit(rng, seq, n_sub, n_ins, n_del):
+    """edits anywhere, adjacent ones included (synth.mutate keeps them apart)"""
+    s = list(seq)
+    for _ in range(n_sub):
+        if s:
+            p = int(rng.integers(0, len(s))); s[p] = "ACGT"[("ACGT".index(s[p]) + 1 + int(rng.integers(3))) % 4]
+    for _ in range(n_ins):
+        p = int(rng.integers(0, len(s) + 1))
+        s[p:p] = list(rand_seq(rng, int(rng.integers(1, 4))))
+    for _ in range(n_del):
+        if len(s) > 8:
+            p = int(rng.integers(0, len(s) - 3)); del s[p:p + int(rng.integers(1, 4))]
+    return "".join(s)
+
+
+def test_align_fuzz(oracle, pkg, gpu_ctx):
+    """seeded random pairs of every shape the core has a special path for: long clean stretches (cooperative scans and the kept
+    scan), substitution runs on one diagonal, indel-heavy paths, diagonals that leave the rectangle, tight and exhausted caps"""
+    import os
+    for seed in [int(x) for x in os.environ.get("SP_FUZZ_SEEDS", "20261003").split(",")]:       # (a list of seeds for a longer hunt)
+        _fuzz_once(oracle, gpu_ctx, seed)
+
+
+def _fuzz_once(oracle, gpu_ctx, seed):
+    rng = np.random.default_rng(seed)
+    A, B = [], []
+    for _ in range(260):
+        ln = int(rng.choice([24, 60, 180, 700, 1500, 3300, 5200, 8800]))
+        a = rand_seq(rng, ln)
+        kind = int(rng.integers(0, 5))
+        if kind == 0:      # substitutions only: the alignment stays on one diagonal
+            core = _edit(rng, a, int(rng.integers(0, 31)), 0, 0)
+        elif kind == 1:    # indel heavy
+            core = _edit(rng, a, int(rng.integers(0, 5)), int(rng.integers(0, 13)), int(rng.integers(0, 13)))
+        elif kind == 2:    # a long repeat inside: many diagonals match for a while
+            unit = rand_seq(rng, int(rng.integers(2, 40)))
+            core = a[:ln // 3] + unit * int(rng.integers(3, 30)) + a[ln // 3:]
+            a = a[:ln // 3] + unit * int(rng.integers(3, 30)) + a[ln // 3:]
+        elif kind == 3:    # partial overlap
+            cut = int(rng.integers(0, max(1, ln // 2)))
+            core = _edit(rng, a[cut:], int(rng.integers(0, 7)), int(rng.integers(0, 4)), int(rng.integers(0, 4)))
+        else:              # unrelated tail
+            core = _edit(rng, a[:ln * 2 // 3], 2, 1, 1) + rand_seq(rng, ln // 3)
+        fl, fr = int(rng.integers(0, 200)), int(rng.integers(0, 200))
+        A.append(a)
+        B.append(rand_seq(rng, fl) + core + rand_seq(rng, fr))
+    idx = np.arange(len(A), dtype=np.uint32)
+    n_ok = compare(oracle, gpu_ctx, A, B, idx, idx)
+    assert n_ok > len(A) // 2
+    for shift, cap in ((-31, 255), (13, 40), (0, 6), (29, 1)):
+        compare(oracle, gpu_ctx, A, B, idx, idx, max_ed=cap, shift=shift)
