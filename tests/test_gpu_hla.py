@@ -169,6 +169,37 @@ def test_k1_long_alleles(oracle, pkg, gpu_ctx):
     db.close()
 
 
+def test_k1_synthetic_fuzz(oracle, pkg, gpu_ctx):
+    """random one-gene databases whose alleles descend from each other (rich shared-prefix structure: chains, snapshots, resumes),
+    clean / noisy / partial reads; the whole cell matrix and every output field against the oracle.  SP_FUZZ_SEEDS widens the hunt."""
+    import os
+    from pb_starphase_amd import synth
+    for seed in [int(x) for x in os.environ.get("SP_FUZZ_SEEDS", "5,6").split(",")]:
+        rng = np.random.default_rng(1000 + seed)
+        ref_len = int(rng.choice([1400, 2600, 4200]))
+        fx = _SyntheticGene(rng, synth, ref_len=ref_len, n_alleles=int(rng.integers(70, 200)))
+        db = pkg.HlaDb(gpu_ctx, fx.gene_of, fx.dna, fx.cdna, fx.gene_ref, fx.gene_fwd, fx.exons, fx.buffer)
+        reads = []
+        for a in rng.choice(len(fx.ids), 6, replace=False).tolist():
+            full = len(fx.dna[a]) > ref_len - 700
+            hap = fx.gene_ref[0][:300] + fx.dna[a] + fx.gene_ref[0][300 + len(fx.dna[a]):] if full else fx.gene_ref[0]
+            reads.append(synth.hifi_errors(rng, hap))
+            reads.append(hap)                                          # error free: bound 0, every other allele cut at once
+            cut = int(rng.integers(100, 500))
+            reads.append(synth.hifi_errors(rng, hap[cut:]))
+        reads.append(synth.mutate(rng, reads[0], 14, 5, 5))
+        rs = gpu_ctx.upload(reads)
+        out, cells = db.realign_reads(rs, cells=True)
+        exp, ecells = hx.k1_expected(oracle, fx, reads)
+        assert (cells == ecells).all(), (seed, np.argwhere(cells != ecells)[:10])
+        for r, e in enumerate(exp):
+            assert out[r]["status"] == e["status"] and out[r]["best_allele"] == e["best_allele"], (seed, r, out[r], e)
+            if e["best_allele"] >= 0:
+                assert (out[r]["nm"], out[r]["target_len"], out[r]["unmapped"]) == (e["nm"], e["target_len"], e["unmapped"])
+        assert db.realign_reads(rs).tobytes() == out.tobytes(), seed
+        db.close()
+
+
 def test_type_consensus(oracle, pkg, gpu_ctx, small):
     """sp_hla_type_consensus = score_consensus + splice_read (src/hla/caller.rs:1258-1319,1518-1576): the hg38-forward
     consensus goes in, the library places it on the gene reference, splices the cDNA and types it."""
