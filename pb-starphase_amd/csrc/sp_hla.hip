@@ -817,7 +817,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     // finalize: private per-wave windows of (allele, read) and (reference, read segment)
     int slot_words = std::max(sp_slot_words(db->dna_fwd, reads, hasn), sp_slot_words(db->ref_fwd, reads, hasn));
     const size_t lds_bytes = (size_t)slot_words * 16 + SP_LDS_TAIL;
-    // cells: one shared read window + four allele slots
+    // cells: the read window and one allele slot of the single wavefront of a workgroup
     // (both multiples of 4 words: the allele slots take 16-byte LDS stores; a slot always holds a whole register prefetch)
     const int b_words = (((reads->max_len + 15) / 16 + 4) + 3) & ~3;
     const int a_words = std::max(K1_PRE_WORDS, (((db->dna_fwd->max_len + 15) / 16 + 4) + 3) & ~3);
