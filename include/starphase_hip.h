@@ -351,6 +351,63 @@ typedef struct {
 int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* problem, const sp_seqset* reads, sp_cyp_call* call,
                          char* consensus /* optional: SP_CYP_MAXCONS * cons_cap bytes */, uint32_t cons_cap);
 
+/* ------------------------------------------------------------------ CYP2D6 templates and typing tables
+ * Replaces generate_cyp_hybrids (src/cyp2d6/definitions.rs:346-464), LoadedVariants::load_variant_database
+ * (src/cyp2d6/haplotyper.rs:650-773) and the table building of Cyp2d6Extractor::new (src/cyp2d6/haplotyper.rs:45-132).
+ *   sp_cyp_locus     Cyp2d6Config::{cyp_coordinates, cyp_regions, cyp2d6_star5_del} (definitions.rs:17-30) as 0-based half-open
+ *                    chromosome coordinates, plus the chromosome bases of a window that contains all of them (the reference reads
+ *                    them with ReferenceGenome::get_slice); exon arrays hold exon1..exon9 of CYP2D6 / CYP2D7
+ *   sp_cyp_gene_def  PgxDatabase::cyp2d6_gene_def (src/database/pgx_database.rs:41; AlleleDefinition / VariantDefinition,
+ *                    src/data_types/alleles.rs:7-81) flattened in key (BTreeMap) order: allele a owns variants
+ *                    [var_off[a], var_off[a+1]); var_id[x] == NULL means Option::None (the label becomes variant_string()),
+ *                    var_vi[x] == NULL means no "VI" entry in extras
+ *   sp_cyp_config    Cyp2d6Config::{cyp_translate, inferred_connections, unexpected_singletons} (definitions.rs:242-301)
+ * Built: the 39 search templates in the visiting order of find_base_type_in_sequence (sorted by full_allele(),
+ * haplotyper.rs:175-183) with type, subtype label and deep-typing flag (mapped_hybrids, :117-123); the ordered variant table
+ * (first occurrence per (position, ref, alt), stable sort by position), labels, VI flags, label and variant look-ups; one 0/1 row per
+ * star allele in haplotype_lookup (BTreeMap<Cyp2d6RegionLabel, _>) order.  ctx may be NULL: the tables are then host only
+ * (sp_cyp_db_problem needs a context: it hands out the templates as a packed set in HBM).
+ * Errors: SP_ERR_INVALID_ARG when a coordinate leaves the window, the CYP2D6 region does not contain every variant (the reference
+ * asserts, haplotyper.rs:110-111) or a variant leaves the backbone. */
+typedef struct {
+    const char* chrom_name;                       /* "chr22" (used for variant_string() labels); NULL = "chr22" */
+    const char* chrom_seq; uint64_t window_start, window_len;
+    uint64_t d6_start, d6_end, d7_start, d7_end, rep6_start, rep6_end, rep7_start, rep7_end;
+    uint64_t spacer_start, spacer_end, link_start, link_end, backbone_start, backbone_end, star5_start, star5_end;
+    uint64_t d6_exon_start[9], d6_exon_end[9], d7_exon_start[9], d7_exon_end[9];
+} sp_cyp_locus;
+typedef struct {
+    uint32_t n_alleles;
+    const char* const* star_allele;               /* "4.001" */
+    const uint32_t* var_off;                      /* n_alleles + 1 */
+    const uint64_t* var_pos;                      /* 0-based on the chromosome */
+    const char* const* var_ref; const char* const* var_alt;
+    const char* const* var_id; const char* const* var_vi;     /* either array may be NULL altogether */
+} sp_cyp_gene_def;
+typedef struct {
+    uint32_t n_translate; const char* const* translate_key; const char* const* translate_val;
+    uint32_t n_connections; const char* const* connection_a; const char* const* connection_b;
+    uint32_t n_singletons; const char* const* singletons;
+} sp_cyp_config;
+typedef struct {
+    uint32_t n_templates, n_variants, n_vi, n_alleles, backbone_len;
+    int64_t first_variant_pos, last_variant_pos;  /* LoadedVariants::{first,last}_variant_pos, -1 when there is none */
+} sp_cyp_db_stats;
+typedef struct sp_cyp_db sp_cyp_db;
+int32_t sp_cyp_db_create(sp_ctx* ctx /* may be NULL */, const sp_cyp_locus* locus, const sp_cyp_gene_def* gene_def, const sp_cyp_config* config /* may be NULL */,
+                         sp_cyp_db** out);
+void    sp_cyp_db_free(sp_cyp_db* db);
+int32_t sp_cyp_db_info(const sp_cyp_db* db, sp_cyp_db_stats* stats);
+/* the pointers stay valid for the life of the database; subtype is NULL for a label without one */
+int32_t sp_cyp_db_template(const sp_cyp_db* db, uint32_t i, int32_t* type, const char** subtype, const char** full_allele, const char** seq, uint32_t* len, int32_t* deep);
+int32_t sp_cyp_db_variant(const sp_cyp_db* db, uint32_t i, int64_t* chrom_pos, const char** ref, const char** alt, const char** label, int32_t* is_vi);
+int32_t sp_cyp_db_index_label(const sp_cyp_db* db, const char* label, uint32_t* idx);                                  /* LoadedVariants::index_label */
+int32_t sp_cyp_db_index_variant(const sp_cyp_db* db, uint64_t position, const char* ref, const char* alt, uint32_t* idx);   /* LoadedVariants::index_variant */
+int32_t sp_cyp_db_allele(const sp_cyp_db* db, uint32_t a, const char** subtype, const uint8_t** row /* n_variants 0/1 */);
+/* everything sp_cyp_diplotype needs, pointing into the database (valid for its life); run parameters get the CLI defaults
+ * (min_consensus_count 3, min_consensus_fraction 0.10, dual_max_ed_delta 100, no inferred connections, all alleles normalise) */
+int32_t sp_cyp_db_problem(const sp_cyp_db* db, sp_cyp_problem* problem);
+
 /* ------------------------------------------------------------------ K6: variant-gene diplotype search
  * Replaces solve_diplotype (src/diplotyper.rs:1211-1371) with find_best_inexact_matches (:1411-1509) and
  * NormalizedPgxHaplotype::quant_match (src/data_types/normalized_variant.rs:431-479) on integer ids.  The caller keeps the

@@ -135,6 +135,29 @@ class sp_cyp_problem(C.Structure):
                 ("infer_connections", C.c_int32), ("normalize_d6_only", C.c_int32)]
 
 
+class sp_cyp_locus(C.Structure):
+    _fields_ = [("chrom_name", C.c_char_p), ("chrom_seq", C.c_char_p), ("window_start", C.c_uint64), ("window_len", C.c_uint64)] + \
+               [(n, C.c_uint64) for n in ("d6_start", "d6_end", "d7_start", "d7_end", "rep6_start", "rep6_end", "rep7_start", "rep7_end",
+                                          "spacer_start", "spacer_end", "link_start", "link_end", "backbone_start", "backbone_end", "star5_start", "star5_end")] + \
+               [(n, C.c_uint64 * 9) for n in ("d6_exon_start", "d6_exon_end", "d7_exon_start", "d7_exon_end")]
+
+
+class sp_cyp_gene_def(C.Structure):
+    _fields_ = [("n_alleles", C.c_uint32), ("star_allele", C.POINTER(C.c_char_p)), ("var_off", C.c_void_p), ("var_pos", C.c_void_p),
+                ("var_ref", C.POINTER(C.c_char_p)), ("var_alt", C.POINTER(C.c_char_p)), ("var_id", C.POINTER(C.c_char_p)), ("var_vi", C.POINTER(C.c_char_p))]
+
+
+class sp_cyp_config(C.Structure):
+    _fields_ = [("n_translate", C.c_uint32), ("translate_key", C.POINTER(C.c_char_p)), ("translate_val", C.POINTER(C.c_char_p)),
+                ("n_connections", C.c_uint32), ("connection_a", C.POINTER(C.c_char_p)), ("connection_b", C.POINTER(C.c_char_p)),
+                ("n_singletons", C.c_uint32), ("singletons", C.POINTER(C.c_char_p))]
+
+
+class sp_cyp_db_stats(C.Structure):
+    _fields_ = [("n_templates", C.c_uint32), ("n_variants", C.c_uint32), ("n_vi", C.c_uint32), ("n_alleles", C.c_uint32), ("backbone_len", C.c_uint32),
+                ("first_variant_pos", C.c_int64), ("last_variant_pos", C.c_int64)]
+
+
 SP_CYP_MAXCONS = 64
 
 
@@ -236,6 +259,15 @@ def lib():
         "sp_hla_diplotype_cohort": (i32, [vp, vp, u32, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
         "sp_diplotype_string": (u32, [C.c_char_p, C.c_char_p, i32, C.c_char_p, u32]),
         "sp_inexact_haplotype": (u32, [C.c_char_p, u32, C.POINTER(C.c_char_p), vp, vp, C.POINTER(i32), C.c_char_p, u32]),
+        "sp_cyp_db_create": (i32, [vp, C.POINTER(sp_cyp_locus), C.POINTER(sp_cyp_gene_def), C.POINTER(sp_cyp_config), C.POINTER(vp)]),
+        "sp_cyp_db_free": (None, [vp]),
+        "sp_cyp_db_info": (i32, [vp, C.POINTER(sp_cyp_db_stats)]),
+        "sp_cyp_db_template": (i32, [vp, u32, C.POINTER(i32), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(u32), C.POINTER(i32)]),
+        "sp_cyp_db_variant": (i32, [vp, u32, C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(i32)]),
+        "sp_cyp_db_index_label": (i32, [vp, C.c_char_p, C.POINTER(u32)]),
+        "sp_cyp_db_index_variant": (i32, [vp, u64, C.c_char_p, C.c_char_p, C.POINTER(u32)]),
+        "sp_cyp_db_allele": (i32, [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_uint8))]),
+        "sp_cyp_db_problem": (i32, [vp, C.POINTER(sp_cyp_problem)]),
         "sp_profile_reset": (i32, [vp]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
@@ -632,6 +664,136 @@ def build_chains(hap_type, read_seg_off, ed, kept):
     chains = [[[int(x) for x in items[co[c]:co[c + 1]]] for c in range(rco[k], rco[k + 1])] for k in range(nk)]
     rows = [[int(x) for x in w_seg[rwo[k]:rwo[k + 1]]] for k in range(nk)]
     return dict(read_index=[int(x) for x in read_index[:nk]], chains=chains, w_rows=rows, unique_counts=uniq, false_allele=false_allele)
+
+
+def _strs(items):
+    arr = (C.c_char_p * max(1, len(items)))()
+    for i, x in enumerate(items):
+        arr[i] = x.encode() if x is not None else None
+    return arr
+
+
+class CypDb:
+    """sp_cyp_db: the CYP2D6 templates and typing tables built from the database's own JSON objects.
+    cyp2d6_config / cyp2d6_gene_def: the objects of the same name in the database JSON (SURVEY.md App. C);
+    chrom_seq: bases of chromosome window [window_start, window_start + len(chrom_seq)).  ctx=None builds host tables only."""
+
+    def __init__(self, ctx, cyp2d6_config, cyp2d6_gene_def, chrom_seq, window_start):
+        self.ctx = ctx
+        cc, reg = cyp2d6_config["cyp_coordinates"], cyp2d6_config["cyp_regions"]
+        L = sp_cyp_locus()
+        chrom = cc["CYP2D6"]["chrom"]
+        self._keep = [chrom.encode(), chrom_seq.encode()]
+        L.chrom_name, L.chrom_seq, L.window_start, L.window_len = self._keep[0], self._keep[1], int(window_start), len(chrom_seq)
+        for name, key in (("d6", "CYP2D6"), ("d7", "CYP2D7"), ("rep6", "REP6"), ("rep7", "REP7"), ("spacer", "spacer"), ("link", "link_region"),
+                          ("backbone", "CYP2D6_wfa_backbone")):
+            setattr(L, name + "_start", int(cc[key]["start"])); setattr(L, name + "_end", int(cc[key]["end"]))
+        L.star5_start, L.star5_end = int(cyp2d6_config["cyp2d6_star5_del"]["start"]), int(cyp2d6_config["cyp2d6_star5_del"]["end"])
+        for x in range(9):
+            L.d6_exon_start[x], L.d6_exon_end[x] = int(reg["CYP2D6"][f"exon{x + 1}"]["start"]), int(reg["CYP2D6"][f"exon{x + 1}"]["end"])
+            L.d7_exon_start[x], L.d7_exon_end[x] = int(reg["CYP2D7"][f"exon{x + 1}"]["start"]), int(reg["CYP2D7"][f"exon{x + 1}"]["end"])
+        keys = sorted(cyp2d6_gene_def, key=lambda k: k.encode())           # BTreeMap<String, _> order
+        star, off, pos, ref, alt, vid, vvi = [], [0], [], [], [], [], []
+        for k in keys:
+            d = cyp2d6_gene_def[k]
+            star.append(d["star_allele"])
+            for v in d["variants"]:
+                pos.append(int(v["position"])); ref.append(v["reference"]); alt.append(v["alternate"]); vid.append(v.get("id"))
+                vvi.append(v.get("extras", {}).get("VI"))
+            off.append(len(pos))
+        G = sp_cyp_gene_def()
+        a_off, a_pos = np.array(off, np.uint32), np.array(pos or [0], np.uint64)
+        self._keep += [a_off, a_pos, _strs(star), _strs(ref), _strs(alt), _strs(vid), _strs(vvi)]
+        G.n_alleles, G.star_allele, G.var_off, G.var_pos = len(keys), self._keep[4], a_off.ctypes.data, a_pos.ctypes.data
+        G.var_ref, G.var_alt, G.var_id, G.var_vi = self._keep[5], self._keep[6], self._keep[7], self._keep[8]
+        tr = sorted(cyp2d6_config.get("cyp_translate", {}).items())
+        con = sorted(tuple(x) for x in cyp2d6_config.get("inferred_connections", []))
+        sg = sorted(cyp2d6_config.get("unexpected_singletons", []))
+        self.cfg = dict(translate=tr, connections=con, singletons=sg)
+        K = sp_cyp_config()
+        self._keep += [_strs([a for a, _ in tr]), _strs([b for _, b in tr]), _strs([a for a, _ in con]), _strs([b for _, b in con]), _strs(sg)]
+        K.n_translate, K.translate_key, K.translate_val = len(tr), self._keep[9], self._keep[10]
+        K.n_connections, K.connection_a, K.connection_b = len(con), self._keep[11], self._keep[12]
+        K.n_singletons, K.singletons = len(sg), self._keep[13]
+        self._h = C.c_void_p()
+        rc = lib().sp_cyp_db_create(ctx._h if ctx is not None else None, C.byref(L), C.byref(G), C.byref(K), C.byref(self._h))
+        if rc != SP_OK:
+            raise StarphaseError(rc, lib().sp_last_error(ctx._h).decode() if ctx is not None else "sp_cyp_db_create")
+        st = sp_cyp_db_stats()
+        lib().sp_cyp_db_info(self._h, C.byref(st))
+        self.stats = st
+
+    def close(self):
+        if self._h:
+            lib().sp_cyp_db_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def templates(self):
+        """[(type, subtype|None, full_allele, sequence, deep)] in visiting order"""
+        out = []
+        for i in range(self.stats.n_templates):
+            t, d, ln = C.c_int32(0), C.c_int32(0), C.c_uint32(0)
+            sub, full, seq = C.c_char_p(), C.c_char_p(), C.c_char_p()
+            lib().sp_cyp_db_template(self._h, i, C.byref(t), C.byref(sub), C.byref(full), C.byref(seq), C.byref(ln), C.byref(d))
+            out.append((t.value, sub.value.decode() if sub.value is not None else None, full.value.decode(), seq.value.decode(), bool(d.value)))
+        return out
+
+    def variants(self):
+        """[(chrom_pos, ref, alt, label, is_vi)] in LoadedVariants::ordered_variants order"""
+        out = []
+        for i in range(self.stats.n_variants):
+            p, vi = C.c_int64(0), C.c_int32(0)
+            r, a, lab = C.c_char_p(), C.c_char_p(), C.c_char_p()
+            lib().sp_cyp_db_variant(self._h, i, C.byref(p), C.byref(r), C.byref(a), C.byref(lab), C.byref(vi))
+            out.append((p.value, r.value.decode(), a.value.decode(), lab.value.decode(), bool(vi.value)))
+        return out
+
+    def index_label(self, label):
+        idx = C.c_uint32(0)
+        rc = lib().sp_cyp_db_index_label(self._h, label.encode(), C.byref(idx))
+        if rc != SP_OK:
+            raise KeyError(label)
+        return idx.value
+
+    def index_variant(self, pos, ref, alt):
+        idx = C.c_uint32(0)
+        rc = lib().sp_cyp_db_index_variant(self._h, int(pos), ref.encode(), alt.encode(), C.byref(idx))
+        if rc != SP_OK:
+            raise KeyError((pos, ref, alt))
+        return idx.value
+
+    def alleles(self):
+        """([star_allele], hap_matrix [n_alleles][n_variants]) in haplotype_lookup order"""
+        names, rows = [], []
+        for a in range(self.stats.n_alleles):
+            sub, row = C.c_char_p(), C.POINTER(C.c_uint8)()
+            lib().sp_cyp_db_allele(self._h, a, C.byref(sub), C.byref(row))
+            names.append(sub.value.decode())
+            rows.append(np.ctypeslib.as_array(row, shape=(self.stats.n_variants,)).copy() if self.stats.n_variants else np.zeros(0, np.uint8))
+        return names, np.array(rows, np.uint8).reshape(len(names), self.stats.n_variants)
+
+    def problem(self, **overrides):
+        pr = sp_cyp_problem()
+        self.ctx.check(lib().sp_cyp_db_problem(self._h, C.byref(pr)))
+        for k, v in overrides.items():
+            setattr(pr, k, v)
+        return pr
+
+    def diplotype(self, reads, cons_cap=16384, **overrides):
+        """sp_cyp_diplotype on this database -> (sp_cyp_call, [consensus strings], [(type, subtype|None)])"""
+        pr = self.problem(**overrides)
+        call = sp_cyp_call()
+        buf = C.create_string_buffer(SP_CYP_MAXCONS * cons_cap)
+        self.ctx.check(lib().sp_cyp_diplotype(self.ctx._h, C.byref(pr), reads._h, C.byref(call), buf, cons_cap))
+        cons = [buf.raw[i * cons_cap:(i + 1) * cons_cap].split(b"\0", 1)[0].decode() for i in range(call.n_consensus)]
+        labels = [(int(call.cons_type[i]), (call.cons_subtype[i].value.decode() or None)) for i in range(call.n_consensus)]
+        return call, cons, labels
 
 
 class SeqSet:

@@ -251,3 +251,108 @@ class CypLocus:
             s = int(rng.integers(0, len(hap) - ln + 1))
             out.append(hifi_errors(rng, hap[s:s + ln]))
         return out
+
+
+class Chr22Locus:
+    """BASELINE.json configs[2]: a synthetic chr22 window laid out with the coordinates of the database's own Cyp2d6Config
+    (src/cyp2d6/definitions.rs:128-240: REP6 2,772 / CYP2D6 6,165 / link_region 2,919 / REP7 2,772 / spacer 1,564 / CYP2D7 5,938) so
+    that the library builds the real 39 templates from it and the real variant table applies.
+      * random ACGT (seed), then the reference allele of every database variant is written at its position (they all come from one
+        real sequence, so they agree where they overlap);
+      * CYP2D7 = CYP2D6 piece by piece (the 19 exon / intron pieces the hybrid breakpoints cut) with ~3 % substitutions and one
+        contiguous insertion / deletion per piece that makes up the piece's real length difference: hybrids are meaningful;
+      * REP7 = REP6 except near its end (two edited stretches and an unrelated 300-base tail), as in the real locus.
+    Haplotypes are the window with CYP2D6 replaced by a star allele (database variants applied), with the *5 region deleted,
+    or with a second gene copy (duplication, or the *68 / *36-style tandem arrangements) inserted upstream of the first."""
+
+    def __init__(self, cyp2d6_config, cyp2d6_gene_def, seed=3, flank=4000):
+        rng = np.random.default_rng(seed)
+        self.config, self.gene_def = cyp2d6_config, cyp2d6_gene_def
+        cc, reg = cyp2d6_config["cyp_coordinates"], cyp2d6_config["cyp_regions"]
+        s5 = cyp2d6_config["cyp2d6_star5_del"]
+        lo = min([v["start"] for v in cc.values()] + [s5["start"] - 500]) - flank
+        hi = max([v["end"] for v in cc.values()] + [s5["end"] + 3000]) + flank
+        self.start = lo
+        seq = rng.choice(list("ACGT"), hi - lo).tolist()
+        put = lambda p, s: seq.__setitem__(slice(p - lo, p - lo + len(s)), list(s))
+        get = lambda a, b: "".join(seq[a - lo:b - lo])
+        for d in cyp2d6_gene_def.values():
+            for v in d["variants"]:
+                put(v["position"], v["reference"])
+        # D7 from D6, piece by piece
+        def cuts(g):
+            b = [cc[g]["start"]]
+            for x in range(9, 0, -1):
+                b += [reg[g][f"exon{x}"]["start"], reg[g][f"exon{x}"]["end"]]
+            return b + [cc[g]["end"]]
+        b6, b7 = cuts("CYP2D6"), cuts("CYP2D7")
+        for i in range(len(b6) - 1):
+            piece = list(get(b6[i], b6[i + 1]))
+            want = b7[i + 1] - b7[i]
+            for p in np.flatnonzero(rng.random(len(piece)) < 0.03):
+                piece[p] = "ACGT"[("ACGT".index(piece[p]) + 1 + int(rng.integers(3))) % 4]
+            if want < len(piece):
+                at = int(rng.integers(10, max(11, want - 10)))
+                del piece[at:at + len(piece) - want]
+            elif want > len(piece):
+                at = int(rng.integers(10, max(11, len(piece) - 10)))
+                piece[at:at] = rng.choice(list("ACGT"), want - len(piece)).tolist()
+            put(b7[i], "".join(piece))
+        # REP7 from REP6
+        rep6 = get(cc["REP6"]["start"], cc["REP6"]["end"])
+        m1, m2 = mutate(rng, rep6[2200:2336], 4, 0, 1), mutate(rng, rep6[2336:2472], 4, 1, 0)
+        rep7 = rep6[:2200] + m1 + m2 + "".join(rng.choice(list("ACGT"), 300))
+        assert len(rep7) == cc["REP7"]["end"] - cc["REP7"]["start"]
+        put(cc["REP7"]["start"], rep7)
+        self.sequence = "".join(seq)
+        self.cc, self.s5 = cc, s5
+
+    def slice(self, a, b):
+        return self.sequence[a - self.start:b - self.start]
+
+    def star_allele(self, star):
+        """the CYP2D6 region carrying the variants of allele `star` ("4.001")"""
+        d = next(v for v in self.gene_def.values() if v["star_allele"] == star)
+        a, b = self.cc["CYP2D6"]["start"], self.cc["CYP2D6"]["end"]
+        s = self.slice(a, b)
+        for v in sorted(d["variants"], key=lambda v: -v["position"]):          # right to left: earlier coordinates stay valid
+            p = v["position"] - a
+            assert s[p:p + len(v["reference"])] == v["reference"], (star, v)
+            s = s[:p] + v["alternate"] + s[p + len(v["reference"]):]
+        return s
+
+    def hybrid(self, name):
+        """a template-shaped hybrid gene, e.g. "CYP2D6::CYP2D7::exon2" (definitions.rs:395-446)"""
+        kind, cut = name.rsplit("::", 1)
+        reg = self.config["cyp_regions"]
+        side = "end" if cut.startswith("exon") else "start"
+        x = cut.replace("exon", "").replace("intron", "")
+        bp1, bp2 = reg["CYP2D6"][f"exon{x}"][side], reg["CYP2D7"][f"exon{x}"][side]
+        cc = self.cc
+        if kind == "CYP2D6::CYP2D7":
+            return self.slice(cc["CYP2D7"]["start"], bp2) + self.slice(bp1, cc["CYP2D6"]["end"])
+        return self.slice(cc["CYP2D6"]["start"], bp1) + self.slice(bp2, cc["CYP2D7"]["end"])
+
+    def haplotype(self, genes):
+        """genes: list of gene bodies in chromosome order (the one next to REP6 first); None = the *5 deletion haplotype.
+        One body: the window with CYP2D6 replaced.  More: REP6 body1 link REP7 body2 link REP7 ... spacer CYP2D7."""
+        cc = self.cc
+        if genes is None:
+            return self.slice(self.start, self.s5["start"]) + self.slice(self.s5["end"], self.start + len(self.sequence))
+        left = self.slice(self.start, cc["CYP2D6"]["start"])                    # flank + REP6 (+ the short piece up to the gene)
+        link = self.slice(cc["CYP2D6"]["end"], cc["REP7"]["end"])               # link_region + REP7
+        right = self.slice(cc["REP7"]["end"], self.start + len(self.sequence))  # spacer + CYP2D7 + flank
+        return left + link.join(genes) + link + right
+
+    def sample(self, rng, haplotypes, n_reads, lo=3000, hi=8000, errors=True):
+        """targeted-style reads: fragments of lo..hi bases drawn from the haplotypes in proportion to their lengths"""
+        total = sum(len(h) for h in haplotypes)
+        reads = []
+        for h in haplotypes:
+            for _ in range(int(round(n_reads * len(h) / total))):
+                ln = int(rng.integers(lo, hi + 1))
+                s = int(rng.integers(0, len(h) - ln + 1))
+                r = h[s:s + ln]
+                reads.append(hifi_errors(rng, r) if errors else r)
+        order = rng.permutation(len(reads))
+        return [reads[i] for i in order]

@@ -13,6 +13,9 @@ Run in the authoring container only (needs /root/reference).  Everything written
   variant_vcfs.json        decoded rows of every test VCF (no htslib needed downstream)
   test_reference.json      test_data/test_reference.fa
   cyp2d6_db_v0.14.1.json.gz  cyp2d6_config + cyp2d6_gene_def of the bundled DB
+  cyp2d6_gene_def_v0.9.0.json.gz  cyp2d6_gene_def of data/v0.9.0/cpic_20240404.json.gz, the database test_load_variant_database
+                           (src/cyp2d6/haplotyper.rs:918-933) loads
+  gene_entries_v0.14.1.json.gz  gene_entries (the CPIC / PharmVar variant genes) of the bundled DB, for the full-panel tests
 """
 import gzip, json, os, sys, glob
 
@@ -49,6 +52,10 @@ def main():
           "hla_sequences": db["hla_sequences"]}, "hla_db_v0.14.1.json.gz", gz=True)
     dump({"database_metadata": db["database_metadata"], "cyp2d6_config": db["cyp2d6_config"],
           "cyp2d6_gene_def": db["cyp2d6_gene_def"]}, "cyp2d6_db_v0.14.1.json.gz", gz=True)
+
+    old = json.load(gzip.open(f"{REF}/data/v0.9.0/cpic_20240404.json.gz"))
+    dump({"database_metadata": old["database_metadata"], "cyp2d6_gene_def": old["cyp2d6_gene_def"]}, "cyp2d6_gene_def_v0.9.0.json.gz", gz=True)
+    dump({"database_metadata": db["database_metadata"], "gene_entries": db["gene_entries"]}, "gene_entries_v0.14.1.json.gz", gz=True)
 
     chr6 = read_fasta(f"{REF}/test_data/refseq_faux/hg38_chr6_masked.fa.gz")["chr6"]
     islands, i, n = [], 0, len(chr6)
