@@ -665,6 +665,13 @@ uint32_t sp_inexact_haplotype(const char* base_haplotype, uint32_t n_variants, c
  * HIP-event timing of the dominant kernel on the context's own stream. */
 int32_t sp_profile_reset(sp_ctx* ctx);
 int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches, uint64_t* cells);
+/* device-side counters since the last sp_profile_reset come back in *cells under the names "count:k1_cells_active" (cells of the
+ * first K1 pass whose gene the read anchors in), "count:k1_cells_executed" (those that ran the DP; the others were settled by prefix
+ * sharing), "count:k1_cells_resumed" (executed cells that started from their predecessor's snapshot), "count:k1_cells_bytes"
+ * (algorithmic bytes of the executed cells), "count:cons_launches", "count:cons_columns" (K8). */
+/* roofline peaks measured on this device in this run: what = "valu_int" (v_add_u32 wave-instructions / s), "match16" (VALU
+ * wave-instructions / s of the WFA cell's 16-base compare), "hbm_copy" (bytes / s, read + written, of a 2 x 1 GiB streaming copy) */
+int32_t sp_microbench(sp_ctx* ctx, const char* what, double* rate);
 
 #ifdef __cplusplus
 }

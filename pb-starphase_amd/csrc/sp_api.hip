@@ -63,11 +63,29 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx) {
     return SP_OK;
 }
 
-int32_t sp_profile_reset(sp_ctx* ctx) { if (!ctx) return SP_ERR_INVALID_ARG; sp_profile_flush(ctx); ctx->prof.clear(); return SP_OK; }
+int32_t sp_profile_reset(sp_ctx* ctx) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    sp_profile_flush(ctx); ctx->prof.clear();
+    unsigned long long* c = sp_counters(ctx);
+    if (c) { hipSetDevice(ctx->device); hipMemsetAsync(c, 0, SPC_N * sizeof(unsigned long long), ctx->stream); }
+    return SP_OK;
+}
 
 int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches, uint64_t* cells) {
     if (!ctx || !kernel) return SP_ERR_INVALID_ARG;
     sp_profile_flush(ctx);
+    // device counters: "count:<name>" returns the value in *cells (ms and launches are 0)
+    static const struct { const char* name; int idx; } counters[] = {
+        {"count:k1_cells_active", SPC_K1_ACTIVE}, {"count:k1_cells_executed", SPC_K1_EXECUTED}, {"count:k1_cells_resumed", SPC_K1_RESUMED},
+        {"count:k1_cells_bytes", SPC_K1_BYTES}, {"count:cons_launches", SPC_CONS_LAUNCHES}, {"count:cons_columns", SPC_CONS_COLUMNS} };
+    for (const auto& c : counters) if (std::strcmp(kernel, c.name) == 0) {
+        unsigned long long v = 0; unsigned long long* d = sp_counters(ctx);
+        if (d) { hipSetDevice(ctx->device); if (hipMemcpyAsync(&v, d + c.idx, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "sp_profile_get: counter read failed"); }
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = 0;
+        if (cells) *cells = v;
+        return SP_OK;
+    }
     auto it = ctx->prof.find(kernel);
     ProfileEntry e; if (it != ctx->prof.end()) e = it->second;
     if (total_ms) *total_ms = e.ms;

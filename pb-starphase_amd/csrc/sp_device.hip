@@ -228,6 +228,14 @@ void* sp_pool(sp_ctx* ctx, const char* name, size_t bytes) {
     return e.first;
 }
 
+unsigned long long* sp_counters(sp_ctx* ctx) {
+    auto it = ctx->pool.find("prof_counters");
+    if (it != ctx->pool.end() && it->second.first) return (unsigned long long*)it->second.first;
+    unsigned long long* c = (unsigned long long*)sp_pool(ctx, "prof_counters", SPC_N * sizeof(unsigned long long));
+    if (c) (void)hipMemsetAsync(c, 0, SPC_N * sizeof(unsigned long long), ctx->stream);
+    return c;
+}
+
 // pinned host memory for results: a device-to-host copy into pageable caller memory goes through the runtime's bounce buffers in
 // pieces (0.25 ms for the 0.8 MB of a K1 batch); into pinned memory it is one DMA, and the memcpy to the caller is ~40 us
 void* sp_host_pool(sp_ctx* ctx, const char* name, size_t bytes) {

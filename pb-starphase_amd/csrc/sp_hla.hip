@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
                                                       uint32_t* __restrict__ cell_out, unsigned long long* __restrict__ bound,
                                                       const uint32_t* __restrict__ read_list, uint32_t* __restrict__ read_maxlen,
                                                       unsigned long long* __restrict__ winner, const uint32_t* __restrict__ order,
-                                                      int pass_cap, int b_words, int a_words) {
+                                                      int pass_cap, int b_words, int a_words, uint2* __restrict__ wg_stats) {
     extern __shared__ uint32_t lds[];
     // layout: [B window b_words (x2 with N plane)][A slot a_words (x2 with N plane)]
     uint32_t* LB = lds;
@@ -200,6 +200,9 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
         // the caps of the group under the bound they were last worked out for (redone only when the bound has moved)
         int u_cap = u.cap; unsigned long long cap_bound = K1_NO_BOUND;
         int jc = active ? __builtin_ctzll(active) : 64;
+        // measurement (bench.py's roofline over the cells actually executed): executed / resumed cells of this workgroup and the
+        // algorithmic bytes of the executed ones (ceil(Lq/4) + ceil(Lt/4) + 32), all in scalar registers
+        uint32_t st_exec = 0, st_resumed = 0, st_bytes = 0;
         while (jc < 64) {
             const int c_key = g * 64 + jc;
             if (pre_for != c_key) prefetch(c_key, (uint32_t)__builtin_amdgcn_readlane((int)u.woff, jc));      // (first of a group, behind a chain)
@@ -222,6 +225,10 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
                 else for (int w = lane; w < ((c_alen + 15) >> 4) + 2; w += SP_WAVE) NA[w] = 0;
             }
             spw::wave_lds_sync();
+            {
+                const int lt = c_alen + SP_BAND < rlen ? c_alen + SP_BAND : rlen;
+                st_exec += 1; st_bytes += (uint32_t)(((c_alen + 3) >> 2) + ((lt + 3) >> 2) + 32);
+            }
             SP_STAT(0, 1); SP_STAT(7, c_cap); SP_STAT(48 + (c_cap < 15 ? c_cap : 15), 1);
             spw::CellOut o; o.ok = 0; o.nm = 0; o.a_start = o.a_end = o.b_start = o.b_end = 0; o.explored = 0x7FFFFFFF;
             int nxt = jn;
@@ -232,6 +239,7 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
                 const int thr2 = has_succ ? __builtin_amdgcn_readlane(u.lcp, (jc + 1) & 63) << 1 : 0;
                 const bool resume = snap_for == jc && snap_s >= 0 && snap_s <= c_cap;
                 SP_STAT(8, resume ? 1 : 0); SP_STAT(9, resume ? snap_s + 1 : 0);
+                st_resumed += resume ? 1u : 0u;
                 int out_s = -1, out_H = 0;
                 spw::wfa_core<false, HASN, false, true>(LA, NA, 0, c_alen, LB, NB, -b_base, rlen, c_kb, c_cap, lane, nullptr, nullptr, o,
                                                         thr2, resume ? snap_s : -1, snap_H, &out_s, &out_H);
@@ -293,6 +301,23 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
             jc = nxt;
         }
         if (cell_out && p_mine < n_alleles) cell_out[(uint64_t)r * n_alleles + p_mine] = res;
+        if (wg_stats && lane == 0) wg_stats[blockIdx.x] = make_uint2(st_exec | (st_resumed << 8) | ((uint32_t)__builtin_popcountll(active) << 16), st_bytes);
+    }
+}
+
+// sums the per-workgroup words of a cells launch into the context's counters: active / executed / resumed cells, algorithmic bytes
+__global__ __launch_bounds__(256) void k1_stats_kernel(const uint2* __restrict__ wg_stats, uint32_t n, unsigned long long* __restrict__ counters) {
+    unsigned long long act = 0, ex = 0, res = 0, by = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint2 w = wg_stats[i];
+        ex += w.x & 0xFFu; res += (w.x >> 8) & 0xFFu; act += w.x >> 16; by += w.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) { act += __shfl_xor(act, o); ex += __shfl_xor(ex, o); res += __shfl_xor(res, o); by += __shfl_xor(by, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (act) atomicAdd(&counters[SPC_K1_ACTIVE], act);
+        if (ex) atomicAdd(&counters[SPC_K1_EXECUTED], ex);
+        if (res) atomicAdd(&counters[SPC_K1_RESUMED], res);
+        if (by) atomicAdd(&counters[SPC_K1_BYTES], by);
     }
 }
 
@@ -841,6 +866,12 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         const int pass_cap = d_bound ? pass_caps[pass] : SP_MAX_ED;
         const uint32_t n_chunks = (((NA + K1_CHUNK - 1) / K1_CHUNK) + 7) & ~7u;       // padded to the 8 XCDs (k1_cells_kernel)
         const uint32_t* d_list = pass == 0 ? nullptr : d_open_list;
+        // per-workgroup measurement words of the first (dominant) pass, summed into the context's counters after the launch
+        uint2* d_wgs = nullptr; unsigned long long* d_cnt = nullptr;
+        if (pass == 0 && ctx->profiling) {
+            d_wgs = (uint2*)sp_pool(ctx, "k1_wg_stats", (size_t)n_open * n_chunks * sizeof(uint2)); d_cnt = sp_counters(ctx);
+            if (d_wgs && d_cnt) (void)hipMemsetAsync(d_wgs, 0, (size_t)n_open * n_chunks * sizeof(uint2), ctx->stream); else d_wgs = nullptr;
+        }
         {
             ProfScope ps(ctx, pass == 0 ? "k1_cells" : "k1_cells_deep", (uint64_t)n_open * NA);
             auto go = [&](auto kernel) {
@@ -849,12 +880,13 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
                 pos.alen = db->d_pos; pos.off = db->d_pos + NA; pos.gene = reinterpret_cast<const uint32_t*>(db->d_pos + (size_t)2 * NA);
                 pos.woff = reinterpret_cast<const uint32_t*>(db->d_pos + (size_t)3 * NA); pos.lcp = db->d_pos + (size_t)4 * NA;
                 hipLaunchKernelGGL(kernel, dim3(n_open * n_chunks), dim3(64), cells_lds, ctx->stream, db->dna_fwd->view(), reads->view(), pos,
-                                   d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, d_win, db->d_order, pass_cap, b_words, a_words);
+                                   d_rg, d_votes, (int)G, NA, n_chunks, d_cells, d_bound, d_list, d_maxlen, d_win, db->d_order, pass_cap, b_words, a_words, d_wgs);
             };
             if (hasn) { if (pass == 0) go(k1_cells_kernel<true, false>); else go(k1_cells_kernel<true, true>); }
             else { if (pass == 0) go(k1_cells_kernel<false, false>); else go(k1_cells_kernel<false, true>); }
             if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_cells launch failed");
         }
+        if (d_wgs) hipLaunchKernelGGL(k1_stats_kernel, dim3(256), dim3(256), 0, ctx->stream, d_wgs, n_open * n_chunks, d_cnt);
         if (rc == SP_OK && d_bound && pass + 1 < n_pass) {
             (void)hipMemsetAsync(d_open, 0, 4, ctx->stream);
             hipLaunchKernelGGL(k1_done_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_bound, d_done, R, pass_cap, d_maxlen, d_open, d_open_list);

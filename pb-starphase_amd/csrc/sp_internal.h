@@ -100,6 +100,9 @@ int sp_make_segments(sp_ctx* ctx, const sp_seqset* reads, const std::vector<uint
 int sp_seqset_make_small(sp_ctx* ctx, const char* prefix, const char* bases, const uint64_t* offsets, uint32_t n, bool with_index, sp_seqset* out);   // pooled, never freed
 int sp_seqset_fetch_host(sp_ctx* ctx, sp_seqset* s);                      // packed words (and N plane) of a set on the host, fetched once
 std::string sp_seqset_decode(sp_ctx* ctx, const sp_seqset* s, uint32_t i); // ASCII of sequence i
+// device-side measurement counters of a context (zeroed by sp_profile_reset, read by sp_profile_get under the names below)
+enum { SPC_K1_ACTIVE = 0, SPC_K1_EXECUTED, SPC_K1_RESUMED, SPC_K1_BYTES, SPC_CONS_LAUNCHES, SPC_CONS_COLUMNS, SPC_N = 16 };
+unsigned long long* sp_counters(sp_ctx* ctx);
 void* sp_scratch(sp_ctx* ctx, size_t bytes);
 void* sp_pool(sp_ctx* ctx, const char* name, size_t bytes);
 void* sp_host_pool(sp_ctx* ctx, const char* name, size_t bytes);

@@ -269,6 +269,7 @@ def lib():
         "sp_cyp_db_allele": (i32, [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_uint8))]),
         "sp_cyp_db_problem": (i32, [vp, C.POINTER(sp_cyp_problem)]),
         "sp_profile_reset": (i32, [vp]),
+        "sp_microbench": (i32, [vp, C.c_char_p, C.POINTER(C.c_double)]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
     }
     for name, (res, args) in sigs.items():
@@ -536,6 +537,14 @@ class Context:
 
     def profile_reset(self):
         self.check(lib().sp_profile_reset(self._h))
+
+    def microbench(self, what):
+        r = C.c_double(0)
+        self.check(lib().sp_microbench(self._h, what.encode(), C.byref(r)))
+        return r.value
+
+    def counter(self, name):
+        return self.profile_get("count:" + name)[2]
 
     def profile_get(self, name):
         ms, launches, cells = C.c_double(0), C.c_uint64(0), C.c_uint64(0)

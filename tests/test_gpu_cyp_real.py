@@ -1,0 +1,75 @@
+"""BASELINE configs[2] at its stated shape: sp_cyp_diplotype on the synthetic chr22 locus laid out with the database's
+own coordinates, all 39 templates of generate_cyp_hybrids (sp_cyp_db_create, row a14), the real ~400-variant / 520-allele table, the six
+scenarios of the survey including the two hybrid ones.
+  * 2,000 targeted-style reads per sample: the library's call equals the simulated truth;
+  * 160 reads per sample: the library equals the same pipeline assembled from the oracle's pieces (tests/cyp_pipeline.py) -- consensus
+    strings, labels, chains, f64 score, haplotype strings -- and the truth."""
+import numpy as np
+import pytest
+
+import cyp_cases_real as cr
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["*1/*2", "*4/*4", "*5/*1", "*4+*68/*1", "*10+*36/*10", "*2x2/*1"]
+
+
+@pytest.fixture(scope="module")
+def real(pkg, gpu_ctx):
+    from pb_starphase_amd import synth
+    import cyp_pipeline as cp
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    db = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
+    tm, vs = db.templates(), db.variants()
+    names, rows = db.alleles()
+    bb = cfg["cyp_coordinates"]["CYP2D6_wfa_backbone"]
+    odb = cp.Db([t[2] for t in tm], [t[0] for t in tm], [t[1] for t in tm], [t[3] for t in tm], [t[4] for t in tm],
+                locus.slice(bb["start"], bb["end"]), [(p - bb["start"], r, a) for p, r, a, _l, _v in vs], [v[4] for v in vs], names, rows)
+    assert db.stats.n_templates == 39 and db.stats.n_variants == 393 and db.stats.n_alleles == 520
+    return locus, db, odb, {n: (h, e) for n, h, e in cr.scenarios(locus)}
+
+
+def core(s):
+    """"*36.001 + *10.001" -> "*36 + *10"; "*2.001x2" stays a run of two sub-alleles that collapse to "*2x2" """
+    parts = []
+    for x in s.split(" + "):
+        body, _, mult = x.partition("x")
+        parts.append((body.split(".")[0], int(mult) if mult else 1))
+    out = []
+    for b, m in parts:                                   # adjacent equal core alleles are counted together (caller.rs:942-953)
+        if out and out[-1][0] == b:
+            out[-1][1] += m
+        else:
+            out.append([b, m])
+    return " + ".join(b + (f"x{m}" if m > 1 else "") for b, m in out)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_stated_shape_equals_truth(gpu_ctx, real, name):
+    locus, db, _odb, sc = real
+    haps, expected = sc[name]
+    reads = locus.sample(np.random.default_rng(7), haps, 2000)
+    assert 1990 <= len(reads) <= 2010
+    call, cons, labels = db.diplotype(gpu_ctx.upload(reads))
+    assert call.status == 0
+    assert sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
+    assert sorted([call.core1.decode(), call.core2.decode()]) == sorted(core(e) for e in expected)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_library_equals_oracle_pipeline(oracle, gpu_ctx, real, name):
+    import cyp_pipeline as cp
+    locus, db, odb, sc = real
+    haps, expected = sc[name]
+    reads = locus.sample(np.random.default_rng(11), haps, 160)
+    exp = cp.diplotype(oracle, odb, reads, cfg=db.cfg)
+    call, cons, labels = db.diplotype(gpu_ctx.upload(reads))
+    assert call.status == exp["status"] == 0
+    assert cons == exp["consensus"]
+    assert labels == [(int(t), s) for t, s in exp["labels"]]
+    assert list(call.chain1[:call.n1]) == exp["chain1"] and list(call.chain2[:call.n2]) == exp["chain2"]
+    assert call.score == exp["score"]
+    got = (call.hap1.decode(), call.hap2.decode(), call.core1.decode(), call.core2.decode())
+    assert got == (exp["hap1"], exp["hap2"], exp["core1"], exp["core2"])
+    assert sorted(got[:2]) == sorted(expected)
