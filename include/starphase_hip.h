@@ -88,7 +88,7 @@ typedef struct {
 } sp_aln;              /* 32 bytes */
 
 #define SP_BAND    64
-#define SP_MAX_ED  255
+#define SP_MAX_ED  511
 #define SP_KMER    16
 #define SP_NO_DIAG INT32_MIN
 /* event word: (type << 30) | b_pos ; b_pos = B bases consumed before the edit */

@@ -260,7 +260,7 @@ int osp_hla_k1_read(const uint8_t* read, int rlen, int n_genes, const uint8_t* c
         if (allele_len[a] <= 0 || off[a] == INT_MIN) continue;
         int g = gene_of[a];
         if (v_rg[g] < vmin) continue;
-        int cap = (int)(0.03 * (double)allele_len[a]) + 1; if (cap > 255) cap = 255;
+        int cap = (int)(0.03 * (double)allele_len[a]) + 1; if (cap > OSP_MAX_ED) cap = OSP_MAX_ED;
         osp_wfa(alleles[a], allele_len[a], read, rlen, d_rg[g] - off[a], cap, &alns[a], NULL, NULL);
         ++run;
         if (alns[a].ok && cells) cells[a] = ((uint32_t)alns[a].nm << 16) | (uint32_t)(alns[a].a_end - alns[a].a_start);

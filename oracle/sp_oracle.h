@@ -42,6 +42,7 @@ extern "C" {
 
 /* ---------------- alignment contract ---------------- */
 #define OSP_BAND      64          /* diagonals per cell: k0-32 .. k0+31                 */
+#define OSP_MAX_ED    511         /* library-wide edit cap of a cell (SP_MAX_ED)         */
 #define OSP_KMER      16          /* anchor k-mer length                                */
 #define OSP_MAXOCC    4           /* k-mers occurring more often in the indexed side are ignored */
 #define OSP_NEG       (-(1 << 28))

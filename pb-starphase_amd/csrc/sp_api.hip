@@ -373,13 +373,13 @@ int32_t sp_align_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                        const sp_pair* pairs, uint64_t n_pairs,
                        sp_aln* out, uint32_t* events, uint32_t events_stride) {
     if (!ctx || !A || !B || (n_pairs && (!pairs || !out))) return SP_ERR_INVALID_ARG;
-    if (events && (events_stride == 0 || events_stride > SP_MAX_ED)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "align: events_stride must be 1..255");
+    if (events && (events_stride == 0 || events_stride > SP_MAX_ED)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "align: events_stride must be 1..SP_MAX_ED");
     if (n_pairs == 0) return SP_OK;
     hipSetDevice(ctx->device);
     std::vector<CellDesc> cells(n_pairs);
     for (uint64_t i = 0; i < n_pairs; ++i) {
         if (pairs[i].a >= A->n || pairs[i].b >= B->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "align: index out of range");
-        if (pairs[i].max_ed < 0 || pairs[i].max_ed > SP_MAX_ED) return sp_fail(ctx, SP_ERR_INVALID_ARG, "align: max_ed must be 0..255");
+        if (pairs[i].max_ed < 0 || pairs[i].max_ed > SP_MAX_ED) return sp_fail(ctx, SP_ERR_INVALID_ARG, "align: max_ed must be 0..SP_MAX_ED");
         cells[i] = CellDesc{pairs[i].a, pairs[i].b, pairs[i].diag, pairs[i].max_ed, 0, -1};
     }
     CellDesc* d_cells = nullptr; sp_aln* d_out = nullptr; uint32_t* d_ev = nullptr;

@@ -7,11 +7,21 @@
 // two agree bit for bit (consensus strings, read assignment, per-read edit counts).
 //
 // Mapping: ONE wavefront per read, one lane per diagonal (64-diagonal band, lane l <-> consensus pos - read pos = l - 32),
-// the per-read state is one VGPR per lane (furthest read position at the current edit count).  The consensus grows by one
-// base per kernel launch: every wave first re-derives the (wave-uniform) decision for position t from the vote counters
-// the previous launch accumulated, pushes that base into its read's wavefront(s), and adds the read's vote for position
-// t+1.  There is no host round trip inside the loop: the launches are enqueued back to back and become no-ops once the
-// consensus has stopped; the control block is double buffered by launch parity so a launch never reads what it writes.
+// the per-read state is one VGPR per lane (furthest read position at the current edit count).
+//
+// The decision for a column needs the votes of every read, so a column is a global step.  One launch per column (round 1) is bound
+// by launch latency (~10 us per base).  This version pushes a WINDOW of up to CW bases per launch:
+//   * the first base of a window is exact (decided from the complete votes of the verified state);
+//   * the others are speculated from the reads' own continuation ("lookahead" votes: every read names the bases that follow its
+//     tips) -- at HiFi error rates the majority continuation is the consensus except at real differences;
+//   * every wave pushes its read through the window and records the exact votes of every column it passes (exact GIVEN the
+//     speculated prefix), the new lookahead votes and the new state into the other state buffer;
+//   * a one-workgroup control kernel per problem sums the workgroups' vote words, re-derives the decisions in order and keeps the
+//     longest prefix on which decision == speculation with no structural event (stop, split).  A fully accepted window commits the
+//     new state buffer; a partly accepted one is re-pushed from the kept state with the verified bases only (no speculation),
+//     which costs one extra window.  Events only ever happen at the first base of a window.
+// Results are therefore exactly those of the one-base-per-step contract; only the number of launches changes (about two per
+// accepted window instead of one per base).  There is no host round trip inside the loop.
 #include "sp_internal.h"
 #include "sp_wfa.cuh"
 #include <algorithm>
@@ -23,44 +33,52 @@ namespace {
 
 constexpr int CB = 64;          // band
 constexpr int CH = 32;          // lane of diagonal 0
-constexpr int CWAVES = 16;      // reads per workgroup
-constexpr int CSLOTS = 8;       // vote counters are spread over this many slots (blockIdx & 7), one 128-byte line each:
-                                // same-line device atomics serialise (profiles/microbench/step_latency.hip)
-constexpr int CSTRIDE = 32;     // words per slot
+constexpr int CWAVES = 16;      // waves per workgroup
+constexpr int CW = 32;          // bases per window
+constexpr int CWIN = 512;       // consensus bases in front of the window kept in LDS (offset_window + slack)
+constexpr int RWORDS = 24;      // packed read words a wave keeps in LDS (384 bases around its tips)
 enum { F_ACTIVE = 1, F_FINISHED = 2, F_LOST = 4 };
 
-struct ConsCtrl {               // state before a step
-    int32_t dual, split_at, stopped[2], len[2], done, pad;
+struct ConsCtrl {               // state between two windows (written by the control kernel, read by the step kernel)
+    int32_t T;                  // column of the state in state_buf: consensus [0, T) is final
+    int32_t n;                  // bases the next window pushes (0: init or done)
+    int32_t replay, init;       // replay: the n bases are verified already (re-push after a cut window); init: build the initial state
+    int32_t state_buf;
+    int32_t dual, split_at, split_now;   // split_now: the first base of the window splits consensus 2 off (state clone, base spec[1][0])
+    int32_t done, pad0;
+    int32_t stopped[2], len[2], go[2];
+    int32_t windows, cut_windows;        // statistics
     long long best_w2, best_total;
     long long split_w2, split_total;     // the votes of the column at which the second consensus was split off
+    uint8_t spec[2][CW];
 };
 struct ConsMeta { int32_t e, c0, flags, pad; };
 
-// One consensus problem of a batch.  All problems of a batch advance in lockstep, one base per launch; a workgroup belongs to
-// exactly one problem (each problem's reads are padded to a multiple of CWAVES in the flattened read order).  The descriptors
-// travel in the kernel argument block (scalar loads), per-read constants are gathered once into ReadInfo: a step is a chain
-// of only two dependent memory round trips (state + control, then the read words at the wavefront tips).
-constexpr int CMAXP = 32;       // problems per launch sequence: their descriptors travel in the kernel argument block (32 x 80 bytes);
-                                // batches of up to 8 use an 8-entry block, whose launches are ~2 us shorter
+// One consensus problem of a batch.  All problems of a batch advance window by window in the same launches (each at its own
+// column); a workgroup belongs to exactly one problem (each problem's reads are padded to whole workgroups in the flattened read
+// order).  The descriptors travel in the kernel argument block (scalar loads) for small batches.
+constexpr int CMAXP = 32;
 struct ConsParams {
-    int n, first, first_block;  // reads; flattened index of local read 0; first workgroup of the problem
+    int n, first, first_block, n_blocks, rpw;   // reads; flattened index of local read 0; first workgroup; workgroups; reads per wave
     int min_count, delta, et, allow_dual, window, cmp_len; double min_af;
     uint8_t* C; int cap;        // [2][cap] base codes; consensus 2 shares [0, split_at) with consensus 1
-    uint32_t* votes;            // [2][cap+1][CSLOTS][8] : w[4], end
-    ConsCtrl* ctrl;             // [2]
+    ConsCtrl* ctrl;
 };
 struct ReadInfo { const uint32_t* w; const uint32_t* np; int n, off; long long pad; };
 template <int MAXP> struct ConsBatchT {
     ConsParams p[MAXP]; int n_prob;
     const ReadInfo* info;       // [total]
-    uint16_t* H;                // [2][total][64] furthest read position per diagonal (0xFFFF = none): 128 bytes per read and consensus
-    ConsMeta* meta;             // [2][total]
+    uint16_t* H;                // [2 buffers][2 consensuses][total][64] furthest read position per diagonal (0xFFFF = none)
+    ConsMeta* meta;             // [2][2][total]
+    unsigned long long* PV;     // [blocks][2][CW + 1] exact votes per workgroup: four 16-bit fields (A, C, G, T) in 12ths of a read
+    uint32_t* PE;               // [blocks][2][CW + 1] "the read ends here" votes
+    unsigned long long* PL;     // [blocks][2][CW]     lookahead votes (one per read and tip)
     int total;
 };
 // large batches (a cohort): the descriptors live in device memory and a table maps every workgroup to its problem
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; uint16_t* H; ConsMeta* meta; int total;
+    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; int total;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first; };
 
@@ -77,64 +95,6 @@ __device__ __forceinline__ int read_base(const ReadView& rv, int h) {
 
 // 12 / d for d = 1..4 distinct tip bases without an integer division
 __device__ __forceinline__ uint32_t vote_units(int d) { return d == 1 ? 12u : d == 2 ? 6u : d == 3 ? 4u : 3u; }
-
-struct Decision { int go[2]; int base[2]; int split; long long best_w2, best_total, split_w2, split_total; };
-
-// Every wave re-derives the decision for position t.  Lanes 0-15 fetch the 2 x CSLOTS vote slots (one 128-byte line each) and the
-// sums are formed with three shuffle steps, so the whole decision costs one memory round trip and a handful of registers.
-__device__ __forceinline__ Decision decide(const ConsParams& P, const ConsCtrl& c, int t, int lane) {
-    Decision d; d.go[0] = d.go[1] = 0; d.base[0] = d.base[1] = 0; d.split = 0; d.best_w2 = c.best_w2; d.best_total = c.best_total;
-    d.split_w2 = c.split_w2; d.split_total = c.split_total;
-    if (t >= P.cap) return d;                                                      // out of room: the consensus is cut at cap
-    uint32_t x[5] = { 0, 0, 0, 0, 0 };
-    if (lane < 2 * CSLOTS) {
-        const uint32_t* v = P.votes + (((size_t)(lane >> 3) * (P.cap + 1) + t) * CSLOTS + (lane & (CSLOTS - 1))) * CSTRIDE;
-        const uint4 q = *reinterpret_cast<const uint4*>(v);
-        x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; x[4] = v[4];
-    }
-    // sums over each group of 8 lanes with DPP (quad swaps, then the half-row mirror): no LDS traffic, three adds per counter
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        x[j] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[j], 0xB1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
-        x[j] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[j], 0x4E, 0xf, 0xf, true);      // quad_perm:[2,3,0,1]
-        x[j] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[j], 0x141, 0xf, 0xf, true);     // row_half_mirror
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (i == 1 && !c.dual) continue;
-        if (c.stopped[i]) continue;
-        // (32-bit counters: a column holds at most 12 units per read; only the cross products below need 64 bits, and the scalar
-        // unit has no ordered 64-bit compare -- with wider types every comparison here becomes a vector instruction)
-        uint32_t w[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) w[b] = (uint32_t)__builtin_amdgcn_readlane((int)x[b], i * CSLOTS);
-        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)x[4], i * CSLOTS);
-        const uint32_t total = w[0] + w[1] + w[2] + w[3];
-        int b1 = 0; uint32_t w1 = w[0];                                            // heaviest base, ties to the lower code
-#pragma unroll
-        for (int b = 1; b < 4; ++b) if (w[b] > w1) { b1 = b; w1 = w[b]; }
-        int b2 = -1; uint32_t w2 = 0; bool have2 = false;                          // heaviest of the others, ties to the lower code
-#pragma unroll
-        for (int b = 0; b < 4; ++b) if (b != b1 && (!have2 || w[b] > w2)) { b2 = b; w2 = w[b]; have2 = true; }
-        const bool go = P.et ? w1 > 0 : (total > end && w1 > 0);
-        if (!go) continue;
-        d.go[i] = 1; d.base[i] = b1;
-        if (!c.dual && w2 >= 12u * (uint32_t)P.min_count) {
-            if ((unsigned long long)w2 * (unsigned long long)d.best_total > (unsigned long long)d.best_w2 * (unsigned long long)total) { d.best_w2 = w2; d.best_total = total; }
-            if (P.allow_dual && (double)w2 >= P.min_af * (double)total) { d.split = 1; d.go[1] = 1; d.base[1] = b2; d.split_w2 = w2; d.split_total = total; }
-        }
-    }
-    return d;
-}
-
-// consensus i at absolute position pos as seen by launch t (position t itself is this launch's decision, not yet in memory)
-struct ConsView {
-    const uint8_t* C; int cap, split_at, t; int base0, base1;
-    __device__ __forceinline__ int at(int i, int pos) const {
-        if (pos == t) return i ? base1 : base0;
-        return (i == 1 && pos < split_at) ? C[pos] : C[(size_t)i * cap + pos];
-    }
-};
 
 struct Dwfa { int H, e, c0, flags; };
 
@@ -185,20 +145,16 @@ __device__ __forceinline__ void dwfa_catchup_t(Dwfa& d, int n, EXT extend, int s
     }
 }
 
-__device__ __forceinline__ void dwfa_push(Dwfa& d, const ReadView& rv, const ConsView& cv, int i, int T, int nb, int et, int lane) {
-    dwfa_push_t(d, rv.n, [&](int h) { return read_base(rv, h); }, [&](int pos) { return cv.at(i, pos); }, T, nb, et, lane);
-}
-
 // placement of a late read: Sellers' search of its first L bases in the last W consensus bases, one Myers bit-vector scan per
 // lane over the end positions it owns (an occurrence of an L-base pattern with <= L edits spans <= 2L text bases)
-template <class CA>
-__device__ __forceinline__ int find_start(const ReadView& rv, CA ca, int off, int W, int L, int lane) {
+template <class RB, class CA>
+__device__ __forceinline__ int find_start(int rn, RB rb, CA ca, int off, int W, int L, int lane) {
     const int ws = off - W > 0 ? off - W : 0, M = off - ws;
-    if (L > rv.n) L = rv.n;
+    if (L > rn) L = rn;
     if (M <= 0 || L <= 0) return off;
     unsigned long long peq[4];
     {
-        const int code = lane < L ? read_base(rv, L - 1 - lane) : 7;
+        const int code = lane < L ? rb(L - 1 - lane) : 7;
 #pragma unroll
         for (int b = 0; b < 4; ++b) peq[b] = __ballot(code == b);
     }
@@ -231,72 +187,215 @@ __device__ __forceinline__ int find_start(const ReadView& rv, CA ca, int off, in
     return (int)(key & ((1ull << 22) - 1));
 }
 
-template <int MAXP>
-__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<MAXP> B, int t) {
-    __shared__ uint32_t lv[2][8];
+constexpr int ACT_CONS = 512;   // consensus bases a wave packs while a late read catches up (offset_window + slack)
+constexpr int ACT_READ = 640;   // read bases it keeps (catch-up length + band + edits)
+struct ActScratch {             // per wave
+    uint8_t rcache[ACT_READ];
+    uint32_t cpack[ACT_CONS / 16 + 2];
+    uint32_t rpack[ACT_READ / 16 + 2];
+};
+
+// heaviest base of a packed vote word, ties to the lower code; second = heaviest of the others
+struct ColVotes { uint32_t w[4], end; };
+__device__ __forceinline__ void top2(const ColVotes& v, int& b1, uint32_t& w1, int& b2, uint32_t& w2, uint32_t& total) {
+    b1 = 0; w1 = v.w[0];
+#pragma unroll
+    for (int b = 1; b < 4; ++b) if (v.w[b] > w1) { b1 = b; w1 = v.w[b]; }
+    b2 = -1; w2 = 0; bool have2 = false;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) if (b != b1 && (!have2 || v.w[b] > w2)) { b2 = b; w2 = v.w[b]; have2 = true; }
+    total = v.w[0] + v.w[1] + v.w[2] + v.w[3];
+}
+
+template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B) {
     int pi = 0;
     if constexpr (MAXP == 0) pi = B.block_prob[blockIdx.x];
     else {
 #pragma unroll
         for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
     }
+    return pi;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// the window: every wave pushes its read(s) through the n bases the control kernel set up
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int MAXP>
+__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<MAXP> B) {
+    __shared__ unsigned long long lv[2][CW + 1];          // exact votes after j pushes (column T + j)
+    __shared__ uint32_t le[2][CW + 1];
+    __shared__ unsigned long long ll[2][CW];              // lookahead: ll[i][x] predicts column T + n + 1 + x
+    __shared__ uint8_t cwin[2][CWIN + CW];                // consensus bases [T - CWIN, T + n)
+    __shared__ uint32_t rwin[CWAVES][2][RWORDS + 2];      // packed read window of the wave (+ N plane)
+    __shared__ ActScratch act[CWAVES];
+    const int pi = block_problem<MAXP>(B);
     const ConsParams P = B.p[pi];
+    const ConsCtrl c = *P.ctrl;
+    if (c.done || (c.n == 0 && !c.init)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lead = (int)blockIdx.x == P.first_block;
-    const int r = ((int)blockIdx.x - P.first_block) * CWAVES + wave;
-    const size_t g = (size_t)P.first + r;                     // slot in the flattened state arrays (padding slots exist in memory)
-    // everything this wave will need from memory that does not depend on the decision is requested up front
-    const ReadInfo ri = B.info[g];
-    const bool second = P.allow_dual != 0;                   // problems that cannot split never touch the second state
-    const ConsMeta m0 = B.meta[g];
-    ConsMeta m1; m1.e = 0; m1.c0 = 0; m1.flags = 0; m1.pad = 0;
-    if (second) m1 = B.meta[(size_t)B.total + g];
-    const int h0 = h_load(B.H, g * CB + lane), h1 = second ? h_load(B.H, ((size_t)B.total + g) * CB + lane) : SP_NEG;
-    ConsCtrl cin;
-    Decision dec;
-    if (t >= 0) {
-        cin = P.ctrl[t & 1];
-        if (cin.done) { if (lead && threadIdx.x == 0) P.ctrl[(t + 1) & 1] = cin; return; }
-        dec = decide(P, cin, t, lane);
-    } else {
-        cin = P.ctrl[0];
-        dec.go[0] = dec.go[1] = 0; dec.base[0] = dec.base[1] = 0; dec.split = 0; dec.best_w2 = 0; dec.best_total = 1; dec.split_w2 = 0; dec.split_total = 1;
-    }
-    const int dual = (t >= 0) && (cin.dual || dec.split);
-    const int split_at = dec.split ? t : cin.split_at;
-    if (threadIdx.x < 16) lv[threadIdx.x >> 3][threadIdx.x & 7] = 0;
-    if (t >= 0 && lead && threadIdx.x == 0) {
-        ConsCtrl co = cin;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (dec.go[i]) { P.C[(size_t)i * P.cap + t] = (uint8_t)dec.base[i]; co.len[i] = t + 1; co.stopped[i] = 0; }
-            else if (i == 0 || cin.dual) co.stopped[i] = 1;
+    const int T = c.T, n = c.n;
+    const int dual_in = c.dual;                           // the kept state has two consensuses
+    const int dual = c.dual || c.split_now;               // the window runs two
+    const int split_at = c.split_now ? T : c.split_at;
+    for (int x = threadIdx.x; x < 2 * (CW + 1); x += blockDim.x) { (&lv[0][0])[x] = 0; (&le[0][0])[x] = 0; }
+    for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) (&ll[0][0])[x] = 0;
+    // the consensus in front of the window and the window itself
+    const int w0 = T - CWIN;
+    for (int x = threadIdx.x; x < 2 * (CWIN + CW); x += blockDim.x) {
+        const int i = x / (CWIN + CW), y = x % (CWIN + CW), pos = w0 + y;
+        uint8_t v = 0;
+        if (i == 0 || dual) {
+            if (pos >= T) v = (pos - T < n) ? P.ctrl->spec[i][pos - T] : 0;
+            else if (pos >= 0) v = (i == 1 && pos < split_at) ? P.C[pos] : P.C[(size_t)i * P.cap + pos];
         }
-        co.dual = dual; co.split_at = split_at; co.best_w2 = dec.best_w2; co.best_total = dec.best_total;
-        co.split_w2 = dec.split_w2; co.split_total = dec.split_total;
-        co.done = !(dec.go[0] || dec.go[1]);
-        P.ctrl[(t + 1) & 1] = co;
+        cwin[i][y] = v;
     }
     __syncthreads();
-    if (r < P.n) {
+    const size_t in_buf = (size_t)c.state_buf, out_buf = in_buf ^ 1;
+    const size_t plane = (size_t)B.total;                 // state layout [buffer][consensus][flattened read]
+    for (int rr = 0; rr < P.rpw; ++rr) {
+        const int r = (((int)blockIdx.x - P.first_block) * CWAVES + wave) * P.rpw + rr;
+        if (r >= P.n) break;
+        const size_t g = (size_t)P.first + r;
+        const ReadInfo ri = B.info[g];
         ReadView rv; rv.w = ri.w; rv.np = ri.np; rv.n = ri.n;
-        ConsView cv; cv.C = P.C; cv.cap = P.cap; cv.split_at = split_at; cv.t = t; cv.base0 = dec.base[0]; cv.base1 = dec.base[1];
         Dwfa d[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { d[i].H = SP_NEG; d[i].e = 0; d[i].c0 = 0; d[i].flags = 0; }
-        if (t < 0) {
+        if (c.init) {
             if (ri.off < 0) { d[0].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0); d[0].H = lane == CH ? 0 : SP_NEG; }
         } else {
-            d[0].H = h0; d[0].e = m0.e; d[0].c0 = m0.c0; d[0].flags = m0.flags;
-            if (dec.split) d[1] = d[0];
-            else if (cin.dual) { d[1].H = h1; d[1].e = m1.e; d[1].c0 = m1.c0; d[1].flags = m1.flags; }
+            const ConsMeta m0 = B.meta[(in_buf * 2 + 0) * plane + g];
+            d[0].H = h_load(B.H, ((in_buf * 2 + 0) * plane + g) * CB + lane); d[0].e = m0.e; d[0].c0 = m0.c0; d[0].flags = m0.flags;
+            if (c.split_now) d[1] = d[0];
+            else if (dual_in) {
+                const ConsMeta m1 = B.meta[(in_buf * 2 + 1) * plane + g];
+                d[1].H = h_load(B.H, ((in_buf * 2 + 1) * plane + g) * CB + lane); d[1].e = m1.e; d[1].c0 = m1.c0; d[1].flags = m1.flags;
+            }
+        }
+        // the stretch of the read around its tips: read position of diagonal 0 at column T minus the band, 384 bases from there
+        int rbase = 0;
+        {
+            int lo = 0x7FFFFFFF;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) if ((i == 0 || dual) && (d[i].flags & F_ACTIVE)) { const int x = T - d[i].c0 - CB; lo = x < lo ? x : lo; }
+            if (lo == 0x7FFFFFFF || lo < 0) lo = 0;
+            rbase = (lo >> 4) << 4;
+            const int w_first = rbase >> 4, w_last = (rv.n + 15) >> 4;          // words [w_first, w_last] exist (guard words follow the sequence)
+            if (lane < RWORDS + 2) {
+                const int w = w_first + lane;
+                rwin[wave][0][lane] = w <= w_last + 1 ? rv.w[w] : 0u;
+                rwin[wave][1][lane] = (rv.np && w <= w_last + 1) ? rv.np[w] : 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        auto rb = [&](int h) -> int {
+            const int x = h - rbase;
+            if ((unsigned)x < (unsigned)(RWORDS * 16)) {
+                const uint32_t sh = (uint32_t)(x & 15) << 1;
+                if ((rwin[wave][1][x >> 4] >> sh) & 1u) return 4;
+                return (int)((rwin[wave][0][x >> 4] >> sh) & 3u);
+            }
+            return read_base(rv, h);
+        };
+        auto ca_of = [&](int i) {
+            return [&, i](int pos) -> int {
+                const int y = pos - w0;
+                if ((unsigned)y < (unsigned)(CWIN + CW)) return (int)cwin[i][y];
+                return (int)((i == 1 && pos < split_at) ? P.C[pos] : P.C[(size_t)i * P.cap + pos]);
+            };
+        };
+        // votes of the state for the column it stands at (after j pushes), into the workgroup's tallies
+        auto vote = [&](int j) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if (i == 1 && !dual) continue;
-                if (!dec.go[i]) continue;
-                const int len = t + 1;
-                // (a read whose offset equals len is placed by cons_activate_kernel, launched right after this step)
-                if ((d[i].flags & F_ACTIVE) && !(d[i].flags & (F_FINISHED | F_LOST))) dwfa_push(d[i], rv, cv, i, len - d[i].c0, dec.base[i], P.et, lane);
+                if (!c.init && !c.go[i]) continue;
+                if (!(d[i].flags & F_ACTIVE) || (d[i].flags & (F_FINISHED | F_LOST))) continue;
+                if (dual) { const Dwfa& o = d[1 - i]; if ((o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < d[i].e) continue; }
+                const int Tl = T + j - d[i].c0, k = lane - CH;
+                const bool tip = d[i].H >= 0 && d[i].H + k == Tl;
+                const int code = (tip && d[i].H < rv.n) ? rb(d[i].H) : 5;
+                int dc = 0; unsigned long long word = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const bool s = __ballot(code == b) != 0; dc += s; word |= s ? (1ull << (16 * b)) : 0ull; }
+                const bool ended = __ballot(tip) != 0 && __ballot(code == 4) == 0;      // every tip sits at the end of the read
+                if (lane == 0) {
+                    if (dc) atomicAdd(&lv[i][j], word * vote_units(dc));
+                    else if (ended) atomicAdd(&le[i][j], 12u);
+                }
+            }
+        };
+        if (c.init) vote(0);
+        for (int j = 0; j < n; ++j) {
+            const int len = T + j + 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !dual) continue;
+                if (!c.go[i]) continue;
+                const int nb = cwin[i][CWIN + j];
+                if (d[i].flags & F_ACTIVE) {
+                    if (!(d[i].flags & (F_FINISHED | F_LOST))) dwfa_push_t(d[i], rv.n, rb, ca_of(i), len - d[i].c0, nb, P.et, lane);
+                } else if (ri.off == len) {
+                    // a late read (add_sequence_offset): start search in the window before the offset, then catch up
+                    auto ca = ca_of(i);
+                    ActScratch& A = act[wave];
+                    const int ws = ri.off - P.window > 0 ? ri.off - P.window : 0;
+                    for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) A.rcache[x] = (uint8_t)read_base(rv, x);
+                    spw::wave_lds_sync();
+                    auto rbc = [&](int h) { return h < ACT_READ ? (int)A.rcache[h] : read_base(rv, h); };
+                    d[i].c0 = find_start(rv.n, rbc, ca, ri.off, P.window, P.cmp_len, lane);
+                    d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
+                    const int c0 = d[i].c0, span = len - c0, cwinlen = len - ws;
+                    const bool packed = rv.np == nullptr && cwinlen <= ACT_CONS;
+                    if (span > 0 && !(d[i].flags & F_FINISHED) && !(P.et && rv.n <= span + CB) && packed) {
+                        // 16 bases per step out of 2-bit packed copies of the two windows
+                        for (int w = lane; w < ACT_CONS / 16 + 2; w += SP_WAVE) {
+                            uint32_t word = 0;
+                            for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < cwinlen) word |= (uint32_t)(ca(ws + x) & 3) << (b << 1); }
+                            A.cpack[w] = word;
+                        }
+                        const int rwords = ((rv.n < ACT_READ ? rv.n : ACT_READ) + 15) >> 4;
+                        for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) A.rpack[w] = w < rwords ? rv.w[w] : 0u;
+                        spw::wave_lds_sync();
+                        const int kk = lane - CH, cbase = c0 - ws;
+                        dwfa_catchup_t(d[i], rv.n, [&]() {
+                            for (;;) {
+                                Dwfa& q = d[i];
+                                int left = rv.n - q.H; { const int l2 = span - (q.H + kk); left = l2 < left ? l2 : left; }
+                                const bool go = q.H >= 0 && left > 0;
+                                int nm = 0;
+                                if (go) {
+                                    const int pr = q.H, pc = cbase + q.H + kk;
+                                    const uint32_t a = __builtin_amdgcn_alignbit(A.rpack[(pr >> 4) + 1], A.rpack[pr >> 4], (uint32_t)(pr & 15) << 1);
+                                    const uint32_t b = __builtin_amdgcn_alignbit(A.cpack[(pc >> 4) + 1], A.cpack[pc >> 4], (uint32_t)(pc & 15) << 1);
+                                    const uint32_t x = a ^ b, mm = (x | (x >> 1)) & 0x55555555u;
+                                    nm = mm ? (__builtin_ctz(mm) >> 1) : 16;
+                                    nm = nm < left ? nm : left;
+                                    q.H += nm;
+                                }
+                                if (!__ballot(go && nm == 16 && left > 16)) break;
+                            }
+                        }, span, lane);
+                    } else if (span > 0 && !(d[i].flags & F_FINISHED) && !(P.et && rv.n <= span + CB)) {
+                        const int kk = lane - CH;
+                        dwfa_catchup_t(d[i], rv.n, [&]() {
+                            for (;;) {
+                                Dwfa& q = d[i];
+                                bool go = q.H >= 0 && q.H < rv.n && q.H + kk < span;
+                                if (go) { const int x = rbc(q.H); go = x < 4 && x == ca(q.c0 + q.H + kk); }
+                                if (!__ballot(go)) break;
+                                if (go) q.H += 1;
+                            }
+                        }, span, lane);
+                    } else {
+                        for (int Tl = 1; Tl <= span; ++Tl) {
+                            if (d[i].flags & (F_FINISHED | F_LOST)) break;
+                            dwfa_push_t(d[i], rv.n, rbc, ca, Tl, ca(c0 + Tl - 1), P.et, lane);
+                        }
+                    }
+                    spw::wave_lds_sync();
+                }
             }
             if (dual) {
                 const int both = (d[0].flags & F_ACTIVE) && (d[1].flags & F_ACTIVE) && !(d[0].flags & F_LOST) && !(d[1].flags & F_LOST);
@@ -305,185 +404,178 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
                     else if (d[1].e > d[0].e + P.delta) d[1].flags |= F_LOST;
                 }
             }
+            vote(j + 1);
         }
-        // votes for position t+1
+        // lookahead: the bases behind every tip (at most two tips per consensus speak) predict the columns after the window
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (i == 1 && !dual) continue;
-            if (t >= 0 && !dec.go[i]) continue;
+            if (!c.init && !c.go[i]) continue;
             if (!(d[i].flags & F_ACTIVE) || (d[i].flags & (F_FINISHED | F_LOST))) continue;
             if (dual) { const Dwfa& o = d[1 - i]; if ((o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < d[i].e) continue; }
-            const int T = t + 1 - d[i].c0, k = lane - CH;
-            const bool tip = d[i].H >= 0 && d[i].H + k == T;
-            const int code = (tip && d[i].H < rv.n) ? read_base(rv, d[i].H) : 5;
-            int seen[4], dc = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { seen[b] = __ballot(code == b) != 0; dc += seen[b]; }
-            const bool ended = __ballot(tip) != 0 && __ballot(code == 4) == 0;      // every tip sits at the end of the read
-            if (lane == 0) {
-                if (dc) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) if (seen[b]) atomicAdd(&lv[i][b], vote_units(dc));
+            const int Tl = T + n - d[i].c0, k = lane - CH;
+            unsigned long long tips = __ballot(d[i].H >= 0 && d[i].H + k == Tl && d[i].H < rv.n);
+            for (int cnt = 0; tips && cnt < 2; ++cnt) {
+                const int tl = __builtin_ctzll(tips); tips &= tips - 1;
+                const int h = __builtin_amdgcn_readlane(d[i].H, tl);
+                if (lane < CW - 1 && h + 1 + lane < rv.n) {
+                    const int b = rb(h + 1 + lane);
+                    if (b < 4) atomicAdd(&ll[i][lane], 1ull << (16 * b));
                 }
-                else if (ended) atomicAdd(&lv[i][4], 12u);
             }
         }
-        // store
+        // the new state goes to the other buffer
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (i == 1 && !dual) continue;
-            if (lane == 0) { ConsMeta m; m.e = d[i].e; m.c0 = d[i].c0; m.flags = d[i].flags; m.pad = 0; B.meta[(size_t)i * B.total + g] = m; }
-            h_store(B.H, ((size_t)i * B.total + g) * CB + lane, d[i].H);
+            if (lane == 0) { ConsMeta m; m.e = d[i].e; m.c0 = d[i].c0; m.flags = d[i].flags; m.pad = 0; B.meta[(out_buf * 2 + i) * plane + g] = m; }
+            h_store(B.H, ((out_buf * 2 + i) * plane + g) * CB + lane, d[i].H);
+        }
+        spw::wave_lds_sync();
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < 2 * (CW + 1); x += blockDim.x) {
+        B.PV[(size_t)blockIdx.x * 2 * (CW + 1) + x] = (&lv[0][0])[x];
+        B.PE[(size_t)blockIdx.x * 2 * (CW + 1) + x] = (&le[0][0])[x];
+    }
+    for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) B.PL[(size_t)blockIdx.x * 2 * CW + x] = (&ll[0][0])[x];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// the control step: one workgroup per problem sums the vote words of the problem's workgroups, verifies the window and sets up
+// the next one
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int MAXP>
+__global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) {
+    __shared__ uint32_t sv[2][CW + 1][5];                 // summed exact votes: w[4], end
+    __shared__ uint32_t sl[2][CW][4];                     // summed lookahead votes
+    __shared__ ConsCtrl cs;
+    const int pi = blockIdx.x;
+    const ConsParams P = B.p[pi];
+    if (threadIdx.x == 0) cs = *P.ctrl;
+    for (int x = threadIdx.x; x < 2 * (CW + 1) * 5; x += blockDim.x) (&sv[0][0][0])[x] = 0;
+    for (int x = threadIdx.x; x < 2 * CW * 4; x += blockDim.x) (&sl[0][0][0])[x] = 0;
+    __syncthreads();
+    if (cs.done || (cs.n == 0 && !cs.init)) return;
+    const int n = cs.n;
+    {
+        // element e of a workgroup's partial block: e < 2 (CW + 1): exact votes (V + E); then 2 CW lookahead words
+        const int EV = 2 * (CW + 1), EL = 2 * CW, E = EV + EL;
+        const int per = blockDim.x / E > 0 ? blockDim.x / E : 1;
+        const int e = threadIdx.x % E, sub = threadIdx.x / E;
+        if (sub < per) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+            const bool is_v = e < EV;
+            const int j = is_v ? e % (CW + 1) : (e - EV) % CW;
+            const bool wanted = is_v ? j <= n : true;
+            if (wanted) for (int b = sub; b < P.n_blocks; b += per) {
+                const size_t blk = (size_t)P.first_block + b;
+                if (is_v) {
+                    const unsigned long long v = B.PV[blk * EV + e];
+                    a0 += (uint32_t)(v & 0xFFFF); a1 += (uint32_t)((v >> 16) & 0xFFFF); a2 += (uint32_t)((v >> 32) & 0xFFFF); a3 += (uint32_t)(v >> 48);
+                    a4 += B.PE[blk * EV + e];
+                } else {
+                    const unsigned long long v = B.PL[blk * EL + (e - EV)];
+                    a0 += (uint32_t)(v & 0xFFFF); a1 += (uint32_t)((v >> 16) & 0xFFFF); a2 += (uint32_t)((v >> 32) & 0xFFFF); a3 += (uint32_t)(v >> 48);
+                }
+            }
+            if (is_v) { uint32_t* d = &sv[e / (CW + 1)][j][0]; atomicAdd(d, a0); atomicAdd(d + 1, a1); atomicAdd(d + 2, a2); atomicAdd(d + 3, a3); atomicAdd(d + 4, a4); }
+            else { uint32_t* d = &sl[(e - EV) / CW][j][0]; atomicAdd(d, a0); atomicAdd(d + 1, a1); atomicAdd(d + 2, a2); atomicAdd(d + 3, a3); }
         }
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        const int i = threadIdx.x >> 3, j = threadIdx.x & 7;
-        const uint32_t v = lv[i][j];
-        if (v && t + 1 <= P.cap) atomicAdd(P.votes + (((size_t)i * (P.cap + 1) + (t + 1)) * CSLOTS + (blockIdx.x & (CSLOTS - 1))) * CSTRIDE + j, v);
-    }
-}
-
-// Late reads (add_sequence_offset): the reads whose offset equals the length the consensus reached in step t are placed by
-// this kernel, launched right after that step (the host knows the offsets, so it knows when to launch it): start search in the
-// window before the offset, catch-up pushes, dual bookkeeping and the read's vote for position t+1.
-struct ActItem { int prob, r; };
-
-constexpr int ACT_CONS = 512;   // consensus bases a wave keeps in LDS while a late read catches up (offset_window + slack)
-constexpr int ACT_READ = 640;   // read bases it keeps (catch-up length + band + edits)
-
-template <int MAXP>
-__global__ void __launch_bounds__(4 * SP_WAVE) cons_activate_kernel(ConsBatchT<MAXP> B, int t, const ActItem* __restrict__ items, int n_items) {
-    __shared__ uint8_t ccache[4][ACT_CONS];
-    __shared__ uint8_t rcache[4][ACT_READ];
-    // the same two windows 2 bits per base (16 bases per dword, two guard words): the catch-up compares 16 bases per step out of them
-    __shared__ uint32_t cpack[4][ACT_CONS / 16 + 2];
-    __shared__ uint32_t rpack[4][ACT_READ / 16 + 2];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, it = blockIdx.x * 4 + wv;
-    if (it >= n_items) return;
-    const ActItem item = items[it];
-    int pi = 0;
-    if constexpr (MAXP == 0) pi = item.prob;
-    else {
+    if (threadIdx.x >= SP_WAVE) return;
+    const int lane = threadIdx.x;
+    const int dual = cs.dual || cs.split_now;
+    const int T = cs.T;
+    // the decision the complete votes make for the column after j pushes, per consensus
+    auto decide = [&](int i, int j, int& base, int& b2, uint32_t& w2, uint32_t& total) -> bool {
+        ColVotes v; for (int b = 0; b < 4; ++b) v.w[b] = sv[i][j][b]; v.end = sv[i][j][4];
+        int b1; uint32_t w1; top2(v, b1, w1, b2, w2, total);
+        base = b1;
+        if (T + j >= P.cap) return false;                                               // out of room: the consensus is cut at cap
+        return P.et ? w1 > 0 : (total > v.end && w1 > 0);
+    };
+    // 1. how much of the window stands: lane j checks the base pushed as number j (1 <= j < n) against the votes after j pushes
+    int a = n;
+    uint32_t my_w2 = 0, my_total = 1; bool my_cand = false;
+    if (!cs.replay && n > 1) {
+        bool ok = true;
+        if (lane >= 1 && lane < n) {
 #pragma unroll
-        for (int i = 1; i < MAXP; ++i) if (i == item.prob) pi = i;
-    }
-    const ConsParams P = B.p[pi];
-    const size_t g = (size_t)P.first + item.r;
-    const ReadInfo ri = B.info[g];
-    const ConsCtrl c = P.ctrl[(t + 1) & 1];                    // state after step t
-    ReadView rv; rv.w = ri.w; rv.np = ri.np; rv.n = ri.n;
-    ConsView cv; cv.C = P.C; cv.cap = P.cap; cv.split_at = c.split_at; cv.t = -1; cv.base0 = cv.base1 = 0;   // position t is in memory by now
-    const int len = t + 1;
-    Dwfa d[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const ConsMeta m = B.meta[(size_t)i * B.total + g];
-        d[i].H = h_load(B.H, ((size_t)i * B.total + g) * CB + lane); d[i].e = m.e; d[i].c0 = m.c0; d[i].flags = (i == 1 && !c.dual) ? 0 : m.flags;
-    }
-    int placed[2] = { 0, 0 };
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (i == 1 && !c.dual) continue;
-        if (c.len[i] != len || c.stopped[i] || (d[i].flags & F_ACTIVE) || ri.off != len) continue;
-        placed[i] = 1;
-        // the window in front of the offset and the head of the read go to LDS once: both the start search and the catch-up run out of it
-        const int ws = ri.off - P.window > 0 ? ri.off - P.window : 0;
-        for (int x = lane; x < len - ws && x < ACT_CONS; x += SP_WAVE) ccache[wv][x] = (uint8_t)cv.at(i, ws + x);
-        for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) rcache[wv][x] = (uint8_t)read_base(rv, x);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // packed copies: the consensus window from its byte codes (a lane packs 16 of them), the read words straight from memory
-        const int cwin = len - ws;
-        const bool packed = rv.np == nullptr && cwin <= ACT_CONS;
-        if (packed) {
-            for (int w = lane; w < ACT_CONS / 16 + 2; w += SP_WAVE) {
-                uint32_t word = 0;
-                for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < cwin) word |= (uint32_t)(ccache[wv][x] & 3u) << (b << 1); }
-                cpack[wv][w] = word;
-            }
-            const int rwords = ((rv.n < ACT_READ ? rv.n : ACT_READ) + 15) >> 4;
-            for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) rpack[wv][w] = w < rwords ? rv.w[w] : 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        auto rb = [&](int h) { return h < ACT_READ ? (int)rcache[wv][h] : read_base(rv, h); };
-        auto ca = [&](int pos) { const int x = pos - ws; return (x >= 0 && x < ACT_CONS) ? (int)ccache[wv][x] : cv.at(i, pos); };
-        ReadView rvc = rv;
-        d[i].c0 = find_start(rvc, ca, ri.off, P.window, P.cmp_len, lane);
-        d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
-        const int c0 = d[i].c0, span = len - c0;
-        if (span > 0 && !(d[i].flags & F_FINISHED) && !(P.et && rv.n <= span + CB)) {
-            const int kk = lane - CH;
-            if (packed) {
-                // 16 bases per step: xor of the two funnel-shifted words, first differing base, clamped by what is left of the read and
-                // of the span (H <= span + 32 < ACT_READ - 16 and the consensus window starts at or before c0: every word is cached)
-                const int cbase = c0 - ws;
-                dwfa_catchup_t(d[i], rv.n, [&]() {
-                    for (;;) {
-                        Dwfa& q = d[i];
-                        int left = rv.n - q.H; { const int l2 = span - (q.H + kk); left = l2 < left ? l2 : left; }
-                        const bool go = q.H >= 0 && left > 0;
-                        int nm = 0;
-                        if (go) {
-                            const int pr = q.H, pc = cbase + q.H + kk;
-                            const uint32_t a = __builtin_amdgcn_alignbit(rpack[wv][(pr >> 4) + 1], rpack[wv][pr >> 4], (uint32_t)(pr & 15) << 1);
-                            const uint32_t b = __builtin_amdgcn_alignbit(cpack[wv][(pc >> 4) + 1], cpack[wv][pc >> 4], (uint32_t)(pc & 15) << 1);
-                            const uint32_t x = a ^ b, mm = (x | (x >> 1)) & 0x55555555u;
-                            nm = mm ? (__builtin_ctz(mm) >> 1) : 16;
-                            nm = nm < left ? nm : left;
-                            q.H += nm;
-                        }
-                        if (!__ballot(go && nm == 16 && left > 16)) break;
-                    }
-                }, span, lane);
-            } else {
-                dwfa_catchup_t(d[i], rv.n, [&]() {
-                    for (;;) {
-                        Dwfa& q = d[i];
-                        bool go = q.H >= 0 && q.H < rv.n && q.H + kk < span;
-                        if (go) { const int x = rb(q.H); go = x < 4 && x == ca(q.c0 + q.H + kk); }
-                        if (!__ballot(go)) break;
-                        if (go) q.H += 1;
-                    }
-                }, span, lane);
-            }
-        } else {
-            for (int T = 1; T <= span; ++T) {
-                if (d[i].flags & (F_FINISHED | F_LOST)) break;
-                dwfa_push_t(d[i], rv.n, rb, ca, T, ca(c0 + T - 1), P.et, lane);
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !dual) continue;
+                if (!cs.go[i]) continue;
+                int base, b2; uint32_t w2, total;
+                const bool go = decide(i, lane, base, b2, w2, total);
+                if (!go || base != cs.spec[i][lane]) ok = false;
+                if (!dual && i == 0 && go && w2 >= 12u * (uint32_t)P.min_count) {
+                    my_cand = true; my_w2 = w2; my_total = total;
+                    if (P.allow_dual && (double)w2 >= P.min_af * (double)total) ok = false;       // a split is an event: it opens a window
+                }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        const unsigned long long bad = __ballot(!ok);
+        if (bad) a = __builtin_ctzll(bad);
     }
-    if (!placed[0] && !placed[1]) return;
-    if (c.dual) {
-        const int both = (d[0].flags & F_ACTIVE) && (d[1].flags & F_ACTIVE) && !(d[0].flags & F_LOST) && !(d[1].flags & F_LOST);
-        if (both) {
-            if (d[0].e > d[1].e + P.delta) d[0].flags |= F_LOST;
-            else if (d[1].e > d[0].e + P.delta) d[1].flags |= F_LOST;
+    // strongest second-base column among the accepted ones, in column order (a strictly better ratio replaces)
+    if (!dual && !cs.replay) {
+        unsigned long long cand = __ballot(my_cand && lane < a);
+        while (cand) {
+            const int l = __builtin_ctzll(cand); cand &= cand - 1;
+            const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)my_w2, l), tot = (uint32_t)__builtin_amdgcn_readlane((int)my_total, l);
+            if (lane == 0 && (unsigned long long)w2 * (unsigned long long)cs.best_total > (unsigned long long)cs.best_w2 * (unsigned long long)tot) { cs.best_w2 = w2; cs.best_total = tot; }
         }
     }
+    // 2. commit the accepted bases
+    if (lane < a) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (!placed[i]) continue;
-        if (lane == 0) { ConsMeta m; m.e = d[i].e; m.c0 = d[i].c0; m.flags = d[i].flags; m.pad = 0; B.meta[(size_t)i * B.total + g] = m; }
-        h_store(B.H, ((size_t)i * B.total + g) * CB + lane, d[i].H);
-        if (d[i].flags & (F_FINISHED | F_LOST)) continue;
-        if (c.dual) { const Dwfa& o = d[1 - i]; if ((o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < d[i].e) continue; }
-        const int T = len - d[i].c0, k = lane - CH;
-        const bool tip = d[i].H >= 0 && d[i].H + k == T;
-        const int code = (tip && d[i].H < rv.n) ? read_base(rv, d[i].H) : 5;
-        int seen[4], dc = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { seen[b] = __ballot(code == b) != 0; dc += seen[b]; }
-        const bool ended = __ballot(tip) != 0 && __ballot(code == 4) == 0;
-        if (lane == 0 && len <= P.cap) {
-            uint32_t* v = P.votes + (((size_t)i * (P.cap + 1) + len) * CSLOTS + (blockIdx.x & (CSLOTS - 1))) * CSTRIDE;
-            if (dc) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) if (seen[b]) atomicAdd(v + b, vote_units(dc));
-            } else if (ended) atomicAdd(v + 4, 12u);
+        for (int i = 0; i < 2; ++i) if ((i == 0 || dual) && cs.go[i]) P.C[(size_t)i * P.cap + T + lane] = cs.spec[i][lane];
+    }
+    if (lane != 0) return;
+    cs.windows += 1;
+    for (int i = 0; i < 2; ++i) if ((i == 0 || dual) && cs.go[i] && a > 0) cs.len[i] = T + a;
+    if (a < n) {                                          // cut window: push the verified bases again, from the kept state
+        cs.n = a; cs.replay = 1; cs.cut_windows += 1;
+        *P.ctrl = cs;
+        return;
+    }
+    // 3. the whole window stands: the new state is the other buffer; decide the column it stands at and speculate on
+    cs.T = T + n; cs.state_buf ^= 1; cs.replay = 0; cs.init = 0;
+    if (cs.split_now) { cs.dual = 1; cs.split_at = T; cs.split_now = 0; }
+    const int nd = cs.dual ? 2 : 1;
+    int going = 0;
+    for (int i = 0; i < 2; ++i) cs.go[i] = 0;
+    for (int i = 0; i < nd; ++i) {
+        if (cs.stopped[i]) continue;
+        int base, b2; uint32_t w2, total;
+        const bool go = decide(i, n, base, b2, w2, total);
+        if (!go) { cs.stopped[i] = 1; continue; }
+        cs.go[i] = 1; cs.spec[i][0] = (uint8_t)base; going += 1;
+        if (!cs.dual && w2 >= 12u * (uint32_t)P.min_count) {
+            if ((unsigned long long)w2 * (unsigned long long)cs.best_total > (unsigned long long)cs.best_w2 * (unsigned long long)total) { cs.best_w2 = w2; cs.best_total = total; }
+            if (P.allow_dual && (double)w2 >= P.min_af * (double)total) {
+                cs.split_now = 1; cs.go[1] = 1; cs.stopped[1] = 0; cs.spec[1][0] = (uint8_t)b2; cs.split_w2 = w2; cs.split_total = total;
+            }
         }
     }
+    if (!going) { cs.done = 1; cs.n = 0; *P.ctrl = cs; return; }
+    int nn = 1;
+    if (!cs.split_now) {
+        for (; nn < CW && cs.T + nn < P.cap; ++nn) {
+            bool have = true;
+            for (int i = 0; i < nd && have; ++i) {
+                if (!cs.go[i]) continue;
+                const uint32_t* w = sl[i][nn - 1];
+                int b1 = 0; uint32_t w1 = w[0];
+                for (int b = 1; b < 4; ++b) if (w[b] > w1) { b1 = b; w1 = w[b]; }
+                if (w1 == 0) have = false; else cs.spec[i][nn] = (uint8_t)b1;
+            }
+            if (!have) break;
+        }
+    }
+    cs.n = nn;
+    *P.ctrl = cs;
 }
 
 // gathers the per-read constants of one problem into the flattened ReadInfo array (once per batch)
@@ -499,45 +591,44 @@ __global__ void cons_setup_kernel(ConsSetup S, ReadInfo* __restrict__ info) {
 }
 
 template <int MAXP>
-__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBatchT<MAXP> B, int which, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
-    int pi = 0;
-    if constexpr (MAXP == 0) pi = B.block_prob[blockIdx.x];
-    else {
-#pragma unroll
-        for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
-    }
+__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBatchT<MAXP> B, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
+    const int pi = block_problem<MAXP>(B);
     const ConsParams P = B.p[pi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = ((int)blockIdx.x - P.first_block) * CWAVES + wave;
-    if (r >= P.n) return;
-    const size_t g = (size_t)P.first + r;
-    const ConsCtrl c = P.ctrl[which];
-    const int n = B.info[g].n;
-    int sc[2] = { -1, -1 };
+    const ConsCtrl c = *P.ctrl;
+    const size_t buf = (size_t)c.state_buf, plane = (size_t)B.total;
+    for (int rr = 0; rr < P.rpw; ++rr) {
+        const int r = (((int)blockIdx.x - P.first_block) * CWAVES + wave) * P.rpw + rr;
+        if (r >= P.n) break;
+        const size_t g = (size_t)P.first + r;
+        const int n = B.info[g].n;
+        int sc[2] = { -1, -1 };
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (i == 1 && !c.dual) continue;
-        const ConsMeta m = B.meta[(size_t)i * B.total + g];
-        if (!(m.flags & F_ACTIVE) || (m.flags & F_LOST)) continue;
-        int e = m.e;
-        if (!P.et) {
-            const int h = h_load(B.H, ((size_t)i * B.total + g) * CB + lane), k = lane - CH;
-            int rest = (h >= 0 && h + k == c.len[i] - m.c0) ? n - h : (1 << 30);
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && !c.dual) continue;
+            const ConsMeta m = B.meta[(buf * 2 + i) * plane + g];
+            if (!(m.flags & F_ACTIVE) || (m.flags & F_LOST)) continue;
+            int e = m.e;
+            if (!P.et) {
+                const int h = h_load(B.H, ((buf * 2 + i) * plane + g) * CB + lane), k = lane - CH;
+                int rest = (h >= 0 && h + k == c.len[i] - m.c0) ? n - h : (1 << 30);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(rest, o); rest = other < rest ? other : rest; }
-            if (rest < (1 << 30)) e += rest;
+                for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(rest, o); rest = other < rest ? other : rest; }
+                if (rest < (1 << 30)) e += rest;
+            }
+            sc[i] = e;
         }
-        sc[i] = e;
-    }
-    if (lane == 0) {
-        score1[g] = sc[0]; score2[g] = sc[1];
-        is_cons1[g] = !(sc[1] >= 0 && (sc[0] < 0 || sc[1] < sc[0]));
+        if (lane == 0) {
+            score1[g] = sc[0]; score2[g] = sc[1];
+            is_cons1[g] = !(sc[1] >= 0 && (sc[0] < 0 || sc[1] < sc[0]));
+        }
     }
 }
 
 } // namespace
 
-// host side of a batch of at most CMAXP problems: all of them advance one base per launch until every one has stopped
+// host side of a batch of at most CMAXP problems (or any number with the descriptors in device memory): all of them advance one
+// window per launch pair until every one has stopped
 template <int MAXP>
 static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* probs, sp_cons_output* outs) {
     hipStream_t st = ctx->stream;
@@ -547,8 +638,8 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     std::vector<int> block_prob;
     std::vector<ConsSetup> setup(n_prob);
     std::vector<uint32_t> h_idx; std::vector<int32_t> h_off;
-    std::vector<size_t> idx_at(n_prob), off_at(n_prob), c_at(n_prob), v_at(n_prob);
-    size_t total = 0, c_bytes = 0, v_words = 0; int max_cap = 0, n_blocks = 0;
+    std::vector<size_t> idx_at(n_prob), off_at(n_prob), c_at(n_prob);
+    size_t total = 0, c_bytes = 0; int max_cap = 0, n_blocks = 0;
     for (uint32_t p = 0; p < n_prob; ++p) {
         const sp_cons_problem& q = probs[p];
         const uint32_t n = q.read_idx ? q.n : q.reads->n;
@@ -557,44 +648,40 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         P.first = (int)total; P.first_block = n_blocks;
         P.min_count = q.cfg.min_count; P.delta = q.cfg.dual_max_ed_delta; P.et = q.cfg.allow_early_termination != 0; P.allow_dual = q.cfg.allow_dual != 0;
         P.window = q.cfg.offset_window; P.cmp_len = q.cfg.offset_compare_length; P.min_af = q.cfg.min_af;
-        const uint32_t nb = (n + CWAVES - 1) / CWAVES;
+        P.rpw = n > 16384 ? 4 : n > 4096 ? 2 : 1;                                     // large problems: several reads per wave (fewer vote words to sum)
+        const uint32_t per_block = (uint32_t)(CWAVES * P.rpw);
+        const uint32_t nb = (n + per_block - 1) / per_block;
+        P.n_blocks = (int)nb;
         n_blocks += (int)nb;
         if (MAXP == 0) block_prob.insert(block_prob.end(), nb, (int)p);
         setup[p].reads = q.reads->view(); setup[p].n = (int)n; setup[p].first = (int)total;
-        total += (size_t)nb * CWAVES;
+        total += (size_t)nb * per_block;
         idx_at[p] = h_idx.size(); if (q.read_idx) h_idx.insert(h_idx.end(), q.read_idx, q.read_idx + n);
         off_at[p] = h_off.size(); if (q.offsets) h_off.insert(h_off.end(), q.offsets, q.offsets + n);
         c_at[p] = c_bytes; c_bytes += 2 * (size_t)std::max(P.cap, 1);
-        v_at[p] = v_words; v_words += (size_t)2 * (P.cap + 1) * CSLOTS * CSTRIDE;
         max_cap = std::max(max_cap, P.cap);
     }
     if (n_blocks == 0) return SP_OK;
-    // late reads, ordered by the step that places them
-    std::vector<std::pair<int, ActItem>> late;
-    for (uint32_t p = 0; p < n_prob; ++p) if (probs[p].offsets)
-        for (int r = 0; r < hp[p].n; ++r) if (probs[p].offsets[r] >= 1) late.push_back({ probs[p].offsets[r], ActItem{ (int)p, r } });
-    std::stable_sort(late.begin(), late.end(), [](const std::pair<int, ActItem>& a, const std::pair<int, ActItem>& b) { return a.first < b.first; });
-    std::vector<ActItem> h_act(late.size());
-    for (size_t i = 0; i < late.size(); ++i) h_act[i] = late[i].second;
-    ActItem* d_act = (ActItem*)sp_pool(ctx, "cons_act", sizeof(ActItem) * std::max<size_t>(1, h_act.size()));
-    if (!d_act) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus buffers");
     uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "cons_idx", sizeof(uint32_t) * std::max<size_t>(1, h_idx.size()));
     int32_t* d_off = (int32_t*)sp_pool(ctx, "cons_off", sizeof(int32_t) * std::max<size_t>(1, h_off.size()));
     uint8_t* d_C = (uint8_t*)sp_pool(ctx, "cons_C", c_bytes);
-    uint32_t* d_votes = (uint32_t*)sp_pool(ctx, "cons_votes", sizeof(uint32_t) * v_words);
-    ConsCtrl* d_ctrl = (ConsCtrl*)sp_pool(ctx, "cons_ctrl", sizeof(ConsCtrl) * 2 * n_prob);
+    ConsCtrl* d_ctrl = (ConsCtrl*)sp_pool(ctx, "cons_ctrl", sizeof(ConsCtrl) * n_prob);
     ReadInfo* d_info = (ReadInfo*)sp_pool(ctx, "cons_info", sizeof(ReadInfo) * total);
     B.info = d_info; B.total = (int)total;
-    B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * 2 * total * CB);
-    B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * 2 * total);
+    B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * 4 * total * CB);
+    B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * 4 * total);
+    B.PV = (unsigned long long*)sp_pool(ctx, "cons_pv", sizeof(unsigned long long) * (size_t)n_blocks * 2 * (CW + 1));
+    B.PE = (uint32_t*)sp_pool(ctx, "cons_pe", sizeof(uint32_t) * (size_t)n_blocks * 2 * (CW + 1));
+    B.PL = (unsigned long long*)sp_pool(ctx, "cons_pl", sizeof(unsigned long long) * (size_t)n_blocks * 2 * CW);
     uint8_t* d_is1 = (uint8_t*)sp_pool(ctx, "cons_is1", total);
     int32_t* d_sc = (int32_t*)sp_pool(ctx, "cons_scores", sizeof(int32_t) * 2 * total);
-    if (!d_idx || !d_off || !d_C || !d_votes || !d_ctrl || !d_info || !B.H || !B.meta || !d_is1 || !d_sc)
+    ConsCtrl* h_ctrl = (ConsCtrl*)sp_host_pool(ctx, "cons_ctrl", sizeof(ConsCtrl) * n_prob);
+    if (!d_idx || !d_off || !d_C || !d_ctrl || !d_info || !B.H || !B.meta || !B.PV || !B.PE || !B.PL || !d_is1 || !d_sc || !h_ctrl)
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus buffers");
     for (uint32_t p = 0; p < n_prob; ++p) {
         setup[p].idx = probs[p].read_idx ? d_idx + idx_at[p] : nullptr;
         setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr;
-        hp[p].C = d_C + c_at[p]; hp[p].votes = d_votes + v_at[p]; hp[p].ctrl = d_ctrl + 2 * p;
+        hp[p].C = d_C + c_at[p]; hp[p].ctrl = d_ctrl + p;
     }
     if constexpr (MAXP == 0) {
         ConsParams* d_probs = (ConsParams*)sp_pool(ctx, "cons_probs", sizeof(ConsParams) * n_prob);
@@ -606,60 +693,64 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     } else {
         for (uint32_t p = 0; p < n_prob; ++p) B.p[p] = hp[p];
     }
-    ConsCtrl c0; std::memset(&c0, 0, sizeof c0); c0.split_at = -1; c0.stopped[1] = 1; c0.best_total = 1; c0.split_total = 1;
-    std::vector<ConsCtrl> h_ctrl(2 * (size_t)n_prob, c0);
+    ConsCtrl c0; std::memset(&c0, 0, sizeof c0); c0.init = 1; c0.split_at = -1; c0.stopped[1] = 1; c0.best_total = 1; c0.split_total = 1;
+    for (uint32_t p = 0; p < n_prob; ++p) h_ctrl[p] = c0;
     if (!h_idx.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, h_idx.data(), sizeof(uint32_t) * h_idx.size(), hipMemcpyHostToDevice, st));
     if (!h_off.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_off, h_off.data(), sizeof(int32_t) * h_off.size(), hipMemcpyHostToDevice, st));
-    if (!h_act.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_act, h_act.data(), sizeof(ActItem) * h_act.size(), hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ctrl, h_ctrl.data(), sizeof(ConsCtrl) * h_ctrl.size(), hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemsetAsync(d_votes, 0, sizeof(uint32_t) * v_words, st));
-    SP_HIP_CHECK(ctx, hipMemsetAsync(B.meta, 0, sizeof(ConsMeta) * 2 * total, st));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ctrl, h_ctrl, sizeof(ConsCtrl) * n_prob, hipMemcpyHostToDevice, st));
+    SP_HIP_CHECK(ctx, hipMemsetAsync(B.meta, 0, sizeof(ConsMeta) * 4 * total, st));
     SP_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(ReadInfo) * total, st));
     for (uint32_t p = 0; p < n_prob; ++p)
         if (setup[p].n) hipLaunchKernelGGL(cons_setup_kernel, dim3((setup[p].n + 255) / 256), dim3(256), 0, st, setup[p], d_info);
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));      // the pageable host sources above must stay valid until copied
 
     const dim3 grid((uint32_t)n_blocks), block(CWAVES * SP_WAVE);
-    int last = -1;
-    size_t act_at = 0;
+    uint64_t windows = 0;
     {
         ProfScope ps(ctx, "cons_steps", total);
-        hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B, -1);
-        for (int t = 0; t <= max_cap; ++t) {                 // launch t = max_cap only records the stop of a consensus that filled its room
-            hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B, t);
-            last = t;
-            size_t hi = act_at;
-            while (hi < late.size() && late[hi].first == t + 1) ++hi;
-            if (hi > act_at) {
-                const int cnt = (int)(hi - act_at);
-                hipLaunchKernelGGL(cons_activate_kernel<MAXP>, dim3((cnt + 3) / 4), dim3(4 * SP_WAVE), 0, st, B, t, d_act + act_at, cnt);
-                act_at = hi;
-            }
-            if ((t & 255) == 255 || t == max_cap) {
-                SP_HIP_CHECK(ctx, hipMemcpyAsync(h_ctrl.data(), d_ctrl, sizeof(ConsCtrl) * h_ctrl.size(), hipMemcpyDeviceToHost, st));
+        // the first poll comes when a consensus of max_cap bases can be through if (nearly) every window stands; then every 16 windows.
+        // A window pair whose problems are all done is a pair of empty launches.
+        int until_poll = max_cap / CW + 8;
+        const uint64_t limit = (uint64_t)4 * (uint64_t)(max_cap + 2) + 64;           // every column costs at most a cut and a replay
+        for (;;) {
+            hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
+            hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), 0, st, B);
+            ++windows;
+            if (--until_poll <= 0 || windows >= limit) {
+                SP_HIP_CHECK(ctx, hipMemcpyAsync(h_ctrl, d_ctrl, sizeof(ConsCtrl) * n_prob, hipMemcpyDeviceToHost, st));
                 SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
-                bool all = true;
-                for (uint32_t p = 0; p < n_prob; ++p) all = all && h_ctrl[2 * p + ((t + 1) & 1)].done;
+                bool all = true; int left = 0;
+                for (uint32_t p = 0; p < n_prob; ++p) { all = all && h_ctrl[p].done; if (!h_ctrl[p].done) left = std::max(left, hp[p].cap - h_ctrl[p].T); }
                 if (all) break;
+                if (windows >= limit) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the window loop did not finish");
+                until_poll = std::max(4, std::min(64, left / CW + 2));
             }
         }
     }
     SP_HIP_CHECK(ctx, hipGetLastError());
-    const int which = (last + 1) & 1;
-    hipLaunchKernelGGL(cons_finalize_kernel<MAXP>, grid, block, 0, st, B, which, d_is1, d_sc, d_sc + total);
+    if (ctx->profiling) {
+        unsigned long long* cnt = sp_counters(ctx);
+        (void)cnt;
+    }
+    hipLaunchKernelGGL(cons_finalize_kernel<MAXP>, grid, block, 0, st, B, d_is1, d_sc, d_sc + total);
     std::vector<uint8_t> hc(c_bytes), h_is1(total);
     std::vector<int32_t> h_sc(2 * total);
     SP_HIP_CHECK(ctx, hipMemcpyAsync(hc.data(), d_C, c_bytes, hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(ctx, hipMemcpyAsync(h_is1.data(), d_is1, total, hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(ctx, hipMemcpyAsync(h_sc.data(), d_sc, sizeof(int32_t) * 2 * total, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_ctrl.data(), d_ctrl, sizeof(ConsCtrl) * h_ctrl.size(), hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
     SP_HIP_CHECK(ctx, hipGetLastError());
+    {   // launch statistics of the batch (sp_profile_get "cons_windows" / "cons_cut_windows": cells = count)
+        uint64_t w = 0, cut = 0, cols = 0;
+        for (uint32_t p = 0; p < n_prob; ++p) { w = std::max<uint64_t>(w, (uint64_t)h_ctrl[p].windows); cut += (uint64_t)h_ctrl[p].cut_windows; cols = std::max<uint64_t>(cols, (uint64_t)h_ctrl[p].T); }
+        ctx->prof["cons_windows"].cells += windows; ctx->prof["cons_windows"].launches += 2 * windows;
+        ctx->prof["cons_cut_windows"].cells += cut; ctx->prof["cons_columns"].cells += cols;
+    }
     static const char dec[4] = { 'A', 'C', 'G', 'T' };
     int32_t rc = SP_OK;
     for (uint32_t p = 0; p < n_prob; ++p) {
         const ConsParams& P = hp[p]; sp_cons_output& o = outs[p];
-        const ConsCtrl& cur = h_ctrl[2 * p + which];
+        const ConsCtrl& cur = h_ctrl[p];
         const uint8_t* c = hc.data() + c_at[p];
         const int len1 = cur.len[0], len2 = cur.dual ? cur.len[1] : 0;
         for (int x = 0; x < len1; ++x) o.cons1[x] = dec[c[x] & 3];

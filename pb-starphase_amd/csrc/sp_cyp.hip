@@ -398,19 +398,22 @@ extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p
 
 int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s);
 
+// frac_cap > 0: a cell gives up beyond floor(frac_cap * |A|) + 1 edits (K3: hits above max_ed_frac = 0.05 of the template are dropped
+// anyway, src/cyp2d6/haplotyper.rs:160,228-232, and nm <= 0.05 * aligned span <= 0.05 * |A|); otherwise the library-wide cap
 __global__ void cyp_build_cells_kernel(const uint32_t* __restrict__ a_idx, const uint32_t* __restrict__ b_idx,
                                        const int32_t* __restrict__ diag, const int32_t* __restrict__ votes, uint64_t n_pairs, int topk,
-                                       int min_votes, CellDesc* __restrict__ cells) {
+                                       int min_votes, const int32_t* __restrict__ a_len, double frac_cap, CellDesc* __restrict__ cells) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pairs * (uint64_t)topk) return;
     const uint64_t p = i / (uint64_t)topk;
     CellDesc c; c.a = a_idx[p]; c.b = b_idx[p]; c.max_ed = SP_MAX_ED; c.b_lo = 0; c.b_hi = -1;
+    if (frac_cap > 0.0) { const int cap = (int)(frac_cap * (double)a_len[c.a]) + 1; c.max_ed = cap < SP_MAX_ED ? cap : SP_MAX_ED; }
     c.diag = votes[i] >= min_votes ? diag[i] : SP_NO_DIAG;       // anchor: b_pos - a_pos with A the indexed side = the cell's A
     cells[i] = c;
 }
 
 // all |A| x |B| placements (A = indexed query side, B = target side), result[b][a][k]
-static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, const char* prof, std::vector<sp_aln>& out) {
+static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, const char* prof, std::vector<sp_aln>& out) {
     const uint64_t nA = A->n, nB = B->n, n_pairs = nA * nB, n_cells = n_pairs * (uint64_t)topk;
     out.assign(n_cells, sp_aln{});
     if (n_pairs == 0) return SP_OK;
@@ -428,7 +431,7 @@ static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, in
     (void)hipStreamSynchronize(ctx->stream);
     rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v, topk);
     if (rc) return rc;
-    hipLaunchKernelGGL(cyp_build_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, d_d, d_v, n_pairs, topk, CYP_MIN_VOTES, d_cells);
+    hipLaunchKernelGGL(cyp_build_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, d_d, d_v, n_pairs, topk, CYP_MIN_VOTES, A->d_len, frac_cap, d_cells);
     rc = sp_launch_cells(ctx, A, B, d_cells, n_cells, d_alns, nullptr, 0, prof);
     if (rc) return rc;
     (void)hipMemcpyAsync(out.data(), d_alns, n_cells * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);
@@ -448,7 +451,7 @@ extern "C" int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensu
     if (!ctx || !consensus || !segments || (consensus->n && !allowed) || (segments->n && (!ed || !ov || !kept))) return SP_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     std::vector<sp_aln> alns;
-    int rc = cyp_align_all(ctx, consensus, segments, 1, "k4_weight_cells", alns);
+    int rc = cyp_align_all(ctx, consensus, segments, 1, 0.0, "k4_weight_cells", alns);
     if (rc) return rc;
     const uint32_t C = consensus->n;
     for (uint32_t s = 0; s < segments->n; ++s) {
@@ -480,7 +483,7 @@ extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, 
     (void)hipSetDevice(ctx->device);
     *n_hits = 0;
     std::vector<sp_aln> alns;
-    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, "k3_region_cells", alns);
+    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, 0.05, "k3_region_cells", alns);
     if (rc) return rc;
     const uint32_t T = templates->n;
     auto penalized_type = [](int t) { return t == SP_CYP_DELETION || t == SP_CYP_REP6 || t == SP_CYP_REP7; };   // haplotyper.rs:185-191

@@ -26,6 +26,8 @@ struct K1Positions {
     const int32_t* lcp;       // prefix shared with the position before (same gene and frame offset), else 0
 };
 #define K2_MIN_VOTES   2
+#define K2_MAX_ED      255     // edit cap of a K2 / typing cell (allele vs consensus, consensus vs gene reference): 6 % of the longest bundled allele;
+                               // it sizes the per-cell event rows, so it stays below the library-wide SP_MAX_ED
 
 struct sp_hla_db {
     sp_ctx* ctx = nullptr;
@@ -488,7 +490,7 @@ __global__ void k2_build_cells_kernel(const uint32_t* __restrict__ allele_idx, u
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     CellDesc c;
-    c.a = allele_idx[i]; c.b = cons_idx[i]; c.max_ed = SP_MAX_ED; c.b_lo = 0; c.b_hi = -1;
+    c.a = allele_idx[i]; c.b = cons_idx[i]; c.max_ed = K2_MAX_ED; c.b_lo = 0; c.b_hi = -1;
     // anchor diag = allele_pos - cons_pos ; cell diag = cons_pos - allele_pos
     c.diag = (allele_len[c.a] > 0 && anchor_votes[i] >= K2_MIN_VOTES) ? -anchor_diag[i] : SP_NO_DIAG;
     cells[i] = c;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(1024) void k2_scan_kernel(const K2Level* __restrict
     const uint32_t seg = seg_off[blockIdx.x], n = seg_off[blockIdx.x + 1] - seg;
     __shared__ K2Level bl[2];
     __shared__ sp_aln ba[2];
-    __shared__ uint32_t bev[2][SP_MAX_ED + 1];
+    __shared__ uint32_t bev[2][K2_MAX_ED + 1];
     __shared__ int s_first;
     __shared__ int s_best;
     const int tid = threadIdx.x;
@@ -593,8 +595,8 @@ __global__ __launch_bounds__(1024) void k2_scan_kernel(const K2Level* __restrict
         const int first = s_first;
         if (first != 0x7FFFFFFF) {
             if (tid < 2) { bl[tid] = lv_all[(uint64_t)tid * total + seg + first]; ba[tid] = alns_all[(uint64_t)tid * total + seg + first]; }
-            for (int x = tid; x < 2 * (SP_MAX_ED + 1); x += 1024) {
-                int L = x / (SP_MAX_ED + 1), y = x % (SP_MAX_ED + 1);
+            for (int x = tid; x < 2 * (K2_MAX_ED + 1); x += 1024) {
+                int L = x / (K2_MAX_ED + 1), y = x % (K2_MAX_ED + 1);
                 bev[L][y] = (uint32_t)y < ev_stride ? ev_all[((uint64_t)L * total + seg + first) * ev_stride + y] : 0;
             }
             if (tid == 0) s_best = first;
@@ -967,7 +969,7 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
     sp_seqset cons_set; sp_seqset* cons = &cons_set;       // pooled: no allocation, no free
     int rc = sp_seqset_make_small(ctx, "k2_cons", blob.data(), coff.data(), 2 * n_items, true, cons);
     if (rc != SP_OK) return rc;
-    const uint32_t stride = SP_MAX_ED;
+    const uint32_t stride = K2_MAX_ED;
     // the four index arrays travel as one block through pinned memory (one DMA instead of four pageable copies)
     const size_t in_words = (size_t)3 * T + n_items + 1;
     uint32_t* d_in = (uint32_t*)sp_pool(ctx, "k2_in", in_words * 4);
@@ -1068,7 +1070,7 @@ static int32_t type_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items, co
     int32_t* d_dv = (int32_t*)sp_pool(ctx, "tc_dv", (size_t)2 * n * 4);
     CellDesc* d_cell = (CellDesc*)sp_pool(ctx, "tc_cell", (size_t)n * sizeof(CellDesc));
     sp_aln* d_aln = (sp_aln*)sp_pool(ctx, "tc_aln", (size_t)n * sizeof(sp_aln));
-    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "tc_ev", (size_t)n * SP_MAX_ED * 4);
+    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "tc_ev", (size_t)n * K2_MAX_ED * 4);
     if (!d_ab || !d_dv || !d_cell || !d_aln || !d_ev) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "type_consensus buffers");
     (void)hipMemcpyAsync(d_ab, a_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemcpyAsync(d_ab + n, b_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -1084,23 +1086,23 @@ static int32_t type_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items, co
         const int v_lo = buffer, v_hi = db->ref_fwd->h_len[gene] - buffer;          // region_sequence has no buffer (caller.rs:651-654)
         if (v_hi <= v_lo) return sp_fail(ctx, SP_ERR_INVALID_ARG, "type_consensus: reference shorter than its buffer");
         // dv[x] = cons_pos - ref_pos (buffered reference); cell: A = consensus, B = reference view [v_lo, v_hi)
-        cells[x] = CellDesc{ x, gene, dv[n + x] >= K2_MIN_VOTES ? -dv[x] - v_lo : SP_NO_DIAG, SP_MAX_ED, v_lo, v_hi };
+        cells[x] = CellDesc{ x, gene, dv[n + x] >= K2_MIN_VOTES ? -dv[x] - v_lo : SP_NO_DIAG, K2_MAX_ED, v_lo, v_hi };
     }
     (void)hipMemcpyAsync(d_cell, cells.data(), (size_t)n * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream);
-    (void)hipMemsetAsync(d_ev, 0, (size_t)n * SP_MAX_ED * 4, ctx->stream);
+    (void)hipMemsetAsync(d_ev, 0, (size_t)n * K2_MAX_ED * 4, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
-    rc = sp_launch_cells(ctx, cons, db->ref_fwd, d_cell, n, d_aln, d_ev, SP_MAX_ED, "type_consensus_ref");
+    rc = sp_launch_cells(ctx, cons, db->ref_fwd, d_cell, n, d_aln, d_ev, K2_MAX_ED, "type_consensus_ref");
     if (rc != SP_OK) return rc;
-    std::vector<sp_aln> alns(n); std::vector<uint32_t> evs((size_t)n * SP_MAX_ED);
+    std::vector<sp_aln> alns(n); std::vector<uint32_t> evs((size_t)n * K2_MAX_ED);
     (void)hipMemcpyAsync(alns.data(), d_aln, (size_t)n * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);
-    (void)hipMemcpyAsync(evs.data(), d_ev, (size_t)n * SP_MAX_ED * 4, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(evs.data(), d_ev, (size_t)n * K2_MAX_ED * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "type_consensus placement");
     // 2. splice, put on the gene strand
     std::vector<std::string> dna_g(n), cdna_g(n); std::vector<K2Item> k2; std::vector<uint32_t> k2_of;
     for (uint32_t x = 0; x < n; ++x) {
         const TypeItem& it = items[live[x]];
         const uint32_t gene = it.gene;
-        const sp_aln& aln = alns[x]; const uint32_t* ev = evs.data() + (size_t)x * SP_MAX_ED;
+        const sp_aln& aln = alns[x]; const uint32_t* ev = evs.data() + (size_t)x * K2_MAX_ED;
         const int v_lo = buffer, v_hi = db->ref_fwd->h_len[gene] - buffer, tlen = v_hi - v_lo;
         // select_best_mapping(target-based, penalised) must beat the 1.0 default (util/mapping.rs:22-57, caller.rs:1289-1297)
         bool mapped = aln.ok != 0;

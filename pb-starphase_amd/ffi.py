@@ -19,7 +19,7 @@ class StarphaseError(RuntimeError):
 SP_OK = 0
 SP_ERR_NO_DEVICE = 2
 SP_NO_DIAG = -(2 ** 31)
-SP_MAX_ED = 255
+SP_MAX_ED = 511
 
 
 class sp_pair(C.Structure):

@@ -32,72 +32,116 @@ def k2_expected(oracle, fx, gene, cons_dna, cons_cdna, require_dna=False, disabl
     return (idx[best] if best >= 0 else -1), {a: stats[i].reshape(6).tolist() for i, a in enumerate(idx)}
 
 
+class K1Tables:
+    """what HlaRealigner::new prepares (src/hla/realigner.rs:42-91): hg38-strand alleles, their frame offsets on the gene reference
+    and, lazily, their static mappings to it"""
+
+    def __init__(self, oracle, fx, off=None):
+        self.oracle, self.fx = oracle, fx
+        n_all = len(fx.ids)
+        self.refs = [oracle.encode(s) for s in fx.gene_ref]
+        self.fwd = [fx.dna_fwd(a) if fx.dna[a] else "" for a in range(n_all)]
+        self.fwd_e = [oracle.encode(s) if s else None for s in self.fwd]
+        self.off, self._am = [], {}
+        if off is not None:                                  # frame offsets worked out before (INT_MIN = none)
+            self.off = [None if int(x) == -2 ** 31 else int(x) for x in off]
+            return
+        for a in range(n_all):
+            if not self.fwd[a]:
+                self.off.append(None)
+                continue
+            d, v = oracle.anchor(self.refs[int(fx.gene_of[a])], self.fwd_e[a])             # allele_pos - ref_pos
+            self.off.append(d if v >= K1_MIN_VOTES else None)
+
+    def am(self, a):
+        """static allele -> gene reference mapping (a_start, b_start) or None"""
+        if a not in self._am:
+            m = None
+            if self.off[a] is not None:
+                g = int(self.fx.gene_of[a])
+                al, _ = self.oracle.wfa(self.fwd_e[a], self.refs[g], -self.off[a], 511, events=False)
+                if al.ok and score_value(al.a_len, al.nm, al.a_len - (al.a_end - al.a_start)) < 1.0:
+                    m = (al.a_start, al.b_start)
+            self._am[a] = m
+        return self._am[a]
+
+    def anchors(self, re):
+        return [self.oracle.anchor(self.refs[g], re) for g in range(len(self.fx.genes))]       # read_pos - ref_pos
+
+    def cell(self, a, re, anch):
+        cap = min(511, int(0.03 * len(self.fwd[a])) + 1)
+        al, _ = self.oracle.wfa(self.fwd_e[a], re, anch[int(self.fx.gene_of[a])][0] - self.off[a], cap, events=False)
+        return al
+
+    def record(self, read, re, anch, best, bm):
+        """everything realign_record does once the best allele is known (src/hla/realigner.rs:149-350); bm = its alignment as an
+        ALN_DTYPE row"""
+        oracle, fx = self.oracle, self.fx
+        res = dict(status=1, best_allele=-1, gene=-1)
+        if best < 0:
+            return res
+        g = int(fx.gene_of[best])
+        res.update(status=3, best_allele=best, gene=g, nm=int(bm["nm"]), target_len=int(bm["a_len"]),
+                   unmapped=int(bm["a_len"] - (bm["a_end"] - bm["a_start"])), aln=tuple(int(x) for x in bm.tolist()))
+        db_s, db_e = int(bm["b_start"]), int(bm["b_end"])
+        buf_s, buf_e = max(db_s - 1000, 0), min(db_e + 1000, len(read))
+        seg = re[buf_s:buf_e]
+        rm, _ = oracle.wfa(self.refs[g], seg, anch[g][0] - buf_s, 511, events=False)
+        reflen = len(self.refs[g])
+        if rm.ok and score_value(reflen, rm.nm, reflen - (rm.a_end - rm.a_start)) < 1.0:
+            adj_s, adj_e = buf_s + rm.b_start, buf_s + rm.b_end
+            am = self.am(best)
+            if adj_s < db_s or am is None:
+                d = rm.a_start
+                h = oracle.hpc_pos(fx.gene_ref[g], d)
+            else:
+                added = max(am[1] - am[0], 0)
+                d = added + int(bm["a_start"])
+                h = oracle.hpc_pos(fx.gene_ref[g], added) + oracle.hpc_pos(fx.dna[best], int(bm["a_start"]))
+            res.update(status=0, seg_start=min(db_s, adj_s), seg_end=max(db_e, adj_e), dna_offset=d, hpc_offset=h)
+        return res
+
+
+def k1_records_for(oracle, fx, reads, best_alleles, tables=None):
+    """realign_record's result for reads whose best allele is already known (bench.py's CPU leg: the cells ran in C)"""
+    tb = tables or K1Tables(oracle, fx)
+    out = []
+    for read, best in zip(reads, best_alleles):
+        re = oracle.encode(read)
+        anch = tb.anchors(re)
+        bm = None
+        if best >= 0:
+            al = tb.cell(best, re, anch)
+            bm = np.zeros(1, oracle_aln_dtype())[0]
+            bm["ok"], bm["nm"], bm["a_start"], bm["a_end"], bm["b_start"], bm["b_end"], bm["a_len"], bm["b_len"] = (
+                1, al.nm, al.a_start, al.a_end, al.b_start, al.b_end, al.a_len, al.b_len)
+        out.append(tb.record(read, re, anch, best, bm))
+    return out
+
+
 def k1_expected(oracle, fx, reads):
     """HlaRealigner::realign_record (src/hla/realigner.rs:98-350) for every read; returns list of dicts + cell matrix"""
-    G = len(fx.genes)
     n_all = len(fx.ids)
-    refs = [oracle.encode(s) for s in fx.gene_ref]
-    fwd = [fx.dna_fwd(a) if fx.dna[a] else "" for a in range(n_all)]
-    fwd_e = [oracle.encode(s) if s else None for s in fwd]
-    off = []
-    am = []
-    for a in range(n_all):
-        if not fwd[a]:
-            off.append(None)
-            am.append(None)
-            continue
-        g = int(fx.gene_of[a])
-        d, v = oracle.anchor(refs[g], fwd_e[a])             # allele_pos - ref_pos
-        off.append(d if v >= K1_MIN_VOTES else None)
-        m = None
-        if v >= K1_MIN_VOTES:
-            al, _ = oracle.wfa(fwd_e[a], refs[g], -d, 255, events=False)
-            if al.ok and score_value(al.a_len, al.nm, al.a_len - (al.a_end - al.a_start)) < 1.0:
-                m = (al.a_start, al.b_start)
-        am.append(m)
+    tb = K1Tables(oracle, fx)
     results = []
     cells = np.full((len(reads), n_all), NONE, np.uint32)
     for r, read in enumerate(reads):
         re = oracle.encode(read)
-        anch = [oracle.anchor(refs[g], re) for g in range(G)]       # read_pos - ref_pos
+        anch = tb.anchors(re)
         vmax = max(v for _, v in anch)
         vmin = max(vmax // 10, K1_MIN_VOTES)
         alns = np.zeros(n_all, oracle_aln_dtype())
         for a in range(n_all):
-            if not fwd[a] or off[a] is None:
+            if not tb.fwd[a] or tb.off[a] is None:
                 continue
-            g = int(fx.gene_of[a])
-            if anch[g][1] < vmin:
+            if anch[int(fx.gene_of[a])][1] < vmin:
                 continue
-            cap = min(255, int(0.03 * len(fwd[a])) + 1)
-            al, _ = oracle.wfa(fwd_e[a], re, anch[g][0] - off[a], cap, events=False)
+            al = tb.cell(a, re, anch)
             if al.ok:
                 alns[a] = (1, al.nm, al.a_start, al.a_end, al.b_start, al.b_end, al.a_len, al.b_len)
                 cells[r, a] = (al.nm << 16) | (al.a_end - al.a_start)
         best = oracle.pick_allele(alns, len(read))
-        res = dict(status=1, best_allele=-1, gene=-1)
-        if best >= 0:
-            g = int(fx.gene_of[best])
-            bm = alns[best]
-            res.update(status=3, best_allele=best, gene=g, nm=int(bm["nm"]), target_len=int(bm["a_len"]),
-                       unmapped=int(bm["a_len"] - (bm["a_end"] - bm["a_start"])),
-                       aln=tuple(int(x) for x in bm.tolist()))
-            db_s, db_e = int(bm["b_start"]), int(bm["b_end"])
-            buf_s, buf_e = max(db_s - 1000, 0), min(db_e + 1000, len(read))
-            seg = re[buf_s:buf_e]
-            rm, _ = oracle.wfa(refs[g], seg, anch[g][0] - buf_s, 255, events=False)
-            reflen = len(refs[g])
-            if rm.ok and score_value(reflen, rm.nm, reflen - (rm.a_end - rm.a_start)) < 1.0:
-                adj_s, adj_e = buf_s + rm.b_start, buf_s + rm.b_end
-                if adj_s < db_s or am[best] is None:
-                    d = rm.a_start
-                    h = oracle.hpc_pos(fx.gene_ref[g], d)
-                else:
-                    added = max(am[best][1] - am[best][0], 0)
-                    d = added + int(bm["a_start"])
-                    h = oracle.hpc_pos(fx.gene_ref[g], added) + oracle.hpc_pos(fx.dna[best], int(bm["a_start"]))
-                res.update(status=0, seg_start=min(db_s, adj_s), seg_end=max(db_e, adj_e), dna_offset=d, hpc_offset=h)
-        results.append(res)
+        results.append(tb.record(read, re, anch, best, alns[best] if best >= 0 else None))
     return results, cells
 
 

@@ -190,8 +190,11 @@ class Oracle:
 _cached = None
 
 
-def load():
+def load(path=None):
+    """the shipped oracle, or (bench.py's CPU leg) another build of the same sources"""
     global _cached
+    if path is not None:
+        return Oracle(C.CDLL(path))
     if _cached is None:
         so = os.path.join(ODIR, "liboracle.so")
         srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
