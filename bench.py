@@ -176,6 +176,7 @@ def cyp_leg(pkg, ctx, n_reads=2000, reps=2):
         R = ctx.upload(reads)
         best = None
         for _ in range(reps):
+            ctx.profile_reset()
             ctx.synchronize()
             t0 = time.perf_counter()
             call, _cons, _labels = db.diplotype(R)
@@ -183,7 +184,9 @@ def cyp_leg(pkg, ctx, n_reads=2000, reps=2):
             best = dt if best is None or dt < best else best
         good = sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
         ok += good
-        out[name] = {"ms": 1e3 * best, "reads": len(reads), "call_equals_truth": bool(good)}
+        out[name] = {"ms": 1e3 * best, "reads": len(reads), "call_equals_truth": bool(good), "cons_ms": ctx.profile_get("cons_steps")[0],
+                     "launch_pairs": ctx.profile_get("cons_windows")[2], "cut_windows": ctx.profile_get("cons_cut_windows")[2],
+                     "expansions": ctx.profile_get("cons_expansions")[2], "nodes_expanded": ctx.profile_get("cons_columns")[2]}
         total_reads += len(reads); total_s += best
     return {"value": total_reads / total_s, "unit": "reads/s", "workload": f"BASELINE configs[2]: six scenarios x {n_reads} targeted-style reads (3-8 kb) on the synthetic chr22 "
             "locus, 39 templates, 393 variants / 520 star alleles of the bundled DB; sp_cyp_diplotype (K3 -> K8 -> K9/K7 -> K4 -> chains -> K5)",
@@ -313,6 +316,7 @@ def main():
     cons_windows = ctx.profile_get("cons_windows")[2]
     cons_cut = ctx.profile_get("cons_cut_windows")[2]
     cons_cols = ctx.profile_get("cons_columns")[2]
+    cons_exp = ctx.profile_get("cons_expansions")[2]
     avg_ms = ms_cells / max(1, launches)
     per_launch = lambda v: v / max(1, launches)
     achieved = per_launch(exec_bytes) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -391,7 +395,8 @@ def main():
             "roofline_valu": valu,
             "kernel_ms": kernel_ms,
             "consensus": {"windows_per_step": cons_windows / max(1, args.steps), "launches_per_step": 2 * cons_windows / max(1, args.steps),
-                          "cut_windows_per_step": cons_cut / max(1, args.steps), "columns_per_step": cons_cols / max(1, args.steps)},
+                          "cut_windows_per_step": cons_cut / max(1, args.steps), "expansions_per_step": cons_exp / max(1, args.steps),
+                          "nodes_expanded_per_step": cons_cols / max(1, args.steps)},
             "concordance": {"k1_gene_correct": k1_gene_ok, "k1_realigned": k1_realigned, "diplotypes_equal_truth": f"{ok}/{len(genes)} genes"},
             "pcie_inclusive_upload_s": t_up,
             "scoring_only": scoring, "cyp2d6": cyp, "cohort": cohort,

@@ -486,14 +486,16 @@ int32_t sp_variant_is_deletion(const sp_sv_definitions* defs, uint64_t start, ui
  * run_dual_consensus_with_offsets (src/hla/caller.rs:1103-1219) and ConsensusDWFA per read group (src/hla/caller.rs:706-747),
  * with the fields of dwfa_config_from_cli (src/hla/caller.rs:1103-1116).  waffle_con v0.4.4 is not on disk: the contract is the
  * one in DESIGN.md section 9 / oracle/consensus.c (every read keeps a 64-diagonal edit wavefront against the growing consensus
- * and votes for the next base; a second consensus is split off where a second base has min_count reads and min_af of the votes).
+ * and votes for the next base; extensions are explored best first -- lowest total edit distance, then longest -- under the bounds
+ * max_queue_size / max_capacity_per_size / max_nodes_wo_constraint; a candidate needs min_count reads and min_af of the votes;
+ * a pair of candidates may start a second consensus).
  *   reads / read_idx   the sequences (read_idx == NULL: all n = sp_seqset_count(reads) of them, in order)
  *   offsets            NULL, or per sequence -1 (None: starts with the consensus) or the consensus length at which the sequence is
  *                      placed; its start is searched in the offset_window bases before that point (add_sequence_offset)
  *   cons1 / cons2      cap bytes each, NUL terminated ASCII; cons2 is empty unless result->is_dual
  *   is_cons1, score1, score2   DualConsensus::{is_consensus1, scores1, scores2}; a score of -1 is None
- * sp_consensus is one pass with cfg->min_af as given.  sp_consensus_dual runs a first pass without splitting to find the
- * strongest second-base column and then allows the split only at columns at least half as strong (never below cfg->min_af). */
+ * sp_consensus runs the search with cfg->allow_dual as given (ConsensusDWFA / DualConsensusDWFA); sp_consensus_dual is the same
+ * with a second consensus allowed. */
 typedef struct {
     int32_t min_count;                 /* 3 */
     int32_t dual_max_ed_delta;         /* 100 */
@@ -502,12 +504,17 @@ typedef struct {
     int32_t offset_window;             /* 400 */
     int32_t offset_compare_length;     /* 50 (at most 64) */
     double  min_af;                    /* 0.10 */
+    int32_t max_queue_size;            /* 20    CdwfaConfig::max_queue_size, set by dwfa_config_from_cli (src/hla/caller.rs:1110) */
+    int32_t max_capacity_per_size;     /* 10    CdwfaConfig::max_capacity_per_size (:1111) */
+    int32_t max_nodes_wo_constraint;   /* 1000  waffle_con's default; the reference does not set it */
+    int32_t reserved;                  /* (<= 0 in any of the three: the value named above) */
 } sp_cons_config;
 
 typedef struct {
     int32_t is_dual, len1, len2, split_at;
     int64_t best_w2, best_total;       /* strongest second-base column before any split: its weight / all votes, in 12ths of a read */
-    int64_t split_w2, split_total;     /* the same two numbers for the column at which consensus 2 was split off */
+    int64_t split_w2, split_total;     /* (both pairs are unused since the best-first search replaced the two-pass split policy) */
+    int64_t nodes_expanded;            /* nodes the search took out of its queue and expanded */
 } sp_cons_result;
 
 /* batched form: independent problems advance in lockstep (one base per kernel launch for all of them), so a batch costs as many

@@ -14,11 +14,16 @@ typedef struct {
     int32_t offset_window;             /* 400 */
     int32_t offset_compare_length;     /* 50 */
     double  min_af;                    /* 0.10 */
+    int32_t max_queue_size;            /* 20   (<= 0: these three take the values dwfa_config_from_cli / waffle_con's defaults give) */
+    int32_t max_capacity_per_size;     /* 10 */
+    int32_t max_nodes_wo_constraint;   /* 1000 */
+    int32_t pad;
 } osp_cons_config;
 
 typedef struct {
     int32_t is_dual, len1, len2, split_at;
-    int64_t best_w2, best_total;       /* the strongest second-base column seen before any split: weight / total (12ths of a read) */
+    int64_t best_w2, best_total;       /* (unused since the best-first search replaced the two-pass split policy) */
+    int64_t nodes_expanded;
 } osp_cons_result;
 
 /* seqs: base codes 0..3 (4 = N).  offsets[r] = -1 (read starts with the consensus) or the consensus length at which the read is

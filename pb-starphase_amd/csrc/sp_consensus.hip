@@ -1,27 +1,31 @@
 // sp_consensus.hip -- K8: read consensus by dynamic wavefront alignment (gfx950).
 //
 // Serves the waffle_con call sites of the reference: DualConsensusDWFA in run_dual_consensus_with_offsets
-// (src/hla/caller.rs:1103-1219) and the per-group ConsensusDWFA (src/hla/caller.rs:706-747), configured as
-// dwfa_config_from_cli does (src/hla/caller.rs:1103-1116).  waffle_con itself (v0.4.4) is a third-party crate that is not
-// on disk, so the contract is the one stated in DESIGN.md section 9 and restated for the CPU in oracle/consensus.c; the
-// two agree bit for bit (consensus strings, read assignment, per-read edit counts).
+// (src/hla/caller.rs:1103-1219), the per-group ConsensusDWFA (src/hla/caller.rs:706-747) and, through the multi-way driver,
+// PriorityConsensusDWFA (src/cyp2d6/caller.rs:145-270), configured as dwfa_config_from_cli does (src/hla/caller.rs:1103-1116).
+// waffle_con itself (v0.4.4) is a third-party crate that is not on disk, so the contract is the one stated in DESIGN.md section 9
+// and restated for the CPU in oracle/consensus.c -- a best-first search over consensus extensions, lowest total edit distance
+// first, bounded as the reference configures it (max_queue_size 20, max_capacity_per_size 10); the two agree bit for bit
+// (consensus strings, read assignment, per-read edit counts, nodes expanded).
 //
-// Mapping: ONE wavefront per read, one lane per diagonal (64-diagonal band, lane l <-> consensus pos - read pos = l - 32),
-// the per-read state is one VGPR per lane (furthest read position at the current edit count).
+// Mapping: ONE wavefront per read, one lane per diagonal (64-diagonal band, lane l <-> consensus pos - read pos = l - 32), the
+// per-read state is one VGPR per lane (furthest read position at the current edit count).  A search node owns two state slots in
+// HBM (the state at its column, and the state a window leaves behind) and one consensus buffer.
 //
-// The decision for a column needs the votes of every read, so a column is a global step.  One launch per column (round 1) is bound
-// by launch latency (~10 us per base).  This version pushes a WINDOW of up to CW bases per launch:
-//   * the first base of a window is exact (decided from the complete votes of the verified state);
-//   * the others are speculated from the reads' own continuation ("lookahead" votes: every read names the bases that follow its
-//     tips) -- at HiFi error rates the majority continuation is the consensus except at real differences;
-//   * every wave pushes its read through the window and records the exact votes of every column it passes (exact GIVEN the
-//     speculated prefix), the new lookahead votes and the new state into the other state buffer;
-//   * a one-workgroup control kernel per problem sums the workgroups' vote words, re-derives the decisions in order and keeps the
-//     longest prefix on which decision == speculation with no structural event (stop, split).  A fully accepted window commits the
-//     new state buffer; a partly accepted one is re-pushed from the kept state with the verified bases only (no speculation),
-//     which costs one extra window.  Events only ever happen at the first base of a window.
-// Results are therefore exactly those of the one-base-per-step contract; only the number of launches changes (about two per
-// accepted window instead of one per base).  There is no host round trip inside the loop.
+// The decision for a column needs the votes of every read, so a column is a global step; and the search decides after every
+// column which node goes on.  Both are taken off the critical path:
+//   * STEP kernel, window mode: the node the search has chosen is pushed through a WINDOW of up to CW bases in one launch.  The first
+//     base is exact (it comes from the complete votes of the state), the others are speculated from the reads' own continuation
+//     ("lookahead" votes).  Every wave records the exact votes of every column it passes (exact GIVEN the speculated prefix), the
+//     change of the node's cost, the new lookahead votes, and leaves the new state in the node's other slot.
+//   * CONTROL kernel (one workgroup per problem): sums the workgroups' vote words, keeps the longest prefix of the window on which
+//     "one candidate, equal to the speculated base" holds -- the node's verified TAPE -- and then plays the search forward over the
+//     tapes exactly as the one-column-per-step search would run: take the best node out, do the bookkeeping of the bounds, let it
+//     consume one column of its tape, again.  Only when the best node stands at the end of its tape does it ask for the next launch:
+//     another window, a replay of a cut window (verified bases only, from the kept state), or
+//   * STEP kernel, expand mode: a node with several candidates gets one child per candidate (and per pair, when a second consensus
+//     may be split off): every wave pushes its read once per child into the child's slot.
+// Results are those of the plain search; only the number of launches changes (about two per window instead of one per column).
 #include "sp_internal.h"
 #include "sp_wfa.cuh"
 #include <algorithm>
@@ -37,48 +41,70 @@ constexpr int CWAVES = 16;      // waves per workgroup
 constexpr int CW = 32;          // bases per window
 constexpr int CWIN = 512;       // consensus bases in front of the window kept in LDS (offset_window + slack)
 constexpr int RWORDS = 24;      // packed read words a wave keeps in LDS (384 bases around its tips)
+constexpr int NQ = 40;          // search nodes per problem: max_queue_size waiting + the children of one expansion + the complete one
+constexpr int MAXKIDS = 16;     // children of one expansion
 enum { F_ACTIVE = 1, F_FINISHED = 2, F_LOST = 4 };
+enum { M_NONE = 0, M_INIT = 1, M_WINDOW = 2, M_EXPAND = 3 };
 
-struct ConsCtrl {               // state between two windows (written by the control kernel, read by the step kernel)
-    int32_t T;                  // column of the state in state_buf: consensus [0, T) is final
-    int32_t n;                  // bases the next window pushes (0: init or done)
-    int32_t replay, init;       // replay: the n bases are verified already (re-push after a cut window); init: build the initial state
-    int32_t state_buf;
-    int32_t dual, split_at, split_now;   // split_now: the first base of the window splits consensus 2 off (state clone, base spec[1][0])
-    int32_t done, pad0;
-    int32_t stopped[2], len[2], go[2];
-    int32_t windows, cut_windows;        // statistics
-    long long best_w2, best_total;
-    long long split_w2, split_total;     // the votes of the column at which the second consensus was split off
+struct CWork {                  // what the next step launch does for this problem (written by the control kernel)
+    int32_t mode, done;
+    int32_t node, in_slot;      // window / init: the node and the slot that holds its state at column T; expand: the parent
+    int32_t T, n, replay;       // window: n bases from column T on; replay: they are verified already
+    int32_t dual, split_at;     // of the state at T
+    int32_t go[2];              // window: which consensuses grow
+    int32_t n_kids, pad;
+    int32_t kid_node[MAXKIDS];
+    int8_t  kid_base[MAXKIDS][2];      // -1: that consensus does not grow
+    int8_t  kid_split[MAXKIDS];        // the child starts consensus 2 as a copy of consensus 1
     uint8_t spec[2][CW];
+};
+struct CNode {
+    int32_t used, id, complete;
+    int32_t T, cur;             // column of the state in slot `cur`
+    int32_t dual, split_at, stopped[2], len[2];
+    int32_t n, a, q;            // the tape: n bases were pushed from T, the first a are verified, q are consumed
+    int32_t have_out, la_valid; // the other slot holds the state at T + n; lookahead votes exist for that state / the state at T
+    long long cost[CW + 1];     // cost after j pushes from T
+    long long rest;             // what the unfinished reads add to the final cost (no early termination), for the state at T
+    long long rest_out;         // the same for the state at T + n
+    uint32_t ev[2][5];          // the complete votes at column T + a
+    uint8_t spec[2][CW];
+};
+struct CSearch {
+    int32_t threshold, farthest, next_id, best_node, inflight, max_queue, per_size, wo_constraint;
+    int32_t windows, cut_windows, expansions, pad;
+    long long pops, best_final;
 };
 struct ConsMeta { int32_t e, c0, flags, pad; };
 
-// One consensus problem of a batch.  All problems of a batch advance window by window in the same launches (each at its own
-// column); a workgroup belongs to exactly one problem (each problem's reads are padded to whole workgroups in the flattened read
-// order).  The descriptors travel in the kernel argument block (scalar loads) for small batches.
-constexpr int CMAXP = 32;
+// One consensus problem of a batch.  All problems of a batch advance in the same launches (each with its own work order); a
+// workgroup belongs to exactly one problem.  The descriptors travel in the kernel argument block for small batches.
+constexpr int CMAXP = 24;
 struct ConsParams {
     int n, first, first_block, n_blocks, rpw;   // reads; flattened index of local read 0; first workgroup; workgroups; reads per wave
     int min_count, delta, et, allow_dual, window, cmp_len; double min_af;
-    uint8_t* C; int cap;        // [2][cap] base codes; consensus 2 shares [0, split_at) with consensus 1
-    ConsCtrl* ctrl;
+    int cap;
+    uint8_t* C;                 // [NQ][2][cap] base codes per node; consensus 2 shares [0, split_at) with consensus 1
+    CWork* work; CSearch* srch; CNode* nodes;
+    uint32_t* la;               // [NQ][2][CW][4] lookahead votes per node
+    uint8_t* processed;         // [cap + 2] nodes expanded per length
 };
 struct ReadInfo { const uint32_t* w; const uint32_t* np; int n, off; long long pad; };
 template <int MAXP> struct ConsBatchT {
     ConsParams p[MAXP]; int n_prob;
     const ReadInfo* info;       // [total]
-    uint16_t* H;                // [2 buffers][2 consensuses][total][64] furthest read position per diagonal (0xFFFF = none)
-    ConsMeta* meta;             // [2][2][total]
+    uint16_t* H;                // [node][slot][consensus][total][64] furthest read position per diagonal (0xFFFF = none)
+    ConsMeta* meta;             // [node][slot][consensus][total]
     unsigned long long* PV;     // [blocks][2][CW + 1] exact votes per workgroup: four 16-bit fields (A, C, G, T) in 12ths of a read
     uint32_t* PE;               // [blocks][2][CW + 1] "the read ends here" votes
     unsigned long long* PL;     // [blocks][2][CW]     lookahead votes (one per read and tip)
+    uint32_t* PC;               // [blocks][CW + 1]    growth of the node's cost at push j (expand: cost the child adds)
+    uint32_t* PR;               // [blocks][CW + 1]    what unfinished reads add to a final cost (index n / child)
     int total;
 };
-// large batches (a cohort): the descriptors live in device memory and a table maps every workgroup to its problem
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; int total;
+    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; int total;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first; };
 
@@ -195,16 +221,79 @@ struct ActScratch {             // per wave
     uint32_t rpack[ACT_READ / 16 + 2];
 };
 
-// heaviest base of a packed vote word, ties to the lower code; second = heaviest of the others
-struct ColVotes { uint32_t w[4], end; };
-__device__ __forceinline__ void top2(const ColVotes& v, int& b1, uint32_t& w1, int& b2, uint32_t& w2, uint32_t& total) {
-    b1 = 0; w1 = v.w[0];
-#pragma unroll
-    for (int b = 1; b < 4; ++b) if (v.w[b] > w1) { b1 = b; w1 = v.w[b]; }
-    b2 = -1; w2 = 0; bool have2 = false;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) if (b != b1 && (!have2 || v.w[b] > w2)) { b2 = b; w2 = v.w[b]; have2 = true; }
-    total = v.w[0] + v.w[1] + v.w[2] + v.w[3];
+
+// consensus i of a node as a step kernel sees it: the LDS copy of [w0, w0 + CWIN + CW), one overriding base (the base a child
+// appends), the node's committed bases elsewhere
+struct ConsAccess {
+    const uint8_t* win; int w0; const uint8_t* C; int cap, split_at, i, ov_pos, ov_base;
+    __device__ __forceinline__ int at(int pos) const {
+        if (pos == ov_pos) return ov_base;
+        const int y = pos - w0;
+        if ((unsigned)y < (unsigned)(CWIN + CW)) return (int)win[y];
+        return (int)((i == 1 && pos < split_at) ? C[pos] : C[(size_t)i * cap + pos]);
+    }
+};
+
+// Placement of a late read (add_sequence_offset) when the consensus reaches length `len` == its offset: start search in the
+// offset_window bases before it, then the catch-up pushes.  Kept out of line: it is rare and needs twice the registers of
+// the window loop.
+__device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScratch* Ap, int off, int len, int window, int cmp_len, int et, int lane) {
+    ActScratch& A = *Ap;
+    Dwfa d;
+    auto ca = [&](int pos) { return cacc.at(pos); };
+    const int ws = off - window > 0 ? off - window : 0;
+    for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) A.rcache[x] = (uint8_t)read_base(rv, x);
+    spw::wave_lds_sync();
+    auto rbc = [&](int h) { return h < ACT_READ ? (int)A.rcache[h] : read_base(rv, h); };
+    d.c0 = find_start(rv.n, rbc, ca, off, window, cmp_len, lane);
+    d.H = lane == CH ? 0 : SP_NEG; d.e = 0; d.flags = F_ACTIVE | ((et && rv.n == 0) ? F_FINISHED : 0);
+    const int c0 = d.c0, span = len - c0, cwinlen = len - ws;
+    const bool packed = rv.np == nullptr && cwinlen <= ACT_CONS;
+    if (span > 0 && !(d.flags & F_FINISHED) && !(et && rv.n <= span + CB) && packed) {
+        // 16 bases per step out of 2-bit packed copies of the two windows
+        for (int w = lane; w < ACT_CONS / 16 + 2; w += SP_WAVE) {
+            uint32_t word = 0;
+            for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < cwinlen) word |= (uint32_t)(ca(ws + x) & 3) << (b << 1); }
+            A.cpack[w] = word;
+        }
+        const int rwords = ((rv.n < ACT_READ ? rv.n : ACT_READ) + 15) >> 4;
+        for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) A.rpack[w] = w < rwords ? rv.w[w] : 0u;
+        spw::wave_lds_sync();
+        const int kk = lane - CH, cbase = c0 - ws;
+        dwfa_catchup_t(d, rv.n, [&]() {
+            for (;;) {
+                int left = rv.n - d.H; { const int l2 = span - (d.H + kk); left = l2 < left ? l2 : left; }
+                const bool go = d.H >= 0 && left > 0;
+                int nm = 0;
+                if (go) {
+                    const int pr = d.H, pc = cbase + d.H + kk;
+                    const uint32_t a = __builtin_amdgcn_alignbit(A.rpack[(pr >> 4) + 1], A.rpack[pr >> 4], (uint32_t)(pr & 15) << 1);
+                    const uint32_t b = __builtin_amdgcn_alignbit(A.cpack[(pc >> 4) + 1], A.cpack[pc >> 4], (uint32_t)(pc & 15) << 1);
+                    const uint32_t x = a ^ b, mm = (x | (x >> 1)) & 0x55555555u;
+                    nm = mm ? (__builtin_ctz(mm) >> 1) : 16;
+                    nm = nm < left ? nm : left;
+                    d.H += nm;
+                }
+                if (!__ballot(go && nm == 16 && left > 16)) break;
+            }
+        }, span, lane);
+    } else if (span > 0 && !(d.flags & F_FINISHED) && !(et && rv.n <= span + CB)) {
+        const int kk = lane - CH;
+        dwfa_catchup_t(d, rv.n, [&]() {
+            for (;;) {
+                bool go = d.H >= 0 && d.H < rv.n && d.H + kk < span;
+                if (go) { const int x = rbc(d.H); go = x < 4 && x == ca(d.c0 + d.H + kk); }
+                if (!__ballot(go)) break;
+                if (go) d.H += 1;
+            }
+        }, span, lane);
+    } else {
+        for (int Tl = 1; Tl <= span; ++Tl) {
+            if (d.flags & (F_FINISHED | F_LOST)) break;
+            dwfa_push_t(d, rv.n, rbc, ca, Tl, ca(c0 + Tl - 1), et, lane);
+        }
+    }
+    return d;
 }
 
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B) {
@@ -217,77 +306,96 @@ template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatch
     return pi;
 }
 
+__device__ __forceinline__ size_t state_plane(int node, int slot, int cons) { return (size_t)((node * 2 + slot) * 2 + cons); }
+
+// the smaller edit count of the placed states of a read (a state that is no longer tracked keeps its count)
+__device__ __forceinline__ int read_cost(const Dwfa& a0, const Dwfa& a1, bool dualrun) {
+    int c = -1;
+    if (a0.flags & F_ACTIVE) c = a0.e;
+    if (dualrun && (a1.flags & F_ACTIVE) && (c < 0 || a1.e < c)) c = a1.e;
+    return c < 0 ? 0 : c;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
-// the window: every wave pushes its read(s) through the n bases the control kernel set up
+// the step: window mode pushes the chosen node through n bases, expand mode makes the children of a node, init builds the root
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int MAXP>
 __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<MAXP> B) {
-    __shared__ unsigned long long lv[2][CW + 1];          // exact votes after j pushes (column T + j)
+    __shared__ unsigned long long lv[2][CW + 1];          // exact votes after j pushes (column T + j) / of child j
     __shared__ uint32_t le[2][CW + 1];
     __shared__ unsigned long long ll[2][CW];              // lookahead: ll[i][x] predicts column T + n + 1 + x
+    __shared__ uint32_t lc[CW + 1], lr[CW + 1];           // cost growth at push j / of child j; final-cost extra of the end state / child
     __shared__ uint8_t cwin[2][CWIN + CW];                // consensus bases [T - CWIN, T + n)
     __shared__ uint32_t rwin[CWAVES][2][RWORDS + 2];      // packed read window of the wave (+ N plane)
+    __shared__ uint32_t spk[2][CW / 16 + 2];              // the window's bases, 2 bits each (clean runs are compared 16 bases at a time)
     __shared__ ActScratch act[CWAVES];
     const int pi = block_problem<MAXP>(B);
     const ConsParams P = B.p[pi];
-    const ConsCtrl c = *P.ctrl;
-    if (c.done || (c.n == 0 && !c.init)) return;
+    const CWork* Wp = P.work;
+    const int mode = Wp->mode;
+    if (Wp->done || mode == M_NONE) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int T = c.T, n = c.n;
-    const int dual_in = c.dual;                           // the kept state has two consensuses
-    const int dual = c.dual || c.split_now;               // the window runs two
-    const int split_at = c.split_now ? T : c.split_at;
+    const int T = Wp->T, n = mode == M_WINDOW ? Wp->n : 0;
+    const int node = Wp->node, in_slot = Wp->in_slot;
+    const int dual_in = Wp->dual, split_at = Wp->split_at;
+    const int go0 = Wp->go[0], go1 = Wp->go[1];
+    const int n_kids = mode == M_EXPAND ? Wp->n_kids : 0;
+    const uint8_t* Cn = P.C + (size_t)node * 2 * P.cap;
     for (int x = threadIdx.x; x < 2 * (CW + 1); x += blockDim.x) { (&lv[0][0])[x] = 0; (&le[0][0])[x] = 0; }
     for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) (&ll[0][0])[x] = 0;
-    // the consensus in front of the window and the window itself
+    for (int x = threadIdx.x; x < CW + 1; x += blockDim.x) { lc[x] = 0; lr[x] = 0; }
+    // the consensus in front of column T (a single node shows its one consensus on both sides: a child may split it) and the window
     const int w0 = T - CWIN;
     for (int x = threadIdx.x; x < 2 * (CWIN + CW); x += blockDim.x) {
         const int i = x / (CWIN + CW), y = x % (CWIN + CW), pos = w0 + y;
         uint8_t v = 0;
-        if (i == 0 || dual) {
-            if (pos >= T) v = (pos - T < n) ? P.ctrl->spec[i][pos - T] : 0;
-            else if (pos >= 0) v = (i == 1 && pos < split_at) ? P.C[pos] : P.C[(size_t)i * P.cap + pos];
-        }
+        if (pos >= T) v = (pos - T < n) ? Wp->spec[i][pos - T] : 0;
+        else if (pos >= 0) v = (i == 1 && dual_in && pos >= split_at) ? Cn[(size_t)P.cap + pos] : Cn[pos];
         cwin[i][y] = v;
     }
+    if (threadIdx.x < 2 * (CW / 16 + 2)) {
+        const int i = threadIdx.x / (CW / 16 + 2), w = threadIdx.x % (CW / 16 + 2);
+        uint32_t word = 0;
+        for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < n) word |= (uint32_t)(Wp->spec[i][x] & 3u) << (b << 1); }
+        spk[i][w] = word;
+    }
     __syncthreads();
-    const size_t in_buf = (size_t)c.state_buf, out_buf = in_buf ^ 1;
-    const size_t plane = (size_t)B.total;                 // state layout [buffer][consensus][flattened read]
+    const size_t plane = (size_t)B.total;                 // reads per state plane
     for (int rr = 0; rr < P.rpw; ++rr) {
         const int r = (((int)blockIdx.x - P.first_block) * CWAVES + wave) * P.rpw + rr;
         if (r >= P.n) break;
         const size_t g = (size_t)P.first + r;
         const ReadInfo ri = B.info[g];
         ReadView rv; rv.w = ri.w; rv.np = ri.np; rv.n = ri.n;
-        Dwfa d[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { d[i].H = SP_NEG; d[i].e = 0; d[i].c0 = 0; d[i].flags = 0; }
-        if (c.init) {
-            if (ri.off < 0) { d[0].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0); d[0].H = lane == CH ? 0 : SP_NEG; }
+        Dwfa d0, d1;
+        d0.H = SP_NEG; d0.e = 0; d0.c0 = 0; d0.flags = 0; d1 = d0;
+        if (mode == M_INIT) {
+            if (ri.off < 0) { d0.flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0); d0.H = lane == CH ? 0 : SP_NEG; }
         } else {
-            const ConsMeta m0 = B.meta[(in_buf * 2 + 0) * plane + g];
-            d[0].H = h_load(B.H, ((in_buf * 2 + 0) * plane + g) * CB + lane); d[0].e = m0.e; d[0].c0 = m0.c0; d[0].flags = m0.flags;
-            if (c.split_now) d[1] = d[0];
-            else if (dual_in) {
-                const ConsMeta m1 = B.meta[(in_buf * 2 + 1) * plane + g];
-                d[1].H = h_load(B.H, ((in_buf * 2 + 1) * plane + g) * CB + lane); d[1].e = m1.e; d[1].c0 = m1.c0; d[1].flags = m1.flags;
+            const size_t p0 = state_plane(node, in_slot, 0) * plane + g;
+            const ConsMeta m0 = B.meta[p0];
+            d0.H = h_load(B.H, p0 * CB + lane); d0.e = m0.e; d0.c0 = m0.c0; d0.flags = m0.flags;
+            if (dual_in) {
+                const size_t p1 = state_plane(node, in_slot, 1) * plane + g;
+                const ConsMeta m1 = B.meta[p1];
+                d1.H = h_load(B.H, p1 * CB + lane); d1.e = m1.e; d1.c0 = m1.c0; d1.flags = m1.flags;
             }
         }
         // the stretch of the read around its tips: read position of diagonal 0 at column T minus the band, 384 bases from there
         int rbase = 0;
         {
             int lo = 0x7FFFFFFF;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) if ((i == 0 || dual) && (d[i].flags & F_ACTIVE)) { const int x = T - d[i].c0 - CB; lo = x < lo ? x : lo; }
+            if (d0.flags & F_ACTIVE) { const int x = T - d0.c0 - CB; lo = x < lo ? x : lo; }
+            if (dual_in && (d1.flags & F_ACTIVE)) { const int x = T - d1.c0 - CB; lo = x < lo ? x : lo; }
             if (lo == 0x7FFFFFFF || lo < 0) lo = 0;
             rbase = (lo >> 4) << 4;
-            const int w_first = rbase >> 4, w_last = (rv.n + 15) >> 4;          // words [w_first, w_last] exist (guard words follow the sequence)
+            const int w_first = rbase >> 4, w_last = (rv.n + 15) >> 4;          // words [w_first, w_last + 1] exist (guard words follow the sequence)
             if (lane < RWORDS + 2) {
                 const int w = w_first + lane;
                 rwin[wave][0][lane] = w <= w_last + 1 ? rv.w[w] : 0u;
                 rwin[wave][1][lane] = (rv.np && w <= w_last + 1) ? rv.np[w] : 0u;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            spw::wave_lds_sync();
         }
         auto rb = [&](int h) -> int {
             const int x = h - rbase;
@@ -298,139 +406,199 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
             }
             return read_base(rv, h);
         };
-        auto ca_of = [&](int i) {
-            return [&, i](int pos) -> int {
-                const int y = pos - w0;
-                if ((unsigned)y < (unsigned)(CWIN + CW)) return (int)cwin[i][y];
-                return (int)((i == 1 && pos < split_at) ? P.C[pos] : P.C[(size_t)i * P.cap + pos]);
-            };
-        };
-        // votes of the state for the column it stands at (after j pushes), into the workgroup's tallies
-        auto vote = [&](int j) {
+        // votes of state a (the other state of the read: o) for column `col`, into tally slot `slot` of consensus i
+        auto vote = [&](const Dwfa& a, const Dwfa& o, bool dualrun, int i, int col, int slot) {
+            if (!(a.flags & F_ACTIVE) || (a.flags & (F_FINISHED | F_LOST))) return;
+            if (dualrun && (o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < a.e) return;      // the read follows its better consensus
+            const int Tl = col - a.c0, k = lane - CH;
+            const bool tip = a.H >= 0 && a.H + k == Tl;
+            const int code = (tip && a.H < rv.n) ? rb(a.H) : 5;
+            int dc = 0; unsigned long long word = 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i == 1 && !dual) continue;
-                if (!c.init && !c.go[i]) continue;
-                if (!(d[i].flags & F_ACTIVE) || (d[i].flags & (F_FINISHED | F_LOST))) continue;
-                if (dual) { const Dwfa& o = d[1 - i]; if ((o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < d[i].e) continue; }
-                const int Tl = T + j - d[i].c0, k = lane - CH;
-                const bool tip = d[i].H >= 0 && d[i].H + k == Tl;
-                const int code = (tip && d[i].H < rv.n) ? rb(d[i].H) : 5;
-                int dc = 0; unsigned long long word = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { const bool s = __ballot(code == b) != 0; dc += s; word |= s ? (1ull << (16 * b)) : 0ull; }
-                const bool ended = __ballot(tip) != 0 && __ballot(code == 4) == 0;      // every tip sits at the end of the read
-                if (lane == 0) {
-                    if (dc) atomicAdd(&lv[i][j], word * vote_units(dc));
-                    else if (ended) atomicAdd(&le[i][j], 12u);
-                }
+            for (int b = 0; b < 4; ++b) { const bool s = __ballot(code == b) != 0; dc += s; word |= s ? (1ull << (16 * b)) : 0ull; }
+            const bool ended = __ballot(tip) != 0 && __ballot(code == 4) == 0;      // every tip sits at the end of the read
+            if (lane == 0) {
+                if (dc) atomicAdd(&lv[i][slot], word * vote_units(dc));
+                else if (ended) atomicAdd(&le[i][slot], 12u);
             }
         };
-        if (c.init) vote(0);
-        for (int j = 0; j < n; ++j) {
-            const int len = T + j + 1;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i == 1 && !dual) continue;
-                if (!c.go[i]) continue;
-                const int nb = cwin[i][CWIN + j];
-                if (d[i].flags & F_ACTIVE) {
-                    if (!(d[i].flags & (F_FINISHED | F_LOST))) dwfa_push_t(d[i], rv.n, rb, ca_of(i), len - d[i].c0, nb, P.et, lane);
-                } else if (ri.off == len) {
-                    // a late read (add_sequence_offset): start search in the window before the offset, then catch up
-                    auto ca = ca_of(i);
-                    ActScratch& A = act[wave];
-                    const int ws = ri.off - P.window > 0 ? ri.off - P.window : 0;
-                    for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) A.rcache[x] = (uint8_t)read_base(rv, x);
-                    spw::wave_lds_sync();
-                    auto rbc = [&](int h) { return h < ACT_READ ? (int)A.rcache[h] : read_base(rv, h); };
-                    d[i].c0 = find_start(rv.n, rbc, ca, ri.off, P.window, P.cmp_len, lane);
-                    d[i].H = lane == CH ? 0 : SP_NEG; d[i].e = 0; d[i].flags = F_ACTIVE | ((P.et && rv.n == 0) ? F_FINISHED : 0);
-                    const int c0 = d[i].c0, span = len - c0, cwinlen = len - ws;
-                    const bool packed = rv.np == nullptr && cwinlen <= ACT_CONS;
-                    if (span > 0 && !(d[i].flags & F_FINISHED) && !(P.et && rv.n <= span + CB) && packed) {
-                        // 16 bases per step out of 2-bit packed copies of the two windows
-                        for (int w = lane; w < ACT_CONS / 16 + 2; w += SP_WAVE) {
-                            uint32_t word = 0;
-                            for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < cwinlen) word |= (uint32_t)(ca(ws + x) & 3) << (b << 1); }
-                            A.cpack[w] = word;
-                        }
-                        const int rwords = ((rv.n < ACT_READ ? rv.n : ACT_READ) + 15) >> 4;
-                        for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) A.rpack[w] = w < rwords ? rv.w[w] : 0u;
-                        spw::wave_lds_sync();
-                        const int kk = lane - CH, cbase = c0 - ws;
-                        dwfa_catchup_t(d[i], rv.n, [&]() {
-                            for (;;) {
-                                Dwfa& q = d[i];
-                                int left = rv.n - q.H; { const int l2 = span - (q.H + kk); left = l2 < left ? l2 : left; }
-                                const bool go = q.H >= 0 && left > 0;
-                                int nm = 0;
-                                if (go) {
-                                    const int pr = q.H, pc = cbase + q.H + kk;
-                                    const uint32_t a = __builtin_amdgcn_alignbit(A.rpack[(pr >> 4) + 1], A.rpack[pr >> 4], (uint32_t)(pr & 15) << 1);
-                                    const uint32_t b = __builtin_amdgcn_alignbit(A.cpack[(pc >> 4) + 1], A.cpack[pc >> 4], (uint32_t)(pc & 15) << 1);
-                                    const uint32_t x = a ^ b, mm = (x | (x >> 1)) & 0x55555555u;
-                                    nm = mm ? (__builtin_ctz(mm) >> 1) : 16;
-                                    nm = nm < left ? nm : left;
-                                    q.H += nm;
-                                }
-                                if (!__ballot(go && nm == 16 && left > 16)) break;
-                            }
-                        }, span, lane);
-                    } else if (span > 0 && !(d[i].flags & F_FINISHED) && !(P.et && rv.n <= span + CB)) {
-                        const int kk = lane - CH;
-                        dwfa_catchup_t(d[i], rv.n, [&]() {
-                            for (;;) {
-                                Dwfa& q = d[i];
-                                bool go = q.H >= 0 && q.H < rv.n && q.H + kk < span;
-                                if (go) { const int x = rbc(q.H); go = x < 4 && x == ca(q.c0 + q.H + kk); }
-                                if (!__ballot(go)) break;
-                                if (go) q.H += 1;
-                            }
-                        }, span, lane);
-                    } else {
-                        for (int Tl = 1; Tl <= span; ++Tl) {
-                            if (d[i].flags & (F_FINISHED | F_LOST)) break;
-                            dwfa_push_t(d[i], rv.n, rbc, ca, Tl, ca(c0 + Tl - 1), P.et, lane);
-                        }
-                    }
-                    spw::wave_lds_sync();
-                }
+        // one column the slow way: consensus i grows by nb_i when g_i; a late read is placed; the two states are compared
+        auto column = [&](Dwfa& a0, Dwfa& a1, bool dualrun, int g0, int g1, int nb0, int nb1, int len, const ConsAccess& c0a, const ConsAccess& c1a) {
+            if (g0) {
+                if (a0.flags & F_ACTIVE) { if (!(a0.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a0, rv.n, rb, [&](int p) { return c0a.at(p); }, len - a0.c0, nb0, P.et, lane); }
+                else if (ri.off == len) { a0 = activate_late(rv, c0a, &act[wave], ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
             }
-            if (dual) {
-                const int both = (d[0].flags & F_ACTIVE) && (d[1].flags & F_ACTIVE) && !(d[0].flags & F_LOST) && !(d[1].flags & F_LOST);
+            if (dualrun && g1) {
+                if (a1.flags & F_ACTIVE) { if (!(a1.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a1, rv.n, rb, [&](int p) { return c1a.at(p); }, len - a1.c0, nb1, P.et, lane); }
+                else if (ri.off == len) { a1 = activate_late(rv, c1a, &act[wave], ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
+            }
+            if (dualrun) {
+                const int both = (a0.flags & F_ACTIVE) && (a1.flags & F_ACTIVE) && !(a0.flags & F_LOST) && !(a1.flags & F_LOST);
                 if (both) {
-                    if (d[0].e > d[1].e + P.delta) d[0].flags |= F_LOST;
-                    else if (d[1].e > d[0].e + P.delta) d[1].flags |= F_LOST;
+                    if (a0.e > a1.e + P.delta) a0.flags |= F_LOST;
+                    else if (a1.e > a0.e + P.delta) a1.flags |= F_LOST;
                 }
             }
-            vote(j + 1);
+        };
+        // what the read adds to a FINAL cost over its running cost when its consensuses end at len0 / len1 (no early termination)
+        auto final_extra = [&](const Dwfa& a0, const Dwfa& a1, bool dualrun, int len0, int len1) -> int {
+            if (P.et) return 0;
+            int best = -1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !dualrun) continue;
+                const Dwfa& a = i ? a1 : a0;
+                if (!(a.flags & F_ACTIVE)) continue;
+                int s = a.e;
+                if (!(a.flags & F_LOST)) {
+                    const int k = lane - CH, Tl = (i ? len1 : len0) - a.c0;
+                    int rest = (a.H >= 0 && a.H + k == Tl) ? rv.n - a.H : (1 << 30);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(rest, o); rest = other < rest ? other : rest; }
+                    if (rest < (1 << 30)) s += rest;
+                }
+                if (best < 0 || s < best) best = s;
+            }
+            return best < 0 ? 0 : best - read_cost(a0, a1, dualrun);
+        };
+        auto store = [&](const Dwfa& a, int nd, int slot, int i) {
+            const size_t p = state_plane(nd, slot, i) * plane + g;
+            if (lane == 0) { ConsMeta m; m.e = a.e; m.c0 = a.c0; m.flags = a.flags; m.pad = 0; B.meta[p] = m; }
+            h_store(B.H, p * CB + lane, a.H);
+        };
+        ConsAccess ca0, ca1;
+        ca0.win = &cwin[0][0]; ca0.w0 = w0; ca0.C = Cn; ca0.cap = P.cap; ca0.split_at = split_at; ca0.i = 0; ca0.ov_pos = -1; ca0.ov_base = 0;
+        ca1 = ca0; ca1.win = &cwin[1][0]; ca1.i = 1;
+
+        if (mode == M_EXPAND) {
+            // one push per child, every child from the parent's state
+            const int base_cost = read_cost(d0, d1, dual_in != 0);
+            for (int k = 0; k < n_kids; ++k) {
+                Dwfa e0 = d0, e1 = d1;
+                const int kb0 = Wp->kid_base[k][0], kb1 = Wp->kid_base[k][1], ksplit = Wp->kid_split[k];
+                if (ksplit) e1 = e0;                                         // consensus 2 starts as a copy of consensus 1
+                const bool kdual = dual_in || ksplit;
+                ConsAccess k0 = ca0, k1 = ca1;
+                k0.ov_pos = kb0 >= 0 ? T : -1; k0.ov_base = kb0;
+                k1.ov_pos = kb1 >= 0 ? T : -1; k1.ov_base = kb1;
+                if (ksplit) { k1.i = 0; }                                      // (its prefix is consensus 1's; only the new base differs)
+                column(e0, e1, kdual, kb0 >= 0, kb1 >= 0, kb0, kb1, T + 1, k0, k1);
+                if (kb0 >= 0) vote(e0, e1, kdual, 0, T + 1, k);
+                if (kdual && kb1 >= 0) vote(e1, e0, kdual, 1, T + 1, k);
+                const int grow = read_cost(e0, e1, kdual) - base_cost;
+                const int len0 = kb0 >= 0 ? T + 1 : (go0 ? T : Wp->in_slot * 0 + P.nodes[node].len[0]);
+                const int len1 = kb1 >= 0 ? T + 1 : (go1 ? T : P.nodes[node].len[1]);
+                const int extra = final_extra(e0, e1, kdual, len0, len1);
+                if (lane == 0) { if (grow) atomicAdd(&lc[k], (uint32_t)grow); if (extra) atomicAdd(&lr[k], (uint32_t)extra); }
+                const int kn = Wp->kid_node[k];
+                store(e0, kn, 0, 0);
+                if (kdual) store(e1, kn, 0, 1);
+            }
+            spw::wave_lds_sync();
+            continue;
+        }
+
+        const bool dualrun = dual_in != 0;
+        if (mode == M_INIT) { vote(d0, d1, false, 0, 0, 0); }
+        // number of leading bases on which read[x0 ..] (position relative to the staged window) and the window's bases [j ..] agree
+        auto match_run = [&](int x0, int i, int j0, int len) -> int {
+            int done = 0;
+            if (x0 < 0 || x0 + len + 16 > RWORDS * 16) return 0;
+            while (done < len) {
+                const int x = x0 + done, jj = j0 + done;
+                const uint32_t a = __builtin_amdgcn_alignbit(rwin[wave][0][(x >> 4) + 1], rwin[wave][0][x >> 4], (uint32_t)(x & 15) << 1);
+                const uint32_t nn = __builtin_amdgcn_alignbit(rwin[wave][1][(x >> 4) + 1], rwin[wave][1][x >> 4], (uint32_t)(x & 15) << 1);
+                const uint32_t b = __builtin_amdgcn_alignbit(spk[i][(jj >> 4) + 1], spk[i][jj >> 4], (uint32_t)(jj & 15) << 1);
+                const uint32_t xr = a ^ b, mm = ((xr | (xr >> 1)) | nn) & 0x55555555u;
+                int run = mm ? (__builtin_ctz(mm) >> 1) : 16;
+                run = run < len - done ? run : len - done;
+                done += run;
+                if (run < 16) break;
+            }
+            return done;
+        };
+        int j = 0;
+        while (j < n) {
+            // A consensus whose state has ONE tip that keeps matching moves nothing but that tip: such a clean run is applied in one go
+            // (the tip's position grows by m, the votes of the m columns are the m read bases behind it, one lane per column).
+            int m = n - j;
+            int tl0 = -1, th0 = 0, tl1 = -1, th1 = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !dualrun) continue;
+                if (!(i ? go1 : go0)) continue;
+                const Dwfa& a = i ? d1 : d0;
+                if (a.flags & F_ACTIVE) {
+                    if (a.flags & (F_FINISHED | F_LOST)) continue;
+                    const int Tl = T + j - a.c0, k = lane - CH;
+                    const unsigned long long tm = __ballot(a.H >= 0 && a.H + k == Tl);
+                    if (__builtin_popcountll(tm) != 1) { m = 0; continue; }
+                    const int tl = __builtin_ctzll(tm), h = __builtin_amdgcn_readlane(a.H, tl);
+                    int room = rv.n - h; room = room < m ? room : m;
+                    const int run = room > 0 ? match_run(h - rbase, i, j, room) : 0;
+                    m = run < m ? run : m;
+                    if (i) { tl1 = tl; th1 = h; } else { tl0 = tl; th0 = h; }
+                } else if (ri.off > T + j && ri.off <= T + n) {
+                    const int before = ri.off - T - 1 - j;                  // pushes before the one that places the read
+                    m = before < m ? before : m;
+                }
+            }
+            if (m > 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int tl = i ? tl1 : tl0, th = i ? th1 : th0;
+                    if (tl < 0) continue;
+                    Dwfa& a = i ? d1 : d0; const Dwfa& o = i ? d0 : d1;
+                    bool speaks = true;
+                    if (dualrun && (o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < a.e) speaks = false;
+                    const int x = lane + 1;                                  // lane l names the vote after l + 1 of the m pushes
+                    if (speaks && x <= m) {
+                        const int pos = th + x;
+                        if (pos < rv.n) { const int code = rb(pos); if (code < 4) atomicAdd(&lv[i][j + x], 12ull << (16 * code)); }
+                        else if (!P.et) atomicAdd(&le[i][j + x], 12u);       // (with early termination the read is finished by that push)
+                    }
+                    if (lane == tl) a.H += m;
+                    if (P.et && th + m == rv.n) a.flags |= F_FINISHED;
+                }
+                j += m;
+                continue;
+            }
+            const int before = read_cost(d0, d1, dualrun);
+            column(d0, d1, dualrun, go0, go1, cwin[0][CWIN + j], cwin[1][CWIN + j], T + j + 1, ca0, ca1);
+            const int grow = read_cost(d0, d1, dualrun) - before;
+            if (grow && lane == 0) atomicAdd(&lc[j + 1], (uint32_t)grow);
+            if (go0) vote(d0, d1, dualrun, 0, T + j + 1, j + 1);
+            if (dualrun && go1) vote(d1, d0, dualrun, 1, T + j + 1, j + 1);
+            j += 1;
         }
         // lookahead: the bases behind every tip (at most two tips per consensus speak) predict the columns after the window
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if (i == 1 && !dual) continue;
-            if (!c.init && !c.go[i]) continue;
-            if (!(d[i].flags & F_ACTIVE) || (d[i].flags & (F_FINISHED | F_LOST))) continue;
-            if (dual) { const Dwfa& o = d[1 - i]; if ((o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < d[i].e) continue; }
-            const int Tl = T + n - d[i].c0, k = lane - CH;
-            unsigned long long tips = __ballot(d[i].H >= 0 && d[i].H + k == Tl && d[i].H < rv.n);
+            if (i == 1 && !dualrun) continue;
+            if (mode != M_INIT && !(i ? go1 : go0)) continue;
+            const Dwfa& a = i ? d1 : d0; const Dwfa& o = i ? d0 : d1;
+            if (!(a.flags & F_ACTIVE) || (a.flags & (F_FINISHED | F_LOST))) continue;
+            if (dualrun && (o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < a.e) continue;
+            const int Tl = T + n - a.c0, k = lane - CH;
+            unsigned long long tips = __ballot(a.H >= 0 && a.H + k == Tl && a.H < rv.n);
             for (int cnt = 0; tips && cnt < 2; ++cnt) {
                 const int tl = __builtin_ctzll(tips); tips &= tips - 1;
-                const int h = __builtin_amdgcn_readlane(d[i].H, tl);
+                const int h = __builtin_amdgcn_readlane(a.H, tl);
                 if (lane < CW - 1 && h + 1 + lane < rv.n) {
                     const int b = rb(h + 1 + lane);
                     if (b < 4) atomicAdd(&ll[i][lane], 1ull << (16 * b));
                 }
             }
         }
-        // the new state goes to the other buffer
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i == 1 && !dual) continue;
-            if (lane == 0) { ConsMeta m; m.e = d[i].e; m.c0 = d[i].c0; m.flags = d[i].flags; m.pad = 0; B.meta[(out_buf * 2 + i) * plane + g] = m; }
-            h_store(B.H, ((out_buf * 2 + i) * plane + g) * CB + lane, d[i].H);
+        {
+            const int len0 = go0 || mode == M_INIT ? T + n : P.nodes[node].len[0], len1 = go1 ? T + n : P.nodes[node].len[1];
+            const int extra = final_extra(d0, d1, dualrun, len0, len1);
+            if (extra && lane == 0) atomicAdd(&lr[n], (uint32_t)extra);
         }
+        // the new state goes to the node's other slot (the root's first state: its slot 0)
+        const int out_slot = mode == M_INIT ? in_slot : in_slot ^ 1;
+        store(d0, node, out_slot, 0);
+        if (dualrun) store(d1, node, out_slot, 1);
         spw::wave_lds_sync();
     }
     __syncthreads();
@@ -439,143 +607,330 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
         B.PE[(size_t)blockIdx.x * 2 * (CW + 1) + x] = (&le[0][0])[x];
     }
     for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) B.PL[(size_t)blockIdx.x * 2 * CW + x] = (&ll[0][0])[x];
+    for (int x = threadIdx.x; x < CW + 1; x += blockDim.x) { B.PC[(size_t)blockIdx.x * (CW + 1) + x] = lc[x]; B.PR[(size_t)blockIdx.x * (CW + 1) + x] = lr[x]; }
+}
+
+// heaviest base of a vote column first (ties to the lower code)
+struct ColVotes { uint32_t w[4], end; };
+
+// candidates of a column (oracle/consensus.c: candidates): 0 = the consensus stops there
+__device__ __forceinline__ int col_candidates(const uint32_t* w5, int col, int cap, int et, int min_count, double min_af, int out[4]) {
+    if (col >= cap) return 0;                                                           // out of room: the consensus is cut at cap
+    int order[4] = { 0, 1, 2, 3 };
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) if (w5[order[b]] > w5[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+    const uint32_t w1 = w5[order[0]], total = w5[0] + w5[1] + w5[2] + w5[3];
+    const bool go = et ? w1 > 0 : (total > w5[4] && w1 > 0);
+    if (!go) return 0;
+    uint32_t need = 12u * (uint32_t)min_count; if (w1 < need) need = w1;
+    int n = 0;
+    out[n++] = order[0];
+#pragma unroll
+    for (int a = 1; a < 4; ++a) { const uint32_t w = w5[order[a]]; if (w > 0 && w >= need && (double)w >= min_af * (double)total) out[n++] = order[a]; }
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// the control step: one workgroup per problem sums the vote words of the problem's workgroups, verifies the window and sets up
-// the next one
+// the control step: one workgroup per problem sums the vote words of the problem's workgroups, takes the result of the last step
+// into the node table and plays the search forward until the best node needs the next launch
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int MAXP>
 __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) {
+    extern __shared__ uint8_t proc[];                     // nodes expanded per length (cap + 2 bytes, padded to 16)
     __shared__ uint32_t sv[2][CW + 1][5];                 // summed exact votes: w[4], end
     __shared__ uint32_t sl[2][CW][4];                     // summed lookahead votes
-    __shared__ ConsCtrl cs;
+    __shared__ uint32_t sc[CW + 1], sr[CW + 1];           // summed cost growth / final-cost extra
+    __shared__ CNode nh[NQ];
+    __shared__ CWork wk;
+    __shared__ CSearch ss;
+    __shared__ int copy_from, copy_len, need_la;
     const int pi = blockIdx.x;
     const ConsParams P = B.p[pi];
-    if (threadIdx.x == 0) cs = *P.ctrl;
-    for (int x = threadIdx.x; x < 2 * (CW + 1) * 5; x += blockDim.x) (&sv[0][0][0])[x] = 0;
-    for (int x = threadIdx.x; x < 2 * CW * 4; x += blockDim.x) (&sl[0][0][0])[x] = 0;
+    const int tid = threadIdx.x;
+    if (P.work->done) return;
+    for (int x = tid; x < 2 * (CW + 1) * 5; x += blockDim.x) (&sv[0][0][0])[x] = 0;
+    for (int x = tid; x < 2 * CW * 4; x += blockDim.x) (&sl[0][0][0])[x] = 0;
+    for (int x = tid; x < CW + 1; x += blockDim.x) { sc[x] = 0; sr[x] = 0; }
+    for (int x = tid; x < (int)(sizeof(CNode) * NQ / 4); x += blockDim.x) ((uint32_t*)nh)[x] = ((const uint32_t*)P.nodes)[x];
+    for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)&wk)[x] = ((const uint32_t*)P.work)[x];
+    for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)&ss)[x] = ((const uint32_t*)P.srch)[x];
+    const int proc_words = (P.cap + 2 + 3) / 4;
+    for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)proc)[x] = ((const uint32_t*)P.processed)[x];
+    if (tid == 0) { copy_from = -1; copy_len = 0; need_la = -1; }
     __syncthreads();
-    if (cs.done || (cs.n == 0 && !cs.init)) return;
-    const int n = cs.n;
+    const int mode_in = wk.mode, n_in = wk.mode == M_WINDOW ? wk.n : 0;
     {
-        // element e of a workgroup's partial block: e < 2 (CW + 1): exact votes (V + E); then 2 CW lookahead words
-        const int EV = 2 * (CW + 1), EL = 2 * CW, E = EV + EL;
+        // element e of a workgroup's partial block: exact votes (V + E), lookahead words, cost growth, final-cost extra
+        const int EV = 2 * (CW + 1), EL = 2 * CW, EC = CW + 1, E = EV + EL + 2 * EC;
         const int per = blockDim.x / E > 0 ? blockDim.x / E : 1;
-        const int e = threadIdx.x % E, sub = threadIdx.x / E;
-        if (sub < per) {
+        const int e = tid % E, sub = tid / E;
+        if (sub < per && mode_in != M_NONE) {
             uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-            const bool is_v = e < EV;
-            const int j = is_v ? e % (CW + 1) : (e - EV) % CW;
-            const bool wanted = is_v ? j <= n : true;
-            if (wanted) for (int b = sub; b < P.n_blocks; b += per) {
-                const size_t blk = (size_t)P.first_block + b;
-                if (is_v) {
-                    const unsigned long long v = B.PV[blk * EV + e];
-                    a0 += (uint32_t)(v & 0xFFFF); a1 += (uint32_t)((v >> 16) & 0xFFFF); a2 += (uint32_t)((v >> 32) & 0xFFFF); a3 += (uint32_t)(v >> 48);
-                    a4 += B.PE[blk * EV + e];
-                } else {
-                    const unsigned long long v = B.PL[blk * EL + (e - EV)];
-                    a0 += (uint32_t)(v & 0xFFFF); a1 += (uint32_t)((v >> 16) & 0xFFFF); a2 += (uint32_t)((v >> 32) & 0xFFFF); a3 += (uint32_t)(v >> 48);
+            const int kind = e < EV ? 0 : e < EV + EL ? 1 : e < EV + EL + EC ? 2 : 3;
+            const int idx = kind == 0 ? e : kind == 1 ? e - EV : kind == 2 ? e - EV - EL : e - EV - EL - EC;
+            const int j = kind == 0 ? idx % (CW + 1) : kind == 1 ? idx % CW : idx;
+            const int top = mode_in == M_EXPAND ? wk.n_kids : n_in;
+            const bool wanted = kind == 1 ? mode_in != M_EXPAND : j <= top;
+            // eight independent loads in flight per thread: the words were written by another kernel and come from memory
+            if (wanted) for (int b0 = sub; b0 < P.n_blocks; b0 += per * 8) {
+                unsigned long long v[8]; uint32_t en[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + u * per;
+                    const size_t blk = (size_t)P.first_block + (b < P.n_blocks ? b : 0);
+                    v[u] = kind == 0 ? B.PV[blk * EV + idx] : kind == 1 ? B.PL[blk * EL + idx] : kind == 2 ? (unsigned long long)B.PC[blk * EC + idx] : (unsigned long long)B.PR[blk * EC + idx];
+                    en[u] = kind == 0 ? B.PE[blk * EV + idx] : 0u;
+                    if (b >= P.n_blocks) { v[u] = 0; en[u] = 0; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (kind < 2) { a0 += (uint32_t)(v[u] & 0xFFFF); a1 += (uint32_t)((v[u] >> 16) & 0xFFFF); a2 += (uint32_t)((v[u] >> 32) & 0xFFFF); a3 += (uint32_t)(v[u] >> 48); }
+                    else a0 += (uint32_t)v[u];
+                    a4 += en[u];
                 }
             }
-            if (is_v) { uint32_t* d = &sv[e / (CW + 1)][j][0]; atomicAdd(d, a0); atomicAdd(d + 1, a1); atomicAdd(d + 2, a2); atomicAdd(d + 3, a3); atomicAdd(d + 4, a4); }
-            else { uint32_t* d = &sl[(e - EV) / CW][j][0]; atomicAdd(d, a0); atomicAdd(d + 1, a1); atomicAdd(d + 2, a2); atomicAdd(d + 3, a3); }
+            if (kind == 0) { uint32_t* d = &sv[idx / (CW + 1)][j][0]; atomicAdd(d, a0); atomicAdd(d + 1, a1); atomicAdd(d + 2, a2); atomicAdd(d + 3, a3); atomicAdd(d + 4, a4); }
+            else if (kind == 1) { uint32_t* d = &sl[idx / CW][j][0]; atomicAdd(d, a0); atomicAdd(d + 1, a1); atomicAdd(d + 2, a2); atomicAdd(d + 3, a3); }
+            else if (kind == 2) atomicAdd(&sc[j], a0);
+            else atomicAdd(&sr[j], a0);
         }
     }
     __syncthreads();
-    if (threadIdx.x >= SP_WAVE) return;
-    const int lane = threadIdx.x;
-    const int dual = cs.dual || cs.split_now;
-    const int T = cs.T;
-    // the decision the complete votes make for the column after j pushes, per consensus
-    auto decide = [&](int i, int j, int& base, int& b2, uint32_t& w2, uint32_t& total) -> bool {
-        ColVotes v; for (int b = 0; b < 4; ++b) v.w[b] = sv[i][j][b]; v.end = sv[i][j][4];
-        int b1; uint32_t w1; top2(v, b1, w1, b2, w2, total);
-        base = b1;
-        if (T + j >= P.cap) return false;                                               // out of room: the consensus is cut at cap
-        return P.et ? w1 > 0 : (total > v.end && w1 > 0);
-    };
-    // 1. how much of the window stands: lane j checks the base pushed as number j (1 <= j < n) against the votes after j pushes
-    int a = n;
-    uint32_t my_w2 = 0, my_total = 1; bool my_cand = false;
-    if (!cs.replay && n > 1) {
-        bool ok = true;
-        if (lane >= 1 && lane < n) {
+    if (tid < SP_WAVE) {
+        const int lane = tid;
+        auto cands = [&](const uint32_t* w5, int col, int out[4]) { return col_candidates(w5, col, P.cap, P.et, P.min_count, P.min_af, out); };
+        auto node_free = [&](int k) { nh[k].used = 0; nh[k].complete = 0; };
+        auto node_alloc = [&]() -> int { for (int k = 0; k < NQ; ++k) if (!nh[k].used) { nh[k].used = 1; nh[k].complete = 0; return k; } return -1; };
+        uint8_t* Cb = P.C;
+        // ---------------------------------------------------------------- 1. the result of the last step
+        if (mode_in == M_INIT) {
+            CNode& x = nh[wk.node];
+            if (lane == 0) {
+                x.used = 1; x.id = ss.next_id++; x.complete = 0; x.T = 0; x.cur = wk.in_slot; x.dual = 0; x.split_at = -1;
+                x.stopped[0] = 0; x.stopped[1] = 1; x.len[0] = x.len[1] = 0; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
+                x.cost[0] = 0; x.rest = sr[0]; x.rest_out = 0;
+                for (int i = 0; i < 2; ++i) for (int b = 0; b < 5; ++b) x.ev[i][b] = sv[i][0][b];
+            }
+            for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
+        } else if (mode_in == M_WINDOW) {
+            CNode& x = nh[wk.node];
+            const int n = n_in, T = wk.T;
+            int a = n;
+            if (!wk.replay && n > 1) {
+                bool ok = true;
+                if (lane >= 1 && lane < n) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i == 1 && !dual) continue;
-                if (!cs.go[i]) continue;
-                int base, b2; uint32_t w2, total;
-                const bool go = decide(i, lane, base, b2, w2, total);
-                if (!go || base != cs.spec[i][lane]) ok = false;
-                if (!dual && i == 0 && go && w2 >= 12u * (uint32_t)P.min_count) {
-                    my_cand = true; my_w2 = w2; my_total = total;
-                    if (P.allow_dual && (double)w2 >= P.min_af * (double)total) ok = false;       // a split is an event: it opens a window
+                    for (int i = 0; i < 2; ++i) {
+                        if (i == 1 && !x.dual) continue;
+                        if (!wk.go[i]) continue;
+                        int c4[4];
+                        const int nc = cands(sv[i][lane], T + lane, c4);
+                        if (nc != 1 || c4[0] != wk.spec[i][lane]) ok = false;     // a stop, a second candidate or another base: the tape ends there
+                    }
+                }
+                const unsigned long long bad = __ballot(!ok);
+                if (bad) a = __builtin_ctzll(bad);
+            }
+            if (lane < a) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wk.go[i]) Cb[((size_t)wk.node * 2 + i) * P.cap + T + lane] = wk.spec[i][lane];
+            }
+            if (lane == 0) {
+                ss.windows += 1; if (a < n) ss.cut_windows += 1;
+                // a replay re-reads columns whose costs are on the tape already: it only brings the state (and the votes) of column T + a
+                if (!wk.replay) {
+                    x.n = n; x.a = a;
+                    long long c = x.cost[0];
+                    for (int j = 1; j <= a; ++j) { c += (long long)sc[j]; x.cost[j] = c; }
+                    for (int i = 0; i < 2; ++i) for (int j = 0; j < n; ++j) x.spec[i][j] = wk.spec[i][j];
+                } else { x.n = n; x.a = n; }
+                for (int i = 0; i < 2; ++i) for (int b = 0; b < 5; ++b) x.ev[i][b] = sv[i][a][b];
+                x.have_out = (a == n) ? 1 : 0;
+                if (a == n) x.rest_out = sr[n];
+            }
+            if (a == n) for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
+        } else if (mode_in == M_EXPAND) {
+            if (lane == 0) {
+                const CNode par = nh[wk.node];
+                const int L = wk.T;
+                const long long pc = par.cost[par.q];
+                for (int k = 0; k < wk.n_kids; ++k) {
+                    CNode& c = nh[wk.kid_node[k]];
+                    c.used = 1; c.complete = 0; c.id = ss.next_id++; c.T = L + 1; c.cur = 0;
+                    c.dual = par.dual || wk.kid_split[k]; c.split_at = wk.kid_split[k] ? L : par.split_at;
+                    for (int i = 0; i < 2; ++i) {
+                        const bool was_going = (i == 0 || par.dual) && !par.stopped[i];
+                        c.stopped[i] = par.stopped[i]; c.len[i] = par.len[i];
+                        if (wk.kid_base[k][i] >= 0) { c.stopped[i] = 0; c.len[i] = L + 1; }
+                        else if (was_going) { c.stopped[i] = 1; c.len[i] = L; }
+                    }
+                    if (!c.dual) c.stopped[1] = 1;
+                    c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = 0;
+                    c.cost[0] = pc + (long long)sc[k]; c.rest = sr[k]; c.rest_out = 0;
+                    for (int i = 0; i < 2; ++i) for (int b = 0; b < 5; ++b) c.ev[i][b] = sv[i][k][b];
+                }
+                node_free(wk.node);
+                ss.expansions += 1;
+                // more than max_queue_size nodes wait: the one the search would take last goes
+                for (;;) {
+                    int waiting = 0, wi = -1;
+                    for (int k = 0; k < NQ; ++k) {
+                        if (!nh[k].used || nh[k].complete) continue;
+                        ++waiting;
+                        if (wi < 0) { wi = k; continue; }
+                        const CNode& p = nh[k]; const CNode& b = nh[wi];
+                        const long long pcst = p.cost[p.q], bcst = b.cost[b.q]; const int pt = p.T + p.q, bt = b.T + b.q;
+                        if (pcst > bcst || (pcst == bcst && (pt < bt || (pt == bt && p.id > b.id)))) wi = k;
+                    }
+                    if (waiting <= ss.max_queue) break;
+                    node_free(wi);
                 }
             }
         }
-        const unsigned long long bad = __ballot(!ok);
-        if (bad) a = __builtin_ctzll(bad);
-    }
-    // strongest second-base column among the accepted ones, in column order (a strictly better ratio replaces)
-    if (!dual && !cs.replay) {
-        unsigned long long cand = __ballot(my_cand && lane < a);
-        while (cand) {
-            const int l = __builtin_ctzll(cand); cand &= cand - 1;
-            const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)my_w2, l), tot = (uint32_t)__builtin_amdgcn_readlane((int)my_total, l);
-            if (lane == 0 && (unsigned long long)w2 * (unsigned long long)cs.best_total > (unsigned long long)cs.best_w2 * (unsigned long long)tot) { cs.best_w2 = w2; cs.best_total = tot; }
+        __threadfence();                                  // (the lookahead words written above are read below by other lanes)
+        spw::wave_lds_sync();
+        // ---------------------------------------------------------------- 2. the search, played forward over the tapes
+        if (lane == 0) {
+            wk.mode = M_NONE; wk.n = 0; wk.replay = 0; wk.n_kids = 0;
+            int guard = 0;
+            // the nodes that wait (a short list: scanning the whole table at every column of a tape is what this loop would spend its time on)
+            int wait_idx[NQ], n_wait = 0;
+            for (int k = 0; k < NQ; ++k) if (nh[k].used && !nh[k].complete) wait_idx[n_wait++] = k;
+            for (;;) {
+                if (++guard > 100000) { wk.done = 1; break; }
+                int xi = ss.inflight;
+                if (xi < 0) {
+                    for (int w = 0; w < n_wait; ++w) {
+                        const int k = wait_idx[w];
+                        if (!nh[k].used || nh[k].complete) { wait_idx[w--] = wait_idx[--n_wait]; continue; }      // (freed or completed since the list was made)
+                        if (xi < 0) { xi = k; continue; }
+                        const CNode& p = nh[k]; const CNode& b = nh[xi];
+                        const long long pc = p.cost[p.q], bc = b.cost[b.q]; const int pt = p.T + p.q, bt = b.T + b.q;
+                        if (pc < bc || (pc == bc && (pt > bt || (pt == bt && p.id < b.id)))) xi = k;
+                    }
+                    if (xi < 0) { wk.done = 1; break; }                                     // nothing waits
+                    CNode& x = nh[xi];
+                    if (ss.best_node >= 0 && x.cost[x.q] >= ss.best_final) { wk.done = 1; break; }   // nothing that waits can beat (or precede) the complete node
+                    const int L = x.T + x.q;
+                    if (L < ss.threshold || proc[L] >= ss.per_size) { node_free(xi); continue; }
+                    proc[L] += 1; ss.pops += 1;
+                    if (L > ss.farthest) ss.farthest = L;
+                    if (ss.pops % ss.wo_constraint == 0 && ss.farthest > ss.threshold) ss.threshold = ss.farthest;
+                }
+                CNode& x = nh[xi];
+                ss.inflight = -1;
+                if (x.q < x.a) { x.q += 1; x.id = ss.next_id++; continue; }                  // a verified column of its tape: the node moves on (its one child)
+                // the node stands at the end of its tape: its state at that column has to be there
+                if (x.q > 0 || x.n > 0) {
+                    if (x.a == x.n && x.have_out) {                                        // the window stood: the other slot is the state
+                        x.T += x.n; x.cur ^= 1; x.cost[0] = x.cost[x.n]; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
+                    } else {
+                        // cut window: push the verified bases again from the kept state (nothing is speculated)
+                        wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = x.a; wk.replay = 1;
+                        wk.dual = x.dual; wk.split_at = x.split_at;
+                        for (int i = 0; i < 2; ++i) { wk.go[i] = (i == 0 || x.dual) && !x.stopped[i]; for (int j = 0; j < x.a; ++j) wk.spec[i][j] = x.spec[i][j]; }
+                        ss.inflight = xi;
+                        break;
+                    }
+                }
+                const int L = x.T;
+                // candidates of every consensus that is still going
+                int nc[2] = { 0, 0 }, cd[2][4];
+                for (int i = 0; i < (x.dual ? 2 : 1); ++i) {
+                    if (x.stopped[i]) continue;
+                    nc[i] = cands(x.ev[i], L, cd[i]);
+                    if (nc[i] == 0) { x.stopped[i] = 1; x.len[i] = L; }
+                }
+                if (nc[0] == 0 && nc[1] == 0) {                                            // complete
+                    const long long fc = x.cost[0] + (P.et ? 0 : x.rest);
+                    if (ss.best_node < 0 || fc < ss.best_final) { if (ss.best_node >= 0) node_free(ss.best_node); ss.best_node = xi; ss.best_final = fc; x.complete = 1; }
+                    else node_free(xi);
+                    continue;
+                }
+                // children, in the oracle's order
+                int kb[MAXKIDS][2], ks[MAXKIDS], nk = 0;
+                if (!x.dual) {
+                    for (int a = 0; a < nc[0]; ++a) { kb[nk][0] = cd[0][a]; kb[nk][1] = -1; ks[nk] = 0; ++nk; }
+                    if (P.allow_dual) for (int a = 0; a < nc[0]; ++a) for (int b = a + 1; b < nc[0]; ++b) { kb[nk][0] = cd[0][a]; kb[nk][1] = cd[0][b]; ks[nk] = 1; ++nk; }
+                } else {
+                    const int n0 = nc[0] ? nc[0] : 1, n1 = nc[1] ? nc[1] : 1;
+                    for (int a = 0; a < n0; ++a) for (int b = 0; b < n1; ++b) { kb[nk][0] = nc[0] ? cd[0][a] : -1; kb[nk][1] = nc[1] ? cd[1][b] : -1; ks[nk] = 0; ++nk; }
+                }
+                if (nk == 1) {
+                    // one child: the node itself goes on, through a window whose first base is this decision
+                    wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = L; wk.replay = 0; wk.dual = x.dual; wk.split_at = x.split_at;
+                    for (int i = 0; i < 2; ++i) { wk.go[i] = kb[0][i] >= 0; wk.spec[i][0] = (uint8_t)(kb[0][i] >= 0 ? kb[0][i] : 0); }
+                    int nn = 1;
+                    need_la = x.la_valid ? xi : -1;
+                    wk.n = nn;
+                    // the pop is under way: when the window is back the node has consumed its first column
+                    x.n = 0; x.a = 0; x.q = 0;
+                    ss.inflight = xi;
+                    break;
+                }
+                // several children: one push each into fresh nodes
+                wk.mode = M_EXPAND; wk.node = xi; wk.in_slot = x.cur; wk.T = L; wk.dual = x.dual; wk.split_at = x.split_at;
+                wk.go[0] = nc[0] > 0; wk.go[1] = nc[1] > 0;
+                int made = 0;
+                for (int k = 0; k < nk && made < MAXKIDS; ++k) {
+                    const int kn = node_alloc();
+                    if (kn < 0) break;                                                  // (the table holds the queue plus one expansion: not reached)
+                    wk.kid_node[made] = kn; wk.kid_base[made][0] = (int8_t)kb[k][0]; wk.kid_base[made][1] = (int8_t)kb[k][1]; wk.kid_split[made] = (int8_t)ks[k];
+                    ++made;
+                }
+                wk.n_kids = made;
+                copy_from = xi; copy_len = L;
+                break;
+            }
         }
-    }
-    // 2. commit the accepted bases
-    if (lane < a) {
+        // the speculated part of a new window: lane j takes the heaviest lookahead vote for push j of every consensus that grows; the
+        // window ends where a consensus has no lookahead votes left (or at cap)
+        spw::wave_lds_sync();
+        if (need_la >= 0) {
+            const uint32_t* la = P.la + (size_t)need_la * 2 * CW * 4;
+            bool have = lane >= 1 && lane < CW && wk.T + lane < P.cap;
+            int pick[2] = { 0, 0 };
+            if (have) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) if ((i == 0 || dual) && cs.go[i]) P.C[(size_t)i * P.cap + T + lane] = cs.spec[i][lane];
+                for (int i = 0; i < 2; ++i) {
+                    if (!wk.go[i]) continue;
+                    const uint4 w = *reinterpret_cast<const uint4*>(la + ((size_t)i * CW + (lane - 1)) * 4);
+                    int b1 = 0; uint32_t w1 = w.x;
+                    if (w.y > w1) { b1 = 1; w1 = w.y; }
+                    if (w.z > w1) { b1 = 2; w1 = w.z; }
+                    if (w.w > w1) { b1 = 3; w1 = w.w; }
+                    if (w1 == 0) have = false;
+                    pick[i] = b1;
+                }
+            }
+            const unsigned long long miss = __ballot(!have) & ~1ull;          // lane 0 is the exact base
+            const int nn = miss ? __builtin_ctzll(miss) : SP_WAVE;
+            if (lane >= 1 && lane < nn && lane < CW) { wk.spec[0][lane] = (uint8_t)pick[0]; wk.spec[1][lane] = (uint8_t)pick[1]; }
+            if (lane == 0) wk.n = nn < CW ? nn : CW;
+        }
     }
-    if (lane != 0) return;
-    cs.windows += 1;
-    for (int i = 0; i < 2; ++i) if ((i == 0 || dual) && cs.go[i] && a > 0) cs.len[i] = T + a;
-    if (a < n) {                                          // cut window: push the verified bases again, from the kept state
-        cs.n = a; cs.replay = 1; cs.cut_windows += 1;
-        *P.ctrl = cs;
-        return;
-    }
-    // 3. the whole window stands: the new state is the other buffer; decide the column it stands at and speculate on
-    cs.T = T + n; cs.state_buf ^= 1; cs.replay = 0; cs.init = 0;
-    if (cs.split_now) { cs.dual = 1; cs.split_at = T; cs.split_now = 0; }
-    const int nd = cs.dual ? 2 : 1;
-    int going = 0;
-    for (int i = 0; i < 2; ++i) cs.go[i] = 0;
-    for (int i = 0; i < nd; ++i) {
-        if (cs.stopped[i]) continue;
-        int base, b2; uint32_t w2, total;
-        const bool go = decide(i, n, base, b2, w2, total);
-        if (!go) { cs.stopped[i] = 1; continue; }
-        cs.go[i] = 1; cs.spec[i][0] = (uint8_t)base; going += 1;
-        if (!cs.dual && w2 >= 12u * (uint32_t)P.min_count) {
-            if ((unsigned long long)w2 * (unsigned long long)cs.best_total > (unsigned long long)cs.best_w2 * (unsigned long long)total) { cs.best_w2 = w2; cs.best_total = total; }
-            if (P.allow_dual && (double)w2 >= P.min_af * (double)total) {
-                cs.split_now = 1; cs.go[1] = 1; cs.stopped[1] = 0; cs.spec[1][0] = (uint8_t)b2; cs.split_w2 = w2; cs.split_total = total;
+    __syncthreads();
+    // a window whose pop was under way comes back with its first column consumed (set here for the next pass: the tape is filled in
+    // by part 1 of that pass); children get their parent's consensus
+    if (copy_from >= 0) {
+        for (int k = 0; k < wk.n_kids; ++k) {
+            const int kn = wk.kid_node[k];
+            const bool split = wk.kid_split[k] != 0;
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !(wk.dual || split)) continue;
+                const uint8_t* src = P.C + ((size_t)copy_from * 2 + ((i == 1 && split) ? 0 : i)) * P.cap;
+                uint8_t* dst = P.C + ((size_t)kn * 2 + i) * P.cap;
+                for (int y = tid; y < copy_len; y += blockDim.x) dst[y] = src[y];
+                if (tid == 0 && wk.kid_base[k][i] >= 0) dst[copy_len] = (uint8_t)wk.kid_base[k][i];
             }
         }
     }
-    if (!going) { cs.done = 1; cs.n = 0; *P.ctrl = cs; return; }
-    int nn = 1;
-    if (!cs.split_now) {
-        for (; nn < CW && cs.T + nn < P.cap; ++nn) {
-            bool have = true;
-            for (int i = 0; i < nd && have; ++i) {
-                if (!cs.go[i]) continue;
-                const uint32_t* w = sl[i][nn - 1];
-                int b1 = 0; uint32_t w1 = w[0];
-                for (int b = 1; b < 4; ++b) if (w[b] > w1) { b1 = b; w1 = w[b]; }
-                if (w1 == 0) have = false; else cs.spec[i][nn] = (uint8_t)b1;
-            }
-            if (!have) break;
-        }
-    }
-    cs.n = nn;
-    *P.ctrl = cs;
+    for (int x = tid; x < (int)(sizeof(CNode) * NQ / 4); x += blockDim.x) ((uint32_t*)P.nodes)[x] = ((const uint32_t*)nh)[x];
+    for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)P.work)[x] = ((const uint32_t*)&wk)[x];
+    for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)P.srch)[x] = ((const uint32_t*)&ss)[x];
+    for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)P.processed)[x] = ((const uint32_t*)proc)[x];
 }
 
 // gathers the per-read constants of one problem into the flattened ReadInfo array (once per batch)
@@ -590,33 +945,38 @@ __global__ void cons_setup_kernel(ConsSetup S, ReadInfo* __restrict__ info) {
     info[S.first + r] = ri;
 }
 
+// scores and assignment of the reads on the complete node the search ended with
 template <int MAXP>
 __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBatchT<MAXP> B, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
     const int pi = block_problem<MAXP>(B);
     const ConsParams P = B.p[pi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const ConsCtrl c = *P.ctrl;
-    const size_t buf = (size_t)c.state_buf, plane = (size_t)B.total;
+    const int best = P.srch->best_node;
+    const size_t plane = (size_t)B.total;
     for (int rr = 0; rr < P.rpw; ++rr) {
         const int r = (((int)blockIdx.x - P.first_block) * CWAVES + wave) * P.rpw + rr;
         if (r >= P.n) break;
         const size_t g = (size_t)P.first + r;
-        const int n = B.info[g].n;
         int sc[2] = { -1, -1 };
+        if (best >= 0) {
+            const CNode* x = P.nodes + best;
+            const int n = B.info[g].n, cur = x->cur, dual = x->dual;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i == 1 && !c.dual) continue;
-            const ConsMeta m = B.meta[(buf * 2 + i) * plane + g];
-            if (!(m.flags & F_ACTIVE) || (m.flags & F_LOST)) continue;
-            int e = m.e;
-            if (!P.et) {
-                const int h = h_load(B.H, ((buf * 2 + i) * plane + g) * CB + lane), k = lane - CH;
-                int rest = (h >= 0 && h + k == c.len[i] - m.c0) ? n - h : (1 << 30);
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !dual) continue;
+                const size_t p = state_plane(best, cur, i) * plane + g;
+                const ConsMeta m = B.meta[p];
+                if (!(m.flags & F_ACTIVE) || (m.flags & F_LOST)) continue;
+                int e = m.e;
+                if (!P.et) {
+                    const int h = h_load(B.H, p * CB + lane), k = lane - CH;
+                    int rest = (h >= 0 && h + k == x->len[i] - m.c0) ? n - h : (1 << 30);
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(rest, o); rest = other < rest ? other : rest; }
-                if (rest < (1 << 30)) e += rest;
+                    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(rest, o); rest = other < rest ? other : rest; }
+                    if (rest < (1 << 30)) e += rest;
+                }
+                sc[i] = e;
             }
-            sc[i] = e;
         }
         if (lane == 0) {
             score1[g] = sc[0]; score2[g] = sc[1];
@@ -628,7 +988,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
 } // namespace
 
 // host side of a batch of at most CMAXP problems (or any number with the descriptors in device memory): all of them advance one
-// window per launch pair until every one has stopped
+// step + control launch pair at a time until every search has ended
 template <int MAXP>
 static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* probs, sp_cons_output* outs) {
     hipStream_t st = ctx->stream;
@@ -638,8 +998,8 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     std::vector<int> block_prob;
     std::vector<ConsSetup> setup(n_prob);
     std::vector<uint32_t> h_idx; std::vector<int32_t> h_off;
-    std::vector<size_t> idx_at(n_prob), off_at(n_prob), c_at(n_prob);
-    size_t total = 0, c_bytes = 0; int max_cap = 0, n_blocks = 0;
+    std::vector<size_t> idx_at(n_prob), off_at(n_prob), c_at(n_prob), proc_at(n_prob);
+    size_t total = 0, c_bytes = 0, proc_bytes = 0; int max_cap = 0, n_blocks = 0;
     for (uint32_t p = 0; p < n_prob; ++p) {
         const sp_cons_problem& q = probs[p];
         const uint32_t n = q.read_idx ? q.n : q.reads->n;
@@ -658,30 +1018,41 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         total += (size_t)nb * per_block;
         idx_at[p] = h_idx.size(); if (q.read_idx) h_idx.insert(h_idx.end(), q.read_idx, q.read_idx + n);
         off_at[p] = h_off.size(); if (q.offsets) h_off.insert(h_off.end(), q.offsets, q.offsets + n);
-        c_at[p] = c_bytes; c_bytes += 2 * (size_t)std::max(P.cap, 1);
+        c_at[p] = c_bytes; c_bytes += (size_t)NQ * 2 * (size_t)std::max(P.cap, 1);
+        proc_at[p] = proc_bytes; proc_bytes += ((size_t)std::max(P.cap, 1) + 2 + 15) & ~(size_t)15;
         max_cap = std::max(max_cap, P.cap);
     }
     if (n_blocks == 0) return SP_OK;
+    const size_t planes = (size_t)NQ * 4;                   // [node][slot][consensus]
     uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "cons_idx", sizeof(uint32_t) * std::max<size_t>(1, h_idx.size()));
     int32_t* d_off = (int32_t*)sp_pool(ctx, "cons_off", sizeof(int32_t) * std::max<size_t>(1, h_off.size()));
     uint8_t* d_C = (uint8_t*)sp_pool(ctx, "cons_C", c_bytes);
-    ConsCtrl* d_ctrl = (ConsCtrl*)sp_pool(ctx, "cons_ctrl", sizeof(ConsCtrl) * n_prob);
+    CWork* d_work = (CWork*)sp_pool(ctx, "cons_work", sizeof(CWork) * n_prob);
+    CSearch* d_srch = (CSearch*)sp_pool(ctx, "cons_srch", sizeof(CSearch) * n_prob);
+    CNode* d_nodes = (CNode*)sp_pool(ctx, "cons_nodes", sizeof(CNode) * NQ * n_prob);
+    uint32_t* d_la = (uint32_t*)sp_pool(ctx, "cons_la", sizeof(uint32_t) * (size_t)NQ * 2 * CW * 4 * n_prob);
+    uint8_t* d_proc = (uint8_t*)sp_pool(ctx, "cons_proc", proc_bytes);
     ReadInfo* d_info = (ReadInfo*)sp_pool(ctx, "cons_info", sizeof(ReadInfo) * total);
     B.info = d_info; B.total = (int)total;
-    B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * 4 * total * CB);
-    B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * 4 * total);
+    B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * planes * total * CB);
+    B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * planes * total);
     B.PV = (unsigned long long*)sp_pool(ctx, "cons_pv", sizeof(unsigned long long) * (size_t)n_blocks * 2 * (CW + 1));
     B.PE = (uint32_t*)sp_pool(ctx, "cons_pe", sizeof(uint32_t) * (size_t)n_blocks * 2 * (CW + 1));
     B.PL = (unsigned long long*)sp_pool(ctx, "cons_pl", sizeof(unsigned long long) * (size_t)n_blocks * 2 * CW);
+    B.PC = (uint32_t*)sp_pool(ctx, "cons_pc", sizeof(uint32_t) * (size_t)n_blocks * (CW + 1));
+    B.PR = (uint32_t*)sp_pool(ctx, "cons_pr", sizeof(uint32_t) * (size_t)n_blocks * (CW + 1));
     uint8_t* d_is1 = (uint8_t*)sp_pool(ctx, "cons_is1", total);
     int32_t* d_sc = (int32_t*)sp_pool(ctx, "cons_scores", sizeof(int32_t) * 2 * total);
-    ConsCtrl* h_ctrl = (ConsCtrl*)sp_host_pool(ctx, "cons_ctrl", sizeof(ConsCtrl) * n_prob);
-    if (!d_idx || !d_off || !d_C || !d_ctrl || !d_info || !B.H || !B.meta || !B.PV || !B.PE || !B.PL || !d_is1 || !d_sc || !h_ctrl)
+    CWork* h_work = (CWork*)sp_host_pool(ctx, "cons_work", sizeof(CWork) * n_prob);
+    CSearch* h_srch = (CSearch*)sp_host_pool(ctx, "cons_srch", sizeof(CSearch) * n_prob);
+    if (!d_idx || !d_off || !d_C || !d_work || !d_srch || !d_nodes || !d_la || !d_proc || !d_info || !B.H || !B.meta || !B.PV || !B.PE || !B.PL || !B.PC || !B.PR ||
+        !d_is1 || !d_sc || !h_work || !h_srch)
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus buffers");
     for (uint32_t p = 0; p < n_prob; ++p) {
         setup[p].idx = probs[p].read_idx ? d_idx + idx_at[p] : nullptr;
         setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr;
-        hp[p].C = d_C + c_at[p]; hp[p].ctrl = d_ctrl + p;
+        hp[p].C = d_C + c_at[p]; hp[p].work = d_work + p; hp[p].srch = d_srch + p; hp[p].nodes = d_nodes + (size_t)p * NQ;
+        hp[p].la = d_la + (size_t)p * NQ * 2 * CW * 4; hp[p].processed = d_proc + proc_at[p];
     }
     if constexpr (MAXP == 0) {
         ConsParams* d_probs = (ConsParams*)sp_pool(ctx, "cons_probs", sizeof(ConsParams) * n_prob);
@@ -693,74 +1064,89 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     } else {
         for (uint32_t p = 0; p < n_prob; ++p) B.p[p] = hp[p];
     }
-    ConsCtrl c0; std::memset(&c0, 0, sizeof c0); c0.init = 1; c0.split_at = -1; c0.stopped[1] = 1; c0.best_total = 1; c0.split_total = 1;
-    for (uint32_t p = 0; p < n_prob; ++p) h_ctrl[p] = c0;
+    for (uint32_t p = 0; p < n_prob; ++p) {
+        CWork& w = h_work[p]; std::memset(&w, 0, sizeof w); w.mode = M_INIT; w.node = 0; w.in_slot = 0; w.split_at = -1;
+        CSearch& s = h_srch[p]; std::memset(&s, 0, sizeof s); s.best_node = -1; s.inflight = -1;
+        const sp_cons_config& cf = probs[p].cfg;
+        s.max_queue = cf.max_queue_size > 0 ? std::min(cf.max_queue_size, NQ - MAXKIDS - 2) : 20;
+        s.per_size = cf.max_capacity_per_size > 0 ? std::min(cf.max_capacity_per_size, 255) : 10;
+        s.wo_constraint = cf.max_nodes_wo_constraint > 0 ? cf.max_nodes_wo_constraint : 1000;
+    }
     if (!h_idx.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, h_idx.data(), sizeof(uint32_t) * h_idx.size(), hipMemcpyHostToDevice, st));
     if (!h_off.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_off, h_off.data(), sizeof(int32_t) * h_off.size(), hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ctrl, h_ctrl, sizeof(ConsCtrl) * n_prob, hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemsetAsync(B.meta, 0, sizeof(ConsMeta) * 4 * total, st));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_work, h_work, sizeof(CWork) * n_prob, hipMemcpyHostToDevice, st));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_srch, h_srch, sizeof(CSearch) * n_prob, hipMemcpyHostToDevice, st));
+    SP_HIP_CHECK(ctx, hipMemsetAsync(d_nodes, 0, sizeof(CNode) * NQ * n_prob, st));
+    SP_HIP_CHECK(ctx, hipMemsetAsync(d_proc, 0, proc_bytes, st));
     SP_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(ReadInfo) * total, st));
     for (uint32_t p = 0; p < n_prob; ++p)
         if (setup[p].n) hipLaunchKernelGGL(cons_setup_kernel, dim3((setup[p].n + 255) / 256), dim3(256), 0, st, setup[p], d_info);
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));      // the pageable host sources above must stay valid until copied
 
     const dim3 grid((uint32_t)n_blocks), block(CWAVES * SP_WAVE);
-    uint64_t windows = 0;
+    const size_t proc_lds = ((size_t)max_cap + 2 + 15) & ~(size_t)15;
+    if (proc_lds > 96 * 1024) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must stay below 98,304");
+    SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cons_control_kernel<MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)proc_lds));
+    uint64_t pairs = 0;
     {
         ProfScope ps(ctx, "cons_steps", total);
-        // the first poll comes when a consensus of max_cap bases can be through if (nearly) every window stands; then every 16 windows.
-        // A window pair whose problems are all done is a pair of empty launches.
+        // the first poll comes when a consensus of max_cap bases can be through if (nearly) every window stands; then every few pairs.
+        // A launch pair whose problems are all done is a pair of empty launches.
         int until_poll = max_cap / CW + 8;
-        const uint64_t limit = (uint64_t)4 * (uint64_t)(max_cap + 2) + 64;           // every column costs at most a cut and a replay
+        const uint64_t limit = (uint64_t)64 * (uint64_t)(max_cap + 2) + 1024;
         for (;;) {
             hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
-            hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), 0, st, B);
-            ++windows;
-            if (--until_poll <= 0 || windows >= limit) {
-                SP_HIP_CHECK(ctx, hipMemcpyAsync(h_ctrl, d_ctrl, sizeof(ConsCtrl) * n_prob, hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, st, B);
+            ++pairs;
+            if (--until_poll <= 0 || pairs >= limit) {
+                SP_HIP_CHECK(ctx, hipMemcpyAsync(h_work, d_work, sizeof(CWork) * n_prob, hipMemcpyDeviceToHost, st));
                 SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
                 bool all = true; int left = 0;
-                for (uint32_t p = 0; p < n_prob; ++p) { all = all && h_ctrl[p].done; if (!h_ctrl[p].done) left = std::max(left, hp[p].cap - h_ctrl[p].T); }
+                for (uint32_t p = 0; p < n_prob; ++p) { all = all && h_work[p].done; if (!h_work[p].done) left = std::max(left, hp[p].cap - h_work[p].T); }
                 if (all) break;
-                if (windows >= limit) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the window loop did not finish");
-                until_poll = std::max(4, std::min(64, left / CW + 2));
+                if (pairs >= limit) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the search did not finish");
+                until_poll = std::max(4, std::min(64, left / CW / 4 + 2));
             }
         }
     }
     SP_HIP_CHECK(ctx, hipGetLastError());
-    if (ctx->profiling) {
-        unsigned long long* cnt = sp_counters(ctx);
-        (void)cnt;
-    }
     hipLaunchKernelGGL(cons_finalize_kernel<MAXP>, grid, block, 0, st, B, d_is1, d_sc, d_sc + total);
-    std::vector<uint8_t> hc(c_bytes), h_is1(total);
+    std::vector<uint8_t> h_is1(total);
     std::vector<int32_t> h_sc(2 * total);
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(hc.data(), d_C, c_bytes, hipMemcpyDeviceToHost, st));
+    std::vector<CNode> h_nodes((size_t)NQ * n_prob);
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_srch, d_srch, sizeof(CSearch) * n_prob, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_nodes.data(), d_nodes, sizeof(CNode) * NQ * n_prob, hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(ctx, hipMemcpyAsync(h_is1.data(), d_is1, total, hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(ctx, hipMemcpyAsync(h_sc.data(), d_sc, sizeof(int32_t) * 2 * total, hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
     SP_HIP_CHECK(ctx, hipGetLastError());
-    {   // launch statistics of the batch (sp_profile_get "cons_windows" / "cons_cut_windows": cells = count)
-        uint64_t w = 0, cut = 0, cols = 0;
-        for (uint32_t p = 0; p < n_prob; ++p) { w = std::max<uint64_t>(w, (uint64_t)h_ctrl[p].windows); cut += (uint64_t)h_ctrl[p].cut_windows; cols = std::max<uint64_t>(cols, (uint64_t)h_ctrl[p].T); }
-        ctx->prof["cons_windows"].cells += windows; ctx->prof["cons_windows"].launches += 2 * windows;
-        ctx->prof["cons_cut_windows"].cells += cut; ctx->prof["cons_columns"].cells += cols;
+    {   // launch statistics of the batch (sp_profile_get: cells = count)
+        uint64_t w = 0, cut = 0, ex = 0, pops = 0;
+        for (uint32_t p = 0; p < n_prob; ++p) { w += (uint64_t)h_srch[p].windows; cut += (uint64_t)h_srch[p].cut_windows; ex += (uint64_t)h_srch[p].expansions; pops += (uint64_t)h_srch[p].pops; }
+        ctx->prof["cons_windows"].cells += pairs; ctx->prof["cons_windows"].launches += 2 * pairs;
+        ctx->prof["cons_cut_windows"].cells += cut; ctx->prof["cons_expansions"].cells += ex; ctx->prof["cons_columns"].cells += pops;
     }
     static const char dec[4] = { 'A', 'C', 'G', 'T' };
     int32_t rc = SP_OK;
+    std::vector<uint8_t> hc;
     for (uint32_t p = 0; p < n_prob; ++p) {
         const ConsParams& P = hp[p]; sp_cons_output& o = outs[p];
-        const ConsCtrl& cur = h_ctrl[p];
-        const uint8_t* c = hc.data() + c_at[p];
-        const int len1 = cur.len[0], len2 = cur.dual ? cur.len[1] : 0;
-        for (int x = 0; x < len1; ++x) o.cons1[x] = dec[c[x] & 3];
-        o.cons1[len1] = '\0';
-        for (int x = 0; x < len2; ++x) o.cons2[x] = dec[(x < cur.split_at ? c[x] : c[(size_t)P.cap + x]) & 3];
-        o.cons2[len2] = '\0';
+        const int best = h_srch[p].best_node;
+        int len1 = 0, len2 = 0, dual = 0, split_at = -1;
+        if (best >= 0) {
+            const CNode& x = h_nodes[(size_t)p * NQ + best];
+            dual = x.dual; split_at = x.split_at; len1 = x.len[0]; len2 = dual ? x.len[1] : 0;
+            hc.resize((size_t)2 * std::max(P.cap, 1));
+            SP_HIP_CHECK(ctx, hipMemcpy(hc.data(), P.C + (size_t)best * 2 * P.cap, (size_t)2 * P.cap, hipMemcpyDeviceToHost));
+            const uint8_t* c = hc.data();
+            for (int x2 = 0; x2 < len1; ++x2) o.cons1[x2] = dec[c[x2] & 3];
+            for (int x2 = 0; x2 < len2; ++x2) o.cons2[x2] = dec[(x2 < split_at ? c[x2] : c[(size_t)P.cap + x2]) & 3];
+        }
+        o.cons1[len1] = '\0'; o.cons2[len2] = '\0';
         for (int r = 0; r < P.n; ++r) { o.is_cons1[r] = h_is1[P.first + r]; o.score1[r] = h_sc[P.first + r]; o.score2[r] = h_sc[total + P.first + r]; }
-        o.result.is_dual = cur.dual; o.result.len1 = len1; o.result.len2 = len2; o.result.split_at = cur.split_at;
-        o.result.best_w2 = cur.best_w2; o.result.best_total = cur.best_total;
-        o.result.split_w2 = cur.split_w2; o.result.split_total = cur.split_total;
+        o.result.is_dual = dual; o.result.len1 = len1; o.result.len2 = len2; o.result.split_at = split_at;
+        o.result.best_w2 = 0; o.result.best_total = 1; o.result.split_w2 = 0; o.result.split_total = 1;
+        o.result.nodes_expanded = h_srch[p].pops;
         // a consensus that filled its buffer was still growing: the caller sized cap too small
         if (len1 >= P.cap || len2 >= P.cap) { o.status = SP_ERR_CAPACITY; rc = SP_ERR_CAPACITY; }
     }
@@ -807,43 +1193,11 @@ int32_t sp_consensus_dual_batch(sp_ctx* ctx, uint32_t n_problems, const sp_cons_
     if (!ctx) return SP_ERR_INVALID_ARG;
     if (n_problems == 0) return SP_OK;
     if (!problems || !outputs) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_dual_batch: null argument");
-    // The two passes of the policy run side by side: next to the pass that never splits (it finds the strongest second-base
-    // column) a speculative pass splits at the first column that reaches cfg.min_af.  No earlier column can reach the final
-    // threshold X >= cfg.min_af either, so if that column also reaches X the speculative pass IS the second pass; only otherwise
-    // the second pass is run on its own.
-    std::vector<sp_cons_problem> pr(2 * (size_t)n_problems); std::vector<sp_cons_output> out(2 * (size_t)n_problems);
-    std::vector<std::vector<char>> text(n_problems); std::vector<std::vector<uint8_t>> fl(n_problems); std::vector<std::vector<int32_t>> sc(n_problems);
-    for (uint32_t p = 0; p < n_problems; ++p) {
-        const uint32_t n = problems[p].read_idx ? problems[p].n : (problems[p].reads ? problems[p].reads->n : 0);
-        text[p].assign((size_t)2 * std::max<uint32_t>(outputs[p].cap, 1), 0); fl[p].assign(std::max<uint32_t>(n, 1), 0); sc[p].assign((size_t)2 * std::max<uint32_t>(n, 1), 0);
-        pr[2 * p] = problems[p]; pr[2 * p].cfg.allow_dual = 0;
-        out[2 * p] = outputs[p];
-        out[2 * p].cons1 = text[p].data(); out[2 * p].cons2 = text[p].data() + outputs[p].cap; out[2 * p].is_cons1 = fl[p].data();
-        out[2 * p].score1 = sc[p].data(); out[2 * p].score2 = sc[p].data() + std::max<uint32_t>(n, 1);
-        pr[2 * p + 1] = problems[p]; pr[2 * p + 1].cfg.allow_dual = 1;
-        out[2 * p + 1] = outputs[p];
-    }
-    int32_t rc = run_batch(ctx, 2 * n_problems, pr.data(), out.data());
-    if (rc != SP_OK && rc != SP_ERR_CAPACITY) return rc;
-    std::vector<sp_cons_problem> again; std::vector<sp_cons_output> outs2; std::vector<uint32_t> who;
-    for (uint32_t p = 0; p < n_problems; ++p) {
-        const sp_cons_result& single = out[2 * p].result; const sp_cons_result& spec = out[2 * p + 1].result;
-        outputs[p] = out[2 * p + 1];
-        if (single.best_w2 == 0 || !spec.is_dual) continue;            // nothing to split, or no column reaches even cfg.min_af: the speculative pass never split
-        const double strongest = 0.5 * (double)single.best_w2 / (double)single.best_total;
-        const double x = problems[p].cfg.min_af > strongest ? problems[p].cfg.min_af : strongest;
-        if ((double)spec.split_w2 >= x * (double)spec.split_total) continue;
-        sp_cons_problem q = problems[p]; q.cfg.allow_dual = 1; q.cfg.min_af = x;
-        again.push_back(q); outs2.push_back(outputs[p]); who.push_back(p);
-    }
-    if (!again.empty()) {
-        const int32_t rc2 = run_batch(ctx, (uint32_t)again.size(), again.data(), outs2.data());
-        if (rc2 != SP_OK && rc2 != SP_ERR_CAPACITY) return rc2;
-        for (size_t k = 0; k < who.size(); ++k) outputs[who[k]] = outs2[k];
-    }
-    rc = SP_OK;
-    for (uint32_t p = 0; p < n_problems; ++p) if (outputs[p].status != SP_OK) rc = outputs[p].status;
-    return rc;
+    // DualConsensusDWFA: the same search with a second consensus allowed (round 1 ran a two-pass split policy here; the best-first
+    // search decides by cost where to split)
+    std::vector<sp_cons_problem> pr(problems, problems + n_problems);
+    for (auto& q : pr) q.cfg.allow_dual = 1;
+    return run_batch(ctx, n_problems, pr.data(), outputs);
 }
 
 int32_t sp_consensus(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* read_idx, uint32_t n, const int32_t* offsets,

@@ -802,7 +802,7 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     rc = sp_make_segments(ctx, reads, c_idx, c_start, c_len, "cypc", &raw, &hpc);
     if (rc != SP_OK) return rc;
     // 3. multi-way consensus, homopolymer-compressed level first (caller.rs:162-270)
-    sp_cons_config cc;
+    sp_cons_config cc{};
     cc.min_count = pr->min_consensus_count; cc.min_af = pr->min_consensus_fraction; cc.dual_max_ed_delta = pr->dual_max_ed_delta;
     cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 100; cc.offset_compare_length = 64;      // the library compares at most 64 bases
     const uint32_t n_in = raw.n;

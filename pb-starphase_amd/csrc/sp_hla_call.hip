@@ -188,7 +188,7 @@ static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
     std::vector<uint8_t> is1(n);
     std::vector<char> text((size_t)2 * n_genes * ccap);
     auto cons_config = [&](uint32_t k, int dual) {
-        sp_cons_config cc;
+        sp_cons_config cc{};
         cc.min_count = cfgs[k].min_consensus_count; cc.min_af = cfgs[k].min_consensus_fraction; cc.dual_max_ed_delta = cfgs[k].dual_max_ed_delta;
         cc.allow_early_termination = 1; cc.allow_dual = dual; cc.offset_window = 400; cc.offset_compare_length = 50;
         return cc;

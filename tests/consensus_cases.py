@@ -53,6 +53,13 @@ def cases(fx, synth, oracle):
         art.append(hap)
     out.append(("dual_artefact_column_first", art, None, dict(early_termination=False, dual=True), True))
     out.append(("dual_artefact_one_pass", art, None, dict(early_termination=False, dual=True), False))
+    # low coverage: three reads per haplotype (min_count 3 is exactly met)
+    few = [synth.hifi_errors(rng, s1) for _ in range(3)] + [synth.hifi_errors(rng, s2) for _ in range(3)]
+    out.append(("dual_low_coverage", [few[i] for i in (0, 3, 1, 4, 2, 5)], None, dict(early_termination=False, dual=True), False))
+    # homopolymer-biased error: 8 of 20 reads carry one extra base in the longest run of the sequence
+    run_at = max(range(len(s1) - 6), key=lambda p: len(s1[p:p + 6].rstrip(s1[p])) == 0 and 6 or 0)
+    biased = [(s1[:run_at] + s1[run_at] + s1[run_at:]) if i % 5 < 2 else s1 for i in range(20)]
+    out.append(("single_homopolymer_biased", biased, None, dict(early_termination=False, dual=False), False))
     # tiny inputs
     out.append(("two_reads", full1[:2], None, dict(early_termination=True, dual=True), True))
     out.append(("one_read", full1[:1], None, dict(early_termination=False, dual=False), False))

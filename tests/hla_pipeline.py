@@ -41,7 +41,20 @@ def type_consensus(oracle, fx, g, cons, synth):
     return best
 
 
-def diplotype_gene(oracle, fx, g, reads, k1, synth, min_count=3, min_fraction=0.10, delta=100):
+def is_hemizygous_better(oracle, dual, n, delta, normalized_coverage):
+    """is_hemizygous_better (src/hla/caller.rs:1583-1653) on a DualConsensus-shaped result dict"""
+    s1 = np.array([int(x) for x in dual["score1"]], np.int64)
+    s2 = np.array([int(x) for x in dual["score2"]], np.int64)
+    is1 = np.array(dual["is_cons1"], np.uint8)
+    h, d = C.c_double(), C.c_double()
+    oracle.L.osp_is_hemizygous_better.restype = C.c_int32
+    r = oracle.L.osp_is_hemizygous_better(s1.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p), is1.ctypes.data_as(C.c_void_p), n,
+                                          1 if dual["is_dual"] else 0, delta, 1 if normalized_coverage is not None else 0,
+                                          float(normalized_coverage if normalized_coverage is not None else 0.0), C.byref(h), C.byref(d))
+    return bool(r)
+
+
+def diplotype_gene(oracle, fx, g, reads, k1, synth, min_count=3, min_fraction=0.10, delta=100, absent_capable=False, normalized_coverage=None):
     """k1 = hx.k1_expected(...)[0] for `reads`.  Returns a dict with the fields of sp_hla_call + consensuses + is_cons1."""
     sel = [r for r, e in enumerate(k1) if e["status"] == 0 and e["gene"] == g]
     out = dict(status=0, n_reads=len(sel), allele1=-1, allele2=-1, typed1=-1, typed2=-1, cons1="", cons2="")
@@ -67,6 +80,9 @@ def diplotype_gene(oracle, fx, g, reads, k1, synth, min_count=3, min_fraction=0.
         c1 = int(dual["is_cons1"].sum()); c2 = len(sel) - c1
         ok, maf, cdf = is_passing_dual(oracle, c1, c2, min_fraction) if dual["is_dual"] else (False, 0.0, 0.0)
         used_dna = True
+    hemi = absent_capable and is_hemizygous_better(oracle, dual, len(sel), delta, normalized_coverage)
+    if hemi:                                                                 # boiler-plate non-dual consensus (caller.rs:687-701)
+        dual = dict(dual, is_dual=False, is_cons1=np.ones(len(sel), bool))
     single = of.cons_config(min_count=min_count, min_af=min_fraction, dual_max_ed_delta=delta, early_termination=True, dual=False)
     cons = []
     for which in ((True, False) if dual["is_dual"] else (True,)):
@@ -90,5 +106,6 @@ def diplotype_gene(oracle, fx, g, reads, k1, synth, min_count=3, min_fraction=0.
         else:
             out.update(allele1=t2, allele2=t2)
     else:
-        out.update(allele1=t1, allele2=t1)
+        out.update(allele1=-2 if hemi else t1, allele2=t1)
+    out["is_hemizygous"] = int(hemi)
     return out

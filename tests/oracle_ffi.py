@@ -402,15 +402,25 @@ def oracle_build_chains(oracle, hap_type, read_seg_off, ed, kept):
 
 class ConsConfig(C.Structure):
     _fields_ = [("min_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("allow_early_termination", C.c_int32), ("allow_dual", C.c_int32),
-                ("offset_window", C.c_int32), ("offset_compare_length", C.c_int32), ("min_af", C.c_double)]
+                ("offset_window", C.c_int32), ("offset_compare_length", C.c_int32), ("min_af", C.c_double),
+                ("max_queue_size", C.c_int32), ("max_capacity_per_size", C.c_int32), ("max_nodes_wo_constraint", C.c_int32), ("pad", C.c_int32)]
 
 
 class ConsResult(C.Structure):
-    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64)]
+    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64),
+                ("nodes_expanded", C.c_int64)]
 
 
-def cons_config(min_count=3, min_af=0.10, dual_max_ed_delta=100, early_termination=True, dual=True, offset_window=400, offset_compare_length=50):
-    return ConsConfig(min_count, dual_max_ed_delta, int(early_termination), int(dual), offset_window, offset_compare_length, min_af)
+def cons_config(min_count=3, min_af=0.10, dual_max_ed_delta=100, early_termination=True, dual=True, offset_window=400, offset_compare_length=50,
+                max_queue_size=0, max_capacity_per_size=0, max_nodes_wo_constraint=0):
+    """the three search bounds default (0) to the values of dwfa_config_from_cli / waffle_con: 20, 10, 1000"""
+    return ConsConfig(min_count, dual_max_ed_delta, int(early_termination), int(dual), offset_window, offset_compare_length, min_af,
+                      max_queue_size, max_capacity_per_size, max_nodes_wo_constraint, 0)
+
+
+def with_dual(cfg, dual):
+    return ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, int(dual), cfg.offset_window, cfg.offset_compare_length, cfg.min_af,
+                      cfg.max_queue_size, cfg.max_capacity_per_size, cfg.max_nodes_wo_constraint, 0)
 
 
 def oracle_consensus(oracle, reads, offsets=None, cfg=None, cap=None):
@@ -431,20 +441,12 @@ def oracle_consensus(oracle, reads, offsets=None, cfg=None, cap=None):
     assert rc == 0
     dec = lambda a, k: "".join("ACGT"[x] for x in a[:k])
     return dict(cons=[dec(c1, res.len1), dec(c2, res.len2) if res.is_dual else None], is_dual=bool(res.is_dual), is_cons1=is1[:n].astype(bool),
-                score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, best_w2=res.best_w2, best_total=res.best_total)
+                score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, nodes_expanded=res.nodes_expanded)
 
 
 def dual_consensus_two_pass(run, reads, offsets=None, cfg=None):
-    """the split policy on top of the one-pass search: pass 1 (no split) finds the strongest second-base column, pass 2 may only
-    split at columns at least half as strong.  run = oracle_consensus-like callable (reads, offsets, cfg)."""
-    cfg = cfg or cons_config()
-    single = ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, 0, cfg.offset_window, cfg.offset_compare_length, cfg.min_af)
-    first = run(reads, offsets, single)
-    if first["best_w2"] == 0:
-        return first
-    af = max(cfg.min_af, 0.5 * float(first["best_w2"]) / float(first["best_total"]))
-    second = ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, 1, cfg.offset_window, cfg.offset_compare_length, af)
-    return run(reads, offsets, second)
+    """(round 1 ran a two-pass split policy here; the best-first search decides where to split by cost, so this is one dual run)"""
+    return run(reads, offsets, with_dual(cfg or cons_config(), True))
 
 
 def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None):
@@ -453,8 +455,7 @@ def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None):
     n, nl = len(levels[0]), len(levels)
     half = cfg.offset_window // 2
     run = lambda rd, offs, c: oracle_consensus(oracle, rd, offs, c)
-    single = ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, 0, cfg.offset_window, cfg.offset_compare_length, cfg.min_af)
-    dual = ConsConfig(cfg.min_count, cfg.dual_max_ed_delta, cfg.allow_early_termination, 1, cfg.offset_window, cfg.offset_compare_length, cfg.min_af)
+    single, dual = with_dual(cfg, False), with_dual(cfg, True)
 
     def rebased(members, level):
         if offsets is None or offsets[level] is None:

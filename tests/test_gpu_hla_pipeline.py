@@ -68,6 +68,43 @@ def test_reads_to_diplotype(oracle, pkg, gpu_ctx, scenario):
     assert call.status == 1 and call.n_reads == 0 and (c1, c2) == ("", "")
 
 
+def test_absent_capable_gene(oracle, pkg, gpu_ctx):
+    """the hemizygous branch of the gene loop (src/hla/caller.rs:676-701,919-923; is_hemizygous_better :1583-1653) on the GPU path: a gene
+    flagged absent-capable (HLA-DRB3/4/5 in the reference, src/hla/alleles.rs:62-69) with the reads of ONE haplotype at haploid coverage
+    is called (absent, allele); with two haplotypes at diploid coverage it stays a heterozygous call.  Library == oracle pipeline."""
+    import hla_expected as hx
+    import hla_pipeline as hp
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture(max_alleles_per_gene=150, seed=4)
+    db = fx.make_db(pkg, gpu_ctx)
+    rng = np.random.default_rng(404)
+    g = 0
+    pick = rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist()
+    per_hap = 22
+    sets = {}
+    for name, alleles in (("hemizygous", pick[:1]), ("diploid", pick)):
+        reads = []
+        for a in alleles:
+            hap, st = fx.haplotype(g, a)
+            reads += synth.simulate_reads(rng, hap, st, len(fx.dna[a]), per_hap, mean_len=7000, sd_len=1500, min_overlap=2500)
+        sets[name] = [reads[i] for i in rng.permutation(len(reads))]
+    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+    for name, reads in sets.items():
+        R = gpu_ctx.upload(reads)
+        k1 = db.realign_reads(R)
+        cfg = pkg.ffi.hla_call_config(absent_capable=True, normalized_coverage=float(per_hap))
+        call, c1, c2, is1 = db.diplotype_gene(g, R, k1, cfg=cfg)
+        k1_exp, _cells = hx.k1_expected(oracle, fx, reads)
+        exp = hp.diplotype_gene(oracle, fx, g, reads, k1_exp, synth, absent_capable=True, normalized_coverage=float(per_hap))
+        assert call.is_hemizygous == exp["is_hemizygous"] == (1 if name == "hemizygous" else 0)
+        assert (call.allele1, call.allele2) == (exp["allele1"], exp["allele2"]) and (c1, c2) == (exp["cons1"], exp["cons2"])
+        if name == "hemizygous":
+            assert call.allele1 == -2 and same(call.allele2, pick[0]) and not call.is_dual
+        else:
+            got = sorted([call.allele1, call.allele2])
+            assert call.is_dual and call.dual_passed and (all(same(x, y) for x, y in zip(got, sorted(pick))) or all(same(x, y) for x, y in zip(got, sorted(pick)[::-1])))
+
+
 def test_cohort_equals_sample_by_sample(oracle, pkg, gpu_ctx):
     """BASELINE configs[4] in miniature: several WGS-sized samples in one read set, one realignment call, every (sample, gene)
     consensus problem in lockstep (sp_hla_diplotype_cohort) -- the same calls and consensuses as one sample at a time, and the truth"""

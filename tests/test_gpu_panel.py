@@ -1,0 +1,135 @@
+"""BASELINE configs[3] (full CPIC panel, one 30x-WGS-like sample) and configs[1] at its stated size, through the C ABI on the GPU.
+
+configs[3]: every variant gene of the bundled v0.14.1 database (gene_entries: 18 CPIC / PharmVar genes, up to 340 haplotypes x 314
+variants) gets synthetic VCF observations drawn from two of its own haplotypes (hom / het, phased / unphased mixes, at most 8 hets), the
+K6 search (sp_variant_solve) must equal oracle/variant.c cell for cell and the call must contain the simulated pair; the same sample
+carries HLA-A/-B (~45 reads per gene, full IMGT/HLA database) and CYP2D6 (~100 reads, real 39 templates / variant table).
+configs[1]: 10,000 reads; the pruned K1 search equals the exhaustive one on 1,000 of them and the oracle's whole-read search on 64."""
+import ctypes as C
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cyp_cases_real as cr
+import variant_glue as vg
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def synthetic_observations(rng, haps, max_hets=8):
+    """observed variants of a sample that carries haplotypes h1 / h2 of the gene: the first non-None alternative of every slot"""
+    usable = [h for h in haps if all(any(nv is not None for nv in s) for s in h["slots"])]
+    for _ in range(50):
+        h1, h2 = rng.choice(len(usable), 2, replace=True).tolist()
+        v1 = {next(nv for nv in s if nv is not None) for s in usable[h1]["slots"]}
+        v2 = {next(nv for nv in s if nv is not None) for s in usable[h2]["slots"]}
+        hets = sorted((v1 | v2) - (v1 & v2))
+        if len(hets) <= max_hets:
+            break
+    obs = {v: (4, None) for v in v1 & v2}
+    phased = rng.random() < 0.6
+    ps = int(rng.integers(1000, 2000))
+    for v in hets:
+        if phased and rng.random() < 0.85:
+            obs[v] = (2 if v in v2 else 3, ps)             # 0|1 when on the second haplotype, 1|0 on the first
+        else:
+            obs[v] = (1, None)
+    return usable[h1]["name"], usable[h2]["name"], obs, phased and all(obs[v][0] != 1 for v in hets)
+
+
+def test_full_panel_sample(oracle, pkg, gpu_ctx):
+    from pb_starphase_amd import synth
+    from test_gpu_variant import gpu_struct
+    rng = np.random.default_rng(30)
+    genes = json.load(gzip.open(os.path.join(GOLDEN, "gene_entries_v0.14.1.json.gz")))["gene_entries"]
+    assert len(genes) == 18
+    n_cells = 0
+    for name in sorted(genes):
+        gene = genes[name]
+        vh, haps = vg.load_database_haplotypes(oracle, gene, None)
+        assert len(haps) >= 2
+        for rep in range(3):
+            h1, h2, obs, fully_phased = synthetic_observations(rng, haps)
+            prob = vg.Problem(vh, haps, obs, gene.get("structural_variants"))
+            exp = vg.oracle_solve(oracle, prob)
+            got = gpu_ctx.variant_solve(gpu_struct(pkg, prob))
+            assert got == exp, (name, rep)
+            called = vg.call_gene(oracle, prob, solver=lambda pr: gpu_ctx.variant_solve(gpu_struct(pkg, pr)))
+            if fully_phased or h1 == h2:
+                pairs = [frozenset(d) for d in called["diplotypes"]]
+                assert exp[0] == (0, 0, 0, 0) and frozenset((h1, h2)) in pairs, (name, rep, h1, h2, called["diplotypes"][:4])
+            n_cells += len(haps)
+    assert n_cells > 3000
+    # ---- HLA-A / -B of the same sample
+    fx = synth.HlaFixture()
+    db = fx.make_db(pkg, gpu_ctx)
+    truth, reads = {}, []
+    for g in range(len(fx.genes)):
+        pick = rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist()
+        truth[g] = sorted(pick)
+        for a in pick:
+            hap, s = fx.haplotype(g, a)
+            reads += synth.simulate_reads(rng, hap, s, len(fx.dna[a]), 23, mean_len=6000, sd_len=1500, min_overlap=2500)
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    R = gpu_ctx.upload(reads)
+    calls, _ = db.diplotype_genes(list(range(len(fx.genes))), R, db.realign_reads(R))
+    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+    for g, (call, _c1, _c2) in enumerate(calls):
+        got = sorted([call.allele1, call.allele2])
+        assert call.status == 0 and call.is_dual and call.dual_passed
+        assert all(same(a, b) for a, b in zip(got, truth[g])) or all(same(a, b) for a, b in zip(got, truth[g][::-1])), (g, got, truth[g])
+    # ---- CYP2D6 of the same sample: ~100 reads on the real-shape locus
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    cdb = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
+    name, haps, expected = cr.scenarios(locus)[0]
+    creads = locus.sample(rng, haps, 100, lo=8000, hi=16000)
+    call, _cons, _labels = cdb.diplotype(gpu_ctx.upload(creads))
+    assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
+
+
+def test_config1_stated_size(oracle, pkg, gpu_ctx):
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture()
+    wl = synth.Config2Workload(fx, n_reads=10000, seed=1000)
+    db = fx.make_db(pkg, gpu_ctx)
+    R = gpu_ctx.upload(wl.reads)
+    out = db.realign_reads(R)
+    assert float(np.mean(out["status"] == 0)) == 1.0
+    assert all(out[r]["gene"] == wl.read_truth[r][0] for r in range(len(wl.reads)))
+    # pruned == exhaustive on 1,000 reads (the exhaustive pass also hands back its cell matrix)
+    pick = np.sort(np.random.default_rng(1).choice(len(wl.reads), 1000, replace=False))
+    sub = gpu_ctx.upload([wl.reads[i] for i in pick])
+    full, cells = db.realign_reads(sub, cells=True)
+    assert full.tolist() == db.realign_reads(sub).tolist()
+    assert full.tolist() == out[pick].tolist()
+    assert int((cells != 0xFFFFFFFF).sum()) > 1000
+    # 64 reads against the oracle's whole-read search (osp_hla_k1_read: anchor, every allele cell, acceptance)
+    import hla_expected as hx
+    tb = hx.K1Tables(oracle, fx)
+    L = oracle.L
+    L.osp_hla_k1_read.restype = C.c_int32
+    refs = tb.refs
+    n_all = len(fx.ids)
+    enc = [e if e is not None else np.zeros(0, np.uint8) for e in tb.fwd_e]
+    off = np.array([(-2 ** 31 if o is None else o) for o in tb.off], np.int32)
+    ref_ptr = (C.c_void_p * len(refs))(*[r.ctypes.data for r in refs]); ref_len = np.array([len(r) for r in refs], np.int32)
+    al_ptr = (C.c_void_p * n_all)(*[(e.ctypes.data if len(e) else None) for e in enc]); al_len = np.array([len(e) for e in enc], np.int32)
+    gene_of = fx.gene_of.astype(np.int32)
+    for r in pick[:64]:
+        re = oracle.encode(wl.reads[r])
+        ncell = C.c_int64(0)
+        b = L.osp_hla_k1_read(re.ctypes.data_as(C.c_void_p), len(re), len(refs), ref_ptr, ref_len.ctypes.data_as(C.c_void_p), n_all, al_ptr,
+                              al_len.ctypes.data_as(C.c_void_p), gene_of.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), None, C.byref(ncell))
+        assert b == int(out[r]["best_allele"]), r
+    # reads -> diplotype at the stated size equals the simulated truth
+    calls, _ = db.diplotype_genes(list(range(len(fx.genes))), R, out)
+    truth = {g: sorted(a for (gg, _c, _d, a) in wl.consensus if gg == g) for g in range(len(fx.genes))}
+    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+    for g, (call, _c1, _c2) in enumerate(calls):
+        got = sorted([call.allele1, call.allele2])
+        assert all(same(a, b) for a, b in zip(got, truth[g])) or all(same(a, b) for a, b in zip(got, truth[g][::-1]))
