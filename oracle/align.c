@@ -110,24 +110,25 @@ static inline int extend(const uint8_t* A, int m, const uint8_t* B, int n, int i
 }
 
 /* candidate evaluation shared by the forward pass and the traceback: priority X > D > I on equal reach */
-static inline int pick(const int32_t* H, int l, int* src, int* type) {
+static inline int pick(const int32_t* H, int l, int band, int* src, int* type) {
     int best = OSP_NEG; *src = l; *type = (int)OSP_EV_X;
     if (H[l] >= 0) best = H[l] + 1;
     if (l > 0 && H[l - 1] >= 0 && H[l - 1] > best) { best = H[l - 1]; *src = l - 1; *type = (int)OSP_EV_D; }
-    if (l < OSP_BAND - 1 && H[l + 1] >= 0 && H[l + 1] + 1 > best) { best = H[l + 1] + 1; *src = l + 1; *type = (int)OSP_EV_I; }
+    if (l < band - 1 && H[l + 1] >= 0 && H[l + 1] + 1 > best) { best = H[l + 1] + 1; *src = l + 1; *type = (int)OSP_EV_I; }
     return best;
 }
 
-int osp_wfa(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed,
-            osp_aln* out, uint32_t* events, int* n_events) {
+/* the cell on `band` diagonals (64: the contract every cell runs on; 256: the retry of a cell that found no alignment, see osp_wfa_retry) */
+int osp_wfa_band(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed, int band,
+                 osp_aln* out, uint32_t* events, int* n_events) {
     memset(out, 0, sizeof(*out));
     out->a_len = m; out->b_len = n;
     if (n_events) *n_events = 0;
     if (m <= 0 || n <= 0 || max_ed < 0) return 0;
-    const int kbase = diag - OSP_BAND / 2;                 /* lane l <-> diagonal kbase + l */
-    int32_t* hist = (int32_t*)malloc(sizeof(int32_t) * OSP_BAND * (size_t)(max_ed + 1));
+    const int kbase = diag - band / 2;                     /* lane l <-> diagonal kbase + l */
+    int32_t* hist = (int32_t*)malloc(sizeof(int32_t) * (size_t)band * (size_t)(max_ed + 1));
     int32_t* H = hist;
-    for (int l = 0; l < OSP_BAND; ++l) {
+    for (int l = 0; l < band; ++l) {
         int k = kbase + l;
         int i0 = k < 0 ? -k : 0, j0 = i0 + k;
         H[l] = (i0 < m && j0 < n) ? extend(A, m, B, n, i0, k) : OSP_NEG;
@@ -136,20 +137,20 @@ int osp_wfa(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_
     for (;;) {
         /* termination: any lane on the last row / last column. longest path, then most central, then lowest lane */
         int64_t best_key = -1;
-        for (int l = 0; l < OSP_BAND; ++l) {
+        for (int l = 0; l < band; ++l) {
             if (H[l] < 0) continue;
             int i = H[l], j = i + kbase + l;
             if (i == m || j == n) {
-                int c = l - OSP_BAND / 2; if (c < 0) c = -c;
-                int64_t key = (int64_t)(i + j) * 8192 + (OSP_BAND - c) * 64 + (OSP_BAND - 1 - l);
+                int c = l - band / 2; if (c < 0) c = -c;
+                int64_t key = (int64_t)(i + j) * (2 * (int64_t)band * band) + (int64_t)(band - c) * band + (band - 1 - l);
                 if (key > best_key) { best_key = key; end_lane = l; }
             }
         }
         if (end_lane >= 0) break;
         if (s == max_ed) { free(hist); return 0; }
-        int32_t* Hn = hist + (size_t)(s + 1) * OSP_BAND;
-        for (int l = 0; l < OSP_BAND; ++l) {
-            int src, type; int b = pick(H, l, &src, &type);
+        int32_t* Hn = hist + (size_t)(s + 1) * band;
+        for (int l = 0; l < band; ++l) {
+            int src, type; int b = pick(H, l, band, &src, &type);
             Hn[l] = b >= 0 ? extend(A, m, B, n, b, kbase + l) : OSP_NEG;
         }
         H = Hn; ++s;
@@ -160,8 +161,8 @@ int osp_wfa(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_
     out->a_end = i; out->b_end = i + kbase + l;
     int ne = 0;
     for (int t = s; t > 0; --t) {
-        const int32_t* Hp = hist + (size_t)(t - 1) * OSP_BAND;
-        int src, type; int b = pick(Hp, l, &src, &type);
+        const int32_t* Hp = hist + (size_t)(t - 1) * band;
+        int src, type; int b = pick(Hp, l, band, &src, &type);
         int k = kbase + l; uint32_t bpos;
         if (type == (int)OSP_EV_X)      { bpos = (uint32_t)(b - 1 + k); i = b - 1; }
         else if (type == (int)OSP_EV_D) { bpos = (uint32_t)(b + k - 1); i = b; }
@@ -177,6 +178,19 @@ int osp_wfa(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_
     if (n_events) *n_events = ne;
     free(hist);
     return 1;
+}
+
+int osp_wfa(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed,
+            osp_aln* out, uint32_t* events, int* n_events) {
+    return osp_wfa_band(A, m, B, n, diag, max_ed, OSP_BAND, out, events, n_events);
+}
+
+/* what the library's generic cell launcher does everywhere but in K1 and K3: a cell that finds no alignment on 64 diagonals within
+ * max_ed is run again on 256 diagonals around the same anchor (an insertion / deletion of 40-120 bases next to the anchor) */
+int osp_wfa_retry(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed,
+                  osp_aln* out, uint32_t* events, int* n_events) {
+    if (osp_wfa_band(A, m, B, n, diag, max_ed, OSP_BAND, out, events, n_events)) return 1;
+    return osp_wfa_band(A, m, B, n, diag, max_ed, OSP_WIDE_BAND, out, events, n_events);
 }
 
 int osp_events_to_cigar(const osp_aln* aln, const uint32_t* events, int n_events, uint32_t* cigar, int cap) {

@@ -390,7 +390,7 @@ int osp_cyp_weight_sequence(const uint8_t* seq, int seq_len, int n_cons, const u
         int diag = 0, votes = osp_anchor(cons[c], cons_len[c], seq, seq_len, &diag);      /* seq_pos - cons_pos */
         if (votes < OSP_CYP_MIN_VOTES) continue;
         osp_aln al;
-        if (!osp_wfa(cons[c], cons_len[c], seq, seq_len, diag, OSP_MAX_ED, &al, NULL, NULL)) continue;
+        if (!osp_wfa_retry(cons[c], cons_len[c], seq, seq_len, diag, OSP_MAX_ED, &al, NULL, NULL)) continue;
         uint64_t nm = (uint64_t)al.nm, unmapped = (uint64_t)(seq_len - (al.b_end - al.b_start));
         uint64_t clipped_start = (uint64_t)al.a_start, clipped_end = (uint64_t)(cons_len[c] - al.a_end);
         uint64_t match_score = nm + unmapped;
@@ -591,7 +591,7 @@ int osp_cyp_variant_states(const uint8_t* seq, int seq_len, const uint8_t* backb
     int diag = 0;
     if (osp_anchor(seq, seq_len, backbone, backbone_len, &diag) < OSP_CYP_MIN_VOTES) return 0;      /* backbone_pos - seq_pos */
     osp_aln al; uint32_t ev[OSP_MAX_ED + 1]; int nev = 0;
-    if (!osp_wfa(seq, seq_len, backbone, backbone_len, diag, OSP_MAX_ED, &al, ev, &nev)) return 0;
+    if (!osp_wfa_retry(seq, seq_len, backbone, backbone_len, diag, OSP_MAX_ED, &al, ev, &nev)) return 0;
     if (aln_out) { aln_out[0] = al.a_start; aln_out[1] = al.a_end; aln_out[2] = al.b_start; aln_out[3] = al.b_end; aln_out[4] = al.nm; }
     for (int v = 0; v < n_variants; ++v) {
         const int p = var_pos[v], rl = (int)strlen(var_ref[v]), alen = (int)strlen(var_alt[v]);

@@ -121,7 +121,7 @@ static void score_level(const uint8_t* allele, int alen, const uint8_t* cons, in
     if (!allele || alen <= 0 || diag == INT_MIN) return;
     uint32_t* ev = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(max_ed + 1));
     int ne = 0;
-    if (!osp_wfa(allele, alen, cons, clen, diag, max_ed, &aln, ev, &ne)) { free(ev); return; }
+    if (!osp_wfa_retry(allele, alen, cons, clen, diag, max_ed, &aln, ev, &ne)) { free(ev); return; }
     /* select_best_mapping with a single candidate: must beat the (1,1,0) default => score < 1.0 */
     uint64_t unmapped = (uint64_t)(alen - (aln.a_end - aln.a_start));
     if (!(osp_custom_score((uint64_t)alen, (uint64_t)aln.nm, unmapped, 1) < osp_custom_score(1, 1, 0, 1))) { free(ev); return; }

@@ -42,6 +42,7 @@ extern "C" {
 
 /* ---------------- alignment contract ---------------- */
 #define OSP_BAND      64          /* diagonals per cell: k0-32 .. k0+31                 */
+#define OSP_WIDE_BAND 256         /* diagonals of the retry of a cell that found nothing on 64 */
 #define OSP_MAX_ED    511         /* library-wide edit cap of a cell (SP_MAX_ED)         */
 #define OSP_KMER      16          /* anchor k-mer length                                */
 #define OSP_MAXOCC    4           /* k-mers occurring more often in the indexed side are ignored */
@@ -70,6 +71,11 @@ void osp_encode(const char* ascii, size_t n, uint8_t* codes);
  * events may be NULL; otherwise it must hold max_ed words. Returns out->ok. */
 int osp_wfa(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed,
             osp_aln* out, uint32_t* events, int* n_events);
+int osp_wfa_band(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed, int band,
+                 osp_aln* out, uint32_t* events, int* n_events);
+/* 64 diagonals, then 256 if nothing was found: the rule of the library's generic cell launcher (everywhere but K1 and K3) */
+int osp_wfa_retry(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed,
+                  osp_aln* out, uint32_t* events, int* n_events);
 
 /* k-mer vote anchor: A is the indexed side. Returns votes (0 = none); *diag = b_pos - a_pos. */
 int osp_anchor(const uint8_t* A, int m, const uint8_t* B, int n, int* diag);

@@ -699,10 +699,11 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     }
     __syncthreads();
     if (tid < SP_WAVE) {
+        // One wavefront runs the search.  Every lane reads the same LDS words (broadcast), so control flow is uniform; lane 0 writes,
+        // and a wave-level fence separates its writes from the reads that follow.
         const int lane = tid;
         auto cands = [&](const uint32_t* w5, int col, int out[4]) { return col_candidates(w5, col, P.cap, P.et, P.min_count, P.min_af, out); };
         auto node_free = [&](int k) { nh[k].used = 0; nh[k].complete = 0; };
-        auto node_alloc = [&]() -> int { for (int k = 0; k < NQ; ++k) if (!nh[k].used) { nh[k].used = 1; nh[k].complete = 0; return k; } return -1; };
         uint8_t* Cb = P.C;
         // ---------------------------------------------------------------- 1. the result of the last step
         if (mode_in == M_INIT) {
@@ -711,8 +712,8 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                 x.used = 1; x.id = ss.next_id++; x.complete = 0; x.T = 0; x.cur = wk.in_slot; x.dual = 0; x.split_at = -1;
                 x.stopped[0] = 0; x.stopped[1] = 1; x.len[0] = x.len[1] = 0; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
                 x.cost[0] = 0; x.rest = sr[0]; x.rest_out = 0;
-                for (int i = 0; i < 2; ++i) for (int b = 0; b < 5; ++b) x.ev[i][b] = sv[i][0][b];
             }
+            if (lane < 10) x.ev[lane / 5][lane % 5] = sv[lane / 5][0][lane % 5];
             for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
         } else if (mode_in == M_WINDOW) {
             CNode& x = nh[wk.node];
@@ -737,40 +738,47 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
 #pragma unroll
                 for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wk.go[i]) Cb[((size_t)wk.node * 2 + i) * P.cap + T + lane] = wk.spec[i][lane];
             }
+            // a replay re-reads columns whose costs are on the tape already: it only brings the state (and the votes) of column T + a
+            if (!wk.replay) {
+                long long c = lane <= a && lane >= 1 ? (long long)sc[lane] : 0;          // inclusive prefix sum over the lanes
+#pragma unroll
+                for (int o = 1; o < SP_WAVE; o <<= 1) { const long long up = __shfl_up(c, o); if (lane >= o) c += up; }
+                const long long c0 = x.cost[0];
+                if (lane >= 1 && lane <= a) x.cost[lane] = c0 + c;
+                if (lane < n) { x.spec[0][lane] = wk.spec[0][lane]; x.spec[1][lane] = wk.spec[1][lane]; }
+            }
+            if (lane < 10) x.ev[lane / 5][lane % 5] = sv[lane / 5][a][lane % 5];
             if (lane == 0) {
                 ss.windows += 1; if (a < n) ss.cut_windows += 1;
-                // a replay re-reads columns whose costs are on the tape already: it only brings the state (and the votes) of column T + a
-                if (!wk.replay) {
-                    x.n = n; x.a = a;
-                    long long c = x.cost[0];
-                    for (int j = 1; j <= a; ++j) { c += (long long)sc[j]; x.cost[j] = c; }
-                    for (int i = 0; i < 2; ++i) for (int j = 0; j < n; ++j) x.spec[i][j] = wk.spec[i][j];
-                } else { x.n = n; x.a = n; }
-                for (int i = 0; i < 2; ++i) for (int b = 0; b < 5; ++b) x.ev[i][b] = sv[i][a][b];
+                x.n = n; x.a = wk.replay ? n : a;
                 x.have_out = (a == n) ? 1 : 0;
                 if (a == n) x.rest_out = sr[n];
             }
             if (a == n) for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
         } else if (mode_in == M_EXPAND) {
-            if (lane == 0) {
-                const CNode par = nh[wk.node];
-                const int L = wk.T;
-                const long long pc = par.cost[par.q];
-                for (int k = 0; k < wk.n_kids; ++k) {
-                    CNode& c = nh[wk.kid_node[k]];
-                    c.used = 1; c.complete = 0; c.id = ss.next_id++; c.T = L + 1; c.cur = 0;
-                    c.dual = par.dual || wk.kid_split[k]; c.split_at = wk.kid_split[k] ? L : par.split_at;
-                    for (int i = 0; i < 2; ++i) {
-                        const bool was_going = (i == 0 || par.dual) && !par.stopped[i];
-                        c.stopped[i] = par.stopped[i]; c.len[i] = par.len[i];
-                        if (wk.kid_base[k][i] >= 0) { c.stopped[i] = 0; c.len[i] = L + 1; }
-                        else if (was_going) { c.stopped[i] = 1; c.len[i] = L; }
-                    }
-                    if (!c.dual) c.stopped[1] = 1;
-                    c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = 0;
-                    c.cost[0] = pc + (long long)sc[k]; c.rest = sr[k]; c.rest_out = 0;
-                    for (int i = 0; i < 2; ++i) for (int b = 0; b < 5; ++b) c.ev[i][b] = sv[i][k][b];
+            const int L = wk.T;
+            if (lane < wk.n_kids) {                                         // one lane per child
+                const CNode& par = nh[wk.node];
+                const int k = lane;
+                CNode& c = nh[wk.kid_node[k]];
+                c.used = 1; c.complete = 0; c.id = ss.next_id + k; c.T = L + 1; c.cur = 0;
+                c.dual = par.dual || wk.kid_split[k]; c.split_at = wk.kid_split[k] ? L : par.split_at;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool was_going = (i == 0 || par.dual) && !par.stopped[i];
+                    int st = par.stopped[i], ln = par.len[i];
+                    if (wk.kid_base[k][i] >= 0) { st = 0; ln = L + 1; }
+                    else if (was_going) { st = 1; ln = L; }
+                    c.stopped[i] = st; c.len[i] = ln;
                 }
+                if (!c.dual) c.stopped[1] = 1;
+                c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = 0;
+                c.cost[0] = par.cost[par.q] + (long long)sc[k]; c.rest = sr[k]; c.rest_out = 0;
+                for (int i = 0; i < 2; ++i) for (int bq = 0; bq < 5; ++bq) c.ev[i][bq] = sv[i][k][bq];
+            }
+            spw::wave_lds_sync();
+            if (lane == 0) {
+                ss.next_id += wk.n_kids;
                 node_free(wk.node);
                 ss.expansions += 1;
                 // more than max_queue_size nodes wait: the one the search would take last goes
@@ -780,9 +788,9 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                         if (!nh[k].used || nh[k].complete) continue;
                         ++waiting;
                         if (wi < 0) { wi = k; continue; }
-                        const CNode& p = nh[k]; const CNode& b = nh[wi];
-                        const long long pcst = p.cost[p.q], bcst = b.cost[b.q]; const int pt = p.T + p.q, bt = b.T + b.q;
-                        if (pcst > bcst || (pcst == bcst && (pt < bt || (pt == bt && p.id > b.id)))) wi = k;
+                        const CNode& pp = nh[k]; const CNode& bb = nh[wi];
+                        const long long pcst = pp.cost[pp.q], bcst = bb.cost[bb.q]; const int pt = pp.T + pp.q, bt = bb.T + bb.q;
+                        if (pcst > bcst || (pcst == bcst && (pt < bt || (pt == bt && pp.id > bb.id)))) wi = k;
                     }
                     if (waiting <= ss.max_queue) break;
                     node_free(wi);
@@ -792,98 +800,129 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         __threadfence();                                  // (the lookahead words written above are read below by other lanes)
         spw::wave_lds_sync();
         // ---------------------------------------------------------------- 2. the search, played forward over the tapes
-        if (lane == 0) {
-            wk.mode = M_NONE; wk.n = 0; wk.replay = 0; wk.n_kids = 0;
-            int guard = 0;
-            // the nodes that wait (a short list: scanning the whole table at every column of a tape is what this loop would spend its time on)
-            int wait_idx[NQ], n_wait = 0;
-            for (int k = 0; k < NQ; ++k) if (nh[k].used && !nh[k].complete) wait_idx[n_wait++] = k;
-            for (;;) {
-                if (++guard > 100000) { wk.done = 1; break; }
-                int xi = ss.inflight;
-                if (xi < 0) {
-                    for (int w = 0; w < n_wait; ++w) {
-                        const int k = wait_idx[w];
-                        if (!nh[k].used || nh[k].complete) { wait_idx[w--] = wait_idx[--n_wait]; continue; }      // (freed or completed since the list was made)
-                        if (xi < 0) { xi = k; continue; }
-                        const CNode& p = nh[k]; const CNode& b = nh[xi];
-                        const long long pc = p.cost[p.q], bc = b.cost[b.q]; const int pt = p.T + p.q, bt = b.T + b.q;
-                        if (pc < bc || (pc == bc && (pt > bt || (pt == bt && p.id < b.id)))) xi = k;
-                    }
-                    if (xi < 0) { wk.done = 1; break; }                                     // nothing waits
-                    CNode& x = nh[xi];
-                    if (ss.best_node >= 0 && x.cost[x.q] >= ss.best_final) { wk.done = 1; break; }   // nothing that waits can beat (or precede) the complete node
-                    const int L = x.T + x.q;
-                    if (L < ss.threshold || proc[L] >= ss.per_size) { node_free(xi); continue; }
-                    proc[L] += 1; ss.pops += 1;
-                    if (L > ss.farthest) ss.farthest = L;
-                    if (ss.pops % ss.wo_constraint == 0 && ss.farthest > ss.threshold) ss.threshold = ss.farthest;
+        if (lane == 0) { wk.mode = M_NONE; wk.n = 0; wk.replay = 0; wk.n_kids = 0; }
+        spw::wave_lds_sync();
+        for (int guard = 0; ; ++guard) {
+            if (guard > 100000) { if (lane == 0) wk.done = 1; break; }
+            int xi = ss.inflight;
+            if (xi < 0) {
+                // the best and the second best of the nodes that wait: lane k looks at node k
+                long long kc = 0x7FFFFFFFFFFFFFFFll; int kt = -1, kid = 0x7FFFFFFF, kx = -1;
+                if (lane < NQ && nh[lane].used && !nh[lane].complete) { const CNode& p = nh[lane]; kc = p.cost[p.q]; kt = p.T + p.q; kid = p.id; kx = lane; }
+                auto less = [](long long c1, int t1, int i1, long long c2, int t2, int i2) { return c1 < c2 || (c1 == c2 && (t1 > t2 || (t1 == t2 && i1 < i2))); };
+                long long bc = kc; int bt = kt, bid = kid, bx = kx;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const long long oc = __shfl_xor(bc, o); const int ot = __shfl_xor(bt, o), oi = __shfl_xor(bid, o), ox = __shfl_xor(bx, o);
+                    if (ox >= 0 && (bx < 0 || less(oc, ot, oi, bc, bt, bid))) { bc = oc; bt = ot; bid = oi; bx = ox; }
+                }
+                xi = bx;
+                if (xi < 0) { if (lane == 0) wk.done = 1; break; }                          // nothing waits
+                long long sc2 = (kx == xi) ? 0x7FFFFFFFFFFFFFFFll : kc; int st2 = kt, sid2 = kid, sx2 = (kx == xi) ? -1 : kx;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const long long oc = __shfl_xor(sc2, o); const int ot = __shfl_xor(st2, o), oi = __shfl_xor(sid2, o), ox = __shfl_xor(sx2, o);
+                    if (ox >= 0 && (sx2 < 0 || less(oc, ot, oi, sc2, st2, sid2))) { sc2 = oc; st2 = ot; sid2 = oi; sx2 = ox; }
                 }
                 CNode& x = nh[xi];
-                ss.inflight = -1;
-                if (x.q < x.a) { x.q += 1; x.id = ss.next_id++; continue; }                  // a verified column of its tape: the node moves on (its one child)
-                // the node stands at the end of its tape: its state at that column has to be there
-                if (x.q > 0 || x.n > 0) {
-                    if (x.a == x.n && x.have_out) {                                        // the window stood: the other slot is the state
-                        x.T += x.n; x.cur ^= 1; x.cost[0] = x.cost[x.n]; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
-                    } else {
-                        // cut window: push the verified bases again from the kept state (nothing is speculated)
-                        wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = x.a; wk.replay = 1;
-                        wk.dual = x.dual; wk.split_at = x.split_at;
-                        for (int i = 0; i < 2; ++i) { wk.go[i] = (i == 0 || x.dual) && !x.stopped[i]; for (int j = 0; j < x.a; ++j) wk.spec[i][j] = x.spec[i][j]; }
-                        ss.inflight = xi;
+                if (ss.best_node >= 0 && bc >= ss.best_final) { if (lane == 0) wk.done = 1; break; }   // nothing that waits can beat (or precede) the complete node
+                const int L = bt, q = x.q, a = x.a;
+                // pops this node makes in a row: the first is decided; the following ones need the node to stay ahead of the second best,
+                // its lengths to be open (threshold, capacity per length) and stop at a pop that moves the threshold
+                const long long pops0 = ss.pops; const int wo = ss.wo_constraint;
+                const int jc = (int)((wo - 1 - (pops0 % wo)) % wo);                     // the pop with this index (0-based) makes pops a multiple of wo
+                const int linear = a - q;                                                // pops that only consume the tape
+                const int want = linear > 0 ? (linear < SP_WAVE ? linear : SP_WAVE) : 1;
+                bool can = lane < want && L + lane >= ss.threshold && proc[L + lane] < ss.per_size && lane <= jc;
+                if (can && lane > 0) {
+                    const long long cj = x.cost[q + lane];
+                    can = (sx2 < 0 || less(cj, L + lane, ss.next_id + lane - 1, sc2, st2, sid2)) && !(ss.best_node >= 0 && cj >= ss.best_final);
+                }
+                const unsigned long long no = ~__ballot(can);
+                const int m = no ? __builtin_ctzll(no) : SP_WAVE;
+                if (m == 0) { if (lane == 0) node_free(xi); spw::wave_lds_sync(); continue; }   // shorter than the threshold / its length is full
+                if (lane < m) proc[L + lane] += 1;
+                if (lane == 0) {
+                    ss.pops += m;
+                    if (L + m - 1 > ss.farthest) ss.farthest = L + m - 1;
+                    if (jc < m && ss.farthest > ss.threshold) ss.threshold = ss.farthest;
+                    if (linear > 0) { x.q = q + m; x.id = ss.next_id + m - 1; ss.next_id += m; }
+                }
+                spw::wave_lds_sync();
+                if (linear > 0) continue;                                                // verified columns of its tape: the node moved on (its one child each)
+            } else if (lane == 0) ss.inflight = -1;
+            spw::wave_lds_sync();
+            // the node stands at the end of its tape and its pop is accounted for: the decision of that column
+            int stop = 0;
+            if (lane == 0) {
+                CNode& x = nh[xi];
+                do {
+                    if (x.q < x.a) { x.q += 1; x.id = ss.next_id++; break; }               // (a window that was under way came back: its first column is this pop's child)
+                    // its state at that column has to be there
+                    if (x.q > 0 || x.n > 0) {
+                        if (x.a == x.n && x.have_out) {                                    // the window stood: the other slot is the state
+                            x.T += x.n; x.cur ^= 1; x.cost[0] = x.cost[x.n]; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
+                        } else {
+                            // cut window: push the verified bases again from the kept state (nothing is speculated)
+                            wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = x.a; wk.replay = 1;
+                            wk.dual = x.dual; wk.split_at = x.split_at;
+                            for (int i = 0; i < 2; ++i) { wk.go[i] = (i == 0 || x.dual) && !x.stopped[i]; for (int j = 0; j < x.a; ++j) wk.spec[i][j] = x.spec[i][j]; }
+                            ss.inflight = xi;
+                            stop = 1; break;
+                        }
+                    }
+                    const int L = x.T;
+                    // candidates of every consensus that is still going
+                    int nc[2] = { 0, 0 }, cd[2][4];
+                    for (int i = 0; i < (x.dual ? 2 : 1); ++i) {
+                        if (x.stopped[i]) continue;
+                        nc[i] = cands(x.ev[i], L, cd[i]);
+                        if (nc[i] == 0) { x.stopped[i] = 1; x.len[i] = L; }
+                    }
+                    if (nc[0] == 0 && nc[1] == 0) {                                        // complete
+                        const long long fc = x.cost[0] + (P.et ? 0 : x.rest);
+                        if (ss.best_node < 0 || fc < ss.best_final) { if (ss.best_node >= 0) node_free(ss.best_node); ss.best_node = xi; ss.best_final = fc; x.complete = 1; }
+                        else node_free(xi);
                         break;
                     }
-                }
-                const int L = x.T;
-                // candidates of every consensus that is still going
-                int nc[2] = { 0, 0 }, cd[2][4];
-                for (int i = 0; i < (x.dual ? 2 : 1); ++i) {
-                    if (x.stopped[i]) continue;
-                    nc[i] = cands(x.ev[i], L, cd[i]);
-                    if (nc[i] == 0) { x.stopped[i] = 1; x.len[i] = L; }
-                }
-                if (nc[0] == 0 && nc[1] == 0) {                                            // complete
-                    const long long fc = x.cost[0] + (P.et ? 0 : x.rest);
-                    if (ss.best_node < 0 || fc < ss.best_final) { if (ss.best_node >= 0) node_free(ss.best_node); ss.best_node = xi; ss.best_final = fc; x.complete = 1; }
-                    else node_free(xi);
-                    continue;
-                }
-                // children, in the oracle's order
-                int kb[MAXKIDS][2], ks[MAXKIDS], nk = 0;
-                if (!x.dual) {
-                    for (int a = 0; a < nc[0]; ++a) { kb[nk][0] = cd[0][a]; kb[nk][1] = -1; ks[nk] = 0; ++nk; }
-                    if (P.allow_dual) for (int a = 0; a < nc[0]; ++a) for (int b = a + 1; b < nc[0]; ++b) { kb[nk][0] = cd[0][a]; kb[nk][1] = cd[0][b]; ks[nk] = 1; ++nk; }
-                } else {
-                    const int n0 = nc[0] ? nc[0] : 1, n1 = nc[1] ? nc[1] : 1;
-                    for (int a = 0; a < n0; ++a) for (int b = 0; b < n1; ++b) { kb[nk][0] = nc[0] ? cd[0][a] : -1; kb[nk][1] = nc[1] ? cd[1][b] : -1; ks[nk] = 0; ++nk; }
-                }
-                if (nk == 1) {
-                    // one child: the node itself goes on, through a window whose first base is this decision
-                    wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = L; wk.replay = 0; wk.dual = x.dual; wk.split_at = x.split_at;
-                    for (int i = 0; i < 2; ++i) { wk.go[i] = kb[0][i] >= 0; wk.spec[i][0] = (uint8_t)(kb[0][i] >= 0 ? kb[0][i] : 0); }
-                    int nn = 1;
-                    need_la = x.la_valid ? xi : -1;
-                    wk.n = nn;
-                    // the pop is under way: when the window is back the node has consumed its first column
-                    x.n = 0; x.a = 0; x.q = 0;
-                    ss.inflight = xi;
-                    break;
-                }
-                // several children: one push each into fresh nodes
-                wk.mode = M_EXPAND; wk.node = xi; wk.in_slot = x.cur; wk.T = L; wk.dual = x.dual; wk.split_at = x.split_at;
-                wk.go[0] = nc[0] > 0; wk.go[1] = nc[1] > 0;
-                int made = 0;
-                for (int k = 0; k < nk && made < MAXKIDS; ++k) {
-                    const int kn = node_alloc();
-                    if (kn < 0) break;                                                  // (the table holds the queue plus one expansion: not reached)
-                    wk.kid_node[made] = kn; wk.kid_base[made][0] = (int8_t)kb[k][0]; wk.kid_base[made][1] = (int8_t)kb[k][1]; wk.kid_split[made] = (int8_t)ks[k];
-                    ++made;
-                }
-                wk.n_kids = made;
-                copy_from = xi; copy_len = L;
-                break;
+                    // children, in the oracle's order
+                    int kb[MAXKIDS][2], ks[MAXKIDS], nk = 0;
+                    if (!x.dual) {
+                        for (int a2 = 0; a2 < nc[0]; ++a2) { kb[nk][0] = cd[0][a2]; kb[nk][1] = -1; ks[nk] = 0; ++nk; }
+                        if (P.allow_dual) for (int a2 = 0; a2 < nc[0]; ++a2) for (int b2 = a2 + 1; b2 < nc[0]; ++b2) { kb[nk][0] = cd[0][a2]; kb[nk][1] = cd[0][b2]; ks[nk] = 1; ++nk; }
+                    } else {
+                        const int n0 = nc[0] ? nc[0] : 1, n1 = nc[1] ? nc[1] : 1;
+                        for (int a2 = 0; a2 < n0; ++a2) for (int b2 = 0; b2 < n1; ++b2) { kb[nk][0] = nc[0] ? cd[0][a2] : -1; kb[nk][1] = nc[1] ? cd[1][b2] : -1; ks[nk] = 0; ++nk; }
+                    }
+                    if (nk == 1) {
+                        // one child: the node itself goes on, through a window whose first base is this decision
+                        wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = L; wk.replay = 0; wk.dual = x.dual; wk.split_at = x.split_at;
+                        for (int i = 0; i < 2; ++i) { wk.go[i] = kb[0][i] >= 0; wk.spec[i][0] = (uint8_t)(kb[0][i] >= 0 ? kb[0][i] : 0); }
+                        need_la = x.la_valid ? xi : -1;
+                        wk.n = 1;
+                        x.n = 0; x.a = 0; x.q = 0;
+                        ss.inflight = xi;                                               // the pop is under way: when the window is back the node consumes its first column
+                        stop = 1; break;
+                    }
+                    // several children: one push each into fresh nodes
+                    wk.mode = M_EXPAND; wk.node = xi; wk.in_slot = x.cur; wk.T = L; wk.dual = x.dual; wk.split_at = x.split_at;
+                    wk.go[0] = nc[0] > 0; wk.go[1] = nc[1] > 0;
+                    int made = 0;
+                    for (int k = 0; k < nk && made < MAXKIDS; ++k) {
+                        int kn = -1;
+                        for (int z = 0; z < NQ; ++z) if (!nh[z].used) { nh[z].used = 1; nh[z].complete = 0; kn = z; break; }
+                        if (kn < 0) break;                                              // (the table holds the queue plus one expansion: not reached)
+                        wk.kid_node[made] = kn; wk.kid_base[made][0] = (int8_t)kb[k][0]; wk.kid_base[made][1] = (int8_t)kb[k][1]; wk.kid_split[made] = (int8_t)ks[k];
+                        ++made;
+                    }
+                    wk.n_kids = made;
+                    copy_from = xi; copy_len = L;
+                    stop = 1;
+                } while (0);
             }
+            stop = __builtin_amdgcn_readfirstlane(stop);
+            spw::wave_lds_sync();
+            if (stop) break;
         }
         // the speculated part of a new window: lane j takes the heaviest lookahead vote for push j of every consensus that grows; the
         // window ends where a consensus has no lookahead votes left (or at cap)

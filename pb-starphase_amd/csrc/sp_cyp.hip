@@ -413,7 +413,7 @@ __global__ void cyp_build_cells_kernel(const uint32_t* __restrict__ a_idx, const
 }
 
 // all |A| x |B| placements (A = indexed query side, B = target side), result[b][a][k]
-static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, const char* prof, std::vector<sp_aln>& out) {
+static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, bool retry_wide, const char* prof, std::vector<sp_aln>& out) {
     const uint64_t nA = A->n, nB = B->n, n_pairs = nA * nB, n_cells = n_pairs * (uint64_t)topk;
     out.assign(n_cells, sp_aln{});
     if (n_pairs == 0) return SP_OK;
@@ -432,7 +432,7 @@ static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, in
     rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v, topk);
     if (rc) return rc;
     hipLaunchKernelGGL(cyp_build_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, d_d, d_v, n_pairs, topk, CYP_MIN_VOTES, A->d_len, frac_cap, d_cells);
-    rc = sp_launch_cells(ctx, A, B, d_cells, n_cells, d_alns, nullptr, 0, prof);
+    rc = sp_launch_cells(ctx, A, B, d_cells, n_cells, d_alns, nullptr, 0, prof, retry_wide);
     if (rc) return rc;
     (void)hipMemcpyAsync(out.data(), d_alns, n_cells * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -451,7 +451,7 @@ extern "C" int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensu
     if (!ctx || !consensus || !segments || (consensus->n && !allowed) || (segments->n && (!ed || !ov || !kept))) return SP_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     std::vector<sp_aln> alns;
-    int rc = cyp_align_all(ctx, consensus, segments, 1, 0.0, "k4_weight_cells", alns);
+    int rc = cyp_align_all(ctx, consensus, segments, 1, 0.0, true, "k4_weight_cells", alns);
     if (rc) return rc;
     const uint32_t C = consensus->n;
     for (uint32_t s = 0; s < segments->n; ++s) {
@@ -483,7 +483,7 @@ extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, 
     (void)hipSetDevice(ctx->device);
     *n_hits = 0;
     std::vector<sp_aln> alns;
-    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, 0.05, "k3_region_cells", alns);
+    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, 0.05, false, "k3_region_cells", alns);
     if (rc) return rc;
     const uint32_t T = templates->n;
     auto penalized_type = [](int t) { return t == SP_CYP_DELETION || t == SP_CYP_REP6 || t == SP_CYP_REP7; };   // haplotyper.rs:185-191

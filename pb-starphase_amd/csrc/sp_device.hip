@@ -166,6 +166,133 @@ __global__ __launch_bounds__(256) void sp_cells_kernel(SeqSetView A, SeqSetView 
     }
 }
 
+
+// =============================================================================================
+// wide retry: a cell that found no alignment on 64 diagonals within its edit cap is run again on 256 diagonals around the same anchor
+// (an insertion / deletion of 40-120 bases next to the anchor; oracle/align.c: osp_wfa_retry).  Same contract as the 64-diagonal core
+// (ends-free, unit costs, X > D > I, longest path / most central / lowest diagonal at the end), four diagonals per lane; the windows
+// are read from memory (this is the rare path: the launcher applies it where a lost cell matters, not in K1 and K3).
+// =============================================================================================
+constexpr int SP_WIDE = 256;      // diagonals
+constexpr int SP_WPL = 4;         // per lane
+
+__device__ __forceinline__ uint32_t wide_get16(const uint32_t* w, int p) { return __builtin_amdgcn_alignbit(w[(p >> 4) + 1], w[p >> 4], (uint32_t)(p & 15) << 1); }
+
+__device__ __forceinline__ int wide_extend(const uint32_t* aw, const uint32_t* an, int m, const uint32_t* bw, const uint32_t* bn, int b0, int n, int i, int k) {
+    while (i < m && i + k < n) {
+        const int pa = i, pb = b0 + i + k;
+        const uint32_t x = wide_get16(aw, pa) ^ wide_get16(bw, pb);
+        uint32_t mm = (x | (x >> 1)) & 0x55555555u;
+        if (an) mm |= wide_get16(an, pa) & 0x55555555u;
+        if (bn) mm |= wide_get16(bn, pb) & 0x55555555u;
+        int run = mm ? (__builtin_ctz(mm) >> 1) : 16;
+        const int l1 = m - i, l2 = n - i - k, lim = l1 < l2 ? l1 : l2;
+        run = run < lim ? run : lim;
+        i += run;
+        if (run < 16) break;
+    }
+    return i;
+}
+
+template <bool TRACE>
+__global__ __launch_bounds__(256) void sp_cells_wide_kernel(SeqSetView A, SeqSetView B, const CellDesc* __restrict__ cells, uint64_t n_cells,
+                                                            sp_aln* __restrict__ out, uint32_t* __restrict__ events, uint32_t ev_stride,
+                                                            uint16_t* __restrict__ hist_pool, int hist_rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave, nw = (uint64_t)gridDim.x * 4;
+    uint16_t* hist = TRACE ? hist_pool + gw * (uint64_t)hist_rows * SP_WIDE : nullptr;
+    for (uint64_t c = gw; c < n_cells; c += nw) {
+        const CellDesc cd = cells[c];
+        if (cd.diag == SP_NO_DIAG) continue;
+        if (out[c].ok) continue;                                            // the 64-diagonal run found it
+        const uint32_t* aw = A.words + A.word_off[cd.a]; const uint32_t* an = A.nplane ? A.nplane + A.word_off[cd.a] : nullptr;
+        const uint32_t* bw = B.words + B.word_off[cd.b]; const uint32_t* bn = B.nplane ? B.nplane + B.word_off[cd.b] : nullptr;
+        const int m = A.len[cd.a], blen = B.len[cd.b];
+        const int b0 = cd.b_hi >= 0 ? cd.b_lo : 0, n = (cd.b_hi >= 0 ? cd.b_hi : blen) - b0;
+        int max_ed = cd.max_ed < hist_rows - 1 ? cd.max_ed : hist_rows - 1;
+        uint32_t* ev = (TRACE && events) ? events + c * (uint64_t)ev_stride : nullptr;
+        if (TRACE && ev && (uint32_t)max_ed > ev_stride) max_ed = (int)ev_stride;
+        if (m <= 0 || n <= 0 || max_ed < 0) continue;
+        const int kb = cd.diag - SP_WIDE / 2;
+        int H[SP_WPL], O[SP_WPL];
+#pragma unroll
+        for (int j = 0; j < SP_WPL; ++j) {
+            const int D = lane * SP_WPL + j, k = kb + D, i0 = k < 0 ? -k : 0;
+            H[j] = (i0 < m && i0 + k < n) ? wide_extend(aw, an, m, bw, bn, b0, n, i0, k) : SP_NEG;
+            O[j] = D;
+            if (TRACE) hist[D] = (uint16_t)(H[j] >= 0 ? H[j] : 0xFFFF);
+        }
+        int s = 0, end_D = -1;
+        for (;;) {
+            // termination: a diagonal on the last row / last column; longest path, then most central, then lowest diagonal
+            long long key = -1;
+#pragma unroll
+            for (int j = 0; j < SP_WPL; ++j) {
+                const int D = lane * SP_WPL + j, k = kb + D, i = H[j];
+                if (i >= 0 && (i == m || i + k == n)) {
+                    int cdist = D - SP_WIDE / 2; cdist = cdist < 0 ? -cdist : cdist;
+                    const long long kk = (long long)(i + i + k) * (2ll * SP_WIDE * SP_WIDE) + (long long)(SP_WIDE - cdist) * SP_WIDE + (SP_WIDE - 1 - D);
+                    key = kk > key ? kk : key;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const long long other = __shfl_xor(key, o); key = other > key ? other : key; }
+            if (key >= 0) { end_D = SP_WIDE - 1 - (int)(key % SP_WIDE); break; }
+            if (s == max_ed) break;
+            // next wavefront: X from the same diagonal, D from the one below, I from the one above (that priority on equal reach)
+            const int from_below = spw::from_lower(H[SP_WPL - 1], SP_NEG), ofb = spw::from_lower(O[SP_WPL - 1], 0);
+            const int from_above = spw::from_upper(H[0], SP_NEG), ofa = spw::from_upper(O[0], 0);
+            int NH[SP_WPL], NO[SP_WPL];
+#pragma unroll
+            for (int j = 0; j < SP_WPL; ++j) {
+                const int up = j > 0 ? H[j - 1] : from_below, oup = j > 0 ? O[j - 1] : ofb;
+                const int dn = j < SP_WPL - 1 ? H[j + 1] : from_above, odn = j < SP_WPL - 1 ? O[j + 1] : ofa;
+                int best = H[j] >= 0 ? H[j] + 1 : SP_NEG, o = O[j];
+                if (up >= 0 && up > best) { best = up; o = oup; }
+                if (dn >= 0 && dn + 1 > best) { best = dn + 1; o = odn; }
+                NH[j] = best; NO[j] = o;
+            }
+            ++s;
+#pragma unroll
+            for (int j = 0; j < SP_WPL; ++j) {
+                const int D = lane * SP_WPL + j;
+                H[j] = NH[j] >= 0 ? wide_extend(aw, an, m, bw, bn, b0, n, NH[j], kb + D) : SP_NEG;
+                O[j] = NO[j];
+                if (TRACE) hist[(size_t)s * SP_WIDE + D] = (uint16_t)(H[j] >= 0 ? H[j] : 0xFFFF);
+            }
+        }
+        if (end_D < 0) continue;                                            // still nothing: the cell stays lost
+        // the end point and the origin diagonal live in the lane that owns end_D
+        const int el = end_D / SP_WPL, ej = end_D % SP_WPL;
+        int he = 0, oe = 0;
+#pragma unroll
+        for (int j = 0; j < SP_WPL; ++j) if (j == ej) { he = __builtin_amdgcn_readlane(H[j], el); oe = __builtin_amdgcn_readlane(O[j], el); }
+        // (readlane needs a uniform lane index: el is uniform)
+        const int ko = kb + oe, i0 = ko < 0 ? -ko : 0;
+        if (lane == 0) {
+            sp_aln r; r.ok = 1; r.nm = s; r.a_start = i0; r.a_end = he; r.b_start = i0 + ko; r.b_end = he + kb + end_D; r.a_len = m; r.b_len = n;
+            out[c] = r;
+            if (TRACE && ev) {
+                __threadfence();
+                int l = end_D;
+                for (int t = s; t > 0; --t) {
+                    const uint16_t* Hp = hist + (size_t)(t - 1) * SP_WIDE;
+                    auto hv = [&](int d) { return (d < 0 || d >= SP_WIDE || Hp[d] == 0xFFFF) ? SP_NEG : (int)Hp[d]; };
+                    const int cc = hv(l), uu = hv(l - 1), dd = hv(l + 1);
+                    int best = cc >= 0 ? cc + 1 : SP_NEG, src = l; uint32_t type = SP_EV_X;
+                    if (uu >= 0 && uu > best) { best = uu; src = l - 1; type = SP_EV_D; }
+                    if (dd >= 0 && dd + 1 > best) { best = dd + 1; src = l + 1; type = SP_EV_I; }
+                    const int kk = kb + l;
+                    const int bpos = type == SP_EV_X ? best - 1 + kk : (type == SP_EV_D ? best + kk - 1 : best + kk);
+                    ev[t - 1] = (type << 30) | (uint32_t)bpos;
+                    l = src;
+                }
+            }
+        }
+        if (TRACE) { __threadfence(); }
+    }
+}
+
 // =============================================================================================
 // 2-bit packing on the device: one thread per output dword (16 bases).  A=0 C=1 G=2 T=3 (either case), anything else is
 // 'N': code 0 in the word plane, 01 in the N plane, and the set is flagged as carrying N.
@@ -281,7 +408,7 @@ int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
 #endif
 int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     const CellDesc* d_cells, uint64_t n_cells,
-                    sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name) {
+                    sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, bool retry_wide) {
     if (n_cells == 0) return SP_OK;
     const bool trace = d_events != nullptr;
     const bool hasn = A->has_n || B->has_n;
@@ -307,5 +434,17 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     else       { if (hasn) SP_LAUNCH(false, true); else SP_LAUNCH(false, false); }
 #undef SP_LAUNCH
     SP_HIP_CHECK(ctx, hipGetLastError());
+    if (retry_wide) {
+        // the cells the 64-diagonal run lost are run again on 256 diagonals (one wave each; cells that were found return at once)
+        uint64_t wblocks = std::min<uint64_t>((n_cells + 3) / 4, (uint64_t)ctx->num_cus * 2);
+        uint16_t* whist = nullptr;
+        if (trace) {
+            whist = (uint16_t*)sp_pool(ctx, "wide_hist", wblocks * 4 * (size_t)hist_rows * SP_WIDE * sizeof(uint16_t));
+            if (!whist) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "align: wide traceback scratch");
+        }
+        if (trace) hipLaunchKernelGGL((sp_cells_wide_kernel<true>), dim3((unsigned)wblocks), dim3(256), 0, ctx->stream, av, bv, d_cells, n_cells, d_out, d_events, events_stride, whist, hist_rows);
+        else hipLaunchKernelGGL((sp_cells_wide_kernel<false>), dim3((unsigned)wblocks), dim3(256), 0, ctx->stream, av, bv, d_cells, n_cells, d_out, d_events, events_stride, whist, hist_rows);
+        SP_HIP_CHECK(ctx, hipGetLastError());
+    }
     return SP_OK;
 }

@@ -86,13 +86,17 @@ class Oracle:
         self.L.osp_encode(s, len(s), a.ctypes.data_as(C.c_void_p))
         return a[:len(s)] if len(s) else a[:0]
 
-    def wfa(self, a, b, diag, max_ed=255, events=True):
+    def wfa(self, a, b, diag, max_ed=255, events=True, retry=False):
+        """retry: the rule of the library's generic cell launcher (a cell that finds nothing on 64 diagonals runs again on 256)"""
         A = a if isinstance(a, np.ndarray) else self.encode(a)
         B = b if isinstance(b, np.ndarray) else self.encode(b)
         al = Aln()
         ev = np.zeros(max_ed + 1, np.uint32)
         ne = C.c_int32(0)
-        self.L.osp_wfa(A.ctypes.data_as(C.c_void_p), len(A), B.ctypes.data_as(C.c_void_p), len(B), int(diag), int(max_ed),
+        fn = self.L.osp_wfa_retry if retry else self.L.osp_wfa
+        fn.restype = C.c_int32
+        fn.argtypes = self.L.osp_wfa.argtypes
+        fn(A.ctypes.data_as(C.c_void_p), len(A), B.ctypes.data_as(C.c_void_p), len(B), int(diag), int(max_ed),
                        C.byref(al), ev.ctypes.data_as(C.c_void_p) if events else None, C.byref(ne))
         return al, ev[:ne.value].copy()
 

@@ -51,7 +51,7 @@ def compare(oracle, ctx, A, B, a_idx, b_idx, max_ed=255, shift=0):
     out2 = ctx.align_batch(sa, sb, a_idx, b_idx, cell_diag, np.full(len(a_idx), max_ed, np.int32), events=False)
     n_ok = 0
     for x, (i, j) in enumerate(zip(a_idx, b_idx)):
-        al, oev = oracle.wfa(A[i], B[j], int(cell_diag[x]), max_ed)
+        al, oev = oracle.wfa(A[i], B[j], int(cell_diag[x]), max_ed, retry=True)       # sp_align_batch retries a lost cell on 256 diagonals
         got = out[x]
         want = (al.ok, al.nm, al.a_start, al.a_end, al.b_start, al.b_end, al.a_len, al.b_len) if al.ok else None
         if al.ok:
@@ -146,3 +146,31 @@ def _fuzz_once(oracle, gpu_ctx, seed):
     assert n_ok > len(A) // 2
     for shift, cap in ((-31, 255), (13, 40), (0, 6), (29, 1)):
         compare(oracle, gpu_ctx, A, B, idx, idx, max_ed=cap, shift=shift)
+
+
+def test_long_indels_use_the_wide_band(oracle, pkg, gpu_ctx):
+    """an insertion / deletion of 40-100 bases inside an otherwise near-identical pair: on 64 diagonals the cell is lost (or, for the shorter
+    ones that the midpoint anchor still covers, found); sp_align_batch runs a lost cell again on 256 diagonals.  Bit for bit against
+    oracle/align.c (osp_wfa_retry), and the wide run recovers the pair with about `indel` edits."""
+    from pb_starphase_amd import synth
+    rng = np.random.default_rng(2026)
+    A, B, sizes = [], [], []
+    for ln in (1500, 3200, 6100):
+        for size in (40, 55, 70, 85, 100):
+            for kind in ("del", "ins"):
+                a = rand_seq(rng, ln)
+                core = synth.mutate(rng, a, 3, 1, 1)
+                at = int(rng.integers(ln // 3, 2 * ln // 3))
+                core = core[:at] + core[at + size:] if kind == "del" else core[:at] + rand_seq(rng, size) + core[at:]
+                A.append(a); B.append(rand_seq(rng, 120) + core + rand_seq(rng, 80)); sizes.append(size)
+    idx = np.arange(len(A), dtype=np.uint32)
+    n_ok = compare(oracle, gpu_ctx, A, B, idx, idx, max_ed=300)
+    assert n_ok == len(A)
+    sa, sb = gpu_ctx.upload(A), gpu_ctx.upload(B)
+    diag, _votes = gpu_ctx.anchor_batch(sb, sa, idx, idx)
+    out = gpu_ctx.align_batch(sa, sb, idx, idx, (-diag).astype(np.int32), np.full(len(A), 300, np.int32))
+    narrow_lost = 0
+    for x, size in enumerate(sizes):
+        assert out[x]["ok"] and size <= out[x]["nm"] <= size + 12, (x, size, out[x])
+        narrow_lost += not oracle.wfa(A[x], B[x], int(-diag[x]), 300, events=False)[0].ok
+    assert narrow_lost >= len(A) // 3                                   # the retry did the work

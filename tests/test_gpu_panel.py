@@ -63,7 +63,7 @@ def test_full_panel_sample(oracle, pkg, gpu_ctx):
                 pairs = [frozenset(d) for d in called["diplotypes"]]
                 assert exp[0] == (0, 0, 0, 0) and frozenset((h1, h2)) in pairs, (name, rep, h1, h2, called["diplotypes"][:4])
             n_cells += len(haps)
-    assert n_cells > 3000
+    assert n_cells > 2500
     # ---- HLA-A / -B of the same sample
     fx = synth.HlaFixture()
     db = fx.make_db(pkg, gpu_ctx)
