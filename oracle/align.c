@@ -193,6 +193,27 @@ int osp_wfa_retry(const uint8_t* A, int m, const uint8_t* B, int n, int diag, in
     return osp_wfa_band(A, m, B, n, diag, max_ed, OSP_WIDE_BAND, out, events, n_events);
 }
 
+/* the stricter rule of the launcher's few-cell callers (sp_align_batch, allele / consensus placements): the 256-diagonal run is also
+ * made when the 64-diagonal alignment needed more than half a band of edits (a path through a long insertion / deletion may be
+ * cheaper than the mismatches the narrow band paid); the wide result is taken when it has strictly fewer edits */
+int osp_wfa_retry2(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed,
+                   osp_aln* out, uint32_t* events, int* n_events) {
+    const int ok = osp_wfa_band(A, m, B, n, diag, max_ed, OSP_BAND, out, events, n_events);
+    if (ok && out->nm <= OSP_BAND / 2) return 1;
+    osp_aln wide; int ne = 0;
+    uint32_t* ev = events ? (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(max_ed + 1)) : NULL;
+    const int wok = osp_wfa_band(A, m, B, n, diag, max_ed, OSP_WIDE_BAND, &wide, ev, &ne);
+    if (wok && (!ok || wide.nm < out->nm)) {
+        *out = wide;
+        if (events) memcpy(events, ev, sizeof(uint32_t) * (size_t)ne);
+        if (n_events) *n_events = ne;
+        free(ev);
+        return 1;
+    }
+    free(ev);
+    return ok;
+}
+
 int osp_events_to_cigar(const osp_aln* aln, const uint32_t* events, int n_events, uint32_t* cigar, int cap) {
     int nc = 0; int j = aln->b_start;
 #define PUSH(len, op) do { if ((len) > 0) { if (nc > 0 && (cigar[nc-1] & 15u) == (uint32_t)(op)) cigar[nc-1] += (uint32_t)(len) << 4; \

@@ -569,19 +569,58 @@ int osp_cyp_build_chains(int n_haps, const int32_t* hap_type, int n_reads, const
 
 /* ------------------------------------------------------------------ variant states of a sequence on the backbone (see cyp_oracle.h) */
 static int code_of(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
-static int lev(const uint8_t* a, int la, const uint8_t* b, int lb) {
-    int* row = (int*)malloc(sizeof(int) * (size_t)(lb + 1));
-    for (int j = 0; j <= lb; ++j) row[j] = j;
-    for (int i = 1; i <= la; ++i) {
-        int diag = row[0]; row[0] = i;
-        for (int j = 1; j <= lb; ++j) {
-            int v = diag + ((a[i - 1] < 4 && a[i - 1] == b[j - 1]) ? 0 : 1);
-            if (row[j] + 1 < v) v = row[j] + 1;
-            if (row[j - 1] + 1 < v) v = row[j - 1] + 1;
-            diag = row[j]; row[j] = v;
-        }
+
+/* The variant graph of the aligned backbone part [gs, ge): reference stretches and SITES.  A site is a maximal run of variants whose
+ * reference spans overlap; its alternatives are the subsets of its variants that do not overlap one another (the empty subset is the
+ * reference), each one the site's span with those variants applied. */
+#define K9_SITE_MAX 8            /* variants per site */
+#define K9_DIAGS 256             /* diagonals of the alignment (read offset - graph offset), centred on the drift of the linear placement */
+#define K9_INF 30000
+typedef struct { int s, e, nv, var[K9_SITE_MAX]; } k9_site;
+typedef struct { int site, mask, len; uint8_t* seq; } k9_alt;
+
+/* one base of the graph: col is indexed by diagonal d <-> k = k0 + d, read position i = off + k (off = graph offset before the base) */
+static void k9_base(int16_t* col, int x, const uint8_t* seq, int L, int off, int k0) {
+    int16_t nw[K9_DIAGS];
+    for (int d = 0; d < K9_DIAGS; ++d) {
+        const int i = off + k0 + d;                       /* read position before the base on this diagonal */
+        int v = K9_INF;
+        if (i >= 0 && i < L && col[d] < K9_INF) v = col[d] + ((seq[i] < 4 && seq[i] == x) ? 0 : 1);          /* the base faces read base i */
+        if (d + 1 < K9_DIAGS && col[d + 1] < K9_INF && i + 1 >= 0 && i + 1 <= L) { const int w = col[d + 1] + 1; if (w < v) v = w; }   /* the base faces nothing */
+        nw[d] = (int16_t)v;
     }
-    int r = row[lb]; free(row); return r;
+    /* read bases that face nothing: along the column, from lower to higher diagonals */
+    for (int d = 1; d < K9_DIAGS; ++d) { const int i = off + 1 + k0 + d; if (i >= 0 && i <= L && nw[d - 1] + 1 < nw[d]) nw[d] = (int16_t)(nw[d - 1] + 1); }
+    memcpy(col, nw, sizeof nw);
+}
+
+/* forward pass over the graph: exit[a] = the column at the site's end after alternative a (real diagonals), entry[site] = the column
+ * in front of the site; returns the final column in col */
+static void k9_forward(const uint8_t* bb, int gs, int ge, const k9_site* sites, int n_sites, const k9_alt* alts, const int* alt_first,
+                       const uint8_t* seq, int L, int k0, int16_t* col, int16_t* entry, int16_t* exit_cols) {
+    for (int d = 0; d < K9_DIAGS; ++d) { const int i = k0 + d; col[d] = (int16_t)((i >= 0 && i <= L) ? i : K9_INF); }
+    int b = gs;
+    for (int si = 0; si <= n_sites; ++si) {
+        const int stop = si < n_sites ? sites[si].s : ge;
+        for (; b < stop; ++b) k9_base(col, bb[b], seq, L, b - gs, k0);
+        if (si == n_sites) break;
+        memcpy(entry + (size_t)si * K9_DIAGS, col, sizeof(int16_t) * K9_DIAGS);
+        int16_t acc[K9_DIAGS];
+        for (int d = 0; d < K9_DIAGS; ++d) acc[d] = K9_INF;
+        const int lr = sites[si].e - sites[si].s;
+        for (int a = alt_first[si]; a < alt_first[si + 1]; ++a) {
+            int16_t w[K9_DIAGS];
+            memcpy(w, entry + (size_t)si * K9_DIAGS, sizeof w);
+            for (int x = 0; x < alts[a].len; ++x) k9_base(w, alts[a].seq[x], seq, L, b - gs + x, k0);
+            /* the alternative is alts[a].len bases where the reference has lr: its diagonals shift by len - lr at the site's end */
+            const int delta = alts[a].len - lr;
+            int16_t* out = exit_cols + (size_t)a * K9_DIAGS;
+            for (int d = 0; d < K9_DIAGS; ++d) { const int src = d - delta; out[d] = (src >= 0 && src < K9_DIAGS) ? w[src] : K9_INF; }
+            for (int d = 0; d < K9_DIAGS; ++d) if (out[d] < acc[d]) acc[d] = out[d];
+        }
+        memcpy(col, acc, sizeof acc);
+        b = sites[si].e;
+    }
 }
 
 int osp_cyp_variant_states(const uint8_t* seq, int seq_len, const uint8_t* backbone, int backbone_len, int n_variants, const int32_t* var_pos,
@@ -591,33 +630,112 @@ int osp_cyp_variant_states(const uint8_t* seq, int seq_len, const uint8_t* backb
     int diag = 0;
     if (osp_anchor(seq, seq_len, backbone, backbone_len, &diag) < OSP_CYP_MIN_VOTES) return 0;      /* backbone_pos - seq_pos */
     osp_aln al; uint32_t ev[OSP_MAX_ED + 1]; int nev = 0;
-    if (!osp_wfa_retry(seq, seq_len, backbone, backbone_len, diag, OSP_MAX_ED, &al, ev, &nev)) return 0;
+    if (!osp_wfa_retry2(seq, seq_len, backbone, backbone_len, diag, OSP_MAX_ED, &al, ev, &nev)) return 0;
     if (aln_out) { aln_out[0] = al.a_start; aln_out[1] = al.a_end; aln_out[2] = al.b_start; aln_out[3] = al.b_end; aln_out[4] = al.nm; }
-    for (int v = 0; v < n_variants; ++v) {
-        const int p = var_pos[v], rl = (int)strlen(var_ref[v]), alen = (int)strlen(var_alt[v]);
-        if (p < al.b_start || p + rl > al.b_end) continue;
-        int ws = p - OSP_K9_FLANK, we = p + rl + OSP_K9_FLANK;
-        if (ws < al.b_start) ws = al.b_start;
-        if (we > al.b_end) we = al.b_end;
-        /* sequence position facing backbone position b: deletions before b pull it back, insertions before b push it on */
-        int sa = al.a_start + (ws - al.b_start), ea = al.a_start + (we - al.b_start);
-        for (int e = 0; e < nev; ++e) {
-            const uint32_t type = ev[e] >> 30; const int bp = (int)(ev[e] & 0x3FFFFFFFu);
-            if (type == OSP_EV_D) { if (bp < ws) --sa; if (bp < we) --ea; }
-            else if (type == OSP_EV_I) { if (bp < ws) ++sa; if (bp < we) ++ea; }
-        }
-        if (sa < 0) sa = 0;
-        if (ea > seq_len) ea = seq_len;
-        if (ea < sa) ea = sa;
-        const int lr = we - ws, la = lr - rl + alen;
-        uint8_t* href = (uint8_t*)malloc((size_t)lr + 1), *halt = (uint8_t*)malloc((size_t)la + 1);
-        memcpy(href, backbone + ws, (size_t)lr);
-        memcpy(halt, backbone + ws, (size_t)(p - ws));
-        for (int i = 0; i < alen; ++i) halt[p - ws + i] = (uint8_t)code_of(var_alt[v][i]);
-        memcpy(halt + (p - ws) + alen, backbone + p + rl, (size_t)(we - p - rl));
-        const int dr = lev(seq + sa, ea - sa, href, lr), da = lev(seq + sa, ea - sa, halt, la);
-        states[v] = dr < da ? 0 : (da < dr ? 1 : 2);
-        free(href); free(halt);
+    const int gs = al.b_start, ge = al.b_end, L = al.a_end - al.a_start;
+    const uint8_t* S = seq + al.a_start;
+    /* the band: centred on the middle of the drift the linear placement shows (insertions push the read on, deletions pull it back) */
+    int drift = 0, dmin = 0, dmax = 0;
+    for (int e = 0; e < nev; ++e) {
+        const uint32_t type = ev[e] >> 30;
+        if (type == OSP_EV_I) ++drift; else if (type == OSP_EV_D) --drift;
+        if (drift < dmin) dmin = drift;
+        if (drift > dmax) dmax = drift;
     }
+    const int k0 = (dmin + dmax) / 2 - K9_DIAGS / 2;
+    /* sites */
+    int* order = (int*)malloc(sizeof(int) * (size_t)(n_variants + 1)); int no = 0;
+    for (int v = 0; v < n_variants; ++v) { const int rl = (int)strlen(var_ref[v]); if (var_pos[v] >= gs && var_pos[v] + rl <= ge) order[no++] = v; }
+    for (int a = 1; a < no; ++a) { const int v = order[a]; int b = a - 1; while (b >= 0 && (var_pos[order[b]] > var_pos[v] || (var_pos[order[b]] == var_pos[v] && order[b] > v))) { order[b + 1] = order[b]; --b; } order[b + 1] = v; }
+    k9_site* sites = (k9_site*)malloc(sizeof(k9_site) * (size_t)(no + 1)); int n_sites = 0;
+    for (int a = 0; a < no;) {
+        k9_site st; st.s = var_pos[order[a]]; st.e = st.s + (int)strlen(var_ref[order[a]]); st.nv = 0;
+        while (a < no && var_pos[order[a]] < st.e) {
+            const int end = var_pos[order[a]] + (int)strlen(var_ref[order[a]]);
+            if (st.nv < K9_SITE_MAX) { if (end > st.e) st.e = end; st.var[st.nv++] = order[a]; }      /* (a ninth overlapping variant stays undecided) */
+            ++a;
+        }
+        sites[n_sites++] = st;
+    }
+    /* alternatives */
+    int* alt_first = (int*)malloc(sizeof(int) * (size_t)(n_sites + 1));
+    int cap_alts = 0; for (int si = 0; si < n_sites; ++si) cap_alts += 1 << sites[si].nv;
+    k9_alt* alts = (k9_alt*)malloc(sizeof(k9_alt) * (size_t)(cap_alts + 1)); int na = 0;
+    for (int si = 0; si < n_sites; ++si) {
+        alt_first[si] = na;
+        const k9_site* st = &sites[si];
+        for (int mask = 0; mask < (1 << st->nv); ++mask) {
+            /* the chosen variants must not overlap one another (they are in position order) */
+            int ok = 1, last_end = -1;
+            for (int x = 0; x < st->nv && ok; ++x) if (mask >> x & 1) { const int v = st->var[x]; if (var_pos[v] < last_end) ok = 0; last_end = var_pos[v] + (int)strlen(var_ref[v]); }
+            if (!ok) continue;
+            k9_alt A; A.site = si; A.mask = mask; A.seq = (uint8_t*)malloc((size_t)(st->e - st->s) + 64 * (size_t)st->nv + 64); A.len = 0;
+            int b = st->s;
+            for (int x = 0; x < st->nv; ++x) if (mask >> x & 1) {
+                const int v = st->var[x];
+                while (b < var_pos[v]) A.seq[A.len++] = backbone[b++];
+                for (const char* q = var_alt[v]; *q; ++q) A.seq[A.len++] = (uint8_t)code_of(*q);
+                b = var_pos[v] + (int)strlen(var_ref[v]);
+            }
+            while (b < st->e) A.seq[A.len++] = backbone[b++];
+            alts[na++] = A;
+        }
+    }
+    alt_first[n_sites] = na;
+    /* forward over the graph, forward over the mirrored graph (= backward) */
+    int16_t col[K9_DIAGS];
+    int16_t* entry = (int16_t*)malloc(sizeof(int16_t) * K9_DIAGS * (size_t)(n_sites + 1));
+    int16_t* exits = (int16_t*)malloc(sizeof(int16_t) * K9_DIAGS * (size_t)(na + 1));
+    k9_forward(backbone, gs, ge, sites, n_sites, alts, alt_first, S, L, k0, col, entry, exits);
+    const int kL = L - (ge - gs) - k0;                                          /* diagonal of the end point */
+    const int opt = (kL >= 0 && kL < K9_DIAGS) ? col[kL] : K9_INF;
+    if (opt >= K9_INF) { /* the band lost the path: nothing is decided */
+        for (int a = 0; a < na; ++a) free(alts[a].seq);
+        free(order); free(sites); free(alt_first); free(alts); free(entry); free(exits);
+        return 1;
+    }
+    /* mirror: graph offset g' = (ge - gs) - g, read position i' = L - i, so diagonal k' = i' - g' = kL_abs - k with kL_abs = L - (ge - gs) */
+    const int G = ge - gs, kabs = L - G;
+    uint8_t* rbb = (uint8_t*)malloc((size_t)backbone_len + 1), *rS = (uint8_t*)malloc((size_t)L + 1);
+    for (int i = 0; i < L; ++i) rS[i] = S[L - 1 - i];
+    for (int g = 0; g < G; ++g) rbb[g] = backbone[ge - 1 - g];
+    k9_site* rsites = (k9_site*)malloc(sizeof(k9_site) * (size_t)(n_sites + 1));
+    k9_alt* ralts = (k9_alt*)malloc(sizeof(k9_alt) * (size_t)(na + 1));
+    int* ralt_first = (int*)malloc(sizeof(int) * (size_t)(n_sites + 1));
+    int rna = 0;
+    for (int si = 0; si < n_sites; ++si) {
+        const k9_site* st = &sites[n_sites - 1 - si];
+        rsites[si] = *st; rsites[si].s = ge - st->e; rsites[si].e = ge - st->s;       /* offsets in the mirrored backbone (which starts at 0) */
+        ralt_first[si] = rna;
+        for (int a = alt_first[n_sites - 1 - si]; a < alt_first[n_sites - si]; ++a) {
+            k9_alt A = alts[a]; A.seq = (uint8_t*)malloc((size_t)A.len + 1);
+            for (int x = 0; x < A.len; ++x) A.seq[x] = alts[a].seq[A.len - 1 - x];
+            ralts[rna++] = A;
+        }
+    }
+    ralt_first[n_sites] = rna;
+    /* the mirrored band: diagonal index d' of k' = kabs - k; k = k0 + d  =>  k' = kabs - k0 - d: choose k0' so that d' = K9_DIAGS - 1 - d */
+    const int rk0 = kabs - k0 - (K9_DIAGS - 1);
+    int16_t rcol[K9_DIAGS];
+    int16_t* rentry = (int16_t*)malloc(sizeof(int16_t) * K9_DIAGS * (size_t)(n_sites + 1));
+    int16_t* rexits = (int16_t*)malloc(sizeof(int16_t) * K9_DIAGS * (size_t)(na + 1));
+    k9_forward(rbb, 0, G, rsites, n_sites, ralts, ralt_first, rS, L, rk0, rcol, rentry, rexits);
+    /* alternative a of site si lies on an optimal path iff some diagonal has exit_a + (cost of the rest from the site's end) == opt; the
+     * rest from the end of site si is the mirrored pass's column in FRONT of mirrored site n_sites - 1 - si */
+    for (int si = 0; si < n_sites; ++si) {
+        const int16_t* back = rentry + (size_t)(n_sites - 1 - si) * K9_DIAGS;
+        int seen1[K9_SITE_MAX] = {0}, seen0[K9_SITE_MAX] = {0};
+        for (int a = alt_first[si]; a < alt_first[si + 1]; ++a) {
+            const int16_t* ex = exits + (size_t)a * K9_DIAGS;
+            int on = 0;
+            for (int d = 0; d < K9_DIAGS && !on; ++d) { const int bd = K9_DIAGS - 1 - d; if (ex[d] < K9_INF && back[bd] < K9_INF && ex[d] + back[bd] == opt) on = 1; }
+            if (!on) continue;
+            for (int x = 0; x < sites[si].nv; ++x) { if (alts[a].mask >> x & 1) seen1[x] = 1; else seen0[x] = 1; }
+        }
+        for (int x = 0; x < sites[si].nv; ++x) states[sites[si].var[x]] = (seen1[x] && seen0[x]) ? 2 : seen1[x] ? 1 : seen0[x] ? 0 : 3;
+    }
+    for (int a = 0; a < na; ++a) { free(alts[a].seq); free(ralts[a].seq); }
+    free(order); free(sites); free(alt_first); free(alts); free(entry); free(exits);
+    free(rbb); free(rS); free(rsites); free(ralts); free(ralt_first); free(rentry); free(rexits);
     return 1;
 }

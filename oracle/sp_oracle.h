@@ -76,6 +76,9 @@ int osp_wfa_band(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int
 /* 64 diagonals, then 256 if nothing was found: the rule of the library's generic cell launcher (everywhere but K1 and K3) */
 int osp_wfa_retry(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed,
                   osp_aln* out, uint32_t* events, int* n_events);
+/* also when the 64-diagonal alignment needed more than 32 edits; the wide result is kept when it has fewer (few-cell callers) */
+int osp_wfa_retry2(const uint8_t* A, int m, const uint8_t* B, int n, int diag, int max_ed,
+                   osp_aln* out, uint32_t* events, int* n_events);
 
 /* k-mer vote anchor: A is the indexed side. Returns votes (0 = none); *diag = b_pos - a_pos. */
 int osp_anchor(const uint8_t* A, int m, const uint8_t* B, int n, int* diag);

@@ -390,7 +390,7 @@ int32_t sp_align_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     } else {
         hipMemcpyAsync(d_cells, cells.data(), n_pairs * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream);
         if (events) hipMemsetAsync(d_ev, 0, n_pairs * (size_t)events_stride * 4, ctx->stream);
-        rc = sp_launch_cells(ctx, A, B, d_cells, n_pairs, d_out, d_ev, events_stride, events ? "align_trace" : "align", true);
+        rc = sp_launch_cells(ctx, A, B, d_cells, n_pairs, d_out, d_ev, events_stride, events ? "align_trace" : "align", 2);
         if (rc == SP_OK) {
             hipMemcpyAsync(out, d_out, n_pairs * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);
             if (events) hipMemcpyAsync(events, d_ev, n_pairs * (size_t)events_stride * 4, hipMemcpyDeviceToHost, ctx->stream);

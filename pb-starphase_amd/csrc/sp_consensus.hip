@@ -38,9 +38,9 @@ namespace {
 constexpr int CB = 64;          // band
 constexpr int CH = 32;          // lane of diagonal 0
 constexpr int CWAVES = 16;      // waves per workgroup
-constexpr int CW = 32;          // bases per window
+constexpr int CW = 64;          // bases per window (<= 64: one lane per window column in the control kernel)
 constexpr int CWIN = 512;       // consensus bases in front of the window kept in LDS (offset_window + slack)
-constexpr int RWORDS = 24;      // packed read words a wave keeps in LDS (384 bases around its tips)
+constexpr int RWORDS = 28;      // packed read words a wave keeps in LDS (448 bases around its tips)
 constexpr int NQ = 40;          // search nodes per problem: max_queue_size waiting + the children of one expansion + the complete one
 constexpr int MAXKIDS = 16;     // children of one expansion
 enum { F_ACTIVE = 1, F_FINISHED = 2, F_LOST = 4 };
@@ -353,10 +353,11 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
         else if (pos >= 0) v = (i == 1 && dual_in && pos >= split_at) ? Cn[(size_t)P.cap + pos] : Cn[pos];
         cwin[i][y] = v;
     }
+    __syncthreads();
     if (threadIdx.x < 2 * (CW / 16 + 2)) {
         const int i = threadIdx.x / (CW / 16 + 2), w = threadIdx.x % (CW / 16 + 2);
         uint32_t word = 0;
-        for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < n) word |= (uint32_t)(Wp->spec[i][x] & 3u) << (b << 1); }
+        for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < n) word |= (uint32_t)(cwin[i][CWIN + x] & 3u) << (b << 1); }
         spk[i][w] = word;
     }
     __syncthreads();
@@ -673,11 +674,11 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             const int j = kind == 0 ? idx % (CW + 1) : kind == 1 ? idx % CW : idx;
             const int top = mode_in == M_EXPAND ? wk.n_kids : n_in;
             const bool wanted = kind == 1 ? mode_in != M_EXPAND : j <= top;
-            // eight independent loads in flight per thread: the words were written by another kernel and come from memory
-            if (wanted) for (int b0 = sub; b0 < P.n_blocks; b0 += per * 8) {
-                unsigned long long v[8]; uint32_t en[8];
+            // sixteen independent loads in flight per thread: the words were written by another kernel and come from memory
+            if (wanted) for (int b0 = sub; b0 < P.n_blocks; b0 += per * 16) {
+                unsigned long long v[16]; uint32_t en[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int b = b0 + u * per;
                     const size_t blk = (size_t)P.first_block + (b < P.n_blocks ? b : 0);
                     v[u] = kind == 0 ? B.PV[blk * EV + idx] : kind == 1 ? B.PL[blk * EL + idx] : kind == 2 ? (unsigned long long)B.PC[blk * EC + idx] : (unsigned long long)B.PR[blk * EC + idx];
@@ -685,7 +686,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                     if (b >= P.n_blocks) { v[u] = 0; en[u] = 0; }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     if (kind < 2) { a0 += (uint32_t)(v[u] & 0xFFFF); a1 += (uint32_t)((v[u] >> 16) & 0xFFFF); a2 += (uint32_t)((v[u] >> 32) & 0xFFFF); a3 += (uint32_t)(v[u] >> 48); }
                     else a0 += (uint32_t)v[u];
                     a4 += en[u];
@@ -740,11 +741,11 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             }
             // a replay re-reads columns whose costs are on the tape already: it only brings the state (and the votes) of column T + a
             if (!wk.replay) {
-                long long c = lane <= a && lane >= 1 ? (long long)sc[lane] : 0;          // inclusive prefix sum over the lanes
+                long long c = lane < a ? (long long)sc[lane + 1] : 0;                     // lane l: push l + 1; inclusive prefix sum over the lanes
 #pragma unroll
                 for (int o = 1; o < SP_WAVE; o <<= 1) { const long long up = __shfl_up(c, o); if (lane >= o) c += up; }
                 const long long c0 = x.cost[0];
-                if (lane >= 1 && lane <= a) x.cost[lane] = c0 + c;
+                if (lane < a) x.cost[lane + 1] = c0 + c;
                 if (lane < n) { x.spec[0][lane] = wk.spec[0][lane]; x.spec[1][lane] = wk.spec[1][lane]; }
             }
             if (lane < 10) x.ev[lane / 5][lane % 5] = sv[lane / 5][a][lane % 5];

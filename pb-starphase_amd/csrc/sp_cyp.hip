@@ -5,6 +5,7 @@
 // reference's operation order (no FMA contraction, table look-ups for ln n! and ln p), so the scores are bit-identical
 // to the CPU path and the (score, i, j) winner is deterministic.
 #include "sp_internal.h"
+#include "sp_wfa.cuh"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -413,7 +414,7 @@ __global__ void cyp_build_cells_kernel(const uint32_t* __restrict__ a_idx, const
 }
 
 // all |A| x |B| placements (A = indexed query side, B = target side), result[b][a][k]
-static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, bool retry_wide, const char* prof, std::vector<sp_aln>& out) {
+static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, int retry_wide, const char* prof, std::vector<sp_aln>& out) {
     const uint64_t nA = A->n, nB = B->n, n_pairs = nA * nB, n_cells = n_pairs * (uint64_t)topk;
     out.assign(n_cells, sp_aln{});
     if (n_pairs == 0) return SP_OK;
@@ -451,7 +452,7 @@ extern "C" int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensu
     if (!ctx || !consensus || !segments || (consensus->n && !allowed) || (segments->n && (!ed || !ov || !kept))) return SP_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     std::vector<sp_aln> alns;
-    int rc = cyp_align_all(ctx, consensus, segments, 1, 0.0, true, "k4_weight_cells", alns);
+    int rc = cyp_align_all(ctx, consensus, segments, 1, 0.0, 1, "k4_weight_cells", alns);
     if (rc) return rc;
     const uint32_t C = consensus->n;
     for (uint32_t s = 0; s < segments->n; ++s) {
@@ -483,7 +484,7 @@ extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, 
     (void)hipSetDevice(ctx->device);
     *n_hits = 0;
     std::vector<sp_aln> alns;
-    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, 0.05, false, "k3_region_cells", alns);
+    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, 0.05, 0, "k3_region_cells", alns);
     if (rc) return rc;
     const uint32_t T = templates->n;
     auto penalized_type = [](int t) { return t == SP_CYP_DELETION || t == SP_CYP_REP6 || t == SP_CYP_REP7; };   // haplotyper.rs:185-191
@@ -585,36 +586,154 @@ extern "C" int32_t sp_cyp_score_alleles(sp_ctx* ctx, uint32_t n_variants, uint32
 
 // =============================================================================================
 // K9: per-variant state of typed sequences on the CYP2D6 backbone -- the role of the graph alignment in assign_haplotype
-// (src/cyp2d6/haplotyper.rs:371-468; hiphase's WFAGraph is not on disk, contract in DESIGN.md section 10 / oracle/cyp.c):
-// each sequence is placed on the backbone with traceback (anchor + cell kernels); for every variant inside the aligned part the
-// sequence window facing [p - 24, p + |ref| + 24) is compared with that backbone window carrying the reference and the alternate
-// allele.  The (window, haplotype) pairs of all sequences and variants are one batch of small global edit distances: one thread
-// per pair, DP row in LDS.
+// (src/cyp2d6/haplotyper.rs:371-468; hiphase's WFAGraph is not on disk, contract in DESIGN.md section 10 / oracle/cyp.c).
+// Each sequence is placed on the backbone with traceback (anchor + cell kernels).  The aligned backbone part with the database
+// variants inside it is a graph: reference stretches and SITES (maximal runs of variants whose reference spans overlap), a site's
+// alternatives being the subsets of its variants that do not overlap one another.  The sequence is aligned to the graph end to end
+// (unit costs) on 256 diagonals around the drift of the placement; a second pass over the mirrored graph gives the cost of the rest
+// from every site's end, so an alternative lies on an optimal path iff  cost through it + cost of the rest == optimum.  A variant is
+// 1 / 0 when every optimal alternative of its site carries / lacks it, 2 when they disagree (conflicting traversals), 3 outside the
+// aligned part.  One workgroup of two wavefronts per sequence: wave 0 runs the graph forwards, wave 1 mirrored; lane l owns diagonals
+// 4l .. 4l+3; both passes read the same pools through mirrored indices.
 // =============================================================================================
-#define K9_FLANK 24
-#define K9_MAXLEN 192          // longest window / haplotype a pair may hold (2 * 24 + alleles)
+#define K9_DIAGS 256
+#define K9_INF 30000
+#define K9_SITE_MAX 8
 
-struct K9Pair { uint32_t a_off, b_off; uint16_t a_len, b_len; };
+struct K9Job {
+    uint32_t seq_off; int32_t L;              // the aligned part of the sequence in the byte pool
+    uint32_t bb_off; int32_t G;               // the aligned part of the backbone
+    int32_t k0;                               // diagonal of lane 0, index 0
+    uint32_t site_first, n_sites;             // into site_so / site_eo / alt_first (alt_first has one more entry per job)
+    uint32_t alt_base;                        // first alternative of the job in alt_len / alt_off
+    uint32_t exit_off, entry_off;             // columns (256 u16 each) in the scratch arrays
+    int32_t opt;                              // (written by the kernel)
+};
 
-__global__ __launch_bounds__(64) void k9_pair_ed_kernel(const uint8_t* __restrict__ pool, const K9Pair* __restrict__ pairs, uint32_t n_pairs, uint16_t* __restrict__ out) {
-    __shared__ uint16_t row[64][K9_MAXLEN + 1];
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_pairs) return;
-    const K9Pair p = pairs[i];
-    const uint8_t* a = pool + p.a_off; const uint8_t* b = pool + p.b_off;
-    uint16_t* r = row[threadIdx.x];
-    for (int j = 0; j <= p.b_len; ++j) r[j] = (uint16_t)j;
-    for (int x = 1; x <= p.a_len; ++x) {
-        const uint8_t ca = a[x - 1];
-        uint16_t diag = r[0]; r[0] = (uint16_t)x;
-        for (int j = 1; j <= p.b_len; ++j) {
-            uint16_t v = (uint16_t)(diag + ((ca < 4 && ca == b[j - 1]) ? 0 : 1));
-            const uint16_t up = (uint16_t)(r[j] + 1), left = (uint16_t)(r[j - 1] + 1);
-            v = up < v ? up : v; v = left < v ? left : v;
-            diag = r[j]; r[j] = v;
+__device__ __forceinline__ void k9_step(int (&c)[4], int x, const uint8_t* S, int L, bool mirror, int off, int k0, int lane) {
+    // one base of the graph: diagonal d <-> k = k0 + d, read position i = off + k in front of the base
+    const int next0 = spw::from_upper(c[0], K9_INF);                      // the lane above's first diagonal
+    int nw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = lane * 4 + j, i = off + k0 + d;
+        int v = K9_INF;
+        if (i >= 0 && i < L && c[j] < K9_INF) { const int r = S[mirror ? L - 1 - i : i]; v = c[j] + ((r < 4 && r == x) ? 0 : 1); }
+        const int up = j < 3 ? c[j + 1] : next0;
+        if (up < K9_INF && i + 1 >= 0 && i + 1 <= L && up + 1 < v) v = up + 1;
+        nw[j] = v;
+    }
+    // read bases that face nothing run up the column: only when some diagonal can be improved from the one below it
+    const int below0 = spw::from_lower(nw[3], K9_INF);
+    bool need = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = lane * 4 + j, i = off + 1 + k0 + d, prev = j ? nw[j - 1] : below0;
+        if (d > 0 && i >= 0 && i <= L && prev + 1 < nw[j]) need = true;
+    }
+    if (__ballot(need)) {
+        // inside the lane, then across lanes (a prefix minimum of value - 4 * lane), then inside again
+#pragma unroll
+        for (int j = 1; j < 4; ++j) { const int i = off + 1 + k0 + lane * 4 + j; if (i >= 0 && i <= L && nw[j - 1] + 1 < nw[j]) nw[j] = nw[j - 1] + 1; }
+        int f = nw[3] < K9_INF ? nw[3] - 4 * lane : (1 << 20);              // what this lane offers the lanes above, in lane-0 units
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int other = __shfl_up(f, o); if (lane >= o && other < f) f = other; }
+        const int before = __shfl_up(f, 1);                               // best offer of the lanes below
+        if (lane > 0 && before < (1 << 19)) {
+            const int in = before + 4 * lane - 3;                         // value arriving at this lane's first diagonal
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int i = off + 1 + k0 + lane * 4 + j; if (i >= 0 && i <= L && in + j < nw[j]) nw[j] = in + j; }
         }
     }
-    out[i] = r[p.b_len];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = nw[j] < K9_INF ? nw[j] : K9_INF;
+}
+
+__global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict__ pool, K9Job* __restrict__ jobs, const int32_t* __restrict__ site_so,
+                                                       const int32_t* __restrict__ site_eo, const uint32_t* __restrict__ alt_first,
+                                                       const int32_t* __restrict__ alt_len, const uint32_t* __restrict__ alt_off,
+                                                       uint16_t* __restrict__ exits, uint16_t* __restrict__ entries, int32_t* __restrict__ alt_on) {
+    __shared__ int shift[2][K9_DIAGS];
+    __shared__ int opt_s;
+    K9Job& J = jobs[blockIdx.x];
+    const int lane = threadIdx.x & 63, mirror = threadIdx.x >> 6;
+    const uint8_t* S = pool + J.seq_off; const uint8_t* bb = pool + J.bb_off;
+    const int L = J.L, G = J.G, ns = (int)J.n_sites;
+    const int k0 = mirror ? (L - G) - J.k0 - (K9_DIAGS - 1) : J.k0;
+    auto gbase = [&](int g) -> int { return bb[mirror ? G - 1 - g : g]; };   // graph base at offset g of this pass
+    int c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = k0 + lane * 4 + j; c[j] = (i >= 0 && i <= L) ? i : K9_INF; }
+    int g = 0;
+    for (int t = 0; t <= ns; ++t) {
+        const int si = mirror ? ns - 1 - t : t;                               // the site this pass meets t-th
+        const int so = t < ns ? (mirror ? G - site_eo[J.site_first + si] : site_so[J.site_first + si]) : G;
+        for (; g < so; ++g) k9_step(c, gbase(g), S, L, mirror, g, k0, lane);
+        if (t == ns) break;
+        const int eo = mirror ? G - site_so[J.site_first + si] : site_eo[J.site_first + si];
+        if (mirror) {                                                         // the mirrored pass leaves the column in FRONT of every site
+            uint16_t* out = entries + ((size_t)J.entry_off + si) * K9_DIAGS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)c[j];
+        }
+        int e0[4], acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { e0[j] = c[j]; acc[j] = K9_INF; }
+        const int lr = eo - so;
+        const uint32_t a_lo = alt_first[J.site_first + blockIdx.x + si], a_hi = alt_first[J.site_first + blockIdx.x + si + 1];
+        for (uint32_t a = a_lo; a < a_hi; ++a) {
+            int w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = e0[j];
+            const int len = alt_len[a]; const uint8_t* as = pool + alt_off[a];
+            for (int x = 0; x < len; ++x) k9_step(w, as[mirror ? len - 1 - x : x], S, L, mirror, so + x, k0, lane);
+            // the alternative is len bases where the reference has lr: its diagonals shift by len - lr at the site's end
+            const int delta = len - lr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) shift[mirror][lane * 4 + j] = w[j];
+            spw::wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int src = lane * 4 + j - delta; w[j] = (src >= 0 && src < K9_DIAGS) ? shift[mirror][src] : K9_INF; }
+            spw::wave_lds_sync();
+            if (!mirror) {
+                uint16_t* out = exits + ((size_t)J.exit_off + (a - J.alt_base)) * K9_DIAGS;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)w[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = w[j] < acc[j] ? w[j] : acc[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = acc[j];
+        g = eo;
+    }
+    if (!mirror) {
+        const int kL = L - G - k0;
+        int v = K9_INF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (lane * 4 + j == kL) v = c[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(v, o); v = other < v ? other : v; }
+        if (lane == 0) { opt_s = v; J.opt = v; }
+    }
+    __threadfence();
+    __syncthreads();
+    // which alternatives lie on an optimal path: cost through it + cost of the rest from the site's end == optimum
+    const int opt = opt_s;
+    if (opt >= K9_INF) return;
+    const int wave = threadIdx.x >> 6;
+    for (int si = wave; si < ns; si += 2) {
+        const uint16_t* back = entries + ((size_t)J.entry_off + si) * K9_DIAGS;
+        const uint32_t a_lo = alt_first[J.site_first + blockIdx.x + si], a_hi = alt_first[J.site_first + blockIdx.x + si + 1];
+        for (uint32_t a = a_lo; a < a_hi; ++a) {
+            const uint16_t* ex = exits + ((size_t)J.exit_off + (a - J.alt_base)) * K9_DIAGS;
+            bool on = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int d = lane * 4 + j; const int e = ex[d], bk = back[K9_DIAGS - 1 - d]; if (e < K9_INF && bk < K9_INF && e + bk == opt) on = true; }
+            const bool any = __ballot(on) != 0;
+            if (lane == 0) alt_on[a] = any ? 1 : 0;
+        }
+    }
 }
 
 extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, const char* backbone, uint32_t backbone_len, uint32_t n_variants,
@@ -627,79 +746,119 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
     if (states) std::memset(states, 3, (size_t)S * n_variants);
     if (S == 0) return SP_OK;
     // place every sequence on the backbone (sequence = indexed / streamed side A, backbone = window side B), with traceback
-    sp_seqset* bb = nullptr;
+    sp_seqset* bbset = nullptr;
     const uint64_t boff[2] = { 0, backbone_len };
-    int32_t rc = sp_seqset_upload(ctx, backbone, boff, 1, &bb);
+    int32_t rc = sp_seqset_upload(ctx, backbone, boff, 1, &bbset);
     if (rc != SP_OK) return rc;
     std::vector<uint32_t> ai(S), bi(S, 0); for (uint32_t i = 0; i < S; ++i) ai[i] = i;
     std::vector<int32_t> diag(S), votes(S);
-    rc = sp_anchor_batch(ctx, seqs, bb, ai.data(), bi.data(), S, diag.data(), votes.data());
+    rc = sp_anchor_batch(ctx, seqs, bbset, ai.data(), bi.data(), S, diag.data(), votes.data());
     std::vector<sp_pair> pairs; std::vector<uint32_t> who;
     if (rc == SP_OK) for (uint32_t i = 0; i < S; ++i) if (votes[i] >= CYP_MIN_VOTES) { pairs.push_back(sp_pair{ i, 0, diag[i], SP_MAX_ED }); who.push_back(i); }
     std::vector<sp_aln> alns(pairs.size()); std::vector<uint32_t> events(pairs.size() * (size_t)SP_MAX_ED);
-    if (rc == SP_OK && !pairs.empty()) rc = sp_align_batch(ctx, seqs, bb, pairs.data(), pairs.size(), alns.data(), events.data(), SP_MAX_ED);
-    sp_seqset_free(bb);
+    if (rc == SP_OK && !pairs.empty()) rc = sp_align_batch(ctx, seqs, bbset, pairs.data(), pairs.size(), alns.data(), events.data(), SP_MAX_ED);
+    sp_seqset_free(bbset);
     if (rc != SP_OK) return rc;
     if (alns_out) { std::memset(alns_out, 0, sizeof(sp_aln) * S); for (size_t x = 0; x < who.size(); ++x) alns_out[who[x]] = alns[x]; }
     if (n_variants == 0) return SP_OK;
     auto code = [](char c) -> uint8_t { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; };
     std::vector<uint8_t> bcode(backbone_len);
     for (uint32_t i = 0; i < backbone_len; ++i) bcode[i] = code(backbone[i]);
-    // the pairs: per (sequence, variant) the sequence window against the reference haplotype and against the alternate haplotype
+    std::vector<int> rlen(n_variants);
+    for (uint32_t v = 0; v < n_variants; ++v) rlen[v] = (int)std::strlen(var_ref[v]);
+    // the graphs: per aligned sequence its sites and alternatives (oracle/cyp.c states the same construction)
     const size_t plane_words = (size_t)seqs->h_word_off[seqs->n] + 4;             // the host copy exists: the anchor step indexed the set
-    std::vector<uint8_t> pool; std::vector<K9Pair> kp; std::vector<std::pair<uint32_t, uint32_t>> owner;
+    std::vector<uint8_t> pool(bcode);                                               // backbone first, then sequences and alternatives
+    std::vector<K9Job> jobs; std::vector<int32_t> site_so, site_eo; std::vector<uint32_t> alt_first; std::vector<int32_t> alt_len; std::vector<uint32_t> alt_off;
+    struct SiteVars { int nv; int var[K9_SITE_MAX]; }; std::vector<SiteVars> site_vars; std::vector<int> alt_mask; std::vector<uint32_t> job_seq;
+    size_t n_exit = 0, n_entry = 0;
     for (size_t x = 0; x < who.size(); ++x) {
         const sp_aln& al = alns[x];
         if (!al.ok) continue;
         const uint32_t sidx = who[x];
         const uint32_t* w = seqs->h_words.data() + seqs->h_word_off[sidx];
         const uint32_t* np = seqs->has_n ? seqs->h_words.data() + plane_words + seqs->h_word_off[sidx] : nullptr;
-        const int slen = seqs->h_len[sidx];
+        K9Job J; std::memset(&J, 0, sizeof J);
+        J.seq_off = (uint32_t)pool.size(); J.L = al.a_end - al.a_start;
+        for (int h = al.a_start; h < al.a_end; ++h) { const uint32_t sh = (uint32_t)(h & 15) << 1; pool.push_back((np && ((np[h >> 4] >> sh) & 1u)) ? 4 : (uint8_t)((w[h >> 4] >> sh) & 3u)); }
+        const int gs = al.b_start, ge = al.b_end;
+        J.bb_off = (uint32_t)gs; J.G = ge - gs;
+        int drift = 0, dmin = 0, dmax = 0;
         const uint32_t* ev = events.data() + x * (size_t)SP_MAX_ED;
-        for (uint32_t v = 0; v < n_variants; ++v) {
-            const int p = var_pos[v], rl = (int)std::strlen(var_ref[v]), alen = (int)std::strlen(var_alt[v]);
-            if (p < al.b_start || p + rl > al.b_end) continue;
-            const int ws = std::max(p - K9_FLANK, al.b_start), we = std::min(p + rl + K9_FLANK, al.b_end);
-            int sa = al.a_start + (ws - al.b_start), ea = al.a_start + (we - al.b_start);
-            for (int e = 0; e < al.nm; ++e) {
-                const uint32_t type = ev[e] >> 30; const int bp = (int)(ev[e] & 0x3FFFFFFFu);
-                if (type == SP_EV_D) { sa -= bp < ws; ea -= bp < we; }
-                else if (type == SP_EV_I) { sa += bp < ws; ea += bp < we; }
+        for (int e = 0; e < al.nm; ++e) { const uint32_t type = ev[e] >> 30; if (type == SP_EV_I) ++drift; else if (type == SP_EV_D) --drift; dmin = std::min(dmin, drift); dmax = std::max(dmax, drift); }
+        J.k0 = (dmin + dmax) / 2 - K9_DIAGS / 2;
+        std::vector<int> order;
+        for (uint32_t v = 0; v < n_variants; ++v) if (var_pos[v] >= gs && var_pos[v] + rlen[v] <= ge) order.push_back((int)v);
+        std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return var_pos[p] < var_pos[q]; });     // (ties keep the variant order)
+        J.site_first = (uint32_t)site_so.size(); J.alt_base = (uint32_t)alt_len.size();
+        J.exit_off = (uint32_t)n_exit; J.entry_off = (uint32_t)n_entry;
+        uint32_t ns = 0;
+        for (size_t a = 0; a < order.size();) {
+            int s0 = var_pos[order[a]], e0 = s0 + rlen[order[a]]; SiteVars sv; sv.nv = 0;
+            while (a < order.size() && var_pos[order[a]] < e0) {
+                const int end = var_pos[order[a]] + rlen[order[a]];
+                if (sv.nv < K9_SITE_MAX) { e0 = std::max(e0, end); sv.var[sv.nv++] = order[a]; }              // (a ninth overlapping variant stays undecided)
+                ++a;
             }
-            sa = std::max(sa, 0); ea = std::min(ea, slen); ea = std::max(ea, sa);
-            const int lr = we - ws, la = lr - rl + alen, lw = ea - sa;
-            if (lr > K9_MAXLEN || la > K9_MAXLEN || lw > K9_MAXLEN) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_cyp_variant_states: variant allele longer than the window buffer");
-            const uint32_t o_w = (uint32_t)pool.size();
-            for (int h = sa; h < ea; ++h) { const uint32_t sh = (uint32_t)(h & 15) << 1; pool.push_back((np && ((np[h >> 4] >> sh) & 1u)) ? 4 : (uint8_t)((w[h >> 4] >> sh) & 3u)); }
-            const uint32_t o_r = (uint32_t)pool.size();
-            pool.insert(pool.end(), bcode.begin() + ws, bcode.begin() + we);
-            const uint32_t o_a = (uint32_t)pool.size();
-            pool.insert(pool.end(), bcode.begin() + ws, bcode.begin() + p);
-            for (int i = 0; i < alen; ++i) pool.push_back(code(var_alt[v][i]));
-            pool.insert(pool.end(), bcode.begin() + p + rl, bcode.begin() + we);
-            kp.push_back(K9Pair{ o_w, o_r, (uint16_t)lw, (uint16_t)lr });
-            kp.push_back(K9Pair{ o_w, o_a, (uint16_t)lw, (uint16_t)la });
-            owner.push_back({ sidx, v });
+            site_so.push_back(s0 - gs); site_eo.push_back(e0 - gs); site_vars.push_back(sv);
+            alt_first.push_back((uint32_t)alt_len.size());
+            for (int mask = 0; mask < (1 << sv.nv); ++mask) {
+                bool ok = true; int last_end = -1;
+                for (int y = 0; y < sv.nv && ok; ++y) if (mask >> y & 1) { const int v = sv.var[y]; if (var_pos[v] < last_end) ok = false; last_end = var_pos[v] + rlen[v]; }
+                if (!ok) continue;
+                alt_off.push_back((uint32_t)pool.size());
+                int b = s0, len = 0;
+                for (int y = 0; y < sv.nv; ++y) if (mask >> y & 1) {
+                    const int v = sv.var[y];
+                    for (; b < var_pos[v]; ++b, ++len) pool.push_back(bcode[b]);
+                    for (const char* q = var_alt[v]; *q; ++q, ++len) pool.push_back(code(*q));
+                    b = var_pos[v] + rlen[v];
+                }
+                for (; b < e0; ++b, ++len) pool.push_back(bcode[b]);
+                alt_len.push_back(len); alt_mask.push_back(mask);
+            }
+            ++ns;
         }
+        alt_first.push_back((uint32_t)alt_len.size());                              // one closing entry per job (the kernel indexes site_first + job + site)
+        J.n_sites = ns;
+        n_exit += alt_len.size() - J.alt_base; n_entry += ns;
+        jobs.push_back(J); job_seq.push_back(sidx);
     }
-    if (kp.empty()) return SP_OK;
-    uint8_t* d_pool = (uint8_t*)sp_pool(ctx, "k9_pool", pool.size());
-    K9Pair* d_pairs = (K9Pair*)sp_pool(ctx, "k9_pairs", kp.size() * sizeof(K9Pair));
-    uint16_t* d_out = (uint16_t*)sp_pool(ctx, "k9_out", kp.size() * sizeof(uint16_t));
-    if (!d_pool || !d_pairs || !d_out) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "k9 buffers");
-    std::vector<uint16_t> ed(kp.size());
+    if (jobs.empty()) return SP_OK;
+    uint8_t* d_pool = (uint8_t*)sp_pool(ctx, "k9_pool", pool.size() + 16);
+    K9Job* d_jobs = (K9Job*)sp_pool(ctx, "k9_jobs", jobs.size() * sizeof(K9Job));
+    int32_t* d_so = (int32_t*)sp_pool(ctx, "k9_so", (site_so.size() + 1) * 4); int32_t* d_eo = (int32_t*)sp_pool(ctx, "k9_eo", (site_eo.size() + 1) * 4);
+    uint32_t* d_af = (uint32_t*)sp_pool(ctx, "k9_af", (alt_first.size() + 1) * 4);
+    int32_t* d_al = (int32_t*)sp_pool(ctx, "k9_al", (alt_len.size() + 1) * 4); uint32_t* d_ao = (uint32_t*)sp_pool(ctx, "k9_ao", (alt_off.size() + 1) * 4);
+    uint16_t* d_exit = (uint16_t*)sp_pool(ctx, "k9_exit", (n_exit + 1) * K9_DIAGS * 2); uint16_t* d_entry = (uint16_t*)sp_pool(ctx, "k9_entry", (n_entry + 1) * K9_DIAGS * 2);
+    int32_t* d_on = (int32_t*)sp_pool(ctx, "k9_on", (alt_len.size() + 1) * 4);
+    if (!d_pool || !d_jobs || !d_so || !d_eo || !d_af || !d_al || !d_ao || !d_exit || !d_entry || !d_on) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "k9 buffers");
     (void)hipMemcpyAsync(d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice, ctx->stream);
-    (void)hipMemcpyAsync(d_pairs, kp.data(), kp.size() * sizeof(K9Pair), hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(K9Job), hipMemcpyHostToDevice, ctx->stream);
+    if (!site_so.empty()) { (void)hipMemcpyAsync(d_so, site_so.data(), site_so.size() * 4, hipMemcpyHostToDevice, ctx->stream); (void)hipMemcpyAsync(d_eo, site_eo.data(), site_eo.size() * 4, hipMemcpyHostToDevice, ctx->stream); }
+    (void)hipMemcpyAsync(d_af, alt_first.data(), alt_first.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (!alt_len.empty()) { (void)hipMemcpyAsync(d_al, alt_len.data(), alt_len.size() * 4, hipMemcpyHostToDevice, ctx->stream); (void)hipMemcpyAsync(d_ao, alt_off.data(), alt_off.size() * 4, hipMemcpyHostToDevice, ctx->stream); }
+    (void)hipMemsetAsync(d_on, 0, (alt_len.size() + 1) * 4, ctx->stream);
     {
-        ProfScope ps(ctx, "k9_pair_ed", kp.size());
-        hipLaunchKernelGGL(k9_pair_ed_kernel, dim3((unsigned)((kp.size() + 63) / 64)), dim3(64), 0, ctx->stream, d_pool, d_pairs, (uint32_t)kp.size(), d_out);
+        ProfScope ps(ctx, "k9_graph", jobs.size());
+        hipLaunchKernelGGL(k9_graph_kernel, dim3((unsigned)jobs.size()), dim3(128), 0, ctx->stream, d_pool, d_jobs, d_so, d_eo, d_af, d_al, d_ao, d_exit, d_entry, d_on);
     }
-    (void)hipMemcpyAsync(ed.data(), d_out, kp.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+    std::vector<int32_t> on(alt_len.size() + 1);
+    (void)hipMemcpyAsync(on.data(), d_on, (alt_len.size() + 1) * 4, hipMemcpyDeviceToHost, ctx->stream);
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("k9: ") + hipGetErrorString(e));
-    for (size_t x = 0; x < owner.size(); ++x) {
-        const uint16_t dr = ed[2 * x], da = ed[2 * x + 1];
-        states[(size_t)owner[x].first * n_variants + owner[x].second] = dr < da ? 0 : (da < dr ? 1 : 2);
+    // a variant is 1 / 0 when every optimal alternative of its site carries / lacks it, 2 when they disagree
+    for (size_t jx = 0; jx < jobs.size(); ++jx) {
+        const K9Job& J = jobs[jx];
+        for (uint32_t si = 0; si < J.n_sites; ++si) {
+            const SiteVars& sv = site_vars[J.site_first + si];
+            bool seen1[K9_SITE_MAX] = {}, seen0[K9_SITE_MAX] = {};
+            for (uint32_t a = alt_first[J.site_first + jx + si]; a < alt_first[J.site_first + jx + si + 1]; ++a) {
+                if (!on[a]) continue;
+                for (int y = 0; y < sv.nv; ++y) { if (alt_mask[a] >> y & 1) seen1[y] = true; else seen0[y] = true; }
+            }
+            for (int y = 0; y < sv.nv; ++y) states[(size_t)job_seq[jx] * n_variants + sv.var[y]] = (seen1[y] && seen0[y]) ? 2 : seen1[y] ? 1 : seen0[y] ? 0 : 3;
+        }
     }
     return SP_OK;
 }

@@ -197,14 +197,15 @@ __device__ __forceinline__ int wide_extend(const uint32_t* aw, const uint32_t* a
 template <bool TRACE>
 __global__ __launch_bounds__(256) void sp_cells_wide_kernel(SeqSetView A, SeqSetView B, const CellDesc* __restrict__ cells, uint64_t n_cells,
                                                             sp_aln* __restrict__ out, uint32_t* __restrict__ events, uint32_t ev_stride,
-                                                            uint16_t* __restrict__ hist_pool, int hist_rows) {
+                                                            uint16_t* __restrict__ hist_pool, int hist_rows, int mode) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave, nw = (uint64_t)gridDim.x * 4;
     uint16_t* hist = TRACE ? hist_pool + gw * (uint64_t)hist_rows * SP_WIDE : nullptr;
     for (uint64_t c = gw; c < n_cells; c += nw) {
         const CellDesc cd = cells[c];
         if (cd.diag == SP_NO_DIAG) continue;
-        if (out[c].ok) continue;                                            // the 64-diagonal run found it
+        const sp_aln narrow = out[c];
+        if (narrow.ok && (mode < 2 || narrow.nm <= SP_BAND / 2)) continue;     // the 64-diagonal run found it (cheaply enough)
         const uint32_t* aw = A.words + A.word_off[cd.a]; const uint32_t* an = A.nplane ? A.nplane + A.word_off[cd.a] : nullptr;
         const uint32_t* bw = B.words + B.word_off[cd.b]; const uint32_t* bn = B.nplane ? B.nplane + B.word_off[cd.b] : nullptr;
         const int m = A.len[cd.a], blen = B.len[cd.b];
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(256) void sp_cells_wide_kernel(SeqSetView A, SeqSet
                 if (TRACE) hist[(size_t)s * SP_WIDE + D] = (uint16_t)(H[j] >= 0 ? H[j] : 0xFFFF);
             }
         }
-        if (end_D < 0) continue;                                            // still nothing: the cell stays lost
+        if (end_D < 0) continue;                                            // still nothing: the cell stays as it was
+        if (narrow.ok && s >= narrow.nm) continue;                          // the narrow alignment is as cheap: it stands
         // the end point and the origin diagonal live in the lane that owns end_D
         const int el = end_D / SP_WPL, ej = end_D % SP_WPL;
         int he = 0, oe = 0;
@@ -408,7 +410,7 @@ int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
 #endif
 int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     const CellDesc* d_cells, uint64_t n_cells,
-                    sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, bool retry_wide) {
+                    sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, int retry_wide) {
     if (n_cells == 0) return SP_OK;
     const bool trace = d_events != nullptr;
     const bool hasn = A->has_n || B->has_n;
@@ -442,8 +444,8 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
             whist = (uint16_t*)sp_pool(ctx, "wide_hist", wblocks * 4 * (size_t)hist_rows * SP_WIDE * sizeof(uint16_t));
             if (!whist) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "align: wide traceback scratch");
         }
-        if (trace) hipLaunchKernelGGL((sp_cells_wide_kernel<true>), dim3((unsigned)wblocks), dim3(256), 0, ctx->stream, av, bv, d_cells, n_cells, d_out, d_events, events_stride, whist, hist_rows);
-        else hipLaunchKernelGGL((sp_cells_wide_kernel<false>), dim3((unsigned)wblocks), dim3(256), 0, ctx->stream, av, bv, d_cells, n_cells, d_out, d_events, events_stride, whist, hist_rows);
+        if (trace) hipLaunchKernelGGL((sp_cells_wide_kernel<true>), dim3((unsigned)wblocks), dim3(256), 0, ctx->stream, av, bv, d_cells, n_cells, d_out, d_events, events_stride, whist, hist_rows, retry_wide);
+        else hipLaunchKernelGGL((sp_cells_wide_kernel<false>), dim3((unsigned)wblocks), dim3(256), 0, ctx->stream, av, bv, d_cells, n_cells, d_out, d_events, events_stride, whist, hist_rows, retry_wide);
         SP_HIP_CHECK(ctx, hipGetLastError());
     }
     return SP_OK;

@@ -729,7 +729,7 @@ int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) 
         }
         CellDesc* d_cells = dev_copy(cells); sp_aln* d_alns = nullptr;
         (void)hipMalloc(&d_alns, std::max<size_t>(1, n) * sizeof(sp_aln));
-        rc = sp_launch_cells(ctx, db->dna_fwd, db->ref_fwd, d_cells, n, d_alns, nullptr, 0, "db_allele_ref", true);
+        rc = sp_launch_cells(ctx, db->dna_fwd, db->ref_fwd, d_cells, n, d_alns, nullptr, 0, "db_allele_ref", 2);
         if (rc == SP_OK) {
             (void)hipStreamSynchronize(ctx->stream);
             std::vector<sp_aln> alns(n);
@@ -994,7 +994,7 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
         rc = sp_launch_anchor(ctx, cons, aset, d_c, d_idx, T, d_diag, d_votes);
         if (rc != SP_OK) break;
         hipLaunchKernelGGL(k2_build_cells_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_idx, T, d_c, d_diag, d_votes, aset->d_len, d_cells);
-        rc = sp_launch_cells(ctx, aset, cons, d_cells, T, d_alns + (size_t)L * T, d_ev + (size_t)L * T * stride, stride, L == 0 ? "k2_cells_cdna" : "k2_cells_dna", true);
+        rc = sp_launch_cells(ctx, aset, cons, d_cells, T, d_alns + (size_t)L * T, d_ev + (size_t)L * T * stride, stride, L == 0 ? "k2_cells_cdna" : "k2_cells_dna", 1);
         if (rc != SP_OK) break;
         hipLaunchKernelGGL(k2_levels_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_alns + (size_t)L * T, T, d_lv + (size_t)L * T);
     }
@@ -1091,7 +1091,7 @@ static int32_t type_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items, co
     (void)hipMemcpyAsync(d_cell, cells.data(), (size_t)n * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemsetAsync(d_ev, 0, (size_t)n * K2_MAX_ED * 4, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
-    rc = sp_launch_cells(ctx, cons, db->ref_fwd, d_cell, n, d_aln, d_ev, K2_MAX_ED, "type_consensus_ref", true);
+    rc = sp_launch_cells(ctx, cons, db->ref_fwd, d_cell, n, d_aln, d_ev, K2_MAX_ED, "type_consensus_ref", 2);
     if (rc != SP_OK) return rc;
     std::vector<sp_aln> alns(n); std::vector<uint32_t> evs((size_t)n * K2_MAX_ED);
     (void)hipMemcpyAsync(alns.data(), d_aln, (size_t)n * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);

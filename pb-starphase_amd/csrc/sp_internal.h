@@ -91,7 +91,7 @@ int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      int32_t* d_diag, int32_t* d_votes, int topk = 1);
 int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     const CellDesc* d_cells, uint64_t n_cells,
-                    sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, bool retry_wide = false);
+                    sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, int retry_wide = 0);   // 0 never, 1 lost cells, 2 lost cells and cells with > 32 edits (few-cell callers)
 
 int sp_launch_pack(sp_ctx* ctx, const char* d_ascii, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
                    uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag);

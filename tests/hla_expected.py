@@ -59,7 +59,7 @@ class K1Tables:
             m = None
             if self.off[a] is not None:
                 g = int(self.fx.gene_of[a])
-                al, _ = self.oracle.wfa(self.fwd_e[a], self.refs[g], -self.off[a], 511, events=False, retry=True)
+                al, _ = self.oracle.wfa(self.fwd_e[a], self.refs[g], -self.off[a], 511, events=False, retry=2)
                 if al.ok and score_value(al.a_len, al.nm, al.a_len - (al.a_end - al.a_start)) < 1.0:
                     m = (al.a_start, al.b_start)
             self._am[a] = m

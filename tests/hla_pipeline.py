@@ -24,7 +24,7 @@ def type_consensus(oracle, fx, g, cons, synth):
     d, v = oracle.anchor(fx.gene_ref[g], cons)
     if v < 2:
         return -1
-    al, ev = oracle.wfa(cons, ref, -d - fx.buffer, retry=True)
+    al, ev = oracle.wfa(cons, ref, -d - fx.buffer, retry=2)
     if not al.ok or hx.score_value(al.a_len, al.nm, al.a_len - (al.a_end - al.a_start)) >= 1.0:
         return -1
     cigar = oracle.cigar(al, ev)

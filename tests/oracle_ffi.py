@@ -87,13 +87,14 @@ class Oracle:
         return a[:len(s)] if len(s) else a[:0]
 
     def wfa(self, a, b, diag, max_ed=255, events=True, retry=False):
-        """retry: the rule of the library's generic cell launcher (a cell that finds nothing on 64 diagonals runs again on 256)"""
+        """retry: the rules of the library's generic cell launcher -- True / 1: a cell that finds nothing on 64 diagonals runs again on
+        256; 2: also when it needed more than 32 edits, the wide result is kept when it has fewer (sp_align_batch, placements)"""
         A = a if isinstance(a, np.ndarray) else self.encode(a)
         B = b if isinstance(b, np.ndarray) else self.encode(b)
         al = Aln()
         ev = np.zeros(max_ed + 1, np.uint32)
         ne = C.c_int32(0)
-        fn = self.L.osp_wfa_retry if retry else self.L.osp_wfa
+        fn = self.L.osp_wfa_retry2 if retry == 2 else self.L.osp_wfa_retry if retry else self.L.osp_wfa
         fn.restype = C.c_int32
         fn.argtypes = self.L.osp_wfa.argtypes
         fn(A.ctypes.data_as(C.c_void_p), len(A), B.ctypes.data_as(C.c_void_p), len(B), int(diag), int(max_ed),

@@ -218,7 +218,7 @@ def test_type_consensus(oracle, pkg, gpu_ctx, small):
             ref = fx.gene_ref[g][fx.buffer:len(fx.gene_ref[g]) - fx.buffer]
             d, v = oracle.anchor(fx.gene_ref[g], cons)                     # cons_pos - ref_pos (buffered reference)
             assert v >= 2
-            al, ev = oracle.wfa(cons, ref, -d - fx.buffer)
+            al, ev = oracle.wfa(cons, ref, -d - fx.buffer, retry=2)
             assert al.ok
             cigar = oracle.cigar(al, ev)
             bam = [(l, {7: 0, 8: 0, 1: 1, 2: 2}[op]) for l, op in cigar]
