@@ -73,3 +73,37 @@ def test_library_equals_oracle_pipeline(oracle, gpu_ctx, real, name):
     got = (call.hap1.decode(), call.hap2.decode(), call.core1.decode(), call.core2.decode())
     assert got == (exp["hap1"], exp["hap2"], exp["core1"], exp["core2"])
     assert sorted(got[:2]) == sorted(expected)
+
+
+def test_variant_states_on_the_real_table(oracle, gpu_ctx, real):
+    """K9 on the real 393-variant table: variants of CYP2D6 sit 16 bases apart on average and many overlap or touch (SNV + indel pairs, indels in
+    runs), so they are decided jointly through the variant graph.  Library == oracle/cyp.c for every star allele tried; on an error-free
+    sequence every state equals the allele's definition unless the graph itself is ambiguous there (state 2: two alternatives spell the
+    same bases)."""
+    import oracle_ffi as of
+    locus, db, odb, _sc = real
+    names, rows = db.alleles()
+    vs = odb.variants
+    pos, refs, alts = [v[0] for v in vs], [v[1] for v in vs], [v[2] for v in vs]
+    # star alleles that carry variants closer than 24 bases to one another, plus a spread of the others
+    def close_pairs(row):
+        on = [pos[i] for i in np.flatnonzero(row)]
+        return sum(1 for a, b in zip(on, on[1:]) if b - a < 24)
+    ranked = sorted(range(len(names)), key=lambda a: -close_pairs(rows[a]))
+    chosen = ranked[:12] + ranked[40::60]
+    assert close_pairs(rows[chosen[0]]) >= 2
+    seqs = [locus.star_allele(names[a]) for a in chosen]
+    states, alns = gpu_ctx.cyp_variant_states(gpu_ctx.upload(seqs), odb.backbone, pos, refs, alts)
+    n_amb = 0
+    for x, a in enumerate(chosen):
+        e_states, e_aln = of.oracle_variant_states(oracle, seqs[x], odb.backbone, pos, refs, alts)
+        assert states[x].tolist() == e_states.tolist(), (names[a], np.flatnonzero(states[x] != e_states)[:8])
+        assert alns[x]["ok"]
+        decided = states[x] != 2
+        assert (states[x][decided] == rows[a][decided]).all(), (names[a], np.flatnonzero((states[x] != rows[a]) & decided)[:8])
+        n_amb += int((~decided).sum())
+    assert n_amb < 4 * len(chosen)
+    # the typing on top of it (K7): every one of these sequences is typed as its own allele or one that is indistinguishable from it
+    bv, ba, tie = gpu_ctx.cyp_score_alleles(rows, odb.is_vi, states)
+    for x, a in enumerate(chosen):
+        assert tie[x][a] == 1, names[a]
