@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9    # 256 CU x 4 SIMD x one wave-instruction per cycle at 2.4 GHz (MI355X_MICROARCH.md); checked against sp_microbench
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2    # 256 CU x 4 SIMD-32 x one wave-instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md); sp_microbench measures it
 
 
 def spawn_ranks(n, argv):

@@ -87,6 +87,28 @@ __device__ __forceinline__ void k5_pair_from_id(uint64_t pid, int P, int& i, int
     i = (int)ii; j = (int)(pid - off(ii)) + i;
 }
 
+// per (chain, read): the best window total of the read's weight rows along the chain and which starts reach it (bit s of the mask).
+// These do not depend on the partner chain, so the pair kernel below looks them up instead of sliding every read along both chains
+// of every pair (containment_score, chaining.rs:683-731).  Tables are read-major ([read][chain]): a wave of consecutive pairs reads them
+// coalesced.
+__global__ __launch_bounds__(256) void k5_chain_read_kernel(int P, int R, int H, int maxlen, const uint8_t* __restrict__ chains, const int32_t* __restrict__ chain_len,
+                                                            const int32_t* __restrict__ read_w_off, const uint32_t* __restrict__ w_ed,
+                                                            unsigned long long* __restrict__ tab_best, unsigned long long* __restrict__ tab_mask) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)P * R) return;
+    const int c = (int)(id % P), r = (int)(id / P);
+    const uint8_t* o = chains + (size_t)c * maxlen; const int on = chain_len[c];
+    const int row0 = read_w_off[r], wl = read_w_off[r + 1] - row0;
+    const uint32_t* ed = w_ed + (size_t)row0 * H;
+    unsigned long long best = ~0ull, mask = 0;
+    for (int s = 0; s + wl <= on; ++s) {
+        unsigned long long tot = 0;
+        for (int x = 0; x < wl; ++x) tot += ed[(size_t)x * H + o[s + x]];
+        if (tot < best) { best = tot; mask = 1ull << s; } else if (tot == best) mask |= 1ull << s;
+    }
+    tab_best[id] = best; tab_mask[id] = mask;
+}
+
 // one thread = one unordered pair (i <= j)
 __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
                                                       const uint8_t* __restrict__ chains, const int32_t* __restrict__ chain_len,   // [P][maxlen]
@@ -94,6 +116,7 @@ __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
                                                       const uint8_t* __restrict__ chain_has_del,
                                                       const uint8_t* __restrict__ hap_lasso, const uint8_t* __restrict__ hap_norm,
                                                       const int32_t* __restrict__ read_w_off, const uint32_t* __restrict__ w_ed, const double* __restrict__ w_ov,
+                                                      const unsigned long long* __restrict__ tab_best, const unsigned long long* __restrict__ tab_mask,
                                                       const uint64_t* __restrict__ read_optimum, const uint64_t* __restrict__ read_worst,
                                                       const double* __restrict__ ln_fact, int ln_fact_n,
                                                       const double* __restrict__ ln_p, int ln_p_stride,      // ln_p[c * stride + total]
@@ -104,6 +127,7 @@ __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
     const uint64_t pid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int H = c.H;
     bool have = false;
+    int scored = 0;
     double primary = 0.0, comp_lned = 0.0, comp_mn = 0.0, comp_exp = 0.0, comp_unexp = 0.0, comp_inf = 0.0;
     unsigned long long ed_out = 0;
     if (pid < c.n_pairs) {
@@ -125,34 +149,31 @@ __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
         // exact pruning: a pair whose cheap partial cost already exceeds the best complete score cannot win (chaining.rs:457-464)
         const double gb = __longlong_as_double((long long)__hip_atomic_load(global_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (!(partial_cost > gb)) {
-            atomicAdd(n_scored, 1ull);
+            scored = 1;
             double hw[K5_MAXH];
             for (int h = 0; h < H; ++h) hw[h] = 0.0;
             unsigned long long read_combined_ed = 0;
             for (int r = 0; r < c.R; ++r) {
                 const int row0 = read_w_off[r], wl = read_w_off[r + 1] - row0;
-                const uint32_t* ed = w_ed + (size_t)row0 * H; const double* ov = w_ov + (size_t)row0 * H;
+                const double* ov = w_ov + (size_t)row0 * H;
+                // containment_score (chaining.rs:683-731): best window total over both chains, ties kept in visiting order (chain i's windows,
+                // then chain j's) -- from the per-chain tables
                 unsigned long long best_score = 2ull * read_worst[r];
                 int n_best = 0;
-                // containment_score (chaining.rs:683-731): best window total over both chains, ties kept in visiting order
-                for (int which = 0; which < 2; ++which) {
-                    const uint8_t* o = which ? cj : ci; const int on = which ? nj : ni;
-                    for (int s = 0; s + wl <= on; ++s) {
-                        unsigned long long tot = 0;
-                        for (int x = 0; x < wl; ++x) tot += ed[(size_t)x * H + o[s + x]];
-                        if (tot < best_score) { best_score = tot; n_best = 1; } else if (tot == best_score) ++n_best;
-                    }
-                }
+                const unsigned long long bi = tab_best[(size_t)r * c.P + i], bj = tab_best[(size_t)r * c.P + j];
+                const unsigned long long mi = tab_mask[(size_t)r * c.P + i], mj = tab_mask[(size_t)r * c.P + j];
+                if (bi < best_score) { best_score = bi; n_best = __popcll(mi); } else if (bi == best_score) n_best += __popcll(mi);
+                if (bj < best_score) { best_score = bj; n_best = __popcll(mj); } else if (bj == best_score) n_best += __popcll(mj);
                 const unsigned long long sc = best_score - read_optimum[r];
                 const unsigned long long sum = read_combined_ed + sc;
                 read_combined_ed = sum < read_combined_ed ? 0xFFFFFFFFFFFFFFFFull : sum;        // saturating_add
                 const double split_frac = 1.0 / (double)n_best;
                 for (int which = 0; which < 2; ++which) {
-                    const uint8_t* o = which ? cj : ci; const int on = which ? nj : ni;
-                    for (int s = 0; s + wl <= on; ++s) {
-                        unsigned long long tot = 0;
-                        for (int x = 0; x < wl; ++x) tot += ed[(size_t)x * H + o[s + x]];
-                        if (tot == best_score) for (int x = 0; x < wl; ++x) { const int con = o[s + x]; hw[con] += split_frac * ov[(size_t)x * H + con]; }
+                    const uint8_t* o = which ? cj : ci;
+                    unsigned long long m = (which ? bj : bi) == best_score ? (which ? mj : mi) : 0ull;
+                    while (m) {
+                        const int s = __builtin_ctzll(m); m &= m - 1;
+                        for (int x = 0; x < wl; ++x) { const int con = o[s + x]; hw[con] += split_frac * ov[(size_t)x * H + con]; }
                     }
                 }
             }
@@ -177,6 +198,10 @@ __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
                 atomicMin(global_best, (unsigned long long)__double_as_longlong(primary));   // scores are >= 0: bit order = numeric order
             }
         }
+    }
+    {   // pairs whose read-level terms were evaluated: one atomic per wavefront, not per pair
+        const unsigned long long m = __ballot(scored != 0);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_scored, (unsigned long long)__popcll(m));
     }
     // block-level lexicographic min (score, pid)
     __shared__ double s_score[256]; __shared__ unsigned long long s_pid[256];
@@ -351,13 +376,20 @@ extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p
     double* d_bc = (double*)sp_pool(ctx, "k5_bc", blocks * 40); unsigned long long* d_be = (unsigned long long*)sp_pool(ctx, "k5_be", blocks * 8);
     if (!d_chains || !d_clen || !d_unexp || !d_ninf || !d_del || !d_lasso || !d_norm || !d_rwo || !d_ed || !d_ov || !d_opt || !d_worst || !d_lf || !d_lp ||
         !d_gb || !d_bs || !d_bp || !d_bc || !d_be) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "chain pair buffers");
+    unsigned long long* d_tb = (unsigned long long*)sp_pool(ctx, "k5_tab_best", std::max<size_t>(1, (size_t)P * R) * 8);
+    unsigned long long* d_tm = (unsigned long long*)sp_pool(ctx, "k5_tab_mask", std::max<size_t>(1, (size_t)P * R) * 8);
+    if (!d_tb || !d_tm) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "chain pair tables");
+    if ((size_t)P * R) {
+        ProfScope ps(ctx, "k5_chain_reads", (uint64_t)P * R);
+        hipLaunchKernelGGL(k5_chain_read_kernel, dim3((unsigned)(((size_t)P * R + 255) / 256)), dim3(256), 0, ctx->stream, P, R, H, maxlen, d_chains, d_clen, d_rwo, d_ed, d_tb, d_tm);
+    }
     const unsigned long long init[2] = {0x7FF0000000000000ull /* +inf */, 0ull};
     (void)hipMemcpyAsync(d_gb, init, 16, hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemsetAsync(d_bp, 0xFF, blocks * 8, ctx->stream);
     {
         ProfScope ps(ctx, "k5_pairs", n_pairs);
         hipLaunchKernelGGL(k5_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pc, d_chains, d_clen, d_unexp, d_ninf, d_del, d_lasso, d_norm,
-                           d_rwo, d_ed, d_ov, d_opt, d_worst, d_lf, lf_n, d_lp, max_total + 1, d_gb, d_bs, d_bp, d_bc, d_be, d_gb + 1);
+                           d_rwo, d_ed, d_ov, d_tb, d_tm, d_opt, d_worst, d_lf, lf_n, d_lp, max_total + 1, d_gb, d_bs, d_bp, d_bc, d_be, d_gb + 1);
         if (hipGetLastError() != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "k5 launch failed");
     }
     std::vector<double> bs(blocks), bc(blocks * 5); std::vector<unsigned long long> bp(blocks), be(blocks);

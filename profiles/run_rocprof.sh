@@ -7,7 +7,7 @@ TAG=${1:-run}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-steps 1"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs"
 # 1. kernel trace + stats (no counters in this pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 # 2. PMC passes, one small counter group each (no tracing domains combined with --pmc)
