@@ -1,0 +1,151 @@
+// sp_json.h -- a small JSON document reader / writer for the database loader and the result writer (host only).
+// Objects keep their members in file order (serde_json's BTreeMap-backed types are re-sorted by the callers that need key order).
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace spj {
+
+struct Value {
+    enum Kind { Null, Bool, Int, Double, String, Array, Object } kind = Null;
+    bool b = false; int64_t i = 0; double d = 0.0; std::string s;
+    std::vector<Value> arr;
+    std::vector<std::pair<std::string, Value>> obj;
+    const Value* get(const char* key) const {
+        if (kind != Object) return nullptr;
+        for (const auto& kv : obj) if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+    bool is_null() const { return kind == Null; }
+    int64_t as_int(int64_t dflt = 0) const { return kind == Int ? i : kind == Double ? (int64_t)d : dflt; }
+    const std::string& as_str() const { static const std::string empty; return kind == String ? s : empty; }
+    bool as_bool(bool dflt = false) const { return kind == Bool ? b : dflt; }
+};
+
+struct Parser {
+    const char* p; const char* end; std::string err;
+    Parser(const char* b, size_t n) : p(b), end(b + n) {}
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+    bool fail(const char* m) { if (err.empty()) err = m; return false; }
+    bool parse_string(std::string& out) {
+        if (p >= end || *p != '"') return fail("expected a string");
+        ++p; out.clear();
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= end) return fail("bad escape");
+                switch (*p) {
+                    case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break; case 'b': out += '\b'; break;
+                    case 'f': out += '\f'; break; case '/': out += '/'; break; case '\\': out += '\\'; break; case '"': out += '"'; break;
+                    case 'u': {
+                        if (end - p < 5) return fail("bad \\u escape");
+                        unsigned cp = (unsigned)std::strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16); p += 4;
+                        if (cp < 0x80) out += (char)cp;
+                        else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+                        else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+                        break;
+                    }
+                    default: return fail("bad escape");
+                }
+                ++p;
+            } else out += *p++;
+        }
+        if (p >= end) return fail("unterminated string");
+        ++p;
+        return true;
+    }
+    bool parse(Value& v) {
+        ws();
+        if (p >= end) return fail("unexpected end");
+        if (*p == '{') {
+            v.kind = Value::Object; ++p; ws();
+            if (p < end && *p == '}') { ++p; return true; }
+            for (;;) {
+                ws();
+                std::string key;
+                if (!parse_string(key)) return false;
+                ws();
+                if (p >= end || *p != ':') return fail("expected ':'");
+                ++p;
+                v.obj.emplace_back(std::move(key), Value());
+                if (!parse(v.obj.back().second)) return false;
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; return true; }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (*p == '[') {
+            v.kind = Value::Array; ++p; ws();
+            if (p < end && *p == ']') { ++p; return true; }
+            for (;;) {
+                v.arr.emplace_back();
+                if (!parse(v.arr.back())) return false;
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == ']') { ++p; return true; }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (*p == '"') { v.kind = Value::String; return parse_string(v.s); }
+        if (end - p >= 4 && std::strncmp(p, "true", 4) == 0) { v.kind = Value::Bool; v.b = true; p += 4; return true; }
+        if (end - p >= 5 && std::strncmp(p, "false", 5) == 0) { v.kind = Value::Bool; v.b = false; p += 5; return true; }
+        if (end - p >= 4 && std::strncmp(p, "null", 4) == 0) { v.kind = Value::Null; p += 4; return true; }
+        const char* q = p; bool is_double = false;
+        if (q < end && (*q == '-' || *q == '+')) ++q;
+        while (q < end && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '-' || *q == '+')) { if (*q == '.' || *q == 'e' || *q == 'E') is_double = true; ++q; }
+        if (q == p) return fail("unexpected character");
+        const std::string num(p, q);
+        if (is_double) { v.kind = Value::Double; v.d = std::strtod(num.c_str(), nullptr); }
+        else { v.kind = Value::Int; v.i = std::strtoll(num.c_str(), nullptr, 10); }
+        p = q;
+        return true;
+    }
+};
+
+// serde_json::to_writer_pretty layout: two-space indent, "key": value, empty containers as [] / {}
+inline void write_string(std::string& out, const std::string& s) {
+    out += '"';
+    for (unsigned char c : s) {
+        switch (c) {
+            case '"': out += "\\\""; break; case '\\': out += "\\\\"; break; case '\n': out += "\\n"; break; case '\r': out += "\\r"; break;
+            case '\t': out += "\\t"; break; case '\b': out += "\\b"; break; case '\f': out += "\\f"; break;
+            default:
+                if (c < 0x20) { char buf[8]; std::snprintf(buf, sizeof buf, "\\u%04x", c); out += buf; } else out += (char)c;
+        }
+    }
+    out += '"';
+}
+inline void write_pretty(std::string& out, const Value& v, int depth = 0) {
+    auto indent = [&](int d) { out.append((size_t)d * 2, ' '); };
+    switch (v.kind) {
+        case Value::Null: out += "null"; break;
+        case Value::Bool: out += v.b ? "true" : "false"; break;
+        case Value::Int: out += std::to_string(v.i); break;
+        case Value::Double: { char buf[40]; std::snprintf(buf, sizeof buf, "%.17g", v.d); std::string t(buf); if (t.find_first_of(".eEn") == std::string::npos) t += ".0"; out += t; break; }
+        case Value::String: write_string(out, v.s); break;
+        case Value::Array:
+            if (v.arr.empty()) { out += "[]"; break; }
+            out += "[\n";
+            for (size_t k = 0; k < v.arr.size(); ++k) { indent(depth + 1); write_pretty(out, v.arr[k], depth + 1); out += k + 1 < v.arr.size() ? ",\n" : "\n"; }
+            indent(depth); out += ']';
+            break;
+        case Value::Object:
+            if (v.obj.empty()) { out += "{}"; break; }
+            out += "{\n";
+            for (size_t k = 0; k < v.obj.size(); ++k) { indent(depth + 1); write_string(out, v.obj[k].first); out += ": "; write_pretty(out, v.obj[k].second, depth + 1); out += k + 1 < v.obj.size() ? ",\n" : "\n"; }
+            indent(depth); out += '}';
+            break;
+    }
+}
+inline Value str(const std::string& s) { Value v; v.kind = Value::String; v.s = s; return v; }
+inline Value num(int64_t i) { Value v; v.kind = Value::Int; v.i = i; return v; }
+inline Value boolean(bool b) { Value v; v.kind = Value::Bool; v.b = b; return v; }
+inline Value object() { Value v; v.kind = Value::Object; return v; }
+inline Value array() { Value v; v.kind = Value::Array; return v; }
+
+} // namespace spj
