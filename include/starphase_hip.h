@@ -668,6 +668,119 @@ enum { SP_INEXACT_UNKNOWN = 0, SP_INEXACT_NO_MATCH = 1, SP_INEXACT_CORE_MATCH = 
 uint32_t sp_inexact_haplotype(const char* base_haplotype, uint32_t n_variants, const char* const* labels, const uint8_t* is_vi,
                               const int32_t* states, int32_t* match_type, char* out, uint32_t cap);
 
+/* ------------------------------------------------------------------ f3: the database file and the result file (host only)
+ * sp_database_* replaces the serde loading of PgxDatabase (src/database/pgx_database.rs:23-41; load_json, src/util/file_io.rs:16-28
+ * -- gzip is recognised by its magic number here, not by the ".gz" extension) and the three flattenings the kernels' inputs need:
+ * hla_sequences + hla_config -> sp_hla_db_desc (src/hla/alleles.rs:332-344; src/hla/realigner.rs:42-91), cyp2d6_config +
+ * cyp2d6_gene_def -> sp_cyp_locus / sp_cyp_gene_def / sp_cyp_config, and one gene entry (PgxGene / PgxVariant / PgxHaplotype,
+ * src/database/pgx_database.rs:373-840) -> sp_variant_gene -> sp_variant_problem.  Files written by older releases load too: a missing
+ * "cyp2d6_config" / "hla_config" gets the reference's defaults, "hla_config" is read in its gene_collection form and in the older
+ * hla_coordinates / hla_exons / hla_is_forward_strand form, is_core_variant / is_core_haplotype default to true.
+ * Every pointer handed out belongs to the object it came from and stays valid until that object is freed (flatten results: until the
+ * next flatten call of the same kind).  Errors: SP_ERR_INVALID_ARG, with the text in err / sp_database_last_error. */
+typedef struct sp_database sp_database;
+int32_t sp_database_load(const char* path, sp_database** out, char* err, uint32_t err_cap);                 /* .json or .json.gz */
+int32_t sp_database_parse(const char* text, uint64_t len, sp_database** out, char* err, uint32_t err_cap);  /* JSON text or gzip bytes */
+void    sp_database_free(sp_database* db);
+const char* sp_database_last_error(const sp_database* db);
+typedef struct {                                  /* PgxMetadata (src/database/pgx_database.rs:358-371) */
+    const char* pbstarphase_version; const char* cpic_version; const char* hla_version; const char* pharmvar_version; const char* build_time;
+} sp_database_metadata;
+int32_t sp_database_get_metadata(const sp_database* db, sp_database_metadata* out);
+typedef struct {
+    uint32_t n_gene_entries, n_hla_sequences, n_hla_genes, n_cyp2d6_alleles, n_collection_genes;
+    int32_t has_hla_config, has_cyp2d6_config, reserved;
+} sp_database_stats;
+int32_t sp_database_info(const sp_database* db, sp_database_stats* out);
+typedef struct {                                  /* GeneDefinition (src/database/gene_definition.rs:18-34); 0-based half-open */
+    const char* name; const char* chrom; uint64_t start, end;
+    int32_t is_forward_strand, is_absent_capable; uint32_t n_exons, reserved;
+    const uint64_t* exon_start; const uint64_t* exon_end;
+} sp_gene_region;
+int32_t sp_database_hla_gene(const sp_database* db, uint32_t g, sp_gene_region* out);         /* g < n_hla_genes, gene-name order */
+int32_t sp_database_gene_entry(const sp_database* db, uint32_t i, const char** gene_name, const char** chromosome);   /* i < n_gene_entries */
+/* the HLA part as sp_hla_db_create wants it.  gene_names: the genes to type, NULL = every gene of hla_config; gene_ref[g] = the hg38
+ * bases of [start - ref_buffer, end + ref_buffer) of gene g; alleles of other genes are left out, the others keep database-key order */
+int32_t sp_database_hla_flatten(sp_database* db, uint32_t n_genes, const char* const* gene_names, const char* const* gene_ref, int32_t ref_buffer,
+                                sp_hla_db_desc* desc);
+/* allele i of the last sp_database_hla_flatten: "HLA:HLA00001", "HLA-A", "01:01:01:01" */
+int32_t sp_database_hla_allele(const sp_database* db, uint32_t i, const char** hla_id, const char** gene_name, const char** star_allele);
+/* the smallest chromosome window holding every CYP2D6 coordinate of the configuration */
+int32_t sp_database_cyp_window(const sp_database* db, const char** chrom, uint64_t* start, uint64_t* end);
+/* the CYP2D6 part as sp_cyp_db_create wants it; chrom_seq = the bases of [window_start, window_start + window_len) */
+int32_t sp_database_cyp_flatten(sp_database* db, const char* chrom_seq, uint64_t window_start, uint64_t window_len,
+                                sp_cyp_locus* locus, sp_cyp_gene_def* gene_def, sp_cyp_config* config);
+
+/* One variant-typed gene: load_database_haplotypes (src/diplotyper.rs:437-538) -- every defined haplotype normalised against the
+ * chromosome (chrom_seq may be NULL: no reference, as NormalizedVariant::new without a genome), haplotypes with a variant that does
+ * not normalise are dropped (n_skipped_haplotypes), the variant table is the BTreeMap<NormalizedVariant, VariantMeta> in key order --
+ * and the gene's structural-variant definitions (PgxStructuralVariants + the database's gene_collection) for is_deletion. */
+typedef struct sp_variant_gene sp_variant_gene;
+int32_t sp_variant_gene_create(sp_database* db, const char* gene_name, const char* chrom_seq, uint64_t chrom_len, sp_variant_gene** out);
+void    sp_variant_gene_free(sp_variant_gene* gene);
+typedef struct { uint32_t n_haplotypes, n_variants, n_skipped_haplotypes, n_full_deletions, n_partial_deletions, reserved; } sp_variant_gene_stats;
+int32_t sp_variant_gene_info(const sp_variant_gene* gene, sp_variant_gene_stats* out);
+int32_t sp_variant_gene_haplotype(const sp_variant_gene* gene, uint32_t h, const char** name, const char** core_allele /* NULL: is one */);
+int32_t sp_variant_gene_variant(const sp_variant_gene* gene, uint32_t v, uint64_t* position, const char** ref, const char** alt,
+                                const char** name, const char** dbsnp_id /* may come back NULL */, int64_t* variant_id, int32_t* is_core);
+int32_t sp_variant_gene_sv_definitions(const sp_variant_gene* gene, sp_sv_definitions* out);      /* for sp_variant_is_deletion */
+int32_t sp_variant_gene_sv_label(const sp_variant_gene* gene, int32_t kind, int32_t index, const char** label);
+/* load_vcf_variants + load_sv_vcf_variants (src/diplotyper.rs:551-857) after the file decoding: the caller hands over the decoded
+ * records -- one sp_vcf_allele per ALT allele of a small-variant record (0-based position, REF, that ALT; gt = SP_GT_* of THIS allele
+ * in the sample's GT, SP_GT_HOM_REF when the allele is not called; ps = phase set or -1), one sp_vcf_deletion per SVTYPE=DEL record
+ * (0-based start, INFO/END).  The library normalises, matches the alleles to the gene's variants (+-50 bp window, the last matching
+ * record wins), decides the deletions with is_deletion (gene span, max_sv_length; 0 = 1,000,000), and fills *problem for
+ * sp_variant_solve.  Variant ids of the problem: the gene's variants and the observed deletions merged in NormalizedVariant order;
+ * sp_variant_gene_problem_variant maps an id back (db_variant = index for sp_variant_gene_variant, or -1 and the deletion label).
+ * Errors (SP_ERR_INVALID_ARG): a homozygous allele with a phase set, two records for the same deletion, a deleted gene without a
+ * definition in the gene collection. */
+typedef struct { uint64_t position; const char* ref; const char* alt; int32_t gt, reserved; int64_t ps; } sp_vcf_allele;
+typedef struct { uint64_t start, end; int32_t gt, reserved; int64_t ps; } sp_vcf_deletion;
+int32_t sp_variant_gene_problem(sp_variant_gene* gene, uint32_t n_alleles, const sp_vcf_allele* alleles, uint32_t n_deletions,
+                                const sp_vcf_deletion* deletions, uint64_t max_sv_length, sp_variant_problem* problem);
+int32_t sp_variant_gene_problem_variant(const sp_variant_gene* gene, int32_t id, int32_t* db_variant, const char** sv_label, uint64_t* sv_start,
+                                        uint64_t* sv_end);
+int32_t sp_variant_gene_problem_sv_label(const sp_variant_gene* gene, int32_t label_id, const char** label);   /* obs_sv_label ids */
+const char* sp_variant_gene_last_error(const sp_variant_gene* gene);
+
+/* The result file: StarphaseJson / PgxGeneDetails (src/data_types/starphase_json.rs:11-326) written as serde_json::to_writer_pretty
+ * does (save_json, src/util/file_io.rs:37-52; two-space indent, struct fields in declaration order, gene_details in key order,
+ * Option::None as null).  A sp_gene_details collects the parts; sp_result_insert applies one of the reference's constructors to it --
+ * with that constructor's checks ("diplotypes and simple_diplotypes must be the same length", "diplotypes and inexact_diplotypes
+ * must be the same length") and StarphaseJson::insert's ("Entry for <gene> is already occupied.") as SP_ERR_INVALID_ARG. */
+typedef struct sp_result sp_result;
+typedef struct sp_gene_details sp_gene_details;
+int32_t sp_result_create(const sp_database* db /* NULL: PgxMetadata::default() */, const char* pbstarphase_version, sp_result** out);
+void    sp_result_free(sp_result* result);
+const char* sp_result_last_error(const sp_result* result);
+int32_t sp_gene_details_create(sp_gene_details** out);
+void    sp_gene_details_free(sp_gene_details* details);
+int32_t sp_gene_details_add_diplotype(sp_gene_details* d, const char* hap1, const char* hap2);             /* Diplotype::new */
+int32_t sp_gene_details_add_simple_diplotype(sp_gene_details* d, const char* hap1, const char* hap2);      /* simple_diplotypes: Some(..) */
+int32_t sp_gene_details_set_simple_diplotypes(sp_gene_details* d, int32_t some);                           /* Some(vec![]) / None */
+/* InexactDiplotype::new(InexactHaplotype::new(base, variants), ..): variants as for sp_inexact_haplotype */
+int32_t sp_gene_details_add_inexact_diplotype(sp_gene_details* d,
+                                              const char* base1, uint32_t n1, const char* const* labels1, const uint8_t* is_vi1, const int32_t* states1,
+                                              const char* base2, uint32_t n2, const char* const* labels2, const uint8_t* is_vi2, const int32_t* states2);
+int32_t sp_gene_details_add_diplotype_only(sp_gene_details* d, const char* hap1, const char* hap2);        /* InexactDiplotype::new_diplotype_only */
+typedef struct {                                  /* PgxVariantDetails (:247-262); sv_label NULL = not a structural variant */
+    uint64_t variant_id; const char* variant_name; const char* dbsnp;
+    const char* chrom; uint64_t position; const char* reference; const char* alternate;
+    const char* sv_label; uint64_t sv_start, sv_end;
+    int32_t genotype /* SP_GT_* */, is_core_variant; int64_t phase_set /* -1 = None */;
+} sp_variant_detail;
+int32_t sp_gene_details_add_variant(sp_gene_details* d, const sp_variant_detail* v);
+typedef struct { int32_t present, has_clips; uint64_t seq_len, nm, unmapped, clipped_start, clipped_end; } sp_mapping_stats;   /* Option<MappingStats> */
+int32_t sp_gene_details_add_mapping(sp_gene_details* d, const char* read_qname, const char* best_hla_id, const char* best_star_allele,
+                                    const sp_mapping_stats* cdna, const sp_mapping_stats* dna, int32_t is_ignored);       /* PgxMappingDetails */
+int32_t sp_gene_details_add_multi_mapping(sp_gene_details* d, const char* read_qname, uint64_t read_start, uint64_t read_end,
+                                          uint64_t consensus_id, const char* consensus_star_allele);                      /* PgxMultiMappingDetails */
+enum { SP_DETAILS_SUBALLELE_MATCH = 0, SP_DETAILS_CORE_MATCH = 1, SP_DETAILS_INEXACT_DIPLOTYPES = 2, SP_DETAILS_FROM_MAPPINGS = 3,
+       SP_DETAILS_FROM_MULTI_MAPPINGS = 4, SP_DETAILS_NO_MATCH = 5 };
+int32_t sp_result_insert(sp_result* result, const char* gene, const sp_gene_details* details, int32_t constructor);
+int32_t sp_result_json(sp_result* result, const char** text, uint64_t* len);
+int32_t sp_result_save(sp_result* result, const char* path);                    /* gzip when the name ends in ".gz" */
+
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */
 int32_t sp_profile_reset(sp_ctx* ctx);

@@ -9,4 +9,5 @@ The directory name contains a hyphen (it mirrors the reference repository name),
 ``__graft_entry__.load_package()`` and registered as module ``pb_starphase_amd``.
 """
 from . import ffi          # noqa: F401
+from . import database     # noqa: F401
 from .ffi import (Context, SeqSet, HlaDb, StarphaseError, lib_path)   # noqa: F401

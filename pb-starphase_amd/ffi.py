@@ -725,6 +725,10 @@ class CypDb:
         K.n_translate, K.translate_key, K.translate_val = len(tr), self._keep[9], self._keep[10]
         K.n_connections, K.connection_a, K.connection_b = len(con), self._keep[11], self._keep[12]
         K.n_singletons, K.singletons = len(sg), self._keep[13]
+        self._create(L, G, K)
+
+    def _create(self, L, G, K):
+        ctx = self.ctx
         self._h = C.c_void_p()
         rc = lib().sp_cyp_db_create(ctx._h if ctx is not None else None, C.byref(L), C.byref(G), C.byref(K), C.byref(self._h))
         if rc != SP_OK:
@@ -732,6 +736,17 @@ class CypDb:
         st = sp_cyp_db_stats()
         lib().sp_cyp_db_info(self._h, C.byref(st))
         self.stats = st
+
+    @classmethod
+    def from_structs(cls, ctx, L, G, K, keep=None):
+        """locus / gene definition / configuration filled elsewhere (sp_database_cyp_flatten)"""
+        self = cls.__new__(cls)
+        self.ctx, self._keep = ctx, keep
+        self.cfg = dict(translate=[(K.translate_key[i].decode(), K.translate_val[i].decode()) for i in range(K.n_translate)],
+                        connections=[(K.connection_a[i].decode(), K.connection_b[i].decode()) for i in range(K.n_connections)],
+                        singletons=[K.singletons[i].decode() for i in range(K.n_singletons)])
+        self._create(L, G, K)
+        return self
 
     def close(self):
         if self._h:
@@ -859,6 +874,15 @@ class HlaDb:
         self._keep = (gene_of, dblob, doff, cblob, coff, rblob, roff, gfwd, eoff, es, ee)
         self._h = C.c_void_p()
         ctx.check(lib().sp_hla_db_create(ctx._h, C.byref(d), C.byref(self._h)))
+
+    @classmethod
+    def from_desc(cls, ctx, desc):
+        """an sp_hla_db_desc filled elsewhere (sp_database_hla_flatten)"""
+        self = cls.__new__(cls)
+        self.ctx, self.n_alleles, self.n_genes, self._keep = ctx, desc.n_alleles, desc.n_genes, None
+        self._h = C.c_void_p()
+        ctx.check(lib().sp_hla_db_create(ctx._h, C.byref(desc), C.byref(self._h)))
+        return self
 
     def close(self):
         if self._h:

@@ -26,8 +26,9 @@ def test_header_symbols_exported(pkg):
 
 def test_binding_matches_header(pkg):
     pkg.ffi.lib()          # binds every function; raises AttributeError on a missing one
+    pkg.database._lib()    # the database / result-file part of the header
     import inspect
-    src = inspect.getsource(pkg.ffi)
+    src = inspect.getsource(pkg.ffi) + inspect.getsource(pkg.database)
     for n in declared_symbols():
         assert n in src, f"{n} has no ctypes binding"
 
