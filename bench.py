@@ -193,6 +193,32 @@ def cyp_leg(pkg, ctx, n_reads=2000, reps=2):
             "calls_equal_truth": f"{ok}/{len(out)}", "scenarios": out}
 
 
+def chain_pair_leg(pkg, ctx, n_d6=4, n_reads=1000, reps=2):
+    """K5 at the scale of a duplication-rich sample: ~1.3k enumerated chains x 1,000 reads -> ~0.9 M chain pairs, each the f64
+    likelihood of all reads under the pair (src/cyp2d6/chaining.rs:421-566).  Larger problems: profiles/r02/k5_scale.json."""
+    from pb_starphase_amd import synth
+    prob = synth.chain_pair_problem(n_d6, n_reads, np.random.default_rng(7))
+    best = None
+    for _ in range(reps):
+        ctx.profile_reset(); ctx.synchronize()
+        t0 = time.perf_counter()
+        rc, res = ctx.cyp_best_chain_pair(**prob)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    P = res.n_possible
+    pairs = P * (P + 1) // 2
+    ms_pairs, ms_tab = ctx.profile_get("k5_pairs")[0], ctx.profile_get("k5_chain_reads")[0]
+    # per pair and read: two table entries (the read's best window total under either chain, u64, + the mask of the starts reaching it, u64)
+    table_bytes = 2 * 16
+    return {"value": pairs / (ms_pairs * 1e-3) if ms_pairs else None, "unit": "chain pairs/s", "status": rc, "chains": P, "reads": n_reads, "pairs": pairs,
+            "pairs_scored": int(res.n_pairs_scored), "k5_pairs_ms": ms_pairs, "k5_chain_reads_ms": ms_tab, "wall_ms": 1e3 * best,
+            "pair_read_terms_per_s": pairs * n_reads / (ms_pairs * 1e-3) if ms_pairs else None,
+            "table_bytes_read_per_s": pairs * n_reads * table_bytes / (ms_pairs * 1e-3) if ms_pairs else None,
+            "table_footprint_bytes": P * n_reads * 16,
+            "workload": f"sp_cyp_best_chain_pair: {n_d6} CYP2D6 consensuses, {n_reads} reads, {P} enumerated chains (the per-(chain, read) tables sit in L2; "
+                        "the kernel is f64-add / compare bound, not HBM bound)"}
+
+
 def cohort_leg(pkg, ctx, fx, db, n_samples=32, reps=2, seed=5):
     """BASELINE configs[4] per GPU: n_samples WGS-style samples (~45 reads per gene) through one K1 call + sp_hla_diplotype_cohort"""
     from pb_starphase_amd import synth
@@ -349,13 +375,14 @@ def main():
                    "workload": "K1 on the same reads + K2 on 4 truth consensuses (no consensus step): the read -> allele and consensus -> allele scoring alone",
                    "k2_truth_calls": f"{k2_ok}/{len(calls)}"}
 
-    peaks, cyp, cohort = None, None, None
+    peaks, cyp, cohort, k5 = None, None, None, None
     if rank == 0:
         peaks = {"valu_int_wave_instr_per_s": ctx.microbench("valu_int"), "match16_valu_wave_instr_per_s": ctx.microbench("match16"),
                  "hbm_copy_bytes_per_s": ctx.microbench("hbm_copy")}
     if rank == 0 and world == 1 and not args.no_extra_legs:
         cyp = cyp_leg(pkg, ctx)
         cohort = cohort_leg(pkg, ctx, fx, db)
+        k5 = chain_pair_leg(pkg, ctx)
 
     if rank == 0:
         # VALU wave-instructions of one k1_cells launch: rocprofv3 --pmc SQ_INSTS_VALU of this workload (profiles/r02/valu_k1_cells.json);
@@ -399,7 +426,7 @@ def main():
                           "nodes_expanded_per_step": cons_cols / max(1, args.steps)},
             "concordance": {"k1_gene_correct": k1_gene_ok, "k1_realigned": k1_realigned, "diplotypes_equal_truth": f"{ok}/{len(genes)} genes"},
             "pcie_inclusive_upload_s": t_up,
-            "scoring_only": scoring, "cyp2d6": cyp, "cohort": cohort,
+            "scoring_only": scoring, "cyp2d6": cyp, "cohort": cohort, "k5_chain_pairs": k5,
         }
         if cb is not None:
             agree = sum(1 for i, b in cpu_best.items() if b == int(out[i]["best_allele"]))

@@ -356,3 +356,33 @@ class Chr22Locus:
                 reads.append(hifi_errors(rng, r) if errors else r)
         order = rng.permutation(len(reads))
         return [reads[i] for i in order]
+
+
+def chain_pair_problem(n_d6, n_reads, rng):
+    """A synthetic find_best_chain_pair input (src/cyp2d6/chaining.rs:421-566) whose chain enumeration explodes the way duplication-rich
+    samples do: labels REP6, n_d6 CYP2D6 alleles, link_region, REP7, spacer, CYP2D7; every read observes a stretch of REP6 -> D6_a ->
+    link -> REP7 -> D6_b -> ... and scores every label per observed segment.  Returns the keyword arguments of
+    Context.cyp_best_chain_pair (configuration tables of the bundled database)."""
+    cfg = json.load(gzip.open(os.path.join(GOLDEN, "cyp2d6_db_v0.14.1.json.gz")))["cyp2d6_config"]
+    codes = {"REP6": 1, "CYP2D6": 2, "link_region": 3, "REP7": 4, "spacer": 5, "CYP2D7": 6}
+    labels = [("REP6", None)] + [("CYP2D6", str(k + 1)) for k in range(n_d6)] + [("link_region", None), ("REP7", None), ("spacer", None), ("CYP2D7", None)]
+    H = len(labels)
+    REP6, LINK, REP7, SP, D7 = 0, n_d6 + 1, n_d6 + 2, n_d6 + 3, n_d6 + 4
+    rco, co, items, rwo, ed, ov = [0], [0], [], [0], [], []
+    for r in range(n_reads):
+        a, b = int(rng.integers(1, n_d6 + 1)), int(rng.integers(1, n_d6 + 1))
+        kind = r % 4
+        chain = [REP6, a, LINK, REP7][: int(rng.integers(2, 5))] if kind == 0 else [a, LINK, REP7, b, LINK][: int(rng.integers(2, 6))] if kind == 1 \
+            else [b, LINK, REP7, SP, D7][int(rng.integers(0, 3)):] if kind == 2 else [LINK, REP7, b, LINK, REP7][: int(rng.integers(2, 6))]
+        items += chain
+        co.append(len(items)); rco.append(len(co) - 1)
+        for h in chain:
+            row = [(int(rng.integers(20, 60)), 1.0) if labels[x][0] == labels[h][0] else (int(rng.integers(300, 900)), 0.9) for x in range(H)]
+            row[h] = (int(rng.integers(0, 4)), 1.0)
+            ed.append([e for e, _ in row]); ov.append([o for _, o in row])
+        rwo.append(len(ed))
+    return dict(hap_type=np.array([codes[t] for t, _ in labels], np.int32), hap_subtype=[s for _, s in labels],
+                translate=sorted(cfg["cyp_translate"].items()), connections=sorted(tuple(x) for x in cfg["inferred_connections"]),
+                singletons=sorted(cfg["unexpected_singletons"]), read_chain_off=np.array(rco, np.uint32), chain_off=np.array(co, np.uint32),
+                chain_items=np.array(items, np.uint32), read_w_off=np.array(rwo, np.uint32), w_ed=np.array(ed, np.uint64), w_ov=np.array(ov, np.float64),
+                infer=False, normalize_all=True, ignore_limits=False, penalties=(4.0, 2.0, 10.0, 2.0))

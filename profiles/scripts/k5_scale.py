@@ -7,42 +7,19 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()
-import oracle_ffi as of
-
-
-def problem(n_d6, n_reads, rng):
-    """labels: REP6, n_d6 CYP2D6 alleles, link_region, REP7, spacer, CYP2D7; reads observe REP6 -> D6_a -> link -> REP7 -> D6_b -> ... chains"""
-    labels = [("REP6", None)] + [("CYP2D6", str(k + 1)) for k in range(n_d6)] + [("link_region", None), ("REP7", None), ("spacer", None), ("CYP2D7", None)]
-    H = len(labels)
-    REP6, LINK, REP7, SP, D7 = 0, n_d6 + 1, n_d6 + 2, n_d6 + 3, n_d6 + 4
-    obs, scores = {}, {}
-    for r in range(n_reads):
-        a, b = int(rng.integers(1, n_d6 + 1)), int(rng.integers(1, n_d6 + 1))
-        kind = r % 4
-        chain = [REP6, a, LINK, REP7][: int(rng.integers(2, 5))] if kind == 0 else [a, LINK, REP7, b, LINK][: int(rng.integers(2, 6))] if kind == 1 \
-            else [b, LINK, REP7, SP, D7][int(rng.integers(0, 3)):] if kind == 2 else [LINK, REP7, b, LINK, REP7][: int(rng.integers(2, 6))]
-        name = f"r{r:06d}"
-        obs[name] = [chain]
-        rows = []
-        for h in chain:
-            row = [(int(rng.integers(20, 60)), 1.0) if labels[x][0] == labels[h][0] else (int(rng.integers(300, 900)), 0.9) for x in range(H)]
-            row[h] = (int(rng.integers(0, 4)), 1.0)
-            rows.append(row)
-        scores[name] = rows
-    return labels, of.ChainInputs(labels, obs, scores, False, True, of.DEFAULT_PENALTIES, False)
+from pb_starphase_amd import synth
 
 
 def main():
-    from test_gpu_cyp import gpu_chain_pair
     ctx = pkg.Context(0)
     out = []
     for n_d6, n_reads in [(int(a), 1000) for a in (sys.argv[1:] or ["4", "6", "8"])]:
-        labels, inp = problem(n_d6, n_reads, np.random.default_rng(7))
+        prob = synth.chain_pair_problem(n_d6, n_reads, np.random.default_rng(7))
         best = None
         for rep in range(2):
             ctx.profile_reset(); ctx.synchronize()
             t0 = time.perf_counter()
-            rc, res = gpu_chain_pair(ctx, inp)
+            rc, res = ctx.cyp_best_chain_pair(**prob)
             dt = time.perf_counter() - t0
             best = dt if best is None or dt < best else best
         P = res.n_possible

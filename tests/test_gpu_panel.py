@@ -133,3 +133,77 @@ def test_config1_stated_size(oracle, pkg, gpu_ctx):
     for g, (call, _c1, _c2) in enumerate(calls):
         got = sorted([call.allele1, call.allele2])
         assert all(same(a, b) for a, b in zip(got, truth[g])) or all(same(a, b) for a, b in zip(got, truth[g][::-1]))
+
+
+def test_sample_from_database_files_to_result_file(oracle, pkg, gpu_ctx, tmp_path):
+    """The f3 route end to end: the database FILES are read and flattened by the library (sp_database_*, sp_variant_gene_*), the calls run
+    on the GPU, the result goes out through sp_result_*.  Every call equals the one made from the Python-flattened inputs / the oracle."""
+    from pb_starphase_amd import synth
+    D = pkg.database
+    rng = np.random.default_rng(31)
+    result = D.Result(D.Database(os.path.join(GOLDEN, "gene_entries_v0.14.1.json.gz")), "test")
+    # ---- variant genes: problem built by the library from VCF-like alleles, solved on the GPU == oracle on the glue's problem
+    path = os.path.join(GOLDEN, "gene_entries_v0.14.1.json.gz")
+    raw = json.load(gzip.open(path))["gene_entries"]
+    db = D.Database(path)
+    for name, _chrom in db.gene_entries():
+        vh, haps = vg.load_database_haplotypes(oracle, raw[name], None)
+        h1, h2, obs, _phased = synthetic_observations(rng, haps)
+        want = vg.Problem(vh, haps, obs, raw[name].get("structural_variants"))
+        gene = db.variant_gene(name)
+        alleles = [(v[1], v[2], v[3], gt, ps) for v, (gt, ps) in sorted(obs.items())]
+        rng.shuffle(alleles)                                                    # record order does not matter
+        prob = gene.problem(alleles)
+        res = pkg.ffi.sp_variant_result()
+        gpu_ctx.check(pkg.ffi.lib().sp_variant_solve(gpu_ctx._h, C.byref(prob), C.byref(res)))
+        got = (tuple(res.score), [(res.dip[i][0], res.dip[i][1], res.dip_comb[i]) for i in range(res.n_dip)])
+        assert got == vg.oracle_solve(oracle, want), name
+        hap_names = [h[0] for h in gene.haplotypes()]
+        d = D.GeneDetails()
+        for a, b, _c in got[1][:4]:
+            d.add_diplotype(hap_names[a], hap_names[b])
+        meta = gene.variants()
+        arr = D.problem_arrays(prob)
+        for o in range(prob.n_obs):
+            k, _label, _s, _e = gene.problem_variant(arr["obs_var"][o])
+            m = meta[k]
+            d.add_variant(m["variant_id"], m["name"], m["dbsnp_id"], raw[name]["chromosome"], m["position"], m["ref"], m["alt"], arr["obs_gt"][o],
+                          None if arr["obs_ps"][o] < 0 else arr["obs_ps"][o], m["is_core_variant"])
+        result.insert(name, d, D.SUBALLELE_MATCH if got[0] == (0, 0, 0, 0) else D.INEXACT_DIPLOTYPES)
+    # ---- HLA: database file -> sp_hla_db, same calls as from the Python-flattened description
+    fx = synth.HlaFixture()
+    hdb_file = D.Database(os.path.join(GOLDEN, "hla_db_v0.14.1.json.gz"))
+    regions = hdb_file.hla_genes()
+    assert [(r["start"], r["end"]) for r in regions] == fx.coords
+    hdb, alleles = hdb_file.hla_db(gpu_ctx, fx.gene_ref)
+    ref_db = fx.make_db(pkg, gpu_ctx)
+    reads = []
+    for g in range(len(fx.genes)):
+        for a in rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist():
+            hap, s = fx.haplotype(g, a)
+            reads += synth.simulate_reads(rng, hap, s, len(fx.dna[a]), 23, mean_len=6000, sd_len=1500, min_overlap=2500)
+    R = gpu_ctx.upload(reads)
+    ra, rb = hdb.realign_reads(R), ref_db.realign_reads(R)
+    assert ra.tolist() == rb.tolist()
+    ca, _ = hdb.diplotype_genes(list(range(len(fx.genes))), R, ra)
+    cb, _ = ref_db.diplotype_genes(list(range(len(fx.genes))), R, rb)
+    for g, ((x, x1, x2), (y, y1, y2)) in enumerate(zip(ca, cb)):
+        assert (x.status, x.allele1, x.allele2, x1, x2) == (y.status, y.allele1, y.allele2, y1, y2) and x.status == 0
+        d = D.GeneDetails().add_diplotype(alleles[x.allele1][2], alleles[x.allele2][2])
+        for r in np.nonzero(ra["gene"] == g)[0][:5]:
+            d.add_mapping(f"read/{r}", alleles[ra[r]["best_allele"]][0], alleles[ra[r]["best_allele"]][2], cdna=None,
+                          dna=(int(ra[r]["target_len"]), int(ra[r]["nm"]), int(ra[r]["unmapped"])))
+        result.insert(fx.genes[g], d, D.FROM_MAPPINGS)
+    # ---- CYP2D6: database file -> sp_cyp_db -> sp_cyp_diplotype
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    cdb = D.Database(os.path.join(GOLDEN, "cyp2d6_db_v0.14.1.json.gz")).cyp_db(gpu_ctx, locus.sequence, locus.start)
+    _name, haps, expected = cr.scenarios(locus)[1]
+    call, _cons, _labels = cdb.diplotype(gpu_ctx.upload(locus.sample(rng, haps, 120, lo=8000, hi=16000)))
+    assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
+    result.insert("CYP2D6", D.GeneDetails().add_diplotype(call.hap1.decode(), call.hap2.decode()), D.FROM_MULTI_MAPPINGS)
+    out = tmp_path / "sample.json.gz"
+    result.save(str(out))
+    obj = json.load(gzip.open(out))
+    assert sorted(obj["gene_details"]) == sorted(list(raw) + fx.genes + ["CYP2D6"]) and len(obj["gene_details"]) == 21
+    assert obj["gene_details"]["CYP2D6"]["diplotypes"][0]["diplotype"] == f"{call.hap1.decode()}/{call.hap2.decode()}"
