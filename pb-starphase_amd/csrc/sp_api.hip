@@ -116,13 +116,18 @@ int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets
     }
     s->h_word_off[n] = total_words;
     auto fail = [&](const char* what) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, what); };
+    // any HIP error from here on frees the half-built set before it is reported
+    hipError_t herr = hipSuccess;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && herr == hipSuccess) herr = e; return e == hipSuccess; };
+    auto hip_fail = [&](const char* what) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(herr)); };
     const size_t wbytes = (total_words + SP_SEQ_PAD_WORDS) * sizeof(uint32_t);
     if (hipMalloc(&s->d_words, wbytes) != hipSuccess) return fail("seqset words");
     if (hipMalloc(&s->d_word_off, ((size_t)n + 1) * sizeof(uint64_t)) != hipSuccess) return fail("seqset offsets");
     if (hipMalloc(&s->d_len, std::max<size_t>(1, n) * sizeof(int32_t)) != hipSuccess) return fail("seqset lengths");
-    hipMemcpyAsync(s->d_word_off, s->h_word_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
-    if (n) hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-    hipMemsetAsync(s->d_words, 0, wbytes, ctx->stream);
+    ok(hipMemcpyAsync(s->d_word_off, s->h_word_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (n) ok(hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    ok(hipMemsetAsync(s->d_words, 0, wbytes, ctx->stream));
+    if (herr != hipSuccess) return hip_fail("seqset upload");
     const uint64_t n_bases = n ? offsets[n] - offsets[0] : 0;
     if (n_bases) {
         // the ASCII bases go over PCIe once and are packed to 2 bits/base on the device (sp_pack_kernel)
@@ -132,21 +137,25 @@ int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets
         if (!d_ascii || !d_off || !d_flag) return fail("seqset staging");
         std::vector<uint64_t> rel((size_t)n + 1);
         for (uint32_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
-        hipMemcpyAsync(d_ascii, bases + offsets[0], n_bases, hipMemcpyHostToDevice, ctx->stream);
-        hipMemcpyAsync(d_off, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-        hipMemsetAsync(d_flag, 0, 4, ctx->stream);
+        ok(hipMemcpyAsync(d_ascii, bases + offsets[0], n_bases, hipMemcpyHostToDevice, ctx->stream));
+        ok(hipMemcpyAsync(d_off, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        ok(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
         sp_launch_pack(ctx, d_ascii, d_off, s->d_word_off, s->d_len, n, s->d_words, nullptr, d_flag);
+        ok(hipGetLastError());
         uint32_t flag = 0;
-        hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
-        SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ok(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ok(hipStreamSynchronize(ctx->stream));          // rel / flag are read by the copies above: wait before they go out of scope
+        if (herr != hipSuccess) return hip_fail("seqset pack");
         if (flag) {
             s->has_n = true;
             if (hipMalloc(&s->d_nplane, wbytes) != hipSuccess) return fail("seqset nplane");
-            hipMemsetAsync(s->d_nplane, 0, wbytes, ctx->stream);
+            ok(hipMemsetAsync(s->d_nplane, 0, wbytes, ctx->stream));
             sp_launch_pack(ctx, d_ascii, d_off, s->d_word_off, s->d_len, n, nullptr, s->d_nplane, d_flag);
+            ok(hipGetLastError());
         }
     }
-    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ok(hipStreamSynchronize(ctx->stream));
+    if (herr != hipSuccess) return hip_fail("seqset upload");
     *out = s;
     return SP_OK;
 }

@@ -42,8 +42,13 @@ int main() {
     hipMemset(votes, 0, 1024 * 256 * 4);
     int columns = 2000;
     for (int threads : {1024, 512}) {
-        int per_cu = 0;
+        // the hand-made barrier spins: every workgroup of the launch has to be resident, so the grid is sized by the
+        // smaller of the two kernels' own occupancies (a grid sized for k_columns alone could leave k_columns_manual waiting
+        // for workgroups that can never start)
+        int per_cu = 0, per_cu_manual = 0;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_columns, threads, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_manual, k_columns_manual, threads, 0);
+        if (per_cu_manual < per_cu) per_cu = per_cu_manual;
         hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
         for (int blocks : {64, 256, per_cu * prop.multiProcessorCount}) {
             void* args[] = { &votes, &columns, &sink };
