@@ -343,6 +343,7 @@ def main():
     cons_cut = ctx.profile_get("cons_cut_windows")[2]
     cons_cols = ctx.profile_get("cons_columns")[2]
     cons_exp = ctx.profile_get("cons_expansions")[2]
+    cons_ticks = {k: ctx.profile_get("cons_ticks_" + k)[2] / 100.0 / max(1, args.steps) for k in ("reduce", "result", "search", "tail")}   # 100 MHz -> us
     avg_ms = ms_cells / max(1, launches)
     per_launch = lambda v: v / max(1, launches)
     achieved = per_launch(exec_bytes) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -423,7 +424,8 @@ def main():
             "kernel_ms": kernel_ms,
             "consensus": {"windows_per_step": cons_windows / max(1, args.steps), "launches_per_step": 2 * cons_windows / max(1, args.steps),
                           "cut_windows_per_step": cons_cut / max(1, args.steps), "expansions_per_step": cons_exp / max(1, args.steps),
-                          "nodes_expanded_per_step": cons_cols / max(1, args.steps)},
+                          "nodes_expanded_per_step": cons_cols / max(1, args.steps),
+                          "control_kernel_us_per_step": cons_ticks},
             "concordance": {"k1_gene_correct": k1_gene_ok, "k1_realigned": k1_realigned, "diplotypes_equal_truth": f"{ok}/{len(genes)} genes"},
             "pcie_inclusive_upload_s": t_up,
             "scoring_only": scoring, "cyp2d6": cyp, "cohort": cohort, "k5_chain_pairs": k5,

@@ -43,6 +43,8 @@ constexpr int CWIN = 512;       // consensus bases in front of the window kept i
 constexpr int RWORDS = 28;      // packed read words a wave keeps in LDS (448 bases around its tips)
 constexpr int NQ = 40;          // search nodes per problem: max_queue_size waiting + the children of one expansion + the complete one
 constexpr int MAXKIDS = 16;     // children of one expansion
+constexpr int CLUSTER = 16;     // workgroups whose vote words are summed by the last of them to finish
+constexpr int QSV = 2 * (CW + 1) * 5, QSL = 2 * CW * 4, QE = QSV + QSL + 2 * (CW + 1);   // one cluster's sums: exact votes (w[4], end), lookahead votes, cost growth, final-cost extra
 enum { F_ACTIVE = 1, F_FINISHED = 2, F_LOST = 4 };
 enum { M_NONE = 0, M_INIT = 1, M_WINDOW = 2, M_EXPAND = 3 };
 
@@ -74,6 +76,7 @@ struct CSearch {
     int32_t threshold, farthest, next_id, best_node, inflight, max_queue, per_size, wo_constraint;
     int32_t windows, cut_windows, expansions, pad;
     long long pops, best_final;
+    long long ticks[4];         // control kernel, 100 MHz wall clock: load + vote reduction / result of the step / search / tail
 };
 struct ConsMeta { int32_t e, c0, flags, pad; };
 
@@ -82,6 +85,7 @@ struct ConsMeta { int32_t e, c0, flags, pad; };
 constexpr int CMAXP = 24;
 struct ConsParams {
     int n, first, first_block, n_blocks, rpw;   // reads; flattened index of local read 0; first workgroup; workgroups; reads per wave
+    int first_cluster, n_clusters;              // clusters of CLUSTER consecutive workgroups (the last one may be smaller)
     int min_count, delta, et, allow_dual, window, cmp_len; double min_af;
     int cap;
     uint8_t* C;                 // [NQ][2][cap] base codes per node; consensus 2 shares [0, split_at) with consensus 1
@@ -100,11 +104,12 @@ template <int MAXP> struct ConsBatchT {
     unsigned long long* PL;     // [blocks][2][CW]     lookahead votes (one per read and tip)
     uint32_t* PC;               // [blocks][CW + 1]    growth of the node's cost at push j (expand: cost the child adds)
     uint32_t* PR;               // [blocks][CW + 1]    what unfinished reads add to a final cost (index n / child)
+    uint32_t* Q;                // [clusters][QE]      the words above summed over a cluster of workgroups, one u32 per field
     int total;
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; int total;
+    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; const int* cluster_prob; int total;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first; };
 
@@ -611,6 +616,42 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
     for (int x = threadIdx.x; x < CW + 1; x += blockDim.x) { B.PC[(size_t)blockIdx.x * (CW + 1) + x] = lc[x]; B.PR[(size_t)blockIdx.x * (CW + 1) + x] = lr[x]; }
 }
 
+// sums the vote words of CLUSTER consecutive workgroups of a problem (a few hundred workgroups would otherwise be summed by the one
+// workgroup of the control kernel, word by word from memory: 35 of its 45 us); one workgroup per cluster
+template <int MAXP>
+__global__ void __launch_bounds__(1024) cons_reduce_kernel(ConsBatchT<MAXP> B) {
+    int pi = 0;
+    if constexpr (MAXP == 0) pi = B.cluster_prob[blockIdx.x];
+    else {
+#pragma unroll
+        for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_cluster) pi = i;
+    }
+    const ConsParams P = B.p[pi];
+    if (P.work->done || P.work->mode == M_NONE) return;
+    const int cl = (int)blockIdx.x - P.first_cluster;
+    const int members = P.n_blocks - cl * CLUSTER < CLUSTER ? P.n_blocks - cl * CLUSTER : CLUSTER;
+    const size_t blk0 = (size_t)P.first_block + (size_t)cl * CLUSTER;
+    constexpr int EV = 2 * (CW + 1), EL = 2 * CW, EC = CW + 1;
+    for (int o = threadIdx.x; o < QE; o += blockDim.x) {
+        uint32_t sum = 0;
+        if (o < QSV) {
+            const int e = o / 5, f = o % 5;
+            if (f < 4) { for (int m = 0; m < members; ++m) sum += (uint32_t)((B.PV[(blk0 + m) * EV + e] >> (16 * f)) & 0xFFFFull); }
+            else for (int m = 0; m < members; ++m) sum += B.PE[(blk0 + m) * EV + e];
+        } else if (o < QSV + QSL) {
+            const int e = (o - QSV) / 4, f = (o - QSV) % 4;
+            for (int m = 0; m < members; ++m) sum += (uint32_t)((B.PL[(blk0 + m) * EL + e] >> (16 * f)) & 0xFFFFull);
+        } else if (o < QSV + QSL + EC) {
+            const int e = o - QSV - QSL;
+            for (int m = 0; m < members; ++m) sum += B.PC[(blk0 + m) * EC + e];
+        } else {
+            const int e = o - QSV - QSL - EC;
+            for (int m = 0; m < members; ++m) sum += B.PR[(blk0 + m) * EC + e];
+        }
+        B.Q[(size_t)blockIdx.x * QE + o] = sum;
+    }
+}
+
 // heaviest base of a vote column first (ties to the lower code)
 struct ColVotes { uint32_t w[4], end; };
 
@@ -640,9 +681,10 @@ __device__ __forceinline__ int col_candidates(const uint32_t* w5, int col, int c
 template <int MAXP>
 __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) {
     extern __shared__ uint8_t proc[];                     // nodes expanded per length (cap + 2 bytes, padded to 16)
-    __shared__ uint32_t sv[2][CW + 1][5];                 // summed exact votes: w[4], end
-    __shared__ uint32_t sl[2][CW][4];                     // summed lookahead votes
-    __shared__ uint32_t sc[CW + 1], sr[CW + 1];           // summed cost growth / final-cost extra
+    __shared__ uint32_t acc[QE];                          // the sums over all workgroups of the problem, in the order of the cluster sums:
+    uint32_t (*sv)[CW + 1][5] = reinterpret_cast<uint32_t (*)[CW + 1][5]>(acc);              // exact votes: w[4], end
+    uint32_t (*sl)[CW][4] = reinterpret_cast<uint32_t (*)[CW][4]>(acc + QSV);                // lookahead votes
+    uint32_t* sc = acc + QSV + QSL; uint32_t* sr = sc + (CW + 1);                              // cost growth / final-cost extra
     __shared__ CNode nh[NQ];
     __shared__ CWork wk;
     __shared__ CSearch ss;
@@ -651,9 +693,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     const ConsParams P = B.p[pi];
     const int tid = threadIdx.x;
     if (P.work->done) return;
-    for (int x = tid; x < 2 * (CW + 1) * 5; x += blockDim.x) (&sv[0][0][0])[x] = 0;
-    for (int x = tid; x < 2 * CW * 4; x += blockDim.x) (&sl[0][0][0])[x] = 0;
-    for (int x = tid; x < CW + 1; x += blockDim.x) { sc[x] = 0; sr[x] = 0; }
+    const long long tk0 = wall_clock64();
     for (int x = tid; x < (int)(sizeof(CNode) * NQ / 4); x += blockDim.x) ((uint32_t*)nh)[x] = ((const uint32_t*)P.nodes)[x];
     for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)&wk)[x] = ((const uint32_t*)P.work)[x];
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)&ss)[x] = ((const uint32_t*)P.srch)[x];
@@ -662,43 +702,24 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     if (tid == 0) { copy_from = -1; copy_len = 0; need_la = -1; }
     __syncthreads();
     const int mode_in = wk.mode, n_in = wk.mode == M_WINDOW ? wk.n : 0;
-    {
-        // element e of a workgroup's partial block: exact votes (V + E), lookahead words, cost growth, final-cost extra
-        const int EV = 2 * (CW + 1), EL = 2 * CW, EC = CW + 1, E = EV + EL + 2 * EC;
-        const int per = blockDim.x / E > 0 ? blockDim.x / E : 1;
-        const int e = tid % E, sub = tid / E;
-        if (sub < per && mode_in != M_NONE) {
-            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-            const int kind = e < EV ? 0 : e < EV + EL ? 1 : e < EV + EL + EC ? 2 : 3;
-            const int idx = kind == 0 ? e : kind == 1 ? e - EV : kind == 2 ? e - EV - EL : e - EV - EL - EC;
-            const int j = kind == 0 ? idx % (CW + 1) : kind == 1 ? idx % CW : idx;
-            const int top = mode_in == M_EXPAND ? wk.n_kids : n_in;
-            const bool wanted = kind == 1 ? mode_in != M_EXPAND : j <= top;
-            // sixteen independent loads in flight per thread: the words were written by another kernel and come from memory
-            if (wanted) for (int b0 = sub; b0 < P.n_blocks; b0 += per * 16) {
-                unsigned long long v[16]; uint32_t en[16];
+    // the cluster sums of the step (a few per problem), eight loads in flight per thread
+    for (int o = tid; o < QE; o += blockDim.x) {
+        uint32_t sum = 0;
+        if (mode_in != M_NONE) {
+            const uint32_t* q = B.Q + (size_t)P.first_cluster * QE + o;
+            for (int c0 = 0; c0 < P.n_clusters; c0 += 8) {
+                uint32_t v[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int b = b0 + u * per;
-                    const size_t blk = (size_t)P.first_block + (b < P.n_blocks ? b : 0);
-                    v[u] = kind == 0 ? B.PV[blk * EV + idx] : kind == 1 ? B.PL[blk * EL + idx] : kind == 2 ? (unsigned long long)B.PC[blk * EC + idx] : (unsigned long long)B.PR[blk * EC + idx];
-                    en[u] = kind == 0 ? B.PE[blk * EV + idx] : 0u;
-                    if (b >= P.n_blocks) { v[u] = 0; en[u] = 0; }
-                }
+                for (int u = 0; u < 8; ++u) v[u] = c0 + u < P.n_clusters ? q[(size_t)(c0 + u) * QE] : 0u;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    if (kind < 2) { a0 += (uint32_t)(v[u] & 0xFFFF); a1 += (uint32_t)((v[u] >> 16) & 0xFFFF); a2 += (uint32_t)((v[u] >> 32) & 0xFFFF); a3 += (uint32_t)(v[u] >> 48); }
-                    else a0 += (uint32_t)v[u];
-                    a4 += en[u];
-                }
+                for (int u = 0; u < 8; ++u) sum += v[u];
             }
-            if (kind == 0) { uint32_t* d = &sv[idx / (CW + 1)][j][0]; atomicAdd(d, a0); atomicAdd(d + 1, a1); atomicAdd(d + 2, a2); atomicAdd(d + 3, a3); atomicAdd(d + 4, a4); }
-            else if (kind == 1) { uint32_t* d = &sl[idx / CW][j][0]; atomicAdd(d, a0); atomicAdd(d + 1, a1); atomicAdd(d + 2, a2); atomicAdd(d + 3, a3); }
-            else if (kind == 2) atomicAdd(&sc[j], a0);
-            else atomicAdd(&sr[j], a0);
         }
+        acc[o] = sum;
     }
     __syncthreads();
+    const long long tk1 = wall_clock64();
+    long long tk2 = tk1, tk3 = tk1;
     if (tid < SP_WAVE) {
         // One wavefront runs the search.  Every lane reads the same LDS words (broadcast), so control flow is uniform; lane 0 writes,
         // and a wave-level fence separates its writes from the reads that follow.
@@ -801,6 +822,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         __threadfence();                                  // (the lookahead words written above are read below by other lanes)
         spw::wave_lds_sync();
         // ---------------------------------------------------------------- 2. the search, played forward over the tapes
+        tk2 = wall_clock64();
         if (lane == 0) { wk.mode = M_NONE; wk.n = 0; wk.replay = 0; wk.n_kids = 0; }
         spw::wave_lds_sync();
         for (int guard = 0; ; ++guard) {
@@ -928,6 +950,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         // the speculated part of a new window: lane j takes the heaviest lookahead vote for push j of every consensus that grows; the
         // window ends where a consensus has no lookahead votes left (or at cap)
         spw::wave_lds_sync();
+        tk3 = wall_clock64();
         if (need_la >= 0) {
             const uint32_t* la = P.la + (size_t)need_la * 2 * CW * 4;
             bool have = lane >= 1 && lane < CW && wk.T + lane < P.cap;
@@ -967,6 +990,8 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             }
         }
     }
+    if (tid == 0) { const long long tk4 = wall_clock64(); ss.ticks[0] += tk1 - tk0; ss.ticks[1] += tk2 - tk1; ss.ticks[2] += tk3 - tk2; ss.ticks[3] += tk4 - tk3; }
+    __syncthreads();
     for (int x = tid; x < (int)(sizeof(CNode) * NQ / 4); x += blockDim.x) ((uint32_t*)P.nodes)[x] = ((const uint32_t*)nh)[x];
     for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)P.work)[x] = ((const uint32_t*)&wk)[x];
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)P.srch)[x] = ((const uint32_t*)&ss)[x];
@@ -1035,11 +1060,11 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     ConsBatchT<MAXP> B; std::memset(&B, 0, sizeof B);
     B.n_prob = (int)n_prob;
     std::vector<ConsParams> hp(n_prob);                      // the descriptors; they end up in the kernel arguments or, for MAXP == 0, in device memory
-    std::vector<int> block_prob;
+    std::vector<int> block_prob, cluster_prob;
     std::vector<ConsSetup> setup(n_prob);
     std::vector<uint32_t> h_idx; std::vector<int32_t> h_off;
     std::vector<size_t> idx_at(n_prob), off_at(n_prob), c_at(n_prob), proc_at(n_prob);
-    size_t total = 0, c_bytes = 0, proc_bytes = 0; int max_cap = 0, n_blocks = 0;
+    size_t total = 0, c_bytes = 0, proc_bytes = 0; int max_cap = 0, n_blocks = 0, n_clusters = 0;
     for (uint32_t p = 0; p < n_prob; ++p) {
         const sp_cons_problem& q = probs[p];
         const uint32_t n = q.read_idx ? q.n : q.reads->n;
@@ -1052,8 +1077,10 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         const uint32_t per_block = (uint32_t)(CWAVES * P.rpw);
         const uint32_t nb = (n + per_block - 1) / per_block;
         P.n_blocks = (int)nb;
+        P.first_cluster = n_clusters; P.n_clusters = (int)((nb + CLUSTER - 1) / CLUSTER);
+        n_clusters += P.n_clusters;
         n_blocks += (int)nb;
-        if (MAXP == 0) block_prob.insert(block_prob.end(), nb, (int)p);
+        if (MAXP == 0) { block_prob.insert(block_prob.end(), nb, (int)p); cluster_prob.insert(cluster_prob.end(), (size_t)P.n_clusters, (int)p); }
         setup[p].reads = q.reads->view(); setup[p].n = (int)n; setup[p].first = (int)total;
         total += (size_t)nb * per_block;
         idx_at[p] = h_idx.size(); if (q.read_idx) h_idx.insert(h_idx.end(), q.read_idx, q.read_idx + n);
@@ -1081,11 +1108,12 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     B.PL = (unsigned long long*)sp_pool(ctx, "cons_pl", sizeof(unsigned long long) * (size_t)n_blocks * 2 * CW);
     B.PC = (uint32_t*)sp_pool(ctx, "cons_pc", sizeof(uint32_t) * (size_t)n_blocks * (CW + 1));
     B.PR = (uint32_t*)sp_pool(ctx, "cons_pr", sizeof(uint32_t) * (size_t)n_blocks * (CW + 1));
+    B.Q = (uint32_t*)sp_pool(ctx, "cons_q", sizeof(uint32_t) * (size_t)n_clusters * QE);
     uint8_t* d_is1 = (uint8_t*)sp_pool(ctx, "cons_is1", total);
     int32_t* d_sc = (int32_t*)sp_pool(ctx, "cons_scores", sizeof(int32_t) * 2 * total);
     CWork* h_work = (CWork*)sp_host_pool(ctx, "cons_work", sizeof(CWork) * n_prob);
     CSearch* h_srch = (CSearch*)sp_host_pool(ctx, "cons_srch", sizeof(CSearch) * n_prob);
-    if (!d_idx || !d_off || !d_C || !d_work || !d_srch || !d_nodes || !d_la || !d_proc || !d_info || !B.H || !B.meta || !B.PV || !B.PE || !B.PL || !B.PC || !B.PR ||
+    if (!d_idx || !d_off || !d_C || !d_work || !d_srch || !d_nodes || !d_la || !d_proc || !d_info || !B.H || !B.meta || !B.PV || !B.PE || !B.PL || !B.PC || !B.PR || !B.Q ||
         !d_is1 || !d_sc || !h_work || !h_srch)
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus buffers");
     for (uint32_t p = 0; p < n_prob; ++p) {
@@ -1097,7 +1125,10 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     if constexpr (MAXP == 0) {
         ConsParams* d_probs = (ConsParams*)sp_pool(ctx, "cons_probs", sizeof(ConsParams) * n_prob);
         int* d_block_prob = (int*)sp_pool(ctx, "cons_block_prob", sizeof(int) * block_prob.size());
-        if (!d_probs || !d_block_prob) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus descriptors");
+        int* d_cluster_prob = (int*)sp_pool(ctx, "cons_cluster_prob", sizeof(int) * cluster_prob.size());
+        if (!d_probs || !d_block_prob || !d_cluster_prob) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus descriptors");
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_cluster_prob, cluster_prob.data(), sizeof(int) * cluster_prob.size(), hipMemcpyHostToDevice, st));
+        B.cluster_prob = d_cluster_prob;
         SP_HIP_CHECK(ctx, hipMemcpyAsync(d_probs, hp.data(), sizeof(ConsParams) * n_prob, hipMemcpyHostToDevice, st));
         SP_HIP_CHECK(ctx, hipMemcpyAsync(d_block_prob, block_prob.data(), sizeof(int) * block_prob.size(), hipMemcpyHostToDevice, st));
         B.p = d_probs; B.block_prob = d_block_prob;
@@ -1136,6 +1167,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         const uint64_t limit = (uint64_t)64 * (uint64_t)(max_cap + 2) + 1024;
         for (;;) {
             hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
+            hipLaunchKernelGGL(cons_reduce_kernel<MAXP>, dim3((uint32_t)n_clusters), dim3(1024), 0, st, B);
             hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, st, B);
             ++pairs;
             if (--until_poll <= 0 || pairs >= limit) {
@@ -1161,10 +1193,13 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
     SP_HIP_CHECK(ctx, hipGetLastError());
     {   // launch statistics of the batch (sp_profile_get: cells = count)
-        uint64_t w = 0, cut = 0, ex = 0, pops = 0;
-        for (uint32_t p = 0; p < n_prob; ++p) { w += (uint64_t)h_srch[p].windows; cut += (uint64_t)h_srch[p].cut_windows; ex += (uint64_t)h_srch[p].expansions; pops += (uint64_t)h_srch[p].pops; }
+        uint64_t cut = 0, ex = 0, pops = 0;
+        for (uint32_t p = 0; p < n_prob; ++p) { cut += (uint64_t)h_srch[p].cut_windows; ex += (uint64_t)h_srch[p].expansions; pops += (uint64_t)h_srch[p].pops; }
         ctx->prof["cons_windows"].cells += pairs; ctx->prof["cons_windows"].launches += 2 * pairs;
         ctx->prof["cons_cut_windows"].cells += cut; ctx->prof["cons_expansions"].cells += ex; ctx->prof["cons_columns"].cells += pops;
+        // where the control kernel's time goes: ticks of the 100 MHz wall clock, the slowest problem of the batch (they run side by side)
+        static const char* tick_names[4] = { "cons_ticks_reduce", "cons_ticks_result", "cons_ticks_search", "cons_ticks_tail" };
+        for (int k = 0; k < 4; ++k) { long long m = 0; for (uint32_t p = 0; p < n_prob; ++p) m = std::max(m, h_srch[p].ticks[k]); ctx->prof[tick_names[k]].cells += (uint64_t)m; }
     }
     static const char dec[4] = { 'A', 'C', 'G', 'T' };
     int32_t rc = SP_OK;
