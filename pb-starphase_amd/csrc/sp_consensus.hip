@@ -37,7 +37,13 @@ namespace {
 
 constexpr int CB = 64;          // band
 constexpr int CH = 32;          // lane of diagonal 0
-constexpr int CWAVES = 16;      // waves per workgroup
+#ifndef SP_K8_WAVES
+#define SP_K8_WAVES 8
+#endif
+#ifndef SP_K8_MIN_WAVES
+#define SP_K8_MIN_WAVES 1
+#endif
+constexpr int CWAVES = SP_K8_WAVES;      // waves per workgroup
 constexpr int CW = 64;          // bases per window (<= 64: one lane per window column in the control kernel)
 constexpr int CWIN = 512;       // consensus bases in front of the window kept in LDS (offset_window + slack)
 constexpr int RWORDS = 28;      // packed read words a wave keeps in LDS (448 bases around its tips)
@@ -105,11 +111,12 @@ template <int MAXP> struct ConsBatchT {
     uint32_t* PC;               // [blocks][CW + 1]    growth of the node's cost at push j (expand: cost the child adds)
     uint32_t* PR;               // [blocks][CW + 1]    what unfinished reads add to a final cost (index n / child)
     uint32_t* Q;                // [clusters][QE]      the words above summed over a cluster of workgroups, one u32 per field
+    unsigned long long* dbg;    // SP_K8_TIMING builds: per launch index [4096][4] = slowest wave, slowest wave that placed no read, sum of waves, waves (ticks)
     int total;
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; const int* cluster_prob; int total;
+    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; const int* cluster_prob; int total;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first; };
 
@@ -130,8 +137,9 @@ __device__ __forceinline__ uint32_t vote_units(int d) { return d == 1 ? 12u : d 
 struct Dwfa { int H, e, c0, flags; };
 
 // the consensus now has T bases after c0; `nb` is its newest base.  rb(h) = read base at h, ca(pos) = consensus base at pos.
-template <class RB, class CA>
-__device__ __forceinline__ void dwfa_push_t(Dwfa& d, int n, RB rb, CA ca, int T, int nb, int et, int lane) {
+// extend(d, T): every diagonal of d as far as its read keeps matching the consensus, inside the read and the T columns
+template <class RB, class EXT>
+__device__ __forceinline__ void dwfa_push_t(Dwfa& d, int n, RB rb, EXT extend, int T, int nb, int et, int lane) {
     const int k = lane - CH;
     if (d.H >= 0 && d.H + k == T - 1 && d.H < n && rb(d.H) == nb) d.H += 1;                       // only the old tips can move
     while (!__ballot(d.H >= 0 && d.H + k == T)) {
@@ -142,12 +150,7 @@ __device__ __forceinline__ void dwfa_push_t(Dwfa& d, int n, RB rb, CA ca, int T,
         if (dn >= 0 && dn < n && dn + 1 + k >= 0 && dn + 1 > best) best = dn + 1;
         if (!__ballot(best >= 0)) { d.flags |= F_LOST; return; }
         d.H = best; d.e += 1;
-        for (;;) {
-            bool go = d.H >= 0 && d.H < n && d.H + k < T;
-            if (go) { const int x = rb(d.H); go = x < 4 && x == ca(d.c0 + d.H + k); }
-            if (!__ballot(go)) break;
-            if (go) d.H += 1;
-        }
+        extend(d, T);
     }
     if (et && __ballot(d.H == n)) d.flags |= F_FINISHED;
 }
@@ -295,7 +298,15 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
     } else {
         for (int Tl = 1; Tl <= span; ++Tl) {
             if (d.flags & (F_FINISHED | F_LOST)) break;
-            dwfa_push_t(d, rv.n, rbc, ca, Tl, ca(c0 + Tl - 1), et, lane);
+            dwfa_push_t(d, rv.n, rbc, [&](Dwfa& x, int Tc) {
+                const int kk = lane - CH;
+                for (;;) {
+                    bool go = x.H >= 0 && x.H < rv.n && x.H + kk < Tc;
+                    if (go) { const int b = rbc(x.H); go = b < 4 && b == ca(x.c0 + x.H + kk); }
+                    if (!__ballot(go)) break;
+                    if (go) x.H += 1;
+                }
+            }, Tl, ca(c0 + Tl - 1), et, lane);
         }
     }
     return d;
@@ -325,14 +336,14 @@ __device__ __forceinline__ int read_cost(const Dwfa& a0, const Dwfa& a1, bool du
 // the step: window mode pushes the chosen node through n bases, expand mode makes the children of a node, init builds the root
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int MAXP>
-__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<MAXP> B) {
+__global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_kernel(ConsBatchT<MAXP> B) {
     __shared__ unsigned long long lv[2][CW + 1];          // exact votes after j pushes (column T + j) / of child j
     __shared__ uint32_t le[2][CW + 1];
     __shared__ unsigned long long ll[2][CW];              // lookahead: ll[i][x] predicts column T + n + 1 + x
     __shared__ uint32_t lc[CW + 1], lr[CW + 1];           // cost growth at push j / of child j; final-cost extra of the end state / child
     __shared__ uint8_t cwin[2][CWIN + CW];                // consensus bases [T - CWIN, T + n)
     __shared__ uint32_t rwin[CWAVES][2][RWORDS + 2];      // packed read window of the wave (+ N plane)
-    __shared__ uint32_t spk[2][CW / 16 + 2];              // the window's bases, 2 bits each (clean runs are compared 16 bases at a time)
+    __shared__ uint32_t cpk[2][(CWIN + CW) / 16 + 2];     // the same bases, 2 bits each (runs are compared 16 bases at a time); the window starts at word CWIN / 16
     __shared__ ActScratch act[CWAVES];
     const int pi = block_problem<MAXP>(B);
     const ConsParams P = B.p[pi];
@@ -359,11 +370,12 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
         cwin[i][y] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 2 * (CW / 16 + 2)) {
-        const int i = threadIdx.x / (CW / 16 + 2), w = threadIdx.x % (CW / 16 + 2);
+    constexpr int CPW = (CWIN + CW) / 16 + 2;
+    if (threadIdx.x < 2 * CPW) {
+        const int i = threadIdx.x / CPW, w = threadIdx.x % CPW;
         uint32_t word = 0;
-        for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < n) word |= (uint32_t)(cwin[i][CWIN + x] & 3u) << (b << 1); }
-        spk[i][w] = word;
+        for (int b = 0; b < 16; ++b) { const int y = w * 16 + b; if (y < CWIN + n) word |= (uint32_t)(cwin[i][y] & 3u) << (b << 1); }
+        cpk[i][w] = word;
     }
     __syncthreads();
     const size_t plane = (size_t)B.total;                 // reads per state plane
@@ -371,6 +383,9 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
         const int r = (((int)blockIdx.x - P.first_block) * CWAVES + wave) * P.rpw + rr;
         if (r >= P.n) break;
         const size_t g = (size_t)P.first + r;
+#ifdef SP_K8_TIMING
+        const long long wt0 = wall_clock64();
+#endif
         const ReadInfo ri = B.info[g];
         ReadView rv; rv.w = ri.w; rv.np = ri.np; rv.n = ri.n;
         Dwfa d0, d1;
@@ -429,13 +444,43 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
             }
         };
         // one column the slow way: consensus i grows by nb_i when g_i; a late read is placed; the two states are compared
+        // the extension of a new wavefront: 16 bases per step out of the packed windows where both lie inside them (window mode; the base
+        // a child appends in expand mode is not in the window), base by base elsewhere
+        auto extender = [&](const ConsAccess& cacc, int i) {
+            return [&cacc, i, &rb, wave, rbase, w0, lane, mode, &rv](Dwfa& d, int Tc) {
+                const int k = lane - CH;
+                for (;;) {
+                    int left = rv.n - d.H; { const int l2 = Tc - (d.H + k); left = l2 < left ? l2 : left; }
+                    const bool go = d.H >= 0 && left > 0;
+                    int nm = 0; bool more = false;
+                    if (go) {
+                        const int xr = d.H - rbase, yc = d.c0 + d.H + k - w0;
+                        if (mode == M_WINDOW && xr >= 0 && xr < RWORDS * 16 && yc >= 0 && yc < CWIN + CW) {
+                            const uint32_t a = __builtin_amdgcn_alignbit(rwin[wave][0][(xr >> 4) + 1], rwin[wave][0][xr >> 4], (uint32_t)(xr & 15) << 1);
+                            const uint32_t nn = __builtin_amdgcn_alignbit(rwin[wave][1][(xr >> 4) + 1], rwin[wave][1][xr >> 4], (uint32_t)(xr & 15) << 1);
+                            const uint32_t b = __builtin_amdgcn_alignbit(cpk[i][(yc >> 4) + 1], cpk[i][yc >> 4], (uint32_t)(yc & 15) << 1);
+                            const uint32_t xo = a ^ b, mm = ((xo | (xo >> 1)) | nn) & 0x55555555u;
+                            nm = mm ? (__builtin_ctz(mm) >> 1) : 16;
+                            nm = nm < left ? nm : left;
+                            more = nm == 16 && left > 16;
+                        } else {
+                            const int x = rb(d.H);
+                            nm = (x < 4 && x == cacc.at(d.c0 + d.H + k)) ? 1 : 0;
+                            more = nm == 1 && left > 1;
+                        }
+                        d.H += nm;
+                    }
+                    if (!__ballot(more)) break;
+                }
+            };
+        };
         auto column = [&](Dwfa& a0, Dwfa& a1, bool dualrun, int g0, int g1, int nb0, int nb1, int len, const ConsAccess& c0a, const ConsAccess& c1a) {
             if (g0) {
-                if (a0.flags & F_ACTIVE) { if (!(a0.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a0, rv.n, rb, [&](int p) { return c0a.at(p); }, len - a0.c0, nb0, P.et, lane); }
+                if (a0.flags & F_ACTIVE) { if (!(a0.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a0, rv.n, rb, extender(c0a, c0a.i), len - a0.c0, nb0, P.et, lane); }
                 else if (ri.off == len) { a0 = activate_late(rv, c0a, &act[wave], ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
             }
             if (dualrun && g1) {
-                if (a1.flags & F_ACTIVE) { if (!(a1.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a1, rv.n, rb, [&](int p) { return c1a.at(p); }, len - a1.c0, nb1, P.et, lane); }
+                if (a1.flags & F_ACTIVE) { if (!(a1.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a1, rv.n, rb, extender(c1a, c1a.i), len - a1.c0, nb1, P.et, lane); }
                 else if (ri.off == len) { a1 = activate_late(rv, c1a, &act[wave], ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
             }
             if (dualrun) {
@@ -514,7 +559,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
                 const int x = x0 + done, jj = j0 + done;
                 const uint32_t a = __builtin_amdgcn_alignbit(rwin[wave][0][(x >> 4) + 1], rwin[wave][0][x >> 4], (uint32_t)(x & 15) << 1);
                 const uint32_t nn = __builtin_amdgcn_alignbit(rwin[wave][1][(x >> 4) + 1], rwin[wave][1][x >> 4], (uint32_t)(x & 15) << 1);
-                const uint32_t b = __builtin_amdgcn_alignbit(spk[i][(jj >> 4) + 1], spk[i][jj >> 4], (uint32_t)(jj & 15) << 1);
+                const uint32_t b = __builtin_amdgcn_alignbit(cpk[i][CWIN / 16 + (jj >> 4) + 1], cpk[i][CWIN / 16 + (jj >> 4)], (uint32_t)(jj & 15) << 1);
                 const uint32_t xr = a ^ b, mm = ((xr | (xr >> 1)) | nn) & 0x55555555u;
                 int run = mm ? (__builtin_ctz(mm) >> 1) : 16;
                 run = run < len - done ? run : len - done;
@@ -524,6 +569,9 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
             return done;
         };
         int j = 0;
+#ifdef SP_K8_TIMING
+        int slow_cols = 0, multi_tip = 0, zero_run = 0;
+#endif
         while (j < n) {
             // A consensus whose state has ONE tip that keeps matching moves nothing but that tip: such a clean run is applied in one go
             // (the tip's position grows by m, the votes of the m columns are the m read bases behind it, one lane per column).
@@ -538,7 +586,11 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
                     if (a.flags & (F_FINISHED | F_LOST)) continue;
                     const int Tl = T + j - a.c0, k = lane - CH;
                     const unsigned long long tm = __ballot(a.H >= 0 && a.H + k == Tl);
-                    if (__builtin_popcountll(tm) != 1) { m = 0; continue; }
+                    if (__builtin_popcountll(tm) != 1) {
+#ifdef SP_K8_TIMING
+                        multi_tip += 1;
+#endif
+                        m = 0; continue; }
                     const int tl = __builtin_ctzll(tm), h = __builtin_amdgcn_readlane(a.H, tl);
                     int room = rv.n - h; room = room < m ? room : m;
                     const int run = room > 0 ? match_run(h - rbase, i, j, room) : 0;
@@ -569,6 +621,9 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
                 j += m;
                 continue;
             }
+#ifdef SP_K8_TIMING
+            slow_cols += 1;
+#endif
             const int before = read_cost(d0, d1, dualrun);
             column(d0, d1, dualrun, go0, go1, cwin[0][CWIN + j], cwin[1][CWIN + j], T + j + 1, ca0, ca1);
             const int grow = read_cost(d0, d1, dualrun) - before;
@@ -606,6 +661,15 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_step_kernel(ConsBatchT<
         store(d0, node, out_slot, 0);
         if (dualrun) store(d1, node, out_slot, 1);
         spw::wave_lds_sync();
+#ifdef SP_K8_TIMING
+        if (B.dbg && lane == 0 && Wp->pad < 256 && g < 16384) {
+            const unsigned long long dt = (unsigned long long)(wall_clock64() - wt0);
+            const bool placed = ri.off > T && ri.off <= T + n;
+            // [launch][read]: ticks | slow columns << 32 | multi-tip events << 40 | placed << 48 | window bases << 52
+            B.dbg[(size_t)Wp->pad * 16384 + g] = (dt & 0xFFFFFFFFull) | ((unsigned long long)(slow_cols & 255) << 32) | ((unsigned long long)(multi_tip & 255) << 40) |
+                                                  ((unsigned long long)placed << 48) | ((unsigned long long)n << 52);
+        }
+#endif
     }
     __syncthreads();
     for (int x = threadIdx.x; x < 2 * (CW + 1); x += blockDim.x) {
@@ -823,7 +887,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         spw::wave_lds_sync();
         // ---------------------------------------------------------------- 2. the search, played forward over the tapes
         tk2 = wall_clock64();
-        if (lane == 0) { wk.mode = M_NONE; wk.n = 0; wk.replay = 0; wk.n_kids = 0; }
+        if (lane == 0) { wk.mode = M_NONE; wk.n = 0; wk.replay = 0; wk.n_kids = 0; wk.pad += 1; }
         spw::wave_lds_sync();
         for (int guard = 0; ; ++guard) {
             if (guard > 100000) { if (lane == 0) wk.done = 1; break; }
@@ -1109,6 +1173,10 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     B.PC = (uint32_t*)sp_pool(ctx, "cons_pc", sizeof(uint32_t) * (size_t)n_blocks * (CW + 1));
     B.PR = (uint32_t*)sp_pool(ctx, "cons_pr", sizeof(uint32_t) * (size_t)n_blocks * (CW + 1));
     B.Q = (uint32_t*)sp_pool(ctx, "cons_q", sizeof(uint32_t) * (size_t)n_clusters * QE);
+#ifdef SP_K8_TIMING
+    B.dbg = (unsigned long long*)sp_pool(ctx, "cons_dbg", (size_t)256 * 16384 * 8);
+    (void)hipMemsetAsync(B.dbg, 0, (size_t)256 * 16384 * 8, st);
+#endif
     uint8_t* d_is1 = (uint8_t*)sp_pool(ctx, "cons_is1", total);
     int32_t* d_sc = (int32_t*)sp_pool(ctx, "cons_scores", sizeof(int32_t) * 2 * total);
     CWork* h_work = (CWork*)sp_host_pool(ctx, "cons_work", sizeof(CWork) * n_prob);
@@ -1192,6 +1260,14 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     SP_HIP_CHECK(ctx, hipMemcpyAsync(h_sc.data(), d_sc, sizeof(int32_t) * 2 * total, hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
     SP_HIP_CHECK(ctx, hipGetLastError());
+#ifdef SP_K8_TIMING
+    if (std::getenv("SP_K8_DUMP")) {
+        std::vector<unsigned long long> h((size_t)256 * 16384);
+        (void)hipMemcpy(h.data(), B.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        FILE* f = std::fopen(std::getenv("SP_K8_DUMP"), "ab");
+        if (f) { const unsigned long long tot = total; std::fwrite(&tot, 8, 1, f); std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+    }
+#endif
     {   // launch statistics of the batch (sp_profile_get: cells = count)
         uint64_t cut = 0, ex = 0, pops = 0;
         for (uint32_t p = 0; p < n_prob; ++p) { cut += (uint64_t)h_srch[p].cut_windows; ex += (uint64_t)h_srch[p].expansions; pops += (uint64_t)h_srch[p].pops; }

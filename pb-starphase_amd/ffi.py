@@ -7,7 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libstarphase_hip.so")
+    """the in-tree library; SP_LIB_PATH names another build of it (kernel-variant experiments)"""
+    return os.environ.get("SP_LIB_PATH") or os.path.join(_HERE, "libstarphase_hip.so")
 
 
 class StarphaseError(RuntimeError):
