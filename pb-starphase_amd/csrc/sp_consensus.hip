@@ -696,22 +696,34 @@ __global__ void __launch_bounds__(1024) cons_reduce_kernel(ConsBatchT<MAXP> B) {
     const int members = P.n_blocks - cl * CLUSTER < CLUSTER ? P.n_blocks - cl * CLUSTER : CLUSTER;
     const size_t blk0 = (size_t)P.first_block + (size_t)cl * CLUSTER;
     constexpr int EV = 2 * (CW + 1), EL = 2 * CW, EC = CW + 1;
+    // all CLUSTER loads of an output are issued before the first is used (a loop over `members` would wait for each in turn)
     for (int o = threadIdx.x; o < QE; o += blockDim.x) {
-        uint32_t sum = 0;
+        uint32_t v[CLUSTER];
         if (o < QSV) {
             const int e = o / 5, f = o % 5;
-            if (f < 4) { for (int m = 0; m < members; ++m) sum += (uint32_t)((B.PV[(blk0 + m) * EV + e] >> (16 * f)) & 0xFFFFull); }
-            else for (int m = 0; m < members; ++m) sum += B.PE[(blk0 + m) * EV + e];
+            if (f < 4) {
+#pragma unroll
+                for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? (uint32_t)((B.PV[(blk0 + m) * EV + e] >> (16 * f)) & 0xFFFFull) : 0u;
+            } else {
+#pragma unroll
+                for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? B.PE[(blk0 + m) * EV + e] : 0u;
+            }
         } else if (o < QSV + QSL) {
             const int e = (o - QSV) / 4, f = (o - QSV) % 4;
-            for (int m = 0; m < members; ++m) sum += (uint32_t)((B.PL[(blk0 + m) * EL + e] >> (16 * f)) & 0xFFFFull);
+#pragma unroll
+            for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? (uint32_t)((B.PL[(blk0 + m) * EL + e] >> (16 * f)) & 0xFFFFull) : 0u;
         } else if (o < QSV + QSL + EC) {
             const int e = o - QSV - QSL;
-            for (int m = 0; m < members; ++m) sum += B.PC[(blk0 + m) * EC + e];
+#pragma unroll
+            for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? B.PC[(blk0 + m) * EC + e] : 0u;
         } else {
             const int e = o - QSV - QSL - EC;
-            for (int m = 0; m < members; ++m) sum += B.PR[(blk0 + m) * EC + e];
+#pragma unroll
+            for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? B.PR[(blk0 + m) * EC + e] : 0u;
         }
+        uint32_t sum = 0;
+#pragma unroll
+        for (int m = 0; m < CLUSTER; ++m) sum += v[m];
         B.Q[(size_t)blockIdx.x * QE + o] = sum;
     }
 }
