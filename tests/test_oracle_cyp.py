@@ -77,3 +77,77 @@ def test_overlap_score(oracle):
     f = oracle.L.osp_cyp_overlap_score
     f.restype = C.c_double
     assert f(0, 1, 1, 2) == 0.0 and f(0, 10, 1, 5) == 1.0 and f(0, 10, 5, 100) == 0.5 and f(15, 100, 0, 20) == 0.25
+
+
+# ------------------------------------------------------------------ K9: the graph statement against brute-force joint enumeration
+def _edit_distance(a, b):
+    """plain global unit-cost edit distance (row by row; the in-row dependency is a running minimum)"""
+    a = np.frombuffer(a.encode(), np.uint8); b = np.frombuffer(b.encode(), np.uint8)
+    idx = np.arange(len(b) + 1)
+    row = idx.copy()
+    for i in range(1, len(a) + 1):
+        diag = row[:-1] + (b != a[i - 1])
+        new = np.empty_like(row)
+        new[0] = i
+        new[1:] = np.minimum(diag, row[1:] + 1)
+        row = np.minimum.accumulate(new - idx) + idx          # insertions along the row
+    return int(row[-1])
+
+
+def test_variant_states_against_joint_enumeration(oracle):
+    """osp_cyp_variant_states (alignment to the variant graph) against the definition it has to meet: over all
+    compatible subsets of the variants inside the aligned stretch, the subsets of minimum edit distance to the sequence; a variant is
+    1 when every such subset holds it, 0 when none does, 2 when they disagree.  Variants sit next to and on top of each other."""
+    rng = np.random.default_rng(9)
+    n_checked = n_two = 0
+    for rep in range(6):
+        backbone = "".join(rng.choice(list("ACGT"), 260))
+        # a cluster: SNV, an overlapping 2-base deletion, an adjacent insertion, a far SNV and a far deletion
+        p = int(rng.integers(60, 120))
+        other = lambda c: "ACGT"[("ACGT".index(c) + 1 + int(rng.integers(0, 3))) % 4]
+        variants = [(p, backbone[p], other(backbone[p])),
+                    (p, backbone[p:p + 3], backbone[p]),
+                    (p + 3, backbone[p + 3], backbone[p + 3] + "".join(rng.choice(list("ACGT"), 2))),
+                    (p + 5, backbone[p + 5], other(backbone[p + 5])),
+                    (p + 60, backbone[p + 60], other(backbone[p + 60])),
+                    (p + 80, backbone[p + 80:p + 84], backbone[p + 80])]
+        variants.sort(key=lambda v: v[0])
+        pos, refs, alts = [v[0] for v in variants], [v[1] for v in variants], [v[2] for v in variants]
+        nv = len(variants)
+        compatible = []
+        for mask in range(1 << nv):
+            chosen = [v for v in range(nv) if mask >> v & 1]
+            if all(variants[x][0] + len(variants[x][1]) <= variants[y][0] for x, y in zip(chosen, chosen[1:])):
+                compatible.append(chosen)
+
+        def applied(chosen, lo, hi):
+            out, at = [], lo
+            for v in chosen:
+                out.append(backbone[at:variants[v][0]]); out.append(variants[v][2]); at = variants[v][0] + len(variants[v][1])
+            out.append(backbone[at:hi])
+            return "".join(out)
+        for k in range(5):
+            truth = compatible[int(rng.integers(0, len(compatible)))]
+            seq = applied(truth, 0, len(backbone))
+            if k % 2:                                                            # a substitution inside the cluster makes ties likely
+                q = min(len(seq) - 1, p + int(rng.integers(0, 8)))
+                seq = seq[:q] + other(seq[q]) + seq[q + 1:]
+            if k == 4:                                                           # a third base at the far SNV: reference and alternate cost the same
+                v = next(x for x in range(nv) if variants[x][0] == p + 60)
+                third = next(c for c in "ACGT" if c not in (variants[v][1], variants[v][2]))
+                seq, truth = backbone[:p + 60] + third + backbone[p + 61:], []
+            states, aln = of.oracle_variant_states(oracle, seq, backbone, pos, refs, alts)
+            assert aln is not None
+            a0, a1, b0, b1, _nm = aln
+            inside = [v for v in range(nv) if variants[v][0] >= b0 and variants[v][0] + len(variants[v][1]) <= b1]
+            subsets = [c for c in compatible if all(v in inside for v in c)]
+            dist = [_edit_distance(seq[a0:a1], applied(c, b0, b1)) for c in subsets]
+            best = [set(c) for c, d in zip(subsets, dist) if d == min(dist)]
+            for v in range(nv):
+                want = 3 if v not in inside else 1 if all(v in c for c in best) else 0 if not any(v in c for c in best) else 2
+                assert states[v] == want, (rep, k, v, variants[v], states.tolist(), best)
+                n_checked += 1; n_two += want == 2
+            if k % 2 == 0 and k < 4:                                             # the isolated variants of a noise-free sequence are the ones it was built from
+                far = [v for v in range(nv) if variants[v][0] >= p + 60]             # (inside the cluster another subset may spell the same bases)
+                assert [v for v in far if states[v] == 1] == [v for v in truth if v in far]
+    assert n_checked >= 100 and n_two >= 1
