@@ -781,6 +781,44 @@ int32_t sp_result_insert(sp_result* result, const char* gene, const sp_gene_deta
 int32_t sp_result_json(sp_result* result, const char** text, uint64_t* len);
 int32_t sp_result_save(sp_result* result, const char* path);                    /* gzip when the name ends in ".gz" */
 
+/* ------------------------------------------------------------------ f2: decoding the input files (host only)
+ * What the reference gets from rust-htslib: the records of an indexed BAM that overlap a region (diplotype_hla_batch,
+ * src/hla/caller.rs:523-596; the CYP2D6 read collection, src/cyp2d6/caller.rs:96-139) and the records of a VCF around a position
+ * (load_vcf_variants / load_sv_vcf_variants, src/diplotyper.rs:551-857).  BGZF is read with zlib; a BAM is read through its .bai when
+ * "<path>.bai" (or "<path minus .bam>.bai") exists and by a linear scan otherwise; a VCF (plain, gzip or bgzip) is read into memory
+ * once -- no tabix index is needed for files of one sample's PGx-gene size, and none is used.  CRAM is not read.
+ * Pointers handed out belong to the reader and stay valid until its next fetch call (or its free). */
+typedef struct sp_bam sp_bam;
+int32_t sp_bam_open(const char* path, sp_bam** out, char* err, uint32_t err_cap);
+void    sp_bam_free(sp_bam* bam);
+const char* sp_bam_last_error(const sp_bam* bam);
+int32_t sp_bam_references(const sp_bam* bam, uint32_t* n, const char* const** names, const uint64_t** lengths);   /* @SQ of the header */
+typedef struct {                                  /* one alignment record */
+    const char* qname; uint32_t flag, mapq; int32_t ref_id, reserved; int64_t pos, end;   /* 0-based [pos, end) on the reference (end from the CIGAR) */
+    uint32_t l_seq, n_cigar; const uint32_t* cigar;                                         /* BAM encoding: len << 4 | op */
+} sp_bam_read;
+/* the records overlapping [start, end) of chrom in file order; exclude_flags drops records with any of these FLAG bits; dedupe != 0
+ * drops a record whose QNAME was handed out since sp_bam_open / sp_bam_forget (the reference's qnames_checked set, :532,565-570).
+ * bases / offsets: the SEQ fields as stored (reference-forward ASCII, "=ACMGRSVTWYHKDBN"), concatenated, n + 1 offsets -- the
+ * arguments of sp_seqset_upload. */
+int32_t sp_bam_fetch(sp_bam* bam, const char* chrom, uint64_t start, uint64_t end, uint32_t exclude_flags, int32_t dedupe,
+                     const sp_bam_read** reads, uint32_t* n, const char** bases, const uint64_t** offsets);
+int32_t sp_bam_forget(sp_bam* bam);               /* empties the set of QNAMEs seen */
+
+typedef struct sp_vcf sp_vcf;
+int32_t sp_vcf_open(const char* path, sp_vcf** out, char* err, uint32_t err_cap);
+void    sp_vcf_free(sp_vcf* vcf);
+const char* sp_vcf_last_error(const sp_vcf* vcf);
+int32_t sp_vcf_samples(const sp_vcf* vcf, uint32_t* n, const char* const** names);
+/* small variants: one sp_vcf_allele per ALT allele of every record of chrom that overlaps [start, end), for one sample (NULL = the
+ * first); gt is the state of THAT allele in the sample's GT -- SP_GT_HOM_ALT a/a, SP_GT_HET_FLIP a|x, SP_GT_HET_PHASED x|a,
+ * SP_GT_HET_UNPHASED a/x or x/a, SP_GT_HOM_REF when the allele is not called; ps = FORMAT/PS of a phased GT or -1.  Records whose GT
+ * is missing or not diploid are skipped (src/diplotyper.rs:606-640).  The rows are the input of sp_variant_gene_problem. */
+int32_t sp_vcf_alleles(sp_vcf* vcf, const char* sample, const char* chrom, uint64_t start, uint64_t end, const sp_vcf_allele** out, uint32_t* n);
+/* structural variants (src/diplotyper.rs:739-857): single-ALT records of chrom with INFO/SVTYPE=DEL that overlap [start, end); the
+ * deleted region is [POS - 1, INFO/END).  SP_ERR_INVALID_ARG where the reference bails: a record without SVTYPE or a DEL without END. */
+int32_t sp_vcf_deletions(sp_vcf* vcf, const char* sample, const char* chrom, uint64_t start, uint64_t end, const sp_vcf_deletion** out, uint32_t* n);
+
 /* ------------------------------------------------------------------ profiling hooks (bench.py)
  * HIP-event timing of the dominant kernel on the context's own stream. */
 int32_t sp_profile_reset(sp_ctx* ctx);

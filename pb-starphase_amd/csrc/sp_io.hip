@@ -1,0 +1,411 @@
+// sp_io.hip -- decoding the input files (host only): BGZF / BAM / BAI and VCF.
+//
+// Replaces what the reference gets from rust-htslib: IndexedReader::fetch + records() over a gene region (src/hla/caller.rs:523-596,
+// src/cyp2d6/caller.rs:96-139) and the region fetches of load_vcf_variants / load_sv_vcf_variants (src/diplotyper.rs:551-857).  The
+// formats are the published ones (SAMv1 section 4: BGZF blocks, BAM records, the BAI binning index; VCFv4.2); nothing here is taken from
+// htslib.  Outputs are the library's own inputs: ASCII bases + offsets for sp_seqset_upload, sp_vcf_allele / sp_vcf_deletion rows for
+// sp_variant_gene_problem.
+#include "sp_internal.h"
+#include <zlib.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace {
+
+void put_err(char* err, uint32_t cap, const std::string& m) { if (err && cap) { const size_t k = std::min<size_t>(cap - 1, m.size()); std::memcpy(err, m.data(), k); err[k] = '\0'; } }
+
+// ------------------------------------------------------------------------------------------------ BGZF
+// a series of gzip members of at most 64 KiB, each with a 'BC' extra field holding its size; a virtual offset is
+// (file offset of the block << 16) | offset inside the inflated block
+struct Bgzf {
+    FILE* f = nullptr;
+    std::vector<uint8_t> raw, block;
+    uint64_t block_at = 0, next_at = 0;           // file offsets of the block in `block` and of the one after it
+    size_t pos = 0;                               // read position inside `block`
+    bool eof = false; std::string err;
+
+    bool open(const char* path) { f = std::fopen(path, "rb"); return f != nullptr; }
+    ~Bgzf() { if (f) std::fclose(f); }
+    bool load(uint64_t at) {
+        block.clear(); pos = 0; block_at = at;
+        if (fseeko(f, (off_t)at, SEEK_SET) != 0) { err = "seek failed"; return false; }
+        uint8_t h[18];
+        const size_t got = std::fread(h, 1, 18, f);
+        if (got == 0) { eof = true; next_at = at; return true; }
+        if (got < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
+        const unsigned xlen = h[10] | (h[11] << 8);
+        // the BC subfield is the first one in every file htslib / bgzip writes; walk the extra field all the same
+        std::vector<uint8_t> extra(xlen);
+        std::memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
+        if (xlen > 6 && std::fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6) { err = "truncated BGZF header"; return false; }
+        int bsize = -1;
+        for (size_t x = 0; x + 4 <= xlen;) {
+            const unsigned slen = extra[x + 2] | (extra[x + 3] << 8);
+            if (extra[x] == 'B' && extra[x + 1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = extra[x + 4] | (extra[x + 5] << 8);
+            x += 4 + slen;
+        }
+        if (bsize < 0) { err = "BGZF block without a BC field"; return false; }
+        const size_t total = (size_t)bsize + 1, header = 12 + xlen;
+        if (total < header + 8) { err = "corrupt BGZF block size"; return false; }
+        raw.resize(total - header);
+        const size_t had = xlen < 6 ? 6 - xlen : 0;                   // bytes of the payload already read with the fixed 18
+        if (had) std::memcpy(raw.data(), h + 12 + xlen, had);
+        if (std::fread(raw.data() + had, 1, raw.size() - had, f) != raw.size() - had) { err = "truncated BGZF block"; return false; }
+        const uint8_t* tail = raw.data() + raw.size() - 8;
+        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        block.resize(isize);
+        if (isize) {
+            z_stream z{};
+            if (inflateInit2(&z, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
+            z.next_in = raw.data(); z.avail_in = (uInt)(raw.size() - 8); z.next_out = block.data(); z.avail_out = isize;
+            const int rc = inflate(&z, Z_FINISH);
+            inflateEnd(&z);
+            if (rc != Z_STREAM_END || z.avail_out != 0) { err = "corrupt BGZF block"; return false; }
+            const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), block.data(), isize) != crc) { err = "BGZF block fails its CRC"; return false; }
+        }
+        next_at = at + total;
+        return true;
+    }
+    bool seek(uint64_t voffset) { eof = false; if (!load(voffset >> 16)) return false; pos = (size_t)(voffset & 0xFFFF); return pos <= block.size(); }
+    uint64_t tell() const { return pos < block.size() ? (block_at << 16) | pos : (next_at << 16); }
+    // n bytes, crossing blocks; false at the end of the file (or on an error: err is set)
+    bool read(void* out, size_t n) {
+        uint8_t* o = (uint8_t*)out;
+        while (n) {
+            if (pos >= block.size()) { if (eof) return false; if (!load(next_at)) return false; if (eof) return false; continue; }
+            const size_t k = std::min(n, block.size() - pos);
+            std::memcpy(o, block.data() + pos, k); o += k; pos += k; n -= k;
+        }
+        return true;
+    }
+};
+
+uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+// the bins of the BAI scheme that overlap [beg, end) (SAMv1 5.3)
+void reg2bins(uint64_t beg, uint64_t end, std::vector<uint32_t>& bins) {
+    --end;
+    bins.push_back(0);
+    for (uint32_t k = 1 + (uint32_t)(beg >> 26); k <= 1 + (uint32_t)(end >> 26); ++k) bins.push_back(k);
+    for (uint32_t k = 9 + (uint32_t)(beg >> 23); k <= 9 + (uint32_t)(end >> 23); ++k) bins.push_back(k);
+    for (uint32_t k = 73 + (uint32_t)(beg >> 20); k <= 73 + (uint32_t)(end >> 20); ++k) bins.push_back(k);
+    for (uint32_t k = 585 + (uint32_t)(beg >> 17); k <= 585 + (uint32_t)(end >> 17); ++k) bins.push_back(k);
+    for (uint32_t k = 4681 + (uint32_t)(beg >> 14); k <= 4681 + (uint32_t)(end >> 14); ++k) bins.push_back(k);
+}
+
+bool slurp(const char* path, std::vector<uint8_t>& out) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    uint8_t buf[1 << 16]; size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
+    std::fclose(f);
+    return true;
+}
+
+} // namespace
+
+struct sp_bam {
+    Bgzf z; std::string err;
+    std::vector<std::string> ref_names; std::vector<uint64_t> ref_len; std::vector<const char*> ref_ptr;
+    uint64_t first_record = 0;                    // virtual offset of the first alignment
+    // index
+    bool indexed = false;
+    struct RefIndex { std::vector<std::pair<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins; std::vector<uint64_t> linear; };
+    std::vector<RefIndex> index;
+    std::set<std::string> seen;
+    // the last fetch
+    std::vector<sp_bam_read> reads; std::vector<std::string> names; std::vector<std::vector<uint32_t>> cigars; std::string bases; std::vector<uint64_t> offsets;
+};
+
+namespace {
+
+int32_t bam_fail(sp_bam* b, const std::string& m) { b->err = m; return SP_ERR_INVALID_ARG; }
+
+bool load_bai(sp_bam* b, const std::string& path) {
+    std::vector<uint8_t> d;
+    if (!slurp(path.c_str(), d) || d.size() < 8 || std::memcmp(d.data(), "BAI\1", 4) != 0) return false;
+    size_t at = 4;
+    auto need = [&](size_t n) { return at + n <= d.size(); };
+    if (!need(4)) return false;
+    const uint32_t n_ref = le32(d.data() + at); at += 4;
+    b->index.assign(n_ref, {});
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if (!need(4)) return false;
+        const uint32_t n_bin = le32(d.data() + at); at += 4;
+        for (uint32_t k = 0; k < n_bin; ++k) {
+            if (!need(8)) return false;
+            const uint32_t bin = le32(d.data() + at), n_chunk = le32(d.data() + at + 4); at += 8;
+            if (!need((size_t)n_chunk * 16)) return false;
+            std::vector<std::pair<uint64_t, uint64_t>> chunks(n_chunk);
+            for (uint32_t c = 0; c < n_chunk; ++c) { chunks[c] = { le64(d.data() + at), le64(d.data() + at + 8) }; at += 16; }
+            if (bin != 37450) b->index[r].bins.emplace_back(bin, std::move(chunks));          // (37450: the metadata pseudo-bin)
+        }
+        if (!need(4)) return false;
+        const uint32_t n_intv = le32(d.data() + at); at += 4;
+        if (!need((size_t)n_intv * 8)) return false;
+        b->index[r].linear.resize(n_intv);
+        for (uint32_t k = 0; k < n_intv; ++k) { b->index[r].linear[k] = le64(d.data() + at); at += 8; }
+    }
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t sp_bam_open(const char* path, sp_bam** out, char* err, uint32_t err_cap) {
+    if (!path || !out) return SP_ERR_INVALID_ARG;
+    *out = nullptr;
+    auto b = std::make_unique<sp_bam>();
+    if (!b->z.open(path)) { put_err(err, err_cap, std::string("cannot open ") + path); return SP_ERR_INVALID_ARG; }
+    auto bad = [&](const std::string& m) { put_err(err, err_cap, m.empty() ? "truncated BAM header" : m); return SP_ERR_INVALID_ARG; };
+    if (!b->z.load(0)) return bad(b->z.err);
+    uint8_t h[12];
+    if (!b->z.read(h, 8) || std::memcmp(h, "BAM\1", 4) != 0) return bad(b->z.err.empty() ? "not a BAM file" : b->z.err);
+    const uint32_t l_text = le32(h + 4);
+    std::vector<uint8_t> skip(l_text);
+    if (l_text && !b->z.read(skip.data(), l_text)) return bad(b->z.err);
+    if (!b->z.read(h, 4)) return bad(b->z.err);
+    const uint32_t n_ref = le32(h);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if (!b->z.read(h, 4)) return bad(b->z.err);
+        const uint32_t l_name = le32(h);
+        std::string name(l_name, '\0');
+        if (l_name && !b->z.read(&name[0], l_name)) return bad(b->z.err);
+        while (!name.empty() && name.back() == '\0') name.pop_back();
+        if (!b->z.read(h, 4)) return bad(b->z.err);
+        b->ref_names.push_back(name); b->ref_len.push_back(le32(h));
+    }
+    for (const std::string& s : b->ref_names) b->ref_ptr.push_back(s.c_str());
+    b->first_record = b->z.tell();
+    const std::string p(path);
+    b->indexed = load_bai(b.get(), p + ".bai");
+    if (!b->indexed && p.size() > 4 && p.compare(p.size() - 4, 4, ".bam") == 0) b->indexed = load_bai(b.get(), p.substr(0, p.size() - 4) + ".bai");
+    if (b->indexed && b->index.size() != b->ref_names.size()) { b->indexed = false; b->index.clear(); }
+    *out = b.release();
+    return SP_OK;
+}
+
+void sp_bam_free(sp_bam* bam) { delete bam; }
+const char* sp_bam_last_error(const sp_bam* bam) { return bam ? bam->err.c_str() : ""; }
+int32_t sp_bam_forget(sp_bam* bam) { if (!bam) return SP_ERR_INVALID_ARG; bam->seen.clear(); return SP_OK; }
+
+int32_t sp_bam_references(const sp_bam* bam, uint32_t* n, const char* const** names, const uint64_t** lengths) {
+    if (!bam || !n) return SP_ERR_INVALID_ARG;
+    *n = (uint32_t)bam->ref_names.size();
+    if (names) *names = bam->ref_ptr.data();
+    if (lengths) *lengths = bam->ref_len.data();
+    return SP_OK;
+}
+
+int32_t sp_bam_fetch(sp_bam* b, const char* chrom, uint64_t start, uint64_t end, uint32_t exclude_flags, int32_t dedupe,
+                     const sp_bam_read** reads, uint32_t* n, const char** bases, const uint64_t** offsets) {
+    if (!b || !chrom || !reads || !n || end <= start) return SP_ERR_INVALID_ARG;
+    b->reads.clear(); b->names.clear(); b->cigars.clear(); b->bases.clear(); b->offsets.assign(1, 0);
+    *reads = nullptr; *n = 0;
+    int ref = -1;
+    for (size_t r = 0; r < b->ref_names.size(); ++r) if (b->ref_names[r] == chrom) ref = (int)r;
+    if (ref < 0) return bam_fail(b, std::string("the BAM header has no reference ") + chrom);
+    // where to read: the chunks of the index that can hold overlapping records, or everything
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    if (b->indexed) {
+        const sp_bam::RefIndex& ix = b->index[(size_t)ref];
+        std::vector<uint32_t> bins; reg2bins(start, end, bins);
+        const size_t win = (size_t)(start >> 14);
+        const uint64_t min_off = ix.linear.empty() ? 0 : ix.linear[std::min(win, ix.linear.size() - 1)];
+        for (const auto& bin : ix.bins) if (std::find(bins.begin(), bins.end(), bin.first) != bins.end())
+            for (const auto& c : bin.second) if (c.second > min_off) chunks.emplace_back(std::max(c.first, min_off), c.second);
+        std::sort(chunks.begin(), chunks.end());
+        std::vector<std::pair<uint64_t, uint64_t>> merged;
+        for (const auto& c : chunks) { if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second); else merged.push_back(c); }
+        chunks.swap(merged);
+    } else chunks.emplace_back(b->first_record, UINT64_MAX);
+    static const char decode[] = "=ACMGRSVTWYHKDBN";
+    std::vector<uint8_t> rec;
+    for (const auto& chunk : chunks) {
+        if (!b->z.seek(chunk.first)) return bam_fail(b, b->z.err.empty() ? "bad virtual offset in the index" : b->z.err);
+        bool past = false;
+        while (!past && b->z.tell() < chunk.second) {
+            uint8_t h4[4];
+            if (!b->z.read(h4, 4)) { if (!b->z.err.empty()) return bam_fail(b, b->z.err); break; }
+            const uint32_t block_size = le32(h4);
+            if (block_size < 32) return bam_fail(b, "corrupt BAM record");
+            rec.resize(block_size);
+            if (!b->z.read(rec.data(), block_size)) return bam_fail(b, b->z.err.empty() ? "truncated BAM record" : b->z.err);
+            const int32_t ref_id = (int32_t)le32(rec.data()); const int64_t pos = (int32_t)le32(rec.data() + 4);
+            const uint32_t l_name = rec[8], mapq = rec[9], n_cigar = rec[12] | (rec[13] << 8), flag = rec[14] | (rec[15] << 8), l_seq = le32(rec.data() + 16);
+            if (32ull + l_name + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq > block_size) return bam_fail(b, "corrupt BAM record");
+            // an indexed file is coordinate-sorted: past the region once a record of this reference starts behind it or a later reference
+            // begins (a file without index is scanned to its end: it need not be sorted)
+            if (b->indexed && ((ref_id == ref && pos >= (int64_t)end) || ref_id > ref || ref_id < 0)) { past = true; break; }
+            if (ref_id != ref) continue;
+            const uint8_t* cg = rec.data() + 32 + l_name;
+            int64_t span = 0;
+            std::vector<uint32_t> cigar(n_cigar);
+            for (uint32_t c = 0; c < n_cigar; ++c) { cigar[c] = le32(cg + 4 * c); const uint32_t op = cigar[c] & 0xF; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += cigar[c] >> 4; }
+            const int64_t rend = pos + (span > 0 ? span : 1);
+            if (!(pos < (int64_t)end && rend > (int64_t)start)) continue;
+            if (flag & exclude_flags) continue;
+            std::string qname((const char*)rec.data() + 32, l_name ? l_name - 1 : 0);
+            if (dedupe && !b->seen.insert(qname).second) continue;
+            const uint8_t* sq = cg + 4 * n_cigar;
+            for (uint32_t x = 0; x < l_seq; ++x) b->bases.push_back(decode[(sq[x >> 1] >> ((x & 1) ? 0 : 4)) & 0xF]);
+            b->offsets.push_back(b->bases.size());
+            b->names.push_back(std::move(qname)); b->cigars.push_back(std::move(cigar));
+            sp_bam_read r{}; r.flag = flag; r.mapq = mapq; r.ref_id = ref_id; r.pos = pos; r.end = rend; r.l_seq = l_seq; r.n_cigar = n_cigar;
+            b->reads.push_back(r);
+        }
+    }
+    for (size_t i = 0; i < b->reads.size(); ++i) { b->reads[i].qname = b->names[i].c_str(); b->reads[i].cigar = b->cigars[i].empty() ? nullptr : b->cigars[i].data(); }
+    *reads = b->reads.data(); *n = (uint32_t)b->reads.size();
+    if (bases) *bases = b->bases.c_str();
+    if (offsets) *offsets = b->offsets.data();
+    return SP_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------ VCF
+struct sp_vcf {
+    std::string err;
+    std::vector<std::string> samples; std::vector<const char*> sample_ptr;
+    struct Record { std::string chrom; uint64_t pos0; std::string ref; std::vector<std::string> alts; std::string info, format; std::vector<std::string> calls; };
+    std::vector<Record> records;
+    std::vector<sp_vcf_allele> alleles; std::vector<sp_vcf_deletion> deletions;
+};
+
+namespace {
+
+std::vector<std::string> split(const std::string& s, char sep) {
+    std::vector<std::string> out; size_t from = 0;
+    for (;;) { const size_t at = s.find(sep, from); out.push_back(s.substr(from, at == std::string::npos ? at : at - from)); if (at == std::string::npos) break; from = at + 1; }
+    return out;
+}
+
+int32_t vcf_fail(sp_vcf* v, const std::string& m) { v->err = m; return SP_ERR_INVALID_ARG; }
+
+int sample_index(sp_vcf* v, const char* sample) {
+    if (!sample) return v->samples.empty() ? -1 : 0;
+    for (size_t i = 0; i < v->samples.size(); ++i) if (v->samples[i] == sample) return (int)i;
+    return -1;
+}
+
+// GT and PS of one sample column: false when the genotype is missing or not diploid
+bool genotype(const sp_vcf::Record& r, int si, int& g1, int& g2, bool& phased, int64_t& ps) {
+    if ((size_t)si >= r.calls.size()) return false;
+    const std::vector<std::string> keys = split(r.format, ':'), vals = split(r.calls[(size_t)si], ':');
+    std::string gt, psv = ".";
+    for (size_t k = 0; k < keys.size() && k < vals.size(); ++k) { if (keys[k] == "GT") gt = vals[k]; else if (keys[k] == "PS") psv = vals[k]; }
+    phased = gt.find('|') != std::string::npos;
+    std::string norm = gt; std::replace(norm.begin(), norm.end(), '|', '/');
+    const std::vector<std::string> a = split(norm, '/');
+    if (a.size() != 2 || a[0].empty() || a[1].empty() || a[0] == "." || a[1] == ".") return false;
+    g1 = std::atoi(a[0].c_str()); g2 = std::atoi(a[1].c_str());
+    ps = (phased && psv != "." && !psv.empty()) ? std::atoll(psv.c_str()) : -1;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t sp_vcf_open(const char* path, sp_vcf** out, char* err, uint32_t err_cap) {
+    if (!path || !out) return SP_ERR_INVALID_ARG;
+    *out = nullptr;
+    gzFile f = gzopen(path, "rb");                 // plain text, gzip and BGZF (gzip members one after the other) alike
+    if (!f) { put_err(err, err_cap, std::string("cannot open ") + path); return SP_ERR_INVALID_ARG; }
+    std::string text; char buf[1 << 16]; int k;
+    while ((k = gzread(f, buf, sizeof buf)) > 0) text.append(buf, (size_t)k);
+    const bool bad = k < 0;
+    gzclose(f);
+    if (bad) { put_err(err, err_cap, std::string("cannot read ") + path); return SP_ERR_INVALID_ARG; }
+    auto v = std::make_unique<sp_vcf>();
+    size_t from = 0; bool have_header = false;
+    while (from < text.size()) {
+        size_t to = text.find('\n', from); if (to == std::string::npos) to = text.size();
+        std::string line = text.substr(from, to - from); from = to + 1;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty() || line.compare(0, 2, "##") == 0) continue;
+        const std::vector<std::string> col = split(line, '\t');
+        if (line[0] == '#') { for (size_t c = 9; c < col.size(); ++c) v->samples.push_back(col[c]); have_header = true; continue; }
+        if (col.size() < 8) { put_err(err, err_cap, "VCF record with fewer than 8 columns"); return SP_ERR_INVALID_ARG; }
+        sp_vcf::Record r; r.chrom = col[0]; r.pos0 = (uint64_t)std::strtoull(col[1].c_str(), nullptr, 10) - 1; r.ref = col[3]; r.alts = split(col[4], ','); r.info = col[7];
+        if (col.size() > 8) r.format = col[8];
+        for (size_t c = 9; c < col.size(); ++c) r.calls.push_back(col[c]);
+        v->records.push_back(std::move(r));
+    }
+    if (!have_header) { put_err(err, err_cap, "no #CHROM header line"); return SP_ERR_INVALID_ARG; }
+    for (const std::string& s : v->samples) v->sample_ptr.push_back(s.c_str());
+    *out = v.release();
+    return SP_OK;
+}
+
+void sp_vcf_free(sp_vcf* vcf) { delete vcf; }
+const char* sp_vcf_last_error(const sp_vcf* vcf) { return vcf ? vcf->err.c_str() : ""; }
+int32_t sp_vcf_samples(const sp_vcf* vcf, uint32_t* n, const char* const** names) {
+    if (!vcf || !n) return SP_ERR_INVALID_ARG;
+    *n = (uint32_t)vcf->samples.size();
+    if (names) *names = vcf->sample_ptr.data();
+    return SP_OK;
+}
+
+int32_t sp_vcf_alleles(sp_vcf* v, const char* sample, const char* chrom, uint64_t start, uint64_t end, const sp_vcf_allele** out, uint32_t* n) {
+    if (!v || !chrom || !out || !n) return SP_ERR_INVALID_ARG;
+    v->alleles.clear(); *out = nullptr; *n = 0;
+    const int si = sample_index(v, sample);
+    if (si < 0) return vcf_fail(v, std::string("the VCF has no sample ") + (sample ? sample : "(first)"));
+    for (const sp_vcf::Record& r : v->records) {
+        if (r.chrom != chrom || !(r.pos0 < end && r.pos0 + r.ref.size() > start)) continue;
+        int g1, g2; bool phased; int64_t ps;
+        if (!genotype(r, si, g1, g2, phased, ps)) continue;
+        for (size_t a = 0; a < r.alts.size(); ++a) {
+            const int ai = (int)a + 1;
+            int32_t gt = SP_GT_HOM_REF;
+            if (ai == g1 && ai == g2) gt = SP_GT_HOM_ALT;
+            else if (ai == g1 && phased) gt = SP_GT_HET_FLIP;
+            else if (ai == g2 && phased) gt = SP_GT_HET_PHASED;
+            else if (ai == g1 || ai == g2) gt = SP_GT_HET_UNPHASED;
+            v->alleles.push_back(sp_vcf_allele{ r.pos0, r.ref.c_str(), r.alts[a].c_str(), gt, 0, ps });
+        }
+    }
+    *out = v->alleles.data(); *n = (uint32_t)v->alleles.size();
+    return SP_OK;
+}
+
+int32_t sp_vcf_deletions(sp_vcf* v, const char* sample, const char* chrom, uint64_t start, uint64_t end, const sp_vcf_deletion** out, uint32_t* n) {
+    if (!v || !chrom || !out || !n) return SP_ERR_INVALID_ARG;
+    v->deletions.clear(); *out = nullptr; *n = 0;
+    const int si = sample_index(v, sample);
+    if (si < 0) return vcf_fail(v, std::string("the VCF has no sample ") + (sample ? sample : "(first)"));
+    for (const sp_vcf::Record& r : v->records) {
+        if (r.chrom != chrom || r.alts.size() != 1) continue;
+        std::string svtype, endv; bool has_type = false, has_end = false;
+        for (const std::string& kv : split(r.info, ';')) {
+            if (kv.compare(0, 7, "SVTYPE=") == 0) { svtype = kv.substr(7); has_type = true; }
+            else if (kv.compare(0, 4, "END=") == 0) { endv = kv.substr(4); has_end = true; }
+        }
+        if (!has_type) return vcf_fail(v, "No INFO:SVTYPE in record");
+        if (svtype != "DEL") continue;
+        if (!has_end) return vcf_fail(v, "No INFO:END in record");
+        const uint64_t e = (uint64_t)std::strtoull(endv.c_str(), nullptr, 10);
+        if (!(r.pos0 < end && e > start)) continue;
+        int g1, g2; bool phased; int64_t ps;
+        if (!genotype(r, si, g1, g2, phased, ps)) continue;
+        int32_t gt;
+        if (g1 == g2) gt = g1 == 0 ? SP_GT_HOM_REF : SP_GT_HOM_ALT;
+        else if (phased) gt = g1 == 0 ? SP_GT_HET_PHASED : SP_GT_HET_FLIP;
+        else gt = SP_GT_HET_UNPHASED;
+        v->deletions.push_back(sp_vcf_deletion{ r.pos0, e, gt, 0, ps });
+    }
+    *out = v->deletions.data(); *n = (uint32_t)v->deletions.size();
+    return SP_OK;
+}
+
+} // extern "C"

@@ -405,3 +405,120 @@ class Result:
 
     def save(self, path):
         self._check(_lib().sp_result_save(self._h, _b(path)))
+
+
+# ------------------------------------------------------------------ input files (sp_bam_*, sp_vcf_*)
+class sp_bam_read(C.Structure):
+    _fields_ = [("qname", _s), ("flag", _u32), ("mapq", _u32), ("ref_id", _i32), ("reserved", _i32), ("pos", _i64), ("end", _i64),
+                ("l_seq", _u32), ("n_cigar", _u32), ("cigar", C.POINTER(_u32))]
+
+
+_io_bound = False
+
+
+def _io():
+    global _io_bound
+    L = _lib()
+    if _io_bound:
+        return L
+    P = C.POINTER
+    sigs = {
+        "sp_bam_open": (_i32, [_s, P(_vp), _s, _u32]),
+        "sp_bam_free": (None, [_vp]),
+        "sp_bam_last_error": (_s, [_vp]),
+        "sp_bam_references": (_i32, [_vp, P(_u32), P(P(_s)), P(P(_u64))]),
+        "sp_bam_fetch": (_i32, [_vp, _s, _u64, _u64, _u32, _i32, P(P(sp_bam_read)), P(_u32), P(_vp), P(P(_u64))]),
+        "sp_bam_forget": (_i32, [_vp]),
+        "sp_vcf_open": (_i32, [_s, P(_vp), _s, _u32]),
+        "sp_vcf_free": (None, [_vp]),
+        "sp_vcf_last_error": (_s, [_vp]),
+        "sp_vcf_samples": (_i32, [_vp, P(_u32), P(P(_s))]),
+        "sp_vcf_alleles": (_i32, [_vp, _s, _s, _u64, _u64, P(P(sp_vcf_allele)), P(_u32)]),
+        "sp_vcf_deletions": (_i32, [_vp, _s, _s, _u64, _u64, P(P(sp_vcf_deletion)), P(_u32)]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _io_bound = True
+    return L
+
+
+class Bam:
+    """sp_bam: an (indexed) BAM file"""
+
+    def __init__(self, path):
+        self._h = _vp()
+        err = C.create_string_buffer(512)
+        rc = _io().sp_bam_open(_b(path), C.byref(self._h), err, 512)
+        if rc != SP_OK:
+            raise StarphaseError(rc, err.value.decode())
+
+    def __del__(self):
+        try:
+            if self._h:
+                _io().sp_bam_free(self._h)
+                self._h = _vp()
+        except Exception:
+            pass
+
+    def references(self):
+        n, names, lens = _u32(), C.POINTER(_s)(), C.POINTER(_u64)()
+        _io().sp_bam_references(self._h, C.byref(n), C.byref(names), C.byref(lens))
+        return [(names[i].decode(), int(lens[i])) for i in range(n.value)]
+
+    def fetch(self, chrom, start, end, exclude_flags=0, dedupe=False):
+        """-> list of dict(qname, flag, mapq, pos, end, cigar [(op, len)], seq)"""
+        reads, n, bases, offs = C.POINTER(sp_bam_read)(), _u32(), _vp(), C.POINTER(_u64)()
+        rc = _io().sp_bam_fetch(self._h, _b(chrom), int(start), int(end), int(exclude_flags), 1 if dedupe else 0, C.byref(reads), C.byref(n), C.byref(bases),
+                                C.byref(offs))
+        if rc != SP_OK:
+            raise StarphaseError(rc, _io().sp_bam_last_error(self._h).decode())
+        blob = C.string_at(bases.value, int(offs[n.value])) if n.value else b""
+        out = []
+        for i in range(n.value):
+            r = reads[i]
+            out.append(dict(qname=r.qname.decode(), flag=r.flag, mapq=r.mapq, pos=r.pos, end=r.end,
+                            cigar=[(r.cigar[k] & 15, r.cigar[k] >> 4) for k in range(r.n_cigar)], seq=blob[offs[i]:offs[i + 1]].decode()))
+        return out
+
+    def forget(self):
+        _io().sp_bam_forget(self._h)
+
+
+class Vcf:
+    """sp_vcf: a VCF file (plain, gzip or bgzip)"""
+
+    def __init__(self, path):
+        self._h = _vp()
+        err = C.create_string_buffer(512)
+        rc = _io().sp_vcf_open(_b(path), C.byref(self._h), err, 512)
+        if rc != SP_OK:
+            raise StarphaseError(rc, err.value.decode())
+
+    def __del__(self):
+        try:
+            if self._h:
+                _io().sp_vcf_free(self._h)
+                self._h = _vp()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != SP_OK:
+            raise StarphaseError(rc, _io().sp_vcf_last_error(self._h).decode())
+
+    def samples(self):
+        n, names = _u32(), C.POINTER(_s)()
+        _io().sp_vcf_samples(self._h, C.byref(n), C.byref(names))
+        return [names[i].decode() for i in range(n.value)]
+
+    def alleles(self, chrom, start=0, end=2 ** 62, sample=None):
+        """-> [(position0, ref, alt, gt, ps|None)], the rows VariantGene.problem takes"""
+        out, n = C.POINTER(sp_vcf_allele)(), _u32()
+        self._check(_io().sp_vcf_alleles(self._h, _b(sample), _b(chrom), int(start), int(end), C.byref(out), C.byref(n)))
+        return [(out[i].position, out[i].ref.decode(), out[i].alt.decode(), out[i].gt, None if out[i].ps < 0 else out[i].ps) for i in range(n.value)]
+
+    def deletions(self, chrom, start=0, end=2 ** 62, sample=None):
+        out, n = C.POINTER(sp_vcf_deletion)(), _u32()
+        self._check(_io().sp_vcf_deletions(self._h, _b(sample), _b(chrom), int(start), int(end), C.byref(out), C.byref(n)))
+        return [(out[i].start, out[i].end, out[i].gt, None if out[i].ps < 0 else out[i].ps) for i in range(n.value)]

@@ -27,6 +27,7 @@ def test_header_symbols_exported(pkg):
 def test_binding_matches_header(pkg):
     pkg.ffi.lib()          # binds every function; raises AttributeError on a missing one
     pkg.database._lib()    # the database / result-file part of the header
+    pkg.database._io()     # the BAM / VCF readers
     import inspect
     src = inspect.getsource(pkg.ffi) + inspect.getsource(pkg.database)
     for n in declared_symbols():

@@ -182,6 +182,19 @@ def test_sample_from_database_files_to_result_file(oracle, pkg, gpu_ctx, tmp_pat
         for a in rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist():
             hap, s = fx.haplotype(g, a)
             reads += synth.simulate_reads(rng, hap, s, len(fx.dna[a]), 23, mean_len=6000, sd_len=1500, min_overlap=2500)
+    # the reads come out of a BAM file (written by the test's own encoder): one region fetch per gene, QNAMEs handed out once
+    import test_io
+    order = rng.permutation(len(reads)).tolist()
+    recs = sorted(((0, int(regions[i % 2]["start"]) + int(rng.integers(0, 2000)), f"m84/{i}/ccs", 0, 60, [("M", len(reads[i]))], reads[i]) for i in order),
+                  key=lambda r: r[1])
+    bam_path = str(tmp_path / "sample.bam")
+    test_io.write_bam(bam_path, [("chr6", 170805979)], recs, 65280)
+    bam = D.Bam(bam_path)
+    fetched = [r for g in regions for r in bam.fetch(g["chrom"], g["start"], g["end"], exclude_flags=0x900, dedupe=True)]
+    assert sorted(r["qname"] for r in fetched) == sorted(r[2] for r in recs)
+    by_name = {r[2]: r[6] for r in recs}
+    assert all(r["seq"] == by_name[r["qname"]] for r in fetched)
+    reads = [r["seq"] for r in fetched]
     R = gpu_ctx.upload(reads)
     ra, rb = hdb.realign_reads(R), ref_db.realign_reads(R)
     assert ra.tolist() == rb.tolist()

@@ -1,0 +1,278 @@
+"""SURVEY.md 8(f) row f2 through the C ABI (host only): the BAM / BAI and VCF readers.
+
+VCF: the reference's own test files (bgzip, tests/golden/vcf/) read by the library == the rows decoded with Python's gzip module
+(tests/golden/variant_vcfs.json), and every diplotyper scenario again from the FILES (database file + VCF file -> sp_variant_problem ==
+the test-side restatement).  BAM: files written here by an independent Python encoder of the published format (BGZF blocks, records, BAI
+bins + linear index); region fetches == a Python filter of the same records, with and without the index."""
+import gzip
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import variant_glue as vg
+from test_database import vcf_alleles, vcf_deletions, check_problem
+from test_oracle_variant import CASES, SV_CASES
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DECODED = json.load(open(os.path.join(GOLDEN, "variant_vcfs.json")))
+
+
+@pytest.fixture(scope="module")
+def D(pkg):
+    return pkg.database
+
+
+# ------------------------------------------------------------------ VCF
+@pytest.mark.parametrize("key", sorted(DECODED))
+def test_vcf_file_equals_decoded_rows(D, key):
+    vcf = D.Vcf(os.path.join(GOLDEN, "vcf", key))
+    want = DECODED[key]
+    sample = [c for c in want["columns"] if c not in ("CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT")]
+    assert vcf.samples() == sample
+    chroms = sorted({r["CHROM"] for r in want["rows"]})
+    got = [a for c in chroms for a in vcf.alleles(c)]
+    exp = [a for c in chroms for a in vcf_alleles({"columns": want["columns"], "rows": [r for r in want["rows"] if r["CHROM"] == c]})]
+    # rows whose GT is missing / haploid are skipped by both; every other ALT allele is a row
+    assert got == exp
+    if "DPYD-sv-test" in key and "del" in key:
+        assert [d for c in chroms for d in vcf.deletions(c)] == vcf_deletions(want) and len(vcf_deletions(want)) >= 1
+    # a window: only the records that overlap it
+    if want["rows"]:
+        r = want["rows"][len(want["rows"]) // 2]
+        p0 = int(r["POS"]) - 1
+        inside = vcf.alleles(r["CHROM"], p0, p0 + 1)
+        assert inside and all(a[0] <= p0 < a[0] + len(a[1]) for a in inside)
+        assert vcf.alleles(r["CHROM"], p0 + len(r["REF"]) + 5000, p0 + len(r["REF"]) + 5001) == [a for a in got if a[0] <= p0 + len(r["REF"]) + 5000 < a[0] + len(a[1])]
+
+
+def test_vcf_plain_gzip_and_errors(D, pkg, tmp_path):
+    key = "UGT1A1-faux/different_phaseset_001.vcf.gz"
+    text = gzip.open(os.path.join(GOLDEN, "vcf", key)).read()
+    (tmp_path / "plain.vcf").write_bytes(text)
+    (tmp_path / "one_member.vcf.gz").write_bytes(gzip.compress(text))
+    ref = D.Vcf(os.path.join(GOLDEN, "vcf", key))
+    chrom = DECODED[key]["rows"][0]["CHROM"]
+    for name in ("plain.vcf", "one_member.vcf.gz"):
+        assert D.Vcf(str(tmp_path / name)).alleles(chrom) == ref.alleles(chrom) != []
+    with pytest.raises(pkg.StarphaseError, match="cannot open"):
+        D.Vcf(str(tmp_path / "missing.vcf.gz"))
+    (tmp_path / "headless.vcf").write_text("chr1\t5\t.\tA\tC\t.\tPASS\t.\tGT\t0/1\n")
+    with pytest.raises(pkg.StarphaseError, match="header"):
+        D.Vcf(str(tmp_path / "headless.vcf"))
+    with pytest.raises(pkg.StarphaseError, match="no sample"):
+        ref.alleles(chrom, sample="nobody")
+    # load_sv_vcf_variants bails on a record without SVTYPE and on a DEL without END (src/diplotyper.rs:795-812)
+    head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+    (tmp_path / "sv1.vcf").write_text(head + "chr1\t100\t.\tA\t<DEL>\t.\tPASS\tEND=500\tGT\t0/1\n")
+    with pytest.raises(pkg.StarphaseError, match="SVTYPE"):
+        D.Vcf(str(tmp_path / "sv1.vcf")).deletions("chr1")
+    (tmp_path / "sv2.vcf").write_text(head + "chr1\t100\t.\tA\t<DEL>\t.\tPASS\tSVTYPE=DEL\tGT\t0/1\n")
+    with pytest.raises(pkg.StarphaseError, match="END"):
+        D.Vcf(str(tmp_path / "sv2.vcf")).deletions("chr1")
+    (tmp_path / "sv3.vcf").write_text(head + "chr1\t100\t.\tA\t<DEL>\t.\tPASS\tSVTYPE=DEL;END=500\tGT:PS\t1|0:77\n"
+                                      + "chr1\t900\t.\tA\t<INS>\t.\tPASS\tSVTYPE=INS;END=900\tGT\t0/1\n" + "chr2\t100\t.\tA\t<DEL>\t.\tPASS\tSVTYPE=DEL;END=300\tGT\t1/1\n")
+    v = D.Vcf(str(tmp_path / "sv3.vcf"))
+    assert v.deletions("chr1") == [(99, 500, 3, 77)] and v.deletions("chr2") == [(99, 300, 4, None)] and v.deletions("chr1", 600, 700) == []
+
+
+@pytest.mark.parametrize("case", CASES + [("DPYD-sv-test", "DPYD-sv-test/empty_small.vcf.gz", True, None, None, c[0]) for c in SV_CASES],
+                         ids=lambda c: c[1] + ("+" + c[5] if len(c) > 5 else ""))
+def test_scenarios_from_the_files(D, oracle, case):
+    """database FILE + VCF FILE(s) -> the integer problem, == the restatement fed with the decoded rows"""
+    db_name, vcf_key, with_ref = case[0], case[1], case[2]
+    sv_key = case[5] if len(case) > 5 else None
+    _name, want = vg.load_case(oracle, db_name, vcf_key, with_ref, sv_vcf_key=sv_key)
+    db = D.Database(os.path.join(GOLDEN, "variant_dbs", db_name + ".json"))
+    gene_name, chrom = db.gene_entries()[0]
+    genome = json.load(open(os.path.join(GOLDEN, "test_reference.json"))) if with_ref else None
+    gene = db.variant_gene(gene_name, genome[chrom] if genome else None)
+    small = D.Vcf(os.path.join(GOLDEN, "vcf", vcf_key)).alleles(chrom)
+    dels = D.Vcf(os.path.join(GOLDEN, "vcf", sv_key)).deletions(chrom) if sv_key else []
+    check_problem(D, gene, gene.problem(small, dels), want)
+
+
+# ------------------------------------------------------------------ BAM: an independent encoder of the published format
+SEQ_CODE = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+CIGAR_OPS = "MIDNSHP=X"
+
+
+def reg2bin(beg, end):
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+def bam_record(ref_id, pos, qname, flag, mapq, cigar, seq):
+    span = sum(n for op, n in cigar if op in "MDN=X") or 1
+    name = qname.encode() + b"\0"
+    packed = bytearray((len(seq) + 1) // 2)
+    for i, c in enumerate(seq):
+        packed[i >> 1] |= SEQ_CODE[c] << (0 if i & 1 else 4)
+    body = struct.pack("<iiBBHHHiiii", ref_id, pos, len(name), mapq, reg2bin(pos, pos + span), len(cigar), flag, len(seq), -1, -1, 0)
+    body += name + b"".join(struct.pack("<I", n << 4 | CIGAR_OPS.index(op)) for op, n in cigar) + bytes(packed) + b"\xff" * len(seq)
+    body += b"NMC\x00"                                                         # one aux tag behind the qualities
+    return struct.pack("<i", len(body)) + body
+
+
+def bgzf_block(data):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    bsize = len(comp) + 25
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + comp + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def write_bam(path, refs, records, block_bytes, index=True):
+    """refs: [(name, length)]; records: sorted [(ref_id, pos, qname, flag, mapq, cigar, seq)].  Blocks of block_bytes uncompressed bytes
+    (records cross block borders); BAI written beside the file when index."""
+    text = b"@HD\tVN:1.6\tSO:coordinate\n" + b"".join(f"@SQ\tSN:{n}\tLN:{l}\n".encode() for n, l in refs)
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
+    for n, l in refs:
+        head += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    stream, spans = bytearray(head), []
+    for r in records:
+        enc = bam_record(*r)
+        spans.append((len(stream), len(stream) + len(enc)))
+        stream += enc
+    blocks = [bytes(stream[i:i + block_bytes]) for i in range(0, len(stream), block_bytes)]
+    coff, out = [], bytearray()
+    for b in blocks:
+        coff.append(len(out)); out += bgzf_block(b)
+    coff.append(len(out))
+    out += bgzf_block(b"")                                                     # the EOF marker block
+    open(path, "wb").write(out)
+    voff = lambda u: (coff[u // block_bytes] << 16) | (u % block_bytes)
+    if not index:
+        return
+    bai = bytearray(b"BAI\1" + struct.pack("<i", len(refs)))
+    for rid in range(len(refs)):
+        bins, linear = {}, {}
+        for (r, (u0, u1)) in zip(records, spans):
+            if r[0] != rid:
+                continue
+            span = sum(n for op, n in r[5] if op in "MDN=X") or 1
+            b = reg2bin(r[1], r[1] + span)
+            chunks = bins.setdefault(b, [])
+            if chunks and chunks[-1][1] == voff(u0):
+                chunks[-1][1] = voff(u1)
+            else:
+                chunks.append([voff(u0), voff(u1)])
+            for w in range(r[1] >> 14, ((r[1] + span - 1) >> 14) + 1):
+                linear[w] = min(linear.get(w, 1 << 63), voff(u0))
+        bai += struct.pack("<i", len(bins))
+        for b in sorted(bins):
+            bai += struct.pack("<Ii", b, len(bins[b])) + b"".join(struct.pack("<QQ", c[0], c[1]) for c in bins[b])
+        n_intv = (max(linear) + 1) if linear else 0
+        bai += struct.pack("<i", n_intv)
+        last = 0
+        for w in range(n_intv):
+            last = linear.get(w, last)
+            bai += struct.pack("<Q", last)
+    open(path + ".bai", "wb").write(bai)
+
+
+def make_records(rng, refs, n):
+    recs = []
+    for i in range(n):
+        rid = int(rng.integers(0, len(refs)))
+        L = int(rng.integers(30, 1500))
+        pos = int(rng.integers(0, refs[rid][1] - 2 * L))
+        seq = "".join(rng.choice(list("ACGTN"), L, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        kind = i % 4
+        if kind == 0:
+            cigar = [("M", L)]
+        elif kind == 1:
+            cigar = [("S", 5), ("M", L - 15), ("I", 4), ("M", 6), ("D", 37)]
+        elif kind == 2:
+            cigar = [("=", L // 2), ("X", 1), ("N", 2000), ("=", L - L // 2 - 1)]
+        else:
+            cigar = [("H", 10), ("M", L)]
+        flag = [0, 16, 256, 2048, 1024][int(rng.integers(0, 5))]
+        recs.append((rid, pos, f"m84/{i % (n - 7)}/ccs", flag, int(rng.integers(0, 61)), cigar, seq))
+    recs.sort(key=lambda r: (r[0], r[1]))
+    return recs
+
+
+def expected(records, refs, chrom, start, end, exclude=0):
+    rid = [n for n, _ in refs].index(chrom)
+    out = []
+    for r in records:
+        span = sum(n for op, n in r[5] if op in "MDN=X") or 1
+        if r[0] == rid and r[1] < end and r[1] + span > start and not (r[3] & exclude):
+            out.append(dict(qname=r[2], flag=r[3], mapq=r[4], pos=r[1], end=r[1] + span, cigar=[(CIGAR_OPS.index(op), n) for op, n in r[5]], seq=r[6]))
+    return out
+
+
+@pytest.mark.parametrize("block_bytes", [700, 65280])
+def test_bam_fetch_equals_python_filter(D, tmp_path, block_bytes):
+    rng = np.random.default_rng(block_bytes)
+    refs = [("chr1", 400000), ("chr6", 2500000), ("chr22", 900000)]
+    records = make_records(rng, refs, 900)
+    path = str(tmp_path / "reads.bam")
+    write_bam(path, refs, records, block_bytes, index=True)
+    scan_path = str(tmp_path / "scan.bam")
+    write_bam(scan_path, refs, records, block_bytes, index=False)
+    indexed, scanned = D.Bam(path), D.Bam(scan_path)
+    assert indexed.references() == refs == scanned.references()
+    regions = [("chr6", 0, 2500000), ("chr1", 1000, 1001), ("chr22", 450000, 470000), ("chr6", 1 << 20, (1 << 20) + 5), ("chr1", 399000, 400000)]
+    regions += [("chr6", a, a + int(rng.integers(1, 300000))) for a in rng.integers(0, 2200000, 12).tolist()]
+    n_hits = 0
+    for chrom, a, b in regions:
+        want = expected(records, refs, chrom, a, b)
+        assert indexed.fetch(chrom, a, b) == want
+        assert scanned.fetch(chrom, a, b) == want
+        n_hits += len(want)
+    assert n_hits > 400
+    # FLAG filter; QNAME dedupe across fetches (qnames_checked, src/hla/caller.rs:532,565-570)
+    want = expected(records, refs, "chr6", 0, 2500000, exclude=0x900)
+    assert indexed.fetch("chr6", 0, 2500000, exclude_flags=0x900) == want and any(r[3] & 0x900 for r in records)
+    first = indexed.fetch("chr6", 0, 1200000, dedupe=True)
+    second = indexed.fetch("chr6", 600000, 2500000, dedupe=True)
+    names = [r["qname"] for r in first + second]
+    assert len(names) == len(set(names)) and set(names) == {r["qname"] for r in expected(records, refs, "chr6", 0, 2500000)}
+    indexed.forget()
+    assert len(indexed.fetch("chr6", 0, 1200000, dedupe=True)) == len(first)
+
+
+def test_bam_errors(D, pkg, tmp_path):
+    with pytest.raises(pkg.StarphaseError, match="cannot open"):
+        D.Bam(str(tmp_path / "none.bam"))
+    (tmp_path / "text.bam").write_bytes(b"@HD\tVN:1.6\n" * 10)
+    with pytest.raises(pkg.StarphaseError, match="BGZF"):
+        D.Bam(str(tmp_path / "text.bam"))
+    (tmp_path / "gz.bam").write_bytes(bgzf_block(b"not a bam at all, but long enough"))
+    with pytest.raises(pkg.StarphaseError, match="not a BAM"):
+        D.Bam(str(tmp_path / "gz.bam"))
+    refs = [("chr1", 100000)]
+    recs = make_records(np.random.default_rng(1), refs, 50)
+    path = str(tmp_path / "ok.bam")
+    write_bam(path, refs, recs, 900)
+    bam = D.Bam(path)
+    with pytest.raises(pkg.StarphaseError, match="no reference"):
+        bam.fetch("chrX", 0, 10)
+    # a flipped byte inside a block: the CRC (or the inflate) catches it
+    data = bytearray(open(path, "rb").read())
+    data[len(data) // 2] ^= 0x5A
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(data)
+    with pytest.raises(pkg.StarphaseError):
+        D.Bam(bad).fetch("chr1", 0, 100000)
+
+
+def test_bam_reads_go_to_the_library(D, pkg, tmp_path):
+    """the fetch hands out exactly what sp_seqset_upload takes (bases + n + 1 offsets); checked on the host side of the call"""
+    import ctypes as C
+    refs = [("chr6", 50000)]
+    recs = make_records(np.random.default_rng(3), refs, 40)
+    path = str(tmp_path / "r.bam")
+    write_bam(path, refs, recs, 4096)
+    bam = D.Bam(path)
+    reads, n, bases, offs = C.POINTER(D.sp_bam_read)(), C.c_uint32(), C.c_void_p(), C.POINTER(C.c_uint64)()
+    assert D._io().sp_bam_fetch(bam._h, b"chr6", 0, 50000, 0, 0, C.byref(reads), C.byref(n), C.byref(bases), C.byref(offs)) == 0
+    assert n.value == 40 and offs[0] == 0 and [offs[i + 1] - offs[i] for i in range(40)] == [len(r[6]) for r in recs]
+    assert C.string_at(bases.value, int(offs[40])).decode() == "".join(r[6] for r in recs)
