@@ -219,6 +219,51 @@ def chain_pair_leg(pkg, ctx, n_d6=4, n_reads=1000, reps=2):
                         "the kernel is f64-add / compare bound, not HBM bound)"}
 
 
+def inflight_leg(pkg, fx, n_streams=3, steps=6, n_reads=10000, device=0):
+    """Several samples in flight on one GPU: n_streams host threads, each with its own context (= HIP stream), database handle and
+    resident 10,000-read sample, run the same reads -> diplotype step as the headline.  The VALU-bound K1 of one sample overlaps the
+    latency-bound consensus launches of the others (ctypes releases the GIL inside the library)."""
+    import threading
+    from pb_starphase_amd import synth
+    workers = []
+    for t in range(n_streams):
+        wl = synth.Config2Workload(fx, n_reads=n_reads, seed=2000 + t)
+        c = pkg.Context(device)
+        d = fx.make_db(pkg, c)
+        workers.append((c, d, c.upload(wl.reads), wl))
+    genes = list(range(len(fx.genes)))
+    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+
+    def run(w, k, out):
+        c, d, reads, _wl = w
+        for _ in range(k):
+            o = d.realign_reads(reads)
+            out[:] = [d.diplotype_genes(genes, reads, o)[0]]
+
+    for w in workers:
+        run(w, 1, [])
+    outs = [[] for _ in workers]
+    th = [threading.Thread(target=run, args=(workers[i], steps, outs[i])) for i in range(n_streams)]
+    for c, _d, _r, _w in workers:
+        c.synchronize()
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for c, _d, _r, _w in workers:
+        c.synchronize()
+    dt = time.perf_counter() - t0
+    ok = 0
+    for (c, d, reads, wl), out in zip(workers, outs):
+        truth = {g: sorted(a for (gg, _c, _d2, a) in wl.consensus if gg == g) for g in genes}
+        for g, (call, _c1, _c2) in enumerate(out[0]):
+            ok += all(same(a, b) for a, b in zip(sorted([call.allele1, call.allele2]), sorted((truth[g] * 2)[:2])))
+    return {"value": n_reads * n_streams * steps / dt, "unit": "reads/s", "streams": n_streams, "samples": n_streams * steps, "ms_per_sample": 1e3 * dt / (n_streams * steps),
+            "diplotypes_equal_truth": f"{ok}/{n_streams * len(genes)}",
+            "workload": f"{n_streams} samples of {n_reads} reads in flight on {n_streams} HIP streams of one GPU, the headline's step each (one process, one host thread per stream)"}
+
+
 def cohort_leg(pkg, ctx, fx, db, n_samples=32, reps=2, seed=5):
     """BASELINE configs[4] per GPU: n_samples WGS-style samples (~45 reads per gene) through one K1 call + sp_hla_diplotype_cohort"""
     from pb_starphase_amd import synth
@@ -343,6 +388,8 @@ def main():
     cons_cut = ctx.profile_get("cons_cut_windows")[2]
     cons_cols = ctx.profile_get("cons_columns")[2]
     cons_exp = ctx.profile_get("cons_expansions")[2]
+    host_ms = {k: ctx.profile_get("host:" + k)[0] / max(1, args.steps) for k in ("hla_select", "hla_segments", "hla_setup", "hla_dual_hpc", "hla_dual_dna", "hla_groups", "hla_typing",
+                                                                                  "k8_prologue", "k8_loop", "k8_result_wait", "k8_epilogue", "k1_total", "k1_result")}
     cons_ticks = {k: ctx.profile_get("cons_ticks_" + k)[2] / 100.0 / max(1, args.steps) for k in ("reduce", "result", "search", "tail")}   # 100 MHz -> us
     avg_ms = ms_cells / max(1, launches)
     per_launch = lambda v: v / max(1, launches)
@@ -376,7 +423,7 @@ def main():
                    "workload": "K1 on the same reads + K2 on 4 truth consensuses (no consensus step): the read -> allele and consensus -> allele scoring alone",
                    "k2_truth_calls": f"{k2_ok}/{len(calls)}"}
 
-    peaks, cyp, cohort, k5 = None, None, None, None
+    peaks, cyp, cohort, k5, inflight = None, None, None, None, None
     if rank == 0:
         peaks = {"valu_int_wave_instr_per_s": ctx.microbench("valu_int"), "match16_valu_wave_instr_per_s": ctx.microbench("match16"),
                  "hbm_copy_bytes_per_s": ctx.microbench("hbm_copy")}
@@ -384,6 +431,7 @@ def main():
         cyp = cyp_leg(pkg, ctx)
         cohort = cohort_leg(pkg, ctx, fx, db)
         k5 = chain_pair_leg(pkg, ctx)
+        inflight = inflight_leg(pkg, fx, device=device_index)
 
     if rank == 0:
         # VALU wave-instructions of one k1_cells launch: rocprofv3 --pmc SQ_INSTS_VALU of this workload (profiles/r02/valu_k1_cells.json);
@@ -421,14 +469,14 @@ def main():
                                  "device, / launch time (HIP events).  The kernel is an integer-DP kernel whose database sits in L2: its limiter is VALU issue "
                                  "(roofline_valu), 'traffic' is what actually crossed HBM"},
             "roofline_valu": valu,
-            "kernel_ms": kernel_ms,
+            "kernel_ms": kernel_ms, "host_wall_ms": host_ms,
             "consensus": {"windows_per_step": cons_windows / max(1, args.steps), "launches_per_step": 2 * cons_windows / max(1, args.steps),
                           "cut_windows_per_step": cons_cut / max(1, args.steps), "expansions_per_step": cons_exp / max(1, args.steps),
                           "nodes_expanded_per_step": cons_cols / max(1, args.steps),
                           "control_kernel_us_per_step": cons_ticks},
             "concordance": {"k1_gene_correct": k1_gene_ok, "k1_realigned": k1_realigned, "diplotypes_equal_truth": f"{ok}/{len(genes)} genes"},
             "pcie_inclusive_upload_s": t_up,
-            "scoring_only": scoring, "cyp2d6": cyp, "cohort": cohort, "k5_chain_pairs": k5,
+            "scoring_only": scoring, "samples_in_flight": inflight, "cyp2d6": cyp, "cohort": cohort, "k5_chain_pairs": k5,
         }
         if cb is not None:
             agree = sum(1 for i, b in cpu_best.items() if b == int(out[i]["best_allele"]))

@@ -85,6 +85,7 @@ struct CSearch {
     long long ticks[4];         // control kernel, 100 MHz wall clock: load + vote reduction / result of the step / search / tail
 };
 struct ConsMeta { int32_t e, c0, flags, pad; };
+struct ConsRes { int32_t best, dual, split_at, len1, len2, pad; };   // what the host needs of the winning node
 
 // One consensus problem of a batch.  All problems of a batch advance in the same launches (each with its own work order); a
 // workgroup belongs to exactly one problem.  The descriptors travel in the kernel argument block for small batches.
@@ -98,6 +99,8 @@ struct ConsParams {
     CWork* work; CSearch* srch; CNode* nodes;
     uint32_t* la;               // [NQ][2][CW][4] lookahead votes per node
     uint8_t* processed;         // [cap + 2] nodes expanded per length
+    uint8_t* out_cons;          // [2][cap] the consensus bytes of the node the search ended with (written by the finalize kernel)
+    struct ConsRes* out_res; CSearch* out_srch;
 };
 struct ReadInfo { const uint32_t* w; const uint32_t* np; int n, off; long long pad; };
 template <int MAXP> struct ConsBatchT {
@@ -1094,6 +1097,19 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int best = P.srch->best_node;
     const size_t plane = (size_t)B.total;
+    if ((int)blockIdx.x == P.first_block) {
+        // everything the host reads of the problem goes to one output region: the search record, the winning node's shape, its bases
+        for (int x = threadIdx.x; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)P.out_srch)[x] = ((const uint32_t*)P.srch)[x];
+        if (threadIdx.x == 0) {
+            ConsRes r; r.best = best; r.dual = 0; r.split_at = -1; r.len1 = r.len2 = 0; r.pad = 0;
+            if (best >= 0) { const CNode* x = P.nodes + best; r.dual = x->dual; r.split_at = x->split_at; r.len1 = x->len[0]; r.len2 = x->dual ? x->len[1] : 0; }
+            *P.out_res = r;
+        }
+        if (best >= 0) {
+            const uint8_t* src = P.C + (size_t)best * 2 * P.cap;
+            for (int x = threadIdx.x; x < 2 * P.cap; x += blockDim.x) P.out_cons[x] = src[x];
+        }
+    }
     for (int rr = 0; rr < P.rpw; ++rr) {
         const int r = (((int)blockIdx.x - P.first_block) * CWAVES + wave) * P.rpw + rr;
         if (r >= P.n) break;
@@ -1133,6 +1149,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
 template <int MAXP>
 static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* probs, sp_cons_output* outs) {
     hipStream_t st = ctx->stream;
+    HostMarks hm(ctx);
     ConsBatchT<MAXP> B; std::memset(&B, 0, sizeof B);
     B.n_prob = (int)n_prob;
     std::vector<ConsParams> hp(n_prob);                      // the descriptors; they end up in the kernel arguments or, for MAXP == 0, in device memory
@@ -1167,15 +1184,30 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     }
     if (n_blocks == 0) return SP_OK;
     const size_t planes = (size_t)NQ * 4;                   // [node][slot][consensus]
-    uint32_t* d_idx = (uint32_t*)sp_pool(ctx, "cons_idx", sizeof(uint32_t) * std::max<size_t>(1, h_idx.size()));
-    int32_t* d_off = (int32_t*)sp_pool(ctx, "cons_off", sizeof(int32_t) * std::max<size_t>(1, h_off.size()));
+    // one staging region each way (pinned host side): the inputs go up in one copy, the results come down in one
+    size_t in_bytes = 0, out_bytes = 0, zero_bytes = 0;
+    auto place = [](size_t& total_bytes, size_t bytes) { const size_t at = (total_bytes + 15) & ~(size_t)15; total_bytes = at + bytes; return at; };
+    const size_t in_idx = place(in_bytes, sizeof(uint32_t) * h_idx.size()), in_off = place(in_bytes, sizeof(int32_t) * h_off.size());
+    const size_t in_work = place(in_bytes, sizeof(CWork) * n_prob), in_srch = place(in_bytes, sizeof(CSearch) * n_prob);
+    const size_t in_probs = place(in_bytes, MAXP == 0 ? sizeof(ConsParams) * n_prob : 0), in_bp = place(in_bytes, sizeof(int) * block_prob.size());
+    const size_t in_cp = place(in_bytes, sizeof(int) * cluster_prob.size());
+    const size_t out_srch = place(out_bytes, sizeof(CSearch) * n_prob), out_res = place(out_bytes, sizeof(ConsRes) * n_prob);
+    const size_t out_is1 = place(out_bytes, total), out_sc = place(out_bytes, sizeof(int32_t) * 2 * total);
+    std::vector<size_t> out_cons(n_prob);
+    for (uint32_t p = 0; p < n_prob; ++p) out_cons[p] = place(out_bytes, (size_t)2 * std::max(hp[p].cap, 1));
+    const size_t zero_nodes = place(zero_bytes, sizeof(CNode) * NQ * n_prob), zero_proc = place(zero_bytes, proc_bytes), zero_info = place(zero_bytes, sizeof(ReadInfo) * total);
+    uint8_t* d_in = (uint8_t*)sp_pool(ctx, "cons_in", in_bytes + 16); uint8_t* h_in = (uint8_t*)sp_host_pool(ctx, "cons_in", in_bytes + 16);
+    uint8_t* d_out = (uint8_t*)sp_pool(ctx, "cons_out", out_bytes + 16); uint8_t* h_out = (uint8_t*)sp_host_pool(ctx, "cons_out", out_bytes + 16);
+    uint8_t* d_zero = (uint8_t*)sp_pool(ctx, "cons_zero", zero_bytes + 16);
+    if (!d_in || !h_in || !d_out || !h_out || !d_zero) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus staging");
+    uint32_t* d_idx = (uint32_t*)(d_in + in_idx); int32_t* d_off = (int32_t*)(d_in + in_off);
     uint8_t* d_C = (uint8_t*)sp_pool(ctx, "cons_C", c_bytes);
-    CWork* d_work = (CWork*)sp_pool(ctx, "cons_work", sizeof(CWork) * n_prob);
-    CSearch* d_srch = (CSearch*)sp_pool(ctx, "cons_srch", sizeof(CSearch) * n_prob);
-    CNode* d_nodes = (CNode*)sp_pool(ctx, "cons_nodes", sizeof(CNode) * NQ * n_prob);
+    CWork* d_work = (CWork*)(d_in + in_work);
+    CSearch* d_srch = (CSearch*)(d_in + in_srch);
+    CNode* d_nodes = (CNode*)(d_zero + zero_nodes);
     uint32_t* d_la = (uint32_t*)sp_pool(ctx, "cons_la", sizeof(uint32_t) * (size_t)NQ * 2 * CW * 4 * n_prob);
-    uint8_t* d_proc = (uint8_t*)sp_pool(ctx, "cons_proc", proc_bytes);
-    ReadInfo* d_info = (ReadInfo*)sp_pool(ctx, "cons_info", sizeof(ReadInfo) * total);
+    uint8_t* d_proc = d_zero + zero_proc;
+    ReadInfo* d_info = (ReadInfo*)(d_zero + zero_info);
     B.info = d_info; B.total = (int)total;
     B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * planes * total * CB);
     B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * planes * total);
@@ -1189,56 +1221,50 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     B.dbg = (unsigned long long*)sp_pool(ctx, "cons_dbg", (size_t)256 * 16384 * 8);
     (void)hipMemsetAsync(B.dbg, 0, (size_t)256 * 16384 * 8, st);
 #endif
-    uint8_t* d_is1 = (uint8_t*)sp_pool(ctx, "cons_is1", total);
-    int32_t* d_sc = (int32_t*)sp_pool(ctx, "cons_scores", sizeof(int32_t) * 2 * total);
-    CWork* h_work = (CWork*)sp_host_pool(ctx, "cons_work", sizeof(CWork) * n_prob);
-    CSearch* h_srch = (CSearch*)sp_host_pool(ctx, "cons_srch", sizeof(CSearch) * n_prob);
+    uint8_t* d_is1 = d_out + out_is1;
+    int32_t* d_sc = (int32_t*)(d_out + out_sc);
+    CWork* h_work = (CWork*)sp_host_pool(ctx, "cons_work", sizeof(CWork) * n_prob);          // (the polls of the loop land here)
+    CWork* h_work0 = (CWork*)(h_in + in_work); CSearch* h_srch0 = (CSearch*)(h_in + in_srch);
+    const CSearch* h_srch = (const CSearch*)(h_out + out_srch);
     if (!d_idx || !d_off || !d_C || !d_work || !d_srch || !d_nodes || !d_la || !d_proc || !d_info || !B.H || !B.meta || !B.PV || !B.PE || !B.PL || !B.PC || !B.PR || !B.Q ||
-        !d_is1 || !d_sc || !h_work || !h_srch)
+        !h_work)
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus buffers");
     for (uint32_t p = 0; p < n_prob; ++p) {
         setup[p].idx = probs[p].read_idx ? d_idx + idx_at[p] : nullptr;
         setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr;
         hp[p].C = d_C + c_at[p]; hp[p].work = d_work + p; hp[p].srch = d_srch + p; hp[p].nodes = d_nodes + (size_t)p * NQ;
         hp[p].la = d_la + (size_t)p * NQ * 2 * CW * 4; hp[p].processed = d_proc + proc_at[p];
+        hp[p].out_cons = d_out + out_cons[p]; hp[p].out_res = (ConsRes*)(d_out + out_res) + p; hp[p].out_srch = (CSearch*)(d_out + out_srch) + p;
     }
     if constexpr (MAXP == 0) {
-        ConsParams* d_probs = (ConsParams*)sp_pool(ctx, "cons_probs", sizeof(ConsParams) * n_prob);
-        int* d_block_prob = (int*)sp_pool(ctx, "cons_block_prob", sizeof(int) * block_prob.size());
-        int* d_cluster_prob = (int*)sp_pool(ctx, "cons_cluster_prob", sizeof(int) * cluster_prob.size());
-        if (!d_probs || !d_block_prob || !d_cluster_prob) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus descriptors");
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_cluster_prob, cluster_prob.data(), sizeof(int) * cluster_prob.size(), hipMemcpyHostToDevice, st));
-        B.cluster_prob = d_cluster_prob;
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_probs, hp.data(), sizeof(ConsParams) * n_prob, hipMemcpyHostToDevice, st));
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_block_prob, block_prob.data(), sizeof(int) * block_prob.size(), hipMemcpyHostToDevice, st));
-        B.p = d_probs; B.block_prob = d_block_prob;
+        std::memcpy(h_in + in_probs, hp.data(), sizeof(ConsParams) * n_prob);
+        std::memcpy(h_in + in_bp, block_prob.data(), sizeof(int) * block_prob.size());
+        std::memcpy(h_in + in_cp, cluster_prob.data(), sizeof(int) * cluster_prob.size());
+        B.p = (const ConsParams*)(d_in + in_probs); B.block_prob = (const int*)(d_in + in_bp); B.cluster_prob = (const int*)(d_in + in_cp);
     } else {
         for (uint32_t p = 0; p < n_prob; ++p) B.p[p] = hp[p];
     }
     for (uint32_t p = 0; p < n_prob; ++p) {
-        CWork& w = h_work[p]; std::memset(&w, 0, sizeof w); w.mode = M_INIT; w.node = 0; w.in_slot = 0; w.split_at = -1;
-        CSearch& s = h_srch[p]; std::memset(&s, 0, sizeof s); s.best_node = -1; s.inflight = -1;
+        CWork& w = h_work0[p]; std::memset(&w, 0, sizeof w); w.mode = M_INIT; w.node = 0; w.in_slot = 0; w.split_at = -1;
+        CSearch& s = h_srch0[p]; std::memset(&s, 0, sizeof s); s.best_node = -1; s.inflight = -1;
         const sp_cons_config& cf = probs[p].cfg;
         s.max_queue = cf.max_queue_size > 0 ? std::min(cf.max_queue_size, NQ - MAXKIDS - 2) : 20;
         s.per_size = cf.max_capacity_per_size > 0 ? std::min(cf.max_capacity_per_size, 255) : 10;
         s.wo_constraint = cf.max_nodes_wo_constraint > 0 ? cf.max_nodes_wo_constraint : 1000;
     }
-    if (!h_idx.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, h_idx.data(), sizeof(uint32_t) * h_idx.size(), hipMemcpyHostToDevice, st));
-    if (!h_off.empty()) SP_HIP_CHECK(ctx, hipMemcpyAsync(d_off, h_off.data(), sizeof(int32_t) * h_off.size(), hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_work, h_work, sizeof(CWork) * n_prob, hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_srch, h_srch, sizeof(CSearch) * n_prob, hipMemcpyHostToDevice, st));
-    SP_HIP_CHECK(ctx, hipMemsetAsync(d_nodes, 0, sizeof(CNode) * NQ * n_prob, st));
-    SP_HIP_CHECK(ctx, hipMemsetAsync(d_proc, 0, proc_bytes, st));
-    SP_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(ReadInfo) * total, st));
+    if (!h_idx.empty()) std::memcpy(h_in + in_idx, h_idx.data(), sizeof(uint32_t) * h_idx.size());
+    if (!h_off.empty()) std::memcpy(h_in + in_off, h_off.data(), sizeof(int32_t) * h_off.size());
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, st));
+    SP_HIP_CHECK(ctx, hipMemsetAsync(d_zero, 0, zero_bytes, st));
     for (uint32_t p = 0; p < n_prob; ++p)
         if (setup[p].n) hipLaunchKernelGGL(cons_setup_kernel, dim3((setup[p].n + 255) / 256), dim3(256), 0, st, setup[p], d_info);
-    SP_HIP_CHECK(ctx, hipStreamSynchronize(st));      // the pageable host sources above must stay valid until copied
 
     const dim3 grid((uint32_t)n_blocks), block(CWAVES * SP_WAVE);
     const size_t proc_lds = ((size_t)max_cap + 2 + 15) & ~(size_t)15;
     if (proc_lds > 96 * 1024) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must stay below 98,304");
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cons_control_kernel<MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)proc_lds));
     uint64_t pairs = 0;
+    hm.mark("host:k8_prologue");
     {
         ProfScope ps(ctx, "cons_steps", total);
         // the first poll comes when a consensus of max_cap bases can be through if (nearly) every window stands; then every few pairs.
@@ -1262,16 +1288,13 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         }
     }
     SP_HIP_CHECK(ctx, hipGetLastError());
+    hm.mark("host:k8_loop");
     hipLaunchKernelGGL(cons_finalize_kernel<MAXP>, grid, block, 0, st, B, d_is1, d_sc, d_sc + total);
-    std::vector<uint8_t> h_is1(total);
-    std::vector<int32_t> h_sc(2 * total);
-    std::vector<CNode> h_nodes((size_t)NQ * n_prob);
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_srch, d_srch, sizeof(CSearch) * n_prob, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_nodes.data(), d_nodes, sizeof(CNode) * NQ * n_prob, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_is1.data(), d_is1, total, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_sc.data(), d_sc, sizeof(int32_t) * 2 * total, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    const uint8_t* h_is1 = h_out + out_is1; const int32_t* h_sc = (const int32_t*)(h_out + out_sc); const ConsRes* h_res = (const ConsRes*)(h_out + out_res);
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
     SP_HIP_CHECK(ctx, hipGetLastError());
+    hm.mark("host:k8_result_wait");
 #ifdef SP_K8_TIMING
     if (std::getenv("SP_K8_DUMP")) {
         std::vector<unsigned long long> h((size_t)256 * 16384);
@@ -1291,17 +1314,12 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     }
     static const char dec[4] = { 'A', 'C', 'G', 'T' };
     int32_t rc = SP_OK;
-    std::vector<uint8_t> hc;
     for (uint32_t p = 0; p < n_prob; ++p) {
         const ConsParams& P = hp[p]; sp_cons_output& o = outs[p];
-        const int best = h_srch[p].best_node;
-        int len1 = 0, len2 = 0, dual = 0, split_at = -1;
+        const ConsRes& res = h_res[p];
+        const int best = res.best, len1 = res.len1, len2 = res.len2, dual = res.dual, split_at = res.split_at;
         if (best >= 0) {
-            const CNode& x = h_nodes[(size_t)p * NQ + best];
-            dual = x.dual; split_at = x.split_at; len1 = x.len[0]; len2 = dual ? x.len[1] : 0;
-            hc.resize((size_t)2 * std::max(P.cap, 1));
-            SP_HIP_CHECK(ctx, hipMemcpy(hc.data(), P.C + (size_t)best * 2 * P.cap, (size_t)2 * P.cap, hipMemcpyDeviceToHost));
-            const uint8_t* c = hc.data();
+            const uint8_t* c = h_out + out_cons[p];
             for (int x2 = 0; x2 < len1; ++x2) o.cons1[x2] = dec[c[x2] & 3];
             for (int x2 = 0; x2 < len2; ++x2) o.cons2[x2] = dec[(x2 < split_at ? c[x2] : c[(size_t)P.cap + x2]) & 3];
         }
@@ -1314,6 +1332,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         if (len1 >= P.cap || len2 >= P.cap) { o.status = SP_ERR_CAPACITY; rc = SP_ERR_CAPACITY; }
     }
     if (rc != SP_OK) sp_fail(ctx, rc, "sp_consensus: a consensus reached cap");
+    hm.mark("host:k8_epilogue");
     return rc;
 }
 

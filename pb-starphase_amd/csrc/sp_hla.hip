@@ -797,6 +797,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
 
 int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads, sp_hla_realign* out, uint32_t* cell_out) {
     if (!ctx || !db || !reads || !out) return SP_ERR_INVALID_ARG;
+    HostScope host_total(ctx, "host:k1_total");
     // big batches go through in slices of 65,536 reads (a shallow view of the same packed words): the read x allele matrix of a
     // slice is what bounds the device memory of a call, however many reads the caller hands over
     const char* env = std::getenv("SP_K1_SLICE");              // (tests shrink the slice to exercise this path)

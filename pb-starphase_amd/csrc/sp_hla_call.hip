@@ -101,23 +101,24 @@ int sp_make_segments(sp_ctx* ctx, const sp_seqset* reads, const std::vector<uint
     const uint64_t total_words = h_woff[n] + 4;
     const std::string px(prefix);
     auto pool = [&](const char* what, size_t bytes) { return sp_pool(ctx, (px + what).c_str(), std::max<size_t>(bytes, 16)); };
-    uint32_t* d_idx = (uint32_t*)pool("_idx", sizeof(uint32_t) * n);
-    int32_t* d_start = (int32_t*)pool("_start", sizeof(int32_t) * n);
-    int32_t* d_len = (int32_t*)pool("_len", sizeof(int32_t) * n);
+    // idx / start / len / word offsets go up in one copy out of a pinned staging buffer (four pageable copies cost ~75 us each)
+    const size_t at_woff = 0, at_idx = (sizeof(uint64_t) * ((size_t)n + 1) + 15) & ~(size_t)15, at_start = at_idx + ((sizeof(uint32_t) * n + 15) & ~(size_t)15),
+                 at_len = at_start + ((sizeof(int32_t) * n + 15) & ~(size_t)15), in_bytes = at_len + ((sizeof(int32_t) * n + 15) & ~(size_t)15);
+    uint8_t* d_in = (uint8_t*)pool("_in", in_bytes);
+    uint8_t* h_in = (uint8_t*)sp_host_pool(ctx, (px + "_in").c_str(), std::max<size_t>(in_bytes, 16));
+    int32_t* h_hl = (int32_t*)sp_host_pool(ctx, (px + "_hlen").c_str(), std::max<size_t>(sizeof(int32_t) * n, 16));
+    if (!d_in || !h_in || !h_hl) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "segment buffers");
+    uint64_t* d_woff = (uint64_t*)(d_in + at_woff); uint32_t* d_idx = (uint32_t*)(d_in + at_idx); int32_t* d_start = (int32_t*)(d_in + at_start); int32_t* d_len = (int32_t*)(d_in + at_len);
     int32_t* d_hlen = hpc ? (int32_t*)pool("_hlen", sizeof(int32_t) * n) : nullptr;
-    uint64_t* d_woff = (uint64_t*)pool("_woff", sizeof(uint64_t) * ((size_t)n + 1));
     uint32_t* d_seg = (uint32_t*)pool("_seg", sizeof(uint32_t) * total_words);
     uint32_t* d_hpc = hpc ? (uint32_t*)pool("_hpc", sizeof(uint32_t) * total_words) : nullptr;
     uint32_t* d_segn = reads->has_n ? (uint32_t*)pool("_segn", sizeof(uint32_t) * total_words) : nullptr;
     uint32_t* d_hpcn = (hpc && reads->has_n) ? (uint32_t*)pool("_hpcn", sizeof(uint32_t) * total_words) : nullptr;
     if (!d_idx || !d_start || !d_len || !d_woff || !d_seg || (hpc && (!d_hlen || !d_hpc)) || (reads->has_n && (!d_segn || (hpc && !d_hpcn))))
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "segment buffers");
-    if (n) {
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, st));
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_start, start.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_len, len.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-    }
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_woff, h_woff.data(), sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, st));
+    std::memcpy(h_in + at_woff, h_woff.data(), sizeof(uint64_t) * ((size_t)n + 1));
+    if (n) { std::memcpy(h_in + at_idx, idx.data(), sizeof(uint32_t) * n); std::memcpy(h_in + at_start, start.data(), sizeof(int32_t) * n); std::memcpy(h_in + at_len, len.data(), sizeof(int32_t) * n); }
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, st));
     std::vector<int32_t> h_hlen(n, 0);
     if (n) {
         ProfScope ps(ctx, "segments", n);
@@ -126,9 +127,10 @@ int sp_make_segments(sp_ctx* ctx, const sp_seqset* reads, const std::vector<uint
         if (hpc) hipLaunchKernelGGL(hpc_kernel, dim3((n + HPC_WAVES - 1) / HPC_WAVES), dim3(HPC_WAVES * SP_WAVE), 0, st,
                                     d_seg, d_segn, d_woff, d_len, (int)n, d_hpc, d_hpcn, d_hlen);
     }
-    if (n && hpc) SP_HIP_CHECK(ctx, hipMemcpyAsync(h_hlen.data(), d_hlen, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    if (n && hpc) SP_HIP_CHECK(ctx, hipMemcpyAsync(h_hl, d_hlen, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
     SP_HIP_CHECK(ctx, hipGetLastError());
+    if (n && hpc) std::memcpy(h_hlen.data(), h_hl, sizeof(int32_t) * n);
     *seg = sp_seqset();
     seg->ctx = ctx; seg->n = n; seg->has_n = reads->has_n; seg->d_words = d_seg; seg->d_nplane = d_segn; seg->d_word_off = d_woff; seg->d_len = d_len; seg->max_len = max_len;
     seg->h_len = len; seg->h_word_off = h_woff;
@@ -145,6 +147,7 @@ static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
                                const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
                                char* cons, uint32_t cap, uint8_t* is_cons1_out) {
     if (is_cons1_out) std::memset(is_cons1_out, 0, reads->n);
+    HostMarks hm(ctx);
     struct Gene { uint32_t first = 0, n = 0; int is_dual = 0, pass = 0, hemi = 0, used_dna = 0; int32_t c1 = 0, c2 = 0; double maf = 0, cdf = 0; };
     std::vector<Gene> G(n_genes);
     // realigned_records of every gene, in input (qname) order, flattened gene after gene
@@ -174,10 +177,12 @@ static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
         max_len = std::max(max_len, h_len[i]);
     }
     sp_seqset seg, hpc;
+    hm.mark("host:hla_select");
     {
         const int32_t e = sp_make_segments(ctx, reads, sel, h_start, h_len, "hc", &seg, &hpc);
         if (e != SP_OK) return e;
     }
+    hm.mark("host:hla_segments");
 
     // ---- run_dual_consensus_with_offsets (caller.rs:1118-1219), all genes in lockstep
     const int half_window = 200;                                                   // offset_window 400 (dwfa_config_from_cli, :1103-1116)
@@ -226,8 +231,10 @@ static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
     };
     std::vector<uint32_t> todo;
     for (uint32_t k = 0; k < n_genes; ++k) if (G[k].n) todo.push_back(k);
+    hm.mark("host:hla_setup");
     int32_t rc = dual_batch(todo, true);
     if (rc != SP_OK) return rc;
+    hm.mark("host:hla_dual_hpc");
     std::vector<uint32_t> retry;
     for (uint32_t k : todo) if (!G[k].pass) retry.push_back(k);                    // HPC did not separate the reads: full-length DNA (:1180-1218)
     if (!retry.empty()) {
@@ -235,6 +242,7 @@ static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
         if (rc != SP_OK) return rc;
         for (uint32_t k : retry) G[k].used_dna = 1;
     }
+    hm.mark("host:hla_dual_dna");
     // ---- hemizygosity (caller.rs:676-684)
     for (uint32_t k : todo) if (cfgs[k].absent_capable) {
         Gene& g = G[k];
@@ -270,6 +278,7 @@ static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
         if (rc != SP_OK && rc != SP_ERR_CAPACITY) return rc;
         for (size_t x = 0; x < groups.size(); ++x) if (O[x].status != SP_OK) O[x].cons1[0] = '\0';   // "Failed to generate a consensus" => empty => unknown (:741-755)
     }
+    hm.mark("host:hla_groups");
     // ---- typing (score_consensus, caller.rs:756,829): every consensus of every unit in one batch
     std::vector<uint32_t> tg; std::vector<const char*> tp; std::vector<uint32_t> tl; std::vector<std::pair<uint32_t, int>> tw;
     for (uint32_t k : todo) {
@@ -295,6 +304,7 @@ static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
         if (rc != SP_OK) return rc;
         for (size_t y = 0; y < at.size(); ++y) (tw[at[y]].second ? calls[tw[at[y]].first].typed2 : calls[tw[at[y]].first].typed1) = tb[y].best_allele;
     }
+    hm.mark("host:hla_typing");
     // ---- the call (caller.rs:889-923)
     for (uint32_t k : todo) {
         Gene& g = G[k]; sp_hla_call& call = calls[k];

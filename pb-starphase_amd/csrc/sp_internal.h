@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <map>
 #include "../../include/starphase_hip.h"
 
@@ -111,6 +112,18 @@ int   sp_fail(sp_ctx* ctx, int code, const std::string& msg);
     return sp_fail((ctx), SP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
 
 void sp_profile_flush(sp_ctx* ctx);                                           // sp_api.hip
+// HostMarks: the same, stretch after stretch: mark(name) charges the time since the previous mark to `name`
+struct HostMarks {
+    sp_ctx* ctx; std::chrono::steady_clock::time_point t;
+    explicit HostMarks(sp_ctx* c) : ctx(c), t(std::chrono::steady_clock::now()) {}
+    void mark(const char* name) { const auto now = std::chrono::steady_clock::now(); if (ctx->profiling) { auto& e = ctx->prof[name]; e.ms += std::chrono::duration<double, std::milli>(now - t).count(); e.launches += 1; } t = now; }
+};
+// wall-clock time of a stretch of HOST code (sp_profile_get("host:...")): where a step waits for the CPU
+struct HostScope {
+    sp_ctx* ctx; const char* name; std::chrono::steady_clock::time_point t0;
+    HostScope(sp_ctx* c, const char* n) : ctx(c), name(n), t0(std::chrono::steady_clock::now()) {}
+    ~HostScope() { if (ctx->profiling) { auto& e = ctx->prof[name]; e.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); e.launches += 1; } }
+};
 struct ProfScope {
     sp_ctx* ctx; const char* name; uint64_t cells; hipEvent_t e0 = nullptr, e1 = nullptr;
     ProfScope(sp_ctx* c, const char* n, uint64_t cells_) : ctx(c), name(n), cells(cells_) {
