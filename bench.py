@@ -219,7 +219,7 @@ def chain_pair_leg(pkg, ctx, n_d6=4, n_reads=1000, reps=2):
                         "the kernel is f64-add / compare bound, not HBM bound)"}
 
 
-def inflight_leg(pkg, fx, n_streams=3, steps=6, n_reads=10000, device=0):
+def inflight_leg(pkg, fx, n_streams=3, steps=10, n_reads=10000, device=0):
     """Several samples in flight on one GPU: n_streams host threads, each with its own context (= HIP stream), database handle and
     resident 10,000-read sample, run the same reads -> diplotype step as the headline.  The VALU-bound K1 of one sample overlaps the
     latency-bound consensus launches of the others (ctypes releases the GIL inside the library)."""
