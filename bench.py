@@ -24,6 +24,9 @@ import time
 
 import numpy as np
 
+# HIP maps streams onto a few hardware queues (4 by default): the streams of the samples-in-flight leg should each get their own
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402

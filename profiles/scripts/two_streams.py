@@ -13,7 +13,7 @@ n_threads = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 workers = []
 for t in range(n_threads):
-    wl = synth.Config2Workload(fx, n_reads=10000, seed=1000 + t)
+    wl = synth.Config2Workload(fx, n_reads=10000, seed=int(os.environ.get("SEED0", "1000")) + t)
     ctx = pkg.Context(0)
     db = fx.make_db(pkg, ctx)
     reads = ctx.upload(wl.reads)
