@@ -189,7 +189,8 @@ def cyp_leg(pkg, ctx, n_reads=2000, reps=2):
         ok += good
         out[name] = {"ms": 1e3 * best, "reads": len(reads), "call_equals_truth": bool(good), "cons_ms": ctx.profile_get("cons_steps")[0],
                      "launch_pairs": ctx.profile_get("cons_windows")[2], "cut_windows": ctx.profile_get("cons_cut_windows")[2],
-                     "expansions": ctx.profile_get("cons_expansions")[2], "nodes_expanded": ctx.profile_get("cons_columns")[2]}
+                     "expansions": ctx.profile_get("cons_expansions")[2], "nodes_expanded": ctx.profile_get("cons_columns")[2],
+                     "host_wall_ms": {k: round(ctx.profile_get("host:cyp_" + k)[0], 2) for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")}}
         total_reads += len(reads); total_s += best
     return {"value": total_reads / total_s, "unit": "reads/s", "workload": f"BASELINE configs[2]: six scenarios x {n_reads} targeted-style reads (3-8 kb) on the synthetic chr22 "
             "locus, 39 templates, 393 variants / 520 star alleles of the bundled DB; sp_cyp_diplotype (K3 -> K8 -> K9/K7 -> K4 -> chains -> K5)",

@@ -778,9 +778,9 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
     if (states) std::memset(states, 3, (size_t)S * n_variants);
     if (S == 0) return SP_OK;
     // place every sequence on the backbone (sequence = indexed / streamed side A, backbone = window side B), with traceback
-    sp_seqset* bbset = nullptr;
+    sp_seqset bb_pooled; sp_seqset* bbset = &bb_pooled;
     const uint64_t boff[2] = { 0, backbone_len };
-    int32_t rc = sp_seqset_upload(ctx, backbone, boff, 1, &bbset);
+    int32_t rc = sp_seqset_make_small(ctx, "k9_backbone", backbone, boff, 1, false, bbset);
     if (rc != SP_OK) return rc;
     std::vector<uint32_t> ai(S), bi(S, 0); for (uint32_t i = 0; i < S; ++i) ai[i] = i;
     std::vector<int32_t> diag(S), votes(S);
@@ -789,7 +789,6 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
     if (rc == SP_OK) for (uint32_t i = 0; i < S; ++i) if (votes[i] >= CYP_MIN_VOTES) { pairs.push_back(sp_pair{ i, 0, diag[i], SP_MAX_ED }); who.push_back(i); }
     std::vector<sp_aln> alns(pairs.size()); std::vector<uint32_t> events(pairs.size() * (size_t)SP_MAX_ED);
     if (rc == SP_OK && !pairs.empty()) rc = sp_align_batch(ctx, seqs, bbset, pairs.data(), pairs.size(), alns.data(), events.data(), SP_MAX_ED);
-    sp_seqset_free(bbset);
     if (rc != SP_OK) return rc;
     if (alns_out) { std::memset(alns_out, 0, sizeof(sp_aln) * S); for (size_t x = 0; x < who.size(); ++x) alns_out[who[x]] = alns[x]; }
     if (n_variants == 0) return SP_OK;
@@ -922,8 +921,8 @@ static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::
     std::string blob; std::vector<uint64_t> off(1, 0);
     for (uint32_t i = 0; i < seqs.size(); ++i) if (!seqs[i].empty()) { live.push_back(i); blob += seqs[i]; off.push_back(blob.size()); }
     if (live.empty()) return SP_OK;
-    sp_seqset* set = nullptr;
-    int32_t rc = sp_seqset_upload(ctx, blob.data(), off.data(), (uint32_t)live.size(), &set);
+    sp_seqset pooled; sp_seqset* set = &pooled;                       // pooled buffers: no allocation, no free (a handful of consensuses)
+    int32_t rc = sp_seqset_make_small(ctx, "cyp_typed", blob.data(), off.data(), (uint32_t)live.size(), true, set);
     if (rc != SP_OK) return rc;
     std::vector<sp_region_hit> hits(live.size() * 16 + 16); uint64_t nh = 0;
     rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh);
@@ -933,7 +932,6 @@ static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::
     std::vector<uint32_t> bvi(live.size()), ball(live.size()); std::vector<uint8_t> tie((size_t)live.size() * std::max<uint32_t>(pr->n_alleles, 1));
     if (rc == SP_OK && pr->n_alleles && pr->n_variants)
         rc = sp_cyp_score_alleles(ctx, pr->n_variants, pr->n_alleles, pr->hap_matrix, pr->var_is_vi, (uint32_t)live.size(), states.data(), bvi.data(), ball.data(), tie.data());
-    sp_seqset_free(set);
     if (rc != SP_OK) return rc;
     for (uint32_t x = 0; x < live.size(); ++x) {
         // the best match of this sequence: lowest penalised score, first on ties (:344-349)
@@ -967,20 +965,24 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     (void)hipSetDevice(ctx->device);
     std::memset(call, 0, sizeof *call);
     const uint32_t R = reads->n;
+    HostMarks hm(ctx);
     // 1. regions of interest (caller.rs:126-139): max_missing_chain_frac = 0.5
     std::vector<sp_region_hit> hits((size_t)R * 8 + 16); uint64_t nh = 0;
     int32_t rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh);
     if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh); }
     if (rc != SP_OK) return rc;
     hits.resize(nh);
+    hm.mark("host:cyp_regions");
     // 2. consensus inputs (caller.rs:176-245): max_missing_consensus_frac = 0.5, offset window +-50
     std::vector<uint32_t> c_idx; std::vector<int32_t> c_start, c_len, boff, hoff, seeds; std::vector<uint32_t> c_hit;
+    std::vector<std::string> guides(pr->templates->n);
     for (uint32_t h = 0; h < hits.size(); ++h) {
         const sp_region_hit& q = hits[h];
         if (cyp_score(q.seq_len, q.nm, q.unmapped, true) > 0.5) continue;
         c_idx.push_back((uint32_t)q.read); c_start.push_back(q.start); c_len.push_back(q.end - q.start); c_hit.push_back(h);
         boff.push_back(q.clip_start == 0 ? -1 : q.clip_start + 50);
-        const std::string guide = sp_seqset_decode(ctx, pr->templates, (uint32_t)q.template_idx);
+        std::string& guide = guides[(size_t)q.template_idx];                                             // (decoded once per template, not once per hit)
+        if (guide.empty()) guide = sp_seqset_decode(ctx, pr->templates, (uint32_t)q.template_idx);
         const int32_t hp = (int32_t)sp_hpc_pos(guide.data(), guide.size(), (uint64_t)q.clip_start);       // hpc_with_guide (homopolymers.rs:53-64)
         hoff.push_back(hp == 0 ? -1 : hp + 50);
         int seed = -1;
@@ -992,6 +994,7 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     sp_seqset raw, hpc;
     rc = sp_make_segments(ctx, reads, c_idx, c_start, c_len, "cypc", &raw, &hpc);
     if (rc != SP_OK) return rc;
+    hm.mark("host:cyp_segments");
     // 3. multi-way consensus, homopolymer-compressed level first (caller.rs:162-270)
     sp_cons_config cc{};
     cc.min_count = pr->min_consensus_count; cc.min_af = pr->min_consensus_fraction; cc.dual_max_ed_delta = pr->dual_max_ed_delta;
@@ -1007,6 +1010,7 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     if (rc != SP_OK) return rc;
     std::vector<std::string> hpc_cons(n_groups), full_cons(n_groups);
     for (uint32_t g = 0; g < n_groups; ++g) { hpc_cons[g] = text.data() + (size_t)(2 * g) * cap; full_cons[g] = text.data() + (size_t)(2 * g + 1) * cap; }
+    hm.mark("host:cyp_consensus");
     // 4. merge_consensus_results (caller.rs:750-898): max_missing_typing_frac = 0.1, no forced assignment
     std::vector<Label> glabel;
     rc = type_sequences(ctx, pr, full_cons, 0.1, false, glabel);
@@ -1051,6 +1055,7 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
         if (!P.empty()) { rc = sp_consensus_batch(ctx, (uint32_t)P.size(), P.data(), O.data()); if (rc != SP_OK) return rc; }
         for (size_t x = 0; x < members.size(); ++x) final_cons[slot[x]] = mtext[x].data();
     }
+    hm.mark("host:cyp_merge");
     // 5. typing of the final consensus regions, forced assignment, duplicates become FalseAllele (caller.rs:331-375)
     std::vector<Label> labels;
     rc = type_sequences(ctx, pr, final_cons, 0.1, true, labels);
@@ -1058,6 +1063,7 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     for (size_t i = 0; i < final_cons.size(); ++i)
         for (size_t j = 0; j < i; ++j) if (final_cons[j] == final_cons[i]) { labels[i].type = SP_CYP_FALSE_ALLELE; break; }
     const uint32_t H = (uint32_t)final_cons.size();
+    hm.mark("host:cyp_typing");
     // 6. weights of every region of interest, chains, best chain pair (caller.rs:429-640)
     std::vector<uint32_t> a_idx(hits.size()); std::vector<int32_t> a_start(hits.size()), a_len(hits.size());
     std::vector<uint32_t> seg_off(R + 1, 0);
@@ -1068,14 +1074,14 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     if (rc != SP_OK) return rc;
     std::string blob; std::vector<uint64_t> off(1, 0);
     for (const std::string& c : final_cons) { blob += c; off.push_back(blob.size()); }
-    sp_seqset* cons_set = nullptr;
-    rc = sp_seqset_upload(ctx, blob.data(), off.data(), H, &cons_set);
+    sp_seqset cons_pooled; sp_seqset* cons_set = &cons_pooled;
+    rc = sp_seqset_make_small(ctx, "cyp_final", blob.data(), off.data(), H, true, cons_set);
     if (rc != SP_OK) return rc;
     std::vector<uint8_t> allowed(H); for (uint32_t h = 0; h < H; ++h) allowed[h] = label_allowed(labels[h]) && !final_cons[h].empty();
     std::vector<uint64_t> ed((size_t)all.n * H); std::vector<double> ov((size_t)all.n * H); std::vector<uint8_t> kept(all.n);
     rc = sp_cyp_weight_segments(ctx, cons_set, allowed.data(), &all, ed.data(), ov.data(), kept.data());
-    sp_seqset_free(cons_set);
     if (rc != SP_OK) return rc;
+    hm.mark("host:cyp_weights");
     std::vector<int32_t> types(H); for (uint32_t h = 0; h < H; ++h) types[h] = labels[h].type;
     std::vector<uint32_t> read_index(R + 1), rco(R + 1), rwo(R + 1), w_seg(all.n + 1), chain_off, chain_items;
     std::vector<uint64_t> uniq(H); std::vector<uint8_t> fa(H);
@@ -1110,7 +1116,9 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     cp.infer_connections = pr->infer_connections; cp.normalize_all_alleles = !pr->normalize_d6_only; cp.ignore_chain_label_limits = 0;
     cp.lasso_penalty = 4.0; cp.ln_ed_penalty = 2.0; cp.unexpected_chain_penalty = 10.0; cp.inferred_edge_penalty = 2.0;      // ChainPenalties::default (chaining.rs:107-139)
     sp_chain_result cr;
+    hm.mark("host:cyp_chains");
     rc = sp_cyp_best_chain_pair(ctx, &cp, &cr);
+    hm.mark("host:cyp_chain_pair");
     if (rc == SP_ERR_NO_CHAINING_HEAD || rc == SP_ERR_NO_CHAINS_FOUND || rc == SP_ERR_NO_SCORE_PAIRS) { call->status = rc; return SP_OK; }
     if (rc != SP_OK) return rc;
     call->n1 = cr.n1; call->n2 = cr.n2; call->score = cr.score;
