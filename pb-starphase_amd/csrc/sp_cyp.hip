@@ -642,7 +642,8 @@ struct K9Job {
     int32_t opt;                              // (written by the kernel)
 };
 
-__device__ __forceinline__ void k9_step(int (&c)[4], int x, const uint8_t* S, int L, bool mirror, int off, int k0, int lane) {
+// r[j]: the sequence base in front of diagonal lane * 4 + j at this graph offset (255: outside the sequence)
+__device__ __forceinline__ void k9_step(int (&c)[4], int x, const int (&r)[4], int L, int off, int k0, int lane) {
     // one base of the graph: diagonal d <-> k = k0 + d, read position i = off + k in front of the base
     const int next0 = spw::from_upper(c[0], K9_INF);                      // the lane above's first diagonal
     int nw[4];
@@ -650,7 +651,7 @@ __device__ __forceinline__ void k9_step(int (&c)[4], int x, const uint8_t* S, in
     for (int j = 0; j < 4; ++j) {
         const int d = lane * 4 + j, i = off + k0 + d;
         int v = K9_INF;
-        if (i >= 0 && i < L && c[j] < K9_INF) { const int r = S[mirror ? L - 1 - i : i]; v = c[j] + ((r < 4 && r == x) ? 0 : 1); }
+        if (r[j] != 255 && c[j] < K9_INF) v = c[j] + ((r[j] < 4 && r[j] == x) ? 0 : 1);
         const int up = j < 3 ? c[j + 1] : next0;
         if (up < K9_INF && i + 1 >= 0 && i + 1 <= L && up + 1 < v) v = up + 1;
         nw[j] = v;
@@ -668,9 +669,19 @@ __device__ __forceinline__ void k9_step(int (&c)[4], int x, const uint8_t* S, in
 #pragma unroll
         for (int j = 1; j < 4; ++j) { const int i = off + 1 + k0 + lane * 4 + j; if (i >= 0 && i <= L && nw[j - 1] + 1 < nw[j]) nw[j] = nw[j - 1] + 1; }
         int f = nw[3] < K9_INF ? nw[3] - 4 * lane : (1 << 20);              // what this lane offers the lanes above, in lane-0 units
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int other = __shfl_up(f, o); if (lane >= o && other < f) f = other; }
-        const int before = __shfl_up(f, 1);                               // best offer of the lanes below
+        // inclusive prefix minimum over the lanes with DPP moves (row_shr 1, 2, 4, 8, then the two row broadcasts): a lane without a
+        // source keeps the identity
+        {
+            const int id = 1 << 20;
+            int t;
+            t = __builtin_amdgcn_update_dpp(id, f, 0x111, 0xf, 0xf, false); f = t < f ? t : f;
+            t = __builtin_amdgcn_update_dpp(id, f, 0x112, 0xf, 0xf, false); f = t < f ? t : f;
+            t = __builtin_amdgcn_update_dpp(id, f, 0x114, 0xf, 0xf, false); f = t < f ? t : f;
+            t = __builtin_amdgcn_update_dpp(id, f, 0x118, 0xf, 0xf, false); f = t < f ? t : f;
+            t = __builtin_amdgcn_update_dpp(id, f, 0x142, 0xa, 0xf, false); f = t < f ? t : f;     // row_bcast:15 into rows 1 and 3
+            t = __builtin_amdgcn_update_dpp(id, f, 0x143, 0xc, 0xf, false); f = t < f ? t : f;     // row_bcast:31 into rows 2 and 3
+        }
+        const int before = spw::from_lower(f, 1 << 20);                    // best offer of the lanes below
         if (lane > 0 && before < (1 << 19)) {
             const int in = before + 4 * lane - 3;                         // value arriving at this lane's first diagonal
 #pragma unroll
@@ -684,23 +695,45 @@ __device__ __forceinline__ void k9_step(int (&c)[4], int x, const uint8_t* S, in
 __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict__ pool, K9Job* __restrict__ jobs, const int32_t* __restrict__ site_so,
                                                        const int32_t* __restrict__ site_eo, const uint32_t* __restrict__ alt_first,
                                                        const int32_t* __restrict__ alt_len, const uint32_t* __restrict__ alt_off,
-                                                       uint16_t* __restrict__ exits, uint16_t* __restrict__ entries, int32_t* __restrict__ alt_on) {
+                                                       uint16_t* __restrict__ exits, uint16_t* __restrict__ entries, int32_t* __restrict__ alt_on, int lds_cap) {
+    extern __shared__ uint8_t seq_lds[];                  // the aligned stretch of the sequence (both passes read it four bases per lane and step)
     __shared__ int shift[2][K9_DIAGS];
     __shared__ int opt_s;
     K9Job& J = jobs[blockIdx.x];
     const int lane = threadIdx.x & 63, mirror = threadIdx.x >> 6;
-    const uint8_t* S = pool + J.seq_off; const uint8_t* bb = pool + J.bb_off;
+    const uint8_t* bb = pool + J.bb_off;           // (re-pointed at the LDS copies below when both fit)
     const int L = J.L, G = J.G, ns = (int)J.n_sites;
+    const uint8_t* S = pool + J.seq_off;
+    if (L + G <= lds_cap) {                               // (longer stretches stay in memory: same results, dependent loads on the way)
+        for (int x = threadIdx.x; x < L; x += blockDim.x) seq_lds[x] = S[x];
+        for (int x = threadIdx.x; x < G; x += blockDim.x) seq_lds[L + x] = bb[x];
+        __syncthreads();
+        S = seq_lds; bb = seq_lds + L;
+    }
     const int k0 = mirror ? (L - G) - J.k0 - (K9_DIAGS - 1) : J.k0;
     auto gbase = [&](int g) -> int { return bb[mirror ? G - 1 - g : g]; };   // graph base at offset g of this pass
+    // The four sequence bases in front of a lane's diagonals move up by one per graph base: they are kept in registers and shifted
+    // through the lanes (the top lane reads the one new base), instead of four loads per lane and step.
+    auto sbase = [&](int i) -> int { return (i >= 0 && i < L) ? (int)S[mirror ? L - 1 - i : i] : 255; };
+    int r[4];
+    auto load_r = [&](int off) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = sbase(off + k0 + lane * 4 + j);
+    };
+    auto advance_r = [&](int new_off) {                                      // r for offset new_off from r for new_off - 1
+        const int from_above = spw::from_upper(r[0], 255);
+        r[0] = r[1]; r[1] = r[2]; r[2] = r[3];
+        r[3] = lane == 63 ? sbase(new_off + k0 + 255) : from_above;
+    };
     int c[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int i = k0 + lane * 4 + j; c[j] = (i >= 0 && i <= L) ? i : K9_INF; }
     int g = 0;
+    load_r(0);
     for (int t = 0; t <= ns; ++t) {
         const int si = mirror ? ns - 1 - t : t;                               // the site this pass meets t-th
         const int so = t < ns ? (mirror ? G - site_eo[J.site_first + si] : site_so[J.site_first + si]) : G;
-        for (; g < so; ++g) k9_step(c, gbase(g), S, L, mirror, g, k0, lane);
+        for (; g < so; ++g) { k9_step(c, gbase(g), r, L, g, k0, lane); advance_r(g + 1); }
         if (t == ns) break;
         const int eo = mirror ? G - site_so[J.site_first + si] : site_eo[J.site_first + si];
         if (mirror) {                                                         // the mirrored pass leaves the column in FRONT of every site
@@ -718,7 +751,8 @@ __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = e0[j];
             const int len = alt_len[a]; const uint8_t* as = pool + alt_off[a];
-            for (int x = 0; x < len; ++x) k9_step(w, as[mirror ? len - 1 - x : x], S, L, mirror, so + x, k0, lane);
+            load_r(so);
+            for (int x = 0; x < len; ++x) { k9_step(w, as[mirror ? len - 1 - x : x], r, L, so + x, k0, lane); advance_r(so + x + 1); }
             // the alternative is len bases where the reference has lr: its diagonals shift by len - lr at the site's end
             const int delta = len - lr;
 #pragma unroll
@@ -738,6 +772,7 @@ __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[j] = acc[j];
         g = eo;
+        load_r(g);
     }
     if (!mirror) {
         const int kL = L - G - k0;
@@ -872,7 +907,10 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
     (void)hipMemsetAsync(d_on, 0, (alt_len.size() + 1) * 4, ctx->stream);
     {
         ProfScope ps(ctx, "k9_graph", jobs.size());
-        hipLaunchKernelGGL(k9_graph_kernel, dim3((unsigned)jobs.size()), dim3(128), 0, ctx->stream, d_pool, d_jobs, d_so, d_eo, d_af, d_al, d_ao, d_exit, d_entry, d_on);
+        int max_l = 0; for (const K9Job& j : jobs) max_l = std::max(max_l, (int)(j.L + j.G));
+        const int lds_cap = std::min(max_l, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)k9_graph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap + 16);
+        hipLaunchKernelGGL(k9_graph_kernel, dim3((unsigned)jobs.size()), dim3(128), (size_t)lds_cap + 16, ctx->stream, d_pool, d_jobs, d_so, d_eo, d_af, d_al, d_ao, d_exit, d_entry, d_on, lds_cap);
     }
     std::vector<int32_t> on(alt_len.size() + 1);
     (void)hipMemcpyAsync(on.data(), d_on, (alt_len.size() + 1) * 4, hipMemcpyDeviceToHost, ctx->stream);
