@@ -474,7 +474,7 @@ def main():
                                  "(roofline_valu), 'traffic' is what actually crossed HBM"},
             "roofline_valu": valu,
             "kernel_ms": kernel_ms, "host_wall_ms": host_ms,
-            "consensus": {"windows_per_step": cons_windows / max(1, args.steps), "launches_per_step": 2 * cons_windows / max(1, args.steps),
+            "consensus": {"windows_per_step": cons_windows / max(1, args.steps), "launches_per_step": 3 * cons_windows / max(1, args.steps),
                           "cut_windows_per_step": cons_cut / max(1, args.steps), "expansions_per_step": cons_exp / max(1, args.steps),
                           "nodes_expanded_per_step": cons_cols / max(1, args.steps),
                           "control_kernel_us_per_step": cons_ticks},

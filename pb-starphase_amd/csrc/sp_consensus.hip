@@ -1306,7 +1306,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     {   // launch statistics of the batch (sp_profile_get: cells = count)
         uint64_t cut = 0, ex = 0, pops = 0;
         for (uint32_t p = 0; p < n_prob; ++p) { cut += (uint64_t)h_srch[p].cut_windows; ex += (uint64_t)h_srch[p].expansions; pops += (uint64_t)h_srch[p].pops; }
-        ctx->prof["cons_windows"].cells += pairs; ctx->prof["cons_windows"].launches += 2 * pairs;
+        ctx->prof["cons_windows"].cells += pairs; ctx->prof["cons_windows"].launches += 3 * pairs;
         ctx->prof["cons_cut_windows"].cells += cut; ctx->prof["cons_expansions"].cells += ex; ctx->prof["cons_columns"].cells += pops;
         // where the control kernel's time goes: ticks of the 100 MHz wall clock, the slowest problem of the batch (they run side by side)
         static const char* tick_names[4] = { "cons_ticks_reduce", "cons_ticks_result", "cons_ticks_search", "cons_ticks_tail" };
