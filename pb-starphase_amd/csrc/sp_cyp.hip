@@ -952,39 +952,52 @@ static std::string label_reduced(const Label& l, const sp_cyp_problem* pr) {
     return label_full(l);
 }
 
-// find_full_type_in_sequence + assign_haplotype for a batch of sequences (src/cyp2d6/haplotyper.rs:326-602)
-static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::vector<std::string>& seqs, double max_missing, bool force, std::vector<Label>& out) {
+// find_full_type_in_sequence + assign_haplotype for a batch of sequences (src/cyp2d6/haplotyper.rs:326-602).  What the device computes
+// for a sequence (its best template, the allele scores over its variant states) does not depend on `force`; the caller types the group
+// consensuses and, after merging, the final ones -- mostly the same strings -- so the results are kept per sequence.
+struct Typed { int best_template = -1; uint32_t bvi = 0, ball = 0; std::vector<uint8_t> tie; };
+using TypeCache = std::map<std::string, Typed>;
+static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::vector<std::string>& seqs, double max_missing, bool force, std::vector<Label>& out,
+                              TypeCache& cache) {
     out.assign(seqs.size(), Label());
-    std::vector<uint32_t> live;                                        // an empty sequence has no matches: Unknown
+    std::vector<const std::string*> fresh;                             // sequences the device has not seen yet (an empty one has no matches: Unknown)
     std::string blob; std::vector<uint64_t> off(1, 0);
-    for (uint32_t i = 0; i < seqs.size(); ++i) if (!seqs[i].empty()) { live.push_back(i); blob += seqs[i]; off.push_back(blob.size()); }
-    if (live.empty()) return SP_OK;
-    sp_seqset pooled; sp_seqset* set = &pooled;                       // pooled buffers: no allocation, no free (a handful of consensuses)
-    int32_t rc = sp_seqset_make_small(ctx, "cyp_typed", blob.data(), off.data(), (uint32_t)live.size(), true, set);
-    if (rc != SP_OK) return rc;
-    std::vector<sp_region_hit> hits(live.size() * 16 + 16); uint64_t nh = 0;
-    rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh);
-    if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh); }
-    std::vector<uint8_t> states((size_t)live.size() * pr->n_variants, 3);
-    if (rc == SP_OK) rc = sp_cyp_variant_states(ctx, set, pr->backbone, pr->backbone_len, pr->n_variants, pr->var_pos, pr->var_ref, pr->var_alt, states.data(), nullptr);
-    std::vector<uint32_t> bvi(live.size()), ball(live.size()); std::vector<uint8_t> tie((size_t)live.size() * std::max<uint32_t>(pr->n_alleles, 1));
-    if (rc == SP_OK && pr->n_alleles && pr->n_variants)
-        rc = sp_cyp_score_alleles(ctx, pr->n_variants, pr->n_alleles, pr->hap_matrix, pr->var_is_vi, (uint32_t)live.size(), states.data(), bvi.data(), ball.data(), tie.data());
-    if (rc != SP_OK) return rc;
-    for (uint32_t x = 0; x < live.size(); ++x) {
-        // the best match of this sequence: lowest penalised score, first on ties (:344-349)
-        int best = -1; double bs = 0;
-        for (uint64_t h = 0; h < nh; ++h) if (hits[h].read == (int32_t)x) {
-            const double sc = cyp_score(hits[h].seq_len, hits[h].nm, hits[h].unmapped, true);
-            if (best < 0 || sc < bs) { best = (int)h; bs = sc; }
+    for (const std::string& q : seqs) if (!q.empty() && !cache.count(q)) { cache[q]; fresh.push_back(&q); blob += q; off.push_back(blob.size()); }
+    if (!fresh.empty()) {
+        sp_seqset pooled; sp_seqset* set = &pooled;                       // pooled buffers: no allocation, no free (a handful of consensuses)
+        int32_t rc = sp_seqset_make_small(ctx, "cyp_typed", blob.data(), off.data(), (uint32_t)fresh.size(), true, set);
+        if (rc != SP_OK) return rc;
+        std::vector<sp_region_hit> hits(fresh.size() * 16 + 16); uint64_t nh = 0;
+        rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh);
+        if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh); }
+        std::vector<uint8_t> states((size_t)fresh.size() * pr->n_variants, 3);
+        if (rc == SP_OK) rc = sp_cyp_variant_states(ctx, set, pr->backbone, pr->backbone_len, pr->n_variants, pr->var_pos, pr->var_ref, pr->var_alt, states.data(), nullptr);
+        std::vector<uint32_t> bvi(fresh.size()), ball(fresh.size()); std::vector<uint8_t> tie((size_t)fresh.size() * std::max<uint32_t>(pr->n_alleles, 1));
+        if (rc == SP_OK && pr->n_alleles && pr->n_variants)
+            rc = sp_cyp_score_alleles(ctx, pr->n_variants, pr->n_alleles, pr->hap_matrix, pr->var_is_vi, (uint32_t)fresh.size(), states.data(), bvi.data(), ball.data(), tie.data());
+        if (rc != SP_OK) return rc;
+        for (uint32_t x = 0; x < fresh.size(); ++x) {
+            Typed& t = cache[*fresh[x]];
+            // the best match of this sequence: lowest penalised score, first on ties (:344-349)
+            double bs = 0;
+            for (uint64_t h = 0; h < nh; ++h) if (hits[h].read == (int32_t)x) {
+                const double sc = cyp_score(hits[h].seq_len, hits[h].nm, hits[h].unmapped, true);
+                if (t.best_template < 0 || sc < bs) { t.best_template = hits[h].template_idx; bs = sc; }
+            }
+            t.bvi = bvi[x]; t.ball = ball[x];
+            t.tie.assign(tie.begin() + (size_t)x * pr->n_alleles, tie.begin() + (size_t)(x + 1) * pr->n_alleles);
         }
-        Label& lab = out[live[x]];
-        if (best < 0) continue;                                        // "no matches found" => Unknown (caller.rs:350-355)
-        const int t = hits[best].template_idx;
+    }
+    for (size_t i = 0; i < seqs.size(); ++i) {
+        if (seqs[i].empty()) continue;
+        const Typed& ty = cache[seqs[i]];
+        Label& lab = out[i];
+        if (ty.best_template < 0) continue;                            // "no matches found" => Unknown (caller.rs:350-355)
+        const int t = ty.best_template;
         if (!pr->template_deep[t]) { lab.type = pr->template_type[t]; lab.has_sub = pr->template_subtype && pr->template_subtype[t]; if (lab.has_sub) lab.sub = pr->template_subtype[t]; continue; }
         std::vector<Label> cands;
-        for (uint32_t a = 0; a < pr->n_alleles; ++a) if (tie[(size_t)x * pr->n_alleles + a]) { Label c; c.type = SP_CYP_CYP2D6; c.has_sub = true; c.sub = pr->allele_subtype[a]; cands.push_back(c); }
-        if (bvi[x] == 0 && ball[x] == 0) cands.push_back(Label());     // the Unknown label the search starts from (haplotyper.rs:471-473)
+        for (uint32_t a = 0; a < pr->n_alleles; ++a) if (ty.tie[a]) { Label c; c.type = SP_CYP_CYP2D6; c.has_sub = true; c.sub = pr->allele_subtype[a]; cands.push_back(c); }
+        if (ty.bvi == 0 && ty.ball == 0) cands.push_back(Label());     // the Unknown label the search starts from (haplotyper.rs:471-473)
         if (cands.empty()) continue;
         if (cands.size() > 1) {
             if (!force) continue;                                       // ambiguous => Unknown (:543-546)
@@ -1051,7 +1064,8 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     hm.mark("host:cyp_consensus");
     // 4. merge_consensus_results (caller.rs:750-898): max_missing_typing_frac = 0.1, no forced assignment
     std::vector<Label> glabel;
-    rc = type_sequences(ctx, pr, full_cons, 0.1, false, glabel);
+    TypeCache typed;
+    rc = type_sequences(ctx, pr, full_cons, 0.1, false, glabel, typed);
     if (rc != SP_OK) return rc;
     std::map<std::pair<std::string, std::string>, std::vector<uint32_t>> cset;
     std::map<std::string, std::vector<uint32_t>> uset;
@@ -1096,7 +1110,7 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     hm.mark("host:cyp_merge");
     // 5. typing of the final consensus regions, forced assignment, duplicates become FalseAllele (caller.rs:331-375)
     std::vector<Label> labels;
-    rc = type_sequences(ctx, pr, final_cons, 0.1, true, labels);
+    rc = type_sequences(ctx, pr, final_cons, 0.1, true, labels, typed);
     if (rc != SP_OK) return rc;
     for (size_t i = 0; i < final_cons.size(); ++i)
         for (size_t j = 0; j < i; ++j) if (final_cons[j] == final_cons[i]) { labels[i].type = SP_CYP_FALSE_ALLELE; break; }
