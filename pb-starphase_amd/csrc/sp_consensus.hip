@@ -574,8 +574,15 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
         int j = 0;
 #ifdef SP_K8_TIMING
         int slow_cols = 0, multi_tip = 0, zero_run = 0;
+        long long tb_fast = 0, tb_col = 0, tb_vote = 0, tb_mark = 0;
+#define K8_T0() tb_mark = clock64()
+#define K8_T(acc) do { const long long _n = clock64(); acc += _n - tb_mark; tb_mark = _n; } while (0)
+#else
+#define K8_T0() do { } while (0)
+#define K8_T(acc) do { } while (0)
 #endif
         while (j < n) {
+            K8_T0();
             // A consensus whose state has ONE tip that keeps matching moves nothing but that tip: such a clean run is applied in one go
             // (the tip's position grows by m, the votes of the m columns are the m read bases behind it, one lane per column).
             int m = n - j;
@@ -622,8 +629,10 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
                     if (P.et && th + m == rv.n) a.flags |= F_FINISHED;
                 }
                 j += m;
+                K8_T(tb_fast);
                 continue;
             }
+            K8_T(tb_fast);
 #ifdef SP_K8_TIMING
             slow_cols += 1;
 #endif
@@ -631,8 +640,10 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             column(d0, d1, dualrun, go0, go1, cwin[0][CWIN + j], cwin[1][CWIN + j], T + j + 1, ca0, ca1);
             const int grow = read_cost(d0, d1, dualrun) - before;
             if (grow && lane == 0) atomicAdd(&lc[j + 1], (uint32_t)grow);
+            K8_T(tb_col);
             if (go0) vote(d0, d1, dualrun, 0, T + j + 1, j + 1);
             if (dualrun && go1) vote(d1, d0, dualrun, 1, T + j + 1, j + 1);
+            K8_T(tb_vote);
             j += 1;
         }
         // lookahead: the bases behind every tip (at most two tips per consensus speak) predict the columns after the window
@@ -669,8 +680,10 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             const unsigned long long dt = (unsigned long long)(wall_clock64() - wt0);
             const bool placed = ri.off > T && ri.off <= T + n;
             // [launch][read]: ticks | slow columns << 32 | multi-tip events << 40 | placed << 48 | window bases << 52
-            B.dbg[(size_t)Wp->pad * 16384 + g] = (dt & 0xFFFFFFFFull) | ((unsigned long long)(slow_cols & 255) << 32) | ((unsigned long long)(multi_tip & 255) << 40) |
-                                                  ((unsigned long long)placed << 48) | ((unsigned long long)n << 52);
+            // ticks | slow columns << 32 | buckets (fast-path tries, column pushes, votes; clock64 / 256, 8 bits each) << 40
+            auto b8 = [](long long c) { const long long v = c >> 8; return (unsigned long long)(v > 255 ? 255 : v); };
+            B.dbg[(size_t)Wp->pad * 16384 + g] = (dt & 0xFFFFFFFFull) | ((unsigned long long)(slow_cols & 255) << 32) | (b8(tb_fast) << 40) | (b8(tb_col) << 48) | (b8(tb_vote) << 56);
+            (void)placed; (void)multi_tip;
         }
 #endif
     }
