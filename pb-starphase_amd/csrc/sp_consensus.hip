@@ -555,21 +555,24 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
         const bool dualrun = dual_in != 0;
         if (mode == M_INIT) { vote(d0, d1, false, 0, 0, 0); }
         // number of leading bases on which read[x0 ..] (position relative to the staged window) and the window's bases [j ..] agree
+        // The blocks of 16 bases are compared side by side, one lane each (a window has at most CW / 16 + 1 of them): one round of LDS reads
+        // instead of one per block.
         auto match_run = [&](int x0, int i, int j0, int len) -> int {
-            int done = 0;
             if (x0 < 0 || x0 + len + 16 > RWORDS * 16) return 0;
-            while (done < len) {
-                const int x = x0 + done, jj = j0 + done;
-                const uint32_t a = __builtin_amdgcn_alignbit(rwin[wave][0][(x >> 4) + 1], rwin[wave][0][x >> 4], (uint32_t)(x & 15) << 1);
-                const uint32_t nn = __builtin_amdgcn_alignbit(rwin[wave][1][(x >> 4) + 1], rwin[wave][1][x >> 4], (uint32_t)(x & 15) << 1);
-                const uint32_t b = __builtin_amdgcn_alignbit(cpk[i][CWIN / 16 + (jj >> 4) + 1], cpk[i][CWIN / 16 + (jj >> 4)], (uint32_t)(jj & 15) << 1);
-                const uint32_t xr = a ^ b, mm = ((xr | (xr >> 1)) | nn) & 0x55555555u;
-                int run = mm ? (__builtin_ctz(mm) >> 1) : 16;
-                run = run < len - done ? run : len - done;
-                done += run;
-                if (run < 16) break;
-            }
-            return done;
+            const int nblk = (len + 15) >> 4;                                  // <= CW / 16
+            const int blk = lane < nblk ? lane : 0;
+            const int x = x0 + (blk << 4), jj = j0 + (blk << 4);
+            const uint32_t a = __builtin_amdgcn_alignbit(rwin[wave][0][(x >> 4) + 1], rwin[wave][0][x >> 4], (uint32_t)(x & 15) << 1);
+            const uint32_t nn = __builtin_amdgcn_alignbit(rwin[wave][1][(x >> 4) + 1], rwin[wave][1][x >> 4], (uint32_t)(x & 15) << 1);
+            const uint32_t b = __builtin_amdgcn_alignbit(cpk[i][CWIN / 16 + (jj >> 4) + 1], cpk[i][CWIN / 16 + (jj >> 4)], (uint32_t)(jj & 15) << 1);
+            const uint32_t xr = a ^ b, mm = ((xr | (xr >> 1)) | nn) & 0x55555555u;
+            int run = mm ? (__builtin_ctz(mm) >> 1) : 16;
+            const int room = len - (blk << 4);
+            run = run < room ? run : room;
+            const unsigned long long stop = __ballot(lane < nblk && run < 16 && run < room);
+            if (!stop) return len;
+            const int t = __builtin_ctzll(stop);
+            return (t << 4) + __builtin_amdgcn_readlane(run, t);
         };
         int j = 0;
 #ifdef SP_K8_TIMING
