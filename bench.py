@@ -440,6 +440,9 @@ def main():
     if rank == 0:
         # VALU wave-instructions of one k1_cells launch: rocprofv3 --pmc SQ_INSTS_VALU of this workload (profiles/r02/valu_k1_cells.json);
         # the peak is measured in this run (sp_microbench: eight independent v_add_u32 chains per lane on every SIMD)
+        import hashlib
+        k1_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "pb-starphase_amd", "csrc", f), "rb").read() for f in ("sp_hla.hip", "sp_wfa.cuh"))).hexdigest()[:16]
+        stale = lambda rec: "" if rec.get("k1_source_sha16") == k1_sha else "STALE: the kernel sources changed after this counter pass; "
         valu = None
         vfile = os.path.join(ROOT, "profiles", "r02", "valu_k1_cells.json")
         if os.path.exists(vfile) and args.reads == 10000 and avg_ms > 0:
@@ -448,12 +451,12 @@ def main():
             valu = {"bound": "valu", "kernel": "k1_cells_kernel", "achieved": rate, "peak": peaks["valu_int_wave_instr_per_s"], "unit": "wave-instr/s",
                     "frac": rate / peaks["valu_int_wave_instr_per_s"], "nominal_peak": VALU_PEAK_WAVE_INSTR,
                     "frac_of_match16_mix_peak": rate / peaks["match16_valu_wave_instr_per_s"],
-                    "note": "instruction count from the committed PMC pass (" + rec["method"] + "), launch time and peak measured in this run"}
+                    "note": stale(rec) + "instruction count from the committed PMC pass (" + rec["method"] + "), launch time and peak measured in this run"}
         traffic, traffic_note = None, None
         tfile = os.path.join(ROOT, "profiles", "r02", "traffic_k1_cells.json")
         if os.path.exists(tfile) and args.reads == 10000:
             rec = json.load(open(tfile))
-            traffic, traffic_note = rec["hbm_bytes_per_launch"], "from the committed rocprofv3 PMC passes of this workload (" + rec["method"] + ")"
+            traffic, traffic_note = rec["hbm_bytes_per_launch"], stale(rec) + "from the committed rocprofv3 PMC passes of this workload (" + rec["method"] + ")"
         total_reads = args.reads * world * args.steps
         line = {
             "metric": "HiFi reads/sec diplotyped (HLA-A + HLA-B, reads -> diplotype: realignment, dual + group consensus, typing, het/hom call)",

@@ -39,6 +39,18 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
 # WRITE_SIZE are KB; gfx950 tallies 128-byte read requests at 64 bytes, so FETCH_SIZE is doubled).  The deep passes of
 # k1_cells_kernel are small launches of the same kernel: only dispatches within 10x of the largest one count as main launches.
 import json
+import hashlib
+
+
+def k1_source_sha16():
+    """the kernel the counters belong to: bench.py marks the committed numbers stale when these sources have changed since"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("pb-starphase_amd/csrc/sp_hla.hip", "pb-starphase_amd/csrc/sp_wfa.cuh"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 vals = {}
 for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     v = []
@@ -54,7 +66,7 @@ if vals.get("FETCH_SIZE") and vals.get("WRITE_SIZE"):
         return sum(big) / len(big), len(big)
     f, nf = per_main(vals["FETCH_SIZE"]); w, nw = per_main(vals["WRITE_SIZE"])
     rec = {"kernel": "k1_cells_kernel", "fetch_kb_per_launch": f, "write_kb_per_launch": w, "main_launches": nf,
-           "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+           "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0, "k1_source_sha16": k1_source_sha16(),
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/run_rocprof.sh); KB -> bytes; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)"}
     json.dump(rec, open(os.path.join(out, "traffic_k1_cells.json"), "w"), indent=1)
     print("== traffic", rec)
@@ -67,7 +79,7 @@ for f in find("pmc_sq/**/*counter_collection.csv"):
             v.append(float(row.get("Counter_Value", 0) or 0))
 if v:
     big = [x for x in v if x * 10 >= max(v)]
-    rec = {"kernel": "k1_cells_kernel", "sq_insts_valu_per_launch": sum(big) / len(big), "main_launches": len(big),
+    rec = {"kernel": "k1_cells_kernel", "sq_insts_valu_per_launch": sum(big) / len(big), "main_launches": len(big), "k1_source_sha16": k1_source_sha16(),
            "method": "rocprofv3 --pmc SQ_INSTS_VALU (pass pmc_sq of profiles/run_rocprof.sh), mean over the main launches"}
     json.dump(rec, open(os.path.join(out, "valu_k1_cells.json"), "w"), indent=1)
     print("== valu", rec)

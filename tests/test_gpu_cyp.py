@@ -227,3 +227,28 @@ def test_weight_sequence_reference_vectors(oracle, pkg, gpu_ctx):
     for k, seg in enumerate(cyp_cases.WEIGHT_SEQUENCE_SEGMENTS):
         e_ed, e_ov, e_kept = of.oracle_weight_sequence(oracle, seg, cyp_cases.WEIGHT_SEQUENCE_CONSENSUS, np.ones(3, np.uint8))
         assert ed[k].tolist() == e_ed.tolist() and ov[k].tolist() == e_ov.tolist() and kept[k] == e_kept
+
+
+def test_find_regions_at_four_to_five_percent_divergence(oracle, pkg, gpu_ctx):
+    """max_ed_frac = 0.05 (src/cyp2d6/haplotyper.rs:160,228-232): a 6.2 kb template hit with 4.5 % edits (280 > the old 255-edit cap) is
+    kept, one with 5.6 % is dropped; library == oracle either way."""
+    from pb_starphase_amd import synth
+    rng = np.random.default_rng(12)
+    template = "".join(rng.choice(list("ACGT"), 6200))
+    flank = lambda n: "".join(rng.choice(list("ACGT"), n))
+    reads, want = [], []
+    for frac, kept in ((0.030, True), (0.045, True), (0.048, True), (0.056, False), (0.070, False)):
+        n_ed = int(frac * len(template))
+        body = synth.mutate(rng, template, n_sub=n_ed - 20, n_ins=10, n_del=10)
+        reads.append(flank(700) + body + flank(900)); want.append(kept)
+    T, R = gpu_ctx.upload([template]), gpu_ctx.upload(reads)
+    types = np.array([2], np.int32)                                              # CYP2D6: unmapped bases are not penalised in the filter
+    hits = gpu_ctx.cyp_find_regions(T, types, R, 1.0)
+    for r, read in enumerate(reads):
+        exp = of.oracle_find_base_type(oracle, read, [template], types, 1.0)
+        got = hits[hits["read"] == r]
+        assert len(got) == len(exp) == (1 if want[r] else 0), (r, len(got), len(exp))
+        for g, e in zip(got, exp):
+            assert tuple(int(g[k]) for k in exp.dtype.names) == tuple(int(x) for x in e.tolist())
+    nm = [int(h["nm"]) for h in hits]
+    assert max(nm) > 255 and all(n <= 0.05 * 6200 + 1 for n in nm), nm

@@ -327,3 +327,30 @@ def test_k1_sliced_batches(oracle, pkg, gpu_ctx, small, monkeypatch):
     sliced, cells2 = db.realign_reads(rs, cells=True)
     assert sliced.tobytes() == whole.tobytes() and (cells2 == cells).all()
     assert db.realign_reads(rs).tobytes() == whole.tobytes()
+
+
+def test_k1_gene_vote_filter(oracle, pkg, gpu_ctx, small):
+    """a read is only scored against the alleles of genes whose reference got >= 16 anchor votes and >= 1/10 of the best
+    gene's votes.  A read of one gene leaves the other gene's cells empty; a chimeric read (an HLA-A haplotype followed by an HLA-B one) anchors in
+    both and has cells in both; the cell matrix equals the oracle's in every case."""
+    fx, db = small
+    ga = [a for a in range(len(fx.ids)) if fx.gene_of[a] == 0 and fx.dna[a]]
+    gb = [a for a in range(len(fx.ids)) if fx.gene_of[a] == 1 and fx.dna[a]]
+    ha, sa = fx.haplotype(0, ga[0]); hb, sb = fx.haplotype(1, gb[0])
+    read_a = ha[sa:sa + len(fx.dna[ga[0]])]
+    read_b = hb[sb:sb + len(fx.dna[gb[0]])]
+    chimera = read_a + read_b
+    reads = [read_a, read_b, chimera]
+    rs = gpu_ctx.upload(reads)
+    out, cells = db.realign_reads(rs, cells=True)
+    exp, ecells = hx.k1_expected(oracle, fx, reads)
+    assert (cells == ecells).all(), np.argwhere(cells != ecells)[:10]
+    for r, e in enumerate(exp):
+        assert out[r]["status"] == e["status"] and out[r]["best_allele"] == e["best_allele"], (r, out[r], e)
+    none = 0xFFFFFFFF
+    in_a, in_b = np.array(fx.gene_of) == 0, np.array(fx.gene_of) == 1
+    has_dna = np.array([bool(d) for d in fx.dna])
+    assert (cells[0][in_b] == none).all() and (cells[0][in_a & has_dna] != none).any()
+    assert (cells[1][in_a] == none).all() and (cells[1][in_b & has_dna] != none).any()
+    # the chimera is anchored in both genes: cells were run in both
+    assert (cells[2][in_a & has_dna] != none).any() and (cells[2][in_b & has_dna] != none).any()
