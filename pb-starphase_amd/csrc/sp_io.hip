@@ -58,6 +58,7 @@ struct Bgzf {
         if (std::fread(raw.data() + had, 1, raw.size() - had, f) != raw.size() - had) { err = "truncated BGZF block"; return false; }
         const uint8_t* tail = raw.data() + raw.size() - 8;
         const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (isize > 65536u) { err = "BGZF block claims more than 64 KiB"; return false; }        // (the format's limit: nothing larger is allocated on a file's say-so)
         block.resize(isize);
         if (isize) {
             z_stream z{};
@@ -135,6 +136,7 @@ bool load_bai(sp_bam* b, const std::string& path) {
     auto need = [&](size_t n) { return at + n <= d.size(); };
     if (!need(4)) return false;
     const uint32_t n_ref = le32(d.data() + at); at += 4;
+    if (n_ref > (1u << 24)) return false;
     b->index.assign(n_ref, {});
     for (uint32_t r = 0; r < n_ref; ++r) {
         if (!need(4)) return false;
@@ -170,13 +172,16 @@ int32_t sp_bam_open(const char* path, sp_bam** out, char* err, uint32_t err_cap)
     uint8_t h[12];
     if (!b->z.read(h, 8) || std::memcmp(h, "BAM\1", 4) != 0) return bad(b->z.err.empty() ? "not a BAM file" : b->z.err);
     const uint32_t l_text = le32(h + 4);
+    if (l_text > (1u << 30)) return bad("corrupt BAM header");
     std::vector<uint8_t> skip(l_text);
     if (l_text && !b->z.read(skip.data(), l_text)) return bad(b->z.err);
     if (!b->z.read(h, 4)) return bad(b->z.err);
     const uint32_t n_ref = le32(h);
+    if (n_ref > (1u << 24)) return bad("corrupt BAM header");
     for (uint32_t r = 0; r < n_ref; ++r) {
         if (!b->z.read(h, 4)) return bad(b->z.err);
         const uint32_t l_name = le32(h);
+        if (l_name > (1u << 16)) return bad("corrupt BAM header");
         std::string name(l_name, '\0');
         if (l_name && !b->z.read(&name[0], l_name)) return bad(b->z.err);
         while (!name.empty() && name.back() == '\0') name.pop_back();
@@ -236,7 +241,7 @@ int32_t sp_bam_fetch(sp_bam* b, const char* chrom, uint64_t start, uint64_t end,
             uint8_t h4[4];
             if (!b->z.read(h4, 4)) { if (!b->z.err.empty()) return bam_fail(b, b->z.err); break; }
             const uint32_t block_size = le32(h4);
-            if (block_size < 32) return bam_fail(b, "corrupt BAM record");
+            if (block_size < 32 || block_size > (1u << 28)) return bam_fail(b, "corrupt BAM record");
             rec.resize(block_size);
             if (!b->z.read(rec.data(), block_size)) return bam_fail(b, b->z.err.empty() ? "truncated BAM record" : b->z.err);
             const int32_t ref_id = (int32_t)le32(rec.data()); const int64_t pos = (int32_t)le32(rec.data() + 4);

@@ -28,7 +28,7 @@ struct Value {
 };
 
 struct Parser {
-    const char* p; const char* end; std::string err;
+    const char* p; const char* end; std::string err; int depth = 0;
     Parser(const char* b, size_t n) : p(b), end(b + n) {}
     void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
     bool fail(const char* m) { if (err.empty()) err = m; return false; }
@@ -59,6 +59,8 @@ struct Parser {
         return true;
     }
     bool parse(Value& v) {
+        struct Depth { int& d; explicit Depth(int& x) : d(x) { ++d; } ~Depth() { --d; } } guard(depth);
+        if (depth > 256) return fail("nested deeper than 256 levels");
         ws();
         if (p >= end) return fail("unexpected end");
         if (*p == '{') {

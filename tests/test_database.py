@@ -52,6 +52,8 @@ def test_load_errors(D, pkg, tmp_path):
         D.Database(b'{"database_metadata": {')
     with pytest.raises(pkg.StarphaseError, match="database_metadata"):
         D.Database(b'{"gene_entries": {}}')
+    with pytest.raises(pkg.StarphaseError, match="256 levels"):
+        D.Database(b'{"database_metadata": ' + b"[" * 400 + b"]" * 400 + b"}")
     bad = gzip.compress(b'{"database_metadata": {}}')[:-9]
     with pytest.raises(pkg.StarphaseError, match="gzip"):
         D.Database(bad)
