@@ -2,6 +2,7 @@
 // Objects keep their members in file order (serde_json's BTreeMap-backed types are re-sorted by the callers that need key order).
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>

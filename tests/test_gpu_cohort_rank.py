@@ -1,0 +1,71 @@
+"""BASELINE configs[4] as one rank sees it: 256 samples sharded over 8 ranks -> this rank's 32 samples.  All of them go through one K1
+call + sp_hla_diplotype_cohort (HLA-A / -B); four of them also get their CYP2D6 call and their 18 variant-gene calls; the per-(sample,
+gene) records of the rank go through the gather of pb-starphase_amd/shard.py (world size 1 here; tests/test_shard_gloo.py and
+tests/test_gpu_bench.py run it with two ranks).  Every HLA and CYP2D6 call equals the simulated truth, every variant-gene solve the oracle."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cyp_cases_real as cr
+import variant_glue as vg
+from test_gpu_panel import synthetic_observations
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_one_rank_of_the_cohort(oracle, pkg, gpu_ctx):
+    from pb_starphase_amd import synth, shard
+    from test_gpu_variant import gpu_struct
+    world, rank, n_total = 8, 3, 256
+    mine = shard.partition(n_total, world, rank)
+    assert len(mine) == 32 and mine[0] == 96
+    fx = synth.HlaFixture()
+    db = fx.make_db(pkg, gpu_ctx)
+    genes = list(range(len(fx.genes)))
+    reads, sample_of, truth = [], [], {}
+    for k, s in enumerate(mine):
+        rng = np.random.default_rng(10_000 + s)                                 # a sample's data depends on its global id, not on the rank
+        for g in genes:
+            pick = sorted(rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist())
+            truth[(s, g)] = pick
+            for a in pick:
+                hap, st = fx.haplotype(g, a)
+                rs = synth.simulate_reads(rng, hap, st, len(fx.dna[a]), 22, mean_len=7000, sd_len=1500, min_overlap=2500)
+                reads += rs; sample_of += [k] * len(rs)
+    R = gpu_ctx.upload(reads)
+    k1 = db.realign_reads(R)
+    cohort, _ = db.diplotype_cohort(len(mine), sample_of, genes, R, k1)
+    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+    records = []
+    for k, s in enumerate(mine):
+        for g in genes:
+            c = cohort[k][g][0]
+            got = sorted([c.allele1, c.allele2])
+            assert c.status == 0 and all(same(x, y) for x, y in zip(got, truth[(s, g)])), (s, g, got, truth[(s, g)])
+            records.append((s, g, c.allele1, c.allele2))
+    # CYP2D6 and the variant genes of four of the rank's samples
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    cdb = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
+    scen = cr.scenarios(locus)
+    entries = json.load(gzip.open(os.path.join(GOLDEN, "gene_entries_v0.14.1.json.gz")))["gene_entries"]
+    prepared = {name: vg.load_database_haplotypes(oracle, entries[name], None) for name in sorted(entries)}
+    for s in mine[:4]:
+        rng = np.random.default_rng(20_000 + s)
+        _name, haps, expected = scen[s % 3]                                     # *1/*2, *4/*4, *5/*1
+        call, _cons, _labels = cdb.diplotype(gpu_ctx.upload(locus.sample(rng, haps, 100, lo=8000, hi=16000)))
+        assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected), (s, call.hap1, call.hap2, expected)
+        records.append((s, len(genes), 0, 0))                                   # (the string call travels beside the integer table in a real run)
+        for gi, name in enumerate(sorted(entries)):
+            vh, hl = prepared[name]
+            _h1, _h2, obs, _ph = synthetic_observations(rng, hl)
+            prob = vg.Problem(vh, hl, obs, entries[name].get("structural_variants"))
+            assert gpu_ctx.variant_solve(gpu_struct(pkg, prob)) == vg.oracle_solve(oracle, prob), (s, name)
+            records.append((s, len(genes) + 1 + gi, 0, 0))
+    table = shard.gather_calls(np.array(records, shard.CALL_DTYPE))
+    assert len(table) == 32 * 2 + 4 * (1 + len(entries)) and table["sample"].min() == 96 and table["sample"].max() == 127
+    assert (np.diff(table["sample"]) >= 0).all()
