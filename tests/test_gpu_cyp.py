@@ -252,3 +252,39 @@ def test_find_regions_at_four_to_five_percent_divergence(oracle, pkg, gpu_ctx):
             assert tuple(int(g[k]) for k in exp.dtype.names) == tuple(int(x) for x in e.tolist())
     nm = [int(h["nm"]) for h in hits]
     assert max(nm) > 255 and all(n <= 0.05 * 6200 + 1 for n in nm), nm
+
+
+def test_variant_states_on_clustered_variants(oracle, pkg, gpu_ctx):
+    """K9 on the graphs of tests/test_oracle_cyp.py::test_variant_states_against_joint_enumeration (overlapping deletion + SNV, adjacent
+    insertion, a third base at a SNV): GPU == oracle, whose states that test proves equal to brute-force joint enumeration."""
+    rng = np.random.default_rng(9)
+    n_two = n = 0
+    for rep in range(8):
+        backbone = "".join(rng.choice(list("ACGT"), 900))
+        p = int(rng.integers(200, 500))
+        other = lambda c: "ACGT"[("ACGT".index(c) + 1 + int(rng.integers(0, 3))) % 4]
+        variants = sorted([(p, backbone[p], other(backbone[p])), (p, backbone[p:p + 3], backbone[p]),
+                           (p + 3, backbone[p + 3], backbone[p + 3] + "".join(rng.choice(list("ACGT"), 2))), (p + 5, backbone[p + 5], other(backbone[p + 5])),
+                           (p + 60, backbone[p + 60], other(backbone[p + 60])), (p + 80, backbone[p + 80:p + 84], backbone[p + 80]),
+                           (p + 200, backbone[p + 200:p + 202], backbone[p + 200]), (p + 201, backbone[p + 201], other(backbone[p + 201]))], key=lambda v: v[0])
+        pos, refs, alts = [v[0] for v in variants], [v[1] for v in variants], [v[2] for v in variants]
+        seqs = []
+        for k in range(6):
+            chosen, end = [], -1
+            for v in range(len(variants)):                                        # a random compatible subset, left to right
+                if variants[v][0] >= end and rng.random() < 0.5:
+                    chosen.append(v); end = variants[v][0] + len(variants[v][1])
+            s = apply_variants(backbone, variants, chosen)
+            if k % 3 == 1:
+                q = p + int(rng.integers(0, 8)); s = s[:q] + other(s[q]) + s[q + 1:]
+            if k % 3 == 2:
+                v = next(x for x in range(len(variants)) if variants[x][0] == p + 60)
+                third = next(c for c in "ACGT" if c not in (variants[v][1], variants[v][2]))
+                s = backbone[:p + 60] + third + backbone[p + 61:]
+            seqs.append(s)
+        states, _alns = gpu_ctx.cyp_variant_states(gpu_ctx.upload(seqs), backbone, pos, refs, alts)
+        for i, s in enumerate(seqs):
+            e_states, _ = of.oracle_variant_states(oracle, s, backbone, pos, refs, alts)
+            assert states[i].tolist() == e_states.tolist(), (rep, i, states[i].tolist(), e_states.tolist())
+            n += len(pos); n_two += int((e_states == 2).sum())
+    assert n >= 300 and n_two >= 4
