@@ -780,6 +780,12 @@ enum { SP_DETAILS_SUBALLELE_MATCH = 0, SP_DETAILS_CORE_MATCH = 1, SP_DETAILS_INE
 int32_t sp_result_insert(sp_result* result, const char* gene, const sp_gene_details* details, int32_t constructor);
 int32_t sp_result_json(sp_result* result, const char** text, uint64_t* len);
 int32_t sp_result_save(sp_result* result, const char* path);                    /* gzip when the name ends in ".gz" */
+/* save_pharmcat_tsv (src/main.rs:190-241): "#gene<TAB>diplotype" and one row per gene in key order -- the de-duplicated simple
+ * diplotypes of the gene (PgxGeneDetails::dedup_simple_diplotypes: equal up to the order of the two haplotypes) give "Multiple/Multiple"
+ * when more than one is left, else Diplotype::pharmcat_diplotype (a haplotype containing '+' in brackets); MT-RNR1 is written as its
+ * single haplotype, "Unknown" when the two differ. */
+int32_t sp_result_pharmcat_tsv(sp_result* result, const char** text, uint64_t* len);
+int32_t sp_result_save_pharmcat_tsv(sp_result* result, const char* path);
 
 /* ------------------------------------------------------------------ f2: decoding the input files (host only)
  * What the reference gets from rust-htslib: the records of an indexed BAM that overlap a region (diplotype_hla_batch,

@@ -20,7 +20,7 @@ struct sp_gene_details {
 };
 
 struct sp_result {
-    std::string version, err, text;
+    std::string version, err, text, tsv;
     std::string md[5];
     std::map<std::string, Value> genes;           // BTreeMap<String, PgxGeneDetails>
 };
@@ -230,6 +230,61 @@ int32_t sp_result_json(sp_result* r, const char** text, uint64_t* len) {
     spj::write_pretty(r->text, root);
     *text = r->text.c_str();
     if (len) *len = r->text.size();
+    return SP_OK;
+}
+
+int32_t sp_result_pharmcat_tsv(sp_result* r, const char** text, uint64_t* len) {
+    if (!r || !text) return SP_ERR_INVALID_ARG;
+    // the csv crate quotes a field that holds the delimiter, a quote or a line break
+    auto field = [](const std::string& f) {
+        if (f.find_first_of("\t\"\r\n") == std::string::npos) return f;
+        std::string q = "\"";
+        for (char c : f) { if (c == '"') q += '"'; q += c; }
+        return q + "\"";
+    };
+    std::string out = "#gene\tdiplotype\n";
+    for (const auto& kv : r->genes) {
+        const Value* simple = kv.second.get("simple_diplotypes");
+        const Value* list = (simple && simple->kind == Value::Array) ? simple : kv.second.get("diplotypes");
+        if (!list || list->arr.empty()) return fail(r, "gene " + kv.first + " has no diplotype to report");
+        // dedup_simple_diplotypes: a BTreeSet over Diplotype, whose order compares the two haplotypes as a sorted pair; the first of equal ones stays
+        struct D { std::string h1, h2; std::pair<std::string, std::string> key; };
+        std::vector<D> set;
+        for (const Value& d : list->arr) {
+            D x; x.h1 = d.get("hap1") ? d.get("hap1")->as_str() : std::string(); x.h2 = d.get("hap2") ? d.get("hap2")->as_str() : std::string();
+            x.key = x.h1 < x.h2 ? std::make_pair(x.h1, x.h2) : std::make_pair(x.h2, x.h1);
+            bool seen = false;
+            for (const D& y : set) if (y.key == x.key) seen = true;
+            if (!seen) set.push_back(std::move(x));
+        }
+        std::sort(set.begin(), set.end(), [](const D& a, const D& b) { return a.key < b.key; });
+        std::string h1 = set[0].h1, h2 = set[0].h2;
+        if (set.size() > 1) h1 = h2 = "Multiple";
+        std::string dip;
+        if (kv.first == "MT-RNR1") dip = h1 == h2 ? h1 : "Unknown";
+        else {
+            char buf[4]; const uint32_t need = sp_diplotype_string(h1.c_str(), h2.c_str(), 1, buf, 0);
+            std::vector<char> full(need + 1);
+            sp_diplotype_string(h1.c_str(), h2.c_str(), 1, full.data(), need + 1);
+            dip = full.data();
+        }
+        out += field(kv.first) + "\t" + field(dip) + "\n";
+    }
+    r->tsv.swap(out);
+    *text = r->tsv.c_str();
+    if (len) *len = r->tsv.size();
+    return SP_OK;
+}
+
+int32_t sp_result_save_pharmcat_tsv(sp_result* r, const char* path) {
+    if (!r || !path) return SP_ERR_INVALID_ARG;
+    const char* text; uint64_t len;
+    const int32_t rc = sp_result_pharmcat_tsv(r, &text, &len);
+    if (rc != SP_OK) return rc;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(r, std::string("cannot create ") + path);
+    const bool ok = std::fwrite(text, 1, (size_t)len, f) == (size_t)len;
+    if (std::fclose(f) != 0 || !ok) return fail(r, std::string("cannot write ") + path);
     return SP_OK;
 }
 

@@ -95,6 +95,8 @@ def _lib():
         "sp_result_insert": (_i32, [_vp, _s, _vp, _i32]),
         "sp_result_json": (_i32, [_vp, P(_s), P(_u64)]),
         "sp_result_save": (_i32, [_vp, _s]),
+        "sp_result_pharmcat_tsv": (_i32, [_vp, P(_s), P(_u64)]),
+        "sp_result_save_pharmcat_tsv": (_i32, [_vp, _s]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -405,6 +407,14 @@ class Result:
 
     def save(self, path):
         self._check(_lib().sp_result_save(self._h, _b(path)))
+
+    def pharmcat_tsv(self):
+        s, n = _s(), _u64()
+        self._check(_lib().sp_result_pharmcat_tsv(self._h, C.byref(s), C.byref(n)))
+        return s.value.decode()
+
+    def save_pharmcat_tsv(self, path):
+        self._check(_lib().sp_result_save_pharmcat_tsv(self._h, _b(path)))
 
 
 # ------------------------------------------------------------------ input files (sp_bam_*, sp_vcf_*)

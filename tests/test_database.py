@@ -425,3 +425,23 @@ def test_multi_mappings_no_match_and_structural_variant(D, tmp_path):
         r.save(str(p))
         data = gzip.open(p).read() if name.endswith(".gz") else p.read_bytes()
         assert data.decode() == r.json()
+
+
+def test_pharmcat_tsv(D, pkg, tmp_path):
+    """save_pharmcat_tsv (src/main.rs:190-241): key order, de-duplicated simple diplotypes, "Multiple", brackets around '+' haplotypes,
+    MT-RNR1 as one haplotype"""
+    r = D.Result(None, "x")
+    r.insert("CYP2D6", D.GeneDetails().add_diplotype("*4.001 + *68", "*1.001").add_simple_diplotype("*4 + *68", "*1"), D.FROM_MULTI_MAPPINGS)
+    r.insert("CYP2C19", D.GeneDetails().add_diplotype("*1", "*2").add_diplotype("*2", "*1").set_simple_diplotypes(False), D.SUBALLELE_MATCH)   # the same pair twice
+    r.insert("UGT1A1", D.GeneDetails().add_diplotype("*1", "*80+*28").add_diplotype("*28", "*80").add_simple_diplotype("*1", "*80+*28").add_simple_diplotype("*28", "*80"),
+             D.SUBALLELE_MATCH)
+    r.insert("MT-RNR1", D.GeneDetails().add_diplotype("961T>del", "961T>del"), D.SUBALLELE_MATCH)
+    r.insert("ABCG2", None, D.NO_MATCH)
+    want = ("#gene\tdiplotype\n" "ABCG2\tNO_MATCH/NO_MATCH\n" "CYP2C19\t*1/*2\n" "CYP2D6\t[*4 + *68]/*1\n" "MT-RNR1\t961T>del\n" "UGT1A1\tMultiple/Multiple\n")
+    assert r.pharmcat_tsv() == want
+    r.save_pharmcat_tsv(str(tmp_path / "p.tsv"))
+    assert (tmp_path / "p.tsv").read_text() == want
+    r2 = D.Result()
+    r2.insert("MT-RNR1", D.GeneDetails().add_diplotype("961T>del", "961T>del+Cn"), D.SUBALLELE_MATCH)
+    r2.insert("G\t1", D.GeneDetails().add_diplotype('a"b', "c"), D.SUBALLELE_MATCH)
+    assert r2.pharmcat_tsv() == '#gene\tdiplotype\n"G\t1"\t"a""b/c"\nMT-RNR1\tUnknown\n'
