@@ -335,6 +335,7 @@ typedef struct {
     uint32_t n_singletons; const char* const* singletons;
     int32_t min_consensus_count, dual_max_ed_delta; double min_consensus_fraction;
     int32_t infer_connections, normalize_d6_only;
+    const char* const* var_label;                 /* LoadedVariants::variant_label per variant, for the deep strings of the call; NULL: none are listed */
 } sp_cyp_problem;
 
 #define SP_CYP_MAXCONS 64
@@ -346,6 +347,10 @@ typedef struct {
     int32_t n1, n2; int32_t chain1[SP_MAX_CHAIN], chain2[SP_MAX_CHAIN];
     double  score;
     char hap1[256], hap2[256], core1[256], core2[256];
+    /* Cyp2d6DetailLevel::DeepAlleles (src/cyp2d6/caller.rs:907-957, Cyp2d6Region::deep_label, src/cyp2d6/region.rs:47-91): every reported
+     * region as "(<index>_<full allele>[ +label | -label | ?label ...])" with the variants that differ from the assigned star allele --
+     * the haplotypes of the InexactDiplotype the reference stores for CYP2D6 (:711-716,737); truncated to the buffer */
+    char deep1[2048], deep2[2048];
 } sp_cyp_call;
 
 int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* problem, const sp_seqset* reads, sp_cyp_call* call,

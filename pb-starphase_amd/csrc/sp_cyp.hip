@@ -952,14 +952,32 @@ static std::string label_reduced(const Label& l, const sp_cyp_problem* pr) {
     return label_full(l);
 }
 
+// The variants of a typed sequence relative to the star allele it was assigned (assign_haplotype, src/cyp2d6/haplotyper.rs:546-595) in the
+// form Cyp2d6Region::deep_label appends them (src/cyp2d6/region.rs:60-91): " +label" unexpected, " -label" missing, " ?label" ambiguous or
+// unknown-but-expected; matches and unknown-and-not-expected are not listed.
+static std::string deep_suffix(const sp_cyp_problem* pr, uint32_t allele, const std::vector<uint8_t>& states) {
+    std::string out;
+    if (states.size() != pr->n_variants || !pr->var_label) return out;
+    const uint8_t* row = pr->hap_matrix + (size_t)allele * pr->n_variants;
+    for (uint32_t v = 0; v < pr->n_variants; ++v) {
+        const int hv = row[v], sv = states[v];
+        char sign = 0;
+        if (hv == 0) sign = sv == 1 ? '+' : sv == 2 ? '?' : 0;               // 0: match, 3: UnknownUnexpected (not listed)
+        else sign = sv == 0 ? '-' : sv == 1 ? 0 : '?';                          // 2: AmbiguousMissing, 3: UnknownMissing
+        if (sign) { out += ' '; out += sign; out += pr->var_label[v]; }
+    }
+    return out;
+}
+
 // find_full_type_in_sequence + assign_haplotype for a batch of sequences (src/cyp2d6/haplotyper.rs:326-602).  What the device computes
 // for a sequence (its best template, the allele scores over its variant states) does not depend on `force`; the caller types the group
 // consensuses and, after merging, the final ones -- mostly the same strings -- so the results are kept per sequence.
-struct Typed { int best_template = -1; uint32_t bvi = 0, ball = 0; std::vector<uint8_t> tie; };
+struct Typed { int best_template = -1; uint32_t bvi = 0, ball = 0; std::vector<uint8_t> tie, states; };
 using TypeCache = std::map<std::string, Typed>;
 static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::vector<std::string>& seqs, double max_missing, bool force, std::vector<Label>& out,
-                              TypeCache& cache) {
+                              TypeCache& cache, std::vector<std::string>* suffix = nullptr) {
     out.assign(seqs.size(), Label());
+    if (suffix) suffix->assign(seqs.size(), std::string());
     std::vector<const std::string*> fresh;                             // sequences the device has not seen yet (an empty one has no matches: Unknown)
     std::string blob; std::vector<uint64_t> off(1, 0);
     for (const std::string& q : seqs) if (!q.empty() && !cache.count(q)) { cache[q]; fresh.push_back(&q); blob += q; off.push_back(blob.size()); }
@@ -986,6 +1004,7 @@ static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::
             }
             t.bvi = bvi[x]; t.ball = ball[x];
             t.tie.assign(tie.begin() + (size_t)x * pr->n_alleles, tie.begin() + (size_t)(x + 1) * pr->n_alleles);
+            t.states.assign(states.begin() + (size_t)x * pr->n_variants, states.begin() + (size_t)(x + 1) * pr->n_variants);
         }
     }
     for (size_t i = 0; i < seqs.size(); ++i) {
@@ -1004,6 +1023,9 @@ static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::
             std::stable_sort(cands.begin(), cands.end(), [](const Label& p, const Label& q) { return label_full(p) < label_full(q); });
         }
         lab = cands[0];
+        // the variants that set the sequence apart from the allele it got (Cyp2d6Region::variants; None for Unknown)
+        if (suffix && lab.type == SP_CYP_CYP2D6 && lab.has_sub)
+            for (uint32_t a = 0; a < pr->n_alleles; ++a) if (lab.sub == pr->allele_subtype[a]) { (*suffix)[i] = deep_suffix(pr, a, ty.states); break; }
     }
     return SP_OK;
 }
@@ -1110,7 +1132,8 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     hm.mark("host:cyp_merge");
     // 5. typing of the final consensus regions, forced assignment, duplicates become FalseAllele (caller.rs:331-375)
     std::vector<Label> labels;
-    rc = type_sequences(ctx, pr, final_cons, 0.1, true, labels, typed);
+    std::vector<std::string> deep_tail;
+    rc = type_sequences(ctx, pr, final_cons, 0.1, true, labels, typed, &deep_tail);
     if (rc != SP_OK) return rc;
     for (size_t i = 0; i < final_cons.size(); ++i)
         for (size_t j = 0; j < i; ++j) if (final_cons[j] == final_cons[i]) { labels[i].type = SP_CYP_FALSE_ALLELE; break; }
@@ -1179,5 +1202,24 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     sp_cyp_chain_to_hap(cr.chain2, cr.n2, types.data(), subs.data(), pr->n_translate, pr->translate_key, pr->translate_val, 1, call->hap2, sizeof call->hap2);
     sp_cyp_chain_to_hap(cr.chain1, cr.n1, types.data(), subs.data(), pr->n_translate, pr->translate_key, pr->translate_val, 0, call->core1, sizeof call->core1);
     sp_cyp_chain_to_hap(cr.chain2, cr.n2, types.data(), subs.data(), pr->n_translate, pr->translate_key, pr->translate_val, 0, call->core2, sizeof call->core2);
+    // Cyp2d6DetailLevel::DeepAlleles (caller.rs:907-957): the same walk with "(<index>_<full allele> <variants>)" as the label of a region
+    auto deep_hap = [&](const int32_t* chain, uint32_t n, char* out, size_t cap2) {
+        auto is_2d = [](int t) { return t == SP_CYP_CYP2D6 || t == SP_CYP_CYP2D7 || t == SP_CYP_DELETION || t == SP_CYP_HYBRID; };
+        int non_deletion = 0;
+        for (uint32_t x = 0; x < n; ++x) { const int t = types[chain[x]]; if (is_2d(t) && t != SP_CYP_CYP2D7 && t != SP_CYP_DELETION) ++non_deletion; }
+        std::string res, prev; int run = 0;
+        auto flush = [&]() { if (run > 0) { if (!res.empty()) res += " + "; res += prev; if (run > 1) res += "x" + std::to_string(run); } };
+        for (int x = (int)n - 1; x >= 0; --x) {
+            const int h = chain[x], t = types[h];
+            if (!(is_2d(t) && t != SP_CYP_CYP2D7)) continue;
+            if (t == SP_CYP_DELETION && non_deletion > 0) continue;
+            const std::string cur = "(" + std::to_string(h) + "_" + label_full(labels[h]) + deep_tail[h] + ")";
+            if (run > 0 && cur == prev) ++run; else { flush(); prev = cur; run = 1; }
+        }
+        flush();
+        std::snprintf(out, cap2, "%s", res.c_str());
+    };
+    deep_hap(cr.chain1, cr.n1, call->deep1, sizeof call->deep1);
+    deep_hap(cr.chain2, cr.n2, call->deep2, sizeof call->deep2);
     return SP_OK;
 }

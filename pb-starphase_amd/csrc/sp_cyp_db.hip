@@ -29,7 +29,7 @@ struct sp_cyp_db {
     // Cyp2d6Config tables (definitions.rs:242-301)
     std::vector<std::string> tr_key, tr_val, con_a, con_b, singles;
     // pointer arrays handed out through sp_cyp_problem
-    std::vector<const char*> p_tsub, p_vref, p_valt, p_asub, p_trk, p_trv, p_ca, p_cb, p_sing;
+    std::vector<const char*> p_tsub, p_vref, p_valt, p_vlab, p_asub, p_trk, p_trv, p_ca, p_cb, p_sing;
 };
 
 namespace {
@@ -156,7 +156,7 @@ int32_t sp_cyp_db_create(sp_ctx* ctx, const sp_cyp_locus* L, const sp_cyp_gene_d
         for (uint32_t i = 0; i < C->n_singletons; ++i) db->singles.push_back(C->singletons[i]);
     }
     for (size_t i = 0; i < db->t_sub.size(); ++i) db->p_tsub.push_back(db->t_has_sub[i] ? db->t_sub[i].c_str() : nullptr);
-    for (uint32_t i = 0; i < NV; ++i) { db->p_vref.push_back(db->v_ref[i].c_str()); db->p_valt.push_back(db->v_alt[i].c_str()); }
+    for (uint32_t i = 0; i < NV; ++i) { db->p_vref.push_back(db->v_ref[i].c_str()); db->p_valt.push_back(db->v_alt[i].c_str()); db->p_vlab.push_back(db->v_label[i].c_str()); }
     for (auto& s : db->a_sub) db->p_asub.push_back(s.c_str());
     for (size_t i = 0; i < db->tr_key.size(); ++i) { db->p_trk.push_back(db->tr_key[i].c_str()); db->p_trv.push_back(db->tr_val[i].c_str()); }
     for (size_t i = 0; i < db->con_a.size(); ++i) { db->p_ca.push_back(db->con_a[i].c_str()); db->p_cb.push_back(db->con_b[i].c_str()); }
@@ -244,6 +244,7 @@ int32_t sp_cyp_db_problem(const sp_cyp_db* db, sp_cyp_problem* pr) {
     pr->n_singletons = (uint32_t)db->singles.size(); pr->singletons = db->p_sing.data();
     // defaults of the CLI (src/cli/diplotype.rs:155-183)
     pr->min_consensus_count = 3; pr->dual_max_ed_delta = 100; pr->min_consensus_fraction = 0.10; pr->infer_connections = 0; pr->normalize_d6_only = 0;
+    pr->var_label = db->p_vlab.data();
     return SP_OK;
 }
 

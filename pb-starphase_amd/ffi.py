@@ -134,7 +134,7 @@ class sp_cyp_problem(C.Structure):
                 ("n_connections", C.c_uint32), ("connection_a", C.POINTER(C.c_char_p)), ("connection_b", C.POINTER(C.c_char_p)),
                 ("n_singletons", C.c_uint32), ("singletons", C.POINTER(C.c_char_p)),
                 ("min_consensus_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("min_consensus_fraction", C.c_double),
-                ("infer_connections", C.c_int32), ("normalize_d6_only", C.c_int32)]
+                ("infer_connections", C.c_int32), ("normalize_d6_only", C.c_int32), ("var_label", C.POINTER(C.c_char_p))]
 
 
 class sp_cyp_locus(C.Structure):
@@ -166,7 +166,8 @@ SP_CYP_MAXCONS = 64
 class sp_cyp_call(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_consensus", C.c_int32), ("cons_type", C.c_int32 * SP_CYP_MAXCONS), ("cons_subtype", (C.c_char * 48) * SP_CYP_MAXCONS),
                 ("n1", C.c_int32), ("n2", C.c_int32), ("chain1", C.c_int32 * 64), ("chain2", C.c_int32 * 64), ("score", C.c_double),
-                ("hap1", C.c_char * 256), ("hap2", C.c_char * 256), ("core1", C.c_char * 256), ("core2", C.c_char * 256)]
+                ("hap1", C.c_char * 256), ("hap2", C.c_char * 256), ("core1", C.c_char * 256), ("core2", C.c_char * 256),
+                ("deep1", C.c_char * 2048), ("deep2", C.c_char * 2048)]
 
 
 class sp_hla_call_config(C.Structure):
@@ -510,7 +511,7 @@ class Context:
         return states, alns[:seqs.n]
 
     def cyp_diplotype(self, templates, template_type, template_subtype, template_deep, backbone, variants, is_vi, allele_subtype, hap_matrix,
-                      cfg, reads, min_count=3, min_af=0.10, delta=100, infer=False, normalize_d6_only=False, cons_cap=16384):
+                      cfg, reads, min_count=3, min_af=0.10, delta=100, infer=False, normalize_d6_only=False, cons_cap=16384, var_labels=None):
         """sp_cyp_diplotype.  templates: SeqSet; variants: [(pos, ref, alt)]; cfg: dict(translate, connections, singletons).
         Returns (sp_cyp_call, [consensus strings], [(type, subtype|None)])"""
         def strs(items):
@@ -529,7 +530,7 @@ class Context:
         pr = sp_cyp_problem(templates._h, tt.ctypes.data, keep[0], deep.ctypes.data, backbone.encode(), len(backbone),
                             len(variants), pos.ctypes.data, keep[1], keep[2], vi.ctypes.data, len(allele_subtype), keep[3], hm.ctypes.data,
                             len(cfg["translate"]), keep[4], keep[5], len(cfg["connections"]), keep[6], keep[7], len(cfg["singletons"]), keep[8],
-                            min_count, delta, min_af, int(infer), int(normalize_d6_only))
+                            min_count, delta, min_af, int(infer), int(normalize_d6_only), strs(list(var_labels)) if var_labels is not None else None)
         call = sp_cyp_call()
         buf = C.create_string_buffer(SP_CYP_MAXCONS * cons_cap)
         self.check(lib().sp_cyp_diplotype(self._h, C.byref(pr), reads._h, C.byref(call), buf, cons_cap))

@@ -310,12 +310,17 @@ class Chr22Locus:
     def slice(self, a, b):
         return self.sequence[a - self.start:b - self.start]
 
-    def star_allele(self, star):
-        """the CYP2D6 region carrying the variants of allele `star` ("4.001")"""
+    def star_allele(self, star, drop=(), add=()):
+        """the CYP2D6 region carrying the variants of allele `star` ("4.001"); drop: variant ids left out, add: (star, id) pairs of variants
+        borrowed from other alleles -- a novel allele for the deep labels"""
         d = next(v for v in self.gene_def.values() if v["star_allele"] == star)
         a, b = self.cc["CYP2D6"]["start"], self.cc["CYP2D6"]["end"]
         s = self.slice(a, b)
-        for v in sorted(d["variants"], key=lambda v: -v["position"]):          # right to left: earlier coordinates stay valid
+        variants = [v for v in d["variants"] if v["id"] not in drop]
+        for other, vid in add:
+            od = next(v for v in self.gene_def.values() if v["star_allele"] == other)
+            variants.append(next(v for v in od["variants"] if v["id"] == vid))
+        for v in sorted(variants, key=lambda v: -v["position"]):               # right to left: earlier coordinates stay valid
             p = v["position"] - a
             assert s[p:p + len(v["reference"])] == v["reference"], (star, v)
             s = s[:p] + v["alternate"] + s[p + len(v["reference"]):]

@@ -32,7 +32,8 @@ def simplify(oracle, typ, sub, cfg):
 
 class Db:
     """the typing database a sample needs: templates in full_allele() order, backbone + variants, star-allele definitions"""
-    def __init__(self, names, types, subtypes, seqs, deep, backbone, variants, is_vi, allele_subtypes, hap_matrix):
+    def __init__(self, names, types, subtypes, seqs, deep, backbone, variants, is_vi, allele_subtypes, hap_matrix, var_labels=None):
+        self.var_labels = var_labels
         self.names, self.types, self.subtypes, self.seqs, self.deep = names, np.asarray(types, np.int32), subtypes, seqs, deep
         self.backbone, self.variants, self.is_vi = backbone, variants, np.asarray(is_vi, np.uint8)
         self.allele_subtypes, self.hap_matrix = allele_subtypes, np.asarray(hap_matrix, np.uint8)
@@ -48,8 +49,39 @@ def score_alleles(oracle, db, states):
     return (bv.value, ba.value), tie[:na]
 
 
-def full_type(oracle, db, seq, max_missing, force):
-    """find_full_type_in_sequence + assign_haplotype (src/cyp2d6/haplotyper.rs:326-602) -> (type, subtype)"""
+def deep_tail(db, allele, states):
+    """the variants of a typed sequence against its assigned star allele as Cyp2d6Region::deep_label lists them (src/cyp2d6/haplotyper.rs:546-595,
+    src/cyp2d6/region.rs:60-91): +unexpected, -missing, ?ambiguous / unknown-but-expected"""
+    if db.var_labels is None:
+        return ""
+    out = []
+    for v, label in enumerate(db.var_labels):
+        hv, sv = int(db.hap_matrix[allele][v]), int(states[v])
+        sign = {(0, 1): "+", (0, 2): "?", (1, 0): "-", (1, 2): "?", (1, 3): "?"}.get((hv, sv))
+        if sign:
+            out.append(f" {sign}{label}")
+    return "".join(out)
+
+
+def deep_hap_string(oracle, chain, labels, tails):
+    """convert_chain_to_hap at Cyp2d6DetailLevel::DeepAlleles (src/cyp2d6/caller.rs:907-957)"""
+    two_d = (T["CYP2D6"], T["CYP2D7"], T["CYP2D6*5"], T["Hybrid"])
+    keep = [h for h in reversed(chain) if labels[h][0] in two_d and labels[h][0] != T["CYP2D7"]]
+    if any(labels[h][0] != T["CYP2D6*5"] for h in keep):
+        keep = [h for h in keep if labels[h][0] != T["CYP2D6*5"]]
+    parts = []
+    for h in keep:
+        text = f"({h}_{full_allele(oracle, *labels[h])}{tails[h]})"
+        if parts and parts[-1][0] == text:
+            parts[-1][1] += 1
+        else:
+            parts.append([text, 1])
+    return " + ".join(t + (f"x{n}" if n > 1 else "") for t, n in parts)
+
+
+def full_type(oracle, db, seq, max_missing, force, tail=None):
+    """find_full_type_in_sequence + assign_haplotype (src/cyp2d6/haplotyper.rs:326-602) -> (type, subtype); tail (a list) receives the
+    deep-label variant list of the sequence"""
     hits = of.oracle_find_base_type(oracle, seq, db.seqs, db.types, max_missing) if seq else []
     if len(hits) == 0:
         return (T["UNKNOWN"], None)                                          # "no matches found" -> Unknown (caller.rs:350-355)
@@ -62,12 +94,15 @@ def full_type(oracle, db, seq, max_missing, force):
     cands = [(T["CYP2D6"], db.allele_subtypes[a]) for a in range(len(tie)) if tie[a]]
     if (bv, ba) == (0, 0):
         cands.append((T["UNKNOWN"], None))
-    if len(cands) == 1:
-        return cands[0]
     if not cands:
         return (T["UNKNOWN"], None)
-    cands.sort(key=lambda c: full_allele(oracle, *c))
-    return cands[0] if force else (T["UNKNOWN"], None)
+    if len(cands) > 1:
+        cands.sort(key=lambda c: full_allele(oracle, *c))
+        if not force:
+            return (T["UNKNOWN"], None)
+    if tail is not None and cands[0][0] == T["CYP2D6"] and cands[0][1] is not None:
+        tail.append(deep_tail(db, list(db.allele_subtypes).index(cands[0][1]), states))
+    return cands[0]
 
 
 def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, infer=False, normalize_d6_only=False):
@@ -126,9 +161,11 @@ def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, 
             offs = [None if v == mn else v - mn + (0 if mn == 0 else 50) for v in vals]
             final.append(of.oracle_consensus(oracle, [raw[s] for s in members], offs, single)["cons"][0])
     # 5. typing (caller.rs:331-375)
-    labels, seen = [], set()
+    labels, seen, tails = [], set(), []
     for fc in final:
-        lab = full_type(oracle, db, fc, 0.1, True)
+        t = []
+        lab = full_type(oracle, db, fc, 0.1, True, t)
+        tails.append(t[0] if t else "")
         if fc in seen:                                                       # two groups with the same sequence: mark_false_allele keeps the subtype
             lab = (T["FalseAllele"], lab[1])
         else:
@@ -161,5 +198,6 @@ def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, 
         ch1, ch2 = list(res.chain1[:res.n1]), list(res.chain2[:res.n2])
         out.update(chain1=ch1, chain2=ch2, score=res.score,
                    hap1=of.chain_hap_string(oracle, ch1, labels2, 1, cfg), hap2=of.chain_hap_string(oracle, ch2, labels2, 1, cfg),
-                   core1=of.chain_hap_string(oracle, ch1, labels2, 0, cfg), core2=of.chain_hap_string(oracle, ch2, labels2, 0, cfg))
+                   core1=of.chain_hap_string(oracle, ch1, labels2, 0, cfg), core2=of.chain_hap_string(oracle, ch2, labels2, 0, cfg),
+                   deep1=deep_hap_string(oracle, ch1, labels2, tails), deep2=deep_hap_string(oracle, ch2, labels2, tails))
     return out

@@ -25,7 +25,8 @@ def real(pkg, gpu_ctx):
     names, rows = db.alleles()
     bb = cfg["cyp_coordinates"]["CYP2D6_wfa_backbone"]
     odb = cp.Db([t[2] for t in tm], [t[0] for t in tm], [t[1] for t in tm], [t[3] for t in tm], [t[4] for t in tm],
-                locus.slice(bb["start"], bb["end"]), [(p - bb["start"], r, a) for p, r, a, _l, _v in vs], [v[4] for v in vs], names, rows)
+                locus.slice(bb["start"], bb["end"]), [(p - bb["start"], r, a) for p, r, a, _l, _v in vs], [v[4] for v in vs], names, rows,
+                var_labels=[v[3] for v in vs])
     assert db.stats.n_templates == 39 and db.stats.n_variants == 393 and db.stats.n_alleles == 520
     return locus, db, odb, {n: (h, e) for n, h, e in cr.scenarios(locus)}
 
@@ -73,6 +74,31 @@ def test_library_equals_oracle_pipeline(oracle, gpu_ctx, real, name):
     got = (call.hap1.decode(), call.hap2.decode(), call.core1.decode(), call.core2.decode())
     assert got == (exp["hap1"], exp["hap2"], exp["core1"], exp["core2"])
     assert sorted(got[:2]) == sorted(expected)
+    # Cyp2d6DetailLevel::DeepAlleles: "(<index>_<full allele> +unexpected -missing ?ambiguous)" per reported region
+    assert (call.deep1.decode(), call.deep2.decode()) == (exp["deep1"], exp["deep2"])
+    assert call.deep1.decode().startswith("(") and "_" in call.deep1.decode()
+
+
+def test_deep_labels_of_a_novel_allele(oracle, gpu_ctx, real):
+    """Cyp2d6DetailLevel::DeepAlleles (src/cyp2d6/caller.rs:907-957, region.rs:60-91): *4.001 without rs2004511 and with rs4987144 of *2 is
+    still typed *4.001, and its deep label lists the missing variant with '-' and the extra one with '+'"""
+    import cyp_pipeline as cp
+    locus, db, odb, _sc = real
+    novel = locus.star_allele("4.001", drop=("rs2004511",), add=(("2.001", "rs4987144"),))
+    haps = [locus.haplotype([novel]), locus.haplotype([locus.star_allele("1.001")])]
+    reads = locus.sample(np.random.default_rng(13), haps, 160)
+    exp = cp.diplotype(oracle, odb, reads, cfg=db.cfg)
+    call, _cons, _labels = db.diplotype(gpu_ctx.upload(reads))
+    assert call.status == exp["status"] == 0
+    deep = (call.deep1.decode(), call.deep2.decode())
+    assert deep == (exp["deep1"], exp["deep2"])
+    assert sorted([call.core1.decode(), call.core2.decode()]) == ["*1", "*4"]
+    d4 = next(d for d, c in zip(deep, (call.core1.decode(), call.core2.decode())) if c == "*4")
+    minus = [w[1:] for w in d4.strip("()").split(" ")[1:] if w[0] == "-"]
+    plus = [w[1:] for w in d4.strip("()").split(" ")[1:] if w[0] == "+"]
+    assert len(minus) == 1 and "rs2004511" in minus[0] and len(plus) == 1 and "rs4987144" in plus[0], d4
+    d1 = next(d for d in deep if d is not d4)
+    assert " " not in d1 and d1.endswith("_CYP2D6*1.001)"), d1
 
 
 def test_variant_states_on_the_real_table(oracle, gpu_ctx, real):

@@ -214,9 +214,16 @@ def test_sample_from_database_files_to_result_file(oracle, pkg, gpu_ctx, tmp_pat
     _name, haps, expected = cr.scenarios(locus)[1]
     call, _cons, _labels = cdb.diplotype(gpu_ctx.upload(locus.sample(rng, haps, 120, lo=8000, hi=16000)))
     assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
-    result.insert("CYP2D6", D.GeneDetails().add_diplotype(call.hap1.decode(), call.hap2.decode()), D.FROM_MULTI_MAPPINGS)
+    # the entry as diplotype_cyp2d6 builds it (src/cyp2d6/caller.rs:709-737): sub-allele diplotype, collapsed one, the deep one without haplotypes
+    d6 = D.GeneDetails().add_diplotype(call.hap1.decode(), call.hap2.decode()).add_simple_diplotype(call.core1.decode(), call.core2.decode()) \
+        .add_diplotype_only(call.deep1.decode(), call.deep2.decode())
+    result.insert("CYP2D6", d6, D.FROM_MULTI_MAPPINGS)
     out = tmp_path / "sample.json.gz"
     result.save(str(out))
     obj = json.load(gzip.open(out))
     assert sorted(obj["gene_details"]) == sorted(list(raw) + fx.genes + ["CYP2D6"]) and len(obj["gene_details"]) == 21
     assert obj["gene_details"]["CYP2D6"]["diplotypes"][0]["diplotype"] == f"{call.hap1.decode()}/{call.hap2.decode()}"
+    assert obj["gene_details"]["CYP2D6"]["simple_diplotypes"] == [{"hap1": "*4", "hap2": "*4", "diplotype": "*4/*4"}]
+    deep = obj["gene_details"]["CYP2D6"]["inexact_diplotypes"]
+    assert len(deep) == 1 and deep[0]["haplotype_1"] is None and deep[0]["haplotype_2"] is None
+    assert sorted(h.split("_", 1)[1] for h in (deep[0]["basic_diplotype"]["hap1"], deep[0]["basic_diplotype"]["hap2"])) == ["CYP2D6*4.001)"] * 2
