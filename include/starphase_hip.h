@@ -356,6 +356,20 @@ typedef struct {
 int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* problem, const sp_seqset* reads, sp_cyp_call* call,
                          char* consensus /* optional: SP_CYP_MAXCONS * cons_cap bytes */, uint32_t cons_cap);
 
+/* The same call, also handing out Cyp2d6Region::variants of every final consensus region (assign_haplotype,
+ * src/cyp2d6/haplotyper.rs:546-595): has_variants[h] = 1 when region h carries a list (typed as a CYP2D6 star allele), and
+ * state[h * n_variants + v] is the VariantAlleleRelationship of variant v against the assigned allele in the codes of
+ * sp_inexact_haplotype (1 Match .. 7 UnknownMissing), 255 = not listed (reference where the allele has the reference).
+ * state: caller's buffer of SP_CYP_MAXCONS * n_variants bytes (NULL: only has_variants is filled).
+ * sp_cyp_alleles_json writes the `cyp2d6_alleles.json` debug file (DeeplotypeDebug, src/cyp2d6/debug.rs:10-70; caller.rs:703-707) from
+ * the call and these lists: the two haplotypes in deep / sub-allele / core form and {index_label: [RegionVariant]} in key order.
+ * out / cap: the text is copied NUL-terminated; *needed = bytes needed incl. the NUL; SP_ERR_CAPACITY when it did not fit. */
+typedef struct { uint8_t has_variants[SP_CYP_MAXCONS]; uint8_t* state; } sp_cyp_region_variants;
+int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* problem, const sp_seqset* reads, sp_cyp_call* call,
+                                  char* consensus, uint32_t cons_cap, sp_cyp_region_variants* region_variants /* optional */);
+int32_t sp_cyp_alleles_json(const sp_cyp_problem* problem, const sp_cyp_call* call, const sp_cyp_region_variants* region_variants,
+                            char* out, uint64_t cap, uint64_t* needed);
+
 /* ------------------------------------------------------------------ CYP2D6 templates and typing tables
  * Replaces generate_cyp_hybrids (src/cyp2d6/definitions.rs:346-464), LoadedVariants::load_variant_database
  * (src/cyp2d6/haplotyper.rs:650-773) and the table building of Cyp2d6Extractor::new (src/cyp2d6/haplotyper.rs:45-132).
@@ -791,6 +805,31 @@ int32_t sp_result_save(sp_result* result, const char* path);                    
  * single haplotype, "Unknown" when the two differ. */
 int32_t sp_result_pharmcat_tsv(sp_result* result, const char** text, uint64_t* len);
 int32_t sp_result_save_pharmcat_tsv(sp_result* result, const char* path);
+
+/* ------------------------------------------------------------------ f4: the debug files (host only)
+ * `hla_debug.json` (HlaDebug, src/hla/debug.rs:7-221; written by diplotype_hla_batch when a debug folder is given,
+ * src/hla/caller.rs:1042-1048): per gene and read (or "consensus1" / "consensus2") the best match and the detailed mappings against the
+ * alleles compared, and per gene the DualPassingStats of is_passing_dual (src/hla/caller.rs:1225-1247).  Errors as the reference's:
+ * "Entry <x> is already occupied" (SP_ERR_INVALID_ARG, text from sp_hla_debug_last_error).
+ * sp_aln_strings turns an alignment of this library (sp_align_batch with events; A = query, B = target) into what
+ * DetailedMappingStats::from_mapping copies from minimap2 (:148-172): the CIGAR string (M / I / D, no --eqx), the MD tag and
+ * match_len (matching bases); query_unmapped / target_unmapped are a_len - (a_end - a_start) and b_len - (b_end - b_start).
+ * `cyp2d6_alleles.json` is written by sp_cyp_alleles_json above. */
+typedef struct { int32_t present, reserved; uint64_t query_len, target_len, match_len, nm, query_unmapped, target_unmapped;
+                 const char* cigar; const char* md; } sp_detailed_mapping;                    /* Option<DetailedMappingStats> */
+int32_t sp_aln_strings(const sp_aln* aln, const uint32_t* events, const char* target, uint64_t target_len,
+                       char* cigar, uint32_t cigar_cap, char* md, uint32_t md_cap, uint64_t* match_len);
+typedef struct sp_hla_debug sp_hla_debug;
+int32_t sp_hla_debug_create(sp_hla_debug** out);
+void    sp_hla_debug_free(sp_hla_debug* debug);
+const char* sp_hla_debug_last_error(const sp_hla_debug* debug);
+int32_t sp_hla_debug_add_read(sp_hla_debug* debug, const char* gene, const char* qname,
+                              const char* best_match_id /* NULL: None */, const char* best_match_star);
+int32_t sp_hla_debug_add_mapping(sp_hla_debug* debug, const char* gene, const char* qname, const char* hla_id,
+                                 const sp_detailed_mapping* cdna, const sp_detailed_mapping* dna);
+int32_t sp_hla_debug_add_dual_stats(sp_hla_debug* debug, const char* gene, const sp_hla_call* call);
+int32_t sp_hla_debug_json(sp_hla_debug* debug, const char** text, uint64_t* len);
+int32_t sp_hla_debug_save(sp_hla_debug* debug, const char* path);             /* gzip when the name ends in ".gz" */
 
 /* ------------------------------------------------------------------ f2: decoding the input files (host only)
  * What the reference gets from rust-htslib: the records of an indexed BAM that overlap a region (diplotype_hla_batch,

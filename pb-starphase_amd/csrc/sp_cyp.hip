@@ -5,6 +5,7 @@
 // reference's operation order (no FMA contraction, table look-ups for ln n! and ln p), so the scores are bit-identical
 // to the CPU path and the (score, i, j) winner is deterministic.
 #include "sp_internal.h"
+#include "sp_json.h"
 #include "sp_wfa.cuh"
 #include <algorithm>
 #include <cmath>
@@ -955,6 +956,18 @@ static std::string label_reduced(const Label& l, const sp_cyp_problem* pr) {
 // The variants of a typed sequence relative to the star allele it was assigned (assign_haplotype, src/cyp2d6/haplotyper.rs:546-595) in the
 // form Cyp2d6Region::deep_label appends them (src/cyp2d6/region.rs:60-91): " +label" unexpected, " -label" missing, " ?label" ambiguous or
 // unknown-but-expected; matches and unknown-and-not-expected are not listed.
+// VariantAlleleRelationship of every variant of a typed sequence against its assigned allele (haplotyper.rs:551-577) as the code
+// sp_inexact_haplotype uses (1 Match, 2 Unexpected, 3 Missing, 4 AmbiguousUnexpected, 5 AmbiguousMissing, 6 UnknownUnexpected,
+// 7 UnknownMissing); 255: reference matching reference, which the region does not list (:579-580)
+static void region_relationships(const sp_cyp_problem* pr, uint32_t allele, const std::vector<uint8_t>& states, std::vector<uint8_t>& out) {
+    out.assign(pr->n_variants, 255);
+    if (states.size() != pr->n_variants) return;
+    const uint8_t* row = pr->hap_matrix + (size_t)allele * pr->n_variants;
+    static const uint8_t expect_ref[4] = { 255, 2, 4, 6 }, expect_alt[4] = { 3, 1, 5, 7 };
+    for (uint32_t v = 0; v < pr->n_variants; ++v) out[v] = (row[v] ? expect_alt : expect_ref)[states[v] & 3];
+}
+struct DeepInfo { std::vector<std::string> suffix; std::vector<std::vector<uint8_t>> rel; std::vector<uint8_t> has; };   // has[i] == 0: Cyp2d6Region::variants is None
+
 static std::string deep_suffix(const sp_cyp_problem* pr, uint32_t allele, const std::vector<uint8_t>& states) {
     std::string out;
     if (states.size() != pr->n_variants || !pr->var_label) return out;
@@ -975,9 +988,9 @@ static std::string deep_suffix(const sp_cyp_problem* pr, uint32_t allele, const 
 struct Typed { int best_template = -1; uint32_t bvi = 0, ball = 0; std::vector<uint8_t> tie, states; };
 using TypeCache = std::map<std::string, Typed>;
 static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::vector<std::string>& seqs, double max_missing, bool force, std::vector<Label>& out,
-                              TypeCache& cache, std::vector<std::string>* suffix = nullptr) {
+                              TypeCache& cache, DeepInfo* deep = nullptr) {
     out.assign(seqs.size(), Label());
-    if (suffix) suffix->assign(seqs.size(), std::string());
+    if (deep) { deep->suffix.assign(seqs.size(), std::string()); deep->rel.assign(seqs.size(), std::vector<uint8_t>()); deep->has.assign(seqs.size(), 0); }
     std::vector<const std::string*> fresh;                             // sequences the device has not seen yet (an empty one has no matches: Unknown)
     std::string blob; std::vector<uint64_t> off(1, 0);
     for (const std::string& q : seqs) if (!q.empty() && !cache.count(q)) { cache[q]; fresh.push_back(&q); blob += q; off.push_back(blob.size()); }
@@ -1024,8 +1037,10 @@ static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::
         }
         lab = cands[0];
         // the variants that set the sequence apart from the allele it got (Cyp2d6Region::variants; None for Unknown)
-        if (suffix && lab.type == SP_CYP_CYP2D6 && lab.has_sub)
-            for (uint32_t a = 0; a < pr->n_alleles; ++a) if (lab.sub == pr->allele_subtype[a]) { (*suffix)[i] = deep_suffix(pr, a, ty.states); break; }
+        if (deep && lab.type == SP_CYP_CYP2D6 && lab.has_sub)
+            for (uint32_t a = 0; a < pr->n_alleles; ++a) if (lab.sub == pr->allele_subtype[a]) {
+                deep->suffix[i] = deep_suffix(pr, a, ty.states); region_relationships(pr, a, ty.states, deep->rel[i]); deep->has[i] = 1; break;
+            }
     }
     return SP_OK;
 }
@@ -1033,7 +1048,13 @@ static int32_t type_sequences(sp_ctx* ctx, const sp_cyp_problem* pr, const std::
 } // namespace
 
 extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, char* consensus, uint32_t cons_cap) {
+    return sp_cyp_diplotype_detailed(ctx, pr, reads, call, consensus, cons_cap, nullptr);
+}
+
+extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, char* consensus, uint32_t cons_cap,
+                                             sp_cyp_region_variants* region_variants) {
     if (!ctx) return SP_ERR_INVALID_ARG;
+    if (region_variants) std::memset(region_variants->has_variants, 0, sizeof region_variants->has_variants);
     if (!pr || !reads || !call || !pr->templates || !pr->template_type || !pr->template_deep || !pr->backbone) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_cyp_diplotype: null argument");
     (void)hipSetDevice(ctx->device);
     std::memset(call, 0, sizeof *call);
@@ -1132,12 +1153,18 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     hm.mark("host:cyp_merge");
     // 5. typing of the final consensus regions, forced assignment, duplicates become FalseAllele (caller.rs:331-375)
     std::vector<Label> labels;
-    std::vector<std::string> deep_tail;
-    rc = type_sequences(ctx, pr, final_cons, 0.1, true, labels, typed, &deep_tail);
+    DeepInfo deep;
+    rc = type_sequences(ctx, pr, final_cons, 0.1, true, labels, typed, &deep);
+    const std::vector<std::string>& deep_tail = deep.suffix;
     if (rc != SP_OK) return rc;
     for (size_t i = 0; i < final_cons.size(); ++i)
         for (size_t j = 0; j < i; ++j) if (final_cons[j] == final_cons[i]) { labels[i].type = SP_CYP_FALSE_ALLELE; break; }
     const uint32_t H = (uint32_t)final_cons.size();
+    if (region_variants)
+        for (uint32_t h = 0; h < H && h < SP_CYP_MAXCONS; ++h) {
+            region_variants->has_variants[h] = deep.has[h];
+            if (deep.has[h] && region_variants->state && pr->n_variants) std::memcpy(region_variants->state + (size_t)h * pr->n_variants, deep.rel[h].data(), pr->n_variants);
+        }
     hm.mark("host:cyp_typing");
     // 6. weights of every region of interest, chains, best chain pair (caller.rs:429-640)
     std::vector<uint32_t> a_idx(hits.size()); std::vector<int32_t> a_start(hits.size()), a_len(hits.size());
@@ -1221,5 +1248,40 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     };
     deep_hap(cr.chain1, cr.n1, call->deep1, sizeof call->deep1);
     deep_hap(cr.chain2, cr.n2, call->deep2, sizeof call->deep2);
+    return SP_OK;
+}
+
+// cyp2d6_alleles.json: DeeplotypeDebug (src/cyp2d6/debug.rs:10-70) written as save_json writes it (serde_json pretty print)
+extern "C" int32_t sp_cyp_alleles_json(const sp_cyp_problem* pr, const sp_cyp_call* call, const sp_cyp_region_variants* rv, char* out, uint64_t cap, uint64_t* needed) {
+    if (!pr || !call || !rv) return SP_ERR_INVALID_ARG;
+    static const char* names[] = { "Unknown", "Match", "Unexpected", "Missing", "AmbiguousUnexpected", "AmbiguousMissing", "UnknownUnexpected", "UnknownMissing" };
+    spj::Value root = spj::object();
+    const char* forms[2][3] = { { call->deep1, call->hap1, call->core1 }, { call->deep2, call->hap2, call->core2 } };
+    for (int h = 0; h < 2; ++h) {
+        spj::Value hap = spj::object();
+        hap.obj.emplace_back("deep_form", spj::str(forms[h][0])); hap.obj.emplace_back("suballele_form", spj::str(forms[h][1])); hap.obj.emplace_back("core_form", spj::str(forms[h][2]));
+        root.obj.emplace_back(h == 0 ? "hap1" : "hap2", std::move(hap));
+    }
+    std::map<std::string, spj::Value> alleles;                        // BTreeMap<String, Vec<RegionVariant>> keyed by index_label()
+    for (int32_t h = 0; h < call->n_consensus && h < SP_CYP_MAXCONS; ++h) {
+        if (!rv->has_variants[h]) continue;
+        if (pr->n_variants && (!rv->state || !pr->var_label)) return SP_ERR_INVALID_ARG;
+        spj::Value list = spj::array();
+        for (uint32_t v = 0; v < pr->n_variants; ++v) {
+            const uint8_t st = rv->state[(size_t)h * pr->n_variants + v];
+            if (st > 7) continue;
+            spj::Value e = spj::object();
+            e.obj.emplace_back("label", spj::str(pr->var_label[v])); e.obj.emplace_back("is_vi", spj::boolean(pr->var_is_vi[v] != 0)); e.obj.emplace_back("variant_state", spj::str(names[st]));
+            list.arr.push_back(std::move(e));
+        }
+        alleles.emplace(std::to_string(h) + "_" + full_allele(call->cons_type[h], call->cons_subtype[h][0] ? call->cons_subtype[h] : nullptr), std::move(list));
+    }
+    spj::Value amap = spj::object();
+    for (auto& kv : alleles) amap.obj.emplace_back(kv.first, std::move(kv.second));
+    root.obj.emplace_back("alleles", std::move(amap));
+    std::string text;
+    spj::write_pretty(text, root);
+    if (needed) *needed = text.size() + 1;
+    if (out && cap) { const size_t n = std::min<size_t>(text.size(), (size_t)cap - 1); std::memcpy(out, text.data(), n); out[n] = 0; if (n < text.size()) return SP_ERR_CAPACITY; }
     return SP_OK;
 }

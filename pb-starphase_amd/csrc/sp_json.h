@@ -1,6 +1,8 @@
 // sp_json.h -- a small JSON document reader / writer for the database loader and the result writer (host only).
 // Objects keep their members in file order (serde_json's BTreeMap-backed types are re-sorted by the callers that need key order).
 #pragma once
+#include <charconv>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -123,13 +125,35 @@ inline void write_string(std::string& out, const std::string& s) {
     }
     out += '"';
 }
+// f64 as serde_json writes it (ryu's shortest round-trip digits in ryu's layout: 12.34, 0.001234, 12340000000.0, 1.234e33, 1e-7;
+// non-finite values become null)
+inline void write_double(std::string& out, double d) {
+    if (!std::isfinite(d)) { out += "null"; return; }
+    if (d == 0.0) { out += std::signbit(d) ? "-0.0" : "0.0"; return; }
+    char buf[48];
+    auto res = std::to_chars(buf, buf + sizeof buf, d, std::chars_format::scientific);      // shortest digits: d[.ddd]e[+-]xx
+    std::string t(buf, res.ptr), digits; bool neg = false; size_t k = 0;
+    if (t[0] == '-') { neg = true; k = 1; }
+    for (; k < t.size() && t[k] != 'e'; ++k) if (t[k] != '.') digits += t[k];
+    const int exp10 = std::atoi(t.c_str() + k + 1);
+    const int length = (int)digits.size(), kexp = exp10 - (length - 1), kk = length + kexp;   // value = digits * 10^kexp; 10^(kk-1) <= v < 10^kk
+    if (neg) out += '-';
+    if (kexp >= 0 && kk <= 16) { out += digits; out.append((size_t)kexp, '0'); out += ".0"; }
+    else if (kk > 0 && kk <= 16) { out.append(digits, 0, (size_t)kk); out += '.'; out.append(digits, (size_t)kk, std::string::npos); }
+    else if (kk > -5 && kk <= 0) { out += "0."; out.append((size_t)-kk, '0'); out += digits; }
+    else {
+        out += digits[0];
+        if (length > 1) { out += '.'; out.append(digits, 1, std::string::npos); }
+        out += 'e'; out += std::to_string(kk - 1);
+    }
+}
 inline void write_pretty(std::string& out, const Value& v, int depth = 0) {
     auto indent = [&](int d) { out.append((size_t)d * 2, ' '); };
     switch (v.kind) {
         case Value::Null: out += "null"; break;
         case Value::Bool: out += v.b ? "true" : "false"; break;
         case Value::Int: out += std::to_string(v.i); break;
-        case Value::Double: { char buf[40]; std::snprintf(buf, sizeof buf, "%.17g", v.d); std::string t(buf); if (t.find_first_of(".eEn") == std::string::npos) t += ".0"; out += t; break; }
+        case Value::Double: write_double(out, v.d); break;
         case Value::String: write_string(out, v.s); break;
         case Value::Array:
             if (v.arr.empty()) { out += "[]"; break; }
@@ -147,6 +171,7 @@ inline void write_pretty(std::string& out, const Value& v, int depth = 0) {
 }
 inline Value str(const std::string& s) { Value v; v.kind = Value::String; v.s = s; return v; }
 inline Value num(int64_t i) { Value v; v.kind = Value::Int; v.i = i; return v; }
+inline Value real(double d) { Value v; v.kind = Value::Double; v.d = d; return v; }
 inline Value boolean(bool b) { Value v; v.kind = Value::Bool; v.b = b; return v; }
 inline Value object() { Value v; v.kind = Value::Object; return v; }
 inline Value array() { Value v; v.kind = Value::Array; return v; }

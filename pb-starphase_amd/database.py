@@ -45,6 +45,11 @@ class sp_mapping_stats(C.Structure):
     _fields_ = [("present", _i32), ("has_clips", _i32), ("seq_len", _u64), ("nm", _u64), ("unmapped", _u64), ("clipped_start", _u64), ("clipped_end", _u64)]
 
 
+class sp_detailed_mapping(C.Structure):
+    _fields_ = [("present", _i32), ("reserved", _i32), ("query_len", _u64), ("target_len", _u64), ("match_len", _u64), ("nm", _u64),
+                ("query_unmapped", _u64), ("target_unmapped", _u64), ("cigar", _s), ("md", _s)]
+
+
 SUBALLELE_MATCH, CORE_MATCH, INEXACT_DIPLOTYPES, FROM_MAPPINGS, FROM_MULTI_MAPPINGS, NO_MATCH = range(6)
 _bound = False
 
@@ -97,6 +102,15 @@ def _lib():
         "sp_result_save": (_i32, [_vp, _s]),
         "sp_result_pharmcat_tsv": (_i32, [_vp, P(_s), P(_u64)]),
         "sp_result_save_pharmcat_tsv": (_i32, [_vp, _s]),
+        "sp_aln_strings": (_i32, [P(ffi.sp_aln), _vp, _s, _u64, _s, _u32, _s, _u32, P(_u64)]),
+        "sp_hla_debug_create": (_i32, [P(_vp)]),
+        "sp_hla_debug_free": (None, [_vp]),
+        "sp_hla_debug_last_error": (_s, [_vp]),
+        "sp_hla_debug_add_read": (_i32, [_vp, _s, _s, _s, _s]),
+        "sp_hla_debug_add_mapping": (_i32, [_vp, _s, _s, _s, P(sp_detailed_mapping), P(sp_detailed_mapping)]),
+        "sp_hla_debug_add_dual_stats": (_i32, [_vp, _s, P(ffi.sp_hla_call)]),
+        "sp_hla_debug_json": (_i32, [_vp, P(_s), P(_u64)]),
+        "sp_hla_debug_save": (_i32, [_vp, _s]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -415,6 +429,76 @@ class Result:
 
     def save_pharmcat_tsv(self, path):
         self._check(_lib().sp_result_save_pharmcat_tsv(self._h, _b(path)))
+
+
+# ------------------------------------------------------------------ debug files (sp_hla_debug_*, sp_aln_strings)
+def aln_strings(aln, events, target):
+    """sp_aln_strings: one row of Context.align_batch(..., events=True) (A = query, B = target) -> (cigar, md, match_len)"""
+    a = ffi.sp_aln(*[int(aln[k]) for k in ("ok", "nm", "a_start", "a_end", "b_start", "b_end", "a_len", "b_len")])
+    ev = np.ascontiguousarray(events, np.uint32)
+    cap = 16 * (int(aln["nm"]) + 2) + 32
+    cg, md, ml = C.create_string_buffer(cap), C.create_string_buffer(cap), _u64()
+    rc = _lib().sp_aln_strings(C.byref(a), ev.ctypes.data, _b(target), len(target), cg, cap, md, cap, C.byref(ml))
+    if rc != SP_OK:
+        raise StarphaseError(rc, "sp_aln_strings")
+    return cg.value.decode(), md.value.decode(), ml.value
+
+
+def detailed_mapping(aln, events, target):
+    """DetailedMappingStats::from_mapping for one alignment row: a dict with the fields of sp_detailed_mapping"""
+    cg, md, ml = aln_strings(aln, events, target)
+    return dict(query_len=int(aln["a_len"]), target_len=int(aln["b_len"]), match_len=ml, nm=int(aln["nm"]),
+                query_unmapped=int(aln["a_len"]) - (int(aln["a_end"]) - int(aln["a_start"])),
+                target_unmapped=int(aln["b_len"]) - (int(aln["b_end"]) - int(aln["b_start"])), cigar=cg, md=md)
+
+
+class HlaDebug:
+    """sp_hla_debug: hla_debug.json"""
+
+    def __init__(self):
+        self._h = _vp()
+        _lib().sp_hla_debug_create(C.byref(self._h))
+
+    def close(self):
+        if self._h:
+            _lib().sp_hla_debug_free(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != SP_OK:
+            raise StarphaseError(rc, _lib().sp_hla_debug_last_error(self._h).decode())
+
+    @staticmethod
+    def _dm(m):
+        if m is None:
+            return None, None
+        keep = (_b(m["cigar"]), _b(m["md"]))
+        return sp_detailed_mapping(1, 0, m["query_len"], m["target_len"], m["match_len"], m["nm"], m["query_unmapped"], m["target_unmapped"], *keep), keep
+
+    def add_read(self, gene, qname, best_id=None, best_star=None):
+        self._check(_lib().sp_hla_debug_add_read(self._h, _b(gene), _b(qname), _b(best_id), _b(best_star))); return self
+
+    def add_mapping(self, gene, qname, hla_id, cdna=None, dna=None):
+        c, _k1 = self._dm(cdna)
+        d, _k2 = self._dm(dna)
+        self._check(_lib().sp_hla_debug_add_mapping(self._h, _b(gene), _b(qname), _b(hla_id), C.byref(c) if c else None, C.byref(d) if d else None)); return self
+
+    def add_dual_stats(self, gene, call):
+        self._check(_lib().sp_hla_debug_add_dual_stats(self._h, _b(gene), C.byref(call))); return self
+
+    def json(self):
+        s, n = _s(), _u64()
+        self._check(_lib().sp_hla_debug_json(self._h, C.byref(s), C.byref(n)))
+        return s.value.decode()
+
+    def save(self, path):
+        self._check(_lib().sp_hla_debug_save(self._h, _b(path)))
 
 
 # ------------------------------------------------------------------ input files (sp_bam_*, sp_vcf_*)

@@ -170,6 +170,10 @@ class sp_cyp_call(C.Structure):
                 ("deep1", C.c_char * 2048), ("deep2", C.c_char * 2048)]
 
 
+class sp_cyp_region_variants(C.Structure):
+    _fields_ = [("has_variants", C.c_uint8 * SP_CYP_MAXCONS), ("state", C.c_void_p)]
+
+
 class sp_hla_call_config(C.Structure):
     _fields_ = [("min_consensus_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("min_consensus_fraction", C.c_double),
                 ("expected_maf", C.c_double), ("min_cdf", C.c_double), ("require_dna", C.c_int32), ("disable_cdna", C.c_int32),
@@ -256,6 +260,8 @@ def lib():
         "sp_consensus_dual_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
         "sp_cyp_variant_states": (i32, [vp, vp, C.c_char_p, u32, u32, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), vp, vp]),
         "sp_cyp_diplotype": (i32, [vp, C.POINTER(sp_cyp_problem), vp, C.POINTER(sp_cyp_call), C.c_char_p, u32]),
+        "sp_cyp_diplotype_detailed": (i32, [vp, C.POINTER(sp_cyp_problem), vp, C.POINTER(sp_cyp_call), C.c_char_p, u32, C.POINTER(sp_cyp_region_variants)]),
+        "sp_cyp_alleles_json": (i32, [C.POINTER(sp_cyp_problem), C.POINTER(sp_cyp_call), C.POINTER(sp_cyp_region_variants), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
         "sp_consensus_priority": (i32, [vp, C.POINTER(sp_priority_problem), u32, u32, C.POINTER(u32), vp, C.c_char_p]),
         "sp_hla_diplotype_gene": (i32, [vp, vp, u32, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, C.c_char_p, u32, vp]),
         "sp_hla_diplotype_genes": (i32, [vp, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
@@ -821,6 +827,22 @@ class CypDb:
         cons = [buf.raw[i * cons_cap:(i + 1) * cons_cap].split(b"\0", 1)[0].decode() for i in range(call.n_consensus)]
         labels = [(int(call.cons_type[i]), (call.cons_subtype[i].value.decode() or None)) for i in range(call.n_consensus)]
         return call, cons, labels
+
+    def diplotype_detailed(self, reads, cons_cap=16384, **overrides):
+        """sp_cyp_diplotype_detailed + sp_cyp_alleles_json -> (sp_cyp_call, {region: [relationship code per variant]}, cyp2d6_alleles.json text)"""
+        pr = self.problem(**overrides)
+        call = sp_cyp_call()
+        buf = C.create_string_buffer(SP_CYP_MAXCONS * cons_cap)
+        state = np.full((SP_CYP_MAXCONS, max(1, pr.n_variants)), 254, np.uint8)
+        rv = sp_cyp_region_variants()
+        rv.state = state.ctypes.data
+        self.ctx.check(lib().sp_cyp_diplotype_detailed(self.ctx._h, C.byref(pr), reads._h, C.byref(call), buf, cons_cap, C.byref(rv)))
+        need = C.c_uint64(0)
+        self.ctx.check(lib().sp_cyp_alleles_json(C.byref(pr), C.byref(call), C.byref(rv), None, 0, C.byref(need)))
+        text = C.create_string_buffer(need.value)
+        self.ctx.check(lib().sp_cyp_alleles_json(C.byref(pr), C.byref(call), C.byref(rv), text, need.value, None))
+        regions = {h: state[h, :pr.n_variants].copy() for h in range(call.n_consensus) if rv.has_variants[h]}
+        return call, regions, text.value.decode()
 
 
 class SeqSet:

@@ -63,6 +63,19 @@ def deep_tail(db, allele, states):
     return "".join(out)
 
 
+def region_variants(db, allele, states):
+    """Cyp2d6Region::variants of a typed sequence (src/cyp2d6/haplotyper.rs:546-595): every variant but reference-on-reference, with its
+    VariantAlleleRelationship -- the lists `cyp2d6_alleles.json` holds (src/cyp2d6/debug.rs:29-37)"""
+    names = {(0, 1): "Unexpected", (0, 2): "AmbiguousUnexpected", (0, 3): "UnknownUnexpected",
+             (1, 0): "Missing", (1, 1): "Match", (1, 2): "AmbiguousMissing", (1, 3): "UnknownMissing"}
+    out = []
+    for v, label in enumerate(db.var_labels):
+        key = (int(db.hap_matrix[allele][v]), int(states[v]))
+        if key in names:
+            out.append({"label": label, "is_vi": bool(db.is_vi[v]), "variant_state": names[key]})
+    return out
+
+
 def deep_hap_string(oracle, chain, labels, tails):
     """convert_chain_to_hap at Cyp2d6DetailLevel::DeepAlleles (src/cyp2d6/caller.rs:907-957)"""
     two_d = (T["CYP2D6"], T["CYP2D7"], T["CYP2D6*5"], T["Hybrid"])
@@ -101,7 +114,8 @@ def full_type(oracle, db, seq, max_missing, force, tail=None):
         if not force:
             return (T["UNKNOWN"], None)
     if tail is not None and cands[0][0] == T["CYP2D6"] and cands[0][1] is not None:
-        tail.append(deep_tail(db, list(db.allele_subtypes).index(cands[0][1]), states))
+        allele = list(db.allele_subtypes).index(cands[0][1])
+        tail.append((deep_tail(db, allele, states), region_variants(db, allele, states) if db.var_labels is not None else None))
     return cands[0]
 
 
@@ -161,11 +175,13 @@ def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, 
             offs = [None if v == mn else v - mn + (0 if mn == 0 else 50) for v in vals]
             final.append(of.oracle_consensus(oracle, [raw[s] for s in members], offs, single)["cons"][0])
     # 5. typing (caller.rs:331-375)
-    labels, seen, tails = [], set(), []
+    labels, seen, tails, region_lists = [], set(), [], {}
     for fc in final:
         t = []
         lab = full_type(oracle, db, fc, 0.1, True, t)
-        tails.append(t[0] if t else "")
+        tails.append(t[0][0] if t else "")
+        if t and t[0][1] is not None:
+            region_lists[len(tails) - 1] = t[0][1]
         if fc in seen:                                                       # two groups with the same sequence: mark_false_allele keeps the subtype
             lab = (T["FalseAllele"], lab[1])
         else:
@@ -200,4 +216,9 @@ def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, 
                    hap1=of.chain_hap_string(oracle, ch1, labels2, 1, cfg), hap2=of.chain_hap_string(oracle, ch2, labels2, 1, cfg),
                    core1=of.chain_hap_string(oracle, ch1, labels2, 0, cfg), core2=of.chain_hap_string(oracle, ch2, labels2, 0, cfg),
                    deep1=deep_hap_string(oracle, ch1, labels2, tails), deep2=deep_hap_string(oracle, ch2, labels2, tails))
+        # DeeplotypeDebug (src/cyp2d6/debug.rs:10-70): cyp2d6_alleles.json
+        out["alleles_json"] = {
+            "hap1": {"deep_form": out["deep1"], "suballele_form": out["hap1"], "core_form": out["core1"]},
+            "hap2": {"deep_form": out["deep2"], "suballele_form": out["hap2"], "core_form": out["core2"]},
+            "alleles": {k: v for k, v in sorted((f"{h}_{full_allele(oracle, *labels2[h])}", lst) for h, lst in region_lists.items())}}
     return out

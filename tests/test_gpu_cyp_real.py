@@ -99,6 +99,18 @@ def test_deep_labels_of_a_novel_allele(oracle, gpu_ctx, real):
     assert len(minus) == 1 and "rs2004511" in minus[0] and len(plus) == 1 and "rs4987144" in plus[0], d4
     d1 = next(d for d in deep if d is not d4)
     assert " " not in d1 and d1.endswith("_CYP2D6*1.001)"), d1
+    # cyp2d6_alleles.json (DeeplotypeDebug, src/cyp2d6/debug.rs:10-70): the same call with the variant list of every typed region
+    import json
+    call2, regions, text = db.diplotype_detailed(gpu_ctx.upload(reads))
+    assert (call2.deep1, call2.deep2, call2.hap1, call2.hap2) == (call.deep1, call.deep2, call.hap1, call.hap2)
+    assert text == json.dumps(exp["alleles_json"], indent=2)
+    lists = json.loads(text)["alleles"]
+    assert len(lists) == len(regions) >= 2
+    k4 = d4.strip("()").split(" ")[0]
+    by_state = {}
+    for v in lists[k4]:
+        by_state.setdefault(v["variant_state"], []).append(v["label"])
+    assert len(by_state["Missing"]) == 1 and len(by_state["Unexpected"]) == 1 and len(by_state["Match"]) == 16    # *4.001 has 17 variants
 
 
 def test_variant_states_on_the_real_table(oracle, gpu_ctx, real):

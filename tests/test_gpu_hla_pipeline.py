@@ -144,3 +144,67 @@ def test_cohort_equals_sample_by_sample(oracle, pkg, gpu_ctx):
             got, want = sorted([c.allele1, c.allele2]), truth[s][g]
             assert all(same(x, y) for x, y in zip(got, want)) or all(same(x, y) for x, y in zip(got, want[::-1])), (s, g, got, want)
         assert is1[mine].tolist() == is1_s.tolist()
+
+
+def test_hla_debug_file(oracle, pkg, gpu_ctx, tmp_path):
+    """hla_debug.json (HlaDebug, /root/reference/src/hla/debug.rs:7-221) of one sample: the DualPassingStats of every gene are the call's, and
+    the consensus entries carry DetailedMappingStats built from the library's alignment -- CIGAR / MD equal to the ones derived from the
+    oracle's alignment of the same pair, and consistent with the sequences"""
+    import json
+    import re
+    from pb_starphase_amd import synth
+    D = pkg.database
+    fx = synth.HlaFixture(max_alleles_per_gene=150, seed=4)
+    db = fx.make_db(pkg, gpu_ctx)
+    rng = np.random.default_rng(21)
+    reads, truth = [], {}
+    for g in range(len(fx.genes)):
+        truth[g] = rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist()
+        reads += simulate(fx, synth, rng, g, truth[g], 14)
+    R = gpu_ctx.upload(reads)
+    k1 = db.realign_reads(R)
+    dbg = D.HlaDebug()
+    expected_dual = {}
+    for g, gene in enumerate(fx.genes):
+        call, c1, c2, _is1 = db.diplotype_gene(g, R, k1)
+        assert call.status == 0 and call.is_dual
+        dbg.add_dual_stats(gene, call)
+        expected_dual[gene] = {"is_passing": bool(call.dual_passed), "is_dual": True, "counts1": call.counts1, "counts2": call.counts2,
+                               "maf": call.maf, "cdf": call.cdf}
+        for name, cons, typed in (("consensus1", c1, call.typed1), ("consensus2", c2, call.typed2)):
+            hap, _s = fx.haplotype(g, typed)                                  # hg38-forward haplotype that carries the typed allele
+            qs, ts = gpu_ctx.upload([cons]), gpu_ctx.upload([hap])
+            diag, votes = gpu_ctx.anchor_batch(qs, ts, [0], [0])
+            aln, ev = gpu_ctx.align_batch(qs, ts, [0], [0], diag, [255], events=True)
+            assert votes[0] > 0 and aln[0]["ok"]
+            m = D.detailed_mapping(aln[0], ev[0], hap)
+            # the same strings from the oracle's alignment of the pair
+            o_al, o_ev = oracle.wfa(cons, hap, int(diag[0]), 255)
+            assert (o_al.nm, o_al.b_start, o_al.b_end) == (aln[0]["nm"], aln[0]["b_start"], aln[0]["b_end"])
+            merged = []
+            for n, op in oracle.cigar(o_al, o_ev):
+                op = "M" if op in (7, 8) else "I" if op == 1 else "D"
+                if merged and merged[-1][1] == op:
+                    merged[-1][0] += n
+                else:
+                    merged.append([n, op])
+            assert m["cigar"] == "".join(f"{n}{op}" for n, op in merged)
+            ops = [(int(n), op) for n, op in re.findall(r"(\d+)([MID])", m["cigar"])]
+            assert sum(n for n, op in ops if op in "MI") == aln[0]["a_end"] - aln[0]["a_start"]
+            assert sum(n for n, op in ops if op in "MD") == aln[0]["b_end"] - aln[0]["b_start"]
+            md_ref = sum(int(x) if x.isdigit() else len(x.lstrip("^")) for x in re.findall(r"\d+|\^[ACGT]+|[ACGT]", m["md"]))
+            assert md_ref == aln[0]["b_end"] - aln[0]["b_start"]
+            assert m["match_len"] == sum(int(x) for x in re.findall(r"\d+", m["md"])) and m["query_len"] == len(cons) and m["target_len"] == len(hap)
+            dbg.add_read(gene, name, fx.ids[typed] if hasattr(fx, "ids") else f"allele{typed}", fx.names[typed] if hasattr(fx, "names") else str(typed))
+            dbg.add_mapping(gene, name, f"allele{typed}", cdna=None, dna=m)
+    out = tmp_path / "hla_debug.json"
+    dbg.save(str(out))
+    obj = json.load(open(out))
+    assert obj["dual_passing_stats"] == expected_dual                        # f64 text round-trips to the same doubles
+    assert list(obj["read_mapping_stats"]) == sorted(fx.genes)
+    for gene in fx.genes:
+        assert list(obj["read_mapping_stats"][gene]) == ["consensus1", "consensus2"]
+        for entry in obj["read_mapping_stats"][gene].values():
+            (stats,) = entry["mapping_stats"].values()
+            assert stats["cdna_mapping"] is None and list(stats["dna_mapping"]) == ["query_len", "target_len", "match_len", "nm", "query_unmapped",
+                                                                                  "target_unmapped", "cigar", "md"]
