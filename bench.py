@@ -382,7 +382,7 @@ def main():
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
 
-    e2e_names = ("anchor", "k1_cells", "k1_cells_deep", "k1_reduce", "k1_finalize", "hla_segments", "cons_steps", "type_consensus_ref",
+    e2e_names = ("anchor", "anchor_k1", "anchor_k2", "anchor_type", "k1_cells", "k1_cells_deep", "k1_reduce", "k1_finalize", "hla_segments", "cons_steps", "type_consensus_ref",
                  "k2_cells_cdna", "k2_cells_dna", "k2_scan")
     kernel_ms = {k: ctx.profile_get(k)[0] / max(1, args.steps) for k in e2e_names}
     ms_cells, launches, cells_all = ctx.profile_get("k1_cells")
@@ -477,6 +477,9 @@ def main():
                                  "(roofline_valu), 'traffic' is what actually crossed HBM"},
             "roofline_valu": valu,
             "kernel_ms": kernel_ms, "host_wall_ms": host_ms,
+            **({"dbg_counters": [ctx.counter(f"dbg{i}") for i in range(8)]} if os.environ.get("SP_BENCH_DBG") else {}),
+            "anchor_pairs_per_step": {k: ctx.profile_get(k)[2] / max(1, args.steps) for k in ("anchor_k1", "anchor_k2", "anchor_type")},
+            "anchor_launches_per_step": {k: ctx.profile_get(k)[1] / max(1, args.steps) for k in ("anchor_k1", "anchor_k2", "anchor_type")},
             "consensus": {"windows_per_step": cons_windows / max(1, args.steps), "launches_per_step": 3 * cons_windows / max(1, args.steps),
                           "cut_windows_per_step": cons_cut / max(1, args.steps), "expansions_per_step": cons_exp / max(1, args.steps),
                           "nodes_expanded_per_step": cons_cols / max(1, args.steps),

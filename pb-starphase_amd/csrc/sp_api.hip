@@ -77,7 +77,9 @@ int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64
     // device counters: "count:<name>" returns the value in *cells (ms and launches are 0)
     static const struct { const char* name; int idx; } counters[] = {
         {"count:k1_cells_active", SPC_K1_ACTIVE}, {"count:k1_cells_executed", SPC_K1_EXECUTED}, {"count:k1_cells_resumed", SPC_K1_RESUMED},
-        {"count:k1_cells_bytes", SPC_K1_BYTES}, {"count:cons_launches", SPC_CONS_LAUNCHES}, {"count:cons_columns", SPC_CONS_COLUMNS} };
+        {"count:k1_cells_bytes", SPC_K1_BYTES}, {"count:cons_launches", SPC_CONS_LAUNCHES}, {"count:cons_columns", SPC_CONS_COLUMNS},
+        // slots of the timing builds (profiles/scripts): zero in the production library
+        {"count:dbg0", 6}, {"count:dbg1", 7}, {"count:dbg2", 8}, {"count:dbg3", 9}, {"count:dbg4", 10}, {"count:dbg5", 11}, {"count:dbg6", 12}, {"count:dbg7", 13} };
     for (const auto& c : counters) if (std::strcmp(kernel, c.name) == 0) {
         unsigned long long v = 0; unsigned long long* d = sp_counters(ctx);
         if (d) { hipSetDevice(ctx->device); if (hipMemcpyAsync(&v, d + c.idx, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "sp_profile_get: counter read failed"); }

@@ -10,44 +10,83 @@
 // Replaces minimap2's minimizer seeding + chaining inside Aligner::map (DESIGN.md section 3.1;
 // CPU restatement: oracle/align.c osp_anchor).
 // =============================================================================================
+#define SP_ANCHOR_BUCKET_BITS 10
 #ifndef SP_ANCHOR_THREADS
 #define SP_ANCHOR_THREADS 512      // 256: 2.65 ms, 512: 2.14 ms, 1024: 3.65 ms for the 20,000 (read, gene) pairs of the bench step
 #endif
 __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView A, KmerIndexView KA, SeqSetView B,
                                                         const uint32_t* __restrict__ a_idx, const uint32_t* __restrict__ b_idx,
                                                         uint64_t n_pairs, int32_t* __restrict__ diag_out, int32_t* __restrict__ votes_out,
-                                                        int bins_cap, int topk, int tab_cap) {
+                                                        int bins_cap, int topk, int tab_cap, unsigned long long* dbg) {
     extern __shared__ uint32_t lds[];                 // [packed u16 vote bins, 2 per dword][A's sorted 16-mer codes][their positions]
     __shared__ unsigned long long red[SP_ANCHOR_THREADS / 64];
     __shared__ int spread[2];
+    // where the codes with each value of the top SP_ANCHOR_BUCKET_BITS bits start in the LDS table: a look-up begins inside its bucket, so
+    // the lower bound takes log2(largest bucket) halvings instead of log2(table) (13 -> 4 for a 5 kb gene)
+    __shared__ uint16_t bucket[(1 << SP_ANCHOR_BUCKET_BITS) + 1];
+    __shared__ int bucket_steps;
     const int tid = threadIdx.x;
     uint32_t* tab_code = lds + ((bins_cap + 1) >> 1);
     int32_t* tab_pos = reinterpret_cast<int32_t*>(tab_code + tab_cap);
     int tab_a = -1;                                   // the A whose table sits in LDS
+    // the description of a pair is three dependent global loads deep (pair -> sequence ids -> lengths and offsets -> bases): it is fetched one
+    // pair ahead, so the chain runs under the work of the pair before (a workgroup has the CU to itself or shares it with one other)
+    struct PairMeta { uint32_t a, b; int m, n; uint64_t woff, k0, k1; };
+    auto fetch = [&](uint64_t q) {
+        PairMeta x;
+        x.a = a_idx[q]; x.b = b_idx[q];
+        x.m = A.len[x.a]; x.n = B.len[x.b]; x.woff = B.word_off[x.b]; x.k0 = KA.off[x.a]; x.k1 = KA.off[x.a + 1];
+        return x;
+    };
+    PairMeta next = {};
+    if (blockIdx.x < n_pairs) next = fetch(blockIdx.x);
     for (uint64_t p = blockIdx.x; p < n_pairs; p += gridDim.x) {
-        const uint32_t a = a_idx[p], b = b_idx[p];
-        const int m = A.len[a], n = B.len[b];
+        const PairMeta cur = next;
+        if (p + gridDim.x < n_pairs) next = fetch(p + gridDim.x);
+        const uint32_t a = cur.a, b = cur.b;
+        const int m = cur.m, n = cur.n;
         const int nbins = m + n + 1;
         if (m < SP_KMER || n < SP_KMER || nbins > bins_cap) {
             if (tid == 0) for (int k2 = 0; k2 < topk; ++k2) { diag_out[p * topk + k2] = 0; votes_out[p * topk + k2] = 0; }
             continue;
         }
         const int nb32 = (nbins + 1) >> 1;
+#ifdef SP_ANCHOR_TIMING
+        long long tq[5]; tq[0] = clock64();
+#define SP_AT(k) tq[k] = clock64()
+#else
+#define SP_AT(k)
+#endif
         for (int i = tid; i < nb32; i += SP_ANCHOR_THREADS) lds[i] = 0;
-        const uint32_t* bw = B.words + B.word_off[b];
-        const uint32_t* bn = B.nplane ? B.nplane + B.word_off[b] : nullptr;
-        const uint64_t k0 = KA.off[a], k1 = KA.off[a + 1];
+        const uint32_t* bw = B.words + cur.woff;
+        const uint32_t* bn = B.nplane ? B.nplane + cur.woff : nullptr;
+        const uint64_t k0 = cur.k0, k1 = cur.k1;
         const int nk = (int)(k1 - k0);
         // A's table moves to LDS once per run of pairs with the same A (a workgroup strides over the pair list, and callers lay
         // pairs out gene-minor, so a workgroup mostly keeps one table): the binary search then runs at LDS latency, not L2 latency
-        const bool in_lds = nk <= tab_cap;
-        if (in_lds && (int)a != tab_a) for (int i = tid; i < nk; i += SP_ANCHOR_THREADS) { tab_code[i] = KA.code[k0 + i]; tab_pos[i] = KA.pos[k0 + i]; }
+        const bool in_lds = nk <= tab_cap && nk < 65536;
+        if (in_lds && (int)a != tab_a) {
+            constexpr int NB = 1 << SP_ANCHOR_BUCKET_BITS, SH = 32 - SP_ANCHOR_BUCKET_BITS;
+            for (int i = tid; i < nk; i += SP_ANCHOR_THREADS) {
+                const uint32_t c = KA.code[k0 + i];
+                tab_code[i] = c; tab_pos[i] = KA.pos[k0 + i];
+                // entry i opens every bucket after its predecessor's up to its own
+                const int from = i > 0 ? (int)(KA.code[k0 + i - 1] >> SH) + 1 : 0, to = (int)(c >> SH);
+                for (int q = from; q <= to; ++q) bucket[q] = (uint16_t)i;
+            }
+            if (tid == 0) { bucket_steps = 0; for (int q = nk > 0 ? (int)(KA.code[k1 - 1] >> SH) + 1 : 0; q <= NB; ++q) bucket[q] = (uint16_t)nk; }
+            __syncthreads();
+            int widest = 0;
+            for (int q = tid; q < NB; q += SP_ANCHOR_THREADS) { const int w = (int)bucket[q + 1] - (int)bucket[q]; widest = w > widest ? w : widest; }
+            if (widest > 0) atomicMax(&bucket_steps, 32 - __builtin_clz((unsigned)widest));
+        }
         tab_a = in_lds ? (int)a : -1;
         const uint32_t* kc = in_lds ? tab_code : KA.code + k0; const int32_t* kp = in_lds ? tab_pos : KA.pos + k0;
         __syncthreads();
+        SP_AT(1);
         // four lookups per thread run side by side: a lower bound over nk entries takes the same number of halvings for every k-mer,
         // so the four dependent load chains overlap instead of queueing behind one another (one wave per SIMD here: nothing else would)
-        const int steps = nk > 0 ? 32 - __builtin_clz((unsigned)nk) : 0;
+        const int steps = in_lds ? bucket_steps : nk > 0 ? 32 - __builtin_clz((unsigned)nk) : 0;
         for (int j0 = tid; j0 + SP_KMER <= n; j0 += SP_ANCHOR_THREADS * 4) {
             uint32_t code[4]; int lo[4], hi[4], jj[4]; bool live[4];
 #pragma unroll
@@ -58,7 +97,8 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
                 const int w = ok ? j >> 4 : 0; const uint32_t sh = (uint32_t)((j & 15) << 1);
                 if (ok && bn && __builtin_amdgcn_alignbit(bn[w + 1], bn[w], sh)) ok = false;
                 code[u] = __builtin_amdgcn_alignbit(bw[w + 1], bw[w], sh);
-                lo[u] = 0; hi[u] = ok ? nk : 0; live[u] = ok;
+                const int q = (int)(code[u] >> (32 - SP_ANCHOR_BUCKET_BITS));
+                lo[u] = in_lds ? (int)bucket[q] : 0; hi[u] = !ok ? lo[u] : in_lds ? (int)bucket[q + 1] : nk; live[u] = ok;
             }
             for (int st = 0; st < steps; ++st) {
 #pragma unroll
@@ -72,18 +112,34 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (!live[u]) continue;
                 const int l = lo[u];
-                int e = l; while (e < nk && e - l <= SP_MAXOCC && kc[e] == code[u]) ++e;
-                const int occ = e - l;
-                if (occ == 0 || occ > SP_MAXOCC) continue;
-                for (int y = l; y < e; ++y) {
-                    const int bin = jj[u] - kp[y] + m;
-                    atomicAdd(&lds[bin >> 1], (bin & 1) ? 0x10000u : 1u);
+                int e = l;
+                if (live[u]) while (e < nk && e - l <= SP_MAXOCC && kc[e] == code[u]) ++e;
+                int occ = e - l;
+                if (occ > SP_MAXOCC) occ = 0;
+                // a read that crosses the gene puts thousands of votes on one diagonal, and neighbouring lanes hold neighbouring k-mers of it:
+                // lanes whose single vote goes to the bin of the lane before them hand it to the first lane of their run, which adds the
+                // run's count once (64 atomics on one LDS address would be carried out one after the other)
+                const int bin1 = occ == 1 ? jj[u] - kp[l] + m : -1;
+                const int prev = __shfl_up(bin1, 1);
+                const int lane = tid & 63;
+                const bool follows = bin1 >= 0 && lane > 0 && prev == bin1;
+                const unsigned long long F = __ballot(follows);
+                if (bin1 >= 0 && !follows) {
+                    const unsigned long long rest = lane == 63 ? 0ull : (F >> (lane + 1));
+                    const uint32_t count = 1u + (uint32_t)__builtin_ctzll(~rest);
+                    atomicAdd(&lds[bin1 >> 1], (bin1 & 1) ? count << 16 : count);
                 }
+                if (occ > 1)
+                    for (int y = l; y < e; ++y) {
+                        const int bin = jj[u] - kp[y] + m;
+                        atomicAdd(&lds[bin >> 1], (bin & 1) ? 0x10000u : 1u);
+                    }
             }
         }
+        SP_AT(2);
         __syncthreads();
+        SP_AT(3);
         // top-K peaks: argmax votes (ties -> smallest diagonal), then clear every bin within +-SP_PEAK_SUPPRESS of it
         for (int round = 0; round < topk; ++round) {
             unsigned long long best = 0;
@@ -128,6 +184,10 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
             }
         }
         __syncthreads();
+#ifdef SP_ANCHOR_TIMING
+        SP_AT(4);
+        if (tid == 0) { for (int k2 = 0; k2 < 4; ++k2) atomicAdd(&dbg[6 + k2], (unsigned long long)(tq[k2 + 1] - tq[k2])); atomicAdd(&dbg[10], 1ull); atomicAdd(&dbg[11], (unsigned long long)n); atomicAdd(&dbg[12], (unsigned long long)m); }
+#endif
     }
 }
 
@@ -385,7 +445,7 @@ int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn) {
 
 int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,
-                     int32_t* d_diag, int32_t* d_votes, int topk) {
+                     int32_t* d_diag, int32_t* d_votes, int topk, const char* prof_name) {
     if (topk < 1 || topk > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: topk must be 1..8");
     if (n_pairs == 0) return SP_OK;
     if (!A->has_index) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: set A has no k-mer index");
@@ -397,10 +457,10 @@ int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     if (lds_bytes + (size_t)tab_cap * 8 > 160 * 1024 - 64) tab_cap = 0;
     lds_bytes += (size_t)tab_cap * 8;
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sp_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    uint64_t grid = std::min<uint64_t>(n_pairs, (uint64_t)ctx->num_cus * 8);
-    ProfScope ps(ctx, "anchor", n_pairs);
+    uint64_t grid = std::min<uint64_t>(n_pairs, (uint64_t)ctx->num_cus * 8);       // 1 / 2 / 4 / 8 / 16 per CU: 3.3 / 2.04 / 2.0 / 1.9 / 1.96 ms of anchors per bench step
+    ProfScope ps(ctx, prof_name, n_pairs);
     hipLaunchKernelGGL(sp_anchor_kernel, dim3((unsigned)grid), dim3(SP_ANCHOR_THREADS), lds_bytes, ctx->stream,
-                       A->view(), A->kview(), B->view(), d_a_idx, d_b_idx, n_pairs, d_diag, d_votes, bins_cap, topk, tab_cap);
+                       A->view(), A->kview(), B->view(), d_a_idx, d_b_idx, n_pairs, d_diag, d_votes, bins_cap, topk, tab_cap, sp_counters(ctx));
     SP_HIP_CHECK(ctx, hipGetLastError());
     return SP_OK;
 }

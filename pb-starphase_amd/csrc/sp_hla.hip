@@ -840,7 +840,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         if (!d_bound) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign bound");
     }
     if (rc == SP_OK) hipLaunchKernelGGL(k1_init_kernel, dim3((R * G + 255) / 256), dim3(256), 0, ctx->stream, d_a, d_b, R, G, d_bound);
-    if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes);
+    if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes, 1, "anchor_k1");
     const bool hasn = db->dna_fwd->has_n || reads->has_n || db->ref_fwd->has_n;
     // finalize: private per-wave windows of (allele, read) and (reference, read segment)
     int slot_words = std::max(sp_slot_words(db->dna_fwd, reads, hasn), sp_slot_words(db->ref_fwd, reads, hasn));
@@ -992,7 +992,7 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
     for (int L = 0; L < 2 && rc == SP_OK; ++L) {
         const sp_seqset* aset = L == 0 ? db->cdna_gene : db->dna_gene;
         const uint32_t* d_c = L == 0 ? d_c0 : d_c1;
-        rc = sp_launch_anchor(ctx, cons, aset, d_c, d_idx, T, d_diag, d_votes);
+        rc = sp_launch_anchor(ctx, cons, aset, d_c, d_idx, T, d_diag, d_votes, 1, "anchor_k2");
         if (rc != SP_OK) break;
         hipLaunchKernelGGL(k2_build_cells_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_idx, T, d_c, d_diag, d_votes, aset->d_len, d_cells);
         rc = sp_launch_cells(ctx, aset, cons, d_cells, T, d_alns + (size_t)L * T, d_ev + (size_t)L * T * stride, stride, L == 0 ? "k2_cells_cdna" : "k2_cells_dna", 1);
@@ -1076,7 +1076,7 @@ static int32_t type_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items, co
     (void)hipMemcpyAsync(d_ab, a_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemcpyAsync(d_ab + n, b_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
-    rc = sp_launch_anchor(ctx, db->ref_fwd, cons, d_ab, d_ab + n, n, d_dv, d_dv + n);
+    rc = sp_launch_anchor(ctx, db->ref_fwd, cons, d_ab, d_ab + n, n, d_dv, d_dv + n, 1, "anchor_type");
     if (rc != SP_OK) return rc;
     std::vector<int32_t> dv((size_t)2 * n);
     (void)hipMemcpyAsync(dv.data(), d_dv, (size_t)2 * n * 4, hipMemcpyDeviceToHost, ctx->stream);

@@ -89,7 +89,7 @@ struct CellDesc {
 // ---------------------------------------------------------------- launchers (sp_device.hip)
 int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,
-                     int32_t* d_diag, int32_t* d_votes, int topk = 1);
+                     int32_t* d_diag, int32_t* d_votes, int topk = 1, const char* prof_name = "anchor");
 int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     const CellDesc* d_cells, uint64_t n_cells,
                     sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, int retry_wide = 0);   // 0 never, 1 lost cells, 2 lost cells and cells with > 32 edits (few-cell callers)
