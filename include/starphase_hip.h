@@ -881,6 +881,17 @@ int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64
  * wave-instructions / s of the WFA cell's 16-base compare), "hbm_copy" (bytes / s, read + written, of a 2 x 1 GiB streaming copy) */
 int32_t sp_microbench(sp_ctx* ctx, const char* what, double* rate);
 
+/* The reference FASTA (ReferenceGenome::from_fasta / get_slice of rust-lib-reference-genome, loaded once in src/cli/diplotype.rs): the
+ * slices sp_database_hla_gene / sp_database_cyp_window / sp_variant_gene_create ask for.  Plain files are read through "<path>.fai"
+ * when it exists (only the requested bases are read), otherwise -- and for gzip / BGZF files -- the file is read into memory once.
+ * Coordinates are 0-based half-open; bases come back upper-cased and stay valid until the next fetch on the handle. */
+typedef struct sp_fasta sp_fasta;
+int32_t sp_fasta_open(const char* path, sp_fasta** out, char* err, uint32_t err_cap);
+void    sp_fasta_free(sp_fasta* fasta);
+const char* sp_fasta_last_error(const sp_fasta* fasta);
+int32_t sp_fasta_sequences(sp_fasta* fasta, uint32_t* n, const char* const** names, const uint64_t** lengths);
+int32_t sp_fasta_fetch(sp_fasta* fasta, const char* chrom, uint64_t start, uint64_t end, const char** bases, uint64_t* len);
+
 #ifdef __cplusplus
 }
 #endif

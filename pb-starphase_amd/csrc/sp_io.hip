@@ -278,6 +278,13 @@ int32_t sp_bam_fetch(sp_bam* b, const char* chrom, uint64_t start, uint64_t end,
 } // extern "C"
 
 // ------------------------------------------------------------------------------------------------ VCF
+struct sp_fasta {
+    struct Seq { std::string name; uint64_t length = 0, offset = 0, line_bases = 0, line_bytes = 0; std::string bases; };
+    std::string path, err, slice;
+    std::vector<Seq> seqs; std::vector<const char*> name_ptr; std::vector<uint64_t> lengths;
+    bool indexed = false; FILE* file = nullptr;
+};
+
 struct sp_vcf {
     std::string err;
     std::vector<std::string> samples; std::vector<const char*> sample_ptr;
@@ -410,6 +417,102 @@ int32_t sp_vcf_deletions(sp_vcf* v, const char* sample, const char* chrom, uint6
         v->deletions.push_back(sp_vcf_deletion{ r.pos0, e, gt, 0, ps });
     }
     *out = v->deletions.data(); *n = (uint32_t)v->deletions.size();
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ reference FASTA
+// What the reference gets from ReferenceGenome::from_fasta / get_slice (rust-lib-reference-genome; src/cli/diplotype.rs loads the file
+// once, the callers take 0-based half-open slices: HlaRealigner::new src/hla/realigner.rs:74-81, Cyp2d6Extractor::new
+// src/cyp2d6/haplotyper.rs:45-132, load_database_haplotypes src/diplotyper.rs:437-548).  A plain file with a "<path>.fai" next to it is
+// read slice by slice through the index (name, length, offset, bases per line, bytes per line); anything else (no index, gzip / BGZF) is
+// read into memory once.  Bases are handed out upper-cased.
+int32_t sp_fasta_open(const char* path, sp_fasta** out, char* err, uint32_t err_cap) {
+    if (!path || !out) return SP_ERR_INVALID_ARG;
+    *out = nullptr;
+    auto fa = std::make_unique<sp_fasta>();
+    fa->path = path;
+    // gzip magic?
+    bool gz = false;
+    { FILE* f = std::fopen(path, "rb"); if (!f) { put_err(err, err_cap, std::string("cannot open ") + path); return SP_ERR_INVALID_ARG; }
+      unsigned char m[2] = { 0, 0 }; gz = std::fread(m, 1, 2, f) == 2 && m[0] == 0x1f && m[1] == 0x8b; std::fclose(f); }
+    FILE* idx = gz ? nullptr : std::fopen((fa->path + ".fai").c_str(), "rb");
+    if (idx) {
+        char line[4096];
+        while (std::fgets(line, sizeof line, idx)) {
+            std::string l(line); while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+            if (l.empty()) continue;
+            const std::vector<std::string> col = split(l, '\t');
+            if (col.size() < 5) { std::fclose(idx); put_err(err, err_cap, "FASTA index line with fewer than 5 columns"); return SP_ERR_INVALID_ARG; }
+            sp_fasta::Seq q; q.name = col[0]; q.length = std::strtoull(col[1].c_str(), nullptr, 10); q.offset = std::strtoull(col[2].c_str(), nullptr, 10);
+            q.line_bases = std::strtoull(col[3].c_str(), nullptr, 10); q.line_bytes = std::strtoull(col[4].c_str(), nullptr, 10);
+            if (q.line_bases == 0 || q.line_bytes < q.line_bases) { std::fclose(idx); put_err(err, err_cap, "FASTA index line with an impossible line width"); return SP_ERR_INVALID_ARG; }
+            fa->seqs.push_back(std::move(q));
+        }
+        std::fclose(idx);
+        fa->file = std::fopen(path, "rb");
+        if (!fa->file) { put_err(err, err_cap, std::string("cannot open ") + path); return SP_ERR_INVALID_ARG; }
+        fa->indexed = true;
+    } else {
+        gzFile f = gzopen(path, "rb");
+        if (!f) { put_err(err, err_cap, std::string("cannot open ") + path); return SP_ERR_INVALID_ARG; }
+        std::string text; char buf[1 << 16]; int k;
+        while ((k = gzread(f, buf, sizeof buf)) > 0) text.append(buf, (size_t)k);
+        const bool bad = k < 0;
+        gzclose(f);
+        if (bad) { put_err(err, err_cap, std::string("cannot read ") + path); return SP_ERR_INVALID_ARG; }
+        size_t from = 0;
+        while (from < text.size()) {
+            size_t to = text.find('\n', from); if (to == std::string::npos) to = text.size();
+            size_t stop = to; if (stop > from && text[stop - 1] == '\r') --stop;
+            if (stop > from && text[from] == '>') {
+                sp_fasta::Seq q; size_t e = from + 1; while (e < stop && text[e] != ' ' && text[e] != '\t') ++e;      // the name ends at the first blank
+                q.name = text.substr(from + 1, e - from - 1);
+                fa->seqs.push_back(std::move(q));
+            } else if (stop > from) {
+                if (fa->seqs.empty()) { put_err(err, err_cap, "FASTA bases before the first header line"); return SP_ERR_INVALID_ARG; }
+                std::string& b = fa->seqs.back().bases;
+                for (size_t i = from; i < stop; ++i) { const char c = text[i]; b += (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+            }
+            from = to + 1;
+        }
+        for (auto& q : fa->seqs) q.length = q.bases.size();
+    }
+    for (auto& q : fa->seqs) { fa->name_ptr.push_back(q.name.c_str()); fa->lengths.push_back(q.length); }
+    *out = fa.release();
+    return SP_OK;
+}
+
+void sp_fasta_free(sp_fasta* fa) { if (fa) { if (fa->file) std::fclose(fa->file); delete fa; } }
+const char* sp_fasta_last_error(const sp_fasta* fa) { return fa ? fa->err.c_str() : ""; }
+
+int32_t sp_fasta_sequences(sp_fasta* fa, uint32_t* n, const char* const** names, const uint64_t** lengths) {
+    if (!fa || !n) return SP_ERR_INVALID_ARG;
+    *n = (uint32_t)fa->seqs.size();
+    if (names) *names = fa->name_ptr.data();
+    if (lengths) *lengths = fa->lengths.data();
+    return SP_OK;
+}
+
+// get_slice(chrom, start, end): 0-based half-open; the slice has to lie inside the sequence
+int32_t sp_fasta_fetch(sp_fasta* fa, const char* chrom, uint64_t start, uint64_t end, const char** bases, uint64_t* len) {
+    if (!fa || !chrom || !bases) return SP_ERR_INVALID_ARG;
+    *bases = nullptr; if (len) *len = 0;
+    const sp_fasta::Seq* q = nullptr;
+    for (const auto& s : fa->seqs) if (s.name == chrom) { q = &s; break; }
+    if (!q) { fa->err = std::string("the FASTA has no sequence ") + chrom; return SP_ERR_INVALID_ARG; }
+    if (start > end || end > q->length) { fa->err = std::string("slice outside of ") + chrom; return SP_ERR_INVALID_ARG; }
+    if (!fa->indexed) fa->slice.assign(q->bases, (size_t)start, (size_t)(end - start));
+    else {
+        fa->slice.clear(); fa->slice.reserve((size_t)(end - start));
+        const uint64_t first = q->offset + (start / q->line_bases) * q->line_bytes + start % q->line_bases;
+        const uint64_t last = end == start ? first : q->offset + ((end - 1) / q->line_bases) * q->line_bytes + (end - 1) % q->line_bases + 1;
+        std::string raw((size_t)(last - first), '\0');
+        if (fseeko(fa->file, (off_t)first, SEEK_SET) != 0 || std::fread(&raw[0], 1, raw.size(), fa->file) != raw.size()) { fa->err = "cannot read " + fa->path; return SP_ERR_INVALID_ARG; }
+        for (char c : raw) if (c != '\n' && c != '\r') fa->slice += (c >= 'a' && c <= 'z') ? (char)(c - 32) : c;
+        if (fa->slice.size() != end - start) { fa->err = "the FASTA index does not describe " + fa->path; return SP_ERR_INVALID_ARG; }
+    }
+    *bases = fa->slice.c_str();
+    if (len) *len = fa->slice.size();
     return SP_OK;
 }
 

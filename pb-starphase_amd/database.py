@@ -529,6 +529,11 @@ def _io():
         "sp_vcf_samples": (_i32, [_vp, P(_u32), P(P(_s))]),
         "sp_vcf_alleles": (_i32, [_vp, _s, _s, _u64, _u64, P(P(sp_vcf_allele)), P(_u32)]),
         "sp_vcf_deletions": (_i32, [_vp, _s, _s, _u64, _u64, P(P(sp_vcf_deletion)), P(_u32)]),
+        "sp_fasta_open": (_i32, [_s, P(_vp), _s, _u32]),
+        "sp_fasta_free": (None, [_vp]),
+        "sp_fasta_last_error": (_s, [_vp]),
+        "sp_fasta_sequences": (_i32, [_vp, P(_u32), P(P(_s)), P(P(_u64))]),
+        "sp_fasta_fetch": (_i32, [_vp, _s, _u64, _u64, P(_s), P(_u64)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -616,3 +621,34 @@ class Vcf:
         out, n = C.POINTER(sp_vcf_deletion)(), _u32()
         self._check(_io().sp_vcf_deletions(self._h, _b(sample), _b(chrom), int(start), int(end), C.byref(out), C.byref(n)))
         return [(out[i].start, out[i].end, out[i].gt, None if out[i].ps < 0 else out[i].ps) for i in range(n.value)]
+
+
+class Fasta:
+    """sp_fasta: the reference FASTA (plain with or without .fai, gzip)"""
+
+    def __init__(self, path):
+        self._h = _vp()
+        err = C.create_string_buffer(512)
+        rc = _io().sp_fasta_open(_b(path), C.byref(self._h), err, 512)
+        if rc != SP_OK:
+            raise StarphaseError(rc, err.value.decode())
+
+    def __del__(self):
+        try:
+            if self._h:
+                _io().sp_fasta_free(self._h)
+                self._h = _vp()
+        except Exception:
+            pass
+
+    def sequences(self):
+        n, names, lens = _u32(), C.POINTER(_s)(), C.POINTER(_u64)()
+        _io().sp_fasta_sequences(self._h, C.byref(n), C.byref(names), C.byref(lens))
+        return [(names[i].decode(), lens[i]) for i in range(n.value)]
+
+    def fetch(self, chrom, start, end):
+        b, n = _s(), _u64()
+        rc = _io().sp_fasta_fetch(self._h, _b(chrom), int(start), int(end), C.byref(b), C.byref(n))
+        if rc != SP_OK:
+            raise StarphaseError(rc, _io().sp_fasta_last_error(self._h).decode())
+        return C.string_at(b, n.value).decode()

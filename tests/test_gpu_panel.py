@@ -175,7 +175,23 @@ def test_sample_from_database_files_to_result_file(oracle, pkg, gpu_ctx, tmp_pat
     hdb_file = D.Database(os.path.join(GOLDEN, "hla_db_v0.14.1.json.gz"))
     regions = hdb_file.hla_genes()
     assert [(r["start"], r["end"]) for r in regions] == fx.coords
-    hdb, alleles = hdb_file.hla_db(gpu_ctx, fx.gene_ref)
+    # the reference bases come out of a FASTA file through its .fai: chr6 with the gene islands, chr22 with the CYP2D6 window (N elsewhere)
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    buffer = (len(fx.gene_ref[0]) - (fx.coords[0][1] - fx.coords[0][0])) // 2
+    chr6 = bytearray(b"N" * (max(e for _s, e in fx.coords) + buffer + 1000))
+    for (s0, _e0), ref in zip(fx.coords, fx.gene_ref):
+        chr6[s0 - buffer:s0 - buffer + len(ref)] = ref.encode()
+    chr22 = bytearray(b"N" * (locus.start + len(locus.sequence) + 1000))
+    chr22[locus.start:locus.start + len(locus.sequence)] = locus.sequence.encode()
+    import test_io
+    fasta_path = tmp_path / "reference.fa"
+    test_io.write_fasta(fasta_path, {"chr6": chr6.decode(), "chr22": chr22.decode()}, 60, index=True)
+    del chr6, chr22
+    fasta = D.Fasta(str(fasta_path))
+    gene_ref = [fasta.fetch(r["chrom"], r["start"] - buffer, r["end"] + buffer) for r in regions]
+    assert gene_ref == fx.gene_ref
+    hdb, alleles = hdb_file.hla_db(gpu_ctx, gene_ref)
     ref_db = fx.make_db(pkg, gpu_ctx)
     reads = []
     for g in range(len(fx.genes)):
@@ -183,7 +199,6 @@ def test_sample_from_database_files_to_result_file(oracle, pkg, gpu_ctx, tmp_pat
             hap, s = fx.haplotype(g, a)
             reads += synth.simulate_reads(rng, hap, s, len(fx.dna[a]), 23, mean_len=6000, sd_len=1500, min_overlap=2500)
     # the reads come out of a BAM file (written by the test's own encoder): one region fetch per gene, QNAMEs handed out once
-    import test_io
     order = rng.permutation(len(reads)).tolist()
     recs = sorted(((0, int(regions[i % 2]["start"]) + int(rng.integers(0, 2000)), f"m84/{i}/ccs", 0, 60, [("M", len(reads[i]))], reads[i]) for i in order),
                   key=lambda r: r[1])
@@ -208,9 +223,10 @@ def test_sample_from_database_files_to_result_file(oracle, pkg, gpu_ctx, tmp_pat
                           dna=(int(ra[r]["target_len"]), int(ra[r]["nm"]), int(ra[r]["unmapped"])))
         result.insert(fx.genes[g], d, D.FROM_MAPPINGS)
     # ---- CYP2D6: database file -> sp_cyp_db -> sp_cyp_diplotype
-    cfg, gene_def = cr.load_db()
-    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
-    cdb = D.Database(os.path.join(GOLDEN, "cyp2d6_db_v0.14.1.json.gz")).cyp_db(gpu_ctx, locus.sequence, locus.start)
+    cyp_file = D.Database(os.path.join(GOLDEN, "cyp2d6_db_v0.14.1.json.gz"))
+    w_chrom, w_start, w_end = cyp_file.cyp_window()
+    assert w_chrom == "chr22" and locus.start <= w_start and w_end <= locus.start + len(locus.sequence)
+    cdb = cyp_file.cyp_db(gpu_ctx, fasta.fetch(w_chrom, locus.start, locus.start + len(locus.sequence)), locus.start)
     _name, haps, expected = cr.scenarios(locus)[1]
     call, _cons, _labels = cdb.diplotype(gpu_ctx.upload(locus.sample(rng, haps, 120, lo=8000, hi=16000)))
     assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)

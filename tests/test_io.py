@@ -276,3 +276,69 @@ def test_bam_reads_go_to_the_library(D, pkg, tmp_path):
     assert D._io().sp_bam_fetch(bam._h, b"chr6", 0, 50000, 0, 0, C.byref(reads), C.byref(n), C.byref(bases), C.byref(offs)) == 0
     assert n.value == 40 and offs[0] == 0 and [offs[i + 1] - offs[i] for i in range(40)] == [len(r[6]) for r in recs]
     assert C.string_at(bases.value, int(offs[40])).decode() == "".join(r[6] for r in recs)
+
+
+# ------------------------------------------------------------------ reference FASTA
+def write_fasta(path, seqs, width, newline="\n", lower=False, index=False, describe=False):
+    """a FASTA file the way samtools faidx expects it (fixed line width per sequence) and, optionally, its .fai"""
+    fai, parts, size = [], [], 0
+    for name, bases in seqs.items():
+        header = ((f">{name} test sequence" if describe else f">{name}") + newline).encode()
+        parts.append(header); size += len(header)
+        fai.append((name, len(bases), size, width, width + len(newline)))
+        body = (bases.lower() if lower else bases).encode()
+        lines = [body[i:i + width] for i in range(0, len(body), width)]
+        block = newline.encode().join(lines) + (newline.encode() if lines else b"")
+        parts.append(block); size += len(block)
+    with open(path, "wb") as f:
+        f.write(b"".join(parts))
+    if index:
+        open(str(path) + ".fai", "w").write("".join("\t".join(map(str, row)) + "\n" for row in fai))
+
+
+@pytest.mark.parametrize("index", [False, True])
+@pytest.mark.parametrize("width,newline", [(10, "\n"), (7, "\n"), (60, "\r\n")])
+def test_fasta_slices(D, tmp_path, index, width, newline):
+    """ReferenceGenome::get_slice on the reference's own test genome (test_data/test_reference.fa, decoded in tests/golden/test_reference.json)
+    plus a long random chromosome: every slice equals the Python slice, with and without the .fai"""
+    seqs = dict(json.load(open(os.path.join(GOLDEN, "test_reference.json"))))
+    rng = np.random.default_rng(3)
+    seqs["chrLong"] = "".join(rng.choice(list("ACGTN"), 5003, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+    path = tmp_path / "ref.fa"
+    write_fasta(path, seqs, width, newline, lower=True, index=index, describe=True)
+    fa = D.Fasta(str(path))
+    assert fa.sequences() == [(k, len(v)) for k, v in seqs.items()]
+    for name, bases in seqs.items():
+        assert fa.fetch(name, 0, len(bases)) == bases                     # soft-masked (lower-case) input comes back upper-cased
+        for _ in range(40):
+            a = int(rng.integers(0, len(bases) + 1)); b = int(rng.integers(a, len(bases) + 1))
+            assert fa.fetch(name, a, b) == bases[a:b]
+    assert fa.fetch("chr1", 5, 5) == ""
+
+
+def test_fasta_gzip_and_errors(D, pkg, tmp_path):
+    seqs = dict(json.load(open(os.path.join(GOLDEN, "test_reference.json"))))
+    plain = tmp_path / "ref.fa"
+    write_fasta(plain, seqs, 10)
+    gz = tmp_path / "ref.fa.gz"
+    gzip.open(gz, "wb").write(open(plain, "rb").read())
+    fa = D.Fasta(str(gz))
+    assert fa.fetch("chr2", 8, 14) == seqs["chr2"][8:14] and fa.fetch("chr3", 0, 20) == seqs["chr3"]
+    with pytest.raises(pkg.StarphaseError, match="no sequence chrX"):
+        fa.fetch("chrX", 0, 1)
+    with pytest.raises(pkg.StarphaseError, match="slice outside of chr1"):
+        fa.fetch("chr1", 0, 21)
+    with pytest.raises(pkg.StarphaseError, match="slice outside of chr1"):
+        fa.fetch("chr1", 5, 4)
+    with pytest.raises(pkg.StarphaseError, match="cannot open"):
+        D.Fasta(str(tmp_path / "missing.fa"))
+    bad = tmp_path / "bad.fa"
+    open(bad, "w").write("ACGT\n>chr1\nACGT\n")
+    with pytest.raises(pkg.StarphaseError, match="before the first header"):
+        D.Fasta(str(bad))
+    # an index that does not describe the file is reported, not trusted
+    write_fasta(plain, seqs, 10, index=True)
+    open(str(plain) + ".fai", "w").write("chr1\t20\t6\t10\t11\nchr2\t20\t5\t4\t5\n")
+    fa = D.Fasta(str(plain))
+    with pytest.raises(pkg.StarphaseError, match="does not describe"):
+        fa.fetch("chr2", 0, 20)
