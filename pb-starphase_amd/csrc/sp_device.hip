@@ -11,6 +11,9 @@
 // CPU restatement: oracle/align.c osp_anchor).
 // =============================================================================================
 #define SP_ANCHOR_BUCKET_BITS 10
+#ifndef SP_ANCHOR_ILP
+#define SP_ANCHOR_ILP 2          // look-ups a thread runs side by side (anchors of a bench step: 1: 1.83 ms, 2: 1.77, 3: 1.83, 4: 1.89, 8: 2.36)
+#endif
 #ifndef SP_ANCHOR_THREADS
 #define SP_ANCHOR_THREADS 512      // 256: 2.65 ms, 512: 2.14 ms, 1024: 3.65 ms for the 20,000 (read, gene) pairs of the bench step
 #endif
@@ -87,10 +90,10 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
         // four lookups per thread run side by side: a lower bound over nk entries takes the same number of halvings for every k-mer,
         // so the four dependent load chains overlap instead of queueing behind one another (one wave per SIMD here: nothing else would)
         const int steps = in_lds ? bucket_steps : nk > 0 ? 32 - __builtin_clz((unsigned)nk) : 0;
-        for (int j0 = tid; j0 + SP_KMER <= n; j0 += SP_ANCHOR_THREADS * 4) {
-            uint32_t code[4]; int lo[4], hi[4], jj[4]; bool live[4];
+        for (int j0 = tid; j0 + SP_KMER <= n; j0 += SP_ANCHOR_THREADS * SP_ANCHOR_ILP) {
+            uint32_t code[SP_ANCHOR_ILP]; int lo[SP_ANCHOR_ILP], hi[SP_ANCHOR_ILP], jj[SP_ANCHOR_ILP]; bool live[SP_ANCHOR_ILP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SP_ANCHOR_ILP; ++u) {
                 const int j = j0 + u * SP_ANCHOR_THREADS;
                 jj[u] = j;
                 bool ok = j + SP_KMER <= n;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
             }
             for (int st = 0; st < steps; ++st) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < SP_ANCHOR_ILP; ++u) {
                     const bool open = lo[u] < hi[u];
                     int mid = (lo[u] + hi[u]) >> 1; mid = mid < nk ? mid : nk - 1;
                     const bool less = kc[mid] < code[u];
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SP_ANCHOR_ILP; ++u) {
                 const int l = lo[u];
                 int e = l;
                 if (live[u]) while (e < nk && e - l <= SP_MAXOCC && kc[e] == code[u]) ++e;
