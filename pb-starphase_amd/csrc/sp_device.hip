@@ -87,7 +87,7 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
         const uint32_t* kc = in_lds ? tab_code : KA.code + k0; const int32_t* kp = in_lds ? tab_pos : KA.pos + k0;
         __syncthreads();
         SP_AT(1);
-        // four lookups per thread run side by side: a lower bound over nk entries takes the same number of halvings for every k-mer,
+        // SP_ANCHOR_ILP look-ups per thread run side by side: a lower bound over nk entries takes the same number of halvings for every k-mer,
         // so the four dependent load chains overlap instead of queueing behind one another (one wave per SIMD here: nothing else would)
         const int steps = in_lds ? bucket_steps : nk > 0 ? 32 - __builtin_clz((unsigned)nk) : 0;
         for (int j0 = tid; j0 + SP_KMER <= n; j0 += SP_ANCHOR_THREADS * SP_ANCHOR_ILP) {
