@@ -88,7 +88,7 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
         __syncthreads();
         SP_AT(1);
         // SP_ANCHOR_ILP look-ups per thread run side by side: a lower bound over nk entries takes the same number of halvings for every k-mer,
-        // so the four dependent load chains overlap instead of queueing behind one another (one wave per SIMD here: nothing else would)
+        // so their dependent load chains overlap instead of queueing behind one another (one wave per SIMD here: nothing else would)
         const int steps = in_lds ? bucket_steps : nk > 0 ? 32 - __builtin_clz((unsigned)nk) : 0;
         for (int j0 = tid; j0 + SP_KMER <= n; j0 += SP_ANCHOR_THREADS * SP_ANCHOR_ILP) {
             uint32_t code[SP_ANCHOR_ILP]; int lo[SP_ANCHOR_ILP], hi[SP_ANCHOR_ILP], jj[SP_ANCHOR_ILP]; bool live[SP_ANCHOR_ILP];
