@@ -939,15 +939,27 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
 
 // K2 for a batch of consensuses: every (consensus, allowed allele) pair of a level is one cell of one launch, one scan workgroup
 // per consensus.  items: gene, gene-strand DNA consensus, spliced cDNA consensus.  stats (optional): per item n_alleles * 6.
+// pair t of a K2 batch belongs to the item k with seg_off[k] <= t < seg_off[k + 1]: allele = t - seg_off[k] of the item's gene list, consensus
+// set entries 2k (cDNA) and 2k + 1 (DNA)
+__global__ __launch_bounds__(256) void k2_pairs_kernel(uint32_t T, uint32_t n_items, const uint32_t* __restrict__ seg_off, const uint32_t* const* __restrict__ lists,
+                                                       uint32_t* __restrict__ idx, uint32_t* __restrict__ c0, uint32_t* __restrict__ c1) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    uint32_t lo = 0, hi = n_items;                                   // last k with seg_off[k] <= t
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_off[mid] <= t) lo = mid; else hi = mid; }
+    idx[t] = lists[lo][t - seg_off[lo]]; c0[t] = 2 * lo; c1[t] = 2 * lo + 1;
+}
+
 struct K2Item { uint32_t gene; const char* dna; uint32_t dna_len; const char* cdna; uint32_t cdna_len; };
 static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items, const K2Item* items, int32_t require_dna, int32_t disable_cdna,
                               sp_hla_best* best, int32_t* const* stats) {
     // "If cDNA scoring is disabled, require HLA DNA must be enabled" (caller.rs:517-520)
     if (disable_cdna && !require_dna) return sp_fail(ctx, SP_ERR_INVALID_ARG, "If cDNA scoring is disabled, require HLA DNA must be enabled");
     (void)hipSetDevice(ctx->device);
+    HostMarks hm(ctx);
     // allowed alleles of each item's gene, database order (is_allowed_allele_def, caller.rs:1090-1095)
     std::vector<const sp_hla_db::GeneList*> lists(n_items);
-    std::vector<uint32_t> seg_off(n_items + 1, 0), h_idx, h_c0, h_c1;
+    std::vector<uint32_t> seg_off(n_items + 1, 0);
     std::string blob; std::vector<uint64_t> coff(1, 0);
     for (uint32_t k = 0; k < n_items; ++k) {
         if (items[k].gene >= db->n_genes) return sp_fail(ctx, SP_ERR_INVALID_ARG, "score_consensus: gene out of range");
@@ -957,8 +969,6 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
         best[k].best_allele = -1; best[k].n_scored = (int32_t)gl.idx.size();
         if (stats && stats[k]) for (uint32_t a = 0; a < db->n_alleles; ++a) for (int x = 0; x < 6; ++x) stats[k][(size_t)a * 6 + x] = -2;
         seg_off[k + 1] = seg_off[k] + (uint32_t)gl.idx.size();
-        h_idx.insert(h_idx.end(), gl.idx.begin(), gl.idx.end());
-        h_c0.insert(h_c0.end(), gl.idx.size(), 2 * k); h_c1.insert(h_c1.end(), gl.idx.size(), 2 * k + 1);
         // consensus set: [2k] = cDNA, [2k+1] = DNA
         if (!disable_cdna) blob.append(items[k].cdna, items[k].cdna_len);
         coff.push_back(blob.size());
@@ -971,24 +981,29 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
     int rc = sp_seqset_make_small(ctx, "k2_cons", blob.data(), coff.data(), 2 * n_items, true, cons);
     if (rc != SP_OK) return rc;
     const uint32_t stride = K2_MAX_ED;
-    // the four index arrays travel as one block through pinned memory (one DMA instead of four pageable copies)
-    const size_t in_words = (size_t)3 * T + n_items + 1;
-    uint32_t* d_in = (uint32_t*)sp_pool(ctx, "k2_in", in_words * 4);
-    uint32_t* h_in = (uint32_t*)sp_host_pool(ctx, "k2_in_stage", in_words * 4);
+    // the pair lists (allele, cDNA consensus, DNA consensus per pair) are written on the device from the genes' allele lists, which already
+    // sit there: what travels is one offset and one pointer per item (a 32-sample cohort has 1.2 M pairs: 14 MB of indices otherwise)
+    const size_t head_bytes = (size_t)(n_items + 1) * 4 + 8 + (size_t)n_items * 8;
+    uint32_t* d_in = (uint32_t*)sp_pool(ctx, "k2_in", (size_t)3 * T * 4);
+    uint8_t* d_head = (uint8_t*)sp_pool(ctx, "k2_head", head_bytes);
+    uint8_t* h_head = (uint8_t*)sp_host_pool(ctx, "k2_head_stage", head_bytes);
     uint32_t* d_idx = d_in; uint32_t* d_c0 = d_in ? d_in + T : nullptr; uint32_t* d_c1 = d_in ? d_in + 2 * (size_t)T : nullptr;
-    uint32_t* d_seg = d_in ? d_in + 3 * (size_t)T : nullptr;
+    uint32_t* d_seg = (uint32_t*)d_head;
+    const size_t lists_at = (((size_t)(n_items + 1) * 4 + 7) / 8) * 8;
     int32_t* d_diag = (int32_t*)sp_pool(ctx, "k2_diag", (size_t)T * 4); int32_t* d_votes = (int32_t*)sp_pool(ctx, "k2_votes", (size_t)T * 4);
     int32_t* d_best = (int32_t*)sp_pool(ctx, "k2_best", (size_t)n_items * 4);
     CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k2_cells", (size_t)T * sizeof(CellDesc));
     sp_aln* d_alns = (sp_aln*)sp_pool(ctx, "k2_alns", (size_t)2 * T * sizeof(sp_aln));
     uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "k2_ev", (size_t)2 * T * stride * 4);
     K2Level* d_lv = (K2Level*)sp_pool(ctx, "k2_lv", (size_t)2 * T * sizeof(K2Level));
-    if (!d_in || !h_in || !d_diag || !d_votes || !d_best || !d_cells || !d_alns || !d_ev || !d_lv)
+    if (!d_in || !d_head || !h_head || !d_diag || !d_votes || !d_best || !d_cells || !d_alns || !d_ev || !d_lv)
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus buffers");
-    std::memcpy(h_in, h_idx.data(), (size_t)T * 4); std::memcpy(h_in + T, h_c0.data(), (size_t)T * 4);
-    std::memcpy(h_in + 2 * (size_t)T, h_c1.data(), (size_t)T * 4); std::memcpy(h_in + 3 * (size_t)T, seg_off.data(), (size_t)(n_items + 1) * 4);
-    (void)hipMemcpyAsync(d_in, h_in, in_words * 4, hipMemcpyHostToDevice, ctx->stream);      // (h_in is reused by the next call: the results' sync below covers it)
+    std::memcpy(h_head, seg_off.data(), (size_t)(n_items + 1) * 4);
+    for (uint32_t k = 0; k < n_items; ++k) { const uint32_t* lp = lists[k]->d_idx; std::memcpy(h_head + lists_at + (size_t)k * 8, &lp, 8); }
+    (void)hipMemcpyAsync(d_head, h_head, head_bytes, hipMemcpyHostToDevice, ctx->stream);    // (h_head is reused by the next call: the results' sync below covers it)
+    hipLaunchKernelGGL(k2_pairs_kernel, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, T, n_items, d_seg, (const uint32_t* const*)(d_head + lists_at), d_idx, d_c0, d_c1);
     const unsigned tb = 256, nb = (T + tb - 1) / tb;
+    hm.mark("host:k2_setup");
     for (int L = 0; L < 2 && rc == SP_OK; ++L) {
         const sp_seqset* aset = L == 0 ? db->cdna_gene : db->dna_gene;
         const uint32_t* d_c = L == 0 ? d_c0 : d_c1;
@@ -999,6 +1014,7 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
         if (rc != SP_OK) break;
         hipLaunchKernelGGL(k2_levels_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_alns + (size_t)L * T, T, d_lv + (size_t)L * T);
     }
+    hm.mark("host:k2_launch");
     if (rc == SP_OK) {
         ProfScope ps(ctx, "k2_scan", T);
         hipLaunchKernelGGL(k2_scan_kernel, dim3(n_items), dim3(1024), 0, ctx->stream, d_lv, d_alns, d_ev, stride, T, d_seg, d_best);
@@ -1021,6 +1037,7 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("score_consensus: ") + hipGetErrorString(e));
         else for (uint32_t k = 0; k < n_items; ++k) best[k].best_allele = b[k] >= 0 ? (int32_t)lists[k]->idx[b[k]] : -1;
     }
+    hm.mark("host:k2_wait");
     return rc;
 }
 
