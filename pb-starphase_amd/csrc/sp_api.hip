@@ -2,6 +2,7 @@
 // (HLA entry points live in sp_hla.hip.)  Declared in include/starphase_hip.h.
 #include "sp_internal.h"
 #include <algorithm>
+#include <thread>
 #include <cstring>
 #include <new>
 
@@ -290,13 +291,15 @@ static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::ve
     koff.assign((size_t)s->n + 1, 0); kcode.clear(); kpos.clear();
     // (code, position) pairs in position order, then a stable LSD radix sort on the code (3 passes of 11 bits): the table is sorted
     // by (code, position) like a comparison sort of the pairs would leave it, in a fraction of the time -- this runs on the host
-    // between two launches every time a consensus is typed
-    std::vector<uint32_t> c0, c1; std::vector<int32_t> p0, p1;
-    for (uint32_t i = 0; i < s->n; ++i) {
+    // between two launches every time a consensus is typed.  The sequences are independent: sets of many (the consensuses of a cohort)
+    // are spread over a few threads.
+    std::vector<std::vector<uint32_t>> codes(s->n); std::vector<std::vector<int32_t>> poss(s->n);
+    auto one = [&](uint32_t i) {
+        std::vector<uint32_t>& c0 = codes[i]; std::vector<int32_t>& p0 = poss[i];
+        std::vector<uint32_t> c1; std::vector<int32_t> p1;
         const uint32_t* w = s->h_words.data() + s->h_word_off[i];
         const uint32_t* np = s->has_n ? s->h_words.data() + plane_words + s->h_word_off[i] : nullptr;
         const int len = s->h_len[i];
-        c0.clear(); p0.clear();
         for (int j = 0; j + SP_KMER <= len; ++j) {
             const int wi = j >> 4; const int sh = (j & 15) << 1;
             auto fetch = [&](const uint32_t* p) -> uint32_t {
@@ -316,10 +319,20 @@ static void kmer_tables(const sp_seqset* s, std::vector<uint64_t>& koff, std::ve
             for (size_t x = 0; x < m; ++x) { const uint32_t at = count[(c0[x] >> shift) & mask]++; c1[at] = c0[x]; p1[at] = p0[x]; }
             c0.swap(c1); p0.swap(p1);
         }
-        koff[i] = kcode.size();
-        kcode.insert(kcode.end(), c0.begin(), c0.end()); kpos.insert(kpos.end(), p0.begin(), p0.end());
+    };
+    const uint32_t n_threads = s->n >= 32 ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+    if (n_threads > 1) {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < n_threads; ++t) pool.emplace_back([&, t]() { for (uint32_t i = t; i < s->n; i += n_threads) one(i); });
+        for (auto& th : pool) th.join();
+    } else for (uint32_t i = 0; i < s->n; ++i) one(i);
+    size_t total = 0;
+    for (uint32_t i = 0; i < s->n; ++i) { koff[i] = total; total += codes[i].size(); }
+    koff[s->n] = total;
+    kcode.resize(total); kpos.resize(total);
+    for (uint32_t i = 0; i < s->n; ++i) if (!codes[i].empty()) {
+        std::memcpy(kcode.data() + koff[i], codes[i].data(), codes[i].size() * 4); std::memcpy(kpos.data() + koff[i], poss[i].data(), poss[i].size() * 4);
     }
-    koff[s->n] = kcode.size();
 }
 
 // sorted 16-mer table of every sequence of the set (device code order: base t of the k-mer in bits 2t..2t+1)

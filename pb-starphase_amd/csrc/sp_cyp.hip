@@ -1265,7 +1265,7 @@ extern "C" int32_t sp_cyp_alleles_json(const sp_cyp_problem* pr, const sp_cyp_ca
     std::map<std::string, spj::Value> alleles;                        // BTreeMap<String, Vec<RegionVariant>> keyed by index_label()
     for (int32_t h = 0; h < call->n_consensus && h < SP_CYP_MAXCONS; ++h) {
         if (!rv->has_variants[h]) continue;
-        if (pr->n_variants && (!rv->state || !pr->var_label)) return SP_ERR_INVALID_ARG;
+        if (pr->n_variants && (!rv->state || !pr->var_label || !pr->var_is_vi)) return SP_ERR_INVALID_ARG;
         spj::Value list = spj::array();
         for (uint32_t v = 0; v < pr->n_variants; ++v) {
             const uint8_t st = rv->state[(size_t)h * pr->n_variants + v];

@@ -2,6 +2,7 @@
 // one-wavefront-per-cell WFA kernel, plus their launchers.
 #include "sp_internal.h"
 #include "sp_wfa.cuh"
+#include "sp_anchor.cuh"
 #include <algorithm>
 
 // =============================================================================================
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
 #else
 #define SP_AT(k)
 #endif
-        for (int i = tid; i < nb32; i += SP_ANCHOR_THREADS) lds[i] = 0;
+        sp_anchor_clear<SP_ANCHOR_THREADS>(lds, nb32);
         const uint32_t* bw = B.words + cur.woff;
         const uint32_t* bn = B.nplane ? B.nplane + cur.woff : nullptr;
         const uint64_t k0 = cur.k0, k1 = cur.k1;
@@ -123,16 +124,7 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
                 // a read that crosses the gene puts thousands of votes on one diagonal, and neighbouring lanes hold neighbouring k-mers of it:
                 // lanes whose single vote goes to the bin of the lane before them hand it to the first lane of their run, which adds the
                 // run's count once (64 atomics on one LDS address would be carried out one after the other)
-                const int bin1 = occ == 1 ? jj[u] - kp[l] + m : -1;
-                const int prev = __shfl_up(bin1, 1);
-                const int lane = tid & 63;
-                const bool follows = bin1 >= 0 && lane > 0 && prev == bin1;
-                const unsigned long long F = __ballot(follows);
-                if (bin1 >= 0 && !follows) {
-                    const unsigned long long rest = lane == 63 ? 0ull : (F >> (lane + 1));
-                    const uint32_t count = 1u + (uint32_t)__builtin_ctzll(~rest);
-                    atomicAdd(&lds[bin1 >> 1], (bin1 & 1) ? count << 16 : count);
-                }
+                sp_anchor_vote_run(lds, occ == 1 ? jj[u] - kp[l] + m : -1);
                 if (occ > 1)
                     for (int y = l; y < e; ++y) {
                         const int bin = jj[u] - kp[y] + m;
@@ -143,49 +135,7 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
         SP_AT(2);
         __syncthreads();
         SP_AT(3);
-        // top-K peaks: argmax votes (ties -> smallest diagonal), then clear every bin within +-SP_PEAK_SUPPRESS of it
-        for (int round = 0; round < topk; ++round) {
-            unsigned long long best = 0;
-            for (int bin = tid; bin < nbins; bin += SP_ANCHOR_THREADS) {
-                uint32_t v = (lds[bin >> 1] >> ((bin & 1) << 4)) & 0xFFFFu;
-                unsigned long long key = ((unsigned long long)v << 32) | (uint32_t)(0x7FFFFFFF - bin);
-                best = key > best ? key : best;
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                unsigned long long other = __shfl_xor(best, o);
-                best = other > best ? other : best;
-            }
-            if ((tid & 63) == 0) red[tid >> 6] = best;
-            __syncthreads();
-            best = red[0];
-            for (int w = 1; w < SP_ANCHOR_THREADS / 64; ++w) best = red[w] > best ? red[w] : best;
-            const int v = (int)(best >> 32);
-            const int bin = 0x7FFFFFFF - (int)(best & 0xFFFFFFFFu);
-            // a long indel splits the votes over two diagonals: centre the band between the outermost diagonals within
-            // +-SP_PEAK_SPREAD of the peak that still hold >= max(2, peak/8) votes
-            if (tid == 0) { spread[0] = bin; spread[1] = bin; }
-            __syncthreads();
-            if (v > 0 && tid <= 2 * SP_PEAK_SPREAD) {
-                const int b2 = bin - SP_PEAK_SPREAD + tid;
-                const int thr = v / 8 > 2 ? v / 8 : 2;
-                if (b2 >= 0 && b2 < nbins && (int)((lds[b2 >> 1] >> ((b2 & 1) << 4)) & 0xFFFFu) >= thr) { atomicMin(&spread[0], b2); atomicMax(&spread[1], b2); }
-            }
-            __syncthreads();
-            if (tid == 0) { diag_out[p * topk + round] = v > 0 ? ((spread[0] + spread[1]) >> 1) - m : 0; votes_out[p * topk + round] = v; }
-            __syncthreads();
-            if (v == 0) {                                   // nothing left: remaining slots are empty
-                if (tid == 0) for (int k2 = round + 1; k2 < topk; ++k2) { diag_out[p * topk + k2] = 0; votes_out[p * topk + k2] = 0; }
-                break;
-            }
-            if (round + 1 < topk) {
-                int lo = bin - SP_PEAK_SUPPRESS, hi = bin + SP_PEAK_SUPPRESS;
-                if (lo < 0) lo = 0;
-                if (hi > nbins - 1) hi = nbins - 1;
-                // bins are packed two per dword: clear them one lane per bin with a masked atomic AND
-                for (int b2 = lo + tid; b2 <= hi; b2 += SP_ANCHOR_THREADS) atomicAnd(&lds[b2 >> 1], (b2 & 1) ? 0x0000FFFFu : 0xFFFF0000u);
-                __syncthreads();
-            }
-        }
+        sp_anchor_peaks<SP_ANCHOR_THREADS>(lds, nbins, m, topk, p, diag_out, votes_out, red, spread);
         __syncthreads();
 #ifdef SP_ANCHOR_TIMING
         SP_AT(4);

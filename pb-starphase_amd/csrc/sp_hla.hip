@@ -6,6 +6,7 @@
 // alignments come from the one-wavefront-per-cell WFA kernel (sp_wfa.cuh).
 #include "sp_internal.h"
 #include "sp_wfa.cuh"
+#include "sp_anchor.cuh"
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -53,6 +54,7 @@ struct sp_hla_db {
     int32_t*  d_am = nullptr;         // n_alleles*3: ok, am.query_start, am.target_start (allele -> gene ref, realigner.rs:289-310)
     int32_t*  d_hpc_ref = nullptr;    // hpc_pos(ref_fwd[g], p) for p in 0..len, concatenated
     uint64_t* d_hpc_ref_off = nullptr;
+    mutable K2Dict kdict[2];          // 16-mer dictionaries of cdna_gene / dna_gene, built at the first K2 call (sp_hla_dict.hip)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -639,6 +641,86 @@ template <typename T> static T* dev_copy(const std::vector<T>& v) {
     return d;
 }
 
+// ---------------------------------------------------------------------------------------------
+// K2 anchors through the allele set's 16-mer dictionary (sp_hla_dict.hip): the votes of a (consensus, allele) pair are the votes
+// sp_anchor_kernel collects -- every 16-mer of the allele votes for allele position - consensus position for each of its <= SP_MAXOCC
+// occurrences in the consensus -- but the occurrences of a 16-mer in a consensus are looked up once per distinct 16-mer of the gene
+// (k2_hits_kernel) instead of once per allele that carries it.
+// hits[item][id] = first entry of the 16-mer in the consensus' sorted table | occurrences << 24; 0 = none, or more than SP_MAXOCC
+__global__ __launch_bounds__(256) void k2_hits_kernel(KmerIndexView KA, const uint32_t* __restrict__ dict, const uint32_t* __restrict__ dict_off,
+                                                      const uint32_t* __restrict__ item_gene, int level, uint32_t max_dict, uint32_t* __restrict__ hits) {
+    const uint32_t k = blockIdx.y, g = item_gene[k], e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= dict_off[g + 1] - dict_off[g]) return;
+    const uint32_t code = dict[dict_off[g] + e];
+    const uint64_t k0 = KA.off[2 * k + level], k1 = KA.off[2 * k + level + 1];
+    uint64_t lo = k0, hi = k1;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (KA.code[mid] < code) lo = mid + 1; else hi = mid; }
+    uint32_t cnt = 0;
+    while (lo + cnt < k1 && cnt <= SP_MAXOCC && KA.code[lo + cnt] == code) ++cnt;
+    hits[(size_t)k * max_dict + e] = (cnt == 0 || cnt > SP_MAXOCC) ? 0u : ((uint32_t)(lo - k0) | cnt << 24);
+}
+
+#ifndef K2_DICT_THREADS
+#define K2_DICT_THREADS 256
+#endif
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k2_anchor_dict_kernel(SeqSetView A, KmerIndexView KA, SeqSetView B, const uint32_t* __restrict__ c_idx, const uint32_t* __restrict__ a_idx,
+                                                             uint64_t n_pairs, const uint32_t* __restrict__ ids, const uint64_t* __restrict__ id_off,
+                                                             const uint32_t* __restrict__ hits, uint32_t max_dict, int32_t* __restrict__ diag_out, int32_t* __restrict__ votes_out,
+                                                             int bins_cap, int tab_cap) {
+    extern __shared__ uint32_t lds[];                 // [packed u16 vote bins][positions of the consensus' sorted 16-mer table]
+    __shared__ unsigned long long red[THREADS / 64];
+    __shared__ int spread[2];
+    constexpr int AHEAD = 4096 / THREADS;          // rounds of a thread that cover an allele of 4 kb
+    const int tid = threadIdx.x;
+    int32_t* tab_pos = reinterpret_cast<int32_t*>(lds + ((bins_cap + 1) >> 1));
+    int tab_c = -1;
+    for (uint64_t p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+        const uint32_t c = c_idx[p], a = a_idx[p];
+        const int m = A.len[c], n = B.len[a];
+        const int nbins = m + n + 1;
+        if (m < SP_KMER || n < SP_KMER || nbins > bins_cap) {
+            if (tid == 0) { diag_out[p] = 0; votes_out[p] = 0; }
+            continue;
+        }
+        const int nb32 = (nbins + 1) >> 1;
+        // the ids of the allele and their hits are two dependent loads from memory: the first AHEAD rounds of a thread are issued
+        // together and ahead of the histogram's clearing (an allele of 4 kb is AHEAD rounds of THREADS positions)
+        const uint32_t* my_ids = ids + id_off[a];
+        const uint32_t* my_hits = hits + (size_t)(c >> 1) * max_dict;
+        uint32_t hv[AHEAD];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) { const int j = tid + u * THREADS; hv[u] = j + SP_KMER <= n ? my_ids[j] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) hv[u] = hv[u] != 0xFFFFFFFFu ? my_hits[hv[u]] : 0u;
+        sp_anchor_clear<THREADS>(lds, nb32);
+        if ((int)c != tab_c) {
+            const uint64_t k0 = KA.off[c]; const int nk = (int)(KA.off[c + 1] - k0);
+            for (int i = tid; i < nk && i < tab_cap; i += THREADS) tab_pos[i] = KA.pos[k0 + i];
+            tab_c = (int)c;
+        }
+        __syncthreads();
+        auto vote = [&](int j, uint32_t h) {
+            const int cnt = (int)(h >> 24), first = (int)(h & 0xFFFFFFu);
+            sp_anchor_vote_run(lds, cnt == 1 ? j - tab_pos[first] + m : -1);
+            if (cnt > 1)
+                for (int y = 0; y < cnt; ++y) {
+                    const int bin = j - tab_pos[first + y] + m;
+                    atomicAdd(&lds[bin >> 1], (bin & 1) ? 0x10000u : 1u);
+                }
+        };
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) if (u * THREADS + SP_KMER <= n) vote(tid + u * THREADS, hv[u]);       // (uniform condition: every lane of a round votes, with or without a bin)
+        for (int j = tid + AHEAD * THREADS; j + SP_KMER <= n; j += THREADS) {
+            const uint32_t id = my_ids[j];
+            vote(j, id != 0xFFFFFFFFu ? my_hits[id] : 0u);
+        }
+        __syncthreads();
+        sp_anchor_peaks<THREADS>(lds, nbins, m, 1, p, diag_out, votes_out, red, spread);
+        __syncthreads();
+    }
+}
+
 extern "C" {
 
 void sp_hla_db_free(sp_hla_db* db) {
@@ -648,6 +730,7 @@ void sp_hla_db_free(sp_hla_db* db) {
     (void)hipFree(db->d_gene_of); (void)hipFree(db->d_off_fwd); (void)hipFree(db->d_am); (void)hipFree(db->d_order); (void)hipFree(db->d_lcp); (void)hipFree(db->d_pos);
     (void)hipFree(db->d_hpc_ref); (void)hipFree(db->d_hpc_ref_off);
     for (auto& kv : db->gene_lists) { (void)hipFree(kv.second.d_idx); (void)hipFree(kv.second.d_l0); (void)hipFree(kv.second.d_l1); }
+    sp_k2_dict_free(&db->kdict[0]); sp_k2_dict_free(&db->kdict[1]);
     delete db;
 }
 
@@ -983,13 +1066,13 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
     const uint32_t stride = K2_MAX_ED;
     // the pair lists (allele, cDNA consensus, DNA consensus per pair) are written on the device from the genes' allele lists, which already
     // sit there: what travels is one offset and one pointer per item (a 32-sample cohort has 1.2 M pairs: 14 MB of indices otherwise)
-    const size_t head_bytes = (size_t)(n_items + 1) * 4 + 8 + (size_t)n_items * 8;
+    const size_t head_bytes = (size_t)(n_items + 1) * 4 + 8 + (size_t)n_items * 8 + (size_t)n_items * 4;
     uint32_t* d_in = (uint32_t*)sp_pool(ctx, "k2_in", (size_t)3 * T * 4);
     uint8_t* d_head = (uint8_t*)sp_pool(ctx, "k2_head", head_bytes);
     uint8_t* h_head = (uint8_t*)sp_host_pool(ctx, "k2_head_stage", head_bytes);
     uint32_t* d_idx = d_in; uint32_t* d_c0 = d_in ? d_in + T : nullptr; uint32_t* d_c1 = d_in ? d_in + 2 * (size_t)T : nullptr;
     uint32_t* d_seg = (uint32_t*)d_head;
-    const size_t lists_at = (((size_t)(n_items + 1) * 4 + 7) / 8) * 8;
+    const size_t lists_at = (((size_t)(n_items + 1) * 4 + 7) / 8) * 8, genes_at = lists_at + (size_t)n_items * 8;
     int32_t* d_diag = (int32_t*)sp_pool(ctx, "k2_diag", (size_t)T * 4); int32_t* d_votes = (int32_t*)sp_pool(ctx, "k2_votes", (size_t)T * 4);
     int32_t* d_best = (int32_t*)sp_pool(ctx, "k2_best", (size_t)n_items * 4);
     CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k2_cells", (size_t)T * sizeof(CellDesc));
@@ -999,7 +1082,7 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
     if (!d_in || !d_head || !h_head || !d_diag || !d_votes || !d_best || !d_cells || !d_alns || !d_ev || !d_lv)
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus buffers");
     std::memcpy(h_head, seg_off.data(), (size_t)(n_items + 1) * 4);
-    for (uint32_t k = 0; k < n_items; ++k) { const uint32_t* lp = lists[k]->d_idx; std::memcpy(h_head + lists_at + (size_t)k * 8, &lp, 8); }
+    for (uint32_t k = 0; k < n_items; ++k) { const uint32_t* lp = lists[k]->d_idx; std::memcpy(h_head + lists_at + (size_t)k * 8, &lp, 8); std::memcpy(h_head + genes_at + (size_t)k * 4, &items[k].gene, 4); }
     (void)hipMemcpyAsync(d_head, h_head, head_bytes, hipMemcpyHostToDevice, ctx->stream);    // (h_head is reused by the next call: the results' sync below covers it)
     hipLaunchKernelGGL(k2_pairs_kernel, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, T, n_items, d_seg, (const uint32_t* const*)(d_head + lists_at), d_idx, d_c0, d_c1);
     const unsigned tb = 256, nb = (T + tb - 1) / tb;
@@ -1007,7 +1090,22 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
     for (int L = 0; L < 2 && rc == SP_OK; ++L) {
         const sp_seqset* aset = L == 0 ? db->cdna_gene : db->dna_gene;
         const uint32_t* d_c = L == 0 ? d_c0 : d_c1;
-        rc = sp_launch_anchor(ctx, cons, aset, d_c, d_idx, T, d_diag, d_votes, 1, "anchor_k2");
+        // anchors: through the allele set's 16-mer dictionary (built at the first call; the generic anchor kernel when it could not be built)
+        K2Dict& kd = db->kdict[L];
+        if (!kd.built && !kd.failed) { rc = sp_k2_dict_build(ctx, aset, db->d_gene_of, db->n_genes, &kd); if (rc != SP_OK) { rc = SP_OK; ctx->err.clear(); } }
+        const int bins_cap = cons->max_len + aset->max_len + 1;
+        const size_t anchor_lds = (size_t)((bins_cap + 1) / 2) * 4 + (size_t)cons->max_len * 4;
+        uint32_t* d_hits = kd.built && anchor_lds <= 160 * 1024 - 256 ? (uint32_t*)sp_pool(ctx, "k2_hits", std::max<size_t>(1, (size_t)n_items * kd.max_dict) * 4) : nullptr;
+        if (d_hits && kd.max_dict) {
+            ProfScope ps(ctx, "anchor_k2", T);
+            hipLaunchKernelGGL(k2_hits_kernel, dim3((kd.max_dict + 255) / 256, n_items), dim3(256), 0, ctx->stream, cons->kview(), kd.d_code, kd.d_dict_off,
+                               (const uint32_t*)(d_head + genes_at), L, kd.max_dict, d_hits);
+            SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k2_anchor_dict_kernel<K2_DICT_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)anchor_lds));
+            const uint64_t grid = std::min<uint64_t>(T, (uint64_t)ctx->num_cus * 16);
+            hipLaunchKernelGGL(k2_anchor_dict_kernel<K2_DICT_THREADS>, dim3((unsigned)grid), dim3(K2_DICT_THREADS), anchor_lds, ctx->stream, cons->view(), cons->kview(), aset->view(), d_c, d_idx, (uint64_t)T,
+                               kd.d_ids, kd.d_id_off, d_hits, kd.max_dict, d_diag, d_votes, bins_cap, cons->max_len);
+            SP_HIP_CHECK(ctx, hipGetLastError());
+        } else rc = sp_launch_anchor(ctx, cons, aset, d_c, d_idx, T, d_diag, d_votes, 1, "anchor_k2");
         if (rc != SP_OK) break;
         hipLaunchKernelGGL(k2_build_cells_kernel, dim3(nb), dim3(tb), 0, ctx->stream, d_idx, T, d_c, d_diag, d_votes, aset->d_len, d_cells);
         rc = sp_launch_cells(ctx, aset, cons, d_cells, T, d_alns + (size_t)L * T, d_ev + (size_t)L * T * stride, stride, L == 0 ? "k2_cells_cdna" : "k2_cells_dna", 1);

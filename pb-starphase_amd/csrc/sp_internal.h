@@ -86,6 +86,19 @@ struct CellDesc {
     int32_t  b_lo, b_hi;    // sub-range of B that is the "real" sequence for this cell (segment views); b_hi<0 => whole
 };
 
+// ---------------------------------------------------------------- 16-mer dictionary of an allele set (sp_hla_dict.hip)
+struct K2Dict {
+    bool built = false, failed = false;
+    uint32_t* d_ids = nullptr;              // every allele, position by position: number of its 16-mer in its gene's part of the dictionary (0xFFFFFFFF: holds an N)
+    uint64_t* d_id_off = nullptr;           // n_alleles + 1: first id slot of each allele
+    uint32_t* d_code = nullptr;             // the dictionary: the distinct 16-mers of each gene in the order of their first appearance
+    uint32_t* d_dict_off = nullptr;         // n_genes + 1: each gene's part of the dictionary
+    std::vector<uint32_t> dict_off;
+    uint32_t n_dict = 0, max_dict = 0;
+};
+int  sp_k2_dict_build(sp_ctx* ctx, const sp_seqset* set, const uint32_t* d_gene_of, uint32_t n_genes, K2Dict* out);
+void sp_k2_dict_free(K2Dict* d);
+
 // ---------------------------------------------------------------- launchers (sp_device.hip)
 int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,
