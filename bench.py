@@ -233,6 +233,7 @@ def inflight_leg(pkg, fx, n_streams=3, steps=10, n_reads=10000, device=0):
     for t in range(n_streams):
         wl = synth.Config2Workload(fx, n_reads=n_reads, seed=2000 + t)
         c = pkg.Context(device)
+        c.set_option("hla_split_genes", 0)          # the other samples' streams fill the gaps: one stream per sample
         d = fx.make_db(pkg, c)
         workers.append((c, d, c.upload(wl.reads), wl))
     genes = list(range(len(fx.genes)))
@@ -393,7 +394,8 @@ def main():
     cons_cols = ctx.profile_get("cons_columns")[2]
     cons_exp = ctx.profile_get("cons_expansions")[2]
     host_ms = {k: ctx.profile_get("host:" + k)[0] / max(1, args.steps) for k in ("hla_select", "hla_segments", "hla_setup", "hla_dual_hpc", "hla_dual_dna", "hla_groups", "hla_typing",
-                                                                                  "k8_prologue", "k8_loop", "k8_result_wait", "k8_epilogue", "k1_total", "k1_result")}
+                                                                                  "k8_prologue", "k8_loop", "k8_result_wait", "k8_epilogue", "k1_total", "k1_result",
+                                                                                  "hla_genes_total", "hla_split_spawn", "hla_split_own", "hla_split_join")}
     cons_ticks = {k: ctx.profile_get("cons_ticks_" + k)[2] / 100.0 / max(1, args.steps) for k in ("reduce", "result", "search", "tail")}   # 100 MHz -> us
     avg_ms = ms_cells / max(1, launches)
     per_launch = lambda v: v / max(1, launches)

@@ -58,6 +58,11 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out);
 void    sp_ctx_destroy(sp_ctx* ctx);
 const char* sp_last_error(const sp_ctx* ctx);
 int32_t sp_ctx_synchronize(sp_ctx* ctx);
+/* Tuning switches of a context.  "hla_split_genes" (default 1): sp_hla_diplotype_genes solves the genes of a sample with >= 1,000
+ * realigned reads on two streams side by side (a helper stream the context owns) -- lowest latency for one sample; set it to 0 when
+ * several samples are in flight on contexts of their own, where the streams of the other samples already fill the gaps.  The calls
+ * are the same either way.  Unknown names: SP_ERR_INVALID_ARG. */
+int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value);
 
 /* ------------------------------------------------------------------ sequences
  * Replaces the targets handed to minimap2 via Aligner::with_seq / with_index

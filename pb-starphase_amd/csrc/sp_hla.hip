@@ -5,6 +5,7 @@
 // Decisions use f64 exactly as the reference does (MappingScore::score_value, src/data_types/mapping.rs:191-195);
 // alignments come from the one-wavefront-per-cell WFA kernel (sp_wfa.cuh).
 #include "sp_internal.h"
+#include <mutex>
 #include "sp_wfa.cuh"
 #include "sp_anchor.cuh"
 #include <algorithm>
@@ -55,6 +56,7 @@ struct sp_hla_db {
     int32_t*  d_hpc_ref = nullptr;    // hpc_pos(ref_fwd[g], p) for p in 0..len, concatenated
     uint64_t* d_hpc_ref_off = nullptr;
     mutable K2Dict kdict[2];          // 16-mer dictionaries of cdna_gene / dna_gene, built at the first K2 call (sp_hla_dict.hip)
+    mutable std::mutex lazy;          // guards gene_lists and kdict: two contexts may type consensuses on one database at the same time
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1046,6 +1048,7 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
     std::string blob; std::vector<uint64_t> coff(1, 0);
     for (uint32_t k = 0; k < n_items; ++k) {
         if (items[k].gene >= db->n_genes) return sp_fail(ctx, SP_ERR_INVALID_ARG, "score_consensus: gene out of range");
+        std::lock_guard<std::mutex> guard(db->lazy);
         sp_hla_db::GeneList& gl = db->gene_lists[items[k].gene * 2 + (require_dna ? 1u : 0u)];
         if (gl.idx.empty() && !gl.d_idx) { for (uint32_t a : db->gene_alleles[items[k].gene]) if (db->has_dna[a] || !require_dna) gl.idx.push_back(a); gl.d_idx = dev_copy(gl.idx); }
         lists[k] = &gl;
@@ -1092,7 +1095,10 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
         const uint32_t* d_c = L == 0 ? d_c0 : d_c1;
         // anchors: through the allele set's 16-mer dictionary (built at the first call; the generic anchor kernel when it could not be built)
         K2Dict& kd = db->kdict[L];
-        if (!kd.built && !kd.failed) { rc = sp_k2_dict_build(ctx, aset, db->d_gene_of, db->n_genes, &kd); if (rc != SP_OK) { rc = SP_OK; ctx->err.clear(); } }
+        {
+            std::lock_guard<std::mutex> guard(db->lazy);
+            if (!kd.built && !kd.failed) { rc = sp_k2_dict_build(ctx, aset, db->d_gene_of, db->n_genes, &kd); if (rc != SP_OK) { rc = SP_OK; ctx->err.clear(); } }
+        }
         const int bins_cap = cons->max_len + aset->max_len + 1;
         const size_t anchor_lds = (size_t)((bins_cap + 1) / 2) * 4 + (size_t)cons->max_len * 4;
         uint32_t* d_hits = kd.built && anchor_lds <= 160 * 1024 - 256 ? (uint32_t*)sp_pool(ctx, "k2_hits", std::max<size_t>(1, (size_t)n_items * kd.max_dict) * 4) : nullptr;

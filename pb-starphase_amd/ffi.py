@@ -226,6 +226,7 @@ def lib():
         "sp_ctx_destroy": (None, [vp]),
         "sp_last_error": (C.c_char_p, [vp]),
         "sp_ctx_synchronize": (i32, [vp]),
+        "sp_ctx_set_option": (i32, [vp, C.c_char_p, C.c_int64]),
         "sp_seqset_upload": (i32, [vp, C.c_char_p, vp, u32, C.POINTER(vp)]),
         "sp_seqset_free": (None, [vp]),
         "sp_seqset_count": (i32, [vp, C.POINTER(u32)]),
@@ -325,6 +326,9 @@ class Context:
 
     def synchronize(self):
         self.check(lib().sp_ctx_synchronize(self._h))
+
+    def set_option(self, name, value):
+        self.check(lib().sp_ctx_set_option(self._h, name.encode(), int(value)))
 
     def upload(self, seqs):
         return SeqSet(self, seqs)

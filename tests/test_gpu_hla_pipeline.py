@@ -208,3 +208,30 @@ def test_hla_debug_file(oracle, pkg, gpu_ctx, tmp_path):
             (stats,) = entry["mapping_stats"].values()
             assert stats["cdna_mapping"] is None and list(stats["dna_mapping"]) == ["query_len", "target_len", "match_len", "nm", "query_unmapped",
                                                                                   "target_unmapped", "cigar", "md"]
+
+
+def test_genes_side_by_side_equal_one_stream(pkg, gpu_ctx):
+    """sp_hla_diplotype_genes on a sample of >= 1,000 realigned reads solves the genes on two streams (sp_ctx_set_option "hla_split_genes");
+    calls, consensuses and read groups are those of the one-stream run"""
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture(max_alleles_per_gene=150, seed=4)
+    db = fx.make_db(pkg, gpu_ctx)
+    wl = synth.Config2Workload(fx, n_reads=1400, seed=9)
+    R = gpu_ctx.upload(wl.reads)
+    k1 = db.realign_reads(R)
+    assert int((k1["status"] == 0).sum()) >= 1000
+    genes = list(range(len(fx.genes)))
+    runs = []
+    for split in (1, 0, 1):
+        gpu_ctx.set_option("hla_split_genes", split)
+        calls, is1 = db.diplotype_genes(genes, R, k1)
+        runs.append(([(c.status, c.allele1, c.allele2, c.typed1, c.typed2, c.n_reads, c.counts1, c.counts2, c.is_dual, c.dual_passed, c.used_dna_dual, c.maf, c.cdf, c1, c2)
+                      for c, c1, c2 in calls], is1.tolist()))
+    gpu_ctx.set_option("hla_split_genes", 1)
+    assert runs[0] == runs[1] == runs[2]
+    assert all(r[0] == 0 for r in runs[0][0])
+    truth = {g: sorted(a for gg, a in wl.truth if gg == g) for g in genes}
+    for g in genes:
+        assert sorted(runs[0][0][g][1:3]) == truth[g]
+    with pytest.raises(pkg.StarphaseError):
+        gpu_ctx.set_option("no_such_switch", 1)
