@@ -8,6 +8,7 @@
 // homopolymer-compressed by the two kernels below.
 #include "sp_internal.h"
 #include <thread>
+#include <system_error>
 #include <algorithm>
 #include <cstring>
 
@@ -354,11 +355,13 @@ int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
         q.rc = hla_solve_units(c, db, (uint32_t)q.at.size(), q.genes.data(), nullptr, nullptr, reads, realign, q.cfgs.data(), q.calls.data(), q.cons.data(), cap, is_cons1_out, false);
     };
     HostMarks hm(ctx);
-    std::thread beside([&]() { solve(helper, part[1]); });
+    std::thread beside;
+    try { beside = std::thread([&]() { solve(helper, part[1]); }); }
+    catch (const std::system_error&) { }                                   // no thread to be had: this one does both parts
     hm.mark("host:hla_split_spawn");
     solve(ctx, part[0]);
     hm.mark("host:hla_split_own");
-    beside.join();
+    if (beside.joinable()) beside.join(); else solve(ctx, part[1]);
     hm.mark("host:hla_split_join");                                   // (the helper's timings are added to this context's when somebody asks for them: sp_profile_get)
     for (Part& q : part)
         for (size_t x = 0; x < q.at.size(); ++x) {
