@@ -330,29 +330,26 @@ static int32_t hla_solve_units(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
 #define SP_HLA_SPLIT_MIN_READS 1000     // realigned reads of a sample from which its genes are solved side by side on two streams
 #endif
 
-extern "C" {
-
-int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_genes, const uint32_t* genes, const sp_seqset* reads,
-                               const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
-                               char* cons, uint32_t cap, uint8_t* is_cons1_out) {
-    if (!ctx) return SP_ERR_INVALID_ARG;
-    if (!db || !reads || !realign || !cfgs || !calls || !cons || !genes || cap == 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_genes: null argument");
-    // The genes of a sample are independent of each other from here on, and each is a chain of launches that wait for one another
-    // (consensus windows, typing levels) without filling the device: with enough reads to make it worth a thread, every other gene runs
-    // on the context's helper (its own stream, pools and events) beside the rest.  The calls are the calls of the single run: nothing
-    // of one gene's solve reads anything of another's.
+// The units (genes of a sample, or (sample, gene) pairs of a cohort) are independent of each other, and each is a chain of launches that
+// wait for one another (consensus windows, typing levels) without filling the device: with enough reads to make it worth a thread, every
+// other unit runs on the context's helper (its own stream, pools and events) beside the rest.  The calls are the calls of the single run:
+// nothing of one unit's solve reads anything of another's.
+static int32_t hla_solve_side_by_side(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_units, const uint32_t* genes, const uint32_t* unit_sample,
+                                      const uint32_t* read_sample, const sp_seqset* reads, const sp_hla_realign* realign, const sp_hla_call_config* cfgs,
+                                      sp_hla_call* calls, char* cons, uint32_t cap, uint8_t* is_cons1_out) {
     HostScope whole(ctx, "host:hla_genes_total");
     uint64_t n_realigned = 0;
     for (uint32_t r = 0; r < reads->n; ++r) n_realigned += realign[r].status == 0;
-    sp_ctx* helper = (ctx->split_genes && n_genes >= 2 && n_realigned >= SP_HLA_SPLIT_MIN_READS) ? sp_ctx_helper(ctx) : nullptr;
-    if (!helper) return hla_solve_units(ctx, db, n_genes, genes, nullptr, nullptr, reads, realign, cfgs, calls, cons, cap, is_cons1_out);
+    sp_ctx* helper = (ctx->split_genes && n_units >= 2 && n_realigned >= SP_HLA_SPLIT_MIN_READS) ? sp_ctx_helper(ctx) : nullptr;
+    if (!helper) return hla_solve_units(ctx, db, n_units, genes, unit_sample, read_sample, reads, realign, cfgs, calls, cons, cap, is_cons1_out);
     if (is_cons1_out) std::memset(is_cons1_out, 0, reads->n);
-    struct Part { std::vector<uint32_t> at, genes; std::vector<sp_hla_call_config> cfgs; std::vector<sp_hla_call> calls; std::vector<char> cons; int32_t rc = SP_OK; };
+    struct Part { std::vector<uint32_t> at, genes, samples; std::vector<sp_hla_call_config> cfgs; std::vector<sp_hla_call> calls; std::vector<char> cons; int32_t rc = SP_OK; };
     Part part[2];
-    for (uint32_t k = 0; k < n_genes; ++k) { Part& q = part[k & 1]; q.at.push_back(k); q.genes.push_back(genes[k]); q.cfgs.push_back(cfgs[k]); }
+    for (uint32_t k = 0; k < n_units; ++k) { Part& q = part[k & 1]; q.at.push_back(k); q.genes.push_back(genes[k]); if (unit_sample) q.samples.push_back(unit_sample[k]); q.cfgs.push_back(cfgs[k]); }
     for (Part& q : part) { q.calls.resize(q.at.size()); q.cons.assign((size_t)2 * q.at.size() * cap, '\0'); }
     auto solve = [&](sp_ctx* c, Part& q) {
-        q.rc = hla_solve_units(c, db, (uint32_t)q.at.size(), q.genes.data(), nullptr, nullptr, reads, realign, q.cfgs.data(), q.calls.data(), q.cons.data(), cap, is_cons1_out, false);
+        q.rc = hla_solve_units(c, db, (uint32_t)q.at.size(), q.genes.data(), unit_sample ? q.samples.data() : nullptr, read_sample, reads, realign, q.cfgs.data(), q.calls.data(),
+                               q.cons.data(), cap, is_cons1_out, false);
     };
     HostMarks hm(ctx);
     std::thread beside;
@@ -361,15 +358,25 @@ int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_gene
     hm.mark("host:hla_split_spawn");
     solve(ctx, part[0]);
     hm.mark("host:hla_split_own");
-    if (beside.joinable()) beside.join(); else solve(ctx, part[1]);
-    hm.mark("host:hla_split_join");                                   // (the helper's timings are added to this context's when somebody asks for them: sp_profile_get)
+    if (beside.joinable()) beside.join(); else solve(ctx, part[1]);      // (the helper's timings are added to this context's when somebody asks for them: sp_profile_get)
+    hm.mark("host:hla_split_join");
     for (Part& q : part)
         for (size_t x = 0; x < q.at.size(); ++x) {
             calls[q.at[x]] = q.calls[x];
             std::memcpy(cons + (size_t)(2 * q.at[x]) * cap, q.cons.data() + (size_t)(2 * x) * cap, (size_t)2 * cap);
         }
-    if (part[1].rc != SP_OK && part[0].rc == SP_OK) { ctx->err = helper->err; return part[1].rc; }
+    if (part[1].rc != SP_OK && part[0].rc == SP_OK) { if (ctx->err.empty()) ctx->err = helper->err; return part[1].rc; }
     return part[0].rc;
+}
+
+extern "C" {
+
+int32_t sp_hla_diplotype_genes(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_genes, const uint32_t* genes, const sp_seqset* reads,
+                               const sp_hla_realign* realign, const sp_hla_call_config* cfgs, sp_hla_call* calls,
+                               char* cons, uint32_t cap, uint8_t* is_cons1_out) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!db || !reads || !realign || !cfgs || !calls || !cons || !genes || cap == 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_hla_diplotype_genes: null argument");
+    return hla_solve_side_by_side(ctx, db, n_genes, genes, nullptr, nullptr, reads, realign, cfgs, calls, cons, cap, is_cons1_out);
 }
 
 int32_t sp_hla_diplotype_cohort(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_samples, const uint32_t* read_sample, uint32_t n_genes, const uint32_t* genes,
@@ -381,7 +388,7 @@ int32_t sp_hla_diplotype_cohort(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_sam
     const uint32_t units = n_samples * n_genes;
     std::vector<uint32_t> ug(units), us(units); std::vector<sp_hla_call_config> uc(units);
     for (uint32_t s = 0; s < n_samples; ++s) for (uint32_t g = 0; g < n_genes; ++g) { ug[s * n_genes + g] = genes[g]; us[s * n_genes + g] = s; uc[s * n_genes + g] = cfgs[g]; }
-    return hla_solve_units(ctx, db, units, ug.data(), us.data(), read_sample, reads, realign, uc.data(), calls, cons, cap, is_cons1_out);
+    return hla_solve_side_by_side(ctx, db, units, ug.data(), us.data(), read_sample, reads, realign, uc.data(), calls, cons, cap, is_cons1_out);
 }
 
 int32_t sp_hla_diplotype_gene(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene, const sp_seqset* reads, const sp_hla_realign* realign,

@@ -233,5 +233,16 @@ def test_genes_side_by_side_equal_one_stream(pkg, gpu_ctx):
     truth = {g: sorted(a for gg, a in wl.truth if gg == g) for g in genes}
     for g in genes:
         assert sorted(runs[0][0][g][1:3]) == truth[g]
+    # the same reads as a cohort of two samples (every other read): (sample, gene) units side by side == on one stream
+    sample_of = np.arange(len(wl.reads)) % 2
+    cohort_runs = []
+    for split in (1, 0):
+        gpu_ctx.set_option("hla_split_genes", split)
+        cohort, is1 = db.diplotype_cohort(2, sample_of, genes, R, k1)
+        cohort_runs.append(([[(c.status, c.allele1, c.allele2, c.typed1, c.typed2, c.n_reads, c.counts1, c.counts2, c.is_dual, c.dual_passed, c1, c2) for c, c1, c2 in row]
+                             for row in cohort], is1.tolist()))
+    gpu_ctx.set_option("hla_split_genes", 1)
+    assert cohort_runs[0] == cohort_runs[1]
+    assert all(u[0] == 0 and sorted(u[1:3]) == truth[g] for row in cohort_runs[0][0] for g, u in enumerate(row))
     with pytest.raises(pkg.StarphaseError):
         gpu_ctx.set_option("no_such_switch", 1)
