@@ -58,10 +58,11 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out);
 void    sp_ctx_destroy(sp_ctx* ctx);
 const char* sp_last_error(const sp_ctx* ctx);
 int32_t sp_ctx_synchronize(sp_ctx* ctx);
-/* Tuning switches of a context.  "hla_split_genes" (default 1): sp_hla_diplotype_genes solves the genes of a sample with >= 1,000
- * realigned reads on two streams side by side (a helper stream the context owns) -- lowest latency for one sample; set it to 0 when
- * several samples are in flight on contexts of their own, where the streams of the other samples already fill the gaps.  The calls
- * are the same either way.  Unknown names: SP_ERR_INVALID_ARG. */
+/* Tuning switches of a context.  "hla_split_genes" (default 1): sp_hla_diplotype_genes / sp_hla_diplotype_cohort solve the units of a
+ * call (the genes of a sample, the (sample, gene) pairs of a cohort) with >= 1,000 realigned reads side by side on up to
+ * "hla_split_streams" (1..4, default 3) streams -- helper streams the context owns, one host thread each for the length of the call:
+ * lowest latency for one call; set hla_split_genes to 0 when several samples are in flight on contexts of their own, where the streams
+ * of the other samples already fill the gaps.  The calls are the same either way.  Unknown names: SP_ERR_INVALID_ARG. */
 int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value);
 
 /* ------------------------------------------------------------------ sequences

@@ -43,7 +43,7 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
 
 void sp_ctx_destroy(sp_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->helper) { sp_ctx_destroy(ctx->helper); ctx->helper = nullptr; }
+    for (sp_ctx*& h : ctx->helper) if (h) { sp_ctx_destroy(h); h = nullptr; }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
@@ -58,10 +58,11 @@ void sp_ctx_destroy(sp_ctx* ctx) {
 }
 
 } // extern "C"
-sp_ctx* sp_ctx_helper(sp_ctx* ctx) {
-    if (!ctx->helper && sp_ctx_create(ctx->device, nullptr, &ctx->helper) != SP_OK) ctx->helper = nullptr;
-    if (ctx->helper) ctx->helper->profiling = ctx->profiling;
-    return ctx->helper;
+sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i) {
+    if (i < 0 || i > 2) return nullptr;
+    if (!ctx->helper[i] && sp_ctx_create(ctx->device, nullptr, &ctx->helper[i]) != SP_OK) ctx->helper[i] = nullptr;
+    if (ctx->helper[i]) ctx->helper[i]->profiling = ctx->profiling;
+    return ctx->helper[i];
 }
 void sp_profile_merge(sp_ctx* into, sp_ctx* from) {
     sp_profile_flush(from);
@@ -81,12 +82,13 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx) {
 int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SP_ERR_INVALID_ARG;
     if (std::strcmp(name, "hla_split_genes") == 0) { ctx->split_genes = value != 0; return SP_OK; }
+    if (std::strcmp(name, "hla_split_streams") == 0) { if (value < 1 || value > 4) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: hla_split_streams is 1..4"); ctx->split_streams = (int)value; return SP_OK; }
     return sp_fail(ctx, SP_ERR_INVALID_ARG, std::string("sp_ctx_set_option: unknown option ") + name);
 }
 
 int32_t sp_profile_reset(sp_ctx* ctx) {
     if (!ctx) return SP_ERR_INVALID_ARG;
-    if (ctx->helper) sp_profile_reset(ctx->helper);
+    for (sp_ctx* h : ctx->helper) if (h) sp_profile_reset(h);
     sp_profile_flush(ctx); ctx->prof.clear();
     unsigned long long* c = sp_counters(ctx);
     if (c) { hipSetDevice(ctx->device); hipMemsetAsync(c, 0, SPC_N * sizeof(unsigned long long), ctx->stream); }
@@ -96,7 +98,7 @@ int32_t sp_profile_reset(sp_ctx* ctx) {
 int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches, uint64_t* cells) {
     if (!ctx || !kernel) return SP_ERR_INVALID_ARG;
     sp_profile_flush(ctx);
-    if (ctx->helper) sp_profile_merge(ctx, ctx->helper);           // what ran beside this context on its helper counts as this context's
+    for (sp_ctx* h : ctx->helper) if (h) sp_profile_merge(ctx, h);  // what ran beside this context on its helpers counts as this context's
     // device counters: "count:<name>" returns the value in *cells (ms and launches are 0)
     static const struct { const char* name; int idx; } counters[] = {
         {"count:k1_cells_active", SPC_K1_ACTIVE}, {"count:k1_cells_executed", SPC_K1_EXECUTED}, {"count:k1_cells_resumed", SPC_K1_RESUMED},

@@ -340,33 +340,40 @@ static int32_t hla_solve_side_by_side(sp_ctx* ctx, const sp_hla_db* db, uint32_t
     HostScope whole(ctx, "host:hla_genes_total");
     uint64_t n_realigned = 0;
     for (uint32_t r = 0; r < reads->n; ++r) n_realigned += realign[r].status == 0;
-    sp_ctx* helper = (ctx->split_genes && n_units >= 2 && n_realigned >= SP_HLA_SPLIT_MIN_READS) ? sp_ctx_helper(ctx) : nullptr;
-    if (!helper) return hla_solve_units(ctx, db, n_units, genes, unit_sample, read_sample, reads, realign, cfgs, calls, cons, cap, is_cons1_out);
+    int n_parts = (ctx->split_genes && n_realigned >= SP_HLA_SPLIT_MIN_READS) ? (int)std::min<uint32_t>(n_units, (uint32_t)ctx->split_streams) : 1;
+    sp_ctx* on[4] = { ctx, nullptr, nullptr, nullptr };
+    for (int x = 1; x < n_parts; ++x) { on[x] = sp_ctx_helper(ctx, x - 1); if (!on[x]) { n_parts = x; break; } }
+    if (n_parts < 2) return hla_solve_units(ctx, db, n_units, genes, unit_sample, read_sample, reads, realign, cfgs, calls, cons, cap, is_cons1_out);
     if (is_cons1_out) std::memset(is_cons1_out, 0, reads->n);
     struct Part { std::vector<uint32_t> at, genes, samples; std::vector<sp_hla_call_config> cfgs; std::vector<sp_hla_call> calls; std::vector<char> cons; int32_t rc = SP_OK; };
-    Part part[2];
-    for (uint32_t k = 0; k < n_units; ++k) { Part& q = part[k & 1]; q.at.push_back(k); q.genes.push_back(genes[k]); if (unit_sample) q.samples.push_back(unit_sample[k]); q.cfgs.push_back(cfgs[k]); }
-    for (Part& q : part) { q.calls.resize(q.at.size()); q.cons.assign((size_t)2 * q.at.size() * cap, '\0'); }
+    Part part[4];
+    for (uint32_t k = 0; k < n_units; ++k) { Part& q = part[k % (uint32_t)n_parts]; q.at.push_back(k); q.genes.push_back(genes[k]); if (unit_sample) q.samples.push_back(unit_sample[k]); q.cfgs.push_back(cfgs[k]); }
+    for (int x = 0; x < n_parts; ++x) { part[x].calls.resize(part[x].at.size()); part[x].cons.assign((size_t)2 * part[x].at.size() * cap, '\0'); }
     auto solve = [&](sp_ctx* c, Part& q) {
         q.rc = hla_solve_units(c, db, (uint32_t)q.at.size(), q.genes.data(), unit_sample ? q.samples.data() : nullptr, read_sample, reads, realign, q.cfgs.data(), q.calls.data(),
                                q.cons.data(), cap, is_cons1_out, false);
     };
     HostMarks hm(ctx);
-    std::thread beside;
-    try { beside = std::thread([&]() { solve(helper, part[1]); }); }
-    catch (const std::system_error&) { }                                   // no thread to be had: this one does both parts
+    std::thread beside[4]; bool started[4] = { false, false, false, false };
+    for (int x = 1; x < n_parts; ++x) {
+        try { beside[x] = std::thread([&, x]() { solve(on[x], part[x]); }); started[x] = true; }
+        catch (const std::system_error&) { }                               // no thread to be had: this one does that part too
+    }
     hm.mark("host:hla_split_spawn");
     solve(ctx, part[0]);
     hm.mark("host:hla_split_own");
-    if (beside.joinable()) beside.join(); else solve(ctx, part[1]);      // (the helper's timings are added to this context's when somebody asks for them: sp_profile_get)
+    for (int x = 1; x < n_parts; ++x) { if (started[x]) beside[x].join(); else solve(ctx, part[x]); }   // (the helpers' timings are added to this context's when somebody asks: sp_profile_get)
     hm.mark("host:hla_split_join");
-    for (Part& q : part)
-        for (size_t x = 0; x < q.at.size(); ++x) {
-            calls[q.at[x]] = q.calls[x];
-            std::memcpy(cons + (size_t)(2 * q.at[x]) * cap, q.cons.data() + (size_t)(2 * x) * cap, (size_t)2 * cap);
+    int32_t rc = SP_OK;
+    for (int x = 0; x < n_parts; ++x) {
+        Part& q = part[x];
+        for (size_t y = 0; y < q.at.size(); ++y) {
+            calls[q.at[y]] = q.calls[y];
+            std::memcpy(cons + (size_t)(2 * q.at[y]) * cap, q.cons.data() + (size_t)(2 * y) * cap, (size_t)2 * cap);
         }
-    if (part[1].rc != SP_OK && part[0].rc == SP_OK) { if (ctx->err.empty()) ctx->err = helper->err; return part[1].rc; }
-    return part[0].rc;
+        if (q.rc != SP_OK && rc == SP_OK) { rc = q.rc; if (x > 0 && started[x]) ctx->err = on[x]->err; }
+    }
+    return rc;
 }
 
 extern "C" {

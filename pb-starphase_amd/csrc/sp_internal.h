@@ -77,7 +77,8 @@ struct sp_ctx {
     std::map<std::string, std::pair<void*, size_t>> host_pool;   // named grow-only pinned host buffers (results leave the device through them)
     int num_cus = 256;
     bool split_genes = true;         // sp_ctx_set_option "hla_split_genes"
-    sp_ctx* helper = nullptr;        // a second context on the same device (own stream, pools, events) for work that runs beside this one's; made on first use
+    int split_streams = 3;           // sp_ctx_set_option "hla_split_streams": streams the units of a call are spread over (1..4; a 32-sample cohort call: 71.5 / 58.4 / 54.9 / 68.6 ms)
+    sp_ctx* helper[3] = { nullptr, nullptr, nullptr };   // further contexts on the same device (own stream, pools, events) for work that runs beside this one's; made on first use
 };
 
 // cell descriptor consumed by the generic WFA kernel
@@ -102,7 +103,7 @@ int  sp_k2_dict_build(sp_ctx* ctx, const sp_seqset* set, const uint32_t* d_gene_
 void sp_k2_dict_free(K2Dict* d);
 
 // ---------------------------------------------------------------- launchers (sp_device.hip)
-sp_ctx* sp_ctx_helper(sp_ctx* ctx);                                      // nullptr when it cannot be made
+sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i = 0);                           // helper i (0..2); nullptr when it cannot be made
 void sp_profile_merge(sp_ctx* into, sp_ctx* from);                       // adds the timings `from` collected to `into` and clears them
 int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,

@@ -8,6 +8,8 @@ pkg = ge.load_package()
 from pb_starphase_amd import synth
 import bench
 ctx = pkg.Context(0)
+if len(sys.argv) > 1:
+    ctx.set_option("hla_split_streams", int(sys.argv[1]))
 fx = synth.HlaFixture()
 db = fx.make_db(pkg, ctx)
 names = ["anchor_k1", "anchor_k2", "anchor_type", "k1_cells", "k1_cells_deep", "k1_reduce", "k1_finalize", "cons_steps", "type_consensus_ref", "k2_cells_cdna", "k2_cells_dna",
