@@ -362,6 +362,13 @@ typedef struct {
 int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* problem, const sp_seqset* reads, sp_cyp_call* call,
                          char* consensus /* optional: SP_CYP_MAXCONS * cons_cap bytes */, uint32_t cons_cap);
 
+/* One GPU's share of a cohort: the call of sp_cyp_diplotype for each of n_samples read sets against the same problem.  The samples are
+ * spread over the context's streams (sp_ctx_set_option), one host thread per stream for the length of the call; calls[i], the
+ * consensus block of sample i (optional: n_samples * SP_CYP_MAXCONS * cons_cap bytes) and sample_rc[i] (optional) are what the single
+ * call would give.  Returns the first status that is not SP_OK. */
+int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* problem, uint32_t n_samples, const sp_seqset* const* reads, sp_cyp_call* calls,
+                                char* consensus, uint32_t cons_cap, int32_t* sample_rc);
+
 /* The same call, also handing out Cyp2d6Region::variants of every final consensus region (assign_haplotype,
  * src/cyp2d6/haplotyper.rs:546-595): has_variants[h] = 1 when region h carries a list (typed as a CYP2D6 star allele), and
  * state[h * n_variants + v] is the VariantAlleleRelationship of variant v against the assigned allele in the codes of

@@ -5,6 +5,9 @@
 // reference's operation order (no FMA contraction, table look-ups for ln n! and ln p), so the scores are bit-identical
 // to the CPU path and the (score, i, j) winner is deterministic.
 #include "sp_internal.h"
+#include <system_error>
+#include <thread>
+#include <atomic>
 #include "sp_json.h"
 #include "sp_wfa.cuh"
 #include <algorithm>
@@ -1249,6 +1252,45 @@ extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* 
     deep_hap(cr.chain1, cr.n1, call->deep1, sizeof call->deep1);
     deep_hap(cr.chain2, cr.n2, call->deep2, sizeof call->deep2);
     return SP_OK;
+}
+
+// The CYP2D6 calls of several samples (one GPU's share of a cohort): the samples are independent and each is a chain of launches that
+// wait for one another, so they are handed out to the context and its helper streams (sp_ctx_set_option "hla_split_genes" /
+// "hla_split_streams"), one host thread per stream for the length of the call.  Every call is the call sp_cyp_diplotype makes.
+extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr, uint32_t n_samples, const sp_seqset* const* reads, sp_cyp_call* calls,
+                                           char* consensus, uint32_t cons_cap, int32_t* sample_rc) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!pr || (n_samples && (!reads || !calls))) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_cyp_diplotype_cohort: null argument");
+    for (uint32_t i = 0; i < n_samples; ++i) if (!reads[i]) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_cyp_diplotype_cohort: null read set");
+    if (n_samples == 0) return SP_OK;
+    // what the first placement would build on the shared template set is built before the streams part
+    if (pr->templates) { const int rc0 = sp_seqset_build_index(ctx, const_cast<sp_seqset*>(pr->templates)); if (rc0 != SP_OK) return rc0; }
+    int n_parts = ctx->split_genes ? (int)std::min<uint32_t>(n_samples, (uint32_t)ctx->split_streams) : 1;
+    sp_ctx* on[4] = { ctx, nullptr, nullptr, nullptr };
+    for (int x = 1; x < n_parts; ++x) { on[x] = sp_ctx_helper(ctx, x - 1); if (!on[x]) { n_parts = x; break; } }
+    std::vector<int32_t> rcs(n_samples, SP_OK); std::vector<int> where(n_samples, 0);
+    std::atomic<uint32_t> next(0);
+    auto work = [&](int x) {
+        for (;;) {
+            const uint32_t i = next.fetch_add(1);
+            if (i >= n_samples) break;
+            where[i] = x;
+            rcs[i] = sp_cyp_diplotype(on[x], pr, reads[i], &calls[i], consensus ? consensus + (size_t)i * SP_CYP_MAXCONS * cons_cap : nullptr, cons_cap);
+        }
+    };
+    std::thread beside[4]; bool started[4] = { false, false, false, false };
+    for (int x = 1; x < n_parts; ++x) {
+        try { beside[x] = std::thread(work, x); started[x] = true; }
+        catch (const std::system_error&) { }
+    }
+    work(0);
+    for (int x = 1; x < n_parts; ++x) if (started[x]) beside[x].join();
+    int32_t rc = SP_OK;
+    for (uint32_t i = 0; i < n_samples; ++i) {
+        if (sample_rc) sample_rc[i] = rcs[i];
+        if (rcs[i] != SP_OK && rc == SP_OK) { rc = rcs[i]; if (where[i] > 0) ctx->err = on[where[i]]->err; }
+    }
+    return rc;
 }
 
 // cyp2d6_alleles.json: DeeplotypeDebug (src/cyp2d6/debug.rs:10-70) written as save_json writes it (serde_json pretty print)

@@ -261,6 +261,7 @@ def lib():
         "sp_consensus_dual_batch": (i32, [vp, u32, C.POINTER(sp_cons_problem), C.POINTER(sp_cons_output)]),
         "sp_cyp_variant_states": (i32, [vp, vp, C.c_char_p, u32, u32, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), vp, vp]),
         "sp_cyp_diplotype": (i32, [vp, C.POINTER(sp_cyp_problem), vp, C.POINTER(sp_cyp_call), C.c_char_p, u32]),
+        "sp_cyp_diplotype_cohort": (i32, [vp, C.POINTER(sp_cyp_problem), u32, C.POINTER(vp), C.POINTER(sp_cyp_call), C.c_char_p, u32, C.POINTER(i32)]),
         "sp_cyp_diplotype_detailed": (i32, [vp, C.POINTER(sp_cyp_problem), vp, C.POINTER(sp_cyp_call), C.c_char_p, u32, C.POINTER(sp_cyp_region_variants)]),
         "sp_cyp_alleles_json": (i32, [C.POINTER(sp_cyp_problem), C.POINTER(sp_cyp_call), C.POINTER(sp_cyp_region_variants), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
         "sp_consensus_priority": (i32, [vp, C.POINTER(sp_priority_problem), u32, u32, C.POINTER(u32), vp, C.c_char_p]),
@@ -831,6 +832,22 @@ class CypDb:
         cons = [buf.raw[i * cons_cap:(i + 1) * cons_cap].split(b"\0", 1)[0].decode() for i in range(call.n_consensus)]
         labels = [(int(call.cons_type[i]), (call.cons_subtype[i].value.decode() or None)) for i in range(call.n_consensus)]
         return call, cons, labels
+
+    def diplotype_cohort(self, read_sets, cons_cap=16384, **overrides):
+        """sp_cyp_diplotype_cohort -> [(sp_cyp_call, [consensus strings], status)] per sample"""
+        pr = self.problem(**overrides)
+        n = len(read_sets)
+        calls = (sp_cyp_call * max(1, n))()
+        handles = (C.c_void_p * max(1, n))(*[r._h.value if isinstance(r._h, C.c_void_p) else r._h for r in read_sets])
+        buf = C.create_string_buffer(max(1, n) * SP_CYP_MAXCONS * cons_cap)
+        rcs = (C.c_int32 * max(1, n))()
+        self.ctx.check(lib().sp_cyp_diplotype_cohort(self.ctx._h, C.byref(pr), n, handles, calls, buf, cons_cap, rcs))
+        out = []
+        for i in range(n):
+            base = i * SP_CYP_MAXCONS * cons_cap
+            cons = [buf.raw[base + k * cons_cap:base + (k + 1) * cons_cap].split(b"\0", 1)[0].decode() for k in range(calls[i].n_consensus)]
+            out.append((calls[i], cons, rcs[i]))
+        return out
 
     def diplotype_detailed(self, reads, cons_cap=16384, **overrides):
         """sp_cyp_diplotype_detailed + sp_cyp_alleles_json -> (sp_cyp_call, {region: [relationship code per variant]}, cyp2d6_alleles.json text)"""

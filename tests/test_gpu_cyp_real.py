@@ -79,6 +79,27 @@ def test_library_equals_oracle_pipeline(oracle, gpu_ctx, real, name):
     assert call.deep1.decode().startswith("(") and "_" in call.deep1.decode()
 
 
+def test_cohort_call_equals_single_calls(gpu_ctx, real):
+    """sp_cyp_diplotype_cohort: the six scenarios as one GPU's share of a cohort, spread over the context's streams == one call per sample"""
+    locus, db, _odb, sc = real
+    sets, single = [], []
+    for k, name in enumerate(NAMES):
+        haps, _expected = sc[name]
+        sets.append(gpu_ctx.upload(locus.sample(np.random.default_rng(40 + k), haps, 200)))
+    key = lambda call, cons: (call.status, call.hap1, call.hap2, call.core1, call.core2, call.deep1, call.deep2, call.score, list(call.chain1[:call.n1]),
+                              list(call.chain2[:call.n2]), [(int(call.cons_type[i]), call.cons_subtype[i].value) for i in range(call.n_consensus)], cons)
+    for rs in sets:
+        call, cons, _labels = db.diplotype(rs)
+        single.append(key(call, cons))
+    for streams in (3, 1):
+        gpu_ctx.set_option("hla_split_streams", streams)
+        cohort = db.diplotype_cohort(sets)
+        assert [key(call, cons) for call, cons, _rc in cohort] == single and all(rc == 0 for _c, _s, rc in cohort)
+    gpu_ctx.set_option("hla_split_streams", 3)
+    assert [k[0] for k in single] == [0] * len(NAMES)
+    assert db.diplotype_cohort([]) == []
+
+
 def test_deep_labels_of_a_novel_allele(oracle, gpu_ctx, real):
     """Cyp2d6DetailLevel::DeepAlleles (src/cyp2d6/caller.rs:907-957, region.rs:60-91): *4.001 without rs2004511 and with rs4987144 of *2 is
     still typed *4.001, and its deep label lists the missing variant with '-' and the extra one with '+'"""
