@@ -1,5 +1,5 @@
 """BASELINE configs[4] as one rank sees it: 256 samples sharded over 8 ranks -> this rank's 32 samples.  All of them go through one K1
-call + sp_hla_diplotype_cohort (HLA-A / -B); four of them also get their CYP2D6 call and their 18 variant-gene calls; the per-(sample,
+call + sp_hla_diplotype_cohort (HLA-A / -B) and one sp_cyp_diplotype_cohort call (CYP2D6); four of them also get their 18 variant-gene calls; the per-(sample,
 gene) records of the rank go through the gather of pb-starphase_amd/shard.py (world size 1 here; tests/test_shard_gloo.py and
 tests/test_gpu_bench.py run it with two ranks).  Every HLA and CYP2D6 call equals the simulated truth, every variant-gene solve the oracle."""
 import gzip
@@ -54,12 +54,14 @@ def test_one_rank_of_the_cohort(oracle, pkg, gpu_ctx):
     scen = cr.scenarios(locus)
     entries = json.load(gzip.open(os.path.join(GOLDEN, "gene_entries_v0.14.1.json.gz")))["gene_entries"]
     prepared = {name: vg.load_database_haplotypes(oracle, entries[name], None) for name in sorted(entries)}
-    for s in mine[:4]:
-        rng = np.random.default_rng(20_000 + s)
-        _name, haps, expected = scen[s % 3]                                     # *1/*2, *4/*4, *5/*1
-        call, _cons, _labels = cdb.diplotype(gpu_ctx.upload(locus.sample(rng, haps, 100, lo=8000, hi=16000)))
-        assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected), (s, call.hap1, call.hap2, expected)
+    # CYP2D6 of every sample of the rank: one sp_cyp_diplotype_cohort call, the samples spread over the context's streams
+    cyp_sets = [gpu_ctx.upload(locus.sample(np.random.default_rng(20_000 + s), scen[s % 3][1], 100, lo=8000, hi=16000)) for s in mine]   # *1/*2, *4/*4, *5/*1
+    for s, (call, _cons, rc) in zip(mine, cdb.diplotype_cohort(cyp_sets)):
+        expected = scen[s % 3][2]
+        assert rc == 0 and call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected), (s, call.hap1, call.hap2, expected)
         records.append((s, len(genes), 0, 0))                                   # (the string call travels beside the integer table in a real run)
+    for s in mine[:4]:
+        rng = np.random.default_rng(30_000 + s)
         for gi, name in enumerate(sorted(entries)):
             vh, hl = prepared[name]
             _h1, _h2, obs, _ph = synthetic_observations(rng, hl)
@@ -67,5 +69,5 @@ def test_one_rank_of_the_cohort(oracle, pkg, gpu_ctx):
             assert gpu_ctx.variant_solve(gpu_struct(pkg, prob)) == vg.oracle_solve(oracle, prob), (s, name)
             records.append((s, len(genes) + 1 + gi, 0, 0))
     table = shard.gather_calls(np.array(records, shard.CALL_DTYPE))
-    assert len(table) == 32 * 2 + 4 * (1 + len(entries)) and table["sample"].min() == 96 and table["sample"].max() == 127
+    assert len(table) == 32 * 3 + 4 * len(entries) and table["sample"].min() == 96 and table["sample"].max() == 127
     assert (np.diff(table["sample"]) >= 0).all()
