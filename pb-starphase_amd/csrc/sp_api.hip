@@ -108,6 +108,10 @@ int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64
     for (const auto& c : counters) if (std::strcmp(kernel, c.name) == 0) {
         unsigned long long v = 0; unsigned long long* d = sp_counters(ctx);
         if (d) { hipSetDevice(ctx->device); if (hipMemcpyAsync(&v, d + c.idx, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "sp_profile_get: counter read failed"); }
+        for (sp_ctx* h : ctx->helper) if (h) {                       // what the helpers counted is this context's too
+            unsigned long long hv = 0; unsigned long long* hd = sp_counters(h);
+            if (hd && hipMemcpyAsync(&hv, hd + c.idx, 8, hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess) v += hv;
+        }
         if (total_ms) *total_ms = 0.0;
         if (launches) *launches = 0;
         if (cells) *cells = v;
