@@ -3,6 +3,7 @@
 #include "sp_internal.h"
 #include <algorithm>
 #include <thread>
+#include <atomic>
 #include <cstring>
 #include <new>
 
@@ -255,16 +256,25 @@ int sp_seqset_make_small(sp_ctx* ctx, const char* prefix, const char* bases, con
     s.h_word_off[n] = total_words;
     const size_t plane_words = (size_t)total_words + SP_SEQ_PAD_WORDS;
     std::vector<uint32_t> words(plane_words, 0), nplane(plane_words, 0);
-    for (uint32_t i = 0; i < n; ++i) {
+    std::atomic<bool> any_n(false);
+    auto pack_one = [&](uint32_t i) {
         const char* src = bases + offsets[i];
         uint32_t* w = words.data() + s.h_word_off[i]; uint32_t* np = nplane.data() + s.h_word_off[i];
         for (int b = 0; b < s.h_len[i]; ++b) {
             uint32_t c = 0;
             switch (src[b]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break;
-                              default: np[b >> 4] |= 1u << ((b & 15) << 1); s.has_n = true; }
+                              default: np[b >> 4] |= 1u << ((b & 15) << 1); any_n.store(true, std::memory_order_relaxed); }
             w[b >> 4] |= c << ((b & 15) << 1);
         }
-    }
+    };
+    // (the sequences own disjoint words: sets of many -- the consensuses of a cohort -- are packed by a few threads)
+    const uint32_t pack_threads = n >= 32 ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+    if (pack_threads > 1) {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < pack_threads; ++t) pool.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += pack_threads) pack_one(i); });
+        for (auto& th : pool) th.join();
+    } else for (uint32_t i = 0; i < n; ++i) pack_one(i);
+    s.has_n = any_n.load();
     s.h_words = words;
     if (s.has_n) s.h_words.insert(s.h_words.end(), nplane.begin(), nplane.end());
     // every array of the set goes into ONE device buffer through ONE pinned staging buffer: a single DMA instead of seven pageable
