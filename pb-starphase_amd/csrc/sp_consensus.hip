@@ -1174,6 +1174,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     std::vector<uint32_t> h_idx; std::vector<int32_t> h_off;
     std::vector<size_t> idx_at(n_prob), off_at(n_prob), c_at(n_prob), proc_at(n_prob);
     size_t total = 0, c_bytes = 0, proc_bytes = 0; int max_cap = 0, n_blocks = 0, n_clusters = 0;
+    std::vector<int> expect(n_prob, 0);
     for (uint32_t p = 0; p < n_prob; ++p) {
         const sp_cons_problem& q = probs[p];
         const uint32_t n = q.read_idx ? q.n : q.reads->n;
@@ -1197,6 +1198,14 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         c_at[p] = c_bytes; c_bytes += (size_t)NQ * 2 * (size_t)std::max(P.cap, 1);
         proc_at[p] = proc_bytes; proc_bytes += ((size_t)std::max(P.cap, 1) + 2 + 15) & ~(size_t)15;
         max_cap = std::max(max_cap, P.cap);
+        // how long the consensus can get: the furthest any read of the problem reaches (its placement offset + its length), within cap
+        int reach = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t r = q.read_idx ? q.read_idx[i] : i;
+            const int o = q.offsets && q.offsets[i] > 0 ? q.offsets[i] : 0;
+            reach = std::max(reach, o + (r < q.reads->h_len.size() ? q.reads->h_len[r] : P.cap));
+        }
+        expect[p] = std::min(P.cap, reach);
     }
     if (n_blocks == 0) return SP_OK;
     const size_t planes = (size_t)NQ * 4;                   // [node][slot][consensus]
@@ -1283,9 +1292,12 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     hm.mark("host:k8_prologue");
     {
         ProfScope ps(ctx, "cons_steps", total);
-        // the first poll comes when a consensus of max_cap bases can be through if (nearly) every window stands; then every few pairs.
-        // A launch pair whose problems are all done is a pair of empty launches.
-        int until_poll = max_cap / CW + 8;
+        // The first poll comes when the longest consensus the reads can give (`expect`: the furthest a read reaches -- not the buffer's
+        // capacity, which for compressed reads is far beyond it) can be through if every window stands; then every few pairs, fewer
+        // the closer the end is.  A launch pair whose problems are all done is three empty launches (~13 us), a poll a ~25 us bubble.
+        int max_expect = 0;
+        for (uint32_t p = 0; p < n_prob; ++p) max_expect = std::max(max_expect, expect[p]);
+        int until_poll = max_expect / CW + 3;
         const uint64_t limit = (uint64_t)64 * (uint64_t)(max_cap + 2) + 1024;
         for (;;) {
             hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
@@ -1296,10 +1308,10 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
                 SP_HIP_CHECK(ctx, hipMemcpyAsync(h_work, d_work, sizeof(CWork) * n_prob, hipMemcpyDeviceToHost, st));
                 SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
                 bool all = true; int left = 0;
-                for (uint32_t p = 0; p < n_prob; ++p) { all = all && h_work[p].done; if (!h_work[p].done) left = std::max(left, hp[p].cap - h_work[p].T); }
+                for (uint32_t p = 0; p < n_prob; ++p) { all = all && h_work[p].done; if (!h_work[p].done) left = std::max(left, expect[p] - h_work[p].T); }
                 if (all) break;
                 if (pairs >= limit) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the search did not finish");
-                until_poll = std::max(4, std::min(64, left / CW / 4 + 2));
+                until_poll = std::max(2, std::min(64, left / CW / 2 + 1));
             }
         }
     }

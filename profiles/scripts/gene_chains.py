@@ -22,4 +22,6 @@ for g in range(len(fx.genes)):
         call, c1, c2, _ = db.diplotype_gene(g, R, k1)
     dt = (time.perf_counter() - t0) / 5
     print(fx.genes[g], f"{1e3 * dt:.2f} ms alone; reads {call.n_reads}, consensus lengths {len(c1)} {len(c2)}, windows {ctx.profile_get('cons_windows')[2] / 5:.0f}")
+    print("    launch triples", ctx.profile_get("cons_windows")[2] / 5, "consensus columns", ctx.profile_get("cons_columns")[2] / 5, "cut windows", ctx.profile_get("cons_cut_windows")[2] / 5,
+          "expansions", ctx.profile_get("cons_expansions")[2] / 5)
     print("   ", {n.replace("host:", "h:"): round(ctx.profile_get(n)[0] / 5, 2) for n in names})
