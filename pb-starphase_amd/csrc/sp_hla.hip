@@ -1101,7 +1101,8 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
         }
         const int bins_cap = cons->max_len + aset->max_len + 1;
         const size_t anchor_lds = (size_t)((bins_cap + 1) / 2) * 4 + (size_t)cons->max_len * 4;
-        uint32_t* d_hits = kd.built && anchor_lds <= 160 * 1024 - 256 ? (uint32_t*)sp_pool(ctx, "k2_hits", std::max<size_t>(1, (size_t)n_items * kd.max_dict) * 4) : nullptr;
+        uint32_t* d_hits = kd.built && anchor_lds <= 160 * 1024 - 256 && n_items <= 65535 /* grid.y of k2_hits_kernel */
+                               ? (uint32_t*)sp_pool(ctx, "k2_hits", std::max<size_t>(1, (size_t)n_items * kd.max_dict) * 4) : nullptr;
         if (d_hits && kd.max_dict) {
             ProfScope ps(ctx, "anchor_k2", T);
             hipLaunchKernelGGL(k2_hits_kernel, dim3((kd.max_dict + 255) / 256, n_items), dim3(256), 0, ctx->stream, cons->kview(), kd.d_code, kd.d_dict_off,
