@@ -5,6 +5,7 @@
 // Decisions use f64 exactly as the reference does (MappingScore::score_value, src/data_types/mapping.rs:191-195);
 // alignments come from the one-wavefront-per-cell WFA kernel (sp_wfa.cuh).
 #include "sp_internal.h"
+#include <tuple>
 #include <mutex>
 #include "sp_wfa.cuh"
 #include "sp_anchor.cuh"
@@ -1041,6 +1042,24 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
     // "If cDNA scoring is disabled, require HLA DNA must be enabled" (caller.rs:517-520)
     if (disable_cdna && !require_dna) return sp_fail(ctx, SP_ERR_INVALID_ARG, "If cDNA scoring is disabled, require HLA DNA must be enabled");
     (void)hipSetDevice(ctx->device);
+    // the samples of a cohort carry the same common alleles: consensuses that are the same gene and the same two strings are scored once
+    if (n_items > 1 && !stats) {
+        std::map<std::tuple<uint32_t, std::string, std::string>, uint32_t> seen;
+        std::vector<K2Item> uniq; std::vector<uint32_t> as(n_items);
+        for (uint32_t k = 0; k < n_items; ++k) {
+            auto key = std::make_tuple(items[k].gene, std::string(items[k].dna, items[k].dna_len), std::string(disable_cdna ? "" : std::string(items[k].cdna, items[k].cdna_len)));
+            auto it = seen.find(key);
+            if (it == seen.end()) { it = seen.emplace(std::move(key), (uint32_t)uniq.size()).first; uniq.push_back(items[k]); }
+            as[k] = it->second;
+        }
+        if (uniq.size() < n_items) {
+            std::vector<sp_hla_best> ub(uniq.size());
+            const int32_t urc = k2_score_batch(ctx, db, (uint32_t)uniq.size(), uniq.data(), require_dna, disable_cdna, ub.data(), nullptr);
+            if (urc != SP_OK) return urc;
+            for (uint32_t k = 0; k < n_items; ++k) best[k] = ub[as[k]];
+            return SP_OK;
+        }
+    }
     HostMarks hm(ctx);
     // allowed alleles of each item's gene, database order (is_allowed_allele_def, caller.rs:1090-1095)
     std::vector<const sp_hla_db::GeneList*> lists(n_items);

@@ -309,6 +309,10 @@ def test_k2_batch_equals_single(oracle, pkg, gpu_ctx, small):
     single_t = [db.type_consensus(g, c, stats=False)[:2] for g, c in fwd_items]
     assert db.type_consensus_batch(fwd_items) == [(b, n) for b, n in single_t]
     assert single_t[-1][0] == -1 and single_t[-2] == (-1, 0)
+    # the samples of a cohort repeat the common alleles: a batch scores equal consensuses once and hands every copy its result
+    repeated = [items[0], items[3], items[0], items[1], items[3], items[0]]
+    assert db.score_consensus_batch(repeated) == [single[k] for k in (0, 3, 0, 1, 3, 0)]
+    assert db.type_consensus_batch([fwd_items[2], fwd_items[2], fwd_items[0]]) == [single_t[2], single_t[2], single_t[0]]
 
 
 def test_k1_sliced_batches(oracle, pkg, gpu_ctx, small, monkeypatch):
