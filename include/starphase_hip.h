@@ -478,6 +478,9 @@ typedef struct {
 } sp_variant_result;
 
 int32_t sp_variant_solve(sp_ctx* ctx, const sp_variant_problem* problem, sp_variant_result* result);
+/* the solves of a panel / of one GPU's share of a cohort in one call, handed out to the context's streams (sp_ctx_set_option):
+ * results[i] and problem_rc[i] (optional) are what sp_variant_solve gives for problems[i]; returns the first status that is not SP_OK */
+int32_t sp_variant_solve_batch(sp_ctx* ctx, uint32_t n, const sp_variant_problem* const* problems, sp_variant_result* results, int32_t* problem_rc);
 
 /* is_deletion (src/diplotyper.rs:1020-1174): which defined deletion haplotype, if any, a deleted region [start, end) (0-based,
  * end exclusive) is; its label is what load_sv_vcf_variants (:739-857) attaches to the observed SV (obs_sv_label above).

@@ -3,6 +3,9 @@
 // (het assignment, haplotype side, database haplotype) cell, scores packed into one u64 so the lexicographic
 // (core missing, core extra, sub missing, sub extra) order is an integer order.
 #include "sp_internal.h"
+#include <system_error>
+#include <thread>
+#include <atomic>
 #include <algorithm>
 #include <climits>
 #include <cstring>
@@ -30,18 +33,22 @@ __global__ __launch_bounds__(256) void k6_cells_kernel(int n_haps, int n_obs, un
     if (hap_skip[h]) { keys[cell] = K6_NOKEY; return; }                       // SV haplotypes are not quantified (:1443-1446)
     unsigned long long matched = 0;
     unsigned ev_core = 0, ev_sub = 0;
-    for (int o = 0; o < n_obs; ++o) {
-        bool in_set = true;
-        if (obs_het[o]) {                                                        // het assignment (diplotyper.rs:1270-1317)
-            const bool is_h1 = ((comb >> obs_group[o]) & 1ull) != 0;
-            const bool to_h1 = is_h1 == (obs_orient01[o] != 0);
-            in_set = side == 0 ? to_h1 : !to_h1;
+    // a side's list is the homozygous variants first (base_haplotype, diplotyper.rs:1219-1222,1269-1270) and then the heterozygous ones that
+    // go to it, each in call order: when two of them compete for one slot (alternatives of an OR-group), the one that comes first takes it
+    for (int pass = 0; pass < 2; ++pass)
+        for (int o = 0; o < n_obs; ++o) {
+            if ((obs_het[o] != 0) != (pass == 1)) continue;
+            bool in_set = true;
+            if (obs_het[o]) {                                                    // het assignment (diplotyper.rs:1270-1317)
+                const bool is_h1 = ((comb >> obs_group[o]) & 1ull) != 0;
+                const bool to_h1 = is_h1 == (obs_orient01[o] != 0);
+                in_set = side == 0 ? to_h1 : !to_h1;
+            }
+            if (!in_set) continue;
+            const int mi = match_slot[(size_t)h * n_obs + o];
+            if (mi >= 0 && !((matched >> mi) & 1ull)) matched |= 1ull << mi;
+            else { if (obs_core[o]) ++ev_core; else ++ev_sub; }
         }
-        if (!in_set) continue;
-        const int mi = match_slot[(size_t)h * n_obs + o];
-        if (mi >= 0 && !((matched >> mi) & 1ull)) matched |= 1ull << mi;
-        else { if (obs_core[o]) ++ev_core; else ++ev_sub; }
-    }
     const unsigned long long missing = slot_need[h] & ~matched;                   // unmatched slots without a None alternative
     const unsigned mv_core = (unsigned)__popcll(missing & slot_core[h]), mv_sub = (unsigned)__popcll(missing & ~slot_core[h]);
     keys[cell] = ((unsigned long long)mv_core << 48) | ((unsigned long long)ev_core << 32) | ((unsigned long long)mv_sub << 16) | (unsigned long long)ev_sub;
@@ -96,11 +103,13 @@ extern "C" int32_t sp_variant_solve(sp_ctx* ctx, const sp_variant_problem* p, sp
     // SV short-circuit is decided per side on the host (diplotyper.rs:1414-1431): collect labels of a side
     auto side_members = [&](unsigned long long comb, int side, std::vector<int>& out) {
         out.clear();
-        for (int o = 0; o < NO; ++o) {
-            bool in_set = true;
-            if (obs_het[o]) { const bool is_h1 = ((comb >> obs_group[o]) & 1ull) != 0; const bool to_h1 = is_h1 == (obs_orient[o] != 0); in_set = side == 0 ? to_h1 : !to_h1; }
-            if (in_set) out.push_back(o);
-        }
+        for (int pass = 0; pass < 2; ++pass)                  // the homozygous variants first, then the side's heterozygous ones (diplotyper.rs:1269-1317)
+            for (int o = 0; o < NO; ++o) {
+                if ((obs_het[o] != 0) != (pass == 1)) continue;
+                bool in_set = true;
+                if (obs_het[o]) { const bool is_h1 = ((comb >> obs_group[o]) & 1ull) != 0; const bool to_h1 = is_h1 == (obs_orient[o] != 0); in_set = side == 0 ? to_h1 : !to_h1; }
+                if (in_set) out.push_back(o);
+            }
     };
 
     // device scoring
@@ -184,4 +193,40 @@ extern "C" int32_t sp_variant_solve(sp_ctx* ctx, const sp_variant_problem* p, sp
     }
     for (int k = 0; k < 4; ++k) res->score[k] = best[k];
     return SP_OK;
+}
+
+// The solves of a panel or of one GPU's share of a cohort (23 genes x 32 samples): they are independent and each is a handful of small
+// copies, one launch and a wait, so they are handed out to the context's streams (sp_ctx_set_option), one host thread per stream for the
+// length of the call.  results[i] / problem_rc[i] are what sp_variant_solve gives for problems[i].
+extern "C" int32_t sp_variant_solve_batch(sp_ctx* ctx, uint32_t n, const sp_variant_problem* const* problems, sp_variant_result* results, int32_t* problem_rc) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (n && (!problems || !results)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_variant_solve_batch: null argument");
+    for (uint32_t i = 0; i < n; ++i) if (!problems[i]) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_variant_solve_batch: null problem");
+    if (n == 0) return SP_OK;
+    int n_parts = ctx->split_genes ? (int)std::min<uint32_t>(n, (uint32_t)ctx->split_streams) : 1;
+    sp_ctx* on[4] = { ctx, nullptr, nullptr, nullptr };
+    for (int x = 1; x < n_parts; ++x) { on[x] = sp_ctx_helper(ctx, x - 1); if (!on[x]) { n_parts = x; break; } }
+    std::vector<int32_t> rcs(n, SP_OK); std::vector<int> where(n, 0);
+    std::atomic<uint32_t> next(0);
+    auto work = [&](int x) {
+        for (;;) {
+            const uint32_t i = next.fetch_add(1);
+            if (i >= n) break;
+            where[i] = x;
+            rcs[i] = sp_variant_solve(on[x], problems[i], &results[i]);
+        }
+    };
+    std::thread beside[4]; bool started[4] = { false, false, false, false };
+    for (int x = 1; x < n_parts; ++x) {
+        try { beside[x] = std::thread(work, x); started[x] = true; }
+        catch (const std::system_error&) { }
+    }
+    work(0);
+    for (int x = 1; x < n_parts; ++x) if (started[x]) beside[x].join();
+    int32_t rc = SP_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (problem_rc) problem_rc[i] = rcs[i];
+        if (rcs[i] != SP_OK && rc == SP_OK) { rc = rcs[i]; if (where[i] > 0) ctx->err = on[where[i]]->err; }
+    }
+    return rc;
 }

@@ -246,6 +246,7 @@ def lib():
         "sp_cyp_weight_segments": (i32, [vp, vp, vp, vp, vp, vp, vp]),
         "sp_cyp_score_alleles": (i32, [vp, u32, u32, vp, vp, u32, vp, vp, vp, vp]),
         "sp_variant_solve": (i32, [vp, C.POINTER(sp_variant_problem), C.POINTER(sp_variant_result)]),
+        "sp_variant_solve_batch": (i32, [vp, u32, C.POINTER(C.POINTER(sp_variant_problem)), C.POINTER(sp_variant_result), C.POINTER(i32)]),
         "sp_variant_is_deletion": (i32, [C.POINTER(sp_sv_definitions), u64, u64, C.POINTER(i32), C.POINTER(i32)]),
         "sp_hla_is_passing_dual": (i32, [u64, u64, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sp_hla_is_hemizygous_better": (i32, [vp, vp, vp, u32, i32, u64, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -441,6 +442,15 @@ class Context:
         if res.overflow:
             raise StarphaseError(5, "more than SP_VAR_MAXDIP tied diplotypes")
         return tuple(res.score), [(res.dip[i][0], res.dip[i][1], res.dip_comb[i]) for i in range(res.n_dip)]
+
+    def variant_solve_batch(self, problems):
+        """sp_variant_solve_batch -> [(score tuple, [(h1, h2, combination)])] per problem"""
+        n = len(problems)
+        ptrs = (C.POINTER(sp_variant_problem) * max(1, n))(*[C.pointer(p) for p in problems])
+        res = (sp_variant_result * max(1, n))()
+        rcs = (C.c_int32 * max(1, n))()
+        self.check(lib().sp_variant_solve_batch(self._h, n, ptrs, res, rcs))
+        return [(tuple(res[i].score), [(res[i].dip[k][0], res[i].dip[k][1], res[i].dip_comb[k]) for k in range(res[i].n_dip)]) for i in range(n)]
 
     def consensus(self, reads, cfg, offsets=None, read_idx=None, cap=None, two_pass=False):
         """sp_consensus / sp_consensus_dual (two_pass) on a SeqSet -> dict like the oracle harness returns"""

@@ -1,5 +1,5 @@
 """BASELINE configs[4] as one rank sees it: 256 samples sharded over 8 ranks -> this rank's 32 samples.  All of them go through one K1
-call + sp_hla_diplotype_cohort (HLA-A / -B) and one sp_cyp_diplotype_cohort call (CYP2D6); four of them also get their 18 variant-gene calls; the per-(sample,
+call + sp_hla_diplotype_cohort (HLA-A / -B) and one sp_cyp_diplotype_cohort call (CYP2D6); four of them also get their 18 variant-gene calls (one sp_variant_solve_batch call); the per-(sample,
 gene) records of the rank go through the gather of pb-starphase_amd/shard.py (world size 1 here; tests/test_shard_gloo.py and
 tests/test_gpu_bench.py run it with two ranks).  Every HLA and CYP2D6 call equals the simulated truth, every variant-gene solve the oracle."""
 import gzip
@@ -60,14 +60,18 @@ def test_one_rank_of_the_cohort(oracle, pkg, gpu_ctx):
         expected = scen[s % 3][2]
         assert rc == 0 and call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected), (s, call.hap1, call.hap2, expected)
         records.append((s, len(genes), 0, 0))                                   # (the string call travels beside the integer table in a real run)
+    # the variant genes of four samples: their solves in one sp_variant_solve_batch call
+    problems, tags = [], []
     for s in mine[:4]:
         rng = np.random.default_rng(30_000 + s)
         for gi, name in enumerate(sorted(entries)):
             vh, hl = prepared[name]
             _h1, _h2, obs, _ph = synthetic_observations(rng, hl)
-            prob = vg.Problem(vh, hl, obs, entries[name].get("structural_variants"))
-            assert gpu_ctx.variant_solve(gpu_struct(pkg, prob)) == vg.oracle_solve(oracle, prob), (s, name)
-            records.append((s, len(genes) + 1 + gi, 0, 0))
+            problems.append(vg.Problem(vh, hl, obs, entries[name].get("structural_variants"))); tags.append((s, gi, name))
+    structs = [gpu_struct(pkg, p) for p in problems]
+    for (s, gi, name), prob, got in zip(tags, problems, gpu_ctx.variant_solve_batch(structs)):
+        assert got == vg.oracle_solve(oracle, prob), (s, name)
+        records.append((s, len(genes) + 1 + gi, 0, 0))
     table = shard.gather_calls(np.array(records, shard.CALL_DTYPE))
     assert len(table) == 32 * 3 + 4 * len(entries) and table["sample"].min() == 96 and table["sample"].max() == 127
     assert (np.diff(table["sample"]) >= 0).all()

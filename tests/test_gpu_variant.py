@@ -108,3 +108,37 @@ def test_random_problems(oracle, pkg, gpu_ctx):
         assert got == exp, (k, got, exp)
         n_nontrivial += len(exp[1]) > 0
     assert n_nontrivial >= 20
+
+
+def test_or_group_with_a_hom_and_a_het_alternative(oracle, pkg, gpu_ctx):
+    """A side's variant list is the homozygous calls first, then its heterozygous ones (solve_diplotype, src/diplotyper.rs:1219-1222,1269-1317):
+    when both alternatives of an OR-group are observed -- one homozygous, one heterozygous -- the homozygous one takes the slot whatever
+    the order of the calls, and the heterozygous one counts as extra (quant_match, src/data_types/normalized_variant.rs:443-462)"""
+    rng = np.random.default_rng(34)
+    probs = [RandomProblem(rng, n_vars=24, n_haps=int(rng.integers(3, 60)), n_obs=int(rng.integers(0, 11))) for _ in range(60)]
+    p = probs[44]                                            # hets 1, 9; homs 16, 20; haplotype h0 = {9|16}, {21}, {6}
+    assert p.obs_var.tolist() == [1, 9, 16, 20] and p.obs_gt.tolist() == [1, 1, 4, 4]
+    exp = vg.oracle_solve(oracle, p)
+    assert exp[0] == (0, 4, 2, 2) and sorted(set(d[:2] for d in exp[1])) == [(1, 1), (1, 6), (6, 1), (6, 6)]
+    assert gpu_ctx.variant_solve(gpu_struct(pkg, p)) == exp
+    # many problems built to have such slots
+    hits = 0
+    for k in range(200):
+        q = RandomProblem(rng, n_vars=8, n_haps=int(rng.integers(3, 12)), n_obs=int(rng.integers(3, 8)))
+        hits += any(len(set(q.alt_var[q.alt_off[s]:q.alt_off[s + 1]].tolist()) & set(q.obs_var.tolist())) > 1 for s in range(len(q.alt_off) - 1))
+        assert gpu_ctx.variant_solve(gpu_struct(pkg, q)) == vg.oracle_solve(oracle, q), k
+    assert hits >= 20
+
+
+def test_batch_equals_single_solves(oracle, pkg, gpu_ctx):
+    """sp_variant_solve_batch: the solves of a panel in one call, handed out to the context's streams == one sp_variant_solve each"""
+    rng = np.random.default_rng(34)
+    probs = [RandomProblem(rng, n_vars=24, n_haps=int(rng.integers(3, 60)), n_obs=int(rng.integers(0, 11))) for _ in range(60)]
+    structs = [gpu_struct(pkg, p) for p in probs]
+    single = [gpu_ctx.variant_solve(s) for s in structs]
+    for streams in (3, 1):
+        gpu_ctx.set_option("hla_split_streams", streams)
+        assert gpu_ctx.variant_solve_batch(structs) == single
+    gpu_ctx.set_option("hla_split_streams", 3)
+    assert single == [vg.oracle_solve(oracle, p) for p in probs]
+    assert gpu_ctx.variant_solve_batch([]) == []
