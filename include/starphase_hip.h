@@ -580,7 +580,10 @@ int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* r
  * level) followed by solve(the others, level); else solve(group, level + 1), or emit the group after the last level.  Initial
  * groups: the unseeded reads, then each seed in ascending order.  Offsets inside a group are re-based on the group's smallest
  * one (that read starts the consensus, the others keep their distance to it plus half the window).  Finally every emitted group
- * gets one consensus per level (sp_consensus).  All problems of a round run in lockstep on the GPU.
+ * gets one consensus per level (sp_consensus).  All problems of a round run in lockstep on the GPU.  A two-way search that gives up (no
+ * complete node: a group of more classes than a search holds consensuses can exhaust the queue / capacity bounds at high depth) is run
+ * again with min_af 0.15, 0.20, 0.30, 0.40 (the first above the configured one that completes); the groups it leaves are solved with the
+ * configured fraction again.
  *   levels[l]   the sequences of level l (n each, same read order); offsets[l] = NULL or n entries (-1 = None); seeds = NULL or n (-1 = None)
  *   group_of    n entries: index of the emitted group of every read (MultiConsensus::sequence_indices)
  *   cons        max_groups * n_levels * cap bytes: consensus of group g at level l at cons + (g * n_levels + l) * cap

@@ -1445,7 +1445,11 @@ int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* pr, uint32
     const uint32_t n = pr->n, NL = pr->n_levels;
     if (n == 0) return SP_OK;
     const int half = pr->cfg.offset_window / 2;
-    struct Item { std::vector<uint32_t> members; uint32_t level; std::string key; };
+    struct Item { std::vector<uint32_t> members; uint32_t level; std::string key; int retry = 0; };
+    // A search that gave up (no complete node: a mixture of more classes than a search holds consensuses can exhaust the queue and capacity
+    // bounds) is run again with only the stronger differences as candidates; the split it finds is the split, the groups it leaves are solved
+    // with the configured fraction again.
+    static const double retry_min_af[4] = { 0.15, 0.20, 0.30, 0.40 };
     // initial groups: unseeded reads first, then the seeds in ascending order
     std::vector<Item> work, done;
     {
@@ -1478,6 +1482,7 @@ int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* pr, uint32
             s1[x].resize(it.members.size()); s2[x].resize(it.members.size()); is1[x].resize(it.members.size()); text[x].assign((size_t)2 * c, 0);
             P[x].reads = set; P[x].read_idx = it.members.data(); P[x].n = (uint32_t)it.members.size(); P[x].offsets = has_off ? offs[x].data() : nullptr;
             P[x].cfg = pr->cfg; P[x].cfg.allow_dual = 1;
+            if (it.retry > 0) P[x].cfg.min_af = retry_min_af[it.retry - 1];
             std::memset(&O[x], 0, sizeof O[x]);
             O[x].cons1 = text[x].data(); O[x].cons2 = text[x].data() + c; O[x].cap = c; O[x].is_cons1 = is1[x].data(); O[x].score1 = s1[x].data(); O[x].score2 = s2[x].data();
         }
@@ -1486,12 +1491,18 @@ int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* pr, uint32
         std::vector<Item> next;
         for (size_t x = 0; x < k; ++x) {
             Item& it = work[x];
+            // gave up: once more with the next stricter fraction of the ladder that is above the configured one
+            if (!O[x].result.is_dual && O[x].cons1[0] == '\0' && !it.members.empty()) {
+                int step = it.retry;
+                while (step < 4 && retry_min_af[step] <= pr->cfg.min_af) ++step;
+                if (step < 4) { it.retry = step + 1; next.push_back(std::move(it)); continue; }
+            }
             std::vector<uint32_t> g1, g2;
             for (size_t i = 0; i < it.members.size(); ++i) (is1[x][i] ? g1 : g2).push_back(it.members[i]);
             if (O[x].result.is_dual && !g1.empty() && !g2.empty()) {
                 Item a; a.members = std::move(g1); a.level = it.level; a.key = it.key + "0"; next.push_back(std::move(a));
                 Item b; b.members = std::move(g2); b.level = it.level; b.key = it.key + "1"; next.push_back(std::move(b));
-            } else if (it.level + 1 < NL) { it.level += 1; it.key += "_"; next.push_back(std::move(it)); }
+            } else if (it.level + 1 < NL) { it.level += 1; it.key += "_"; it.retry = 0; next.push_back(std::move(it)); }
             else done.push_back(std::move(it));
         }
         work.swap(next);

@@ -454,6 +454,9 @@ def dual_consensus_two_pass(run, reads, offsets=None, cfg=None):
     return run(reads, offsets, with_dual(cfg or cons_config(), True))
 
 
+PRIORITY_RETRY_MIN_AF = (0.15, 0.20, 0.30, 0.40)          # sp_consensus_priority's ladder for searches that give up
+
+
 def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None):
     """The multi-way contract of sp_consensus_priority on top of the oracle's two-way consensus (include/starphase_hip.h):
     levels = list (per level) of lists of strings.  Returns (group_of, [[consensus per level] per group])."""
@@ -471,6 +474,15 @@ def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None):
 
     def solve(members, level):
         res = dual_consensus_two_pass(run, [levels[level][r] for r in members], rebased(members, level), dual)
+        # a search that gave up (no complete node: a mixture of more classes than a search holds consensuses can exhaust the queue and capacity
+        # bounds) is run again with only the stronger differences as candidates; the split it finds is the split, the groups it leaves are
+        # solved with the configured fraction again
+        for af in PRIORITY_RETRY_MIN_AF:
+            if res["cons"][0] or af <= cfg.min_af:                  # (a search that gave up has no consensus: an empty string)
+                continue
+            stricter = ConsConfig(dual.min_count, dual.dual_max_ed_delta, dual.allow_early_termination, 1, dual.offset_window, dual.offset_compare_length, af,
+                                  dual.max_queue_size, dual.max_capacity_per_size, dual.max_nodes_wo_constraint, 0)
+            res = run([levels[level][r] for r in members], rebased(members, level), stricter)
         g1 = [r for r, f in zip(members, res["is_cons1"]) if f]
         g2 = [r for r, f in zip(members, res["is_cons1"]) if not f]
         if res["is_dual"] and g1 and g2:

@@ -100,6 +100,22 @@ def test_cohort_call_equals_single_calls(gpu_ctx, real):
     assert db.diplotype_cohort([]) == []
 
 
+def test_hybrid_sample_on_a_second_locus(pkg, gpu_ctx):
+    """The `*4+*68/*1` sample on another random chr22 locus, 2,000 reads: the 884 unseeded sequences are four classes (`*4`, `*1`, CYP2D7, the hybrid)
+    for a search that holds two consensuses, and at this depth the search with the configured min_af exhausts its queue / capacity bounds and
+    gives up.  sp_consensus_priority then runs it again with only the stronger differences as candidates (0.15, 0.20, 0.30, 0.40), takes that
+    split and solves the halves with the configured fraction: the call is the truth (without the retry the group stayed whole: `*68x2/*68x2`).
+    Library == oracle pipeline on this sample: profiles/scripts/cyp_other_locus.py (a minute of CPU, not part of the suite)."""
+    from pb_starphase_amd import synth
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=2003)
+    db = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
+    _name, haps, expected = [s for s in cr.scenarios(locus) if s[0] == "*4+*68/*1"][0]
+    call, _cons, labels = db.diplotype(gpu_ctx.upload(locus.sample(np.random.default_rng(2007), haps, 2000)))
+    assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
+    assert sorted(s for t, s in labels if t == 2) == ["1.001", "4.001"]
+
+
 def test_deep_labels_of_a_novel_allele(oracle, gpu_ctx, real):
     """Cyp2d6DetailLevel::DeepAlleles (src/cyp2d6/caller.rs:907-957, region.rs:60-91): *4.001 without rs2004511 and with rs4987144 of *2 is
     still typed *4.001, and its deep label lists the missing variant with '-' and the extra one with '+'"""
