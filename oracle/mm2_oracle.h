@@ -1,0 +1,96 @@
+/*
+ * mm2_oracle.h -- CPU ORACLE, second statement of the base-level aligner.  TEST INFRASTRUCTURE ONLY.
+ *
+ * The reference takes every (nm, start, end, strand, cigar) from minimap2 2.28 through the crate
+ * `minimap2 0.1.23+minimap2.2.28` (Cargo.lock:1137-1152); `standard_hifi_aligner`
+ * (src/util/mapping.rs:8-14) fixes the configuration: preset `map-hifi`, CIGAR on, `best_n = 5`;
+ * `score_read` raises the match score to 5 (src/hla/caller.rs:1370-1379).  minimap2's sources are not under
+ * /root/reference and cannot be fetched; this file restates its PUBLISHED algorithm (Li 2018, Bioinformatics
+ * 34:3094; Li 2021, Bioinformatics 37:4572; Suzuki & Kasahara 2018 for the difference-recurrence DP whose plain
+ * form is used here) with the documented `map-hifi` parameters:
+ *
+ *   seeding   (k,w) = (19,19) minimizers of the invertible 64-bit integer hash, both strands, occurrence
+ *             filter mid_occ in [50,500] from the top 2e-4 fraction, rescue of high-occurrence streaks
+ *             (<= 4095 occurrences, one seed per 500 query bases)
+ *   chaining  f(i) = max_j f(j) + min(span, gap) - (0.01*0.8*k*|dd| + 0.5*log2(|dd|+1)); max gap 10,000;
+ *             band 500; skip 25; at least 3 seeds and score 40; chains cut where the score falls by > band
+ *   selection chains overlapping >= 0.5 of the shorter on the QUERY are secondary to the better one;
+ *             secondaries within 0.8 of their primary, at most best_n, are kept and base-aligned
+ *   alignment two-piece affine gaps  min(q + k*e, q2 + k*e2) = min(6+2k, 26+k), match a = 1 (5 in score_read),
+ *             mismatch b = 4, ambiguous base -1; global DP between seeds in stretches >= 200 bases, extension
+ *             from the outermost seeds with z-drop 400 ending at the best-scoring cell (end bonus off): a mismatch
+ *             within b/a bases of an end is clipped; NM = mismatches + gap bases + ambiguous bases;
+ *             alignments whose peak DP score is below 200 are dropped
+ *
+ * It is a "second opinion": parity of the library is defined against osp_wfa / osp_anchor;
+ * this file measures how often that contract and minimap2's algorithm disagree (profiles/r03/aligner_divergence.*)
+ * and provides the reference's CALL PATTERN for the CPU baseline (one seeded map of a read against the whole allele
+ * index, base-level alignment of the best chains only).  It is pinned on the same reference-held cases as osp_wfa
+ * (tests/test_oracle_mm2.py) and against a brute-force Gotoh DP; beyond them it is, like every statement of
+ * minimap2 made without its sources, unpinned.
+ */
+#ifndef MM2_ORACLE_H
+#define MM2_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t k, w;                          /* 19, 19 */
+    int32_t a, b, q, e, q2, e2, sc_ambi;   /* 1, 4, 6, 2, 26, 1, 1 */
+    int32_t zdrop, zdrop_inv, end_bonus;   /* 400, 200, -1 */
+    int32_t bw, max_gap;                   /* 500, 10000 */
+    int32_t min_cnt, min_chain_score;      /* 3, 40 */
+    int32_t max_chain_skip, max_chain_iter;/* 25, 5000 */
+    float   chain_gap_scale;               /* 0.8 */
+    float   mask_level, pri_ratio;         /* 0.5, 0.8 */
+    int32_t best_n;                        /* 5 */
+    int32_t min_dp_max, min_ksw_len;       /* 200, 200 */
+    int32_t min_mid_occ, max_mid_occ, max_max_occ, occ_dist;   /* 50, 500, 4095, 500 */
+    float   mid_occ_frac;                  /* 2e-4 */
+    int32_t forward_only;                  /* 0: both strands (minimap2); 1: skip the reverse strand (faster audits) */
+} omm_opts;
+
+typedef struct {
+    int32_t rid, rev;                      /* target sequence; 1 = query's reverse complement aligned */
+    int32_t q_start, q_end, q_len;         /* on the query as given (forward coordinates, as minimap2 reports) */
+    int32_t t_start, t_end, t_len;
+    int32_t nm, mlen, blen, n_ambi;        /* NM = blen - mlen + n_ambi */
+    int32_t dp_score, dp_max, chain_score, n_seeds;
+    int32_t primary;                       /* 1 = primary, 0 = secondary */
+    int32_t n_cigar, cigar_off;            /* ops (len<<4|op; 7 '=', 8 'X', 1 'I', 2 'D') at cigar_pool[cigar_off..] */
+} omm_hit;
+
+typedef struct omm_index omm_index;
+
+void omm_default_opts(omm_opts* o);        /* map-hifi + with_cigar + best_n 5 */
+
+/* codes: A=0 C=1 G=2 T=3, anything else 4; offsets[n_seqs+1] into codes */
+omm_index* omm_index_build(const uint8_t* codes, const int64_t* offsets, int32_t n_seqs, const omm_opts* o);
+void       omm_index_free(omm_index* idx);
+int32_t    omm_index_mid_occ(const omm_index* idx);
+int64_t    omm_index_n_minimizers(const omm_index* idx);
+
+/* Aligner::map: hits in minimap2's output order (primary first, then by peak DP score); returns the number written
+ * (<= max_hits); cigar_pool may be NULL */
+int32_t omm_map(const omm_index* idx, const uint8_t* q, int32_t qlen, const omm_opts* o,
+                omm_hit* hits, int32_t max_hits, uint32_t* cigar_pool, int32_t cigar_cap);
+
+/* `aligner.with_seq(target)` + `.map(query)` in one call */
+int32_t omm_map_pair(const uint8_t* target, int32_t tlen, const uint8_t* q, int32_t qlen, const omm_opts* o,
+                     omm_hit* hits, int32_t max_hits, uint32_t* cigar_pool, int32_t cigar_cap);
+
+/* the DP alone (tests): mode 0 = global, 1 = extension from (0,0) ending at the best cell.  out8 = {score, max,
+ * max_t, max_q, zdropped, reach_end, t_end, q_end}; cigar ops written to cigar (cap entries), *n_cigar set */
+void omm_dp(const uint8_t* t, int32_t tlen, const uint8_t* q, int32_t qlen, const omm_opts* o, int32_t band,
+            int32_t mode, int32_t right_align, int32_t* out8, uint32_t* cigar, int32_t cap, int32_t* n_cigar);
+
+/* brute-force two-piece affine global score (O(mn) Gotoh with five states), for the tests */
+int32_t omm_global_score_bruteforce(const uint8_t* t, int32_t tlen, const uint8_t* q, int32_t qlen, const omm_opts* o);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

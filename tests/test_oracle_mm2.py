@@ -1,0 +1,201 @@
+"""The minimap2 restatement of the oracle (oracle/mm2.c) -- the "second opinion" on the base-level aligner.
+
+Pinned here: (1) its DP against a brute-force two-piece affine alignment; (2) the cases the reference's own tests hold for
+`Aligner::map`: identical sequence => (len, 0, 0) over the full span (`test_reference_alleles`,
+/root/reference/src/hla/caller.rs:1710-1773), a 4-base read => no mapping (`test_score_bad_read`, :1784-1809), one mismatch ranks
+strictly worse and N mismatches everything (`test_weight_sequence`, /root/reference/src/cyp2d6/chaining.rs:1051-1080); (3) the documented
+behaviours that distinguish it from the library's unit-cost contract: end clipping at a = 1 and its absence at a = 5
+(/root/reference/src/hla/caller.rs:1370-1379), z-drop, strand."""
+import numpy as np
+import pytest
+
+import mm2_ffi
+
+
+@pytest.fixture(scope="module")
+def mm():
+    return mm2_ffi.Mm2()
+
+
+def rnd(rng, n):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+
+def mutate(rng, s, n_sub=0, n_ins=0, n_del=0, lo=0, hi=None):
+    s = list(s)
+    hi = len(s) if hi is None else hi
+    for _ in range(n_sub):
+        p = int(rng.integers(lo, hi))
+        s[p] = "ACGT"[("ACGT".index(s[p]) + 1 + int(rng.integers(0, 3))) % 4]
+    for _ in range(n_ins):
+        p = int(rng.integers(lo, hi))
+        s.insert(p, "ACGT"[int(rng.integers(0, 4))])
+    for _ in range(n_del):
+        p = int(rng.integers(lo, min(hi, len(s))))
+        del s[p]
+    return "".join(s)
+
+
+def rescore(cigar, t, q, o):
+    i = j = sc = 0
+    for ln, op in cigar:
+        if op in "M=X":
+            for x in range(ln):
+                a, b = t[i + x], q[j + x]
+                sc += -o.sc_ambi if "N" in (a, b) else (o.a if a == b else -o.b)
+            i += ln
+            j += ln
+        else:
+            sc -= min(o.q + ln * o.e, o.q2 + ln * o.e2)
+            if op == "I":
+                j += ln
+            else:
+                i += ln
+    return sc, i, j
+
+
+def revcomp(s):
+    return s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+
+
+def test_global_dp_equals_bruteforce(mm):
+    rng = np.random.default_rng(11)
+    o = mm.opts()
+    for case in range(300):
+        n = int(rng.integers(1, 70))
+        t = rnd(rng, n)
+        q = mutate(rng, t, n_sub=int(rng.integers(0, 4)), n_ins=int(rng.integers(0, 3)), n_del=int(rng.integers(0, 3)))
+        if case % 5 == 0 and n > 45:                    # a long gap: the second affine piece (26 + l) is the cheaper one beyond 20 bases
+            p = int(rng.integers(5, n - 40))
+            q = t[:p] + t[p + int(rng.integers(21, 35)):]
+        if case % 7 == 0:
+            q = q[:len(q) // 2] + "N" + q[len(q) // 2 + 1:]
+        if not q:
+            q = "A"
+        r = mm.dp(t, q, o, band=200, mode=0)
+        assert r["score"] == mm.brute(t, q, o), (t, q)
+        sc, i, j = rescore(r["cigar"], t, q, o)
+        assert (sc, i, j) == (r["score"], len(t), len(q))
+
+
+def test_global_dp_with_match_score_5(mm):
+    rng = np.random.default_rng(12)
+    o = mm.opts(a=5)
+    for _ in range(100):
+        t = rnd(rng, int(rng.integers(10, 60)))
+        q = mutate(rng, t, 2, 1, 1)
+        r = mm.dp(t, q, o, band=200, mode=0)
+        assert r["score"] == mm.brute(t, q, o)
+        assert rescore(r["cigar"], t, q, o) == (r["score"], len(t), len(q))
+
+
+def test_extension_ends_at_the_best_cell_and_clips_a_near_end_mismatch(mm):
+    rng = np.random.default_rng(13)
+    t = rnd(rng, 120)
+    r = mm.dp(t, t, mm.opts(), mode=1)
+    assert (r["max"], r["t_end"], r["q_end"]) == (120, 120, 120) and r["cigar"] == [(120, "M")]
+    q = t[:117] + ("A" if t[117] != "A" else "C") + t[118:]            # a mismatch three bases before the end: +2 - 4 < 0
+    r = mm.dp(t, q, mm.opts(), mode=1)
+    assert (r["max"], r["t_end"], r["q_end"]) == (117, 117, 117)
+    r = mm.dp(t, q, mm.opts(a=5), mode=1)                               # a = 5 (score_read): 2 * 5 - 4 > 0, no clipping
+    assert (r["t_end"], r["q_end"]) == (120, 120) and r["max"] == 5 * 119 - 4
+    q = t[:110] + ("A" if t[110] != "A" else "C") + t[111:]            # nine matches behind the mismatch pay for it
+    r = mm.dp(t, q, mm.opts(), mode=1)
+    assert (r["t_end"], r["q_end"]) == (120, 120) and r["max"] == 119 - 4
+
+
+def test_extension_z_drop(mm):
+    rng = np.random.default_rng(14)
+    head = rnd(rng, 300)
+    t = head + rnd(rng, 1500)
+    q = head + rnd(rng, 1500)                                            # unrelated tails: the score falls by > 400 and the extension stops
+    r = mm.dp(t, q, mm.opts(), mode=1, band=751)
+    assert r["zdropped"] == 1 and 300 <= r["t_end"] <= 330 and r["max"] >= 300
+    r = mm.dp(t, q, mm.opts(zdrop=-1), mode=1, band=751)
+    assert r["zdropped"] == 0
+
+
+def test_reference_pinned_cases(mm):
+    rng = np.random.default_rng(15)
+    allele = rnd(rng, 3200)
+    h = mm.map_pair(allele, allele)
+    assert len(h) == 1
+    h = h[0]
+    assert (h["nm"], h["q_start"], h["q_end"], h["t_start"], h["t_end"], h["rev"], h["primary"]) == (0, 0, 3200, 0, 3200, 0, 1)
+    assert h["cigar"] == [(3200, "=")]
+    assert mm.map_pair(allele, "ACGT") == []                             # test_score_bad_read: no seed, no mapping
+    # test_weight_sequence: 218-base strings, one mismatch is strictly worse; N in the target: every candidate pays it alike
+    cons = [rnd(rng, 218)]
+    cons.append(cons[0][:100] + ("A" if cons[0][100] != "A" else "G") + cons[0][101:])
+    seg = cons[0]
+    hits = [mm.map_pair(seg, c) for c in cons]
+    assert [x[0]["nm"] for x in hits] == [0, 1]
+    seg_n = seg[:100] + "N" + seg[101:]
+    hits = [mm.map_pair(seg_n, c) for c in cons]
+    assert [x[0]["nm"] for x in hits] == [1, 1]
+    assert hits[0][0]["n_ambi"] == 1
+
+
+def test_mismatches_indels_and_nm(mm):
+    rng = np.random.default_rng(16)
+    for _ in range(20):
+        t = rnd(rng, 3000)
+        n_sub, n_ins, n_del = int(rng.integers(0, 10)), int(rng.integers(0, 5)), int(rng.integers(0, 5))
+        q = mutate(rng, t, n_sub, n_ins, n_del, lo=50, hi=2900)           # away from the ends: nothing to clip
+        h = mm.map_pair(t, q)
+        assert len(h) == 1
+        h = h[0]
+        assert h["nm"] <= n_sub + n_ins + n_del
+        assert (h["q_start"], h["q_end"], h["t_start"], h["t_end"]) == (0, len(q), 0, 3000)
+        cons_t = sum(ln for ln, op in h["cigar"] if op in "=XD")
+        cons_q = sum(ln for ln, op in h["cigar"] if op in "=XI")
+        assert (cons_t, cons_q) == (3000, len(q))
+        assert h["nm"] == sum(ln for ln, op in h["cigar"] if op in "XID")
+
+
+def test_end_clipping_shows_up_as_unmapped(mm):
+    rng = np.random.default_rng(17)
+    t = rnd(rng, 2000)
+    q = ("A" if t[0] != "A" else "C") + t[1:1997] + ("A" if t[1997] != "A" else "C") + t[1998:]
+    h = mm.map_pair(t, q)[0]
+    assert (h["q_start"], h["q_end"], h["nm"]) == (1, 1997, 0)            # both terminal mismatches are clipped away, not counted
+    h = mm.map_pair(t, q, mm.opts(a=5))[0]
+    assert (h["q_start"], h["q_end"], h["nm"]) == (1, 2000, 1)            # the first base still has nothing to gain (5 - 4 - ... the mismatch itself is the end)
+
+
+def test_read_in_flank_and_strand(mm):
+    rng = np.random.default_rng(18)
+    allele = rnd(rng, 3300)
+    read = rnd(rng, 2100) + mutate(rng, allele, 3, 1, 1, lo=100, hi=3000) + rnd(rng, 1800)
+    h = mm.map_pair(allele, read)
+    assert len(h) == 1 and h[0]["rev"] == 0
+    assert (h[0]["t_start"], h[0]["t_end"]) == (0, 3300) and h[0]["q_start"] == 2100 and h[0]["nm"] <= 5
+    h = mm.map_pair(allele, revcomp(read))
+    assert len(h) == 1 and h[0]["rev"] == 1 and (h[0]["t_start"], h[0]["t_end"]) == (0, 3300) and h[0]["nm"] <= 5
+    assert h[0]["q_end"] == len(read) - 2100                                # query coordinates are reported on the read as given
+    assert mm.map_pair(allele, revcomp(read), mm.opts(forward_only=1)) == []
+
+
+def test_divergent_stretch_splits_the_alignment(mm):
+    rng = np.random.default_rng(19)
+    a, b = rnd(rng, 1500), rnd(rng, 1500)
+    t = a + rnd(rng, 400) + b
+    q = a + rnd(rng, 400) + b                                            # 400 unrelated bases in the middle: 300 mismatches, z-drop
+    h = mm.map_pair(t, q)
+    assert len(h) == 2 and all(x["nm"] <= 12 for x in h)
+    spans = sorted((x["t_start"], x["t_end"]) for x in h)
+    assert spans[0][0] == 0 and 1500 <= spans[0][1] <= 1530 and 1870 <= spans[1][0] <= 1900 and spans[1][1] == 3400
+
+
+def test_index_of_many_alleles_picks_the_source(mm):
+    rng = np.random.default_rng(20)
+    base = rnd(rng, 3000)
+    alleles = [mutate(rng, base, n_sub=int(rng.integers(3, 25))) for _ in range(60)]
+    idx = mm2_ffi.Index(mm, alleles)
+    for src in (0, 17, 59):
+        read = rnd(rng, 900) + mutate(rng, alleles[src], 2, 1, 0, lo=200, hi=2800) + rnd(rng, 700)
+        hits = idx.map(read)
+        assert 1 <= len(hits) <= 6                                       # primary + at most best_n secondaries
+        best = min(hits, key=lambda h: (max(h["nm"], 0.1) / (h["t_end"] - h["t_start"]), h["rid"]))
+        assert best["rid"] == src or alleles[best["rid"]] == alleles[src]
+    idx.close()
