@@ -44,9 +44,13 @@ constexpr int CH = 32;          // lane of diagonal 0
 #define SP_K8_MIN_WAVES 1
 #endif
 constexpr int CWAVES = SP_K8_WAVES;      // waves per workgroup
-constexpr int CW = 64;          // bases per window (<= 64: one lane per window column in the control kernel)
+#ifndef SP_K8_CW
+#define SP_K8_CW 256
+#endif
+constexpr int CW = SP_K8_CW;    // bases per window (a multiple of 64: the control kernel walks a window 64 columns -- one per lane -- at a time)
+static_assert(CW % 64 == 0 && CW >= 64 && CW <= 512, "window length");
 constexpr int CWIN = 512;       // consensus bases in front of the window kept in LDS (offset_window + slack)
-constexpr int RWORDS = 28;      // packed read words a wave keeps in LDS (448 bases around its tips)
+constexpr int RWORDS = (2 * CW + 320) / 16;   // packed read words a wave keeps in LDS: band + window + lookahead + slack around its tips
 constexpr int NQ = 40;          // search nodes per problem: max_queue_size waiting + the children of one expansion + the complete one
 constexpr int MAXKIDS = 16;     // children of one expansion
 constexpr int CLUSTER = 16;     // workgroups whose vote words are summed by the last of them to finish
@@ -72,7 +76,9 @@ struct CNode {
     int32_t dual, split_at, stopped[2], len[2];
     int32_t n, a, q;            // the tape: n bases were pushed from T, the first a are verified, q are consumed
     int32_t have_out, la_valid; // the other slot holds the state at T + n; lookahead votes exist for that state / the state at T
-    long long cost[CW + 1];     // cost after j pushes from T
+    long long cost0;            // cost of the state at T
+    int32_t dc[CW + 1];         // cost after j pushes from T, minus cost0 (dc[0] = 0)
+    __device__ __forceinline__ long long cost_at(int j) const { return cost0 + (long long)dc[j]; }
     long long rest;             // what the unfinished reads add to the final cost (no early termination), for the state at T
     long long rest_out;         // the same for the state at T + n
     uint32_t ev[2][5];          // the complete votes at column T + a
@@ -622,8 +628,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
                     Dwfa& a = i ? d1 : d0; const Dwfa& o = i ? d0 : d1;
                     bool speaks = true;
                     if (dualrun && (o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < a.e) speaks = false;
-                    const int x = lane + 1;                                  // lane l names the vote after l + 1 of the m pushes
-                    if (speaks && x <= m) {
+                    if (speaks) for (int x = lane + 1; x <= m; x += SP_WAVE) {   // lane l names the votes after l + 1, l + 65, ... of the m pushes
                         const int pos = th + x;
                         if (pos < rv.n) { const int code = rb(pos); if (code < 4) atomicAdd(&lv[i][j + x], 12ull << (16 * code)); }
                         else if (!P.et) atomicAdd(&le[i][j + x], 12u);       // (with early termination the read is finished by that push)
@@ -662,9 +667,9 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             for (int cnt = 0; tips && cnt < 2; ++cnt) {
                 const int tl = __builtin_ctzll(tips); tips &= tips - 1;
                 const int h = __builtin_amdgcn_readlane(a.H, tl);
-                if (lane < CW - 1 && h + 1 + lane < rv.n) {
-                    const int b = rb(h + 1 + lane);
-                    if (b < 4) atomicAdd(&ll[i][lane], 1ull << (16 * b));
+                for (int x = lane; x < CW - 1 && h + 1 + x < rv.n; x += SP_WAVE) {
+                    const int b = rb(h + 1 + x);
+                    if (b < 4) atomicAdd(&ll[i][x], 1ull << (16 * b));
                 }
             }
         }
@@ -789,7 +794,15 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     const int tid = threadIdx.x;
     if (P.work->done) return;
     const long long tk0 = wall_clock64();
-    for (int x = tid; x < (int)(sizeof(CNode) * NQ / 4); x += blockDim.x) ((uint32_t*)nh)[x] = ((const uint32_t*)P.nodes)[x];
+    // only the nodes in use travel between memory and LDS (a node is 1.7 KB at 256-column windows; a linear search holds one or two)
+    __shared__ int was_used[NQ];
+    if (tid < NQ) { const int u = P.nodes[tid].used; was_used[tid] = u; if (!u) { nh[tid].used = 0; nh[tid].complete = 0; } }
+    __syncthreads();
+    constexpr int NODE_WORDS = (int)(sizeof(CNode) / 4);
+    for (int k = 0; k < NQ; ++k) {
+        if (!was_used[k]) continue;
+        for (int x = tid; x < NODE_WORDS; x += blockDim.x) ((uint32_t*)&nh[k])[x] = ((const uint32_t*)&P.nodes[k])[x];
+    }
     for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)&wk)[x] = ((const uint32_t*)P.work)[x];
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)&ss)[x] = ((const uint32_t*)P.srch)[x];
     const int proc_words = (P.cap + 2 + 3) / 4;
@@ -828,7 +841,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             if (lane == 0) {
                 x.used = 1; x.id = ss.next_id++; x.complete = 0; x.T = 0; x.cur = wk.in_slot; x.dual = 0; x.split_at = -1;
                 x.stopped[0] = 0; x.stopped[1] = 1; x.len[0] = x.len[1] = 0; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
-                x.cost[0] = 0; x.rest = sr[0]; x.rest_out = 0;
+                x.cost0 = 0; x.dc[0] = 0; x.rest = sr[0]; x.rest_out = 0;
             }
             if (lane < 10) x.ev[lane / 5][lane % 5] = sv[lane / 5][0][lane % 5];
             for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
@@ -837,32 +850,39 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             const int n = n_in, T = wk.T;
             int a = n;
             if (!wk.replay && n > 1) {
-                bool ok = true;
-                if (lane >= 1 && lane < n) {
+                for (int base = 0; base < n; base += SP_WAVE) {                  // 64 columns of the window at a time, one per lane
+                    const int col = base + lane;
+                    bool ok = true;
+                    if (col >= 1 && col < n) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        if (i == 1 && !x.dual) continue;
-                        if (!wk.go[i]) continue;
-                        int c4[4];
-                        const int nc = cands(sv[i][lane], T + lane, c4);
-                        if (nc != 1 || c4[0] != wk.spec[i][lane]) ok = false;     // a stop, a second candidate or another base: the tape ends there
+                        for (int i = 0; i < 2; ++i) {
+                            if (i == 1 && !x.dual) continue;
+                            if (!wk.go[i]) continue;
+                            int c4[4];
+                            const int nc = cands(sv[i][col], T + col, c4);
+                            if (nc != 1 || c4[0] != wk.spec[i][col]) ok = false;   // a stop, a second candidate or another base: the tape ends there
+                        }
                     }
+                    const unsigned long long bad = __ballot(!ok);
+                    if (bad) { a = base + __builtin_ctzll(bad); break; }
                 }
-                const unsigned long long bad = __ballot(!ok);
-                if (bad) a = __builtin_ctzll(bad);
             }
-            if (lane < a) {
+            for (int col = lane; col < a; col += SP_WAVE) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wk.go[i]) Cb[((size_t)wk.node * 2 + i) * P.cap + T + lane] = wk.spec[i][lane];
+                for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wk.go[i]) Cb[((size_t)wk.node * 2 + i) * P.cap + T + col] = wk.spec[i][col];
             }
             // a replay re-reads columns whose costs are on the tape already: it only brings the state (and the votes) of column T + a
             if (!wk.replay) {
-                long long c = lane < a ? (long long)sc[lane + 1] : 0;                     // lane l: push l + 1; inclusive prefix sum over the lanes
+                long long carry = 0;
+                for (int base = 0; base < a; base += SP_WAVE) {
+                    const int col = base + lane;
+                    long long c = col < a ? (long long)sc[col + 1] : 0;                   // push col + 1; inclusive prefix sum over the lanes
 #pragma unroll
-                for (int o = 1; o < SP_WAVE; o <<= 1) { const long long up = __shfl_up(c, o); if (lane >= o) c += up; }
-                const long long c0 = x.cost[0];
-                if (lane < a) x.cost[lane + 1] = c0 + c;
-                if (lane < n) { x.spec[0][lane] = wk.spec[0][lane]; x.spec[1][lane] = wk.spec[1][lane]; }
+                    for (int o = 1; o < SP_WAVE; o <<= 1) { const long long up = __shfl_up(c, o); if (lane >= o) c += up; }
+                    if (col < a) x.dc[col + 1] = (int32_t)(carry + c);
+                    carry += __shfl(c, SP_WAVE - 1);
+                }
+                for (int col = lane; col < n; col += SP_WAVE) { x.spec[0][col] = wk.spec[0][col]; x.spec[1][col] = wk.spec[1][col]; }
             }
             if (lane < 10) x.ev[lane / 5][lane % 5] = sv[lane / 5][a][lane % 5];
             if (lane == 0) {
@@ -890,7 +910,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                 }
                 if (!c.dual) c.stopped[1] = 1;
                 c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = 0;
-                c.cost[0] = par.cost[par.q] + (long long)sc[k]; c.rest = sr[k]; c.rest_out = 0;
+                c.cost0 = par.cost_at(par.q) + (long long)sc[k]; c.dc[0] = 0; c.rest = sr[k]; c.rest_out = 0;
                 for (int i = 0; i < 2; ++i) for (int bq = 0; bq < 5; ++bq) c.ev[i][bq] = sv[i][k][bq];
             }
             spw::wave_lds_sync();
@@ -906,7 +926,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                         ++waiting;
                         if (wi < 0) { wi = k; continue; }
                         const CNode& pp = nh[k]; const CNode& bb = nh[wi];
-                        const long long pcst = pp.cost[pp.q], bcst = bb.cost[bb.q]; const int pt = pp.T + pp.q, bt = bb.T + bb.q;
+                        const long long pcst = pp.cost_at(pp.q), bcst = bb.cost_at(bb.q); const int pt = pp.T + pp.q, bt = bb.T + bb.q;
                         if (pcst > bcst || (pcst == bcst && (pt < bt || (pt == bt && pp.id > bb.id)))) wi = k;
                     }
                     if (waiting <= ss.max_queue) break;
@@ -926,7 +946,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             if (xi < 0) {
                 // the best and the second best of the nodes that wait: lane k looks at node k
                 long long kc = 0x7FFFFFFFFFFFFFFFll; int kt = -1, kid = 0x7FFFFFFF, kx = -1;
-                if (lane < NQ && nh[lane].used && !nh[lane].complete) { const CNode& p = nh[lane]; kc = p.cost[p.q]; kt = p.T + p.q; kid = p.id; kx = lane; }
+                if (lane < NQ && nh[lane].used && !nh[lane].complete) { const CNode& p = nh[lane]; kc = p.cost_at(p.q); kt = p.T + p.q; kid = p.id; kx = lane; }
                 auto less = [](long long c1, int t1, int i1, long long c2, int t2, int i2) { return c1 < c2 || (c1 == c2 && (t1 > t2 || (t1 == t2 && i1 < i2))); };
                 long long bc = kc; int bt = kt, bid = kid, bx = kx;
 #pragma unroll
@@ -953,7 +973,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                 const int want = linear > 0 ? (linear < SP_WAVE ? linear : SP_WAVE) : 1;
                 bool can = lane < want && L + lane >= ss.threshold && proc[L + lane] < ss.per_size && lane <= jc;
                 if (can && lane > 0) {
-                    const long long cj = x.cost[q + lane];
+                    const long long cj = x.cost_at(q + lane);
                     can = (sx2 < 0 || less(cj, L + lane, ss.next_id + lane - 1, sc2, st2, sid2)) && !(ss.best_node >= 0 && cj >= ss.best_final);
                 }
                 const unsigned long long no = ~__ballot(can);
@@ -979,7 +999,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                     // its state at that column has to be there
                     if (x.q > 0 || x.n > 0) {
                         if (x.a == x.n && x.have_out) {                                    // the window stood: the other slot is the state
-                            x.T += x.n; x.cur ^= 1; x.cost[0] = x.cost[x.n]; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
+                            x.T += x.n; x.cur ^= 1; x.cost0 = x.cost_at(x.n); x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
                         } else {
                             // cut window: push the verified bases again from the kept state (nothing is speculated)
                             wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = x.a; wk.replay = 1;
@@ -998,7 +1018,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                         if (nc[i] == 0) { x.stopped[i] = 1; x.len[i] = L; }
                     }
                     if (nc[0] == 0 && nc[1] == 0) {                                        // complete
-                        const long long fc = x.cost[0] + (P.et ? 0 : x.rest);
+                        const long long fc = x.cost0 + (P.et ? 0 : x.rest);
                         if (ss.best_node < 0 || fc < ss.best_final) { if (ss.best_node >= 0) node_free(ss.best_node); ss.best_node = xi; ss.best_final = fc; x.complete = 1; }
                         else node_free(xi);
                         break;
@@ -1048,24 +1068,30 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         tk3 = wall_clock64();
         if (need_la >= 0) {
             const uint32_t* la = P.la + (size_t)need_la * 2 * CW * 4;
-            bool have = lane >= 1 && lane < CW && wk.T + lane < P.cap;
-            int pick[2] = { 0, 0 };
-            if (have) {
+            int nn = CW;
+            for (int base = 0; base < CW; base += SP_WAVE) {
+                const int col = base + lane;
+                bool have = col >= 1 && wk.T + col < P.cap;
+                int pick[2] = { 0, 0 };
+                if (have) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (!wk.go[i]) continue;
-                    const uint4 w = *reinterpret_cast<const uint4*>(la + ((size_t)i * CW + (lane - 1)) * 4);
-                    int b1 = 0; uint32_t w1 = w.x;
-                    if (w.y > w1) { b1 = 1; w1 = w.y; }
-                    if (w.z > w1) { b1 = 2; w1 = w.z; }
-                    if (w.w > w1) { b1 = 3; w1 = w.w; }
-                    if (w1 == 0) have = false;
-                    pick[i] = b1;
+                    for (int i = 0; i < 2; ++i) {
+                        if (!wk.go[i]) continue;
+                        const uint4 w = *reinterpret_cast<const uint4*>(la + ((size_t)i * CW + (col - 1)) * 4);
+                        int b1 = 0; uint32_t w1 = w.x;
+                        if (w.y > w1) { b1 = 1; w1 = w.y; }
+                        if (w.z > w1) { b1 = 2; w1 = w.z; }
+                        if (w.w > w1) { b1 = 3; w1 = w.w; }
+                        if (w1 == 0) have = false;
+                        pick[i] = b1;
+                    }
                 }
+                unsigned long long miss = __ballot(!have);
+                if (base == 0) miss &= ~1ull;                                  // column 0 is the exact base
+                const int first = miss ? __builtin_ctzll(miss) : SP_WAVE;
+                if (col >= 1 && lane < first) { wk.spec[0][col] = (uint8_t)pick[0]; wk.spec[1][col] = (uint8_t)pick[1]; }
+                if (miss) { nn = base + first; break; }
             }
-            const unsigned long long miss = __ballot(!have) & ~1ull;          // lane 0 is the exact base
-            const int nn = miss ? __builtin_ctzll(miss) : SP_WAVE;
-            if (lane >= 1 && lane < nn && lane < CW) { wk.spec[0][lane] = (uint8_t)pick[0]; wk.spec[1][lane] = (uint8_t)pick[1]; }
             if (lane == 0) wk.n = nn < CW ? nn : CW;
         }
     }
@@ -1087,7 +1113,10 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     }
     if (tid == 0) { const long long tk4 = wall_clock64(); ss.ticks[0] += tk1 - tk0; ss.ticks[1] += tk2 - tk1; ss.ticks[2] += tk3 - tk2; ss.ticks[3] += tk4 - tk3; }
     __syncthreads();
-    for (int x = tid; x < (int)(sizeof(CNode) * NQ / 4); x += blockDim.x) ((uint32_t*)P.nodes)[x] = ((const uint32_t*)nh)[x];
+    for (int k = 0; k < NQ; ++k) {
+        if (!was_used[k] && !nh[k].used) continue;
+        for (int x = tid; x < NODE_WORDS; x += blockDim.x) ((uint32_t*)&P.nodes[k])[x] = ((const uint32_t*)&nh[k])[x];
+    }
     for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)P.work)[x] = ((const uint32_t*)&wk)[x];
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)P.srch)[x] = ((const uint32_t*)&ss)[x];
     for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)P.processed)[x] = ((const uint32_t*)proc)[x];
@@ -1286,7 +1315,11 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
 
     const dim3 grid((uint32_t)n_blocks), block(CWAVES * SP_WAVE);
     const size_t proc_lds = ((size_t)max_cap + 2 + 15) & ~(size_t)15;
-    if (proc_lds > 96 * 1024) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must stay below 98,304");
+    {   // the control kernel's node table and vote sums are static LDS; the per-length counters come on top (160 KiB per workgroup on gfx950)
+        hipFuncAttributes fa;
+        SP_HIP_CHECK(ctx, hipFuncGetAttributes(&fa, (const void*)cons_control_kernel<MAXP>));
+        if (fa.sharedSizeBytes + proc_lds > 160 * 1024) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must stay below ~65,000");
+    }
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cons_control_kernel<MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)proc_lds));
     uint64_t pairs = 0;
     hm.mark("host:k8_prologue");
