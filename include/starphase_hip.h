@@ -71,6 +71,28 @@ int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value);
  * src/cyp2d6/chaining.rs:29-30).  bases: concatenated ASCII; offsets[n+1]: start of each sequence.
  * Packed on upload to 2 bits/base + an N plane; anything outside ACGT is 'N' and never matches. */
 int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets, uint32_t n, sp_seqset** out);
+/* The reads of a sample are new for every sample (the read loop of diplotype_hla_batch, src/hla/caller.rs:544-596, and of
+ * diplotype_cyp2d6, src/cyp2d6/caller.rs:96-139, hands every record's SEQ to the aligner): their way to the device is part of the
+ * path.  An upload stages the caller's bytes through pinned memory in chunks on a copy stream of the context (the copy of chunk k + 1
+ * into the staging ring runs under the DMA of chunk k) and packs them on the device.
+ *   format SP_SEQ_ASCII    one byte per base (any case; everything but ACGT is 'N'); offsets count bases = bytes
+ *          SP_SEQ_BAM4     BAM's SEQ field as stored (SAMv1 4.2: 4 bits per base, high nibble first, "=ACMGRSVTWYHKDBN", each read starting
+ *                          on a byte boundary): half the bytes of ASCII over PCIe; offsets[n + 1] count BYTES, lengths[n] bases
+ *          SP_SEQ_PACKED2  2 bits per base, four per byte (base b in bits 2 (b & 3) of byte b >> 2, A C G T = 0 1 2 3, no N), each
+ *                          sequence starting on a byte boundary: a quarter of the bytes; offsets count BYTES, lengths[n] bases
+ * lengths may be NULL for SP_SEQ_ASCII.  A sequence longer than 65,534 bases does not fail the call (one ultra-long read must not cost
+ * the sample): it enters the set with length 0, is never aligned, and sp_seqset_skipped counts it.
+ * sp_seqset_upload_async returns as soon as the set's tables exist; a worker thread of the library moves the bytes.  The caller's
+ * buffers must stay untouched and the set must not be used until sp_seqset_wait has returned SP_OK (it reports what the upload hit).
+ * One upload per context is in flight at a time (a second one waits for the first).  While it runs, the context's other calls
+ * proceed: the reads of sample i + 1 travel under the kernels of sample i. */
+#define SP_SEQ_ASCII   0
+#define SP_SEQ_BAM4    1
+#define SP_SEQ_PACKED2 2
+int32_t sp_seqset_upload_format(sp_ctx* ctx, int32_t format, const void* data, const uint64_t* offsets, const uint32_t* lengths, uint32_t n, sp_seqset** out);
+int32_t sp_seqset_upload_async(sp_ctx* ctx, int32_t format, const void* data, const uint64_t* offsets, const uint32_t* lengths, uint32_t n, sp_seqset** out);
+int32_t sp_seqset_wait(sp_seqset* set);
+int32_t sp_seqset_skipped(const sp_seqset* set, uint32_t* n_skipped);       /* sequences dropped for their length */
 void    sp_seqset_free(sp_seqset* set);
 int32_t sp_seqset_count(const sp_seqset* set, uint32_t* n);
 int32_t sp_seqset_length(const sp_seqset* set, uint32_t idx, uint32_t* len);
@@ -873,6 +895,9 @@ typedef struct {                                  /* one alignment record */
 int32_t sp_bam_fetch(sp_bam* bam, const char* chrom, uint64_t start, uint64_t end, uint32_t exclude_flags, int32_t dedupe,
                      const sp_bam_read** reads, uint32_t* n, const char** bases, const uint64_t** offsets);
 int32_t sp_bam_forget(sp_bam* bam);               /* empties the set of QNAMEs seen */
+/* the SEQ fields of the records of the last fetch exactly as the file stores them (4 bits per base, high nibble first, every read on a
+ * byte boundary): the arguments of sp_seqset_upload_format(ctx, SP_SEQ_BAM4, ...) -- half of what the ASCII form sends over PCIe */
+int32_t sp_bam_last_seq4(const sp_bam* bam, const uint8_t** seq4, const uint64_t** byte_offsets, const uint32_t** lengths, uint32_t* n);
 
 typedef struct sp_vcf sp_vcf;
 int32_t sp_vcf_open(const char* path, sp_vcf** out, char* err, uint32_t err_cap);

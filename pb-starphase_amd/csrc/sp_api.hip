@@ -42,10 +42,13 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
     return SP_OK;
 }
 
+static int32_t upload_finish(sp_seqset* s);
 void sp_ctx_destroy(sp_ctx* ctx) {
     if (!ctx) return;
     for (sp_ctx*& h : ctx->helper) if (h) { sp_ctx_destroy(h); h = nullptr; }
     hipSetDevice(ctx->device);
+    if (ctx->uploading) (void)upload_finish(ctx->uploading);
+    if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     for (auto& kv : ctx->pool) if (kv.second.first) hipFree(kv.second.first);
@@ -128,73 +131,155 @@ int32_t sp_profile_get(sp_ctx* ctx, const char* kernel, double* total_ms, uint64
 
 // ------------------------------------------------------------------ sequence sets
 
-int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets, uint32_t n, sp_seqset** out) {
-    if (!ctx || !out || (n && (!bases || !offsets))) return SP_ERR_INVALID_ARG;
+// An upload under way: everything the worker thread needs, owned by the set until sp_seqset_wait joins the thread
+struct sp_upload {
+    std::thread th;
+    int32_t rc = SP_OK; std::string err;
+    int format = SP_SEQ_ASCII;
+    const uint8_t* src = nullptr; uint64_t src_bytes = 0;
+    std::vector<uint64_t> rel;                  // n + 1 offsets into the staged bytes
+    uint8_t* d_stage = nullptr; uint64_t* d_off = nullptr; uint32_t* d_flag = nullptr;   // device staging (the context's pools)
+    uint8_t* ring = nullptr; size_t chunk = 0; int slots = 0;                             // pinned staging ring (the context's)
+    hipEvent_t slot_ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    size_t wbytes = 0;
+};
+
+static constexpr size_t UPLOAD_CHUNK = (size_t)8 << 20;
+static constexpr int UPLOAD_SLOTS = 4;
+
+// the worker: tables, then the payload chunk by chunk through the pinned ring, then the packing kernel(s); ends when the set is complete
+static void upload_run(sp_seqset* s) {
+    sp_upload* u = s->up; sp_ctx* ctx = s->ctx;
+    hipStream_t st = ctx->copy_stream;
+    auto bad = [&](hipError_t e, const char* what) { if (e != hipSuccess && u->rc == SP_OK) { u->rc = SP_ERR_HIP; u->err = std::string(what) + ": " + hipGetErrorString(e); } return e != hipSuccess; };
+    if (bad(hipSetDevice(ctx->device), "hipSetDevice")) return;
+    const uint32_t n = s->n;
+    bad(hipMemcpyAsync(s->d_word_off, s->h_word_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st), "offsets");
+    if (n) bad(hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st), "lengths");
+    bad(hipMemsetAsync(s->d_words, 0, u->wbytes, st), "clear");
+    if (u->src_bytes && u->rc == SP_OK) {
+        bad(hipMemcpyAsync(u->d_off, u->rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st), "staged offsets");
+        bad(hipMemsetAsync(u->d_flag, 0, 4, st), "flag");
+        int k = 0;
+        for (uint64_t at = 0; at < u->src_bytes && u->rc == SP_OK; at += u->chunk, ++k) {
+            const int slot = k % u->slots;
+            const size_t len = (size_t)std::min<uint64_t>(u->chunk, u->src_bytes - at);
+            if (k >= u->slots && bad(hipEventSynchronize(u->slot_ev[slot]), "staging slot")) break;     // the DMA that last read this slot
+            std::memcpy(u->ring + (size_t)slot * u->chunk, u->src + at, len);
+            if (bad(hipMemcpyAsync(u->d_stage + at, u->ring + (size_t)slot * u->chunk, len, hipMemcpyHostToDevice, st), "payload")) break;
+            bad(hipEventRecord(u->slot_ev[slot], st), "staging event");
+        }
+        if (u->rc == SP_OK && sp_launch_pack_on(st, ctx->num_cus, u->format, u->d_stage, u->d_off, s->d_word_off, s->d_len, n, s->d_words, nullptr, u->d_flag) != SP_OK) { u->rc = SP_ERR_HIP; u->err = "pack kernel launch"; }
+        uint32_t flag = 0;
+        if (u->rc == SP_OK && u->format != SP_SEQ_PACKED2) {
+            bad(hipMemcpyAsync(&flag, u->d_flag, 4, hipMemcpyDeviceToHost, st), "flag read");
+            bad(hipStreamSynchronize(st), "upload");
+            if (u->rc == SP_OK && flag) {
+                s->has_n = true;
+                if (hipMalloc(&s->d_nplane, u->wbytes) != hipSuccess) { u->rc = SP_ERR_OUT_OF_MEMORY; u->err = "seqset nplane"; }
+                else {
+                    bad(hipMemsetAsync(s->d_nplane, 0, u->wbytes, st), "clear N plane");
+                    if (sp_launch_pack_on(st, ctx->num_cus, u->format, u->d_stage, u->d_off, s->d_word_off, s->d_len, n, nullptr, s->d_nplane, u->d_flag) != SP_OK) { u->rc = SP_ERR_HIP; u->err = "pack kernel launch"; }
+                }
+            }
+        }
+    }
+    bad(hipStreamSynchronize(st), "upload");
+}
+
+static int32_t upload_finish(sp_seqset* s) {
+    sp_upload* u = s->up;
+    if (!u) return s->up_rc == SP_OK ? SP_OK : sp_fail(s->ctx, s->up_rc, "seqset upload: " + s->up_err);     // (ended earlier: a later upload of the context waited for it)
+    if (u->th.joinable()) u->th.join();
+    sp_ctx* ctx = s->ctx;
+    if (ctx->uploading == s) ctx->uploading = nullptr;
+    s->up_rc = u->rc; s->up_err = u->err;
+    for (hipEvent_t e : u->slot_ev) if (e) hipEventDestroy(e);
+    delete u; s->up = nullptr;
+    return s->up_rc == SP_OK ? SP_OK : sp_fail(ctx, s->up_rc, "seqset upload: " + s->up_err);
+}
+
+static int32_t upload_start(sp_ctx* ctx, int32_t format, const void* data, const uint64_t* offsets, const uint32_t* lengths, uint32_t n, sp_seqset** out) {
+    if (!ctx || !out || (n && (!data || !offsets)) || format < SP_SEQ_ASCII || format > SP_SEQ_PACKED2 || (format != SP_SEQ_ASCII && n && !lengths)) return SP_ERR_INVALID_ARG;
     *out = nullptr;
     hipSetDevice(ctx->device);
+    if (ctx->uploading) (void)upload_finish(ctx->uploading);      // (how it ended stays in that set: its own sp_seqset_wait reports it)
     sp_seqset* s = new (std::nothrow) sp_seqset();
     if (!s) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seqset");
     s->ctx = ctx; s->n = n;
     s->h_len.resize(n); s->h_word_off.resize((size_t)n + 1);
     uint64_t total_words = 0;
+    const uint64_t per_byte = format == SP_SEQ_ASCII ? 1 : format == SP_SEQ_BAM4 ? 2 : 4;
     for (uint32_t i = 0; i < n; ++i) {
-        uint64_t len = offsets[i + 1] - offsets[i];
-        if (offsets[i + 1] < offsets[i] || len > 65534) { delete s; return sp_fail(ctx, SP_ERR_TOO_LONG, "seqset: sequence longer than 65,534 bases"); }
+        if (offsets[i + 1] < offsets[i]) { delete s; return sp_fail(ctx, SP_ERR_INVALID_ARG, "seqset: offsets must not decrease"); }
+        const uint64_t bytes = offsets[i + 1] - offsets[i];
+        uint64_t len = lengths ? lengths[i] : bytes;
+        if (len > bytes * per_byte) { delete s; return sp_fail(ctx, SP_ERR_INVALID_ARG, "seqset: a sequence is longer than its bytes"); }
+        if (len > 65534) { len = 0; s->n_skipped += 1; }          // an over-long sequence is left out of every alignment instead of failing the sample
         s->h_len[i] = (int32_t)len;
         s->max_len = std::max<int32_t>(s->max_len, (int32_t)len);
         s->h_word_off[i] = total_words;
-        uint64_t w = (len + 15) / 16 + 2;          // data + 2 guard words
-        total_words += (w + 3) & ~3ull;            // 16-byte aligned starts
+        const uint64_t w = (len + 15) / 16 + 2;     // data + 2 guard words
+        total_words += (w + 3) & ~3ull;             // 16-byte aligned starts
     }
     s->h_word_off[n] = total_words;
     auto fail = [&](const char* what) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, what); };
-    // any HIP error from here on frees the half-built set before it is reported
-    hipError_t herr = hipSuccess;
-    auto ok = [&](hipError_t e) { if (e != hipSuccess && herr == hipSuccess) herr = e; return e == hipSuccess; };
-    auto hip_fail = [&](const char* what) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(herr)); };
     const size_t wbytes = (total_words + SP_SEQ_PAD_WORDS) * sizeof(uint32_t);
     if (hipMalloc(&s->d_words, wbytes) != hipSuccess) return fail("seqset words");
     if (hipMalloc(&s->d_word_off, ((size_t)n + 1) * sizeof(uint64_t)) != hipSuccess) return fail("seqset offsets");
     if (hipMalloc(&s->d_len, std::max<size_t>(1, n) * sizeof(int32_t)) != hipSuccess) return fail("seqset lengths");
-    ok(hipMemcpyAsync(s->d_word_off, s->h_word_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    if (n) ok(hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    ok(hipMemsetAsync(s->d_words, 0, wbytes, ctx->stream));
-    if (herr != hipSuccess) return hip_fail("seqset upload");
-    const uint64_t n_bases = n ? offsets[n] - offsets[0] : 0;
-    if (n_bases) {
-        // the ASCII bases go over PCIe once and are packed to 2 bits/base on the device (sp_pack_kernel)
-        char* d_ascii = (char*)sp_pool(ctx, "upload_ascii", n_bases);
-        uint64_t* d_off = (uint64_t*)sp_pool(ctx, "upload_off", ((size_t)n + 1) * 8);
-        uint32_t* d_flag = (uint32_t*)sp_pool(ctx, "upload_flag", 4);
-        if (!d_ascii || !d_off || !d_flag) return fail("seqset staging");
-        std::vector<uint64_t> rel((size_t)n + 1);
-        for (uint32_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
-        ok(hipMemcpyAsync(d_ascii, bases + offsets[0], n_bases, hipMemcpyHostToDevice, ctx->stream));
-        ok(hipMemcpyAsync(d_off, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        ok(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
-        sp_launch_pack(ctx, d_ascii, d_off, s->d_word_off, s->d_len, n, s->d_words, nullptr, d_flag);
-        ok(hipGetLastError());
-        uint32_t flag = 0;
-        ok(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-        ok(hipStreamSynchronize(ctx->stream));          // rel / flag are read by the copies above: wait before they go out of scope
-        if (herr != hipSuccess) return hip_fail("seqset pack");
-        if (flag) {
-            s->has_n = true;
-            if (hipMalloc(&s->d_nplane, wbytes) != hipSuccess) return fail("seqset nplane");
-            ok(hipMemsetAsync(s->d_nplane, 0, wbytes, ctx->stream));
-            sp_launch_pack(ctx, d_ascii, d_off, s->d_word_off, s->d_len, n, nullptr, s->d_nplane, d_flag);
-            ok(hipGetLastError());
-        }
+    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_HIP, "copy stream"); }
+    sp_upload* u = new (std::nothrow) sp_upload();
+    if (!u) return fail("seqset upload");
+    s->up = u; u->format = format; u->wbytes = wbytes;
+    const uint64_t src_bytes = n ? offsets[n] - offsets[0] : 0;
+    u->src = (const uint8_t*)data + (n ? offsets[0] : 0); u->src_bytes = src_bytes;
+    if (src_bytes) {
+        u->rel.resize((size_t)n + 1);
+        for (uint32_t i = 0; i <= n; ++i) u->rel[i] = offsets[i] - offsets[0];
+        u->chunk = std::min<size_t>(UPLOAD_CHUNK, (size_t)((src_bytes + 4095) & ~4095ull));
+        u->slots = UPLOAD_SLOTS;
+        u->d_stage = (uint8_t*)sp_pool(ctx, "upload_ascii", src_bytes);
+        u->d_off = (uint64_t*)sp_pool(ctx, "upload_off", ((size_t)n + 1) * 8);
+        u->d_flag = (uint32_t*)sp_pool(ctx, "upload_flag", 4);
+        u->ring = (uint8_t*)sp_host_pool(ctx, "upload_ring", UPLOAD_CHUNK * UPLOAD_SLOTS);
+        if (!u->d_stage || !u->d_off || !u->d_flag || !u->ring) return fail("seqset staging");
+        for (int k = 0; k < u->slots; ++k) if (hipEventCreateWithFlags(&u->slot_ev[k], hipEventDisableTiming) != hipSuccess) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_HIP, "staging events"); }
     }
-    ok(hipStreamSynchronize(ctx->stream));
-    if (herr != hipSuccess) return hip_fail("seqset upload");
+    ctx->uploading = s;
+    try { u->th = std::thread(upload_run, s); }
+    catch (...) { ctx->uploading = nullptr; sp_seqset_free(s); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seqset upload thread"); }
     *out = s;
     return SP_OK;
 }
 
+int32_t sp_seqset_upload_async(sp_ctx* ctx, int32_t format, const void* data, const uint64_t* offsets, const uint32_t* lengths, uint32_t n, sp_seqset** out) {
+    return upload_start(ctx, format, data, offsets, lengths, n, out);
+}
+
+int32_t sp_seqset_wait(sp_seqset* s) {
+    if (!s) return SP_ERR_INVALID_ARG;
+    return upload_finish(s);
+}
+
+int32_t sp_seqset_upload_format(sp_ctx* ctx, int32_t format, const void* data, const uint64_t* offsets, const uint32_t* lengths, uint32_t n, sp_seqset** out) {
+    const int32_t rc = upload_start(ctx, format, data, offsets, lengths, n, out);
+    if (rc != SP_OK) return rc;
+    const int32_t rc2 = upload_finish(*out);
+    if (rc2 != SP_OK) { sp_seqset_free(*out); *out = nullptr; }
+    return rc2;
+}
+
+int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets, uint32_t n, sp_seqset** out) {
+    return sp_seqset_upload_format(ctx, SP_SEQ_ASCII, bases, offsets, nullptr, n, out);
+}
+
+int32_t sp_seqset_skipped(const sp_seqset* s, uint32_t* n_skipped) { if (!s || !n_skipped) return SP_ERR_INVALID_ARG; *n_skipped = s->n_skipped; return SP_OK; }
+
 void sp_seqset_free(sp_seqset* s) {
     if (!s) return;
     if (s->ctx) hipSetDevice(s->ctx->device);
+    if (s->up) { (void)upload_finish(s); }                        // an upload still under way ends first
     if (s->d_words) hipFree(s->d_words);
     if (s->d_nplane) hipFree(s->d_nplane);
     if (s->d_word_off) hipFree(s->d_word_off);

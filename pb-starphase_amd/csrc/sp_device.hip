@@ -337,12 +337,61 @@ __global__ __launch_bounds__(256) void sp_pack_kernel(const char* __restrict__ a
     }
 }
 
+// BAM's SEQ field as stored (SAMv1 4.2: two bases per byte, high nibble first, "=ACMGRSVTWYHKDBN"; every sequence starts on a byte):
+// 1 / 2 / 4 / 8 are A / C / G / T, every other code is 'N'.  One thread per output dword = 8 input bytes.
+__global__ __launch_bounds__(256) void sp_pack4_kernel(const uint8_t* __restrict__ seq4, const uint64_t* __restrict__ off, const uint64_t* __restrict__ word_off,
+                                                       const int32_t* __restrict__ len, uint32_t n, uint32_t* __restrict__ words, uint32_t* __restrict__ nplane,
+                                                       uint32_t* __restrict__ flag) {
+    for (uint32_t s = blockIdx.x; s < n; s += gridDim.x) {
+        const int L = len[s]; const uint8_t* src = seq4 + off[s];
+        const int nw = (L + 15) >> 4;
+        for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+            uint32_t word = 0, nw_bits = 0;
+            const int b0 = w << 4, b1 = b0 + 16 < L ? b0 + 16 : L;
+            for (int b = b0; b < b1; ++b) {
+                const uint32_t nib = (src[b >> 1] >> ((b & 1) ? 0 : 4)) & 0xFu;
+                uint32_t c = 0;
+                if (nib == 1) c = 0; else if (nib == 2) c = 1; else if (nib == 4) c = 2; else if (nib == 8) c = 3; else nw_bits |= 1u << ((b & 15) << 1);
+                word |= c << ((b & 15) << 1);
+            }
+            if (words) words[word_off[s] + w] = word;
+            if (nplane) nplane[word_off[s] + w] = nw_bits;
+            if (nw_bits && flag) atomicOr(flag, 1u);
+        }
+    }
+}
+
+// 2 bits per base already (four bases per byte, base b in bits 2 (b & 3) of byte b >> 2, every sequence starts on a byte, A C G T only):
+// a dword of the set is four input bytes, little end first; only the starts move (16-byte aligned in the set) and the tail is masked
+__global__ __launch_bounds__(256) void sp_pack2_kernel(const uint8_t* __restrict__ seq2, const uint64_t* __restrict__ off, const uint64_t* __restrict__ word_off,
+                                                       const int32_t* __restrict__ len, uint32_t n, uint32_t* __restrict__ words) {
+    for (uint32_t s = blockIdx.x; s < n; s += gridDim.x) {
+        const int L = len[s]; const uint8_t* src = seq2 + off[s];
+        const int nw = (L + 15) >> 4, nbytes = (L + 3) >> 2;
+        for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+            uint32_t word = 0;
+            for (int k = 0; k < 4; ++k) { const int y = 4 * w + k; if (y < nbytes) word |= (uint32_t)src[y] << (8 * k); }
+            const int left = L - (w << 4);
+            if (left < 16) word &= (1u << (2 * left)) - 1u;
+            words[word_off[s] + w] = word;
+        }
+    }
+}
+
+int sp_launch_pack_on(hipStream_t stream, int num_cus, int format, const void* d_src, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
+                      uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag) {
+    if (n == 0) return SP_OK;
+    const unsigned grid = std::min<unsigned>(n, (unsigned)num_cus * 16);
+    if (format == SP_SEQ_ASCII) hipLaunchKernelGGL(sp_pack_kernel, dim3(grid), dim3(256), 0, stream, (const char*)d_src, d_off, d_word_off, d_len, n, d_words, d_nplane, d_flag);
+    else if (format == SP_SEQ_BAM4) hipLaunchKernelGGL(sp_pack4_kernel, dim3(grid), dim3(256), 0, stream, (const uint8_t*)d_src, d_off, d_word_off, d_len, n, d_words, d_nplane, d_flag);
+    else if (d_words) hipLaunchKernelGGL(sp_pack2_kernel, dim3(grid), dim3(256), 0, stream, (const uint8_t*)d_src, d_off, d_word_off, d_len, n, d_words);
+    return hipGetLastError() == hipSuccess ? SP_OK : SP_ERR_HIP;
+}
+
 int sp_launch_pack(sp_ctx* ctx, const char* d_ascii, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
                    uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag) {
-    if (n == 0) return SP_OK;
-    const unsigned grid = std::min<unsigned>(n, (unsigned)ctx->num_cus * 16);
-    hipLaunchKernelGGL(sp_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_ascii, d_off, d_word_off, d_len, n, d_words, d_nplane, d_flag);
-    SP_HIP_CHECK(ctx, hipGetLastError());
+    if (sp_launch_pack_on(ctx->stream, ctx->num_cus, SP_SEQ_ASCII, d_ascii, d_off, d_word_off, d_len, n, d_words, d_nplane, d_flag) != SP_OK)
+        return sp_fail(ctx, SP_ERR_HIP, "pack kernel launch");
     return SP_OK;
 }
 

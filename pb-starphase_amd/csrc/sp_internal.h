@@ -49,6 +49,9 @@ struct sp_seqset {
     uint64_t* d_word_off = nullptr;
     int32_t*  d_len = nullptr;
     int32_t   max_len = 0;
+    uint32_t  n_skipped = 0;           // sequences longer than 65,534 bases: kept as empty entries
+    struct sp_upload* up = nullptr;    // an upload that is still under way (sp_seqset_upload_async); sp_seqset_wait ends it
+    int32_t up_rc = 0; std::string up_err;   // how it ended
     // lazily built k-mer index
     bool has_index = false;
     uint32_t* d_kcode = nullptr; int32_t* d_kpos = nullptr; uint64_t* d_koff = nullptr;
@@ -78,6 +81,8 @@ struct sp_ctx {
     int num_cus = 256;
     bool split_genes = true;         // sp_ctx_set_option "hla_split_genes"
     int split_streams = 3;           // sp_ctx_set_option "hla_split_streams": streams the units of a call are spread over (1..4; a 32-sample cohort call: 71.5 / 58.4 / 54.9 / 68.6 ms)
+    hipStream_t copy_stream = nullptr;   // uploads travel on a stream of their own, beside the kernels of ctx->stream
+    sp_seqset* uploading = nullptr;      // the one upload a context has in flight (the staging buffers are the context's)
     sp_ctx* helper[3] = { nullptr, nullptr, nullptr };   // further contexts on the same device (own stream, pools, events) for work that runs beside this one's; made on first use
 };
 
@@ -112,6 +117,8 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     const CellDesc* d_cells, uint64_t n_cells,
                     sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, int retry_wide = 0);   // 0 never, 1 lost cells, 2 lost cells and cells with > 32 edits (few-cell callers)
 
+int sp_launch_pack_on(hipStream_t stream, int num_cus, int format, const void* d_src, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
+                      uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag);   // format: SP_SEQ_ASCII / SP_SEQ_BAM4 / SP_SEQ_PACKED2
 int sp_launch_pack(sp_ctx* ctx, const char* d_ascii, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
                    uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag);
 int sp_make_segments(sp_ctx* ctx, const sp_seqset* reads, const std::vector<uint32_t>& idx, const std::vector<int32_t>& start,

@@ -6,6 +6,8 @@
 // htslib.  Outputs are the library's own inputs: ASCII bases + offsets for sp_seqset_upload, sp_vcf_allele / sp_vcf_deletion rows for
 // sp_variant_gene_problem.
 #include "sp_internal.h"
+#include <atomic>
+#include <thread>
 #include <zlib.h>
 #include <algorithm>
 #include <cstdio>
@@ -24,19 +26,24 @@ void put_err(char* err, uint32_t cap, const std::string& m) { if (err && cap) { 
 // (file offset of the block << 16) | offset inside the inflated block
 struct Bgzf {
     FILE* f = nullptr;
-    std::vector<uint8_t> raw, block;
-    uint64_t block_at = 0, next_at = 0;           // file offsets of the block in `block` and of the one after it
-    size_t pos = 0;                               // read position inside `block`
+    // A batch of consecutive blocks, inflated together by a few threads (a block is an independent gzip member).  The first batch after a
+    // seek is small -- a region fetch of a handful of reads reads little more than it needs -- and batches grow while the reading goes on.
+    std::vector<uint8_t> raw, data;               // the blocks' deflate payloads back to back / the inflated bytes of the batch
+    struct Blk { uint64_t at; size_t raw_off, raw_len, out_off; uint32_t isize, crc; };
+    std::vector<Blk> blks;
+    uint64_t next_at = 0;                         // file offset behind the batch
+    size_t pos = 0, cur = 0;                      // read position inside `data`, block it lies in
+    int grow = 4;
     bool eof = false; std::string err;
 
     bool open(const char* path) { f = std::fopen(path, "rb"); return f != nullptr; }
     ~Bgzf() { if (f) std::fclose(f); }
-    bool load(uint64_t at) {
-        block.clear(); pos = 0; block_at = at;
-        if (fseeko(f, (off_t)at, SEEK_SET) != 0) { err = "seek failed"; return false; }
+    // reads the header and payload of the block at `at`; false + err on a damaged block; eof when the file ends there
+    bool read_block(uint64_t at, Blk& k, bool& at_end) {
+        at_end = false;
         uint8_t h[18];
         const size_t got = std::fread(h, 1, 18, f);
-        if (got == 0) { eof = true; next_at = at; return true; }
+        if (got == 0) { at_end = true; return true; }
         if (got < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
         const unsigned xlen = h[10] | (h[11] << 8);
         // the BC subfield is the first one in every file htslib / bgzip writes; walk the extra field all the same
@@ -52,36 +59,95 @@ struct Bgzf {
         if (bsize < 0) { err = "BGZF block without a BC field"; return false; }
         const size_t total = (size_t)bsize + 1, header = 12 + xlen;
         if (total < header + 8) { err = "corrupt BGZF block size"; return false; }
-        raw.resize(total - header);
+        const size_t body = total - header;
+        k.at = at; k.raw_off = raw.size(); k.raw_len = body - 8;
+        raw.resize(raw.size() + body);
+        uint8_t* dst = raw.data() + k.raw_off;
         const size_t had = xlen < 6 ? 6 - xlen : 0;                   // bytes of the payload already read with the fixed 18
-        if (had) std::memcpy(raw.data(), h + 12 + xlen, had);
-        if (std::fread(raw.data() + had, 1, raw.size() - had, f) != raw.size() - had) { err = "truncated BGZF block"; return false; }
-        const uint8_t* tail = raw.data() + raw.size() - 8;
-        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
-        if (isize > 65536u) { err = "BGZF block claims more than 64 KiB"; return false; }        // (the format's limit: nothing larger is allocated on a file's say-so)
-        block.resize(isize);
-        if (isize) {
-            z_stream z{};
-            if (inflateInit2(&z, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
-            z.next_in = raw.data(); z.avail_in = (uInt)(raw.size() - 8); z.next_out = block.data(); z.avail_out = isize;
-            const int rc = inflate(&z, Z_FINISH);
-            inflateEnd(&z);
-            if (rc != Z_STREAM_END || z.avail_out != 0) { err = "corrupt BGZF block"; return false; }
-            const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
-            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), block.data(), isize) != crc) { err = "BGZF block fails its CRC"; return false; }
-        }
+        if (had) std::memcpy(dst, h + 12 + xlen, had);
+        if (std::fread(dst + had, 1, body - had, f) != body - had) { err = "truncated BGZF block"; return false; }
+        const uint8_t* tail = dst + body - 8;
+        k.crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        k.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (k.isize > 65536u) { err = "BGZF block claims more than 64 KiB"; return false; }        // (the format's limit: nothing larger is allocated on a file's say-so)
         next_at = at + total;
         return true;
     }
-    bool seek(uint64_t voffset) { eof = false; if (!load(voffset >> 16)) return false; pos = (size_t)(voffset & 0xFFFF); return pos <= block.size(); }
-    uint64_t tell() const { return pos < block.size() ? (block_at << 16) | pos : (next_at << 16); }
+    static const char* inflate_one(const uint8_t* src, size_t n, uint8_t* dst, uint32_t isize, uint32_t crc) {
+        if (!isize) return nullptr;
+        z_stream z{};
+        if (inflateInit2(&z, -15) != Z_OK) return "inflateInit2 failed";
+        z.next_in = const_cast<uint8_t*>(src); z.avail_in = (uInt)n; z.next_out = dst; z.avail_out = isize;
+        const int rc = inflate(&z, Z_FINISH);
+        inflateEnd(&z);
+        if (rc != Z_STREAM_END || z.avail_out != 0) return "corrupt BGZF block";
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, isize) != crc) return "BGZF block fails its CRC";
+        return nullptr;
+    }
+    // the batch of up to max_blocks blocks that starts at file offset `at`
+    bool load(uint64_t at, int max_blocks) {
+        raw.clear(); data.clear(); blks.clear(); pos = 0; cur = 0;
+        if (fseeko(f, (off_t)at, SEEK_SET) != 0) { err = "seek failed"; return false; }
+        next_at = at;
+        size_t out = 0;
+        for (int k = 0; k < max_blocks; ++k) {
+            Blk b{}; bool at_end = false;
+            if (!read_block(next_at, b, at_end)) return false;
+            if (at_end) { if (blks.empty()) eof = true; break; }
+            b.out_off = out; out += b.isize;
+            blks.push_back(b);
+        }
+        data.resize(out);
+        const size_t nb = blks.size();
+        unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1;
+        const size_t nt = std::min<size_t>({ (size_t)hw, (size_t)16, nb / 4 });
+        std::atomic<size_t> next_blk(0);
+        std::atomic<const char*> first_err(nullptr);
+        auto work = [&]() {
+            for (;;) {
+                const size_t i = next_blk.fetch_add(1);
+                if (i >= nb) break;
+                const char* e = inflate_one(raw.data() + blks[i].raw_off, blks[i].raw_len, data.data() + blks[i].out_off, blks[i].isize, blks[i].crc);
+                if (e) { const char* none = nullptr; first_err.compare_exchange_strong(none, e); }
+            }
+        };
+        if (nt <= 1) work();
+        else {
+            std::vector<std::thread> th;
+            try { for (size_t t = 0; t + 1 < nt; ++t) th.emplace_back(work); } catch (...) { }
+            work();
+            for (auto& t : th) t.join();
+        }
+        if (first_err.load()) { err = first_err.load(); return false; }
+        return true;
+    }
+    bool seek(uint64_t voffset) {
+        eof = false; grow = 4;
+        if (!load(voffset >> 16, grow)) return false;
+        const size_t in = (size_t)(voffset & 0xFFFF);
+        if (blks.empty()) return in == 0;
+        if (in > blks[0].isize) return false;
+        pos = in;
+        return true;
+    }
+    uint64_t tell() {
+        while (cur + 1 < blks.size() && pos >= blks[cur + 1].out_off) ++cur;
+        if (!blks.empty() && pos < data.size()) return (blks[cur].at << 16) | (uint64_t)(pos - blks[cur].out_off);
+        return next_at << 16;
+    }
     // n bytes, crossing blocks; false at the end of the file (or on an error: err is set)
     bool read(void* out, size_t n) {
         uint8_t* o = (uint8_t*)out;
         while (n) {
-            if (pos >= block.size()) { if (eof) return false; if (!load(next_at)) return false; if (eof) return false; continue; }
-            const size_t k = std::min(n, block.size() - pos);
-            std::memcpy(o, block.data() + pos, k); o += k; pos += k; n -= k;
+            if (pos >= data.size()) {
+                if (eof) return false;
+                grow = std::min(grow * 4, 256);
+                if (!load(next_at, grow)) return false;
+                if (eof) return false;
+                continue;
+            }
+            const size_t k = std::min(n, data.size() - pos);
+            std::memcpy(o, data.data() + pos, k); o += k; pos += k; n -= k;
         }
         return true;
     }
@@ -123,6 +189,7 @@ struct sp_bam {
     std::set<std::string> seen;
     // the last fetch
     std::vector<sp_bam_read> reads; std::vector<std::string> names; std::vector<std::vector<uint32_t>> cigars; std::string bases; std::vector<uint64_t> offsets;
+    std::vector<uint8_t> seq4; std::vector<uint64_t> seq4_off; std::vector<uint32_t> seq_len;      // the SEQ fields as stored (4 bits per base)
 };
 
 namespace {
@@ -168,7 +235,7 @@ int32_t sp_bam_open(const char* path, sp_bam** out, char* err, uint32_t err_cap)
     auto b = std::make_unique<sp_bam>();
     if (!b->z.open(path)) { put_err(err, err_cap, std::string("cannot open ") + path); return SP_ERR_INVALID_ARG; }
     auto bad = [&](const std::string& m) { put_err(err, err_cap, m.empty() ? "truncated BAM header" : m); return SP_ERR_INVALID_ARG; };
-    if (!b->z.load(0)) return bad(b->z.err);
+    if (!b->z.load(0, 4)) return bad(b->z.err);
     uint8_t h[12];
     if (!b->z.read(h, 8) || std::memcmp(h, "BAM\1", 4) != 0) return bad(b->z.err.empty() ? "not a BAM file" : b->z.err);
     const uint32_t l_text = le32(h + 4);
@@ -200,6 +267,12 @@ int32_t sp_bam_open(const char* path, sp_bam** out, char* err, uint32_t err_cap)
 
 void sp_bam_free(sp_bam* bam) { delete bam; }
 const char* sp_bam_last_error(const sp_bam* bam) { return bam ? bam->err.c_str() : ""; }
+int32_t sp_bam_last_seq4(const sp_bam* bam, const uint8_t** seq4, const uint64_t** byte_offsets, const uint32_t** lengths, uint32_t* n) {
+    if (!bam || !seq4 || !byte_offsets || !lengths) return SP_ERR_INVALID_ARG;
+    *seq4 = bam->seq4.data(); *byte_offsets = bam->seq4_off.data(); *lengths = bam->seq_len.data();
+    if (n) *n = (uint32_t)bam->seq_len.size();
+    return SP_OK;
+}
 int32_t sp_bam_forget(sp_bam* bam) { if (!bam) return SP_ERR_INVALID_ARG; bam->seen.clear(); return SP_OK; }
 
 int32_t sp_bam_references(const sp_bam* bam, uint32_t* n, const char* const** names, const uint64_t** lengths) {
@@ -214,6 +287,7 @@ int32_t sp_bam_fetch(sp_bam* b, const char* chrom, uint64_t start, uint64_t end,
                      const sp_bam_read** reads, uint32_t* n, const char** bases, const uint64_t** offsets) {
     if (!b || !chrom || !reads || !n || end <= start) return SP_ERR_INVALID_ARG;
     b->reads.clear(); b->names.clear(); b->cigars.clear(); b->bases.clear(); b->offsets.assign(1, 0);
+    b->seq4.clear(); b->seq4_off.assign(1, 0); b->seq_len.clear();
     *reads = nullptr; *n = 0;
     int ref = -1;
     for (size_t r = 0; r < b->ref_names.size(); ++r) if (b->ref_names[r] == chrom) ref = (int)r;
@@ -263,6 +337,7 @@ int32_t sp_bam_fetch(sp_bam* b, const char* chrom, uint64_t start, uint64_t end,
             const uint8_t* sq = cg + 4 * n_cigar;
             for (uint32_t x = 0; x < l_seq; ++x) b->bases.push_back(decode[(sq[x >> 1] >> ((x & 1) ? 0 : 4)) & 0xF]);
             b->offsets.push_back(b->bases.size());
+            b->seq4.insert(b->seq4.end(), sq, sq + (l_seq + 1) / 2); b->seq4_off.push_back(b->seq4.size()); b->seq_len.push_back(l_seq);
             b->names.push_back(std::move(qname)); b->cigars.push_back(std::move(cigar));
             sp_bam_read r{}; r.flag = flag; r.mapq = mapq; r.ref_id = ref_id; r.pos = pos; r.end = rend; r.l_seq = l_seq; r.n_cigar = n_cigar;
             b->reads.push_back(r);

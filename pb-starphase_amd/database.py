@@ -523,6 +523,7 @@ def _io():
         "sp_bam_references": (_i32, [_vp, P(_u32), P(P(_s)), P(P(_u64))]),
         "sp_bam_fetch": (_i32, [_vp, _s, _u64, _u64, _u32, _i32, P(P(sp_bam_read)), P(_u32), P(_vp), P(P(_u64))]),
         "sp_bam_forget": (_i32, [_vp]),
+        "sp_bam_last_seq4": (_i32, [_vp, P(_vp), P(P(_u64)), P(P(_u32)), P(_u32)]),
         "sp_vcf_open": (_i32, [_s, P(_vp), _s, _u32]),
         "sp_vcf_free": (None, [_vp]),
         "sp_vcf_last_error": (_s, [_vp]),
@@ -579,6 +580,19 @@ class Bam:
             out.append(dict(qname=r.qname.decode(), flag=r.flag, mapq=r.mapq, pos=r.pos, end=r.end,
                             cigar=[(r.cigar[k] & 15, r.cigar[k] >> 4) for k in range(r.n_cigar)], seq=blob[offs[i]:offs[i + 1]].decode()))
         return out
+
+    def last_seq4(self):
+        """the SEQ fields of the last fetch as the file stores them -> (bytes as uint8 array, byte offsets[n + 1], lengths[n]): the arguments
+        of Context.upload_format(SP_SEQ_BAM4, ...)"""
+        import numpy as np
+        seq, off, ln, n = _vp(), C.POINTER(_u64)(), C.POINTER(_u32)(), _u32()
+        rc = _io().sp_bam_last_seq4(self._h, C.byref(seq), C.byref(off), C.byref(ln), C.byref(n))
+        if rc != SP_OK:
+            raise StarphaseError(rc, "sp_bam_last_seq4")
+        k = n.value
+        offs = np.array([off[i] for i in range(k + 1)], np.uint64) if k else np.zeros(1, np.uint64)
+        blob = np.frombuffer(C.string_at(seq.value, int(offs[-1])), np.uint8).copy() if k and offs[-1] else np.zeros(0, np.uint8)
+        return blob, offs, np.array([ln[i] for i in range(k)], np.uint32)
 
     def forget(self):
         _io().sp_bam_forget(self._h)

@@ -228,6 +228,10 @@ def lib():
         "sp_ctx_synchronize": (i32, [vp]),
         "sp_ctx_set_option": (i32, [vp, C.c_char_p, C.c_int64]),
         "sp_seqset_upload": (i32, [vp, C.c_char_p, vp, u32, C.POINTER(vp)]),
+        "sp_seqset_upload_format": (i32, [vp, i32, vp, vp, vp, u32, C.POINTER(vp)]),
+        "sp_seqset_upload_async": (i32, [vp, i32, vp, vp, vp, u32, C.POINTER(vp)]),
+        "sp_seqset_wait": (i32, [vp]),
+        "sp_seqset_skipped": (i32, [vp, C.POINTER(u32)]),
         "sp_seqset_free": (None, [vp]),
         "sp_seqset_count": (i32, [vp, C.POINTER(u32)]),
         "sp_seqset_length": (i32, [vp, u32, C.POINTER(u32)]),
@@ -334,6 +338,10 @@ class Context:
 
     def upload(self, seqs):
         return SeqSet(self, seqs)
+
+    def upload_format(self, fmt, blob, offsets, lengths=None, wait=True):
+        """sp_seqset_upload_format / sp_seqset_upload_async: bytes already in an upload format (SP_SEQ_ASCII / SP_SEQ_BAM4 / SP_SEQ_PACKED2)"""
+        return SeqSet(self, None, blob=blob, offsets=offsets, lengths=lengths, fmt=fmt, wait=wait)
 
     def anchor_batch(self, A, B, a_idx, b_idx):
         a_idx = np.ascontiguousarray(a_idx, np.uint32)
@@ -876,14 +884,79 @@ class CypDb:
         return call, regions, text.value.decode()
 
 
+SP_SEQ_ASCII, SP_SEQ_BAM4, SP_SEQ_PACKED2 = 0, 1, 2
+_BAM_CODE = np.full(256, 15, np.uint8)
+for _i, _c in enumerate("=ACMGRSVTWYHKDBN"):
+    _BAM_CODE[ord(_c)] = _i
+    _BAM_CODE[ord(_c.lower())] = _i
+
+
+def encode_bam4(seqs):
+    """the SEQ fields a BAM file would hold for these reads: (bytes, byte offsets[n + 1], lengths[n])"""
+    lens = np.array([len(s) for s in seqs], np.uint32)
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum((lens.astype(np.uint64) + 1) // 2)
+    out = np.zeros(int(offs[-1]), np.uint8)
+    for i, s in enumerate(seqs):
+        c = _BAM_CODE[np.frombuffer(s.encode(), np.uint8)]
+        if len(c) & 1:
+            c = np.append(c, 0)
+        out[int(offs[i]):int(offs[i + 1])] = (c[0::2] << 4) | c[1::2]
+    return out, offs, lens
+
+
+def encode_packed2(seqs):
+    """2 bits per base, four per byte, base b in bits 2 (b & 3): (bytes, byte offsets[n + 1], lengths[n]); A C G T only"""
+    code = np.zeros(256, np.uint8)
+    for i, c in enumerate("ACGT"):
+        code[ord(c)] = i
+        code[ord(c.lower())] = i
+    lens = np.array([len(s) for s in seqs], np.uint32)
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum((lens.astype(np.uint64) + 3) // 4)
+    out = np.zeros(int(offs[-1]), np.uint8)
+    for i, s in enumerate(seqs):
+        c = code[np.frombuffer(s.encode(), np.uint8)]
+        pad = (-len(c)) % 4
+        if pad:
+            c = np.append(c, np.zeros(pad, np.uint8))
+        out[int(offs[i]):int(offs[i + 1])] = c[0::4] | (c[1::4] << 2) | (c[2::4] << 4) | (c[3::4] << 6)
+    return out, offs, lens
+
+
 class SeqSet:
-    def __init__(self, ctx, seqs):
+    def __init__(self, ctx, seqs=None, blob=None, offsets=None, lengths=None, fmt=SP_SEQ_ASCII, wait=True):
+        """seqs: Python strings (sent as ASCII); or blob / offsets / lengths already in one of the upload formats (numpy arrays or bytes).
+        wait=False: sp_seqset_upload_async -- call .wait() before the set is used; the buffers are kept alive by this object until then"""
         self.ctx = ctx
-        self.n = len(seqs)
-        self.lengths = np.array([len(s) for s in seqs], np.int64)
-        blob, offs = _concat(list(seqs))
+        if seqs is not None:
+            blob, offsets = _concat(list(seqs))
+            self.lengths = np.array([len(s) for s in seqs], np.int64)
+            lengths = None
+        else:
+            self.lengths = np.asarray(lengths if lengths is not None else np.diff(np.asarray(offsets)), np.int64)
+        self.n = len(self.lengths)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        ln = None if lengths is None else np.ascontiguousarray(lengths, np.uint32)
+        data = blob if isinstance(blob, (bytes, bytearray)) else np.ascontiguousarray(blob)
+        dptr = C.cast(C.c_char_p(data), C.c_void_p) if isinstance(data, (bytes, bytearray)) else _ptr(data)
+        self._keep = (data, offsets, ln)
         self._h = C.c_void_p()
-        ctx.check(lib().sp_seqset_upload(ctx._h, blob, _ptr(offs), self.n, C.byref(self._h)))
+        fn = lib().sp_seqset_upload_format if wait else lib().sp_seqset_upload_async
+        ctx.check(fn(ctx._h, int(fmt), dptr, _ptr(offsets), _ptr(ln), self.n, C.byref(self._h)))
+        if wait:
+            self._keep = None
+
+    def wait(self):
+        self.ctx.check(lib().sp_seqset_wait(self._h))
+        self._keep = None
+        return self
+
+    @property
+    def skipped(self):
+        k = C.c_uint32(0)
+        self.ctx.check(lib().sp_seqset_skipped(self._h, C.byref(k)))
+        return k.value
 
     def close(self):
         if self._h:

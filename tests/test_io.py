@@ -278,6 +278,30 @@ def test_bam_reads_go_to_the_library(D, pkg, tmp_path):
     assert C.string_at(bases.value, int(offs[40])).decode() == "".join(r[6] for r in recs)
 
 
+def test_bam_many_blocks_inflate_side_by_side(D, pkg, tmp_path):
+    """a region of several hundred BGZF blocks: the reader inflates them in batches on a few threads (sp_io.hip, Bgzf::load); the records
+    and the SEQ fields as stored (sp_bam_last_seq4: the input of sp_seqset_upload_format(SP_SEQ_BAM4)) equal the Python filter's"""
+    rng = np.random.default_rng(77)
+    refs = [("chr6", 3000000)]
+    records = make_records(rng, refs, 4000)
+    path = str(tmp_path / "big.bam")
+    write_bam(path, refs, records, 8000, index=True)                       # ~ 400 blocks
+    assert os.path.getsize(path) > 1000000
+    bam = D.Bam(path)
+    for a, b in ((0, 3000000), (1000000, 1900000)):
+        want = expected(records, refs, "chr6", a, b)
+        got = bam.fetch("chr6", a, b)
+        assert got == want and len(want) > 1000
+        blob, offs, lens = bam.last_seq4()
+        assert lens.tolist() == [len(r["seq"]) for r in want] and int(offs[-1]) == len(blob)
+        eb, eo, el = pkg.ffi.encode_bam4([r["seq"] for r in want])
+        assert eo.tolist() == offs.tolist() and bytes(eb) == bytes(blob)
+    scan = D.Bam(path)
+    os.remove(path + ".bai")
+    scan = D.Bam(path)
+    assert scan.fetch("chr6", 1000000, 1900000) == expected(records, refs, "chr6", 1000000, 1900000)
+
+
 # ------------------------------------------------------------------ reference FASTA
 def write_fasta(path, seqs, width, newline="\n", lower=False, index=False, describe=False):
     """a FASTA file the way samtools faidx expects it (fixed line width per sequence) and, optionally, its .fai"""
