@@ -872,6 +872,22 @@ int32_t sp_hla_debug_add_dual_stats(sp_hla_debug* debug, const char* gene, const
 int32_t sp_hla_debug_json(sp_hla_debug* debug, const char** text, uint64_t* len);
 int32_t sp_hla_debug_save(sp_hla_debug* debug, const char* path);             /* gzip when the name ends in ".gz" */
 
+/* ------------------------------------------------------------------ e: gathering the ranks' results (the path's one exchange step)
+ * The reference has no counterpart: it is single-threaded and a cohort is N process runs (src/cli/diplotype.rs:185-191).  BASELINE.json's
+ * north_star shards independent units (samples, genes) over the GPUs of a node, one process and one sp_ctx per GPU, with "RCCL over xGMI used
+ * only to gather per-gene results" (SURVEY.md 8(b) sp_gather_results, 8(e)).  Rank 0 makes a 128-byte id (ncclGetUniqueId) and the host hands it
+ * to the other ranks over whatever channel it has (a file, a socket, MPI, a torch store); every rank then joins the group on its context's device.
+ * sp_gather_results: every rank contributes bytes_per_rank bytes of packed records (host memory) and receives all ranks' records in rank order
+ * (n_ranks * bytes_per_rank bytes) -- one ncclAllGather on the context's stream, synchronous on return.  librccl is opened at run time; without it
+ * sp_group_* fail with SP_ERR_NO_DEVICE and nothing else in the library is affected. */
+typedef struct sp_group sp_group;
+#define SP_GROUP_ID_BYTES 128
+int32_t sp_group_unique_id(uint8_t* id /* SP_GROUP_ID_BYTES */);
+int32_t sp_group_create(sp_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n_ranks, sp_group** out);
+void    sp_group_free(sp_group* group);
+int32_t sp_group_size(const sp_group* group, int32_t* rank, int32_t* n_ranks);
+int32_t sp_gather_results(sp_group* group, const void* records, uint64_t bytes_per_rank, void* all_records);
+
 /* ------------------------------------------------------------------ f2: decoding the input files (host only)
  * What the reference gets from rust-htslib: the records of an indexed BAM that overlap a region (diplotype_hla_batch,
  * src/hla/caller.rs:523-596; the CYP2D6 read collection, src/cyp2d6/caller.rs:96-139) and the records of a VCF around a position

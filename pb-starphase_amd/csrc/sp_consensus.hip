@@ -53,7 +53,9 @@ constexpr int CWIN = 512;       // consensus bases in front of the window kept i
 constexpr int RWORDS = (2 * CW + 320) / 16;   // packed read words a wave keeps in LDS: band + window + lookahead + slack around its tips
 constexpr int NQ = 40;          // search nodes per problem: max_queue_size waiting + the children of one expansion + the complete one
 constexpr int MAXKIDS = 16;     // children of one expansion
-constexpr int CLUSTER = 16;     // workgroups whose vote words are summed by the last of them to finish
+constexpr int CLUSTER = 64;     // workgroups whose vote words the reduce kernel sums into one set of cluster sums
+constexpr int RSLICES = 16;     // reduce-kernel workgroups per cluster: each sums one slice of the cluster's words
+constexpr int RGROUP = 16;      // members of a cluster one thread loads side by side
 constexpr int QSV = 2 * (CW + 1) * 5, QSL = 2 * CW * 4, QE = QSV + QSL + 2 * (CW + 1);   // one cluster's sums: exact votes (w[4], end), lookahead votes, cost growth, final-cost extra
 enum { F_ACTIVE = 1, F_FINISHED = 2, F_LOST = 4 };
 enum { M_NONE = 0, M_INIT = 1, M_WINDOW = 2, M_EXPAND = 3 };
@@ -121,11 +123,12 @@ template <int MAXP> struct ConsBatchT {
     uint32_t* PR;               // [blocks][CW + 1]    what unfinished reads add to a final cost (index n / child)
     uint32_t* Q;                // [clusters][QE]      the words above summed over a cluster of workgroups, one u32 per field
     unsigned long long* dbg;    // SP_K8_TIMING builds: per launch index [4096][4] = slowest wave, slowest wave that placed no read, sum of waves, waves (ticks)
+    uint32_t* prog;             // host memory the device writes: per problem { control steps made, search ended }: the host enqueues a few launches ahead of it
     int total;
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; const int* cluster_prob; int total;
+    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; const int* cluster_prob; int total;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first; };
 
@@ -704,51 +707,60 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
     for (int x = threadIdx.x; x < CW + 1; x += blockDim.x) { B.PC[(size_t)blockIdx.x * (CW + 1) + x] = lc[x]; B.PR[(size_t)blockIdx.x * (CW + 1) + x] = lr[x]; }
 }
 
-// sums the vote words of CLUSTER consecutive workgroups of a problem (a few hundred workgroups would otherwise be summed by the one
-// workgroup of the control kernel, word by word from memory: 35 of its 45 us); one workgroup per cluster
+// sums the vote words of CLUSTER consecutive workgroups of a problem (several hundred workgroups would otherwise be summed by the one
+// workgroup of the control kernel, word by word from memory).  RSLICES workgroups per cluster, each a slice of the words: with 256-column
+// windows a workgroup leaves 12 KB of words behind, 7.7 MB per launch of a 5,000-read problem, and ten workgroups would be alone with them.
+// A thread sums one word over RGROUP members (all their loads issued before the first is used), the CLUSTER / RGROUP threads of a word sit in
+// neighbouring lanes and add up through DPP.
 template <int MAXP>
-__global__ void __launch_bounds__(1024) cons_reduce_kernel(ConsBatchT<MAXP> B) {
+__global__ void __launch_bounds__(512) cons_reduce_kernel(ConsBatchT<MAXP> B) {
+    const int cluster = (int)blockIdx.x / RSLICES, slice = (int)blockIdx.x % RSLICES;
     int pi = 0;
-    if constexpr (MAXP == 0) pi = B.cluster_prob[blockIdx.x];
+    if constexpr (MAXP == 0) pi = B.cluster_prob[cluster];
     else {
 #pragma unroll
-        for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_cluster) pi = i;
+        for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && cluster >= B.p[i].first_cluster) pi = i;
     }
     const ConsParams P = B.p[pi];
     if (P.work->done || P.work->mode == M_NONE) return;
-    const int cl = (int)blockIdx.x - P.first_cluster;
+    const int cl = cluster - P.first_cluster;
     const int members = P.n_blocks - cl * CLUSTER < CLUSTER ? P.n_blocks - cl * CLUSTER : CLUSTER;
     const size_t blk0 = (size_t)P.first_block + (size_t)cl * CLUSTER;
     constexpr int EV = 2 * (CW + 1), EL = 2 * CW, EC = CW + 1;
-    // all CLUSTER loads of an output are issued before the first is used (a loop over `members` would wait for each in turn)
-    for (int o = threadIdx.x; o < QE; o += blockDim.x) {
-        uint32_t v[CLUSTER];
+    constexpr int PER = (QE + RSLICES - 1) / RSLICES, NG = CLUSTER / RGROUP;
+    const int o_lo = slice * PER, o_hi = o_lo + PER < QE ? o_lo + PER : QE;
+    for (int idx = threadIdx.x; idx < (o_hi - o_lo) * NG; idx += blockDim.x) {
+        const int o = o_lo + idx / NG, m0 = (idx % NG) * RGROUP;
+        uint32_t v[RGROUP];
         if (o < QSV) {
             const int e = o / 5, f = o % 5;
             if (f < 4) {
 #pragma unroll
-                for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? (uint32_t)((B.PV[(blk0 + m) * EV + e] >> (16 * f)) & 0xFFFFull) : 0u;
+                for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? (uint32_t)((B.PV[(blk0 + m0 + m) * EV + e] >> (16 * f)) & 0xFFFFull) : 0u;
             } else {
 #pragma unroll
-                for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? B.PE[(blk0 + m) * EV + e] : 0u;
+                for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? B.PE[(blk0 + m0 + m) * EV + e] : 0u;
             }
         } else if (o < QSV + QSL) {
             const int e = (o - QSV) / 4, f = (o - QSV) % 4;
 #pragma unroll
-            for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? (uint32_t)((B.PL[(blk0 + m) * EL + e] >> (16 * f)) & 0xFFFFull) : 0u;
+            for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? (uint32_t)((B.PL[(blk0 + m0 + m) * EL + e] >> (16 * f)) & 0xFFFFull) : 0u;
         } else if (o < QSV + QSL + EC) {
             const int e = o - QSV - QSL;
 #pragma unroll
-            for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? B.PC[(blk0 + m) * EC + e] : 0u;
+            for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? B.PC[(blk0 + m0 + m) * EC + e] : 0u;
         } else {
             const int e = o - QSV - QSL - EC;
 #pragma unroll
-            for (int m = 0; m < CLUSTER; ++m) v[m] = m < members ? B.PR[(blk0 + m) * EC + e] : 0u;
+            for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? B.PR[(blk0 + m0 + m) * EC + e] : 0u;
         }
         uint32_t sum = 0;
 #pragma unroll
-        for (int m = 0; m < CLUSTER; ++m) sum += v[m];
-        B.Q[(size_t)blockIdx.x * QE + o] = sum;
+        for (int m = 0; m < RGROUP; ++m) sum += v[m];
+        // the NG threads of a word are neighbouring lanes (NG divides 64 and the block size: they never straddle a wavefront)
+#pragma unroll
+        for (int d = 1; d < NG; d <<= 1) sum += __shfl_xor(sum, d);
+        if (idx % NG == 0) B.Q[(size_t)cluster * QE + o] = sum;
     }
 }
 
@@ -1120,6 +1132,10 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)P.work)[x] = ((const uint32_t*)&wk)[x];
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)P.srch)[x] = ((const uint32_t*)&ss)[x];
     for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)P.processed)[x] = ((const uint32_t*)proc)[x];
+    if (tid == 0 && B.prog) {
+        __hip_atomic_store(B.prog + 2 * pi, (uint32_t)wk.pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (wk.done) __hip_atomic_store(B.prog + 2 * pi + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // gathers the per-read constants of one problem into the flattened ReadInfo array (once per batch)
@@ -1212,7 +1228,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         P.first = (int)total; P.first_block = n_blocks;
         P.min_count = q.cfg.min_count; P.delta = q.cfg.dual_max_ed_delta; P.et = q.cfg.allow_early_termination != 0; P.allow_dual = q.cfg.allow_dual != 0;
         P.window = q.cfg.offset_window; P.cmp_len = q.cfg.offset_compare_length; P.min_af = q.cfg.min_af;
-        P.rpw = n > 16384 ? 4 : n > 4096 ? 2 : 1;                                     // large problems: several reads per wave (fewer vote words to sum)
+        P.rpw = n > 65536 ? 4 : n > 32768 ? 2 : 1;                                    // one read per wave while that stays below 4,096 workgroups
         const uint32_t per_block = (uint32_t)(CWAVES * P.rpw);
         const uint32_t nb = (n + per_block - 1) / per_block;
         P.n_blocks = (int)nb;
@@ -1277,7 +1293,11 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
 #endif
     uint8_t* d_is1 = d_out + out_is1;
     int32_t* d_sc = (int32_t*)(d_out + out_sc);
-    CWork* h_work = (CWork*)sp_host_pool(ctx, "cons_work", sizeof(CWork) * n_prob);          // (the polls of the loop land here)
+    uint32_t* h_prog = (uint32_t*)sp_host_pool(ctx, "cons_prog", sizeof(uint32_t) * 2 * n_prob);
+    if (!h_prog) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus progress words");
+    std::memset(h_prog, 0, sizeof(uint32_t) * 2 * n_prob);
+    { void* dp = nullptr; SP_HIP_CHECK(ctx, hipHostGetDevicePointer(&dp, h_prog, 0)); B.prog = (uint32_t*)dp; }
+    CWork* h_work = (CWork*)sp_host_pool(ctx, "cons_work", sizeof(CWork) * n_prob);
     CWork* h_work0 = (CWork*)(h_in + in_work); CSearch* h_srch0 = (CSearch*)(h_in + in_srch);
     const CSearch* h_srch = (const CSearch*)(h_out + out_srch);
     if (!d_idx || !d_off || !d_C || !d_work || !d_srch || !d_nodes || !d_la || !d_proc || !d_info || !B.H || !B.meta || !B.PV || !B.PE || !B.PL || !B.PC || !B.PR || !B.Q ||
@@ -1325,27 +1345,40 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     hm.mark("host:k8_prologue");
     {
         ProfScope ps(ctx, "cons_steps", total);
-        // The first poll comes when the longest consensus the reads can give (`expect`: the furthest a read reaches -- not the buffer's
-        // capacity, which for compressed reads is far beyond it) can be through if every window stands; then every few pairs, fewer
-        // the closer the end is.  A launch pair whose problems are all done is three empty launches (~13 us), a poll a ~25 us bubble.
-        int max_expect = 0;
-        for (uint32_t p = 0; p < n_prob; ++p) max_expect = std::max(max_expect, expect[p]);
-        int until_poll = max_expect / CW + 3;
+        // The host stays a few launch triples ahead of the device and never waits for it: the control kernel of a problem writes the number
+        // of steps it has made and, at the end, "done" into host memory (fine-grained pinned: the write is seen here without a copy or a
+        // stream synchronisation), and the host reads those words between launches.  A search that ends leaves at most `ahead` empty triples
+        // behind (~4 us per empty launch).  Before: a device-to-host copy + stream synchronisation every few triples, ~40 us of idle device
+        // each, 35 of them per 10,000-read sample.
         const uint64_t limit = (uint64_t)64 * (uint64_t)(max_cap + 2) + 1024;
-        for (;;) {
+        const uint32_t ahead = 3;
+        volatile uint32_t* prog = h_prog;
+        bool finished = false;
+        while (!finished) {
             hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
-            hipLaunchKernelGGL(cons_reduce_kernel<MAXP>, dim3((uint32_t)n_clusters), dim3(1024), 0, st, B);
+            hipLaunchKernelGGL(cons_reduce_kernel<MAXP>, dim3((uint32_t)n_clusters * RSLICES), dim3(512), 0, st, B);
             hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, st, B);
             ++pairs;
-            if (--until_poll <= 0 || pairs >= limit) {
-                SP_HIP_CHECK(ctx, hipMemcpyAsync(h_work, d_work, sizeof(CWork) * n_prob, hipMemcpyDeviceToHost, st));
-                SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
-                bool all = true; int left = 0;
-                for (uint32_t p = 0; p < n_prob; ++p) { all = all && h_work[p].done; if (!h_work[p].done) left = std::max(left, expect[p] - h_work[p].T); }
-                if (all) break;
-                if (pairs >= limit) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the search did not finish");
-                until_poll = std::max(2, std::min(64, left / CW / 2 + 1));
+            uint64_t spins = 0;
+            for (;;) {
+                bool all = true; uint32_t slowest = 0xFFFFFFFFu;
+                for (uint32_t p = 0; p < n_prob; ++p) if (!prog[2 * p + 1]) { all = false; const uint32_t v = prog[2 * p]; slowest = v < slowest ? v : slowest; }
+                if (all) { finished = true; break; }
+                if (pairs - slowest <= ahead) break;
+                __builtin_ia32_pause();
+                if ((++spins & 0xFFFFF) == 0) {                          // now and then: is the stream still alive?
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q != hipSuccess && q != hipErrorNotReady) return sp_fail(ctx, SP_ERR_HIP, std::string("sp_consensus: ") + hipGetErrorString(q));
+                    if (q == hipSuccess) {                                // everything enqueued has run and the words did not move
+                        bool all2 = true; uint32_t slow2 = 0xFFFFFFFFu;
+                        for (uint32_t p = 0; p < n_prob; ++p) if (!prog[2 * p + 1]) { all2 = false; const uint32_t v = prog[2 * p]; slow2 = v < slow2 ? v : slow2; }
+                        if (all2) { finished = true; break; }
+                        if (pairs - slow2 <= ahead) break;
+                        return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the device stopped reporting progress");
+                    }
+                }
             }
+            if (!finished && pairs >= limit) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the search did not finish");
         }
     }
     SP_HIP_CHECK(ctx, hipGetLastError());

@@ -284,6 +284,11 @@ def lib():
         "sp_cyp_db_index_variant": (i32, [vp, u64, C.c_char_p, C.c_char_p, C.POINTER(u32)]),
         "sp_cyp_db_allele": (i32, [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_uint8))]),
         "sp_cyp_db_problem": (i32, [vp, C.POINTER(sp_cyp_problem)]),
+        "sp_group_unique_id": (i32, [vp]),
+        "sp_group_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "sp_group_free": (None, [vp]),
+        "sp_group_size": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "sp_gather_results": (i32, [vp, vp, u64, vp]),
         "sp_profile_reset": (i32, [vp]),
         "sp_microbench": (i32, [vp, C.c_char_p, C.POINTER(C.c_double)]),
         "sp_profile_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
@@ -922,6 +927,46 @@ def encode_packed2(seqs):
             c = np.append(c, np.zeros(pad, np.uint8))
         out[int(offs[i]):int(offs[i + 1])] = c[0::4] | (c[1::4] << 2) | (c[2::4] << 4) | (c[3::4] << 6)
     return out, offs, lens
+
+
+SP_GROUP_ID_BYTES = 128
+
+
+def group_unique_id():
+    """sp_group_unique_id: the 128-byte id rank 0 makes and hands to the other ranks"""
+    buf = np.zeros(SP_GROUP_ID_BYTES, np.uint8)
+    rc = lib().sp_group_unique_id(_ptr(buf))
+    if rc != SP_OK:
+        raise StarphaseError(rc, "sp_group_unique_id (librccl missing?)")
+    return buf
+
+
+class Group:
+    """sp_group: the ranks of a node, one context each; gather() is the path's one exchange step (ncclAllGather over RCCL / xGMI)"""
+
+    def __init__(self, ctx, unique_id, rank, n_ranks):
+        self.ctx, self.rank, self.n_ranks = ctx, rank, n_ranks
+        uid = np.ascontiguousarray(unique_id, np.uint8)
+        self._h = C.c_void_p()
+        ctx.check(lib().sp_group_create(ctx._h, _ptr(uid), int(rank), int(n_ranks), C.byref(self._h)))
+
+    def gather(self, records):
+        """records: a numpy array (any dtype, the same shape on every rank) -> array of shape (n_ranks,) + records.shape"""
+        rec = np.ascontiguousarray(records)
+        out = np.zeros((self.n_ranks,) + rec.shape, rec.dtype)
+        self.ctx.check(lib().sp_gather_results(self._h, _ptr(rec), rec.nbytes, _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().sp_group_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SeqSet:

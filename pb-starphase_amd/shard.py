@@ -23,32 +23,57 @@ def partition(n_units, world, rank, cost=None):
     return [u for u in range(n_units) if owner[u] == rank]
 
 
-def gather_calls(calls, device=None, same_count=False):
-    """All ranks contribute their call records; every rank receives the full, sample/gene-sorted table.
-    Records are fixed size, so one all_gather of the counts and one of a padded int32 tensor suffice; with same_count (every
-    rank holds the same number of records, e.g. one sample with G genes each) the counts are not exchanged: one collective,
-    no host round trip for the sizes."""
+class TorchGroup:
+    """the same gather as ffi.Group.gather (sp_gather_results) through torch.distributed: `gloo` in the CPU tests and on a one-GPU box
+    (RCCL refuses two ranks on one device), `nccl` where the host prefers torch's communicator"""
+
+    def __init__(self, device=None):
+        import torch.distributed as dist
+        self.n_ranks, self.rank = dist.get_world_size(), dist.get_rank()
+        self.device = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+
+    def gather(self, records):
+        import torch
+        import torch.distributed as dist
+        rec = np.ascontiguousarray(records)
+        mine = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.device)
+        parts = [torch.zeros_like(mine) for _ in range(self.n_ranks)]
+        dist.all_gather(parts, mine)
+        out = np.stack([p.cpu().numpy() for p in parts]).view(rec.dtype)
+        return out.reshape((self.n_ranks,) + rec.shape)
+
+
+def make_group(ctx, ffi, backend="nccl", device=None):
+    """The group a rank gathers through.  `nccl`: an sp_group of the library (librccl, ncclAllGather on the context's stream); its 128-byte
+    id is made by rank 0 and handed out through the process group the launcher set up.  Anything else: the torch group."""
     import torch
     import torch.distributed as dist
-    calls = np.ascontiguousarray(calls, CALL_DTYPE)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return np.sort(calls, order=["sample", "gene"])
-    world = dist.get_world_size()
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    if same_count:
-        counts = [torch.tensor([len(calls)], dtype=torch.int64) for _ in range(world)]
-    else:
-        n = torch.tensor([len(calls)], dtype=torch.int64, device=dev)
-        counts = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(counts, n)
-    nmax = int(max(int(c.item()) for c in counts))
-    flat = np.zeros((nmax, 4), np.int32)
-    if len(calls):
-        flat[:len(calls)] = calls.view(np.int32).reshape(-1, 4)
-    mine = torch.from_numpy(flat).to(dev)
-    parts = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
-    rows = [p.cpu().numpy()[:int(c.item())] for p, c in zip(parts, counts)]
-    out = np.concatenate(rows, axis=0).astype(np.int32) if rows else np.zeros((0, 4), np.int32)
-    out = np.ascontiguousarray(out).view(CALL_DTYPE).reshape(-1)
+        return None
+    if backend != "nccl":
+        return TorchGroup(device)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    uid = torch.from_numpy(ffi.group_unique_id() if rank == 0 else np.zeros(ffi.SP_GROUP_ID_BYTES, np.uint8)).to(device or "cuda")
+    dist.broadcast(uid, 0)
+    return ffi.Group(ctx, uid.cpu().numpy(), rank, world)
+
+
+def gather_calls(calls, device=None, same_count=False, group=None):
+    """All ranks contribute their call records; every rank receives the full, sample/gene-sorted table.
+    Records are fixed size: one gather of the counts and one of the padded records; with same_count (every rank holds the same number of
+    records, e.g. its share of a cohort) the counts are not exchanged: one collective, no round trip for the sizes.
+    group: ffi.Group (sp_gather_results: RCCL) or TorchGroup; None = the torch process group when there is one, else a single rank."""
+    calls = np.ascontiguousarray(calls, CALL_DTYPE)
+    if group is None:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return np.sort(calls, order=["sample", "gene"])
+        group = TorchGroup(device)
+    world = group.n_ranks
+    counts = [len(calls)] * world if same_count else [int(c) for c in group.gather(np.array([len(calls)], np.int64)).reshape(-1)]
+    nmax = max(counts) if counts else 0
+    pad = np.zeros(nmax, CALL_DTYPE)
+    pad[:len(calls)] = calls
+    everyone = group.gather(pad)
+    out = np.concatenate([everyone[r][:counts[r]] for r in range(world)]) if world else pad
     return np.sort(out, order=["sample", "gene"])

@@ -93,3 +93,26 @@ def test_upload_argument_errors(pkg, gpu_ctx):
         gpu_ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, blob, offs, np.array([1000], np.uint32))      # longer than its bytes
     with pytest.raises(pkg.StarphaseError):
         gpu_ctx.upload_format(7, blob, offs, lens)
+
+
+def test_group_of_one_rank_gathers_through_rccl(pkg, gpu_ctx):
+    """sp_group_* / sp_gather_results on the one GPU of this box: a group of a single rank still goes through ncclCommInitRank and
+    ncclAllGather (the N > 1 node is the driver's to run; two ranks on one device are refused by RCCL itself)"""
+    from pb_starphase_amd import shard
+    uid = pkg.ffi.group_unique_id()
+    assert uid.shape == (128,) and uid.any()
+    g = pkg.ffi.Group(gpu_ctx, uid, 0, 1)
+    import ctypes as C
+    r, n = C.c_int32(-1), C.c_int32(-1)
+    assert pkg.ffi.lib().sp_group_size(g._h, C.byref(r), C.byref(n)) == 0 and (r.value, n.value) == (0, 1)
+    rec = np.zeros(5, shard.CALL_DTYPE)
+    for k in range(5):
+        rec[k] = (3, k, 10 + k, 20 + k)
+    out = g.gather(rec)
+    assert out.shape == (1, 5) and out[0].tolist() == rec.tolist()
+    table = shard.gather_calls(rec[::-1].copy(), group=g, same_count=True)
+    assert table.tolist() == rec.tolist()
+    assert shard.gather_calls(rec, group=g).tolist() == rec.tolist()
+    big = np.arange(100000, dtype=np.int64)
+    assert (g.gather(big)[0] == big).all()
+    g.close()
