@@ -1,38 +1,46 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric "HiFi reads/sec diplotyped (HLA+CYP2D6)" on one node of MI355X.
 
-Headline (`value`): BASELINE configs[1] from READS TO DIPLOTYPE -- HLA-A/-B, 10,000 synthetic HiFi reads already resident in HBM
-    K1  sp_hla_realign_reads      every read x every DNA allele of the bundled IMGT/HLA DB (anchor, cells, reduce, finalize)
-    --  sp_hla_diplotype_genes    segments + homopolymer compression on the device, K8 dual consensus (HPC, DNA fallback) and
-                                  per-group consensus, K2 typing of the consensuses against every allele, het / hom decision
-Beside it in the same JSON line:
-    scoring_only   K1 + K2 on truth consensuses (round 1's headline; the read -> allele and consensus -> allele scoring without K8)
-    roofline       k1_cells_kernel over the cells it actually EXECUTED; roofline_valu: its real limiter
-    cyp2d6         BASELINE configs[2]: sp_cyp_diplotype on 2,000 targeted reads, real 39 templates / variant table
-    cohort         BASELINE configs[4] shape per GPU: 32 WGS-style samples through sp_hla_diplotype_cohort
-    cpu_baseline   the oracle (scalar C port of the same contract) on a bounded sample of the same reads: K1 + consensus + K2
-`--gpus N` with N > 1: one process per GPU (spawned here when no launcher set WORLD_SIZE), each rank owns one synthetic sample (weak
-scaling, no data-path collective); the per-gene calls are gathered with one RCCL all_gather -- the only exchange of the path.
+N = 1, headline (`value`): ONE synthetic sample carrying both loci of the metric -- BASELINE configs[1] (HLA-A / -B, 10,000 HiFi reads against the
+bundled IMGT/HLA database) and configs[2] (CYP2D6, 2,000 targeted reads) -- from the reads' bytes in host memory to the diplotypes, a NEW sample
+every step:
+    upload   sp_seqset_upload_async: BAM's 4-bit SEQ bytes through the pinned staging ring, the bytes of sample i + 1 under the kernels of sample i
+    HLA      sp_hla_realign_reads (K1: anchors, every read x every DNA allele) -> sp_hla_diplotype_genes (segments, HPC dual + group consensus = K8,
+             typing of the consensuses against every allele = K2, het / hom call)
+    CYP2D6   sp_cyp_diplotype (K3 regions -> multi-way consensus K8 -> K9 / K7 typing -> K4 weights -> chains -> K5 chain pair) on a context of its own,
+             beside the HLA half on the same GPU (two host threads, two HIP streams + their helpers)
+Beside it in the same JSON line: `roofline` (k1_cells_kernel), `cpu_baseline` (the reference's call pattern on the minimap2
+restatement of the oracle, see tests/cpu_port_seeded.py), `legs` (HLA alone with resident reads = round 2's headline, the six CYP2D6 scenarios, the
+256-sample cohort on this one GPU, K5 at scale).
+
+N > 1 (`--gpus N`, or under torch.distributed.run): BASELINE configs[4], the 256-sample cohort sharded by sample over the ranks, one process per
+GPU: every rank uploads its samples' reads, runs sp_hla_diplotype_cohort + sp_cyp_diplotype_cohort + sp_variant_solve_batch and the per-(sample,
+gene) call records are gathered with ONE sp_gather_results (ncclAllGather over RCCL / xGMI) per step -- the only exchange of the path.  The total
+work is fixed (strong scaling); the N = 1 line carries the same cohort as `legs.cohort` for the efficiency figure.
 """
 import argparse
+import gzip
 import json
 import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
 
-# HIP maps streams onto a few hardware queues (4 by default): the streams of the samples-in-flight leg should each get their own
+# HIP maps streams onto a few hardware queues (4 by default): the two halves of a sample and their helper streams should each get their own
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2    # 256 CU x 4 SIMD-32 x one wave-instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md); sp_microbench measures it
+COUNTER_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 def spawn_ranks(n, argv):
@@ -58,44 +66,20 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def host_description():
+    """CPU model / sockets / cores of the box the CPU leg runs on"""
+    out = {"logical_cpus": len(os.sched_getaffinity(0))}
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            if k.strip() in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU max MHz"):
+                out[k.strip()] = v.strip()
+    except Exception:
+        pass
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------- CPU baseline
-_CB = {}
-
-
-def _cpu_k1_worker(args):
-    """one worker process: whole-read K1 searches on its slice of reads until the time budget is spent"""
-    import ctypes as C
-    lo, hi, budget_s = args
-    o, L = _CB["o"], _CB["L"]
-    done, best, t0 = 0, [], time.perf_counter()
-    for r in range(lo, hi):
-        re = o.encode(_CB["reads"][r])
-        ncell = C.c_int64(0)
-        b = L.osp_hla_k1_read(re.ctypes.data_as(C.c_void_p), len(re), len(_CB["refs"]), _CB["ref_ptr"], _CB["ref_len"].ctypes.data_as(C.c_void_p),
-                              _CB["n_all"], _CB["al_ptr"], _CB["al_len"].ctypes.data_as(C.c_void_p), _CB["gene_of"].ctypes.data_as(C.c_void_p),
-                              _CB["off"].ctypes.data_as(C.c_void_p), None, C.byref(ncell))
-        best.append((r, b))
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    return done, time.perf_counter() - t0, best
-
-
-def _cpu_gene_worker(args):
-    """one worker process: the gene loop of one gene on the sample (dual consensus, group consensus, typing = K2) from oracle pieces"""
-    g, sample = args
-    import hla_expected as hx
-    import hla_pipeline as hp
-    from pb_starphase_amd import synth
-    o, fx = _CB["o"], _CB["fx"]
-    reads = [_CB["reads"][r] for r in sample]
-    t0 = time.perf_counter()
-    k1 = hx.k1_records_for(o, fx, reads, [_CB["best"][r] for r in sample], hx.K1Tables(o, fx, _CB["off"]))   # segments and offsets of the reads K1 placed
-    t1 = time.perf_counter()
-    res = hp.diplotype_gene(o, fx, g, reads, k1, synth)
-    return g, t1 - t0, time.perf_counter() - t1, (res["allele1"], res["allele2"])
-
-
 def native_oracle():
     """the oracle rebuilt on THIS host with -O3 -march=native (the CPU leg is compiled for the machine it runs on); the
     shipped liboracle.so (-O3, generic x86-64) is the fallback when no compiler is at hand"""
@@ -111,67 +95,97 @@ def native_oracle():
         return None, "-O3 (shipped build)"
 
 
-def cpu_baseline(fx, wl, budget_s=10.0):
-    """The oracle ("port": the same contract in scalar C, one alignment per (read, allele) cell -- an EXHAUSTIVE search, not
-    minimap2's seed-chain-extend with best_n = 5, which does orders of magnitude less base-level work per read and is not on disk)
-    on a bounded sample of the same batch, BEFORE the GPU is touched (workers are forked): K1 over every host core, then per gene
-    the dual + group consensus and the typing of the consensuses against every allele (K2).  The reference itself is
-    single-threaded (src/cli/diplotype.rs:185-191): the one-thread K1 rate is given as well."""
-    import ctypes as C
-    import multiprocessing as mp
+def cpu_baseline(fx, reads, n_sample=1500):
+    """The reference's CPU path in its own call pattern (tests/cpu_port_seeded.py): one seeded minimap2-style map per read against the index of all
+    DNA alleles with the best chains base-aligned (`best_n 5`), the consensus of the oracle, every allele of the gene mapped to every consensus --
+    on a bounded sample of the same batch, BEFORE the GPU is touched (the workers are forked)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi
+    import cpu_port_seeded
     lib, flags = native_oracle()
     o = oracle_ffi.load(lib) if lib else oracle_ffi.load()
-    L = o.L
-    L.osp_hla_k1_read.restype = C.c_int32
-    refs = [o.encode(s) for s in fx.gene_ref]
-    n_all = len(fx.ids)
-    enc = [o.encode(fx.dna_fwd(a)) if fx.dna[a] else np.zeros(0, np.uint8) for a in range(n_all)]
-    off = np.full(n_all, -2 ** 31, np.int32)
-    for a in range(n_all):                       # untimed set-up (the reference builds its index once too)
-        if len(enc[a]):
-            d, v = o.anchor(refs[int(fx.gene_of[a])], enc[a])
-            if v >= 16:
-                off[a] = d
-    _CB.update(o=o, L=L, fx=fx, reads=wl.reads, refs=refs, n_all=n_all, enc=enc, off=off,
-               ref_ptr=(C.c_void_p * len(refs))(*[r.ctypes.data for r in refs]), ref_len=np.array([len(r) for r in refs], np.int32),
-               al_ptr=(C.c_void_p * n_all)(*[(e.ctypes.data if len(e) else None) for e in enc]),
-               al_len=np.array([len(e) for e in enc], np.int32), gene_of=fx.gene_of.astype(np.int32))
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64, len(wl.reads) // 8))
-    per = len(wl.reads) // cores                  # reads reserved per worker (not exhausted inside the budget at bench sizes)
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_k1_worker, [(w * per, min(len(wl.reads), (w + 1) * per), budget_s) for w in range(cores)])
-    t_k1 = max(r[1] for r in res)
-    done = sum(r[0] for r in res)
-    single = res[0][0] / res[0][1] if res[0][1] > 0 else 0.0
-    best = dict(b for r in res for b in r[2])
-    # the rest of the path on the reads K1 just placed: per gene, consensus + typing (two workers, one per gene)
-    _CB["best"] = best
-    sample = sorted(best)
-    t1 = time.perf_counter()
-    with mp.get_context("fork").Pool(len(fx.genes)) as pool:
-        gres = pool.map(_cpu_gene_worker, [(g, sample) for g in range(len(fx.genes))])
-    t_rest = time.perf_counter() - t1
-    calls = {g: c for g, _a, _b, c in gres}
-    wall = time.perf_counter() - t0
-    return {"value": done / (t_k1 + t_rest), "unit": "reads/s", "cores": cores, "kind": "port", "compiler_flags": flags,
-            "single_thread_k1_value": single, "k1_s": t_k1, "consensus_and_k2_s": t_rest,
-            "sample": f"{done} reads of the same batch: K1 (anchor + every allele cell + acceptance) over {cores} forked workers in {t_k1:.1f} s, then per gene "
-                      f"(2 workers) dual + group consensus and typing against every allele (K2) in {t_rest:.1f} s; {wall:.1f} s wall",
-            "note": "exhaustive scalar port of the library's alignment contract, NOT minimap2 (absent): a reported baseline, not the >= 20x target"}, best, calls
+    res, best, calls, cons, done = cpu_port_seeded.run(o, fx, reads, n_sample=n_sample)
+    res["compiler_flags"] = flags
+    res["host"] = host_description()
+    return res, best, calls, done
+
+
+# ---------------------------------------------------------------------------------------------------------------- workloads
+class HlaSample:
+    """BASELINE configs[1]: the reads of one sample as a BAM reader hands them over (sp_bam_last_seq4: 4 bits per base)"""
+
+    def __init__(self, pkg, fx, n_reads, seed):
+        from pb_starphase_amd import synth
+        self.wl = synth.Config2Workload(fx, n_reads=n_reads, seed=seed)
+        self.n = len(self.wl.reads)
+        self.payload = pkg.ffi.encode_bam4(self.wl.reads)
+        self.ascii_bytes = sum(len(r) for r in self.wl.reads)
+        genes = range(len(fx.genes))
+        self.truth = {g: sorted(a for (gg, _c, _d, a) in self.wl.consensus if gg == g) for g in genes}
+
+
+class CypSample:
+    """BASELINE configs[2]: 2,000 targeted-style reads of one scenario on the synthetic chr22 locus"""
+
+    def __init__(self, pkg, locus, scenario, n_reads, seed):
+        self.name, haps, self.expected = scenario
+        self.reads = locus.sample(np.random.default_rng(seed), haps, n_reads)
+        self.n = len(self.reads)
+        self.payload = pkg.ffi.encode_bam4(self.reads)
+        self.ascii_bytes = sum(len(r) for r in self.reads)
+
+
+def same_allele(fx, a, b):
+    return a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+
+
+class Lane(threading.Thread):
+    """one locus of the stream of samples on a context of its own: wait for this sample's bytes, start the next sample's upload, compute"""
+
+    def __init__(self, pkg, ctx, payloads, work, steps, fresh_upload=True):
+        super().__init__()
+        self.pkg, self.ctx, self.payloads, self.work, self.steps, self.fresh = pkg, ctx, payloads, work, steps, fresh_upload
+        self.result, self.error = None, None
+        self.pending = self.start_upload(0) if fresh_upload else None
+        self.resident = None if fresh_upload else [ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *p) for p in payloads]
+
+    def start_upload(self, i):
+        blob, offs, lens = self.payloads[i % len(self.payloads)]
+        return self.ctx.upload_format(self.pkg.ffi.SP_SEQ_BAM4, blob, offs, lens, wait=False)
+
+    def run(self):
+        try:
+            for i in range(self.steps):
+                if self.fresh:
+                    cur = self.pending.wait()
+                    self.pending = self.start_upload(i + 1)          # the next sample's bytes travel under this sample's kernels
+                else:
+                    cur = self.resident[i % len(self.resident)]
+                self.result = self.work(cur, i)
+                if self.fresh:
+                    cur.close()
+            if self.fresh:
+                self.pending.wait().close()
+                self.pending = None
+        except Exception as e:                                      # surfaces in the main thread
+            self.error = e
+
+
+def run_lanes(lanes):
+    for x in lanes:
+        x.start()
+    for x in lanes:
+        x.join()
+    for x in lanes:
+        if x.error is not None:
+            raise x.error
 
 
 # ---------------------------------------------------------------------------------------------------------------- legs
-def cyp_leg(pkg, ctx, n_reads=2000, reps=2):
-    """BASELINE configs[2]: sp_cyp_diplotype on the synthetic chr22 locus (database coordinates, 39 templates, real variant table)"""
+def cyp_leg(pkg, ctx, cdb, locus, n_reads=2000, reps=2):
+    """BASELINE configs[2]: sp_cyp_diplotype on the six scenarios of the survey (database coordinates, 39 templates, real variant table)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cyp_cases_real as cr
-    from pb_starphase_amd import synth
-    cfg, gene_def = cr.load_db()
-    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
-    db = pkg.ffi.CypDb(ctx, cfg, gene_def, locus.sequence, locus.start)
     out, sets = {}, []
     total_reads, total_s, ok = 0, 0.0, 0
     for name, haps, expected in cr.scenarios(locus):
@@ -182,37 +196,26 @@ def cyp_leg(pkg, ctx, n_reads=2000, reps=2):
             ctx.profile_reset()
             ctx.synchronize()
             t0 = time.perf_counter()
-            call, _cons, _labels = db.diplotype(R)
+            call, _cons, _labels = cdb.diplotype(R)
             dt = time.perf_counter() - t0
             best = dt if best is None or dt < best else best
         good = sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
         ok += good
         out[name] = {"ms": 1e3 * best, "reads": len(reads), "call_equals_truth": bool(good), "cons_ms": ctx.profile_get("cons_steps")[0],
-                     "launch_pairs": ctx.profile_get("cons_windows")[2], "cut_windows": ctx.profile_get("cons_cut_windows")[2],
+                     "launch_triples": ctx.profile_get("cons_windows")[2], "cut_windows": ctx.profile_get("cons_cut_windows")[2],
                      "expansions": ctx.profile_get("cons_expansions")[2], "nodes_expanded": ctx.profile_get("cons_columns")[2],
                      "host_wall_ms": {k: round(ctx.profile_get("host:cyp_" + k)[0], 2) for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")}}
         total_reads += len(reads); total_s += best
         sets.append(R)
-    # the same six samples as one GPU's share of a cohort: one sp_cyp_diplotype_cohort call, samples spread over the context's streams
-    cohort_best = None
-    for _ in range(reps):
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        cohort = db.diplotype_cohort(sets)
-        dt = time.perf_counter() - t0
-        cohort_best = dt if cohort_best is None or dt < cohort_best else cohort_best
-    cohort_ok = sum(sorted([c.hap1.decode(), c.hap2.decode()]) == sorted(exp) for (c, _cons, _rc), (_n, _h, exp) in zip(cohort, cr.scenarios(locus)))
     return {"value": total_reads / total_s, "unit": "reads/s",
-            "cohort_call": {"value": total_reads / cohort_best, "unit": "reads/s", "samples_per_s": len(sets) / cohort_best, "ms": 1e3 * cohort_best,
-                            "calls_equal_truth": f"{cohort_ok}/{len(sets)}", "workload": "the six samples in one sp_cyp_diplotype_cohort call"},
             "workload": f"BASELINE configs[2]: six scenarios x {n_reads} targeted-style reads (3-8 kb) on the synthetic chr22 "
-            "locus, 39 templates, 393 variants / 520 star alleles of the bundled DB; sp_cyp_diplotype (K3 -> K8 -> K9/K7 -> K4 -> chains -> K5)",
+            "locus, 39 templates, 393 variants / 520 star alleles of the bundled DB; sp_cyp_diplotype one sample at a time, reads resident",
             "calls_equal_truth": f"{ok}/{len(out)}", "scenarios": out}
 
 
 def chain_pair_leg(pkg, ctx, n_d6=4, n_reads=1000, reps=2):
     """K5 at the scale of a duplication-rich sample: ~1.3k enumerated chains x 1,000 reads -> ~0.9 M chain pairs, each the f64
-    likelihood of all reads under the pair (src/cyp2d6/chaining.rs:421-566).  Larger problems: profiles/r02/k5_scale.json."""
+    likelihood of all reads under the pair (src/cyp2d6/chaining.rs:421-566)."""
     from pb_starphase_amd import synth
     prob = synth.chain_pair_problem(n_d6, n_reads, np.random.default_rng(7))
     best = None
@@ -225,103 +228,182 @@ def chain_pair_leg(pkg, ctx, n_d6=4, n_reads=1000, reps=2):
     P = res.n_possible
     pairs = P * (P + 1) // 2
     ms_pairs, ms_tab = ctx.profile_get("k5_pairs")[0], ctx.profile_get("k5_chain_reads")[0]
-    # per pair and read: two table entries (the read's best window total under either chain, u64, + the mask of the starts reaching it, u64)
-    table_bytes = 2 * 16
     return {"value": pairs / (ms_pairs * 1e-3) if ms_pairs else None, "unit": "chain pairs/s", "status": rc, "chains": P, "reads": n_reads, "pairs": pairs,
             "pairs_scored": int(res.n_pairs_scored), "k5_pairs_ms": ms_pairs, "k5_chain_reads_ms": ms_tab, "wall_ms": 1e3 * best,
-            "pair_read_terms_per_s": pairs * n_reads / (ms_pairs * 1e-3) if ms_pairs else None,
-            "table_bytes_read_per_s": pairs * n_reads * table_bytes / (ms_pairs * 1e-3) if ms_pairs else None,
-            "table_footprint_bytes": P * n_reads * 16,
             "workload": f"sp_cyp_best_chain_pair: {n_d6} CYP2D6 consensuses, {n_reads} reads, {P} enumerated chains (the per-(chain, read) tables sit in L2; "
                         "the kernel is f64-add / compare bound, not HBM bound)"}
 
 
-def inflight_leg(pkg, fx, n_streams=3, steps=10, n_reads=10000, device=0):
-    """Several samples in flight on one GPU: n_streams host threads, each with its own context (= HIP stream), database handle and
-    resident 10,000-read sample, run the same reads -> diplotype step as the headline.  The VALU-bound K1 of one sample overlaps the
-    latency-bound consensus launches of the others (ctypes releases the GIL inside the library)."""
-    import threading
-    from pb_starphase_amd import synth
-    workers = []
-    for t in range(n_streams):
-        wl = synth.Config2Workload(fx, n_reads=n_reads, seed=2000 + t)
-        c = pkg.Context(device)
-        c.set_option("hla_split_genes", 0)          # the other samples' streams fill the gaps: one stream per sample
-        d = fx.make_db(pkg, c)
-        workers.append((c, d, c.upload(wl.reads), wl))
-    genes = list(range(len(fx.genes)))
-    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+# ---------------------------------------------------------------------------------------------------------------- the cohort (configs[4])
+class VariantPanel:
+    """the variant genes of the bundled database as K6 problems (sp_variant_gene_problem builds the haplotype side); the observed side of a
+    synthetic sample is written straight into the integer arrays the kernel reads"""
 
-    def run(w, k, out):
-        c, d, reads, _wl = w
-        for _ in range(k):
-            o = d.realign_reads(reads)
-            out[:] = [d.diplotype_genes(genes, reads, o)[0]]
+    def __init__(self, pkg):
+        D = pkg.database
+        path = os.path.join(GOLDEN, "gene_entries_v0.14.1.json.gz")
+        names = sorted(json.load(gzip.open(path))["gene_entries"])
+        self.db = D.Database(path)
+        self.genes = []
+        for name in names:
+            gene = self.db.variant_gene(name)
+            base = gene.problem()
+            arr = D.problem_arrays(base)
+            slots = []
+            for h in range(arr["n_haps"]):
+                sl = []
+                for s in range(arr["slot_off"][h], arr["slot_off"][h + 1]):
+                    alts = arr["alt_var"][arr["alt_off"][s]:arr["alt_off"][s + 1]]
+                    sl.append([int(v) for v in alts])
+                slots.append(sl)
+            usable = [h for h in range(arr["n_haps"]) if not arr["hap_is_sv"][h] and all(any(v >= 0 for v in s) for s in slots[h])]
+            keep = {k: np.ascontiguousarray(arr[k], t) for k, t in (("hap_is_sv", np.uint8), ("hap_is_core", np.uint8), ("slot_off", np.int32), ("alt_off", np.int32),
+                                                                     ("alt_var", np.int32), ("var_is_core", np.uint8))}
+            self.genes.append(dict(name=name, gene=gene, n_haps=arr["n_haps"], n_vars=arr["n_vars"], slots=slots, usable=usable, arrays=keep))
 
-    for w in workers:
-        run(w, 1, [])
-    outs = [[] for _ in workers]
-    th = [threading.Thread(target=run, args=(workers[i], steps, outs[i])) for i in range(n_streams)]
-    for c, _d, _r, _w in workers:
-        c.synchronize()
-    t0 = time.perf_counter()
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    for c, _d, _r, _w in workers:
-        c.synchronize()
-    dt = time.perf_counter() - t0
-    ok = 0
-    for (c, d, reads, wl), out in zip(workers, outs):
-        truth = {g: sorted(a for (gg, _c, _d2, a) in wl.consensus if gg == g) for g in genes}
-        for g, (call, _c1, _c2) in enumerate(out[0]):
-            ok += all(same(a, b) for a, b in zip(sorted([call.allele1, call.allele2]), sorted((truth[g] * 2)[:2])))
-    return {"value": n_reads * n_streams * steps / dt, "unit": "reads/s", "streams": n_streams, "samples": n_streams * steps, "ms_per_sample": 1e3 * dt / (n_streams * steps),
-            "diplotypes_equal_truth": f"{ok}/{n_streams * len(genes)}",
-            "workload": f"{n_streams} samples of {n_reads} reads in flight on {n_streams} HIP streams of one GPU, the headline's step each (one process, one host thread per stream)"}
+    def problems(self, pkg, rng, max_hets=8):
+        """one synthetic sample: per gene a diplotype of two defined haplotypes and the variants a VCF would show for it"""
+        out, keep, truth = [], [], []
+        for G in self.genes:
+            for _ in range(50):
+                h1, h2 = (G["usable"][int(i)] for i in rng.integers(0, len(G["usable"]), 2))
+                v1 = {next(v for v in s if v >= 0) for s in G["slots"][h1]}
+                v2 = {next(v for v in s if v >= 0) for s in G["slots"][h2]}
+                hets = sorted((v1 | v2) - (v1 & v2))
+                if len(hets) <= max_hets:
+                    break
+            obs = {v: (4, -1) for v in v1 & v2}
+            phased, ps = rng.random() < 0.6, int(rng.integers(1000, 2000))
+            for v in hets:
+                obs[v] = ((2 if v in v2 else 3), ps) if (phased and rng.random() < 0.85) else (1, -1)
+            order = sorted(obs)
+            a = G["arrays"]
+            ov, og = np.array(order, np.int32), np.array([obs[v][0] for v in order], np.int32)
+            op, ol = np.array([obs[v][1] for v in order], np.int64), np.full(len(order), -1, np.int32)
+            p = pkg.ffi.sp_variant_problem()
+            p.n_haps, p.n_vars, p.n_obs = G["n_haps"], G["n_vars"], len(order)
+            for k in ("hap_is_sv", "hap_is_core", "slot_off", "alt_off", "alt_var", "var_is_core"):
+                setattr(p, k, a[k].ctypes.data)
+            p.obs_var, p.obs_gt, p.obs_ps, p.obs_sv_label = ov.ctypes.data, og.ctypes.data, op.ctypes.data, ol.ctypes.data
+            out.append(p); keep.append((ov, og, op, ol)); truth.append((h1, h2))
+        return out, keep, truth
 
 
-def cohort_leg(pkg, ctx, fx, db, n_samples=32, reps=2, seed=5):
-    """BASELINE configs[4] per GPU: n_samples WGS-style samples (~45 reads per gene) through one K1 call + sp_hla_diplotype_cohort"""
-    from pb_starphase_amd import synth
-    rng = np.random.default_rng(seed)
-    reads, sample_of, truth = [], [], []
-    for s in range(n_samples):
-        t = {}
-        for g in range(len(fx.genes)):
-            pick = rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist()
-            t[g] = sorted(pick)
-            for a in pick:
-                hap, st = fx.haplotype(g, a)
-                rs = synth.simulate_reads(rng, hap, st, len(fx.dna[a]), 22, mean_len=7000, sd_len=1500, min_overlap=2500)
-                reads += rs; sample_of += [s] * len(rs)
-        truth.append(t)
-    R = ctx.upload(reads)
-    genes = list(range(len(fx.genes)))
-    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
-    best = None
-    for _ in range(reps + 1):
-        ctx.synchronize()
-        t0 = time.perf_counter()
+class CohortShare:
+    """a rank's share of BASELINE configs[4]: 256 WGS-style samples, all supported genes -- HLA-A / -B (~44 reads per gene), CYP2D6 (~100 reads),
+    the 18 variant genes of the bundled database (synthetic VCF observations).  A sample's data depends on its global id only."""
+
+    def __init__(self, pkg, fx, locus, scen, panel, samples):
+        from pb_starphase_amd import synth
+        self.samples, self.fx = list(samples), fx
+        self.hla_reads, self.sample_of, self.hla_truth = [], [], {}
+        self.cyp_payloads, self.cyp_expected, self.cyp_reads = [], [], 0
+        self.var_problems, self._keep, self.var_truth = [], [], []
+        genes = range(len(fx.genes))
+        for k, s in enumerate(self.samples):
+            rng = np.random.default_rng(10_000 + s)
+            for g in genes:
+                pick = sorted(rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist())
+                self.hla_truth[(k, g)] = pick
+                for a in pick:
+                    hap, st = fx.haplotype(g, a)
+                    rs = synth.simulate_reads(rng, hap, st, len(fx.dna[a]), 22, mean_len=7000, sd_len=1500, min_overlap=2500)
+                    self.hla_reads += rs; self.sample_of += [k] * len(rs)
+            sc = scen[s % 3]                                                       # *1/*2, *4/*4, *5/*1
+            cr_ = locus.sample(np.random.default_rng(20_000 + s), sc[1], 100, lo=8000, hi=16000)
+            self.cyp_payloads.append(pkg.ffi.encode_bam4(cr_)); self.cyp_expected.append(sc[2]); self.cyp_reads += len(cr_)
+            pr, keep, truth = panel.problems(pkg, np.random.default_rng(30_000 + s))
+            self.var_problems += pr; self._keep.append(keep); self.var_truth += truth
+        self.hla_payload = pkg.ffi.encode_bam4(self.hla_reads)
+        self.n_reads = len(self.hla_reads) + self.cyp_reads
+        self.n_genes_panel = len(panel.genes)
+
+    def step(self, pkg, ctx, db, cdb, shard, group, rank):
+        """uploads, calls and the gather of one pass over the share; returns (records table, counts of calls equal to the truth)"""
+        fx = self.fx
+        genes = list(range(len(fx.genes)))
+        up = ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *self.hla_payload, wait=False)
+        cyp_sets = []
+        R = up.wait()
+        for p in self.cyp_payloads:                                              # (one upload in flight per context: each waits for the one before)
+            cyp_sets.append(ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *p, wait=False))
         k1 = db.realign_reads(R)
-        cohort, _ = db.diplotype_cohort(n_samples, sample_of, genes, R, k1)
-        dt = time.perf_counter() - t0
-        best = dt if best is None or dt < best else best
-    ok = sum(all(same(x, y) for x, y in zip(sorted([cohort[s][g][0].allele1, cohort[s][g][0].allele2]), truth[s][g])) for s in range(n_samples) for g in genes)
-    return {"value": len(reads) / best, "unit": "reads/s", "samples_per_s": n_samples / best, "ms": 1e3 * best, "samples": n_samples, "reads": len(reads),
-            "workload": f"BASELINE configs[4] per GPU: {n_samples} WGS-style samples x HLA-A/-B (~44 reads per gene), one K1 call + sp_hla_diplotype_cohort",
-            "calls_equal_truth": f"{ok}/{n_samples * len(genes)}"}
+        cohort, _ = db.diplotype_cohort(len(self.samples), self.sample_of, genes, R, k1)
+        for c in cyp_sets:
+            c.wait()
+        cyp = cdb.diplotype_cohort(cyp_sets)
+        var = ctx.variant_solve_batch(self.var_problems)
+        n_rec = len(self.samples) * (len(genes) + 1 + self.n_genes_panel)
+        rec = np.zeros(n_rec, shard.CALL_DTYPE)
+        ok_hla = ok_cyp = ok_var = 0
+        at = 0
+        for k, s in enumerate(self.samples):
+            for g in genes:
+                c = cohort[k][g][0]
+                rec[at] = (s, g, c.allele1, c.allele2); at += 1
+                ok_hla += all(same_allele(fx, x, y) for x, y in zip(sorted([c.allele1, c.allele2]), self.hla_truth[(k, g)]))
+            call = cyp[k][0]
+            ok_cyp += sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(self.cyp_expected[k])
+            rec[at] = (s, len(genes), int(call.status), int(call.n_consensus)); at += 1
+            for gi in range(self.n_genes_panel):
+                score, dips = var[k * self.n_genes_panel + gi]
+                h1, h2 = self.var_truth[k * self.n_genes_panel + gi]
+                ok_var += any({d[0], d[1]} == {h1, h2} for d in dips)
+                d0 = dips[0] if dips else (-1, -1, 0)
+                rec[at] = (s, len(genes) + 1 + gi, d0[0], d0[1]); at += 1
+        table = shard.gather_calls(rec, group=group, same_count=True)
+        R.close()
+        for c in cyp_sets:
+            c.close()
+        return table, (ok_hla, ok_cyp, ok_var)
 
 
+def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, barrier, max_over_ranks):
+    from pb_starphase_amd import shard
+    panel = VariantPanel(pkg)
+    mine = shard.partition(args.cohort_samples, world, rank)
+    per_call = 32                                                       # samples per cohort call (one GPU's share of the 8-GPU node)
+    chunks = [mine[i:i + per_call] for i in range(0, len(mine), per_call)]
+    shares = [CohortShare(pkg, fx, locus, scen, panel, c) for c in chunks]
+    for _ in range(args.warmup):
+        shares[0].step(pkg, ctx, db, cdb, shard, group, rank)
+    barrier()
+    t0 = time.perf_counter()
+    ok = np.zeros(3, np.int64)
+    n_table = 0
+    for _ in range(args.steps):
+        for sh in shares:
+            table, good = sh.step(pkg, ctx, db, cdb, shard, group, rank)
+            ok += np.array(good); n_table += len(table)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    my_reads = sum(sh.n_reads for sh in shares)
+    totals = np.array([my_reads, len(mine), ok[0], ok[1], ok[2]], np.int64)
+    if group is not None:
+        totals = group.gather(totals).sum(0)
+    reads_all, samples_all = int(totals[0]), int(totals[1])
+    n_genes = len(fx.genes)
+    return {"value": reads_all * args.steps / dt, "unit": "reads/s", "samples_per_s": samples_all * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+            "samples": samples_all, "reads_per_pass": reads_all, "records_gathered_per_pass": n_table // max(1, args.steps),
+            "calls_equal_truth": {"hla": f"{int(totals[2])}/{samples_all * n_genes * args.steps}", "cyp2d6": f"{int(totals[3])}/{samples_all * args.steps}",
+                                  "variant_genes_truth_among_reported": f"{int(totals[4])}/{samples_all * len(panel.genes) * args.steps}"},
+            "workload": f"BASELINE configs[4]: {args.cohort_samples} synthetic WGS-style samples x (HLA-A / -B ~44 reads per gene, CYP2D6 ~100 reads, {len(panel.genes)} variant genes), "
+                        f"sharded by sample over {world} rank(s) in calls of {per_call} samples: upload (BAM 4-bit) -> sp_hla_realign_reads + sp_hla_diplotype_cohort -> "
+                        "sp_cyp_diplotype_cohort -> sp_variant_solve_batch -> one gather of the call records"}
+
+
+# ---------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=10000)
+    ap.add_argument("--reads", type=int, default=10000, help="HLA reads of the sample (configs[1])")
+    ap.add_argument("--cyp-reads", type=int, default=2000, help="CYP2D6 reads of the sample (configs[2])")
+    ap.add_argument("--cohort-samples", type=int, default=256)
+    ap.add_argument("--workload", choices=("auto", "sample", "cohort"), default="auto", help="auto: the sample at N = 1, the cohort at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the scoring-only, CYP2D6 and cohort legs")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-HLA, CYP2D6-scenario, cohort and K5 legs")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -330,13 +412,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    workload = args.workload if args.workload != "auto" else ("sample" if world == 1 else "cohort")
     pkg = ge.load_package()
     from pb_starphase_amd import synth, shard
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cyp_cases_real as cr
     fx = synth.HlaFixture()
-    wl = synth.Config2Workload(fx, n_reads=args.reads, seed=1000 + rank)
-    cb, cpu_best, cpu_calls = (None, None, None)
-    if not args.no_cpu_baseline and world == 1:
-        cb, cpu_best, cpu_calls = cpu_baseline(fx, wl)          # forks workers: must happen before anything touches the GPU
+    samples = [HlaSample(pkg, fx, args.reads, 1000 + rank + 100 * k) for k in range(2)] if workload == "sample" else []
+    cb, cpu_best, cpu_calls, cpu_done = (None, None, None, None)
+    if not args.no_cpu_baseline and world == 1 and workload == "sample":
+        cb, cpu_best, cpu_calls, cpu_done = cpu_baseline(fx, samples[0].wl.reads)          # forks workers: must happen before anything touches the GPU
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -356,10 +441,11 @@ def main():
 
     ctx = pkg.Context(device_index)
     db = fx.make_db(pkg, ctx)
-    t_up = time.perf_counter()
-    reads = ctx.upload(wl.reads)
-    t_up = time.perf_counter() - t_up
-    genes = list(range(len(fx.genes)))
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    cdb = pkg.ffi.CypDb(ctx, cfg, gene_def, locus.sequence, locus.start)
+    scen = cr.scenarios(locus)
+    group = shard.make_group(ctx, pkg.ffi, backend=backend, device=coll_dev) if world > 1 else None      # sp_group: RCCL through the library
 
     def barrier():
         if world > 1:
@@ -374,145 +460,182 @@ def main():
             return float(t.item())
         return dt
 
-    # ---- headline: reads -> diplotype
-    def step():
-        o = db.realign_reads(reads)
-        gene_calls = db.diplotype_genes(genes, reads, o)[0]
+    if workload == "cohort":
+        line = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, barrier, max_over_ranks)
+        if rank == 0:
+            out = {"metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)", "value": line["value"], "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": line["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                   "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
+                   "config": {"workload": line["workload"], "samples": line["samples"], "parallelism": f"samples sharded over {world} GPU(s), one sp_gather_results (RCCL all-gather) per pass"
+                              if backend == "nccl" else f"samples sharded over {world} rank(s) on shared devices, gather through torch.distributed ({backend})"},
+                   "cohort": line, "roofline": None, "cpu_baseline": None,
+                   "note": "strong scaling: the cohort's work is fixed, every rank owns samples / N of it; the N = 1 figure for the same cohort is `legs.cohort` of the N = 1 line"}
+            print(json.dumps(out), flush=True)
+        if group is not None and hasattr(group, "close"):
+            group.close()
         if world > 1:
-            # RCCL: the only exchange step of the path -- one gather of the per-(sample, gene) call records
-            rec = np.zeros(len(genes), shard.CALL_DTYPE)
-            for g, (c, _c1, _c2) in enumerate(gene_calls):
-                rec[g] = (rank, g, c.allele1, c.allele2)
-            shard.gather_calls(rec, device=coll_dev, same_count=True)
-        return o, gene_calls
+            dist.destroy_process_group()
+        return
 
-    for _ in range(args.warmup):
-        out, gene_calls = step()
-    ctx.profile_reset()
-    barrier()
+    # ------------------------------------------------------------------------------------------------ the sample: HLA-A / -B + CYP2D6, a new one every step
+    ctx_c = pkg.Context(device_index)                       # the CYP2D6 half runs beside the HLA half on a context (stream, pools) of its own
+    cdb_c = pkg.ffi.CypDb(ctx_c, cfg, gene_def, locus.sequence, locus.start)
+    cyp_samples = [CypSample(pkg, locus, scen[k], args.cyp_reads, 7 + k) for k in (0, 1)]          # *1/*2 and *4/*4 alternate
+    genes = list(range(len(fx.genes)))
+    last = {}
+
+    def hla_work(R, i):
+        o = db.realign_reads(R)
+        calls = db.diplotype_genes(genes, R, o)[0]
+        last["hla"] = (i, o, calls)
+        return calls
+
+    def cyp_work(R, i):
+        call, _cons, _labels = cdb_c.diplotype(R)
+        last["cyp"] = (i, call)
+        return call
+
+    def make_lanes(steps, fresh=True):
+        return [Lane(pkg, ctx, [s.payload for s in samples], hla_work, steps, fresh), Lane(pkg, ctx_c, [s.payload for s in cyp_samples], cyp_work, steps, fresh)]
+
+    run_lanes(make_lanes(max(1, args.warmup)))
+    ctx.profile_reset(); ctx_c.profile_reset()
+    lanes = make_lanes(args.steps)                          # (sample 0's bytes start travelling here: the pipeline is full when the clock starts)
+    for x in lanes:
+        x.pending.wait()
+    barrier(); ctx_c.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, gene_calls = step()
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    run_lanes(lanes)
+    barrier(); ctx_c.synchronize()
+    dt = time.perf_counter() - t0
+    reads_per_step = samples[0].n + cyp_samples[0].n
 
-    e2e_names = ("anchor", "anchor_k1", "anchor_k2", "anchor_type", "k1_cells", "k1_cells_deep", "k1_reduce", "k1_finalize", "hla_segments", "cons_steps", "type_consensus_ref",
+    e2e_names = ("anchor_k1", "anchor_k2", "anchor_type", "k1_cells", "k1_cells_deep", "k1_reduce", "k1_finalize", "cons_steps", "type_consensus_ref",
                  "k2_cells_cdna", "k2_cells_dna", "k2_scan")
     kernel_ms = {k: ctx.profile_get(k)[0] / max(1, args.steps) for k in e2e_names}
-    ms_cells, launches, cells_all = ctx.profile_get("k1_cells")
+    cyp_kernel_ms = {k: ctx_c.profile_get(k)[0] / max(1, args.steps) for k in ("cons_steps", "k5_pairs", "k9_graph")}
+    ms_cells, launches, _cells_all = ctx.profile_get("k1_cells")
     executed, resumed, active = ctx.counter("k1_cells_executed"), ctx.counter("k1_cells_resumed"), ctx.counter("k1_cells_active")
     exec_bytes = ctx.counter("k1_cells_bytes")
-    cons_windows = ctx.profile_get("cons_windows")[2]
-    cons_cut = ctx.profile_get("cons_cut_windows")[2]
-    cons_cols = ctx.profile_get("cons_columns")[2]
-    cons_exp = ctx.profile_get("cons_expansions")[2]
-    host_ms = {k: ctx.profile_get("host:" + k)[0] / max(1, args.steps) for k in ("hla_select", "hla_segments", "hla_setup", "hla_dual_hpc", "hla_dual_dna", "hla_groups", "hla_typing",
-                                                                                  "k8_prologue", "k8_loop", "k8_result_wait", "k8_epilogue", "k1_total", "k1_result",
-                                                                                  "hla_genes_total", "hla_split_spawn", "hla_split_own", "hla_split_join")}
-    cons_ticks = {k: ctx.profile_get("cons_ticks_" + k)[2] / 100.0 / max(1, args.steps) for k in ("reduce", "result", "search", "tail")}   # 100 MHz -> us
+    cons = {k: ctx.profile_get(n)[2] / max(1, args.steps) for k, n in (("launch_triples_per_step", "cons_windows"), ("cut_windows_per_step", "cons_cut_windows"),
+                                                                         ("expansions_per_step", "cons_expansions"), ("nodes_expanded_per_step", "cons_columns"))}
+    host_ms = {k: ctx.profile_get("host:" + k)[0] / max(1, args.steps) for k in ("hla_segments", "hla_dual_hpc", "hla_groups", "hla_typing", "k8_loop", "k1_total", "hla_genes_total")}
+    cyp_host_ms = {k: ctx_c.profile_get("host:cyp_" + k)[0] / max(1, args.steps) for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")}
     avg_ms = ms_cells / max(1, launches)
     per_launch = lambda v: v / max(1, launches)
     achieved = per_launch(exec_bytes) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
 
-    truth = {g: sorted(a for (gg, _c, _d, a) in wl.consensus if gg == g) for g in genes}
-    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
-    ok = 0
-    for g, (c, _c1, _c2) in enumerate(gene_calls):
-        got, want = sorted([c.allele1, c.allele2]), (truth[g] * 2)[:2]
-        ok += all(same(a, b) for a, b in zip(got, sorted(want)))
-    k1_gene_ok = float(np.mean([out[r]["gene"] == wl.read_truth[r][0] for r in range(len(wl.reads))]))
-    k1_realigned = float(np.mean(out["status"] == 0))
+    # the calls of the last step against the truth the reads were simulated from
+    i_h, k1_out, gene_calls = last["hla"]
+    smp = samples[i_h % 2]
+    ok = sum(all(same_allele(fx, a, b) for a, b in zip(sorted([c.allele1, c.allele2]), sorted((smp.truth[g] * 2)[:2]))) for g, (c, _c1, _c2) in enumerate(gene_calls))
+    i_c, cyp_call = last["cyp"]
+    cyp_ok = sorted([cyp_call.hap1.decode(), cyp_call.hap2.decode()]) == sorted(cyp_samples[i_c % 2].expected)
+    k1_gene_ok = float(np.mean([k1_out[r]["gene"] == smp.wl.read_truth[r][0] for r in range(smp.n)]))
 
-    # ---- scoring only (round 1's step): K1 + K2 on the truth consensuses
-    scoring = None
+    # the bytes' way alone: one synchronous upload of the HLA half in either form
+    t_up = {}
+    for name, fmt, payload in (("bam4", pkg.ffi.SP_SEQ_BAM4, samples[0].payload), ("ascii", pkg.ffi.SP_SEQ_ASCII, pkg.ffi._concat(samples[0].wl.reads) + (None,))):
+        best = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            S = ctx.upload_format(fmt, payload[0], payload[1], payload[2])
+            d = time.perf_counter() - t1
+            S.close()
+            best = d if best is None or d < best else best
+        t_up[name] = {"seconds": best, "bytes": int(len(payload[0])), "GBps": len(payload[0]) / best / 1e9, "bases_per_s": samples[0].ascii_bytes / best}
+
+    legs = {}
     if not args.no_extra_legs:
-        def score_step():
-            o = db.realign_reads(reads)
-            return o, [b for b, _n in db.score_consensus_batch([(g, cons_dna, cons_cdna) for (g, cons_dna, cons_cdna, _a) in wl.consensus])]
-        score_step()
-        barrier()
+        # HLA alone, reads resident in HBM (round 2's headline): the K1 launch the roofline block describes runs here exactly as in the headline
+        res_lane = Lane(pkg, ctx, [s.payload for s in samples], hla_work, args.steps, fresh_upload=False)
+        ctx.synchronize()
         t1 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            _o, calls = score_step()
-        barrier()
-        dts = max_over_ranks(time.perf_counter() - t1)
-        k2_ok = sum(1 for (g, _c, _d, a), b in zip(wl.consensus, calls) if same(a, b))
-        scoring = {"value": args.reads * world * reps / dts, "unit": "reads/s", "ms_per_step": 1e3 * dts / reps,
-                   "workload": "K1 on the same reads + K2 on 4 truth consensuses (no consensus step): the read -> allele and consensus -> allele scoring alone",
-                   "k2_truth_calls": f"{k2_ok}/{len(calls)}"}
+        run_lanes([res_lane])
+        ctx.synchronize()
+        d_res = time.perf_counter() - t1
+        legs["hla_resident"] = {"value": samples[0].n * args.steps / d_res, "unit": "reads/s", "ms_per_step": 1e3 * d_res / args.steps,
+                                "workload": "BASELINE configs[1] alone: K1 + sp_hla_diplotype_genes on reads already in HBM, one sample at a time (the headline of round 2)"}
+        legs["cyp2d6"] = cyp_leg(pkg, ctx, cdb, locus)
+        legs["k5_chain_pairs"] = chain_pair_leg(pkg, ctx)
+        co_args = argparse.Namespace(**vars(args)); co_args.steps, co_args.warmup = 1, 1
+        legs["cohort"] = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, 1, 0, None, co_args, barrier, max_over_ranks)
 
-    peaks, cyp, cohort, k5, inflight = None, None, None, None, None
-    if rank == 0:
-        peaks = {"valu_int_wave_instr_per_s": ctx.microbench("valu_int"), "match16_valu_wave_instr_per_s": ctx.microbench("match16"),
-                 "hbm_copy_bytes_per_s": ctx.microbench("hbm_copy")}
-    if rank == 0 and world == 1 and not args.no_extra_legs:
-        cyp = cyp_leg(pkg, ctx)
-        cohort = cohort_leg(pkg, ctx, fx, db)
-        k5 = chain_pair_leg(pkg, ctx)
-        inflight = inflight_leg(pkg, fx, device=device_index)
-
-    if rank == 0:
-        # VALU wave-instructions of one k1_cells launch: rocprofv3 --pmc SQ_INSTS_VALU of this workload (profiles/r02/valu_k1_cells.json);
-        # the peak is measured in this run (sp_microbench: eight independent v_add_u32 chains per lane on every SIMD)
-        import hashlib
-        k1_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "pb-starphase_amd", "csrc", f), "rb").read() for f in ("sp_hla.hip", "sp_wfa.cuh"))).hexdigest()[:16]
-        stale = lambda rec: "" if rec.get("k1_source_sha16") == k1_sha else "STALE: the kernel sources changed after this counter pass; "
-        valu = None
-        vfile = os.path.join(ROOT, "profiles", "r02", "valu_k1_cells.json")
-        if os.path.exists(vfile) and args.reads == 10000 and avg_ms > 0:
-            rec = json.load(open(vfile))
+    peaks = {"valu_int_wave_instr_per_s": ctx.microbench("valu_int"), "match16_valu_wave_instr_per_s": ctx.microbench("match16"),
+             "hbm_copy_bytes_per_s": ctx.microbench("hbm_copy")}
+    # VALU wave-instructions and HBM bytes of one k1_cells launch come from the committed rocprofv3 PMC passes of this workload; a pass made on other
+    # kernel sources is not quoted (the block is left out and the line says so)
+    import hashlib
+    k1_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "pb-starphase_amd", "csrc", f), "rb").read() for f in ("sp_hla.hip", "sp_wfa.hip.h"))).hexdigest()[:16]
+    valu, traffic, traffic_note, stale = None, None, None, []
+    vfile, tfile = os.path.join(COUNTER_DIR, "valu_k1_cells.json"), os.path.join(COUNTER_DIR, "traffic_k1_cells.json")
+    if os.path.exists(vfile) and args.reads == 10000 and avg_ms > 0:
+        rec = json.load(open(vfile))
+        if rec.get("k1_source_sha16") == k1_sha:
             rate = rec["sq_insts_valu_per_launch"] / (avg_ms * 1e-3)
             valu = {"bound": "valu", "kernel": "k1_cells_kernel", "achieved": rate, "peak": peaks["valu_int_wave_instr_per_s"], "unit": "wave-instr/s",
-                    "frac": rate / peaks["valu_int_wave_instr_per_s"], "nominal_peak": VALU_PEAK_WAVE_INSTR,
-                    "frac_of_match16_mix_peak": rate / peaks["match16_valu_wave_instr_per_s"],
-                    "note": stale(rec) + "instruction count from the committed PMC pass (" + rec["method"] + "), launch time and peak measured in this run"}
-        traffic, traffic_note = None, None
-        tfile = os.path.join(ROOT, "profiles", "r02", "traffic_k1_cells.json")
-        if os.path.exists(tfile) and args.reads == 10000:
-            rec = json.load(open(tfile))
-            traffic, traffic_note = rec["hbm_bytes_per_launch"], stale(rec) + "from the committed rocprofv3 PMC passes of this workload (" + rec["method"] + ")"
-        total_reads = args.reads * world * args.steps
-        line = {
-            "metric": "HiFi reads/sec diplotyped (HLA-A + HLA-B, reads -> diplotype: realignment, dual + group consensus, typing, het/hom call)",
-            "value": total_reads / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: HLA-A/-B, %d synthetic HiFi reads/GPU vs bundled IMGT/HLA DB v0.14.1 "
-                                   "(18,461 alleles, 11,199 with DNA), reads -> diplotype" % args.reads,
-                       "reads_per_gpu": args.reads, "alleles": len(fx.ids), "parallelism": "one sample per GPU, RCCL all_gather of calls"},
-            "roofline": {"bound": "hbm", "kernel": "k1_cells_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "algorithmic_bytes_per_launch": per_launch(exec_bytes), "cells_executed_per_launch": per_launch(executed),
-                         "cells_resumed_per_launch": per_launch(resumed), "cells_active_per_launch": per_launch(active),
-                         "cells_settled_without_running_per_launch": per_launch(active - executed), "avg_launch_ms": avg_ms,
-                         "measured_hbm_copy_GBs": peaks["hbm_copy_bytes_per_s"] / 1e9,
-                         "note": "'achieved' = algorithmic bytes (SURVEY 8(d): ceil(Lq/4) + ceil(Lt/4) + 32 per cell) of the cells the launch EXECUTED, counted on the "
-                                 "device, / launch time (HIP events).  The kernel is an integer-DP kernel whose database sits in L2: its limiter is VALU issue "
-                                 "(roofline_valu), 'traffic' is what actually crossed HBM"},
-            "roofline_valu": valu,
-            "kernel_ms": kernel_ms, "host_wall_ms": host_ms,
-            **({"dbg_counters": [ctx.counter(f"dbg{i}") for i in range(8)]} if os.environ.get("SP_BENCH_DBG") else {}),
-            "anchor_pairs_per_step": {k: ctx.profile_get(k)[2] / max(1, args.steps) for k in ("anchor_k1", "anchor_k2", "anchor_type")},
-            "anchor_launches_per_step": {k: ctx.profile_get(k)[1] / max(1, args.steps) for k in ("anchor_k1", "anchor_k2", "anchor_type")},
-            "consensus": {"windows_per_step": cons_windows / max(1, args.steps), "launches_per_step": 3 * cons_windows / max(1, args.steps),
-                          "cut_windows_per_step": cons_cut / max(1, args.steps), "expansions_per_step": cons_exp / max(1, args.steps),
-                          "nodes_expanded_per_step": cons_cols / max(1, args.steps),
-                          "control_kernel_us_per_step": cons_ticks},
-            "concordance": {"k1_gene_correct": k1_gene_ok, "k1_realigned": k1_realigned, "diplotypes_equal_truth": f"{ok}/{len(genes)} genes"},
-            "pcie_inclusive_upload_s": t_up,
-            "scoring_only": scoring, "samples_in_flight": inflight, "cyp2d6": cyp, "cohort": cohort, "k5_chain_pairs": k5,
-        }
-        if cb is not None:
-            agree = sum(1 for i, b in cpu_best.items() if b == int(out[i]["best_allele"]))
-            cb["k1_calls_identical_to_gpu"] = f"{agree}/{len(cpu_best)}"
-            cb["diplotypes_of_the_sample"] = {fx.genes[g]: [int(x) for x in c] for g, c in cpu_calls.items()}
-            line["cpu_baseline"] = cb
+                    "frac": rate / peaks["valu_int_wave_instr_per_s"], "nominal_peak": VALU_PEAK_WAVE_INSTR, "frac_of_match16_mix_peak": rate / peaks["match16_valu_wave_instr_per_s"],
+                    "sq_insts_salu_per_launch": rec.get("sq_insts_salu_per_launch"),
+                    "note": "instruction count from the committed PMC pass (" + rec["method"] + "), launch time and peak measured in this run"}
         else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            stale.append("valu_k1_cells.json")
+    if os.path.exists(tfile) and args.reads == 10000:
+        rec = json.load(open(tfile))
+        if rec.get("k1_source_sha16") == k1_sha:
+            traffic, traffic_note = rec["hbm_bytes_per_launch"], "from the committed rocprofv3 PMC passes of this workload (" + rec["method"] + ")"
+        else:
+            stale.append("traffic_k1_cells.json")
+    line = {
+        "metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)",
+        "value": reads_per_step * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1] + configs[2] as ONE sample per step: HLA-A / -B, %d synthetic HiFi reads vs the bundled IMGT/HLA DB v0.14.1 (18,461 alleles, 11,199 with "
+                               "DNA) and CYP2D6, %d targeted reads (39 templates, 393 variants / 520 star alleles); a new sample's bytes (BAM 4-bit SEQ) uploaded every step "
+                               "under the previous sample's kernels; reads -> diplotypes of both loci" % (samples[0].n, cyp_samples[0].n),
+                   "reads_per_step": reads_per_step, "hla_reads": samples[0].n, "cyp2d6_reads": cyp_samples[0].n, "alleles": len(fx.ids),
+                   "parallelism": "one GPU: the two loci side by side on two contexts (host threads, HIP streams), uploads on copy streams"},
+        "roofline": {"bound": "hbm", "kernel": "k1_cells_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                     "algorithmic_bytes_per_launch": per_launch(exec_bytes), "cells_executed_per_launch": per_launch(executed),
+                     "cells_resumed_per_launch": per_launch(resumed), "cells_active_per_launch": per_launch(active),
+                     "cells_settled_without_running_per_launch": per_launch(active - executed), "avg_launch_ms": avg_ms,
+                     "measured_hbm_copy_GBs": peaks["hbm_copy_bytes_per_s"] / 1e9,
+                     "note": "'achieved' = algorithmic bytes (SURVEY 8(d): ceil(Lq/4) + ceil(Lt/4) + 32 per cell) of the cells the launch EXECUTED, counted on the "
+                             "device, / launch time (HIP events on the library's stream, CYP2D6 kernels running beside it).  The kernel is an integer-DP kernel whose "
+                             "database sits in L2: its limiter is instruction issue (roofline_valu), 'traffic' is what actually crossed HBM"},
+        "roofline_valu": valu,
+        "stale_counter_files": stale or None,
+        "kernel_ms": {"hla": kernel_ms, "cyp2d6": cyp_kernel_ms}, "host_wall_ms": {"hla": host_ms, "cyp2d6": cyp_host_ms},
+        "consensus_hla": cons,
+        "concordance": {"hla_diplotypes_equal_truth": f"{ok}/{len(genes)} genes", "cyp2d6_call_equals_truth": bool(cyp_ok), "k1_gene_correct": k1_gene_ok,
+                        "cyp2d6_call": [cyp_call.hap1.decode(), cyp_call.hap2.decode()]},
+        "upload": {"per_step_bytes": int(len(samples[0].payload[0]) + len(cyp_samples[0].payload[0])), "alone": t_up,
+                   "note": "inside `value` every step uploads a new sample (4-bit SEQ bytes, sp_seqset_upload_async); `alone` = one synchronous upload of the HLA half"},
+        "legs": legs or None,
+    }
+    if cb is not None:
+        # the GPU on exactly the reads the CPU leg saw: the calls of the two have to be the same
+        sub = [samples[0].wl.reads[r] for r in cpu_done]
+        Rs = ctx.upload(sub)
+        o = db.realign_reads(Rs)
+        g_calls = db.diplotype_genes(genes, Rs, o)[0]
+        gpu_calls = {g: sorted([int(c.allele1), int(c.allele2)]) for g, (c, _a, _b) in enumerate(g_calls)}
+        cpu_c = {g: sorted(int(x) for x in cpu_calls[g]) for g in cpu_calls}
+        cb["diplotypes_cpu"] = {fx.genes[g]: cpu_c[g] for g in cpu_c}
+        cb["diplotypes_gpu_same_reads"] = {fx.genes[g]: gpu_calls[g] for g in gpu_calls}
+        cb["diplotypes_identical"] = all(all(same_allele(fx, a, b) for a, b in zip(cpu_c[g], gpu_calls[g])) for g in cpu_c)
+        agree = sum(1 for k, r in enumerate(cpu_done) if cpu_best[r][0] == int(o[k]["best_allele"]))
+        gene_agree = sum(1 for k, r in enumerate(cpu_done) if cpu_best[r][0] >= 0 and int(o[k]["gene"]) == int(fx.gene_of[cpu_best[r][0]]))
+        cb["k1_same_allele_as_gpu"] = f"{agree}/{len(cpu_done)}"
+        cb["k1_same_gene_as_gpu"] = f"{gene_agree}/{len(cpu_done)}"
+        cb["gpu_over_cpu_all_cores_hla_alone"] = (legs["hla_resident"]["value"] / cb["value"]) if legs else None
+        line["cpu_baseline"] = cb
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line), flush=True)
+    if stale:                                                 # (the blocks they feed were left out of the line above)
+        print("bench.py: the counter files " + ", ".join(stale) + " were collected on other kernel sources: re-run profiles/scripts/k1_counters.sh", file=sys.stderr)
 
 
 if __name__ == "__main__":

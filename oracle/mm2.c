@@ -767,3 +767,71 @@ int32_t omm_map_pair(const uint8_t* target, int32_t tlen, const uint8_t* q, int3
     omm_index_free(idx);
     return n;
 }
+
+/* ------------------------------------------------------------------ score_read on the restatement's mappings */
+#include "sp_oracle.h"
+
+/* score_read (src/hla/caller.rs:1411-1510): every allele of the gene mapped to the consensus at cDNA and DNA level (the caller passes
+ * opts with a = 5), Forward mappings only (:1443-1445), select_best_mapping query based and penalised (:1450), HlaProcessedMatch::add_mapping
+ * (src/hla/processed_match.rs:53-100) and the running best by is_better_match (:103-184).  Alleles in database order; returns the best index or
+ * -1; stats (may be NULL) = [(allele * 2 + level) * 3 + {len, nm, unmapped}], -1 where a level has no mapping. */
+int32_t omm_hla_score_read(const uint8_t* cons_cdna, int32_t cdna_len, const uint8_t* cons_dna, int32_t dna_len, int32_t n_alleles,
+                           const uint8_t* const* cdna, const int32_t* cdna_lens, const uint8_t* const* dna, const int32_t* dna_lens,
+                           const omm_opts* o, int64_t* stats) {
+    const uint8_t* cons[2] = { cons_cdna, cons_dna };
+    const int32_t clen[2] = { cdna_len, dna_len };
+    omm_index* idx[2] = { NULL, NULL };
+    for (int lv = 0; lv < 2; ++lv) if (cons[lv] && clen[lv] > 0) { const int64_t off[2] = { 0, clen[lv] }; idx[lv] = omm_index_build(cons[lv], off, 1, o); }
+    osp_hla_level best[2]; memset(best, 0, sizeof(best));
+    uint64_t* best_pc[2] = { NULL, NULL };
+    int best_idx = -1;
+    enum { MAXH = 8 };
+    for (int a = 0; a < n_alleles; ++a) {
+        osp_hla_level cur[2]; uint64_t* cur_pc[2] = { NULL, NULL };
+        memset(cur, 0, sizeof(cur));
+        for (int lv = 0; lv < 2; ++lv) {
+            const uint8_t* seq = lv ? (dna ? dna[a] : NULL) : (cdna ? cdna[a] : NULL);
+            const int32_t slen = lv ? (dna_lens ? dna_lens[a] : 0) : (cdna_lens ? cdna_lens[a] : 0);
+            if (stats) { int64_t* st = stats + ((size_t)a * 2 + (size_t)lv) * 3; st[0] = st[1] = st[2] = -1; }
+            if (!seq || slen <= 0 || !idx[lv]) continue;
+            omm_hit hits[MAXH];
+            const int cap = 4 * (slen + clen[lv]) + 64;
+            uint32_t* pool = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap);
+            const int nh = omm_map(idx[lv], seq, slen, o, hits, MAXH, pool, cap);
+            int pick = -1; double ps = 1.0;
+            for (int h = 0; h < nh; ++h) {
+                if (hits[h].rev) continue;
+                const int um = hits[h].q_len - (hits[h].q_end - hits[h].q_start);
+                double v = (double)(hits[h].nm + um); if (v < 0.1) v = 0.1;
+                v /= (double)hits[h].q_len;
+                if (v < ps) { ps = v; pick = h; }
+            }
+            if (pick >= 0) {
+                const omm_hit* H = &hits[pick];
+                uint32_t* cl = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(H->n_cigar + 1));
+                uint8_t* co = (uint8_t*)malloc((size_t)(H->n_cigar + 1));
+                for (int c = 0; c < H->n_cigar; ++c) { cl[c] = pool[H->cigar_off + c] >> 4; co[c] = (uint8_t)(pool[H->cigar_off + c] & 15u); }
+                uint64_t* pc = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(clen[lv] + 1));
+                const uint64_t cs = (uint64_t)H->q_start, ce = (uint64_t)(H->q_len - H->q_end);
+                if (osp_process_mm_cigar(cl, co, H->n_cigar, (uint64_t)H->t_start, (uint64_t)clen[lv], cs, ce, pc) == 0) {
+                    cur[lv].present = 1;
+                    cur[lv].range_start = H->t_start - (int)cs > 0 ? H->t_start - (int)cs : 0;
+                    { const int room = clen[lv] - H->t_end; cur[lv].range_end = H->t_end + ((int)ce < room ? (int)ce : room); }
+                    cur[lv].len = H->q_len; cur[lv].nm = H->nm; cur[lv].unmapped = H->q_len - (H->q_end - H->q_start);
+                    cur[lv].pc = pc; cur_pc[lv] = pc;
+                    if (stats) { int64_t* st = stats + ((size_t)a * 2 + (size_t)lv) * 3; st[0] = cur[lv].len; st[1] = cur[lv].nm; st[2] = cur[lv].unmapped; }
+                } else free(pc);
+                free(cl); free(co);
+            }
+            free(pool);
+        }
+        if (osp_is_better_match(cur, best)) {
+            for (int lv = 0; lv < 2; ++lv) { free(best_pc[lv]); best_pc[lv] = cur_pc[lv]; best[lv] = cur[lv]; }
+            best_idx = a;
+        } else {
+            for (int lv = 0; lv < 2; ++lv) free(cur_pc[lv]);
+        }
+    }
+    for (int lv = 0; lv < 2; ++lv) { free(best_pc[lv]); omm_index_free(idx[lv]); }
+    return best_idx;
+}

@@ -90,6 +90,12 @@ void omm_dp(const uint8_t* t, int32_t tlen, const uint8_t* q, int32_t qlen, cons
 /* brute-force two-piece affine global score (O(mn) Gotoh with five states), for the tests */
 int32_t omm_global_score_bruteforce(const uint8_t* t, int32_t tlen, const uint8_t* q, int32_t qlen, const omm_opts* o);
 
+/* score_read (src/hla/caller.rs:1411-1510) on this file's mappings: alleles in database order, level sequences as codes (NULL / 0 = absent);
+ * pass opts with a = 5 (src/hla/caller.rs:1370-1379).  Returns the best index or -1; stats may be NULL ([(allele * 2 + level) * 3]). */
+int32_t omm_hla_score_read(const uint8_t* cons_cdna, int32_t cdna_len, const uint8_t* cons_dna, int32_t dna_len, int32_t n_alleles,
+                           const uint8_t* const* cdna, const int32_t* cdna_lens, const uint8_t* const* dna, const int32_t* dna_lens,
+                           const omm_opts* o, int64_t* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,9 +1,9 @@
-// sp_anchor.cuh -- the two halves of the k-mer vote anchor that every way of producing the votes shares (sp_anchor_kernel, sp_device.hip;
+// sp_anchor.hip.h -- the two halves of the k-mer vote anchor that every way of producing the votes shares (sp_anchor_kernel, sp_device.hip;
 // k2_anchor_dict_kernel, sp_hla.hip): adding a wave's runs of equal single votes, and reading the peaks out of the histogram.
 // Bins are u16 counters packed two per dword in LDS; bin = b_pos - a_pos + len(A).
 #pragma once
 #include "sp_internal.h"
-#include "sp_wfa.cuh"
+#include "sp_wfa.hip.h"
 
 // a read that crosses the gene puts thousands of votes on one diagonal, and neighbouring lanes hold neighbouring k-mers of it: lanes
 // whose single vote goes to the bin of the lane before them hand it to the first lane of their run, which adds the run's count once

@@ -27,7 +27,7 @@
 //     may be split off): every wave pushes its read once per child into the child's slot.
 // Results are those of the plain search; only the number of launches changes (about two per window instead of one per column).
 #include "sp_internal.h"
-#include "sp_wfa.cuh"
+#include "sp_wfa.hip.h"
 #include <algorithm>
 #include <cstring>
 #include <map>

@@ -9,7 +9,7 @@
 #include <thread>
 #include <atomic>
 #include "sp_json.h"
-#include "sp_wfa.cuh"
+#include "sp_wfa.hip.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>

@@ -1,8 +1,8 @@
 // sp_device.hip -- generic device kernels of libstarphase_hip (gfx950): k-mer vote anchor and the
 // one-wavefront-per-cell WFA kernel, plus their launchers.
 #include "sp_internal.h"
-#include "sp_wfa.cuh"
-#include "sp_anchor.cuh"
+#include "sp_wfa.hip.h"
+#include "sp_anchor.hip.h"
 #include <algorithm>
 
 // =============================================================================================

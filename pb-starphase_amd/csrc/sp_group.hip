@@ -7,6 +7,7 @@
 // carries RCCL (torch) shares that copy.
 #include "sp_internal.h"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -29,8 +30,13 @@ Rccl* rccl() {
     static bool tried = false;
     if (tried) return &R;
     tried = true;
+    // a copy the process already carries (a host that links RCCL, or Python with torch imported) is the one to use: two RCCLs in one process
+    // do not get along; SP_RCCL_PATH names a particular file
+    const char* env = std::getenv("SP_RCCL_PATH");
+    if (env && *env) R.h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    if (!R.h) R.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-    for (const char* n : names) { R.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (R.h) break; }
+    for (const char* n : names) { if (R.h) break; R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
     if (!R.h) { R.err = "librccl.so not found"; return &R; }
     R.GetUniqueId = (int (*)(NcclId*))dlsym(R.h, "ncclGetUniqueId");
     R.CommInitRank = (int (*)(ncclComm_t*, int, NcclId, int))dlsym(R.h, "ncclCommInitRank");

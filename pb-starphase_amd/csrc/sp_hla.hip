@@ -3,12 +3,12 @@
 //   K2  sp_hla_score_consensus  replaces score_read's allele loop + HlaProcessedMatch
 //                               (src/hla/caller.rs:1411-1510, src/hla/processed_match.rs:53-263)
 // Decisions use f64 exactly as the reference does (MappingScore::score_value, src/data_types/mapping.rs:191-195);
-// alignments come from the one-wavefront-per-cell WFA kernel (sp_wfa.cuh).
+// alignments come from the one-wavefront-per-cell WFA kernel (sp_wfa.hip.h).
 #include "sp_internal.h"
 #include <tuple>
 #include <mutex>
-#include "sp_wfa.cuh"
-#include "sp_anchor.cuh"
+#include "sp_wfa.hip.h"
+#include "sp_anchor.hip.h"
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>

@@ -1,4 +1,4 @@
-// sp_wfa.cuh -- the wavefront-alignment cell for gfx950: ONE 64-lane wavefront per (A, B) cell,
+// sp_wfa.hip.h -- the wavefront-alignment cell for gfx950: ONE 64-lane wavefront per (A, B) cell,
 // lane l <-> diagonal (diag - 32 + l).  Device-side mirror of the contract in DESIGN.md section 3
 // (restated for the CPU in oracle/align.c; the two must agree bit for bit).
 //

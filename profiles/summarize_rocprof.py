@@ -46,7 +46,7 @@ def k1_source_sha16():
     """the kernel the counters belong to: bench.py marks the committed numbers stale when these sources have changed since"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("pb-starphase_amd/csrc/sp_hla.hip", "pb-starphase_amd/csrc/sp_wfa.cuh"):
+    for f in ("pb-starphase_amd/csrc/sp_hla.hip", "pb-starphase_amd/csrc/sp_wfa.hip.h"):
         h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -1,0 +1,191 @@
+"""The reference's CPU path for one HLA sample in its own CALL PATTERN (test infrastructure: bench.py's cpu_baseline leg and the tests).
+
+What the reference does per sample (src/hla/caller.rs:510-1083) and what stands in for it here:
+  * per read ONE seeded map against the index of all DNA alleles, base-level alignment of the best chains only (`best_n 5`), the acceptance
+    of realign_record (src/hla/realigner.rs:98-146): oracle/mm2.c (minimap2's published algorithm restated; minimap2 itself is not on disk);
+    then the segment / offset bookkeeping of realign_record (:226-325) with the oracle's routines
+  * per gene the dual consensus on the compressed reads, the group consensuses (waffle_con: oracle/consensus.c)
+  * per consensus score_consensus + score_read: the consensus placed on the gene reference, spliced, and EVERY allele of the gene mapped to it at
+    cDNA and DNA level with a = 5, running best by HlaProcessedMatch (src/hla/caller.rs:1258-1511): oracle/mm2.c + oracle/hla.c
+It is a scalar port (no SSE in the DP, where minimap2 has it): a reported baseline, see DESIGN.md section 11."""
+import ctypes as C
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+
+G = {}
+OPMAP = {"=": 7, "X": 8, "I": 1, "D": 2}
+
+
+def realign_pick(hits):
+    """src/hla/realigner.rs:124-146"""
+    best, bs = None, None
+    for h in hits:
+        tl = h["t_len"]; um = tl - (h["t_end"] - h["t_start"]); nm = h["nm"]
+        if (nm + um) / tl <= 0.5 and max(nm, 0.1) / (tl - um) <= 0.03:
+            s = max(nm, 0.1) / (tl - um)
+            if bs is None or s < bs:
+                best, bs = h, s
+    return best
+
+
+def _k1_worker(args):
+    lo, hi, budget_s = args
+    idx, reads, dna_ids = G["idx"], G["reads"], G["dna_ids"]
+    out, t0 = [], time.perf_counter()
+    for r in range(lo, hi):
+        h = realign_pick(idx.map(reads[r]))
+        # a best mapping on the reverse strand is dropped (src/hla/realigner.rs:178-193)
+        out.append((r, -1, None) if (h is None or h["rev"]) else (r, dna_ids[h["rid"]], (h["nm"], h["t_start"], h["t_end"], h["q_start"], h["q_end"], h["t_len"], h["q_len"])))
+        if time.perf_counter() - t0 > budget_s:
+            break
+    return out, time.perf_counter() - t0
+
+
+def k2_scan_mm2(mm, o, alleles, cons_dna, cons_cdna):
+    """score_read (src/hla/caller.rs:1411-1510) with the restatement's mappings, in C (omm_hla_score_read): alleles = [(index, cdna, dna)] in
+    database order"""
+    n = len(alleles)
+    enc = [(o.encode(cd) if cd else None, o.encode(dn) if dn else None) for _a, cd, dn in alleles]
+    cp, dp = (C.c_void_p * max(1, n))(), (C.c_void_p * max(1, n))()
+    cl, dl = np.zeros(max(1, n), np.int32), np.zeros(max(1, n), np.int32)
+    for i, (c, d) in enumerate(enc):
+        if c is not None:
+            cp[i], cl[i] = c.ctypes.data, len(c)
+        if d is not None:
+            dp[i], dl[i] = d.ctypes.data, len(d)
+    cc, cd_ = o.encode(cons_cdna), o.encode(cons_dna)
+    opts5 = mm.opts(a=5)
+    L = o.L
+    L.omm_hla_score_read.restype = C.c_int32
+    L.omm_hla_score_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    b = L.omm_hla_score_read(cc.ctypes.data if len(cc) else None, len(cc), cd_.ctypes.data if len(cd_) else None, len(cd_), n, cp, cl.ctypes.data, dp, dl.ctypes.data,
+                             C.byref(opts5), None)
+    return alleles[b][0] if b >= 0 else -1
+
+
+def type_consensus_mm2(o, fx, g, cons, synth):
+    """score_consensus + splice_read + score_read (src/hla/caller.rs:1258-1319,1332-1511,1518-1576) on the restatement's mappings"""
+    import mm2_ffi
+    import oracle_ffi
+    if not cons:
+        return -1
+    mm = G.get("mm") or mm2_ffi.Mm2(o)
+    ref = fx.gene_ref[g][fx.buffer:len(fx.gene_ref[g]) - fx.buffer]
+    best, bs = None, 1.0                                        # select_best_mapping(unmapped from the target, penalised): caller.rs:1290-1294
+    for h in mm.map_pair(ref, cons, max_hits=8):
+        s = max(float(h["nm"] + (h["t_len"] - (h["t_end"] - h["t_start"]))), 0.1) / float(h["t_len"])
+        if s < bs:
+            best, bs = h, s
+    if best is None or best["rev"]:
+        return -1
+    bam = [(ln, {"=": 0, "X": 0, "I": 1, "D": 2}[op]) for ln, op in best["cigar"]]
+    if best["q_start"]:
+        bam.insert(0, (best["q_start"], 4))
+    exons = [(e0 - fx.buffer, e1 - fx.buffer) for e0, e1 in fx.exons[g]]
+    segs, _ = o.splice_read(best["t_start"], bam, exons)
+    spliced = "".join(cons[x:y] for x, y in segs)
+    fwd = bool(fx.gene_fwd[g])
+    e_dna = cons if fwd else synth.revcomp(cons)
+    e_cdna = spliced if fwd else synth.revcomp(spliced)
+    alleles = [(a, fx.cdna[a], fx.dna[a]) for a in range(len(fx.ids)) if fx.gene_of[a] == g]
+    return k2_scan_mm2(mm, o, alleles, e_dna, e_cdna)
+
+
+def _gene_worker(args):
+    g, sample = args
+    import hla_expected as hx
+    import hla_pipeline as hp
+    from pb_starphase_amd import synth
+    o, fx = G["o"], G["fx"]
+    reads = [G["reads"][r] for r in sample]
+    t0 = time.perf_counter()
+    tb = hx.K1Tables(o, fx, G["off"])
+    k1 = []
+    for r in sample:                                           # realign_record's bookkeeping behind the best mapping (segment, offsets)
+        a, m = G["best"][r]
+        re = o.encode(G["reads"][r])
+        anch = tb.anchors(re)
+        bm = None
+        if a >= 0:
+            nm, ts, te, qs, qe, tl, ql = m
+            bm = np.zeros(1, hx.oracle_aln_dtype())[0]
+            bm["ok"], bm["nm"], bm["a_start"], bm["a_end"], bm["b_start"], bm["b_end"], bm["a_len"], bm["b_len"] = 1, nm, ts, te, qs, qe, tl, ql
+        k1.append(tb.record(G["reads"][r], re, anch, a, bm))
+    t1 = time.perf_counter()
+    typed = {}
+
+    def typer(oracle, fx_, g_, cons, synth_):
+        t = time.perf_counter()
+        out = type_consensus_mm2(oracle, fx_, g_, cons, synth_)
+        typed[len(typed)] = time.perf_counter() - t
+        return out
+
+    res = hp.diplotype_gene(o, fx, g, reads, k1, synth, type_fn=typer)
+    t2 = time.perf_counter()
+    t_type = sum(typed.values())
+    return g, t1 - t0, (t2 - t1) - t_type, t_type, (res["allele1"], res["allele2"]), (res["cons1"], res["cons2"])
+
+
+def run(o, fx, reads, n_sample=2000, budget_s=12.0, cores=None, seed=0):
+    """-> dict for bench.py's cpu_baseline block, {read: best allele} and {gene: (allele1, allele2)} of the sample"""
+    import mm2_ffi
+    mm = mm2_ffi.Mm2(o)
+    cores = cores or max(1, min(len(os.sched_getaffinity(0)), 128))
+    rng = np.random.default_rng(seed)
+    sample = sorted(rng.choice(len(reads), min(n_sample, len(reads)), replace=False).tolist())
+    t0 = time.perf_counter()
+    dna_ids = [a for a in range(len(fx.ids)) if fx.dna[a]]
+    idx = mm2_ffi.Index(mm, [fx.dna_fwd(a) for a in dna_ids])
+    t_index = time.perf_counter() - t0
+    off = np.full(len(fx.ids), -2 ** 31, np.int32)              # frame offsets of the alleles on their gene reference (HlaRealigner::new; untimed set-up)
+    refs = [o.encode(s) for s in fx.gene_ref]
+    for a in dna_ids:
+        d, v = o.anchor(refs[int(fx.gene_of[a])], o.encode(fx.dna_fwd(a)))
+        if v >= 16:
+            off[a] = d
+    G.update(o=o, mm=mm, fx=fx, reads=reads, idx=idx, dna_ids=dna_ids, off=off)
+    sub = [reads[r] for r in sample]
+    G["reads"] = reads
+    # K1, one thread: the reference's own concurrency (src/cli/diplotype.rs:185-191)
+    t1 = time.perf_counter()
+    single = []
+    for r in sample[:64]:
+        single.append(realign_pick(idx.map(reads[r])))
+    t_single = (time.perf_counter() - t1) / max(1, len(single))
+    # K1, every core
+    per = (len(sample) + cores - 1) // cores
+    G["reads"] = sub
+    t1 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        parts = pool.map(_k1_worker, [(w * per, min(len(sub), (w + 1) * per), budget_s) for w in range(cores) if w * per < len(sub)])
+    t_k1 = time.perf_counter() - t1
+    best = {}
+    for out, _dt in parts:
+        for r, a, m in out:
+            best[sample[r]] = (a, m)
+    done = sorted(best)
+    G["reads"], G["best"] = reads, best
+    # per gene: consensus + typing (one worker per gene; inside a gene the reference is sequential)
+    t1 = time.perf_counter()
+    with mp.get_context("fork").Pool(len(fx.genes)) as pool:
+        gres = pool.map(_gene_worker, [(g, done) for g in range(len(fx.genes))])
+    t_genes = time.perf_counter() - t1
+    idx.close()
+    calls = {g: c for g, _a, _b, _c, c, _s in gres}
+    cons = {g: s for g, _a, _b, _c, _d, s in gres}
+    bookkeeping_s = sum(x[1] for x in gres); cons_s = sum(x[2] for x in gres); typing_s = sum(x[3] for x in gres)
+    n = len(done)
+    one_thread_s = n * t_single + bookkeeping_s + cons_s + typing_s
+    return {"value": n / (t_k1 + t_genes), "unit": "reads/s", "cores": cores, "kind": "port-seeded",
+            "single_thread_value": n / one_thread_s,
+            "k1_seeded_ms_per_read_one_thread": 1e3 * t_single, "k1_all_cores_s": t_k1, "genes_wall_s": t_genes,
+            "per_gene_cpu_s": {"realign_bookkeeping": bookkeeping_s, "consensus": cons_s, "typing_every_allele": typing_s},
+            "index_build_s": t_index,
+            "sample": f"{n} reads drawn from the same 10,000-read batch: K1 = one seeded map per read against the index of {len(dna_ids)} DNA alleles, the best chains "
+                      f"base-aligned (best_n 5), over {cores} forked workers in {t_k1:.1f} s ({1e3 * t_single:.1f} ms per read on one thread); then per gene (one worker each) "
+                      f"segments + offsets, dual + group consensus and the typing of the consensuses against every allele in {t_genes:.1f} s wall",
+            "note": "the reference's call pattern on minimap2's published algorithm restated in scalar C (oracle/mm2.c; minimap2 itself and its SSE kernels are not on disk); "
+                    "consensus = oracle/consensus.c.  single_thread_value is what one thread needs for the same sample (the reference is single-threaded)"}, best, calls, cons, done

@@ -54,7 +54,7 @@ def is_hemizygous_better(oracle, dual, n, delta, normalized_coverage):
     return bool(r)
 
 
-def diplotype_gene(oracle, fx, g, reads, k1, synth, min_count=3, min_fraction=0.10, delta=100, absent_capable=False, normalized_coverage=None):
+def diplotype_gene(oracle, fx, g, reads, k1, synth, min_count=3, min_fraction=0.10, delta=100, absent_capable=False, normalized_coverage=None, type_fn=None):
     """k1 = hx.k1_expected(...)[0] for `reads`.  Returns a dict with the fields of sp_hla_call + consensuses + is_cons1."""
     sel = [r for r, e in enumerate(k1) if e["status"] == 0 and e["gene"] == g]
     out = dict(status=0, n_reads=len(sel), allele1=-1, allele2=-1, typed1=-1, typed2=-1, cons1="", cons2="")
@@ -93,11 +93,12 @@ def diplotype_gene(oracle, fx, g, reads, k1, synth, min_count=3, min_fraction=0.
         offs = offsets("dna_offset", members)
         grp = [i for i, m in enumerate(members) if m]
         cons.append(of.oracle_consensus(oracle, [segs[i] for i in grp], [offs[i] for i in grp], single)["cons"][0])
-    t1 = type_consensus(oracle, fx, g, cons[0], synth)
+    type_consensus_ = type_fn or type_consensus                  # (bench.py's CPU leg types with the minimap2 restatement: tests/cpu_port_seeded.py)
+    t1 = type_consensus_(oracle, fx, g, cons[0], synth)
     out.update(cons1=cons[0], typed1=t1, is_dual=int(dual["is_dual"]), dual_passed=0, counts1=c1, counts2=c2, maf=maf, cdf=cdf,
                used_dna_dual=int(used_dna), is_cons1=dual["is_cons1"])
     if dual["is_dual"]:
-        t2 = type_consensus(oracle, fx, g, cons[1], synth)
+        t2 = type_consensus_(oracle, fx, g, cons[1], synth)
         out.update(cons2=cons[1], typed2=t2, dual_passed=int(ok))
         if ok:
             out.update(allele1=t1, allele2=t2)

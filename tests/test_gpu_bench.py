@@ -21,15 +21,22 @@ def run_bench(extra, env=None):
     return json.loads(lines[0])
 
 
-def test_two_ranks_over_gloo_on_one_device():
-    one = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "2000", "--no-cpu-baseline", "--no-extra-legs"])
-    two = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "2000", "--no-cpu-baseline", "--no-extra-legs"],
-                    env={"SP_BENCH_BACKEND": "gloo"})
-    for line, n in ((one, 1), (two, 2)):
-        assert line["n_gpus"] == n and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
-        assert line["metric"] == one["metric"] and line["unit"] == one["unit"] and line["higher_is_better"] is True
-        assert line["value"] > 0 and line["ms_per_step"] > 0 and line["vs_baseline"] is None
-        assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
-    # every rank types its own 2,000-read sample: the job's reads double, both samples are called correctly
-    assert two["config"]["reads_per_gpu"] == one["config"]["reads_per_gpu"] == 2000
-    assert two["concordance"]["diplotypes_equal_truth"] == one["concordance"]["diplotypes_equal_truth"] == "2/2 genes"
+def test_sample_line_and_two_rank_cohort_over_gloo():
+    """N = 1: one sample with both loci, a new upload every step.  N = 2: the cohort sharded by sample (two ranks sharing device 0, the gather over
+    gloo: RCCL refuses two ranks on one device; the RCCL gather of one rank runs in tests/test_gpu_upload.py)."""
+    one = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "2000", "--cyp-reads", "400", "--no-cpu-baseline", "--no-extra-legs"])
+    assert one["n_gpus"] == 1 and one["steps"] == 2 and one["warmup"] == 1 and one["scaling"] == "weak"
+    assert one["metric"] == "HiFi reads/sec diplotyped (HLA+CYP2D6)" and one["unit"] == "reads/s" and one["higher_is_better"] is True
+    assert one["value"] > 0 and one["ms_per_step"] > 0 and one["vs_baseline"] is None
+    assert set(one["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert one["config"]["hla_reads"] == 2000 and 380 <= one["config"]["cyp2d6_reads"] <= 420
+    assert one["concordance"]["hla_diplotypes_equal_truth"] == "2/2 genes" and one["concordance"]["cyp2d6_call_equals_truth"] is True
+    assert one["upload"]["per_step_bytes"] > 5_000_000 and one["upload"]["alone"]["bam4"]["GBps"] > 0
+    for n in (1, 2):
+        line = run_bench(["--gpus", str(n), "--steps", "1", "--warmup", "1", "--workload", "cohort", "--cohort-samples", "8"],
+                         env={"SP_BENCH_BACKEND": "gloo"})
+        assert line["n_gpus"] == n and line["scaling"] == "strong" and line["metric"] == one["metric"] and line["value"] > 0
+        c = line["cohort"]
+        assert c["samples"] == 8 and c["records_gathered_per_pass"] == 8 * (2 + 1 + 18)              # HLA-A, HLA-B, CYP2D6, 18 variant genes per sample
+        assert c["calls_equal_truth"]["hla"] == "16/16" and c["calls_equal_truth"]["cyp2d6"] == "8/8"
+        assert c["calls_equal_truth"]["variant_genes_truth_among_reported"] == "144/144"
