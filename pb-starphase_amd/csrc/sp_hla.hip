@@ -44,6 +44,7 @@ struct sp_hla_db {
     sp_seqset* cdna_gene = nullptr;   // allele cDNA as stored
     sp_seqset* dna_fwd = nullptr;     // allele DNA in hg38 orientation (create_hla_fasta, realigner.rs:497-526)
     sp_seqset* ref_fwd = nullptr;     // buffered gene references, hg38 forward (realigner.rs:74-81)
+    sp_seqset* ref_rev = nullptr;     // their reverse complements: a read that anchors better there has its best mapping on the reverse strand (realigner.rs:178-193)
     uint32_t* d_gene_of = nullptr;
     int32_t*  d_off_fwd = nullptr;    // allele_fwd_pos - ref_fwd_pos (SP_NO_DIAG = no anchor)
     std::vector<uint32_t> h_order;
@@ -342,6 +343,35 @@ __global__ void k1_done_kernel(const unsigned long long* __restrict__ bound, uin
     if (max_alen == 0 ||                                                  // no cell at all: nothing deeper can appear
         (nb10 != 0xFFFFFFFFull && 10ull * (unsigned long long)(pass_cap + 1) * sb > nb10 * max_alen)) done[r] = 1;
     else open_list[atomicAdd(n_open, 1u)] = r;
+}
+
+// Reverse strand (src/hla/realigner.rs:178-193: a read whose best mapping is not Forward is dropped).  The strand is decided where minimap2
+// decides it, at the seeds: a read whose best anchor on the reverse-complemented gene references collects more 16-mer votes than its best
+// forward anchor (and at least K1_MIN_VOTES) is dropped with status 2.  Only reads with a WEAK forward anchor (< K1_WEAK_VOTES) can lose that
+// comparison -- a read cannot share hundreds of exact 16-mers with both strands of one locus -- so only those are anchored a second time.
+constexpr int K1_WEAK_VOTES = 512, K1_MIN_VOTES_REV = 16;
+__global__ void k1_weak_kernel(const int32_t* __restrict__ votes, uint32_t n_reads, uint32_t n_genes, uint32_t* __restrict__ n_weak, uint32_t* __restrict__ weak_list) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int best = 0;
+    for (uint32_t g = 0; g < n_genes; ++g) { const int v = votes[(size_t)r * n_genes + g]; best = v > best ? v : best; }
+    if (best < K1_WEAK_VOTES) weak_list[atomicAdd(n_weak, 1u)] = r;
+}
+__global__ void k1_weak_pairs_kernel(const uint32_t* __restrict__ weak_list, uint32_t n_weak, uint32_t n_genes, uint32_t* __restrict__ a_idx, uint32_t* __restrict__ b_idx) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_weak * n_genes) { a_idx[p] = p % n_genes; b_idx[p] = weak_list[p / n_genes]; }
+}
+__global__ void k1_reverse_kernel(const uint32_t* __restrict__ weak_list, uint32_t n_weak, uint32_t n_genes, const int32_t* __restrict__ votes_fwd,
+                                  const int32_t* __restrict__ votes_rev, uint8_t* __restrict__ is_reverse) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_weak) return;
+    const uint32_t r = weak_list[k];
+    int fb = 0, rb = 0;
+    for (uint32_t g = 0; g < n_genes; ++g) {
+        const int f = votes_fwd[(size_t)r * n_genes + g], v = votes_rev[(size_t)k * n_genes + g];
+        fb = f > fb ? f : fb; rb = v > rb ? v : rb;
+    }
+    is_reverse[r] = (rb >= K1_MIN_VOTES_REV && rb > fb) ? 1 : 0;
 }
 
 // K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
@@ -729,7 +759,7 @@ extern "C" {
 void sp_hla_db_free(sp_hla_db* db) {
     if (!db) return;
     if (db->ctx) (void)hipSetDevice(db->ctx->device);
-    sp_seqset_free(db->dna_gene); sp_seqset_free(db->cdna_gene); sp_seqset_free(db->dna_fwd); sp_seqset_free(db->ref_fwd);
+    sp_seqset_free(db->dna_gene); sp_seqset_free(db->cdna_gene); sp_seqset_free(db->dna_fwd); sp_seqset_free(db->ref_fwd); sp_seqset_free(db->ref_rev);
     (void)hipFree(db->d_gene_of); (void)hipFree(db->d_off_fwd); (void)hipFree(db->d_am); (void)hipFree(db->d_order); (void)hipFree(db->d_lcp); (void)hipFree(db->d_pos);
     (void)hipFree(db->d_hpc_ref); (void)hipFree(db->d_hpc_ref_off);
     for (auto& kv : db->gene_lists) { (void)hipFree(kv.second.d_idx); (void)hipFree(kv.second.d_l0); (void)hipFree(kv.second.d_l1); }
@@ -772,8 +802,14 @@ int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) 
         }
         rc = sp_seqset_upload(ctx, blob.data(), off.data(), d->n_alleles, &db->dna_fwd);
     }
+    if (rc == SP_OK) {
+        std::string rblob; std::vector<uint64_t> roff(d->n_genes + 1, 0);
+        for (uint32_t g = 0; g < d->n_genes; ++g) { rblob += revcomp(d->gene_ref + d->gene_ref_off[g], d->gene_ref_off[g + 1] - d->gene_ref_off[g]); roff[g + 1] = rblob.size(); }
+        rc = sp_seqset_upload(ctx, rblob.data(), roff.data(), d->n_genes, &db->ref_rev);
+    }
     if (rc != SP_OK) { sp_hla_db_free(db); return rc; }
     if ((rc = sp_seqset_build_index(ctx, db->ref_fwd)) != SP_OK) { sp_hla_db_free(db); return rc; }
+    if ((rc = sp_seqset_build_index(ctx, db->ref_rev)) != SP_OK) { sp_hla_db_free(db); return rc; }
     db->d_gene_of = dev_copy(db->gene_of);
 
     // hpc_pos tables of the gene references (homopolymers.rs:25-42)
@@ -927,6 +963,16 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     }
     if (rc == SP_OK) hipLaunchKernelGGL(k1_init_kernel, dim3((R * G + 255) / 256), dim3(256), 0, ctx->stream, d_a, d_b, R, G, d_bound);
     if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes, 1, "anchor_k1");
+    // reads with a weak forward anchor are listed now; their count comes back with the first pass's own host synchronisation
+    uint32_t* d_weak_n = (uint32_t*)sp_pool(ctx, "k1_weak_n", 4);
+    uint32_t* d_weak = (uint32_t*)sp_pool(ctx, "k1_weak", (size_t)R * 4);
+    uint8_t* d_isrev = (uint8_t*)sp_pool(ctx, "k1_isrev", R);
+    uint32_t n_weak = 0; bool weak_known = false;
+    if (rc == SP_OK && (!d_weak_n || !d_weak || !d_isrev)) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign strand buffers");
+    if (rc == SP_OK) {
+        (void)hipMemsetAsync(d_weak_n, 0, 4, ctx->stream); (void)hipMemsetAsync(d_isrev, 0, R, ctx->stream);
+        hipLaunchKernelGGL(k1_weak_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_votes, R, G, d_weak_n, d_weak);
+    }
     const bool hasn = db->dna_fwd->has_n || reads->has_n || db->ref_fwd->has_n;
     // finalize: private per-wave windows of (allele, read) and (reference, read segment)
     int slot_words = std::max(sp_slot_words(db->dna_fwd, reads, hasn), sp_slot_words(db->ref_fwd, reads, hasn));
@@ -980,9 +1026,27 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
             (void)hipMemsetAsync(d_open, 0, 4, ctx->stream);
             hipLaunchKernelGGL(k1_done_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_bound, d_done, R, pass_cap, d_maxlen, d_open, d_open_list);
             (void)hipMemcpyAsync(&n_open, d_open, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (!weak_known) (void)hipMemcpyAsync(&n_weak, d_weak_n, 4, hipMemcpyDeviceToHost, ctx->stream);
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1 done sync");
+            weak_known = true;
             if (n_open == 0) break;
         }
+    }
+    if (rc == SP_OK && !weak_known) {                          // (the cell-matrix mode has no synchronisation of its own before this point)
+        (void)hipMemcpyAsync(&n_weak, d_weak_n, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1 strand sync");
+        weak_known = true;
+    }
+    if (rc == SP_OK && n_weak > 0) {
+        const uint64_t np = (uint64_t)n_weak * G;
+        uint32_t* d_a2 = (uint32_t*)sp_pool(ctx, "k1_rev_a", np * 4); uint32_t* d_b2 = (uint32_t*)sp_pool(ctx, "k1_rev_b", np * 4);
+        int32_t* d_rg2 = (int32_t*)sp_pool(ctx, "k1_rev_rg", np * 4); int32_t* d_votes2 = (int32_t*)sp_pool(ctx, "k1_rev_votes", np * 4);
+        if (!d_a2 || !d_b2 || !d_rg2 || !d_votes2) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign strand anchors");
+        if (rc == SP_OK) {
+            hipLaunchKernelGGL(k1_weak_pairs_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, d_weak, n_weak, G, d_a2, d_b2);
+            rc = sp_launch_anchor(ctx, db->ref_rev, reads, d_a2, d_b2, np, d_rg2, d_votes2, 1, "anchor_k1_rev");
+        }
+        if (rc == SP_OK) hipLaunchKernelGGL(k1_reverse_kernel, dim3((n_weak + 255) / 256), dim3(256), 0, ctx->stream, d_weak, n_weak, G, d_votes, d_votes2, d_isrev);
     }
     if (rc == SP_OK) {
         ProfScope ps(ctx, "k1_reduce", R);
@@ -1006,11 +1070,15 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     }
     if (rc == SP_OK) {
         void* h_out = sp_host_pool(ctx, "k1_out", (size_t)R * sizeof(sp_hla_realign));
+        uint8_t* h_isrev = n_weak ? (uint8_t*)sp_host_pool(ctx, "k1_isrev", R) : nullptr;
+        if (h_isrev) (void)hipMemcpyAsync(h_isrev, d_isrev, R, hipMemcpyDeviceToHost, ctx->stream);
         (void)hipMemcpyAsync(h_out ? h_out : (void*)out, d_out, (size_t)R * sizeof(sp_hla_realign), hipMemcpyDeviceToHost, ctx->stream);
         if (cell_out) (void)hipMemcpyAsync(cell_out, d_cells, (size_t)R * NA * 4, hipMemcpyDeviceToHost, ctx->stream);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("realign: ") + hipGetErrorString(e));
         else if (h_out) std::memcpy(out, h_out, (size_t)R * sizeof(sp_hla_realign));
+        // a read that anchors better on the reverse strand is dropped whatever it found forwards (the record keeps what the forward search found)
+        if (rc == SP_OK && h_isrev) for (uint32_t r = 0; r < R; ++r) if (h_isrev[r]) out[r].status = 2;
         if (rc == SP_OK && cell_out) {                        // the device rows are in visiting order: hand them out by allele index
             std::vector<uint32_t> row(NA);
             for (uint32_t r = 0; r < R; ++r) {

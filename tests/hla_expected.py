@@ -3,6 +3,7 @@ Each function mirrors the reference routine named in its docstring on top of the
 import numpy as np
 
 K1_MIN_VOTES = 16
+K1_WEAK_VOTES = 512
 K2_MIN_VOTES = 2
 NONE = 0xFFFFFFFF
 
@@ -68,6 +69,18 @@ class K1Tables:
     def anchors(self, re):
         return [self.oracle.anchor(self.refs[g], re) for g in range(len(self.fx.genes))]       # read_pos - ref_pos
 
+    def is_reverse(self, re, anch):
+        """src/hla/realigner.rs:178-193 at the level of the seeds (include/starphase_hip.h, sp_hla_realign.status 2): a read with a weak forward
+        anchor (< 512 votes) whose best anchor on the reverse-complemented gene references has more votes (and >= 16) is dropped"""
+        fwd = max((v for _d, v in anch), default=0)
+        if fwd >= K1_WEAK_VOTES:
+            return False
+        if not hasattr(self, "refs_rev"):
+            comp = np.array([3, 2, 1, 0, 4], np.uint8)
+            self.refs_rev = [np.ascontiguousarray(comp[r][::-1]) for r in self.refs]
+        rev = max((self.oracle.anchor(rr, re)[1] for rr in self.refs_rev), default=0)
+        return rev >= K1_MIN_VOTES and rev > fwd
+
     def cell(self, a, re, anch):
         cap = min(511, int(0.03 * len(self.fwd[a])) + 1)
         al, _ = self.oracle.wfa(self.fwd_e[a], re, anch[int(self.fx.gene_of[a])][0] - self.off[a], cap, events=False)
@@ -79,6 +92,8 @@ class K1Tables:
         oracle, fx = self.oracle, self.fx
         res = dict(status=1, best_allele=-1, gene=-1)
         if best < 0:
+            if self.is_reverse(re, anch):
+                res["status"] = 2
             return res
         g = int(fx.gene_of[best])
         res.update(status=3, best_allele=best, gene=g, nm=int(bm["nm"]), target_len=int(bm["a_len"]),
@@ -99,6 +114,8 @@ class K1Tables:
                 d = added + int(bm["a_start"])
                 h = oracle.hpc_pos(fx.gene_ref[g], added) + oracle.hpc_pos(fx.dna[best], int(bm["a_start"]))
             res.update(status=0, seg_start=min(db_s, adj_s), seg_end=max(db_e, adj_e), dna_offset=d, hpc_offset=h)
+        if self.is_reverse(re, anch):
+            res["status"] = 2                                  # (the other fields keep what the forward search found)
         return res
 
 

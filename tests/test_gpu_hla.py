@@ -358,3 +358,28 @@ def test_k1_gene_vote_filter(oracle, pkg, gpu_ctx, small):
     assert (cells[1][in_a] == none).all() and (cells[1][in_b & has_dna] != none).any()
     # the chimera is anchored in both genes: cells were run in both
     assert (cells[2][in_a & has_dna] != none).any() and (cells[2][in_b & has_dna] != none).any()
+
+
+def test_k1_reverse_strand_reads_are_dropped(oracle, pkg, gpu_ctx, small):
+    """src/hla/realigner.rs:178-193: a read whose best mapping is on the reverse strand is dropped.  The library decides the strand at the seeds
+    (status 2: the best anchor on the reverse-complemented gene references out-votes the best forward anchor); == the oracle's statement.  The
+    reverse complement of a good read is dropped, the read itself is not; junk stays status 1; a read whose forward half is long enough stays."""
+    from pb_starphase_amd import synth
+    fx, db = small
+    rng = np.random.default_rng(21)
+    g = 0
+    a = int(rng.choice(fx.full_length_alleles(g)))
+    hap, gs = fx.haplotype(g, a)
+    good = synth.simulate_reads(rng, hap, gs, len(fx.dna[a]), 4, mean_len=6500, sd_len=1000)
+    reads = list(good) + [synth.revcomp(r) for r in good]
+    reads.append("".join(rng.choice(list("ACGT"), 4000)))                                   # junk: neither strand
+    reads.append(good[0][:3000] + synth.revcomp(good[1])[:600])                              # mostly forward: stays
+    reads.append(good[0][:300] + synth.revcomp(good[1])[:3000])                              # mostly reverse, forward anchor weak: dropped
+    rs = gpu_ctx.upload(reads)
+    out = db.realign_reads(rs)
+    exp, _cells = hx.k1_expected(oracle, fx, reads)
+    assert [int(o["status"]) for o in out] == [e["status"] for e in exp]
+    assert [int(o["status"]) for o in out[:4]] == [0, 0, 0, 0] and [int(o["status"]) for o in out[4:8]] == [2, 2, 2, 2]
+    assert int(out[8]["status"]) == 1 and int(out[9]["status"]) == 0 and int(out[10]["status"]) == 2
+    full, _c = db.realign_reads(rs, cells=True)
+    assert full.tobytes() == out.tobytes()
