@@ -324,6 +324,34 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
     return d;
 }
 
+// The words a step launch leaves behind that anybody reads: the slots 0 .. used - 1 of the exact votes, the cost growth and the final-cost extra
+// (window mode: one per push + the state's own; expand mode: one per child; init: slot 0) and, outside expand mode, the lookahead votes.  The
+// reduce and the control kernel walk them through a compact index; an expansion of a 100-read group moves 0.3 KB per workgroup instead of 12.
+struct UsedWords {
+    int used, has_la, a_end, b_end, total;
+    __device__ __forceinline__ UsedWords(int mode, int n, int n_kids) {
+        used = mode == M_EXPAND ? n_kids : (mode == M_WINDOW ? n + 1 : 1);
+        has_la = mode != M_EXPAND;
+        a_end = 2 * used * 5; b_end = a_end + (has_la ? QSL : 0); total = b_end + 2 * used;
+    }
+    // compact index -> position in the QE-word layout of the cluster sums
+    __device__ __forceinline__ int at(int c) const {
+        if (c < a_end) { const int i = c / (used * 5), rem = c % (used * 5); return (i * (CW + 1) + rem / 5) * 5 + rem % 5; }
+        if (c < b_end) return QSV + (c - a_end);
+        const int r = c - b_end;
+        return r < used ? QSV + QSL + r : QSV + QSL + (CW + 1) + (r - used);
+    }
+};
+// word o (QE layout) of workgroup blk
+template <class BT> __device__ __forceinline__ uint32_t block_word(const BT& B, size_t blk, int o) {
+    constexpr int EV = 2 * (CW + 1), EL = 2 * CW, EC = CW + 1;
+    if (o < QSV) { const int e = o / 5, f = o % 5; return f < 4 ? (uint32_t)((B.PV[blk * EV + e] >> (16 * f)) & 0xFFFFull) : B.PE[blk * EV + e]; }
+    if (o < QSV + QSL) { const int e = (o - QSV) / 4, f = (o - QSV) % 4; return (uint32_t)((B.PL[blk * EL + e] >> (16 * f)) & 0xFFFFull); }
+    if (o < QSV + QSL + EC) return B.PC[blk * EC + (o - QSV - QSL)];
+    return B.PR[blk * EC + (o - QSV - QSL - EC)];
+}
+constexpr int DIRECT_LOADS = 24576;     // workgroups x words below which the control kernel sums the workgroups' words itself (the reduce launch returns at once)
+
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B) {
     int pi = 0;
     if constexpr (MAXP == 0) pi = B.block_prob[blockIdx.x];
@@ -699,12 +727,14 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
 #endif
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < 2 * (CW + 1); x += blockDim.x) {
-        B.PV[(size_t)blockIdx.x * 2 * (CW + 1) + x] = (&lv[0][0])[x];
-        B.PE[(size_t)blockIdx.x * 2 * (CW + 1) + x] = (&le[0][0])[x];
+    const UsedWords uw(mode, n, n_kids);
+    for (int x = threadIdx.x; x < 2 * uw.used; x += blockDim.x) {
+        const int i = x / uw.used, e = i * (CW + 1) + x % uw.used;
+        B.PV[(size_t)blockIdx.x * 2 * (CW + 1) + e] = (&lv[0][0])[e];
+        B.PE[(size_t)blockIdx.x * 2 * (CW + 1) + e] = (&le[0][0])[e];
     }
-    for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) B.PL[(size_t)blockIdx.x * 2 * CW + x] = (&ll[0][0])[x];
-    for (int x = threadIdx.x; x < CW + 1; x += blockDim.x) { B.PC[(size_t)blockIdx.x * (CW + 1) + x] = lc[x]; B.PR[(size_t)blockIdx.x * (CW + 1) + x] = lr[x]; }
+    if (uw.has_la) for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) B.PL[(size_t)blockIdx.x * 2 * CW + x] = (&ll[0][0])[x];
+    for (int x = threadIdx.x; x < uw.used; x += blockDim.x) { B.PC[(size_t)blockIdx.x * (CW + 1) + x] = lc[x]; B.PR[(size_t)blockIdx.x * (CW + 1) + x] = lr[x]; }
 }
 
 // sums the vote words of CLUSTER consecutive workgroups of a problem (several hundred workgroups would otherwise be summed by the one
@@ -722,38 +752,21 @@ __global__ void __launch_bounds__(512) cons_reduce_kernel(ConsBatchT<MAXP> B) {
         for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && cluster >= B.p[i].first_cluster) pi = i;
     }
     const ConsParams P = B.p[pi];
-    if (P.work->done || P.work->mode == M_NONE) return;
+    const int mode = P.work->mode;
+    if (P.work->done || mode == M_NONE) return;
+    const UsedWords uw(mode, mode == M_WINDOW ? P.work->n : 0, mode == M_EXPAND ? P.work->n_kids : 0);
+    if ((long long)P.n_blocks * uw.total <= DIRECT_LOADS) return;            // the control kernel sums these few words itself
     const int cl = cluster - P.first_cluster;
     const int members = P.n_blocks - cl * CLUSTER < CLUSTER ? P.n_blocks - cl * CLUSTER : CLUSTER;
     const size_t blk0 = (size_t)P.first_block + (size_t)cl * CLUSTER;
-    constexpr int EV = 2 * (CW + 1), EL = 2 * CW, EC = CW + 1;
-    constexpr int PER = (QE + RSLICES - 1) / RSLICES, NG = CLUSTER / RGROUP;
-    const int o_lo = slice * PER, o_hi = o_lo + PER < QE ? o_lo + PER : QE;
-    for (int idx = threadIdx.x; idx < (o_hi - o_lo) * NG; idx += blockDim.x) {
-        const int o = o_lo + idx / NG, m0 = (idx % NG) * RGROUP;
+    constexpr int NG = CLUSTER / RGROUP;
+    const int per = (uw.total + RSLICES - 1) / RSLICES;
+    const int c_lo = slice * per, c_hi = c_lo + per < uw.total ? c_lo + per : uw.total;
+    for (int idx = threadIdx.x; idx < (c_hi - c_lo) * NG; idx += blockDim.x) {
+        const int o = uw.at(c_lo + idx / NG), m0 = (idx % NG) * RGROUP;
         uint32_t v[RGROUP];
-        if (o < QSV) {
-            const int e = o / 5, f = o % 5;
-            if (f < 4) {
 #pragma unroll
-                for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? (uint32_t)((B.PV[(blk0 + m0 + m) * EV + e] >> (16 * f)) & 0xFFFFull) : 0u;
-            } else {
-#pragma unroll
-                for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? B.PE[(blk0 + m0 + m) * EV + e] : 0u;
-            }
-        } else if (o < QSV + QSL) {
-            const int e = (o - QSV) / 4, f = (o - QSV) % 4;
-#pragma unroll
-            for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? (uint32_t)((B.PL[(blk0 + m0 + m) * EL + e] >> (16 * f)) & 0xFFFFull) : 0u;
-        } else if (o < QSV + QSL + EC) {
-            const int e = o - QSV - QSL;
-#pragma unroll
-            for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? B.PC[(blk0 + m0 + m) * EC + e] : 0u;
-        } else {
-            const int e = o - QSV - QSL - EC;
-#pragma unroll
-            for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? B.PR[(blk0 + m0 + m) * EC + e] : 0u;
-        }
+        for (int m = 0; m < RGROUP; ++m) v[m] = m0 + m < members ? block_word(B, blk0 + m0 + m, o) : 0u;
         uint32_t sum = 0;
 #pragma unroll
         for (int m = 0; m < RGROUP; ++m) sum += v[m];
@@ -822,20 +835,24 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     if (tid == 0) { copy_from = -1; copy_len = 0; need_la = -1; }
     __syncthreads();
     const int mode_in = wk.mode, n_in = wk.mode == M_WINDOW ? wk.n : 0;
-    // the cluster sums of the step (a few per problem), eight loads in flight per thread
-    for (int o = tid; o < QE; o += blockDim.x) {
-        uint32_t sum = 0;
-        if (mode_in != M_NONE) {
-            const uint32_t* q = B.Q + (size_t)P.first_cluster * QE + o;
-            for (int c0 = 0; c0 < P.n_clusters; c0 += 8) {
+    // the words of the step that are in use: the cluster sums (a few per problem), or -- when they are few -- the workgroups' own words; eight
+    // loads in flight per thread
+    if (mode_in != M_NONE) {
+        const UsedWords uw(mode_in, n_in, mode_in == M_EXPAND ? wk.n_kids : 0);
+        const bool direct = (long long)P.n_blocks * uw.total <= DIRECT_LOADS;
+        const int parts = direct ? P.n_blocks : P.n_clusters;
+        for (int c = tid; c < uw.total; c += blockDim.x) {
+            const int o = uw.at(c);
+            uint32_t sum = 0;
+            for (int c0 = 0; c0 < parts; c0 += 8) {
                 uint32_t v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = c0 + u < P.n_clusters ? q[(size_t)(c0 + u) * QE] : 0u;
+                for (int u = 0; u < 8; ++u) v[u] = c0 + u >= parts ? 0u : direct ? block_word(B, (size_t)P.first_block + c0 + u, o) : B.Q[(size_t)(P.first_cluster + c0 + u) * QE + o];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) sum += v[u];
             }
+            acc[o] = sum;
         }
-        acc[o] = sum;
     }
     __syncthreads();
     const long long tk1 = wall_clock64();

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 
 namespace {
 
@@ -30,13 +31,25 @@ Rccl* rccl() {
     static bool tried = false;
     if (tried) return &R;
     tried = true;
-    // a copy the process already carries (a host that links RCCL, or Python with torch imported) is the one to use: two RCCLs in one process
-    // do not get along; SP_RCCL_PATH names a particular file
+    // The RCCL to use is the one that sits on the HIP runtime THIS library is bound to: a Python process with torch carries a second HIP runtime
+    // and a second RCCL (torch/lib), and a stream of one runtime means nothing to the other.  Where our own hipMalloc lives tells which runtime
+    // that is; its directory holds the matching librccl.  RTLD_DEEPBIND makes that RCCL resolve its HIP calls through its own dependencies
+    // (the same file, hence the same loaded runtime) whatever else is in the global scope.  SP_RCCL_PATH names a particular file instead.
     const char* env = std::getenv("SP_RCCL_PATH");
-    if (env && *env) R.h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-    if (!R.h) R.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (env && *env) R.h = dlopen(env, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+    if (!R.h) {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipMalloc), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t cut = dir.rfind('/');
+            if (cut != std::string::npos) {
+                dir.resize(cut + 1);
+                for (const char* n : { "librccl.so.1", "librccl.so" }) { if (R.h) break; R.h = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND); }
+            }
+        }
+    }
     const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-    for (const char* n : names) { if (R.h) break; R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
+    for (const char* n : names) { if (R.h) break; R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND); }
     if (!R.h) { R.err = "librccl.so not found"; return &R; }
     R.GetUniqueId = (int (*)(NcclId*))dlsym(R.h, "ncclGetUniqueId");
     R.CommInitRank = (int (*)(ncclComm_t*, int, NcclId, int))dlsym(R.h, "ncclCommInitRank");

@@ -373,8 +373,8 @@ def test_k1_reverse_strand_reads_are_dropped(oracle, pkg, gpu_ctx, small):
     good = synth.simulate_reads(rng, hap, gs, len(fx.dna[a]), 4, mean_len=6500, sd_len=1000)
     reads = list(good) + [synth.revcomp(r) for r in good]
     reads.append("".join(rng.choice(list("ACGT"), 4000)))                                   # junk: neither strand
-    reads.append(good[0][:3000] + synth.revcomp(good[1])[:600])                              # mostly forward: stays
-    reads.append(good[0][:300] + synth.revcomp(good[1])[:3000])                              # mostly reverse, forward anchor weak: dropped
+    reads.append(good[0] + synth.revcomp(good[1])[:600])                                     # a forward read with a reverse tail: stays
+    reads.append(good[0][:300] + synth.revcomp(good[1]))                                     # a reverse read with a short forward head: dropped
     rs = gpu_ctx.upload(reads)
     out = db.realign_reads(rs)
     exp, _cells = hx.k1_expected(oracle, fx, reads)

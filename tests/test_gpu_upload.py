@@ -98,7 +98,6 @@ def test_upload_argument_errors(pkg, gpu_ctx):
 def test_group_of_one_rank_gathers_through_rccl(pkg, gpu_ctx):
     """sp_group_* / sp_gather_results on the one GPU of this box: a group of a single rank still goes through ncclCommInitRank and
     ncclAllGather (the N > 1 node is the driver's to run; two ranks on one device are refused by RCCL itself)"""
-    import torch  # noqa: F401  (torch carries a librccl of its own: it has to be in the process first, the library then shares that copy)
     from pb_starphase_amd import shard
     uid = pkg.ffi.group_unique_id()
     assert uid.shape == (128,) and uid.any()
