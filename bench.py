@@ -322,17 +322,23 @@ class CohortShare:
         """uploads, calls and the gather of one pass over the share; returns (records table, counts of calls equal to the truth)"""
         fx = self.fx
         genes = list(range(len(fx.genes)))
+        tm = self.host_s = getattr(self, "host_s", {"upload": 0.0, "hla": 0.0, "cyp2d6": 0.0, "variant_genes": 0.0, "records_and_gather": 0.0})
+        t0 = time.perf_counter()
         up = ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *self.hla_payload, wait=False)
         cyp_sets = []
         R = up.wait()
         for p in self.cyp_payloads:                                              # (one upload in flight per context: each waits for the one before)
             cyp_sets.append(ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *p, wait=False))
+        t1 = time.perf_counter(); tm["upload"] += t1 - t0
         k1 = db.realign_reads(R)
         cohort, _ = db.diplotype_cohort(len(self.samples), self.sample_of, genes, R, k1)
+        t2 = time.perf_counter(); tm["hla"] += t2 - t1
         for c in cyp_sets:
             c.wait()
         cyp = cdb.diplotype_cohort(cyp_sets)
+        t3 = time.perf_counter(); tm["cyp2d6"] += t3 - t2
         var = ctx.variant_solve_batch(self.var_problems)
+        t4 = time.perf_counter(); tm["variant_genes"] += t4 - t3
         n_rec = len(self.samples) * (len(genes) + 1 + self.n_genes_panel)
         rec = np.zeros(n_rec, shard.CALL_DTYPE)
         ok_hla = ok_cyp = ok_var = 0
@@ -355,6 +361,7 @@ class CohortShare:
         R.close()
         for c in cyp_sets:
             c.close()
+        tm["records_and_gather"] += time.perf_counter() - t4
         return table, (ok_hla, ok_cyp, ok_var)
 
 
@@ -367,6 +374,8 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     shares = [CohortShare(pkg, fx, locus, scen, panel, c) for c in chunks]
     for _ in range(args.warmup):
         shares[0].step(pkg, ctx, db, cdb, shard, group, rank)
+    for sh in shares:
+        sh.host_s = {"upload": 0.0, "hla": 0.0, "cyp2d6": 0.0, "variant_genes": 0.0, "records_and_gather": 0.0}
     barrier()
     t0 = time.perf_counter()
     ok = np.zeros(3, np.int64)
@@ -384,7 +393,8 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     reads_all, samples_all = int(totals[0]), int(totals[1])
     n_genes = len(fx.genes)
     return {"value": reads_all * args.steps / dt, "unit": "reads/s", "samples_per_s": samples_all * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
-            "samples": samples_all, "reads_per_pass": reads_all, "records_gathered_per_pass": n_table // max(1, args.steps),
+            "samples": samples_all, "reads_per_pass": reads_all,
+            "rank0_host_seconds_per_pass": {k: sum(sh.host_s[k] for sh in shares) / max(1, args.steps) for k in shares[0].host_s}, "records_gathered_per_pass": n_table // max(1, args.steps),
             "calls_equal_truth": {"hla": f"{int(totals[2])}/{samples_all * n_genes * args.steps}", "cyp2d6": f"{int(totals[3])}/{samples_all * args.steps}",
                                   "variant_genes_truth_among_reported": f"{int(totals[4])}/{samples_all * len(panel.genes) * args.steps}"},
             "workload": f"BASELINE configs[4]: {args.cohort_samples} synthetic WGS-style samples x (HLA-A / -B ~44 reads per gene, CYP2D6 ~100 reads, {len(panel.genes)} variant genes), "

@@ -62,7 +62,9 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * call (the genes of a sample, the (sample, gene) pairs of a cohort) with >= 1,000 realigned reads side by side on up to
  * "hla_split_streams" (1..4, default 3) streams -- helper streams the context owns, one host thread each for the length of the call:
  * lowest latency for one call; set hla_split_genes to 0 when several samples are in flight on contexts of their own, where the streams
- * of the other samples already fill the gaps.  The calls are the same either way.  Unknown names: SP_ERR_INVALID_ARG. */
+ * of the other samples already fill the gaps.  The calls are the same either way.  "cons_retry_ladder" (default 1): 0 makes sp_cyp_diplotype* run
+ * its multi-way consensus without the retry of searches that give up (sp_cons_config.no_retry_ladder, see sp_consensus_priority).
+ * Unknown names: SP_ERR_INVALID_ARG. */
 int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value);
 
 /* ------------------------------------------------------------------ sequences
@@ -566,13 +568,14 @@ typedef struct {
     int32_t max_queue_size;            /* 20    CdwfaConfig::max_queue_size, set by dwfa_config_from_cli (src/hla/caller.rs:1110) */
     int32_t max_capacity_per_size;     /* 10    CdwfaConfig::max_capacity_per_size (:1111) */
     int32_t max_nodes_wo_constraint;   /* 1000  waffle_con's default; the reference does not set it */
-    int32_t reserved;                  /* (<= 0 in any of the three: the value named above) */
+    int32_t no_retry_ladder;           /* (<= 0 in any of the three above: the value named there)  sp_consensus_priority only: 1 = a two-way search that
+                                        * gives up is NOT run again with stricter fractions (see there); 0 = the default */
 } sp_cons_config;
 
 typedef struct {
     int32_t is_dual, len1, len2, split_at;
-    int64_t best_w2, best_total;       /* strongest second-base column before any split: its weight / all votes, in 12ths of a read */
-    int64_t split_w2, split_total;     /* (both pairs are unused since the best-first search replaced the two-pass split policy) */
+    int64_t gave_up, best_total;       /* gave_up = 1: the search ended without a complete node (its bounds exhausted): no consensus, every read in group 1 */
+    int64_t split_w2, split_total;     /* (best_total and this pair are unused since the best-first search replaced the two-pass split policy) */
     int64_t nodes_expanded;            /* nodes the search took out of its queue and expanded */
 } sp_cons_result;
 
@@ -607,7 +610,8 @@ int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* r
  * gets one consensus per level (sp_consensus).  All problems of a round run in lockstep on the GPU.  A two-way search that gives up (no
  * complete node: a group of more classes than a search holds consensuses can exhaust the queue / capacity bounds at high depth) is run
  * again with min_af 0.15, 0.20, 0.30, 0.40 (the first above the configured one that completes); the groups it leaves are solved with the
- * configured fraction again.
+ * configured fraction again.  This retry is a rule of this library, not of waffle_con: cfg.no_retry_ladder = 1 switches it off (the group then
+ * stays whole, as a search that gives up leaves it).  "Gave up" is sp_cons_result.gave_up of the two-way search, not an empty string.
  *   levels[l]   the sequences of level l (n each, same read order); offsets[l] = NULL or n entries (-1 = None); seeds = NULL or n (-1 = None)
  *   group_of    n entries: index of the emitted group of every read (MultiConsensus::sequence_indices)
  *   cons        max_groups * n_levels * cap bytes: consensus of group g at level l at cons + (g * n_levels + l) * cap

@@ -348,7 +348,7 @@ int osp_consensus(int n_reads, const uint8_t* const* seqs, const int32_t* lens, 
     free(processed);
     memset(res, 0, sizeof *res); res->split_at = -1; res->best_total = 1;
     res->nodes_expanded = pops;
-    if (!best) { for (int r = 0; r < n_reads; ++r) { score1[r] = score2[r] = -1; is_cons1[r] = 1; } return 0; }
+    if (!best) { res->gave_up = 1; for (int r = 0; r < n_reads; ++r) { score1[r] = score2[r] = -1; is_cons1[r] = 1; } return 0; }
     memcpy(cons1, best->C[0], (size_t)best->len[0]);
     if (best->dual) memcpy(cons2, best->C[1], (size_t)best->len[1]);
     for (int r = 0; r < n_reads; ++r) {

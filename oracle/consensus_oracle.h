@@ -22,7 +22,7 @@ typedef struct {
 
 typedef struct {
     int32_t is_dual, len1, len2, split_at;
-    int64_t best_w2, best_total;       /* (unused since the best-first search replaced the two-pass split policy) */
+    int64_t gave_up, best_total;       /* gave_up = 1: no complete node was found (best_total is unused since the best-first search replaced the two-pass split policy) */
     int64_t nodes_expanded;
 } osp_cons_result;
 

@@ -86,6 +86,7 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx) {
 int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SP_ERR_INVALID_ARG;
     if (std::strcmp(name, "hla_split_genes") == 0) { ctx->split_genes = value != 0; return SP_OK; }
+    if (std::strcmp(name, "cons_retry_ladder") == 0) { ctx->cons_retry_ladder = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->cons_retry_ladder = ctx->cons_retry_ladder; return SP_OK; }
     if (std::strcmp(name, "hla_split_streams") == 0) { if (value < 1 || value > 4) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: hla_split_streams is 1..4"); ctx->split_streams = (int)value; return SP_OK; }
     return sp_fail(ctx, SP_ERR_INVALID_ARG, std::string("sp_ctx_set_option: unknown option ") + name);
 }

@@ -1437,7 +1437,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         o.cons1[len1] = '\0'; o.cons2[len2] = '\0';
         for (int r = 0; r < P.n; ++r) { o.is_cons1[r] = h_is1[P.first + r]; o.score1[r] = h_sc[P.first + r]; o.score2[r] = h_sc[total + P.first + r]; }
         o.result.is_dual = dual; o.result.len1 = len1; o.result.len2 = len2; o.result.split_at = split_at;
-        o.result.best_w2 = 0; o.result.best_total = 1; o.result.split_w2 = 0; o.result.split_total = 1;
+        o.result.gave_up = best < 0 ? 1 : 0; o.result.best_total = 1; o.result.split_w2 = 0; o.result.split_total = 1;
         o.result.nodes_expanded = h_srch[p].pops;
         // a consensus that filled its buffer was still growing: the caller sized cap too small
         if (len1 >= P.cap || len2 >= P.cap) { o.status = SP_ERR_CAPACITY; rc = SP_ERR_CAPACITY; }
@@ -1575,7 +1575,7 @@ int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* pr, uint32
         for (size_t x = 0; x < k; ++x) {
             Item& it = work[x];
             // gave up: once more with the next stricter fraction of the ladder that is above the configured one
-            if (!O[x].result.is_dual && O[x].cons1[0] == '\0' && !it.members.empty()) {
+            if (O[x].result.gave_up && !pr->cfg.no_retry_ladder && !it.members.empty()) {
                 int step = it.retry;
                 while (step < 4 && retry_min_af[step] <= pr->cfg.min_af) ++step;
                 if (step < 4) { it.retry = step + 1; next.push_back(std::move(it)); continue; }

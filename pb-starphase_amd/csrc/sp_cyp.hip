@@ -1095,6 +1095,7 @@ extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* 
     // 3. multi-way consensus, homopolymer-compressed level first (caller.rs:162-270)
     sp_cons_config cc{};
     cc.min_count = pr->min_consensus_count; cc.min_af = pr->min_consensus_fraction; cc.dual_max_ed_delta = pr->dual_max_ed_delta;
+    cc.no_retry_ladder = ctx->cons_retry_ladder ? 0 : 1;
     cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 100; cc.offset_compare_length = 64;      // the library compares at most 64 bases
     const uint32_t n_in = raw.n;
     const sp_seqset* levels[2] = { &hpc, &raw };

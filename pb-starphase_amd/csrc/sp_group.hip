@@ -39,7 +39,8 @@ Rccl* rccl() {
     if (env && *env) R.h = dlopen(env, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
     if (!R.h) {
         Dl_info info;
-        if (dladdr(reinterpret_cast<void*>(&hipMalloc), &info) && info.dli_fname) {
+        hipError_t (*own_malloc)(void**, size_t) = &hipMalloc;          // (the plain overload: where it lives is the runtime this library calls)
+        if (dladdr(reinterpret_cast<void*>(own_malloc), &info) && info.dli_fname) {
             std::string dir(info.dli_fname);
             const size_t cut = dir.rfind('/');
             if (cut != std::string::npos) {

@@ -103,11 +103,11 @@ class sp_sv_definitions(C.Structure):
 class sp_cons_config(C.Structure):
     _fields_ = [("min_count", C.c_int32), ("dual_max_ed_delta", C.c_int32), ("allow_early_termination", C.c_int32), ("allow_dual", C.c_int32),
                 ("offset_window", C.c_int32), ("offset_compare_length", C.c_int32), ("min_af", C.c_double),
-                ("max_queue_size", C.c_int32), ("max_capacity_per_size", C.c_int32), ("max_nodes_wo_constraint", C.c_int32), ("reserved", C.c_int32)]
+                ("max_queue_size", C.c_int32), ("max_capacity_per_size", C.c_int32), ("max_nodes_wo_constraint", C.c_int32), ("no_retry_ladder", C.c_int32)]
 
 
 class sp_cons_result(C.Structure):
-    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64),
+    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("gave_up", C.c_int64), ("best_total", C.c_int64),
                 ("split_w2", C.c_int64), ("split_total", C.c_int64), ("nodes_expanded", C.c_int64)]
 
 
@@ -481,7 +481,7 @@ class Context:
         fn = lib().sp_consensus_dual if two_pass else lib().sp_consensus
         self.check(fn(self._h, reads._h, _ptr(idx), n, _ptr(offs), C.byref(cfg), c1, c2, cap + 1, _ptr(is1), _ptr(s1), _ptr(s2), C.byref(res)))
         return dict(cons=[c1.value.decode(), c2.value.decode() if res.is_dual else None], is_dual=bool(res.is_dual), is_cons1=is1[:n].astype(bool),
-                    score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, nodes_expanded=res.nodes_expanded)
+                    score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, nodes_expanded=res.nodes_expanded, gave_up=bool(res.gave_up))
 
     def consensus_batch(self, problems, two_pass=False):
         """problems: list of dict(reads=SeqSet, cfg=sp_cons_config, offsets=None|list, read_idx=None|array, cap=None).
@@ -507,7 +507,7 @@ class Context:
         for j, (idx, offs, c1, c2, is1, s1, s2, n) in enumerate(keep):
             res = O[j].result
             out.append(dict(cons=[c1.value.decode(), c2.value.decode() if res.is_dual else None], is_dual=bool(res.is_dual), is_cons1=is1[:n].astype(bool),
-                            score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, nodes_expanded=res.nodes_expanded))
+                            score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, nodes_expanded=res.nodes_expanded, gave_up=bool(res.gave_up)))
         return out
 
     def consensus_priority(self, levels, cfg, offsets=None, seeds=None, max_groups=64, cap=None):

@@ -412,7 +412,7 @@ class ConsConfig(C.Structure):
 
 
 class ConsResult(C.Structure):
-    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("best_w2", C.c_int64), ("best_total", C.c_int64),
+    _fields_ = [("is_dual", C.c_int32), ("len1", C.c_int32), ("len2", C.c_int32), ("split_at", C.c_int32), ("gave_up", C.c_int64), ("best_total", C.c_int64),
                 ("nodes_expanded", C.c_int64)]
 
 
@@ -429,7 +429,7 @@ def with_dual(cfg, dual):
 
 
 def oracle_consensus(oracle, reads, offsets=None, cfg=None, cap=None):
-    """osp_consensus -> dict(cons=[str, str|None], is_dual, is_cons1, score1, score2 (None = -1), split_at, best_w2, best_total)"""
+    """osp_consensus -> dict(cons=[str, str|None], is_dual, is_cons1, score1, score2 (None = -1), split_at, nodes_expanded, gave_up)"""
     cfg = cfg or cons_config()
     enc = [oracle.encode(r) for r in reads]
     n = len(reads)
@@ -446,7 +446,7 @@ def oracle_consensus(oracle, reads, offsets=None, cfg=None, cap=None):
     assert rc == 0
     dec = lambda a, k: "".join("ACGT"[x] for x in a[:k])
     return dict(cons=[dec(c1, res.len1), dec(c2, res.len2) if res.is_dual else None], is_dual=bool(res.is_dual), is_cons1=is1[:n].astype(bool),
-                score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, nodes_expanded=res.nodes_expanded)
+                score1=s1[:n].copy(), score2=s2[:n].copy(), split_at=res.split_at, nodes_expanded=res.nodes_expanded, gave_up=bool(res.gave_up))
 
 
 def dual_consensus_two_pass(run, reads, offsets=None, cfg=None):
@@ -457,7 +457,7 @@ def dual_consensus_two_pass(run, reads, offsets=None, cfg=None):
 PRIORITY_RETRY_MIN_AF = (0.15, 0.20, 0.30, 0.40)          # sp_consensus_priority's ladder for searches that give up
 
 
-def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None):
+def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None, retry_ladder=True):
     """The multi-way contract of sp_consensus_priority on top of the oracle's two-way consensus (include/starphase_hip.h):
     levels = list (per level) of lists of strings.  Returns (group_of, [[consensus per level] per group])."""
     n, nl = len(levels[0]), len(levels)
@@ -478,7 +478,7 @@ def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None):
         # bounds) is run again with only the stronger differences as candidates; the split it finds is the split, the groups it leaves are
         # solved with the configured fraction again
         for af in PRIORITY_RETRY_MIN_AF:
-            if res["cons"][0] or af <= cfg.min_af:                  # (a search that gave up has no consensus: an empty string)
+            if not retry_ladder or not res["gave_up"] or af <= cfg.min_af:
                 continue
             stricter = ConsConfig(dual.min_count, dual.dual_max_ed_delta, dual.allow_early_termination, 1, dual.offset_window, dual.offset_compare_length, af,
                                   dual.max_queue_size, dual.max_capacity_per_size, dual.max_nodes_wo_constraint, 0)

@@ -182,3 +182,40 @@ def test_variant_states_on_the_real_table(oracle, gpu_ctx, real):
     bv, ba, tie = gpu_ctx.cyp_score_alleles(rows, odb.is_vi, states)
     for x, a in enumerate(chosen):
         assert tie[x][a] == 1, names[a]
+
+
+def test_retry_ladder_is_an_option(pkg, gpu_ctx):
+    """The retry of two-way searches that give up (min_af 0.15 .. 0.40) is a rule of this library, not of waffle_con: it can be switched off
+    (sp_ctx_set_option "cons_retry_ladder" -> sp_cons_config.no_retry_ladder), and "gave up" is an explicit field of the search's result.  On the
+    second-locus hybrid sample the search of the 884 unseeded sequences gives up at the configured fraction: without the retry the group stays
+    whole (the pre-ladder contract: one hybrid, `*68x2/*68x2`), with it the call is the truth."""
+    from pb_starphase_amd import synth
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=2003)
+    db = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
+    _name, haps, expected = [s for s in cr.scenarios(locus) if s[0] == "*4+*68/*1"][0]
+    R = gpu_ctx.upload(locus.sample(np.random.default_rng(2007), haps, 2000))
+    gpu_ctx.set_option("cons_retry_ladder", 0)
+    try:
+        off, _cons, labels_off = db.diplotype(R)
+    finally:
+        gpu_ctx.set_option("cons_retry_ladder", 1)
+    on, _cons, labels_on = db.diplotype(R)
+    assert on.status == 0 and sorted([on.hap1.decode(), on.hap2.decode()]) == sorted(expected)
+    assert sorted([off.hap1.decode(), off.hap2.decode()]) != sorted(expected)
+    assert len(labels_off) < len(labels_on)                       # the group that gave up stayed whole
+
+
+def test_gave_up_is_reported(pkg, gpu_ctx):
+    """a two-way search whose bounds are exhausted reports gave_up = 1 (and no consensus); one that completes reports 0"""
+    rng = np.random.default_rng(5)
+    base = "".join(rng.choice(list("ACGT"), 400))
+    reads = [base] * 12
+    out = gpu_ctx.consensus(gpu_ctx.upload(reads), pkg.ffi.sp_cons_config(3, 100, 1, 1, 400, 50, 0.10, 20, 10, 1000, 0))
+    assert out["cons"][0] == base and out["gave_up"] is False
+    # every read its own sequence and a queue of one node with capacity one per length: the search cannot keep any branch alive
+    noisy = ["".join(rng.choice(list("ACGT"), 300)) for _ in range(12)]
+    out = gpu_ctx.consensus(gpu_ctx.upload(noisy), pkg.ffi.sp_cons_config(1, 100, 1, 1, 400, 50, 0.01, 1, 1, 1, 0))
+    assert isinstance(out["gave_up"], bool)
+    if out["gave_up"]:
+        assert out["cons"][0] == ""
