@@ -1276,7 +1276,9 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
             const uint32_t i = next.fetch_add(1);
             if (i >= n_samples) break;
             where[i] = x;
-            rcs[i] = sp_cyp_diplotype(on[x], pr, reads[i], &calls[i], consensus ? consensus + (size_t)i * SP_CYP_MAXCONS * cons_cap : nullptr, cons_cap);
+            try { rcs[i] = sp_cyp_diplotype(on[x], pr, reads[i], &calls[i], consensus ? consensus + (size_t)i * SP_CYP_MAXCONS * cons_cap : nullptr, cons_cap); }
+            catch (const std::bad_alloc&) { rcs[i] = SP_ERR_OUT_OF_MEMORY; on[x]->err = "sp_cyp_diplotype: out of host memory"; }      // (an exception must not leave a thread, nor
+            catch (const std::exception& e) { rcs[i] = SP_ERR_INVALID_ARG; on[x]->err = std::string("sp_cyp_diplotype: ") + e.what(); }   // the caller while threads are joinable)
         }
     };
     std::thread beside[4]; bool started[4] = { false, false, false, false };

@@ -413,6 +413,7 @@ int32_t sp_vcf_open(const char* path, sp_vcf** out, char* err, uint32_t err_cap)
     const bool bad = k < 0;
     gzclose(f);
     if (bad) { put_err(err, err_cap, std::string("cannot read ") + path); return SP_ERR_INVALID_ARG; }
+    try {
     auto v = std::make_unique<sp_vcf>();
     size_t from = 0; bool have_header = false;
     while (from < text.size()) {
@@ -432,6 +433,8 @@ int32_t sp_vcf_open(const char* path, sp_vcf** out, char* err, uint32_t err_cap)
     for (const std::string& s : v->samples) v->sample_ptr.push_back(s.c_str());
     *out = v.release();
     return SP_OK;
+    } catch (const std::bad_alloc&) { put_err(err, err_cap, "out of memory reading the VCF"); return SP_ERR_OUT_OF_MEMORY; }
+    catch (const std::exception& e) { put_err(err, err_cap, std::string("VCF: ") + e.what()); return SP_ERR_INVALID_ARG; }
 }
 
 void sp_vcf_free(sp_vcf* vcf) { delete vcf; }
@@ -473,16 +476,18 @@ int32_t sp_vcf_deletions(sp_vcf* v, const char* sample, const char* chrom, uint6
     if (si < 0) return vcf_fail(v, std::string("the VCF has no sample ") + (sample ? sample : "(first)"));
     for (const sp_vcf::Record& r : v->records) {
         if (r.chrom != chrom || r.alts.size() != 1) continue;
+        if (r.pos0 >= end) continue;                                 // the reference only sees what its region fetch returns (src/diplotyper.rs:796-815)
         std::string svtype, endv; bool has_type = false, has_end = false;
         for (const std::string& kv : split(r.info, ';')) {
             if (kv.compare(0, 7, "SVTYPE=") == 0) { svtype = kv.substr(7); has_type = true; }
             else if (kv.compare(0, 4, "END=") == 0) { endv = kv.substr(4); has_end = true; }
         }
+        // a record's extent for the fetch is INFO/END when it has one, its REF allele otherwise (htslib's rlen)
+        const uint64_t e = has_end ? (uint64_t)std::strtoull(endv.c_str(), nullptr, 10) : r.pos0 + r.ref.size();
+        if (!(e > start)) continue;                                  // outside the region: never fetched, its INFO fields are never looked at
         if (!has_type) return vcf_fail(v, "No INFO:SVTYPE in record");
         if (svtype != "DEL") continue;
         if (!has_end) return vcf_fail(v, "No INFO:END in record");
-        const uint64_t e = (uint64_t)std::strtoull(endv.c_str(), nullptr, 10);
-        if (!(r.pos0 < end && e > start)) continue;
         int g1, g2; bool phased; int64_t ps;
         if (!genotype(r, si, g1, g2, phased, ps)) continue;
         int32_t gt;
@@ -576,16 +581,23 @@ int32_t sp_fasta_fetch(sp_fasta* fa, const char* chrom, uint64_t start, uint64_t
     for (const auto& s : fa->seqs) if (s.name == chrom) { q = &s; break; }
     if (!q) { fa->err = std::string("the FASTA has no sequence ") + chrom; return SP_ERR_INVALID_ARG; }
     if (start > end || end > q->length) { fa->err = std::string("slice outside of ") + chrom; return SP_ERR_INVALID_ARG; }
+    try {
     if (!fa->indexed) fa->slice.assign(q->bases, (size_t)start, (size_t)(end - start));
     else {
         fa->slice.clear(); fa->slice.reserve((size_t)(end - start));
         const uint64_t first = q->offset + (start / q->line_bases) * q->line_bytes + start % q->line_bases;
         const uint64_t last = end == start ? first : q->offset + ((end - 1) / q->line_bases) * q->line_bytes + (end - 1) % q->line_bases + 1;
+        // what the index says is held against the file before anything of that size is allocated (a damaged .fai can name any length)
+        if (fseeko(fa->file, 0, SEEK_END) != 0) { fa->err = "cannot read " + fa->path; return SP_ERR_INVALID_ARG; }
+        const uint64_t file_size = (uint64_t)ftello(fa->file);
+        if (last < first || last > file_size) { fa->err = "the FASTA index does not describe " + fa->path; return SP_ERR_INVALID_ARG; }
         std::string raw((size_t)(last - first), '\0');
         if (fseeko(fa->file, (off_t)first, SEEK_SET) != 0 || std::fread(&raw[0], 1, raw.size(), fa->file) != raw.size()) { fa->err = "cannot read " + fa->path; return SP_ERR_INVALID_ARG; }
         for (char c : raw) if (c != '\n' && c != '\r') fa->slice += (c >= 'a' && c <= 'z') ? (char)(c - 32) : c;
         if (fa->slice.size() != end - start) { fa->err = "the FASTA index does not describe " + fa->path; return SP_ERR_INVALID_ARG; }
     }
+    } catch (const std::bad_alloc&) { fa->err = "out of memory reading " + fa->path; return SP_ERR_OUT_OF_MEMORY; }
+    catch (const std::exception& e) { fa->err = std::string("FASTA: ") + e.what(); return SP_ERR_INVALID_ARG; }
     *bases = fa->slice.c_str();
     if (len) *len = fa->slice.size();
     return SP_OK;

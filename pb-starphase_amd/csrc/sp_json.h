@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -19,10 +20,24 @@ struct Value {
     bool b = false; int64_t i = 0; double d = 0.0; std::string s;
     std::vector<Value> arr;
     std::vector<std::pair<std::string, Value>> obj;
+    std::vector<uint32_t> by_key;                 // large objects: member numbers sorted by (key, position), built when the object has been read
+    // the member of that name; of members with one name the LAST counts, as in the maps serde fills (a later insert replaces an earlier one)
     const Value* get(const char* key) const {
         if (kind != Object) return nullptr;
-        for (const auto& kv : obj) if (kv.first == key) return &kv.second;
-        return nullptr;
+        if (by_key.size() == obj.size() && !obj.empty()) {
+            size_t lo = 0, hi = by_key.size();                                   // first member whose key is greater than `key`
+            while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (obj[by_key[mid]].first.compare(key) <= 0) lo = mid + 1; else hi = mid; }
+            return (lo > 0 && obj[by_key[lo - 1]].first == key) ? &obj[by_key[lo - 1]].second : nullptr;
+        }
+        const Value* found = nullptr;
+        for (const auto& kv : obj) if (kv.first == key) found = &kv.second;
+        return found;
+    }
+    void index_members() {                        // (a linear scan is as good for the few members of an ordinary object)
+        if (kind != Object || obj.size() < 32) return;
+        by_key.resize(obj.size());
+        for (uint32_t k = 0; k < (uint32_t)obj.size(); ++k) by_key[k] = k;
+        std::sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) { const int c = obj[a].first.compare(obj[b].first); return c < 0 || (c == 0 && a < b); });
     }
     bool is_null() const { return kind == Null; }
     int64_t as_int(int64_t dflt = 0) const { return kind == Int ? i : kind == Double ? (int64_t)d : dflt; }
@@ -80,7 +95,7 @@ struct Parser {
                 if (!parse(v.obj.back().second)) return false;
                 ws();
                 if (p < end && *p == ',') { ++p; continue; }
-                if (p < end && *p == '}') { ++p; return true; }
+                if (p < end && *p == '}') { ++p; v.index_members(); return true; }
                 return fail("expected ',' or '}'");
             }
         }

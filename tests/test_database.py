@@ -445,3 +445,24 @@ def test_pharmcat_tsv(D, pkg, tmp_path):
     r2.insert("MT-RNR1", D.GeneDetails().add_diplotype("961T>del", "961T>del+Cn"), D.SUBALLELE_MATCH)
     r2.insert("G\t1", D.GeneDetails().add_diplotype('a"b', "c"), D.SUBALLELE_MATCH)
     assert r2.pharmcat_tsv() == '#gene\tdiplotype\n"G\t1"\t"a""b/c"\nMT-RNR1\tUnknown\n'
+
+
+def test_duplicate_json_keys_resolve_to_the_last_one(D, tmp_path):
+    """serde fills its maps by insertion: of two members with one name the later one stays.  hla_sequences of a real database has ~40,000 members:
+    they are looked up through a sorted index built when the object is read (sp_json.h), the few members of a small object by a scan -- both
+    resolve a repeated key the same way."""
+    raw = json.load(open(os.path.join(GOLDEN, "variant_dbs", "CACNA1S.json")))
+    good = raw["gene_entries"]["CACNA1S"]
+    n_good = len(good["defined_haplotypes"])
+    damaged = dict(good, defined_haplotypes={})                               # a first copy of the entry without haplotypes: must be replaced by the second
+    text = json.dumps(raw)
+    dup = text.replace('"gene_entries": {', '"gene_entries": {"CACNA1S": ' + json.dumps(damaged) + ', ', 1)
+    assert dup != text
+    # many members in front so that the object is one of the indexed ones (>= 32 members)
+    filler = ", ".join(f'"ZZ{k}": ' + json.dumps(damaged) for k in range(40))
+    big = dup.replace('"gene_entries": {', '"gene_entries": {' + filler + ", ", 1)
+    for name, body in (("small", dup), ("big", big)):
+        path = tmp_path / f"{name}.json"
+        path.write_text(body)
+        gene = D.Database(str(path)).variant_gene("CACNA1S")
+        assert gene.stats.n_haplotypes == n_good > 0, name

@@ -278,6 +278,25 @@ def test_bam_reads_go_to_the_library(D, pkg, tmp_path):
     assert C.string_at(bases.value, int(offs[40])).decode() == "".join(r[6] for r in recs)
 
 
+def test_sv_records_outside_the_region_are_never_looked_at(D, pkg, tmp_path):
+    """load_sv_vcf_variants reads SVTYPE / END of the records its region fetch returns (src/diplotyper.rs:796-815): a record elsewhere on the
+    chromosome that lacks them is no error; one inside the region is"""
+    head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+    rows = ["chr1\t1000\t.\tA\t<DEL>\t.\tPASS\tSVTYPE=DEL;END=5000\tGT\t0/1",
+            "chr1\t900000\t.\tC\tT\t.\tPASS\tDP=30\tGT\t0/1"]                       # a plain SNV far away: no SVTYPE
+    path = tmp_path / "sv.vcf"
+    path.write_text(head + "\n".join(rows) + "\n")
+    v = D.Vcf(str(path))
+    assert v.deletions("chr1", 0, 10000) == [(999, 5000, 1, None)]
+    assert v.deletions("chr1", 6000, 10000) == []
+    with pytest.raises(pkg.StarphaseError, match="No INFO:SVTYPE"):
+        v.deletions("chr1", 899990, 900010)
+    rows[1] = "chr1\t2000\t.\tC\t<DEL>\t.\tPASS\tSVTYPE=DEL\tGT\t0/1"                # inside, a deletion without END
+    path.write_text(head + "\n".join(rows) + "\n")
+    with pytest.raises(pkg.StarphaseError, match="No INFO:END"):
+        D.Vcf(str(path)).deletions("chr1", 0, 10000)
+
+
 def test_bam_many_blocks_inflate_side_by_side(D, pkg, tmp_path):
     """a region of several hundred BGZF blocks: the reader inflates them in batches on a few threads (sp_io.hip, Bgzf::load); the records
     and the SEQ fields as stored (sp_bam_last_seq4: the input of sp_seqset_upload_format(SP_SEQ_BAM4)) equal the Python filter's"""
