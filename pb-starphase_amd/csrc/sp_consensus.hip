@@ -29,6 +29,7 @@
 #include "sp_internal.h"
 #include "sp_wfa.hip.h"
 #include <algorithm>
+#include <cstddef>
 #include <cstring>
 #include <map>
 #include <string>
@@ -73,19 +74,24 @@ struct CWork {                  // what the next step launch does for this probl
     uint8_t spec[2][CW];
 };
 struct CNode {
+    // the head (128 bytes): every node's head travels between memory and LDS in every control step
     int32_t used, id, complete;
     int32_t T, cur;             // column of the state in slot `cur`
     int32_t dual, split_at, stopped[2], len[2];
     int32_t n, a, q;            // the tape: n bases were pushed from T, the first a are verified, q are consumed
     int32_t have_out, la_valid; // the other slot holds the state at T + n; lookahead votes exist for that state / the state at T
     long long cost0;            // cost of the state at T
-    int32_t dc[CW + 1];         // cost after j pushes from T, minus cost0 (dc[0] = 0)
-    __device__ __forceinline__ long long cost_at(int j) const { return cost0 + (long long)dc[j]; }
     long long rest;             // what the unfinished reads add to the final cost (no early termination), for the state at T
     long long rest_out;         // the same for the state at T + n
     uint32_t ev[2][5];          // the complete votes at column T + a
+    // the tape (1.5 KB at 256-column windows): only the part a node with a tape uses travels (a branching search holds twenty nodes that have none)
+    int32_t dc[CW + 1];         // cost after j pushes from T, minus cost0 (dc[0] = 0)
     uint8_t spec[2][CW];
+    int32_t pad_[3];
+    __device__ __forceinline__ long long cost_at(int j) const { return cost0 + (long long)dc[j]; }
 };
+constexpr int NODE_HEAD_WORDS = 32, NODE_WORDS = (int)(sizeof(CNode) / 4), NODE_TAPE_WORDS = NODE_WORDS - NODE_HEAD_WORDS;
+static_assert(offsetof(CNode, dc) == 4 * NODE_HEAD_WORDS && sizeof(CNode) % 16 == 0, "CNode layout");
 struct CSearch {
     int32_t threshold, farthest, next_id, best_node, inflight, max_queue, per_size, wo_constraint;
     int32_t windows, cut_windows, expansions, pad;
@@ -820,13 +826,19 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     if (P.work->done) return;
     const long long tk0 = wall_clock64();
     // only the nodes in use travel between memory and LDS (a node is 1.7 KB at 256-column windows; a linear search holds one or two)
-    __shared__ int was_used[NQ];
-    if (tid < NQ) { const int u = P.nodes[tid].used; was_used[tid] = u; if (!u) { nh[tid].used = 0; nh[tid].complete = 0; } }
+    for (int x = tid; x < NQ * NODE_HEAD_WORDS; x += blockDim.x)
+        ((uint32_t*)&nh[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS] = ((const uint32_t*)&P.nodes[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS];
     __syncthreads();
-    constexpr int NODE_WORDS = (int)(sizeof(CNode) / 4);
-    for (int k = 0; k < NQ; ++k) {
-        if (!was_used[k]) continue;
-        for (int x = tid; x < NODE_WORDS; x += blockDim.x) ((uint32_t*)&nh[k])[x] = ((const uint32_t*)&P.nodes[k])[x];
+    // the tapes of the nodes that have one: dc[0 .. n] and spec[i][0 .. n) (one flat loop: every load is in flight at once)
+    auto tape_word_used = [](const CNode& x, int w) {                       // word w of the tape area
+        if (!x.used || x.n <= 0) return false;
+        if (w < CW + 1) return w <= x.n;
+        const int sw = w - (CW + 1);                                        // spec words: [i][CW / 4]
+        return sw < 2 * (CW / 4) && (sw % (CW / 4)) * 4 < x.n;
+    };
+    for (int x = tid; x < NQ * NODE_TAPE_WORDS; x += blockDim.x) {
+        const int k = x / NODE_TAPE_WORDS, w = x % NODE_TAPE_WORDS;
+        if (tape_word_used(nh[k], w)) ((uint32_t*)&nh[k])[NODE_HEAD_WORDS + w] = ((const uint32_t*)&P.nodes[k])[NODE_HEAD_WORDS + w];
     }
     for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)&wk)[x] = ((const uint32_t*)P.work)[x];
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)&ss)[x] = ((const uint32_t*)P.srch)[x];
@@ -1142,9 +1154,11 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     }
     if (tid == 0) { const long long tk4 = wall_clock64(); ss.ticks[0] += tk1 - tk0; ss.ticks[1] += tk2 - tk1; ss.ticks[2] += tk3 - tk2; ss.ticks[3] += tk4 - tk3; }
     __syncthreads();
-    for (int k = 0; k < NQ; ++k) {
-        if (!was_used[k] && !nh[k].used) continue;
-        for (int x = tid; x < NODE_WORDS; x += blockDim.x) ((uint32_t*)&P.nodes[k])[x] = ((const uint32_t*)&nh[k])[x];
+    for (int x = tid; x < NQ * NODE_HEAD_WORDS; x += blockDim.x)
+        ((uint32_t*)&P.nodes[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS] = ((const uint32_t*)&nh[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS];
+    for (int x = tid; x < NQ * NODE_TAPE_WORDS; x += blockDim.x) {
+        const int k = x / NODE_TAPE_WORDS, w = x % NODE_TAPE_WORDS;
+        if (tape_word_used(nh[k], w)) ((uint32_t*)&P.nodes[k])[NODE_HEAD_WORDS + w] = ((const uint32_t*)&nh[k])[NODE_HEAD_WORDS + w];
     }
     for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)P.work)[x] = ((const uint32_t*)&wk)[x];
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)P.srch)[x] = ((const uint32_t*)&ss)[x];
