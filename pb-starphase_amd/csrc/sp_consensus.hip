@@ -831,7 +831,9 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     __syncthreads();
     // the tapes of the nodes that have one: dc[0 .. n] and spec[i][0 .. n) (one flat loop: every load is in flight at once)
     auto tape_word_used = [](const CNode& x, int w) {                       // word w of the tape area
-        if (!x.used || x.n <= 0) return false;
+        if (!x.used) return false;
+        if (w == 0) return true;                                            // dc[0] (= 0) is read through cost_at(0) whether or not the node has a tape
+        if (x.n <= 0) return false;
         if (w < CW + 1) return w <= x.n;
         const int sw = w - (CW + 1);                                        // spec words: [i][CW / 4]
         return sw < 2 * (CW / 4) && (sw % (CW / 4)) * 4 < x.n;
