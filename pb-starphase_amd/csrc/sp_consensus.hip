@@ -245,6 +245,7 @@ struct ActScratch {             // per wave
     uint8_t rcache[ACT_READ];
     uint32_t cpack[ACT_CONS / 16 + 2];
     uint32_t rpack[ACT_READ / 16 + 2];
+    uint32_t npack[ACT_READ / 16 + 2];
 };
 
 
@@ -268,7 +269,17 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
     Dwfa d;
     auto ca = [&](int pos) { return cacc.at(pos); };
     const int ws = off - window > 0 ? off - window : 0;
-    for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) A.rcache[x] = (uint8_t)read_base(rv, x);
+    // the read's first 640 bases: one packed word (and N word) per lane from memory, the byte per base the search and the slow catch-up read
+    // unpacked out of LDS (a base at a time from memory was ten dependent round trips)
+    {
+        const int rwords0 = ((rv.n < ACT_READ ? rv.n : ACT_READ) + 15) >> 4;
+        for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) { A.rpack[w] = w < rwords0 ? rv.w[w] : 0u; A.npack[w] = (rv.np && w < rwords0) ? rv.np[w] : 0u; }
+        spw::wave_lds_sync();
+        for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) {
+            const uint32_t sh = (uint32_t)(x & 15) << 1;
+            A.rcache[x] = ((A.npack[x >> 4] >> sh) & 1u) ? (uint8_t)4 : (uint8_t)((A.rpack[x >> 4] >> sh) & 3u);
+        }
+    }
     spw::wave_lds_sync();
     auto rbc = [&](int h) { return h < ACT_READ ? (int)A.rcache[h] : read_base(rv, h); };
     d.c0 = find_start(rv.n, rbc, ca, off, window, cmp_len, lane);
@@ -282,9 +293,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < cwinlen) word |= (uint32_t)(ca(ws + x) & 3) << (b << 1); }
             A.cpack[w] = word;
         }
-        const int rwords = ((rv.n < ACT_READ ? rv.n : ACT_READ) + 15) >> 4;
-        for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) A.rpack[w] = w < rwords ? rv.w[w] : 0u;
-        spw::wave_lds_sync();
+        spw::wave_lds_sync();                                  // (rpack holds the read's packed words since the start)
         const int kk = lane - CH, cbase = c0 - ws;
         dwfa_catchup_t(d, rv.n, [&]() {
             for (;;) {
