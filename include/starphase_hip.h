@@ -683,6 +683,11 @@ int32_t sp_hla_is_passing_dual(uint64_t counts1, uint64_t counts2, double min_co
 int32_t sp_hla_is_hemizygous_better(const int64_t* scores1, const int64_t* scores2, const uint8_t* is_consensus1, uint32_t n_reads,
                                     int32_t is_dual, uint64_t dual_max_ed_delta, double normalized_coverage,
                                     double* haploid_cost, double* diploid_cost);
+/* the coverage normalisation of diplotype_hla_batch (src/hla/caller.rs:598-617): reads realigned to the normalising genes (NORMALIZING_HLA_GENES,
+ * src/hla/alleles.rs:49-59: HLA-DRB1) over two haplotypes for each of those genes that has reads; *normalized_coverage = -1 (None) when none has --
+ * the value sp_hla_call_config.normalized_coverage takes for the absent-capable genes (DRB3 / 4 / 5) */
+int32_t sp_hla_normalized_coverage(const sp_hla_realign* realign, uint32_t n_reads, const uint32_t* normalizing_genes, uint32_t n_normalizing,
+                                   double* normalized_coverage);
 /* hpc_pos / hpc_bytes (src/util/homopolymers.rs:18-42) */
 uint64_t sp_hpc_pos(const char* seq, uint64_t len, uint64_t position);
 uint64_t sp_hpc(const char* seq, uint64_t len, char* out);

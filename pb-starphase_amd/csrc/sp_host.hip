@@ -356,4 +356,17 @@ int32_t sp_variant_is_deletion(const sp_sv_definitions* defs, uint64_t start, ui
     return SP_OK;
 }
 
+
+int32_t sp_hla_normalized_coverage(const sp_hla_realign* realign, uint32_t n_reads, const uint32_t* normalizing_genes, uint32_t n_normalizing,
+                                   double* normalized_coverage) {
+    if ((n_reads && !realign) || (n_normalizing && !normalizing_genes) || !normalized_coverage) return SP_ERR_INVALID_ARG;
+    uint64_t read_total = 0, hap_total = 0;
+    for (uint32_t k = 0; k < n_normalizing; ++k) {
+        uint64_t in_bucket = 0;                                        // gene_buckets holds the reads realign_record placed in the gene (caller.rs:584)
+        for (uint32_t r = 0; r < n_reads; ++r) if (realign[r].status == 0 && realign[r].gene == (int32_t)normalizing_genes[k]) ++in_bucket;
+        if (in_bucket) { read_total += in_bucket; hap_total += 2; }
+    }
+    *normalized_coverage = hap_total ? (double)read_total / (double)hap_total : -1.0;
+    return SP_OK;
+}
 } // extern "C"

@@ -254,6 +254,7 @@ def lib():
         "sp_variant_is_deletion": (i32, [C.POINTER(sp_sv_definitions), u64, u64, C.POINTER(i32), C.POINTER(i32)]),
         "sp_hla_is_passing_dual": (i32, [u64, u64, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sp_hla_is_hemizygous_better": (i32, [vp, vp, vp, u32, i32, u64, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "sp_hla_normalized_coverage": (i32, [vp, u32, vp, u32, C.POINTER(C.c_double)]),
         "sp_hpc_pos": (u64, [C.c_char_p, u64, u64]),
         "sp_hpc": (u64, [C.c_char_p, u64, C.c_char_p]),
         "sp_cyp_chain_to_hap": (u32, [vp, u32, vp, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i32, C.c_char_p, u32]),

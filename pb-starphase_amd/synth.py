@@ -391,3 +391,95 @@ def chain_pair_problem(n_d6, n_reads, rng):
                 singletons=sorted(cfg["unexpected_singletons"]), read_chain_off=np.array(rco, np.uint32), chain_off=np.array(co, np.uint32),
                 chain_items=np.array(items, np.uint32), read_w_off=np.array(rwo, np.uint32), w_ed=np.array(ed, np.uint64), w_ov=np.array(ov, np.float64),
                 infer=False, normalize_all=True, ignore_limits=False, penalties=(4.0, 2.0, 10.0, 2.0))
+
+
+class SyntheticHlaFixture:
+    """An HLA database of the SHAPE of the reference's current release (data/v2.0.0/pbstarphase_20251106.db_stat.txt: 41,374 alleles over 11 genes,
+    23,152 with DNA; the blob itself is not shipped): class I genes of ~3.5 kb, class II genes of 11-16 kb, a few dozen lineages per gene ~1 % apart,
+    alleles a handful of substitutions away from their lineage (indels only in one intron so that the cDNA stays a coordinate slice), partial DNA
+    alleles, three absent-capable genes (DRB3 / 4 / 5) and the normalising gene DRB1 (src/hla/alleles.rs:18-69).  Same interface as HlaFixture.
+    scale < 1 shrinks the allele counts (tests); the sequences are random, only the shape is real."""
+
+    GENES = [("HLA-A", 3500, True, 8600, 5300), ("HLA-B", 4080, False, 10700, 6800), ("HLA-C", 4300, False, 9600, 6400),
+             ("HLA-DPA1", 9700, False, 800, 350), ("HLA-DPB1", 11500, True, 2600, 900), ("HLA-DQA1", 6500, True, 800, 400),
+             ("HLA-DQB1", 7500, False, 2800, 1100), ("HLA-DRB1", 13500, False, 4300, 1000), ("HLA-DRB3", 13200, False, 600, 350),
+             ("HLA-DRB4", 15500, False, 300, 250), ("HLA-DRB5", 13300, False, 274, 302)]
+    ABSENT_CAPABLE = ("HLA-DRB3", "HLA-DRB4", "HLA-DRB5")
+    NORMALIZING = ("HLA-DRB1",)
+
+    def __init__(self, scale=1.0, seed=0):
+        rng = np.random.default_rng(seed)
+        self.buffer = 100
+        self.genes = [g[0] for g in self.GENES]
+        self.gene_fwd, self.gene_ref, self.exons, self.island = [], [], [], []
+        self.ids, gene_of, self.dna, self.cdna, self.star = [], [], [], [], []
+        self.absent_capable = [g in self.ABSENT_CAPABLE for g in self.genes]
+        flank = 2500
+        comp = bytes.maketrans(b"ACGT", b"TGCA")
+        for gi, (name, length, fwd, n_all, n_dna) in enumerate(self.GENES):
+            n_all, n_dna = max(6, int(n_all * scale)), max(4, int(min(n_dna, n_all) * scale))
+            isl = rng.integers(0, 4, length + 2 * flank).astype(np.uint8)
+            base = isl[flank:flank + length]                                    # hg38-forward gene body
+            # exons: 6 stretches of 150-280 bases in the first 70 % of the gene (hg38 order), the indel-carrying intron behind them
+            cuts = np.sort(rng.choice(np.arange(200, int(0.7 * length), 50), 12, replace=False))
+            exons = [(int(cuts[2 * k]), int(min(cuts[2 * k] + rng.integers(150, 280), cuts[2 * k + 1] - 20))) for k in range(6)]
+            indel_zone = (int(0.75 * length), int(0.9 * length))
+            self.gene_fwd.append(1 if fwd else 0)
+            self.gene_ref.append("".join("ACGT"[c] for c in isl[flank - self.buffer:flank + length + self.buffer]))
+            self.exons.append([(a + self.buffer, b + self.buffer) for a, b in exons])
+            self.island.append({"sequence": "".join("ACGT"[c] for c in isl), "start": 0, "gene_start": flank, "length": length})
+            n_lin = max(3, min(40, n_all // 60))
+            lineages = []
+            for _ in range(n_lin):
+                s = base.copy()
+                pos = rng.choice(length, max(5, length // 100), replace=False)
+                s[pos] = (s[pos] + rng.integers(1, 4, len(pos))) % 4
+                lineages.append(s)
+            with_dna = set(rng.choice(n_all, n_dna, replace=False).tolist())
+            lut = np.frombuffer(b"ACGT", np.uint8)
+            for a in range(n_all):
+                s = lineages[int(rng.integers(0, n_lin))].copy()
+                k = int(rng.integers(0, 9))
+                if k:
+                    pos = rng.choice(length, k, replace=False)
+                    s[pos] = (s[pos] + rng.integers(1, 4, k)) % 4
+                fwd_bytes = lut[s].tobytes()
+                cd = b"".join(fwd_bytes[x:y] for x, y in exons)
+                if rng.random() < 0.1:                                          # a small indel in the designated intron
+                    p = int(rng.integers(*indel_zone))
+                    fwd_bytes = fwd_bytes[:p] + (fwd_bytes[p + 2:] if rng.random() < 0.5 else b"AC" + fwd_bytes[p:])
+                lo, hi = 0, len(fwd_bytes)
+                if rng.random() < 0.2:                                          # a partial allele: the ends are not in the record
+                    lo, hi = int(rng.integers(0, 300)), len(fwd_bytes) - int(rng.integers(0, 300))
+                dna_fwd = fwd_bytes[lo:hi]
+                if not fwd:
+                    dna_gene, cd = dna_fwd.translate(comp)[::-1], cd.translate(comp)[::-1]
+                else:
+                    dna_gene = dna_fwd
+                self.ids.append(f"HLA:SYN{gi:02d}{a:05d}")
+                gene_of.append(gi)
+                self.dna.append(dna_gene.decode() if a in with_dna else "")
+                self.cdna.append(cd.decode())
+                self.star.append(f"{a // 97 + 1:02d}:{a % 97 + 1:02d}")
+        order = sorted(range(len(self.ids)), key=lambda i: self.ids[i])      # (generated in key order already)
+        assert order == list(range(len(self.ids)))
+        self.gene_of = np.array(gene_of, np.uint32)
+
+    def dna_fwd(self, a):
+        s = self.dna[a]
+        return s if self.gene_fwd[self.gene_of[a]] else revcomp(s)
+
+    def make_db(self, pkg, ctx):
+        return pkg.HlaDb(ctx, self.gene_of, self.dna, self.cdna, self.gene_ref, self.gene_fwd, self.exons, self.buffer)
+
+    def full_length_alleles(self, g, frac=0.97):
+        lens = [len(self.dna[a]) for a in range(len(self.ids)) if self.gene_of[a] == g]
+        cut = frac * max(lens)
+        return [a for a in range(len(self.ids)) if self.gene_of[a] == g and len(self.dna[a]) >= cut]
+
+    def haplotype(self, g, a):
+        """the island with the gene body replaced by allele a (hg38 orientation) -> (sequence, allele start)"""
+        I = self.island[g]
+        al = self.dna_fwd(a)
+        s = I["gene_start"]
+        return I["sequence"][:s] + al + I["sequence"][s + I["length"]:], s

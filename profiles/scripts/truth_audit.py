@@ -35,7 +35,10 @@ def body_of(name):
     """gene body of a reported / simulated allele name ("*4.001", "*68", a hybrid's own name)"""
     if name not in _seq:
         if name.startswith("*") and name[1:] in stars:
-            _seq[name] = locus.star_allele(name[1:])
+            try:
+                _seq[name] = locus.star_allele(name[1:])
+            except AssertionError:
+                _seq[name] = None
         else:
             _seq[name] = None
     return _seq[name]
@@ -89,8 +92,13 @@ def gene_body():
     if rng.random() < 0.15:
         h = str(rng.choice(HYBRIDS))
         return locus.hybrid(h), ("*" + translate[h]) if h in translate else h
-    s = str(rng.choice(stars))
-    return locus.star_allele(s), "*" + s
+    for _ in range(100):
+        s = str(rng.choice(stars))
+        try:
+            return locus.star_allele(s), "*" + s
+        except AssertionError:                                # (a few database alleles list overlapping variants the simple generator cannot apply)
+            continue
+    raise RuntimeError("no star allele could be realised")
 
 
 def haplotype():

@@ -1,0 +1,95 @@
+"""The HLA path at the SHAPE of the reference's current database (v2.0.0: 41,374 alleles over 11 genes, 23,152 with DNA, class II alleles of 11-16 kb;
+the blob is not shipped, pb_starphase_amd.synth.SyntheticHlaFixture draws one of that shape): K1 pruned == exhaustive, every read lands in its gene,
+the eleven genes of a WGS-style sample are called with the coverage normalisation and the hemizygous branch of the absent-capable genes
+(src/hla/caller.rs:598-617,677-701, src/hla/alleles.rs:49-69).  VERDICT round 2, item 8."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(pkg, gpu_ctx):
+    from pb_starphase_amd import synth
+    fx = synth.SyntheticHlaFixture(scale=1.0, seed=5)
+    assert len(fx.ids) > 41000 and sum(1 for d in fx.dna if d) > 23000 and max(len(d) for d in fx.dna) > 15000
+    return fx, fx.make_db(pkg, gpu_ctx)
+
+
+def normalized_coverage(pkg, fx, out):
+    genes = np.array([fx.genes.index(g) for g in fx.NORMALIZING], np.uint32)
+    nc = C.c_double(0)
+    o = np.ascontiguousarray(out)
+    assert pkg.ffi.lib().sp_hla_normalized_coverage(o.ctypes.data_as(C.c_void_p), len(o), genes.ctypes.data_as(C.c_void_p), len(genes), C.byref(nc)) == 0
+    return nc.value
+
+
+def sample(fx, rng, per_hap, absent=()):
+    from pb_starphase_amd import synth
+    reads, truth_gene, truth = [], [], {}
+    for g in range(len(fx.genes)):
+        if g in absent:                                                       # both haplotypes lack the gene
+            truth[g] = None
+            continue
+        full = fx.full_length_alleles(g)
+        pick = sorted(rng.choice(full, 2, replace=False).tolist())
+        hemi = fx.absent_capable[g] and rng.random() < 0.5
+        if hemi:
+            pick = pick[:1]
+        truth[g] = pick
+        for a in pick:
+            hap, s = fx.haplotype(g, a)
+            rs = synth.simulate_reads(rng, hap, s, len(fx.dna[a]), per_hap, mean_len=16000, sd_len=2500, min_overlap=min(9000, len(fx.dna[a]) - 200))
+            reads += rs; truth_gene += [g] * len(rs)
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order], [truth_gene[i] for i in order], truth
+
+
+def test_k1_pruned_equals_exhaustive_at_scale(pkg, gpu_ctx, big):
+    fx, db = big
+    rng = np.random.default_rng(31)
+    reads, truth_gene, _truth = sample(fx, rng, 6)
+    assert len(reads) > 100 and max(len(r) for r in reads) > 12000
+    R = gpu_ctx.upload(reads)
+    full, cells = db.realign_reads(R, cells=True)
+    pruned = db.realign_reads(R)
+    assert pruned.tobytes() == full.tobytes()
+    ok = full["status"] == 0
+    assert ok.mean() > 0.97
+    assert all(int(full[r]["gene"]) == truth_gene[r] for r in range(len(reads)) if ok[r])
+    # the winner of the matrix is the winner reported (ties to the lowest database index)
+    valid = cells != 0xFFFFFFFF
+    assert valid.any(axis=1)[ok].all()
+
+
+def test_eleven_genes_with_normalisation_and_absent_genes(pkg, gpu_ctx, big):
+    fx, db = big
+    rng = np.random.default_rng(32)
+    absent = (fx.genes.index("HLA-DRB4"),)
+    reads, _tg, truth = sample(fx, rng, 14, absent=absent)
+    R = gpu_ctx.upload(reads)
+    out = db.realign_reads(R)
+    nc = normalized_coverage(pkg, fx, out)
+    drb1 = fx.genes.index("HLA-DRB1")
+    assert abs(nc - ((out["status"] == 0) & (out["gene"] == drb1)).sum() / 2.0) < 1e-9 and 10 <= nc <= 16
+    genes = list(range(len(fx.genes)))
+    cfgs = [pkg.ffi.hla_call_config(absent_capable=int(fx.absent_capable[g]), normalized_coverage=nc) for g in genes]
+    calls, _is1 = db.diplotype_genes(genes, R, out, cfgs=cfgs)
+    same = lambda a, b: a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+    n_ok = 0
+    for g, (call, _c1, _c2) in enumerate(calls):
+        t = truth[g]
+        if t is None:
+            assert call.status == 1, (fx.genes[g], call.status)                    # no reads: NO_CALL for an absent-capable gene (caller.rs:662-668)
+            n_ok += 1
+        elif len(t) == 1:                                                          # hemizygous: (".", allele) -> allele1 = -2
+            good = call.status == 0 and call.allele1 == -2 and same(call.allele2, t[0])
+            n_ok += good
+            assert good, (fx.genes[g], call.allele1, call.allele2, t)
+        else:
+            good = call.status == 0 and all(same(x, y) for x, y in zip(sorted([call.allele1, call.allele2]), t))
+            n_ok += good
+            assert good, (fx.genes[g], call.allele1, call.allele2, t)
+    assert n_ok == len(genes)
