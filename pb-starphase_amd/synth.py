@@ -439,10 +439,9 @@ class SyntheticHlaFixture:
             lut = np.frombuffer(b"ACGT", np.uint8)
             for a in range(n_all):
                 s = lineages[int(rng.integers(0, n_lin))].copy()
-                k = int(rng.integers(0, 9))
-                if k:
-                    pos = rng.choice(length, k, replace=False)
-                    s[pos] = (s[pos] + rng.integers(1, 4, k)) % 4
+                k = int(rng.integers(1, 9))                                     # (at least one: no two alleles of a lineage are the same sequence)
+                pos = rng.choice(length, k, replace=False)
+                s[pos] = (s[pos] + rng.integers(1, 4, k)) % 4
                 fwd_bytes = lut[s].tobytes()
                 cd = b"".join(fwd_bytes[x:y] for x, y in exons)
                 if rng.random() < 0.1:                                          # a small indel in the designated intron

@@ -21,3 +21,8 @@ for k in ("anchor", "k3_region_cells", "segments", "cons_steps", "align", "align
           "host:cyp_regions", "host:cyp_segments", "host:cyp_consensus", "host:cyp_merge", "host:cyp_typing", "host:cyp_weights", "host:cyp_chains", "host:cyp_chain_pair"):
     ms, n, cells = ctx.profile_get(k)
     print(f"  {k:22s} {ms:8.3f} ms  launches {n:5d}  cells {cells}")
+# where the control kernel's time goes (100 MHz ticks of the slowest problem of every batch, summed) and how the launches split
+for k in ("cons_ticks_reduce", "cons_ticks_result", "cons_ticks_search", "cons_ticks_tail"):
+    print(f"  {k:22s} {ctx.profile_get(k)[2] / 100.0 / 1e3:8.3f} ms")
+for k in ("cons_windows", "cons_cut_windows", "cons_expansions", "cons_columns"):
+    print(f"  {k:22s} {ctx.profile_get(k)[2]}")
