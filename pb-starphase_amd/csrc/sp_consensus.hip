@@ -864,17 +864,23 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         const UsedWords uw(mode_in, n_in, mode_in == M_EXPAND ? wk.n_kids : 0);
         const bool direct = (long long)P.n_blocks * uw.total <= DIRECT_LOADS;
         const int parts = direct ? P.n_blocks : P.n_clusters;
-        for (int c = tid; c < uw.total; c += blockDim.x) {
-            const int o = uw.at(c);
+        // every word is summed over `parts` sources; when the words are few (an expansion: a few dozen) the sources of a word are split over
+        // several threads, each with at most eight loads in flight, and the partial sums meet in LDS
+        int nsl = (int)blockDim.x / (uw.total > 0 ? uw.total : 1); nsl = nsl < 1 ? 1 : (nsl > parts ? parts : nsl);
+        const int per = (parts + nsl - 1) / nsl;
+        for (int c = tid; c < uw.total; c += blockDim.x) acc[uw.at(c)] = 0;
+        __syncthreads();
+        for (int idx = tid; idx < uw.total * nsl; idx += blockDim.x) {
+            const int o = uw.at(idx % uw.total), m_lo = (idx / uw.total) * per, m_hi = m_lo + per < parts ? m_lo + per : parts;
             uint32_t sum = 0;
-            for (int c0 = 0; c0 < parts; c0 += 8) {
+            for (int c0 = m_lo; c0 < m_hi; c0 += 8) {
                 uint32_t v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = c0 + u >= parts ? 0u : direct ? block_word(B, (size_t)P.first_block + c0 + u, o) : B.Q[(size_t)(P.first_cluster + c0 + u) * QE + o];
+                for (int u = 0; u < 8; ++u) v[u] = c0 + u >= m_hi ? 0u : direct ? block_word(B, (size_t)P.first_block + c0 + u, o) : B.Q[(size_t)(P.first_cluster + c0 + u) * QE + o];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) sum += v[u];
             }
-            acc[o] = sum;
+            if (nsl == 1) acc[o] = sum; else if (sum) atomicAdd(&acc[o], sum);
         }
     }
     __syncthreads();
