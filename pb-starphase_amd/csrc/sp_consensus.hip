@@ -45,6 +45,10 @@ constexpr int CH = 32;          // lane of diagonal 0
 #define SP_K8_MIN_WAVES 1
 #endif
 constexpr int CWAVES = SP_K8_WAVES;      // waves per workgroup
+#ifndef SP_K8_DBG_READS
+#define SP_K8_DBG_READS 16384          // SP_K8_TIMING builds: reads per launch the per-read record array holds (4 Mi records in all)
+#endif
+#define SP_K8_DBG_LAUNCHES (4194304 / SP_K8_DBG_READS)
 #ifndef SP_K8_CW
 #define SP_K8_CW 256
 #endif
@@ -108,8 +112,8 @@ struct ConsParams {
     int n, first, first_block, n_blocks, rpw;   // reads; flattened index of local read 0; first workgroup; workgroups; reads per wave
     int first_cluster, n_clusters;              // clusters of CLUSTER consecutive workgroups (the last one may be smaller)
     int min_count, delta, et, allow_dual, window, cmp_len; double min_af;
-    int cap;
-    uint8_t* C;                 // [NQ][2][cap] base codes per node; consensus 2 shares [0, split_at) with consensus 1
+    int cap, cs;                // longest consensus; bytes between the two consensuses of a node (cap rounded up to 16: children copy their parent 16 bytes at a time)
+    uint8_t* C;                 // [NQ][2][cs] base codes per node; consensus 2 shares [0, split_at) with consensus 1
     CWork* work; CSearch* srch; CNode* nodes;
     uint32_t* la;               // [NQ][2][CW][4] lookahead votes per node
     uint8_t* processed;         // [cap + 2] nodes expanded per length
@@ -365,7 +369,7 @@ template <class BT> __device__ __forceinline__ uint32_t block_word(const BT& B, 
     if (o < QSV + QSL + EC) return B.PC[blk * EC + (o - QSV - QSL)];
     return B.PR[blk * EC + (o - QSV - QSL - EC)];
 }
-constexpr int DIRECT_LOADS = 24576;     // workgroups x words below which the control kernel sums the workgroups' words itself (the reduce launch returns at once)
+constexpr int DIRECT_BLOCKS = 16;       // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
 
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B) {
     int pi = 0;
@@ -411,7 +415,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
     const int dual_in = Wp->dual, split_at = Wp->split_at;
     const int go0 = Wp->go[0], go1 = Wp->go[1];
     const int n_kids = mode == M_EXPAND ? Wp->n_kids : 0;
-    const uint8_t* Cn = P.C + (size_t)node * 2 * P.cap;
+    const uint8_t* Cn = P.C + (size_t)node * 2 * P.cs;
     for (int x = threadIdx.x; x < 2 * (CW + 1); x += blockDim.x) { (&lv[0][0])[x] = 0; (&le[0][0])[x] = 0; }
     for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) (&ll[0][0])[x] = 0;
     for (int x = threadIdx.x; x < CW + 1; x += blockDim.x) { lc[x] = 0; lr[x] = 0; }
@@ -421,7 +425,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
         const int i = x / (CWIN + CW), y = x % (CWIN + CW), pos = w0 + y;
         uint8_t v = 0;
         if (pos >= T) v = (pos - T < n) ? Wp->spec[i][pos - T] : 0;
-        else if (pos >= 0) v = (i == 1 && dual_in && pos >= split_at) ? Cn[(size_t)P.cap + pos] : Cn[pos];
+        else if (pos >= 0) v = (i == 1 && dual_in && pos >= split_at) ? Cn[(size_t)P.cs + pos] : Cn[pos];
         cwin[i][y] = v;
     }
     __syncthreads();
@@ -573,7 +577,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             h_store(B.H, p * CB + lane, a.H);
         };
         ConsAccess ca0, ca1;
-        ca0.win = &cwin[0][0]; ca0.w0 = w0; ca0.C = Cn; ca0.cap = P.cap; ca0.split_at = split_at; ca0.i = 0; ca0.ov_pos = -1; ca0.ov_base = 0;
+        ca0.win = &cwin[0][0]; ca0.w0 = w0; ca0.C = Cn; ca0.cap = P.cs; ca0.split_at = split_at; ca0.i = 0; ca0.ov_pos = -1; ca0.ov_base = 0;
         ca1 = ca0; ca1.win = &cwin[1][0]; ca1.i = 1;
 
         if (mode == M_EXPAND) {
@@ -730,14 +734,20 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
         if (dualrun) store(d1, node, out_slot, 1);
         spw::wave_lds_sync();
 #ifdef SP_K8_TIMING
-        if (B.dbg && lane == 0 && Wp->pad < 256 && g < 16384) {
+        if (B.dbg && lane == 0 && Wp->pad < SP_K8_DBG_LAUNCHES && g < SP_K8_DBG_READS) {
             const unsigned long long dt = (unsigned long long)(wall_clock64() - wt0);
-            const bool placed = ri.off > T && ri.off <= T + n;
-            // [launch][read]: ticks | slow columns << 32 | multi-tip events << 40 | placed << 48 | window bases << 52
-            // ticks | slow columns << 32 | buckets (fast-path tries, column pushes, votes; clock64 / 256, 8 bits each) << 40
-            auto b8 = [](long long c) { const long long v = c >> 8; return (unsigned long long)(v > 255 ? 255 : v); };
-            B.dbg[(size_t)Wp->pad * 16384 + g] = (dt & 0xFFFFFFFFull) | ((unsigned long long)(slow_cols & 255) << 32) | (b8(tb_fast) << 40) | (b8(tb_col) << 48) | (b8(tb_vote) << 56);
-            (void)placed; (void)multi_tip;
+            const unsigned long long placed = ri.off > T && ri.off <= T + n;
+            // [launch][read]: ticks (24 bits, 100 MHz) | slow columns (9) | multi-tip events (9) | a late read was placed (1) | mode (2) | window bases (9) | column pushes, clock64 / 1024 (10)
+            auto cl = [](long long v, long long cap) { return (unsigned long long)(v > cap ? cap : v); };
+#ifdef SP_K8_DBG_EDITS
+            // (variant: the edit counts of the two states instead of the multi-tip events and the column-push clocks)
+            B.dbg[(size_t)Wp->pad * SP_K8_DBG_READS + g] = cl((long long)dt, 0xFFFFFF) | (cl(slow_cols, 511) << 24) | (cl(d0.e, 511) << 33) | (placed << 42) | ((unsigned long long)mode << 43) |
+                                                            (cl(n, 511) << 45) | (cl((d1.flags & F_ACTIVE) ? d1.e : 1023, 1023) << 54);
+#else
+            B.dbg[(size_t)Wp->pad * SP_K8_DBG_READS + g] = cl((long long)dt, 0xFFFFFF) | (cl(slow_cols, 511) << 24) | (cl(multi_tip, 511) << 33) | (placed << 42) | ((unsigned long long)mode << 43) |
+                                                            (cl(n, 511) << 45) | (cl(tb_col >> 10, 1023) << 54);
+#endif
+            (void)tb_fast; (void)tb_vote;
         }
 #endif
     }
@@ -770,7 +780,7 @@ __global__ void __launch_bounds__(512) cons_reduce_kernel(ConsBatchT<MAXP> B) {
     const int mode = P.work->mode;
     if (P.work->done || mode == M_NONE) return;
     const UsedWords uw(mode, mode == M_WINDOW ? P.work->n : 0, mode == M_EXPAND ? P.work->n_kids : 0);
-    if ((long long)P.n_blocks * uw.total <= DIRECT_LOADS) return;            // the control kernel sums these few words itself
+    if (P.n_blocks <= DIRECT_BLOCKS) return;                                 // the control kernel sums the words of so few workgroups itself
     const int cl = cluster - P.first_cluster;
     const int members = P.n_blocks - cl * CLUSTER < CLUSTER ? P.n_blocks - cl * CLUSTER : CLUSTER;
     const size_t blk0 = (size_t)P.first_block + (size_t)cl * CLUSTER;
@@ -832,12 +842,20 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     const int pi = blockIdx.x;
     const ConsParams P = B.p[pi];
     const int tid = threadIdx.x;
-    if (P.work->done) return;
     const long long tk0 = wall_clock64();
-    // only the nodes in use travel between memory and LDS (a node is 1.7 KB at 256-column windows; a linear search holds one or two)
+    // first round of loads, all independent: the heads of the nodes, the work order, the search state, the per-length counters
+    // (only the nodes in use travel whole between memory and LDS: a node is 1.7 KB at 256-column windows; a linear search holds one or two)
     for (int x = tid; x < NQ * NODE_HEAD_WORDS; x += blockDim.x)
         ((uint32_t*)&nh[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS] = ((const uint32_t*)&P.nodes[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS];
+    for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)&wk)[x] = ((const uint32_t*)P.work)[x];
+    for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)&ss)[x] = ((const uint32_t*)P.srch)[x];
+    const int proc_words = (P.cap + 2 + 3) / 4;
+    for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)proc)[x] = ((const uint32_t*)P.processed)[x];
+    for (int x = tid; x < QE; x += blockDim.x) acc[x] = 0;
+    if (tid == 0) { copy_from = -1; copy_len = 0; need_la = -1; }
     __syncthreads();
+    if (wk.done) return;
+    // second round: the tapes of the nodes that have one and the vote words of the step
     // the tapes of the nodes that have one: dc[0 .. n] and spec[i][0 .. n) (one flat loop: every load is in flight at once)
     auto tape_word_used = [](const CNode& x, int w) {                       // word w of the tape area
         if (!x.used) return false;
@@ -851,36 +869,68 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         const int k = x / NODE_TAPE_WORDS, w = x % NODE_TAPE_WORDS;
         if (tape_word_used(nh[k], w)) ((uint32_t*)&nh[k])[NODE_HEAD_WORDS + w] = ((const uint32_t*)&P.nodes[k])[NODE_HEAD_WORDS + w];
     }
-    for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)&wk)[x] = ((const uint32_t*)P.work)[x];
-    for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)&ss)[x] = ((const uint32_t*)P.srch)[x];
-    const int proc_words = (P.cap + 2 + 3) / 4;
-    for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)proc)[x] = ((const uint32_t*)P.processed)[x];
-    if (tid == 0) { copy_from = -1; copy_len = 0; need_la = -1; }
-    __syncthreads();
     const int mode_in = wk.mode, n_in = wk.mode == M_WINDOW ? wk.n : 0;
-    // the words of the step that are in use: the cluster sums (a few per problem), or -- when they are few -- the workgroups' own words; eight
-    // loads in flight per thread
+    // the words of the step that are in use: the cluster sums (a few per problem) or, for a problem of at most DIRECT_BLOCKS workgroups, the
+    // workgroups' own words (no reduce launch at all for a batch of such problems); eight loads in flight per thread
     if (mode_in != M_NONE) {
         const UsedWords uw(mode_in, n_in, mode_in == M_EXPAND ? wk.n_kids : 0);
-        const bool direct = (long long)P.n_blocks * uw.total <= DIRECT_LOADS;
-        const int parts = direct ? P.n_blocks : P.n_clusters;
-        // every word is summed over `parts` sources; when the words are few (an expansion: a few dozen) the sources of a word are split over
-        // several threads, each with at most eight loads in flight, and the partial sums meet in LDS
-        int nsl = (int)blockDim.x / (uw.total > 0 ? uw.total : 1); nsl = nsl < 1 ? 1 : (nsl > parts ? parts : nsl);
-        const int per = (parts + nsl - 1) / nsl;
-        for (int c = tid; c < uw.total; c += blockDim.x) acc[uw.at(c)] = 0;
-        __syncthreads();
-        for (int idx = tid; idx < uw.total * nsl; idx += blockDim.x) {
-            const int o = uw.at(idx % uw.total), m_lo = (idx / uw.total) * per, m_hi = m_lo + per < parts ? m_lo + per : parts;
-            uint32_t sum = 0;
-            for (int c0 = m_lo; c0 < m_hi; c0 += 8) {
-                uint32_t v[8];
+        if (P.n_blocks <= DIRECT_BLOCKS) {
+            // the workgroups' words as they lie in memory: the exact and the lookahead votes are four 16-bit fields per 64-bit word (a field of one
+            // workgroup is at most 12 x 8 reads, so the words of sixteen workgroups add up without a carry between fields)
+            const int u = uw.used, ev = 2 * u, el = uw.has_la ? 2 * CW : 0, E = ev + ev + el + u + u;
+            const int parts = P.n_blocks;
+            int nsl = (int)blockDim.x / (E > 0 ? E : 1); nsl = nsl < 1 ? 1 : (nsl > parts ? parts : nsl);
+            const int per = (parts + nsl - 1) / nsl;
+            constexpr int EV = 2 * (CW + 1), EL = 2 * CW, EC = CW + 1;
+            for (int idx = tid; idx < E * nsl; idx += blockDim.x) {
+                const int c = idx % E, m_lo = (idx / E) * per, m_hi = m_lo + per < parts ? m_lo + per : parts;
+                const size_t b0 = (size_t)P.first_block;
+                if (c < ev || (c >= 2 * ev && c < 2 * ev + el)) {                              // 64-bit words of four fields
+                    const bool exact = c < ev;
+                    const int e = exact ? (c / u) * (CW + 1) + c % u : c - 2 * ev;
+                    const unsigned long long* src = exact ? B.PV + e : B.PL + e;
+                    const size_t stride = exact ? EV : EL;
+                    unsigned long long sum = 0;
+                    for (int c0 = m_lo; c0 < m_hi; c0 += 8) {
+                        unsigned long long v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = c0 + u >= m_hi ? 0u : direct ? block_word(B, (size_t)P.first_block + c0 + u, o) : B.Q[(size_t)(P.first_cluster + c0 + u) * QE + o];
+                        for (int q = 0; q < 8; ++q) v[q] = c0 + q < m_hi ? src[(b0 + c0 + q) * stride] : 0ull;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sum += v[u];
+                        for (int q = 0; q < 8; ++q) sum += v[q];
+                    }
+                    uint32_t* dst = exact ? acc + e * 5 : acc + QSV + e * 4;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) { const uint32_t x = (uint32_t)((sum >> (16 * f)) & 0xFFFFull); if (x) { if (nsl == 1) dst[f] = x; else atomicAdd(&dst[f], x); } }
+                } else {
+                    const uint32_t* src; size_t stride; uint32_t* dst;
+                    if (c < 2 * ev) { const int cc = c - ev, e = (cc / u) * (CW + 1) + cc % u; src = B.PE + e; stride = EV; dst = acc + e * 5 + 4; }
+                    else if (c < 2 * ev + el + u) { const int e = c - 2 * ev - el; src = B.PC + e; stride = EC; dst = acc + QSV + QSL + e; }
+                    else { const int e = c - 2 * ev - el - u; src = B.PR + e; stride = EC; dst = acc + QSV + QSL + (CW + 1) + e; }
+                    uint32_t sum = 0;
+                    for (int c0 = m_lo; c0 < m_hi; c0 += 8) {
+                        uint32_t v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = c0 + q < m_hi ? src[(b0 + c0 + q) * stride] : 0u;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) sum += v[q];
+                    }
+                    if (sum) { if (nsl == 1) *dst = sum; else atomicAdd(dst, sum); }
+                }
             }
-            if (nsl == 1) acc[o] = sum; else if (sum) atomicAdd(&acc[o], sum);
+        } else {
+            const int parts = P.n_clusters;
+            for (int c = tid; c < uw.total; c += blockDim.x) {
+                const int o = uw.at(c);
+                uint32_t sum = 0;
+                for (int c0 = 0; c0 < parts; c0 += 8) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = c0 + q < parts ? B.Q[(size_t)(P.first_cluster + c0 + q) * QE + o] : 0u;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sum += v[q];
+                }
+                acc[o] = sum;
+            }
         }
     }
     __syncthreads();
@@ -893,8 +943,10 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         auto cands = [&](const uint32_t* w5, int col, int out[4]) { return col_candidates(w5, col, P.cap, P.et, P.min_count, P.min_af, out); };
         auto node_free = [&](int k) { nh[k].used = 0; nh[k].complete = 0; };
         uint8_t* Cb = P.C;
+        int la_fresh = -1;                                // the node whose lookahead votes are the sums of this very step (still in LDS)
         // ---------------------------------------------------------------- 1. the result of the last step
         if (mode_in == M_INIT) {
+            la_fresh = wk.node;
             CNode& x = nh[wk.node];
             if (lane == 0) {
                 x.used = 1; x.id = ss.next_id++; x.complete = 0; x.T = 0; x.cur = wk.in_slot; x.dual = 0; x.split_at = -1;
@@ -927,7 +979,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             }
             for (int col = lane; col < a; col += SP_WAVE) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wk.go[i]) Cb[((size_t)wk.node * 2 + i) * P.cap + T + col] = wk.spec[i][col];
+                for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wk.go[i]) Cb[((size_t)wk.node * 2 + i) * P.cs + T + col] = wk.spec[i][col];
             }
             // a replay re-reads columns whose costs are on the tape already: it only brings the state (and the votes) of column T + a
             if (!wk.replay) {
@@ -949,7 +1001,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                 x.have_out = (a == n) ? 1 : 0;
                 if (a == n) x.rest_out = sr[n];
             }
-            if (a == n) for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
+            if (a == n) { la_fresh = wk.node; for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y]; }
         } else if (mode_in == M_EXPAND) {
             const int L = wk.T;
             if (lane < wk.n_kids) {                                         // one lane per child
@@ -976,24 +1028,25 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                 ss.next_id += wk.n_kids;
                 node_free(wk.node);
                 ss.expansions += 1;
-                // more than max_queue_size nodes wait: the one the search would take last goes
-                for (;;) {
-                    int waiting = 0, wi = -1;
-                    for (int k = 0; k < NQ; ++k) {
-                        if (!nh[k].used || nh[k].complete) continue;
-                        ++waiting;
-                        if (wi < 0) { wi = k; continue; }
-                        const CNode& pp = nh[k]; const CNode& bb = nh[wi];
-                        const long long pcst = pp.cost_at(pp.q), bcst = bb.cost_at(bb.q); const int pt = pp.T + pp.q, bt = bb.T + bb.q;
-                        if (pcst > bcst || (pcst == bcst && (pt < bt || (pt == bt && pp.id > bb.id)))) wi = k;
-                    }
-                    if (waiting <= ss.max_queue) break;
-                    node_free(wi);
+            }
+            spw::wave_lds_sync();
+            // more than max_queue_size nodes wait: the one the search would take last goes (lane k looks at node k)
+            for (;;) {
+                const bool waits = lane < NQ && nh[lane].used && !nh[lane].complete;
+                const int waiting = __builtin_popcountll(__ballot(waits));
+                if (waiting <= ss.max_queue) break;
+                long long wc = 0; int wt = 0, wid = 0, wx = -1;
+                if (waits) { const CNode& pp = nh[lane]; wc = pp.cost_at(pp.q); wt = pp.T + pp.q; wid = pp.id; wx = lane; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const long long oc = __shfl_xor(wc, o); const int ot = __shfl_xor(wt, o), oi = __shfl_xor(wid, o), ox = __shfl_xor(wx, o);
+                    if (ox >= 0 && (wx < 0 || oc > wc || (oc == wc && (ot < wt || (ot == wt && oi > wid))))) { wc = oc; wt = ot; wid = oi; wx = ox; }
                 }
+                if (lane == 0) node_free(wx);
+                spw::wave_lds_sync();
             }
         }
-        __threadfence();                                  // (the lookahead words written above are read below by other lanes)
-        spw::wave_lds_sync();
+        spw::wave_lds_sync();                             // (the lookahead words written above are read below out of LDS, not back from memory)
         // ---------------------------------------------------------------- 2. the search, played forward over the tapes
         tk2 = wall_clock64();
         if (lane == 0) { wk.mode = M_NONE; wk.n = 0; wk.replay = 0; wk.n_kids = 0; wk.pad += 1; }
@@ -1049,7 +1102,8 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             } else if (lane == 0) ss.inflight = -1;
             spw::wave_lds_sync();
             // the node stands at the end of its tape and its pop is accounted for: the decision of that column
-            int stop = 0;
+            int stop = 0, replay_of = -1;
+            unsigned long long free_nodes = __ballot(lane < NQ && !nh[lane].used);
             if (lane == 0) {
                 CNode& x = nh[xi];
                 do {
@@ -1062,7 +1116,8 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                             // cut window: push the verified bases again from the kept state (nothing is speculated)
                             wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = x.a; wk.replay = 1;
                             wk.dual = x.dual; wk.split_at = x.split_at;
-                            for (int i = 0; i < 2; ++i) { wk.go[i] = (i == 0 || x.dual) && !x.stopped[i]; for (int j = 0; j < x.a; ++j) wk.spec[i][j] = x.spec[i][j]; }
+                            for (int i = 0; i < 2; ++i) wk.go[i] = (i == 0 || x.dual) && !x.stopped[i];
+                            replay_of = xi;                                             // (the bases are copied below, a lane each)
                             ss.inflight = xi;
                             stop = 1; break;
                         }
@@ -1105,9 +1160,9 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                     wk.go[0] = nc[0] > 0; wk.go[1] = nc[1] > 0;
                     int made = 0;
                     for (int k = 0; k < nk && made < MAXKIDS; ++k) {
-                        int kn = -1;
-                        for (int z = 0; z < NQ; ++z) if (!nh[z].used) { nh[z].used = 1; nh[z].complete = 0; kn = z; break; }
-                        if (kn < 0) break;                                              // (the table holds the queue plus one expansion: not reached)
+                        if (!free_nodes) break;                                         // (the table holds the queue plus one expansion: not reached)
+                        const int kn = __builtin_ctzll(free_nodes); free_nodes &= free_nodes - 1;
+                        nh[kn].used = 1; nh[kn].complete = 0;
                         wk.kid_node[made] = kn; wk.kid_base[made][0] = (int8_t)kb[k][0]; wk.kid_base[made][1] = (int8_t)kb[k][1]; wk.kid_split[made] = (int8_t)ks[k];
                         ++made;
                     }
@@ -1116,8 +1171,12 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                     stop = 1;
                 } while (0);
             }
-            stop = __builtin_amdgcn_readfirstlane(stop);
+            stop = __builtin_amdgcn_readfirstlane(stop); replay_of = __builtin_amdgcn_readfirstlane(replay_of);
             spw::wave_lds_sync();
+            if (replay_of >= 0) {
+                const CNode& x = nh[replay_of];
+                for (int jq = lane; jq < x.a; jq += SP_WAVE) { wk.spec[0][jq] = x.spec[0][jq]; wk.spec[1][jq] = x.spec[1][jq]; }
+            }
             if (stop) break;
         }
         // the speculated part of a new window: lane j takes the heaviest lookahead vote for push j of every consensus that grows; the
@@ -1125,7 +1184,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         spw::wave_lds_sync();
         tk3 = wall_clock64();
         if (need_la >= 0) {
-            const uint32_t* la = P.la + (size_t)need_la * 2 * CW * 4;
+            const uint32_t* la = need_la == la_fresh ? &sl[0][0][0] : P.la + (size_t)need_la * 2 * CW * 4;
             int nn = CW;
             for (int base = 0; base < CW; base += SP_WAVE) {
                 const int col = base + lane;
@@ -1162,10 +1221,15 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             const bool split = wk.kid_split[k] != 0;
             for (int i = 0; i < 2; ++i) {
                 if (i == 1 && !(wk.dual || split)) continue;
-                const uint8_t* src = P.C + ((size_t)copy_from * 2 + ((i == 1 && split) ? 0 : i)) * P.cap;
-                uint8_t* dst = P.C + ((size_t)kn * 2 + i) * P.cap;
-                for (int y = tid; y < copy_len; y += blockDim.x) dst[y] = src[y];
-                if (tid == 0 && wk.kid_base[k][i] >= 0) dst[copy_len] = (uint8_t)wk.kid_base[k][i];
+                const uint4* src = reinterpret_cast<const uint4*>(P.C + ((size_t)copy_from * 2 + ((i == 1 && split) ? 0 : i)) * P.cs);
+                uint8_t* dst = P.C + ((size_t)kn * 2 + i) * P.cs;
+                const int whole = copy_len >> 4, tail = copy_len & 15;                  // (the rows are 16-byte aligned)
+                for (int y = tid; y < whole + (tail ? 1 : 0); y += blockDim.x) {
+                    uint4 v = src[y];
+                    if (y == whole && wk.kid_base[k][i] >= 0) reinterpret_cast<uint8_t*>(&v)[tail] = (uint8_t)wk.kid_base[k][i];   // the child's own base lies in the last word
+                    reinterpret_cast<uint4*>(dst)[y] = v;
+                }
+                if (tid == 0 && tail == 0 && wk.kid_base[k][i] >= 0) dst[copy_len] = (uint8_t)wk.kid_base[k][i];
             }
         }
     }
@@ -1215,8 +1279,8 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
             *P.out_res = r;
         }
         if (best >= 0) {
-            const uint8_t* src = P.C + (size_t)best * 2 * P.cap;
-            for (int x = threadIdx.x; x < 2 * P.cap; x += blockDim.x) P.out_cons[x] = src[x];
+            const uint8_t* src = P.C + (size_t)best * 2 * P.cs;
+            for (int x = threadIdx.x; x < 2 * P.cap; x += blockDim.x) P.out_cons[x] = src[(size_t)(x / P.cap) * P.cs + x % P.cap];
         }
     }
     for (int rr = 0; rr < P.rpw; ++rr) {
@@ -1273,6 +1337,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         const uint32_t n = q.read_idx ? q.n : q.reads->n;
         ConsParams& P = hp[p];
         P.n = (int)n; P.cap = (int)outs[p].cap - 1;                                   // one byte of the caller's buffer is the NUL
+        P.cs = (std::max(P.cap, 1) + 1 + 15) & ~15;
         P.first = (int)total; P.first_block = n_blocks;
         P.min_count = q.cfg.min_count; P.delta = q.cfg.dual_max_ed_delta; P.et = q.cfg.allow_early_termination != 0; P.allow_dual = q.cfg.allow_dual != 0;
         P.window = q.cfg.offset_window; P.cmp_len = q.cfg.offset_compare_length; P.min_af = q.cfg.min_af;
@@ -1288,7 +1353,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         total += (size_t)nb * per_block;
         idx_at[p] = h_idx.size(); if (q.read_idx) h_idx.insert(h_idx.end(), q.read_idx, q.read_idx + n);
         off_at[p] = h_off.size(); if (q.offsets) h_off.insert(h_off.end(), q.offsets, q.offsets + n);
-        c_at[p] = c_bytes; c_bytes += (size_t)NQ * 2 * (size_t)std::max(P.cap, 1);
+        c_at[p] = c_bytes; c_bytes += (size_t)NQ * 2 * (size_t)P.cs;
         proc_at[p] = proc_bytes; proc_bytes += ((size_t)std::max(P.cap, 1) + 2 + 15) & ~(size_t)15;
         max_cap = std::max(max_cap, P.cap);
         // how long the consensus can get: the furthest any read of the problem reaches (its placement offset + its length), within cap
@@ -1336,8 +1401,8 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     B.PR = (uint32_t*)sp_pool(ctx, "cons_pr", sizeof(uint32_t) * (size_t)n_blocks * (CW + 1));
     B.Q = (uint32_t*)sp_pool(ctx, "cons_q", sizeof(uint32_t) * (size_t)n_clusters * QE);
 #ifdef SP_K8_TIMING
-    B.dbg = (unsigned long long*)sp_pool(ctx, "cons_dbg", (size_t)256 * 16384 * 8);
-    (void)hipMemsetAsync(B.dbg, 0, (size_t)256 * 16384 * 8, st);
+    B.dbg = (unsigned long long*)sp_pool(ctx, "cons_dbg", (size_t)SP_K8_DBG_LAUNCHES * SP_K8_DBG_READS * 8);
+    (void)hipMemsetAsync(B.dbg, 0, (size_t)SP_K8_DBG_LAUNCHES * SP_K8_DBG_READS * 8, st);
 #endif
     uint8_t* d_is1 = d_out + out_is1;
     int32_t* d_sc = (int32_t*)(d_out + out_sc);
@@ -1400,11 +1465,13 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         // each, 35 of them per 10,000-read sample.
         const uint64_t limit = (uint64_t)64 * (uint64_t)(max_cap + 2) + 1024;
         const uint32_t ahead = 3;
+        bool need_reduce = false;
+        for (uint32_t p = 0; p < n_prob; ++p) need_reduce = need_reduce || hp[p].n_blocks > DIRECT_BLOCKS;
         volatile uint32_t* prog = h_prog;
         bool finished = false;
         while (!finished) {
             hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
-            hipLaunchKernelGGL(cons_reduce_kernel<MAXP>, dim3((uint32_t)n_clusters * RSLICES), dim3(512), 0, st, B);
+            if (need_reduce) hipLaunchKernelGGL(cons_reduce_kernel<MAXP>, dim3((uint32_t)n_clusters * RSLICES), dim3(512), 0, st, B);
             hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, st, B);
             ++pairs;
             uint64_t spins = 0;
@@ -1439,7 +1506,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     hm.mark("host:k8_result_wait");
 #ifdef SP_K8_TIMING
     if (std::getenv("SP_K8_DUMP")) {
-        std::vector<unsigned long long> h((size_t)256 * 16384);
+        std::vector<unsigned long long> h((size_t)SP_K8_DBG_LAUNCHES * SP_K8_DBG_READS);
         (void)hipMemcpy(h.data(), B.dbg, h.size() * 8, hipMemcpyDeviceToHost);
         FILE* f = std::fopen(std::getenv("SP_K8_DUMP"), "ab");
         if (f) { const unsigned long long tot = total; std::fwrite(&tot, 8, 1, f); std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
@@ -1448,7 +1515,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     {   // launch statistics of the batch (sp_profile_get: cells = count)
         uint64_t cut = 0, ex = 0, pops = 0;
         for (uint32_t p = 0; p < n_prob; ++p) { cut += (uint64_t)h_srch[p].cut_windows; ex += (uint64_t)h_srch[p].expansions; pops += (uint64_t)h_srch[p].pops; }
-        ctx->prof["cons_windows"].cells += pairs; ctx->prof["cons_windows"].launches += 3 * pairs;
+        ctx->prof["cons_windows"].cells += pairs; ctx->prof["cons_windows"].launches += 3 * pairs;           // (two per step for a batch of small problems)
         ctx->prof["cons_cut_windows"].cells += cut; ctx->prof["cons_expansions"].cells += ex; ctx->prof["cons_columns"].cells += pops;
         // where the control kernel's time goes: ticks of the 100 MHz wall clock, the slowest problem of the batch (they run side by side)
         static const char* tick_names[4] = { "cons_ticks_reduce", "cons_ticks_result", "cons_ticks_search", "cons_ticks_tail" };

@@ -1266,8 +1266,8 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
     if (n_samples == 0) return SP_OK;
     // what the first placement would build on the shared template set is built before the streams part
     if (pr->templates) { const int rc0 = sp_seqset_build_index(ctx, const_cast<sp_seqset*>(pr->templates)); if (rc0 != SP_OK) return rc0; }
-    int n_parts = ctx->split_genes ? (int)std::min<uint32_t>(n_samples, (uint32_t)ctx->split_streams) : 1;
-    sp_ctx* on[4] = { ctx, nullptr, nullptr, nullptr };
+    int n_parts = ctx->split_genes ? (int)std::min<uint32_t>(n_samples, (uint32_t)ctx->cyp_cohort_streams) : 1;
+    sp_ctx* on[8] = { ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     for (int x = 1; x < n_parts; ++x) { on[x] = sp_ctx_helper(ctx, x - 1); if (!on[x]) { n_parts = x; break; } }
     std::vector<int32_t> rcs(n_samples, SP_OK); std::vector<int> where(n_samples, 0);
     std::atomic<uint32_t> next(0);
@@ -1281,7 +1281,7 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
             catch (const std::exception& e) { rcs[i] = SP_ERR_INVALID_ARG; on[x]->err = std::string("sp_cyp_diplotype: ") + e.what(); }   // the caller while threads are joinable)
         }
     };
-    std::thread beside[4]; bool started[4] = { false, false, false, false };
+    std::thread beside[8]; bool started[8] = { false, false, false, false, false, false, false, false };
     for (int x = 1; x < n_parts; ++x) {
         try { beside[x] = std::thread(work, x); started[x] = true; }
         catch (const std::system_error&) { }

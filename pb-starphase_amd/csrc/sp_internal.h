@@ -84,7 +84,8 @@ struct sp_ctx {
     bool cons_retry_ladder = true;   // sp_ctx_set_option "cons_retry_ladder": sp_consensus_priority's retry of searches that give up (the drivers pass it on)
     hipStream_t copy_stream = nullptr;   // uploads travel on a stream of their own, beside the kernels of ctx->stream
     sp_seqset* uploading = nullptr;      // the one upload a context has in flight (the staging buffers are the context's)
-    sp_ctx* helper[3] = { nullptr, nullptr, nullptr };   // further contexts on the same device (own stream, pools, events) for work that runs beside this one's; made on first use
+    int cyp_cohort_streams = 6;      // sp_ctx_set_option "cyp_cohort_streams": samples of sp_cyp_diplotype_cohort in flight (1..8; WGS-sized samples are chains of tiny launches)
+    sp_ctx* helper[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // further contexts on the same device (own stream, pools, events) for work that runs beside this one's; made on first use
 };
 
 // cell descriptor consumed by the generic WFA kernel
@@ -109,7 +110,7 @@ int  sp_k2_dict_build(sp_ctx* ctx, const sp_seqset* set, const uint32_t* d_gene_
 void sp_k2_dict_free(K2Dict* d);
 
 // ---------------------------------------------------------------- launchers (sp_device.hip)
-sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i = 0);                           // helper i (0..2); nullptr when it cannot be made
+sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i = 0);                           // helper i (0..6); nullptr when it cannot be made
 void sp_profile_merge(sp_ctx* into, sp_ctx* from);                       // adds the timings `from` collected to `into` and clears them
 int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,

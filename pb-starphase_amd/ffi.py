@@ -302,6 +302,11 @@ def lib():
     return L
 
 
+def _cstr(buf, off, cap):
+    """the NUL-terminated text at buf[off : off + cap] (buf.raw would copy the whole buffer for every string: 67 MB per consensus of a 256-sample cohort call)"""
+    return bytes(memoryview(buf)[off:off + cap]).split(b"\0", 1)[0].decode()
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
@@ -531,7 +536,7 @@ class Context:
         group_of = np.zeros(max(1, n), np.int32)
         buf = C.create_string_buffer(max_groups * nl * cap)
         self.check(lib().sp_consensus_priority(self._h, C.byref(pr), max_groups, cap, C.byref(ng), _ptr(group_of), buf))
-        text = lambda j: buf.raw[j * cap:(j + 1) * cap].split(b"\0", 1)[0].decode()
+        text = lambda j: _cstr(buf, j * cap, cap)
         return group_of[:n].copy(), [[text(g * nl + l) for l in range(nl)] for g in range(ng.value)]
 
     def cyp_variant_states(self, seqs, backbone, var_pos, var_ref, var_alt):
@@ -569,7 +574,7 @@ class Context:
         call = sp_cyp_call()
         buf = C.create_string_buffer(SP_CYP_MAXCONS * cons_cap)
         self.check(lib().sp_cyp_diplotype(self._h, C.byref(pr), reads._h, C.byref(call), buf, cons_cap))
-        cons = [buf.raw[i * cons_cap:(i + 1) * cons_cap].split(b"\0", 1)[0].decode() for i in range(call.n_consensus)]
+        cons = [_cstr(buf, i * cons_cap, cons_cap) for i in range(call.n_consensus)]
         labels = [(int(call.cons_type[i]), (call.cons_subtype[i].value.decode() or None)) for i in range(call.n_consensus)]
         return call, cons, labels
 
@@ -853,7 +858,7 @@ class CypDb:
         call = sp_cyp_call()
         buf = C.create_string_buffer(SP_CYP_MAXCONS * cons_cap)
         self.ctx.check(lib().sp_cyp_diplotype(self.ctx._h, C.byref(pr), reads._h, C.byref(call), buf, cons_cap))
-        cons = [buf.raw[i * cons_cap:(i + 1) * cons_cap].split(b"\0", 1)[0].decode() for i in range(call.n_consensus)]
+        cons = [_cstr(buf, i * cons_cap, cons_cap) for i in range(call.n_consensus)]
         labels = [(int(call.cons_type[i]), (call.cons_subtype[i].value.decode() or None)) for i in range(call.n_consensus)]
         return call, cons, labels
 
@@ -869,7 +874,7 @@ class CypDb:
         out = []
         for i in range(n):
             base = i * SP_CYP_MAXCONS * cons_cap
-            cons = [buf.raw[base + k * cons_cap:base + (k + 1) * cons_cap].split(b"\0", 1)[0].decode() for k in range(calls[i].n_consensus)]
+            cons = [_cstr(buf, base + k * cons_cap, cons_cap) for k in range(calls[i].n_consensus)]
             out.append((calls[i], cons, rcs[i]))
         return out
 
@@ -1095,7 +1100,7 @@ class HlaDb:
         is1 = np.zeros(max(1, reads.n), np.uint8)
         realign = np.ascontiguousarray(realign)
         self.ctx.check(lib().sp_hla_diplotype_genes(self.ctx._h, self._h, k, _ptr(g), reads._h, _ptr(realign), cf, calls, buf, cap, _ptr(is1)))
-        text = lambda j: buf.raw[j * cap:(j + 1) * cap].split(b"\0", 1)[0].decode()
+        text = lambda j: _cstr(buf, j * cap, cap)
         return [(calls[i], text(2 * i), text(2 * i + 1)) for i in range(k)], is1[:reads.n].astype(bool)
 
     def diplotype_cohort(self, n_samples, read_sample, genes, reads, realign, cfgs=None, cap=16384):
@@ -1109,7 +1114,7 @@ class HlaDb:
         is1 = np.zeros(max(1, reads.n), np.uint8)
         realign = np.ascontiguousarray(realign)
         self.ctx.check(lib().sp_hla_diplotype_cohort(self.ctx._h, self._h, n_samples, _ptr(rs), k, _ptr(g), reads._h, _ptr(realign), cf, calls, buf, cap, _ptr(is1)))
-        text = lambda j: buf.raw[j * cap:(j + 1) * cap].split(b"\0", 1)[0].decode()
+        text = lambda j: _cstr(buf, j * cap, cap)
         return [[(calls[s * k + i], text(2 * (s * k + i)), text(2 * (s * k + i) + 1)) for i in range(k)] for s in range(n_samples)], is1[:reads.n].astype(bool)
 
     def type_consensus(self, gene, consensus_fwd, require_dna=False, disable_cdna=False, stats=True):

@@ -1,4 +1,4 @@
-"""longer hunt for K8 != oracle: prints the first differing random problem in full (run on the GPU box)"""
+"""longer hunt for K8 != oracle: prints the first differing random problem in full (run on the GPU box).  Seeds >= 1000: low-complexity haplotypes and noisier reads."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -18,13 +18,25 @@ for seed in seeds:
     for it in range(25):
         L = int(rng.integers(150, 700))
         h1 = "".join(rng.choice(list("ACGT"), L))
+        perr = 0.004
+        if seed >= 1000:
+            # low-complexity haplotypes (homopolymers, tandem repeats) and noisier reads: wavefronts keep several tips for many columns
+            parts, tot = [], 0
+            while tot < L:
+                if rng.random() < 0.5:
+                    motif = "".join(rng.choice(list("ACGT"), int(rng.integers(1, 5)))); seg = (motif * 40)[:int(rng.integers(8, 60))]
+                else:
+                    seg = "".join(rng.choice(list("ACGT"), int(rng.integers(5, 40))))
+                parts.append(seg); tot += len(seg)
+            h1 = "".join(parts)[:L]
+            perr = float(rng.choice([0.004, 0.01, 0.03]))
         h2 = synth.mutate(rng, h1, int(rng.integers(1, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2))) if L > 200 else h1
         reads, offs = [], []
         for _ in range(int(rng.integers(1, 14))):
             hap = h1 if rng.random() < 0.5 else h2
             a = int(rng.integers(0, L // 3)) if rng.random() < 0.5 else 0
             b = int(rng.integers(2 * L // 3, len(hap) + 1))
-            reads.append(synth.hifi_errors(rng, hap[a:b], p_sub=0.004, p_ins=0.004, p_del=0.004))
+            reads.append(synth.hifi_errors(rng, hap[a:b], p_sub=perr, p_ins=perr, p_del=perr))
             offs.append(None if a == 0 else a + int(rng.integers(0, 40)))
         if all(o is not None for o in offs):
             offs[0] = None
