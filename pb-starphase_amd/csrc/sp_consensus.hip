@@ -42,7 +42,7 @@ constexpr int CH = 32;          // lane of diagonal 0
 #define SP_K8_WAVES 8
 #endif
 #ifndef SP_K8_MIN_WAVES
-#define SP_K8_MIN_WAVES 1
+#define SP_K8_MIN_WAVES 4      // two workgroups of eight waves per CU: the step kernel then fits 128 VGPRs (16 bytes of scratch per lane); at 134 VGPRs and three waves the 10,000-read sample took 3.4 ms longer
 #endif
 constexpr int CWAVES = SP_K8_WAVES;      // waves per workgroup
 #ifndef SP_K8_DBG_READS
@@ -369,6 +369,7 @@ template <class BT> __device__ __forceinline__ uint32_t block_word(const BT& B, 
     if (o < QSV + QSL + EC) return B.PC[blk * EC + (o - QSV - QSL)];
     return B.PR[blk * EC + (o - QSV - QSL - EC)];
 }
+constexpr int BULK_MARGIN = 8;         // edits a read's worse state must be behind the better one to go through a window ahead of it (a state that close may draw level)
 constexpr int DIRECT_BLOCKS = 16;       // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
 
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B) {
@@ -630,6 +631,52 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             const int t = __builtin_ctzll(stop);
             return (t << 4) + __builtin_amdgcn_readlane(run, t);
         };
+        // The worse state of a read that follows two consensuses goes through the whole window FIRST, wavefront by wavefront (as a late read
+        // catches up: dwfa_catchup_t), not column by column.  While it has more edits than the other state it has no say in any column (vote),
+        // so all the columns need of it is its edit count -- for the comparison that stops tracking it (dual_max_ed_delta) and for the moment
+        // it would draw level -- and a wavefront with e edits that reaches column c names that count for every column up to c.  A state 3 %
+        // off its consensus (the other gene copy, the other haplotype) costs ten wavefronts per window this way instead of a hundred and
+        // fifty single-column pushes, and no longer cuts the clean runs of the good state short.  If the other state catches up with it inside the
+        // window, the state is rebuilt at that column from its copy and the two go on column by column.
+        // (its edit count after j pushes, 16 bits each, lies in the wave's placement scratch: a read with both states placed has no use for that)
+        static_assert(sizeof(((ActScratch*)nullptr)->rcache) >= 2 * (CW + 1), "edit-count profile");
+        uint16_t* const ewp = reinterpret_cast<uint16_t*>(act[wave].rcache);
+        auto bulk_push = [&](Dwfa& d, int i, const ConsAccess& cacc, int Tl0, int cols, bool record) -> bool {
+            auto ext = extender(cacc, i);
+            const int k = lane - CH, span = Tl0 + cols;
+            int reached = Tl0;
+            if (record && lane == 0) ewp[0] = (uint16_t)d.e;
+            for (;;) {
+                ext(d, span);
+                int far = spw::wave_max(d.H >= 0 ? d.H + k : -1);
+                far = far < span ? far : span;
+                if (record) for (int c = reached + 1 + lane; c <= far; c += SP_WAVE) ewp[c - Tl0] = (uint16_t)d.e;
+                reached = far > reached ? far : reached;
+                if (reached >= span) break;
+                const int c = d.H, up = spw::from_lower(d.H, SP_NEG), dn = spw::from_upper(d.H, SP_NEG);
+                int best = SP_NEG;
+                if (c >= 0 && c < rv.n && c + k < span) best = c + 1;
+                if (up >= 0 && up + k <= span && up + k >= 0 && up > best) best = up;
+                if (dn >= 0 && dn < rv.n && dn + 1 + k >= 0 && dn + 1 > best) best = dn + 1;
+                if (!__ballot(best >= 0)) return false;
+                d.H = best; d.e += 1;
+            }
+            spw::wave_lds_sync();
+            return true;
+        };
+        int bulk = -1;                                                       // the state that went ahead (0 / 1), none: -1
+        int wsave_H = 0, wsave_e = 0;                                        // its state at column T (c0 and flags do not change on the way)
+        if (mode == M_WINDOW && dualrun && go0 && go1 && n >= 8 && (d0.flags & F_ACTIVE) && (d1.flags & F_ACTIVE) &&
+            !((d0.flags | d1.flags) & (F_FINISHED | F_LOST)) && (d0.e >= d1.e + BULK_MARGIN || d1.e >= d0.e + BULK_MARGIN)) {
+            const int wi = d0.e > d1.e ? 0 : 1;
+            Dwfa& w = wi ? d1 : d0;
+            const int Tl0 = T - w.c0;
+            if ((!P.et || rv.n > Tl0 + n + CB) && w.e < 60000) {            // (early termination: a read that could end inside the window freezes at that column)
+                wsave_H = w.H; wsave_e = w.e;
+                if (bulk_push(w, wi, wi ? ca1 : ca0, Tl0, n, true)) { bulk = wi; w.e = wsave_e; }      // w.e follows the columns: its count after j pushes
+                else { w.H = wsave_H; w.e = wsave_e; }
+            }
+        }
         int j = 0;
 #ifdef SP_K8_TIMING
         int slow_cols = 0, multi_tip = 0, zero_run = 0;
@@ -650,6 +697,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             for (int i = 0; i < 2; ++i) {
                 if (i == 1 && !dualrun) continue;
                 if (!(i ? go1 : go0)) continue;
+                if (i == bulk) continue;
                 const Dwfa& a = i ? d1 : d0;
                 if (a.flags & F_ACTIVE) {
                     if (a.flags & (F_FINISHED | F_LOST)) continue;
@@ -686,6 +734,22 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
                     if (lane == tl) a.H += m;
                     if (P.et && th + m == rv.n) a.flags |= F_FINISHED;
                 }
+                if (bulk >= 0) {
+                    // the state that went ahead: is it dropped in one of these columns?  (the other state's count does not move in a clean run)
+                    Dwfa& w = bulk ? d1 : d0; const Dwfa& b = bulk ? d0 : d1;
+                    if (!(w.flags & F_LOST)) {
+                        int hit = -1;
+                        if (!(b.flags & F_LOST)) {
+                            const int thr = b.e + P.delta;
+                            for (int base = 0; base < m; base += SP_WAVE) {
+                                const int x = j + 1 + base + lane;
+                                const unsigned long long over = __ballot(x <= j + m && (int)ewp[x] > thr);
+                                if (over) { hit = j + 1 + base + __builtin_ctzll(over); break; }
+                            }
+                        }
+                        if (hit >= 0) { w.flags |= F_LOST; w.e = (int)ewp[hit]; } else w.e = (int)ewp[j + m];
+                    }
+                }
                 j += m;
                 K8_T(tb_fast);
                 continue;
@@ -695,12 +759,25 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             slow_cols += 1;
 #endif
             const int before = read_cost(d0, d1, dualrun);
-            column(d0, d1, dualrun, go0, go1, cwin[0][CWIN + j], cwin[1][CWIN + j], T + j + 1, ca0, ca1);
+            if (bulk >= 0) {
+                // only the other state is pushed; the one that went ahead shows its count at the new column to the comparison in column()
+                Dwfa& w = bulk ? d1 : d0; const Dwfa& b = bulk ? d0 : d1;
+                if (!(w.flags & F_LOST)) w.e = (int)ewp[j + 1];
+                column(d0, d1, dualrun, bulk != 0, bulk != 1, cwin[0][CWIN + j], cwin[1][CWIN + j], T + j + 1, ca0, ca1);
+                if (!(w.flags & F_LOST) && ((b.flags & F_LOST) || w.e <= b.e)) {
+                    // the other state has caught up (or is no longer tracked): from this column on this one has a say.  The state as it stands at
+                    // this column, from its copy
+                    w.H = wsave_H; w.e = wsave_e;
+                    (void)bulk_push(w, bulk, bulk ? ca1 : ca0, T - w.c0, j + 1, false);
+                    bulk = -1;
+                }
+            } else
+                column(d0, d1, dualrun, go0, go1, cwin[0][CWIN + j], cwin[1][CWIN + j], T + j + 1, ca0, ca1);
             const int grow = read_cost(d0, d1, dualrun) - before;
             if (grow && lane == 0) atomicAdd(&lc[j + 1], (uint32_t)grow);
             K8_T(tb_col);
-            if (go0) vote(d0, d1, dualrun, 0, T + j + 1, j + 1);
-            if (dualrun && go1) vote(d1, d0, dualrun, 1, T + j + 1, j + 1);
+            if (go0 && bulk != 0) vote(d0, d1, dualrun, 0, T + j + 1, j + 1);
+            if (dualrun && go1 && bulk != 1) vote(d1, d0, dualrun, 1, T + j + 1, j + 1);
             K8_T(tb_vote);
             j += 1;
         }

@@ -198,7 +198,9 @@ __global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSet
             for (int w = lane; w < nw; w += SP_WAVE) { LB[w] = rw[w0 + w]; if (HASN) NB[w] = rn ? rn[w0 + w] : 0u; }
             b_base = w0 << 4;
         }
-        if (read_maxlen && lane == 0) atomicMax(&read_maxlen[r], (uint32_t)longest);     // longest allele any cell of this read uses
+        // longest allele any cell of this read uses; the word only grows, so a (possibly stale) plain read that already shows the value saves the atomic:
+        // one 8-byte atomic per workgroup was half of the kernel's 62.8 MB of HBM writes per launch (the other half: the wg_stats word below)
+        if (read_maxlen && lane == 0 && __builtin_nontemporal_load(&read_maxlen[r]) < (uint32_t)longest) atomicMax(&read_maxlen[r], (uint32_t)longest);
         const unsigned long long active = __ballot(u.act != 0);
         uint32_t res = SP_CELL_NONE;
         // lane j: is the cell right before it in the order active too?  (a chain or a saved state never crosses a gap or a group)

@@ -1,11 +1,11 @@
-# per-read records of the consensus window launches of one CYP2D6 call (timing build: build/variants/lib_timing.so, -DSP_K8_TIMING -DSP_K8_DBG_READS=1024):
+# per-read records of the consensus window launches of one CYP2D6 call (timing build: build/variants/lib_timing.so, -DSP_K8_TIMING -DSP_K8_DBG_READS=4096):
 # what the slowest wave of every window launch was doing
 SC=${1:-3}
 rm -f gpurun_out/k8_dump.bin
 SP_K8_DUMP=$PWD/gpurun_out/k8_dump.bin SP_LIB_PATH=$PWD/build/variants/lib_timing.so python profiles/scripts/cyp_kernels.py $SC 2>&1 | grep -E "total ms|cons_steps"
 python - <<'PY'
 import numpy as np
-R, L = 1024, 4096
+R, L = 4096, 1024
 raw = np.fromfile('gpurun_out/k8_dump.bin', dtype=np.uint64)
 rec = 1 + R * L
 n_chunks = len(raw) // rec

@@ -1,4 +1,4 @@
-"""longer hunt for K8 != oracle: prints the first differing random problem in full (run on the GPU box).  Seeds >= 1000: low-complexity haplotypes and noisier reads."""
+"""longer hunt for K8 != oracle: prints the first differing random problem in full (run on the GPU box).  Seeds >= 1000: low-complexity haplotypes and noisier reads; seeds >= 2000: haplotypes 1-5 % apart, recombinant reads."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -31,9 +31,18 @@ for seed in seeds:
             h1 = "".join(parts)[:L]
             perr = float(rng.choice([0.004, 0.01, 0.03]))
         h2 = synth.mutate(rng, h1, int(rng.integers(1, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2))) if L > 200 else h1
+        if seed >= 2000:
+            # two haplotypes a few percent apart (as two gene copies are), longer, and reads that switch from one to the other: the worse state
+            # of a read falls behind by dozens of edits, is dropped at dual_max_ed_delta, or draws level again behind a switch
+            L = int(rng.integers(400, 1500)); h1 = "".join(rng.choice(list("ACGT"), L))
+            k = max(3, int(L * float(rng.choice([0.01, 0.03, 0.05])) / 1.0)); k = min(k, (L - 40) // 12 - 1)
+            h2 = synth.mutate(rng, h1, k - k // 8 - k // 8, k // 8, k // 8)
         reads, offs = [], []
         for _ in range(int(rng.integers(1, 14))):
             hap = h1 if rng.random() < 0.5 else h2
+            if seed >= 2000 and rng.random() < 0.3:
+                x = int(rng.integers(L // 4, 3 * L // 4)); other = h2 if hap is h1 else h1
+                hap = hap[:x] + other[min(x, len(other)):]
             a = int(rng.integers(0, L // 3)) if rng.random() < 0.5 else 0
             b = int(rng.integers(2 * L // 3, len(hap) + 1))
             reads.append(synth.hifi_errors(rng, hap[a:b], p_sub=perr, p_ins=perr, p_del=perr))
