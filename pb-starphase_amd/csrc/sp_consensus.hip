@@ -121,9 +121,13 @@ struct ConsParams {
     struct ConsRes* out_res; CSearch* out_srch;
 };
 struct ReadInfo { const uint32_t* w; const uint32_t* np; int n, off; long long pad; };
+// The last placement search of a read on consensus 1 / 2 and its answer.  Every node of a search that reaches the read's offset places it again,
+// mostly in front of the very same bases (siblings differ at one column): 2.7 searches per read in a CYP2D6 region batch, 20 us each.
+struct PlaceMemo { int valid, M, off, c0; uint32_t text[512 / 16 + 2]; };
 template <int MAXP> struct ConsBatchT {
     ConsParams p[MAXP]; int n_prob;
     const ReadInfo* info;       // [total]
+    PlaceMemo* memo;            // [total][2]
     uint16_t* H;                // [node][slot][consensus][total][64] furthest read position per diagonal (0xFFFF = none)
     ConsMeta* meta;             // [node][slot][consensus][total]
     unsigned long long* PV;     // [blocks][2][CW + 1] exact votes per workgroup: four 16-bit fields (A, C, G, T) in 12ths of a read
@@ -138,7 +142,7 @@ template <int MAXP> struct ConsBatchT {
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; const int* cluster_prob; int total;
+    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; const int* cluster_prob; int total;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first; };
 
@@ -201,10 +205,10 @@ __device__ __forceinline__ void dwfa_catchup_t(Dwfa& d, int n, EXT extend, int s
     }
 }
 
-// placement of a late read: Sellers' search of its first L bases in the last W consensus bases, one Myers bit-vector scan per
+// the same search for windows that do not fit the wave's scratch (offset_window > 512): Sellers' search, one Myers bit-vector scan per
 // lane over the end positions it owns (an occurrence of an L-base pattern with <= L edits spans <= 2L text bases)
 template <class RB, class CA>
-__device__ __forceinline__ int find_start(int rn, RB rb, CA ca, int off, int W, int L, int lane) {
+__device__ __noinline__ int find_start_scan(int rn, RB rb, CA ca, int off, int W, int L, int lane) {
     const int ws = off - W > 0 ? off - W : 0, M = off - ws;
     if (L > rn) L = rn;
     if (M <= 0 || L <= 0) return off;
@@ -243,6 +247,52 @@ __device__ __forceinline__ int find_start(int rn, RB rb, CA ca, int off, int W, 
     return (int)(key & ((1ull << 22) - 1));
 }
 
+// placement of a late read: Sellers' search of its first L bases (read backwards) in the last W consensus bases (backwards from `off`): the
+// distance matrix D[i][j] (i bases of the pattern against a stretch that ends at text position j; D[0][j] = 0, D[i][0] = i) is filled one
+// anti-diagonal per step, lane l holding row l + 1: a cell needs the lane's own last value and the last two of the lane below (two DPP moves).
+// The last row names, for every start position p = off - j, the edits of the best occurrence (kept per column in `score`); the smallest
+// (edits, distance from the middle of the window, p) wins.  L + M short steps; the per-lane Myers scan this replaces (every lane its own 2 L
+// warm-up columns and its own 64-bit bit-vector) took 28 us per state: more than half of a CYP2D6 window launch that places a read.
+// pc: the lane's pattern base (read base L - 1 - lane; 7 behind the pattern, 4 for an N: neither matches anything)
+// tr: the text, backwards, 2 bits per base (text position j = 1 .. M at bit 2 (j - 1)); score: M bytes.  Out of line: its loop wants few registers.
+__device__ __noinline__ int find_start_diag(int pc, int L_, int M_, int off_, int W_, int lane, const uint32_t* tr_, uint8_t* score_) {
+    // (arguments of an out-of-line function arrive in vector registers: the uniform ones go back to scalars, the two LDS pointers to LDS addresses --
+    //  through generic pointers every access is a flat load the loop has to wait for)
+    const int L = __builtin_amdgcn_readfirstlane(L_), M = __builtin_amdgcn_readfirstlane(M_), off = __builtin_amdgcn_readfirstlane(off_), W = __builtin_amdgcn_readfirstlane(W_);
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    spw::lds_cu32* tr = (spw::lds_cu32*)(uintptr_t)spw::lds_addr(tr_);
+    lds_u8* score = (lds_u8*)(uintptr_t)spw::lds_addr(reinterpret_cast<const uint32_t*>(score_));
+    const int i = lane + 1;                                                  // this lane's row
+    int prev1 = i, prev2 = i;                                                // the lane's value one and two steps ago
+    uint32_t tw = tr[0], tw_next = tw;
+    const bool last_row = lane == L - 1;
+    for (int d = 1; d <= L + M; ++d) {
+        const int j = d - i;                                                 // the lane's column in this step
+        const int up = spw::from_lower(prev1, 0), diag = spw::from_lower(prev2, 0);   // row i - 1 at columns j and j - 1 (row 0 is all zeros)
+        if (j >= 1 && ((j - 1) & 15) == 0) tw = tw_next;
+        int cur = i;                                                         // column 0 (and the steps before the lane starts)
+        if (j >= 1 && j <= M) {
+            const int tc = (int)((tw >> (((j - 1) & 15) << 1)) & 3u);
+            const int a = diag + (pc != tc ? 1 : 0), bmin = (up < prev1 ? up : prev1) + 1;
+            cur = a < bmin ? a : bmin;
+            if (last_row) score[j - 1] = (uint8_t)cur;
+        }
+        if (j >= 0 && (j & 15) == 0) tw_next = tr[j >> 4];                   // the word the lane starts in the next step
+        prev2 = prev1; prev1 = cur;
+    }
+    spw::wave_lds_sync();
+    const int centre = off - W / 2;
+    unsigned long long key = ~0ull;
+    for (int j = lane + 1; j <= M; j += SP_WAVE) {
+        const int p = off - j, dist = p > centre ? p - centre : centre - p;
+        const unsigned long long kk = ((unsigned long long)score[j - 1] << 44) | ((unsigned long long)dist << 22) | (unsigned long long)p;
+        key = kk < key ? kk : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
+    return (int)(key & ((1ull << 22) - 1));
+}
+
 constexpr int ACT_CONS = 512;   // consensus bases a wave packs while a late read catches up (offset_window + slack)
 constexpr int ACT_READ = 640;   // read bases it keeps (catch-up length + band + edits)
 struct ActScratch {             // per wave
@@ -250,6 +300,10 @@ struct ActScratch {             // per wave
     uint32_t cpack[ACT_CONS / 16 + 2];
     uint32_t rpack[ACT_READ / 16 + 2];
     uint32_t npack[ACT_READ / 16 + 2];
+    uint8_t score[ACT_CONS];    // placement search: edits of the best occurrence per start position
+#ifdef SP_K8_TIMING
+    long long tk[4];            // ticks (100 MHz) spent in a placement: read staging, start search, consensus packing, catch-up
+#endif
 };
 
 
@@ -268,9 +322,15 @@ struct ConsAccess {
 // Placement of a late read (add_sequence_offset) when the consensus reaches length `len` == its offset: start search in the
 // offset_window bases before it, then the catch-up pushes.  Kept out of line: it is rare and needs twice the registers of
 // the window loop.
-__device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScratch* Ap, int off, int len, int window, int cmp_len, int et, int lane) {
+__device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScratch* Ap, PlaceMemo* memo, int off, int len, int window, int cmp_len, int et, int lane) {
     ActScratch& A = *Ap;
     Dwfa d;
+#ifdef SP_K8_TIMING
+    long long tq = wall_clock64();
+#define ACT_T(k) do { const long long _n = wall_clock64(); if (lane == 0) A.tk[k] += _n - tq; tq = _n; } while (0)
+#else
+#define ACT_T(k) do { } while (0)
+#endif
     auto ca = [&](int pos) { return cacc.at(pos); };
     const int ws = off - window > 0 ? off - window : 0;
     // the read's first 640 bases: one packed word (and N word) per lane from memory, the byte per base the search and the slow catch-up read
@@ -286,7 +346,38 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
     }
     spw::wave_lds_sync();
     auto rbc = [&](int h) { return h < ACT_READ ? (int)A.rcache[h] : read_base(rv, h); };
-    d.c0 = find_start(rv.n, rbc, ca, off, window, cmp_len, lane);
+    ACT_T(0);
+    {
+        const int ws0 = off - window > 0 ? off - window : 0, M = off - ws0, L = cmp_len < rv.n ? cmp_len : rv.n;
+        if (M <= 0 || L <= 0) d.c0 = off;
+        else if (M > ACT_CONS) d.c0 = find_start_scan(rv.n, rbc, ca, off, window, cmp_len, lane);
+        else {
+            for (int w = lane; w < ((M + 15) >> 4) + 1; w += SP_WAVE) {      // the text backwards, 2 bits per base (cpack is rebuilt for the catch-up below)
+                uint32_t word = 0;
+                for (int b = 0; b < 16; ++b) { const int j = w * 16 + b + 1; if (j <= M) word |= (uint32_t)(ca(off - j) & 3) << (b << 1); }
+                A.cpack[w] = word;
+            }
+            spw::wave_lds_sync();
+            const int nw = ((M + 15) >> 4) + 1;                                // (<= 33 words: a lane each)
+            PlaceMemo* mm = memo + cacc.i;
+            // (loads that go past this CU's L1: the wave may have written the entry a moment ago, for another child of the same expansion; the text
+            //  is read before it is known whether the entry holds anything: one round trip)
+            auto peek = [](const int* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            const uint32_t seen = lane < nw ? (uint32_t)peek(reinterpret_cast<const int*>(&mm->text[lane])) : 0u;
+            const int m_c0 = peek(&mm->c0);
+            bool known = peek(&mm->valid) && peek(&mm->M) == M && peek(&mm->off) == off;
+            if (known) known = __ballot(lane < nw && seen != A.cpack[lane]) == 0;
+            ACT_T(0);
+            if (known) d.c0 = m_c0;
+            else {
+                d.c0 = find_start_diag(lane < L ? rbc(L - 1 - lane) : 7, L, M, off, window, lane, A.cpack, A.score);
+                if (lane < nw) mm->text[lane] = A.cpack[lane];
+                if (lane == 0) { mm->valid = 1; mm->M = M; mm->off = off; mm->c0 = d.c0; }
+            }
+            spw::wave_lds_sync();
+        }
+    }
+    ACT_T(1);
     d.H = lane == CH ? 0 : SP_NEG; d.e = 0; d.flags = F_ACTIVE | ((et && rv.n == 0) ? F_FINISHED : 0);
     const int c0 = d.c0, span = len - c0, cwinlen = len - ws;
     const bool packed = rv.np == nullptr && cwinlen <= ACT_CONS;
@@ -298,6 +389,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             A.cpack[w] = word;
         }
         spw::wave_lds_sync();                                  // (rpack holds the read's packed words since the start)
+        ACT_T(2);
         const int kk = lane - CH, cbase = c0 - ws;
         dwfa_catchup_t(d, rv.n, [&]() {
             for (;;) {
@@ -340,6 +432,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             }, Tl, ca(c0 + Tl - 1), et, lane);
         }
     }
+    ACT_T(3);
     return d;
 }
 
@@ -445,6 +538,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
         const size_t g = (size_t)P.first + r;
 #ifdef SP_K8_TIMING
         const long long wt0 = wall_clock64();
+        if (lane == 0) { act[wave].tk[0] = act[wave].tk[1] = act[wave].tk[2] = act[wave].tk[3] = 0; }
 #endif
         const ReadInfo ri = B.info[g];
         ReadView rv; rv.w = ri.w; rv.np = ri.np; rv.n = ri.n;
@@ -537,11 +631,11 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
         auto column = [&](Dwfa& a0, Dwfa& a1, bool dualrun, int g0, int g1, int nb0, int nb1, int len, const ConsAccess& c0a, const ConsAccess& c1a) {
             if (g0) {
                 if (a0.flags & F_ACTIVE) { if (!(a0.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a0, rv.n, rb, extender(c0a, c0a.i), len - a0.c0, nb0, P.et, lane); }
-                else if (ri.off == len) { a0 = activate_late(rv, c0a, &act[wave], ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
+                else if (ri.off == len) { a0 = activate_late(rv, c0a, &act[wave], B.memo + 2 * g, ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
             }
             if (dualrun && g1) {
                 if (a1.flags & F_ACTIVE) { if (!(a1.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a1, rv.n, rb, extender(c1a, c1a.i), len - a1.c0, nb1, P.et, lane); }
-                else if (ri.off == len) { a1 = activate_late(rv, c1a, &act[wave], ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
+                else if (ri.off == len) { a1 = activate_late(rv, c1a, &act[wave], B.memo + 2 * g, ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
             }
             if (dualrun) {
                 const int both = (a0.flags & F_ACTIVE) && (a1.flags & F_ACTIVE) && !(a0.flags & F_LOST) && !(a1.flags & F_LOST);
@@ -818,8 +912,10 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             auto cl = [](long long v, long long cap) { return (unsigned long long)(v > cap ? cap : v); };
 #ifdef SP_K8_DBG_EDITS
             // (variant: the edit counts of the two states instead of the multi-tip events and the column-push clocks)
-            B.dbg[(size_t)Wp->pad * SP_K8_DBG_READS + g] = cl((long long)dt, 0xFFFFFF) | (cl(slow_cols, 511) << 24) | (cl(d0.e, 511) << 33) | (placed << 42) | ((unsigned long long)mode << 43) |
-                                                            (cl(n, 511) << 45) | (cl((d1.flags & F_ACTIVE) ? d1.e : 1023, 1023) << 54);
+            // (variant: where a placement's time goes instead of the multi-tip events and the column-push clocks: start search and catch-up, 0.32 us units;
+            //  staging + packing in the slow-column field)
+            B.dbg[(size_t)Wp->pad * SP_K8_DBG_READS + g] = cl((long long)dt, 0xFFFFFF) | (cl((act[wave].tk[0] + act[wave].tk[2]) >> 5, 511) << 24) | (cl(act[wave].tk[1] >> 5, 511) << 33) | (placed << 42) |
+                                                            ((unsigned long long)mode << 43) | (cl(n, 511) << 45) | (cl(act[wave].tk[3] >> 5, 1023) << 54);
 #else
             B.dbg[(size_t)Wp->pad * SP_K8_DBG_READS + g] = cl((long long)dt, 0xFFFFFF) | (cl(slow_cols, 511) << 24) | (cl(multi_tip, 511) << 33) | (placed << 42) | ((unsigned long long)mode << 43) |
                                                             (cl(n, 511) << 45) | (cl(tb_col >> 10, 1023) << 54);
@@ -1455,7 +1551,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     const size_t out_is1 = place(out_bytes, total), out_sc = place(out_bytes, sizeof(int32_t) * 2 * total);
     std::vector<size_t> out_cons(n_prob);
     for (uint32_t p = 0; p < n_prob; ++p) out_cons[p] = place(out_bytes, (size_t)2 * std::max(hp[p].cap, 1));
-    const size_t zero_nodes = place(zero_bytes, sizeof(CNode) * NQ * n_prob), zero_proc = place(zero_bytes, proc_bytes), zero_info = place(zero_bytes, sizeof(ReadInfo) * total);
+    const size_t zero_nodes = place(zero_bytes, sizeof(CNode) * NQ * n_prob), zero_proc = place(zero_bytes, proc_bytes), zero_info = place(zero_bytes, sizeof(ReadInfo) * total), zero_memo = place(zero_bytes, sizeof(PlaceMemo) * 2 * total);
     uint8_t* d_in = (uint8_t*)sp_pool(ctx, "cons_in", in_bytes + 16); uint8_t* h_in = (uint8_t*)sp_host_pool(ctx, "cons_in", in_bytes + 16);
     uint8_t* d_out = (uint8_t*)sp_pool(ctx, "cons_out", out_bytes + 16); uint8_t* h_out = (uint8_t*)sp_host_pool(ctx, "cons_out", out_bytes + 16);
     uint8_t* d_zero = (uint8_t*)sp_pool(ctx, "cons_zero", zero_bytes + 16);
@@ -1468,6 +1564,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     uint32_t* d_la = (uint32_t*)sp_pool(ctx, "cons_la", sizeof(uint32_t) * (size_t)NQ * 2 * CW * 4 * n_prob);
     uint8_t* d_proc = d_zero + zero_proc;
     ReadInfo* d_info = (ReadInfo*)(d_zero + zero_info);
+    B.memo = (PlaceMemo*)(d_zero + zero_memo);
     B.info = d_info; B.total = (int)total;
     B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * planes * total * CB);
     B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * planes * total);

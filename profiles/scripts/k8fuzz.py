@@ -50,7 +50,7 @@ for seed in seeds:
         if all(o is not None for o in offs):
             offs[0] = None
         kw = dict(early_termination=bool(rng.integers(0, 2)), dual=True, min_count=int(rng.integers(1, 4)), min_af=float(rng.choice([0.1, 0.25])),
-                  dual_max_ed_delta=int(rng.choice([2, 20, 100])), offset_window=int(rng.choice([60, 120, 400])), offset_compare_length=int(rng.choice([20, 50, 64])))
+                  dual_max_ed_delta=int(rng.choice([2, 20, 100])), offset_window=int(rng.choice([60, 120, 400] if seed < 2000 else [60, 120, 400, 700])), offset_compare_length=int(rng.choice([20, 50, 64])))
         two_pass = bool(rng.integers(0, 2))
         exp = run_case(oracle, reads, offs, kw, two_pass)
         got = ctx.consensus(ctx.upload(reads), gpu_cfg(pkg, **kw), offsets=offs, two_pass=two_pass)
