@@ -83,7 +83,8 @@ struct CNode {
     int32_t T, cur;             // column of the state in slot `cur`
     int32_t dual, split_at, stopped[2], len[2];
     int32_t n, a, q;            // the tape: n bases were pushed from T, the first a are verified, q are consumed
-    int32_t have_out, la_valid; // the other slot holds the state at T + n; lookahead votes exist for that state / the state at T
+    int16_t have_out, la_valid; // the other slot holds the state at T + n; lookahead votes exist for that state / the state at T
+    int32_t wcap;               // longest window the node may ask for: a child of an expansion starts with WRAMP0 columns and doubles with every window that stood
     long long cost0;            // cost of the state at T
     long long rest;             // what the unfinished reads add to the final cost (no early termination), for the state at T
     long long rest_out;         // the same for the state at T + n
@@ -462,6 +463,10 @@ template <class BT> __device__ __forceinline__ uint32_t block_word(const BT& B, 
     if (o < QSV + QSL + EC) return B.PC[blk * EC + (o - QSV - QSL)];
     return B.PR[blk * EC + (o - QSV - QSL - EC)];
 }
+#ifndef SP_K8_WRAMP0
+#define SP_K8_WRAMP0 64
+#endif
+constexpr int WRAMP0 = SP_K8_WRAMP0;           // first window of a node born in an expansion (most such nodes are dropped after a few columns: a 256-column window costs its slowest read 4 x as long)
 constexpr int BULK_MARGIN = 8;         // edits a read's worse state must be behind the better one to go through a window ahead of it (a state that close may draw level)
 constexpr int DIRECT_BLOCKS = 16;       // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
 
@@ -1123,7 +1128,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             CNode& x = nh[wk.node];
             if (lane == 0) {
                 x.used = 1; x.id = ss.next_id++; x.complete = 0; x.T = 0; x.cur = wk.in_slot; x.dual = 0; x.split_at = -1;
-                x.stopped[0] = 0; x.stopped[1] = 1; x.len[0] = x.len[1] = 0; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
+                x.stopped[0] = 0; x.stopped[1] = 1; x.len[0] = x.len[1] = 0; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1; x.wcap = CW;
                 x.cost0 = 0; x.dc[0] = 0; x.rest = sr[0]; x.rest_out = 0;
             }
             if (lane < 10) x.ev[lane / 5][lane % 5] = sv[lane / 5][0][lane % 5];
@@ -1192,7 +1197,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                     c.stopped[i] = st; c.len[i] = ln;
                 }
                 if (!c.dual) c.stopped[1] = 1;
-                c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = 0;
+                c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = 0; c.wcap = WRAMP0;
                 c.cost0 = par.cost_at(par.q) + (long long)sc[k]; c.dc[0] = 0; c.rest = sr[k]; c.rest_out = 0;
                 for (int i = 0; i < 2; ++i) for (int bq = 0; bq < 5; ++bq) c.ev[i][bq] = sv[i][k][bq];
             }
@@ -1284,6 +1289,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                     // its state at that column has to be there
                     if (x.q > 0 || x.n > 0) {
                         if (x.a == x.n && x.have_out) {                                    // the window stood: the other slot is the state
+                            if (x.n > 1) x.wcap = 2 * x.wcap < CW ? 2 * x.wcap : CW;
                             x.T += x.n; x.cur ^= 1; x.cost0 = x.cost_at(x.n); x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
                         } else {
                             // cut window: push the verified bases again from the kept state (nothing is speculated)
@@ -1358,10 +1364,11 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         tk3 = wall_clock64();
         if (need_la >= 0) {
             const uint32_t* la = need_la == la_fresh ? &sl[0][0][0] : P.la + (size_t)need_la * 2 * CW * 4;
-            int nn = CW;
-            for (int base = 0; base < CW; base += SP_WAVE) {
+            const int lim = nh[need_la].wcap;
+            int nn = lim;
+            for (int base = 0; base < lim; base += SP_WAVE) {
                 const int col = base + lane;
-                bool have = col >= 1 && wk.T + col < P.cap;
+                bool have = col >= 1 && col < lim && wk.T + col < P.cap;
                 int pick[2] = { 0, 0 };
                 if (have) {
 #pragma unroll
@@ -1382,7 +1389,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                 if (col >= 1 && lane < first) { wk.spec[0][col] = (uint8_t)pick[0]; wk.spec[1][col] = (uint8_t)pick[1]; }
                 if (miss) { nn = base + first; break; }
             }
-            if (lane == 0) wk.n = nn < CW ? nn : CW;
+            if (lane == 0) wk.n = nn < lim ? nn : lim;
         }
     }
     __syncthreads();

@@ -72,14 +72,18 @@ if vals.get("FETCH_SIZE") and vals.get("WRITE_SIZE"):
     print("== traffic", rec)
 
 # VALU wave-instructions of the dominant kernel per main launch, for bench.py's roofline_valu (SQ_INSTS_VALU of the pmc_sq pass)
-v = []
+v, sa = [], []
 for f in find("pmc_sq/**/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         if "k1_cells_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == "SQ_INSTS_VALU":
             v.append(float(row.get("Counter_Value", 0) or 0))
+        if "k1_cells_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == "SQ_INSTS_SALU":
+            sa.append(float(row.get("Counter_Value", 0) or 0))
 if v:
     big = [x for x in v if x * 10 >= max(v)]
-    rec = {"kernel": "k1_cells_kernel", "sq_insts_valu_per_launch": sum(big) / len(big), "main_launches": len(big), "k1_source_sha16": k1_source_sha16(),
-           "method": "rocprofv3 --pmc SQ_INSTS_VALU (pass pmc_sq of profiles/run_rocprof.sh), mean over the main launches"}
+    bigs = [x for x in sa if x * 10 >= max(sa)] if sa else []
+    rec = {"kernel": "k1_cells_kernel", "sq_insts_valu_per_launch": sum(big) / len(big), "sq_insts_salu_per_launch": (sum(bigs) / len(bigs)) if bigs else None,
+           "main_launches": len(big), "k1_source_sha16": k1_source_sha16(),
+           "method": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU (pass pmc_sq of profiles/run_rocprof.sh), mean over the main launches"}
     json.dump(rec, open(os.path.join(out, "valu_k1_cells.json"), "w"), indent=1)
     print("== valu", rec)
