@@ -2,7 +2,7 @@
 simulated from.  VERDICT round 2, item 1(b): "library == oracle" says nothing about a contract both share; this counts how often the call is RIGHT,
 by depth and by what the truth looks like, and gives every miss at >= 160 reads a cause.
 
-usage: truth_audit.py <n per depth> [seed]      -> prints a report; profiles/r03/truth_accuracy.txt keeps the run that DESIGN.md quotes"""
+usage: truth_audit.py <n per depth> [seed [shortest longest fragment]]      -> prints a report; profiles/r03/truth_accuracy.txt keeps the run that DESIGN.md quotes"""
 import os
 import sys
 import time
@@ -18,7 +18,8 @@ import cyp_cases_real as cr
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-DEPTHS = (60, 160, 400, 1000)
+LO, HI = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3000, 8000)      # fragment lengths (8000 16000: reads that can span two gene copies)
+DEPTHS = (60, 160, 400, 1000) if len(sys.argv) <= 4 else (160, 400)
 ctx = pkg.Context(0)
 rng = np.random.default_rng(SEED)
 
@@ -125,14 +126,14 @@ def cause(call, truth):
     return "an allele typed as another star allele"
 
 
-print(f"# truth accuracy, seed {SEED}, {N} random samples per depth; sample generator of profiles/scripts/pipeline_fuzz.py (8 % *5, 30 % tandems, 15 % hybrids)")
+print(f"# truth accuracy, seed {SEED}, {N} random samples per depth, fragments of {LO}-{HI} bases; sample generator of profiles/scripts/pipeline_fuzz.py (8 % *5, 30 % tandems, 15 % hybrids)")
 rows = []
 for depth in DEPTHS:
     stats = Counter()
     t0 = time.time()
     for it in range(N):
         (h1, n1), (h2, n2) = haplotype(), haplotype()
-        reads = locus.sample(rng, [h1, h2], depth)
+        reads = locus.sample(rng, [h1, h2], depth, lo=LO, hi=HI)
         call, _cons, _labels = db.diplotype(ctx.upload(reads))
         tandem = len(n1) > 1 or len(n2) > 1
         kind = "tandem" if tandem else "single-copy"
@@ -165,6 +166,8 @@ for depth, stats, dt in rows:
         print(f"| {depth} | {kind} | {n} | {stats[kind, 'exact']} ({100.0 * stats[kind, 'exact'] / n:.0f} %) | {stats[kind, 'core']} ({100.0 * stats[kind, 'core'] / n:.0f} %) | {causes or ('-' if depth >= 160 else '(not classified below 160 reads)')} |")
 
 # ---------------------------------------------------------------- HLA: the reduced database of pipeline_fuzz.py and the full one
+if len(sys.argv) > 4:
+    sys.exit(0)
 print()
 print("| HLA database | reads per haplotype | per-base error | gene calls | == truth |")
 print("|---|---|---|---|---|")
