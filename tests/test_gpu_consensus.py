@@ -89,6 +89,24 @@ def test_random_small_inputs(oracle, pkg, gpu_ctx):
     assert n_dual >= 5 * len(seeds) - 4
 
 
+def test_low_complexity_and_divergent_inputs(oracle, pkg, gpu_ctx):
+    """the inputs that make a read's states expensive (tests/consensus_fuzz.py): repeats and noisy reads (many tips per column), haplotypes 1-5 % apart with recombinant
+    reads (the worse state goes through a window ahead of the other, is dropped at dual_max_ed_delta, or is rebuilt where the other catches up), placement windows
+    of 700 bases (the wide-window search)"""
+    import consensus_fuzz
+    from pb_starphase_amd import synth
+    for seed in (1003, 2001, 2005):
+        rng = np.random.default_rng(seed)
+        for it in range(25):
+            _L, reads, offs, kw, two_pass = consensus_fuzz.problem(rng, seed, synth)
+            exp = run_case(oracle, reads, offs, kw, two_pass)
+            got = gpu_ctx.consensus(gpu_ctx.upload(reads), gpu_cfg(pkg, **kw), offsets=offs, two_pass=two_pass)
+            try:
+                same(got, exp)
+            except AssertionError as e:
+                raise AssertionError(f"seed {seed} iteration {it}: {e}")
+
+
 def test_batch_equals_one_by_one(oracle, pkg, gpu_ctx):
     """independent problems advanced in lockstep (sp_consensus_batch / sp_consensus_dual_batch) give what they give alone"""
     from pb_starphase_amd import synth

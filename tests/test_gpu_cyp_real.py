@@ -91,11 +91,14 @@ def test_cohort_call_equals_single_calls(gpu_ctx, real):
     for rs in sets:
         call, cons, _labels = db.diplotype(rs)
         single.append(key(call, cons))
-    for streams in (3, 1):
-        gpu_ctx.set_option("hla_split_streams", streams)
+    for streams in (6, 3, 1, 8):
+        gpu_ctx.set_option("cyp_cohort_streams", streams)
         cohort = db.diplotype_cohort(sets)
         assert [key(call, cons) for call, cons, _rc in cohort] == single and all(rc == 0 for _c, _s, rc in cohort)
-    gpu_ctx.set_option("hla_split_streams", 3)
+    gpu_ctx.set_option("cyp_cohort_streams", 6)
+    for bad in (0, 9):
+        with pytest.raises(Exception):
+            gpu_ctx.set_option("cyp_cohort_streams", bad)
     assert [k[0] for k in single] == [0] * len(NAMES)
     assert db.diplotype_cohort([]) == []
 
