@@ -468,7 +468,7 @@ template <class BT> __device__ __forceinline__ uint32_t block_word(const BT& B, 
 #endif
 constexpr int WRAMP0 = SP_K8_WRAMP0;           // first window of a node born in an expansion (most such nodes are dropped after a few columns: a 256-column window costs its slowest read 4 x as long)
 constexpr int BULK_MARGIN = 8;         // edits a read's worse state must be behind the better one to go through a window ahead of it (a state that close may draw level)
-constexpr int DIRECT_BLOCKS = 16;       // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
+constexpr int DIRECT_BLOCKS = 128;      // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
 
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B) {
     int pi = 0;
@@ -1054,8 +1054,10 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         const UsedWords uw(mode_in, n_in, mode_in == M_EXPAND ? wk.n_kids : 0);
         if (P.n_blocks <= DIRECT_BLOCKS) {
             // the workgroups' words as they lie in memory: the exact and the lookahead votes are four 16-bit fields per 64-bit word (a field of one
-            // workgroup is at most 12 x 8 reads, so the words of sixteen workgroups add up without a carry between fields)
-            const int u = uw.used, ev = 2 * u, el = uw.has_la ? 2 * CW : 0, E = ev + ev + el + u + u;
+            // workgroup is at most 12 x 8 reads, so the words of 128 workgroups add up without a carry between fields)
+            // (of the lookahead votes only the columns the node's next window can use: twice its present allowance at most)
+            const int la_cols = mode_in == M_INIT ? CW : (2 * nh[wk.node].wcap < CW ? 2 * nh[wk.node].wcap : CW);
+            const int u = uw.used, ev = 2 * u, el = uw.has_la ? 2 * la_cols : 0, E = ev + ev + el + u + u;
             const int parts = P.n_blocks;
             int nsl = (int)blockDim.x / (E > 0 ? E : 1); nsl = nsl < 1 ? 1 : (nsl > parts ? parts : nsl);
             const int per = (parts + nsl - 1) / nsl;
@@ -1065,7 +1067,7 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                 const size_t b0 = (size_t)P.first_block;
                 if (c < ev || (c >= 2 * ev && c < 2 * ev + el)) {                              // 64-bit words of four fields
                     const bool exact = c < ev;
-                    const int e = exact ? (c / u) * (CW + 1) + c % u : c - 2 * ev;
+                    const int e = exact ? (c / u) * (CW + 1) + c % u : ((c - 2 * ev) / la_cols) * CW + (c - 2 * ev) % la_cols;
                     const unsigned long long* src = exact ? B.PV + e : B.PL + e;
                     const size_t stride = exact ? EV : EL;
                     unsigned long long sum = 0;
