@@ -1071,12 +1071,12 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                     const unsigned long long* src = exact ? B.PV + e : B.PL + e;
                     const size_t stride = exact ? EV : EL;
                     unsigned long long sum = 0;
-                    for (int c0 = m_lo; c0 < m_hi; c0 += 8) {
-                        unsigned long long v[8];
+                    for (int c0 = m_lo; c0 < m_hi; c0 += 16) {                               // sixteen loads in flight per thread
+                        unsigned long long v[16];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = c0 + q < m_hi ? src[(b0 + c0 + q) * stride] : 0ull;
+                        for (int q = 0; q < 16; ++q) v[q] = c0 + q < m_hi ? src[(b0 + c0 + q) * stride] : 0ull;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) sum += v[q];
+                        for (int q = 0; q < 16; ++q) sum += v[q];
                     }
                     uint32_t* dst = exact ? acc + e * 5 : acc + QSV + e * 4;
 #pragma unroll
@@ -1087,12 +1087,12 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                     else if (c < 2 * ev + el + u) { const int e = c - 2 * ev - el; src = B.PC + e; stride = EC; dst = acc + QSV + QSL + e; }
                     else { const int e = c - 2 * ev - el - u; src = B.PR + e; stride = EC; dst = acc + QSV + QSL + (CW + 1) + e; }
                     uint32_t sum = 0;
-                    for (int c0 = m_lo; c0 < m_hi; c0 += 8) {
-                        uint32_t v[8];
+                    for (int c0 = m_lo; c0 < m_hi; c0 += 16) {
+                        uint32_t v[16];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = c0 + q < m_hi ? src[(b0 + c0 + q) * stride] : 0u;
+                        for (int q = 0; q < 16; ++q) v[q] = c0 + q < m_hi ? src[(b0 + c0 + q) * stride] : 0u;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) sum += v[q];
+                        for (int q = 0; q < 16; ++q) sum += v[q];
                     }
                     if (sum) { if (nsl == 1) *dst = sum; else atomicAdd(dst, sum); }
                 }

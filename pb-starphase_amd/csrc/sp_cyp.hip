@@ -154,21 +154,39 @@ __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
         const double gb = __longlong_as_double((long long)__hip_atomic_load(global_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (!(partial_cost > gb)) {
             scored = 1;
-            double hw[K5_MAXH];
-            for (int h = 0; h < H; ++h) hw[h] = 0.0;
+            // per-haplotype coverage of this thread's pair, in LDS ([h][thread]: conflict-free): indexed by data, the array lived in scratch memory and
+            // every add was a dependent round trip there -- 1.6 us per read for the 210 pairs of a sample
+            extern __shared__ double k5_hw[];
+            double* const hw = k5_hw + threadIdx.x;
+#define HW(h) hw[(size_t)(h) * 256]
+            for (int h = 0; h < H; ++h) HW(h) = 0.0;
             unsigned long long read_combined_ed = 0;
+            // (the reads are taken in order -- the f64 sums below depend on it --, but what a read needs from memory does not depend on the sums: the
+            //  next read's seven words are on their way while this one is added up; a read used to cost four dependent round trips, 1.7 us)
+            struct ReadWords { int row0, row1; unsigned long long bi, bj, mi, mj, worst, opt; };
+            auto fetch = [&](int r) {
+                ReadWords w;
+                w.row0 = read_w_off[r]; w.row1 = read_w_off[r + 1];
+                w.bi = tab_best[(size_t)r * c.P + i]; w.bj = tab_best[(size_t)r * c.P + j];
+                w.mi = tab_mask[(size_t)r * c.P + i]; w.mj = tab_mask[(size_t)r * c.P + j];
+                w.worst = read_worst[r]; w.opt = read_optimum[r];
+                return w;
+            };
+            ReadWords nxt = c.R > 0 ? fetch(0) : ReadWords();
             for (int r = 0; r < c.R; ++r) {
-                const int row0 = read_w_off[r], wl = read_w_off[r + 1] - row0;
+                const ReadWords cur = nxt;
+                if (r + 1 < c.R) nxt = fetch(r + 1);
+                const int row0 = cur.row0, wl = cur.row1 - row0;
                 const double* ov = w_ov + (size_t)row0 * H;
                 // containment_score (chaining.rs:683-731): best window total over both chains, ties kept in visiting order (chain i's windows,
                 // then chain j's) -- from the per-chain tables
-                unsigned long long best_score = 2ull * read_worst[r];
+                unsigned long long best_score = 2ull * cur.worst;
                 int n_best = 0;
-                const unsigned long long bi = tab_best[(size_t)r * c.P + i], bj = tab_best[(size_t)r * c.P + j];
-                const unsigned long long mi = tab_mask[(size_t)r * c.P + i], mj = tab_mask[(size_t)r * c.P + j];
+                const unsigned long long bi = cur.bi, bj = cur.bj;
+                const unsigned long long mi = cur.mi, mj = cur.mj;
                 if (bi < best_score) { best_score = bi; n_best = __popcll(mi); } else if (bi == best_score) n_best += __popcll(mi);
                 if (bj < best_score) { best_score = bj; n_best = __popcll(mj); } else if (bj == best_score) n_best += __popcll(mj);
-                const unsigned long long sc = best_score - read_optimum[r];
+                const unsigned long long sc = best_score - cur.opt;
                 const unsigned long long sum = read_combined_ed + sc;
                 read_combined_ed = sum < read_combined_ed ? 0xFFFFFFFFFFFFFFFFull : sum;        // saturating_add
                 const double split_frac = 1.0 / (double)n_best;
@@ -177,22 +195,22 @@ __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
                     unsigned long long m = (which ? bj : bi) == best_score ? (which ? mj : mi) : 0ull;
                     while (m) {
                         const int s = __builtin_ctzll(m); m &= m - 1;
-                        for (int x = 0; x < wl; ++x) { const int con = o[s + x]; hw[con] += split_frac * ov[(size_t)x * H + con]; }
+                        for (int x = 0; x < wl; ++x) { const int con = o[s + x]; HW(con) += split_frac * ov[(size_t)x * H + con]; }
                     }
                 }
             }
             const double ln_ed_penalty = (double)read_combined_ed * c.ln_ed;
             // get_multinomial_score (chaining.rs:854-903) + multinomial_ln_pmf (util/stats.rs:11-37)
             int nr = 0, total = 0; unsigned long long cov_sum = 0;
-            for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) { ++nr; total += cnt[h]; cov_sum += (unsigned long long)round(hw[h]); }
+            for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) { ++nr; total += cnt[h]; cov_sum += (unsigned long long)round(HW(h)); }
             bool valid = true; double mn = 0.0;
             if (nr == 0 || cov_sum == 0) {
                 valid = !c.normalize_all && chain_has_del[i] && chain_has_del[j];
             } else {
                 double coeff = cov_sum < (unsigned long long)ln_fact_n ? ln_fact[cov_sum] : ln_fact[ln_fact_n - 1];
-                for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) coeff -= ln_fact[(unsigned long long)round(hw[h])];
+                for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) coeff -= ln_fact[(unsigned long long)round(HW(h))];
                 double acc = 0.0;
-                for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) acc = acc + (double)((unsigned long long)round(hw[h])) * ln_p[(size_t)cnt[h] * ln_p_stride + total];
+                for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) acc = acc + (double)((unsigned long long)round(HW(h))) * ln_p[(size_t)cnt[h] * ln_p_stride + total];
                 mn = fabs(coeff + acc);
             }
             if (valid) {
@@ -392,7 +410,8 @@ extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p
     (void)hipMemsetAsync(d_bp, 0xFF, blocks * 8, ctx->stream);
     {
         ProfScope ps(ctx, "k5_pairs", n_pairs);
-        hipLaunchKernelGGL(k5_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pc, d_chains, d_clen, d_unexp, d_ninf, d_del, d_lasso, d_norm,
+        (void)hipFuncSetAttribute((const void*)k5_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)256 * H * sizeof(double)));
+        hipLaunchKernelGGL(k5_pair_kernel, dim3((unsigned)blocks), dim3(256), (size_t)256 * H * sizeof(double), ctx->stream, pc, d_chains, d_clen, d_unexp, d_ninf, d_del, d_lasso, d_norm,
                            d_rwo, d_ed, d_ov, d_tb, d_tm, d_opt, d_worst, d_lf, lf_n, d_lp, max_total + 1, d_gb, d_bs, d_bp, d_bc, d_be, d_gb + 1);
         if (hipGetLastError() != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "k5 launch failed");
     }
