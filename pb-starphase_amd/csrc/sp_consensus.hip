@@ -112,6 +112,7 @@ constexpr int CMAXP = 24;
 struct ConsParams {
     int n, first, first_block, n_blocks, rpw;   // reads; flattened index of local read 0; first workgroup; workgroups; reads per wave
     int first_cluster, n_clusters;              // clusters of CLUSTER consecutive workgroups (the last one may be smaller)
+    int acc_block;                              // problems of <= DIRECT_BLOCKS workgroups: the word block their workgroups ADD their words to (atomics), read and cleared by the control step
     int min_count, delta, et, allow_dual, window, cmp_len; double min_af;
     int cap, cs;                // longest consensus; bytes between the two consensuses of a node (cap rounded up to 16: children copy their parent 16 bytes at a time)
     uint8_t* C;                 // [NQ][2][cs] base codes per node; consensus 2 shares [0, split_at) with consensus 1
@@ -931,6 +932,23 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
     }
     __syncthreads();
     const UsedWords uw(mode, n, n_kids);
+    if (P.n_blocks <= DIRECT_BLOCKS) {
+        // a problem of few workgroups: every workgroup adds its words to the problem's one block (fire-and-forget atomics, zeros skipped; a 16-bit field of
+        // 128 workgroups cannot carry into the next); the control step then reads one block instead of up to 128 -- its sums were half of its time
+        const size_t blk = (size_t)P.acc_block;
+        for (int x = threadIdx.x; x < 2 * uw.used; x += blockDim.x) {
+            const int i = x / uw.used, e = i * (CW + 1) + x % uw.used;
+            const unsigned long long v = (&lv[0][0])[e]; const uint32_t w = (&le[0][0])[e];
+            if (v) atomicAdd(&B.PV[blk * 2 * (CW + 1) + e], v);
+            if (w) atomicAdd(&B.PE[blk * 2 * (CW + 1) + e], w);
+        }
+        if (uw.has_la) for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) { const unsigned long long v = (&ll[0][0])[x]; if (v) atomicAdd(&B.PL[blk * 2 * CW + x], v); }
+        for (int x = threadIdx.x; x < uw.used; x += blockDim.x) {
+            if (lc[x]) atomicAdd(&B.PC[blk * (CW + 1) + x], lc[x]);
+            if (lr[x]) atomicAdd(&B.PR[blk * (CW + 1) + x], lr[x]);
+        }
+        return;
+    }
     for (int x = threadIdx.x; x < 2 * uw.used; x += blockDim.x) {
         const int i = x / uw.used, e = i * (CW + 1) + x % uw.used;
         B.PV[(size_t)blockIdx.x * 2 * (CW + 1) + e] = (&lv[0][0])[e];
@@ -1053,48 +1071,29 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     if (mode_in != M_NONE) {
         const UsedWords uw(mode_in, n_in, mode_in == M_EXPAND ? wk.n_kids : 0);
         if (P.n_blocks <= DIRECT_BLOCKS) {
-            // the workgroups' words as they lie in memory: the exact and the lookahead votes are four 16-bit fields per 64-bit word (a field of one
-            // workgroup is at most 12 x 8 reads, so the words of 128 workgroups add up without a carry between fields)
-            // (of the lookahead votes only the columns the node's next window can use: twice its present allowance at most)
-            const int la_cols = mode_in == M_INIT ? CW : (2 * nh[wk.node].wcap < CW ? 2 * nh[wk.node].wcap : CW);
-            const int u = uw.used, ev = 2 * u, el = uw.has_la ? 2 * la_cols : 0, E = ev + ev + el + u + u;
-            const int parts = P.n_blocks;
-            int nsl = (int)blockDim.x / (E > 0 ? E : 1); nsl = nsl < 1 ? 1 : (nsl > parts ? parts : nsl);
-            const int per = (parts + nsl - 1) / nsl;
-            constexpr int EV = 2 * (CW + 1), EL = 2 * CW, EC = CW + 1;
-            for (int idx = tid; idx < E * nsl; idx += blockDim.x) {
-                const int c = idx % E, m_lo = (idx / E) * per, m_hi = m_lo + per < parts ? m_lo + per : parts;
-                const size_t b0 = (size_t)P.first_block;
-                if (c < ev || (c >= 2 * ev && c < 2 * ev + el)) {                              // 64-bit words of four fields
+            // the problem's one block of words (its workgroups added theirs to it): read and cleared for the next step.  The exact and the lookahead
+            // votes are four 16-bit fields per 64-bit word
+            const int u = uw.used, ev = 2 * u, el = uw.has_la ? 2 * CW : 0, E = ev + ev + el + u + u;
+            const size_t blk = (size_t)P.acc_block;
+            for (int c = tid; c < E; c += blockDim.x) {
+                if (c < ev || (c >= 2 * ev && c < 2 * ev + el)) {
                     const bool exact = c < ev;
-                    const int e = exact ? (c / u) * (CW + 1) + c % u : ((c - 2 * ev) / la_cols) * CW + (c - 2 * ev) % la_cols;
-                    const unsigned long long* src = exact ? B.PV + e : B.PL + e;
-                    const size_t stride = exact ? EV : EL;
-                    unsigned long long sum = 0;
-                    for (int c0 = m_lo; c0 < m_hi; c0 += 16) {                               // sixteen loads in flight per thread
-                        unsigned long long v[16];
+                    const int e = exact ? (c / u) * (CW + 1) + c % u : c - 2 * ev;
+                    unsigned long long* src = exact ? B.PV + blk * 2 * (CW + 1) + e : B.PL + blk * 2 * CW + e;
+                    const unsigned long long sum = *src;
+                    if (sum) {
+                        *src = 0ull;
+                        uint32_t* dst = exact ? acc + e * 5 : acc + QSV + e * 4;
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) v[q] = c0 + q < m_hi ? src[(b0 + c0 + q) * stride] : 0ull;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) sum += v[q];
+                        for (int f = 0; f < 4; ++f) dst[f] = (uint32_t)((sum >> (16 * f)) & 0xFFFFull);
                     }
-                    uint32_t* dst = exact ? acc + e * 5 : acc + QSV + e * 4;
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) { const uint32_t x = (uint32_t)((sum >> (16 * f)) & 0xFFFFull); if (x) { if (nsl == 1) dst[f] = x; else atomicAdd(&dst[f], x); } }
                 } else {
-                    const uint32_t* src; size_t stride; uint32_t* dst;
-                    if (c < 2 * ev) { const int cc = c - ev, e = (cc / u) * (CW + 1) + cc % u; src = B.PE + e; stride = EV; dst = acc + e * 5 + 4; }
-                    else if (c < 2 * ev + el + u) { const int e = c - 2 * ev - el; src = B.PC + e; stride = EC; dst = acc + QSV + QSL + e; }
-                    else { const int e = c - 2 * ev - el - u; src = B.PR + e; stride = EC; dst = acc + QSV + QSL + (CW + 1) + e; }
-                    uint32_t sum = 0;
-                    for (int c0 = m_lo; c0 < m_hi; c0 += 16) {
-                        uint32_t v[16];
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) v[q] = c0 + q < m_hi ? src[(b0 + c0 + q) * stride] : 0u;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) sum += v[q];
-                    }
-                    if (sum) { if (nsl == 1) *dst = sum; else atomicAdd(dst, sum); }
+                    uint32_t* src; uint32_t* dst;
+                    if (c < 2 * ev) { const int cc = c - ev, e = (cc / u) * (CW + 1) + cc % u; src = B.PE + blk * 2 * (CW + 1) + e; dst = acc + e * 5 + 4; }
+                    else if (c < 2 * ev + el + u) { const int e = c - 2 * ev - el; src = B.PC + blk * (CW + 1) + e; dst = acc + QSV + QSL + e; }
+                    else { const int e = c - 2 * ev - el - u; src = B.PR + blk * (CW + 1) + e; dst = acc + QSV + QSL + (CW + 1) + e; }
+                    const uint32_t sum = *src;
+                    if (sum) { *src = 0u; *dst = sum; }
                 }
             }
         } else {
@@ -1577,11 +1576,12 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     B.info = d_info; B.total = (int)total;
     B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * planes * total * CB);
     B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * planes * total);
-    B.PV = (unsigned long long*)sp_pool(ctx, "cons_pv", sizeof(unsigned long long) * (size_t)n_blocks * 2 * (CW + 1));
-    B.PE = (uint32_t*)sp_pool(ctx, "cons_pe", sizeof(uint32_t) * (size_t)n_blocks * 2 * (CW + 1));
-    B.PL = (unsigned long long*)sp_pool(ctx, "cons_pl", sizeof(unsigned long long) * (size_t)n_blocks * 2 * CW);
-    B.PC = (uint32_t*)sp_pool(ctx, "cons_pc", sizeof(uint32_t) * (size_t)n_blocks * (CW + 1));
-    B.PR = (uint32_t*)sp_pool(ctx, "cons_pr", sizeof(uint32_t) * (size_t)n_blocks * (CW + 1));
+    const size_t wblocks = (size_t)n_blocks + n_prob;         // the workgroups' word blocks + one block per problem its workgroups add to (acc_block)
+    B.PV = (unsigned long long*)sp_pool(ctx, "cons_pv", sizeof(unsigned long long) * wblocks * 2 * (CW + 1));
+    B.PE = (uint32_t*)sp_pool(ctx, "cons_pe", sizeof(uint32_t) * wblocks * 2 * (CW + 1));
+    B.PL = (unsigned long long*)sp_pool(ctx, "cons_pl", sizeof(unsigned long long) * wblocks * 2 * CW);
+    B.PC = (uint32_t*)sp_pool(ctx, "cons_pc", sizeof(uint32_t) * wblocks * (CW + 1));
+    B.PR = (uint32_t*)sp_pool(ctx, "cons_pr", sizeof(uint32_t) * wblocks * (CW + 1));
     B.Q = (uint32_t*)sp_pool(ctx, "cons_q", sizeof(uint32_t) * (size_t)n_clusters * QE);
 #ifdef SP_K8_TIMING
     B.dbg = (unsigned long long*)sp_pool(ctx, "cons_dbg", (size_t)SP_K8_DBG_LAUNCHES * SP_K8_DBG_READS * 8);
@@ -1604,6 +1604,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr;
         hp[p].C = d_C + c_at[p]; hp[p].work = d_work + p; hp[p].srch = d_srch + p; hp[p].nodes = d_nodes + (size_t)p * NQ;
         hp[p].la = d_la + (size_t)p * NQ * 2 * CW * 4; hp[p].processed = d_proc + proc_at[p];
+        hp[p].acc_block = n_blocks + (int)p;
         hp[p].out_cons = d_out + out_cons[p]; hp[p].out_res = (ConsRes*)(d_out + out_res) + p; hp[p].out_srch = (CSearch*)(d_out + out_srch) + p;
     }
     if constexpr (MAXP == 0) {
@@ -1626,6 +1627,14 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     if (!h_off.empty()) std::memcpy(h_in + in_off, h_off.data(), sizeof(int32_t) * h_off.size());
     SP_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, st));
     SP_HIP_CHECK(ctx, hipMemsetAsync(d_zero, 0, zero_bytes, st));
+    {   // the blocks the workgroups of small problems add their words to start at zero (the control step clears what it reads)
+        const size_t nb = (size_t)n_blocks, np = (size_t)n_prob;
+        SP_HIP_CHECK(ctx, hipMemsetAsync(B.PV + nb * 2 * (CW + 1), 0, sizeof(unsigned long long) * np * 2 * (CW + 1), st));
+        SP_HIP_CHECK(ctx, hipMemsetAsync(B.PE + nb * 2 * (CW + 1), 0, sizeof(uint32_t) * np * 2 * (CW + 1), st));
+        SP_HIP_CHECK(ctx, hipMemsetAsync(B.PL + nb * 2 * CW, 0, sizeof(unsigned long long) * np * 2 * CW, st));
+        SP_HIP_CHECK(ctx, hipMemsetAsync(B.PC + nb * (CW + 1), 0, sizeof(uint32_t) * np * (CW + 1), st));
+        SP_HIP_CHECK(ctx, hipMemsetAsync(B.PR + nb * (CW + 1), 0, sizeof(uint32_t) * np * (CW + 1), st));
+    }
     for (uint32_t p = 0; p < n_prob; ++p)
         if (setup[p].n) hipLaunchKernelGGL(cons_setup_kernel, dim3((setup[p].n + 255) / 256), dim3(256), 0, st, setup[p], d_info);
 
