@@ -1115,6 +1115,9 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     __syncthreads();
     const long long tk1 = wall_clock64();
     long long tk2 = tk1, tk3 = tk1;
+#ifdef SP_K8_SEARCH_TICKS
+    long long ts_pick = 0, ts_block = 0, ts_iters = 0;
+#endif
     if (tid < SP_WAVE) {
         // One wavefront runs the search.  Every lane reads the same LDS words (broadcast), so control flow is uniform; lane 0 writes,
         // and a wave-level fence separates its writes from the reads that follow.
@@ -1232,6 +1235,9 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         spw::wave_lds_sync();
         for (int guard = 0; ; ++guard) {
             if (guard > 100000) { if (lane == 0) wk.done = 1; break; }
+#ifdef SP_K8_SEARCH_TICKS
+            const long long ts0 = wall_clock64(); ts_iters += 1;
+#endif
             int xi = ss.inflight;
             if (xi < 0) {
                 // the best and the second best of the nodes that wait: lane k looks at node k
@@ -1254,34 +1260,47 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                 }
                 CNode& x = nh[xi];
                 if (ss.best_node >= 0 && bc >= ss.best_final) { if (lane == 0) wk.done = 1; break; }   // nothing that waits can beat (or precede) the complete node
-                const int L = bt, q = x.q, a = x.a;
                 // pops this node makes in a row: the first is decided; the following ones need the node to stay ahead of the second best,
-                // its lengths to be open (threshold, capacity per length) and stop at a pop that moves the threshold
-                const long long pops0 = ss.pops; const int wo = ss.wo_constraint;
-                const int jc = (int)((wo - 1 - (pops0 % wo)) % wo);                     // the pop with this index (0-based) makes pops a multiple of wo
-                const int linear = a - q;                                                // pops that only consume the tape
-                const int want = linear > 0 ? (linear < SP_WAVE ? linear : SP_WAVE) : 1;
-                bool can = lane < want && L + lane >= ss.threshold && proc[L + lane] < ss.per_size && lane <= jc;
-                if (can && lane > 0) {
-                    const long long cj = x.cost_at(q + lane);
-                    can = (sx2 < 0 || less(cj, L + lane, ss.next_id + lane - 1, sc2, st2, sid2)) && !(ss.best_node >= 0 && cj >= ss.best_final);
+                // its lengths to be open (threshold, capacity per length) and stop at a pop that moves the threshold.  A tape longer than the wave is
+                // consumed 64 columns at a time without looking for the best node again: the others have not moved, and the comparison a new look
+                // would make for the node's next pop is the one every further pop of a row has to pass anyway
+                const int linear0 = x.a - x.q;
+                bool again = false, freed = false;
+                int Lc = bt;
+                for (;;) {
+                    const int L = Lc, q = x.q, a = x.a;
+                    const long long pops0 = ss.pops; const int wo = ss.wo_constraint;
+                    const int jc = (int)((wo - 1 - (pops0 % wo)) % wo);                 // the pop with this index (0-based) makes pops a multiple of wo
+                    const int linear = a - q;                                            // pops that only consume the tape
+                    const int want = linear > 0 ? (linear < SP_WAVE ? linear : SP_WAVE) : 1;
+                    bool can = lane < want && L + lane >= ss.threshold && proc[L + lane] < ss.per_size && lane <= jc;
+                    if (can && (lane > 0 || again)) {
+                        const long long cj = x.cost_at(q + lane);
+                        can = (sx2 < 0 || less(cj, L + lane, ss.next_id + lane - 1, sc2, st2, sid2)) && !(ss.best_node >= 0 && cj >= ss.best_final);
+                    }
+                    const unsigned long long no = ~__ballot(can);
+                    const int m = no ? __builtin_ctzll(no) : SP_WAVE;
+                    if (m == 0) { if (!again) { if (lane == 0) node_free(xi); freed = true; } break; }   // shorter than the threshold / its length is full (a further chunk: just look again)
+                    if (lane < m) proc[L + lane] += 1;
+                    if (lane == 0) {
+                        ss.pops += m;
+                        if (L + m - 1 > ss.farthest) ss.farthest = L + m - 1;
+                        if (jc < m && ss.farthest > ss.threshold) ss.threshold = ss.farthest;
+                        if (linear > 0) { x.q = q + m; x.id = ss.next_id + m - 1; ss.next_id += m; }
+                    }
+                    spw::wave_lds_sync();
+                    if (!(linear > 0 && m == SP_WAVE && q + m < a)) break;
+                    again = true; Lc = L + m;
                 }
-                const unsigned long long no = ~__ballot(can);
-                const int m = no ? __builtin_ctzll(no) : SP_WAVE;
-                if (m == 0) { if (lane == 0) node_free(xi); spw::wave_lds_sync(); continue; }   // shorter than the threshold / its length is full
-                if (lane < m) proc[L + lane] += 1;
-                if (lane == 0) {
-                    ss.pops += m;
-                    if (L + m - 1 > ss.farthest) ss.farthest = L + m - 1;
-                    if (jc < m && ss.farthest > ss.threshold) ss.threshold = ss.farthest;
-                    if (linear > 0) { x.q = q + m; x.id = ss.next_id + m - 1; ss.next_id += m; }
-                }
-                spw::wave_lds_sync();
-                if (linear > 0) continue;                                                // verified columns of its tape: the node moved on (its one child each)
+                if (freed) { spw::wave_lds_sync(); continue; }
+                if (linear0 > 0) continue;                                               // verified columns of its tape: the node moved on (its one child each)
             } else if (lane == 0) ss.inflight = -1;
             spw::wave_lds_sync();
             // the node stands at the end of its tape and its pop is accounted for: the decision of that column
             int stop = 0, replay_of = -1;
+#ifdef SP_K8_SEARCH_TICKS
+            const long long ts1 = wall_clock64(); ts_pick += ts1 - ts0;
+#endif
             unsigned long long free_nodes = __ballot(lane < NQ && !nh[lane].used);
             if (lane == 0) {
                 CNode& x = nh[xi];
@@ -1353,6 +1372,9 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             }
             stop = __builtin_amdgcn_readfirstlane(stop); replay_of = __builtin_amdgcn_readfirstlane(replay_of);
             spw::wave_lds_sync();
+#ifdef SP_K8_SEARCH_TICKS
+            ts_block += wall_clock64() - ts1;
+#endif
             if (replay_of >= 0) {
                 const CNode& x = nh[replay_of];
                 for (int jq = lane; jq < x.a; jq += SP_WAVE) { wk.spec[0][jq] = x.spec[0][jq]; wk.spec[1][jq] = x.spec[1][jq]; }
@@ -1415,6 +1437,10 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
         }
     }
     if (tid == 0) { const long long tk4 = wall_clock64(); ss.ticks[0] += tk1 - tk0; ss.ticks[1] += tk2 - tk1; ss.ticks[2] += tk3 - tk2; ss.ticks[3] += tk4 - tk3; }
+#ifdef SP_K8_SEARCH_TICKS
+    // (variant: the search split into picking the node + tape consumption / the decision block / loop iterations x 100, in place of result, tail and load)
+    if (tid == 0) { ss.ticks[0] += 100 * ts_iters - (tk1 - tk0); ss.ticks[1] += ts_pick - (tk2 - tk1); ss.ticks[3] += ts_block - (wall_clock64() - tk3); }
+#endif
     __syncthreads();
     for (int x = tid; x < NQ * NODE_HEAD_WORDS; x += blockDim.x)
         ((uint32_t*)&P.nodes[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS] = ((const uint32_t*)&nh[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS];
