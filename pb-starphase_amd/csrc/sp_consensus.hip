@@ -468,6 +468,7 @@ template <class BT> __device__ __forceinline__ uint32_t block_word(const BT& B, 
 #define SP_K8_WRAMP0 64
 #endif
 constexpr int WRAMP0 = SP_K8_WRAMP0;           // first window of a node born in an expansion (most such nodes are dropped after a few columns: a 256-column window costs its slowest read 4 x as long)
+constexpr int BULK_MARGIN_PLACED = 2;  // the same right behind the column that placed the read (its states have only the catch-up's edits yet)
 constexpr int BULK_MARGIN = 8;         // edits a read's worse state must be behind the better one to go through a window ahead of it (a state that close may draw level)
 constexpr int DIRECT_BLOCKS = 128;      // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
 
@@ -741,16 +742,17 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
         // (its edit count after j pushes, 16 bits each, lies in the wave's placement scratch: a read with both states placed has no use for that)
         static_assert(sizeof(((ActScratch*)nullptr)->rcache) >= 2 * (CW + 1), "edit-count profile");
         uint16_t* const ewp = reinterpret_cast<uint16_t*>(act[wave].rcache);
-        auto bulk_push = [&](Dwfa& d, int i, const ConsAccess& cacc, int Tl0, int cols, bool record) -> bool {
+        auto bulk_push = [&](Dwfa& d, int i, const ConsAccess& cacc, int Tl0, int cols, int jbase) -> bool {   // jbase >= 0: the counts go to ewp[jbase ..]
             auto ext = extender(cacc, i);
             const int k = lane - CH, span = Tl0 + cols;
             int reached = Tl0;
-            if (record && lane == 0) ewp[0] = (uint16_t)d.e;
+            const bool record = jbase >= 0;
+            if (record && lane == 0) ewp[jbase] = (uint16_t)d.e;
             for (;;) {
                 ext(d, span);
                 int far = spw::wave_max(d.H >= 0 ? d.H + k : -1);
                 far = far < span ? far : span;
-                if (record) for (int c = reached + 1 + lane; c <= far; c += SP_WAVE) ewp[c - Tl0] = (uint16_t)d.e;
+                if (record) for (int c = reached + 1 + lane; c <= far; c += SP_WAVE) ewp[jbase + c - Tl0] = (uint16_t)d.e;
                 reached = far > reached ? far : reached;
                 if (reached >= span) break;
                 const int c = d.H, up = spw::from_lower(d.H, SP_NEG), dn = spw::from_upper(d.H, SP_NEG);
@@ -765,18 +767,8 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             return true;
         };
         int bulk = -1;                                                       // the state that went ahead (0 / 1), none: -1
-        int wsave_H = 0, wsave_e = 0;                                        // its state at column T (c0 and flags do not change on the way)
-        if (mode == M_WINDOW && dualrun && go0 && go1 && n >= 8 && (d0.flags & F_ACTIVE) && (d1.flags & F_ACTIVE) &&
-            !((d0.flags | d1.flags) & (F_FINISHED | F_LOST)) && (d0.e >= d1.e + BULK_MARGIN || d1.e >= d0.e + BULK_MARGIN)) {
-            const int wi = d0.e > d1.e ? 0 : 1;
-            Dwfa& w = wi ? d1 : d0;
-            const int Tl0 = T - w.c0;
-            if ((!P.et || rv.n > Tl0 + n + CB) && w.e < 60000) {            // (early termination: a read that could end inside the window freezes at that column)
-                wsave_H = w.H; wsave_e = w.e;
-                if (bulk_push(w, wi, wi ? ca1 : ca0, Tl0, n, true)) { bulk = wi; w.e = wsave_e; }      // w.e follows the columns: its count after j pushes
-                else { w.H = wsave_H; w.e = wsave_e; }
-            }
-        }
+        int wsave_H = 0, wsave_e = 0, wsave_j = 0;                           // its state at the column it left from (c0 and flags do not change on the way)
+        int want_bulk = BULK_MARGIN;                                         // > 0: at the head of the loop, send the worse state ahead if it is that many edits behind
         int j = 0;
 #ifdef SP_K8_TIMING
         int slow_cols = 0, multi_tip = 0, zero_run = 0;
@@ -788,6 +780,22 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
 #define K8_T(acc) do { } while (0)
 #endif
         while (j < n) {
+            // (one place for it: at the start of the window, and behind the column that placed the read -- its wrong state would otherwise cost a slow
+            //  column every few bases until the window ends)
+            if (want_bulk > 0) {
+                const int margin = want_bulk; want_bulk = 0;
+                if (mode == M_WINDOW && dualrun && go0 && go1 && n - j >= 8 && (d0.flags & F_ACTIVE) && (d1.flags & F_ACTIVE) &&
+                    !((d0.flags | d1.flags) & (F_FINISHED | F_LOST)) && (d0.e >= d1.e + margin || d1.e >= d0.e + margin)) {
+                    const int wi = d0.e > d1.e ? 0 : 1;
+                    Dwfa& w = wi ? d1 : d0;
+                    const int Tl0 = T + j - w.c0;
+                    if ((!P.et || rv.n > Tl0 + (n - j) + CB) && w.e < 60000) {      // (early termination: a read that could end inside the window freezes at that column)
+                        wsave_H = w.H; wsave_e = w.e; wsave_j = j;
+                        if (bulk_push(w, wi, wi ? ca1 : ca0, Tl0, n - j, j)) { bulk = wi; w.e = wsave_e; }   // w.e follows the columns: its count after j pushes
+                        else { w.H = wsave_H; w.e = wsave_e; }
+                    }
+                }
+            }
             K8_T0();
             // A consensus whose state has ONE tip that keeps matching moves nothing but that tip: such a clean run is applied in one go
             // (the tip's position grows by m, the votes of the m columns are the m read bases behind it, one lane per column).
@@ -859,6 +867,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             slow_cols += 1;
 #endif
             const int before = read_cost(d0, d1, dualrun);
+            const int active_before = (d0.flags & F_ACTIVE) + (d1.flags & F_ACTIVE);
             if (bulk >= 0) {
                 // only the other state is pushed; the one that went ahead shows its count at the new column to the comparison in column()
                 Dwfa& w = bulk ? d1 : d0; const Dwfa& b = bulk ? d0 : d1;
@@ -868,7 +877,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
                     // the other state has caught up (or is no longer tracked): from this column on this one has a say.  The state as it stands at
                     // this column, from its copy
                     w.H = wsave_H; w.e = wsave_e;
-                    (void)bulk_push(w, bulk, bulk ? ca1 : ca0, T - w.c0, j + 1, false);
+                    (void)bulk_push(w, bulk, bulk ? ca1 : ca0, T + wsave_j - w.c0, j + 1 - wsave_j, -1);
                     bulk = -1;
                 }
             } else
@@ -880,6 +889,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             if (dualrun && go1 && bulk != 1) vote(d1, d0, dualrun, 1, T + j + 1, j + 1);
             K8_T(tb_vote);
             j += 1;
+            if (bulk < 0 && (d0.flags & F_ACTIVE) + (d1.flags & F_ACTIVE) != active_before) want_bulk = BULK_MARGIN_PLACED;   // a read placed in this column
         }
         // lookahead: the bases behind every tip (at most two tips per consensus speak) predict the columns after the window
 #pragma unroll
