@@ -303,6 +303,7 @@ struct ActScratch {             // per wave
     uint32_t rpack[ACT_READ / 16 + 2];
     uint32_t npack[ACT_READ / 16 + 2];
     uint8_t score[ACT_CONS];    // placement search: edits of the best occurrence per start position
+    const uint32_t* staged;     // the read whose first bases rcache / rpack / npack hold (both states of a read, and every child of an expansion, place the same read)
 #ifdef SP_K8_TIMING
     long long tk[4];            // ticks (100 MHz) spent in a placement: read staging, start search, consensus packing, catch-up
 #endif
@@ -337,7 +338,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
     const int ws = off - window > 0 ? off - window : 0;
     // the read's first 640 bases: one packed word (and N word) per lane from memory, the byte per base the search and the slow catch-up read
     // unpacked out of LDS (a base at a time from memory was ten dependent round trips)
-    {
+    if (A.staged != rv.w) {
         const int rwords0 = ((rv.n < ACT_READ ? rv.n : ACT_READ) + 15) >> 4;
         for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) { A.rpack[w] = w < rwords0 ? rv.w[w] : 0u; A.npack[w] = (rv.np && w < rwords0) ? rv.np[w] : 0u; }
         spw::wave_lds_sync();
@@ -345,6 +346,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             const uint32_t sh = (uint32_t)(x & 15) << 1;
             A.rcache[x] = ((A.npack[x >> 4] >> sh) & 1u) ? (uint8_t)4 : (uint8_t)((A.rpack[x >> 4] >> sh) & 3u);
         }
+        if (lane == 0) A.staged = rv.w;
     }
     spw::wave_lds_sync();
     auto rbc = [&](int h) { return h < ACT_READ ? (int)A.rcache[h] : read_base(rv, h); };
@@ -549,6 +551,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
 #endif
         const ReadInfo ri = B.info[g];
         ReadView rv; rv.w = ri.w; rv.np = ri.np; rv.n = ri.n;
+        if (lane == 0) act[wave].staged = nullptr;                   // (the placement scratch holds no read yet; the worse-state profile shares its bytes)
         Dwfa d0, d1;
         d0.H = SP_NEG; d0.e = 0; d0.c0 = 0; d0.flags = 0; d1 = d0;
         if (mode == M_INIT) {
