@@ -455,7 +455,23 @@ def main():
     locus = synth.Chr22Locus(cfg, gene_def, seed=3)
     cdb = pkg.ffi.CypDb(ctx, cfg, gene_def, locus.sequence, locus.start)
     scen = cr.scenarios(locus)
-    group = shard.make_group(ctx, pkg.ffi, backend=backend, device=coll_dev) if world > 1 else None      # sp_group: RCCL through the library
+    group, gather_via = None, "single rank"
+    if world > 1:
+        # sp_group: RCCL through the library (sp_gather_results).  Should the library's communicator not come up on this node, every rank falls back to the
+        # torch process group together (the decision is agreed on with one all-reduce) and the line says which path gathered
+        try:
+            group = shard.make_group(ctx, pkg.ffi, backend=backend, device=coll_dev)
+            ok_here = 1
+        except Exception as e:
+            print(f"rank {rank}: sp_group_create failed ({e}); gathering through torch.distributed instead", file=sys.stderr, flush=True)
+            group, ok_here = None, 0
+        flag = torch.tensor([ok_here], dtype=torch.int32, device=coll_dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if group is not None and hasattr(group, "close") and not isinstance(group, shard.TorchGroup):
+                group.close()
+            group = shard.TorchGroup(coll_dev)
+        gather_via = "torch.distributed" if isinstance(group, shard.TorchGroup) else "sp_gather_results (librccl)"
 
     def barrier():
         if world > 1:
@@ -476,7 +492,7 @@ def main():
             out = {"metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)", "value": line["value"], "unit": "reads/s", "n_gpus": world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": line["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                    "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
-                   "config": {"workload": line["workload"], "samples": line["samples"], "parallelism": f"samples sharded over {world} GPU(s), one sp_gather_results (RCCL all-gather) per pass"
+                   "config": {"workload": line["workload"], "samples": line["samples"], "parallelism": f"samples sharded over {world} GPU(s), one all-gather of the call records per pass through {gather_via}"
                               if backend == "nccl" else f"samples sharded over {world} rank(s) on shared devices, gather through torch.distributed ({backend})"},
                    "cohort": line, "roofline": None, "cpu_baseline": None,
                    "note": "strong scaling: the cohort's work is fixed, every rank owns samples / N of it; the N = 1 figure for the same cohort is `legs.cohort` of the N = 1 line"}
