@@ -1092,14 +1092,22 @@ extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* 
     // 2. consensus inputs (caller.rs:176-245): max_missing_consensus_frac = 0.5, offset window +-50
     std::vector<uint32_t> c_idx; std::vector<int32_t> c_start, c_len, boff, hoff, seeds; std::vector<uint32_t> c_hit;
     std::vector<std::string> guides(pr->templates->n);
+    std::vector<std::vector<int32_t>> run_of(pr->templates->n);          // sp_hpc_pos of every position of a template, built once (a scan per hit was 1 ms of a 2,000-read sample)
     for (uint32_t h = 0; h < hits.size(); ++h) {
         const sp_region_hit& q = hits[h];
         if (cyp_score(q.seq_len, q.nm, q.unmapped, true) > 0.5) continue;
         c_idx.push_back((uint32_t)q.read); c_start.push_back(q.start); c_len.push_back(q.end - q.start); c_hit.push_back(h);
         boff.push_back(q.clip_start == 0 ? -1 : q.clip_start + 50);
         std::string& guide = guides[(size_t)q.template_idx];                                             // (decoded once per template, not once per hit)
-        if (guide.empty()) guide = sp_seqset_decode(ctx, pr->templates, (uint32_t)q.template_idx);
-        const int32_t hp = (int32_t)sp_hpc_pos(guide.data(), guide.size(), (uint64_t)q.clip_start);       // hpc_with_guide (homopolymers.rs:53-64)
+        std::vector<int32_t>& runs = run_of[(size_t)q.template_idx];
+        if (guide.empty()) {
+            guide = sp_seqset_decode(ctx, pr->templates, (uint32_t)q.template_idx);
+            runs.resize(guide.size() + 1);
+            int32_t r = -1;
+            for (size_t x = 0; x < guide.size(); ++x) { if (x == 0 || guide[x] != guide[x - 1]) ++r; runs[x] = r; }
+            runs[guide.size()] = r + 1;                                                                  // (a position behind the end: the number of runs)
+        }
+        const int32_t hp = q.clip_start < 0 ? 0 : runs[std::min<size_t>((size_t)q.clip_start, guide.size())];   // sp_hpc_pos: hpc_with_guide (homopolymers.rs:53-64)
         hoff.push_back(hp == 0 ? -1 : hp + 50);
         int seed = -1;
         switch (pr->template_type[q.template_idx]) { case SP_CYP_DELETION: seed = 0; break; case SP_CYP_REP6: seed = 1; break; case SP_CYP_REP7: seed = 2; break;
