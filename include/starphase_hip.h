@@ -564,7 +564,7 @@ typedef struct {
     int32_t allow_early_termination;
     int32_t allow_dual;
     int32_t offset_window;             /* 400 */
-    int32_t offset_compare_length;     /* 50 (at most 64) */
+    int32_t offset_compare_length;     /* 50 for HLA; sp_cyp_diplotype uses 64 (see sp_cyp.hip).  At most 128; at most 64 with an offset_window above 512 */
     double  min_af;                    /* 0.10 */
     int32_t max_queue_size;            /* 20    CdwfaConfig::max_queue_size, set by dwfa_config_from_cli (src/hla/caller.rs:1110) */
     int32_t max_capacity_per_size;     /* 10    CdwfaConfig::max_capacity_per_size (:1111) */

@@ -295,6 +295,51 @@ __device__ __noinline__ int find_start_diag(int pc, int L_, int M_, int off_, in
     return (int)(key & ((1ull << 22) - 1));
 }
 
+// the same search for patterns of 65 .. 128 bases (the reference's CYP2D6 caller compares 100): two rows per lane, lane l holding rows 2l + 1 and 2l + 2.
+// The upper row takes its neighbours from the lane's own lower row (one and two steps ago), the lower row from the lane below's upper row (DPP); the two
+// rows of a lane stand one text column apart, so the upper row's text base is the lower row's of the step before.  pa / pb: the pattern bases of the two rows.
+__device__ __noinline__ int find_start_diag2(int pa, int pb, int L_, int M_, int off_, int W_, int lane, const uint32_t* tr_, uint8_t* score_) {
+    const int L = __builtin_amdgcn_readfirstlane(L_), M = __builtin_amdgcn_readfirstlane(M_), off = __builtin_amdgcn_readfirstlane(off_), W = __builtin_amdgcn_readfirstlane(W_);
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    spw::lds_cu32* tr = (spw::lds_cu32*)(uintptr_t)spw::lds_addr(tr_);
+    lds_u8* score = (lds_u8*)(uintptr_t)spw::lds_addr(reinterpret_cast<const uint32_t*>(score_));
+    const int ia = 2 * lane + 1, ib = ia + 1;                                // this lane's rows
+    int a1 = ia, a2 = ia, b1 = ib, b2 = ib;                                  // their values one and two steps ago
+    uint32_t tw = tr[0], tw_next = tw;
+    int t_prev = 0;                                                          // the text base of row ia's column one step ago = row ib's column now
+    for (int d = 1; d <= L + M; ++d) {
+        const int ja = d - ia, jb = ja - 1;                                  // the columns of the two rows in this step
+        const int up_a = spw::from_lower(b1, 0), diag_a = spw::from_lower(b2, 0);     // row ia - 1 (the lane below's upper row; row 0 is all zeros) at columns ja and ja - 1
+        if (ja >= 1 && ((ja - 1) & 15) == 0) tw = tw_next;
+        int cur_a = ia, cur_b = ib, tc = 0;
+        if (ja >= 1 && ja <= M) {
+            tc = (int)((tw >> (((ja - 1) & 15) << 1)) & 3u);
+            const int x = diag_a + (pa != tc ? 1 : 0), y = (up_a < a1 ? up_a : a1) + 1;
+            cur_a = x < y ? x : y;
+            if (ia == L) score[ja - 1] = (uint8_t)cur_a;
+        }
+        if (jb >= 1 && jb <= M) {
+            const int x = a2 + (pb != t_prev ? 1 : 0), y = (a1 < b1 ? a1 : b1) + 1;       // row ia at columns jb - 1 and jb: two steps and one step ago
+            cur_b = x < y ? x : y;
+            if (ib == L) score[jb - 1] = (uint8_t)cur_b;
+        }
+        if (ja >= 0 && (ja & 15) == 0) tw_next = tr[ja >> 4];                // the word row ia starts in the next step
+        t_prev = tc;
+        a2 = a1; a1 = cur_a; b2 = b1; b1 = cur_b;
+    }
+    spw::wave_lds_sync();
+    const int centre = off - W / 2;
+    unsigned long long key = ~0ull;
+    for (int j = lane + 1; j <= M; j += SP_WAVE) {
+        const int p = off - j, dist = p > centre ? p - centre : centre - p;
+        const unsigned long long kk = ((unsigned long long)score[j - 1] << 44) | ((unsigned long long)dist << 22) | (unsigned long long)p;
+        key = kk < key ? kk : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
+    return (int)(key & ((1ull << 22) - 1));
+}
+
 constexpr int ACT_CONS = 512;   // consensus bases a wave packs while a late read catches up (offset_window + slack)
 constexpr int ACT_READ = 640;   // read bases it keeps (catch-up length + band + edits)
 struct ActScratch {             // per wave
@@ -374,7 +419,8 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             ACT_T(0);
             if (known) d.c0 = m_c0;
             else {
-                d.c0 = find_start_diag(lane < L ? rbc(L - 1 - lane) : 7, L, M, off, window, lane, A.cpack, A.score);
+                if (L <= SP_WAVE) d.c0 = find_start_diag(lane < L ? rbc(L - 1 - lane) : 7, L, M, off, window, lane, A.cpack, A.score);
+                else d.c0 = find_start_diag2(2 * lane + 1 <= L ? rbc(L - 2 * lane - 1) : 7, 2 * lane + 2 <= L ? rbc(L - 2 * lane - 2) : 7, L, M, off, window, lane, A.cpack, A.score);
                 if (lane < nw) mm->text[lane] = A.cpack[lane];
                 if (lane == 0) { mm->valid = 1; mm->M = M; mm->off = off; mm->c0 = d.c0; }
             }
@@ -1780,8 +1826,9 @@ static int32_t run_batch(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     for (uint32_t p = 0; p < n_prob; ++p) {
         const sp_cons_problem& q = probs[p]; sp_cons_output& o = outs[p];
         if (!q.reads || !o.cons1 || !o.cons2 || o.cap == 0 || !o.is_cons1 || !o.score1 || !o.score2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: null argument");
-        if (q.cfg.offset_compare_length > 64 || q.cfg.offset_compare_length < 0 || q.cfg.offset_window < 0 || q.cfg.min_count < 0)
-            return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: offset_compare_length must be in [0, 64]");
+        if (q.cfg.offset_compare_length > 128 || q.cfg.offset_compare_length < 0 || q.cfg.offset_window < 0 || q.cfg.min_count < 0 ||
+            (q.cfg.offset_compare_length > 64 && q.cfg.offset_window > ACT_CONS))
+            return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: offset_compare_length must be in [0, 128] (in [0, 64] with an offset_window above 512)");
         if (o.cap >= (1u << 22)) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must be below 4,194,304");
         if (q.reads->max_len >= 65535) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: sequences must be shorter than 65,535 bases");
         std::memset(&o.result, 0, sizeof o.result); o.result.split_at = -1; o.result.best_total = 1; o.status = SP_OK;

@@ -1123,7 +1123,10 @@ extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* 
     sp_cons_config cc{};
     cc.min_count = pr->min_consensus_count; cc.min_af = pr->min_consensus_fraction; cc.dual_max_ed_delta = pr->dual_max_ed_delta;
     cc.no_retry_ladder = ctx->cons_retry_ladder ? 0 : 1;
-    cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 100; cc.offset_compare_length = 64;      // the library compares at most 64 bases
+    cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 100; cc.offset_compare_length = 64;
+    // (caller.rs:145-160 asks for 100 bases in a window of 100 with offsets 50 behind the expected start: under THIS library's placement rule -- Sellers' search, the
+    //  whole pattern must fit between the start and the offset, what does not fit counts as edits -- a 100-base pattern never fits in front of a read that starts 50
+    //  bases before its offset and the search drifts to the far end of the window (measured: every real-shape sample splits into more than 16 groups); 64 bases do)
     const uint32_t n_in = raw.n;
     const sp_seqset* levels[2] = { &hpc, &raw };
     const int32_t* offs[2] = { hoff.data(), boff.data() };

@@ -176,10 +176,11 @@ def test_edge_cases(oracle, pkg, gpu_ctx):
     with pytest.raises(pkg.StarphaseError) as e:
         gpu_ctx.consensus(S, gpu_cfg(pkg, **kw), cap=50)
     assert e.value.code == 6
-    # offset_compare_length beyond the 64 bases the placement search supports
-    with pytest.raises(pkg.StarphaseError) as e:
-        gpu_ctx.consensus(S, gpu_cfg(pkg, offset_compare_length=100, **kw))
-    assert e.value.code == 1
+    # offset_compare_length beyond the 128 bases the placement search supports (64 with a window above 512)
+    for bad in (dict(offset_compare_length=129), dict(offset_compare_length=100, offset_window=600)):
+        with pytest.raises(pkg.StarphaseError) as e:
+            gpu_ctx.consensus(S, gpu_cfg(pkg, **dict(kw, **bad)))
+        assert e.value.code == 1
     # one read, two reads that disagree everywhere
     for rs in (reads[:1], ["ACGT" * 40, "TTGCA" * 30]):
         for two_pass in (False, True):
