@@ -39,8 +39,13 @@ if n_cyp:
     def gene_body():
         if rng.random() < 0.15:
             return locus.hybrid(str(rng.choice(hybrid_names))), "hybrid"
-        s = str(rng.choice(stars))
-        return locus.star_allele(s), s
+        for _ in range(100):
+            s = str(rng.choice(stars))
+            try:
+                return locus.star_allele(s), s
+            except AssertionError:                            # (a few database alleles list overlapping variants the simple generator cannot apply)
+                continue
+        raise RuntimeError("no star allele could be realised")
 
     def haplotype():
         u = rng.random()

@@ -34,6 +34,19 @@ def test_binding_matches_header(pkg):
         assert n in src, f"{n} has no ctypes binding"
 
 
+def test_rust_extern_block_is_complete_and_current():
+    """include/starphase_hip.rs -- the `extern "C"` block a Rust host (the reference's language) binds, INTEGRATION.md -- is generated from the header:
+    every declared function is in it, and it is the generator's output for the header as it stands"""
+    import subprocess
+    import sys
+    rs = open(os.path.join(ROOT, "include", "starphase_hip.rs")).read()
+    fns = set(re.findall(r"pub fn (sp_[a-z0-9_]+)\(", rs))
+    decl = set(declared_symbols())
+    assert decl <= fns, f"not in the Rust block: {sorted(decl - fns)}"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "rust_externs.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 def test_no_device_is_an_error_not_a_fallback(pkg):
     import torch
     if torch.cuda.is_available():
