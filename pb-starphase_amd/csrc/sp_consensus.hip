@@ -1733,6 +1733,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cons_control_kernel<MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)proc_lds));
     uint64_t pairs = 0;
     hm.mark("host:k8_prologue");
+    double t_launch = 0.0;                                              // host time inside the launch calls (sp_profile_get "host:k8_launch": several host threads share the runtime's launch path)
     {
         ProfScope ps(ctx, "cons_steps", total);
         // The host stays a few launch triples ahead of the device and never waits for it: the control kernel of a problem writes the number
@@ -1747,9 +1748,11 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         volatile uint32_t* prog = h_prog;
         bool finished = false;
         while (!finished) {
+            const auto tl0 = std::chrono::steady_clock::now();
             hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
             if (need_reduce) hipLaunchKernelGGL(cons_reduce_kernel<MAXP>, dim3((uint32_t)n_clusters * RSLICES), dim3(512), 0, st, B);
             hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, st, B);
+            t_launch += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
             ++pairs;
             uint64_t spins = 0;
             for (;;) {
@@ -1775,6 +1778,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     }
     SP_HIP_CHECK(ctx, hipGetLastError());
     hm.mark("host:k8_loop");
+    if (ctx->profiling) { auto& e = ctx->prof["host:k8_launch"]; e.ms += t_launch; e.launches += (uint32_t)(2 * pairs); }
     hipLaunchKernelGGL(cons_finalize_kernel<MAXP>, grid, block, 0, st, B, d_is1, d_sc, d_sc + total);
     SP_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     const uint8_t* h_is1 = h_out + out_is1; const int32_t* h_sc = (const int32_t*)(h_out + out_sc); const ConsRes* h_res = (const ConsRes*)(h_out + out_res);

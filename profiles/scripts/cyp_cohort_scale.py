@@ -29,5 +29,6 @@ for streams in (1, 2, 4, 6, 8):
     db.diplotype_cohort(sets[:2 * streams])
     ctx.profile_reset()
     t0 = time.perf_counter(); out = db.diplotype_cohort(sets); dt = time.perf_counter() - t0
-    host = {k: round(ctx.profile_get("host:" + k)[0], 1) for k in ("cyp_regions", "cyp_segments", "cyp_consensus", "cyp_merge", "cyp_typing", "cyp_weights", "cyp_chains", "cyp_chain_pair")}
+    host = {k: round(ctx.profile_get("host:" + k)[0], 1) for k in ("cyp_regions", "cyp_segments", "cyp_consensus", "cyp_merge", "cyp_typing", "cyp_weights", "cyp_chains", "cyp_chain_pair", "k8_loop", "k8_launch")}
+    host["k8_launches"] = int(ctx.profile_get("host:k8_launch")[1])
     print(f"{streams} stream(s): {N} samples in {dt*1e3:.0f} ms = {dt*1e3/N:.1f} ms per sample, ok {ok([o[0] for o in out])}/{N}; host ms summed over streams {host}", flush=True)
