@@ -627,6 +627,16 @@ typedef struct {
 int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* problem, uint32_t max_groups, uint32_t cap,
                               uint32_t* n_groups, int32_t* group_of, char* cons);
 
+/* Several multi-way consensus problems (the samples of a cohort) in lockstep: what sp_consensus_priority does for each, with all open groups of all
+ * problems of a round in the same launches.  status: SP_OK, or why this job alone could not be solved (SP_ERR_CAPACITY: more groups than max_groups). */
+typedef struct sp_priority_job {
+    const sp_priority_problem* problem;
+    uint32_t max_groups, cap;
+    uint32_t* n_groups; int32_t* group_of; char* cons;      /* as the arguments of sp_consensus_priority */
+    int32_t status;
+} sp_priority_job;
+int32_t sp_consensus_priority_many(sp_ctx* ctx, uint32_t n_jobs, sp_priority_job* jobs);
+
 /* ------------------------------------------------------------------ one HLA gene, reads to diplotype
  * The gene loop of diplotype_hla_batch (src/hla/caller.rs:642-1040) on top of K1 / K8 / K2, without I/O and debug artefacts:
  * the realigned segments of `gene` (realign[r].status == 0, in input order = qname order) are cut out of the packed reads and

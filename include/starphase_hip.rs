@@ -343,6 +343,16 @@ pub struct sp_priority_problem {
     pub cfg: sp_cons_config,
 }
 #[repr(C)]
+pub struct sp_priority_job {
+    pub problem: *const sp_priority_problem,
+    pub max_groups: u32,
+    pub cap: u32,
+    pub n_groups: *mut u32,
+    pub group_of: *mut i32,
+    pub cons: *mut c_char,
+    pub status: i32,
+}
+#[repr(C)]
 pub struct sp_hla_call_config {
     pub min_consensus_count: i32,
     pub dual_max_ed_delta: i32,
@@ -558,6 +568,7 @@ extern "C" {
     pub fn sp_consensus(ctx: *mut sp_ctx, reads: *const sp_seqset, read_idx: *const u32, n: u32, offsets: *const i32, cfg: *const sp_cons_config, cons1: *mut c_char, cons2: *mut c_char, cap: u32, is_cons1: *mut u8, score1: *mut i32, score2: *mut i32, result: *mut sp_cons_result) -> i32;
     pub fn sp_consensus_dual(ctx: *mut sp_ctx, reads: *const sp_seqset, read_idx: *const u32, n: u32, offsets: *const i32, cfg: *const sp_cons_config, cons1: *mut c_char, cons2: *mut c_char, cap: u32, is_cons1: *mut u8, score1: *mut i32, score2: *mut i32, result: *mut sp_cons_result) -> i32;
     pub fn sp_consensus_priority(ctx: *mut sp_ctx, problem: *const sp_priority_problem, max_groups: u32, cap: u32, n_groups: *mut u32, group_of: *mut i32, cons: *mut c_char) -> i32;
+    pub fn sp_consensus_priority_many(ctx: *mut sp_ctx, n_jobs: u32, jobs: *mut sp_priority_job) -> i32;
     pub fn sp_hla_diplotype_gene(ctx: *mut sp_ctx, db: *const sp_hla_db, gene: u32, reads: *const sp_seqset, realign: *const sp_hla_realign, cfg: *const sp_hla_call_config, call: *mut sp_hla_call, cons1: *mut c_char, cons2: *mut c_char, cap: u32, is_cons1: *mut u8) -> i32;
     pub fn sp_hla_diplotype_genes(ctx: *mut sp_ctx, db: *const sp_hla_db, n_genes: u32, genes: *const u32, reads: *const sp_seqset, realign: *const sp_hla_realign, cfgs: *const sp_hla_call_config, calls: *mut sp_hla_call, cons: *mut c_char, cap: u32, is_cons1: *mut u8) -> i32;
     pub fn sp_hla_diplotype_cohort(ctx: *mut sp_ctx, db: *const sp_hla_db, n_samples: u32, read_sample: *const u32, n_genes: u32, genes: *const u32, reads: *const sp_seqset, realign: *const sp_hla_realign, cfgs: *const sp_hla_call_config, calls: *mut sp_hla_call, cons: *mut c_char, cap: u32, is_cons1: *mut u8) -> i32;

@@ -1899,47 +1899,60 @@ int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* r
     return rc;
 }
 
-int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* pr, uint32_t max_groups, uint32_t cap,
-                              uint32_t* n_groups, int32_t* group_of, char* cons) {
+// The multi-way consensus of SEVERAL independent problems (the samples of a cohort) in lockstep: every round all open groups of all problems
+// are one batch of two-way searches -- the launches a round costs are those of its slowest search, not their sum over the problems.  Each job
+// is what sp_consensus_priority does for it alone; a job that fails (more groups than max_groups, ...) carries its own status.
+int32_t sp_consensus_priority_many(sp_ctx* ctx, uint32_t n_jobs, sp_priority_job* jobs) {
     if (!ctx) return SP_ERR_INVALID_ARG;
-    if (!pr || !n_groups || !group_of || !cons || !pr->levels || pr->n_levels == 0 || cap < 2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: null argument");
-    for (uint32_t l = 0; l < pr->n_levels; ++l) if (!pr->levels[l] || pr->levels[l]->n != pr->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: every level needs one sequence per read");
-    *n_groups = 0;
-    const uint32_t n = pr->n, NL = pr->n_levels;
-    if (n == 0) return SP_OK;
-    const int half = pr->cfg.offset_window / 2;
+    if (n_jobs && !jobs) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority_many: null argument");
     struct Item { std::vector<uint32_t> members; uint32_t level; std::string key; int retry = 0; };
+    struct JobState { std::vector<Item> work, done; int half = 0; bool live = false; };
     // A search that gave up (no complete node: a mixture of more classes than a search holds consensuses can exhaust the queue and capacity
     // bounds) is run again with only the stronger differences as candidates; the split it finds is the split, the groups it leaves are solved
     // with the configured fraction again.
     static const double retry_min_af[4] = { 0.15, 0.20, 0.30, 0.40 };
-    // initial groups: unseeded reads first, then the seeds in ascending order
-    std::vector<Item> work, done;
-    {
+    std::vector<JobState> S(n_jobs);
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        sp_priority_job& J = jobs[j];
+        J.status = SP_OK;
+        const sp_priority_problem* pr = J.problem;
+        if (!pr || !J.n_groups || !J.group_of || !J.cons || !pr->levels || pr->n_levels == 0 || J.cap < 2) { J.status = SP_ERR_INVALID_ARG; continue; }
+        bool ok = true;
+        for (uint32_t l = 0; l < pr->n_levels; ++l) if (!pr->levels[l] || pr->levels[l]->n != pr->n) ok = false;
+        if (!ok) { J.status = SP_ERR_INVALID_ARG; continue; }
+        *J.n_groups = 0;
+        if (pr->n == 0) continue;
+        S[j].half = pr->cfg.offset_window / 2; S[j].live = true;
+        // initial groups: unseeded reads first, then the seeds in ascending order
         std::map<int32_t, std::vector<uint32_t>> by_seed;
-        for (uint32_t r = 0; r < n; ++r) by_seed[pr->seeds ? (pr->seeds[r] < 0 ? -1 : pr->seeds[r]) : -1].push_back(r);
+        for (uint32_t r = 0; r < pr->n; ++r) by_seed[pr->seeds ? (pr->seeds[r] < 0 ? -1 : pr->seeds[r]) : -1].push_back(r);
         uint32_t ord = 0;
-        for (auto& kv : by_seed) { Item it; it.members = kv.second; it.level = 0; it.key = std::string(1, (char)('a' + std::min<uint32_t>(ord, 25))) + std::to_string(ord); ++ord; work.push_back(std::move(it)); }
+        for (auto& kv : by_seed) { Item it; it.members = kv.second; it.level = 0; it.key = std::string(1, (char)('a' + std::min<uint32_t>(ord, 25))) + std::to_string(ord); ++ord; S[j].work.push_back(std::move(it)); }
     }
-    auto rebased = [&](const std::vector<uint32_t>& m, uint32_t level, std::vector<int32_t>& out) -> bool {
+    auto rebased = [&](uint32_t j, const std::vector<uint32_t>& m, uint32_t level, std::vector<int32_t>& out) -> bool {
+        const sp_priority_problem* pr = jobs[j].problem;
         const int32_t* src = pr->offsets ? pr->offsets[level] : nullptr;
         if (!src) return false;
         int64_t mn = INT64_MAX;
         for (uint32_t r : m) mn = std::min<int64_t>(mn, src[r] < 0 ? 0 : src[r]);
         out.resize(m.size());
-        for (size_t i = 0; i < m.size(); ++i) { const int64_t o = src[m[i]] < 0 ? 0 : src[m[i]]; out[i] = o == mn ? -1 : (int32_t)(o - mn + (mn == 0 ? 0 : half)); }
+        for (size_t i = 0; i < m.size(); ++i) { const int64_t o = src[m[i]] < 0 ? 0 : src[m[i]]; out[i] = o == mn ? -1 : (int32_t)(o - mn + (mn == 0 ? 0 : S[j].half)); }
         return true;
     };
-    while (!work.empty()) {
-        // one round: every open group as one two-way problem, all in lockstep
-        const size_t k = work.size();
+    for (;;) {
+        // one round: every open group of every job as one two-way problem, all in lockstep
+        std::vector<std::pair<uint32_t, size_t>> at;                           // (job, index in its work list)
+        for (uint32_t j = 0; j < n_jobs; ++j) if (S[j].live) for (size_t x = 0; x < S[j].work.size(); ++x) at.push_back({ j, x });
+        const size_t k = at.size();
+        if (k == 0) break;
         std::vector<sp_cons_problem> P(k); std::vector<sp_cons_output> O(k);
         std::vector<std::vector<int32_t>> offs(k), s1(k), s2(k); std::vector<std::vector<uint8_t>> is1(k); std::vector<std::vector<char>> text(k);
         for (size_t x = 0; x < k; ++x) {
-            const Item& it = work[x];
+            const uint32_t j = at[x].first; const Item& it = S[j].work[at[x].second];
+            const sp_priority_problem* pr = jobs[j].problem;
             const sp_seqset* set = pr->levels[it.level];
             int32_t longest = 0; for (uint32_t r : it.members) longest = std::max(longest, set->h_len[r]);
-            const bool has_off = rebased(it.members, it.level, offs[x]);
+            const bool has_off = rebased(j, it.members, it.level, offs[x]);
             int32_t far = 0; if (has_off) for (int32_t o : offs[x]) far = std::max(far, o);
             const uint32_t c = (uint32_t)longest + (uint32_t)far + 66;
             s1[x].resize(it.members.size()); s2[x].resize(it.members.size()); is1[x].resize(it.members.size()); text[x].assign((size_t)2 * c, 0);
@@ -1951,44 +1964,74 @@ int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* pr, uint32
         }
         const int32_t rc = sp_consensus_dual_batch(ctx, (uint32_t)k, P.data(), O.data());
         if (rc != SP_OK) return rc;
-        std::vector<Item> next;
+        std::vector<std::vector<Item>> next(n_jobs);
         for (size_t x = 0; x < k; ++x) {
-            Item& it = work[x];
+            const uint32_t j = at[x].first; Item& it = S[j].work[at[x].second];
+            const sp_priority_problem* pr = jobs[j].problem;
+            const uint32_t NL = pr->n_levels;
             // gave up: once more with the next stricter fraction of the ladder that is above the configured one
             if (O[x].result.gave_up && !pr->cfg.no_retry_ladder && !it.members.empty()) {
                 int step = it.retry;
                 while (step < 4 && retry_min_af[step] <= pr->cfg.min_af) ++step;
-                if (step < 4) { it.retry = step + 1; next.push_back(std::move(it)); continue; }
+                if (step < 4) { it.retry = step + 1; next[j].push_back(std::move(it)); continue; }
             }
             std::vector<uint32_t> g1, g2;
             for (size_t i = 0; i < it.members.size(); ++i) (is1[x][i] ? g1 : g2).push_back(it.members[i]);
             if (O[x].result.is_dual && !g1.empty() && !g2.empty()) {
-                Item a; a.members = std::move(g1); a.level = it.level; a.key = it.key + "0"; next.push_back(std::move(a));
-                Item b; b.members = std::move(g2); b.level = it.level; b.key = it.key + "1"; next.push_back(std::move(b));
-            } else if (it.level + 1 < NL) { it.level += 1; it.key += "_"; it.retry = 0; next.push_back(std::move(it)); }
-            else done.push_back(std::move(it));
+                Item a; a.members = std::move(g1); a.level = it.level; a.key = it.key + "0"; next[j].push_back(std::move(a));
+                Item b; b.members = std::move(g2); b.level = it.level; b.key = it.key + "1"; next[j].push_back(std::move(b));
+            } else if (it.level + 1 < NL) { it.level += 1; it.key += "_"; it.retry = 0; next[j].push_back(std::move(it)); }
+            else S[j].done.push_back(std::move(it));
         }
-        work.swap(next);
-        if (done.size() + work.size() > (size_t)n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: more groups than reads");
+        for (uint32_t j = 0; j < n_jobs; ++j) if (S[j].live) {
+            S[j].work.swap(next[j]);
+            if (S[j].done.size() + S[j].work.size() > (size_t)jobs[j].problem->n) { jobs[j].status = SP_ERR_INVALID_ARG; S[j].live = false; S[j].work.clear(); }
+        }
     }
-    std::sort(done.begin(), done.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
-    *n_groups = (uint32_t)done.size();
-    for (size_t g = 0; g < done.size(); ++g) for (uint32_t r : done[g].members) group_of[r] = (int32_t)g;
-    if (done.size() > max_groups) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_consensus_priority: more groups than max_groups");
-    // one consensus per emitted group and level
-    const size_t k = done.size() * NL;
-    std::vector<sp_cons_problem> P(k); std::vector<sp_cons_output> O(k);
-    std::vector<std::vector<int32_t>> offs(k), s1(k), s2(k); std::vector<std::vector<uint8_t>> is1(k); std::vector<std::vector<char>> spare(k);
-    for (size_t g = 0; g < done.size(); ++g) for (uint32_t l = 0; l < NL; ++l) {
-        const size_t x = g * NL + l; const Item& it = done[g];
-        const bool has_off = rebased(it.members, l, offs[x]);
-        s1[x].resize(it.members.size()); s2[x].resize(it.members.size()); is1[x].resize(it.members.size()); spare[x].assign(cap, 0);
-        P[x].reads = pr->levels[l]; P[x].read_idx = it.members.data(); P[x].n = (uint32_t)it.members.size(); P[x].offsets = has_off ? offs[x].data() : nullptr;
-        P[x].cfg = pr->cfg; P[x].cfg.allow_dual = 0;
-        std::memset(&O[x], 0, sizeof O[x]);
-        O[x].cons1 = cons + x * (size_t)cap; O[x].cons2 = spare[x].data(); O[x].cap = cap; O[x].is_cons1 = is1[x].data(); O[x].score1 = s1[x].data(); O[x].score2 = s2[x].data();
+    // one consensus per emitted group and level, all jobs in one batch
+    std::vector<sp_cons_problem> P; std::vector<sp_cons_output> O;
+    std::vector<std::vector<int32_t>> offs, s1, s2; std::vector<std::vector<uint8_t>> is1; std::vector<std::vector<char>> spare;
+    size_t k = 0;
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        if (!S[j].live) continue;
+        sp_priority_job& J = jobs[j];
+        auto& done = S[j].done;
+        std::sort(done.begin(), done.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
+        *J.n_groups = (uint32_t)done.size();
+        for (size_t g = 0; g < done.size(); ++g) for (uint32_t r : done[g].members) J.group_of[r] = (int32_t)g;
+        if (done.size() > J.max_groups) { J.status = SP_ERR_CAPACITY; S[j].live = false; continue; }
+        k += done.size() * J.problem->n_levels;
     }
+    P.resize(k); O.resize(k); offs.resize(k); s1.resize(k); s2.resize(k); is1.resize(k); spare.resize(k);
+    size_t x = 0;
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        if (!S[j].live) continue;
+        sp_priority_job& J = jobs[j]; const sp_priority_problem* pr = J.problem; const uint32_t NL = pr->n_levels;
+        for (size_t g = 0; g < S[j].done.size(); ++g) for (uint32_t l = 0; l < NL; ++l, ++x) {
+            const Item& it = S[j].done[g];
+            const bool has_off = rebased(j, it.members, l, offs[x]);
+            s1[x].resize(it.members.size()); s2[x].resize(it.members.size()); is1[x].resize(it.members.size()); spare[x].assign(J.cap, 0);
+            P[x].reads = pr->levels[l]; P[x].read_idx = it.members.data(); P[x].n = (uint32_t)it.members.size(); P[x].offsets = has_off ? offs[x].data() : nullptr;
+            P[x].cfg = pr->cfg; P[x].cfg.allow_dual = 0;
+            std::memset(&O[x], 0, sizeof O[x]);
+            O[x].cons1 = J.cons + (g * NL + l) * (size_t)J.cap; O[x].cons2 = spare[x].data(); O[x].cap = J.cap; O[x].is_cons1 = is1[x].data(); O[x].score1 = s1[x].data(); O[x].score2 = s2[x].data();
+        }
+    }
+    if (k == 0) return SP_OK;
     return sp_consensus_batch(ctx, (uint32_t)k, P.data(), O.data());
+}
+
+int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* pr, uint32_t max_groups, uint32_t cap,
+                              uint32_t* n_groups, int32_t* group_of, char* cons) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    if (!pr || !n_groups || !group_of || !cons || !pr->levels || pr->n_levels == 0 || cap < 2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: null argument");
+    for (uint32_t l = 0; l < pr->n_levels; ++l) if (!pr->levels[l] || pr->levels[l]->n != pr->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: every level needs one sequence per read");
+    sp_priority_job J; J.problem = pr; J.max_groups = max_groups; J.cap = cap; J.n_groups = n_groups; J.group_of = group_of; J.cons = cons; J.status = SP_OK;
+    const int32_t rc = sp_consensus_priority_many(ctx, 1, &J);
+    if (rc != SP_OK) return rc;
+    if (J.status == SP_ERR_CAPACITY) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_consensus_priority: more groups than max_groups");
+    if (J.status == SP_ERR_INVALID_ARG) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: more groups than reads");
+    return J.status;
 }
 
 } // extern "C"

@@ -8,6 +8,8 @@
 #include <system_error>
 #include <thread>
 #include <atomic>
+#include <memory>
+#include <map>
 #include "sp_json.h"
 #include "sp_wfa.hip.h"
 #include <algorithm>
@@ -1073,24 +1075,40 @@ extern "C" int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* pr, const
     return sp_cyp_diplotype_detailed(ctx, pr, reads, call, consensus, cons_cap, nullptr);
 }
 
-extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, char* consensus, uint32_t cons_cap,
-                                             sp_cyp_region_variants* region_variants) {
-    if (!ctx) return SP_ERR_INVALID_ARG;
+namespace {
+
+// What a CYP2D6 call holds between its three parts: (a) regions of interest and the consensus inputs, (b) the multi-way consensus -- alone
+// (sp_consensus_priority) or in lockstep with the other samples of a cohort (sp_consensus_priority_many) --, (c) merge, typing, weights, chains.
+struct CypMid {
+    uint32_t R = 0;
+    std::vector<sp_region_hit> hits;
+    std::vector<uint32_t> c_idx, c_hit; std::vector<int32_t> c_start, c_len, boff, hoff, seeds;
+    sp_seqset raw, hpc;                                   // the segments (pooled buffers named after the call's segment prefix)
+    sp_cons_config cc{};
+    const sp_seqset* levels[2] = { nullptr, nullptr }; const int32_t* offs[2] = { nullptr, nullptr };
+    sp_priority_problem pp{};
+    uint32_t n_in = 0, cap = 0, n_groups = 0;
+    std::vector<int32_t> group_of; std::vector<char> text;
+    bool finished = false;                                // the call is complete after part (a) already (no reads)
+};
+
+int32_t cyp_part_a(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, sp_cyp_region_variants* region_variants, const char* seg_prefix, CypMid& m) {
     if (region_variants) std::memset(region_variants->has_variants, 0, sizeof region_variants->has_variants);
     if (!pr || !reads || !call || !pr->templates || !pr->template_type || !pr->template_deep || !pr->backbone) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_cyp_diplotype: null argument");
     (void)hipSetDevice(ctx->device);
     std::memset(call, 0, sizeof *call);
-    const uint32_t R = reads->n;
+    const uint32_t R = m.R = reads->n;
+    auto& hits = m.hits; auto& c_idx = m.c_idx; auto& c_hit = m.c_hit; auto& c_start = m.c_start; auto& c_len = m.c_len; auto& boff = m.boff; auto& hoff = m.hoff; auto& seeds = m.seeds;
+    sp_seqset& raw = m.raw; sp_seqset& hpc = m.hpc;
     HostMarks hm(ctx);
     // 1. regions of interest (caller.rs:126-139): max_missing_chain_frac = 0.5
-    std::vector<sp_region_hit> hits((size_t)R * 8 + 16); uint64_t nh = 0;
+    hits.assign((size_t)R * 8 + 16, sp_region_hit{}); uint64_t nh = 0;
     int32_t rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh);
     if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh); }
     if (rc != SP_OK) return rc;
     hits.resize(nh);
     hm.mark("host:cyp_regions");
     // 2. consensus inputs (caller.rs:176-245): max_missing_consensus_frac = 0.5, offset window +-50
-    std::vector<uint32_t> c_idx; std::vector<int32_t> c_start, c_len, boff, hoff, seeds; std::vector<uint32_t> c_hit;
     std::vector<std::string> guides(pr->templates->n);
     std::vector<std::vector<int32_t>> run_of(pr->templates->n);          // sp_hpc_pos of every position of a template, built once (a scan per hit was 1 ms of a 2,000-read sample)
     for (uint32_t h = 0; h < hits.size(); ++h) {
@@ -1114,31 +1132,35 @@ extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* 
                                                      case SP_CYP_SPACER: seed = 3; break; case SP_CYP_LINK_REGION: seed = 4; break; default: break; }
         seeds.push_back(seed);
     }
-    if (c_idx.empty()) { call->status = 1; return SP_OK; }                                                 // NO_READS (caller.rs:254-266)
-    sp_seqset raw, hpc;
-    rc = sp_make_segments(ctx, reads, c_idx, c_start, c_len, "cypc", &raw, &hpc);
+    if (c_idx.empty()) { call->status = 1; m.finished = true; return SP_OK; }                               // NO_READS (caller.rs:254-266)
+    rc = sp_make_segments(ctx, reads, c_idx, c_start, c_len, seg_prefix, &raw, &hpc);
     if (rc != SP_OK) return rc;
     hm.mark("host:cyp_segments");
-    // 3. multi-way consensus, homopolymer-compressed level first (caller.rs:162-270)
-    sp_cons_config cc{};
+    // 3. multi-way consensus, homopolymer-compressed level first (caller.rs:162-270): the problem
+    sp_cons_config& cc = m.cc;
     cc.min_count = pr->min_consensus_count; cc.min_af = pr->min_consensus_fraction; cc.dual_max_ed_delta = pr->dual_max_ed_delta;
     cc.no_retry_ladder = ctx->cons_retry_ladder ? 0 : 1;
     cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 100; cc.offset_compare_length = 64;
     // (caller.rs:145-160 asks for 100 bases in a window of 100 with offsets 50 behind the expected start: under THIS library's placement rule -- Sellers' search, the
     //  whole pattern must fit between the start and the offset, what does not fit counts as edits -- a 100-base pattern never fits in front of a read that starts 50
     //  bases before its offset and the search drifts to the far end of the window (measured: every real-shape sample splits into more than 16 groups); 64 bases do)
-    const uint32_t n_in = raw.n;
-    const sp_seqset* levels[2] = { &hpc, &raw };
-    const int32_t* offs[2] = { hoff.data(), boff.data() };
-    sp_priority_problem pp; pp.n_levels = 2; pp.n = n_in; pp.levels = levels; pp.offsets = offs; pp.seeds = seeds.data(); pp.cfg = cc;
-    const uint32_t cap = (uint32_t)raw.max_len + 1024;
-    std::vector<int32_t> group_of(n_in); uint32_t n_groups = 0;
-    std::vector<char> text((size_t)SP_CYP_MAXCONS * 2 * cap);
-    rc = sp_consensus_priority(ctx, &pp, SP_CYP_MAXCONS, cap, &n_groups, group_of.data(), text.data());
-    if (rc != SP_OK) return rc;
+    m.n_in = raw.n;
+    m.levels[0] = &hpc; m.levels[1] = &raw; m.offs[0] = hoff.data(); m.offs[1] = boff.data();
+    m.pp.n_levels = 2; m.pp.n = m.n_in; m.pp.levels = m.levels; m.pp.offsets = m.offs; m.pp.seeds = seeds.data(); m.pp.cfg = cc;
+    m.cap = (uint32_t)raw.max_len + 1024;
+    m.group_of.assign(m.n_in, 0); m.n_groups = 0;
+    m.text.assign((size_t)SP_CYP_MAXCONS * 2 * m.cap, 0);
+    return SP_OK;
+}
+
+int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, char* consensus, uint32_t cons_cap, sp_cyp_region_variants* region_variants, CypMid& m) {
+    const uint32_t R = m.R, n_in = m.n_in, cap = m.cap, n_groups = m.n_groups;
+    auto& hits = m.hits; auto& boff = m.boff; auto& group_of = m.group_of; auto& text = m.text;
+    sp_seqset& raw = m.raw; const sp_cons_config cc = m.cc;
+    int32_t rc = SP_OK;
+    HostMarks hm(ctx);
     std::vector<std::string> hpc_cons(n_groups), full_cons(n_groups);
     for (uint32_t g = 0; g < n_groups; ++g) { hpc_cons[g] = text.data() + (size_t)(2 * g) * cap; full_cons[g] = text.data() + (size_t)(2 * g + 1) * cap; }
-    hm.mark("host:cyp_consensus");
     // 4. merge_consensus_results (caller.rs:750-898): max_missing_typing_frac = 0.1, no forced assignment
     std::vector<Label> glabel;
     TypeCache typed;
@@ -1285,6 +1307,22 @@ extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* 
     return SP_OK;
 }
 
+} // namespace
+
+extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, char* consensus, uint32_t cons_cap,
+                                             sp_cyp_region_variants* region_variants) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    CypMid m;
+    int32_t rc = cyp_part_a(ctx, pr, reads, call, region_variants, "cypc", m);
+    if (rc != SP_OK || m.finished) return rc;
+    {
+        HostScope hs(ctx, "host:cyp_consensus");
+        rc = sp_consensus_priority(ctx, &m.pp, SP_CYP_MAXCONS, m.cap, &m.n_groups, m.group_of.data(), m.text.data());
+    }
+    if (rc != SP_OK) return rc;
+    return cyp_part_c(ctx, pr, reads, call, consensus, cons_cap, region_variants, m);
+}
+
 // The CYP2D6 calls of several samples (one GPU's share of a cohort): the samples are independent and each is a chain of launches that
 // wait for one another, so they are handed out to the context and its helper streams (sp_ctx_set_option "hla_split_genes" /
 // "hla_split_streams"), one host thread per stream for the length of the call.  Every call is the call sp_cyp_diplotype makes.
@@ -1301,14 +1339,41 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
     for (int x = 1; x < n_parts; ++x) { on[x] = sp_ctx_helper(ctx, x - 1); if (!on[x]) { n_parts = x; break; } }
     std::vector<int32_t> rcs(n_samples, SP_OK); std::vector<int> where(n_samples, 0);
     std::atomic<uint32_t> next(0);
+    // A stream takes a GROUP of samples at a time and keeps them in lockstep through the multi-way consensus (sp_consensus_priority_many): the launches of
+    // that stage -- two thirds of a sample's chain -- are then those of the group's slowest search, not their sum over its samples.  Regions, typing,
+    // weights and chains stay sample by sample.  Every call is the call sp_cyp_diplotype makes.
+    const uint32_t group = std::min<uint32_t>(64, std::max<uint32_t>(1, (n_samples + (uint32_t)n_parts - 1) / (uint32_t)n_parts));
     auto work = [&](int x) {
+        sp_ctx* c = on[x];
         for (;;) {
-            const uint32_t i = next.fetch_add(1);
-            if (i >= n_samples) break;
-            where[i] = x;
-            try { rcs[i] = sp_cyp_diplotype(on[x], pr, reads[i], &calls[i], consensus ? consensus + (size_t)i * SP_CYP_MAXCONS * cons_cap : nullptr, cons_cap); }
-            catch (const std::bad_alloc&) { rcs[i] = SP_ERR_OUT_OF_MEMORY; on[x]->err = "sp_cyp_diplotype: out of host memory"; }      // (an exception must not leave a thread, nor
-            catch (const std::exception& e) { rcs[i] = SP_ERR_INVALID_ARG; on[x]->err = std::string("sp_cyp_diplotype: ") + e.what(); }   // the caller while threads are joinable)
+            const uint32_t first = next.fetch_add(group);
+            if (first >= n_samples) break;
+            const uint32_t n = std::min<uint32_t>(group, n_samples - first);
+            std::vector<std::unique_ptr<CypMid>> mids(n);
+            std::vector<sp_priority_job> jobs; std::vector<uint32_t> job_of;
+            try {
+                for (uint32_t k = 0; k < n; ++k) {
+                    const uint32_t i = first + k;
+                    where[i] = x;
+                    mids[k].reset(new CypMid());
+                    const std::string prefix = "cypc" + std::to_string(k);
+                    rcs[i] = cyp_part_a(c, pr, reads[i], &calls[i], nullptr, prefix.c_str(), *mids[k]);
+                    if (rcs[i] != SP_OK || mids[k]->finished) continue;
+                    CypMid& m = *mids[k];
+                    sp_priority_job J; J.problem = &m.pp; J.max_groups = SP_CYP_MAXCONS; J.cap = m.cap; J.n_groups = &m.n_groups; J.group_of = m.group_of.data(); J.cons = m.text.data(); J.status = SP_OK;
+                    jobs.push_back(J); job_of.push_back(k);
+                }
+                int32_t rc_all = SP_OK;
+                if (!jobs.empty()) { HostScope hs(c, "host:cyp_consensus"); rc_all = sp_consensus_priority_many(c, (uint32_t)jobs.size(), jobs.data()); }
+                for (size_t q = 0; q < jobs.size(); ++q) {
+                    const uint32_t k = job_of[q], i = first + k;
+                    if (rc_all != SP_OK) { rcs[i] = rc_all; continue; }
+                    if (jobs[q].status != SP_OK) { rcs[i] = jobs[q].status; c->err = jobs[q].status == SP_ERR_CAPACITY ? "sp_consensus_priority: more groups than max_groups" : "sp_consensus_priority: more groups than reads"; continue; }
+                    rcs[i] = cyp_part_c(c, pr, reads[i], &calls[i], consensus ? consensus + (size_t)i * SP_CYP_MAXCONS * cons_cap : nullptr, cons_cap, nullptr, *mids[k]);
+                }
+            }
+            catch (const std::bad_alloc&) { for (uint32_t k = 0; k < n; ++k) rcs[first + k] = SP_ERR_OUT_OF_MEMORY; c->err = "sp_cyp_diplotype: out of host memory"; }      // (an exception must not leave a thread, nor
+            catch (const std::exception& e) { for (uint32_t k = 0; k < n; ++k) rcs[first + k] = SP_ERR_INVALID_ARG; c->err = std::string("sp_cyp_diplotype: ") + e.what(); }   // the caller while threads are joinable)
         }
     };
     std::thread beside[8]; bool started[8] = { false, false, false, false, false, false, false, false };

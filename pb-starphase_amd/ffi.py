@@ -125,6 +125,11 @@ class sp_priority_problem(C.Structure):
                 ("cfg", sp_cons_config)]
 
 
+class sp_priority_job(C.Structure):
+    _fields_ = [("problem", C.POINTER(sp_priority_problem)), ("max_groups", C.c_uint32), ("cap", C.c_uint32), ("n_groups", C.POINTER(C.c_uint32)),
+                ("group_of", C.c_void_p), ("cons", C.c_void_p), ("status", C.c_int32)]
+
+
 class sp_cyp_problem(C.Structure):
     _fields_ = [("templates", C.c_void_p), ("template_type", C.c_void_p), ("template_subtype", C.POINTER(C.c_char_p)), ("template_deep", C.c_void_p),
                 ("backbone", C.c_char_p), ("backbone_len", C.c_uint32),
@@ -271,6 +276,7 @@ def lib():
         "sp_cyp_diplotype_detailed": (i32, [vp, C.POINTER(sp_cyp_problem), vp, C.POINTER(sp_cyp_call), C.c_char_p, u32, C.POINTER(sp_cyp_region_variants)]),
         "sp_cyp_alleles_json": (i32, [C.POINTER(sp_cyp_problem), C.POINTER(sp_cyp_call), C.POINTER(sp_cyp_region_variants), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
         "sp_consensus_priority": (i32, [vp, C.POINTER(sp_priority_problem), u32, u32, C.POINTER(u32), vp, C.c_char_p]),
+        "sp_consensus_priority_many": (i32, [vp, u32, C.POINTER(sp_priority_job)]),
         "sp_hla_diplotype_gene": (i32, [vp, vp, u32, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, C.c_char_p, u32, vp]),
         "sp_hla_diplotype_genes": (i32, [vp, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
         "sp_hla_diplotype_cohort": (i32, [vp, vp, u32, vp, u32, vp, vp, vp, C.POINTER(sp_hla_call_config), C.POINTER(sp_hla_call), C.c_char_p, u32, vp]),
@@ -538,6 +544,31 @@ class Context:
         self.check(lib().sp_consensus_priority(self._h, C.byref(pr), max_groups, cap, C.byref(ng), _ptr(group_of), buf))
         text = lambda j: _cstr(buf, j * cap, cap)
         return group_of[:n].copy(), [[text(g * nl + l) for l in range(nl)] for g in range(ng.value)]
+
+    def consensus_priority_many(self, problems, max_groups=64):
+        """sp_consensus_priority_many: problems = [(levels, cfg, offsets, seeds)] in lockstep -> [(status, group_of, [[consensus per level] per group])]"""
+        keep, jobs = [], (sp_priority_job * max(1, len(problems)))()
+        for q, (levels, cfg, offsets, seeds) in enumerate(problems):
+            nl, n = len(levels), levels[0].n
+            cap = int(max(int(L.lengths.max()) if L.n else 0 for L in levels)) + 1024
+            lv = (C.c_void_p * nl)(*[L._h for L in levels])
+            of = (C.c_void_p * nl)()
+            arrs = []
+            for l in range(nl):
+                if offsets is not None and offsets[l] is not None:
+                    a = np.array([-1 if o is None else int(o) for o in offsets[l]], np.int32); arrs.append(a); of[l] = a.ctypes.data
+                else:
+                    of[l] = None
+            sd = np.array([-1 if x is None else int(x) for x in seeds], np.int32) if seeds is not None else None
+            pr = sp_priority_problem(nl, n, lv, of, (sd.ctypes.data if sd is not None else None), cfg)
+            ng = C.c_uint32(0); group_of = np.zeros(max(1, n), np.int32); buf = C.create_string_buffer(max_groups * nl * cap)
+            keep.append((lv, of, arrs, sd, pr, ng, group_of, buf, nl, n, cap))
+            jobs[q] = sp_priority_job(C.pointer(pr), max_groups, cap, C.pointer(ng), group_of.ctypes.data, C.cast(buf, C.c_void_p), 0)
+        self.check(lib().sp_consensus_priority_many(self._h, len(problems), jobs))
+        out = []
+        for q, (lv, of, arrs, sd, pr, ng, group_of, buf, nl, n, cap) in enumerate(keep):
+            out.append((jobs[q].status, group_of[:n].copy(), [[_cstr(buf, (g * nl + l) * cap, cap) for l in range(nl)] for g in range(ng.value)]))
+        return out
 
     def cyp_variant_states(self, seqs, backbone, var_pos, var_ref, var_alt):
         """sp_cyp_variant_states on a SeqSet -> (states [n_seqs][n_variants] uint8, placements sp_aln array)"""

@@ -159,6 +159,40 @@ def test_priority_consensus(oracle, pkg, gpu_ctx):
         assert g_cons[g][1] == want[next(iter(ts))]
 
 
+def test_priority_consensus_of_several_problems_in_lockstep(pkg, gpu_ctx):
+    """sp_consensus_priority_many (the samples of a cohort): every problem comes out as it does alone, a problem with too many groups fails alone"""
+    from pb_starphase_amd import synth
+    kw = dict(early_termination=True, dual=True, offset_window=100, offset_compare_length=64)
+    problems, alone = [], []
+    for seed, n_alleles, depth in ((41, 3, 8), (42, 1, 5), (43, 4, 7), (44, 2, 12)):
+        rng = np.random.default_rng(seed)
+        base = "".join(rng.choice(list("ACGT"), int(rng.integers(600, 1400))))
+        alleles = [base] + [synth.mutate(rng, base, int(rng.integers(3, 6)), int(rng.integers(0, 2)), int(rng.integers(0, 2))) for _ in range(n_alleles - 1)]
+        raw, offs, seeds = [], [], []
+        for seq in alleles:
+            for _ in range(depth):
+                clip = int(rng.integers(40, 200)) if rng.random() < 0.3 else 0
+                raw.append(synth.hifi_errors(rng, seq[clip:])); offs.append(None if clip == 0 else clip + 50); seeds.append(None)
+        hpc = ["".join(c for i, c in enumerate(r) if i == 0 or r[i - 1] != c) for r in raw]
+        hoffs = [None if o is None else max(1, int(o * 0.75)) for o in offs]
+        levels = [gpu_ctx.upload(hpc), gpu_ctx.upload(raw)]
+        problems.append((levels, gpu_cfg(pkg, **kw), [hoffs, offs], seeds))
+        alone.append(gpu_ctx.consensus_priority(levels, gpu_cfg(pkg, **kw), [hoffs, offs], seeds))
+    many = gpu_ctx.consensus_priority_many(problems)
+    assert [m[0] for m in many] == [0] * 4
+    for (st, group_of, cons), (g1, c1) in zip(many, alone):
+        assert group_of.tolist() == g1.tolist() and cons == c1
+    n_groups = [len(c) for _g, c in alone]
+    assert min(n_groups) == 1 and max(n_groups) >= 3
+    # max_groups 2: the problems with more groups fail alone (status 6), the others are solved as before
+    few = gpu_ctx.consensus_priority_many(problems, max_groups=2)
+    assert [f[0] for f in few] == [6 if k > 2 else 0 for k in n_groups] and 0 in [f[0] for f in few] and 6 in [f[0] for f in few]
+    for f, (g1, c1), k in zip(few, alone, n_groups):
+        if k <= 2:
+            assert f[1].tolist() == g1.tolist() and f[2] == c1
+    assert gpu_ctx.consensus_priority_many([]) == []
+
+
 def test_edge_cases(oracle, pkg, gpu_ctx):
     """empty inputs, no read at the start, room too small, bad configuration"""
     import ctypes as C
