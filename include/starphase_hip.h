@@ -64,7 +64,7 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * lowest latency for one call; set hla_split_genes to 0 when several samples are in flight on contexts of their own, where the streams
  * of the other samples already fill the gaps.  The calls are the same either way.  "cons_retry_ladder" (default 1): 0 makes sp_cyp_diplotype* run
  * its multi-way consensus without the retry of searches that give up (sp_cons_config.no_retry_ladder, see sp_consensus_priority).
- * "cyp_cohort_streams" (1..8, default 6): samples sp_cyp_diplotype_cohort keeps in flight (one stream and one host thread each).
+ * "cyp_cohort_streams" (1..8, default 6): streams sp_cyp_diplotype_cohort spreads its groups of samples over (one host thread each).
  * Unknown names: SP_ERR_INVALID_ARG. */
 int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value);
 
