@@ -115,6 +115,23 @@ __global__ __launch_bounds__(256) void k5_chain_read_kernel(int P, int R, int H,
     tab_best[id] = best; tab_mask[id] = mask;
 }
 
+// get_multinomial_score (chaining.rs:854-903) + multinomial_ln_pmf (util/stats.rs:11-37) of a pair: cnt(h) = copies of region h in the two chains, hw(h) = the
+// coverage the reads gave it
+template <typename Cnt, typename Hw>
+__device__ __forceinline__ double k5_multinomial(const PairConsts& c, Cnt cnt, Hw hw, const uint8_t* __restrict__ hap_norm, const double* __restrict__ ln_fact, int ln_fact_n,
+                                                 const double* __restrict__ ln_p, int ln_p_stride, bool both_have_deletion, bool& valid) {
+    const int H = c.H;
+    int nr = 0, total = 0; unsigned long long cov_sum = 0;
+    for (int h = 0; h < H; ++h) if (cnt(h) > 0 && hap_norm[h]) { ++nr; total += cnt(h); cov_sum += (unsigned long long)round(hw(h)); }
+    valid = true;
+    if (nr == 0 || cov_sum == 0) { valid = !c.normalize_all && both_have_deletion; return 0.0; }
+    double coeff = cov_sum < (unsigned long long)ln_fact_n ? ln_fact[cov_sum] : ln_fact[ln_fact_n - 1];
+    for (int h = 0; h < H; ++h) if (cnt(h) > 0 && hap_norm[h]) coeff -= ln_fact[(unsigned long long)round(hw(h))];
+    double acc = 0.0;
+    for (int h = 0; h < H; ++h) if (cnt(h) > 0 && hap_norm[h]) acc = acc + (double)((unsigned long long)round(hw(h))) * ln_p[(size_t)cnt(h) * ln_p_stride + total];
+    return fabs(coeff + acc);
+}
+
 // one thread = one unordered pair (i <= j)
 __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
                                                       const uint8_t* __restrict__ chains, const int32_t* __restrict__ chain_len,   // [P][maxlen]
@@ -202,19 +219,9 @@ __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
                 }
             }
             const double ln_ed_penalty = (double)read_combined_ed * c.ln_ed;
-            // get_multinomial_score (chaining.rs:854-903) + multinomial_ln_pmf (util/stats.rs:11-37)
-            int nr = 0, total = 0; unsigned long long cov_sum = 0;
-            for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) { ++nr; total += cnt[h]; cov_sum += (unsigned long long)round(HW(h)); }
-            bool valid = true; double mn = 0.0;
-            if (nr == 0 || cov_sum == 0) {
-                valid = !c.normalize_all && chain_has_del[i] && chain_has_del[j];
-            } else {
-                double coeff = cov_sum < (unsigned long long)ln_fact_n ? ln_fact[cov_sum] : ln_fact[ln_fact_n - 1];
-                for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) coeff -= ln_fact[(unsigned long long)round(HW(h))];
-                double acc = 0.0;
-                for (int h = 0; h < H; ++h) if (cnt[h] > 0 && hap_norm[h]) acc = acc + (double)((unsigned long long)round(HW(h))) * ln_p[(size_t)cnt[h] * ln_p_stride + total];
-                mn = fabs(coeff + acc);
-            }
+            bool valid = true;
+            const double mn = k5_multinomial(c, [&](int h) { return (int)cnt[h]; }, [&](int h) { return HW(h); }, hap_norm, ln_fact, ln_fact_n, ln_p, ln_p_stride,
+                                             chain_has_del[i] && chain_has_del[j], valid);
             if (valid) {
                 primary = ln_ed_penalty + mn + allele_expected_penalty + unexpected_chain_penalty + inferred_chain_penalty;    // chaining.rs:172-174
                 have = true; comp_lned = ln_ed_penalty; comp_mn = mn; comp_exp = allele_expected_penalty; comp_unexp = unexpected_chain_penalty;
@@ -245,6 +252,147 @@ __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
     } else if (threadIdx.x == 0 && s_pid[0] == 0xFFFFFFFFFFFFFFFFull) {
         blk_pid[blockIdx.x] = 0xFFFFFFFFFFFFFFFFull;
     }
+}
+
+// The same score with one WORKGROUP per pair, for the few pairs of an ordinary sample (tens to hundreds: a thread per pair walks the reads one after another, 1.1 us
+// each, 2.3 ms for 2,000 reads whatever the number of pairs).  What a read adds to the coverage of the regions -- (region, value) addends, in the order the walk
+// would add them -- is worked out for 256 reads at a time, a read per thread; then thread h adds up region h's addends read by read: the f64 sums see the same
+// operands in the same order.  A read with more than K5_ADDS addends is added up from memory at its turn.
+#define K5_TILE 256
+#define K5_ADDS 8
+#define K5_BLOCK_PAIRS 4096
+__global__ __launch_bounds__(K5_TILE) void k5_pair_block_kernel(PairConsts c,
+                                                      const uint8_t* __restrict__ chains, const int32_t* __restrict__ chain_len,
+                                                      const uint32_t* __restrict__ chain_unexp, const uint32_t* __restrict__ chain_inf,
+                                                      const uint8_t* __restrict__ chain_has_del,
+                                                      const uint8_t* __restrict__ hap_lasso, const uint8_t* __restrict__ hap_norm,
+                                                      const int32_t* __restrict__ read_w_off, const double* __restrict__ w_ov,
+                                                      const unsigned long long* __restrict__ tab_best, const unsigned long long* __restrict__ tab_mask,
+                                                      const uint64_t* __restrict__ read_optimum, const uint64_t* __restrict__ read_worst,
+                                                      const double* __restrict__ ln_fact, int ln_fact_n,
+                                                      const double* __restrict__ ln_p, int ln_p_stride,
+                                                      unsigned long long* __restrict__ global_best,
+                                                      double* __restrict__ blk_score, unsigned long long* __restrict__ blk_pid,
+                                                      double* __restrict__ blk_comp, unsigned long long* __restrict__ blk_ed,
+                                                      unsigned long long* __restrict__ n_scored) {
+    __shared__ double s_val[K5_TILE * K5_ADDS];
+    __shared__ unsigned long long s_con[K5_TILE];                             // the regions of a read's addends, a byte each (255: none)
+    __shared__ int s_nadd[K5_TILE];
+    __shared__ unsigned long long s_ed[K5_TILE];
+    __shared__ double s_hw[K5_MAXH];
+    __shared__ unsigned char s_cnt[K5_MAXH];
+    __shared__ double s_cost[3];
+    __shared__ int s_go;
+    const uint64_t pid = blockIdx.x;
+    const int H = c.H, tid = (int)threadIdx.x;
+    int i, j; k5_pair_from_id(pid, c.P, i, j);
+    const uint8_t* ci = chains + (size_t)i * c.maxlen; const uint8_t* cj = chains + (size_t)j * c.maxlen;
+    if (tid == 0) {
+        const int ni = chain_len[i], nj = chain_len[j];
+        for (int h = 0; h < H; ++h) s_cnt[h] = 0;
+        for (int x = 0; x < ni; ++x) s_cnt[ci[x]]++;
+        for (int x = 0; x < nj; ++x) s_cnt[cj[x]]++;
+        int unexpected_alleles = 0;                                           // count_unexpected_alleles (chaining.rs:794-819)
+        for (int h = 0; h < H; ++h) if (hap_lasso[h] && s_cnt[h] > 0) unexpected_alleles += s_cnt[h] - 1;
+        s_cost[0] = c.lasso * (double)unexpected_alleles;
+        s_cost[1] = (double)(c.ignore_limits ? 0u : chain_unexp[i] + chain_unexp[j]) * c.unexpected;
+        s_cost[2] = (double)(c.infer ? chain_inf[i] + chain_inf[j] : 0u) * c.inferred;
+        const double partial_cost = s_cost[0] + s_cost[1] + s_cost[2];
+        const double gb = __longlong_as_double((long long)__hip_atomic_load(global_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        s_go = !(partial_cost > gb);                                          // exact pruning (chaining.rs:457-464)
+        if (!s_go) blk_pid[pid] = 0xFFFFFFFFFFFFFFFFull;
+    }
+    __syncthreads();
+    if (!s_go) return;
+    struct ReadTerms { int row0, wl; unsigned long long mi, mj, sc; double split_frac; };
+    auto terms = [&](int r) {
+        ReadTerms t;
+        t.row0 = read_w_off[r]; t.wl = read_w_off[r + 1] - t.row0;
+        const unsigned long long bi = tab_best[(size_t)r * c.P + i], bj = tab_best[(size_t)r * c.P + j];
+        const unsigned long long mi = tab_mask[(size_t)r * c.P + i], mj = tab_mask[(size_t)r * c.P + j];
+        unsigned long long best_score = 2ull * read_worst[r];                 // containment_score (chaining.rs:683-731), as in k5_pair_kernel
+        int n_best = 0;
+        if (bi < best_score) { best_score = bi; n_best = __popcll(mi); } else if (bi == best_score) n_best += __popcll(mi);
+        if (bj < best_score) { best_score = bj; n_best = __popcll(mj); } else if (bj == best_score) n_best += __popcll(mj);
+        t.sc = best_score - read_optimum[r];
+        t.split_frac = 1.0 / (double)n_best;
+        t.mi = bi == best_score ? mi : 0ull; t.mj = bj == best_score ? mj : 0ull;
+        return t;
+    };
+    double acc = 0.0;                                                         // thread h: the coverage of region h
+    unsigned long long ed_part = 0;
+    for (int base = 0; base < c.R; base += K5_TILE) {
+        const int r = base + tid;
+        int nadd = 0;
+        if (r < c.R) {
+            const ReadTerms t = terms(r);
+            const unsigned long long sum = ed_part + t.sc;
+            ed_part = sum < ed_part ? 0xFFFFFFFFFFFFFFFFull : sum;            // saturating_add (the order does not matter: every term is >= 0)
+            const int total = (__popcll(t.mi) + __popcll(t.mj)) * t.wl;
+            unsigned long long cons = ~0ull;
+            if (total > K5_ADDS) nadd = -1;
+            else {
+                const double* ov = w_ov + (size_t)t.row0 * H;
+                for (int which = 0; which < 2; ++which) {
+                    const uint8_t* o = which ? cj : ci;
+                    unsigned long long m = which ? t.mj : t.mi;
+                    while (m) {
+                        const int s = __builtin_ctzll(m); m &= m - 1;
+                        for (int x = 0; x < t.wl; ++x) {
+                            const int con = o[s + x];
+                            cons = (cons & ~(0xFFull << (8 * nadd))) | ((unsigned long long)con << (8 * nadd));
+                            s_val[tid * K5_ADDS + nadd] = t.split_frac * ov[(size_t)x * H + con]; ++nadd;
+                        }
+                    }
+                }
+            }
+            s_con[tid] = cons;
+        }
+        s_nadd[tid] = nadd;
+        __syncthreads();
+        if (tid < H) {
+            const int lim = c.R - base < K5_TILE ? c.R - base : K5_TILE;
+#pragma unroll 2
+            for (int q = 0; q < lim; ++q) {
+                if (s_nadd[q] >= 0) {                                          // (the eight slots are read together; an empty slot names region 255)
+                    const unsigned long long cons = s_con[q];
+                    double v[K5_ADDS];
+#pragma unroll
+                    for (int a = 0; a < K5_ADDS; ++a) v[a] = s_val[q * K5_ADDS + a];
+#pragma unroll
+                    for (int a = 0; a < K5_ADDS; ++a) if ((int)((cons >> (8 * a)) & 0xFF) == tid) acc += v[a];
+                } else {
+                    const ReadTerms t = terms(base + q);
+                    const double* ov = w_ov + (size_t)t.row0 * H;
+                    for (int which = 0; which < 2; ++which) {
+                        const uint8_t* o = which ? cj : ci;
+                        unsigned long long m = which ? t.mj : t.mi;
+                        while (m) {
+                            const int s = __builtin_ctzll(m); m &= m - 1;
+                            for (int x = 0; x < t.wl; ++x) { const int con = o[s + x]; if (con == tid) acc += t.split_frac * ov[(size_t)x * H + con]; }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < H) s_hw[tid] = acc;
+    s_ed[tid] = ed_part;
+    __syncthreads();
+    if (tid != 0) return;
+    unsigned long long read_combined_ed = 0;
+    for (int q = 0; q < K5_TILE; ++q) { const unsigned long long sum = read_combined_ed + s_ed[q]; read_combined_ed = sum < read_combined_ed ? 0xFFFFFFFFFFFFFFFFull : sum; }
+    const double ln_ed_penalty = (double)read_combined_ed * c.ln_ed;
+    bool valid = true;
+    const double mn = k5_multinomial(c, [&](int h) { return (int)s_cnt[h]; }, [&](int h) { return s_hw[h]; }, hap_norm, ln_fact, ln_fact_n, ln_p, ln_p_stride,
+                                     chain_has_del[i] && chain_has_del[j], valid);
+    atomicAdd(n_scored, 1ull);
+    if (!valid) { blk_pid[pid] = 0xFFFFFFFFFFFFFFFFull; return; }
+    const double primary = ln_ed_penalty + mn + s_cost[0] + s_cost[1] + s_cost[2];                                        // chaining.rs:172-174
+    blk_score[pid] = primary; blk_pid[pid] = pid; blk_ed[pid] = read_combined_ed;
+    double* cp = blk_comp + (size_t)pid * 5; cp[0] = ln_ed_penalty; cp[1] = mn; cp[2] = s_cost[0]; cp[3] = s_cost[1]; cp[4] = s_cost[2];
+    atomicMin(global_best, (unsigned long long)__double_as_longlong(primary));
 }
 
 // =============================================================================================
@@ -384,7 +532,8 @@ extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p
     for (int cc = 1; cc <= max_cnt; ++cc) for (int t = cc; t <= max_total; ++t) ln_p[(size_t)cc * (max_total + 1) + t] = std::log((double)cc / (double)t);
 
     const uint64_t n_pairs = (uint64_t)P * ((uint64_t)P + 1) / 2;
-    const uint64_t blocks = (n_pairs + 255) / 256;
+    const bool block_per_pair = n_pairs <= K5_BLOCK_PAIRS;                  // (k5_pair_block_kernel)
+    const uint64_t blocks = block_per_pair ? n_pairs : (n_pairs + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return sp_fail(ctx, SP_ERR_TOO_LONG, "chain pair: too many chain pairs for one launch");
     PairConsts pc{H, P, maxlen, R, ignore ? 1 : 0, norm_all ? 1 : 0, infer ? 1 : 0, p->lasso_penalty, p->ln_ed_penalty, p->unexpected_chain_penalty,
                   p->inferred_edge_penalty, n_pairs};
@@ -412,9 +561,14 @@ extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p
     (void)hipMemsetAsync(d_bp, 0xFF, blocks * 8, ctx->stream);
     {
         ProfScope ps(ctx, "k5_pairs", n_pairs);
+        if (block_per_pair)
+            hipLaunchKernelGGL(k5_pair_block_kernel, dim3((unsigned)blocks), dim3(K5_TILE), 0, ctx->stream, pc, d_chains, d_clen, d_unexp, d_ninf, d_del, d_lasso, d_norm,
+                               d_rwo, d_ov, d_tb, d_tm, d_opt, d_worst, d_lf, lf_n, d_lp, max_total + 1, d_gb, d_bs, d_bp, d_bc, d_be, d_gb + 1);
+        else {
         (void)hipFuncSetAttribute((const void*)k5_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)256 * H * sizeof(double)));
         hipLaunchKernelGGL(k5_pair_kernel, dim3((unsigned)blocks), dim3(256), (size_t)256 * H * sizeof(double), ctx->stream, pc, d_chains, d_clen, d_unexp, d_ninf, d_del, d_lasso, d_norm,
                            d_rwo, d_ed, d_ov, d_tb, d_tm, d_opt, d_worst, d_lf, lf_n, d_lp, max_total + 1, d_gb, d_bs, d_bp, d_bc, d_be, d_gb + 1);
+        }
         if (hipGetLastError() != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "k5 launch failed");
     }
     std::vector<double> bs(blocks), bc(blocks * 5); std::vector<unsigned long long> bp(blocks), be(blocks);
@@ -504,6 +658,8 @@ static inline double cyp_score(int seq_len, int nm, int unmapped, bool penalize)
     return num / (double)len;
 }
 
+static void cyp_weights_from_alns(uint32_t C, const int32_t* cons_len, const uint8_t* allowed, uint32_t n_segments, const int32_t* seg_len, const std::vector<sp_aln>& alns,
+                                  uint64_t* ed, double* ov, uint8_t* kept);
 extern "C" int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensus, const uint8_t* allowed, const sp_seqset* segments,
                                           uint64_t* ed, double* ov, uint8_t* kept) {
     if (!ctx || !consensus || !segments || (consensus->n && !allowed) || (segments->n && (!ed || !ov || !kept))) return SP_ERR_INVALID_ARG;
@@ -511,16 +667,22 @@ extern "C" int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensu
     std::vector<sp_aln> alns;
     int rc = cyp_align_all(ctx, consensus, segments, 1, 0.0, 1, "k4_weight_cells", alns);
     if (rc) return rc;
-    const uint32_t C = consensus->n;
-    for (uint32_t s = 0; s < segments->n; ++s) {
-        const int seq_len = segments->h_len[s];
+    cyp_weights_from_alns(consensus->n, consensus->h_len.data(), allowed, segments->n, segments->h_len.data(), alns, ed, ov, kept);
+    return SP_OK;
+}
+
+// the host half of sp_cyp_weight_segments: alns[segment * C + consensus] are the placements of every segment on every consensus
+static void cyp_weights_from_alns(uint32_t C, const int32_t* cons_len, const uint8_t* allowed, uint32_t n_segments, const int32_t* seg_len, const std::vector<sp_aln>& alns,
+                                  uint64_t* ed, double* ov, uint8_t* kept) {
+    for (uint32_t s = 0; s < n_segments; ++s) {
+        const int seq_len = seg_len[s];
         double min_ed_frac = 1.0;
         for (uint32_t c = 0; c < C; ++c) {
             uint64_t& e = ed[(size_t)s * C + c]; double& o = ov[(size_t)s * C + c];
             e = (uint64_t)seq_len; o = 0.0;                                  // "deleted" default (chaining.rs:40-41)
             const sp_aln& al = alns[(size_t)s * C + c];
             if (!allowed[c] || !al.ok) continue;
-            const int con_len = consensus->h_len[c];
+            const int con_len = cons_len[c];
             const uint64_t nm = (uint64_t)al.nm, unmapped = (uint64_t)(seq_len - (al.b_end - al.b_start));
             const uint64_t match_score = nm + unmapped;
             const double overlap_score = 1.0 - (double)(al.a_start + (con_len - al.a_end)) / (double)con_len;
@@ -532,7 +694,6 @@ extern "C" int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensu
         }
         kept[s] = min_ed_frac <= 0.05 ? 1 : 0;                                // maximum_allowed_ed (chaining.rs:45,96-102)
     }
-    return SP_OK;
 }
 
 extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
@@ -672,22 +833,38 @@ __device__ __forceinline__ void k9_step(int (&c)[4], int x, const int (&r)[4], i
     // one base of the graph: diagonal d <-> k = k0 + d, read position i = off + k in front of the base
     const int next0 = spw::from_upper(c[0], K9_INF);                      // the lane above's first diagonal
     int nw[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int d = lane * 4 + j, i = off + k0 + d;
-        int v = K9_INF;
-        if (r[j] != 255 && c[j] < K9_INF) v = c[j] + ((r[j] < 4 && r[j] == x) ? 0 : 1);
-        const int up = j < 3 ? c[j + 1] : next0;
-        if (up < K9_INF && i + 1 >= 0 && i + 1 <= L && up + 1 < v) v = up + 1;
-        nw[j] = v;
-    }
-    // read bases that face nothing run up the column: only when some diagonal can be improved from the one below it
-    const int below0 = spw::from_lower(nw[3], K9_INF);
     bool need = false;
+    int below0;
+    if (off + k0 >= 0 && off + k0 + K9_DIAGS + 1 <= L) {
+        // every diagonal of the band faces a sequence base here and behind this graph base (all but the first and last columns of a job): the same
+        // recurrence without the range tests -- values above K9_INF only arise as K9_INF + 1 and are cut back before anyone compares them
+        const int xm = x < 4 ? x : 99;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int d = lane * 4 + j, i = off + 1 + k0 + d, prev = j ? nw[j - 1] : below0;
-        if (d > 0 && i >= 0 && i <= L && prev + 1 < nw[j]) need = true;
+        for (int j = 0; j < 4; ++j) {
+            const int up = j < 3 ? c[j + 1] : next0;
+            const int v = min(c[j] + (r[j] == xm ? 0 : 1), up + 1);
+            nw[j] = min(v, K9_INF);
+        }
+        below0 = spw::from_lower(nw[3], K9_INF);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int prev = j ? nw[j - 1] : below0; need |= prev + 1 < nw[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = lane * 4 + j, i = off + k0 + d;
+            int v = K9_INF;
+            if (r[j] != 255 && c[j] < K9_INF) v = c[j] + ((r[j] < 4 && r[j] == x) ? 0 : 1);
+            const int up = j < 3 ? c[j + 1] : next0;
+            if (up < K9_INF && i + 1 >= 0 && i + 1 <= L && up + 1 < v) v = up + 1;
+            nw[j] = v;
+        }
+        // read bases that face nothing run up the column: only when some diagonal can be improved from the one below it
+        below0 = spw::from_lower(nw[3], K9_INF);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = lane * 4 + j, i = off + 1 + k0 + d, prev = j ? nw[j - 1] : below0;
+            if (d > 0 && i >= 0 && i <= L && prev + 1 < nw[j]) need = true;
+        }
     }
     if (__ballot(need)) {
         // inside the lane, then across lanes (a prefix minimum of value - 4 * lane), then inside again
@@ -1170,6 +1347,31 @@ int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
     HostMarks hm(ctx);
     std::vector<std::string> hpc_cons(n_groups), full_cons(n_groups);
     for (uint32_t g = 0; g < n_groups; ++g) { hpc_cons[g] = text.data() + (size_t)(2 * g) * cap; full_cons[g] = text.data() + (size_t)(2 * g + 1) * cap; }
+    // (step 6's device half ahead of its turn: the placements of every region of interest on every group consensus do not depend on the typing, and unless step 4
+    //  merges groups the group consensuses ARE the final ones -- a helper stream places them while this one types, a 2,000-read sample's 3 ms under its 7 ms)
+    std::vector<uint32_t> a_idx(hits.size()); std::vector<int32_t> a_start(hits.size()), a_len(hits.size());
+    std::vector<uint32_t> seg_off(R + 1, 0);
+    for (size_t h = 0; h < hits.size(); ++h) { a_idx[h] = (uint32_t)hits[h].read; a_start[h] = hits[h].start; a_len[h] = hits[h].end - hits[h].start; seg_off[hits[h].read + 1] += 1; }
+    for (uint32_t r = 0; r < R; ++r) seg_off[r + 1] += seg_off[r];
+    struct Ahead { std::thread th; bool started = false; int32_t rc = -1; sp_seqset all, cons; std::vector<sp_aln> alns; } ahead;
+    struct JoinAhead { Ahead& a; ~JoinAhead() { if (a.started && a.th.joinable()) a.th.join(); } } join_ahead{ahead};
+    sp_ctx* beside = (!shared_types && n_groups && hits.size() * n_groups >= 2048) ? sp_ctx_helper(ctx, 0) : nullptr;     // (a cohort's streams are busy already)
+    if (beside) {
+        try {
+            ahead.th = std::thread([&]() {
+                try {
+                    (void)hipSetDevice(beside->device);
+                    int32_t r2 = sp_make_segments(beside, reads, a_idx, a_start, a_len, "cypa", &ahead.all, nullptr);
+                    std::string blob; std::vector<uint64_t> off(1, 0);
+                    for (const std::string& c : full_cons) { blob += c; off.push_back(blob.size()); }
+                    if (r2 == SP_OK) r2 = sp_seqset_make_small(beside, "cyp_final", blob.data(), off.data(), n_groups, true, &ahead.cons);
+                    if (r2 == SP_OK) r2 = cyp_align_all(beside, &ahead.cons, &ahead.all, 1, 0.0, 1, "k4_weight_cells", ahead.alns);
+                    ahead.rc = r2;
+                } catch (...) { ahead.rc = SP_ERR_OUT_OF_MEMORY; }
+            });
+            ahead.started = true;
+        } catch (const std::system_error&) { }
+    }
     // 4. merge_consensus_results (caller.rs:750-898): max_missing_typing_frac = 0.1, no forced assignment
     std::vector<Label> glabel;
     TypeCache own_types;
@@ -1191,6 +1393,7 @@ int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
     }
     if (cset.size() > SP_CYP_MAXCONS) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_cyp_diplotype: more than SP_CYP_MAXCONS consensus regions");
     std::vector<std::string> final_cons; std::vector<int32_t> seq_idx(n_in, -1);
+    std::vector<int32_t> final_group;                                     // the group a final consensus is the consensus of (-1: merged from several, or ignored)
     {
         std::vector<sp_cons_problem> P; std::vector<sp_cons_output> O; std::vector<size_t> slot;
         std::vector<std::vector<uint32_t>> members; std::vector<std::vector<int32_t>> moffs, ms1, ms2; std::vector<std::vector<uint8_t>> mis; std::vector<std::vector<char>> mtext;
@@ -1199,9 +1402,9 @@ int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
             const size_t ci = final_cons.size();
             std::vector<uint32_t> mem;
             for (uint32_t s2 = 0; s2 < n_in; ++s2) if (std::find(kv.second.begin(), kv.second.end(), (uint32_t)group_of[s2]) != kv.second.end()) { mem.push_back(s2); seq_idx[s2] = (int32_t)ci; }
-            if (std::find(ignored.begin(), ignored.end(), kv.first) != ignored.end()) { final_cons.push_back(std::string()); continue; }
-            if (kv.second.size() == 1) { final_cons.push_back(full_cons[kv.second[0]]); continue; }
-            final_cons.push_back(std::string());                                                             // merge: one consensus over all their reads (:852-871)
+            if (std::find(ignored.begin(), ignored.end(), kv.first) != ignored.end()) { final_cons.push_back(std::string()); final_group.push_back(-1); continue; }
+            if (kv.second.size() == 1) { final_cons.push_back(full_cons[kv.second[0]]); final_group.push_back((int32_t)kv.second[0]); continue; }
+            final_cons.push_back(std::string()); final_group.push_back(-1);                                  // merge: one consensus over all their reads (:852-871)
             int32_t mn = INT32_MAX; for (uint32_t s2 : mem) mn = std::min(mn, boff[s2] < 0 ? 0 : boff[s2]);
             std::vector<int32_t> mo; for (uint32_t s2 : mem) { const int32_t v = boff[s2] < 0 ? 0 : boff[s2]; mo.push_back(v == mn ? -1 : v - mn + (mn == 0 ? 0 : 50)); }
             members.push_back(mem); moffs.push_back(mo); slot.push_back(ci);
@@ -1233,22 +1436,30 @@ int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
         }
     hm.mark("host:cyp_typing");
     // 6. weights of every region of interest, chains, best chain pair (caller.rs:429-640)
-    std::vector<uint32_t> a_idx(hits.size()); std::vector<int32_t> a_start(hits.size()), a_len(hits.size());
-    std::vector<uint32_t> seg_off(R + 1, 0);
-    for (size_t h = 0; h < hits.size(); ++h) { a_idx[h] = (uint32_t)hits[h].read; a_start[h] = hits[h].start; a_len[h] = hits[h].end - hits[h].start; seg_off[hits[h].read + 1] += 1; }
-    for (uint32_t r = 0; r < R; ++r) seg_off[r + 1] += seg_off[r];
-    sp_seqset all;
-    rc = sp_make_segments(ctx, reads, a_idx, a_start, a_len, "cypa", &all, nullptr);
-    if (rc != SP_OK) return rc;
-    std::string blob; std::vector<uint64_t> off(1, 0);
-    for (const std::string& c : final_cons) { blob += c; off.push_back(blob.size()); }
-    sp_seqset cons_pooled; sp_seqset* cons_set = &cons_pooled;
-    rc = sp_seqset_make_small(ctx, "cyp_final", blob.data(), off.data(), H, true, cons_set);
-    if (rc != SP_OK) return rc;
     std::vector<uint8_t> allowed(H); for (uint32_t h = 0; h < H; ++h) allowed[h] = label_allowed(labels[h]) && !final_cons[h].empty();
-    std::vector<uint64_t> ed((size_t)all.n * H); std::vector<double> ov((size_t)all.n * H); std::vector<uint8_t> kept(all.n);
-    rc = sp_cyp_weight_segments(ctx, cons_set, allowed.data(), &all, ed.data(), ov.data(), kept.data());
-    if (rc != SP_OK) return rc;
+    if (ahead.started) ahead.th.join();
+    bool from_ahead = ahead.started && ahead.rc == SP_OK;                 // every final consensus that counts is a group's own: its placements are there already
+    for (uint32_t h = 0; h < H && from_ahead; ++h) if (allowed[h] && final_group[h] < 0) from_ahead = false;
+    sp_seqset all_here; sp_seqset& all = from_ahead ? ahead.all : all_here;
+    std::vector<uint64_t> ed; std::vector<double> ov; std::vector<uint8_t> kept;
+    if (from_ahead) {
+        ed.resize((size_t)all.n * H); ov.resize((size_t)all.n * H); kept.resize(all.n);
+        std::vector<sp_aln> alns((size_t)all.n * H, sp_aln{}); std::vector<int32_t> cons_len(H);
+        for (uint32_t h = 0; h < H; ++h) cons_len[h] = (int32_t)final_cons[h].size();
+        for (uint32_t sx = 0; sx < all.n; ++sx) for (uint32_t h = 0; h < H; ++h) if (final_group[h] >= 0) alns[(size_t)sx * H + h] = ahead.alns[(size_t)sx * n_groups + final_group[h]];
+        cyp_weights_from_alns(H, cons_len.data(), allowed.data(), all.n, all.h_len.data(), alns, ed.data(), ov.data(), kept.data());
+    } else {
+        rc = sp_make_segments(ctx, reads, a_idx, a_start, a_len, "cypa", &all, nullptr);
+        if (rc != SP_OK) return rc;
+        std::string blob; std::vector<uint64_t> off(1, 0);
+        for (const std::string& c : final_cons) { blob += c; off.push_back(blob.size()); }
+        sp_seqset cons_pooled; sp_seqset* cons_set = &cons_pooled;
+        rc = sp_seqset_make_small(ctx, "cyp_final", blob.data(), off.data(), H, true, cons_set);
+        if (rc != SP_OK) return rc;
+        ed.resize((size_t)all.n * H); ov.resize((size_t)all.n * H); kept.resize(all.n);
+        rc = sp_cyp_weight_segments(ctx, cons_set, allowed.data(), &all, ed.data(), ov.data(), kept.data());
+        if (rc != SP_OK) return rc;
+    }
     hm.mark("host:cyp_weights");
     std::vector<int32_t> types(H); for (uint32_t h = 0; h < H; ++h) types[h] = labels[h].type;
     std::vector<uint32_t> read_index(R + 1), rco(R + 1), rwo(R + 1), w_seg(all.n + 1), chain_off, chain_items;
