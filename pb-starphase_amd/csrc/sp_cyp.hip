@@ -641,7 +641,7 @@ static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, in
     (void)hipMemcpyAsync(d_a, ai.data(), n_pairs * 4, hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemcpyAsync(d_b, bi.data(), n_pairs * 4, hipMemcpyHostToDevice, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
-    rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v, topk);
+    rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v, topk, "anchor", (uint32_t)nA);
     if (rc) return rc;
     hipLaunchKernelGGL(cyp_build_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, d_d, d_v, n_pairs, topk, CYP_MIN_VOTES, A->d_len, frac_cap, d_cells);
     rc = sp_launch_cells(ctx, A, B, d_cells, n_cells, d_alns, nullptr, 0, prof, retry_wide);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
     for (uint64_t p = blockIdx.x; p < n_pairs; p += gridDim.x) {
         const PairMeta cur = next;
         if (p + gridDim.x < n_pairs) next = fetch(p + gridDim.x);
-        const uint32_t a = cur.a, b = cur.b;
+        const uint32_t a = cur.a;
         const int m = cur.m, n = cur.n;
         const int nbins = m + n + 1;
         if (m < SP_KMER || n < SP_KMER || nbins > bins_cap) {
@@ -447,7 +447,7 @@ int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn) {
 
 int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,
-                     int32_t* d_diag, int32_t* d_votes, int topk, const char* prof_name) {
+                     int32_t* d_diag, int32_t* d_votes, int topk, const char* prof_name, uint32_t a_period) {
     if (topk < 1 || topk > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: topk must be 1..8");
     if (n_pairs == 0) return SP_OK;
     if (!A->has_index) return sp_fail(ctx, SP_ERR_INVALID_ARG, "anchor: set A has no k-mer index");
@@ -460,6 +460,7 @@ int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     lds_bytes += (size_t)tab_cap * 8;
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sp_anchor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     uint64_t grid = std::min<uint64_t>(n_pairs, (uint64_t)ctx->num_cus * 8);       // 1 / 2 / 4 / 8 / 16 per CU: 3.3 / 2.04 / 2.0 / 1.9 / 1.96 ms of anchors per bench step
+    if (a_period > 1 && grid > a_period) grid -= grid % a_period;           // (39 templates: a workgroup's stride of 2,048 pairs changed A every time, 72 KB of table per pair)
     ProfScope ps(ctx, prof_name, n_pairs);
     hipLaunchKernelGGL(sp_anchor_kernel, dim3((unsigned)grid), dim3(SP_ANCHOR_THREADS), lds_bytes, ctx->stream,
                        A->view(), A->kview(), B->view(), d_a_idx, d_b_idx, n_pairs, d_diag, d_votes, bins_cap, topk, tab_cap, sp_counters(ctx));

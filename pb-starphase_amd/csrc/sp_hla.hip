@@ -964,7 +964,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         if (!d_bound) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign bound");
     }
     if (rc == SP_OK) hipLaunchKernelGGL(k1_init_kernel, dim3((R * G + 255) / 256), dim3(256), 0, ctx->stream, d_a, d_b, R, G, d_bound);
-    if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes, 1, "anchor_k1");
+    if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes, 1, "anchor_k1", G);
     // reads with a weak forward anchor are listed now; their count comes back with the first pass's own host synchronisation
     uint32_t* d_weak_n = (uint32_t*)sp_pool(ctx, "k1_weak_n", 4);
     uint32_t* d_weak = (uint32_t*)sp_pool(ctx, "k1_weak", (size_t)R * 4);
@@ -1046,7 +1046,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         if (!d_a2 || !d_b2 || !d_rg2 || !d_votes2) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign strand anchors");
         if (rc == SP_OK) {
             hipLaunchKernelGGL(k1_weak_pairs_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, d_weak, n_weak, G, d_a2, d_b2);
-            rc = sp_launch_anchor(ctx, db->ref_rev, reads, d_a2, d_b2, np, d_rg2, d_votes2, 1, "anchor_k1_rev");
+            rc = sp_launch_anchor(ctx, db->ref_rev, reads, d_a2, d_b2, np, d_rg2, d_votes2, 1, "anchor_k1_rev", G);
         }
         if (rc == SP_OK) hipLaunchKernelGGL(k1_reverse_kernel, dim3((n_weak + 255) / 256), dim3(256), 0, ctx->stream, d_weak, n_weak, G, d_votes, d_votes2, d_isrev);
     }

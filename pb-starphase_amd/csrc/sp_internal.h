@@ -114,7 +114,9 @@ sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i = 0);                           // help
 void sp_profile_merge(sp_ctx* into, sp_ctx* from);                       // adds the timings `from` collected to `into` and clears them
 int sp_launch_anchor(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                      const uint32_t* d_a_idx, const uint32_t* d_b_idx, uint64_t n_pairs,
-                     int32_t* d_diag, int32_t* d_votes, int topk = 1, const char* prof_name = "anchor");
+                     int32_t* d_diag, int32_t* d_votes, int topk = 1, const char* prof_name = "anchor", uint32_t a_period = 1);
+                     // a_period: the pair list repeats its A indices with this period (pair p has A = p % a_period): the grid is made a multiple of it, so that a
+                     // workgroup striding over the list keeps ONE table of A in LDS instead of loading another for every pair
 int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     const CellDesc* d_cells, uint64_t n_cells,
                     sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, int retry_wide = 0);   // 0 never, 1 lost cells, 2 lost cells and cells with > 32 edits (few-cell callers)
