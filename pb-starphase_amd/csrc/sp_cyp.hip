@@ -902,21 +902,26 @@ __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict
     __shared__ int shift[2][K9_DIAGS];
     __shared__ int opt_s;
     K9Job& J = jobs[blockIdx.x];
-    const int lane = threadIdx.x & 63, mirror = threadIdx.x >> 6;
-    const uint8_t* bb = pool + J.bb_off;           // (re-pointed at the LDS copies below when both fit)
-    const int L = J.L, G = J.G, ns = (int)J.n_sites;
+    // (what is the same for a whole wavefront is said to be: the pass, the job's sizes and the band's position live in scalar registers, the branches on them are
+    //  scalar branches, and the staged bases are read with LDS instructions -- through generic pointers every step waited for a flat load)
+    const int lane = threadIdx.x & 63, mirror = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint8_t* bb = pool + J.bb_off;
+    const int L = __builtin_amdgcn_readfirstlane(J.L), G = __builtin_amdgcn_readfirstlane(J.G), ns = __builtin_amdgcn_readfirstlane((int)J.n_sites);
     const uint8_t* S = pool + J.seq_off;
-    if (L + G <= lds_cap) {                               // (longer stretches stay in memory: same results, dependent loads on the way)
+    const bool staged = L + G <= lds_cap;                 // (longer stretches stay in memory: same results, dependent loads on the way)
+    if (staged) {
         for (int x = threadIdx.x; x < L; x += blockDim.x) seq_lds[x] = S[x];
         for (int x = threadIdx.x; x < G; x += blockDim.x) seq_lds[L + x] = bb[x];
         __syncthreads();
-        S = seq_lds; bb = seq_lds + L;
     }
-    const int k0 = mirror ? (L - G) - J.k0 - (K9_DIAGS - 1) : J.k0;
-    auto gbase = [&](int g) -> int { return bb[mirror ? G - 1 - g : g]; };   // graph base at offset g of this pass
+    typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+    lds_cu8* const S3 = (lds_cu8*)(uintptr_t)spw::lds_addr(reinterpret_cast<const uint32_t*>(seq_lds));
+    lds_cu8* const B3 = S3 + L;
+    const int k0 = __builtin_amdgcn_readfirstlane(mirror ? (L - G) - J.k0 - (K9_DIAGS - 1) : J.k0);
+    auto gbase = [&](int g) -> int { const int x = mirror ? G - 1 - g : g; return staged ? (int)B3[x] : (int)bb[x]; };   // graph base at offset g of this pass
     // The four sequence bases in front of a lane's diagonals move up by one per graph base: they are kept in registers and shifted
     // through the lanes (the top lane reads the one new base), instead of four loads per lane and step.
-    auto sbase = [&](int i) -> int { return (i >= 0 && i < L) ? (int)S[mirror ? L - 1 - i : i] : 255; };
+    auto sbase = [&](int i) -> int { if (i < 0 || i >= L) return 255; const int x = mirror ? L - 1 - i : i; return staged ? (int)S3[x] : (int)S[x]; };
     int r[4];
     auto load_r = [&](int off) {
 #pragma unroll
