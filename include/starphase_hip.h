@@ -65,6 +65,8 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * of the other samples already fill the gaps.  The calls are the same either way.  "cons_retry_ladder" (default 1): 0 makes sp_cyp_diplotype* run
  * its multi-way consensus without the retry of searches that give up (sp_cons_config.no_retry_ladder, see sp_consensus_priority).
  * "cyp_cohort_streams" (1..8, default 6): streams sp_cyp_diplotype_cohort spreads its groups of samples over (one host thread each).
+ * "k5_block_pairs" (0..1048576, default 4096): sp_cyp_best_chain_pair scores up to this many chain pairs with one workgroup per pair (the few pairs
+ * of an ordinary sample: the reads of a pair are shared out over the workgroup), more with one thread per pair; the results are the same.
  * Unknown names: SP_ERR_INVALID_ARG. */
 int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value);
 

@@ -65,7 +65,7 @@ void sp_ctx_destroy(sp_ctx* ctx) {
 sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i) {
     if (i < 0 || i > 6) return nullptr;
     if (!ctx->helper[i] && sp_ctx_create(ctx->device, nullptr, &ctx->helper[i]) != SP_OK) ctx->helper[i] = nullptr;
-    if (ctx->helper[i]) ctx->helper[i]->profiling = ctx->profiling;
+    if (ctx->helper[i]) { ctx->helper[i]->profiling = ctx->profiling; ctx->helper[i]->k5_block_pairs = ctx->k5_block_pairs; }
     return ctx->helper[i];
 }
 void sp_profile_merge(sp_ctx* into, sp_ctx* from) {
@@ -87,6 +87,7 @@ int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SP_ERR_INVALID_ARG;
     if (std::strcmp(name, "hla_split_genes") == 0) { ctx->split_genes = value != 0; return SP_OK; }
     if (std::strcmp(name, "cons_retry_ladder") == 0) { ctx->cons_retry_ladder = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->cons_retry_ladder = ctx->cons_retry_ladder; return SP_OK; }
+    if (std::strcmp(name, "k5_block_pairs") == 0) { if (value < 0 || value > (1 << 20)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k5_block_pairs is 0..1048576"); ctx->k5_block_pairs = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k5_block_pairs = ctx->k5_block_pairs; return SP_OK; }
     if (std::strcmp(name, "cyp_cohort_streams") == 0) { if (value < 1 || value > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: cyp_cohort_streams is 1..8"); ctx->cyp_cohort_streams = (int)value; return SP_OK; }
     if (std::strcmp(name, "hla_split_streams") == 0) { if (value < 1 || value > 4) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: hla_split_streams is 1..4"); ctx->split_streams = (int)value; return SP_OK; }
     return sp_fail(ctx, SP_ERR_INVALID_ARG, std::string("sp_ctx_set_option: unknown option ") + name);

@@ -260,7 +260,6 @@ __global__ __launch_bounds__(256) void k5_pair_kernel(PairConsts c,
 // operands in the same order.  A read with more than K5_ADDS addends is added up from memory at its turn.
 #define K5_TILE 256
 #define K5_ADDS 8
-#define K5_BLOCK_PAIRS 4096
 __global__ __launch_bounds__(K5_TILE) void k5_pair_block_kernel(PairConsts c,
                                                       const uint8_t* __restrict__ chains, const int32_t* __restrict__ chain_len,
                                                       const uint32_t* __restrict__ chain_unexp, const uint32_t* __restrict__ chain_inf,
@@ -532,7 +531,7 @@ extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p
     for (int cc = 1; cc <= max_cnt; ++cc) for (int t = cc; t <= max_total; ++t) ln_p[(size_t)cc * (max_total + 1) + t] = std::log((double)cc / (double)t);
 
     const uint64_t n_pairs = (uint64_t)P * ((uint64_t)P + 1) / 2;
-    const bool block_per_pair = n_pairs <= K5_BLOCK_PAIRS;                  // (k5_pair_block_kernel)
+    const bool block_per_pair = n_pairs <= (uint64_t)ctx->k5_block_pairs;   // (k5_pair_block_kernel)
     const uint64_t blocks = block_per_pair ? n_pairs : (n_pairs + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return sp_fail(ctx, SP_ERR_TOO_LONG, "chain pair: too many chain pairs for one launch");
     PairConsts pc{H, P, maxlen, R, ignore ? 1 : 0, norm_all ? 1 : 0, infer ? 1 : 0, p->lasso_penalty, p->ln_ed_penalty, p->unexpected_chain_penalty,

@@ -84,6 +84,7 @@ struct sp_ctx {
     bool cons_retry_ladder = true;   // sp_ctx_set_option "cons_retry_ladder": sp_consensus_priority's retry of searches that give up (the drivers pass it on)
     hipStream_t copy_stream = nullptr;   // uploads travel on a stream of their own, beside the kernels of ctx->stream
     sp_seqset* uploading = nullptr;      // the one upload a context has in flight (the staging buffers are the context's)
+    int k5_block_pairs = 4096;       // sp_ctx_set_option "k5_block_pairs": up to this many chain pairs K5 runs one workgroup per pair (0: always one thread per pair)
     int cyp_cohort_streams = 6;      // sp_ctx_set_option "cyp_cohort_streams": samples of sp_cyp_diplotype_cohort in flight (1..8; WGS-sized samples are chains of tiny launches)
     sp_ctx* helper[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // further contexts on the same device (own stream, pools, events) for work that runs beside this one's; made on first use
 };

@@ -53,6 +53,26 @@ def test_synthetic_loci(oracle, gpu_ctx):
     assert n_ok >= 10
 
 
+def test_chain_pairs_by_workgroup_and_by_thread(oracle, gpu_ctx):
+    """K5's two kernels (one workgroup per pair for few pairs, one thread per pair for many) on the same problems: both equal the oracle bit for bit;
+    reads with many equally good windows take the workgroup kernel's from-memory path (more than eight addends)"""
+    rng = np.random.default_rng(23)
+    seen = {0: 0, 1 << 20: 0}
+    try:
+        for k in range(8):
+            labels, obs, sc, infer = cyp_cases.synthetic_problem(rng, n_d6=3 + k % 4, n_reads=300 + 150 * k, noise=0.0 if k % 2 else 0.15, infer=bool(k % 2))
+            inp = of.ChainInputs(labels, obs, sc, infer, True, of.DEFAULT_PENALTIES, False)
+            for limit in seen:
+                gpu_ctx.set_option("k5_block_pairs", limit)
+                rc, exp = same(oracle, gpu_ctx, inp)
+                seen[limit] += rc == 0
+    finally:
+        gpu_ctx.set_option("k5_block_pairs", 4096)
+    assert min(seen.values()) >= 4
+    with pytest.raises(Exception):
+        gpu_ctx.set_option("k5_block_pairs", -1)
+
+
 def test_topk_anchors(oracle, pkg, gpu_ctx):
     """a template that occurs twice in a read must give two placements (D6 and its D7 paralog / duplications)"""
     import ctypes as C
