@@ -590,9 +590,9 @@ def main():
             extra = []
             for k in range(1, K):
                 ch, cc = pkg.Context(device_index), pkg.Context(device_index)
-                ch.set_option("hla_split_genes", 0)
+                ch.set_option("hla_split_genes", 0); cc.set_option("hla_split_genes", 0)
                 extra.append((ch, fx.make_db(pkg, ch), cc, pkg.ffi.CypDb(cc, cfg, gene_def, locus.sequence, locus.start)))
-            ctx.set_option("hla_split_genes", 0)
+            ctx.set_option("hla_split_genes", 0); ctx_c.set_option("hla_split_genes", 0)
 
             def flight_lanes(steps):
                 ls = make_lanes(steps)
@@ -614,7 +614,7 @@ def main():
             d_fl = time.perf_counter() - t1
             legs["samples_in_flight"] = {"samples_in_flight": K, "value": K * reads_per_step * args.steps / d_fl, "unit": "reads/s", "ms_per_sample": 1e3 * d_fl / (K * args.steps),
                                          "workload": "the headline's sample (HLA-A/-B 10,000 reads + CYP2D6 2,000 reads, upload included), three of them in flight on six contexts"}
-            ctx.set_option("hla_split_genes", 1)
+            ctx.set_option("hla_split_genes", 1); ctx_c.set_option("hla_split_genes", 1)
             del extra
         except Exception as e:                                                  # (a leg, not the headline: say so and go on)
             legs["samples_in_flight"] = {"error": str(e)}

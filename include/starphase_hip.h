@@ -62,7 +62,8 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * call (the genes of a sample, the (sample, gene) pairs of a cohort) with >= 1,000 realigned reads side by side on up to
  * "hla_split_streams" (1..4, default 3) streams -- helper streams the context owns, one host thread each for the length of the call:
  * lowest latency for one call; set hla_split_genes to 0 when several samples are in flight on contexts of their own, where the streams
- * of the other samples already fill the gaps.  The calls are the same either way.  "cons_retry_ladder" (default 1): 0 makes sp_cyp_diplotype* run
+ * of the other samples already fill the gaps (sp_cyp_diplotype follows the same switch: with 1 it places the regions of interest on the consensuses
+ * for its weights on a helper stream while it types the consensuses).  The calls are the same either way.  "cons_retry_ladder" (default 1): 0 makes sp_cyp_diplotype* run
  * its multi-way consensus without the retry of searches that give up (sp_cons_config.no_retry_ladder, see sp_consensus_priority).
  * "cyp_cohort_streams" (1..8, default 6): streams sp_cyp_diplotype_cohort spreads its groups of samples over (one host thread each).
  * "k5_block_pairs" (0..1048576, default 4096): sp_cyp_best_chain_pair scores up to this many chain pairs with one workgroup per pair (the few pairs

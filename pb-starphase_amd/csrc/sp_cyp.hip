@@ -623,15 +623,14 @@ __global__ void cyp_build_cells_kernel(const uint32_t* __restrict__ a_idx, const
     cells[i] = c;
 }
 
-// all |A| x |B| placements (A = indexed query side, B = target side), result[b][a][k]
-static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, int retry_wide, const char* prof, std::vector<sp_aln>& out) {
-    const uint64_t nA = A->n, nB = B->n, n_pairs = nA * nB, n_cells = n_pairs * (uint64_t)topk;
+// placements of a list of (A, B) pairs (A = indexed query side, B = target side), result[pair][k]; a_period as in sp_launch_anchor
+static int cyp_align_pairs(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const std::vector<uint32_t>& ai, const std::vector<uint32_t>& bi, uint32_t a_period,
+                           int topk, double frac_cap, int retry_wide, const char* prof, std::vector<sp_aln>& out) {
+    const uint64_t n_pairs = ai.size(), n_cells = n_pairs * (uint64_t)topk;
     out.assign(n_cells, sp_aln{});
     if (n_pairs == 0) return SP_OK;
     int rc = sp_seqset_build_index(ctx, const_cast<sp_seqset*>(A));
     if (rc) return rc;
-    std::vector<uint32_t> ai(n_pairs), bi(n_pairs);
-    for (uint64_t b = 0; b < nB; ++b) for (uint64_t a = 0; a < nA; ++a) { ai[b * nA + a] = (uint32_t)a; bi[b * nA + a] = (uint32_t)b; }
     uint32_t* d_a = (uint32_t*)sp_pool(ctx, "cyp_a", n_pairs * 4); uint32_t* d_b = (uint32_t*)sp_pool(ctx, "cyp_b", n_pairs * 4);
     int32_t* d_d = (int32_t*)sp_pool(ctx, "cyp_d", n_cells * 4); int32_t* d_v = (int32_t*)sp_pool(ctx, "cyp_v", n_cells * 4);
     CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "cyp_cells", n_cells * sizeof(CellDesc));
@@ -640,7 +639,7 @@ static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, in
     (void)hipMemcpyAsync(d_a, ai.data(), n_pairs * 4, hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemcpyAsync(d_b, bi.data(), n_pairs * 4, hipMemcpyHostToDevice, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
-    rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v, topk, "anchor", (uint32_t)nA);
+    rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v, topk, "anchor", a_period);
     if (rc) return rc;
     hipLaunchKernelGGL(cyp_build_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, d_d, d_v, n_pairs, topk, CYP_MIN_VOTES, A->d_len, frac_cap, d_cells);
     rc = sp_launch_cells(ctx, A, B, d_cells, n_cells, d_alns, nullptr, 0, prof, retry_wide);
@@ -649,6 +648,14 @@ static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, in
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("cyp placements: ") + hipGetErrorString(e));
     return SP_OK;
+}
+
+// all |A| x |B| placements, result[b][a][k]
+static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, int retry_wide, const char* prof, std::vector<sp_aln>& out) {
+    const uint64_t nA = A->n, nB = B->n, n_pairs = nA * nB;
+    std::vector<uint32_t> ai(n_pairs), bi(n_pairs);
+    for (uint64_t b = 0; b < nB; ++b) for (uint64_t a = 0; a < nA; ++a) { ai[b * nA + a] = (uint32_t)a; bi[b * nA + a] = (uint32_t)b; }
+    return cyp_align_pairs(ctx, A, B, ai, bi, (uint32_t)nA, topk, frac_cap, retry_wide, prof, out);
 }
 
 static inline double cyp_score(int seq_len, int nm, int unmapped, bool penalize) {        // MappingStats::custom_score (data_types/mapping.rs:60-84)
@@ -1279,9 +1286,13 @@ struct CypMid {
     uint32_t n_in = 0, cap = 0, n_groups = 0;
     std::vector<int32_t> group_of; std::vector<char> text;
     bool finished = false;                                // the call is complete after part (a) already (no reads)
+    // between (c1), the weights and (c2)
+    std::vector<std::string> full_cons, final_cons; std::vector<int32_t> final_group; std::vector<Label> labels; DeepInfo deep; std::vector<uint8_t> allowed;
+    std::vector<uint32_t> a_idx, seg_off; std::vector<int32_t> a_start, a_len; uint32_t H = 0;
 };
 
-int32_t cyp_part_a(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, sp_cyp_region_variants* region_variants, const char* seg_prefix, CypMid& m) {
+int32_t cyp_part_a(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, sp_cyp_region_variants* region_variants, const char* seg_prefix, CypMid& m,
+                   const std::vector<sp_region_hit>* found_hits = nullptr) {
     if (region_variants) std::memset(region_variants->has_variants, 0, sizeof region_variants->has_variants);
     if (!pr || !reads || !call || !pr->templates || !pr->template_type || !pr->template_deep || !pr->backbone) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_cyp_diplotype: null argument");
     (void)hipSetDevice(ctx->device);
@@ -1291,11 +1302,15 @@ int32_t cyp_part_a(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
     sp_seqset& raw = m.raw; sp_seqset& hpc = m.hpc;
     HostMarks hm(ctx);
     // 1. regions of interest (caller.rs:126-139): max_missing_chain_frac = 0.5
-    hits.assign((size_t)R * 8 + 16, sp_region_hit{}); uint64_t nh = 0;
-    int32_t rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh);
-    if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh); }
-    if (rc != SP_OK) return rc;
-    hits.resize(nh);
+    int32_t rc = SP_OK;
+    if (found_hits) hits = *found_hits;                                   // (a cohort's group of samples searched its regions in one call: cyp_group_regions)
+    else {
+        hits.assign((size_t)R * 8 + 16, sp_region_hit{}); uint64_t nh = 0;
+        rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh);
+        if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh); }
+        if (rc != SP_OK) return rc;
+        hits.resize(nh);
+    }
     hm.mark("host:cyp_regions");
     // 2. consensus inputs (caller.rs:176-245): max_missing_consensus_frac = 0.5, offset window +-50
     std::vector<std::string> guides(pr->templates->n);
@@ -1342,32 +1357,86 @@ int32_t cyp_part_a(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
     return SP_OK;
 }
 
-int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, char* consensus, uint32_t cons_cap, sp_cyp_region_variants* region_variants, CypMid& m,
-                   TypeCache* shared_types = nullptr) {
+// The read sets of several samples seen as ONE set -- no bases move: a set addresses its packed words as base + 64-bit word offset, so the offsets of all the
+// sets are rewritten relative to the lowest of their bases.  first[i] = number of the first read of sample i in the view.  false when the sets cannot be
+// seen as one (a set with an N plane, more reads than one search should take).
+#define CYP_GROUP_READS 16384
+bool cyp_group_view(sp_ctx* ctx, const sp_seqset* const* reads, uint32_t n, const char* prefix, sp_seqset& all, std::vector<uint32_t>& first, int32_t& rc) {
+    rc = SP_OK;
+    uint64_t total = 0; const uint32_t* base = nullptr;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (reads[i]->has_n || reads[i]->d_nplane) return false;
+        total += reads[i]->n;
+        if (reads[i]->n && (!base || (uintptr_t)reads[i]->d_words < (uintptr_t)base)) base = reads[i]->d_words;
+    }
+    if (n < 2 || total == 0 || total > CYP_GROUP_READS) return false;
+    all = sp_seqset(); all.ctx = ctx; all.n = (uint32_t)total; all.has_n = false;
+    all.h_len.reserve(total); all.h_word_off.reserve(total + 1);
+    first.assign(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t shift = reads[i]->n ? (uint64_t)(((uintptr_t)reads[i]->d_words - (uintptr_t)base) / sizeof(uint32_t)) : 0;
+        for (uint32_t r = 0; r < reads[i]->n; ++r) { all.h_len.push_back(reads[i]->h_len[r]); all.h_word_off.push_back(shift + reads[i]->h_word_off[r]); }
+        all.max_len = std::max(all.max_len, reads[i]->max_len);
+        first[i + 1] = first[i] + reads[i]->n;
+    }
+    all.h_word_off.push_back(all.h_word_off.back());
+    all.d_words = const_cast<uint32_t*>(base);
+    const std::string px(prefix);
+    all.d_word_off = (uint64_t*)sp_pool(ctx, (px + "_woff").c_str(), (total + 1) * 8); all.d_len = (int32_t*)sp_pool(ctx, (px + "_len").c_str(), total * 4);
+    if (!all.d_word_off || !all.d_len) { rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "cyp group read set"); return true; }
+    (void)hipMemcpyAsync(all.d_word_off, all.h_word_off.data(), (total + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(all.d_len, all.h_len.data(), total * 4, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    return true;
+}
+
+// The regions of interest of several samples in ONE search (the result for a read does not depend on the other reads); the hits go back to their samples with
+// the read numbered inside its sample.  false: the caller searches sample by sample.
+bool cyp_group_regions(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset& all, const std::vector<uint32_t>& first, uint32_t n, std::vector<std::vector<sp_region_hit>>& per_sample, int32_t& rc) {
+    HostScope hs(ctx, "host:cyp_regions");
+    std::vector<sp_region_hit> hits((size_t)all.n * 8 + 16); uint64_t nh = 0;
+    rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, &all, 0.5, hits.data(), hits.size(), &nh);
+    if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, &all, 0.5, hits.data(), hits.size(), &nh); }
+    if (rc != SP_OK) return true;
+    per_sample.assign(n, std::vector<sp_region_hit>());
+    uint32_t i = 0;
+    for (uint64_t h = 0; h < nh; ++h) {                                    // (hits come read by read)
+        while ((uint32_t)hits[h].read >= first[i + 1]) ++i;
+        sp_region_hit q = hits[h]; q.read -= (int32_t)first[i];
+        per_sample[i].push_back(q);
+    }
+    return true;
+}
+
+// Part (c) in three steps, so that a cohort's group of samples can take the middle one together: (c1) merge + typing of the final consensus regions, the weights
+// (cyp_weights_one for a sample alone, cyp_weights_group for a group), (c2) chains + best chain pair + the call.
+struct Ahead { std::thread th; bool started = false; int32_t rc = -1; sp_seqset all, cons; std::vector<sp_aln> alns; };
+struct JoinAhead { Ahead& a; ~JoinAhead() { if (a.started && a.th.joinable()) a.th.join(); } };
+
+int32_t cyp_part_c1(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_region_variants* region_variants, CypMid& m, TypeCache* shared_types, Ahead* ahead_p) {
     const uint32_t R = m.R, n_in = m.n_in, cap = m.cap, n_groups = m.n_groups;
     auto& hits = m.hits; auto& boff = m.boff; auto& group_of = m.group_of; auto& text = m.text;
     sp_seqset& raw = m.raw; const sp_cons_config cc = m.cc;
     int32_t rc = SP_OK;
     HostMarks hm(ctx);
-    std::vector<std::string> hpc_cons(n_groups), full_cons(n_groups);
+    std::vector<std::string> hpc_cons(n_groups); std::vector<std::string>& full_cons = m.full_cons; full_cons.assign(n_groups, std::string());
     for (uint32_t g = 0; g < n_groups; ++g) { hpc_cons[g] = text.data() + (size_t)(2 * g) * cap; full_cons[g] = text.data() + (size_t)(2 * g + 1) * cap; }
     // (step 6's device half ahead of its turn: the placements of every region of interest on every group consensus do not depend on the typing, and unless step 4
     //  merges groups the group consensuses ARE the final ones -- a helper stream places them while this one types, a 2,000-read sample's 3 ms under its 7 ms)
-    std::vector<uint32_t> a_idx(hits.size()); std::vector<int32_t> a_start(hits.size()), a_len(hits.size());
-    std::vector<uint32_t> seg_off(R + 1, 0);
+    std::vector<uint32_t>& a_idx = m.a_idx; std::vector<int32_t>& a_start = m.a_start; std::vector<int32_t>& a_len = m.a_len; std::vector<uint32_t>& seg_off = m.seg_off;
+    a_idx.assign(hits.size(), 0); a_start.assign(hits.size(), 0); a_len.assign(hits.size(), 0); seg_off.assign(R + 1, 0);
     for (size_t h = 0; h < hits.size(); ++h) { a_idx[h] = (uint32_t)hits[h].read; a_start[h] = hits[h].start; a_len[h] = hits[h].end - hits[h].start; seg_off[hits[h].read + 1] += 1; }
     for (uint32_t r = 0; r < R; ++r) seg_off[r + 1] += seg_off[r];
-    struct Ahead { std::thread th; bool started = false; int32_t rc = -1; sp_seqset all, cons; std::vector<sp_aln> alns; } ahead;
-    struct JoinAhead { Ahead& a; ~JoinAhead() { if (a.started && a.th.joinable()) a.th.join(); } } join_ahead{ahead};
-    sp_ctx* beside = (!shared_types && n_groups && hits.size() * n_groups >= 2048) ? sp_ctx_helper(ctx, 0) : nullptr;     // (a cohort's streams are busy already)
+    sp_ctx* beside = (ahead_p && ctx->split_genes && !shared_types && n_groups && hits.size() * n_groups >= 2048) ? sp_ctx_helper(ctx, 0) : nullptr;     // (a cohort's streams are busy already; so is a GPU with several samples in flight: "hla_split_genes" 0)
     if (beside) {
+        Ahead& ahead = *ahead_p;
         try {
-            ahead.th = std::thread([&]() {
+            ahead.th = std::thread([&m, &ahead, beside, reads, n_groups]() {      // (outlives this function: nothing of its frame is referred to)
                 try {
                     (void)hipSetDevice(beside->device);
-                    int32_t r2 = sp_make_segments(beside, reads, a_idx, a_start, a_len, "cypa", &ahead.all, nullptr);
+                    int32_t r2 = sp_make_segments(beside, reads, m.a_idx, m.a_start, m.a_len, "cypa", &ahead.all, nullptr);
                     std::string blob; std::vector<uint64_t> off(1, 0);
-                    for (const std::string& c : full_cons) { blob += c; off.push_back(blob.size()); }
+                    for (const std::string& c : m.full_cons) { blob += c; off.push_back(blob.size()); }
                     if (r2 == SP_OK) r2 = sp_seqset_make_small(beside, "cyp_final", blob.data(), off.data(), n_groups, true, &ahead.cons);
                     if (r2 == SP_OK) r2 = cyp_align_all(beside, &ahead.cons, &ahead.all, 1, 0.0, 1, "k4_weight_cells", ahead.alns);
                     ahead.rc = r2;
@@ -1396,8 +1465,8 @@ int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
         else { if (others.size() > 1) ignored.push_back({ u.first, "UNKNOWN" }); cset[{ u.first, "UNKNOWN" }] = u.second; }
     }
     if (cset.size() > SP_CYP_MAXCONS) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_cyp_diplotype: more than SP_CYP_MAXCONS consensus regions");
-    std::vector<std::string> final_cons; std::vector<int32_t> seq_idx(n_in, -1);
-    std::vector<int32_t> final_group;                                     // the group a final consensus is the consensus of (-1: merged from several, or ignored)
+    std::vector<std::string>& final_cons = m.final_cons; final_cons.clear(); std::vector<int32_t> seq_idx(n_in, -1);
+    std::vector<int32_t>& final_group = m.final_group; final_group.clear();                                     // the group a final consensus is the consensus of (-1: merged from several, or ignored)
     {
         std::vector<sp_cons_problem> P; std::vector<sp_cons_output> O; std::vector<size_t> slot;
         std::vector<std::vector<uint32_t>> members; std::vector<std::vector<int32_t>> moffs, ms1, ms2; std::vector<std::vector<uint8_t>> mis; std::vector<std::vector<char>> mtext;
@@ -1425,10 +1494,9 @@ int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
     }
     hm.mark("host:cyp_merge");
     // 5. typing of the final consensus regions, forced assignment, duplicates become FalseAllele (caller.rs:331-375)
-    std::vector<Label> labels;
-    DeepInfo deep;
+    std::vector<Label>& labels = m.labels;
+    DeepInfo& deep = m.deep;
     rc = type_sequences(ctx, pr, final_cons, 0.1, true, labels, typed, &deep);
-    const std::vector<std::string>& deep_tail = deep.suffix;
     if (rc != SP_OK) return rc;
     for (size_t i = 0; i < final_cons.size(); ++i)
         for (size_t j = 0; j < i; ++j) if (final_cons[j] == final_cons[i]) { labels[i].type = SP_CYP_FALSE_ALLELE; break; }
@@ -1439,13 +1507,23 @@ int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
             if (deep.has[h] && region_variants->state && pr->n_variants) std::memcpy(region_variants->state + (size_t)h * pr->n_variants, deep.rel[h].data(), pr->n_variants);
         }
     hm.mark("host:cyp_typing");
-    // 6. weights of every region of interest, chains, best chain pair (caller.rs:429-640)
-    std::vector<uint8_t> allowed(H); for (uint32_t h = 0; h < H; ++h) allowed[h] = label_allowed(labels[h]) && !final_cons[h].empty();
+    m.H = H;
+    m.allowed.assign(H, 0); for (uint32_t h = 0; h < H; ++h) m.allowed[h] = label_allowed(labels[h]) && !final_cons[h].empty();
+    return SP_OK;
+}
+
+// 6. weights of every region of interest (caller.rs:429-640), one sample: from the placements a helper stream made ahead, or here
+int32_t cyp_weights_one(sp_ctx* ctx, const sp_seqset* reads, CypMid& m, Ahead& ahead, std::vector<uint64_t>& ed, std::vector<double>& ov, std::vector<uint8_t>& kept, sp_seqset& all_here, const sp_seqset*& all_p) {
+    const uint32_t H = m.H, n_groups = m.n_groups;
+    const std::vector<uint8_t>& allowed = m.allowed; const std::vector<int32_t>& final_group = m.final_group; const std::vector<std::string>& final_cons = m.final_cons;
+    const std::vector<uint32_t>& a_idx = m.a_idx; const std::vector<int32_t>& a_start = m.a_start; const std::vector<int32_t>& a_len = m.a_len;
+    int32_t rc = SP_OK;
+    HostMarks hm(ctx);
     if (ahead.started) ahead.th.join();
     bool from_ahead = ahead.started && ahead.rc == SP_OK;                 // every final consensus that counts is a group's own: its placements are there already
     for (uint32_t h = 0; h < H && from_ahead; ++h) if (allowed[h] && final_group[h] < 0) from_ahead = false;
-    sp_seqset all_here; sp_seqset& all = from_ahead ? ahead.all : all_here;
-    std::vector<uint64_t> ed; std::vector<double> ov; std::vector<uint8_t> kept;
+    sp_seqset& all = from_ahead ? ahead.all : all_here;
+    all_p = &all;
     if (from_ahead) {
         ed.resize((size_t)all.n * H); ov.resize((size_t)all.n * H); kept.resize(all.n);
         std::vector<sp_aln> alns((size_t)all.n * H, sp_aln{}); std::vector<int32_t> cons_len(H);
@@ -1465,10 +1543,64 @@ int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
         if (rc != SP_OK) return rc;
     }
     hm.mark("host:cyp_weights");
+    return SP_OK;
+}
+
+// The same weights for a cohort's group of samples in one go: the regions of interest of all its samples are cut out of the group view of their reads as one set,
+// their final consensuses are one indexed set, and one list of pairs (every region of a sample x every consensus of that sample that counts) goes through the
+// placement kernels; a placement does not depend on what else is in the sets.  ms[k] == nullptr: sample k is not in play.
+int32_t cyp_weights_group(sp_ctx* ctx, const sp_seqset& view, const std::vector<uint32_t>& first, const std::vector<CypMid*>& ms,
+                          std::vector<std::vector<uint64_t>>& ed, std::vector<std::vector<double>>& ov, std::vector<std::vector<uint8_t>>& kept) {
+    HostScope hs(ctx, "host:cyp_weights");
+    const uint32_t n = (uint32_t)ms.size();
+    std::vector<uint32_t> a_idx; std::vector<int32_t> a_start, a_len;
+    std::vector<uint32_t> seg_first(n + 1, 0), cons_first(n + 1, 0);
+    std::string blob; std::vector<uint64_t> off(1, 0);
+    for (uint32_t k = 0; k < n; ++k) {
+        seg_first[k + 1] = seg_first[k]; cons_first[k + 1] = cons_first[k];
+        if (!ms[k]) continue;
+        const CypMid& m = *ms[k];
+        for (size_t x = 0; x < m.a_idx.size(); ++x) { a_idx.push_back(first[k] + m.a_idx[x]); a_start.push_back(m.a_start[x]); a_len.push_back(m.a_len[x]); }
+        for (const std::string& c : m.final_cons) { blob += c; off.push_back(blob.size()); }
+        seg_first[k + 1] += (uint32_t)m.a_idx.size(); cons_first[k + 1] += m.H;
+    }
+    ed.assign(n, {}); ov.assign(n, {}); kept.assign(n, {});
+    if (a_idx.empty()) return SP_OK;
+    sp_seqset all, cons;
+    int32_t rc = sp_make_segments(ctx, &view, a_idx, a_start, a_len, "cypga", &all, nullptr);
+    if (rc == SP_OK) rc = sp_seqset_make_small(ctx, "cypg_final", blob.data(), off.data(), cons_first[n], true, &cons);
+    if (rc != SP_OK) return rc;
+    std::vector<uint32_t> ai, bi;
+    for (uint32_t k = 0; k < n; ++k) if (ms[k])
+        for (uint32_t sx = seg_first[k]; sx < seg_first[k + 1]; ++sx)
+            for (uint32_t h = 0; h < ms[k]->H; ++h) if (ms[k]->allowed[h]) { ai.push_back(cons_first[k] + h); bi.push_back(sx); }
+    std::vector<sp_aln> alns;
+    rc = cyp_align_pairs(ctx, &cons, &all, ai, bi, 1, 1, 0.0, 1, "k4_weight_cells", alns);
+    if (rc != SP_OK) return rc;
+    size_t p = 0;
+    for (uint32_t k = 0; k < n; ++k) if (ms[k]) {
+        const CypMid& m = *ms[k];
+        const uint32_t H = m.H, ns = seg_first[k + 1] - seg_first[k];
+        std::vector<sp_aln> mine((size_t)ns * H, sp_aln{}); std::vector<int32_t> cons_len(H);
+        for (uint32_t h = 0; h < H; ++h) cons_len[h] = (int32_t)m.final_cons[h].size();
+        for (uint32_t sx = 0; sx < ns; ++sx) for (uint32_t h = 0; h < H; ++h) if (m.allowed[h]) mine[(size_t)sx * H + h] = alns[p++];
+        ed[k].resize((size_t)ns * H); ov[k].resize((size_t)ns * H); kept[k].resize(ns);
+        cyp_weights_from_alns(H, cons_len.data(), m.allowed.data(), ns, all.h_len.data() + seg_first[k], mine, ed[k].data(), ov[k].data(), kept[k].data());
+    }
+    return SP_OK;
+}
+
+int32_t cyp_part_c2(sp_ctx* ctx, const sp_cyp_problem* pr, sp_cyp_call* call, char* consensus, uint32_t cons_cap, CypMid& m, const std::vector<uint64_t>& ed, const std::vector<double>& ov,
+                    const std::vector<uint8_t>& kept, uint32_t n_all) {
+    const uint32_t R = m.R, H = m.H;
+    std::vector<Label>& labels = m.labels; const std::vector<std::string>& final_cons = m.final_cons; const std::vector<std::string>& deep_tail = m.deep.suffix;
+    const std::vector<uint32_t>& seg_off = m.seg_off;
+    int32_t rc = SP_OK;
+    HostMarks hm(ctx);
     std::vector<int32_t> types(H); for (uint32_t h = 0; h < H; ++h) types[h] = labels[h].type;
-    std::vector<uint32_t> read_index(R + 1), rco(R + 1), rwo(R + 1), w_seg(all.n + 1), chain_off, chain_items;
+    std::vector<uint32_t> read_index(R + 1), rco(R + 1), rwo(R + 1), w_seg(n_all + 1), chain_off, chain_items;
     std::vector<uint64_t> uniq(H); std::vector<uint8_t> fa(H);
-    sp_chain_build_info info; uint32_t chain_cap = 4 * R + 16, item_cap = 8 * all.n + 64;
+    sp_chain_build_info info; uint32_t chain_cap = 4 * R + 16, item_cap = 8 * n_all + 64;
     for (;;) {
         chain_off.assign(chain_cap + 1, 0); chain_items.assign(item_cap, 0);
         rc = sp_cyp_build_chains(H, types.data(), R, seg_off.data(), ed.data(), kept.data(), read_index.data(), rco.data(), chain_off.data(), chain_cap,
@@ -1532,6 +1664,18 @@ int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
     return SP_OK;
 }
 
+
+int32_t cyp_part_c(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, char* consensus, uint32_t cons_cap, sp_cyp_region_variants* region_variants, CypMid& m,
+                   TypeCache* shared_types = nullptr) {
+    Ahead ahead; JoinAhead join_ahead{ahead};
+    int32_t rc = cyp_part_c1(ctx, pr, reads, region_variants, m, shared_types, &ahead);
+    if (rc != SP_OK) return rc;
+    std::vector<uint64_t> ed; std::vector<double> ov; std::vector<uint8_t> kept; sp_seqset all_here; const sp_seqset* all = nullptr;
+    rc = cyp_weights_one(ctx, reads, m, ahead, ed, ov, kept, all_here, all);
+    if (rc != SP_OK) return rc;
+    return cyp_part_c2(ctx, pr, call, consensus, cons_cap, m, ed, ov, kept, all->n);
+}
+
 } // namespace
 
 extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads, sp_cyp_call* call, char* consensus, uint32_t cons_cap,
@@ -1579,12 +1723,17 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
             std::vector<std::unique_ptr<CypMid>> mids(n);
             std::vector<sp_priority_job> jobs; std::vector<uint32_t> job_of;
             try {
+                std::vector<std::vector<sp_region_hit>> group_hits; int32_t rc_regions = SP_OK;
+                sp_seqset view; std::vector<uint32_t> view_first;
+                const bool viewed = pr->templates && pr->template_type && cyp_group_view(c, reads + first, n, "cypg", view, view_first, rc_regions);
+                const bool searched = viewed && (rc_regions != SP_OK || cyp_group_regions(c, pr, view, view_first, n, group_hits, rc_regions));
                 for (uint32_t k = 0; k < n; ++k) {
                     const uint32_t i = first + k;
                     where[i] = x;
                     mids[k].reset(new CypMid());
                     const std::string prefix = "cypc" + std::to_string(k);
-                    rcs[i] = cyp_part_a(c, pr, reads[i], &calls[i], nullptr, prefix.c_str(), *mids[k]);
+                    if (searched && rc_regions != SP_OK) { rcs[i] = rc_regions; continue; }
+                    rcs[i] = cyp_part_a(c, pr, reads[i], &calls[i], nullptr, prefix.c_str(), *mids[k], searched ? &group_hits[k] : nullptr);
                     if (rcs[i] != SP_OK || mids[k]->finished) continue;
                     CypMid& m = *mids[k];
                     sp_priority_job J; J.problem = &m.pp; J.max_groups = SP_CYP_MAXCONS; J.cap = m.cap; J.n_groups = &m.n_groups; J.group_of = m.group_of.data(); J.cons = m.text.data(); J.status = SP_OK;
@@ -1604,11 +1753,28 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
                     HostScope hs(c, "host:cyp_merge");
                     rc_all = type_fresh(c, pr, all, 0.1, types);
                 }
+                // (c1) per sample, the weights of the group in one go (or sample by sample when its read sets cannot be seen as one), (c2) per sample
+                std::vector<CypMid*> in_play(n, nullptr);
                 for (size_t q = 0; q < jobs.size(); ++q) {
                     const uint32_t k = job_of[q], i = first + k;
                     if (rc_all != SP_OK) { rcs[i] = rc_all; continue; }
                     if (jobs[q].status != SP_OK) { rcs[i] = jobs[q].status; c->err = jobs[q].status == SP_ERR_CAPACITY ? "sp_consensus_priority: more groups than max_groups" : "sp_consensus_priority: more groups than reads"; continue; }
-                    rcs[i] = cyp_part_c(c, pr, reads[i], &calls[i], consensus ? consensus + (size_t)i * SP_CYP_MAXCONS * cons_cap : nullptr, cons_cap, nullptr, *mids[k], &types);
+                    rcs[i] = cyp_part_c1(c, pr, reads[i], nullptr, *mids[k], &types, nullptr);
+                    if (rcs[i] == SP_OK) in_play[k] = mids[k].get();
+                }
+                std::vector<std::vector<uint64_t>> ed; std::vector<std::vector<double>> ov; std::vector<std::vector<uint8_t>> kept;
+                const bool together = viewed && rc_regions == SP_OK;
+                if (together) {
+                    const int32_t rc_w = cyp_weights_group(c, view, view_first, in_play, ed, ov, kept);
+                    if (rc_w != SP_OK) for (uint32_t k = 0; k < n; ++k) if (in_play[k]) { rcs[first + k] = rc_w; in_play[k] = nullptr; }
+                }
+                for (uint32_t k = 0; k < n; ++k) if (in_play[k]) {
+                    const uint32_t i = first + k;
+                    char* cons_out = consensus ? consensus + (size_t)i * SP_CYP_MAXCONS * cons_cap : nullptr;
+                    if (together) { rcs[i] = cyp_part_c2(c, pr, &calls[i], cons_out, cons_cap, *mids[k], ed[k], ov[k], kept[k], (uint32_t)kept[k].size()); continue; }
+                    Ahead none; std::vector<uint64_t> e1; std::vector<double> o1; std::vector<uint8_t> k1; sp_seqset all_here; const sp_seqset* all = nullptr;
+                    rcs[i] = cyp_weights_one(c, reads[i], *mids[k], none, e1, o1, k1, all_here, all);
+                    if (rcs[i] == SP_OK) rcs[i] = cyp_part_c2(c, pr, &calls[i], cons_out, cons_cap, *mids[k], e1, o1, k1, all->n);
                 }
             }
             catch (const std::bad_alloc&) { for (uint32_t k = 0; k < n; ++k) rcs[first + k] = SP_ERR_OUT_OF_MEMORY; c->err = "sp_cyp_diplotype: out of host memory"; }      // (an exception must not leave a thread, nor
