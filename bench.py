@@ -30,8 +30,10 @@ import time
 
 import numpy as np
 
-# HIP maps streams onto a few hardware queues (4 by default): the two halves of a sample and their helper streams should each get their own
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP maps streams onto a few hardware queues (4 by default), in the order the streams are made: the two halves of a sample, their helper and copy streams should
+# each get their own (with 8, one more idle helper stream moved the CYP2D6 chain of a later context onto the queue of another sample's K1: 300k -> 230k reads/s
+# with three samples in flight; 16 and 24 measure the same)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # the bench asks for 8 hardware queues through os.environ; under rocprofv3 the runtime is up before Python starts, so the shell sets it
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=16
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs"
 # 1. kernel trace + stats (no counters in this pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1

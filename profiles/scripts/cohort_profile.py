@@ -1,6 +1,6 @@
 """where the 32-sample cohort call (BASELINE configs[4] per GPU) spends its time: HIP-event and host-clock totals per name"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # as bench.py: the streams of a call each get a hardware queue
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")          # as bench.py: the streams of a call each get a hardware queue
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -1,6 +1,6 @@
 """sp_cyp_diplotype_cohort by number of streams ("cyp_cohort_streams"), against the same samples called one by one: the CYP2D6 share of the cohort leg"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -2,7 +2,7 @@
 threads share ONE database handle.  Every step's records and calls must equal the thread's first step's (run on the GPU box).
 usage: thread_stress.py <threads> <steps>"""
 import os, sys, threading, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
