@@ -45,4 +45,9 @@ t0 = time.perf_counter()
 for t in th: t.start()
 for t in th: t.join()
 dt = time.perf_counter() - t0
+for x, (kind, c, _f) in enumerate(lanes):
+    if kind == "cyp":
+        ticks = {k: round(c.profile_get("cons_ticks_" + k)[2] / 100.0 / 1e3 / max(1, reps + 2), 2) for k in ("reduce", "result", "search", "tail")}
+        print("   cyp lane", x, "per sample: control-kernel device ms", ticks, "cons_steps ms", round(c.profile_get("cons_steps")[0] / (reps + 2), 1), "k9", round(c.profile_get("k9_graph")[0] / (reps + 2), 2),
+              "anchor", round(c.profile_get("anchor")[0] / (reps + 2), 2))
 print(f"{n_hla} hla + {n_cyp} cyp lanes, {reps} samples each: wall {1e3 * dt:.0f} ms; per sample on its lane:", [(lanes[x][0], round(1e3 * took[x] / reps, 1)) for x in range(len(lanes))])
