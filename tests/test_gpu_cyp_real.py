@@ -103,6 +103,27 @@ def test_cohort_call_equals_single_calls(gpu_ctx, real):
     assert db.diplotype_cohort([]) == []
 
 
+def test_cohort_groups_with_an_empty_sample_and_with_an_n_plane(gpu_ctx, real):
+    """A group's read sets are seen as one set for the region search and the weights (cyp_group_view): a sample without reads in the middle of the group keeps
+    its place; a sample whose reads hold an N (a set with an N plane) makes the whole group go sample by sample -- either way the calls are the single calls"""
+    locus, db, _odb, sc = real
+    reads = [locus.sample(np.random.default_rng(60 + k), sc[name][0], 160) for k, name in enumerate(NAMES[:4])]
+    key = lambda call, cons: (call.status, call.hap1, call.hap2, call.score, list(call.chain1[:call.n1]), list(call.chain2[:call.n2]), cons)
+    for with_n in (False, True):
+        rs = [list(r) for r in reads]
+        if with_n:
+            rs[2][5] = rs[2][5][:1000] + "N" + rs[2][5][1001:]
+        rs.insert(1, [])                                            # a sample without reads
+        sets = [gpu_ctx.upload(r) for r in rs]
+        single = []
+        for st in sets:
+            call, cons, _labels = db.diplotype(st)
+            single.append(key(call, cons))
+        cohort = db.diplotype_cohort(sets)
+        assert [key(call, cons) for call, cons, _rc in cohort] == single and all(rc == 0 for _c, _s, rc in cohort)
+        assert single[1][0] == 1 and [k[0] for k in single[:1] + single[2:]] == [0] * 4      # NO_READS for the empty one
+
+
 def test_hybrid_sample_on_a_second_locus(pkg, gpu_ctx):
     """The `*4+*68/*1` sample on another random chr22 locus, 2,000 reads: the 884 unseeded sequences are four classes (`*4`, `*1`, CYP2D7, the hybrid)
     for a search that holds two consensuses, and at this depth the search with the configured min_af exhausts its queue / capacity bounds and
