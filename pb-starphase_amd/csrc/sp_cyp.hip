@@ -1692,9 +1692,9 @@ extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* 
     return cyp_part_c(ctx, pr, reads, call, consensus, cons_cap, region_variants, m);
 }
 
-// The CYP2D6 calls of several samples (one GPU's share of a cohort): the samples are independent and each is a chain of launches that
-// wait for one another, so they are handed out to the context and its helper streams (sp_ctx_set_option "hla_split_genes" /
-// "hla_split_streams"), one host thread per stream for the length of the call.  Every call is the call sp_cyp_diplotype makes.
+// The CYP2D6 calls of several samples (one GPU's share of a cohort): each sample alone is a chain of small launches that wait for one another, so
+// GROUPS of samples are handed to the context and its helper streams (sp_ctx_set_option "hla_split_genes" / "cyp_cohort_streams"), one host thread
+// per stream for the length of the call, and a group goes through every stage that allows it together.  Every call is the call sp_cyp_diplotype makes.
 extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr, uint32_t n_samples, const sp_seqset* const* reads, sp_cyp_call* calls,
                                            char* consensus, uint32_t cons_cap, int32_t* sample_rc) {
     if (!ctx) return SP_ERR_INVALID_ARG;
@@ -1711,8 +1711,9 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
     std::vector<int32_t> rcs(n_samples, SP_OK); std::vector<int> where(n_samples, 0);
     std::atomic<uint32_t> next(0);
     // A stream takes a GROUP of samples at a time and keeps them in lockstep through the multi-way consensus (sp_consensus_priority_many): the launches of
-    // that stage -- two thirds of a sample's chain -- are then those of the group's slowest search, not their sum over its samples.  Regions, typing,
-    // weights and chains stay sample by sample.  Every call is the call sp_cyp_diplotype makes.
+    // that stage -- two thirds of a sample's chain -- are then those of the group's slowest search, not their sum over its samples.  The group's read
+    // sets are seen as one set (cyp_group_view): its regions of interest are one search, its weights one list of placements; its consensuses are typed in one
+    // batch.  Consensus inputs, merge, chains and the best chain pair stay sample by sample.
     const uint32_t group = std::min<uint32_t>(64, std::max<uint32_t>(1, (n_samples + (uint32_t)n_parts - 1) / (uint32_t)n_parts));
     auto work = [&](int x) {
         sp_ctx* c = on[x];
