@@ -1528,6 +1528,25 @@ __global__ void cons_setup_kernel(ConsSetup S, ReadInfo* __restrict__ info) {
     info[S.first + r] = ri;
 }
 
+// the same for ALL the problems of a batch in one launch (a cohort's lockstep round holds hundreds of problems: a launch each was 2 ms of a round): thread t is
+// read t of the flattened array; its problem is the last one that starts at or before t
+__global__ void cons_setup_many_kernel(const ConsSetup* __restrict__ S, int n_prob, int total, ReadInfo* __restrict__ info) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int lo = 0, hi = n_prob - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (S[mid].first <= t) lo = mid; else hi = mid - 1; }
+    while (lo + 1 < n_prob && S[lo].n == 0 && S[lo + 1].first <= t) ++lo;          // (problems without reads share their start with their successor)
+    const ConsSetup& q = S[lo];
+    const int r = t - q.first;
+    if (r < 0 || r >= q.n) return;
+    const uint32_t rid = q.idx ? q.idx[r] : (uint32_t)r;
+    ReadInfo ri;
+    ri.w = q.reads.words + q.reads.word_off[rid];
+    ri.np = q.reads.nplane ? q.reads.nplane + q.reads.word_off[rid] : nullptr;
+    ri.n = q.reads.len[rid]; ri.off = q.offsets ? q.offsets[r] : -1; ri.pad = 0;
+    info[t] = ri;
+}
+
 // scores and assignment of the reads on the complete node the search ended with
 template <int MAXP>
 __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBatchT<MAXP> B, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
@@ -1640,6 +1659,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     const size_t in_work = place(in_bytes, sizeof(CWork) * n_prob), in_srch = place(in_bytes, sizeof(CSearch) * n_prob);
     const size_t in_probs = place(in_bytes, MAXP == 0 ? sizeof(ConsParams) * n_prob : 0), in_bp = place(in_bytes, sizeof(int) * block_prob.size());
     const size_t in_cp = place(in_bytes, sizeof(int) * cluster_prob.size());
+    const size_t in_setup = place(in_bytes, n_prob > 8 ? sizeof(ConsSetup) * n_prob : 0);
     const size_t out_srch = place(out_bytes, sizeof(CSearch) * n_prob), out_res = place(out_bytes, sizeof(ConsRes) * n_prob);
     const size_t out_is1 = place(out_bytes, total), out_sc = place(out_bytes, sizeof(int32_t) * 2 * total);
     std::vector<size_t> out_cons(n_prob);
@@ -1710,6 +1730,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     }
     if (!h_idx.empty()) std::memcpy(h_in + in_idx, h_idx.data(), sizeof(uint32_t) * h_idx.size());
     if (!h_off.empty()) std::memcpy(h_in + in_off, h_off.data(), sizeof(int32_t) * h_off.size());
+    if (n_prob > 8) std::memcpy(h_in + in_setup, setup.data(), sizeof(ConsSetup) * n_prob);
     SP_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, st));
     SP_HIP_CHECK(ctx, hipMemsetAsync(d_zero, 0, zero_bytes, st));
     {   // the blocks the workgroups of small problems add their words to start at zero (the control step clears what it reads)
@@ -1720,7 +1741,8 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         SP_HIP_CHECK(ctx, hipMemsetAsync(B.PC + nb * (CW + 1), 0, sizeof(uint32_t) * np * (CW + 1), st));
         SP_HIP_CHECK(ctx, hipMemsetAsync(B.PR + nb * (CW + 1), 0, sizeof(uint32_t) * np * (CW + 1), st));
     }
-    for (uint32_t p = 0; p < n_prob; ++p)
+    if (n_prob > 8) hipLaunchKernelGGL(cons_setup_many_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const ConsSetup*)(d_in + in_setup), (int)n_prob, (int)total, d_info);
+    else for (uint32_t p = 0; p < n_prob; ++p)
         if (setup[p].n) hipLaunchKernelGGL(cons_setup_kernel, dim3((setup[p].n + 255) / 256), dim3(256), 0, st, setup[p], d_info);
 
     const dim3 grid((uint32_t)n_blocks), block(CWAVES * SP_WAVE);
