@@ -556,9 +556,13 @@ extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p
     int32_t* d_rwo = (int32_t*)(d_in + at_rwo); uint32_t* d_ed = (uint32_t*)(d_in + at_ed); double* d_ov = (double*)(d_in + at_ov);
     uint64_t* d_opt = (uint64_t*)(d_in + at_opt); uint64_t* d_worst = (uint64_t*)(d_in + at_worst);
     double* d_lf = (double*)(d_in + at_lf); double* d_lp = (double*)(d_in + at_lp);
-    unsigned long long* d_gb = (unsigned long long*)sp_pool(ctx, "k5_gb", 16);
-    double* d_bs = (double*)sp_pool(ctx, "k5_bs", blocks * 8); unsigned long long* d_bp = (unsigned long long*)sp_pool(ctx, "k5_bp", blocks * 8);
-    double* d_bc = (double*)sp_pool(ctx, "k5_bc", blocks * 40); unsigned long long* d_be = (unsigned long long*)sp_pool(ctx, "k5_be", blocks * 8);
+    // the results likewise come down in one copy: [global best, pairs scored | block scores | block pair ids | block edit distances | block components]
+    const size_t out_bytes = 16 + (size_t)blocks * (8 + 8 + 8 + 40);
+    uint8_t* d_out = (uint8_t*)sp_pool(ctx, "k5_out", out_bytes); uint8_t* h_out = (uint8_t*)sp_host_pool(ctx, "k5_out", out_bytes);
+    unsigned long long* d_gb = (unsigned long long*)d_out;
+    double* d_bs = (double*)(d_out + 16); unsigned long long* d_bp = (unsigned long long*)(d_out + 16 + (size_t)blocks * 8);
+    unsigned long long* d_be = (unsigned long long*)(d_out + 16 + (size_t)blocks * 16); double* d_bc = (double*)(d_out + 16 + (size_t)blocks * 24);
+    if (!d_out || !h_out) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "chain pair buffers");
     if (!d_chains || !d_clen || !d_unexp || !d_ninf || !d_del || !d_lasso || !d_norm || !d_rwo || !d_ed || !d_ov || !d_opt || !d_worst || !d_lf || !d_lp ||
         !d_gb || !d_bs || !d_bp || !d_bc || !d_be) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "chain pair buffers");
     unsigned long long* d_tb = (unsigned long long*)sp_pool(ctx, "k5_tab_best", std::max<size_t>(1, (size_t)P * R) * 8);
@@ -583,13 +587,10 @@ extern "C" int32_t sp_cyp_best_chain_pair(sp_ctx* ctx, const sp_chain_problem* p
         }
         if (hipGetLastError() != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "k5 launch failed");
     }
-    std::vector<double> bs(blocks), bc(blocks * 5); std::vector<unsigned long long> bp(blocks), be(blocks);
-    unsigned long long gb[2];
-    (void)hipMemcpyAsync(bs.data(), d_bs, blocks * 8, hipMemcpyDeviceToHost, ctx->stream);
-    (void)hipMemcpyAsync(bp.data(), d_bp, blocks * 8, hipMemcpyDeviceToHost, ctx->stream);
-    (void)hipMemcpyAsync(bc.data(), d_bc, blocks * 40, hipMemcpyDeviceToHost, ctx->stream);
-    (void)hipMemcpyAsync(be.data(), d_be, blocks * 8, hipMemcpyDeviceToHost, ctx->stream);
-    (void)hipMemcpyAsync(gb, d_gb, 16, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    const unsigned long long* gb = (const unsigned long long*)h_out;
+    const double* bs = (const double*)(h_out + 16); const unsigned long long* bp = (const unsigned long long*)(h_out + 16 + (size_t)blocks * 8);
+    const unsigned long long* be = (const unsigned long long*)(h_out + 16 + (size_t)blocks * 16); const double* bc = (const double*)(h_out + 16 + (size_t)blocks * 24);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("chain pair: ") + hipGetErrorString(e));
     res->n_pairs_scored = gb[1];
