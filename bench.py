@@ -371,7 +371,9 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     from pb_starphase_amd import shard
     panel = VariantPanel(pkg)
     mine = shard.partition(args.cohort_samples, world, rank)
-    per_call = 32                                                       # samples per cohort call (one GPU's share of the 8-GPU node)
+    # samples per cohort call: a rank's whole share (the calls keep groups of samples in lockstep, and the larger the groups the fewer launches a sample costs:
+    # 256 samples in calls of 32 / 64 / 128 / 256: 170 / 201 / 257 / 280 samples/s on one GPU)
+    per_call = max(1, min(len(mine), int(os.environ.get("SP_BENCH_PER_CALL", "256"))))
     chunks = [mine[i:i + per_call] for i in range(0, len(mine), per_call)]
     shares = [CohortShare(pkg, fx, locus, scen, panel, c) for c in chunks]
     for _ in range(args.warmup):
@@ -497,7 +499,7 @@ def main():
                    "config": {"workload": line["workload"], "samples": line["samples"], "parallelism": f"samples sharded over {world} GPU(s), one all-gather of the call records per pass through {gather_via}"
                               if backend == "nccl" else f"samples sharded over {world} rank(s) on shared devices, gather through torch.distributed ({backend})"},
                    "cohort": line, "roofline": None, "cpu_baseline": None,
-                   "note": "strong scaling: the cohort's work is fixed, every rank owns samples / N of it; the N = 1 figure for the same cohort is `legs.cohort` of the N = 1 line"}
+                   "note": "strong scaling: the cohort's work is fixed, every rank owns samples / N of it and hands its whole share to the library in one call; the calls keep groups of samples in lockstep, so a rank's rate falls with its share (one GPU: 280 / 257 / 201 / 165 samples/s for shares of 256 / 128 / 64 / 32 samples) -- the N = 1 figure for the same cohort is `legs.cohort` of the N = 1 line"}
             print(json.dumps(out), flush=True)
         if group is not None and hasattr(group, "close"):
             group.close()
