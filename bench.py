@@ -320,8 +320,9 @@ class CohortShare:
         self.n_reads = len(self.hla_reads) + self.cyp_reads
         self.n_genes_panel = len(panel.genes)
 
-    def step(self, pkg, ctx, db, cdb, shard, group, rank):
-        """uploads, calls and the gather of one pass over the share; returns (records table, counts of calls equal to the truth)"""
+    def step(self, pkg, ctx, db, cdb, shard, group, rank, same_count=False):
+        """uploads, calls and the gather of one pass over the share; returns (records table, counts of calls equal to the truth).
+        same_count: every rank holds the same number of records in this round (the caller knows: equal shares), so the counts are not exchanged"""
         fx = self.fx
         genes = list(range(len(fx.genes)))
         tm = self.host_s = getattr(self, "host_s", {"upload": 0.0, "hla": 0.0, "cyp2d6": 0.0, "variant_genes": 0.0, "records_and_gather": 0.0})
@@ -359,7 +360,7 @@ class CohortShare:
                 ok_var += any({d[0], d[1]} == {h1, h2} for d in dips)
                 d0 = dips[0] if dips else (-1, -1, 0)
                 rec[at] = (s, len(genes) + 1 + gi, d0[0], d0[1]); at += 1
-        table = shard.gather_calls(rec, group=group, same_count=True)
+        table = shard.gather_calls(rec, group=group, same_count=same_count)
         R.close()
         for c in cyp_sets:
             c.close()
@@ -376,8 +377,26 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     per_call = max(1, min(len(mine), int(os.environ.get("SP_BENCH_PER_CALL", "256"))))
     chunks = [mine[i:i + per_call] for i in range(0, len(mine), per_call)]
     shares = [CohortShare(pkg, fx, locus, scen, panel, c) for c in chunks]
+    # every rank makes the same number of gathers per pass, whatever its share: shares differ by one sample when the cohort does not divide by the ranks (and a rank
+    # may hold none at all), so the rounds a rank has no chunk for are gathers of zero records, and the counts are only taken as known when all shares are equal
+    cap_call = int(os.environ.get("SP_BENCH_PER_CALL", "256"))
+    sizes = [len(shard.partition(args.cohort_samples, world, r)) for r in range(world)]
+    rounds = max(-(-n // max(1, min(n, cap_call))) if n else 0 for n in sizes)
+    equal_shares = len(set(sizes)) == 1
+    empty = np.zeros(0, shard.CALL_DTYPE)
+
+    def one_pass(only_first=False):
+        good_sum, n_tab = np.zeros(3, np.int64), 0
+        for q in range(1 if only_first else rounds):
+            if q < len(shares):
+                table, good = shares[q].step(pkg, ctx, db, cdb, shard, group, rank, same_count=equal_shares)
+                good_sum += np.array(good)
+            else:
+                table = shard.gather_calls(empty, group=group, same_count=False)
+            n_tab += len(table)
+        return good_sum, n_tab
     for _ in range(args.warmup):
-        shares[0].step(pkg, ctx, db, cdb, shard, group, rank)
+        one_pass(only_first=True)
     for sh in shares:
         sh.host_s = {"upload": 0.0, "hla": 0.0, "cyp2d6": 0.0, "variant_genes": 0.0, "records_and_gather": 0.0}
     barrier()
@@ -385,9 +404,8 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     ok = np.zeros(3, np.int64)
     n_table = 0
     for _ in range(args.steps):
-        for sh in shares:
-            table, good = sh.step(pkg, ctx, db, cdb, shard, group, rank)
-            ok += np.array(good); n_table += len(table)
+        good, n_tab = one_pass()
+        ok += good; n_table += n_tab
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     my_reads = sum(sh.n_reads for sh in shares)
@@ -398,7 +416,7 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     n_genes = len(fx.genes)
     return {"value": reads_all * args.steps / dt, "unit": "reads/s", "samples_per_s": samples_all * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
             "samples": samples_all, "reads_per_pass": reads_all,
-            "rank0_host_seconds_per_pass": {k: sum(sh.host_s[k] for sh in shares) / max(1, args.steps) for k in shares[0].host_s}, "records_gathered_per_pass": n_table // max(1, args.steps),
+            "rank0_host_seconds_per_pass": {k: sum(sh.host_s[k] for sh in shares) / max(1, args.steps) for k in (shares[0].host_s if shares else {})}, "records_gathered_per_pass": n_table // max(1, args.steps),
             "calls_equal_truth": {"hla": f"{int(totals[2])}/{samples_all * n_genes * args.steps}", "cyp2d6": f"{int(totals[3])}/{samples_all * args.steps}",
                                   "variant_genes_truth_among_reported": f"{int(totals[4])}/{samples_all * len(panel.genes) * args.steps}"},
             "workload": f"BASELINE configs[4]: {args.cohort_samples} synthetic WGS-style samples x (HLA-A / -B ~44 reads per gene, CYP2D6 ~100 reads, {len(panel.genes)} variant genes), "

@@ -188,8 +188,9 @@ void    sp_hla_db_free(sp_hla_db* db);
  *   seg_start/end  optimal_segment_start..end on the read (:266-267), dna_offset / hpc_offset (:270-325);
  *                status 0 = realigned, 1 = no acceptable allele, 2 = best mapping not Forward (:178-193; decided at the seeds: the
  *                read's best anchor on the reverse-complemented gene references has more 16-mer votes than its best forward
- *                anchor -- only reads with fewer than 512 forward votes are anchored a second time; the other fields then hold what
- *                the forward search found), 3 = segment failed to map to the gene reference.
+ *                anchor -- only reads with fewer than 512 forward votes are anchored a second time, and a read that realigned
+ *                acceptably forwards is only dropped when the reverse anchor has at least twice the votes; the other fields then
+ *                hold what the forward search found), 3 = segment failed to map to the gene reference.
  */
 typedef struct {
     int32_t status;

@@ -1731,6 +1731,7 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
     const uint32_t group = std::min<uint32_t>(64, std::max<uint32_t>(1, (n_samples + (uint32_t)n_parts - 1) / (uint32_t)n_parts));
     auto work = [&](int x) {
         sp_ctx* c = on[x];
+        (void)hipSetDevice(c->device);             // a new host thread starts on device 0: everything below (pools, copies, launches) belongs to the context's device
         for (;;) {
             const uint32_t first = next.fetch_add(group);
             if (first >= n_samples) break;

@@ -402,6 +402,7 @@ int sp_fail(sp_ctx* ctx, int code, const std::string& msg) { if (ctx) ctx->err =
 
 void* sp_scratch(sp_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return ctx->scratch;
+    (void)hipSetDevice(ctx->device);       // the current device is per host thread: a helper thread's first HIP call may be this allocation
     if (ctx->scratch) { hipFree(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
     size_t want = bytes + bytes / 4;
     if (hipMalloc(&ctx->scratch, want) != hipSuccess) { ctx->scratch = nullptr; return nullptr; }
@@ -412,6 +413,7 @@ void* sp_scratch(sp_ctx* ctx, size_t bytes) {
 void* sp_pool(sp_ctx* ctx, const char* name, size_t bytes) {
     auto& e = ctx->pool[name];
     if (bytes <= e.second && e.first) return e.first;
+    (void)hipSetDevice(ctx->device);       // (as in sp_scratch: never allocate on whatever device the calling thread happens to have current)
     if (e.first) { (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
     size_t want = bytes + bytes / 8 + 256;
     if (hipMalloc(&e.first, want) != hipSuccess) { e.first = nullptr; return nullptr; }
@@ -432,6 +434,7 @@ unsigned long long* sp_counters(sp_ctx* ctx) {
 void* sp_host_pool(sp_ctx* ctx, const char* name, size_t bytes) {
     auto& e = ctx->host_pool[name];
     if (bytes <= e.second && e.first) return e.first;
+    (void)hipSetDevice(ctx->device);
     if (e.first) { (void)hipHostFree(e.first); e.first = nullptr; e.second = 0; }
     size_t want = bytes + bytes / 8 + 256;
     if (hipHostMalloc(&e.first, want, hipHostMallocDefault) != hipSuccess) { e.first = nullptr; return nullptr; }

@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -26,11 +27,14 @@ struct Rccl {
     std::string err;
 };
 
+void rccl_load(Rccl& R);
 Rccl* rccl() {
     static Rccl R;
-    static bool tried = false;
-    if (tried) return &R;
-    tried = true;
+    static std::once_flag once;                      // (two host threads on different contexts may come here together: the table is filled exactly once, before anyone reads it)
+    std::call_once(once, []() { rccl_load(R); });
+    return &R;
+}
+void rccl_load(Rccl& R) {
     // The RCCL to use is the one that sits on the HIP runtime THIS library is bound to: a Python process with torch carries a second HIP runtime
     // and a second RCCL (torch/lib), and a stream of one runtime means nothing to the other.  Where our own hipMalloc lives tells which runtime
     // that is; its directory holds the matching librccl.  RTLD_DEEPBIND makes that RCCL resolve its HIP calls through its own dependencies
@@ -51,14 +55,13 @@ Rccl* rccl() {
     }
     const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
     for (const char* n : names) { if (R.h) break; R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND); }
-    if (!R.h) { R.err = "librccl.so not found"; return &R; }
+    if (!R.h) { R.err = "librccl.so not found"; return; }
     R.GetUniqueId = (int (*)(NcclId*))dlsym(R.h, "ncclGetUniqueId");
     R.CommInitRank = (int (*)(ncclComm_t*, int, NcclId, int))dlsym(R.h, "ncclCommInitRank");
     R.CommDestroy = (int (*)(ncclComm_t))dlsym(R.h, "ncclCommDestroy");
     R.AllGather = (int (*)(const void*, void*, size_t, int, ncclComm_t, hipStream_t))dlsym(R.h, "ncclAllGather");
     R.GetErrorString = (const char* (*)(int))dlsym(R.h, "ncclGetErrorString");
     if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) { R.err = "librccl.so lacks the collective entry points"; dlclose(R.h); R.h = nullptr; }
-    return &R;
 }
 
 } // namespace

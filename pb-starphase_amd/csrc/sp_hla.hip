@@ -373,7 +373,7 @@ __global__ void k1_reverse_kernel(const uint32_t* __restrict__ weak_list, uint32
         const int f = votes_fwd[(size_t)r * n_genes + g], v = votes_rev[(size_t)k * n_genes + g];
         fb = f > fb ? f : fb; rb = v > rb ? v : rb;
     }
-    is_reverse[r] = (rb >= K1_MIN_VOTES_REV && rb > fb) ? 1 : 0;
+    is_reverse[r] = (rb >= K1_MIN_VOTES_REV && rb > fb) ? (rb >= 2 * fb ? 2 : 1) : 0;      // 2: a clear margin, 1: out-voted narrowly (only counts against a read that found nothing acceptable forwards)
 }
 
 // K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
@@ -1079,8 +1079,10 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("realign: ") + hipGetErrorString(e));
         else if (h_out) std::memcpy(out, h_out, (size_t)R * sizeof(sp_hla_realign));
-        // a read that anchors better on the reverse strand is dropped whatever it found forwards (the record keeps what the forward search found)
-        if (rc == SP_OK && h_isrev) for (uint32_t r = 0; r < R; ++r) if (h_isrev[r]) out[r].status = 2;
+        // a read that anchors better on the reverse strand is dropped (the record keeps what the forward search found) -- unless it realigned acceptably forwards and the
+        // reverse anchor leads by less than a factor of two: the reference drops a read only when minimap2's best SCORING mapping is reverse (realigner.rs:178-193), and a
+        // read that passes the forward filters with a weak, repeat-ridden anchor is not one of those
+        if (rc == SP_OK && h_isrev) for (uint32_t r = 0; r < R; ++r) if (h_isrev[r] == 2 || (h_isrev[r] == 1 && out[r].status != 0)) out[r].status = 2;
         if (rc == SP_OK && cell_out) {                        // the device rows are in visiting order: hand them out by allele index
             std::vector<uint32_t> row(NA);
             for (uint32_t r = 0; r < R; ++r) {

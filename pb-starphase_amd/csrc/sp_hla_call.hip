@@ -350,6 +350,7 @@ static int32_t hla_solve_side_by_side(sp_ctx* ctx, const sp_hla_db* db, uint32_t
     for (uint32_t k = 0; k < n_units; ++k) { Part& q = part[k % (uint32_t)n_parts]; q.at.push_back(k); q.genes.push_back(genes[k]); if (unit_sample) q.samples.push_back(unit_sample[k]); q.cfgs.push_back(cfgs[k]); }
     for (int x = 0; x < n_parts; ++x) { part[x].calls.resize(part[x].at.size()); part[x].cons.assign((size_t)2 * part[x].at.size() * cap, '\0'); }
     auto solve = [&](sp_ctx* c, Part& q) {                             // (never lets an exception out: a thread that is still joinable when the stack unwinds ends the process)
+        (void)hipSetDevice(c->device);                                 // (a helper thread starts on device 0)
         try {
             q.rc = hla_solve_units(c, db, (uint32_t)q.at.size(), q.genes.data(), unit_sample ? q.samples.data() : nullptr, read_sample, reads, realign, q.cfgs.data(), q.calls.data(),
                                    q.cons.data(), cap, is_cons1_out, false);

@@ -92,7 +92,13 @@ struct Bgzf {
         size_t out = 0;
         for (int k = 0; k < max_blocks; ++k) {
             Blk b{}; bool at_end = false;
-            if (!read_block(next_at, b, at_end)) return false;
+            const uint64_t here = next_at;
+            if (!read_block(next_at, b, at_end)) {
+                // a damaged or truncated block behind good ones: the batch ends in front of it, and the error is raised only if the reader ever gets there
+                // (a region fetch whose records all lie before it must succeed, as it did when blocks were read one at a time)
+                if (blks.empty()) return false;
+                err.clear(); next_at = here; break;
+            }
             if (at_end) { if (blks.empty()) eof = true; break; }
             b.out_off = out; out += b.isize;
             blks.push_back(b);
@@ -102,13 +108,12 @@ struct Bgzf {
         unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1;
         const size_t nt = std::min<size_t>({ (size_t)hw, (size_t)16, nb / 4 });
         std::atomic<size_t> next_blk(0);
-        std::atomic<const char*> first_err(nullptr);
+        std::vector<const char*> blk_err(nb, nullptr);
         auto work = [&]() {
             for (;;) {
                 const size_t i = next_blk.fetch_add(1);
                 if (i >= nb) break;
-                const char* e = inflate_one(raw.data() + blks[i].raw_off, blks[i].raw_len, data.data() + blks[i].out_off, blks[i].isize, blks[i].crc);
-                if (e) { const char* none = nullptr; first_err.compare_exchange_strong(none, e); }
+                blk_err[i] = inflate_one(raw.data() + blks[i].raw_off, blks[i].raw_len, data.data() + blks[i].out_off, blks[i].isize, blks[i].crc);
             }
         };
         if (nt <= 1) work();
@@ -118,7 +123,11 @@ struct Bgzf {
             work();
             for (auto& t : th) t.join();
         }
-        if (first_err.load()) { err = first_err.load(); return false; }
+        for (size_t i = 0; i < nb; ++i) if (blk_err[i]) {
+            if (i == 0) { err = blk_err[0]; return false; }
+            next_at = blks[i].at; data.resize(blks[i].out_off); blks.resize(i);       // (as above: the blocks in front of the bad one are served)
+            break;
+        }
         return true;
     }
     bool seek(uint64_t voffset) {
@@ -308,9 +317,10 @@ int32_t sp_bam_fetch(sp_bam* b, const char* chrom, uint64_t start, uint64_t end,
     } else chunks.emplace_back(b->first_record, UINT64_MAX);
     static const char decode[] = "=ACMGRSVTWYHKDBN";
     std::vector<uint8_t> rec;
+    bool past = false;                        // (chunks are visited in file order and the file is sorted: a record behind the region ends the fetch, not only its chunk -- htslib's iterator does the same)
     for (const auto& chunk : chunks) {
+        if (past) break;
         if (!b->z.seek(chunk.first)) return bam_fail(b, b->z.err.empty() ? "bad virtual offset in the index" : b->z.err);
-        bool past = false;
         while (!past && b->z.tell() < chunk.second) {
             uint8_t h4[4];
             if (!b->z.read(h4, 4)) { if (!b->z.err.empty()) return bam_fail(b, b->z.err); break; }

@@ -71,15 +71,16 @@ class K1Tables:
 
     def is_reverse(self, re, anch):
         """src/hla/realigner.rs:178-193 at the level of the seeds (include/starphase_hip.h, sp_hla_realign.status 2): a read with a weak forward
-        anchor (< 512 votes) whose best anchor on the reverse-complemented gene references has more votes (and >= 16) is dropped"""
+        anchor (< 512 votes) whose best anchor on the reverse-complemented gene references has more votes (and >= 16) is dropped: 2 when the
+        reverse anchor leads by a factor of two or more, 1 when it leads by less (then only a read that did not realign forwards is dropped)"""
         fwd = max((v for _d, v in anch), default=0)
         if fwd >= K1_WEAK_VOTES:
-            return False
+            return 0
         if not hasattr(self, "refs_rev"):
             comp = np.array([3, 2, 1, 0, 4], np.uint8)
             self.refs_rev = [np.ascontiguousarray(comp[r][::-1]) for r in self.refs]
         rev = max((self.oracle.anchor(rr, re)[1] for rr in self.refs_rev), default=0)
-        return rev >= K1_MIN_VOTES and rev > fwd
+        return (2 if rev >= 2 * fwd else 1) if (rev >= K1_MIN_VOTES and rev > fwd) else 0
 
     def cell(self, a, re, anch):
         cap = min(511, int(0.03 * len(self.fwd[a])) + 1)
@@ -114,7 +115,8 @@ class K1Tables:
                 d = added + int(bm["a_start"])
                 h = oracle.hpc_pos(fx.gene_ref[g], added) + oracle.hpc_pos(fx.dna[best], int(bm["a_start"]))
             res.update(status=0, seg_start=min(db_s, adj_s), seg_end=max(db_e, adj_e), dna_offset=d, hpc_offset=h)
-        if self.is_reverse(re, anch):
+        rv = self.is_reverse(re, anch)
+        if rv == 2 or (rv == 1 and res["status"] != 0):
             res["status"] = 2                                  # (the other fields keep what the forward search found)
         return res
 

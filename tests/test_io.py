@@ -321,6 +321,31 @@ def test_bam_many_blocks_inflate_side_by_side(D, pkg, tmp_path):
     assert scan.fetch("chr6", 1000000, 1900000) == expected(records, refs, "chr6", 1000000, 1900000)
 
 
+def test_bam_damage_behind_the_region_does_not_fail_the_fetch(D, pkg, tmp_path):
+    """the reader inflates batches of blocks ahead of the records it hands out: a damaged or truncated block that lies behind everything the region
+    needs ends the batch in front of it, and is an error only for a fetch that gets there (ADVICE r3, sp_io.hip Bgzf::load)"""
+    rng = np.random.default_rng(5)
+    refs = [("chr6", 3000000)]
+    records = make_records(rng, refs, 3000)
+    path = str(tmp_path / "big.bam")
+    write_bam(path, refs, records, 6000, index=True)
+    data = bytearray(open(path, "rb").read())
+    early = expected(records, refs, "chr6", 0, 400000)
+    assert len(early) > 100
+    for name, frac in (("flip16", 0.16), ("flip18", 0.18), ("flip22", 0.22), ("flip30", 0.30), ("flip90", 0.9), ("cut17", 0.17), ("cut25", 0.25), ("cut90", 0.9)):
+        d2 = bytearray(data)
+        if name.startswith("flip"):
+            d2[int(len(d2) * frac)] ^= 0x5A
+        else:
+            d2 = d2[:int(len(d2) * frac)]
+        bad = str(tmp_path / (name + ".bam"))
+        open(bad, "wb").write(d2)
+        open(bad + ".bai", "wb").write(open(path + ".bai", "rb").read())
+        assert D.Bam(bad).fetch("chr6", 0, 400000) == early
+        with pytest.raises(pkg.StarphaseError):
+            D.Bam(bad).fetch("chr6", 0, 3000000)
+
+
 # ------------------------------------------------------------------ reference FASTA
 def write_fasta(path, seqs, width, newline="\n", lower=False, index=False, describe=False):
     """a FASTA file the way samtools faidx expects it (fixed line width per sequence) and, optionally, its .fai"""
