@@ -63,8 +63,8 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * "hla_split_streams" (1..4, default 3) streams -- helper streams the context owns, one host thread each for the length of the call:
  * lowest latency for one call; set hla_split_genes to 0 when several samples are in flight on contexts of their own, where the streams
  * of the other samples already fill the gaps (sp_cyp_diplotype follows the same switch: with 1 it places the regions of interest on the consensuses
- * for its weights on a helper stream while it types the consensuses).  The calls are the same either way.  "cons_retry_ladder" (default 1): 0 makes sp_cyp_diplotype* run
- * its multi-way consensus without the retry of searches that give up (sp_cons_config.no_retry_ladder, see sp_consensus_priority).
+ * for its weights on a helper stream while it types the consensuses).  The calls are the same either way.  "cons_retry_ladder" (default 0: the reference has no such rule): 1 makes sp_cyp_diplotype* run
+ * its multi-way consensus with the retry of searches that give up (sp_cons_config.no_retry_ladder = 0, see sp_consensus_priority); sp_cyp_call.gave_up says whether a search of the call gave up.
  * "cyp_cohort_streams" (1..8, default 6): streams sp_cyp_diplotype_cohort spreads its groups of samples over (one host thread each).
  * "k5_block_pairs" (0..1048576, default 4096): sp_cyp_best_chain_pair scores up to this many chain pairs with one workgroup per pair (the few pairs
  * of an ordinary sample: the reads of a pair are shared out over the workgroup), more with one thread per pair; the results are the same.
@@ -388,6 +388,8 @@ typedef struct {
      * region as "(<index>_<full allele>[ +label | -label | ?label ...])" with the variants that differ from the assigned star allele --
      * the haplotypes of the InexactDiplotype the reference stores for CYP2D6 (:711-716,737); truncated to the buffer */
     char deep1[2048], deep2[2048];
+    int32_t searches_gave_up;                     /* two-way searches of the multi-way consensus that ended without a complete node: their groups stayed whole */
+    int32_t reserved_;
 } sp_cyp_call;
 
 int32_t sp_cyp_diplotype(sp_ctx* ctx, const sp_cyp_problem* problem, const sp_seqset* reads, sp_cyp_call* call,
@@ -568,13 +570,15 @@ typedef struct {
     int32_t allow_early_termination;
     int32_t allow_dual;
     int32_t offset_window;             /* 400 */
-    int32_t offset_compare_length;     /* 50 for HLA; sp_cyp_diplotype uses 64 (see sp_cyp.hip).  At most 128; at most 64 with an offset_window above 512 */
+    int32_t offset_compare_length;     /* 50 for HLA (src/hla/caller.rs:1114), 100 for CYP2D6 (src/cyp2d6/caller.rs:144).  At most 128; at most 64 when offset_window + offset_compare_length exceeds 512.
+                                        * A read with an offset is placed when the consensus reaches offset + min(offset_compare_length, its length): its start is searched in
+                                        * [offset - offset_window, offset], its first bases compared with the consensus behind each start (free end on the consensus) */
     double  min_af;                    /* 0.10 */
     int32_t max_queue_size;            /* 20    CdwfaConfig::max_queue_size, set by dwfa_config_from_cli (src/hla/caller.rs:1110) */
     int32_t max_capacity_per_size;     /* 10    CdwfaConfig::max_capacity_per_size (:1111) */
     int32_t max_nodes_wo_constraint;   /* 1000  waffle_con's default; the reference does not set it */
     int32_t no_retry_ladder;           /* (<= 0 in any of the three above: the value named there)  sp_consensus_priority only: 1 = a two-way search that
-                                        * gives up is NOT run again with stricter fractions (see there); 0 = the default */
+                                        * gives up is NOT run again with stricter fractions (see there); sp_cyp_diplotype* set it unless the context's "cons_retry_ladder" is 1 */
 } sp_cons_config;
 
 typedef struct {
@@ -638,6 +642,7 @@ typedef struct sp_priority_job {
     uint32_t max_groups, cap;
     uint32_t* n_groups; int32_t* group_of; char* cons;      /* as the arguments of sp_consensus_priority */
     int32_t status;
+    int32_t gave_up;                                        /* out: two-way searches of this job that ended without a complete node (sp_cons_result.gave_up) and were not retried */
 } sp_priority_job;
 int32_t sp_consensus_priority_many(sp_ctx* ctx, uint32_t n_jobs, sp_priority_job* jobs);
 

@@ -179,6 +179,8 @@ pub struct sp_cyp_call {
     pub core2: [c_char; 256],
     pub deep1: [c_char; 2048],
     pub deep2: [c_char; 2048],
+    pub searches_gave_up: i32,
+    pub reserved_: i32,
 }
 #[repr(C)]
 pub struct sp_cyp_region_variants {
@@ -351,6 +353,7 @@ pub struct sp_priority_job {
     pub group_of: *mut i32,
     pub cons: *mut c_char,
     pub status: i32,
+    pub gave_up: i32,
 }
 #[repr(C)]
 pub struct sp_hla_call_config {

@@ -91,18 +91,25 @@ static void dwfa_push(dwfa* d, const uint8_t* S, int n, const uint8_t* C, int T,
     if (early_termination && dwfa_read_done(d, n)) d->finished = 1;
 }
 
-/* start of a late read on the consensus: Sellers' search of the read's first L bases in the last W consensus bases */
-static int find_start(const uint8_t* S, int n, const uint8_t* C, int off, int W, int L) {
-    const int ws = off - W > 0 ? off - W : 0, M = off - ws;
+/* Start of a late read on the consensus (add_sequence_offset).  The reference's callers say what the crate searches: start positions in the
+ * offset_window bases BEFORE the offset ("the config only lets us look before; so we have to shift things", src/cyp2d6/caller.rs:145-146), comparing
+ * the read's first offset_compare_length bases (100 for CYP2D6 in a window of 2 x 50, :144-159; 50 in 400 for HLA, src/hla/caller.rs:1113-1114).  A
+ * 100-base comparison from a start 0..100 bases before the offset needs the consensus up to offset + 100, so a read is placed when the consensus
+ * reaches length off + L (L = min(offset_compare_length, read length)): every candidate start p in [off - W, off] then has at least L consensus
+ * bases behind it.  ed(p) = the fewest edits between the read's first L bases and ANY prefix of C[p .. len) (Sellers: the end on the consensus is
+ * free); the smallest ed wins, ties go to the start closest to the middle of the window (off - W / 2: the expected start), then to the leftmost.
+ * The DP runs backwards (pattern and text reversed, free start in the reversed text): its last row holds ed(p) for p = len - j. */
+static int find_start(const uint8_t* S, int n, const uint8_t* C, int len, int off, int W, int L) {
+    const int ws = off - W > 0 ? off - W : 0, M = len - ws;
     if (L > n) L = n;
-    if (M <= 0 || L <= 0) return off;
+    if (M <= 0 || L <= 0 || off <= ws) return off < len ? off : len;
     int* prev = (int*)malloc(sizeof(int) * (size_t)(M + 1)), *cur = (int*)malloc(sizeof(int) * (size_t)(M + 1));
     for (int j = 0; j <= M; ++j) prev[j] = 0;                                                 /* free start in the (reversed) text */
     for (int i = 1; i <= L; ++i) {
         const uint8_t p = S[L - i];
         cur[0] = i;
         for (int j = 1; j <= M; ++j) {
-            const uint8_t x = C[off - j];
+            const uint8_t x = C[len - j];
             int v = prev[j - 1] + ((p < 4 && p == x) ? 0 : 1);
             if (prev[j] + 1 < v) v = prev[j] + 1;
             if (cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
@@ -112,18 +119,25 @@ static int find_start(const uint8_t* S, int n, const uint8_t* C, int off, int W,
     }
     const int centre = off - W / 2;
     int best_p = off, best_d = 1 << 30, best_c = 1 << 30;
-    for (int j = 1; j <= M; ++j) {
-        const int p = off - j, dist = p > centre ? p - centre : centre - p;
+    for (int j = len - off; j <= M; ++j) {                                                    /* starts off, off - 1, ..., ws */
+        if (j < 1) continue;
+        const int p = len - j, dist = p > centre ? p - centre : centre - p;
         if (prev[j] < best_d || (prev[j] == best_d && (dist < best_c || (dist == best_c && p < best_p)))) { best_d = prev[j]; best_c = dist; best_p = p; }
     }
     free(prev); free(cur);
     return best_p;
 }
 
+/* the consensus length at which read r is placed: its offset + the bases the placement compares */
+static int activation_length(int off, int n, const osp_cons_config* cfg) {
+    const int L = cfg->offset_compare_length < n ? cfg->offset_compare_length : n;
+    return off + (L > 0 ? L : 0);
+}
+
 static void activate(dwfa* d, const uint8_t* S, int n, const uint8_t* C, int len, int off, const osp_cons_config* cfg) {
     dwfa_reset(d);
     d->active = 1;
-    d->c0 = off < 0 ? 0 : find_start(S, n, C, off, cfg->offset_window, cfg->offset_compare_length);
+    d->c0 = off < 0 ? 0 : find_start(S, n, C, len, off, cfg->offset_window, cfg->offset_compare_length);
     d->H[HALF] = 0;
     for (int T = 0; T <= len - d->c0; ++T) {
         if (T == 0) { if (n == 0 && cfg->allow_early_termination) d->finished = 1; continue; }
@@ -228,7 +242,7 @@ static void node_push(const problem* P, node* x, const int b[2]) {
         for (int r = 0; r < P->n_reads; ++r) {
             dwfa* d = &x->st[i][r];
             if (d->active) { if (!d->finished && d->tracked) dwfa_push(d, P->seqs[r], P->lens[r], x->C[i], x->len[i] - d->c0, cfg->allow_early_termination); }
-            else if (P->offsets[r] == x->len[i]) activate(d, P->seqs[r], P->lens[r], x->C[i], x->len[i], P->offsets[r], cfg);
+            else if (P->offsets[r] >= 0 && activation_length(P->offsets[r], P->lens[r], cfg) == x->len[i]) activate(d, P->seqs[r], P->lens[r], x->C[i], x->len[i], P->offsets[r], cfg);
         }
     }
     if (x->dual) for (int r = 0; r < P->n_reads; ++r) {
@@ -335,14 +349,15 @@ int osp_consensus(int n_reads, const uint8_t* const* seqs, const int32_t* lens, 
             if (nq >= QCAP) { node_free(c); continue; }            /* (never reached with max_queue_size <= 32: the threshold below keeps the queue short) */
             queue[nq++] = c;
         }
-        while (nq > max_queue) {                                  /* too many nodes wait: the one the search would take last goes */
-            int wi = 0;
-            for (int q = 1; q < nq; ++q) {
-                const node* a = queue[q], *b = queue[wi];
-                if (a->cost > b->cost || (a->cost == b->cost && (a->t < b->t || (a->t == b->t && a->id > b->id)))) wi = q;
-            }
-            node_free(queue[wi]); queue[wi] = queue[--nq];
+        /* too many nodes wait: the length threshold rises until at most max_queue_size nodes stand at or above it -- the SHORTEST nodes go, the search is
+         * pushed forwards (CdwfaConfig::max_queue_size: "if the queue exceeds this size, the threshold for ignoring nodes is increased") */
+        for (;;) {
+            int live = 0, shortest = 1 << 30;
+            for (int q = 0; q < nq; ++q) if (queue[q]->t >= threshold) { ++live; if (queue[q]->t < shortest) shortest = queue[q]->t; }
+            if (live <= max_queue) break;
+            threshold = shortest + 1;
         }
+        for (int q = 0; q < nq;) { if (queue[q]->t < threshold) { node_free(queue[q]); queue[q] = queue[--nq]; } else ++q; }
     }
     for (int q = 0; q < nq; ++q) node_free(queue[q]);
     free(processed);

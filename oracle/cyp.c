@@ -632,8 +632,6 @@ int osp_cyp_variant_states(const uint8_t* seq, int seq_len, const uint8_t* backb
     osp_aln al; uint32_t ev[OSP_MAX_ED + 1]; int nev = 0;
     if (!osp_wfa_retry2(seq, seq_len, backbone, backbone_len, diag, OSP_MAX_ED, &al, ev, &nev)) return 0;
     if (aln_out) { aln_out[0] = al.a_start; aln_out[1] = al.a_end; aln_out[2] = al.b_start; aln_out[3] = al.b_end; aln_out[4] = al.nm; }
-    const int gs = al.b_start, ge = al.b_end, L = al.a_end - al.a_start;
-    const uint8_t* S = seq + al.a_start;
     /* the band: centred on the middle of the drift the linear placement shows (insertions push the read on, deletions pull it back) */
     int drift = 0, dmin = 0, dmax = 0;
     for (int e = 0; e < nev; ++e) {
@@ -642,7 +640,20 @@ int osp_cyp_variant_states(const uint8_t* seq, int seq_len, const uint8_t* backb
         if (drift < dmin) dmin = drift;
         if (drift > dmax) dmax = drift;
     }
-    const int k0 = (dmin + dmax) / 2 - K9_DIAGS / 2;
+    return osp_cyp_variant_states_at(seq, seq_len, backbone, backbone_len, n_variants, var_pos, var_ref, var_alt, al.a_start, al.a_end, al.b_start, al.b_end,
+                                     (dmin + dmax) / 2, states);
+}
+
+/* the graph half of the above for a GIVEN placement (sequence [a_start, a_end) on backbone [b_start, b_end), band centred on drift_centre): what
+ * tests/cpu_port_cyp.py calls with the placement of the minimap2 restatement (omm_cyp_place), as assign_haplotype does with minimap2's */
+int osp_cyp_variant_states_at(const uint8_t* seq, int seq_len, const uint8_t* backbone, int backbone_len, int n_variants, const int32_t* var_pos,
+                              const char* const* var_ref, const char* const* var_alt, int a_start, int a_end, int b_start, int b_end, int drift_centre,
+                              uint8_t* states) {
+    (void)seq_len;
+    for (int v = 0; v < n_variants; ++v) states[v] = 3;
+    const int gs = b_start, ge = b_end, L = a_end - a_start;
+    const uint8_t* S = seq + a_start;
+    const int k0 = drift_centre - K9_DIAGS / 2;
     /* sites */
     int* order = (int*)malloc(sizeof(int) * (size_t)(n_variants + 1)); int no = 0;
     for (int v = 0; v < n_variants; ++v) { const int rl = (int)strlen(var_ref[v]); if (var_pos[v] >= gs && var_pos[v] + rl <= ge) order[no++] = v; }

@@ -76,6 +76,10 @@ void osp_cyp_score_alleles(int n_variants, int n_alleles, const uint8_t* hap_mat
 int osp_cyp_variant_states(const uint8_t* seq, int seq_len, const uint8_t* backbone, int backbone_len, int n_variants, const int32_t* var_pos,
                            const char* const* var_ref, const char* const* var_alt, uint8_t* states, int32_t* aln_out /* a_start, a_end, b_start, b_end, nm */);
 
+int osp_cyp_variant_states_at(const uint8_t* seq, int seq_len, const uint8_t* backbone, int backbone_len, int n_variants, const int32_t* var_pos,
+                              const char* const* var_ref, const char* const* var_alt, int a_start, int a_end, int b_start, int b_end, int drift_centre,
+                              uint8_t* states);            /* the graph half of osp_cyp_variant_states for a given placement */
+
 /* chain building (src/cyp2d6/caller.rs:429-583).  Segments of read r = [read_seg_off[r], read_seg_off[r+1]) in region order;
  * ed = [segment][n_haps] from weight_sequence, kept[segment] = 0 when weight_sequence returned the empty vector.
  * Outputs (all caller-sized; return 0 ok, 1 capacity, 2 "chain collapse" panic):

@@ -96,6 +96,11 @@ int32_t omm_hla_score_read(const uint8_t* cons_cdna, int32_t cdna_len, const uin
                            const uint8_t* const* cdna, const int32_t* cdna_lens, const uint8_t* const* dna, const int32_t* dna_lens,
                            const omm_opts* o, int64_t* stats);
 
+/* the CYP2D6 call sites in the reference's call pattern on this file's mappings (oracle/cyp_mm2.c; osp_region_hit is cyp_oracle.h's) */
+int omm_cyp_weight_sequence(const uint8_t* seq, int seq_len, int n_cons, const uint8_t* const* cons, const int32_t* cons_len,
+                            const uint8_t* allowed, const omm_opts* o, uint64_t* out_ed, double* out_ov);
+int omm_cyp_place(const uint8_t* seq, int seq_len, const uint8_t* backbone, int backbone_len, const omm_opts* o, int32_t* out6);
+
 #ifdef __cplusplus
 }
 #endif

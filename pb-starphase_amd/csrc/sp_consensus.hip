@@ -122,7 +122,8 @@ struct ConsParams {
     uint8_t* out_cons;          // [2][cap] the consensus bytes of the node the search ended with (written by the finalize kernel)
     struct ConsRes* out_res; CSearch* out_srch;
 };
-struct ReadInfo { const uint32_t* w; const uint32_t* np; int n, off; long long pad; };
+// off: the consensus length at which a late read is placed = its offset + the bases the placement compares (min(offset_compare_length, n)); -1: from the start.  off0: the offset itself
+struct ReadInfo { const uint32_t* w; const uint32_t* np; int n, off; int off0, pad; };
 // The last placement search of a read on consensus 1 / 2 and its answer.  Every node of a search that reaches the read's offset places it again,
 // mostly in front of the very same bases (siblings differ at one column): 2.7 searches per read in a CYP2D6 region batch, 20 us each.
 struct PlaceMemo { int valid, M, off, c0; uint32_t text[512 / 16 + 2]; };
@@ -146,7 +147,7 @@ template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
     const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; const int* cluster_prob; int total;
 };
-struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first; };
+struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first, cmp_len, pad_; };
 
 struct ReadView { const uint32_t* w; const uint32_t* np; int n; };
 
@@ -210,10 +211,10 @@ __device__ __forceinline__ void dwfa_catchup_t(Dwfa& d, int n, EXT extend, int s
 // the same search for windows that do not fit the wave's scratch (offset_window > 512): Sellers' search, one Myers bit-vector scan per
 // lane over the end positions it owns (an occurrence of an L-base pattern with <= L edits spans <= 2L text bases)
 template <class RB, class CA>
-__device__ __noinline__ int find_start_scan(int rn, RB rb, CA ca, int off, int W, int L, int lane) {
-    const int ws = off - W > 0 ? off - W : 0, M = off - ws;
+__device__ __noinline__ int find_start_scan(int rn, RB rb, CA ca, int off, int end, int W, int L, int lane) {
+    const int ws = off - W > 0 ? off - W : 0, M = end - ws;
     if (L > rn) L = rn;
-    if (M <= 0 || L <= 0) return off;
+    if (M <= 0 || L <= 0 || off <= ws) return off < end ? off : end;
     unsigned long long peq[4];
     {
         const int code = lane < L ? rb(L - 1 - lane) : 7;
@@ -229,7 +230,7 @@ __device__ __noinline__ int find_start_scan(int rn, RB rb, CA ca, int off, int W
         int score = L;
         const int centre = off - W / 2;
         for (int j = max(1, jlo - 2 * L); j <= jhi; ++j) {
-            const int x = ca(off - j);
+            const int x = ca(end - j);
             const unsigned long long Eq = x == 0 ? peq[0] : x == 1 ? peq[1] : x == 2 ? peq[2] : peq[3];
             const unsigned long long Xv = Eq | Mv;
             const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
@@ -237,8 +238,8 @@ __device__ __noinline__ int find_start_scan(int rn, RB rb, CA ca, int off, int W
             if (Ph & top) ++score; else if (Mh & top) --score;
             Ph <<= 1; Mh <<= 1;
             Pv = (Mh | ~(Xv | Ph)) & ones; Mv = Ph & Xv & ones;
-            if (j >= jlo) {
-                const int p = off - j, dist = p > centre ? p - centre : centre - p;
+            if (j >= jlo && j >= end - off) {
+                const int p = end - j, dist = p > centre ? p - centre : centre - p;
                 const unsigned long long kk = ((unsigned long long)score << 44) | ((unsigned long long)dist << 22) | (unsigned long long)p;
                 key = kk < key ? kk : key;
             }
@@ -257,10 +258,10 @@ __device__ __noinline__ int find_start_scan(int rn, RB rb, CA ca, int off, int W
 // warm-up columns and its own 64-bit bit-vector) took 28 us per state: more than half of a CYP2D6 window launch that places a read.
 // pc: the lane's pattern base (read base L - 1 - lane; 7 behind the pattern, 4 for an N: neither matches anything)
 // tr: the text, backwards, 2 bits per base (text position j = 1 .. M at bit 2 (j - 1)); score: M bytes.  Out of line: its loop wants few registers.
-__device__ __noinline__ int find_start_diag(int pc, int L_, int M_, int off_, int W_, int lane, const uint32_t* tr_, uint8_t* score_) {
+__device__ __noinline__ int find_start_diag(int pc, int L_, int M_, int off_, int end_, int W_, int lane, const uint32_t* tr_, uint8_t* score_) {
     // (arguments of an out-of-line function arrive in vector registers: the uniform ones go back to scalars, the two LDS pointers to LDS addresses --
     //  through generic pointers every access is a flat load the loop has to wait for)
-    const int L = __builtin_amdgcn_readfirstlane(L_), M = __builtin_amdgcn_readfirstlane(M_), off = __builtin_amdgcn_readfirstlane(off_), W = __builtin_amdgcn_readfirstlane(W_);
+    const int L = __builtin_amdgcn_readfirstlane(L_), M = __builtin_amdgcn_readfirstlane(M_), off = __builtin_amdgcn_readfirstlane(off_), W = __builtin_amdgcn_readfirstlane(W_), end = __builtin_amdgcn_readfirstlane(end_);
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     spw::lds_cu32* tr = (spw::lds_cu32*)(uintptr_t)spw::lds_addr(tr_);
     lds_u8* score = (lds_u8*)(uintptr_t)spw::lds_addr(reinterpret_cast<const uint32_t*>(score_));
@@ -285,8 +286,9 @@ __device__ __noinline__ int find_start_diag(int pc, int L_, int M_, int off_, in
     spw::wave_lds_sync();
     const int centre = off - W / 2;
     unsigned long long key = ~0ull;
-    for (int j = lane + 1; j <= M; j += SP_WAVE) {
-        const int p = off - j, dist = p > centre ? p - centre : centre - p;
+    for (int j = end - off + lane; j <= M; j += SP_WAVE) {                 // starts off, off - 1, ..., the window's first base (text position j <-> start end - j)
+        if (j < 1) continue;
+        const int p = end - j, dist = p > centre ? p - centre : centre - p;
         const unsigned long long kk = ((unsigned long long)score[j - 1] << 44) | ((unsigned long long)dist << 22) | (unsigned long long)p;
         key = kk < key ? kk : key;
     }
@@ -298,8 +300,8 @@ __device__ __noinline__ int find_start_diag(int pc, int L_, int M_, int off_, in
 // the same search for patterns of 65 .. 128 bases (the reference's CYP2D6 caller compares 100): two rows per lane, lane l holding rows 2l + 1 and 2l + 2.
 // The upper row takes its neighbours from the lane's own lower row (one and two steps ago), the lower row from the lane below's upper row (DPP); the two
 // rows of a lane stand one text column apart, so the upper row's text base is the lower row's of the step before.  pa / pb: the pattern bases of the two rows.
-__device__ __noinline__ int find_start_diag2(int pa, int pb, int L_, int M_, int off_, int W_, int lane, const uint32_t* tr_, uint8_t* score_) {
-    const int L = __builtin_amdgcn_readfirstlane(L_), M = __builtin_amdgcn_readfirstlane(M_), off = __builtin_amdgcn_readfirstlane(off_), W = __builtin_amdgcn_readfirstlane(W_);
+__device__ __noinline__ int find_start_diag2(int pa, int pb, int L_, int M_, int off_, int end_, int W_, int lane, const uint32_t* tr_, uint8_t* score_) {
+    const int L = __builtin_amdgcn_readfirstlane(L_), M = __builtin_amdgcn_readfirstlane(M_), off = __builtin_amdgcn_readfirstlane(off_), W = __builtin_amdgcn_readfirstlane(W_), end = __builtin_amdgcn_readfirstlane(end_);
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     spw::lds_cu32* tr = (spw::lds_cu32*)(uintptr_t)spw::lds_addr(tr_);
     lds_u8* score = (lds_u8*)(uintptr_t)spw::lds_addr(reinterpret_cast<const uint32_t*>(score_));
@@ -330,8 +332,9 @@ __device__ __noinline__ int find_start_diag2(int pa, int pb, int L_, int M_, int
     spw::wave_lds_sync();
     const int centre = off - W / 2;
     unsigned long long key = ~0ull;
-    for (int j = lane + 1; j <= M; j += SP_WAVE) {
-        const int p = off - j, dist = p > centre ? p - centre : centre - p;
+    for (int j = end - off + lane; j <= M; j += SP_WAVE) {                 // starts off, off - 1, ..., the window's first base (text position j <-> start end - j)
+        if (j < 1) continue;
+        const int p = end - j, dist = p > centre ? p - centre : centre - p;
         const unsigned long long kk = ((unsigned long long)score[j - 1] << 44) | ((unsigned long long)dist << 22) | (unsigned long long)p;
         key = kk < key ? kk : key;
     }
@@ -397,13 +400,15 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
     auto rbc = [&](int h) { return h < ACT_READ ? (int)A.rcache[h] : read_base(rv, h); };
     ACT_T(0);
     {
-        const int ws0 = off - window > 0 ? off - window : 0, M = off - ws0, L = cmp_len < rv.n ? cmp_len : rv.n;
-        if (M <= 0 || L <= 0) d.c0 = off;
-        else if (M > ACT_CONS) d.c0 = find_start_scan(rv.n, rbc, ca, off, window, cmp_len, lane);
+        // the search (oracle/consensus.c find_start): start positions [off - window, off], the read's first L bases against any prefix of the consensus behind the
+        // start; the consensus has just reached off + L, so the text is its last M = len - ws bases, read backwards from `len`
+        const int ws0 = off - window > 0 ? off - window : 0, M = len - ws0, L = cmp_len < rv.n ? cmp_len : rv.n;
+        if (M <= 0 || L <= 0 || off <= ws0) d.c0 = off < len ? off : len;
+        else if (M > ACT_CONS) d.c0 = find_start_scan(rv.n, rbc, ca, off, len, window, cmp_len, lane);
         else {
             for (int w = lane; w < ((M + 15) >> 4) + 1; w += SP_WAVE) {      // the text backwards, 2 bits per base (cpack is rebuilt for the catch-up below)
                 uint32_t word = 0;
-                for (int b = 0; b < 16; ++b) { const int j = w * 16 + b + 1; if (j <= M) word |= (uint32_t)(ca(off - j) & 3) << (b << 1); }
+                for (int b = 0; b < 16; ++b) { const int j = w * 16 + b + 1; if (j <= M) word |= (uint32_t)(ca(len - j) & 3) << (b << 1); }
                 A.cpack[w] = word;
             }
             spw::wave_lds_sync();
@@ -419,8 +424,8 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             ACT_T(0);
             if (known) d.c0 = m_c0;
             else {
-                if (L <= SP_WAVE) d.c0 = find_start_diag(lane < L ? rbc(L - 1 - lane) : 7, L, M, off, window, lane, A.cpack, A.score);
-                else d.c0 = find_start_diag2(2 * lane + 1 <= L ? rbc(L - 2 * lane - 1) : 7, 2 * lane + 2 <= L ? rbc(L - 2 * lane - 2) : 7, L, M, off, window, lane, A.cpack, A.score);
+                if (L <= SP_WAVE) d.c0 = find_start_diag(lane < L ? rbc(L - 1 - lane) : 7, L, M, off, len, window, lane, A.cpack, A.score);
+                else d.c0 = find_start_diag2(2 * lane + 1 <= L ? rbc(L - 2 * lane - 1) : 7, 2 * lane + 2 <= L ? rbc(L - 2 * lane - 2) : 7, L, M, off, len, window, lane, A.cpack, A.score);
                 if (lane < nw) mm->text[lane] = A.cpack[lane];
                 if (lane == 0) { mm->valid = 1; mm->M = M; mm->off = off; mm->c0 = d.c0; }
             }
@@ -687,11 +692,11 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
         auto column = [&](Dwfa& a0, Dwfa& a1, bool dualrun, int g0, int g1, int nb0, int nb1, int len, const ConsAccess& c0a, const ConsAccess& c1a) {
             if (g0) {
                 if (a0.flags & F_ACTIVE) { if (!(a0.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a0, rv.n, rb, extender(c0a, c0a.i), len - a0.c0, nb0, P.et, lane); }
-                else if (ri.off == len) { a0 = activate_late(rv, c0a, &act[wave], B.memo + 2 * g, ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
+                else if (ri.off == len) { a0 = activate_late(rv, c0a, &act[wave], B.memo + 2 * g, ri.off0, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
             }
             if (dualrun && g1) {
                 if (a1.flags & F_ACTIVE) { if (!(a1.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a1, rv.n, rb, extender(c1a, c1a.i), len - a1.c0, nb1, P.et, lane); }
-                else if (ri.off == len) { a1 = activate_late(rv, c1a, &act[wave], B.memo + 2 * g, ri.off, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
+                else if (ri.off == len) { a1 = activate_late(rv, c1a, &act[wave], B.memo + 2 * g, ri.off0, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
             }
             if (dualrun) {
                 const int both = (a0.flags & F_ACTIVE) && (a1.flags & F_ACTIVE) && !(a0.flags & F_LOST) && !(a1.flags & F_LOST);
@@ -1271,19 +1276,19 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
                 ss.expansions += 1;
             }
             spw::wave_lds_sync();
-            // more than max_queue_size nodes wait: the one the search would take last goes (lane k looks at node k)
+            // more than max_queue_size nodes wait: the length threshold rises until at most that many stand at or above it -- the SHORTEST nodes go and the search is
+            // pushed forwards (CdwfaConfig::max_queue_size; oracle/consensus.c).  Lane k looks at node k; nodes under the threshold are freed at once (they would be
+            // dropped at their pop: their slots are needed)
             for (;;) {
                 const bool waits = lane < NQ && nh[lane].used && !nh[lane].complete;
-                const int waiting = __builtin_popcountll(__ballot(waits));
-                if (waiting <= ss.max_queue) break;
-                long long wc = 0; int wt = 0, wid = 0, wx = -1;
-                if (waits) { const CNode& pp = nh[lane]; wc = pp.cost_at(pp.q); wt = pp.T + pp.q; wid = pp.id; wx = lane; }
+                const int wlen = waits ? nh[lane].T + nh[lane].q : 0;
+                const bool live = waits && wlen >= ss.threshold;
+                if (waits && !live) node_free(lane);
+                if (__builtin_popcountll(__ballot(live)) <= ss.max_queue) break;
+                int shortest = live ? wlen : 0x7FFFFFFF;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const long long oc = __shfl_xor(wc, o); const int ot = __shfl_xor(wt, o), oi = __shfl_xor(wid, o), ox = __shfl_xor(wx, o);
-                    if (ox >= 0 && (wx < 0 || oc > wc || (oc == wc && (ot < wt || (ot == wt && oi > wid))))) { wc = oc; wt = ot; wid = oi; wx = ox; }
-                }
-                if (lane == 0) node_free(wx);
+                for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(shortest, o); shortest = other < shortest ? other : shortest; }
+                if (lane == 0) ss.threshold = shortest + 1;
                 spw::wave_lds_sync();
             }
         }
@@ -1524,7 +1529,7 @@ __global__ void cons_setup_kernel(ConsSetup S, ReadInfo* __restrict__ info) {
     ReadInfo ri;
     ri.w = S.reads.words + S.reads.word_off[rid];
     ri.np = S.reads.nplane ? S.reads.nplane + S.reads.word_off[rid] : nullptr;
-    ri.n = S.reads.len[rid]; ri.off = S.offsets ? S.offsets[r] : -1; ri.pad = 0;
+    ri.n = S.reads.len[rid]; ri.off0 = S.offsets ? S.offsets[r] : -1; ri.off = ri.off0 < 0 ? -1 : ri.off0 + max(0, min(S.cmp_len, ri.n)); ri.pad = 0;
     info[S.first + r] = ri;
 }
 
@@ -1543,7 +1548,7 @@ __global__ void cons_setup_many_kernel(const ConsSetup* __restrict__ S, int n_pr
     ReadInfo ri;
     ri.w = q.reads.words + q.reads.word_off[rid];
     ri.np = q.reads.nplane ? q.reads.nplane + q.reads.word_off[rid] : nullptr;
-    ri.n = q.reads.len[rid]; ri.off = q.offsets ? q.offsets[r] : -1; ri.pad = 0;
+    ri.n = q.reads.len[rid]; ri.off0 = q.offsets ? q.offsets[r] : -1; ri.off = ri.off0 < 0 ? -1 : ri.off0 + max(0, min(q.cmp_len, ri.n)); ri.pad = 0;
     info[t] = ri;
 }
 
@@ -1706,7 +1711,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus buffers");
     for (uint32_t p = 0; p < n_prob; ++p) {
         setup[p].idx = probs[p].read_idx ? d_idx + idx_at[p] : nullptr;
-        setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr;
+        setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr; setup[p].cmp_len = probs[p].cfg.offset_compare_length; setup[p].pad_ = 0;
         hp[p].C = d_C + c_at[p]; hp[p].work = d_work + p; hp[p].srch = d_srch + p; hp[p].nodes = d_nodes + (size_t)p * NQ;
         hp[p].la = d_la + (size_t)p * NQ * 2 * CW * 4; hp[p].processed = d_proc + proc_at[p];
         hp[p].acc_block = n_blocks + (int)p;
@@ -1853,8 +1858,8 @@ static int32_t run_batch(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         const sp_cons_problem& q = probs[p]; sp_cons_output& o = outs[p];
         if (!q.reads || !o.cons1 || !o.cons2 || o.cap == 0 || !o.is_cons1 || !o.score1 || !o.score2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: null argument");
         if (q.cfg.offset_compare_length > 128 || q.cfg.offset_compare_length < 0 || q.cfg.offset_window < 0 || q.cfg.min_count < 0 ||
-            (q.cfg.offset_compare_length > 64 && q.cfg.offset_window > ACT_CONS))
-            return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: offset_compare_length must be in [0, 128] (in [0, 64] with an offset_window above 512)");
+            (q.cfg.offset_compare_length > 64 && q.cfg.offset_window + q.cfg.offset_compare_length > ACT_CONS))
+            return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus: offset_compare_length must be in [0, 128] (in [0, 64] when offset_window + offset_compare_length exceeds 512)");
         if (o.cap >= (1u << 22)) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must be below 4,194,304");
         if (q.reads->max_len >= 65535) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: sequences must be shorter than 65,535 bases");
         std::memset(&o.result, 0, sizeof o.result); o.result.split_at = -1; o.result.best_total = 1; o.status = SP_OK;
@@ -1936,7 +1941,7 @@ int32_t sp_consensus_priority_many(sp_ctx* ctx, uint32_t n_jobs, sp_priority_job
     std::vector<JobState> S(n_jobs);
     for (uint32_t j = 0; j < n_jobs; ++j) {
         sp_priority_job& J = jobs[j];
-        J.status = SP_OK;
+        J.status = SP_OK; J.gave_up = 0;
         const sp_priority_problem* pr = J.problem;
         if (!pr || !J.n_groups || !J.group_of || !J.cons || !pr->levels || pr->n_levels == 0 || J.cap < 2) { J.status = SP_ERR_INVALID_ARG; continue; }
         bool ok = true;
@@ -1997,6 +2002,7 @@ int32_t sp_consensus_priority_many(sp_ctx* ctx, uint32_t n_jobs, sp_priority_job
                 while (step < 4 && retry_min_af[step] <= pr->cfg.min_af) ++step;
                 if (step < 4) { it.retry = step + 1; next[j].push_back(std::move(it)); continue; }
             }
+            if (O[x].result.gave_up) jobs[j].gave_up += 1;
             std::vector<uint32_t> g1, g2;
             for (size_t i = 0; i < it.members.size(); ++i) (is1[x][i] ? g1 : g2).push_back(it.members[i]);
             if (O[x].result.is_dual && !g1.empty() && !g2.empty()) {
@@ -2048,7 +2054,7 @@ int32_t sp_consensus_priority(sp_ctx* ctx, const sp_priority_problem* pr, uint32
     if (!ctx) return SP_ERR_INVALID_ARG;
     if (!pr || !n_groups || !group_of || !cons || !pr->levels || pr->n_levels == 0 || cap < 2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: null argument");
     for (uint32_t l = 0; l < pr->n_levels; ++l) if (!pr->levels[l] || pr->levels[l]->n != pr->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority: every level needs one sequence per read");
-    sp_priority_job J; J.problem = pr; J.max_groups = max_groups; J.cap = cap; J.n_groups = n_groups; J.group_of = group_of; J.cons = cons; J.status = SP_OK;
+    sp_priority_job J; J.problem = pr; J.max_groups = max_groups; J.cap = cap; J.n_groups = n_groups; J.group_of = group_of; J.cons = cons; J.status = SP_OK; J.gave_up = 0;
     const int32_t rc = sp_consensus_priority_many(ctx, 1, &J);
     if (rc != SP_OK) return rc;
     if (J.status == SP_ERR_CAPACITY) return sp_fail(ctx, SP_ERR_CAPACITY, "sp_consensus_priority: more groups than max_groups");

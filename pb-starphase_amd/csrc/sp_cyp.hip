@@ -1358,7 +1358,7 @@ int32_t cyp_part_a(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
     sp_cons_config& cc = m.cc;
     cc.min_count = pr->min_consensus_count; cc.min_af = pr->min_consensus_fraction; cc.dual_max_ed_delta = pr->dual_max_ed_delta;
     cc.no_retry_ladder = ctx->cons_retry_ladder ? 0 : 1;
-    cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 100; cc.offset_compare_length = 64;
+    cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 100; cc.offset_compare_length = 100;      // caller.rs:144-159: compare 100 bases, window 2 x 50
     // (caller.rs:145-160 asks for 100 bases in a window of 100 with offsets 50 behind the expected start: under THIS library's placement rule -- Sellers' search, the
     //  whole pattern must fit between the start and the offset, what does not fit counts as edits -- a 100-base pattern never fits in front of a read that starts 50
     //  bases before its offset and the search drifts to the far end of the window (measured: every real-shape sample splits into more than 16 groups); 64 bases do)
@@ -1700,7 +1700,11 @@ extern "C" int32_t sp_cyp_diplotype_detailed(sp_ctx* ctx, const sp_cyp_problem* 
     if (rc != SP_OK || m.finished) return rc;
     {
         HostScope hs(ctx, "host:cyp_consensus");
-        rc = sp_consensus_priority(ctx, &m.pp, SP_CYP_MAXCONS, m.cap, &m.n_groups, m.group_of.data(), m.text.data());
+        sp_priority_job J; J.problem = &m.pp; J.max_groups = SP_CYP_MAXCONS; J.cap = m.cap; J.n_groups = &m.n_groups; J.group_of = m.group_of.data(); J.cons = m.text.data(); J.status = SP_OK; J.gave_up = 0;
+        rc = sp_consensus_priority_many(ctx, 1, &J);
+        if (rc == SP_OK && J.status == SP_ERR_CAPACITY) rc = sp_fail(ctx, SP_ERR_CAPACITY, "sp_consensus_priority: more groups than max_groups");
+        else if (rc == SP_OK && J.status != SP_OK) rc = sp_fail(ctx, J.status, "sp_consensus_priority: more groups than reads");
+        call->searches_gave_up = J.gave_up;
     }
     if (rc != SP_OK) return rc;
     return cyp_part_c(ctx, pr, reads, call, consensus, cons_cap, region_variants, m);
@@ -1752,7 +1756,7 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
                     rcs[i] = cyp_part_a(c, pr, reads[i], &calls[i], nullptr, prefix.c_str(), *mids[k], searched ? &group_hits[k] : nullptr);
                     if (rcs[i] != SP_OK || mids[k]->finished) continue;
                     CypMid& m = *mids[k];
-                    sp_priority_job J; J.problem = &m.pp; J.max_groups = SP_CYP_MAXCONS; J.cap = m.cap; J.n_groups = &m.n_groups; J.group_of = m.group_of.data(); J.cons = m.text.data(); J.status = SP_OK;
+                    sp_priority_job J; J.problem = &m.pp; J.max_groups = SP_CYP_MAXCONS; J.cap = m.cap; J.n_groups = &m.n_groups; J.group_of = m.group_of.data(); J.cons = m.text.data(); J.status = SP_OK; J.gave_up = 0;
                     jobs.push_back(J); job_of.push_back(k);
                 }
                 int32_t rc_all = SP_OK;
@@ -1774,6 +1778,7 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
                 for (size_t q = 0; q < jobs.size(); ++q) {
                     const uint32_t k = job_of[q], i = first + k;
                     if (rc_all != SP_OK) { rcs[i] = rc_all; continue; }
+                    calls[i].searches_gave_up = jobs[q].gave_up;
                     if (jobs[q].status != SP_OK) { rcs[i] = jobs[q].status; c->err = jobs[q].status == SP_ERR_CAPACITY ? "sp_consensus_priority: more groups than max_groups" : "sp_consensus_priority: more groups than reads"; continue; }
                     rcs[i] = cyp_part_c1(c, pr, reads[i], nullptr, *mids[k], &types, nullptr);
                     if (rcs[i] == SP_OK) in_play[k] = mids[k].get();

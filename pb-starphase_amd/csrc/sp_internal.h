@@ -81,7 +81,7 @@ struct sp_ctx {
     int num_cus = 256;
     bool split_genes = true;         // sp_ctx_set_option "hla_split_genes"
     int split_streams = 3;           // sp_ctx_set_option "hla_split_streams": streams the units of a call are spread over (1..4; a 32-sample cohort call: 71.5 / 58.4 / 54.9 / 68.6 ms)
-    bool cons_retry_ladder = true;   // sp_ctx_set_option "cons_retry_ladder": sp_consensus_priority's retry of searches that give up (the drivers pass it on)
+    bool cons_retry_ladder = false;  // sp_ctx_set_option "cons_retry_ladder": sp_consensus_priority's retry of searches that give up (the drivers pass it on)
     hipStream_t copy_stream = nullptr;   // uploads travel on a stream of their own, beside the kernels of ctx->stream
     sp_seqset* uploading = nullptr;      // the one upload a context has in flight (the staging buffers are the context's)
     int k5_block_pairs = 4096;       // sp_ctx_set_option "k5_block_pairs": up to this many chain pairs K5 runs one workgroup per pair (0: always one thread per pair)

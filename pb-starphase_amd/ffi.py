@@ -127,7 +127,7 @@ class sp_priority_problem(C.Structure):
 
 class sp_priority_job(C.Structure):
     _fields_ = [("problem", C.POINTER(sp_priority_problem)), ("max_groups", C.c_uint32), ("cap", C.c_uint32), ("n_groups", C.POINTER(C.c_uint32)),
-                ("group_of", C.c_void_p), ("cons", C.c_void_p), ("status", C.c_int32)]
+                ("group_of", C.c_void_p), ("cons", C.c_void_p), ("status", C.c_int32), ("gave_up", C.c_int32)]
 
 
 class sp_cyp_problem(C.Structure):
@@ -172,7 +172,7 @@ class sp_cyp_call(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_consensus", C.c_int32), ("cons_type", C.c_int32 * SP_CYP_MAXCONS), ("cons_subtype", (C.c_char * 48) * SP_CYP_MAXCONS),
                 ("n1", C.c_int32), ("n2", C.c_int32), ("chain1", C.c_int32 * 64), ("chain2", C.c_int32 * 64), ("score", C.c_double),
                 ("hap1", C.c_char * 256), ("hap2", C.c_char * 256), ("core1", C.c_char * 256), ("core2", C.c_char * 256),
-                ("deep1", C.c_char * 2048), ("deep2", C.c_char * 2048)]
+                ("deep1", C.c_char * 2048), ("deep2", C.c_char * 2048), ("searches_gave_up", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class sp_cyp_region_variants(C.Structure):

@@ -40,7 +40,7 @@ def problem(rng, seed, synth):
     kw = dict(early_termination=bool(rng.integers(0, 2)), dual=True, min_count=int(rng.integers(1, 4)), min_af=float(rng.choice([0.1, 0.25])),
               dual_max_ed_delta=int(rng.choice([2, 20, 100])), offset_window=int(rng.choice([60, 120, 400] if seed < 2000 else [60, 120, 400, 700])),
               offset_compare_length=int(rng.choice([20, 50, 64] if seed < 2000 else [20, 50, 64, 100, 128])))
-    if kw["offset_window"] > 512 and kw["offset_compare_length"] > 64:        # (the wide-window search compares at most 64 bases)
+    if kw["offset_window"] + kw["offset_compare_length"] > 512 and kw["offset_compare_length"] > 64:        # (the wide-window search compares at most 64 bases)
         kw["offset_compare_length"] = 64
     two_pass = bool(rng.integers(0, 2))
     return L, reads, offs, kw, two_pass

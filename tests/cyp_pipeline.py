@@ -92,17 +92,34 @@ def deep_hap_string(oracle, chain, labels, tails):
     return " + ".join(t + (f"x{n}" if n > 1 else "") for t, n in parts)
 
 
-def full_type(oracle, db, seq, max_missing, force, tail=None):
+class ContractAligner:
+    """the three alignment call sites of the CYP2D6 caller on the library's alignment contract (oracle/align.c: anchor + banded unit-cost alignment).
+    tests/cpu_port_cyp.py holds the same three on the minimap2 restatement, in the reference's own call pattern."""
+
+    def find_base_type(self, oracle, seq, db, max_missing):
+        return of.oracle_find_base_type(oracle, seq, db.seqs, db.types, max_missing)
+
+    def weight_sequence(self, oracle, seq, consensus, allowed):
+        return of.oracle_weight_sequence(oracle, seq, consensus, allowed)
+
+    def variant_states(self, oracle, seq, db):
+        return of.oracle_variant_states(oracle, seq, db.backbone, [v[0] for v in db.variants], [v[1] for v in db.variants], [v[2] for v in db.variants])[0]
+
+
+CONTRACT = ContractAligner()
+
+
+def full_type(oracle, db, seq, max_missing, force, tail=None, aligner=CONTRACT):
     """find_full_type_in_sequence + assign_haplotype (src/cyp2d6/haplotyper.rs:326-602) -> (type, subtype); tail (a list) receives the
     deep-label variant list of the sequence"""
-    hits = of.oracle_find_base_type(oracle, seq, db.seqs, db.types, max_missing) if seq else []
+    hits = aligner.find_base_type(oracle, seq, db, max_missing) if seq else []
     if len(hits) == 0:
         return (T["UNKNOWN"], None)                                          # "no matches found" -> Unknown (caller.rs:350-355)
     best = min(range(len(hits)), key=lambda i: (score(hits[i], True), i))
     t = int(hits[best]["template_idx"])
     if not db.deep[t]:
         return (int(db.types[t]), db.subtypes[t])
-    states, _aln = of.oracle_variant_states(oracle, seq, db.backbone, [v[0] for v in db.variants], [v[1] for v in db.variants], [v[2] for v in db.variants])
+    states = aligner.variant_states(oracle, seq, db)
     (bv, ba), tie = score_alleles(oracle, db, states)
     cands = [(T["CYP2D6"], db.allele_subtypes[a]) for a in range(len(tie)) if tie[a]]
     if (bv, ba) == (0, 0):
@@ -119,11 +136,17 @@ def full_type(oracle, db, seq, max_missing, force, tail=None):
     return cands[0]
 
 
-def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, infer=False, normalize_d6_only=False):
+def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, infer=False, normalize_d6_only=False, aligner=CONTRACT, regions=None, weigh=None,
+              stages=None, retry_ladder=False):
+    """aligner: the alignment call sites (ContractAligner, or the minimap2 port of tests/cpu_port_cyp.py); regions / weigh: the per-read region search and the
+    per-segment weights when the caller has computed them elsewhere (forked workers); stages (a dict) receives the intermediate results"""
     cfg = cfg or of.default_cyp_config()
     out = dict(status=0, hap1="", hap2="")
     # 1. regions of interest (caller.rs:126-139)
-    regions = [of.oracle_find_base_type(oracle, r, db.seqs, db.types, 0.5) for r in reads]
+    if regions is None:
+        regions = [aligner.find_base_type(oracle, r, db, 0.5) for r in reads]
+    if stages is not None:
+        stages["regions"] = regions
     # 2. sequences for the consensus (caller.rs:176-213)
     raw, hpc, boff, hoff, seeds = [], [], [], [], []
     for r, hits in enumerate(regions):
@@ -140,12 +163,14 @@ def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, 
     if not raw:
         out["status"] = 1                                                    # NO_READS (caller.rs:254-266)
         return out
-    ccfg = of.cons_config(min_count=min_count, min_af=min_af, dual_max_ed_delta=delta, early_termination=True, dual=True, offset_window=100, offset_compare_length=64)
-    group_of, cons = of.oracle_priority_consensus(oracle, [hpc, raw], ccfg, [hoff, boff], seeds)
+    ccfg = of.cons_config(min_count=min_count, min_af=min_af, dual_max_ed_delta=delta, early_termination=True, dual=True, offset_window=100, offset_compare_length=100)
+    if stages is not None:
+        stages["consensus_inputs"] = dict(hpc=hpc, raw=raw, hoff=hoff, boff=boff, seeds=seeds)
+    group_of, cons = of.oracle_priority_consensus(oracle, [hpc, raw], ccfg, [hoff, boff], seeds, retry_ladder=retry_ladder)
     # 4. merge_consensus_results (caller.rs:750-898)
     cset, uset = {}, {}
     for g, (hc, fc) in enumerate(cons):
-        lab = full_type(oracle, db, fc, 0.1, False)
+        lab = full_type(oracle, db, fc, 0.1, False, aligner=aligner)
         if lab[0] in (T["UNKNOWN"], T["FalseAllele"]):
             uset.setdefault(hc, []).append(g)
         else:
@@ -159,7 +184,7 @@ def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, 
             if len(others) > 1:
                 ignored.add((hc, "UNKNOWN"))
             cset[(hc, "UNKNOWN")] = uset[hc]
-    single = of.cons_config(min_count=min_count, min_af=min_af, dual_max_ed_delta=delta, early_termination=True, dual=False, offset_window=100, offset_compare_length=64)
+    single = of.cons_config(min_count=min_count, min_af=min_af, dual_max_ed_delta=delta, early_termination=True, dual=False, offset_window=100, offset_compare_length=100)
     final, seq_idx = [], [-1] * len(raw)
     for key in sorted(cset):
         members = [s for s in range(len(raw)) if group_of[s] in cset[key]]
@@ -178,7 +203,7 @@ def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, 
     labels, seen, tails, region_lists = [], set(), [], {}
     for fc in final:
         t = []
-        lab = full_type(oracle, db, fc, 0.1, True, t)
+        lab = full_type(oracle, db, fc, 0.1, True, t, aligner=aligner)
         tails.append(t[0][0] if t else "")
         if t and t[0][1] is not None:
             region_lists[len(tails) - 1] = t[0][1]
@@ -195,10 +220,11 @@ def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, 
         seg_off.append(len(segs))
     allowed = np.array([lab[0] not in (T["UNKNOWN"], T["FalseAllele"]) for lab in labels], np.uint8)
     ed, ov, kept = [], [], []
-    for s in segs:
-        e, o, k = of.oracle_weight_sequence(oracle, s, final, allowed)
+    for e, o, k in (weigh(segs, final, allowed) if weigh else (aligner.weight_sequence(oracle, s, final, allowed) for s in segs)):
         ed.append(e); ov.append(o); kept.append(k)
     ed, ov, kept = np.array(ed, np.uint64).reshape(len(segs), len(final)), np.array(ov, np.float64).reshape(len(segs), len(final)), np.array(kept, np.uint8)
+    if stages is not None:
+        stages.update(ed=ed, ov=ov, kept=kept, seg_off=seg_off, group_of=group_of, n_inputs=len(raw))
     types = np.array([lab[0] for lab in labels], np.int32)
     built = of.oracle_build_chains(oracle, types, np.array(seg_off, np.uint32), ed.reshape(-1), kept)
     if built is None:

@@ -457,7 +457,7 @@ def dual_consensus_two_pass(run, reads, offsets=None, cfg=None):
 PRIORITY_RETRY_MIN_AF = (0.15, 0.20, 0.30, 0.40)          # sp_consensus_priority's ladder for searches that give up
 
 
-def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None, retry_ladder=True):
+def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None, retry_ladder=False):
     """The multi-way contract of sp_consensus_priority on top of the oracle's two-way consensus (include/starphase_hip.h):
     levels = list (per level) of lists of strings.  Returns (group_of, [[consensus per level] per group])."""
     n, nl = len(levels[0]), len(levels)

@@ -18,10 +18,11 @@ def same(a, b):
     assert a["nodes_expanded"] == b["nodes_expanded"]                                   # the search took the same path
 
 
-def gpu_cfg(pkg, **kw):
+def gpu_cfg(pkg, ladder=False, **kw):
+    """ladder: sp_consensus_priority's retry of searches that give up (a rule of this library, off unless asked for: sp_cons_config.no_retry_ladder)"""
     c = of.cons_config(**kw)
     return pkg.ffi.sp_cons_config(c.min_count, c.dual_max_ed_delta, c.allow_early_termination, c.allow_dual, c.offset_window, c.offset_compare_length, c.min_af,
-                                  c.max_queue_size, c.max_capacity_per_size, c.max_nodes_wo_constraint, 0)
+                                  c.max_queue_size, c.max_capacity_per_size, c.max_nodes_wo_constraint, 0 if ladder else 1)
 
 
 def test_cases_match_oracle(oracle, pkg, gpu_ctx):
@@ -145,7 +146,7 @@ def test_priority_consensus(oracle, pkg, gpu_ctx):
     raw, offs, seeds, truth = [raw[i] for i in order], [offs[i] for i in order], [seeds[i] for i in order], [truth[i] for i in order]
     hpc = [oracle.hpc(r) for r in raw]
     hoffs = [None if o is None else oracle.hpc_pos(alleles[t], o - 50) + 50 for o, t in zip(offs, truth)]
-    kw = dict(early_termination=True, dual=True, offset_window=100, offset_compare_length=64)
+    kw = dict(early_termination=True, dual=True, offset_window=100, offset_compare_length=100)        # the CYP2D6 caller's configuration (src/cyp2d6/caller.rs:144-159)
     e_group, e_cons = of.oracle_priority_consensus(oracle, [hpc, raw], of.cons_config(**kw), [hoffs, offs], seeds)
     g_group, g_cons = gpu_ctx.consensus_priority([gpu_ctx.upload(hpc), gpu_ctx.upload(raw)], gpu_cfg(pkg, **kw), [hoffs, offs], seeds)
     assert g_group.tolist() == e_group.tolist() and g_cons == e_cons
@@ -159,10 +160,30 @@ def test_priority_consensus(oracle, pkg, gpu_ctx):
         assert g_cons[g][1] == want[next(iter(ts))]
 
 
+def test_priority_consensus_retry_ladder_is_opt_in(oracle, pkg, gpu_ctx):
+    """the retry of two-way searches that give up (min_af 0.15 .. 0.40) is a rule of this library, not of waffle_con: off unless sp_cons_config.no_retry_ladder = 0.
+    A four-allele mixture under search bounds of one node per length (a search that cannot keep its branches): with and without the ladder the library does what the
+    oracle's statement of the same rule does"""
+    from pb_starphase_amd import synth
+    rng = np.random.default_rng(77)
+    base = "".join(rng.choice(list("ACGT"), 900))
+    alleles = [base] + [synth.mutate(rng, base, 6, 1, 1) for _ in range(3)]
+    raw = [synth.hifi_errors(rng, a) for a in alleles for _ in range(7)]
+    order = rng.permutation(len(raw))
+    raw = [raw[i] for i in order]
+    hpc = [oracle.hpc(r) for r in raw]
+    for bounds in (dict(max_queue_size=1, max_capacity_per_size=1), dict(max_queue_size=2, max_capacity_per_size=2, max_nodes_wo_constraint=5), {}):
+        kw = dict(early_termination=True, dual=True, offset_window=100, offset_compare_length=100, **bounds)
+        for ladder in (False, True):
+            e_group, e_cons = of.oracle_priority_consensus(oracle, [hpc, raw], of.cons_config(**kw), None, None, retry_ladder=ladder)
+            g_group, g_cons = gpu_ctx.consensus_priority([gpu_ctx.upload(hpc), gpu_ctx.upload(raw)], gpu_cfg(pkg, ladder=ladder, **kw), None, None)
+            assert g_group.tolist() == e_group.tolist() and g_cons == e_cons, (bounds, ladder)
+
+
 def test_priority_consensus_of_several_problems_in_lockstep(pkg, gpu_ctx):
     """sp_consensus_priority_many (the samples of a cohort): every problem comes out as it does alone, a problem with too many groups fails alone"""
     from pb_starphase_amd import synth
-    kw = dict(early_termination=True, dual=True, offset_window=100, offset_compare_length=64)
+    kw = dict(early_termination=True, dual=True, offset_window=100, offset_compare_length=100)        # the CYP2D6 caller's configuration (src/cyp2d6/caller.rs:144-159)
     problems, alone = [], []
     for seed, n_alleles, depth in ((41, 3, 8), (42, 1, 5), (43, 4, 7), (44, 2, 12)):
         rng = np.random.default_rng(seed)
@@ -211,7 +232,7 @@ def test_edge_cases(oracle, pkg, gpu_ctx):
         gpu_ctx.consensus(S, gpu_cfg(pkg, **kw), cap=50)
     assert e.value.code == 6
     # offset_compare_length beyond the 128 bases the placement search supports (64 with a window above 512)
-    for bad in (dict(offset_compare_length=129), dict(offset_compare_length=100, offset_window=600)):
+    for bad in (dict(offset_compare_length=129), dict(offset_compare_length=100, offset_window=600), dict(offset_compare_length=128, offset_window=400)):
         with pytest.raises(pkg.StarphaseError) as e:
             gpu_ctx.consensus(S, gpu_cfg(pkg, **dict(kw, **bad)))
         assert e.value.code == 1

@@ -73,7 +73,8 @@ def test_library_equals_oracle_pipeline(oracle, gpu_ctx, real, name):
     assert call.score == exp["score"]
     got = (call.hap1.decode(), call.hap2.decode(), call.core1.decode(), call.core2.decode())
     assert got == (exp["hap1"], exp["hap2"], exp["core1"], exp["core2"])
-    assert sorted(got[:2]) == sorted(expected)
+    if name != "*4+*68/*1":     # (at 160 reads the hybrid's reads that start behind its CYP2D7 part end up in a group of their own, in the oracle as in the library: truth at 2,000 reads above)
+        assert sorted(got[:2]) == sorted(expected)
     # Cyp2d6DetailLevel::DeepAlleles: "(<index>_<full allele> +unexpected -missing ?ambiguous)" per reported region
     assert (call.deep1.decode(), call.deep2.decode()) == (exp["deep1"], exp["deep2"])
     assert call.deep1.decode().startswith("(") and "_" in call.deep1.decode()
@@ -126,18 +127,27 @@ def test_cohort_groups_with_an_empty_sample_and_with_an_n_plane(gpu_ctx, real):
 
 def test_hybrid_sample_on_a_second_locus(pkg, gpu_ctx):
     """The `*4+*68/*1` sample on another random chr22 locus, 2,000 reads: the 884 unseeded sequences are four classes (`*4`, `*1`, CYP2D7, the hybrid)
-    for a search that holds two consensuses, and at this depth the search with the configured min_af exhausts its queue / capacity bounds and
-    gives up.  sp_consensus_priority then runs it again with only the stronger differences as candidates (0.15, 0.20, 0.30, 0.40), takes that
-    split and solves the halves with the configured fraction: the call is the truth (without the retry the group stayed whole: `*68x2/*68x2`).
-    Library == oracle pipeline on this sample: profiles/scripts/cyp_other_locus.py (a minute of CPU, not part of the suite)."""
+    for a search that holds two consensuses.  Under round 3's queue rule (the highest-cost node goes when more than max_queue_size wait) the search lost its
+    most advanced nodes, gave up, and needed a retry ladder of this library's own; with the length threshold raised instead (the shortest nodes go: the reading
+    of CdwfaConfig::max_queue_size in oracle/consensus.c) it completes with the reference's configuration as written (offset_compare_length 100, no ladder)
+    and the call is the truth.  Library == oracle pipeline on this sample: profiles/scripts/cyp_other_locus.py (a minute of CPU, not part of the suite)."""
     from pb_starphase_amd import synth
     cfg, gene_def = cr.load_db()
     locus = synth.Chr22Locus(cfg, gene_def, seed=2003)
     db = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
     _name, haps, expected = [s for s in cr.scenarios(locus) if s[0] == "*4+*68/*1"][0]
-    call, _cons, labels = db.diplotype(gpu_ctx.upload(locus.sample(np.random.default_rng(2007), haps, 2000)))
+    R = gpu_ctx.upload(locus.sample(np.random.default_rng(2007), haps, 2000))
+    call, _cons, labels = db.diplotype(R)
     assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
     assert sorted(s for t, s in labels if t == 2) == ["1.001", "4.001"]
+    assert 0 <= call.searches_gave_up <= 2          # (a search of a group that is one class already may still end on its bounds: the group then stays whole, which is right)
+    # the ladder is an option of the context (off by default: the reference has no such rule); where no search gives up it changes nothing
+    gpu_ctx.set_option("cons_retry_ladder", 1)
+    try:
+        on, _cons2, labels_on = db.diplotype(R)
+    finally:
+        gpu_ctx.set_option("cons_retry_ladder", 0)
+    assert (on.hap1, on.hap2, on.score, labels_on) == (call.hap1, call.hap2, call.score, labels)
 
 
 def test_deep_labels_of_a_novel_allele(oracle, gpu_ctx, real):
@@ -206,28 +216,6 @@ def test_variant_states_on_the_real_table(oracle, gpu_ctx, real):
     bv, ba, tie = gpu_ctx.cyp_score_alleles(rows, odb.is_vi, states)
     for x, a in enumerate(chosen):
         assert tie[x][a] == 1, names[a]
-
-
-def test_retry_ladder_is_an_option(pkg, gpu_ctx):
-    """The retry of two-way searches that give up (min_af 0.15 .. 0.40) is a rule of this library, not of waffle_con: it can be switched off
-    (sp_ctx_set_option "cons_retry_ladder" -> sp_cons_config.no_retry_ladder), and "gave up" is an explicit field of the search's result.  On the
-    second-locus hybrid sample the search of the 884 unseeded sequences gives up at the configured fraction: without the retry the group stays
-    whole (the pre-ladder contract: one hybrid, `*68x2/*68x2`), with it the call is the truth."""
-    from pb_starphase_amd import synth
-    cfg, gene_def = cr.load_db()
-    locus = synth.Chr22Locus(cfg, gene_def, seed=2003)
-    db = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
-    _name, haps, expected = [s for s in cr.scenarios(locus) if s[0] == "*4+*68/*1"][0]
-    R = gpu_ctx.upload(locus.sample(np.random.default_rng(2007), haps, 2000))
-    gpu_ctx.set_option("cons_retry_ladder", 0)
-    try:
-        off, _cons, labels_off = db.diplotype(R)
-    finally:
-        gpu_ctx.set_option("cons_retry_ladder", 1)
-    on, _cons, labels_on = db.diplotype(R)
-    assert on.status == 0 and sorted([on.hap1.decode(), on.hap2.decode()]) == sorted(expected)
-    assert sorted([off.hap1.decode(), off.hap2.decode()]) != sorted(expected)
-    assert len(labels_off) < len(labels_on)                       # the group that gave up stayed whole
 
 
 def test_gave_up_is_reported(pkg, gpu_ctx):
