@@ -97,19 +97,44 @@ def native_oracle():
         return None, "-O3 (shipped build)"
 
 
-def cpu_baseline(fx, reads, n_sample=1500):
-    """The reference's CPU path in its own call pattern (tests/cpu_port_seeded.py): one seeded minimap2-style map per read against the index of all
-    DNA alleles with the best chains base-aligned (`best_n 5`), the consensus of the oracle, every allele of the gene mapped to every consensus --
-    on a bounded sample of the same batch, BEFORE the GPU is touched (the workers are forked)."""
+def cpu_baseline(fx, hla_reads, cyp_setup, cyp_reads, n_hla=None, n_cyp=None):
+    """The reference's CPU path in its own call pattern for BOTH loci of the sample (tests/cpu_port_seeded.py, tests/cpu_port_cyp.py): every alignment is the minimap2
+    restatement's (oracle/mm2.c: seeded maps, `best_n 5`, two-piece affine gaps), the consensus is oracle/consensus.c, typing and chains are the oracle's routines --
+    on the reads `value` is measured on (or on the first n of each, when asked), BEFORE the GPU is touched (the workers are forked).
+    -> (the cpu_baseline block, what the GPU has to reproduce: reads used, calls)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi
     import cpu_port_seeded
+    import cpu_port_cyp
     lib, flags = native_oracle()
     o = oracle_ffi.load(lib) if lib else oracle_ffi.load()
-    res, best, calls, cons, done = cpu_port_seeded.run(o, fx, reads, n_sample=n_sample)
-    res["compiler_flags"] = flags
-    res["host"] = host_description()
-    return res, best, calls, done
+    n_hla = len(hla_reads) if not n_hla else min(n_hla, len(hla_reads))
+    t0 = time.perf_counter()
+    hres, best, calls, _cons, done = cpu_port_seeded.run(o, fx, hla_reads, n_sample=n_hla, budget_s=1e9)
+    t_hla = time.perf_counter() - t0
+    cfg, gene_def, locus = cyp_setup
+    cdb, ccfg = cpu_port_cyp.tables(cfg, gene_def, locus)
+    creads = cyp_reads if not n_cyp else cyp_reads[:n_cyp]
+    t0 = time.perf_counter()
+    cres, ctm = cpu_port_cyp.run(o, cdb, ccfg, creads)
+    t_cyp = time.perf_counter() - t0
+    n = len(done) + len(creads)
+    wall = hres["wall_s"] + ctm["wall_s"]
+    one = hres["one_thread_s"] + ctm["one_thread_s"]
+    block = {"value": n / wall, "unit": "reads/s", "cores": int(max(hres["cores"], ctm["cores"])), "kind": "port",
+             "sample": f"the sample `value` is measured on: {len(done)} of its {len(hla_reads)} HLA reads and {len(creads)} of its {len(cyp_reads)} CYP2D6 reads, one locus after the "
+                       "other, each with its parallel stages over the host's cores (per-stage worker counts below) and its sequential stages (consensus, chains) on one",
+             "single_thread_value": n / one, "wall_s": wall, "one_thread_s": one,
+             "hla": hres, "cyp2d6": {"reads": len(creads), "value": len(creads) / ctm["wall_s"], "unit": "reads/s", "wall_s": ctm["wall_s"], "one_thread_s": ctm["one_thread_s"],
+                                     "workers_per_stage": {"find_base_type_in_sequence (39 template maps per read)": ctm["cores"], "weight_sequence (per region segment)": ctm["cores"],
+                                                           "multi-way consensus, typing, chains, chain pair": 1},
+                                     "cpu_s": {"regions": ctm["regions_cpu_s"], "weights": ctm.get("weights_cpu_s", 0.0), "consensus_typing_chains": ctm["rest_wall_s"]},
+                                     "call": [cres.get("hap1", ""), cres.get("hap2", "")], "status": int(cres["status"])},
+             "compiler_flags": flags, "host": host_description(),
+             "note": "kind 'port': the reference's call pattern on minimap2's published algorithm restated in scalar C (oracle/mm2.c; minimap2 itself and its SSE kernels are "
+                     "not on disk), waffle_con = oracle/consensus.c.  `cores` = the most workers any stage used; the reference itself is single-threaded "
+                     "(src/cli/diplotype.rs:185-191): single_thread_value is what one thread needs for the same reads"}
+    return block, {"hla_best": best, "hla_calls": calls, "hla_done": done, "cyp_reads": creads, "cyp_call": cres}
 
 
 # ---------------------------------------------------------------------------------------------------------------- workloads
@@ -435,6 +460,8 @@ def main():
     ap.add_argument("--cohort-samples", type=int, default=256)
     ap.add_argument("--workload", choices=("auto", "sample", "cohort"), default="auto", help="auto: the sample at N = 1, the cohort at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-hla-reads", type=int, default=0, help="HLA reads of the sample the CPU leg runs (0: all of them, the reads `value` is measured on)")
+    ap.add_argument("--cpu-cyp-reads", type=int, default=0, help="CYP2D6 reads of the sample the CPU leg runs (0: all of them)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-HLA, CYP2D6-scenario, cohort and K5 legs")
     args = ap.parse_args()
 
@@ -451,9 +478,14 @@ def main():
     import cyp_cases_real as cr
     fx = synth.HlaFixture()
     samples = [HlaSample(pkg, fx, args.reads, 1000 + rank + 100 * k) for k in range(2)] if workload == "sample" else []
-    cb, cpu_best, cpu_calls, cpu_done = (None, None, None, None)
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    scen = cr.scenarios(locus)
+    cyp_samples = [CypSample(pkg, locus, scen[k], args.cyp_reads, 7 + k) for k in (0, 1)] if workload == "sample" else []         # *1/*2 and *4/*4 alternate
+    cb, cpu_ref = None, None
     if not args.no_cpu_baseline and world == 1 and workload == "sample":
-        cb, cpu_best, cpu_calls, cpu_done = cpu_baseline(fx, samples[0].wl.reads)          # forks workers: must happen before anything touches the GPU
+        # both loci of sample 0 through the reference-call-pattern CPU port; forks workers: must happen before anything touches the GPU
+        cb, cpu_ref = cpu_baseline(fx, samples[0].wl.reads, (cfg, gene_def, locus), cyp_samples[0].reads, args.cpu_hla_reads, args.cpu_cyp_reads)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -473,10 +505,7 @@ def main():
 
     ctx = pkg.Context(device_index)
     db = fx.make_db(pkg, ctx)
-    cfg, gene_def = cr.load_db()
-    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
     cdb = pkg.ffi.CypDb(ctx, cfg, gene_def, locus.sequence, locus.start)
-    scen = cr.scenarios(locus)
     group, gather_via = None, "single rank"
     if world > 1:
         # sp_group: RCCL through the library (sp_gather_results).  Should the library's communicator not come up on this node, every rank falls back to the
@@ -528,7 +557,6 @@ def main():
     # ------------------------------------------------------------------------------------------------ the sample: HLA-A / -B + CYP2D6, a new one every step
     ctx_c = pkg.Context(device_index)                       # the CYP2D6 half runs beside the HLA half on a context (stream, pools) of its own
     cdb_c = pkg.ffi.CypDb(ctx_c, cfg, gene_def, locus.sequence, locus.start)
-    cyp_samples = [CypSample(pkg, locus, scen[k], args.cyp_reads, 7 + k) for k in (0, 1)]          # *1/*2 and *4/*4 alternate
     genes = list(range(len(fx.genes)))
     last = {}
 
@@ -697,23 +725,38 @@ def main():
         "upload": {"per_step_bytes": int(len(samples[0].payload[0]) + len(cyp_samples[0].payload[0])), "alone": t_up,
                    "note": "inside `value` every step uploads a new sample (4-bit SEQ bytes, sp_seqset_upload_async); `alone` = one synchronous upload of the HLA half"},
         "legs": legs or None,
+        "context": ctx.info(),          # sp_ctx_get_info: the hardware queues the streams of the run were mapped onto (this script exports GPU_MAX_HW_QUEUES=16 before torch initialises HIP)
     }
     if cb is not None:
-        # the GPU on exactly the reads the CPU leg saw: the calls of the two have to be the same
+        # the GPU on exactly the reads the CPU leg saw: the calls of the two have to be the same, for both loci
+        cpu_done, cpu_best, cpu_calls = cpu_ref["hla_done"], cpu_ref["hla_best"], cpu_ref["hla_calls"]
         sub = [samples[0].wl.reads[r] for r in cpu_done]
         Rs = ctx.upload(sub)
         o = db.realign_reads(Rs)
         g_calls = db.diplotype_genes(genes, Rs, o)[0]
         gpu_calls = {g: sorted([int(c.allele1), int(c.allele2)]) for g, (c, _a, _b) in enumerate(g_calls)}
         cpu_c = {g: sorted(int(x) for x in cpu_calls[g]) for g in cpu_calls}
-        cb["diplotypes_cpu"] = {fx.genes[g]: cpu_c[g] for g in cpu_c}
-        cb["diplotypes_gpu_same_reads"] = {fx.genes[g]: gpu_calls[g] for g in gpu_calls}
-        cb["diplotypes_identical"] = all(all(same_allele(fx, a, b) for a, b in zip(cpu_c[g], gpu_calls[g])) for g in cpu_c)
+        cb["hla"]["diplotypes_cpu"] = {fx.genes[g]: cpu_c[g] for g in cpu_c}
+        cb["hla"]["diplotypes_gpu_same_reads"] = {fx.genes[g]: gpu_calls[g] for g in gpu_calls}
+        hla_same = all(all(same_allele(fx, a, b) for a, b in zip(cpu_c[g], gpu_calls[g])) for g in cpu_c)
         agree = sum(1 for k, r in enumerate(cpu_done) if cpu_best[r][0] == int(o[k]["best_allele"]))
         gene_agree = sum(1 for k, r in enumerate(cpu_done) if cpu_best[r][0] >= 0 and int(o[k]["gene"]) == int(fx.gene_of[cpu_best[r][0]]))
-        cb["k1_same_allele_as_gpu"] = f"{agree}/{len(cpu_done)}"
-        cb["k1_same_gene_as_gpu"] = f"{gene_agree}/{len(cpu_done)}"
-        cb["gpu_over_cpu_all_cores_hla_alone"] = (legs["hla_resident"]["value"] / cb["value"]) if legs else None
+        cb["hla"]["k1_same_allele_as_gpu"] = f"{agree}/{len(cpu_done)}"
+        cb["hla"]["k1_same_gene_as_gpu"] = f"{gene_agree}/{len(cpu_done)}"
+        Rc = ctx.upload(cpu_ref["cyp_reads"])
+        g_cyp, _cons, _labels = cdb.diplotype(Rc)
+        cb["cyp2d6"]["call_gpu_same_reads"] = [g_cyp.hap1.decode(), g_cyp.hap2.decode()]
+        cyp_same = int(g_cyp.status) == cb["cyp2d6"]["status"] and sorted(cb["cyp2d6"]["call_gpu_same_reads"]) == sorted(cb["cyp2d6"]["call"])
+        cb["diplotypes_identical"] = {"hla": bool(hla_same), "cyp2d6": bool(cyp_same)}
+        # like for like: the GPU on the same reads, one sample at a time, reads resident (the headline also uploads a new sample per step)
+        ctx.synchronize(); t1 = time.perf_counter()
+        o2 = db.realign_reads(Rs); db.diplotype_genes(genes, Rs, o2); cdb.diplotype(Rc)
+        ctx.synchronize(); d_same = time.perf_counter() - t1
+        cb["gpu_same_reads_one_after_the_other"] = {"value": (len(sub) + len(cpu_ref["cyp_reads"])) / d_same, "unit": "reads/s", "seconds": d_same}
+        cb["gpu_over_cpu"] = {"all_cores": cb["gpu_same_reads_one_after_the_other"]["value"] / cb["value"],
+                              "one_thread": cb["gpu_same_reads_one_after_the_other"]["value"] / cb["single_thread_value"],
+                              "note": "same reads, both loci, the GPU running the loci one after the other as the CPU leg does; a ratio to a scalar restatement, not to minimap2's SSE build"}
+        Rs.close(); Rc.close()
         line["cpu_baseline"] = cb
     else:
         line["cpu_baseline"] = None

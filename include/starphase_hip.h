@@ -55,6 +55,19 @@ int32_t sp_abi_version(void);
 int32_t sp_device_count(int32_t* count);
 /* device: HIP ordinal.  stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create one. */
 int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out);
+/* What a context found when it was made.  hw_queues: the number of hardware queues the HIP runtime maps this process's streams onto (its GPU_MAX_HW_QUEUES
+ * setting; the runtime's own default is 4).  The library runs the loci / genes / samples of a call on streams of their own and wants >= 16: with fewer, two chains
+ * of small dependent launches can share a queue with another sample's large grids (measured: 230k instead of 300k reads/s with three samples in flight).  The
+ * first sp_ctx_create of a process therefore sets GPU_MAX_HW_QUEUES=16 when the variable is not set (hw_queues_set_by_library = 1) -- which only takes effect
+ * if the HIP runtime has not been initialised yet (a host that initialises HIP first should export the variable itself); a value below 16 found in the
+ * environment is left alone and reported in `warning` (and once through sp_last_error of that context, status SP_OK). */
+typedef struct {
+    int32_t device, num_cus;
+    int32_t hw_queues;                 /* GPU_MAX_HW_QUEUES as seen at sp_ctx_create (after the library's own default, if it set one) */
+    int32_t hw_queues_set_by_library;  /* 1: the variable was not set and the library set it to 16 */
+    char warning[256];                 /* "" or what the host should change */
+} sp_ctx_info;
+int32_t sp_ctx_get_info(const sp_ctx* ctx, sp_ctx_info* out);
 void    sp_ctx_destroy(sp_ctx* ctx);
 const char* sp_last_error(const sp_ctx* ctx);
 int32_t sp_ctx_synchronize(sp_ctx* ctx);
@@ -616,7 +629,9 @@ int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* r
  * level) followed by solve(the others, level); else solve(group, level + 1), or emit the group after the last level.  Initial
  * groups: the unseeded reads, then each seed in ascending order.  Offsets inside a group are re-based on the group's smallest
  * one (that read starts the consensus, the others keep their distance to it plus half the window).  Finally every emitted group
- * gets one consensus per level (sp_consensus).  All problems of a round run in lockstep on the GPU.  A two-way search that gives up (no
+ * gets one consensus per level: the consensus its own two-way search at that level left when that search ended with ONE consensus at the configured
+ * fraction (the search that found the group indivisible), otherwise (a group born from a split at a later level, a search that gave up or was retried) a
+ * search of its own (sp_consensus).  All problems of a round run in lockstep on the GPU.  A two-way search that gives up (no
  * complete node: a group of more classes than a search holds consensuses can exhaust the queue / capacity bounds at high depth) is run
  * again with min_af 0.15, 0.20, 0.30, 0.40 (the first above the configured one that completes); the groups it leaves are solved with the
  * configured fraction again.  This retry is a rule of this library, not of waffle_con: cfg.no_retry_ladder = 1 switches it off (the group then
@@ -949,6 +964,11 @@ int32_t sp_bam_last_seq4(const sp_bam* bam, const uint8_t** seq4, const uint64_t
 typedef struct sp_vcf sp_vcf;
 int32_t sp_vcf_open(const char* path, sp_vcf** out, char* err, uint32_t err_cap);
 void    sp_vcf_free(sp_vcf* vcf);
+/* A BGZF-compressed VCF with a tabix (<path>.tbi) or CSI (<path>.csi) index beside it is opened by its header alone; every query below then reads only the chunks
+ * the index names for its region (bcf::IndexedReader::fetch, src/diplotyper.rs:569-575,800) -- a 5 M-record WGS VCF costs a query a few blocks, not a scan.  Without
+ * an index (or with one that cannot be read) the file is read once as a whole.  indexed: which of the two; lines_parsed_by_fetches: record lines the queries so far
+ * have parsed (either may be NULL). */
+int32_t sp_vcf_index_info(const sp_vcf* vcf, int32_t* indexed, uint64_t* lines_parsed_by_fetches);
 const char* sp_vcf_last_error(const sp_vcf* vcf);
 int32_t sp_vcf_samples(const sp_vcf* vcf, uint32_t* n, const char* const** names);
 /* small variants: one sp_vcf_allele per ALT allele of every record of chrom that overlaps [start, end), for one sample (NULL = the

@@ -20,6 +20,14 @@ pub const SP_VAR_MAXDIP: i64 = 4096;
 pub const SP_GROUP_ID_BYTES: i64 = 128;
 
 #[repr(C)]
+pub struct sp_ctx_info {
+    pub device: i32,
+    pub num_cus: i32,
+    pub hw_queues: i32,
+    pub hw_queues_set_by_library: i32,
+    pub warning: [c_char; 256],
+}
+#[repr(C)]
 pub struct sp_pair {
     pub a: u32,
     pub b: u32,
@@ -523,6 +531,7 @@ extern "C" {
     pub fn sp_abi_version() -> i32;
     pub fn sp_device_count(count: *mut i32) -> i32;
     pub fn sp_ctx_create(device: i32, stream: *mut c_void, out: *mut *mut sp_ctx) -> i32;
+    pub fn sp_ctx_get_info(ctx: *const sp_ctx, out: *mut sp_ctx_info) -> i32;
     pub fn sp_ctx_destroy(ctx: *mut sp_ctx);
     pub fn sp_last_error(ctx: *const sp_ctx) -> *const c_char;
     pub fn sp_ctx_synchronize(ctx: *mut sp_ctx) -> i32;
@@ -650,6 +659,7 @@ extern "C" {
     pub fn sp_bam_last_seq4(bam: *const sp_bam, seq4: *mut *const u8, byte_offsets: *mut *const u64, lengths: *mut *const u32, n: *mut u32) -> i32;
     pub fn sp_vcf_open(path: *const c_char, out: *mut *mut sp_vcf, err: *mut c_char, err_cap: u32) -> i32;
     pub fn sp_vcf_free(vcf: *mut sp_vcf);
+    pub fn sp_vcf_index_info(vcf: *const sp_vcf, indexed: *mut i32, lines_parsed_by_fetches: *mut u64) -> i32;
     pub fn sp_vcf_last_error(vcf: *const sp_vcf) -> *const c_char;
     pub fn sp_vcf_samples(vcf: *const sp_vcf, n: *mut u32, names: *mut *const *const c_char) -> i32;
     pub fn sp_vcf_alleles(vcf: *mut sp_vcf, sample: *const c_char, chrom: *const c_char, start: u64, end: u64, out: *mut *const sp_vcf_allele, n: *mut u32) -> i32;

@@ -21,6 +21,11 @@ int32_t sp_device_count(int32_t* count) {
 int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
     if (!out) return SP_ERR_INVALID_ARG;
     *out = nullptr;
+    // hardware queues: asked for before the first HIP call of this function (see sp_ctx_info in the header)
+    bool by_library = false;
+    if (!std::getenv("GPU_MAX_HW_QUEUES")) { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); by_library = true; }
+    const char* hq = std::getenv("GPU_MAX_HW_QUEUES");
+    const int hw_queues = hq ? std::atoi(hq) : 4;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SP_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return SP_ERR_NO_DEVICE;
@@ -32,6 +37,14 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
     if (!ctx) return SP_ERR_OUT_OF_MEMORY;
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    static bool set_here = false;                     // (a later context of the process finds the variable the first one set)
+    if (by_library) set_here = true;
+    ctx->hw_queues = hw_queues; ctx->hw_queues_by_library = set_here;
+    if (hw_queues < 16) {
+        ctx->warning = "GPU_MAX_HW_QUEUES=" + std::to_string(hw_queues) + ": the library's streams share " + std::to_string(hw_queues) +
+                       " hardware queues; export GPU_MAX_HW_QUEUES=16 (or more) before the process initialises HIP";
+        ctx->err = ctx->warning;
+    }
     if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SP_ERR_HIP; }
@@ -39,6 +52,14 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
     }
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return SP_ERR_HIP; }
     *out = ctx;
+    return SP_OK;
+}
+
+int32_t sp_ctx_get_info(const sp_ctx* ctx, sp_ctx_info* out) {
+    if (!ctx || !out) return SP_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    out->device = ctx->device; out->num_cus = ctx->num_cus; out->hw_queues = ctx->hw_queues; out->hw_queues_set_by_library = ctx->hw_queues_by_library ? 1 : 0;
+    std::snprintf(out->warning, sizeof out->warning, "%s", ctx->warning.c_str());
     return SP_OK;
 }
 

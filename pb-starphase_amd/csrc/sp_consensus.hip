@@ -1932,7 +1932,9 @@ int32_t sp_consensus_dual(sp_ctx* ctx, const sp_seqset* reads, const uint32_t* r
 int32_t sp_consensus_priority_many(sp_ctx* ctx, uint32_t n_jobs, sp_priority_job* jobs) {
     if (!ctx) return SP_ERR_INVALID_ARG;
     if (n_jobs && !jobs) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_consensus_priority_many: null argument");
-    struct Item { std::vector<uint32_t> members; uint32_t level; std::string key; int retry = 0; };
+    // kept[l]: the consensus of level l when the two-way search of exactly these members ended with ONE consensus at the configured fraction: it is the group's
+    // consensus at that level, and only the levels without one are solved again at the end (a third of a CYP2D6 sample's launches were those repeats)
+    struct Item { std::vector<uint32_t> members; uint32_t level; std::string key; int retry = 0; std::vector<std::string> kept; std::vector<uint8_t> have; };
     struct JobState { std::vector<Item> work, done; int half = 0; bool live = false; };
     // A search that gave up (no complete node: a mixture of more classes than a search holds consensuses can exhaust the queue and capacity
     // bounds) is run again with only the stronger differences as candidates; the split it finds is the split, the groups it leaves are solved
@@ -2008,18 +2010,26 @@ int32_t sp_consensus_priority_many(sp_ctx* ctx, uint32_t n_jobs, sp_priority_job
             if (O[x].result.is_dual && !g1.empty() && !g2.empty()) {
                 Item a; a.members = std::move(g1); a.level = it.level; a.key = it.key + "0"; next[j].push_back(std::move(a));
                 Item b; b.members = std::move(g2); b.level = it.level; b.key = it.key + "1"; next[j].push_back(std::move(b));
-            } else if (it.level + 1 < NL) { it.level += 1; it.key += "_"; it.retry = 0; next[j].push_back(std::move(it)); }
-            else S[j].done.push_back(std::move(it));
+            } else {
+                if (it.retry == 0 && !O[x].result.is_dual && !O[x].result.gave_up) {
+                    it.kept.resize(NL); it.have.resize(NL, 0);
+                    it.kept[it.level] = std::string(text[x].data()); it.have[it.level] = 1;
+                }
+                if (it.level + 1 < NL) { it.level += 1; it.key += "_"; it.retry = 0; next[j].push_back(std::move(it)); }
+                else S[j].done.push_back(std::move(it));
+            }
         }
         for (uint32_t j = 0; j < n_jobs; ++j) if (S[j].live) {
             S[j].work.swap(next[j]);
             if (S[j].done.size() + S[j].work.size() > (size_t)jobs[j].problem->n) { jobs[j].status = SP_ERR_INVALID_ARG; S[j].live = false; S[j].work.clear(); }
         }
     }
-    // one consensus per emitted group and level, all jobs in one batch
+    // one consensus per emitted group and level: the one its own two-way search left when that ended with one consensus, else a search of its own -- those of all
+    // jobs in one batch
     std::vector<sp_cons_problem> P; std::vector<sp_cons_output> O;
     std::vector<std::vector<int32_t>> offs, s1, s2; std::vector<std::vector<uint8_t>> is1; std::vector<std::vector<char>> spare;
     size_t k = 0;
+    auto has_kept = [](const Item& it, uint32_t l) { return l < it.have.size() && it.have[l]; };
     for (uint32_t j = 0; j < n_jobs; ++j) {
         if (!S[j].live) continue;
         sp_priority_job& J = jobs[j];
@@ -2028,21 +2038,31 @@ int32_t sp_consensus_priority_many(sp_ctx* ctx, uint32_t n_jobs, sp_priority_job
         *J.n_groups = (uint32_t)done.size();
         for (size_t g = 0; g < done.size(); ++g) for (uint32_t r : done[g].members) J.group_of[r] = (int32_t)g;
         if (done.size() > J.max_groups) { J.status = SP_ERR_CAPACITY; S[j].live = false; continue; }
-        k += done.size() * J.problem->n_levels;
+        const uint32_t NL = J.problem->n_levels;
+        for (size_t g = 0; g < done.size() && S[j].live; ++g) for (uint32_t l = 0; l < NL; ++l) {
+            if (!has_kept(done[g], l)) { ++k; continue; }
+            const std::string& c = done[g].kept[l];
+            if (c.size() + 1 > (size_t)J.cap) { J.status = SP_ERR_CAPACITY; S[j].live = false; break; }
+            std::memcpy(J.cons + (g * NL + l) * (size_t)J.cap, c.c_str(), c.size() + 1);
+        }
     }
+    k = 0;
+    for (uint32_t j = 0; j < n_jobs; ++j) if (S[j].live) for (const Item& it : S[j].done) for (uint32_t l = 0; l < jobs[j].problem->n_levels; ++l) if (!has_kept(it, l)) ++k;
     P.resize(k); O.resize(k); offs.resize(k); s1.resize(k); s2.resize(k); is1.resize(k); spare.resize(k);
     size_t x = 0;
     for (uint32_t j = 0; j < n_jobs; ++j) {
         if (!S[j].live) continue;
         sp_priority_job& J = jobs[j]; const sp_priority_problem* pr = J.problem; const uint32_t NL = pr->n_levels;
-        for (size_t g = 0; g < S[j].done.size(); ++g) for (uint32_t l = 0; l < NL; ++l, ++x) {
+        for (size_t g = 0; g < S[j].done.size(); ++g) for (uint32_t l = 0; l < NL; ++l) {
             const Item& it = S[j].done[g];
+            if (has_kept(it, l)) continue;
             const bool has_off = rebased(j, it.members, l, offs[x]);
             s1[x].resize(it.members.size()); s2[x].resize(it.members.size()); is1[x].resize(it.members.size()); spare[x].assign(J.cap, 0);
             P[x].reads = pr->levels[l]; P[x].read_idx = it.members.data(); P[x].n = (uint32_t)it.members.size(); P[x].offsets = has_off ? offs[x].data() : nullptr;
             P[x].cfg = pr->cfg; P[x].cfg.allow_dual = 0;
             std::memset(&O[x], 0, sizeof O[x]);
             O[x].cons1 = J.cons + (g * NL + l) * (size_t)J.cap; O[x].cons2 = spare[x].data(); O[x].cap = J.cap; O[x].is_cons1 = is1[x].data(); O[x].score1 = s1[x].data(); O[x].score2 = s2[x].data();
+            ++x;
         }
     }
     if (k == 0) return SP_OK;

@@ -79,6 +79,7 @@ struct sp_ctx {
     std::map<std::string, std::pair<void*, size_t>> pool;   // named grow-only device buffers (no malloc/free per call)
     std::map<std::string, std::pair<void*, size_t>> host_pool;   // named grow-only pinned host buffers (results leave the device through them)
     int num_cus = 256;
+    int hw_queues = 4; bool hw_queues_by_library = false; std::string warning;     // sp_ctx_get_info
     bool split_genes = true;         // sp_ctx_set_option "hla_split_genes"
     int split_streams = 3;           // sp_ctx_set_option "hla_split_streams": streams the units of a call are spread over (1..4; a 32-sample cohort call: 71.5 / 58.4 / 54.9 / 68.6 ms)
     bool cons_retry_ladder = false;  // sp_ctx_set_option "cons_retry_ladder": sp_consensus_priority's retry of searches that give up (the drivers pass it on)

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <set>
 #include <string>
@@ -161,6 +162,24 @@ struct Bgzf {
         return true;
     }
 };
+
+// one text line (without its newline) from the read position on; false at the end of the file (or on an error: err is set)
+bool bgzf_getline(Bgzf& z, std::string& line) {
+    line.clear();
+    for (;;) {
+        if (z.pos >= z.data.size()) {
+            if (z.eof) return !line.empty();
+            z.grow = std::min(z.grow * 4, 256);
+            if (!z.load(z.next_at, z.grow)) return false;
+            if (z.eof) return !line.empty();
+            continue;
+        }
+        const uint8_t* from = z.data.data() + z.pos;
+        const uint8_t* nl = (const uint8_t*)std::memchr(from, '\n', z.data.size() - z.pos);
+        if (nl) { line.append((const char*)from, (size_t)(nl - from)); z.pos += (size_t)(nl - from) + 1; return true; }
+        line.append((const char*)from, z.data.size() - z.pos); z.pos = z.data.size();
+    }
+}
 
 uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
@@ -374,8 +393,15 @@ struct sp_vcf {
     std::string err;
     std::vector<std::string> samples; std::vector<const char*> sample_ptr;
     struct Record { std::string chrom; uint64_t pos0; std::string ref; std::vector<std::string> alts; std::string info, format; std::vector<std::string> calls; };
-    std::vector<Record> records;
+    std::vector<Record> records;                  // linear mode: every record of the file; indexed mode: the records of the last region fetch
     std::vector<sp_vcf_allele> alleles; std::vector<sp_vcf_deletion> deletions;
+    // indexed mode (a BGZF file with a .tbi / .csi beside it): only the header is read at open; a query reads the chunks the index names
+    // (bcf::IndexedReader::fetch, src/diplotyper.rs:569-575,800)
+    bool indexed = false; Bgzf z;
+    int min_shift = 14, depth = 5;
+    struct RefIndex { std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::map<uint32_t, uint64_t> loffset; std::vector<uint64_t> linear; };
+    std::map<std::string, RefIndex> index;
+    uint64_t n_fetched_lines = 0;                 // lines parsed by region fetches so far (the tests' evidence that a fetch does not scan the file)
 };
 
 namespace {
@@ -409,6 +435,132 @@ bool genotype(const sp_vcf::Record& r, int si, int& g1, int& g2, bool& phased, i
     return true;
 }
 
+// one record line -> Record; false + message on a malformed line
+bool vcf_parse_record(const std::string& line, sp_vcf::Record& r, std::string& why) {
+    const std::vector<std::string> col = split(line, '\t');
+    if (col.size() < 8) { why = "VCF record with fewer than 8 columns"; return false; }
+    r = sp_vcf::Record();
+    r.chrom = col[0]; r.pos0 = (uint64_t)std::strtoull(col[1].c_str(), nullptr, 10) - 1; r.ref = col[3]; r.alts = split(col[4], ','); r.info = col[7];
+    if (col.size() > 8) r.format = col[8];
+    for (size_t c = 9; c < col.size(); ++c) r.calls.push_back(col[c]);
+    return true;
+}
+
+// a whole gzip / BGZF file inflated (the index files are BGZF themselves)
+bool inflate_file(const std::string& path, std::vector<uint8_t>& out) {
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint8_t buf[1 << 16]; int k;
+    while ((k = gzread(f, buf, sizeof buf)) > 0) out.insert(out.end(), buf, buf + k);
+    gzclose(f);
+    return k == 0;
+}
+
+// tabix (.tbi, SAM/VCF specification "The tabix index format") and CSI (.csi, CSIv1) indices of a BGZF text file.  Both give, per reference name, bins of
+// chunks (pairs of virtual offsets); the bin scheme is UCSC's with min_shift / depth (14 / 5 in a .tbi).  Bin 37450 of a .tbi (depth-5 scheme + 1) is metadata.
+bool load_vcf_index(sp_vcf* v, const std::string& path) {
+    std::vector<uint8_t> d;
+    bool csi = false;
+    if (inflate_file(path + ".tbi", d) && d.size() >= 36 && std::memcmp(d.data(), "TBI\1", 4) == 0) csi = false;
+    else { d.clear(); if (inflate_file(path + ".csi", d) && d.size() >= 16 && std::memcmp(d.data(), "CSI\1", 4) == 0) csi = true; else return false; }
+    size_t at = 4;
+    auto need = [&](size_t n) { return at + n <= d.size(); };
+    auto i32 = [&]() { const int32_t x = (int32_t)le32(d.data() + at); at += 4; return x; };
+    int32_t n_ref = 0; std::vector<std::string> names;
+    auto read_names = [&](size_t l_nm) {
+        if (!need(l_nm)) return false;
+        size_t from = at; const size_t stop = at + l_nm;
+        while (from < stop) { const void* z = std::memchr(d.data() + from, 0, stop - from); const size_t to = z ? (size_t)((const uint8_t*)z - d.data()) : stop; names.emplace_back((const char*)d.data() + from, to - from); from = to + 1; }
+        at = stop;
+        return true;
+    };
+    if (!csi) {
+        if (!need(32)) return false;
+        n_ref = i32(); at += 24;                                   // format, col_seq, col_beg, col_end, meta, skip
+        const int32_t l_nm = i32();
+        if (l_nm < 0 || !read_names((size_t)l_nm)) return false;
+        v->min_shift = 14; v->depth = 5;
+    } else {
+        if (!need(12)) return false;
+        v->min_shift = i32(); v->depth = i32(); const int32_t l_aux = i32();
+        if (v->min_shift < 1 || v->min_shift > 30 || v->depth < 1 || v->depth > 10 || l_aux < 0 || !need((size_t)l_aux)) return false;
+        const size_t aux_end = at + (size_t)l_aux;
+        if (l_aux >= 28) { at += 24; const int32_t l_nm = i32(); if (l_nm < 0 || at + (size_t)l_nm > aux_end || !read_names((size_t)l_nm)) return false; }
+        at = aux_end;
+        if (!need(4)) return false;
+        n_ref = i32();
+    }
+    if (n_ref < 0 || n_ref > (1 << 24) || (size_t)n_ref > names.size()) return false;
+    const uint32_t meta_bin = csi ? 0xFFFFFFFFu : 37450u;
+    for (int32_t r = 0; r < n_ref; ++r) {
+        sp_vcf::RefIndex ix;
+        if (!need(4)) return false;
+        const int32_t n_bin = i32();
+        if (n_bin < 0) return false;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (!need(csi ? 16 : 8)) return false;
+            const uint32_t bin = le32(d.data() + at); at += 4;
+            if (csi) { ix.loffset[bin] = le64(d.data() + at); at += 8; }
+            const int32_t n_chunk = i32();
+            if (n_chunk < 0 || !need((size_t)n_chunk * 16)) return false;
+            std::vector<std::pair<uint64_t, uint64_t>> chunks((size_t)n_chunk);
+            for (int32_t c = 0; c < n_chunk; ++c) { chunks[(size_t)c] = { le64(d.data() + at), le64(d.data() + at + 8) }; at += 16; }
+            if (bin != meta_bin) ix.bins[bin] = std::move(chunks);
+        }
+        if (!csi) {
+            if (!need(4)) return false;
+            const int32_t n_intv = i32();
+            if (n_intv < 0 || !need((size_t)n_intv * 8)) return false;
+            ix.linear.resize((size_t)n_intv);
+            for (int32_t k = 0; k < n_intv; ++k) { ix.linear[(size_t)k] = le64(d.data() + at); at += 8; }
+        }
+        v->index[names[(size_t)r]] = std::move(ix);
+    }
+    return true;
+}
+
+// the records of chrom that may overlap [start, end), read through the index into v->records
+int32_t vcf_fetch(sp_vcf* v, const char* chrom, uint64_t start, uint64_t end) {
+    v->records.clear();
+    const auto it = v->index.find(chrom);
+    if (it == v->index.end() || end <= start) return SP_OK;         // (a chromosome without records is not in the index)
+    const sp_vcf::RefIndex& ix = it->second;
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    {
+        const uint64_t cap = 1ull << (v->min_shift + 3 * v->depth);
+        const uint64_t b0 = std::min(start, cap - 1), e0 = std::min(end, cap) - 1;
+        uint64_t t = 0; int s = v->min_shift + 3 * v->depth;
+        for (int l = 0; l <= v->depth; ++l, s -= 3) {
+            for (uint64_t k = t + (b0 >> s); k <= t + (e0 >> s); ++k) { const auto b = ix.bins.find((uint32_t)k); if (b != ix.bins.end()) chunks.insert(chunks.end(), b->second.begin(), b->second.end()); }
+            t += 1ull << (3 * l);
+        }
+    }
+    const uint64_t min_off = ix.linear.empty() ? 0 : ix.linear[std::min<size_t>((size_t)(start >> 14), ix.linear.size() - 1)];
+    std::vector<std::pair<uint64_t, uint64_t>> kept;
+    for (const auto& c : chunks) if (c.second > min_off) kept.emplace_back(std::max(c.first, min_off), c.second);
+    std::sort(kept.begin(), kept.end());
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    for (const auto& c : kept) { if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second); else merged.push_back(c); }
+    std::string line, why;
+    bool past = false;
+    for (const auto& c : merged) {
+        if (past) break;
+        if (!v->z.seek(c.first)) return vcf_fail(v, v->z.err.empty() ? "bad virtual offset in the VCF index" : v->z.err);
+        while (!past && v->z.tell() < c.second) {
+            if (!bgzf_getline(v->z, line)) { if (!v->z.err.empty()) return vcf_fail(v, v->z.err); break; }
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty() || line[0] == '#') continue;
+            v->n_fetched_lines += 1;
+            sp_vcf::Record r;
+            if (!vcf_parse_record(line, r, why)) return vcf_fail(v, why);
+            if (r.chrom != chrom) continue;
+            if (r.pos0 >= end) { past = true; break; }              // sorted: nothing behind it starts inside the region
+            v->records.push_back(std::move(r));
+        }
+    }
+    return SP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -416,6 +568,28 @@ extern "C" {
 int32_t sp_vcf_open(const char* path, sp_vcf** out, char* err, uint32_t err_cap) {
     if (!path || !out) return SP_ERR_INVALID_ARG;
     *out = nullptr;
+    // a BGZF file with a tabix / CSI index beside it: header only, records come through the index query by query
+    try {
+        auto v = std::make_unique<sp_vcf>();
+        if (load_vcf_index(v.get(), path) && v->z.open(path) && v->z.seek(0)) {
+            std::string line; bool have_header = false;
+            while (bgzf_getline(v->z, line)) {
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                if (line.empty() || line.compare(0, 2, "##") == 0) continue;
+                if (line[0] != '#') break;
+                const std::vector<std::string> col = split(line, '\t');
+                for (size_t c = 9; c < col.size(); ++c) v->samples.push_back(col[c]);
+                have_header = true; break;
+            }
+            if (v->z.err.empty() && have_header) {
+                for (const std::string& s : v->samples) v->sample_ptr.push_back(s.c_str());
+                v->indexed = true;
+                *out = v.release();
+                return SP_OK;
+            }
+        }
+    } catch (const std::bad_alloc&) { put_err(err, err_cap, "out of memory reading the VCF index"); return SP_ERR_OUT_OF_MEMORY; }
+    catch (const std::exception&) { }                // (an index that cannot be used: the file is read as a whole)
     gzFile f = gzopen(path, "rb");                 // plain text, gzip and BGZF (gzip members one after the other) alike
     if (!f) { put_err(err, err_cap, std::string("cannot open ") + path); return SP_ERR_INVALID_ARG; }
     std::string text; char buf[1 << 16]; int k;
@@ -431,12 +605,9 @@ int32_t sp_vcf_open(const char* path, sp_vcf** out, char* err, uint32_t err_cap)
         std::string line = text.substr(from, to - from); from = to + 1;
         if (!line.empty() && line.back() == '\r') line.pop_back();
         if (line.empty() || line.compare(0, 2, "##") == 0) continue;
-        const std::vector<std::string> col = split(line, '\t');
-        if (line[0] == '#') { for (size_t c = 9; c < col.size(); ++c) v->samples.push_back(col[c]); have_header = true; continue; }
-        if (col.size() < 8) { put_err(err, err_cap, "VCF record with fewer than 8 columns"); return SP_ERR_INVALID_ARG; }
-        sp_vcf::Record r; r.chrom = col[0]; r.pos0 = (uint64_t)std::strtoull(col[1].c_str(), nullptr, 10) - 1; r.ref = col[3]; r.alts = split(col[4], ','); r.info = col[7];
-        if (col.size() > 8) r.format = col[8];
-        for (size_t c = 9; c < col.size(); ++c) r.calls.push_back(col[c]);
+        if (line[0] == '#') { const std::vector<std::string> col = split(line, '\t'); for (size_t c = 9; c < col.size(); ++c) v->samples.push_back(col[c]); have_header = true; continue; }
+        sp_vcf::Record r; std::string why;
+        if (!vcf_parse_record(line, r, why)) { put_err(err, err_cap, why); return SP_ERR_INVALID_ARG; }
         v->records.push_back(std::move(r));
     }
     if (!have_header) { put_err(err, err_cap, "no #CHROM header line"); return SP_ERR_INVALID_ARG; }
@@ -448,6 +619,12 @@ int32_t sp_vcf_open(const char* path, sp_vcf** out, char* err, uint32_t err_cap)
 }
 
 void sp_vcf_free(sp_vcf* vcf) { delete vcf; }
+int32_t sp_vcf_index_info(const sp_vcf* vcf, int32_t* indexed, uint64_t* lines_parsed_by_fetches) {
+    if (!vcf) return SP_ERR_INVALID_ARG;
+    if (indexed) *indexed = vcf->indexed ? 1 : 0;
+    if (lines_parsed_by_fetches) *lines_parsed_by_fetches = vcf->n_fetched_lines;
+    return SP_OK;
+}
 const char* sp_vcf_last_error(const sp_vcf* vcf) { return vcf ? vcf->err.c_str() : ""; }
 int32_t sp_vcf_samples(const sp_vcf* vcf, uint32_t* n, const char* const** names) {
     if (!vcf || !n) return SP_ERR_INVALID_ARG;
@@ -461,6 +638,7 @@ int32_t sp_vcf_alleles(sp_vcf* v, const char* sample, const char* chrom, uint64_
     v->alleles.clear(); *out = nullptr; *n = 0;
     const int si = sample_index(v, sample);
     if (si < 0) return vcf_fail(v, std::string("the VCF has no sample ") + (sample ? sample : "(first)"));
+    if (v->indexed) { const int32_t rc = vcf_fetch(v, chrom, start, end); if (rc != SP_OK) return rc; }
     for (const sp_vcf::Record& r : v->records) {
         if (r.chrom != chrom || !(r.pos0 < end && r.pos0 + r.ref.size() > start)) continue;
         int g1, g2; bool phased; int64_t ps;
@@ -484,6 +662,7 @@ int32_t sp_vcf_deletions(sp_vcf* v, const char* sample, const char* chrom, uint6
     v->deletions.clear(); *out = nullptr; *n = 0;
     const int si = sample_index(v, sample);
     if (si < 0) return vcf_fail(v, std::string("the VCF has no sample ") + (sample ? sample : "(first)"));
+    if (v->indexed) { const int32_t rc = vcf_fetch(v, chrom, start, end); if (rc != SP_OK) return rc; }
     for (const sp_vcf::Record& r : v->records) {
         if (r.chrom != chrom || r.alts.size() != 1) continue;
         if (r.pos0 >= end) continue;                                 // the reference only sees what its region fetch returns (src/diplotyper.rs:796-815)

@@ -2,6 +2,7 @@
 // the sustained integer VALU issue rate of the chip and its streaming HBM copy rate.  Not on the product path.
 #include "sp_internal.h"
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -30,9 +31,22 @@ __global__ __launch_bounds__(256) void mb_match_kernel(unsigned* __restrict__ ou
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc ^ p;
 }
 
-__global__ __launch_bounds__(256) void mb_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+// streaming copy: every workgroup owns contiguous 16 KiB tiles (256 lanes x 16 B x 4 loads in flight per lane before the first store), non-temporal
+// both ways (nothing is read twice: the lines need not stay in L2 / MALL).  One load per lane and iteration with a grid-wide stride reached 4.6 TB/s;
+// VARIANT selects what bench.py's "hbm_copy" runs (profiles/r04/hbm_copy_variants.txt)
+typedef unsigned mb_u4 __attribute__((ext_vector_type(4)));
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void mb_copy_kernel(const mb_u4* __restrict__ src, mb_u4* __restrict__ dst, size_t n) {
+    const size_t tile = (size_t)256 * UNROLL, n_tiles = n / tile;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const mb_u4* s = src + t * tile + threadIdx.x; mb_u4* d = dst + t * tile + threadIdx.x;
+        mb_u4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(s + u * 256) : s[u * 256];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { if (NT) __builtin_nontemporal_store(v[u], d + u * 256); else d[u * 256] = v[u]; }
+    }
+    for (size_t i = n_tiles * tile + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 } // namespace
@@ -63,12 +77,21 @@ extern "C" int32_t sp_microbench(sp_ctx* ctx, const char* what, double* rate) {
         units = (double)blocks * 4.0 * MB_ITER * (plain ? 8.0 : 17.0);
     } else if (std::strcmp(what, "hbm_copy") == 0) {
         const size_t bytes = (size_t)1 << 30;
-        uint4* src = (uint4*)sp_pool(ctx, "mb_src", bytes); uint4* dst = (uint4*)sp_pool(ctx, "mb_dst", bytes);
+        mb_u4* src = (mb_u4*)sp_pool(ctx, "mb_src", bytes); mb_u4* dst = (mb_u4*)sp_pool(ctx, "mb_dst", bytes);
         if (!src || !dst) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_microbench");
         (void)hipMemsetAsync(src, 1, bytes, ctx->stream);
         for (int rep = 0; rep < 3; ++rep) {
             (void)hipEventRecord(e0, ctx->stream);
-            hipLaunchKernelGGL(mb_copy_kernel, dim3(ctx->num_cus * 16), dim3(256), 0, ctx->stream, src, dst, bytes / 16);
+            const char* var = std::getenv("SP_MB_COPY_VARIANT");
+            const int v = var ? std::atoi(var) : 3;
+            const dim3 grid(ctx->num_cus * (v >= 10 ? 32 : 16));
+            switch (v % 10) {
+                case 0: hipLaunchKernelGGL((mb_copy_kernel<1, false>), grid, dim3(256), 0, ctx->stream, src, dst, bytes / 16); break;
+                case 1: hipLaunchKernelGGL((mb_copy_kernel<4, false>), grid, dim3(256), 0, ctx->stream, src, dst, bytes / 16); break;
+                case 2: hipLaunchKernelGGL((mb_copy_kernel<1, true>), grid, dim3(256), 0, ctx->stream, src, dst, bytes / 16); break;
+                case 3: hipLaunchKernelGGL((mb_copy_kernel<4, true>), grid, dim3(256), 0, ctx->stream, src, dst, bytes / 16); break;
+                default: hipLaunchKernelGGL((mb_copy_kernel<8, true>), grid, dim3(256), 0, ctx->stream, src, dst, bytes / 16); break;
+            }
             (void)hipEventRecord(e1, ctx->stream);
             SP_HIP_CHECK(ctx, hipEventSynchronize(e1));
             (void)hipEventElapsedTime(&ms, e0, e1);

@@ -526,6 +526,7 @@ def _io():
         "sp_bam_last_seq4": (_i32, [_vp, P(_vp), P(P(_u64)), P(P(_u32)), P(_u32)]),
         "sp_vcf_open": (_i32, [_s, P(_vp), _s, _u32]),
         "sp_vcf_free": (None, [_vp]),
+        "sp_vcf_index_info": (_i32, [_vp, P(_i32), P(_u64)]),
         "sp_vcf_last_error": (_s, [_vp]),
         "sp_vcf_samples": (_i32, [_vp, P(_u32), P(P(_s))]),
         "sp_vcf_alleles": (_i32, [_vp, _s, _s, _u64, _u64, P(P(sp_vcf_allele)), P(_u32)]),
@@ -619,6 +620,12 @@ class Vcf:
     def _check(self, rc):
         if rc != SP_OK:
             raise StarphaseError(rc, _io().sp_vcf_last_error(self._h).decode())
+
+    def index_info(self):
+        """-> (read through a tabix / CSI index?, record lines the region fetches have parsed so far)"""
+        ix, n = _i32(), _u64()
+        _io().sp_vcf_index_info(self._h, C.byref(ix), C.byref(n))
+        return bool(ix.value), int(n.value)
 
     def samples(self):
         n, names = _u32(), C.POINTER(_s)()

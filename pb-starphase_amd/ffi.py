@@ -229,6 +229,7 @@ def lib():
         "sp_device_count": (i32, [C.POINTER(i32)]),
         "sp_ctx_create": (i32, [i32, vp, C.POINTER(vp)]),
         "sp_ctx_destroy": (None, [vp]),
+        "sp_ctx_get_info": (i32, [vp, C.POINTER(sp_ctx_info)]),
         "sp_last_error": (C.c_char_p, [vp]),
         "sp_ctx_synchronize": (i32, [vp]),
         "sp_ctx_set_option": (i32, [vp, C.c_char_p, C.c_int64]),
@@ -325,6 +326,10 @@ def _concat(seqs):
     return blob, offs
 
 
+class sp_ctx_info(C.Structure):
+    _fields_ = [("device", C.c_int32), ("num_cus", C.c_int32), ("hw_queues", C.c_int32), ("hw_queues_set_by_library", C.c_int32), ("warning", C.c_char * 256)]
+
+
 class Context:
     def __init__(self, device=0, stream=None):
         self._h = C.c_void_p()
@@ -335,6 +340,12 @@ class Context:
     def check(self, rc):
         if rc != SP_OK:
             raise StarphaseError(rc, lib().sp_last_error(self._h).decode())
+
+    def info(self):
+        """sp_ctx_get_info -> dict(device, num_cus, hw_queues, hw_queues_set_by_library, warning)"""
+        st = sp_ctx_info()
+        self.check(lib().sp_ctx_get_info(self._h, C.byref(st)))
+        return dict(device=st.device, num_cus=st.num_cus, hw_queues=st.hw_queues, hw_queues_set_by_library=bool(st.hw_queues_set_by_library), warning=st.warning.decode())
 
     def close(self):
         if self._h:

@@ -32,16 +32,32 @@ def realign_pick(hits):
 
 
 def _k1_worker(args):
+    """realign_record for a share of the reads: the seeded map + acceptance (src/hla/realigner.rs:98-146), then the segment / offset bookkeeping behind the best
+    mapping (:226-325)"""
+    import hla_expected as hx
     lo, hi, budget_s = args
-    idx, reads, dna_ids = G["idx"], G["reads"], G["dna_ids"]
-    out, t0 = [], time.perf_counter()
+    idx, reads, dna_ids, o = G["idx"], G["reads"], G["dna_ids"], G["o"]
+    tb = G.get("tb") or hx.K1Tables(o, G["fx"], G["off"])
+    G["tb"] = tb
+    out, t0, t_map = [], time.perf_counter(), 0.0
     for r in range(lo, hi):
+        t1 = time.perf_counter()
         h = realign_pick(idx.map(reads[r]))
+        t_map += time.perf_counter() - t1
         # a best mapping on the reverse strand is dropped (src/hla/realigner.rs:178-193)
-        out.append((r, -1, None) if (h is None or h["rev"]) else (r, dna_ids[h["rid"]], (h["nm"], h["t_start"], h["t_end"], h["q_start"], h["q_end"], h["t_len"], h["q_len"])))
+        a, m = (-1, None) if (h is None or h["rev"]) else (dna_ids[h["rid"]], (h["nm"], h["t_start"], h["t_end"], h["q_start"], h["q_end"], h["t_len"], h["q_len"]))
+        re = o.encode(reads[r])
+        bm = None
+        if a >= 0:
+            nm, ts, te, qs, qe, tl, ql = m
+            bm = np.zeros(1, hx.oracle_aln_dtype())[0]
+            bm["ok"], bm["nm"], bm["a_start"], bm["a_end"], bm["b_start"], bm["b_end"], bm["a_len"], bm["b_len"] = 1, nm, ts, te, qs, qe, tl, ql
+        rec = tb.record(reads[r], re, tb.anchors(re), a, bm)
+        rec.pop("aln", None)
+        out.append((r, a, m, rec))
         if time.perf_counter() - t0 > budget_s:
             break
-    return out, time.perf_counter() - t0
+    return out, time.perf_counter() - t0, t_map
 
 
 def k2_scan_mm2(mm, o, alleles, cons_dna, cons_cdna):
@@ -102,31 +118,22 @@ def _gene_worker(args):
     o, fx = G["o"], G["fx"]
     reads = [G["reads"][r] for r in sample]
     t0 = time.perf_counter()
-    tb = hx.K1Tables(o, fx, G["off"])
-    k1 = []
-    for r in sample:                                           # realign_record's bookkeeping behind the best mapping (segment, offsets)
-        a, m = G["best"][r]
-        re = o.encode(G["reads"][r])
-        anch = tb.anchors(re)
-        bm = None
-        if a >= 0:
-            nm, ts, te, qs, qe, tl, ql = m
-            bm = np.zeros(1, hx.oracle_aln_dtype())[0]
-            bm["ok"], bm["nm"], bm["a_start"], bm["a_end"], bm["b_start"], bm["b_end"], bm["a_len"], bm["b_len"] = 1, nm, ts, te, qs, qe, tl, ql
-        k1.append(tb.record(G["reads"][r], re, anch, a, bm))
+    k1 = [G["records"][r] for r in sample]                     # (realign_record's bookkeeping ran with the maps, spread over the workers)
     t1 = time.perf_counter()
-    typed = {}
+    typed = []
 
     def typer(oracle, fx_, g_, cons, synth_):
         t = time.perf_counter()
         out = type_consensus_mm2(oracle, fx_, g_, cons, synth_)
-        typed[len(typed)] = time.perf_counter() - t
+        typed.append((t, time.perf_counter()))
         return out
+    typer.threads = True                                       # the two consensuses of a gene are typed side by side
 
     res = hp.diplotype_gene(o, fx, g, reads, k1, synth, type_fn=typer)
     t2 = time.perf_counter()
-    t_type = sum(typed.values())
-    return g, t1 - t0, (t2 - t1) - t_type, t_type, (res["allele1"], res["allele2"]), (res["cons1"], res["cons2"])
+    t_type = sum(b - a for a, b in typed)                                  # CPU seconds of the typing; its wall clock (two threads) is the span they cover
+    t_type_wall = (max(b for _a, b in typed) - min(a for a, _b in typed)) if typed else 0.0
+    return g, t1 - t0, (t2 - t1) - t_type_wall, t_type, (res["allele1"], res["allele2"]), (res["cons1"], res["cons2"])
 
 
 def run(o, fx, reads, n_sample=2000, budget_s=12.0, cores=None, seed=0):
@@ -162,12 +169,13 @@ def run(o, fx, reads, n_sample=2000, budget_s=12.0, cores=None, seed=0):
     with mp.get_context("fork").Pool(cores) as pool:
         parts = pool.map(_k1_worker, [(w * per, min(len(sub), (w + 1) * per), budget_s) for w in range(cores) if w * per < len(sub)])
     t_k1 = time.perf_counter() - t1
-    best = {}
-    for out, _dt in parts:
-        for r, a, m in out:
-            best[sample[r]] = (a, m)
+    best, records = {}, {}
+    for out, _dt, _tm in parts:
+        for r, a, m, rec in out:
+            best[sample[r]] = (a, m); records[sample[r]] = rec
     done = sorted(best)
-    G["reads"], G["best"] = reads, best
+    G["reads"], G["best"], G["records"] = reads, best, records
+    map_cpu_s, k1_cpu_s = sum(p[2] for p in parts), sum(p[1] for p in parts)
     # per gene: consensus + typing (one worker per gene; inside a gene the reference is sequential)
     t1 = time.perf_counter()
     with mp.get_context("fork").Pool(len(fx.genes)) as pool:
@@ -176,16 +184,20 @@ def run(o, fx, reads, n_sample=2000, budget_s=12.0, cores=None, seed=0):
     idx.close()
     calls = {g: c for g, _a, _b, _c, c, _s in gres}
     cons = {g: s for g, _a, _b, _c, _d, s in gres}
-    bookkeeping_s = sum(x[1] for x in gres); cons_s = sum(x[2] for x in gres); typing_s = sum(x[3] for x in gres)
+    cons_s = sum(x[2] for x in gres); typing_s = sum(x[3] for x in gres)
+    bookkeeping_s = k1_cpu_s - map_cpu_s
     n = len(done)
     one_thread_s = n * t_single + bookkeeping_s + cons_s + typing_s
-    return {"value": n / (t_k1 + t_genes), "unit": "reads/s", "cores": cores, "kind": "port-seeded",
-            "single_thread_value": n / one_thread_s,
+    k1_workers = min(cores, (len(sub) + per - 1) // per)
+    return {"value": n / (t_k1 + t_genes), "unit": "reads/s", "cores": cores, "kind": "port", "reads": n,
+            "wall_s": t_k1 + t_genes, "single_thread_value": n / one_thread_s, "one_thread_s": one_thread_s,
+            "workers_per_stage": {"realign_record (seeded map + segment / offsets)": k1_workers, "consensus (per gene)": len(fx.genes),
+                                  "typing every allele (two consensuses per gene side by side)": 2 * len(fx.genes)},
             "k1_seeded_ms_per_read_one_thread": 1e3 * t_single, "k1_all_cores_s": t_k1, "genes_wall_s": t_genes,
-            "per_gene_cpu_s": {"realign_bookkeeping": bookkeeping_s, "consensus": cons_s, "typing_every_allele": typing_s},
+            "cpu_s": {"seeded_maps": map_cpu_s, "realign_bookkeeping": bookkeeping_s, "consensus": cons_s, "typing_every_allele": typing_s},
             "index_build_s": t_index,
-            "sample": f"{n} reads drawn from the same 10,000-read batch: K1 = one seeded map per read against the index of {len(dna_ids)} DNA alleles, the best chains "
-                      f"base-aligned (best_n 5), over {cores} forked workers in {t_k1:.1f} s ({1e3 * t_single:.1f} ms per read on one thread); then per gene (one worker each) "
-                      f"segments + offsets, dual + group consensus and the typing of the consensuses against every allele in {t_genes:.1f} s wall",
+            "sample": f"{n} of the sample's {len(reads)} HLA reads: realign_record (one seeded map per read against the index of {len(dna_ids)} DNA alleles, best_n 5, + segment / "
+                      f"offset bookkeeping) over {k1_workers} forked workers in {t_k1:.1f} s ({1e3 * t_single:.1f} ms per map on one thread); then per gene (one worker each, the two "
+                      f"consensuses of a gene typed on two threads) dual + group consensus and the typing of the consensuses against every allele in {t_genes:.1f} s wall",
             "note": "the reference's call pattern on minimap2's published algorithm restated in scalar C (oracle/mm2.c; minimap2 itself and its SSE kernels are not on disk); "
                     "consensus = oracle/consensus.c.  single_thread_value is what one thread needs for the same sample (the reference is single-threaded)"}, best, calls, cons, done

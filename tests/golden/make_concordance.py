@@ -47,7 +47,7 @@ def hla_section(o, synth):
             "calls": {fx.genes[g]: sorted(int(x) for x in calls[g]) for g in calls}, "call_ids": {fx.genes[g]: sorted(fx.ids[int(x)] for x in calls[g] if x >= 0) for g in calls},
             "consensus": {fx.genes[g]: list(cons[g]) for g in cons},
             "truth": {fx.genes[g]: sorted(int(a) for (gg, _c, _d, a) in wl.consensus if gg == g) for g in range(len(fx.genes))},
-            "cpu": {k: res[k] for k in ("k1_seeded_ms_per_read_one_thread", "k1_all_cores_s", "genes_wall_s", "per_gene_cpu_s", "cores")}}
+            "cpu": {k: res[k] for k in ("k1_seeded_ms_per_read_one_thread", "k1_all_cores_s", "genes_wall_s", "cpu_s", "cores")}}
 
 
 def cyp_section(o, synth):

@@ -11,7 +11,7 @@ Run in the authoring container only (needs /root/reference).  Everything written
   hla_faux_database.json   test_data/HLA-faux/database.json (2 real IMGT alleles)
   variant_dbs/*.json       test_data/{CACNA1S,RNR1-faux,UGT1A1-faux,CYP2C8-faux,DPYD-sv-test}/database.json
   variant_vcfs.json        decoded rows of every test VCF (no htslib needed downstream)
-  vcf/<set>/*.vcf.gz       the same test VCFs as they are (bgzip data files)
+  vcf/<set>/*.vcf.gz       the same test VCFs as they are (bgzip data files), and their tabix indices (*.vcf.gz.tbi, as htslib wrote them)
   test_reference.json      test_data/test_reference.fa
   cyp2d6_db_v0.14.1.json.gz  cyp2d6_config + cyp2d6_gene_def of the bundled DB
   cyp2d6_gene_def_v0.9.0.json.gz  cyp2d6_gene_def of data/v0.9.0/cpic_20240404.json.gz, the database test_load_variant_database
@@ -89,6 +89,8 @@ def main():
         # the data file itself (bgzip; the reference's tests read it through htslib): input of the library's VCF reader
         os.makedirs(os.path.join(OUT, "vcf", os.path.dirname(key)), exist_ok=True)
         shutil.copyfile(path, os.path.join(OUT, "vcf", key))
+        if os.path.exists(path + ".tbi"):                                  # the tabix index htslib wrote for it (a data file of the reference's tests)
+            shutil.copyfile(path + ".tbi", os.path.join(OUT, "vcf", key + ".tbi"))
     dump(vcfs, "variant_vcfs.json")
     dump(read_fasta(f"{REF}/test_data/test_reference.fa"), "test_reference.json")
     for d in ["HLA_configs", "CYP2D6_configs"]:

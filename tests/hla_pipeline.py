@@ -94,11 +94,16 @@ def diplotype_gene(oracle, fx, g, reads, k1, synth, min_count=3, min_fraction=0.
         grp = [i for i, m in enumerate(members) if m]
         cons.append(of.oracle_consensus(oracle, [segs[i] for i in grp], [offs[i] for i in grp], single)["cons"][0])
     type_consensus_ = type_fn or type_consensus                  # (bench.py's CPU leg types with the minimap2 restatement: tests/cpu_port_seeded.py)
-    t1 = type_consensus_(oracle, fx, g, cons[0], synth)
+    both = None
+    if dual["is_dual"] and getattr(type_consensus_, "threads", False):      # (the CPU port types the two consensuses side by side: one long C call each, the GIL is released)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as ex:
+            both = [f.result() for f in [ex.submit(type_consensus_, oracle, fx, g, c, synth) for c in cons[:2]]]
+    t1 = both[0] if both else type_consensus_(oracle, fx, g, cons[0], synth)
     out.update(cons1=cons[0], typed1=t1, is_dual=int(dual["is_dual"]), dual_passed=0, counts1=c1, counts2=c2, maf=maf, cdf=cdf,
                used_dna_dual=int(used_dna), is_cons1=dual["is_cons1"])
     if dual["is_dual"]:
-        t2 = type_consensus_(oracle, fx, g, cons[1], synth)
+        t2 = both[1] if both else type_consensus_(oracle, fx, g, cons[1], synth)
         out.update(cons2=cons[1], typed2=t2, dual_passed=int(ok))
         if ok:
             out.update(allele1=t1, allele2=t2)

@@ -472,8 +472,12 @@ def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None, ret
         mn = min(vals)
         return [None if v == mn else v - mn + (0 if mn == 0 else half) for v in vals]
 
-    def solve(members, level):
+    def solve(members, level, kept=None):
+        """-> [(members, {level: consensus})]: `kept` holds the consensus of every level whose two-way search on exactly these members ended with ONE consensus at
+        the configured fraction -- that search's consensus is the group's consensus at that level; only levels without one are solved again at the end"""
+        kept = dict(kept or {})
         res = dual_consensus_two_pass(run, [levels[level][r] for r in members], rebased(members, level), dual)
+        first_try = True
         # a search that gave up (no complete node: a mixture of more classes than a search holds consensuses can exhaust the queue and capacity
         # bounds) is run again with only the stronger differences as candidates; the split it finds is the split, the groups it leaves are
         # solved with the configured fraction again
@@ -483,13 +487,16 @@ def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None, ret
             stricter = ConsConfig(dual.min_count, dual.dual_max_ed_delta, dual.allow_early_termination, 1, dual.offset_window, dual.offset_compare_length, af,
                                   dual.max_queue_size, dual.max_capacity_per_size, dual.max_nodes_wo_constraint, 0)
             res = run([levels[level][r] for r in members], rebased(members, level), stricter)
+            first_try = False
         g1 = [r for r, f in zip(members, res["is_cons1"]) if f]
         g2 = [r for r, f in zip(members, res["is_cons1"]) if not f]
         if res["is_dual"] and g1 and g2:
             return solve(g1, level) + solve(g2, level)
+        if first_try and not res["is_dual"] and not res["gave_up"]:
+            kept[level] = res["cons"][0]
         if level + 1 < nl:
-            return solve(members, level + 1)
-        return [members]
+            return solve(members, level + 1, kept)
+        return [(members, kept)]
 
     keys = sorted(set(-1 if (seeds is None or seeds[r] is None) else int(seeds[r]) for r in range(n)))
     groups = []
@@ -498,10 +505,10 @@ def oracle_priority_consensus(oracle, levels, cfg, offsets=None, seeds=None, ret
         groups += solve(members, 0)
     group_of = np.zeros(n, np.int32)
     cons = []
-    for g, members in enumerate(groups):
+    for g, (members, kept) in enumerate(groups):
         for r in members:
             group_of[r] = g
-        cons.append([oracle_consensus(oracle, [levels[l][r] for r in members], rebased(members, l), single)["cons"][0] for l in range(nl)])
+        cons.append([kept[l] if l in kept else oracle_consensus(oracle, [levels[l][r] for r in members], rebased(members, l), single)["cons"][0] for l in range(nl)])
     return group_of, cons
 
 

@@ -59,7 +59,24 @@ def test_no_device_is_an_error_not_a_fallback(pkg):
         pkg.Context(0)
 
 
+def test_hardware_queue_default_is_asked_for_before_hip_starts(pkg):
+    """sp_ctx_create exports GPU_MAX_HW_QUEUES=16 when the host has not set it (before its own first HIP call; include/starphase_hip.h, sp_ctx_info) and leaves a
+    host's own value alone -- checked in child processes, without a device (the call then fails with SP_ERR_NO_DEVICE, after the variable was dealt with)"""
+    import subprocess
+    import sys
+    code = ("import os, sys, ctypes as C; sys.path.insert(0, %r); import __graft_entry__ as ge; pkg = ge.load_package(); h = C.c_void_p(); "
+            "pkg.ffi.lib().sp_ctx_create(0, None, C.byref(h)); g = C.CDLL(None).getenv; g.restype = C.c_char_p; print((g(b'GPU_MAX_HW_QUEUES') or b'None').decode())" % ROOT)
+    for given, want in ((None, "16"), ("8", "8"), ("24", "24")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if given:
+            env["GPU_MAX_HW_QUEUES"] = given
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-1000:]
+        assert out.stdout.strip().splitlines()[-1] == want
+
+
 def test_struct_layouts(pkg):
+    assert C.sizeof(pkg.ffi.sp_ctx_info) == 16 + 256
     assert C.sizeof(pkg.ffi.sp_aln) == 32
     assert C.sizeof(pkg.ffi.sp_pair) == 16
     assert pkg.ffi.ALN_DTYPE.itemsize == 32

@@ -1,0 +1,158 @@
+"""The HIP path held to the REFERENCE-CALL-PATTERN CPU port: what `diplotype_hla_batch` / `diplotype_cyp2d6` compute when every
+alignment is the minimap2 restatement's (oracle/mm2.c: seeded map with `best_n 5`, two-piece affine gaps, end clipping) instead of the library's own
+alignment contract.  The port ran on the CPU (tests/cpu_port_seeded.py, tests/cpu_port_cyp.py); its results on the BASELINE workloads are the committed
+fixture tests/golden/concordance.json.gz (tests/golden/make_concordance.py; ~15 CPU-minutes, too slow for the GPU box).  Inputs are regenerated from
+the same seeds here.
+
+  (i)   diplotypes identical: configs[1] at 10,000 reads, all six configs[2] scenarios at 2,000 reads
+  (ii)  per-stage divergence counters (K1 gene / allele, K2 winner on the port's own consensuses, K3 hit sets, K4 minimum-edit sets on the port's own
+        consensuses and segments) asserted at the values measured when the fixture was made: a kernel change that moves them fails here
+  (iii) the configs[4] samples whose library call differs from the simulated truth: the port makes the same calls"""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cyp_cases_real as cr
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "concordance.json.gz")
+NAMES = ["*1/*2", "*4/*4", "*5/*1", "*4+*68/*1", "*10+*36/*10", "*2x2/*1"]
+
+# the counters as measured on MI355X when the fixture was generated (round 4).  Floors, not targets: see DESIGN.md section 3.4 for the classes behind them.
+K1_SAME_GENE = 10000            # of 10,000 reads: every read enters the same gene's consensus
+K1_SAME_ALLELE_MIN = 8200       # the K1 winner is the seeded map's winner (82.6 % in round 3: the exhaustive argmin prefers partial alleles the seeded map never base-aligns)
+K3_READS_ALL_EQUAL_MIN = 0.93   # share of reads whose whole hit list (template, start, end) is the port's
+K3_HITS_SAME_NM_MIN = 0.95      # share of the port's hits the library finds with the same (start, end) and the same nm / unmapped
+K4_SAME_MIN_SET_MIN = 0.995     # share of segments whose set of minimum-edit consensuses is the port's (what the chains are built from, caller.rs:462-487)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with gzip.open(GOLDEN, "rt") as f:
+        return json.load(f)
+
+
+def same_allele(fx, a, b):
+    return a == b or (a >= 0 and b >= 0 and fx.cdna[a] == fx.cdna[b] and fx.dna[a] == fx.dna[b])
+
+
+@pytest.fixture(scope="module")
+def hla(pkg, gpu_ctx):
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture()
+    return fx, fx.make_db(pkg, gpu_ctx)
+
+
+def test_configs1_diplotypes_and_stage_counters(pkg, gpu_ctx, hla, gold):
+    from pb_starphase_amd import synth
+    fx, db = hla
+    g = gold["hla"]
+    wl = synth.Config2Workload(fx, n_reads=10000, seed=1000)
+    assert len(wl.reads) == len(g["winner"]) == 10000
+    R = gpu_ctx.upload(wl.reads)
+    out = db.realign_reads(R)
+    genes = list(range(len(fx.genes)))
+    calls, _is1 = db.diplotype_genes(genes, R, out)
+    # (i) the diplotypes
+    for gi, (call, c1, c2) in enumerate(calls):
+        want = g["calls"][fx.genes[gi]]
+        got = sorted([int(call.allele1), int(call.allele2)])
+        assert all(same_allele(fx, a, b) for a, b in zip(got, want)), (fx.genes[gi], got, want)
+    # (ii) K1: gene and allele of every read against the seeded map of the port
+    win = np.array(g["winner"])
+    found = win >= 0
+    gene_of = np.array(fx.gene_of)
+    same_gene = int(((out["status"] == 0) & found & (out["gene"] == gene_of[np.maximum(win, 0)])).sum())
+    same_allele_n = int(((out["status"] == 0) & found & (out["best_allele"] == win)).sum())
+    print("K1 same gene", same_gene, "same allele", same_allele_n, "of", int(found.sum()))
+    assert same_gene == K1_SAME_GENE == int(found.sum())
+    assert same_allele_n >= K1_SAME_ALLELE_MIN
+    # K2: the port's own consensuses typed on the GPU name the port's alleles
+    for gi, name in enumerate(fx.genes):
+        typed = sorted(int(db.type_consensus(gi, c, stats=False)[0]) for c in g["consensus"][name] if c)
+        want = g["calls"][name] if len(typed) == 2 else g["calls"][name][:1]
+        assert all(same_allele(fx, a, b) for a, b in zip(typed, sorted(want))), (name, typed, want)
+    # the library's consensuses are the port's, base for base (the port cuts its segments around the seeded winner's extent, the library around K1's)
+    same_cons = sum(sorted([c1, c2]) == sorted(g["consensus"][fx.genes[gi]]) for gi, (_c, c1, c2) in enumerate(calls))
+    print("consensus pairs identical to the port's:", same_cons, "of", len(calls))
+    assert same_cons == len(calls)
+
+
+@pytest.fixture(scope="module")
+def cyp(pkg, gpu_ctx):
+    from pb_starphase_amd import synth
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    db = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
+    tm = db.templates()
+    return locus, db, gpu_ctx.upload([t[3] for t in tm]), np.array([t[0] for t in tm], np.int32), {n: (h, e) for n, h, e in cr.scenarios(locus)}
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_configs2_diplotypes_and_stage_counters(gpu_ctx, cyp, gold, name):
+    locus, db, tset, ttype, sc = cyp
+    g = gold["cyp"]["scenarios"][name]
+    reads = locus.sample(np.random.default_rng(7), sc[name][0], 2000)
+    assert len(reads) == g["n_reads"]
+    R = gpu_ctx.upload(reads)
+    # (i) the call
+    call, cons, labels = db.diplotype(R)
+    assert call.status == g["status"] == 0
+    assert sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(g["hap"]) == sorted(g["expected_truth"])
+    assert sorted([call.core1.decode(), call.core2.decode()]) == sorted(g["core"])
+    # the final consensus regions are the port's, base for base and label for label
+    assert sorted(zip(cons, [list(l) for l in labels])) == sorted(zip(g["consensus"], [list(l) for l in g["labels"]]))
+    # (ii) K3: the region hits of every read
+    hits = gpu_ctx.cyp_find_regions(tset, ttype, R, 0.5)
+    mine = [[] for _ in reads]
+    for h in hits:
+        mine[int(h["read"])].append((int(h["template_idx"]), int(h["start"]), int(h["end"]), int(h["nm"]), int(h["unmapped"])))
+    reads_equal = sum([x[:3] for x in a] == [tuple(y[:3]) for y in b] for a, b in zip(mine, g["regions"]))
+    port_hits = sum(len(b) for b in g["regions"])
+    found = {(r, x[0], x[1], x[2]): x[3:] for r, a in enumerate(mine) for x in a}
+    same_nm = sum(found.get((r, y[0], y[1], y[2])) == (y[3], y[4]) for r, b in enumerate(g["regions"]) for y in b)
+    print(name, "K3 reads with the port's hit list", reads_equal, "of", len(reads), "; port hits found with the same nm / unmapped", same_nm, "of", port_hits)
+    assert reads_equal >= K3_READS_ALL_EQUAL_MIN * len(reads)
+    assert same_nm >= K3_HITS_SAME_NM_MIN * port_hits
+    # K4: the port's own segments against the port's own consensuses: the minimum-edit sets the chains are built from
+    segs = [reads[r][y[1]:y[2]] for r, b in enumerate(g["regions"]) for y in b]
+    assert len(segs) == len(g["min_ed_sets"])
+    ed, _ov, kept = gpu_ctx.cyp_weight_segments(gpu_ctx.upload(g["consensus"]), np.array(g["allowed"], np.uint8), gpu_ctx.upload(segs))
+    same_set = same_ed = 0
+    for s, (m, cols, k) in enumerate(g["min_ed_sets"]):
+        row = [int(x) for x in ed[s]]
+        mm = min(row)
+        same_set += [c for c in range(len(row)) if row[c] == mm] == cols and int(kept[s]) == k
+        same_ed += mm == m
+    print(name, "K4 segments with the port's minimum-edit set", same_set, "and the same minimum", same_ed, "of", len(segs))
+    assert same_set >= K4_SAME_MIN_SET_MIN * len(segs)
+
+
+def test_cohort_samples_whose_call_differs_from_the_truth(pkg, gpu_ctx, hla, gold):
+    """bench.py's cohort leg reports 510 / 512 HLA calls equal to the simulated truth.  The two others (samples 47 and 166) and four controls went through the
+    port: the library's call is the port's call on every one of them -- the two are what the reference's call pattern makes of those reads, not a kernel's doing"""
+    from pb_starphase_amd import synth
+    fx, db = hla
+    genes = list(range(len(fx.genes)))
+    differs_from_truth = 0
+    for s, rec in sorted(gold["cohort"]["samples"].items(), key=lambda kv: int(kv[0])):
+        rng = np.random.default_rng(10_000 + int(s))
+        reads = []
+        for gi in genes:
+            pick = sorted(rng.choice(fx.full_length_alleles(gi), 2, replace=False).tolist())
+            assert pick == rec["truth"][fx.genes[gi]]
+            for a in pick:
+                hap, st = fx.haplotype(gi, a)
+                reads += synth.simulate_reads(rng, hap, st, len(fx.dna[a]), 22, mean_len=7000, sd_len=1500, min_overlap=2500)
+        assert len(reads) == rec["n_reads"]
+        R = gpu_ctx.upload(reads)
+        out = db.realign_reads(R)
+        calls, _ = db.diplotype_genes(genes, R, out)
+        for gi, (call, _c1, _c2) in enumerate(calls):
+            got, want = sorted([int(call.allele1), int(call.allele2)]), rec["calls"][fx.genes[gi]]
+            assert all(same_allele(fx, a, b) for a, b in zip(got, want)), (s, fx.genes[gi], got, want)
+            differs_from_truth += not all(same_allele(fx, a, b) for a, b in zip(got, rec["truth"][fx.genes[gi]]))
+    assert differs_from_truth == 2

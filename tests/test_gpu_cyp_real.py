@@ -141,13 +141,14 @@ def test_hybrid_sample_on_a_second_locus(pkg, gpu_ctx):
     assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
     assert sorted(s for t, s in labels if t == 2) == ["1.001", "4.001"]
     assert 0 <= call.searches_gave_up <= 2          # (a search of a group that is one class already may still end on its bounds: the group then stays whole, which is right)
-    # the ladder is an option of the context (off by default: the reference has no such rule); where no search gives up it changes nothing
+    # the ladder is an option of the context (off by default: the reference has no such rule): the one search that still ends on its bounds is then run again with
+    # stricter fractions -- another grouping of the same reads, the same call
     gpu_ctx.set_option("cons_retry_ladder", 1)
     try:
         on, _cons2, labels_on = db.diplotype(R)
     finally:
         gpu_ctx.set_option("cons_retry_ladder", 0)
-    assert (on.hap1, on.hap2, on.score, labels_on) == (call.hap1, call.hap2, call.score, labels)
+    assert on.status == 0 and sorted([on.hap1.decode(), on.hap2.decode()]) == sorted(expected) and on.searches_gave_up <= call.searches_gave_up
 
 
 def test_deep_labels_of_a_novel_allele(oracle, gpu_ctx, real):

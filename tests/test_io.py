@@ -49,6 +49,160 @@ def test_vcf_file_equals_decoded_rows(D, key):
         assert vcf.alleles(r["CHROM"], p0 + len(r["REF"]) + 5000, p0 + len(r["REF"]) + 5001) == [a for a in got if a[0] <= p0 + len(r["REF"]) + 5000 < a[0] + len(a[1])]
 
 
+@pytest.mark.parametrize("key", sorted(DECODED))
+def test_vcf_through_the_reference_tabix_index_equals_the_scan(D, tmp_path, key):
+    """bcf::IndexedReader::fetch (src/diplotyper.rs:569-575,800): with the .tbi htslib wrote for the reference's test files beside them the library opens a file by its
+    header and reads records through the index; the same file without its index is read as a whole.  Same rows either way, region by region."""
+    import shutil
+    src = os.path.join(GOLDEN, "vcf", key)
+    assert os.path.exists(src + ".tbi")
+    alone = str(tmp_path / "alone.vcf.gz")
+    shutil.copyfile(src, alone)
+    ix, scan = D.Vcf(src), D.Vcf(alone)
+    assert ix.index_info()[0] is True and scan.index_info()[0] is False
+    assert ix.samples() == scan.samples()
+    rows = DECODED[key]["rows"]
+    for c in sorted({r["CHROM"] for r in rows}) + ["chrNone"]:
+        assert ix.alleles(c) == scan.alleles(c)
+        pos = sorted({int(r["POS"]) - 1 for r in rows if r["CHROM"] == c})
+        for p0 in pos:
+            for a, b in ((p0 - 50, p0 + 50), (p0, p0 + 1), (p0 + 1, p0 + 2), (max(0, p0 - 3), p0)):
+                a = max(0, a)
+                assert ix.alleles(c, a, b) == scan.alleles(c, a, b)
+                if "DPYD-sv-test" in key:
+                    assert ix.deletions(c, a, b) == scan.deletions(c, a, b)
+        if "DPYD-sv-test" in key:
+            assert ix.deletions(c) == scan.deletions(c)
+
+
+def tbx_reg2bin(beg, end, min_shift=14, depth=5):
+    """the smallest bin that holds [beg, end) (CSIv1 / tabix specification)"""
+    end -= 1
+    s, t = min_shift, ((1 << depth * 3) - 1) // 7
+    for l in range(depth, 0, -1):
+        if beg >> s == end >> s:
+            return t + (beg >> s)
+        s += 3
+        t -= 1 << ((l - 1) * 3)
+    return 0
+
+
+def write_indexed_vcf(path, samples, records, block_bytes, kind):
+    """records: sorted [(chrom, pos0, ref, alt, info, fmt, calls)].  A bgzip file of block_bytes blocks (lines cross block borders) and, written here from the published
+    formats by an encoder of its own, a tabix (.tbi) or CSI (.csi, min_shift 12 / depth 6) index; a record's extent is INFO/END for a symbolic ALT, else its REF"""
+    head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples) + "\n"
+    stream, spans = bytearray(head.encode()), []
+    for (c, p0, ref, alt, info, fmt, calls) in records:
+        line = f"{c}\t{p0 + 1}\t.\t{ref}\t{alt}\t.\tPASS\t{info}\t{fmt}\t" + "\t".join(calls) + "\n"
+        spans.append((len(stream), len(stream) + len(line)))
+        stream += line.encode()
+    coff, out = [], bytearray()
+    for i in range(0, len(stream), block_bytes):
+        coff.append(len(out)); out += bgzf_block(bytes(stream[i:i + block_bytes]))
+    coff.append(len(out))
+    out += bgzf_block(b"")
+    open(path, "wb").write(out)
+    voff = lambda u: (coff[u // block_bytes] << 16) | (u % block_bytes)
+    min_shift, depth = (14, 5) if kind == "tbi" else (12, 6)
+    names = []
+    for r in records:
+        if r[0] not in names:
+            names.append(r[0])
+    per_ref = {n: ({}, {}, {}) for n in names}                  # bins -> chunks, linear, loffset
+    for r, (u0, u1) in zip(records, spans):
+        c, p0, ref, alt, info = r[0], r[1], r[2], r[3], r[4]
+        end = p0 + len(ref)
+        if alt.startswith("<"):
+            for kv in info.split(";"):
+                if kv.startswith("END="):
+                    end = int(kv[4:])
+        bins, linear, loff = per_ref[c]
+        b = tbx_reg2bin(p0, end, min_shift, depth)
+        chunks = bins.setdefault(b, [])
+        if chunks and chunks[-1][1] == voff(u0):
+            chunks[-1][1] = voff(u1)
+        else:
+            chunks.append([voff(u0), voff(u1)])
+        loff[b] = min(loff.get(b, 1 << 63), voff(u0))
+        for w in range(p0 >> 14, ((end - 1) >> 14) + 1):
+            linear[w] = min(linear.get(w, 1 << 63), voff(u0))
+    nm = b"".join(n.encode() + b"\0" for n in names)
+    tbx_head = struct.pack("<6i", 2, 1, 2, 0, ord("#"), 0) + struct.pack("<i", len(nm)) + nm      # format VCF, col_seq 1, col_beg 2, col_end 0, meta '#', skip 0
+    if kind == "tbi":
+        body = bytearray(b"TBI\1" + struct.pack("<i", len(names)) + tbx_head)
+    else:
+        body = bytearray(b"CSI\1" + struct.pack("<3i", min_shift, depth, len(tbx_head)) + tbx_head + struct.pack("<i", len(names)))
+    for n in names:
+        bins, linear, loff = per_ref[n]
+        body += struct.pack("<i", len(bins))
+        for b in sorted(bins):
+            body += struct.pack("<I", b)
+            if kind == "csi":
+                body += struct.pack("<Q", loff[b])
+            body += struct.pack("<i", len(bins[b])) + b"".join(struct.pack("<QQ", x, y) for x, y in bins[b])
+        if kind == "tbi":
+            n_intv = (max(linear) + 1) if linear else 0
+            body += struct.pack("<i", n_intv)
+            last = 0
+            for w in range(n_intv):
+                last = linear.get(w, last)
+                body += struct.pack("<Q", last)
+    comp = bytearray()
+    for i in range(0, len(body), 60000):
+        comp += bgzf_block(bytes(body[i:i + 60000]))
+    comp += bgzf_block(b"")
+    open(path + "." + kind, "wb").write(comp)
+
+
+@pytest.mark.parametrize("kind", ["tbi", "csi"])
+def test_vcf_region_fetch_on_a_large_file_reads_a_few_blocks(D, tmp_path, kind):
+    """a VCF of WGS shape (60,000 records, three chromosomes, multi-allelic records, symbolic deletions with INFO/END that reach far to the right): region fetches through
+    an index written by the test's own encoder (tabix, and CSI with another bin scheme) == the scan of the same file without an index, and a fetch parses dozens of lines,
+    not the file"""
+    import shutil
+    rng = np.random.default_rng(4)
+    recs = []
+    for c, n, length in (("chr1", 30000, 50_000_000), ("chr6", 20000, 30_000_000), ("chr22", 10000, 8_000_000)):
+        for p0 in sorted(rng.choice(length, n, replace=False).tolist()):
+            u = rng.random()
+            gt = str(rng.choice(["0/1", "1/1", "0|1", "1|0", "./.", "1/2"]))
+            if u < 0.02:
+                end = p0 + int(rng.integers(50, 300000))
+                recs.append((c, p0, "N", "<DEL>", f"SVTYPE=DEL;END={end}", "GT", [gt if gt != "1/2" else "0/1"]))
+            elif u < 0.1:
+                recs.append((c, p0, "ACGT"[int(rng.integers(4))] * int(rng.integers(1, 6)), "A,T", "DP=30", "GT:PS", [gt + ":" + str(p0 - p0 % 1000)]))
+            else:
+                recs.append((c, p0, "ACGT"[int(rng.integers(4))], "ACGT"[int(rng.integers(4))], "DP=30", "GT:PS", [gt + ":" + str(p0 - p0 % 1000)]))
+    path = str(tmp_path / f"big_{kind}.vcf.gz")
+    write_indexed_vcf(path, ["S1"], recs, 20000, kind)
+    alone = str(tmp_path / "alone.vcf.gz")
+    shutil.copyfile(path, alone)
+    ix, scan = D.Vcf(path), D.Vcf(alone)
+    assert ix.index_info() == (True, 0) and scan.index_info()[0] is False
+    small = [r for r in recs if not r[3].startswith("<")]
+    for q in range(60):
+        r = recs[int(rng.integers(len(recs)))] if q % 2 else small[int(rng.integers(len(small)))]
+        a = max(0, r[1] - int(rng.integers(0, 60)))
+        b = r[1] + int(rng.integers(1, 120))
+        before = ix.index_info()[1]
+        got = ix.alleles(r[0], a, b)
+        assert got == scan.alleles(r[0], a, b) and (got or r[3].startswith("<") or "." in r[6][0])
+        assert ix.index_info()[1] - before < 1500                       # (one or two 20,000-byte blocks of ~40-byte lines, not 60,000 records)
+        try:
+            want = ("ok", scan.deletions(r[0], a, b))
+        except Exception as e:
+            want = ("error", str(e))
+        try:
+            have = ("ok", ix.deletions(r[0], a, b))
+        except Exception as e:
+            have = ("error", str(e))
+        assert have == want
+    assert ix.alleles("chr22") == scan.alleles("chr22") and ix.alleles("chrUn", 0, 1000) == []
+    dels = [(r[0], r[1]) for r in recs if r[3].startswith("<")]
+    c, p0 = dels[len(dels) // 2]
+    assert any(d[0] == p0 for d in ix.deletions(c, p0, p0 + 1))
+
+
 def test_vcf_plain_gzip_and_errors(D, pkg, tmp_path):
     key = "UGT1A1-faux/different_phaseset_001.vcf.gz"
     text = gzip.open(os.path.join(GOLDEN, "vcf", key)).read()
