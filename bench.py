@@ -320,28 +320,41 @@ class CohortShare:
     """a rank's share of BASELINE configs[4]: 256 WGS-style samples, all supported genes -- HLA-A / -B (~44 reads per gene), CYP2D6 (~100 reads),
     the 18 variant genes of the bundled database (synthetic VCF observations).  A sample's data depends on its global id only."""
 
-    def __init__(self, pkg, fx, locus, scen, panel, samples):
+    CACHE = {}                                   # sample id -> its data (a sample's data depends on its id only: the shares of every size are cut from the same samples)
+
+    @classmethod
+    def sample_data(cls, pkg, fx, locus, scen, panel, s):
         from pb_starphase_amd import synth
+        if s not in cls.CACHE:
+            rng = np.random.default_rng(10_000 + s)
+            reads, truth = [], {}
+            for g in range(len(fx.genes)):
+                pick = sorted(rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist())
+                truth[g] = pick
+                for a in pick:
+                    hap, st = fx.haplotype(g, a)
+                    reads += synth.simulate_reads(rng, hap, st, len(fx.dna[a]), 22, mean_len=7000, sd_len=1500, min_overlap=2500)
+            sc = scen[s % 3]                                                       # *1/*2, *4/*4, *5/*1
+            cr_ = locus.sample(np.random.default_rng(20_000 + s), sc[1], 100, lo=8000, hi=16000)
+            pr, keep, vtruth = panel.problems(pkg, np.random.default_rng(30_000 + s))
+            cls.CACHE[s] = dict(hla_reads=reads, hla_truth=truth, cyp_payload=pkg.ffi.encode_bam4(cr_), cyp_expected=sc[2], cyp_n=len(cr_), var=(pr, keep, vtruth))
+        return cls.CACHE[s]
+
+    def __init__(self, pkg, fx, locus, scen, panel, samples):
         self.samples, self.fx = list(samples), fx
         self.hla_reads, self.sample_of, self.hla_truth = [], [], {}
         self.cyp_payloads, self.cyp_expected, self.cyp_reads = [], [], 0
         self.var_problems, self._keep, self.var_truth = [], [], []
-        genes = range(len(fx.genes))
         for k, s in enumerate(self.samples):
-            rng = np.random.default_rng(10_000 + s)
-            for g in genes:
-                pick = sorted(rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist())
+            d = self.sample_data(pkg, fx, locus, scen, panel, s)
+            self.hla_reads += d["hla_reads"]; self.sample_of += [k] * len(d["hla_reads"])
+            for g, pick in d["hla_truth"].items():
                 self.hla_truth[(k, g)] = pick
-                for a in pick:
-                    hap, st = fx.haplotype(g, a)
-                    rs = synth.simulate_reads(rng, hap, st, len(fx.dna[a]), 22, mean_len=7000, sd_len=1500, min_overlap=2500)
-                    self.hla_reads += rs; self.sample_of += [k] * len(rs)
-            sc = scen[s % 3]                                                       # *1/*2, *4/*4, *5/*1
-            cr_ = locus.sample(np.random.default_rng(20_000 + s), sc[1], 100, lo=8000, hi=16000)
-            self.cyp_payloads.append(pkg.ffi.encode_bam4(cr_)); self.cyp_expected.append(sc[2]); self.cyp_reads += len(cr_)
-            pr, keep, truth = panel.problems(pkg, np.random.default_rng(30_000 + s))
+            self.cyp_payloads.append(d["cyp_payload"]); self.cyp_expected.append(d["cyp_expected"]); self.cyp_reads += d["cyp_n"]
+            pr, keep, truth = d["var"]
             self.var_problems += pr; self._keep.append(keep); self.var_truth += truth
         self.hla_payload = pkg.ffi.encode_bam4(self.hla_reads)
+        self.beside = None                       # (context, CypDb) the CYP2D6 half of a pass runs on, beside the HLA half (cohort_line sets it)
         self.n_reads = len(self.hla_reads) + self.cyp_reads
         self.n_genes_panel = len(panel.genes)
 
@@ -350,21 +363,43 @@ class CohortShare:
         same_count: every rank holds the same number of records in this round (the caller knows: equal shares), so the counts are not exchanged"""
         fx = self.fx
         genes = list(range(len(fx.genes)))
-        tm = self.host_s = getattr(self, "host_s", {"upload": 0.0, "hla": 0.0, "cyp2d6": 0.0, "variant_genes": 0.0, "records_and_gather": 0.0})
+        import collections
+        tm = self.host_s = collections.defaultdict(float, getattr(self, "host_s", {}))
         t0 = time.perf_counter()
-        up = ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *self.hla_payload, wait=False)
-        cyp_sets = []
-        R = up.wait()
-        for p in self.cyp_payloads:                                              # (one upload in flight per context: each waits for the one before)
-            cyp_sets.append(ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *p, wait=False))
+        # the two loci of the share side by side, each on a context of its own (a host thread, a stream and its helpers, a copy stream): the HLA call is K1's big grids and
+        # a few hundred consensus problems in lockstep, the CYP2D6 call chains of small launches -- back to back they took 0.27 + 0.45 s for 256 samples
+        cyp_ctx, cyp_db = self.beside or (ctx, cdb)
+        box = {}
+
+        def cyp_half():
+            try:
+                ts = time.perf_counter()
+                sets = []
+                for p in self.cyp_payloads:                                      # (one upload in flight per context: each waits for the one before)
+                    sets.append(cyp_ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *p, wait=False))
+                for c in sets:
+                    c.wait()
+                box["sets"] = sets
+                box["calls"] = cyp_db.diplotype_cohort(sets)
+                box["seconds"] = time.perf_counter() - ts
+            except Exception as e:                                              # surfaces in the main thread
+                box["error"] = e
+        th = threading.Thread(target=cyp_half) if self.beside else None
+        if th:
+            th.start()
+        R = ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *self.hla_payload, wait=False).wait()
         t1 = time.perf_counter(); tm["upload"] += t1 - t0
         k1 = db.realign_reads(R)
         cohort, _ = db.diplotype_cohort(len(self.samples), self.sample_of, genes, R, k1)
         t2 = time.perf_counter(); tm["hla"] += t2 - t1
-        for c in cyp_sets:
-            c.wait()
-        cyp = cdb.diplotype_cohort(cyp_sets)
-        t3 = time.perf_counter(); tm["cyp2d6"] += t3 - t2
+        if th:
+            th.join()
+        else:
+            cyp_half()
+        if "error" in box:
+            raise box["error"]
+        cyp_sets, cyp = box["sets"], box["calls"]
+        t3 = time.perf_counter(); tm["cyp2d6"] += box["seconds"]; tm["loci_side_by_side"] += t3 - t1
         var = ctx.variant_solve_batch(self.var_problems)
         t4 = time.perf_counter(); tm["variant_genes"] += t4 - t3
         n_rec = len(self.samples) * (len(genes) + 1 + self.n_genes_panel)
@@ -393,7 +428,7 @@ class CohortShare:
         return table, (ok_hla, ok_cyp, ok_var)
 
 
-def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, barrier, max_over_ranks):
+def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, barrier, max_over_ranks, cdb_source=None, ctx_device=0):
     from pb_starphase_amd import shard
     panel = VariantPanel(pkg)
     mine = shard.partition(args.cohort_samples, world, rank)
@@ -402,6 +437,12 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     per_call = max(1, min(len(mine), int(os.environ.get("SP_BENCH_PER_CALL", "256"))))
     chunks = [mine[i:i + per_call] for i in range(0, len(mine), per_call)]
     shares = [CohortShare(pkg, fx, locus, scen, panel, c) for c in chunks]
+    if os.environ.get("SP_BENCH_COHORT_SERIAL", "0") != "1":
+        cfg2, gd2 = cdb_source
+        ctx2 = pkg.Context(ctx_device)
+        cdb2 = pkg.ffi.CypDb(ctx2, cfg2, gd2, locus.sequence, locus.start)
+        for sh in shares:
+            sh.beside = (ctx2, cdb2)
     # every rank makes the same number of gathers per pass, whatever its share: shares differ by one sample when the cohort does not divide by the ranks (and a rank
     # may hold none at all), so the rounds a rank has no chunk for are gathers of zero records, and the counts are only taken as known when all shares are equal
     cap_call = int(os.environ.get("SP_BENCH_PER_CALL", "256"))
@@ -423,7 +464,7 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     for _ in range(args.warmup):
         one_pass(only_first=True)
     for sh in shares:
-        sh.host_s = {"upload": 0.0, "hla": 0.0, "cyp2d6": 0.0, "variant_genes": 0.0, "records_and_gather": 0.0}
+        sh.host_s = {}
     barrier()
     t0 = time.perf_counter()
     ok = np.zeros(3, np.int64)
@@ -433,6 +474,25 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
         ok += good; n_table += n_tab
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    # what a rank's share costs by its size (one GPU): the share a rank holds at N = 8 / 4 / 2 of a 256-sample cohort, each in one pass after a warm-up pass
+    by_share = None
+    if world == 1 and getattr(args, "cohort_shares", False) and mine:
+        by_share = {}
+        for n_sh in (32, 64, 128):
+            if n_sh >= len(mine):
+                continue
+            sh = CohortShare(pkg, fx, locus, scen, panel, mine[:n_sh])
+            sh.beside = shares[0].beside
+            sh.step(pkg, ctx, db, cdb, shard, None, 0)
+            best = None
+            for _ in range(2):
+                sh.host_s = {}
+                barrier(); t1 = time.perf_counter()
+                sh.step(pkg, ctx, db, cdb, shard, None, 0)
+                barrier(); d1 = time.perf_counter() - t1
+                if best is None or d1 < best[0]:
+                    best = (d1, dict(sh.host_s))
+            by_share[str(n_sh)] = {"seconds": best[0], "samples_per_s": n_sh / best[0], "host_seconds": {k: round(v, 4) for k, v in best[1].items()}}
     my_reads = sum(sh.n_reads for sh in shares)
     totals = np.array([my_reads, len(mine), ok[0], ok[1], ok[2]], np.int64)
     if group is not None:
@@ -440,8 +500,8 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     reads_all, samples_all = int(totals[0]), int(totals[1])
     n_genes = len(fx.genes)
     return {"value": reads_all * args.steps / dt, "unit": "reads/s", "samples_per_s": samples_all * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
-            "samples": samples_all, "reads_per_pass": reads_all,
-            "rank0_host_seconds_per_pass": {k: sum(sh.host_s[k] for sh in shares) / max(1, args.steps) for k in (shares[0].host_s if shares else {})}, "records_gathered_per_pass": n_table // max(1, args.steps),
+            "samples": samples_all, "reads_per_pass": reads_all, "by_share_size": by_share,
+            "rank0_host_seconds_per_pass": {k: sum(sh.host_s.get(k, 0.0) for sh in shares) / max(1, args.steps) for k in ("upload", "hla", "cyp2d6", "loci_side_by_side", "variant_genes", "records_and_gather")}, "records_gathered_per_pass": n_table // max(1, args.steps),
             "calls_equal_truth": {"hla": f"{int(totals[2])}/{samples_all * n_genes * args.steps}", "cyp2d6": f"{int(totals[3])}/{samples_all * args.steps}",
                                   "variant_genes_truth_among_reported": f"{int(totals[4])}/{samples_all * len(panel.genes) * args.steps}"},
             "workload": f"BASELINE configs[4]: {args.cohort_samples} synthetic WGS-style samples x (HLA-A / -B ~44 reads per gene, CYP2D6 ~100 reads, {len(panel.genes)} variant genes), "
@@ -538,7 +598,7 @@ def main():
         return dt
 
     if workload == "cohort":
-        line = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, barrier, max_over_ranks)
+        line = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, barrier, max_over_ranks, (cfg, gene_def), device_index)
         if rank == 0:
             out = {"metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)", "value": line["value"], "unit": "reads/s", "n_gpus": world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": line["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -590,6 +650,22 @@ def main():
                  "k2_cells_cdna", "k2_cells_dna", "k2_scan")
     kernel_ms = {k: ctx.profile_get(k)[0] / max(1, args.steps) for k in e2e_names}
     cyp_kernel_ms = {k: ctx_c.profile_get(k)[0] / max(1, args.steps) for k in ("cons_steps", "k5_pairs", "k9_graph")}
+
+    def critical_path(c):
+        """the consensus launch chain of a context per step: how many dependent steps the slowest problem of every batch made, and where their time went -- the step
+        kernel from its first workgroup's start to its last one's end, the single-workgroup control step, and what lies between the kernels (100 MHz device clock,
+        written by the kernels themselves: sp_consensus.hip, CSearch::step_ticks / gap_ticks / ticks)"""
+        ms = lambda name: c.profile_get(name)[2] / 1e5 / max(1, args.steps)
+        steps = c.profile_get("cons_path_steps")[2] / max(1, args.steps)
+        out = {"dependent_steps": steps, "launches_per_step": 2, "step_kernel_ms": ms("cons_path_step_ticks"), "control_kernel_ms": ms("cons_path_control_ticks"),
+               "between_kernels_ms": ms("cons_path_gap_ticks"), "chain_ms": c.profile_get("cons_steps")[0] / max(1, args.steps)}
+        if steps > 0:
+            out["per_step_us"] = {"step_kernel": 1e3 * out["step_kernel_ms"] / steps, "control_kernel": 1e3 * out["control_kernel_ms"] / steps,
+                                  "between_kernels_per_boundary": 1e3 * out["between_kernels_ms"] / (2 * steps)}
+        out["note"] = ("the chain is latency bound: every step is step kernel -> control kernel -> next step kernel on one stream; MI355X_MICROARCH.md puts a dependent "
+                       "same-stream kernel boundary at 1.45 us")
+        return out
+    crit = {"kernel": "cons_step_kernel + cons_control_kernel (K8, the consensus search)", "cyp2d6": critical_path(ctx_c), "hla": critical_path(ctx)}
     ms_cells, launches, _cells_all = ctx.profile_get("k1_cells")
     executed, resumed, active = ctx.counter("k1_cells_executed"), ctx.counter("k1_cells_resumed"), ctx.counter("k1_cells_active")
     exec_bytes = ctx.counter("k1_cells_bytes")
@@ -670,8 +746,8 @@ def main():
             legs["samples_in_flight"] = {"error": str(e)}
         legs["cyp2d6"] = cyp_leg(pkg, ctx, cdb, locus)
         legs["k5_chain_pairs"] = chain_pair_leg(pkg, ctx)
-        co_args = argparse.Namespace(**vars(args)); co_args.steps, co_args.warmup = 1, 1
-        legs["cohort"] = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, 1, 0, None, co_args, barrier, max_over_ranks)
+        co_args = argparse.Namespace(**vars(args)); co_args.steps, co_args.warmup, co_args.cohort_shares = 1, 1, True
+        legs["cohort"] = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, 1, 0, None, co_args, barrier, max_over_ranks, (cfg, gene_def), device_index)
 
     peaks = {"valu_int_wave_instr_per_s": ctx.microbench("valu_int"), "match16_valu_wave_instr_per_s": ctx.microbench("match16"),
              "hbm_copy_bytes_per_s": ctx.microbench("hbm_copy")}
@@ -719,6 +795,7 @@ def main():
         "roofline_valu": valu,
         "stale_counter_files": stale or None,
         "kernel_ms": {"hla": kernel_ms, "cyp2d6": cyp_kernel_ms}, "host_wall_ms": {"hla": host_ms, "cyp2d6": cyp_host_ms},
+        "critical_path": crit,
         "consensus_hla": cons,
         "concordance": {"hla_diplotypes_equal_truth": f"{ok}/{len(genes)} genes", "cyp2d6_call_equals_truth": bool(cyp_ok), "k1_gene_correct": k1_gene_ok,
                         "cyp2d6_call": [cyp_call.hap1.decode(), cyp_call.hap2.decode()]},

@@ -102,6 +102,8 @@ struct CSearch {
     int32_t windows, cut_windows, expansions, pad;
     long long pops, best_final;
     long long ticks[4];         // control kernel, 100 MHz wall clock: load + vote reduction / result of the step / search / tail
+    long long step_ticks, gap_ticks, last_end;   // profiling contexts: the step kernel from its first workgroup's start to its last one's end, summed over the steps; what lies
+                                                 // between the kernels of the chain (control end -> step start, step end -> control start); the wall clock at the last control end
 };
 struct ConsMeta { int32_t e, c0, flags, pad; };
 struct ConsRes { int32_t best, dual, split_at, len1, len2, pad; };   // what the host needs of the winning node
@@ -141,11 +143,12 @@ template <int MAXP> struct ConsBatchT {
     uint32_t* Q;                // [clusters][QE]      the words above summed over a cluster of workgroups, one u32 per field
     unsigned long long* dbg;    // SP_K8_TIMING builds: per launch index [4096][4] = slowest wave, slowest wave that placed no read, sum of waves, waves (ticks)
     uint32_t* prog;             // host memory the device writes: per problem { control steps made, search ended }: the host enqueues a few launches ahead of it
+    unsigned long long* step_t; // profiling contexts (else nullptr): per problem { earliest workgroup start, latest workgroup end } of the step kernel, reset by the control step
     int total;
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; const int* cluster_prob; int total;
+    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; const int* cluster_prob; int total;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first, cmp_len, pad_; };
 
@@ -563,6 +566,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
     const CWork* Wp = P.work;
     const int mode = Wp->mode;
     if (Wp->done || mode == M_NONE) return;
+    if (B.step_t && threadIdx.x == 0) atomicMin(&B.step_t[2 * pi], (unsigned long long)wall_clock64());
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int T = Wp->T, n = mode == M_WINDOW ? Wp->n : 0;
     const int node = Wp->node, in_slot = Wp->in_slot;
@@ -1011,6 +1015,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
             if (lc[x]) atomicAdd(&B.PC[blk * (CW + 1) + x], lc[x]);
             if (lr[x]) atomicAdd(&B.PR[blk * (CW + 1) + x], lr[x]);
         }
+        if (B.step_t && threadIdx.x == 0) atomicMax(&B.step_t[2 * pi + 1], (unsigned long long)wall_clock64());
         return;
     }
     for (int x = threadIdx.x; x < 2 * uw.used; x += blockDim.x) {
@@ -1020,6 +1025,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
     }
     if (uw.has_la) for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) B.PL[(size_t)blockIdx.x * 2 * CW + x] = (&ll[0][0])[x];
     for (int x = threadIdx.x; x < uw.used; x += blockDim.x) { B.PC[(size_t)blockIdx.x * (CW + 1) + x] = lc[x]; B.PR[(size_t)blockIdx.x * (CW + 1) + x] = lr[x]; }
+    if (B.step_t && threadIdx.x == 0) atomicMax(&B.step_t[2 * pi + 1], (unsigned long long)wall_clock64());
 }
 
 // sums the vote words of CLUSTER consecutive workgroups of a problem (several hundred workgroups would otherwise be summed by the one
@@ -1500,7 +1506,19 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
             }
         }
     }
-    if (tid == 0) { const long long tk4 = wall_clock64(); ss.ticks[0] += tk1 - tk0; ss.ticks[1] += tk2 - tk1; ss.ticks[2] += tk3 - tk2; ss.ticks[3] += tk4 - tk3; }
+    if (tid == 0) {
+        const long long tk4 = wall_clock64(); ss.ticks[0] += tk1 - tk0; ss.ticks[1] += tk2 - tk1; ss.ticks[2] += tk3 - tk2; ss.ticks[3] += tk4 - tk3;
+        if (B.step_t) {
+            const long long st0 = (long long)B.step_t[2 * pi], st1 = (long long)B.step_t[2 * pi + 1];
+            if (st1 > 0 && st0 <= st1) {
+                ss.step_ticks += st1 - st0;
+                if (ss.last_end > 0 && st0 >= ss.last_end) ss.gap_ticks += st0 - ss.last_end;
+                if (tk0 >= st1) ss.gap_ticks += tk0 - st1;
+            }
+            B.step_t[2 * pi] = ~0ull; B.step_t[2 * pi + 1] = 0ull;
+            ss.last_end = tk4;
+        }
+    }
 #ifdef SP_K8_SEARCH_TICKS
     // (variant: the search split into picking the node + tape consumption / the decision block / loop iterations x 100, in place of result, tail and load)
     if (tid == 0) { ss.ticks[0] += 100 * ts_iters - (tk1 - tk0); ss.ticks[1] += ts_pick - (tk2 - tk1); ss.ticks[3] += ts_block - (wall_clock64() - tk3); }
@@ -1699,6 +1717,16 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
 #endif
     uint8_t* d_is1 = d_out + out_is1;
     int32_t* d_sc = (int32_t*)(d_out + out_sc);
+    B.step_t = nullptr;
+    if (ctx->profiling) {
+        B.step_t = (unsigned long long*)sp_pool(ctx, "cons_step_t", sizeof(unsigned long long) * 2 * n_prob);
+        if (B.step_t) {
+            std::vector<unsigned long long> init((size_t)2 * n_prob);
+            for (uint32_t p = 0; p < n_prob; ++p) { init[2 * p] = ~0ull; init[2 * p + 1] = 0ull; }
+            unsigned long long* h_st = (unsigned long long*)sp_host_pool(ctx, "cons_step_t", sizeof(unsigned long long) * 2 * n_prob);
+            if (h_st) { std::memcpy(h_st, init.data(), init.size() * 8); (void)hipMemcpyAsync(B.step_t, h_st, init.size() * 8, hipMemcpyHostToDevice, st); } else B.step_t = nullptr;
+        }
+    }
     uint32_t* h_prog = (uint32_t*)sp_host_pool(ctx, "cons_prog", sizeof(uint32_t) * 2 * n_prob);
     if (!h_prog) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus progress words");
     std::memset(h_prog, 0, sizeof(uint32_t) * 2 * n_prob);
@@ -1828,6 +1856,17 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         // where the control kernel's time goes: ticks of the 100 MHz wall clock, the slowest problem of the batch (they run side by side)
         static const char* tick_names[4] = { "cons_ticks_reduce", "cons_ticks_result", "cons_ticks_search", "cons_ticks_tail" };
         for (int k = 0; k < 4; ++k) { long long m = 0; for (uint32_t p = 0; p < n_prob; ++p) m = std::max(m, h_srch[p].ticks[k]); ctx->prof[tick_names[k]].cells += (uint64_t)m; }
+        // the critical path of the batch: the problem with the largest step + control + gap total (they run side by side; its chain is the batch's)
+        if (B.step_t) {
+            long long best = -1; uint32_t bp = 0;
+            for (uint32_t p = 0; p < n_prob; ++p) {
+                const long long tot = h_srch[p].step_ticks + h_srch[p].gap_ticks + h_srch[p].ticks[0] + h_srch[p].ticks[1] + h_srch[p].ticks[2] + h_srch[p].ticks[3];
+                if (tot > best) { best = tot; bp = p; }
+            }
+            ctx->prof["cons_path_step_ticks"].cells += (uint64_t)h_srch[bp].step_ticks; ctx->prof["cons_path_gap_ticks"].cells += (uint64_t)h_srch[bp].gap_ticks;
+            ctx->prof["cons_path_control_ticks"].cells += (uint64_t)(h_srch[bp].ticks[0] + h_srch[bp].ticks[1] + h_srch[bp].ticks[2] + h_srch[bp].ticks[3]);
+            ctx->prof["cons_path_steps"].cells += (uint64_t)h_srch[bp].windows + (uint64_t)h_srch[bp].expansions;
+        }
     }
     static const char dec[4] = { 'A', 'C', 'G', 'T' };
     int32_t rc = SP_OK;

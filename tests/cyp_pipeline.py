@@ -224,7 +224,7 @@ def diplotype(oracle, db, reads, cfg=None, min_count=3, min_af=0.10, delta=100, 
         ed.append(e); ov.append(o); kept.append(k)
     ed, ov, kept = np.array(ed, np.uint64).reshape(len(segs), len(final)), np.array(ov, np.float64).reshape(len(segs), len(final)), np.array(kept, np.uint8)
     if stages is not None:
-        stages.update(ed=ed, ov=ov, kept=kept, seg_off=seg_off, group_of=group_of, n_inputs=len(raw))
+        stages.update(ed=ed, ov=ov, kept=kept, seg_off=seg_off, group_of=group_of, n_inputs=len(raw), allowed=[bool(x) for x in allowed])
     types = np.array([lab[0] for lab in labels], np.int32)
     built = of.oracle_build_chains(oracle, types, np.array(seg_off, np.uint32), ed.reshape(-1), kept)
     if built is None:

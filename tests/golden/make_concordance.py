@@ -63,7 +63,7 @@ def cyp_section(o, synth):
         res, tm = cpc.run(o, db, ccfg, reads, stages=st)
         regions = [[[int(h[k]) for k in ("template_idx", "start", "end", "nm", "unmapped")] for h in hits] for hits in st["regions"]]
         ed = np.asarray(st["ed"])
-        allowed = [lab[0] not in (cpc.of.REGION_TYPES["UNKNOWN"], cpc.of.REGION_TYPES["FalseAllele"]) for lab in res.get("labels", [])]
+        allowed = st["allowed"]                 # what weight_sequence saw (is_allowed_label before the chains mark consensuses without unique support, caller.rs:574-583)
         min_sets = []
         for s in range(len(ed)):
             row = [int(x) for x in ed[s]]
