@@ -40,6 +40,7 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
     static bool set_here = false;                     // (a later context of the process finds the variable the first one set)
     if (by_library) set_here = true;
     ctx->hw_queues = hw_queues; ctx->hw_queues_by_library = set_here;
+    { const char* kp = std::getenv("SP_K8_PERSISTENT"); if (kp && *kp) ctx->k8_persistent = std::atoi(kp) != 0; }      // (several processes on one device cannot see each other's persistent batches: they switch the mode off)
     if (hw_queues < 16) {
         ctx->warning = "GPU_MAX_HW_QUEUES=" + std::to_string(hw_queues) + ": the library's streams share " + std::to_string(hw_queues) +
                        " hardware queues; export GPU_MAX_HW_QUEUES=16 (or more) before the process initialises HIP";
@@ -70,6 +71,9 @@ void sp_ctx_destroy(sp_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->uploading) (void)upload_finish(ctx->uploading);
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
+    if (ctx->ctl_stream) { hipStreamSynchronize(ctx->ctl_stream); hipStreamDestroy(ctx->ctl_stream); ctx->ctl_stream = nullptr; }
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     for (auto& kv : ctx->pool) if (kv.second.first) hipFree(kv.second.first);
@@ -86,7 +90,7 @@ void sp_ctx_destroy(sp_ctx* ctx) {
 sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i) {
     if (i < 0 || i > 6) return nullptr;
     if (!ctx->helper[i] && sp_ctx_create(ctx->device, nullptr, &ctx->helper[i]) != SP_OK) ctx->helper[i] = nullptr;
-    if (ctx->helper[i]) { ctx->helper[i]->profiling = ctx->profiling; ctx->helper[i]->k5_block_pairs = ctx->k5_block_pairs; }
+    if (ctx->helper[i]) { ctx->helper[i]->profiling = ctx->profiling; ctx->helper[i]->k5_block_pairs = ctx->k5_block_pairs; ctx->helper[i]->k8_persistent = ctx->k8_persistent; }
     return ctx->helper[i];
 }
 void sp_profile_merge(sp_ctx* into, sp_ctx* from) {
@@ -107,6 +111,7 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx) {
 int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SP_ERR_INVALID_ARG;
     if (std::strcmp(name, "hla_split_genes") == 0) { ctx->split_genes = value != 0; return SP_OK; }
+    if (std::strcmp(name, "k8_persistent") == 0) { ctx->k8_persistent = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->k8_persistent = ctx->k8_persistent; return SP_OK; }
     if (std::strcmp(name, "cons_retry_ladder") == 0) { ctx->cons_retry_ladder = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->cons_retry_ladder = ctx->cons_retry_ladder; return SP_OK; }
     if (std::strcmp(name, "k5_block_pairs") == 0) { if (value < 0 || value > (1 << 20)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k5_block_pairs is 0..1048576"); ctx->k5_block_pairs = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k5_block_pairs = ctx->k5_block_pairs; return SP_OK; }
     if (std::strcmp(name, "cyp_cohort_streams") == 0) { if (value < 1 || value > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: cyp_cohort_streams is 1..8"); ctx->cyp_cohort_streams = (int)value; return SP_OK; }

@@ -27,6 +27,8 @@
 //     may be split off): every wave pushes its read once per child into the child's slot.
 // Results are those of the plain search; only the number of launches changes (about two per window instead of one per column).
 #include "sp_internal.h"
+#include <atomic>
+#include <cstdlib>
 #include "sp_wfa.hip.h"
 #include <algorithm>
 #include <cstddef>
@@ -144,11 +146,13 @@ template <int MAXP> struct ConsBatchT {
     unsigned long long* dbg;    // SP_K8_TIMING builds: per launch index [4096][4] = slowest wave, slowest wave that placed no read, sum of waves, waves (ticks)
     uint32_t* prog;             // host memory the device writes: per problem { control steps made, search ended }: the host enqueues a few launches ahead of it
     unsigned long long* step_t; // profiling contexts (else nullptr): per problem { earliest workgroup start, latest workgroup end } of the step kernel, reset by the control step
+    uint32_t* sync;             // persistent mode (else nullptr): per problem { steps the control workgroup has answered, arrivals of step workgroups, -, - }, then one abort word for the batch
+    uint32_t* ready;            // persistent mode: host memory, counts the control workgroups that have started (the step workgroups are launched behind them)
     int total;
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; const int* cluster_prob; int total;
+    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; const int* cluster_prob; int total;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first, cmp_len, pad_; };
 
@@ -552,7 +556,7 @@ __device__ __forceinline__ int read_cost(const Dwfa& a0, const Dwfa& a1, bool du
 // the step: window mode pushes the chosen node through n bases, expand mode makes the children of a node, init builds the root
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int MAXP>
-__global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_kernel(ConsBatchT<MAXP> B) {
+__device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
     __shared__ unsigned long long lv[2][CW + 1];          // exact votes after j pushes (column T + j) / of child j
     __shared__ uint32_t le[2][CW + 1];
     __shared__ unsigned long long ll[2][CW];              // lookahead: ll[i][x] predicts column T + n + 1 + x
@@ -1028,6 +1032,9 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_k
     if (B.step_t && threadIdx.x == 0) atomicMax(&B.step_t[2 * pi + 1], (unsigned long long)wall_clock64());
 }
 
+template <int MAXP>
+__global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_kernel(ConsBatchT<MAXP> B) { cons_step_body<MAXP>(B); }
+
 // sums the vote words of CLUSTER consecutive workgroups of a problem (several hundred workgroups would otherwise be summed by the one
 // workgroup of the control kernel, word by word from memory).  RSLICES workgroups per cluster, each a slice of the words: with 256-column
 // windows a workgroup leaves 12 KB of words behind, 7.7 MB per launch of a 5,000-read problem, and ten workgroups would be alone with them.
@@ -1095,7 +1102,7 @@ __device__ __forceinline__ int col_candidates(const uint32_t* w5, int col, int c
 // into the node table and plays the search forward until the best node needs the next launch
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int MAXP>
-__global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) {
+__device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     extern __shared__ uint8_t proc[];                     // nodes expanded per length (cap + 2 bytes, padded to 16)
     __shared__ uint32_t acc[QE];                          // the sums over all workgroups of the problem, in the order of the cluster sums:
     uint32_t (*sv)[CW + 1][5] = reinterpret_cast<uint32_t (*)[CW + 1][5]>(acc);              // exact votes: w[4], end
@@ -1539,6 +1546,74 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
     }
 }
 
+template <int MAXP>
+__global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) { cons_control_body<MAXP>(B); }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Persistent mode (batches whose problems all have <= DIRECT_BLOCKS workgroups and whose workgroups fit the device together): the same two bodies, each in a
+// loop of its own kernel, started ONCE per batch on two streams.  A step workgroup runs step k when the problem's control workgroup has answered step k - 1,
+// then reports in; the control workgroup runs control step k when all workgroups of its problem have reported step k.  Every hand-over is a device-scope
+// release / acquire pair on one word per problem -- no kernel boundary, no dispatch, and no lockstep between the problems of the batch: each search runs at
+// the pace of its own chain.  (A launch pair per step cost a CYP2D6 sample 34 of its 105 us per step between the kernels while K1's grids ran beside it:
+// bench.py critical_path.)  All workgroups have to be resident together: the host admits a batch only within a budget of CUs (run_chunk).  A wait that
+// lasts longer than PERSIST_TIMEOUT ticks of the 100 MHz clock raises the batch's abort word: every loop ends and the host reports the failure.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr long long PERSIST_TIMEOUT = 400000000ll;                 // 4 s
+__device__ __forceinline__ bool persist_wait(const uint32_t* word, uint32_t at_least, uint32_t* abort_word) {
+    const long long t0 = wall_clock64();
+    for (uint32_t spins = 1;; ++spins) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= at_least) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 63u) == 0) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            if (wall_clock64() - t0 > PERSIST_TIMEOUT) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        }
+    }
+}
+
+template <int MAXP>
+__global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_persist_kernel(ConsBatchT<MAXP> B) {
+    __shared__ int go_on;
+    const int pi = block_problem<MAXP>(B);
+    uint32_t* sy = B.sync + 4 * pi; uint32_t* abort_word = B.sync + 4 * B.n_prob;
+    for (uint32_t k = 1;; ++k) {
+        if (threadIdx.x == 0) go_on = persist_wait(sy + 0, k - 1, abort_word) ? 1 : 0;
+        __syncthreads();
+        if (!go_on) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // what the control step wrote (work order, consensus bytes, cleared vote words)
+        if (B.p[pi].work->done) break;
+        cons_step_body<MAXP>(B);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                      // this wave's states and vote words, before the workgroup reports in
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sy + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int MAXP>
+__global__ void __launch_bounds__(1024) cons_control_persist_kernel(ConsBatchT<MAXP> B) {
+    __shared__ int go_on;
+    const int pi = blockIdx.x;
+    const uint32_t nb = (uint32_t)B.p[pi].n_blocks;
+    uint32_t* sy = B.sync + 4 * pi; uint32_t* abort_word = B.sync + 4 * B.n_prob;
+    // a control workgroup takes a whole CU (16 waves at 128 registers): they are started first and say so, the step workgroups are launched once all of them
+    // have a CU (with a step workgroup on every CU and spinning, no control workgroup would ever start)
+    if (threadIdx.x == 0 && B.ready) __hip_atomic_fetch_add(B.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (uint32_t k = 1;; ++k) {
+        if (threadIdx.x == 0) go_on = persist_wait(sy + 1, nb * k, abort_word) ? 1 : 0;
+        __syncthreads();
+        if (!go_on) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        cons_control_body<MAXP>(B);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        const bool done = B.p[pi].work->done != 0;
+        if (threadIdx.x == 0) __hip_atomic_store(sy + 0, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (done) break;
+    }
+    if (threadIdx.x == 0 && B.prog && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_store(B.prog + 2 * pi + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);           // "ended" with 2: the batch was aborted
+}
+
 // gathers the per-read constants of one problem into the flattened ReadInfo array (once per batch)
 __global__ void cons_setup_kernel(ConsSetup S, ReadInfo* __restrict__ info) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1625,6 +1700,20 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
 
 } // namespace
 
+// CUs (in halves: a step workgroup takes half a CU, a control workgroup a whole one) the persistent batches of this process hold on each device
+struct PersistLease {
+    int device = -1, taken = 0;
+    static std::atomic<int>& used(int device) { static std::atomic<int> u[64]; return u[device & 63]; }
+    bool take(int dev, int budget, int want) {
+        std::atomic<int>& u = used(dev);
+        int cur = u.load();
+        while (cur + want <= budget) if (u.compare_exchange_weak(cur, cur + want)) { device = dev; taken = want; return true; }
+        return false;
+    }
+    void give_back() { if (taken) { used(device).fetch_sub(taken); taken = 0; } }
+    ~PersistLease() { give_back(); }
+};
+
 // host side of a batch of at most CMAXP problems (or any number with the descriptors in device memory): all of them advance one
 // step + control launch pair at a time until every search has ended
 template <int MAXP>
@@ -1640,6 +1729,31 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     std::vector<size_t> idx_at(n_prob), off_at(n_prob), c_at(n_prob), proc_at(n_prob);
     size_t total = 0, c_bytes = 0, proc_bytes = 0; int max_cap = 0, n_blocks = 0, n_clusters = 0;
     std::vector<int> expect(n_prob, 0);
+    // Persistent mode (see cons_step_persist_kernel): every problem small enough to do without a reduce launch, and all workgroups of the batch -- step workgroups at
+    // two per CU, a control workgroup per problem and CU -- resident together within the device's budget of CUs (32 stay free for everybody else; a process-wide
+    // count per device, taken for the length of the batch).  A batch that is too wide gives its waves up to four reads each; one that still does not fit, or finds the
+    // budget taken by other batches, runs launch by launch as before.
+    PersistLease lease;
+    int persist_rpw = 0;
+    if (ctx->k8_persistent && n_prob > 0) {
+        uint64_t blocks1 = 0; bool small = true;
+        for (uint32_t p = 0; p < n_prob; ++p) {
+            const uint32_t n = probs[p].read_idx ? probs[p].n : probs[p].reads->n;
+            const uint32_t nb = (n + CWAVES - 1) / CWAVES;
+            small = small && nb <= (uint32_t)DIRECT_BLOCKS;
+            blocks1 += nb;
+        }
+        int budget = 2 * std::max(0, ctx->num_cus - 32); const int ctl = 2 * (int)n_prob;
+        { const char* e = std::getenv("SP_K8_BUDGET"); if (e && *e) budget = std::atoi(e); }
+        if (small && ctl < budget) {
+            for (int scale = 1; scale <= 4 && !persist_rpw; ++scale) {
+                uint64_t nb = 0;
+                for (uint32_t p = 0; p < n_prob; ++p) { const uint32_t n = probs[p].read_idx ? probs[p].n : probs[p].reads->n; nb += (n + CWAVES * scale - 1) / (CWAVES * scale); }
+                if ((int64_t)nb + ctl <= budget && lease.take(ctx->device, budget, (int)nb + ctl)) persist_rpw = scale;
+                else if ((int64_t)nb + ctl <= budget) break;                       // it would fit, but the budget is taken right now
+            }
+        }
+    }
     for (uint32_t p = 0; p < n_prob; ++p) {
         const sp_cons_problem& q = probs[p];
         const uint32_t n = q.read_idx ? q.n : q.reads->n;
@@ -1649,7 +1763,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         P.first = (int)total; P.first_block = n_blocks;
         P.min_count = q.cfg.min_count; P.delta = q.cfg.dual_max_ed_delta; P.et = q.cfg.allow_early_termination != 0; P.allow_dual = q.cfg.allow_dual != 0;
         P.window = q.cfg.offset_window; P.cmp_len = q.cfg.offset_compare_length; P.min_af = q.cfg.min_af;
-        P.rpw = n > 65536 ? 4 : n > 32768 ? 2 : 1;                                    // one read per wave while that stays below 4,096 workgroups
+        P.rpw = persist_rpw ? persist_rpw : n > 65536 ? 4 : n > 32768 ? 2 : 1;       // one read per wave while that stays below 4,096 workgroups
         const uint32_t per_block = (uint32_t)(CWAVES * P.rpw);
         const uint32_t nb = (n + per_block - 1) / per_block;
         P.n_blocks = (int)nb;
@@ -1688,6 +1802,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     std::vector<size_t> out_cons(n_prob);
     for (uint32_t p = 0; p < n_prob; ++p) out_cons[p] = place(out_bytes, (size_t)2 * std::max(hp[p].cap, 1));
     const size_t zero_nodes = place(zero_bytes, sizeof(CNode) * NQ * n_prob), zero_proc = place(zero_bytes, proc_bytes), zero_info = place(zero_bytes, sizeof(ReadInfo) * total), zero_memo = place(zero_bytes, sizeof(PlaceMemo) * 2 * total);
+    const size_t zero_sync = place(zero_bytes, sizeof(uint32_t) * (4 * (size_t)n_prob + 4));
     uint8_t* d_in = (uint8_t*)sp_pool(ctx, "cons_in", in_bytes + 16); uint8_t* h_in = (uint8_t*)sp_host_pool(ctx, "cons_in", in_bytes + 16);
     uint8_t* d_out = (uint8_t*)sp_pool(ctx, "cons_out", out_bytes + 16); uint8_t* h_out = (uint8_t*)sp_host_pool(ctx, "cons_out", out_bytes + 16);
     uint8_t* d_zero = (uint8_t*)sp_pool(ctx, "cons_zero", zero_bytes + 16);
@@ -1701,6 +1816,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     uint8_t* d_proc = d_zero + zero_proc;
     ReadInfo* d_info = (ReadInfo*)(d_zero + zero_info);
     B.memo = (PlaceMemo*)(d_zero + zero_memo);
+    B.sync = persist_rpw ? (uint32_t*)(d_zero + zero_sync) : nullptr;
     B.info = d_info; B.total = (int)total;
     B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * planes * total * CB);
     B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * planes * total);
@@ -1802,6 +1918,32 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         for (uint32_t p = 0; p < n_prob; ++p) need_reduce = need_reduce || hp[p].n_blocks > DIRECT_BLOCKS;
         volatile uint32_t* prog = h_prog;
         bool finished = false;
+        if (persist_rpw) {
+            // two kernels for the whole batch: the control workgroups on the context's control stream, the step workgroups on its own stream; the control stream
+            // joins in behind the set-up work and hands back when its kernel has ended
+            if (!ctx->ctl_stream && hipStreamCreateWithFlags(&ctx->ctl_stream, hipStreamNonBlocking) != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: control stream");
+            if (!ctx->ev_fork && (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess))
+                return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: events");
+            SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cons_control_persist_kernel<MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)proc_lds));
+            SP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, st));
+            SP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->ctl_stream, ctx->ev_fork, 0));
+            uint32_t* h_ready = (uint32_t*)sp_host_pool(ctx, "cons_ready", 64);
+            if (!h_ready) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus ready word");
+            *(volatile uint32_t*)h_ready = 0;
+            { void* dp = nullptr; SP_HIP_CHECK(ctx, hipHostGetDevicePointer(&dp, h_ready, 0)); B.ready = (uint32_t*)dp; }
+            hipLaunchKernelGGL(cons_control_persist_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, ctx->ctl_stream, B);
+            {   // (a control workgroup that finds no CU within two seconds: the step workgroups are launched all the same, the batch then ends on its own time-out)
+                const auto t_wait = std::chrono::steady_clock::now();
+                while (*(volatile uint32_t*)h_ready < n_prob) {
+                    __builtin_ia32_pause();
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() > 2.0) break;
+                }
+            }
+            hipLaunchKernelGGL(cons_step_persist_kernel<MAXP>, grid, block, 0, st, B);
+            SP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->ctl_stream));
+            SP_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+            finished = true;
+        }
         while (!finished) {
             const auto tl0 = std::chrono::steady_clock::now();
             hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
@@ -1839,6 +1981,14 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     const uint8_t* h_is1 = h_out + out_is1; const int32_t* h_sc = (const int32_t*)(h_out + out_sc); const ConsRes* h_res = (const ConsRes*)(h_out + out_res);
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
     SP_HIP_CHECK(ctx, hipGetLastError());
+    lease.give_back();
+    if (persist_rpw) {
+        for (uint32_t p = 0; p < n_prob; ++p) {
+            if (h_prog[2 * p + 1] == 2u) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the persistent kernels of a batch waited for each other for more than four seconds and gave up");
+            pairs = std::max<uint64_t>(pairs, h_prog[2 * p]);
+        }
+        ctx->prof["cons_persistent_batches"].cells += 1;
+    }
     hm.mark("host:k8_result_wait");
 #ifdef SP_K8_TIMING
     if (std::getenv("SP_K8_DUMP")) {

@@ -84,6 +84,10 @@ struct sp_ctx {
     int split_streams = 3;           // sp_ctx_set_option "hla_split_streams": streams the units of a call are spread over (1..4; a 32-sample cohort call: 71.5 / 58.4 / 54.9 / 68.6 ms)
     bool cons_retry_ladder = false;  // sp_ctx_set_option "cons_retry_ladder": sp_consensus_priority's retry of searches that give up (the drivers pass it on)
     hipStream_t copy_stream = nullptr;   // uploads travel on a stream of their own, beside the kernels of ctx->stream
+    hipStream_t ctl_stream = nullptr;    // the control workgroups of a persistent consensus batch run here, beside the step workgroups on ctx->stream (made on first use)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool k8_persistent = false;          // sp_ctx_set_option "k8_persistent" (or SP_K8_PERSISTENT=1): small consensus batches run as two persistent kernels instead of a launch pair per
+                                         // step.  Off by default: the agent-scope release / acquire fences of every hand-over cost what the kernel boundaries cost (measured)
     sp_seqset* uploading = nullptr;      // the one upload a context has in flight (the staging buffers are the context's)
     int k5_block_pairs = 4096;       // sp_ctx_set_option "k5_block_pairs": up to this many chain pairs K5 runs one workgroup per pair (0: always one thread per pair)
     int cyp_cohort_streams = 6;      // sp_ctx_set_option "cyp_cohort_streams": samples of sp_cyp_diplotype_cohort in flight (1..8; WGS-sized samples are chains of tiny launches)

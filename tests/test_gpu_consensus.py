@@ -108,6 +108,48 @@ def test_low_complexity_and_divergent_inputs(oracle, pkg, gpu_ctx):
                 raise AssertionError(f"seed {seed} iteration {it}: {e}")
 
 
+def test_persistent_kernels_run_the_same_search(oracle, pkg, gpu_ctx):
+    """sp_ctx_set_option "k8_persistent": batches of small problems as two persistent kernels (step workgroups + a control workgroup per problem, handing over through
+    release / acquire words) instead of a launch pair per step -- consensus, assignment, scores and the number of nodes expanded are the oracle's, as in the default mode;
+    a batch of many problems (each at its own pace, no lockstep) and a multi-way problem included"""
+    import consensus_fuzz
+    from pb_starphase_amd import synth
+    gpu_ctx.set_option("k8_persistent", 1)
+    try:
+        gpu_ctx.profile_reset()
+        for seed in (3, 1002, 2004):
+            rng = np.random.default_rng(seed)
+            for it in range(12):
+                _L, reads, offs, kw, two_pass = consensus_fuzz.problem(rng, seed, synth)
+                exp = run_case(oracle, reads, offs, kw, two_pass)
+                got = gpu_ctx.consensus(gpu_ctx.upload(reads), gpu_cfg(pkg, **kw), offsets=offs, two_pass=two_pass)
+                try:
+                    same(got, exp)
+                except AssertionError as e:
+                    raise AssertionError(f"seed {seed} iteration {it}: {e}")
+        assert gpu_ctx.profile_get("cons_persistent_batches")[2] >= 30
+        # forty problems in one batch
+        rng = np.random.default_rng(9)
+        bases = ["".join(rng.choice(list("ACGT"), int(rng.integers(300, 900)))) for _ in range(40)]
+        reads = [synth.hifi_errors(rng, b) for b in bases for _ in range(9)]
+        S = gpu_ctx.upload(reads)
+        kw = dict(early_termination=True, dual=True)
+        outs = gpu_ctx.consensus_batch([dict(reads=S, read_idx=np.arange(9 * j, 9 * j + 9, dtype=np.uint32), cfg=gpu_cfg(pkg, **kw)) for j in range(40)])
+        for j, got in enumerate(outs):
+            same(got, run_case(oracle, reads[9 * j:9 * j + 9], None, kw, False))
+        # a multi-way problem (the CYP2D6 caller's shape)
+        base = "".join(rng.choice(list("ACGT"), 900))
+        alleles = [base] + [synth.mutate(rng, base, 5, 1, 0) for _ in range(2)]
+        raw = [synth.hifi_errors(rng, a) for a in alleles for _ in range(8)]
+        hpc = [oracle.hpc(r) for r in raw]
+        kw = dict(early_termination=True, dual=True, offset_window=100, offset_compare_length=100)
+        e_group, e_cons = of.oracle_priority_consensus(oracle, [hpc, raw], of.cons_config(**kw), None, None)
+        g_group, g_cons = gpu_ctx.consensus_priority([gpu_ctx.upload(hpc), gpu_ctx.upload(raw)], gpu_cfg(pkg, **kw), None, None)
+        assert g_group.tolist() == e_group.tolist() and g_cons == e_cons
+    finally:
+        gpu_ctx.set_option("k8_persistent", 0)
+
+
 def test_batch_equals_one_by_one(oracle, pkg, gpu_ctx):
     """independent problems advanced in lockstep (sp_consensus_batch / sp_consensus_dual_batch) give what they give alone"""
     from pb_starphase_amd import synth
