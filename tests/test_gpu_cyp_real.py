@@ -80,6 +80,25 @@ def test_library_equals_oracle_pipeline(oracle, gpu_ctx, real, name):
     assert call.deep1.decode().startswith("(") and "_" in call.deep1.decode()
 
 
+@pytest.mark.parametrize("name", ["*1/*2", "*4+*68/*1"])
+def test_library_equals_oracle_pipeline_at_the_stated_size(gpu_ctx, real, name):
+    """configs[2] at its 2,000 reads -- the size bench.py times, the branching multi-way search of `*4+*68/*1` (1,469 expansions) included -- against the oracle-assembled
+    pipeline run on the CPU when the fixture was made (tests/golden/make_fullsize.py): consensus strings, labels, chains, the f64 score, every haplotype string"""
+    import gzip, json, os
+    gold = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_oracle.json.gz"), "rt"))["cyp"]["scenarios"][name]
+    locus, db, _odb, sc = real
+    reads = locus.sample(np.random.default_rng(7), sc[name][0], 2000)
+    call, cons, labels = db.diplotype(gpu_ctx.upload(reads))
+    assert call.status == gold["status"] == 0
+    assert cons == gold["consensus"]
+    assert [[int(t), s] for t, s in labels] == gold["labels"]
+    assert list(call.chain1[:call.n1]) == gold["chain1"] and list(call.chain2[:call.n2]) == gold["chain2"]
+    assert call.score == gold["score"]
+    assert [call.hap1.decode(), call.hap2.decode()] == gold["hap"] and [call.core1.decode(), call.core2.decode()] == gold["core"]
+    assert [call.deep1.decode(), call.deep2.decode()] == gold["deep"]
+    assert sorted(gold["hap"]) == sorted(sc[name][1])
+
+
 def test_cohort_call_equals_single_calls(gpu_ctx, real):
     """sp_cyp_diplotype_cohort: the six scenarios as one GPU's share of a cohort, spread over the context's streams == one call per sample"""
     locus, db, _odb, sc = real

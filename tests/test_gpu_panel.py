@@ -126,6 +126,11 @@ def test_config1_stated_size(oracle, pkg, gpu_ctx):
         b = L.osp_hla_k1_read(re.ctypes.data_as(C.c_void_p), len(re), len(refs), ref_ptr, ref_len.ctypes.data_as(C.c_void_p), n_all, al_ptr,
                               al_len.ctypes.data_as(C.c_void_p), gene_of.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), None, C.byref(ncell))
         assert b == int(out[r]["best_allele"]), r
+    # all 1,000 of them against what that search found on the CPU when the fixture was made (tests/golden/make_fullsize.py: eight CPU-minutes)
+    import gzip, json, os
+    gold = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_oracle.json.gz"), "rt"))["k1"]
+    assert gold["reads"] == pick.tolist()
+    assert [int(out[r]["best_allele"]) for r in pick] == gold["best_allele"]
     # reads -> diplotype at the stated size equals the simulated truth
     calls, _ = db.diplotype_genes(list(range(len(fx.genes))), R, out)
     truth = {g: sorted(a for (gg, _c, _d, a) in wl.consensus if gg == g) for g in range(len(fx.genes))}
