@@ -166,6 +166,19 @@ int32_t sp_align_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                        const sp_pair* pairs, uint64_t n_pairs,
                        sp_aln* out, uint32_t* events, uint32_t events_stride);
 
+/* Two-piece affine re-score of alignments the library found: the numbers the reference reports.  Every (nm, start, end) of the reference is minimap2's
+ * (standard_hifi_aligner, src/util/mapping.rs:8-14: match a = 1 -- 5 in score_read, src/hla/caller.rs:1370-1379 --, mismatch 4, gaps min(6 + 2 l, 26 + l),
+ * ambiguous bases -1): the best local alignment through the chain's seeds.  For each pair (a = minimap2's query in set A, b = its target in set B, diag = the
+ * diagonal b_pos - a_pos the library's own cell aligned it on) the banded Smith-Waterman optimum under those scores on `band` (64 or 256) diagonals around diag,
+ * with the forward decisions and end rules of the restatement's DP (oracle/affine.c is the CPU statement): score, NM = mismatches + gap bases + ambiguous bases,
+ * and the half-open spans on both sequences; score 0 = nothing aligns.  On the audited pair classes the numbers equal the minimap2 restatement's
+ * (tests/test_oracle_affine.py).  sp_hla_realign_reads, sp_hla_score_consensus / sp_hla_type_consensus, sp_cyp_find_regions and sp_cyp_weight_segments report
+ * them beside the library's own counts (fields mm2_*). */
+typedef struct { int32_t a, b, q, e, q2, e2, sc_ambi; } sp_affine_opts;           /* map-hifi: 1, 4, 6, 2, 26, 1, 1 */
+typedef struct { int32_t score, nm, a_start, a_end, b_start, b_end; } sp_affine_aln;
+int32_t sp_affine_rescore_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const sp_pair* pairs, uint64_t n_pairs, const sp_affine_opts* opts,
+                                int32_t band, sp_affine_aln* out);
+
 /* ------------------------------------------------------------------ HLA database
  * Replaces HlaRealigner::new + create_hla_fasta (src/hla/realigner.rs:42-91,497-526) and the per-call
  * one-sequence indexes of score_read (src/hla/caller.rs:1370-1379).

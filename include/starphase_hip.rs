@@ -46,6 +46,25 @@ pub struct sp_aln {
     pub b_len: i32,
 }
 #[repr(C)]
+pub struct sp_affine_opts {
+    pub a: i32,
+    pub b: i32,
+    pub q: i32,
+    pub e: i32,
+    pub q2: i32,
+    pub e2: i32,
+    pub sc_ambi: i32,
+}
+#[repr(C)]
+pub struct sp_affine_aln {
+    pub score: i32,
+    pub nm: i32,
+    pub a_start: i32,
+    pub a_end: i32,
+    pub b_start: i32,
+    pub b_end: i32,
+}
+#[repr(C)]
 pub struct sp_hla_db_desc {
     pub n_alleles: u32,
     pub n_genes: u32,
@@ -547,6 +566,7 @@ extern "C" {
     pub fn sp_anchor_batch(ctx: *mut sp_ctx, A: *const sp_seqset, B: *const sp_seqset, a_idx: *const u32, b_idx: *const u32, n_pairs: u64, diag_out: *mut i32, votes_out: *mut i32) -> i32;
     pub fn sp_anchor_batch_topk(ctx: *mut sp_ctx, A: *const sp_seqset, B: *const sp_seqset, a_idx: *const u32, b_idx: *const u32, n_pairs: u64, topk: i32, diag_out: *mut i32, votes_out: *mut i32) -> i32;
     pub fn sp_align_batch(ctx: *mut sp_ctx, A: *const sp_seqset, B: *const sp_seqset, pairs: *const sp_pair, n_pairs: u64, out: *mut sp_aln, events: *mut u32, events_stride: u32) -> i32;
+    pub fn sp_affine_rescore_batch(ctx: *mut sp_ctx, A: *const sp_seqset, B: *const sp_seqset, pairs: *const sp_pair, n_pairs: u64, opts: *const sp_affine_opts, band: i32, out: *mut sp_affine_aln) -> i32;
     pub fn sp_hla_db_create(ctx: *mut sp_ctx, desc: *const sp_hla_db_desc, out: *mut *mut sp_hla_db) -> i32;
     pub fn sp_hla_db_free(db: *mut sp_hla_db);
     pub fn sp_hla_realign_reads(ctx: *mut sp_ctx, db: *const sp_hla_db, reads: *const sp_seqset, out: *mut sp_hla_realign, cell_out: *mut u32) -> i32;

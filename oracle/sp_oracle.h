@@ -40,6 +40,11 @@
 extern "C" {
 #endif
 
+/* ---------------- two-piece affine re-score of an alignment (oracle/affine.c) ---------------- */
+typedef struct { int32_t a, b, q, e, q2, e2, sc_ambi; } osp_affine_opts;                 /* map-hifi: 1, 4, 6, 2, 26, 1, 1 (a = 5 in score_read) */
+typedef struct { int32_t score, nm, t_start, t_end, q_start, q_end; } osp_affine_out;   /* half-open spans; score 0 = nothing aligns */
+void osp_affine_local(const uint8_t* T, int tlen, const uint8_t* Q, int qlen, int k0 /* centre diagonal, q_pos - t_pos */, int band /* 64 | 256 */, const osp_affine_opts* o, osp_affine_out* out);
+
 /* ---------------- alignment contract ---------------- */
 #define OSP_BAND      64          /* diagonals per cell: k0-32 .. k0+31                 */
 #define OSP_WIDE_BAND 256         /* diagonals of the retry of a cell that found nothing on 64 */

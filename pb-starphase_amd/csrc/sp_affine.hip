@@ -1,0 +1,207 @@
+// sp_affine.hip -- the two-piece affine re-score of an alignment the library found: the numbers the reference reports.
+//
+// Every (nm, start, end) of the reference is minimap2's (`standard_hifi_aligner`, src/util/mapping.rs:8-14: map-hifi, match 1 -- 5 in score_read,
+// src/hla/caller.rs:1370-1379 --, mismatch 4, gaps min(6 + 2 l, 26 + l), ambiguous bases -1): an alignment through the chain's seeds, global between
+// them and extended from the outermost ones to the best-scoring cell, i.e. the best LOCAL alignment through its seeds.  The library's own cell (anchor +
+// unit-cost wavefront, sp_wfa.hip.h) decides which pairs align and on which diagonal; this kernel then re-scores a pair the reference's way: the banded
+// Smith-Waterman optimum under those scores on the 64 or 256 diagonals around the cell's diagonal, with the forward decisions and end rules of
+// oracle/affine.c (the CPU statement this kernel is bit-exact against; oracle/mm2.c is the minimap2 restatement it is measured against:
+// tests/test_oracle_affine.py -- identical (nm, spans) on every audited K1 / K2 pair, 98.7 % of the K3 hits inside the 5 % filter).
+//
+// One wavefront per pair, lane l holds DPL consecutive diagonals (1: 64 diagonals, 4: 256), one target row per step.  Per cell three states come from the
+// row before (H on the same diagonal, H / E / E2 on the next one: one DPP move each) and the two insertion states run ALONG the row: F(j) = max over
+// j' < j of H(j') - q - (j - j') e is a max-plus prefix scan over the lanes -- the gfx9 DPP scan (row_shr 1, 2, 4, 8, row_bcast 15 / 31) on a packed
+// key (score + position * e, ties to the nearest opening, as the sequential recurrence decides them) with the path's counters riding along.  Every state
+// carries the mismatch + gap + ambiguous bases of its path and the cell it began in: the result needs no traceback and no memory beyond the two packed
+// sequences in LDS.
+#include "sp_internal.h"
+#include "sp_wfa.hip.h"
+
+namespace {
+
+constexpr int AF_NEG = -(1 << 28);
+constexpr uint32_t AF_BIAS = 1u << 22;
+
+struct AfState { int s; uint32_t m0, m1; };                 // score; start cell (i << 16 | j); mismatch + gap + ambiguous bases of the path
+struct AfKey { uint32_t k, m0, m1; };                       // scan element: (score + pos * e + bias) << 8 | pos, and the counters of that cell's path
+
+__device__ __forceinline__ AfState af_none() { AfState x; x.s = AF_NEG; x.m0 = 0; x.m1 = 0; return x; }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ AfKey af_dpp(const AfKey& v) {
+    AfKey r;
+    r.k = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.k, CTRL, ROW_MASK, 0xf, false);
+    r.m0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.m0, CTRL, ROW_MASK, 0xf, false);
+    r.m1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.m1, CTRL, ROW_MASK, 0xf, false);
+    return r;
+}
+__device__ __forceinline__ AfKey af_max(const AfKey& a, const AfKey& b) { return b.k > a.k ? b : a; }
+// inclusive prefix maximum over the 64 lanes (keys are unique per position, 0 = nothing)
+__device__ __forceinline__ AfKey af_scan(AfKey v) {
+    v = af_max(v, af_dpp<0x111, 0xf>(v));                   // row_shr:1
+    v = af_max(v, af_dpp<0x112, 0xf>(v));                   // row_shr:2
+    v = af_max(v, af_dpp<0x114, 0xf>(v));                   // row_shr:4
+    v = af_max(v, af_dpp<0x118, 0xf>(v));                   // row_shr:8
+    v = af_max(v, af_dpp<0x142, 0xa>(v));                   // row_bcast:15 into rows 1 and 3
+    v = af_max(v, af_dpp<0x143, 0xc>(v));                   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ AfKey af_from_lower(const AfKey& v) {          // lane l - 1's value, nothing for lane 0
+    AfKey r;
+    r.k = (uint32_t)spw::from_lower((int)v.k, 0); r.m0 = (uint32_t)spw::from_lower((int)v.m0, 0); r.m1 = (uint32_t)spw::from_lower((int)v.m1, 0);
+    return r;
+}
+__device__ __forceinline__ AfState af_from_upper(const AfState& v) {      // lane l + 1's value, nothing for lane 63
+    AfState r;
+    r.s = spw::from_upper(v.s, AF_NEG); r.m0 = (uint32_t)spw::from_upper((int)v.m0, 0); r.m1 = (uint32_t)spw::from_upper((int)v.m1, 0);
+    return r;
+}
+
+struct AfPair { uint32_t a, b; int32_t diag, pad; };        // a = query (set A), b = target (set B), diag = b_pos - a_pos (the library's convention)
+
+template <int DPL>
+__global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, const AfPair* __restrict__ pairs, uint32_t n_pairs, sp_affine_opts o,
+                                                     sp_affine_aln* __restrict__ out, int t_words_max) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t p = blockIdx.x;
+    if (p >= n_pairs) return;
+    const int lane = threadIdx.x;
+    const AfPair pr = pairs[p];
+    const int tlen = B.len[pr.b], qlen = A.len[pr.a];
+    sp_affine_aln res; res.score = 0; res.nm = 0; res.a_start = res.a_end = res.b_start = res.b_end = 0;
+    constexpr int BAND = 64 * DPL;
+    const int klo = -pr.diag - BAND / 2;                    // diagonal k = q_pos - t_pos of lane 0's first cell
+    int i_lo = -(klo + BAND - 1); if (i_lo < 0) i_lo = 0;
+    int i_hi = qlen - 1 - klo; if (i_hi > tlen - 1) i_hi = tlen - 1;
+    if (tlen <= 0 || qlen <= 0 || i_lo > i_hi) { if (lane == 0) out[p] = res; return; }
+    // the rows of the target and the query bases they can meet, packed as they are in memory (2 bits per base, + the N plane when the set has one)
+    const bool hasn = A.nplane != nullptr || B.nplane != nullptr;
+    const int tw0 = i_lo >> 4, tw1 = (i_hi >> 4) + 1;                                   // target words [tw0, tw1)
+    int q_lo = i_lo + klo; if (q_lo < 0) q_lo = 0;
+    int q_hi = i_hi + klo + BAND - 1; if (q_hi > qlen - 1) q_hi = qlen - 1;
+    const int qw0 = q_lo >> 4, qw1 = (q_hi >> 4) + 1;
+    uint32_t* LT = lds; uint32_t* LQ = LT + t_words_max; uint32_t* NT = LQ + t_words_max + 2 * BAND / 16 + 8; uint32_t* NQ = NT + t_words_max;
+    {
+        const uint32_t* tw = B.words + B.word_off[pr.b]; const uint32_t* qw = A.words + A.word_off[pr.a];
+        const uint32_t* tn = B.nplane ? B.nplane + B.word_off[pr.b] : nullptr; const uint32_t* qn = A.nplane ? A.nplane + A.word_off[pr.a] : nullptr;
+        for (int w = lane; w < tw1 - tw0; w += SP_WAVE) { LT[w] = tw[tw0 + w]; if (hasn) NT[w] = tn ? tn[tw0 + w] : 0u; }
+        for (int w = lane; w < qw1 - qw0; w += SP_WAVE) { LQ[w] = qw[qw0 + w]; if (hasn) NQ[w] = qn ? qn[qw0 + w] : 0u; }
+    }
+    spw::wave_lds_sync();
+    auto base_of = [&](const uint32_t* W, const uint32_t* N, int pos, int w0) {
+        const int w = (pos >> 4) - w0; const uint32_t sh = (uint32_t)(pos & 15) << 1;
+        if (hasn && ((N[w] >> sh) & 1u)) return 4;
+        return (int)((W[w] >> sh) & 3u);
+    };
+    AfState H[DPL], E1[DPL], E2[DPL];
+#pragma unroll
+    for (int c = 0; c < DPL; ++c) H[c] = E1[c] = E2[c] = af_none();
+    int bs = 0, bi = -1, bj = -1; uint32_t bm0 = 0, bm1 = 0;
+    const int q1 = o.q, e1 = o.e, q2 = o.q2, e2 = o.e2;
+    for (int i = i_lo; i <= i_hi; ++i) {
+        const int ct = base_of(LT, NT, i, tw0);
+        // the diagonal above lane's last cell: lane l + 1's first cell of the row before
+        const AfState upH = af_from_upper(H[0]), upE1 = af_from_upper(E1[0]), upE2 = af_from_upper(E2[0]);
+        AfState hA[DPL], e1n[DPL], e2n[DPL]; AfKey k1[DPL], k2[DPL]; bool valid[DPL];
+#pragma unroll
+        for (int c = 0; c < DPL; ++c) {
+            const int idx = lane * DPL + c, j = i + klo + idx;
+            valid[c] = (unsigned)j < (unsigned)qlen;
+            const AfState hu = c + 1 < DPL ? H[c + 1] : upH, eu = c + 1 < DPL ? E1[c + 1] : upE1, eu2 = c + 1 < DPL ? E2[c + 1] : upE2;
+            AfState a1, a2;
+            { const int eo = hu.s - q1; if (eu.s > eo) { a1 = eu; a1.s = eu.s - e1; } else { a1 = hu; a1.s = eo - e1; } a1.m1 += 1; }
+            { const int eo = hu.s - q2; if (eu2.s > eo) { a2 = eu2; a2.s = eu2.s - e2; } else { a2 = hu; a2.s = eo - e2; } a2.m1 += 1; }
+            if (a1.s < AF_NEG) a1.s = AF_NEG;
+            if (a2.s < AF_NEG) a2.s = AF_NEG;
+            AfState h = H[c];
+            const int cq = valid[c] ? base_of(LQ, NQ, j, qw0) : 4;
+            const bool ambi = ct > 3 || cq > 3;
+            const int sub = ambi ? -o.sc_ambi : (ct == cq ? o.a : -o.b);
+            if (h.s <= 0) { h.s = 0; h.m1 = 0; h.m0 = ((uint32_t)i << 16) | (uint32_t)(j & 0xFFFF); }
+            h.s += sub; h.m1 += (ambi || ct != cq) ? 1u : 0u;
+            if (a1.s > h.s) h = a1;                         // (F comes between E and E2 in the order of ties: below)
+            if (!valid[c]) { h = af_none(); a1 = af_none(); a2 = af_none(); }
+            hA[c] = h; e1n[c] = a1; e2n[c] = a2;
+            // what this cell offers to the cells to its right as the opening of a gap: the best of its non-F states (an opening behind an F is never better
+            // than that F continued), keyed so that the maximum over the cells to the left is the sequential recurrence's choice
+            AfState src = h; if (a2.s > src.s) src = a2;
+            if (src.s <= 0) { src.s = 0; }                 // (a cell nothing ends in: opening a gap from it scores below zero and never wins)
+            const bool offer = valid[c] && src.s > 0;
+            k1[c].k = offer ? (((uint32_t)(src.s + idx * e1) + AF_BIAS) << 8 | (uint32_t)idx) : 0u; k1[c].m0 = src.m0; k1[c].m1 = src.m1;
+            k2[c].k = offer ? (((uint32_t)(src.s + idx * e2) + AF_BIAS) << 8 | (uint32_t)idx) : 0u; k2[c].m0 = src.m0; k2[c].m1 = src.m1;
+        }
+        // exclusive prefix maxima over the diagonals to the left: across the lanes by DPP, inside a lane cell by cell
+        AfKey in1 = k1[0], in2 = k2[0];
+#pragma unroll
+        for (int c = 1; c < DPL; ++c) { in1 = af_max(in1, k1[c]); in2 = af_max(in2, k2[c]); }
+        in1 = af_from_lower(af_scan(in1)); in2 = af_from_lower(af_scan(in2));
+#pragma unroll
+        for (int c = 0; c < DPL; ++c) {
+            const int idx = lane * DPL + c, j = i + klo + idx;
+            AfState f1 = af_none(), f2 = af_none();
+            if (in1.k) { const int src_idx = (int)(in1.k & 0xFFu), v = (int)((in1.k >> 8) - AF_BIAS); f1.s = v - q1 - idx * e1; f1.m0 = in1.m0; f1.m1 = in1.m1 + (uint32_t)(idx - src_idx); }
+            if (in2.k) { const int src_idx = (int)(in2.k & 0xFFu), v = (int)((in2.k >> 8) - AF_BIAS); f2.s = v - q2 - idx * e2; f2.m0 = in2.m0; f2.m1 = in2.m1 + (uint32_t)(idx - src_idx); }
+            AfState h = hA[c];
+            if (valid[c]) {
+                if (f1.s > h.s) h = f1;
+                if (e2n[c].s > h.s) h = e2n[c];
+                if (f2.s > h.s) h = f2;
+                if (h.s <= 0) { h.s = 0; h.m1 = 0; h.m0 = ((uint32_t)i << 16) | (uint32_t)(j & 0xFFFF); }
+                if (h.s > bs || (h.s == bs && h.s > 0 && (i + j < bi + bj || (i + j == bi + bj && i < bi)))) { bs = h.s; bi = i; bj = j; bm0 = h.m0; bm1 = h.m1; }
+            }
+            H[c] = h; E1[c] = e1n[c]; E2[c] = e2n[c];
+            in1 = af_max(in1, k1[c]); in2 = af_max(in2, k2[c]);
+        }
+    }
+    // the best cell of the wave: highest score, then the smallest anti-diagonal, then the smallest row
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int os = __shfl_xor(bs, d), oi = __shfl_xor(bi, d), oj = __shfl_xor(bj, d);
+        const uint32_t om0 = (uint32_t)__shfl_xor((int)bm0, d), om1 = (uint32_t)__shfl_xor((int)bm1, d);
+        if (os > bs || (os == bs && os > 0 && (oi + oj < bi + bj || (oi + oj == bi + bj && oi < bi)))) { bs = os; bi = oi; bj = oj; bm0 = om0; bm1 = om1; }
+    }
+    if (lane == 0) {
+        if (bs > 0) { res.score = bs; res.nm = (int32_t)bm1; res.b_start = (int32_t)(bm0 >> 16); res.b_end = bi + 1; res.a_start = (int32_t)(bm0 & 0xFFFFu); res.a_end = bj + 1; }
+        out[p] = res;
+    }
+}
+
+} // namespace
+
+// device-side entry for the library's own callers: pairs and results in device memory
+int sp_launch_affine(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const void* d_pairs, uint64_t n_pairs, const sp_affine_opts& o, int band, sp_affine_aln* d_out,
+                     const char* prof_name) {
+    if (n_pairs == 0) return SP_OK;
+    if (band != 64 && band != 256) return sp_fail(ctx, SP_ERR_INVALID_ARG, "affine: band must be 64 or 256");
+    if (B->max_len > 65535 || A->max_len > 65535) return sp_fail(ctx, SP_ERR_TOO_LONG, "affine: sequences of up to 65,535 bases");
+    const int t_words_max = (B->max_len >> 4) + 4;
+    const size_t lds_bytes = sizeof(uint32_t) * (size_t)(4 * t_words_max + 2 * (2 * band / 16 + 8));
+    ProfScope ps(ctx, prof_name, n_pairs);
+    if (band == 64) {
+        (void)hipFuncSetAttribute((const void*)affine_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(affine_kernel<1>, dim3((uint32_t)n_pairs), dim3(64), lds_bytes, ctx->stream, A->view(), B->view(), (const AfPair*)d_pairs, (uint32_t)n_pairs, o, d_out, t_words_max);
+    } else {
+        (void)hipFuncSetAttribute((const void*)affine_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(affine_kernel<4>, dim3((uint32_t)n_pairs), dim3(64), lds_bytes, ctx->stream, A->view(), B->view(), (const AfPair*)d_pairs, (uint32_t)n_pairs, o, d_out, t_words_max);
+    }
+    if (hipGetLastError() != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "affine launch failed");
+    return SP_OK;
+}
+
+extern "C" int32_t sp_affine_rescore_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const sp_pair* pairs, uint64_t n_pairs, const sp_affine_opts* opts,
+                                           int32_t band, sp_affine_aln* out) {
+    if (!ctx || !A || !B || !opts || (n_pairs && (!pairs || !out))) return SP_ERR_INVALID_ARG;
+    if (n_pairs == 0) return SP_OK;
+    if (n_pairs > 0xFFFFFFFFull) return sp_fail(ctx, SP_ERR_INVALID_ARG, "affine: too many pairs");
+    (void)hipSetDevice(ctx->device);
+    for (uint64_t i = 0; i < n_pairs; ++i) if (pairs[i].a >= A->n || pairs[i].b >= B->n) return sp_fail(ctx, SP_ERR_INVALID_ARG, "affine: index out of range");
+    static_assert(sizeof(sp_pair) == sizeof(AfPair), "pair layout");
+    void* d_pairs = sp_pool(ctx, "affine_pairs", n_pairs * sizeof(sp_pair));
+    sp_affine_aln* d_out = (sp_affine_aln*)sp_pool(ctx, "affine_out", n_pairs * sizeof(sp_affine_aln));
+    if (!d_pairs || !d_out) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "affine buffers");
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(sp_pair), hipMemcpyHostToDevice, ctx->stream));
+    const int rc = sp_launch_affine(ctx, A, B, d_pairs, n_pairs, *opts, band, d_out, "affine_rescore");
+    if (rc != SP_OK) return rc;
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, n_pairs * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}

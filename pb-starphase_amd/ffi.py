@@ -229,6 +229,7 @@ def lib():
         "sp_device_count": (i32, [C.POINTER(i32)]),
         "sp_ctx_create": (i32, [i32, vp, C.POINTER(vp)]),
         "sp_ctx_destroy": (None, [vp]),
+        "sp_affine_rescore_batch": (i32, [vp, vp, vp, vp, u64, C.POINTER(sp_affine_opts), i32, vp]),
         "sp_ctx_get_info": (i32, [vp, C.POINTER(sp_ctx_info)]),
         "sp_last_error": (C.c_char_p, [vp]),
         "sp_ctx_synchronize": (i32, [vp]),
@@ -326,6 +327,14 @@ def _concat(seqs):
     return blob, offs
 
 
+class sp_affine_opts(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("a", "b", "q", "e", "q2", "e2", "sc_ambi")]
+
+
+PAIR_DTYPE = np.dtype([("a", np.uint32), ("b", np.uint32), ("diag", np.int32), ("max_ed", np.int32)])                 # sp_pair
+AFFINE_DTYPE = np.dtype([(k, np.int32) for k in ("score", "nm", "a_start", "a_end", "b_start", "b_end")])
+
+
 class sp_ctx_info(C.Structure):
     _fields_ = [("device", C.c_int32), ("num_cus", C.c_int32), ("hw_queues", C.c_int32), ("hw_queues_set_by_library", C.c_int32), ("warning", C.c_char * 256)]
 
@@ -340,6 +349,16 @@ class Context:
     def check(self, rc):
         if rc != SP_OK:
             raise StarphaseError(rc, lib().sp_last_error(self._h).decode())
+
+    def affine_rescore(self, A, B, pairs, a=1, band=64):
+        """sp_affine_rescore_batch: pairs = [(a index, b index, diag = b_pos - a_pos)] -> structured array (score, nm, a_start, a_end, b_start, b_end)"""
+        rows = np.zeros(len(pairs), PAIR_DTYPE)
+        for i, (x, y, d) in enumerate(pairs):
+            rows[i] = (x, y, d, 0)
+        out = np.zeros(len(pairs), AFFINE_DTYPE)
+        op = sp_affine_opts(a, 4, 6, 2, 26, 1, 1)
+        self.check(lib().sp_affine_rescore_batch(self._h, A._h, B._h, _ptr(rows), len(pairs), C.byref(op), int(band), _ptr(out)))
+        return out
 
     def info(self):
         """sp_ctx_get_info -> dict(device, num_cus, hw_queues, hw_queues_set_by_library, warning)"""

@@ -195,6 +195,25 @@ class Oracle:
 _cached = None
 
 
+class AffineOpts(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("a", "b", "q", "e", "q2", "e2", "sc_ambi")]
+
+
+class AffineOut(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("score", "nm", "t_start", "t_end", "q_start", "q_end")]
+
+
+def oracle_affine(oracle, target, query, k0, band=64, a=1):
+    """osp_affine_local (oracle/affine.c): target / query as strings or code arrays, k0 = q_pos - t_pos -> (score, nm, t_start, t_end, q_start, q_end)"""
+    t = target if isinstance(target, np.ndarray) else oracle.encode(target)
+    q = query if isinstance(query, np.ndarray) else oracle.encode(query)
+    op, out = AffineOpts(a, 4, 6, 2, 26, 1, 1), AffineOut()
+    oracle.L.osp_affine_local.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(AffineOpts), C.POINTER(AffineOut)]
+    oracle.L.osp_affine_local.restype = None
+    oracle.L.osp_affine_local(t.ctypes.data, len(t), q.ctypes.data, len(q), int(k0), int(band), C.byref(op), C.byref(out))
+    return (out.score, out.nm, out.t_start, out.t_end, out.q_start, out.q_end)
+
+
 def load(path=None):
     """the shipped oracle, or (bench.py's CPU leg) another build of the same sources"""
     global _cached
