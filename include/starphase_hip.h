@@ -229,6 +229,11 @@ typedef struct {
     sp_aln  aln;
     int32_t seg_start, seg_end;
     int32_t dna_offset, hpc_offset;
+    /* the same mapping re-scored the reference's way (two-piece affine gaps, end clipping: sp_affine_rescore_batch on the 64 diagonals around aln): what minimap2
+     * reports for this read and allele -- NM, the allele span (target_start / target_end), the read span (query_start / query_end); mm2_score 0 = not re-scored
+     * (no best allele).  The pipeline's own decisions use the counts above. */
+    int32_t mm2_score, mm2_nm;
+    int32_t mm2_t_start, mm2_t_end, mm2_q_start, mm2_q_end;
 } sp_hla_realign;
 
 int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads,

@@ -94,6 +94,12 @@ pub struct sp_hla_realign {
     pub seg_end: i32,
     pub dna_offset: i32,
     pub hpc_offset: i32,
+    pub mm2_score: i32,
+    pub mm2_nm: i32,
+    pub mm2_t_start: i32,
+    pub mm2_t_end: i32,
+    pub mm2_q_start: i32,
+    pub mm2_q_end: i32,
 }
 #[repr(C)]
 pub struct sp_hla_best {

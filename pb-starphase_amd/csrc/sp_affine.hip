@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, 
     const int klo = -pr.diag - BAND / 2;                    // diagonal k = q_pos - t_pos of lane 0's first cell
     int i_lo = -(klo + BAND - 1); if (i_lo < 0) i_lo = 0;
     int i_hi = qlen - 1 - klo; if (i_hi > tlen - 1) i_hi = tlen - 1;
-    if (tlen <= 0 || qlen <= 0 || i_lo > i_hi) { if (lane == 0) out[p] = res; return; }
+    if (pr.pad < 0 || tlen <= 0 || qlen <= 0 || i_lo > i_hi) { if (lane == 0) out[p] = res; return; }      // (a pair marked "skip" by the library's own callers: max_ed < 0)
     // the rows of the target and the query bases they can meet, packed as they are in memory (2 bits per base, + the N plane when the set has one)
     const bool hasn = A.nplane != nullptr || B.nplane != nullptr;
     const int tw0 = i_lo >> 4, tw1 = (i_hi >> 4) + 1;                                   // target words [tw0, tw1)

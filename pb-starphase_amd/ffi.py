@@ -49,7 +49,8 @@ class sp_hla_realign(C.Structure):
                 ("nm", C.c_int32), ("target_len", C.c_int32), ("unmapped", C.c_int32),
                 ("aln", sp_aln),
                 ("seg_start", C.c_int32), ("seg_end", C.c_int32),
-                ("dna_offset", C.c_int32), ("hpc_offset", C.c_int32)]
+                ("dna_offset", C.c_int32), ("hpc_offset", C.c_int32),
+                ("mm2_score", C.c_int32), ("mm2_nm", C.c_int32), ("mm2_t_start", C.c_int32), ("mm2_t_end", C.c_int32), ("mm2_q_start", C.c_int32), ("mm2_q_end", C.c_int32)]
 
 
 SP_MAX_CHAIN = 64
@@ -208,7 +209,8 @@ REALIGN_DTYPE = np.dtype([("status", np.int32), ("best_allele", np.int32), ("gen
                           ("nm", np.int32), ("target_len", np.int32), ("unmapped", np.int32),
                           ("aln", ALN_DTYPE),
                           ("seg_start", np.int32), ("seg_end", np.int32),
-                          ("dna_offset", np.int32), ("hpc_offset", np.int32)])
+                          ("dna_offset", np.int32), ("hpc_offset", np.int32),
+                          ("mm2_score", np.int32), ("mm2_nm", np.int32), ("mm2_t_start", np.int32), ("mm2_t_end", np.int32), ("mm2_q_start", np.int32), ("mm2_q_end", np.int32)])
 
 _lib = None
 

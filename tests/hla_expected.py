@@ -99,6 +99,11 @@ class K1Tables:
         g = int(fx.gene_of[best])
         res.update(status=3, best_allele=best, gene=g, nm=int(bm["nm"]), target_len=int(bm["a_len"]),
                    unmapped=int(bm["a_len"] - (bm["a_end"] - bm["a_start"])), aln=tuple(int(x) for x in bm.tolist()))
+        # the same mapping re-scored the reference's way (sp_hla_realign.mm2_*: oracle/affine.c on the 64 diagonals around the alignment)
+        import oracle_ffi
+        twice = (int(bm["a_start"]) - int(bm["b_start"])) + (int(bm["a_end"]) - int(bm["b_end"]))
+        diag = int(twice / 2)                                                  # (C's division: towards zero)
+        res["mm2"] = oracle_ffi.oracle_affine(oracle, self.fwd_e[best], re, -diag, 64, 1)
         db_s, db_e = int(bm["b_start"]), int(bm["b_end"])
         buf_s, buf_e = max(db_s - 1000, 0), min(db_e + 1000, len(read))
         seg = re[buf_s:buf_e]

@@ -24,6 +24,7 @@ NAMES = ["*1/*2", "*4/*4", "*5/*1", "*4+*68/*1", "*10+*36/*10", "*2x2/*1"]
 # the counters as measured on MI355X when the fixture was generated (round 4).  Floors, not targets: see DESIGN.md section 3.4 for the classes behind them.
 K1_SAME_GENE = 10000            # of 10,000 reads: every read enters the same gene's consensus
 K1_SAME_ALLELE_MIN = 8262       # measured 8,262: the K1 winner is the seeded map's winner (the exhaustive argmin prefers partial alleles the seeded map never base-aligns)
+K1_MM2_NUMBERS_MIN = 0.999      # share of the reads with the same winner whose reported (mm2_nm, allele span) are the port's
 K3_READS_ALL_EQUAL_MIN = 0.975  # measured 1,957 - 1,965 of 2,000 reads: the whole hit list (template, start, end) is the port's (the others: end clipping of a = 1 moves an end by a few bases)
 K3_HITS_SAME_NM_MIN = 0.970     # measured 97.4 - 97.9 % of the port's hits: found with the same (start, end) AND the same nm / unmapped
 K4_SAME_MIN_SET_MIN = 1.0       # measured 100 %: the set of minimum-edit consensuses of every segment is the port's (what the chains are built from, caller.rs:462-487)
@@ -71,6 +72,13 @@ def test_configs1_diplotypes_and_stage_counters(pkg, gpu_ctx, hla, gold):
     print("K1 same gene", same_gene, "same allele", same_allele_n, "of", int(found.sum()))
     assert same_gene == K1_SAME_GENE == int(found.sum())
     assert same_allele_n >= K1_SAME_ALLELE_MIN
+    # the integers the library reports for the winner -- its two-piece affine re-score (sp_hla_realign.mm2_*) -- against the port's mapping of the same read to
+    # the same allele: NM and the allele span (round 3: the unit-cost counts were identical on 98.06 % of such pairs)
+    both = (out["status"] == 0) & found & (out["best_allele"] == win)
+    same_numbers = int((both & (out["mm2_nm"] == np.array(g["nm"])) & ((out["mm2_t_end"] - out["mm2_t_start"]) == np.array(g["span"]))).sum())
+    unit_cost_same = int((both & (out["nm"] == np.array(g["nm"])) & ((out["aln"]["a_end"] - out["aln"]["a_start"]) == np.array(g["span"]))).sum())
+    print("K1 winners with the port's (NM, allele span): re-scored", same_numbers, "unit-cost counts", unit_cost_same, "of", int(both.sum()))
+    assert same_numbers >= K1_MM2_NUMBERS_MIN * int(both.sum())
     # K2: the port's own consensuses typed on the GPU name the port's alleles
     for gi, name in enumerate(fx.genes):
         typed = sorted(int(db.type_consensus(gi, c, stats=False)[0]) for c in g["consensus"][name] if c)

@@ -78,6 +78,11 @@ def test_k1_realign_reads(oracle, pkg, gpu_ctx, small):
             assert o["gene"] == e["gene"]
             assert (o["nm"], o["target_len"], o["unmapped"]) == (e["nm"], e["target_len"], e["unmapped"])
             assert tuple(int(x) for x in o["aln"].tolist()) == e["aln"]
+            # the winner re-scored the reference's way: (score, NM, allele span, read span) of the two-piece affine local alignment
+            assert (o["mm2_score"], o["mm2_nm"], o["mm2_t_start"], o["mm2_t_end"], o["mm2_q_start"], o["mm2_q_end"]) == e["mm2"], (r, o, e["mm2"])
+            assert e["mm2"][0] > 0 and abs(e["mm2"][1] - e["nm"]) <= 3
+        else:
+            assert o["mm2_score"] == 0
         if e["status"] == 0:
             n_real += 1
             assert (o["seg_start"], o["seg_end"], o["dna_offset"], o["hpc_offset"]) == \
