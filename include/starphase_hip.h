@@ -78,6 +78,8 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * of the other samples already fill the gaps (sp_cyp_diplotype follows the same switch: with 1 it places the regions of interest on the consensuses
  * for its weights on a helper stream while it types the consensuses).  The calls are the same either way.  "cons_retry_ladder" (default 0: the reference has no such rule): 1 makes sp_cyp_diplotype* run
  * its multi-way consensus with the retry of searches that give up (sp_cons_config.no_retry_ladder = 0, see sp_consensus_priority); sp_cyp_call.gave_up says whether a search of the call gave up.
+ * "mm2_rescore" (default 1): sp_hla_realign_reads, sp_cyp_find_regions and sp_cyp_weight_segments also report every mapping they return re-scored the reference's
+ * way (fields mm2_*; sp_affine_rescore_batch); 0 leaves those fields zero and saves the extra launch.
  * "k8_persistent" (default 0; also the environment variable SP_K8_PERSISTENT): 1 runs consensus batches whose problems have at most 1,024 reads each as two persistent
  * kernels (step workgroups and one control workgroup per problem, handing over through device-scope release / acquire words) instead of a launch pair per step --
  * the same search, bit for bit; one process per device only (the workgroups of a batch have to be resident together, and the budget of CUs is counted per process).
@@ -344,6 +346,11 @@ typedef struct {
     int32_t start, end;                 /* region on the read */
     int32_t seq_len, nm, unmapped;      /* MappingStats of the template */
     int32_t clip_start, clip_end;
+    /* the hit re-scored the reference's way (two-piece affine gaps, end clipping; 256 diagonals: sp_affine_rescore_batch): minimap2's NM, region on the read and
+     * template span for this mapping; mm2_score 0 = not re-scored (context option "mm2_rescore" 0).  The filters above use the library's own counts. */
+    int32_t mm2_score, mm2_nm;
+    int32_t mm2_start, mm2_end;         /* region on the read */
+    int32_t mm2_q_start, mm2_q_end;     /* span on the template: unmapped = seq_len - (mm2_q_end - mm2_q_start), clips = mm2_q_start, seq_len - mm2_q_end */
 } sp_region_hit;
 
 int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,

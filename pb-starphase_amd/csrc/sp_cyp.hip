@@ -716,8 +716,16 @@ static void cyp_weights_from_alns(uint32_t C, const int32_t* cons_len, const uin
     }
 }
 
+static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
+                                double max_missing_frac, sp_region_hit* hits, uint64_t hits_cap, uint64_t* n_hits, bool rescore);
 extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
                                        double max_missing_frac, sp_region_hit* hits, uint64_t hits_cap, uint64_t* n_hits) {
+    if (!ctx) return SP_ERR_INVALID_ARG;
+    return cyp_find_regions(ctx, templates, template_type, reads, max_missing_frac, hits, hits_cap, n_hits, ctx->mm2_rescore);
+}
+// (the callers inside the library -- the CYP2D6 drivers -- never look at the re-scored numbers and skip the launch)
+static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
+                                double max_missing_frac, sp_region_hit* hits, uint64_t hits_cap, uint64_t* n_hits, bool rescore) {
     if (!ctx || !templates || !reads || !n_hits || (templates->n && !template_type) || (hits_cap && !hits)) return SP_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     *n_hits = 0;
@@ -734,7 +742,7 @@ extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, 
             const sp_aln& al = alns[((size_t)r * T + t) * CYP_TOPK + k];
             if (!al.ok) continue;
             const int tlen = templates->h_len[t];
-            sp_region_hit h{(int32_t)r, (int32_t)t, al.b_start, al.b_end, tlen, al.nm, tlen - (al.a_end - al.a_start), al.a_start, tlen - al.a_end};
+            sp_region_hit h{(int32_t)r, (int32_t)t, al.b_start, al.b_end, tlen, al.nm, tlen - (al.a_end - al.a_start), al.a_start, tlen - al.a_end, 0, 0, 0, 0, 0, 0};
             if (cyp_score(h.seq_len, h.nm, h.unmapped, penalized_type(template_type[t])) > 0.05) continue;   // max_ed_frac, :228-232
             un.push_back(h);
         }
@@ -757,6 +765,23 @@ extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, 
             if (cyp_score(h.seq_len, h.nm, h.unmapped, true) > max_missing_frac) continue;                     // :303-306
             if (*n_hits < hits_cap) hits[*n_hits] = h;
             ++*n_hits;
+        }
+    }
+    // the hits that are handed out, re-scored the reference's way: template (query) against read (target) on the 256 diagonals around the hit's own
+    const uint64_t n_out = std::min<uint64_t>(*n_hits, hits_cap);
+    if (rescore && n_out) {
+        std::vector<sp_pair> pairs(n_out); std::vector<sp_affine_aln> af(n_out);
+        for (uint64_t x = 0; x < n_out; ++x) {
+            const sp_region_hit& h = hits[x];
+            const int d0 = h.start - h.clip_start, d1 = h.end - (h.seq_len - h.clip_end);
+            pairs[x] = sp_pair{ (uint32_t)h.template_idx, (uint32_t)h.read, (d0 + d1) / 2, 0 };
+        }
+        const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
+        rc = sp_affine_rescore_batch(ctx, templates, reads, pairs.data(), n_out, &ao, 256, af.data());
+        if (rc != SP_OK) return rc;
+        for (uint64_t x = 0; x < n_out; ++x) {
+            sp_region_hit& h = hits[x];
+            h.mm2_score = af[x].score; h.mm2_nm = af[x].nm; h.mm2_start = af[x].b_start; h.mm2_end = af[x].b_end; h.mm2_q_start = af[x].a_start; h.mm2_q_end = af[x].a_end;
         }
     }
     return SP_OK;
@@ -1224,8 +1249,8 @@ static int32_t type_fresh(sp_ctx* ctx, const sp_cyp_problem* pr, const std::vect
         int32_t rc = sp_seqset_make_small(ctx, "cyp_typed", blob.data(), off.data(), (uint32_t)fresh.size(), true, set);
         if (rc != SP_OK) return rc;
         std::vector<sp_region_hit> hits(fresh.size() * 16 + 16); uint64_t nh = 0;
-        rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh);
-        if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh); }
+        rc = cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh, false);
+        if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh, false); }
         std::vector<uint8_t> states((size_t)fresh.size() * pr->n_variants, 3);
         if (rc == SP_OK) rc = sp_cyp_variant_states(ctx, set, pr->backbone, pr->backbone_len, pr->n_variants, pr->var_pos, pr->var_ref, pr->var_alt, states.data(), nullptr);
         std::vector<uint32_t> bvi(fresh.size()), ball(fresh.size()); std::vector<uint8_t> tie((size_t)fresh.size() * std::max<uint32_t>(pr->n_alleles, 1));
@@ -1320,8 +1345,8 @@ int32_t cyp_part_a(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
     if (found_hits) hits = *found_hits;                                   // (a cohort's group of samples searched its regions in one call: cyp_group_regions)
     else {
         hits.assign((size_t)R * 8 + 16, sp_region_hit{}); uint64_t nh = 0;
-        rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh);
-        if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh); }
+        rc = cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh, false);
+        if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = cyp_find_regions(ctx, pr->templates, pr->template_type, reads, 0.5, hits.data(), hits.size(), &nh, false); }
         if (rc != SP_OK) return rc;
         hits.resize(nh);
     }
@@ -1409,8 +1434,8 @@ bool cyp_group_view(sp_ctx* ctx, const sp_seqset* const* reads, uint32_t n, cons
 bool cyp_group_regions(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset& all, const std::vector<uint32_t>& first, uint32_t n, std::vector<std::vector<sp_region_hit>>& per_sample, int32_t& rc) {
     HostScope hs(ctx, "host:cyp_regions");
     std::vector<sp_region_hit> hits((size_t)all.n * 8 + 16); uint64_t nh = 0;
-    rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, &all, 0.5, hits.data(), hits.size(), &nh);
-    if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = sp_cyp_find_regions(ctx, pr->templates, pr->template_type, &all, 0.5, hits.data(), hits.size(), &nh); }
+    rc = cyp_find_regions(ctx, pr->templates, pr->template_type, &all, 0.5, hits.data(), hits.size(), &nh, false);
+    if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = cyp_find_regions(ctx, pr->templates, pr->template_type, &all, 0.5, hits.data(), hits.size(), &nh, false); }
     if (rc != SP_OK) return true;
     per_sample.assign(n, std::vector<sp_region_hit>());
     uint32_t i = 0;

@@ -1091,7 +1091,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_finalize launch failed");
     }
     // 3b. the winners re-scored the reference's way (two-piece affine gaps, end clipping): the numbers minimap2 reports for the read and its allele
-    if (rc == SP_OK) {
+    if (rc == SP_OK && ctx->mm2_rescore) {
         sp_pair* d_pairs = (sp_pair*)sp_pool(ctx, "k1_af_pairs", (size_t)R * sizeof(sp_pair));
         sp_affine_aln* d_af = (sp_affine_aln*)sp_pool(ctx, "k1_af_out", (size_t)R * sizeof(sp_affine_aln));
         uint32_t* d_live = (uint32_t*)sp_pool(ctx, "k1_af_live", 64);

@@ -86,6 +86,7 @@ struct sp_ctx {
     hipStream_t copy_stream = nullptr;   // uploads travel on a stream of their own, beside the kernels of ctx->stream
     hipStream_t ctl_stream = nullptr;    // the control workgroups of a persistent consensus batch run here, beside the step workgroups on ctx->stream (made on first use)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool mm2_rescore = true;             // sp_ctx_set_option "mm2_rescore": the entry points that return mappings also report them re-scored with the reference's affine scores (mm2_* fields)
     bool k8_persistent = false;          // sp_ctx_set_option "k8_persistent" (or SP_K8_PERSISTENT=1): small consensus batches run as two persistent kernels instead of a launch pair per
                                          // step.  Off by default: the agent-scope release / acquire fences of every hand-over cost what the kernel boundaries cost (measured)
     sp_seqset* uploading = nullptr;      // the one upload a context has in flight (the staging buffers are the context's)

@@ -76,7 +76,8 @@ class sp_chain_result(C.Structure):
                 ("edit_distance", C.c_uint64), ("n_pairs_scored", C.c_uint64)]
 
 
-REGION_HIT_DTYPE = np.dtype([(n, np.int32) for n in ("read", "template_idx", "start", "end", "seq_len", "nm", "unmapped", "clip_start", "clip_end")])
+REGION_HIT_DTYPE = np.dtype([(n, np.int32) for n in ("read", "template_idx", "start", "end", "seq_len", "nm", "unmapped", "clip_start", "clip_end",
+                                                     "mm2_score", "mm2_nm", "mm2_start", "mm2_end", "mm2_q_start", "mm2_q_end")])
 
 
 SP_VAR_MAXDIP = 4096

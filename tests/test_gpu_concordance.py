@@ -27,6 +27,7 @@ K1_SAME_ALLELE_MIN = 8262       # measured 8,262: the K1 winner is the seeded ma
 K1_MM2_NUMBERS_MIN = 0.999      # share of the reads with the same winner whose reported (mm2_nm, allele span) are the port's
 K3_READS_ALL_EQUAL_MIN = 0.975  # measured 1,957 - 1,965 of 2,000 reads: the whole hit list (template, start, end) is the port's (the others: end clipping of a = 1 moves an end by a few bases)
 K3_HITS_SAME_NM_MIN = 0.970     # measured 97.4 - 97.9 % of the port's hits: found with the same (start, end) AND the same nm / unmapped
+K3_MM2_SAME_MIN = 0.999         # share of the port's hits the library reports with identical (start, end, NM, unmapped) in its re-scored fields
 K4_SAME_MIN_SET_MIN = 1.0       # measured 100 %: the set of minimum-edit consensuses of every segment is the port's (what the chains are built from, caller.rs:462-487)
 K4_SAME_MINIMUM_MIN = 0.99      # measured 99.4 - 99.5 %: the minimum itself (two-piece affine gaps vs unit costs on adjacent edits move it by one)
 
@@ -126,6 +127,12 @@ def test_configs2_diplotypes_and_stage_counters(gpu_ctx, cyp, gold, name):
     print(name, "K3 reads with the port's hit list", reads_equal, "of", len(reads), "; port hits found with the same nm / unmapped", same_nm, "of", port_hits)
     assert reads_equal >= K3_READS_ALL_EQUAL_MIN * len(reads)
     assert same_nm >= K3_HITS_SAME_NM_MIN * port_hits
+    # the numbers the library REPORTS for its hits -- re-scored the reference's way (sp_region_hit.mm2_*) -- against the port's hits of the same read and template
+    rescored = {(int(h["read"]), int(h["template_idx"]), int(h["mm2_start"]), int(h["mm2_end"])): (int(h["mm2_nm"]), int(h["seq_len"]) - (int(h["mm2_q_end"]) - int(h["mm2_q_start"])))
+                for h in hits}
+    same_mm2 = sum(rescored.get((r, y[0], y[1], y[2])) == (y[3], y[4]) for r, b in enumerate(g["regions"]) for y in b)
+    print(name, "K3 port hits the library reports with the port's (start, end, NM, unmapped) after the re-score", same_mm2, "of", port_hits)
+    assert same_mm2 >= K3_MM2_SAME_MIN * port_hits
     # K4: the port's own segments against the port's own consensuses: the minimum-edit sets the chains are built from
     segs = [reads[r][y[1]:y[2]] for r, b in enumerate(g["regions"]) for y in b]
     assert len(segs) == len(g["min_ed_sets"])
