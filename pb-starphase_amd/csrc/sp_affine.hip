@@ -16,6 +16,9 @@
 // sequences in LDS.
 #include "sp_internal.h"
 #include "sp_wfa.hip.h"
+#include <mutex>
+#include <set>
+#include <string>
 
 namespace {
 
@@ -58,12 +61,12 @@ __device__ __forceinline__ AfState af_from_upper(const AfState& v) {      // lan
 
 struct AfPair { uint32_t a, b; int32_t diag, pad; };        // a = query (set A), b = target (set B), diag = b_pos - a_pos (the library's convention)
 
-template <int DPL>
-__global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, const AfPair* __restrict__ pairs, uint32_t n_pairs, sp_affine_opts o,
+template <int DPL, bool HASN>
+__global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, const AfPair* __restrict__ pairs, uint32_t n_pairs, const uint32_t* __restrict__ n_live, sp_affine_opts o,
                                                      sp_affine_aln* __restrict__ out, int t_words_max) {
     extern __shared__ uint32_t lds[];
     const uint32_t p = blockIdx.x;
-    if (p >= n_pairs) return;
+    if (p >= n_pairs || (n_live && p >= *n_live)) return;              // (n_live: the number of pairs a kernel before this one left in the list)
     const int lane = threadIdx.x;
     const AfPair pr = pairs[p];
     const int tlen = B.len[pr.b], qlen = A.len[pr.a];
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, 
     int i_hi = qlen - 1 - klo; if (i_hi > tlen - 1) i_hi = tlen - 1;
     if (pr.pad < 0 || tlen <= 0 || qlen <= 0 || i_lo > i_hi) { if (lane == 0) out[p] = res; return; }      // (a pair marked "skip" by the library's own callers: max_ed < 0)
     // the rows of the target and the query bases they can meet, packed as they are in memory (2 bits per base, + the N plane when the set has one)
-    const bool hasn = A.nplane != nullptr || B.nplane != nullptr;
+    constexpr bool hasn = HASN;
     const int tw0 = i_lo >> 4, tw1 = (i_hi >> 4) + 1;                                   // target words [tw0, tw1)
     int q_lo = i_lo + klo; if (q_lo < 0) q_lo = 0;
     int q_hi = i_hi + klo + BAND - 1; if (q_hi > qlen - 1) q_hi = qlen - 1;
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, 
                 if (e2n[c].s > h.s) h = e2n[c];
                 if (f2.s > h.s) h = f2;
                 if (h.s <= 0) { h.s = 0; h.m1 = 0; h.m0 = ((uint32_t)i << 16) | (uint32_t)(j & 0xFFFF); }
-                if (h.s > bs || (h.s == bs && h.s > 0 && (i + j < bi + bj || (i + j == bi + bj && i < bi)))) { bs = h.s; bi = i; bj = j; bm0 = h.m0; bm1 = h.m1; }
+                const bool better = h.s > bs || (h.s == bs && h.s > 0 && (i + j < bi + bj || (i + j == bi + bj && i < bi)));
+                bs = better ? h.s : bs; bi = better ? i : bi; bj = better ? j : bj; bm0 = better ? h.m0 : bm0; bm1 = better ? h.m1 : bm1;
             }
             H[c] = h; E1[c] = e1n[c]; E2[c] = e2n[c];
             in1 = af_max(in1, k1[c]); in2 = af_max(in2, k2[c]);
@@ -169,21 +173,108 @@ __global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, 
 
 // device-side entry for the library's own callers: pairs and results in device memory
 int sp_launch_affine(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const void* d_pairs, uint64_t n_pairs, const sp_affine_opts& o, int band, sp_affine_aln* d_out,
-                     const char* prof_name) {
+                     const char* prof_name, const uint32_t* d_n_live) {
     if (n_pairs == 0) return SP_OK;
     if (band != 64 && band != 256) return sp_fail(ctx, SP_ERR_INVALID_ARG, "affine: band must be 64 or 256");
     if (B->max_len > 65535 || A->max_len > 65535) return sp_fail(ctx, SP_ERR_TOO_LONG, "affine: sequences of up to 65,535 bases");
     const int t_words_max = (B->max_len >> 4) + 4;
     const size_t lds_bytes = sizeof(uint32_t) * (size_t)(4 * t_words_max + 2 * (2 * band / 16 + 8));
     ProfScope ps(ctx, prof_name, n_pairs);
-    if (band == 64) {
-        (void)hipFuncSetAttribute((const void*)affine_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(affine_kernel<1>, dim3((uint32_t)n_pairs), dim3(64), lds_bytes, ctx->stream, A->view(), B->view(), (const AfPair*)d_pairs, (uint32_t)n_pairs, o, d_out, t_words_max);
-    } else {
-        (void)hipFuncSetAttribute((const void*)affine_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(affine_kernel<4>, dim3((uint32_t)n_pairs), dim3(64), lds_bytes, ctx->stream, A->view(), B->view(), (const AfPair*)d_pairs, (uint32_t)n_pairs, o, d_out, t_words_max);
-    }
+    const bool hasn = A->has_n || B->has_n;
+#define SP_AF_LAUNCH(D, N) do { \
+        (void)hipFuncSetAttribute((const void*)affine_kernel<D, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        hipLaunchKernelGGL((affine_kernel<D, N>), dim3((uint32_t)n_pairs), dim3(64), lds_bytes, ctx->stream, A->view(), B->view(), (const AfPair*)d_pairs, (uint32_t)n_pairs, d_n_live, o, d_out, t_words_max); } while (0)
+    if (band == 64) { if (hasn) SP_AF_LAUNCH(1, true); else SP_AF_LAUNCH(1, false); }
+    else { if (hasn) SP_AF_LAUNCH(4, true); else SP_AF_LAUNCH(4, false); }
+#undef SP_AF_LAUNCH
     if (hipGetLastError() != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, "affine launch failed");
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Re-score of mappings the library already has, cheaply: most of them need no DP.  A mapping whose edits all stand alone -- at least AF_ISOLATED bases from one
+// another and from both ends of the alignment on the window sequence, no ambiguous base in either sequence -- has the same optimum under the two-piece affine scores
+// as under unit costs (a lone mismatch or one-base gap is spelled the same way by both, and an edit that far from an end is not clipped: -4 or -8 against at
+// least +16): its numbers are the unit-cost numbers, its score a * matches - b * mismatches - (q + e) * gap bases.  (Measured on 1,242 K1 pairs: every mapping
+// with all distances >= 12 had identical numbers; 16 is used.)  The others -- a third of the K1 winners -- go through the DP above.
+// The cells are run again with their traceback (sp_cells_kernel<TRACE>) for the positions of the edits; a cell whose second run differs from the alignment the
+// caller holds takes the DP as well.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int AF_ISOLATED = 16;
+
+// d_ref: the alignment the caller holds for each pair (WFA orientation: a_* on Aw, b_* on Bw); cells[x].max_ed < 0: no mapping (score 0)
+__global__ void af_classify_kernel(const CellDesc* __restrict__ cells, const sp_aln* __restrict__ ref, const sp_aln* __restrict__ tr, const uint32_t* __restrict__ ev,
+                                   uint32_t stride, uint32_t n, int target_is_a, int has_n, sp_affine_opts o, sp_affine_aln* __restrict__ out,
+                                   AfPair* __restrict__ todo, uint32_t* __restrict__ todo_at, uint32_t* __restrict__ n_todo) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    sp_affine_aln res; res.score = 0; res.nm = 0; res.a_start = res.a_end = res.b_start = res.b_end = 0;
+    const CellDesc c = cells[x];
+    if (c.max_ed < 0) { out[x] = res; return; }
+    const sp_aln r = ref[x], t = tr[x];
+    bool simple = !has_n && r.ok && t.ok && t.nm == r.nm && t.a_start == r.a_start && t.a_end == r.a_end && t.b_start == r.b_start && t.b_end == r.b_end && (uint32_t)r.nm <= stride;
+    int nx = 0, ngap = 0;
+    if (simple) {
+        const uint32_t* e = ev + (size_t)x * stride;
+        int prev = -(1 << 29);
+        for (int k = 0; k < r.nm && simple; ++k) {
+            const uint32_t w = e[k]; const int pos = (int)(w & 0x3FFFFFFFu), type = (int)(w >> 30);
+            const int gap = pos > prev ? pos - prev : prev - pos;
+            if (k > 0 && gap < AF_ISOLATED) simple = false;
+            if (pos - r.b_start < AF_ISOLATED || r.b_end - pos < AF_ISOLATED) simple = false;
+            if (type == (int)SP_EV_X) ++nx; else ++ngap;
+            prev = pos;
+        }
+    }
+    if (simple) {
+        // columns: M matches, X mismatches, gap bases on either side; a_span = M + X + (A-only bases), b_span = M + X + (B-only bases), gap bases = ngap
+        const int a_span = r.a_end - r.a_start, b_span = r.b_end - r.b_start;
+        const int m2 = a_span + b_span - 2 * nx - ngap;                          // = 2 M
+        const int M = m2 / 2;
+        res.score = o.a * M - o.b * nx - (o.q + o.e) * ngap; res.nm = r.nm;
+        if (target_is_a) { res.b_start = r.a_start; res.b_end = r.a_end; res.a_start = r.b_start; res.a_end = r.b_end; }
+        else { res.a_start = r.a_start; res.a_end = r.a_end; res.b_start = r.b_start; res.b_end = r.b_end; }
+        out[x] = res;
+        return;
+    }
+    // the DP: query / target in the affine kernel's order, on the diagonal the alignment lies on
+    const uint32_t at = atomicAdd(n_todo, 1u);
+    const int d_mid = ((r.b_start - r.a_start) + (r.b_end - r.a_end)) / 2;         // b_pos - a_pos (WFA orientation)
+    AfPair p;
+    if (target_is_a) { p.a = c.b; p.b = c.a; p.diag = -d_mid; } else { p.a = c.a; p.b = c.b; p.diag = d_mid; }
+    p.pad = 0;
+    if (!r.ok) p.diag = target_is_a ? -c.diag : c.diag;
+    todo[at] = p; todo_at[at] = x;
+}
+__global__ void af_scatter_kernel(const sp_affine_aln* __restrict__ part, const uint32_t* __restrict__ todo_at, const uint32_t* __restrict__ n_todo, sp_affine_aln* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < *n_todo) out[todo_at[k]] = part[k];
+}
+
+// the mappings of cells (WFA orientation: Aw streamed, Bw window; d_ref = the alignments the caller holds) re-scored into d_out (a_* on minimap2's query, b_* on its target:
+// target_is_a tells which of the two sets is the target); everything stays on the device
+int sp_rescore_mappings(sp_ctx* ctx, const sp_seqset* Aw, const sp_seqset* Bw, const CellDesc* d_cells, const sp_aln* d_ref, uint64_t n, bool target_is_a,
+                        const sp_affine_opts& o, int band, sp_affine_aln* d_out, const char* prefix, uint32_t stride) {
+    if (n == 0) return SP_OK;
+    const std::string pre(prefix);
+    static std::mutex names_lock; static std::set<std::string> names;                 // (the profiler keeps the pointers it is given)
+    auto stable = [&](const std::string& n2) { std::lock_guard<std::mutex> g(names_lock); return names.insert(n2).first->c_str(); };
+    sp_aln* d_tr = (sp_aln*)sp_pool(ctx, (pre + "_tr").c_str(), n * sizeof(sp_aln));
+    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, (pre + "_ev").c_str(), n * (size_t)stride * 4);
+    AfPair* d_todo = (AfPair*)sp_pool(ctx, (pre + "_todo").c_str(), n * sizeof(AfPair));
+    uint32_t* d_at = (uint32_t*)sp_pool(ctx, (pre + "_at").c_str(), n * 4 + 64);
+    sp_affine_aln* d_part = (sp_affine_aln*)sp_pool(ctx, (pre + "_part").c_str(), n * sizeof(sp_affine_aln));
+    if (!d_tr || !d_ev || !d_todo || !d_at || !d_part) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "rescore buffers");
+    uint32_t* d_n = d_at + n;
+    (void)hipMemsetAsync(d_n, 0, 4, ctx->stream);
+    int rc = sp_launch_cells(ctx, Aw, Bw, d_cells, n, d_tr, d_ev, stride, stable(pre + "_trace"), 0);
+    if (rc != SP_OK) return rc;
+    hipLaunchKernelGGL(af_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cells, d_ref, d_tr, d_ev, stride, (uint32_t)n, target_is_a ? 1 : 0,
+                       (Aw->has_n || Bw->has_n) ? 1 : 0, o, d_out, d_todo, d_at, d_n);
+    // the DP over the list the classification left: launched for every pair, the workgroups behind the list's end return at once (no host round trip for the count)
+    rc = sp_launch_affine(ctx, target_is_a ? Bw : Aw, target_is_a ? Aw : Bw, d_todo, n, o, band, d_part, stable(pre + "_dp"), d_n);
+    if (rc != SP_OK) return rc;
+    hipLaunchKernelGGL(af_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_part, d_at, d_n, d_out);
     return SP_OK;
 }
 
@@ -199,7 +290,7 @@ extern "C" int32_t sp_affine_rescore_batch(sp_ctx* ctx, const sp_seqset* A, cons
     sp_affine_aln* d_out = (sp_affine_aln*)sp_pool(ctx, "affine_out", n_pairs * sizeof(sp_affine_aln));
     if (!d_pairs || !d_out) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "affine buffers");
     SP_HIP_CHECK(ctx, hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(sp_pair), hipMemcpyHostToDevice, ctx->stream));
-    const int rc = sp_launch_affine(ctx, A, B, d_pairs, n_pairs, *opts, band, d_out, "affine_rescore");
+    const int rc = sp_launch_affine(ctx, A, B, d_pairs, n_pairs, *opts, band, d_out, "affine_rescore", nullptr);
     if (rc != SP_OK) return rc;
     SP_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, n_pairs * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

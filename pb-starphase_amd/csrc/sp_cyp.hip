@@ -743,6 +743,7 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
             if (!al.ok) continue;
             const int tlen = templates->h_len[t];
             sp_region_hit h{(int32_t)r, (int32_t)t, al.b_start, al.b_end, tlen, al.nm, tlen - (al.a_end - al.a_start), al.a_start, tlen - al.a_end, 0, 0, 0, 0, 0, 0};
+            h.mm2_score = (int32_t)(((size_t)r * T + t) * CYP_TOPK + k);                     // (until the end of this routine: which alignment the hit is)
             if (cyp_score(h.seq_len, h.nm, h.unmapped, penalized_type(template_type[t])) > 0.05) continue;   // max_ed_frac, :228-232
             un.push_back(h);
         }
@@ -767,18 +768,29 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
             ++*n_hits;
         }
     }
-    // the hits that are handed out, re-scored the reference's way: template (query) against read (target) on the 256 diagonals around the hit's own
+    // the hits that are handed out, re-scored the reference's way: template (minimap2's query) against read (its target) on the 256 diagonals around the hit's own;
+    // hits whose edits all stand alone keep their counts without a DP (sp_rescore_mappings)
     const uint64_t n_out = std::min<uint64_t>(*n_hits, hits_cap);
+    std::vector<uint32_t> which(n_out);
+    for (uint64_t x = 0; x < n_out; ++x) { which[x] = (uint32_t)hits[x].mm2_score; hits[x].mm2_score = 0; }
     if (rescore && n_out) {
-        std::vector<sp_pair> pairs(n_out); std::vector<sp_affine_aln> af(n_out);
+        std::vector<CellDesc> cells(n_out); std::vector<sp_aln> ref(n_out); std::vector<sp_affine_aln> af(n_out);
         for (uint64_t x = 0; x < n_out; ++x) {
-            const sp_region_hit& h = hits[x];
-            const int d0 = h.start - h.clip_start, d1 = h.end - (h.seq_len - h.clip_end);
-            pairs[x] = sp_pair{ (uint32_t)h.template_idx, (uint32_t)h.read, (d0 + d1) / 2, 0 };
+            const sp_region_hit& h = hits[x]; const sp_aln& al = alns[which[x]];
+            cells[x] = CellDesc{ (uint32_t)h.template_idx, (uint32_t)h.read, ((al.b_start - al.a_start) + (al.b_end - al.a_end)) / 2, 320, 0, -1 };
+            ref[x] = al;
         }
+        CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k3_af_cells", n_out * sizeof(CellDesc));
+        sp_aln* d_ref = (sp_aln*)sp_pool(ctx, "k3_af_ref", n_out * sizeof(sp_aln));
+        sp_affine_aln* d_af = (sp_affine_aln*)sp_pool(ctx, "k3_af_out", n_out * sizeof(sp_affine_aln));
+        if (!d_cells || !d_ref || !d_af) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "find_regions: re-score buffers");
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_cells, cells.data(), n_out * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream));
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ref, ref.data(), n_out * sizeof(sp_aln), hipMemcpyHostToDevice, ctx->stream));
         const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
-        rc = sp_affine_rescore_batch(ctx, templates, reads, pairs.data(), n_out, &ao, 256, af.data());
+        rc = sp_rescore_mappings(ctx, templates, reads, d_cells, d_ref, n_out, false, ao, 256, d_af, "k3_af", 320);
         if (rc != SP_OK) return rc;
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(af.data(), d_af, n_out * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         for (uint64_t x = 0; x < n_out; ++x) {
             sp_region_hit& h = hits[x];
             h.mm2_score = af[x].score; h.mm2_nm = af[x].nm; h.mm2_start = af[x].b_start; h.mm2_end = af[x].b_end; h.mm2_q_start = af[x].a_start; h.mm2_q_end = af[x].a_end;

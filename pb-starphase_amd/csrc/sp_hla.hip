@@ -376,24 +376,22 @@ __global__ void k1_reverse_kernel(const uint32_t* __restrict__ weak_list, uint32
     is_reverse[r] = (rb >= K1_MIN_VOTES_REV && rb > fb) ? (rb >= 2 * fb ? 2 : 1) : 0;      // 2: a clear margin, 1: out-voted narrowly (only counts against a read that found nothing acceptable forwards)
 }
 
-// the pairs of the affine re-score of a K1 batch: read r (query, set A) against its best allele (target, set B = dna_fwd) on the diagonal its alignment lies on
-// (the middle of the diagonals at its two ends); reads without a best allele get an empty pair (allele index = n_alleles: the kernel leaves score 0)
-__global__ void k1_affine_pairs_kernel(const sp_hla_realign* __restrict__ rec, uint32_t n_reads, sp_pair* __restrict__ pairs, uint32_t* __restrict__ n_live) {
+// the cells of the re-score of a K1 batch (sp_rescore_mappings): read r (the window side, minimap2's query) against its best allele (the streamed side, minimap2's
+// target) on the diagonal its alignment lies on; reads without a best allele are marked "no mapping"
+__global__ void k1_rescore_cells_kernel(const sp_hla_realign* __restrict__ rec, uint32_t n_reads, CellDesc* __restrict__ cells, sp_aln* __restrict__ ref) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const sp_hla_realign& q = rec[r];
-    sp_pair p; p.a = r; p.b = 0; p.diag = 0; p.max_ed = -1;
-    if (q.best_allele >= 0 && q.aln.ok) { p.b = (uint32_t)q.best_allele; p.diag = ((q.aln.a_start - q.aln.b_start) + (q.aln.a_end - q.aln.b_end)) / 2; p.max_ed = 1; atomicAdd(n_live, 1u); }
-    pairs[r] = p;
+    CellDesc c; c.a = 0; c.b = r; c.diag = 0; c.max_ed = -1; c.b_lo = 0; c.b_hi = -1;
+    if (q.best_allele >= 0 && q.aln.ok) { c.a = (uint32_t)q.best_allele; c.diag = ((q.aln.b_start - q.aln.a_start) + (q.aln.b_end - q.aln.a_end)) / 2; c.max_ed = 127; }
+    cells[r] = c; ref[r] = q.aln;
 }
-__global__ void k1_affine_store_kernel(sp_hla_realign* __restrict__ rec, uint32_t n_reads, const sp_pair* __restrict__ pairs, const sp_affine_aln* __restrict__ af) {
+__global__ void k1_affine_store_kernel(sp_hla_realign* __restrict__ rec, uint32_t n_reads, const sp_affine_aln* __restrict__ af) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     sp_hla_realign& q = rec[r];
-    const bool live = pairs[r].max_ed > 0;
     const sp_affine_aln a = af[r];
-    q.mm2_score = live ? a.score : 0; q.mm2_nm = live ? a.nm : 0;
-    q.mm2_t_start = live ? a.b_start : 0; q.mm2_t_end = live ? a.b_end : 0; q.mm2_q_start = live ? a.a_start : 0; q.mm2_q_end = live ? a.a_end : 0;
+    q.mm2_score = a.score; q.mm2_nm = a.nm; q.mm2_t_start = a.b_start; q.mm2_t_end = a.b_end; q.mm2_q_start = a.a_start; q.mm2_q_end = a.a_end;
 }
 
 // K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
@@ -1092,16 +1090,15 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     }
     // 3b. the winners re-scored the reference's way (two-piece affine gaps, end clipping): the numbers minimap2 reports for the read and its allele
     if (rc == SP_OK && ctx->mm2_rescore) {
-        sp_pair* d_pairs = (sp_pair*)sp_pool(ctx, "k1_af_pairs", (size_t)R * sizeof(sp_pair));
+        CellDesc* d_rc = (CellDesc*)sp_pool(ctx, "k1_af_cells", (size_t)R * sizeof(CellDesc));
+        sp_aln* d_ref = (sp_aln*)sp_pool(ctx, "k1_af_ref", (size_t)R * sizeof(sp_aln));
         sp_affine_aln* d_af = (sp_affine_aln*)sp_pool(ctx, "k1_af_out", (size_t)R * sizeof(sp_affine_aln));
-        uint32_t* d_live = (uint32_t*)sp_pool(ctx, "k1_af_live", 64);
-        if (!d_pairs || !d_af || !d_live) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+        if (!d_rc || !d_ref || !d_af) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
         else {
-            (void)hipMemsetAsync(d_live, 0, 4, ctx->stream);
-            hipLaunchKernelGGL(k1_affine_pairs_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, d_pairs, d_live);
+            hipLaunchKernelGGL(k1_rescore_cells_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, d_rc, d_ref);
             const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
-            rc = sp_launch_affine(ctx, reads, db->dna_fwd, d_pairs, R, ao, 64, d_af, "k1_affine");
-            if (rc == SP_OK) hipLaunchKernelGGL(k1_affine_store_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, d_pairs, d_af);
+            rc = sp_rescore_mappings(ctx, db->dna_fwd, reads, d_rc, d_ref, R, true, ao, 64, d_af, "k1_af", 128);
+            if (rc == SP_OK) hipLaunchKernelGGL(k1_affine_store_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, d_af);
         }
     }
     if (rc == SP_OK) {

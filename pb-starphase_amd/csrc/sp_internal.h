@@ -129,7 +129,9 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, int retry_wide = 0);   // 0 never, 1 lost cells, 2 lost cells and cells with > 32 edits (few-cell callers)
 
 int sp_launch_affine(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const void* d_pairs /* sp_pair rows */, uint64_t n_pairs, const sp_affine_opts& o, int band,
-                     sp_affine_aln* d_out, const char* prof_name);                 // sp_affine.hip: two-piece affine re-score, pairs and results in device memory
+                     sp_affine_aln* d_out, const char* prof_name, const uint32_t* d_n_live = nullptr);   // sp_affine.hip: two-piece affine re-score, pairs and results in device memory
+int sp_rescore_mappings(sp_ctx* ctx, const sp_seqset* Aw, const sp_seqset* Bw, const CellDesc* d_cells, const sp_aln* d_ref, uint64_t n, bool target_is_a,
+                        const sp_affine_opts& o, int band, sp_affine_aln* d_out, const char* prefix, uint32_t stride);   // sp_affine.hip: mappings the caller holds, re-scored (no DP for isolated edits)
 int sp_launch_pack_on(hipStream_t stream, int num_cus, int format, const void* d_src, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
                       uint32_t* d_words, uint32_t* d_nplane, uint32_t* d_flag);   // format: SP_SEQ_ASCII / SP_SEQ_BAM4 / SP_SEQ_PACKED2
 int sp_launch_pack(sp_ctx* ctx, const char* d_ascii, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
