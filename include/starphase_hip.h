@@ -253,6 +253,9 @@ int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* 
 typedef struct {
     int32_t best_allele;
     int32_t n_scored;            /* alleles visited (gene match and allowed) */
+    /* HlaMappingStats of the best allele re-scored the reference's way (a = 5, two-piece affine gaps: sp_affine_rescore_batch): cDNA (len, nm, unmapped), DNA (len, nm,
+     * unmapped); -1, -1, -1 = level absent or not re-scored (context option "mm2_rescore" 0).  The running-best scan itself uses the library's own counts. */
+    int32_t mm2_stats[6];
 } sp_hla_best;
 
 int32_t sp_hla_score_consensus(sp_ctx* ctx, const sp_hla_db* db, uint32_t gene,

@@ -105,6 +105,7 @@ pub struct sp_hla_realign {
 pub struct sp_hla_best {
     pub best_allele: i32,
     pub n_scored: i32,
+    pub mm2_stats: [i32; 6],
 }
 #[repr(C)]
 pub struct sp_chain_problem {
@@ -163,6 +164,12 @@ pub struct sp_region_hit {
     pub unmapped: i32,
     pub clip_start: i32,
     pub clip_end: i32,
+    pub mm2_score: i32,
+    pub mm2_nm: i32,
+    pub mm2_start: i32,
+    pub mm2_end: i32,
+    pub mm2_q_start: i32,
+    pub mm2_q_end: i32,
 }
 #[repr(C)]
 pub struct sp_cyp_problem {

@@ -551,6 +551,22 @@ __global__ void k2_build_cells_kernel(const uint32_t* __restrict__ allele_idx, u
     cells[i] = c;
 }
 
+// the cells of the re-score of the winners of a K2 batch at one level (sp_rescore_mappings): item k's best allele (streamed side, minimap2's query) against the item's
+// consensus (window side, its target) on the diagonal the level's alignment lies on
+__global__ void k2_rescore_cells_kernel(const int32_t* __restrict__ best, const uint32_t* __restrict__ seg, uint32_t n_items, const uint32_t* __restrict__ allele_idx,
+                                        const uint32_t* __restrict__ cons_idx, const sp_aln* __restrict__ alns, CellDesc* __restrict__ cells, sp_aln* __restrict__ ref) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_items) return;
+    CellDesc c; c.a = 0; c.b = 0; c.diag = 0; c.max_ed = -1; c.b_lo = 0; c.b_hi = -1;
+    sp_aln al; al.ok = 0; al.nm = 0; al.a_start = al.a_end = al.b_start = al.b_end = al.a_len = al.b_len = 0;
+    if (best[k] >= 0) {
+        const uint32_t x = seg[k] + (uint32_t)best[k];
+        al = alns[x];
+        if (al.ok) { c.a = allele_idx[x]; c.b = cons_idx[x]; c.diag = ((al.b_start - al.a_start) + (al.b_end - al.a_end)) / 2; c.max_ed = K2_MAX_ED; }
+    }
+    cells[k] = c; ref[k] = al;
+}
+
 // select_best_mapping(query-based, penalised) + add_mapping bookkeeping (caller.rs:1447-1461, processed_match.rs:53-100)
 __global__ void k2_levels_kernel(const sp_aln* __restrict__ alns, uint32_t n, K2Level* __restrict__ lv) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1174,7 +1190,7 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
         sp_hla_db::GeneList& gl = db->gene_lists[items[k].gene * 2 + (require_dna ? 1u : 0u)];
         if (gl.idx.empty() && !gl.d_idx) { for (uint32_t a : db->gene_alleles[items[k].gene]) if (db->has_dna[a] || !require_dna) gl.idx.push_back(a); gl.d_idx = dev_copy(gl.idx); }
         lists[k] = &gl;
-        best[k].best_allele = -1; best[k].n_scored = (int32_t)gl.idx.size();
+        best[k].best_allele = -1; best[k].n_scored = (int32_t)gl.idx.size(); for (int x = 0; x < 6; ++x) best[k].mm2_stats[x] = -1;
         if (stats && stats[k]) for (uint32_t a = 0; a < db->n_alleles; ++a) for (int x = 0; x < 6; ++x) stats[k][(size_t)a * 6 + x] = -2;
         seg_off[k + 1] = seg_off[k] + (uint32_t)gl.idx.size();
         // consensus set: [2k] = cDNA, [2k+1] = DNA
@@ -1257,12 +1273,36 @@ static int32_t k2_score_batch(sp_ctx* ctx, const sp_hla_db* db, uint32_t n_items
             (void)hipStreamSynchronize(ctx->stream);
         }
     }
+    // the winners re-scored the reference's way (a = 5): what minimap2 reports for the best allele at both levels
+    std::vector<sp_affine_aln> af;
+    if (rc == SP_OK && ctx->mm2_rescore) {
+        CellDesc* d_rc = (CellDesc*)sp_pool(ctx, "k2_af_cells", (size_t)n_items * sizeof(CellDesc));
+        sp_aln* d_ref = (sp_aln*)sp_pool(ctx, "k2_af_ref", (size_t)n_items * sizeof(sp_aln));
+        sp_affine_aln* d_af = (sp_affine_aln*)sp_pool(ctx, "k2_af_out", (size_t)2 * n_items * sizeof(sp_affine_aln));
+        if (!d_rc || !d_ref || !d_af) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "score_consensus re-score buffers");
+        const sp_affine_opts ao = { 5, 4, 6, 2, 26, 1, 1 };
+        for (int L = 0; L < 2 && rc == SP_OK; ++L) {
+            hipLaunchKernelGGL(k2_rescore_cells_kernel, dim3((n_items + 255) / 256), dim3(256), 0, ctx->stream, d_best, d_seg, n_items, d_idx, L == 0 ? d_c0 : d_c1,
+                               d_alns + (size_t)L * T, d_rc, d_ref);
+            rc = sp_rescore_mappings(ctx, L == 0 ? db->cdna_gene : db->dna_gene, cons, d_rc, d_ref, n_items, false, ao, 64, d_af + (size_t)L * n_items, L == 0 ? "k2_af0" : "k2_af1", stride);
+        }
+        if (rc == SP_OK) { af.resize((size_t)2 * n_items); (void)hipMemcpyAsync(af.data(), d_af, af.size() * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream); }
+    }
     if (rc == SP_OK) {
         std::vector<int32_t> b(n_items, -1);
         (void)hipMemcpyAsync(b.data(), d_best, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("score_consensus: ") + hipGetErrorString(e));
-        else for (uint32_t k = 0; k < n_items; ++k) best[k].best_allele = b[k] >= 0 ? (int32_t)lists[k]->idx[b[k]] : -1;
+        else for (uint32_t k = 0; k < n_items; ++k) {
+            best[k].best_allele = b[k] >= 0 ? (int32_t)lists[k]->idx[b[k]] : -1;
+            for (int x = 0; x < 6; ++x) best[k].mm2_stats[x] = -1;
+            if (best[k].best_allele >= 0 && !af.empty()) for (int L = 0; L < 2; ++L) {
+                const sp_affine_aln& a = af[(size_t)L * n_items + k];
+                if (a.score <= 0) continue;
+                const int len = (L == 0 ? db->cdna_gene : db->dna_gene)->h_len[best[k].best_allele];
+                best[k].mm2_stats[3 * L] = len; best[k].mm2_stats[3 * L + 1] = a.nm; best[k].mm2_stats[3 * L + 2] = len - (a.a_end - a.a_start);
+            }
+        }
     }
     hm.mark("host:k2_wait");
     return rc;

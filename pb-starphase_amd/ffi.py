@@ -202,7 +202,7 @@ def hla_call_config(min_consensus_count=3, dual_max_ed_delta=100, min_consensus_
 
 
 class sp_hla_best(C.Structure):
-    _fields_ = [("best_allele", C.c_int32), ("n_scored", C.c_int32)]
+    _fields_ = [("best_allele", C.c_int32), ("n_scored", C.c_int32), ("mm2_stats", C.c_int32 * 6)]
 
 
 ALN_DTYPE = np.dtype([(n, np.int32) for n in ("ok", "nm", "a_start", "a_end", "b_start", "b_end", "a_len", "b_len")])
@@ -1189,6 +1189,7 @@ class HlaDb:
         n = C.c_uint32(0)
         self.ctx.check(lib().sp_hla_type_consensus(self.ctx._h, self._h, int(gene), consensus_fwd.encode(), len(consensus_fwd),
                                                    int(require_dna), int(disable_cdna), C.byref(best), _ptr(st), buf, len(buf), C.byref(n)))
+        self.last_mm2_stats = [int(x) for x in best.mm2_stats]                 # sp_hla_best.mm2_stats of this call
         return best.best_allele, best.n_scored, st, buf.raw[:n.value].decode()
 
     def score_consensus_batch(self, items, require_dna=False, disable_cdna=False):
@@ -1216,4 +1217,5 @@ class HlaDb:
         self.ctx.check(lib().sp_hla_score_consensus(
             self.ctx._h, self._h, int(gene), cons_dna.encode(), len(cons_dna), cons_cdna.encode(), len(cons_cdna),
             int(require_dna), int(disable_cdna), C.byref(best), _ptr(st)))
+        self.last_mm2_stats = [int(x) for x in best.mm2_stats]
         return best.best_allele, best.n_scored, st

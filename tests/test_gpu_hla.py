@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import hla_expected as hx
+import oracle_ffi as of
 
 pytestmark = pytest.mark.gpu
 
@@ -240,6 +241,16 @@ def test_type_consensus(oracle, pkg, gpu_ctx, small):
             assert best == ebest and n_scored == len(estats)
             for al_i, st in estats.items():
                 assert stats[al_i].tolist() == st
+            # the winner's stats re-scored the reference's way (sp_hla_best.mm2_stats; a = 5): oracle/affine.c of the allele (query) on the consensus (target)
+            want = []
+            for seq_a, seq_c in ((fx.cdna[best], e_cdna), (fx.dna[best], e_dna)):
+                if not seq_a or not seq_c:
+                    want += [-1, -1, -1]
+                    continue
+                dd, _vv = oracle.anchor(seq_a, seq_c)                       # cons_pos - allele_pos
+                sc, nm2, _ts, _te, qs, qe = of.oracle_affine(oracle, seq_c, seq_a, -dd, 64, 5)
+                want += [len(seq_a), nm2, len(seq_a) - (qe - qs)] if sc > 0 else [-1, -1, -1]
+            assert db.last_mm2_stats == want, (db.last_mm2_stats, want, stats[best].tolist())
             if trial == 0:
                 assert best == a or (fx.cdna[best] == fx.cdna[a] and fx.dna[best] == fx.dna[a])
     # empty / unalignable consensus => unknown (caller.rs:1263-1267,1282-1287)
