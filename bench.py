@@ -617,6 +617,10 @@ def main():
     # ------------------------------------------------------------------------------------------------ the sample: HLA-A / -B + CYP2D6, a new one every step
     ctx_c = pkg.Context(device_index)                       # the CYP2D6 half runs beside the HLA half on a context (stream, pools) of its own
     cdb_c = pkg.ffi.CypDb(ctx_c, cfg, gene_def, locus.sequence, locus.start)
+    if os.environ.get("SP_BENCH_CYP_PERSISTENT"):           # (an experiment switch: the persistent consensus kernels for the CYP2D6 context only)
+        ctx_c.set_option("k8_persistent", int(os.environ["SP_BENCH_CYP_PERSISTENT"]))
+    if os.environ.get("SP_BENCH_MM2_RESCORE"):              # (an experiment switch: what the re-scored numbers of K1 / K2 cost the step)
+        ctx.set_option("mm2_rescore", int(os.environ["SP_BENCH_MM2_RESCORE"]))
     genes = list(range(len(fx.genes)))
     last = {}
 

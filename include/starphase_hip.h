@@ -79,7 +79,8 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * for its weights on a helper stream while it types the consensuses).  The calls are the same either way.  "cons_retry_ladder" (default 0: the reference has no such rule): 1 makes sp_cyp_diplotype* run
  * its multi-way consensus with the retry of searches that give up (sp_cons_config.no_retry_ladder = 0, see sp_consensus_priority); sp_cyp_call.gave_up says whether a search of the call gave up.
  * "mm2_rescore" (default 1): sp_hla_realign_reads, sp_cyp_find_regions and sp_cyp_weight_segments also report every mapping they return re-scored the reference's
- * way (fields mm2_*; sp_affine_rescore_batch); 0 leaves those fields zero and saves the extra launch.
+ * way (fields mm2_*; sp_affine_rescore_batch); 0 leaves those fields zero and saves the extra launches; 2 = as 1, but every mapping with edits that do not stand alone
+ * takes the DP over all of its rows instead of over the rows around those edits (a check of the shortcut, an order of magnitude slower).
  * "k8_persistent" (default 0; also the environment variable SP_K8_PERSISTENT): 1 runs consensus batches whose problems have at most 1,024 reads each as two persistent
  * kernels (step workgroups and one control workgroup per problem, handing over through device-scope release / acquire words) instead of a launch pair per step --
  * the same search, bit for bit; one process per device only (the workgroups of a batch have to be resident together, and the budget of CUs is counted per process).

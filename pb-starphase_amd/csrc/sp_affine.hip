@@ -60,10 +60,18 @@ __device__ __forceinline__ AfState af_from_upper(const AfState& v) {      // lan
 }
 
 struct AfPair { uint32_t a, b; int32_t diag, pad; };        // a = query (set A), b = target (set B), diag = b_pos - a_pos (the library's convention)
+// The rows of a pair the DP has to run (sp_rescore_mappings, below): the stretches of the alignment whose edits do not stand alone.  r0 >= 0: the DP starts at target
+// row r0 with ONE live cell in the row before it, diagonal index idx_in, holding the alignment's closed-form score up to there (s_in, nm_in, start_cell); r1 >= 0:
+// when row r1 is done and the cell on diagonal idx_out is the one best cell of the row, the rest of the alignment is added in closed form (d_score, d_nm, its end
+// end_t / end_q) and the DP stops; otherwise it runs on to the last row.  Between two stretches (n_mid of them, AfMid): when row r_exit is done and the cell on idx_out
+// is the one best cell of the row, the DP goes on at row r_entry from that cell alone, d_score / d_nm later, on diagonal idx_in; otherwise it runs through.
+struct AfWin { int32_t r0, idx_in, s_in, nm_in; uint32_t start_cell; int32_t r1, idx_out, d_score, d_nm, end_t, end_q, n_mid; };
+struct AfMid { int32_t r_exit, idx_out, d_score, d_nm, r_entry, idx_in; };
+constexpr int AF_MAXMID = 15;
 
 template <int DPL, bool HASN>
 __global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, const AfPair* __restrict__ pairs, uint32_t n_pairs, const uint32_t* __restrict__ n_live, sp_affine_opts o,
-                                                     sp_affine_aln* __restrict__ out, int t_words_max) {
+                                                     sp_affine_aln* __restrict__ out, int t_words_max, const AfWin* __restrict__ wins, const AfMid* __restrict__ mids) {
     extern __shared__ uint32_t lds[];
     const uint32_t p = blockIdx.x;
     if (p >= n_pairs || (n_live && p >= *n_live)) return;              // (n_live: the number of pairs a kernel before this one left in the list)
@@ -100,7 +108,24 @@ __global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, 
     for (int c = 0; c < DPL; ++c) H[c] = E1[c] = E2[c] = af_none();
     int bs = 0, bi = -1, bj = -1; uint32_t bm0 = 0, bm1 = 0;
     const int q1 = o.q, e1 = o.e, q2 = o.q2, e2 = o.e2;
-    for (int i = i_lo; i <= i_hi; ++i) {
+    AfWin win; win.r0 = -1; win.r1 = -1; win.n_mid = 0;
+    if (wins) win = wins[p];
+    int i_first = i_lo;
+    if (win.r0 > i_lo && win.r0 <= i_hi && (unsigned)win.idx_in < (unsigned)BAND) {
+        i_first = win.r0;
+#pragma unroll
+        for (int c = 0; c < DPL; ++c)
+            if (lane * DPL + c == win.idx_in) {
+                H[c].s = win.s_in; H[c].m0 = win.start_cell; H[c].m1 = (uint32_t)win.nm_in;
+                bs = win.s_in; bi = win.r0 - 1; bj = win.r0 - 1 + klo + win.idx_in; bm0 = win.start_cell; bm1 = (uint32_t)win.nm_in;
+            }
+    }
+    const int i_tail = (win.r1 >= i_first && win.r1 < i_hi && (unsigned)win.idx_out < (unsigned)BAND) ? win.r1 : -1;
+    bool tail_ok = false; int tail_s = 0; uint32_t tail_m0 = 0, tail_m1 = 0;
+    int mid_k = 0; AfMid mid; mid.r_exit = -1;
+    if (win.n_mid > 0) mid = mids[(size_t)p * AF_MAXMID];
+    int i_check = mid_k < win.n_mid ? mid.r_exit : i_tail, chk_idx = mid_k < win.n_mid ? mid.idx_out : win.idx_out;
+    for (int i = i_first; i <= i_hi; ++i) {
         const int ct = base_of(LT, NT, i, tw0);
         // the diagonal above lane's last cell: lane l + 1's first cell of the row before
         const AfState upH = af_from_upper(H[0]), upE1 = af_from_upper(E1[0]), upE2 = af_from_upper(E2[0]);
@@ -155,6 +180,41 @@ __global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, 
             H[c] = h; E1[c] = e1n[c]; E2[c] = e2n[c];
             in1 = af_max(in1, k1[c]); in2 = af_max(in2, k2[c]);
         }
+        if (i == i_check) {
+            // the row behind the last cluster: is the alignment where the library's own one runs, alone at the top of the row?
+            int mine = AF_NEG, others = AF_NEG; uint32_t m0 = 0, m1 = 0;
+#pragma unroll
+            for (int c = 0; c < DPL; ++c) {
+                if (lane * DPL + c == chk_idx) { mine = H[c].s; m0 = H[c].m0; m1 = H[c].m1; }
+                else if (H[c].s > others) others = H[c].s;
+            }
+            const int src = chk_idx / DPL;
+            const int s_exit = __shfl(mine, src);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { const int v = __shfl_xor(others, d); others = v > others ? v : others; }
+            const bool alone = s_exit > 0 && others < s_exit;
+            m0 = (uint32_t)__shfl((int)m0, src); m1 = (uint32_t)__shfl((int)m1, src);
+            if (mid_k < win.n_mid) {
+                if (alone && mid.r_entry > i && mid.r_entry <= i_hi && (unsigned)mid.idx_in < (unsigned)BAND) {
+#pragma unroll
+                    for (int c = 0; c < DPL; ++c) {
+                        H[c] = E1[c] = E2[c] = af_none();
+                        if (lane * DPL + c == mid.idx_in) {
+                            const int s = s_exit + mid.d_score;
+                            H[c].s = s; H[c].m0 = m0; H[c].m1 = m1 + (uint32_t)mid.d_nm;
+                            if (s > bs) { bs = s; bi = mid.r_entry - 1; bj = mid.r_entry - 1 + klo + mid.idx_in; bm0 = m0; bm1 = H[c].m1; }
+                        }
+                    }
+                    i = mid.r_entry - 1;
+                }
+                ++mid_k;
+                if (mid_k < win.n_mid) mid = mids[(size_t)p * AF_MAXMID + mid_k];
+                i_check = mid_k < win.n_mid ? mid.r_exit : i_tail; chk_idx = mid_k < win.n_mid ? mid.idx_out : win.idx_out;
+            } else if (alone) {
+                tail_ok = true; tail_s = s_exit + win.d_score; tail_m0 = m0; tail_m1 = m1 + (uint32_t)win.d_nm;
+                break;
+            } else i_check = -1;
+        }
     }
     // the best cell of the wave: highest score, then the smallest anti-diagonal, then the smallest row
 #pragma unroll
@@ -163,6 +223,7 @@ __global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, 
         const uint32_t om0 = (uint32_t)__shfl_xor((int)bm0, d), om1 = (uint32_t)__shfl_xor((int)bm1, d);
         if (os > bs || (os == bs && os > 0 && (oi + oj < bi + bj || (oi + oj == bi + bj && oi < bi)))) { bs = os; bi = oi; bj = oj; bm0 = om0; bm1 = om1; }
     }
+    if (tail_ok && tail_s > bs) { bs = tail_s; bi = win.end_t - 1; bj = win.end_q - 1; bm0 = tail_m0; bm1 = tail_m1; }      // (the end of the alignment lies behind every cell of the rows run: it wins only with the higher score)
     if (lane == 0) {
         if (bs > 0) { res.score = bs; res.nm = (int32_t)bm1; res.b_start = (int32_t)(bm0 >> 16); res.b_end = bi + 1; res.a_start = (int32_t)(bm0 & 0xFFFFu); res.a_end = bj + 1; }
         out[p] = res;
@@ -173,7 +234,7 @@ __global__ __launch_bounds__(64) void affine_kernel(SeqSetView A, SeqSetView B, 
 
 // device-side entry for the library's own callers: pairs and results in device memory
 int sp_launch_affine(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const void* d_pairs, uint64_t n_pairs, const sp_affine_opts& o, int band, sp_affine_aln* d_out,
-                     const char* prof_name, const uint32_t* d_n_live) {
+                     const char* prof_name, const uint32_t* d_n_live, const void* d_wins, const void* d_mids) {
     if (n_pairs == 0) return SP_OK;
     if (band != 64 && band != 256) return sp_fail(ctx, SP_ERR_INVALID_ARG, "affine: band must be 64 or 256");
     if (B->max_len > 65535 || A->max_len > 65535) return sp_fail(ctx, SP_ERR_TOO_LONG, "affine: sequences of up to 65,535 bases");
@@ -183,7 +244,7 @@ int sp_launch_affine(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const 
     const bool hasn = A->has_n || B->has_n;
 #define SP_AF_LAUNCH(D, N) do { \
         (void)hipFuncSetAttribute((const void*)affine_kernel<D, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-        hipLaunchKernelGGL((affine_kernel<D, N>), dim3((uint32_t)n_pairs), dim3(64), lds_bytes, ctx->stream, A->view(), B->view(), (const AfPair*)d_pairs, (uint32_t)n_pairs, d_n_live, o, d_out, t_words_max); } while (0)
+        hipLaunchKernelGGL((affine_kernel<D, N>), dim3((uint32_t)n_pairs), dim3(64), lds_bytes, ctx->stream, A->view(), B->view(), (const AfPair*)d_pairs, (uint32_t)n_pairs, d_n_live, o, d_out, t_words_max, (const AfWin*)d_wins, (const AfMid*)d_mids); } while (0)
     if (band == 64) { if (hasn) SP_AF_LAUNCH(1, true); else SP_AF_LAUNCH(1, false); }
     else { if (hasn) SP_AF_LAUNCH(4, true); else SP_AF_LAUNCH(4, false); }
 #undef SP_AF_LAUNCH
@@ -201,11 +262,12 @@ int sp_launch_affine(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const 
 // caller holds takes the DP as well.
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr int AF_ISOLATED = 16;
+constexpr int AF_MARGIN = 24;
 
 // d_ref: the alignment the caller holds for each pair (WFA orientation: a_* on Aw, b_* on Bw); cells[x].max_ed < 0: no mapping (score 0)
 __global__ void af_classify_kernel(const CellDesc* __restrict__ cells, const sp_aln* __restrict__ ref, const sp_aln* __restrict__ tr, const uint32_t* __restrict__ ev,
                                    uint32_t stride, uint32_t n, int target_is_a, int has_n, sp_affine_opts o, sp_affine_aln* __restrict__ out,
-                                   AfPair* __restrict__ todo, uint32_t* __restrict__ todo_at, uint32_t* __restrict__ n_todo) {
+                                   AfPair* __restrict__ todo, uint32_t* __restrict__ todo_at, uint32_t* __restrict__ n_todo, AfWin* __restrict__ wins, AfMid* __restrict__ mids, int band, int windows) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n) return;
     sp_affine_aln res; res.score = 0; res.nm = 0; res.a_start = res.a_end = res.b_start = res.b_end = 0;
@@ -213,6 +275,7 @@ __global__ void af_classify_kernel(const CellDesc* __restrict__ cells, const sp_
     if (c.max_ed < 0) { out[x] = res; return; }
     const sp_aln r = ref[x], t = tr[x];
     bool simple = !has_n && r.ok && t.ok && t.nm == r.nm && t.a_start == r.a_start && t.a_end == r.a_end && t.b_start == r.b_start && t.b_end == r.b_end && (uint32_t)r.nm <= stride;
+    const bool traced = simple;
     int nx = 0, ngap = 0;
     if (simple) {
         const uint32_t* e = ev + (size_t)x * stride;
@@ -245,6 +308,75 @@ __global__ void af_classify_kernel(const CellDesc* __restrict__ cells, const sp_
     p.pad = 0;
     if (!r.ok) p.diag = target_is_a ? -c.diag : c.diag;
     todo[at] = p; todo_at[at] = x;
+    // the rows the DP has to run: for every run of edits that do not stand alone, from AF_MARGIN bases before its first edit to AF_MARGIN behind its last one, both ends
+    // moved outwards until no other edit lies within AF_ISOLATED bases of them; what lies before, between and behind these stretches is spelled by both scoring schemes
+    // the same way (the argument above) and enters in closed form.  An end that would come within AF_ISOLATED bases of the alignment's own end is left to the DP, two
+    // stretches less than AF_ISOLATED apart are one, and so are the stretches beyond the AF_MAXMID + 1 a pair can have.
+    AfWin w; w.r0 = -1; w.r1 = -1; w.idx_in = w.idx_out = 0; w.s_in = w.nm_in = w.d_score = w.d_nm = w.end_t = w.end_q = w.n_mid = 0; w.start_cell = 0;
+    if (traced && windows && r.nm > 0) {
+        const uint32_t* e = ev + (size_t)x * stride;
+        auto pos_of = [&](int k) { return (int)(e[k] & 0x3FFFFFFFu); };
+        int wF[AF_MAXMID + 1], wL[AF_MAXMID + 1], wIn[AF_MAXMID + 1], wOut[AF_MAXMID + 1], nw = 0;
+        for (int k = 0; k < r.nm; ++k) {
+            const int pos = pos_of(k);
+            const bool lone = !(pos - r.b_start < AF_ISOLATED || r.b_end - pos < AF_ISOLATED) && !(k > 0 && pos - pos_of(k - 1) < AF_ISOLATED) && !(k + 1 < r.nm && pos_of(k + 1) - pos < AF_ISOLATED);
+            if (lone) continue;
+            int kF = k, kL = k;
+            const int floor_k = nw ? wL[nw - 1] + 1 : 0;
+            int entry = pos_of(kF) - AF_MARGIN;
+            while (kF > floor_k && pos_of(kF - 1) > entry - AF_ISOLATED) { --kF; entry = pos_of(kF) - AF_MARGIN; }
+            int leave = pos_of(kL) + AF_MARGIN;
+            while (kL + 1 < r.nm && pos_of(kL + 1) < leave + AF_ISOLATED) { ++kL; leave = pos_of(kL) + AF_MARGIN; }
+            if (nw && (entry - wOut[nw - 1] < AF_ISOLATED || nw == AF_MAXMID + 1)) { wL[nw - 1] = kL; wOut[nw - 1] = leave; }
+            else { wF[nw] = kF; wL[nw] = kL; wIn[nw] = entry; wOut[nw] = leave; ++nw; }
+            k = kL;
+        }
+        if (nw > 0) {
+            const int klo = -p.diag - band / 2;
+            // the walk along the alignment: (i, j) = the next bases of the streamed and the window sequence; cx / cd / ci = the lone edits since the last stretch
+            int i = r.a_start, j = r.b_start, cx = 0, cd = 0, ci = 0, k = 0;
+            auto step_to = [&](int k2) { const int pos = pos_of(k2), type = (int)(e[k2] >> 30); i += pos - j; j = pos; if (type == (int)SP_EV_X) { ++i; ++j; ++cx; } else if (type == (int)SP_EV_D) { ++j; ++cd; } else { ++i; ++ci; } };
+            AfMid* mid = mids + (size_t)at * AF_MAXMID;
+            int out_t = 0, out_idx = 0, out_b = 0; bool have_out = false;
+            for (int v = 0; v < nw; ++v) {
+                for (; k < wF[v]; ++k) step_to(k);
+                {
+                    const int ia = i + (wIn[v] - j), jb = wIn[v];                                   // the first cell the DP scores; the one before it is a match on the same diagonal
+                    const int t_in = target_is_a ? ia : jb, q_in = target_is_a ? jb : ia;
+                    const int idx = (q_in - t_in) - klo;
+                    const bool fits = idx >= 0 && idx < band && t_in >= 1 && q_in >= 1;
+                    if (v == 0) {
+                        if (wIn[0] - r.b_start >= AF_ISOLATED && fits) {
+                            w.r0 = t_in; w.idx_in = idx;
+                            w.s_in = o.a * ((wIn[0] - r.b_start) - cx - cd) - o.b * cx - (o.q + o.e) * (cd + ci); w.nm_in = cx + cd + ci;
+                            const int ts = target_is_a ? r.a_start : r.b_start, qs = target_is_a ? r.b_start : r.a_start;
+                            w.start_cell = ((uint32_t)ts << 16) | (uint32_t)(qs & 0xFFFF);
+                        }
+                    } else if (have_out && fits && t_in > out_t + 1) {
+                        AfMid m; m.r_exit = out_t; m.idx_out = out_idx; m.r_entry = t_in; m.idx_in = idx;
+                        m.d_score = o.a * ((wIn[v] - out_b - 1) - cx - cd) - o.b * cx - (o.q + o.e) * (cd + ci); m.d_nm = cx + cd + ci;
+                        mid[w.n_mid++] = m;
+                    }
+                }
+                for (; k <= wL[v]; ++k) step_to(k);
+                cx = cd = ci = 0;
+                {
+                    const int ia = i + (wOut[v] - j), jb = wOut[v];                                 // a matching cell AF_MARGIN behind the last edit of the stretch
+                    const int t_out = target_is_a ? ia : jb, q_out = target_is_a ? jb : ia;
+                    const int idx = (q_out - t_out) - klo;
+                    have_out = idx >= 0 && idx < band && wOut[v] >= j;
+                    out_t = t_out; out_idx = idx; out_b = wOut[v];
+                }
+            }
+            if (have_out && r.b_end - out_b >= AF_ISOLATED) {
+                for (; k < r.nm; ++k) step_to(k);
+                w.r1 = out_t; w.idx_out = out_idx;
+                w.d_score = o.a * ((r.b_end - out_b - 1) - cx - cd) - o.b * cx - (o.q + o.e) * (cd + ci); w.d_nm = cx + cd + ci;
+                w.end_t = target_is_a ? r.a_end : r.b_end; w.end_q = target_is_a ? r.b_end : r.a_end;
+            }
+        }
+    }
+    wins[at] = w;
 }
 __global__ void af_scatter_kernel(const sp_affine_aln* __restrict__ part, const uint32_t* __restrict__ todo_at, const uint32_t* __restrict__ n_todo, sp_affine_aln* __restrict__ out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,15 +396,17 @@ int sp_rescore_mappings(sp_ctx* ctx, const sp_seqset* Aw, const sp_seqset* Bw, c
     AfPair* d_todo = (AfPair*)sp_pool(ctx, (pre + "_todo").c_str(), n * sizeof(AfPair));
     uint32_t* d_at = (uint32_t*)sp_pool(ctx, (pre + "_at").c_str(), n * 4 + 64);
     sp_affine_aln* d_part = (sp_affine_aln*)sp_pool(ctx, (pre + "_part").c_str(), n * sizeof(sp_affine_aln));
-    if (!d_tr || !d_ev || !d_todo || !d_at || !d_part) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "rescore buffers");
+    AfWin* d_win = (AfWin*)sp_pool(ctx, (pre + "_win").c_str(), n * sizeof(AfWin));
+    AfMid* d_mid = (AfMid*)sp_pool(ctx, (pre + "_mid").c_str(), n * sizeof(AfMid) * AF_MAXMID);
+    if (!d_tr || !d_ev || !d_todo || !d_at || !d_part || !d_win || !d_mid) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "rescore buffers");
     uint32_t* d_n = d_at + n;
     (void)hipMemsetAsync(d_n, 0, 4, ctx->stream);
     int rc = sp_launch_cells(ctx, Aw, Bw, d_cells, n, d_tr, d_ev, stride, stable(pre + "_trace"), 0);
     if (rc != SP_OK) return rc;
     hipLaunchKernelGGL(af_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cells, d_ref, d_tr, d_ev, stride, (uint32_t)n, target_is_a ? 1 : 0,
-                       (Aw->has_n || Bw->has_n) ? 1 : 0, o, d_out, d_todo, d_at, d_n);
+                       (Aw->has_n || Bw->has_n) ? 1 : 0, o, d_out, d_todo, d_at, d_n, d_win, d_mid, band, ctx->mm2_rescore == 2 ? 0 : 1);
     // the DP over the list the classification left: launched for every pair, the workgroups behind the list's end return at once (no host round trip for the count)
-    rc = sp_launch_affine(ctx, target_is_a ? Bw : Aw, target_is_a ? Aw : Bw, d_todo, n, o, band, d_part, stable(pre + "_dp"), d_n);
+    rc = sp_launch_affine(ctx, target_is_a ? Bw : Aw, target_is_a ? Aw : Bw, d_todo, n, o, band, d_part, stable(pre + "_dp"), d_n, d_win, d_mid);
     if (rc != SP_OK) return rc;
     hipLaunchKernelGGL(af_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_part, d_at, d_n, d_out);
     return SP_OK;
@@ -290,7 +424,7 @@ extern "C" int32_t sp_affine_rescore_batch(sp_ctx* ctx, const sp_seqset* A, cons
     sp_affine_aln* d_out = (sp_affine_aln*)sp_pool(ctx, "affine_out", n_pairs * sizeof(sp_affine_aln));
     if (!d_pairs || !d_out) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "affine buffers");
     SP_HIP_CHECK(ctx, hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(sp_pair), hipMemcpyHostToDevice, ctx->stream));
-    const int rc = sp_launch_affine(ctx, A, B, d_pairs, n_pairs, *opts, band, d_out, "affine_rescore", nullptr);
+    const int rc = sp_launch_affine(ctx, A, B, d_pairs, n_pairs, *opts, band, d_out, "affine_rescore", nullptr, nullptr, nullptr);
     if (rc != SP_OK) return rc;
     SP_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, n_pairs * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

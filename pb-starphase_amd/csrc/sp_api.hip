@@ -111,7 +111,7 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx) {
 int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SP_ERR_INVALID_ARG;
     if (std::strcmp(name, "hla_split_genes") == 0) { ctx->split_genes = value != 0; return SP_OK; }
-    if (std::strcmp(name, "mm2_rescore") == 0) { ctx->mm2_rescore = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->mm2_rescore = ctx->mm2_rescore; return SP_OK; }
+    if (std::strcmp(name, "mm2_rescore") == 0) { ctx->mm2_rescore = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->mm2_rescore = ctx->mm2_rescore; return SP_OK; }
     if (std::strcmp(name, "k8_persistent") == 0) { ctx->k8_persistent = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->k8_persistent = ctx->k8_persistent; return SP_OK; }
     if (std::strcmp(name, "cons_retry_ladder") == 0) { ctx->cons_retry_ladder = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->cons_retry_ladder = ctx->cons_retry_ladder; return SP_OK; }
     if (std::strcmp(name, "k5_block_pairs") == 0) { if (value < 0 || value > (1 << 20)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k5_block_pairs is 0..1048576"); ctx->k5_block_pairs = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k5_block_pairs = ctx->k5_block_pairs; return SP_OK; }

@@ -429,7 +429,46 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             bool known = peek(&mm->valid) && peek(&mm->M) == M && peek(&mm->off) == off;
             if (known) known = __ballot(lane < nw && seen != A.cpack[lane]) == 0;
             ACT_T(0);
+            // Most reads have no error in their first L bases: the pattern then occurs in the text as it is, an occurrence has no edits, and the search's answer is the
+            // exact occurrence closest to the middle of the window (then the leftmost) -- found with a few word compares per start position instead of the L x M
+            // matrix (a placement was 89 us of the slowest wave of a CYP2D6 window launch with the reference's 100-base comparison, two thirds of the slowest-wave time
+            // of a sample's first batch).  Both are packed backwards here: pattern word k holds pattern bases L - 1 - 16 k downwards.
+            int exact_c0 = -1;
+            if (!known && rv.np == nullptr && L >= 16) {
+                uint32_t pw = 0;
+                const int npw = (L + 15) >> 4;
+                if (lane < npw) for (int b = 0; b < 16; ++b) { const int u = lane * 16 + b; if (u < L) pw |= (uint32_t)(rbc(L - 1 - u) & 3) << (b << 1); }
+                const uint32_t tail_mask = (L & 15) ? ((1u << ((L & 15) << 1)) - 1u) : 0xFFFFFFFFu;
+                const int centre = off - window / 2;
+                unsigned long long key = ~0ull;
+                for (int j = len - off + lane; j <= M; j += SP_WAVE) {                // text position j (1-based, backwards from len) <-> start len - j
+                    const int s0 = j - L;                                            // 0-based index of the occurrence's first base in the backward text
+                    bool same = s0 >= 0;
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)pw, k);
+                        if (k < npw && same) {
+                            const int wi = (s0 >> 4) + k;
+                            const uint32_t have = __builtin_amdgcn_alignbit(A.cpack[wi + 1], A.cpack[wi], (uint32_t)(s0 & 15) << 1);
+                            const uint32_t diff = (have ^ want) & (k == npw - 1 ? tail_mask : 0xFFFFFFFFu);
+                            same = diff == 0;
+                        }
+                    }
+                    if (same) {
+                        const int p = len - j, dist = p > centre ? p - centre : centre - p;
+                        const unsigned long long kk = ((unsigned long long)dist << 22) | (unsigned long long)p;
+                        key = kk < key ? kk : key;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
+                if (key != ~0ull) exact_c0 = (int)(key & ((1ull << 22) - 1));
+            }
             if (known) d.c0 = m_c0;
+            else if (exact_c0 >= 0) {
+                d.c0 = exact_c0;
+                if (lane < nw) mm->text[lane] = A.cpack[lane];
+                if (lane == 0) { mm->valid = 1; mm->M = M; mm->off = off; mm->c0 = d.c0; }
+            }
             else {
                 if (L <= SP_WAVE) d.c0 = find_start_diag(lane < L ? rbc(L - 1 - lane) : 7, L, M, off, len, window, lane, A.cpack, A.score);
                 else d.c0 = find_start_diag2(2 * lane + 1 <= L ? rbc(L - 2 * lane - 1) : 7, 2 * lane + 2 <= L ? rbc(L - 2 * lane - 2) : 7, L, M, off, len, window, lane, A.cpack, A.score);

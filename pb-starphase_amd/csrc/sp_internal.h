@@ -86,7 +86,7 @@ struct sp_ctx {
     hipStream_t copy_stream = nullptr;   // uploads travel on a stream of their own, beside the kernels of ctx->stream
     hipStream_t ctl_stream = nullptr;    // the control workgroups of a persistent consensus batch run here, beside the step workgroups on ctx->stream (made on first use)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool mm2_rescore = true;             // sp_ctx_set_option "mm2_rescore": the entry points that return mappings also report them re-scored with the reference's affine scores (mm2_* fields)
+    int mm2_rescore = 1;                 // sp_ctx_set_option "mm2_rescore": the entry points that return mappings also report them re-scored with the reference's affine scores (mm2_* fields)
     bool k8_persistent = false;          // sp_ctx_set_option "k8_persistent" (or SP_K8_PERSISTENT=1): small consensus batches run as two persistent kernels instead of a launch pair per
                                          // step.  Off by default: the agent-scope release / acquire fences of every hand-over cost what the kernel boundaries cost (measured)
     sp_seqset* uploading = nullptr;      // the one upload a context has in flight (the staging buffers are the context's)
@@ -129,7 +129,7 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
                     sp_aln* d_out, uint32_t* d_events, uint32_t events_stride, const char* prof_name, int retry_wide = 0);   // 0 never, 1 lost cells, 2 lost cells and cells with > 32 edits (few-cell callers)
 
 int sp_launch_affine(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const void* d_pairs /* sp_pair rows */, uint64_t n_pairs, const sp_affine_opts& o, int band,
-                     sp_affine_aln* d_out, const char* prof_name, const uint32_t* d_n_live = nullptr);   // sp_affine.hip: two-piece affine re-score, pairs and results in device memory
+                     sp_affine_aln* d_out, const char* prof_name, const uint32_t* d_n_live = nullptr, const void* d_wins = nullptr, const void* d_mids = nullptr);   // sp_affine.hip: two-piece affine re-score, pairs and results in device memory
 int sp_rescore_mappings(sp_ctx* ctx, const sp_seqset* Aw, const sp_seqset* Bw, const CellDesc* d_cells, const sp_aln* d_ref, uint64_t n, bool target_is_a,
                         const sp_affine_opts& o, int band, sp_affine_aln* d_out, const char* prefix, uint32_t stride);   // sp_affine.hip: mappings the caller holds, re-scored (no DP for isolated edits)
 int sp_launch_pack_on(hipStream_t stream, int num_cus, int format, const void* d_src, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,

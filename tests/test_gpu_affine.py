@@ -89,3 +89,35 @@ def test_random_pairs_with_n_and_edges(oracle, pkg, gpu_ctx):
     for band in (64, 256):
         check(oracle, gpu_ctx, targets, queries, pairs, band)
         check(oracle, gpu_ctx, targets, queries, pairs, band, a=5)
+
+
+def test_rows_around_the_clusters_equal_all_rows(pkg, gpu_ctx):
+    """the re-score of the library's own mappings runs the DP over the rows around the edits that do not stand alone (context option mm2_rescore 1, the default);
+    2 runs it over all rows of such a mapping: the same numbers for every K1 winner of 3,000 of configs[1]'s reads and every K3 hit of 600 of a configs[2] sample"""
+    from pb_starphase_amd import synth
+    import cyp_cases_real as cr
+    fx = synth.HlaFixture(); db = fx.make_db(pkg, gpu_ctx)
+    wl = synth.Config2Workload(fx, n_reads=3000, seed=1000)
+    R = gpu_ctx.upload(wl.reads)
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    cdb = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
+    tm = cdb.templates(); tset = gpu_ctx.upload([t[3] for t in tm]); ttype = np.array([t[0] for t in tm], np.int32)
+    sc = {n: (h, e) for n, h, e in cr.scenarios(locus)}
+    Rc = gpu_ctx.upload(locus.sample(np.random.default_rng(11), sc["*10+*36/*10"][0], 600))
+    got = {}
+    try:
+        for mode in (1, 2):
+            gpu_ctx.set_option("mm2_rescore", mode)
+            gpu_ctx.profile_reset()
+            got[mode] = (db.realign_reads(R), gpu_ctx.cyp_find_regions(tset, ttype, Rc, 0.5))
+            got[mode] += (gpu_ctx.profile_get("k1_af_dp")[0], gpu_ctx.profile_get("k3_af_dp")[0])
+    finally:
+        gpu_ctx.set_option("mm2_rescore", 1)
+    for f in ("mm2_score", "mm2_nm", "mm2_t_start", "mm2_t_end", "mm2_q_start", "mm2_q_end"):
+        assert (got[1][0][f] == got[2][0][f]).all(), f
+    assert (got[1][0]["mm2_score"] > 0).sum() > 2500
+    assert len(got[1][1]) == len(got[2][1]) > 600
+    for f in ("mm2_score", "mm2_nm", "mm2_start", "mm2_end", "mm2_q_start", "mm2_q_end"):
+        assert (got[1][1][f] == got[2][1][f]).all(), f
+    print("DP ms, rows around the clusters / all rows: K1", round(got[1][2], 3), "/", round(got[2][2], 3), " K3", round(got[1][3], 3), "/", round(got[2][3], 3))
