@@ -115,6 +115,7 @@ int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (std::strcmp(name, "k8_persistent") == 0) { ctx->k8_persistent = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->k8_persistent = ctx->k8_persistent; return SP_OK; }
     if (std::strcmp(name, "cons_retry_ladder") == 0) { ctx->cons_retry_ladder = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->cons_retry_ladder = ctx->cons_retry_ladder; return SP_OK; }
     if (std::strcmp(name, "k5_block_pairs") == 0) { if (value < 0 || value > (1 << 20)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k5_block_pairs is 0..1048576"); ctx->k5_block_pairs = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k5_block_pairs = ctx->k5_block_pairs; return SP_OK; }
+    if (std::strcmp(name, "cyp_cohort_min_group") == 0) { if (value < 1 || value > 64) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: cyp_cohort_min_group is 1..64"); ctx->cyp_cohort_min_group = (int)value; return SP_OK; }
     if (std::strcmp(name, "cyp_cohort_streams") == 0) { if (value < 1 || value > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: cyp_cohort_streams is 1..8"); ctx->cyp_cohort_streams = (int)value; return SP_OK; }
     if (std::strcmp(name, "hla_split_streams") == 0) { if (value < 1 || value > 4) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: hla_split_streams is 1..4"); ctx->split_streams = (int)value; return SP_OK; }
     return sp_fail(ctx, SP_ERR_INVALID_ARG, std::string("sp_ctx_set_option: unknown option ") + name);

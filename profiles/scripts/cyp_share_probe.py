@@ -1,0 +1,31 @@
+"""A rank's small share of configs[4] (32 samples): what the CYP2D6 cohort call costs by streams / samples per stream, and where its host time goes."""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from pb_starphase_amd import synth
+import bench, cyp_cases_real as cr
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+ctx = pkg.Context(0)
+fx = synth.HlaFixture()
+cfg, gene_def = cr.load_db()
+locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+cdb = pkg.ffi.CypDb(ctx, cfg, gene_def, locus.sequence, locus.start)
+scen = cr.scenarios(locus)
+panel = bench.VariantPanel(pkg)
+sh = bench.CohortShare(pkg, fx, locus, scen, panel, list(range(N)))
+sets = [ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *p) for p in sh.cyp_payloads]
+stages = ["host:cyp_" + k for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")] + ["host:k8_loop", "host:k8_result_wait", "cons_steps", "k9_graph"]
+for streams, mg, pers in ((6, 12, 0), (6, 12, 1), (1, 64, 0), (1, 64, 1), (2, 8, 1), (4, 8, 0), (4, 8, 1), (6, 5, 1), (6, 12, 0), (6, 12, 1)):
+    ctx.set_option("cyp_cohort_streams", streams); ctx.set_option("cyp_cohort_min_group", mg); ctx.set_option("k8_persistent", pers)
+    cdb.diplotype_cohort(sets)
+    ctx.profile_reset(); ctx.synchronize(); t0 = time.perf_counter()
+    calls = cdb.diplotype_cohort(sets)
+    dt = time.perf_counter() - t0
+    good = sum(sorted([c[0].hap1.decode(), c[0].hap2.decode()]) == sorted(e) for c, e in zip(calls, sh.cyp_expected))
+    parts = min(max(1, N // mg), streams)
+    print("persistent" if pers else "launches  ", int(ctx.profile_get("cons_persistent_batches")[2]), f"{N} samples, {parts} stream(s) x groups of {-(-N // parts)}: {1e3 * dt:7.1f} ms  ({1e3 * dt / N:5.2f} ms per sample, {good}/{N} equal truth)  " +
+          " ".join(f"{s.split(':')[-1].replace('cyp_', '')} {ctx.profile_get(s)[0]:.0f}" for s in stages), flush=True)

@@ -1,0 +1,10 @@
+python bench.py --no-cpu-baseline > gpurun_out/r04_bench_f.json 2> gpurun_out/r04_bench_f.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r04_bench_f.json').read().strip().splitlines()[-1])
+print(round(d['value']), round(d['ms_per_step'],2), {k:round(v,2) for k,v in d['kernel_ms']['cyp2d6'].items()}, round(d['kernel_ms']['hla']['cons_steps'],2), round(d['kernel_ms']['hla']['k1_cells'],2))
+print({k:round(v,1) for k,v in d['host_wall_ms']['cyp2d6'].items()}); print({k:round(v,1) for k,v in d['host_wall_ms']['hla'].items()})
+L=d['legs']
+for k,v in L.items():
+    print(k, {a:b for a,b in v.items() if a in ('value','unit','ms','ms_per_step','by_share_size','calls_equal_truth')} if isinstance(v,dict) else v)
+PY

@@ -40,3 +40,9 @@ def test_sample_line_and_two_rank_cohort_over_gloo():
         assert c["samples"] == 8 and c["records_gathered_per_pass"] == 8 * (2 + 1 + 18)              # HLA-A, HLA-B, CYP2D6, 18 variant genes per sample
         assert c["calls_equal_truth"]["hla"] == "16/16" and c["calls_equal_truth"]["cyp2d6"] == "8/8"
         assert c["calls_equal_truth"]["variant_genes_truth_among_reported"] == "144/144"
+        assert c["samples_per_s"] > 0 and c["rank0_host_seconds_per_pass"]["cyp2d6"] > 0
+    # shares that differ by one sample (7 samples over 2 ranks: 4 + 3): every record arrives once, every call equals the truth
+    line = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "cohort", "--cohort-samples", "7"], env={"SP_BENCH_BACKEND": "gloo"})
+    c = line["cohort"]
+    assert c["samples"] == 7 and c["records_gathered_per_pass"] == 7 * (2 + 1 + 18)
+    assert c["calls_equal_truth"]["hla"] == "14/14" and c["calls_equal_truth"]["cyp2d6"] == "7/7"

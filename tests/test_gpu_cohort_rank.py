@@ -75,3 +75,47 @@ def test_one_rank_of_the_cohort(oracle, pkg, gpu_ctx):
     table = shard.gather_calls(np.array(records, shard.CALL_DTYPE))
     assert len(table) == 32 * 3 + 4 * len(entries) and table["sample"].min() == 96 and table["sample"].max() == 127
     assert (np.diff(table["sample"]) >= 0).all()
+
+
+def test_all_256_samples_in_one_call_equal_the_single_calls(pkg, gpu_ctx):
+    """BASELINE configs[4] on one GPU: the 256 samples of the cohort in ONE sp_hla_diplotype_cohort and ONE sp_cyp_diplotype_cohort call (the samples in lockstep groups
+    on the context's streams) against every sample called alone (sp_hla_diplotype_genes on its own reads, sp_cyp_diplotype): the same alleles, statuses and consensus
+    sequences, sample by sample."""
+    import bench                                                                # (the repository root is on sys.path: tests/conftest.py)
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture()
+    db = fx.make_db(pkg, gpu_ctx)
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    cdb = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
+    scen = cr.scenarios(locus)
+    panel = bench.VariantPanel(pkg)
+    n = 256
+    share = bench.CohortShare(pkg, fx, locus, scen, panel, list(range(n)))
+    genes = list(range(len(fx.genes)))
+    R = gpu_ctx.upload(share.hla_reads)
+    k1 = db.realign_reads(R)
+    cohort, _ = db.diplotype_cohort(n, share.sample_of, genes, R, k1)
+    sample_of = np.array(share.sample_of)
+    cyp_sets = [gpu_ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *p) for p in share.cyp_payloads]
+    cyp_all = cdb.diplotype_cohort(cyp_sets)
+    hla_good = cyp_good = 0
+    for s in range(n):
+        idx = np.nonzero(sample_of == s)[0]
+        Rs = gpu_ctx.upload([share.hla_reads[i] for i in idx])
+        k1s = db.realign_reads(Rs)
+        for f in ("status", "best_allele", "gene", "nm", "unmapped", "mm2_score", "mm2_nm"):
+            assert (k1s[f] == k1[f][idx]).all(), (s, f)                         # a read's K1 record does not depend on the reads beside it
+        alone, _ = db.diplotype_genes(genes, Rs, k1s)
+        for g in genes:
+            a, b = cohort[s][g], alone[g]
+            assert (a[0].status, a[0].allele1, a[0].allele2, a[1], a[2]) == (b[0].status, b[0].allele1, b[0].allele2, b[1], b[2]), (s, g)
+            hla_good += all(bench.same_allele(fx, x, y) for x, y in zip(sorted([a[0].allele1, a[0].allele2]), share.hla_truth[(s, g)]))
+        call, cons, _labels = cdb.diplotype(cyp_sets[s])
+        c = cyp_all[s]
+        assert c[2] == 0 and (c[0].status, c[0].hap1, c[0].hap2, c[0].n_consensus, c[0].searches_gave_up) == (call.status, call.hap1, call.hap2, call.n_consensus, call.searches_gave_up), s
+        assert sorted(c[1]) == sorted(cons), s
+        cyp_good += sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(share.cyp_expected[s])
+        Rs.close()
+    print("256 samples: HLA calls equal to the truth", hla_good, "of", n * len(genes), "; CYP2D6", cyp_good, "of", n)
+    assert hla_good >= n * len(genes) - 2 and cyp_good == n                     # (the two HLA misses: tests/test_gpu_concordance.py, the CPU port makes the same calls)
