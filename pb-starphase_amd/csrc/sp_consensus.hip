@@ -429,39 +429,84 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             bool known = peek(&mm->valid) && peek(&mm->M) == M && peek(&mm->off) == off;
             if (known) known = __ballot(lane < nw && seen != A.cpack[lane]) == 0;
             ACT_T(0);
-            // Most reads have no error in their first L bases: the pattern then occurs in the text as it is, an occurrence has no edits, and the search's answer is the
-            // exact occurrence closest to the middle of the window (then the leftmost) -- found with a few word compares per start position instead of the L x M
-            // matrix (a placement was 89 us of the slowest wave of a CYP2D6 window launch with the reference's 100-base comparison, two thirds of the slowest-wave time
-            // of a sample's first batch).  Both are packed backwards here: pattern word k holds pattern bases L - 1 - 16 k downwards.
+            // The search by diagonal transition first (Landau-Vishkin for Sellers' matrix): for e = 0, 1, 2, ... the furthest pattern row every diagonal of the matrix
+            // reaches with at most e edits -- a slide along the equal bases (word compares on the two packed sequences) after the step from the neighbouring diagonals'
+            // reach with e - 1 -- until a diagonal that ends at a start position of the window reaches the pattern's last row: the occurrences with e edits, and e is the
+            // smallest number any has; among them the start closest to the middle of the window, then the leftmost, exactly what the matrix's last row says.  A read's
+            // first bases hold a handful of errors at most: one to four rounds of a few word compares instead of the L x M matrix (89 us of the slowest wave of a CYP2D6
+            // window launch with the reference's 100-base comparison -- two thirds of the slowest-wave time of a sample's first batch).  Both sequences are packed
+            // backwards here; a pattern with an N, more than LV_MAX edits or more diagonals than a lane holds eight of go to the matrix.
             int exact_c0 = -1;
-            if (!known && rv.np == nullptr && L >= 16) {
-                uint32_t pw = 0;
+            constexpr int LV_MAX = 12;
+            const int lv_nd = M - L + 1 + 2 * LV_MAX;                                    // diagonals d = x - LV_MAX (text column - pattern row), x = c * 64 + lane
+            if (!known && rv.np == nullptr && M >= L && lv_nd <= 8 * SP_WAVE) {
+                uint32_t* ppack = reinterpret_cast<uint32_t*>(A.score);                  // (the matrix's score bytes are not in use yet)
                 const int npw = (L + 15) >> 4;
-                if (lane < npw) for (int b = 0; b < 16; ++b) { const int u = lane * 16 + b; if (u < L) pw |= (uint32_t)(rbc(L - 1 - u) & 3) << (b << 1); }
-                const uint32_t tail_mask = (L & 15) ? ((1u << ((L & 15) << 1)) - 1u) : 0xFFFFFFFFu;
-                const int centre = off - window / 2;
-                unsigned long long key = ~0ull;
-                for (int j = len - off + lane; j <= M; j += SP_WAVE) {                // text position j (1-based, backwards from len) <-> start len - j
-                    const int s0 = j - L;                                            // 0-based index of the occurrence's first base in the backward text
-                    bool same = s0 >= 0;
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)pw, k);
-                        if (k < npw && same) {
-                            const int wi = (s0 >> 4) + k;
-                            const uint32_t have = __builtin_amdgcn_alignbit(A.cpack[wi + 1], A.cpack[wi], (uint32_t)(s0 & 15) << 1);
-                            const uint32_t diff = (have ^ want) & (k == npw - 1 ? tail_mask : 0xFFFFFFFFu);
-                            same = diff == 0;
+                if (lane < 10) {
+                    uint32_t pw = 0;
+                    if (lane < npw) for (int b = 0; b < 16; ++b) { const int u = lane * 16 + b; if (u < L) pw |= (uint32_t)(rbc(L - 1 - u) & 3) << (b << 1); }
+                    ppack[lane] = pw;
+                }
+                spw::wave_lds_sync();
+                const int npl = (lv_nd + SP_WAVE - 1) / SP_WAVE, centre = off - window / 2;
+                // slide: from pattern row r on diagonal dd along the equal bases (pattern base r against text base r + dd, both 0-based in the backward packing)
+                auto slide = [&](int r, int dd) {
+                    const int lim = L < M - dd ? L : M - dd;
+                    while (r < lim) {
+                        const int t = r + dd;
+                        const uint32_t pwd = __builtin_amdgcn_alignbit(ppack[(r >> 4) + 1], ppack[r >> 4], (uint32_t)(r & 15) << 1);
+                        const uint32_t twd = __builtin_amdgcn_alignbit(A.cpack[(t >> 4) + 1], A.cpack[t >> 4], (uint32_t)(t & 15) << 1);
+                        const uint32_t diff = pwd ^ twd;
+                        const int same = diff ? (__builtin_ctz(diff) >> 1) : 16;
+                        r += same;
+                        if (same < 16) break;
+                    }
+                    return r < lim ? r : lim;
+                };
+                int reach[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int x = c * SP_WAVE + lane, dd = x - LV_MAX;
+                    reach[c] = (c < npl && x < lv_nd && dd >= 0 && dd <= M) ? slide(0, dd) : -1;
+                }
+                for (int e = 0; e <= LV_MAX; ++e) {
+                    unsigned long long key = ~0ull;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int x = c * SP_WAVE + lane, dd = x - LV_MAX;
+                        if (c < npl && x < lv_nd && dd >= 0 && dd + L >= len - off && dd <= M - L && reach[c] >= L) {      // ends at text position dd + L <-> start len - dd - L (the starts off, off - 1, ... of the window)
+                            const int p = len - dd - L, dist = p > centre ? p - centre : centre - p;
+                            const unsigned long long kk = ((unsigned long long)dist << 22) | (unsigned long long)p;
+                            key = kk < key ? kk : key;
                         }
                     }
-                    if (same) {
-                        const int p = len - j, dist = p > centre ? p - centre : centre - p;
-                        const unsigned long long kk = ((unsigned long long)dist << 22) | (unsigned long long)p;
-                        key = kk < key ? kk : key;
-                    }
-                }
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
-                if (key != ~0ull) exact_c0 = (int)(key & ((1ull << 22) - 1));
+                    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
+                    if (key != ~0ull) { exact_c0 = (int)(key & ((1ull << 22) - 1)); break; }
+                    if (e == LV_MAX) break;
+                    int nxt[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        nxt[c] = -1;
+                        if (c < npl) {
+                            const int x = c * SP_WAVE + lane, dd = x - LV_MAX;
+                            int left = __shfl_up(reach[c], 1), up = __shfl_down(reach[c], 1);           // diagonals dd - 1 and dd + 1
+                            const int wrap_l = c > 0 ? __shfl(reach[c > 0 ? c - 1 : 0], SP_WAVE - 1) : -1, wrap_u = c + 1 < 8 ? __shfl(reach[c + 1 < 8 ? c + 1 : 7], 0) : -1;
+                            if (lane == 0) left = wrap_l;
+                            if (lane == SP_WAVE - 1) up = (c + 1 < npl) ? wrap_u : -1;
+                            int best = reach[c] >= 0 ? reach[c] + 1 : -1;                               // a mismatch on the diagonal
+                            if (up >= 0 && up + 1 > best) best = up + 1;                                // a pattern base without a text base (from dd + 1, one row down)
+                            if (left > best) best = left;                                               // a text base without a pattern base (from dd - 1, same row)
+                            if (x < lv_nd && dd <= M && best >= 0) {
+                                const int lim = L < M - dd ? L : M - dd;
+                                nxt[c] = slide(best < lim ? best : lim, dd);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) reach[c] = nxt[c];
+                }
+                spw::wave_lds_sync();
             }
             if (known) d.c0 = m_c0;
             else if (exact_c0 >= 0) {
