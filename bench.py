@@ -42,7 +42,7 @@ import __graft_entry__ as ge  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2    # 256 CU x 4 SIMD-32 x one wave-instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md); sp_microbench measures it
-COUNTER_DIR = os.path.join(ROOT, "profiles", "r03")
+COUNTER_DIR = os.path.join(ROOT, "profiles", "r04")
 
 
 def spawn_ranks(n, argv):
@@ -843,7 +843,7 @@ def main():
         line["cpu_baseline"] = None
     print(json.dumps(line), flush=True)
     if stale:                                                 # (the blocks they feed were left out of the line above)
-        print("bench.py: the counter files " + ", ".join(stale) + " were collected on other kernel sources: re-run profiles/scripts/k1_counters.sh", file=sys.stderr)
+        print("bench.py: the counter files " + ", ".join(stale) + " were collected on other kernel sources: re-run profiles/run_rocprof.sh and copy the two files into profiles/r04", file=sys.stderr)
 
 
 if __name__ == "__main__":
