@@ -257,7 +257,7 @@ int sp_launch_affine(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const 
 // another and from both ends of the alignment on the window sequence, no ambiguous base in either sequence -- has the same optimum under the two-piece affine scores
 // as under unit costs (a lone mismatch or one-base gap is spelled the same way by both, and an edit that far from an end is not clipped: -4 or -8 against at
 // least +16): its numbers are the unit-cost numbers, its score a * matches - b * mismatches - (q + e) * gap bases.  (Measured on 1,242 K1 pairs: every mapping
-// with all distances >= 12 had identical numbers; 16 is used.)  The others -- a third of the K1 winners -- go through the DP above.
+// with all distances >= 12 had identical numbers; 16 is used.)  The others -- one in nine of the K1 winners -- go through the DP above, over the rows around their clustered edits (below).
 // The cells are run again with their traceback (sp_cells_kernel<TRACE>) for the positions of the edits; a cell whose second run differs from the alignment the
 // caller holds takes the DP as well.
 // ------------------------------------------------------------------------------------------------------------------------------

@@ -1396,9 +1396,8 @@ int32_t cyp_part_a(sp_ctx* ctx, const sp_cyp_problem* pr, const sp_seqset* reads
     cc.min_count = pr->min_consensus_count; cc.min_af = pr->min_consensus_fraction; cc.dual_max_ed_delta = pr->dual_max_ed_delta;
     cc.no_retry_ladder = ctx->cons_retry_ladder ? 0 : 1;
     cc.allow_early_termination = 1; cc.allow_dual = 1; cc.offset_window = 100; cc.offset_compare_length = 100;      // caller.rs:144-159: compare 100 bases, window 2 x 50
-    // (caller.rs:145-160 asks for 100 bases in a window of 100 with offsets 50 behind the expected start: under THIS library's placement rule -- Sellers' search, the
-    //  whole pattern must fit between the start and the offset, what does not fit counts as edits -- a 100-base pattern never fits in front of a read that starts 50
-    //  bases before its offset and the search drifts to the far end of the window (measured: every real-shape sample splits into more than 16 groups); 64 bases do)
+    // (the reference's own numbers: the placement rule -- the read is placed when the consensus reaches offset + compare length, the end of the comparison on the consensus is
+    //  free -- makes a 100-base pattern in a window of 100 work as written: sp_consensus.hip activate_late, oracle/consensus.c find_start)
     m.n_in = raw.n;
     m.levels[0] = &hpc; m.levels[1] = &raw; m.offs[0] = hoff.data(); m.offs[1] = boff.data();
     m.pp.n_levels = 2; m.pp.n = m.n_in; m.pp.levels = m.levels; m.pp.offsets = m.offs; m.pp.seeds = seeds.data(); m.pp.cfg = cc;
