@@ -45,6 +45,14 @@ VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2    # 256 CU x 4 SIMD-32 x one wave-in
 COUNTER_DIR = os.path.join(ROOT, "profiles", "r04")
 
 
+def cyp_persistent():
+    """SP_BENCH_CYP_PERSISTENT=1: the contexts that run CYP2D6 consensus chains use the library's persistent consensus kernels (sp_ctx_set_option "k8_persistent": all
+    workgroups of a batch resident, hand-overs through memory instead of a launch pair per step).  Off by default here as in the library: the chain itself is a third faster
+    beside the HLA half (cons_steps 27 -> 19.5 ms) but the resident workgroups take the CUs from everything else, and the line as a whole does not move (headline +1.5 %,
+    cohort -7 %: profiles/r04/k8_persistent_coherent_ab.txt)."""
+    return int(os.environ.get("SP_BENCH_CYP_PERSISTENT", "0"))
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks as child processes BEFORE this process touches the GPU (never
     re-exec a process that has), wait for them, fail if any of them fails.  Rank 0's stdout is the JSON line."""
@@ -441,6 +449,7 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
         cfg2, gd2 = cdb_source
         ctx2 = pkg.Context(ctx_device)
         cdb2 = pkg.ffi.CypDb(ctx2, cfg2, gd2, locus.sequence, locus.start)
+        ctx2.set_option("k8_persistent", cyp_persistent())
         for sh in shares:
             sh.beside = (ctx2, cdb2)
     # every rank makes the same number of gathers per pass, whatever its share: shares differ by one sample when the cohort does not divide by the ranks (and a rank
@@ -617,8 +626,7 @@ def main():
     # ------------------------------------------------------------------------------------------------ the sample: HLA-A / -B + CYP2D6, a new one every step
     ctx_c = pkg.Context(device_index)                       # the CYP2D6 half runs beside the HLA half on a context (stream, pools) of its own
     cdb_c = pkg.ffi.CypDb(ctx_c, cfg, gene_def, locus.sequence, locus.start)
-    if os.environ.get("SP_BENCH_CYP_PERSISTENT"):           # (an experiment switch: the persistent consensus kernels for the CYP2D6 context only)
-        ctx_c.set_option("k8_persistent", int(os.environ["SP_BENCH_CYP_PERSISTENT"]))
+    ctx_c.set_option("k8_persistent", cyp_persistent())     # the CYP2D6 chain as persistent kernels: this process has the device to itself
     if os.environ.get("SP_BENCH_MM2_RESCORE"):              # (an experiment switch: what the re-scored numbers of K1 / K2 cost the step)
         ctx.set_option("mm2_rescore", int(os.environ["SP_BENCH_MM2_RESCORE"]))
     genes = list(range(len(fx.genes)))
@@ -661,13 +669,16 @@ def main():
         written by the kernels themselves: sp_consensus.hip, CSearch::step_ticks / gap_ticks / ticks)"""
         ms = lambda name: c.profile_get(name)[2] / 1e5 / max(1, args.steps)
         steps = c.profile_get("cons_path_steps")[2] / max(1, args.steps)
-        out = {"dependent_steps": steps, "launches_per_step": 2, "step_kernel_ms": ms("cons_path_step_ticks"), "control_kernel_ms": ms("cons_path_control_ticks"),
+        persistent = c.profile_get("cons_persistent_batches")[2] > 0
+        out = {"mode": "persistent kernels: two launches per batch, the step and control workgroups of a problem hand over through one word each in memory" if persistent
+                       else "a launch pair per step", "dependent_steps": steps, "launches_per_step": 0 if persistent else 2,
+               "step_kernel_ms": ms("cons_path_step_ticks"), "control_kernel_ms": ms("cons_path_control_ticks"),
                "between_kernels_ms": ms("cons_path_gap_ticks"), "chain_ms": c.profile_get("cons_steps")[0] / max(1, args.steps)}
         if steps > 0:
             out["per_step_us"] = {"step_kernel": 1e3 * out["step_kernel_ms"] / steps, "control_kernel": 1e3 * out["control_kernel_ms"] / steps,
                                   "between_kernels_per_boundary": 1e3 * out["between_kernels_ms"] / (2 * steps)}
-        out["note"] = ("the chain is latency bound: every step is step kernel -> control kernel -> next step kernel on one stream; MI355X_MICROARCH.md puts a dependent "
-                       "same-stream kernel boundary at 1.45 us")
+        out["note"] = ("the chain is latency bound: every step is step body -> control body -> next step body; as a launch pair per step each arrow is a dependent same-stream "
+                       "kernel boundary (MI355X_MICROARCH.md: 1.45 us on an idle device), in persistent mode a write-through store + drain + flag and a poll (handoff-flag: 1.3-5 us)")
         return out
     crit = {"kernel": "cons_step_kernel + cons_control_kernel (K8, the consensus search)", "cyp2d6": critical_path(ctx_c), "hla": critical_path(ctx)}
     ms_cells, launches, _cells_all = ctx.profile_get("k1_cells")
@@ -720,7 +731,7 @@ def main():
             extra = []
             for k in range(1, K):
                 ch, cc = pkg.Context(device_index), pkg.Context(device_index)
-                ch.set_option("hla_split_genes", 0); cc.set_option("hla_split_genes", 0)
+                ch.set_option("hla_split_genes", 0); cc.set_option("hla_split_genes", 0); cc.set_option("k8_persistent", cyp_persistent())
                 extra.append((ch, fx.make_db(pkg, ch), cc, pkg.ffi.CypDb(cc, cfg, gene_def, locus.sequence, locus.start)))
             ctx.set_option("hla_split_genes", 0); ctx_c.set_option("hla_split_genes", 0)
 
@@ -806,7 +817,7 @@ def main():
         "upload": {"per_step_bytes": int(len(samples[0].payload[0]) + len(cyp_samples[0].payload[0])), "alone": t_up,
                    "note": "inside `value` every step uploads a new sample (4-bit SEQ bytes, sp_seqset_upload_async); `alone` = one synchronous upload of the HLA half"},
         "legs": legs or None,
-        "context": ctx.info(),          # sp_ctx_get_info: the hardware queues the streams of the run were mapped onto (this script exports GPU_MAX_HW_QUEUES=16 before torch initialises HIP)
+        "context": dict(ctx.info(), cyp2d6_contexts_k8_persistent=cyp_persistent()),          # sp_ctx_get_info: the hardware queues the streams of the run were mapped onto (this script exports GPU_MAX_HW_QUEUES=16 before torch initialises HIP)
     }
     if cb is not None:
         # the GPU on exactly the reads the CPU leg saw: the calls of the two have to be the same, for both loci

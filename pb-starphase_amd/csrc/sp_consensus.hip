@@ -367,13 +367,21 @@ struct ActScratch {             // per wave
 
 // consensus i of a node as a step kernel sees it: the LDS copy of [w0, w0 + CWIN + CW), one overriding base (the base a child
 // appends), the node's committed bases elsewhere
+// What the control step and the step workgroups of a problem hand each other in PERSISTENT mode crosses no kernel boundary, so it crosses the caches explicitly: the
+// writer stores it write-through (agent-scope relaxed atomic stores: `sc1`, the line leaves the XCD's L2), waits for its stores (s_waitcnt vmcnt(0)) and only then raises
+// the problem's word; the reader loads it past its CU's L1 (`sc1` loads).  No L2 write-back and no invalidate per step (an agent-scope release / acquire pair cost 7 us
+// of every hand-over).  In launch-pair mode the same accessors are harmless: an `sc1` load is served by L2 like a plain one.
+template <class T> __device__ __forceinline__ T coh_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void coh_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void put(T* p, T v, bool coh) { if (coh) coh_store(p, v); else *p = v; }       // (a write-through store drops the line from L2: only where it is needed)
+
 struct ConsAccess {
     const uint8_t* win; int w0; const uint8_t* C; int cap, split_at, i, ov_pos, ov_base;
     __device__ __forceinline__ int at(int pos) const {
         if (pos == ov_pos) return ov_base;
         const int y = pos - w0;
         if ((unsigned)y < (unsigned)(CWIN + CW)) return (int)win[y];
-        return (int)((i == 1 && pos < split_at) ? C[pos] : C[(size_t)i * cap + pos]);
+        return (int)coh_load((i == 1 && pos < split_at) ? &C[pos] : &C[(size_t)i * cap + pos]);      // (bases the control step wrote: rarely outside the staged window)
     }
 };
 
@@ -649,9 +657,15 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
     __shared__ uint32_t rwin[CWAVES][2][RWORDS + 2];      // packed read window of the wave (+ N plane)
     __shared__ uint32_t cpk[2][(CWIN + CW) / 16 + 2];     // the same bases, 2 bits each (runs are compared 16 bases at a time); the window starts at word CWIN / 16
     __shared__ ActScratch act[CWAVES];
+    __shared__ CWork wk_s;                                // persistent mode: the work order as the control step published it
     const int pi = block_problem<MAXP>(B);
     const ConsParams P = B.p[pi];
-    const CWork* Wp = P.work;
+    const bool coh = B.sync != nullptr;                   // persistent mode: no kernel boundary between the control step's stores and these loads
+    if (coh) {
+        for (int x = threadIdx.x; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)&wk_s)[x] = coh_load(((const uint32_t*)P.work) + x);
+        __syncthreads();
+    }
+    const CWork* Wp = coh ? &wk_s : P.work;
     const int mode = Wp->mode;
     if (Wp->done || mode == M_NONE) return;
     if (B.step_t && threadIdx.x == 0) atomicMin(&B.step_t[2 * pi], (unsigned long long)wall_clock64());
@@ -671,7 +685,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         const int i = x / (CWIN + CW), y = x % (CWIN + CW), pos = w0 + y;
         uint8_t v = 0;
         if (pos >= T) v = (pos - T < n) ? Wp->spec[i][pos - T] : 0;
-        else if (pos >= 0) v = (i == 1 && dual_in && pos >= split_at) ? Cn[(size_t)P.cs + pos] : Cn[pos];
+        else if (pos >= 0) v = coh_load((i == 1 && dual_in && pos >= split_at) ? &Cn[(size_t)P.cs + pos] : &Cn[pos]);
         cwin[i][y] = v;
     }
     __syncthreads();
@@ -844,8 +858,8 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
                 if (kb0 >= 0) vote(e0, e1, kdual, 0, T + 1, k);
                 if (kdual && kb1 >= 0) vote(e1, e0, kdual, 1, T + 1, k);
                 const int grow = read_cost(e0, e1, kdual) - base_cost;
-                const int len0 = kb0 >= 0 ? T + 1 : (go0 ? T : Wp->in_slot * 0 + P.nodes[node].len[0]);
-                const int len1 = kb1 >= 0 ? T + 1 : (go1 ? T : P.nodes[node].len[1]);
+                const int len0 = kb0 >= 0 ? T + 1 : (go0 ? T : coh_load(&P.nodes[node].len[0]));
+                const int len1 = kb1 >= 0 ? T + 1 : (go1 ? T : coh_load(&P.nodes[node].len[1]));
                 const int extra = final_extra(e0, e1, kdual, len0, len1);
                 if (lane == 0) { if (grow) atomicAdd(&lc[k], (uint32_t)grow); if (extra) atomicAdd(&lr[k], (uint32_t)extra); }
                 const int kn = Wp->kid_node[k];
@@ -1057,7 +1071,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
             }
         }
         {
-            const int len0 = go0 || mode == M_INIT ? T + n : P.nodes[node].len[0], len1 = go1 ? T + n : P.nodes[node].len[1];
+            const int len0 = go0 || mode == M_INIT ? T + n : coh_load(&P.nodes[node].len[0]), len1 = go1 ? T + n : coh_load(&P.nodes[node].len[1]);
             const int extra = final_extra(d0, d1, dualrun, len0, len1);
             if (extra && lane == 0) atomicAdd(&lr[n], (uint32_t)extra);
         }
@@ -1199,6 +1213,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     const int pi = blockIdx.x;
     const ConsParams P = B.p[pi];
     const int tid = threadIdx.x;
+    const bool coh = B.sync != nullptr;                   // persistent mode: what the step workgroups read next is stored write-through, their words are fetched where the atomics ran
     const long long tk0 = wall_clock64();
     // first round of loads, all independent: the heads of the nodes, the work order, the search state, the per-length counters
     // (only the nodes in use travel whole between memory and LDS: a node is 1.7 KB at 256-column windows; a linear search holds one or two)
@@ -1241,9 +1256,9 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                     const bool exact = c < ev;
                     const int e = exact ? (c / u) * (CW + 1) + c % u : c - 2 * ev;
                     unsigned long long* src = exact ? B.PV + blk * 2 * (CW + 1) + e : B.PL + blk * 2 * CW + e;
-                    const unsigned long long sum = *src;
+                    const unsigned long long sum = coh ? __hip_atomic_exchange(src, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
                     if (sum) {
-                        *src = 0ull;
+                        if (!coh) *src = 0ull;
                         uint32_t* dst = exact ? acc + e * 5 : acc + QSV + e * 4;
 #pragma unroll
                         for (int f = 0; f < 4; ++f) dst[f] = (uint32_t)((sum >> (16 * f)) & 0xFFFFull);
@@ -1253,8 +1268,8 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                     if (c < 2 * ev) { const int cc = c - ev, e = (cc / u) * (CW + 1) + cc % u; src = B.PE + blk * 2 * (CW + 1) + e; dst = acc + e * 5 + 4; }
                     else if (c < 2 * ev + el + u) { const int e = c - 2 * ev - el; src = B.PC + blk * (CW + 1) + e; dst = acc + QSV + QSL + e; }
                     else { const int e = c - 2 * ev - el - u; src = B.PR + blk * (CW + 1) + e; dst = acc + QSV + QSL + (CW + 1) + e; }
-                    const uint32_t sum = *src;
-                    if (sum) { *src = 0u; *dst = sum; }
+                    const uint32_t sum = coh ? __hip_atomic_exchange(src, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+                    if (sum) { if (!coh) *src = 0u; *dst = sum; }
                 }
             }
         } else {
@@ -1322,7 +1337,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             }
             for (int col = lane; col < a; col += SP_WAVE) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wk.go[i]) Cb[((size_t)wk.node * 2 + i) * P.cs + T + col] = wk.spec[i][col];
+                for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wk.go[i]) put(&Cb[((size_t)wk.node * 2 + i) * P.cs + T + col], wk.spec[i][col], coh);
             }
             // a replay re-reads columns whose costs are on the tape already: it only brings the state (and the votes) of column T + a
             if (!wk.replay) {
@@ -1589,24 +1604,32 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                 uint8_t* dst = P.C + ((size_t)kn * 2 + i) * P.cs;
                 const int whole = copy_len >> 4, tail = copy_len & 15;                  // (the rows are 16-byte aligned)
                 for (int y = tid; y < whole + (tail ? 1 : 0); y += blockDim.x) {
-                    uint4 v = src[y];
+                    uint4 v;
+                    if (coh) {                                                          // (the parent's bytes were stored write-through; 8 bytes per access both ways)
+                        const unsigned long long* s8 = reinterpret_cast<const unsigned long long*>(src + y);
+                        const unsigned long long lo = coh_load(s8), hi = coh_load(s8 + 1);
+                        v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32); v.z = (uint32_t)hi; v.w = (uint32_t)(hi >> 32);
+                    } else v = src[y];
                     if (y == whole && wk.kid_base[k][i] >= 0) reinterpret_cast<uint8_t*>(&v)[tail] = (uint8_t)wk.kid_base[k][i];   // the child's own base lies in the last word
-                    reinterpret_cast<uint4*>(dst)[y] = v;
+                    if (coh) {
+                        unsigned long long* d8 = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint4*>(dst) + y);
+                        coh_store(d8, (unsigned long long)v.x | ((unsigned long long)v.y << 32)); coh_store(d8 + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32));
+                    } else reinterpret_cast<uint4*>(dst)[y] = v;
                 }
-                if (tid == 0 && tail == 0 && wk.kid_base[k][i] >= 0) dst[copy_len] = (uint8_t)wk.kid_base[k][i];
+                if (tid == 0 && tail == 0 && wk.kid_base[k][i] >= 0) put(&dst[copy_len], (uint8_t)wk.kid_base[k][i], coh);
             }
         }
     }
     if (tid == 0) {
         const long long tk4 = wall_clock64(); ss.ticks[0] += tk1 - tk0; ss.ticks[1] += tk2 - tk1; ss.ticks[2] += tk3 - tk2; ss.ticks[3] += tk4 - tk3;
         if (B.step_t) {
-            const long long st0 = (long long)B.step_t[2 * pi], st1 = (long long)B.step_t[2 * pi + 1];
+            const long long st0 = (long long)coh_load(&B.step_t[2 * pi]), st1 = (long long)coh_load(&B.step_t[2 * pi + 1]);
             if (st1 > 0 && st0 <= st1) {
                 ss.step_ticks += st1 - st0;
                 if (ss.last_end > 0 && st0 >= ss.last_end) ss.gap_ticks += st0 - ss.last_end;
                 if (tk0 >= st1) ss.gap_ticks += tk0 - st1;
             }
-            B.step_t[2 * pi] = ~0ull; B.step_t[2 * pi + 1] = 0ull;
+            put(&B.step_t[2 * pi], ~0ull, coh); put(&B.step_t[2 * pi + 1], 0ull, coh);
             ss.last_end = tk4;
         }
     }
@@ -1615,13 +1638,13 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     if (tid == 0) { ss.ticks[0] += 100 * ts_iters - (tk1 - tk0); ss.ticks[1] += ts_pick - (tk2 - tk1); ss.ticks[3] += ts_block - (wall_clock64() - tk3); }
 #endif
     __syncthreads();
-    for (int x = tid; x < NQ * NODE_HEAD_WORDS; x += blockDim.x)
-        ((uint32_t*)&P.nodes[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS] = ((const uint32_t*)&nh[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS];
+    for (int x = tid; x < NQ * NODE_HEAD_WORDS; x += blockDim.x)          // (the step workgroups read the nodes' lengths: write-through)
+        put(&((uint32_t*)&P.nodes[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS], ((const uint32_t*)&nh[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS], coh);
     for (int x = tid; x < NQ * NODE_TAPE_WORDS; x += blockDim.x) {
         const int k = x / NODE_TAPE_WORDS, w = x % NODE_TAPE_WORDS;
         if (tape_word_used(nh[k], w)) ((uint32_t*)&P.nodes[k])[NODE_HEAD_WORDS + w] = ((const uint32_t*)&nh[k])[NODE_HEAD_WORDS + w];
     }
-    for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)P.work)[x] = ((const uint32_t*)&wk)[x];
+    for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) put(&((uint32_t*)P.work)[x], ((const uint32_t*)&wk)[x], coh);
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)P.srch)[x] = ((const uint32_t*)&ss)[x];
     for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)P.processed)[x] = ((const uint32_t*)proc)[x];
     if (tid == 0 && B.prog) {
@@ -1664,12 +1687,13 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_p
         if (threadIdx.x == 0) go_on = persist_wait(sy + 0, k - 1, abort_word) ? 1 : 0;
         __syncthreads();
         if (!go_on) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // what the control step wrote (work order, consensus bytes, cleared vote words)
-        if (B.p[pi].work->done) break;
+        // (what the control step wrote -- work order, node lengths, consensus bytes -- is loaded past the L1, the vote words it cleared were cleared where the atomics run:
+        //  no acquire; a wave's states are its own from step to step)
+        if (coh_load(&B.p[pi].work->done)) break;
         cons_step_body<MAXP>(B);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                      // this wave's states and vote words, before the workgroup reports in
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's atomic adds have been acknowledged before the workgroup reports in
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(sy + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sy + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1686,12 +1710,12 @@ __global__ void __launch_bounds__(1024) cons_control_persist_kernel(ConsBatchT<M
         if (threadIdx.x == 0) go_on = persist_wait(sy + 1, nb * k, abort_word) ? 1 : 0;
         __syncthreads();
         if (!go_on) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // (this CU's L1 only: the workgroup's own state of the step before comes from L2, not from stale lines)
         cons_control_body<MAXP>(B);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        const bool done = B.p[pi].work->done != 0;
-        if (threadIdx.x == 0) __hip_atomic_store(sy + 0, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // every thread's write-through stores have been acknowledged ...
+        __syncthreads();                                                        // ... before one of them raises the word
+        const bool done = coh_load(&B.p[pi].work->done) != 0;
+        if (threadIdx.x == 0) __hip_atomic_store(sy + 0, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done) break;
     }
     if (threadIdx.x == 0 && B.prog && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
