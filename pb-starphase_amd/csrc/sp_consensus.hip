@@ -351,7 +351,7 @@ __device__ __noinline__ int find_start_diag2(int pa, int pb, int L_, int M_, int
 }
 
 constexpr int ACT_CONS = 512;   // consensus bases a wave packs while a late read catches up (offset_window + slack)
-constexpr int ACT_READ = 640;   // read bases it keeps (catch-up length + band + edits)
+constexpr int ACT_READ = 2 * (CW + 1) > 640 ? ((2 * (CW + 1) + 63) / 64) * 64 : 640;   // read bases it keeps (catch-up length + band + edits; the edit-count profile of a window shares the bytes)
 struct ActScratch {             // per wave
     uint8_t rcache[ACT_READ];
     uint32_t cpack[ACT_CONS / 16 + 2];
