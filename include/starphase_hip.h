@@ -78,8 +78,9 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * of the other samples already fill the gaps (sp_cyp_diplotype follows the same switch: with 1 it places the regions of interest on the consensuses
  * for its weights on a helper stream while it types the consensuses).  The calls are the same either way.  "cons_retry_ladder" (default 0: the reference has no such rule): 1 makes sp_cyp_diplotype* run
  * its multi-way consensus with the retry of searches that give up (sp_cons_config.no_retry_ladder = 0, see sp_consensus_priority); sp_cyp_call.gave_up says whether a search of the call gave up.
- * "mm2_rescore" (default 1): sp_hla_realign_reads, sp_cyp_find_regions and sp_cyp_weight_segments also report every mapping they return re-scored the reference's
- * way (fields mm2_*; sp_affine_rescore_batch); 0 leaves those fields zero and saves the extra launches; 2 = as 1, but every mapping with edits that do not stand alone
+ * "mm2_rescore" (default 1): sp_hla_realign_reads, sp_hla_type_consensus / sp_hla_score_consensus and sp_cyp_find_regions also report every mapping they return re-scored
+ * the reference's way (fields mm2_*; sp_affine_rescore_batch), and the weights of sp_cyp_weight_segments / sp_cyp_diplotype* are taken from the re-scored placement wherever it is
+ * within 16 (edits + unmapped bases) of its segment's smallest; 0 leaves the fields zero, the weights on unit-cost counts, and saves the extra launches; 2 = as 1, but every mapping with edits that do not stand alone
  * takes the DP over all of its rows instead of over the rows around those edits (a check of the shortcut, an order of magnitude slower).
  * "k8_persistent" (default 0; also the environment variable SP_K8_PERSISTENT): 1 runs consensus batches whose problems have at most 1,024 reads each as two persistent
  * kernels (step workgroups and one control workgroup per problem, handing over through device-scope release / acquire words) instead of a launch pair per step --
@@ -175,8 +176,8 @@ int32_t sp_align_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
  * diagonal b_pos - a_pos the library's own cell aligned it on) the banded Smith-Waterman optimum under those scores on `band` (64 or 256) diagonals around diag,
  * with the forward decisions and end rules of the restatement's DP (oracle/affine.c is the CPU statement): score, NM = mismatches + gap bases + ambiguous bases,
  * and the half-open spans on both sequences; score 0 = nothing aligns.  On the audited pair classes the numbers equal the minimap2 restatement's
- * (tests/test_oracle_affine.py).  sp_hla_realign_reads, sp_hla_score_consensus / sp_hla_type_consensus, sp_cyp_find_regions and sp_cyp_weight_segments report
- * them beside the library's own counts (fields mm2_*). */
+ * (tests/test_oracle_affine.py).  sp_hla_realign_reads, sp_hla_score_consensus / sp_hla_type_consensus, and sp_cyp_find_regions report
+ * them beside the library's own counts (fields mm2_*); sp_cyp_weight_segments takes its weights from them near a segment's minimum. */
 typedef struct { int32_t a, b, q, e, q2, e2, sc_ambi; } sp_affine_opts;           /* map-hifi: 1, 4, 6, 2, 26, 1, 1 */
 typedef struct { int32_t score, nm, a_start, a_end, b_start, b_end; } sp_affine_aln;
 int32_t sp_affine_rescore_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const sp_pair* pairs, uint64_t n_pairs, const sp_affine_opts* opts,
@@ -364,7 +365,9 @@ int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32
  * Replaces weight_sequence (src/cyp2d6/chaining.rs:28-103) for a batch of read segments: every allowed consensus
  * (allowed[c] = label.is_allowed_label()) is placed on every segment; ed[s][c] = nm + un-mapped segment bases,
  * ov[s][c] = 1 - clipped consensus fraction, defaults (segment length, 0.0); kept[s] = 0 when the reference returns the
- * empty vector (best penalised fraction > 0.05). */
+ * empty vector (best penalised fraction > 0.05).  With the context option "mm2_rescore" (default 1) a placement whose nm + un-mapped bases are within 16 of the
+ * segment's smallest over the allowed consensuses enters with the reference's numbers -- re-scored with minimap2's two-piece affine scores on 256 diagonals
+ * (sp_affine_rescore_batch): its NM, spans and clips --, the others with the unit-cost count (a lower bound of the other). */
 int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensus, const uint8_t* allowed, const sp_seqset* segments,
                                uint64_t* ed, double* ov, uint8_t* kept);
 

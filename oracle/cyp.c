@@ -385,12 +385,29 @@ int osp_cyp_weight_sequence(const uint8_t* seq, int seq_len, int n_cons, const u
     const double maximum_allowed_ed = 0.05;
     double min_ed_frac = 1.0;
     for (int c = 0; c < n_cons; ++c) { out_ed[c] = (uint64_t)seq_len; out_ov[c] = 0.0; }
+    /* the placements of the segment on every consensus that counts (the library's alignment contract), then -- the rule of sp_cyp.hip cyp_pick_near_min -- those
+     * within OSP_CYP_K4_NEAR of the smallest edits + unmapped bases re-scored the reference's way: minimap2's two-piece affine scores on the 256 diagonals around
+     * the placement (osp_affine_local: the segment is minimap2's target, the consensus its query), i.e. its NM, its clipping, its spans */
+    osp_aln* als = (osp_aln*)calloc((size_t)(n_cons > 0 ? n_cons : 1), sizeof(osp_aln));
+    int64_t best = INT64_MAX;
     for (int c = 0; c < n_cons; ++c) {
         if (!allowed[c]) continue;                                      /* Unknown / FalseAllele labels are skipped (:52-55) */
         int diag = 0, votes = osp_anchor(cons[c], cons_len[c], seq, seq_len, &diag);      /* seq_pos - cons_pos */
         if (votes < OSP_CYP_MIN_VOTES) continue;
-        osp_aln al;
-        if (!osp_wfa_retry(cons[c], cons_len[c], seq, seq_len, diag, OSP_MAX_ED, &al, NULL, NULL)) continue;
+        if (!osp_wfa_retry(cons[c], cons_len[c], seq, seq_len, diag, OSP_MAX_ED, &als[c], NULL, NULL)) { als[c].ok = 0; continue; }
+        const int64_t ms = (int64_t)als[c].nm + (seq_len - (als[c].b_end - als[c].b_start));
+        if (ms < best) best = ms;
+    }
+    for (int c = 0; c < n_cons; ++c) {
+        if (!allowed[c] || !als[c].ok) continue;
+        osp_aln al = als[c];
+        if ((int64_t)al.nm + (seq_len - (al.b_end - al.b_start)) <= best + OSP_CYP_K4_NEAR) {
+            const osp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
+            osp_affine_out r;
+            const int d_mid = ((al.b_start - al.a_start) + (al.b_end - al.a_end)) / 2;                /* seq_pos - cons_pos along the placement */
+            osp_affine_local(seq, seq_len, cons[c], cons_len[c], -d_mid, OSP_WIDE_BAND, &ao, &r);
+            if (r.score > 0) { al.nm = r.nm; al.a_start = r.q_start; al.a_end = r.q_end; al.b_start = r.t_start; al.b_end = r.t_end; }
+        }
         uint64_t nm = (uint64_t)al.nm, unmapped = (uint64_t)(seq_len - (al.b_end - al.b_start));
         uint64_t clipped_start = (uint64_t)al.a_start, clipped_end = (uint64_t)(cons_len[c] - al.a_end);
         uint64_t match_score = nm + unmapped;
@@ -401,6 +418,7 @@ int osp_cyp_weight_sequence(const uint8_t* seq, int seq_len, int n_cons, const u
             if (sc < min_ed_frac) min_ed_frac = sc;
         }
     }
+    free(als);
     return min_ed_frac <= maximum_allowed_ed;
 }
 

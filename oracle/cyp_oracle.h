@@ -55,6 +55,7 @@ int  osp_cyp_find_best_chain_pair(const osp_chain_problem* p, osp_chain_result* 
 
 #define OSP_CYP_TOPK      4          /* placements tried per (template, read) */
 #define OSP_CYP_MIN_VOTES 4          /* an anchor needs this many 16-mer votes */
+#define OSP_CYP_K4_NEAR 16           /* weight_sequence: placements within this many (edits + unmapped bases) of the segment's smallest are re-scored the reference's way */
 typedef struct { int32_t template_idx, start, end, seq_len, nm, unmapped, clip_start, clip_end; } osp_region_hit;   /* AlleleMapping */
 int  osp_cyp_weight_sequence(const uint8_t* seq, int seq_len, int n_cons, const uint8_t* const* cons, const int32_t* cons_len,
                              const uint8_t* allowed, uint64_t* out_ed, double* out_ov);

@@ -679,7 +679,57 @@ static inline double cyp_score(int seq_len, int nm, int unmapped, bool penalize)
 }
 
 static void cyp_weights_from_alns(uint32_t C, const int32_t* cons_len, const uint8_t* allowed, uint32_t n_segments, const int32_t* seg_len, const std::vector<sp_aln>& alns,
-                                  uint64_t* ed, double* ov, uint8_t* kept);
+                                  uint64_t* ed, double* ov, uint8_t* kept, const sp_affine_aln* af = nullptr);
+
+// The placements that can decide a segment's weights -- those whose edits + unmapped bases are within CYP_K4_NEAR of the segment's smallest over the consensuses that
+// count -- carry the reference's numbers: the placement re-scored with minimap2's two-piece affine scores on the 256 diagonals around it (sp_rescore_mappings: the rows
+// around the clustered edits only; oracle/cyp.c osp_cyp_weight_sequence states the same rule with the DP over all rows).  A segment against the consensus of another
+// gene copy is hundreds of clustered edits away and never near the minimum: those keep the unit-cost count, a lower bound of the other.
+constexpr int CYP_K4_NEAR = 16;
+struct K4Pick { uint32_t a, b; const sp_aln* al; sp_affine_aln* out; };
+// grid alns[s * C + c]: segment s is sequence b0 + s of the segment set, consensus c sequence a_of_c[c] (or a0 + c) of the consensus set; af: the same grid, zeroed here
+static void cyp_pick_near_min(uint32_t C, const uint8_t* allowed, uint32_t n_segments, const int32_t* seg_len, const std::vector<sp_aln>& alns, std::vector<sp_affine_aln>& af,
+                              uint32_t a0, const int32_t* a_of_c, uint32_t b0, std::vector<K4Pick>& picks) {
+    af.assign((size_t)n_segments * C, sp_affine_aln{});
+    for (uint32_t s = 0; s < n_segments; ++s) {
+        int64_t best = INT64_MAX;
+        for (uint32_t c = 0; c < C; ++c) {
+            const sp_aln& al = alns[(size_t)s * C + c];
+            if (!allowed[c] || !al.ok) continue;
+            best = std::min<int64_t>(best, (int64_t)al.nm + (seg_len[s] - (al.b_end - al.b_start)));
+        }
+        if (best == INT64_MAX) continue;
+        for (uint32_t c = 0; c < C; ++c) {
+            const sp_aln& al = alns[(size_t)s * C + c];
+            if (!allowed[c] || !al.ok || (int64_t)al.nm + (seg_len[s] - (al.b_end - al.b_start)) > best + CYP_K4_NEAR) continue;
+            picks.push_back(K4Pick{ a_of_c ? (uint32_t)a_of_c[c] : a0 + c, b0 + s, &al, &af[(size_t)s * C + c] });
+        }
+    }
+}
+static int cyp_rescore_picks(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const std::vector<K4Pick>& picks) {
+    const uint64_t n = picks.size();
+    if (n == 0 || !ctx->mm2_rescore) return SP_OK;
+    std::vector<CellDesc> cells(n); std::vector<sp_aln> ref(n); std::vector<sp_affine_aln> out(n);
+    for (uint64_t x = 0; x < n; ++x) {
+        const sp_aln& al = *picks[x].al;
+        cells[x] = CellDesc{ picks[x].a, picks[x].b, ((al.b_start - al.a_start) + (al.b_end - al.a_end)) / 2, 320, 0, -1 };
+        ref[x] = al;
+    }
+    CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k4_af_cells", n * sizeof(CellDesc));
+    sp_aln* d_ref = (sp_aln*)sp_pool(ctx, "k4_af_ref", n * sizeof(sp_aln));
+    sp_affine_aln* d_af = (sp_affine_aln*)sp_pool(ctx, "k4_af_out", n * sizeof(sp_affine_aln));
+    if (!d_cells || !d_ref || !d_af) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "weights: re-score buffers");
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_cells, cells.data(), n * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ref, ref.data(), n * sizeof(sp_aln), hipMemcpyHostToDevice, ctx->stream));
+    const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
+    const int rc = sp_rescore_mappings(ctx, A, B, d_cells, d_ref, n, false, ao, 256, d_af, "k4_af", 320);
+    if (rc != SP_OK) return rc;
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(out.data(), d_af, n * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint64_t x = 0; x < n; ++x) *picks[x].out = out[x];
+    return SP_OK;
+}
+
 extern "C" int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensus, const uint8_t* allowed, const sp_seqset* segments,
                                           uint64_t* ed, double* ov, uint8_t* kept) {
     if (!ctx || !consensus || !segments || (consensus->n && !allowed) || (segments->n && (!ed || !ov || !kept))) return SP_ERR_INVALID_ARG;
@@ -687,21 +737,31 @@ extern "C" int32_t sp_cyp_weight_segments(sp_ctx* ctx, const sp_seqset* consensu
     std::vector<sp_aln> alns;
     int rc = cyp_align_all(ctx, consensus, segments, 1, 0.0, 1, "k4_weight_cells", alns);
     if (rc) return rc;
-    cyp_weights_from_alns(consensus->n, consensus->h_len.data(), allowed, segments->n, segments->h_len.data(), alns, ed, ov, kept);
+    std::vector<sp_affine_aln> af; std::vector<K4Pick> picks;
+    if (ctx->mm2_rescore) {
+        cyp_pick_near_min(consensus->n, allowed, segments->n, segments->h_len.data(), alns, af, 0, nullptr, 0, picks);
+        rc = cyp_rescore_picks(ctx, consensus, segments, picks);
+        if (rc) return rc;
+    }
+    cyp_weights_from_alns(consensus->n, consensus->h_len.data(), allowed, segments->n, segments->h_len.data(), alns, ed, ov, kept, af.empty() ? nullptr : af.data());
     return SP_OK;
 }
 
 // the host half of sp_cyp_weight_segments: alns[segment * C + consensus] are the placements of every segment on every consensus
 static void cyp_weights_from_alns(uint32_t C, const int32_t* cons_len, const uint8_t* allowed, uint32_t n_segments, const int32_t* seg_len, const std::vector<sp_aln>& alns,
-                                  uint64_t* ed, double* ov, uint8_t* kept) {
+                                  uint64_t* ed, double* ov, uint8_t* kept, const sp_affine_aln* af) {
     for (uint32_t s = 0; s < n_segments; ++s) {
         const int seq_len = seg_len[s];
         double min_ed_frac = 1.0;
         for (uint32_t c = 0; c < C; ++c) {
             uint64_t& e = ed[(size_t)s * C + c]; double& o = ov[(size_t)s * C + c];
             e = (uint64_t)seq_len; o = 0.0;                                  // "deleted" default (chaining.rs:40-41)
-            const sp_aln& al = alns[(size_t)s * C + c];
+            sp_aln al = alns[(size_t)s * C + c];
             if (!allowed[c] || !al.ok) continue;
+            if (af && af[(size_t)s * C + c].score > 0) {                     // the placement with the reference's numbers (cyp_pick_near_min)
+                const sp_affine_aln& r = af[(size_t)s * C + c];
+                al.nm = r.nm; al.a_start = r.a_start; al.a_end = r.a_end; al.b_start = r.b_start; al.b_end = r.b_end;
+            }
             const int con_len = cons_len[c];
             const uint64_t nm = (uint64_t)al.nm, unmapped = (uint64_t)(seq_len - (al.b_end - al.b_start));
             const uint64_t match_score = nm + unmapped;
@@ -1579,7 +1639,13 @@ int32_t cyp_weights_one(sp_ctx* ctx, const sp_seqset* reads, CypMid& m, Ahead& a
         std::vector<sp_aln> alns((size_t)all.n * H, sp_aln{}); std::vector<int32_t> cons_len(H);
         for (uint32_t h = 0; h < H; ++h) cons_len[h] = (int32_t)final_cons[h].size();
         for (uint32_t sx = 0; sx < all.n; ++sx) for (uint32_t h = 0; h < H; ++h) if (final_group[h] >= 0) alns[(size_t)sx * H + h] = ahead.alns[(size_t)sx * n_groups + final_group[h]];
-        cyp_weights_from_alns(H, cons_len.data(), allowed.data(), all.n, all.h_len.data(), alns, ed.data(), ov.data(), kept.data());
+        std::vector<sp_affine_aln> af; std::vector<K4Pick> picks;
+        if (ctx->mm2_rescore) {
+            cyp_pick_near_min(H, allowed.data(), all.n, all.h_len.data(), alns, af, 0, final_group.data(), 0, picks);      // (consensus h is sequence final_group[h] of the set placed ahead)
+            rc = cyp_rescore_picks(ctx, &ahead.cons, &all, picks);
+            if (rc != SP_OK) return rc;
+        }
+        cyp_weights_from_alns(H, cons_len.data(), allowed.data(), all.n, all.h_len.data(), alns, ed.data(), ov.data(), kept.data(), af.empty() ? nullptr : af.data());
     } else {
         rc = sp_make_segments(ctx, reads, a_idx, a_start, a_len, "cypa", &all, nullptr);
         if (rc != SP_OK) return rc;
@@ -1628,14 +1694,23 @@ int32_t cyp_weights_group(sp_ctx* ctx, const sp_seqset& view, const std::vector<
     rc = cyp_align_pairs(ctx, &cons, &all, ai, bi, 1, 1, 0.0, 1, "k4_weight_cells", alns);
     if (rc != SP_OK) return rc;
     size_t p = 0;
+    std::vector<std::vector<sp_aln>> mine(n); std::vector<std::vector<sp_affine_aln>> af(n); std::vector<K4Pick> picks;
     for (uint32_t k = 0; k < n; ++k) if (ms[k]) {
         const CypMid& m = *ms[k];
         const uint32_t H = m.H, ns = seg_first[k + 1] - seg_first[k];
-        std::vector<sp_aln> mine((size_t)ns * H, sp_aln{}); std::vector<int32_t> cons_len(H);
+        mine[k].assign((size_t)ns * H, sp_aln{});
+        for (uint32_t sx = 0; sx < ns; ++sx) for (uint32_t h = 0; h < H; ++h) if (m.allowed[h]) mine[k][(size_t)sx * H + h] = alns[p++];
+        if (ctx->mm2_rescore) cyp_pick_near_min(H, m.allowed.data(), ns, all.h_len.data() + seg_first[k], mine[k], af[k], cons_first[k], nullptr, seg_first[k], picks);
+    }
+    rc = cyp_rescore_picks(ctx, &cons, &all, picks);                        // (the whole group's placements near a minimum in one go)
+    if (rc != SP_OK) return rc;
+    for (uint32_t k = 0; k < n; ++k) if (ms[k]) {
+        const CypMid& m = *ms[k];
+        const uint32_t H = m.H, ns = seg_first[k + 1] - seg_first[k];
+        std::vector<int32_t> cons_len(H);
         for (uint32_t h = 0; h < H; ++h) cons_len[h] = (int32_t)m.final_cons[h].size();
-        for (uint32_t sx = 0; sx < ns; ++sx) for (uint32_t h = 0; h < H; ++h) if (m.allowed[h]) mine[(size_t)sx * H + h] = alns[p++];
         ed[k].resize((size_t)ns * H); ov[k].resize((size_t)ns * H); kept[k].resize(ns);
-        cyp_weights_from_alns(H, cons_len.data(), m.allowed.data(), ns, all.h_len.data() + seg_first[k], mine, ed[k].data(), ov[k].data(), kept[k].data());
+        cyp_weights_from_alns(H, cons_len.data(), m.allowed.data(), ns, all.h_len.data() + seg_first[k], mine[k], ed[k].data(), ov[k].data(), kept[k].data(), af[k].empty() ? nullptr : af[k].data());
     }
     return SP_OK;
 }

@@ -29,7 +29,7 @@ K3_READS_ALL_EQUAL_MIN = 0.975  # measured 1,957 - 1,965 of 2,000 reads: the who
 K3_HITS_SAME_NM_MIN = 0.970     # measured 97.4 - 97.9 % of the port's hits: found with the same (start, end) AND the same nm / unmapped
 K3_MM2_SAME_MIN = 0.999         # share of the port's hits the library reports with identical (start, end, NM, unmapped) in its re-scored fields
 K4_SAME_MIN_SET_MIN = 1.0       # measured 100 %: the set of minimum-edit consensuses of every segment is the port's (what the chains are built from, caller.rs:462-487)
-K4_SAME_MINIMUM_MIN = 0.99      # measured 99.4 - 99.5 %: the minimum itself (two-piece affine gaps vs unit costs on adjacent edits move it by one)
+K4_SAME_MINIMUM_MIN = 1.0       # measured 100 % since the placements near a segment's minimum carry the re-scored numbers (99.4 - 99.5 % with unit-cost counts)
 
 
 @pytest.fixture(scope="module")
