@@ -450,6 +450,8 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
         ctx2 = pkg.Context(ctx_device)
         cdb2 = pkg.ffi.CypDb(ctx2, cfg2, gd2, locus.sequence, locus.start)
         ctx2.set_option("k8_persistent", cyp_persistent())
+        if os.environ.get("SP_BENCH_CYP_STREAMS"):           # (an experiment switch: streams of the CYP2D6 cohort call, library default 6)
+            ctx2.set_option("cyp_cohort_streams", int(os.environ["SP_BENCH_CYP_STREAMS"]))
         for sh in shares:
             sh.beside = (ctx2, cdb2)
     # every rank makes the same number of gathers per pass, whatever its share: shares differ by one sample when the cohort does not divide by the ranks (and a rank

@@ -85,7 +85,7 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * "k8_persistent" (default 0; also the environment variable SP_K8_PERSISTENT): 1 runs consensus batches whose problems have at most 1,024 reads each as two persistent
  * kernels (step workgroups and one control workgroup per problem, handing over through device-scope release / acquire words) instead of a launch pair per step --
  * the same search, bit for bit; one process per device only (the workgroups of a batch have to be resident together, and the budget of CUs is counted per process).
- * "cyp_cohort_streams" (1..8, default 6): streams sp_cyp_diplotype_cohort spreads its groups of samples over (one host thread each).
+ * "cyp_cohort_streams" (1..8, default 8): streams sp_cyp_diplotype_cohort spreads its groups of samples over (one host thread each).
  * "k5_block_pairs" (0..1048576, default 4096): sp_cyp_best_chain_pair scores up to this many chain pairs with one workgroup per pair (the few pairs
  * of an ordinary sample: the reads of a pair are shared out over the workgroup), more with one thread per pair; the results are the same.
  * Unknown names: SP_ERR_INVALID_ARG. */

@@ -92,7 +92,7 @@ struct sp_ctx {
     sp_seqset* uploading = nullptr;      // the one upload a context has in flight (the staging buffers are the context's)
     int k5_block_pairs = 4096;       // sp_ctx_set_option "k5_block_pairs": up to this many chain pairs K5 runs one workgroup per pair (0: always one thread per pair)
     int cyp_cohort_min_group = 12;   // sp_ctx_set_option "cyp_cohort_min_group": a stream is only added when it leaves this many samples per stream
-    int cyp_cohort_streams = 6;      // sp_ctx_set_option "cyp_cohort_streams": samples of sp_cyp_diplotype_cohort in flight (1..8; WGS-sized samples are chains of tiny launches)
+    int cyp_cohort_streams = 8;      // sp_ctx_set_option "cyp_cohort_streams": samples of sp_cyp_diplotype_cohort in flight (1..8; WGS-sized samples are chains of tiny launches)
     sp_ctx* helper[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // further contexts on the same device (own stream, pools, events) for work that runs beside this one's; made on first use
 };
 

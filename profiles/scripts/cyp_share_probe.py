@@ -19,7 +19,12 @@ panel = bench.VariantPanel(pkg)
 sh = bench.CohortShare(pkg, fx, locus, scen, panel, list(range(N)))
 sets = [ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *p) for p in sh.cyp_payloads]
 stages = ["host:cyp_" + k for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")] + ["host:k8_loop", "host:k8_result_wait", "cons_steps", "k9_graph"]
-for streams, mg, pers in ((6, 12, 0), (6, 12, 1), (1, 64, 0), (1, 64, 1), (2, 8, 1), (4, 8, 0), (4, 8, 1), (6, 5, 1), (6, 12, 0), (6, 12, 1)):
+CASES = ((6, 12, 0), (6, 12, 1), (1, 64, 0), (1, 64, 1), (2, 8, 1), (4, 8, 0), (4, 8, 1), (6, 5, 1), (6, 12, 0), (6, 12, 1))
+if len(sys.argv) > 2 and sys.argv[2] == "three":
+    CASES = ((6, 12, 0), (3, 10, 0), (6, 12, 0), (3, 10, 0), (3, 10, 1))
+if len(sys.argv) > 2 and sys.argv[2] == "streams":
+    CASES = ((6, 12, 0), (2, 12, 0), (3, 12, 0), (4, 12, 0), (6, 12, 0), (8, 12, 0), (2, 12, 0), (3, 12, 0), (4, 12, 0))
+for streams, mg, pers in CASES:
     ctx.set_option("cyp_cohort_streams", streams); ctx.set_option("cyp_cohort_min_group", mg); ctx.set_option("k8_persistent", pers)
     cdb.diplotype_cohort(sets)
     ctx.profile_reset(); ctx.synchronize(); t0 = time.perf_counter()
