@@ -631,6 +631,8 @@ def main():
     ctx_c.set_option("k8_persistent", cyp_persistent())     # the CYP2D6 chain as persistent kernels: this process has the device to itself
     if os.environ.get("SP_BENCH_MM2_RESCORE"):              # (an experiment switch: what the re-scored numbers of K1 / K2 cost the step)
         ctx.set_option("mm2_rescore", int(os.environ["SP_BENCH_MM2_RESCORE"]))
+    if os.environ.get("SP_BENCH_HLA_SPLIT"):                # (an experiment switch: the two HLA genes of the sample on one stream (0) or two (1, the library's default))
+        ctx.set_option("hla_split_genes", int(os.environ["SP_BENCH_HLA_SPLIT"]))
     genes = list(range(len(fx.genes)))
     last = {}
 
