@@ -345,15 +345,31 @@ __global__ __launch_bounds__(256) void sp_pack4_kernel(const uint8_t* __restrict
     for (uint32_t s = blockIdx.x; s < n; s += gridDim.x) {
         const int L = len[s]; const uint8_t* src = seq4 + off[s];
         const int nw = (L + 15) >> 4;
+        const int nbytes = (L + 1) >> 1;
         for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+            // the word's eight input bytes in two loads, all sixteen nibbles decoded side by side: a code has ONE bit set (A 1, C 2, G 4, T 8): its 2-bit value is
+            // (bit 1 | bit 3, bit 2 | bit 3); any other number of set bits is an N.  (A byte load and a compare chain per base was 2.1 ms per 10,000-read sample.)
+            const int y0 = w << 3;
+            uint32_t half[2] = { 0u, 0u };
+            if (y0 + 8 <= nbytes) __builtin_memcpy(half, src + y0, 8);
+            else for (int k = 0; y0 + k < nbytes; ++k) half[k >> 2] |= (uint32_t)src[y0 + k] << ((k & 3) << 3);
             uint32_t word = 0, nw_bits = 0;
-            const int b0 = w << 4, b1 = b0 + 16 < L ? b0 + 16 : L;
-            for (int b = b0; b < b1; ++b) {
-                const uint32_t nib = (src[b >> 1] >> ((b & 1) ? 0 : 4)) & 0xFu;
-                uint32_t c = 0;
-                if (nib == 1) c = 0; else if (nib == 2) c = 1; else if (nib == 4) c = 2; else if (nib == 8) c = 3; else nw_bits |= 1u << ((b & 15) << 1);
-                word |= c << ((b & 15) << 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t v = half[h], M = 0x11111111u;
+                const uint32_t p0 = v & M, p1 = (v >> 1) & M, p2 = (v >> 2) & M, p3 = (v >> 3) & M;
+                const uint32_t lo = p1 | p3, hi = p2 | p3, odd = (p0 + p1 + p2 + p3) ^ M;          // odd: a nibble is 0 where exactly one bit was set
+                const uint32_t inv = (odd | (odd >> 1) | (odd >> 2)) & M;
+                const uint32_t code = (lo | (hi << 1)) & ~(inv * 3u);                                // 2-bit code in the low bits of every nibble, 0 for an N
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                                                        // byte k: its high nibble is the earlier base
+                    const int at = (h << 4) + (k << 2);
+                    word |= ((code >> ((k << 3) + 4)) & 3u) << at | ((code >> (k << 3)) & 3u) << (at + 2);
+                    nw_bits |= ((inv >> ((k << 3) + 4)) & 1u) << at | ((inv >> (k << 3)) & 1u) << (at + 2);
+                }
             }
+            const int left = L - (w << 4);
+            if (left < 16) { const uint32_t keep = (1u << (left << 1)) - 1u; word &= keep; nw_bits &= keep; }
             if (words) words[word_off[s] + w] = word;
             if (nplane) nplane[word_off[s] + w] = nw_bits;
             if (nw_bits && flag) atomicOr(flag, 1u);
