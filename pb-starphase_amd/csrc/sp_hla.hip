@@ -112,8 +112,14 @@ __device__ __forceinline__ int k1_dyn_cap(unsigned long long b, int alen, int ca
 // behind it in the order, its run would be the same run cut at the same or an earlier step: it fails too and is not executed.
 // The chain carries on from a skipped cell with the executed run's extent and the smaller cap (caps along a chain never grow).
 // Any bound value ever observed is a valid one (bounds only tighten), so the caps of a group may come from one read of it.
+// eight waves per SIMD (63 registers, no scratch) instead of the seven the compiler's own 72 registers allow: the rounds of a cell are chains of dependent DPP / ballot /
+// branch steps, and one more wave to switch to is worth 3 % of the launch (9.86 -> 9.53 ms; six and five waves: 10.4 and 11.4)
+#ifndef K1_WAVES_PER_EU
+#define K1_WAVES_PER_EU 8
+#endif
+#define K1_OCC __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER_EU, K1_WAVES_PER_EU)))
 template <bool HASN, bool DEEP>
-__global__ __launch_bounds__(64) void k1_cells_kernel(SeqSetView alleles, SeqSetView reads, K1Positions pos,
+__global__ __launch_bounds__(64) K1_OCC void k1_cells_kernel(SeqSetView alleles, SeqSetView reads, K1Positions pos,
                                                       const int32_t* __restrict__ d_rg, const int32_t* __restrict__ votes_rg,
                                                       int n_genes, uint32_t n_alleles, uint32_t n_chunks,
                                                       uint32_t* __restrict__ cell_out, unsigned long long* __restrict__ bound,
