@@ -678,6 +678,8 @@ def main():
                        else "a launch pair per step", "dependent_steps": steps, "launches_per_step": 0 if persistent else 2,
                "step_kernel_ms": ms("cons_path_step_ticks"), "control_kernel_ms": ms("cons_path_control_ticks"),
                "between_kernels_ms": ms("cons_path_gap_ticks"), "chain_ms": c.profile_get("cons_steps")[0] / max(1, args.steps)}
+        if out["chain_ms"] > 0:                             # the share of the chain's wall time in which one of its kernels is running at all (the rest: the device waits for the next launch)
+            out["kernels_running_fraction"] = (out["step_kernel_ms"] + out["control_kernel_ms"]) / out["chain_ms"]
         if steps > 0:
             out["per_step_us"] = {"step_kernel": 1e3 * out["step_kernel_ms"] / steps, "control_kernel": 1e3 * out["control_kernel_ms"] / steps,
                                   "between_kernels_per_boundary": 1e3 * out["between_kernels_ms"] / (2 * steps)}
