@@ -617,7 +617,7 @@ def main():
                    "config": {"workload": line["workload"], "samples": line["samples"], "parallelism": f"samples sharded over {world} GPU(s), one all-gather of the call records per pass through {gather_via}"
                               if backend == "nccl" else f"samples sharded over {world} rank(s) on shared devices, gather through torch.distributed ({backend})"},
                    "cohort": line, "roofline": None, "cpu_baseline": None,
-                   "note": "strong scaling: the cohort's work is fixed, every rank owns samples / N of it and hands its whole share to the library in one call; the calls keep groups of samples in lockstep, so a rank's rate falls with its share (one GPU: 280 / 257 / 201 / 165 samples/s for shares of 256 / 128 / 64 / 32 samples) -- the N = 1 figure for the same cohort is `legs.cohort` of the N = 1 line"}
+                   "note": "strong scaling: the cohort's work is fixed, every rank owns samples / N of it and hands its whole share to the library in one call; the calls keep groups of samples in lockstep, so a rank's rate falls with its share (one GPU, round 4: 348 / 309 / 260 / 208 samples/s for shares of 256 / 128 / 64 / 32 samples: `legs.cohort.by_share_size` of the N = 1 line) -- the N = 1 figure for the same cohort is `legs.cohort` of the N = 1 line"}
             print(json.dumps(out), flush=True)
         if group is not None and hasattr(group, "close"):
             group.close()
