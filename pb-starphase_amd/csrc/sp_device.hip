@@ -12,7 +12,9 @@
 // CPU restatement: oracle/align.c osp_anchor).
 // =============================================================================================
 #ifndef SP_ANCHOR_BUCKET_BITS
+#ifndef SP_ANCHOR_BUCKET_BITS
 #define SP_ANCHOR_BUCKET_BITS 10
+#endif
 #endif
 #ifndef SP_ANCHOR_ILP
 #define SP_ANCHOR_ILP 2          // look-ups a thread runs side by side (anchors of a bench step: 1: 1.83 ms, 2: 1.77, 3: 1.83, 4: 1.89, 8: 2.36)

@@ -1,5 +1,5 @@
 # anchor look-ups: buckets by the top 10 (default) / 12 / 13 / 14 bits of the code
-for v in default bb12 bb13 bb14 default bb12 bb13; do
+for v in default am default am; do
   if [ $v = default ]; then unset SP_LIB_PATH; else export SP_LIB_PATH=$PWD/build/variants/lib_$v.so; fi
   python profiles/scripts/cyp_kernels.py 1 2>/dev/null | grep -E "total|anchor " | tr '\n' ' '; echo " [$v]"
   python bench.py --no-cpu-baseline --no-extra-legs 2>/dev/null | python -c "
