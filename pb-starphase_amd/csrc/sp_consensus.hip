@@ -1421,18 +1421,28 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                 if (lane < NQ && nh[lane].used && !nh[lane].complete) { const CNode& p = nh[lane]; kc = p.cost_at(p.q); kt = p.T + p.q; kid = p.id; kx = lane; }
                 auto less = [](long long c1, int t1, int i1, long long c2, int t2, int i2) { return c1 < c2 || (c1 == c2 && (t1 > t2 || (t1 == t2 && i1 < i2))); };
                 long long bc = kc; int bt = kt, bid = kid, bx = kx;
+                long long sc2 = 0x7FFFFFFFFFFFFFFFll; int st2 = -1, sid2 = 0x7FFFFFFF, sx2 = -1;
+                const unsigned long long waiting = __ballot(kx >= 0);
+                if (__builtin_popcountll(waiting) == 1) {
+                    // one node waits (a linear search: most steps of most searches): it is the best, there is no second best -- no reductions
+                    const int only = __builtin_ctzll(waiting);
+                    const CNode& p = nh[only];
+                    bc = p.cost_at(p.q); bt = p.T + p.q; bid = p.id; bx = only;
+                    xi = only;
+                } else {
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const long long oc = __shfl_xor(bc, o); const int ot = __shfl_xor(bt, o), oi = __shfl_xor(bid, o), ox = __shfl_xor(bx, o);
-                    if (ox >= 0 && (bx < 0 || less(oc, ot, oi, bc, bt, bid))) { bc = oc; bt = ot; bid = oi; bx = ox; }
-                }
-                xi = bx;
-                if (xi < 0) { if (lane == 0) wk.done = 1; break; }                          // nothing waits
-                long long sc2 = (kx == xi) ? 0x7FFFFFFFFFFFFFFFll : kc; int st2 = kt, sid2 = kid, sx2 = (kx == xi) ? -1 : kx;
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const long long oc = __shfl_xor(bc, o); const int ot = __shfl_xor(bt, o), oi = __shfl_xor(bid, o), ox = __shfl_xor(bx, o);
+                        if (ox >= 0 && (bx < 0 || less(oc, ot, oi, bc, bt, bid))) { bc = oc; bt = ot; bid = oi; bx = ox; }
+                    }
+                    xi = bx;
+                    if (xi < 0) { if (lane == 0) wk.done = 1; break; }                          // nothing waits
+                    sc2 = (kx == xi) ? 0x7FFFFFFFFFFFFFFFll : kc; st2 = kt; sid2 = kid; sx2 = (kx == xi) ? -1 : kx;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const long long oc = __shfl_xor(sc2, o); const int ot = __shfl_xor(st2, o), oi = __shfl_xor(sid2, o), ox = __shfl_xor(sx2, o);
-                    if (ox >= 0 && (sx2 < 0 || less(oc, ot, oi, sc2, st2, sid2))) { sc2 = oc; st2 = ot; sid2 = oi; sx2 = ox; }
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const long long oc = __shfl_xor(sc2, o); const int ot = __shfl_xor(st2, o), oi = __shfl_xor(sid2, o), ox = __shfl_xor(sx2, o);
+                        if (ox >= 0 && (sx2 < 0 || less(oc, ot, oi, sc2, st2, sid2))) { sc2 = oc; st2 = ot; sid2 = oi; sx2 = ox; }
+                    }
                 }
                 CNode& x = nh[xi];
                 if (ss.best_node >= 0 && bc >= ss.best_final) { if (lane == 0) wk.done = 1; break; }   // nothing that waits can beat (or precede) the complete node
