@@ -593,11 +593,23 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
 // The words a step launch leaves behind that anybody reads: the slots 0 .. used - 1 of the exact votes, the cost growth and the final-cost extra
 // (window mode: one per push + the state's own; expand mode: one per child; init: slot 0) and, outside expand mode, the lookahead votes.  The
 // reduce and the control kernel walk them through a compact index; an expansion of a 100-read group moves 0.3 KB per workgroup instead of 12.
+// An expansion of up to KID_LA_KIDS children collects their lookahead votes as well -- KID_LA columns each, the lookahead words of a launch shared out
+// [child][consensus][column] -- so that a child's first window is a speculated one (a child without them first needs a launch of one column to have any: every
+// expansion cost its surviving child a launch pair more).
+constexpr int KID_LA_KIDS = 4, KID_LA = CW / KID_LA_KIDS;
+#ifndef SP_K8_KID_W0
+#define SP_K8_KID_W0 32
+#endif
+constexpr int KID_W0 = SP_K8_KID_W0 < KID_LA ? SP_K8_KID_W0 : KID_LA;      // first window of such a child in a crowded search (most children are dropped after a few columns)
+#ifndef SP_K8_KID_CALM
+#define SP_K8_KID_CALM 6
+#endif
+constexpr int KID_CALM = SP_K8_KID_CALM;                                   // up to this many other nodes waiting: the child's first window is KID_LA columns
 struct UsedWords {
     int used, has_la, a_end, b_end, total;
     __device__ __forceinline__ UsedWords(int mode, int n, int n_kids) {
         used = mode == M_EXPAND ? n_kids : (mode == M_WINDOW ? n + 1 : 1);
-        has_la = mode != M_EXPAND;
+        has_la = mode != M_EXPAND || n_kids <= KID_LA_KIDS;
         a_end = 2 * used * 5; b_end = a_end + (has_la ? QSL : 0); total = b_end + 2 * used;
     }
     // compact index -> position in the QE-word layout of the cluster sums
@@ -857,6 +869,29 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
                 column(e0, e1, kdual, kb0 >= 0, kb1 >= 0, kb0, kb1, T + 1, k0, k1);
                 if (kb0 >= 0) vote(e0, e1, kdual, 0, T + 1, k);
                 if (kdual && kb1 >= 0) vote(e1, e0, kdual, 1, T + 1, k);
+                if (n_kids <= KID_LA_KIDS && (P.n < 256 || (r & 3) == 0)) {
+                    // the child's lookahead votes (as behind a window: the bases behind every tip, at most two tips per consensus speak), KID_LA columns of them; of a
+                    // large problem every fourth read speaks -- a speculated base only has to be the likely one, the exact votes of the window decide
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (i == 1 && !kdual) continue;
+                        if ((i ? kb1 : kb0) < 0) continue;
+                        const Dwfa& a = i ? e1 : e0; const Dwfa& o = i ? e0 : e1;
+                        if (!(a.flags & F_ACTIVE) || (a.flags & (F_FINISHED | F_LOST))) continue;
+                        if (kdual && (o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < a.e) continue;
+                        const int Tl = T + 1 - a.c0, kd = lane - CH;
+                        unsigned long long tips = __ballot(a.H >= 0 && a.H + kd == Tl && a.H < rv.n);
+                        unsigned long long* const kl = &ll[0][0] + (size_t)(k * 2 + i) * KID_LA;
+                        for (int cnt = 0; tips && cnt < 2; ++cnt) {
+                            const int tl = __builtin_ctzll(tips); tips &= tips - 1;
+                            const int h = __builtin_amdgcn_readlane(a.H, tl);
+                            for (int x = lane; x < KID_LA - 1 && h + 1 + x < rv.n; x += SP_WAVE) {
+                                const int b = rb(h + 1 + x);
+                                if (b < 4) atomicAdd(&kl[x], 1ull << (16 * b));
+                            }
+                        }
+                    }
+                }
                 const int grow = read_cost(e0, e1, kdual) - base_cost;
                 const int len0 = kb0 >= 0 ? T + 1 : (go0 ? T : coh_load(&P.nodes[node].len[0]));
                 const int len1 = kb1 >= 0 ? T + 1 : (go1 ? T : coh_load(&P.nodes[node].len[1]));
@@ -1362,6 +1397,10 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             if (a == n) { la_fresh = wk.node; for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y]; }
         } else if (mode_in == M_EXPAND) {
             const int L = wk.T;
+            // how crowded the search is: the nodes that wait beside the parent and its children.  In a search that branches a little (two haplotypes: a handful of nodes)
+            // a child's first window may be long; where the queue is full most children are dropped within a few columns
+            const int others = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used && !nh[lane].complete)) - wk.n_kids - 1;
+            const int kid_w0 = others <= KID_CALM ? KID_LA : KID_W0;
             if (lane < wk.n_kids) {                                         // one lane per child
                 const CNode& par = nh[wk.node];
                 const int k = lane;
@@ -1377,9 +1416,20 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                     c.stopped[i] = st; c.len[i] = ln;
                 }
                 if (!c.dual) c.stopped[1] = 1;
-                c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = 0; c.wcap = WRAMP0;
+                c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = wk.n_kids <= KID_LA_KIDS ? 1 : 0; c.wcap = wk.n_kids <= KID_LA_KIDS ? kid_w0 : WRAMP0;
                 c.cost0 = par.cost_at(par.q) + (long long)sc[k]; c.dc[0] = 0; c.rest = sr[k]; c.rest_out = 0;
                 for (int i = 0; i < 2; ++i) for (int bq = 0; bq < 5; ++bq) c.ev[i][bq] = sv[i][k][bq];
+            }
+            if (wk.n_kids <= KID_LA_KIDS) {
+                // the children's lookahead votes ([child][consensus][KID_LA columns] in the launch's lookahead words) into the children's rows; the columns behind them
+                // are empty: a child's first window ends there at the latest.  (The rows are read back below, if a child is the next to go: a fence and the wave's
+                // own order make the stores visible to its loads.)
+                const uint32_t* flat = &sl[0][0][0];
+                for (int y = lane; y < wk.n_kids * 2 * KID_LA * 4; y += SP_WAVE) {                // (column KID_LA - 1 of a child has no votes: its window ends there, what lies behind is never read)
+                    const int k = y / (2 * KID_LA * 4), i = (y / (KID_LA * 4)) & 1, xb = y % (KID_LA * 4);
+                    P.la[(size_t)wk.kid_node[k] * 2 * CW * 4 + (size_t)i * CW * 4 + xb] = flat[y];
+                }
+                __threadfence_block();
             }
             spw::wave_lds_sync();
             if (lane == 0) {
