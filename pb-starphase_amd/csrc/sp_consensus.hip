@@ -601,6 +601,9 @@ constexpr int KID_LA_KIDS = 4, KID_LA = CW / KID_LA_KIDS;
 #define SP_K8_KID_W0 32
 #endif
 constexpr int KID_W0 = SP_K8_KID_W0 < KID_LA ? SP_K8_KID_W0 : KID_LA;      // first window of such a child in a crowded search (most children are dropped after a few columns)
+#ifndef SP_K8_RAMP
+#define SP_K8_RAMP 2            // a node's window grows by this factor with every window of its that stood
+#endif
 #ifndef SP_K8_KID_CALM
 #define SP_K8_KID_CALM 6
 #endif
@@ -1545,7 +1548,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                     // its state at that column has to be there
                     if (x.q > 0 || x.n > 0) {
                         if (x.a == x.n && x.have_out) {                                    // the window stood: the other slot is the state
-                            if (x.n > 1) x.wcap = 2 * x.wcap < CW ? 2 * x.wcap : CW;
+                            if (x.n > 1) x.wcap = SP_K8_RAMP * x.wcap < CW ? SP_K8_RAMP * x.wcap : CW;
                             x.T += x.n; x.cur ^= 1; x.cost0 = x.cost_at(x.n); x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
                         } else {
                             // cut window: push the verified bases again from the kept state (nothing is speculated)

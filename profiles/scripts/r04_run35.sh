@@ -1,5 +1,5 @@
 # first window of a child that has lookahead votes from its expansion: 32 columns (default) / 16 / 64
-for v in default kc3 kc12 default; do
+for v in default rp4 rp8 default rp4; do
   if [ $v = default ]; then unset SP_LIB_PATH; else export SP_LIB_PATH=$PWD/build/variants/lib_$v.so; fi
   echo "== $v"
   timeout 600 python profiles/scripts/k8persist_dbg3.py "*1/*2" "*4/*4" "*4+*68/*1" "*10+*36/*10" 2>&1 | grep -E "classic" | awk 'NR%2==0' | cut -c1-150
