@@ -74,6 +74,7 @@ struct CWork {                  // what the next step launch does for this probl
     int32_t dual, split_at;     // of the state at T
     int32_t go[2];              // window: which consensuses grow
     int32_t n_kids, pad;
+    int32_t pre_go[2];          // expand behind a cut window (n > 0): which consensuses the n verified bases in front of the branch grow
     int32_t kid_node[MAXKIDS];
     int8_t  kid_base[MAXKIDS][2];      // -1: that consensus does not grow
     int8_t  kid_split[MAXKIDS];        // the child starts consensus 2 as a copy of consensus 1
@@ -685,7 +686,10 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
     if (Wp->done || mode == M_NONE) return;
     if (B.step_t && threadIdx.x == 0) atomicMin(&B.step_t[2 * pi], (unsigned long long)wall_clock64());
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int T = Wp->T, n = mode == M_WINDOW ? Wp->n : 0;
+    // window mode: n bases from column T on.  Expand mode: the parent's kept state stands at column T as well, `pre` verified bases of a window that was cut lie between it
+    // and the column that branches (the replay launch a cut window used to need runs inside the expansion), the children are born at column T + pre + 1
+    const int T = Wp->T, n = (mode == M_WINDOW || mode == M_EXPAND) ? Wp->n : 0;
+    const int pre = mode == M_EXPAND ? n : 0;
     const int node = Wp->node, in_slot = Wp->in_slot;
     const int dual_in = Wp->dual, split_at = Wp->split_at;
     const int go0 = Wp->go[0], go1 = Wp->go[1];
@@ -699,7 +703,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
     for (int x = threadIdx.x; x < 2 * (CWIN + CW); x += blockDim.x) {
         const int i = x / (CWIN + CW), y = x % (CWIN + CW), pos = w0 + y;
         uint8_t v = 0;
-        if (pos >= T) v = (pos - T < n) ? Wp->spec[i][pos - T] : 0;
+        if (pos >= T) v = (pos - T < n) ? Wp->spec[dual_in ? i : 0][pos - T] : 0;       // (a single node shows its one consensus on both sides here too: a child that splits it behind a cut window reads the verified bases on its second side)
         else if (pos >= 0) v = coh_load((i == 1 && dual_in && pos >= split_at) ? &Cn[(size_t)P.cs + pos] : &Cn[pos]);
         cwin[i][y] = v;
     }
@@ -782,8 +786,9 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         // one column the slow way: consensus i grows by nb_i when g_i; a late read is placed; the two states are compared
         // the extension of a new wavefront: 16 bases per step out of the packed windows where both lie inside them (window mode; the base
         // a child appends in expand mode is not in the window), base by base elsewhere
+        bool use_pk = mode == M_WINDOW;                  // the packed compares may read the window (expand mode: only while the verified bases in front of the branch are replayed)
         auto extender = [&](const ConsAccess& cacc, int i) {
-            return [&cacc, i, &rb, wave, rbase, w0, lane, mode, &rv](Dwfa& d, int Tc) {
+            return [&cacc, i, &rb, wave, rbase, w0, lane, &use_pk, &rv](Dwfa& d, int Tc) {
                 const int k = lane - CH;
                 for (;;) {
                     int left = rv.n - d.H; { const int l2 = Tc - (d.H + k); left = l2 < left ? l2 : left; }
@@ -791,7 +796,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
                     int nm = 0; bool more = false;
                     if (go) {
                         const int xr = d.H - rbase, yc = d.c0 + d.H + k - w0;
-                        if (mode == M_WINDOW && xr >= 0 && xr < RWORDS * 16 && yc >= 0 && yc < CWIN + CW) {
+                        if (use_pk && xr >= 0 && xr < RWORDS * 16 && yc >= 0 && yc < CWIN + CW) {
                             const uint32_t a = __builtin_amdgcn_alignbit(rwin[wave][0][(xr >> 4) + 1], rwin[wave][0][xr >> 4], (uint32_t)(xr & 15) << 1);
                             const uint32_t nn = __builtin_amdgcn_alignbit(rwin[wave][1][(xr >> 4) + 1], rwin[wave][1][xr >> 4], (uint32_t)(xr & 15) << 1);
                             const uint32_t b = __builtin_amdgcn_alignbit(cpk[i][(yc >> 4) + 1], cpk[i][yc >> 4], (uint32_t)(yc & 15) << 1);
@@ -857,59 +862,10 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         ca0.win = &cwin[0][0]; ca0.w0 = w0; ca0.C = Cn; ca0.cap = P.cs; ca0.split_at = split_at; ca0.i = 0; ca0.ov_pos = -1; ca0.ov_base = 0;
         ca1 = ca0; ca1.win = &cwin[1][0]; ca1.i = 1;
 
-        if (mode == M_EXPAND) {
-            // one push per child, every child from the parent's state
-            const int base_cost = read_cost(d0, d1, dual_in != 0);
-            for (int k = 0; k < n_kids; ++k) {
-                Dwfa e0 = d0, e1 = d1;
-                const int kb0 = Wp->kid_base[k][0], kb1 = Wp->kid_base[k][1], ksplit = Wp->kid_split[k];
-                if (ksplit) e1 = e0;                                         // consensus 2 starts as a copy of consensus 1
-                const bool kdual = dual_in || ksplit;
-                ConsAccess k0 = ca0, k1 = ca1;
-                k0.ov_pos = kb0 >= 0 ? T : -1; k0.ov_base = kb0;
-                k1.ov_pos = kb1 >= 0 ? T : -1; k1.ov_base = kb1;
-                if (ksplit) { k1.i = 0; }                                      // (its prefix is consensus 1's; only the new base differs)
-                column(e0, e1, kdual, kb0 >= 0, kb1 >= 0, kb0, kb1, T + 1, k0, k1);
-                if (kb0 >= 0) vote(e0, e1, kdual, 0, T + 1, k);
-                if (kdual && kb1 >= 0) vote(e1, e0, kdual, 1, T + 1, k);
-                if (n_kids <= KID_LA_KIDS && (P.n < 256 || (r & 3) == 0)) {
-                    // the child's lookahead votes (as behind a window: the bases behind every tip, at most two tips per consensus speak), KID_LA columns of them; of a
-                    // large problem every fourth read speaks -- a speculated base only has to be the likely one, the exact votes of the window decide
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        if (i == 1 && !kdual) continue;
-                        if ((i ? kb1 : kb0) < 0) continue;
-                        const Dwfa& a = i ? e1 : e0; const Dwfa& o = i ? e0 : e1;
-                        if (!(a.flags & F_ACTIVE) || (a.flags & (F_FINISHED | F_LOST))) continue;
-                        if (kdual && (o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < a.e) continue;
-                        const int Tl = T + 1 - a.c0, kd = lane - CH;
-                        unsigned long long tips = __ballot(a.H >= 0 && a.H + kd == Tl && a.H < rv.n);
-                        unsigned long long* const kl = &ll[0][0] + (size_t)(k * 2 + i) * KID_LA;
-                        for (int cnt = 0; tips && cnt < 2; ++cnt) {
-                            const int tl = __builtin_ctzll(tips); tips &= tips - 1;
-                            const int h = __builtin_amdgcn_readlane(a.H, tl);
-                            for (int x = lane; x < KID_LA - 1 && h + 1 + x < rv.n; x += SP_WAVE) {
-                                const int b = rb(h + 1 + x);
-                                if (b < 4) atomicAdd(&kl[x], 1ull << (16 * b));
-                            }
-                        }
-                    }
-                }
-                const int grow = read_cost(e0, e1, kdual) - base_cost;
-                const int len0 = kb0 >= 0 ? T + 1 : (go0 ? T : coh_load(&P.nodes[node].len[0]));
-                const int len1 = kb1 >= 0 ? T + 1 : (go1 ? T : coh_load(&P.nodes[node].len[1]));
-                const int extra = final_extra(e0, e1, kdual, len0, len1);
-                if (lane == 0) { if (grow) atomicAdd(&lc[k], (uint32_t)grow); if (extra) atomicAdd(&lr[k], (uint32_t)extra); }
-                const int kn = Wp->kid_node[k];
-                store(e0, kn, 0, 0);
-                if (kdual) store(e1, kn, 0, 1);
-            }
-            spw::wave_lds_sync();
-            continue;
-        }
-
-        const bool dualrun = dual_in != 0;
-        if (mode == M_INIT) { vote(d0, d1, false, 0, 0, 0); }
+        // one pass of a read through the n bases of the window behind column T.  quiet: the pass only moves the state (the verified bases of a cut window in front of an
+        // expansion: their votes and costs are on the parent's tape already)
+        auto win_pass = [&](Dwfa& d0, Dwfa& d1, const bool dualrun, const int go0, const int go1, const int n, const bool quiet) {
+        if (!quiet && mode == M_INIT) { vote(d0, d1, false, 0, 0, 0); }
         // number of leading bases on which read[x0 ..] (position relative to the staged window) and the window's bases [j ..] agree
         // The blocks of 16 bases are compared side by side, one lane each (a window has at most CW / 16 + 1 of them): one round of LDS reads
         // instead of one per block.
@@ -982,7 +938,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
             //  column every few bases until the window ends)
             if (want_bulk > 0) {
                 const int margin = want_bulk; want_bulk = 0;
-                if (mode == M_WINDOW && dualrun && go0 && go1 && n - j >= 8 && (d0.flags & F_ACTIVE) && (d1.flags & F_ACTIVE) &&
+                if (!quiet && mode == M_WINDOW && dualrun && go0 && go1 && n - j >= 8 && (d0.flags & F_ACTIVE) && (d1.flags & F_ACTIVE) &&
                     !((d0.flags | d1.flags) & (F_FINISHED | F_LOST)) && (d0.e >= d1.e + margin || d1.e >= d0.e + margin)) {
                     const int wi = d0.e > d1.e ? 0 : 1;
                     Dwfa& w = wi ? d1 : d0;
@@ -1032,7 +988,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
                     Dwfa& a = i ? d1 : d0; const Dwfa& o = i ? d0 : d1;
                     bool speaks = true;
                     if (dualrun && (o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < a.e) speaks = false;
-                    if (speaks) for (int x = lane + 1; x <= m; x += SP_WAVE) {   // lane l names the votes after l + 1, l + 65, ... of the m pushes
+                    if (speaks && !quiet) for (int x = lane + 1; x <= m; x += SP_WAVE) {   // lane l names the votes after l + 1, l + 65, ... of the m pushes
                         const int pos = th + x;
                         if (pos < rv.n) { const int code = rb(pos); if (code < 4) atomicAdd(&lv[i][j + x], 12ull << (16 * code)); }
                         else if (!P.et) atomicAdd(&le[i][j + x], 12u);       // (with early termination the read is finished by that push)
@@ -1081,10 +1037,10 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
             } else
                 column(d0, d1, dualrun, go0, go1, cwin[0][CWIN + j], cwin[1][CWIN + j], T + j + 1, ca0, ca1);
             const int grow = read_cost(d0, d1, dualrun) - before;
-            if (grow && lane == 0) atomicAdd(&lc[j + 1], (uint32_t)grow);
+            if (grow && lane == 0 && !quiet) atomicAdd(&lc[j + 1], (uint32_t)grow);
             K8_T(tb_col);
-            if (go0 && bulk != 0) vote(d0, d1, dualrun, 0, T + j + 1, j + 1);
-            if (dualrun && go1 && bulk != 1) vote(d1, d0, dualrun, 1, T + j + 1, j + 1);
+            if (!quiet && go0 && bulk != 0) vote(d0, d1, dualrun, 0, T + j + 1, j + 1);
+            if (!quiet && dualrun && go1 && bulk != 1) vote(d1, d0, dualrun, 1, T + j + 1, j + 1);
             K8_T(tb_vote);
             j += 1;
             if (bulk < 0 && (d0.flags & F_ACTIVE) + (d1.flags & F_ACTIVE) != active_before) want_bulk = BULK_MARGIN_PLACED;   // a read placed in this column
@@ -1092,6 +1048,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         // lookahead: the bases behind every tip (at most two tips per consensus speak) predict the columns after the window
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (quiet) continue;
             if (i == 1 && !dualrun) continue;
             if (mode != M_INIT && !(i ? go1 : go0)) continue;
             const Dwfa& a = i ? d1 : d0; const Dwfa& o = i ? d0 : d1;
@@ -1111,15 +1068,17 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         {
             const int len0 = go0 || mode == M_INIT ? T + n : coh_load(&P.nodes[node].len[0]), len1 = go1 ? T + n : coh_load(&P.nodes[node].len[1]);
             const int extra = final_extra(d0, d1, dualrun, len0, len1);
-            if (extra && lane == 0) atomicAdd(&lr[n], (uint32_t)extra);
+            if (extra && lane == 0 && !quiet) atomicAdd(&lr[n], (uint32_t)extra);
         }
         // the new state goes to the node's other slot (the root's first state: its slot 0)
-        const int out_slot = mode == M_INIT ? in_slot : in_slot ^ 1;
-        store(d0, node, out_slot, 0);
-        if (dualrun) store(d1, node, out_slot, 1);
+        if (!quiet) {
+            const int out_slot = mode == M_INIT ? in_slot : in_slot ^ 1;
+            store(d0, node, out_slot, 0);
+            if (dualrun) store(d1, node, out_slot, 1);
+        }
         spw::wave_lds_sync();
 #ifdef SP_K8_TIMING
-        if (B.dbg && lane == 0 && Wp->pad < SP_K8_DBG_LAUNCHES && g < SP_K8_DBG_READS) {
+        if (!quiet && B.dbg && lane == 0 && Wp->pad < SP_K8_DBG_LAUNCHES && g < SP_K8_DBG_READS) {
             const unsigned long long dt = (unsigned long long)(wall_clock64() - wt0);
             const unsigned long long placed = ri.off > T && ri.off <= T + n;
             // [launch][read]: ticks (24 bits, 100 MHz) | slow columns (9) | multi-tip events (9) | a late read was placed (1) | mode (2) | window bases (9) | column pushes, clock64 / 1024 (10)
@@ -1137,6 +1096,62 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
             (void)tb_fast; (void)tb_vote;
         }
 #endif
+        };
+        if (mode == M_EXPAND) {
+            // behind a cut window: first the verified bases in front of the branch (no votes: they are on the parent's tape), then ...
+            if (pre > 0) { use_pk = true; win_pass(d0, d1, dual_in != 0, Wp->pre_go[0], Wp->pre_go[1], pre, true); use_pk = false; }
+            const int TB = T + pre;                                          // the column that branches
+            // ... one push per child, every child from the parent's state
+            const int base_cost = read_cost(d0, d1, dual_in != 0);
+            for (int k = 0; k < n_kids; ++k) {
+                Dwfa e0 = d0, e1 = d1;
+                const int kb0 = Wp->kid_base[k][0], kb1 = Wp->kid_base[k][1], ksplit = Wp->kid_split[k];
+                if (ksplit) e1 = e0;                                         // consensus 2 starts as a copy of consensus 1
+                const bool kdual = dual_in || ksplit;
+                ConsAccess k0 = ca0, k1 = ca1;
+                k0.ov_pos = kb0 >= 0 ? TB : -1; k0.ov_base = kb0;
+                k1.ov_pos = kb1 >= 0 ? TB : -1; k1.ov_base = kb1;
+                if (ksplit) { k1.i = 0; }                                      // (its prefix is consensus 1's; only the new base differs)
+                column(e0, e1, kdual, kb0 >= 0, kb1 >= 0, kb0, kb1, TB + 1, k0, k1);
+                if (kb0 >= 0) vote(e0, e1, kdual, 0, TB + 1, k);
+                if (kdual && kb1 >= 0) vote(e1, e0, kdual, 1, TB + 1, k);
+                if (n_kids <= KID_LA_KIDS && (P.n < 256 || (r & 3) == 0)) {
+                    // the child's lookahead votes (as behind a window: the bases behind every tip, at most two tips per consensus speak), KID_LA columns of them; of a
+                    // large problem every fourth read speaks -- a speculated base only has to be the likely one, the exact votes of the window decide
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (i == 1 && !kdual) continue;
+                        if ((i ? kb1 : kb0) < 0) continue;
+                        const Dwfa& a = i ? e1 : e0; const Dwfa& o = i ? e0 : e1;
+                        if (!(a.flags & F_ACTIVE) || (a.flags & (F_FINISHED | F_LOST))) continue;
+                        if (kdual && (o.flags & F_ACTIVE) && !(o.flags & F_LOST) && o.e < a.e) continue;
+                        const int Tl = TB + 1 - a.c0, kd = lane - CH;
+                        unsigned long long tips = __ballot(a.H >= 0 && a.H + kd == Tl && a.H < rv.n);
+                        unsigned long long* const kl = &ll[0][0] + (size_t)(k * 2 + i) * KID_LA;
+                        for (int cnt = 0; tips && cnt < 2; ++cnt) {
+                            const int tl = __builtin_ctzll(tips); tips &= tips - 1;
+                            const int h = __builtin_amdgcn_readlane(a.H, tl);
+                            for (int x = lane; x < KID_LA - 1 && h + 1 + x < rv.n; x += SP_WAVE) {
+                                const int b = rb(h + 1 + x);
+                                if (b < 4) atomicAdd(&kl[x], 1ull << (16 * b));
+                            }
+                        }
+                    }
+                }
+                const int grow = read_cost(e0, e1, kdual) - base_cost;
+                const int len0 = kb0 >= 0 ? TB + 1 : (go0 ? TB : coh_load(&P.nodes[node].len[0]));
+                const int len1 = kb1 >= 0 ? TB + 1 : (go1 ? TB : coh_load(&P.nodes[node].len[1]));
+                const int extra = final_extra(e0, e1, kdual, len0, len1);
+                if (lane == 0) { if (grow) atomicAdd(&lc[k], (uint32_t)grow); if (extra) atomicAdd(&lr[k], (uint32_t)extra); }
+                const int kn = Wp->kid_node[k];
+                store(e0, kn, 0, 0);
+                if (kdual) store(e1, kn, 0, 1);
+            }
+            spw::wave_lds_sync();
+            continue;
+        }
+
+        win_pass(d0, d1, dual_in != 0, go0, go1, n, false);
     }
     __syncthreads();
     const UsedWords uw(mode, n, n_kids);
@@ -1279,7 +1294,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         const int k = x / NODE_TAPE_WORDS, w = x % NODE_TAPE_WORDS;
         if (tape_word_used(nh[k], w)) ((uint32_t*)&nh[k])[NODE_HEAD_WORDS + w] = ((const uint32_t*)&P.nodes[k])[NODE_HEAD_WORDS + w];
     }
-    const int mode_in = wk.mode, n_in = wk.mode == M_WINDOW ? wk.n : 0;
+    const int mode_in = wk.mode, n_in = (wk.mode == M_WINDOW || wk.mode == M_EXPAND) ? wk.n : 0;     // (expand mode: the verified bases that were replayed in front of the branch)
     // the words of the step that are in use: the cluster sums (a few per problem) or, for a problem of at most DIRECT_BLOCKS workgroups, the
     // workgroups' own words (no reduce launch at all for a batch of such problems); eight loads in flight per thread
     if (mode_in != M_NONE) {
@@ -1399,7 +1414,10 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             }
             if (a == n) { la_fresh = wk.node; for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y]; }
         } else if (mode_in == M_EXPAND) {
-            const int L = wk.T;
+            const int L = wk.T + n_in;                                      // the column that branched
+#ifdef SP_K8_TRACE
+            if (lane == 0 && pi == 0) { printf("EXP L %d pre %d kids %d parcost %lld :", L, n_in, wk.n_kids, nh[wk.node].cost_at(nh[wk.node].q)); for (int k = 0; k < wk.n_kids; ++k) printf(" [%d/%d sc %u sr %u ev %u %u %u %u %u]", wk.kid_base[k][0], wk.kid_base[k][1], sc[k], sr[k], sv[0][k][0], sv[0][k][1], sv[0][k][2], sv[0][k][3], sv[0][k][4]); printf("\n"); }
+#endif
             // how crowded the search is: the nodes that wait beside the parent and its children.  In a search that branches a little (two haplotypes: a handful of nodes)
             // a child's first window may be long; where the queue is full most children are dropped within a few columns
             const int others = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used && !nh[lane].complete)) - wk.n_kids - 1;
@@ -1543,6 +1561,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             unsigned long long free_nodes = __ballot(lane < NQ && !nh[lane].used);
             if (lane == 0) {
                 CNode& x = nh[xi];
+                int cut = -1;                                                            // >= 0: the node stands behind that many verified bases of a window that was cut
                 do {
                     if (x.q < x.a) { x.q += 1; x.id = ss.next_id++; break; }               // (a window that was under way came back: its first column is this pop's child)
                     // its state at that column has to be there
@@ -1550,17 +1569,25 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                         if (x.a == x.n && x.have_out) {                                    // the window stood: the other slot is the state
                             if (x.n > 1) x.wcap = SP_K8_RAMP * x.wcap < CW ? SP_K8_RAMP * x.wcap : CW;
                             x.T += x.n; x.cur ^= 1; x.cost0 = x.cost_at(x.n); x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
-                        } else {
-                            // cut window: push the verified bases again from the kept state (nothing is speculated)
-                            wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = x.a; wk.replay = 1;
-                            wk.dual = x.dual; wk.split_at = x.split_at;
-                            for (int i = 0; i < 2; ++i) wk.go[i] = (i == 0 || x.dual) && !x.stopped[i];
-                            replay_of = xi;                                             // (the bases are copied below, a lane each)
-                            ss.inflight = xi;
-                            stop = 1; break;
-                        }
+                        } else cut = x.a;                                                  // cut window: the state at the end of the verified bases is not there
                     }
-                    const int L = x.T;
+                    // (which consensuses grew in that window: as they stand BEFORE this column's decision, which may end one)
+                    const int pre_go[2] = { !x.stopped[0] ? 1 : 0, (x.dual && !x.stopped[1]) ? 1 : 0 };
+                    auto order_replay = [&]() {
+                        // push the verified bases again from the kept state (nothing is speculated)
+                        wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = x.a; wk.replay = 1;
+                        wk.dual = x.dual; wk.split_at = x.split_at;
+                        for (int i = 0; i < 2; ++i) wk.go[i] = pre_go[i];
+                        replay_of = xi;                                                 // (the bases are copied below, a lane each)
+                        ss.inflight = xi;
+                        stop = 1;
+                    };
+                    // (a cut window: the votes of the column behind the verified bases are there -- x.ev -- and say whether the node branches; if it does, the expansion
+                    //  launch pushes the verified bases itself in front of the children's: the replay launch is only made where the node goes on alone)
+#ifdef SP_K8_NO_PRE
+                    if (cut >= 0 && (SP_K8_NO_PRE == 0 || (SP_K8_NO_PRE == 1 && x.dual) || (SP_K8_NO_PRE == 2 && !x.dual))) { order_replay(); break; }
+#endif
+                    const int L = x.T + (cut > 0 ? cut : 0);
                     // candidates of every consensus that is still going
                     int nc[2] = { 0, 0 }, cd[2][4];
                     for (int i = 0; i < (x.dual ? 2 : 1); ++i) {
@@ -1568,6 +1595,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                         nc[i] = cands(x.ev[i], L, cd[i]);
                         if (nc[i] == 0) { x.stopped[i] = 1; x.len[i] = L; }
                     }
+                    if (cut >= 0 && (nc[0] == 0 && nc[1] == 0)) { order_replay(); break; }   // (its final cost needs the state: the replay brings it)
                     if (nc[0] == 0 && nc[1] == 0) {                                        // complete
                         const long long fc = x.cost0 + (P.et ? 0 : x.rest);
                         if (ss.best_node < 0 || fc < ss.best_final) { if (ss.best_node >= 0) node_free(ss.best_node); ss.best_node = xi; ss.best_final = fc; x.complete = 1; }
@@ -1583,6 +1611,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                         const int n0 = nc[0] ? nc[0] : 1, n1 = nc[1] ? nc[1] : 1;
                         for (int a2 = 0; a2 < n0; ++a2) for (int b2 = 0; b2 < n1; ++b2) { kb[nk][0] = nc[0] ? cd[0][a2] : -1; kb[nk][1] = nc[1] ? cd[1][b2] : -1; ks[nk] = 0; ++nk; }
                     }
+                    if (nk == 1 && cut >= 0) { order_replay(); break; }
                     if (nk == 1) {
                         // one child: the node itself goes on, through a window whose first base is this decision
                         wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = L; wk.replay = 0; wk.dual = x.dual; wk.split_at = x.split_at;
@@ -1594,8 +1623,9 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                         stop = 1; break;
                     }
                     // several children: one push each into fresh nodes
-                    wk.mode = M_EXPAND; wk.node = xi; wk.in_slot = x.cur; wk.T = L; wk.dual = x.dual; wk.split_at = x.split_at;
-                    wk.go[0] = nc[0] > 0; wk.go[1] = nc[1] > 0;
+                    wk.mode = M_EXPAND; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = cut > 0 ? cut : 0; wk.dual = x.dual; wk.split_at = x.split_at;
+                    wk.go[0] = nc[0] > 0; wk.go[1] = nc[1] > 0; wk.pre_go[0] = pre_go[0]; wk.pre_go[1] = pre_go[1];
+                    if (cut > 0) replay_of = xi;                                        // (the verified bases go into the work order below, a lane each)
                     int made = 0;
                     for (int k = 0; k < nk && made < MAXKIDS; ++k) {
                         if (!free_nodes) break;                                         // (the table holds the queue plus one expansion: not reached)
