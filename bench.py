@@ -719,6 +719,30 @@ def main():
         t_up[name] = {"seconds": best, "bytes": int(len(payload[0])), "GBps": len(payload[0]) / best / 1e9, "bases_per_s": samples[0].ascii_bytes / best}
 
     legs = {}
+    if not args.no_extra_legs and not cyp_persistent():
+        # the headline's step once more with the CYP2D6 context's consensus as persistent kernels (sp_ctx_set_option "k8_persistent"; off by default: DESIGN 9): the same
+        # samples, uploads and calls.  A leg, not `value`: the mode needs every stream of the process on a hardware queue of its own and fails with an error (after a
+        # four-second time-out) where it is not -- which is reported here instead of raised
+        try:
+            ctx_c.set_option("k8_persistent", 1)
+            run_lanes(make_lanes(max(1, args.warmup)))
+            ctx_c.profile_reset()
+            lanes_p = make_lanes(args.steps)
+            for x in lanes_p:
+                x.pending.wait()
+            ctx_c.synchronize(); ctx.synchronize()
+            t1 = time.perf_counter()
+            run_lanes(lanes_p)
+            ctx_c.synchronize(); ctx.synchronize()
+            d_p = time.perf_counter() - t1
+            legs["headline_with_persistent_consensus"] = {"value": reads_per_step * args.steps / d_p, "unit": "reads/s", "ms_per_step": 1e3 * d_p / args.steps,
+                                                          "cyp2d6_cons_steps_ms": ctx_c.profile_get("cons_steps")[0] / max(1, args.steps),
+                                                          "cyp2d6_call_equals_truth": sorted([last["cyp"][1].hap1.decode(), last["cyp"][1].hap2.decode()]) == sorted(cyp_samples[last["cyp"][0] % 2].expected),
+                                                          "critical_path_cyp2d6": critical_path(ctx_c)}
+        except Exception as e:                                                   # (the library's own error text)
+            legs["headline_with_persistent_consensus"] = {"error": str(e)}
+        finally:
+            ctx_c.set_option("k8_persistent", 0)
     if not args.no_extra_legs:
         # HLA alone, reads resident in HBM (round 2's headline): the K1 launch the roofline block describes runs here exactly as in the headline
         res_lane = Lane(pkg, ctx, [s.payload for s in samples], hla_work, args.steps, fresh_upload=False)

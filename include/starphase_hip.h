@@ -84,7 +84,9 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * takes the DP over all of its rows instead of over the rows around those edits (a check of the shortcut, an order of magnitude slower).
  * "k8_persistent" (default 0; also the environment variable SP_K8_PERSISTENT): 1 runs consensus batches whose problems have at most 1,024 reads each as two persistent
  * kernels (step workgroups and one control workgroup per problem, handing over through device-scope release / acquire words) instead of a launch pair per step --
- * the same search, bit for bit; one process per device only (the workgroups of a batch have to be resident together, and the budget of CUs is counted per process).
+ * the same search, bit for bit; one process per device only (the workgroups of a batch have to be resident together, and the budget of CUs is counted per process), and every
+ * stream of the process on a hardware queue of its own (a batch's two kernels wait for each other: GPU_MAX_HW_QUEUES, sp_ctx_get_info; at most four batches run this way at
+ * once, sp_cyp_diplotype_cohort keeps to four streams).
  * "cyp_cohort_streams" (1..8, default 8): streams sp_cyp_diplotype_cohort spreads its groups of samples over (one host thread each).
  * "k5_block_pairs" (0..1048576, default 4096): sp_cyp_best_chain_pair scores up to this many chain pairs with one workgroup per pair (the few pairs
  * of an ordinary sample: the reads of a pair are shared out over the workgroup), more with one thread per pair; the results are the same.

@@ -1902,16 +1902,23 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
 } // namespace
 
 // CUs (in halves: a step workgroup takes half a CU, a control workgroup a whole one) the persistent batches of this process hold on each device
+// and how many persistent batches run at once: each holds two hardware queues for its whole length (its step kernel and its control kernel wait for each other), and two
+// batches whose kernels queue up behind one another on shared queues wait for ever (seen with eight cohort streams, each with a batch of its own, beside the HLA half's
+// streams on the 16 queues of a process: the four-second time-out).  PERSIST_MAX_BATCHES at once, the others go the launch-pair way.
+constexpr int PERSIST_MAX_BATCHES = 4;
 struct PersistLease {
     int device = -1, taken = 0;
     static std::atomic<int>& used(int device) { static std::atomic<int> u[64]; return u[device & 63]; }
+    static std::atomic<int>& batches(int device) { static std::atomic<int> b[64]; return b[device & 63]; }
     bool take(int dev, int budget, int want) {
+        if (batches(dev).fetch_add(1) >= PERSIST_MAX_BATCHES) { batches(dev).fetch_sub(1); return false; }
         std::atomic<int>& u = used(dev);
         int cur = u.load();
         while (cur + want <= budget) if (u.compare_exchange_weak(cur, cur + want)) { device = dev; taken = want; return true; }
+        batches(dev).fetch_sub(1);
         return false;
     }
-    void give_back() { if (taken) { used(device).fetch_sub(taken); taken = 0; } }
+    void give_back() { if (taken) { used(device).fetch_sub(taken); batches(device).fetch_sub(1); taken = 0; } }
     ~PersistLease() { give_back(); }
 };
 

@@ -1834,7 +1834,10 @@ extern "C" int32_t sp_cyp_diplotype_cohort(sp_ctx* ctx, const sp_cyp_problem* pr
     if (pr->templates) { const int rc0 = sp_seqset_build_index(ctx, const_cast<sp_seqset*>(pr->templates)); if (rc0 != SP_OK) return rc0; }
     // streams: up to cyp_cohort_streams, but no more than leave a dozen samples per stream -- a stream keeps its samples in lockstep through the consensus and types
     // their consensuses in one batch, which pays with the size of the group (48 samples: 6.7 / 4.8 / 4.7 / 4.7 ms per sample on 1 / 2 / 4 / 6 streams)
-    int n_parts = ctx->split_genes ? (int)std::min<uint32_t>(std::max<uint32_t>(1, n_samples / (uint32_t)ctx->cyp_cohort_min_group), (uint32_t)ctx->cyp_cohort_streams) : 1;
+    // (with the persistent consensus kernels at most four: a persistent batch holds two hardware queues for its whole length, and two of its own streams on ONE queue -- more
+    //  streams in the process than queues -- is a batch whose step kernel waits behind its own control kernel for ever: the four-second time-out, seen with eight streams)
+    const uint32_t stream_cap = ctx->k8_persistent ? std::min(ctx->cyp_cohort_streams, 4) : ctx->cyp_cohort_streams;
+    int n_parts = ctx->split_genes ? (int)std::min<uint32_t>(std::max<uint32_t>(1, n_samples / (uint32_t)ctx->cyp_cohort_min_group), stream_cap) : 1;
     sp_ctx* on[8] = { ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     for (int x = 1; x < n_parts; ++x) { on[x] = sp_ctx_helper(ctx, x - 1); if (!on[x]) { n_parts = x; break; } }
     std::vector<int32_t> rcs(n_samples, SP_OK); std::vector<int> where(n_samples, 0);
