@@ -560,10 +560,12 @@ int32_t sp_align_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
         if (pairs[i].max_ed < 0 || pairs[i].max_ed > SP_MAX_ED) return sp_fail(ctx, SP_ERR_INVALID_ARG, "align: max_ed must be 0..SP_MAX_ED");
         cells[i] = CellDesc{pairs[i].a, pairs[i].b, pairs[i].diag, pairs[i].max_ed, 0, -1};
     }
-    CellDesc* d_cells = nullptr; sp_aln* d_out = nullptr; uint32_t* d_ev = nullptr;
+    // (the context's pooled buffers: three allocations and three frees per call -- a free waits for the device -- were most of the 4 ms this call took for the
+    //  three consensus sequences K9 places on the backbone)
+    CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "align_cells", n_pairs * sizeof(CellDesc)); sp_aln* d_out = (sp_aln*)sp_pool(ctx, "align_out", n_pairs * sizeof(sp_aln));
+    uint32_t* d_ev = events ? (uint32_t*)sp_pool(ctx, "align_ev", n_pairs * (size_t)events_stride * 4) : nullptr;
     int rc = SP_OK;
-    if (hipMalloc(&d_cells, n_pairs * sizeof(CellDesc)) != hipSuccess || hipMalloc(&d_out, n_pairs * sizeof(sp_aln)) != hipSuccess ||
-        (events && hipMalloc(&d_ev, n_pairs * (size_t)events_stride * 4) != hipSuccess)) {
+    if (!d_cells || !d_out || (events && !d_ev)) {
         rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "align buffers");
     } else {
         hipMemcpyAsync(d_cells, cells.data(), n_pairs * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream);
@@ -575,7 +577,6 @@ int32_t sp_align_batch(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, std::string("align: ") + hipGetErrorString(hipGetLastError()));
         }
     }
-    hipFree(d_cells); hipFree(d_out); hipFree(d_ev);
     return rc;
 }
 

@@ -935,12 +935,15 @@ extern "C" int32_t sp_cyp_score_alleles(sp_ctx* ctx, uint32_t n_variants, uint32
 #define K9_INF 30000
 #define K9_SITE_MAX 8
 
+__host__ __device__ inline int k9_lds_bytes(int L, int G, int alt_bytes, int n_sites, int n_alts) { return ((L + G + alt_bytes + 3) & ~3) + 4 * (3 * n_sites + 1 + 2 * n_alts); }
+
 struct K9Job {
     uint32_t seq_off; int32_t L;              // the aligned part of the sequence in the byte pool
     uint32_t bb_off; int32_t G;               // the aligned part of the backbone
     int32_t k0;                               // diagonal of lane 0, index 0
     uint32_t site_first, n_sites;             // into site_so / site_eo / alt_first (alt_first has one more entry per job)
-    uint32_t alt_base;                        // first alternative of the job in alt_len / alt_off
+    uint32_t alt_base, n_alts;                // the job's alternatives in alt_len / alt_off
+    uint32_t alt_bytes_off, alt_bytes;        // their bases: one stretch of the byte pool
     uint32_t exit_off, entry_off;             // columns (256 u16 each) in the scratch arrays
     int32_t opt;                              // (written by the kernel)
 };
@@ -954,17 +957,30 @@ __device__ __forceinline__ void k9_step(int (&c)[4], int x, const int (&r)[4], i
     int below0;
     if (off + k0 >= 0 && off + k0 + K9_DIAGS + 1 <= L) {
         // every diagonal of the band faces a sequence base here and behind this graph base (all but the first and last columns of a job): the same
-        // recurrence without the range tests -- values above K9_INF only arise as K9_INF + 1 and are cut back before anyone compares them
+        // recurrence without the range tests, and the run up the column without asking whether it is needed -- it nearly always is: a diagonal above the
+        // path's own mismatches three steps in four and gets its value back from the one below; the test, its ballot and the branch cost more than they saved
+        // (1,000 cycles per step before, the step's chain of dependent instructions cut by half).  Values above K9_INF only arise as K9_INF + a few and are
+        // cut back at the end of the step, before anyone compares them.
         const int xm = x < 4 ? x : 99;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int up = j < 3 ? c[j + 1] : next0;
-            const int v = min(c[j] + (r[j] == xm ? 0 : 1), up + 1);
-            nw[j] = min(v, K9_INF);
+            nw[j] = min(c[j] + (r[j] == xm ? 0 : 1), up + 1);
         }
-        below0 = spw::from_lower(nw[3], K9_INF);
+        nw[1] = min(nw[1], nw[0] + 1); nw[2] = min(nw[2], nw[1] + 1); nw[3] = min(nw[3], nw[2] + 1);
+        int f = nw[3] - 4 * lane;                                           // what this lane offers the lanes above, in lane-0 units
+        // inclusive prefix minimum over the lanes, the DPP operand riding on v_min_i32 (a lane without a source is not written: it keeps its own value)
+        asm("s_nop 4\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(f));
+        const int in = spw::from_lower(f, 1 << 20) + 4 * lane - 3;         // value arriving at this lane's first diagonal from the lanes below
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int prev = j ? nw[j - 1] : below0; need |= prev + 1 < nw[j]; }
+        for (int j = 0; j < 4; ++j) c[j] = min(min(nw[j], in + j), K9_INF);
+        return;
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1011,11 +1027,12 @@ __device__ __forceinline__ void k9_step(int (&c)[4], int x, const int (&r)[4], i
     for (int j = 0; j < 4; ++j) c[j] = nw[j] < K9_INF ? nw[j] : K9_INF;
 }
 
+template <bool STAGED>
 __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict__ pool, K9Job* __restrict__ jobs, const int32_t* __restrict__ site_so,
                                                        const int32_t* __restrict__ site_eo, const uint32_t* __restrict__ alt_first,
                                                        const int32_t* __restrict__ alt_len, const uint32_t* __restrict__ alt_off,
                                                        uint16_t* __restrict__ exits, uint16_t* __restrict__ entries, int32_t* __restrict__ alt_on, int lds_cap) {
-    extern __shared__ uint8_t seq_lds[];                  // the aligned stretch of the sequence (both passes read it four bases per lane and step)
+    extern __shared__ __align__(16) uint8_t seq_lds[];    // the aligned stretch of the sequence (both passes read it four bases per lane and step)
     __shared__ int shift[2][K9_DIAGS];
     __shared__ int opt_s;
     K9Job& J = jobs[blockIdx.x];
@@ -1025,15 +1042,31 @@ __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict
     const uint8_t* bb = pool + J.bb_off;
     const int L = __builtin_amdgcn_readfirstlane(J.L), G = __builtin_amdgcn_readfirstlane(J.G), ns = __builtin_amdgcn_readfirstlane((int)J.n_sites);
     const uint8_t* S = pool + J.seq_off;
-    const bool staged = L + G <= lds_cap;                 // (longer stretches stay in memory: same results, dependent loads on the way)
+    // Everything a pass reads step by step lies in LDS: the two stretches, the bases of the job's alternatives and its site / alternative tables (a site's offsets,
+    // an alternative's length and bases were dependent loads from memory before: with some 400 sites and 800 alternatives per sequence, half of the pass's time)
+    const int na = __builtin_amdgcn_readfirstlane((int)J.n_alts), AB = __builtin_amdgcn_readfirstlane((int)J.alt_bytes);
+    const uint32_t ab = __builtin_amdgcn_readfirstlane(J.alt_base);
+    const int tab0 = (L + G + AB + 3) & ~3;               // byte offset of the tables: so[ns], eo[ns], first[ns + 1], len[na], off[na]
+    constexpr bool staged = STAGED;                       // (a batch with a job too long for that stays in memory: same results, dependent loads on the way)
+    int* const T_so = reinterpret_cast<int*>(seq_lds + tab0); int* const T_eo = T_so + ns; int* const T_af = T_eo + ns; int* const T_al = T_af + ns + 1; int* const T_ao = T_al + na;
     if (staged) {
+        const uint8_t* ap = pool + J.alt_bytes_off;
         for (int x = threadIdx.x; x < L; x += blockDim.x) seq_lds[x] = S[x];
         for (int x = threadIdx.x; x < G; x += blockDim.x) seq_lds[L + x] = bb[x];
+        for (int x = threadIdx.x; x < AB; x += blockDim.x) seq_lds[L + G + x] = ap[x];
+        for (int x = threadIdx.x; x < ns; x += blockDim.x) { T_so[x] = site_so[J.site_first + x]; T_eo[x] = site_eo[J.site_first + x]; }
+        for (int x = threadIdx.x; x <= ns; x += blockDim.x) T_af[x] = (int)alt_first[J.site_first + blockIdx.x + x];
+        for (int x = threadIdx.x; x < na; x += blockDim.x) { T_al[x] = alt_len[ab + x]; T_ao[x] = (int)(alt_off[ab + x] - J.alt_bytes_off); }
         __syncthreads();
     }
     typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
     lds_cu8* const S3 = (lds_cu8*)(uintptr_t)spw::lds_addr(reinterpret_cast<const uint32_t*>(seq_lds));
     lds_cu8* const B3 = S3 + L;
+    lds_cu8* const A3 = B3 + G;
+    // (what comes out of LDS is the same for the whole wavefront: said so, the loops on it stay scalar loops)
+    auto so_at = [&](int si) -> int { return staged ? __builtin_amdgcn_readfirstlane(T_so[si]) : site_so[J.site_first + si]; };
+    auto eo_at = [&](int si) -> int { return staged ? __builtin_amdgcn_readfirstlane(T_eo[si]) : site_eo[J.site_first + si]; };
+    auto af_at = [&](int si) -> uint32_t { return staged ? (uint32_t)__builtin_amdgcn_readfirstlane(T_af[si]) : alt_first[J.site_first + blockIdx.x + si]; };
     const int k0 = __builtin_amdgcn_readfirstlane(mirror ? (L - G) - J.k0 - (K9_DIAGS - 1) : J.k0);
     auto gbase = [&](int g) -> int { const int x = mirror ? G - 1 - g : g; return staged ? (int)B3[x] : (int)bb[x]; };   // graph base at offset g of this pass
     // The four sequence bases in front of a lane's diagonals move up by one per graph base: they are kept in registers and shifted
@@ -1044,10 +1077,12 @@ __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[j] = sbase(off + k0 + lane * 4 + j);
     };
-    auto advance_r = [&](int new_off) {                                      // r for offset new_off from r for new_off - 1
+    // (the one new base of a step -- and the step's graph base -- are asked for BEFORE the step's arithmetic and used behind it: their LDS latency hides under it)
+    auto top_base = [&](int new_off) -> int { return sbase(new_off + k0 + 255); };
+    auto advance_r = [&](int top) {                                          // r for the next offset; top = top_base(that offset)
         const int from_above = spw::from_upper(r[0], 255);
         r[0] = r[1]; r[1] = r[2]; r[2] = r[3];
-        r[3] = lane == 63 ? sbase(new_off + k0 + 255) : from_above;
+        r[3] = lane == 63 ? top : from_above;
     };
     int c[4];
 #pragma unroll
@@ -1056,27 +1091,42 @@ __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict
     load_r(0);
     for (int t = 0; t <= ns; ++t) {
         const int si = mirror ? ns - 1 - t : t;                               // the site this pass meets t-th
-        const int so = t < ns ? (mirror ? G - site_eo[J.site_first + si] : site_so[J.site_first + si]) : G;
-        for (; g < so; ++g) { k9_step(c, gbase(g), r, L, g, k0, lane); advance_r(g + 1); }
+        const int so = t < ns ? (mirror ? G - eo_at(si) : so_at(si)) : G;
+        if (g < so) {
+            int xn = gbase(g);
+            for (; g < so; ++g) {
+                const int x = xn, top = top_base(g + 1);
+                xn = g + 1 < G ? gbase(g + 1) : 0;
+                k9_step(c, x, r, L, g, k0, lane); advance_r(top);
+            }
+        }
         if (t == ns) break;
-        const int eo = mirror ? G - site_so[J.site_first + si] : site_eo[J.site_first + si];
+        const int eo = mirror ? G - so_at(si) : eo_at(si);
         if (mirror) {                                                         // the mirrored pass leaves the column in FRONT of every site
             uint16_t* out = entries + ((size_t)J.entry_off + si) * K9_DIAGS;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)c[j];
+            reinterpret_cast<uint2*>(out)[lane] = make_uint2((uint32_t)c[0] | ((uint32_t)c[1] << 16), (uint32_t)c[2] | ((uint32_t)c[3] << 16));      // (values <= K9_INF)
         }
         int e0[4], acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { e0[j] = c[j]; acc[j] = K9_INF; }
         const int lr = eo - so;
-        const uint32_t a_lo = alt_first[J.site_first + blockIdx.x + si], a_hi = alt_first[J.site_first + blockIdx.x + si + 1];
+        const uint32_t a_lo = af_at(si), a_hi = af_at(si + 1);
         for (uint32_t a = a_lo; a < a_hi; ++a) {
             int w[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = e0[j];
-            const int len = alt_len[a]; const uint8_t* as = pool + alt_off[a];
+            const int len = staged ? __builtin_amdgcn_readfirstlane(T_al[a - ab]) : alt_len[a];
+            const uint8_t* as = pool + (staged ? 0u : alt_off[a]); lds_cu8* const as3 = A3 + (staged ? __builtin_amdgcn_readfirstlane(T_ao[a - ab]) : 0);
+            auto abase = [&](int x) -> int { const int y = mirror ? len - 1 - x : x; return staged ? (int)as3[y] : (int)as[y]; };
             load_r(so);
-            for (int x = 0; x < len; ++x) { k9_step(w, as[mirror ? len - 1 - x : x], r, L, so + x, k0, lane); advance_r(so + x + 1); }
+            if (len > 0) {
+                int xn = abase(0);
+                for (int x = 0; x < len; ++x) {
+                    const int b = xn, top = top_base(so + x + 1);
+                    xn = x + 1 < len ? abase(x + 1) : 0;
+                    k9_step(w, b, r, L, so + x, k0, lane); advance_r(top);
+                }
+            }
             // the alternative is len bases where the reference has lr: its diagonals shift by len - lr at the site's end
             const int delta = len - lr;
 #pragma unroll
@@ -1087,8 +1137,7 @@ __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict
             spw::wave_lds_sync();
             if (!mirror) {
                 uint16_t* out = exits + ((size_t)J.exit_off + (a - J.alt_base)) * K9_DIAGS;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)w[j];
+                reinterpret_cast<uint2*>(out)[lane] = make_uint2((uint32_t)w[0] | ((uint32_t)w[1] << 16), (uint32_t)w[2] | ((uint32_t)w[3] << 16));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = w[j] < acc[j] ? w[j] : acc[j];
@@ -1115,12 +1164,16 @@ __global__ __launch_bounds__(128) void k9_graph_kernel(const uint8_t* __restrict
     const int wave = threadIdx.x >> 6;
     for (int si = wave; si < ns; si += 2) {
         const uint16_t* back = entries + ((size_t)J.entry_off + si) * K9_DIAGS;
-        const uint32_t a_lo = alt_first[J.site_first + blockIdx.x + si], a_hi = alt_first[J.site_first + blockIdx.x + si + 1];
+        const uint32_t a_lo = af_at(si), a_hi = af_at(si + 1);
         for (uint32_t a = a_lo; a < a_hi; ++a) {
             const uint16_t* ex = exits + ((size_t)J.exit_off + (a - J.alt_base)) * K9_DIAGS;
             bool on = false;
+            const uint2 e4 = reinterpret_cast<const uint2*>(ex)[lane], b4 = reinterpret_cast<const uint2*>(back)[63 - lane];      // diagonal d of the exit faces K9_DIAGS - 1 - d of the mirrored pass
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int d = lane * 4 + j; const int e = ex[d], bk = back[K9_DIAGS - 1 - d]; if (e < K9_INF && bk < K9_INF && e + bk == opt) on = true; }
+            for (int j = 0; j < 4; ++j) {
+                const int e = (int)(((j < 2 ? e4.x : e4.y) >> (16 * (j & 1))) & 0xFFFFu), bk = (int)(((j < 2 ? b4.y : b4.x) >> (16 * (1 - (j & 1)))) & 0xFFFFu);
+                if (e < K9_INF && bk < K9_INF && e + bk == opt) on = true;
+            }
             const bool any = __ballot(on) != 0;
             if (lane == 0) alt_on[a] = any ? 1 : 0;
         }
@@ -1136,6 +1189,8 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
     const uint32_t S = seqs->n;
     if (states) std::memset(states, 3, (size_t)S * n_variants);
     if (S == 0) return SP_OK;
+    const bool k9dbg = std::getenv("SP_K9_DEBUG") != nullptr; auto k9t0 = std::chrono::steady_clock::now();
+    auto k9mark = [&](const char* what) { if (!k9dbg) return; const auto n = std::chrono::steady_clock::now(); std::fprintf(stderr, "k9 %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - k9t0).count()); k9t0 = n; };
     // place every sequence on the backbone (sequence = indexed / streamed side A, backbone = window side B), with traceback
     sp_seqset bb_pooled; sp_seqset* bbset = &bb_pooled;
     const uint64_t boff[2] = { 0, backbone_len };
@@ -1143,12 +1198,15 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
     if (rc != SP_OK) return rc;
     std::vector<uint32_t> ai(S), bi(S, 0); for (uint32_t i = 0; i < S; ++i) ai[i] = i;
     std::vector<int32_t> diag(S), votes(S);
+    k9mark("backbone set");
     rc = sp_anchor_batch(ctx, seqs, bbset, ai.data(), bi.data(), S, diag.data(), votes.data());
+    k9mark("anchor");
     std::vector<sp_pair> pairs; std::vector<uint32_t> who;
     if (rc == SP_OK) for (uint32_t i = 0; i < S; ++i) if (votes[i] >= CYP_MIN_VOTES) { pairs.push_back(sp_pair{ i, 0, diag[i], SP_MAX_ED }); who.push_back(i); }
     std::vector<sp_aln> alns(pairs.size()); std::vector<uint32_t> events(pairs.size() * (size_t)SP_MAX_ED);
     if (rc == SP_OK && !pairs.empty()) rc = sp_align_batch(ctx, seqs, bbset, pairs.data(), pairs.size(), alns.data(), events.data(), SP_MAX_ED);
     if (rc != SP_OK) return rc;
+    k9mark("align + traceback");
     if (alns_out) { std::memset(alns_out, 0, sizeof(sp_aln) * S); for (size_t x = 0; x < who.size(); ++x) alns_out[who[x]] = alns[x]; }
     if (n_variants == 0) return SP_OK;
     auto code = [](char c) -> uint8_t { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; };
@@ -1180,7 +1238,7 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
         std::vector<int> order;
         for (uint32_t v = 0; v < n_variants; ++v) if (var_pos[v] >= gs && var_pos[v] + rlen[v] <= ge) order.push_back((int)v);
         std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return var_pos[p] < var_pos[q]; });     // (ties keep the variant order)
-        J.site_first = (uint32_t)site_so.size(); J.alt_base = (uint32_t)alt_len.size();
+        J.site_first = (uint32_t)site_so.size(); J.alt_base = (uint32_t)alt_len.size(); J.alt_bytes_off = (uint32_t)pool.size();
         J.exit_off = (uint32_t)n_exit; J.entry_off = (uint32_t)n_entry;
         uint32_t ns = 0;
         for (size_t a = 0; a < order.size();) {
@@ -1210,11 +1268,12 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
             ++ns;
         }
         alt_first.push_back((uint32_t)alt_len.size());                              // one closing entry per job (the kernel indexes site_first + job + site)
-        J.n_sites = ns;
+        J.n_sites = ns; J.n_alts = (uint32_t)alt_len.size() - J.alt_base; J.alt_bytes = (uint32_t)pool.size() - J.alt_bytes_off;
         n_exit += alt_len.size() - J.alt_base; n_entry += ns;
         jobs.push_back(J); job_seq.push_back(sidx);
     }
     if (jobs.empty()) return SP_OK;
+    k9mark("graphs on the host");
     uint8_t* d_pool = (uint8_t*)sp_pool(ctx, "k9_pool", pool.size() + 16);
     K9Job* d_jobs = (K9Job*)sp_pool(ctx, "k9_jobs", jobs.size() * sizeof(K9Job));
     int32_t* d_so = (int32_t*)sp_pool(ctx, "k9_so", (site_so.size() + 1) * 4); int32_t* d_eo = (int32_t*)sp_pool(ctx, "k9_eo", (site_eo.size() + 1) * 4);
@@ -1231,15 +1290,21 @@ extern "C" int32_t sp_cyp_variant_states(sp_ctx* ctx, const sp_seqset* seqs, con
     (void)hipMemsetAsync(d_on, 0, (alt_len.size() + 1) * 4, ctx->stream);
     {
         ProfScope ps(ctx, "k9_graph", jobs.size());
-        int max_l = 0; for (const K9Job& j : jobs) max_l = std::max(max_l, (int)(j.L + j.G));
-        const int lds_cap = std::min(max_l, 60 * 1024);
-        (void)hipFuncSetAttribute((const void*)k9_graph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap + 16);
-        hipLaunchKernelGGL(k9_graph_kernel, dim3((unsigned)jobs.size()), dim3(128), (size_t)lds_cap + 16, ctx->stream, d_pool, d_jobs, d_so, d_eo, d_af, d_al, d_ao, d_exit, d_entry, d_on, lds_cap);
+        int max_l = 0; for (const K9Job& j : jobs) max_l = std::max(max_l, k9_lds_bytes(j.L, j.G, (int)j.alt_bytes, (int)j.n_sites, (int)j.n_alts));
+        const bool fits = max_l <= 60 * 1024;
+        const int lds_cap = fits ? max_l : 0;
+        if (std::getenv("SP_K9_DEBUG")) for (const K9Job& j : jobs) std::fprintf(stderr, "k9 job L %d G %d sites %u alts %u alt_bytes %u need %d cap %d\n", j.L, j.G, j.n_sites, j.n_alts, j.alt_bytes, k9_lds_bytes(j.L, j.G, (int)j.alt_bytes, (int)j.n_sites, (int)j.n_alts), lds_cap);
+        if (fits) {
+            (void)hipFuncSetAttribute((const void*)k9_graph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap + 16);
+            hipLaunchKernelGGL(k9_graph_kernel<true>, dim3((unsigned)jobs.size()), dim3(128), (size_t)lds_cap + 16, ctx->stream, d_pool, d_jobs, d_so, d_eo, d_af, d_al, d_ao, d_exit, d_entry, d_on, lds_cap);
+        } else
+            hipLaunchKernelGGL(k9_graph_kernel<false>, dim3((unsigned)jobs.size()), dim3(128), 16, ctx->stream, d_pool, d_jobs, d_so, d_eo, d_af, d_al, d_ao, d_exit, d_entry, d_on, 0);
     }
     std::vector<int32_t> on(alt_len.size() + 1);
     (void)hipMemcpyAsync(on.data(), d_on, (alt_len.size() + 1) * 4, hipMemcpyDeviceToHost, ctx->stream);
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("k9: ") + hipGetErrorString(e));
+    k9mark("uploads + kernel + sync");
     // a variant is 1 / 0 when every optimal alternative of its site carries / lacks it, 2 when they disagree
     for (size_t jx = 0; jx < jobs.size(); ++jx) {
         const K9Job& J = jobs[jx];
@@ -1323,23 +1388,37 @@ static int32_t type_fresh(sp_ctx* ctx, const sp_cyp_problem* pr, const std::vect
         std::vector<sp_region_hit> hits(fresh.size() * 16 + 16); uint64_t nh = 0;
         rc = cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh, false);
         if (rc == SP_OK && nh > hits.size()) { hits.resize(nh); rc = cyp_find_regions(ctx, pr->templates, pr->template_type, set, max_missing, hits.data(), hits.size(), &nh, false); }
-        std::vector<uint8_t> states((size_t)fresh.size() * pr->n_variants, 3);
-        if (rc == SP_OK) rc = sp_cyp_variant_states(ctx, set, pr->backbone, pr->backbone_len, pr->n_variants, pr->var_pos, pr->var_ref, pr->var_alt, states.data(), nullptr);
-        std::vector<uint32_t> bvi(fresh.size()), ball(fresh.size()); std::vector<uint8_t> tie((size_t)fresh.size() * std::max<uint32_t>(pr->n_alleles, 1));
-        if (rc == SP_OK && pr->n_alleles && pr->n_variants)
-            rc = sp_cyp_score_alleles(ctx, pr->n_variants, pr->n_alleles, pr->hap_matrix, pr->var_is_vi, (uint32_t)fresh.size(), states.data(), bvi.data(), ball.data(), tie.data());
         if (rc != SP_OK) return rc;
-        for (uint32_t x = 0; x < fresh.size(); ++x) {
+        // the best match of a sequence: lowest penalised score, first on ties (:344-349)
+        std::vector<uint32_t> deep_of;                                   // the sequences whose best match is a CYP2D6 template: only they are looked at variant by variant
+        std::string dblob; std::vector<uint64_t> doff(1, 0);             // (assign_haplotype is only called for them, haplotyper.rs:371; a CYP2D7 consensus is 4 % away from the
+        for (uint32_t x = 0; x < fresh.size(); ++x) {                    //  backbone: its placement alone was a third of this step)
             Typed& t = cache[*fresh[x]];
-            // the best match of this sequence: lowest penalised score, first on ties (:344-349)
             double bs = 0;
             for (uint64_t h = 0; h < nh; ++h) if (hits[h].read == (int32_t)x) {
                 const double sc = cyp_score(hits[h].seq_len, hits[h].nm, hits[h].unmapped, true);
                 if (t.best_template < 0 || sc < bs) { t.best_template = hits[h].template_idx; bs = sc; }
             }
-            t.bvi = bvi[x]; t.ball = ball[x];
-            t.tie.assign(tie.begin() + (size_t)x * pr->n_alleles, tie.begin() + (size_t)(x + 1) * pr->n_alleles);
-            t.states.assign(states.begin() + (size_t)x * pr->n_variants, states.begin() + (size_t)(x + 1) * pr->n_variants);
+            t.bvi = 0; t.ball = 0; t.tie.assign(pr->n_alleles, 0); t.states.assign(pr->n_variants, 3);
+            if (t.best_template >= 0 && pr->template_deep[t.best_template]) { deep_of.push_back(x); dblob += *fresh[x]; doff.push_back(dblob.size()); }
+        }
+        if (!deep_of.empty()) {
+            const uint32_t D = (uint32_t)deep_of.size();
+            sp_seqset dpooled; sp_seqset* dset = &dpooled;
+            const bool all = D == fresh.size();
+            if (!all) { rc = sp_seqset_make_small(ctx, "cyp_typed_deep", dblob.data(), doff.data(), D, true, dset); if (rc != SP_OK) return rc; }
+            std::vector<uint8_t> states((size_t)D * pr->n_variants, 3);
+            rc = sp_cyp_variant_states(ctx, all ? set : dset, pr->backbone, pr->backbone_len, pr->n_variants, pr->var_pos, pr->var_ref, pr->var_alt, states.data(), nullptr);
+            std::vector<uint32_t> bvi(D), ball(D); std::vector<uint8_t> tie((size_t)D * std::max<uint32_t>(pr->n_alleles, 1));
+            if (rc == SP_OK && pr->n_alleles && pr->n_variants)
+                rc = sp_cyp_score_alleles(ctx, pr->n_variants, pr->n_alleles, pr->hap_matrix, pr->var_is_vi, D, states.data(), bvi.data(), ball.data(), tie.data());
+            if (rc != SP_OK) return rc;
+            for (uint32_t y = 0; y < D; ++y) {
+                Typed& t = cache[*fresh[deep_of[y]]];
+                t.bvi = bvi[y]; t.ball = ball[y];
+                t.tie.assign(tie.begin() + (size_t)y * pr->n_alleles, tie.begin() + (size_t)(y + 1) * pr->n_alleles);
+                t.states.assign(states.begin() + (size_t)y * pr->n_variants, states.begin() + (size_t)(y + 1) * pr->n_variants);
+            }
         }
     }
     return SP_OK;
