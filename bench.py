@@ -694,6 +694,7 @@ def main():
                                                                          ("expansions_per_step", "cons_expansions"), ("nodes_expanded_per_step", "cons_columns"))}
     host_ms = {k: ctx.profile_get("host:" + k)[0] / max(1, args.steps) for k in ("hla_segments", "hla_dual_hpc", "hla_groups", "hla_typing", "k8_loop", "k1_total", "hla_genes_total")}
     cyp_host_ms = {k: ctx_c.profile_get("host:cyp_" + k)[0] / max(1, args.steps) for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")}
+    cyp_host_ms["k8"] = {k: [round(ctx_c.profile_get("host:k8_" + k)[0] / max(1, args.steps), 2), ctx_c.profile_get("host:k8_" + k)[1] // max(1, args.steps)] for k in ("prologue", "loop", "result_wait", "epilogue")}
     avg_ms = ms_cells / max(1, launches)
     per_launch = lambda v: v / max(1, launches)
     achieved = per_launch(exec_bytes) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -738,6 +739,8 @@ def main():
             legs["headline_with_persistent_consensus"] = {"value": reads_per_step * args.steps / d_p, "unit": "reads/s", "ms_per_step": 1e3 * d_p / args.steps,
                                                           "cyp2d6_cons_steps_ms": ctx_c.profile_get("cons_steps")[0] / max(1, args.steps),
                                                           "cyp2d6_call_equals_truth": sorted([last["cyp"][1].hap1.decode(), last["cyp"][1].hap2.decode()]) == sorted(cyp_samples[last["cyp"][0] % 2].expected),
+                                                          "host_wall_ms_cyp2d6": {k: round(ctx_c.profile_get("host:cyp_" + k)[0] / max(1, args.steps), 2) for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")},
+                                                          "host_wall_ms_k8": {k: [round(ctx_c.profile_get("host:k8_" + k)[0] / max(1, args.steps), 2), ctx_c.profile_get("host:k8_" + k)[1] // max(1, args.steps)] for k in ("prologue", "loop", "result_wait", "epilogue")},
                                                           "critical_path_cyp2d6": critical_path(ctx_c)}
         except Exception as e:                                                   # (the library's own error text)
             legs["headline_with_persistent_consensus"] = {"error": str(e)}

@@ -11,7 +11,7 @@ cfg, gene_def = cr.load_db()
 locus = synth.Chr22Locus(cfg, gene_def, seed=3)
 cdb = pkg.ffi.CypDb(ctx, cfg, gene_def, locus.sequence, locus.start)
 scen = cr.scenarios(locus)
-R = ctx.upload(locus.sample(np.random.default_rng(5), scen[0][1], 2000, lo=8000, hi=16000))
+R = ctx.upload(locus.sample(np.random.default_rng(5), scen[0][1], 2000))       # (the reads of the bench: 3-8 kb)
 for _ in range(3):
     print("--- call", file=sys.stderr, flush=True)
     call, cons, labels = cdb.diplotype(R)
