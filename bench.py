@@ -683,6 +683,9 @@ def main():
         if steps > 0:
             out["per_step_us"] = {"step_kernel": 1e3 * out["step_kernel_ms"] / steps, "control_kernel": 1e3 * out["control_kernel_ms"] / steps,
                                   "between_kernels_per_boundary": 1e3 * out["between_kernels_ms"] / (2 * steps)}
+            # the control step by part (the slowest problem of every batch, all steps of the batch -- not only the chain's): loading the work order and adding up the
+            # workgroups' votes / the result of the step (columns decided, tapes written) / the search for the next node / the next work order and the write-back
+            out["control_parts_us_per_step"] = {k: 1e3 * ms("cons_ticks_" + k) / steps for k in ("reduce", "result", "search", "tail")}
         out["note"] = ("the chain is latency bound: every step is step body -> control body -> next step body; as a launch pair per step each arrow is a dependent same-stream "
                        "kernel boundary (MI355X_MICROARCH.md: 1.45 us on an idle device), in persistent mode a write-through store + drain + flag and a poll (handoff-flag: 1.3-5 us)")
         return out
