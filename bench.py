@@ -53,6 +53,15 @@ def cyp_persistent():
     return int(os.environ.get("SP_BENCH_CYP_PERSISTENT", "0"))
 
 
+def headline_persistent():
+    """SP_BENCH_HEADLINE_PERSISTENT (default 1): the headline's CYP2D6 context runs its consensus chains as persistent kernels (sp_ctx_set_option "k8_persistent").  In this
+    pipeline -- one process per GPU, a dozen streams, 16 hardware queues -- the mode's condition holds (every stream of the process on a hardware queue of its own), and the
+    step is 8-11 % faster (profiles/r04/k8_persistent_final.txt).  Where it does not hold the library ends the batch after four seconds with an error: the warm-up steps would
+    show that, and the run then goes on with a launch pair per step and says so in config.cyp2d6_consensus.  The other legs (cohort, samples in flight: many streams) and every
+    run under a profiler that serialises kernels (profiles/run_rocprof.sh sets 0) use launch pairs."""
+    return int(os.environ.get("SP_BENCH_HEADLINE_PERSISTENT", "1"))
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks as child processes BEFORE this process touches the GPU (never
     re-exec a process that has), wait for them, fail if any of them fails.  Rank 0's stdout is the JSON line."""
@@ -192,13 +201,19 @@ class Lane(threading.Thread):
         try:
             for i in range(self.steps):
                 if self.fresh:
+                    t_u = time.perf_counter()
                     cur = self.pending.wait()
+                    t_v = time.perf_counter()
                     self.pending = self.start_upload(i + 1)          # the next sample's bytes travel under this sample's kernels
+                    self.t_wait = getattr(self, "t_wait", 0.0) + (t_v - t_u); self.t_start = getattr(self, "t_start", 0.0) + (time.perf_counter() - t_v)
                 else:
                     cur = self.resident[i % len(self.resident)]
+                t_w = time.perf_counter()
                 self.result = self.work(cur, i)
+                t_c = time.perf_counter()
                 if self.fresh:
                     cur.close()
+                self.t_work = getattr(self, "t_work", 0.0) + (t_c - t_w); self.t_close = getattr(self, "t_close", 0.0) + (time.perf_counter() - t_c)
             if self.fresh:
                 self.pending.wait().close()
                 self.pending = None
@@ -628,7 +643,8 @@ def main():
     # ------------------------------------------------------------------------------------------------ the sample: HLA-A / -B + CYP2D6, a new one every step
     ctx_c = pkg.Context(device_index)                       # the CYP2D6 half runs beside the HLA half on a context (stream, pools) of its own
     cdb_c = pkg.ffi.CypDb(ctx_c, cfg, gene_def, locus.sequence, locus.start)
-    ctx_c.set_option("k8_persistent", cyp_persistent())     # the CYP2D6 chain as persistent kernels: this process has the device to itself
+    headline_mode = {"persistent": bool(headline_persistent() or cyp_persistent()), "fallback": None}
+    ctx_c.set_option("k8_persistent", 1 if headline_mode["persistent"] else 0)     # the CYP2D6 chain as persistent kernels: this process has the device to itself
     if os.environ.get("SP_BENCH_MM2_RESCORE"):              # (an experiment switch: what the re-scored numbers of K1 / K2 cost the step)
         ctx.set_option("mm2_rescore", int(os.environ["SP_BENCH_MM2_RESCORE"]))
     if os.environ.get("SP_BENCH_HLA_SPLIT"):                # (an experiment switch: the two HLA genes of the sample on one stream (0) or two (1, the library's default))
@@ -650,17 +666,30 @@ def main():
     def make_lanes(steps, fresh=True):
         return [Lane(pkg, ctx, [s.payload for s in samples], hla_work, steps, fresh), Lane(pkg, ctx_c, [s.payload for s in cyp_samples], cyp_work, steps, fresh)]
 
-    run_lanes(make_lanes(max(1, args.warmup)))
-    ctx.profile_reset(); ctx_c.profile_reset()
-    lanes = make_lanes(args.steps)                          # (sample 0's bytes start travelling here: the pipeline is full when the clock starts)
-    for x in lanes:
-        x.pending.wait()
-    barrier(); ctx_c.synchronize()
-    t0 = time.perf_counter()
-    run_lanes(lanes)
-    barrier(); ctx_c.synchronize()
-    dt = time.perf_counter() - t0
+    def timed_region():
+        run_lanes(make_lanes(max(1, args.warmup)))
+        ctx.profile_reset(); ctx_c.profile_reset()
+        lanes = make_lanes(args.steps)                      # (sample 0's bytes start travelling here: the pipeline is full when the clock starts)
+        for x in lanes:
+            x.pending.wait()
+        barrier(); ctx_c.synchronize()
+        t0 = time.perf_counter()
+        run_lanes(lanes)
+        barrier(); ctx_c.synchronize()
+        return lanes, time.perf_counter() - t0
+    try:
+        lanes, dt = timed_region()
+    except Exception as e:
+        if not headline_mode["persistent"] or world > 1:    # (ranks run in lockstep: one of them starting over would leave the others at a barrier)
+            raise
+        # the persistent kernels of a batch could not run side by side here (the library's own error, after its four-second time-out): a launch pair per step instead
+        headline_mode.update(persistent=False, fallback=str(e))
+        sys.stderr.write("bench: persistent consensus kernels failed (%s): the headline runs with a launch pair per step\n" % e)
+        ctx_c.set_option("k8_persistent", 0)
+        lanes, dt = timed_region()
     reads_per_step = samples[0].n + cyp_samples[0].n
+    # a lane's host time per step: waiting for the sample's bytes / starting the next upload / the library calls / closing the sample's read set
+    lane_ms = [{k: round(1e3 * getattr(x, "t_" + k, 0.0) / max(1, args.steps), 3) for k in ("wait", "start", "work", "close")} for x in lanes]
 
     e2e_names = ("anchor_k1", "anchor_k2", "anchor_type", "k1_cells", "k1_cells_deep", "k1_reduce", "k1_finalize", "cons_steps", "type_consensus_ref",
                  "k2_cells_cdna", "k2_cells_dna", "k2_scan")
@@ -723,12 +752,13 @@ def main():
         t_up[name] = {"seconds": best, "bytes": int(len(payload[0])), "GBps": len(payload[0]) / best / 1e9, "bases_per_s": samples[0].ascii_bytes / best}
 
     legs = {}
-    if not args.no_extra_legs and not cyp_persistent():
-        # the headline's step once more with the CYP2D6 context's consensus as persistent kernels (sp_ctx_set_option "k8_persistent"; off by default: DESIGN 9): the same
-        # samples, uploads and calls.  A leg, not `value`: the mode needs every stream of the process on a hardware queue of its own and fails with an error (after a
-        # four-second time-out) where it is not -- which is reported here instead of raised
+    other_leg = "headline_with_launch_pairs" if headline_mode["persistent"] else "headline_with_persistent_consensus"
+    if not args.no_extra_legs and not cyp_persistent() and headline_mode["fallback"] is None:
+        # the headline's step once more in the other consensus mode of the CYP2D6 context (sp_ctx_set_option "k8_persistent"): the same samples, uploads and calls.
+        # (persistent kernels need every stream of the process on a hardware queue of its own and fail with an error, after a four-second time-out, where it is not --
+        #  which is reported here instead of raised)
         try:
-            ctx_c.set_option("k8_persistent", 1)
+            ctx_c.set_option("k8_persistent", 0 if headline_mode["persistent"] else 1)
             run_lanes(make_lanes(max(1, args.warmup)))
             ctx_c.profile_reset()
             lanes_p = make_lanes(args.steps)
@@ -739,16 +769,15 @@ def main():
             run_lanes(lanes_p)
             ctx_c.synchronize(); ctx.synchronize()
             d_p = time.perf_counter() - t1
-            legs["headline_with_persistent_consensus"] = {"value": reads_per_step * args.steps / d_p, "unit": "reads/s", "ms_per_step": 1e3 * d_p / args.steps,
+            legs[other_leg] = {"value": reads_per_step * args.steps / d_p, "unit": "reads/s", "ms_per_step": 1e3 * d_p / args.steps,
                                                           "cyp2d6_cons_steps_ms": ctx_c.profile_get("cons_steps")[0] / max(1, args.steps),
                                                           "cyp2d6_call_equals_truth": sorted([last["cyp"][1].hap1.decode(), last["cyp"][1].hap2.decode()]) == sorted(cyp_samples[last["cyp"][0] % 2].expected),
                                                           "host_wall_ms_cyp2d6": {k: round(ctx_c.profile_get("host:cyp_" + k)[0] / max(1, args.steps), 2) for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")},
                                                           "host_wall_ms_k8": {k: [round(ctx_c.profile_get("host:k8_" + k)[0] / max(1, args.steps), 2), ctx_c.profile_get("host:k8_" + k)[1] // max(1, args.steps)] for k in ("prologue", "loop", "result_wait", "epilogue")},
                                                           "critical_path_cyp2d6": critical_path(ctx_c)}
         except Exception as e:                                                   # (the library's own error text)
-            legs["headline_with_persistent_consensus"] = {"error": str(e)}
-        finally:
-            ctx_c.set_option("k8_persistent", 0)
+            legs[other_leg] = {"error": str(e)}
+    ctx_c.set_option("k8_persistent", cyp_persistent())     # (the legs below: many streams, launch pairs unless SP_BENCH_CYP_PERSISTENT asks otherwise)
     if not args.no_extra_legs:
         # HLA alone, reads resident in HBM (round 2's headline): the K1 launch the roofline block describes runs here exactly as in the headline
         res_lane = Lane(pkg, ctx, [s.payload for s in samples], hla_work, args.steps, fresh_upload=False)
@@ -833,7 +862,9 @@ def main():
                                "DNA) and CYP2D6, %d targeted reads (39 templates, 393 variants / 520 star alleles); a new sample's bytes (BAM 4-bit SEQ) uploaded every step "
                                "under the previous sample's kernels; reads -> diplotypes of both loci" % (samples[0].n, cyp_samples[0].n),
                    "reads_per_step": reads_per_step, "hla_reads": samples[0].n, "cyp2d6_reads": cyp_samples[0].n, "alleles": len(fx.ids),
-                   "parallelism": "one GPU: the two loci side by side on two contexts (host threads, HIP streams), uploads on copy streams"},
+                   "parallelism": "one GPU: the two loci side by side on two contexts (host threads, HIP streams), uploads on copy streams",
+                   "cyp2d6_consensus": ("persistent kernels (sp_ctx_set_option k8_persistent = 1 on the CYP2D6 context: two launches per batch, hand-overs through memory; SP_BENCH_HEADLINE_PERSISTENT=0 for launch pairs)"
+                                        if headline_mode["persistent"] else "a launch pair per step" + ("" if headline_mode["fallback"] is None else " (the persistent kernels failed here: %s)" % headline_mode["fallback"]))},
         "roofline": {"bound": "hbm", "kernel": "k1_cells_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "algorithmic_bytes_per_launch": per_launch(exec_bytes), "cells_executed_per_launch": per_launch(executed),
@@ -845,7 +876,7 @@ def main():
                              "database sits in L2: its limiter is instruction issue (roofline_valu), 'traffic' is what actually crossed HBM"},
         "roofline_valu": valu,
         "stale_counter_files": stale or None,
-        "kernel_ms": {"hla": kernel_ms, "cyp2d6": cyp_kernel_ms}, "host_wall_ms": {"hla": host_ms, "cyp2d6": cyp_host_ms},
+        "kernel_ms": {"hla": kernel_ms, "cyp2d6": cyp_kernel_ms}, "host_wall_ms": {"hla": host_ms, "cyp2d6": cyp_host_ms, "lanes_hla_cyp2d6": lane_ms},
         "critical_path": crit,
         "consensus_hla": cons,
         "concordance": {"hla_diplotypes_equal_truth": f"{ok}/{len(genes)} genes", "cyp2d6_call_equals_truth": bool(cyp_ok), "k1_gene_correct": k1_gene_ok,

@@ -75,6 +75,11 @@ void sp_ctx_destroy(sp_ctx* ctx) {
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     hipStreamSynchronize(ctx->stream);
+    for (sp_seqset* s : ctx->live_sets) {                        // read sets that outlive the context keep their buffers and free them themselves
+        for (void* p : { (void*)s->d_words, (void*)s->d_nplane, (void*)s->d_word_off, (void*)s->d_len, (void*)s->d_kcode, (void*)s->d_kpos, (void*)s->d_koff }) if (p) ctx->dev_cap.erase(p);
+        s->ctx = nullptr;
+    }
+    for (auto& kv : ctx->dev_cap) (void)hipFree(kv.first);       // the idle ones
     if (ctx->scratch) hipFree(ctx->scratch);
     for (auto& kv : ctx->pool) if (kv.second.first) hipFree(kv.second.first);
     for (auto& kv : ctx->host_pool) if (kv.second.first) hipHostFree(kv.second.first);
@@ -207,7 +212,7 @@ static void upload_run(sp_seqset* s) {
             bad(hipStreamSynchronize(st), "upload");
             if (u->rc == SP_OK && flag) {
                 s->has_n = true;
-                if (hipMalloc(&s->d_nplane, u->wbytes) != hipSuccess) { u->rc = SP_ERR_OUT_OF_MEMORY; u->err = "seqset nplane"; }
+                if (!(s->d_nplane = (uint32_t*)sp_dev_alloc(ctx, u->wbytes))) { u->rc = SP_ERR_OUT_OF_MEMORY; u->err = "seqset nplane"; }
                 else {
                     bad(hipMemsetAsync(s->d_nplane, 0, u->wbytes, st), "clear N plane");
                     if (sp_launch_pack_on(st, ctx->num_cus, u->format, u->d_stage, u->d_off, s->d_word_off, s->d_len, n, nullptr, s->d_nplane, u->d_flag) != SP_OK) { u->rc = SP_ERR_HIP; u->err = "pack kernel launch"; }
@@ -238,6 +243,7 @@ static int32_t upload_start(sp_ctx* ctx, int32_t format, const void* data, const
     sp_seqset* s = new (std::nothrow) sp_seqset();
     if (!s) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seqset");
     s->ctx = ctx; s->n = n;
+    { std::lock_guard<std::mutex> g(ctx->dev_cache_mu); ctx->live_sets.insert(s); }
     s->h_len.resize(n); s->h_word_off.resize((size_t)n + 1);
     uint64_t total_words = 0;
     const uint64_t per_byte = format == SP_SEQ_ASCII ? 1 : format == SP_SEQ_BAM4 ? 2 : 4;
@@ -256,9 +262,9 @@ static int32_t upload_start(sp_ctx* ctx, int32_t format, const void* data, const
     s->h_word_off[n] = total_words;
     auto fail = [&](const char* what) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, what); };
     const size_t wbytes = (total_words + SP_SEQ_PAD_WORDS) * sizeof(uint32_t);
-    if (hipMalloc(&s->d_words, wbytes) != hipSuccess) return fail("seqset words");
-    if (hipMalloc(&s->d_word_off, ((size_t)n + 1) * sizeof(uint64_t)) != hipSuccess) return fail("seqset offsets");
-    if (hipMalloc(&s->d_len, std::max<size_t>(1, n) * sizeof(int32_t)) != hipSuccess) return fail("seqset lengths");
+    if (!(s->d_words = (uint32_t*)sp_dev_alloc(ctx, wbytes))) return fail("seqset words");
+    if (!(s->d_word_off = (uint64_t*)sp_dev_alloc(ctx, ((size_t)n + 1) * sizeof(uint64_t)))) return fail("seqset offsets");
+    if (!(s->d_len = (int32_t*)sp_dev_alloc(ctx, std::max<size_t>(1, n) * sizeof(int32_t)))) return fail("seqset lengths");
     if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_HIP, "copy stream"); }
     sp_upload* u = new (std::nothrow) sp_upload();
     if (!u) return fail("seqset upload");
@@ -305,19 +311,67 @@ int32_t sp_seqset_upload(sp_ctx* ctx, const char* bases, const uint64_t* offsets
     return sp_seqset_upload_format(ctx, SP_SEQ_ASCII, bases, offsets, nullptr, n, out);
 }
 
+} // extern "C"
+// ---- the cache of read-set buffers (sp_ctx::dev_cache)
+static size_t dev_round(size_t bytes) {           // sizes that differ by a few per cent share a class: the samples of a run are about the same size
+    size_t g = 4096; while (g * 16 < bytes) g <<= 1;               // granule: 1/16 .. 1/8 of the size
+    return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
+}
+void* sp_dev_alloc(sp_ctx* ctx, size_t bytes) {
+    const size_t want = dev_round(bytes);
+    {
+        std::lock_guard<std::mutex> g(ctx->dev_cache_mu);
+        auto it = ctx->dev_cache.lower_bound(want);
+        if (it != ctx->dev_cache.end() && it->first <= 2 * want) { void* p = it->second; ctx->dev_cache_bytes -= it->first; ctx->dev_cache.erase(it); return p; }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        // out of memory with buffers lying idle: give them back and try once more
+        std::vector<void*> idle;
+        { std::lock_guard<std::mutex> g(ctx->dev_cache_mu); for (auto& kv : ctx->dev_cache) { idle.push_back(kv.second); ctx->dev_cap.erase(kv.second); } ctx->dev_cache.clear(); ctx->dev_cache_bytes = 0; }
+        for (void* q : idle) (void)hipFree(q);
+        if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+    }
+    std::lock_guard<std::mutex> g(ctx->dev_cache_mu);
+    ctx->dev_cap[p] = want;
+    return p;
+}
+void sp_dev_release(sp_ctx* ctx, void* p) {
+    if (!p) return;
+    constexpr size_t MAX_BYTES = (size_t)2 << 30, MAX_BUFFERS = 64;
+    {
+        std::lock_guard<std::mutex> g(ctx->dev_cache_mu);
+        auto it = ctx->dev_cap.find(p);
+        if (it == ctx->dev_cap.end()) { (void)hipFree(p); return; }        // (not one of ours)
+        if (ctx->dev_cache.size() < MAX_BUFFERS && ctx->dev_cache_bytes + it->second <= MAX_BYTES) { ctx->dev_cache.emplace(it->second, p); ctx->dev_cache_bytes += it->second; return; }
+        ctx->dev_cap.erase(it);
+    }
+    (void)hipFree(p);
+}
+extern "C" {
+
 int32_t sp_seqset_skipped(const sp_seqset* s, uint32_t* n_skipped) { if (!s || !n_skipped) return SP_ERR_INVALID_ARG; *n_skipped = s->n_skipped; return SP_OK; }
 
 void sp_seqset_free(sp_seqset* s) {
     if (!s) return;
     if (s->ctx) hipSetDevice(s->ctx->device);
     if (s->up) { (void)upload_finish(s); }                        // an upload still under way ends first
-    if (s->d_words) hipFree(s->d_words);
-    if (s->d_nplane) hipFree(s->d_nplane);
-    if (s->d_word_off) hipFree(s->d_word_off);
-    if (s->d_len) hipFree(s->d_len);
-    if (s->d_kcode) hipFree(s->d_kcode);
-    if (s->d_kpos) hipFree(s->d_kpos);
-    if (s->d_koff) hipFree(s->d_koff);
+    if (s->ctx) {
+        // the buffers go back to the context for the next read set (no hipFree: that waits for every stream of the device).  Every call that was given the set has
+        // returned, i.e. has waited for its own streams; the context's stream is waited for once more here, which costs nothing when it is idle
+        (void)hipStreamSynchronize(s->ctx->stream);
+        { std::lock_guard<std::mutex> g(s->ctx->dev_cache_mu); s->ctx->live_sets.erase(s); }
+        sp_dev_release(s->ctx, s->d_words); sp_dev_release(s->ctx, s->d_nplane); sp_dev_release(s->ctx, s->d_word_off); sp_dev_release(s->ctx, s->d_len);
+        sp_dev_release(s->ctx, s->d_kcode); sp_dev_release(s->ctx, s->d_kpos); sp_dev_release(s->ctx, s->d_koff);
+    } else {
+        if (s->d_words) hipFree(s->d_words);
+        if (s->d_nplane) hipFree(s->d_nplane);
+        if (s->d_word_off) hipFree(s->d_word_off);
+        if (s->d_len) hipFree(s->d_len);
+        if (s->d_kcode) hipFree(s->d_kcode);
+        if (s->d_kpos) hipFree(s->d_kpos);
+        if (s->d_koff) hipFree(s->d_koff);
+    }
     delete s;
 }
 
@@ -502,8 +556,10 @@ int sp_seqset_build_index(sp_ctx* ctx, sp_seqset* s) {
     std::vector<uint64_t> koff; std::vector<uint32_t> kcode; std::vector<int32_t> kpos;
     kmer_tables(s, koff, kcode, kpos);
     size_t ne = std::max<size_t>(1, kcode.size());
-    if (hipMalloc(&s->d_kcode, ne * 4) != hipSuccess || hipMalloc(&s->d_kpos, ne * 4) != hipSuccess ||
-        hipMalloc(&s->d_koff, koff.size() * 8) != hipSuccess)
+    // (through the owning context's cache when the set has one: sp_seqset_free hands them back there)
+    sp_ctx* owner = s->ctx ? s->ctx : ctx;
+    s->d_kcode = (uint32_t*)sp_dev_alloc(owner, ne * 4); s->d_kpos = (int32_t*)sp_dev_alloc(owner, ne * 4); s->d_koff = (uint64_t*)sp_dev_alloc(owner, koff.size() * 8);
+    if (!s->d_kcode || !s->d_kpos || !s->d_koff)
         return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "k-mer index");
     if (!kcode.empty()) {
         hipMemcpy(s->d_kcode, kcode.data(), kcode.size() * 4, hipMemcpyHostToDevice);

@@ -5,6 +5,8 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <set>
+#include <mutex>
 #include <map>
 #include "../../include/starphase_hip.h"
 
@@ -78,6 +80,10 @@ struct sp_ctx {
     void* scratch = nullptr; size_t scratch_bytes = 0;
     std::map<std::string, std::pair<void*, size_t>> pool;   // named grow-only device buffers (no malloc/free per call)
     std::map<std::string, std::pair<void*, size_t>> host_pool;   // named grow-only pinned host buffers (results leave the device through them)
+    // device buffers of read sets that were freed, kept for the next upload (sp_dev_alloc / sp_dev_release, sp_api.hip): hipFree waits for EVERY stream of the device --
+    // a lane that closed its sample's read set stood still until the other lane's kernels had ended, 1.2 ms per sample -- and an upload began with three hipMalloc
+    std::multimap<size_t, void*> dev_cache; std::map<void*, size_t> dev_cap; size_t dev_cache_bytes = 0; std::mutex dev_cache_mu;
+    std::set<sp_seqset*> live_sets;   // the read sets that will hand their buffers back (a context destroyed before them lets go of them: they free their buffers themselves)
     int num_cus = 256;
     int hw_queues = 4; bool hw_queues_by_library = false; std::string warning;     // sp_ctx_get_info
     bool split_genes = true;         // sp_ctx_set_option "hla_split_genes"
@@ -114,6 +120,8 @@ struct K2Dict {
     std::vector<uint32_t> dict_off;
     uint32_t n_dict = 0, max_dict = 0;
 };
+void* sp_dev_alloc(sp_ctx* ctx, size_t bytes);    // a device buffer of >= bytes: one a freed read set left behind when one fits, hipMalloc otherwise; nullptr: out of memory
+void sp_dev_release(sp_ctx* ctx, void* p);        // hands it back (nullptr is fine); buffers beyond the cache's bounds are freed
 int  sp_k2_dict_build(sp_ctx* ctx, const sp_seqset* set, const uint32_t* d_gene_of, uint32_t n_genes, K2Dict* out);
 void sp_k2_dict_free(K2Dict* d);
 

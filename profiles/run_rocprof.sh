@@ -9,6 +9,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # the bench asks for 8 hardware queues through os.environ; under rocprofv3 the runtime is up before Python starts, so the shell sets it
 export GPU_MAX_HW_QUEUES=16
+# counter passes run one kernel at a time: the persistent consensus kernels of the headline's CYP2D6 context (two kernels that wait for each other) cannot run under them,
+# and the kernel statistics are those of the launch pairs (cons_step_kernel / cons_control_kernel per step) in every round's summary
+export SP_BENCH_HEADLINE_PERSISTENT=0
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs"
 # 1. kernel trace + stats (no counters in this pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1

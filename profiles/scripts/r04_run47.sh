@@ -5,6 +5,6 @@ python bench.py --no-cpu-baseline > gpurun_out/r04_k9_$i.json 2> gpurun_out/r04_
 python - <<PY
 import json
 d=json.loads(open("gpurun_out/r04_k9_$i.json").read().strip().splitlines()[-1])
-print(round(d["value"]), round(d["ms_per_step"],2), d["kernel_ms"]["cyp2d6"], {k:round(v,2) for k,v in d["host_wall_ms"]["cyp2d6"].items() if not isinstance(v, dict)}, round(d["legs"]["cohort"]["samples_per_s"],1), round(d["legs"]["headline_with_persistent_consensus"]["value"]))
+print(round(d["value"]), round(d["ms_per_step"],2), d["kernel_ms"]["cyp2d6"], {k:round(v,2) for k,v in d["host_wall_ms"]["cyp2d6"].items() if not isinstance(v, dict)}, round(d["legs"]["cohort"]["samples_per_s"],1), round((d["legs"].get("headline_with_persistent_consensus") or d["legs"].get("headline_with_launch_pairs"))["value"]))
 PY
 done
