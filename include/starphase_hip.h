@@ -121,7 +121,9 @@ int32_t sp_seqset_upload_format(sp_ctx* ctx, int32_t format, const void* data, c
 int32_t sp_seqset_upload_async(sp_ctx* ctx, int32_t format, const void* data, const uint64_t* offsets, const uint32_t* lengths, uint32_t n, sp_seqset** out);
 int32_t sp_seqset_wait(sp_seqset* set);
 int32_t sp_seqset_skipped(const sp_seqset* set, uint32_t* n_skipped);       /* sequences dropped for their length */
-void    sp_seqset_free(sp_seqset* set);
+void    sp_seqset_free(sp_seqset* set);                                      /* the set's device buffers go back to its context for the next upload (no hipFree, which
+                                                                             * would wait for every stream of the device); the context frees them when it is destroyed.
+                                                                             * Call it when every call that was given the set has returned */
 int32_t sp_seqset_count(const sp_seqset* set, uint32_t* n);
 int32_t sp_seqset_length(const sp_seqset* set, uint32_t idx, uint32_t* len);
 
