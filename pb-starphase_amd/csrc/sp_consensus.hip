@@ -1863,8 +1863,19 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
             *P.out_res = r;
         }
         if (best >= 0) {
+            // (four bases per load: behind persistent kernels the winner's bytes come from memory, not from L2 -- they were stored write-through --, and a byte per load
+            //  with a division per byte made this the slowest part of the batch's tail, 0.4 ms)
             const uint8_t* src = P.C + (size_t)best * 2 * P.cs;
-            for (int x = threadIdx.x; x < 2 * P.cap; x += blockDim.x) P.out_cons[x] = src[(size_t)(x / P.cap) * P.cs + x % P.cap];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + (size_t)i * P.cs);       // (the rows are 16-byte aligned and cs >= cap rounded up to 16)
+                uint8_t* dst = P.out_cons + (size_t)i * P.cap;
+                for (int x = (int)threadIdx.x * 4; x < P.cap; x += (int)blockDim.x * 4) {
+                    const uint32_t w = s4[x >> 2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (x + q < P.cap) dst[x + q] = (uint8_t)(w >> (8 * q));
+                }
+            }
         }
     }
     for (int rr = 0; rr < P.rpw; ++rr) {
