@@ -338,7 +338,7 @@ void* sp_dev_alloc(sp_ctx* ctx, size_t bytes) {
 }
 void sp_dev_release(sp_ctx* ctx, void* p) {
     if (!p) return;
-    constexpr size_t MAX_BYTES = (size_t)2 << 30, MAX_BUFFERS = 64;
+    constexpr size_t MAX_BYTES = (size_t)2 << 30, MAX_BUFFERS = 4096;      // (a cohort pass frees a thousand small buffers at once: the bytes are the bound that matters)
     {
         std::lock_guard<std::mutex> g(ctx->dev_cache_mu);
         auto it = ctx->dev_cap.find(p);
