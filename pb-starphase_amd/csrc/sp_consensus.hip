@@ -102,7 +102,7 @@ constexpr int NODE_HEAD_WORDS = 32, NODE_WORDS = (int)(sizeof(CNode) / 4), NODE_
 static_assert(offsetof(CNode, dc) == 4 * NODE_HEAD_WORDS && sizeof(CNode) % 16 == 0, "CNode layout");
 struct CSearch {
     int32_t threshold, farthest, next_id, best_node, inflight, max_queue, per_size, wo_constraint;
-    int32_t windows, cut_windows, expansions, pad;
+    int32_t windows, cut_windows, expansions, pops_mod;   // pops_mod = pops % wo_constraint, kept beside pops (a 64-bit remainder in every pass of the search was half a microsecond)
     long long pops, best_final;
     long long ticks[4];         // control kernel, 100 MHz wall clock: load + vote reduction / result of the step / search / tail
     long long step_ticks, gap_ticks, last_end;   // profiling contexts: the step kernel from its first workgroup's start to its last one's end, summed over the steps; what lies
@@ -1496,9 +1496,9 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                 const unsigned long long waiting = __ballot(kx >= 0);
                 if (__builtin_popcountll(waiting) == 1) {
                     // one node waits (a linear search: most steps of most searches): it is the best, there is no second best -- no reductions
-                    const int only = __builtin_ctzll(waiting);
-                    const CNode& p = nh[only];
-                    bc = p.cost_at(p.q); bt = p.T + p.q; bid = p.id; bx = only;
+                    const int only = __builtin_ctzll(waiting);                      // (its lane holds what was just read of it)
+                    bc = ((long long)__builtin_amdgcn_readlane((int)(kc >> 32), only) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)kc, only);
+                    bt = __builtin_amdgcn_readlane(kt, only); bid = __builtin_amdgcn_readlane(kid, only); bx = only;
                     xi = only;
                 } else {
 #pragma unroll
@@ -1526,8 +1526,8 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                 int Lc = bt;
                 for (;;) {
                     const int L = Lc, q = x.q, a = x.a;
-                    const long long pops0 = ss.pops; const int wo = ss.wo_constraint;
-                    const int jc = (int)((wo - 1 - (pops0 % wo)) % wo);                 // the pop with this index (0-based) makes pops a multiple of wo
+                    const int wo = ss.wo_constraint;
+                    const int jc = wo - 1 - ss.pops_mod;                                  // the pop with this index (0-based) makes pops a multiple of wo
                     const int linear = a - q;                                            // pops that only consume the tape
                     const int want = linear > 0 ? (linear < SP_WAVE ? linear : SP_WAVE) : 1;
                     bool can = lane < want && L + lane >= ss.threshold && proc[L + lane] < ss.per_size && lane <= jc;
@@ -1541,6 +1541,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                     if (lane < m) proc[L + lane] += 1;
                     if (lane == 0) {
                         ss.pops += m;
+                        { int pm = ss.pops_mod + m; if (pm >= wo) pm %= wo; ss.pops_mod = pm; }
                         if (L + m - 1 > ss.farthest) ss.farthest = L + m - 1;
                         if (jc < m && ss.farthest > ss.threshold) ss.threshold = ss.farthest;
                         if (linear > 0) { x.q = q + m; x.id = ss.next_id + m - 1; ss.next_id += m; }
