@@ -659,6 +659,8 @@ def main():
         return calls
 
     def cyp_work(R, i):
+        if headline_mode["persistent"] and os.environ.get("SP_BENCH_INJECT_FAILURE"):       # (a test of the fall-back below: profiles/scripts/r04_run67.sh)
+            raise RuntimeError("injected failure of the persistent mode")
         call, _cons, _labels = cdb_c.diplotype(R)
         last["cyp"] = (i, call)
         return call
