@@ -243,7 +243,6 @@ static int32_t upload_start(sp_ctx* ctx, int32_t format, const void* data, const
     sp_seqset* s = new (std::nothrow) sp_seqset();
     if (!s) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seqset");
     s->ctx = ctx; s->n = n;
-    { std::lock_guard<std::mutex> g(ctx->dev_cache_mu); ctx->live_sets.insert(s); }
     s->h_len.resize(n); s->h_word_off.resize((size_t)n + 1);
     uint64_t total_words = 0;
     const uint64_t per_byte = format == SP_SEQ_ASCII ? 1 : format == SP_SEQ_BAM4 ? 2 : 4;
@@ -260,6 +259,7 @@ static int32_t upload_start(sp_ctx* ctx, int32_t format, const void* data, const
         total_words += (w + 3) & ~3ull;             // 16-byte aligned starts
     }
     s->h_word_off[n] = total_words;
+    { std::lock_guard<std::mutex> g(ctx->dev_cache_mu); ctx->live_sets.insert(s); }      // (from here on the set leaves through sp_seqset_free, which takes it off the list)
     auto fail = [&](const char* what) { sp_seqset_free(s); return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, what); };
     const size_t wbytes = (total_words + SP_SEQ_PAD_WORDS) * sizeof(uint32_t);
     if (!(s->d_words = (uint32_t*)sp_dev_alloc(ctx, wbytes))) return fail("seqset words");

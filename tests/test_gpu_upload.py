@@ -72,6 +72,35 @@ def test_async_upload_runs_beside_the_contexts_work(pkg, gpu_ctx):
     assert (out["nm"] == 0).all()
 
 
+def test_freed_sets_hand_their_buffers_to_the_next_ones(pkg):
+    """sp_seqset_free keeps the device buffers in the context for the next upload (hipFree would wait for every stream of the device): sets uploaded into buffers other
+    sets left behind -- larger ones, smaller ones, with and without an N plane or a k-mer index -- hold exactly their own reads; a context that is destroyed before one of its
+    sets leaves that set its buffers (the set frees them itself)."""
+    rng = np.random.default_rng(17)
+    ctx = pkg.Context(0)
+    previous = None
+    for round_ in range(12):
+        n = int(rng.integers(3, 120))
+        seqs = [rnd(rng, int(m)) for m in rng.integers(20, 6000, n)]
+        if round_ % 3 == 0:                                                      # a few Ns: the set gets an N plane (a fourth buffer)
+            seqs = [q if len(q) < 40 else "".join("N" if i in (7, len(q) // 2, len(q) - 9) else c for i, c in enumerate(q)) for q in seqs]
+        S = ctx.upload(seqs) if round_ % 2 else ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *pkg.ffi.encode_bam4(seqs))
+        T = ctx.upload(seqs)                                                     # a second copy: the pair aligns base for base (N positions count as edits on both sides)
+        idx = np.arange(n, dtype=np.uint32)
+        diag, votes = ctx.anchor_batch(S, T, idx, idx)                            # (builds S's k-mer index: three more buffers that go back to the cache)
+        out = ctx.align_batch(S, T, idx, idx, np.zeros(n, np.int32), 255)
+        assert (out["ok"] == 1).all(), round_
+        assert (out["a_end"] - out["a_start"]).tolist() == [len(q) for q in seqs], round_
+        assert out["nm"].tolist() == [q.count("N") for q in seqs], round_
+        if previous is not None:
+            previous.close()                                                    # the set of the round before goes back while this round's sets are alive
+        previous = S
+        T.close()
+    last = ctx.upload([rnd(rng, 500)])
+    ctx.close()                                                                 # the context first ...
+    last.close(); previous.close()                                              # ... then sets it had handed buffers to
+
+
 def test_an_over_long_read_is_left_out_not_fatal(pkg, gpu_ctx):
     rng = np.random.default_rng(8)
     seqs = [rnd(rng, 2000), rnd(rng, 70000), rnd(rng, 2500), ""]
