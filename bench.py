@@ -13,10 +13,12 @@ Beside it in the same JSON line: `roofline` (k1_cells_kernel), `
 restatement of the oracle, see tests/cpu_port_seeded.py), `legs` (HLA alone with resident reads = round 2's headline, the six CYP2D6 scenarios, the
 256-sample cohort on this one GPU, K5 at scale).
 
-N > 1 (`--gpus N`, or under torch.distributed.run): BASELINE configs[4], the 256-sample cohort sharded by sample over the ranks, one process per
-GPU: every rank uploads its samples' reads, runs sp_hla_diplotype_cohort + sp_cyp_diplotype_cohort + sp_variant_solve_batch and the per-(sample,
-gene) call records are gathered with ONE sp_gather_results (ncclAllGather over RCCL / xGMI) per step -- the only exchange of the path.  The total
-work is fixed (strong scaling); the N = 1 line carries the same cohort as `legs.cohort` for the efficiency figure.
+N > 1 (`--gpus N`, or under torch.distributed.run), one process per GPU: every rank runs the same stream of samples (its own samples) -- per-GPU work
+fixed, nothing exchanged, `value` = all ranks' reads / the slowest rank's time between the barriers (weak scaling by independent samples).
+`--workload cohort` asks the other question at any N: BASELINE configs[4], the 256-sample cohort sharded by sample over the ranks -- every rank uploads
+its samples' reads, runs sp_hla_diplotype_cohort + sp_cyp_diplotype_cohort + sp_variant_solve_batch and the per-(sample, gene) call records are gathered
+with ONE sp_gather_results (ncclAllGather over RCCL / xGMI) per step, the only exchange of the path; the total work is fixed (strong scaling), and the
+N = 1 line carries the same cohort as `legs.cohort`.
 """
 import argparse
 import gzip
@@ -557,7 +559,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    workload = args.workload if args.workload != "auto" else ("sample" if world == 1 else "cohort")
+    # N ranks: every rank runs the same stream of samples on its own GPU (its own samples: the seeds carry the rank) -- per-GPU work fixed, nothing shared, `value` the sum over
+    # the ranks (weak scaling by independent samples); `--workload cohort` is the other question: ONE 256-sample cohort sharded over the ranks (strong scaling)
+    workload = args.workload if args.workload != "auto" else "sample"
     pkg = ge.load_package()
     from pb_starphase_amd import synth, shard
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -678,7 +682,7 @@ def main():
         t0 = time.perf_counter()
         run_lanes(lanes)
         barrier(); ctx_c.synchronize()
-        return lanes, time.perf_counter() - t0
+        return lanes, max_over_ranks(time.perf_counter() - t0)
     try:
         lanes, dt = timed_region()
     except Exception as e:
@@ -690,6 +694,8 @@ def main():
         ctx_c.set_option("k8_persistent", 0)
         lanes, dt = timed_region()
     reads_per_step = samples[0].n + cyp_samples[0].n
+    if world > 1:
+        args.no_extra_legs = True                           # (the legs are one-GPU questions; the ranks only run the headline together)
     # a lane's host time per step: waiting for the sample's bytes / starting the next upload / the library calls / closing the sample's read set
     lane_ms = [{k: round(1e3 * getattr(x, "t_" + k, 0.0) / max(1, args.steps), 3) for k in ("wait", "start", "work", "close")} for x in lanes]
 
@@ -857,14 +863,15 @@ def main():
             stale.append("traffic_k1_cells.json")
     line = {
         "metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)",
-        "value": reads_per_step * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": world * reads_per_step * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1] + configs[2] as ONE sample per step: HLA-A / -B, %d synthetic HiFi reads vs the bundled IMGT/HLA DB v0.14.1 (18,461 alleles, 11,199 with "
                                "DNA) and CYP2D6, %d targeted reads (39 templates, 393 variants / 520 star alleles); a new sample's bytes (BAM 4-bit SEQ) uploaded every step "
                                "under the previous sample's kernels; reads -> diplotypes of both loci" % (samples[0].n, cyp_samples[0].n),
                    "reads_per_step": reads_per_step, "hla_reads": samples[0].n, "cyp2d6_reads": cyp_samples[0].n, "alleles": len(fx.ids),
-                   "parallelism": "one GPU: the two loci side by side on two contexts (host threads, HIP streams), uploads on copy streams",
+                   "parallelism": ("one GPU: " if world == 1 else "%d GPUs, one process each with its own stream of samples (no exchange; `value` = all ranks' reads / the slowest rank's time); per GPU: " % world) +
+                                  "the two loci side by side on two contexts (host threads, HIP streams), uploads on copy streams",
                    "cyp2d6_consensus": ("persistent kernels (sp_ctx_set_option k8_persistent = 1 on the CYP2D6 context: two launches per batch, hand-overs through memory; SP_BENCH_HEADLINE_PERSISTENT=0 for launch pairs)"
                                         if headline_mode["persistent"] else "a launch pair per step" + ("" if headline_mode["fallback"] is None else " (the persistent kernels failed here: %s)" % headline_mode["fallback"]))},
         "roofline": {"bound": "hbm", "kernel": "k1_cells_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -921,8 +928,14 @@ def main():
         line["cpu_baseline"] = cb
     else:
         line["cpu_baseline"] = None
-    print(json.dumps(line), flush=True)
-    if stale:                                                 # (the blocks they feed were left out of the line above)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        if group is not None and hasattr(group, "close") and not isinstance(group, shard.TorchGroup):
+            group.close()
+        dist.destroy_process_group()
+    if stale and rank == 0:                                                 # (the blocks they feed were left out of the line above)
         print("bench.py: the counter files " + ", ".join(stale) + " were collected on other kernel sources: re-run profiles/run_rocprof.sh and copy the two files into profiles/r04", file=sys.stderr)
 
 

@@ -46,3 +46,17 @@ def test_sample_line_and_two_rank_cohort_over_gloo():
     c = line["cohort"]
     assert c["samples"] == 7 and c["records_gathered_per_pass"] == 7 * (2 + 1 + 18)
     assert c["calls_equal_truth"]["hla"] == "14/14" and c["calls_equal_truth"]["cyp2d6"] == "7/7"
+
+
+def test_two_ranks_each_with_its_own_stream_of_samples():
+    """`bench.py --gpus 2` (the default workload at every N): each rank runs the headline's stream of samples -- its own samples, both loci, a new upload every step --, the
+    ranks meet at the barriers around the timed steps, `value` is the sum over the ranks and rank 0 prints the one line.  Two ranks share device 0 here (gloo for the
+    barrier and the maximum; launch pairs: two processes' persistent batches would wait for each other's CUs on one device)."""
+    two = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "1500", "--cyp-reads", "300", "--no-cpu-baseline"],
+                    env={"SP_BENCH_BACKEND": "gloo", "SP_BENCH_HEADLINE_PERSISTENT": "0"})
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["scaling"] == "weak" and two["metric"] == "HiFi reads/sec diplotyped (HLA+CYP2D6)"
+    assert two["config"]["parallelism"].startswith("2 GPUs") and two["config"]["cyp2d6_consensus"].startswith("a launch pair per step")
+    per_rank_reads = two["config"]["reads_per_step"] * two["steps"]
+    assert abs(two["value"] - 2 * per_rank_reads / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-6 * two["value"]      # all ranks' reads / the slowest rank's time
+    assert not two["legs"] and two["cpu_baseline"] is None
+    assert two["concordance"]["hla_diplotypes_equal_truth"] == "2/2 genes" and two["concordance"]["cyp2d6_call_equals_truth"] is True
