@@ -597,7 +597,7 @@ def main():
     db = fx.make_db(pkg, ctx)
     cdb = pkg.ffi.CypDb(ctx, cfg, gene_def, locus.sequence, locus.start)
     group, gather_via = None, "single rank"
-    if world > 1:
+    if world > 1 and workload == "cohort":                  # (the streams of samples exchange nothing: no communicator)
         # sp_group: RCCL through the library (sp_gather_results).  Should the library's communicator not come up on this node, every rank falls back to the
         # torch process group together (the decision is agreed on with one all-reduce) and the line says which path gathered
         try:
