@@ -640,15 +640,16 @@ constexpr int BULK_MARGIN_PLACED = 2;  // the same right behind the column that 
 constexpr int BULK_MARGIN = 8;         // edits a read's worse state must be behind the better one to go through a window ahead of it (a state that close may draw level)
 constexpr int DIRECT_BLOCKS = 128;      // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
 
-template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B) {
+template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B, int block) {
     int pi = 0;
-    if constexpr (MAXP == 0) pi = B.block_prob[blockIdx.x];
+    if constexpr (MAXP == 0) pi = B.block_prob[block];
     else {
 #pragma unroll
-        for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && (int)blockIdx.x >= B.p[i].first_block) pi = i;
+        for (int i = 1; i < MAXP; ++i) if (i < B.n_prob && block >= B.p[i].first_block) pi = i;
     }
     return pi;
 }
+template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B) { return block_problem<MAXP>(B, (int)blockIdx.x); }
 
 __device__ __forceinline__ size_t state_plane(int node, int slot, int cons) { return (size_t)((node * 2 + slot) * 2 + cons); }
 
@@ -1848,14 +1849,18 @@ __global__ void cons_setup_many_kernel(const ConsSetup* __restrict__ S, int n_pr
 }
 
 // scores and assignment of the reads on the complete node the search ended with
+// One wavefront per workgroup (workgroup b stands for wave b % CWAVES of the step kernel's workgroup b / CWAVES): beside K1's grid of single-wave workgroups, which refill
+// every wave slot that frees up, an 8-wave workgroup can wait for two free slots on each SIMD of one CU until that grid is through -- this 6 us kernel took 8-10 ms twice
+// in four steps of a trace (profiles/r04/rocprof_r04_kernel_stats.csv), at the end of a consensus batch of the other lane.
 template <int MAXP>
-__global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBatchT<MAXP> B, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
-    const int pi = block_problem<MAXP>(B);
+__global__ void __launch_bounds__(SP_WAVE) cons_finalize_kernel(ConsBatchT<MAXP> B, uint8_t* is_cons1, int32_t* score1, int32_t* score2) {
+    const int vblock = (int)blockIdx.x / CWAVES, wave = (int)blockIdx.x % CWAVES;
+    const int pi = block_problem<MAXP>(B, vblock);
     const ConsParams P = B.p[pi];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
     const int best = P.srch->best_node;
     const size_t plane = (size_t)B.total;
-    if ((int)blockIdx.x == P.first_block) {
+    if (vblock == P.first_block && wave == 0) {
         // everything the host reads of the problem goes to one output region: the search record, the winning node's shape, its bases
         for (int x = threadIdx.x; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)P.out_srch)[x] = ((const uint32_t*)P.srch)[x];
         if (threadIdx.x == 0) {
@@ -1880,7 +1885,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE) cons_finalize_kernel(ConsBat
         }
     }
     for (int rr = 0; rr < P.rpw; ++rr) {
-        const int r = (((int)blockIdx.x - P.first_block) * CWAVES + wave) * P.rpw + rr;
+        const int r = ((vblock - P.first_block) * CWAVES + wave) * P.rpw + rr;
         if (r >= P.n) break;
         const size_t g = (size_t)P.first + r;
         int sc[2] = { -1, -1 };
@@ -2196,7 +2201,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     SP_HIP_CHECK(ctx, hipGetLastError());
     hm.mark("host:k8_loop");
     if (ctx->profiling) { auto& e = ctx->prof["host:k8_launch"]; e.ms += t_launch; e.launches += (uint32_t)(2 * pairs); }
-    hipLaunchKernelGGL(cons_finalize_kernel<MAXP>, grid, block, 0, st, B, d_is1, d_sc, d_sc + total);
+    hipLaunchKernelGGL(cons_finalize_kernel<MAXP>, dim3((uint32_t)n_blocks * CWAVES), dim3(SP_WAVE), 0, st, B, d_is1, d_sc, d_sc + total);
     SP_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     const uint8_t* h_is1 = h_out + out_is1; const int32_t* h_sc = (const int32_t*)(h_out + out_sc); const ConsRes* h_res = (const ConsRes*)(h_out + out_res);
     SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
