@@ -60,3 +60,14 @@ def test_two_ranks_each_with_its_own_stream_of_samples():
     assert abs(two["value"] - 2 * per_rank_reads / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-6 * two["value"]      # all ranks' reads / the slowest rank's time
     assert not two["legs"] and two["cpu_baseline"] is None
     assert two["concordance"]["hla_diplotypes_equal_truth"] == "2/2 genes" and two["concordance"]["cyp2d6_call_equals_truth"] is True
+
+
+def test_the_headline_falls_back_to_launch_pairs_when_the_persistent_mode_fails():
+    """The headline's CYP2D6 context runs its consensus as persistent kernels; if the library reports that a batch's kernels could not run side by side (its time-out, an
+    error) the bench starts the region over with a launch pair per step and says so in the line.  The failure is injected here (SP_BENCH_INJECT_FAILURE)."""
+    line = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "1500", "--cyp-reads", "300", "--no-cpu-baseline", "--no-extra-legs"],
+                     env={"SP_BENCH_INJECT_FAILURE": "1"})
+    assert line["config"]["cyp2d6_consensus"].startswith("a launch pair per step (the persistent kernels failed here: injected failure")
+    assert line["value"] > 0 and line["concordance"]["cyp2d6_call_equals_truth"] is True and line["concordance"]["hla_diplotypes_equal_truth"] == "2/2 genes"
+    ok = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "1500", "--cyp-reads", "300", "--no-cpu-baseline", "--no-extra-legs"])
+    assert ok["config"]["cyp2d6_consensus"].startswith("persistent kernels") and ok["critical_path"]["cyp2d6"]["launches_per_step"] == 0
