@@ -524,7 +524,9 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
     SP_HIP_CHECK(ctx, hipGetLastError());
     if (retry_wide) {
         // the cells the 64-diagonal run lost are run again on 256 diagonals (one wave each; cells that were found return at once)
-        uint64_t wblocks = std::min<uint64_t>((n_cells + 3) / 4, (uint64_t)ctx->num_cus * 2);
+        // (untraced: enough workgroups that a wave meets a lost cell or two, not six -- a lost cell is hundreds of rounds of one wave, and the launch took as long as its
+        //  unluckiest wave: 1.7 ms for the weights' placements of a 2,000-read CYP2D6 sample at two workgroups per CU; traced runs keep that size: every wave owns history scratch)
+        uint64_t wblocks = std::min<uint64_t>((n_cells + 3) / 4, (uint64_t)ctx->num_cus * (trace ? 2 : 8));
         uint16_t* whist = nullptr;
         if (trace) {
             whist = (uint16_t*)sp_pool(ctx, "wide_hist", wblocks * 4 * (size_t)hist_rows * SP_WIDE * sizeof(uint16_t));
