@@ -8,6 +8,7 @@
  * is checked against minimap2 itself, only against the cases the reference's tests pin and a brute-force DP.
  */
 #include "mm2_oracle.h"
+#include "sp_oracle.h"
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
@@ -769,7 +770,6 @@ int32_t omm_map_pair(const uint8_t* target, int32_t tlen, const uint8_t* q, int3
 }
 
 /* ------------------------------------------------------------------ score_read on the restatement's mappings */
-#include "sp_oracle.h"
 
 /* score_read (src/hla/caller.rs:1411-1510): every allele of the gene mapped to the consensus at cDNA and DNA level (the caller passes
  * opts with a = 5), Forward mappings only (:1443-1445), select_best_mapping query based and penalised (:1450), HlaProcessedMatch::add_mapping
@@ -834,4 +834,157 @@ int32_t omm_hla_score_read(const uint8_t* cons_cdna, int32_t cdna_len, const uin
     }
     for (int lv = 0; lv < 2; ++lv) { free(best_pc[lv]); omm_index_free(idx[lv]); }
     return best_idx;
+}
+
+/* ------------------------------------------------------------------ the stages of omm_map, one by one (parity tests of the seeded K1 path) */
+
+int32_t omm_sketch(const uint8_t* s, int32_t len, const omm_opts* o, uint64_t* hash, int32_t* end_pos, uint8_t* strand, int32_t cap) {
+    mzv_t mv = { 0, 0, 0 };
+    sketch(s, len, o->w, o->k, 0, &mv);
+    const int32_t n = (int32_t)mv.n;
+    for (int32_t i = 0; i < n && i < cap; ++i) {
+        if (hash) hash[i] = mv.a[i].x >> 8;
+        if (end_pos) end_pos[i] = (int32_t)((uint32_t)mv.a[i].y >> 1);
+        if (strand) strand[i] = (uint8_t)(mv.a[i].y & 1);
+    }
+    free(mv.a);
+    return n;
+}
+
+/* seeding + chaining + selection of omm_map without the base-level alignment.  regs: [cap][10] = {rid, rev, chain score, seeds, qs, qe (forward
+ * coordinates), rs, re, parent (index into this list after selection), kept (1 = survives set_parent + select_sub, in the order align_chain sees them)};
+ * the list is every chain in chain_anchors' order (score descending, stable); stats[8] = {minimizers of the query, seeds found in the index, seeds kept
+ * by the occurrence filter, anchors, distinct (strand, target) pairs among the anchors, chains, chains selected, mid_occ}.  Returns the number of chains. */
+int32_t omm_chain_stage(const omm_index* idx, const uint8_t* q, int32_t qlen, const omm_opts* o, int32_t* regs_out, int32_t cap, int64_t* stats) {
+    int64_t na = 0;
+    if (stats) {
+        mzv_t mv = { 0, 0, 0 };
+        sketch(q, qlen, o->w, o->k, 0, &mv);
+        stats[0] = mv.n; stats[1] = 0;
+        for (int64_t i = 0; i < mv.n; ++i) { int64_t n; idx_lookup(idx, mv.a[i].x >> 8, &n); if (n) ++stats[1]; }
+        free(mv.a);
+        stats[7] = idx->mid_occ;
+    }
+    an_t* a = collect_anchors(idx, q, qlen, o, &na);
+    if (stats) {
+        stats[3] = na; stats[4] = 0;
+        for (int64_t i = 0; i < na; ++i) if (i == 0 || a[i].x >> 32 != a[i - 1].x >> 32) ++stats[4];
+        /* kept seeds = distinct query positions among the anchors */
+        int64_t kept = 0;
+        uint8_t* seen = (uint8_t*)calloc((size_t)qlen + 1, 1);
+        for (int64_t i = 0; i < na; ++i) {
+            int32_t qp = (int32_t)a[i].y;
+            if (a[i].x >> 63) qp = qlen - 1 - qp + (int32_t)(a[i].y >> 32 & 0xff) - 1;     /* back to the forward end position */
+            if (qp >= 0 && qp <= qlen && !seen[qp]) { seen[qp] = 1; ++kept; }
+        }
+        free(seen);
+        stats[2] = kept;
+    }
+    an_t* v = NULL; int nr = 0;
+    reg_t* regs = chain_anchors(a, na, qlen, o, &v, &nr);
+    free(a);
+    if (stats) { stats[5] = nr; stats[6] = 0; }
+    if (nr == 0) { free(regs); free(v); return 0; }
+    reg_t* sel = (reg_t*)malloc(sizeof(reg_t) * (size_t)nr);
+    memcpy(sel, regs, sizeof(reg_t) * (size_t)nr);
+    for (int i = 0; i < nr; ++i) sel[i].id = i;
+    set_parent(sel, nr, o->mask_level);
+    const int nk = select_sub(sel, nr, o->pri_ratio, o->k * 2, o->best_n);
+    if (stats) stats[6] = nk;
+    for (int i = 0; i < nr && i < cap; ++i) {
+        int32_t* r = regs_out + (size_t)i * 10;
+        r[0] = regs[i].rid; r[1] = regs[i].rev; r[2] = regs[i].score; r[3] = regs[i].cnt;
+        r[4] = regs[i].qs; r[5] = regs[i].qe; r[6] = regs[i].rs; r[7] = regs[i].re; r[8] = -1; r[9] = 0;
+    }
+    for (int i = 0; i < nk; ++i) if (sel[i].id < cap) { int32_t* r = regs_out + (size_t)sel[i].id * 10; r[8] = sel[sel[i].parent].id; r[9] = i + 1; }
+    free(sel); free(regs); free(v);
+    return nr;
+}
+
+/* the sorted anchors of omm_map (collect_anchors): x = rev << 63 | rid << 32 | target end position, y = span << 32 | query end position on the mapped
+ * strand; returns their number (may exceed cap) */
+int64_t omm_anchors(const omm_index* idx, const uint8_t* q, int32_t qlen, const omm_opts* o, uint64_t* x, uint64_t* y, int64_t cap) {
+    int64_t na = 0;
+    an_t* a = collect_anchors(idx, q, qlen, o, &na);
+    for (int64_t i = 0; i < na && i < cap; ++i) { if (x) x[i] = a[i].x; if (y) y[i] = a[i].y; }
+    free(a);
+    return na;
+}
+
+/* ------------------------------------------------------------------ realign_record's seeded map as the library runs it (K1, `k1_best_n` > 0)
+ *
+ * The statement the HIP path of sp_hla_realign_reads is held to, bit for bit, in seeded mode: seeding, chaining and the selection of the chains that get a
+ * base-level alignment are omm_map's (collect_anchors, chain_anchors, set_parent, select_sub above: minimap2's published algorithm at the reference's
+ * settings, src/util/mapping.rs:8-14); the base-level alignment of a selected chain is the library's: the unit-cost cell on the 64 diagonals around the
+ * chain (256 when that finds nothing: osp_wfa_retry) and its two-piece affine re-score (osp_affine_local on the 64 diagonals around
+ * the cell's alignment), which stands in for align_chain + finish_hit; the filters, the output order (peak score, descending), the
+ * second set_parent / select_sub and the acceptance loop of realign_record (src/hla/realigner.rs:124-146) follow as in omm_map / the reference.
+ * At most OMM_SEED_SEL selected chains are aligned (the best ranked; minimap2 has no such bound: a read with more than ten primary chains is not a read of one locus). */
+int32_t omm_hla_k1_seeded(const omm_index* idx, const uint8_t* q, int32_t qlen, const omm_opts* o, omm_seed_hit* hits, int32_t* n_hits, int32_t* n_chains) {
+    *n_hits = 0; if (n_chains) *n_chains = 0;
+    if (qlen <= 0) return -1;
+    int64_t na = 0;
+    an_t* a = collect_anchors(idx, q, qlen, o, &na);
+    an_t* v = NULL; int nr = 0;
+    reg_t* regs = chain_anchors(a, na, qlen, o, &v, &nr);
+    free(a);
+    if (n_chains) *n_chains = nr;
+    if (nr == 0) { free(regs); free(v); return -1; }
+    set_parent(regs, nr, o->mask_level);
+    nr = select_sub(regs, nr, o->pri_ratio, o->k * 2, o->best_n);
+    if (nr > OMM_SEED_SEL) nr = OMM_SEED_SEL;
+    uint8_t* qrev = NULL;
+    omm_seed_hit tmp[OMM_SEED_SEL]; reg_t hr[OMM_SEED_SEL];
+    const osp_affine_opts ao = { o->a, o->b, o->q, o->e, o->q2, o->e2, o->sc_ambi };
+    int nh = 0;
+    for (int r = 0; r < nr; ++r) {
+        const uint8_t* qc = q;
+        if (regs[r].rev) {
+            if (!qrev) { qrev = (uint8_t*)malloc((size_t)qlen); for (int i = 0; i < qlen; ++i) { const uint8_t c = q[qlen - 1 - i]; qrev[i] = c > 3 ? c : (uint8_t)(3 - c); } }
+            qc = qrev;
+        }
+        const an_t* first = &v[regs[r].as]; const an_t* last = &v[regs[r].as + regs[r].cnt - 1];
+        const int d0 = (int32_t)(uint32_t)first->y - (int32_t)(uint32_t)first->x, d1 = (int32_t)(uint32_t)last->y - (int32_t)(uint32_t)last->x;   /* query position - target position of the outermost seeds */
+        const int rid = regs[r].rid;
+        const uint8_t* tseq = idx->codes + idx->off[rid];
+        const int tlen = (int)(idx->off[rid + 1] - idx->off[rid]);
+        omm_seed_hit h; memset(&h, 0, sizeof(h));
+        h.rid = rid; h.rev = regs[r].rev; h.chain_score = regs[r].score; h.n_seeds = regs[r].cnt; h.t_len = tlen; h.sel_rank = r;
+        h.diag = (d0 + d1) >> 1;
+        int cap = (int)(0.03 * (double)tlen) + 1; if (cap > OSP_MAX_ED) cap = OSP_MAX_ED;          /* nm <= 0.03 * span <= 0.03 * allele length (realigner.rs:138-141) */
+        osp_aln al;
+        h.ok = osp_wfa_retry(tseq, tlen, qc, qlen, h.diag, cap, &al, NULL, NULL);
+        if (h.ok) {
+            h.cell_nm = al.nm; h.a_start = al.a_start; h.a_end = al.a_end; h.b_start = al.b_start; h.b_end = al.b_end;
+            const int twice = (al.b_start - al.a_start) + (al.b_end - al.a_end);
+            osp_affine_out af;
+            osp_affine_local(tseq, tlen, qc, qlen, twice / 2, 64, &ao, &af);
+            h.dp_max = af.score; h.nm = af.nm; h.t_start = af.t_start; h.t_end = af.t_end;
+            if (h.rev) { h.q_start = qlen - af.q_end; h.q_end = qlen - af.q_start; } else { h.q_start = af.q_start; h.q_end = af.q_end; }
+        }
+        /* mm_filter_regs: too few seeds (never: chains have >= min_cnt), too few matching bases (implied by the peak score at a = 1), or a peak score below min_dp_max */
+        if (h.ok && h.dp_max >= o->min_dp_max && h.dp_max > 0) {
+            hr[nh] = regs[r]; hr[nh].qs = h.q_start; hr[nh].qe = h.q_end; hr[nh].rs = h.t_start; hr[nh].re = h.t_end; hr[nh].id = nh;
+            tmp[nh++] = h;
+        }
+    }
+    /* output order: by peak score, descending (stable); parents again on the aligned intervals; secondaries by chain score */
+    int ord[OMM_SEED_SEL];
+    for (int i = 0; i < nh; ++i) ord[i] = i;
+    for (int i = 1; i < nh; ++i) { const int c = ord[i]; int j = i - 1; while (j >= 0 && tmp[ord[j]].dp_max < tmp[c].dp_max) { ord[j + 1] = ord[j]; --j; } ord[j + 1] = c; }
+    reg_t hs[OMM_SEED_SEL];
+    for (int i = 0; i < nh; ++i) hs[i] = hr[ord[i]];
+    set_parent(hs, nh, o->mask_level);
+    const int nk = nh ? select_sub(hs, nh, o->pri_ratio, o->k * 2, o->best_n) : 0;
+    /* the acceptance loop of realign_record (src/hla/realigner.rs:124-146) over the mappings in output order */
+    int pick = -1; double best = 1.0;                           /* custom_score(false) of MappingStats(read_len, read_len, 0) */
+    for (int i = 0; i < nk; ++i) {
+        hits[i] = tmp[hs[i].id]; hits[i].primary = hs[i].parent == i;
+        const omm_seed_hit* h = &hits[i];
+        const uint64_t tl = (uint64_t)h->t_len, um = tl - (uint64_t)(h->t_end - h->t_start), nm = (uint64_t)h->nm;
+        if (osp_custom_score(tl, nm, um, 1) <= 0.5 && osp_custom_score(tl, nm, um, 0) <= 0.03 && osp_custom_score(tl, nm, um, 0) < best) { best = osp_custom_score(tl, nm, um, 0); pick = i; }
+    }
+    *n_hits = nk;
+    free(qrev); free(regs); free(v);
+    return pick;
 }

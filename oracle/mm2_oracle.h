@@ -82,6 +82,32 @@ int32_t omm_map(const omm_index* idx, const uint8_t* q, int32_t qlen, const omm_
 int32_t omm_map_pair(const uint8_t* target, int32_t tlen, const uint8_t* q, int32_t qlen, const omm_opts* o,
                      omm_hit* hits, int32_t max_hits, uint32_t* cigar_pool, int32_t cigar_cap);
 
+/* the stages of omm_map one by one (parity tests of the seeded K1 path): the (w,k)-minimizers of a sequence in position order (hash, end position of the
+ * k-mer, strand of the smaller k-mer); returns their number (may exceed cap) */
+int32_t omm_sketch(const uint8_t* s, int32_t len, const omm_opts* o, uint64_t* hash, int32_t* end_pos, uint8_t* strand, int32_t cap);
+/* seeding + chaining + selection without the base-level alignment: regs [cap][10] = {rid, rev, chain score, seeds, qs, qe, rs, re, parent, kept rank (1-based
+ * position in the list align_chain sees, 0 = not selected)} in chain_anchors' order; stats[8] = {minimizers, seeds in the index, seeds kept, anchors, distinct
+ * (strand, target) pairs, chains, chains selected, mid_occ}; returns the number of chains */
+int32_t omm_chain_stage(const omm_index* idx, const uint8_t* q, int32_t qlen, const omm_opts* o, int32_t* regs_out, int32_t cap, int64_t* stats);
+
+/* the sorted anchors of omm_map: x = rev << 63 | rid << 32 | target end position, y = span << 32 | query end position on the mapped strand; returns their
+ * number (may exceed cap) */
+int64_t omm_anchors(const omm_index* idx, const uint8_t* q, int32_t qlen, const omm_opts* o, uint64_t* x, uint64_t* y, int64_t cap);
+
+/* realign_record's seeded map as the library runs it in seeded mode (sp_hla_realign_reads with `k1_best_n` > 0): minimap2's seeding, chaining and selection
+ * (this file), the library's unit-cost cell + two-piece affine re-score for the base-level alignment of the selected chains (at most OMM_SEED_SEL), then the
+ * output order, second selection and acceptance loop (src/hla/realigner.rs:124-146).  hits: the mappings in output order; returns the accepted one or -1. */
+#define OMM_SEED_SEL 16
+typedef struct {
+    int32_t rid, rev, chain_score, n_seeds, t_len;
+    int32_t sel_rank;                        /* position among the selected chains (the order align_chain sees them) */
+    int32_t diag;                            /* the cell's diagonal: query position - target position, midway between the outermost seeds */
+    int32_t ok, cell_nm, a_start, a_end, b_start, b_end;   /* the unit-cost cell: A = target allele, B = query on the mapped strand */
+    int32_t dp_max, nm, t_start, t_end, q_start, q_end;    /* the re-scored mapping (query in forward coordinates, as minimap2 reports) */
+    int32_t primary;
+} omm_seed_hit;
+int32_t omm_hla_k1_seeded(const omm_index* idx, const uint8_t* q, int32_t qlen, const omm_opts* o, omm_seed_hit* hits /* OMM_SEED_SEL */, int32_t* n_hits, int32_t* n_chains);
+
 /* the DP alone (tests): mode 0 = global, 1 = extension from (0,0) ending at the best cell.  out8 = {score, max,
  * max_t, max_q, zdropped, reach_end, t_end, q_end}; cigar ops written to cigar (cap entries), *n_cigar set */
 void omm_dp(const uint8_t* t, int32_t tlen, const uint8_t* q, int32_t qlen, const omm_opts* o, int32_t band,

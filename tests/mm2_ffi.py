@@ -27,6 +27,12 @@ HIT_DTYPE = np.dtype([(n, np.int32) for n in HIT_FIELDS])
 
 OPS = {0: "M", 1: "I", 2: "D", 7: "=", 8: "X"}
 
+SEED_SEL = 16                                           # OMM_SEED_SEL
+SEED_HIT_FIELDS = ("rid", "rev", "chain_score", "n_seeds", "t_len", "sel_rank", "diag", "ok", "cell_nm", "a_start", "a_end", "b_start", "b_end",
+                   "dp_max", "nm", "t_start", "t_end", "q_start", "q_end", "primary")
+SEED_HIT_DTYPE = np.dtype([(n, np.int32) for n in SEED_HIT_FIELDS])
+REG_FIELDS = ("rid", "rev", "score", "cnt", "qs", "qe", "rs", "re", "parent", "kept")
+
 
 class Mm2:
     def __init__(self, oracle=None):
@@ -48,6 +54,14 @@ class Mm2:
         L.omm_dp.argtypes = [vp, i32, vp, i32, C.POINTER(Opts), i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
         L.omm_global_score_bruteforce.restype = i32
         L.omm_global_score_bruteforce.argtypes = [vp, i32, vp, i32, C.POINTER(Opts)]
+        L.omm_sketch.restype = i32
+        L.omm_sketch.argtypes = [vp, i32, C.POINTER(Opts), vp, vp, vp, i32]
+        L.omm_chain_stage.restype = i32
+        L.omm_chain_stage.argtypes = [vp, vp, i32, C.POINTER(Opts), vp, i32, vp]
+        L.omm_anchors.restype = C.c_int64
+        L.omm_anchors.argtypes = [vp, vp, i32, C.POINTER(Opts), vp, vp, C.c_int64]
+        L.omm_hla_k1_seeded.restype = i32
+        L.omm_hla_k1_seeded.argtypes = [vp, vp, i32, C.POINTER(Opts), vp, C.POINTER(i32), C.POINTER(i32)]
 
     def opts(self, **kw):
         o = Opts()
@@ -76,6 +90,15 @@ class Mm2:
         n = self.L.omm_map_pair(t.ctypes.data, len(t), q.ctypes.data, len(q), C.byref(o), hits.ctypes.data, max_hits,
                                 pool.ctypes.data, len(pool))
         return self._hits(n, hits, pool)
+
+    def sketch(self, seq, opts=None):
+        """the (w,k)-minimizers of a sequence in position order -> (hash u64[], end position i32[], strand u8[])"""
+        o = opts or self.opts()
+        q = self.codes(seq)
+        cap = len(q) + 1
+        h, p, st = np.zeros(cap, np.uint64), np.zeros(cap, np.int32), np.zeros(cap, np.uint8)
+        n = self.L.omm_sketch(q.ctypes.data, len(q), C.byref(o), h.ctypes.data, p.ctypes.data, st.ctypes.data, cap)
+        return h[:n].copy(), p[:n].copy(), st[:n].copy()
 
     def dp(self, target, query, opts=None, band=751, mode=0, right=0):
         o = opts or self.opts()
@@ -122,6 +145,30 @@ class Index:
         hits = np.zeros(max_hits, HIT_DTYPE)
         n = self.mm.L.omm_map(self.h, q.ctypes.data, len(q), C.byref(o), hits.ctypes.data, max_hits, None, 0)
         return hits[:n]
+
+    def chain_stage(self, query, opts=None, cap=65536):
+        """seeding + chaining + selection without the base-level alignment -> (regs int32[n][10] in chain_anchors' order, stats int64[8])"""
+        o = opts or self.o
+        q = self.mm.codes(query)
+        regs, st = np.zeros((cap, 10), np.int32), np.zeros(8, np.int64)
+        n = self.mm.L.omm_chain_stage(self.h, q.ctypes.data, len(q), C.byref(o), regs.ctypes.data, cap, st.ctypes.data)
+        return regs[:min(n, cap)].copy(), st
+
+    def anchors(self, query, opts=None, cap=1 << 21):
+        o = opts or self.o
+        q = self.mm.codes(query)
+        x, y = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+        n = self.mm.L.omm_anchors(self.h, q.ctypes.data, len(q), C.byref(o), x.ctypes.data, y.ctypes.data, cap)
+        return x[:min(n, cap)].copy(), y[:min(n, cap)].copy()
+
+    def k1_seeded(self, query, opts=None):
+        """realign_record's seeded map as the library runs it (omm_hla_k1_seeded) -> (index of the accepted hit or -1, hits in output order, number of chains)"""
+        o = opts or self.o
+        q = self.mm.codes(query)
+        hits = np.zeros(SEED_SEL, SEED_HIT_DTYPE)
+        nh, nc = C.c_int32(0), C.c_int32(0)
+        pick = self.mm.L.omm_hla_k1_seeded(self.h, q.ctypes.data, len(q), C.byref(o), hits.ctypes.data, C.byref(nh), C.byref(nc))
+        return pick, hits[:nh.value].copy(), nc.value
 
     @property
     def mid_occ(self):
