@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 1
+#define SP_ABI_VERSION 2      /* 2 (round 5): sp_hla_realign grew (k1_* fields); the records that grew in round 4 (mm2_* fields of sp_hla_realign, sp_hla_best, sp_region_hit;
+                               * sp_cyp_call.searches_gave_up; sp_priority_job.gave_up) are covered by the same step.  A caller checks sp_abi_version() == SP_ABI_VERSION and
+                               * sp_struct_size() of every record it allocates before its first call */
 
 /* status codes: "expected" outcomes the reference downgrades (CallerError -> NO_MATCH,
  * src/diplotyper.rs:316-327; src/cyp2d6/errors.rs:4-11) are distinct from fatal ones (src/main.rs:181-185). */
@@ -52,6 +54,9 @@ typedef struct sp_hla_db sp_hla_db;
 
 /* ------------------------------------------------------------------ context */
 int32_t sp_abi_version(void);
+/* sizeof of a record of this header as THIS build of the library lays it out ("sp_hla_realign", "sp_region_hit", ...; every struct typedef'd here); -1 for an unknown name.
+ * A binding checks the records it allocates and the library fills (a record that grew since the binding was generated would overflow the caller's array). */
+int32_t sp_struct_size(const char* name);
 int32_t sp_device_count(int32_t* count);
 /* device: HIP ordinal.  stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create one. */
 int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out);
@@ -78,6 +83,9 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * of the other samples already fill the gaps (sp_cyp_diplotype follows the same switch: with 1 it places the regions of interest on the consensuses
  * for its weights on a helper stream while it types the consensuses).  The calls are the same either way.  "cons_retry_ladder" (default 0: the reference has no such rule): 1 makes sp_cyp_diplotype* run
  * its multi-way consensus with the retry of searches that give up (sp_cons_config.no_retry_ladder = 0, see sp_consensus_priority); sp_cyp_call.gave_up says whether a search of the call gave up.
+ * "k1_best_n" (0..8, default 5 = the reference's `best_n`, src/util/mapping.rs:12): sp_hla_realign_reads maps a read the way realign_record does -- minimizer seeding, chaining and
+ * selection of the chains that get a base-level alignment as minimap2's `map-hifi` does them, at most k1_best_n secondary chains per read (sp_hla_seed.hip; statement: oracle/mm2.c
+ * omm_hla_k1_seeded) -- and accepts among those mappings only; 0 = the exhaustive search of every allele of every anchored gene (the exact argmin the reference approximates).
  * "mm2_rescore" (default 1): sp_hla_realign_reads, sp_hla_type_consensus / sp_hla_score_consensus and sp_cyp_find_regions also report every mapping they return re-scored
  * the reference's way (fields mm2_*; sp_affine_rescore_batch), and the weights of sp_cyp_weight_segments / sp_cyp_diplotype* are taken from the re-scored placement wherever it is
  * within 16 (edits + unmapped bases) of its segment's smallest; 0 leaves the fields zero, the weights on unit-cost counts, and saves the extra launches; 2 = as 1, but every mapping with edits that do not stand alone
@@ -223,11 +231,16 @@ void    sp_hla_db_free(sp_hla_db* db);
  *   aln          alignment of the read (B) against that allele in hg38 orientation (A): bm.query_* = b_*,
  *                bm.target_* = a_*
  *   seg_start/end  optimal_segment_start..end on the read (:266-267), dna_offset / hpc_offset (:270-325);
- *                status 0 = realigned, 1 = no acceptable allele, 2 = best mapping not Forward (:178-193; decided at the seeds: the
- *                read's best anchor on the reverse-complemented gene references has more 16-mer votes than its best forward
- *                anchor -- only reads with fewer than 512 forward votes are anchored a second time, and a read that realigned
- *                acceptably forwards is only dropped when the reverse anchor has at least twice the votes; the other fields then
- *                hold what the forward search found), 3 = segment failed to map to the gene reference.
+ *                status 0 = realigned, 1 = no acceptable allele, 2 = best mapping not Forward (:178-193), 3 = segment failed to map to the gene reference.
+ * Seeded mode (context option "k1_best_n" > 0, the default): the mappings a read is judged on are the ones minimap2 would return -- (19,19)-minimizer seeds through the occurrence
+ * filter, chains per (strand, allele), the primary chains and the k1_best_n best secondaries within 0.8 of their primary -- base-aligned by the library's cell (64 diagonals around the
+ * chain, 256 when that finds nothing) and re-scored with the two-piece affine scores; the acceptance loop runs over them in minimap2's output order on the re-scored numbers
+ * (aln = the accepted mapping's cell, mm2_* = its re-score); status 2 = the accepted mapping is on the reverse strand.  k1_chains / k1_mappings / k1_chain_score: chains found for
+ * the read, mappings that came back, chain score of the accepted one.  Exhaustive mode ("k1_best_n" = 0; always when cell_out is given): every allele of every gene the read anchors
+ * in (>= 16 16-mer votes and >= 1/10 of the best gene's) is a cell, the lowest index wins ties, the counts are the unit-cost ones and mm2_* a report beside them; status 2 is decided at the
+ * seeds (the read's best anchor on the reverse-complemented gene references has more 16-mer votes than its best forward anchor -- only reads with fewer than 512 forward votes are
+ * anchored a second time, and a read that realigned acceptably forwards is only dropped when the reverse anchor has at least twice the votes; the other fields then hold what the
+ * forward search found); k1_* are 0.
  */
 typedef struct {
     int32_t status;
@@ -242,7 +255,31 @@ typedef struct {
      * (no best allele).  The pipeline's own decisions use the counts above. */
     int32_t mm2_score, mm2_nm;
     int32_t mm2_t_start, mm2_t_end, mm2_q_start, mm2_q_end;
+    int32_t k1_chains, k1_mappings, k1_chain_score;      /* seeded mode: chains of the read, mappings returned, chain score of the accepted mapping */
+    int32_t reserved_;
 } sp_hla_realign;
+
+/* what the seeded map of a read came to (the audit entry point below; sp_hla_realign carries the same counts) */
+#define SP_K1_SEL 16                      /* selected chains per read that are base-aligned (primaries + k1_best_n secondaries; the best ranked when a read has more) */
+typedef struct { int32_t n_chains, n_selected, n_mappings, pick, chain_score, rev; } sp_k1_seed_info;
+typedef struct {
+    int32_t allele, rev, chain_score, n_seeds, t_len;
+    int32_t sel_rank;                        /* position among the selected chains */
+    int32_t diag;                            /* the cell's diagonal: read position - allele position, midway between the chain's outermost seeds */
+    int32_t ok, cell_nm, a_start, a_end, b_start, b_end;   /* the unit-cost cell: A = allele, B = read on the mapped strand */
+    int32_t dp_max, nm, t_start, t_end, q_start, q_end;    /* the re-scored mapping (read in forward coordinates, as minimap2 reports) */
+    int32_t primary;
+} sp_k1_seed_hit;
+/* Audit of the seeded stage (tests hold every stage to oracle/mm2.c):
+ *   sp_hla_seed_index_info   out[4] = minimizers in the index of the database's DNA alleles, distinct minimizers, the occurrence threshold mid_occ, indexed alleles (built on first use)
+ *   sp_seqset_sketch         the (19,19)-minimizers of sequence idx of a set in position order: hash, end position of the k-mer, strand of the smaller k-mer; *n_out may exceed cap
+ *   sp_hla_realign_seeded_audit  for read `read` of the set: its chains in rank order (chains[i*10..] = {indexed allele number, rev, chain score, seeds, query start, query end (forward
+ *                            coordinates), target start, target end, -, selected}), its mappings in output order (hits, SP_K1_SEL entries), the accepted one (*pick or -1) and
+ *                            counters[4] = {kept seeds, anchors, largest anchor count of a read, reads that hit a capacity} of the whole batch */
+int32_t sp_hla_seed_index_info(sp_ctx* ctx, const sp_hla_db* db, int64_t* out /* 4 */);
+int32_t sp_seqset_sketch(sp_ctx* ctx, const sp_seqset* set, uint32_t idx, uint64_t* hash, int32_t* end_pos, uint8_t* strand, uint32_t cap, uint32_t* n_out);
+int32_t sp_hla_realign_seeded_audit(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads, uint32_t read, int32_t* chains, uint32_t chain_cap, uint32_t* n_chains,
+                                    sp_k1_seed_hit* hits /* SP_K1_SEL */, uint32_t* n_hits, int32_t* pick, uint64_t* counters /* 4 */);
 
 int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads,
                              sp_hla_realign* out /* n_reads */,

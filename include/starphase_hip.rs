@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types, non_snake_case, dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const SP_ABI_VERSION: i64 = 1;
+pub const SP_ABI_VERSION: i64 = 2;
 pub const SP_SEQ_ASCII: i64 = 0;
 pub const SP_SEQ_BAM4: i64 = 1;
 pub const SP_SEQ_PACKED2: i64 = 2;
@@ -14,6 +14,7 @@ pub const SP_NO_DIAG: i64 = -2147483648;
 pub const SP_EV_X: i64 = 0;
 pub const SP_EV_D: i64 = 1;
 pub const SP_EV_I: i64 = 2;
+pub const SP_K1_SEL: i64 = 16;
 pub const SP_MAX_CHAIN: i64 = 64;
 pub const SP_CYP_MAXCONS: i64 = 64;
 pub const SP_VAR_MAXDIP: i64 = 4096;
@@ -100,6 +101,42 @@ pub struct sp_hla_realign {
     pub mm2_t_end: i32,
     pub mm2_q_start: i32,
     pub mm2_q_end: i32,
+    pub k1_chains: i32,
+    pub k1_mappings: i32,
+    pub k1_chain_score: i32,
+    pub reserved_: i32,
+}
+#[repr(C)]
+pub struct sp_k1_seed_info {
+    pub n_chains: i32,
+    pub n_selected: i32,
+    pub n_mappings: i32,
+    pub pick: i32,
+    pub chain_score: i32,
+    pub rev: i32,
+}
+#[repr(C)]
+pub struct sp_k1_seed_hit {
+    pub allele: i32,
+    pub rev: i32,
+    pub chain_score: i32,
+    pub n_seeds: i32,
+    pub t_len: i32,
+    pub sel_rank: i32,
+    pub diag: i32,
+    pub ok: i32,
+    pub cell_nm: i32,
+    pub a_start: i32,
+    pub a_end: i32,
+    pub b_start: i32,
+    pub b_end: i32,
+    pub dp_max: i32,
+    pub nm: i32,
+    pub t_start: i32,
+    pub t_end: i32,
+    pub q_start: i32,
+    pub q_end: i32,
+    pub primary: i32,
 }
 #[repr(C)]
 pub struct sp_hla_best {
@@ -561,6 +598,7 @@ pub struct sp_bam_read {
 #[link(name = "starphase_hip")]
 extern "C" {
     pub fn sp_abi_version() -> i32;
+    pub fn sp_struct_size(name: *const c_char) -> i32;
     pub fn sp_device_count(count: *mut i32) -> i32;
     pub fn sp_ctx_create(device: i32, stream: *mut c_void, out: *mut *mut sp_ctx) -> i32;
     pub fn sp_ctx_get_info(ctx: *const sp_ctx, out: *mut sp_ctx_info) -> i32;
@@ -582,6 +620,9 @@ extern "C" {
     pub fn sp_affine_rescore_batch(ctx: *mut sp_ctx, A: *const sp_seqset, B: *const sp_seqset, pairs: *const sp_pair, n_pairs: u64, opts: *const sp_affine_opts, band: i32, out: *mut sp_affine_aln) -> i32;
     pub fn sp_hla_db_create(ctx: *mut sp_ctx, desc: *const sp_hla_db_desc, out: *mut *mut sp_hla_db) -> i32;
     pub fn sp_hla_db_free(db: *mut sp_hla_db);
+    pub fn sp_hla_seed_index_info(ctx: *mut sp_ctx, db: *const sp_hla_db, out: *mut i64) -> i32;
+    pub fn sp_seqset_sketch(ctx: *mut sp_ctx, set: *const sp_seqset, idx: u32, hash: *mut u64, end_pos: *mut i32, strand: *mut u8, cap: u32, n_out: *mut u32) -> i32;
+    pub fn sp_hla_realign_seeded_audit(ctx: *mut sp_ctx, db: *const sp_hla_db, reads: *const sp_seqset, read: u32, chains: *mut i32, chain_cap: u32, n_chains: *mut u32, hits: *mut sp_k1_seed_hit, n_hits: *mut u32, pick: *mut i32, counters: *mut u64) -> i32;
     pub fn sp_hla_realign_reads(ctx: *mut sp_ctx, db: *const sp_hla_db, reads: *const sp_seqset, out: *mut sp_hla_realign, cell_out: *mut u32) -> i32;
     pub fn sp_hla_score_consensus(ctx: *mut sp_ctx, db: *const sp_hla_db, gene: u32, cons_dna: *const c_char, cons_dna_len: u32, cons_cdna: *const c_char, cons_cdna_len: u32, require_dna: i32, disable_cdna: i32, best: *mut sp_hla_best, stats: *mut i32) -> i32;
     pub fn sp_hla_score_consensus_batch(ctx: *mut sp_ctx, db: *const sp_hla_db, n: u32, genes: *const u32, cons_dna: *const *const c_char, cons_dna_len: *const u32, cons_cdna: *const *const c_char, cons_cdna_len: *const u32, require_dna: i32, disable_cdna: i32, best: *mut sp_hla_best) -> i32;

@@ -95,7 +95,7 @@ void sp_ctx_destroy(sp_ctx* ctx) {
 sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i) {
     if (i < 0 || i > 6) return nullptr;
     if (!ctx->helper[i] && sp_ctx_create(ctx->device, nullptr, &ctx->helper[i]) != SP_OK) ctx->helper[i] = nullptr;
-    if (ctx->helper[i]) { ctx->helper[i]->profiling = ctx->profiling; ctx->helper[i]->k5_block_pairs = ctx->k5_block_pairs; ctx->helper[i]->k8_persistent = ctx->k8_persistent; ctx->helper[i]->mm2_rescore = ctx->mm2_rescore; }
+    if (ctx->helper[i]) { ctx->helper[i]->profiling = ctx->profiling; ctx->helper[i]->k5_block_pairs = ctx->k5_block_pairs; ctx->helper[i]->k8_persistent = ctx->k8_persistent; ctx->helper[i]->mm2_rescore = ctx->mm2_rescore; ctx->helper[i]->k1_best_n = ctx->k1_best_n; }
     return ctx->helper[i];
 }
 void sp_profile_merge(sp_ctx* into, sp_ctx* from) {
@@ -104,6 +104,54 @@ void sp_profile_merge(sp_ctx* into, sp_ctx* from) {
     from->prof.clear();
 }
 extern "C" {
+
+int32_t sp_struct_size(const char* name) {
+    if (!name) return -1;
+#define SP_SZ(T) if (std::strcmp(name, #T) == 0) return (int32_t)sizeof(T);
+    SP_SZ(sp_ctx_info)
+    SP_SZ(sp_pair)
+    SP_SZ(sp_aln)
+    SP_SZ(sp_hla_db_desc)
+    SP_SZ(sp_hla_realign)
+    SP_SZ(sp_k1_seed_hit)
+    SP_SZ(sp_hla_best)
+    SP_SZ(sp_chain_problem)
+    SP_SZ(sp_chain_result)
+    SP_SZ(sp_region_hit)
+    SP_SZ(sp_cyp_problem)
+    SP_SZ(sp_cyp_call)
+    SP_SZ(sp_cyp_locus)
+    SP_SZ(sp_cyp_gene_def)
+    SP_SZ(sp_cyp_config)
+    SP_SZ(sp_cyp_db_stats)
+    SP_SZ(sp_variant_problem)
+    SP_SZ(sp_variant_result)
+    SP_SZ(sp_sv_definitions)
+    SP_SZ(sp_cons_config)
+    SP_SZ(sp_cons_result)
+    SP_SZ(sp_cons_problem)
+    SP_SZ(sp_cons_output)
+    SP_SZ(sp_priority_problem)
+    SP_SZ(sp_priority_job)
+    SP_SZ(sp_hla_call_config)
+    SP_SZ(sp_hla_call)
+    SP_SZ(sp_database_metadata)
+    SP_SZ(sp_database_stats)
+    SP_SZ(sp_gene_region)
+    SP_SZ(sp_variant_detail)
+    SP_SZ(sp_bam_read)
+    SP_SZ(sp_affine_opts)
+    SP_SZ(sp_affine_aln)
+    SP_SZ(sp_k1_seed_info)
+    SP_SZ(sp_cyp_region_variants)
+    SP_SZ(sp_chain_build_info)
+    SP_SZ(sp_variant_gene_stats)
+    SP_SZ(sp_vcf_allele)
+    SP_SZ(sp_vcf_deletion)
+    SP_SZ(sp_mapping_stats)
+#undef SP_SZ
+    return -1;
+}
 
 const char* sp_last_error(const sp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -116,6 +164,7 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx) {
 int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SP_ERR_INVALID_ARG;
     if (std::strcmp(name, "hla_split_genes") == 0) { ctx->split_genes = value != 0; return SP_OK; }
+    if (std::strcmp(name, "k1_best_n") == 0) { if (value < 0 || value > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k1_best_n is 0..8"); ctx->k1_best_n = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k1_best_n = ctx->k1_best_n; return SP_OK; }
     if (std::strcmp(name, "mm2_rescore") == 0) { ctx->mm2_rescore = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->mm2_rescore = ctx->mm2_rescore; return SP_OK; }
     if (std::strcmp(name, "k8_persistent") == 0) { ctx->k8_persistent = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->k8_persistent = ctx->k8_persistent; return SP_OK; }
     if (std::strcmp(name, "cons_retry_ladder") == 0) { ctx->cons_retry_ladder = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->cons_retry_ladder = ctx->cons_retry_ladder; return SP_OK; }

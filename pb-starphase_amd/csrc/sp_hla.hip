@@ -57,6 +57,7 @@ struct sp_hla_db {
     int32_t*  d_am = nullptr;         // n_alleles*3: ok, am.query_start, am.target_start (allele -> gene ref, realigner.rs:289-310)
     int32_t*  d_hpc_ref = nullptr;    // hpc_pos(ref_fwd[g], p) for p in 0..len, concatenated
     uint64_t* d_hpc_ref_off = nullptr;
+    mutable K1Seed* seed = nullptr;   // minimizer index of dna_fwd for the seeded K1 (sp_hla_seed.hip), built at the first seeded call
     mutable K2Dict kdict[2];          // 16-mer dictionaries of cdna_gene / dna_gene, built at the first K2 call (sp_hla_dict.hip)
     mutable std::mutex lazy;          // guards gene_lists and kdict: two contexts may type consensuses on one database at the same time
 };
@@ -400,6 +401,18 @@ __global__ void k1_affine_store_kernel(sp_hla_realign* __restrict__ rec, uint32_
     q.mm2_score = a.score; q.mm2_nm = a.nm; q.mm2_t_start = a.b_start; q.mm2_t_end = a.b_end; q.mm2_q_start = a.a_start; q.mm2_q_end = a.a_end;
 }
 
+// seeded mode: the accepted mapping's re-score and the counts of the seeded stage go into the record; a read whose accepted mapping is on the reverse strand is dropped
+// (src/hla/realigner.rs:178-193)
+__global__ void k1_seed_store_kernel(sp_hla_realign* __restrict__ rec, uint32_t n_reads, const sp_k1_seed_info* __restrict__ info, const sp_affine_aln* __restrict__ af) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    sp_hla_realign& q = rec[r];
+    const sp_k1_seed_info i = info[r]; const sp_affine_aln a = af[r];
+    q.k1_chains = i.n_chains; q.k1_mappings = i.n_mappings; q.k1_chain_score = i.chain_score;
+    if (i.pick >= 0 && i.rev) q.status = 2;
+    q.mm2_score = a.score; q.mm2_nm = a.nm; q.mm2_t_start = a.b_start; q.mm2_t_end = a.b_end; q.mm2_q_start = a.a_start; q.mm2_q_end = a.a_end;
+}
+
 // K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
 // pair p of the K1 anchor is (gene p % G, read p / G); every read starts without a bound
 __global__ void k1_init_kernel(uint32_t* __restrict__ a_idx, uint32_t* __restrict__ b_idx, uint32_t n_reads, uint32_t n_genes,
@@ -470,7 +483,7 @@ __global__ __launch_bounds__(256) void k1_finalize_kernel(SeqSetView alleles_fwd
                                                           const int32_t* __restrict__ am, const int32_t* __restrict__ hpc_ref,
                                                           const uint64_t* __restrict__ hpc_ref_off,
                                                           const int32_t* __restrict__ best_in, uint32_t n_reads,
-                                                          sp_hla_realign* __restrict__ out, int slot_words) {
+                                                          sp_hla_realign* __restrict__ out, int slot_words, const sp_aln* __restrict__ aln_in) {
     extern __shared__ uint32_t lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* slot = lds + wave * slot_words;
@@ -495,7 +508,10 @@ __global__ __launch_bounds__(256) void k1_finalize_kernel(SeqSetView alleles_fwd
         int cap = (int)(0.03 * (double)alen) + 1; if (cap > SP_MAX_ED) cap = SP_MAX_ED;
         in.max_ed = cap;
         spw::CellOut bm;
-        spw::wfa_cell<false, HASN>(in, slot, slot_words, lane, nullptr, nullptr, bm);
+        if (aln_in) {                      // seeded mode: the accepted mapping's cell was run on its chain's diagonal (sp_hla_seed.hip)
+            const sp_aln w = aln_in[r];
+            bm.ok = w.ok; bm.nm = w.nm; bm.a_start = w.a_start; bm.a_end = w.a_end; bm.b_start = w.b_start; bm.b_end = w.b_end; bm.explored = 0;
+        } else spw::wfa_cell<false, HASN>(in, slot, slot_words, lane, nullptr, nullptr, bm);
         res.best_allele = a; res.gene = (int)g;
         res.nm = bm.nm; res.target_len = alen; res.unmapped = alen - (bm.a_end - bm.a_start);
         res.aln.ok = bm.ok; res.aln.nm = bm.nm; res.aln.a_start = bm.a_start; res.aln.a_end = bm.a_end;
@@ -806,6 +822,7 @@ void sp_hla_db_free(sp_hla_db* db) {
     (void)hipFree(db->d_hpc_ref); (void)hipFree(db->d_hpc_ref_off);
     for (auto& kv : db->gene_lists) { (void)hipFree(kv.second.d_idx); (void)hipFree(kv.second.d_l0); (void)hipFree(kv.second.d_l1); }
     sp_k2_dict_free(&db->kdict[0]); sp_k2_dict_free(&db->kdict[1]);
+    sp_k1_seed_free(db->seed);
     delete db;
 }
 
@@ -959,6 +976,46 @@ int32_t sp_hla_db_create(sp_ctx* ctx, const sp_hla_db_desc* d, sp_hla_db** out) 
 
 static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads, sp_hla_realign* out, uint32_t* cell_out);
 
+static int32_t k1_seed_index(sp_ctx* ctx, const sp_hla_db* db) {
+    std::lock_guard<std::mutex> guard(db->lazy);
+    if (db->seed) return SP_OK;
+    (void)hipSetDevice(ctx->device);
+    return sp_k1_seed_build(ctx, db->dna_fwd, &db->seed);
+}
+
+int32_t sp_hla_seed_index_info(sp_ctx* ctx, const sp_hla_db* db, int64_t* out) {
+    if (!ctx || !db || !out) return SP_ERR_INVALID_ARG;
+    const int32_t rc = k1_seed_index(ctx, db);
+    if (rc != SP_OK) return rc;
+    sp_k1_seed_stats(db->seed, out);
+    return SP_OK;
+}
+
+int32_t sp_seqset_sketch(sp_ctx* ctx, const sp_seqset* set, uint32_t idx, uint64_t* hash, int32_t* end_pos, uint8_t* strand, uint32_t cap, uint32_t* n_out) {
+    if (!ctx || !set || !n_out || idx >= set->n) return SP_ERR_INVALID_ARG;
+    return sp_k1_seed_sketch(ctx, set, idx, hash, end_pos, strand, cap, n_out);
+}
+
+int32_t sp_hla_realign_seeded_audit(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads, uint32_t read, int32_t* chains, uint32_t chain_cap, uint32_t* n_chains,
+                                    sp_k1_seed_hit* hits, uint32_t* n_hits, int32_t* pick, uint64_t* counters) {
+    if (!ctx || !db || !reads || read >= reads->n || !chains || !n_chains || !hits || !n_hits || !pick || !counters) return SP_ERR_INVALID_ARG;
+    int32_t rc = k1_seed_index(ctx, db);
+    if (rc != SP_OK) return rc;
+    const uint32_t R = reads->n;
+    int32_t* d_best = (int32_t*)sp_pool(ctx, "k1_best", (size_t)R * 4);
+    sp_aln* d_win_aln = (sp_aln*)sp_pool(ctx, "k1s_win_aln", (size_t)R * sizeof(sp_aln)); sp_affine_aln* d_win_af = (sp_affine_aln*)sp_pool(ctx, "k1s_win_af", (size_t)R * sizeof(sp_affine_aln));
+    sp_k1_seed_info* d_info = (sp_k1_seed_info*)sp_pool(ctx, "k1s_info", (size_t)R * sizeof(sp_k1_seed_info));
+    if (!d_best || !d_win_aln || !d_win_af || !d_info) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "audit buffers");
+    K1SeedDebug dbg; dbg.read = read; dbg.chains = chains; dbg.chain_cap = chain_cap; dbg.n_chains = n_chains; dbg.hits = hits; dbg.n_hits = n_hits; dbg.counters = counters;
+    rc = sp_k1_seed_map(ctx, db->seed, db->dna_fwd, reads, ctx->k1_best_n > 0 ? ctx->k1_best_n : 5, d_best, d_info, d_win_aln, d_win_af, &dbg);
+    if (rc != SP_OK) return rc;
+    sp_k1_seed_info inf;
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(&inf, d_info + read, sizeof(inf), hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *pick = inf.pick;
+    return SP_OK;
+}
+
 int32_t sp_hla_realign_reads(sp_ctx* ctx, const sp_hla_db* db, const sp_seqset* reads, sp_hla_realign* out, uint32_t* cell_out) {
     if (!ctx || !db || !reads || !out) return SP_ERR_INVALID_ARG;
     HostScope host_total(ctx, "host:k1_total");
@@ -984,6 +1041,13 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     const uint32_t R = reads->n, G = db->n_genes, NA = db->n_alleles;
     if (R == 0) return SP_OK;
     (void)hipSetDevice(ctx->device);
+    // the reference's call pattern (seeds, chains, best_n: sp_hla_seed.hip) unless the caller wants every cell or has switched it off
+    const bool seeded = ctx->k1_best_n > 0 && !cell_out;
+    sp_aln* d_win_aln = nullptr; sp_affine_aln* d_win_af = nullptr; sp_k1_seed_info* d_seed_info = nullptr;
+    if (seeded) {
+        std::lock_guard<std::mutex> guard(db->lazy);
+        if (!db->seed) { const int brc = sp_k1_seed_build(ctx, db->dna_fwd, &db->seed); if (brc != SP_OK) return brc; }
+    }
     // 1. anchors read x gene
     uint32_t* d_a = (uint32_t*)sp_pool(ctx, "k1_a_idx", (size_t)R * G * 4);
     uint32_t* d_b = (uint32_t*)sp_pool(ctx, "k1_b_idx", (size_t)R * G * 4);
@@ -999,7 +1063,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     if (rc == SP_OK && d_win) (void)hipMemsetAsync(d_win, 0xFF, (size_t)R * 8, ctx->stream);
     // the (gene, read) pair list of the anchor and the empty bounds are written on the device: no host vectors, no waiting for copies
     unsigned long long* d_bound = nullptr;
-    if (rc == SP_OK && !cell_out) {
+    if (rc == SP_OK && !cell_out && !seeded) {
         d_bound = (unsigned long long*)sp_pool(ctx, "k1_bound", (size_t)R * 8);
         if (!d_bound) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign bound");
     }
@@ -1011,7 +1075,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
     uint8_t* d_isrev = (uint8_t*)sp_pool(ctx, "k1_isrev", R);
     uint32_t n_weak = 0; bool weak_known = false;
     if (rc == SP_OK && (!d_weak_n || !d_weak || !d_isrev)) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign strand buffers");
-    if (rc == SP_OK) {
+    if (rc == SP_OK && !seeded) {
         (void)hipMemsetAsync(d_weak_n, 0, 4, ctx->stream); (void)hipMemsetAsync(d_isrev, 0, R, ctx->stream);
         hipLaunchKernelGGL(k1_weak_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_votes, R, G, d_weak_n, d_weak);
     }
@@ -1037,8 +1101,15 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         else { (void)hipMemsetAsync(d_done, 0, R, ctx->stream); (void)hipMemsetAsync(d_maxlen, 0, (size_t)R * 4, ctx->stream); }
     }
     const int pass_caps[3] = {K1_CAP1, 40, SP_MAX_ED};
-    const int n_pass = d_bound ? 3 : 1;
+    const int n_pass = seeded ? 0 : d_bound ? 3 : 1;
     uint32_t n_open = R;
+    if (rc == SP_OK && seeded) {
+        d_win_aln = (sp_aln*)sp_pool(ctx, "k1s_win_aln", (size_t)R * sizeof(sp_aln)); d_win_af = (sp_affine_aln*)sp_pool(ctx, "k1s_win_af", (size_t)R * sizeof(sp_affine_aln));
+        d_seed_info = (sp_k1_seed_info*)sp_pool(ctx, "k1s_info", (size_t)R * sizeof(sp_k1_seed_info));
+        if (!d_win_aln || !d_win_af || !d_seed_info) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+        else rc = sp_k1_seed_map(ctx, db->seed, db->dna_fwd, reads, ctx->k1_best_n, d_best, d_seed_info, d_win_aln, d_win_af, nullptr);
+        weak_known = true;
+    }
     for (int pass = 0; pass < n_pass && rc == SP_OK; ++pass) {
         const int pass_cap = d_bound ? pass_caps[pass] : SP_MAX_ED;
         const uint32_t n_chunks = (((NA + K1_CHUNK - 1) / K1_CHUNK) + 7) & ~7u;       // padded to the 8 XCDs (k1_cells_kernel)
@@ -1090,7 +1161,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         }
         if (rc == SP_OK) hipLaunchKernelGGL(k1_reverse_kernel, dim3((n_weak + 255) / 256), dim3(256), 0, ctx->stream, d_weak, n_weak, G, d_votes, d_votes2, d_isrev);
     }
-    if (rc == SP_OK) {
+    if (rc == SP_OK && !seeded) {
         ProfScope ps(ctx, "k1_reduce", R);
         if (d_win) hipLaunchKernelGGL(k1_winner_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_win, R, d_best);
         else hipLaunchKernelGGL(k1_reduce_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, d_cells, db->dna_fwd->d_len, db->d_order, NA, R, d_best);
@@ -1101,17 +1172,18 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
             (void)hipFuncSetAttribute((const void*)k1_finalize_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             hipLaunchKernelGGL(k1_finalize_kernel<true>, dim3((R + 3) / 4), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), db->dna_gene->view(),
                                db->ref_fwd->view(), reads->view(), db->d_gene_of, db->d_off_fwd, d_rg, (int)G, db->d_am, db->d_hpc_ref, db->d_hpc_ref_off,
-                               d_best, R, d_out, slot_words);
+                               d_best, R, d_out, slot_words, d_win_aln);
         } else {
             (void)hipFuncSetAttribute((const void*)k1_finalize_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             hipLaunchKernelGGL(k1_finalize_kernel<false>, dim3((R + 3) / 4), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), db->dna_gene->view(),
                                db->ref_fwd->view(), reads->view(), db->d_gene_of, db->d_off_fwd, d_rg, (int)G, db->d_am, db->d_hpc_ref, db->d_hpc_ref_off,
-                               d_best, R, d_out, slot_words);
+                               d_best, R, d_out, slot_words, d_win_aln);
         }
         if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_finalize launch failed");
     }
     // 3b. the winners re-scored the reference's way (two-piece affine gaps, end clipping): the numbers minimap2 reports for the read and its allele
-    if (rc == SP_OK && ctx->mm2_rescore) {
+    if (rc == SP_OK && seeded) hipLaunchKernelGGL(k1_seed_store_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, d_seed_info, d_win_af);
+    if (rc == SP_OK && ctx->mm2_rescore && !seeded) {
         CellDesc* d_rc = (CellDesc*)sp_pool(ctx, "k1_af_cells", (size_t)R * sizeof(CellDesc));
         sp_aln* d_ref = (sp_aln*)sp_pool(ctx, "k1_af_ref", (size_t)R * sizeof(sp_aln));
         sp_affine_aln* d_af = (sp_affine_aln*)sp_pool(ctx, "k1_af_out", (size_t)R * sizeof(sp_affine_aln));

@@ -92,6 +92,8 @@ struct sp_ctx {
     hipStream_t copy_stream = nullptr;   // uploads travel on a stream of their own, beside the kernels of ctx->stream
     hipStream_t ctl_stream = nullptr;    // the control workgroups of a persistent consensus batch run here, beside the step workgroups on ctx->stream (made on first use)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int k1_best_n = 5;                   // sp_ctx_set_option "k1_best_n": K1 base-aligns the chains minimap2's seeding and chaining select (best_n secondaries per read, the reference's 5);
+                                         // 0 = every allele of every anchored gene (the exhaustive argmin of rounds 1-4)
     int mm2_rescore = 1;                 // sp_ctx_set_option "mm2_rescore": the entry points that return mappings also report them re-scored with the reference's affine scores (mm2_* fields)
     bool k8_persistent = false;          // sp_ctx_set_option "k8_persistent" (or SP_K8_PERSISTENT=1): small consensus batches run as two persistent kernels instead of a launch pair per
                                          // step.  Off by default: the agent-scope release / acquire fences of every hand-over cost what the kernel boundaries cost (measured)
@@ -124,6 +126,21 @@ void* sp_dev_alloc(sp_ctx* ctx, size_t bytes);    // a device buffer of >= bytes
 void sp_dev_release(sp_ctx* ctx, void* p);        // hands it back (nullptr is fine); buffers beyond the cache's bounds are freed
 int  sp_k2_dict_build(sp_ctx* ctx, const sp_seqset* set, const uint32_t* d_gene_of, uint32_t n_genes, K2Dict* out);
 void sp_k2_dict_free(K2Dict* d);
+
+// ---------------------------------------------------------------- K1 in the reference's call pattern: minimizer index, chains, best_n (sp_hla_seed.hip)
+struct K1Seed;
+struct K1SeedDebug {                        // the chain list, selection and mappings of ONE read of the batch (sp_hla_realign_seeded_audit)
+    uint32_t read;
+    int32_t* chains; uint32_t chain_cap; uint32_t* n_chains;      // [cap][10] = {rid, rev, score, seeds, qs, qe, rs, re, parent, selected} in rank order
+    sp_k1_seed_hit* hits; uint32_t* n_hits;                       // SP_K1_SEL entries, output order
+    uint64_t* counters;                                           // 4: kept seeds, anchors, largest anchor count of a read, reads that hit a capacity
+};
+int  sp_k1_seed_build(sp_ctx* ctx, const sp_seqset* alleles, K1Seed** out);
+void sp_k1_seed_free(K1Seed* s);
+void sp_k1_seed_stats(const K1Seed* s, int64_t out[4]);            // minimizers, distinct minimizers, mid_occ, indexed sequences
+int  sp_k1_seed_sketch(sp_ctx* ctx, const sp_seqset* set, uint32_t idx, uint64_t* hash, int32_t* end_pos, uint8_t* strand, uint32_t cap, uint32_t* n_out);
+int  sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, const sp_seqset* reads, int best_n, int32_t* d_best, sp_k1_seed_info* d_info,
+                    sp_aln* d_win_aln, sp_affine_aln* d_win_af, const K1SeedDebug* dbg);
 
 // ---------------------------------------------------------------- launchers (sp_device.hip)
 sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i = 0);                           // helper i (0..6); nullptr when it cannot be made

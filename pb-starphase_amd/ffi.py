@@ -50,9 +50,14 @@ class sp_hla_realign(C.Structure):
                 ("aln", sp_aln),
                 ("seg_start", C.c_int32), ("seg_end", C.c_int32),
                 ("dna_offset", C.c_int32), ("hpc_offset", C.c_int32),
-                ("mm2_score", C.c_int32), ("mm2_nm", C.c_int32), ("mm2_t_start", C.c_int32), ("mm2_t_end", C.c_int32), ("mm2_q_start", C.c_int32), ("mm2_q_end", C.c_int32)]
+                ("mm2_score", C.c_int32), ("mm2_nm", C.c_int32), ("mm2_t_start", C.c_int32), ("mm2_t_end", C.c_int32), ("mm2_q_start", C.c_int32), ("mm2_q_end", C.c_int32),
+                ("k1_chains", C.c_int32), ("k1_mappings", C.c_int32), ("k1_chain_score", C.c_int32), ("reserved_", C.c_int32)]
 
 
+SP_ABI_VERSION = 2          # include/starphase_hip.h
+SP_K1_SEL = 16
+K1_HIT_FIELDS = ("allele", "rev", "chain_score", "n_seeds", "t_len", "sel_rank", "diag", "ok", "cell_nm", "a_start", "a_end", "b_start", "b_end",
+                 "dp_max", "nm", "t_start", "t_end", "q_start", "q_end", "primary")
 SP_MAX_CHAIN = 64
 
 
@@ -211,7 +216,9 @@ REALIGN_DTYPE = np.dtype([("status", np.int32), ("best_allele", np.int32), ("gen
                           ("aln", ALN_DTYPE),
                           ("seg_start", np.int32), ("seg_end", np.int32),
                           ("dna_offset", np.int32), ("hpc_offset", np.int32),
-                          ("mm2_score", np.int32), ("mm2_nm", np.int32), ("mm2_t_start", np.int32), ("mm2_t_end", np.int32), ("mm2_q_start", np.int32), ("mm2_q_end", np.int32)])
+                          ("mm2_score", np.int32), ("mm2_nm", np.int32), ("mm2_t_start", np.int32), ("mm2_t_end", np.int32), ("mm2_q_start", np.int32), ("mm2_q_end", np.int32),
+                          ("k1_chains", np.int32), ("k1_mappings", np.int32), ("k1_chain_score", np.int32), ("reserved_", np.int32)])
+K1_HIT_DTYPE = np.dtype([(n, np.int32) for n in K1_HIT_FIELDS])
 
 _lib = None
 
@@ -229,6 +236,10 @@ def lib():
     vp, u32, i32, u64 = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint64
     sigs = {
         "sp_abi_version": (i32, []),
+        "sp_struct_size": (i32, [C.c_char_p]),
+        "sp_hla_seed_index_info": (i32, [vp, vp, vp]),
+        "sp_seqset_sketch": (i32, [vp, vp, u32, vp, vp, vp, u32, C.POINTER(u32)]),
+        "sp_hla_realign_seeded_audit": (i32, [vp, vp, vp, u32, vp, u32, C.POINTER(u32), vp, C.POINTER(u32), C.POINTER(i32), vp]),
         "sp_device_count": (i32, [C.POINTER(i32)]),
         "sp_ctx_create": (i32, [i32, vp, C.POINTER(vp)]),
         "sp_ctx_destroy": (None, [vp]),
@@ -309,6 +320,13 @@ def lib():
         fn = getattr(L, name)           # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    # a library built from another header would fill records of another size into the arrays allocated here: refuse it
+    if L.sp_abi_version() != SP_ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {L.sp_abi_version()}, this binding was written for {SP_ABI_VERSION} (rebuild: __graft_entry__.build())")
+    for name, size in (("sp_hla_realign", REALIGN_DTYPE.itemsize), ("sp_aln", ALN_DTYPE.itemsize), ("sp_k1_seed_hit", K1_HIT_DTYPE.itemsize),
+                       ("sp_hla_best", C.sizeof(sp_hla_best)), ("sp_hla_realign", C.sizeof(sp_hla_realign))):
+        if L.sp_struct_size(name.encode()) != size:
+            raise ImportError(f"{path}: {name} is {L.sp_struct_size(name.encode())} bytes in the library, {size} in this binding")
     _lib = L
     return L
 
@@ -1067,6 +1085,14 @@ class SeqSet:
         self._keep = None
         return self
 
+    def sketch(self, idx):
+        """sp_seqset_sketch: the (19,19)-minimizers of sequence idx in position order -> (hash u64[], end position i32[], strand u8[])"""
+        cap = 1 << 16
+        h, p, st = np.zeros(cap, np.uint64), np.zeros(cap, np.int32), np.zeros(cap, np.uint8)
+        n = C.c_uint32(0)
+        self.ctx.check(lib().sp_seqset_sketch(self.ctx._h, self._h, int(idx), _ptr(h), _ptr(p), _ptr(st), cap, C.byref(n)))
+        return h[:n.value].copy(), p[:n.value].copy(), st[:n.value].copy()
+
     @property
     def skipped(self):
         k = C.c_uint32(0)
@@ -1143,6 +1169,22 @@ class HlaDb:
         cell = np.zeros((reads.n, self.n_alleles), np.uint32) if cells else None
         self.ctx.check(lib().sp_hla_realign_reads(self.ctx._h, self._h, reads._h, _ptr(out), _ptr(cell)))
         return (out, cell) if cells else out
+
+    def seed_index_info(self):
+        """sp_hla_seed_index_info -> dict(minimizers, distinct, mid_occ, sequences) of the minimizer index of the DNA alleles (built on first use)"""
+        out = np.zeros(4, np.int64)
+        self.ctx.check(lib().sp_hla_seed_index_info(self.ctx._h, self._h, _ptr(out)))
+        return dict(minimizers=int(out[0]), distinct=int(out[1]), mid_occ=int(out[2]), sequences=int(out[3]))
+
+    def realign_seeded_audit(self, reads, read, chain_cap=65536):
+        """sp_hla_realign_seeded_audit for one read of the set -> dict(chains int32[n][10] in rank order, hits (output order), pick, counters)"""
+        chains = np.zeros((chain_cap, 10), np.int32)
+        hits = np.zeros(SP_K1_SEL, K1_HIT_DTYPE)
+        nc, nh, pick = C.c_uint32(0), C.c_uint32(0), C.c_int32(-1)
+        ctr = np.zeros(4, np.uint64)
+        self.ctx.check(lib().sp_hla_realign_seeded_audit(self.ctx._h, self._h, reads._h, int(read), _ptr(chains), chain_cap, C.byref(nc), _ptr(hits), C.byref(nh), C.byref(pick), _ptr(ctr)))
+        return dict(chains=chains[:min(nc.value, chain_cap)].copy(), n_chains=nc.value, hits=hits[:nh.value].copy(), pick=pick.value,
+                    counters=dict(seeds=int(ctr[0]), anchors=int(ctr[1]), max_anchors=int(ctr[2]), capacity_hits=int(ctr[3])))
 
     def diplotype_gene(self, gene, reads, realign, cfg=None, cap=65536):
         """sp_hla_diplotype_gene -> (sp_hla_call, consensus1, consensus2, is_consensus1 of the gene's realigned reads)"""

@@ -21,7 +21,7 @@ def test_header_symbols_exported(pkg):
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/starphase_hip.h but not exported"
-    assert lib.sp_abi_version() == 1
+    assert lib.sp_abi_version() == pkg.ffi.SP_ABI_VERSION == 2
 
 
 def test_binding_matches_header(pkg):
@@ -73,6 +73,30 @@ def test_hardware_queue_default_is_asked_for_before_hip_starts(pkg):
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-1000:]
         assert out.stdout.strip().splitlines()[-1] == want
+
+
+def test_the_binding_refuses_a_library_of_another_abi(pkg, monkeypatch):
+    """records the caller allocates have grown (round 4: mm2_* fields; round 5: k1_* fields): the version and the record sizes are checked when the library is bound"""
+    L = pkg.ffi.lib()
+    text = open(os.path.join(ROOT, "include", "starphase_hip.h")).read()
+    assert int(re.search(r"#define SP_ABI_VERSION (\d+)", text).group(1)) == pkg.ffi.SP_ABI_VERSION
+    rs = open(os.path.join(ROOT, "include", "starphase_hip.rs")).read()
+    assert int(re.search(r"SP_ABI_VERSION: i64 = (\d+)", rs).group(1)) == pkg.ffi.SP_ABI_VERSION
+    # every struct of the binding that the header names has the library's size
+    for name in dir(pkg.ffi):
+        t = getattr(pkg.ffi, name)
+        if isinstance(t, type) and issubclass(t, C.Structure) and name.startswith("sp_"):
+            size = L.sp_struct_size(name.encode())
+            assert size in (-1, C.sizeof(t)), f"{name}: binding {C.sizeof(t)} bytes, library {size}"
+    assert L.sp_struct_size(b"sp_hla_realign") == pkg.ffi.REALIGN_DTYPE.itemsize == 112
+    assert L.sp_struct_size(b"no_such_record") == -1
+    monkeypatch.setattr(pkg.ffi, "_lib", None)
+    monkeypatch.setattr(pkg.ffi, "SP_ABI_VERSION", 1)
+    with pytest.raises(ImportError, match="ABI version"):
+        pkg.ffi.lib()
+    monkeypatch.setattr(pkg.ffi, "SP_ABI_VERSION", 2)
+    monkeypatch.setattr(pkg.ffi, "_lib", None)
+    pkg.ffi.lib()
 
 
 def test_struct_layouts(pkg):
