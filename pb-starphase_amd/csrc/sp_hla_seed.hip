@@ -10,11 +10,15 @@
 // CPU statement, bit for bit: oracle/mm2.c (collect_anchors, chain_anchors, set_parent, select_sub, omm_hla_k1_seeded).  The exhaustive search of
 // sp_hla.hip (every allele of every anchored gene) stays available: context option "k1_best_n" = 0.
 #include <cstring>
+#include <cstdio>
 #include "sp_internal.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <cmath>
 
+#ifndef SP_DP_EXP
+#define SP_DP_EXP 0
+#endif
 namespace {
 
 // ---- the reference's settings (map-hifi; oracle/mm2.c omm_default_opts)
@@ -145,7 +149,17 @@ __global__ __launch_bounds__(256) void mz_sketch_kernel(SeqSetView S, const uint
 // seeds of a read: minimizers that occur in the index, in query order, through the occurrence filter (oracle/mm2.c collect_anchors):
 // a seed with <= mid_occ occurrences is kept; of a streak of seeds above it the `(streak length on the query) / 500` ones with the fewest
 // occurrences are kept when they have <= 4095.  seeds[]: {query end position << 1 | strand, first occurrence, occurrences, 0}
-struct SeedCounters { unsigned long long seeds, anchors; uint32_t max_anchors, max_seeds, overflow_reads, seed_overflow, rev_selected, pad; };
+struct SeedCounters { unsigned long long seeds, anchors; uint32_t max_anchors, max_seeds, overflow_reads, seed_overflow, rev_selected, pad; unsigned long long t[8]; };
+#ifdef SP_K1S_TIMING
+#define K1S_T(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&ctr->t[i], now_ - t_last); t_last = now_; } } while (0)
+#else
+#define K1S_T(i) do { } while (0)
+#endif
+#ifdef SP_K1S_TIMING
+#define K1S_TW(i) do { if (lane == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&ctr->t[i], now_ - t_last); t_last = now_; } } while (0)
+#else
+#define K1S_TW(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256) void k1s_seed_kernel(SeqSetView reads, IndexView ix, uint32_t n_reads, int sd_cap, uint4* __restrict__ seeds, uint32_t seed_cap,
                                                        uint2* __restrict__ read_seed, uint32_t* __restrict__ read_anchors, SeedCounters* __restrict__ ctr) {
@@ -237,19 +251,23 @@ __global__ __launch_bounds__(256) void k1s_seed_kernel(SeqSetView reads, IndexVi
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// chains of a read.  One workgroup per read at a time (the grid strides over the reads), a private scratch region in device memory per workgroup.
-// Per window of targets (strand, [rid_lo, rid_lo + W)): count the anchors of every target in an LDS table, lay the targets with >= 3 anchors out one
-// after the other (their anchors as target end position << 16 | query end position on the mapped strand: ascending = the order of oracle/mm2.c an_cmp),
-// scatter seed by seed so that a colinear target's anchors arrive sorted, then the chaining DP of chain_anchors, one thread per target, out of LDS.
+// chains of the reads of a batch, in three kernels:
+//   k1s_group_kernel   one workgroup per read: per window of targets (strand, [rid_lo, rid_lo + W)) the anchors of every target are counted in an LDS table, the targets
+//                      with >= 3 anchors get a stretch of the batch's anchor array (anchor = target end position << 16 | query end position on the mapped strand:
+//                      ascending = the order of oracle/mm2.c an_cmp) and a record in the batch's group list, largest first
+//   k1s_dp_kernel      the chaining DP of chain_anchors, one THREAD per target, over the whole batch's group list: a wave's 64 targets are neighbours in a read's
+//                      size order, so its lanes run DPs of like length, and nothing waits for a read's largest target
+//   k1s_select_kernel  one workgroup per read: its chains ranked, primaries / secondaries (set_parent), the best_n secondaries within pri_ratio (select_sub)
 struct SChain { int32_t score, f_end; uint32_t key, end, first, cnt; };       // key = rev << 15 | rid; end / first = target end position << 16 | query end position (strand coordinates)
-struct SGroup { uint32_t key, off, cnt; };
+struct SGroup { uint32_t read, key, off, cnt; };                              // off: first anchor in the batch's anchor array
 struct SSel { int32_t rid, rev, score, cnt, diag, qs, qe, rs, re, n_chains; };        // qs / qe in forward coordinates
+struct SDp { uint32_t key; int32_t f; int16_t p; uint16_t t; };               // one anchor of a DP: 12 bytes of LDS
 
 constexpr int CH_THREADS = 256;
-constexpr int DP_CAP = 3584;                    // anchors a DP round holds in LDS (12 bytes each)
+constexpr int DP_CAP = 3584;                    // anchors a DP round of a workgroup holds in LDS
+constexpr int DP_CHUNK = 1024;                  // targets a workgroup takes from the list at a time
 constexpr int WIN_KEYS = 12288;                 // targets per window (4 bytes each in LDS)
-
-struct ChainScratch { uint32_t* anchors; SGroup* groups; uint32_t* perm; SChain* chains; int32_t* parent; uint32_t anchor_cap, group_cap, chain_cap; };
+constexpr int CHAIN_SLACK = 32;                 // chain slots of a read beyond one per target (a target can yield several chains)
 
 __device__ __forceinline__ int32_t chain_sc(uint32_t ai, uint32_t aj, const int32_t* __restrict__ pen) {
     const int32_t dq = (int32_t)(ai & 0xFFFFu) - (int32_t)(aj & 0xFFFFu);
@@ -262,6 +280,19 @@ __device__ __forceinline__ int32_t chain_sc(uint32_t ai, uint32_t aj, const int3
     int32_t sc = MZ_K < dg ? MZ_K : dg;
     if (dd || dg > MZ_K) sc -= pen[dd];               // (int)(0.01 * 0.8 * k * dd + 0.5 * log2(dd + 1)), tabulated on the host
     return sc;
+}
+
+// inclusive prefix sum over the block in thread order; total = the block's sum.  All threads call it.
+__device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t* wave_tot, uint32_t& total) {
+    uint32_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int wv = 0; wv < CH_THREADS / 64; ++wv) { const uint32_t c = wave_tot[wv]; if (wv < (int)(threadIdx.x >> 6)) base += c; tot += c; }
+    total = tot;
+    return base + incl;
 }
 
 // the block's best (largest) 128-bit key and its index; -1 when no thread offers one.  All threads call it.
@@ -285,280 +316,720 @@ __device__ __forceinline__ void chain_interval(const SChain& c, int qlen, int& q
     if (c.key >> 15) { qs = qlen - e; qe = qlen - s; } else { qs = s; qe = e; }
 }
 
-__global__ __launch_bounds__(CH_THREADS) void k1s_chain_kernel(SeqSetView reads, IndexView ix, uint32_t n_reads, const uint4* __restrict__ seeds, const uint2* __restrict__ read_seed,
-                                                               const int32_t* __restrict__ pen_tab, uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t anchor_cap,
-                                                               uint32_t group_cap, uint32_t chain_cap, SSel* __restrict__ sel, uint32_t* __restrict__ sel_cnt, SeedCounters* __restrict__ ctr,
-                                                               int best_n, SChain* __restrict__ dbg_chains, int32_t* __restrict__ dbg_parent, uint32_t* __restrict__ dbg_n, uint32_t dbg_read) {
-    extern __shared__ uint32_t lds[];
-    // [table / DP arrays (union)] [penalty table 512]
-    uint32_t* tab = lds;
-    uint32_t* dp_key = lds; int32_t* dp_f = reinterpret_cast<int32_t*>(lds + DP_CAP); int16_t* dp_p = reinterpret_cast<int16_t*>(lds + 2 * DP_CAP); int16_t* dp_t = dp_p + DP_CAP;
-    constexpr int UNION_WORDS = WIN_KEYS > 3 * DP_CAP ? WIN_KEYS : 3 * DP_CAP;
-    int32_t* pen = reinterpret_cast<int32_t*>(lds + UNION_WORDS);
-    __shared__ uint32_t s_hist[256];
+struct BatchCursors { unsigned long long groups_anchors; uint32_t chains, dp_chunk, big_items, big_members, big_chunk, pad; };        // groups << 32 | anchors: one reservation keeps both lists in step
+struct SBigItem { SGroup g; uint32_t member_off, n_members, pad0, pad1; };      // a large target that is chained by a wave of its own, and the targets that take its chains (itself among them)
+struct SMember { uint32_t read, key, shift, pad; };
+
+__global__ __launch_bounds__(CH_THREADS) void k1s_group_kernel(SeqSetView reads, IndexView ix, uint32_t r0, uint32_t n_batch, const uint4* __restrict__ seeds, const uint2* __restrict__ read_seed,
+                                                               uint32_t* __restrict__ anchors, uint32_t anchor_cap, SGroup* __restrict__ groups, uint32_t group_cap,
+                                                               uint3* __restrict__ read_chain, BatchCursors* __restrict__ cur, SeedCounters* __restrict__ ctr) {
+    extern __shared__ uint32_t tab[];                   // WIN_KEYS
+    __shared__ uint32_t s_hist[256], s_hista[256], s_first[256];
     __shared__ uint32_t s_scan[CH_THREADS / 64];
-    __shared__ uint32_t s_u[8];
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x;
+    const uint32_t r = r0 + blockIdx.x;
+    if (blockIdx.x >= n_batch) return;
+    const uint2 rs_ = read_seed[r];
+    const uint32_t s0 = rs_.x, K = rs_.y;
+    const int qlen = reads.len[r];
+    uint32_t n_groups_read = 0;
+    unsigned long long t_last = 0;
+#ifdef SP_K1S_TIMING
+    t_last = wall_clock64();
+#endif
+    (void)t_last;
+    bool any_rev = false;                     // does the read have an anchor on the reverse strand at all?  (mostly not: those windows are skipped)
+    for (int rev = 0; rev < 2 && K; ++rev) {
+        if (rev == 1 && !any_rev) break;
+        for (uint32_t rid_lo = 0; rid_lo < ix.n_seqs; rid_lo += WIN_KEYS) {
+            const uint32_t rid_hi = rid_lo + WIN_KEYS < ix.n_seqs ? rid_lo + WIN_KEYS : ix.n_seqs, W = rid_hi - rid_lo;
+            __syncthreads();
+            for (uint32_t i = tid; i < W; i += CH_THREADS) tab[i] = 0;
+            __syncthreads();
+            // A. anchors per target; `other` = anchors of this target range on the other strand
+            uint32_t other = 0;
+            for (uint32_t s = 0; s < K; ++s) {
+                const uint4 sd = seeds[s0 + s];
+                const uint32_t strand = sd.x & 1u;
+                for (uint32_t k = tid; k < sd.z; k += CH_THREADS) {
+                    const uint32_t o = ix.occ[sd.y + k], rid = o >> 17;
+                    if (rid < rid_lo || rid >= rid_hi) continue;
+                    if ((int)((o & 1u) != strand) == rev) atomicAdd(&tab[rid - rid_lo], 1u); else ++other;
+                }
+            }
+            if (rev == 0) any_rev |= __syncthreads_or(other != 0) != 0; else __syncthreads();
+            K1S_T(0);
+            // B. the targets with >= min_cnt anchors get their stretch of the anchor array and their group record, LARGEST FIRST: the targets of one size lie side by side
+            // (their anchors too), so the 64 targets of a DP wave run loops of like length and read one compact piece of the anchor array
+            const uint32_t per = (W + CH_THREADS - 1) / CH_THREADS, lo = (uint32_t)tid * per, hi = lo + per < W ? lo + per : W;
+            s_hist[tid] = 0; s_hista[tid] = 0;
+            __syncthreads();
+            uint32_t my_g = 0;
+            for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = tab[i]; if (c >= (uint32_t)CH_MIN_CNT) { ++my_g; const uint32_t k = 255 - (c > 255 ? 255 : c); atomicAdd(&s_hist[k], 1u); atomicAdd(&s_hista[k], c); } }
+            __syncthreads();
+            uint32_t tot_a, tot_g;
+            {
+                const uint32_t vg = s_hist[tid], va = s_hista[tid];
+                const uint32_t ig = block_scan(vg, s_scan, tot_g), ia = block_scan(va, s_scan, tot_a);
+                __syncthreads();
+                s_hist[tid] = ig - vg; s_hista[tid] = ia - va; s_first[tid] = ig - vg;          // first group / first anchor of every size class
+                __syncthreads();
+            }
+            (void)my_g;
+            if (tot_g == 0) { K1S_T(1); continue; }
+            if (tid == 0) s_base = atomicAdd(&cur->groups_anchors, (unsigned long long)tot_g << 32 | tot_a);
+            __syncthreads();
+            const unsigned long long base = s_base;
+            const uint32_t base_g = (uint32_t)(base >> 32), base_a = (uint32_t)base;
+            const bool fits = (unsigned long long)base_a + tot_a <= anchor_cap && (unsigned long long)base_g + tot_g <= group_cap;
+            if (!fits) { if (tid == 0) atomicAdd(&ctr->overflow_reads, 1u); continue; }
+            for (uint32_t i = lo; i < hi; ++i) {
+                const uint32_t c = tab[i];
+                if (c < (uint32_t)CH_MIN_CNT) { tab[i] = 0xFFFFFFFFu; continue; }
+                const uint32_t k = 255 - (c > 255 ? 255 : c);
+                const uint32_t slot = atomicAdd(&s_hist[k], 1u);                       // (the class's next group; its anchors: slot * c behind the class's first, or the class's running end)
+                const uint32_t a_off = base_a + (c < 255 ? s_hista[k] + (slot - s_first[k]) * c : atomicAdd(&s_hista[k], c));
+                SGroup g; g.read = r; g.key = (uint32_t)rev << 15 | (rid_lo + i); g.off = a_off; g.cnt = c;
+                groups[base_g + slot] = g;
+                tab[i] = a_off;                                                      // the running slot of the target's anchors
+            }
+            __syncthreads();
+            K1S_T(1);
+            // C. scatter (any order: the DP sorts its target's anchors)
+            for (uint32_t s = 0; s < K; ++s) {
+                const uint4 sd = seeds[s0 + s];
+                const uint32_t strand = sd.x & 1u, qpos = sd.x >> 1;
+                const uint32_t qp = rev ? (uint32_t)(qlen - ((int)qpos + 1 - MZ_K) - 1) : qpos;
+                for (uint32_t k = tid; k < sd.z; k += CH_THREADS) {
+                    const uint32_t o = ix.occ[sd.y + k], rid = o >> 17;
+                    if ((int)((o & 1u) != strand) == rev && rid >= rid_lo && rid < rid_hi && tab[rid - rid_lo] != 0xFFFFFFFFu) {
+                        const uint32_t slot = atomicAdd(&tab[rid - rid_lo], 1u);
+                        anchors[slot] = ((o >> 1) & 0xFFFFu) << 16 | (qp & 0xFFFFu);
+                    }
+                }
+            }
+            __syncthreads();
+            K1S_T(2);
+            n_groups_read += tot_g;
+            K1S_T(3);
+        }
+    }
+    // the read's stretch of the batch's chain list: a slot per target and some slack (a target can give several chains)
+    if (tid == 0) {
+        const uint32_t cap = n_groups_read ? n_groups_read + CHAIN_SLACK : 0u;
+        const uint32_t off = cap ? atomicAdd(&cur->chains, cap) : 0u;
+        read_chain[r] = make_uint3(off, cap, 0u);
+    }
+}
+
+// The chaining DP.  A wave takes 64 neighbouring targets of the group list, one lane each.  For a target with n <= 26 anchors the bounds of chain_anchors cannot act: its inner loop
+// looks at < 26 predecessors, so the skip counter never passes max_chain_skip = 25 (no early break, hence no use of the marks t[] and no rescue through max_ii), and max_chain_iter
+// = 5000 is out of reach; what is left is the plain recurrence  f[i] = max(k, max_{j < i, r_i - r_j <= max_gap} f[j] + sc(i, j)),  ties to the largest j  -- run here out of REGISTERS,
+// fully unrolled (sizes 4 / 8 / 16 / 26 by the wave's largest target), after a sorting network has put the anchors in an_cmp's order.  The packed (f, p) rows then go to LDS for the
+// backtrack, which walks data-dependent links.  Targets with more anchors (about one in a hundred) run chain_anchors step for step out of LDS, a few lanes at a time.
+constexpr int DP_REG_MAX = 26;
+constexpr int DP_BIG_WORDS = 768;                       // LDS words of a wave of k1s_dp_big_kernel: the 12-byte entries of a target with more than 64 anchors (up to 256)
+constexpr int DP_WAVE_WORDS = DP_REG_MAX * 64 * 2;      // LDS words of a wave: [row][lane] of packed rows (4 bytes for up to 8 anchors, 8 bytes for up to 26), or 12-byte SDp entries of the large targets
+
+template <int N> __device__ __forceinline__ void sort_network(uint32_t (&k)[N]) {
+#pragma unroll
+    for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ stride;
+                if (l > i) {
+                    const bool up = (i & size) == 0;
+                    const uint32_t a = k[i], b = k[l];
+                    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+                    k[i] = up ? lo : hi; k[l] = up ? hi : lo;
+                }
+            }
+        }
+    }
+}
+template <int N> __device__ __forceinline__ uint32_t pick_key(const uint32_t (&k)[N], int idx) {
+    uint32_t v = k[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) v = idx == i ? k[i] : v;
+    return v;
+}
+
+// The chains the lanes of a wave found (have) go to their reads' stretches of the chain list: the lanes that share a read make ONE reservation (the 64 targets of a wave are
+// mostly one read's: a lane-by-lane atomic put 64 same-address operations behind one another, 19 M of them per 10,000 reads -- that, not the DP, was the kernel's time).
+// Called by all lanes that are active together.
+__device__ __forceinline__ void emit_chains(bool have, const SGroup& grp, int sc, int zf, uint32_t end_key, uint32_t first_key, int cnt, SChain* __restrict__ chains, uint32_t chain_cap,
+                                            uint3* __restrict__ read_chain, int lane) {
+    unsigned long long todo = __ballot(have);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)grp.read, leader);
+        const unsigned long long same = __ballot(have && grp.read == r0);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&read_chain[r0].z, (uint32_t)__builtin_popcountll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (have && grp.read == r0) {
+            const uint3 rc = read_chain[r0];
+            const uint32_t at = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+            if (at < rc.y && rc.x + at < chain_cap) { SChain c; c.score = sc; c.f_end = zf; c.key = grp.key; c.end = end_key; c.first = first_key; c.cnt = (uint32_t)cnt; chains[rc.x + at] = c; }
+        }
+        todo &= ~same;
+    }
+}
+
+// NS: size of the sorting network (power of two), ND: rows of the DP (<= NS)
+template <int NS, int ND>
+__device__ __forceinline__ void dp_in_registers(const SGroup& grp, int n, const uint32_t* __restrict__ anchors, const int32_t* __restrict__ pen, uint32_t* __restrict__ wl, int lane,
+                                                SChain* __restrict__ chains, uint32_t chain_cap, uint3* __restrict__ read_chain) {
+    uint32_t k[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) k[i] = i < n ? anchors[grp.off + i] : 0xFFFFFFFFu;
+#if SP_DP_EXP == 1
+    if (k[0] == 12345u) wl[lane] = k[NS - 1];
+    return;
+#endif
+    sort_network<NS>(k);
+#if SP_DP_EXP == 2
+    if (k[0] == 12345u) wl[lane] = k[NS - 1];
+    return;
+#endif
+    int f[ND]; int p[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        int fi = MZ_K, pi = 0xFF;
+        const int ri = (int)(k[i] >> 16), qi = (int)(k[i] & 0xFFFFu);
+#pragma unroll
+        for (int j = i - 1; j >= 0; --j) {
+            const int dq = qi - (int)(k[j] & 0xFFFFu), dr = ri - (int)(k[j] >> 16);
+            const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+            const bool ok = dq > 0 && dq <= CH_MAX_GAP && dr != 0 && dr <= CH_MAX_GAP && dd <= CH_BW;
+            const int cand = f[j] + (MZ_K < dg ? MZ_K : dg) - pen[dd <= CH_BW ? dd : 0];
+            const bool better = ok && cand > fi;
+            fi = better ? cand : fi; pi = better ? j : pi;
+        }
+        f[i] = fi; p[i] = pi;
+        if (i < n) wl[i * 64 + lane] = (uint32_t)fi << 8 | (uint32_t)pi;
+    }
+#if SP_DP_EXP == 3
+    return;
+#endif
+    // backtrack, best end first ((f, index) descending); t (bits 24..26): 0 free, 1 in a chain, 2 being walked, 4 tried as an end whose best cut was itself
+    auto F = [&](int i) { return (int)((wl[i * 64 + lane] >> 8) & 0xFFFFu); };
+    auto P = [&](int i) { const int v = (int)(wl[i * 64 + lane] & 0xFFu); return v == 0xFF ? -1 : v; };
+    auto T = [&](int i) { return (int)(wl[i * 64 + lane] >> 24); };
+    auto setT = [&](int i, int t) { wl[i * 64 + lane] = (wl[i * 64 + lane] & 0x00FFFFFFu) | (uint32_t)t << 24; };
+    bool active = n > 0;
+    while (__ballot(active)) {
+        bool have = false; int sc = 0, zf = 0, cnt = 0; uint32_t end_key = 0, first_key = 0;
+        if (active) {
+            int zi = -1;
+            for (int i = 0; i < n; ++i) { const uint32_t v = wl[i * 64 + lane]; const int fi = (int)((v >> 8) & 0xFFFFu); if ((v >> 24) == 0 && fi >= CH_MIN_SCORE && (zi < 0 || fi >= zf)) { zi = i; zf = fi; } }
+            if (zi < 0) active = false;
+            else {
+                int i = zi, end_i = -1, max_i = zi, max_s = 0;
+                do {
+                    setT(i, 2); end_i = i = P(i);
+                    const int s2 = i < 0 ? zf : zf - F(i);
+                    if (s2 > max_s) { max_s = s2; max_i = i; }
+                    else if (max_s - s2 > CH_BW) break;
+                } while (i >= 0 && (T(i) & 3) == 0);
+                for (i = zi; i >= 0 && i != end_i; i = P(i)) setT(i, 0);
+                end_i = max_i;
+                int first = zi;
+                for (i = zi; i != end_i; i = P(i)) { setT(i, 1); first = i; ++cnt; }
+                sc = i < 0 ? zf : zf - F(i);
+                if (cnt == 0) setT(zi, 4);
+                have = sc >= CH_MIN_SCORE && cnt >= CH_MIN_CNT;
+                if (have) { end_key = pick_key<NS>(k, zi); first_key = pick_key<NS>(k, first); }
+            }
+        }
+        emit_chains(have, grp, sc, zf, end_key, first_key, cnt, chains, chain_cap, read_chain, lane);
+    }
+}
+
+// Targets of 9 .. 26 anchors: the same recurrence with the rows in LDS ([row][lane], 8 bytes: key | f << 32 | p << 48 | t << 56) and rolled loops -- unrolled over registers the
+// 26-row form alone was 65 KB of code, more than the instruction cache the CUs share, and every wave of the kernel waited for instruction fetches.
+__device__ __forceinline__ void dp_in_lds_rows(const SGroup& grp, int n, int mx, const uint32_t* __restrict__ anchors, const int32_t* __restrict__ pen, unsigned long long* __restrict__ wl, int lane,
+                                               SChain* __restrict__ chains, uint32_t chain_cap, uint3* __restrict__ read_chain) {
+    {
+        uint32_t k[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) k[i] = i < n ? anchors[grp.off + i] : 0xFFFFFFFFu;
+        sort_network<32>(k);
+#pragma unroll
+        for (int i = 0; i < DP_REG_MAX; ++i) if (i < n) wl[i * 64 + lane] = k[i];
+    }
+    for (int i = 0; i < mx; ++i) {
+        if (i >= n) continue;
+        const uint32_t ki = (uint32_t)wl[i * 64 + lane];
+        const int ri = (int)(ki >> 16), qi = (int)(ki & 0xFFFFu);
+        int fi = MZ_K, pi = 0xFF;
+#pragma unroll 4
+        for (int j = i - 1; j >= 0; --j) {
+            const unsigned long long e = wl[j * 64 + lane];
+            const int dq = qi - (int)((uint32_t)e & 0xFFFFu), dr = ri - (int)((uint32_t)e >> 16);
+            const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+            const bool ok = dq > 0 && dq <= CH_MAX_GAP && dr != 0 && dr <= CH_MAX_GAP && dd <= CH_BW;
+            const int cand = (int)((e >> 32) & 0xFFFFu) + (MZ_K < dg ? MZ_K : dg) - pen[dd <= CH_BW ? dd : 0];
+            const bool better = ok && cand > fi;
+            fi = better ? cand : fi; pi = better ? j : pi;
+        }
+        wl[i * 64 + lane] = (unsigned long long)ki | (unsigned long long)fi << 32 | (unsigned long long)pi << 48;
+    }
+    // backtrack, best end first ((f, index) descending); t: 0 free, 1 in a chain, 2 being walked, 4 tried as an end whose best cut was itself
+    auto F = [&](int i) { return (int)((wl[i * 64 + lane] >> 32) & 0xFFFFu); };
+    auto P = [&](int i) { const int v = (int)((wl[i * 64 + lane] >> 48) & 0xFFu); return v == 0xFF ? -1 : v; };
+    auto T = [&](int i) { return (int)(wl[i * 64 + lane] >> 56); };
+    auto setT = [&](int i, int t) { wl[i * 64 + lane] = (wl[i * 64 + lane] & 0x00FFFFFFFFFFFFFFull) | (unsigned long long)t << 56; };
+    bool active = n > 0;
+    while (__ballot(active)) {
+        bool have = false; int sc = 0, zf = 0, cnt = 0; uint32_t end_key = 0, first_key = 0;
+        if (active) {
+            int zi = -1;
+            for (int i = 0; i < n; ++i) { const unsigned long long v = wl[i * 64 + lane]; const int fi = (int)((v >> 32) & 0xFFFFu); if ((v >> 56) == 0 && fi >= CH_MIN_SCORE && (zi < 0 || fi >= zf)) { zi = i; zf = fi; } }
+            if (zi < 0) active = false;
+            else {
+                int i = zi, end_i = -1, max_i = zi, max_s = 0;
+                do {
+                    setT(i, 2); end_i = i = P(i);
+                    const int s2 = i < 0 ? zf : zf - F(i);
+                    if (s2 > max_s) { max_s = s2; max_i = i; }
+                    else if (max_s - s2 > CH_BW) break;
+                } while (i >= 0 && (T(i) & 3) == 0);
+                for (i = zi; i >= 0 && i != end_i; i = P(i)) setT(i, 0);
+                end_i = max_i;
+                int first = zi;
+                for (i = zi; i != end_i; i = P(i)) { setT(i, 1); first = i; ++cnt; }
+                sc = i < 0 ? zf : zf - F(i);
+                if (cnt == 0) setT(zi, 4);
+                have = sc >= CH_MIN_SCORE && cnt >= CH_MIN_CNT;
+                if (have) { end_key = (uint32_t)wl[zi * 64 + lane]; first_key = (uint32_t)wl[first * 64 + lane]; }
+            }
+        }
+        emit_chains(have, grp, sc, zf, end_key, first_key, cnt, chains, chain_cap, read_chain, lane);
+    }
+}
+
+// cross-lane moves by DPP (no LDS traffic): src from `shift` lanes below inside a row of 16, from the last lane of the row(s) below (row_bcast), from the lane below across the wave;
+// lanes without a source keep `fill`
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_move(int fill, int src) { return __builtin_amdgcn_update_dpp(fill, src, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_prefix_max(int v) {          // inclusive, lanes 0..63
+    const int NEG = INT32_MIN;
+    int t;
+    t = dpp_move<0x111, 0xf>(NEG, v); v = t > v ? t : v;
+    t = dpp_move<0x112, 0xf>(NEG, v); v = t > v ? t : v;
+    t = dpp_move<0x114, 0xf>(NEG, v); v = t > v ? t : v;
+    t = dpp_move<0x118, 0xf>(NEG, v); v = t > v ? t : v;
+    t = dpp_move<0x142, 0xa>(NEG, v); v = t > v ? t : v;
+    t = dpp_move<0x143, 0xc>(NEG, v); v = t > v ? t : v;
+    return v;
+}
+// inclusive prefix composition of the maps n -> max(n + a, b), the lower lane's map first
+__device__ __forceinline__ void wave_prefix_maps(int& a, int& b) {
+    const int NEG = -(1 << 20);
+#define SP_MAP_STEP(CTRL, MASK) { const int ta = dpp_move<CTRL, MASK>(0, a), tb = dpp_move<CTRL, MASK>(NEG, b); const int nb = tb + a > b ? tb + a : b; a = ta + a; b = nb; }
+    SP_MAP_STEP(0x111, 0xf) SP_MAP_STEP(0x112, 0xf) SP_MAP_STEP(0x114, 0xf) SP_MAP_STEP(0x118, 0xf) SP_MAP_STEP(0x142, 0xa) SP_MAP_STEP(0x143, 0xc)
+#undef SP_MAP_STEP
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// chain_anchors (oracle/mm2.c) on the anchors of ONE target with more than DP_REG_MAX anchors, by a whole wave: anchor i takes its predecessors 64 at a time, lane l looking at
+// j = jb - l, and the loop's running state -- the best score so far, the skip counter with its marks, the early break -- is replayed over the lanes in the order the loop would
+// visit them:
+//   * a predecessor's mark t[j] == i + 1 is set by the predecessors above it that chain through it (p[j'] == j, j' > j): every valid lane writes its mark, then reads its own
+//     (marks of lanes behind a break are never looked at again: the marks of step i only count in step i);
+//   * "improves on everything before it" is an exclusive prefix maximum; the skip counter (- 1 but not below 0 at an improvement, + 1 at a marked predecessor that does not improve)
+//     is a prefix composition of maps n -> max(n + a, b); the loop breaks at the first lane whose increment takes the counter past max_chain_skip.
+// all: the wave's lanes are all here (uniform arguments)
+// grp: the target the wave chains (uniform).  Its chains also go to the lanes that hold a target with the very same anchors but for a shift along the target (member; mine =
+// the lane's own target, shift = its target positions minus grp's): the alleles nearest a read mostly carry the read's seeds at the same places
+__device__ __forceinline__ void dp_by_wave(const SGroup& grp, SDp* __restrict__ a, const uint32_t* __restrict__ anchors, const int32_t* __restrict__ pen,
+                                           SChain* __restrict__ chains, uint32_t chain_cap, uint3* __restrict__ read_chain, int lane, SeedCounters* __restrict__ ctr,
+                                           bool member, const SGroup& mine, uint32_t shift) {
+    const int n = (int)grp.cnt;
+    unsigned long long t_last = 0;
+#ifdef SP_K1S_TIMING
+    t_last = wall_clock64();
+#endif
+    (void)t_last; (void)ctr;
+    for (int i = lane; i < n; i += 64) a[i].key = anchors[grp.off + i];
+    wave_sync();
+    // an_cmp's order: every key's rank among the target's keys (they are distinct), the keys moved to their ranks through the (p, t) words
+    for (int i = lane; i < n; i += 64) { const uint32_t kx = a[i].key; int rk = 0; for (int j = 0; j < n; ++j) rk += a[j].key < kx ? 1 : 0; a[i].f = rk; }
+    wave_sync();
+    for (int i = lane; i < n; i += 64) { uint32_t* dst = reinterpret_cast<uint32_t*>(&a[a[i].f].p); *dst = a[i].key; }
+    wave_sync();
+    for (int i = lane; i < n; i += 64) { a[i].key = *reinterpret_cast<uint32_t*>(&a[i].p); }
+    wave_sync();
+    for (int i = lane; i < n; i += 64) { a[i].t = 0; a[i].p = -1; a[i].f = 0; }
+    wave_sync();
+    int st = 0, max_ii = -1;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t ai = a[i].key; const int ri = (int)(ai >> 16);
+        while (st < i && ri > (int)(a[st].key >> 16) + CH_MAX_GAP) ++st;
+        if (i - st > CH_MAX_ITER) st = i - CH_MAX_ITER;
+        int max_f = MZ_K, max_j = -1, n_skip = 0, end_j = st - 1;
+        for (int jb = i - 1; jb >= st; jb -= 64) {
+            const int j = jb - lane;
+            const bool in = j >= st;
+            SDp aj; aj.key = 0; aj.f = 0; aj.p = -1; aj.t = 0;
+            if (in) aj = a[j];
+            int32_t sc = in ? chain_sc(ai, aj.key, pen) : INT32_MIN;
+            const bool valid = sc != INT32_MIN;
+            const int v = valid ? sc + aj.f : INT32_MIN;
+            if (valid && aj.p >= 0) a[aj.p].t = (uint16_t)(i + 1);
+            wave_sync();
+            const bool marked = in && a[j].t == (uint16_t)(i + 1);
+            // exclusive prefix maximum of v over the lanes, behind the incoming best
+            int before = dpp_move<0x138, 0xf>(INT32_MIN, wave_prefix_max(v));       // (wave_shr:1)
+            before = before > max_f ? before : max_f;
+            const bool isnew = valid && v > before;
+            // the skip counter after every lane: maps n -> max(n + ca, cb), composed lane by lane
+            int ca = isnew ? -1 : (valid && marked ? 1 : 0), cb = isnew ? 0 : -(1 << 20);
+            wave_prefix_maps(ca, cb);
+            const int n_after = n_skip + ca > cb ? n_skip + ca : cb;
+            const unsigned long long brk = __ballot(valid && !isnew && marked && n_after > CH_MAX_SKIP);
+            const int lb = brk ? __builtin_ctzll(brk) : 64;                    // the lane at which the loop breaks
+            const unsigned long long news = __ballot(isnew) & (lb >= 63 ? ~0ull : ((2ull << lb) - 1ull));
+            if (news) { const int ln = 63 - __builtin_clzll(news); max_f = __builtin_amdgcn_readlane(v, ln); max_j = jb - ln; }
+            if (brk) { end_j = jb - lb; n_skip = __builtin_amdgcn_readlane(n_after, lb); break; }
+            const int last = jb - st < 63 ? jb - st : 63;                       // the chunk's last lane in range
+            n_skip = __builtin_amdgcn_readlane(n_after, last);
+            end_j = st - 1;
+        }
+        if (max_ii < 0 || ri - (int)(a[max_ii].key >> 16) > CH_MAX_GAP) {
+            // the best f among [st, i): the largest index among equals (the loop walks downwards and takes strict improvements)
+            int bf = INT32_MIN, bj = -1;
+            for (int j = i - 1 - lane; j >= st; j -= 64) { const int fj = a[j].f; if (fj > bf) { bf = fj; bj = j; } }
+            for (int o = 32; o > 0; o >>= 1) { const int of = __shfl_xor(bf, o), oj = __shfl_xor(bj, o); if (of > bf || (of == bf && oj > bj)) { bf = of; bj = oj; } }
+            max_ii = bj;
+        }
+        if (max_ii >= 0 && max_ii < end_j) {
+            const int32_t tmp = chain_sc(ai, a[max_ii].key, pen);
+            if (tmp != INT32_MIN && max_f < tmp + a[max_ii].f) { max_f = tmp + a[max_ii].f; max_j = max_ii; }
+        }
+        wave_sync();
+        if (lane == 0) { a[i].f = max_f; a[i].p = (int16_t)max_j; }
+        wave_sync();
+        if (max_ii < 0 || (ri - (int)(a[max_ii].key >> 16) <= CH_MAX_GAP && a[max_ii].f < max_f)) max_ii = i;
+    }
+    // backtrack, best end first ((f, index) descending); t: 0 free, 1 in a chain, 2 being walked, 4 tried as an end whose best cut was itself.  The walk is one lane's work
+    // (data-dependent links); every lane follows it on the same addresses
+    for (int i = lane; i < n; i += 64) a[i].t = 0;
+    wave_sync();
+    for (;;) {
+        int zf = INT32_MIN, zi = -1;
+        for (int i = lane; i < n; i += 64) { const int fi = a[i].f; if (a[i].t == 0 && fi >= CH_MIN_SCORE && (fi > zf || (fi == zf && i > zi))) { zf = fi; zi = i; } }
+        for (int o = 32; o > 0; o >>= 1) { const int of = __shfl_xor(zf, o), oi = __shfl_xor(zi, o); if (of > zf || (of == zf && oi > zi)) { zf = of; zi = oi; } }
+        if (zi < 0) break;
+        // (every lane walks the same links and writes the same marks: a wave's LDS operations keep their order, no barrier is needed inside the walk)
+        int i = zi, end_i = -1, max_i = zi, max_s = 0;
+        do {
+            a[i].t = 2;
+            end_i = i = a[i].p;
+            const int s2 = i < 0 ? zf : zf - a[i].f;
+            if (s2 > max_s) { max_s = s2; max_i = i; }
+            else if (max_s - s2 > CH_BW) break;
+        } while (i >= 0 && (a[i].t & 3) == 0);
+        for (i = zi; i >= 0 && i != end_i; i = a[i].p) a[i].t = 0;
+        end_i = max_i;
+        int cnt = 0, first = zi;
+        for (i = zi; i != end_i; i = a[i].p) { a[i].t = 1; first = i; ++cnt; }
+        const int sc = i < 0 ? zf : zf - a[i].f;
+        if (cnt == 0) a[zi].t = 4;
+        wave_sync();
+        emit_chains(member && sc >= CH_MIN_SCORE && cnt >= CH_MIN_CNT, mine, sc, zf, a[zi].key + (shift << 16), a[first].key + (shift << 16), cnt, chains, chain_cap, read_chain, lane);
+    }
+    wave_sync();
+}
+
+// The same for a target of up to 64 anchors without LDS: anchor j lives in the registers of lane 63 - j (key, f, p, mark), so that the loop's downward walk over the
+// predecessors is the upward order of the lanes and the prefix operations run as they stand.  Row i: every lane in [63 - (i - 1), 63 - st] scores its own anchor against
+// anchor i (read by v_readlane); the marks t[p[j]] = i + 1 travel as ONE forward permute (a lane that has none sends a zero to lane 63 - i, which is not looked at); the
+// backtrack follows the links with v_readlane.  About 0.2 us a row against 1 us out of LDS.
+__device__ __forceinline__ int rl(int v, int lane_idx) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane_idx)); }
+
+__device__ __forceinline__ void dp_by_wave_regs(const SGroup& grp, const uint32_t* __restrict__ anchors, const int32_t* __restrict__ pen, SChain* __restrict__ chains, uint32_t chain_cap,
+                                                uint3* __restrict__ read_chain, int lane, bool member, const SGroup& mine, uint32_t shift) {
+    const int n = (int)grp.cnt;                                     // 27 .. 64
+    const int my_j = 63 - lane;
+    // the anchors into an_cmp's order: rank of every key among the target's keys (they are distinct), sent to lane 63 - rank
+    uint32_t raw = lane < n ? anchors[grp.off + lane] : 0xFFFFFFFFu;
+    int rank = 0;
+    for (int x = 0; x < n; ++x) { const uint32_t kx = (uint32_t)__builtin_amdgcn_readlane((int)raw, x); rank += kx < raw ? 1 : 0; }
+    // (lanes >= n hold 0xFFFFFFFF and rank n: they send their filler to the lanes 63 - n and below, which hold no anchor; several may land on one lane, all the same value)
+    const int dst = lane < n ? 63 - rank : lane - n;                // lanes n .. 63 fill lanes 0 .. 63 - n: a bijection together with the ranks
+    const uint32_t key = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)raw);
+    int f = 0, p = -1;
+    int st = 0, max_ii = -1;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t ai = (uint32_t)rl((int)key, 63 - i); const int ri = (int)(ai >> 16);
+        while (st < i && ri > (int)((uint32_t)rl((int)key, 63 - st) >> 16) + CH_MAX_GAP) ++st;
+        int max_f = MZ_K, max_j = -1, end_j = st - 1;
+        if (i > st) {
+            const bool in = my_j >= st && my_j < i;
+            const int32_t sc = in ? chain_sc(ai, key, pen) : INT32_MIN;
+            const bool valid = sc != INT32_MIN;
+            const int v = valid ? sc + f : INT32_MIN;
+            const bool sends = valid && p >= 0;
+            const int got = __builtin_amdgcn_ds_permute((sends ? 63 - p : 63 - i) << 2, sends ? 1 : 0);
+            const bool marked = in && got == 1;
+            int before = dpp_move<0x138, 0xf>(INT32_MIN, wave_prefix_max(v));
+            before = before > max_f ? before : max_f;
+            const bool isnew = valid && v > before;
+            int ca = isnew ? -1 : (valid && marked ? 1 : 0), cb = isnew ? 0 : -(1 << 20);
+            wave_prefix_maps(ca, cb);
+            const int n_after = ca > cb ? ca : cb;                               // (the counter starts every row at 0)
+            const unsigned long long brk = __ballot(valid && !isnew && marked && n_after > CH_MAX_SKIP);
+            const int lb = brk ? __builtin_ctzll(brk) : 64;
+            const unsigned long long news = __ballot(isnew) & (lb >= 63 ? ~0ull : ((2ull << lb) - 1ull));
+            if (news) { const int ln = 63 - __builtin_clzll(news); max_f = rl(v, ln); max_j = 63 - ln; }
+            if (brk) end_j = 63 - lb;
+        }
+        if (max_ii < 0 || ri - (int)((uint32_t)rl((int)key, 63 - max_ii) >> 16) > CH_MAX_GAP) {
+            // the best f among [st, i): the largest index among equals
+            const bool in = my_j >= st && my_j < i;
+            int bk = in ? (f << 8 | my_j) : -1;
+            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(bk, o); bk = t > bk ? t : bk; }
+            max_ii = bk < 0 ? -1 : (bk & 0xFF);
+        }
+        if (max_ii >= 0 && max_ii < end_j) {
+            const int32_t tmp = chain_sc(ai, (uint32_t)rl((int)key, 63 - max_ii), pen);
+            const int fm = rl(f, 63 - max_ii);
+            if (tmp != INT32_MIN && max_f < tmp + fm) { max_f = tmp + fm; max_j = max_ii; }
+        }
+        if (my_j == i) { f = max_f; p = max_j; }
+        if (max_ii < 0 || (ri - (int)((uint32_t)rl((int)key, 63 - max_ii) >> 16) <= CH_MAX_GAP && rl(f, 63 - max_ii) < max_f)) max_ii = i;
+    }
+    // backtrack, best end first ((f, index) descending); t: 0 free, 1 in a chain, 2 being walked, 4 tried as an end whose best cut was itself
+    int t = 0;
+    for (;;) {
+        int bk = (my_j < n && t == 0 && f >= CH_MIN_SCORE) ? (f << 8 | my_j) : -1;
+        for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(bk, o); bk = x > bk ? x : bk; }
+        if (bk < 0) break;
+        const int zi = bk & 0xFF, zf = bk >> 8;
+        int i = zi, end_i = -1, max_i = zi, max_s = 0;
+        do {
+            if (my_j == i) t = 2;
+            end_i = i = rl(p, 63 - i);
+            const int s2 = i < 0 ? zf : zf - rl(f, 63 - i);
+            if (s2 > max_s) { max_s = s2; max_i = i; }
+            else if (max_s - s2 > CH_BW) break;
+        } while (i >= 0 && (rl(t, 63 - i) & 3) == 0);
+        for (i = zi; i >= 0 && i != end_i; i = rl(p, 63 - i)) { if (my_j == i) t = 0; }
+        end_i = max_i;
+        int cnt = 0, first = zi;
+        for (i = zi; i != end_i; i = rl(p, 63 - i)) { if (my_j == i) t = 1; first = i; ++cnt; }
+        const int sc = i < 0 ? zf : zf - rl(f, 63 - i);
+        if (cnt == 0 && my_j == zi) t = 4;
+        const uint32_t end_key = (uint32_t)rl((int)key, 63 - zi), first_key = (uint32_t)rl((int)key, 63 - first);
+        emit_chains(member && sc >= CH_MIN_SCORE && cnt >= CH_MIN_CNT, mine, sc, zf, end_key + (shift << 16), first_key + (shift << 16), cnt, chains, chain_cap, read_chain, lane);
+    }
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k1s_dp_kernel(const SGroup* __restrict__ groups, const uint32_t* __restrict__ anchors, const int32_t* __restrict__ pen_tab,
+                                                            BatchCursors* __restrict__ cur, SChain* __restrict__ chains, uint32_t chain_cap, uint3* __restrict__ read_chain,
+                                                            SBigItem* __restrict__ items, SMember* __restrict__ members, uint32_t big_cap, SeedCounters* __restrict__ ctr) {
+    extern __shared__ uint32_t lds[];
+    int32_t* pen = reinterpret_cast<int32_t*>(lds);                          // 512
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* wl = lds + 512 + wave * DP_WAVE_WORDS;
+    for (int i = tid; i <= CH_BW; i += CH_THREADS) pen[i] = pen_tab[i];
+    __syncthreads();
+    const uint32_t n_groups = (uint32_t)(cur->groups_anchors >> 32);
+    // a wave takes the next 64 targets of the list (a counter, not a stride: the first task of every read holds its large targets, and a stride that divides the reads' period
+    // handed all of those to a few hundred waves)
+    for (;;) {
+        uint32_t g0 = 0;
+        if (lane == 0) g0 = atomicAdd(&cur->dp_chunk, 1u) * 64u;
+        g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
+        if (g0 >= n_groups) break;
+        const uint32_t gi = g0 + lane;
+        SGroup grp; grp.read = 0; grp.key = 0; grp.off = 0; grp.cnt = 0;
+        if (gi < n_groups) grp = groups[gi];
+        const int n = (int)grp.cnt;
+        const int small_n = n <= DP_REG_MAX ? n : 0;
+        int mx = small_n;
+        for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+        if (mx > 8) dp_in_lds_rows(grp, small_n, mx, anchors, pen, reinterpret_cast<unsigned long long*>(wl), lane, chains, chain_cap, read_chain);
+        else if (mx > 4) dp_in_registers<8, 8>(grp, small_n, anchors, pen, wl, lane, chains, chain_cap, read_chain);
+        else if (mx > 0) dp_in_registers<4, 4>(grp, small_n, anchors, pen, wl, lane, chains, chain_cap, read_chain);
+        // the large targets of the wave (more than DP_REG_MAX anchors: the first tasks of a read hold them).  Their signatures -- the anchors of a target relative to its first
+        // target position, as an unordered set (two 64-bit sums of mixed words): targets with the same signature and size chain alike, up to the shift -- and one work item per
+        // signature for k1s_dp_big_kernel, which gives every item a wave of its own
+        const unsigned long long big = __ballot(n > DP_REG_MAX);
+        if (!big) continue;
+        unsigned long long h1 = 0, h2 = 0; uint32_t min_r = 0;
+        for (unsigned long long todo = big; todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)grp.off, l), cnt = (uint32_t)__builtin_amdgcn_readlane((int)grp.cnt, l);
+            uint32_t mn = 0xFFFFu;
+            for (uint32_t i = lane; i < cnt; i += 64) { const uint32_t r = anchors[off + i] >> 16; mn = r < mn ? r : mn; }
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)mn, o); mn = t < mn ? t : mn; }
+            unsigned long long s1 = 0, s2 = 0;
+            for (uint32_t i = lane; i < cnt; i += 64) {
+                const unsigned long long x = anchors[off + i] - (mn << 16);
+                s1 += mix64((x ^ 0x9E3779B97F4A7C15ull) & MZ_MASK) * 0x9E3779B97F4A7C15ull + x;
+                unsigned long long y = (x + 0x632BE59BD9B4E019ull) * 0xD6E8FEB86659FD93ull; y ^= y >> 32; y *= 0xD6E8FEB86659FD93ull; y ^= y >> 32;
+                s2 += y;
+            }
+            for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            if (lane == l) { h1 = s1; h2 = s2; min_r = mn; }
+        }
+        // the first lane of every signature is chained; the others take its chains
+        int rep = -1;
+        for (unsigned long long todo = big; todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const unsigned long long b1 = __shfl(h1, l), b2 = __shfl(h2, l);
+            const int bn = __builtin_amdgcn_readlane(n, l);
+            if (rep < 0 && n > DP_REG_MAX && n == bn && h1 == b1 && h2 == b2) rep = l;
+        }
+        const unsigned long long reps = __ballot(n > DP_REG_MAX && rep == lane);
+        uint32_t item0 = 0, mem0 = 0;
+        if (lane == 0) { item0 = atomicAdd(&cur->big_items, (uint32_t)__builtin_popcountll(reps)); mem0 = atomicAdd(&cur->big_members, (uint32_t)__builtin_popcountll(big)); }
+        item0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)item0); mem0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mem0);
+        uint32_t k_item = 0, k_mem = 0;
+        for (unsigned long long todo = reps; todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const unsigned long long mem = __ballot(n > DP_REG_MAX && rep == l);
+            const uint32_t rep_min = (uint32_t)__builtin_amdgcn_readlane((int)min_r, l);
+            if (item0 + k_item < big_cap && mem0 + k_mem + (uint32_t)__builtin_popcountll(mem) <= big_cap) {
+                if (rep == l && n > DP_REG_MAX) {
+                    SMember m; m.read = grp.read; m.key = grp.key; m.shift = min_r - rep_min; m.pad = 0;
+                    members[mem0 + k_mem + (uint32_t)__builtin_popcountll(mem & ((1ull << lane) - 1ull))] = m;
+                }
+                if (lane == l) { SBigItem it; it.g = grp; it.member_off = mem0 + k_mem; it.n_members = (uint32_t)__builtin_popcountll(mem); it.pad0 = it.pad1 = 0; items[item0 + k_item] = it; }
+            } else if (lane == l) atomicAdd(&ctr->overflow_reads, 1u);
+            ++k_item; k_mem += (uint32_t)__builtin_popcountll(mem);
+        }
+    }
+}
+
+// every large target's item: the whole wave chains it (registers up to 64 anchors, LDS beyond) and hands the chains to the item's members
+__global__ __launch_bounds__(CH_THREADS) void k1s_dp_big_kernel(const SBigItem* __restrict__ items, const SMember* __restrict__ members, const uint32_t* __restrict__ anchors,
+                                                                const int32_t* __restrict__ pen_tab, BatchCursors* __restrict__ cur, uint32_t big_cap, SChain* __restrict__ chains,
+                                                                uint32_t chain_cap, uint3* __restrict__ read_chain, SeedCounters* __restrict__ ctr) {
+    extern __shared__ uint32_t lds[];
+    int32_t* pen = reinterpret_cast<int32_t*>(lds);                          // 512
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* wl = lds + 512 + wave * DP_BIG_WORDS;
+    for (int i = tid; i <= CH_BW; i += CH_THREADS) pen[i] = pen_tab[i];
+    __syncthreads();
+    const uint32_t n_items = cur->big_items < big_cap ? cur->big_items : big_cap;
+    for (;;) {
+        uint32_t x = 0;
+        if (lane == 0) x = atomicAdd(&cur->big_chunk, 1u);
+        x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+        if (x >= n_items) break;
+        const SBigItem it = items[x];
+        for (uint32_t m0 = 0; m0 < it.n_members; m0 += 64) {              // (more than 64 members: the target is chained once per 64 of them)
+            const bool member = m0 + lane < it.n_members;
+            SGroup mine = it.g; uint32_t shift = 0;
+            if (member) { const SMember m = members[it.member_off + m0 + lane]; mine.read = m.read; mine.key = m.key; shift = m.shift; }
+            if (it.g.cnt <= 64) dp_by_wave_regs(it.g, anchors, pen, chains, chain_cap, read_chain, lane, member, mine, shift);
+            else if (3 * it.g.cnt <= (uint32_t)DP_BIG_WORDS) dp_by_wave(it.g, reinterpret_cast<SDp*>(wl), anchors, pen, chains, chain_cap, read_chain, lane, ctr, member, mine, shift);
+            else if (lane == 0) atomicAdd(&ctr->overflow_reads, 1u);      // more anchors than the wave's LDS holds: not chained (counted)
+        }
+    }
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k1s_select_kernel(SeqSetView reads, uint32_t r0, uint32_t n_batch, const SChain* __restrict__ chains, int32_t* __restrict__ parent,
+                                                                const uint3* __restrict__ read_chain, SSel* __restrict__ sel, uint32_t* __restrict__ sel_cnt,
+                                                                SeedCounters* __restrict__ ctr, int best_n, SChain* __restrict__ dbg_chains, int32_t* __restrict__ dbg_parent,
+                                                                uint32_t* __restrict__ dbg_n, uint32_t dbg_read) {
     __shared__ unsigned long long s_r1[CH_THREADS / 64], s_r2[CH_THREADS / 64];
     __shared__ int s_ri[CH_THREADS / 64];
     __shared__ int s_prim[PRIM_CAP];
     __shared__ int s_sel[PRIM_CAP + 8];
     const int tid = threadIdx.x;
-    for (int i = tid; i <= CH_BW; i += CH_THREADS) pen[i] = pen_tab[i];
-    uint8_t* my = scratch + (size_t)blockIdx.x * scratch_stride;
-    uint32_t* sc_anchor = reinterpret_cast<uint32_t*>(my);
-    SGroup* sc_group = reinterpret_cast<SGroup*>(sc_anchor + anchor_cap);
-    uint32_t* sc_perm = reinterpret_cast<uint32_t*>(sc_group + group_cap);
-    SChain* sc_chain = reinterpret_cast<SChain*>(sc_perm + group_cap);
-    int32_t* sc_parent = reinterpret_cast<int32_t*>(sc_chain + chain_cap);
-    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
-        __syncthreads();
-        const uint2 rs_ = read_seed[r];
-        const uint32_t s0 = rs_.x, K = rs_.y;
-        const int qlen = reads.len[r];
-        if (tid == 0) s_u[0] = 0;                         // chains of this read
-        __syncthreads();
-        for (int rev = 0; rev < 2 && K; ++rev) {
-            for (uint32_t rid_lo = 0; rid_lo < ix.n_seqs; rid_lo += WIN_KEYS) {
-                const uint32_t rid_hi = rid_lo + WIN_KEYS < ix.n_seqs ? rid_lo + WIN_KEYS : ix.n_seqs, W = rid_hi - rid_lo;
-                __syncthreads();
-                for (uint32_t i = tid; i < W; i += CH_THREADS) tab[i] = 0;
-                __syncthreads();
-                // A. anchors per target
-                for (uint32_t s = 0; s < K; ++s) {
-                    const uint4 sd = seeds[s0 + s];
-                    const uint32_t strand = sd.x & 1u;
-                    for (uint32_t k = tid; k < sd.z; k += CH_THREADS) {
-                        const uint32_t o = ix.occ[sd.y + k], rid = o >> 17;
-                        if ((int)((o & 1u) != strand) == rev && rid >= rid_lo && rid < rid_hi) atomicAdd(&tab[rid - rid_lo], 1u);
-                    }
-                }
-                __syncthreads();
-                // B. the targets with >= min_cnt anchors, one after the other: tab[] becomes the running slot of each (0xFFFFFFFF: dropped)
-                uint32_t run_a = 0, run_g = 0;            // uniform: anchors / groups laid out so far in this window
-                for (uint32_t i0 = 0; i0 < W; i0 += CH_THREADS) {
-                    const uint32_t i = i0 + tid;
-                    const uint32_t c = i < W ? tab[i] : 0u;
-                    const bool kept = c >= (uint32_t)CH_MIN_CNT;
-                    // exclusive prefix of the kept counts in thread order
-                    uint32_t v = kept ? c : 0u, incl = v;
-                    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((tid & 63) >= o) incl += t; }
-                    uint32_t total_g;
-                    const uint32_t g_rank = block_rank(kept, s_scan, total_g);
-                    __syncthreads();
-                    if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
-                    __syncthreads();
-                    uint32_t base = 0, tot = 0;
-                    for (int wv = 0; wv < CH_THREADS / 64; ++wv) { if (wv < (tid >> 6)) base += s_scan[wv]; tot += s_scan[wv]; }
-                    const uint32_t off = run_a + base + incl - v;
-                    const bool placed = kept && off + c <= anchor_cap && run_g + g_rank < group_cap;
-                    if (i < W) tab[i] = placed ? off : 0xFFFFFFFFu;
-                    if (placed) { SGroup g; g.key = (uint32_t)rev << 15 | (rid_lo + i); g.off = off; g.cnt = c; sc_group[run_g + g_rank] = g; }
-                    run_a += tot; run_g += total_g;
-                    __syncthreads();
-                }
-                if (run_g == 0) continue;
-                if (run_a > anchor_cap || run_g > group_cap) { if (tid == 0) atomicAdd(&ctr->overflow_reads, 1u); if (run_g > group_cap) run_g = group_cap; }
-                // C. scatter, seed by seed in the order of the query on the mapped strand
-                for (uint32_t step = 0; step < K; ++step) {
-                    const uint32_t s = rev ? K - 1 - step : step;
-                    const uint4 sd = seeds[s0 + s];
-                    const uint32_t strand = sd.x & 1u, qpos = sd.x >> 1;
-                    const uint32_t qp = rev ? (uint32_t)(qlen - ((int)qpos + 1 - MZ_K) - 1) : qpos;
-                    for (uint32_t k = tid; k < sd.z; k += CH_THREADS) {
-                        const uint32_t o = ix.occ[sd.y + k], rid = o >> 17;
-                        if ((int)((o & 1u) != strand) == rev && rid >= rid_lo && rid < rid_hi && tab[rid - rid_lo] != 0xFFFFFFFFu) {
-                            const uint32_t slot = atomicAdd(&tab[rid - rid_lo], 1u);
-                            sc_anchor[slot] = ((o >> 1) & 0xFFFFu) << 16 | (qp & 0xFFFFu);
-                        }
-                    }
-                    __syncthreads();
-                }
-                __threadfence_block();
-                __syncthreads();
-                // D. the targets by size, largest first (the threads of a wave then run DPs of like length)
-                s_hist[tid] = 0;
-                __syncthreads();
-                for (uint32_t g = tid; g < run_g; g += CH_THREADS) { const uint32_t c = sc_group[g].cnt; atomicAdd(&s_hist[255 - (c > 255 ? 255 : c)], 1u); }
-                __syncthreads();
-                {
-                    uint32_t v = s_hist[tid], incl = v;
-                    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((tid & 63) >= o) incl += t; }
-                    if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
-                    __syncthreads();
-                    uint32_t base = 0; for (int wv = 0; wv < (tid >> 6); ++wv) base += s_scan[wv];
-                    __syncthreads();
-                    s_hist[tid] = base + incl - v;
-                }
-                __syncthreads();
-                for (uint32_t g = tid; g < run_g; g += CH_THREADS) { const uint32_t c = sc_group[g].cnt; sc_perm[atomicAdd(&s_hist[255 - (c > 255 ? 255 : c)], 1u)] = g; }
-                __threadfence_block();
-                __syncthreads();
-                // rounds of the DP: the next targets of the size order that fit DP_CAP anchors together, one thread each
-                uint32_t g0 = 0;
-                while (g0 < run_g) {
-                    const uint32_t gi = g0 + tid;
-                    SGroup grp; grp.key = 0; grp.off = 0; grp.cnt = 0;
-                    if (gi < run_g) grp = sc_group[sc_perm[gi]];
-                    uint32_t v = grp.cnt, incl = v;
-                    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((tid & 63) >= o) incl += t; }
-                    __syncthreads();
-                    if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
-                    __syncthreads();
-                    uint32_t base = 0; for (int wv = 0; wv < (tid >> 6); ++wv) base += s_scan[wv];
-                    const uint32_t b0 = base + incl - v;                                 // my slice [b0, b0 + cnt)
-                    const bool in_round = gi < run_g && b0 + v <= (uint32_t)DP_CAP;       // (sizes descend: whoever fits is a prefix of the round)
-                    uint32_t n_round;
-                    (void)block_rank(in_round, s_scan, n_round);
-                    if (n_round == 0) {
-                        // a target with more anchors than a round holds: not chained (counted); never seen with the reference's settings on an allele set
-                        if (tid == 0) atomicAdd(&ctr->overflow_reads, 1u);
-                        g0 += 1;
-                        continue;
-                    }
-                    if (in_round) {
-                        const int n = (int)grp.cnt;
-                        uint32_t* key = dp_key + b0; int32_t* f = dp_f + b0; int16_t* p = dp_p + b0; int16_t* t = dp_t + b0;
-                        bool sorted = true;
-                        for (int i = 0; i < n; ++i) { key[i] = sc_anchor[grp.off + i]; if (i && key[i] <= key[i - 1]) sorted = false; t[i] = 0; }
-                        if (!sorted) for (int i = 1; i < n; ++i) { const uint32_t kx = key[i]; int j = i - 1; while (j >= 0 && key[j] > kx) { key[j + 1] = key[j]; --j; } key[j + 1] = kx; }
-                        // chain_anchors (oracle/mm2.c), the anchors of ONE target
-                        int st = 0, max_ii = -1;
-                        for (int i = 0; i < n; ++i) {
-                            const uint32_t ai = key[i]; const int ri = (int)(ai >> 16);
-                            int max_j = -1, max_f = MZ_K, n_skip = 0;
-                            while (st < i && ri > (int)(key[st] >> 16) + CH_MAX_GAP) ++st;
-                            if (i - st > CH_MAX_ITER) st = i - CH_MAX_ITER;
-                            int j;
-                            for (j = i - 1; j >= st; --j) {
-                                int32_t sc = chain_sc(ai, key[j], pen);
-                                if (sc == INT32_MIN) continue;
-                                sc += f[j];
-                                if (sc > max_f) { max_f = sc; max_j = j; if (n_skip > 0) --n_skip; }
-                                else if (t[j] == i + 1) { if (++n_skip > CH_MAX_SKIP) break; }
-                                if (p[j] >= 0) t[p[j]] = (int16_t)(i + 1);
-                            }
-                            const int end_j = j;
-                            if (max_ii < 0 || ri - (int)(key[max_ii] >> 16) > CH_MAX_GAP) {
-                                int mx = INT32_MIN; max_ii = -1;
-                                for (j = i - 1; j >= st; --j) if (mx < f[j]) { mx = f[j]; max_ii = j; }
-                            }
-                            if (max_ii >= 0 && max_ii < end_j) {
-                                const int32_t tmp = chain_sc(ai, key[max_ii], pen);
-                                if (tmp != INT32_MIN && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
-                            }
-                            f[i] = max_f; p[i] = (int16_t)max_j;
-                            if (max_ii < 0 || (ri - (int)(key[max_ii] >> 16) <= CH_MAX_GAP && f[max_ii] < f[i])) max_ii = i;
-                        }
-                        // backtrack, best end first ((f, index) descending); t: 0 free, 1 in a chain, 2 being walked; +4 tried as an end
-                        for (int i = 0; i < n; ++i) t[i] = 0;
-                        for (;;) {
-                            int zi = -1;
-                            for (int i = 0; i < n; ++i) if (t[i] == 0 && f[i] >= CH_MIN_SCORE && (zi < 0 || f[i] >= f[zi])) zi = i;
-                            if (zi < 0) break;
-                            const int zf = f[zi];
-                            int i = zi, end_i = -1, max_i = zi, max_s = 0;
-                            do {
-                                t[i] = 2; end_i = i = p[i];
-                                const int s = i < 0 ? zf : zf - f[i];
-                                if (s > max_s) { max_s = s; max_i = i; }
-                                else if (max_s - s > CH_BW) break;
-                            } while (i >= 0 && (t[i] & 3) == 0);
-                            for (i = zi; i >= 0 && i != end_i; i = p[i]) t[i] = 0;
-                            end_i = max_i;
-                            int cnt = 0, first = zi;
-                            for (i = zi; i != end_i; i = p[i]) { t[i] = 1; first = i; ++cnt; }
-                            const int sc = i < 0 ? zf : zf - f[i];
-                            if (cnt == 0) t[zi] = 4;                                     // (an end whose best cut is itself: tried, left free for other chains to run into)
-                            if (sc >= CH_MIN_SCORE && cnt >= CH_MIN_CNT) {
-                                const uint32_t at = atomicAdd(&s_u[0], 1u);
-                                if (at < chain_cap) { SChain c; c.score = sc; c.f_end = zf; c.key = grp.key; c.end = key[zi]; c.first = key[first]; c.cnt = (uint32_t)cnt; sc_chain[at] = c; }
-                            }
-                        }
-                    }
-                    g0 += n_round;
-                    __syncthreads();
-                }
-            }
+    if (blockIdx.x >= n_batch) return;
+    const uint32_t r = r0 + blockIdx.x;
+    const int qlen = reads.len[r];
+    const uint3 rc = read_chain[r];
+    uint32_t nc = rc.z;
+    if (nc > rc.y) { nc = rc.y; if (tid == 0) atomicAdd(&ctr->overflow_reads, 1u); }
+    const SChain* sc_chain = chains + rc.x; int32_t* sc_parent = parent + rc.x;
+    // rank, parents, selection (set_parent + select_sub of oracle/mm2.c on the ranked list: score, then creation order = (f of the end anchor, anchor index) descending)
+    auto k1_of = [](const SChain& c) { return (unsigned long long)(uint32_t)c.score << 32 | (uint32_t)c.f_end; };
+    auto k2_of = [](const SChain& c) { return (unsigned long long)c.key << 32 | c.end; };
+    for (uint32_t i = tid; i < nc; i += CH_THREADS) sc_parent[i] = -1;
+    __syncthreads();
+    int n_prim = 0;
+    while (n_prim < PRIM_CAP) {
+        bool have = false; unsigned long long b1 = 0, b2 = 0; int bi = -1;
+        for (uint32_t i = tid; i < nc; i += CH_THREADS) if (sc_parent[i] == -1) {
+            const SChain c = sc_chain[i]; const unsigned long long a1 = k1_of(c), a2 = k2_of(c);
+            if (!have || a1 > b1 || (a1 == b1 && a2 > b2)) { have = true; b1 = a1; b2 = a2; bi = (int)i; }
         }
-        __threadfence_block();
+        const int P = block_argmax(have, b1, b2, bi, s_r1, s_r2, s_ri);
+        if (P < 0) break;
+        if (tid == 0) { sc_parent[P] = P; s_prim[n_prim] = P; }
+        ++n_prim;
+        const SChain pc = sc_chain[P];
+        int pqs, pqe, prs, pre; chain_interval(pc, qlen, pqs, pqe, prs, pre);
         __syncthreads();
-        // E. rank, parents, selection (set_parent + select_sub of oracle/mm2.c on the ranked list: score, then creation order = (f of the end anchor, anchor index) descending)
-        uint32_t nc = s_u[0];
-        if (nc > chain_cap) { nc = chain_cap; if (tid == 0) atomicAdd(&ctr->overflow_reads, 1u); }
-        auto k1_of = [](const SChain& c) { return (unsigned long long)(uint32_t)c.score << 32 | (uint32_t)c.f_end; };
-        auto k2_of = [](const SChain& c) { return (unsigned long long)c.key << 32 | c.end; };
-        for (uint32_t i = tid; i < nc; i += CH_THREADS) sc_parent[i] = -1;
-        __syncthreads();
-        int n_prim = 0;
-        while (n_prim < PRIM_CAP) {
-            bool have = false; unsigned long long b1 = 0, b2 = 0; int bi = -1;
-            for (uint32_t i = tid; i < nc; i += CH_THREADS) if (sc_parent[i] == -1) {
-                const SChain c = sc_chain[i]; const unsigned long long a1 = k1_of(c), a2 = k2_of(c);
-                if (!have || a1 > b1 || (a1 == b1 && a2 > b2)) { have = true; b1 = a1; b2 = a2; bi = (int)i; }
-            }
-            const int P = block_argmax(have, b1, b2, bi, s_r1, s_r2, s_ri);
-            if (P < 0) break;
-            if (tid == 0) { sc_parent[P] = P; s_prim[n_prim] = P; }
-            ++n_prim;
-            const SChain pc = sc_chain[P];
-            int pqs, pqe, prs, pre; chain_interval(pc, qlen, pqs, pqe, prs, pre);
-            __syncthreads();
-            for (uint32_t i = tid; i < nc; i += CH_THREADS) if (sc_parent[i] == -1) {
-                int qs, qe, rs, re; chain_interval(sc_chain[i], qlen, qs, qe, rs, re);
-                const int mn = (pqe - pqs) < (qe - qs) ? (pqe - pqs) : (qe - qs);
-                const int ol = (qe < pqe ? qe : pqe) - (qs > pqs ? qs : pqs);
-                if (ol > 0 && (float)ol > MASK_LEVEL * (float)mn) sc_parent[i] = P;
-            }
-            __syncthreads();
-        }
-        // the best_n best-ranked secondaries within pri_ratio of their primary (or min_diff = 2 k of it) that are not its very interval
-        int n_sec = 0;
-        for (; n_sec < best_n; ++n_sec) {
-            bool have = false; unsigned long long b1 = 0, b2 = 0; int bi = -1;
-            for (uint32_t i = tid; i < nc; i += CH_THREADS) {
-                const int p = sc_parent[i];
-                if (p < 0 || p == (int)i) continue;
-                const SChain c = sc_chain[i], pc = sc_chain[p];
-                if (!((float)c.score >= (float)pc.score * PRI_RATIO || c.score + 2 * MZ_K >= pc.score)) continue;
-                int qs, qe, rs, re, pqs, pqe, prs, pre; chain_interval(c, qlen, qs, qe, rs, re); chain_interval(pc, qlen, pqs, pqe, prs, pre);
-                if (qs == pqs && qe == pqe && (c.key & 0x7FFFu) == (pc.key & 0x7FFFu) && rs == prs && re == pre) continue;
-                const unsigned long long a1 = k1_of(c), a2 = k2_of(c);
-                if (!have || a1 > b1 || (a1 == b1 && a2 > b2)) { have = true; b1 = a1; b2 = a2; bi = (int)i; }
-            }
-            const int S = block_argmax(have, b1, b2, bi, s_r1, s_r2, s_ri);
-            if (S < 0) break;
-            if (tid == 0) { sc_parent[S] = -2 - sc_parent[S]; s_sel[n_prim + n_sec] = S; }          // (taken: no longer a candidate; the parent stays readable)
-            __syncthreads();
+        for (uint32_t i = tid; i < nc; i += CH_THREADS) if (sc_parent[i] == -1) {
+            int qs, qe, rs, re; chain_interval(sc_chain[i], qlen, qs, qe, rs, re);
+            const int mn = (pqe - pqs) < (qe - qs) ? (pqe - pqs) : (qe - qs);
+            const int ol = (qe < pqe ? qe : pqe) - (qs > pqs ? qs : pqs);
+            if (ol > 0 && (float)ol > MASK_LEVEL * (float)mn) sc_parent[i] = P;
         }
         __syncthreads();
-        if (dbg_chains && r == dbg_read) {
-            for (uint32_t i = tid; i < nc; i += CH_THREADS) { dbg_chains[i] = sc_chain[i]; dbg_parent[i] = sc_parent[i]; }
-            if (tid == 0) *dbg_n = nc;
+    }
+    // the best_n best-ranked secondaries within pri_ratio of their primary (or min_diff = 2 k of it) that are not its very interval
+    int n_sec = 0;
+    for (; n_sec < best_n; ++n_sec) {
+        bool have = false; unsigned long long b1 = 0, b2 = 0; int bi = -1;
+        for (uint32_t i = tid; i < nc; i += CH_THREADS) {
+            const int p = sc_parent[i];
+            if (p < 0 || p == (int)i) continue;
+            const SChain c = sc_chain[i], pc = sc_chain[p];
+            if (!((float)c.score >= (float)pc.score * PRI_RATIO || c.score + 2 * MZ_K >= pc.score)) continue;
+            int qs, qe, rs, re, pqs, pqe, prs, pre; chain_interval(c, qlen, qs, qe, rs, re); chain_interval(pc, qlen, pqs, pqe, prs, pre);
+            if (qs == pqs && qe == pqe && (c.key & 0x7FFFu) == (pc.key & 0x7FFFu) && rs == prs && re == pre) continue;
+            const unsigned long long a1 = k1_of(c), a2 = k2_of(c);
+            if (!have || a1 > b1 || (a1 == b1 && a2 > b2)) { have = true; b1 = a1; b2 = a2; bi = (int)i; }
         }
-        if (tid == 0) {
-            // the selected chains in rank order
-            int n = 0;
-            for (int i = 0; i < n_prim; ++i) s_sel[n++] = s_prim[i];
-            for (int i = 0; i < n_sec; ++i) s_sel[n++] = s_sel[n_prim + i];
-            for (int i = 1; i < n; ++i) {
-                const int x = s_sel[i]; const SChain cx = sc_chain[x]; int j = i - 1;
-                while (j >= 0) { const SChain cj = sc_chain[s_sel[j]]; if (k1_of(cj) > k1_of(cx) || (k1_of(cj) == k1_of(cx) && k2_of(cj) > k2_of(cx))) break; s_sel[j + 1] = s_sel[j]; --j; }
-                s_sel[j + 1] = x;
-            }
-            if (n > SEL_CAP) n = SEL_CAP;
-            uint32_t n_rev = 0;
-            for (int i = 0; i < n; ++i) {
-                const SChain c = sc_chain[s_sel[i]];
-                SSel o; o.rid = (int32_t)(c.key & 0x7FFFu); o.rev = (int32_t)(c.key >> 15); o.score = c.score; o.cnt = (int32_t)c.cnt; o.n_chains = (int32_t)nc;
-                chain_interval(c, qlen, o.qs, o.qe, o.rs, o.re);
-                const int d0 = (int)(c.first & 0xFFFFu) - (int)(c.first >> 16), d1 = (int)(c.end & 0xFFFFu) - (int)(c.end >> 16);
-                o.diag = (d0 + d1) >> 1;
-                sel[(size_t)r * SEL_CAP + i] = o;
-                n_rev += (uint32_t)o.rev;
-            }
-            sel_cnt[r] = (uint32_t)n;
-            if (n_rev) atomicAdd(&ctr->rev_selected, n_rev);
+        const int S = block_argmax(have, b1, b2, bi, s_r1, s_r2, s_ri);
+        if (S < 0) break;
+        if (tid == 0) { sc_parent[S] = -2 - sc_parent[S]; s_sel[n_prim + n_sec] = S; }          // (taken: no longer a candidate; the parent stays readable)
+        __syncthreads();
+    }
+    __syncthreads();
+    if (dbg_chains && r == dbg_read) {
+        for (uint32_t i = tid; i < nc; i += CH_THREADS) { dbg_chains[i] = sc_chain[i]; dbg_parent[i] = sc_parent[i]; }
+        if (tid == 0) *dbg_n = nc;
+    }
+    if (tid == 0) {
+        // the selected chains in rank order
+        int n = 0;
+        for (int i = 0; i < n_prim; ++i) s_sel[n++] = s_prim[i];
+        for (int i = 0; i < n_sec; ++i) s_sel[n++] = s_sel[n_prim + i];
+        for (int i = 1; i < n; ++i) {
+            const int x = s_sel[i]; const SChain cx = sc_chain[x]; int j = i - 1;
+            while (j >= 0) { const SChain cj = sc_chain[s_sel[j]]; if (k1_of(cj) > k1_of(cx) || (k1_of(cj) == k1_of(cx) && k2_of(cj) > k2_of(cx))) break; s_sel[j + 1] = s_sel[j]; --j; }
+            s_sel[j + 1] = x;
         }
+        if (n > SEL_CAP) n = SEL_CAP;
+        uint32_t n_rev = 0;
+        for (int i = 0; i < n; ++i) {
+            const SChain c = sc_chain[s_sel[i]];
+            SSel o; o.rid = (int32_t)(c.key & 0x7FFFu); o.rev = (int32_t)(c.key >> 15); o.score = c.score; o.cnt = (int32_t)c.cnt; o.n_chains = (int32_t)nc;
+            chain_interval(c, qlen, o.qs, o.qe, o.rs, o.re);
+            const int d0 = (int)(c.first & 0xFFFFu) - (int)(c.first >> 16), d1 = (int)(c.end & 0xFFFFu) - (int)(c.end >> 16);
+            o.diag = (d0 + d1) >> 1;
+            sel[(size_t)r * SEL_CAP + i] = o;
+            n_rev += (uint32_t)o.rev;
+        }
+        sel_cnt[r] = (uint32_t)n;
+        if (n_rev) atomicAdd(&ctr->rev_selected, n_rev);
     }
 }
 
@@ -857,31 +1328,67 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
         if (attempt == 1 || hc.seeds > 0xFFFFFFF0ull) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seeded K1: seed list overflow");
         seed_cap = (uint32_t)hc.seeds + 1024;
     }
-    // 2. chains: a grid of resident workgroups, each with a scratch region sized for the batch's largest read
+    // 2. chains, in batches of reads whose anchors fit the batch buffers (a read of the bundled database has about 20,000 anchors in 2,000 targets)
     uint32_t* d_sel_cnt = (uint32_t*)sp_pool(ctx, "k1s_sel_cnt", (size_t)R * 4);
     SSel* d_sel = (SSel*)sp_pool(ctx, "k1s_sel", (size_t)R * SEL_CAP * sizeof(SSel));
-    if (!d_sel_cnt || !d_sel) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seeded K1: selection");
-    const uint32_t anchor_cap = std::max<uint32_t>(hc.max_anchors, 16), group_cap = std::min<uint32_t>(anchor_cap / CH_MIN_CNT + 1, 2 * idx->n_seqs), chain_cap = anchor_cap / CH_MIN_CNT + 1;
-    const size_t stride = (((size_t)anchor_cap * 4 + (size_t)group_cap * (sizeof(SGroup) + 4) + (size_t)chain_cap * (sizeof(SChain) + 4)) + 255) & ~(size_t)255;
-    const uint32_t grid = std::min<uint32_t>(R, (uint32_t)ctx->num_cus * 3);
-    uint8_t* d_scratch = (uint8_t*)sp_pool(ctx, "k1s_scratch", stride * grid);
-    if (!d_scratch) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seeded K1: chain scratch");
-    constexpr int UNION_WORDS = WIN_KEYS > 3 * DP_CAP ? WIN_KEYS : 3 * DP_CAP;
-    const size_t chain_lds = (size_t)(UNION_WORDS + 512) * 4;
-    SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k1s_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds));
+    uint3* d_read_chain = (uint3*)sp_pool(ctx, "k1s_read_chain", (size_t)R * sizeof(uint3));
+    BatchCursors* d_cur = (BatchCursors*)sp_pool(ctx, "k1s_cursors", sizeof(BatchCursors));
+    uint32_t* h_anchors = (uint32_t*)sp_host_pool(ctx, "k1s_read_anchors", (size_t)R * 4);
+    if (!d_sel_cnt || !d_sel || !d_read_chain || !d_cur || !h_anchors) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seeded K1: selection");
+    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_anchors, d_read_anchors, (size_t)R * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t batch_anchors = std::max<uint64_t>(hc.max_anchors, 64ull << 20);            // 256 MB of anchors
+    const uint64_t a_cap = std::min<uint64_t>(hc.anchors, batch_anchors + hc.max_anchors), g_cap = a_cap / CH_MIN_CNT + 1;
+    if (a_cap >= (1ull << 32)) return sp_fail(ctx, SP_ERR_TOO_LONG, "seeded K1: a read with more than 4 G anchors");
+    uint32_t r_batch_max = 0;
+    for (uint32_t r0 = 0; r0 < R;) { uint64_t a = 0; uint32_t r1 = r0; while (r1 < R && (r1 == r0 || a + h_anchors[r1] <= batch_anchors)) a += h_anchors[r1++]; r_batch_max = std::max(r_batch_max, r1 - r0); r0 = r1; }
+    const uint64_t c_cap = g_cap + (uint64_t)r_batch_max * CHAIN_SLACK;
+    uint32_t* d_anchors = (uint32_t*)sp_pool(ctx, "k1s_anchors", std::max<uint64_t>(a_cap, 1) * 4);
+    SGroup* d_groups = (SGroup*)sp_pool(ctx, "k1s_groups", g_cap * sizeof(SGroup));
+    SChain* d_chains = (SChain*)sp_pool(ctx, "k1s_chains", c_cap * sizeof(SChain));
+    int32_t* d_parent = (int32_t*)sp_pool(ctx, "k1s_parent", c_cap * 4);
+    const uint64_t big_cap = a_cap / (DP_REG_MAX + 1) + 64;
+    SBigItem* d_items = (SBigItem*)sp_pool(ctx, "k1s_big_items", big_cap * sizeof(SBigItem));
+    SMember* d_members = (SMember*)sp_pool(ctx, "k1s_big_members", big_cap * sizeof(SMember));
+    if (!d_anchors || !d_groups || !d_chains || !d_parent || !d_items || !d_members) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seeded K1: chain buffers");
+    const size_t group_lds = (size_t)WIN_KEYS * 4, dp_lds = (size_t)(512 + (CH_THREADS / 64) * DP_WAVE_WORDS) * 4;
+    SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k1s_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds));
+    SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k1s_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
+    const size_t big_lds = (size_t)(512 + (CH_THREADS / 64) * DP_BIG_WORDS) * 4;
     SChain* dbg_chains = nullptr; int32_t* dbg_parent = nullptr; uint32_t* dbg_n = nullptr;
     if (dbg) {
-        dbg_chains = (SChain*)sp_pool(ctx, "k1s_dbg_chains", (size_t)chain_cap * sizeof(SChain)); dbg_parent = (int32_t*)sp_pool(ctx, "k1s_dbg_parent", (size_t)chain_cap * 4);
+        dbg_chains = (SChain*)sp_pool(ctx, "k1s_dbg_chains", g_cap * sizeof(SChain)); dbg_parent = (int32_t*)sp_pool(ctx, "k1s_dbg_parent", g_cap * 4);
         dbg_n = (uint32_t*)sp_pool(ctx, "k1s_dbg_n", 8);
         if (!dbg_chains || !dbg_parent || !dbg_n) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seeded K1: debug buffers");
         SP_HIP_CHECK(ctx, hipMemsetAsync(dbg_n, 0, 8, ctx->stream));
     }
-    {
-        ProfScope ps(ctx, "k1s_chains", hc.anchors);
-        hipLaunchKernelGGL(k1s_chain_kernel, dim3(grid), dim3(CH_THREADS), chain_lds, ctx->stream, reads->view(), ix, R, d_seeds, d_read_seed, idx->d_pen, d_scratch, stride, anchor_cap,
-                           group_cap, chain_cap, d_sel, d_sel_cnt, d_ctr, best_n, dbg_chains, dbg_parent, dbg_n, dbg ? dbg->read : 0u);
+    for (uint32_t r0 = 0; r0 < R;) {
+        uint64_t a = 0; uint32_t r1 = r0;
+        while (r1 < R && (r1 == r0 || a + h_anchors[r1] <= batch_anchors)) a += h_anchors[r1++];
+        const uint32_t nb_reads = r1 - r0;
+        SP_HIP_CHECK(ctx, hipMemsetAsync(d_cur, 0, sizeof(BatchCursors), ctx->stream));
+        {
+            ProfScope ps(ctx, "k1s_groups", a);
+            hipLaunchKernelGGL(k1s_group_kernel, dim3(nb_reads), dim3(CH_THREADS), group_lds, ctx->stream, reads->view(), ix, r0, nb_reads, d_seeds, d_read_seed, d_anchors, (uint32_t)a_cap,
+                               d_groups, (uint32_t)g_cap, d_read_chain, d_cur, d_ctr);
+        }
+        {
+            ProfScope ps(ctx, "k1s_dp", a);
+            hipLaunchKernelGGL(k1s_dp_kernel, dim3((unsigned)ctx->num_cus * 8), dim3(CH_THREADS), dp_lds, ctx->stream, d_groups, d_anchors, idx->d_pen, d_cur, d_chains, (uint32_t)c_cap, d_read_chain, d_items, d_members, (uint32_t)big_cap, d_ctr);
+        }
+        {
+            ProfScope ps(ctx, "k1s_dp_big", a);
+            hipLaunchKernelGGL(k1s_dp_big_kernel, dim3((unsigned)ctx->num_cus * 8), dim3(CH_THREADS), big_lds, ctx->stream, d_items, d_members, d_anchors, idx->d_pen, d_cur, (uint32_t)big_cap,
+                               d_chains, (uint32_t)c_cap, d_read_chain, d_ctr);
+        }
+        {
+            ProfScope ps(ctx, "k1s_select", nb_reads);
+            hipLaunchKernelGGL(k1s_select_kernel, dim3(nb_reads), dim3(CH_THREADS), 0, ctx->stream, reads->view(), r0, nb_reads, d_chains, d_parent, d_read_chain, d_sel, d_sel_cnt, d_ctr, best_n,
+                               dbg_chains, dbg_parent, dbg_n, dbg ? dbg->read : 0xFFFFFFFFu);
+        }
+        SP_HIP_CHECK(ctx, hipGetLastError());
+        r0 = r1;
     }
-    SP_HIP_CHECK(ctx, hipGetLastError());
     // 3. the selected chains through the cell and its re-score
     const uint64_t NC = (uint64_t)R * SEL_CAP;
     CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k1s_cells", NC * sizeof(CellDesc)); CellDesc* d_rc = (CellDesc*)sp_pool(ctx, "k1s_rc", NC * sizeof(CellDesc));
@@ -898,6 +1405,9 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
     // chains on the reverse strand (a read from the other strand, the homologous gene on the other strand): the same through the reads' reverse complements
     SP_HIP_CHECK(ctx, hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef SP_K1S_TIMING
+    fprintf(stderr, "k1s_group phases (100 MHz ticks summed over workgroups): count %llu scan %llu scatter %llu records %llu; large targets %llu: signatures %llu ticks; chained in registers %llu targets, %llu ticks\n", hc.t[0], hc.t[1], hc.t[2], hc.t[3], hc.t[7], hc.t[4], hc.t[6], hc.t[5]);
+#endif
     if (hc.rev_selected) {
         const size_t words = (size_t)reads->h_word_off[R] + SP_SEQ_PAD_WORDS;
         uint32_t* d_rw = (uint32_t*)sp_pool(ctx, "k1s_rev_words", words * 4);
