@@ -430,7 +430,7 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_group_kernel(SeqSetView reads,
 // backtrack, which walks data-dependent links.  Targets with more anchors (about one in a hundred) run chain_anchors step for step out of LDS, a few lanes at a time.
 constexpr int DP_REG_MAX = 26;
 constexpr int DP_BIG_WORDS = 768;                       // LDS words of a wave of k1s_dp_big_kernel: the 12-byte entries of a target with more than 64 anchors (up to 256)
-constexpr int DP_WAVE_WORDS = DP_REG_MAX * 64 * 2;      // LDS words of a wave: [row][lane] of packed rows (4 bytes for up to 8 anchors, 8 bytes for up to 26), or 12-byte SDp entries of the large targets
+constexpr int DP_WAVE_WORDS = DP_REG_MAX * 32 * 2;      // LDS words of a wave: [row][lane] of packed rows (4 bytes for up to 8 anchors, 8 bytes for up to 26), or 12-byte SDp entries of the large targets
 
 template <int N> __device__ __forceinline__ void sort_network(uint32_t (&k)[N]) {
 #pragma unroll
@@ -551,24 +551,31 @@ __device__ __forceinline__ void dp_in_registers(const SGroup& grp, int n, const 
 
 // Targets of 9 .. 26 anchors: the same recurrence with the rows in LDS ([row][lane], 8 bytes: key | f << 32 | p << 48 | t << 56) and rolled loops -- unrolled over registers the
 // 26-row form alone was 65 KB of code, more than the instruction cache the CUs share, and every wave of the kernel waited for instruction fetches.
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ void dp_in_lds_rows(const SGroup& grp, int n, int mx, const uint32_t* __restrict__ anchors, const int32_t* __restrict__ pen, unsigned long long* __restrict__ wl, int lane,
                                                SChain* __restrict__ chains, uint32_t chain_cap, uint3* __restrict__ read_chain) {
-    {
-        uint32_t k[32];
+    uint32_t k[32];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) k[i] = i < n ? anchors[grp.off + i] : 0xFFFFFFFFu;
-        sort_network<32>(k);
+    for (int i = 0; i < 32; ++i) k[i] = i < n ? anchors[grp.off + i] : 0xFFFFFFFFu;
+    sort_network<32>(k);
+    // the two halves of the wave one after the other on the same rows (13 KB of rows per wave left the kernel two workgroups per CU, and its short paths live on occupancy)
+    const int n_all = n, col = lane & 31;
+    for (int half = 0; half < 2; ++half) {
+    n = (lane >> 5) == half ? n_all : 0;
 #pragma unroll
-        for (int i = 0; i < DP_REG_MAX; ++i) if (i < n) wl[i * 64 + lane] = k[i];
-    }
+    for (int i = 0; i < DP_REG_MAX; ++i) if (i < n) wl[i * 32 + col] = k[i];
     for (int i = 0; i < mx; ++i) {
         if (i >= n) continue;
-        const uint32_t ki = (uint32_t)wl[i * 64 + lane];
+        const uint32_t ki = (uint32_t)wl[i * 32 + col];
         const int ri = (int)(ki >> 16), qi = (int)(ki & 0xFFFFu);
         int fi = MZ_K, pi = 0xFF;
 #pragma unroll 4
         for (int j = i - 1; j >= 0; --j) {
-            const unsigned long long e = wl[j * 64 + lane];
+            const unsigned long long e = wl[j * 32 + col];
             const int dq = qi - (int)((uint32_t)e & 0xFFFFu), dr = ri - (int)((uint32_t)e >> 16);
             const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
             const bool ok = dq > 0 && dq <= CH_MAX_GAP && dr != 0 && dr <= CH_MAX_GAP && dd <= CH_BW;
@@ -576,19 +583,19 @@ __device__ __forceinline__ void dp_in_lds_rows(const SGroup& grp, int n, int mx,
             const bool better = ok && cand > fi;
             fi = better ? cand : fi; pi = better ? j : pi;
         }
-        wl[i * 64 + lane] = (unsigned long long)ki | (unsigned long long)fi << 32 | (unsigned long long)pi << 48;
+        wl[i * 32 + col] = (unsigned long long)ki | (unsigned long long)fi << 32 | (unsigned long long)pi << 48;
     }
     // backtrack, best end first ((f, index) descending); t: 0 free, 1 in a chain, 2 being walked, 4 tried as an end whose best cut was itself
-    auto F = [&](int i) { return (int)((wl[i * 64 + lane] >> 32) & 0xFFFFu); };
-    auto P = [&](int i) { const int v = (int)((wl[i * 64 + lane] >> 48) & 0xFFu); return v == 0xFF ? -1 : v; };
-    auto T = [&](int i) { return (int)(wl[i * 64 + lane] >> 56); };
-    auto setT = [&](int i, int t) { wl[i * 64 + lane] = (wl[i * 64 + lane] & 0x00FFFFFFFFFFFFFFull) | (unsigned long long)t << 56; };
+    auto F = [&](int i) { return (int)((wl[i * 32 + col] >> 32) & 0xFFFFu); };
+    auto P = [&](int i) { const int v = (int)((wl[i * 32 + col] >> 48) & 0xFFu); return v == 0xFF ? -1 : v; };
+    auto T = [&](int i) { return (int)(wl[i * 32 + col] >> 56); };
+    auto setT = [&](int i, int t) { wl[i * 32 + col] = (wl[i * 32 + col] & 0x00FFFFFFFFFFFFFFull) | (unsigned long long)t << 56; };
     bool active = n > 0;
     while (__ballot(active)) {
         bool have = false; int sc = 0, zf = 0, cnt = 0; uint32_t end_key = 0, first_key = 0;
         if (active) {
             int zi = -1;
-            for (int i = 0; i < n; ++i) { const unsigned long long v = wl[i * 64 + lane]; const int fi = (int)((v >> 32) & 0xFFFFu); if ((v >> 56) == 0 && fi >= CH_MIN_SCORE && (zi < 0 || fi >= zf)) { zi = i; zf = fi; } }
+            for (int i = 0; i < n; ++i) { const unsigned long long v = wl[i * 32 + col]; const int fi = (int)((v >> 32) & 0xFFFFu); if ((v >> 56) == 0 && fi >= CH_MIN_SCORE && (zi < 0 || fi >= zf)) { zi = i; zf = fi; } }
             if (zi < 0) active = false;
             else {
                 int i = zi, end_i = -1, max_i = zi, max_s = 0;
@@ -605,10 +612,12 @@ __device__ __forceinline__ void dp_in_lds_rows(const SGroup& grp, int n, int mx,
                 sc = i < 0 ? zf : zf - F(i);
                 if (cnt == 0) setT(zi, 4);
                 have = sc >= CH_MIN_SCORE && cnt >= CH_MIN_CNT;
-                if (have) { end_key = (uint32_t)wl[zi * 64 + lane]; first_key = (uint32_t)wl[first * 64 + lane]; }
+                if (have) { end_key = (uint32_t)wl[zi * 32 + col]; first_key = (uint32_t)wl[first * 32 + col]; }
             }
         }
         emit_chains(have, grp, sc, zf, end_key, first_key, cnt, chains, chain_cap, read_chain, lane);
+    }
+    wave_sync_lds();
     }
 }
 
@@ -773,7 +782,14 @@ __device__ __forceinline__ void dp_by_wave_regs(const SGroup& grp, const uint32_
         const uint32_t ai = (uint32_t)rl((int)key, 63 - i); const int ri = (int)(ai >> 16);
         while (st < i && ri > (int)((uint32_t)rl((int)key, 63 - st) >> 16) + CH_MAX_GAP) ++st;
         int max_f = MZ_K, max_j = -1, end_j = st - 1;
-        if (i > st) {
+        if (i > st && i <= CH_MAX_SKIP) {
+            // fewer than 26 predecessors: the skip counter cannot pass max_chain_skip, the loop sees them all -- the best score, ties to the largest index (the first met walking down)
+            const bool in = my_j >= st && my_j < i;
+            const int32_t sc = in ? chain_sc(ai, key, pen) : INT32_MIN;
+            const int v = sc != INT32_MIN ? sc + f : INT32_MIN;
+            const int m = __builtin_amdgcn_readlane(wave_prefix_max(v), 63);
+            if (m > max_f) { max_f = m; max_j = 63 - (int)__builtin_ctzll(__ballot(v == m)); }
+        } else if (i > st) {
             const bool in = my_j >= st && my_j < i;
             const int32_t sc = in ? chain_sc(ai, key, pen) : INT32_MIN;
             const bool valid = sc != INT32_MIN;
@@ -844,13 +860,20 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_dp_kernel(const SGroup* __rest
     for (int i = tid; i <= CH_BW; i += CH_THREADS) pen[i] = pen_tab[i];
     __syncthreads();
     const uint32_t n_groups = (uint32_t)(cur->groups_anchors >> 32);
-    // a wave takes the next 64 targets of the list (a counter, not a stride: the first task of every read holds its large targets, and a stride that divides the reads' period
-    // handed all of those to a few hundred waves)
-    for (;;) {
-        uint32_t g0 = 0;
-        if (lane == 0) g0 = atomicAdd(&cur->dp_chunk, 1u) * 64u;
-        g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
-        if (g0 >= n_groups) break;
+    unsigned long long t_last = 0;
+#ifdef SP_K1S_TIMING
+    t_last = wall_clock64();
+#endif
+    (void)t_last;
+    // the tasks (64 neighbouring targets each) go to the waves in a scrambled order: the first task of every read holds its large targets, and a plain stride that divides the
+    // reads' period handed all of those to a few hundred waves; a shared counter (one atomic per task) queued 300,000 operations on one address
+    const uint32_t n_tasks = (n_groups + 63) / 64;
+    uint32_t pow2 = 1; while (pow2 < n_tasks) pow2 <<= 1;
+    const uint32_t n_waves = gridDim.x * (CH_THREADS / 64);
+    for (uint32_t k = blockIdx.x * (CH_THREADS / 64) + wave; k < pow2; k += n_waves) {
+        const uint32_t task = (k * 0x9E3779B1u) & (pow2 - 1);              // (an odd multiplier: a permutation of [0, pow2))
+        if (task >= n_tasks) continue;
+        const uint32_t g0 = task * 64;
         const uint32_t gi = g0 + lane;
         SGroup grp; grp.read = 0; grp.key = 0; grp.off = 0; grp.cnt = 0;
         if (gi < n_groups) grp = groups[gi];
@@ -858,13 +881,25 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_dp_kernel(const SGroup* __rest
         const int small_n = n <= DP_REG_MAX ? n : 0;
         int mx = small_n;
         for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+        K1S_TW(7);
+#if SP_DP_EXP == 5
+        if (mx > 8) { }
+        else
+#endif
         if (mx > 8) dp_in_lds_rows(grp, small_n, mx, anchors, pen, reinterpret_cast<unsigned long long*>(wl), lane, chains, chain_cap, read_chain);
         else if (mx > 4) dp_in_registers<8, 8>(grp, small_n, anchors, pen, wl, lane, chains, chain_cap, read_chain);
         else if (mx > 0) dp_in_registers<4, 4>(grp, small_n, anchors, pen, wl, lane, chains, chain_cap, read_chain);
+#ifdef SP_K1S_TIMING
+        if (lane == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&ctr->t[mx > 8 ? 5 : 4], now_ - t_last); t_last = now_; }
+#endif
         // the large targets of the wave (more than DP_REG_MAX anchors: the first tasks of a read hold them).  Their signatures -- the anchors of a target relative to its first
         // target position, as an unordered set (two 64-bit sums of mixed words): targets with the same signature and size chain alike, up to the shift -- and one work item per
         // signature for k1s_dp_big_kernel, which gives every item a wave of its own
+#if SP_DP_EXP == 4
+        const unsigned long long big = 0;
+#else
         const unsigned long long big = __ballot(n > DP_REG_MAX);
+#endif
         if (!big) continue;
         unsigned long long h1 = 0, h2 = 0; uint32_t min_r = 0;
         for (unsigned long long todo = big; todo; todo &= todo - 1) {
@@ -909,6 +944,7 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_dp_kernel(const SGroup* __rest
             } else if (lane == l) atomicAdd(&ctr->overflow_reads, 1u);
             ++k_item; k_mem += (uint32_t)__builtin_popcountll(mem);
         }
+        K1S_TW(6);
     }
 }
 
@@ -923,11 +959,11 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_dp_big_kernel(const SBigItem* 
     for (int i = tid; i <= CH_BW; i += CH_THREADS) pen[i] = pen_tab[i];
     __syncthreads();
     const uint32_t n_items = cur->big_items < big_cap ? cur->big_items : big_cap;
-    for (;;) {
-        uint32_t x = 0;
-        if (lane == 0) x = atomicAdd(&cur->big_chunk, 1u);
-        x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
-        if (x >= n_items) break;
+    uint32_t pow2 = 1; while (pow2 < n_items) pow2 <<= 1;
+    const uint32_t n_waves = gridDim.x * (CH_THREADS / 64);
+    for (uint32_t k = blockIdx.x * (CH_THREADS / 64) + wave; k < pow2; k += n_waves) {          // (scrambled order, as in k1s_dp_kernel: neighbouring items are one read's, of like length)
+        const uint32_t x = (k * 0x9E3779B1u) & (pow2 - 1);
+        if (x >= n_items) continue;
         const SBigItem it = items[x];
         for (uint32_t m0 = 0; m0 < it.n_members; m0 += 64) {              // (more than 64 members: the target is chained once per 64 of them)
             const bool member = m0 + lane < it.n_members;
@@ -1406,7 +1442,7 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
     SP_HIP_CHECK(ctx, hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 #ifdef SP_K1S_TIMING
-    fprintf(stderr, "k1s_group phases (100 MHz ticks summed over workgroups): count %llu scan %llu scatter %llu records %llu; large targets %llu: signatures %llu ticks; chained in registers %llu targets, %llu ticks\n", hc.t[0], hc.t[1], hc.t[2], hc.t[3], hc.t[7], hc.t[4], hc.t[6], hc.t[5]);
+    fprintf(stderr, "k1s_group phases (100 MHz ticks summed over workgroups): count %llu scan %llu scatter %llu records %llu; dp kernel waves: task + load %llu, up to 8 anchors %llu, 9..26 %llu, signatures of the large %llu\n", hc.t[0], hc.t[1], hc.t[2], hc.t[3], hc.t[7], hc.t[4], hc.t[5], hc.t[6]);
 #endif
     if (hc.rev_selected) {
         const size_t words = (size_t)reads->h_word_off[R] + SP_SEQ_PAD_WORDS;
