@@ -429,7 +429,8 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_group_kernel(SeqSetView reads,
 // fully unrolled (sizes 4 / 8 / 16 / 26 by the wave's largest target), after a sorting network has put the anchors in an_cmp's order.  The packed (f, p) rows then go to LDS for the
 // backtrack, which walks data-dependent links.  Targets with more anchors (about one in a hundred) run chain_anchors step for step out of LDS, a few lanes at a time.
 constexpr int DP_REG_MAX = 26;
-constexpr int DP_BIG_WORDS = 768;                       // LDS words of a wave of k1s_dp_big_kernel: the 12-byte entries of a target with more than 64 anchors (up to 256)
+constexpr int DP_BIG_MAX = 4096;                        // anchors of the largest target that is chained (a small database: every minimizer of a read is a seed, and a target holds them all)
+constexpr int DP_BIG_WORDS = 3 * DP_BIG_MAX;            // LDS words of the one-wave workgroups of k1s_dp_big_kernel<true>: the 12-byte entries of a target with more than 64 anchors
 constexpr int DP_WAVE_WORDS = DP_REG_MAX * 32 * 2;      // LDS words of a wave: [row][lane] of packed rows (4 bytes for up to 8 anchors, 8 bytes for up to 26), or 12-byte SDp entries of the large targets
 
 template <int N> __device__ __forceinline__ void sort_network(uint32_t (&k)[N]) {
@@ -948,30 +949,33 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_dp_kernel(const SGroup* __rest
     }
 }
 
-// every large target's item: the whole wave chains it (registers up to 64 anchors, LDS beyond) and hands the chains to the item's members
-__global__ __launch_bounds__(CH_THREADS) void k1s_dp_big_kernel(const SBigItem* __restrict__ items, const SMember* __restrict__ members, const uint32_t* __restrict__ anchors,
-                                                                const int32_t* __restrict__ pen_tab, BatchCursors* __restrict__ cur, uint32_t big_cap, SChain* __restrict__ chains,
-                                                                uint32_t chain_cap, uint3* __restrict__ read_chain, SeedCounters* __restrict__ ctr) {
+// every large target's item: a whole wave chains it and hands the chains to the item's members.  Two launches share the list: LONG = false takes the targets of up to 64 anchors
+// (registers, no LDS beyond the penalty table: four waves a workgroup), LONG = true the longer ones (one wave a workgroup with 48 KB of LDS rows)
+template <bool LONG>
+__global__ __launch_bounds__(LONG ? 64 : CH_THREADS) void k1s_dp_big_kernel(const SBigItem* __restrict__ items, const SMember* __restrict__ members, const uint32_t* __restrict__ anchors,
+                                                                            const int32_t* __restrict__ pen_tab, BatchCursors* __restrict__ cur, uint32_t big_cap, SChain* __restrict__ chains,
+                                                                            uint32_t chain_cap, uint3* __restrict__ read_chain, SeedCounters* __restrict__ ctr) {
     extern __shared__ uint32_t lds[];
     int32_t* pen = reinterpret_cast<int32_t*>(lds);                          // 512
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t* wl = lds + 512 + wave * DP_BIG_WORDS;
-    for (int i = tid; i <= CH_BW; i += CH_THREADS) pen[i] = pen_tab[i];
+    uint32_t* wl = lds + 512;
+    for (int i = tid; i <= CH_BW; i += (int)blockDim.x) pen[i] = pen_tab[i];
     __syncthreads();
     const uint32_t n_items = cur->big_items < big_cap ? cur->big_items : big_cap;
     uint32_t pow2 = 1; while (pow2 < n_items) pow2 <<= 1;
-    const uint32_t n_waves = gridDim.x * (CH_THREADS / 64);
-    for (uint32_t k = blockIdx.x * (CH_THREADS / 64) + wave; k < pow2; k += n_waves) {          // (scrambled order, as in k1s_dp_kernel: neighbouring items are one read's, of like length)
+    const uint32_t n_waves = gridDim.x * (blockDim.x / 64);
+    for (uint32_t k = blockIdx.x * (blockDim.x / 64) + wave; k < pow2; k += n_waves) {          // (scrambled order, as in k1s_dp_kernel: neighbouring items are one read's, of like length)
         const uint32_t x = (k * 0x9E3779B1u) & (pow2 - 1);
         if (x >= n_items) continue;
         const SBigItem it = items[x];
+        if ((it.g.cnt > 64) != LONG) continue;
+        if (LONG && it.g.cnt > (uint32_t)DP_BIG_MAX) { if (lane == 0) atomicAdd(&ctr->overflow_reads, 1u); continue; }      // more anchors than the LDS rows hold: not chained (counted)
         for (uint32_t m0 = 0; m0 < it.n_members; m0 += 64) {              // (more than 64 members: the target is chained once per 64 of them)
             const bool member = m0 + lane < it.n_members;
             SGroup mine = it.g; uint32_t shift = 0;
             if (member) { const SMember m = members[it.member_off + m0 + lane]; mine.read = m.read; mine.key = m.key; shift = m.shift; }
-            if (it.g.cnt <= 64) dp_by_wave_regs(it.g, anchors, pen, chains, chain_cap, read_chain, lane, member, mine, shift);
-            else if (3 * it.g.cnt <= (uint32_t)DP_BIG_WORDS) dp_by_wave(it.g, reinterpret_cast<SDp*>(wl), anchors, pen, chains, chain_cap, read_chain, lane, ctr, member, mine, shift);
-            else if (lane == 0) atomicAdd(&ctr->overflow_reads, 1u);      // more anchors than the wave's LDS holds: not chained (counted)
+            if (!LONG) dp_by_wave_regs(it.g, anchors, pen, chains, chain_cap, read_chain, lane, member, mine, shift);
+            else dp_by_wave(it.g, reinterpret_cast<SDp*>(wl), anchors, pen, chains, chain_cap, read_chain, lane, ctr, member, mine, shift);
         }
     }
 }
@@ -1390,7 +1394,8 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
     const size_t group_lds = (size_t)WIN_KEYS * 4, dp_lds = (size_t)(512 + (CH_THREADS / 64) * DP_WAVE_WORDS) * 4;
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k1s_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds));
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k1s_dp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
-    const size_t big_lds = (size_t)(512 + (CH_THREADS / 64) * DP_BIG_WORDS) * 4;
+    const size_t big_lds = (size_t)(512 + DP_BIG_WORDS) * 4;
+    SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k1s_dp_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
     SChain* dbg_chains = nullptr; int32_t* dbg_parent = nullptr; uint32_t* dbg_n = nullptr;
     if (dbg) {
         dbg_chains = (SChain*)sp_pool(ctx, "k1s_dbg_chains", g_cap * sizeof(SChain)); dbg_parent = (int32_t*)sp_pool(ctx, "k1s_dbg_parent", g_cap * 4);
@@ -1414,7 +1419,9 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
         }
         {
             ProfScope ps(ctx, "k1s_dp_big", a);
-            hipLaunchKernelGGL(k1s_dp_big_kernel, dim3((unsigned)ctx->num_cus * 8), dim3(CH_THREADS), big_lds, ctx->stream, d_items, d_members, d_anchors, idx->d_pen, d_cur, (uint32_t)big_cap,
+            hipLaunchKernelGGL(k1s_dp_big_kernel<false>, dim3((unsigned)ctx->num_cus * 8), dim3(CH_THREADS), 512 * 4, ctx->stream, d_items, d_members, d_anchors, idx->d_pen, d_cur, (uint32_t)big_cap,
+                               d_chains, (uint32_t)c_cap, d_read_chain, d_ctr);
+            hipLaunchKernelGGL(k1s_dp_big_kernel<true>, dim3((unsigned)ctx->num_cus * 3), dim3(64), big_lds, ctx->stream, d_items, d_members, d_anchors, idx->d_pen, d_cur, (uint32_t)big_cap,
                                d_chains, (uint32_t)c_cap, d_read_chain, d_ctr);
         }
         {

@@ -36,3 +36,12 @@ def gpu_ctx(pkg):
     ctx = pkg.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture
+def k1_exhaustive(gpu_ctx):
+    """sp_hla_realign_reads on every allele of every anchored gene (context option k1_best_n = 0) for the length of a test; the default is the
+    reference's call pattern (seeds, chains, best_n 5)"""
+    gpu_ctx.set_option("k1_best_n", 0)
+    yield gpu_ctx
+    gpu_ctx.set_option("k1_best_n", 5)

@@ -87,13 +87,16 @@ class K1Tables:
         al, _ = self.oracle.wfa(self.fwd_e[a], re, anch[int(self.fx.gene_of[a])][0] - self.off[a], cap, events=False)
         return al
 
-    def record(self, read, re, anch, best, bm):
+    def record(self, read, re, anch, best, bm, seeded=None):
         """everything realign_record does once the best allele is known (src/hla/realigner.rs:149-350); bm = its alignment as an
-        ALN_DTYPE row"""
+        ALN_DTYPE row.  seeded: None = the exhaustive mode (strand decided at the seeds, mm2 = the re-score of bm), else dict(rev, mm2, chains, mappings,
+        chain_score) of the seeded map (omm_hla_k1_seeded): a best mapping on the reverse strand drops the read, mm2 = the accepted mapping's re-score"""
         oracle, fx = self.oracle, self.fx
         res = dict(status=1, best_allele=-1, gene=-1)
+        if seeded is not None:
+            res.update(k1_chains=seeded["chains"], k1_mappings=seeded["mappings"], k1_chain_score=seeded["chain_score"])
         if best < 0:
-            if self.is_reverse(re, anch):
+            if (seeded["rev"] if seeded is not None else self.is_reverse(re, anch)):
                 res["status"] = 2
             return res
         g = int(fx.gene_of[best])
@@ -103,7 +106,7 @@ class K1Tables:
         import oracle_ffi
         twice = (int(bm["a_start"]) - int(bm["b_start"])) + (int(bm["a_end"]) - int(bm["b_end"]))
         diag = int(twice / 2)                                                  # (C's division: towards zero)
-        res["mm2"] = oracle_ffi.oracle_affine(oracle, self.fwd_e[best], re, -diag, 64, 1)
+        res["mm2"] = seeded["mm2"] if seeded is not None else oracle_ffi.oracle_affine(oracle, self.fwd_e[best], re, -diag, 64, 1)
         db_s, db_e = int(bm["b_start"]), int(bm["b_end"])
         buf_s, buf_e = max(db_s - 1000, 0), min(db_e + 1000, len(read))
         seg = re[buf_s:buf_e]
@@ -120,9 +123,10 @@ class K1Tables:
                 d = added + int(bm["a_start"])
                 h = oracle.hpc_pos(fx.gene_ref[g], added) + oracle.hpc_pos(fx.dna[best], int(bm["a_start"]))
             res.update(status=0, seg_start=min(db_s, adj_s), seg_end=max(db_e, adj_e), dna_offset=d, hpc_offset=h)
-        rv = self.is_reverse(re, anch)
-        if rv == 2 or (rv == 1 and res["status"] != 0):
-            res["status"] = 2                                  # (the other fields keep what the forward search found)
+        if seeded is None:
+            rv = self.is_reverse(re, anch)
+            if rv == 2 or (rv == 1 and res["status"] != 0):
+                res["status"] = 2                                  # (the other fields keep what the forward search found)
         return res
 
 
@@ -167,6 +171,47 @@ def k1_expected(oracle, fx, reads):
         best = oracle.pick_allele(alns, len(read))
         results.append(tb.record(read, re, anch, best, alns[best] if best >= 0 else None))
     return results, cells
+
+
+_SEED_INDEX = {}
+
+
+def seed_index(oracle, fx):
+    """the minimizer index of the fixture's DNA alleles in hg38 orientation (aligner.with_index of HlaRealigner::new), cached per fixture"""
+    import mm2_ffi
+    key = id(fx)
+    if key not in _SEED_INDEX:
+        mm = mm2_ffi.Mm2(oracle)
+        dna_ids = [a for a in range(len(fx.ids)) if fx.dna[a]]
+        _SEED_INDEX[key] = (mm2_ffi.Index(mm, [fx.dna_fwd(a) for a in dna_ids]), dna_ids, fx)
+    return _SEED_INDEX[key][0], _SEED_INDEX[key][1]
+
+
+def k1_expected_seeded(oracle, fx, reads, tables=None):
+    """HlaRealigner::realign_record in the reference's call pattern (sp_hla_realign_reads with k1_best_n > 0): the seeded map of oracle/mm2.c
+    (omm_hla_k1_seeded: minimap2's seeding, chaining and selection, the library's cell + re-score for the selected chains, the acceptance loop over the
+    mappings in output order), then the bookkeeping behind the accepted mapping.  Returns the records and the per-read (pick, hits)."""
+    idx, dna_ids = seed_index(oracle, fx)
+    tb = tables or K1Tables(oracle, fx)
+    out, audits = [], []
+    for read in reads:
+        re = oracle.encode(read)
+        pick, hits, n_chains = idx.k1_seeded(read) if len(read) else (-1, [], 0)
+        best, bm, info = -1, None, dict(rev=False, mm2=(0, 0, 0, 0, 0, 0), chains=n_chains, mappings=len(hits), chain_score=0)
+        if pick >= 0:
+            h = hits[pick]
+            info["chain_score"] = int(h["chain_score"])
+            info["rev"] = bool(h["rev"])
+            if not h["rev"]:
+                best = dna_ids[int(h["rid"])]
+                bm = np.zeros(1, oracle_aln_dtype())[0]
+                bm["ok"], bm["nm"], bm["a_start"], bm["a_end"], bm["b_start"], bm["b_end"], bm["a_len"], bm["b_len"] = (
+                    1, h["cell_nm"], h["a_start"], h["a_end"], h["b_start"], h["b_end"], h["t_len"], len(read))
+                info["mm2"] = (int(h["dp_max"]), int(h["nm"]), int(h["t_start"]), int(h["t_end"]), int(h["q_start"]), int(h["q_end"]))
+        anch = tb.anchors(re) if len(read) else [(0, 0)] * len(fx.genes)
+        out.append(tb.record(read, re, anch, best, bm, seeded=info))
+        audits.append((pick, hits))
+    return out, audits
 
 
 def oracle_aln_dtype():

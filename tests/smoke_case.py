@@ -18,12 +18,20 @@ def run(pkg):
     hap, s = fx.haplotype(g, a)
     reads = synth.simulate_reads(rng, hap, s, len(fx.dna[a]), 6, mean_len=6000, sd_len=800)
     rs = ctx.upload(reads)
-    out, cells = db.realign_reads(rs, cells=True)            # K1, full matrix
-    exp, ecells = hx.k1_expected(oracle, fx, reads)
+    ctx.set_option("k1_best_n", 0)                             # K1 over every allele: the full cell matrix, and the pruned search that must equal it
+    full, cells = db.realign_reads(rs, cells=True)
+    exp0, ecells = hx.k1_expected(oracle, fx, reads)
     assert (cells == ecells).all(), "K1 cell matrix differs from the oracle"
+    for r, e in enumerate(exp0):
+        assert full[r]["best_allele"] == e["best_allele"] and full[r]["status"] == e["status"], (r, full[r], e)
+    assert db.realign_reads(rs).tobytes() == full.tobytes(), "pruned K1 differs from exhaustive K1"
+    ctx.set_option("k1_best_n", 5)                             # K1 in the reference's call pattern (the default): seeds, chains, best_n, against oracle/mm2.c's statement
+    out = db.realign_reads(rs)
+    exp, _audits = hx.k1_expected_seeded(oracle, fx, reads)
     for r, e in enumerate(exp):
         assert out[r]["best_allele"] == e["best_allele"] and out[r]["status"] == e["status"], (r, out[r], e)
-    assert db.realign_reads(rs).tobytes() == out.tobytes(), "pruned K1 differs from exhaustive K1"
+        if e["best_allele"] >= 0:
+            assert (out[r]["mm2_score"], out[r]["mm2_nm"], out[r]["mm2_t_start"], out[r]["mm2_t_end"], out[r]["mm2_q_start"], out[r]["mm2_q_end"]) == e["mm2"], (r, out[r], e)
     cons = hap[max(0, s - 80):s + len(fx.dna[a]) + 80]
     best, n_scored, stats, cdna = db.type_consensus(g, cons)  # K2 through score_consensus
     ebest, estats = hx.k2_expected(oracle, fx, g, cons if fx.gene_fwd[g] else synth.revcomp(cons), cdna)

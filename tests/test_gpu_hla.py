@@ -48,7 +48,7 @@ def test_k2_score_consensus(oracle, pkg, gpu_ctx, small):
     assert all(s == [-1] * 6 for s in stats[[a for a in range(len(fx.ids)) if fx.gene_of[a] == 0 and fx.dna[a]]].tolist())
 
 
-def test_k1_realign_reads(oracle, pkg, gpu_ctx, small):
+def test_k1_realign_reads(oracle, pkg, gpu_ctx, small, k1_exhaustive):
     from pb_starphase_amd import synth
     fx, db = small
     rng = np.random.default_rng(9)
@@ -96,7 +96,7 @@ def test_k1_realign_reads(oracle, pkg, gpu_ctx, small):
         assert pruned.tobytes() == out.tobytes()
 
 
-def test_k1_reads_with_n(oracle, pkg, gpu_ctx, small):
+def test_k1_reads_with_n(oracle, pkg, gpu_ctx, small, k1_exhaustive):
     """reads carrying N bases take the N-plane variants of every K1 kernel (an N never matches, not even another N)"""
     from pb_starphase_amd import synth
     fx, db = small
@@ -149,7 +149,7 @@ class _SyntheticGene:
         return self.dna[a]
 
 
-def test_k1_long_alleles(oracle, pkg, gpu_ctx):
+def test_k1_long_alleles(oracle, pkg, gpu_ctx, k1_exhaustive):
     """alleles longer than the fixed-shape register prefetch (5,088 bases) go through the direct staging path of k1_cells and
     through cooperative extensions of several thousand bases"""
     from pb_starphase_amd import synth
@@ -175,7 +175,7 @@ def test_k1_long_alleles(oracle, pkg, gpu_ctx):
     db.close()
 
 
-def test_k1_synthetic_fuzz(oracle, pkg, gpu_ctx):
+def test_k1_synthetic_fuzz(oracle, pkg, gpu_ctx, k1_exhaustive):
     """random one-gene databases whose alleles descend from each other (rich shared-prefix structure: chains, snapshots, resumes),
     clean / noisy / partial reads; the whole cell matrix and every output field against the oracle.  SP_FUZZ_SEEDS widens the hunt."""
     import os
@@ -259,7 +259,7 @@ def test_type_consensus(oracle, pkg, gpu_ctx, small):
     assert db.type_consensus(0, junk)[0] == -1
 
 
-def test_k1_full_database_pruned_equals_exhaustive(oracle, pkg, gpu_ctx):
+def test_k1_full_database_pruned_equals_exhaustive(oracle, pkg, gpu_ctx, k1_exhaustive):
     """BASELINE configs[1] shape at reduced read count: the full bundled IMGT/HLA database (18,461 alleles), 240 synthetic HiFi
     reads.  Size-independent properties: the production (branch-and-bound + iterative deepening) mode must reproduce the
     exhaustive mode byte for byte, every read must land in its gene, and a sample of reads is checked against the oracle."""
@@ -331,7 +331,7 @@ def test_k2_batch_equals_single(oracle, pkg, gpu_ctx, small):
     assert db.type_consensus_batch([fwd_items[2], fwd_items[2], fwd_items[0]]) == [single_t[2], single_t[2], single_t[0]]
 
 
-def test_k1_sliced_batches(oracle, pkg, gpu_ctx, small, monkeypatch):
+def test_k1_sliced_batches(oracle, pkg, gpu_ctx, small, monkeypatch, k1_exhaustive):
     """big read batches are processed in slices (shallow views of the same packed reads): identical output, slice by slice"""
     from pb_starphase_amd import synth
     fx, db = small
@@ -349,7 +349,7 @@ def test_k1_sliced_batches(oracle, pkg, gpu_ctx, small, monkeypatch):
     assert db.realign_reads(rs).tobytes() == whole.tobytes()
 
 
-def test_k1_gene_vote_filter(oracle, pkg, gpu_ctx, small):
+def test_k1_gene_vote_filter(oracle, pkg, gpu_ctx, small, k1_exhaustive):
     """a read is only scored against the alleles of genes whose reference got >= 16 anchor votes and >= 1/10 of the best
     gene's votes.  A read of one gene leaves the other gene's cells empty; a chimeric read (an HLA-A haplotype followed by an HLA-B one) anchors in
     both and has cells in both; the cell matrix equals the oracle's in every case."""
@@ -376,7 +376,7 @@ def test_k1_gene_vote_filter(oracle, pkg, gpu_ctx, small):
     assert (cells[2][in_a & has_dna] != none).any() and (cells[2][in_b & has_dna] != none).any()
 
 
-def test_k1_reverse_strand_reads_are_dropped(oracle, pkg, gpu_ctx, small):
+def test_k1_reverse_strand_reads_are_dropped(oracle, pkg, gpu_ctx, small, k1_exhaustive):
     """src/hla/realigner.rs:178-193: a read whose best mapping is on the reverse strand is dropped.  The library decides the strand at the seeds
     (status 2: the best anchor on the reverse-complemented gene references out-votes the best forward anchor); == the oracle's statement.  The
     reverse complement of a good read is dropped, the read itself is not; junk stays status 1; a read whose forward half is long enough stays."""

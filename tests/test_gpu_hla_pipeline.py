@@ -40,7 +40,7 @@ def test_reads_to_diplotype(oracle, pkg, gpu_ctx, scenario):
     reads = [reads[i] for i in order]
     R = gpu_ctx.upload(reads)
     k1_gpu = db.realign_reads(R)
-    k1_exp, _ = hx.k1_expected(oracle, fx, reads)
+    k1_exp, _ = hx.k1_expected_seeded(oracle, fx, reads)
     for g in range(len(fx.genes)):
         call, c1, c2, is1 = db.diplotype_gene(g, R, k1_gpu)
         exp = hp.diplotype_gene(oracle, fx, g, reads, k1_exp, synth)
@@ -94,7 +94,7 @@ def test_absent_capable_gene(oracle, pkg, gpu_ctx):
         k1 = db.realign_reads(R)
         cfg = pkg.ffi.hla_call_config(absent_capable=True, normalized_coverage=float(per_hap))
         call, c1, c2, is1 = db.diplotype_gene(g, R, k1, cfg=cfg)
-        k1_exp, _cells = hx.k1_expected(oracle, fx, reads)
+        k1_exp, _cells = hx.k1_expected_seeded(oracle, fx, reads)
         exp = hp.diplotype_gene(oracle, fx, g, reads, k1_exp, synth, absent_capable=True, normalized_coverage=float(per_hap))
         assert call.is_hemizygous == exp["is_hemizygous"] == (1 if name == "hemizygous" else 0)
         assert (call.allele1, call.allele2) == (exp["allele1"], exp["allele2"]) and (c1, c2) == (exp["cons1"], exp["cons2"])

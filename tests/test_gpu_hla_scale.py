@@ -47,7 +47,7 @@ def sample(fx, rng, per_hap, absent=()):
     return [reads[i] for i in order], [truth_gene[i] for i in order], truth
 
 
-def test_k1_pruned_equals_exhaustive_at_scale(pkg, gpu_ctx, big):
+def test_k1_pruned_equals_exhaustive_at_scale(pkg, gpu_ctx, big, k1_exhaustive):
     fx, db = big
     rng = np.random.default_rng(31)
     reads, truth_gene, _truth = sample(fx, rng, 6)

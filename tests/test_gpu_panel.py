@@ -92,7 +92,7 @@ def test_full_panel_sample(oracle, pkg, gpu_ctx):
     assert call.status == 0 and sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(expected)
 
 
-def test_config1_stated_size(oracle, pkg, gpu_ctx):
+def test_config1_stated_size(oracle, pkg, gpu_ctx, k1_exhaustive):
     from pb_starphase_amd import synth
     fx = synth.HlaFixture()
     wl = synth.Config2Workload(fx, n_reads=10000, seed=1000)

@@ -1,0 +1,181 @@
+"""K1 in the reference's call pattern (sp_hla_seed.hip; context option k1_best_n > 0, the default) against its CPU statement, stage by stage:
+oracle/mm2.c's sketch, index, anchors -> chains -> selection (omm_chain_stage) and the mappings + acceptance (omm_hla_k1_seeded).  Bit exact: minimizers,
+the ranked chain list with its selection marks, every mapping's numbers, the accepted mapping, the K1 record."""
+import numpy as np
+import pytest
+
+import hla_expected as hx
+import mm2_ffi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small(pkg, gpu_ctx):
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture(max_alleles_per_gene=300, seed=5)
+    db = fx.make_db(pkg, gpu_ctx)
+    yield fx, db
+    db.close()
+
+
+def varied_reads(fx, synth, rng, n_per=4):
+    reads = []
+    for g in range(len(fx.genes)):
+        for a in rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist():
+            hap, gs = fx.haplotype(g, a)
+            reads += synth.simulate_reads(rng, hap, gs, len(fx.dna[a]), n_per, mean_len=6500, sd_len=1200)
+    base = list(reads)
+    base = [base[i % len(base)] for i in range(16)]           # (indexed below; fewer reads per haplotype just repeat)
+    reads.append(synth.mutate(rng, base[1], 20, 10, 10))                       # noisy
+    reads.append(synth.mutate(rng, base[5], 150, 60, 60))                      # beyond the 3 % cut-off
+    reads.append("".join(rng.choice(list("ACGT"), 5000)))                     # junk: no seed in the index
+    reads.append(base[0][:3100])                                               # truncated
+    reads.append(base[2][len(base[2]) - 2600:])
+    reads.append(synth.revcomp(base[3]))                                       # the other strand: its best mapping is reverse, the read is dropped
+    reads.append(base[0] + synth.revcomp(base[4])[:900])                      # a forward read with a reverse tail
+    reads.append(base[6][:2500] + base[9][1200:])                              # a chimera of the two genes
+    k = len(base[7]) // 2
+    reads.append(base[7][:k] + base[7][k + 70:])                               # a 70-base deletion: the cell needs the wide band
+    reads.append(base[8][:k] + "".join(rng.choice(list("ACGT"), 90)) + base[8][k:])     # a 90-base insertion
+    reads.append(base[10][:1500] + "N" * 30 + base[10][1530:])                 # a stretch of N
+    reads.append("A" * 400 + base[11][400:])                                   # low complexity: every k-mer of the head ties
+    reads.append("ACGT")                                                       # shorter than a k-mer
+    reads.append(base[12][:30])                                                # shorter than a window of k-mers
+    return reads
+
+
+def test_index_and_sketch(oracle, pkg, gpu_ctx, small):
+    from pb_starphase_amd import synth
+    fx, db = small
+    idx, dna_ids = hx.seed_index(oracle, fx)
+    info = db.seed_index_info()
+    assert info["minimizers"] == idx.mm.L.omm_index_n_minimizers(idx.h) and info["mid_occ"] == idx.mid_occ and info["sequences"] == len(dna_ids)
+    rng = np.random.default_rng(3)
+    seqs = varied_reads(fx, synth, rng, n_per=2)
+    seqs += ["ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACG", "C" * 300, "ACG" * 200, "N" * 50, "AC" * 9 + "G",                      # tandem repeats, homopolymers
+             "".join(rng.choice(list("ACGT"), 18)) + "N" + "".join(rng.choice(list("ACGT"), 25)) + "N" + "".join(rng.choice(list("ACGT"), 400)),   # short stretches between N
+             "".join(rng.choice(list("ACGT"), 1024 + 7)), "".join(rng.choice(list("ACGT"), 2048 + 18)), "".join(rng.choice(list("ACGT"), 1024 + 19))]   # tile boundaries of the kernel
+    pal = "".join(rng.choice(list("ACGT"), 200))
+    seqs.append(pal + synth.revcomp(pal))                                                       # k-mers that are their own reverse complement sit at the joint
+    S = gpu_ctx.upload(seqs)
+    mm = idx.mm
+    for i, s in enumerate(seqs):
+        h, p, st = S.sketch(i)
+        H, P, ST = mm.sketch(s)
+        assert np.array_equal(h, H) and np.array_equal(p, P) and np.array_equal(st, ST), (i, len(s), len(h), len(H))
+    S.close()
+
+
+def check_read(pkg, db, R, idx, dna_ids, reads, r):
+    au = db.realign_seeded_audit(R, r)
+    regs, st = idx.chain_stage(reads[r]) if len(reads[r]) else (np.zeros((0, 10), np.int32), None)
+    exp = np.column_stack([regs[:, :8], (regs[:, 9] > 0).astype(np.int32)]) if len(regs) else np.zeros((0, 9), np.int32)
+    got = np.column_stack([au["chains"][:, :8], au["chains"][:, 9]]) if len(au["chains"]) else np.zeros((0, 9), np.int32)
+    assert exp.shape == got.shape and np.array_equal(exp, got), (r, exp.shape, got.shape)
+    pick, hits, nc = idx.k1_seeded(reads[r]) if len(reads[r]) else (-1, [], 0)
+    assert len(au["hits"]) == len(hits) and au["pick"] == pick and au["n_chains"] == nc, (r, len(au["hits"]), len(hits), au["pick"], pick)
+    for a, b in zip(au["hits"], hits):
+        ea = (dna_ids[int(b["rid"])],) + tuple(int(b[k]) for k in mm2_ffi.SEED_HIT_FIELDS[1:])
+        ga = tuple(int(a[k]) for k in pkg.ffi.K1_HIT_FIELDS)
+        assert ea == ga, (r, ea, ga)
+    return au, pick, hits
+
+
+def test_chains_mappings_and_pick_equal_the_statement(oracle, pkg, gpu_ctx, small):
+    from pb_starphase_amd import synth
+    fx, db = small
+    idx, dna_ids = hx.seed_index(oracle, fx)
+    rng = np.random.default_rng(9)
+    reads = varied_reads(fx, synth, rng)
+    R = gpu_ctx.upload(reads)
+    n_rev = n_wide = n_none = 0
+    for r in range(len(reads)):
+        au, pick, hits = check_read(pkg, db, R, idx, dna_ids, reads, r)
+        n_rev += int(pick >= 0 and hits[pick]["rev"])
+        n_none += int(pick < 0)
+        n_wide += int(any(abs((h["b_start"] - h["a_start"]) - (h["b_end"] - h["a_end"])) > 32 for h in hits))
+    assert n_rev >= 1 and n_none >= 4 and n_wide >= 1, (n_rev, n_none, n_wide)
+    assert au["counters"]["capacity_hits"] == 0
+    R.close()
+
+
+def test_records_equal_the_statement(oracle, pkg, gpu_ctx, small):
+    """sp_hla_realign_reads in its default mode: every field of every record"""
+    from pb_starphase_amd import synth
+    fx, db = small
+    rng = np.random.default_rng(10)
+    reads = varied_reads(fx, synth, rng)
+    R = gpu_ctx.upload(reads)
+    out = db.realign_reads(R)
+    exp, _aud = hx.k1_expected_seeded(oracle, fx, reads)
+    seen = set()
+    for r, e in enumerate(exp):
+        o = out[r]
+        assert o["status"] == e["status"] and o["best_allele"] == e["best_allele"], (r, o, e)
+        assert (o["k1_chains"], o["k1_mappings"], o["k1_chain_score"]) == (e["k1_chains"], e["k1_mappings"], e["k1_chain_score"]), (r, o, e)
+        seen.add(int(e["status"]))
+        if e["best_allele"] >= 0:
+            assert o["gene"] == e["gene"]
+            assert (o["nm"], o["target_len"], o["unmapped"]) == (e["nm"], e["target_len"], e["unmapped"])
+            assert tuple(int(x) for x in o["aln"].tolist()) == e["aln"]
+            assert (o["mm2_score"], o["mm2_nm"], o["mm2_t_start"], o["mm2_t_end"], o["mm2_q_start"], o["mm2_q_end"]) == e["mm2"], (r, o, e["mm2"])
+        else:
+            assert o["mm2_score"] == 0
+        if e["status"] == 0:
+            assert (o["seg_start"], o["seg_end"], o["dna_offset"], o["hpc_offset"]) == (e["seg_start"], e["seg_end"], e["dna_offset"], e["hpc_offset"]), (r, o, e)
+    assert {0, 1, 2} <= seen
+    # the same records whatever the batch: the reads one by one, and in slices
+    for r in (0, 5, len(reads) - 9):
+        one = gpu_ctx.upload([reads[r]])
+        assert db.realign_reads(one).tobytes() == out[r:r + 1].tobytes(), r
+        one.close()
+    R.close()
+
+
+def test_sliced_batches_and_best_n(oracle, pkg, gpu_ctx, small, monkeypatch):
+    from pb_starphase_amd import synth
+    fx, db = small
+    idx, dna_ids = hx.seed_index(oracle, fx)
+    rng = np.random.default_rng(12)
+    reads = varied_reads(fx, synth, rng, n_per=3)[:20]
+    R = gpu_ctx.upload(reads)
+    whole = db.realign_reads(R)
+    monkeypatch.setenv("SP_K1_SLICE", "7")
+    assert db.realign_reads(R).tobytes() == whole.tobytes()
+    monkeypatch.delenv("SP_K1_SLICE")
+    # best_n = 2: two secondaries per read (the statement with the same option)
+    gpu_ctx.set_option("k1_best_n", 2)
+    try:
+        o2 = idx.mm.opts(best_n=2)
+        for r in (0, 3, 11):
+            au = db.realign_seeded_audit(R, r)
+            pick, hits, nc = idx.k1_seeded(reads[r], opts=o2)
+            assert au["pick"] == pick and len(au["hits"]) == len(hits) <= 3
+            assert [int(h["allele"]) for h in au["hits"]] == [dna_ids[int(h["rid"])] for h in hits]
+    finally:
+        gpu_ctx.set_option("k1_best_n", 5)
+    with pytest.raises(pkg.StarphaseError):
+        gpu_ctx.set_option("k1_best_n", 9)
+    R.close()
+
+
+def test_full_database_reads(oracle, pkg, gpu_ctx):
+    """the bundled database (11,199 DNA alleles, 3.6 M minimizers): index, and chains / mappings / pick of 24 configs[1] reads"""
+    from pb_starphase_amd import synth
+    fx = synth.HlaFixture()
+    db = fx.make_db(pkg, gpu_ctx)
+    idx, dna_ids = hx.seed_index(oracle, fx)
+    info = db.seed_index_info()
+    assert info["minimizers"] == idx.mm.L.omm_index_n_minimizers(idx.h) == 3582682 and info["mid_occ"] == idx.mid_occ == 500
+    wl = synth.Config2Workload(fx, n_reads=240, seed=77)
+    reads = wl.reads[:24]
+    R = gpu_ctx.upload(reads)
+    n_large = 0
+    for r in range(len(reads)):
+        au, pick, hits = check_read(pkg, db, R, idx, dna_ids, reads, r)
+        assert pick >= 0 and len(hits) == 6 and au["n_chains"] > 500
+        n_large += int((au["chains"][:, 3] > 26).sum())
+    assert n_large > 100            # targets with more than 26 anchors: chained by a whole wave, the skip counter and its marks replayed
+    R.close()
+    db.close()
