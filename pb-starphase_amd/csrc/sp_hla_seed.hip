@@ -267,7 +267,6 @@ constexpr int CH_THREADS = 256;
 constexpr int DP_CAP = 3584;                    // anchors a DP round of a workgroup holds in LDS
 constexpr int DP_CHUNK = 1024;                  // targets a workgroup takes from the list at a time
 constexpr int WIN_KEYS = 12288;                 // targets per window (4 bytes each in LDS)
-constexpr int CHAIN_SLACK = 32;                 // chain slots of a read beyond one per target (a target can yield several chains)
 
 __device__ __forceinline__ int32_t chain_sc(uint32_t ai, uint32_t aj, const int32_t* __restrict__ pen) {
     const int32_t dq = (int32_t)(ai & 0xFFFFu) - (int32_t)(aj & 0xFFFFu);
@@ -333,7 +332,7 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_group_kernel(SeqSetView reads,
     const uint2 rs_ = read_seed[r];
     const uint32_t s0 = rs_.x, K = rs_.y;
     const int qlen = reads.len[r];
-    uint32_t n_groups_read = 0;
+    uint32_t n_groups_read = 0, n_anchors_read = 0;
     unsigned long long t_last = 0;
 #ifdef SP_K1S_TIMING
     t_last = wall_clock64();
@@ -411,13 +410,14 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_group_kernel(SeqSetView reads,
             }
             __syncthreads();
             K1S_T(2);
-            n_groups_read += tot_g;
+            n_groups_read += tot_g; n_anchors_read += tot_a;
             K1S_T(3);
         }
     }
-    // the read's stretch of the batch's chain list: a slot per target and some slack (a target can give several chains)
+    // the read's stretch of the batch's chain list: a chain has at least min_cnt anchors of its own, so a third of the anchors of the read's targets bounds their number
+    // (a target often gives more than one chain: a chimeric read has two on every target)
     if (tid == 0) {
-        const uint32_t cap = n_groups_read ? n_groups_read + CHAIN_SLACK : 0u;
+        const uint32_t cap = n_groups_read ? n_anchors_read / CH_MIN_CNT : 0u;
         const uint32_t off = cap ? atomicAdd(&cur->chains, cap) : 0u;
         read_chain[r] = make_uint3(off, cap, 0u);
     }
@@ -1382,7 +1382,7 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
     if (a_cap >= (1ull << 32)) return sp_fail(ctx, SP_ERR_TOO_LONG, "seeded K1: a read with more than 4 G anchors");
     uint32_t r_batch_max = 0;
     for (uint32_t r0 = 0; r0 < R;) { uint64_t a = 0; uint32_t r1 = r0; while (r1 < R && (r1 == r0 || a + h_anchors[r1] <= batch_anchors)) a += h_anchors[r1++]; r_batch_max = std::max(r_batch_max, r1 - r0); r0 = r1; }
-    const uint64_t c_cap = g_cap + (uint64_t)r_batch_max * CHAIN_SLACK;
+    const uint64_t c_cap = g_cap;                    // (a chain takes at least min_cnt anchors, like a target)
     uint32_t* d_anchors = (uint32_t*)sp_pool(ctx, "k1s_anchors", std::max<uint64_t>(a_cap, 1) * 4);
     SGroup* d_groups = (SGroup*)sp_pool(ctx, "k1s_groups", g_cap * sizeof(SGroup));
     SChain* d_chains = (SChain*)sp_pool(ctx, "k1s_chains", c_cap * sizeof(SChain));

@@ -69,6 +69,7 @@ def test_index_and_sketch(oracle, pkg, gpu_ctx, small):
 
 def check_read(pkg, db, R, idx, dna_ids, reads, r):
     au = db.realign_seeded_audit(R, r)
+    assert au["counters"]["capacity_hits"] == 0, au["counters"]
     regs, st = idx.chain_stage(reads[r]) if len(reads[r]) else (np.zeros((0, 10), np.int32), None)
     exp = np.column_stack([regs[:, :8], (regs[:, 9] > 0).astype(np.int32)]) if len(regs) else np.zeros((0, 9), np.int32)
     got = np.column_stack([au["chains"][:, :8], au["chains"][:, 9]]) if len(au["chains"]) else np.zeros((0, 9), np.int32)

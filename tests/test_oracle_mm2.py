@@ -199,3 +199,53 @@ def test_index_of_many_alleles_picks_the_source(mm):
         best = min(hits, key=lambda h: (max(h["nm"], 0.1) / (h["t_end"] - h["t_start"]), h["rid"]))
         assert best["rid"] == src or alleles[best["rid"]] == alleles[src]
     idx.close()
+
+
+# ------------------------------------------------------------------ the stages one by one, and the statement of K1's seeded mode
+
+def test_stages_agree_with_the_map(mm):
+    """omm_sketch / omm_anchors / omm_chain_stage are omm_map's own stages: the chains selected are the mappings that come back (same targets, in the chain
+    order, when every selected chain survives the filters), minimizers come in position order and a (w,k)-window never goes without one"""
+    rng = np.random.default_rng(21)
+    base = rnd(rng, 3200)
+    alleles = [mutate(rng, base, n_sub=int(rng.integers(2, 20))) for _ in range(80)]
+    idx = mm2_ffi.Index(mm, alleles)
+    read = rnd(rng, 700) + mutate(rng, alleles[11], 3, 1, 1, lo=100, hi=3000) + rnd(rng, 500)
+    h, p, st = mm.sketch(read)
+    assert len(h) > len(read) // 12 and np.all(np.diff(p) > 0) and p[0] >= 18 and np.all(np.diff(p) <= 19) and set(st.tolist()) <= {0, 1}
+    x, y = idx.anchors(read)
+    assert len(x) > 0 and np.all((x[1:] > x[:-1]) | ((x[1:] == x[:-1]) & (y[1:] >= y[:-1])))            # an_cmp's order
+    regs, stats = idx.chain_stage(read)
+    assert stats[0] == len(h) and stats[3] == len(x) and stats[5] == len(regs) and stats[6] == int((regs[:, 9] > 0).sum())
+    assert np.all(np.diff(regs[:, 2]) <= 0)                                                             # by chain score, descending
+    sel = regs[regs[:, 9] > 0]
+    sel = sel[np.argsort(sel[:, 9])]
+    hits = idx.map(read)
+    assert sorted(int(r) for r in sel[:, 0]) == sorted(h2["rid"] for h2 in hits) and 1 <= len(hits) <= 6
+    assert int(sel[0, 8]) >= 0
+    idx.close()
+
+
+def test_k1_seeded_statement_on_the_port_fixture(oracle):
+    """omm_hla_k1_seeded -- minimap2's seeding / chaining / selection + the library's cell and re-score for the selected chains -- names the allele the port's
+    seeded map names (base-level alignment by the restatement's own DP, tests/cpu_port_seeded.py), with its (NM, allele span): 40 reads of configs[1] spread
+    over the committed fixture (tests/golden/concordance.json.gz; the GPU test holds all 10,000 to it)"""
+    import gzip
+    import json
+    import os
+    import __graft_entry__ as ge
+    ge.load_package()
+    from pb_starphase_amd import synth
+    import hla_expected as hx
+    doc = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "concordance.json.gz"), "rt"))["hla"]
+    fx = synth.HlaFixture()
+    wl = synth.Config2Workload(fx, n_reads=10000, seed=1000)
+    idx, dna_ids = hx.seed_index(oracle, fx)
+    assert idx.mid_occ == 500 and idx.mm.L.omm_index_n_minimizers(idx.h) == 3582682
+    for r in range(0, 10000, 250):
+        pick, hits, n_chains = idx.k1_seeded(wl.reads[r])
+        assert pick >= 0 and not hits[pick]["rev"] and len(hits) == 6 and n_chains > 500
+        h = hits[pick]
+        assert dna_ids[int(h["rid"])] == doc["winner"][r], r
+        assert (int(h["nm"]), int(h["t_end"] - h["t_start"])) == (doc["nm"][r], doc["span"][r]), r
+        assert [int(x["dp_max"]) for x in hits] == sorted((int(x["dp_max"]) for x in hits), reverse=True)       # output order: by peak score
