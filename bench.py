@@ -87,6 +87,19 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def one_socket_cpus():
+    """the logical CPUs of ONE socket (north_star: "single-socket CPU"): those of this process's affinity set that sit in the package of the first of them"""
+    mine = sorted(os.sched_getaffinity(0))
+    pkg_of = {}
+    for c in mine:
+        try:
+            pkg_of[c] = int(open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id").read())
+        except Exception:
+            pkg_of[c] = 0
+    first = pkg_of[mine[0]]
+    return [c for c in mine if pkg_of[c] == first], len(set(pkg_of.values()))
+
+
 def host_description():
     """CPU model / sockets / cores of the box the CPU leg runs on"""
     out = {"logical_cpus": len(os.sched_getaffinity(0))}
@@ -116,44 +129,55 @@ def native_oracle():
         return None, "-O3 (shipped build)"
 
 
-def cpu_baseline(fx, hla_reads, cyp_setup, cyp_reads, n_hla=None, n_cyp=None):
-    """The reference's CPU path in its own call pattern for BOTH loci of the sample (tests/cpu_port_seeded.py, tests/cpu_port_cyp.py): every alignment is the minimap2
+def cpu_baseline(fx, hla_reads, cyp_setup, cyp_sets, n_hla=None, n_cyp=None):
+    """The reference's CPU path in its own call pattern for BOTH loci of the headline's mix (tests/cpu_port_seeded.py, tests/cpu_port_cyp.py): every alignment is the minimap2
     restatement's (oracle/mm2.c: seeded maps, `best_n 5`, two-piece affine gaps), the consensus is oracle/consensus.c, typing and chains are the oracle's routines --
-    on the reads `value` is measured on (or on the first n of each, when asked), BEFORE the GPU is touched (the workers are forked).
+    on a bounded share of the reads `value` is measured on (the first n_hla HLA reads of sample 0, the first n_cyp reads of EVERY CYP2D6 scenario of the mix), on the
+    logical CPUs of ONE socket (north_star: single-socket CPU), BEFORE the GPU is touched (the workers are forked).
     -> (the cpu_baseline block, what the GPU has to reproduce: reads used, calls)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi
     import cpu_port_seeded
     import cpu_port_cyp
-    lib, flags = native_oracle()
-    o = oracle_ffi.load(lib) if lib else oracle_ffi.load()
-    n_hla = len(hla_reads) if not n_hla else min(n_hla, len(hla_reads))
-    t0 = time.perf_counter()
-    hres, best, calls, _cons, done = cpu_port_seeded.run(o, fx, hla_reads, n_sample=n_hla, budget_s=1e9)
-    t_hla = time.perf_counter() - t0
-    cfg, gene_def, locus = cyp_setup
-    cdb, ccfg = cpu_port_cyp.tables(cfg, gene_def, locus)
-    creads = cyp_reads if not n_cyp else cyp_reads[:n_cyp]
-    t0 = time.perf_counter()
-    cres, ctm = cpu_port_cyp.run(o, cdb, ccfg, creads)
-    t_cyp = time.perf_counter() - t0
-    n = len(done) + len(creads)
-    wall = hres["wall_s"] + ctm["wall_s"]
-    one = hres["one_thread_s"] + ctm["one_thread_s"]
-    block = {"value": n / wall, "unit": "reads/s", "cores": int(max(hres["cores"], ctm["cores"])), "kind": "port",
-             "sample": f"the sample `value` is measured on: {len(done)} of its {len(hla_reads)} HLA reads and {len(creads)} of its {len(cyp_reads)} CYP2D6 reads, one locus after the "
-                       "other, each with its parallel stages over the host's cores (per-stage worker counts below) and its sequential stages (consensus, chains) on one",
+    all_cpus = os.sched_getaffinity(0)
+    socket_cpus, n_sockets = one_socket_cpus()
+    os.sched_setaffinity(0, socket_cpus)
+    try:
+        lib, flags = native_oracle()
+        o = oracle_ffi.load(lib) if lib else oracle_ffi.load()
+        n_hla = len(hla_reads) if not n_hla else min(n_hla, len(hla_reads))
+        hres, best, calls, _cons, done = cpu_port_seeded.run(o, fx, hla_reads[:n_hla], n_sample=n_hla, budget_s=1e9, cores=len(socket_cpus))
+        cfg, gene_def, locus = cyp_setup
+        cdb, ccfg = cpu_port_cyp.tables(cfg, gene_def, locus)
+        cyp_blocks, cyp_refs = {}, []
+        cyp_wall = cyp_one = 0.0
+        n_cyp_total = 0
+        for name, reads in cyp_sets:
+            creads = reads if not n_cyp else reads[:n_cyp]
+            cres, ctm = cpu_port_cyp.run(o, cdb, ccfg, creads)
+            cyp_wall += ctm["wall_s"]; cyp_one += ctm["one_thread_s"]; n_cyp_total += len(creads)
+            cyp_blocks[name] = {"reads": len(creads), "wall_s": ctm["wall_s"], "one_thread_s": ctm["one_thread_s"], "cores": ctm["cores"],
+                                "cpu_s": {"regions": ctm["regions_cpu_s"], "weights": ctm.get("weights_cpu_s", 0.0), "consensus_typing_chains": ctm["rest_wall_s"]},
+                                "call": [cres.get("hap1", ""), cres.get("hap2", "")], "status": int(cres["status"])}
+            cyp_refs.append((name, creads, cres))
+    finally:
+        os.sched_setaffinity(0, all_cpus)
+    n = len(done) + n_cyp_total
+    wall = hres["wall_s"] + cyp_wall
+    one = hres["one_thread_s"] + cyp_one
+    block = {"value": n / wall, "unit": "reads/s", "cores": len(socket_cpus), "kind": "port",
+             "sample": f"a bounded share of the mix `value` is measured on: the first {len(done)} of sample 0's {len(hla_reads)} HLA reads and the first {n_cyp or 'all'} reads of each of the "
+                       f"{len(cyp_sets)} CYP2D6 scenarios the steps cycle through ({n_cyp_total} reads), one locus and one scenario after the other, each with its parallel stages over the "
+                       f"{len(socket_cpus)} logical CPUs of one socket (of {n_sockets}) and its sequential stages (consensus, chains) on one",
              "single_thread_value": n / one, "wall_s": wall, "one_thread_s": one,
-             "hla": hres, "cyp2d6": {"reads": len(creads), "value": len(creads) / ctm["wall_s"], "unit": "reads/s", "wall_s": ctm["wall_s"], "one_thread_s": ctm["one_thread_s"],
-                                     "workers_per_stage": {"find_base_type_in_sequence (39 template maps per read)": ctm["cores"], "weight_sequence (per region segment)": ctm["cores"],
-                                                           "multi-way consensus, typing, chains, chain pair": 1},
-                                     "cpu_s": {"regions": ctm["regions_cpu_s"], "weights": ctm.get("weights_cpu_s", 0.0), "consensus_typing_chains": ctm["rest_wall_s"]},
-                                     "call": [cres.get("hap1", ""), cres.get("hap2", "")], "status": int(cres["status"])},
-             "compiler_flags": flags, "host": host_description(),
+             "hla": hres, "cyp2d6": {"reads": n_cyp_total, "value": n_cyp_total / cyp_wall, "unit": "reads/s", "wall_s": cyp_wall, "one_thread_s": cyp_one, "scenarios": cyp_blocks,
+                                     "workers_per_stage": {"find_base_type_in_sequence (39 template maps per read)": len(socket_cpus), "weight_sequence (per region segment)": len(socket_cpus),
+                                                           "multi-way consensus, typing, chains, chain pair": 1}},
+             "compiler_flags": flags, "host": host_description(), "affinity": f"{len(socket_cpus)} logical CPUs of socket 0 (sched_setaffinity), {n_sockets} socket(s) on the box",
              "note": "kind 'port': the reference's call pattern on minimap2's published algorithm restated in scalar C (oracle/mm2.c; minimap2 itself and its SSE kernels are "
-                     "not on disk), waffle_con = oracle/consensus.c.  `cores` = the most workers any stage used; the reference itself is single-threaded "
+                     "not on disk), waffle_con = oracle/consensus.c.  `cores` = the logical CPUs of the one socket the leg is pinned to; the reference itself is single-threaded "
                      "(src/cli/diplotype.rs:185-191): single_thread_value is what one thread needs for the same reads"}
-    return block, {"hla_best": best, "hla_calls": calls, "hla_done": done, "cyp_reads": creads, "cyp_call": cres}
+    return block, {"hla_best": best, "hla_calls": calls, "hla_done": done, "cyp": cyp_refs}
 
 
 # ---------------------------------------------------------------------------------------------------------------- workloads
@@ -537,19 +561,57 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
                         "sp_cyp_diplotype_cohort -> sp_variant_solve_batch -> one gather of the call records"}
 
 
+def streams_block(pkg, fx, db, ctx, cfg, gene_def, locus, scen, device_index, rank, world, steps, reads, cyp_reads, barrier, max_over_ranks):
+    """the second block of the N > 1 line: every rank its own stream of the headline's samples (one sample per step, both loci, a new upload every step, the six CYP2D6 scenarios
+    in turn), nothing exchanged -- `value` = all ranks' reads / the slowest rank's time between the barriers (weak scaling by independent samples; launch pairs, not persistent kernels)"""
+    samples = [HlaSample(pkg, fx, reads, 1000 + rank + 100 * k) for k in range(2)]
+    cyp_samples = [CypSample(pkg, locus, scen[k], cyp_reads, 7 + k) for k in range(len(scen))]
+    ctx_c = pkg.Context(device_index)
+    cdb_c = pkg.ffi.CypDb(ctx_c, cfg, gene_def, locus.sequence, locus.start)
+    genes = list(range(len(fx.genes)))
+    ok = [0, 0]
+
+    def hla_work(R, i):
+        return db.diplotype_genes(genes, R, db.realign_reads(R))[0]
+
+    def cyp_work(R, i):
+        call = cdb_c.diplotype(R)[0]
+        ok[0] += int(sorted([call.hap1.decode(), call.hap2.decode()]) == sorted(cyp_samples[i % len(cyp_samples)].expected)); ok[1] += 1
+        return call
+
+    def lanes(n):
+        return [Lane(pkg, ctx, [s_.payload for s_ in samples], hla_work, n, True), Lane(pkg, ctx_c, [c.payload for c in cyp_samples], cyp_work, n, True)]
+    run_lanes(lanes(1))
+    ok[0] = ok[1] = 0
+    ls = lanes(steps)
+    for x in ls:
+        x.pending.wait()
+    barrier(); ctx_c.synchronize()
+    t0 = time.perf_counter()
+    run_lanes(ls)
+    barrier(); ctx_c.synchronize()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    per_step = samples[0].n + cyp_samples[0].n
+    return {"value": world * per_step * steps / dt, "unit": "reads/s", "scaling": "weak", "ms_per_step": 1e3 * dt / steps, "steps": steps, "reads_per_step_per_rank": per_step,
+            "cyp2d6_calls_equal_truth_rank0": f"{ok[0]}/{ok[1]}",
+            "workload": "the N = 1 headline's stream of samples on every rank (its own samples; HLA-A / -B %d reads + CYP2D6 %d reads per step, the six scenarios in turn), no exchange" % (samples[0].n, cyp_samples[0].n)}
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=10000, help="HLA reads of the sample (configs[1])")
     ap.add_argument("--cyp-reads", type=int, default=2000, help="CYP2D6 reads of the sample (configs[2])")
     ap.add_argument("--cohort-samples", type=int, default=256)
-    ap.add_argument("--workload", choices=("auto", "sample", "cohort"), default="auto", help="auto: the sample at N = 1, the cohort at N > 1")
+    ap.add_argument("--workload", choices=("auto", "sample", "cohort"), default="auto",
+                    help="auto: at N = 1 the sample (one sample per step, both loci: BASELINE configs[1] + configs[2]); at N > 1 the cohort (BASELINE configs[4]: 256 samples sharded over "
+                         "the ranks, the call records gathered through sp_gather_results over RCCL), with the ranks' independent streams of samples as a second block of the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-hla-reads", type=int, default=0, help="HLA reads of the sample the CPU leg runs (0: all of them, the reads `value` is measured on)")
-    ap.add_argument("--cpu-cyp-reads", type=int, default=0, help="CYP2D6 reads of the sample the CPU leg runs (0: all of them)")
+    ap.add_argument("--cpu-hla-reads", type=int, default=5000, help="HLA reads of sample 0 the CPU leg runs (0: all of them)")
+    ap.add_argument("--cpu-cyp-reads", type=int, default=1000, help="reads of every CYP2D6 scenario of the mix the CPU leg runs (0: all of them)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-HLA, CYP2D6-scenario, cohort and K5 legs")
     args = ap.parse_args()
 
@@ -561,7 +623,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # N ranks: every rank runs the same stream of samples on its own GPU (its own samples: the seeds carry the rank) -- per-GPU work fixed, nothing shared, `value` the sum over
     # the ranks (weak scaling by independent samples); `--workload cohort` is the other question: ONE 256-sample cohort sharded over the ranks (strong scaling)
-    workload = args.workload if args.workload != "auto" else "sample"
+    workload = args.workload if args.workload != "auto" else ("sample" if world == 1 else "cohort")
     pkg = ge.load_package()
     from pb_starphase_amd import synth, shard
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -571,11 +633,12 @@ def main():
     cfg, gene_def = cr.load_db()
     locus = synth.Chr22Locus(cfg, gene_def, seed=3)
     scen = cr.scenarios(locus)
-    cyp_samples = [CypSample(pkg, locus, scen[k], args.cyp_reads, 7 + k) for k in (0, 1)] if workload == "sample" else []         # *1/*2 and *4/*4 alternate
+    # the steps cycle through ALL SIX configs[2] scenarios (*1/*2, *4/*4, *5/*1, *4+*68/*1, *10+*36/*10, *2x2/*1; round 4 alternated the first two, the cheap third of the config)
+    cyp_samples = [CypSample(pkg, locus, scen[k], args.cyp_reads, 7 + k) for k in range(len(scen))] if workload == "sample" else []
     cb, cpu_ref = None, None
     if not args.no_cpu_baseline and world == 1 and workload == "sample":
         # both loci of sample 0 through the reference-call-pattern CPU port; forks workers: must happen before anything touches the GPU
-        cb, cpu_ref = cpu_baseline(fx, samples[0].wl.reads, (cfg, gene_def, locus), cyp_samples[0].reads, args.cpu_hla_reads, args.cpu_cyp_reads)
+        cb, cpu_ref = cpu_baseline(fx, samples[0].wl.reads, (cfg, gene_def, locus), [(c.name, c.reads) for c in cyp_samples], args.cpu_hla_reads, args.cpu_cyp_reads)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -629,18 +692,37 @@ def main():
 
     if workload == "cohort":
         line = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, barrier, max_over_ranks, (cfg, gene_def), device_index)
+        blocks = {}
+        if world > 1 and not args.no_extra_legs:
+            # (a) the same cohort on ONE GPU (rank 0 alone, the others wait): what the N ranks' value is to be held against; (b) the ranks' independent streams of samples
+            try:
+                if rank == 0:
+                    one_args = argparse.Namespace(**vars(args)); one_args.steps, one_args.warmup = 1, 1
+                    solo = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, 1, 0, None, one_args, lambda: (torch.cuda.synchronize(), ctx.synchronize()), lambda d: d, (cfg, gene_def), device_index)
+                    blocks["one_gpu_same_cohort"] = {"value": solo["value"], "samples_per_s": solo["samples_per_s"], "ms_per_step": solo["ms_per_step"],
+                                                     "value_over_n_times_this": line["value"] / (world * solo["value"])}
+                barrier()
+                blocks["independent_streams"] = streams_block(pkg, fx, db, ctx, cfg, gene_def, locus, scen, device_index, rank, world, min(args.steps, 6), args.reads, args.cyp_reads,
+                                                              barrier, max_over_ranks)
+            except Exception as e:                                                  # (second blocks, not the line's value: say so and go on -- all ranks fail or pass alike up to here)
+                blocks["error"] = str(e)
         if rank == 0:
             out = {"metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)", "value": line["value"], "unit": "reads/s", "n_gpus": world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": line["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                    "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
                    "config": {"workload": line["workload"], "samples": line["samples"], "parallelism": f"samples sharded over {world} GPU(s), one all-gather of the call records per pass through {gather_via}"
                               if backend == "nccl" else f"samples sharded over {world} rank(s) on shared devices, gather through torch.distributed ({backend})"},
-                   "cohort": line, "roofline": None, "cpu_baseline": None,
-                   "note": "strong scaling: the cohort's work is fixed, every rank owns samples / N of it and hands its whole share to the library in one call; the calls keep groups of samples in lockstep, so a rank's rate falls with its share (one GPU, round 4: 348 / 309 / 260 / 208 samples/s for shares of 256 / 128 / 64 / 32 samples: `legs.cohort.by_share_size` of the N = 1 line) -- the N = 1 figure for the same cohort is `legs.cohort` of the N = 1 line"}
+                   "cohort": line, "one_gpu_same_cohort": blocks.get("one_gpu_same_cohort"), "independent_streams": blocks.get("independent_streams"), "second_blocks_error": blocks.get("error"),
+                   "roofline": None, "cpu_baseline": None,
+                   "note": "BASELINE configs[4], strong scaling: the cohort's work is fixed, every rank owns samples / N of it and hands its whole share to the library in one call; the only exchange is ONE "
+                           "all-gather of the call records per pass (sp_gather_results).  The calls keep groups of samples in lockstep, so a rank's rate falls with its share (`legs.cohort.by_share_size` "
+                           "of the N = 1 line: one GPU on shares of 32 / 64 / 128 samples).  `one_gpu_same_cohort`: the same 256 samples on rank 0 alone, in this run; `independent_streams`: every rank "
+                           "its own stream of the N = 1 headline's samples (weak scaling, nothing exchanged).  roofline / cpu_baseline: the N = 1 line carries them"}
             print(json.dumps(out), flush=True)
         if group is not None and hasattr(group, "close"):
             group.close()
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -662,19 +744,44 @@ def main():
         last["hla"] = (i, o, calls)
         return calls
 
+    cyp_log = []                                            # (step, scenario index, call strings, seconds of the library call) of every CYP2D6 call of the lanes
+
     def cyp_work(R, i):
         if headline_mode["persistent"] and os.environ.get("SP_BENCH_INJECT_FAILURE"):       # (a test of the fall-back below: profiles/scripts/r04_run67.sh)
             raise RuntimeError("injected failure of the persistent mode")
+        t_ = time.perf_counter()
         call, _cons, _labels = cdb_c.diplotype(R)
         last["cyp"] = (i, call)
+        cyp_log.append((i, i % len(cyp_samples), call.hap1.decode(), call.hap2.decode(), time.perf_counter() - t_))
         return call
 
     def make_lanes(steps, fresh=True):
         return [Lane(pkg, ctx, [s.payload for s in samples], hla_work, steps, fresh), Lane(pkg, ctx_c, [s.payload for s in cyp_samples], cyp_work, steps, fresh)]
 
+    def agree(failed):
+        """has the persistent mode failed on ANY rank?  (one all-reduce: the ranks switch to launch pairs together instead of one of them raising and the others waiting at a barrier)"""
+        if world == 1:
+            return failed
+        t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
     def timed_region():
-        run_lanes(make_lanes(max(1, args.warmup)))
+        # the warm-up steps (no barrier inside): where the persistent kernels of a batch cannot run side by side the library ends the batch after its time-out with an error -- here
+        err = None
+        try:
+            run_lanes(make_lanes(max(1, args.warmup)))
+        except Exception as e:
+            if not headline_mode["persistent"]:
+                raise
+            err = e
+        if headline_mode["persistent"] and agree(err is not None):
+            headline_mode.update(persistent=False, fallback=str(err) if err is not None else "another rank's persistent consensus kernels failed")
+            sys.stderr.write("bench: persistent consensus kernels failed (%s): the headline runs with a launch pair per step\n" % headline_mode["fallback"])
+            ctx_c.set_option("k8_persistent", 0)
+            run_lanes(make_lanes(max(1, args.warmup)))
         ctx.profile_reset(); ctx_c.profile_reset()
+        del cyp_log[:]
         lanes = make_lanes(args.steps)                      # (sample 0's bytes start travelling here: the pipeline is full when the clock starts)
         for x in lanes:
             x.pending.wait()
@@ -686,14 +793,21 @@ def main():
     try:
         lanes, dt = timed_region()
     except Exception as e:
-        if not headline_mode["persistent"] or world > 1:    # (ranks run in lockstep: one of them starting over would leave the others at a barrier)
+        if not headline_mode["persistent"] or world > 1:    # (a failure inside the timed steps of a multi-rank run: the ranks are in lockstep, nothing to agree on any more)
             raise
-        # the persistent kernels of a batch could not run side by side here (the library's own error, after its four-second time-out): a launch pair per step instead
+        # the persistent kernels failed after the warm-up: a launch pair per step instead, from the start
         headline_mode.update(persistent=False, fallback=str(e))
         sys.stderr.write("bench: persistent consensus kernels failed (%s): the headline runs with a launch pair per step\n" % e)
         ctx_c.set_option("k8_persistent", 0)
         lanes, dt = timed_region()
-    reads_per_step = samples[0].n + cyp_samples[0].n
+    reads_per_step = samples[0].n + cyp_samples[0].n        # (every scenario has the same number of reads)
+    timed_cyp = list(cyp_log)
+    mix = {}
+    for _i, k, h1, h2, sec in timed_cyp:
+        m = mix.setdefault(cyp_samples[k].name, {"steps": 0, "calls_equal_truth": 0, "call_ms": 0.0})
+        m["steps"] += 1; m["calls_equal_truth"] += int(sorted([h1, h2]) == sorted(cyp_samples[k].expected)); m["call_ms"] += 1e3 * sec
+    for m in mix.values():
+        m["call_ms"] = round(m["call_ms"] / max(1, m["steps"]), 2)
     if world > 1:
         args.no_extra_legs = True                           # (the legs are one-GPU questions; the ranks only run the headline together)
     # a lane's host time per step: waiting for the sample's bytes / starting the next upload / the library calls / closing the sample's read set
@@ -744,7 +858,7 @@ def main():
     smp = samples[i_h % 2]
     ok = sum(all(same_allele(fx, a, b) for a, b in zip(sorted([c.allele1, c.allele2]), sorted((smp.truth[g] * 2)[:2]))) for g, (c, _c1, _c2) in enumerate(gene_calls))
     i_c, cyp_call = last["cyp"]
-    cyp_ok = sorted([cyp_call.hap1.decode(), cyp_call.hap2.decode()]) == sorted(cyp_samples[i_c % 2].expected)
+    cyp_ok = all(m["calls_equal_truth"] == m["steps"] for m in mix.values())
     k1_gene_ok = float(np.mean([k1_out[r]["gene"] == smp.wl.read_truth[r][0] for r in range(smp.n)]))
 
     # the bytes' way alone: one synchronous upload of the HLA half in either form
@@ -779,7 +893,7 @@ def main():
             d_p = time.perf_counter() - t1
             legs[other_leg] = {"value": reads_per_step * args.steps / d_p, "unit": "reads/s", "ms_per_step": 1e3 * d_p / args.steps,
                                                           "cyp2d6_cons_steps_ms": ctx_c.profile_get("cons_steps")[0] / max(1, args.steps),
-                                                          "cyp2d6_call_equals_truth": sorted([last["cyp"][1].hap1.decode(), last["cyp"][1].hap2.decode()]) == sorted(cyp_samples[last["cyp"][0] % 2].expected),
+                                                          "cyp2d6_call_equals_truth": sorted([last["cyp"][1].hap1.decode(), last["cyp"][1].hap2.decode()]) == sorted(cyp_samples[last["cyp"][0] % len(cyp_samples)].expected),
                                                           "host_wall_ms_cyp2d6": {k: round(ctx_c.profile_get("host:cyp_" + k)[0] / max(1, args.steps), 2) for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")},
                                                           "host_wall_ms_k8": {k: [round(ctx_c.profile_get("host:k8_" + k)[0] / max(1, args.steps), 2), ctx_c.profile_get("host:k8_" + k)[1] // max(1, args.steps)] for k in ("prologue", "loop", "result_wait", "epilogue")},
                                                           "critical_path_cyp2d6": critical_path(ctx_c)}
@@ -867,8 +981,10 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1] + configs[2] as ONE sample per step: HLA-A / -B, %d synthetic HiFi reads vs the bundled IMGT/HLA DB v0.14.1 (18,461 alleles, 11,199 with "
-                               "DNA) and CYP2D6, %d targeted reads (39 templates, 393 variants / 520 star alleles); a new sample's bytes (BAM 4-bit SEQ) uploaded every step "
-                               "under the previous sample's kernels; reads -> diplotypes of both loci" % (samples[0].n, cyp_samples[0].n),
+                               "DNA) and CYP2D6, %d targeted reads (39 templates, 393 variants / 520 star alleles), the steps cycling through ALL SIX configs[2] scenarios (%s); a new "
+                               "sample's bytes (BAM 4-bit SEQ) uploaded every step under the previous sample's kernels; reads -> diplotypes of both loci"
+                               % (samples[0].n, cyp_samples[0].n, ", ".join(c.name for c in cyp_samples)),
+                   "cyp2d6_mix": mix,
                    "reads_per_step": reads_per_step, "hla_reads": samples[0].n, "cyp2d6_reads": cyp_samples[0].n, "alleles": len(fx.ids),
                    "parallelism": ("one GPU: " if world == 1 else "%d GPUs, one process each with its own stream of samples (no exchange; `value` = all ranks' reads / the slowest rank's time); per GPU: " % world) +
                                   "the two loci side by side on two contexts (host threads, HIP streams), uploads on copy streams",
@@ -911,20 +1027,31 @@ def main():
         gene_agree = sum(1 for k, r in enumerate(cpu_done) if cpu_best[r][0] >= 0 and int(o[k]["gene"]) == int(fx.gene_of[cpu_best[r][0]]))
         cb["hla"]["k1_same_allele_as_gpu"] = f"{agree}/{len(cpu_done)}"
         cb["hla"]["k1_same_gene_as_gpu"] = f"{gene_agree}/{len(cpu_done)}"
-        Rc = ctx.upload(cpu_ref["cyp_reads"])
-        g_cyp, _cons, _labels = cdb.diplotype(Rc)
-        cb["cyp2d6"]["call_gpu_same_reads"] = [g_cyp.hap1.decode(), g_cyp.hap2.decode()]
-        cyp_same = int(g_cyp.status) == cb["cyp2d6"]["status"] and sorted(cb["cyp2d6"]["call_gpu_same_reads"]) == sorted(cb["cyp2d6"]["call"])
+        cyp_same, cyp_sets_gpu = True, []
+        for name, creads, cres in cpu_ref["cyp"]:
+            Rc = ctx.upload(creads)
+            g_cyp, _cons, _labels = cdb.diplotype(Rc)
+            got = [g_cyp.hap1.decode(), g_cyp.hap2.decode()]
+            cb["cyp2d6"]["scenarios"][name]["call_gpu_same_reads"] = got
+            same_here = int(g_cyp.status) == int(cres["status"]) and sorted(got) == sorted([cres.get("hap1", ""), cres.get("hap2", "")])
+            cb["cyp2d6"]["scenarios"][name]["identical"] = bool(same_here)
+            cyp_same = cyp_same and same_here
+            cyp_sets_gpu.append(Rc)
         cb["diplotypes_identical"] = {"hla": bool(hla_same), "cyp2d6": bool(cyp_same)}
         # like for like: the GPU on the same reads, one sample at a time, reads resident (the headline also uploads a new sample per step)
         ctx.synchronize(); t1 = time.perf_counter()
-        o2 = db.realign_reads(Rs); db.diplotype_genes(genes, Rs, o2); cdb.diplotype(Rc)
+        o2 = db.realign_reads(Rs); db.diplotype_genes(genes, Rs, o2)
+        for Rc in cyp_sets_gpu:
+            cdb.diplotype(Rc)
         ctx.synchronize(); d_same = time.perf_counter() - t1
-        cb["gpu_same_reads_one_after_the_other"] = {"value": (len(sub) + len(cpu_ref["cyp_reads"])) / d_same, "unit": "reads/s", "seconds": d_same}
-        cb["gpu_over_cpu"] = {"all_cores": cb["gpu_same_reads_one_after_the_other"]["value"] / cb["value"],
+        n_same = len(sub) + sum(len(c[1]) for c in cpu_ref["cyp"])
+        cb["gpu_same_reads_one_after_the_other"] = {"value": n_same / d_same, "unit": "reads/s", "seconds": d_same}
+        cb["gpu_over_cpu"] = {"one_socket": cb["gpu_same_reads_one_after_the_other"]["value"] / cb["value"],
                               "one_thread": cb["gpu_same_reads_one_after_the_other"]["value"] / cb["single_thread_value"],
-                              "note": "same reads, both loci, the GPU running the loci one after the other as the CPU leg does; a ratio to a scalar restatement, not to minimap2's SSE build"}
-        Rs.close(); Rc.close()
+                              "note": "same reads, both loci, the GPU running the loci and scenarios one after the other as the CPU leg does; a ratio to a scalar restatement, not to minimap2's SSE build"}
+        for Rc in cyp_sets_gpu:
+            Rc.close()
+        Rs.close()
         line["cpu_baseline"] = cb
     else:
         line["cpu_baseline"] = None
