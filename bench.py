@@ -44,7 +44,7 @@ import __graft_entry__ as ge  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2    # 256 CU x 4 SIMD-32 x one wave-instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md); sp_microbench measures it
-COUNTER_DIR = os.path.join(ROOT, "profiles", "r04")
+COUNTER_DIR = os.path.join(ROOT, "profiles", "r05")
 
 
 def cyp_persistent():
@@ -813,7 +813,7 @@ def main():
     # a lane's host time per step: waiting for the sample's bytes / starting the next upload / the library calls / closing the sample's read set
     lane_ms = [{k: round(1e3 * getattr(x, "t_" + k, 0.0) / max(1, args.steps), 3) for k in ("wait", "start", "work", "close")} for x in lanes]
 
-    e2e_names = ("anchor_k1", "anchor_k2", "anchor_type", "k1_cells", "k1_cells_deep", "k1_reduce", "k1_finalize", "cons_steps", "type_consensus_ref",
+    e2e_names = ("anchor_k1", "k1s_seeds", "k1s_groups", "k1s_dp", "k1s_dp_big", "k1s_select", "k1s_cells", "k1s_af_trace", "k1s_af_dp", "anchor_k2", "anchor_type", "k1_finalize", "cons_steps", "type_consensus_ref",
                  "k2_cells_cdna", "k2_cells_dna", "k2_scan")
     kernel_ms = {k: ctx.profile_get(k)[0] / max(1, args.steps) for k in e2e_names}
     cyp_kernel_ms = {k: ctx_c.profile_get(k)[0] / max(1, args.steps) for k in ("cons_steps", "k5_pairs", "k9_graph")}
@@ -841,18 +841,12 @@ def main():
                        "kernel boundary (MI355X_MICROARCH.md: 1.45 us on an idle device), in persistent mode a write-through store + drain + flag and a poll (handoff-flag: 1.3-5 us)")
         return out
     crit = {"kernel": "cons_step_kernel + cons_control_kernel (K8, the consensus search)", "cyp2d6": critical_path(ctx_c), "hla": critical_path(ctx)}
-    ms_cells, launches, _cells_all = ctx.profile_get("k1_cells")
-    executed, resumed, active = ctx.counter("k1_cells_executed"), ctx.counter("k1_cells_resumed"), ctx.counter("k1_cells_active")
-    exec_bytes = ctx.counter("k1_cells_bytes")
+    batches_per_step = ctx_c.profile_get("cons_persistent_batches")[2] / max(1, args.steps)
     cons = {k: ctx.profile_get(n)[2] / max(1, args.steps) for k, n in (("launch_triples_per_step", "cons_windows"), ("cut_windows_per_step", "cons_cut_windows"),
                                                                          ("expansions_per_step", "cons_expansions"), ("nodes_expanded_per_step", "cons_columns"))}
     host_ms = {k: ctx.profile_get("host:" + k)[0] / max(1, args.steps) for k in ("hla_segments", "hla_dual_hpc", "hla_groups", "hla_typing", "k8_loop", "k1_total", "hla_genes_total")}
     cyp_host_ms = {k: ctx_c.profile_get("host:cyp_" + k)[0] / max(1, args.steps) for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")}
     cyp_host_ms["k8"] = {k: [round(ctx_c.profile_get("host:k8_" + k)[0] / max(1, args.steps), 2), ctx_c.profile_get("host:k8_" + k)[1] // max(1, args.steps)] for k in ("prologue", "loop", "result_wait", "epilogue")}
-    avg_ms = ms_cells / max(1, launches)
-    per_launch = lambda v: v / max(1, launches)
-    achieved = per_launch(exec_bytes) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-
     # the calls of the last step against the truth the reads were simulated from
     i_h, k1_out, gene_calls = last["hla"]
     smp = samples[i_h % 2]
@@ -910,6 +904,36 @@ def main():
         d_res = time.perf_counter() - t1
         legs["hla_resident"] = {"value": samples[0].n * args.steps / d_res, "unit": "reads/s", "ms_per_step": 1e3 * d_res / args.steps,
                                 "workload": "BASELINE configs[1] alone: K1 + sp_hla_diplotype_genes on reads already in HBM, one sample at a time (the headline of round 2)"}
+        # K1 both ways on sample 0's resident reads: the reference's call pattern (k1_best_n = 5, the default: seeds, chains, best_n) and the exhaustive search of every allele
+        # (k1_best_n = 0, rounds 1-4), whose cells kernel was the roofline's kernel until round 5 (algorithmic bytes of the cells the launch executed)
+        Rk = ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *samples[0].payload)
+        k1 = {}
+        for mode, label in ((5, "seeded_best_n_5"), (0, "exhaustive")):
+            ctx.set_option("k1_best_n", mode)
+            o_ = db.realign_reads(Rk)
+            ctx.profile_reset(); ctx.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                o_ = db.realign_reads(Rk)
+            d_k = (time.perf_counter() - t1) / 3
+            k1[label] = {"ms_per_call": 1e3 * d_k, "reads_per_s": samples[0].n / d_k, "best_alleles_crc": int(np.bitwise_xor.reduce(o_["best_allele"].astype(np.int64) * 2654435761 % (1 << 31))),
+                         "kernel_ms": {k: round(ctx.profile_get(k)[0] / 3, 3) for k in ("anchor_k1", "k1s_seeds", "k1s_groups", "k1s_dp", "k1s_dp_big", "k1s_select", "k1s_cells", "k1s_af_trace", "k1s_af_dp",
+                                                                                       "k1_cells", "k1_cells_deep", "k1_finalize", "k1_af_trace", "k1_af_dp") if ctx.profile_get(k)[1]}}
+            if mode == 0:
+                ms_cells, launches, _c = ctx.profile_get("k1_cells")
+                executed, resumed, active, exec_bytes = (ctx.counter("k1_cells_" + k) for k in ("executed", "resumed", "active", "bytes"))
+                avg_ms = ms_cells / max(1, launches)
+                k1[label]["cells_kernel"] = {"kernel": "k1_cells_kernel", "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": exec_bytes / max(1, launches),
+                                             "algorithmic_GBs": exec_bytes / max(1, launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
+                                             "cells_executed_per_launch": executed / max(1, launches), "cells_resumed_per_launch": resumed / max(1, launches),
+                                             "cells_active_per_launch": active / max(1, launches),
+                                             "note": "an integer-DP kernel whose database sits in L2: instruction issue bounds it (profiles/r04/valu_k1_cells.json: 0.49 of the measured VALU peak), "
+                                                     "0.19 GB cross HBM per launch (profiles/r04/traffic_k1_cells.json); the algorithmic bytes bill every executed cell its two whole sequences"}
+            else:
+                pass
+        ctx.set_option("k1_best_n", 5)
+        Rk.close()
+        legs["k1_modes"] = k1
         # throughput mode: K whole samples (both loci) in flight at once, each locus of each sample on a context of its own; same uploads, same calls.  The
         # headline is ONE sample's latency chain (the CYP2D6 consensus: small launches that wait for one another); this is what the GPU does when a host
         # keeps several samples going
@@ -953,28 +977,42 @@ def main():
 
     peaks = {"valu_int_wave_instr_per_s": ctx.microbench("valu_int"), "match16_valu_wave_instr_per_s": ctx.microbench("match16"),
              "hbm_copy_bytes_per_s": ctx.microbench("hbm_copy")}
-    # VALU wave-instructions and HBM bytes of one k1_cells launch come from the committed rocprofv3 PMC passes of this workload; a pass made on other
-    # kernel sources is not quoted (the block is left out and the line says so)
+    # The dominant kernel of the step since round 5 is the consensus step kernel of the CYP2D6 context (K8: cons_step_persist_kernel<8>, cons_step_kernel<8> as launch pairs;
+    # 55 % of the kernel time of profiles/r05/rocprof_r05_kernel_stats.csv with its control kernel).  Its time per step is measured live -- the chain between HIP events on the
+    # library's stream (cons_steps) and, inside it, the step body by the device clock the kernels stamp (critical_path) --; its instruction and HBM byte counts per bench step come
+    # from the committed rocprofv3 PMC passes of this workload (profiles/r05/counters_cons_step.json), quoted only while the kernel's source is the one they were made on
     import hashlib
-    k1_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "pb-starphase_amd", "csrc", f), "rb").read() for f in ("sp_hla.hip", "sp_wfa.hip.h"))).hexdigest()[:16]
-    valu, traffic, traffic_note, stale = None, None, None, []
-    vfile, tfile = os.path.join(COUNTER_DIR, "valu_k1_cells.json"), os.path.join(COUNTER_DIR, "traffic_k1_cells.json")
-    if os.path.exists(vfile) and args.reads == 10000 and avg_ms > 0:
-        rec = json.load(open(vfile))
-        if rec.get("k1_source_sha16") == k1_sha:
-            rate = rec["sq_insts_valu_per_launch"] / (avg_ms * 1e-3)
-            valu = {"bound": "valu", "kernel": "k1_cells_kernel", "achieved": rate, "peak": peaks["valu_int_wave_instr_per_s"], "unit": "wave-instr/s",
-                    "frac": rate / peaks["valu_int_wave_instr_per_s"], "nominal_peak": VALU_PEAK_WAVE_INSTR, "frac_of_match16_mix_peak": rate / peaks["match16_valu_wave_instr_per_s"],
-                    "sq_insts_salu_per_launch": rec.get("sq_insts_salu_per_launch"),
-                    "note": "instruction count from the committed PMC pass (" + rec["method"] + "), launch time and peak measured in this run"}
+    cons_sha = hashlib.sha256(open(os.path.join(ROOT, "pb-starphase_amd", "csrc", "sp_consensus.hip"), "rb").read()).hexdigest()[:16]
+    stale, pmc = [], None
+    cfile = os.path.join(COUNTER_DIR, "counters_cons_step.json")
+    if os.path.exists(cfile):
+        rec = json.load(open(cfile))
+        if rec.get("cons_source_sha16") == cons_sha and args.cyp_reads == 2000:
+            pmc = rec
         else:
-            stale.append("valu_k1_cells.json")
-    if os.path.exists(tfile) and args.reads == 10000:
-        rec = json.load(open(tfile))
-        if rec.get("k1_source_sha16") == k1_sha:
-            traffic, traffic_note = rec["hbm_bytes_per_launch"], "from the committed rocprofv3 PMC passes of this workload (" + rec["method"] + ")"
-        else:
-            stale.append("traffic_k1_cells.json")
+            stale.append("counters_cons_step.json")
+    cp = crit["cyp2d6"]
+    step_ms, chain_ms, dep_steps = cp["step_kernel_ms"], cp["chain_ms"], cp["dependent_steps"]
+    batches = batches_per_step if batches_per_step > 0 else None
+    cyp_packed_bytes = float(np.mean([c.ascii_bytes for c in cyp_samples])) / 4.0
+    # SURVEY 8(d)'s streaming model for the consensus: every search level reads the packed bases of its reads once and writes one 32-byte record per read
+    searches = batches if batches else 3.0                  # (a batch = the searches of one level of the multi-way consensus, all open groups in lockstep)
+    algo_bytes = searches * (cyp_packed_bytes + 32.0 * cyp_samples[0].n)
+    roof = {"bound": "valu", "kernel": "cons_step_persist_kernel<8>" if headline_mode["persistent"] else "cons_step_kernel<8>",
+            "achieved": (pmc["sq_insts_valu_per_bench_step"] / (step_ms * 1e-3)) if (pmc and step_ms > 0) else None, "peak": peaks["valu_int_wave_instr_per_s"], "unit": "wave-instr/s",
+            "frac": (pmc["sq_insts_valu_per_bench_step"] / (step_ms * 1e-3) / peaks["valu_int_wave_instr_per_s"]) if (pmc and step_ms > 0) else None,
+            "traffic": pmc["hbm_bytes_per_bench_step"] if pmc else None,
+            "per": "bench step (the consensus searches of one 2,000-read CYP2D6 sample: %.0f dependent window / expansion steps%s)" % (dep_steps, "" if batches is None else ", %.1f persistent launches" % batches),
+            "step_kernel_ms_per_step": step_ms, "chain_ms_per_step_hip_events": chain_ms, "nominal_peak": VALU_PEAK_WAVE_INSTR,
+            "sq_insts_valu_per_step": pmc["sq_insts_valu_per_bench_step"] if pmc else None, "sq_insts_salu_per_step": pmc["sq_insts_salu_per_bench_step"] if pmc else None,
+            "sq_insts_lds_per_step": pmc["sq_insts_lds_per_bench_step"] if pmc else None,
+            "hbm": {"algorithmic_bytes_per_step": algo_bytes, "achieved_GBs": algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else None, "peak_GBs": HBM_PEAK_GBS,
+                    "frac": algo_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if step_ms > 0 else None, "measured_hbm_copy_GBs": peaks["hbm_copy_bytes_per_s"] / 1e9,
+                    "note": "SURVEY 8(d)'s streaming model applied to the consensus: every search reads its reads' packed bases once and writes a 32-byte record per read"},
+            "counters_from": ("profiles/r05/counters_cons_step.json: " + pmc["method"]) if pmc else "no counter file for this kernel source (profiles/run_rocprof.sh makes it)",
+            "note": "the step's dominant kernel is a LATENCY chain, not a throughput kernel: a sample's searches are a few hundred dependent steps (critical_path), each the slowest "
+                    "wavefront of a launch that fills a fraction of the device -- the fraction of the VALU peak (and of HBM: the reads are 3 MB) says how little of the machine one "
+                    "sample's chain can use; what bounds it is per-step latency (critical_path.cyp2d6.per_step_us) and the number of steps"}
     line = {
         "metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)",
         "value": world * reads_per_step * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -990,16 +1028,7 @@ def main():
                                   "the two loci side by side on two contexts (host threads, HIP streams), uploads on copy streams",
                    "cyp2d6_consensus": ("persistent kernels (sp_ctx_set_option k8_persistent = 1 on the CYP2D6 context: two launches per batch, hand-overs through memory; SP_BENCH_HEADLINE_PERSISTENT=0 for launch pairs)"
                                         if headline_mode["persistent"] else "a launch pair per step" + ("" if headline_mode["fallback"] is None else " (the persistent kernels failed here: %s)" % headline_mode["fallback"]))},
-        "roofline": {"bound": "hbm", "kernel": "k1_cells_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                     "algorithmic_bytes_per_launch": per_launch(exec_bytes), "cells_executed_per_launch": per_launch(executed),
-                     "cells_resumed_per_launch": per_launch(resumed), "cells_active_per_launch": per_launch(active),
-                     "cells_settled_without_running_per_launch": per_launch(active - executed), "avg_launch_ms": avg_ms,
-                     "measured_hbm_copy_GBs": peaks["hbm_copy_bytes_per_s"] / 1e9,
-                     "note": "'achieved' = algorithmic bytes (SURVEY 8(d): ceil(Lq/4) + ceil(Lt/4) + 32 per cell) of the cells the launch EXECUTED, counted on the "
-                             "device, / launch time (HIP events on the library's stream, CYP2D6 kernels running beside it).  The kernel is an integer-DP kernel whose "
-                             "database sits in L2: its limiter is instruction issue (roofline_valu), 'traffic' is what actually crossed HBM"},
-        "roofline_valu": valu,
+        "roofline": roof,
         "stale_counter_files": stale or None,
         "kernel_ms": {"hla": kernel_ms, "cyp2d6": cyp_kernel_ms}, "host_wall_ms": {"hla": host_ms, "cyp2d6": cyp_host_ms, "lanes_hla_cyp2d6": lane_ms},
         "critical_path": crit,
@@ -1063,7 +1092,7 @@ def main():
             group.close()
         dist.destroy_process_group()
     if stale and rank == 0:                                                 # (the blocks they feed were left out of the line above)
-        print("bench.py: the counter files " + ", ".join(stale) + " were collected on other kernel sources: re-run profiles/run_rocprof.sh and copy the two files into profiles/r04", file=sys.stderr)
+        print("bench.py: the counter files " + ", ".join(stale) + " were collected on other kernel sources: re-run profiles/run_rocprof.sh and copy counters_cons_step.json into profiles/r05", file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,9 @@ export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=16
 # (the kernel trace runs the bench as it is -- the headline's CYP2D6 context with persistent consensus kernels --; the counter passes run one kernel at a time, under which
 #  two kernels that wait for each other cannot run: they get SP_BENCH_HEADLINE_PERSISTENT=0, i.e. a launch pair per step; K1, the kernel the roofline is about, is the same in both)
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs"
+# six steps = one turn through the configs[2] scenarios; SP_PROF_STEPS = steps + warm-up (summarize_rocprof.py divides the pass sums by it)
+ARGS="bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extra-legs"
+export SP_PROF_STEPS=7
 # 1. kernel trace + stats (no counters in this pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 # 2. PMC passes, one small counter group each (no tracing domains combined with --pmc)
