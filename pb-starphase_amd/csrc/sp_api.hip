@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cstring>
 #include <new>
+#include <unistd.h>
 
 extern "C" {
 
@@ -21,11 +22,25 @@ int32_t sp_device_count(int32_t* count) {
 int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
     if (!out) return SP_ERR_INVALID_ARG;
     *out = nullptr;
-    // hardware queues: asked for before the first HIP call of this function (see sp_ctx_info in the header)
+    // hardware queues: asked for before the first HIP call of this function (see sp_ctx_info in the header).  The variable only counts if the HIP runtime reads it when it
+    // comes up: a host that initialised HIP before this call (torch, say) has the runtime's own default of 4 unless it exported the variable itself -- told apart by whether
+    // this process already holds the compute driver's device file
+    static std::atomic<int> effective{-1};              // GPU_MAX_HW_QUEUES as HIP met it (-1: not known yet)
     bool by_library = false;
-    if (!std::getenv("GPU_MAX_HW_QUEUES")) { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); by_library = true; }
-    const char* hq = std::getenv("GPU_MAX_HW_QUEUES");
-    const int hw_queues = hq ? std::atoi(hq) : 4;
+    if (effective.load() < 0) {
+        bool hip_up = false;
+        char link[64];
+        for (int fd = 0; fd < 1024 && !hip_up; ++fd) {
+            char path[64]; std::snprintf(path, sizeof path, "/proc/self/fd/%d", fd);
+            const ssize_t k = readlink(path, link, sizeof link - 1);
+            if (k > 0) { link[k] = 0; hip_up = std::strcmp(link, "/dev/kfd") == 0; }
+        }
+        const char* had = std::getenv("GPU_MAX_HW_QUEUES");
+        if (!had && !hip_up) { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); by_library = true; }
+        const char* now = std::getenv("GPU_MAX_HW_QUEUES");
+        effective.store(now ? std::atoi(now) : (hip_up ? 0 : 4));
+    }
+    const int hw_queues = effective.load() > 0 ? effective.load() : 4;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SP_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return SP_ERR_NO_DEVICE;
@@ -40,12 +55,14 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
     static bool set_here = false;                     // (a later context of the process finds the variable the first one set)
     if (by_library) set_here = true;
     ctx->hw_queues = hw_queues; ctx->hw_queues_by_library = set_here;
-    { const char* kp = std::getenv("SP_K8_PERSISTENT"); if (kp && *kp) ctx->k8_persistent = std::atoi(kp) != 0; }      // (several processes on one device cannot see each other's persistent batches: they switch the mode off)
-    if (hw_queues < 16) {
+    ctx->hw_queues_effective = effective.load();
+    { const char* kp = std::getenv("SP_K8_PERSISTENT"); if (kp && *kp) ctx->k8_persistent = std::atoi(kp); }      // (several processes on one device cannot see each other's persistent batches: they switch the mode off)
+    if (effective.load() == 0)
+        ctx->warning = "the HIP runtime was initialised before the library's first context and GPU_MAX_HW_QUEUES was not set: the process's streams share the runtime's 4 hardware queues; "
+                       "export GPU_MAX_HW_QUEUES=16 (or more) before the process initialises HIP";
+    else if (hw_queues < 16)
         ctx->warning = "GPU_MAX_HW_QUEUES=" + std::to_string(hw_queues) + ": the library's streams share " + std::to_string(hw_queues) +
                        " hardware queues; export GPU_MAX_HW_QUEUES=16 (or more) before the process initialises HIP";
-        ctx->err = ctx->warning;
-    }
     if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SP_ERR_HIP; }
@@ -166,7 +183,7 @@ int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (std::strcmp(name, "hla_split_genes") == 0) { ctx->split_genes = value != 0; return SP_OK; }
     if (std::strcmp(name, "k1_best_n") == 0) { if (value < 0 || value > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k1_best_n is 0..8"); ctx->k1_best_n = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k1_best_n = ctx->k1_best_n; return SP_OK; }
     if (std::strcmp(name, "mm2_rescore") == 0) { ctx->mm2_rescore = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->mm2_rescore = ctx->mm2_rescore; return SP_OK; }
-    if (std::strcmp(name, "k8_persistent") == 0) { ctx->k8_persistent = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->k8_persistent = ctx->k8_persistent; return SP_OK; }
+    if (std::strcmp(name, "k8_persistent") == 0) { if (value < 0 || value > 2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k8_persistent is 0 (never), 1 (whenever a batch fits) or 2 (the library decides)"); ctx->k8_persistent = (int)value; ctx->k8_persist_backoff = 0; for (sp_ctx* h : ctx->helper) if (h) h->k8_persistent = ctx->k8_persistent; return SP_OK; }
     if (std::strcmp(name, "cons_retry_ladder") == 0) { ctx->cons_retry_ladder = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->cons_retry_ladder = ctx->cons_retry_ladder; return SP_OK; }
     if (std::strcmp(name, "k5_block_pairs") == 0) { if (value < 0 || value > (1 << 20)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k5_block_pairs is 0..1048576"); ctx->k5_block_pairs = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k5_block_pairs = ctx->k5_block_pairs; return SP_OK; }
     if (std::strcmp(name, "cyp_cohort_min_group") == 0) { if (value < 1 || value > 64) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: cyp_cohort_min_group is 1..64"); ctx->cyp_cohort_min_group = (int)value; return SP_OK; }

@@ -149,11 +149,12 @@ template <int MAXP> struct ConsBatchT {
     unsigned long long* step_t; // profiling contexts (else nullptr): per problem { earliest workgroup start, latest workgroup end } of the step kernel, reset by the control step
     uint32_t* sync;             // persistent mode (else nullptr): per problem { steps the control workgroup has answered, arrivals of step workgroups, -, - }, then one abort word for the batch
     uint32_t* ready;            // persistent mode: host memory, counts the control workgroups that have started (the step workgroups are launched behind them)
+    uint32_t step_cap;          // persistent mode: a search that has not ended after this many steps ends the batch (the launch-pair loop's own bound)
     int total;
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; const int* cluster_prob; int total;
+    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; uint32_t step_cap; const int* cluster_prob; int total;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first, cmp_len, pad_; };
 
@@ -1754,13 +1755,21 @@ __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Persistent mode (batches whose problems all have <= DIRECT_BLOCKS workgroups and whose workgroups fit the device together): the same two bodies, each in a
 // loop of its own kernel, started ONCE per batch on two streams.  A step workgroup runs step k when the problem's control workgroup has answered step k - 1,
-// then reports in; the control workgroup runs control step k when all workgroups of its problem have reported step k.  Every hand-over is a device-scope
-// release / acquire pair on one word per problem -- no kernel boundary, no dispatch, and no lockstep between the problems of the batch: each search runs at
-// the pace of its own chain.  (A launch pair per step cost a CYP2D6 sample 34 of its 105 us per step between the kernels while K1's grids ran beside it:
-// bench.py critical_path.)  All workgroups have to be resident together: the host admits a batch only within a budget of CUs (run_chunk).  A wait that
-// lasts longer than PERSIST_TIMEOUT ticks of the 100 MHz clock raises the batch's abort word: every loop ends and the host reports the failure.
+// then reports in; the control workgroup runs control step k when all workgroups of its problem have reported step k.  No kernel boundary, no dispatch, and no
+// lockstep between the problems of the batch: each search runs at the pace of its own chain.  (A launch pair per step cost a CYP2D6 sample 34 of its 105 us per
+// step between the kernels while K1's grids ran beside it: bench.py critical_path.)
+// THE HAND-OVER (gfx950; measured, DESIGN.md section 9 -- not a release / acquire pair of the memory model, whose agent-scope fences cost an L2 write-back and an
+// invalidate per step, 14.8 us):  control -> step: everything the step workgroups read next (work order, node lengths, consensus bytes) is stored write-through (sc1,
+// relaxed agent-scope atomic stores), every thread drains its stores (s_waitcnt vmcnt(0)), a workgroup barrier, then ONE relaxed store raises the problem's word; the
+// step workgroups poll the word and read those data with sc1 loads (past their L1).  step -> control: the vote words are memory-side atomics, drained (s_waitcnt vmcnt(0))
+// before the workgroup's relaxed fetch_add reports in; the control workgroup fetches and clears them where the atomics ran and invalidates its own L1 once per step for
+// its private state.  This relies on gfx950's write-through L1 / memory-side atomics and is guarded by the architecture check of sp_ctx_create (gfx950 only).
+// All workgroups have to be resident together: the host admits a batch only within a budget of CUs (run_chunk), launches the control workgroups first and the step
+// workgroups only when all of them have started; if they have not within PERSIST_READY_S the batch is aborted and run launch by launch.  A wait that lasts longer than
+// PERSIST_TIMEOUT ticks of the 100 MHz clock, or a search that passes step_cap steps, raises the batch's abort word: every loop ends and the host reports the failure.
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr long long PERSIST_TIMEOUT = 400000000ll;                 // 4 s
+constexpr double PERSIST_READY_S = 0.5;                            // how long the host waits for every control workgroup of a batch to start
 __device__ __forceinline__ bool persist_wait(const uint32_t* word, uint32_t at_least, uint32_t* abort_word) {
     const long long t0 = wall_clock64();
     for (uint32_t spins = 1;; ++spins) {
@@ -1802,7 +1811,10 @@ __global__ void __launch_bounds__(1024) cons_control_persist_kernel(ConsBatchT<M
     // have a CU (with a step workgroup on every CU and spinning, no control workgroup would ever start)
     if (threadIdx.x == 0 && B.ready) __hip_atomic_fetch_add(B.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (uint32_t k = 1;; ++k) {
-        if (threadIdx.x == 0) go_on = persist_wait(sy + 1, nb * k, abort_word) ? 1 : 0;
+        if (threadIdx.x == 0) {
+            go_on = persist_wait(sy + 1, nb * k, abort_word) ? 1 : 0;
+            if (go_on && k > B.step_cap) { __hip_atomic_store(abort_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); go_on = 0; }      // the search did not finish
+        }
         __syncthreads();
         if (!go_on) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // (this CU's L1 only: the workgroup's own state of the step before comes from L2, not from stale lines)
@@ -1813,8 +1825,10 @@ __global__ void __launch_bounds__(1024) cons_control_persist_kernel(ConsBatchT<M
         if (threadIdx.x == 0) __hip_atomic_store(sy + 0, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done) break;
     }
-    if (threadIdx.x == 0 && B.prog && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        __hip_atomic_store(B.prog + 2 * pi + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);           // "ended" with 2: the batch was aborted
+    if (threadIdx.x == 0 && B.prog) {
+        const uint32_t ab = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ab) __hip_atomic_store(B.prog + 2 * pi + 1, 1u + ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // "ended" with 2: a wait timed out (or the host gave the batch up); 3: a search passed the step cap
+    }
 }
 
 // gathers the per-read constants of one problem into the flattened ReadInfo array (once per batch)
@@ -1960,7 +1974,10 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     // budget taken by other batches, runs launch by launch as before.
     PersistLease lease;
     int persist_rpw = 0;
-    if (ctx->k8_persistent && n_prob > 0) {
+    // (k8_persistent 2 = the library decides: a single sample's batches, when the streams have hardware queues of their own and the mode has not just failed here)
+    const bool persist_wanted = ctx->k8_persistent == 1 || (ctx->k8_persistent == 2 && n_prob <= 8 && ctx->hw_queues_effective >= 16 && ctx->k8_persist_failures < 3);
+    if (ctx->k8_persist_backoff > 0) --ctx->k8_persist_backoff;
+    else if (persist_wanted && n_prob > 0) {
         uint64_t blocks1 = 0; bool small = true;
         for (uint32_t p = 0; p < n_prob; ++p) {
             const uint32_t n = probs[p].read_idx ? probs[p].n : probs[p].reads->n;
@@ -2128,6 +2145,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     }
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cons_control_kernel<MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)proc_lds));
     uint64_t pairs = 0;
+    bool persist_ran = false;                                           // the batch's two persistent kernels were launched (and may be running)
     hm.mark("host:k8_prologue");
     double t_launch = 0.0;                                              // host time inside the launch calls (sp_profile_get "host:k8_launch": several host threads share the runtime's launch path)
     {
@@ -2156,18 +2174,50 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
             if (!h_ready) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "sp_consensus ready word");
             *(volatile uint32_t*)h_ready = 0;
             { void* dp = nullptr; SP_HIP_CHECK(ctx, hipHostGetDevicePointer(&dp, h_ready, 0)); B.ready = (uint32_t*)dp; }
+            B.step_cap = (uint32_t)std::min<uint64_t>(limit, 0xFFFFFFFFull);
+            // from here on two kernels may be running: whatever goes wrong, both streams are waited for before this function returns (the lease and the pooled buffers
+            // go back to other batches when it does)
+            auto drain = [&]() { (void)hipStreamSynchronize(ctx->ctl_stream); (void)hipStreamSynchronize(st); };
             hipLaunchKernelGGL(cons_control_persist_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, ctx->ctl_stream, B);
-            {   // (a control workgroup that finds no CU within two seconds: the step workgroups are launched all the same, the batch then ends on its own time-out)
+            bool all_ready = true;
+            {   // a control workgroup takes a whole CU: on a device whose CUs are held by others (another process's batches, which this process's lease cannot see) some
+                // of them never start.  Then the batch is given up HERE -- the abort word ends the ones that did start -- and run launch by launch below, and the context
+                // keeps away from the mode for a while
                 const auto t_wait = std::chrono::steady_clock::now();
                 while (*(volatile uint32_t*)h_ready < n_prob) {
                     __builtin_ia32_pause();
-                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() > 2.0) break;
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() > PERSIST_READY_S) { all_ready = false; break; }
                 }
             }
-            hipLaunchKernelGGL(cons_step_persist_kernel<MAXP>, grid, block, 0, st, B);
-            SP_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->ctl_stream));
-            SP_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
-            finished = true;
+            if (all_ready) {
+                hipLaunchKernelGGL(cons_step_persist_kernel<MAXP>, grid, block, 0, st, B);
+                const hipError_t e1 = hipGetLastError();
+                const hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ctx->ev_join, ctx->ctl_stream) : e1;
+                const hipError_t e3 = e2 == hipSuccess ? hipStreamWaitEvent(st, ctx->ev_join, 0) : e2;
+                if (e3 != hipSuccess) {
+                    const uint32_t one = 1;                    // end the control workgroups (and any step workgroup that started), then wait for both streams
+                    if (!ctx->copy_stream) (void)hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+                    if (ctx->copy_stream) { (void)hipMemcpyAsync(B.sync + 4 * n_prob, &one, 4, hipMemcpyHostToDevice, ctx->copy_stream); (void)hipStreamSynchronize(ctx->copy_stream); }
+                    drain();
+                    return sp_fail(ctx, SP_ERR_HIP, std::string("sp_consensus: persistent launch: ") + hipGetErrorString(e3));
+                }
+                finished = true; persist_ran = true;
+            } else {
+                const uint32_t one = 1;
+                if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { drain(); return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: copy stream"); }
+                (void)hipMemcpyAsync(B.sync + 4 * n_prob, &one, 4, hipMemcpyHostToDevice, ctx->copy_stream);
+                (void)hipStreamSynchronize(ctx->copy_stream);
+                (void)hipStreamSynchronize(ctx->ctl_stream);                       // the control workgroups that had started have seen the word (they poll it) and ended
+                lease.give_back();
+                ctx->k8_persist_failures += 1; ctx->k8_persist_backoff = 64;
+                ctx->warning = "persistent consensus kernels: the control workgroups of a batch found no free CUs within " + std::to_string(PERSIST_READY_S) +
+                               " s (another process on this device?): the batch ran launch by launch, and so will the next 64";
+                // the same batch as a launch pair per step: nothing has run yet but `ready` counts and abort marks
+                (void)hipMemsetAsync(B.sync, 0, sizeof(uint32_t) * (4 * (size_t)n_prob + 1), st);
+                std::memset(h_prog, 0, sizeof(uint32_t) * 2 * n_prob);
+                B.sync = nullptr; B.ready = nullptr;
+                persist_rpw = 0;
+            }
         }
         while (!finished) {
             const auto tl0 = std::chrono::steady_clock::now();
@@ -2198,18 +2248,23 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
             if (!finished && pairs >= limit) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the search did not finish");
         }
     }
-    SP_HIP_CHECK(ctx, hipGetLastError());
+    // (with persistent kernels under way an error below still waits for both streams before it returns: the lease and the pooled buffers are other batches' the moment it does)
+#define SP_K8_CHECK(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) { if (persist_ran) { (void)hipStreamSynchronize(ctx->ctl_stream); (void)hipStreamSynchronize(st); } \
+        return sp_fail(ctx, SP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    SP_K8_CHECK(hipGetLastError());
     hm.mark("host:k8_loop");
     if (ctx->profiling) { auto& e = ctx->prof["host:k8_launch"]; e.ms += t_launch; e.launches += (uint32_t)(2 * pairs); }
     hipLaunchKernelGGL(cons_finalize_kernel<MAXP>, dim3((uint32_t)n_blocks * CWAVES), dim3(SP_WAVE), 0, st, B, d_is1, d_sc, d_sc + total);
-    SP_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    SP_K8_CHECK(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     const uint8_t* h_is1 = h_out + out_is1; const int32_t* h_sc = (const int32_t*)(h_out + out_sc); const ConsRes* h_res = (const ConsRes*)(h_out + out_res);
-    SP_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    SP_HIP_CHECK(ctx, hipGetLastError());
+    SP_K8_CHECK(hipStreamSynchronize(st));
+    SP_K8_CHECK(hipGetLastError());
+#undef SP_K8_CHECK
     lease.give_back();
-    if (persist_rpw) {
+    if (persist_ran) {
         for (uint32_t p = 0; p < n_prob; ++p) {
-            if (h_prog[2 * p + 1] == 2u) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the persistent kernels of a batch waited for each other for more than four seconds and gave up");
+            if (h_prog[2 * p + 1] == 2u) { ctx->k8_persist_failures += 1; ctx->k8_persist_backoff = 64; return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the persistent kernels of a batch waited for each other for more than four seconds and gave up"); }
+            if (h_prog[2 * p + 1] == 3u) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the search did not finish");
             pairs = std::max<uint64_t>(pairs, h_prog[2 * p]);
         }
         ctx->prof["cons_persistent_batches"].cells += 1;

@@ -95,8 +95,12 @@ struct sp_ctx {
     int k1_best_n = 5;                   // sp_ctx_set_option "k1_best_n": K1 base-aligns the chains minimap2's seeding and chaining select (best_n secondaries per read, the reference's 5);
                                          // 0 = every allele of every anchored gene (the exhaustive argmin of rounds 1-4)
     int mm2_rescore = 1;                 // sp_ctx_set_option "mm2_rescore": the entry points that return mappings also report them re-scored with the reference's affine scores (mm2_* fields)
-    bool k8_persistent = false;          // sp_ctx_set_option "k8_persistent" (or SP_K8_PERSISTENT=1): small consensus batches run as two persistent kernels instead of a launch pair per
-                                         // step.  Off by default: the agent-scope release / acquire fences of every hand-over cost what the kernel boundaries cost (measured)
+    int k8_persistent = 2;               // sp_ctx_set_option "k8_persistent" (or SP_K8_PERSISTENT): small consensus batches as two persistent kernels instead of a launch pair per step.
+                                         // 0 never, 1 whenever a batch fits, 2 (default) the library decides: a single sample's batches (<= 8 problems) when the process's streams
+                                         // have hardware queues of their own (hw_queues_effective >= 16) and the mode has not just failed on this context
+    int hw_queues_effective = 0;         // what the HIP runtime was initialised with: GPU_MAX_HW_QUEUES as it stood when HIP came up (0: HIP was up before the library could look, and the variable was not set)
+    int k8_persist_backoff = 0;          // batches that still go the launch-pair way after the control workgroups of a persistent batch found no CUs; k8_persist_failures counts those events
+    int k8_persist_failures = 0;
     sp_seqset* uploading = nullptr;      // the one upload a context has in flight (the staging buffers are the context's)
     int k5_block_pairs = 4096;       // sp_ctx_set_option "k5_block_pairs": up to this many chain pairs K5 runs one workgroup per pair (0: always one thread per pair)
     int cyp_cohort_min_group = 12;   // sp_ctx_set_option "cyp_cohort_min_group": a stream is only added when it leaves this many samples per stream
