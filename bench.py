@@ -314,6 +314,13 @@ def chain_pair_leg(pkg, ctx, n_d6=4, n_reads=1000, reps=2):
 class VariantPanel:
     """the variant genes of the bundled database as K6 problems (sp_variant_gene_problem builds the haplotype side); the observed side of a
     synthetic sample is written straight into the integer arrays the kernel reads"""
+    _shared = None
+
+    @classmethod
+    def shared(cls, pkg):
+        if cls._shared is None:
+            cls._shared = cls(pkg)
+        return cls._shared
 
     def __init__(self, pkg):
         D = pkg.database
@@ -479,7 +486,7 @@ class CohortShare:
 
 def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, barrier, max_over_ranks, cdb_source=None, ctx_device=0):
     from pb_starphase_amd import shard
-    panel = VariantPanel(pkg)
+    panel = VariantPanel.shared(pkg)          # (one panel per process: the cached samples' problems point into its arrays)
     mine = shard.partition(args.cohort_samples, world, rank)
     # samples per cohort call: a rank's whole share (the calls keep groups of samples in lockstep, and the larger the groups the fewer launches a sample costs:
     # 256 samples in calls of 32 / 64 / 128 / 256: 170 / 201 / 257 / 280 samples/s on one GPU)
@@ -561,13 +568,17 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
                         "sp_cyp_diplotype_cohort -> sp_variant_solve_batch -> one gather of the call records"}
 
 
-def streams_block(pkg, fx, db, ctx, cfg, gene_def, locus, scen, device_index, rank, world, steps, reads, cyp_reads, barrier, max_over_ranks):
+def streams_block(pkg, fx, db, ctx, cfg, gene_def, locus, scen, device_index, rank, world, steps, reads, cyp_reads, barrier, max_over_ranks, own_device=True):
     """the second block of the N > 1 line: every rank its own stream of the headline's samples (one sample per step, both loci, a new upload every step, the six CYP2D6 scenarios
-    in turn), nothing exchanged -- `value` = all ranks' reads / the slowest rank's time between the barriers (weak scaling by independent samples; launch pairs, not persistent kernels)"""
+    in turn), nothing exchanged -- `value` = all ranks' reads / the slowest rank's time between the barriers (weak scaling by independent samples).  The CYP2D6 consensus runs in the
+    library's own choice of mode (k8_persistent auto) when the rank has its device to itself, as launch pairs when ranks share a device (two processes' persistent batches would wait
+    for each other's CUs)"""
     samples = [HlaSample(pkg, fx, reads, 1000 + rank + 100 * k) for k in range(2)]
     cyp_samples = [CypSample(pkg, locus, scen[k], cyp_reads, 7 + k) for k in range(len(scen))]
     ctx_c = pkg.Context(device_index)
     cdb_c = pkg.ffi.CypDb(ctx_c, cfg, gene_def, locus.sequence, locus.start)
+    if not own_device:
+        ctx_c.set_option("k8_persistent", 0)
     genes = list(range(len(fx.genes)))
     ok = [0, 0]
 
@@ -695,17 +706,17 @@ def main():
         blocks = {}
         if world > 1 and not args.no_extra_legs:
             # (a) the same cohort on ONE GPU (rank 0 alone, the others wait): what the N ranks' value is to be held against; (b) the ranks' independent streams of samples
-            try:
-                if rank == 0:
+            if rank == 0:
+                try:
                     one_args = argparse.Namespace(**vars(args)); one_args.steps, one_args.warmup = 1, 1
-                    solo = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, 1, 0, None, one_args, lambda: (torch.cuda.synchronize(), ctx.synchronize()), lambda d: d, (cfg, gene_def), device_index)
+                    solo = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, 1, 0, shard.SoloGroup(), one_args, lambda: (torch.cuda.synchronize(), ctx.synchronize()), lambda d: d, (cfg, gene_def), device_index)
                     blocks["one_gpu_same_cohort"] = {"value": solo["value"], "samples_per_s": solo["samples_per_s"], "ms_per_step": solo["ms_per_step"],
                                                      "value_over_n_times_this": line["value"] / (world * solo["value"])}
-                barrier()
-                blocks["independent_streams"] = streams_block(pkg, fx, db, ctx, cfg, gene_def, locus, scen, device_index, rank, world, min(args.steps, 6), args.reads, args.cyp_reads,
-                                                              barrier, max_over_ranks)
-            except Exception as e:                                                  # (second blocks, not the line's value: say so and go on -- all ranks fail or pass alike up to here)
-                blocks["error"] = str(e)
+                except Exception as e:                                              # (a second block, not the line's value: say so and go on; no collective inside)
+                    blocks["error"] = "one_gpu_same_cohort: " + str(e)
+            barrier()
+            blocks["independent_streams"] = streams_block(pkg, fx, db, ctx, cfg, gene_def, locus, scen, device_index, rank, world, min(args.steps, 6), args.reads, args.cyp_reads,
+                                                          barrier, max_over_ranks, own_device=(backend == "nccl"))
         if rank == 0:
             out = {"metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)", "value": line["value"], "unit": "reads/s", "n_gpus": world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": line["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

@@ -43,6 +43,14 @@ class TorchGroup:
         return out.reshape((self.n_ranks,) + rec.shape)
 
 
+class SoloGroup:
+    """one rank on its own inside a larger job (nothing exchanged): what a rank passes to keep a call off the process group"""
+    n_ranks, rank = 1, 0
+
+    def gather(self, records):
+        return np.ascontiguousarray(records)[None]
+
+
 def make_group(ctx, ffi, backend="nccl", device=None):
     """The group a rank gathers through.  `nccl`: an sp_group of the library (librccl, ncclAllGather on the context's stream); its 128-byte
     id is made by rank 0 and handed out through the process group the launcher set up.  Anything else: the torch group."""

@@ -33,26 +33,42 @@ def test_sample_line_and_two_rank_cohort_over_gloo():
     assert one["concordance"]["hla_diplotypes_equal_truth"] == "2/2 genes" and one["concordance"]["cyp2d6_call_equals_truth"] is True
     assert one["upload"]["per_step_bytes"] > 5_000_000 and one["upload"]["alone"]["bam4"]["GBps"] > 0
     for n in (1, 2):
-        line = run_bench(["--gpus", str(n), "--steps", "1", "--warmup", "1", "--workload", "cohort", "--cohort-samples", "8"],
-                         env={"SP_BENCH_BACKEND": "gloo"})
+        line = run_bench(["--gpus", str(n), "--steps", "1", "--warmup", "1", "--cohort-samples", "8", "--reads", "1500", "--cyp-reads", "300"] + (["--workload", "cohort"] if n == 1 else []),
+                         env={"SP_BENCH_BACKEND": "gloo"})              # (N > 1: the cohort is the default workload)
         assert line["n_gpus"] == n and line["scaling"] == "strong" and line["metric"] == one["metric"] and line["value"] > 0
         c = line["cohort"]
         assert c["samples"] == 8 and c["records_gathered_per_pass"] == 8 * (2 + 1 + 18)              # HLA-A, HLA-B, CYP2D6, 18 variant genes per sample
         assert c["calls_equal_truth"]["hla"] == "16/16" and c["calls_equal_truth"]["cyp2d6"] == "8/8"
         assert c["calls_equal_truth"]["variant_genes_truth_among_reported"] == "144/144"
         assert c["samples_per_s"] > 0 and c["rank0_host_seconds_per_pass"]["cyp2d6"] > 0
+        if n == 2:
+            # the second blocks of the N > 1 line: the same cohort on rank 0 alone, and the ranks' independent streams of samples (weak scaling, nothing exchanged)
+            assert line["second_blocks_error"] is None, line["second_blocks_error"]
+            assert line["one_gpu_same_cohort"]["value"] > 0 and line["one_gpu_same_cohort"]["value_over_n_times_this"] > 0
+            st = line["independent_streams"]
+            assert st["scaling"] == "weak" and st["value"] > 0 and st["cyp2d6_calls_equal_truth_rank0"].split("/")[0] == st["cyp2d6_calls_equal_truth_rank0"].split("/")[1]
     # shares that differ by one sample (7 samples over 2 ranks: 4 + 3): every record arrives once, every call equals the truth
-    line = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "cohort", "--cohort-samples", "7"], env={"SP_BENCH_BACKEND": "gloo"})
+    line = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--cohort-samples", "7", "--no-extra-legs"], env={"SP_BENCH_BACKEND": "gloo"})
     c = line["cohort"]
     assert c["samples"] == 7 and c["records_gathered_per_pass"] == 7 * (2 + 1 + 18)
     assert c["calls_equal_truth"]["hla"] == "14/14" and c["calls_equal_truth"]["cyp2d6"] == "7/7"
 
 
+def test_eight_rank_cohort_of_sixteen_samples_over_gloo():
+    """the round-end scaling run's shape on one device: `bench.py --gpus 8` with a 16-sample cohort, two samples per rank, the records of all eight ranks in rank 0's table"""
+    line = run_bench(["--gpus", "8", "--steps", "1", "--warmup", "1", "--cohort-samples", "16", "--no-extra-legs"], env={"SP_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["value"] > 0
+    c = line["cohort"]
+    assert c["samples"] == 16 and c["records_gathered_per_pass"] == 16 * (2 + 1 + 18)
+    assert c["calls_equal_truth"]["hla"] == "32/32" and c["calls_equal_truth"]["cyp2d6"] == "16/16"
+    assert c["calls_equal_truth"]["variant_genes_truth_among_reported"] == "288/288"
+
+
 def test_two_ranks_each_with_its_own_stream_of_samples():
-    """`bench.py --gpus 2` (the default workload at every N): each rank runs the headline's stream of samples -- its own samples, both loci, a new upload every step --, the
+    """`bench.py --gpus 2 --workload sample`: each rank runs the headline's stream of samples -- its own samples, both loci, a new upload every step --, the
     ranks meet at the barriers around the timed steps, `value` is the sum over the ranks and rank 0 prints the one line.  Two ranks share device 0 here (gloo for the
     barrier and the maximum; launch pairs: two processes' persistent batches would wait for each other's CUs on one device)."""
-    two = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "1500", "--cyp-reads", "300", "--no-cpu-baseline"],
+    two = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "1500", "--cyp-reads", "300", "--no-cpu-baseline", "--workload", "sample"],
                     env={"SP_BENCH_BACKEND": "gloo", "SP_BENCH_HEADLINE_PERSISTENT": "0"})
     assert two["n_gpus"] == 2 and two["steps"] == 2 and two["scaling"] == "weak" and two["metric"] == "HiFi reads/sec diplotyped (HLA+CYP2D6)"
     assert two["config"]["parallelism"].startswith("2 GPUs") and two["config"]["cyp2d6_consensus"].startswith("a launch pair per step")
