@@ -48,20 +48,10 @@ COUNTER_DIR = os.path.join(ROOT, "profiles", "r05")
 
 
 def cyp_persistent():
-    """SP_BENCH_CYP_PERSISTENT=1: the contexts that run CYP2D6 consensus chains use the library's persistent consensus kernels (sp_ctx_set_option "k8_persistent": all
-    workgroups of a batch resident, hand-overs through memory instead of a launch pair per step).  Off by default here as in the library: the chain itself is a third faster
-    beside the HLA half (cons_steps 27 -> 19.5 ms) but the resident workgroups take the CUs from everything else, and the line as a whole does not move (headline +1.5 %,
-    cohort -7 %: profiles/r04/k8_persistent_coherent_ab.txt)."""
-    return int(os.environ.get("SP_BENCH_CYP_PERSISTENT", "0"))
-
-
-def headline_persistent():
-    """SP_BENCH_HEADLINE_PERSISTENT (default 1): the headline's CYP2D6 context runs its consensus chains as persistent kernels (sp_ctx_set_option "k8_persistent").  In this
-    pipeline -- one process per GPU, a dozen streams, 16 hardware queues -- the mode's condition holds (every stream of the process on a hardware queue of its own), and the
-    step is 8-11 % faster (profiles/r04/k8_persistent_final.txt).  Where it does not hold the library ends the batch after four seconds with an error: the warm-up steps would
-    show that, and the run then goes on with a launch pair per step and says so in config.cyp2d6_consensus.  The other legs (cohort, samples in flight: many streams) and every
-    run under a profiler that serialises kernels (profiles/run_rocprof.sh sets 0) use launch pairs."""
-    return int(os.environ.get("SP_BENCH_HEADLINE_PERSISTENT", "1"))
+    """what the legs' contexts that run CYP2D6 consensus chains set "k8_persistent" to: 2 = the library's own choice (its default: persistent kernels for a single sample's
+    batches when the process's streams have hardware queues of their own, a launch pair per step for the wide batches of a cohort call); SP_BENCH_CYP_PERSISTENT=0 / 1 forces
+    launch pairs / persistent kernels"""
+    return int(os.environ.get("SP_BENCH_CYP_PERSISTENT", "2"))
 
 
 def spawn_ranks(n, argv):
@@ -212,27 +202,41 @@ def same_allele(fx, a, b):
 class Lane(threading.Thread):
     """one locus of the stream of samples on a context of its own: wait for this sample's bytes, start the next sample's upload, compute"""
 
-    def __init__(self, pkg, ctx, payloads, work, steps, fresh_upload=True):
+    def __init__(self, pkg, ctx, payloads, work, steps, fresh_upload=True, tickets=None):
         super().__init__()
         self.pkg, self.ctx, self.payloads, self.work, self.steps, self.fresh = pkg, ctx, payloads, work, steps, fresh_upload
         self.result, self.error = None, None
-        self.pending = self.start_upload(0) if fresh_upload else None
+        # tickets: several lanes of one locus share the stream of samples -- a lane takes the next sample's number when it starts that sample's upload
+        self.tickets = tickets if tickets is not None else Tickets(steps)
+        self.pending = self.start_upload(self.tickets.take()) if fresh_upload else None
         self.resident = None if fresh_upload else [ctx.upload_format(pkg.ffi.SP_SEQ_BAM4, *p) for p in payloads]
 
     def start_upload(self, i):
+        if i is None:
+            return None
         blob, offs, lens = self.payloads[i % len(self.payloads)]
-        return self.ctx.upload_format(self.pkg.ffi.SP_SEQ_BAM4, blob, offs, lens, wait=False)
+        return (i, self.ctx.upload_format(self.pkg.ffi.SP_SEQ_BAM4, blob, offs, lens, wait=False))
+
+    def wait_first(self):
+        if self.pending is not None:
+            self.pending[1].wait()
 
     def run(self):
         try:
-            for i in range(self.steps):
+            while True:
                 if self.fresh:
+                    if self.pending is None:
+                        break
                     t_u = time.perf_counter()
-                    cur = self.pending.wait()
+                    i, up = self.pending
+                    cur = up.wait()
                     t_v = time.perf_counter()
-                    self.pending = self.start_upload(i + 1)          # the next sample's bytes travel under this sample's kernels
+                    self.pending = self.start_upload(self.tickets.take())    # the next sample's bytes travel under this sample's kernels
                     self.t_wait = getattr(self, "t_wait", 0.0) + (t_v - t_u); self.t_start = getattr(self, "t_start", 0.0) + (time.perf_counter() - t_v)
                 else:
+                    i = self.tickets.take()
+                    if i is None:
+                        break
                     cur = self.resident[i % len(self.resident)]
                 t_w = time.perf_counter()
                 self.result = self.work(cur, i)
@@ -240,11 +244,45 @@ class Lane(threading.Thread):
                 if self.fresh:
                     cur.close()
                 self.t_work = getattr(self, "t_work", 0.0) + (t_c - t_w); self.t_close = getattr(self, "t_close", 0.0) + (time.perf_counter() - t_c)
-            if self.fresh:
-                self.pending.wait().close()
-                self.pending = None
         except Exception as e:                                      # surfaces in the main thread
             self.error = e
+
+
+class Tickets:
+    """the numbers 0 .. steps - 1, handed out once each to the lanes that share them"""
+
+    def __init__(self, steps):
+        self.n, self.next, self.lock = steps, 0, threading.Lock()
+
+    def take(self):
+        with self.lock:
+            if self.next >= self.n:
+                return None
+            self.next += 1
+            return self.next - 1
+
+
+class ContextGroup:
+    """the contexts of the lanes of one locus, read as one: option settings go to all of them, profile records add up"""
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+
+    def set_option(self, name, value):
+        for c in self.ctxs:
+            c.set_option(name, value)
+
+    def profile_reset(self):
+        for c in self.ctxs:
+            c.profile_reset()
+
+    def synchronize(self):
+        for c in self.ctxs:
+            c.synchronize()
+
+    def profile_get(self, name):
+        rows = [c.profile_get(name) for c in self.ctxs]
+        return tuple(sum(r[k] for r in rows) for k in range(3))
 
 
 def run_lanes(lanes):
@@ -535,7 +573,7 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     dt = max_over_ranks(time.perf_counter() - t0)
     # what a rank's share costs by its size (one GPU): the share a rank holds at N = 8 / 4 / 2 of a 256-sample cohort, each in one pass after a warm-up pass
     by_share = None
-    if world == 1 and getattr(args, "cohort_shares", False) and mine:
+    if world == 1 and (getattr(args, "cohort_shares", False) or os.environ.get("SP_BENCH_COHORT_SHARES")) and mine:
         by_share = {}
         for n_sh in (32, 64, 128):
             if n_sh >= len(mine):
@@ -596,7 +634,7 @@ def streams_block(pkg, fx, db, ctx, cfg, gene_def, locus, scen, device_index, ra
     ok[0] = ok[1] = 0
     ls = lanes(steps)
     for x in ls:
-        x.pending.wait()
+        x.wait_first()
     barrier(); ctx_c.synchronize()
     t0 = time.perf_counter()
     run_lanes(ls)
@@ -620,6 +658,7 @@ def main():
     ap.add_argument("--workload", choices=("auto", "sample", "cohort"), default="auto",
                     help="auto: at N = 1 the sample (one sample per step, both loci: BASELINE configs[1] + configs[2]); at N > 1 the cohort (BASELINE configs[4]: 256 samples sharded over "
                          "the ranks, the call records gathered through sp_gather_results over RCCL), with the ranks' independent streams of samples as a second block of the line")
+    ap.add_argument("--cyp-lanes", type=int, default=4, help="CYP2D6 samples in flight beside the HLA half of the stream (contexts that share the stream of CYP2D6 samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-hla-reads", type=int, default=5000, help="HLA reads of sample 0 the CPU leg runs (0: all of them)")
     ap.add_argument("--cpu-cyp-reads", type=int, default=1000, help="reads of every CYP2D6 scenario of the mix the CPU leg runs (0: all of them)")
@@ -738,10 +777,24 @@ def main():
         return
 
     # ------------------------------------------------------------------------------------------------ the sample: HLA-A / -B + CYP2D6, a new one every step
-    ctx_c = pkg.Context(device_index)                       # the CYP2D6 half runs beside the HLA half on a context (stream, pools) of its own
-    cdb_c = pkg.ffi.CypDb(ctx_c, cfg, gene_def, locus.sequence, locus.start)
-    headline_mode = {"persistent": bool(headline_persistent() or cyp_persistent()), "fallback": None}
-    ctx_c.set_option("k8_persistent", 1 if headline_mode["persistent"] else 0)     # the CYP2D6 chain as persistent kernels: this process has the device to itself
+    # the CYP2D6 half runs beside the HLA half on contexts (stream, pools) of its own: `--cyp-lanes` of them share the stream of CYP2D6 samples (a lane takes the next sample
+    # when it is free).  One CYP2D6 sample is a chain of a few hundred dependent consensus steps that keeps a fraction of the device busy (critical_path below); two of them in
+    # flight fill the time the HLA half of a step takes
+    n_cyp_lanes = max(1, args.cyp_lanes)
+    prio_streams = []
+    if os.environ.get("SP_BENCH_CYP_PRIORITY"):             # (an experiment switch: the CYP2D6 contexts on high-priority streams the caller hands to sp_ctx_create)
+        import ctypes
+        prio_streams = [torch.cuda.Stream(device=device_index, priority=-1) for _ in range(n_cyp_lanes)]
+        cyp_ctxs = [pkg.Context(device_index, ctypes.c_void_p(st_.cuda_stream)) for st_ in prio_streams]
+    else:
+        cyp_ctxs = [pkg.Context(device_index) for _ in range(n_cyp_lanes)]
+    cyp_dbs = [pkg.ffi.CypDb(c, cfg, gene_def, locus.sequence, locus.start) for c in cyp_ctxs]
+    ctx_c = ContextGroup(cyp_ctxs)                         # (the group reads the list: lanes a leg adds later count)
+    # the consensus mode is the library's own choice (k8_persistent 2 = auto, the default of every context); SP_BENCH_HEADLINE_PERSISTENT = 0 / 1 forces launch pairs / persistent kernels
+    forced = os.environ.get("SP_BENCH_HEADLINE_PERSISTENT")
+    headline_mode = {"persistent": forced != "0", "fallback": None, "forced": forced}
+    if forced is not None:
+        ctx_c.set_option("k8_persistent", int(forced))
     if os.environ.get("SP_BENCH_MM2_RESCORE"):              # (an experiment switch: what the re-scored numbers of K1 / K2 cost the step)
         ctx.set_option("mm2_rescore", int(os.environ["SP_BENCH_MM2_RESCORE"]))
     if os.environ.get("SP_BENCH_HLA_SPLIT"):                # (an experiment switch: the two HLA genes of the sample on one stream (0) or two (1, the library's default))
@@ -761,13 +814,15 @@ def main():
         if headline_mode["persistent"] and os.environ.get("SP_BENCH_INJECT_FAILURE"):       # (a test of the fall-back below: profiles/scripts/r04_run67.sh)
             raise RuntimeError("injected failure of the persistent mode")
         t_ = time.perf_counter()
-        call, _cons, _labels = cdb_c.diplotype(R)
+        call, _cons, _labels = cyp_dbs[cyp_ctxs.index(R.ctx)].diplotype(R)
         last["cyp"] = (i, call)
         cyp_log.append((i, i % len(cyp_samples), call.hap1.decode(), call.hap2.decode(), time.perf_counter() - t_))
         return call
 
-    def make_lanes(steps, fresh=True):
-        return [Lane(pkg, ctx, [s.payload for s in samples], hla_work, steps, fresh), Lane(pkg, ctx_c, [s.payload for s in cyp_samples], cyp_work, steps, fresh)]
+    def make_lanes(steps, fresh=True, n_lanes=None):
+        shared = Tickets(steps)
+        return [Lane(pkg, ctx, [s.payload for s in samples], hla_work, steps, fresh)] + [Lane(pkg, c, [s.payload for s in cyp_samples], cyp_work, steps, fresh, tickets=shared)
+                                                                                          for c in cyp_ctxs[:n_lanes if n_lanes else n_cyp_lanes]]
 
     def agree(failed):
         """has the persistent mode failed on ANY rank?  (one all-reduce: the ranks switch to launch pairs together instead of one of them raising and the others waiting at a barrier)"""
@@ -795,7 +850,7 @@ def main():
         del cyp_log[:]
         lanes = make_lanes(args.steps)                      # (sample 0's bytes start travelling here: the pipeline is full when the clock starts)
         for x in lanes:
-            x.pending.wait()
+            x.wait_first()
         barrier(); ctx_c.synchronize()
         t0 = time.perf_counter()
         run_lanes(lanes)
@@ -812,6 +867,7 @@ def main():
         ctx_c.set_option("k8_persistent", 0)
         lanes, dt = timed_region()
     reads_per_step = samples[0].n + cyp_samples[0].n        # (every scenario has the same number of reads)
+    line_value = world * reads_per_step * args.steps / dt
     timed_cyp = list(cyp_log)
     mix = {}
     for _i, k, h1, h2, sec in timed_cyp:
@@ -853,6 +909,8 @@ def main():
         return out
     crit = {"kernel": "cons_step_kernel + cons_control_kernel (K8, the consensus search)", "cyp2d6": critical_path(ctx_c), "hla": critical_path(ctx)}
     batches_per_step = ctx_c.profile_get("cons_persistent_batches")[2] / max(1, args.steps)
+    if headline_mode["persistent"] and batches_per_step == 0:
+        headline_mode["persistent"] = False                 # (the library chose launch pairs: its condition for the persistent kernels does not hold in this process)
     cons = {k: ctx.profile_get(n)[2] / max(1, args.steps) for k, n in (("launch_triples_per_step", "cons_windows"), ("cut_windows_per_step", "cons_cut_windows"),
                                                                          ("expansions_per_step", "cons_expansions"), ("nodes_expanded_per_step", "cons_columns"))}
     host_ms = {k: ctx.profile_get("host:" + k)[0] / max(1, args.steps) for k in ("hla_segments", "hla_dual_hpc", "hla_groups", "hla_typing", "k8_loop", "k1_total", "hla_genes_total")}
@@ -880,7 +938,7 @@ def main():
 
     legs = {}
     other_leg = "headline_with_launch_pairs" if headline_mode["persistent"] else "headline_with_persistent_consensus"
-    if not args.no_extra_legs and not cyp_persistent() and headline_mode["fallback"] is None:
+    if not args.no_extra_legs and headline_mode["fallback"] is None:
         # the headline's step once more in the other consensus mode of the CYP2D6 context (sp_ctx_set_option "k8_persistent"): the same samples, uploads and calls.
         # (persistent kernels need every stream of the process on a hardware queue of its own and fail with an error, after a four-second time-out, where it is not --
         #  which is reported here instead of raised)
@@ -890,7 +948,7 @@ def main():
             ctx_c.profile_reset()
             lanes_p = make_lanes(args.steps)
             for x in lanes_p:
-                x.pending.wait()
+                x.wait_first()
             ctx_c.synchronize(); ctx.synchronize()
             t1 = time.perf_counter()
             run_lanes(lanes_p)
@@ -945,42 +1003,29 @@ def main():
         ctx.set_option("k1_best_n", 5)
         Rk.close()
         legs["k1_modes"] = k1
-        # throughput mode: K whole samples (both loci) in flight at once, each locus of each sample on a context of its own; same uploads, same calls.  The
-        # headline is ONE sample's latency chain (the CYP2D6 consensus: small launches that wait for one another); this is what the GPU does when a host
-        # keeps several samples going
+        # the same stream of samples with other numbers of CYP2D6 lanes (CYP2D6 samples in flight beside the HLA lane): one lane = a step is one locus's latency chain
+        # (rounds 3-4's headline); more lanes = the chains of several samples fill the device's idle time until the HLA lane bounds the step
+        lane_table = {str(n_cyp_lanes): {"value": line_value, "ms_per_step": 1e3 * dt / args.steps}}
         try:
-            K = 3
-            extra = []
-            for k in range(1, K):
-                ch, cc = pkg.Context(device_index), pkg.Context(device_index)
-                ch.set_option("hla_split_genes", 0); cc.set_option("hla_split_genes", 0); cc.set_option("k8_persistent", cyp_persistent())
-                extra.append((ch, fx.make_db(pkg, ch), cc, pkg.ffi.CypDb(cc, cfg, gene_def, locus.sequence, locus.start)))
-            ctx.set_option("hla_split_genes", 0); ctx_c.set_option("hla_split_genes", 0)
-
-            def flight_lanes(steps):
-                ls = make_lanes(steps)
-                for ch, dbh, cc, dbc in extra:
-                    hw = (lambda dbh: lambda R, i: dbh.diplotype_genes(genes, R, dbh.realign_reads(R))[0])(dbh)
-                    cw = (lambda dbc: lambda R, i: dbc.diplotype(R)[0])(dbc)
-                    ls += [Lane(pkg, ch, [s_.payload for s_ in samples], hw, steps, True), Lane(pkg, cc, [s_.payload for s_ in cyp_samples], cw, steps, True)]
-                return ls
-            run_lanes(flight_lanes(1))
-            fl = flight_lanes(args.steps)
-            for x in fl:
-                x.pending.wait()
-            ctx.synchronize()
-            t1 = time.perf_counter()
-            run_lanes(fl)
-            for ch, _d, cc, _c in extra:
-                ch.synchronize(); cc.synchronize()
-            ctx.synchronize(); ctx_c.synchronize()
-            d_fl = time.perf_counter() - t1
-            legs["samples_in_flight"] = {"samples_in_flight": K, "value": K * reads_per_step * args.steps / d_fl, "unit": "reads/s", "ms_per_sample": 1e3 * d_fl / (K * args.steps),
-                                         "workload": "the headline's sample (HLA-A/-B 10,000 reads + CYP2D6 2,000 reads, upload included), three of them in flight on six contexts"}
-            ctx.set_option("hla_split_genes", 1); ctx_c.set_option("hla_split_genes", 1)
-            del extra
+            for n_l in (1, 2, 4):
+                if str(n_l) in lane_table:
+                    continue
+                while len(cyp_ctxs) < n_l:
+                    cyp_ctxs.append(pkg.Context(device_index)); cyp_dbs.append(pkg.ffi.CypDb(cyp_ctxs[-1], cfg, gene_def, locus.sequence, locus.start))
+                    ctx_c.ctxs = cyp_ctxs
+                run_lanes(make_lanes(1, n_lanes=n_l))
+                fl = make_lanes(args.steps, n_lanes=n_l)
+                for x in fl:
+                    x.wait_first()
+                ctx.synchronize(); ctx_c.synchronize()
+                t1 = time.perf_counter()
+                run_lanes(fl)
+                ctx.synchronize(); ctx_c.synchronize()
+                d_fl = time.perf_counter() - t1
+                lane_table[str(n_l)] = {"value": reads_per_step * args.steps / d_fl, "ms_per_step": 1e3 * d_fl / args.steps}
+            legs["cyp2d6_lanes"] = dict(lane_table, unit="reads/s", note="the headline's stream of samples with 1 / 2 / 4 CYP2D6 samples in flight beside the HLA lane (`--cyp-lanes`; the headline's own entry is the line's value)")
         except Exception as e:                                                  # (a leg, not the headline: say so and go on)
-            legs["samples_in_flight"] = {"error": str(e)}
+            legs["cyp2d6_lanes"] = {"error": str(e)}
         legs["cyp2d6"] = cyp_leg(pkg, ctx, cdb, locus)
         legs["k5_chain_pairs"] = chain_pair_leg(pkg, ctx)
         co_args = argparse.Namespace(**vars(args)); co_args.steps, co_args.warmup, co_args.cohort_shares = 1, 1, True
@@ -1036,9 +1081,12 @@ def main():
                    "cyp2d6_mix": mix,
                    "reads_per_step": reads_per_step, "hla_reads": samples[0].n, "cyp2d6_reads": cyp_samples[0].n, "alleles": len(fx.ids),
                    "parallelism": ("one GPU: " if world == 1 else "%d GPUs, one process each with its own stream of samples (no exchange; `value` = all ranks' reads / the slowest rank's time); per GPU: " % world) +
-                                  "the two loci side by side on two contexts (host threads, HIP streams), uploads on copy streams",
-                   "cyp2d6_consensus": ("persistent kernels (sp_ctx_set_option k8_persistent = 1 on the CYP2D6 context: two launches per batch, hand-overs through memory; SP_BENCH_HEADLINE_PERSISTENT=0 for launch pairs)"
-                                        if headline_mode["persistent"] else "a launch pair per step" + ("" if headline_mode["fallback"] is None else " (the persistent kernels failed here: %s)" % headline_mode["fallback"]))},
+                                  "the two loci side by side on contexts of their own (host threads, HIP streams): one HLA lane, %d CYP2D6 lane(s) sharing the stream of CYP2D6 samples "
+                                  "(`--cyp-lanes`: that many CYP2D6 samples in flight, each a latency chain of dependent consensus steps); uploads on copy streams" % n_cyp_lanes,
+                   "cyp2d6_lanes": n_cyp_lanes,
+                   "cyp2d6_consensus": ("persistent kernels (%s: two launches per batch, hand-overs through memory; SP_BENCH_HEADLINE_PERSISTENT=0 for launch pairs)"
+                                        % ("the library's own choice, k8_persistent = 2 (auto), the default of every context" if forced is None else "forced by SP_BENCH_HEADLINE_PERSISTENT=" + forced)
+                                        if headline_mode["persistent"] and batches_per_step > 0 else "a launch pair per step" + ("" if headline_mode["fallback"] is None else " (the persistent kernels failed here: %s)" % headline_mode["fallback"]))},
         "roofline": roof,
         "stale_counter_files": stale or None,
         "kernel_ms": {"hla": kernel_ms, "cyp2d6": cyp_kernel_ms}, "host_wall_ms": {"hla": host_ms, "cyp2d6": cyp_host_ms, "lanes_hla_cyp2d6": lane_ms},
@@ -1049,7 +1097,7 @@ def main():
         "upload": {"per_step_bytes": int(len(samples[0].payload[0]) + len(cyp_samples[0].payload[0])), "alone": t_up,
                    "note": "inside `value` every step uploads a new sample (4-bit SEQ bytes, sp_seqset_upload_async); `alone` = one synchronous upload of the HLA half"},
         "legs": legs or None,
-        "context": dict(ctx.info(), cyp2d6_contexts_k8_persistent=cyp_persistent()),          # sp_ctx_get_info: the hardware queues the streams of the run were mapped onto (this script exports GPU_MAX_HW_QUEUES=16 before torch initialises HIP)
+        "context": dict(ctx.info(), legs_k8_persistent=cyp_persistent()),          # sp_ctx_get_info: the hardware queues the streams of the run were mapped onto (this script exports GPU_MAX_HW_QUEUES=16 before torch initialises HIP)
     }
     if cb is not None:
         # the GPU on exactly the reads the CPU leg saw: the calls of the two have to be the same, for both loci

@@ -639,6 +639,10 @@ template <class BT> __device__ __forceinline__ uint32_t block_word(const BT& B, 
 constexpr int WRAMP0 = SP_K8_WRAMP0;           // first window of a node born in an expansion (most such nodes are dropped after a few columns: a 256-column window costs its slowest read 4 x as long)
 constexpr int BULK_MARGIN_PLACED = 2;  // the same right behind the column that placed the read (its states have only the catch-up's edits yet)
 constexpr int BULK_MARGIN = 8;         // edits a read's worse state must be behind the better one to go through a window ahead of it (a state that close may draw level)
+#ifndef SP_K8_AUTO_BATCHES
+#define SP_K8_AUTO_BATCHES 1
+#endif
+constexpr int PERSIST_AUTO_BATCHES = SP_K8_AUTO_BATCHES;
 constexpr int DIRECT_BLOCKS = 128;      // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
 
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B, int block) {
@@ -927,10 +931,16 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         int want_bulk = BULK_MARGIN;                                         // > 0: at the head of the loop, send the worse state ahead if it is that many edits behind
         int j = 0;
 #ifdef SP_K8_TIMING
-        int slow_cols = 0, multi_tip = 0, zero_run = 0;
-        long long tb_fast = 0, tb_col = 0, tb_vote = 0, tb_mark = 0;
+        int slow_cols = 0, multi_tip = 0, zero_run = 0, fast_iters = 0;
+        long long tb_fast = 0, tb_col = 0, tb_vote = 0, tb_mark = 0, tb_bulk = 0;
+#ifdef SP_K8_DBG_PARTS
+        const long long tb_pre = wall_clock64() - wt0;                       // (parts build: everything on the 100 MHz wall clock)
+#define K8_T0() tb_mark = wall_clock64()
+#define K8_T(acc) do { const long long _n = wall_clock64(); acc += _n - tb_mark; tb_mark = _n; } while (0)
+#else
 #define K8_T0() tb_mark = clock64()
 #define K8_T(acc) do { const long long _n = clock64(); acc += _n - tb_mark; tb_mark = _n; } while (0)
+#endif
 #else
 #define K8_T0() do { } while (0)
 #define K8_T(acc) do { } while (0)
@@ -938,6 +948,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         while (j < n) {
             // (one place for it: at the start of the window, and behind the column that placed the read -- its wrong state would otherwise cost a slow
             //  column every few bases until the window ends)
+            K8_T0();
             if (want_bulk > 0) {
                 const int margin = want_bulk; want_bulk = 0;
                 if (!quiet && mode == M_WINDOW && dualrun && go0 && go1 && n - j >= 8 && (d0.flags & F_ACTIVE) && (d1.flags & F_ACTIVE) &&
@@ -952,7 +963,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
                     }
                 }
             }
-            K8_T0();
+            K8_T(tb_bulk);
             // A consensus whose state has ONE tip that keeps matching moves nothing but that tip: such a clean run is applied in one go
             // (the tip's position grows by m, the votes of the m columns are the m read bases behind it, one lane per column).
             int m = n - j;
@@ -1016,6 +1027,9 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
                 }
                 j += m;
                 K8_T(tb_fast);
+#ifdef SP_K8_TIMING
+                fast_iters += 1;
+#endif
                 continue;
             }
             K8_T(tb_fast);
@@ -1080,12 +1094,24 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         }
         spw::wave_lds_sync();
 #ifdef SP_K8_TIMING
+#ifdef SP_K8_DBG_PARTS
+        if (!quiet && B.dbg && lane == 0 && Wp->pad < SP_K8_DBG_LAUNCHES / 2 && g < SP_K8_DBG_READS) {
+#else
         if (!quiet && B.dbg && lane == 0 && Wp->pad < SP_K8_DBG_LAUNCHES && g < SP_K8_DBG_READS) {
+#endif
             const unsigned long long dt = (unsigned long long)(wall_clock64() - wt0);
             const unsigned long long placed = ri.off > T && ri.off <= T + n;
             // [launch][read]: ticks (24 bits, 100 MHz) | slow columns (9) | multi-tip events (9) | a late read was placed (1) | mode (2) | window bases (9) | column pushes, clock64 / 1024 (10)
             auto cl = [](long long v, long long cap) { return (unsigned long long)(v > cap ? cap : v); };
-#ifdef SP_K8_DBG_EDITS
+#ifdef SP_K8_DBG_PARTS
+            // (variant: two words per read.  The second: where the wave's time went, 20 ns units -- loads in front of the loop (10 bits) / clean runs (12) / column pushes (12) /
+            //  votes (12) / the worse state sent ahead (12) / clean-run iterations (6))
+            B.dbg[((size_t)Wp->pad * SP_K8_DBG_READS + g) * 2] = cl((long long)dt, 0xFFFFFF) | (cl(slow_cols, 511) << 24) | (cl(multi_tip, 511) << 33) | (placed << 42) | ((unsigned long long)mode << 43) |
+                                                            (cl(n, 511) << 45);
+            B.dbg[((size_t)Wp->pad * SP_K8_DBG_READS + g) * 2 + 1] = cl(tb_pre >> 1, 1023) | (cl(tb_fast >> 1, 4095) << 10) | (cl(tb_col >> 1, 4095) << 22) | (cl(tb_vote >> 1, 4095) << 34) |
+                                                            (cl(tb_bulk >> 1, 4095) << 46) | (cl(fast_iters, 63) << 58);
+            (void)tb_pre;
+#elif defined(SP_K8_DBG_EDITS)
             // (variant: the edit counts of the two states instead of the multi-tip events and the column-push clocks)
             // (variant: where a placement's time goes instead of the multi-tip events and the column-push clocks: start search and catch-up, 0.32 us units;
             //  staging + packing in the slow-column field)
@@ -1095,7 +1121,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
             B.dbg[(size_t)Wp->pad * SP_K8_DBG_READS + g] = cl((long long)dt, 0xFFFFFF) | (cl(slow_cols, 511) << 24) | (cl(multi_tip, 511) << 33) | (placed << 42) | ((unsigned long long)mode << 43) |
                                                             (cl(n, 511) << 45) | (cl(tb_col >> 10, 1023) << 54);
 #endif
-            (void)tb_fast; (void)tb_vote;
+            (void)tb_fast; (void)tb_vote; (void)tb_bulk; (void)fast_iters;
         }
 #endif
         };
@@ -1150,6 +1176,13 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
                 if (kdual) store(e1, kn, 0, 1);
             }
             spw::wave_lds_sync();
+#ifdef SP_K8_DBG_PARTS
+            if (B.dbg && lane == 0 && Wp->pad < SP_K8_DBG_LAUNCHES / 2 && g < SP_K8_DBG_READS) {
+                const unsigned long long dt = (unsigned long long)(wall_clock64() - wt0);
+                B.dbg[((size_t)Wp->pad * SP_K8_DBG_READS + g) * 2] = (dt > 0xFFFFFF ? 0xFFFFFFull : dt) | ((unsigned long long)(n_kids > 511 ? 511 : n_kids) << 24) | (3ull << 43) | ((unsigned long long)(pre > 511 ? 511 : pre) << 45);
+                B.dbg[((size_t)Wp->pad * SP_K8_DBG_READS + g) * 2 + 1] = 0;
+            }
+#endif
             continue;
         }
 
@@ -1941,8 +1974,8 @@ struct PersistLease {
     int device = -1, taken = 0;
     static std::atomic<int>& used(int device) { static std::atomic<int> u[64]; return u[device & 63]; }
     static std::atomic<int>& batches(int device) { static std::atomic<int> b[64]; return b[device & 63]; }
-    bool take(int dev, int budget, int want) {
-        if (batches(dev).fetch_add(1) >= PERSIST_MAX_BATCHES) { batches(dev).fetch_sub(1); return false; }
+    bool take(int dev, int budget, int want, int max_batches) {
+        if (batches(dev).fetch_add(1) >= max_batches) { batches(dev).fetch_sub(1); return false; }
         std::atomic<int>& u = used(dev);
         int cur = u.load();
         while (cur + want <= budget) if (u.compare_exchange_weak(cur, cur + want)) { device = dev; taken = want; return true; }
@@ -1974,8 +2007,18 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     // budget taken by other batches, runs launch by launch as before.
     PersistLease lease;
     int persist_rpw = 0;
-    // (k8_persistent 2 = the library decides: a single sample's batches, when the streams have hardware queues of their own and the mode has not just failed here)
-    const bool persist_wanted = ctx->k8_persistent == 1 || (ctx->k8_persistent == 2 && n_prob <= 8 && ctx->hw_queues_effective >= 16 && ctx->k8_persist_failures < 3);
+    // consensus batches of this process under way on the device (this one included from here on)
+    struct InFlight {
+        int dev;
+        static std::atomic<int>& count(int d) { static std::atomic<int> c[64]; return c[d & 63]; }
+        explicit InFlight(int d) : dev(d) { others = count(dev).fetch_add(1); }
+        ~InFlight() { count(dev).fetch_sub(1); }
+        int others;
+    } in_flight(ctx->device);
+    // (k8_persistent 2 = the library decides: a single sample's batches, when the streams have hardware queues of their own, the mode has not just failed here AND no other
+    //  consensus batch of the process is under way on the device -- resident workgroups are a third faster for a chain that has the device to itself and take the CUs from
+    //  everything that runs beside them: with four CYP2D6 samples in flight a launch pair per step made 292-303k reads/s of bench.py's stream, one persistent batch at a time 272k)
+    const bool persist_wanted = ctx->k8_persistent == 1 || (ctx->k8_persistent == 2 && n_prob <= 8 && ctx->hw_queues_effective >= 16 && ctx->k8_persist_failures < 3 && in_flight.others == 0);
     if (ctx->k8_persist_backoff > 0) --ctx->k8_persist_backoff;
     else if (persist_wanted && n_prob > 0) {
         uint64_t blocks1 = 0; bool small = true;
@@ -1985,13 +2028,16 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
             small = small && nb <= (uint32_t)DIRECT_BLOCKS;
             blocks1 += nb;
         }
-        int budget = 2 * std::max(0, ctx->num_cus - 32); const int ctl = 2 * (int)n_prob;
+        constexpr int WG_PER_CU = SP_K8_MIN_WAVES * 4 / CWAVES;             // step workgroups a CU holds at the kernel's register budget
+        int budget = WG_PER_CU * std::max(0, ctx->num_cus - 32); const int ctl = 2 * (int)n_prob;
         { const char* e = std::getenv("SP_K8_BUDGET"); if (e && *e) budget = std::atoi(e); }
         if (small && ctl < budget) {
             for (int scale = 1; scale <= 4 && !persist_rpw; ++scale) {
                 uint64_t nb = 0;
                 for (uint32_t p = 0; p < n_prob; ++p) { const uint32_t n = probs[p].read_idx ? probs[p].n : probs[p].reads->n; nb += (n + CWAVES * scale - 1) / (CWAVES * scale); }
-                if ((int64_t)nb + ctl <= budget && lease.take(ctx->device, budget, (int)nb + ctl)) persist_rpw = scale;
+                // (the library's own choice, k8_persistent 2: one persistent batch per device at a time -- the resident workgroups of two would take the CUs the other's and
+                //  everybody else's kernels need; a second batch in flight runs as launch pairs in the gaps of the first)
+                if ((int64_t)nb + ctl <= budget && lease.take(ctx->device, budget, (int)nb + ctl, ctx->k8_persistent == 2 ? PERSIST_AUTO_BATCHES : PERSIST_MAX_BATCHES)) persist_rpw = scale;
                 else if ((int64_t)nb + ctl <= budget) break;                       // it would fit, but the budget is taken right now
             }
         }

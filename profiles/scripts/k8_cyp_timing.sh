@@ -2,7 +2,7 @@
 # what the slowest wave of every window launch was doing
 SC=${1:-3}
 rm -f gpurun_out/k8_dump.bin
-SP_K8_DUMP=$PWD/gpurun_out/k8_dump.bin SP_LIB_PATH=$PWD/build/variants/lib_timing.so python profiles/scripts/cyp_kernels.py $SC 2>&1 | grep -E "total ms|cons_steps"
+SP_K8_PERSISTENT=0 SP_K8_DUMP=$PWD/gpurun_out/k8_dump.bin SP_LIB_PATH=$PWD/build/variants/lib_timing.so python profiles/scripts/cyp_kernels.py $SC 2>&1 | grep -E "total ms|cons_steps"
 python - <<'PY'
 import numpy as np
 R, L = 4096, 1024
