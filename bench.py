@@ -659,6 +659,7 @@ def main():
                     help="auto: at N = 1 the sample (one sample per step, both loci: BASELINE configs[1] + configs[2]); at N > 1 the cohort (BASELINE configs[4]: 256 samples sharded over "
                          "the ranks, the call records gathered through sp_gather_results over RCCL), with the ranks' independent streams of samples as a second block of the line")
     ap.add_argument("--cyp-lanes", type=int, default=4, help="CYP2D6 samples in flight beside the HLA half of the stream (contexts that share the stream of CYP2D6 samples)")
+    ap.add_argument("--hla-lanes", type=int, default=1, help="HLA samples in flight (contexts that share the stream of HLA samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-hla-reads", type=int, default=5000, help="HLA reads of sample 0 the CPU leg runs (0: all of them)")
     ap.add_argument("--cpu-cyp-reads", type=int, default=1000, help="reads of every CYP2D6 scenario of the mix the CPU leg runs (0: all of them)")
@@ -780,7 +781,10 @@ def main():
     # the CYP2D6 half runs beside the HLA half on contexts (stream, pools) of its own: `--cyp-lanes` of them share the stream of CYP2D6 samples (a lane takes the next sample
     # when it is free).  One CYP2D6 sample is a chain of a few hundred dependent consensus steps that keeps a fraction of the device busy (critical_path below); two of them in
     # flight fill the time the HLA half of a step takes
-    n_cyp_lanes = max(1, args.cyp_lanes)
+    n_cyp_lanes, n_hla_lanes = max(1, args.cyp_lanes), max(1, args.hla_lanes)
+    hla_ctxs = [ctx] + [pkg.Context(device_index) for _ in range(n_hla_lanes - 1)]
+    hla_dbs = [db] + [fx.make_db(pkg, c) for c in hla_ctxs[1:]]
+    ctx_h = ContextGroup(hla_ctxs)
     prio_streams = []
     if os.environ.get("SP_BENCH_CYP_PRIORITY"):             # (an experiment switch: the CYP2D6 contexts on high-priority streams the caller hands to sp_ctx_create)
         import ctypes
@@ -803,8 +807,9 @@ def main():
     last = {}
 
     def hla_work(R, i):
-        o = db.realign_reads(R)
-        calls = db.diplotype_genes(genes, R, o)[0]
+        db_ = hla_dbs[hla_ctxs.index(R.ctx)]
+        o = db_.realign_reads(R)
+        calls = db_.diplotype_genes(genes, R, o)[0]
         last["hla"] = (i, o, calls)
         return calls
 
@@ -820,8 +825,8 @@ def main():
         return call
 
     def make_lanes(steps, fresh=True, n_lanes=None):
-        shared = Tickets(steps)
-        return [Lane(pkg, ctx, [s.payload for s in samples], hla_work, steps, fresh)] + [Lane(pkg, c, [s.payload for s in cyp_samples], cyp_work, steps, fresh, tickets=shared)
+        shared, shared_h = Tickets(steps), Tickets(steps)
+        return [Lane(pkg, c, [s.payload for s in samples], hla_work, steps, fresh, tickets=shared_h) for c in hla_ctxs] + [Lane(pkg, c, [s.payload for s in cyp_samples], cyp_work, steps, fresh, tickets=shared)
                                                                                           for c in cyp_ctxs[:n_lanes if n_lanes else n_cyp_lanes]]
 
     def agree(failed):
@@ -846,15 +851,15 @@ def main():
             sys.stderr.write("bench: persistent consensus kernels failed (%s): the headline runs with a launch pair per step\n" % headline_mode["fallback"])
             ctx_c.set_option("k8_persistent", 0)
             run_lanes(make_lanes(max(1, args.warmup)))
-        ctx.profile_reset(); ctx_c.profile_reset()
+        ctx_h.profile_reset(); ctx_c.profile_reset()
         del cyp_log[:]
         lanes = make_lanes(args.steps)                      # (sample 0's bytes start travelling here: the pipeline is full when the clock starts)
         for x in lanes:
             x.wait_first()
-        barrier(); ctx_c.synchronize()
+        barrier(); ctx_c.synchronize(); ctx_h.synchronize()
         t0 = time.perf_counter()
         run_lanes(lanes)
-        barrier(); ctx_c.synchronize()
+        barrier(); ctx_c.synchronize(); ctx_h.synchronize()
         return lanes, max_over_ranks(time.perf_counter() - t0)
     try:
         lanes, dt = timed_region()
@@ -882,7 +887,7 @@ def main():
 
     e2e_names = ("anchor_k1", "k1s_seeds", "k1s_groups", "k1s_dp", "k1s_dp_big", "k1s_select", "k1s_cells", "k1s_af_trace", "k1s_af_dp", "anchor_k2", "anchor_type", "k1_finalize", "cons_steps", "type_consensus_ref",
                  "k2_cells_cdna", "k2_cells_dna", "k2_scan")
-    kernel_ms = {k: ctx.profile_get(k)[0] / max(1, args.steps) for k in e2e_names}
+    kernel_ms = {k: ctx_h.profile_get(k)[0] / max(1, args.steps) for k in e2e_names}
     cyp_kernel_ms = {k: ctx_c.profile_get(k)[0] / max(1, args.steps) for k in ("cons_steps", "k5_pairs", "k9_graph")}
 
     def critical_path(c):
@@ -907,13 +912,13 @@ def main():
         out["note"] = ("the chain is latency bound: every step is step body -> control body -> next step body; as a launch pair per step each arrow is a dependent same-stream "
                        "kernel boundary (MI355X_MICROARCH.md: 1.45 us on an idle device), in persistent mode a write-through store + drain + flag and a poll (handoff-flag: 1.3-5 us)")
         return out
-    crit = {"kernel": "cons_step_kernel + cons_control_kernel (K8, the consensus search)", "cyp2d6": critical_path(ctx_c), "hla": critical_path(ctx)}
+    crit = {"kernel": "cons_step_kernel + cons_control_kernel (K8, the consensus search)", "cyp2d6": critical_path(ctx_c), "hla": critical_path(ctx_h)}
     batches_per_step = ctx_c.profile_get("cons_persistent_batches")[2] / max(1, args.steps)
     if headline_mode["persistent"] and batches_per_step == 0:
         headline_mode["persistent"] = False                 # (the library chose launch pairs: its condition for the persistent kernels does not hold in this process)
-    cons = {k: ctx.profile_get(n)[2] / max(1, args.steps) for k, n in (("launch_triples_per_step", "cons_windows"), ("cut_windows_per_step", "cons_cut_windows"),
+    cons = {k: ctx_h.profile_get(n)[2] / max(1, args.steps) for k, n in (("launch_triples_per_step", "cons_windows"), ("cut_windows_per_step", "cons_cut_windows"),
                                                                          ("expansions_per_step", "cons_expansions"), ("nodes_expanded_per_step", "cons_columns"))}
-    host_ms = {k: ctx.profile_get("host:" + k)[0] / max(1, args.steps) for k in ("hla_segments", "hla_dual_hpc", "hla_groups", "hla_typing", "k8_loop", "k1_total", "hla_genes_total")}
+    host_ms = {k: ctx_h.profile_get("host:" + k)[0] / max(1, args.steps) for k in ("hla_segments", "hla_dual_hpc", "hla_groups", "hla_typing", "k8_loop", "k1_total", "hla_genes_total")}
     cyp_host_ms = {k: ctx_c.profile_get("host:cyp_" + k)[0] / max(1, args.steps) for k in ("regions", "segments", "consensus", "merge", "typing", "weights", "chains", "chain_pair")}
     cyp_host_ms["k8"] = {k: [round(ctx_c.profile_get("host:k8_" + k)[0] / max(1, args.steps), 2), ctx_c.profile_get("host:k8_" + k)[1] // max(1, args.steps)] for k in ("prologue", "loop", "result_wait", "epilogue")}
     # the calls of the last step against the truth the reads were simulated from
@@ -1081,9 +1086,9 @@ def main():
                    "cyp2d6_mix": mix,
                    "reads_per_step": reads_per_step, "hla_reads": samples[0].n, "cyp2d6_reads": cyp_samples[0].n, "alleles": len(fx.ids),
                    "parallelism": ("one GPU: " if world == 1 else "%d GPUs, one process each with its own stream of samples (no exchange; `value` = all ranks' reads / the slowest rank's time); per GPU: " % world) +
-                                  "the two loci side by side on contexts of their own (host threads, HIP streams): one HLA lane, %d CYP2D6 lane(s) sharing the stream of CYP2D6 samples "
-                                  "(`--cyp-lanes`: that many CYP2D6 samples in flight, each a latency chain of dependent consensus steps); uploads on copy streams" % n_cyp_lanes,
-                   "cyp2d6_lanes": n_cyp_lanes,
+                                  "the two loci side by side on contexts of their own (host threads, HIP streams): %d HLA lane(s), %d CYP2D6 lane(s) sharing the stream of CYP2D6 samples "
+                                  "(`--hla-lanes`, `--cyp-lanes`: that many samples of the locus in flight; a CYP2D6 sample is a latency chain of dependent consensus steps); uploads on copy streams" % (n_hla_lanes, n_cyp_lanes),
+                   "cyp2d6_lanes": n_cyp_lanes, "hla_lanes": n_hla_lanes,
                    "cyp2d6_consensus": ("persistent kernels (%s: two launches per batch, hand-overs through memory; SP_BENCH_HEADLINE_PERSISTENT=0 for launch pairs)"
                                         % ("the library's own choice, k8_persistent = 2 (auto), the default of every context" if forced is None else "forced by SP_BENCH_HEADLINE_PERSISTENT=" + forced)
                                         if headline_mode["persistent"] and batches_per_step > 0 else "a launch pair per step" + ("" if headline_mode["fallback"] is None else " (the persistent kernels failed here: %s)" % headline_mode["fallback"]))},

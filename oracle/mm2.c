@@ -957,8 +957,11 @@ int32_t omm_hla_k1_seeded(const omm_index* idx, const uint8_t* q, int32_t qlen, 
         if (h.ok) {
             h.cell_nm = al.nm; h.a_start = al.a_start; h.a_end = al.a_end; h.b_start = al.b_start; h.b_end = al.b_end;
             const int twice = (al.b_start - al.a_start) + (al.b_end - al.a_end);
+            /* an alignment whose ends lie more than 32 diagonals apart crosses a long insertion / deletion (the cell found it on the wide band): its re-score runs on 256
+             * diagonals -- minimap2 chains and aligns across such gaps (bw 500, max_gap 10000 above), 64 diagonals would clip the alignment at the gap */
+            const int shift = (al.b_end - al.a_end) - (al.b_start - al.a_start);
             osp_affine_out af;
-            osp_affine_local(tseq, tlen, qc, qlen, twice / 2, 64, &ao, &af);
+            osp_affine_local(tseq, tlen, qc, qlen, twice / 2, (shift > 32 || shift < -32) ? 256 : 64, &ao, &af);
             h.dp_max = af.score; h.nm = af.nm; h.t_start = af.t_start; h.t_end = af.t_end;
             if (h.rev) { h.q_start = qlen - af.q_end; h.q_end = qlen - af.q_start; } else { h.q_start = af.q_start; h.q_end = af.q_end; }
         }

@@ -386,7 +386,7 @@ __global__ void af_scatter_kernel(const sp_affine_aln* __restrict__ part, const 
 // the mappings of cells (WFA orientation: Aw streamed, Bw window; d_ref = the alignments the caller holds) re-scored into d_out (a_* on minimap2's query, b_* on its target:
 // target_is_a tells which of the two sets is the target); everything stays on the device
 int sp_rescore_mappings(sp_ctx* ctx, const sp_seqset* Aw, const sp_seqset* Bw, const CellDesc* d_cells, const sp_aln* d_ref, uint64_t n, bool target_is_a,
-                        const sp_affine_opts& o, int band, sp_affine_aln* d_out, const char* prefix, uint32_t stride) {
+                        const sp_affine_opts& o, int band, sp_affine_aln* d_out, const char* prefix, uint32_t stride, int trace_retry_wide) {
     if (n == 0) return SP_OK;
     const std::string pre(prefix);
     static std::mutex names_lock; static std::set<std::string> names;                 // (the profiler keeps the pointers it is given)
@@ -401,7 +401,7 @@ int sp_rescore_mappings(sp_ctx* ctx, const sp_seqset* Aw, const sp_seqset* Bw, c
     if (!d_tr || !d_ev || !d_todo || !d_at || !d_part || !d_win || !d_mid) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "rescore buffers");
     uint32_t* d_n = d_at + n;
     (void)hipMemsetAsync(d_n, 0, 4, ctx->stream);
-    int rc = sp_launch_cells(ctx, Aw, Bw, d_cells, n, d_tr, d_ev, stride, stable(pre + "_trace"), 0);
+    int rc = sp_launch_cells(ctx, Aw, Bw, d_cells, n, d_tr, d_ev, stride, stable(pre + "_trace"), trace_retry_wide);
     if (rc != SP_OK) return rc;
     hipLaunchKernelGGL(af_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cells, d_ref, d_tr, d_ev, stride, (uint32_t)n, target_is_a ? 1 : 0,
                        (Aw->has_n || Bw->has_n) ? 1 : 0, o, d_out, d_todo, d_at, d_n, d_win, d_mid, band, ctx->mm2_rescore == 2 ? 0 : 1);

@@ -462,6 +462,16 @@ void* sp_host_pool(sp_ctx* ctx, const char* name, size_t bytes) {
     return e.first;
 }
 
+// only the wide-band pass of sp_launch_cells (untraced): every listed cell whose entry of d_out is not found yet runs on 256 diagonals; cells without a diagonal are skipped
+int sp_launch_cells_wide(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const CellDesc* d_cells, uint64_t n_cells, sp_aln* d_out) {
+    if (n_cells == 0) return SP_OK;
+    const uint64_t wblocks = std::min<uint64_t>((n_cells + 3) / 4, (uint64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL((sp_cells_wide_kernel<false>), dim3((unsigned)wblocks), dim3(256), 0, ctx->stream, A->view(), B->view(), d_cells, n_cells, d_out, (uint32_t*)nullptr, 0u,
+                       (uint16_t*)nullptr, SP_MAX_ED + 1, 1);
+    SP_HIP_CHECK(ctx, hipGetLastError());
+    return SP_OK;
+}
+
 int sp_slot_words(const sp_seqset* A, const sp_seqset* B, bool hasn) {
     int mn = std::min(A->max_len, B->max_len);
     int w = (mn + SP_BAND + 30) / 16 + 3;

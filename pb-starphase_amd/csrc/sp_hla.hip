@@ -474,6 +474,65 @@ __device__ __forceinline__ int hpc_pos_wave(const uint32_t* __restrict__ w, int 
     return cnt;
 }
 
+// the end of realign_record once the segment is mapped to the gene's reference (realigner.rs:262-331): the segment's bounds and the DNA / HPC offsets.  One wavefront.
+__device__ __forceinline__ void k1_finish_segment(sp_hla_realign& res, int rm_ok, int rm_nm, int rm_a_start, int rm_a_end, int rm_b_start, int rm_b_end, int buf_start, int reflen,
+                                                  int a, uint32_t g, int bm_a_start, const SeqSetView& alleles_gene, const int32_t* __restrict__ am,
+                                                  const int32_t* __restrict__ hpc_ref, const uint64_t* __restrict__ hpc_ref_off, int lane) {
+    // select_best_mapping(target-based, penalised): must beat the 1.0 default (util/mapping.rs:22-57)
+    if (!(rm_ok && score_value(reflen, rm_nm, reflen - (rm_a_end - rm_a_start)) < 1.0)) return;
+    const int db_start = res.aln.b_start, db_end = res.aln.b_end;
+    const int adj_start = buf_start + rm_b_start, adj_end = buf_start + rm_b_end;
+    res.seg_start = db_start < adj_start ? db_start : adj_start;
+    res.seg_end = db_end > adj_end ? db_end : adj_end;
+    const int32_t* hp = hpc_ref + hpc_ref_off[g];
+    int d, h;
+    if (adj_start < db_start || !am[a * 3 + 0]) {
+        d = rm_a_start; h = hp[d];
+    } else {
+        int added = am[a * 3 + 2] - am[a * 3 + 1]; if (added < 0) added = 0;
+        d = added + bm_a_start;
+        const uint32_t* gw = alleles_gene.words + alleles_gene.word_off[a];
+        h = hp[added < reflen ? added : reflen] + hpc_pos_wave(gw, alleles_gene.len[a], bm_a_start, lane);
+    }
+    res.dna_offset = d; res.hpc_offset = h;
+    res.status = 0;
+}
+
+// Seeded mode (the reference's call pattern): a segment whose 64-diagonal cell against the gene's reference found nothing -- a read with a 40+ base insertion or
+// deletion against the reference, which minimap2 chains across -- is run again on the wide band (sp_cells_wide_kernel), like the chains' own cells.
+// k1_seg_retry_cells_kernel lists those reads' cells (the others: no cell), k1_seg_retry_finish_kernel completes their records.
+__global__ void k1_seg_retry_cells_kernel(const sp_hla_realign* __restrict__ out, uint32_t n_reads, const int32_t* __restrict__ read_len, const int32_t* __restrict__ d_rg, int n_genes,
+                                          CellDesc* __restrict__ cells, sp_aln* __restrict__ alns) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    CellDesc c; c.a = 0; c.b = r; c.diag = SP_NO_DIAG; c.max_ed = SP_MAX_ED; c.b_lo = 0; c.b_hi = -1;
+    const sp_hla_realign o = out[r];
+    if (o.status == 3 && o.best_allele >= 0 && o.aln.ok) {
+        const int rlen = read_len[r], buffer = 1000;
+        const int buf_start = o.aln.b_start > buffer ? o.aln.b_start - buffer : 0;
+        const int buf_end = o.aln.b_end + buffer < rlen ? o.aln.b_end + buffer : rlen;
+        c.a = (uint32_t)o.gene; c.b_lo = buf_start; c.b_hi = buf_end;
+        c.diag = d_rg[(uint64_t)r * n_genes + o.gene] - buf_start;
+    }
+    cells[r] = c;
+    sp_aln z; memset(&z, 0, sizeof z);
+    alns[r] = z;
+}
+__global__ __launch_bounds__(256) void k1_seg_retry_finish_kernel(SeqSetView alleles_gene, SeqSetView refs, const int32_t* __restrict__ am, const int32_t* __restrict__ hpc_ref,
+                                                                  const uint64_t* __restrict__ hpc_ref_off, const CellDesc* __restrict__ cells, const sp_aln* __restrict__ alns,
+                                                                  uint32_t n_reads, sp_hla_realign* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * 4 + wave;
+    if (r >= n_reads) return;
+    const CellDesc c = cells[r];
+    if (c.diag == SP_NO_DIAG) return;
+    const sp_aln rm = alns[r];
+    if (!rm.ok) return;
+    sp_hla_realign res = out[r];
+    k1_finish_segment(res, rm.ok, rm.nm, rm.a_start, rm.a_end, rm.b_start, rm.b_end, c.b_lo, refs.len[c.a], res.best_allele, c.a, res.aln.a_start, alleles_gene, am, hpc_ref, hpc_ref_off, lane);
+    if (lane == 0 && res.status == 0) out[r] = res;
+}
+
 // K1 finalize: one wavefront per read: full alignment of the accepted allele, segment +-1000 against the
 // gene reference, offsets (realigner.rs:219-331).
 template <bool HASN>
@@ -530,24 +589,7 @@ __global__ __launch_bounds__(256) void k1_finalize_kernel(SeqSetView alleles_fwd
             in2.diag = drg - buf_start; in2.max_ed = SP_MAX_ED;
             spw::CellOut rm;
             spw::wfa_cell<false, HASN>(in2, slot, slot_words, lane, nullptr, nullptr, rm);
-            // select_best_mapping(target-based, penalised): must beat the 1.0 default (util/mapping.rs:22-57)
-            if (rm.ok && score_value(reflen, rm.nm, reflen - (rm.a_end - rm.a_start)) < 1.0) {
-                const int adj_start = buf_start + rm.b_start, adj_end = buf_start + rm.b_end;
-                res.seg_start = db_start < adj_start ? db_start : adj_start;
-                res.seg_end = db_end > adj_end ? db_end : adj_end;
-                const int32_t* hp = hpc_ref + hpc_ref_off[g];
-                int d, h;
-                if (adj_start < db_start || !am[a * 3 + 0]) {
-                    d = rm.a_start; h = hp[d];
-                } else {
-                    int added = am[a * 3 + 2] - am[a * 3 + 1]; if (added < 0) added = 0;
-                    d = added + bm.a_start;
-                    const uint32_t* gw = alleles_gene.words + alleles_gene.word_off[a];
-                    h = hp[added < reflen ? added : reflen] + hpc_pos_wave(gw, alleles_gene.len[a], bm.a_start, lane);
-                }
-                res.dna_offset = d; res.hpc_offset = h;
-                res.status = 0;
-            }
+            k1_finish_segment(res, rm.ok, rm.nm, rm.a_start, rm.a_end, rm.b_start, rm.b_end, buf_start, reflen, a, g, bm.a_start, alleles_gene, am, hpc_ref, hpc_ref_off, lane);
         }
     }
     if (lane == 0) out[r] = res;
@@ -1180,6 +1222,20 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
                                d_best, R, d_out, slot_words, d_win_aln);
         }
         if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_finalize launch failed");
+    }
+    if (rc == SP_OK && seeded) {
+        // segments whose cell against the gene's reference left the 64-diagonal band: once more on the wide band
+        ProfScope ps(ctx, "k1_seg_retry", R);
+        CellDesc* d_sc = (CellDesc*)sp_pool(ctx, "k1_seg_cells", (size_t)R * sizeof(CellDesc));
+        sp_aln* d_sa = (sp_aln*)sp_pool(ctx, "k1_seg_alns", (size_t)R * sizeof(sp_aln));
+        if (!d_sc || !d_sa) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+        else {
+            hipLaunchKernelGGL(k1_seg_retry_cells_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, reads->d_len, d_rg, (int)G, d_sc, d_sa);
+            rc = sp_launch_cells_wide(ctx, db->ref_fwd, reads, d_sc, R, d_sa);
+            if (rc == SP_OK) hipLaunchKernelGGL(k1_seg_retry_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, db->dna_gene->view(), db->ref_fwd->view(), db->d_am, db->d_hpc_ref,
+                                                db->d_hpc_ref_off, d_sc, d_sa, R, d_out);
+            if (rc == SP_OK && hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1 segment retry launch failed");
+        }
     }
     // 3b. the winners re-scored the reference's way (two-piece affine gaps, end clipping): the numbers minimap2 reports for the read and its allele
     if (rc == SP_OK && seeded) hipLaunchKernelGGL(k1_seed_store_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, d_seed_info, d_win_af);

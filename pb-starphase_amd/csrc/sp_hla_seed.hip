@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void mz_sketch_kernel(SeqSetView S, const uint
 // seeds of a read: minimizers that occur in the index, in query order, through the occurrence filter (oracle/mm2.c collect_anchors):
 // a seed with <= mid_occ occurrences is kept; of a streak of seeds above it the `(streak length on the query) / 500` ones with the fewest
 // occurrences are kept when they have <= 4095.  seeds[]: {query end position << 1 | strand, first occurrence, occurrences, 0}
-struct SeedCounters { unsigned long long seeds, anchors; uint32_t max_anchors, max_seeds, overflow_reads, seed_overflow, rev_selected, pad; unsigned long long t[8]; };
+struct SeedCounters { unsigned long long seeds, anchors; uint32_t max_anchors, max_seeds, overflow_reads, seed_overflow, rev_selected, wide_cells; unsigned long long t[8]; };
 #ifdef SP_K1S_TIMING
 #define K1S_T(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&ctr->t[i], now_ - t_last); t_last = now_; } } while (0)
 #else
@@ -1093,14 +1093,25 @@ __global__ void k1s_cells_kernel(const SSel* __restrict__ sel, const uint32_t* _
     cells[x] = c;
 }
 // the cells of their re-score: on the diagonal the alignment lies on; a chain whose cell found nothing is not a mapping
-__global__ void k1s_rescore_cells_kernel(const CellDesc* __restrict__ cells, const sp_aln* __restrict__ alns, uint32_t n, CellDesc* __restrict__ out) {
+// the cells of the re-score (at the middle diagonal of the found alignment).  An alignment whose ends lie more than K1S_WIDE_SHIFT diagonals apart -- it crosses a long
+// insertion / deletion, the cell found it on the wide band -- is re-scored on 256 diagonals in a pass of its own (wide = 1 lists those, wide = 0 the others): minimap2
+// chains and aligns across such gaps (bw 500), the 64-diagonal band of the re-score would clip the alignment at the gap
+constexpr int K1S_WIDE_SHIFT = 32;
+__global__ void k1s_rescore_cells_kernel(const CellDesc* __restrict__ cells, const sp_aln* __restrict__ alns, uint32_t n, CellDesc* __restrict__ out, int wide, SeedCounters* __restrict__ ctr) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n) return;
     CellDesc c = cells[x];
     const sp_aln a = alns[x];
-    if (c.diag == SP_NO_DIAG || !a.ok) { c.diag = 0; c.max_ed = -1; }
+    bool is_wide = false;
+    if (c.diag != SP_NO_DIAG && a.ok) { const int shift = (a.b_end - a.a_end) - (a.b_start - a.a_start); is_wide = shift > K1S_WIDE_SHIFT || shift < -K1S_WIDE_SHIFT; }
+    if (c.diag == SP_NO_DIAG || !a.ok || is_wide != (wide != 0)) { c.diag = wide ? SP_NO_DIAG : 0; c.max_ed = -1; }
     else { c.diag = ((a.b_start - a.a_start) + (a.b_end - a.a_end)) / 2; c.max_ed = 127; }
     out[x] = c;
+    if (!wide && is_wide && ctr) atomicAdd(&ctr->wide_cells, 1u);
+}
+__global__ void k1s_merge_wide_kernel(const CellDesc* __restrict__ wide_cells, const sp_affine_aln* __restrict__ af_wide, uint32_t n, sp_affine_aln* __restrict__ af) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n && wide_cells[x].diag != SP_NO_DIAG) af[x] = af_wide[x];
 }
 // merges the reverse-strand results into the slots of the forward arrays
 __global__ void k1s_merge_rev_kernel(const SSel* __restrict__ sel, const uint32_t* __restrict__ sel_cnt, uint32_t n_reads, const sp_aln* __restrict__ aln_rev,
@@ -1442,7 +1453,7 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
     hipLaunchKernelGGL(k1s_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_sel, d_sel_cnt, R, idx->d_rid_allele, alleles->d_len, 0, d_cells);
     int rc = sp_launch_cells(ctx, alleles, reads, d_cells, NC, d_aln, nullptr, 0, "k1s_cells", 1);
     if (rc != SP_OK) return rc;
-    hipLaunchKernelGGL(k1s_rescore_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_cells, d_aln, (uint32_t)NC, d_rc);
+    hipLaunchKernelGGL(k1s_rescore_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_cells, d_aln, (uint32_t)NC, d_rc, 0, d_ctr);
     rc = sp_rescore_mappings(ctx, alleles, reads, d_rc, d_aln, NC, true, ao, 64, d_af, "k1s_af", 128);
     if (rc != SP_OK) return rc;
     // chains on the reverse strand (a read from the other strand, the homologous gene on the other strand): the same through the reads' reverse complements
@@ -1451,6 +1462,15 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
 #ifdef SP_K1S_TIMING
     fprintf(stderr, "k1s_group phases (100 MHz ticks summed over workgroups): count %llu scan %llu scatter %llu records %llu; dp kernel waves: task + load %llu, up to 8 anchors %llu, 9..26 %llu, signatures of the large %llu\n", hc.t[0], hc.t[1], hc.t[2], hc.t[3], hc.t[7], hc.t[4], hc.t[5], hc.t[6]);
 #endif
+    if (hc.wide_cells) {
+        // alignments across long insertions / deletions: their re-score on 256 diagonals (the trace on the wide band as well)
+        sp_affine_aln* d_afw = (sp_affine_aln*)sp_pool(ctx, "k1s_af_wide", NC * sizeof(sp_affine_aln));
+        if (!d_afw) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seeded K1: wide re-score");
+        hipLaunchKernelGGL(k1s_rescore_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_cells, d_aln, (uint32_t)NC, d_rc, 1, (SeedCounters*)nullptr);
+        rc = sp_rescore_mappings(ctx, alleles, reads, d_rc, d_aln, NC, true, ao, 256, d_afw, "k1s_afw", 128, 1);
+        if (rc != SP_OK) return rc;
+        hipLaunchKernelGGL(k1s_merge_wide_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_rc, d_afw, (uint32_t)NC, d_af);
+    }
     if (hc.rev_selected) {
         const size_t words = (size_t)reads->h_word_off[R] + SP_SEQ_PAD_WORDS;
         uint32_t* d_rw = (uint32_t*)sp_pool(ctx, "k1s_rev_words", words * 4);
@@ -1467,9 +1487,17 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
         hipLaunchKernelGGL(k1s_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_sel, d_sel_cnt, R, idx->d_rid_allele, alleles->d_len, 1, d_cells2);
         rc = sp_launch_cells(ctx, alleles, &rset, d_cells2, NC, d_aln2, nullptr, 0, "k1s_cells_rev", 1);
         if (rc != SP_OK) return rc;
-        hipLaunchKernelGGL(k1s_rescore_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_cells2, d_aln2, (uint32_t)NC, d_rc);
+        hipLaunchKernelGGL(k1s_rescore_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_cells2, d_aln2, (uint32_t)NC, d_rc, 0, d_ctr);
         rc = sp_rescore_mappings(ctx, alleles, &rset, d_rc, d_aln2, NC, true, ao, 64, d_af2, "k1s_af_rev", 128);
         if (rc != SP_OK) return rc;
+        {   // (the reverse strand's alignments across long gaps: whether there are any is known one round trip later; the pass is cheap when there are none)
+            sp_affine_aln* d_afw = (sp_affine_aln*)sp_pool(ctx, "k1s_af_wide", NC * sizeof(sp_affine_aln));
+            if (!d_afw) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seeded K1: wide re-score");
+            hipLaunchKernelGGL(k1s_rescore_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_cells2, d_aln2, (uint32_t)NC, d_rc, 1, (SeedCounters*)nullptr);
+            rc = sp_rescore_mappings(ctx, alleles, &rset, d_rc, d_aln2, NC, true, ao, 256, d_afw, "k1s_afw_rev", 128, 1);
+            if (rc != SP_OK) return rc;
+            hipLaunchKernelGGL(k1s_merge_wide_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_rc, d_afw, (uint32_t)NC, d_af2);
+        }
         hipLaunchKernelGGL(k1s_merge_rev_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_sel, d_sel_cnt, R, d_aln2, d_af2, d_aln, d_af);
         SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));           // (rset's vectors go out of scope: nothing of it may still be queued)
     }

@@ -110,7 +110,8 @@ class K1Tables:
         db_s, db_e = int(bm["b_start"]), int(bm["b_end"])
         buf_s, buf_e = max(db_s - 1000, 0), min(db_e + 1000, len(read))
         seg = re[buf_s:buf_e]
-        rm, _ = oracle.wfa(self.refs[g], seg, anch[g][0] - buf_s, 511, events=False)
+        # (seeded mode: a segment the 64-diagonal cell loses -- a long insertion / deletion against the reference -- runs again on the wide band, as the chains' cells do)
+        rm, _ = oracle.wfa(self.refs[g], seg, anch[g][0] - buf_s, 511, events=False, retry=1 if seeded is not None else 0)
         reflen = len(self.refs[g])
         if rm.ok and score_value(reflen, rm.nm, reflen - (rm.a_end - rm.a_start)) < 1.0:
             adj_s, adj_e = buf_s + rm.b_start, buf_s + rm.b_end

@@ -180,3 +180,45 @@ def test_full_database_reads(oracle, pkg, gpu_ctx):
     assert n_large > 100            # targets with more than 26 anchors: chained by a whole wave, the skip counter and its marks replayed
     R.close()
     db.close()
+
+
+def test_reads_with_long_indels_are_mapped_across_them(oracle, pkg, gpu_ctx, small):
+    """Reads with a 40 - 100 base deletion or insertion against their allele (minimap2 chains across such gaps: bw 500, max_gap 10000; `realign_record`,
+    src/hla/realigner.rs:116-146, therefore keeps them): the chain's cell leaves the 64-diagonal band, the library runs it -- and its re-score, and the segment's cell
+    against the gene's reference -- again on the wide band, and the read is accepted on its own allele with the statement's numbers: the whole record equals
+    oracle/mm2.c's omm_hla_k1_seeded, and the mapping spans the indel.  120 bases are more than 3 % of a 3.5 kb allele: the acceptance rule itself (:138-141) drops
+    those reads, here as in the statement"""
+    from pb_starphase_amd import synth
+    fx, db = small
+    rng = np.random.default_rng(21)
+    reads, truth, kinds = [], [], []
+    for g in range(len(fx.genes)):
+        for a in rng.choice(fx.full_length_alleles(g), 2, replace=False).tolist():
+            hap, gs = fx.haplotype(g, a)
+            base = hap[gs - 300:gs + len(fx.dna[a]) + 300]
+            for size in (40, 80, 100, 120):
+                k = int(rng.integers(len(base) // 3, 2 * len(base) // 3))
+                reads.append(base[:k] + base[k + size:]); truth.append(a); kinds.append(-size)
+                reads.append(base[:k] + "".join(rng.choice(list("ACGT"), size)) + base[k:]); truth.append(a); kinds.append(size)
+    R = gpu_ctx.upload(reads)
+    out = db.realign_reads(R)
+    exp, _aud = hx.k1_expected_seeded(oracle, fx, reads)
+    n_wide = n_dropped = 0
+    for r, e in enumerate(exp):
+        o = out[r]
+        if abs(kinds[r]) == 120 and e["status"] != 0:
+            # more than 3 % of a 3.5 kb allele: dropped by the acceptance rule (status 1); on a longer allele the segment's cell against the gene's reference may still
+            # leave the 256 diagonals around its anchor (status 3): the limit of the wide band, stated the same way in the oracle
+            assert o["status"] == e["status"] and o["best_allele"] == e["best_allele"] and (e["status"] == 3 or 120 > 0.03 * len(fx.dna[truth[r]])), (r, kinds[r], o, e)
+            n_dropped += 1
+            continue
+        assert o["status"] == e["status"] == 0 and o["best_allele"] == e["best_allele"] >= 0, (r, kinds[r], o, e)
+        assert fx.gene_of[int(o["best_allele"])] == fx.gene_of[truth[r]]
+        assert (o["nm"], o["target_len"], o["unmapped"]) == (e["nm"], e["target_len"], e["unmapped"]) and tuple(int(x) for x in o["aln"].tolist()) == e["aln"]
+        assert (o["mm2_score"], o["mm2_nm"], o["mm2_t_start"], o["mm2_t_end"], o["mm2_q_start"], o["mm2_q_end"]) == e["mm2"], (r, o, e["mm2"])
+        # the accepted mapping covers the whole allele: the indel lies inside it (NM counts its bases), the diagonal shifts by its size between the ends
+        assert o["unmapped"] == 0 and o["mm2_nm"] >= abs(kinds[r])
+        al = o["aln"]
+        n_wide += int(abs((int(al["b_start"]) - int(al["a_start"])) - (int(al["b_end"]) - int(al["a_end"]))) >= 40)
+    assert n_wide + n_dropped == len(reads) and 0 < n_dropped <= len(reads) // 4, (n_wide, n_dropped, len(reads))
+    R.close()
