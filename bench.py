@@ -167,7 +167,7 @@ def cpu_baseline(fx, hla_reads, cyp_setup, cyp_sets, n_hla=None, n_cyp=None):
              "note": "kind 'port': the reference's call pattern on minimap2's published algorithm restated in scalar C (oracle/mm2.c; minimap2 itself and its SSE kernels are "
                      "not on disk), waffle_con = oracle/consensus.c.  `cores` = the logical CPUs of the one socket the leg is pinned to; the reference itself is single-threaded "
                      "(src/cli/diplotype.rs:185-191): single_thread_value is what one thread needs for the same reads"}
-    return block, {"hla_best": best, "hla_calls": calls, "hla_done": done, "cyp": cyp_refs}
+    return block, {"hla_best": best, "hla_calls": calls, "hla_done": done, "hla_records": dict(cpu_port_seeded.G.get("records", {})), "cyp": cyp_refs}
 
 
 # ---------------------------------------------------------------------------------------------------------------- workloads
@@ -1119,6 +1119,11 @@ def main():
         agree = sum(1 for k, r in enumerate(cpu_done) if cpu_best[r][0] == int(o[k]["best_allele"]))
         gene_agree = sum(1 for k, r in enumerate(cpu_done) if cpu_best[r][0] >= 0 and int(o[k]["gene"]) == int(fx.gene_of[cpu_best[r][0]]))
         cb["hla"]["k1_same_allele_as_gpu"] = f"{agree}/{len(cpu_done)}"
+        # the whole realign_record result: status, the segment cut out of the read, its DNA / HPC offsets on the gene's reference (what the consensus stage is fed)
+        recs = cpu_ref.get("hla_records", {})
+        same_rec = sum(1 for k, r in enumerate(cpu_done) if r in recs and int(recs[r]["status"]) == int(o[k]["status"]) and (int(recs[r]["status"]) != 0 or all(
+            int(recs[r][f]) == int(o[k][f]) for f in ("seg_start", "seg_end", "dna_offset", "hpc_offset"))))
+        cb["hla"]["k1_records_identical_to_gpu"] = f"{same_rec}/{len(cpu_done)} (status; segment start / end, DNA and HPC offset of every realigned read)"
         cb["hla"]["k1_same_gene_as_gpu"] = f"{gene_agree}/{len(cpu_done)}"
         cyp_same, cyp_sets_gpu = True, []
         for name, creads, cres in cpu_ref["cyp"]:

@@ -476,11 +476,10 @@ __device__ __forceinline__ int hpc_pos_wave(const uint32_t* __restrict__ w, int 
 
 // the end of realign_record once the segment is mapped to the gene's reference (realigner.rs:262-331): the segment's bounds and the DNA / HPC offsets.  One wavefront.
 __device__ __forceinline__ void k1_finish_segment(sp_hla_realign& res, int rm_ok, int rm_nm, int rm_a_start, int rm_a_end, int rm_b_start, int rm_b_end, int buf_start, int reflen,
-                                                  int a, uint32_t g, int bm_a_start, const SeqSetView& alleles_gene, const int32_t* __restrict__ am,
+                                                  int a, uint32_t g, int db_start, int db_end, int bm_a_start, const SeqSetView& alleles_gene, const int32_t* __restrict__ am,
                                                   const int32_t* __restrict__ hpc_ref, const uint64_t* __restrict__ hpc_ref_off, int lane) {
     // select_best_mapping(target-based, penalised): must beat the 1.0 default (util/mapping.rs:22-57)
     if (!(rm_ok && score_value(reflen, rm_nm, reflen - (rm_a_end - rm_a_start)) < 1.0)) return;
-    const int db_start = res.aln.b_start, db_end = res.aln.b_end;
     const int adj_start = buf_start + rm_b_start, adj_end = buf_start + rm_b_end;
     res.seg_start = db_start < adj_start ? db_start : adj_start;
     res.seg_end = db_end > adj_end ? db_end : adj_end;
@@ -498,19 +497,30 @@ __device__ __forceinline__ void k1_finish_segment(sp_hla_realign& res, int rm_ok
     res.status = 0;
 }
 
+// what realign_record takes from the accepted mapping (bm.query_start / query_end / target_start, realigner.rs:219-221,307): in seeded mode the re-scored mapping's numbers
+// (minimap2's end-clipped extent), else the cell's
+struct K1Span { int db_start, db_end, t_start; };
+__device__ __forceinline__ K1Span k1_span(const sp_aln& cell, const sp_affine_aln* af) {
+    K1Span s; s.db_start = cell.b_start; s.db_end = cell.b_end; s.t_start = cell.a_start;
+    if (af && af->score > 0) { s.db_start = af->a_start; s.db_end = af->a_end; s.t_start = af->b_start; }
+    return s;
+}
+
 // Seeded mode (the reference's call pattern): a segment whose 64-diagonal cell against the gene's reference found nothing -- a read with a 40+ base insertion or
 // deletion against the reference, which minimap2 chains across -- is run again on the wide band (sp_cells_wide_kernel), like the chains' own cells.
 // k1_seg_retry_cells_kernel lists those reads' cells (the others: no cell), k1_seg_retry_finish_kernel completes their records.
 __global__ void k1_seg_retry_cells_kernel(const sp_hla_realign* __restrict__ out, uint32_t n_reads, const int32_t* __restrict__ read_len, const int32_t* __restrict__ d_rg, int n_genes,
-                                          CellDesc* __restrict__ cells, sp_aln* __restrict__ alns) {
+                                          const sp_affine_aln* __restrict__ af, CellDesc* __restrict__ cells, sp_aln* __restrict__ alns) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     CellDesc c; c.a = 0; c.b = r; c.diag = SP_NO_DIAG; c.max_ed = SP_MAX_ED; c.b_lo = 0; c.b_hi = -1;
     const sp_hla_realign o = out[r];
     if (o.status == 3 && o.best_allele >= 0 && o.aln.ok) {
         const int rlen = read_len[r], buffer = 1000;
-        const int buf_start = o.aln.b_start > buffer ? o.aln.b_start - buffer : 0;
-        const int buf_end = o.aln.b_end + buffer < rlen ? o.aln.b_end + buffer : rlen;
+        const sp_affine_aln fa = af[r];
+        const K1Span sp = k1_span(o.aln, &fa);
+        const int buf_start = sp.db_start > buffer ? sp.db_start - buffer : 0;
+        const int buf_end = sp.db_end + buffer < rlen ? sp.db_end + buffer : rlen;
         c.a = (uint32_t)o.gene; c.b_lo = buf_start; c.b_hi = buf_end;
         c.diag = d_rg[(uint64_t)r * n_genes + o.gene] - buf_start;
     }
@@ -520,7 +530,7 @@ __global__ void k1_seg_retry_cells_kernel(const sp_hla_realign* __restrict__ out
 }
 __global__ __launch_bounds__(256) void k1_seg_retry_finish_kernel(SeqSetView alleles_gene, SeqSetView refs, const int32_t* __restrict__ am, const int32_t* __restrict__ hpc_ref,
                                                                   const uint64_t* __restrict__ hpc_ref_off, const CellDesc* __restrict__ cells, const sp_aln* __restrict__ alns,
-                                                                  uint32_t n_reads, sp_hla_realign* __restrict__ out) {
+                                                                  const sp_affine_aln* __restrict__ af, uint32_t n_reads, sp_hla_realign* __restrict__ out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t r = blockIdx.x * 4 + wave;
     if (r >= n_reads) return;
@@ -529,7 +539,9 @@ __global__ __launch_bounds__(256) void k1_seg_retry_finish_kernel(SeqSetView all
     const sp_aln rm = alns[r];
     if (!rm.ok) return;
     sp_hla_realign res = out[r];
-    k1_finish_segment(res, rm.ok, rm.nm, rm.a_start, rm.a_end, rm.b_start, rm.b_end, c.b_lo, refs.len[c.a], res.best_allele, c.a, res.aln.a_start, alleles_gene, am, hpc_ref, hpc_ref_off, lane);
+    const sp_affine_aln fa = af[r];
+    const K1Span sp = k1_span(res.aln, &fa);
+    k1_finish_segment(res, rm.ok, rm.nm, rm.a_start, rm.a_end, rm.b_start, rm.b_end, c.b_lo, refs.len[c.a], res.best_allele, c.a, sp.db_start, sp.db_end, sp.t_start, alleles_gene, am, hpc_ref, hpc_ref_off, lane);
     if (lane == 0 && res.status == 0) out[r] = res;
 }
 
@@ -542,7 +554,8 @@ __global__ __launch_bounds__(256) void k1_finalize_kernel(SeqSetView alleles_fwd
                                                           const int32_t* __restrict__ am, const int32_t* __restrict__ hpc_ref,
                                                           const uint64_t* __restrict__ hpc_ref_off,
                                                           const int32_t* __restrict__ best_in, uint32_t n_reads,
-                                                          sp_hla_realign* __restrict__ out, int slot_words, const sp_aln* __restrict__ aln_in) {
+                                                          sp_hla_realign* __restrict__ out, int slot_words, const sp_aln* __restrict__ aln_in,
+                                                          const sp_affine_aln* __restrict__ af_in) {
     extern __shared__ uint32_t lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* slot = lds + wave * slot_words;
@@ -577,7 +590,9 @@ __global__ __launch_bounds__(256) void k1_finalize_kernel(SeqSetView alleles_fwd
         res.aln.b_start = bm.b_start; res.aln.b_end = bm.b_end; res.aln.a_len = alen; res.aln.b_len = rlen;
         res.status = 3;
         if (bm.ok) {
-            const int db_start = bm.b_start, db_end = bm.b_end;
+            sp_affine_aln fa; if (af_in) fa = af_in[r];
+            const K1Span sp = k1_span(res.aln, af_in ? &fa : nullptr);
+            const int db_start = sp.db_start, db_end = sp.db_end;
             const int buffer = 1000;
             const int buf_start = db_start > buffer ? db_start - buffer : 0;
             const int buf_end = db_end + buffer < rlen ? db_end + buffer : rlen;
@@ -589,7 +604,7 @@ __global__ __launch_bounds__(256) void k1_finalize_kernel(SeqSetView alleles_fwd
             in2.diag = drg - buf_start; in2.max_ed = SP_MAX_ED;
             spw::CellOut rm;
             spw::wfa_cell<false, HASN>(in2, slot, slot_words, lane, nullptr, nullptr, rm);
-            k1_finish_segment(res, rm.ok, rm.nm, rm.a_start, rm.a_end, rm.b_start, rm.b_end, buf_start, reflen, a, g, bm.a_start, alleles_gene, am, hpc_ref, hpc_ref_off, lane);
+            k1_finish_segment(res, rm.ok, rm.nm, rm.a_start, rm.a_end, rm.b_start, rm.b_end, buf_start, reflen, a, g, db_start, db_end, sp.t_start, alleles_gene, am, hpc_ref, hpc_ref_off, lane);
         }
     }
     if (lane == 0) out[r] = res;
@@ -1214,12 +1229,12 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
             (void)hipFuncSetAttribute((const void*)k1_finalize_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             hipLaunchKernelGGL(k1_finalize_kernel<true>, dim3((R + 3) / 4), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), db->dna_gene->view(),
                                db->ref_fwd->view(), reads->view(), db->d_gene_of, db->d_off_fwd, d_rg, (int)G, db->d_am, db->d_hpc_ref, db->d_hpc_ref_off,
-                               d_best, R, d_out, slot_words, d_win_aln);
+                               d_best, R, d_out, slot_words, d_win_aln, seeded ? d_win_af : nullptr);
         } else {
             (void)hipFuncSetAttribute((const void*)k1_finalize_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             hipLaunchKernelGGL(k1_finalize_kernel<false>, dim3((R + 3) / 4), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), db->dna_gene->view(),
                                db->ref_fwd->view(), reads->view(), db->d_gene_of, db->d_off_fwd, d_rg, (int)G, db->d_am, db->d_hpc_ref, db->d_hpc_ref_off,
-                               d_best, R, d_out, slot_words, d_win_aln);
+                               d_best, R, d_out, slot_words, d_win_aln, seeded ? d_win_af : nullptr);
         }
         if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_finalize launch failed");
     }
@@ -1230,10 +1245,10 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         sp_aln* d_sa = (sp_aln*)sp_pool(ctx, "k1_seg_alns", (size_t)R * sizeof(sp_aln));
         if (!d_sc || !d_sa) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
         else {
-            hipLaunchKernelGGL(k1_seg_retry_cells_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, reads->d_len, d_rg, (int)G, d_sc, d_sa);
+            hipLaunchKernelGGL(k1_seg_retry_cells_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, reads->d_len, d_rg, (int)G, d_win_af, d_sc, d_sa);
             rc = sp_launch_cells_wide(ctx, db->ref_fwd, reads, d_sc, R, d_sa);
             if (rc == SP_OK) hipLaunchKernelGGL(k1_seg_retry_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, db->dna_gene->view(), db->ref_fwd->view(), db->d_am, db->d_hpc_ref,
-                                                db->d_hpc_ref_off, d_sc, d_sa, R, d_out);
+                                                db->d_hpc_ref_off, d_sc, d_sa, d_win_af, R, d_out);
             if (rc == SP_OK && hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1 segment retry launch failed");
         }
     }

@@ -107,7 +107,11 @@ class K1Tables:
         twice = (int(bm["a_start"]) - int(bm["b_start"])) + (int(bm["a_end"]) - int(bm["b_end"]))
         diag = int(twice / 2)                                                  # (C's division: towards zero)
         res["mm2"] = seeded["mm2"] if seeded is not None else oracle_ffi.oracle_affine(oracle, self.fwd_e[best], re, -diag, 64, 1)
-        db_s, db_e = int(bm["b_start"]), int(bm["b_end"])
+        # what realign_record takes from the accepted mapping (bm.query_start / query_end / target_start, realigner.rs:219-221,307): in seeded mode the numbers of the
+        # re-scored mapping (minimap2's end-clipped extent), in the exhaustive mode the cell's
+        db_s, db_e, t_s = int(bm["b_start"]), int(bm["b_end"]), int(bm["a_start"])
+        if seeded is not None and res["mm2"][0] > 0:
+            _sc, _nm, t_s, _te, db_s, db_e = (int(x) for x in res["mm2"])
         buf_s, buf_e = max(db_s - 1000, 0), min(db_e + 1000, len(read))
         seg = re[buf_s:buf_e]
         # (seeded mode: a segment the 64-diagonal cell loses -- a long insertion / deletion against the reference -- runs again on the wide band, as the chains' cells do)
@@ -121,8 +125,8 @@ class K1Tables:
                 h = oracle.hpc_pos(fx.gene_ref[g], d)
             else:
                 added = max(am[1] - am[0], 0)
-                d = added + int(bm["a_start"])
-                h = oracle.hpc_pos(fx.gene_ref[g], added) + oracle.hpc_pos(fx.dna[best], int(bm["a_start"]))
+                d = added + t_s
+                h = oracle.hpc_pos(fx.gene_ref[g], added) + oracle.hpc_pos(fx.dna[best], t_s)
             res.update(status=0, seg_start=min(db_s, adj_s), seg_end=max(db_e, adj_e), dna_offset=d, hpc_offset=h)
         if seeded is None:
             rv = self.is_reverse(re, anch)
