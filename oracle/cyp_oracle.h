@@ -61,6 +61,8 @@ int  osp_cyp_weight_sequence(const uint8_t* seq, int seq_len, int n_cons, const 
                              const uint8_t* allowed, uint64_t* out_ed, double* out_ov);
 int  osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, const uint8_t* const* tmpl, const int32_t* tmpl_len,
                             const int32_t* tmpl_type, double max_missing_frac, osp_region_hit* out, int cap);
+int  osp_cyp_find_base_type_ex(const uint8_t* seq, int seq_len, int n_templates, const uint8_t* const* tmpl, const int32_t* tmpl_len,
+                               const int32_t* tmpl_type, double max_missing_frac, int rescore, osp_region_hit* out, int cap);   /* rescore: the hits carry minimap2's numbers (two-piece affine re-score) */
 
 double osp_cyp_overlap_score(int s1, int e1, int s2, int e2);          /* overlap_score (src/cyp2d6/haplotyper.rs:877-892) */
 void osp_cyp_score_alleles(int n_variants, int n_alleles, const uint8_t* hap_matrix, const uint8_t* is_vi, const uint8_t* states,

@@ -364,8 +364,9 @@ def chain_hap_string(oracle, chain, hap_labels, detail, cfg=None):
 REGION_HIT_DTYPE = np.dtype([(n, np.int32) for n in ("template_idx", "start", "end", "seq_len", "nm", "unmapped", "clip_start", "clip_end")])
 
 
-def oracle_find_base_type(oracle, seq, templates, template_type, max_missing_frac):
-    """find_base_type_in_sequence (src/cyp2d6/haplotyper.rs:142-315) on the alignment contract"""
+def oracle_find_base_type(oracle, seq, templates, template_type, max_missing_frac, rescore=True):
+    """find_base_type_in_sequence (src/cyp2d6/haplotyper.rs:142-315) on the alignment contract; rescore (the library's default, context option "mm2_rescore"): the placements
+    that pass max_ed_frac are re-scored the reference's way and the rules run on minimap2's numbers (osp_cyp_find_base_type_ex)"""
     L = oracle.L
     enc = [oracle.encode(t) for t in templates]
     ptrs = (C.c_void_p * len(enc))(*[e.ctypes.data for e in enc])
@@ -373,10 +374,10 @@ def oracle_find_base_type(oracle, seq, templates, template_type, max_missing_fra
     tt = np.ascontiguousarray(template_type, np.int32)
     s = oracle.encode(seq)
     out = np.zeros(64, REGION_HIT_DTYPE)
-    L.osp_cyp_find_base_type.restype = C.c_int32
-    L.osp_cyp_find_base_type.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int32]
-    n = L.osp_cyp_find_base_type(s.ctypes.data_as(C.c_void_p), len(s), len(enc), ptrs, lens.ctypes.data_as(C.c_void_p),
-                                 tt.ctypes.data_as(C.c_void_p), float(max_missing_frac), out.ctypes.data_as(C.c_void_p), len(out))
+    L.osp_cyp_find_base_type_ex.restype = C.c_int32
+    L.osp_cyp_find_base_type_ex.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_int32]
+    n = L.osp_cyp_find_base_type_ex(s.ctypes.data_as(C.c_void_p), len(s), len(enc), ptrs, lens.ctypes.data_as(C.c_void_p),
+                                    tt.ctypes.data_as(C.c_void_p), float(max_missing_frac), 1 if rescore else 0, out.ctypes.data_as(C.c_void_p), len(out))
     return out[:n]
 
 

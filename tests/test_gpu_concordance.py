@@ -22,14 +22,16 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "con
 NAMES = ["*1/*2", "*4/*4", "*5/*1", "*4+*68/*1", "*10+*36/*10", "*2x2/*1"]
 
 # the counters as measured on MI355X.  K1 (round 5, the reference's call pattern on the device: sp_hla_seed.hip): EXACT -- every read names the port's allele with the
-# port's numbers.  The others as measured when the fixture was generated (round 4): see DESIGN.md section 3.4 for the classes behind them.
+# port's numbers.  K3 and K4 likewise (every hit, every minimum-edit set).
 K1_SAME_GENE = 10000            # of 10,000 reads: every read enters the same gene's consensus
 K1_SAME_ALLELE = 10000          # the accepted allele of every read is the seeded map's (8,262 while K1 was the exhaustive argmin over every allele: k1_best_n = 0, below)
 K1_MM2_NUMBERS = 10000          # ... with the port's (NM, allele span)
 K1_EXHAUSTIVE_SAME_ALLELE = 8262  # context option k1_best_n = 0: the exact argmin prefers partial alleles the seeded map never base-aligns
-K3_READS_ALL_EQUAL_MIN = 0.975  # measured 1,957 - 1,965 of 2,000 reads: the whole hit list (template, start, end) is the port's (the others: end clipping of a = 1 moves an end by a few bases)
-K3_HITS_SAME_NM_MIN = 0.970     # measured 97.4 - 97.9 % of the port's hits: found with the same (start, end) AND the same nm / unmapped
-K3_MM2_SAME_MIN = 0.999         # share of the port's hits the library reports with identical (start, end, NM, unmapped) in its re-scored fields
+# K3 (round 5: the region search runs the reference's rules on the re-scored numbers of its placements, sp_cyp.hip cyp_find_regions): EXACT -- every read's whole hit list
+# (template, start, end) is the port's and every hit carries the port's nm / unmapped, in all six scenarios (13,045 hits; rounds 3-4, rules on the unit-cost counts: 97.5 - 98.3 % of reads)
+K3_READS_ALL_EQUAL_MIN = 1.0
+K3_HITS_SAME_NM_MIN = 1.0
+K3_MM2_SAME_MIN = 1.0
 K4_SAME_MIN_SET_MIN = 1.0       # measured 100 %: the set of minimum-edit consensuses of every segment is the port's (what the chains are built from, caller.rs:462-487)
 K4_SAME_MINIMUM_MIN = 1.0       # measured 100 % since the placements near a segment's minimum carry the re-scored numbers (99.4 - 99.5 % with unit-cost counts)
 
