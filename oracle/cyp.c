@@ -439,10 +439,10 @@ int osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, con
                            const int32_t* tmpl_type, double max_missing_frac, osp_region_hit* out, int cap) {
     return osp_cyp_find_base_type_ex(seq, seq_len, n_templates, tmpl, tmpl_len, tmpl_type, max_missing_frac, 0, out, cap);
 }
-/* rescore: every placement that passes max_ed_frac on the contract's own counts is re-scored the reference's way -- the template is minimap2's query, the sequence its
- * target: two-piece affine gaps and end clipping (osp_affine_local, map-hifi scores) on the 256 diagonals around the placement's middle diagonal -- and the reference's rules
- * (the filter again, the collapse, the missing-fraction filter) run on those numbers: start / end / nm / unmapped / clips of a hit are what minimap2 reports for the mapping
- * (the library's sp_cyp_find_regions under its context option "mm2_rescore", the default) */
+/* rescore: the hits that survive the collapse are re-scored the reference's way -- the template is minimap2's query, the sequence its target: two-piece affine gaps and end
+ * clipping (osp_affine_local, map-hifi scores) on the 256 diagonals around the placement's middle diagonal -- and start / end / nm / unmapped / clips of a hit are those numbers
+ * (what minimap2 reports for the mapping; what the segments are cut from, what the missing-fraction filter sees).  max_ed_frac and the collapse in front run on the contract's own
+ * counts.  (The library's sp_cyp_find_regions under its context option "mm2_rescore", the default.) */
 int osp_cyp_find_base_type_ex(const uint8_t* seq, int seq_len, int n_templates, const uint8_t* const* tmpl, const int32_t* tmpl_len,
                               const int32_t* tmpl_type, double max_missing_frac, int rescore, osp_region_hit* out, int cap) {
     if (seq_len == 0) return 0;
@@ -463,16 +463,6 @@ int osp_cyp_find_base_type_ex(const uint8_t* seq, int seq_len, int n_templates, 
             h.seq_len = tmpl_len[t]; h.nm = al.nm; h.unmapped = tmpl_len[t] - (al.a_end - al.a_start);
             h.clip_start = al.a_start; h.clip_end = tmpl_len[t] - al.a_end;
             if (hit_score(&h, is_penalized_type(tmpl_type[t])) > max_ed_frac) continue;           /* :228-232 ; Forward only */
-            if (rescore) {
-                const osp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
-                const int twice = (al.b_start - al.a_start) + (al.b_end - al.a_end);            /* (sequence position - template position) at both ends */
-                osp_affine_out af;
-                osp_affine_local(seq, seq_len, tmpl[t], tmpl_len[t], -(twice / 2), 256, &ao, &af);
-                if (af.score <= 0) continue;
-                h.start = af.t_start; h.end = af.t_end; h.nm = af.nm;
-                h.unmapped = tmpl_len[t] - (af.q_end - af.q_start); h.clip_start = af.q_start; h.clip_end = tmpl_len[t] - af.q_end;
-                if (hit_score(&h, is_penalized_type(tmpl_type[t])) > max_ed_frac) continue;
-            }
             un[n_un++] = h;
         }
     }
@@ -496,6 +486,18 @@ int osp_cyp_find_base_type_ex(const uint8_t* seq, int seq_len, int n_templates, 
         } else { coll[n_coll++] = cur; cur = un[i]; }
     }
     if (have_cur) coll[n_coll++] = cur;
+    if (rescore) for (int i = 0; i < n_coll; ++i) {
+        osp_region_hit* h = &coll[i];
+        const int t = h->template_idx;
+        const osp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
+        /* (sequence position - template position) at both ends of the placement, as the contract reports them */
+        const int twice = (h->start - h->clip_start) + (h->end - (tmpl_len[t] - h->clip_end));
+        osp_affine_out af;
+        osp_affine_local(seq, seq_len, tmpl[t], tmpl_len[t], -(twice / 2), 256, &ao, &af);
+        if (af.score <= 0) continue;
+        h->start = af.t_start; h->end = af.t_end; h->nm = af.nm;
+        h->unmapped = tmpl_len[t] - (af.q_end - af.q_start); h->clip_start = af.q_start; h->clip_end = tmpl_len[t] - af.q_end;
+    }
     for (int i = 0; i < n_coll; ++i) {
         if (hit_score(&coll[i], 1) > max_missing_frac) continue;                                   /* :303-306 */
         if (n_out < cap) out[n_out] = coll[i];

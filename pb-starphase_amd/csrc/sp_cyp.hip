@@ -783,10 +783,12 @@ extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, 
     if (!ctx) return SP_ERR_INVALID_ARG;
     return cyp_find_regions(ctx, templates, template_type, reads, max_missing_frac, hits, hits_cap, n_hits, ctx->mm2_rescore);
 }
-// rescore (context option "mm2_rescore", the default): every placement that passes the edit-fraction filter on the library's own counts is re-scored the reference's way --
-// template (minimap2's query) against read (its target), two-piece affine gaps and end clipping on the 256 diagonals around the placement's own (sp_rescore_mappings) -- and
-// the reference's rules (the filter again, the collapse of overlapping hits, the missing-fraction filter) then run on THOSE numbers: start / end / nm / unmapped / clips of a hit
-// are what minimap2 reports for the mapping (oracle/cyp.c osp_cyp_find_base_type_ex states the same with the DP over all rows).  The drivers inside the library take the same path.
+// rescore (context option "mm2_rescore", the default): the hits that survive the collapse of overlapping placements are re-scored the reference's way -- template (minimap2's
+// query) against read (its target), two-piece affine gaps and end clipping on the 256 diagonals around the placement's own (sp_rescore_mappings; hits whose edits all stand
+// alone keep their counts without a DP) -- and start / end / nm / unmapped / clips of a hit ARE those numbers: what minimap2 reports for the mapping, what the segments are cut
+// from and what the missing-fraction filter sees (oracle/cyp.c osp_cyp_find_base_type_ex states the same with the DP over all rows).  The edit-fraction filter and the collapse
+// in front run on the library's own counts: re-scoring every placement first (45,365 per 2,000-read sample instead of 2,162 hits, most of them the other gene copy's templates at
+// 3 - 5 % divergence) cost 39 ms per sample and changed ONE hit in 13,045 against the CPU port (tests/test_gpu_concordance.py).  The drivers inside the library take the same path.
 static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
                                 double max_missing_frac, sp_region_hit* hits, uint64_t hits_cap, uint64_t* n_hits, bool rescore) {
     if (!ctx || !templates || !reads || !n_hits || (templates->n && !template_type) || (hits_cap && !hits)) return SP_ERR_INVALID_ARG;
@@ -797,56 +799,19 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
     if (rc) return rc;
     const uint32_t T = templates->n;
     auto penalized_type = [](int t) { return t == SP_CYP_DELETION || t == SP_CYP_REP6 || t == SP_CYP_REP7; };   // haplotyper.rs:185-191
-    // 1. the placements that pass max_ed_frac on the library's own counts, in (read, template, anchor) order
-    std::vector<sp_region_hit> cand; std::vector<uint32_t> which; std::vector<uint64_t> first(reads->n + 1, 0);
+    std::vector<sp_region_hit> un, coll; std::vector<uint32_t> which;
     for (uint32_t r = 0; r < reads->n; ++r) {
-        first[r] = cand.size();
         if (reads->h_len[r] == 0) continue;
+        un.clear();
         for (uint32_t t = 0; t < T; ++t) for (int k = 0; k < CYP_TOPK; ++k) {
-            const size_t at = ((size_t)r * T + t) * CYP_TOPK + k;
-            const sp_aln& al = alns[at];
+            const sp_aln& al = alns[((size_t)r * T + t) * CYP_TOPK + k];
             if (!al.ok) continue;
             const int tlen = templates->h_len[t];
             sp_region_hit h{(int32_t)r, (int32_t)t, al.b_start, al.b_end, tlen, al.nm, tlen - (al.a_end - al.a_start), al.a_start, tlen - al.a_end, 0, 0, 0, 0, 0, 0};
+            h.mm2_score = (int32_t)(((size_t)r * T + t) * CYP_TOPK + k);                     // (until the re-score below: which alignment the hit is)
             if (cyp_score(h.seq_len, h.nm, h.unmapped, penalized_type(template_type[t])) > 0.05) continue;   // max_ed_frac, :228-232
-            cand.push_back(h); which.push_back((uint32_t)at);
+            un.push_back(h);
         }
-    }
-    first[reads->n] = cand.size();
-    // 2. their numbers the reference's way
-    const uint64_t nc = cand.size();
-    if (rescore && nc) {
-        std::vector<CellDesc> cells(nc); std::vector<sp_aln> ref(nc); std::vector<sp_affine_aln> af(nc);
-        for (uint64_t x = 0; x < nc; ++x) {
-            const sp_region_hit& h = cand[x]; const sp_aln& al = alns[which[x]];
-            cells[x] = CellDesc{ (uint32_t)h.template_idx, (uint32_t)h.read, ((al.b_start - al.a_start) + (al.b_end - al.a_end)) / 2, 320, 0, -1 };
-            ref[x] = al;
-        }
-        CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k3_af_cells", nc * sizeof(CellDesc));
-        sp_aln* d_ref = (sp_aln*)sp_pool(ctx, "k3_af_ref", nc * sizeof(sp_aln));
-        sp_affine_aln* d_af = (sp_affine_aln*)sp_pool(ctx, "k3_af_out", nc * sizeof(sp_affine_aln));
-        if (!d_cells || !d_ref || !d_af) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "find_regions: re-score buffers");
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_cells, cells.data(), nc * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream));
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ref, ref.data(), nc * sizeof(sp_aln), hipMemcpyHostToDevice, ctx->stream));
-        const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
-        rc = sp_rescore_mappings(ctx, templates, reads, d_cells, d_ref, nc, false, ao, 256, d_af, "k3_af", 320);
-        if (rc != SP_OK) return rc;
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(af.data(), d_af, nc * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
-        SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint64_t x = 0; x < nc; ++x) {
-            sp_region_hit& h = cand[x];
-            if (af[x].score <= 0) { h.seq_len = -1; continue; }                                                  // (nothing aligns the reference's way: no mapping)
-            h.mm2_score = af[x].score; h.mm2_nm = af[x].nm; h.mm2_start = af[x].b_start; h.mm2_end = af[x].b_end; h.mm2_q_start = af[x].a_start; h.mm2_q_end = af[x].a_end;
-            h.start = af[x].b_start; h.end = af[x].b_end; h.nm = af[x].nm;
-            h.unmapped = h.seq_len - (af[x].a_end - af[x].a_start); h.clip_start = af[x].a_start; h.clip_end = h.seq_len - af[x].a_end;
-            if (cyp_score(h.seq_len, h.nm, h.unmapped, penalized_type(template_type[h.template_idx])) > 0.05) h.seq_len = -1;      // max_ed_frac on minimap2's numbers
-        }
-    }
-    // 3. the reference's rules per read
-    std::vector<sp_region_hit> un, coll;
-    for (uint32_t r = 0; r < reads->n; ++r) {
-        un.clear(); coll.clear();
-        for (uint64_t x = first[r]; x < first[r + 1]; ++x) if (cand[x].seq_len >= 0) un.push_back(cand[x]);
         std::stable_sort(un.begin(), un.end(), [](const sp_region_hit& x, const sp_region_hit& y) {
             return x.start != y.start ? x.start < y.start : x.end < y.end; });
         bool have = false; sp_region_hit cur{};
@@ -862,11 +827,41 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
             } else { coll.push_back(cur); cur = u; }
         }
         if (have) coll.push_back(cur);
-        for (const sp_region_hit& h : coll) {
-            if (cyp_score(h.seq_len, h.nm, h.unmapped, true) > max_missing_frac) continue;                     // :303-306
-            if (*n_hits < hits_cap) hits[*n_hits] = h;
-            ++*n_hits;
+    }
+    // the collapsed hits with the reference's numbers
+    const uint64_t nc = coll.size();
+    which.resize(nc);
+    for (uint64_t x = 0; x < nc; ++x) { which[x] = (uint32_t)coll[x].mm2_score; coll[x].mm2_score = 0; }
+    if (rescore && nc) {
+        std::vector<CellDesc> cells(nc); std::vector<sp_aln> ref(nc); std::vector<sp_affine_aln> af(nc);
+        for (uint64_t x = 0; x < nc; ++x) {
+            const sp_region_hit& h = coll[x]; const sp_aln& al = alns[which[x]];
+            cells[x] = CellDesc{ (uint32_t)h.template_idx, (uint32_t)h.read, ((al.b_start - al.a_start) + (al.b_end - al.a_end)) / 2, 320, 0, -1 };
+            ref[x] = al;
         }
+        CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k3_af_cells", nc * sizeof(CellDesc));
+        sp_aln* d_ref = (sp_aln*)sp_pool(ctx, "k3_af_ref", nc * sizeof(sp_aln));
+        sp_affine_aln* d_af = (sp_affine_aln*)sp_pool(ctx, "k3_af_out", nc * sizeof(sp_affine_aln));
+        if (!d_cells || !d_ref || !d_af) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "find_regions: re-score buffers");
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_cells, cells.data(), nc * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream));
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ref, ref.data(), nc * sizeof(sp_aln), hipMemcpyHostToDevice, ctx->stream));
+        const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
+        rc = sp_rescore_mappings(ctx, templates, reads, d_cells, d_ref, nc, false, ao, 256, d_af, "k3_af", 320);
+        if (rc != SP_OK) return rc;
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(af.data(), d_af, nc * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint64_t x = 0; x < nc; ++x) {
+            sp_region_hit& h = coll[x];
+            if (af[x].score <= 0) continue;                                                                      // (nothing aligns the reference's way: the hit keeps the library's counts)
+            h.mm2_score = af[x].score; h.mm2_nm = af[x].nm; h.mm2_start = af[x].b_start; h.mm2_end = af[x].b_end; h.mm2_q_start = af[x].a_start; h.mm2_q_end = af[x].a_end;
+            h.start = af[x].b_start; h.end = af[x].b_end; h.nm = af[x].nm;
+            h.unmapped = h.seq_len - (af[x].a_end - af[x].a_start); h.clip_start = af[x].a_start; h.clip_end = h.seq_len - af[x].a_end;
+        }
+    }
+    for (const sp_region_hit& h : coll) {
+        if (cyp_score(h.seq_len, h.nm, h.unmapped, true) > max_missing_frac) continue;                     // :303-306
+        if (*n_hits < hits_cap) hits[*n_hits] = h;
+        ++*n_hits;
     }
     return SP_OK;
 }

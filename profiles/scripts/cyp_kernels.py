@@ -17,7 +17,7 @@ db.diplotype(R)
 ctx.profile_reset(); ctx.synchronize()
 t0 = time.perf_counter(); call, _c, _l = db.diplotype(R); dt = time.perf_counter() - t0
 print(name, "total ms", round(1e3 * dt, 1), call.hap1.decode(), call.hap2.decode())
-for k in ("anchor", "k3_region_cells", "segments", "cons_steps", "align", "align_trace", "k9_graph", "k7_score", "k4_weight_cells", "k5_chain_reads", "k5_pairs",
+for k in ("anchor", "k3_region_cells", "k3_af_trace", "k3_af_dp", "k4_af_trace", "k4_af_dp", "segments", "cons_steps", "align", "align_trace", "k9_graph", "k7_score", "k4_weight_cells", "k5_chain_reads", "k5_pairs",
           "host:cyp_regions", "host:cyp_segments", "host:cyp_consensus", "host:cyp_merge", "host:cyp_typing", "host:cyp_weights", "host:cyp_chains", "host:cyp_chain_pair"):
     ms, n, cells = ctx.profile_get(k)
     print(f"  {k:22s} {ms:8.3f} ms  launches {n:5d}  cells {cells}")
