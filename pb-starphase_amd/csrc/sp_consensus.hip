@@ -2230,9 +2230,10 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
                 // of them never start.  Then the batch is given up HERE -- the abort word ends the ones that did start -- and run launch by launch below, and the context
                 // keeps away from the mode for a while
                 const auto t_wait = std::chrono::steady_clock::now();
-                while (*(volatile uint32_t*)h_ready < n_prob) {
+                const bool forced = std::getenv("SP_K8_FORCE_READY_TIMEOUT") != nullptr;      // (tests: take the time-out's path whatever the device does)
+                while (forced || *(volatile uint32_t*)h_ready < n_prob) {
                     __builtin_ia32_pause();
-                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() > PERSIST_READY_S) { all_ready = false; break; }
+                    if (forced || std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() > PERSIST_READY_S) { all_ready = false; break; }
                 }
             }
             if (all_ready) {

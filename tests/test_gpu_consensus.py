@@ -147,7 +147,34 @@ def test_persistent_kernels_run_the_same_search(oracle, pkg, gpu_ctx):
         g_group, g_cons = gpu_ctx.consensus_priority([gpu_ctx.upload(hpc), gpu_ctx.upload(raw)], gpu_cfg(pkg, **kw), None, None)
         assert g_group.tolist() == e_group.tolist() and g_cons == e_cons
     finally:
-        gpu_ctx.set_option("k8_persistent", 0)
+        gpu_ctx.set_option("k8_persistent", 2)            # (the default: the library decides)
+
+
+def test_a_batch_whose_control_workgroups_do_not_come_up_runs_as_launch_pairs(oracle, pkg, monkeypatch):
+    """the persistent mode's way out: the control workgroups are launched first and the host waits half a second for all of them to have started; when they have not
+    (SP_K8_FORCE_READY_TIMEOUT takes that path whatever the device does) the abort word ends the ones that did, both streams are drained and THE SAME batch runs as a launch
+    pair per step -- same results --, the context keeps away from the mode for the next 64 batches and says so in sp_ctx_get_info().warning"""
+    import consensus_fuzz
+    from pb_starphase_amd import synth
+    ctx = pkg.Context(0)
+    ctx.set_option("k8_persistent", 1)
+    monkeypatch.setenv("SP_K8_FORCE_READY_TIMEOUT", "1")
+    rng = np.random.default_rng(77)
+    cases = [consensus_fuzz.problem(rng, 77, synth) for _ in range(4)]
+    for _L, reads, offs, kw, two_pass in cases:
+        same(ctx.consensus(ctx.upload(reads), gpu_cfg(pkg, **kw), offsets=offs, two_pass=two_pass), run_case(oracle, reads, offs, kw, two_pass))
+    assert ctx.profile_get("cons_persistent_batches")[2] == 0
+    assert "launch by launch" in ctx.info()["warning"]
+    # without the switch the context is still backing off (64 batches): launch pairs, same results; then the mode comes back
+    monkeypatch.delenv("SP_K8_FORCE_READY_TIMEOUT")
+    _L, reads, offs, kw, two_pass = cases[0]
+    S, cfg = ctx.upload(reads), gpu_cfg(pkg, **kw)
+    exp = run_case(oracle, reads, offs, kw, two_pass)
+    for _ in range(70):
+        got = ctx.consensus(S, cfg, offsets=offs, two_pass=two_pass)
+    same(got, exp)
+    assert ctx.profile_get("cons_persistent_batches")[2] > 0
+    ctx.close()
 
 
 def test_batch_equals_one_by_one(oracle, pkg, gpu_ctx):
