@@ -2007,18 +2007,32 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     // budget taken by other batches, runs launch by launch as before.
     PersistLease lease;
     int persist_rpw = 0;
-    // consensus batches of this process under way on the device (this one included from here on)
+    // Consensus batches of this process under way on the device, this one included from here on; and, for the library's own choice of mode, when two batches that could
+    // run as persistent kernels (single samples' searches) last ran side by side: a host that keeps several samples in flight on one device
     struct InFlight {
-        int dev;
+        int dev; bool cand; int others = 0;
         static std::atomic<int>& count(int d) { static std::atomic<int> c[64]; return c[d & 63]; }
-        explicit InFlight(int d) : dev(d) { others = count(dev).fetch_add(1); }
-        ~InFlight() { count(dev).fetch_sub(1); }
-        int others;
-    } in_flight(ctx->device);
-    // (k8_persistent 2 = the library decides: a single sample's batches, when the streams have hardware queues of their own, the mode has not just failed here AND no other
-    //  consensus batch of the process is under way on the device -- resident workgroups are a third faster for a chain that has the device to itself and take the CUs from
-    //  everything that runs beside them: with four CYP2D6 samples in flight a launch pair per step made 292-303k reads/s of bench.py's stream, one persistent batch at a time 272k)
-    const bool persist_wanted = ctx->k8_persistent == 1 || (ctx->k8_persistent == 2 && n_prob <= 8 && ctx->hw_queues_effective >= 16 && ctx->k8_persist_failures < 3 && in_flight.others == 0);
+        static std::atomic<int>& cands(int d) { static std::atomic<int> c[64]; return c[d & 63]; }
+        static std::atomic<long long>& overlap_ns(int d) { static std::atomic<long long> t[64]; return t[d & 63]; }
+        static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+        bool recent_overlap = false;
+        InFlight(int d, bool candidate) : dev(d), cand(candidate) {
+            others = count(dev).fetch_add(1);
+            if (cand) {
+                const long long t = now_ns();
+                if (cands(dev).fetch_add(1) > 0) overlap_ns(dev).store(t);
+                const long long last = overlap_ns(dev).load();
+                recent_overlap = last != 0 && t - last < 1000000000ll;
+            }
+        }
+        ~InFlight() { count(dev).fetch_sub(1); if (cand) cands(dev).fetch_sub(1); }
+    } in_flight(ctx->device, n_prob > 0 && n_prob <= 8);
+    // (k8_persistent 2 = the library decides: a single sample's batches, when the streams have hardware queues of their own, the mode has not just failed here, no other
+    //  consensus batch of the process is under way on the device AND no two such batches ran side by side within the last second -- resident workgroups are a third faster for
+    //  a chain that has the device to itself and take the CUs from everything that runs beside them: with four CYP2D6 samples in flight a launch pair per step made 301-324k
+    //  reads/s of bench.py's stream, persistent kernels whenever a batch happened to start alone 282-303k, one persistent batch at a time 272k)
+    const bool persist_wanted = ctx->k8_persistent == 1 || (ctx->k8_persistent == 2 && n_prob <= 8 && ctx->hw_queues_effective >= 16 && ctx->k8_persist_failures < 3 &&
+                                                            in_flight.others == 0 && !in_flight.recent_overlap);
     if (ctx->k8_persist_backoff > 0) --ctx->k8_persist_backoff;
     else if (persist_wanted && n_prob > 0) {
         uint64_t blocks1 = 0; bool small = true;
