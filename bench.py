@@ -646,6 +646,24 @@ def streams_block(pkg, fx, db, ctx, cfg, gene_def, locus, scen, device_index, ra
             "workload": "the N = 1 headline's stream of samples on every rank (its own samples; HLA-A / -B %d reads + CYP2D6 %d reads per step, the six scenarios in turn), no exchange" % (samples[0].n, cyp_samples[0].n)}
 
 
+def cohort_leg_in_a_process_of_its_own(n_samples):
+    """BASELINE configs[4] on this one GPU, in a process of its own, started like a rank of the N > 1 run and BEFORE this process touches the GPU: by the time the legs run this
+    process holds two dozen streams, and the HIP runtime deals streams to its 16 hardware queues in the order they are made -- a cohort call's streams then share queues with
+    each other and run their chains one after the other (a 32-sample share: 0.18 s there against 0.14 s in a process that runs nothing else)"""
+    try:
+        env = dict(os.environ, SP_BENCH_COHORT_SHARES="1")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cohort", "--steps", "2", "--warmup", "1", "--no-extra-legs", "--cohort-samples", str(n_samples)],
+                               env=env, capture_output=True, text=True, timeout=900)
+        rows = [l for l in child.stdout.splitlines() if l.startswith("{")]
+        if child.returncode != 0 or not rows:
+            raise RuntimeError("the cohort leg's process ended with %d: %s" % (child.returncode, child.stderr[-500:]))
+        return json.loads(rows[-1])["cohort"]
+    except Exception as e:                                                      # (a leg, not the headline: say so and go on)
+        return {"error": str(e)}
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -686,6 +704,7 @@ def main():
     scen = cr.scenarios(locus)
     # the steps cycle through ALL SIX configs[2] scenarios (*1/*2, *4/*4, *5/*1, *4+*68/*1, *10+*36/*10, *2x2/*1; round 4 alternated the first two, the cheap third of the config)
     cyp_samples = [CypSample(pkg, locus, scen[k], args.cyp_reads, 7 + k) for k in range(len(scen))] if workload == "sample" else []
+    cohort_in_own_process = cohort_leg_in_a_process_of_its_own(args.cohort_samples) if (world == 1 and workload == "sample" and not args.no_extra_legs) else None
     cb, cpu_ref = None, None
     if not args.no_cpu_baseline and world == 1 and workload == "sample":
         # both loci of sample 0 through the reference-call-pattern CPU port; forks workers: must happen before anything touches the GPU
@@ -1033,8 +1052,7 @@ def main():
             legs["cyp2d6_lanes"] = {"error": str(e)}
         legs["cyp2d6"] = cyp_leg(pkg, ctx, cdb, locus)
         legs["k5_chain_pairs"] = chain_pair_leg(pkg, ctx)
-        co_args = argparse.Namespace(**vars(args)); co_args.steps, co_args.warmup, co_args.cohort_shares = 1, 1, True
-        legs["cohort"] = cohort_line(pkg, ctx, fx, db, cdb, locus, scen, 1, 0, None, co_args, barrier, max_over_ranks, (cfg, gene_def), device_index)
+        legs["cohort"] = cohort_in_own_process             # (measured before this process touched the GPU: cohort_leg_in_a_process_of_its_own)
 
     peaks = {"valu_int_wave_instr_per_s": ctx.microbench("valu_int"), "match16_valu_wave_instr_per_s": ctx.microbench("match16"),
              "hbm_copy_bytes_per_s": ctx.microbench("hbm_copy")}

@@ -643,6 +643,10 @@ constexpr int BULK_MARGIN = 8;         // edits a read's worse state must be beh
 #define SP_K8_AUTO_BATCHES 1
 #endif
 constexpr int PERSIST_AUTO_BATCHES = SP_K8_AUTO_BATCHES;
+#ifndef SP_K8_LIGHT
+#define SP_K8_LIGHT 64
+#endif
+constexpr int PERSIST_LIGHT = SP_K8_LIGHT;          // resident workgroups (step + 2 per control workgroup) up to which a batch's footprint counts as light
 constexpr int DIRECT_BLOCKS = 128;      // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
 
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B, int block) {
@@ -2018,21 +2022,27 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         bool recent_overlap = false;
         InFlight(int d, bool candidate) : dev(d), cand(candidate) {
             others = count(dev).fetch_add(1);
-            if (cand) {
-                const long long t = now_ns();
-                if (cands(dev).fetch_add(1) > 0) overlap_ns(dev).store(t);
-                const long long last = overlap_ns(dev).load();
-                recent_overlap = last != 0 && t - last < 1000000000ll;
-            }
+            const long long t = now_ns();
+            if (cand && cands(dev).fetch_add(1) > 0) overlap_ns(dev).store(t);
+            const long long last = overlap_ns(dev).load();
+            recent_overlap = last != 0 && t - last < 1000000000ll;
         }
         ~InFlight() { count(dev).fetch_sub(1); if (cand) cands(dev).fetch_sub(1); }
-    } in_flight(ctx->device, n_prob > 0 && n_prob <= 8);
-    // (k8_persistent 2 = the library decides: a single sample's batches, when the streams have hardware queues of their own, the mode has not just failed here, no other
-    //  consensus batch of the process is under way on the device AND no two such batches ran side by side within the last second -- resident workgroups are a third faster for
-    //  a chain that has the device to itself and take the CUs from everything that runs beside them: with four CYP2D6 samples in flight a launch pair per step made 301-324k
-    //  reads/s of bench.py's stream, persistent kernels whenever a batch happened to start alone 282-303k, one persistent batch at a time 272k)
+    } in_flight(ctx->device, n_prob > 0 && n_prob <= 8 && [&] { uint64_t f = 2 * (uint64_t)n_prob; for (uint32_t p = 0; p < n_prob; ++p) f += ((probs[p].read_idx ? probs[p].n : probs[p].reads->n) + CWAVES - 1) / CWAVES; return f > (uint64_t)PERSIST_LIGHT; }());
+    // (k8_persistent 2 = the library decides.  A batch of at most eight problems, when the streams have hardware queues of their own and the mode has not just failed here, and
+    //  -- a batch of a LIGHT footprint, at most PERSIST_LIGHT resident workgroups (the late levels of a cohort call's lockstep searches: a few problems of a hundred reads):
+    //     whenever no two heavy batches ran side by side within the last second (a host with several samples in flight: there the light batches of one sample run beside the
+    //     other samples' chains and cost them 5 %); up to PERSIST_MAX_BATCHES of them at once.  A 256-sample cohort 330 -> 349-362 samples/s, a rank's share of 32 samples
+    //     0.169-0.184 -> 0.138-0.145 s against launch pairs;
+    //  -- a heavier one (a single 2,000-read sample: 250 step workgroups, half of the device's register files for the length of the batch): only when no other consensus batch
+    //     of the process is under way on the device AND no two such batches ran side by side within the last second, one at a time.  Resident workgroups are a third faster for a
+    //     chain that has the device to itself and take the CUs from everything that runs beside them: with four CYP2D6 samples in flight a launch pair per step made 301-324k
+    //     reads/s of bench.py's stream, persistent kernels whenever a batch happened to start alone 282-303k, one persistent batch at a time 272k)
+    uint64_t footprint = 2 * (uint64_t)n_prob;
+    for (uint32_t p = 0; p < n_prob; ++p) footprint += ((probs[p].read_idx ? probs[p].n : probs[p].reads->n) + CWAVES - 1) / CWAVES;
+    const bool light = footprint <= (uint64_t)PERSIST_LIGHT;
     const bool persist_wanted = ctx->k8_persistent == 1 || (ctx->k8_persistent == 2 && n_prob <= 8 && ctx->hw_queues_effective >= 16 && ctx->k8_persist_failures < 3 &&
-                                                            in_flight.others == 0 && !in_flight.recent_overlap);
+                                                            !in_flight.recent_overlap && (light || in_flight.others == 0));
     if (ctx->k8_persist_backoff > 0) --ctx->k8_persist_backoff;
     else if (persist_wanted && n_prob > 0) {
         uint64_t blocks1 = 0; bool small = true;
@@ -2051,7 +2061,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
                 for (uint32_t p = 0; p < n_prob; ++p) { const uint32_t n = probs[p].read_idx ? probs[p].n : probs[p].reads->n; nb += (n + CWAVES * scale - 1) / (CWAVES * scale); }
                 // (the library's own choice, k8_persistent 2: one persistent batch per device at a time -- the resident workgroups of two would take the CUs the other's and
                 //  everybody else's kernels need; a second batch in flight runs as launch pairs in the gaps of the first)
-                if ((int64_t)nb + ctl <= budget && lease.take(ctx->device, budget, (int)nb + ctl, ctx->k8_persistent == 2 ? PERSIST_AUTO_BATCHES : PERSIST_MAX_BATCHES)) persist_rpw = scale;
+                if ((int64_t)nb + ctl <= budget && lease.take(ctx->device, budget, (int)nb + ctl, (ctx->k8_persistent == 2 && !light) ? PERSIST_AUTO_BATCHES : PERSIST_MAX_BATCHES)) persist_rpw = scale;
                 else if ((int64_t)nb + ctl <= budget) break;                       // it would fit, but the budget is taken right now
             }
         }

@@ -175,7 +175,7 @@ def test_full_database_reads(oracle, pkg, gpu_ctx):
     n_large = 0
     for r in range(len(reads)):
         au, pick, hits = check_read(pkg, db, R, idx, dna_ids, reads, r)
-        assert pick >= 0 and len(hits) == 6 and au["n_chains"] > 500
+        assert pick >= 0 and 2 <= len(hits) <= 6 and au["n_chains"] > 500      # (the primary + at most best_n = 5 secondaries)
         n_large += int((au["chains"][:, 3] > 26).sum())
     assert n_large > 100            # targets with more than 26 anchors: chained by a whole wave, the skip counter and its marks replayed
     R.close()
