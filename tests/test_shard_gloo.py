@@ -82,3 +82,34 @@ def test_two_rank_gloo_gather(tmp_path):
     expected = [[s, g, 100 * s + g, 100 * s + g + 1] for s in range(7) for g in range(3)]
     for o in outs:
         assert [list(r) for r in o["table"]] == expected            # every rank holds the full, sorted table
+
+
+def test_solo_group_and_the_stream_tickets():
+    """a rank on its own inside a larger job gathers only its own records (bench.py's `one_gpu_same_cohort` block: no collective while the other ranks wait at a barrier);
+    the lanes of one locus take every sample of the stream exactly once (bench.py's Tickets)"""
+    sys.path.insert(0, ROOT)
+    import threading
+    import __graft_entry__ as ge
+    ge.load_package()
+    from pb_starphase_amd import shard
+    import bench
+    calls = np.zeros(5, shard.CALL_DTYPE)
+    calls["sample"] = [4, 1, 3, 1, 0]; calls["gene"] = [0, 1, 0, 0, 2]
+    out = shard.gather_calls(calls, group=shard.SoloGroup())
+    assert out["sample"].tolist() == [0, 1, 1, 3, 4] and out["gene"].tolist() == [2, 0, 1, 0, 0]
+    assert shard.SoloGroup().gather(np.arange(3, dtype=np.int64)).tolist() == [[0, 1, 2]]
+    t = bench.Tickets(1000)
+    taken = [[] for _ in range(4)]
+
+    def lane(k):
+        while True:
+            i = t.take()
+            if i is None:
+                return
+            taken[k].append(i)
+    threads = [threading.Thread(target=lane, args=(k,)) for k in range(4)]
+    for x in threads:
+        x.start()
+    for x in threads:
+        x.join()
+    assert sorted(sum(taken, [])) == list(range(1000)) and t.take() is None
