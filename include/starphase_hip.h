@@ -90,11 +90,15 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * the reference's way (fields mm2_*; sp_affine_rescore_batch), and the weights of sp_cyp_weight_segments / sp_cyp_diplotype* are taken from the re-scored placement wherever it is
  * within 16 (edits + unmapped bases) of its segment's smallest; 0 leaves the fields zero, the weights on unit-cost counts, and saves the extra launches; 2 = as 1, but every mapping with edits that do not stand alone
  * takes the DP over all of its rows instead of over the rows around those edits (a check of the shortcut, an order of magnitude slower).
- * "k8_persistent" (default 0; also the environment variable SP_K8_PERSISTENT): 1 runs consensus batches whose problems have at most 1,024 reads each as two persistent
- * kernels (step workgroups and one control workgroup per problem, handing over through device-scope release / acquire words) instead of a launch pair per step --
- * the same search, bit for bit; one process per device only (the workgroups of a batch have to be resident together, and the budget of CUs is counted per process), and every
- * stream of the process on a hardware queue of its own (a batch's two kernels wait for each other: GPU_MAX_HW_QUEUES, sp_ctx_get_info; at most four batches run this way at
- * once, sp_cyp_diplotype_cohort keeps to four streams).
+ * "k8_persistent" (0 | 1 | 2, default 2; also the environment variable SP_K8_PERSISTENT): consensus batches whose problems have at most 1,024 reads each can run as two
+ * persistent kernels (step workgroups and one control workgroup per problem on a second stream, resident for the length of the batch; the two sides hand over through one word
+ * each in memory: write-through stores, `sc1` loads and memory-side atomics, no L2 fences -- gfx950 behaviour) instead of a launch pair per step -- the
+ * same search, bit for bit.  0 never, 1 whenever a batch qualifies, 2 = the library decides: batches of at most eight problems, when the HIP runtime came up with >= 16 hardware
+ * queues (a batch's two kernels wait for each other: GPU_MAX_HW_QUEUES, sp_ctx_get_info), a heavy batch (a single large sample) only while nothing else of the process runs a
+ * consensus on the device, light ones (a cohort call's late levels) unless single-sample batches ran side by side within the last second.  The budget of CUs is counted per
+ * process (several processes on one device: set 0).  A batch whose control workgroups have not all started within half a second runs as launch pairs instead, by itself (the
+ * context then stays away from the mode for 64 batches and says so in sp_ctx_get_info().warning); a search that exceeds the launch-pair loop's own step bound ends the batch
+ * with the same error in both modes; no path returns while one of the two kernels is still running.
  * "cyp_cohort_streams" (1..8, default 8): streams sp_cyp_diplotype_cohort spreads its groups of samples over (one host thread each).
  * "k5_block_pairs" (0..1048576, default 4096): sp_cyp_best_chain_pair scores up to this many chain pairs with one workgroup per pair (the few pairs
  * of an ordinary sample: the reads of a pair are shared out over the workgroup), more with one thread per pair; the results are the same.

@@ -110,7 +110,7 @@ def test_low_complexity_and_divergent_inputs(oracle, pkg, gpu_ctx):
 
 def test_persistent_kernels_run_the_same_search(oracle, pkg, gpu_ctx):
     """sp_ctx_set_option "k8_persistent": batches of small problems as two persistent kernels (step workgroups + a control workgroup per problem, handing over through
-    release / acquire words) instead of a launch pair per step -- consensus, assignment, scores and the number of nodes expanded are the oracle's, as in the default mode;
+    one word each in memory: write-through stores, sc1 loads, memory-side atomics) instead of a launch pair per step -- consensus, assignment, scores and the number of nodes expanded are the oracle's, as in the default mode;
     a batch of many problems (each at its own pace, no lockstep) and a multi-way problem included"""
     import consensus_fuzz
     from pb_starphase_amd import synth
