@@ -822,6 +822,8 @@ def main():
         ctx.set_option("mm2_rescore", int(os.environ["SP_BENCH_MM2_RESCORE"]))
     if os.environ.get("SP_BENCH_HLA_SPLIT"):                # (an experiment switch: the two HLA genes of the sample on one stream (0) or two (1, the library's default))
         ctx.set_option("hla_split_genes", int(os.environ["SP_BENCH_HLA_SPLIT"]))
+    if os.environ.get("SP_BENCH_CYP_SPLIT"):                # (an experiment switch: the CYP2D6 calls' helper stream for the weights' placements off (0) / on (1, the default))
+        ctx_c.set_option("hla_split_genes", int(os.environ["SP_BENCH_CYP_SPLIT"]))
     genes = list(range(len(fx.genes)))
     last = {}
 
