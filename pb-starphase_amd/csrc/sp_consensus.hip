@@ -647,7 +647,14 @@ constexpr int PERSIST_AUTO_BATCHES = SP_K8_AUTO_BATCHES;
 #define SP_K8_LIGHT 64
 #endif
 constexpr int PERSIST_LIGHT = SP_K8_LIGHT;          // resident workgroups (step + 2 per control workgroup) up to which a batch's footprint counts as light
-constexpr int DIRECT_BLOCKS = 128;      // workgroups of a problem up to which the control kernel sums their words itself (a batch of such problems has no reduce launch)
+#ifndef SP_K8_DIRECT_BLOCKS
+#define SP_K8_DIRECT_BLOCKS 680
+#endif
+// Workgroups of a problem up to which its workgroups ADD their vote words to one block per problem (memory-side atomics) and the control kernel reads that block: a batch of such
+// problems has no reduce launch -- two launches per step instead of three.  The bound is the 16-bit vote fields: 12 units per read and column, 5,461 reads = 682 workgroups at one
+// read per wave (128 until round 5: an HLA gene of a 10,000-read sample has 625 workgroups and paid the third launch and its boundary in every step).
+constexpr int DIRECT_BLOCKS = SP_K8_DIRECT_BLOCKS;
+constexpr int PERSIST_BLOCKS = 128;     // workgroups of a problem up to which a batch may run as persistent kernels (all workgroups of the batch resident together)
 
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B, int block) {
     int pi = 0;
@@ -1790,7 +1797,7 @@ template <int MAXP>
 __global__ void __launch_bounds__(1024) cons_control_kernel(ConsBatchT<MAXP> B) { cons_control_body<MAXP>(B); }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Persistent mode (batches whose problems all have <= DIRECT_BLOCKS workgroups and whose workgroups fit the device together): the same two bodies, each in a
+// Persistent mode (batches whose problems all have <= PERSIST_BLOCKS workgroups and whose workgroups fit the device together): the same two bodies, each in a
 // loop of its own kernel, started ONCE per batch on two streams.  A step workgroup runs step k when the problem's control workgroup has answered step k - 1,
 // then reports in; the control workgroup runs control step k when all workgroups of its problem have reported step k.  No kernel boundary, no dispatch, and no
 // lockstep between the problems of the batch: each search runs at the pace of its own chain.  (A launch pair per step cost a CYP2D6 sample 34 of its 105 us per
@@ -2049,7 +2056,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         for (uint32_t p = 0; p < n_prob; ++p) {
             const uint32_t n = probs[p].read_idx ? probs[p].n : probs[p].reads->n;
             const uint32_t nb = (n + CWAVES - 1) / CWAVES;
-            small = small && nb <= (uint32_t)DIRECT_BLOCKS;
+            small = small && nb <= (uint32_t)PERSIST_BLOCKS;
             blocks1 += nb;
         }
         constexpr int WG_PER_CU = SP_K8_MIN_WAVES * 4 / CWAVES;             // step workgroups a CU holds at the kernel's register budget
