@@ -1079,7 +1079,8 @@ def main():
     # SURVEY 8(d)'s streaming model for the consensus: every search level reads the packed bases of its reads once and writes one 32-byte record per read
     searches = batches if batches else 3.0                  # (a batch = the searches of one level of the multi-way consensus, all open groups in lockstep)
     algo_bytes = searches * (cyp_packed_bytes + 32.0 * cyp_samples[0].n)
-    roof = {"bound": "valu", "kernel": "cons_step_kernel<8>" if batches_per_step == 0 else "cons_step_kernel<8> / cons_step_persist_kernel<8> (one body; %.1f batches per step ran as persistent kernels, the library's choice)" % batches_per_step,
+    roof = {"bound": "valu", "kernel": "cons_step_wide_kernel<8> / cons_step_kernel<8> (one body at 2 / 4 waves per SIMD: batches of up to 320 / more workgroups)" +
+                                       ("" if batches_per_step == 0 else "; %.1f batches per step ran as cons_step_persist_kernel<8>, the library's choice" % batches_per_step),
             "achieved": (pmc["sq_insts_valu_per_bench_step"] / (step_ms * 1e-3)) if (pmc and step_ms > 0) else None, "peak": peaks["valu_int_wave_instr_per_s"], "unit": "wave-instr/s",
             "frac": (pmc["sq_insts_valu_per_bench_step"] / (step_ms * 1e-3) / peaks["valu_int_wave_instr_per_s"]) if (pmc and step_ms > 0) else None,
             "traffic": pmc["hbm_bytes_per_bench_step"] if pmc else None,

@@ -1231,6 +1231,12 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
 
 template <int MAXP>
 __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_kernel(ConsBatchT<MAXP> B) { cons_step_body<MAXP>(B); }
+// The same body at two waves per SIMD (one workgroup per CU): 240 registers and no spill code, where the first instantiation keeps 128 and spills 73 to scratch -- 11 MB of dirty
+// scratch lines per launch that the launch's end writes back (profiles/r05/counters_cons_step.json).  For a batch whose workgroups fit the device in one round either way (a
+// single sample's searches: <= one workgroup per CU) it is the faster one (`*4+*68/*1` alone 165 -> 155 ms; a rank's 32-sample share 0.138 -> 0.133 s); a batch with more workgroups
+// than CUs (an HLA gene of 5,000 reads: 625) needs the two workgroups per CU of the first (its step 111 -> 133 us with this one).
+template <int MAXP>
+__global__ void __launch_bounds__(CWAVES * SP_WAVE, 2) cons_step_wide_kernel(ConsBatchT<MAXP> B) { cons_step_body<MAXP>(B); }
 
 // sums the vote words of CLUSTER consecutive workgroups of a problem (several hundred workgroups would otherwise be summed by the one
 // workgroup of the control kernel, word by word from memory).  RSLICES workgroups per cluster, each a slice of the words: with 256-column
@@ -2214,6 +2220,10 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         if (setup[p].n) hipLaunchKernelGGL(cons_setup_kernel, dim3((setup[p].n + 255) / 256), dim3(256), 0, st, setup[p], d_info);
 
     const dim3 grid((uint32_t)n_blocks), block(CWAVES * SP_WAVE);
+    // (the step kernel's instantiation for batches that fit the device at one workgroup per CU, give or take a few: cons_step_wide_kernel.  A 2,000-read CYP2D6 sample's first batch
+    //  has 271 workgroups -- its 2,162 region segments -- and is still faster there)
+    static const int wide_max = std::getenv("SP_K8_WIDE_MAX") ? std::atoi(std::getenv("SP_K8_WIDE_MAX")) : -1;      // (experiment switch)
+    const bool one_round = n_blocks <= (wide_max >= 0 ? wide_max : ctx->num_cus + ctx->num_cus / 4);
     const size_t proc_lds = ((size_t)max_cap + 2 + 15) & ~(size_t)15;
     {   // the control kernel's node table and vote sums are static LDS; the per-length counters come on top (160 KiB per workgroup on gfx950)
         hipFuncAttributes fa;
@@ -2299,7 +2309,8 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         }
         while (!finished) {
             const auto tl0 = std::chrono::steady_clock::now();
-            hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
+            if (one_round) hipLaunchKernelGGL(cons_step_wide_kernel<MAXP>, grid, block, 0, st, B);
+            else hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
             if (need_reduce) hipLaunchKernelGGL(cons_reduce_kernel<MAXP>, dim3((uint32_t)n_clusters * RSLICES), dim3(512), 0, st, B);
             hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, st, B);
             t_launch += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();

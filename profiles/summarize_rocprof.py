@@ -101,10 +101,10 @@ tot = defaultdict(float); ndisp = defaultdict(int)
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     for f in find(sub + "/**/*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
-            if "cons_step_kernel<8>" in row.get("Kernel_Name", ""):
+            if "cons_step_kernel<8>" in row.get("Kernel_Name", "") or "cons_step_wide_kernel<8>" in row.get("Kernel_Name", ""):
                 tot[row.get("Counter_Name")] += float(row.get("Counter_Value", 0) or 0); ndisp[row.get("Counter_Name")] += 1
 if tot.get("SQ_INSTS_VALU"):
-    rec = {"kernel": "cons_step_kernel<8> (the CYP2D6 context's consensus steps as launch pairs)", "steps_in_pass": steps_in_pass,
+    rec = {"kernel": "cons_step_wide_kernel<8> + cons_step_kernel<8> (the CYP2D6 contexts' consensus steps as launch pairs: one body, two register budgets)", "steps_in_pass": steps_in_pass,
            "dispatches_per_bench_step": ndisp["SQ_INSTS_VALU"] / steps_in_pass,
            "sq_insts_valu_per_bench_step": tot["SQ_INSTS_VALU"] / steps_in_pass, "sq_insts_salu_per_bench_step": tot.get("SQ_INSTS_SALU", 0.0) / steps_in_pass,
            "sq_insts_lds_per_bench_step": tot.get("SQ_INSTS_LDS", 0.0) / steps_in_pass,
@@ -112,6 +112,6 @@ if tot.get("SQ_INSTS_VALU"):
            "hbm_bytes_per_bench_step": (2.0 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024.0 / steps_in_pass,
            "cons_source_sha16": cons_source_sha16(),
            "method": "rocprofv3 --pmc passes of profiles/run_rocprof.sh (SQ_INSTS_VALU / SALU / LDS, FETCH_SIZE, WRITE_SIZE in separate passes; KB -> bytes, FETCH_SIZE doubled: "
-                     "gfx950 tallies 128-B requests at 64 B), summed over every cons_step_kernel<8> dispatch of the pass and divided by the pass's %d bench steps (the six configs[2] scenarios + the warm-up step)" % steps_in_pass}
+                     "gfx950 tallies 128-B requests at 64 B), summed over every cons_step_wide_kernel<8> / cons_step_kernel<8> dispatch of the pass and divided by the pass's %d bench steps (the six configs[2] scenarios + the warm-up step)" % steps_in_pass}
     json.dump(rec, open(os.path.join(out, "counters_cons_step.json"), "w"), indent=1)
     print("== cons_step", rec)
