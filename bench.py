@@ -830,7 +830,10 @@ def main():
     def hla_work(R, i):
         db_ = hla_dbs[hla_ctxs.index(R.ctx)]
         o = db_.realign_reads(R)
-        calls = db_.diplotype_genes(genes, R, o)[0]
+        if os.environ.get("SP_BENCH_HLA_LOCKSTEP"):           # (an experiment switch: the sample's genes as ONE lockstep batch through sp_hla_diplotype_cohort instead of a stream each)
+            calls = db_.diplotype_cohort(1, np.zeros(R.n, np.uint32), genes, R, o)[0][0]
+        else:
+            calls = db_.diplotype_genes(genes, R, o)[0]
         last["hla"] = (i, o, calls)
         return calls
 
