@@ -386,13 +386,14 @@ __global__ void af_scatter_kernel(const sp_affine_aln* __restrict__ part, const 
 // the mappings of cells (WFA orientation: Aw streamed, Bw window; d_ref = the alignments the caller holds) re-scored into d_out (a_* on minimap2's query, b_* on its target:
 // target_is_a tells which of the two sets is the target); everything stays on the device
 int sp_rescore_mappings(sp_ctx* ctx, const sp_seqset* Aw, const sp_seqset* Bw, const CellDesc* d_cells, const sp_aln* d_ref, uint64_t n, bool target_is_a,
-                        const sp_affine_opts& o, int band, sp_affine_aln* d_out, const char* prefix, uint32_t stride, int trace_retry_wide) {
+                        const sp_affine_opts& o, int band, sp_affine_aln* d_out, const char* prefix, uint32_t stride, int trace_retry_wide, const sp_aln* d_tr_in, const uint32_t* d_ev_in) {
     if (n == 0) return SP_OK;
     const std::string pre(prefix);
     static std::mutex names_lock; static std::set<std::string> names;                 // (the profiler keeps the pointers it is given)
     auto stable = [&](const std::string& n2) { std::lock_guard<std::mutex> g(names_lock); return names.insert(n2).first->c_str(); };
-    sp_aln* d_tr = (sp_aln*)sp_pool(ctx, (pre + "_tr").c_str(), n * sizeof(sp_aln));
-    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, (pre + "_ev").c_str(), n * (size_t)stride * 4);
+    // (d_tr_in / d_ev_in: the caller ran its cells with their traceback itself -- d_ref's own alignments and their edit events, `stride` words each: no second run of the cells)
+    const sp_aln* d_tr = d_tr_in ? d_tr_in : (const sp_aln*)sp_pool(ctx, (pre + "_tr").c_str(), n * sizeof(sp_aln));
+    const uint32_t* d_ev = d_ev_in ? d_ev_in : (const uint32_t*)sp_pool(ctx, (pre + "_ev").c_str(), n * (size_t)stride * 4);
     AfPair* d_todo = (AfPair*)sp_pool(ctx, (pre + "_todo").c_str(), n * sizeof(AfPair));
     uint32_t* d_at = (uint32_t*)sp_pool(ctx, (pre + "_at").c_str(), n * 4 + 64);
     sp_affine_aln* d_part = (sp_affine_aln*)sp_pool(ctx, (pre + "_part").c_str(), n * sizeof(sp_affine_aln));
@@ -401,7 +402,8 @@ int sp_rescore_mappings(sp_ctx* ctx, const sp_seqset* Aw, const sp_seqset* Bw, c
     if (!d_tr || !d_ev || !d_todo || !d_at || !d_part || !d_win || !d_mid) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "rescore buffers");
     uint32_t* d_n = d_at + n;
     (void)hipMemsetAsync(d_n, 0, 4, ctx->stream);
-    int rc = sp_launch_cells(ctx, Aw, Bw, d_cells, n, d_tr, d_ev, stride, stable(pre + "_trace"), trace_retry_wide);
+    int rc = SP_OK;
+    if (!d_tr_in) rc = sp_launch_cells(ctx, Aw, Bw, d_cells, n, const_cast<sp_aln*>(d_tr), const_cast<uint32_t*>(d_ev), stride, stable(pre + "_trace"), trace_retry_wide);
     if (rc != SP_OK) return rc;
     hipLaunchKernelGGL(af_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cells, d_ref, d_tr, d_ev, stride, (uint32_t)n, target_is_a ? 1 : 0,
                        (Aw->has_n || Bw->has_n) ? 1 : 0, o, d_out, d_todo, d_at, d_n, d_win, d_mid, band, ctx->mm2_rescore == 2 ? 0 : 1);

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(SP_ANCHOR_THREADS) void sp_anchor_kernel(SeqSetView
     auto fetch = [&](uint64_t q) {
         PairMeta x;
         x.a = a_idx[q]; x.b = b_idx[q];
+        if (x.b == SP_ANCHOR_SKIP) { x.m = 0; x.n = 0; x.woff = 0; x.k0 = 0; x.k1 = 0; return x; }       // (a pair the caller does not need: no votes, diagonal 0)
         x.m = A.len[x.a]; x.n = B.len[x.b]; x.woff = B.word_off[x.b]; x.k0 = KA.off[x.a]; x.k1 = KA.off[x.a + 1];
         return x;
     };

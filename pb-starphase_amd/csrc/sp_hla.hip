@@ -414,6 +414,14 @@ __global__ void k1_seed_store_kernel(sp_hla_realign* __restrict__ rec, uint32_t 
 }
 
 // K1 reduce: one wavefront per read, exact restatement of the acceptance loop (realigner.rs:124-146)
+// seeded mode: the same pair list with every pair but (gene of the read's accepted allele, read) marked for the anchor kernel to skip
+__global__ void k1_seed_pairs_kernel(const int32_t* __restrict__ best, const uint32_t* __restrict__ gene_of, uint32_t n_reads, uint32_t n_genes, uint32_t* __restrict__ a_idx, uint32_t* __restrict__ b_idx) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_reads * n_genes) return;
+    const uint32_t r = p / n_genes, g = p % n_genes;
+    const int b = best[r];
+    a_idx[p] = g; b_idx[p] = (b >= 0 && gene_of[b] == g) ? r : SP_ANCHOR_SKIP;
+}
 // pair p of the K1 anchor is (gene p % G, read p / G); every read starts without a bound
 __global__ void k1_init_kernel(uint32_t* __restrict__ a_idx, uint32_t* __restrict__ b_idx, uint32_t n_reads, uint32_t n_genes,
                                unsigned long long* __restrict__ bound) {
@@ -1124,8 +1132,10 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         d_bound = (unsigned long long*)sp_pool(ctx, "k1_bound", (size_t)R * 8);
         if (!d_bound) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign bound");
     }
-    if (rc == SP_OK) hipLaunchKernelGGL(k1_init_kernel, dim3((R * G + 255) / 256), dim3(256), 0, ctx->stream, d_a, d_b, R, G, d_bound);
-    if (rc == SP_OK) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes, 1, "anchor_k1", G);
+    // (seeded mode: the anchors against the genes' references only serve the finalize stage -- the diagonal of the read's segment on the reference of the ACCEPTED allele's gene --
+    //  and are made behind the seeded map, for that gene alone)
+    if (rc == SP_OK && !seeded) hipLaunchKernelGGL(k1_init_kernel, dim3((R * G + 255) / 256), dim3(256), 0, ctx->stream, d_a, d_b, R, G, d_bound);
+    if (rc == SP_OK && !seeded) rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes, 1, "anchor_k1", G);
     // reads with a weak forward anchor are listed now; their count comes back with the first pass's own host synchronisation
     uint32_t* d_weak_n = (uint32_t*)sp_pool(ctx, "k1_weak_n", 4);
     uint32_t* d_weak = (uint32_t*)sp_pool(ctx, "k1_weak", (size_t)R * 4);
@@ -1165,6 +1175,10 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         d_seed_info = (sp_k1_seed_info*)sp_pool(ctx, "k1s_info", (size_t)R * sizeof(sp_k1_seed_info));
         if (!d_win_aln || !d_win_af || !d_seed_info) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
         else rc = sp_k1_seed_map(ctx, db->seed, db->dna_fwd, reads, ctx->k1_best_n, d_best, d_seed_info, d_win_aln, d_win_af, nullptr);
+        if (rc == SP_OK) {
+            hipLaunchKernelGGL(k1_seed_pairs_kernel, dim3((R * G + 255) / 256), dim3(256), 0, ctx->stream, d_best, db->d_gene_of, R, G, d_a, d_b);
+            rc = sp_launch_anchor(ctx, db->ref_fwd, reads, d_a, d_b, (uint64_t)R * G, d_rg, d_votes, 1, "anchor_k1", G);
+        }
         weak_known = true;
     }
     for (int pass = 0; pass < n_pass && rc == SP_OK; ++pass) {

@@ -90,6 +90,41 @@ __device__ __forceinline__ bool is_minimizer(const uint64_t* __restrict__ h, int
     if (l + r >= MZ_W - 1) return true;
     return lb && rb && !tie;
 }
+// is_minimizer for every position of a tile (all threads of the 256-thread workgroup call it, h[] complete and synchronised): mzf[j] = 1 when the k-mer at slot HALO + j is one.
+// The scan of a true minimizer reads all 36 neighbours and the lanes of its wave wait for it (two thirds of the seeds kernel's time): a first pass looks MZ_QUICK neighbours
+// either way with every lane in step -- a k-mer that meets a smaller one on both sides within that reach is decided there (l + r < w - 1; the stretch rule needs both ends inside
+// the reach too) --, the others (a third of the positions) go on a list and the full scans run with the waves packed with them.
+#ifndef SP_MZ_QUICK
+#define SP_MZ_QUICK 5
+#endif
+constexpr int MZ_QUICK = SP_MZ_QUICK;
+__device__ __forceinline__ void tile_minimizers(const uint64_t* __restrict__ h, int lo, int len, uint8_t* __restrict__ mzf, uint16_t* __restrict__ cand, uint32_t* __restrict__ n_cand) {
+    if (threadIdx.x == 0) *n_cand = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < TILE; j += 256) {
+        const int c = HALO + j;
+        const uint64_t hp = h[c];
+        uint8_t f = 0;
+        if (lo + j < len && hp < H_PAL) {
+            int l = MZ_QUICK, r = MZ_QUICK; bool lb = false, rb = false, tie = false;
+#pragma unroll
+            for (int x = MZ_QUICK - 1; x >= 0; --x) {                      // (nearest stop wins: walk inwards)
+                const uint64_t vl = h[c - 1 - x], vr = h[c + 1 + x];
+                if (vl == H_NONE) { l = x; lb = true; } else if (vl < hp) { l = x; lb = false; }
+                if (vr == H_NONE) { r = x; rb = true; } else if (vr < hp) { r = x; rb = false; }
+            }
+            if (l < MZ_QUICK && r < MZ_QUICK) {
+                // both scans end inside the reach: l + r < w - 1, so only a stretch shorter than a window can make it one (its last smallest k-mer: no tie to the right)
+                if (lb && rb) { for (int x = 0; x < r; ++x) tie |= h[c + 1 + x] == hp; f = tie ? 0 : 1; }
+            } else cand[atomicAdd(n_cand, 1u)] = (uint16_t)c;
+        }
+        mzf[j] = f;
+    }
+    __syncthreads();
+    const uint32_t nc = *n_cand;
+    for (uint32_t i = threadIdx.x; i < nc; i += 256) { const int c = cand[i]; mzf[c - HALO] = is_minimizer(h, c) ? 1 : 0; }
+    __syncthreads();
+}
 // rank of the calling thread among the threads of the block that pass `flag`, in thread order; total = how many do
 __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* wave_tot, uint32_t& total) {
     const unsigned long long b = __ballot(flag);
@@ -118,7 +153,9 @@ __global__ __launch_bounds__(256) void mz_sketch_kernel(SeqSetView S, const uint
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ occ) {
     __shared__ uint64_t h[TILE + 2 * HALO];
     __shared__ uint8_t zs[TILE + 2 * HALO];
-    __shared__ uint32_t wave_tot[4];
+    __shared__ uint8_t mzf[TILE];
+    __shared__ uint16_t cand[TILE];
+    __shared__ uint32_t wave_tot[4], n_cand;
     const uint32_t rid = blockIdx.x;
     if (rid >= n) return;
     const uint32_t s = seq_of ? seq_of[rid] : rid;
@@ -130,9 +167,10 @@ __global__ __launch_bounds__(256) void mz_sketch_kernel(SeqSetView S, const uint
         __syncthreads();
         for (int c = threadIdx.x; c < TILE + 2 * HALO; c += 256) { uint8_t z; h[c] = kmer_hash(w, np, len, lo - HALO + c, z); zs[c] = z; }
         __syncthreads();
+        tile_minimizers(h, lo, len, mzf, cand, &n_cand);
         for (int j = 0; j < TILE; j += 256) {
             const int c = HALO + j + (int)threadIdx.x, pos = lo + j + (int)threadIdx.x;
-            const bool flag = pos < len && is_minimizer(h, c);
+            const bool flag = pos < len && mzf[j + (int)threadIdx.x] != 0;
             uint32_t total;
             const uint32_t rk = block_rank(flag, wave_tot, total);
             if (FILL && flag) {
@@ -170,8 +208,10 @@ __global__ __launch_bounds__(256) void k1s_seed_kernel(SeqSetView reads, IndexVi
     uint16_t* sd_n = reinterpret_cast<uint16_t*>(sd_st + sd_cap);       // occurrences, capped at 65535 (only values <= 4095 are ever told apart, see below)
     uint8_t* zs = reinterpret_cast<uint8_t*>(sd_n + sd_cap);            // TILE + 2 HALO
     uint8_t* keep = zs + TILE + 2 * HALO + 8;                            // sd_cap
-    __shared__ uint32_t wave_tot[4], s_sum[4];
+    __shared__ uint32_t wave_tot[4], s_sum[4], n_cand;
     __shared__ unsigned long long s_base;
+    __shared__ uint8_t mzf[TILE];
+    __shared__ uint16_t cand[TILE];
     const uint32_t r = blockIdx.x;
     if (r >= n_reads) return;
     const int len = reads.len[r];
@@ -182,9 +222,10 @@ __global__ __launch_bounds__(256) void k1s_seed_kernel(SeqSetView reads, IndexVi
         __syncthreads();
         for (int c = threadIdx.x; c < TILE + 2 * HALO; c += 256) { uint8_t z; h[c] = kmer_hash(w, np, len, lo - HALO + c, z); zs[c] = z; }
         __syncthreads();
+        tile_minimizers(h, lo, len, mzf, cand, &n_cand);
         for (int j = 0; j < TILE; j += 256) {
             const int c = HALO + j + (int)threadIdx.x, pos = lo + j + (int)threadIdx.x;
-            bool flag = pos < len && is_minimizer(h, c);
+            bool flag = pos < len && mzf[j + (int)threadIdx.x] != 0;
             uint32_t st = 0, n = 0;
             if (flag) { index_lookup(ix, h[c], st, n); flag = n > 0; }
             uint32_t total;
@@ -1451,10 +1492,15 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
     const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
     const unsigned nb = (unsigned)((NC + 255) / 256);
     hipLaunchKernelGGL(k1s_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_sel, d_sel_cnt, R, idx->d_rid_allele, alleles->d_len, 0, d_cells);
-    int rc = sp_launch_cells(ctx, alleles, reads, d_cells, NC, d_aln, nullptr, 0, "k1s_cells", 1);
+    // the cells run WITH their traceback: the re-score needs the edit positions of exactly these alignments (it used to run every cell a second time for them).  The events of a
+    // cell take as many words as its edit cap can reach: 3 % of the longest allele
+    const uint32_t ev_stride = (uint32_t)std::min<int64_t>(SP_MAX_ED, (int64_t)(0.03 * (double)alleles->max_len) + 2);
+    uint32_t* d_ev = (uint32_t*)sp_pool(ctx, "k1s_ev", NC * (size_t)ev_stride * 4);
+    if (!d_ev) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "seeded K1: cell events");
+    int rc = sp_launch_cells(ctx, alleles, reads, d_cells, NC, d_aln, d_ev, ev_stride, "k1s_cells", 1);
     if (rc != SP_OK) return rc;
     hipLaunchKernelGGL(k1s_rescore_cells_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_cells, d_aln, (uint32_t)NC, d_rc, 0, d_ctr);
-    rc = sp_rescore_mappings(ctx, alleles, reads, d_rc, d_aln, NC, true, ao, 64, d_af, "k1s_af", 128);
+    rc = sp_rescore_mappings(ctx, alleles, reads, d_rc, d_aln, NC, true, ao, 64, d_af, "k1s_af", ev_stride, 0, d_aln, d_ev);
     if (rc != SP_OK) return rc;
     // chains on the reverse strand (a read from the other strand, the homologous gene on the other strand): the same through the reads' reverse complements
     SP_HIP_CHECK(ctx, hipMemcpyAsync(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
