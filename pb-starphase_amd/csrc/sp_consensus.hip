@@ -654,6 +654,7 @@ constexpr int PERSIST_LIGHT = SP_K8_LIGHT;          // resident workgroups (step
 // problems has no reduce launch -- two launches per step instead of three.  The bound is the 16-bit vote fields: 12 units per read and column, 5,461 reads = 682 workgroups at one
 // read per wave (128 until round 5: an HLA gene of a 10,000-read sample has 625 workgroups and paid the third launch and its boundary in every step).
 constexpr int DIRECT_BLOCKS = SP_K8_DIRECT_BLOCKS;
+constexpr int32_t SP_K8_AGAIN = -777;    // run_chunk to its caller: run the batch again (never leaves the library)
 constexpr int PERSIST_BLOCKS = 128;     // workgroups of a problem up to which a batch may run as persistent kernels (all workgroups of the batch resident together)
 
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B, int block) {
@@ -2352,7 +2353,18 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     lease.give_back();
     if (persist_ran) {
         for (uint32_t p = 0; p < n_prob; ++p) {
-            if (h_prog[2 * p + 1] == 2u) { ctx->k8_persist_failures += 1; ctx->k8_persist_backoff = 64; return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the persistent kernels of a batch waited for each other for more than four seconds and gave up"); }
+            if (h_prog[2 * p + 1] == 2u) {
+                // a wait of the batch's kernels for each other timed out (other processes' resident workgroups on the device, which this process's lease cannot see): both kernels have
+                // ended (the stream is synchronised).  Where the mode was the library's own choice the batch is run again from its start as launch pairs (the caller below), the
+                // context stays away from the mode for a while and says so; a caller that asked for the mode gets the error
+                ctx->k8_persist_failures += 1; ctx->k8_persist_backoff = 64;
+                if (ctx->k8_persistent == 2) {
+                    ctx->warning = "persistent consensus kernels: the kernels of a batch waited for each other for more than four seconds (another process on this device?): the batch ran "
+                                   "again launch by launch, and so will the next 64";
+                    return SP_K8_AGAIN;
+                }
+                return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the persistent kernels of a batch waited for each other for more than four seconds and gave up");
+            }
             if (h_prog[2 * p + 1] == 3u) return sp_fail(ctx, SP_ERR_HIP, "sp_consensus: the search did not finish");
             pairs = std::max<uint64_t>(pairs, h_prog[2 * p]);
         }
@@ -2430,8 +2442,10 @@ static int32_t run_batch(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     const uint32_t big = 4096;                               // problems per launch sequence once the descriptors live in device memory
     for (uint32_t at = 0; at < n_prob; at += big) {
         const uint32_t k = std::min<uint32_t>(big, n_prob - at);
-        const int32_t e = k <= 4 ? run_chunk<4>(ctx, k, probs + at, outs + at) : k <= 8 ? run_chunk<8>(ctx, k, probs + at, outs + at)
-                        : k <= CMAXP ? run_chunk<CMAXP>(ctx, k, probs + at, outs + at) : run_chunk<0>(ctx, k, probs + at, outs + at);
+        auto run = [&]() { return k <= 4 ? run_chunk<4>(ctx, k, probs + at, outs + at) : k <= 8 ? run_chunk<8>(ctx, k, probs + at, outs + at)
+                                  : k <= CMAXP ? run_chunk<CMAXP>(ctx, k, probs + at, outs + at) : run_chunk<0>(ctx, k, probs + at, outs + at); };
+        int32_t e = run();
+        if (e == SP_K8_AGAIN) e = run();                    // (the library's own persistent batch timed out: once more, as launch pairs -- the context's back-off sees to that)
         if (e != SP_OK && e != SP_ERR_CAPACITY) return e;
         if (e != SP_OK) rc = e;
     }
