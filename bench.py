@@ -676,7 +676,7 @@ def main():
     ap.add_argument("--workload", choices=("auto", "sample", "cohort"), default="auto",
                     help="auto: at N = 1 the sample (one sample per step, both loci: BASELINE configs[1] + configs[2]); at N > 1 the cohort (BASELINE configs[4]: 256 samples sharded over "
                          "the ranks, the call records gathered through sp_gather_results over RCCL), with the ranks' independent streams of samples as a second block of the line")
-    ap.add_argument("--cyp-lanes", type=int, default=6, help="CYP2D6 samples in flight beside the HLA half of the stream (contexts that share the stream of CYP2D6 samples)")
+    ap.add_argument("--cyp-lanes", type=int, default=4, help="CYP2D6 samples in flight beside the HLA half of the stream (contexts that share the stream of CYP2D6 samples)")
     ap.add_argument("--hla-lanes", type=int, default=1, help="HLA samples in flight (contexts that share the stream of HLA samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-hla-reads", type=int, default=5000, help="HLA reads of sample 0 the CPU leg runs (0: all of them)")
