@@ -22,6 +22,8 @@ stages = ["host:cyp_" + k for k in ("regions", "segments", "consensus", "merge",
 CASES = ((6, 12, 0), (6, 12, 1), (1, 64, 0), (1, 64, 1), (2, 8, 1), (4, 8, 0), (4, 8, 1), (6, 5, 1), (6, 12, 0), (6, 12, 1))
 if len(sys.argv) > 2 and sys.argv[2] == "three":
     CASES = ((6, 12, 0), (3, 10, 0), (6, 12, 0), (3, 10, 0), (3, 10, 1))
+if len(sys.argv) > 2 and sys.argv[2] == "auto":           # the library's own choice of consensus mode (k8_persistent 2), round 5
+    CASES = ((2, 12, 2), (2, 12, 2), (2, 12, 0), (1, 64, 2), (4, 8, 2), (2, 12, 2))
 if len(sys.argv) > 2 and sys.argv[2] == "streams":
     CASES = ((6, 12, 0), (2, 12, 0), (3, 12, 0), (4, 12, 0), (6, 12, 0), (8, 12, 0), (2, 12, 0), (3, 12, 0), (4, 12, 0))
 for streams, mg, pers in CASES:
@@ -32,5 +34,6 @@ for streams, mg, pers in CASES:
     dt = time.perf_counter() - t0
     good = sum(sorted([c[0].hap1.decode(), c[0].hap2.decode()]) == sorted(e) for c, e in zip(calls, sh.cyp_expected))
     parts = min(max(1, N // mg), streams)
-    print("persistent" if pers else "launches  ", int(ctx.profile_get("cons_persistent_batches")[2]), f"{N} samples, {parts} stream(s) x groups of {-(-N // parts)}: {1e3 * dt:7.1f} ms  ({1e3 * dt / N:5.2f} ms per sample, {good}/{N} equal truth)  " +
-          " ".join(f"{s.split(':')[-1].replace('cyp_', '')} {ctx.profile_get(s)[0]:.0f}" for s in stages), flush=True)
+    print({0: "launches  ", 1: "persistent", 2: "auto      "}[pers], int(ctx.profile_get("cons_persistent_batches")[2]), f"{N} samples, {parts} stream(s) x groups of {-(-N // parts)}: {1e3 * dt:7.1f} ms  ({1e3 * dt / N:5.2f} ms per sample, {good}/{N} equal truth)  " +
+          " ".join(f"{s.split(':')[-1].replace('cyp_', '')} {ctx.profile_get(s)[0]:.0f}" for s in stages) +
+          f" | batches {ctx.profile_get('cons_steps')[1]} steps {ctx.profile_get('cons_windows')[2]} expansions {ctx.profile_get('cons_expansions')[2]} columns {ctx.profile_get('cons_columns')[2]}", flush=True)
