@@ -732,21 +732,45 @@ def main():
     db = fx.make_db(pkg, ctx)
     cdb = pkg.ffi.CypDb(ctx, cfg, gene_def, locus.sequence, locus.start)
     group, gather_via = None, "single rank"
+    group_fallback = None
     if world > 1 and workload == "cohort":                  # (the streams of samples exchange nothing: no communicator)
-        # sp_group: RCCL through the library (sp_gather_results).  Should the library's communicator not come up on this node, every rank falls back to the
-        # torch process group together (the decision is agreed on with one all-reduce) and the line says which path gathered
-        try:
-            group = shard.make_group(ctx, pkg.ffi, backend=backend, device=coll_dev)
-            ok_here = 1
-        except Exception as e:
-            print(f"rank {rank}: sp_group_create failed ({e}); gathering through torch.distributed instead", file=sys.stderr, flush=True)
+        # sp_group: RCCL through the library (sp_gather_results).  The communicator is made AND tried -- one small gather whose answer is known -- on a helper thread with a
+        # time limit, before anything is timed: should the library's communicator not come up on this node (an error, or a rank that never returns from the library's
+        # ncclCommInitRank / first all-gather), every rank falls back to the torch process group together -- the decision is agreed on with one all-reduce -- and the line says
+        # which path gathered and why.  A communicator that was given up is left alone (no destroy call that could wait for the same peers)
+        box = {}
+
+        def bring_up():
+            try:
+                torch.cuda.set_device(device_index)           # (the current device is a per-thread setting)
+                if os.environ.get("SP_BENCH_INJECT_GROUP_HANG") == "1":
+                    time.sleep(3600)
+                g = shard.make_group(ctx, pkg.ffi, backend=backend, device=coll_dev)
+                probe = np.zeros(2, shard.CALL_DTYPE); probe["sample"] = rank; probe["gene"] = [0, 1]; probe["allele1"] = 1000 + rank
+                got = g.gather(probe)
+                want = np.stack([np.array([(r, 0, 1000 + r, 0), (r, 1, 1000 + r, 0)], shard.CALL_DTYPE) for r in range(world)])
+                if got.shape != want.shape or not (got == want).all():
+                    raise RuntimeError("the first gather did not return every rank's records")
+                box["group"] = g
+            except Exception as e:
+                box["error"] = e
+        th = threading.Thread(target=bring_up, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("SP_BENCH_GROUP_TIMEOUT_S", "180")))
+        if th.is_alive():
+            box["error"] = TimeoutError("the communicator did not come up within the time limit")
+        group, ok_here = box.get("group"), 1
+        if "error" in box:
+            print(f"rank {rank}: the library's group failed ({box['error']}); gathering through torch.distributed instead", file=sys.stderr, flush=True)
             group, ok_here = None, 0
         flag = torch.tensor([ok_here], dtype=torch.int32, device=coll_dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            if group is not None and hasattr(group, "close") and not isinstance(group, shard.TorchGroup):
-                group.close()
+            if group is not None and hasattr(group, "_h") and not isinstance(group, shard.TorchGroup):
+                import ctypes
+                group._h = ctypes.c_void_p()                 # given up, not destroyed
             group = shard.TorchGroup(coll_dev)
+            group_fallback = str(box.get("error", "another rank's group failed"))
         gather_via = "torch.distributed" if isinstance(group, shard.TorchGroup) else "sp_gather_results (librccl)"
 
     def barrier():
@@ -784,7 +808,7 @@ def main():
                    "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
                    "config": {"workload": line["workload"], "samples": line["samples"], "parallelism": f"samples sharded over {world} GPU(s), one all-gather of the call records per pass through {gather_via}"
                               if backend == "nccl" else f"samples sharded over {world} rank(s) on shared devices, gather through torch.distributed ({backend})"},
-                   "cohort": line, "one_gpu_same_cohort": blocks.get("one_gpu_same_cohort"), "independent_streams": blocks.get("independent_streams"), "second_blocks_error": blocks.get("error"),
+                   "cohort": line, "gather_via": gather_via, "group_fallback": group_fallback, "one_gpu_same_cohort": blocks.get("one_gpu_same_cohort"), "independent_streams": blocks.get("independent_streams"), "second_blocks_error": blocks.get("error"),
                    "roofline": None, "cpu_baseline": None,
                    "note": "BASELINE configs[4], strong scaling: the cohort's work is fixed, every rank owns samples / N of it and hands its whole share to the library in one call; the only exchange is ONE "
                            "all-gather of the call records per pass (sp_gather_results).  The calls keep groups of samples in lockstep, so a rank's rate falls with its share (`legs.cohort.by_share_size` "

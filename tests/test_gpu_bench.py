@@ -52,6 +52,18 @@ def test_sample_line_and_two_rank_cohort_over_gloo():
     c = line["cohort"]
     assert c["samples"] == 7 and c["records_gathered_per_pass"] == 7 * (2 + 1 + 18)
     assert c["calls_equal_truth"]["hla"] == "14/14" and c["calls_equal_truth"]["cyp2d6"] == "7/7"
+    assert line["group_fallback"] is None and line["gather_via"] == "torch.distributed"          # (gloo: the torch group is the path asked for, not a fall-back)
+
+
+def test_a_group_that_never_comes_up_falls_back_to_the_torch_group():
+    """`bench.py --gpus N` brings the ranks' group up -- and tries it with one small gather -- on a helper thread with a time limit before anything is timed; a rank whose
+    group never returns (injected here: SP_BENCH_INJECT_GROUP_HANG) makes every rank gather through torch.distributed, and the line says so"""
+    line = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--cohort-samples", "4", "--no-extra-legs"],
+                     env={"SP_BENCH_BACKEND": "gloo", "SP_BENCH_INJECT_GROUP_HANG": "1", "SP_BENCH_GROUP_TIMEOUT_S": "2"})
+    assert "time limit" in line["group_fallback"] and line["gather_via"] == "torch.distributed"
+    c = line["cohort"]
+    assert c["samples"] == 4 and c["records_gathered_per_pass"] == 4 * (2 + 1 + 18)
+    assert c["calls_equal_truth"]["hla"] == "8/8" and c["calls_equal_truth"]["cyp2d6"] == "4/4"
 
 
 def test_eight_rank_cohort_of_sixteen_samples_over_gloo():
