@@ -44,7 +44,7 @@ import __graft_entry__ as ge  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2    # 256 CU x 4 SIMD-32 x one wave-instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md); sp_microbench measures it
-COUNTER_DIR = os.path.join(ROOT, "profiles", "r05")
+COUNTER_DIR = os.path.join(ROOT, "profiles", "r06")
 
 
 def cyp_persistent():
@@ -103,6 +103,39 @@ def host_description():
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------------------- the printed line
+LINE_LIMIT = 4000          # bytes of the ONE JSON line on stdout (BENCH_r05.json: a 22 KB line came back unparsed); everything else goes to the side file
+
+
+def _r(x, digits=4):
+    """a float to `digits` significant digits (None stays None)"""
+    if isinstance(x, float):
+        return float(("%." + str(digits) + "g") % x)
+    return x
+
+
+def emit(full, compact, path):
+    """write the whole record to `path` (bench_full.json: legs, critical path, per-scenario CPU blocks) and print the compact line -- the contract's keys, the roofline and
+    cpu_baseline blocks, a few summary numbers -- as the only line on stdout.  Optional blocks are dropped, last first, should the line ever pass LINE_LIMIT"""
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f)
+        compact["full"] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        compact["full"] = "not written: %s" % e
+    optional = ["summary", "concordance", "cohort"]
+    text = json.dumps(compact)
+    while len(text) >= LINE_LIMIT and optional:
+        compact.pop(optional.pop(0), None)
+        text = json.dumps(compact)
+    if len(text) >= LINE_LIMIT:
+        raise SystemExit("bench.py: the line's required blocks alone are %d bytes" % len(text))
+    if os.environ.get("SP_BENCH_FULL_STDERR") == "1":
+        sys.stderr.write(json.dumps(full) + "\n")
+    print(text, flush=True)
+
+
 # ---------------------------------------------------------------------------------------------------------------- CPU baseline
 def native_oracle():
     """the oracle rebuilt on THIS host with -O3 -march=native (the CPU leg is compiled for the machine it runs on); the
@@ -155,7 +188,15 @@ def cpu_baseline(fx, hla_reads, cyp_setup, cyp_sets, n_hla=None, n_cyp=None):
     n = len(done) + n_cyp_total
     wall = hres["wall_s"] + cyp_wall
     one = hres["one_thread_s"] + cyp_one
-    block = {"value": n / wall, "unit": "reads/s", "cores": len(socket_cpus), "kind": "port",
+    phys = set()
+    for c in socket_cpus:
+        try:
+            phys.add(open(f"/sys/devices/system/cpu/cpu{c}/topology/core_id").read().strip())
+        except Exception:
+            phys.add(str(c))
+    block = {"value": n / wall, "unit": "reads/s", "cores": len(socket_cpus), "physical_cores": len(phys), "kind": "port",
+             "sample_short": f"a SAMPLE of the mix `value` runs on: the first {len(done)} of sample 0's {len(hla_reads)} HLA reads + the first {n_cyp or 'all'} reads of each of the {len(cyp_sets)} "
+                             f"CYP2D6 scenarios ({n_cyp_total}); {len(socket_cpus)} logical CPUs ({len(phys)} cores) of one socket of {n_sockets}; the reference's call pattern on oracle/mm2.c + oracle/consensus.c",
              "sample": f"a bounded share of the mix `value` is measured on: the first {len(done)} of sample 0's {len(hla_reads)} HLA reads and the first {n_cyp or 'all'} reads of each of the "
                        f"{len(cyp_sets)} CYP2D6 scenarios the steps cycle through ({n_cyp_total} reads), one locus and one scenario after the other, each with its parallel stages over the "
                        f"{len(socket_cpus)} logical CPUs of one socket (of {n_sockets}) and its sequential stages (consensus, chains) on one",
@@ -531,15 +572,12 @@ def cohort_line(pkg, ctx, fx, db, cdb, locus, scen, world, rank, group, args, ba
     per_call = max(1, min(len(mine), int(os.environ.get("SP_BENCH_PER_CALL", "256"))))
     chunks = [mine[i:i + per_call] for i in range(0, len(mine), per_call)]
     shares = [CohortShare(pkg, fx, locus, scen, panel, c) for c in chunks]
-    if os.environ.get("SP_BENCH_COHORT_SERIAL", "0") != "1":
-        cfg2, gd2 = cdb_source
-        ctx2 = pkg.Context(ctx_device)
-        cdb2 = pkg.ffi.CypDb(ctx2, cfg2, gd2, locus.sequence, locus.start)
-        ctx2.set_option("k8_persistent", cyp_persistent())
-        if os.environ.get("SP_BENCH_CYP_STREAMS"):           # (an experiment switch: streams of the CYP2D6 cohort call, library default 6)
-            ctx2.set_option("cyp_cohort_streams", int(os.environ["SP_BENCH_CYP_STREAMS"]))
-        for sh in shares:
-            sh.beside = (ctx2, cdb2)
+    cfg2, gd2 = cdb_source
+    ctx2 = pkg.Context(ctx_device)
+    cdb2 = pkg.ffi.CypDb(ctx2, cfg2, gd2, locus.sequence, locus.start)
+    ctx2.set_option("k8_persistent", cyp_persistent())
+    for sh in shares:
+        sh.beside = (ctx2, cdb2)
     # every rank makes the same number of gathers per pass, whatever its share: shares differ by one sample when the cohort does not divide by the ranks (and a rank
     # may hold none at all), so the rounds a rank has no chunk for are gathers of zero records, and the counts are only taken as known when all shares are equal
     cap_call = int(os.environ.get("SP_BENCH_PER_CALL", "256"))
@@ -654,12 +692,14 @@ def cohort_leg_in_a_process_of_its_own(n_samples):
         env = dict(os.environ, SP_BENCH_COHORT_SHARES="1")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
-        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cohort", "--steps", "2", "--warmup", "1", "--no-extra-legs", "--cohort-samples", str(n_samples)],
-                               env=env, capture_output=True, text=True, timeout=900)
-        rows = [l for l in child.stdout.splitlines() if l.startswith("{")]
-        if child.returncode != 0 or not rows:
-            raise RuntimeError("the cohort leg's process ended with %d: %s" % (child.returncode, child.stderr[-500:]))
-        return json.loads(rows[-1])["cohort"]
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            side = os.path.join(tmp, "cohort_full.json")
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cohort", "--steps", "2", "--warmup", "1", "--no-extra-legs", "--cohort-samples", str(n_samples),
+                                    "--full-out", side], env=env, capture_output=True, text=True, timeout=900)
+            if child.returncode != 0 or not os.path.exists(side):
+                raise RuntimeError("the cohort leg's process ended with %d: %s" % (child.returncode, child.stderr[-500:]))
+            return json.load(open(side))["cohort"]
     except Exception as e:                                                      # (a leg, not the headline: say so and go on)
         return {"error": str(e)}
 
@@ -682,6 +722,7 @@ def main():
     ap.add_argument("--cpu-hla-reads", type=int, default=5000, help="HLA reads of sample 0 the CPU leg runs (0: all of them)")
     ap.add_argument("--cpu-cyp-reads", type=int, default=1000, help="reads of every CYP2D6 scenario of the mix the CPU leg runs (0: all of them)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-HLA, CYP2D6-scenario, cohort and K5 legs")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "bench_full.json"), help="where the whole record goes (legs, critical path, per-scenario CPU blocks); stdout carries ONE compact line")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -805,7 +846,7 @@ def main():
         if rank == 0:
             out = {"metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)", "value": line["value"], "unit": "reads/s", "n_gpus": world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": line["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                   "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
+                   "dtype": "int32", "data": "synthetic",
                    "config": {"workload": line["workload"], "samples": line["samples"], "parallelism": f"samples sharded over {world} GPU(s), one all-gather of the call records per pass through {gather_via}"
                               if backend == "nccl" else f"samples sharded over {world} rank(s) on shared devices, gather through torch.distributed ({backend})"},
                    "cohort": line, "gather_via": gather_via, "group_fallback": group_fallback, "one_gpu_same_cohort": blocks.get("one_gpu_same_cohort"), "independent_streams": blocks.get("independent_streams"), "second_blocks_error": blocks.get("error"),
@@ -814,7 +855,19 @@ def main():
                            "all-gather of the call records per pass (sp_gather_results).  The calls keep groups of samples in lockstep, so a rank's rate falls with its share (`legs.cohort.by_share_size` "
                            "of the N = 1 line: one GPU on shares of 32 / 64 / 128 samples).  `one_gpu_same_cohort`: the same 256 samples on rank 0 alone, in this run; `independent_streams`: every rank "
                            "its own stream of the N = 1 headline's samples (weak scaling, nothing exchanged).  roofline / cpu_baseline: the N = 1 line carries them"}
-            print(json.dumps(out), flush=True)
+            compact = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+            compact["value"], compact["ms_per_step"] = _r(out["value"], 6), _r(out["ms_per_step"], 6)
+            compact["config"] = {"workload": "BASELINE configs[4]: %d-sample synthetic cohort (HLA-A/-B, CYP2D6, %d variant genes per sample) sharded by sample over the ranks"
+                                             % (line["samples"], line["records_gathered_per_pass"] // max(1, line["samples"]) - 3),
+                                 "samples": line["samples"], "reads_per_pass": line["reads_per_pass"], "ranks": world, "gather_via": gather_via, "group_fallback": group_fallback}
+            compact["roofline"], compact["cpu_baseline"] = None, None
+            compact["cohort"] = {"samples_per_s": _r(line["samples_per_s"]), "calls_equal_truth": line["calls_equal_truth"], "records_gathered_per_pass": line["records_gathered_per_pass"],
+                                 "by_share_size_samples_per_s": {k: _r(v["samples_per_s"]) for k, v in (line.get("by_share_size") or {}).items()} or None}
+            one, ind = blocks.get("one_gpu_same_cohort"), blocks.get("independent_streams")
+            compact["summary"] = {"one_gpu_same_cohort_reads_per_s": _r(one["value"]) if one else None, "value_over_n_times_one_gpu": _r(one["value_over_n_times_this"]) if one else None,
+                                  "independent_streams_reads_per_s": _r(ind["value"]) if ind else None, "second_blocks_error": blocks.get("error"),
+                                  "note": "roofline / cpu_baseline: the N = 1 line carries them"}
+            emit(out, compact, args.full_out)
         if group is not None and hasattr(group, "close"):
             group.close()
         if world > 1:
@@ -830,13 +883,7 @@ def main():
     hla_ctxs = [ctx] + [pkg.Context(device_index) for _ in range(n_hla_lanes - 1)]
     hla_dbs = [db] + [fx.make_db(pkg, c) for c in hla_ctxs[1:]]
     ctx_h = ContextGroup(hla_ctxs)
-    prio_streams = []
-    if os.environ.get("SP_BENCH_CYP_PRIORITY"):             # (an experiment switch: the CYP2D6 contexts on high-priority streams the caller hands to sp_ctx_create)
-        import ctypes
-        prio_streams = [torch.cuda.Stream(device=device_index, priority=-1) for _ in range(n_cyp_lanes)]
-        cyp_ctxs = [pkg.Context(device_index, ctypes.c_void_p(st_.cuda_stream)) for st_ in prio_streams]
-    else:
-        cyp_ctxs = [pkg.Context(device_index) for _ in range(n_cyp_lanes)]
+    cyp_ctxs = [pkg.Context(device_index) for _ in range(n_cyp_lanes)]
     cyp_dbs = [pkg.ffi.CypDb(c, cfg, gene_def, locus.sequence, locus.start) for c in cyp_ctxs]
     ctx_c = ContextGroup(cyp_ctxs)                         # (the group reads the list: lanes a leg adds later count)
     # the consensus mode is the library's own choice (k8_persistent 2 = auto, the default of every context); SP_BENCH_HEADLINE_PERSISTENT = 0 / 1 forces launch pairs / persistent kernels
@@ -844,22 +891,13 @@ def main():
     headline_mode = {"persistent": forced != "0", "fallback": None, "forced": forced}
     if forced is not None:
         ctx_c.set_option("k8_persistent", int(forced))
-    if os.environ.get("SP_BENCH_MM2_RESCORE"):              # (an experiment switch: what the re-scored numbers of K1 / K2 cost the step)
-        ctx.set_option("mm2_rescore", int(os.environ["SP_BENCH_MM2_RESCORE"]))
-    if os.environ.get("SP_BENCH_HLA_SPLIT"):                # (an experiment switch: the two HLA genes of the sample on one stream (0) or two (1, the library's default))
-        ctx.set_option("hla_split_genes", int(os.environ["SP_BENCH_HLA_SPLIT"]))
-    if os.environ.get("SP_BENCH_CYP_SPLIT"):                # (an experiment switch: the CYP2D6 calls' helper stream for the weights' placements off (0) / on (1, the default))
-        ctx_c.set_option("hla_split_genes", int(os.environ["SP_BENCH_CYP_SPLIT"]))
     genes = list(range(len(fx.genes)))
     last = {}
 
     def hla_work(R, i):
         db_ = hla_dbs[hla_ctxs.index(R.ctx)]
         o = db_.realign_reads(R)
-        if os.environ.get("SP_BENCH_HLA_LOCKSTEP"):           # (an experiment switch: the sample's genes as ONE lockstep batch through sp_hla_diplotype_cohort instead of a stream each)
-            calls = db_.diplotype_cohort(1, np.zeros(R.n, np.uint32), genes, R, o)[0][0]
-        else:
-            calls = db_.diplotype_genes(genes, R, o)[0]
+        calls = db_.diplotype_genes(genes, R, o)[0]
         last["hla"] = (i, o, calls)
         return calls
 
@@ -1108,10 +1146,16 @@ def main():
     # SURVEY 8(d)'s streaming model for the consensus: every search level reads the packed bases of its reads once and writes one 32-byte record per read
     searches = batches if batches else 3.0                  # (a batch = the searches of one level of the multi-way consensus, all open groups in lockstep)
     algo_bytes = searches * (cyp_packed_bytes + 32.0 * cyp_samples[0].n)
+    achieved = (pmc["sq_insts_valu_per_bench_step"] / (step_ms * 1e-3)) if (pmc and step_ms > 0) else None
+    # `peak` is the NOMINAL VALU issue rate (256 CUs x 4 SIMDs x one wave-instruction per 2 cycles at 2.4 GHz = 1,229 G wave-instr/s, MI355X_MICROARCH.md); the measured rate of
+    # sp_microbench's integer loop (`measured_peak`) is beside it
     roof = {"bound": "valu", "kernel": "cons_step_wide_kernel<8> / cons_step_kernel<8> (one body at 2 / 4 waves per SIMD: batches of up to 320 / more workgroups)" +
                                        ("" if batches_per_step == 0 else "; %.1f batches per step ran as cons_step_persist_kernel<8>, the library's choice" % batches_per_step),
-            "achieved": (pmc["sq_insts_valu_per_bench_step"] / (step_ms * 1e-3)) if (pmc and step_ms > 0) else None, "peak": peaks["valu_int_wave_instr_per_s"], "unit": "wave-instr/s",
-            "frac": (pmc["sq_insts_valu_per_bench_step"] / (step_ms * 1e-3) / peaks["valu_int_wave_instr_per_s"]) if (pmc and step_ms > 0) else None,
+            "kernel_short": "cons_step_wide_kernel<8> (K8 consensus step)" if batches_per_step == 0 else "cons_step_persist_kernel<8> (K8 consensus step)",
+            "achieved": achieved, "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instr/s",
+            "frac": (achieved / VALU_PEAK_WAVE_INSTR) if achieved else None,
+            "measured_peak": peaks["valu_int_wave_instr_per_s"], "frac_of_measured_peak": (achieved / peaks["valu_int_wave_instr_per_s"]) if achieved else None,
+            "avg_launch_us": _r(1e3 * step_ms / dep_steps, 4) if dep_steps > 0 else None, "avg_launch_us_rocprof": (pmc or {}).get("rocprof_avg_launch_us"),
             "traffic": pmc["hbm_bytes_per_bench_step"] if pmc else None,
             "per": "bench step (the consensus searches of one 2,000-read CYP2D6 sample: %.0f dependent window / expansion steps%s)" % (dep_steps, "" if batches is None else ", %.1f persistent launches" % batches),
             "step_kernel_ms_per_step": step_ms, "chain_ms_per_step_hip_events": chain_ms, "nominal_peak": VALU_PEAK_WAVE_INSTR,
@@ -1120,7 +1164,7 @@ def main():
             "hbm": {"algorithmic_bytes_per_step": algo_bytes, "achieved_GBs": algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else None, "peak_GBs": HBM_PEAK_GBS,
                     "frac": algo_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if step_ms > 0 else None, "measured_hbm_copy_GBs": peaks["hbm_copy_bytes_per_s"] / 1e9,
                     "note": "SURVEY 8(d)'s streaming model applied to the consensus: every search reads its reads' packed bases once and writes a 32-byte record per read"},
-            "counters_from": ("profiles/r05/counters_cons_step.json: " + pmc["method"]) if pmc else "no counter file for this kernel source (profiles/run_rocprof.sh makes it)",
+            "counters_from": ("profiles/r06/counters_cons_step.json: " + pmc["method"]) if pmc else "no counter file for this kernel source (profiles/run_rocprof.sh makes it)",
             "note": "the step's dominant kernel is a LATENCY chain, not a throughput kernel: a sample's searches are a few hundred dependent steps (critical_path), each the slowest "
                     "wavefront of a launch that fills a fraction of the device -- the fraction of the VALU peak (and of HBM: the reads are 3 MB) says how little of the machine one "
                     "sample's chain can use; what bounds it is per-step latency (critical_path.cyp2d6.per_step_us) and the number of steps"}
@@ -1128,7 +1172,7 @@ def main():
         "metric": "HiFi reads/sec diplotyped (HLA+CYP2D6)",
         "value": world * reads_per_step * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8 (2-bit packed bases, int32 wavefront DP, f64 score ratios)", "data": "synthetic",
+        "dtype": "int32", "dtype_note": "2-bit packed bases (u8 in, 16 per dword), int32 wavefront DP, f64 score ratios", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1] + configs[2] as ONE sample per step: HLA-A / -B, %d synthetic HiFi reads vs the bundled IMGT/HLA DB v0.14.1 (18,461 alleles, 11,199 with "
                                "DNA) and CYP2D6, %d targeted reads (39 templates, 393 variants / 520 star alleles), the steps cycling through ALL SIX configs[2] scenarios (%s); a new "
                                "sample's bytes (BAM 4-bit SEQ) uploaded every step under the previous sample's kernels; reads -> diplotypes of both loci"
@@ -1204,14 +1248,49 @@ def main():
     else:
         line["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        compact = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+        compact["value"], compact["ms_per_step"] = _r(line["value"], 6), _r(line["ms_per_step"], 6)
+        compact["config"] = {"workload": "BASELINE configs[1] + configs[2] as ONE sample per step: HLA-A/-B %d HiFi reads vs IMGT/HLA v0.14.1 (11,199 DNA alleles) + CYP2D6 %d targeted reads "
+                                         "(39 templates), the six configs[2] scenarios in turn; a new sample uploaded every step; reads -> diplotypes" % (samples[0].n, cyp_samples[0].n),
+                             "reads_per_step": reads_per_step, "hla_reads": samples[0].n, "cyp2d6_reads": cyp_samples[0].n, "cyp2d6_lanes": n_cyp_lanes, "hla_lanes": n_hla_lanes,
+                             "cyp2d6_consensus": "persistent kernels" if (headline_mode["persistent"] and batches_per_step > 0) else "launch pairs"}
+        rf = roof
+        compact["roofline"] = {"bound": rf["bound"], "kernel": rf["kernel_short"], "achieved": _r(rf["achieved"]), "peak": rf["peak"], "unit": rf["unit"], "frac": _r(rf["frac"]),
+                               "traffic": rf["traffic"], "per": "bench step", "measured_peak": _r(rf["measured_peak"]), "frac_of_measured_peak": _r(rf["frac_of_measured_peak"]),
+                               "kernel_ms_per_step_device_clock": _r(rf["step_kernel_ms_per_step"]), "kernel_avg_launch_us": rf.get("avg_launch_us"),
+                               "kernel_avg_launch_us_rocprof": rf.get("avg_launch_us_rocprof"),
+                               "hbm": {"algorithmic_bytes_per_step": _r(rf["hbm"]["algorithmic_bytes_per_step"]), "achieved_GBs": _r(rf["hbm"]["achieved_GBs"]), "peak_GBs": HBM_PEAK_GBS,
+                                       "frac": _r(rf["hbm"]["frac"])},
+                               "counters_from": ("profiles/%s/counters_cons_step.json" % os.path.basename(COUNTER_DIR)) if rf["traffic"] is not None else None}
+        cbf = line["cpu_baseline"]
+        if cbf is not None:
+            compact["cpu_baseline"] = {"value": _r(cbf["value"]), "unit": cbf["unit"], "cores": cbf["cores"], "kind": cbf["kind"], "sample": cbf["sample_short"],
+                                       "single_thread_value": _r(cbf["single_thread_value"]), "physical_cores": cbf.get("physical_cores"), "wall_s": _r(cbf["wall_s"]),
+                                       "diplotypes_identical": cbf.get("diplotypes_identical"), "k1_records_identical_to_gpu": cbf["hla"].get("k1_records_identical_to_gpu", "").split(" ")[0],
+                                       "k1_same_allele_as_gpu": cbf["hla"].get("k1_same_allele_as_gpu"),
+                                       "gpu_same_reads_value": _r(cbf.get("gpu_same_reads_one_after_the_other", {}).get("value"))}
+        else:
+            compact["cpu_baseline"] = None
+        compact["concordance"] = {"hla_diplotypes_equal_truth": line["concordance"]["hla_diplotypes_equal_truth"], "cyp2d6_calls_equal_truth": "%d/%d" % (
+            sum(m["calls_equal_truth"] for m in mix.values()), sum(m["steps"] for m in mix.values()))}
+        coh = (legs or {}).get("cohort") or {}
+        if "samples_per_s" in coh:
+            compact["cohort"] = {"samples_per_s": _r(coh["samples_per_s"]), "samples": coh["samples"], "calls_equal_truth": coh["calls_equal_truth"],
+                                 "share_rate_over_cohort_rate": {k: _r(v["samples_per_s"] / coh["samples_per_s"], 3) for k, v in (coh.get("by_share_size") or {}).items()}}
+        cpc = crit["cyp2d6"]
+        compact["summary"] = {"cyp2d6_chain": {"dependent_steps": _r(cpc["dependent_steps"]), "chain_ms": _r(cpc["chain_ms"]), "per_step_us": {k: _r(v, 3) for k, v in cpc.get("per_step_us", {}).items()},
+                                               "kernels_running_fraction": _r(cpc.get("kernels_running_fraction"), 3)},
+                              "one_lane_reads_per_s": _r((legs.get("cyp2d6_lanes") or {}).get("1", {}).get("value")) if legs else None,
+                              "hla_resident_reads_per_s": _r((legs.get("hla_resident") or {}).get("value")) if legs else None,
+                              "cyp2d6_scenarios_ms": {k: _r(v["ms"], 3) for k, v in ((legs.get("cyp2d6") or {}).get("scenarios") or {}).items()} if legs else None}
+        emit(line, compact, args.full_out)
     if world > 1:
         dist.barrier()
         if group is not None and hasattr(group, "close") and not isinstance(group, shard.TorchGroup):
             group.close()
         dist.destroy_process_group()
     if stale and rank == 0:                                                 # (the blocks they feed were left out of the line above)
-        print("bench.py: the counter files " + ", ".join(stale) + " were collected on other kernel sources: re-run profiles/run_rocprof.sh and copy counters_cons_step.json into profiles/r05", file=sys.stderr)
+        print("bench.py: the counter files " + ", ".join(stale) + " were collected on other kernel sources: re-run profiles/run_rocprof.sh and copy counters_cons_step.json into profiles/r06", file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -107,6 +107,10 @@ struct CSearch {
     long long ticks[4];         // control kernel, 100 MHz wall clock: load + vote reduction / result of the step / search / tail
     long long step_ticks, gap_ticks, last_end;   // profiling contexts: the step kernel from its first workgroup's start to its last one's end, summed over the steps; what lies
                                                  // between the kernels of the chain (control end -> step start, step end -> control start); the wall clock at the last control end
+#ifdef SP_K8_PF_PROBE
+    int32_t pf_win, pf_replay, pf_exp, pf_pad;   // probe build: orders whose node stood idle at the end of its tape when the order before was made (a launch that one could have carried)
+    unsigned long long idle_mask;
+#endif
 };
 struct ConsMeta { int32_t e, c0, flags, pad; };
 struct ConsRes { int32_t best, dual, split_at, len1, len2, pad; };   // what the host needs of the winning node
@@ -1704,6 +1708,17 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             }
             if (stop) break;
         }
+#ifdef SP_K8_PF_PROBE
+        if (wk.mode == M_WINDOW || wk.mode == M_EXPAND) {
+            bool idle = lane < NQ && nh[lane].used && !nh[lane].complete && lane != wk.node && nh[lane].q >= nh[lane].a;
+            if (wk.mode == M_EXPAND) for (int k = 0; k < wk.n_kids; ++k) if (wk.kid_node[k] == lane) idle = false;
+            const unsigned long long mask = __ballot(idle);
+            if (lane == 0) {
+                if ((ss.idle_mask >> wk.node) & 1ull) { if (wk.mode == M_EXPAND) ss.pf_exp += 1; else if (wk.replay) ss.pf_replay += 1; else ss.pf_win += 1; }
+                ss.idle_mask = mask;
+            }
+        }
+#endif
         // the speculated part of a new window: lane j takes the heaviest lookahead vote for push j of every consensus that grows; the
         // window ends where a consensus has no lookahead votes left (or at cap)
         spw::wave_lds_sync();
@@ -2384,6 +2399,18 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         for (uint32_t p = 0; p < n_prob; ++p) { cut += (uint64_t)h_srch[p].cut_windows; ex += (uint64_t)h_srch[p].expansions; pops += (uint64_t)h_srch[p].pops; }
         ctx->prof["cons_windows"].cells += pairs; ctx->prof["cons_windows"].launches += 3 * pairs;           // (two per step for a batch of small problems)
         ctx->prof["cons_cut_windows"].cells += cut; ctx->prof["cons_expansions"].cells += ex; ctx->prof["cons_columns"].cells += pops;
+#ifdef SP_K8_PF_PROBE
+        {   // the batch's chain is its slowest problem's: steps as they are / without the window orders a launch before could have carried / without any such order
+            uint64_t c0 = 0, c1 = 0, c2 = 0;
+            for (uint32_t p = 0; p < n_prob; ++p) {
+                const uint64_t st = (uint64_t)h_srch[p].windows + (uint64_t)h_srch[p].expansions, w = (uint64_t)h_srch[p].pf_win + (uint64_t)h_srch[p].pf_replay, e = (uint64_t)h_srch[p].pf_exp;
+                c0 = std::max(c0, st); c1 = std::max(c1, st - w); c2 = std::max(c2, st - w - e);
+                ctx->prof["cons_pf_win"].cells += (uint64_t)h_srch[p].pf_win; ctx->prof["cons_pf_replay"].cells += (uint64_t)h_srch[p].pf_replay; ctx->prof["cons_pf_exp"].cells += e;
+                ctx->prof["cons_all_windows"].cells += (uint64_t)h_srch[p].windows;
+            }
+            ctx->prof["cons_pf_chain"].cells += c0; ctx->prof["cons_pf_chain_win"].cells += c1; ctx->prof["cons_pf_chain_all"].cells += c2;
+        }
+#endif
         // where the control kernel's time goes: ticks of the 100 MHz wall clock, the slowest problem of the batch (they run side by side)
         static const char* tick_names[4] = { "cons_ticks_reduce", "cons_ticks_result", "cons_ticks_search", "cons_ticks_tail" };
         for (int k = 0; k < 4; ++k) { long long m = 0; for (uint32_t p = 0; p < n_prob; ++p) m = std::max(m, h_srch[p].ticks[k]); ctx->prof[tick_names[k]].cells += (uint64_t)m; }

@@ -11,14 +11,31 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(extra, env=None):
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def run_bench(extra, env=None, tmp=None):
+    """-> the whole record (the side file `--full-out` names); the ONE line on stdout is the compact one the driver parses: under 4 KB, every key of the contract"""
+    import tempfile
     e = dict(os.environ, **(env or {}))
     e.pop("RANK", None); e.pop("WORLD_SIZE", None); e.pop("LOCAL_RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=e, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as d:
+        side = os.path.join(d, "full.json")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-out", side] + extra, env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        printed = [l for l in out.stdout.splitlines() if l.strip()]
+        lines = [l for l in printed if l.startswith("{")]                  # (gloo announces its peers on stdout; the JSON line is the last line and the only one of its kind)
+        assert len(lines) == 1 and printed[-1] == lines[0], out.stdout[-2000:]
+        assert len(lines[0]) < 4096, len(lines[0])
+        line = json.loads(lines[0])
+        assert set(line) >= set(REQUIRED), sorted(set(REQUIRED) - set(line))
+        assert "workload" in line["config"] and "model" not in line["config"]
+        full = json.load(open(side))
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "higher_is_better", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k], k
+    assert abs(line["value"] - full["value"]) <= 1e-5 * full["value"] and abs(line["ms_per_step"] - full["ms_per_step"]) <= 1e-5 * full["ms_per_step"]
+    full["_line"] = line
+    return full
 
 
 def test_sample_line_and_two_rank_cohort_over_gloo():
@@ -29,6 +46,8 @@ def test_sample_line_and_two_rank_cohort_over_gloo():
     assert one["metric"] == "HiFi reads/sec diplotyped (HLA+CYP2D6)" and one["unit"] == "reads/s" and one["higher_is_better"] is True
     assert one["value"] > 0 and one["ms_per_step"] > 0 and one["vs_baseline"] is None
     assert set(one["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(one["_line"]["roofline"]) >= {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm"} and one["_line"]["roofline"]["peak"] == 256 * 4 * 2.4e9 / 2
+    assert one["_line"]["config"]["reads_per_step"] == one["config"]["reads_per_step"] and one["_line"]["concordance"]["cyp2d6_calls_equal_truth"] == "2/2"
     assert one["config"]["hla_reads"] == 2000 and 380 <= one["config"]["cyp2d6_reads"] <= 420
     assert one["concordance"]["hla_diplotypes_equal_truth"] == "2/2 genes" and one["concordance"]["cyp2d6_call_equals_truth"] is True
     assert one["upload"]["per_step_bytes"] > 5_000_000 and one["upload"]["alone"]["bam4"]["GBps"] > 0
