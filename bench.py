@@ -136,6 +136,73 @@ def emit(full, compact, path):
     print(text, flush=True)
 
 
+
+# ---------------------------------------------------------------------------------------------------------------- the ranks' group
+ABANDONED = []             # what a group that was given up leaves behind: kept alive and never touched again (no destroy call that could wait for the same peers)
+
+
+def bring_up_group(pkg, shard, backend, coll_dev, device_index, rank, world):
+    """sp_group: RCCL through the library (sp_gather_results).  The communicator is made AND tried -- one small gather whose answer is known -- before anything is timed, on a
+    helper thread with a time limit and on a CONTEXT OF ITS OWN (its own stream: a collective that never completes sits there, not on a stream the run needs; the helper never
+    touches the run's context, which is not thread safe).  The id travels through the rendezvous store, not through a collective of the process group, so a rank that hangs or
+    fails anywhere on the way leaves nothing pending on that group; the ranks then agree with ONE all-reduce -- the first collective every rank issues -- and fall back to the
+    torch process group together.  What was given up is never touched again (ABANDONED); a run that gave up a thread still inside the library leaves through os._exit.
+    -> (group, which path gathers, why the library's group was given up or None)"""
+    import torch
+    import torch.distributed as dist
+    box = {}
+    inject = os.environ.get("SP_BENCH_INJECT_GROUP_HANG", "")     # tests: "1" = every rank hangs; "<rank>:before" / "<rank>:after" / "<rank>:error" = that rank only, before / after its group is made
+
+    def injected(where):
+        if inject == "1":
+            return where == "before"
+        if ":" in inject:
+            r, w = inject.split(":")
+            return int(r) == rank and w == where
+        return False
+
+    def bring_up():
+        try:
+            torch.cuda.set_device(device_index)           # (the current device is a per-thread setting)
+            if injected("before"):
+                time.sleep(3600)
+            if injected("error"):
+                raise RuntimeError("injected error")
+            gctx = pkg.Context(device_index) if backend == "nccl" else None
+            box["gctx"] = gctx
+            g = shard.make_group(gctx, pkg.ffi, backend=backend, device=coll_dev)
+            box["made"] = g
+            if injected("after"):
+                time.sleep(3600)
+            if not isinstance(g, shard.TorchGroup):       # (the torch group is the process group itself: nothing to try, and no collective of it belongs on a helper thread)
+                probe = np.zeros(2, shard.CALL_DTYPE); probe["sample"] = rank; probe["gene"] = [0, 1]; probe["allele1"] = 1000 + rank
+                got = g.gather(probe)
+                want = np.stack([np.array([(r, 0, 1000 + r, 0), (r, 1, 1000 + r, 0)], shard.CALL_DTYPE) for r in range(world)])
+                if got.shape != want.shape or not (got == want).all():
+                    raise RuntimeError("the first gather did not return every rank's records")
+            box["group"] = g
+        except Exception as e:
+            box["error"] = e
+    th = threading.Thread(target=bring_up, daemon=True)
+    th.start()
+    th.join(timeout=float(os.environ.get("SP_BENCH_GROUP_TIMEOUT_S", "180")))
+    timed_out = th.is_alive()
+    err = TimeoutError("the communicator did not come up within the time limit") if timed_out else box.get("error")
+    ok_here = 0 if err is not None else 1
+    if err is not None:
+        print(f"rank {rank}: the library's group failed ({err}); gathering through torch.distributed instead", file=sys.stderr, flush=True)
+    flag = torch.tensor([ok_here], dtype=torch.int32, device=coll_dev if backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        g = box["group"]
+        return g, ("torch.distributed" if isinstance(g, shard.TorchGroup) else "sp_gather_results (librccl)"), None
+    # given up on every rank together.  This rank's own group may be fine, half made, or still inside the library on the helper thread: it is left alone either way
+    ABANDONED.append((box, th))
+    if timed_out:
+        ABANDONED.append("exit without teardown")           # (main() leaves through os._exit: a thread inside ncclCommInitRank / a gather on a dead peer would hold the interpreter's exit)
+    return shard.TorchGroup(coll_dev), "torch.distributed", str(err if err is not None else "another rank's group failed")
+
+
 # ---------------------------------------------------------------------------------------------------------------- CPU baseline
 def native_oracle():
     """the oracle rebuilt on THIS host with -O3 -march=native (the CPU leg is compiled for the machine it runs on); the
@@ -775,44 +842,7 @@ def main():
     group, gather_via = None, "single rank"
     group_fallback = None
     if world > 1 and workload == "cohort":                  # (the streams of samples exchange nothing: no communicator)
-        # sp_group: RCCL through the library (sp_gather_results).  The communicator is made AND tried -- one small gather whose answer is known -- on a helper thread with a
-        # time limit, before anything is timed: should the library's communicator not come up on this node (an error, or a rank that never returns from the library's
-        # ncclCommInitRank / first all-gather), every rank falls back to the torch process group together -- the decision is agreed on with one all-reduce -- and the line says
-        # which path gathered and why.  A communicator that was given up is left alone (no destroy call that could wait for the same peers)
-        box = {}
-
-        def bring_up():
-            try:
-                torch.cuda.set_device(device_index)           # (the current device is a per-thread setting)
-                if os.environ.get("SP_BENCH_INJECT_GROUP_HANG") == "1":
-                    time.sleep(3600)
-                g = shard.make_group(ctx, pkg.ffi, backend=backend, device=coll_dev)
-                probe = np.zeros(2, shard.CALL_DTYPE); probe["sample"] = rank; probe["gene"] = [0, 1]; probe["allele1"] = 1000 + rank
-                got = g.gather(probe)
-                want = np.stack([np.array([(r, 0, 1000 + r, 0), (r, 1, 1000 + r, 0)], shard.CALL_DTYPE) for r in range(world)])
-                if got.shape != want.shape or not (got == want).all():
-                    raise RuntimeError("the first gather did not return every rank's records")
-                box["group"] = g
-            except Exception as e:
-                box["error"] = e
-        th = threading.Thread(target=bring_up, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get("SP_BENCH_GROUP_TIMEOUT_S", "180")))
-        if th.is_alive():
-            box["error"] = TimeoutError("the communicator did not come up within the time limit")
-        group, ok_here = box.get("group"), 1
-        if "error" in box:
-            print(f"rank {rank}: the library's group failed ({box['error']}); gathering through torch.distributed instead", file=sys.stderr, flush=True)
-            group, ok_here = None, 0
-        flag = torch.tensor([ok_here], dtype=torch.int32, device=coll_dev if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if group is not None and hasattr(group, "_h") and not isinstance(group, shard.TorchGroup):
-                import ctypes
-                group._h = ctypes.c_void_p()                 # given up, not destroyed
-            group = shard.TorchGroup(coll_dev)
-            group_fallback = str(box.get("error", "another rank's group failed"))
-        gather_via = "torch.distributed" if isinstance(group, shard.TorchGroup) else "sp_gather_results (librccl)"
+        group, gather_via, group_fallback = bring_up_group(pkg, shard, backend, coll_dev, device_index, rank, world)
 
     def barrier():
         if world > 1:
@@ -873,6 +903,9 @@ def main():
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
+        if "exit without teardown" in ABANDONED:
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
         return
 
     # ------------------------------------------------------------------------------------------------ the sample: HLA-A / -B + CYP2D6, a new one every step

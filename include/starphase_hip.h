@@ -256,7 +256,10 @@ typedef struct {
     int32_t dna_offset, hpc_offset;
     /* the same mapping re-scored the reference's way (two-piece affine gaps, end clipping: sp_affine_rescore_batch on the 64 diagonals around aln): what minimap2
      * reports for this read and allele -- NM, the allele span (target_start / target_end), the read span (query_start / query_end); mm2_score 0 = not re-scored
-     * (no best allele).  The pipeline's own decisions use the counts above. */
+     * (no best allele).  Exhaustive mode: a report beside the counts above, which decide; left zero with context option "mm2_rescore" 0.
+     * Seeded mode: these ARE the numbers the acceptance loop ran on (<= 0.03 edit fraction, <= 0.5 penalised: mm2_nm over the re-scored extent) and they are written whatever
+     * "mm2_rescore" says; nm / unmapped / aln above stay the unit-cost cell's numbers of the same mapping, so a record judged by nm / target_len alone may look as if it
+     * missed or passed a cut-off it did not.  status 2 in seeded mode: best_allele is -1 and mm2_* describe the reverse-strand mapping that was accepted. */
     int32_t mm2_score, mm2_nm;
     int32_t mm2_t_start, mm2_t_end, mm2_q_start, mm2_q_end;
     int32_t k1_chains, k1_mappings, k1_chain_score;      /* seeded mode: chains of the read, mappings returned, chain score of the accepted mapping */

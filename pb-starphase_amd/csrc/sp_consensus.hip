@@ -58,7 +58,9 @@ constexpr int CW = SP_K8_CW;    // bases per window (a multiple of 64: the contr
 static_assert(CW % 64 == 0 && CW >= 64 && CW <= 512, "window length");
 constexpr int CWIN = 512;       // consensus bases in front of the window kept in LDS (offset_window + slack)
 constexpr int RWORDS = (2 * CW + 320) / 16;   // packed read words a wave keeps in LDS: band + window + lookahead + slack around its tips
-constexpr int NQ = 40;          // search nodes per problem: max_queue_size waiting + the children of one expansion + the complete one
+constexpr int NQ = 56;          // search nodes per problem: max_queue_size waiting + the children of one expansion + the complete one + the children of the expansions made ahead (side orders)
+constexpr int NWORK = 4;        // work orders per problem and step: the search's own (order 0) and up to NWORK - 1 SIDE ORDERS -- the window or the expansion another waiting node will need when
+                                // its turn comes, made in the same launch (the step kernel's grid has one row of workgroups per order)
 constexpr int MAXKIDS = 16;     // children of one expansion
 constexpr int CLUSTER = 64;     // workgroups whose vote words the reduce kernel sums into one set of cluster sums
 constexpr int RSLICES = 16;     // reduce-kernel workgroups per cluster: each sums one slice of the cluster's words
@@ -81,8 +83,8 @@ struct CWork {                  // what the next step launch does for this probl
     uint8_t spec[2][CW];
 };
 struct CNode {
-    // the head (128 bytes): every node's head travels between memory and LDS in every control step
-    int32_t used, id, complete;
+    // the head (160 bytes): every node's head travels between memory and LDS in every control step
+    int32_t used, id, complete; // used: 0 free, 1 in the search, 2 a child made ahead of its parent's turn (pex_kid of that parent)
     int32_t T, cur;             // column of the state in slot `cur`
     int32_t dual, split_at, stopped[2], len[2];
     int32_t n, a, q;            // the tape: n bases were pushed from T, the first a are verified, q are consumed
@@ -92,13 +94,18 @@ struct CNode {
     long long rest;             // what the unfinished reads add to the final cost (no early termination), for the state at T
     long long rest_out;         // the same for the state at T + n
     uint32_t ev[2][5];          // the complete votes at column T + a
+    // an expansion made ahead of the node's turn (a side order): its children wait in node slots marked used = 2, unseen by the search, until the node is taken out at that
+    // column and adopts them without a launch (or is dropped, and they with it)
+    int32_t pex_n, pex_L;       // children made ahead (0: none); the column that branched
+    int8_t  pex_kid[MAXKIDS];
+    int32_t pad_head[2];
     // the tape (1.5 KB at 256-column windows): only the part a node with a tape uses travels (a branching search holds twenty nodes that have none)
     int32_t dc[CW + 1];         // cost after j pushes from T, minus cost0 (dc[0] = 0)
     uint8_t spec[2][CW];
     int32_t pad_[3];
     __device__ __forceinline__ long long cost_at(int j) const { return cost0 + (long long)dc[j]; }
 };
-constexpr int NODE_HEAD_WORDS = 32, NODE_WORDS = (int)(sizeof(CNode) / 4), NODE_TAPE_WORDS = NODE_WORDS - NODE_HEAD_WORDS;
+constexpr int NODE_HEAD_WORDS = 40, NODE_WORDS = (int)(sizeof(CNode) / 4), NODE_TAPE_WORDS = NODE_WORDS - NODE_HEAD_WORDS;
 static_assert(offsetof(CNode, dc) == 4 * NODE_HEAD_WORDS && sizeof(CNode) % 16 == 0, "CNode layout");
 struct CSearch {
     int32_t threshold, farthest, next_id, best_node, inflight, max_queue, per_size, wo_constraint;
@@ -107,6 +114,7 @@ struct CSearch {
     long long ticks[4];         // control kernel, 100 MHz wall clock: load + vote reduction / result of the step / search / tail
     long long step_ticks, gap_ticks, last_end;   // profiling contexts: the step kernel from its first workgroup's start to its last one's end, summed over the steps; what lies
                                                  // between the kernels of the chain (control end -> step start, step end -> control start); the wall clock at the last control end
+    int32_t steps, side_windows, side_expansions, adopted;   // control steps that ordered a launch; side orders made; expansions adopted from a side order (no launch of their own)
 #ifdef SP_K8_PF_PROBE
     int32_t pf_win, pf_replay, pf_exp, pf_pad;   // probe build: orders whose node stood idle at the end of its tape when the order before was made (a launch that one could have carried)
     unsigned long long idle_mask;
@@ -121,11 +129,11 @@ constexpr int CMAXP = 24;
 struct ConsParams {
     int n, first, first_block, n_blocks, rpw;   // reads; flattened index of local read 0; first workgroup; workgroups; reads per wave
     int first_cluster, n_clusters;              // clusters of CLUSTER consecutive workgroups (the last one may be smaller)
-    int acc_block;                              // problems of <= DIRECT_BLOCKS workgroups: the word block their workgroups ADD their words to (atomics), read and cleared by the control step
+    int acc_block;                              // problems of <= DIRECT_BLOCKS workgroups: the first of the NWORK word blocks (one per order) their workgroups ADD their words to (atomics), read and cleared by the control step
     int min_count, delta, et, allow_dual, window, cmp_len; double min_af;
     int cap, cs;                // longest consensus; bytes between the two consensuses of a node (cap rounded up to 16: children copy their parent 16 bytes at a time)
     uint8_t* C;                 // [NQ][2][cs] base codes per node; consensus 2 shares [0, split_at) with consensus 1
-    CWork* work; CSearch* srch; CNode* nodes;
+    CWork* work; CSearch* srch; CNode* nodes;   // work: [NWORK] orders
     uint32_t* la;               // [NQ][2][CW][4] lookahead votes per node
     uint8_t* processed;         // [cap + 2] nodes expanded per length
     uint8_t* out_cons;          // [2][cap] the consensus bytes of the node the search ended with (written by the finalize kernel)
@@ -139,7 +147,7 @@ struct PlaceMemo { int valid, M, off, c0; uint32_t text[512 / 16 + 2]; };
 template <int MAXP> struct ConsBatchT {
     ConsParams p[MAXP]; int n_prob;
     const ReadInfo* info;       // [total]
-    PlaceMemo* memo;            // [total][2]
+    PlaceMemo* memo;            // [NWORK][total][2] (a set per order row: two rows of a launch may place the same read at once)
     uint16_t* H;                // [node][slot][consensus][total][64] furthest read position per diagonal (0xFFFF = none)
     ConsMeta* meta;             // [node][slot][consensus][total]
     unsigned long long* PV;     // [blocks][2][CW + 1] exact votes per workgroup: four 16-bit fields (A, C, G, T) in 12ths of a read
@@ -155,10 +163,11 @@ template <int MAXP> struct ConsBatchT {
     uint32_t* ready;            // persistent mode: host memory, counts the control workgroups that have started (the step workgroups are launched behind them)
     uint32_t step_cap;          // persistent mode: a search that has not ended after this many steps ends the batch (the launch-pair loop's own bound)
     int total;
+    int nside;                  // side orders per problem and step (0 .. NWORK - 1): the step kernel's grid has 1 + nside rows
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; uint32_t step_cap; const int* cluster_prob; int total;
+    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; uint32_t step_cap; const int* cluster_prob; int total; int nside;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first, cmp_len, pad_; };
 
@@ -686,7 +695,7 @@ __device__ __forceinline__ int read_cost(const Dwfa& a0, const Dwfa& a1, bool du
 // the step: window mode pushes the chosen node through n bases, expand mode makes the children of a node, init builds the root
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int MAXP>
-__device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
+__device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const int wrow) {       // wrow: the order of the problem this workgroup works on (0: the search's own)
     __shared__ unsigned long long lv[2][CW + 1];          // exact votes after j pushes (column T + j) / of child j
     __shared__ uint32_t le[2][CW + 1];
     __shared__ unsigned long long ll[2][CW];              // lookahead: ll[i][x] predicts column T + n + 1 + x
@@ -703,9 +712,10 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         for (int x = threadIdx.x; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)&wk_s)[x] = coh_load(((const uint32_t*)P.work) + x);
         __syncthreads();
     }
-    const CWork* Wp = coh ? &wk_s : P.work;
+    const CWork* Wp = coh ? &wk_s : P.work + wrow;
     const int mode = Wp->mode;
-    if (Wp->done || mode == M_NONE) return;
+    if (P.work->done || mode == M_NONE) return;
+    if (wrow > 0 && P.n_blocks > DIRECT_BLOCKS) return;   // (side orders exist only where the workgroups add their words to a block per order)
     if (B.step_t && threadIdx.x == 0) atomicMin(&B.step_t[2 * pi], (unsigned long long)wall_clock64());
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // window mode: n bases from column T on.  Expand mode: the parent's kept state stands at column T as well, `pre` verified bases of a window that was cut lie between it
@@ -840,11 +850,11 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
         auto column = [&](Dwfa& a0, Dwfa& a1, bool dualrun, int g0, int g1, int nb0, int nb1, int len, const ConsAccess& c0a, const ConsAccess& c1a) {
             if (g0) {
                 if (a0.flags & F_ACTIVE) { if (!(a0.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a0, rv.n, rb, extender(c0a, c0a.i), len - a0.c0, nb0, P.et, lane); }
-                else if (ri.off == len) { a0 = activate_late(rv, c0a, &act[wave], B.memo + 2 * g, ri.off0, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
+                else if (ri.off == len) { a0 = activate_late(rv, c0a, &act[wave], B.memo + 2 * ((size_t)wrow * plane + g), ri.off0, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
             }
             if (dualrun && g1) {
                 if (a1.flags & F_ACTIVE) { if (!(a1.flags & (F_FINISHED | F_LOST))) dwfa_push_t(a1, rv.n, rb, extender(c1a, c1a.i), len - a1.c0, nb1, P.et, lane); }
-                else if (ri.off == len) { a1 = activate_late(rv, c1a, &act[wave], B.memo + 2 * g, ri.off0, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
+                else if (ri.off == len) { a1 = activate_late(rv, c1a, &act[wave], B.memo + 2 * ((size_t)wrow * plane + g), ri.off0, len, P.window, P.cmp_len, P.et, lane); spw::wave_lds_sync(); }
             }
             if (dualrun) {
                 const int both = (a0.flags & F_ACTIVE) && (a1.flags & F_ACTIVE) && !(a0.flags & F_LOST) && !(a1.flags & F_LOST);
@@ -1209,7 +1219,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
     if (P.n_blocks <= DIRECT_BLOCKS) {
         // a problem of few workgroups: every workgroup adds its words to the problem's one block (fire-and-forget atomics, zeros skipped; a 16-bit field of
         // 128 workgroups cannot carry into the next); the control step then reads one block instead of up to 128 -- its sums were half of its time
-        const size_t blk = (size_t)P.acc_block;
+        const size_t blk = (size_t)P.acc_block + (size_t)wrow;
         for (int x = threadIdx.x; x < 2 * uw.used; x += blockDim.x) {
             const int i = x / uw.used, e = i * (CW + 1) + x % uw.used;
             const unsigned long long v = (&lv[0][0])[e]; const uint32_t w = (&le[0][0])[e];
@@ -1235,13 +1245,13 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B) {
 }
 
 template <int MAXP>
-__global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_kernel(ConsBatchT<MAXP> B) { cons_step_body<MAXP>(B); }
+__global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_kernel(ConsBatchT<MAXP> B) { cons_step_body<MAXP>(B, (int)blockIdx.y); }
 // The same body at two waves per SIMD (one workgroup per CU): 240 registers and no spill code, where the first instantiation keeps 128 and spills 73 to scratch -- 11 MB of dirty
 // scratch lines per launch that the launch's end writes back (profiles/r05/counters_cons_step.json).  For a batch whose workgroups fit the device in one round either way (a
 // single sample's searches: <= one workgroup per CU) it is the faster one (`*4+*68/*1` alone 165 -> 155 ms; a rank's 32-sample share 0.138 -> 0.133 s); a batch with more workgroups
 // than CUs (an HLA gene of 5,000 reads: 625) needs the two workgroups per CU of the first (its step 111 -> 133 us with this one).
 template <int MAXP>
-__global__ void __launch_bounds__(CWAVES * SP_WAVE, 2) cons_step_wide_kernel(ConsBatchT<MAXP> B) { cons_step_body<MAXP>(B); }
+__global__ void __launch_bounds__(CWAVES * SP_WAVE, 2) cons_step_wide_kernel(ConsBatchT<MAXP> B) { cons_step_body<MAXP>(B, (int)blockIdx.y); }
 
 // sums the vote words of CLUSTER consecutive workgroups of a problem (several hundred workgroups would otherwise be summed by the one
 // workgroup of the control kernel, word by word from memory).  RSLICES workgroups per cluster, each a slice of the words: with 256-column
@@ -1312,29 +1322,33 @@ __device__ __forceinline__ int col_candidates(const uint32_t* w5, int col, int c
 template <int MAXP>
 __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     extern __shared__ uint8_t proc[];                     // nodes expanded per length (cap + 2 bytes, padded to 16)
-    __shared__ uint32_t acc[QE];                          // the sums over all workgroups of the problem, in the order of the cluster sums:
+    __shared__ uint32_t acc[QE];                          // the sums over all workgroups of the problem for ONE order, in the order of the cluster sums:
     uint32_t (*sv)[CW + 1][5] = reinterpret_cast<uint32_t (*)[CW + 1][5]>(acc);              // exact votes: w[4], end
     uint32_t (*sl)[CW][4] = reinterpret_cast<uint32_t (*)[CW][4]>(acc + QSV);                // lookahead votes
     uint32_t* sc = acc + QSV + QSL; uint32_t* sr = sc + (CW + 1);                              // cost growth / final-cost extra
     __shared__ CNode nh[NQ];
-    __shared__ CWork wk;
+    __shared__ CWork wks[NWORK];                          // the orders of the last step on the way in, those of the next step on the way out; wks[0] is the search's own
     __shared__ CSearch ss;
-    __shared__ int copy_from, copy_len, need_la;
+    __shared__ int copy_from[NWORK], copy_len[NWORK], need_la[NWORK];
     const int pi = blockIdx.x;
     const ConsParams P = B.p[pi];
     const int tid = threadIdx.x;
     const bool coh = B.sync != nullptr;                   // persistent mode: what the step workgroups read next is stored write-through, their words are fetched where the atomics ran
+    // side orders: only where every order has a word block of its own (problems whose workgroups add their words up), and not between persistent kernels (one row of resident workgroups)
+    const int nside = (coh || P.n_blocks > DIRECT_BLOCKS) ? 0 : (B.nside < NWORK - 1 ? B.nside : NWORK - 1);
+    const int n_orders = 1 + nside;
+    CWork& wk = wks[0];
     const long long tk0 = wall_clock64();
-    // first round of loads, all independent: the heads of the nodes, the work order, the search state, the per-length counters
+    // first round of loads, all independent: the heads of the nodes, the work orders, the search state, the per-length counters
     // (only the nodes in use travel whole between memory and LDS: a node is 1.7 KB at 256-column windows; a linear search holds one or two)
     for (int x = tid; x < NQ * NODE_HEAD_WORDS; x += blockDim.x)
         ((uint32_t*)&nh[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS] = ((const uint32_t*)&P.nodes[x / NODE_HEAD_WORDS])[x % NODE_HEAD_WORDS];
-    for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)&wk)[x] = ((const uint32_t*)P.work)[x];
+    for (int x = tid; x < n_orders * (int)(sizeof(CWork) / 4); x += blockDim.x) ((uint32_t*)wks)[x] = ((const uint32_t*)P.work)[x];
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)&ss)[x] = ((const uint32_t*)P.srch)[x];
     const int proc_words = (P.cap + 2 + 3) / 4;
     for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)proc)[x] = ((const uint32_t*)P.processed)[x];
     for (int x = tid; x < QE; x += blockDim.x) acc[x] = 0;
-    if (tid == 0) { copy_from = -1; copy_len = 0; need_la = -1; }
+    if (tid < NWORK) { copy_from[tid] = -1; copy_len[tid] = 0; need_la[tid] = -1; if (tid >= n_orders) wks[tid].mode = M_NONE; }
     __syncthreads();
     if (wk.done) return;
     // second round: the tapes of the nodes that have one and the vote words of the step
@@ -1351,16 +1365,17 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         const int k = x / NODE_TAPE_WORDS, w = x % NODE_TAPE_WORDS;
         if (tape_word_used(nh[k], w)) ((uint32_t*)&nh[k])[NODE_HEAD_WORDS + w] = ((const uint32_t*)&P.nodes[k])[NODE_HEAD_WORDS + w];
     }
-    const int mode_in = wk.mode, n_in = (wk.mode == M_WINDOW || wk.mode == M_EXPAND) ? wk.n : 0;     // (expand mode: the verified bases that were replayed in front of the branch)
-    // the words of the step that are in use: the cluster sums (a few per problem) or, for a problem of at most DIRECT_BLOCKS workgroups, the
-    // workgroups' own words (no reduce launch at all for a batch of such problems); eight loads in flight per thread
-    if (mode_in != M_NONE) {
-        const UsedWords uw(mode_in, n_in, mode_in == M_EXPAND ? wk.n_kids : 0);
+    // the words of one order of the step that are in use: the cluster sums (a few per problem) or, for a problem of at most DIRECT_BLOCKS workgroups, the block its
+    // workgroups added their words to (no reduce launch at all for a batch of such problems)
+    auto load_votes = [&](const int w) {
+        const int mode_in = wks[w].mode, n_in = (mode_in == M_WINDOW || mode_in == M_EXPAND) ? wks[w].n : 0;
+        if (mode_in == M_NONE) return;
+        const UsedWords uw(mode_in, n_in, mode_in == M_EXPAND ? wks[w].n_kids : 0);
         if (P.n_blocks <= DIRECT_BLOCKS) {
-            // the problem's one block of words (its workgroups added theirs to it): read and cleared for the next step.  The exact and the lookahead
+            // the order's one block of words (the workgroups added theirs to it): read and cleared for the next step.  The exact and the lookahead
             // votes are four 16-bit fields per 64-bit word
             const int u = uw.used, ev = 2 * u, el = uw.has_la ? 2 * CW : 0, E = ev + ev + el + u + u;
-            const size_t blk = (size_t)P.acc_block;
+            const size_t blk = (size_t)P.acc_block + (size_t)w;
             for (int c = tid; c < E; c += blockDim.x) {
                 if (c < ev || (c >= 2 * ev && c < 2 * ev + el)) {
                     const bool exact = c < ev;
@@ -1397,37 +1412,112 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                 acc[o] = sum;
             }
         }
-    }
-    __syncthreads();
-    const long long tk1 = wall_clock64();
-    long long tk2 = tk1, tk3 = tk1;
-#ifdef SP_K8_SEARCH_TICKS
-    long long ts_pick = 0, ts_block = 0, ts_iters = 0;
-#endif
-    if (tid < SP_WAVE) {
-        // One wavefront runs the search.  Every lane reads the same LDS words (broadcast), so control flow is uniform; lane 0 writes,
-        // and a wave-level fence separates its writes from the reads that follow.
-        const int lane = tid;
-        auto cands = [&](const uint32_t* w5, int col, int out[4]) { return col_candidates(w5, col, P.cap, P.et, P.min_count, P.min_af, out); };
-        auto node_free = [&](int k) { nh[k].used = 0; nh[k].complete = 0; };
-        uint8_t* Cb = P.C;
-        int la_fresh = -1;                                // the node whose lookahead votes are the sums of this very step (still in LDS)
-        // ---------------------------------------------------------------- 1. the result of the last step
+    };
+    // ---- what the search wave works with (the lambdas below run on the workgroup's first wave only: every lane reads the same LDS words, so control flow is uniform;
+    //      lane 0 writes, and a wave-level fence separates its writes from the reads that follow)
+    const int lane = tid & (SP_WAVE - 1);
+    auto cands = [&](const uint32_t* w5, int col, int out[4]) { return col_candidates(w5, col, P.cap, P.et, P.min_count, P.min_af, out); };
+    // a node leaves the table -- and with it the children an expansion made ahead of its turn
+    auto node_free = [&](int k) {
+        const int np = nh[k].pex_n;
+        for (int j = 0; j < np; ++j) { CNode& c = nh[nh[k].pex_kid[j]]; c.used = 0; c.complete = 0; }
+        nh[k].pex_n = 0; nh[k].used = 0; nh[k].complete = 0;
+    };
+    uint8_t* Cb = P.C;
+    int la_fresh = -1;                                    // the node whose lookahead votes are the sums of the search's own order of this very step (still in LDS)
+    // More than max_queue_size nodes wait: the length threshold rises until at most that many stand at or above it -- the SHORTEST nodes go and the search is
+    // pushed forwards (CdwfaConfig::max_queue_size; oracle/consensus.c).  Lane k looks at node k; nodes under the threshold are freed at once (they would be
+    // dropped at their pop: their slots are needed)
+    auto trim_queue = [&]() {
+        for (;;) {
+            const bool waits = lane < NQ && nh[lane].used == 1 && !nh[lane].complete;
+            const int wlen = waits ? nh[lane].T + nh[lane].q : 0;
+            const bool live = waits && wlen >= ss.threshold;
+            if (waits && !live) node_free(lane);
+            if (__builtin_popcountll(__ballot(live)) <= ss.max_queue) break;
+            int shortest = live ? wlen : 0x7FFFFFFF;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(shortest, o); shortest = other < shortest ? other : shortest; }
+            if (lane == 0) ss.threshold = shortest + 1;
+            spw::wave_lds_sync();
+        }
+    };
+    // The children of an expansion join the search: their ids, the length of their first window by how crowded the search is -- in a search that branches a little (two
+    // haplotypes: a handful of nodes) a child's first window may be long; where the queue is full most children are dropped within a few columns --, the parent leaves.
+    // kid(k): the node slot of child k.  (The children's other fields were filled when the expansion's launch came back: kids_from_sums.)
+    auto adopt = [&](const int parent, const int n_kids, const bool kids_wait, auto kid) {      // kids_wait: the children's slots are marked as the search's already
+        const int others = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 1 && !nh[lane].complete)) - 1 - (kids_wait ? n_kids : 0);
+        const int kid_w0 = others <= KID_CALM ? KID_LA : KID_W0;
+        if (lane < n_kids) {
+            CNode& c = nh[kid(lane)];
+            c.used = 1; c.id = ss.next_id + lane;
+            c.wcap = n_kids <= KID_LA_KIDS ? kid_w0 : WRAMP0;
+        }
+        spw::wave_lds_sync();
+        if (lane == 0) {
+            ss.next_id += n_kids;
+            nh[parent].pex_n = 0;                         // (its children are the search's now)
+            node_free(parent);
+            ss.expansions += 1;
+        }
+        spw::wave_lds_sync();
+        trim_queue();
+    };
+    // the sums of an expansion's launch into its children's node slots (one lane per child); `mark`: 1 = the children join the search at once (adopt follows), 2 = made ahead
+    auto kids_from_sums = [&](const CWork& w, const int mark) {
+        const int L = w.T + w.n;                                            // the column that branched (w.n: the verified bases that were replayed in front of it)
+        if (lane < w.n_kids) {
+            const CNode& par = nh[w.node];
+            const int k = lane;
+            CNode& c = nh[w.kid_node[k]];
+            c.used = mark; c.complete = 0; c.id = 0; c.T = L + 1; c.cur = 0; c.pex_n = 0; c.pex_L = 0;
+            c.dual = par.dual || w.kid_split[k]; c.split_at = w.kid_split[k] ? L : par.split_at;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool was_going = (i == 0 || par.dual) && !par.stopped[i];
+                int st = par.stopped[i], ln = par.len[i];
+                if (w.kid_base[k][i] >= 0) { st = 0; ln = L + 1; }
+                else if (was_going) { st = 1; ln = L; }
+                c.stopped[i] = st; c.len[i] = ln;
+            }
+            if (!c.dual) c.stopped[1] = 1;
+            c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = w.n_kids <= KID_LA_KIDS ? 1 : 0; c.wcap = WRAMP0;
+            c.cost0 = par.cost_at(par.q) + (long long)sc[k]; c.dc[0] = 0; c.rest = sr[k]; c.rest_out = 0;
+            for (int i = 0; i < 2; ++i) for (int bq = 0; bq < 5; ++bq) c.ev[i][bq] = sv[i][k][bq];
+        }
+        if (w.n_kids <= KID_LA_KIDS) {
+            // the children's lookahead votes ([child][consensus][KID_LA columns] in the launch's lookahead words) into the children's rows; the columns behind them
+            // are empty: a child's first window ends there at the latest.  (The rows are read back below, if a child is the next to go: a fence and the wave's
+            // own order make the stores visible to its loads.)
+            const uint32_t* flat = &sl[0][0][0];
+            for (int y = lane; y < w.n_kids * 2 * KID_LA * 4; y += SP_WAVE) {                // (column KID_LA - 1 of a child has no votes: its window ends there, what lies behind is never read)
+                const int k = y / (2 * KID_LA * 4), i = (y / (KID_LA * 4)) & 1, xb = y % (KID_LA * 4);
+                P.la[(size_t)w.kid_node[k] * 2 * CW * 4 + (size_t)i * CW * 4 + xb] = flat[y];
+            }
+            __threadfence_block();
+        }
+        spw::wave_lds_sync();
+    };
+    // ---------------------------------------------------------------- 1. the result of the last step, order by order (`acc` holds the order's sums)
+    auto take_result = [&](const int w) {
+        const CWork& wo = wks[w];
+        const int mode_in = wo.mode, n_in = (mode_in == M_WINDOW || mode_in == M_EXPAND) ? wo.n : 0;
+        const bool side = w > 0;
         if (mode_in == M_INIT) {
-            la_fresh = wk.node;
-            CNode& x = nh[wk.node];
+            la_fresh = wo.node;
+            CNode& x = nh[wo.node];
             if (lane == 0) {
-                x.used = 1; x.id = ss.next_id++; x.complete = 0; x.T = 0; x.cur = wk.in_slot; x.dual = 0; x.split_at = -1;
+                x.used = 1; x.id = ss.next_id++; x.complete = 0; x.T = 0; x.cur = wo.in_slot; x.dual = 0; x.split_at = -1;
                 x.stopped[0] = 0; x.stopped[1] = 1; x.len[0] = x.len[1] = 0; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1; x.wcap = CW;
-                x.cost0 = 0; x.dc[0] = 0; x.rest = sr[0]; x.rest_out = 0;
+                x.cost0 = 0; x.dc[0] = 0; x.rest = sr[0]; x.rest_out = 0; x.pex_n = 0; x.pex_L = 0;
             }
             if (lane < 10) x.ev[lane / 5][lane % 5] = sv[lane / 5][0][lane % 5];
-            for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
+            for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wo.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
         } else if (mode_in == M_WINDOW) {
-            CNode& x = nh[wk.node];
-            const int n = n_in, T = wk.T;
+            CNode& x = nh[wo.node];
+            const int n = n_in, T = wo.T;
             int a = n;
-            if (!wk.replay && n > 1) {
+            if (!wo.replay && n > 1) {
                 for (int base = 0; base < n; base += SP_WAVE) {                  // 64 columns of the window at a time, one per lane
                     const int col = base + lane;
                     bool ok = true;
@@ -1435,10 +1525,10 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             if (i == 1 && !x.dual) continue;
-                            if (!wk.go[i]) continue;
+                            if (!wo.go[i]) continue;
                             int c4[4];
                             const int nc = cands(sv[i][col], T + col, c4);
-                            if (nc != 1 || c4[0] != wk.spec[i][col]) ok = false;   // a stop, a second candidate or another base: the tape ends there
+                            if (nc != 1 || c4[0] != wo.spec[i][col]) ok = false;   // a stop, a second candidate or another base: the tape ends there
                         }
                     }
                     const unsigned long long bad = __ballot(!ok);
@@ -1447,10 +1537,10 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             }
             for (int col = lane; col < a; col += SP_WAVE) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wk.go[i]) put(&Cb[((size_t)wk.node * 2 + i) * P.cs + T + col], wk.spec[i][col], coh);
+                for (int i = 0; i < 2; ++i) if ((i == 0 || x.dual) && wo.go[i]) put(&Cb[((size_t)wo.node * 2 + i) * P.cs + T + col], wo.spec[i][col], coh);
             }
             // a replay re-reads columns whose costs are on the tape already: it only brings the state (and the votes) of column T + a
-            if (!wk.replay) {
+            if (!wo.replay) {
                 long long carry = 0;
                 for (int base = 0; base < a; base += SP_WAVE) {
                     const int col = base + lane;
@@ -1460,83 +1550,155 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                     if (col < a) x.dc[col + 1] = (int32_t)(carry + c);
                     carry += __shfl(c, SP_WAVE - 1);
                 }
-                for (int col = lane; col < n; col += SP_WAVE) { x.spec[0][col] = wk.spec[0][col]; x.spec[1][col] = wk.spec[1][col]; }
+                for (int col = lane; col < n; col += SP_WAVE) { x.spec[0][col] = wo.spec[0][col]; x.spec[1][col] = wo.spec[1][col]; }
             }
             if (lane < 10) x.ev[lane / 5][lane % 5] = sv[lane / 5][a][lane % 5];
             if (lane == 0) {
                 ss.windows += 1; if (a < n) ss.cut_windows += 1;
-                x.n = n; x.a = wk.replay ? n : a;
+                x.n = n; x.a = wo.replay ? n : a;
                 x.have_out = (a == n) ? 1 : 0;
                 if (a == n) x.rest_out = sr[n];
             }
-            if (a == n) { la_fresh = wk.node; for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wk.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y]; }
+            if (a == n) {
+                if (!side) la_fresh = wo.node;
+                for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wo.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
+                if (side) __threadfence_block();          // (a side order's rows may be read back from memory further down in this very pass)
+            }
         } else if (mode_in == M_EXPAND) {
-            const int L = wk.T + n_in;                                      // the column that branched
 #ifdef SP_K8_TRACE
-            if (lane == 0 && pi == 0) { printf("EXP L %d pre %d kids %d parcost %lld :", L, n_in, wk.n_kids, nh[wk.node].cost_at(nh[wk.node].q)); for (int k = 0; k < wk.n_kids; ++k) printf(" [%d/%d sc %u sr %u ev %u %u %u %u %u]", wk.kid_base[k][0], wk.kid_base[k][1], sc[k], sr[k], sv[0][k][0], sv[0][k][1], sv[0][k][2], sv[0][k][3], sv[0][k][4]); printf("\n"); }
+            if (lane == 0 && pi == 0) { printf("EXP%s L %d pre %d kids %d parcost %lld :", side ? " (side)" : "", wo.T + n_in, n_in, wo.n_kids, nh[wo.node].cost_at(nh[wo.node].q)); for (int k = 0; k < wo.n_kids; ++k) printf(" [%d/%d sc %u sr %u ev %u %u %u %u %u]", wo.kid_base[k][0], wo.kid_base[k][1], sc[k], sr[k], sv[0][k][0], sv[0][k][1], sv[0][k][2], sv[0][k][3], sv[0][k][4]); printf("\n"); }
 #endif
-            // how crowded the search is: the nodes that wait beside the parent and its children.  In a search that branches a little (two haplotypes: a handful of nodes)
-            // a child's first window may be long; where the queue is full most children are dropped within a few columns
-            const int others = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used && !nh[lane].complete)) - wk.n_kids - 1;
-            const int kid_w0 = others <= KID_CALM ? KID_LA : KID_W0;
-            if (lane < wk.n_kids) {                                         // one lane per child
-                const CNode& par = nh[wk.node];
-                const int k = lane;
-                CNode& c = nh[wk.kid_node[k]];
-                c.used = 1; c.complete = 0; c.id = ss.next_id + k; c.T = L + 1; c.cur = 0;
-                c.dual = par.dual || wk.kid_split[k]; c.split_at = wk.kid_split[k] ? L : par.split_at;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bool was_going = (i == 0 || par.dual) && !par.stopped[i];
-                    int st = par.stopped[i], ln = par.len[i];
-                    if (wk.kid_base[k][i] >= 0) { st = 0; ln = L + 1; }
-                    else if (was_going) { st = 1; ln = L; }
-                    c.stopped[i] = st; c.len[i] = ln;
+            if (!side) {
+                kids_from_sums(wo, 1);
+                adopt(wo.node, wo.n_kids, true, [&](int k) { return (int)wo.kid_node[k]; });
+            } else {
+                // made ahead of the parent's turn: the children wait unseen (used = 2) until the search takes the parent out at that column
+                kids_from_sums(wo, 2);
+                if (lane == 0) {
+                    CNode& par = nh[wo.node];
+                    par.pex_n = wo.n_kids; par.pex_L = wo.T + n_in;
+                    for (int k = 0; k < wo.n_kids; ++k) par.pex_kid[k] = (int8_t)wo.kid_node[k];
                 }
-                if (!c.dual) c.stopped[1] = 1;
-                c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = wk.n_kids <= KID_LA_KIDS ? 1 : 0; c.wcap = wk.n_kids <= KID_LA_KIDS ? kid_w0 : WRAMP0;
-                c.cost0 = par.cost_at(par.q) + (long long)sc[k]; c.dc[0] = 0; c.rest = sr[k]; c.rest_out = 0;
-                for (int i = 0; i < 2; ++i) for (int bq = 0; bq < 5; ++bq) c.ev[i][bq] = sv[i][k][bq];
-            }
-            if (wk.n_kids <= KID_LA_KIDS) {
-                // the children's lookahead votes ([child][consensus][KID_LA columns] in the launch's lookahead words) into the children's rows; the columns behind them
-                // are empty: a child's first window ends there at the latest.  (The rows are read back below, if a child is the next to go: a fence and the wave's
-                // own order make the stores visible to its loads.)
-                const uint32_t* flat = &sl[0][0][0];
-                for (int y = lane; y < wk.n_kids * 2 * KID_LA * 4; y += SP_WAVE) {                // (column KID_LA - 1 of a child has no votes: its window ends there, what lies behind is never read)
-                    const int k = y / (2 * KID_LA * 4), i = (y / (KID_LA * 4)) & 1, xb = y % (KID_LA * 4);
-                    P.la[(size_t)wk.kid_node[k] * 2 * CW * 4 + (size_t)i * CW * 4 + xb] = flat[y];
-                }
-                __threadfence_block();
-            }
-            spw::wave_lds_sync();
-            if (lane == 0) {
-                ss.next_id += wk.n_kids;
-                node_free(wk.node);
-                ss.expansions += 1;
-            }
-            spw::wave_lds_sync();
-            // more than max_queue_size nodes wait: the length threshold rises until at most that many stand at or above it -- the SHORTEST nodes go and the search is
-            // pushed forwards (CdwfaConfig::max_queue_size; oracle/consensus.c).  Lane k looks at node k; nodes under the threshold are freed at once (they would be
-            // dropped at their pop: their slots are needed)
-            for (;;) {
-                const bool waits = lane < NQ && nh[lane].used && !nh[lane].complete;
-                const int wlen = waits ? nh[lane].T + nh[lane].q : 0;
-                const bool live = waits && wlen >= ss.threshold;
-                if (waits && !live) node_free(lane);
-                if (__builtin_popcountll(__ballot(live)) <= ss.max_queue) break;
-                int shortest = live ? wlen : 0x7FFFFFFF;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(shortest, o); shortest = other < shortest ? other : shortest; }
-                if (lane == 0) ss.threshold = shortest + 1;
-                spw::wave_lds_sync();
             }
         }
-        spw::wave_lds_sync();                             // (the lookahead words written above are read below out of LDS, not back from memory)
+        spw::wave_lds_sync();
+    };
+    // side orders first, the search's own last: its sums stay in LDS for the search (la_fresh)
+    for (int w = n_orders - 1; w >= 0; --w) {
+        if (wks[w].mode == M_NONE) continue;
+        load_votes(w);
+        __syncthreads();
+        if (tid < SP_WAVE) take_result(w);
+        __syncthreads();
+        if (w > 0) {                                       // clear the sums for the next order
+            for (int x = tid; x < QE; x += blockDim.x) acc[x] = 0;
+            __syncthreads();
+        }
+    }
+    const long long tk1 = wall_clock64();
+    long long tk2 = tk1, tk3 = tk1;
+#ifdef SP_K8_SEARCH_TICKS
+    long long ts_pick = 0, ts_block = 0, ts_iters = 0;
+#endif
+    if (tid < SP_WAVE) {
         // ---------------------------------------------------------------- 2. the search, played forward over the tapes
         tk2 = wall_clock64();
-        if (lane == 0) { wk.mode = M_NONE; wk.n = 0; wk.replay = 0; wk.n_kids = 0; wk.pad += 1; }
+        if (lane == 0) { const int steps_made = wk.pad + 1; for (int w = 0; w < n_orders; ++w) { wks[w].mode = M_NONE; wks[w].n = 0; wks[w].replay = 0; wks[w].n_kids = 0; } wk.pad = steps_made; }
         spw::wave_lds_sync();
+        // The decision of a node that stands at the end of its tape, written as work order `w` (lane 0 only).  w == 0: the search's own -- the node has just been taken out at
+        // that column.  w > 0: a side order, made AHEAD of the node's turn for a node that waits -- nothing the search can observe changes: the node keeps its place, cost
+        // and id; its window comes back as a tape it consumes when its turn comes, the children of its expansion wait unseen until then.
+        // -> 0: no launch for this node (it completed, or -- side orders -- it is left for its turn), 1: the order was written
+        int replay_of_w[NWORK];
+#pragma unroll
+        for (int w = 0; w < NWORK; ++w) replay_of_w[w] = -1;
+        auto decide = [&](const int xi, const int w, unsigned long long& free_nodes, int& hidden) -> int {
+            CNode& x = nh[xi];
+            CWork& W = wks[w];
+            const bool side = w > 0;
+            int cut = -1;                                                            // >= 0: the node stands behind that many verified bases of a window that was cut
+            // its state at that column has to be there
+            if (x.q > 0 || x.n > 0) {
+                if (x.a == x.n && x.have_out) {                                    // the window stood: the other slot is the state
+                    if (x.n > 1) x.wcap = SP_K8_RAMP * x.wcap < CW ? SP_K8_RAMP * x.wcap : CW;
+                    x.T += x.n; x.cur ^= 1; x.cost0 = x.cost_at(x.n); x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
+                } else cut = x.a;                                                  // cut window: the state at the end of the verified bases is not there
+            }
+            // (which consensuses grew in that window: as they stand BEFORE this column's decision, which may end one)
+            const int pre_go[2] = { !x.stopped[0] ? 1 : 0, (x.dual && !x.stopped[1]) ? 1 : 0 };
+            auto order_replay = [&]() {
+                // push the verified bases again from the kept state (nothing is speculated)
+                W.mode = M_WINDOW; W.node = xi; W.in_slot = x.cur; W.T = x.T; W.n = x.a; W.replay = 1;
+                W.dual = x.dual; W.split_at = x.split_at;
+                for (int i = 0; i < 2; ++i) W.go[i] = pre_go[i];
+                replay_of_w[w] = xi;                                            // (the bases are copied below, a lane each)
+                ss.inflight = xi;
+            };
+            // (a cut window: the votes of the column behind the verified bases are there -- x.ev -- and say whether the node branches; if it does, the expansion
+            //  launch pushes the verified bases itself in front of the children's: the replay launch is only made where the node goes on alone)
+#ifdef SP_K8_NO_PRE
+            if (!side && cut >= 0 && (SP_K8_NO_PRE == 0 || (SP_K8_NO_PRE == 1 && x.dual) || (SP_K8_NO_PRE == 2 && !x.dual))) { order_replay(); return 1; }
+#endif
+            const int L = x.T + (cut > 0 ? cut : 0);
+            // candidates of every consensus that is still going
+            int nc[2] = { 0, 0 }, cd[2][4];
+            for (int i = 0; i < (x.dual ? 2 : 1); ++i) {
+                if (x.stopped[i]) continue;
+                nc[i] = cands(x.ev[i], L, cd[i]);
+                if (nc[i] == 0 && !side) { x.stopped[i] = 1; x.len[i] = L; }
+            }
+            if (nc[0] == 0 && nc[1] == 0) {
+                if (side) return 0;                                               // (complete: nothing to launch; its turn sees to it)
+                if (cut >= 0) { order_replay(); return 1; }                       // (its final cost needs the state: the replay brings it)
+                const long long fc = x.cost0 + (P.et ? 0 : x.rest);               // complete
+                if (ss.best_node < 0 || fc < ss.best_final) { if (ss.best_node >= 0) node_free(ss.best_node); ss.best_node = xi; ss.best_final = fc; x.complete = 1; }
+                else node_free(xi);
+                return 0;
+            }
+            if (side) for (int i = 0; i < (x.dual ? 2 : 1); ++i) if (!x.stopped[i] && nc[i] == 0) return 0;   // a consensus of the node ends at this column: left for its turn (the node's lengths change there)
+            // children, in the oracle's order
+            int kb[MAXKIDS][2], ks[MAXKIDS], nk = 0;
+            if (!x.dual) {
+                for (int a2 = 0; a2 < nc[0]; ++a2) { kb[nk][0] = cd[0][a2]; kb[nk][1] = -1; ks[nk] = 0; ++nk; }
+                if (P.allow_dual) for (int a2 = 0; a2 < nc[0]; ++a2) for (int b2 = a2 + 1; b2 < nc[0]; ++b2) { kb[nk][0] = cd[0][a2]; kb[nk][1] = cd[0][b2]; ks[nk] = 1; ++nk; }
+            } else {
+                const int n0 = nc[0] ? nc[0] : 1, n1 = nc[1] ? nc[1] : 1;
+                for (int a2 = 0; a2 < n0; ++a2) for (int b2 = 0; b2 < n1; ++b2) { kb[nk][0] = nc[0] ? cd[0][a2] : -1; kb[nk][1] = nc[1] ? cd[1][b2] : -1; ks[nk] = 0; ++nk; }
+            }
+            if (nk == 1 && cut >= 0) { if (side) return 0; order_replay(); return 1; }
+            if (nk == 1) {
+                // one child: the node itself goes on, through a window whose first base is this decision
+                W.mode = M_WINDOW; W.node = xi; W.in_slot = x.cur; W.T = L; W.replay = 0; W.dual = x.dual; W.split_at = x.split_at;
+                for (int i = 0; i < 2; ++i) { W.go[i] = kb[0][i] >= 0; W.spec[i][0] = (uint8_t)(kb[0][i] >= 0 ? kb[0][i] : 0); }
+                need_la[w] = x.la_valid ? xi : -1;
+                W.n = 1;
+                x.n = 0; x.a = 0; x.q = 0;
+                if (!side) ss.inflight = xi;                                     // the pop is under way: when the window is back the node consumes its first column
+                else ss.side_windows += 1;
+                return 1;
+            }
+            // several children: one push each into fresh nodes
+            if (side) {
+                // the node table keeps room for the queue, the complete node and the children of the search's own next expansion whatever is made ahead
+                const int room = NQ - (ss.max_queue + 1) - MAXKIDS;
+                if (nk > MAXKIDS || hidden + nk > room || __builtin_popcountll(free_nodes) < nk + MAXKIDS) return 0;
+            }
+            W.mode = M_EXPAND; W.node = xi; W.in_slot = x.cur; W.T = x.T; W.n = cut > 0 ? cut : 0; W.dual = x.dual; W.split_at = x.split_at; W.replay = 0;
+            W.go[0] = nc[0] > 0; W.go[1] = nc[1] > 0; W.pre_go[0] = pre_go[0]; W.pre_go[1] = pre_go[1];
+            if (cut > 0) replay_of_w[w] = xi;                                   // (the verified bases go into the work order below, a lane each)
+            int made = 0;
+            for (int k = 0; k < nk && made < MAXKIDS; ++k) {
+                if (!free_nodes) break;                                         // (the table holds the queue plus one expansion: not reached)
+                const int kn = __builtin_ctzll(free_nodes); free_nodes &= free_nodes - 1;
+                nh[kn].used = side ? 2 : 1; nh[kn].complete = 0; nh[kn].pex_n = 0;
+                W.kid_node[made] = kn; W.kid_base[made][0] = (int8_t)kb[k][0]; W.kid_base[made][1] = (int8_t)kb[k][1]; W.kid_split[made] = (int8_t)ks[k];
+                ++made;
+            }
+            W.n_kids = made;
+            copy_from[w] = xi; copy_len[w] = L;
+            if (side) { hidden += made; ss.side_expansions += 1; }
+            return 1;
+        };
         for (int guard = 0; ; ++guard) {
             if (guard > 100000) { if (lane == 0) wk.done = 1; break; }
 #ifdef SP_K8_SEARCH_TICKS
@@ -1546,7 +1708,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             if (xi < 0) {
                 // the best and the second best of the nodes that wait: lane k looks at node k
                 long long kc = 0x7FFFFFFFFFFFFFFFll; int kt = -1, kid = 0x7FFFFFFF, kx = -1;
-                if (lane < NQ && nh[lane].used && !nh[lane].complete) { const CNode& p = nh[lane]; kc = p.cost_at(p.q); kt = p.T + p.q; kid = p.id; kx = lane; }
+                if (lane < NQ && nh[lane].used == 1 && !nh[lane].complete) { const CNode& p = nh[lane]; kc = p.cost_at(p.q); kt = p.T + p.q; kid = p.id; kx = lane; }
                 auto less = [](long long c1, int t1, int i1, long long c2, int t2, int i2) { return c1 < c2 || (c1 == c2 && (t1 > t2 || (t1 == t2 && i1 < i2))); };
                 long long bc = kc; int bt = kt, bid = kid, bx = kx;
                 long long sc2 = 0x7FFFFFFFFFFFFFFFll; int st2 = -1, sid2 = 0x7FFFFFFF, sx2 = -1;
@@ -1612,105 +1774,97 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             } else if (lane == 0) ss.inflight = -1;
             spw::wave_lds_sync();
             // the node stands at the end of its tape and its pop is accounted for: the decision of that column
-            int stop = 0, replay_of = -1;
+            int stop = 0;
 #ifdef SP_K8_SEARCH_TICKS
             const long long ts1 = wall_clock64(); ts_pick += ts1 - ts0;
 #endif
-            unsigned long long free_nodes = __ballot(lane < NQ && !nh[lane].used);
-            if (lane == 0) {
-                CNode& x = nh[xi];
-                int cut = -1;                                                            // >= 0: the node stands behind that many verified bases of a window that was cut
-                do {
-                    if (x.q < x.a) { x.q += 1; x.id = ss.next_id++; break; }               // (a window that was under way came back: its first column is this pop's child)
-                    // its state at that column has to be there
-                    if (x.q > 0 || x.n > 0) {
-                        if (x.a == x.n && x.have_out) {                                    // the window stood: the other slot is the state
-                            if (x.n > 1) x.wcap = SP_K8_RAMP * x.wcap < CW ? SP_K8_RAMP * x.wcap : CW;
-                            x.T += x.n; x.cur ^= 1; x.cost0 = x.cost_at(x.n); x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
-                        } else cut = x.a;                                                  // cut window: the state at the end of the verified bases is not there
-                    }
-                    // (which consensuses grew in that window: as they stand BEFORE this column's decision, which may end one)
-                    const int pre_go[2] = { !x.stopped[0] ? 1 : 0, (x.dual && !x.stopped[1]) ? 1 : 0 };
-                    auto order_replay = [&]() {
-                        // push the verified bases again from the kept state (nothing is speculated)
-                        wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = x.a; wk.replay = 1;
-                        wk.dual = x.dual; wk.split_at = x.split_at;
-                        for (int i = 0; i < 2; ++i) wk.go[i] = pre_go[i];
-                        replay_of = xi;                                                 // (the bases are copied below, a lane each)
-                        ss.inflight = xi;
-                        stop = 1;
-                    };
-                    // (a cut window: the votes of the column behind the verified bases are there -- x.ev -- and say whether the node branches; if it does, the expansion
-                    //  launch pushes the verified bases itself in front of the children's: the replay launch is only made where the node goes on alone)
-#ifdef SP_K8_NO_PRE
-                    if (cut >= 0 && (SP_K8_NO_PRE == 0 || (SP_K8_NO_PRE == 1 && x.dual) || (SP_K8_NO_PRE == 2 && !x.dual))) { order_replay(); break; }
-#endif
-                    const int L = x.T + (cut > 0 ? cut : 0);
-                    // candidates of every consensus that is still going
-                    int nc[2] = { 0, 0 }, cd[2][4];
-                    for (int i = 0; i < (x.dual ? 2 : 1); ++i) {
-                        if (x.stopped[i]) continue;
-                        nc[i] = cands(x.ev[i], L, cd[i]);
-                        if (nc[i] == 0) { x.stopped[i] = 1; x.len[i] = L; }
-                    }
-                    if (cut >= 0 && (nc[0] == 0 && nc[1] == 0)) { order_replay(); break; }   // (its final cost needs the state: the replay brings it)
-                    if (nc[0] == 0 && nc[1] == 0) {                                        // complete
-                        const long long fc = x.cost0 + (P.et ? 0 : x.rest);
-                        if (ss.best_node < 0 || fc < ss.best_final) { if (ss.best_node >= 0) node_free(ss.best_node); ss.best_node = xi; ss.best_final = fc; x.complete = 1; }
-                        else node_free(xi);
-                        break;
-                    }
-                    // children, in the oracle's order
-                    int kb[MAXKIDS][2], ks[MAXKIDS], nk = 0;
-                    if (!x.dual) {
-                        for (int a2 = 0; a2 < nc[0]; ++a2) { kb[nk][0] = cd[0][a2]; kb[nk][1] = -1; ks[nk] = 0; ++nk; }
-                        if (P.allow_dual) for (int a2 = 0; a2 < nc[0]; ++a2) for (int b2 = a2 + 1; b2 < nc[0]; ++b2) { kb[nk][0] = cd[0][a2]; kb[nk][1] = cd[0][b2]; ks[nk] = 1; ++nk; }
-                    } else {
-                        const int n0 = nc[0] ? nc[0] : 1, n1 = nc[1] ? nc[1] : 1;
-                        for (int a2 = 0; a2 < n0; ++a2) for (int b2 = 0; b2 < n1; ++b2) { kb[nk][0] = nc[0] ? cd[0][a2] : -1; kb[nk][1] = nc[1] ? cd[1][b2] : -1; ks[nk] = 0; ++nk; }
-                    }
-                    if (nk == 1 && cut >= 0) { order_replay(); break; }
-                    if (nk == 1) {
-                        // one child: the node itself goes on, through a window whose first base is this decision
-                        wk.mode = M_WINDOW; wk.node = xi; wk.in_slot = x.cur; wk.T = L; wk.replay = 0; wk.dual = x.dual; wk.split_at = x.split_at;
-                        for (int i = 0; i < 2; ++i) { wk.go[i] = kb[0][i] >= 0; wk.spec[i][0] = (uint8_t)(kb[0][i] >= 0 ? kb[0][i] : 0); }
-                        need_la = x.la_valid ? xi : -1;
-                        wk.n = 1;
-                        x.n = 0; x.a = 0; x.q = 0;
-                        ss.inflight = xi;                                               // the pop is under way: when the window is back the node consumes its first column
-                        stop = 1; break;
-                    }
-                    // several children: one push each into fresh nodes
-                    wk.mode = M_EXPAND; wk.node = xi; wk.in_slot = x.cur; wk.T = x.T; wk.n = cut > 0 ? cut : 0; wk.dual = x.dual; wk.split_at = x.split_at;
-                    wk.go[0] = nc[0] > 0; wk.go[1] = nc[1] > 0; wk.pre_go[0] = pre_go[0]; wk.pre_go[1] = pre_go[1];
-                    if (cut > 0) replay_of = xi;                                        // (the verified bases go into the work order below, a lane each)
-                    int made = 0;
-                    for (int k = 0; k < nk && made < MAXKIDS; ++k) {
-                        if (!free_nodes) break;                                         // (the table holds the queue plus one expansion: not reached)
-                        const int kn = __builtin_ctzll(free_nodes); free_nodes &= free_nodes - 1;
-                        nh[kn].used = 1; nh[kn].complete = 0;
-                        wk.kid_node[made] = kn; wk.kid_base[made][0] = (int8_t)kb[k][0]; wk.kid_base[made][1] = (int8_t)kb[k][1]; wk.kid_split[made] = (int8_t)ks[k];
-                        ++made;
-                    }
-                    wk.n_kids = made;
-                    copy_from = xi; copy_len = L;
-                    stop = 1;
-                } while (0);
+            {
+                const CNode& x = nh[xi];
+                if (x.q < x.a) {                                                         // (a window that was under way came back: its first column is this pop's child)
+                    if (lane == 0) { nh[xi].q += 1; nh[xi].id = ss.next_id++; }
+                    spw::wave_lds_sync();
+                    continue;
+                }
+                if (x.pex_n > 0) {
+                    // its expansion was made ahead of its turn (a side order): the children join the search here, where the launch would have been ordered
+                    const int np = x.pex_n;
+                    if (lane == 0) ss.adopted += 1;
+                    adopt(xi, np, false, [&](int k) { return (int)nh[xi].pex_kid[k]; });
+                    continue;
+                }
             }
-            stop = __builtin_amdgcn_readfirstlane(stop); replay_of = __builtin_amdgcn_readfirstlane(replay_of);
+            unsigned long long free_nodes = __ballot(lane < NQ && !nh[lane].used);
+            int hidden = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 2));
+            if (lane == 0) stop = decide(xi, 0, free_nodes, hidden);
+            stop = __builtin_amdgcn_readfirstlane(stop);
             spw::wave_lds_sync();
 #ifdef SP_K8_SEARCH_TICKS
             ts_block += wall_clock64() - ts1;
 #endif
-            if (replay_of >= 0) {
-                const CNode& x = nh[replay_of];
-                for (int jq = lane; jq < x.a; jq += SP_WAVE) { wk.spec[0][jq] = x.spec[0][jq]; wk.spec[1][jq] = x.spec[1][jq]; }
-            }
             if (stop) break;
+        }
+        spw::wave_lds_sync();
+        // ---------------------------------------------------------------- 3. side orders: what the nodes that wait beside the search's own order will need at their turn
+        if (nside > 0 && !wk.done && wk.mode != M_NONE) {
+            if (lane == 0) ss.steps += 1;
+            // lane k looks at node k: does it stand at the end of its tape with its state at hand, would it be taken out at all, and what would its decision be
+            int kind = 0;                                                                // 1: it goes on alone (a window), 2: it branches (an expansion)
+            long long kc = 0x7FFFFFFFFFFFFFFFll; int kt = -1, kid = 0x7FFFFFFF;
+            if (lane < NQ && nh[lane].used == 1 && !nh[lane].complete && lane != wk.node && nh[lane].q >= nh[lane].a && nh[lane].pex_n == 0) {
+                const CNode& x = nh[lane];
+                bool mine = true;
+                if (wk.mode == M_EXPAND) for (int k = 0; k < wk.n_kids; ++k) if (wk.kid_node[k] == lane) mine = false;   // (children of the order just written: their slots are filled when it comes back)
+                const int Lq = x.T + x.q;
+                if (mine && Lq >= ss.threshold && Lq < P.cap + 2 && proc[Lq] < ss.per_size) {
+                    const bool stood = x.n == 0 || (x.a == x.n && x.have_out);
+                    const int L = x.T + x.a;
+                    int nc0 = 0, nc1 = 0, tmp[4];
+                    bool ends = false;                                                   // a consensus of the node ends at this column: left for its turn
+                    if (!x.stopped[0]) { nc0 = cands(x.ev[0], L, tmp); ends = ends || nc0 == 0; }
+                    if (x.dual && !x.stopped[1]) { nc1 = cands(x.ev[1], L, tmp); ends = ends || nc1 == 0; }
+                    int nk = 0;
+                    if (!x.dual) nk = nc0 + (P.allow_dual ? nc0 * (nc0 - 1) / 2 : 0);
+                    else if (nc0 || nc1) nk = (nc0 ? nc0 : 1) * (nc1 ? nc1 : 1);
+                    if (!ends && nk == 1 && stood) kind = 1;
+                    else if (!ends && nk > 1 && nk <= MAXKIDS) kind = 2;
+                    if (kind) { kc = x.cost_at(x.q); kt = Lq; kid = x.id; }
+                }
+            }
+            unsigned long long free_nodes = __ballot(lane < NQ && !nh[lane].used);
+            int hidden = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 2));
+            auto less = [](long long c1, int t1, int i1, long long c2, int t2, int i2) { return c1 < c2 || (c1 == c2 && (t1 > t2 || (t1 == t2 && i1 < i2))); };
+            int w = 1;
+            for (int tries = 0; w <= nside && tries < 8; ++tries) {
+                // the next node in the search's own order among those that are left
+                long long bc = kc; int bt = kt, bid = kid, bx = kind ? lane : -1;
+                if (!__ballot(kind != 0)) break;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const long long oc = __shfl_xor(bc, o); const int ot = __shfl_xor(bt, o), oi = __shfl_xor(bid, o), ox = __shfl_xor(bx, o);
+                    if (ox >= 0 && (bx < 0 || less(oc, ot, oi, bc, bt, bid))) { bc = oc; bt = ot; bid = oi; bx = ox; }
+                }
+                if (bx < 0) break;
+                int made = 0;
+                if (lane == 0) made = decide(bx, w, free_nodes, hidden);
+                made = __builtin_amdgcn_readfirstlane(made);
+                free_nodes = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(free_nodes >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)free_nodes);
+                hidden = __builtin_amdgcn_readfirstlane(hidden);
+                spw::wave_lds_sync();
+                if (lane == bx) kind = 0;
+                if (made) ++w;
+            }
+        } else if (lane == 0 && !wk.done && wk.mode != M_NONE) ss.steps += 1;
+        spw::wave_lds_sync();
+        for (int w = 0; w < n_orders; ++w) {
+            const int ro = replay_of_w[w] = __builtin_amdgcn_readfirstlane(replay_of_w[w]);
+            if (ro >= 0) {
+                const CNode& x = nh[ro];
+                for (int jq = lane; jq < x.a; jq += SP_WAVE) { wks[w].spec[0][jq] = x.spec[0][jq]; wks[w].spec[1][jq] = x.spec[1][jq]; }
+            }
         }
 #ifdef SP_K8_PF_PROBE
         if (wk.mode == M_WINDOW || wk.mode == M_EXPAND) {
-            bool idle = lane < NQ && nh[lane].used && !nh[lane].complete && lane != wk.node && nh[lane].q >= nh[lane].a;
+            bool idle = lane < NQ && nh[lane].used == 1 && !nh[lane].complete && lane != wk.node && nh[lane].q >= nh[lane].a;
             if (wk.mode == M_EXPAND) for (int k = 0; k < wk.n_kids; ++k) if (wk.kid_node[k] == lane) idle = false;
             const unsigned long long mask = __ballot(idle);
             if (lane == 0) {
@@ -1723,23 +1877,26 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         // window ends where a consensus has no lookahead votes left (or at cap)
         spw::wave_lds_sync();
         tk3 = wall_clock64();
-        if (need_la >= 0) {
-            const uint32_t* la = need_la == la_fresh ? &sl[0][0][0] : P.la + (size_t)need_la * 2 * CW * 4;
-            const int lim = nh[need_la].wcap;
+        for (int w = 0; w < n_orders; ++w) {
+            const int nl = need_la[w];
+            if (nl < 0) continue;
+            CWork& W = wks[w];
+            const uint32_t* la = (w == 0 && nl == la_fresh) ? &sl[0][0][0] : P.la + (size_t)nl * 2 * CW * 4;
+            const int lim = nh[nl].wcap;
             int nn = lim;
             for (int base = 0; base < lim; base += SP_WAVE) {
                 const int col = base + lane;
-                bool have = col >= 1 && col < lim && wk.T + col < P.cap;
+                bool have = col >= 1 && col < lim && W.T + col < P.cap;
                 int pick[2] = { 0, 0 };
                 if (have) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        if (!wk.go[i]) continue;
-                        const uint4 w = *reinterpret_cast<const uint4*>(la + ((size_t)i * CW + (col - 1)) * 4);
-                        int b1 = 0; uint32_t w1 = w.x;
-                        if (w.y > w1) { b1 = 1; w1 = w.y; }
-                        if (w.z > w1) { b1 = 2; w1 = w.z; }
-                        if (w.w > w1) { b1 = 3; w1 = w.w; }
+                        if (!W.go[i]) continue;
+                        const uint4 wv = *reinterpret_cast<const uint4*>(la + ((size_t)i * CW + (col - 1)) * 4);
+                        int b1 = 0; uint32_t w1 = wv.x;
+                        if (wv.y > w1) { b1 = 1; w1 = wv.y; }
+                        if (wv.z > w1) { b1 = 2; w1 = wv.z; }
+                        if (wv.w > w1) { b1 = 3; w1 = wv.w; }
                         if (w1 == 0) have = false;
                         pick[i] = b1;
                     }
@@ -1747,24 +1904,26 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                 unsigned long long miss = __ballot(!have);
                 if (base == 0) miss &= ~1ull;                                  // column 0 is the exact base
                 const int first = miss ? __builtin_ctzll(miss) : SP_WAVE;
-                if (col >= 1 && lane < first) { wk.spec[0][col] = (uint8_t)pick[0]; wk.spec[1][col] = (uint8_t)pick[1]; }
+                if (col >= 1 && lane < first) { W.spec[0][col] = (uint8_t)pick[0]; W.spec[1][col] = (uint8_t)pick[1]; }
                 if (miss) { nn = base + first; break; }
             }
-            if (lane == 0) wk.n = nn < lim ? nn : lim;
+            if (lane == 0) W.n = nn < lim ? nn : lim;
         }
     }
     __syncthreads();
-    // a window whose pop was under way comes back with its first column consumed (set here for the next pass: the tape is filled in
-    // by part 1 of that pass); children get their parent's consensus
-    if (copy_from >= 0) {
-        for (int k = 0; k < wk.n_kids; ++k) {
-            const int kn = wk.kid_node[k];
-            const bool split = wk.kid_split[k] != 0;
+    // children get their parent's consensus (and their own base behind it)
+    for (int w = 0; w < n_orders; ++w) {
+        if (copy_from[w] < 0) continue;
+        const CWork& W = wks[w];
+        const int cfrom = copy_from[w], clen = copy_len[w];
+        for (int k = 0; k < W.n_kids; ++k) {
+            const int kn = W.kid_node[k];
+            const bool split = W.kid_split[k] != 0;
             for (int i = 0; i < 2; ++i) {
-                if (i == 1 && !(wk.dual || split)) continue;
-                const uint4* src = reinterpret_cast<const uint4*>(P.C + ((size_t)copy_from * 2 + ((i == 1 && split) ? 0 : i)) * P.cs);
+                if (i == 1 && !(W.dual || split)) continue;
+                const uint4* src = reinterpret_cast<const uint4*>(P.C + ((size_t)cfrom * 2 + ((i == 1 && split) ? 0 : i)) * P.cs);
                 uint8_t* dst = P.C + ((size_t)kn * 2 + i) * P.cs;
-                const int whole = copy_len >> 4, tail = copy_len & 15;                  // (the rows are 16-byte aligned)
+                const int whole = clen >> 4, tail = clen & 15;                  // (the rows are 16-byte aligned)
                 for (int y = tid; y < whole + (tail ? 1 : 0); y += blockDim.x) {
                     uint4 v;
                     if (coh) {                                                          // (the parent's bytes were stored write-through; 8 bytes per access both ways)
@@ -1772,13 +1931,13 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                         const unsigned long long lo = coh_load(s8), hi = coh_load(s8 + 1);
                         v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32); v.z = (uint32_t)hi; v.w = (uint32_t)(hi >> 32);
                     } else v = src[y];
-                    if (y == whole && wk.kid_base[k][i] >= 0) reinterpret_cast<uint8_t*>(&v)[tail] = (uint8_t)wk.kid_base[k][i];   // the child's own base lies in the last word
+                    if (y == whole && W.kid_base[k][i] >= 0) reinterpret_cast<uint8_t*>(&v)[tail] = (uint8_t)W.kid_base[k][i];   // the child's own base lies in the last word
                     if (coh) {
                         unsigned long long* d8 = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint4*>(dst) + y);
                         coh_store(d8, (unsigned long long)v.x | ((unsigned long long)v.y << 32)); coh_store(d8 + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32));
                     } else reinterpret_cast<uint4*>(dst)[y] = v;
                 }
-                if (tid == 0 && tail == 0 && wk.kid_base[k][i] >= 0) put(&dst[copy_len], (uint8_t)wk.kid_base[k][i], coh);
+                if (tid == 0 && tail == 0 && W.kid_base[k][i] >= 0) put(&dst[clen], (uint8_t)W.kid_base[k][i], coh);
             }
         }
     }
@@ -1806,7 +1965,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         const int k = x / NODE_TAPE_WORDS, w = x % NODE_TAPE_WORDS;
         if (tape_word_used(nh[k], w)) ((uint32_t*)&P.nodes[k])[NODE_HEAD_WORDS + w] = ((const uint32_t*)&nh[k])[NODE_HEAD_WORDS + w];
     }
-    for (int x = tid; x < (int)(sizeof(CWork) / 4); x += blockDim.x) put(&((uint32_t*)P.work)[x], ((const uint32_t*)&wk)[x], coh);
+    for (int x = tid; x < n_orders * (int)(sizeof(CWork) / 4); x += blockDim.x) put(&((uint32_t*)P.work)[x], ((const uint32_t*)wks)[x], coh);
     for (int x = tid; x < (int)(sizeof(CSearch) / 4); x += blockDim.x) ((uint32_t*)P.srch)[x] = ((const uint32_t*)&ss)[x];
     for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)P.processed)[x] = ((const uint32_t*)proc)[x];
     if (tid == 0 && B.prog) {
@@ -1860,7 +2019,7 @@ __global__ void __launch_bounds__(CWAVES * SP_WAVE, SP_K8_MIN_WAVES) cons_step_p
         // (what the control step wrote -- work order, node lengths, consensus bytes -- is loaded past the L1, the vote words it cleared were cleared where the atomics run:
         //  no acquire; a wave's states are its own from step to step)
         if (coh_load(&B.p[pi].work->done)) break;
-        cons_step_body<MAXP>(B);
+        cons_step_body<MAXP>(B, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's atomic adds have been acknowledged before the workgroup reports in
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(sy + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2040,6 +2199,14 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     // budget taken by other batches, runs launch by launch as before.
     PersistLease lease;
     int persist_rpw = 0;
+    // side orders per step (sp_ctx_set_option "k8_side_orders", default NWORK - 1): one more row of workgroups in every step launch each.  A batch of very many workgroups (a
+    // cohort's first lockstep rounds) keeps to the search's own order: its launches are wide already and rows of workgroups that mostly find no order still have to be dealt out
+    int nside = std::max(0, std::min(ctx->k8_side_orders, NWORK - 1));
+    {
+        uint64_t nb_all = 0;
+        for (uint32_t p = 0; p < n_prob; ++p) nb_all += ((probs[p].read_idx ? probs[p].n : probs[p].reads->n) + CWAVES - 1) / CWAVES;
+        if (nb_all > (uint64_t)ctx->k8_side_max_blocks) nside = 0;
+    }
     // Consensus batches of this process under way on the device, this one included from here on; and, for the library's own choice of mode, when two batches that could
     // run as persistent kernels (single samples' searches) last ran side by side: a host that keeps several samples in flight on one device
     struct InFlight {
@@ -2134,7 +2301,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     size_t in_bytes = 0, out_bytes = 0, zero_bytes = 0;
     auto place = [](size_t& total_bytes, size_t bytes) { const size_t at = (total_bytes + 15) & ~(size_t)15; total_bytes = at + bytes; return at; };
     const size_t in_idx = place(in_bytes, sizeof(uint32_t) * h_idx.size()), in_off = place(in_bytes, sizeof(int32_t) * h_off.size());
-    const size_t in_work = place(in_bytes, sizeof(CWork) * n_prob), in_srch = place(in_bytes, sizeof(CSearch) * n_prob);
+    const size_t in_work = place(in_bytes, sizeof(CWork) * NWORK * n_prob), in_srch = place(in_bytes, sizeof(CSearch) * n_prob);
     const size_t in_probs = place(in_bytes, MAXP == 0 ? sizeof(ConsParams) * n_prob : 0), in_bp = place(in_bytes, sizeof(int) * block_prob.size());
     const size_t in_cp = place(in_bytes, sizeof(int) * cluster_prob.size());
     const size_t in_setup = place(in_bytes, n_prob > 8 ? sizeof(ConsSetup) * n_prob : 0);
@@ -2142,7 +2309,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     const size_t out_is1 = place(out_bytes, total), out_sc = place(out_bytes, sizeof(int32_t) * 2 * total);
     std::vector<size_t> out_cons(n_prob);
     for (uint32_t p = 0; p < n_prob; ++p) out_cons[p] = place(out_bytes, (size_t)2 * std::max(hp[p].cap, 1));
-    const size_t zero_nodes = place(zero_bytes, sizeof(CNode) * NQ * n_prob), zero_proc = place(zero_bytes, proc_bytes), zero_info = place(zero_bytes, sizeof(ReadInfo) * total), zero_memo = place(zero_bytes, sizeof(PlaceMemo) * 2 * total);
+    const size_t zero_nodes = place(zero_bytes, sizeof(CNode) * NQ * n_prob), zero_proc = place(zero_bytes, proc_bytes), zero_info = place(zero_bytes, sizeof(ReadInfo) * total), zero_memo = place(zero_bytes, sizeof(PlaceMemo) * 2 * total * (size_t)(1 + nside));
     const size_t zero_sync = place(zero_bytes, sizeof(uint32_t) * (4 * (size_t)n_prob + 4));
     uint8_t* d_in = (uint8_t*)sp_pool(ctx, "cons_in", in_bytes + 16); uint8_t* h_in = (uint8_t*)sp_host_pool(ctx, "cons_in", in_bytes + 16);
     uint8_t* d_out = (uint8_t*)sp_pool(ctx, "cons_out", out_bytes + 16); uint8_t* h_out = (uint8_t*)sp_host_pool(ctx, "cons_out", out_bytes + 16);
@@ -2161,7 +2328,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     B.info = d_info; B.total = (int)total;
     B.H = (uint16_t*)sp_pool(ctx, "cons_H", sizeof(uint16_t) * planes * total * CB);
     B.meta = (ConsMeta*)sp_pool(ctx, "cons_meta", sizeof(ConsMeta) * planes * total);
-    const size_t wblocks = (size_t)n_blocks + n_prob;         // the workgroups' word blocks + one block per problem its workgroups add to (acc_block)
+    const size_t wblocks = (size_t)n_blocks + (size_t)NWORK * n_prob;         // the workgroups' word blocks + one block per problem and order its workgroups add to (acc_block + order)
     B.PV = (unsigned long long*)sp_pool(ctx, "cons_pv", sizeof(unsigned long long) * wblocks * 2 * (CW + 1));
     B.PE = (uint32_t*)sp_pool(ctx, "cons_pe", sizeof(uint32_t) * wblocks * 2 * (CW + 1));
     B.PL = (unsigned long long*)sp_pool(ctx, "cons_pl", sizeof(unsigned long long) * wblocks * 2 * CW);
@@ -2197,9 +2364,9 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     for (uint32_t p = 0; p < n_prob; ++p) {
         setup[p].idx = probs[p].read_idx ? d_idx + idx_at[p] : nullptr;
         setup[p].offsets = probs[p].offsets ? d_off + off_at[p] : nullptr; setup[p].cmp_len = probs[p].cfg.offset_compare_length; setup[p].pad_ = 0;
-        hp[p].C = d_C + c_at[p]; hp[p].work = d_work + p; hp[p].srch = d_srch + p; hp[p].nodes = d_nodes + (size_t)p * NQ;
+        hp[p].C = d_C + c_at[p]; hp[p].work = d_work + (size_t)p * NWORK; hp[p].srch = d_srch + p; hp[p].nodes = d_nodes + (size_t)p * NQ;
         hp[p].la = d_la + (size_t)p * NQ * 2 * CW * 4; hp[p].processed = d_proc + proc_at[p];
-        hp[p].acc_block = n_blocks + (int)p;
+        hp[p].acc_block = n_blocks + (int)p * NWORK;
         hp[p].out_cons = d_out + out_cons[p]; hp[p].out_res = (ConsRes*)(d_out + out_res) + p; hp[p].out_srch = (CSearch*)(d_out + out_srch) + p;
     }
     if constexpr (MAXP == 0) {
@@ -2211,7 +2378,8 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         for (uint32_t p = 0; p < n_prob; ++p) B.p[p] = hp[p];
     }
     for (uint32_t p = 0; p < n_prob; ++p) {
-        CWork& w = h_work0[p]; std::memset(&w, 0, sizeof w); w.mode = M_INIT; w.node = 0; w.in_slot = 0; w.split_at = -1;
+        std::memset(&h_work0[(size_t)p * NWORK], 0, sizeof(CWork) * NWORK);       // (the side orders of the first step: none)
+        CWork& w = h_work0[(size_t)p * NWORK]; w.mode = M_INIT; w.node = 0; w.in_slot = 0; w.split_at = -1;
         CSearch& s = h_srch0[p]; std::memset(&s, 0, sizeof s); s.best_node = -1; s.inflight = -1;
         const sp_cons_config& cf = probs[p].cfg;
         s.max_queue = cf.max_queue_size > 0 ? std::min(cf.max_queue_size, NQ - MAXKIDS - 2) : 20;
@@ -2224,7 +2392,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     SP_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, st));
     SP_HIP_CHECK(ctx, hipMemsetAsync(d_zero, 0, zero_bytes, st));
     {   // the blocks the workgroups of small problems add their words to start at zero (the control step clears what it reads)
-        const size_t nb = (size_t)n_blocks, np = (size_t)n_prob;
+        const size_t nb = (size_t)n_blocks, np = (size_t)n_prob * NWORK;
         SP_HIP_CHECK(ctx, hipMemsetAsync(B.PV + nb * 2 * (CW + 1), 0, sizeof(unsigned long long) * np * 2 * (CW + 1), st));
         SP_HIP_CHECK(ctx, hipMemsetAsync(B.PE + nb * 2 * (CW + 1), 0, sizeof(uint32_t) * np * 2 * (CW + 1), st));
         SP_HIP_CHECK(ctx, hipMemsetAsync(B.PL + nb * 2 * CW, 0, sizeof(unsigned long long) * np * 2 * CW, st));
@@ -2235,7 +2403,8 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     else for (uint32_t p = 0; p < n_prob; ++p)
         if (setup[p].n) hipLaunchKernelGGL(cons_setup_kernel, dim3((setup[p].n + 255) / 256), dim3(256), 0, st, setup[p], d_info);
 
-    const dim3 grid((uint32_t)n_blocks), block(CWAVES * SP_WAVE);
+    B.nside = persist_rpw ? 0 : nside;
+    const dim3 grid((uint32_t)n_blocks, (uint32_t)(1 + B.nside)), block(CWAVES * SP_WAVE);
     // (the step kernel's instantiation for batches that fit the device at one workgroup per CU, give or take a few: cons_step_wide_kernel.  A 2,000-read CYP2D6 sample's first batch
     //  has 271 workgroups -- its 2,162 region segments -- and is still faster there)
     static const int wide_max = std::getenv("SP_K8_WIDE_MAX") ? std::atoi(std::getenv("SP_K8_WIDE_MAX")) : -1;      // (experiment switch)
@@ -2294,7 +2463,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
                 }
             }
             if (all_ready) {
-                hipLaunchKernelGGL(cons_step_persist_kernel<MAXP>, grid, block, 0, st, B);
+                hipLaunchKernelGGL(cons_step_persist_kernel<MAXP>, dim3((uint32_t)n_blocks), block, 0, st, B);
                 const hipError_t e1 = hipGetLastError();
                 const hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ctx->ev_join, ctx->ctl_stream) : e1;
                 const hipError_t e3 = e2 == hipSuccess ? hipStreamWaitEvent(st, ctx->ev_join, 0) : e2;
@@ -2399,6 +2568,10 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         for (uint32_t p = 0; p < n_prob; ++p) { cut += (uint64_t)h_srch[p].cut_windows; ex += (uint64_t)h_srch[p].expansions; pops += (uint64_t)h_srch[p].pops; }
         ctx->prof["cons_windows"].cells += pairs; ctx->prof["cons_windows"].launches += 3 * pairs;           // (two per step for a batch of small problems)
         ctx->prof["cons_cut_windows"].cells += cut; ctx->prof["cons_expansions"].cells += ex; ctx->prof["cons_columns"].cells += pops;
+        for (uint32_t p = 0; p < n_prob; ++p) {
+            ctx->prof["cons_side_windows"].cells += (uint64_t)h_srch[p].side_windows; ctx->prof["cons_side_expansions"].cells += (uint64_t)h_srch[p].side_expansions;
+            ctx->prof["cons_adopted"].cells += (uint64_t)h_srch[p].adopted;
+        }
 #ifdef SP_K8_PF_PROBE
         {   // the batch's chain is its slowest problem's: steps as they are / without the window orders a launch before could have carried / without any such order
             uint64_t c0 = 0, c1 = 0, c2 = 0;
@@ -2423,7 +2596,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
             }
             ctx->prof["cons_path_step_ticks"].cells += (uint64_t)h_srch[bp].step_ticks; ctx->prof["cons_path_gap_ticks"].cells += (uint64_t)h_srch[bp].gap_ticks;
             ctx->prof["cons_path_control_ticks"].cells += (uint64_t)(h_srch[bp].ticks[0] + h_srch[bp].ticks[1] + h_srch[bp].ticks[2] + h_srch[bp].ticks[3]);
-            ctx->prof["cons_path_steps"].cells += (uint64_t)h_srch[bp].windows + (uint64_t)h_srch[bp].expansions;
+            ctx->prof["cons_path_steps"].cells += (uint64_t)h_srch[bp].steps;
         }
     }
     static const char dec[4] = { 'A', 'C', 'G', 'T' };

@@ -1098,6 +1098,9 @@ __global__ __launch_bounds__(CH_THREADS) void k1s_select_kernel(SeqSetView reads
             while (j >= 0) { const SChain cj = sc_chain[s_sel[j]]; if (k1_of(cj) > k1_of(cx) || (k1_of(cj) == k1_of(cx) && k2_of(cj) > k2_of(cx))) break; s_sel[j + 1] = s_sel[j]; --j; }
             s_sel[j + 1] = x;
         }
+        // (both caps are far above what `best_n 5` lets through -- a handful of primaries and their secondaries; a read that meets one is counted like every other
+        //  truncation: sp_hla_realign_reads reports the count, sp_profile_get "k1s_truncated_reads")
+        if (n > SEL_CAP || n_prim >= PRIM_CAP) atomicAdd(&ctr->overflow_reads, 1u);
         if (n > SEL_CAP) n = SEL_CAP;
         uint32_t n_rev = 0;
         for (int i = 0; i < n; ++i) {
@@ -1508,6 +1511,13 @@ int sp_k1_seed_map(sp_ctx* ctx, const K1Seed* idx, const sp_seqset* alleles, con
 #ifdef SP_K1S_TIMING
     fprintf(stderr, "k1s_group phases (100 MHz ticks summed over workgroups): count %llu scan %llu scatter %llu records %llu; dp kernel waves: task + load %llu, up to 8 anchors %llu, 9..26 %llu, signatures of the large %llu\n", hc.t[0], hc.t[1], hc.t[2], hc.t[3], hc.t[7], hc.t[4], hc.t[5], hc.t[6]);
 #endif
+    if (hc.overflow_reads) {
+        // a capacity of the seeded map was met (seeds per read, the anchor / group batch buffers, more than DP_BIG_MAX anchors on one target, chains per read, PRIM_CAP / SEL_CAP of
+        // the selection): the reads concerned were mapped from a truncated list -- minimap2 has no such bounds -- and the caller is told so instead of finding out from a call
+        ctx->prof["k1s_truncated_reads"].cells += hc.overflow_reads;
+        ctx->warning = "seeded K1: " + std::to_string(hc.overflow_reads) + " capacity events (seed / anchor / chain lists of a read cut short) in the last sp_hla_realign_reads call: "
+                       "those reads were mapped from truncated lists; k1_best_n 0 (the exhaustive search) has no such bounds";
+    }
     if (hc.wide_cells) {
         // alignments across long insertions / deletions: their re-score on 256 diagonals (the trace on the wide band as well)
         sp_affine_aln* d_afw = (sp_affine_aln*)sp_pool(ctx, "k1s_af_wide", NC * sizeof(sp_affine_aln));

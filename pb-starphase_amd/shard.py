@@ -53,17 +53,20 @@ class SoloGroup:
 
 def make_group(ctx, ffi, backend="nccl", device=None):
     """The group a rank gathers through.  `nccl`: an sp_group of the library (librccl, ncclAllGather on the context's stream); its 128-byte
-    id is made by rank 0 and handed out through the process group the launcher set up.  Anything else: the torch group."""
-    import torch
+    id is made by rank 0 and handed out through the KEY-VALUE STORE of the launcher's rendezvous -- not through a collective of the process group: a rank
+    that never gets here then leaves nothing pending on that group (its peers wait in store.get, which times out).  Anything else: the torch group.
+    Give it a context of its own (pkg.Context(device)): should the first gather never complete, it sits on that context's stream and on no stream the run needs."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return None
     if backend != "nccl":
         return TorchGroup(device)
     rank, world = dist.get_rank(), dist.get_world_size()
-    uid = torch.from_numpy(ffi.group_unique_id() if rank == 0 else np.zeros(ffi.SP_GROUP_ID_BYTES, np.uint8)).to(device or "cuda")
-    dist.broadcast(uid, 0)
-    return ffi.Group(ctx, uid.cpu().numpy(), rank, world)
+    store = dist.distributed_c10d._get_default_store()
+    if rank == 0:
+        store.set("sp_group_unique_id", bytes(np.ascontiguousarray(ffi.group_unique_id(), np.uint8)))
+    uid = np.frombuffer(store.get("sp_group_unique_id"), np.uint8).copy()
+    return ffi.Group(ctx, uid, rank, world)
 
 
 def gather_calls(calls, device=None, same_count=False, group=None):

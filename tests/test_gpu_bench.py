@@ -85,6 +85,18 @@ def test_a_group_that_never_comes_up_falls_back_to_the_torch_group():
     assert c["calls_equal_truth"]["hla"] == "8/8" and c["calls_equal_truth"]["cyp2d6"] == "4/4"
 
 
+@pytest.mark.parametrize("inject", ["1:before", "0:after", "1:error"])
+def test_one_rank_whose_group_hangs_or_fails_takes_every_rank_to_the_torch_group(inject):
+    """only ONE rank's group bring-up hangs (before or after the group is made) or raises: the id travels through the rendezvous store and the agreement is the first collective
+    every rank issues, so the healthy rank is not left waiting in a collective the other never joins; every rank gathers through torch.distributed and the line is complete"""
+    line = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--cohort-samples", "4", "--no-extra-legs"],
+                     env={"SP_BENCH_BACKEND": "gloo", "SP_BENCH_INJECT_GROUP_HANG": inject, "SP_BENCH_GROUP_TIMEOUT_S": "2"})
+    assert line["group_fallback"] and line["gather_via"] == "torch.distributed"
+    c = line["cohort"]
+    assert c["samples"] == 4 and c["records_gathered_per_pass"] == 4 * (2 + 1 + 18)
+    assert c["calls_equal_truth"]["hla"] == "8/8" and c["calls_equal_truth"]["cyp2d6"] == "4/4"
+
+
 def test_eight_rank_cohort_of_sixteen_samples_over_gloo():
     """the round-end scaling run's shape on one device: `bench.py --gpus 8` with a 16-sample cohort, two samples per rank, the records of all eight ranks in rank 0's table"""
     line = run_bench(["--gpus", "8", "--steps", "1", "--warmup", "1", "--cohort-samples", "16", "--no-extra-legs"], env={"SP_BENCH_BACKEND": "gloo"})

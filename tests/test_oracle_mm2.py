@@ -249,3 +249,62 @@ def test_k1_seeded_statement_on_the_port_fixture(oracle):
         assert dna_ids[int(h["rid"])] == doc["winner"][r], r
         assert (int(h["nm"]), int(h["t_end"] - h["t_start"])) == (doc["nm"][r], doc["span"][r]), r
         assert [int(x["dp_max"]) for x in hits] == sorted((int(x["dp_max"]) for x in hits), reverse=True)       # output order: by peak score
+
+
+def _islands():
+    import json, os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chr6_hla_islands.json")))
+    return {(i["start"], i["end"]): i["sequence"] for i in d["islands"]}
+
+
+def _faux_alleles():
+    """tests/golden/HLA-faux/hla_gen.fa: the two genomic alleles of the reference's test_data/HLA-faux (data: A*01:01:01:01, B*07:02:01:01)"""
+    import os
+    out, name = {}, None
+    for line in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "HLA-faux", "hla_gen.fa")):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[1]
+            out[name] = []
+        elif line:
+            out[name].append(line.upper())
+    return {k: "".join(v) for k, v in out.items()}
+
+
+# RefSeq gene records of the reference's test_data/refseq_faux/refseq_small.gff.gz (1-based inclusive, as GFF has them) and what HlaConfig::new must extend them to
+# (HlaConfig::default_gene_collection, /root/reference/src/hla/alleles.rs:232-243)
+HLACONFIG_CASES = (("A*01:01:01:01", 29942532, 29945870, (29942253, 29945870)), ("B*07:02:01:01", 31353875, 31357179, (31353361, 31357442)))
+
+
+def hlaconfig_extend(map_best, islands, alleles):
+    """HlaConfig::new for one allele per gene (/root/reference/src/hla/alleles.rs:108-196): the RefSeq record +- 2,000 bases is the target, the allele the query; of the
+    mappings the one with the lowest (nm + unmapped) / len wins (strict <, first wins ties); the gene's coordinates are extended to cover it.
+    map_best(target, query) -> list of mappings with q_start, q_end, t_start, t_end, nm"""
+    out = {}
+    for name, gff_start, gff_end, _want in HLACONFIG_CASES:
+        start, end = gff_start - 1, gff_end                                   # 0-based half-open
+        a_start, a_end = start - 2000, end + 2000
+        (i_start, i_end), seq = next((k, v) for k, v in islands.items() if k[0] <= a_start and a_end <= k[1])
+        target = seq[a_start - i_start:a_end - i_start]
+        query = alleles[name]
+        best, best_score = None, 1.0                                          # MappingStats::new(ref_len, ref_len, 0): score 1.0
+        for m in map_best(target, query):
+            unmapped = len(query) - (m["q_end"] - m["q_start"])
+            score = max(m["nm"] + unmapped, 0.1) / len(query)                 # MappingStats::mapping_score, penalised (src/data_types/mapping.rs:60-84)
+            if score < best_score:
+                best, best_score = m, score
+        assert best is not None, name
+        out[name] = (min(start, a_start + best["t_start"]), max(end, a_start + best["t_end"]), best)
+    return out
+
+
+def test_hlaconfig_new(mm):
+    """The reference's one real-data pin of minimap2 (`test_hlaconfig_new`, /root/reference/src/hla/alleles.rs:512-547): two real IMGT alleles mapped onto the RefSeq records
+    +- 2,000 bases of the chr6 islands must extend the coordinates to HlaConfig::default()'s -- the allele that is 42 edits from the reference included, i.e. with
+    minimap2's end clipping on real divergence."""
+    got = hlaconfig_extend(lambda t, q: mm.map_pair(t, q), _islands(), _faux_alleles())
+    for name, _s, _e, want in HLACONFIG_CASES:
+        assert got[name][:2] == want, (name, got[name])
+    a, b = got["A*01:01:01:01"][2], got["B*07:02:01:01"][2]
+    assert (a["rev"], a["nm"]) == (0, 42) and (b["rev"], b["nm"]) == (1, 0)          # HLA-A lies on the forward strand of hg38, HLA-B on the reverse one
+    assert 2000 - (29942532 - 1 - 29942253) == a["t_start"] and a["t_end"] == 29945755 - (29942531 - 2000)
