@@ -1315,6 +1315,27 @@ __device__ __forceinline__ int col_candidates(const uint32_t* w5, int col, int c
     return n;
 }
 
+// the same list without an array (an `out[n++]` lives in scratch memory: a round trip to memory per access in the one lane that decides): the bases 2 bits each, heaviest
+// first, in `packed`; the weights are ordered by the very compare-and-swap sequence of the loops above
+__device__ __forceinline__ int col_candidates_packed(const uint32_t* w5, int col, int cap, int et, int min_count, double min_af, uint32_t& packed) {
+    packed = 0;
+    if (col >= cap) return 0;
+    uint32_t wa = w5[0], wb = w5[1], wc = w5[2], wd = w5[3]; uint32_t ca = 0, cb = 1, cc = 2, cd = 3;
+#define SP_CSW(x, y, cx, cy) if (y > x) { const uint32_t tw_ = x; x = y; y = tw_; const uint32_t tc_ = cx; cx = cy; cy = tc_; }
+    SP_CSW(wa, wb, ca, cb) SP_CSW(wa, wc, ca, cc) SP_CSW(wa, wd, ca, cd) SP_CSW(wb, wc, cb, cc) SP_CSW(wb, wd, cb, cd) SP_CSW(wc, wd, cc, cd)
+#undef SP_CSW
+    const uint32_t total = wa + wb + wc + wd;
+    const bool go = et ? wa > 0 : (total > w5[4] && wa > 0);
+    if (!go) return 0;
+    uint32_t need = 12u * (uint32_t)min_count; if (wa < need) need = wa;
+    int n = 1; packed = ca;
+    const double floor_w = min_af * (double)total;
+    if (wb > 0 && wb >= need && (double)wb >= floor_w) { packed |= cb << (2 * n); ++n; }
+    if (wc > 0 && wc >= need && (double)wc >= floor_w) { packed |= cc << (2 * n); ++n; }
+    if (wd > 0 && wd >= need && (double)wd >= floor_w) { packed |= cd << (2 * n); ++n; }
+    return n;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // the control step: one workgroup per problem sums the vote words of the problem's workgroups, takes the result of the last step
 // into the node table and plays the search forward until the best node needs the next launch
@@ -1329,7 +1350,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     __shared__ CNode nh[NQ];
     __shared__ CWork wks[NWORK];                          // the orders of the last step on the way in, those of the next step on the way out; wks[0] is the search's own
     __shared__ CSearch ss;
-    __shared__ int copy_from[NWORK], copy_len[NWORK], need_la[NWORK];
+    __shared__ int copy_from[NWORK], copy_len[NWORK], need_la[NWORK], replay_of[NWORK];
     const int pi = blockIdx.x;
     const ConsParams P = B.p[pi];
     const int tid = threadIdx.x;
@@ -1348,7 +1369,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     const int proc_words = (P.cap + 2 + 3) / 4;
     for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)proc)[x] = ((const uint32_t*)P.processed)[x];
     for (int x = tid; x < QE; x += blockDim.x) acc[x] = 0;
-    if (tid < NWORK) { copy_from[tid] = -1; copy_len[tid] = 0; need_la[tid] = -1; if (tid >= n_orders) wks[tid].mode = M_NONE; }
+    if (tid < NWORK) { copy_from[tid] = -1; copy_len[tid] = 0; need_la[tid] = -1; replay_of[tid] = -1; if (tid >= n_orders) wks[tid].mode = M_NONE; }
     __syncthreads();
     if (wk.done) return;
     // second round: the tapes of the nodes that have one and the vote words of the step
@@ -1609,96 +1630,102 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         // that column.  w > 0: a side order, made AHEAD of the node's turn for a node that waits -- nothing the search can observe changes: the node keeps its place, cost
         // and id; its window comes back as a tape it consumes when its turn comes, the children of its expansion wait unseen until then.
         // -> 0: no launch for this node (it completed, or -- side orders -- it is left for its turn), 1: the order was written
-        int replay_of_w[NWORK];
-#pragma unroll
-        for (int w = 0; w < NWORK; ++w) replay_of_w[w] = -1;
-        auto decide = [&](const int xi, const int w, unsigned long long& free_nodes, int& hidden) -> int {
+        // The decision of a node that stands at the end of its tape, in two parts: what it will be (plan_of: reads the node, changes nothing) and the work order that carries it
+        // out (act).  The search's own order (w = 0) is planned and written by lane 0 for the node that has just been taken out at that column.  Side orders (w > 0) are made
+        // AHEAD of a waiting node's turn -- every lane plans the node of its number, the chosen ones write their orders side by side -- and change nothing the search can observe:
+        // the node keeps its place, cost and id; its window comes back as a tape it consumes when its turn comes, the children of its expansion wait unseen until then.
+        struct Plan { int kind, nk, nc0, nc1, cut, L; uint32_t cd0, cd1; bool ends; };   // kind 0: no candidates at all (complete), 1: goes on alone, 2: branches
+        auto cands_p = [&](const uint32_t* w5, int col, uint32_t& packed) { return col_candidates_packed(w5, col, P.cap, P.et, P.min_count, P.min_af, packed); };
+        auto plan_of = [&](const CNode& x) -> Plan {
+            Plan p;
+            const bool has = x.q > 0 || x.n > 0, stood = !has || (x.a == x.n && x.have_out);
+            p.cut = stood ? -1 : x.a;                                             // >= 0: the node stands behind that many verified bases of a window that was cut
+            p.L = (has && stood ? x.T + x.n : x.T) + (p.cut > 0 ? p.cut : 0);     // the column of the decision (a window that stood: the other slot holds the state there)
+            p.nc0 = p.nc1 = 0; p.cd0 = p.cd1 = 0; p.ends = false;
+            if (!x.stopped[0]) { p.nc0 = cands_p(x.ev[0], p.L, p.cd0); p.ends = p.ends || p.nc0 == 0; }
+            if (x.dual && !x.stopped[1]) { p.nc1 = cands_p(x.ev[1], p.L, p.cd1); p.ends = p.ends || p.nc1 == 0; }
+            if (!x.dual) p.nk = p.nc0 + (P.allow_dual ? p.nc0 * (p.nc0 - 1) / 2 : 0);
+            else p.nk = (p.nc0 || p.nc1) ? (p.nc0 ? p.nc0 : 1) * (p.nc1 ? p.nc1 : 1) : 0;
+            p.kind = p.nk == 0 ? 0 : p.nk == 1 ? 1 : 2;
+            return p;
+        };
+        // -> 0: no launch for this node (it completed), 1: the order was written.  free_bits: the free node slots the children of an expansion are taken from, lowest first
+        auto act = [&](const int xi, const int w, const Plan& pl, unsigned long long& free_bits) -> int {
             CNode& x = nh[xi];
             CWork& W = wks[w];
             const bool side = w > 0;
-            int cut = -1;                                                            // >= 0: the node stands behind that many verified bases of a window that was cut
+            const int cut = pl.cut;
             // its state at that column has to be there
-            if (x.q > 0 || x.n > 0) {
-                if (x.a == x.n && x.have_out) {                                    // the window stood: the other slot is the state
-                    if (x.n > 1) x.wcap = SP_K8_RAMP * x.wcap < CW ? SP_K8_RAMP * x.wcap : CW;
-                    x.T += x.n; x.cur ^= 1; x.cost0 = x.cost_at(x.n); x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
-                } else cut = x.a;                                                  // cut window: the state at the end of the verified bases is not there
+            if ((x.q > 0 || x.n > 0) && cut < 0) {                                 // the window stood: the other slot is the state
+                const int xn = x.n;
+                if (xn > 1) x.wcap = SP_K8_RAMP * x.wcap < CW ? SP_K8_RAMP * x.wcap : CW;
+                const long long c_end = x.cost_at(xn);
+                x.T += xn; x.cur ^= 1; x.cost0 = c_end; x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
             }
             // (which consensuses grew in that window: as they stand BEFORE this column's decision, which may end one)
-            const int pre_go[2] = { !x.stopped[0] ? 1 : 0, (x.dual && !x.stopped[1]) ? 1 : 0 };
+            const int dual = x.dual, cur = x.cur, split_at = x.split_at, xT = x.T;
+            const int pre_go0 = !x.stopped[0] ? 1 : 0, pre_go1 = (dual && !x.stopped[1]) ? 1 : 0;
             auto order_replay = [&]() {
                 // push the verified bases again from the kept state (nothing is speculated)
-                W.mode = M_WINDOW; W.node = xi; W.in_slot = x.cur; W.T = x.T; W.n = x.a; W.replay = 1;
-                W.dual = x.dual; W.split_at = x.split_at;
-                for (int i = 0; i < 2; ++i) W.go[i] = pre_go[i];
-                replay_of_w[w] = xi;                                            // (the bases are copied below, a lane each)
+                W.mode = M_WINDOW; W.node = xi; W.in_slot = cur; W.T = xT; W.n = x.a; W.replay = 1;
+                W.dual = dual; W.split_at = split_at; W.go[0] = pre_go0; W.go[1] = pre_go1;
+                replay_of[w] = xi;                                              // (the bases are copied below, a lane each)
                 ss.inflight = xi;
             };
             // (a cut window: the votes of the column behind the verified bases are there -- x.ev -- and say whether the node branches; if it does, the expansion
             //  launch pushes the verified bases itself in front of the children's: the replay launch is only made where the node goes on alone)
 #ifdef SP_K8_NO_PRE
-            if (!side && cut >= 0 && (SP_K8_NO_PRE == 0 || (SP_K8_NO_PRE == 1 && x.dual) || (SP_K8_NO_PRE == 2 && !x.dual))) { order_replay(); return 1; }
+            if (!side && cut >= 0 && (SP_K8_NO_PRE == 0 || (SP_K8_NO_PRE == 1 && dual) || (SP_K8_NO_PRE == 2 && !dual))) { order_replay(); return 1; }
 #endif
-            const int L = x.T + (cut > 0 ? cut : 0);
-            // candidates of every consensus that is still going
-            int nc[2] = { 0, 0 }, cd[2][4];
-            for (int i = 0; i < (x.dual ? 2 : 1); ++i) {
-                if (x.stopped[i]) continue;
-                nc[i] = cands(x.ev[i], L, cd[i]);
-                if (nc[i] == 0 && !side) { x.stopped[i] = 1; x.len[i] = L; }
+            const int L = pl.L;
+            if (!side) {                                                          // a consensus without candidates ends here
+                if (!x.stopped[0] && pl.nc0 == 0) { x.stopped[0] = 1; x.len[0] = L; }
+                if (dual && !x.stopped[1] && pl.nc1 == 0) { x.stopped[1] = 1; x.len[1] = L; }
             }
-            if (nc[0] == 0 && nc[1] == 0) {
-                if (side) return 0;                                               // (complete: nothing to launch; its turn sees to it)
+            if (pl.nk == 0) {
                 if (cut >= 0) { order_replay(); return 1; }                       // (its final cost needs the state: the replay brings it)
                 const long long fc = x.cost0 + (P.et ? 0 : x.rest);               // complete
                 if (ss.best_node < 0 || fc < ss.best_final) { if (ss.best_node >= 0) node_free(ss.best_node); ss.best_node = xi; ss.best_final = fc; x.complete = 1; }
                 else node_free(xi);
                 return 0;
             }
-            if (side) for (int i = 0; i < (x.dual ? 2 : 1); ++i) if (!x.stopped[i] && nc[i] == 0) return 0;   // a consensus of the node ends at this column: left for its turn (the node's lengths change there)
-            // children, in the oracle's order
-            int kb[MAXKIDS][2], ks[MAXKIDS], nk = 0;
-            if (!x.dual) {
-                for (int a2 = 0; a2 < nc[0]; ++a2) { kb[nk][0] = cd[0][a2]; kb[nk][1] = -1; ks[nk] = 0; ++nk; }
-                if (P.allow_dual) for (int a2 = 0; a2 < nc[0]; ++a2) for (int b2 = a2 + 1; b2 < nc[0]; ++b2) { kb[nk][0] = cd[0][a2]; kb[nk][1] = cd[0][b2]; ks[nk] = 1; ++nk; }
-            } else {
-                const int n0 = nc[0] ? nc[0] : 1, n1 = nc[1] ? nc[1] : 1;
-                for (int a2 = 0; a2 < n0; ++a2) for (int b2 = 0; b2 < n1; ++b2) { kb[nk][0] = nc[0] ? cd[0][a2] : -1; kb[nk][1] = nc[1] ? cd[1][b2] : -1; ks[nk] = 0; ++nk; }
-            }
-            if (nk == 1 && cut >= 0) { if (side) return 0; order_replay(); return 1; }
-            if (nk == 1) {
+            // child k in the oracle's order: a single node's candidates, then (a second consensus allowed) its pairs; a dual node's combinations
+            const int nc0 = pl.nc0, nc1 = pl.nc1, n1 = nc1 ? nc1 : 1;
+            auto code = [](uint32_t packed, int j) { return (int)((packed >> (2 * j)) & 3u); };
+            if (pl.nk == 1 && cut >= 0) { order_replay(); return 1; }
+            if (pl.nk == 1) {
                 // one child: the node itself goes on, through a window whose first base is this decision
-                W.mode = M_WINDOW; W.node = xi; W.in_slot = x.cur; W.T = L; W.replay = 0; W.dual = x.dual; W.split_at = x.split_at;
-                for (int i = 0; i < 2; ++i) { W.go[i] = kb[0][i] >= 0; W.spec[i][0] = (uint8_t)(kb[0][i] >= 0 ? kb[0][i] : 0); }
+                const int b0 = nc0 ? code(pl.cd0, 0) : -1, b1 = (dual && nc1) ? code(pl.cd1, 0) : -1;
+                W.mode = M_WINDOW; W.node = xi; W.in_slot = cur; W.T = L; W.replay = 0; W.dual = dual; W.split_at = split_at;
+                W.go[0] = b0 >= 0; W.spec[0][0] = (uint8_t)(b0 >= 0 ? b0 : 0); W.go[1] = b1 >= 0; W.spec[1][0] = (uint8_t)(b1 >= 0 ? b1 : 0);
                 need_la[w] = x.la_valid ? xi : -1;
                 W.n = 1;
                 x.n = 0; x.a = 0; x.q = 0;
                 if (!side) ss.inflight = xi;                                     // the pop is under way: when the window is back the node consumes its first column
-                else ss.side_windows += 1;
                 return 1;
             }
             // several children: one push each into fresh nodes
-            if (side) {
-                // the node table keeps room for the queue, the complete node and the children of the search's own next expansion whatever is made ahead
-                const int room = NQ - (ss.max_queue + 1) - MAXKIDS;
-                if (nk > MAXKIDS || hidden + nk > room || __builtin_popcountll(free_nodes) < nk + MAXKIDS) return 0;
-            }
-            W.mode = M_EXPAND; W.node = xi; W.in_slot = x.cur; W.T = x.T; W.n = cut > 0 ? cut : 0; W.dual = x.dual; W.split_at = x.split_at; W.replay = 0;
-            W.go[0] = nc[0] > 0; W.go[1] = nc[1] > 0; W.pre_go[0] = pre_go[0]; W.pre_go[1] = pre_go[1];
-            if (cut > 0) replay_of_w[w] = xi;                                   // (the verified bases go into the work order below, a lane each)
-            int made = 0;
-            for (int k = 0; k < nk && made < MAXKIDS; ++k) {
-                if (!free_nodes) break;                                         // (the table holds the queue plus one expansion: not reached)
-                const int kn = __builtin_ctzll(free_nodes); free_nodes &= free_nodes - 1;
+            W.mode = M_EXPAND; W.node = xi; W.in_slot = cur; W.T = xT; W.n = cut > 0 ? cut : 0; W.dual = dual; W.split_at = split_at; W.replay = 0;
+            W.go[0] = nc0 > 0; W.go[1] = nc1 > 0; W.pre_go[0] = pre_go0; W.pre_go[1] = pre_go1;
+            if (cut > 0) replay_of[w] = xi;                                     // (the verified bases go into the work order below, a lane each)
+            int made = 0, pa = 0, pb = 1;                                       // (pa, pb): the next pair of a single node's candidates
+            for (int k = 0; k < pl.nk && made < MAXKIDS; ++k) {
+                if (!free_bits) break;                                          // (the table holds the queue plus one expansion: not reached)
+                int b0, b1, sp = 0;
+                if (!dual) {
+                    if (k < nc0) { b0 = code(pl.cd0, k); b1 = -1; }
+                    else { b0 = code(pl.cd0, pa); b1 = code(pl.cd0, pb); sp = 1; if (++pb >= nc0) { ++pa; pb = pa + 1; } }
+                } else { const int a2 = k / n1, b2 = k - a2 * n1; b0 = nc0 ? code(pl.cd0, a2) : -1; b1 = nc1 ? code(pl.cd1, b2) : -1; }
+                const int kn = __builtin_ctzll(free_bits); free_bits &= free_bits - 1;
                 nh[kn].used = side ? 2 : 1; nh[kn].complete = 0; nh[kn].pex_n = 0;
-                W.kid_node[made] = kn; W.kid_base[made][0] = (int8_t)kb[k][0]; W.kid_base[made][1] = (int8_t)kb[k][1]; W.kid_split[made] = (int8_t)ks[k];
+                W.kid_node[made] = kn; W.kid_base[made][0] = (int8_t)b0; W.kid_base[made][1] = (int8_t)b1; W.kid_split[made] = (int8_t)sp;
                 ++made;
             }
             W.n_kids = made;
             copy_from[w] = xi; copy_len[w] = L;
-            if (side) { hidden += made; ss.side_expansions += 1; }
             return 1;
         };
+        unsigned long long main_kids = 0;                                       // the node slots the search's own order gave to the children of its expansion
         for (int guard = 0; ; ++guard) {
             if (guard > 100000) { if (lane == 0) wk.done = 1; break; }
 #ifdef SP_K8_SEARCH_TICKS
@@ -1793,10 +1820,12 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                     continue;
                 }
             }
-            unsigned long long free_nodes = __ballot(lane < NQ && !nh[lane].used);
-            int hidden = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 2));
-            if (lane == 0) stop = decide(xi, 0, free_nodes, hidden);
+            const unsigned long long free_before = __ballot(lane < NQ && !nh[lane].used);
+            unsigned long long free_nodes = free_before;
+            if (lane == 0) { const Plan pl = plan_of(nh[xi]); stop = act(xi, 0, pl, free_nodes); }
             stop = __builtin_amdgcn_readfirstlane(stop);
+            free_nodes = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(free_nodes >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)free_nodes);
+            main_kids = free_before & ~free_nodes;
             spw::wave_lds_sync();
 #ifdef SP_K8_SEARCH_TICKS
             ts_block += wall_clock64() - ts1;
@@ -1805,58 +1834,60 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         }
         spw::wave_lds_sync();
         // ---------------------------------------------------------------- 3. side orders: what the nodes that wait beside the search's own order will need at their turn
-        if (nside > 0 && !wk.done && wk.mode != M_NONE) {
-            if (lane == 0) ss.steps += 1;
-            // lane k looks at node k: does it stand at the end of its tape with its state at hand, would it be taken out at all, and what would its decision be
-            int kind = 0;                                                                // 1: it goes on alone (a window), 2: it branches (an expansion)
+        if (lane == 0 && !wk.done && wk.mode != M_NONE) ss.steps += 1;
+        if (nside > 0 && !wk.done && wk.mode != M_NONE && __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 1 && !nh[lane].complete)) > 1) {
+            // lane k plans node k: does it stand at the end of its tape, would it be taken out at all, and what would its decision be
+            Plan pl; pl.kind = 0; pl.nk = 0;
+            bool cand = false;
             long long kc = 0x7FFFFFFFFFFFFFFFll; int kt = -1, kid = 0x7FFFFFFF;
-            if (lane < NQ && nh[lane].used == 1 && !nh[lane].complete && lane != wk.node && nh[lane].q >= nh[lane].a && nh[lane].pex_n == 0) {
+            if (lane < NQ && nh[lane].used == 1 && !nh[lane].complete && lane != wk.node && !((main_kids >> lane) & 1ull) && nh[lane].q >= nh[lane].a && nh[lane].pex_n == 0) {
                 const CNode& x = nh[lane];
-                bool mine = true;
-                if (wk.mode == M_EXPAND) for (int k = 0; k < wk.n_kids; ++k) if (wk.kid_node[k] == lane) mine = false;   // (children of the order just written: their slots are filled when it comes back)
                 const int Lq = x.T + x.q;
-                if (mine && Lq >= ss.threshold && Lq < P.cap + 2 && proc[Lq] < ss.per_size) {
-                    const bool stood = x.n == 0 || (x.a == x.n && x.have_out);
-                    const int L = x.T + x.a;
-                    int nc0 = 0, nc1 = 0, tmp[4];
-                    bool ends = false;                                                   // a consensus of the node ends at this column: left for its turn
-                    if (!x.stopped[0]) { nc0 = cands(x.ev[0], L, tmp); ends = ends || nc0 == 0; }
-                    if (x.dual && !x.stopped[1]) { nc1 = cands(x.ev[1], L, tmp); ends = ends || nc1 == 0; }
-                    int nk = 0;
-                    if (!x.dual) nk = nc0 + (P.allow_dual ? nc0 * (nc0 - 1) / 2 : 0);
-                    else if (nc0 || nc1) nk = (nc0 ? nc0 : 1) * (nc1 ? nc1 : 1);
-                    if (!ends && nk == 1 && stood) kind = 1;
-                    else if (!ends && nk > 1 && nk <= MAXKIDS) kind = 2;
-                    if (kind) { kc = x.cost_at(x.q); kt = Lq; kid = x.id; }
+                if (Lq >= ss.threshold && Lq < P.cap + 2 && proc[Lq] < ss.per_size) {
+                    pl = plan_of(x);
+                    // a window needs the state at that column (a cut window is replayed at the node's turn); a column that ends a consensus is left for the node's turn as well
+                    cand = !pl.ends && ((pl.kind == 1 && pl.cut < 0) || (pl.kind == 2 && pl.nk <= MAXKIDS));
+                    if (cand) { kc = x.cost_at(x.q); kt = Lq; kid = x.id; }
                 }
             }
-            unsigned long long free_nodes = __ballot(lane < NQ && !nh[lane].used);
-            int hidden = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 2));
-            auto less = [](long long c1, int t1, int i1, long long c2, int t2, int i2) { return c1 < c2 || (c1 == c2 && (t1 > t2 || (t1 == t2 && i1 < i2))); };
-            int w = 1;
-            for (int tries = 0; w <= nside && tries < 8; ++tries) {
-                // the next node in the search's own order among those that are left
-                long long bc = kc; int bt = kt, bid = kid, bx = kind ? lane : -1;
-                if (!__ballot(kind != 0)) break;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const long long oc = __shfl_xor(bc, o); const int ot = __shfl_xor(bt, o), oi = __shfl_xor(bid, o), ox = __shfl_xor(bx, o);
-                    if (ox >= 0 && (bx < 0 || less(oc, ot, oi, bc, bt, bid))) { bc = oc; bt = ot; bid = oi; bx = ox; }
+            const unsigned long long cm = __ballot(cand);
+            if (cm) {
+                // the candidates in the search's own order: the rank of a lane = how many of the others go before it (they are few: a scalar pass over them, no reductions)
+                auto less = [](long long c1, int t1, int i1, long long c2, int t2, int i2) { return c1 < c2 || (c1 == c2 && (t1 > t2 || (t1 == t2 && i1 < i2))); };
+                int my_rank = 0;
+                for (unsigned long long m = cm; m; m &= m - 1) {
+                    const int b = __builtin_ctzll(m);
+                    const long long oc = ((long long)__builtin_amdgcn_readlane((int)(kc >> 32), b) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)kc, b);
+                    const int ot = __builtin_amdgcn_readlane(kt, b), oi = __builtin_amdgcn_readlane(kid, b);
+                    if (b != lane && less(oc, ot, oi, kc, kt, kid)) ++my_rank;
                 }
-                if (bx < 0) break;
-                int made = 0;
-                if (lane == 0) made = decide(bx, w, free_nodes, hidden);
-                made = __builtin_amdgcn_readfirstlane(made);
-                free_nodes = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(free_nodes >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)free_nodes);
-                hidden = __builtin_amdgcn_readfirstlane(hidden);
-                spw::wave_lds_sync();
-                if (lane == bx) kind = 0;
-                if (made) ++w;
+                const unsigned long long free_nodes = __ballot(lane < NQ && !nh[lane].used);
+                const int hidden = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 2)), n_free = __builtin_popcountll(free_nodes);
+                // the node table keeps room for the queue, the complete node and the children of the search's own next expansion whatever is made ahead
+                const int room = NQ - (ss.max_queue + 1) - MAXKIDS;
+                const int n_cand = __builtin_popcountll(cm);
+                int my_w = 0, my_skip = 0, accepted = 0, taken = 0, n_sw = 0, n_se = 0;
+                for (int r = 0; r < n_cand && accepted < nside; ++r) {
+                    const unsigned long long who = __ballot(cand && my_rank == r);
+                    if (!who) continue;
+                    const int b = __builtin_ctzll(who);
+                    const int bkind = __builtin_amdgcn_readlane(pl.kind, b), bnk = __builtin_amdgcn_readlane(pl.nk, b);
+                    if (bkind == 2 && (hidden + taken + bnk > room || n_free - taken < bnk + MAXKIDS)) continue;
+                    if (lane == b) { my_w = 1 + accepted; my_skip = taken; }
+                    ++accepted;
+                    if (bkind == 2) { taken += bnk; ++n_se; } else ++n_sw;
+                }
+                if (lane == 0) { ss.side_windows += n_sw; ss.side_expansions += n_se; }
+                if (my_w > 0) {                                                      // the chosen lanes write their orders side by side
+                    unsigned long long mine = free_nodes;
+                    for (int j = 0; j < my_skip; ++j) mine &= mine - 1;              // (the slots the orders in front of this one take)
+                    (void)act(lane, my_w, pl, mine);
+                }
             }
-        } else if (lane == 0 && !wk.done && wk.mode != M_NONE) ss.steps += 1;
+        }
         spw::wave_lds_sync();
         for (int w = 0; w < n_orders; ++w) {
-            const int ro = replay_of_w[w] = __builtin_amdgcn_readfirstlane(replay_of_w[w]);
+            const int ro = replay_of[w];
             if (ro >= 0) {
                 const CNode& x = nh[ro];
                 for (int jq = lane; jq < x.a; jq += SP_WAVE) { wks[w].spec[0][jq] = x.spec[0][jq]; wks[w].spec[1][jq] = x.spec[1][jq]; }
