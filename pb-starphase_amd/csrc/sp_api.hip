@@ -56,6 +56,7 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
     if (by_library) set_here = true;
     ctx->hw_queues = hw_queues; ctx->hw_queues_by_library = set_here;
     ctx->hw_queues_effective = effective.load();
+    { const char* kc = std::getenv("SP_K8_COMPOUND"); if (kc && *kc) ctx->k8_compound = std::atoi(kc); }
     { const char* ks = std::getenv("SP_K8_SIDE_ORDERS"); if (ks && *ks) ctx->k8_side_orders = std::max(0, std::min(3, std::atoi(ks))); }
     { const char* kp = std::getenv("SP_K8_PERSISTENT"); if (kp && *kp) ctx->k8_persistent = std::atoi(kp); }      // (several processes on one device cannot see each other's persistent batches: they switch the mode off)
     if (effective.load() == 0)
@@ -113,7 +114,7 @@ void sp_ctx_destroy(sp_ctx* ctx) {
 sp_ctx* sp_ctx_helper(sp_ctx* ctx, int i) {
     if (i < 0 || i > 6) return nullptr;
     if (!ctx->helper[i] && sp_ctx_create(ctx->device, nullptr, &ctx->helper[i]) != SP_OK) ctx->helper[i] = nullptr;
-    if (ctx->helper[i]) { ctx->helper[i]->profiling = ctx->profiling; ctx->helper[i]->k5_block_pairs = ctx->k5_block_pairs; ctx->helper[i]->k8_persistent = ctx->k8_persistent; ctx->helper[i]->k8_side_orders = ctx->k8_side_orders; ctx->helper[i]->k8_side_max_blocks = ctx->k8_side_max_blocks; ctx->helper[i]->mm2_rescore = ctx->mm2_rescore; ctx->helper[i]->k1_best_n = ctx->k1_best_n; }
+    if (ctx->helper[i]) { ctx->helper[i]->profiling = ctx->profiling; ctx->helper[i]->k5_block_pairs = ctx->k5_block_pairs; ctx->helper[i]->k8_persistent = ctx->k8_persistent; ctx->helper[i]->k8_side_orders = ctx->k8_side_orders; ctx->helper[i]->k8_compound = ctx->k8_compound; ctx->helper[i]->k8_side_max_blocks = ctx->k8_side_max_blocks; ctx->helper[i]->mm2_rescore = ctx->mm2_rescore; ctx->helper[i]->k1_best_n = ctx->k1_best_n; }
     return ctx->helper[i];
 }
 void sp_profile_merge(sp_ctx* into, sp_ctx* from) {
@@ -185,6 +186,7 @@ int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (std::strcmp(name, "k1_best_n") == 0) { if (value < 0 || value > 8) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k1_best_n is 0..8"); ctx->k1_best_n = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k1_best_n = ctx->k1_best_n; return SP_OK; }
     if (std::strcmp(name, "mm2_rescore") == 0) { ctx->mm2_rescore = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->mm2_rescore = ctx->mm2_rescore; return SP_OK; }
     if (std::strcmp(name, "k8_side_orders") == 0) { if (value < 0 || value > 3) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k8_side_orders is 0 .. 3"); ctx->k8_side_orders = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k8_side_orders = ctx->k8_side_orders; return SP_OK; }
+    if (std::strcmp(name, "k8_compound") == 0) { ctx->k8_compound = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k8_compound = ctx->k8_compound; return SP_OK; }
     if (std::strcmp(name, "k8_side_max_blocks") == 0) { if (value < 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k8_side_max_blocks >= 0"); ctx->k8_side_max_blocks = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k8_side_max_blocks = ctx->k8_side_max_blocks; return SP_OK; }
     if (std::strcmp(name, "k8_persistent") == 0) { if (value < 0 || value > 2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k8_persistent is 0 (never), 1 (whenever a batch fits) or 2 (the library decides)"); ctx->k8_persistent = (int)value; ctx->k8_persist_backoff = 0; for (sp_ctx* h : ctx->helper) if (h) h->k8_persistent = ctx->k8_persistent; return SP_OK; }
     if (std::strcmp(name, "cons_retry_ladder") == 0) { ctx->cons_retry_ladder = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->cons_retry_ladder = ctx->cons_retry_ladder; return SP_OK; }

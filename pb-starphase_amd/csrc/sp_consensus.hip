@@ -114,6 +114,7 @@ struct CSearch {
     long long ticks[4];         // control kernel, 100 MHz wall clock: load + vote reduction / result of the step / search / tail
     long long step_ticks, gap_ticks, last_end;   // profiling contexts: the step kernel from its first workgroup's start to its last one's end, summed over the steps; what lies
                                                  // between the kernels of the chain (control end -> step start, step end -> control start); the wall clock at the last control end
+    int32_t compound, compound_ok, pad_c[2];     // windows ordered with the children of the branch they were foreseen to end in; those whose children were taken
     int32_t steps, side_windows, side_expansions, adopted;   // control steps that ordered a launch; side orders made; expansions adopted from a side order (no launch of their own)
 #ifdef SP_K8_PF_PROBE
     int32_t pf_win, pf_replay, pf_exp, pf_pad;   // probe build: orders whose node stood idle at the end of its tape when the order before was made (a launch that one could have carried)
@@ -164,10 +165,11 @@ template <int MAXP> struct ConsBatchT {
     uint32_t step_cap;          // persistent mode: a search that has not ended after this many steps ends the batch (the launch-pair loop's own bound)
     int total;
     int nside;                  // side orders per problem and step (0 .. NWORK - 1): the step kernel's grid has 1 + nside rows
+    int k8_compound;            // windows may be ordered with the children of the branch the lookahead votes foresee at their end
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; uint32_t step_cap; const int* cluster_prob; int total; int nside;
+    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; uint32_t step_cap; const int* cluster_prob; int total; int nside; int k8_compound;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first, cmp_len, pad_; };
 
@@ -626,7 +628,7 @@ constexpr int KID_CALM = SP_K8_KID_CALM;                                   // up
 struct UsedWords {
     int used, has_la, a_end, b_end, total;
     __device__ __forceinline__ UsedWords(int mode, int n, int n_kids) {
-        used = mode == M_EXPAND ? n_kids : (mode == M_WINDOW ? n + 1 : 1);
+        used = mode == M_EXPAND ? n_kids : (mode == M_WINDOW ? n + 1 + n_kids : 1);      // (a window that branches at its end: the children's words lie behind its columns')
         has_la = mode != M_EXPAND || n_kids <= KID_LA_KIDS;
         a_end = 2 * used * 5; b_end = a_end + (has_la ? QSL : 0); total = b_end + 2 * used;
     }
@@ -725,7 +727,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const 
     const int node = Wp->node, in_slot = Wp->in_slot;
     const int dual_in = Wp->dual, split_at = Wp->split_at;
     const int go0 = Wp->go[0], go1 = Wp->go[1];
-    const int n_kids = mode == M_EXPAND ? Wp->n_kids : 0;
+    const int n_kids = (mode == M_EXPAND || mode == M_WINDOW) ? Wp->n_kids : 0;      // (window mode: the children of the expansion the window ends in, DESIGN.md section 9 "a window that branches")
     const uint8_t* Cn = P.C + (size_t)node * 2 * P.cs;
     for (int x = threadIdx.x; x < 2 * (CW + 1); x += blockDim.x) { (&lv[0][0])[x] = 0; (&le[0][0])[x] = 0; }
     for (int x = threadIdx.x; x < 2 * CW; x += blockDim.x) (&ll[0][0])[x] = 0;
@@ -1091,6 +1093,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (quiet) continue;
+            if (mode == M_WINDOW && n_kids > 0) continue;                        // (the lookahead words belong to the children of the expansion behind the window)
             if (i == 1 && !dualrun) continue;
             if (mode != M_INIT && !(i ? go1 : go0)) continue;
             const Dwfa& a = i ? d1 : d0; const Dwfa& o = i ? d0 : d1;
@@ -1151,11 +1154,8 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const 
         }
 #endif
         };
-        if (mode == M_EXPAND) {
-            // behind a cut window: first the verified bases in front of the branch (no votes: they are on the parent's tape), then ...
-            if (pre > 0) { use_pk = true; win_pass(d0, d1, dual_in != 0, Wp->pre_go[0], Wp->pre_go[1], pre, true); use_pk = false; }
-            const int TB = T + pre;                                          // the column that branches
-            // ... one push per child, every child from the parent's state
+        // one push per child, every child from the parent's state (d0, d1) at column TB; child k's words go to slot s0 + k
+        auto expand_kids = [&](const Dwfa& d0, const Dwfa& d1, const int TB, const int s0) {
             const int base_cost = read_cost(d0, d1, dual_in != 0);
             for (int k = 0; k < n_kids; ++k) {
                 Dwfa e0 = d0, e1 = d1;
@@ -1167,8 +1167,8 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const 
                 k1.ov_pos = kb1 >= 0 ? TB : -1; k1.ov_base = kb1;
                 if (ksplit) { k1.i = 0; }                                      // (its prefix is consensus 1's; only the new base differs)
                 column(e0, e1, kdual, kb0 >= 0, kb1 >= 0, kb0, kb1, TB + 1, k0, k1);
-                if (kb0 >= 0) vote(e0, e1, kdual, 0, TB + 1, k);
-                if (kdual && kb1 >= 0) vote(e1, e0, kdual, 1, TB + 1, k);
+                if (kb0 >= 0) vote(e0, e1, kdual, 0, TB + 1, s0 + k);
+                if (kdual && kb1 >= 0) vote(e1, e0, kdual, 1, TB + 1, s0 + k);
                 if (n_kids <= KID_LA_KIDS && (P.n < 256 || (r & 3) == 0)) {
                     // the child's lookahead votes (as behind a window: the bases behind every tip, at most two tips per consensus speak), KID_LA columns of them; of a
                     // large problem every fourth read speaks -- a speculated base only has to be the likely one, the exact votes of the window decide
@@ -1196,12 +1196,17 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const 
                 const int len0 = kb0 >= 0 ? TB + 1 : (go0 ? TB : coh_load(&P.nodes[node].len[0]));
                 const int len1 = kb1 >= 0 ? TB + 1 : (go1 ? TB : coh_load(&P.nodes[node].len[1]));
                 const int extra = final_extra(e0, e1, kdual, len0, len1);
-                if (lane == 0) { if (grow) atomicAdd(&lc[k], (uint32_t)grow); if (extra) atomicAdd(&lr[k], (uint32_t)extra); }
+                if (lane == 0) { if (grow) atomicAdd(&lc[s0 + k], (uint32_t)grow); if (extra) atomicAdd(&lr[s0 + k], (uint32_t)extra); }
                 const int kn = Wp->kid_node[k];
                 store(e0, kn, 0, 0);
                 if (kdual) store(e1, kn, 0, 1);
             }
             spw::wave_lds_sync();
+        };
+        if (mode == M_EXPAND) {
+            // behind a cut window: first the verified bases in front of the branch (no votes: they are on the parent's tape), then the children
+            if (pre > 0) { use_pk = true; win_pass(d0, d1, dual_in != 0, Wp->pre_go[0], Wp->pre_go[1], pre, true); use_pk = false; }
+            expand_kids(d0, d1, T + pre, 0);
 #ifdef SP_K8_DBG_PARTS
             if (B.dbg && lane == 0 && Wp->pad < SP_K8_DBG_LAUNCHES / 2 && g < SP_K8_DBG_READS) {
                 const unsigned long long dt = (unsigned long long)(wall_clock64() - wt0);
@@ -1213,6 +1218,14 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const 
         }
 
         win_pass(d0, d1, dual_in != 0, go0, go1, n, false);
+        // a window that branches at its end (the control step foresaw the branch from the lookahead votes): the children of that expansion in the same launch, from the state
+        // the window has just left at column T + n -- if the window stands and the exact votes of that column name these very children, no launch is needed for them
+        if (n_kids > 0) {
+            use_pk = false;
+            if (lane == 0) act[wave].staged = nullptr;                        // (the window pass may have written a worse state's edit-count profile over the staged read: a child that places the read stages it again)
+            spw::wave_lds_sync();
+            expand_kids(d0, d1, T + n, n + 1);
+        }
     }
     __syncthreads();
     const UsedWords uw(mode, n, n_kids);
@@ -1351,6 +1364,10 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     __shared__ CWork wks[NWORK];                          // the orders of the last step on the way in, those of the next step on the way out; wks[0] is the search's own
     __shared__ CSearch ss;
     __shared__ int copy_from[NWORK], copy_len[NWORK], need_la[NWORK], replay_of[NWORK];
+    // the children a window that branched at its end brought with it (take_result): their consensus rows are written at the end of the pass
+    struct KidCopy { int from, T, n, nk, dual; int8_t node[4], b0[4], b1[4], sp[4]; uint8_t spec[2][CW]; };
+    static_assert(KID_LA_KIDS <= 4, "KidCopy");
+    __shared__ KidCopy kcopy[NWORK];
     const int pi = blockIdx.x;
     const ConsParams P = B.p[pi];
     const int tid = threadIdx.x;
@@ -1369,7 +1386,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     const int proc_words = (P.cap + 2 + 3) / 4;
     for (int x = tid; x < proc_words; x += blockDim.x) ((uint32_t*)proc)[x] = ((const uint32_t*)P.processed)[x];
     for (int x = tid; x < QE; x += blockDim.x) acc[x] = 0;
-    if (tid < NWORK) { copy_from[tid] = -1; copy_len[tid] = 0; need_la[tid] = -1; replay_of[tid] = -1; if (tid >= n_orders) wks[tid].mode = M_NONE; }
+    if (tid < NWORK) { copy_from[tid] = -1; copy_len[tid] = 0; need_la[tid] = -1; replay_of[tid] = -1; kcopy[tid].nk = 0; if (tid >= n_orders) wks[tid].mode = M_NONE; }
     __syncthreads();
     if (wk.done) return;
     // second round: the tapes of the nodes that have one and the vote words of the step
@@ -1391,7 +1408,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     auto load_votes = [&](const int w) {
         const int mode_in = wks[w].mode, n_in = (mode_in == M_WINDOW || mode_in == M_EXPAND) ? wks[w].n : 0;
         if (mode_in == M_NONE) return;
-        const UsedWords uw(mode_in, n_in, mode_in == M_EXPAND ? wks[w].n_kids : 0);
+        const UsedWords uw(mode_in, n_in, wks[w].n_kids);
         if (P.n_blocks <= DIRECT_BLOCKS) {
             // the order's one block of words (the workgroups added theirs to it): read and cleared for the next step.  The exact and the lookahead
             // votes are four 16-bit fields per 64-bit word
@@ -1484,12 +1501,38 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         spw::wave_lds_sync();
         trim_queue();
     };
-    // the sums of an expansion's launch into its children's node slots (one lane per child); `mark`: 1 = the children join the search at once (adopt follows), 2 = made ahead
-    auto kids_from_sums = [&](const CWork& w, const int mark) {
-        const int L = w.T + w.n;                                            // the column that branched (w.n: the verified bases that were replayed in front of it)
-        if (lane < w.n_kids) {
+    struct Plan { int kind, nk, nc0, nc1, cut, L; uint32_t cd0, cd1; bool ends; };   // kind 0: no candidates at all (complete), 1: goes on alone, 2: branches
+    auto cands_p = [&](const uint32_t* w5, int col, uint32_t& packed) { return col_candidates_packed(w5, col, P.cap, P.et, P.min_count, P.min_af, packed); };
+    auto plan_of = [&](const CNode& x) -> Plan {
+        Plan p;
+        const bool has = x.q > 0 || x.n > 0, stood = !has || (x.a == x.n && x.have_out);
+        p.cut = stood ? -1 : x.a;                                             // >= 0: the node stands behind that many verified bases of a window that was cut
+        p.L = (has && stood ? x.T + x.n : x.T) + (p.cut > 0 ? p.cut : 0);     // the column of the decision (a window that stood: the other slot holds the state there)
+        p.nc0 = p.nc1 = 0; p.cd0 = p.cd1 = 0; p.ends = false;
+        if (!x.stopped[0]) { p.nc0 = cands_p(x.ev[0], p.L, p.cd0); p.ends = p.ends || p.nc0 == 0; }
+        if (x.dual && !x.stopped[1]) { p.nc1 = cands_p(x.ev[1], p.L, p.cd1); p.ends = p.ends || p.nc1 == 0; }
+        if (!x.dual) p.nk = p.nc0 + (P.allow_dual ? p.nc0 * (p.nc0 - 1) / 2 : 0);
+        else p.nk = (p.nc0 || p.nc1) ? (p.nc0 ? p.nc0 : 1) * (p.nc1 ? p.nc1 : 1) : 0;
+        p.kind = p.nk == 0 ? 0 : p.nk == 1 ? 1 : 2;
+        return p;
+    };
+    // child k of a decision in the oracle's order: a single node's candidates, then (a second consensus allowed) its pairs; a dual node's combinations
+    auto kid_of = [&](const Plan& pl, const int dual, const int k, int& b0, int& b1, int& sp) {
+        auto code = [](uint32_t packed, int j) { return (int)((packed >> (2 * j)) & 3u); };
+        sp = 0;
+        if (!dual) {
+            if (k < pl.nc0) { b0 = code(pl.cd0, k); b1 = -1; }
+            else { int pa = 0, pb = 1; for (int j = pl.nc0; j < k; ++j) if (++pb >= pl.nc0) { ++pa; pb = pa + 1; } b0 = code(pl.cd0, pa); b1 = code(pl.cd0, pb); sp = 1; }
+        } else { const int n1 = pl.nc1 ? pl.nc1 : 1, a2 = k / n1, b2 = k - a2 * n1; b0 = pl.nc0 ? code(pl.cd0, a2) : -1; b1 = pl.nc1 ? code(pl.cd1, b2) : -1; }
+    };
+    // the sums of an expansion's launch into its children's node slots (one lane per child); `mark`: 1 = the children join the search at once (adopt follows), 2 = made ahead.
+    // L: the column that branched; par_cost: the parent's cost there; my_j: which of the order's children this lane's child is (-1: none) -- the order of an expansion lists
+    // them in the search's own order (my_j = lane), a window that branches at its end lists the children it FORESAW and the exact votes say which of them there are, in
+    // which order; s0: where the children's words start among the launch's sums
+    auto kids_from_sums = [&](const CWork& w, const int mark, const int L, const long long par_cost, const int my_j, const int s0) {
+        if (my_j >= 0) {
             const CNode& par = nh[w.node];
-            const int k = lane;
+            const int k = my_j;
             CNode& c = nh[w.kid_node[k]];
             c.used = mark; c.complete = 0; c.id = 0; c.T = L + 1; c.cur = 0; c.pex_n = 0; c.pex_L = 0;
             c.dual = par.dual || w.kid_split[k]; c.split_at = w.kid_split[k] ? L : par.split_at;
@@ -1503,8 +1546,8 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             }
             if (!c.dual) c.stopped[1] = 1;
             c.n = c.a = c.q = 0; c.have_out = 0; c.la_valid = w.n_kids <= KID_LA_KIDS ? 1 : 0; c.wcap = WRAMP0;
-            c.cost0 = par.cost_at(par.q) + (long long)sc[k]; c.dc[0] = 0; c.rest = sr[k]; c.rest_out = 0;
-            for (int i = 0; i < 2; ++i) for (int bq = 0; bq < 5; ++bq) c.ev[i][bq] = sv[i][k][bq];
+            c.cost0 = par_cost + (long long)sc[s0 + k]; c.dc[0] = 0; c.rest = sr[s0 + k]; c.rest_out = 0;
+            for (int i = 0; i < 2; ++i) for (int bq = 0; bq < 5; ++bq) c.ev[i][bq] = sv[i][s0 + k][bq];
         }
         if (w.n_kids <= KID_LA_KIDS) {
             // the children's lookahead votes ([child][consensus][KID_LA columns] in the launch's lookahead words) into the children's rows; the columns behind them
@@ -1577,10 +1620,50 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             if (lane == 0) {
                 ss.windows += 1; if (a < n) ss.cut_windows += 1;
                 x.n = n; x.a = wo.replay ? n : a;
-                x.have_out = (a == n) ? 1 : 0;
+                x.have_out = (a == n) ? (wo.n_kids > 0 ? 2 : 1) : 0;        // 2: the state is there, lookahead votes for it are not (the launch's lookahead words were the children's)
                 if (a == n) x.rest_out = sr[n];
             }
-            if (a == n) {
+            if (wo.n_kids > 0) {
+                // the window was ordered with the children of the branch the lookahead votes foresaw behind its last base.  They are taken when the window stood and the
+                // exact votes of that column name no other children: then the node carries them as an expansion made ahead (pex) and adopts them at its turn without a launch
+                spw::wave_lds_sync();
+                bool take = a == n && B.k8_compound != 2;                        // (k8_compound 2, an experiment switch: the children are ordered and never taken)
+                int my_j = -1, nk = 0;
+                if (take) {
+                    Plan pl;                                                        // what the node's decision at column T + n will be: its votes are the sums of this launch
+                    pl.nc0 = pl.nc1 = 0; pl.cd0 = pl.cd1 = 0; bool ends = false;
+                    if (!x.stopped[0]) { pl.nc0 = cands_p(sv[0][n], T + n, pl.cd0); ends = ends || pl.nc0 == 0; }
+                    if (x.dual && !x.stopped[1]) { pl.nc1 = cands_p(sv[1][n], T + n, pl.cd1); ends = ends || pl.nc1 == 0; }
+                    if (!x.dual) nk = pl.nc0 + (P.allow_dual ? pl.nc0 * (pl.nc0 - 1) / 2 : 0);
+                    else nk = (pl.nc0 || pl.nc1) ? (pl.nc0 ? pl.nc0 : 1) * (pl.nc1 ? pl.nc1 : 1) : 0;
+                    take = !ends && nk >= 2 && nk <= wo.n_kids;
+                    if (take) {
+                        bool found = true;
+                        if (lane < nk) {                                            // lane k: child k in the search's own order, and which of the foreseen children it is
+                            int b0, b1, sp;
+                            kid_of(pl, x.dual, lane, b0, b1, sp);
+                            for (int j = 0; j < wo.n_kids; ++j) if (wo.kid_base[j][0] == b0 && wo.kid_base[j][1] == b1 && wo.kid_split[j] == sp) my_j = j;
+                            found = my_j >= 0;
+                        }
+                        take = __ballot(!found) == 0;
+                    }
+                }
+                if (take) {
+                    kids_from_sums(wo, 2, T + n, x.cost_at(n), lane < nk ? my_j : -1, n + 1);
+                    // the node carries them in the search's order; foreseen children the exact votes do not name go back to the free slots
+                    for (int k = 0; k < nk; ++k) { const int j = __builtin_amdgcn_readlane(my_j, k); if (lane == 0) x.pex_kid[k] = (int8_t)wo.kid_node[j]; }
+                    if (lane < wo.n_kids) { bool mine = false; for (int k = 0; k < nk; ++k) mine = mine || __builtin_amdgcn_readlane(my_j, k) == lane; if (!mine) { nh[wo.kid_node[lane]].used = 0; nh[wo.kid_node[lane]].complete = 0; } }
+                    if (lane == 0) {
+                        x.pex_n = nk; x.pex_L = T + n; ss.compound_ok += 1;
+                        // the children's consensus rows: the parent's bases in front of the window, the window's own (they reach the parent's row in this pass), their base
+                        KidCopy& kc = kcopy[w];
+                        kc.from = wo.node; kc.T = T; kc.n = n; kc.nk = nk; kc.dual = x.dual;
+                    }
+                    if (lane < nk) { KidCopy& kc = kcopy[w]; kc.node[lane] = (int8_t)wo.kid_node[my_j]; kc.b0[lane] = wo.kid_base[my_j][0]; kc.b1[lane] = wo.kid_base[my_j][1]; kc.sp[lane] = wo.kid_split[my_j]; }
+                    for (int col = lane; col < n; col += SP_WAVE) { kcopy[w].spec[0][col] = wo.spec[0][col]; kcopy[w].spec[1][col] = wo.spec[1][col]; }
+                } else if (lane < wo.n_kids) { nh[wo.kid_node[lane]].used = 0; nh[wo.kid_node[lane]].complete = 0; }
+                spw::wave_lds_sync();
+            } else if (a == n) {
                 if (!side) la_fresh = wo.node;
                 for (int y = lane; y < 2 * CW * 4; y += SP_WAVE) P.la[(size_t)wo.node * 2 * CW * 4 + y] = (&sl[0][0][0])[y];
                 if (side) __threadfence_block();          // (a side order's rows may be read back from memory further down in this very pass)
@@ -1589,12 +1672,13 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
 #ifdef SP_K8_TRACE
             if (lane == 0 && pi == 0) { printf("EXP%s L %d pre %d kids %d parcost %lld :", side ? " (side)" : "", wo.T + n_in, n_in, wo.n_kids, nh[wo.node].cost_at(nh[wo.node].q)); for (int k = 0; k < wo.n_kids; ++k) printf(" [%d/%d sc %u sr %u ev %u %u %u %u %u]", wo.kid_base[k][0], wo.kid_base[k][1], sc[k], sr[k], sv[0][k][0], sv[0][k][1], sv[0][k][2], sv[0][k][3], sv[0][k][4]); printf("\n"); }
 #endif
+            const long long par_cost = nh[wo.node].cost_at(nh[wo.node].q);
             if (!side) {
-                kids_from_sums(wo, 1);
+                kids_from_sums(wo, 1, wo.T + n_in, par_cost, lane < wo.n_kids ? lane : -1, 0);
                 adopt(wo.node, wo.n_kids, true, [&](int k) { return (int)wo.kid_node[k]; });
             } else {
                 // made ahead of the parent's turn: the children wait unseen (used = 2) until the search takes the parent out at that column
-                kids_from_sums(wo, 2);
+                kids_from_sums(wo, 2, wo.T + n_in, par_cost, lane < wo.n_kids ? lane : -1, 0);
                 if (lane == 0) {
                     CNode& par = nh[wo.node];
                     par.pex_n = wo.n_kids; par.pex_L = wo.T + n_in;
@@ -1604,6 +1688,31 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         }
         spw::wave_lds_sync();
     };
+    // the children a window brought with it get their consensus rows right behind the window's result, while the parent is still in the table (the search below may take it out,
+    // adopt the children and hand its slot to another node's child in this very pass): the parent's row up to the window (whole 16-byte words from memory), then byte by byte
+    // the rest of the last word, the window's own bases (kept in LDS: they reached the parent's row in this very pass) and the child's base
+    auto copy_window_kids = [&](const int w) {
+        const KidCopy& kc = kcopy[w];
+        if (kc.nk <= 0) return;
+        const int whole = kc.T >> 4, L = kc.T + kc.n;
+        for (int k = 0; k < kc.nk; ++k) {
+            const bool split = kc.sp[k] != 0;
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !(kc.dual || split)) continue;
+                const int si = (i == 1 && split) ? 0 : i;
+                const uint8_t* srow = P.C + ((size_t)kc.from * 2 + si) * P.cs;
+                uint8_t* dst = P.C + ((size_t)kc.node[k] * 2 + i) * P.cs;
+                for (int y = tid; y < whole; y += blockDim.x) reinterpret_cast<uint4*>(dst)[y] = reinterpret_cast<const uint4*>(srow)[y];
+                for (int y = (whole << 4) + tid; y <= L; y += blockDim.x) {
+                    int v;
+                    if (y < kc.T) v = srow[y];
+                    else if (y < L) v = kc.spec[kc.dual ? si : 0][y - kc.T];
+                    else v = i ? kc.b1[k] : kc.b0[k];
+                    if (v >= 0) dst[y] = (uint8_t)v;
+                }
+            }
+        }
+    };
     // side orders first, the search's own last: its sums stay in LDS for the search (la_fresh)
     for (int w = n_orders - 1; w >= 0; --w) {
         if (wks[w].mode == M_NONE) continue;
@@ -1611,6 +1720,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         __syncthreads();
         if (tid < SP_WAVE) take_result(w);
         __syncthreads();
+        copy_window_kids(w);
         if (w > 0) {                                       // clear the sums for the next order
             for (int x = tid; x < QE; x += blockDim.x) acc[x] = 0;
             __syncthreads();
@@ -1634,21 +1744,6 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
         // out (act).  The search's own order (w = 0) is planned and written by lane 0 for the node that has just been taken out at that column.  Side orders (w > 0) are made
         // AHEAD of a waiting node's turn -- every lane plans the node of its number, the chosen ones write their orders side by side -- and change nothing the search can observe:
         // the node keeps its place, cost and id; its window comes back as a tape it consumes when its turn comes, the children of its expansion wait unseen until then.
-        struct Plan { int kind, nk, nc0, nc1, cut, L; uint32_t cd0, cd1; bool ends; };   // kind 0: no candidates at all (complete), 1: goes on alone, 2: branches
-        auto cands_p = [&](const uint32_t* w5, int col, uint32_t& packed) { return col_candidates_packed(w5, col, P.cap, P.et, P.min_count, P.min_af, packed); };
-        auto plan_of = [&](const CNode& x) -> Plan {
-            Plan p;
-            const bool has = x.q > 0 || x.n > 0, stood = !has || (x.a == x.n && x.have_out);
-            p.cut = stood ? -1 : x.a;                                             // >= 0: the node stands behind that many verified bases of a window that was cut
-            p.L = (has && stood ? x.T + x.n : x.T) + (p.cut > 0 ? p.cut : 0);     // the column of the decision (a window that stood: the other slot holds the state there)
-            p.nc0 = p.nc1 = 0; p.cd0 = p.cd1 = 0; p.ends = false;
-            if (!x.stopped[0]) { p.nc0 = cands_p(x.ev[0], p.L, p.cd0); p.ends = p.ends || p.nc0 == 0; }
-            if (x.dual && !x.stopped[1]) { p.nc1 = cands_p(x.ev[1], p.L, p.cd1); p.ends = p.ends || p.nc1 == 0; }
-            if (!x.dual) p.nk = p.nc0 + (P.allow_dual ? p.nc0 * (p.nc0 - 1) / 2 : 0);
-            else p.nk = (p.nc0 || p.nc1) ? (p.nc0 ? p.nc0 : 1) * (p.nc1 ? p.nc1 : 1) : 0;
-            p.kind = p.nk == 0 ? 0 : p.nk == 1 ? 1 : 2;
-            return p;
-        };
         // -> 0: no launch for this node (it completed), 1: the order was written.  free_bits: the free node slots the children of an expansion are taken from, lowest first
         auto act = [&](const int xi, const int w, const Plan& pl, unsigned long long& free_bits) -> int {
             CNode& x = nh[xi];
@@ -1660,7 +1755,8 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                 const int xn = x.n;
                 if (xn > 1) x.wcap = SP_K8_RAMP * x.wcap < CW ? SP_K8_RAMP * x.wcap : CW;
                 const long long c_end = x.cost_at(xn);
-                x.T += xn; x.cur ^= 1; x.cost0 = c_end; x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = 1;
+                const int la_ok = x.have_out == 1 ? 1 : 0;
+                x.T += xn; x.cur ^= 1; x.cost0 = c_end; x.dc[0] = 0; x.rest = x.rest_out; x.n = x.a = x.q = 0; x.have_out = 0; x.la_valid = la_ok;
             }
             // (which consensuses grew in that window: as they stand BEFORE this column's decision, which may end one)
             const int dual = x.dual, cur = x.cur, split_at = x.split_at, xT = x.T;
@@ -1690,7 +1786,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
                 return 0;
             }
             // child k in the oracle's order: a single node's candidates, then (a second consensus allowed) its pairs; a dual node's combinations
-            const int nc0 = pl.nc0, nc1 = pl.nc1, n1 = nc1 ? nc1 : 1;
+            const int nc0 = pl.nc0, nc1 = pl.nc1;
             auto code = [](uint32_t packed, int j) { return (int)((packed >> (2 * j)) & 3u); };
             if (pl.nk == 1 && cut >= 0) { order_replay(); return 1; }
             if (pl.nk == 1) {
@@ -1708,14 +1804,11 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             W.mode = M_EXPAND; W.node = xi; W.in_slot = cur; W.T = xT; W.n = cut > 0 ? cut : 0; W.dual = dual; W.split_at = split_at; W.replay = 0;
             W.go[0] = nc0 > 0; W.go[1] = nc1 > 0; W.pre_go[0] = pre_go0; W.pre_go[1] = pre_go1;
             if (cut > 0) replay_of[w] = xi;                                     // (the verified bases go into the work order below, a lane each)
-            int made = 0, pa = 0, pb = 1;                                       // (pa, pb): the next pair of a single node's candidates
+            int made = 0;
             for (int k = 0; k < pl.nk && made < MAXKIDS; ++k) {
                 if (!free_bits) break;                                          // (the table holds the queue plus one expansion: not reached)
-                int b0, b1, sp = 0;
-                if (!dual) {
-                    if (k < nc0) { b0 = code(pl.cd0, k); b1 = -1; }
-                    else { b0 = code(pl.cd0, pa); b1 = code(pl.cd0, pb); sp = 1; if (++pb >= nc0) { ++pa; pb = pa + 1; } }
-                } else { const int a2 = k / n1, b2 = k - a2 * n1; b0 = nc0 ? code(pl.cd0, a2) : -1; b1 = nc1 ? code(pl.cd1, b2) : -1; }
+                int b0, b1, sp;
+                kid_of(pl, dual, k, b0, b1, sp);
                 const int kn = __builtin_ctzll(free_bits); free_bits &= free_bits - 1;
                 nh[kn].used = side ? 2 : 1; nh[kn].complete = 0; nh[kn].pex_n = 0;
                 W.kid_node[made] = kn; W.kid_base[made][0] = (int8_t)b0; W.kid_base[made][1] = (int8_t)b1; W.kid_split[made] = (int8_t)sp;
@@ -1914,31 +2007,81 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             CWork& W = wks[w];
             const uint32_t* la = (w == 0 && nl == la_fresh) ? &sl[0][0][0] : P.la + (size_t)nl * 2 * CW * 4;
             const int lim = nh[nl].wcap;
-            int nn = lim;
+            // A WINDOW THAT BRANCHES AT ITS END.  The lookahead votes also say where the node will probably branch: the first column at which a second base has a fair share
+            // of them.  The window is then ordered up to that column WITH the children of the foreseen expansion (the step kernel makes them from the state the window leaves
+            // there, their words behind the window's): if the window stands and the exact votes of that column name no other children, the node adopts them at its turn
+            // without a launch of its own -- the expansion launch that follows nearly every cut window of a branching search.  Needs free node slots like a side expansion.
+            const int hidden = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 2)), n_free = __builtin_popcountll(__ballot(lane < NQ && !nh[lane].used));
+            const bool may_branch = B.k8_compound && !coh && P.n_blocks <= DIRECT_BLOCKS && hidden + KID_LA_KIDS <= NQ - (ss.max_queue + 1) - MAXKIDS && n_free >= KID_LA_KIDS + MAXKIDS;
+            int nn = lim, bcol = -1, bn0 = 0, bn1 = 0; uint32_t bc0 = 0, bc1 = 0;
             for (int base = 0; base < lim; base += SP_WAVE) {
                 const int col = base + lane;
                 bool have = col >= 1 && col < lim && W.T + col < P.cap;
                 int pick[2] = { 0, 0 };
+                int n2[2] = { 0, 0 }; uint32_t pc[2] = { 0, 0 };                // the bases with a fair share of the column's lookahead votes, heaviest first
                 if (have) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (!W.go[i]) continue;
                         const uint4 wv = *reinterpret_cast<const uint4*>(la + ((size_t)i * CW + (col - 1)) * 4);
-                        int b1 = 0; uint32_t w1 = wv.x;
-                        if (wv.y > w1) { b1 = 1; w1 = wv.y; }
-                        if (wv.z > w1) { b1 = 2; w1 = wv.z; }
-                        if (wv.w > w1) { b1 = 3; w1 = wv.w; }
-                        if (w1 == 0) have = false;
-                        pick[i] = b1;
+                        uint32_t wa = wv.x, wb = wv.y, wc = wv.z, wd = wv.w, ca = 0, cb = 1, cc = 2, cd = 3;
+#define SP_CSW(x, y, cx, cy) if (y > x) { const uint32_t tw_ = x; x = y; y = tw_; const uint32_t tc_ = cx; cx = cy; cy = tc_; }
+                        SP_CSW(wa, wb, ca, cb) SP_CSW(wa, wc, ca, cc) SP_CSW(wa, wd, ca, cd) SP_CSW(wb, wc, cb, cc) SP_CSW(wb, wd, cb, cd) SP_CSW(wc, wd, cc, cd)
+#undef SP_CSW
+                        if (wa == 0) have = false;
+                        pick[i] = (int)ca;
+                        // (a foreseen branch that does not come costs a window cut short; one that comes saves a launch: only the clear cases -- a second base with SHARE
+                        //  per cent of the column's lookahead votes, k8_compound >= 10 names another share)
+                        const double share = B.k8_compound >= 10 ? 0.01 * (double)B.k8_compound : 0.25;
+                        const double fair = (share > P.min_af ? share : P.min_af) * (double)(wa + wb + wc + wd);
+                        int m = 1; uint32_t pk = ca;
+                        if (wb >= 2 && (double)wb >= fair) { pk |= cb << (2 * m); ++m; }
+                        if (wc >= 2 && (double)wc >= fair) { pk |= cc << (2 * m); ++m; }
+                        if (wd >= 2 && (double)wd >= fair) { pk |= cd << (2 * m); ++m; }
+                        n2[i] = m; pc[i] = pk;
                     }
                 }
                 unsigned long long miss = __ballot(!have);
                 if (base == 0) miss &= ~1ull;                                  // column 0 is the exact base
-                const int first = miss ? __builtin_ctzll(miss) : SP_WAVE;
+                int first = miss ? __builtin_ctzll(miss) : SP_WAVE;
+                const unsigned long long brm = may_branch ? __ballot(have && col >= 1 && col <= CW - KID_LA_KIDS - 1 && (n2[0] > 1 || n2[1] > 1)) : 0ull;
+                const int fb = brm ? __builtin_ctzll(brm) : SP_WAVE;
+                if (fb < first) {
+                    // how many children would that be?  (the node's candidates there, as plan_of counts them)
+                    const int c0 = W.go[0] ? __builtin_amdgcn_readlane(n2[0], fb) : 0, c1 = (W.dual && W.go[1]) ? __builtin_amdgcn_readlane(n2[1], fb) : 0;
+                    const int kids = !W.dual ? c0 + (P.allow_dual ? c0 * (c0 - 1) / 2 : 0) : (c0 ? c0 : 1) * (c1 ? c1 : 1);
+                    if (kids >= 2 && kids <= KID_LA_KIDS) {
+                        bcol = base + fb; bn0 = c0; bn1 = c1;
+                        bc0 = (uint32_t)__builtin_amdgcn_readlane((int)pc[0], fb); bc1 = (uint32_t)__builtin_amdgcn_readlane((int)pc[1], fb);
+                        first = fb;
+                    }
+                }
                 if (col >= 1 && lane < first) { W.spec[0][col] = (uint8_t)pick[0]; W.spec[1][col] = (uint8_t)pick[1]; }
-                if (miss) { nn = base + first; break; }
+                if (miss || bcol >= 0) { nn = base + first; break; }
             }
-            if (lane == 0) W.n = nn < lim ? nn : lim;
+            if (lane == 0) {
+                W.n = nn < lim ? nn : lim;
+            }
+            if (bcol >= 1) {
+                const unsigned long long free_mask = __ballot(lane < NQ && !nh[lane].used);
+                if (lane == 0 && W.n == bcol) {
+                    Plan fp; fp.nc0 = bn0; fp.nc1 = bn1; fp.cd0 = bc0; fp.cd1 = bc1;
+                    const int kids = !W.dual ? bn0 + (P.allow_dual ? bn0 * (bn0 - 1) / 2 : 0) : (bn0 ? bn0 : 1) * (bn1 ? bn1 : 1);
+                    unsigned long long fm = free_mask;
+                    int made = 0;
+                    for (int k = 0; k < kids && fm; ++k) {
+                        int b0, b1, sp;
+                        kid_of(fp, W.dual, k, b0, b1, sp);
+                        const int kn = __builtin_ctzll(fm); fm &= fm - 1;
+                        nh[kn].used = 2; nh[kn].complete = 0; nh[kn].pex_n = 0;
+                        W.kid_node[made] = kn; W.kid_base[made][0] = (int8_t)b0; W.kid_base[made][1] = (int8_t)b1; W.kid_split[made] = (int8_t)sp;
+                        ++made;
+                    }
+                    W.n_kids = made;
+                    ss.compound += 1;
+                }
+                spw::wave_lds_sync();
+            }
         }
     }
     __syncthreads();
@@ -2435,6 +2578,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         if (setup[p].n) hipLaunchKernelGGL(cons_setup_kernel, dim3((setup[p].n + 255) / 256), dim3(256), 0, st, setup[p], d_info);
 
     B.nside = persist_rpw ? 0 : nside;
+    B.k8_compound = ctx->k8_compound;
     const dim3 grid((uint32_t)n_blocks, (uint32_t)(1 + B.nside)), block(CWAVES * SP_WAVE);
     // (the step kernel's instantiation for batches that fit the device at one workgroup per CU, give or take a few: cons_step_wide_kernel.  A 2,000-read CYP2D6 sample's first batch
     //  has 271 workgroups -- its 2,162 region segments -- and is still faster there)
@@ -2602,6 +2746,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
         for (uint32_t p = 0; p < n_prob; ++p) {
             ctx->prof["cons_side_windows"].cells += (uint64_t)h_srch[p].side_windows; ctx->prof["cons_side_expansions"].cells += (uint64_t)h_srch[p].side_expansions;
             ctx->prof["cons_adopted"].cells += (uint64_t)h_srch[p].adopted;
+            ctx->prof["cons_compound"].cells += (uint64_t)h_srch[p].compound; ctx->prof["cons_compound_ok"].cells += (uint64_t)h_srch[p].compound_ok;
         }
 #ifdef SP_K8_PF_PROBE
         {   // the batch's chain is its slowest problem's: steps as they are / without the window orders a launch before could have carried / without any such order

@@ -101,6 +101,7 @@ struct sp_ctx {
     int hw_queues_effective = 0;         // what the HIP runtime was initialised with: GPU_MAX_HW_QUEUES as it stood when HIP came up (0: HIP was up before the library could look, and the variable was not set)
     int k8_side_orders = 3;              // sp_ctx_set_option "k8_side_orders" (or SP_K8_SIDE_ORDERS): work orders per consensus problem and step beside the search's own (0 .. 3): the window or
                                          // expansion another waiting node will need at its turn, made in the same launch.  Results do not depend on it
+    int k8_compound = 1;                 // sp_ctx_set_option "k8_compound" (or SP_K8_COMPOUND): a consensus window may be ordered with the children of the branch foreseen at its end
     int k8_side_max_blocks = 4096;       // batches with more step workgroups than this keep to the search's own order
     int k8_persist_backoff = 0;          // batches that still go the launch-pair way after the control workgroups of a persistent batch found no CUs; k8_persist_failures counts those events
     int k8_persist_failures = 0;

@@ -25,7 +25,7 @@ locus = synth.Chr22Locus(cfg, gene_def, seed=3)
 ctx = pkg.Context(0)
 ctx.set_option("k8_persistent", int(os.environ.get("K8P", "0")))
 db = pkg.ffi.CypDb(ctx, cfg, gene_def, locus.sequence, locus.start)
-names = ("cons_windows", "cons_expansions", "cons_cut_windows", "cons_side_windows", "cons_side_expansions", "cons_adopted", "cons_columns")
+names = ("cons_windows", "cons_expansions", "cons_cut_windows", "cons_side_windows", "cons_side_expansions", "cons_adopted", "cons_compound", "cons_compound_ok", "cons_columns")
 for name, haps, expected in cr.scenarios(locus):
     if only and name not in only:
         continue
