@@ -99,8 +99,9 @@ struct sp_ctx {
                                          // 0 never, 1 whenever a batch fits, 2 (default) the library decides: a single sample's batches (<= 8 problems) when the process's streams
                                          // have hardware queues of their own (hw_queues_effective >= 16) and the mode has not just failed on this context
     int hw_queues_effective = 0;         // what the HIP runtime was initialised with: GPU_MAX_HW_QUEUES as it stood when HIP came up (0: HIP was up before the library could look, and the variable was not set)
-    int k8_side_orders = 3;              // sp_ctx_set_option "k8_side_orders" (or SP_K8_SIDE_ORDERS): work orders per consensus problem and step beside the search's own (0 .. 3): the window or
-                                         // expansion another waiting node will need at its turn, made in the same launch.  Results do not depend on it
+    int k8_side_orders = 1;              // sp_ctx_set_option "k8_side_orders" (or SP_K8_SIDE_ORDERS): work orders per consensus problem and step beside the search's own (0 .. 3): the window or
+                                         // expansion another waiting node will need at its turn, made in the same launch.  Results do not depend on it.  One:
+                                         // a second and third row of workgroups save 5 % more launches and cost every launch more than that (profiles/r06/k8_side_orders.txt)
     int k8_compound = 1;                 // sp_ctx_set_option "k8_compound" (or SP_K8_COMPOUND): a consensus window may be ordered with the children of the branch foreseen at its end
     int k8_side_max_blocks = 4096;       // batches with more step workgroups than this keep to the search's own order
     int k8_persist_backoff = 0;          // batches that still go the launch-pair way after the control workgroups of a persistent batch found no CUs; k8_persist_failures counts those events

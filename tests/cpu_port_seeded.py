@@ -60,9 +60,10 @@ def _k1_worker(args):
     return out, time.perf_counter() - t0, t_map
 
 
-def k2_scan_mm2(mm, o, alleles, cons_dna, cons_cdna):
+def k2_scan_mm2(mm, o, alleles, cons_dna, cons_cdna, stats_out=None):
     """score_read (src/hla/caller.rs:1411-1510) with the restatement's mappings, in C (omm_hla_score_read): alleles = [(index, cdna, dna)] in
-    database order"""
+    database order.  stats_out (a list): receives the per-allele HlaMappingStats the reference prints into hla_debug.json -- an int64 array
+    [allele][level: cDNA, DNA][len, nm, unmapped], -1 where a level has no mapping"""
     n = len(alleles)
     enc = [(o.encode(cd) if cd else None, o.encode(dn) if dn else None) for _a, cd, dn in alleles]
     cp, dp = (C.c_void_p * max(1, n))(), (C.c_void_p * max(1, n))()
@@ -77,13 +78,17 @@ def k2_scan_mm2(mm, o, alleles, cons_dna, cons_cdna):
     L = o.L
     L.omm_hla_score_read.restype = C.c_int32
     L.omm_hla_score_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    st = np.zeros((max(1, n), 2, 3), np.int64) if stats_out is not None else None
     b = L.omm_hla_score_read(cc.ctypes.data if len(cc) else None, len(cc), cd_.ctypes.data if len(cd_) else None, len(cd_), n, cp, cl.ctypes.data, dp, dl.ctypes.data,
-                             C.byref(opts5), None)
+                             C.byref(opts5), st.ctypes.data if st is not None else None)
+    if stats_out is not None:
+        stats_out.append(st[:n])
     return alleles[b][0] if b >= 0 else -1
 
 
-def type_consensus_mm2(o, fx, g, cons, synth):
-    """score_consensus + splice_read + score_read (src/hla/caller.rs:1258-1319,1332-1511,1518-1576) on the restatement's mappings"""
+def type_consensus_mm2(o, fx, g, cons, synth, stats_out=None):
+    """score_consensus + splice_read + score_read (src/hla/caller.rs:1258-1319,1332-1511,1518-1576) on the restatement's mappings.
+    stats_out (a list): receives ([allele indices in database order], the per-allele stats of k2_scan_mm2)"""
     import mm2_ffi
     import oracle_ffi
     if not cons:
@@ -107,7 +112,12 @@ def type_consensus_mm2(o, fx, g, cons, synth):
     e_dna = cons if fwd else synth.revcomp(cons)
     e_cdna = spliced if fwd else synth.revcomp(spliced)
     alleles = [(a, fx.cdna[a], fx.dna[a]) for a in range(len(fx.ids)) if fx.gene_of[a] == g]
-    return k2_scan_mm2(mm, o, alleles, e_dna, e_cdna)
+    if stats_out is None:
+        return k2_scan_mm2(mm, o, alleles, e_dna, e_cdna)
+    st = []
+    best = k2_scan_mm2(mm, o, alleles, e_dna, e_cdna, stats_out=st)
+    stats_out.append(([a for a, _c, _d in alleles], st[0]))
+    return best
 
 
 def _gene_worker(args):

@@ -6,6 +6,8 @@ so that tests/test_gpu_concordance.py can hold the HIP path to it on the GPU box
            the diplotype (database ids)
   cyp      the six configs[2] scenarios at 2,000 reads (rng 7): per read the region hits, the final consensuses + labels, the minimum-edit consensus sets of
            every region segment, the call strings
+  k2       score_read's per-allele numbers (src/hla/caller.rs:1411-1510: what the reference prints into hla_debug.json) of the port for the four consensuses of the hla
+           section: for every allele of the gene (nm, unmapped) at the cDNA and the DNA level, and the winner
   cohort   the configs[4] samples named in tests/golden/cohort_samples.json (those whose library call differs from the simulated truth, plus controls): the
            port's HLA diplotype per (sample, gene)
 
@@ -79,6 +81,28 @@ def cyp_section(o, synth):
     return out
 
 
+def k2_section(o, synth, hla):
+    """the port's score_read on the hla section's own consensuses: per consensus the winner and, allele by allele in database order, (cDNA nm, cDNA unmapped, DNA nm,
+    DNA unmapped) -- -1 where the level has no mapping (the lengths are the alleles' own)"""
+    import cpu_port_seeded as cps
+    from concurrent.futures import ThreadPoolExecutor
+    fx = synth.HlaFixture()
+    jobs = [(g, name, c) for g, name in enumerate(fx.genes) for c in hla["consensus"][name] if c]
+
+    def one(job):
+        g, name, c = job
+        st = []
+        best = cps.type_consensus_mm2(o, fx, g, c, synth, stats_out=st)
+        idx, arr = st[0]
+        return {"gene": name, "consensus_crc": crc(c), "winner": int(best), "first_allele": int(idx[0]), "n_alleles": len(idx),
+                "alleles_are_consecutive": bool(idx == list(range(idx[0], idx[0] + len(idx)))),
+                "nm_unmapped": [[int(arr[k][0][1]), int(arr[k][0][2]), int(arr[k][1][1]), int(arr[k][1][2])] for k in range(len(idx))]}
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:               # (the C routine releases the GIL: ctypes)
+        rows = list(ex.map(one, jobs))
+    return {"workload": "the consensus strings of the hla section, typed by tests/cpu_port_seeded.py type_consensus_mm2 (omm_hla_score_read, a = 5)", "seconds": time.time() - t0, "consensuses": rows}
+
+
 def cohort_section(o, synth):
     """the HLA half of the configs[4] samples named in cohort_samples.json through the port: ~44 reads per gene, every allele of the gene typed against the
     consensuses (the expensive part: ~12 CPU-s per consensus)"""
@@ -111,10 +135,10 @@ def main():
     from pb_starphase_amd import synth
     import oracle_ffi
     o = oracle_ffi.load()
-    what = sys.argv[1:] or ["hla", "cyp", "cohort"]
+    what = sys.argv[1:] or ["hla", "cyp", "k2", "cohort"]
     doc = json.load(gzip.open(OUT, "rt")) if os.path.exists(OUT) else {}
     doc["generator"] = "tests/golden/make_concordance.py"
-    for key, fn in (("hla", hla_section), ("cyp", cyp_section), ("cohort", cohort_section)):
+    for key, fn in (("hla", hla_section), ("cyp", cyp_section), ("k2", lambda o_, s_: k2_section(o_, s_, doc["hla"])), ("cohort", cohort_section)):
         if key in what:
             doc[key] = fn(o, synth)
             with gzip.open(OUT, "wt", compresslevel=9) as f:
