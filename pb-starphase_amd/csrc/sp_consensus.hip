@@ -2012,9 +2012,10 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             // there, their words behind the window's): if the window stands and the exact votes of that column name no other children, the node adopts them at its turn
             // without a launch of its own -- the expansion launch that follows nearly every cut window of a branching search.  Needs free node slots like a side expansion.
             const int hidden = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 2)), n_free = __builtin_popcountll(__ballot(lane < NQ && !nh[lane].used));
-            // (only for a node whose windows have not grown to full length yet -- a child of an expansion a window or two ago, i.e. a search that is branching: in a linear
-            //  search a branch foreseen in vain cuts a 256-column window short, 18 of 92 windows of the HLA sample for 2 children taken)
-            const bool may_branch = B.k8_compound && !coh && P.n_blocks <= DIRECT_BLOCKS && (lim < CW || B.k8_compound == 3) && hidden + KID_LA_KIDS <= NQ - (ss.max_queue + 1) - MAXKIDS && n_free >= KID_LA_KIDS + MAXKIDS;
+            const int n_waiting = __builtin_popcountll(__ballot(lane < NQ && nh[lane].used == 1 && !nh[lane].complete));
+            // (only in a search that is branching -- other nodes wait beside this one, or its windows have not grown to full length since it was born in an expansion --: in a
+            //  linear search a branch foreseen in vain cuts a 256-column window short, 18 of 92 windows of the HLA sample for 2 children taken)
+            const bool may_branch = B.k8_compound && !coh && P.n_blocks <= DIRECT_BLOCKS && (lim < CW || n_waiting > 1 || B.k8_compound == 3) && hidden + KID_LA_KIDS <= NQ - (ss.max_queue + 1) - MAXKIDS && n_free >= KID_LA_KIDS + MAXKIDS;
             int nn = lim, bcol = -1, bn0 = 0, bn1 = 0; uint32_t bc0 = 0, bc1 = 0;
             for (int base = 0; base < lim; base += SP_WAVE) {
                 const int col = base + lane;

@@ -9,6 +9,7 @@ the same seeds here.
         consensuses and segments) asserted at the values measured when the fixture was made: a kernel change that moves them fails here
   (iii) the configs[4] samples whose library call differs from the simulated truth: the port makes the same calls"""
 import gzip
+import zlib
 import json
 import os
 
@@ -33,6 +34,11 @@ K1_EXHAUSTIVE_SAME_ALLELE = 8262  # context option k1_best_n = 0: the exact argm
 # scenario -> reads whose hit list differs from the port's: the edit-fraction filter / the collapse of two overlapping placements decided on the unit-cost counts (one read keeps a
 # hit the port drops, one read's collapse keeps another placement)
 K3_RESIDUE = {"*5/*1": 1, "*4+*68/*1": 1}
+# K2 (round 6): score_read's numbers, allele by allele.  The WINNER's (len, nm, unmapped) at both levels as the library reports them (sp_hla_best.mm2_stats: the two-piece affine
+# re-score at a = 5) equal the port's on 4 of 4 consensuses; the per-allele numbers of the running-best scan are the library's unit-cost counts: the share of
+# (allele, level) pairs whose (nm, unmapped) equal the port's is a measured number, gated from below
+K2_WINNER_STATS = 4
+K2_PER_ALLELE_SAME_MIN = 0.80
 K4_SAME_MIN_SET_MIN = 1.0       # measured 100 %: the set of minimum-edit consensuses of every segment is the port's (what the chains are built from, caller.rs:462-487)
 K4_SAME_MINIMUM_MIN = 1.0       # measured 100 % since the placements near a segment's minimum carry the re-scored numbers (99.4 - 99.5 % with unit-cost counts)
 
@@ -105,6 +111,46 @@ def test_configs1_diplotypes_and_stage_counters(pkg, gpu_ctx, hla, gold):
     same_cons = sum(sorted([c1, c2]) == sorted(g["consensus"][fx.genes[gi]]) for gi, (_c, c1, c2) in enumerate(calls))
     print("consensus pairs identical to the port's:", same_cons, "of", len(calls))
     assert same_cons == len(calls)
+
+
+def test_configs1_score_read_numbers_allele_by_allele(pkg, gpu_ctx, hla, gold):
+    """score_read (src/hla/caller.rs:1411-1510) prints (len, nm, unmapped) of every allele at the cDNA and the DNA level into hla_debug.json.  The port's numbers for the four
+    consensuses of configs[1] are in the fixture (`k2`, tests/golden/make_concordance.py: omm_hla_score_read); the library's: sp_hla_type_consensus' per-allele rows (the
+    unit-cost counts its scan runs on) and, for the winner, mm2_stats (re-scored the reference's way).  Winner: exact.  Per allele: counted and gated from below."""
+    fx, db = hla
+    rows = gold["k2"]["consensuses"]
+    assert len(rows) == 4
+    winners_ok, same_pairs, all_pairs, same_present, detail = 0, 0, 0, 0, []
+    for row in rows:
+        gi = fx.genes.index(row["gene"])
+        cons = [c for c in gold["hla"]["consensus"][row["gene"]] if zlib.crc32(c.encode()) & 0xFFFFFFFF == row["consensus_crc"]][0]
+        best, _n, st, _cdna = db.type_consensus(gi, cons, stats=True)
+        idx = [a for a in range(len(fx.ids)) if fx.gene_of[a] == gi]              # the gene's alleles in database order: the rows of the fixture
+        assert len(idx) == row["n_alleles"] and idx[0] == row["first_allele"]
+        port = np.array(row["nm_unmapped"], np.int64)
+        assert same_allele(fx, int(best), row["winner"]), (row["gene"], int(best), row["winner"])
+        # the winner as the library reports it against the port's numbers of the same allele
+        w = idx.index(row["winner"])
+        want = [len(fx.cdna[row["winner"]]) if port[w][0] >= 0 else -1, int(port[w][0]), int(port[w][1]), len(fx.dna[row["winner"]]) if port[w][2] >= 0 else -1, int(port[w][2]), int(port[w][3])]
+        got = list(db.last_mm2_stats)
+        if int(best) == row["winner"]:
+            winners_ok += got == want
+            detail.append((row["gene"], got, want))
+        else:                                   # (an allele with the same sequences: its own numbers are the same by construction)
+            winners_ok += got[1:3] == want[1:3] and got[4:6] == want[4:6]
+        # every allele of the gene, both levels: the library's unit-cost (nm, unmapped) against the port's
+        lib = st[idx].astype(np.int64)
+        for lv, (cn, cu) in enumerate(((1, 2), (4, 5))):
+            p_nm, p_un = port[:, 2 * lv], port[:, 2 * lv + 1]
+            l_nm, l_un = lib[:, cn], lib[:, cu]
+            both = (p_nm >= 0) & (l_nm >= 0)
+            all_pairs += int(((p_nm >= 0) | (l_nm >= 0)).sum())
+            same_present += int(both.sum())
+            same_pairs += int((both & (p_nm == l_nm) & (p_un == l_un)).sum())
+    print("K2 winners with the port's (len, nm, unmapped) at both levels:", winners_ok, "of", len(rows), detail)
+    print("K2 (allele, level) pairs: mapped by either", all_pairs, "mapped by both", same_present, "same (nm, unmapped)", same_pairs, "= %.4f" % (same_pairs / max(1, all_pairs)))
+    assert winners_ok == K2_WINNER_STATS
+    assert same_pairs >= K2_PER_ALLELE_SAME_MIN * all_pairs
 
 
 @pytest.fixture(scope="module")
