@@ -439,16 +439,37 @@ int osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, con
                            const int32_t* tmpl_type, double max_missing_frac, osp_region_hit* out, int cap) {
     return osp_cyp_find_base_type_ex(seq, seq_len, n_templates, tmpl, tmpl_len, tmpl_type, max_missing_frac, 0, out, cap);
 }
-/* rescore: the hits that survive the collapse are re-scored the reference's way -- the template is minimap2's query, the sequence its target: two-piece affine gaps and end
- * clipping (osp_affine_local, map-hifi scores) on the 256 diagonals around the placement's middle diagonal -- and start / end / nm / unmapped / clips of a hit are those numbers
- * (what minimap2 reports for the mapping; what the segments are cut from, what the missing-fraction filter sees).  max_ed_frac and the collapse in front run on the contract's own
- * counts.  (The library's sp_cyp_find_regions under its context option "mm2_rescore", the default.) */
+/* rescore: the numbers of a hit are the reference's -- the template is minimap2's query, the sequence its target: two-piece affine gaps and end clipping (osp_affine_local,
+ * map-hifi scores) on the 256 diagonals around the placement's middle diagonal; start / end / nm / unmapped / clips of a hit are those numbers (what minimap2 reports for the
+ * mapping; what the segments are cut from, what the missing-fraction filter sees).  (The library's sp_cyp_find_regions under its context option "mm2_rescore", the default.)
+ * Round 6: the decisions in front of the hit list -- the max_ed_frac filter (:228-232) and the collapse of overlapping placements (:260-296) -- see those numbers too wherever they
+ * can decide: a placement (with a score of at most OSP_K3_CAP_HI by the contract's count: cells give up one edit past the 0.05 cap) is re-scored BEFORE the filter and the
+ * collapse when it is CRITICAL:
+ *       no other placement of the same sequence that overlaps it by more than OSP_K3_OVL (the collapse asks for 0.9) clearly beats it -- "clearly": the rival's score, taken
+ *       the way the collapse would compare the two, is lower by more than a quarter of itself plus 0.001 (a handful of edits: less than that, end clipping or an affine gap can
+ *       turn the pair round);
+ * every other placement keeps the contract's own counts through the filter and the collapse (the other gene copy's templates, hundreds of clustered edits behind a rival),
+ * is re-scored if it survives them and then has to pass the max_ed_frac filter on its re-scored numbers once more. */
+#define OSP_K3_CAP_HI 0.056
+#define OSP_K3_OVL 0.85
+static void k3_rescore_hit(const uint8_t* seq, int seq_len, const uint8_t* const* tmpl, const int32_t* tmpl_len, osp_region_hit* h) {
+    const int t = h->template_idx;
+    const osp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
+    /* (sequence position - template position) at both ends of the placement, as the contract reports them */
+    const int twice = (h->start - h->clip_start) + (h->end - (tmpl_len[t] - h->clip_end));
+    osp_affine_out af;
+    osp_affine_local(seq, seq_len, tmpl[t], tmpl_len[t], -(twice / 2), 256, &ao, &af);
+    if (af.score <= 0) return;                                                                  /* nothing aligns the reference's way: the hit keeps the contract's counts */
+    h->start = af.t_start; h->end = af.t_end; h->nm = af.nm;
+    h->unmapped = tmpl_len[t] - (af.q_end - af.q_start); h->clip_start = af.q_start; h->clip_end = tmpl_len[t] - af.q_end;
+}
 int osp_cyp_find_base_type_ex(const uint8_t* seq, int seq_len, int n_templates, const uint8_t* const* tmpl, const int32_t* tmpl_len,
                               const int32_t* tmpl_type, double max_missing_frac, int rescore, osp_region_hit* out, int cap) {
     if (seq_len == 0) return 0;
     const double max_ed_frac = 0.05;
     int n_un = 0, un_cap = n_templates * OSP_CYP_TOPK + 1;
     osp_region_hit* un = (osp_region_hit*)malloc(sizeof(osp_region_hit) * (size_t)un_cap);
+    uint8_t* done = (uint8_t*)calloc((size_t)un_cap, 1);                                       /* the placement carries its re-scored numbers */
     for (int t = 0; t < n_templates; ++t) {
         int diags[OSP_CYP_TOPK], votes[OSP_CYP_TOPK];
         int np = osp_anchor_topk(tmpl[t], tmpl_len[t], seq, seq_len, OSP_CYP_TOPK, diags, votes);      /* seq_pos - template_pos */
@@ -462,48 +483,66 @@ int osp_cyp_find_base_type_ex(const uint8_t* seq, int seq_len, int n_templates, 
             h.template_idx = t; h.start = al.b_start; h.end = al.b_end;
             h.seq_len = tmpl_len[t]; h.nm = al.nm; h.unmapped = tmpl_len[t] - (al.a_end - al.a_start);
             h.clip_start = al.a_start; h.clip_end = tmpl_len[t] - al.a_end;
-            if (hit_score(&h, is_penalized_type(tmpl_type[t])) > max_ed_frac) continue;           /* :228-232 ; Forward only */
+            if (hit_score(&h, is_penalized_type(tmpl_type[t])) > (rescore ? OSP_K3_CAP_HI : max_ed_frac)) continue;           /* :228-232 ; Forward only */
             un[n_un++] = h;
         }
     }
+    if (rescore) {
+        /* the critical placements, by the contract's own counts: near the cap, or not clearly beaten by a rival that overlaps them */
+        uint8_t* crit = (uint8_t*)calloc((size_t)n_un + 1, 1);
+        for (int i = 0; i < n_un; ++i) crit[i] = 1;
+        for (int i = 0; i < n_un; ++i) for (int j = i + 1; j < n_un; ++j) {
+            if (!(osp_cyp_overlap_score(un[i].start, un[i].end, un[j].start, un[j].end) > OSP_K3_OVL)) continue;
+            const int pen = is_penalized_type(tmpl_type[un[i].template_idx]) || is_penalized_type(tmpl_type[un[j].template_idx]);
+            const double a = hit_score(&un[i], pen), b = hit_score(&un[j], pen);
+            if (a > 1.25 * b + 0.001) crit[i] = 0;                                           /* i is clearly beaten by j */
+            if (b > 1.25 * a + 0.001) crit[j] = 0;
+        }
+        for (int i = 0; i < n_un; ++i) if (crit[i]) { k3_rescore_hit(seq, seq_len, tmpl, tmpl_len, &un[i]); done[i] = 1; }
+        free(crit);
+        /* the filter, on what every placement carries now */
+        int m = 0;
+        for (int i = 0; i < n_un; ++i) if (!(hit_score(&un[i], is_penalized_type(tmpl_type[un[i].template_idx])) > max_ed_frac)) { un[m] = un[i]; done[m] = done[i]; ++m; }
+        n_un = m;
+    }
     /* stable sort by (start, end) (:252-255) */
     for (int i = 1; i < n_un; ++i) {
-        osp_region_hit x = un[i]; int j = i - 1;
-        while (j >= 0 && (un[j].start > x.start || (un[j].start == x.start && un[j].end > x.end))) { un[j + 1] = un[j]; --j; }
-        un[j + 1] = x;
+        osp_region_hit x = un[i]; const uint8_t dx = done[i]; int j = i - 1;
+        while (j >= 0 && (un[j].start > x.start || (un[j].start == x.start && un[j].end > x.end))) { un[j + 1] = un[j]; done[j + 1] = done[j]; --j; }
+        un[j + 1] = x; done[j + 1] = dx;
     }
     /* collapse overlapping hits (:260-296) */
-    int n_out = 0, have_cur = 0; osp_region_hit cur; memset(&cur, 0, sizeof(cur));
+    int n_out = 0, have_cur = 0; osp_region_hit cur; memset(&cur, 0, sizeof(cur)); uint8_t cur_done = 0;
     osp_region_hit* coll = (osp_region_hit*)malloc(sizeof(osp_region_hit) * (size_t)(n_un + 1));
+    uint8_t* coll_done = (uint8_t*)calloc((size_t)n_un + 1, 1);
     int n_coll = 0;
     for (int i = 0; i < n_un; ++i) {
-        if (!have_cur) { cur = un[i]; have_cur = 1; continue; }
+        if (!have_cur) { cur = un[i]; cur_done = done[i]; have_cur = 1; continue; }
         if (osp_cyp_overlap_score(un[i].start, un[i].end, cur.start, cur.end) > 0.9) {
             int star5_pairing = is_penalized_type(tmpl_type[un[i].template_idx]) || is_penalized_type(tmpl_type[cur.template_idx]);
             int penalized_scoring = star5_pairing ? 1 : 0;
             int up = tmpl_type[un[i].template_idx] == OSP_DELETION ? 1 : 0, cp = tmpl_type[cur.template_idx] == OSP_DELETION ? 1 : 0;   /* :897-902 */
-            if ((hit_score(&un[i], penalized_scoring) < hit_score(&cur, penalized_scoring) && up >= cp) || up > cp) cur = un[i];
-        } else { coll[n_coll++] = cur; cur = un[i]; }
+            if ((hit_score(&un[i], penalized_scoring) < hit_score(&cur, penalized_scoring) && up >= cp) || up > cp) { cur = un[i]; cur_done = done[i]; }
+        } else { coll_done[n_coll] = cur_done; coll[n_coll++] = cur; cur = un[i]; cur_done = done[i]; }
     }
-    if (have_cur) coll[n_coll++] = cur;
-    if (rescore) for (int i = 0; i < n_coll; ++i) {
-        osp_region_hit* h = &coll[i];
-        const int t = h->template_idx;
-        const osp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
-        /* (sequence position - template position) at both ends of the placement, as the contract reports them */
-        const int twice = (h->start - h->clip_start) + (h->end - (tmpl_len[t] - h->clip_end));
-        osp_affine_out af;
-        osp_affine_local(seq, seq_len, tmpl[t], tmpl_len[t], -(twice / 2), 256, &ao, &af);
-        if (af.score <= 0) continue;
-        h->start = af.t_start; h->end = af.t_end; h->nm = af.nm;
-        h->unmapped = tmpl_len[t] - (af.q_end - af.q_start); h->clip_start = af.q_start; h->clip_end = tmpl_len[t] - af.q_end;
+    if (have_cur) { coll_done[n_coll] = cur_done; coll[n_coll++] = cur; }
+    if (rescore) {
+        int m = 0;
+        for (int i = 0; i < n_coll; ++i) {
+            if (!coll_done[i]) {
+                k3_rescore_hit(seq, seq_len, tmpl, tmpl_len, &coll[i]);
+                if (hit_score(&coll[i], is_penalized_type(tmpl_type[coll[i].template_idx])) > max_ed_frac) continue;       /* (the filter once more, on the re-scored numbers) */
+            }
+            coll[m++] = coll[i];
+        }
+        n_coll = m;
     }
     for (int i = 0; i < n_coll; ++i) {
         if (hit_score(&coll[i], 1) > max_missing_frac) continue;                                   /* :303-306 */
         if (n_out < cap) out[n_out] = coll[i];
         ++n_out;
     }
-    free(un); free(coll);
+    free(un); free(coll); free(done); free(coll_done);
     return n_out;
 }
 

@@ -783,12 +783,17 @@ extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, 
     if (!ctx) return SP_ERR_INVALID_ARG;
     return cyp_find_regions(ctx, templates, template_type, reads, max_missing_frac, hits, hits_cap, n_hits, ctx->mm2_rescore);
 }
-// rescore (context option "mm2_rescore", the default): the hits that survive the collapse of overlapping placements are re-scored the reference's way -- template (minimap2's
-// query) against read (its target), two-piece affine gaps and end clipping on the 256 diagonals around the placement's own (sp_rescore_mappings; hits whose edits all stand
-// alone keep their counts without a DP) -- and start / end / nm / unmapped / clips of a hit ARE those numbers: what minimap2 reports for the mapping, what the segments are cut
-// from and what the missing-fraction filter sees (oracle/cyp.c osp_cyp_find_base_type_ex states the same with the DP over all rows).  The edit-fraction filter and the collapse
-// in front run on the library's own counts: re-scoring every placement first (45,365 per 2,000-read sample instead of 2,162 hits, most of them the other gene copy's templates at
-// 3 - 5 % divergence) cost 39 ms per sample and changed ONE hit in 13,045 against the CPU port (tests/test_gpu_concordance.py).  The drivers inside the library take the same path.
+// rescore (context option "mm2_rescore", the default): the numbers of a hit are the reference's -- template (minimap2's query) against read (its target), two-piece affine gaps
+// and end clipping on the 256 diagonals around the placement's own (sp_rescore_mappings; placements whose edits all stand alone keep their counts without a DP) -- and start / end /
+// nm / unmapped / clips of a hit ARE those numbers: what minimap2 reports for the mapping, what the segments are cut from and what the missing-fraction filter sees
+// (oracle/cyp.c osp_cyp_find_base_type_ex states the same with the DP over all rows).
+// Round 6: the decisions in front of the hit list see those numbers too wherever they can decide.  A placement is re-scored BEFORE the edit-fraction filter and the collapse when
+// it is CRITICAL (among those with a score of at most K3_CAP_HI by the library's count: cells give up one edit past the 0.05 cap): no other placement on the same read that overlaps it by
+// more than K3_OVL (the collapse asks for 0.9) clearly beats it -- the rival's score, taken as the collapse would compare the two, lower by more than a quarter of itself plus 0.001
+// (less than that, end clipping or an affine gap can turn the pair round).  Every other placement -- the other gene copy's templates, hundreds of clustered edits behind a rival: re-scoring
+// ALL 45,365 placements of a 2,000-read sample cost 39 ms (round 5) -- keeps the library's counts through the filter and the collapse, is re-scored if it survives them and then has
+// to pass the filter on its re-scored numbers once more.  The drivers inside the library take the same path.
+constexpr double K3_CAP_HI = 0.056, K3_OVL = 0.85;
 static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
                                 double max_missing_frac, sp_region_hit* hits, uint64_t hits_cap, uint64_t* n_hits, bool rescore) {
     if (!ctx || !templates || !reads || !n_hits || (templates->n && !template_type) || (hits_cap && !hits)) return SP_ERR_INVALID_ARG;
@@ -799,43 +804,19 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
     if (rc) return rc;
     const uint32_t T = templates->n;
     auto penalized_type = [](int t) { return t == SP_CYP_DELETION || t == SP_CYP_REP6 || t == SP_CYP_REP7; };   // haplotyper.rs:185-191
-    std::vector<sp_region_hit> un, coll; std::vector<uint32_t> which;
-    for (uint32_t r = 0; r < reads->n; ++r) {
-        if (reads->h_len[r] == 0) continue;
-        un.clear();
-        for (uint32_t t = 0; t < T; ++t) for (int k = 0; k < CYP_TOPK; ++k) {
-            const sp_aln& al = alns[((size_t)r * T + t) * CYP_TOPK + k];
-            if (!al.ok) continue;
-            const int tlen = templates->h_len[t];
-            sp_region_hit h{(int32_t)r, (int32_t)t, al.b_start, al.b_end, tlen, al.nm, tlen - (al.a_end - al.a_start), al.a_start, tlen - al.a_end, 0, 0, 0, 0, 0, 0};
-            h.mm2_score = (int32_t)(((size_t)r * T + t) * CYP_TOPK + k);                     // (until the re-score below: which alignment the hit is)
-            if (cyp_score(h.seq_len, h.nm, h.unmapped, penalized_type(template_type[t])) > 0.05) continue;   // max_ed_frac, :228-232
-            un.push_back(h);
-        }
-        std::stable_sort(un.begin(), un.end(), [](const sp_region_hit& x, const sp_region_hit& y) {
-            return x.start != y.start ? x.start < y.start : x.end < y.end; });
-        bool have = false; sp_region_hit cur{};
-        for (const sp_region_hit& u : un) {
-            if (!have) { cur = u; have = true; continue; }
-            const int min_end = std::min(u.end, cur.end), max_start = std::max(u.start, cur.start);
-            double ovl = 0.0;                                                        // overlap_score (haplotyper.rs:877-892)
-            if (max_start < min_end) ovl = (double)(min_end - max_start) / std::min((double)(u.end - u.start), (double)(cur.end - cur.start));
-            if (ovl > 0.9) {
-                const bool pen = penalized_type(template_type[u.template_idx]) || penalized_type(template_type[cur.template_idx]);
-                const int up = template_type[u.template_idx] == SP_CYP_DELETION, cp = template_type[cur.template_idx] == SP_CYP_DELETION;
-                if ((cyp_score(u.seq_len, u.nm, u.unmapped, pen) < cyp_score(cur.seq_len, cur.nm, cur.unmapped, pen) && up >= cp) || up > cp) cur = u;
-            } else { coll.push_back(cur); cur = u; }
-        }
-        if (have) coll.push_back(cur);
-    }
-    // the collapsed hits with the reference's numbers
-    const uint64_t nc = coll.size();
-    which.resize(nc);
-    for (uint64_t x = 0; x < nc; ++x) { which[x] = (uint32_t)coll[x].mm2_score; coll[x].mm2_score = 0; }
-    if (rescore && nc) {
+    auto own_score = [&](const sp_region_hit& h) { return cyp_score(h.seq_len, h.nm, h.unmapped, penalized_type(template_type[h.template_idx])); };
+    auto overlap = [](const sp_region_hit& u, const sp_region_hit& v) {                                       // overlap_score (haplotyper.rs:877-892)
+        const int min_end = std::min(u.end, v.end), max_start = std::max(u.start, v.start);
+        return max_start < min_end ? (double)(min_end - max_start) / std::min((double)(u.end - u.start), (double)(v.end - v.start)) : 0.0;
+    };
+    // a list of placements (hit + which alignment it is) re-scored in place
+    struct Pl { sp_region_hit h; uint32_t which; uint8_t done; };
+    auto rescore_list = [&](std::vector<Pl*>& list, const char* prof) -> int {
+        const uint64_t nc = list.size();
+        if (!nc) return SP_OK;
         std::vector<CellDesc> cells(nc); std::vector<sp_aln> ref(nc); std::vector<sp_affine_aln> af(nc);
         for (uint64_t x = 0; x < nc; ++x) {
-            const sp_region_hit& h = coll[x]; const sp_aln& al = alns[which[x]];
+            const sp_region_hit& h = list[x]->h; const sp_aln& al = alns[list[x]->which];
             cells[x] = CellDesc{ (uint32_t)h.template_idx, (uint32_t)h.read, ((al.b_start - al.a_start) + (al.b_end - al.a_end)) / 2, 320, 0, -1 };
             ref[x] = al;
         }
@@ -846,19 +827,85 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
         SP_HIP_CHECK(ctx, hipMemcpyAsync(d_cells, cells.data(), nc * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream));
         SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ref, ref.data(), nc * sizeof(sp_aln), hipMemcpyHostToDevice, ctx->stream));
         const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
-        rc = sp_rescore_mappings(ctx, templates, reads, d_cells, d_ref, nc, false, ao, 256, d_af, "k3_af", 320);
-        if (rc != SP_OK) return rc;
+        const int rc2 = sp_rescore_mappings(ctx, templates, reads, d_cells, d_ref, nc, false, ao, 256, d_af, prof, 320);
+        if (rc2 != SP_OK) return rc2;
         SP_HIP_CHECK(ctx, hipMemcpyAsync(af.data(), d_af, nc * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
         SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         for (uint64_t x = 0; x < nc; ++x) {
-            sp_region_hit& h = coll[x];
+            sp_region_hit& h = list[x]->h;
+            list[x]->done = 1;
             if (af[x].score <= 0) continue;                                                                      // (nothing aligns the reference's way: the hit keeps the library's counts)
             h.mm2_score = af[x].score; h.mm2_nm = af[x].nm; h.mm2_start = af[x].b_start; h.mm2_end = af[x].b_end; h.mm2_q_start = af[x].a_start; h.mm2_q_end = af[x].a_end;
             h.start = af[x].b_start; h.end = af[x].b_end; h.nm = af[x].nm;
             h.unmapped = h.seq_len - (af[x].a_end - af[x].a_start); h.clip_start = af[x].a_start; h.clip_end = h.seq_len - af[x].a_end;
         }
+        return SP_OK;
+    };
+    // the placements of every read by the library's counts (cells give up one edit past the cap: a little above it they still exist)
+    std::vector<Pl> un; std::vector<uint32_t> first(reads->n + 1, 0);
+    for (uint32_t r = 0; r < reads->n; ++r) {
+        first[r] = (uint32_t)un.size();
+        if (reads->h_len[r] == 0) continue;
+        for (uint32_t t = 0; t < T; ++t) for (int k = 0; k < CYP_TOPK; ++k) {
+            const uint32_t which = (uint32_t)(((size_t)r * T + t) * CYP_TOPK + k);
+            const sp_aln& al = alns[which];
+            if (!al.ok) continue;
+            const int tlen = templates->h_len[t];
+            sp_region_hit h{(int32_t)r, (int32_t)t, al.b_start, al.b_end, tlen, al.nm, tlen - (al.a_end - al.a_start), al.a_start, tlen - al.a_end, 0, 0, 0, 0, 0, 0};
+            if (own_score(h) > (rescore ? K3_CAP_HI : 0.05)) continue;                                          // max_ed_frac, :228-232
+            un.push_back(Pl{ h, which, 0 });
+        }
     }
-    for (const sp_region_hit& h : coll) {
+    first[reads->n] = (uint32_t)un.size();
+    if (rescore) {
+        std::vector<Pl*> crit;
+        std::vector<uint8_t> mark(un.size(), 1);
+        // (both scores of every placement once: the pair loop below runs ~ 250 times per read)
+        std::vector<double> s_own(un.size()), s_pen(un.size()); std::vector<uint8_t> is_pen(un.size());
+        for (size_t i = 0; i < un.size(); ++i) {
+            const sp_region_hit& h = un[i].h;
+            s_own[i] = cyp_score(h.seq_len, h.nm, h.unmapped, false); s_pen[i] = cyp_score(h.seq_len, h.nm, h.unmapped, true); is_pen[i] = penalized_type(template_type[h.template_idx]);
+        }
+        for (uint32_t r = 0; r < reads->n; ++r) for (uint32_t i = first[r]; i < first[r + 1]; ++i) for (uint32_t j = i + 1; j < first[r + 1]; ++j) {
+            const sp_region_hit& u = un[i].h; const sp_region_hit& v = un[j].h;
+            const int shared = std::min(u.end, v.end) - std::max(u.start, v.start);
+            if (shared <= 0 || !(overlap(u, v) > K3_OVL)) continue;
+            const bool pen = is_pen[i] || is_pen[j];
+            const double a = pen ? s_pen[i] : s_own[i], b = pen ? s_pen[j] : s_own[j];
+            if (a > 1.25 * b + 0.001) mark[i] = 0;                                           // i is clearly beaten by j
+            if (b > 1.25 * a + 0.001) mark[j] = 0;
+        }
+        for (size_t i = 0; i < un.size(); ++i) if (mark[i]) crit.push_back(&un[i]);
+        rc = rescore_list(crit, "k3_af_crit");
+        if (rc != SP_OK) return rc;
+        if (ctx->profiling) ctx->prof["k3_critical_placements"].cells += crit.size();
+    }
+    std::vector<Pl> coll;
+    std::vector<Pl> cur_read;
+    for (uint32_t r = 0; r < reads->n; ++r) {
+        cur_read.clear();
+        for (uint32_t i = first[r]; i < first[r + 1]; ++i) if (!(own_score(un[i].h) > 0.05)) cur_read.push_back(un[i]);         // the filter, on what every placement carries now
+        std::stable_sort(cur_read.begin(), cur_read.end(), [](const Pl& x, const Pl& y) { return x.h.start != y.h.start ? x.h.start < y.h.start : x.h.end < y.h.end; });
+        bool have = false; Pl cur{};
+        for (const Pl& u : cur_read) {
+            if (!have) { cur = u; have = true; continue; }
+            if (overlap(u.h, cur.h) > 0.9) {
+                const bool pen = penalized_type(template_type[u.h.template_idx]) || penalized_type(template_type[cur.h.template_idx]);
+                const int up = template_type[u.h.template_idx] == SP_CYP_DELETION, cp = template_type[cur.h.template_idx] == SP_CYP_DELETION;
+                if ((cyp_score(u.h.seq_len, u.h.nm, u.h.unmapped, pen) < cyp_score(cur.h.seq_len, cur.h.nm, cur.h.unmapped, pen) && up >= cp) || up > cp) cur = u;
+            } else { coll.push_back(cur); cur = u; }
+        }
+        if (have) coll.push_back(cur);
+    }
+    if (rescore) {
+        std::vector<Pl*> rest;
+        for (Pl& c : coll) if (!c.done) rest.push_back(&c);
+        rc = rescore_list(rest, "k3_af");
+        if (rc != SP_OK) return rc;
+    }
+    for (const Pl& c : coll) {
+        const sp_region_hit& h = c.h;
+        if (rescore && own_score(h) > 0.05) continue;                                                      // (the filter once more, on the re-scored numbers)
         if (cyp_score(h.seq_len, h.nm, h.unmapped, true) > max_missing_frac) continue;                     // :303-306
         if (*n_hits < hits_cap) hits[*n_hits] = h;
         ++*n_hits;

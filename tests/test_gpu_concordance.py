@@ -28,12 +28,12 @@ K1_SAME_GENE = 10000            # of 10,000 reads: every read enters the same ge
 K1_SAME_ALLELE = 10000          # the accepted allele of every read is the seeded map's (8,262 while K1 was the exhaustive argmin over every allele: k1_best_n = 0, below)
 K1_MM2_NUMBERS = 10000          # ... with the port's (NM, allele span)
 K1_EXHAUSTIVE_SAME_ALLELE = 8262  # context option k1_best_n = 0: the exact argmin prefers partial alleles the seeded map never base-aligns
-# K3 (round 5: the hits that survive the collapse carry their re-scored numbers, sp_cyp.hip cyp_find_regions): 11,998 of the 12,000 reads of the six scenarios have the port's
-# whole hit list (template, start, end) with the port's nm / unmapped -- K3_RESIDUE below names the two others; rounds 3-4, hits with the unit-cost counts: 97.5 - 98.3 % of
-# reads.  (With every placement re-scored BEFORE the collapse all 12,000 are the port's, at 39 ms per sample for the 45,365 placements: measured and not kept, see cyp_find_regions.)
-# scenario -> reads whose hit list differs from the port's: the edit-fraction filter / the collapse of two overlapping placements decided on the unit-cost counts (one read keeps a
-# hit the port drops, one read's collapse keeps another placement)
-K3_RESIDUE = {"*5/*1": 1, "*4+*68/*1": 1}
+# K3: every one of the 12,000 reads of the six scenarios has the port's whole hit list (template, start, end) with the port's nm / unmapped.  Round 5: the hits that survive
+# the collapse carry their re-scored numbers -- 11,998 reads (rounds 3-4, unit-cost counts: 97.5 - 98.3 %).  Round 6: the placements whose filter or collapse decision a handful
+# of edits could turn are re-scored BEFORE those decisions (sp_cyp.hip cyp_find_regions: K3_CAP_LO / K3_OVL), the survivors pass the 5 % filter once more on their re-scored
+# numbers -- the two residual reads (one kept a REP7 hit at 0.0498 by the unit-cost count, 0.0523 re-scored; one collapse preferred the gene over a hybrid at 0.00379 against
+# 0.00406, 0.00352 after end clipping) agree as well.  scenario -> reads whose hit list differs from the port's:
+K3_RESIDUE = {}
 # K2 (round 6): score_read's numbers, allele by allele.  The WINNER's (len, nm, unmapped) at both levels as the library reports them (sp_hla_best.mm2_stats: the two-piece affine
 # re-score at a = 5) equal the port's on 4 of 4 consensuses; the per-allele numbers of the running-best scan are the library's unit-cost counts: the share of
 # (allele, level) pairs whose (nm, unmapped) equal the port's is a measured number, gated from below
