@@ -166,10 +166,11 @@ template <int MAXP> struct ConsBatchT {
     int total;
     int nside;                  // side orders per problem and step (0 .. NWORK - 1): the step kernel's grid has 1 + nside rows
     int k8_compound;            // windows may be ordered with the children of the branch the lookahead votes foresee at their end
+    int k8_ctl_prio;
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; uint32_t step_cap; const int* cluster_prob; int total; int nside; int k8_compound;
+    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; uint32_t step_cap; const int* cluster_prob; int total; int nside; int k8_compound; int k8_ctl_prio;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first, cmp_len, pad_; };
 
@@ -1371,6 +1372,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     const int pi = blockIdx.x;
     const ConsParams P = B.p[pi];
     const int tid = threadIdx.x;
+    if (B.k8_ctl_prio) __builtin_amdgcn_s_setprio(3);    // (experiment switch SP_K8_CTL_PRIO: the control step is one wave's latency chain; beside other kernels' waves on its SIMD it runs 2 - 3 x slower)
     const bool coh = B.sync != nullptr;                   // persistent mode: what the step workgroups read next is stored write-through, their words are fetched where the atomics ran
     // side orders: only where every order has a word block of its own (problems whose workgroups add their words up), and not between persistent kernels (one row of resident workgroups)
     const int nside = (coh || P.n_blocks > DIRECT_BLOCKS) ? 0 : (B.nside < NWORK - 1 ? B.nside : NWORK - 1);
@@ -2582,16 +2584,23 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
 
     B.nside = persist_rpw ? 0 : nside;
     B.k8_compound = ctx->k8_compound;
+    static const int ctl_prio = std::getenv("SP_K8_CTL_PRIO") ? std::atoi(std::getenv("SP_K8_CTL_PRIO")) : 0, ctl_pad = std::getenv("SP_K8_CTL_LDS_PAD") ? std::atoi(std::getenv("SP_K8_CTL_LDS_PAD")) : 0;      // (experiment switches)
+    B.k8_ctl_prio = ctl_prio;
     const dim3 grid((uint32_t)n_blocks, (uint32_t)(1 + B.nside)), block(CWAVES * SP_WAVE);
     // (the step kernel's instantiation for batches that fit the device at one workgroup per CU, give or take a few: cons_step_wide_kernel.  A 2,000-read CYP2D6 sample's first batch
     //  has 271 workgroups -- its 2,162 region segments -- and is still faster there)
     static const int wide_max = std::getenv("SP_K8_WIDE_MAX") ? std::atoi(std::getenv("SP_K8_WIDE_MAX")) : -1;      // (experiment switch)
     const bool one_round = n_blocks <= (wide_max >= 0 ? wide_max : ctx->num_cus + ctx->num_cus / 4);
-    const size_t proc_lds = ((size_t)max_cap + 2 + 15) & ~(size_t)15;
+    size_t proc_lds = ((size_t)max_cap + 2 + 15) & ~(size_t)15;
     {   // the control kernel's node table and vote sums are static LDS; the per-length counters come on top (160 KiB per workgroup on gfx950)
         hipFuncAttributes fa;
         SP_HIP_CHECK(ctx, hipFuncGetAttributes(&fa, (const void*)cons_control_kernel<MAXP>));
         if (fa.sharedSizeBytes + proc_lds > 160 * 1024) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must stay below ~65,000");
+    }
+    if (ctl_pad) {                                          // (experiment: the control workgroup takes the CU's whole LDS, so that no other kernel's LDS-using workgroups sit beside it)
+        hipFuncAttributes fa2;
+        SP_HIP_CHECK(ctx, hipFuncGetAttributes(&fa2, (const void*)cons_control_kernel<MAXP>));
+        if (fa2.sharedSizeBytes + proc_lds < 160 * 1024) proc_lds = ((160 * 1024 - fa2.sharedSizeBytes) / 16) * 16;
     }
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cons_control_kernel<MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)proc_lds));
     uint64_t pairs = 0;

@@ -31,14 +31,68 @@ def realign_pick(hits):
     return best
 
 
+def select_best_mapping(hits, unmapped_from_target, penalize=True):
+    """src/util/mapping.rs:22-57: the default is a 100 % mismatch rate (score 1.0), strict <: the first of equals stays"""
+    best, bs = None, 1.0
+    for h in hits:
+        bl = h["t_len"] if unmapped_from_target else h["q_len"]
+        um = bl - ((h["t_end"] - h["t_start"]) if unmapped_from_target else (h["q_end"] - h["q_start"]))
+        s = max(float(h["nm"] + um), 0.1) / float(bl) if penalize else max(float(h["nm"]), 0.1) / float(bl - um)
+        if s < bs:
+            best, bs = h, s
+    return best
+
+
+def record_mm2(mm, o, fx, read, a, m, rev, am_cache):
+    """realign_record behind the accepted mapping (src/hla/realigner.rs:214-337) IN THE REFERENCE'S CALL PATTERN: the accepted mapping's read segment +- 1,000 bases is mapped
+    to the gene's reference (gene_aligner.map, :231) and the best mapping picked by select_best_mapping (unmapped from the target, penalised, :238-242); where the reference
+    mapping does not start in front of the allele mapping the ALLELE is mapped to the reference as well (:290, Forward only, unmapped from the query) and the two offsets add
+    up (:307-317).  m = (nm, t_start, t_end, q_start, q_end, t_len, q_len) of the accepted mapping, a = its allele (-1: none; rev: a best mapping on the reverse strand)"""
+    res = dict(status=1, best_allele=-1, gene=-1)
+    if a < 0:
+        if rev:
+            res["status"] = 2
+        return res
+    nm, ts, te, qs, qe, tl, _ql = m
+    g = int(fx.gene_of[a])
+    res.update(status=3, best_allele=a, gene=g, nm=int(nm), target_len=int(tl), unmapped=int(tl - (te - ts)))
+    ref = fx.gene_ref[g]
+    db_s, db_e = int(qs), int(qe)
+    buf_s, buf_e = max(db_s - 1000, 0), min(db_e + 1000, len(read))
+    rm = select_best_mapping(mm.map_pair(ref, read[buf_s:buf_e]), unmapped_from_target=True)
+    if rm is None or rm["rev"]:                                               # "Remapping ... failed" / "was to Reverse strand, ignoring" (:326-337)
+        return res
+    adj_s, adj_e = buf_s + rm["q_start"], buf_s + rm["q_end"]
+    if adj_s < db_s:
+        d = rm["t_start"]
+        h = o.hpc_pos(ref, d)
+    else:
+        if a not in am_cache:
+            am_cache[a] = select_best_mapping([x for x in mm.map_pair(ref, fx.dna_fwd(a)) if not x["rev"]], unmapped_from_target=False)
+        am = am_cache[a]
+        if am is not None:
+            added = max(am["t_start"] - am["q_start"], 0)
+            d = added + int(ts)
+            h = o.hpc_pos(ref, added) + o.hpc_pos(fx.dna[a], int(ts))
+        else:
+            d = rm["t_start"]
+            h = o.hpc_pos(ref, d)
+    res.update(status=0, seg_start=min(db_s, adj_s), seg_end=max(db_e, adj_e), dna_offset=int(d), hpc_offset=int(h))
+    return res
+
+
 def _k1_worker(args):
     """realign_record for a share of the reads: the seeded map + acceptance (src/hla/realigner.rs:98-146), then the segment / offset bookkeeping behind the best
     mapping (:226-325)"""
     import hla_expected as hx
     lo, hi, budget_s = args
     idx, reads, dna_ids, o = G["idx"], G["reads"], G["dna_ids"], G["o"]
-    tb = G.get("tb") or hx.K1Tables(o, G["fx"], G["off"])
-    G["tb"] = tb
+    contract = os.environ.get("SP_PORT_K1_SECOND_STAGE", "mm2") == "contract"        # (the second stage on the library's own alignment contract, as until round 5)
+    tb = None
+    if contract:
+        tb = G.get("tb") or hx.K1Tables(o, G["fx"], G["off"])
+        G["tb"] = tb
+    am_cache = G.setdefault("am_cache", {})
     out, t0, t_map = [], time.perf_counter(), 0.0
     for r in range(lo, hi):
         t1 = time.perf_counter()
@@ -46,14 +100,17 @@ def _k1_worker(args):
         t_map += time.perf_counter() - t1
         # a best mapping on the reverse strand is dropped (src/hla/realigner.rs:178-193)
         a, m = (-1, None) if (h is None or h["rev"]) else (dna_ids[h["rid"]], (h["nm"], h["t_start"], h["t_end"], h["q_start"], h["q_end"], h["t_len"], h["q_len"]))
-        re = o.encode(reads[r])
-        bm = None
-        if a >= 0:
-            nm, ts, te, qs, qe, tl, ql = m
-            bm = np.zeros(1, hx.oracle_aln_dtype())[0]
-            bm["ok"], bm["nm"], bm["a_start"], bm["a_end"], bm["b_start"], bm["b_end"], bm["a_len"], bm["b_len"] = 1, nm, ts, te, qs, qe, tl, ql
-        rec = tb.record(reads[r], re, tb.anchors(re), a, bm)
-        rec.pop("aln", None)
+        if contract:
+            re = o.encode(reads[r])
+            bm = None
+            if a >= 0:
+                nm, ts, te, qs, qe, tl, ql = m
+                bm = np.zeros(1, hx.oracle_aln_dtype())[0]
+                bm["ok"], bm["nm"], bm["a_start"], bm["a_end"], bm["b_start"], bm["b_end"], bm["a_len"], bm["b_len"] = 1, nm, ts, te, qs, qe, tl, ql
+            rec = tb.record(reads[r], re, tb.anchors(re), a, bm)
+            rec.pop("aln", None)
+        else:
+            rec = record_mm2(G["mm"], o, G["fx"], reads[r], a, m, bool(h is not None and h["rev"]), am_cache)
         out.append((r, a, m, rec))
         if time.perf_counter() - t0 > budget_s:
             break

@@ -44,8 +44,12 @@ def hla_section(o, synth):
     win = [int(best[r][0]) for r in done]
     nm = [int(best[r][1][0]) if best[r][1] else -1 for r in done]
     span = [int(best[r][1][2] - best[r][1][1]) if best[r][1] else 0 for r in done]
+    # realign_record's whole result per read, second stage in the reference's call pattern (cpu_port_seeded.record_mm2: gene_aligner.map + select_best_mapping,
+    # src/hla/realigner.rs:231-317): [status, seg_start, seg_end, dna_offset, hpc_offset] (-1 where the record has none)
+    recs = cps.G["records"]
+    records = [[int(recs[r].get(k, -1)) for k in ("status", "seg_start", "seg_end", "dna_offset", "hpc_offset")] for r in done]
     return {"workload": "synth.Config2Workload(HlaFixture(), n_reads=10000, seed=1000)", "seconds": time.time() - t0,
-            "winner": win, "nm": nm, "span": span,
+            "winner": win, "nm": nm, "span": span, "records": records,
             "calls": {fx.genes[g]: sorted(int(x) for x in calls[g]) for g in calls}, "call_ids": {fx.genes[g]: sorted(fx.ids[int(x)] for x in calls[g] if x >= 0) for g in calls},
             "consensus": {fx.genes[g]: list(cons[g]) for g in cons},
             "truth": {fx.genes[g]: sorted(int(a) for (gg, _c, _d, a) in wl.consensus if gg == g) for g in range(len(fx.genes))},
