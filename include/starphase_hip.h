@@ -99,6 +99,13 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * process (several processes on one device: set 0).  A batch whose control workgroups have not all started within half a second runs as launch pairs instead, by itself (the
  * context then stays away from the mode for 64 batches and says so in sp_ctx_get_info().warning); a search that exceeds the launch-pair loop's own step bound ends the batch
  * with the same error in both modes; no path returns while one of the two kernels is still running.
+ * "k8_side_orders" (0..3, default 1; also SP_K8_SIDE_ORDERS) and "k8_compound" (0 | 1, default 1; also SP_K8_COMPOUND): how many work orders a consensus step launch carries
+ * per problem beside the search's own -- the window or the expansion another WAITING node of the best-first search will need when its turn comes, made in the same launch
+ * (a second row of workgroups); the children of an expansion made ahead wait unseen until the search takes their parent out at that column and are adopted without a launch --
+ * and whether a window may be ordered WITH the children of the branch its lookahead votes foresee at its end (taken when the window stands and the exact votes of that column
+ * name no other children).  Neither changes what the search does -- strings, read assignment, per-read scores and the number of nodes expanded are those of the one-order search,
+ * bit for bit --, only how many dependent launches it takes (a 2,000-read CYP2D6 sample 423 -> 285 launches, the branching `*4+*68/*1` 2,485 -> 1,417).
+ * "k8_side_max_blocks" (default 4096): batches with more step workgroups than this keep to the search's own order.  Persistent batches keep to the search's own order as well.
  * "cyp_cohort_streams" (1..8, default 8): streams sp_cyp_diplotype_cohort spreads its groups of samples over (one host thread each).
  * "k5_block_pairs" (0..1048576, default 4096): sp_cyp_best_chain_pair scores up to this many chain pairs with one workgroup per pair (the few pairs
  * of an ordinary sample: the reads of a pair are shared out over the workgroup), more with one thread per pair; the results are the same.
