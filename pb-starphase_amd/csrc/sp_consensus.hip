@@ -2586,6 +2586,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     B.k8_compound = ctx->k8_compound;
     static const int ctl_prio = std::getenv("SP_K8_CTL_PRIO") ? std::atoi(std::getenv("SP_K8_CTL_PRIO")) : 0, ctl_pad = std::getenv("SP_K8_CTL_LDS_PAD") ? std::atoi(std::getenv("SP_K8_CTL_LDS_PAD")) : 0;      // (experiment switches)
     B.k8_ctl_prio = ctl_prio;
+    static const int ctl_threads = std::getenv("SP_K8_CTL_THREADS") ? std::max(64, std::min(1024, std::atoi(std::getenv("SP_K8_CTL_THREADS")))) : 1024;      // (experiment switch)
     const dim3 grid((uint32_t)n_blocks, (uint32_t)(1 + B.nside)), block(CWAVES * SP_WAVE);
     // (the step kernel's instantiation for batches that fit the device at one workgroup per CU, give or take a few: cons_step_wide_kernel.  A 2,000-read CYP2D6 sample's first batch
     //  has 271 workgroups -- its 2,162 region segments -- and is still faster there)
@@ -2684,7 +2685,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
             if (one_round) hipLaunchKernelGGL(cons_step_wide_kernel<MAXP>, grid, block, 0, st, B);
             else hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
             if (need_reduce) hipLaunchKernelGGL(cons_reduce_kernel<MAXP>, dim3((uint32_t)n_clusters * RSLICES), dim3(512), 0, st, B);
-            hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, st, B);
+            hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(ctl_threads), proc_lds, st, B);
             t_launch += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
             ++pairs;
             uint64_t spins = 0;

@@ -538,7 +538,7 @@ __global__ void k1_seg_retry_cells_kernel(const sp_hla_realign* __restrict__ out
 }
 __global__ __launch_bounds__(256) void k1_seg_retry_finish_kernel(SeqSetView alleles_gene, SeqSetView refs, const int32_t* __restrict__ am, const int32_t* __restrict__ hpc_ref,
                                                                   const uint64_t* __restrict__ hpc_ref_off, const CellDesc* __restrict__ cells, const sp_aln* __restrict__ alns,
-                                                                  const sp_affine_aln* __restrict__ af, uint32_t n_reads, sp_hla_realign* __restrict__ out) {
+                                                                  const sp_affine_aln* __restrict__ af, uint32_t n_reads, sp_hla_realign* __restrict__ out, sp_aln* __restrict__ rm_out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t r = blockIdx.x * 4 + wave;
     if (r >= n_reads) return;
@@ -546,11 +546,80 @@ __global__ __launch_bounds__(256) void k1_seg_retry_finish_kernel(SeqSetView all
     if (c.diag == SP_NO_DIAG) return;
     const sp_aln rm = alns[r];
     if (!rm.ok) return;
+    if (rm_out && lane == 0) { sp_aln w = rm; w.a_len = refs.len[c.a]; w.b_len = c.b_hi - c.b_lo; rm_out[r] = w; }
     sp_hla_realign res = out[r];
     const sp_affine_aln fa = af[r];
     const K1Span sp = k1_span(res.aln, &fa);
     k1_finish_segment(res, rm.ok, rm.nm, rm.a_start, rm.a_end, rm.b_start, rm.b_end, c.b_lo, refs.len[c.a], res.best_allele, c.a, sp.db_start, sp.db_end, sp.t_start, alleles_gene, am, hpc_ref, hpc_ref_off, lane);
     if (lane == 0 && res.status == 0) out[r] = res;
+}
+
+// Seeded mode, the second stage of realign_record in the reference's numbers (round 6).  The read's segment +- 1,000 bases is mapped to the gene's reference by minimap2
+// (gene_aligner.map, src/hla/realigner.rs:231) and the record takes that mapping's query span and target start (:262-283): the library's cell found the placement (rm: ends-free unit
+// cost, wide band when needed); its extent as minimap2 reports it -- two-piece affine gaps, END CLIPPING at the ends of the reference -- is the re-score of that placement on the 256
+// diagonals around it, segment = query, reference = target (sp_rescore_mappings).  k1_seg_rs_prep_kernel lists the placements and cuts the segments out of the reads into a set of
+// their own (the re-score knows whole sequences only: the segment must end where the buffer ends), k1_seg_rs_finish_kernel completes the records from the re-scored extents
+// (tests/hla_expected.py K1Tables.record states the same; against the reference-call-pattern port: tests/test_gpu_concordance.py K1_RECORDS_SAME_MIN).
+__global__ void k1_seg_rs_prep_kernel(const sp_hla_realign* __restrict__ out, uint32_t n_reads, const int32_t* __restrict__ read_len, const sp_affine_aln* __restrict__ af,
+                                      const sp_aln* __restrict__ rm, CellDesc* __restrict__ cells, sp_aln* __restrict__ ref, int32_t* __restrict__ seg_start, int32_t* __restrict__ seg_len) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    CellDesc c; c.a = 0; c.b = r; c.diag = 0; c.max_ed = -1; c.b_lo = 0; c.b_hi = -1;
+    sp_aln w = rm[r];
+    int s0 = 0, sl = 0;
+    const sp_hla_realign o = out[r];
+    if (o.best_allele >= 0 && o.aln.ok && w.ok && (o.status == 0 || o.status == 3)) {
+        const int rlen = read_len[r], buffer = 1000;
+        const sp_affine_aln fa = af[r];
+        const K1Span sp = k1_span(o.aln, &fa);
+        s0 = sp.db_start > buffer ? sp.db_start - buffer : 0;
+        const int buf_end = sp.db_end + buffer < rlen ? sp.db_end + buffer : rlen;
+        sl = buf_end - s0;
+        c.a = (uint32_t)o.gene; c.diag = ((w.b_start - w.a_start) + (w.b_end - w.a_end)) / 2; c.max_ed = SP_MAX_ED;
+    } else w.ok = 0;
+    cells[r] = c; ref[r] = w; seg_start[r] = s0; seg_len[r] = sl;
+}
+// segment r = bases [start[r], start[r] + len[r]) of read r, in the read's own slot of a second word buffer (the set shares the reads' word offsets)
+__global__ void __launch_bounds__(256) k1_seg_slice_kernel(SeqSetView reads, const int32_t* __restrict__ start, const int32_t* __restrict__ len, uint32_t n,
+                                                           uint32_t* __restrict__ out_words, uint32_t* __restrict__ out_nplane) {
+    const int lane = threadIdx.x & 63; const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const uint64_t off = reads.word_off[r];
+    const uint32_t* src = reads.words + off;
+    const uint32_t* nsrc = reads.nplane ? reads.nplane + off : nullptr;
+    const int p0 = start[r], L = len[r];
+    const int nw = ((reads.len[r] + 15) >> 4) + 2;                            // (the read's slot holds at least this many words: its bases + the guard words)
+    const int w0 = p0 >> 4; const uint32_t sh = (uint32_t)(p0 & 15) << 1;
+    for (int j = lane; j < nw; j += 64) {
+        uint32_t v = 0, nv = 0;
+        const int first = j << 4;
+        if (first < L) {
+            v = __builtin_amdgcn_alignbit(src[w0 + j + 1], src[w0 + j], sh);
+            if (nsrc) nv = __builtin_amdgcn_alignbit(nsrc[w0 + j + 1], nsrc[w0 + j], sh);
+            const int rem = L - first;
+            if (rem < 16) { const uint32_t m = (1u << (rem << 1)) - 1; v &= m; nv &= m; }
+        }
+        out_words[off + j] = v;
+        if (out_nplane) out_nplane[off + j] = nv;
+    }
+}
+__global__ __launch_bounds__(256) void k1_seg_rs_finish_kernel(SeqSetView alleles_gene, SeqSetView refs, const int32_t* __restrict__ am, const int32_t* __restrict__ hpc_ref,
+                                                               const uint64_t* __restrict__ hpc_ref_off, const CellDesc* __restrict__ cells, const int32_t* __restrict__ seg_start,
+                                                               const sp_affine_aln* __restrict__ seg_af, const sp_affine_aln* __restrict__ af, uint32_t n_reads, sp_hla_realign* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * 4 + wave;
+    if (r >= n_reads) return;
+    const CellDesc c = cells[r];
+    if (c.max_ed < 0) return;
+    const sp_affine_aln sa = seg_af[r];
+    if (sa.score <= 0) return;                                              // (nothing aligns the reference's way: the record keeps the cell's extent)
+    sp_hla_realign res = out[r];
+    res.status = 3; res.seg_start = 0; res.seg_end = 0; res.dna_offset = 0; res.hpc_offset = 0;
+    const sp_affine_aln fa = af[r];
+    const K1Span sp = k1_span(res.aln, &fa);
+    // the re-scored mapping: a_* on the query (the segment), b_* on the target (the reference)
+    k1_finish_segment(res, 1, sa.nm, sa.b_start, sa.b_end, sa.a_start, sa.a_end, seg_start[r], refs.len[c.a], res.best_allele, c.a, sp.db_start, sp.db_end, sp.t_start, alleles_gene, am, hpc_ref, hpc_ref_off, lane);
+    if (lane == 0) out[r] = res;
 }
 
 // K1 finalize: one wavefront per read: full alignment of the accepted allele, segment +-1000 against the
@@ -563,7 +632,7 @@ __global__ __launch_bounds__(256) void k1_finalize_kernel(SeqSetView alleles_fwd
                                                           const uint64_t* __restrict__ hpc_ref_off,
                                                           const int32_t* __restrict__ best_in, uint32_t n_reads,
                                                           sp_hla_realign* __restrict__ out, int slot_words, const sp_aln* __restrict__ aln_in,
-                                                          const sp_affine_aln* __restrict__ af_in) {
+                                                          const sp_affine_aln* __restrict__ af_in, sp_aln* __restrict__ rm_out) {
     extern __shared__ uint32_t lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* slot = lds + wave * slot_words;
@@ -613,6 +682,10 @@ __global__ __launch_bounds__(256) void k1_finalize_kernel(SeqSetView alleles_fwd
             spw::CellOut rm;
             spw::wfa_cell<false, HASN>(in2, slot, slot_words, lane, nullptr, nullptr, rm);
             k1_finish_segment(res, rm.ok, rm.nm, rm.a_start, rm.a_end, rm.b_start, rm.b_end, buf_start, reflen, a, g, db_start, db_end, sp.t_start, alleles_gene, am, hpc_ref, hpc_ref_off, lane);
+            if (rm_out && lane == 0) {                                      // (seeded mode: the segment's mapping on the reference is re-scored the reference's way, k1_seg_rs_*)
+                sp_aln w; w.ok = rm.ok; w.nm = rm.nm; w.a_start = rm.a_start; w.a_end = rm.a_end; w.b_start = rm.b_start; w.b_end = rm.b_end; w.a_len = reflen; w.b_len = buf_end - buf_start;
+                rm_out[r] = w;
+            }
         }
     }
     if (lane == 0) out[r] = res;
@@ -1237,18 +1310,24 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
         if (d_win) hipLaunchKernelGGL(k1_winner_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_win, R, d_best);
         else hipLaunchKernelGGL(k1_reduce_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, d_cells, db->dna_fwd->d_len, db->d_order, NA, R, d_best);
     }
+    sp_aln* d_rm = nullptr;                                    // seeded mode: the placement of every read's segment on its gene's reference (for the second stage's re-score)
+    if (rc == SP_OK && seeded) {
+        d_rm = (sp_aln*)sp_pool(ctx, "k1_seg_rm", (size_t)R * sizeof(sp_aln));
+        if (!d_rm) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+        else (void)hipMemsetAsync(d_rm, 0, (size_t)R * sizeof(sp_aln), ctx->stream);
+    }
     if (rc == SP_OK) {
         ProfScope ps(ctx, "k1_finalize", R);
         if (hasn) {
             (void)hipFuncSetAttribute((const void*)k1_finalize_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             hipLaunchKernelGGL(k1_finalize_kernel<true>, dim3((R + 3) / 4), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), db->dna_gene->view(),
                                db->ref_fwd->view(), reads->view(), db->d_gene_of, db->d_off_fwd, d_rg, (int)G, db->d_am, db->d_hpc_ref, db->d_hpc_ref_off,
-                               d_best, R, d_out, slot_words, d_win_aln, seeded ? d_win_af : nullptr);
+                               d_best, R, d_out, slot_words, d_win_aln, seeded ? d_win_af : nullptr, d_rm);
         } else {
             (void)hipFuncSetAttribute((const void*)k1_finalize_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             hipLaunchKernelGGL(k1_finalize_kernel<false>, dim3((R + 3) / 4), dim3(256), lds_bytes, ctx->stream, db->dna_fwd->view(), db->dna_gene->view(),
                                db->ref_fwd->view(), reads->view(), db->d_gene_of, db->d_off_fwd, d_rg, (int)G, db->d_am, db->d_hpc_ref, db->d_hpc_ref_off,
-                               d_best, R, d_out, slot_words, d_win_aln, seeded ? d_win_af : nullptr);
+                               d_best, R, d_out, slot_words, d_win_aln, seeded ? d_win_af : nullptr, d_rm);
         }
         if (hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1_finalize launch failed");
     }
@@ -1262,8 +1341,33 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
             hipLaunchKernelGGL(k1_seg_retry_cells_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, reads->d_len, d_rg, (int)G, d_win_af, d_sc, d_sa);
             rc = sp_launch_cells_wide(ctx, db->ref_fwd, reads, d_sc, R, d_sa);
             if (rc == SP_OK) hipLaunchKernelGGL(k1_seg_retry_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, db->dna_gene->view(), db->ref_fwd->view(), db->d_am, db->d_hpc_ref,
-                                                db->d_hpc_ref_off, d_sc, d_sa, d_win_af, R, d_out);
+                                                db->d_hpc_ref_off, d_sc, d_sa, d_win_af, R, d_out, d_rm);
             if (rc == SP_OK && hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1 segment retry launch failed");
+        }
+    }
+    if (rc == SP_OK && seeded) {
+        // the second stage in the reference's numbers: the segments' placements re-scored (segment = query, reference = target), the records completed from those extents
+        ProfScope ps(ctx, "k1_seg_rescore", R);
+        const size_t words = (size_t)reads->h_word_off[R] + SP_SEQ_PAD_WORDS;
+        CellDesc* d_c2 = (CellDesc*)sp_pool(ctx, "k1_segrs_cells", (size_t)R * sizeof(CellDesc));
+        sp_aln* d_r2 = (sp_aln*)sp_pool(ctx, "k1_segrs_ref", (size_t)R * sizeof(sp_aln));
+        int32_t* d_s0 = (int32_t*)sp_pool(ctx, "k1_segrs_start", (size_t)R * 4); int32_t* d_sl = (int32_t*)sp_pool(ctx, "k1_segrs_len", (size_t)R * 4);
+        uint32_t* d_sw = (uint32_t*)sp_pool(ctx, "k1_segrs_words", words * 4);
+        uint32_t* d_sn = reads->d_nplane ? (uint32_t*)sp_pool(ctx, "k1_segrs_nplane", words * 4) : nullptr;
+        sp_affine_aln* d_saf = (sp_affine_aln*)sp_pool(ctx, "k1_segrs_af", (size_t)R * sizeof(sp_affine_aln));
+        if (!d_c2 || !d_r2 || !d_s0 || !d_sl || !d_sw || (reads->d_nplane && !d_sn) || !d_saf) rc = sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "realign buffers");
+        else {
+            hipLaunchKernelGGL(k1_seg_rs_prep_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, d_out, R, reads->d_len, d_win_af, d_rm, d_c2, d_r2, d_s0, d_sl);
+            hipLaunchKernelGGL(k1_seg_slice_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, reads->view(), d_s0, d_sl, R, d_sw, d_sn);
+            sp_seqset segs;                                    // the segments as a set of their own: the reads' slots in a second buffer, their own lengths
+            segs.ctx = ctx; segs.n = R; segs.has_n = reads->has_n; segs.d_words = d_sw; segs.d_nplane = d_sn; segs.d_word_off = reads->d_word_off; segs.d_len = d_sl; segs.max_len = reads->max_len;
+            segs.h_len = reads->h_len; segs.h_word_off = reads->h_word_off;
+            const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
+            rc = sp_rescore_mappings(ctx, db->ref_fwd, &segs, d_c2, d_r2, R, true, ao, 256, d_saf, "k1_segrs", SP_MAX_ED + 1, 1);
+            segs.d_words = nullptr; segs.d_nplane = nullptr; segs.d_word_off = nullptr; segs.d_len = nullptr;       // (pooled buffers: the set owns nothing)
+            if (rc == SP_OK) hipLaunchKernelGGL(k1_seg_rs_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, db->dna_gene->view(), db->ref_fwd->view(), db->d_am, db->d_hpc_ref,
+                                                db->d_hpc_ref_off, d_c2, d_s0, d_saf, d_win_af, R, d_out);
+            if (rc == SP_OK && hipGetLastError() != hipSuccess) rc = sp_fail(ctx, SP_ERR_HIP, "k1 segment re-score launch failed");
         }
     }
     // 3b. the winners re-scored the reference's way (two-piece affine gaps, end clipping): the numbers minimap2 reports for the read and its allele

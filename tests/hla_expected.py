@@ -117,11 +117,19 @@ class K1Tables:
         # (seeded mode: a segment the 64-diagonal cell loses -- a long insertion / deletion against the reference -- runs again on the wide band, as the chains' cells do)
         rm, _ = oracle.wfa(self.refs[g], seg, anch[g][0] - buf_s, 511, events=False, retry=1 if seeded is not None else 0)
         reflen = len(self.refs[g])
-        if rm.ok and score_value(reflen, rm.nm, reflen - (rm.a_end - rm.a_start)) < 1.0:
-            adj_s, adj_e = buf_s + rm.b_start, buf_s + rm.b_end
+        rm_nm, rm_a_start, rm_a_end, rm_b_start, rm_b_end = rm.nm, rm.a_start, rm.a_end, rm.b_start, rm.b_end
+        if seeded is not None and rm.ok:
+            # round 6: the second stage in the reference's numbers -- the segment's placement on the reference re-scored as minimap2 reports a mapping (two-piece affine gaps,
+            # end clipping; segment = query, reference = target) on the 256 diagonals around it: its query span and target start are what realign_record takes (realigner.rs:262-283)
+            twice2 = (rm.a_start - rm.b_start) + (rm.a_end - rm.b_end)
+            af = oracle_ffi.oracle_affine(oracle, self.refs[g], seg, -int(twice2 / 2), 256, 1)      # (score, nm, t_start, t_end, q_start, q_end)
+            if af[0] > 0:
+                _sc2, rm_nm, rm_a_start, rm_a_end, rm_b_start, rm_b_end = (int(x) for x in af)
+        if rm.ok and score_value(reflen, rm_nm, reflen - (rm_a_end - rm_a_start)) < 1.0:
+            adj_s, adj_e = buf_s + rm_b_start, buf_s + rm_b_end
             am = self.am(best)
             if adj_s < db_s or am is None:
-                d = rm.a_start
+                d = rm_a_start
                 h = oracle.hpc_pos(fx.gene_ref[g], d)
             else:
                 added = max(am[1] - am[0], 0)

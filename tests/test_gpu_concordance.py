@@ -29,9 +29,9 @@ K1_SAME_ALLELE = 10000          # the accepted allele of every read is the seede
 K1_MM2_NUMBERS = 10000          # ... with the port's (NM, allele span)
 # realign_record's whole result (status; segment start / end, DNA and HPC offset) against the port with the SECOND stage in the reference's call pattern too (round 6:
 # cpu_port_seeded.record_mm2 -- the segment +- 1,000 bases and, where needed, the allele mapped to the gene's reference with mm.map_pair + select_best_mapping,
-# src/hla/realigner.rs:231-317).  The library places the segment and the allele on the reference with its own cell (ends-free unit cost, wide-band retry): where minimap2
-# clips a near-end mismatch at an end of the reference the segment or the offset differs by a few bases.  Measured on MI355X; gated from below.
-K1_RECORDS_SAME_MIN = 9600
+# src/hla/realigner.rs:231-317).  EXACT since the library takes the segment's extent on the reference from the re-score of its placement (two-piece affine gaps, minimap2's end
+# clipping: sp_hla.hip k1_seg_rs_*); with the cell's own ends-free extent 9,735 records were the port's (differences of up to 9 bases at the ends of the reference).
+K1_RECORDS_SAME_MIN = 10000
 K1_EXHAUSTIVE_SAME_ALLELE = 8262  # context option k1_best_n = 0: the exact argmin prefers partial alleles the seeded map never base-aligns
 # K3: every one of the 12,000 reads of the six scenarios has the port's whole hit list (template, start, end) with the port's nm / unmapped.  Round 5: the hits that survive
 # the collapse carry their re-scored numbers -- 11,998 reads (rounds 3-4, unit-cost counts: 97.5 - 98.3 %).  Round 6: the placements whose filter or collapse decision a handful
