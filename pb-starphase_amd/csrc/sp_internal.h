@@ -166,7 +166,7 @@ int sp_launch_cells(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B,
 int sp_launch_affine(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const void* d_pairs /* sp_pair rows */, uint64_t n_pairs, const sp_affine_opts& o, int band,
                      sp_affine_aln* d_out, const char* prof_name, const uint32_t* d_n_live = nullptr, const void* d_wins = nullptr, const void* d_mids = nullptr);   // sp_affine.hip: two-piece affine re-score, pairs and results in device memory
 int sp_rescore_mappings(sp_ctx* ctx, const sp_seqset* Aw, const sp_seqset* Bw, const CellDesc* d_cells, const sp_aln* d_ref, uint64_t n, bool target_is_a,
-                        const sp_affine_opts& o, int band, sp_affine_aln* d_out, const char* prefix, uint32_t stride, int trace_retry_wide = 0, const sp_aln* d_tr_in = nullptr, const uint32_t* d_ev_in = nullptr);   // sp_affine.hip: mappings the caller holds, re-scored (no DP for isolated edits); trace_retry_wide: the trace of a mapping the 64-diagonal cell loses runs on the wide band
+                        const sp_affine_opts& o, int band, sp_affine_aln* d_out, const char* prefix, uint32_t stride, int trace_retry_wide = 0, const sp_aln* d_tr_in = nullptr, const uint32_t* d_ev_in = nullptr, int ends_only = 0);   // sp_affine.hip: mappings the caller holds, re-scored (no DP for isolated edits); trace_retry_wide: the trace of a mapping the 64-diagonal cell loses runs on the wide band; ends_only > 0: the caller takes the EXTENT of the mapping only -- edits that far from both ends of the alignment never take the DP (af_classify_kernel)
 constexpr uint32_t SP_ANCHOR_SKIP = 0xFFFFFFFFu;     // b index of a pair of a device-made pair list that sp_launch_anchor is to skip (votes 0, diagonal 0)
 int sp_launch_cells_wide(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const CellDesc* d_cells, uint64_t n_cells, sp_aln* d_out);
 int sp_launch_pack_on(hipStream_t stream, int num_cus, int format, const void* d_src, const uint64_t* d_off, const uint64_t* d_word_off, const int32_t* d_len, uint32_t n,
