@@ -94,8 +94,9 @@ int32_t sp_ctx_synchronize(sp_ctx* ctx);
  * persistent kernels (step workgroups and one control workgroup per problem on a second stream, resident for the length of the batch; the two sides hand over through one word
  * each in memory: write-through stores, `sc1` loads and memory-side atomics, no L2 fences -- gfx950 behaviour) instead of a launch pair per step -- the
  * same search, bit for bit.  0 never, 1 whenever a batch qualifies, 2 = the library decides: batches of at most eight problems, when the HIP runtime came up with >= 16 hardware
- * queues (a batch's two kernels wait for each other: GPU_MAX_HW_QUEUES, sp_ctx_get_info), a heavy batch (a single large sample) only while nothing else of the process runs a
- * consensus on the device, light ones (a cohort call's late levels) unless single-sample batches ran side by side within the last second.  The budget of CUs is counted per
+ * queues (a batch's two kernels wait for each other: GPU_MAX_HW_QUEUES, sp_ctx_get_info), LIGHT batches only (at most 64 resident workgroups: a cohort call's late levels, a
+ * small sample) and not while single-sample batches ran side by side within the last second; a heavy batch (a single large sample) runs as launch pairs since round 6 -- a launch
+ * carries side orders and branching windows, the resident workgroups do not.  The budget of CUs is counted per
  * process (several processes on one device: set 0).  A batch whose control workgroups have not all started within half a second runs as launch pairs instead, by itself (the
  * context then stays away from the mode for 64 batches and says so in sp_ctx_get_info().warning); a search that exceeds the launch-pair loop's own step bound ends the batch
  * with the same error in both modes; no path returns while one of the two kernels is still running.

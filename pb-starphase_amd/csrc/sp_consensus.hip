@@ -2417,7 +2417,9 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     for (uint32_t p = 0; p < n_prob; ++p) footprint += ((probs[p].read_idx ? probs[p].n : probs[p].reads->n) + CWAVES - 1) / CWAVES;
     const bool light = footprint <= (uint64_t)PERSIST_LIGHT;
     const bool persist_wanted = ctx->k8_persistent == 1 || (ctx->k8_persistent == 2 && n_prob <= 8 && ctx->hw_queues_effective >= 16 && ctx->k8_persist_failures < 3 &&
-                                                            !in_flight.recent_overlap && (light || in_flight.others == 0));
+                                                            !in_flight.recent_overlap && light);      // (round 6: a heavy batch -- a single large sample -- runs faster as launch pairs
+                                                                                                               //  now that a launch carries side orders and branching windows, which the resident
+                                                                                                               //  workgroups do not: one CYP2D6 lane beside the HLA lane 183k -> 199k reads/s)
     if (ctx->k8_persist_backoff > 0) --ctx->k8_persist_backoff;
     else if (persist_wanted && n_prob > 0) {
         uint64_t blocks1 = 0; bool small = true;
