@@ -452,6 +452,8 @@ int osp_cyp_find_base_type(const uint8_t* seq, int seq_len, int n_templates, con
  * is re-scored if it survives them and then has to pass the max_ed_frac filter on its re-scored numbers once more. */
 #define OSP_K3_CAP_HI 0.056
 #define OSP_K3_OVL 0.85
+#define OSP_K3_RETRY_VOTES 128
+#define OSP_K3_RETRY_HOLE 500
 static void k3_rescore_hit(const uint8_t* seq, int seq_len, const uint8_t* const* tmpl, const int32_t* tmpl_len, osp_region_hit* h) {
     const int t = h->template_idx;
     const osp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
@@ -470,23 +472,64 @@ int osp_cyp_find_base_type_ex(const uint8_t* seq, int seq_len, int n_templates, 
     int n_un = 0, un_cap = n_templates * OSP_CYP_TOPK + 1;
     osp_region_hit* un = (osp_region_hit*)malloc(sizeof(osp_region_hit) * (size_t)un_cap);
     uint8_t* done = (uint8_t*)calloc((size_t)un_cap, 1);                                       /* the placement carries its re-scored numbers */
+    /* every placement of every template (top-k anchors, 64 diagonals, the edit cap of max_ed_frac) */
+    osp_aln* al = (osp_aln*)calloc((size_t)n_templates * OSP_CYP_TOPK, sizeof(osp_aln));
+    uint8_t* al_ok = (uint8_t*)calloc((size_t)n_templates * OSP_CYP_TOPK, 1);
+    int* d0 = (int*)calloc((size_t)n_templates, sizeof(int)); int* v0 = (int*)calloc((size_t)n_templates, sizeof(int));
     for (int t = 0; t < n_templates; ++t) {
         int diags[OSP_CYP_TOPK], votes[OSP_CYP_TOPK];
         int np = osp_anchor_topk(tmpl[t], tmpl_len[t], seq, seq_len, OSP_CYP_TOPK, diags, votes);      /* seq_pos - template_pos */
+        if (np > 0) { d0[t] = diags[0]; v0[t] = votes[0]; }
         for (int k = 0; k < np; ++k) {
             if (votes[k] < OSP_CYP_MIN_VOTES) continue;
-            osp_aln al;
             /* nm <= max_ed_frac * aligned span <= 0.05 * template length (haplotyper.rs:160,228-232): beyond that the hit is dropped anyway */
             int cap = (int)(0.05 * (double)tmpl_len[t]) + 1; if (cap > OSP_MAX_ED) cap = OSP_MAX_ED;
-            if (!osp_wfa(tmpl[t], tmpl_len[t], seq, seq_len, diags[k], cap, &al, NULL, NULL)) continue;
-            osp_region_hit h;
-            h.template_idx = t; h.start = al.b_start; h.end = al.b_end;
-            h.seq_len = tmpl_len[t]; h.nm = al.nm; h.unmapped = tmpl_len[t] - (al.a_end - al.a_start);
-            h.clip_start = al.a_start; h.clip_end = tmpl_len[t] - al.a_end;
-            if (hit_score(&h, is_penalized_type(tmpl_type[t])) > (rescore ? OSP_K3_CAP_HI : max_ed_frac)) continue;           /* :228-232 ; Forward only */
-            un[n_un++] = h;
+            if (osp_wfa(tmpl[t], tmpl_len[t], seq, seq_len, diags[k], cap, &al[t * OSP_CYP_TOPK + k], NULL, NULL)) al_ok[t * OSP_CYP_TOPK + k] = 1;
         }
     }
+    if (rescore) {
+        /* the wide-band retry (round 6): minimap2 chains a template across a 40 - 120 base insertion or deletion in the sequence; the 64-diagonal cell leaves its band there and
+         * is lost, and so is every other template over that stretch.  Every template that is lost altogether although it anchors strongly (>= OSP_K3_RETRY_VOTES votes on its best
+         * diagonal) and whose expected span has >= OSP_K3_RETRY_HOLE bases that NO placement covers runs once more on 256 diagonals around that anchor, same edit cap */
+        int n_iv = 0, any_lost = 0;
+        int* iv = (int*)malloc(sizeof(int) * 2 * (size_t)(n_templates * OSP_CYP_TOPK + 1));
+        for (int t = 0; t < n_templates; ++t) {
+            int placed = 0;
+            for (int k = 0; k < OSP_CYP_TOPK; ++k) if (al_ok[t * OSP_CYP_TOPK + k]) { placed = 1; iv[2 * n_iv] = al[t * OSP_CYP_TOPK + k].b_start; iv[2 * n_iv + 1] = al[t * OSP_CYP_TOPK + k].b_end; ++n_iv; }
+            if (!placed && v0[t] >= OSP_K3_RETRY_VOTES) any_lost = 1;
+        }
+        if (any_lost) {
+            for (int i = 1; i < n_iv; ++i) {                                                      /* by (start, end) */
+                const int s0 = iv[2 * i], e0 = iv[2 * i + 1]; int j = i - 1;
+                while (j >= 0 && (iv[2 * j] > s0 || (iv[2 * j] == s0 && iv[2 * j + 1] > e0))) { iv[2 * j + 2] = iv[2 * j]; iv[2 * j + 3] = iv[2 * j + 1]; --j; }
+                iv[2 * j + 2] = s0; iv[2 * j + 3] = e0;
+            }
+            for (int t = 0; t < n_templates; ++t) {
+                int placed = 0;
+                for (int k = 0; k < OSP_CYP_TOPK; ++k) placed |= al_ok[t * OSP_CYP_TOPK + k];
+                if (placed || v0[t] < OSP_K3_RETRY_VOTES) continue;
+                const int s0 = d0[t] > 0 ? d0[t] : 0, e0 = d0[t] + tmpl_len[t] < seq_len ? d0[t] + tmpl_len[t] : seq_len;
+                int uncovered = 0, at = s0;
+                for (int i = 0; i < n_iv; ++i) { if (iv[2 * i + 1] <= at) continue; if (iv[2 * i] >= e0) break; if (iv[2 * i] > at) uncovered += iv[2 * i] - at; if (iv[2 * i + 1] > at) at = iv[2 * i + 1]; if (at >= e0) break; }
+                if (at < e0) uncovered += e0 - at;
+                if (uncovered < OSP_K3_RETRY_HOLE) continue;
+                int cap = (int)(0.05 * (double)tmpl_len[t]) + 1; if (cap > OSP_MAX_ED) cap = OSP_MAX_ED;
+                if (osp_wfa_band(tmpl[t], tmpl_len[t], seq, seq_len, d0[t], cap, OSP_WIDE_BAND, &al[t * OSP_CYP_TOPK], NULL, NULL)) al_ok[t * OSP_CYP_TOPK] = 1;
+            }
+        }
+        free(iv);
+    }
+    for (int t = 0; t < n_templates; ++t) for (int k = 0; k < OSP_CYP_TOPK; ++k) {
+        if (!al_ok[t * OSP_CYP_TOPK + k]) continue;
+        const osp_aln* a = &al[t * OSP_CYP_TOPK + k];
+        osp_region_hit h;
+        h.template_idx = t; h.start = a->b_start; h.end = a->b_end;
+        h.seq_len = tmpl_len[t]; h.nm = a->nm; h.unmapped = tmpl_len[t] - (a->a_end - a->a_start);
+        h.clip_start = a->a_start; h.clip_end = tmpl_len[t] - a->a_end;
+        if (hit_score(&h, is_penalized_type(tmpl_type[t])) > (rescore ? OSP_K3_CAP_HI : max_ed_frac)) continue;           /* :228-232 ; Forward only */
+        un[n_un++] = h;
+    }
+    free(al); free(al_ok); free(d0); free(v0);
     if (rescore) {
         /* the critical placements, by the contract's own counts: near the cap, or not clearly beaten by a rival that overlaps them */
         uint8_t* crit = (uint8_t*)calloc((size_t)n_un + 1, 1);

@@ -639,7 +639,7 @@ __global__ void cyp_build_cells_kernel(const uint32_t* __restrict__ a_idx, const
 
 // placements of a list of (A, B) pairs (A = indexed query side, B = target side), result[pair][k]; a_period as in sp_launch_anchor
 static int cyp_align_pairs(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, const std::vector<uint32_t>& ai, const std::vector<uint32_t>& bi, uint32_t a_period,
-                           int topk, double frac_cap, int retry_wide, const char* prof, std::vector<sp_aln>& out) {
+                           int topk, double frac_cap, int retry_wide, const char* prof, std::vector<sp_aln>& out, std::vector<int32_t>* diag_out = nullptr, std::vector<int32_t>* votes_out = nullptr) {
     const uint64_t n_pairs = ai.size(), n_cells = n_pairs * (uint64_t)topk;
     out.assign(n_cells, sp_aln{});
     if (n_pairs == 0) return SP_OK;
@@ -659,17 +659,23 @@ static int cyp_align_pairs(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, 
     rc = sp_launch_cells(ctx, A, B, d_cells, n_cells, d_alns, nullptr, 0, prof, retry_wide);
     if (rc) return rc;
     (void)hipMemcpyAsync(out.data(), d_alns, n_cells * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);
+    if (diag_out && votes_out) {                          // (the anchors too: the region search looks for reads whose templates were all lost over a stretch, cyp_find_regions)
+        diag_out->resize(n_cells); votes_out->resize(n_cells);
+        (void)hipMemcpyAsync(diag_out->data(), d_d, n_cells * 4, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipMemcpyAsync(votes_out->data(), d_v, n_cells * 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("cyp placements: ") + hipGetErrorString(e));
     return SP_OK;
 }
 
 // all |A| x |B| placements, result[b][a][k]
-static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, int retry_wide, const char* prof, std::vector<sp_aln>& out) {
+static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, int retry_wide, const char* prof, std::vector<sp_aln>& out,
+                         std::vector<int32_t>* diag_out = nullptr, std::vector<int32_t>* votes_out = nullptr) {
     const uint64_t nA = A->n, nB = B->n, n_pairs = nA * nB;
     std::vector<uint32_t> ai(n_pairs), bi(n_pairs);
     for (uint64_t b = 0; b < nB; ++b) for (uint64_t a = 0; a < nA; ++a) { ai[b * nA + a] = (uint32_t)a; bi[b * nA + a] = (uint32_t)b; }
-    return cyp_align_pairs(ctx, A, B, ai, bi, (uint32_t)nA, topk, frac_cap, retry_wide, prof, out);
+    return cyp_align_pairs(ctx, A, B, ai, bi, (uint32_t)nA, topk, frac_cap, retry_wide, prof, out, diag_out, votes_out);
 }
 
 static inline double cyp_score(int seq_len, int nm, int unmapped, bool penalize) {        // MappingStats::custom_score (data_types/mapping.rs:60-84)
@@ -794,16 +800,68 @@ extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, 
 // ALL 45,365 placements of a 2,000-read sample cost 39 ms (round 5) -- keeps the library's counts through the filter and the collapse, is re-scored if it survives them and then has
 // to pass the filter on its re-scored numbers once more.  The drivers inside the library take the same path.
 constexpr double K3_CAP_HI = 0.056, K3_OVL = 0.85;
+constexpr int K3_RETRY_VOTES = 128, K3_RETRY_HOLE = 500;
 static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
                                 double max_missing_frac, sp_region_hit* hits, uint64_t hits_cap, uint64_t* n_hits, bool rescore) {
     if (!ctx || !templates || !reads || !n_hits || (templates->n && !template_type) || (hits_cap && !hits)) return SP_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     *n_hits = 0;
-    std::vector<sp_aln> alns;
-    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, 0.05, 0, "k3_region_cells", alns);
+    std::vector<sp_aln> alns; std::vector<int32_t> adiag, avotes;
+    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, 0.05, 0, "k3_region_cells", alns, &adiag, &avotes);
     if (rc) return rc;
     const uint32_t T = templates->n;
     auto penalized_type = [](int t) { return t == SP_CYP_DELETION || t == SP_CYP_REP6 || t == SP_CYP_REP7; };   // haplotyper.rs:185-191
+    // THE WIDE-BAND RETRY (round 6).  minimap2 chains a template across a 40 - 120 base insertion or deletion in the read (bw 500, max_gap 10000); the 64-diagonal cell leaves
+    // its band there and is lost -- and so is every other template over that stretch of the read.  A cell does not know whether it ran out of band or of edits (17 % of the
+    // strongly anchored pairs are lost: the other gene copy's templates, which drift out of the band over a few kb and lose the collapse to the right copy's anyway), but the READ
+    // shows it: a stretch of it where a template anchors strongly (>= K3_RETRY_VOTES 16-mer votes on its best diagonal) and NO template was placed.  Every template lost over such
+    // a hole (>= K3_RETRY_HOLE uncovered bases of its expected span) runs once more on 256 diagonals around its best anchor, same edit cap; reads without a hole -- all reads
+    // of the six scenarios -- cost nothing.  (oracle/cyp.c osp_cyp_find_base_type_ex states the same rule.)
+    if (rescore) {
+        std::vector<CellDesc> retry; std::vector<uint32_t> retry_at;
+        std::vector<std::pair<int, int>> iv;
+        for (uint32_t r = 0; r < reads->n; ++r) {
+            const int rlen = reads->h_len[r];
+            if (rlen == 0) continue;
+            iv.clear();
+            bool any_lost = false;
+            for (uint32_t t = 0; t < T; ++t) {
+                bool placed = false;
+                for (int k = 0; k < CYP_TOPK; ++k) { const sp_aln& al = alns[((size_t)r * T + t) * CYP_TOPK + k]; if (al.ok) { placed = true; iv.push_back({ al.b_start, al.b_end }); } }
+                if (!placed && avotes[((size_t)r * T + t) * CYP_TOPK] >= K3_RETRY_VOTES) any_lost = true;
+            }
+            if (!any_lost) continue;
+            std::sort(iv.begin(), iv.end());
+            for (uint32_t t = 0; t < T; ++t) {
+                const size_t c0 = ((size_t)r * T + t) * CYP_TOPK;
+                bool placed = false;
+                for (int k = 0; k < CYP_TOPK; ++k) placed = placed || alns[c0 + k].ok;
+                if (placed || avotes[c0] < K3_RETRY_VOTES) continue;
+                const int tlen = templates->h_len[t], d0 = adiag[c0];                                    // read position - template position
+                const int s0 = std::max(0, d0), e0 = std::min(rlen, d0 + tlen);
+                int uncovered = 0, at = s0;
+                for (const auto& x : iv) { if (x.second <= at) continue; if (x.first >= e0) break; if (x.first > at) uncovered += x.first - at; at = std::max(at, x.second); if (at >= e0) break; }
+                if (at < e0) uncovered += e0 - at;
+                if (uncovered < K3_RETRY_HOLE) continue;
+                int cap = (int)(0.05 * (double)tlen) + 1; if (cap > SP_MAX_ED) cap = SP_MAX_ED;
+                retry.push_back(CellDesc{ t, r, d0, cap, 0, -1 }); retry_at.push_back((uint32_t)c0);
+            }
+        }
+        if (!retry.empty()) {
+            const size_t nr = retry.size();
+            CellDesc* d_rc = (CellDesc*)sp_pool(ctx, "k3_retry_cells", nr * sizeof(CellDesc)); sp_aln* d_ro = (sp_aln*)sp_pool(ctx, "k3_retry_alns", nr * sizeof(sp_aln));
+            if (!d_rc || !d_ro) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "find_regions: retry buffers");
+            std::vector<sp_aln> got(nr);
+            SP_HIP_CHECK(ctx, hipMemcpyAsync(d_rc, retry.data(), nr * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream));
+            SP_HIP_CHECK(ctx, hipMemsetAsync(d_ro, 0, nr * sizeof(sp_aln), ctx->stream));
+            { ProfScope ps(ctx, "k3_retry_wide", nr); rc = sp_launch_cells_wide(ctx, templates, reads, d_rc, nr, d_ro); }
+            if (rc != SP_OK) return rc;
+            SP_HIP_CHECK(ctx, hipMemcpyAsync(got.data(), d_ro, nr * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream));
+            SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            for (size_t x = 0; x < nr; ++x) if (got[x].ok) alns[retry_at[x]] = got[x];
+            if (ctx->profiling) ctx->prof["k3_retried_pairs"].cells += nr;
+        }
+    }
     auto own_score = [&](const sp_region_hit& h) { return cyp_score(h.seq_len, h.nm, h.unmapped, penalized_type(template_type[h.template_idx])); };
     auto overlap = [](const sp_region_hit& u, const sp_region_hit& v) {                                       // overlap_score (haplotyper.rs:877-892)
         const int min_end = std::min(u.end, v.end), max_start = std::max(u.start, v.start);

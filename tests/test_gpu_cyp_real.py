@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import cyp_cases_real as cr
+import oracle_ffi as of
 
 pytestmark = pytest.mark.gpu
 
@@ -251,3 +252,56 @@ def test_gave_up_is_reported(pkg, gpu_ctx):
     assert isinstance(out["gave_up"], bool)
     if out["gave_up"]:
         assert out["cons"][0] == ""
+
+
+def test_reads_with_long_indels_keep_their_regions(oracle, pkg, gpu_ctx):
+    """K3's twin of tests/test_gpu_seeded.py::test_reads_with_long_indels_are_mapped_across_them.  minimap2 chains a template across a 40 - 100 base deletion or insertion in
+    the read (bw 500, max_gap 10000), so find_base_type_in_sequence (src/cyp2d6/haplotyper.rs:193-249) still reports the gene's region; the library's 64-diagonal cell is lost
+    there, for EVERY template -- a hole in the read that strongly anchored templates expect to cover --, and the templates lost over the hole run once more on 256 diagonals
+    (sp_cyp.hip cyp_find_regions).  Held to: oracle/cyp.c (the same rule, bit for bit) and the reference-call-pattern port on oracle/mm2.c (template, start, end, nm, unmapped
+    of every hit); the hit of the gene spans the indel."""
+    import cpu_port_cyp as cpc
+    from pb_starphase_amd import synth
+    cfg, gene_def = cr.load_db()
+    locus = synth.Chr22Locus(cfg, gene_def, seed=3)
+    db = pkg.ffi.CypDb(gpu_ctx, cfg, gene_def, locus.sequence, locus.start)
+    tm = db.templates()
+    tseqs, ttype = [t[3] for t in tm], np.array([t[0] for t in tm], np.int32)
+    T = gpu_ctx.upload(tseqs)
+    rng = np.random.default_rng(33)
+    name, haps, _exp = cr.scenarios(locus)[0]                               # *1/*2
+    base_reads = [r for r in locus.sample(np.random.default_rng(7), haps, 400, lo=7000, hi=9000)]
+    hits0 = gpu_ctx.cyp_find_regions(T, ttype, gpu_ctx.upload(base_reads), 0.5)
+    reads, kinds, where = [], [], []
+    for r, read in enumerate(base_reads):
+        mine = [h for h in hits0 if int(h["read"]) == r and int(h["end"]) - int(h["start"]) >= 4000]
+        if not mine or len(reads) >= 48:
+            continue
+        h = mine[0]
+        k = int(rng.integers(int(h["start"]) + 1200, int(h["end"]) - 1200))
+        size = (40, 80, 100)[len(reads) % 3]
+        if len(reads) % 2:
+            reads.append(read[:k] + read[k + size:]); kinds.append(-size)
+        else:
+            reads.append(read[:k] + "".join(rng.choice(list("ACGT"), size)) + read[k:]); kinds.append(size)
+        where.append(k)
+    assert len(reads) >= 24
+    R = gpu_ctx.upload(reads)
+    gpu_ctx.profile_reset()
+    hits = gpu_ctx.cyp_find_regions(T, ttype, R, 0.5)
+    assert gpu_ctx.profile_get("k3_retried_pairs")[2] > 0
+    pdb, _ccfg = cpc.tables(cfg, gene_def, locus)
+    al = cpc.Mm2Aligner(oracle)
+    n_span = same_as_port = 0
+    for r, read in enumerate(reads):
+        got = [tuple(int(h[k]) for k in ("template_idx", "start", "end", "nm", "unmapped")) for h in hits if int(h["read"]) == r]
+        exp = of.oracle_find_base_type(oracle, read, tseqs, ttype, 0.5)
+        assert got == [tuple(int(e[k]) for k in ("template_idx", "start", "end", "nm", "unmapped")) for e in exp], (r, kinds[r], got, exp)
+        # a hit spans the indel: its edits count the indel's bases
+        spanning = [g for g in got if g[1] < where[r] - 500 and g[2] > where[r] + 500]
+        n_span += bool(spanning) and all(g[3] >= abs(kinds[r]) for g in spanning)
+        port = [tuple(int(p[k]) for k in ("template_idx", "start", "end", "nm", "unmapped")) for p in al.find_base_type(oracle, read, pdb, 0.5)]
+        same_as_port += got == port
+    print("K3 reads with a 40 - 100 base indel: a hit spans the indel on", n_span, "of", len(reads), "; the whole hit list equals the port's on", same_as_port)
+    assert n_span == len(reads)
+    assert same_as_port == len(reads)
