@@ -806,9 +806,11 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
     if (!ctx || !templates || !reads || !n_hits || (templates->n && !template_type) || (hits_cap && !hits)) return SP_ERR_INVALID_ARG;
     (void)hipSetDevice(ctx->device);
     *n_hits = 0;
+    HostMarks hm(ctx);
     std::vector<sp_aln> alns; std::vector<int32_t> adiag, avotes;
     int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, 0.05, 0, "k3_region_cells", alns, &adiag, &avotes);
     if (rc) return rc;
+    hm.mark("host:k3_cells");
     const uint32_t T = templates->n;
     auto penalized_type = [](int t) { return t == SP_CYP_DELETION || t == SP_CYP_REP6 || t == SP_CYP_REP7; };   // haplotyper.rs:185-191
     // THE WIDE-BAND RETRY (round 6).  minimap2 chains a template across a 40 - 120 base insertion or deletion in the read (bw 500, max_gap 10000); the 64-diagonal cell leaves
@@ -899,6 +901,7 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
         }
         return SP_OK;
     };
+    hm.mark("host:k3_retry");
     // the placements of every read by the library's counts (cells give up one edit past the cap: a little above it they still exist)
     std::vector<Pl> un; std::vector<uint32_t> first(reads->n + 1, 0);
     for (uint32_t r = 0; r < reads->n; ++r) {
@@ -915,6 +918,7 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
         }
     }
     first[reads->n] = (uint32_t)un.size();
+    hm.mark("host:k3_list");
     if (rescore) {
         std::vector<Pl*> crit;
         std::vector<uint8_t> mark(un.size(), 1);
@@ -934,9 +938,11 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
             if (b > 1.25 * a + 0.001) mark[j] = 0;
         }
         for (size_t i = 0; i < un.size(); ++i) if (mark[i]) crit.push_back(&un[i]);
+        hm.mark("host:k3_mark");
         rc = rescore_list(crit, "k3_af_crit");
         if (rc != SP_OK) return rc;
         if (ctx->profiling) ctx->prof["k3_critical_placements"].cells += crit.size();
+        hm.mark("host:k3_crit_rescore");
     }
     std::vector<Pl> coll;
     std::vector<Pl> cur_read;
@@ -955,11 +961,13 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
         }
         if (have) coll.push_back(cur);
     }
+    hm.mark("host:k3_collapse");
     if (rescore) {
         std::vector<Pl*> rest;
         for (Pl& c : coll) if (!c.done) rest.push_back(&c);
         rc = rescore_list(rest, "k3_af");
         if (rc != SP_OK) return rc;
+        hm.mark("host:k3_rest_rescore");
     }
     for (const Pl& c : coll) {
         const sp_region_hit& h = c.h;
