@@ -783,8 +783,8 @@ def main():
     ap.add_argument("--workload", choices=("auto", "sample", "cohort"), default="auto",
                     help="auto: at N = 1 the sample (one sample per step, both loci: BASELINE configs[1] + configs[2]); at N > 1 the cohort (BASELINE configs[4]: 256 samples sharded over "
                          "the ranks, the call records gathered through sp_gather_results over RCCL), with the ranks' independent streams of samples as a second block of the line")
-    ap.add_argument("--cyp-lanes", type=int, default=4, help="CYP2D6 samples in flight beside the HLA half of the stream (contexts that share the stream of CYP2D6 samples)")
-    ap.add_argument("--hla-lanes", type=int, default=1, help="HLA samples in flight (contexts that share the stream of HLA samples)")
+    ap.add_argument("--cyp-lanes", type=int, default=6, help="CYP2D6 samples in flight beside the HLA half of the stream (contexts that share the stream of CYP2D6 samples)")
+    ap.add_argument("--hla-lanes", type=int, default=2, help="HLA samples in flight (contexts that share the stream of HLA samples)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-hla-reads", type=int, default=5000, help="HLA reads of sample 0 the CPU leg runs (0: all of them)")
     ap.add_argument("--cpu-cyp-reads", type=int, default=1000, help="reads of every CYP2D6 scenario of the mix the CPU leg runs (0: all of them)")
@@ -1149,7 +1149,7 @@ def main():
                 ctx.synchronize(); ctx_c.synchronize()
                 d_fl = time.perf_counter() - t1
                 lane_table[str(n_l)] = {"value": reads_per_step * args.steps / d_fl, "ms_per_step": 1e3 * d_fl / args.steps}
-            legs["cyp2d6_lanes"] = dict(lane_table, unit="reads/s", note="the headline's stream of samples with 1 / 2 / 4 CYP2D6 samples in flight beside the HLA lane (`--cyp-lanes`; the headline's own entry is the line's value)")
+            legs["cyp2d6_lanes"] = dict(lane_table, unit="reads/s", note="the headline's stream of samples with 1 / 2 / 4 CYP2D6 samples in flight beside the HLA lanes (`--cyp-lanes`; the headline's own entry is the line's value)")
         except Exception as e:                                                  # (a leg, not the headline: say so and go on)
             legs["cyp2d6_lanes"] = {"error": str(e)}
         legs["cyp2d6"] = cyp_leg(pkg, ctx, cdb, locus)
@@ -1190,6 +1190,9 @@ def main():
             "measured_peak": peaks["valu_int_wave_instr_per_s"], "frac_of_measured_peak": (achieved / peaks["valu_int_wave_instr_per_s"]) if achieved else None,
             "avg_launch_us": _r(1e3 * step_ms / dep_steps, 4) if dep_steps > 0 else None, "avg_launch_us_rocprof": (pmc or {}).get("rocprof_avg_launch_us"),
             "traffic": pmc["hbm_bytes_per_bench_step"] if pmc else None,
+            # (PMC passes: the waves resident on average while a step launch is active / the wave slots of the device at the kernel's register budget, and the share of a
+            #  resident wave's cycles in which it issues anything -- a launch lasts as long as its slowest wave, most of its waves are done in a sixth of that)
+            "occupancy": (pmc or {}).get("occupancy"),
             "per": "bench step (the consensus searches of one 2,000-read CYP2D6 sample: %.0f dependent window / expansion steps%s)" % (dep_steps, "" if batches is None else ", %.1f persistent launches" % batches),
             "step_kernel_ms_per_step": step_ms, "chain_ms_per_step_hip_events": chain_ms, "nominal_peak": VALU_PEAK_WAVE_INSTR,
             "sq_insts_valu_per_step": pmc["sq_insts_valu_per_bench_step"] if pmc else None, "sq_insts_salu_per_step": pmc["sq_insts_salu_per_bench_step"] if pmc else None,
@@ -1292,6 +1295,7 @@ def main():
                                "traffic": rf["traffic"], "per": "bench step", "measured_peak": _r(rf["measured_peak"]), "frac_of_measured_peak": _r(rf["frac_of_measured_peak"]),
                                "kernel_ms_per_step_device_clock": _r(rf["step_kernel_ms_per_step"]), "kernel_avg_launch_us": rf.get("avg_launch_us"),
                                "kernel_avg_launch_us_rocprof": rf.get("avg_launch_us_rocprof"),
+                               "mean_resident_waves_over_slots": _r((rf.get("occupancy") or {}).get("mean_resident_over_slots")),
                                "hbm": {"algorithmic_bytes_per_step": _r(rf["hbm"]["algorithmic_bytes_per_step"]), "achieved_GBs": _r(rf["hbm"]["achieved_GBs"]), "peak_GBs": HBM_PEAK_GBS,
                                        "frac": _r(rf["hbm"]["frac"])},
                                "counters_from": ("profiles/%s/counters_cons_step.json" % os.path.basename(COUNTER_DIR)) if rf["traffic"] is not None else None}

@@ -166,11 +166,10 @@ template <int MAXP> struct ConsBatchT {
     int total;
     int nside;                  // side orders per problem and step (0 .. NWORK - 1): the step kernel's grid has 1 + nside rows
     int k8_compound;            // windows may be ordered with the children of the branch the lookahead votes foresee at their end
-    int k8_ctl_prio;
 };
 template <> struct ConsBatchT<0> {
     const ConsParams* p; const int* block_prob; int n_prob;
-    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; uint32_t step_cap; const int* cluster_prob; int total; int nside; int k8_compound; int k8_ctl_prio;
+    const ReadInfo* info; PlaceMemo* memo; uint16_t* H; ConsMeta* meta; unsigned long long* PV; uint32_t* PE; unsigned long long* PL; uint32_t* PC; uint32_t* PR; uint32_t* Q; unsigned long long* dbg; uint32_t* prog; unsigned long long* step_t; uint32_t* sync; uint32_t* ready; uint32_t step_cap; const int* cluster_prob; int total; int nside; int k8_compound;
 };
 struct ConsSetup { SeqSetView reads; const uint32_t* idx; const int32_t* offsets; int n, first, cmp_len, pad_; };
 
@@ -664,14 +663,14 @@ constexpr int PERSIST_AUTO_BATCHES = SP_K8_AUTO_BATCHES;
 #endif
 constexpr int PERSIST_LIGHT = SP_K8_LIGHT;          // resident workgroups (step + 2 per control workgroup) up to which a batch's footprint counts as light
 #ifndef SP_K8_DIRECT_BLOCKS
-#define SP_K8_DIRECT_BLOCKS 680
+#define SP_K8_DIRECT_BLOCKS (680 * 8 / SP_K8_WAVES)
 #endif
 // Workgroups of a problem up to which its workgroups ADD their vote words to one block per problem (memory-side atomics) and the control kernel reads that block: a batch of such
 // problems has no reduce launch -- two launches per step instead of three.  The bound is the 16-bit vote fields: 12 units per read and column, 5,461 reads = 682 workgroups at one
 // read per wave (128 until round 5: an HLA gene of a 10,000-read sample has 625 workgroups and paid the third launch and its boundary in every step).
 constexpr int DIRECT_BLOCKS = SP_K8_DIRECT_BLOCKS;
 constexpr int32_t SP_K8_AGAIN = -777;    // run_chunk to its caller: run the batch again (never leaves the library)
-constexpr int PERSIST_BLOCKS = 128;     // workgroups of a problem up to which a batch may run as persistent kernels (all workgroups of the batch resident together)
+constexpr int PERSIST_BLOCKS = 128 * 8 / CWAVES;     // workgroups of a problem up to which a batch may run as persistent kernels (all workgroups of the batch resident together)
 
 template <int MAXP> __device__ __forceinline__ int block_problem(const ConsBatchT<MAXP>& B, int block) {
     int pi = 0;
@@ -744,8 +743,8 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const 
     }
     __syncthreads();
     constexpr int CPW = (CWIN + CW) / 16 + 2;
-    if (threadIdx.x < 2 * CPW) {
-        const int i = threadIdx.x / CPW, w = threadIdx.x % CPW;
+    for (int x = threadIdx.x; x < 2 * CPW; x += blockDim.x) {
+        const int i = x / CPW, w = x % CPW;
         uint32_t word = 0;
         for (int b = 0; b < 16; ++b) { const int y = w * 16 + b; if (y < CWIN + n) word |= (uint32_t)(cwin[i][y] & 3u) << (b << 1); }
         cpk[i][w] = word;
@@ -1372,7 +1371,6 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
     const int pi = blockIdx.x;
     const ConsParams P = B.p[pi];
     const int tid = threadIdx.x;
-    if (B.k8_ctl_prio) __builtin_amdgcn_s_setprio(3);    // (experiment switch SP_K8_CTL_PRIO: the control step is one wave's latency chain; beside other kernels' waves on its SIMD it runs 2 - 3 x slower)
     const bool coh = B.sync != nullptr;                   // persistent mode: what the step workgroups read next is stored write-through, their words are fetched where the atomics ran
     // side orders: only where every order has a word block of its own (problems whose workgroups add their words up), and not between persistent kernels (one row of resident workgroups)
     const int nside = (coh || P.n_blocks > DIRECT_BLOCKS) ? 0 : (B.nside < NWORK - 1 ? B.nside : NWORK - 1);
@@ -2384,7 +2382,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
     {
         uint64_t nb_all = 0;
         for (uint32_t p = 0; p < n_prob; ++p) nb_all += ((probs[p].read_idx ? probs[p].n : probs[p].reads->n) + CWAVES - 1) / CWAVES;
-        if (nb_all > (uint64_t)ctx->k8_side_max_blocks) nside = 0;
+        if (nb_all * CWAVES > (uint64_t)ctx->k8_side_max_blocks * 8) nside = 0;      // (the option counts workgroups of eight waves)
     }
     // Consensus batches of this process under way on the device, this one included from here on; and, for the library's own choice of mode, when two batches that could
     // run as persistent kernels (single samples' searches) last ran side by side: a host that keeps several samples in flight on one device
@@ -2586,24 +2584,15 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
 
     B.nside = persist_rpw ? 0 : nside;
     B.k8_compound = ctx->k8_compound;
-    static const int ctl_prio = std::getenv("SP_K8_CTL_PRIO") ? std::atoi(std::getenv("SP_K8_CTL_PRIO")) : 0, ctl_pad = std::getenv("SP_K8_CTL_LDS_PAD") ? std::atoi(std::getenv("SP_K8_CTL_LDS_PAD")) : 0;      // (experiment switches)
-    B.k8_ctl_prio = ctl_prio;
-    static const int ctl_threads = std::getenv("SP_K8_CTL_THREADS") ? std::max(64, std::min(1024, std::atoi(std::getenv("SP_K8_CTL_THREADS")))) : 1024;      // (experiment switch)
     const dim3 grid((uint32_t)n_blocks, (uint32_t)(1 + B.nside)), block(CWAVES * SP_WAVE);
     // (the step kernel's instantiation for batches that fit the device at one workgroup per CU, give or take a few: cons_step_wide_kernel.  A 2,000-read CYP2D6 sample's first batch
     //  has 271 workgroups -- its 2,162 region segments -- and is still faster there)
-    static const int wide_max = std::getenv("SP_K8_WIDE_MAX") ? std::atoi(std::getenv("SP_K8_WIDE_MAX")) : -1;      // (experiment switch)
-    const bool one_round = n_blocks <= (wide_max >= 0 ? wide_max : ctx->num_cus + ctx->num_cus / 4);
+    const bool one_round = n_blocks <= (ctx->num_cus + ctx->num_cus / 4) * (8 / CWAVES);
     size_t proc_lds = ((size_t)max_cap + 2 + 15) & ~(size_t)15;
     {   // the control kernel's node table and vote sums are static LDS; the per-length counters come on top (160 KiB per workgroup on gfx950)
         hipFuncAttributes fa;
         SP_HIP_CHECK(ctx, hipFuncGetAttributes(&fa, (const void*)cons_control_kernel<MAXP>));
         if (fa.sharedSizeBytes + proc_lds > 160 * 1024) return sp_fail(ctx, SP_ERR_TOO_LONG, "sp_consensus: cap must stay below ~65,000");
-    }
-    if (ctl_pad) {                                          // (experiment: the control workgroup takes the CU's whole LDS, so that no other kernel's LDS-using workgroups sit beside it)
-        hipFuncAttributes fa2;
-        SP_HIP_CHECK(ctx, hipFuncGetAttributes(&fa2, (const void*)cons_control_kernel<MAXP>));
-        if (fa2.sharedSizeBytes + proc_lds < 160 * 1024) proc_lds = ((160 * 1024 - fa2.sharedSizeBytes) / 16) * 16;
     }
     SP_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cons_control_kernel<MAXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)proc_lds));
     uint64_t pairs = 0;
@@ -2687,7 +2676,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
             if (one_round) hipLaunchKernelGGL(cons_step_wide_kernel<MAXP>, grid, block, 0, st, B);
             else hipLaunchKernelGGL(cons_step_kernel<MAXP>, grid, block, 0, st, B);
             if (need_reduce) hipLaunchKernelGGL(cons_reduce_kernel<MAXP>, dim3((uint32_t)n_clusters * RSLICES), dim3(512), 0, st, B);
-            hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(ctl_threads), proc_lds, st, B);
+            hipLaunchKernelGGL(cons_control_kernel<MAXP>, dim3(n_prob), dim3(1024), proc_lds, st, B);
             t_launch += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
             ++pairs;
             uint64_t spins = 0;

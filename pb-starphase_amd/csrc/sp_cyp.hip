@@ -928,14 +928,22 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
             const sp_region_hit& h = un[i].h;
             s_own[i] = cyp_score(h.seq_len, h.nm, h.unmapped, false); s_pen[i] = cyp_score(h.seq_len, h.nm, h.unmapped, true); is_pen[i] = penalized_type(template_type[h.template_idx]);
         }
-        for (uint32_t r = 0; r < reads->n; ++r) for (uint32_t i = first[r]; i < first[r + 1]; ++i) for (uint32_t j = i + 1; j < first[r + 1]; ++j) {
-            const sp_region_hit& u = un[i].h; const sp_region_hit& v = un[j].h;
-            const int shared = std::min(u.end, v.end) - std::max(u.start, v.start);
-            if (shared <= 0 || !(overlap(u, v) > K3_OVL)) continue;
-            const bool pen = is_pen[i] || is_pen[j];
-            const double a = pen ? s_pen[i] : s_own[i], b = pen ? s_pen[j] : s_own[j];
-            if (a > 1.25 * b + 0.001) mark[i] = 0;                                           // i is clearly beaten by j
-            if (b > 1.25 * a + 0.001) mark[j] = 0;
+        // (start / end / length of every placement side by side: the loop reads three ints per partner; the division of overlap() only where the spans can reach K3_OVL at all)
+        std::vector<int> p_s(un.size()), p_e(un.size());
+        for (size_t i = 0; i < un.size(); ++i) { p_s[i] = un[i].h.start; p_e[i] = un[i].h.end; }
+        for (uint32_t r = 0; r < reads->n; ++r) for (uint32_t i = first[r]; i < first[r + 1]; ++i) {
+            const int us = p_s[i], ue = p_e[i], ul = ue - us;
+            for (uint32_t j = i + 1; j < first[r + 1]; ++j) {
+                const int shared = std::min(ue, p_e[j]) - std::max(us, p_s[j]);
+                if (shared <= 0) continue;
+                const int vl = p_e[j] - p_s[j], ml = std::min(ul, vl);
+                if ((int64_t)shared * 100 < (int64_t)84 * ml) continue;                        // (well under K3_OVL: no division)
+                if (!((double)shared / (double)ml > K3_OVL)) continue;                         // overlap(u, v)
+                const bool pen = is_pen[i] || is_pen[j];
+                const double a = pen ? s_pen[i] : s_own[i], b = pen ? s_pen[j] : s_own[j];
+                if (a > 1.25 * b + 0.001) mark[i] = 0;                                       // i is clearly beaten by j
+                if (b > 1.25 * a + 0.001) mark[j] = 0;
+            }
         }
         for (size_t i = 0; i < un.size(); ++i) if (mark[i]) crit.push_back(&un[i]);
         hm.mark("host:k3_mark");

@@ -1365,7 +1365,7 @@ static int32_t k1_realign_chunk(sp_ctx* ctx, const sp_hla_db* db, const sp_seqse
             const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
             // (ends only: the record takes the mapping's query span and target start; an HLA read is 40 - 100 clustered edits from the reference, and the DP over all of its
             //  rows cost 17.5 ms per 10,000 reads)
-            static const int ends_knob = std::getenv("SP_K1_SEGRS_ENDS") ? std::atoi(std::getenv("SP_K1_SEGRS_ENDS")) : 64, band_knob = std::getenv("SP_K1_SEGRS_BAND") ? std::atoi(std::getenv("SP_K1_SEGRS_BAND")) : 256;   // (experiment switches)
+            constexpr int ends_knob = 64, band_knob = 256;      // bases from either end inside which an edit sends the placement to the DP; diagonals of that DP
             rc = sp_rescore_mappings(ctx, db->ref_fwd, &segs, d_c2, d_r2, R, true, ao, band_knob, d_saf, "k1_segrs", SP_MAX_ED + 1, 1, nullptr, nullptr, ends_knob);
             segs.d_words = nullptr; segs.d_nplane = nullptr; segs.d_word_off = nullptr; segs.d_len = nullptr;       // (pooled buffers: the set owns nothing)
             if (rc == SP_OK) hipLaunchKernelGGL(k1_seg_rs_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, db->dna_gene->view(), db->ref_fwd->view(), db->d_am, db->d_hpc_ref,

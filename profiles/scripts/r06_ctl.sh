@@ -1,3 +1,4 @@
+# (an experiment of round 6 -- profiles/r06/lanes_matrix.txt (d): no effect; the switch it sets was taken out of the library afterwards)
 mkdir -p gpurun_out/r06e
 for th in 1024 256 512 1024 256; do
   SP_K8_CTL_THREADS=$th python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extra-legs --full-out gpurun_out/r06e/full_t$th.json > /dev/null 2> gpurun_out/r06e/err.txt

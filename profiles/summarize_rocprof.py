@@ -113,5 +113,24 @@ if tot.get("SQ_INSTS_VALU"):
            "cons_source_sha16": cons_source_sha16(),
            "method": "rocprofv3 --pmc passes of profiles/run_rocprof.sh (SQ_INSTS_VALU / SALU / LDS, FETCH_SIZE, WRITE_SIZE in separate passes; KB -> bytes, FETCH_SIZE doubled: "
                      "gfx950 tallies 128-B requests at 64 B), summed over every cons_step_wide_kernel<8> / cons_step_kernel<8> dispatch of the pass and divided by the pass's %d bench steps (the six configs[2] scenarios + the warm-up step)" % steps_in_pass}
+    # the same kernel in the kernel trace of the unprofiled command (bench.py's roofline block quotes it beside its own device-clock figure)
+    for f in find("trace/**/*kernel_stats.csv"):
+        for row in csv.DictReader(open(f)):
+            if "cons_step_wide_kernel<8>" in row.get("Name", ""):
+                rec["rocprof_avg_launch_us"] = round(float(row.get("AverageNs", 0) or 0) / 1e3, 2); rec["rocprof_calls_in_trace"] = int(row.get("Calls", 0) or 0)
+    # how much of the device a step launch holds (the counter passes run one kernel at a time): waves launched, the cycles they were resident, the cycles the
+    # shader engines were busy at all and the cycles the GPU was active, all summed over the dispatches
+    for name in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY"):
+        if name in tot:
+            rec[name.lower() + "_per_bench_step"] = tot[name] / steps_in_pass
+    if tot.get("SQ_WAVE_CYCLES") and tot.get("GRBM_GUI_ACTIVE") and tot.get("SQ_WAVES"):
+        # MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_ACTIVE_* count quad-cycles, GRBM_GUI_ACTIVE is the sum over the 8 XCDs
+        active_cycles = tot["GRBM_GUI_ACTIVE"] / 8.0
+        rec["occupancy"] = {"waves_per_dispatch": tot["SQ_WAVES"] / ndisp["SQ_WAVES"], "active_cycles_per_dispatch": active_cycles / ndisp["GRBM_GUI_ACTIVE"],
+                            "mean_resident_waves": 4.0 * tot["SQ_WAVE_CYCLES"] / active_cycles,
+                            "wave_slots_at_240_vgprs": 256 * 4 * 2, "mean_resident_over_slots": 4.0 * tot["SQ_WAVE_CYCLES"] / active_cycles / (256 * 4 * 2),
+                            "issuing_share_of_resident_wave_cycles": (tot.get("SQ_ACTIVE_INST_ANY", 0.0) / tot["SQ_WAVE_CYCLES"]) if tot.get("SQ_ACTIVE_INST_ANY") else None,
+                            "note": "SQ_WAVE_CYCLES x 4 / (GRBM_GUI_ACTIVE / 8): the waves resident on average while a step launch is active (one kernel at a time under the counter pass); "
+                                    "the launch's length is its slowest wave's, most waves are done in a sixth of it"}
     json.dump(rec, open(os.path.join(out, "counters_cons_step.json"), "w"), indent=1)
     print("== cons_step", rec)
