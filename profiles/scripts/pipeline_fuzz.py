@@ -103,7 +103,7 @@ if n_hla:
         reads = [reads[i] for i in order]
         R = ctx.upload(reads)
         k1_gpu = hdb.realign_reads(R)
-        k1_exp, _ = hx.k1_expected(oracle, fx, reads)
+        k1_exp, _ = hx.k1_expected_seeded(oracle, fx, reads)       # (the library's default since round 5: K1 in the reference's call pattern)
         diff = []
         for g in range(len(fx.genes)):
             call, c1, c2, is1 = hdb.diplotype_gene(g, R, k1_gpu)

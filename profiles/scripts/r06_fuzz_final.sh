@@ -5,4 +5,4 @@ S2=$(python -c "print(','.join(str(x) for x in list(range(81,101))+list(range(10
 timeout 1500 python profiles/scripts/k8fuzz.py $S1 2>&1 | tail -3
 SP_K8_SIDE_ORDERS=3 SP_K8_COMPOUND=3 timeout 1500 python profiles/scripts/k8fuzz.py $S2 2>&1 | tail -3
 SP_K8_SIDE_ORDERS=2 SP_K8_COMPOUND=50 SP_K8_PERSISTENT=0 timeout 1500 python profiles/scripts/k8fuzz.py $S2 2>&1 | tail -3
-timeout 1200 python profiles/scripts/pipeline_fuzz.py 2>&1 | tail -3
+timeout 1200 python profiles/scripts/pipeline_fuzz.py 16 6 606 2>&1 | tail -3
