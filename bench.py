@@ -1027,6 +1027,10 @@ def main():
         if steps > 0:
             out["per_step_us"] = {"step_kernel": 1e3 * out["step_kernel_ms"] / steps, "control_kernel": 1e3 * out["control_kernel_ms"] / steps,
                                   "between_kernels_per_boundary": 1e3 * out["between_kernels_ms"] / (2 * steps)}
+            # the two boundaries of a step apart: the step kernel's end -> the control step's start (one workgroup with ~ 130 KB of LDS looking for a CU), the control step's end ->
+            # the first step workgroup's start (eight waves at 240 registers looking for a CU)
+            gc = ms("cons_path_gap_ctl_ticks")
+            out["boundary_us"] = {"step_end_to_control_start": 1e3 * gc / steps, "control_end_to_step_start": 1e3 * (out["between_kernels_ms"] - gc) / steps}
             # the control step by part (the slowest problem of every batch, all steps of the batch -- not only the chain's): loading the work order and adding up the
             # workgroups' votes / the result of the step (columns decided, tapes written) / the search for the next node / the next work order and the write-back
             out["control_parts_us_per_step"] = {k: 1e3 * ms("cons_ticks_" + k) / steps for k in ("reduce", "result", "search", "tail")}

@@ -114,7 +114,8 @@ struct CSearch {
     long long ticks[4];         // control kernel, 100 MHz wall clock: load + vote reduction / result of the step / search / tail
     long long step_ticks, gap_ticks, last_end;   // profiling contexts: the step kernel from its first workgroup's start to its last one's end, summed over the steps; what lies
                                                  // between the kernels of the chain (control end -> step start, step end -> control start); the wall clock at the last control end
-    int32_t compound, compound_ok, pad_c[2];     // windows ordered with the children of the branch they were foreseen to end in; those whose children were taken
+    int32_t compound, compound_ok;               // windows ordered with the children of the branch they were foreseen to end in; those whose children were taken
+    long long gap_ctl_ticks;                     // the part of gap_ticks in front of the control steps (step end -> control start)
     int32_t steps, side_windows, side_expansions, adopted;   // control steps that ordered a launch; side orders made; expansions adopted from a side order (no launch of their own)
 #ifdef SP_K8_PF_PROBE
     int32_t pf_win, pf_replay, pf_exp, pf_pad;   // probe build: orders whose node stood idle at the end of its tape when the order before was made (a launch that one could have carried)
@@ -2125,7 +2126,7 @@ __device__ __forceinline__ void cons_control_body(const ConsBatchT<MAXP>& B) {
             if (st1 > 0 && st0 <= st1) {
                 ss.step_ticks += st1 - st0;
                 if (ss.last_end > 0 && st0 >= ss.last_end) ss.gap_ticks += st0 - ss.last_end;
-                if (tk0 >= st1) ss.gap_ticks += tk0 - st1;
+                if (tk0 >= st1) { ss.gap_ticks += tk0 - st1; ss.gap_ctl_ticks += tk0 - st1; }
             }
             put(&B.step_t[2 * pi], ~0ull, coh); put(&B.step_t[2 * pi + 1], 0ull, coh);
             ss.last_end = tk4;
@@ -2774,7 +2775,7 @@ static int32_t run_chunk(sp_ctx* ctx, uint32_t n_prob, const sp_cons_problem* pr
                 const long long tot = h_srch[p].step_ticks + h_srch[p].gap_ticks + h_srch[p].ticks[0] + h_srch[p].ticks[1] + h_srch[p].ticks[2] + h_srch[p].ticks[3];
                 if (tot > best) { best = tot; bp = p; }
             }
-            ctx->prof["cons_path_step_ticks"].cells += (uint64_t)h_srch[bp].step_ticks; ctx->prof["cons_path_gap_ticks"].cells += (uint64_t)h_srch[bp].gap_ticks;
+            ctx->prof["cons_path_step_ticks"].cells += (uint64_t)h_srch[bp].step_ticks; ctx->prof["cons_path_gap_ticks"].cells += (uint64_t)h_srch[bp].gap_ticks; ctx->prof["cons_path_gap_ctl_ticks"].cells += (uint64_t)h_srch[bp].gap_ctl_ticks;
             ctx->prof["cons_path_control_ticks"].cells += (uint64_t)(h_srch[bp].ticks[0] + h_srch[bp].ticks[1] + h_srch[bp].ticks[2] + h_srch[bp].ticks[3]);
             ctx->prof["cons_path_steps"].cells += (uint64_t)h_srch[bp].steps;
         }
