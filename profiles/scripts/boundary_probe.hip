@@ -39,6 +39,9 @@ __global__ void __launch_bounds__(256) bg_read(const uint4* src, size_t n, unsig
 }
 int main() {
     hipStream_t chain_st; (void)hipStreamCreateWithFlags(&chain_st, hipStreamNonBlocking);
+    int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hipStream_t chain_hi; (void)hipStreamCreateWithPriority(&chain_hi, hipStreamNonBlocking, prio_hi);
+    printf("stream priorities: lowest %d, highest %d\n", prio_lo, prio_hi); fflush(stdout);
     unsigned* out; (void)hipMalloc(&out, 1 << 20); (void)hipMemset(out, 0, 1 << 20);
     const int NB = 3; std::vector<hipStream_t> bst(NB); std::vector<uint4*> buf(NB); const size_t bytes = (size_t)1 << 30, n4 = bytes / 16;
     unsigned* sink; (void)hipMalloc(&sink, 64);
@@ -49,8 +52,9 @@ int main() {
     (void)hipDeviceSynchronize();
     const char* names[] = { "alone", "beside arithmetic-only kernels (3 streams, device full)", "beside streaming WRITES (3 streams, 1 GB each per kernel)", "beside streaming READS (3 streams)",
                             "beside short kernels that write 4 MB each (3 streams)", "beside arithmetic-only kernels of 64 workgroups (3 streams: a quarter of the CUs)",
-                            "beside arithmetic-only kernels (device full) on streams MASKED to 3/4 of the CUs", "beside streaming WRITES on streams MASKED to 3/4 of the CUs" };
-    for (int mode : {0, 6, 7, 2, 3, 4, 5, 1}) {
+                            "beside arithmetic-only kernels (device full) on streams MASKED to 3/4 of the CUs", "beside streaming WRITES on streams MASKED to 3/4 of the CUs",
+                            "on a HIGH-PRIORITY stream beside arithmetic-only kernels (device full)", "on a HIGH-PRIORITY stream beside streaming WRITES" };
+    for (int mode : {0, 8, 9, 7, 2, 3, 4, 5}) {
         std::atomic<bool> stop{false};
         std::vector<std::thread> th;
         if (mode > 0) for (int b = 0; b < NB; ++b) th.emplace_back([&, b]() {
@@ -58,25 +62,26 @@ int main() {
             unsigned k = 0;
             while (!stop.load()) {
                 for (int r = 0; r < 4; ++r) {
-                    if (mode == 1) hipLaunchKernelGGL(bg_alu, dim3(256 * 64), dim3(256), 0, bst[b], sink, 3000);
-                    else if (mode == 2) hipLaunchKernelGGL(bg_write, dim3(256 * 8), dim3(256), 0, bst[b], buf[b], n4, ++k);
+                    if (mode == 1 || mode == 8) hipLaunchKernelGGL(bg_alu, dim3(256 * 64), dim3(256), 0, bst[b], sink, 3000);
+                    else if (mode == 2 || mode == 9) hipLaunchKernelGGL(bg_write, dim3(256 * 8), dim3(256), 0, bst[b], buf[b], n4, ++k);
                     else if (mode == 3) hipLaunchKernelGGL(bg_read, dim3(256 * 8), dim3(256), 0, bst[b], (const uint4*)buf[b], n4, sink);
                     else if (mode == 4) hipLaunchKernelGGL(bg_write, dim3(256), dim3(256), 0, bst[b], buf[b], (size_t)(4 << 20) / 16, ++k);
                     else if (mode == 5) hipLaunchKernelGGL(bg_alu, dim3(64), dim3(256), 0, bst[b], sink, 100000);
                     else if (mode == 6) hipLaunchKernelGGL(bg_alu, dim3(256 * 64), dim3(256), 0, mst[b], sink, 3000);
                     else hipLaunchKernelGGL(bg_write, dim3(256 * 8), dim3(256), 0, mst[b], buf[b], n4, ++k);
                 }
-                (void)hipStreamSynchronize(mode >= 6 ? mst[b] : bst[b]);
+                (void)hipStreamSynchronize((mode == 6 || mode == 7) ? mst[b] : bst[b]);
             }
         });
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
         for (int blocks : {13, 271}) {
-            const int iters = mode == 1 ? 20 : 600;
-            for (int i = 0; i < (mode == 1 ? 2 : 50); ++i) { hipLaunchKernelGGL(step_like, dim3(blocks), dim3(512), 0, chain_st, out); hipLaunchKernelGGL(control_like, dim3(1), dim3(1024), 0, chain_st, out, blocks * 64); }
-            (void)hipStreamSynchronize(chain_st);
+            hipStream_t cs = mode >= 8 ? chain_hi : chain_st;
+            const int iters = (mode == 1 || mode == 8 || mode == 6) ? 40 : 600;
+            for (int i = 0; i < ((mode == 1 || mode == 8 || mode == 6) ? 2 : 50); ++i) { hipLaunchKernelGGL(step_like, dim3(blocks), dim3(512), 0, cs, out); hipLaunchKernelGGL(control_like, dim3(1), dim3(1024), 0, cs, out, blocks * 64); }
+            (void)hipStreamSynchronize(cs);
             auto t0 = std::chrono::steady_clock::now();
-            for (int i = 0; i < iters; ++i) { hipLaunchKernelGGL(step_like, dim3(blocks), dim3(512), 0, chain_st, out); hipLaunchKernelGGL(control_like, dim3(1), dim3(1024), 0, chain_st, out, blocks * 64); }
-            (void)hipStreamSynchronize(chain_st);
+            for (int i = 0; i < iters; ++i) { hipLaunchKernelGGL(step_like, dim3(blocks), dim3(512), 0, cs, out); hipLaunchKernelGGL(control_like, dim3(1), dim3(1024), 0, cs, out, blocks * 64); }
+            (void)hipStreamSynchronize(cs);
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters;
             printf("chain of dependent pairs (%3d + 1 workgroups) %-80s %7.2f us per pair\n", blocks, names[mode], us); fflush(stdout);
         }

@@ -128,7 +128,7 @@ if tot.get("SQ_INSTS_VALU"):
         active_cycles = tot["GRBM_GUI_ACTIVE"] / 8.0
         rec["occupancy"] = {"waves_per_dispatch": tot["SQ_WAVES"] / ndisp["SQ_WAVES"], "active_cycles_per_dispatch": active_cycles / ndisp["GRBM_GUI_ACTIVE"],
                             "mean_resident_waves": 4.0 * tot["SQ_WAVE_CYCLES"] / active_cycles,
-                            "wave_slots_at_240_vgprs": 256 * 4 * 2, "mean_resident_over_slots": 4.0 * tot["SQ_WAVE_CYCLES"] / active_cycles / (256 * 4 * 2),
+                            "wave_slots_at_2_per_simd": 256 * 4 * 2, "mean_resident_over_slots": 4.0 * tot["SQ_WAVE_CYCLES"] / active_cycles / (256 * 4 * 2),
                             "issuing_share_of_resident_wave_cycles": (tot.get("SQ_ACTIVE_INST_ANY", 0.0) / tot["SQ_WAVE_CYCLES"]) if tot.get("SQ_ACTIVE_INST_ANY") else None,
                             "note": "SQ_WAVE_CYCLES x 4 / (GRBM_GUI_ACTIVE / 8): the waves resident on average while a step launch is active (one kernel at a time under the counter pass); "
                                     "the launch's length is its slowest wave's, most waves are done in a sixth of it"}
