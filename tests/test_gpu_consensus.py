@@ -108,6 +108,44 @@ def test_low_complexity_and_divergent_inputs(oracle, pkg, gpu_ctx):
                 raise AssertionError(f"seed {seed} iteration {it}: {e}")
 
 
+@pytest.mark.parametrize("side_orders,compound", [(0, 0), (1, 1), (2, 2), (3, 3), (3, 50)])
+def test_side_orders_and_branching_windows_leave_the_search_unchanged(oracle, pkg, gpu_ctx, side_orders, compound):
+    """sp_ctx_set_option "k8_side_orders" / "k8_compound" (round 6): a step launch also makes the window or expansion another waiting node will need (adopted later without a
+    launch), and a window may be ordered with the children of the branch its lookahead votes foresee -- speculation only: consensus, assignment, scores and the number of nodes
+    expanded stay the oracle's under every setting (0 / 0 = off; 2 = branching windows ordered but never taken; 3 = ordered wherever one is foreseen; 50 = at a 50 % vote share),
+    as launch pairs (the resident kernels carry neither), and the counters show that the paths ran"""
+    import consensus_fuzz
+    from pb_starphase_amd import synth
+    gpu_ctx.set_option("k8_persistent", 0); gpu_ctx.set_option("k8_side_orders", side_orders); gpu_ctx.set_option("k8_compound", compound)
+    try:
+        gpu_ctx.profile_reset()
+        for seed in (5, 1003, 2002, 2005):
+            rng = np.random.default_rng(seed)
+            for it in range(12):
+                _L, reads, offs, kw, two_pass = consensus_fuzz.problem(rng, seed, synth)
+                exp = run_case(oracle, reads, offs, kw, two_pass)
+                got = gpu_ctx.consensus(gpu_ctx.upload(reads), gpu_cfg(pkg, **kw), offsets=offs, two_pass=two_pass)
+                try:
+                    same(got, exp)
+                except AssertionError as e:
+                    raise AssertionError(f"side orders {side_orders}, branching windows {compound}, seed {seed} iteration {it}: {e}")
+        made = gpu_ctx.profile_get("cons_side_windows")[2] + gpu_ctx.profile_get("cons_side_expansions")[2]
+        adopted, ordered, taken = (gpu_ctx.profile_get(k)[2] for k in ("cons_adopted", "cons_compound", "cons_compound_ok"))
+        assert gpu_ctx.profile_get("cons_persistent_batches")[2] == 0
+        if side_orders == 0:
+            assert made == 0 and adopted == 0
+        else:
+            assert made > 0 and adopted > 0
+        if compound == 0:
+            assert ordered == 0 and taken == 0
+        elif compound == 2:
+            assert ordered > 0 and taken == 0
+        else:
+            assert ordered > 0 and taken > 0
+    finally:
+        gpu_ctx.set_option("k8_persistent", 2); gpu_ctx.set_option("k8_side_orders", 1); gpu_ctx.set_option("k8_compound", 1)
+
+
 def test_persistent_kernels_run_the_same_search(oracle, pkg, gpu_ctx):
     """sp_ctx_set_option "k8_persistent": batches of small problems as two persistent kernels (step workgroups + a control workgroup per problem, handing over through
     one word each in memory: write-through stores, sc1 loads, memory-side atomics) instead of a launch pair per step -- consensus, assignment, scores and the number of nodes expanded are the oracle's, as in the default mode;
