@@ -669,6 +669,43 @@ static int cyp_align_pairs(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, 
     return SP_OK;
 }
 
+// the pair list of "every A against every B" made on the device (pair b * nA + a)
+__global__ void cyp_all_pairs_kernel(uint32_t nA, uint64_t n_pairs, uint32_t* __restrict__ a_idx, uint32_t* __restrict__ b_idx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    a_idx[i] = (uint32_t)(i % nA); b_idx[i] = (uint32_t)(i / nA);
+}
+// all |A| x |B| placements for the region search, result[b][a][k], in PINNED host memory of the context (valid until the context's next region search): the grid of a
+// 2,000-read sample is 12.5 MB of alignments + 2.5 MB of anchors -- into a fresh std::vector that was a zero-fill, a page fault per 4 KB and a device-to-host copy through
+// the runtime's bounce buffers, 0.6 - 9 ms of the search depending on what the allocator had at hand (and several samples' searches at once share the process's page tables)
+static int cyp_align_all_pinned(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, const char* prof, sp_aln** out, int32_t** diag_out, int32_t** votes_out) {
+    const uint64_t nA = A->n, n_pairs = nA * (uint64_t)B->n, n_cells = n_pairs * (uint64_t)topk;
+    *out = nullptr; *diag_out = nullptr; *votes_out = nullptr;
+    if (n_pairs == 0) return SP_OK;
+    int rc = sp_seqset_build_index(ctx, const_cast<sp_seqset*>(A));
+    if (rc) return rc;
+    uint32_t* d_a = (uint32_t*)sp_pool(ctx, "cyp_a", n_pairs * 4); uint32_t* d_b = (uint32_t*)sp_pool(ctx, "cyp_b", n_pairs * 4);
+    int32_t* d_d = (int32_t*)sp_pool(ctx, "cyp_d", n_cells * 4); int32_t* d_v = (int32_t*)sp_pool(ctx, "cyp_v", n_cells * 4);
+    CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "cyp_cells", n_cells * sizeof(CellDesc));
+    sp_aln* d_alns = (sp_aln*)sp_pool(ctx, "cyp_alns", n_cells * sizeof(sp_aln));
+    sp_aln* h_alns = (sp_aln*)sp_host_pool(ctx, "k3_alns_host", n_cells * sizeof(sp_aln));
+    int32_t* h_d = (int32_t*)sp_host_pool(ctx, "k3_diag_host", n_cells * 4); int32_t* h_v = (int32_t*)sp_host_pool(ctx, "k3_votes_host", n_cells * 4);
+    if (!d_a || !d_b || !d_d || !d_v || !d_cells || !d_alns || !h_alns || !h_d || !h_v) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "cyp placement buffers");
+    hipLaunchKernelGGL(cyp_all_pairs_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)nA, n_pairs, d_a, d_b);
+    rc = sp_launch_anchor(ctx, A, B, d_a, d_b, n_pairs, d_d, d_v, topk, "anchor", (uint32_t)nA);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cyp_build_cells_kernel, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, d_d, d_v, n_pairs, topk, CYP_MIN_VOTES, A->d_len, frac_cap, d_cells);
+    rc = sp_launch_cells(ctx, A, B, d_cells, n_cells, d_alns, nullptr, 0, prof, 0);
+    if (rc) return rc;
+    (void)hipMemcpyAsync(h_alns, d_alns, n_cells * sizeof(sp_aln), hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(h_d, d_d, n_cells * 4, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(h_v, d_v, n_cells * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return sp_fail(ctx, SP_ERR_HIP, std::string("cyp placements: ") + hipGetErrorString(e));
+    *out = h_alns; *diag_out = h_d; *votes_out = h_v;
+    return SP_OK;
+}
+
 // all |A| x |B| placements, result[b][a][k]
 static int cyp_align_all(sp_ctx* ctx, const sp_seqset* A, const sp_seqset* B, int topk, double frac_cap, int retry_wide, const char* prof, std::vector<sp_aln>& out,
                          std::vector<int32_t>* diag_out = nullptr, std::vector<int32_t>* votes_out = nullptr) {
@@ -782,6 +819,19 @@ static void cyp_weights_from_alns(uint32_t C, const int32_t* cons_len, const uin
     }
 }
 
+// The host's share of the region search works read by read (which placements exist, which are critical, which survive the collapse): the reads in K3_HOST_THREADS ranges, a
+// thread each, every range's output appended in read order -- the lists are the ones one thread would make (4.1 -> 1.5 ms of a 2,000-read sample's 10)
+constexpr uint32_t K3_HOST_THREADS = 4, K3_HOST_MIN_READS = 256;
+template <class F> static void k3_read_ranges(uint32_t n_reads, F&& fn) {                                   // fn(range index, first read, one past the last)
+    const uint32_t nt = n_reads >= K3_HOST_MIN_READS ? K3_HOST_THREADS : 1, per = (n_reads + nt - 1) / nt;
+    std::thread th[K3_HOST_THREADS]; bool started[K3_HOST_THREADS] = {};
+    for (uint32_t t = 1; t < nt; ++t) {
+        const uint32_t lo = std::min(n_reads, t * per), hi = std::min(n_reads, lo + per);
+        try { th[t] = std::thread([&fn, t, lo, hi]() { fn(t, lo, hi); }); started[t] = true; } catch (...) { fn(t, lo, hi); }      // (no thread to be had: this one does the range)
+    }
+    fn(0u, 0u, std::min(n_reads, per));
+    for (uint32_t t = 1; t < nt; ++t) if (started[t]) th[t].join();
+}
 static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
                                 double max_missing_frac, sp_region_hit* hits, uint64_t hits_cap, uint64_t* n_hits, bool rescore);
 extern "C" int32_t sp_cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const int32_t* template_type, const sp_seqset* reads,
@@ -807,10 +857,11 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
     (void)hipSetDevice(ctx->device);
     *n_hits = 0;
     HostMarks hm(ctx);
-    std::vector<sp_aln> alns; std::vector<int32_t> adiag, avotes;
-    int rc = cyp_align_all(ctx, templates, reads, CYP_TOPK, 0.05, 0, "k3_region_cells", alns, &adiag, &avotes);
+    sp_aln* alns = nullptr; int32_t* adiag = nullptr; int32_t* avotes = nullptr;
+    int rc = cyp_align_all_pinned(ctx, templates, reads, CYP_TOPK, 0.05, "k3_region_cells", &alns, &adiag, &avotes);
     if (rc) return rc;
     hm.mark("host:k3_cells");
+    if (!alns) return SP_OK;                                                                                 // (no templates or no reads: no hits)
     const uint32_t T = templates->n;
     auto penalized_type = [](int t) { return t == SP_CYP_DELETION || t == SP_CYP_REP6 || t == SP_CYP_REP7; };   // haplotyper.rs:185-191
     // THE WIDE-BAND RETRY (round 6).  minimap2 chains a template across a 40 - 120 base insertion or deletion in the read (bw 500, max_gap 10000); the 64-diagonal cell leaves
@@ -821,8 +872,11 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
     // of the six scenarios -- cost nothing.  (oracle/cyp.c osp_cyp_find_base_type_ex states the same rule.)
     if (rescore) {
         std::vector<CellDesc> retry; std::vector<uint32_t> retry_at;
+        std::vector<CellDesc> retry_of[K3_HOST_THREADS]; std::vector<uint32_t> retry_at_of[K3_HOST_THREADS];
+        k3_read_ranges(reads->n, [&](uint32_t part, uint32_t r_lo, uint32_t r_hi) {
+        std::vector<CellDesc>& retry = retry_of[part]; std::vector<uint32_t>& retry_at = retry_at_of[part];
         std::vector<std::pair<int, int>> iv;
-        for (uint32_t r = 0; r < reads->n; ++r) {
+        for (uint32_t r = r_lo; r < r_hi; ++r) {
             const int rlen = reads->h_len[r];
             if (rlen == 0) continue;
             iv.clear();
@@ -849,6 +903,8 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
                 retry.push_back(CellDesc{ t, r, d0, cap, 0, -1 }); retry_at.push_back((uint32_t)c0);
             }
         }
+        });
+        for (uint32_t part = 0; part < K3_HOST_THREADS; ++part) { retry.insert(retry.end(), retry_of[part].begin(), retry_of[part].end()); retry_at.insert(retry_at.end(), retry_at_of[part].begin(), retry_at_of[part].end()); }
         if (!retry.empty()) {
             const size_t nr = retry.size();
             CellDesc* d_rc = (CellDesc*)sp_pool(ctx, "k3_retry_cells", nr * sizeof(CellDesc)); sp_aln* d_ro = (sp_aln*)sp_pool(ctx, "k3_retry_alns", nr * sizeof(sp_aln));
@@ -874,47 +930,67 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
     auto rescore_list = [&](std::vector<Pl*>& list, const char* prof) -> int {
         const uint64_t nc = list.size();
         if (!nc) return SP_OK;
-        std::vector<CellDesc> cells(nc); std::vector<sp_aln> ref(nc); std::vector<sp_affine_aln> af(nc);
-        for (uint64_t x = 0; x < nc; ++x) {
-            const sp_region_hit& h = list[x]->h; const sp_aln& al = alns[list[x]->which];
-            cells[x] = CellDesc{ (uint32_t)h.template_idx, (uint32_t)h.read, ((al.b_start - al.a_start) + (al.b_end - al.a_end)) / 2, 320, 0, -1 };
-            ref[x] = al;
-        }
+        // (descriptions and results through pinned memory of the context, filled and read back by the host threads in ranges of the list)
+        CellDesc* cells = (CellDesc*)sp_host_pool(ctx, "k3_af_cells_host", nc * sizeof(CellDesc));
+        sp_aln* ref = (sp_aln*)sp_host_pool(ctx, "k3_af_ref_host", nc * sizeof(sp_aln));
+        sp_affine_aln* af = (sp_affine_aln*)sp_host_pool(ctx, "k3_af_out_host", nc * sizeof(sp_affine_aln));
         CellDesc* d_cells = (CellDesc*)sp_pool(ctx, "k3_af_cells", nc * sizeof(CellDesc));
         sp_aln* d_ref = (sp_aln*)sp_pool(ctx, "k3_af_ref", nc * sizeof(sp_aln));
         sp_affine_aln* d_af = (sp_affine_aln*)sp_pool(ctx, "k3_af_out", nc * sizeof(sp_affine_aln));
-        if (!d_cells || !d_ref || !d_af) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "find_regions: re-score buffers");
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_cells, cells.data(), nc * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream));
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ref, ref.data(), nc * sizeof(sp_aln), hipMemcpyHostToDevice, ctx->stream));
+        if (!cells || !ref || !af || !d_cells || !d_ref || !d_af) return sp_fail(ctx, SP_ERR_OUT_OF_MEMORY, "find_regions: re-score buffers");
+        k3_read_ranges((uint32_t)nc, [&](uint32_t, uint32_t lo, uint32_t hi) {
+            for (uint64_t x = lo; x < hi; ++x) {
+                const sp_region_hit& h = list[x]->h; const sp_aln& al = alns[list[x]->which];
+                cells[x] = CellDesc{ (uint32_t)h.template_idx, (uint32_t)h.read, ((al.b_start - al.a_start) + (al.b_end - al.a_end)) / 2, 320, 0, -1 };
+                ref[x] = al;
+            }
+        });
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_cells, cells, nc * sizeof(CellDesc), hipMemcpyHostToDevice, ctx->stream));
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(d_ref, ref, nc * sizeof(sp_aln), hipMemcpyHostToDevice, ctx->stream));
         const sp_affine_opts ao = { 1, 4, 6, 2, 26, 1, 1 };
         const int rc2 = sp_rescore_mappings(ctx, templates, reads, d_cells, d_ref, nc, false, ao, 256, d_af, prof, 320);
         if (rc2 != SP_OK) return rc2;
-        SP_HIP_CHECK(ctx, hipMemcpyAsync(af.data(), d_af, nc * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP_CHECK(ctx, hipMemcpyAsync(af, d_af, nc * sizeof(sp_affine_aln), hipMemcpyDeviceToHost, ctx->stream));
         SP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint64_t x = 0; x < nc; ++x) {
-            sp_region_hit& h = list[x]->h;
-            list[x]->done = 1;
-            if (af[x].score <= 0) continue;                                                                      // (nothing aligns the reference's way: the hit keeps the library's counts)
-            h.mm2_score = af[x].score; h.mm2_nm = af[x].nm; h.mm2_start = af[x].b_start; h.mm2_end = af[x].b_end; h.mm2_q_start = af[x].a_start; h.mm2_q_end = af[x].a_end;
-            h.start = af[x].b_start; h.end = af[x].b_end; h.nm = af[x].nm;
-            h.unmapped = h.seq_len - (af[x].a_end - af[x].a_start); h.clip_start = af[x].a_start; h.clip_end = h.seq_len - af[x].a_end;
-        }
+        k3_read_ranges((uint32_t)nc, [&](uint32_t, uint32_t lo, uint32_t hi) {
+            for (uint64_t x = lo; x < hi; ++x) {
+                sp_region_hit& h = list[x]->h;
+                list[x]->done = 1;
+                if (af[x].score <= 0) continue;                                                                  // (nothing aligns the reference's way: the hit keeps the library's counts)
+                h.mm2_score = af[x].score; h.mm2_nm = af[x].nm; h.mm2_start = af[x].b_start; h.mm2_end = af[x].b_end; h.mm2_q_start = af[x].a_start; h.mm2_q_end = af[x].a_end;
+                h.start = af[x].b_start; h.end = af[x].b_end; h.nm = af[x].nm;
+                h.unmapped = h.seq_len - (af[x].a_end - af[x].a_start); h.clip_start = af[x].a_start; h.clip_end = h.seq_len - af[x].a_end;
+            }
+        });
         return SP_OK;
     };
     hm.mark("host:k3_retry");
     // the placements of every read by the library's counts (cells give up one edit past the cap: a little above it they still exist)
     std::vector<Pl> un; std::vector<uint32_t> first(reads->n + 1, 0);
-    for (uint32_t r = 0; r < reads->n; ++r) {
-        first[r] = (uint32_t)un.size();
-        if (reads->h_len[r] == 0) continue;
-        for (uint32_t t = 0; t < T; ++t) for (int k = 0; k < CYP_TOPK; ++k) {
-            const uint32_t which = (uint32_t)(((size_t)r * T + t) * CYP_TOPK + k);
-            const sp_aln& al = alns[which];
-            if (!al.ok) continue;
-            const int tlen = templates->h_len[t];
-            sp_region_hit h{(int32_t)r, (int32_t)t, al.b_start, al.b_end, tlen, al.nm, tlen - (al.a_end - al.a_start), al.a_start, tlen - al.a_end, 0, 0, 0, 0, 0, 0};
-            if (own_score(h) > (rescore ? K3_CAP_HI : 0.05)) continue;                                          // max_ed_frac, :228-232
-            un.push_back(Pl{ h, which, 0 });
+    {
+        std::vector<Pl> un_of[K3_HOST_THREADS]; uint32_t lo_of[K3_HOST_THREADS] = {}, hi_of[K3_HOST_THREADS] = {};
+        k3_read_ranges(reads->n, [&](uint32_t part, uint32_t r_lo, uint32_t r_hi) {
+            std::vector<Pl>& mine = un_of[part]; lo_of[part] = r_lo; hi_of[part] = r_hi;
+            for (uint32_t r = r_lo; r < r_hi; ++r) {
+                first[r] = (uint32_t)mine.size();                                                               // (within the range: the range's base is added below)
+                if (reads->h_len[r] == 0) continue;
+                for (uint32_t t = 0; t < T; ++t) for (int k = 0; k < CYP_TOPK; ++k) {
+                    const uint32_t which = (uint32_t)(((size_t)r * T + t) * CYP_TOPK + k);
+                    const sp_aln& al = alns[which];
+                    if (!al.ok) continue;
+                    const int tlen = templates->h_len[t];
+                    sp_region_hit h{(int32_t)r, (int32_t)t, al.b_start, al.b_end, tlen, al.nm, tlen - (al.a_end - al.a_start), al.a_start, tlen - al.a_end, 0, 0, 0, 0, 0, 0};
+                    if (own_score(h) > (rescore ? K3_CAP_HI : 0.05)) continue;                                  // max_ed_frac, :228-232
+                    mine.push_back(Pl{ h, which, 0 });
+                }
+            }
+        });
+        size_t total = 0; for (uint32_t part = 0; part < K3_HOST_THREADS; ++part) total += un_of[part].size();
+        un.reserve(total);
+        for (uint32_t part = 0; part < K3_HOST_THREADS; ++part) {
+            const uint32_t base = (uint32_t)un.size();
+            for (uint32_t r = lo_of[part]; r < hi_of[part]; ++r) first[r] += base;
+            un.insert(un.end(), un_of[part].begin(), un_of[part].end());
         }
     }
     first[reads->n] = (uint32_t)un.size();
@@ -924,14 +1000,15 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
         std::vector<uint8_t> mark(un.size(), 1);
         // (both scores of every placement once: the pair loop below runs ~ 250 times per read)
         std::vector<double> s_own(un.size()), s_pen(un.size()); std::vector<uint8_t> is_pen(un.size());
-        for (size_t i = 0; i < un.size(); ++i) {
-            const sp_region_hit& h = un[i].h;
-            s_own[i] = cyp_score(h.seq_len, h.nm, h.unmapped, false); s_pen[i] = cyp_score(h.seq_len, h.nm, h.unmapped, true); is_pen[i] = penalized_type(template_type[h.template_idx]);
-        }
         // (start / end / length of every placement side by side: the loop reads three ints per partner; the division of overlap() only where the spans can reach K3_OVL at all)
         std::vector<int> p_s(un.size()), p_e(un.size());
-        for (size_t i = 0; i < un.size(); ++i) { p_s[i] = un[i].h.start; p_e[i] = un[i].h.end; }
-        for (uint32_t r = 0; r < reads->n; ++r) for (uint32_t i = first[r]; i < first[r + 1]; ++i) {
+        k3_read_ranges(reads->n, [&](uint32_t, uint32_t r_lo, uint32_t r_hi) {                              // (a read's placements are its own: every range writes its own stretch of the arrays)
+        for (size_t i = first[r_lo]; i < first[r_hi]; ++i) {
+            const sp_region_hit& h = un[i].h;
+            s_own[i] = cyp_score(h.seq_len, h.nm, h.unmapped, false); s_pen[i] = cyp_score(h.seq_len, h.nm, h.unmapped, true); is_pen[i] = penalized_type(template_type[h.template_idx]);
+            p_s[i] = h.start; p_e[i] = h.end;
+        }
+        for (uint32_t r = r_lo; r < r_hi; ++r) for (uint32_t i = first[r]; i < first[r + 1]; ++i) {
             const int us = p_s[i], ue = p_e[i], ul = ue - us;
             for (uint32_t j = i + 1; j < first[r + 1]; ++j) {
                 const int shared = std::min(ue, p_e[j]) - std::max(us, p_s[j]);
@@ -945,6 +1022,7 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
                 if (b > 1.25 * a + 0.001) mark[j] = 0;
             }
         }
+        });
         for (size_t i = 0; i < un.size(); ++i) if (mark[i]) crit.push_back(&un[i]);
         hm.mark("host:k3_mark");
         rc = rescore_list(crit, "k3_af_crit");
@@ -953,8 +1031,11 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
         hm.mark("host:k3_crit_rescore");
     }
     std::vector<Pl> coll;
+    std::vector<Pl> coll_of[K3_HOST_THREADS];
+    k3_read_ranges(reads->n, [&](uint32_t part, uint32_t r_lo, uint32_t r_hi) {
+    std::vector<Pl>& coll = coll_of[part];
     std::vector<Pl> cur_read;
-    for (uint32_t r = 0; r < reads->n; ++r) {
+    for (uint32_t r = r_lo; r < r_hi; ++r) {
         cur_read.clear();
         for (uint32_t i = first[r]; i < first[r + 1]; ++i) if (!(own_score(un[i].h) > 0.05)) cur_read.push_back(un[i]);         // the filter, on what every placement carries now
         std::stable_sort(cur_read.begin(), cur_read.end(), [](const Pl& x, const Pl& y) { return x.h.start != y.h.start ? x.h.start < y.h.start : x.h.end < y.h.end; });
@@ -969,6 +1050,8 @@ static int32_t cyp_find_regions(sp_ctx* ctx, const sp_seqset* templates, const i
         }
         if (have) coll.push_back(cur);
     }
+    });
+    for (uint32_t part = 0; part < K3_HOST_THREADS; ++part) coll.insert(coll.end(), coll_of[part].begin(), coll_of[part].end());
     hm.mark("host:k3_collapse");
     if (rescore) {
         std::vector<Pl*> rest;
