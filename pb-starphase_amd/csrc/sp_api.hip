@@ -37,6 +37,9 @@ int32_t sp_ctx_create(int32_t device, void* stream, sp_ctx** out) {
         }
         const char* had = std::getenv("GPU_MAX_HW_QUEUES");
         if (!had && !hip_up) { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); by_library = true; }
+        // (a variable that is there while HIP is already up is taken at its word: a host may have set it in-process BEFORE its first HIP call -- bench.py does, through
+        //  os.environ ahead of `import torch` -- and /proc/self/environ, the environment at exec time, cannot tell that from one set too late.  If it was too late, the
+        //  persistent batches time out: three failures switch the library's own choice off for the context until sp_ctx_set_option("k8_persistent") is called again)
         const char* now = std::getenv("GPU_MAX_HW_QUEUES");
         effective.store(now ? std::atoi(now) : (hip_up ? 0 : 4));
     }
@@ -188,7 +191,7 @@ int32_t sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value) {
     if (std::strcmp(name, "k8_side_orders") == 0) { if (value < 0 || value > 3) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k8_side_orders is 0 .. 3"); ctx->k8_side_orders = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k8_side_orders = ctx->k8_side_orders; return SP_OK; }
     if (std::strcmp(name, "k8_compound") == 0) { ctx->k8_compound = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k8_compound = ctx->k8_compound; return SP_OK; }
     if (std::strcmp(name, "k8_side_max_blocks") == 0) { if (value < 0) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k8_side_max_blocks >= 0"); ctx->k8_side_max_blocks = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k8_side_max_blocks = ctx->k8_side_max_blocks; return SP_OK; }
-    if (std::strcmp(name, "k8_persistent") == 0) { if (value < 0 || value > 2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k8_persistent is 0 (never), 1 (whenever a batch fits) or 2 (the library decides)"); ctx->k8_persistent = (int)value; ctx->k8_persist_backoff = 0; for (sp_ctx* h : ctx->helper) if (h) h->k8_persistent = ctx->k8_persistent; return SP_OK; }
+    if (std::strcmp(name, "k8_persistent") == 0) { if (value < 0 || value > 2) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k8_persistent is 0 (never), 1 (whenever a batch fits) or 2 (the library decides)"); ctx->k8_persistent = (int)value; ctx->k8_persist_backoff = 0; ctx->k8_persist_failures = 0; for (sp_ctx* h : ctx->helper) if (h) h->k8_persistent = ctx->k8_persistent; return SP_OK; }
     if (std::strcmp(name, "cons_retry_ladder") == 0) { ctx->cons_retry_ladder = value != 0; for (sp_ctx* h : ctx->helper) if (h) h->cons_retry_ladder = ctx->cons_retry_ladder; return SP_OK; }
     if (std::strcmp(name, "k5_block_pairs") == 0) { if (value < 0 || value > (1 << 20)) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: k5_block_pairs is 0..1048576"); ctx->k5_block_pairs = (int)value; for (sp_ctx* h : ctx->helper) if (h) h->k5_block_pairs = ctx->k5_block_pairs; return SP_OK; }
     if (std::strcmp(name, "cyp_cohort_min_group") == 0) { if (value < 1 || value > 64) return sp_fail(ctx, SP_ERR_INVALID_ARG, "sp_ctx_set_option: cyp_cohort_min_group is 1..64"); ctx->cyp_cohort_min_group = (int)value; return SP_OK; }
