@@ -395,6 +395,14 @@ template <class T> __device__ __forceinline__ void put(T* p, T v, bool coh) { if
 
 struct ConsAccess {
     const uint8_t* win; int w0; const uint8_t* C; int cap, split_at, i, ov_pos, ov_base;
+    const uint32_t* pk;         // the same window 2 bits a base (word k = window bases 16 k .. 16 k + 15; zero where the window has no base)
+    // the 16 bases from `pos` on as one packed word, where they all lie in the staged window and none of them is the overriding base
+    __device__ __forceinline__ bool word16(int pos, uint32_t& out) const {
+        const int y = pos - w0;
+        if (y < 0 || y + 16 > CWIN + CW || (ov_pos >= pos && ov_pos < pos + 16)) return false;
+        out = __builtin_amdgcn_alignbit(pk[(y >> 4) + 1], pk[y >> 4], (uint32_t)(y & 15) << 1);
+        return true;
+    }
     __device__ __forceinline__ int at(int pos) const {
         if (pos == ov_pos) return ov_base;
         const int y = pos - w0;
@@ -440,8 +448,18 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
         else if (M > ACT_CONS) d.c0 = find_start_scan(rv.n, rbc, ca, off, len, window, cmp_len, lane);
         else {
             for (int w = lane; w < ((M + 15) >> 4) + 1; w += SP_WAVE) {      // the text backwards, 2 bits per base (cpack is rebuilt for the catch-up below)
-                uint32_t word = 0;
-                for (int b = 0; b < 16; ++b) { const int j = w * 16 + b + 1; if (j <= M) word |= (uint32_t)(ca(len - j) & 3) << (b << 1); }
+                // (out of the window's packed copy where the 16 bases lie in it: two loads and a digit reversal; base by base through cacc.at() -- a flat load and three
+                //  branches each -- the two packings of a placement were 8 of the 33 us of a wave that places a read)
+                uint32_t word = 0, fw;
+                const int left = M - w * 16;                                   // text positions of this word that exist
+                if (left <= 0) word = 0;
+                else if (cacc.word16(len - w * 16 - 16, fw)) {
+                    fw = ((fw >> 2) & 0x33333333u) | ((fw & 0x33333333u) << 2);
+                    fw = ((fw >> 4) & 0x0F0F0F0Fu) | ((fw & 0x0F0F0F0Fu) << 4);
+                    word = __builtin_bswap32(fw);
+                    if (left < 16) word &= (1u << (left << 1)) - 1u;
+                }
+                else for (int b = 0; b < 16; ++b) { const int j = w * 16 + b + 1; if (j <= M) word |= (uint32_t)(ca(len - j) & 3) << (b << 1); }
                 A.cpack[w] = word;
             }
             spw::wave_lds_sync();
@@ -451,8 +469,10 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             //  is read before it is known whether the entry holds anything: one round trip)
             auto peek = [](const int* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
             const uint32_t seen = lane < nw ? (uint32_t)peek(reinterpret_cast<const int*>(&mm->text[lane])) : 0u;
-            const int m_c0 = peek(&mm->c0);
-            bool known = peek(&mm->valid) && peek(&mm->M) == M && peek(&mm->off) == off;
+            // (the entry's four words asked for together: `valid && M == .. && off == ..` on the loads themselves asked for one after the other -- an atomic load is not moved
+            //  across the && in front of it --, three round trips to memory in front of every placement: 4 - 5 us of the slowest wave of a window launch)
+            const int m_c0 = peek(&mm->c0), m_valid = peek(&mm->valid), m_M = peek(&mm->M), m_off = peek(&mm->off);
+            bool known = m_valid && m_M == M && m_off == off;
             if (known) known = __ballot(lane < nw && seen != A.cpack[lane]) == 0;
             ACT_T(0);
             // The search by diagonal transition first (Landau-Vishkin for Sellers' matrix): for e = 0, 1, 2, ... the furthest pattern row every diagonal of the matrix
@@ -557,7 +577,10 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
         // 16 bases per step out of 2-bit packed copies of the two windows
         for (int w = lane; w < ACT_CONS / 16 + 2; w += SP_WAVE) {
             uint32_t word = 0;
-            for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < cwinlen) word |= (uint32_t)(ca(ws + x) & 3) << (b << 1); }
+            const int left = cwinlen - w * 16;
+            if (left <= 0) word = 0;
+            else if (cacc.word16(ws + w * 16, word)) { if (left < 16) word &= (1u << (left << 1)) - 1u; }
+            else { word = 0; for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < cwinlen) word |= (uint32_t)(ca(ws + x) & 3) << (b << 1); } }
             A.cpack[w] = word;
         }
         spw::wave_lds_sync();                                  // (rpack holds the read's packed words since the start)
@@ -894,8 +917,8 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const 
             h_store(B.H, p * CB + lane, a.H);
         };
         ConsAccess ca0, ca1;
-        ca0.win = &cwin[0][0]; ca0.w0 = w0; ca0.C = Cn; ca0.cap = P.cs; ca0.split_at = split_at; ca0.i = 0; ca0.ov_pos = -1; ca0.ov_base = 0;
-        ca1 = ca0; ca1.win = &cwin[1][0]; ca1.i = 1;
+        ca0.win = &cwin[0][0]; ca0.w0 = w0; ca0.C = Cn; ca0.cap = P.cs; ca0.split_at = split_at; ca0.i = 0; ca0.ov_pos = -1; ca0.ov_base = 0; ca0.pk = &cpk[0][0];
+        ca1 = ca0; ca1.win = &cwin[1][0]; ca1.i = 1; ca1.pk = &cpk[1][0];
 
         // one pass of a read through the n bases of the window behind column T.  quiet: the pass only moves the state (the verified bases of a cut window in front of an
         // expansion: their votes and costs are on the parent's tape already)
