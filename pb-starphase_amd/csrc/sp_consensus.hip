@@ -416,6 +416,14 @@ struct ConsAccess {
 // the window loop.
 __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScratch* Ap, PlaceMemo* memo, int off, int len, int window, int cmp_len, int et, int lane) {
     ActScratch& A = *Ap;
+    // the scratch arrays through LDS addresses (Ap arrives as a generic pointer: every access through it is a flat load or store that the loops below wait for)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    lds_u32* const L_rpack = (lds_u32*)(uintptr_t)spw::lds_addr(A.rpack);
+    lds_u32* const L_npack = (lds_u32*)(uintptr_t)spw::lds_addr(A.npack);
+    lds_u32* const L_cpack = (lds_u32*)(uintptr_t)spw::lds_addr(A.cpack);
+    lds_u32* const L_score32 = (lds_u32*)(uintptr_t)spw::lds_addr(reinterpret_cast<const uint32_t*>(A.score));
+    lds_u8* const L_rcache = (lds_u8*)(uintptr_t)spw::lds_addr(reinterpret_cast<const uint32_t*>(A.rcache));
     Dwfa d;
 #ifdef SP_K8_TIMING
     long long tq = wall_clock64();
@@ -429,16 +437,16 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
     // unpacked out of LDS (a base at a time from memory was ten dependent round trips)
     if (A.staged != rv.w) {
         const int rwords0 = ((rv.n < ACT_READ ? rv.n : ACT_READ) + 15) >> 4;
-        for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) { A.rpack[w] = w < rwords0 ? rv.w[w] : 0u; A.npack[w] = (rv.np && w < rwords0) ? rv.np[w] : 0u; }
+        for (int w = lane; w < ACT_READ / 16 + 2; w += SP_WAVE) { L_rpack[w] = w < rwords0 ? rv.w[w] : 0u; L_npack[w] = (rv.np && w < rwords0) ? rv.np[w] : 0u; }
         spw::wave_lds_sync();
         for (int x = lane; x < rv.n && x < ACT_READ; x += SP_WAVE) {
             const uint32_t sh = (uint32_t)(x & 15) << 1;
-            A.rcache[x] = ((A.npack[x >> 4] >> sh) & 1u) ? (uint8_t)4 : (uint8_t)((A.rpack[x >> 4] >> sh) & 3u);
+            L_rcache[x] = ((L_npack[x >> 4] >> sh) & 1u) ? (uint8_t)4 : (uint8_t)((L_rpack[x >> 4] >> sh) & 3u);
         }
         if (lane == 0) A.staged = rv.w;
     }
     spw::wave_lds_sync();
-    auto rbc = [&](int h) { return h < ACT_READ ? (int)A.rcache[h] : read_base(rv, h); };
+    auto rbc = [&](int h) { return h < ACT_READ ? (int)L_rcache[h] : read_base(rv, h); };
     ACT_T(0);
     {
         // the search (oracle/consensus.c find_start): start positions [off - window, off], the read's first L bases against any prefix of the consensus behind the
@@ -460,7 +468,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
                     if (left < 16) word &= (1u << (left << 1)) - 1u;
                 }
                 else for (int b = 0; b < 16; ++b) { const int j = w * 16 + b + 1; if (j <= M) word |= (uint32_t)(ca(len - j) & 3) << (b << 1); }
-                A.cpack[w] = word;
+                L_cpack[w] = word;
             }
             spw::wave_lds_sync();
             const int nw = ((M + 15) >> 4) + 1;                                // (<= 33 words: a lane each)
@@ -473,7 +481,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             //  across the && in front of it --, three round trips to memory in front of every placement: 4 - 5 us of the slowest wave of a window launch)
             const int m_c0 = peek(&mm->c0), m_valid = peek(&mm->valid), m_M = peek(&mm->M), m_off = peek(&mm->off);
             bool known = m_valid && m_M == M && m_off == off;
-            if (known) known = __ballot(lane < nw && seen != A.cpack[lane]) == 0;
+            if (known) known = __ballot(lane < nw && seen != L_cpack[lane]) == 0;
             ACT_T(0);
             // The search by diagonal transition first (Landau-Vishkin for Sellers' matrix): for e = 0, 1, 2, ... the furthest pattern row every diagonal of the matrix
             // reaches with at most e edits -- a slide along the equal bases (word compares on the two packed sequences) after the step from the neighbouring diagonals'
@@ -486,7 +494,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             constexpr int LV_MAX = 12;
             const int lv_nd = M - L + 1 + 2 * LV_MAX;                                    // diagonals d = x - LV_MAX (text column - pattern row), x = c * 64 + lane
             if (!known && rv.np == nullptr && M >= L && lv_nd <= 8 * SP_WAVE) {
-                uint32_t* ppack = reinterpret_cast<uint32_t*>(A.score);                  // (the matrix's score bytes are not in use yet)
+                lds_u32* const ppack = L_score32;                                        // (the matrix's score bytes are not in use yet)
                 const int npw = (L + 15) >> 4;
                 if (lane < 10) {
                     uint32_t pw = 0;
@@ -501,7 +509,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
                     while (r < lim) {
                         const int t = r + dd;
                         const uint32_t pwd = __builtin_amdgcn_alignbit(ppack[(r >> 4) + 1], ppack[r >> 4], (uint32_t)(r & 15) << 1);
-                        const uint32_t twd = __builtin_amdgcn_alignbit(A.cpack[(t >> 4) + 1], A.cpack[t >> 4], (uint32_t)(t & 15) << 1);
+                        const uint32_t twd = __builtin_amdgcn_alignbit(L_cpack[(t >> 4) + 1], L_cpack[t >> 4], (uint32_t)(t & 15) << 1);
                         const uint32_t diff = pwd ^ twd;
                         const int same = diff ? (__builtin_ctz(diff) >> 1) : 16;
                         r += same;
@@ -557,13 +565,13 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             if (known) d.c0 = m_c0;
             else if (exact_c0 >= 0) {
                 d.c0 = exact_c0;
-                if (lane < nw) mm->text[lane] = A.cpack[lane];
+                if (lane < nw) mm->text[lane] = L_cpack[lane];
                 if (lane == 0) { mm->valid = 1; mm->M = M; mm->off = off; mm->c0 = d.c0; }
             }
             else {
                 if (L <= SP_WAVE) d.c0 = find_start_diag(lane < L ? rbc(L - 1 - lane) : 7, L, M, off, len, window, lane, A.cpack, A.score);
                 else d.c0 = find_start_diag2(2 * lane + 1 <= L ? rbc(L - 2 * lane - 1) : 7, 2 * lane + 2 <= L ? rbc(L - 2 * lane - 2) : 7, L, M, off, len, window, lane, A.cpack, A.score);
-                if (lane < nw) mm->text[lane] = A.cpack[lane];
+                if (lane < nw) mm->text[lane] = L_cpack[lane];
                 if (lane == 0) { mm->valid = 1; mm->M = M; mm->off = off; mm->c0 = d.c0; }
             }
             spw::wave_lds_sync();
@@ -581,7 +589,7 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
             if (left <= 0) word = 0;
             else if (cacc.word16(ws + w * 16, word)) { if (left < 16) word &= (1u << (left << 1)) - 1u; }
             else { word = 0; for (int b = 0; b < 16; ++b) { const int x = w * 16 + b; if (x < cwinlen) word |= (uint32_t)(ca(ws + x) & 3) << (b << 1); } }
-            A.cpack[w] = word;
+            L_cpack[w] = word;
         }
         spw::wave_lds_sync();                                  // (rpack holds the read's packed words since the start)
         ACT_T(2);
@@ -593,8 +601,8 @@ __device__ __noinline__ Dwfa activate_late(ReadView rv, ConsAccess cacc, ActScra
                 int nm = 0;
                 if (go) {
                     const int pr = d.H, pc = cbase + d.H + kk;
-                    const uint32_t a = __builtin_amdgcn_alignbit(A.rpack[(pr >> 4) + 1], A.rpack[pr >> 4], (uint32_t)(pr & 15) << 1);
-                    const uint32_t b = __builtin_amdgcn_alignbit(A.cpack[(pc >> 4) + 1], A.cpack[pc >> 4], (uint32_t)(pc & 15) << 1);
+                    const uint32_t a = __builtin_amdgcn_alignbit(L_rpack[(pr >> 4) + 1], L_rpack[pr >> 4], (uint32_t)(pr & 15) << 1);
+                    const uint32_t b = __builtin_amdgcn_alignbit(L_cpack[(pc >> 4) + 1], L_cpack[pc >> 4], (uint32_t)(pc & 15) << 1);
                     const uint32_t x = a ^ b, mm = (x | (x >> 1)) & 0x55555555u;
                     nm = mm ? (__builtin_ctz(mm) >> 1) : 16;
                     nm = nm < left ? nm : left;
