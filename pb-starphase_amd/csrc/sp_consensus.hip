@@ -1033,6 +1033,7 @@ __device__ __forceinline__ void cons_step_body(const ConsBatchT<MAXP>& B, const 
                 if (i == 1 && !dualrun) continue;
                 if (!(i ? go1 : go0)) continue;
                 if (i == bulk) continue;
+                if (m == 0) continue;                                       // (the other state has already ruled a clean run out: the column goes the slow way whatever this one would say)
                 const Dwfa& a = i ? d1 : d0;
                 if (a.flags & F_ACTIVE) {
                     if (a.flags & (F_FINISHED | F_LOST)) continue;
